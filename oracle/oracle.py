@@ -1,0 +1,286 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY.  May be imported by tests/, __graft_entry__.smoke() and the
+``cpu_baseline`` leg of bench.py — never by the shipped package (thunderbolt.jl_amd).
+The arithmetic lives in tb_oracle.c; this file only marshals numpy arrays.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+LINE2, QUAD4, HEX8, TET4, HEX27 = 1, 2, 3, 4, 5
+COEF_CONST_SCALAR, COEF_CONST_TENSOR, COEF_FIELD_SCALAR = 0, 1, 2
+COEF_SPECTRAL_CONST, COEF_SPECTRAL_FIELD, COEF_TRANSVERSE_CONST = 3, 4, 5
+SRC_CONST, SRC_NORM_PLUS_T, SRC_COS_EXP, SRC_TABULATED = 0, 1, 2, 3
+CELL_FHN, CELL_ALIEV_PANFILOV, CELL_PCG2019 = 0, 1, 2
+LAYOUT_SOA, LAYOUT_AOS = 0, 1
+
+_dp = C.POINTER(C.c_double)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+
+
+class _Mesh(C.Structure):
+    _fields_ = [("kind", C.c_int), ("qorder", C.c_int), ("n_cells", C.c_int64), ("n_nodes", C.c_int64),
+                ("xyz", _dp), ("conn", _i32p), ("cell_dofs", _i32p)]
+
+
+class _Coef(C.Structure):
+    _fields_ = [("kind", C.c_int), ("p", _dp), ("field", _dp), ("Cm", C.c_double), ("chi", C.c_double),
+                ("wrap", C.c_int)]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "tb_oracle.c")
+    if force or not os.path.exists(so) or (
+            os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.orc_close_dofs.restype = C.c_int64
+        _LIB.orc_build_pattern.restype = C.c_int64
+    return _LIB
+
+
+def _d(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _i32(a):
+    return None if a is None else a.ctypes.data_as(_i32p)
+
+
+def _i64(a):
+    return None if a is None else a.ctypes.data_as(_i64p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+# ---------------------------------------------------------------- FE substrate
+def elem_info(kind):
+    rd, nb = C.c_int(), C.c_int()
+    assert lib().orc_elem_info(kind, C.byref(rd), C.byref(nb)) == 0
+    return rd.value, nb.value
+
+
+def quadrature(kind, order):
+    rd, _ = elem_info(kind)
+    xi = np.zeros(64 * 3)
+    w = np.zeros(64)
+    nq = lib().orc_quadrature(kind, order, _d(xi), _d(w))
+    assert nq > 0
+    return xi[:nq * rd].reshape(nq, rd).copy(), w[:nq].copy()
+
+
+def shape(kind, xi):
+    rd, nb = elem_info(kind)
+    xi = _f64(xi)
+    N = np.zeros(nb)
+    dN = np.zeros((nb, rd))
+    assert lib().orc_shape(kind, _d(xi), _d(N), _d(dN)) == 0
+    return N, dN
+
+
+def mapping(x, dM):
+    x = _f64(x)
+    dM = _f64(dM)
+    ngeo, dim = x.shape
+    J = np.zeros((dim, dim))
+    Jinv = np.zeros((dim, dim))
+    det = C.c_double()
+    rc = lib().orc_mapping(dim, ngeo, _d(x), _d(dM), _d(J), C.byref(det), _d(Jinv))
+    return rc, J, det.value, Jinv
+
+
+def eval_field(Nq, data_cell):
+    Nq = _f64(Nq)
+    data = _f64(data_cell).reshape(len(Nq), -1)
+    out = np.zeros(data.shape[1])
+    lib().orc_eval_field(len(Nq), data.shape[1], _d(Nq), _d(data), _d(out))
+    return out
+
+
+def eval_cartesian(Nq, coords):
+    return eval_field(Nq, coords)
+
+
+def eval_spectral(vecs, lam):
+    vecs = _f64(np.atleast_2d(vecs))
+    lam = _f64(lam)
+    nvec, dim = vecs.shape
+    D = np.zeros((dim, dim))
+    lib().orc_eval_spectral(dim, nvec, _d(vecs), _d(lam), _d(D))
+    return D
+
+
+def orthogonalize(f, s, n=None):
+    f, s = _f64(f).copy(), _f64(s).copy()
+    n = None if n is None else _f64(n).copy()
+    lib().orc_orthogonalize(len(f), _d(f), _d(s), _d(n))
+    return (f, s) if n is None else (f, s, n)
+
+
+def conductivity_to_diffusivity(kappa, Cm, chi):
+    k = _f64(kappa)
+    D = np.zeros_like(k)
+    lib().orc_conductivity_to_diffusivity(k.size, _d(k), C.c_double(Cm), C.c_double(chi), _d(D))
+    return D
+
+
+def homogeneous_data_index(timings, t):
+    tm = _f64(timings)
+    return lib().orc_eval_homogeneous_data_index(len(tm), _d(tm), C.c_double(t))
+
+
+# ---------------------------------------------------------------- generators
+def generate_grid_hex(nx, ny, nz, left=(-1.0, -1.0, -1.0), right=(1.0, 1.0, 1.0)):
+    nn = (nx + 1) * (ny + 1) * (nz + 1)
+    xyz = np.zeros((nn, 3))
+    conn = np.zeros((nx * ny * nz, 8), dtype=np.int32)
+    lib().orc_generate_grid_hex(nx, ny, nz, _d(_f64(left)), _d(_f64(right)), _d(xyz), _i32(conn))
+    return xyz, conn
+
+
+def close_dofs(kind, ncomp, conn, n_nodes):
+    conn = np.ascontiguousarray(conn, dtype=np.int32)
+    _, nb = elem_info(kind)
+    cd = np.zeros((conn.shape[0], nb * ncomp), dtype=np.int32)
+    nd = lib().orc_close_dofs(kind, ncomp, C.c_int64(conn.shape[0]), C.c_int64(n_nodes), _i32(conn), _i32(cd))
+    return cd, int(nd)
+
+
+def build_pattern(cell_dofs, ndofs):
+    cd = np.ascontiguousarray(cell_dofs, dtype=np.int32)
+    rowptr = np.zeros(ndofs + 1, dtype=np.int64)
+    nnz = lib().orc_build_pattern(C.c_int64(cd.shape[0]), cd.shape[1], _i32(cd), C.c_int64(ndofs), _i64(rowptr), None)
+    colidx = np.zeros(nnz, dtype=np.int32)
+    lib().orc_build_pattern(C.c_int64(cd.shape[0]), cd.shape[1], _i32(cd), C.c_int64(ndofs), _i64(rowptr), _i32(colidx))
+    return rowptr, colidx
+
+
+def color_cells(cell_dofs, ndofs):
+    cd = np.ascontiguousarray(cell_dofs, dtype=np.int32)
+    color = np.zeros(cd.shape[0], dtype=np.int32)
+    nc = lib().orc_color_cells(C.c_int64(cd.shape[0]), cd.shape[1], _i32(cd), C.c_int64(ndofs), _i32(color))
+    assert nc > 0
+    return color, nc
+
+
+# ---------------------------------------------------------------- element kernels / drivers
+class Mesh:
+    def __init__(self, kind, qorder, xyz, conn, cell_dofs):
+        self.kind, self.qorder = kind, qorder
+        self.xyz = _f64(xyz)
+        self.conn = np.ascontiguousarray(conn, dtype=np.int32)
+        self.cell_dofs = np.ascontiguousarray(cell_dofs, dtype=np.int32)
+        self.ndofs = int(self.cell_dofs.max()) + 1
+        self.c = _Mesh(kind, qorder, self.conn.shape[0], self.xyz.shape[0], _d(self.xyz), _i32(self.conn),
+                       _i32(self.cell_dofs))
+
+
+class Coef:
+    def __init__(self, kind, p=None, field=None, Cm=1.0, chi=1.0, wrap=False):
+        self.p = _f64(p if p is not None else [0.0])
+        self.field = None if field is None else _f64(field)
+        self.c = _Coef(kind, _d(self.p), _d(self.field), Cm, chi, int(wrap))
+
+
+def element_matrix(mesh, form, coef, cell, t=0.0):
+    nb = mesh.cell_dofs.shape[1]
+    Ke = np.zeros((nb, nb))
+    f = lib().orc_element_mass if form == 0 else lib().orc_element_diffusion
+    rc = f(C.byref(mesh.c), C.c_int64(cell), C.byref(coef.c), C.c_double(t), _d(Ke))
+    assert rc == 0, rc
+    return Ke
+
+
+def element_source(mesh, cell, src_kind, p=None, table=None, t=0.0):
+    nb = mesh.cell_dofs.shape[1]
+    be = np.zeros(nb)
+    p = _f64(p if p is not None else [0.0])
+    table = None if table is None else _f64(table)
+    rc = lib().orc_element_source(C.byref(mesh.c), C.c_int64(cell), src_kind, _d(p), _d(table), C.c_double(t), _d(be))
+    assert rc == 0, rc
+    return be
+
+
+def assemble_matrix(mesh, form, coef, rowptr, colidx, t=0.0, nthreads=1, color=None, ncolors=0):
+    nz = np.zeros(int(rowptr[-1]))
+    rc = lib().orc_assemble_matrix(C.byref(mesh.c), form, C.byref(coef.c), C.c_double(t), _i64(rowptr),
+                                   _i32(colidx), _d(nz), nthreads, _i32(color), ncolors)
+    assert rc == 0, rc
+    return nz
+
+
+def assemble_source(mesh, src_kind, p=None, table=None, t=0.0, nthreads=1):
+    b = np.zeros(mesh.ndofs)
+    p = _f64(p if p is not None else [0.0])
+    table = None if table is None else _f64(table)
+    rc = lib().orc_assemble_source(C.byref(mesh.c), src_kind, _d(p), _d(table), C.c_double(t), _d(b), nthreads)
+    assert rc == 0, rc
+    return b
+
+
+# ---------------------------------------------------------------- reaction
+def cell_nstates(model):
+    return lib().orc_cell_nstates(model)
+
+
+def cell_default_params(model):
+    p = np.zeros(lib().orc_cell_nparams(model))
+    lib().orc_cell_default_params(model, _d(p))
+    return p
+
+
+def cell_default_state(model, p=None):
+    p = cell_default_params(model) if p is None else _f64(p)
+    u0 = np.zeros(cell_nstates(model))
+    lib().orc_cell_default_state(model, _d(p), _d(u0))
+    return u0
+
+
+def cell_rhs(model, p, u, t=0.0):
+    p, u = _f64(p), _f64(u)
+    du = np.zeros_like(u)
+    lib().orc_cell_rhs(model, _d(p), _d(u), C.c_double(t), _d(du))
+    return du
+
+
+def reaction_step(model, p, u, npoints, layout=LAYOUT_SOA, t=0.0, dt=1.0, substeps=1, threshold=0.1, nthreads=1,
+                  want_du=True):
+    """In place on `u` (float64, contiguous). Returns du (or None)."""
+    assert u.dtype == np.float64 and u.flags.c_contiguous
+    p = _f64(p)
+    du = np.zeros_like(u) if want_du else None
+    rc = lib().orc_reaction_step(model, _d(p), _d(u), _d(du), C.c_int64(npoints), layout, C.c_double(t),
+                                 C.c_double(dt), substeps, C.c_double(threshold), nthreads)
+    assert rc == 0
+    return du
+
+
+# ---------------------------------------------------------------- heat-step algebra
+def heat_matrix(Mnz, Knz, dt):
+    A = np.zeros_like(Mnz)
+    lib().orc_heat_matrix(C.c_int64(Mnz.size), _d(_f64(Mnz)), _d(_f64(Knz)), C.c_double(dt), _d(A))
+    return A
+
+
+def spmv_csr(rowptr, colidx, nz, x, alpha=1.0, beta=0.0, y=None, nthreads=1):
+    n = len(rowptr) - 1
+    y = np.zeros(n) if y is None else y
+    lib().orc_spmv_csr(C.c_int64(n), _i64(rowptr), _i32(colidx), _d(_f64(nz)), _d(_f64(x)), C.c_double(alpha),
+                       C.c_double(beta), _d(y), nthreads)
+    return y

@@ -1,0 +1,915 @@
+/*
+ * tb_oracle.c — CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT).  See tb_oracle.h for the rules.
+ *
+ * Plain-C restatement of the Thunderbolt.jl v0.0.4 hot path.  Loops are written the way the
+ * reference writes them (same nesting, same association of the floating-point products) so that
+ * the sequential driver reproduces SequentialAssemblyStrategy(SequentialCPUDevice()) semantics.
+ * Every function cites the reference file:line it follows (paths relative to /root/reference).
+ */
+#define _GNU_SOURCE
+#include "tb_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define MAXNB 27
+#define MAXQ 64
+
+/* ------------------------------------------------------------------------------------------ */
+/* FE substrate: Ferrite.jl 1.6 conventions (third party, not vendored → UNPINNED)  */
+/* ------------------------------------------------------------------------------------------ */
+
+int orc_elem_info(int kind, int *refdim, int *nbasis)
+{
+    switch (kind) {
+    case ORC_LINE2: *refdim = 1; *nbasis = 2; return 0;
+    case ORC_QUAD4: *refdim = 2; *nbasis = 4; return 0;
+    case ORC_HEX8:  *refdim = 3; *nbasis = 8; return 0;
+    case ORC_TET4:  *refdim = 3; *nbasis = 4; return 0;
+    case ORC_HEX27: *refdim = 3; *nbasis = 27; return 0;
+    }
+    return -1;
+}
+
+/* Gauss–Legendre points on [-1,1] (FastGaussQuadrature values) */
+static int gauss1d(int n, double *x, double *w)
+{
+    switch (n) {
+    case 1: x[0] = 0.0; w[0] = 2.0; return 0;
+    case 2: x[0] = -0.5773502691896258; x[1] = 0.5773502691896258; w[0] = w[1] = 1.0; return 0;
+    case 3:
+        x[0] = -0.7745966692414834; x[1] = 0.0; x[2] = 0.7745966692414834;
+        w[0] = 0.5555555555555556; w[1] = 0.8888888888888888; w[2] = 0.5555555555555556;
+        return 0;
+    case 4:
+        x[0] = -0.8611363115940526; x[1] = -0.3399810435848563;
+        x[2] = 0.3399810435848563;  x[3] = 0.8611363115940526;
+        w[0] = 0.34785484513745385; w[1] = 0.6521451548625462;
+        w[2] = 0.6521451548625462;  w[3] = 0.34785484513745385;
+        return 0;
+    }
+    return -1;
+}
+
+/* Tensor rule on hypercubes: Iterators.product ordering → first coordinate runs fastest.
+ * Default order for the path: max(2p-1,2) points per direction, src/discretization/fem.jl:52-55. */
+int orc_quadrature(int kind, int order, double *xi, double *w)
+{
+    double x1[4], w1[4];
+    if (kind == ORC_TET4) {
+        if (order == 1) {
+            xi[0] = xi[1] = xi[2] = 0.25; w[0] = 1.0 / 6.0; return 1;
+        }
+        if (order == 2) { /* 4-point degree-2 rule (Keast / Jaśkowiec–Sukumar) */
+            const double a = 0.1381966011250105, b = 0.5854101966249685;
+            const double P[4][3] = {{a, a, a}, {b, a, a}, {a, b, a}, {a, a, b}};
+            for (int q = 0; q < 4; ++q) {
+                for (int d = 0; d < 3; ++d) xi[3 * q + d] = P[q][d];
+                w[q] = 1.0 / 24.0;
+            }
+            return 4;
+        }
+        return -1;
+    }
+    if (order < 1 || order > 4 || gauss1d(order, x1, w1)) return -1;
+    int dim = (kind == ORC_LINE2) ? 1 : (kind == ORC_QUAD4) ? 2 : 3;
+    int nq = 1;
+    for (int d = 0; d < dim; ++d) nq *= order;
+    for (int q = 0; q < nq; ++q) {
+        int r = q; double ww = 1.0;
+        for (int d = 0; d < dim; ++d) {
+            int id = r % order; r /= order;
+            xi[dim * q + d] = x1[id]; ww *= w1[id];
+        }
+        w[q] = ww;
+    }
+    return nq;
+}
+
+/* 1-D quadratic Lagrange on [0,1] as Ferrite's Lagrange{RefHexahedron,2} builds them */
+static double q0(double x) { return 2 * x * x - 3 * x + 1; }
+static double q1(double x) { return -4 * x * x + 4 * x; }
+static double q2(double x) { return 2 * x * x - x; }
+static double dq0(double x) { return 4 * x - 3; }
+static double dq1(double x) { return -8 * x + 4; }
+static double dq2(double x) { return 4 * x - 1; }
+
+/* tensor index (0: node at -1, 1: midpoint, 2: node at +1) per Ferrite local basis number:
+ * vertices, edges (1-2,2-3,3-4,4-1,5-6,6-7,7-8,8-5,1-5,2-6,3-7,4-8), faces (bottom,front,right,back,left,top), volume */
+static const int HEX27_IDX[27][3] = {
+    {0,0,0},{2,0,0},{2,2,0},{0,2,0},{0,0,2},{2,0,2},{2,2,2},{0,2,2},
+    {1,0,0},{2,1,0},{1,2,0},{0,1,0},{1,0,2},{2,1,2},{1,2,2},{0,1,2},
+    {0,0,1},{2,0,1},{2,2,1},{0,2,1},
+    {1,1,0},{1,0,1},{2,1,1},{1,2,1},{0,1,1},{1,1,2},{1,1,1}};
+
+int orc_shape(int kind, const double *xi, double *N, double *dN)
+{
+    switch (kind) {
+    case ORC_LINE2: {
+        double x = xi[0];
+        N[0] = (1 - x) * 0.5; N[1] = (1 + x) * 0.5;
+        dN[0] = -0.5; dN[1] = 0.5;
+        return 0;
+    }
+    case ORC_QUAD4: {
+        double x = xi[0], y = xi[1];
+        const int sx[4] = {-1, 1, 1, -1}, sy[4] = {-1, -1, 1, 1};
+        for (int a = 0; a < 4; ++a) {
+            N[a] = (1 + sx[a] * x) * (1 + sy[a] * y) * 0.25;
+            dN[2 * a + 0] = sx[a] * (1 + sy[a] * y) * 0.25;
+            dN[2 * a + 1] = (1 + sx[a] * x) * sy[a] * 0.25;
+        }
+        return 0;
+    }
+    case ORC_HEX8: {
+        double x = xi[0], y = xi[1], z = xi[2];
+        const int sx[8] = {-1, 1, 1, -1, -1, 1, 1, -1};
+        const int sy[8] = {-1, -1, 1, 1, -1, -1, 1, 1};
+        const int sz[8] = {-1, -1, -1, -1, 1, 1, 1, 1};
+        for (int a = 0; a < 8; ++a) {
+            double fx = 1 + sx[a] * x, fy = 1 + sy[a] * y, fz = 1 + sz[a] * z;
+            N[a] = 0.125 * fx * fy * fz;
+            dN[3 * a + 0] = 0.125 * sx[a] * fy * fz;
+            dN[3 * a + 1] = 0.125 * fx * sy[a] * fz;
+            dN[3 * a + 2] = 0.125 * fx * fy * sz[a];
+        }
+        return 0;
+    }
+    case ORC_TET4: {
+        double x = xi[0], y = xi[1], z = xi[2];
+        N[0] = 1 - x - y - z; N[1] = x; N[2] = y; N[3] = z;
+        const double G[4][3] = {{-1, -1, -1}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+        for (int a = 0; a < 4; ++a) for (int d = 0; d < 3; ++d) dN[3 * a + d] = G[a][d];
+        return 0;
+    }
+    case ORC_HEX27: {
+        double c[3] = {(xi[0] + 1) * 0.5, (xi[1] + 1) * 0.5, (xi[2] + 1) * 0.5};
+        double v[3][3], d[3][3];
+        for (int k = 0; k < 3; ++k) {
+            v[k][0] = q0(c[k]); v[k][1] = q1(c[k]); v[k][2] = q2(c[k]);
+            d[k][0] = 0.5 * dq0(c[k]); d[k][1] = 0.5 * dq1(c[k]); d[k][2] = 0.5 * dq2(c[k]);
+        }
+        for (int a = 0; a < 27; ++a) {
+            int i = HEX27_IDX[a][0], j = HEX27_IDX[a][1], k = HEX27_IDX[a][2];
+            N[a] = v[0][i] * v[1][j] * v[2][k];
+            dN[3 * a + 0] = d[0][i] * v[1][j] * v[2][k];
+            dN[3 * a + 1] = v[0][i] * d[1][j] * v[2][k];
+            dN[3 * a + 2] = v[0][i] * v[1][j] * d[2][k];
+        }
+        return 0;
+    }
+    }
+    return -1;
+}
+
+/* src/ferrite-addons/PR883.jl:253-263 (J = Σ xⱼ ⊗ dMⱼ/dξ) and :367-387 (detJ, J⁻¹).
+ * x: ngeo*dim, dM: ngeo*dim, J/Jinv: dim*dim row-major. returns -1 when detJ <= 0 (PR883.jl:376). */
+int orc_mapping(int dim, int ngeo, const double *x, const double *dM, double *J, double *detJ, double *Jinv)
+{
+    for (int i = 0; i < dim * dim; ++i) J[i] = 0.0;
+    for (int a = 0; a < ngeo; ++a)
+        for (int i = 0; i < dim; ++i)
+            for (int k = 0; k < dim; ++k) J[dim * i + k] += x[dim * a + i] * dM[dim * a + k];
+    double det;
+    if (dim == 1) {
+        det = J[0]; Jinv[0] = 1.0 / det;
+    } else if (dim == 2) {
+        det = J[0] * J[3] - J[1] * J[2];
+        double id = 1.0 / det;
+        Jinv[0] = J[3] * id; Jinv[1] = -J[1] * id; Jinv[2] = -J[2] * id; Jinv[3] = J[0] * id;
+    } else {
+        double c00 = J[4] * J[8] - J[5] * J[7], c01 = J[5] * J[6] - J[3] * J[8], c02 = J[3] * J[7] - J[4] * J[6];
+        det = J[0] * c00 + J[1] * c01 + J[2] * c02;
+        double id = 1.0 / det;
+        Jinv[0] = c00 * id; Jinv[1] = (J[2] * J[7] - J[1] * J[8]) * id; Jinv[2] = (J[1] * J[5] - J[2] * J[4]) * id;
+        Jinv[3] = c01 * id; Jinv[4] = (J[0] * J[8] - J[2] * J[6]) * id; Jinv[5] = (J[2] * J[3] - J[0] * J[5]) * id;
+        Jinv[6] = c02 * id; Jinv[7] = (J[1] * J[6] - J[0] * J[7]) * id; Jinv[8] = (J[0] * J[4] - J[1] * J[3]) * id;
+    }
+    *detJ = det;
+    return det > 0.0 ? 0 : -1;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* coefficient evaluators                                                                      */
+/* ------------------------------------------------------------------------------------------ */
+
+/* src/modeling/core/coefficients.jl:85-99: val += shape_value(cv,qp,i) * data[i, cell] */
+void orc_eval_field(int nb, int ncomp, const double *Nq, const double *data_cell, double *out)
+{
+    for (int c = 0; c < ncomp; ++c) out[c] = 0.0;
+    for (int i = 0; i < nb; ++i)
+        for (int c = 0; c < ncomp; ++c) out[c] += Nq[i] * data_cell[ncomp * i + c];
+}
+
+/* src/modeling/core/coefficients.jl:279-292: x += shape_value(cv,qp,i) * coords[i] */
+void orc_eval_cartesian(int nb, int sdim, const double *Nq, const double *coords, double *x)
+{
+    orc_eval_field(nb, sdim, Nq, coords, x);
+}
+
+/* src/utils.jl:120-139: normalise, then Gram–Schmidt in the order f, s, n */
+void orc_orthogonalize(int dim, double *f, double *s, double *n)
+{
+    double nf = 0, ns = 0, nn = 0;
+    for (int d = 0; d < dim; ++d) { nf += f[d] * f[d]; ns += s[d] * s[d]; if (n) nn += n[d] * n[d]; }
+    nf = sqrt(nf); ns = sqrt(ns); nn = sqrt(nn);
+    for (int d = 0; d < dim; ++d) { f[d] /= nf; s[d] /= ns; if (n) n[d] /= nn; }
+    double fs = 0;
+    for (int d = 0; d < dim; ++d) fs += f[d] * s[d];
+    double w2[3];
+    for (int d = 0; d < dim; ++d) w2[d] = s[d] - fs * f[d];
+    if (n) {
+        double fn = 0, w2n = 0;
+        for (int d = 0; d < dim; ++d) { fn += f[d] * n[d]; w2n += w2[d] * n[d]; }
+        for (int d = 0; d < dim; ++d) n[d] = n[d] - fn * f[d] - w2n * w2[d];
+    }
+    for (int d = 0; d < dim; ++d) s[d] = w2[d];
+}
+
+/* src/modeling/microstructure.jl:36-38 (planar f,s), :89-92 (transversely isotropic: nvec==1 →
+ * λ₁ f⊗f + λ₂ (I − f⊗f)), :136-138 (orthotropic λ₁ff+λ₂ss+λ₃nn). vecs: nvec*dim */
+void orc_eval_spectral(int dim, int nvec, const double *vecs, const double *lambda, double *D)
+{
+    if (nvec == 1) {
+        for (int i = 0; i < dim; ++i)
+            for (int j = 0; j < dim; ++j) {
+                double ff = vecs[i] * vecs[j];
+                D[dim * i + j] = lambda[0] * ff + lambda[1] * ((i == j ? 1.0 : 0.0) - ff);
+            }
+        return;
+    }
+    for (int i = 0; i < dim * dim; ++i) D[i] = 0.0;
+    for (int v = 0; v < nvec; ++v)
+        for (int i = 0; i < dim; ++i)
+            for (int j = 0; j < dim; ++j) D[dim * i + j] += lambda[v] * vecs[dim * v + i] * vecs[dim * v + j];
+}
+
+/* src/modeling/core/coefficients.jl:152-162: return κ/(Cₘ*χ) */
+void orc_conductivity_to_diffusivity(int n, const double *kappa, double Cm, double chi, double *D)
+{
+    double den = Cm * chi;
+    for (int i = 0; i < n; ++i) D[i] = kappa[i] / den;
+}
+
+/* src/modeling/core/coefficients.jl:519-531; returns the 0-based data index */
+int orc_eval_homogeneous_data_index(int ntimings, const double *timings, double t)
+{
+    int i = 1;
+    double ti = timings[0];
+    while (ti < t) {
+        i += 1;
+        if (i > ntimings) return ntimings; /* data[end], data has ntimings+1 entries */
+        ti = timings[i - 1];
+    }
+    return i - 1;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* mesh / dof / pattern generators (Ferrite conventions)                                       */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Ferrite generate_grid(Hexahedron,(nx,ny,nz),left,right) (wrapped by src/mesh/generators.jl:942):
+ * nodes x-fastest on the lattice, cells x-fastest, local vertex order as src/mesh/generators.jl:62-79 */
+void orc_generate_grid_hex(int nx, int ny, int nz, const double *left, const double *right,
+                           double *xyz, int32_t *conn)
+{
+    int npx = nx + 1, npy = ny + 1, npz = nz + 1;
+    int64_t n = 0;
+    for (int k = 0; k < npz; ++k)
+        for (int j = 0; j < npy; ++j)
+            for (int i = 0; i < npx; ++i) {
+                /* range(left, stop=right, length=n)[i] */
+                xyz[3 * n + 0] = nx ? left[0] + (right[0] - left[0]) * ((double)i / nx) : left[0];
+                xyz[3 * n + 1] = ny ? left[1] + (right[1] - left[1]) * ((double)j / ny) : left[1];
+                xyz[3 * n + 2] = nz ? left[2] + (right[2] - left[2]) * ((double)k / nz) : left[2];
+                if (i == nx) xyz[3 * n + 0] = right[0];
+                if (j == ny) xyz[3 * n + 1] = right[1];
+                if (k == nz) xyz[3 * n + 2] = right[2];
+                ++n;
+            }
+#define NODE(i, j, k) ((int32_t)((i) + (int64_t)npx * ((j) + (int64_t)npy * (k))))
+    int64_t c = 0;
+    for (int k = 0; k < nz; ++k)
+        for (int j = 0; j < ny; ++j)
+            for (int i = 0; i < nx; ++i) {
+                int32_t *e = conn + 8 * c++;
+                e[0] = NODE(i, j, k);         e[1] = NODE(i + 1, j, k);
+                e[2] = NODE(i + 1, j + 1, k); e[3] = NODE(i, j + 1, k);
+                e[4] = NODE(i, j, k + 1);     e[5] = NODE(i + 1, j, k + 1);
+                e[6] = NODE(i + 1, j + 1, k + 1); e[7] = NODE(i, j + 1, k + 1);
+            }
+#undef NODE
+}
+
+/* tiny open-addressing hash map (key: up to 4 sorted node ids) for edge / face entities */
+typedef struct { int64_t cap; int32_t *keys; int32_t *vals; } emap;
+static void emap_init(emap *m, int64_t n) {
+    m->cap = 16; while (m->cap < 2 * n + 16) m->cap <<= 1;
+    m->keys = (int32_t *)malloc(sizeof(int32_t) * 4 * m->cap);
+    m->vals = (int32_t *)malloc(sizeof(int32_t) * m->cap);
+    for (int64_t i = 0; i < m->cap; ++i) m->vals[i] = -1;
+}
+static void emap_free(emap *m) { free(m->keys); free(m->vals); }
+static int32_t *emap_slot(emap *m, const int32_t *key) {
+    uint64_t h = 1469598103934665603ull;
+    for (int i = 0; i < 4; ++i) { h ^= (uint64_t)(uint32_t)key[i]; h *= 1099511628211ull; }
+    int64_t s = (int64_t)(h & (uint64_t)(m->cap - 1));
+    for (;;) {
+        if (m->vals[s] < 0) { memcpy(m->keys + 4 * s, key, 16); return &m->vals[s]; }
+        if (!memcmp(m->keys + 4 * s, key, 16)) return &m->vals[s];
+        s = (s + 1) & (m->cap - 1);
+    }
+}
+static void sort4(int32_t *k, int n) {
+    for (int i = 1; i < n; ++i) { int32_t v = k[i]; int j = i - 1; while (j >= 0 && k[j] > v) { k[j + 1] = k[j]; --j; } k[j + 1] = v; }
+}
+
+/* Ferrite close!(dh): cells visited in order; within a cell vertices, then edges, then faces, then
+ * the volume; an entity gets `ncomp` consecutive dofs the first time it is seen.  The node-major /
+ * component-minor local order is confirmed in-tree by src/ferrite-addons/io.jl:233-238. */
+int64_t orc_close_dofs(int kind, int ncomp, int64_t n_cells, int64_t n_nodes, const int32_t *conn,
+                       int32_t *cell_dofs)
+{
+    static const int E[12][2] = {{0,1},{1,2},{2,3},{3,0},{4,5},{5,6},{6,7},{7,4},{0,4},{1,5},{2,6},{3,7}};
+    static const int F[6][4] = {{0,3,2,1},{0,1,5,4},{1,2,6,5},{2,3,7,6},{0,4,7,3},{4,5,6,7}};
+    int nverts = (kind == ORC_TET4) ? 4 : 8;
+    int nb = (kind == ORC_HEX27) ? 27 : nverts;
+    int32_t *vdof = (int32_t *)malloc(sizeof(int32_t) * n_nodes);
+    for (int64_t i = 0; i < n_nodes; ++i) vdof[i] = -1;
+    emap em, fm;
+    if (kind == ORC_HEX27) { emap_init(&em, 4 * n_cells + 8); emap_init(&fm, 4 * n_cells + 8); }
+    int32_t next = 0;
+    for (int64_t c = 0; c < n_cells; ++c) {
+        const int32_t *e = conn + nverts * c;
+        int32_t *d = cell_dofs + (int64_t)nb * ncomp * c;
+        int l = 0;
+        for (int v = 0; v < nverts; ++v) {
+            if (vdof[e[v]] < 0) { vdof[e[v]] = next; next += ncomp; }
+            for (int k = 0; k < ncomp; ++k) d[l++] = vdof[e[v]] + k;
+        }
+        if (kind == ORC_HEX27) {
+            for (int ed = 0; ed < 12; ++ed) {
+                int32_t key[4] = {e[E[ed][0]], e[E[ed][1]], -1, -1};
+                sort4(key, 2);
+                int32_t *s = emap_slot(&em, key);
+                if (*s < 0) { *s = next; next += ncomp; }
+                for (int k = 0; k < ncomp; ++k) d[l++] = *s + k;
+            }
+            for (int f = 0; f < 6; ++f) {
+                int32_t key[4] = {e[F[f][0]], e[F[f][1]], e[F[f][2]], e[F[f][3]]};
+                sort4(key, 4);
+                int32_t *s = emap_slot(&fm, key);
+                if (*s < 0) { *s = next; next += ncomp; }
+                for (int k = 0; k < ncomp; ++k) d[l++] = *s + k;
+            }
+            for (int k = 0; k < ncomp; ++k) d[l++] = next + k;
+            next += ncomp;
+        }
+    }
+    free(vdof);
+    if (kind == ORC_HEX27) { emap_free(&em); emap_free(&fm); }
+    return next;
+}
+
+static int cmp_i32(const void *a, const void *b) { int32_t x = *(const int32_t *)a, y = *(const int32_t *)b; return (x > y) - (x < y); }
+
+/* Ferrite allocate_matrix(dh) → sparsity pattern of all intra-cell couplings, columns sorted;
+ * CSR by transposition of the symmetric CSC pattern (src/solver/interface.jl:162-168). */
+int64_t orc_build_pattern(int64_t n_cells, int ndpc, const int32_t *cell_dofs, int64_t ndofs,
+                          int64_t *rowptr, int32_t *colidx)
+{
+    /* dof → cells (CSR) */
+    int64_t *cnt = (int64_t *)calloc(ndofs + 1, sizeof(int64_t));
+    for (int64_t i = 0; i < n_cells * ndpc; ++i) cnt[cell_dofs[i] + 1]++;
+    for (int64_t i = 0; i < ndofs; ++i) cnt[i + 1] += cnt[i];
+    int64_t *pos = (int64_t *)malloc(sizeof(int64_t) * ndofs);
+    memcpy(pos, cnt, sizeof(int64_t) * ndofs);
+    int64_t *cells = (int64_t *)malloc(sizeof(int64_t) * n_cells * ndpc);
+    for (int64_t c = 0; c < n_cells; ++c)
+        for (int l = 0; l < ndpc; ++l) cells[pos[cell_dofs[c * ndpc + l]]++] = c;
+    int32_t *tmp = (int32_t *)malloc(sizeof(int32_t) * 64 * ndpc * 8);
+    int64_t tmpcap = 64 * ndpc * 8;
+    int64_t nnz = 0;
+    rowptr[0] = 0;
+    for (int64_t r = 0; r < ndofs; ++r) {
+        int64_t nc = cnt[r + 1] - cnt[r];
+        if (nc * ndpc > tmpcap) { tmpcap = nc * ndpc * 2; tmp = (int32_t *)realloc(tmp, sizeof(int32_t) * tmpcap); }
+        int64_t n = 0;
+        for (int64_t k = cnt[r]; k < cnt[r + 1]; ++k)
+            for (int l = 0; l < ndpc; ++l) tmp[n++] = cell_dofs[cells[k] * ndpc + l];
+        qsort(tmp, n, sizeof(int32_t), cmp_i32);
+        int64_t u = 0;
+        for (int64_t k = 0; k < n; ++k)
+            if (k == 0 || tmp[k] != tmp[k - 1]) { if (colidx) colidx[nnz + u] = tmp[k]; ++u; }
+        nnz += u;
+        rowptr[r + 1] = nnz;
+    }
+    free(tmp); free(cells); free(pos); free(cnt);
+    return nnz;
+}
+
+/* Greedy colouring in cell order: two cells conflict iff they share a dof.  (FerriteOperators'
+ * PerColorAssemblyStrategy delegates to Ferrite.create_coloring — third party, UNPINNED; any valid
+ * colouring gives the same assembled matrix up to summation order.) */
+int orc_color_cells(int64_t n_cells, int ndpc, const int32_t *cell_dofs, int64_t ndofs, int32_t *color)
+{
+    /* per-dof bitmask of colours already used by cells touching it (≤64 colours) */
+    uint64_t *used = (uint64_t *)calloc(ndofs, sizeof(uint64_t));
+    int ncolors = 0;
+    for (int64_t c = 0; c < n_cells; ++c) {
+        uint64_t m = 0;
+        for (int l = 0; l < ndpc; ++l) m |= used[cell_dofs[c * ndpc + l]];
+        int col = 0;
+        while (col < 64 && (m >> col) & 1) ++col;
+        if (col >= 64) { free(used); return -1; }
+        color[c] = col;
+        if (col + 1 > ncolors) ncolors = col + 1;
+        for (int l = 0; l < ndpc; ++l) used[cell_dofs[c * ndpc + l]] |= (1ull << col);
+    }
+    free(used);
+    return ncolors;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* element kernels                                                                             */
+/* ------------------------------------------------------------------------------------------ */
+
+/* CellValues(qr, ip, ip_geo): function values N/dN and geometric values M/dM.  The geometry is
+ * always the cell's own linear interpolation (geometric_subdomain_interpolation, src/utils.jl:412-418) */
+typedef struct {
+    int dim, nb, ngeo, nq;
+    double N[MAXQ][MAXNB], dN[MAXQ][MAXNB * 3], M[MAXQ][8], dM[MAXQ][24], w[MAXQ], xi[MAXQ * 3];
+} cellvalues;
+
+static int cv_setup(cellvalues *cv, int kind, int qorder)
+{
+    if (orc_elem_info(kind, &cv->dim, &cv->nb)) return -1;
+    cv->nq = orc_quadrature(kind == ORC_HEX27 ? ORC_HEX8 : kind, qorder, cv->xi, cv->w);
+    if (cv->nq <= 0 || cv->nq > MAXQ) return -1;
+    int gkind = kind == ORC_HEX27 ? ORC_HEX8 : kind, gd;
+    orc_elem_info(gkind, &gd, &cv->ngeo);
+    for (int q = 0; q < cv->nq; ++q) {
+        orc_shape(kind, cv->xi + cv->dim * q, cv->N[q], cv->dN[q]);
+        orc_shape(gkind, cv->xi + cv->dim * q, cv->M[q], cv->dM[q]);
+    }
+    return 0;
+}
+
+static void gather_coords(const orc_mesh *m, const cellvalues *cv, int64_t cell, double *x)
+{
+    for (int a = 0; a < cv->ngeo; ++a)
+        for (int d = 0; d < cv->dim; ++d) x[cv->dim * a + d] = m->xyz[(int64_t)cv->dim * m->conn[cell * cv->ngeo + a] + d];
+}
+
+/* Ferrite reinit!(cv, cell) ≡ PR883.jl:253-291: detJ·w and dNdx = dNdξ ⋅ J⁻¹ at point q */
+static int reinit_qp(const cellvalues *cv, int q, const double *x, double *dOmega, double *dNdx)
+{
+    double J[9], Jinv[9], det;
+    int dim = cv->dim;
+    if (orc_mapping(dim, cv->ngeo, x, cv->dM[q], J, &det, Jinv)) return -1;
+    *dOmega = det * cv->w[q];
+    if (dNdx)
+        for (int a = 0; a < cv->nb; ++a)
+            for (int k = 0; k < dim; ++k) {
+                double s = 0;
+                for (int mm = 0; mm < dim; ++mm) s += cv->dN[q][dim * a + mm] * Jinv[dim * mm + k];
+                dNdx[dim * a + k] = s;
+            }
+    return 0;
+}
+
+/* evaluate a (tensor-valued) diffusion coefficient at quadrature point q of `cell` */
+static void eval_tensor_coef(const orc_coef *c, const cellvalues *cv, int q, int64_t cell, double *D)
+{
+    int dim = cv->dim, nb = cv->nb;
+    double k[9];
+    switch (c->kind) {
+    case ORC_COEF_CONST_SCALAR:
+        for (int i = 0; i < dim * dim; ++i) k[i] = 0;
+        for (int i = 0; i < dim; ++i) k[dim * i + i] = c->p[0];
+        break;
+    case ORC_COEF_CONST_TENSOR:
+        for (int i = 0; i < dim * dim; ++i) k[i] = c->p[i];
+        break;
+    case ORC_COEF_SPECTRAL_CONST:
+        orc_eval_spectral(dim, dim, c->p, c->p + dim * dim, k);
+        break;
+    case ORC_COEF_TRANSVERSE_CONST:
+        orc_eval_spectral(dim, 1, c->p, c->p + dim, k);
+        break;
+    case ORC_COEF_SPECTRAL_FIELD: {
+        /* microstructure.jl:176-187: interpolate f,s,n (coefficients.jl:85-99), orthogonalise */
+        double v[9];
+        const double *base = c->field + (int64_t)cell * nb * 9; /* [cell][basis][f|s|n][3] */
+        double tmp[3 * MAXNB];
+        for (int which = 0; which < 3; ++which) {
+            for (int a = 0; a < nb; ++a) for (int d = 0; d < 3; ++d) tmp[3 * a + d] = base[9 * a + 3 * which + d];
+            orc_eval_field(nb, 3, cv->N[q], tmp, v + 3 * which);
+        }
+        orc_orthogonalize(3, v, v + 3, v + 6);
+        orc_eval_spectral(3, 3, v, c->p, k);
+        break;
+    }
+    default:
+        for (int i = 0; i < dim * dim; ++i) k[i] = 0;
+    }
+    if (c->wrap) orc_conductivity_to_diffusivity(dim * dim, k, c->Cm, c->chi, D);
+    else memcpy(D, k, sizeof(double) * dim * dim);
+}
+
+static double eval_scalar_coef(const orc_coef *c, const cellvalues *cv, int q, int64_t cell)
+{
+    if (c->kind == ORC_COEF_FIELD_SCALAR) {
+        double v;
+        orc_eval_field(cv->nb, 1, cv->N[q], c->field + (int64_t)cell * cv->nb, &v);
+        return v;
+    }
+    return c->p[0];
+}
+
+/* src/modeling/core/mass.jl:28-43 */
+static int element_mass_cv(const orc_mesh *m, const cellvalues *cv, int64_t cell, const orc_coef *rho, double *Me)
+{
+    double x[3 * MAXNB];
+    int nb = cv->nb;
+    gather_coords(m, cv, cell, x);
+    for (int q = 0; q < cv->nq; ++q) {
+        double dO;
+        if (reinit_qp(cv, q, x, &dO, NULL)) return -1;
+        double r = eval_scalar_coef(rho, cv, q, cell);
+        for (int i = 0; i < nb; ++i) {
+            double Ni = cv->N[q][i];
+            for (int j = 0; j < nb; ++j) {
+                double Nj = cv->N[q][j];
+                Me[nb * i + j] += r * (Ni * Nj) * dO;
+            }
+        }
+    }
+    return 0;
+}
+
+/* src/modeling/core/diffusion.jl:28-50; _inner_product_helper(∇Nⱼ, D, ∇Nᵢ) = (∇Nⱼ⋅D)⋅∇Nᵢ, src/utils.jl:409 */
+static int element_diffusion_cv(const orc_mesh *m, const cellvalues *cv, int64_t cell, const orc_coef *Dc, double *Ke)
+{
+    double x[3 * MAXNB], dNdx[3 * MAXNB], D[9];
+    int nb = cv->nb, dim = cv->dim;
+    gather_coords(m, cv, cell, x);
+    for (int q = 0; q < cv->nq; ++q) {
+        double dO;
+        if (reinit_qp(cv, q, x, &dO, dNdx)) return -1;
+        eval_tensor_coef(Dc, cv, q, cell, D);
+        for (int i = 0; i < nb; ++i) {
+            const double *gi = dNdx + dim * i;
+            for (int j = 0; j < nb; ++j) {
+                const double *gj = dNdx + dim * j;
+                double s = 0;
+                for (int k = 0; k < dim; ++k) {
+                    double gjD = 0;
+                    for (int mm = 0; mm < dim; ++mm) gjD += gj[mm] * D[dim * mm + k];
+                    s += gjD * gi[k];
+                }
+                Ke[nb * i + j] -= s * dO;
+            }
+        }
+    }
+    return 0;
+}
+
+static double eval_source(int kind, const double *p, const double *table, int dim, const double *x, double t,
+                          int64_t cell, int q, int nq)
+{
+    switch (kind) {
+    case ORC_SRC_CONST: return p[0];
+    case ORC_SRC_NORM_PLUS_T: {
+        double n2 = 0; for (int d = 0; d < dim; ++d) n2 += x[d] * x[d];
+        return sqrt(n2) + t;
+    }
+    case ORC_SRC_COS_EXP: {
+        double n2 = 0; for (int d = 0; d < dim; ++d) n2 += x[d] * x[d];
+        double nr = sqrt(n2);
+        return cos(2 * M_PI * t) * exp(-(nr * nr));
+    }
+    case ORC_SRC_TABULATED: return table[(int64_t)cell * nq + q];
+    }
+    return 0.0;
+}
+
+/* src/modeling/core/analytical_coefficient.jl:80-101 */
+static int element_source_cv(const orc_mesh *m, const cellvalues *cv, int64_t cell, int kind, const double *p,
+                             const double *table, double t, double *be)
+{
+    double x[3 * MAXNB], xq[3];
+    gather_coords(m, cv, cell, x);
+    for (int q = 0; q < cv->nq; ++q) {
+        double dO;
+        if (reinit_qp(cv, q, x, &dO, NULL)) return -1;
+        orc_eval_cartesian(cv->ngeo, cv->dim, cv->M[q], x, xq);
+        double fx = eval_source(kind, p, table, cv->dim, xq, t, cell, q, cv->nq);
+        for (int j = 0; j < cv->nb; ++j) be[j] += fx * cv->N[q][j] * dO;
+    }
+    return 0;
+}
+
+int orc_element_mass(const orc_mesh *m, int64_t cell, const orc_coef *rho, double t, double *Me)
+{
+    (void)t; cellvalues cv;
+    if (cv_setup(&cv, m->kind, m->qorder)) return -2;
+    return element_mass_cv(m, &cv, cell, rho, Me);
+}
+int orc_element_diffusion(const orc_mesh *m, int64_t cell, const orc_coef *D, double t, double *Ke)
+{
+    (void)t; cellvalues cv;
+    if (cv_setup(&cv, m->kind, m->qorder)) return -2;
+    return element_diffusion_cv(m, &cv, cell, D, Ke);
+}
+int orc_element_source(const orc_mesh *m, int64_t cell, int src_kind, const double *p, const double *table,
+                       double t, double *be)
+{
+    cellvalues cv;
+    if (cv_setup(&cv, m->kind, m->qorder)) return -2;
+    return element_source_cv(m, &cv, cell, src_kind, p, table, t, be);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* drivers                                                                                     */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Ferrite assemble!(assembler, dofs, Ke) on a CSR pattern: K[dofs[i], dofs[j]] += Ke[i,j] */
+static int scatter_matrix(int nb, const int32_t *dofs, const double *Ke, const int64_t *rowptr,
+                          const int32_t *colidx, double *nzval)
+{
+    for (int i = 0; i < nb; ++i) {
+        int64_t lo0 = rowptr[dofs[i]], hi0 = rowptr[dofs[i] + 1];
+        for (int j = 0; j < nb; ++j) {
+            int64_t lo = lo0, hi = hi0;
+            int32_t c = dofs[j];
+            while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (colidx[mid] < c) lo = mid + 1; else hi = mid; }
+            if (lo >= hi0 || colidx[lo] != c) return -3;
+            nzval[lo] += Ke[nb * i + j];
+        }
+    }
+    return 0;
+}
+
+/* Canonical sequential loop, src/modeling/core/coordinate_systems.jl:145-171:
+ * start_assemble (zero fill) → for cell: fill!(Ke,0); element kernel; assemble!(…) */
+int orc_assemble_matrix(const orc_mesh *m, int form, const orc_coef *c, double t, const int64_t *rowptr,
+                        const int32_t *colidx, double *nzval, int nthreads, const int32_t *color, int ncolors)
+{
+    (void)t;
+    cellvalues cv;
+    if (cv_setup(&cv, m->kind, m->qorder)) return -2;
+    int nb = cv.nb;
+    int64_t ndofs = 0;
+    for (int64_t i = 0; i < m->n_cells * nb; ++i) if (m->cell_dofs[i] + 1 > ndofs) ndofs = m->cell_dofs[i] + 1;
+    memset(nzval, 0, sizeof(double) * rowptr[ndofs]);
+    int err = 0;
+    if (nthreads <= 1 || !color) {
+        double Ke[MAXNB * MAXNB];
+        for (int64_t cell = 0; cell < m->n_cells && !err; ++cell) {
+            memset(Ke, 0, sizeof(double) * nb * nb);
+            int r = form == 0 ? element_mass_cv(m, &cv, cell, c, Ke) : element_diffusion_cv(m, &cv, cell, c, Ke);
+            if (r) { err = r; break; }
+            r = scatter_matrix(nb, m->cell_dofs + cell * nb, Ke, rowptr, colidx, nzval);
+            if (r) err = r;
+        }
+        return err;
+    }
+    /* PerColorAssemblyStrategy(PolyesterDevice(n)) semantics: colours in sequence, cells of one
+     * colour concurrently (test/integration/test_solid_mechanics.jl:40) — CPU baseline only */
+#ifdef _OPENMP
+    omp_set_num_threads(nthreads);
+#endif
+    for (int col = 0; col < ncolors; ++col) {
+#pragma omp parallel for schedule(static) reduction(|| : err)
+        for (int64_t cell = 0; cell < m->n_cells; ++cell) {
+            if (color[cell] != col) continue;
+            double Ke[MAXNB * MAXNB];
+            memset(Ke, 0, sizeof(double) * nb * nb);
+            int r = form == 0 ? element_mass_cv(m, &cv, cell, c, Ke) : element_diffusion_cv(m, &cv, cell, c, Ke);
+            if (!r) r = scatter_matrix(nb, m->cell_dofs + cell * nb, Ke, rowptr, colidx, nzval);
+            err = err || (r != 0);
+        }
+    }
+    return err ? -1 : 0;
+}
+
+/* Source vector.  The reference forces ElementAssemblyStrategy for it (src/solver/time/euler.jl:148-153):
+ * element vectors are stored per cell and gathered per dof; the sequential form below adds in cell
+ * order (coordinate_systems.jl:203-230 scatter-add).  nthreads>1: EA form (store bₑ, then gather). */
+int orc_assemble_source(const orc_mesh *m, int src_kind, const double *p, const double *table, double t,
+                        double *b, int nthreads)
+{
+    cellvalues cv;
+    if (cv_setup(&cv, m->kind, m->qorder)) return -2;
+    int nb = cv.nb;
+    int64_t ndofs = 0;
+    for (int64_t i = 0; i < m->n_cells * nb; ++i) if (m->cell_dofs[i] + 1 > ndofs) ndofs = m->cell_dofs[i] + 1;
+    memset(b, 0, sizeof(double) * ndofs);
+    if (nthreads <= 1) {
+        double be[MAXNB];
+        for (int64_t cell = 0; cell < m->n_cells; ++cell) {
+            memset(be, 0, sizeof(double) * nb);
+            if (element_source_cv(m, &cv, cell, src_kind, p, table, t, be)) return -1;
+            for (int j = 0; j < nb; ++j) b[m->cell_dofs[cell * nb + j]] += be[j];
+        }
+        return 0;
+    }
+#ifdef _OPENMP
+    omp_set_num_threads(nthreads);
+#endif
+    double *ea = (double *)malloc(sizeof(double) * m->n_cells * nb);
+    int err = 0;
+#pragma omp parallel for schedule(static) reduction(|| : err)
+    for (int64_t cell = 0; cell < m->n_cells; ++cell) {
+        double *be = ea + cell * nb;
+        memset(be, 0, sizeof(double) * nb);
+        err = err || element_source_cv(m, &cv, cell, src_kind, p, table, t, be);
+    }
+    /* dof → (cell, local) map, then gather in cell order */
+    int64_t *cnt = (int64_t *)calloc(ndofs + 1, sizeof(int64_t));
+    for (int64_t i = 0; i < m->n_cells * nb; ++i) cnt[m->cell_dofs[i] + 1]++;
+    for (int64_t i = 0; i < ndofs; ++i) cnt[i + 1] += cnt[i];
+    int64_t *pos = (int64_t *)malloc(sizeof(int64_t) * ndofs);
+    memcpy(pos, cnt, sizeof(int64_t) * ndofs);
+    int64_t *src = (int64_t *)malloc(sizeof(int64_t) * m->n_cells * nb);
+    for (int64_t i = 0; i < m->n_cells * nb; ++i) src[pos[m->cell_dofs[i]]++] = i;
+#pragma omp parallel for schedule(static)
+    for (int64_t d = 0; d < ndofs; ++d) {
+        double s = 0;
+        for (int64_t k = cnt[d]; k < cnt[d + 1]; ++k) s += ea[src[k]];
+        b[d] = s;
+    }
+    free(src); free(pos); free(cnt); free(ea);
+    return err ? -1 : 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* ionic models                                                                                */
+/* ------------------------------------------------------------------------------------------ */
+
+int orc_cell_nstates(int model) { return model == ORC_CELL_PCG2019 ? 7 : (model == ORC_CELL_FHN || model == ORC_CELL_ALIEV_PANFILOV) ? 2 : -1; }
+int orc_cell_nparams(int model) { return model == ORC_CELL_PCG2019 ? 36 : (model == ORC_CELL_FHN || model == ORC_CELL_ALIEV_PANFILOV) ? 6 : -1; }
+
+/* PCG2019 parameter order = struct field order, src/modeling/cells/pcg2019.jl:4-48 */
+enum { P_gNa, P_Em, P_km, P_taum, P_Eh, P_kh, P_dh, P_tauh0, P_gK1, P_Ez, P_kz, P_gto, P_Er, P_kr, P_Es, P_ks,
+       P_taus, P_gCaL, P_Ed, P_kd, P_Ef, P_kf, P_tauf, P_gKr, P_Exr, P_kxr, P_tauxr, P_Ey, P_ky, P_gKs, P_Exs,
+       P_kxs, P_tauxs, P_ENa, P_EK, P_ECa, P_NPAR };
+
+void orc_cell_default_params(int model, double *p)
+{
+    if (model == ORC_CELL_FHN) { /* cells/fhn.jl:6-13 */
+        const double d[6] = {0.1, 0.5, 1.0, 0.0, 0.01, 1.0};
+        memcpy(p, d, sizeof d);
+    } else if (model == ORC_CELL_ALIEV_PANFILOV) { /* cells/aliev-panfilov.jl:1-8 */
+        const double d[6] = {1.0 / 12.9, 8.0, 0.05, 0.002, 0.2, 0.3};
+        memcpy(p, d, sizeof d);
+    } else if (model == ORC_CELL_PCG2019) { /* cells/pcg2019.jl:4-48 */
+        const double d[36] = {12.0, -52.244, 6.5472, 0.12, -78.7, 5.93, 0.799163, 6.80738,
+                              0.73893, -91.9655, 12.4997,
+                              0.1688, 14.3116, 11.462, -47.9286, 4.9314, 9.90669,
+                              0.11503, 0.7, 4.3, -15.7, 4.6, 30.0,
+                              0.056, -26.6, 6.5, 334.0, -49.6, 23.5,
+                              0.008, 24.6, 12.1, 628.0,
+                              65.0, -85.0, 50.0};
+        memcpy(p, d, sizeof d);
+    }
+}
+
+static double sigmoid(double phi, double E, double k, double sign) { return 1.0 / (1.0 + exp(sign * (phi - E) / k)); }
+
+/* cells/pcg2019.jl:137-152; FHN / AP default to zeros (fhn.jl:19, aliev-panfilov.jl:15) */
+void orc_cell_default_state(int model, const double *p, double *u0)
+{
+    if (model != ORC_CELL_PCG2019) { u0[0] = u0[1] = 0.0; return; }
+    u0[0] = p[P_EK];
+    u0[1] = sigmoid(u0[0], p[P_Eh], p[P_kh], 1.0);
+    u0[2] = sigmoid(u0[0], p[P_Em], p[P_km], -1.0);
+    u0[3] = sigmoid(u0[0], p[P_Ef], p[P_kf], 1.0);
+    u0[4] = sigmoid(u0[0], p[P_Es], p[P_ks], 1.0);
+    u0[5] = sigmoid(u0[0], p[P_Exs], p[P_kxs], -1.0);
+    u0[6] = sigmoid(u0[0], p[P_Exr], p[P_kxr], -1.0);
+}
+
+void orc_cell_rhs(int model, const double *p, const double *u, double t, double *du)
+{
+    (void)t;
+    if (model == ORC_CELL_FHN) { /* cells/fhn.jl:21-34 */
+        double a = p[0], b = p[1], c = p[2], d = p[3], e = p[4], f = p[5];
+        double phi = u[0], s = u[1];
+        du[0] = f * (phi * (1 - phi) * (phi - a) - s);
+        du[1] = e * (b * phi - c * s - d);
+    } else if (model == ORC_CELL_ALIEV_PANFILOV) { /* cells/aliev-panfilov.jl:17-31 — state order (s, φₘ) */
+        double ct = p[0], k = p[1], a = p[2], e0 = p[3], mu1 = p[4], mu2 = p[5];
+        double phi = u[1], s = u[0];
+        double eps = e0 + s * mu1 / (phi + mu2);
+        du[1] = ct * (k * phi * (phi - 1.0) * (phi - a) - phi * s);
+        du[0] = ct * eps * (-s - k * phi * (phi - a - 1.0));
+    } else if (model == ORC_CELL_PCG2019) { /* cells/pcg2019.jl:52-133 */
+        double phi = u[0];
+        double h = u[1], mg = u[2], f = u[3], s = u[4], xs = u[5], xr = u[6];
+        const double C_m = 1.0; /* pcg2019.jl:55 */
+        double rinf = sigmoid(phi, p[P_Er], p[P_kr], -1.0);
+        double dinf = sigmoid(phi, p[P_Ed], p[P_kd], -1.0);
+        double zinf = sigmoid(phi, p[P_Ez], p[P_kz], 1.0);
+        double yinf = sigmoid(phi, p[P_Ey], p[P_ky], 1.0);
+        double I_Na = p[P_gNa] * mg * mg * mg * h * h * (phi - p[P_ENa]);
+        double I_K1 = p[P_gK1] * zinf * (phi - p[P_EK]);
+        double I_to = p[P_gto] * rinf * s * (phi - p[P_EK]);
+        double I_CaL = p[P_gCaL] * dinf * f * (phi - p[P_ECa]);
+        double I_Kr = p[P_gKr] * xr * yinf * (phi - p[P_EK]);
+        double I_Ks = p[P_gKs] * xs * (phi - p[P_EK]);
+        double I_total = I_Na + I_K1 + I_to + I_CaL + I_Kr + I_Ks;
+        du[0] = -I_total / C_m;
+        double tau_h = (2.0 * p[P_tauh0] * exp(p[P_dh] * (phi - p[P_Eh]) / p[P_kh])) / (1.0 + exp((phi - p[P_Eh]) / p[P_kh]));
+        double hinf = sigmoid(phi, p[P_Eh], p[P_kh], 1.0);
+        du[1] = (hinf - h) / tau_h;
+        double minf = sigmoid(phi, p[P_Em], p[P_km], -1.0);
+        du[2] = (minf - mg) / p[P_taum];
+        double finf = sigmoid(phi, p[P_Ef], p[P_kf], 1.0);
+        du[3] = (finf - f) / p[P_tauf];
+        double sinf = sigmoid(phi, p[P_Es], p[P_ks], 1.0);
+        du[4] = (sinf - s) / p[P_taus];
+        double xsinf = sigmoid(phi, p[P_Exs], p[P_kxs], -1.0);
+        du[5] = (xsinf - xs) / p[P_tauxs];
+        double xrinf = sigmoid(phi, p[P_Exr], p[P_kxr], -1.0);
+        du[6] = (xrinf - xr) / p[P_tauxr];
+    }
+}
+
+/* transmembranepotential_index, src/modeling/electrophysiology.jl:149-153 (position of :φₘ) */
+static int phi_index(int model) { return model == ORC_CELL_ALIEV_PANFILOV ? 1 : 0; }
+
+/* src/solver/time/partitioned_solver.jl:80-99 (FE) and :196-234 (adaptive) for one point */
+static void point_step(int model, const double *p, double *ul, double *dul, int ns, double t, double dt,
+                       int substeps, double threshold)
+{
+    orc_cell_rhs(model, p, ul, t, dul);
+    if (substeps <= 1) {
+        for (int j = 0; j < ns; ++j) ul[j] += dt * dul[j];
+        return;
+    }
+    if (fabs(dul[phi_index(model)]) < threshold) {
+        for (int j = 0; j < ns; ++j) ul[j] += dt * dul[j];
+    } else {
+        double dts = dt / substeps;
+        for (int j = 0; j < ns; ++j) ul[j] += dts * dul[j];
+        for (int s = 2; s <= substeps; ++s) {
+            double ts = t + (s - 1) * dts;
+            orc_cell_rhs(model, p, ul, ts, dul);
+            for (int j = 0; j < ns; ++j) ul[j] += dts * dul[j];
+        }
+    }
+}
+
+/* outer loop, partitioned_solver.jl:38-52; layouts: SoA uₙmat = reshape(uₙ,(npoints,nstates)) (:113-116),
+ * AoS reshape(view,(nstates,npoints))' (:137-148); du is materialised like dumat. */
+int orc_reaction_step(int model, const double *p, double *u, double *du, int64_t npoints, int layout,
+                      double t, double dt, int substeps, double threshold, int nthreads)
+{
+    int ns = orc_cell_nstates(model);
+    if (ns < 0) return -1;
+#ifdef _OPENMP
+    if (nthreads > 1) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(static) if (nthreads > 1)
+    for (int64_t i = 0; i < npoints; ++i) {
+        double ul[8], dul[8];
+        for (int j = 0; j < ns; ++j) ul[j] = layout == ORC_LAYOUT_SOA ? u[i + j * npoints] : u[i * ns + j];
+        point_step(model, p, ul, dul, ns, t, dt, substeps, threshold);
+        for (int j = 0; j < ns; ++j) {
+            int64_t k = layout == ORC_LAYOUT_SOA ? i + j * npoints : i * ns + j;
+            u[k] = ul[j];
+            if (du) du[k] = dul[j];
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* heat-step algebra                                                                           */
+/* ------------------------------------------------------------------------------------------ */
+
+/* src/solver/time/euler.jl:110-116: Anz = Mnz - Δt * Knz */
+void orc_heat_matrix(int64_t nnz, const double *Mnz, const double *Knz, double dt, double *Anz)
+{
+    for (int64_t i = 0; i < nnz; ++i) Anz[i] = Mnz[i] - dt * Knz[i];
+}
+
+/* src/utils.jl:185-231: y[row] = alpha*Σ nz·x[col] + beta*y[row] (3-arg form: alpha=1, beta=0) */
+void orc_spmv_csr(int64_t nrows, const int64_t *rowptr, const int32_t *colidx, const double *nz,
+                  const double *x, double alpha, double beta, double *y, int nthreads)
+{
+#ifdef _OPENMP
+    if (nthreads > 1) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(static) if (nthreads > 1)
+    for (int64_t r = 0; r < nrows; ++r) {
+        double v = 0;
+        for (int64_t k = rowptr[r]; k < rowptr[r + 1]; ++k) v += nz[k] * x[colidx[k]];
+        y[r] = (beta == 0.0) ? alpha * v : alpha * v + beta * y[r];
+    }
+}

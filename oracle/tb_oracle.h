@@ -1,0 +1,146 @@
+/*
+ * tb_oracle.h — CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT).
+ *
+ * Plain-C restatement of the Thunderbolt.jl v0.0.4 hot path (per-cell FE integration + pointwise
+ * ionic reaction step).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library; the shipped path (thunderbolt.jl_amd/csrc) never links, imports or calls it.
+ *
+ * PARITY STATUS: the Julia reference cannot be executed in the build container (no julia binary,
+ * Ferrite.jl / FerriteOperators.jl / Tensors.jl are not vendored under /root/reference).  The
+ * coefficient evaluators are pinned against the closed-form expectations of the reference's own
+ * test/test_coefficients.jl (tests/golden/coefficients.json); the geometry stage is pinned by the
+ * identities of the reference's "Static interpolation values" test on its distorted cells; the cell
+ * models / steppers are closed forms.  Assembled K, M, b, DoF numbering and sparsity order have no
+ * golden vector in the reference: for those rows this oracle is "parity unpinned" (see DESIGN.md).
+ *
+ * All file:line citations are relative to /root/reference.
+ */
+#ifndef TB_ORACLE_H
+#define TB_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* reference cell kinds (Ferrite reference shapes, [-1,1]^d hypercubes, unit simplices) */
+enum { ORC_LINE2 = 1, ORC_QUAD4 = 2, ORC_HEX8 = 3, ORC_TET4 = 4, ORC_HEX27 = 5 };
+
+/* coefficient kinds */
+enum {
+    ORC_COEF_CONST_SCALAR = 0,   /* p[0]                                         coefficients.jl:101-120 */
+    ORC_COEF_CONST_TENSOR = 1,   /* p[0..d*d) row-major                          coefficients.jl:101-120 */
+    ORC_COEF_FIELD_SCALAR = 2,   /* field[basis + nb*cell]                       coefficients.jl:85-99   */
+    ORC_COEF_SPECTRAL_CONST = 3, /* p = f,s,n (d each), lambda[d]; no orthogonalisation microstructure.jl:136-138 */
+    ORC_COEF_SPECTRAL_FIELD = 4, /* field = f,s,n nodal Vec3 per cell; p = lambda[3]  microstructure.jl:176-187 */
+    ORC_COEF_TRANSVERSE_CONST = 5/* p = f (d), lambda[2]                         microstructure.jl:89-92 */
+};
+
+/* closed-form source terms f(x,t) (Julia closures cannot cross a C ABI — SURVEY F10) */
+enum {
+    ORC_SRC_CONST = 0,             /* p[0] */
+    ORC_SRC_NORM_PLUS_T = 1,       /* norm(x)+t              benchmarks/benchmarks-linear-form.jl:16-20 */
+    ORC_SRC_COS_EXP = 2,           /* cos(2πt)·exp(-‖x‖²)    test/gpu/test_operators.jl:13-18 */
+    ORC_SRC_TABULATED = 3          /* table[q + nq*cell] (host-evaluated closure) */
+};
+
+enum { ORC_CELL_FHN = 0, ORC_CELL_ALIEV_PANFILOV = 1, ORC_CELL_PCG2019 = 2 };
+enum { ORC_LAYOUT_SOA = 0, ORC_LAYOUT_AOS = 1 };
+
+/* ---- FE substrate (Ferrite conventions restated; UNPINNED where SURVEY §8c says so) ---- */
+int orc_elem_info(int kind, int *refdim, int *nbasis);
+/* Gauss rule with `order` points per direction (hypercubes) / Ferrite's order-`order` simplex rule.
+ * xi: nq*refdim, w: nq. returns nq (or <0). */
+int orc_quadrature(int kind, int order, double *xi, double *w);
+/* N[nb], dN[nb*refdim] at reference point xi */
+int orc_shape(int kind, const double *xi, double *N, double *dN);
+
+/* src/ferrite-addons/PR883.jl:253-263 + :367-387 — J, detJ, dNdx = dNdξ·J⁻¹ (square J only) */
+int orc_mapping(int dim, int ngeo, const double *x, const double *dM, double *J, double *detJ, double *Jinv);
+
+/* ---- coefficient evaluators at one quadrature point (dimension generic) ---- */
+/* src/modeling/core/coefficients.jl:85-99 */
+void orc_eval_field(int nb, int ncomp, const double *Nq, const double *data_cell, double *out);
+/* src/modeling/core/coefficients.jl:279-292 */
+void orc_eval_cartesian(int nb, int sdim, const double *Nq, const double *coords, double *x);
+/* src/modeling/microstructure.jl:36-38,89-92,136-138 */
+void orc_eval_spectral(int dim, int nvec, const double *vecs, const double *lambda, double *D);
+/* src/utils.jl:131-139 (3D) and :120-124 (2D) */
+void orc_orthogonalize(int dim, double *f, double *s, double *n);
+/* src/modeling/core/coefficients.jl:152-162: κ/(Cₘ·χ) */
+void orc_conductivity_to_diffusivity(int n, const double *kappa, double Cm, double chi, double *D);
+/* src/modeling/core/coefficients.jl:519-531 */
+int orc_eval_homogeneous_data_index(int ntimings, const double *timings, double t);
+
+/* ---- mesh / dof / pattern generators (Ferrite.jl 1.6 conventions, UNPINNED) ---- */
+void orc_generate_grid_hex(int nx, int ny, int nz, const double *left, const double *right,
+                           double *xyz, int32_t *conn);
+/* Ferrite close!(dh): first-visit numbering, cells in order, vertices→edges→faces→volume,
+ * `ncomp` components interleaved per entity. kind HEX8 (order 1) or HEX27 (order 2 field on HEX8 grid).
+ * cell_dofs: n_cells*ndofs_per_cell (0-based). returns ndofs. */
+int64_t orc_close_dofs(int kind, int ncomp, int64_t n_cells, int64_t n_nodes, const int32_t *conn,
+                       int32_t *cell_dofs);
+/* allocate_matrix(dh): all intra-cell couplings, sorted columns per row. Two-pass:
+ * colidx==NULL → fills rowptr only; returns nnz. */
+int64_t orc_build_pattern(int64_t n_cells, int ndpc, const int32_t *cell_dofs, int64_t ndofs,
+                          int64_t *rowptr, int32_t *colidx);
+/* greedy colouring of the cell-conflict graph (cells sharing a dof) — semantics of
+ * PerColorAssemblyStrategy; returns ncolors */
+int orc_color_cells(int64_t n_cells, int ndpc, const int32_t *cell_dofs, int64_t ndofs, int32_t *color);
+
+/* ---- element kernels ---- */
+typedef struct {
+    int kind;          /* geometry/field cell kind (ORC_HEX8, ORC_TET4, ...) */
+    int qorder;        /* quadrature order (points per direction) */
+    int64_t n_cells, n_nodes;
+    const double *xyz; /* n_nodes*dim */
+    const int32_t *conn;
+    const int32_t *cell_dofs; /* n_cells*nb */
+} orc_mesh;
+
+typedef struct {
+    int kind;
+    const double *p;      /* parameters */
+    const double *field;  /* per-cell nodal data or tabulated values */
+    double Cm, chi;       /* applied as D/(Cm*chi) when wrap != 0  (fem.jl:413-419) */
+    int wrap;
+} orc_coef;
+
+/* mass.jl:28-43 */
+int orc_element_mass(const orc_mesh *m, int64_t cell, const orc_coef *rho, double t, double *Me);
+/* diffusion.jl:28-50 + utils.jl:409-410 */
+int orc_element_diffusion(const orc_mesh *m, int64_t cell, const orc_coef *D, double t, double *Ke);
+/* analytical_coefficient.jl:80-101 */
+int orc_element_source(const orc_mesh *m, int64_t cell, int src_kind, const double *p,
+                       const double *table, double t, double *be);
+
+/* ---- drivers: sequential cell loop + assemble! (coordinate_systems.jl:145-171, :203-230) ---- */
+/* form: 0 = mass, 1 = diffusion. nzval overwritten. nthreads>1 → per-colour OpenMP (baseline only) */
+int orc_assemble_matrix(const orc_mesh *m, int form, const orc_coef *c, double t,
+                        const int64_t *rowptr, const int32_t *colidx, double *nzval,
+                        int nthreads, const int32_t *color, int ncolors);
+int orc_assemble_source(const orc_mesh *m, int src_kind, const double *p, const double *table,
+                        double t, double *b, int nthreads);
+
+/* ---- reaction ---- */
+/* cells/fhn.jl:21-34, cells/aliev-panfilov.jl:17-31, cells/pcg2019.jl:52-133 */
+int orc_cell_nstates(int model);
+int orc_cell_nparams(int model);
+void orc_cell_default_params(int model, double *p);
+void orc_cell_default_state(int model, const double *p, double *u0);   /* pcg2019.jl:137-152 */
+void orc_cell_rhs(int model, const double *p, const double *u, double t, double *du);
+/* partitioned_solver.jl:38-52 (outer), :80-99 (FE), :196-234 (adaptive). substeps<=1 → plain FE. */
+int orc_reaction_step(int model, const double *p, double *u, double *du, int64_t npoints, int layout,
+                      double t, double dt, int substeps, double threshold, int nthreads);
+
+/* ---- heat-step algebra ---- */
+/* euler.jl:110-116 */
+void orc_heat_matrix(int64_t nnz, const double *Mnz, const double *Knz, double dt, double *Anz);
+/* utils.jl:185-231 */
+void orc_spmv_csr(int64_t nrows, const int64_t *rowptr, const int32_t *colidx, const double *nz,
+                  const double *x, double alpha, double beta, double *y, int nthreads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
