@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path on N MI355X (one process per GPU).
+
+A "step" is one pass of the hot path over one synthetic batch: the three monodomain element
+integrations over the whole mesh — mass matrix M, diffusion matrix K (κ/(Cₘχ)), source vector b —
+then the halo sum of b over the slab interfaces (N > 1) and one forward-Euler reaction step of the
+ionic model on every dof.  Workload at N = 1: BASELINE.json's metric configuration, the 10M-hex Q1
+monodomain mesh (216³ = 10 077 696 hexahedra, 10 218 313 dofs), PCG2019 as the 7-state ionic model
+(the reference has no ten Tusscher 2006 — SURVEY F6).  N > 1: weak scaling, every rank owns one such
+slab of a box that is N times longer in z; assembly has no data-path collective, the only exchange
+is the neighbour halo sum of shared-node vector entries.
+
+Prints ONE JSON line (rank 0).  `value` = element-integrations/s of the whole job over the timed
+region (3·cells per step / step time, reaction included in the step time); DoF-updates/s and the
+per-phase rates are extra keys.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+FP64_VECTOR_TFLOPS = 78.6      # AMD spec sheet; FP64 MFMA runs at the same rate on CDNA4
+BYTES_PER_CELL_MATRIX = 272.0  # 32 B conn + 24 B coords + 27 nz × 8 B
+BYTES_PER_CELL_VECTOR = 64.0   # 32 + 24 + 8
+BYTES_PER_DOF_UPDATE = 16.0    # in place; 24 when du is materialised
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=216, help="cells per edge of each rank's box (216 → 10M hexahedra)")
+    ap.add_argument("--strategy", default="patch", choices=["patch", "atomic", "color"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-n", type=int, default=64, help="edge of the CPU-baseline sample mesh")
+    ap.add_argument("--keep-du", action="store_true", help="materialise du (dumat) in the reaction step")
+    return ap.parse_args()
+
+
+def cpu_baseline(n, kap, threads):
+    """Oracle ("port": C restatement of the reference CPU path, NOT Julia) on a bounded sample of the same workload."""
+    from oracle import oracle as o
+    xyz, conn = o.generate_grid_hex(n, n, n, (0, 0, 0), (1, 1, 1))
+    cd, nd = o.close_dofs(o.HEX8, 1, conn, len(xyz))
+    rp, ci = o.build_pattern(cd, nd)
+    col, nc = o.color_cells(cd, nd)
+    m = o.Mesh(o.HEX8, 2, xyz, conn, cd)
+    cM = o.Coef(o.COEF_CONST_SCALAR, [1.0])
+    cK = o.Coef(o.COEF_CONST_TENSOR, kap.ravel(), Cm=1.0, chi=1.0, wrap=True)
+    p = o.cell_default_params(o.CELL_PCG2019)
+    u = np.ascontiguousarray(np.tile(o.cell_default_state(o.CELL_PCG2019, p), (nd, 1)).T).ravel().copy()
+    best_asm, best_rx = 1e30, 1e30
+    t_end = time.time() + 20.0
+    reps = 0
+    while reps < 2 or (time.time() < t_end and reps < 8):
+        t0 = time.perf_counter()
+        o.assemble_matrix(m, 0, cM, rp, ci, nthreads=threads, color=col, ncolors=nc)
+        o.assemble_matrix(m, 1, cK, rp, ci, nthreads=threads, color=col, ncolors=nc)
+        o.assemble_source(m, o.SRC_COS_EXP, t=0.0, nthreads=threads)
+        t1 = time.perf_counter()
+        o.reaction_step(o.CELL_PCG2019, p, u, nd, o.LAYOUT_SOA, dt=0.01, nthreads=threads, want_du=False)
+        t2 = time.perf_counter()
+        best_asm, best_rx = min(best_asm, t1 - t0), min(best_rx, t2 - t1)
+        reps += 1
+    ncell = n ** 3
+    return {"value": 3 * ncell / best_asm, "unit": "element-integrations/s", "cores": threads, "kind": "port",
+            "sample": "%d^3 hex Q1 mesh (%d cells): M + K + b per-colour/EA OpenMP, min of %d reps; C restatement of the reference CPU path, not Julia" % (n, ncell, reps),
+            "dof_updates_per_s": 7 * nd / best_rx}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    import thunderbolt_jl_amd as tb
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = tb.MI355XDevice(local_rank)
+    dev.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    n = args.n
+    part = tb.distributed.SlabPartition((n, n, n * world), (0.0, 0.0, 0.0), (1.0, 1.0, float(world)), world, rank)
+    g = tb.generate_mesh(tb.Hexahedron, part.local_nel(), part.left, part.right, perturb=0.2)
+    dh = tb.DofHandler(g)
+    sp = tb.allocate_matrix(dh)
+    st = {"patch": tb.PatchAssemblyStrategy, "atomic": tb.AtomicAssemblyStrategy, "color": tb.PerColorAssemblyStrategy}[args.strategy](dev)
+    st_vec = tb.PatchAssemblyStrategy(dev) if args.strategy == "patch" else st
+    kap = np.diag([4.5e-5, 2.0e-5, 2.0e-5])  # docs/src/literate-tutorials/ep01_spiral-wave.jl:39-41 style conductivities
+    D = tb.ConductivityToDiffusivityCoefficient(tb.ConstantCoefficient(kap), tb.ConstantCoefficient(1.0), tb.ConstantCoefficient(1.0))
+    M = tb.setup_operator(st, tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.0)), dh, sp)
+    K = tb.setup_operator(st, tb.BilinearDiffusionIntegrator(D), dh, sp)
+    src = tb.setup_operator(st_vec, tb.LinearIntegrator(tb.AnalyticalCoefficient("cos_exp")), dh)
+    # source vector lives in a torch tensor so RCCL can exchange its interface entries
+    b = torch.zeros(dh.ndofs, dtype=torch.float64, device="cuda")
+    src.b = tb.DeviceVector.wrap(dev, b)
+    lo_idx = up_idx = None
+    if world > 1:
+        n2d = tb.distributed.node_to_dof(dh)
+        lo, up = part.interface_nodes()
+        lo_idx = None if lo is None else torch.from_numpy(n2d[lo]).cuda()
+        up_idx = None if up is None else torch.from_numpy(n2d[up]).cuda()
+
+    model = tb.PCG2019()
+    npts = dh.ndofs
+    u0 = np.tile(model.default_initial_state(), (npts, 1))
+    u0[:, 0] += np.linspace(0.0, 60.0, npts)
+    u = torch.from_numpy(np.ascontiguousarray(u0.T).ravel()).cuda()
+    f = tb.PointwiseODEFunction(npts, model)
+    cache = tb.setup_solver_cache(f, tb.ForwardEulerCellSolver(dev), u=u, keep_du=args.keep_du)
+
+    ev = [dev.event() for _ in range(6)]
+    phase = {"mass": 0.0, "diffusion": 0.0, "source": 0.0, "halo": 0.0, "reaction": 0.0}
+
+    def step(i, timed):
+        t = 0.01 * i
+        ev[0].record(); tb.update_operator(M, t)
+        ev[1].record(); tb.update_operator(K, t)
+        ev[2].record(); tb.update_operator(src, t)
+        ev[3].record()
+        if world > 1:
+            tb.distributed.halo_sum(b, lo_idx, up_idx, rank, world, dist)
+        ev[4].record(); tb.perform_step(f, cache, t, 0.01)
+        ev[5].record()
+        if timed:
+            for k, name in enumerate(phase):
+                phase[name] += ev[k].elapsed_ms(ev[k + 1])
+
+    for i in range(args.warmup):
+        step(i, False)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i, True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        K_ = args.steps
+        cells_total = g.n_cells * world
+        dofs_total = npts * world
+        ms = elapsed / K_ * 1e3
+        k_ms = phase["diffusion"] / K_
+        achieved = BYTES_PER_CELL_MATRIX * g.n_cells / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "element-integrations/sec + DoF-updates/sec, 10M-hex Q1 monodomain",
+            "value": 3 * cells_total * K_ / elapsed, "unit": "element-integrations/s",
+            "n_gpus": world, "steps": K_, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "monodomain hot path on %d^3 hex Q1 per GPU (%d cells, %d dofs): assemble M + K + b (%s scatter)%s + PCG2019 forward-Euler reaction step"
+                                   % (n, g.n_cells, npts, args.strategy, " + neighbour halo sum of b" if world > 1 else ""),
+                       "cells_per_gpu": g.n_cells, "dofs_per_gpu": npts, "nnz_per_gpu": sp.nnz, "ionic_states": 7,
+                       "partition": "z-slabs"},
+            "dof_updates_per_s": 7 * dofs_total * K_ / elapsed,
+            "phase_ms": {k: v / K_ for k, v in phase.items()},
+            "phase_rates": {"mass_cells_per_s": g.n_cells / (phase["mass"] / K_ * 1e-3),
+                            "diffusion_cells_per_s": g.n_cells / (k_ms * 1e-3),
+                            "source_cells_per_s": g.n_cells / (phase["source"] / K_ * 1e-3),
+                            "reaction_dof_updates_per_s": 7 * npts / (phase["reaction"] / K_ * 1e-3)},
+            "roofline": {"kernel": "k_matrix_patch<Hex8<2>,DIFFUSION>" if args.strategy == "patch" else "k_matrix_direct<Hex8<2>,DIFFUSION>",
+                         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None,
+                         "note": "algorithmic 272 B/cell; the kernel is FP64-VALU-bound (≈5 kflop/cell, FP64 MFMA = vector rate on CDNA4), see DESIGN.md",
+                         "reaction": {"bound": "hbm", "achieved": (BYTES_PER_DOF_UPDATE + (8 if args.keep_du else 0)) * 7 * npts / (phase["reaction"] / K_ * 1e-3) / 1e9,
+                                      "peak": HBM_PEAK_GBS, "unit": "GB/s"}},
+        }
+        out["roofline"]["reaction"]["frac"] = out["roofline"]["reaction"]["achieved"] / HBM_PEAK_GBS
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_n, kap, os.cpu_count() or 1)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,209 @@
+/*
+ * tbhip.h — C ABI of the MI355X (gfx950) hot-path backend for Thunderbolt.jl.
+ *
+ * This is the drop-in boundary: exactly what a Julia `ccall` binding (julia/ThunderboltHIPBackend.jl,
+ * see INTEGRATION.md) needs to provide `MI355XDevice <: AbstractGPUDevice` behind Thunderbolt's
+ * operator API.  Plain pointers and sizes only; no C++ types, no exceptions, every function returns
+ * an `int` status (0 = TB_OK, <0 = error) and `tb_last_error_string()` describes the last failure
+ * on the calling thread.
+ *
+ * Each entry cites the reference interface it replaces (paths relative to the Thunderbolt.jl
+ * v0.0.4 tree).  The cell loop / scatter the kernels replace lives in FerriteOperators.jl (third
+ * party); its visible call sites are cited instead.
+ *
+ * Pointer naming: `d_*` = device pointer (owned by the caller, e.g. a Julia GC-managed wrapper with
+ * a finaliser calling tb_free), everything else = host pointer.  All indices handed in may be 0- or
+ * 1-based (`index_base`); the library stores 0-based Int32 on device.
+ * Output arrays of the assembly calls are OVERWRITTEN (the reference zero-fills before assembling:
+ * src/solver/nonlinear/newton_raphson.jl:231, src/disambiguation.jl:26-35).
+ *
+ * Threading: calls on one tb_device are serialised on that device's HIP stream and are synchronous
+ * on return only where stated; different devices may be driven from different threads.
+ */
+#ifndef TBHIP_H
+#define TBHIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tb_device tb_device;
+typedef struct tb_mesh tb_mesh;
+typedef struct tb_pattern tb_pattern;
+typedef struct tb_form tb_form;
+
+enum {
+    TB_OK = 0,
+    TB_ERR_BAD_ARG = -1,
+    TB_ERR_HIP = -2,
+    TB_ERR_NEG_DETJ = -3,    /* detJ <= 0 in some cell (src/ferrite-addons/PR883.jl:376 "TODO: return error code") */
+    TB_ERR_PATTERN = -4,     /* a cell coupling is missing from the CSR pattern */
+    TB_ERR_UNSUPPORTED = -5,
+    TB_ERR_NOMEM = -6
+};
+
+/* cell kinds (Ferrite reference shapes; local vertex order as src/mesh/generators.jl:62-79) */
+enum { TB_HEX8 = 3, TB_TET4 = 4, TB_HEX27 = 5 /* Q2 field on trilinear HEX8 geometry */ };
+
+/* assembly strategies — device analogues of the FerriteOperators strategies Thunderbolt re-exports
+ * (src/Thunderbolt.jl:22-32; selected via FiniteElementDiscretization(; assembly_strategy), src/discretization/fem.jl:38-46) */
+enum {
+    TB_STRATEGY_ATOMIC = 0,    /* one thread per cell, FP64 hardware atomics                                   */
+    TB_STRATEGY_PER_COLOR = 1, /* PerColorAssemblyStrategy: colours in sequence, plain read-modify-write       */
+    TB_STRATEGY_ELEMENT = 2,   /* ElementAssemblyStrategy: element vectors stored, gathered per dof (vectors;  */
+                               /* forced for the source term by src/solver/time/euler.jl:148-153)              */
+    TB_STRATEGY_PATCH = 3      /* native: Morton patches of cells, rows accumulated in LDS, each nz / dof      */
+                               /* written exactly once with coalesced stores (default, fastest)                */
+};
+
+/* bilinear / linear forms */
+enum {
+    TB_FORM_MASS = 0,      /* Mₑ[i,j] += ρ NᵢNⱼ dΩ          src/modeling/core/mass.jl:28-43       */
+    TB_FORM_DIFFUSION = 1, /* Kₑ[i,j] -= ∇Nⱼ·D·∇Nᵢ dΩ       src/modeling/core/diffusion.jl:28-50  */
+    TB_FORM_SOURCE = 2     /* bₑ[j]  += f(x_q,t) Nⱼ dΩ      src/modeling/core/analytical_coefficient.jl:80-101 */
+};
+
+/* coefficients (src/modeling/core/coefficients.jl, src/modeling/microstructure.jl).  Julia closures cannot
+ * cross a C ABI, so analytical coefficients are enumerated closed forms or host-tabulated values. */
+enum {
+    TB_COEF_CONST_SCALAR = 0,    /* p[0]: ρ, or isotropic D = p[0]·I         ConstantCoefficient, coefficients.jl:101-120 */
+    TB_COEF_CONST_TENSOR = 1,    /* p[0..9) row-major 3×3                    ConstantCoefficient(Tensor)                  */
+    TB_COEF_FIELD_SCALAR = 2,    /* field[basis + nb·cell]                   FieldCoefficient, coefficients.jl:85-99      */
+    TB_COEF_SPECTRAL_CONST = 3,  /* p = f[3],s[3],n[3],λ[3]                  SpectralTensorCoefficient of constants, microstructure.jl:136-138 */
+    TB_COEF_SPECTRAL_FIELD = 4,  /* field = per cell, per basis: f[3],s[3],n[3]; p = λ[3]; interpolated, normalised and
+                                    Gram–Schmidt-orthogonalised per quadrature point  microstructure.jl:176-187, utils.jl:131-139 */
+    TB_COEF_TRANSVERSE_CONST = 5 /* p = f[3], λ[2]:  λ₁ f⊗f + λ₂ (I − f⊗f)   microstructure.jl:89-92 */
+};
+enum {
+    TB_SRC_CONST = 0,        /* p[0] */
+    TB_SRC_NORM_PLUS_T = 1,  /* ‖x‖ + t               benchmarks/benchmarks-linear-form.jl:16-20 */
+    TB_SRC_COS_EXP = 2,      /* cos(2πt)·exp(−‖x‖²)   test/gpu/test_operators.jl:13-18, benchmarks/benchmarks-cuda-linear-form.jl:15-18 */
+    TB_SRC_TABULATED = 3     /* table[q + nq·cell], host-evaluated closure (tb_form_set_table) */
+};
+
+typedef struct tb_coef {
+    int32_t kind;        /* TB_COEF_* (mass, diffusion) or TB_SRC_* (source) */
+    int32_t wrap;        /* != 0: ConductivityToDiffusivityCoefficient, D = κ/(Cₘ·χ)  coefficients.jl:152-162, fem.jl:413-419 */
+    double Cm, chi;
+    double p[16];
+    const double *field; /* HOST pointer, copied at tb_form_create; may be NULL */
+    int64_t field_len;   /* number of doubles behind `field` */
+} tb_coef;
+
+/* ionic models (src/modeling/cells/{fhn,aliev-panfilov,pcg2019}.jl) and state layouts (src/modeling/solution_variables.jl:40-68) */
+enum { TB_CELL_FHN = 0, TB_CELL_ALIEV_PANFILOV = 1, TB_CELL_PCG2019 = 2 };
+enum {
+    TB_LAYOUT_SOA = 0, /* StateBlockedLayout: u[k + s·npoints]  */
+    TB_LAYOUT_AOS = 1  /* PointBlockedLayout: u[k·nstates + s]  */
+};
+
+/* ------------------------------------------------------------------ errors */
+const char *tb_last_error_string(void);
+const char *tb_version(void);
+
+/* ------------------------------------------------------------------ device (AbstractGPUDevice, src/devices.jl:3-4;
+ * replaces FerriteOperators.CudaDevice as used in ext/CuThunderboltExt.jl:48-49) */
+int tb_device_create(int hip_device_id, tb_device **out);
+int tb_device_destroy(tb_device *dev);
+/* adopt an external hipStream_t (e.g. the host framework's current stream); NULL → library-owned stream */
+int tb_device_set_stream(tb_device *dev, void *hip_stream);
+int tb_device_synchronize(tb_device *dev);
+int tb_device_info(tb_device *dev, char *name, size_t name_len, int *n_cu, size_t *hbm_bytes);
+
+/* vectors / matrices storage (create_system_vector / create_system_matrix, ext/CuThunderboltExt.jl:126-146) */
+int tb_malloc(tb_device *dev, size_t bytes, void **d_ptr);
+int tb_free(tb_device *dev, void *d_ptr);
+int tb_memcpy_h2d(tb_device *dev, void *d_dst, const void *src, size_t bytes); /* synchronous */
+int tb_memcpy_d2h(tb_device *dev, void *dst, const void *d_src, size_t bytes); /* synchronous */
+int tb_memcpy_d2d(tb_device *dev, void *d_dst, const void *d_src, size_t bytes);
+int tb_memset(tb_device *dev, void *d_ptr, int byte, size_t bytes);
+
+/* HIP events on the device's stream (for hosts that time kernels, cf. TimerOutputs sections of
+ * src/solver/time/euler.jl:85-94) */
+int tb_event_create(tb_device *dev, void **event);
+int tb_event_record(tb_device *dev, void *event);
+int tb_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronises on `stop` */
+int tb_event_destroy(void *event);
+
+/* ------------------------------------------------------------------ mesh + dof table
+ * Grid + DofHandler of ONE SubDofHandler with ONE field (src/utils.jl:52-56 celldofsview,
+ * dh.cell_dofs / dh.cell_dofs_offset).  The host supplies Ferrite's own node coordinates, cell
+ * connectivity and dof table, so DoF indexing is inherited bit-exactly, never re-derived.
+ *   xyz        n_nodes×3 (AoS);  conn  n_cells×nverts;  cell_dofs  n_cells×(nbasis·ncomp)
+ *   field_kind TB_HEX8 | TB_TET4 | TB_HEX27 (must match geom_kind's shape); ncomp 1 (scalar) or 3 */
+int tb_mesh_create(tb_device *dev, int geom_kind, int64_t n_nodes, const double *xyz, int64_t n_cells,
+                   const int32_t *conn, int field_kind, int ncomp, const int32_t *cell_dofs, int64_t ndofs,
+                   int index_base, tb_mesh **out);
+int tb_mesh_destroy(tb_mesh *mesh);
+int64_t tb_mesh_ncells(const tb_mesh *mesh);
+int64_t tb_mesh_ndofs(const tb_mesh *mesh);
+
+/* ------------------------------------------------------------------ sparsity pattern
+ * CSR pattern of allocate_matrix(dh) after transposition (src/solver/interface.jl:162-168),
+ * shared by every operator of one DofHandler (src/solver/time/euler.jl:110-116, newmark.jl:105-110).
+ * Builds the cell→nz scatter map on device.  Returns TB_ERR_PATTERN if a coupling is missing. */
+int tb_pattern_create(tb_mesh *mesh, int64_t n_rows, const int64_t *rowptr, const int32_t *colidx,
+                      int index_base, tb_pattern **out);
+int tb_pattern_destroy(tb_pattern *pat);
+int64_t tb_pattern_nnz(const tb_pattern *pat);
+/* device copies (0-based) so the host can wrap them into its own device CSR type */
+const int64_t *tb_pattern_rowptr_device(const tb_pattern *pat);
+const int32_t *tb_pattern_colidx_device(const tb_pattern *pat);
+
+/* ------------------------------------------------------------------ forms (setup_element_cache + Adapt.adapt_structure,
+ * src/modeling/core/mass.jl:45-55, diffusion.jl:52-60, ext/CuThunderboltExt.jl:151-170)
+ * qorder = Gauss points per direction; 0 → reference default max(2p−1,2) (src/discretization/fem.jl:52-55) */
+int tb_form_create(tb_mesh *mesh, int form_kind, int qorder, const tb_coef *coef, tb_form **out);
+int tb_form_destroy(tb_form *form);
+/* TB_SRC_TABULATED: upload host-evaluated f(x_q,t) values, n = n_cells·nq */
+int tb_form_set_table(tb_form *form, const double *values, int64_t n);
+
+/* ------------------------------------------------------------------ assembly
+ * update_operator!(op, t) for bilinear operators → fills op.A's nzval
+ * (src/solver/time/euler.jl:172-176; canonical loop src/modeling/core/coordinate_systems.jl:145-171) */
+int tb_assemble_matrix(tb_form *form, tb_pattern *pat, int strategy, double t, double *d_nzval);
+/* update_operator!(op, t) for linear operators → fills op.b (src/solver/time/euler.jl:119,176;
+ * test/gpu/test_operators.jl:24-30) */
+int tb_assemble_vector(tb_form *form, int strategy, double t, double *d_b);
+
+/* ------------------------------------------------------------------ pointwise reaction step
+ * _pointwise_step_outer_kernel!(f, t, Δt, cache, ::DeviceVector) (src/solver/time/partitioned_solver.jl:38-52,
+ * ext/CuThunderboltExt.jl:103-124).  substeps <= 1: ForwardEulerCellSolver (:80-99); substeps > 1:
+ * AdaptiveForwardEulerSubstepper with reaction_threshold (:196-234).  d_du (dumat) may be NULL when the
+ * caller does not need the rates (the RTC controller does: src/solver/time/rtc.jl:64-73).
+ * Returns TB_OK (the reference kernels always return true; NaNs are the host's business). */
+int tb_reaction_step(tb_device *dev, int model, const double *params, int n_params, double *d_u, double *d_du,
+                     int64_t n_points, int n_states, int layout, double t, double dt, int substeps,
+                     double threshold);
+int tb_cell_model_info(int model, int *n_states, int *n_params, int *phi_index);
+int tb_cell_model_defaults(int model, double *params, double *u0);
+
+/* ------------------------------------------------------------------ heat-step algebra
+ * Anz = Mnz − Δt·Knz (src/solver/time/euler.jl:110-116) */
+int tb_heat_matrix(tb_device *dev, int64_t nnz, const double *d_Mnz, const double *d_Knz, double dt, double *d_Anz);
+/* y = α·A·x + β·y, CSR (src/utils.jl:185-231; `b = M uₙ₋₁`, src/solver/time/euler.jl:85) */
+int tb_spmv_csr(tb_pattern *pat, const double *d_nzval, const double *d_x, double alpha, double beta, double *d_y);
+/* y += x (add!(b, source), src/solver/time/euler.jl:90) and max |x[i]| over a strided slice
+ * (RTC reads max(dumat[:,φₘidx]), src/solver/time/rtc.jl:64-73) */
+int tb_axpy(tb_device *dev, int64_t n, double a, const double *d_x, double *d_y);
+int tb_absmax(tb_device *dev, int64_t n, const double *d_x, int64_t stride, double *result);
+
+/* ------------------------------------------------------------------ host-side generators (no GPU needed)
+ * Ferrite-convention synthetic inputs for benchmarks and tests: generate_grid (src/mesh/generators.jl:942),
+ * close!(dh) numbering, allocate_matrix pattern.  Conventions are documented in DESIGN.md (UNPINNED
+ * third-party behaviour; at run time the Julia host passes Ferrite's own arrays instead). */
+int tb_host_generate_grid_hex(int nx, int ny, int nz, const double *left, const double *right,
+                              double *xyz, int32_t *conn);
+int tb_host_perturb_nodes(int nx, int ny, int nz, double amplitude_rel, double *xyz);
+int64_t tb_host_close_dofs(int field_kind, int ncomp, int64_t n_cells, int64_t n_nodes, const int32_t *conn,
+                           int32_t *cell_dofs);
+/* two-pass: colidx == NULL → counts only (fills rowptr, returns nnz) */
+int64_t tb_host_build_pattern(int64_t n_cells, int ndofs_per_cell, const int32_t *cell_dofs, int64_t ndofs,
+                              int64_t *rowptr, int32_t *colidx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TBHIP_H */

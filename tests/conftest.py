@@ -1,0 +1,32 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """CPU oracle (test infrastructure only)."""
+    from oracle import oracle as o
+    o.lib()
+    return o
+
+
+@pytest.fixture(scope="session")
+def tb():
+    import thunderbolt_jl_amd as tb
+    tb.lib()
+    return tb
+
+
+@pytest.fixture(scope="session")
+def device(tb):
+    return tb.MI355XDevice(0)

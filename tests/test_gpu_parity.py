@@ -1,0 +1,361 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on identical seeded
+inputs.  Tolerance: north_star's 1e-10 relative F64 for assembled K / M / b (we assert 1e-12, summation
+order and FMA contraction are the only differences); reaction states 1e-12 relative (device `exp` vs libm);
+integer work (scatter graph) is exact by construction of the comparison (same nz positions)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import hex_to_tets, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-12
+
+
+def make_problem(tb, oracle, nel=(4, 3, 5), perturb=0.25, left=(0, 0, 0), right=(1.0, 0.8, 1.3)):
+    g = tb.generate_mesh(tb.Hexahedron, nel, left, right, perturb=perturb)
+    dh = tb.DofHandler(g)
+    sp = tb.allocate_matrix(dh)
+    om = oracle.Mesh(oracle.HEX8, 2, g.xyz, g.conn, dh.cell_dofs)
+    return g, dh, sp, om
+
+
+def strategies(tb, device, matrix=True):
+    s = [tb.AtomicAssemblyStrategy(device), tb.PerColorAssemblyStrategy(device), tb.PatchAssemblyStrategy(device)]
+    if not matrix:
+        s.append(tb.ElementAssemblyStrategy(device))
+    return s
+
+
+def coef_cases(tb, oracle, g, rng):
+    nc = g.n_cells
+    kap = np.diag([4.5e-5, 2.0e-5, 2.0e-5])
+    full = np.array([[2.0, 0.3, 0.1], [0.3, 1.5, -0.2], [0.1, -0.2, 1.0]])
+    nonsym = full + np.array([[0, 0.4, 0], [0, 0, 0], [0.25, 0, 0]])
+    f, s, n = np.array([1, 1, 0.0]) / np.sqrt(2), np.array([-1, 1, 0.0]) / np.sqrt(2), np.array([0, 0, 1.0])
+    lam = np.array([3.0, 2.0, 0.5])
+    ffield = rng.normal(size=(nc, 8, 3)) + np.array([2.0, 0, 0])
+    sfield = rng.normal(size=(nc, 8, 3)) * 0.3 + np.array([0, 2.0, 0])
+    nfield = rng.normal(size=(nc, 8, 3)) * 0.3 + np.array([0, 0, 2.0])
+    fsn = np.stack([ffield, sfield, nfield], axis=2)
+    T, O = tb, oracle
+    return [
+        ("iso", T.ConstantCoefficient(1.0), O.Coef(O.COEF_CONST_SCALAR, [1.0])),
+        ("diag", T.ConstantCoefficient(kap), O.Coef(O.COEF_CONST_TENSOR, kap.ravel())),
+        ("full", T.ConstantCoefficient(full), O.Coef(O.COEF_CONST_TENSOR, full.ravel())),
+        ("nonsym", T.ConstantCoefficient(nonsym), O.Coef(O.COEF_CONST_TENSOR, nonsym.ravel())),
+        ("spectral", T.SpectralTensorCoefficient(T.ConstantCoefficient(T.OrthotropicMicrostructure(f, s, n)), T.ConstantCoefficient(lam)),
+         O.Coef(O.COEF_SPECTRAL_CONST, np.concatenate([f, s, n, lam]))),
+        ("transverse", T.SpectralTensorCoefficient(T.ConstantCoefficient(T.TransverselyIsotropicMicrostructure(f)), T.ConstantCoefficient(lam[:2])),
+         O.Coef(O.COEF_TRANSVERSE_CONST, np.concatenate([f, lam[:2]]))),
+        ("monodomain", T.ConductivityToDiffusivityCoefficient(
+            T.SpectralTensorCoefficient(T.ConstantCoefficient(T.OrthotropicMicrostructure(f, s, n)), T.ConstantCoefficient(lam)),
+            T.ConstantCoefficient(2.0), T.ConstantCoefficient(0.5)),
+         O.Coef(O.COEF_SPECTRAL_CONST, np.concatenate([f, s, n, lam]), Cm=2.0, chi=0.5, wrap=True)),
+        ("fibre_field", T.ConductivityToDiffusivityCoefficient(
+            T.SpectralTensorCoefficient(T.OrthotropicMicrostructureModel(ffield, sfield, nfield), T.ConstantCoefficient(lam)),
+            T.ConstantCoefficient(1.3), T.ConstantCoefficient(0.9)),
+         O.Coef(O.COEF_SPECTRAL_FIELD, lam, field=fsn, Cm=1.3, chi=0.9, wrap=True)),
+    ]
+
+
+def test_diffusion_matrix_parity(tb, oracle, device):
+    g, dh, sp, om = make_problem(tb, oracle)
+    rng = np.random.default_rng(0)
+    for name, tc, oc in coef_cases(tb, oracle, g, rng):
+        ref = oracle.assemble_matrix(om, 1, oc, sp.rowptr, sp.colidx)
+        for st in strategies(tb, device):
+            op = tb.setup_operator(st, tb.BilinearDiffusionIntegrator(tc), dh, sp)
+            tb.update_operator(op, 0.0)
+            got = op.A.to_host()
+            assert rel_err(got, ref) < TOL, (name, type(st).__name__, rel_err(got, ref))
+            tb.update_operator(op, 1.0)  # output is overwritten, not accumulated
+            assert rel_err(op.A.to_host(), ref) < TOL
+
+
+def test_mass_matrix_parity(tb, oracle, device):
+    g, dh, sp, om = make_problem(tb, oracle)
+    rng = np.random.default_rng(1)
+    rho_field = rng.uniform(0.5, 2.0, size=(g.n_cells, 8))
+    for name, tc, oc in (("const", tb.ConstantCoefficient(1.7), oracle.Coef(oracle.COEF_CONST_SCALAR, [1.7])),
+                         ("field", tb.FieldCoefficient(rho_field), oracle.Coef(oracle.COEF_FIELD_SCALAR, field=rho_field))):
+        ref = oracle.assemble_matrix(om, 0, oc, sp.rowptr, sp.colidx)
+        for st in strategies(tb, device):
+            op = tb.update_operator(tb.setup_operator(st, tb.BilinearMassIntegrator(tc), dh, sp), 0.0)
+            assert rel_err(op.A.to_host(), ref) < TOL, (name, type(st).__name__)
+
+
+def test_source_vector_parity(tb, oracle, device):
+    g, dh, sp, om = make_problem(tb, oracle, left=(-1, -1, -1), right=(1, 1, 1))
+    for kind, okind, t in (("norm_plus_t", oracle.SRC_NORM_PLUS_T, 0.0), ("norm_plus_t", oracle.SRC_NORM_PLUS_T, 0.7),
+                           ("cos_exp", oracle.SRC_COS_EXP, 0.1), ("const", oracle.SRC_CONST, 0.0)):
+        ref = oracle.assemble_source(om, okind, [2.5], t=t)
+        for st in strategies(tb, device, matrix=False):
+            op = tb.setup_operator(st, tb.LinearIntegrator(tb.AnalyticalCoefficient(kind, 2.5)), dh)
+            tb.update_operator(op, t)
+            assert rel_err(op.b.to_host(), ref) < TOL, (kind, type(st).__name__)
+    # host-tabulated closure == closed form
+    f = lambda x, t: np.linalg.norm(x) + t  # noqa: E731
+    op = tb.setup_operator(tb.PatchAssemblyStrategy(device), tb.LinearIntegrator(tb.AnalyticalCoefficient(f)), dh)
+    tb.update_operator(op, 0.3)
+    assert rel_err(op.b.to_host(), oracle.assemble_source(om, oracle.SRC_NORM_PLUS_T, t=0.3)) < TOL
+    # the EA strategy sums in cell order exactly like the sequential reference loop: bit-identical to itself
+    a = tb.update_operator(tb.setup_operator(tb.ElementAssemblyStrategy(device), tb.LinearIntegrator(tb.AnalyticalCoefficient("cos_exp")), dh), 0.2).b.to_host()
+    b = tb.update_operator(tb.setup_operator(tb.ElementAssemblyStrategy(device), tb.LinearIntegrator(tb.AnalyticalCoefficient("cos_exp")), dh), 0.2).b.to_host()
+    np.testing.assert_array_equal(a, b)
+
+
+def test_needs_update_closed_interval(tb, device):
+    g = tb.generate_mesh(tb.Hexahedron, (1, 1, 1))
+    dh = tb.DofHandler(g)
+    op = tb.setup_operator(tb.PatchAssemblyStrategy(device), tb.LinearIntegrator(tb.AnalyticalCoefficient("const", 1.0), nonzero_intervals=[(0.0, 1.0)]), dh)
+    assert tb.needs_update(op, 0.0) and tb.needs_update(op, 1.0) and not tb.needs_update(op, 1.0001)
+
+
+def test_single_cell_and_edge_shapes(tb, oracle, device):
+    for nel in ((1, 1, 1), (1, 1, 7), (2, 1, 1)):
+        g, dh, sp, om = make_problem(tb, oracle, nel=nel, perturb=0.0)
+        for st in strategies(tb, device):
+            K = tb.update_operator(tb.setup_operator(st, tb.BilinearDiffusionIntegrator(tb.ConstantCoefficient(1.0)), dh, sp), 0.0)
+            assert rel_err(K.A.to_host(), oracle.assemble_matrix(om, 1, oracle.Coef(oracle.COEF_CONST_SCALAR, [1.0]), sp.rowptr, sp.colidx)) < TOL
+
+
+def test_tet_mesh_parity(tb, oracle, device):
+    g0 = tb.generate_mesh(tb.Hexahedron, (3, 3, 2), (0, 0, 0), (1, 1, 1), perturb=0.2)
+    tets = hex_to_tets(g0.xyz, g0.conn)
+    cd, nd = oracle.close_dofs(oracle.TET4, 1, tets, len(g0.xyz))
+    g = tb.Grid(tb.Tetrahedron, g0.xyz, tets)
+    dh = tb.DofHandler(g, cell_dofs=cd, ndofs=nd)
+    sp = tb.allocate_matrix(dh)
+    rp, ci = oracle.build_pattern(cd, nd)
+    np.testing.assert_array_equal(sp.colidx, ci)
+    om = oracle.Mesh(oracle.TET4, 2, g.xyz, tets, cd)
+    D = np.array([[2.0, 0.3, 0.1], [0.3, 1.5, -0.2], [0.1, -0.2, 1.0]])
+    for st in strategies(tb, device):
+        K = tb.update_operator(tb.setup_operator(st, tb.BilinearDiffusionIntegrator(tb.ConstantCoefficient(D)), dh, sp), 0.0)
+        assert rel_err(K.A.to_host(), oracle.assemble_matrix(om, 1, oracle.Coef(oracle.COEF_CONST_TENSOR, D.ravel()), rp, ci)) < TOL
+        M = tb.update_operator(tb.setup_operator(st, tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.0)), dh, sp), 0.0)
+        assert rel_err(M.A.to_host(), oracle.assemble_matrix(om, 0, oracle.Coef(oracle.COEF_CONST_SCALAR, [1.0]), rp, ci)) < TOL
+    for st in strategies(tb, device, matrix=False):
+        b = tb.update_operator(tb.setup_operator(st, tb.LinearIntegrator(tb.AnalyticalCoefficient("norm_plus_t")), dh), 0.4)
+        assert rel_err(b.b.to_host(), oracle.assemble_source(om, oracle.SRC_NORM_PLUS_T, t=0.4)) < TOL
+
+
+def test_error_codes(tb, oracle, device):
+    g = tb.generate_mesh(tb.Hexahedron, (2, 2, 2))
+    bad = tb.Grid(tb.Hexahedron, g.xyz, g.conn[:, [0, 3, 2, 1, 4, 7, 6, 5]])  # inverted orientation → detJ < 0
+    dh = tb.DofHandler(bad)
+    sp = tb.allocate_matrix(dh)
+    for st in strategies(tb, device):
+        op = tb.setup_operator(st, tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.0)), dh, sp)
+        with pytest.raises(tb.TBError) as e:
+            tb.update_operator(op, 0.0)
+        assert e.value.code == tb._lib.TB_ERR_NEG_DETJ
+    # a pattern that lacks a coupling is rejected at setup
+    dh = tb.DofHandler(g)
+    sp = tb.allocate_matrix(dh)
+    keep = np.ones(sp.nnz, dtype=bool)
+    keep[1] = False
+    rp = sp.rowptr.copy(); rp[1:] -= 1
+    broken = tb.SparsityPattern(rp, sp.colidx[keep])
+    with pytest.raises(tb.TBError) as e:
+        tb.setup_operator(tb.PatchAssemblyStrategy(device), tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.0)), dh, broken)
+    assert e.value.code == tb._lib.TB_ERR_PATTERN
+    with pytest.raises(tb.TBError):  # wrong number of rows
+        tb.setup_operator(tb.PatchAssemblyStrategy(device), tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.0)), dh,
+                          tb.SparsityPattern(sp.rowptr[:-1], sp.colidx))
+
+
+# ------------------------------------------------------------------------------------------- reaction
+MODELS = [("FHNModel", "CELL_FHN"), ("AlievPanfilovModel", "CELL_ALIEV_PANFILOV"), ("PCG2019", "CELL_PCG2019")]
+
+
+def initial_points(tb, model, n, rng):
+    u0 = model.default_initial_state()
+    pts = np.tile(u0, (n, 1))
+    if model.nstates == 2:
+        pts += rng.uniform(0.0, 1.0, size=pts.shape)
+    else:
+        pts[:, 0] += rng.uniform(0.0, 100.0, size=n)          # φₘ from rest to plateau
+        pts[:, 1:] = np.clip(pts[:, 1:] + rng.uniform(-0.2, 0.2, size=(n, 6)), 0.0, 1.0)
+    return pts
+
+
+@pytest.mark.parametrize("cls,oid", MODELS)
+@pytest.mark.parametrize("layout", ["SOA", "AOS"])
+def test_reaction_forward_euler_parity(tb, oracle, device, cls, oid, layout):
+    model = getattr(tb, cls)()
+    oid = getattr(oracle, oid)
+    n = 1000 + 37
+    rng = np.random.default_rng(42)
+    pts = initial_points(tb, model, n, rng)
+    host = (np.ascontiguousarray(pts.T) if layout == "SOA" else pts).ravel().copy()
+    f = tb.PointwiseODEFunction(n, model, layout=tb.StateBlockedLayout() if layout == "SOA" else tb.PointBlockedLayout())
+    cache = tb.setup_solver_cache(f, tb.ForwardEulerCellSolver(device), u=device.to_device(host))
+    ref = host.copy()
+    dt = 0.01 if model.nstates == 7 else 0.1
+    for step in range(20):
+        assert tb.perform_step(f, cache, step * dt, dt) is True
+        du_ref = oracle.reaction_step(oid, model.params, ref, n, getattr(oracle, "LAYOUT_" + layout), t=step * dt, dt=dt)
+    assert rel_err(cache.un.to_host(), ref) < TOL
+    assert rel_err(cache.du.to_host(), du_ref) < 1e-10      # dumat is materialised (RTC reads it)
+    phi = model.phi_index
+    sl = du_ref.reshape(model.nstates, n)[phi] if layout == "SOA" else du_ref.reshape(n, model.nstates)[:, phi]
+    np.testing.assert_allclose(tb.reaction_rate_max(device, f, cache), np.abs(sl).max(), rtol=1e-10)
+    # without du the states are identical
+    cache2 = tb.setup_solver_cache(f, tb.ForwardEulerCellSolver(device), u=device.to_device(host), keep_du=False)
+    for step in range(20):
+        tb.perform_step(f, cache2, step * dt, dt)
+    np.testing.assert_array_equal(cache2.un.to_host(), cache.un.to_host())
+
+
+@pytest.mark.parametrize("cls,oid", MODELS)
+def test_reaction_adaptive_substepper_parity(tb, oracle, device, cls, oid):
+    model = getattr(tb, cls)()
+    oid = getattr(oracle, oid)
+    n = 513
+    rng = np.random.default_rng(7)
+    pts = initial_points(tb, model, n, rng)
+    host = np.ascontiguousarray(pts.T).ravel().copy()
+    f = tb.PointwiseODEFunction(n, model)
+    thr = 0.05 if model.nstates == 2 else 1.0
+    cache = tb.setup_solver_cache(f, tb.AdaptiveForwardEulerSubstepper(device, substeps=7, reaction_threshold=thr), u=device.to_device(host))
+    ref = host.copy()
+    dt = 0.05
+    for step in range(5):
+        tb.perform_step(f, cache, step * dt, dt)
+        oracle.reaction_step(oid, model.params, ref, n, oracle.LAYOUT_SOA, t=step * dt, dt=dt, substeps=7, threshold=thr)
+    assert rel_err(cache.un.to_host(), ref) < TOL
+    # both branches were exercised
+    du0 = np.array([oracle.cell_rhs(oid, model.params, p)[model.phi_index] for p in pts])
+    assert (np.abs(du0) < thr).any() and (np.abs(du0) >= thr).any()
+
+
+def test_reaction_argument_checks(tb, device):
+    m = tb.FHNModel()
+    u = device.zeros(4)
+    lib = tb.lib()
+    rc = lib.tb_reaction_step(device.h, m.model_id, m.params.ctypes.data_as(tb._lib.c_dp), 6, u.ptr, None, 2, 3, 0, 0.0, 0.1, 1, 0.0)
+    assert rc == tb._lib.TB_ERR_BAD_ARG and b"states" in lib.tb_last_error_string()
+    rc = lib.tb_reaction_step(device.h, m.model_id, m.params.ctypes.data_as(tb._lib.c_dp), 6, u.ptr, None, 0, 2, 0, 0.0, 0.1, 1, 0.0)
+    assert rc == 0  # empty input is fine
+
+
+# ------------------------------------------------------------------------------------------- algebra
+def test_heat_algebra_parity(tb, oracle, device):
+    g, dh, sp, om = make_problem(tb, oracle, nel=(5, 4, 3))
+    st = tb.PatchAssemblyStrategy(device)
+    kap = np.diag([4.5e-5, 2.0e-5, 2.0e-5])
+    M = tb.update_operator(tb.setup_operator(st, tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.0)), dh, sp), 0.0)
+    K = tb.update_operator(tb.setup_operator(st, tb.BilinearDiffusionIntegrator(tb.ConstantCoefficient(kap)), dh, sp), 0.0)
+    A = tb.heat_system_matrix(device, M, K, 0.25)
+    Mh, Kh = M.A.to_host(), K.A.to_host()
+    assert rel_err(A.to_host(), oracle.heat_matrix(Mh, Kh, 0.25)) < 1e-15
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=dh.ndofs)
+    y0 = rng.normal(size=dh.ndofs)
+    dx, dy = device.to_device(x), device.to_device(y0)
+    M.mul(dy, dx)                                   # b = M uₙ₋₁ (euler.jl:85)
+    assert rel_err(dy.to_host(), oracle.spmv_csr(sp.rowptr, sp.colidx, Mh, x)) < 1e-13
+    dy.copy_from_host(y0)
+    K.mul(dy, dx, alpha=-0.5, beta=2.0)             # 5-argument mul! (newmark.jl:82-102)
+    assert rel_err(dy.to_host(), oracle.spmv_csr(sp.rowptr, sp.colidx, Kh, x, -0.5, 2.0, y0.copy())) < 1e-13
+    src = tb.update_operator(tb.setup_operator(st, tb.LinearIntegrator(tb.AnalyticalCoefficient("cos_exp")), dh), 0.0)
+    dy.copy_from_host(y0)
+    tb.add(dy, src, device)                         # add!(b, source) (euler.jl:90)
+    assert rel_err(dy.to_host(), y0 + src.b.to_host()) < 1e-15
+    # odd length for the vectorised axpby
+    n = 1001
+    a, b = rng.normal(size=n), rng.normal(size=n)
+    out = device.zeros(n)
+    tb._lib.check(tb.lib().tb_heat_matrix(device.h, n, device.to_device(a).ptr, device.to_device(b).ptr, 0.3, out.ptr))
+    np.testing.assert_allclose(out.to_host(), a - 0.3 * b, rtol=1e-15)
+
+
+# ------------------------------------------------------------------------------------------- BASELINE sizes
+def _property_checks(tb, oracle, device, n, sample=200):
+    """Size-independent properties at BASELINE sizes (the oracle checks a random sample of rows exactly)."""
+    g = tb.generate_mesh(tb.Hexahedron, (n, n, n), (0, 0, 0), (1, 1, 1), perturb=0.2)
+    dh = tb.DofHandler(g)
+    sp = tb.allocate_matrix(dh)
+    assert g.n_cells == n ** 3 and dh.ndofs == (n + 1) ** 3 and sp.nnz == (3 * n + 1) ** 3
+    st = tb.PatchAssemblyStrategy(device)
+    kap = np.array([[4.5e-5, 1e-5, 0], [1e-5, 2.0e-5, 0], [0, 0, 2.0e-5]])
+    M = tb.update_operator(tb.setup_operator(st, tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.0)), dh, sp), 0.0)
+    K = tb.update_operator(tb.setup_operator(st, tb.BilinearDiffusionIntegrator(tb.ConstantCoefficient(kap)), dh, sp), 0.0)
+    b1 = tb.update_operator(tb.setup_operator(st, tb.LinearIntegrator(tb.AnalyticalCoefficient("const", 1.0)), dh), 0.0)
+    one = device.to_device(np.ones(dh.ndofs))
+    y = device.zeros(dh.ndofs)
+    K.mul(y, one)
+    Kh_scale = 4.5e-5 / n
+    assert np.abs(y.to_host()).max() < 1e-11 * Kh_scale * 27            # constants are in the kernel of K
+    M.mul(y, one)
+    m1 = y.to_host()
+    np.testing.assert_allclose(m1.sum(), 1.0, rtol=1e-11)                # Σ M = volume of the unit box
+    assert rel_err(b1.b.to_host(), m1) < 1e-12                           # ∫ 1·Nⱼ = (M·1)ⱼ
+    rng = np.random.default_rng(0)
+    x, z = rng.normal(size=dh.ndofs), rng.normal(size=dh.ndofs)
+    dx, dz = device.to_device(x), device.to_device(z)
+    K.mul(y, dx)
+    zKx = z @ y.to_host()
+    K.mul(y, dz)
+    np.testing.assert_allclose(zKx, x @ y.to_host(), rtol=1e-9)          # symmetry
+    assert zKx != 0 and (x @ (lambda v: (K.mul(y, device.to_device(v)), y.to_host())[1])(x)) < 0  # K is negative semi-definite (minus sign, diffusion.jl:44)
+    # exact oracle check on the cells around a random sample of rows
+    Kh = K.A.to_host()
+    om = oracle.Mesh(oracle.HEX8, 2, g.xyz, g.conn, dh.cell_dofs)
+    oc = oracle.Coef(oracle.COEF_CONST_TENSOR, kap.ravel())
+    rows = rng.choice(dh.ndofs, size=sample, replace=False)
+    n2d_cells = {}
+    flat = dh.cell_dofs
+    sel = np.isin(flat, rows)
+    cells = np.nonzero(sel.any(axis=1))[0]
+    acc = {}
+    for c in cells:
+        Ke = oracle.element_matrix(om, 1, oc, int(c))
+        d = flat[c]
+        for i in range(8):
+            if sel[c, i]:
+                for j in range(8):
+                    acc[(d[i], d[j])] = acc.get((d[i], d[j]), 0.0) + Ke[i, j]
+    worst = 0.0
+    for (r, c_), v in acc.items():
+        k0, k1 = sp.rowptr[r], sp.rowptr[r + 1]
+        k = k0 + np.searchsorted(sp.colidx[k0:k1], c_)
+        worst = max(worst, abs(Kh[k] - v))
+    assert worst < 1e-12 * np.abs(Kh).max()
+    # strategies agree with each other at size
+    Ka = tb.update_operator(tb.setup_operator(tb.AtomicAssemblyStrategy(device), tb.BilinearDiffusionIntegrator(tb.ConstantCoefficient(kap)), dh, sp), 0.0)
+    assert rel_err(Ka.A.to_host(), Kh) < 1e-12
+    return g.n_cells
+
+
+def test_properties_64_cubed(tb, oracle, device):
+    assert _property_checks(tb, oracle, device, 64) == 262144
+
+
+def test_properties_100_cubed(tb, oracle, device):
+    assert _property_checks(tb, oracle, device, 100) == 1000000
+
+
+def test_reaction_full_size_roundtrip(tb, oracle, device):
+    """10M-point PCG2019 (BASELINE config 3 size): identical points evolve identically; a sample matches the oracle."""
+    n = 10218313
+    model = tb.PCG2019()
+    rng = np.random.default_rng(5)
+    base = initial_points(tb, model, 1024, rng)
+    pts = np.tile(base, (n // 1024 + 1, 1))[:n]
+    host = np.ascontiguousarray(pts.T).ravel()
+    f = tb.PointwiseODEFunction(n, model)
+    cache = tb.setup_solver_cache(f, tb.ForwardEulerCellSolver(device), u=device.to_device(host), keep_du=False)
+    for step in range(3):
+        tb.perform_step(f, cache, 0.01 * step, 0.01)
+    out = cache.un.to_host().reshape(7, n)
+    np.testing.assert_array_equal(out[:, :1024], out[:, 1024 * 5000:1024 * 5001])   # periodic copies stay identical
+    ref = np.ascontiguousarray(base.T).ravel().copy()
+    for step in range(3):
+        oracle.reaction_step(oracle.CELL_PCG2019, model.params, ref, 1024, oracle.LAYOUT_SOA, t=0.01 * step, dt=0.01)
+    assert rel_err(out[:, :1024].ravel(), ref) < TOL
+    assert np.isfinite(out).all()

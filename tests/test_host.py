@@ -1,0 +1,113 @@
+"""CPU-only checks of the shipped library: it loads, exports every symbol include/tbhip.h declares, its
+host-side generators reproduce the oracle's Ferrite-convention mesh / dof numbering / sparsity graph
+BIT-EXACTLY (integer parity), and argument errors are reported through the C-ABI error channel."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(tb):
+    hdr = open(os.path.join(ROOT, "include", "tbhip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(tb_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 40
+    lib = C.CDLL(tb._lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libtbhip.so does not export %s" % name
+    assert declared == set(tb._lib.SIGNATURES), declared ^ set(tb._lib.SIGNATURES)
+    assert b"gfx950" in tb.lib().tb_version()
+
+
+def test_missing_library_fails_loudly(tb, monkeypatch):
+    monkeypatch.setattr(tb._lib, "_lib", None)
+    monkeypatch.setattr(tb._lib, "LIB_PATH", "/nonexistent/libtbhip.so")
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        tb._lib.lib()
+
+
+@pytest.mark.parametrize("nel", [(1, 1, 1), (3, 2, 4), (5, 5, 5)])
+def test_grid_dofs_pattern_bit_exact(tb, oracle, nel):
+    g = tb.generate_mesh(tb.Hexahedron, nel, (-1, -1, -1), (1, 1, 1))
+    xyz, conn = oracle.generate_grid_hex(*nel, (-1, -1, -1), (1, 1, 1))
+    np.testing.assert_array_equal(g.conn, conn)
+    np.testing.assert_array_equal(g.xyz, xyz)
+    # Ferrite generate_grid: first cell of the default box, local vertex order of src/mesh/generators.jl:62-79
+    px, py = nel[0] + 1, nel[1] + 1
+    assert list(conn[0]) == [0, 1, px + 1, px, px * py, px * py + 1, px * py + px + 1, px * py + px]
+    for kind, okind, order, ncomp in ((tb._lib.TB_HEX8, oracle.HEX8, 1, 1), (tb._lib.TB_HEX8, oracle.HEX8, 1, 3),
+                                      (tb._lib.TB_HEX27, oracle.HEX27, 2, 1), (tb._lib.TB_HEX27, oracle.HEX27, 2, 3)):
+        dh = tb.DofHandler(g, tb.LagrangeCollection(order) ** ncomp)
+        cd, nd = oracle.close_dofs(okind, ncomp, conn, len(xyz))
+        assert dh.ndofs == nd
+        np.testing.assert_array_equal(dh.cell_dofs, cd)
+        if order == 1 and ncomp == 1:
+            assert nd == len(xyz)
+            assert list(cd[0]) == list(range(8))  # first cell numbers its vertices 1..8 (close!: first visit)
+        sp = tb.allocate_matrix(dh)
+        rp, ci = oracle.build_pattern(cd, nd)
+        np.testing.assert_array_equal(sp.rowptr, rp)
+        np.testing.assert_array_equal(sp.colidx, ci)
+    n = nel
+    dh = tb.DofHandler(g)
+    assert tb.allocate_matrix(dh).nnz == (3 * n[0] + 1) * (3 * n[1] + 1) * (3 * n[2] + 1)  # SURVEY §8 sizes
+
+
+def test_q2_dof_count(tb):
+    g = tb.generate_mesh(tb.Hexahedron, (4, 3, 2))
+    dh = tb.DofHandler(g, tb.LagrangeCollection(2) ** 3)
+    assert dh.ndofs == 3 * 9 * 7 * 5
+    assert dh.cell_dofs.shape == (24, 81)
+    # vector field: node-major, component-minor (src/ferrite-addons/io.jl:233-238)
+    assert list(dh.cell_dofs[0][:6]) == [0, 1, 2, 3, 4, 5]
+
+
+def test_perturbation_keeps_boundary_and_orientation(tb, oracle):
+    g = tb.generate_mesh(tb.Hexahedron, (6, 6, 6), (0, 0, 0), (1, 1, 1), perturb=0.2)
+    g0 = tb.generate_mesh(tb.Hexahedron, (6, 6, 6), (0, 0, 0), (1, 1, 1))
+    on_bnd = np.any((g0.xyz == 0) | (g0.xyz == 1), axis=1)
+    assert np.abs(g.xyz[on_bnd] - g0.xyz[on_bnd]).max() < 1e-15
+    assert np.abs(g.xyz - g0.xyz).max() > 1e-3
+    dh = tb.DofHandler(g)
+    m = oracle.Mesh(oracle.HEX8, 2, g.xyz, g.conn, dh.cell_dofs)
+    vol = sum(oracle.element_matrix(m, 0, oracle.Coef(oracle.COEF_CONST_SCALAR, [1.0]), c).sum() for c in range(g.n_cells))
+    np.testing.assert_allclose(vol, 1.0, rtol=1e-12)
+
+
+def test_error_channel_without_gpu(tb):
+    lib = tb.lib()
+    assert lib.tb_host_generate_grid_hex(0, 1, 1, None, None, None, None) == tb._lib.TB_ERR_BAD_ARG
+    assert b"bad argument" in lib.tb_last_error_string()
+    ns, npar, phi = C.c_int(), C.c_int(), C.c_int()
+    assert lib.tb_cell_model_info(99, C.byref(ns), C.byref(npar), C.byref(phi)) == tb._lib.TB_ERR_BAD_ARG
+    assert lib.tb_cell_model_info(tb._lib.TB_CELL_ALIEV_PANFILOV, C.byref(ns), C.byref(npar), C.byref(phi)) == 0
+    assert (ns.value, npar.value, phi.value) == (2, 6, 1)
+    assert lib.tb_reaction_step(None, 0, None, 0, None, None, 0, 0, 0, 0.0, 0.0, 1, 0.0) == tb._lib.TB_ERR_BAD_ARG
+
+
+def test_cell_model_defaults_match_oracle(tb, oracle):
+    for cls, oid in ((tb.FHNModel, oracle.CELL_FHN), (tb.AlievPanfilovModel, oracle.CELL_ALIEV_PANFILOV),
+                     (tb.PCG2019, oracle.CELL_PCG2019)):
+        m = cls()
+        np.testing.assert_array_equal(m.params, oracle.cell_default_params(oid))
+        np.testing.assert_allclose(m.default_initial_state(), oracle.cell_default_state(oid), rtol=1e-15)
+        assert tb.num_states(m) == oracle.cell_nstates(oid)
+    assert tb.transmembranepotential_index(tb.AlievPanfilovModel()) == 2  # state order (s, φₘ)
+    assert tb.FHNModel(a=0.3).params[0] == 0.3
+
+
+def test_slab_partition(tb):
+    D = tb.distributed
+    covered = []
+    for r in range(3):
+        z0, z1 = D.slab_range(8, 3, r)
+        covered += list(range(z0, z1))
+    assert covered == list(range(8))
+    p = D.SlabPartition((4, 4, 8), (0, 0, 0), (1, 1, 2), 2, 1)
+    assert p.local_nel() == (4, 4, 4) and p.left[2] == 1.0 and p.right[2] == 2
+    lo, up = p.interface_nodes()
+    assert up is None and len(lo) == 25

@@ -1,0 +1,8 @@
+"""thunderbolt.jl_amd — MI355X (gfx950) backend for Thunderbolt.jl's per-cell FE integration and
+pointwise reaction hot path.  The compute lives in libtbhip.so (hand-written HIP, C ABI in
+include/tbhip.h); this package is the host-side mirror of the reference's operator API.
+Import as ``import thunderbolt_jl_amd`` (shim at the repository root)."""
+from . import _lib
+from ._lib import TBError, build_library, lib  # noqa: F401
+from .api import *  # noqa: F401,F403
+from . import distributed  # noqa: F401

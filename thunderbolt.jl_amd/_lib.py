@@ -1,0 +1,122 @@
+"""ctypes declarations for libtbhip.so (include/tbhip.h).  Loading fails loudly when the HIP
+library has not been built: there is no CPU fallback anywhere in this package."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtbhip.so")
+
+# enums of include/tbhip.h
+TB_OK = 0
+TB_ERR_BAD_ARG, TB_ERR_HIP, TB_ERR_NEG_DETJ, TB_ERR_PATTERN, TB_ERR_UNSUPPORTED, TB_ERR_NOMEM = -1, -2, -3, -4, -5, -6
+TB_HEX8, TB_TET4, TB_HEX27 = 3, 4, 5
+TB_STRATEGY_ATOMIC, TB_STRATEGY_PER_COLOR, TB_STRATEGY_ELEMENT, TB_STRATEGY_PATCH = 0, 1, 2, 3
+TB_FORM_MASS, TB_FORM_DIFFUSION, TB_FORM_SOURCE = 0, 1, 2
+TB_COEF_CONST_SCALAR, TB_COEF_CONST_TENSOR, TB_COEF_FIELD_SCALAR = 0, 1, 2
+TB_COEF_SPECTRAL_CONST, TB_COEF_SPECTRAL_FIELD, TB_COEF_TRANSVERSE_CONST = 3, 4, 5
+TB_SRC_CONST, TB_SRC_NORM_PLUS_T, TB_SRC_COS_EXP, TB_SRC_TABULATED = 0, 1, 2, 3
+TB_CELL_FHN, TB_CELL_ALIEV_PANFILOV, TB_CELL_PCG2019 = 0, 1, 2
+TB_LAYOUT_SOA, TB_LAYOUT_AOS = 0, 1
+
+c_dp = C.POINTER(C.c_double)
+c_i32p = C.POINTER(C.c_int32)
+c_i64p = C.POINTER(C.c_int64)
+vp = C.c_void_p
+
+
+class tb_coef(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("wrap", C.c_int32), ("Cm", C.c_double), ("chi", C.c_double),
+                ("p", C.c_double * 16), ("field", c_dp), ("field_len", C.c_int64)]
+
+
+# name -> (restype, argtypes): every symbol include/tbhip.h declares
+SIGNATURES = {
+    "tb_last_error_string": (C.c_char_p, []),
+    "tb_version": (C.c_char_p, []),
+    "tb_device_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+    "tb_device_destroy": (C.c_int, [vp]),
+    "tb_device_set_stream": (C.c_int, [vp, vp]),
+    "tb_device_synchronize": (C.c_int, [vp]),
+    "tb_device_info": (C.c_int, [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
+    "tb_malloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
+    "tb_free": (C.c_int, [vp, vp]),
+    "tb_memcpy_h2d": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "tb_memcpy_d2h": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "tb_memcpy_d2d": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "tb_memset": (C.c_int, [vp, vp, C.c_int, C.c_size_t]),
+    "tb_event_create": (C.c_int, [vp, C.POINTER(vp)]),
+    "tb_event_record": (C.c_int, [vp, vp]),
+    "tb_event_elapsed_ms": (C.c_int, [vp, vp, C.POINTER(C.c_float)]),
+    "tb_event_destroy": (C.c_int, [vp]),
+    "tb_mesh_create": (C.c_int, [vp, C.c_int, C.c_int64, c_dp, C.c_int64, c_i32p, C.c_int, C.c_int, c_i32p, C.c_int64,
+                                 C.c_int, C.POINTER(vp)]),
+    "tb_mesh_destroy": (C.c_int, [vp]),
+    "tb_mesh_ncells": (C.c_int64, [vp]),
+    "tb_mesh_ndofs": (C.c_int64, [vp]),
+    "tb_pattern_create": (C.c_int, [vp, C.c_int64, c_i64p, c_i32p, C.c_int, C.POINTER(vp)]),
+    "tb_pattern_destroy": (C.c_int, [vp]),
+    "tb_pattern_nnz": (C.c_int64, [vp]),
+    "tb_pattern_rowptr_device": (vp, [vp]),
+    "tb_pattern_colidx_device": (vp, [vp]),
+    "tb_form_create": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(tb_coef), C.POINTER(vp)]),
+    "tb_form_destroy": (C.c_int, [vp]),
+    "tb_form_set_table": (C.c_int, [vp, c_dp, C.c_int64]),
+    "tb_assemble_matrix": (C.c_int, [vp, vp, C.c_int, C.c_double, vp]),
+    "tb_assemble_vector": (C.c_int, [vp, C.c_int, C.c_double, vp]),
+    "tb_reaction_step": (C.c_int, [vp, C.c_int, c_dp, C.c_int, vp, vp, C.c_int64, C.c_int, C.c_int, C.c_double,
+                                   C.c_double, C.c_int, C.c_double]),
+    "tb_cell_model_info": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "tb_cell_model_defaults": (C.c_int, [C.c_int, c_dp, c_dp]),
+    "tb_heat_matrix": (C.c_int, [vp, C.c_int64, vp, vp, C.c_double, vp]),
+    "tb_spmv_csr": (C.c_int, [vp, vp, vp, C.c_double, C.c_double, vp]),
+    "tb_axpy": (C.c_int, [vp, C.c_int64, C.c_double, vp, vp]),
+    "tb_absmax": (C.c_int, [vp, C.c_int64, vp, C.c_int64, C.POINTER(C.c_double)]),
+    "tb_host_generate_grid_hex": (C.c_int, [C.c_int, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_i32p]),
+    "tb_host_perturb_nodes": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, c_dp]),
+    "tb_host_close_dofs": (C.c_int64, [C.c_int, C.c_int, C.c_int64, C.c_int64, c_i32p, c_i32p]),
+    "tb_host_build_pattern": (C.c_int64, [C.c_int64, C.c_int, c_i32p, C.c_int64, c_i64p, c_i32p]),
+}
+
+
+class TBError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libtbhip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def build_library(force=False):
+    """Compile thunderbolt.jl_amd/csrc for gfx950 (hipcc cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-C", csrc, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", csrc, "-j4"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "thunderbolt.jl_amd: %s is missing — run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(make -C thunderbolt.jl_amd/csrc). There is no CPU fallback." % LIB_PATH)
+        try:  # share one HIP runtime with the host framework when it is present (same soname)
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover
+            pass
+        _lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(_lib, name)  # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+    return _lib
+
+
+def check(rc):
+    if rc != TB_OK:
+        raise TBError(rc, lib().tb_last_error_string().decode("utf-8", "replace"))
+    return rc

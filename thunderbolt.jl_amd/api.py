@@ -1,0 +1,700 @@
+"""Host-side mirror of Thunderbolt.jl's device / operator API for the hot path, bound to libtbhip.so.
+
+The reference host language is Julia; no Julia toolchain exists in the build image, so this mirror is
+Python over ctypes (the Julia `ccall` binding a maintainer would add is in INTEGRATION.md and
+julia/ThunderboltHIPBackend.jl).  Names, argument meaning and error behaviour follow the reference:
+
+  reference (file:line)                                              here
+  ------------------------------------------------------------------------------------------------
+  AbstractGPUDevice / CudaDevice   ext/CuThunderboltExt.jl:48-49      MI355XDevice
+  PerColor/ElementAssemblyStrategy src/Thunderbolt.jl:22-32           *AssemblyStrategy(device)
+  generate_mesh                    src/mesh/generators.jl:942         generate_mesh
+  DofHandler/add!/close!           src/discretization/fem.jl:170-196  DofHandler(mesh, ip)
+  allocate_matrix                  src/solver/interface.jl:162-168    allocate_matrix(dh)
+  Bilinear{Mass,Diffusion}Integrator  core/mass.jl:6-11, diffusion.jl:6-11
+  LinearIntegrator                 core/linear.jl:6-14                LinearIntegrator
+  setup_operator / update_operator!   src/solver/interface.jl:17-94, euler.jl:172-176
+  PointwiseODEFunction             src/modeling/functions.jl:46-65
+  ForwardEulerCellSolver / AdaptiveForwardEulerSubstepper / setup_solver_cache / perform_step!
+                                   src/solver/time/partitioned_solver.jl:14-52,54-60,101-124,162-175
+Julia's `f!` becomes `f_` is avoided: mutating functions simply drop the bang.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from ._lib import check, lib
+
+
+def _ptr(x):
+    """device pointer of a DeviceVector, a torch tensor, or a raw int"""
+    if x is None:
+        return None
+    if isinstance(x, DeviceVector):
+        return x.ptr
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    return C.c_void_p(int(x))
+
+
+# --------------------------------------------------------------------------------------- device
+class MI355XDevice:
+    """`MI355XDevice{Tv,Ti} <: AbstractGPUDevice` — value type Float64, index type Int32."""
+    value_type = np.float64
+    index_type = np.int32
+
+    def __init__(self, device_id=0):
+        h = C.c_void_p()
+        check(lib().tb_device_create(device_id, C.byref(h)))
+        self.h = h
+        self.device_id = device_id
+
+    def set_stream(self, hip_stream):
+        check(lib().tb_device_set_stream(self.h, C.c_void_p(hip_stream) if hip_stream else None))
+
+    def synchronize(self):
+        check(lib().tb_device_synchronize(self.h))
+
+    def info(self):
+        name = C.create_string_buffer(64)
+        ncu, mem = C.c_int(), C.c_size_t()
+        check(lib().tb_device_info(self.h, name, 64, C.byref(ncu), C.byref(mem)))
+        return {"name": name.value.decode(), "n_cu": ncu.value, "hbm_bytes": mem.value}
+
+    def zeros(self, n, dtype=np.float64):
+        v = DeviceVector(self, n, dtype)
+        v.fill_zero()
+        return v
+
+    def to_device(self, a):
+        a = np.ascontiguousarray(a)
+        v = DeviceVector(self, a.size, a.dtype)
+        v.copy_from_host(a)
+        return v
+
+    def event(self):
+        return Event(self)
+
+    def close(self):
+        if self.h:
+            lib().tb_device_destroy(self.h)
+            self.h = None
+
+
+class Event:
+    def __init__(self, dev):
+        self.dev = dev
+        self.h = C.c_void_p()
+        check(lib().tb_event_create(dev.h, C.byref(self.h)))
+
+    def record(self):
+        check(lib().tb_event_record(self.dev.h, self.h))
+        return self
+
+    def elapsed_ms(self, stop):
+        ms = C.c_float()
+        check(lib().tb_event_elapsed_ms(self.h, stop.h, C.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().tb_event_destroy(self.h)
+        except Exception:
+            pass
+
+
+class DeviceVector:
+    """create_system_vector(::Type{<:DeviceVector}, …) (ext/CuThunderboltExt.jl:126-127)."""
+
+    def __init__(self, dev, n, dtype=np.float64):
+        self.dev, self.n, self.dtype = dev, int(n), np.dtype(dtype)
+        self.ptr = C.c_void_p()
+        self._owner = None
+        check(lib().tb_malloc(dev.h, self.n * self.dtype.itemsize, C.byref(self.ptr)))
+
+    @classmethod
+    def wrap(cls, dev, tensor):
+        """Non-owning view of a host framework's device buffer (e.g. a torch tensor used for RCCL exchange)."""
+        v = cls.__new__(cls)
+        v.dev, v.n, v.dtype = dev, int(tensor.numel()), np.dtype(np.float64)
+        v.ptr = C.c_void_p(tensor.data_ptr())
+        v._owner = tensor
+        return v
+
+    @property
+    def nbytes(self):
+        return self.n * self.dtype.itemsize
+
+    def data_ptr(self):
+        return self.ptr.value or 0
+
+    def fill_zero(self):
+        check(lib().tb_memset(self.dev.h, self.ptr, 0, self.nbytes))
+
+    def copy_from_host(self, a):
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        assert a.size == self.n
+        check(lib().tb_memcpy_h2d(self.dev.h, self.ptr, a.ctypes.data_as(C.c_void_p), self.nbytes))
+
+    def to_host(self):
+        out = np.empty(self.n, dtype=self.dtype)
+        check(lib().tb_memcpy_d2h(self.dev.h, out.ctypes.data_as(C.c_void_p), self.ptr, self.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr and self._owner is None:
+            lib().tb_free(self.dev.h, self.ptr)
+        self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+# --------------------------------------------------------------------------------------- strategies
+class _Strategy:
+    code = None
+
+    def __init__(self, device):
+        self.device = device
+
+
+class AtomicAssemblyStrategy(_Strategy):
+    code = L.TB_STRATEGY_ATOMIC
+
+
+class PerColorAssemblyStrategy(_Strategy):
+    code = L.TB_STRATEGY_PER_COLOR
+
+
+class ElementAssemblyStrategy(_Strategy):
+    code = L.TB_STRATEGY_ELEMENT
+
+
+class PatchAssemblyStrategy(_Strategy):
+    code = L.TB_STRATEGY_PATCH
+
+
+# --------------------------------------------------------------------------------------- mesh / dofs
+Hexahedron, Tetrahedron = L.TB_HEX8, L.TB_TET4
+
+
+class LagrangeCollection:
+    """LagrangeCollection{order}() (src/ferrite-addons/collections.jl:48-58); `** 3` vectorises."""
+
+    def __init__(self, order=1, ncomp=1):
+        self.order, self.ncomp = order, ncomp
+
+    def __pow__(self, n):
+        return LagrangeCollection(self.order, n)
+
+
+class Grid:
+    def __init__(self, cell_kind, xyz, conn, dims=None):
+        self.cell_kind = cell_kind
+        self.xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+        self.conn = np.ascontiguousarray(conn, dtype=np.int32)
+        self.dims = dims
+
+    @property
+    def n_cells(self):
+        return self.conn.shape[0]
+
+    @property
+    def n_nodes(self):
+        return self.xyz.shape[0]
+
+
+def generate_mesh(cell_kind, nel, left=(-1.0, -1.0, -1.0), right=(1.0, 1.0, 1.0), perturb=0.0):
+    """generate_mesh(Hexahedron, (nx,ny,nz), left, right) — Ferrite generate_grid conventions."""
+    if cell_kind != Hexahedron:
+        raise NotImplementedError("generate_mesh: only Hexahedron boxes are generated; pass your own Grid for others")
+    nx, ny, nz = nel
+    nn = (nx + 1) * (ny + 1) * (nz + 1)
+    xyz = np.empty((nn, 3))
+    conn = np.empty((nx * ny * nz, 8), dtype=np.int32)
+    le, ri = np.asarray(left, dtype=np.float64), np.asarray(right, dtype=np.float64)
+    check(lib().tb_host_generate_grid_hex(nx, ny, nz, le.ctypes.data_as(L.c_dp), ri.ctypes.data_as(L.c_dp),
+                                         xyz.ctypes.data_as(L.c_dp), conn.ctypes.data_as(L.c_i32p)))
+    if perturb:
+        check(lib().tb_host_perturb_nodes(nx, ny, nz, float(perturb), xyz.ctypes.data_as(L.c_dp)))
+    return Grid(cell_kind, xyz, conn, dims=(nx, ny, nz))
+
+
+class DofHandler:
+    """DofHandler(mesh); add!(dh, :u, ip); close!(dh) for ONE field on ONE subdomain."""
+
+    def __init__(self, grid, ip=None, cell_dofs=None, ndofs=None):
+        ip = ip or LagrangeCollection(1)
+        self.grid, self.ip = grid, ip
+        if grid.cell_kind == Hexahedron:
+            self.field_kind = L.TB_HEX8 if ip.order == 1 else L.TB_HEX27
+        else:
+            if ip.order != 1:
+                raise NotImplementedError("only first-order tetrahedra")
+            self.field_kind = L.TB_TET4
+        nb = {L.TB_HEX8: 8, L.TB_HEX27: 27, L.TB_TET4: 4}[self.field_kind]
+        self.ndofs_per_cell = nb * ip.ncomp
+        if cell_dofs is None:  # close!(dh)
+            cd = np.empty((grid.n_cells, self.ndofs_per_cell), dtype=np.int32)
+            nd = lib().tb_host_close_dofs(self.field_kind, ip.ncomp, grid.n_cells, grid.n_nodes,
+                                          grid.conn.ctypes.data_as(L.c_i32p), cd.ctypes.data_as(L.c_i32p))
+            if nd < 0:
+                check(int(nd))
+            self.cell_dofs, self.ndofs = cd, int(nd)
+        else:  # Ferrite's own table handed over by the host
+            self.cell_dofs = np.ascontiguousarray(cell_dofs, dtype=np.int32)
+            self.ndofs = int(ndofs if ndofs is not None else self.cell_dofs.max() + 1)
+        self._mesh = {}
+
+    def device_mesh(self, device):
+        key = id(device)
+        if key not in self._mesh:
+            self._mesh[key] = DeviceMesh(device, self)
+        return self._mesh[key]
+
+
+def ndofs(dh):
+    return dh.ndofs
+
+
+class SparsityPattern:
+    def __init__(self, rowptr, colidx):
+        self.rowptr, self.colidx = rowptr, colidx
+
+    @property
+    def nnz(self):
+        return int(self.rowptr[-1])
+
+
+def allocate_matrix(dh):
+    """Sparsity pattern of allocate_matrix(dh), as CSR (create_system_matrix, src/solver/interface.jl:162-168)."""
+    cd = dh.cell_dofs
+    rowptr = np.empty(dh.ndofs + 1, dtype=np.int64)
+    nnz = lib().tb_host_build_pattern(cd.shape[0], cd.shape[1], cd.ctypes.data_as(L.c_i32p), dh.ndofs,
+                                      rowptr.ctypes.data_as(L.c_i64p), None)
+    if nnz < 0:
+        check(int(nnz))
+    colidx = np.empty(nnz, dtype=np.int32)
+    lib().tb_host_build_pattern(cd.shape[0], cd.shape[1], cd.ctypes.data_as(L.c_i32p), dh.ndofs,
+                                rowptr.ctypes.data_as(L.c_i64p), colidx.ctypes.data_as(L.c_i32p))
+    return SparsityPattern(rowptr, colidx)
+
+
+class DeviceMesh:
+    """Adapt.adapt_structure(device, dh/grid): device-resident coordinates, connectivity, dof table."""
+
+    def __init__(self, device, dh):
+        self.device, self.dh = device, dh
+        g = dh.grid
+        self.h = C.c_void_p()
+        check(lib().tb_mesh_create(device.h, g.cell_kind, g.n_nodes, g.xyz.ctypes.data_as(L.c_dp), g.n_cells,
+                                   g.conn.ctypes.data_as(L.c_i32p), dh.field_kind, dh.ip.ncomp,
+                                   dh.cell_dofs.ctypes.data_as(L.c_i32p), dh.ndofs, 0, C.byref(self.h)))
+        self._patterns = {}
+
+    def pattern(self, sp):
+        key = id(sp)
+        if key not in self._patterns:
+            self._patterns[key] = DevicePattern(self, sp)
+        return self._patterns[key]
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().tb_mesh_destroy(self.h)
+        except Exception:
+            pass
+
+
+class DevicePattern:
+    def __init__(self, dmesh, sp):
+        self.dmesh, self.sp = dmesh, sp
+        self.h = C.c_void_p()
+        check(lib().tb_pattern_create(dmesh.h, len(sp.rowptr) - 1, sp.rowptr.ctypes.data_as(L.c_i64p),
+                                      sp.colidx.ctypes.data_as(L.c_i32p), 0, C.byref(self.h)))
+        self.nnz = sp.nnz
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().tb_pattern_destroy(self.h)
+        except Exception:
+            pass
+
+
+# --------------------------------------------------------------------------------------- coefficients
+class ConstantCoefficient:
+    def __init__(self, val):
+        self.val = val
+
+
+class FieldCoefficient:
+    """FieldCoefficient(data[basis, cell]) — scalar nodal data per cell (coefficients.jl:85-99)."""
+
+    def __init__(self, data):
+        self.data = np.ascontiguousarray(data, dtype=np.float64)  # stored [cell][basis]
+
+
+class OrthotropicMicrostructure:
+    def __init__(self, f, s, n):
+        self.f, self.s, self.n = (np.asarray(v, dtype=np.float64) for v in (f, s, n))
+
+
+class TransverselyIsotropicMicrostructure:
+    def __init__(self, f):
+        self.f = np.asarray(f, dtype=np.float64)
+
+
+class OrthotropicMicrostructureModel:
+    """Nodal f, s, n fields per cell, shape (n_cells, nbasis, 3) each (microstructure.jl:145-187)."""
+
+    def __init__(self, f, s, n):
+        self.fsn = np.ascontiguousarray(np.stack([f, s, n], axis=2), dtype=np.float64)  # [cell][basis][3][3]
+
+
+class SpectralTensorCoefficient:
+    def __init__(self, eigenvectors, eigenvalues):
+        self.eigenvectors, self.eigenvalues = eigenvectors, eigenvalues
+
+
+class ConductivityToDiffusivityCoefficient:
+    """κ/(Cₘ·χ) (coefficients.jl:124-162; built by fem.jl:413-419)."""
+
+    def __init__(self, conductivity, capacitance, chi):
+        self.conductivity, self.capacitance, self.chi = conductivity, capacitance, chi
+
+
+class AnalyticalCoefficient:
+    """AnalyticalCoefficient(f, CartesianCoordinateSystem): `f` is a closed-form id
+    ("const", "norm_plus_t", "cos_exp") or a Python callable f(x, t) that is tabulated on the host."""
+    KINDS = {"const": L.TB_SRC_CONST, "norm_plus_t": L.TB_SRC_NORM_PLUS_T, "cos_exp": L.TB_SRC_COS_EXP}
+
+    def __init__(self, f, value=0.0):
+        self.f, self.value = f, value
+
+
+def _lower_coef(coef, wrap=False, Cm=1.0, chi=1.0):
+    c = L.tb_coef()
+    c.wrap, c.Cm, c.chi = int(wrap), float(Cm), float(chi)
+    keep = None
+    if isinstance(coef, ConductivityToDiffusivityCoefficient):
+        Cm_, chi_ = coef.capacitance, coef.chi
+        Cm_ = Cm_.val if isinstance(Cm_, ConstantCoefficient) else Cm_
+        chi_ = chi_.val if isinstance(chi_, ConstantCoefficient) else chi_
+        return _lower_coef(coef.conductivity, True, float(Cm_), float(chi_))
+    if isinstance(coef, ConstantCoefficient):
+        v = np.asarray(coef.val, dtype=np.float64)
+        if v.ndim == 0:
+            c.kind = L.TB_COEF_CONST_SCALAR
+            c.p[0] = float(v)
+        else:
+            assert v.shape == (3, 3)
+            c.kind = L.TB_COEF_CONST_TENSOR
+            for i, x in enumerate(v.ravel()):
+                c.p[i] = x
+    elif isinstance(coef, FieldCoefficient):
+        c.kind = L.TB_COEF_FIELD_SCALAR
+        keep = coef.data
+    elif isinstance(coef, SpectralTensorCoefficient):
+        lam = coef.eigenvalues.val if isinstance(coef.eigenvalues, ConstantCoefficient) else coef.eigenvalues
+        lam = np.asarray(lam, dtype=np.float64)
+        ev = coef.eigenvectors.val if isinstance(coef.eigenvectors, ConstantCoefficient) else coef.eigenvectors
+        if isinstance(ev, OrthotropicMicrostructure):
+            c.kind = L.TB_COEF_SPECTRAL_CONST
+            for i, x in enumerate(np.concatenate([ev.f, ev.s, ev.n, lam])):
+                c.p[i] = x
+        elif isinstance(ev, TransverselyIsotropicMicrostructure):
+            c.kind = L.TB_COEF_TRANSVERSE_CONST
+            for i, x in enumerate(np.concatenate([ev.f, lam])):
+                c.p[i] = x
+        elif isinstance(ev, OrthotropicMicrostructureModel):
+            c.kind = L.TB_COEF_SPECTRAL_FIELD
+            for i, x in enumerate(lam):
+                c.p[i] = x
+            keep = ev.fsn
+        else:
+            raise TypeError("SpectralTensorCoefficient: unsupported eigenvector coefficient %r" % (ev,))
+    else:
+        raise TypeError("unsupported coefficient %r" % (coef,))
+    if keep is not None:
+        c.field = keep.ctypes.data_as(L.c_dp)
+        c.field_len = keep.size
+    return c, keep
+
+
+# --------------------------------------------------------------------------------------- integrators / operators
+class BilinearMassIntegrator:
+    form = L.TB_FORM_MASS
+
+    def __init__(self, rho, qorder=0):
+        self.coef, self.qorder = rho, qorder
+
+
+class BilinearDiffusionIntegrator:
+    form = L.TB_FORM_DIFFUSION
+
+    def __init__(self, D, qorder=0):
+        self.coef, self.qorder = D, qorder
+
+
+class LinearIntegrator:
+    """LinearIntegrator(source_term, qrc); nonzero_intervals as in AnalyticalTransmembraneStimulationProtocol
+    (src/modeling/electrophysiology.jl:260-283), tested by needs_update (src/discretization/operator.jl:17-26)."""
+    form = L.TB_FORM_SOURCE
+
+    def __init__(self, source, qorder=0, nonzero_intervals=None):
+        self.coef, self.qorder, self.nonzero_intervals = source, qorder, nonzero_intervals
+
+
+class _Form:
+    def __init__(self, dmesh, kind, qorder, c):
+        self.h = C.c_void_p()
+        check(lib().tb_form_create(dmesh.h, kind, qorder, C.byref(c), C.byref(self.h)))
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().tb_form_destroy(self.h)
+        except Exception:
+            pass
+
+
+class BilinearOperator:
+    """Assembled bilinear operator: `.A` is the CSR nzval vector on device, pattern shared per DofHandler."""
+
+    def __init__(self, strategy, integrator, dh, pattern):
+        self.strategy, self.integrator, self.dh = strategy, integrator, dh
+        self.dmesh = dh.device_mesh(strategy.device)
+        self.pattern = self.dmesh.pattern(pattern)
+        c, self._keep = _lower_coef(integrator.coef)
+        self.form = _Form(self.dmesh, integrator.form, integrator.qorder, c)
+        self.A = DeviceVector(strategy.device, pattern.nnz)
+
+    def update(self, t):
+        check(lib().tb_assemble_matrix(self.form.h, self.pattern.h, self.strategy.code, float(t), self.A.ptr))
+
+    def mul(self, y, x, alpha=1.0, beta=0.0):
+        """mul!(y, op, x, α, β) (src/utils.jl:185-231)."""
+        check(lib().tb_spmv_csr(self.pattern.h, self.A.ptr, _ptr(x), alpha, beta, _ptr(y)))
+
+
+class LinearOperator:
+    """Assembled linear operator: `.b` on device (test/gpu/test_operators.jl:24-30)."""
+
+    def __init__(self, strategy, integrator, dh):
+        self.strategy, self.integrator, self.dh = strategy, integrator, dh
+        self.dmesh = dh.device_mesh(strategy.device)
+        src = integrator.coef
+        c = L.tb_coef()
+        self._callable = None
+        if callable(src.f):
+            c.kind = L.TB_SRC_TABULATED
+            self._callable = src.f
+        else:
+            c.kind = AnalyticalCoefficient.KINDS[src.f]
+            c.p[0] = float(src.value)
+        self.form = _Form(self.dmesh, L.TB_FORM_SOURCE, integrator.qorder, c)
+        self.b = DeviceVector(strategy.device, dh.ndofs)
+
+    def _tabulate(self, t):
+        # host evaluation of the closure at every quadrature point: x_q = Σ Mₐ(ξ_q) Xₐ
+        g = self.dh.grid
+        if g.cell_kind != Hexahedron:
+            raise NotImplementedError("callable sources are tabulated on hexahedra only")
+        q = self.integrator.qorder or 2
+        pts = {2: [-0.5773502691896258, 0.5773502691896258], 3: [-0.7745966692414834, 0.0, 0.7745966692414834]}[q]
+        sx = np.array([-1, 1, 1, -1, -1, 1, 1, -1.0])
+        sy = np.array([-1, -1, 1, 1, -1, -1, 1, 1.0])
+        sz = np.array([-1, -1, -1, -1, 1, 1, 1, 1.0])
+        X = g.xyz[g.conn]  # (nc, 8, 3)
+        vals = np.empty((g.n_cells, q ** 3))
+        k = 0
+        for c_ in pts:
+            for b_ in pts:
+                for a_ in pts:
+                    M = 0.125 * (1 + sx * a_) * (1 + sy * b_) * (1 + sz * c_)
+                    xq = np.einsum("a,cad->cd", M, X)
+                    vals[:, k] = [self._callable(x, t) for x in xq]
+                    k += 1
+        check(lib().tb_form_set_table(self.form.h, vals.ctypes.data_as(L.c_dp), vals.size))
+
+    def update(self, t):
+        if self._callable is not None:
+            self._tabulate(t)
+        check(lib().tb_assemble_vector(self.form.h, self.strategy.code, float(t), self.b.ptr))
+
+
+def setup_operator(strategy, integrator, dh, pattern=None):
+    """setup_operator(strategy, integrator, [solver,] dh) (src/solver/interface.jl:17-94)."""
+    if isinstance(integrator, LinearIntegrator):
+        return LinearOperator(strategy, integrator, dh)
+    if pattern is None:
+        pattern = allocate_matrix(dh)
+    return BilinearOperator(strategy, integrator, dh, pattern)
+
+
+def update_operator(op, t):
+    """update_operator!(op, t) (src/solver/time/euler.jl:172-176)."""
+    op.update(t)
+    return op
+
+
+def needs_update(op, t):
+    """needs_update(op::LinearOperator, t) (src/discretization/operator.jl:17-26): closed-interval test."""
+    iv = getattr(op.integrator, "nonzero_intervals", None)
+    if iv is None:
+        return True
+    return any(a <= t <= b for a, b in iv)
+
+
+def heat_system_matrix(device, M, K, dt, A=None):
+    """_implicit_euler_heat_solver_update_system_matrix!(A, M, K, Δt): Anz = Mnz − Δt·Knz (euler.jl:110-116)."""
+    A = A or DeviceVector(device, M.A.n)
+    check(lib().tb_heat_matrix(device.h, M.A.n, M.A.ptr, K.A.ptr, float(dt), A.ptr))
+    return A
+
+
+def add(b, op, device):
+    """add!(b, op) (src/solver/time/euler.jl:90)."""
+    check(lib().tb_axpy(device.h, op.b.n, 1.0, op.b.ptr, _ptr(b)))
+
+
+# --------------------------------------------------------------------------------------- reaction
+class _IonicModel:
+    model_id = None
+
+    def __init__(self, **params):
+        ns, npar, phi = C.c_int(), C.c_int(), C.c_int()
+        check(lib().tb_cell_model_info(self.model_id, C.byref(ns), C.byref(npar), C.byref(phi)))
+        self.nstates, self.phi_index = ns.value, phi.value
+        p = np.zeros(npar.value)
+        u0 = np.zeros(ns.value)
+        check(lib().tb_cell_model_defaults(self.model_id, p.ctypes.data_as(L.c_dp), u0.ctypes.data_as(L.c_dp)))
+        for k, v in params.items():
+            p[self.param_names.index(k)] = v
+        self.params, self._u0 = p, u0
+
+    def default_initial_state(self):
+        if self.model_id == L.TB_CELL_PCG2019 and True:
+            # recompute from the (possibly modified) parameters, pcg2019.jl:137-152
+            p = self.params
+            sig = lambda phi, E, k, s: 1.0 / (1.0 + np.exp(s * (phi - E) / k))  # noqa: E731
+            n = self.param_names.index
+            u0 = np.zeros(7)
+            u0[0] = p[n("E_K")]
+            u0[1] = sig(u0[0], p[n("E_h")], p[n("k_h")], 1.0)
+            u0[2] = sig(u0[0], p[n("E_m")], p[n("k_m")], -1.0)
+            u0[3] = sig(u0[0], p[n("E_f")], p[n("k_f")], 1.0)
+            u0[4] = sig(u0[0], p[n("E_s")], p[n("k_s")], 1.0)
+            u0[5] = sig(u0[0], p[n("E_xs")], p[n("k_xs")], -1.0)
+            u0[6] = sig(u0[0], p[n("E_xr")], p[n("k_xr")], -1.0)
+            return u0
+        return self._u0.copy()
+
+
+def num_states(model):
+    return model.nstates
+
+
+def transmembranepotential_index(model):
+    """1-based like the reference (src/modeling/electrophysiology.jl:149-153)."""
+    return model.phi_index + 1
+
+
+class FHNModel(_IonicModel):
+    model_id = L.TB_CELL_FHN
+    param_names = ["a", "b", "c", "d", "e", "f"]
+    state_symbols = ("φₘ", "s")
+
+
+class AlievPanfilovModel(_IonicModel):
+    model_id = L.TB_CELL_ALIEV_PANFILOV
+    param_names = ["c_t", "k", "a", "eps0", "mu1", "mu2"]
+    state_symbols = ("s", "φₘ")
+
+
+class PCG2019(_IonicModel):
+    model_id = L.TB_CELL_PCG2019
+    param_names = ["g_Na", "E_m", "k_m", "tau_m", "E_h", "k_h", "delta_h", "tau_h0", "g_K1", "E_z", "k_z", "g_to", "E_r",
+                   "k_r", "E_s", "k_s", "tau_s", "g_CaL", "E_d", "k_d", "E_f", "k_f", "tau_f", "g_Kr", "E_xr", "k_xr",
+                   "tau_xr", "E_y", "k_y", "g_Ks", "E_xs", "k_xs", "tau_xs", "E_Na", "E_K", "E_Ca"]
+    state_symbols = ("φₘ", "h", "m", "f", "s", "xs", "xr")
+
+
+class StateBlockedLayout:
+    code = L.TB_LAYOUT_SOA
+
+
+class PointBlockedLayout:
+    code = L.TB_LAYOUT_AOS
+
+
+class PointwiseODEFunction:
+    """PointwiseODEFunction(npoints, ode[, x]) (src/modeling/functions.jl:46-65); SoA by default (fem.jl:385-408)."""
+
+    def __init__(self, npoints, ode, x=None, layout=None):
+        self.npoints, self.ode, self.x = int(npoints), ode, x
+        self.layout = layout or StateBlockedLayout()
+
+
+def solution_size(f):
+    return f.npoints * f.ode.nstates
+
+
+class ForwardEulerCellSolver:
+    def __init__(self, device, batch_size_hint=32):
+        self.device, self.batch_size_hint = device, batch_size_hint
+        self.substeps, self.reaction_threshold = 1, 0.0
+
+
+class AdaptiveForwardEulerSubstepper:
+    def __init__(self, device, substeps=10, reaction_threshold=0.1, batch_size_hint=32):
+        self.device, self.substeps, self.reaction_threshold = device, substeps, reaction_threshold
+        self.batch_size_hint = batch_size_hint
+
+
+class PointwiseSolverCache:
+    """ForwardEulerCellSolverCache / AdaptiveForwardEulerSubstepperCache (partitioned_solver.jl:63-77,178-194):
+    `du` is materialised (dumat), `un` is advanced in place."""
+
+    def __init__(self, f, solver, u=None, keep_du=True):
+        self.solver = solver
+        self.un = u if u is not None else solver.device.zeros(solution_size(f))
+        self.du = solver.device.zeros(solution_size(f)) if keep_du else None
+        self.substeps, self.reaction_threshold = solver.substeps, solver.reaction_threshold
+
+
+def setup_solver_cache(f, solver, t0=0.0, u=None, keep_du=True):
+    return PointwiseSolverCache(f, solver, u=u, keep_du=keep_du)
+
+
+def pointwise_step_outer_kernel(f, t, dt, cache):
+    """_pointwise_step_outer_kernel!(f, t, Δt, cache, ::DeviceVector) → Bool (partitioned_solver.jl:38-52)."""
+    m = f.ode
+    check(lib().tb_reaction_step(cache.solver.device.h, m.model_id, m.params.ctypes.data_as(L.c_dp), len(m.params),
+                                 _ptr(cache.un), _ptr(cache.du), f.npoints, m.nstates, f.layout.code, float(t),
+                                 float(dt), int(cache.substeps), float(cache.reaction_threshold)))
+    return True
+
+
+def perform_step(f, cache, t, dt):
+    """perform_step!(f::PointwiseODEFunction, cache, t, Δt) (partitioned_solver.jl:14-21)."""
+    return pointwise_step_outer_kernel(f, t, dt, cache)
+
+
+def reaction_rate_max(device, f, cache):
+    """max |dumat[:, φₘidx]| as the RTC controller reads it (src/solver/time/rtc.jl:64-73)."""
+    m = f.ode
+    out = C.c_double()
+    if f.layout.code == L.TB_LAYOUT_SOA:
+        base = cache.du.data_ptr() + 8 * m.phi_index * f.npoints
+        check(lib().tb_absmax(device.h, f.npoints, C.c_void_p(base), 1, C.byref(out)))
+    else:
+        base = cache.du.data_ptr() + 8 * m.phi_index
+        check(lib().tb_absmax(device.h, f.npoints, C.c_void_p(base), m.nstates, C.byref(out)))
+    return out.value

@@ -1,0 +1,489 @@
+// tb_api.cpp — C-ABI entry points (include/tbhip.h): objects, memory, argument checking, error strings.
+// No arithmetic of the path lives here; kernels are in tb_assembly.hip / tb_reaction.hip / tb_algebra.hip.
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+
+#include "tb_internal.h"
+
+namespace tb {
+
+static thread_local std::string g_error;
+
+void set_error(const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_error = buf;
+}
+
+int reset_status(tb_device *dev)
+{
+    TB_HIP(hipMemsetAsync(dev->d_status, 0, sizeof(Status), dev->stream));
+    return TB_OK;
+}
+
+int check_status(tb_device *dev)
+{
+    TB_HIP(hipMemcpyAsync(dev->h_status, dev->d_status, sizeof(Status), hipMemcpyDeviceToHost, dev->stream));
+    TB_HIP(hipStreamSynchronize(dev->stream));
+    if (dev->h_status->neg_detj) {
+        set_error("detJ <= 0 in cell %lld (0-based)", dev->h_status->cell);
+        return TB_ERR_NEG_DETJ;
+    }
+    if (dev->h_status->pattern_missing) {
+        set_error("coupling of cell %lld (0-based) missing from the CSR pattern", dev->h_status->cell);
+        return TB_ERR_PATTERN;
+    }
+    return TB_OK;
+}
+
+template <class T>
+static void copy_rebased(std::vector<T> &dst, const T *src, size_t n, int base)
+{
+    dst.resize(n);
+    for (size_t i = 0; i < n; ++i) dst[i] = src[i] - (T)base;
+}
+
+} // namespace tb
+
+using namespace tb;
+
+extern "C" {
+
+const char *tb_last_error_string(void) { return g_error.c_str(); }
+const char *tb_version(void) { return "thunderbolt.jl_amd 0.1 (gfx950)"; }
+
+// ------------------------------------------------------------------ device
+int tb_device_create(int hip_device_id, tb_device **out)
+{
+    TB_REQUIRE(out, "tb_device_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    TB_HIP(hipGetDeviceCount(&n));
+    TB_REQUIRE(hip_device_id >= 0 && hip_device_id < n, "tb_device_create: device %d of %d", hip_device_id, n);
+    TB_HIP(hipSetDevice(hip_device_id));
+    auto dev = std::make_unique<tb_device>();
+    dev->id = hip_device_id;
+    hipDeviceProp_t prop;
+    TB_HIP(hipGetDeviceProperties(&prop, hip_device_id));
+    dev->n_cu = prop.multiProcessorCount;
+    dev->hbm_bytes = prop.totalGlobalMem;
+    dev->name = prop.gcnArchName;
+    TB_HIP(hipStreamCreateWithFlags(&dev->stream, hipStreamNonBlocking));
+    TB_HIP(hipMalloc((void **)&dev->d_status, sizeof(Status)));
+    TB_HIP(hipHostMalloc((void **)&dev->h_status, sizeof(Status), hipHostMallocDefault));
+    *out = dev.release();
+    return TB_OK;
+}
+
+int tb_device_destroy(tb_device *dev)
+{
+    if (!dev) return TB_OK;
+    hipSetDevice(dev->id);
+    if (dev->own_stream && dev->stream) hipStreamDestroy(dev->stream);
+    if (dev->d_status) hipFree(dev->d_status);
+    if (dev->h_status) hipHostFree(dev->h_status);
+    delete dev;
+    return TB_OK;
+}
+
+int tb_device_set_stream(tb_device *dev, void *hip_stream)
+{
+    TB_REQUIRE(dev, "tb_device_set_stream: dev is NULL");
+    TB_HIP(hipStreamSynchronize(dev->stream));
+    if (dev->own_stream && dev->stream) TB_HIP(hipStreamDestroy(dev->stream));
+    if (hip_stream) {
+        dev->stream = (hipStream_t)hip_stream;
+        dev->own_stream = false;
+    } else {
+        TB_HIP(hipStreamCreateWithFlags(&dev->stream, hipStreamNonBlocking));
+        dev->own_stream = true;
+    }
+    return TB_OK;
+}
+
+int tb_device_synchronize(tb_device *dev)
+{
+    TB_REQUIRE(dev, "tb_device_synchronize: dev is NULL");
+    TB_HIP(hipStreamSynchronize(dev->stream));
+    return TB_OK;
+}
+
+int tb_device_info(tb_device *dev, char *name, size_t name_len, int *n_cu, size_t *hbm_bytes)
+{
+    TB_REQUIRE(dev, "tb_device_info: dev is NULL");
+    if (name && name_len) { strncpy(name, dev->name.c_str(), name_len - 1); name[name_len - 1] = 0; }
+    if (n_cu) *n_cu = dev->n_cu;
+    if (hbm_bytes) *hbm_bytes = dev->hbm_bytes;
+    return TB_OK;
+}
+
+int tb_malloc(tb_device *dev, size_t bytes, void **d_ptr)
+{
+    TB_REQUIRE(dev && d_ptr, "tb_malloc: NULL argument");
+    *d_ptr = nullptr;
+    TB_HIP(hipSetDevice(dev->id));
+    if (bytes == 0) return TB_OK;
+    hipError_t e = hipMalloc(d_ptr, bytes);
+    if (e != hipSuccess) { set_error("tb_malloc(%zu): %s", bytes, hipGetErrorString(e)); return TB_ERR_NOMEM; }
+    return TB_OK;
+}
+
+int tb_free(tb_device *dev, void *d_ptr)
+{
+    TB_REQUIRE(dev, "tb_free: dev is NULL");
+    if (d_ptr) TB_HIP(hipFree(d_ptr));
+    return TB_OK;
+}
+
+int tb_memcpy_h2d(tb_device *dev, void *d_dst, const void *src, size_t bytes)
+{
+    TB_REQUIRE(dev && (bytes == 0 || (d_dst && src)), "tb_memcpy_h2d: NULL argument");
+    if (!bytes) return TB_OK;
+    TB_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, dev->stream));
+    TB_HIP(hipStreamSynchronize(dev->stream));
+    return TB_OK;
+}
+
+int tb_memcpy_d2h(tb_device *dev, void *dst, const void *d_src, size_t bytes)
+{
+    TB_REQUIRE(dev && (bytes == 0 || (dst && d_src)), "tb_memcpy_d2h: NULL argument");
+    if (!bytes) return TB_OK;
+    TB_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, dev->stream));
+    TB_HIP(hipStreamSynchronize(dev->stream));
+    return TB_OK;
+}
+
+int tb_memcpy_d2d(tb_device *dev, void *d_dst, const void *d_src, size_t bytes)
+{
+    TB_REQUIRE(dev && (bytes == 0 || (d_dst && d_src)), "tb_memcpy_d2d: NULL argument");
+    if (!bytes) return TB_OK;
+    TB_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, dev->stream));
+    return TB_OK;
+}
+
+int tb_memset(tb_device *dev, void *d_ptr, int byte, size_t bytes)
+{
+    TB_REQUIRE(dev && (bytes == 0 || d_ptr), "tb_memset: NULL argument");
+    if (!bytes) return TB_OK;
+    TB_HIP(hipMemsetAsync(d_ptr, byte, bytes, dev->stream));
+    return TB_OK;
+}
+
+int tb_event_create(tb_device *dev, void **event)
+{
+    TB_REQUIRE(dev && event, "tb_event_create: NULL argument");
+    hipEvent_t e;
+    TB_HIP(hipEventCreate(&e));
+    *event = (void *)e;
+    return TB_OK;
+}
+int tb_event_record(tb_device *dev, void *event)
+{
+    TB_REQUIRE(dev && event, "tb_event_record: NULL argument");
+    TB_HIP(hipEventRecord((hipEvent_t)event, dev->stream));
+    return TB_OK;
+}
+int tb_event_elapsed_ms(void *start, void *stop, float *ms)
+{
+    TB_REQUIRE(start && stop && ms, "tb_event_elapsed_ms: NULL argument");
+    TB_HIP(hipEventSynchronize((hipEvent_t)stop));
+    TB_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return TB_OK;
+}
+int tb_event_destroy(void *event)
+{
+    if (event) TB_HIP(hipEventDestroy((hipEvent_t)event));
+    return TB_OK;
+}
+
+// ------------------------------------------------------------------ mesh
+int tb_mesh_create(tb_device *dev, int geom_kind, int64_t n_nodes, const double *xyz, int64_t n_cells,
+                   const int32_t *conn, int field_kind, int ncomp, const int32_t *cell_dofs, int64_t ndofs,
+                   int index_base, tb_mesh **out)
+{
+    TB_REQUIRE(dev && out && xyz && conn && cell_dofs, "tb_mesh_create: NULL argument");
+    *out = nullptr;
+    TB_REQUIRE(geom_kind == TB_HEX8 || geom_kind == TB_TET4, "tb_mesh_create: geometry kind %d (need TB_HEX8 or TB_TET4)", geom_kind);
+    TB_REQUIRE(field_kind == geom_kind || (geom_kind == TB_HEX8 && field_kind == TB_HEX27),
+               "tb_mesh_create: field kind %d does not live on geometry kind %d", field_kind, geom_kind);
+    TB_REQUIRE(ncomp == 1 || ncomp == 3, "tb_mesh_create: ncomp must be 1 or 3 (got %d)", ncomp);
+    TB_REQUIRE(index_base == 0 || index_base == 1, "tb_mesh_create: index_base must be 0 or 1");
+    TB_REQUIRE(n_nodes > 0 && n_cells >= 0 && ndofs > 0 && n_nodes < 0x7fffffff && ndofs < 0x7fffffff,
+               "tb_mesh_create: sizes out of range (nodes %lld, cells %lld, dofs %lld)", (long long)n_nodes, (long long)n_cells, (long long)ndofs);
+    auto m = std::make_unique<tb_mesh>();
+    m->dev = dev;
+    m->geom_kind = geom_kind; m->field_kind = field_kind; m->ncomp = ncomp;
+    m->nverts = kind_nverts(geom_kind); m->nb = kind_nbasis(field_kind); m->ndpc = m->nb * ncomp;
+    m->n_nodes = n_nodes; m->n_cells = n_cells; m->ndofs = ndofs;
+    m->h_xyz.assign(xyz, xyz + 3 * n_nodes);
+    copy_rebased(m->h_conn, conn, (size_t)n_cells * m->nverts, index_base);
+    copy_rebased(m->h_cell_dofs, cell_dofs, (size_t)n_cells * m->ndpc, index_base);
+    for (int32_t v : m->h_conn) TB_REQUIRE(v >= 0 && v < n_nodes, "tb_mesh_create: node id %d out of range", v + index_base);
+    for (int32_t v : m->h_cell_dofs) TB_REQUIRE(v >= 0 && v < ndofs, "tb_mesh_create: dof id %d out of range", v + index_base);
+    TB_HIP(hipSetDevice(dev->id));
+    int rc;
+    if ((rc = upload(dev, m->h_xyz, &m->d_xyz))) return rc;
+    if ((rc = upload(dev, m->h_conn, &m->d_conn))) return rc;
+    if ((rc = upload(dev, m->h_cell_dofs, &m->d_cell_dofs))) return rc;
+    *out = m.release();
+    return TB_OK;
+}
+
+int tb_mesh_destroy(tb_mesh *m)
+{
+    if (!m) return TB_OK;
+    hipFree(m->d_xyz); hipFree(m->d_conn); hipFree(m->d_cell_dofs);
+    if (m->colors) hipFree(m->colors->d_cells);
+    if (m->ea) { hipFree(m->ea->d_ptr); hipFree(m->ea->d_src); hipFree(m->ea->d_ea); }
+    if (m->patches) {
+        hipFree(m->patches->d_elem_ptr); hipFree(m->patches->d_row_ptr); hipFree(m->patches->d_elem_cell);
+        hipFree(m->patches->d_elem_lrow); hipFree(m->patches->d_row_dof);
+    }
+    delete m;
+    return TB_OK;
+}
+
+int64_t tb_mesh_ncells(const tb_mesh *m) { return m ? m->n_cells : -1; }
+int64_t tb_mesh_ndofs(const tb_mesh *m) { return m ? m->ndofs : -1; }
+
+// ------------------------------------------------------------------ pattern
+int tb_pattern_create(tb_mesh *mesh, int64_t n_rows, const int64_t *rowptr, const int32_t *colidx, int index_base,
+                      tb_pattern **out)
+{
+    TB_REQUIRE(mesh && rowptr && colidx && out, "tb_pattern_create: NULL argument");
+    *out = nullptr;
+    TB_REQUIRE(n_rows == mesh->ndofs, "tb_pattern_create: %lld rows but the dof table has %lld dofs", (long long)n_rows, (long long)mesh->ndofs);
+    TB_REQUIRE(index_base == 0 || index_base == 1, "tb_pattern_create: index_base must be 0 or 1");
+    auto p = std::make_unique<tb_pattern>();
+    p->mesh = mesh;
+    p->n_rows = n_rows;
+    copy_rebased(p->h_rowptr, rowptr, (size_t)n_rows + 1, index_base);
+    TB_REQUIRE(p->h_rowptr[0] == 0, "tb_pattern_create: rowptr does not start at index_base");
+    p->nnz = p->h_rowptr[n_rows];
+    for (int64_t r = 0; r < n_rows; ++r) TB_REQUIRE(p->h_rowptr[r + 1] >= p->h_rowptr[r], "tb_pattern_create: rowptr not monotone at row %lld", (long long)r);
+    copy_rebased(p->h_colidx, colidx, (size_t)p->nnz, index_base);
+    for (int64_t r = 0; r < n_rows; ++r)
+        for (int64_t k = p->h_rowptr[r]; k < p->h_rowptr[r + 1]; ++k) {
+            TB_REQUIRE(p->h_colidx[k] >= 0 && p->h_colidx[k] < n_rows, "tb_pattern_create: column out of range in row %lld", (long long)r);
+            TB_REQUIRE(k == p->h_rowptr[r] || p->h_colidx[k] > p->h_colidx[k - 1], "tb_pattern_create: columns of row %lld not sorted", (long long)r);
+        }
+    TB_HIP(hipSetDevice(mesh->dev->id));
+    int rc;
+    if ((rc = upload(mesh->dev, p->h_rowptr, &p->d_rowptr))) return rc;
+    if ((rc = upload(mesh->dev, p->h_colidx, &p->d_colidx))) return rc;
+    if ((rc = launch_build_emap(p.get()))) { tb_pattern_destroy(p.release()); return rc; }
+    *out = p.release();
+    return TB_OK;
+}
+
+int tb_pattern_destroy(tb_pattern *p)
+{
+    if (!p) return TB_OK;
+    hipFree(p->d_rowptr); hipFree(p->d_colidx); hipFree(p->d_emap);
+    if (p->patch_mat) { hipFree(p->patch_mat->d_row_off); hipFree(p->patch_mat->d_colpos8); hipFree(p->patch_mat->d_colpos16); }
+    delete p;
+    return TB_OK;
+}
+
+int64_t tb_pattern_nnz(const tb_pattern *p) { return p ? p->nnz : -1; }
+const int64_t *tb_pattern_rowptr_device(const tb_pattern *p) { return p ? p->d_rowptr : nullptr; }
+const int32_t *tb_pattern_colidx_device(const tb_pattern *p) { return p ? p->d_colidx : nullptr; }
+
+// ------------------------------------------------------------------ forms
+int tb_form_create(tb_mesh *mesh, int form_kind, int qorder, const tb_coef *coef, tb_form **out)
+{
+    TB_REQUIRE(mesh && coef && out, "tb_form_create: NULL argument");
+    *out = nullptr;
+    TB_REQUIRE(form_kind == TB_FORM_MASS || form_kind == TB_FORM_DIFFUSION || form_kind == TB_FORM_SOURCE,
+               "tb_form_create: unknown form kind %d", form_kind);
+    if (qorder == 0) qorder = std::max(2 * kind_order(mesh->field_kind) - 1, 2); // src/discretization/fem.jl:52-55
+    auto f = std::make_unique<tb_form>();
+    f->mesh = mesh; f->kind = form_kind; f->qorder = qorder; f->coef = *coef; f->coef.field = nullptr;
+    const int nb = mesh->nb;
+    int64_t need_field = 0;
+    if (form_kind == TB_FORM_MASS) {
+        TB_REQUIRE(coef->kind == TB_COEF_CONST_SCALAR || coef->kind == TB_COEF_FIELD_SCALAR, "mass form: coefficient kind %d", coef->kind);
+        if (coef->kind == TB_COEF_FIELD_SCALAR) { f->field = true; need_field = mesh->n_cells * nb; }
+    } else if (form_kind == TB_FORM_DIFFUSION) {
+        double k[9] = {0};
+        switch (coef->kind) {
+        case TB_COEF_CONST_SCALAR: k[0] = k[4] = k[8] = coef->p[0]; break;
+        case TB_COEF_CONST_TENSOR: for (int i = 0; i < 9; ++i) k[i] = coef->p[i]; break;
+        case TB_COEF_SPECTRAL_CONST: // λ₁ f⊗f + λ₂ s⊗s + λ₃ n⊗n, microstructure.jl:136-138
+            for (int v = 0; v < 3; ++v)
+                for (int i = 0; i < 3; ++i)
+                    for (int j = 0; j < 3; ++j) k[3 * i + j] += coef->p[9 + v] * coef->p[3 * v + i] * coef->p[3 * v + j];
+            break;
+        case TB_COEF_TRANSVERSE_CONST: // λ₁ f⊗f + λ₂ (I − f⊗f), microstructure.jl:89-92
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) {
+                    const double ff = coef->p[i] * coef->p[j];
+                    k[3 * i + j] = coef->p[3] * ff + coef->p[4] * ((i == j ? 1.0 : 0.0) - ff);
+                }
+            break;
+        case TB_COEF_SPECTRAL_FIELD: f->field = true; need_field = mesh->n_cells * nb * 9; break;
+        default: set_error("diffusion form: coefficient kind %d", coef->kind); return TB_ERR_BAD_ARG;
+        }
+        const double den = coef->Cm * coef->chi;
+        for (int i = 0; i < 9; ++i) f->Dconst[i] = coef->wrap ? k[i] / den : k[i]; // κ/(Cₘ·χ), coefficients.jl:158-161
+        f->symmetric = f->Dconst[1] == f->Dconst[3] && f->Dconst[2] == f->Dconst[6] && f->Dconst[5] == f->Dconst[7];
+    } else {
+        TB_REQUIRE(coef->kind >= TB_SRC_CONST && coef->kind <= TB_SRC_TABULATED, "source form: source kind %d", coef->kind);
+    }
+    if (need_field) {
+        TB_REQUIRE(coef->field && coef->field_len == need_field, "tb_form_create: field coefficient needs %lld values, got %lld",
+                   (long long)need_field, (long long)coef->field_len);
+        TB_HIP(hipMalloc((void **)&f->d_field, sizeof(double) * need_field));
+        TB_HIP(hipMemcpyAsync(f->d_field, coef->field, sizeof(double) * need_field, hipMemcpyHostToDevice, mesh->dev->stream));
+        TB_HIP(hipStreamSynchronize(mesh->dev->stream));
+    }
+    *out = f.release();
+    return TB_OK;
+}
+
+int tb_form_destroy(tb_form *f)
+{
+    if (!f) return TB_OK;
+    hipFree(f->d_field); hipFree(f->d_table);
+    delete f;
+    return TB_OK;
+}
+
+int tb_form_set_table(tb_form *f, const double *values, int64_t n)
+{
+    TB_REQUIRE(f && values, "tb_form_set_table: NULL argument");
+    TB_REQUIRE(f->kind == TB_FORM_SOURCE && f->coef.kind == TB_SRC_TABULATED, "tb_form_set_table: form is not a tabulated source");
+    const int nq = f->mesh->field_kind == TB_TET4 ? (f->qorder == 1 ? 1 : 4) : f->qorder * f->qorder * f->qorder;
+    TB_REQUIRE(n == f->mesh->n_cells * nq, "tb_form_set_table: expected %lld values, got %lld", (long long)(f->mesh->n_cells * nq), (long long)n);
+    if (!f->d_table) TB_HIP(hipMalloc((void **)&f->d_table, sizeof(double) * n));
+    f->table_len = n;
+    TB_HIP(hipMemcpyAsync(f->d_table, values, sizeof(double) * n, hipMemcpyHostToDevice, f->mesh->dev->stream));
+    TB_HIP(hipStreamSynchronize(f->mesh->dev->stream));
+    return TB_OK;
+}
+
+// ------------------------------------------------------------------ assembly
+int tb_assemble_matrix(tb_form *form, tb_pattern *pat, int strategy, double t, double *d_nzval)
+{
+    TB_REQUIRE(form && pat && d_nzval, "tb_assemble_matrix: NULL argument");
+    TB_REQUIRE(form->mesh == pat->mesh, "tb_assemble_matrix: form and pattern belong to different meshes");
+    TB_REQUIRE(form->kind == TB_FORM_MASS || form->kind == TB_FORM_DIFFUSION, "tb_assemble_matrix: form is not bilinear");
+    TB_REQUIRE(form->mesh->ncomp == 1, "tb_assemble_matrix: scalar fields only");
+    TB_HIP(hipSetDevice(form->mesh->dev->id));
+    return launch_assemble_matrix(form, pat, strategy, t, d_nzval);
+}
+
+int tb_assemble_vector(tb_form *form, int strategy, double t, double *d_b)
+{
+    TB_REQUIRE(form && d_b, "tb_assemble_vector: NULL argument");
+    TB_REQUIRE(form->kind == TB_FORM_SOURCE, "tb_assemble_vector: form is not linear");
+    TB_REQUIRE(form->coef.kind != TB_SRC_TABULATED || form->d_table, "tb_assemble_vector: tabulated source without table");
+    TB_HIP(hipSetDevice(form->mesh->dev->id));
+    return launch_assemble_vector(form, strategy, t, d_b);
+}
+
+// ------------------------------------------------------------------ reaction
+int tb_cell_model_info(int model, int *n_states, int *n_params, int *phi_index)
+{
+    int ns, np, pi = 0;
+    switch (model) {
+    case TB_CELL_FHN: ns = 2; np = 6; break;
+    case TB_CELL_ALIEV_PANFILOV: ns = 2; np = 6; pi = 1; break; // state order (s, φₘ): aliev-panfilov.jl:13
+    case TB_CELL_PCG2019: ns = 7; np = 36; break;
+    default: set_error("unknown cell model %d", model); return TB_ERR_BAD_ARG;
+    }
+    if (n_states) *n_states = ns;
+    if (n_params) *n_params = np;
+    if (phi_index) *phi_index = pi;
+    return TB_OK;
+}
+
+int tb_cell_model_defaults(int model, double *params, double *u0)
+{
+    TB_REQUIRE(params, "tb_cell_model_defaults: params is NULL");
+    switch (model) {
+    case TB_CELL_FHN: { // src/modeling/cells/fhn.jl:6-13
+        const double d[6] = {0.1, 0.5, 1.0, 0.0, 0.01, 1.0};
+        memcpy(params, d, sizeof d);
+        if (u0) u0[0] = u0[1] = 0.0;
+        return TB_OK;
+    }
+    case TB_CELL_ALIEV_PANFILOV: { // src/modeling/cells/aliev-panfilov.jl:1-8
+        const double d[6] = {1.0 / 12.9, 8.0, 0.05, 0.002, 0.2, 0.3};
+        memcpy(params, d, sizeof d);
+        if (u0) u0[0] = u0[1] = 0.0;
+        return TB_OK;
+    }
+    case TB_CELL_PCG2019: { // src/modeling/cells/pcg2019.jl:4-48 (field order), :137-152 (initial state)
+        const double d[36] = {12.0, -52.244, 6.5472, 0.12, -78.7, 5.93, 0.799163, 6.80738, 0.73893, -91.9655, 12.4997, 0.1688,
+                              14.3116, 11.462, -47.9286, 4.9314, 9.90669, 0.11503, 0.7, 4.3, -15.7, 4.6, 30.0, 0.056,
+                              -26.6, 6.5, 334.0, -49.6, 23.5, 0.008, 24.6, 12.1, 628.0, 65.0, -85.0, 50.0};
+        memcpy(params, d, sizeof d);
+        if (u0) {
+            auto sig = [](double phi, double E, double k, double sign) { return 1.0 / (1.0 + std::exp(sign * (phi - E) / k)); };
+            u0[0] = d[34];
+            u0[1] = sig(u0[0], d[4], d[5], 1.0);    // h
+            u0[2] = sig(u0[0], d[1], d[2], -1.0);   // m
+            u0[3] = sig(u0[0], d[20], d[21], 1.0);  // f
+            u0[4] = sig(u0[0], d[14], d[15], 1.0);  // s
+            u0[5] = sig(u0[0], d[30], d[31], -1.0); // xs
+            u0[6] = sig(u0[0], d[24], d[25], -1.0); // xr
+        }
+        return TB_OK;
+    }
+    }
+    set_error("unknown cell model %d", model);
+    return TB_ERR_BAD_ARG;
+}
+
+int tb_reaction_step(tb_device *dev, int model, const double *params, int n_params, double *d_u, double *d_du,
+                     int64_t n_points, int n_states, int layout, double t, double dt, int substeps, double threshold)
+{
+    TB_REQUIRE(dev && params && d_u, "tb_reaction_step: NULL argument");
+    int ns, np;
+    int rc = tb_cell_model_info(model, &ns, &np, nullptr);
+    if (rc) return rc;
+    TB_REQUIRE(n_states == ns, "tb_reaction_step: model has %d states, caller says %d", ns, n_states);
+    TB_REQUIRE(n_params == np, "tb_reaction_step: model has %d parameters, caller passed %d", np, n_params);
+    TB_REQUIRE(layout == TB_LAYOUT_SOA || layout == TB_LAYOUT_AOS, "tb_reaction_step: unknown layout %d", layout);
+    TB_REQUIRE(n_points >= 0, "tb_reaction_step: negative point count");
+    if (n_points == 0) return TB_OK;
+    TB_HIP(hipSetDevice(dev->id));
+    return launch_reaction(dev, model, params, n_params, d_u, d_du, n_points, layout, t, dt, substeps, threshold);
+}
+
+// ------------------------------------------------------------------ algebra
+int tb_heat_matrix(tb_device *dev, int64_t nnz, const double *d_Mnz, const double *d_Knz, double dt, double *d_Anz)
+{
+    TB_REQUIRE(dev && d_Mnz && d_Knz && d_Anz && nnz >= 0, "tb_heat_matrix: bad argument");
+    if (!nnz) return TB_OK;
+    return launch_heat_matrix(dev, nnz, d_Mnz, d_Knz, dt, d_Anz);
+}
+
+int tb_spmv_csr(tb_pattern *pat, const double *d_nzval, const double *d_x, double alpha, double beta, double *d_y)
+{
+    TB_REQUIRE(pat && d_nzval && d_x && d_y, "tb_spmv_csr: NULL argument");
+    TB_REQUIRE(d_x != d_y, "tb_spmv_csr: x and y alias");
+    return launch_spmv(pat, d_nzval, d_x, alpha, beta, d_y);
+}
+
+int tb_axpy(tb_device *dev, int64_t n, double a, const double *d_x, double *d_y)
+{
+    TB_REQUIRE(dev && d_x && d_y && n >= 0, "tb_axpy: bad argument");
+    if (!n) return TB_OK;
+    return launch_axpy(dev, n, a, d_x, d_y);
+}
+
+int tb_absmax(tb_device *dev, int64_t n, const double *d_x, int64_t stride, double *result)
+{
+    TB_REQUIRE(dev && d_x && result && n >= 0 && stride >= 1, "tb_absmax: bad argument");
+    if (!n) { *result = 0.0; return TB_OK; }
+    return launch_absmax(dev, n, d_x, stride, result);
+}
+
+} // extern "C"

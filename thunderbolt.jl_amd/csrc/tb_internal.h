@@ -1,0 +1,171 @@
+// tb_internal.h — private declarations shared by the host objects and the HIP kernel launchers.
+// Nothing here is part of the ABI (include/tbhip.h is).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "tbhip.h"
+
+namespace tb {
+
+void set_error(const char *fmt, ...);
+
+#define TB_HIP(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e__ = (call);                                                              \
+        if (e__ != hipSuccess) {                                                              \
+            tb::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return TB_ERR_HIP;                                                                \
+        }                                                                                     \
+    } while (0)
+
+#define TB_REQUIRE(cond, ...)             \
+    do {                                  \
+        if (!(cond)) {                    \
+            tb::set_error(__VA_ARGS__);   \
+            return TB_ERR_BAD_ARG;        \
+        }                                 \
+    } while (0)
+
+// status word written by kernels (device) and read back after each launch group
+struct Status {
+    int neg_detj;        // != 0: some cell had detJ <= 0
+    int pattern_missing; // != 0: a coupling was not found in the CSR pattern
+    long long cell;      // one offending cell (0-based)
+};
+
+inline int kind_nverts(int kind) { return kind == TB_TET4 ? 4 : 8; }
+inline int kind_nbasis(int kind) { return kind == TB_TET4 ? 4 : kind == TB_HEX27 ? 27 : 8; }
+inline int kind_order(int kind) { return kind == TB_HEX27 ? 2 : 1; }
+
+// ---- assembly plans (built lazily on the host, cached on the mesh / pattern) ----
+struct ColorPlan {
+    int ncolors = 0;
+    std::vector<int64_t> offsets; // ncolors+1, into d_cells
+    int32_t *d_cells = nullptr;   // cells grouped by colour
+};
+
+struct EAPlan {                // dof → contributing (cell, local) slots, cell-ordered
+    int64_t *d_ptr = nullptr;  // ndofs+1
+    int32_t *d_src = nullptr;  // n_cells*ndpc indices into the element-vector buffer
+    double *d_ea = nullptr;    // n_cells*ndpc element vectors
+};
+
+// Patch plan: cells in Morton order are cut into patches; every dof (row) is owned by exactly one
+// patch, which (re)computes all cells touching its rows, accumulates in LDS and stores once.
+struct PatchPlan {
+    int cells_per_patch = 0;
+    int64_t n_patches = 0;
+    int max_elems = 0, max_rows = 0;
+    int64_t total_elems = 0, total_rows = 0;
+    // per patch
+    int64_t *d_elem_ptr = nullptr; // n_patches+1 → element instances
+    int64_t *d_row_ptr = nullptr;  // n_patches+1 → owned rows
+    // per element instance
+    int32_t *d_elem_cell = nullptr; // global cell id
+    uint16_t *d_elem_lrow = nullptr; // ndpc local-row slots per instance (0xFFFF = row not owned here)
+    // per owned row
+    int32_t *d_row_dof = nullptr;   // global dof id
+    // matrix extension (needs a pattern)
+    std::vector<int64_t> h_elem_ptr, h_row_ptr;
+    std::vector<int32_t> h_elem_cell, h_row_dof;
+    std::vector<uint16_t> h_elem_lrow;
+};
+
+struct PatchMatPlan {
+    int max_lds_entries = 0;        // max over patches of Σ rowlen of owned rows
+    uint32_t *d_row_off = nullptr;  // per owned row: offset of its accumulators in the patch's LDS block
+    uint8_t *d_colpos8 = nullptr;   // per element instance: ndpc*ndpc positions inside the row (rowlen <= 255)
+    uint16_t *d_colpos16 = nullptr; // same, 16-bit, when some row is longer
+};
+
+} // namespace tb
+
+struct tb_device {
+    int id = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    int n_cu = 0;
+    size_t hbm_bytes = 0;
+    std::string name;
+    tb::Status *d_status = nullptr;
+    tb::Status *h_status = nullptr; // pinned
+};
+
+struct tb_mesh {
+    tb_device *dev = nullptr;
+    int geom_kind = 0, field_kind = 0, ncomp = 1;
+    int nverts = 0, nb = 0, ndpc = 0;
+    int64_t n_nodes = 0, n_cells = 0, ndofs = 0;
+    double *d_xyz = nullptr;
+    int32_t *d_conn = nullptr;
+    int32_t *d_cell_dofs = nullptr;
+    std::vector<double> h_xyz;
+    std::vector<int32_t> h_conn, h_cell_dofs;
+    std::unique_ptr<tb::ColorPlan> colors;
+    std::unique_ptr<tb::EAPlan> ea;
+    std::unique_ptr<tb::PatchPlan> patches;
+};
+
+struct tb_pattern {
+    tb_mesh *mesh = nullptr;
+    int64_t n_rows = 0, nnz = 0;
+    int64_t *d_rowptr = nullptr;
+    int32_t *d_colidx = nullptr;
+    std::vector<int64_t> h_rowptr;
+    std::vector<int32_t> h_colidx;
+    bool map64 = false;
+    void *d_emap = nullptr; // [ndpc*ndpc][n_cells] nz index of (cell,i,j): int32 (nnz < 2^31) or int64
+    std::unique_ptr<tb::PatchMatPlan> patch_mat;
+};
+
+struct tb_form {
+    tb_mesh *mesh = nullptr;
+    int kind = 0, qorder = 0;
+    tb_coef coef{};
+    double Dconst[9] = {0}; // folded constant tensor (incl. κ/(Cₘχ))
+    bool field = false, symmetric = true;
+    double *d_field = nullptr;
+    double *d_table = nullptr;
+    int64_t table_len = 0;
+};
+
+namespace tb {
+
+// ---- plan builders (tb_plans.cpp) ----
+int build_color_plan(tb_mesh *m);
+int build_ea_plan(tb_mesh *m);
+int build_patch_plan(tb_mesh *m, int cells_per_patch);
+int build_patch_mat_plan(tb_pattern *p);
+
+// ---- kernel launchers (tb_assembly.hip / tb_reaction.hip / tb_algebra.hip) ----
+int launch_build_emap(tb_pattern *p);
+int launch_assemble_matrix(tb_form *f, tb_pattern *p, int strategy, double t, double *d_nz);
+int launch_assemble_vector(tb_form *f, int strategy, double t, double *d_b);
+int launch_reaction(tb_device *dev, int model, const double *params, int n_params, double *d_u, double *d_du,
+                    int64_t n_points, int layout, double t, double dt, int substeps, double thr);
+int launch_heat_matrix(tb_device *dev, int64_t nnz, const double *M, const double *K, double dt, double *A);
+int launch_spmv(tb_pattern *p, const double *nz, const double *x, double alpha, double beta, double *y);
+int launch_axpy(tb_device *dev, int64_t n, double a, const double *x, double *y);
+int launch_absmax(tb_device *dev, int64_t n, const double *x, int64_t stride, double *result);
+
+int check_status(tb_device *dev);
+int reset_status(tb_device *dev);
+
+template <class T>
+int upload(tb_device *dev, const std::vector<T> &h, T **d)
+{
+    *d = nullptr;
+    if (h.empty()) return TB_OK;
+    TB_HIP(hipMalloc((void **)d, h.size() * sizeof(T)));
+    TB_HIP(hipMemcpyAsync(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, dev->stream));
+    TB_HIP(hipStreamSynchronize(dev->stream));
+    return TB_OK;
+}
+
+} // namespace tb

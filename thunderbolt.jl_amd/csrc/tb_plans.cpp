@@ -1,0 +1,255 @@
+// tb_plans.cpp — host-side assembly plans, built once per mesh / pattern (the analogue of
+// setup_operator, src/solver/interface.jl:17-94: colouring, element-assembly maps, patch decomposition).
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+
+#include "tb_internal.h"
+
+namespace tb {
+
+// dof → contributing element-vector slots (cell*ndpc + local), ordered by cell
+static void dof_slots(const tb_mesh *m, std::vector<int64_t> &ptr, std::vector<int32_t> &src)
+{
+    const int64_t n = m->n_cells * m->ndpc;
+    ptr.assign(m->ndofs + 1, 0);
+    for (int64_t i = 0; i < n; ++i) ptr[m->h_cell_dofs[i] + 1]++;
+    for (int64_t d = 0; d < m->ndofs; ++d) ptr[d + 1] += ptr[d];
+    std::vector<int64_t> pos(ptr.begin(), ptr.end() - 1);
+    src.resize(n);
+    for (int64_t i = 0; i < n; ++i) src[pos[m->h_cell_dofs[i]]++] = (int32_t)i;
+}
+
+int build_ea_plan(tb_mesh *m)
+{
+    if (m->n_cells * m->ndpc >= (int64_t)0x7fffffff) { set_error("element-assembly plan: too many slots for int32"); return TB_ERR_UNSUPPORTED; }
+    std::vector<int64_t> ptr;
+    std::vector<int32_t> src;
+    dof_slots(m, ptr, src);
+    auto plan = std::make_unique<EAPlan>();
+    int rc = upload(m->dev, ptr, &plan->d_ptr);
+    if (rc) return rc;
+    rc = upload(m->dev, src, &plan->d_src);
+    if (rc) return rc;
+    TB_HIP(hipMalloc((void **)&plan->d_ea, sizeof(double) * m->n_cells * m->ndpc));
+    m->ea = std::move(plan);
+    return TB_OK;
+}
+
+// Greedy colouring of the cell conflict graph (two cells conflict iff they share a dof): smallest
+// colour not used by any neighbour, neighbours found through a per-dof colour bitmask.
+int build_color_plan(tb_mesh *m)
+{
+    std::vector<uint64_t> used(m->ndofs, 0);
+    std::vector<int32_t> color(m->n_cells);
+    int ncolors = 0;
+    for (int64_t c = 0; c < m->n_cells; ++c) {
+        const int32_t *d = &m->h_cell_dofs[c * m->ndpc];
+        uint64_t mask = 0;
+        for (int l = 0; l < m->ndpc; ++l) mask |= used[d[l]];
+        const int col = mask == ~0ull ? 64 : __builtin_ctzll(~mask);
+        if (col >= 64) { set_error("colouring needs more than 64 colours"); return TB_ERR_UNSUPPORTED; }
+        color[c] = col;
+        ncolors = std::max(ncolors, col + 1);
+        for (int l = 0; l < m->ndpc; ++l) used[d[l]] |= 1ull << col;
+    }
+    auto plan = std::make_unique<ColorPlan>();
+    plan->ncolors = ncolors;
+    plan->offsets.assign(ncolors + 1, 0);
+    for (int64_t c = 0; c < m->n_cells; ++c) plan->offsets[color[c] + 1]++;
+    for (int k = 0; k < ncolors; ++k) plan->offsets[k + 1] += plan->offsets[k];
+    std::vector<int64_t> pos(plan->offsets.begin(), plan->offsets.end() - 1);
+    std::vector<int32_t> cells(m->n_cells);
+    for (int64_t c = 0; c < m->n_cells; ++c) cells[pos[color[c]]++] = (int32_t)c;
+    int rc = upload(m->dev, cells, &plan->d_cells);
+    if (rc) return rc;
+    m->colors = std::move(plan);
+    return TB_OK;
+}
+
+static inline uint64_t spread21(uint64_t v)
+{
+    v &= 0x1fffff;
+    v = (v | v << 32) & 0x1f00000000ffffull;
+    v = (v | v << 16) & 0x1f0000ff0000ffull;
+    v = (v | v << 8) & 0x100f00f00f00f00full;
+    v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+    v = (v | v << 2) & 0x1249249249249249ull;
+    return v;
+}
+
+// Patch decomposition.  Cells are ordered along a Morton curve through their centroids (works for any
+// unstructured mesh), cut into runs of `cells_per_patch`; a dof is owned by the first patch (in that
+// order) that touches it; a patch's element list = every cell touching one of its rows.
+int build_patch_plan(tb_mesh *m, int cells_per_patch)
+{
+    if (cells_per_patch <= 0) {
+        const char *e = getenv("TB_PATCH_CELLS");
+        cells_per_patch = e ? atoi(e) : 256;
+        if (cells_per_patch <= 0) cells_per_patch = 256;
+    }
+    const int64_t nc = m->n_cells;
+    const int ndpc = m->ndpc, nv = m->nverts;
+    // 1. Morton order
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int64_t i = 0; i < m->n_nodes; ++i)
+        for (int d = 0; d < 3; ++d) { lo[d] = std::min(lo[d], m->h_xyz[3 * i + d]); hi[d] = std::max(hi[d], m->h_xyz[3 * i + d]); }
+    double ext = 0;
+    for (int d = 0; d < 3; ++d) ext = std::max(ext, hi[d] - lo[d]);
+    if (!(ext > 0)) ext = 1;
+    std::vector<std::pair<uint64_t, int32_t>> keyed(nc);
+#pragma omp parallel for schedule(static)
+    for (int64_t c = 0; c < nc; ++c) {
+        double cen[3] = {0, 0, 0};
+        for (int a = 0; a < nv; ++a)
+            for (int d = 0; d < 3; ++d) cen[d] += m->h_xyz[3 * (int64_t)m->h_conn[c * nv + a] + d];
+        uint64_t key = 0;
+        for (int d = 0; d < 3; ++d) {
+            double u = (cen[d] / nv - lo[d]) / ext;
+            u = std::min(std::max(u, 0.0), 1.0);
+            key |= spread21((uint64_t)(u * 2097151.0)) << d;
+        }
+        keyed[c] = {key, (int32_t)c};
+    }
+    std::sort(keyed.begin(), keyed.end());
+
+    const int64_t np = (nc + cells_per_patch - 1) / cells_per_patch;
+    // 2. row ownership by first touch in patch order
+    std::vector<int32_t> owner(m->ndofs, -1);
+    for (int64_t k = 0; k < nc; ++k) {
+        const int32_t c = keyed[k].second;
+        const int32_t p = (int32_t)(k / cells_per_patch);
+        for (int l = 0; l < ndpc; ++l) {
+            int32_t &o = owner[m->h_cell_dofs[(int64_t)c * ndpc + l]];
+            if (o < 0) o = p;
+        }
+    }
+    // 3. dof → cells
+    std::vector<int64_t> sptr;
+    std::vector<int32_t> ssrc;
+    dof_slots(m, sptr, ssrc);
+
+    auto plan = std::make_unique<PatchPlan>();
+    plan->cells_per_patch = cells_per_patch;
+    plan->n_patches = np;
+    plan->h_elem_ptr.assign(np + 1, 0);
+    plan->h_row_ptr.assign(np + 1, 0);
+    plan->h_elem_cell.reserve((size_t)(nc * 1.7) + 1024);
+    plan->h_row_dof.reserve(m->ndofs);
+    plan->h_elem_lrow.reserve((size_t)(nc * 1.7 * ndpc) + 1024);
+    std::vector<int32_t> slot_of(m->ndofs, -1);
+    std::vector<int32_t> cell_stamp(nc, -1);
+    for (int64_t p = 0; p < np; ++p) {
+        const int64_t k0 = p * cells_per_patch, k1 = std::min(nc, k0 + cells_per_patch);
+        const size_t row_begin = plan->h_row_dof.size(), elem_begin = plan->h_elem_cell.size();
+        // owned rows in first-touch order; own cells first in the element list
+        for (int64_t k = k0; k < k1; ++k) {
+            const int32_t c = keyed[k].second;
+            cell_stamp[c] = (int32_t)p;
+            plan->h_elem_cell.push_back(c);
+            for (int l = 0; l < ndpc; ++l) {
+                const int32_t d = m->h_cell_dofs[(int64_t)c * ndpc + l];
+                if (owner[d] == p && slot_of[d] < 0) {
+                    slot_of[d] = (int32_t)(plan->h_row_dof.size() - row_begin);
+                    plan->h_row_dof.push_back(d);
+                }
+            }
+        }
+        // halo cells: every other cell touching an owned row
+        const size_t row_end = plan->h_row_dof.size();
+        for (size_t r = row_begin; r < row_end; ++r) {
+            const int32_t d = plan->h_row_dof[r];
+            for (int64_t s = sptr[d]; s < sptr[d + 1]; ++s) {
+                const int32_t c = ssrc[s] / ndpc;
+                if (cell_stamp[c] != p) { cell_stamp[c] = (int32_t)p; plan->h_elem_cell.push_back(c); }
+            }
+        }
+        const size_t elem_end = plan->h_elem_cell.size();
+        if (row_end - row_begin >= 0xFFFF) { set_error("patch owns too many rows (%zu)", row_end - row_begin); return TB_ERR_UNSUPPORTED; }
+        for (size_t e = elem_begin; e < elem_end; ++e) {
+            const int32_t c = plan->h_elem_cell[e];
+            for (int l = 0; l < ndpc; ++l) {
+                const int32_t d = m->h_cell_dofs[(int64_t)c * ndpc + l];
+                plan->h_elem_lrow.push_back(owner[d] == p ? (uint16_t)slot_of[d] : (uint16_t)0xFFFF);
+            }
+        }
+        for (size_t r = row_begin; r < row_end; ++r) slot_of[plan->h_row_dof[r]] = -1;
+        plan->h_elem_ptr[p + 1] = (int64_t)elem_end;
+        plan->h_row_ptr[p + 1] = (int64_t)row_end;
+        plan->max_elems = std::max<int>(plan->max_elems, (int)(elem_end - elem_begin));
+        plan->max_rows = std::max<int>(plan->max_rows, (int)(row_end - row_begin));
+    }
+    plan->total_elems = (int64_t)plan->h_elem_cell.size();
+    plan->total_rows = (int64_t)plan->h_row_dof.size();
+    if (plan->total_rows != m->ndofs) { set_error("patch plan: %lld rows owned, %lld dofs", (long long)plan->total_rows, (long long)m->ndofs); return TB_ERR_BAD_ARG; }
+    int rc;
+    if ((rc = upload(m->dev, plan->h_elem_ptr, &plan->d_elem_ptr))) return rc;
+    if ((rc = upload(m->dev, plan->h_row_ptr, &plan->d_row_ptr))) return rc;
+    if ((rc = upload(m->dev, plan->h_elem_cell, &plan->d_elem_cell))) return rc;
+    if ((rc = upload(m->dev, plan->h_elem_lrow, &plan->d_elem_lrow))) return rc;
+    if ((rc = upload(m->dev, plan->h_row_dof, &plan->d_row_dof))) return rc;
+    m->patches = std::move(plan);
+    return TB_OK;
+}
+
+// Matrix extension of the patch plan: LDS offsets of the owned rows and, per element instance, the
+// position of every (i,j) coupling inside its row.
+int build_patch_mat_plan(tb_pattern *p)
+{
+    tb_mesh *m = p->mesh;
+    const PatchPlan *pp = m->patches.get();
+    const int ndpc = m->ndpc;
+    auto plan = std::make_unique<PatchMatPlan>();
+    std::vector<uint32_t> row_off(pp->total_rows);
+    int64_t maxlen = 0;
+    int64_t max_entries = 0;
+    for (int64_t q = 0; q < pp->n_patches; ++q) {
+        uint64_t off = 0;
+        for (int64_t r = pp->h_row_ptr[q]; r < pp->h_row_ptr[q + 1]; ++r) {
+            const int32_t d = pp->h_row_dof[r];
+            const int64_t len = p->h_rowptr[d + 1] - p->h_rowptr[d];
+            row_off[r] = (uint32_t)off;
+            off += (uint64_t)len;
+            maxlen = std::max(maxlen, len);
+        }
+        max_entries = std::max<int64_t>(max_entries, (int64_t)off);
+    }
+    if (max_entries * 8 > 160 * 1024) {
+        set_error("patch plan needs %lld B of LDS per patch (>160 KiB): lower TB_PATCH_CELLS", (long long)(max_entries * 8));
+        return TB_ERR_UNSUPPORTED;
+    }
+    plan->max_lds_entries = (int)max_entries;
+    const bool wide = maxlen > 255;
+    std::vector<uint8_t> cp8;
+    std::vector<uint16_t> cp16;
+    const size_t n = (size_t)pp->total_elems * ndpc * ndpc;
+    if (wide) cp16.assign(n, 0); else cp8.assign(n, 0);
+    bool missing = false;
+#pragma omp parallel for schedule(static) reduction(|| : missing)
+    for (int64_t e = 0; e < pp->total_elems; ++e) {
+        const int32_t c = pp->h_elem_cell[e];
+        const int32_t *d = &m->h_cell_dofs[(int64_t)c * ndpc];
+        for (int i = 0; i < ndpc; ++i) {
+            if (pp->h_elem_lrow[e * ndpc + i] == 0xFFFF) continue;
+            const int32_t *b = &p->h_colidx[p->h_rowptr[d[i]]];
+            const int32_t *en = &p->h_colidx[p->h_rowptr[d[i] + 1]];
+            for (int j = 0; j < ndpc; ++j) {
+                const int32_t *it = std::lower_bound(b, en, d[j]);
+                if (it == en || *it != d[j]) { missing = true; continue; }
+                const size_t k = ((size_t)e * ndpc + i) * ndpc + j;
+                if (wide) cp16[k] = (uint16_t)(it - b); else cp8[k] = (uint8_t)(it - b);
+            }
+        }
+    }
+    if (missing) { set_error("patch plan: a cell coupling is missing from the CSR pattern"); return TB_ERR_PATTERN; }
+    int rc;
+    if ((rc = upload(m->dev, row_off, &plan->d_row_off))) return rc;
+    if (wide) { if ((rc = upload(m->dev, cp16, &plan->d_colpos16))) return rc; }
+    else { if ((rc = upload(m->dev, cp8, &plan->d_colpos8))) return rc; }
+    p->patch_mat = std::move(plan);
+    return TB_OK;
+}
+
+} // namespace tb

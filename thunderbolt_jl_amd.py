@@ -1,0 +1,12 @@
+"""Import shim: the package directory is named ``thunderbolt.jl_amd`` (a dotted name cannot be imported
+directly), so ``import thunderbolt_jl_amd`` loads it under this module name."""
+import importlib.util
+import os
+import sys
+
+_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "thunderbolt.jl_amd")
+_spec = importlib.util.spec_from_file_location(
+    __name__, os.path.join(_dir, "__init__.py"), submodule_search_locations=[_dir])
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules[__name__] = _mod
+_spec.loader.exec_module(_mod)
