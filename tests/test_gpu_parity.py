@@ -269,8 +269,8 @@ def test_heat_algebra_parity(tb, oracle, device):
     # odd length for the vectorised axpby
     n = 1001
     a, b = rng.normal(size=n), rng.normal(size=n)
-    out = device.zeros(n)
-    tb._lib.check(tb.lib().tb_heat_matrix(device.h, n, device.to_device(a).ptr, device.to_device(b).ptr, 0.3, out.ptr))
+    out, da, db = device.zeros(n), device.to_device(a), device.to_device(b)
+    tb._lib.check(tb.lib().tb_heat_matrix(device.h, n, da.ptr, db.ptr, 0.3, out.ptr))
     np.testing.assert_allclose(out.to_host(), a - 0.3 * b, rtol=1e-15)
 
 
