@@ -1,5 +1,6 @@
 // tb_api.cpp — C-ABI entry points (include/tbhip.h): objects, memory, argument checking, error strings.
 // No arithmetic of the path lives here; kernels are in tb_assembly.hip / tb_reaction.hip / tb_algebra.hip.
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstring>
@@ -276,7 +277,23 @@ int tb_pattern_create(tb_mesh *mesh, int64_t n_rows, const int64_t *rowptr, cons
     int rc;
     if ((rc = upload(mesh->dev, p->h_rowptr, &p->d_rowptr))) return rc;
     if ((rc = upload(mesh->dev, p->h_colidx, &p->d_colidx))) return rc;
-    if ((rc = launch_build_emap(p.get()))) { tb_pattern_destroy(p.release()); return rc; }
+    // every cell coupling must exist in the pattern (host check; the device scatter map is built lazily)
+    {
+        const int ndpc = mesh->ndpc;
+        bool missing = false;
+#pragma omp parallel for schedule(static) reduction(|| : missing)
+        for (int64_t c = 0; c < mesh->n_cells; ++c) {
+            const int32_t *d = &mesh->h_cell_dofs[c * ndpc];
+            for (int i = 0; i < ndpc; ++i) {
+                const int32_t *b = &p->h_colidx[p->h_rowptr[d[i]]], *e = &p->h_colidx[p->h_rowptr[d[i] + 1]];
+                for (int j = 0; j < ndpc; ++j) {
+                    const int32_t *it = std::lower_bound(b, e, d[j]);
+                    if (it == e || *it != d[j]) missing = true;
+                }
+            }
+        }
+        if (missing) { set_error("tb_pattern_create: a cell coupling is missing from the CSR pattern"); return TB_ERR_PATTERN; }
+    }
     *out = p.release();
     return TB_OK;
 }
@@ -285,7 +302,7 @@ int tb_pattern_destroy(tb_pattern *p)
 {
     if (!p) return TB_OK;
     hipFree(p->d_rowptr); hipFree(p->d_colidx); hipFree(p->d_emap);
-    if (p->patch_mat) { hipFree(p->patch_mat->d_row_off); hipFree(p->patch_mat->d_colpos8); hipFree(p->patch_mat->d_colpos16); }
+    if (p->patch_mat) { hipFree(p->patch_mat->d_row_desc); hipFree(p->patch_mat->d_elem_rowoff); hipFree(p->patch_mat->d_colpos8); hipFree(p->patch_mat->d_colpos16); }
     delete p;
     return TB_OK;
 }

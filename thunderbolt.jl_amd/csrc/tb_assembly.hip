@@ -44,6 +44,7 @@ struct FormArgs {
     double p0;
     const double *table;
     double t;
+    int debug; // diagnostic ablation bits (TB_DEBUG_FLAGS): 1 skip LDS adds, 2 skip write-out, 4 skip arithmetic
 };
 
 template <int NB> __host__ __device__ constexpr int sym_idx(int i, int j)
@@ -83,40 +84,44 @@ __device__ __forceinline__ void orthonormal_frame(double (&f)[3], double (&s)[3]
 }
 
 // Kₑ / Mₑ of one cell.  SYM: upper triangle packed (requires symmetric D), else full row-major.
+// Diffusion is evaluated in reference coordinates: with G = −dΩ·J⁻¹·D·J⁻ᵀ (3×3, per point),
+//   Kₑ[i,j] += ∂Nⱼ/∂ξ · G · ∂Nᵢ/∂ξ   ( = −(∇Nⱼ·D·∇Nᵢ) dΩ with ∇N = ∂N/∂ξ·J⁻¹, diffusion.jl:44 / PR883.jl:287-290 ),
+// so the mapped gradients are never materialised and ∂N/∂ξ stays a scalar-register operand.
 template <class E, int FORM, bool FIELD, bool SYM>
 __device__ __forceinline__ bool element_matrix(const double (&x)[E::NV][3], const FormArgs &fa, int64_t cell,
                                                double (&Ke)[SYM ? E::NB *(E::NB + 1) / 2 : E::NB * E::NB])
 {
     constexpr int NB = E::NB;
+    const Tables<E> &tb = g_tables<E>;
+    GeoCoeffs<E> gc;
+    geo_prepare(x, gc);
     bool ok = true;
-    for_each_qp<0, E::NQ>([&](auto qc) {
-        constexpr int Q = decltype(qc)::value;
+#pragma unroll 1
+    for (int q = 0; q < E::NQ; ++q) {
         Geom g;
-        geometry<E, Q>(x, g);
+        geometry_rt<E>(tb, q, gc, g);
         ok = ok && (g.dOmega > 0.0);
         if constexpr (FORM == TB_FORM_MASS) {
             double r = fa.rho;
             if constexpr (FIELD) {
                 r = 0.0;
 #pragma unroll
-                for (int a = 0; a < NB; ++a) r += E::N(Q, a) * fa.field[cell * NB + a];
+                for (int a = 0; a < NB; ++a) r += tb.N[q][a] * fa.field[cell * NB + a];
             }
             const double rw = r * g.dOmega;
 #pragma unroll
             for (int i = 0; i < NB; ++i)
 #pragma unroll
                 for (int j = SYM ? i : 0; j < NB; ++j)
-                    Ke[SYM ? sym_idx<NB>(i, j) : i * NB + j] += rw * (E::N(Q, i) * E::N(Q, j));
+                    Ke[SYM ? sym_idx<NB>(i, j) : i * NB + j] += rw * tb.NN[q][sym_idx<NB>(i, j)];
         } else {
-            double grad[NB][3];
-            mapped_gradients<E, Q>(g, grad);
             double D[3][3];
             if constexpr (FIELD) {
                 double f[3] = {0, 0, 0}, s[3] = {0, 0, 0}, n[3] = {0, 0, 0};
                 const double *fc = fa.field + cell * (NB * 9);
 #pragma unroll
                 for (int a = 0; a < NB; ++a) {
-                    const double Na = E::N(Q, a);
+                    const double Na = tb.N[q][a];
 #pragma unroll
                     for (int d = 0; d < 3; ++d) {
                         f[d] += Na * fc[9 * a + d];
@@ -136,19 +141,30 @@ __device__ __forceinline__ bool element_matrix(const double (&x)[E::NV][3], cons
 #pragma unroll
                     for (int j = 0; j < 3; ++j) D[i][j] = fa.D[3 * i + j];
             }
+            // H = J⁻¹·D ;  G[m][n] = −dΩ · Σₗ H[m][l]·J⁻¹[n][l]
+            double H[3][3], G[3][3];
             const double mw = -g.dOmega;
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                // T = −dΩ · D · ∇Nᵢ ;  Kₑ[i,j] += ∇Nⱼ · T   ( = −(∇Nⱼ·D·∇Nᵢ) dΩ, diffusion.jl:44 )
-                double T[3];
+            for (int m = 0; m < 3; ++m)
 #pragma unroll
-                for (int m = 0; m < 3; ++m) T[m] = mw * (D[m][0] * grad[i][0] + D[m][1] * grad[i][1] + D[m][2] * grad[i][2]);
+                for (int l = 0; l < 3; ++l) H[m][l] = g.Jinv[m][0] * D[0][l] + g.Jinv[m][1] * D[1][l] + g.Jinv[m][2] * D[2][l];
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int n = (SYM ? m : 0); n < 3; ++n)
+                    G[m][n] = mw * (H[m][0] * g.Jinv[n][0] + H[m][1] * g.Jinv[n][1] + H[m][2] * g.Jinv[n][2]);
+            if constexpr (SYM) { G[1][0] = G[0][1]; G[2][0] = G[0][2]; G[2][1] = G[1][2]; }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                double T[3]; // T = G · ∂Nᵢ/∂ξ
+#pragma unroll
+                for (int m = 0; m < 3; ++m) T[m] = G[m][0] * tb.dN[q][i][0] + G[m][1] * tb.dN[q][i][1] + G[m][2] * tb.dN[q][i][2];
 #pragma unroll
                 for (int j = SYM ? i : 0; j < NB; ++j)
-                    Ke[SYM ? sym_idx<NB>(i, j) : i * NB + j] += grad[j][0] * T[0] + grad[j][1] * T[1] + grad[j][2] * T[2];
+                    Ke[SYM ? sym_idx<NB>(i, j) : i * NB + j] += tb.dN[q][j][0] * T[0] + tb.dN[q][j][1] * T[1] + tb.dN[q][j][2] * T[2];
             }
         }
-    });
+    }
     return ok;
 }
 
@@ -170,21 +186,21 @@ __device__ __forceinline__ double eval_source(const FormArgs &fa, const double (
 template <class E>
 __device__ __forceinline__ bool element_source(const double (&x)[E::NV][3], const FormArgs &fa, int64_t cell, double (&be)[E::NB])
 {
+    const Tables<E> &tb = g_tables<E>;
+    GeoCoeffs<E> gc;
+    geo_prepare(x, gc);
     bool ok = true;
-    for_each_qp<0, E::NQ>([&](auto qc) {
-        constexpr int Q = decltype(qc)::value;
+#pragma unroll 1
+    for (int q = 0; q < E::NQ; ++q) {
         Geom g;
-        geometry<E, Q>(x, g);
+        geometry_rt<E>(tb, q, gc, g);
         ok = ok && (g.dOmega > 0.0);
-        double xq[3] = {0, 0, 0};
+        double xq[3];
+        geo_position(gc, tb, q, xq);
+        const double fw = eval_source(fa, xq, cell, q, E::NQ) * g.dOmega;
 #pragma unroll
-        for (int a = 0; a < E::NV; ++a)
-#pragma unroll
-            for (int d = 0; d < 3; ++d) xq[d] += E::M(Q, a) * x[a][d];
-        const double fw = eval_source(fa, xq, cell, Q, E::NQ) * g.dOmega;
-#pragma unroll
-        for (int j = 0; j < E::NB; ++j) be[j] += fw * E::N(Q, j);
-    });
+        for (int j = 0; j < E::NB; ++j) be[j] += fw * tb.N[q][j];
+    }
     return ok;
 }
 
@@ -294,85 +310,119 @@ struct PatchView {
     const uint16_t *elem_lrow;
     const int32_t *row_dof;
     // matrix
-    const uint32_t *row_off;
+    const RowDesc *row_desc;
+    const uint16_t *elem_rowoff;
     const void *colpos;
-    const int64_t *rowptr; // CSR row pointer (global)
+    int lds_entries, max_rows;
 };
 
-template <class E, int FORM, bool FIELD, bool SYM, class PosT, int THREADS>
-__global__ void __launch_bounds__(THREADS)
+constexpr int PATCH_MAX_THREADS = 512;
+__device__ __forceinline__ double Ke_sink() { return 0.0; }
+
+// One workgroup per patch, (about) one thread per element instance.
+//   phase 0  zero the patch's row accumulators in LDS
+//   phase 1  every thread integrates one cell and adds Kₑ into the owned rows (ds_add_f64); all scatter
+//            metadata of a cell is one 16-B rowoff load + the colpos bytes, issued before the arithmetic
+//   phase 2  each wave streams 64 rows: descriptors are loaded coalesced, broadcast with v_readlane, and
+//            every row leaves as one contiguous store — each nz is written exactly once, no zero-fill pass
+template <class E, int FORM, bool FIELD, bool SYM, class PosT, int W>
+__global__ void __launch_bounds__(PATCH_MAX_THREADS, W)
 k_matrix_patch(MeshView m, FormArgs fa, PatchView pv, double *__restrict__ nz, Status *st)
 {
     constexpr int NB = E::NB;
     extern __shared__ double acc[];
+    const int T = blockDim.x;
     const int64_t p = blockIdx.x;
     const int64_t e0 = pv.elem_ptr[p], e1 = pv.elem_ptr[p + 1];
     const int64_t r0 = pv.row_ptr[p], r1 = pv.row_ptr[p + 1];
     const int nrows = (int)(r1 - r0);
-    // total accumulator entries of this patch = offset past the last owned row
-    const int64_t last_dof = pv.row_dof[r1 - 1];
-    const int nacc = (int)(pv.row_off[r1 - 1] + (uint32_t)(pv.rowptr[last_dof + 1] - pv.rowptr[last_dof]));
-    for (int k = threadIdx.x; k < nacc; k += THREADS) acc[k] = 0.0;
+    const RowDesc last = pv.row_desc[r1 - 1];
+    const int nacc = (int)(last.off + last.len);
+    // row descriptors live behind the accumulators: nz0[max_rows] (int64) then {off,len}[max_rows]
+    int64_t *dnz = (int64_t *)(acc + pv.lds_entries);
+    uint2 *dol = (uint2 *)(dnz + pv.max_rows);
+    for (int k = threadIdx.x; k < nacc; k += T) acc[k] = 0.0;
+    for (int s = threadIdx.x; s < nrows; s += T) {
+        const RowDesc d = pv.row_desc[r0 + s];
+        dnz[s] = d.nz0;
+        dol[s] = make_uint2(d.off, d.len);
+    }
     __syncthreads();
 
-    for (int64_t e = e0 + threadIdx.x; e < e1; e += THREADS) {
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += T) {
         const int64_t cell = pv.elem_cell[e];
+        // scatter metadata first: independent of the arithmetic, so its latency hides behind it
+        uint16_t ro[NB];
+        PosT cp[NB * NB];
+        {
+            const uint16_t *rp = pv.elem_rowoff + e * NB;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) ro[i] = rp[i];
+            const PosT *cpp = (const PosT *)pv.colpos + e * (NB * NB);
+#pragma unroll
+            for (int k = 0; k < NB * NB; ++k) cp[k] = cpp[k];
+        }
         double x[E::NV][3];
         load_coords<E>(m, cell, x);
         double Ke[SYM ? NB * (NB + 1) / 2 : NB * NB];
 #pragma unroll
         for (int k = 0; k < (SYM ? NB * (NB + 1) / 2 : NB * NB); ++k) Ke[k] = 0.0;
-        if (!element_matrix<E, FORM, FIELD, SYM>(x, fa, cell, Ke)) flag_neg_detj(st, cell);
-        const uint16_t *lr = pv.elem_lrow + e * NB;
-        const PosT *cp = (const PosT *)pv.colpos + e * (NB * NB);
+        if (!(fa.debug & 4)) { if (!element_matrix<E, FORM, FIELD, SYM>(x, fa, cell, Ke)) flag_neg_detj(st, cell); }
+        else { Ke[0] = x[0][0] + x[7][2]; }
+        if (!(fa.debug & 1))
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const uint16_t s = lr[i];
-            if (s == 0xFFFF) continue;
-            const uint32_t base = pv.row_off[r0 + s];
+            if (ro[i] == 0xFFFF) continue;
+            double *row = acc + ro[i];
 #pragma unroll
-            for (int j = 0; j < NB; ++j)
-                unsafeAtomicAdd(&acc[base + cp[i * NB + j]], Ke[SYM ? sym_idx<NB>(i, j) : i * NB + j]);
+            for (int j = 0; j < NB; ++j) unsafeAtomicAdd(row + cp[i * NB + j], Ke[SYM ? sym_idx<NB>(i, j) : i * NB + j]);
         }
     }
     __syncthreads();
-    // write-out: 32 lanes per row (row-contiguous, coalesced), rows round-robin over half-waves
-    const int half = threadIdx.x >> 5, lane = threadIdx.x & 31;
-    for (int s = half; s < nrows; s += THREADS / 32) {
-        const int64_t dof = pv.row_dof[r0 + s];
-        const int64_t g0 = pv.rowptr[dof];
-        const int len = (int)(pv.rowptr[dof + 1] - g0);
-        const uint32_t base = pv.row_off[r0 + s];
-        for (int k = lane; k < len; k += 32) nz[g0 + k] = acc[base + k];
+
+    if (fa.debug & 1) { if (threadIdx.x == 0) nz[p] = acc[0] + Ke_sink(); }
+    if (fa.debug & 2) return;
+    // write-out: one row per half-wave, descriptors from LDS, several rows in flight per wave
+    const int half = threadIdx.x >> 5, hl = threadIdx.x & 31, nhalves = T >> 5;
+#pragma unroll 4
+    for (int s = half; s < nrows; s += nhalves) {
+        const int64_t g0 = dnz[s];
+        const uint2 ol = dol[s];
+        double *dst = nz + g0;
+        for (uint32_t k = hl; k < ol.y; k += 32) dst[k] = acc[ol.x + k];
     }
 }
 
-template <class E, int THREADS>
-__global__ void __launch_bounds__(THREADS)
+template <class E>
+__global__ void __launch_bounds__(PATCH_MAX_THREADS)
 k_vector_patch(MeshView m, FormArgs fa, PatchView pv, double *__restrict__ b, Status *st)
 {
     extern __shared__ double acc[];
+    const int T = blockDim.x;
     const int64_t p = blockIdx.x;
     const int64_t e0 = pv.elem_ptr[p], e1 = pv.elem_ptr[p + 1];
     const int64_t r0 = pv.row_ptr[p], r1 = pv.row_ptr[p + 1];
     const int nrows = (int)(r1 - r0);
-    for (int k = threadIdx.x; k < nrows; k += THREADS) acc[k] = 0.0;
+    for (int k = threadIdx.x; k < nrows; k += T) acc[k] = 0.0;
     __syncthreads();
-    for (int64_t e = e0 + threadIdx.x; e < e1; e += THREADS) {
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += T) {
         const int64_t cell = pv.elem_cell[e];
+        uint16_t lr[E::NB];
+        const uint16_t *lp = pv.elem_lrow + e * E::NB;
+#pragma unroll
+        for (int j = 0; j < E::NB; ++j) lr[j] = lp[j];
         double x[E::NV][3];
         load_coords<E>(m, cell, x);
         double be[E::NB];
 #pragma unroll
         for (int j = 0; j < E::NB; ++j) be[j] = 0.0;
         if (!element_source<E>(x, fa, cell, be)) flag_neg_detj(st, cell);
-        const uint16_t *lr = pv.elem_lrow + e * E::NB;
 #pragma unroll
         for (int j = 0; j < E::NB; ++j)
             if (lr[j] != 0xFFFF) unsafeAtomicAdd(&acc[lr[j]], be[j]);
     }
     __syncthreads();
-    for (int s = threadIdx.x; s < nrows; s += THREADS) b[pv.row_dof[r0 + s]] = acc[s];
+    for (int s = threadIdx.x; s < nrows; s += T) b[pv.row_dof[r0 + s]] = acc[s];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -380,8 +430,9 @@ k_vector_patch(MeshView m, FormArgs fa, PatchView pv, double *__restrict__ b, St
 // ------------------------------------------------------------------------------------------------
 static inline unsigned nblocks(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
-int launch_build_emap(tb_pattern *p)
+int ensure_emap(tb_pattern *p)
 {
+    if (p->d_emap) return TB_OK;
     tb_mesh *m = p->mesh;
     tb_device *dev = m->dev;
     const int64_t n = m->n_cells * m->ndpc;
@@ -412,6 +463,8 @@ static FormArgs make_args(const tb_form *f, double t)
     a.p0 = f->coef.p[0];
     a.table = f->d_table;
     a.t = t;
+    static const int dbg = getenv("TB_DEBUG_FLAGS") ? atoi(getenv("TB_DEBUG_FLAGS")) : 0;
+    a.debug = dbg;
     return a;
 }
 
@@ -425,9 +478,11 @@ static PatchView make_patch_view(const tb_mesh *m, const tb_pattern *p)
     v.elem_lrow = pp->d_elem_lrow; v.row_dof = pp->d_row_dof;
     if (p) {
         const PatchMatPlan *pm = p->patch_mat.get();
-        v.row_off = pm->d_row_off;
+        v.row_desc = pm->d_row_desc;
+        v.elem_rowoff = pm->d_elem_rowoff;
         v.colpos = pm->d_colpos8 ? (const void *)pm->d_colpos8 : (const void *)pm->d_colpos16;
-        v.rowptr = p->d_rowptr;
+        v.lds_entries = pm->max_lds_entries;
+        v.max_rows = pp->max_rows;
     }
     return v;
 }
@@ -443,20 +498,21 @@ static int run_matrix(tb_form *f, tb_pattern *p, int strategy, double t, double 
         if (!m->patches) { int rc = build_patch_plan(m, 0); if (rc) return rc; }
         if (!p->patch_mat) { int rc = build_patch_mat_plan(p); if (rc) return rc; }
         const PatchView pv = make_patch_view(m, p);
-        const size_t lds = (size_t)p->patch_mat->max_lds_entries * sizeof(double);
-        constexpr int T = 256;
-        if (p->patch_mat->d_colpos8) {
-            auto k = k_matrix_patch<E, FORM, FIELD, SYM, uint8_t, T>;
+        const size_t lds = (size_t)p->patch_mat->max_lds_entries * sizeof(double) + (size_t)m->patches->max_rows * 16;
+        const int T = m->patches->threads;
+        auto launch = [&](auto k) -> int {
             TB_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(k, dim3((unsigned)m->patches->n_patches), dim3(T), lds, dev->stream, mv, fa, pv, d_nz, dev->d_status);
-        } else {
-            auto k = k_matrix_patch<E, FORM, FIELD, SYM, uint16_t, T>;
-            TB_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k, dim3((unsigned)m->patches->n_patches), dim3(T), lds, dev->stream, mv, fa, pv, d_nz, dev->d_status);
-        }
+            return TB_OK;
+        };
+        int rc;
+        if (p->patch_mat->d_colpos8) rc = launch(k_matrix_patch<E, FORM, FIELD, SYM, uint8_t, 2>);
+        else rc = launch(k_matrix_patch<E, FORM, FIELD, SYM, uint16_t, 2>);
+        if (rc) return rc;
         TB_HIP(hipGetLastError());
         return TB_OK;
     }
+    { int rc = ensure_emap(p); if (rc) return rc; }
     TB_HIP(hipMemsetAsync(d_nz, 0, (size_t)p->nnz * sizeof(double), dev->stream));
     auto go = [&](const int32_t *list, int64_t n, int atomic) -> int {
         if (n == 0) return TB_OK;
@@ -522,8 +578,8 @@ static int run_vector(tb_form *f, int strategy, double t, double *d_b)
     if (strategy == TB_STRATEGY_PATCH) {
         if (!m->patches) { int rc = build_patch_plan(m, 0); if (rc) return rc; }
         const PatchView pv = make_patch_view(m, nullptr);
-        constexpr int T = 256;
-        hipLaunchKernelGGL((k_vector_patch<E, T>), dim3((unsigned)m->patches->n_patches), dim3(T),
+        const int T = m->patches->threads;
+        hipLaunchKernelGGL((k_vector_patch<E>), dim3((unsigned)m->patches->n_patches), dim3(T),
                            (size_t)m->patches->max_rows * sizeof(double), dev->stream, mv, fa, pv, d_b, dev->d_status);
         TB_HIP(hipGetLastError());
         return TB_OK;

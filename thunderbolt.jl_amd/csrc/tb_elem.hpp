@@ -106,6 +106,121 @@ __device__ __forceinline__ void mapped_gradients(const Geom &g, double (&grad)[E
             grad[a][k] = E::dN(Q, a, 0) * g.Jinv[0][k] + E::dN(Q, a, 1) * g.Jinv[1][k] + E::dN(Q, a, 2) * g.Jinv[2][k];
 }
 
+// Reference-element tables in constant memory.  The kernels loop over quadrature points at run time (keeps
+// the register footprint to ONE point's worth of temporaries); the point index is wave-uniform, so every
+// table entry is fetched with scalar loads and enters the FP64 FMAs as an SGPR operand.
+template <class E> struct Tables {
+    double N[E::NQ][E::NB];
+    double dN[E::NQ][E::NB][3];
+    double NN[E::NQ][E::NB * (E::NB + 1) / 2]; // NᵢNⱼ, upper triangle packed
+    double w[E::NQ];
+    double xi[E::NQ][6]; // ξ, η, ζ, ηζ, ζξ, ξη
+};
+template <class E> constexpr Tables<E> make_tables()
+{
+    Tables<E> t{};
+    for (int q = 0; q < E::NQ; ++q) {
+        t.w[q] = E::w(q);
+        t.xi[q][0] = E::xi(q, 0); t.xi[q][1] = E::xi(q, 1); t.xi[q][2] = E::xi(q, 2);
+        t.xi[q][3] = E::xi(q, 1) * E::xi(q, 2); t.xi[q][4] = E::xi(q, 2) * E::xi(q, 0); t.xi[q][5] = E::xi(q, 0) * E::xi(q, 1);
+        int k = 0;
+        for (int a = 0; a < E::NB; ++a) {
+            t.N[q][a] = E::N(q, a);
+            for (int d = 0; d < 3; ++d) t.dN[q][a][d] = E::dN(q, a, d);
+            for (int b = a; b < E::NB; ++b) t.NN[q][k++] = E::N(q, a) * E::N(q, b);
+        }
+    }
+    return t;
+}
+template <class E> __constant__ Tables<E> g_tables = make_tables<E>();
+
+// Geometry of a cell in "modal" form.  Hexahedron: the trilinear map is
+//   x(ξ) = c0 + c1 ξ + c2 η + c3 ζ + c4 ξη + c5 ηζ + c6 ζξ + c7 ξηζ      (cₖ = ⅛ Σₐ σₖ(a) Xₐ, a Walsh transform of the vertices)
+// so J = Σₐ Xₐ ⊗ ∂Mₐ/∂ξ (PR883.jl:253-263) costs 27 FMAs per point instead of 72:
+//   ∂x/∂ξ = c1 + c4 η + c6 ζ + c7 ηζ,  ∂x/∂η = c2 + c4 ξ + c5 ζ + c7 ζξ,  ∂x/∂ζ = c3 + c5 η + c6 ξ + c7 ξη.
+// Tetrahedron: J is constant, stored directly (c[1..3] = edge vectors, c[0] = first vertex).
+template <class E> struct GeoCoeffs { double c[E::NV][3]; };
+
+template <int ORDER>
+__device__ __forceinline__ void geo_prepare(const double (&x)[8][3], GeoCoeffs<Hex8<ORDER>> &g)
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        // stage ξ: (y,z) = (−,−): 0|1, (+,−): 3|2, (−,+): 4|5, (+,+): 7|6
+        const double s0 = x[1][i] + x[0][i], d0 = x[1][i] - x[0][i];
+        const double s1 = x[2][i] + x[3][i], d1 = x[2][i] - x[3][i];
+        const double s2 = x[5][i] + x[4][i], d2 = x[5][i] - x[4][i];
+        const double s3 = x[6][i] + x[7][i], d3 = x[6][i] - x[7][i];
+        // stage η (per z)
+        const double ss0 = s1 + s0, sd0 = s1 - s0, ds0 = d1 + d0, dd0 = d1 - d0; // z = −
+        const double ss1 = s3 + s2, sd1 = s3 - s2, ds1 = d3 + d2, dd1 = d3 - d2; // z = +
+        // stage ζ
+        g.c[0][i] = 0.125 * (ss1 + ss0); g.c[3][i] = 0.125 * (ss1 - ss0);
+        g.c[1][i] = 0.125 * (ds1 + ds0); g.c[6][i] = 0.125 * (ds1 - ds0);
+        g.c[2][i] = 0.125 * (sd1 + sd0); g.c[5][i] = 0.125 * (sd1 - sd0);
+        g.c[4][i] = 0.125 * (dd1 + dd0); g.c[7][i] = 0.125 * (dd1 - dd0);
+    }
+}
+template <int ORDER>
+__device__ __forceinline__ void geo_jacobian(const GeoCoeffs<Hex8<ORDER>> &g, const Tables<Hex8<ORDER>> &tb, int q, double (&J)[3][3])
+{
+    const double xi = tb.xi[q][0], eta = tb.xi[q][1], zeta = tb.xi[q][2], ez = tb.xi[q][3], zx = tb.xi[q][4], xe = tb.xi[q][5];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        J[i][0] = g.c[1][i] + g.c[4][i] * eta + g.c[6][i] * zeta + g.c[7][i] * ez;
+        J[i][1] = g.c[2][i] + g.c[4][i] * xi + g.c[5][i] * zeta + g.c[7][i] * zx;
+        J[i][2] = g.c[3][i] + g.c[5][i] * eta + g.c[6][i] * xi + g.c[7][i] * xe;
+    }
+}
+template <int ORDER>
+__device__ __forceinline__ void geo_position(const GeoCoeffs<Hex8<ORDER>> &g, const Tables<Hex8<ORDER>> &tb, int q, double (&xq)[3])
+{
+    const double xi = tb.xi[q][0], eta = tb.xi[q][1], zeta = tb.xi[q][2], ez = tb.xi[q][3], zx = tb.xi[q][4], xe = tb.xi[q][5];
+    const double xez = xi * ez;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        xq[i] = g.c[0][i] + g.c[1][i] * xi + g.c[2][i] * eta + g.c[3][i] * zeta + g.c[4][i] * xe + g.c[5][i] * ez + g.c[6][i] * zx + g.c[7][i] * xez;
+}
+
+template <int ORDER>
+__device__ __forceinline__ void geo_prepare(const double (&x)[4][3], GeoCoeffs<Tet4<ORDER>> &g)
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        g.c[0][i] = x[0][i];
+        g.c[1][i] = x[1][i] - x[0][i]; g.c[2][i] = x[2][i] - x[0][i]; g.c[3][i] = x[3][i] - x[0][i];
+    }
+}
+template <int ORDER>
+__device__ __forceinline__ void geo_jacobian(const GeoCoeffs<Tet4<ORDER>> &g, const Tables<Tet4<ORDER>> &, int, double (&J)[3][3])
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { J[i][0] = g.c[1][i]; J[i][1] = g.c[2][i]; J[i][2] = g.c[3][i]; }
+}
+template <int ORDER>
+__device__ __forceinline__ void geo_position(const GeoCoeffs<Tet4<ORDER>> &g, const Tables<Tet4<ORDER>> &tb, int q, double (&xq)[3])
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xq[i] = g.c[0][i] + g.c[1][i] * tb.xi[q][0] + g.c[2][i] * tb.xi[q][1] + g.c[3][i] * tb.xi[q][2];
+}
+
+// J, detJ·w, J⁻¹ at run-time quadrature point q (geometry interpolation == field interpolation, first-order cells)
+template <class E>
+__device__ __forceinline__ void geometry_rt(const Tables<E> &tb, int q, const GeoCoeffs<E> &gc, Geom &g)
+{
+    double J[3][3];
+    geo_jacobian(gc, tb, q, J);
+    const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+    const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+    const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+    const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+    const double id = 1.0 / det;
+    g.Jinv[0][0] = c00 * id; g.Jinv[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * id; g.Jinv[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * id;
+    g.Jinv[1][0] = c01 * id; g.Jinv[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * id; g.Jinv[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * id;
+    g.Jinv[2][0] = c02 * id; g.Jinv[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * id; g.Jinv[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * id;
+    g.dOmega = det * tb.w[q];
+}
+
 // compile-time loop over quadrature points
 template <int Q, int NQ, class F>
 __device__ __forceinline__ void for_each_qp(F &&f)

@@ -61,7 +61,7 @@ struct EAPlan {                // dof → contributing (cell, local) slots, cell
 struct PatchPlan {
     int cells_per_patch = 0;
     int64_t n_patches = 0;
-    int max_elems = 0, max_rows = 0;
+    int max_elems = 0, max_rows = 0, threads = 256; // threads: workgroup size used by the patch kernels
     int64_t total_elems = 0, total_rows = 0;
     // per patch
     int64_t *d_elem_ptr = nullptr; // n_patches+1 → element instances
@@ -77,11 +77,18 @@ struct PatchPlan {
     std::vector<uint16_t> h_elem_lrow;
 };
 
+struct RowDesc {      // one owned row of a patch
+    int64_t nz0;      // first nz of the row in the global CSR arrays
+    uint32_t off;     // offset of its accumulators in the patch's LDS block (in entries)
+    uint32_t len;     // row length
+};
+
 struct PatchMatPlan {
-    int max_lds_entries = 0;        // max over patches of Σ rowlen of owned rows
-    uint32_t *d_row_off = nullptr;  // per owned row: offset of its accumulators in the patch's LDS block
-    uint8_t *d_colpos8 = nullptr;   // per element instance: ndpc*ndpc positions inside the row (rowlen <= 255)
-    uint16_t *d_colpos16 = nullptr; // same, 16-bit, when some row is longer
+    int max_lds_entries = 0;           // max over patches of Σ rowlen of owned rows
+    RowDesc *d_row_desc = nullptr;     // per owned row
+    uint16_t *d_elem_rowoff = nullptr; // per element instance × local dof: LDS offset of that row, 0xFFFF = not owned here
+    uint8_t *d_colpos8 = nullptr;      // per element instance: ndpc*ndpc positions inside the row (rowlen <= 255)
+    uint16_t *d_colpos16 = nullptr;    // same, 16-bit, when some row is longer
 };
 
 } // namespace tb
@@ -144,7 +151,7 @@ int build_patch_plan(tb_mesh *m, int cells_per_patch);
 int build_patch_mat_plan(tb_pattern *p);
 
 // ---- kernel launchers (tb_assembly.hip / tb_reaction.hip / tb_algebra.hip) ----
-int launch_build_emap(tb_pattern *p);
+int ensure_emap(tb_pattern *p);
 int launch_assemble_matrix(tb_form *f, tb_pattern *p, int strategy, double t, double *d_nz);
 int launch_assemble_vector(tb_form *f, int strategy, double t, double *d_b);
 int launch_reaction(tb_device *dev, int model, const double *params, int n_params, double *d_u, double *d_du,

@@ -92,40 +92,82 @@ int build_patch_plan(tb_mesh *m, int cells_per_patch)
     }
     const int64_t nc = m->n_cells;
     const int ndpc = m->ndpc, nv = m->nverts;
-    // 1. Morton order
-    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-    for (int64_t i = 0; i < m->n_nodes; ++i)
-        for (int d = 0; d < 3; ++d) { lo[d] = std::min(lo[d], m->h_xyz[3 * i + d]); hi[d] = std::max(hi[d], m->h_xyz[3 * i + d]); }
-    double ext = 0;
-    for (int d = 0; d < 3; ++d) ext = std::max(ext, hi[d] - lo[d]);
-    if (!(ext > 0)) ext = 1;
+    // 1. Morton order over quantile buckets.  Per axis the cells are ranked by centroid coordinate and cut into
+    //    R_d equal-count buckets, R_d = extent / mean cell extent: on (mildly distorted) structured grids the
+    //    buckets are exactly the cell layers (i,j,k), on unstructured meshes they adapt to the local density.
     std::vector<std::pair<uint64_t, int32_t>> keyed(nc);
-#pragma omp parallel for schedule(static)
-    for (int64_t c = 0; c < nc; ++c) {
-        double cen[3] = {0, 0, 0};
-        for (int a = 0; a < nv; ++a)
-            for (int d = 0; d < 3; ++d) cen[d] += m->h_xyz[3 * (int64_t)m->h_conn[c * nv + a] + d];
-        uint64_t key = 0;
-        for (int d = 0; d < 3; ++d) {
-            double u = (cen[d] / nv - lo[d]) / ext;
-            u = std::min(std::max(u, 0.0), 1.0);
-            key |= spread21((uint64_t)(u * 2097151.0)) << d;
+    std::vector<uint32_t> bucket((size_t)nc * 3);
+    {
+        std::vector<double> cen((size_t)nc * 3);
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, hsum[3] = {0, 0, 0};
+#pragma omp parallel for schedule(static) reduction(min : lo[:3]) reduction(max : hi[:3]) reduction(+ : hsum[:3])
+        for (int64_t c = 0; c < nc; ++c) {
+            double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300}, sum[3] = {0, 0, 0};
+            for (int a = 0; a < nv; ++a)
+                for (int d = 0; d < 3; ++d) {
+                    const double v = m->h_xyz[3 * (int64_t)m->h_conn[c * nv + a] + d];
+                    sum[d] += v; mn[d] = std::min(mn[d], v); mx[d] = std::max(mx[d], v);
+                }
+            for (int d = 0; d < 3; ++d) {
+                cen[3 * c + d] = sum[d] / nv;
+                lo[d] = std::min(lo[d], mn[d]); hi[d] = std::max(hi[d], mx[d]); hsum[d] += mx[d] - mn[d];
+            }
         }
-        keyed[c] = {key, (int32_t)c};
+#pragma omp parallel for schedule(static, 1) num_threads(3)
+        for (int d = 0; d < 3; ++d) {
+            const double hmean = hsum[d] / (double)std::max<int64_t>(nc, 1);
+            int64_t R = hmean > 0 ? (int64_t)std::llround((hi[d] - lo[d]) / hmean) : 1;
+            R = std::min<int64_t>(std::max<int64_t>(R, 1), 1 << 21);
+            std::vector<std::pair<double, int32_t>> byc(nc);
+            for (int64_t c = 0; c < nc; ++c) byc[c] = {cen[3 * c + d], (int32_t)c};
+            std::sort(byc.begin(), byc.end());
+            for (int64_t r = 0; r < nc; ++r) bucket[3 * (size_t)byc[r].second + d] = (uint32_t)((r * R) / nc);
+        }
+#pragma omp parallel for schedule(static)
+        for (int64_t c = 0; c < nc; ++c)
+            keyed[c] = {spread21(bucket[3 * c]) | spread21(bucket[3 * c + 1]) << 1 | spread21(bucket[3 * c + 2]) << 2, (int32_t)c};
     }
     std::sort(keyed.begin(), keyed.end());
 
-    const int64_t np = (nc + cells_per_patch - 1) / cells_per_patch;
-    // 2. row ownership by first touch in patch order
+    // 2. patch boundaries + row ownership by first touch, in Morton order.  A patch closes after `cells_per_patch`
+    //    cells or when it would own more than 9/8 of that many rows (domain-boundary patches own the extra
+    //    boundary layers), which bounds the LDS accumulator block of every workgroup.
+    const int max_rows_cfg = cells_per_patch + cells_per_patch / 8;
     std::vector<int32_t> owner(m->ndofs, -1);
-    for (int64_t k = 0; k < nc; ++k) {
-        const int32_t c = keyed[k].second;
-        const int32_t p = (int32_t)(k / cells_per_patch);
-        for (int l = 0; l < ndpc; ++l) {
-            int32_t &o = owner[m->h_cell_dofs[(int64_t)c * ndpc + l]];
-            if (o < 0) o = p;
+    std::vector<int64_t> pstart(1, 0);
+    {
+        int rows_in = 0, cells_in = 0;
+        for (int64_t k = 0; k < nc; ++k) {
+            const int32_t c = keyed[k].second;
+            int newrows = 0;
+            for (int l = 0; l < ndpc; ++l) newrows += owner[m->h_cell_dofs[(int64_t)c * ndpc + l]] < 0;
+            if (cells_in == cells_per_patch || (cells_in > 0 && rows_in + newrows > max_rows_cfg)) {
+                pstart.push_back(k);
+                rows_in = 0; cells_in = 0;
+            }
+            const int32_t pid = (int32_t)pstart.size() - 1;
+            for (int l = 0; l < ndpc; ++l) {
+                int32_t &o = owner[m->h_cell_dofs[(int64_t)c * ndpc + l]];
+                if (o < 0) { o = pid; ++rows_in; }
+            }
+            ++cells_in;
         }
+        pstart.push_back(nc);
     }
+    const int64_t np = (int64_t)pstart.size() - 1;
+    // Inside a patch, cells (= threads) and hence row slots are ordered lexicographically (x fastest): lanes of a
+    // wave then hit consecutive rows of the LDS accumulator block — stride-27 addresses, free of bank conflicts.
+    auto lex_less = [&](int32_t a, int32_t b) {
+        const uint32_t *A = &bucket[3 * (size_t)a], *B = &bucket[3 * (size_t)b];
+        if (A[2] != B[2]) return A[2] < B[2];
+        if (A[1] != B[1]) return A[1] < B[1];
+        if (A[0] != B[0]) return A[0] < B[0];
+        return a < b;
+    };
+#pragma omp parallel for schedule(static)
+    for (int64_t q = 0; q < np; ++q)
+        std::sort(keyed.begin() + pstart[q], keyed.begin() + pstart[q + 1],
+                  [&](const std::pair<uint64_t, int32_t> &a, const std::pair<uint64_t, int32_t> &b) { return lex_less(a.second, b.second); });
     // 3. dof → cells
     std::vector<int64_t> sptr;
     std::vector<int32_t> ssrc;
@@ -142,7 +184,7 @@ int build_patch_plan(tb_mesh *m, int cells_per_patch)
     std::vector<int32_t> slot_of(m->ndofs, -1);
     std::vector<int32_t> cell_stamp(nc, -1);
     for (int64_t p = 0; p < np; ++p) {
-        const int64_t k0 = p * cells_per_patch, k1 = std::min(nc, k0 + cells_per_patch);
+        const int64_t k0 = pstart[p], k1 = pstart[p + 1];
         const size_t row_begin = plan->h_row_dof.size(), elem_begin = plan->h_elem_cell.size();
         // owned rows in first-touch order; own cells first in the element list
         for (int64_t k = k0; k < k1; ++k) {
@@ -167,6 +209,7 @@ int build_patch_plan(tb_mesh *m, int cells_per_patch)
             }
         }
         const size_t elem_end = plan->h_elem_cell.size();
+        std::sort(plan->h_elem_cell.begin() + elem_begin + (k1 - k0), plan->h_elem_cell.begin() + elem_end, lex_less); // halo cells
         if (row_end - row_begin >= 0xFFFF) { set_error("patch owns too many rows (%zu)", row_end - row_begin); return TB_ERR_UNSUPPORTED; }
         for (size_t e = elem_begin; e < elem_end; ++e) {
             const int32_t c = plan->h_elem_cell[e];
@@ -181,6 +224,10 @@ int build_patch_plan(tb_mesh *m, int cells_per_patch)
         plan->max_elems = std::max<int>(plan->max_elems, (int)(elem_end - elem_begin));
         plan->max_rows = std::max<int>(plan->max_rows, (int)(row_end - row_begin));
     }
+    // 256-thread workgroups (two resident per CU at the kernels' register / LDS budget, so one patch's write-out
+    // overlaps the other's arithmetic); measured best on MI355X among 64…512
+    plan->threads = std::min(256, std::max(64, (plan->max_elems + 63) / 64 * 64));
+    if (const char *e = getenv("TB_PATCH_THREADS")) { const int t = atoi(e); if (t >= 64 && t <= 512 && t % 64 == 0) plan->threads = t; }
     plan->total_elems = (int64_t)plan->h_elem_cell.size();
     plan->total_rows = (int64_t)plan->h_row_dof.size();
     if (plan->total_rows != m->ndofs) { set_error("patch plan: %lld rows owned, %lld dofs", (long long)plan->total_rows, (long long)m->ndofs); return TB_ERR_BAD_ARG; }
@@ -202,7 +249,7 @@ int build_patch_mat_plan(tb_pattern *p)
     const PatchPlan *pp = m->patches.get();
     const int ndpc = m->ndpc;
     auto plan = std::make_unique<PatchMatPlan>();
-    std::vector<uint32_t> row_off(pp->total_rows);
+    std::vector<RowDesc> row_desc(pp->total_rows);
     int64_t maxlen = 0;
     int64_t max_entries = 0;
     for (int64_t q = 0; q < pp->n_patches; ++q) {
@@ -210,13 +257,13 @@ int build_patch_mat_plan(tb_pattern *p)
         for (int64_t r = pp->h_row_ptr[q]; r < pp->h_row_ptr[q + 1]; ++r) {
             const int32_t d = pp->h_row_dof[r];
             const int64_t len = p->h_rowptr[d + 1] - p->h_rowptr[d];
-            row_off[r] = (uint32_t)off;
+            row_desc[r] = RowDesc{p->h_rowptr[d], (uint32_t)off, (uint32_t)len};
             off += (uint64_t)len;
             maxlen = std::max(maxlen, len);
         }
         max_entries = std::max<int64_t>(max_entries, (int64_t)off);
     }
-    if (max_entries * 8 > 160 * 1024) {
+    if (max_entries * 8 + (int64_t)pp->max_rows * 16 > 160 * 1024 || max_entries >= 0xFFFF) {
         set_error("patch plan needs %lld B of LDS per patch (>160 KiB): lower TB_PATCH_CELLS", (long long)(max_entries * 8));
         return TB_ERR_UNSUPPORTED;
     }
@@ -226,13 +273,20 @@ int build_patch_mat_plan(tb_pattern *p)
     std::vector<uint16_t> cp16;
     const size_t n = (size_t)pp->total_elems * ndpc * ndpc;
     if (wide) cp16.assign(n, 0); else cp8.assign(n, 0);
+    std::vector<uint16_t> rowoff((size_t)pp->total_elems * ndpc, 0xFFFF);
+    std::vector<int32_t> patch_of_elem(pp->total_elems);
+    for (int64_t q = 0; q < pp->n_patches; ++q)
+        for (int64_t e = pp->h_elem_ptr[q]; e < pp->h_elem_ptr[q + 1]; ++e) patch_of_elem[e] = (int32_t)q;
     bool missing = false;
 #pragma omp parallel for schedule(static) reduction(|| : missing)
     for (int64_t e = 0; e < pp->total_elems; ++e) {
         const int32_t c = pp->h_elem_cell[e];
         const int32_t *d = &m->h_cell_dofs[(int64_t)c * ndpc];
+        const int64_t r0 = pp->h_row_ptr[patch_of_elem[e]];
         for (int i = 0; i < ndpc; ++i) {
-            if (pp->h_elem_lrow[e * ndpc + i] == 0xFFFF) continue;
+            const uint16_t slot = pp->h_elem_lrow[e * ndpc + i];
+            if (slot == 0xFFFF) continue;
+            rowoff[e * ndpc + i] = (uint16_t)row_desc[r0 + slot].off;
             const int32_t *b = &p->h_colidx[p->h_rowptr[d[i]]];
             const int32_t *en = &p->h_colidx[p->h_rowptr[d[i] + 1]];
             for (int j = 0; j < ndpc; ++j) {
@@ -245,7 +299,8 @@ int build_patch_mat_plan(tb_pattern *p)
     }
     if (missing) { set_error("patch plan: a cell coupling is missing from the CSR pattern"); return TB_ERR_PATTERN; }
     int rc;
-    if ((rc = upload(m->dev, row_off, &plan->d_row_off))) return rc;
+    if ((rc = upload(m->dev, row_desc, &plan->d_row_desc))) return rc;
+    if ((rc = upload(m->dev, rowoff, &plan->d_elem_rowoff))) return rc;
     if (wide) { if ((rc = upload(m->dev, cp16, &plan->d_colpos16))) return rc; }
     else { if ((rc = upload(m->dev, cp8, &plan->d_colpos8))) return rc; }
     p->patch_mat = std::move(plan);
