@@ -57,8 +57,18 @@ def cpu_baseline(n, kap, threads):
     cK = o.Coef(o.COEF_CONST_TENSOR, kap.ravel(), Cm=1.0, chi=1.0, wrap=True)
     p = o.cell_default_params(o.CELL_PCG2019)
     u = np.ascontiguousarray(np.tile(o.cell_default_state(o.CELL_PCG2019, p), (nd, 1)).T).ravel().copy()
+    # the oracle's OpenMP loops stop scaling (and collapse when oversubscribed) well below the box's 256 hardware
+    # threads: pick the fastest of a few thread counts on one diffusion assembly, then time the sample with it
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else threads
+    cands = sorted({t for t in (8, 16, 32, 64) if t <= avail} | {min(avail, 8)})
+    probe = {}
+    for t in cands:
+        t0 = time.perf_counter()
+        o.assemble_matrix(m, 1, cK, rp, ci, nthreads=t, color=col, ncolors=nc)
+        probe[t] = time.perf_counter() - t0
+    threads = min(probe, key=probe.get)
     best_asm, best_rx = 1e30, 1e30
-    t_end = time.time() + 20.0
+    t_end = time.time() + 15.0
     reps = 0
     while reps < 2 or (time.time() < t_end and reps < 8):
         t0 = time.perf_counter()

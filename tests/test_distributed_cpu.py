@@ -1,0 +1,99 @@
+"""N>1 path on CPU: world_size-2 `gloo` run of the slab partition + neighbour halo sum that bench.py uses over
+RCCL.  The reference has no distributed code (README.md:7), so correctness is defined as
+"P-rank result == 1-rank result" (SURVEY §8e).  Local assembly is done by the CPU oracle here (no GPU);
+the partition / interface bookkeeping / exchange under test are the shipped ones."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, nel, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import thunderbolt_jl_amd as tb
+    from oracle import oracle as o
+    D = tb.distributed
+    left, right = (0.0, 0.0, 0.0), (1.0, 1.0, 2.0)
+    part = D.SlabPartition(nel, left, right, world, rank)
+    g = tb.generate_mesh(tb.Hexahedron, part.local_nel(), part.left, part.right)
+    dh = tb.DofHandler(g)
+    sp = tb.allocate_matrix(dh)
+    om = o.Mesh(o.HEX8, 2, g.xyz, g.conn, dh.cell_dofs)
+    n2d = D.node_to_dof(dh)
+    lo, up = part.interface_nodes()
+    lo_idx = None if lo is None else torch.from_numpy(n2d[lo])
+    up_idx = None if up is None else torch.from_numpy(n2d[up])
+    # source vector: local assembly, then halo sum
+    b = torch.from_numpy(o.assemble_source(om, o.SRC_COS_EXP, t=0.1))
+    D.halo_sum(b, lo_idx, up_idx, rank, world, dist)
+    # operator action y = K x with sub-domain (unassembled-at-the-interface) matrices: local SpMV + halo sum
+    kap = np.diag([4.5e-5, 2.0e-5, 2.0e-5])
+    Kp = o.assemble_matrix(om, 1, o.Coef(o.COEF_CONST_TENSOR, kap.ravel()), sp.rowptr, sp.colidx)
+    xg = lambda X: np.sin(3 * X[:, 0]) + X[:, 1] ** 2 - 0.5 * X[:, 2]  # noqa: E731  (a global nodal field)
+    xnode = xg(g.xyz)
+    xl = np.empty(dh.ndofs)
+    xl[n2d] = xnode
+    y = torch.from_numpy(o.spmv_csr(sp.rowptr, sp.colidx, Kp, xl))
+    D.halo_sum(y, lo_idx, up_idx, rank, world, dist)
+    # report by global node id
+    nx, ny, _ = nel
+    plane = (nx + 1) * (ny + 1)
+    gnode = np.arange(g.n_nodes) + part.z0 * plane
+    q.put((rank, gnode, b.numpy()[n2d], y.numpy()[n2d]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nel", [(3, 2, 4), (4, 4, 5)])
+def test_two_rank_halo_sum_equals_single_domain(nel):
+    from oracle import oracle as o
+    import thunderbolt_jl_amd as tb
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, nel, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-domain reference
+    g = tb.generate_mesh(tb.Hexahedron, nel, (0.0, 0.0, 0.0), (1.0, 1.0, 2.0))
+    dh = tb.DofHandler(g)
+    sp = tb.allocate_matrix(dh)
+    om = o.Mesh(o.HEX8, 2, g.xyz, g.conn, dh.cell_dofs)
+    n2d = tb.distributed.node_to_dof(dh)
+    bref = o.assemble_source(om, o.SRC_COS_EXP, t=0.1)[n2d]
+    K = o.assemble_matrix(om, 1, o.Coef(o.COEF_CONST_TENSOR, np.diag([4.5e-5, 2.0e-5, 2.0e-5]).ravel()), sp.rowptr, sp.colidx)
+    x = np.empty(dh.ndofs)
+    x[n2d] = np.sin(3 * g.xyz[:, 0]) + g.xyz[:, 1] ** 2 - 0.5 * g.xyz[:, 2]
+    yref = o.spmv_csr(sp.rowptr, sp.colidx, K, x)[n2d]
+    seen = np.zeros(g.n_nodes, dtype=int)
+    for rank, gnode, b, y in res:
+        # local slab coordinates must coincide with the global lattice
+        np.testing.assert_allclose(b, bref[gnode], rtol=1e-12, atol=1e-18)
+        np.testing.assert_allclose(y, yref[gnode], rtol=1e-10, atol=1e-16)
+        seen[gnode] += 1
+    assert seen.min() == 1 and seen.max() == 2  # interface plane is held by both ranks
+    plane = (nel[0] + 1) * (nel[1] + 1)
+    assert (seen == 2).sum() == plane
