@@ -30,6 +30,7 @@ FP64_VECTOR_TFLOPS = 78.6      # AMD spec sheet; FP64 MFMA runs at the same rate
 BYTES_PER_CELL_MATRIX = 272.0  # 32 B conn + 24 B coords + 27 nz × 8 B
 BYTES_PER_CELL_VECTOR = 64.0   # 32 + 24 + 8
 BYTES_PER_DOF_UPDATE = 16.0    # in place; 24 when du is materialised
+FLOP_PER_CELL_DIFFUSION = 6000.0  # ≈3000 FP64 instructions per cell counted as FMAs (ISA count)
 
 
 def parse():
@@ -196,6 +197,15 @@ def main():
                                       "peak": HBM_PEAK_GBS, "unit": "GB/s"}},
         }
         out["roofline"]["reaction"]["frac"] = out["roofline"]["reaction"]["achieved"] / HBM_PEAK_GBS
+        out["roofline"]["fp64_frac"] = FLOP_PER_CELL_DIFFUSION * g.n_cells / (k_ms * 1e-3) / (FP64_VECTOR_TFLOPS * 1e12)
+        try:  # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            if tj["cells"] == g.n_cells and args.strategy == "patch":
+                kk = [v for k, v in tj["kernels"].items() if "k_matrix_patch" in k and ", 1," in k][0]
+                out["roofline"]["traffic"] = kk["fetch_bytes"] + kk["write_bytes"]
+                out["roofline"]["traffic_note"] = "bytes per launch, " + tj["source"] + "; FETCH_SIZE uncorrected (lower bound, see profiles/traffic.json)"
+        except Exception:
+            pass
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_n, kap, os.cpu_count() or 1)
         print(json.dumps(out))

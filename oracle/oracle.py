@@ -284,3 +284,35 @@ def spmv_csr(rowptr, colidx, nz, x, alpha=1.0, beta=0.0, y=None, nthreads=1):
     lib().orc_spmv_csr(C.c_int64(n), _i64(rowptr), _i32(colidx), _d(_f64(nz)), _d(_f64(x)), C.c_double(alpha),
                        C.c_double(beta), _d(y), nthreads)
     return y
+
+
+# ---------------------------------------------------------------- quasi-static hyperelasticity
+HO_DEFAULTS = np.array([0.059, 8.023, 18.472, 16.026, 2.581, 11.120, 0.216, 11.436, 1.0])  # energies.jl:136-146, :80-82
+
+
+def ho_energy(F, p=HO_DEFAULTS, fsn=np.eye(3)):
+    F, p, fsn = _f64(F), _f64(p), _f64(fsn)
+    P = np.zeros((3, 3))
+    A = np.zeros((9, 9))
+    lib().orc_ho_energy.restype = C.c_double
+    psi = lib().orc_ho_energy(_d(p), _d(fsn), _d(F), _d(P), _d(A))
+    return psi, P, A
+
+
+def element_hyperelastic(mesh, cell, ue, p=HO_DEFAULTS, fsn=np.eye(3), want_K=True, want_r=True):
+    nd = mesh.cell_dofs.shape[1]
+    Ke = np.zeros((nd, nd)) if want_K else None
+    re = np.zeros(nd) if want_r else None
+    rc = lib().orc_element_hyperelastic(C.byref(mesh.c), C.c_int64(cell), _d(_f64(p)), _d(_f64(fsn)), _d(_f64(ue)), _d(Ke), _d(re))
+    assert rc == 0, rc
+    return Ke, re
+
+
+def assemble_hyperelastic(mesh, u, rowptr=None, colidx=None, p=HO_DEFAULTS, fsn=np.eye(3), want_K=True, want_r=True,
+                          nthreads=1, color=None, ncolors=0):
+    nz = np.zeros(int(rowptr[-1])) if want_K else None
+    r = np.zeros(mesh.ndofs) if want_r else None
+    rc = lib().orc_assemble_hyperelastic(C.byref(mesh.c), _d(_f64(p)), _d(_f64(fsn)), _d(_f64(u)), _i64(rowptr), _i32(colidx),
+                                         _d(nz), _d(r), nthreads, _i32(color), ncolors)
+    assert rc == 0, rc
+    return nz, r

@@ -913,3 +913,179 @@ void orc_spmv_csr(int64_t nrows, const int64_t *rowptr, const int32_t *colidx, c
         y[r] = (beta == 0.0) ? alpha * v : alpha * v + beta * y[r];
     }
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* quasi-static hyperelasticity                                                                */
+/* ------------------------------------------------------------------------------------------ */
+
+/* hyper-dual number: value, 9 first and 45 (packed symmetric) second partials w.r.t. F — the C
+ * counterpart of the nested ForwardDiff duals Tensors.hessian builds (materials.jl:1036-1040) */
+typedef struct { double v, g[9], h[45]; } hd;
+static int hidx(int i, int j) { if (i > j) { int t = i; i = j; j = t; } return i * 9 - i * (i - 1) / 2 + (j - i); }
+static hd hd_const(double c) { hd r; memset(&r, 0, sizeof r); r.v = c; return r; }
+static hd hd_var(double v, int k) { hd r = hd_const(v); r.g[k] = 1.0; return r; }
+static hd hd_add(hd a, hd b) { for (int i = 0; i < 9; ++i) a.g[i] += b.g[i]; for (int i = 0; i < 45; ++i) a.h[i] += b.h[i]; a.v += b.v; return a; }
+static hd hd_sub(hd a, hd b) { for (int i = 0; i < 9; ++i) a.g[i] -= b.g[i]; for (int i = 0; i < 45; ++i) a.h[i] -= b.h[i]; a.v -= b.v; return a; }
+static hd hd_scale(hd a, double s) { for (int i = 0; i < 9; ++i) a.g[i] *= s; for (int i = 0; i < 45; ++i) a.h[i] *= s; a.v *= s; return a; }
+static hd hd_addc(hd a, double c) { a.v += c; return a; }
+static hd hd_mul(hd a, hd b)
+{
+    hd r;
+    r.v = a.v * b.v;
+    for (int i = 0; i < 9; ++i) r.g[i] = a.g[i] * b.v + a.v * b.g[i];
+    for (int i = 0; i < 9; ++i)
+        for (int j = i; j < 9; ++j)
+            r.h[hidx(i, j)] = a.h[hidx(i, j)] * b.v + a.v * b.h[hidx(i, j)] + a.g[i] * b.g[j] + a.g[j] * b.g[i];
+    return r;
+}
+/* f(u) with f' = d1, f'' = d2 at u.v */
+static hd hd_chain(hd u, double f, double d1, double d2)
+{
+    hd r;
+    r.v = f;
+    for (int i = 0; i < 9; ++i) r.g[i] = d1 * u.g[i];
+    for (int i = 0; i < 9; ++i)
+        for (int j = i; j < 9; ++j) r.h[hidx(i, j)] = d1 * u.h[hidx(i, j)] + d2 * u.g[i] * u.g[j];
+    return r;
+}
+static hd hd_exp(hd u) { double e = exp(u.v); return hd_chain(u, e, e, e); }
+static hd hd_log(hd u) { return hd_chain(u, log(u.v), 1.0 / u.v, -1.0 / (u.v * u.v)); }
+static hd hd_sqrt(hd u) { double s = sqrt(u.v); return hd_chain(u, s, 0.5 / s, -0.25 / (s * u.v)); }
+static hd hd_cbrt(hd u) { double c = cbrt(u.v); return hd_chain(u, c, c / (3.0 * u.v), -2.0 * c / (9.0 * u.v * u.v)); }
+static hd hd_inv(hd u) { return hd_chain(u, 1.0 / u.v, -1.0 / (u.v * u.v), 2.0 / (u.v * u.v * u.v)); }
+
+/* Ψ of HolzapfelOgden2009Model with SimpleCompressionPenalty, src/modeling/solid/energies.jl:147-168 and :83-87 */
+static hd ho_psi(const double *p, const double *fsn, hd F[3][3])
+{
+    const double a = p[0], b = p[1], af = p[2], bf = p[3], as = p[4], bs = p[5], afs = p[6], bfs = p[7], beta = p[8];
+    const double *f0 = fsn, *s0 = fsn + 3;
+    hd C[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) { /* C = tdot(F) = Fᵀ·F */
+            hd s = hd_const(0.0);
+            for (int k = 0; k < 3; ++k) s = hd_add(s, hd_mul(F[k][i], F[k][j]));
+            C[i][j] = s;
+        }
+    hd I3 = hd_add(hd_sub(hd_mul(C[0][0], hd_sub(hd_mul(C[1][1], C[2][2]), hd_mul(C[1][2], C[2][1]))),
+                          hd_mul(C[0][1], hd_sub(hd_mul(C[1][0], C[2][2]), hd_mul(C[1][2], C[2][0])))),
+                   hd_mul(C[0][2], hd_sub(hd_mul(C[1][0], C[2][1]), hd_mul(C[1][1], C[2][0]))));
+    hd I1 = hd_mul(hd_add(hd_add(C[0][0], C[1][1]), C[2][2]), hd_inv(hd_cbrt(I3))); /* tr(C/cbrt(I₃)) */
+    hd I4f = hd_const(0.0), I4s = hd_const(0.0), I8 = hd_const(0.0);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            I4f = hd_add(I4f, hd_scale(C[i][j], f0[i] * f0[j]));
+            I4s = hd_add(I4s, hd_scale(C[i][j], s0[i] * s0[j]));
+            I8 = hd_add(I8, hd_scale(C[i][j], 0.5 * (f0[i] * s0[j] + s0[i] * f0[j])));
+        }
+    /* Ψᵖ = a/(2b)(exp(b(I₁−3))−1) + aᶠˢ/(2bᶠˢ)(exp(bᶠˢ I₈²)−1) + U(I₃) */
+    hd psi = hd_scale(hd_addc(hd_exp(hd_scale(hd_addc(I1, -3.0), b)), -1.0), a / (2.0 * b));
+    psi = hd_add(psi, hd_scale(hd_addc(hd_exp(hd_scale(hd_mul(I8, I8), bfs)), -1.0), afs / (2.0 * bfs)));
+    /* U(I₃) = β (I₃ − 1 − 2 log(√I₃)) */
+    psi = hd_add(psi, hd_scale(hd_sub(hd_addc(I3, -1.0), hd_scale(hd_log(hd_sqrt(I3)), 2.0)), beta));
+    if (I4f.v >= 1.0) {
+        hd d = hd_addc(I4f, -1.0);
+        psi = hd_add(psi, hd_scale(hd_addc(hd_exp(hd_scale(hd_mul(d, d), bf)), -1.0), af / (2.0 * bf)));
+    }
+    if (I4s.v >= 1.0) {
+        hd d = hd_addc(I4s, -1.0);
+        psi = hd_add(psi, hd_scale(hd_addc(hd_exp(hd_scale(hd_mul(d, d), bs)), -1.0), as / (2.0 * bs)));
+    }
+    return psi;
+}
+
+double orc_ho_energy(const double *p, const double *fsn, const double *F, double *P, double *A)
+{
+    hd Fd[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Fd[i][j] = hd_var(F[3 * i + j], 3 * i + j);
+    hd psi = ho_psi(p, fsn, Fd);
+    if (P) for (int i = 0; i < 9; ++i) P[i] = psi.g[i];
+    if (A) for (int i = 0; i < 9; ++i) for (int j = 0; j < 9; ++j) A[9 * i + j] = psi.h[hidx(i, j)];
+    return psi.v;
+}
+
+/* src/modeling/solid/elements.jl:177-313.  Vector-valued shape functions: dof 3a+c ↔ e_c ⊗ ∇N_a
+ * (node-major, component-minor: src/ferrite-addons/io.jl:233-238). */
+static int element_hyperelastic_cv(const orc_mesh *m, const cellvalues *cv, int64_t cell, const double *p,
+                                   const double *fsn, const double *ue, double *Ke, double *re)
+{
+    double x[24], dNdx[3 * MAXNB], P[9], A[81];
+    int nb = cv->nb, nd = 3 * nb;
+    gather_coords(m, cv, cell, x);
+    for (int q = 0; q < cv->nq; ++q) {
+        double dO;
+        if (reinit_qp(cv, q, x, &dO, dNdx)) return -1;
+        /* ∇u = function_gradient(cv, qp, dₑ); F = one(∇u) + ∇u */
+        double F[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        for (int a = 0; a < nb; ++a)
+            for (int c = 0; c < 3; ++c)
+                for (int k = 0; k < 3; ++k) F[3 * c + k] += ue[3 * a + c] * dNdx[3 * a + k];
+        orc_ho_energy(p, fsn, F, P, Ke ? A : NULL);
+        for (int i = 0; i < nd; ++i) {
+            int a = i / 3, c = i % 3;
+            /* residualₑ[i] += ∇δui ⊡ P * dΩ */
+            if (re) {
+                double s = 0;
+                for (int k = 0; k < 3; ++k) s += dNdx[3 * a + k] * P[3 * c + k];
+                re[i] += s * dO;
+            }
+            if (!Ke) continue;
+            /* ∇δui_tangent = ∇δui ⊡ tangent;  Kₑ[i,j] += (∇δui_tangent ⊡ ∇δuj) * dΩ */
+            double T[9];
+            for (int dl = 0; dl < 9; ++dl) {
+                double s = 0;
+                for (int k = 0; k < 3; ++k) s += dNdx[3 * a + k] * A[9 * (3 * c + k) + dl];
+                T[dl] = s;
+            }
+            for (int j = 0; j < nd; ++j) {
+                int bb = j / 3, d = j % 3;
+                double s = 0;
+                for (int l = 0; l < 3; ++l) s += T[3 * d + l] * dNdx[3 * bb + l];
+                Ke[nd * i + j] += s * dO;
+            }
+        }
+    }
+    return 0;
+}
+
+int orc_element_hyperelastic(const orc_mesh *m, int64_t cell, const double *p, const double *fsn,
+                             const double *ue, double *Ke, double *re)
+{
+    cellvalues cv;
+    if (cv_setup(&cv, m->kind, m->qorder)) return -2;
+    return element_hyperelastic_cv(m, &cv, cell, p, fsn, ue, Ke, re);
+}
+
+int orc_assemble_hyperelastic(const orc_mesh *m, const double *p, const double *fsn, const double *u,
+                              const int64_t *rowptr, const int32_t *colidx, double *nzval, double *r, int nthreads,
+                              const int32_t *color, int ncolors)
+{
+    static cellvalues cv; /* large: keep off the stack */
+    if (cv_setup(&cv, m->kind, m->qorder)) return -2;
+    int nd = 3 * cv.nb;
+    int64_t ndofs = 0;
+    for (int64_t i = 0; i < m->n_cells * nd; ++i) if (m->cell_dofs[i] + 1 > ndofs) ndofs = m->cell_dofs[i] + 1;
+    if (nzval) memset(nzval, 0, sizeof(double) * rowptr[ndofs]);
+    if (r) memset(r, 0, sizeof(double) * ndofs);
+    int err = 0;
+    int npass = (nthreads > 1 && color) ? ncolors : 1;
+#ifdef _OPENMP
+    if (nthreads > 1) omp_set_num_threads(nthreads);
+#endif
+    for (int pass = 0; pass < npass; ++pass) {
+#pragma omp parallel for schedule(dynamic, 16) reduction(|| : err) if (nthreads > 1 && color)
+        for (int64_t cell = 0; cell < m->n_cells; ++cell) {
+            if (npass > 1 && color[cell] != pass) continue;
+            double *Ke = nzval ? (double *)calloc((size_t)nd * nd, sizeof(double)) : NULL;
+            double re[81], ue[81];
+            memset(re, 0, sizeof re);
+            const int32_t *dofs = m->cell_dofs + cell * nd;
+            for (int i = 0; i < nd; ++i) ue[i] = u[dofs[i]]; /* load_element_unknowns!, elements.jl:125-132 */
+            int rc = element_hyperelastic_cv(m, &cv, cell, p, fsn, ue, Ke, r ? re : NULL);
+            if (!rc && nzval) rc = scatter_matrix(nd, dofs, Ke, rowptr, colidx, nzval);
+            if (!rc && r) for (int i = 0; i < nd; ++i) r[dofs[i]] += re[i];
+            free(Ke);
+            err = err || (rc != 0);
+        }
+    }
+    return err ? -1 : 0;
+}

@@ -144,3 +144,28 @@ void orc_spmv_csr(int64_t nrows, const int64_t *rowptr, const int32_t *colidx, c
 }
 #endif
 #endif
+
+/* ---- quasi-static hyperelasticity (appended) ---- */
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* material parameters of HolzapfelOgden2009Model + SimpleCompressionPenalty, src/modeling/solid/energies.jl:136-146,80-87:
+ * p = a, b, af, bf, as, bs, afs, bfs, beta */
+/* Ψ(F), P = ∂Ψ/∂F, A = ∂²Ψ/∂F² by forward-mode (hyper-dual) differentiation of the energy, exactly what
+ * Tensors.gradient / Tensors.hessian do in src/modeling/solid/materials.jl:1025-1040.
+ * F, P row-major 3×3 (F[i][j] = ∂x_i/∂X_j); A[9*(3i+j) + 3k+l] = ∂P_ij/∂F_kl; fsn = f,s,n (3 each). */
+double orc_ho_energy(const double *p, const double *fsn, const double *F, double *P, double *A);
+/* src/modeling/solid/elements.jl:177-225 (K + r), :227-273 (K), :275-313 (r): cell of a HEX8 (order 1) or HEX27
+ * (order 2, trilinear geometry) vector field, ue = element unknowns (node-major, component-minor).
+ * Ke (ndofs×ndofs) and/or re (ndofs) may be NULL; both are ACCUMULATED into. */
+int orc_element_hyperelastic(const orc_mesh *m, int64_t cell, const double *p, const double *fsn,
+                             const double *ue, double *Ke, double *re);
+/* update_linearization!(op, residual, u, p) / residual!(op, residual, u, p) call sites
+ * src/solver/nonlinear/newton_raphson.jl:234-238: zero-fill, cell loop, load_element_unknowns!
+ * (elements.jl:125-132), element kernel, assemble!.  nzval and/or r may be NULL. */
+int orc_assemble_hyperelastic(const orc_mesh *m, const double *p, const double *fsn, const double *u,
+                              const int64_t *rowptr, const int32_t *colidx, double *nzval, double *r, int nthreads,
+                              const int32_t *color, int ncolors);
+#ifdef __cplusplus
+}
+#endif
