@@ -62,7 +62,8 @@ enum {
 enum {
     TB_FORM_MASS = 0,      /* Mₑ[i,j] += ρ NᵢNⱼ dΩ          src/modeling/core/mass.jl:28-43       */
     TB_FORM_DIFFUSION = 1, /* Kₑ[i,j] -= ∇Nⱼ·D·∇Nᵢ dΩ       src/modeling/core/diffusion.jl:28-50  */
-    TB_FORM_SOURCE = 2     /* bₑ[j]  += f(x_q,t) Nⱼ dΩ      src/modeling/core/analytical_coefficient.jl:80-101 */
+    TB_FORM_SOURCE = 2,    /* bₑ[j]  += f(x_q,t) Nⱼ dΩ      src/modeling/core/analytical_coefficient.jl:80-101 */
+    TB_FORM_HYPERELASTIC = 3 /* rₑ[i] += ∇δuᵢ⊡P dΩ, Kₑ[i,j] += (∇δuᵢ⊡𝔸)⊡∇δuⱼ dΩ   src/modeling/solid/elements.jl:177-313 */
 };
 
 /* coefficients (src/modeling/core/coefficients.jl, src/modeling/microstructure.jl).  Julia closures cannot
@@ -91,6 +92,15 @@ typedef struct tb_coef {
     const double *field; /* HOST pointer, copied at tb_form_create; may be NULL */
     int64_t field_len;   /* number of doubles behind `field` */
 } tb_coef;
+
+/* constitutive models for the quasi-static path: PK1Model(material, microstructure) (src/modeling/solid/materials.jl:442-453) */
+enum { TB_MATERIAL_HOLZAPFEL_OGDEN_2009 = 0 /* + SimpleCompressionPenalty, src/modeling/solid/energies.jl:136-168,80-87 */ };
+typedef struct tb_material {
+    int32_t kind;
+    int32_t reserved;
+    double p[16];               /* HO2009: a, b, aᶠ, bᶠ, aˢ, bˢ, aᶠˢ, bᶠˢ, β (struct field order) */
+    double f[3], s[3], n[3];    /* ConstantCoefficient(OrthotropicMicrostructure(f, s, n)) */
+} tb_material;
 
 /* ionic models (src/modeling/cells/{fhn,aliev-panfilov,pcg2019}.jl) and state layouts (src/modeling/solution_variables.jl:40-68) */
 enum { TB_CELL_FHN = 0, TB_CELL_ALIEV_PANFILOV = 1, TB_CELL_PCG2019 = 2 };
@@ -167,6 +177,20 @@ int tb_assemble_matrix(tb_form *form, tb_pattern *pat, int strategy, double t, d
 /* update_operator!(op, t) for linear operators → fills op.b (src/solver/time/euler.jl:119,176;
  * test/gpu/test_operators.jl:24-30) */
 int tb_assemble_vector(tb_form *form, int strategy, double t, double *d_b);
+
+/* ------------------------------------------------------------------ quasi-static hyperelasticity (vector field, ncomp = 3)
+ * setup_element_cache(QuasiStaticModel(:u, PK1Model(...), ()), qr, sdh) (test/test_elements.jl:99-125);
+ * operator creation via setup_operator(strategy, volume_integrator, dh) (src/solver/time/homotopy.jl:61-67).
+ * qorder 0 → max(2p−1, 2) (src/discretization/fem.jl:52-55): 2 for Q1, 3 for Q2. */
+int tb_hyperelastic_create(tb_mesh *mesh, int qorder, const tb_material *material, tb_form **out);
+/* residual!(op, residual, u, p) (src/solver/nonlinear/newton_raphson.jl:234): d_r overwritten */
+int tb_residual(tb_form *form, int strategy, const double *d_u, double t, double *d_r);
+/* update_linearization!(op, residual, u, p) / update_linearization!(op, u, p) (newton_raphson.jl:238,
+ * src/solver/time/newmark.jl:112-137): fills J's nzval, and the residual when d_r != NULL.  Dirichlet
+ * elimination is NOT part of it (applied afterwards on the host: src/solver/nonlinear/nlsolve_common.jl:12-26). */
+int tb_linearize(tb_form *form, tb_pattern *pat, int strategy, const double *d_u, double t, double *d_nzval, double *d_r);
+/* host evaluation of the device material routine (Ψ, P = ∂Ψ/∂F, 𝔸 = ∂²Ψ/∂F²; row-major F[3i+j], A[9(3i+j)+3k+l]) */
+int tb_host_material_eval(const tb_material *material, const double *F, double *psi, double *P, double *A);
 
 /* ------------------------------------------------------------------ pointwise reaction step
  * _pointwise_step_outer_kernel!(f, t, Δt, cache, ::DeviceVector) (src/solver/time/partitioned_solver.jl:38-52,

@@ -359,3 +359,60 @@ def test_reaction_full_size_roundtrip(tb, oracle, device):
         oracle.reaction_step(oracle.CELL_PCG2019, model.params, ref, 1024, oracle.LAYOUT_SOA, t=0.01 * step, dt=0.01)
     assert rel_err(out[:, :1024].ravel(), ref) < TOL
     assert np.isfinite(out).all()
+
+
+# ------------------------------------------------------------------------------------------- quasi-static mechanics
+def mech_problem(tb, oracle, nel, order, perturb=0.15):
+    g = tb.generate_mesh(tb.Hexahedron, nel, (0, 0, 0), (1.0, 0.7, 0.5), perturb=perturb)
+    dh = tb.DofHandler(g, tb.LagrangeCollection(order) ** 3)
+    sp = tb.allocate_matrix(dh)
+    okind, q = (oracle.HEX8, 2) if order == 1 else (oracle.HEX27, 3)
+    om = oracle.Mesh(okind, q, g.xyz, g.conn, dh.cell_dofs)
+    return g, dh, sp, om
+
+
+@pytest.mark.parametrize("order,nel", [(1, (4, 3, 3)), (2, (3, 2, 2))])
+def test_hyperelastic_residual_and_tangent_parity(tb, oracle, device, order, nel):
+    """update_linearization! / residual! against the AD oracle (elements.jl:177-313); 1e-10 rel per north_star."""
+    g, dh, sp, om = mech_problem(tb, oracle, nel, order)
+    f, s, n = np.array([1, 1, 0.0]) / np.sqrt(2), np.array([-1, 1, 0.0]) / np.sqrt(2), np.array([0, 0, 1.0])
+    model = tb.QuasiStaticModel("u", tb.PK1Model(tb.HolzapfelOgden2009Model(), tb.ConstantCoefficient(tb.OrthotropicMicrostructure(f, s, n))))
+    rng = np.random.default_rng(0)
+    u = rng.uniform(-1e-2, 1e-2, dh.ndofs)            # SURVEY §8d value distribution
+    Kref, rref = oracle.assemble_hyperelastic(om, u, sp.rowptr, sp.colidx, fsn=np.stack([f, s, n]))
+    du = device.to_device(u)
+    for st in (tb.AtomicAssemblyStrategy(device), tb.PerColorAssemblyStrategy(device)):
+        op = tb.setup_operator(st, model, dh, sp)
+        res = device.zeros(dh.ndofs)
+        tb.update_linearization(op, du, 0.0, residual=res)
+        assert rel_err(op.J.to_host(), Kref) < 1e-11, (order, type(st).__name__, rel_err(op.J.to_host(), Kref))
+        assert rel_err(res.to_host(), rref) < 1e-11
+        # the three call variants agree (test/test_elements.jl:113-125)
+        res2 = device.zeros(dh.ndofs)
+        tb.residual(op, res2, du, 0.0)
+        assert rel_err(res2.to_host(), rref) < 1e-11
+        Jfirst = op.J.to_host()
+        tb.update_linearization(op, du, 0.0)          # K only; output overwritten, not accumulated
+        assert rel_err(op.J.to_host(), Jfirst) < 1e-13
+    # u = 0: zero residual, symmetric tangent with rigid translations in its kernel
+    z = device.zeros(dh.ndofs)
+    res = device.zeros(dh.ndofs)
+    op = tb.setup_operator(tb.AtomicAssemblyStrategy(device), model, dh, sp)
+    tb.update_linearization(op, z, 0.0, residual=res)
+    assert np.abs(res.to_host()).max() < 1e-14
+    t = np.tile([0.3, -0.2, 0.5], dh.ndofs // 3)
+    y = oracle.spmv_csr(sp.rowptr, sp.colidx, op.J.to_host(), t)
+    assert np.abs(y).max() < 1e-10 * np.abs(op.J.to_host()).max()
+
+
+def test_hyperelastic_negative_jacobian_and_bad_field(tb, device):
+    g = tb.generate_mesh(tb.Hexahedron, (2, 2, 2))
+    bad = tb.Grid(tb.Hexahedron, g.xyz, g.conn[:, [0, 3, 2, 1, 4, 7, 6, 5]])
+    dh = tb.DofHandler(bad, tb.LagrangeCollection(1) ** 3)
+    model = tb.QuasiStaticModel("u", tb.PK1Model(tb.HolzapfelOgden2009Model(), tb.ConstantCoefficient(tb.OrthotropicMicrostructure([1, 0, 0], [0, 1, 0], [0, 0, 1]))))
+    op = tb.setup_operator(tb.AtomicAssemblyStrategy(device), model, dh)
+    with pytest.raises(tb.TBError) as e:
+        tb.update_linearization(op, device.zeros(dh.ndofs))
+    assert e.value.code == tb._lib.TB_ERR_NEG_DETJ
+    with pytest.raises(tb.TBError):  # scalar field cannot carry the mechanics form
+        tb.setup_operator(tb.AtomicAssemblyStrategy(device), model, tb.DofHandler(g))

@@ -1,0 +1,90 @@
+"""CPU checks for the quasi-static hyperelastic path: the oracle's hyper-dual differentiation of Ψ (what
+Tensors.hessian does, materials.jl:1025-1040) against the reference's own assertions (Ψ(I)=0, P(I)=0,
+test/test_type_stability.jl:29-63; the three assemble_element! variants agree, test/test_elements.jl:99-150)
+and the shipped hand-derived device routine (compiled for the host) against that oracle."""
+import numpy as np
+import pytest
+
+FSN = np.stack([np.array([1, 1, 0.0]) / np.sqrt(2), np.array([-1, 1, 0.0]) / np.sqrt(2), np.array([0, 0, 1.0])])
+
+
+def test_energy_identities(oracle):
+    psi, P, A = oracle.ho_energy(np.eye(3))
+    assert psi == 0.0 and np.abs(P).max() == 0.0                 # Ψ(I) = 0, P(I) = 0
+    np.testing.assert_allclose(A, A.T, atol=1e-13)               # major symmetry of ∂²Ψ/∂F²
+    rng = np.random.default_rng(0)
+    F = np.eye(3) + 0.1 * rng.normal(size=(3, 3))
+    psi, P, A = oracle.ho_energy(F, fsn=FSN)
+    h = 1e-6
+    for i in range(3):
+        for j in range(3):
+            Fp, Fm = F.copy(), F.copy()
+            Fp[i, j] += h; Fm[i, j] -= h
+            assert abs((oracle.ho_energy(Fp, fsn=FSN)[0] - oracle.ho_energy(Fm, fsn=FSN)[0]) / (2 * h) - P[i, j]) < 1e-8 * np.abs(P).max()
+            dP = (oracle.ho_energy(Fp, fsn=FSN)[1] - oracle.ho_energy(Fm, fsn=FSN)[1]) / (2 * h)
+            np.testing.assert_allclose(A[:, 3 * i + j], dP.ravel(), atol=1e-7 * np.abs(A).max())
+    # frame indifference of Ψ: Ψ(QF) = Ψ(F)
+    th = 0.7
+    Q = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1.0]])
+    np.testing.assert_allclose(oracle.ho_energy(Q @ F, fsn=FSN)[0], psi, rtol=1e-13)
+
+
+@pytest.mark.parametrize("stretch", [0.8, 1.0, 1.25])
+def test_device_material_routine_matches_ad_oracle(tb, oracle, stretch):
+    """I₄ ≥ 1 switches (energies.jl:160-165): compression along f (off), identity (boundary), tension (on)."""
+    fsn = np.eye(3) if stretch == 1.0 else FSN   # exact unit frame for the I₄ == 1 boundary case
+    model = tb.PK1Model(tb.HolzapfelOgden2009Model(), tb.ConstantCoefficient(tb.OrthotropicMicrostructure(*fsn)))
+    rng = np.random.default_rng(3)
+    R = np.stack(fsn).T                      # columns f, s, n
+    F = R @ np.diag([stretch, 1.0 / np.sqrt(stretch), 1.0 / np.sqrt(stretch)]) @ R.T
+    F = np.eye(3) if stretch == 1.0 else F + 0.02 * rng.normal(size=(3, 3))   # I₄ == 1 exactly: branch is taken (>=)
+    psi, P, A = tb.material_routine(model, F)
+    psi0, P0, A0 = oracle.ho_energy(F, fsn=fsn)
+    I4f = np.linalg.norm(F @ fsn[0]) ** 2
+    assert (I4f >= 1.0) == (stretch >= 1.0)
+    np.testing.assert_allclose(psi, psi0, rtol=1e-12, atol=1e-16)
+    np.testing.assert_allclose(P, P0, rtol=0, atol=1e-12 * max(np.abs(P0).max(), 1e-3))
+    np.testing.assert_allclose(A, A0, rtol=0, atol=1e-12 * np.abs(A0).max())
+
+
+def test_element_variants_agree_and_composite(oracle):
+    """test/test_elements.jl:99-150: K+r, r-only and K-only calls agree; uₑ = ±1e-4 pattern of :52-78."""
+    xyz, conn = oracle.generate_grid_hex(1, 1, 1)
+    for kind, order, q in ((oracle.HEX8, 1, 2), (oracle.HEX27, 2, 3)):
+        cd, nd = oracle.close_dofs(kind, 3, conn, len(xyz))
+        m = oracle.Mesh(kind, q, xyz, conn, cd)
+        nb = nd // 3
+        rng = np.random.default_rng(order)
+        ue = 1e-4 * np.sign(rng.normal(size=nd))
+        K1, r1 = oracle.element_hyperelastic(m, 0, ue)
+        K2, _ = oracle.element_hyperelastic(m, 0, ue, want_r=False)
+        _, r2 = oracle.element_hyperelastic(m, 0, ue, want_K=False)
+        assert np.abs(K1).max() > 0 and np.abs(r1).max() > 0
+        np.testing.assert_array_equal(K1, K2)
+        np.testing.assert_array_equal(r1, r2)
+        np.testing.assert_allclose(K1, K1.T, atol=1e-12 * np.abs(K1).max())
+        # rigid translation is in the kernel of the tangent; the residual of u = 0 vanishes
+        t = np.tile([0.3, -0.2, 0.5], nb)
+        np.testing.assert_allclose(K1 @ t, 0, atol=1e-11 * np.abs(K1).max())
+        _, r0 = oracle.element_hyperelastic(m, 0, np.zeros(nd), want_K=False)
+        np.testing.assert_allclose(r0, 0, atol=1e-16)
+        # tangent = derivative of the residual
+        h = 1e-7
+        for i in (0, nd // 2, nd - 1):
+            up, um = ue.copy(), ue.copy()
+            up[i] += h; um[i] -= h
+            fd = (oracle.element_hyperelastic(m, 0, up, want_K=False)[1] - oracle.element_hyperelastic(m, 0, um, want_K=False)[1]) / (2 * h)
+            np.testing.assert_allclose(K1[:, i], fd, atol=1e-6 * np.abs(K1).max())
+
+
+def test_threaded_hyperelastic_assembly(oracle):
+    xyz, conn = oracle.generate_grid_hex(3, 2, 2, (0, 0, 0), (1, 1, 1))
+    cd, nd = oracle.close_dofs(oracle.HEX8, 3, conn, len(xyz))
+    rp, ci = oracle.build_pattern(cd, nd)
+    m = oracle.Mesh(oracle.HEX8, 2, xyz, conn, cd)
+    u = 1e-2 * np.random.default_rng(0).uniform(-1, 1, nd)
+    K, r = oracle.assemble_hyperelastic(m, u, rp, ci)
+    col, nc = oracle.color_cells(cd, nd)
+    K2, r2 = oracle.assemble_hyperelastic(m, u, rp, ci, nthreads=4, color=col, ncolors=nc)
+    np.testing.assert_allclose(K2, K, rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(r2, r, rtol=1e-12, atol=1e-16)

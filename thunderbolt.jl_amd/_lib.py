@@ -12,7 +12,8 @@ TB_OK = 0
 TB_ERR_BAD_ARG, TB_ERR_HIP, TB_ERR_NEG_DETJ, TB_ERR_PATTERN, TB_ERR_UNSUPPORTED, TB_ERR_NOMEM = -1, -2, -3, -4, -5, -6
 TB_HEX8, TB_TET4, TB_HEX27 = 3, 4, 5
 TB_STRATEGY_ATOMIC, TB_STRATEGY_PER_COLOR, TB_STRATEGY_ELEMENT, TB_STRATEGY_PATCH = 0, 1, 2, 3
-TB_FORM_MASS, TB_FORM_DIFFUSION, TB_FORM_SOURCE = 0, 1, 2
+TB_FORM_MASS, TB_FORM_DIFFUSION, TB_FORM_SOURCE, TB_FORM_HYPERELASTIC = 0, 1, 2, 3
+TB_MATERIAL_HOLZAPFEL_OGDEN_2009 = 0
 TB_COEF_CONST_SCALAR, TB_COEF_CONST_TENSOR, TB_COEF_FIELD_SCALAR = 0, 1, 2
 TB_COEF_SPECTRAL_CONST, TB_COEF_SPECTRAL_FIELD, TB_COEF_TRANSVERSE_CONST = 3, 4, 5
 TB_SRC_CONST, TB_SRC_NORM_PLUS_T, TB_SRC_COS_EXP, TB_SRC_TABULATED = 0, 1, 2, 3
@@ -28,6 +29,11 @@ vp = C.c_void_p
 class tb_coef(C.Structure):
     _fields_ = [("kind", C.c_int32), ("wrap", C.c_int32), ("Cm", C.c_double), ("chi", C.c_double),
                 ("p", C.c_double * 16), ("field", c_dp), ("field_len", C.c_int64)]
+
+
+class tb_material(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("p", C.c_double * 16), ("f", C.c_double * 3),
+                ("s", C.c_double * 3), ("n", C.c_double * 3)]
 
 
 # name -> (restype, argtypes): every symbol include/tbhip.h declares
@@ -64,6 +70,10 @@ SIGNATURES = {
     "tb_form_set_table": (C.c_int, [vp, c_dp, C.c_int64]),
     "tb_assemble_matrix": (C.c_int, [vp, vp, C.c_int, C.c_double, vp]),
     "tb_assemble_vector": (C.c_int, [vp, C.c_int, C.c_double, vp]),
+    "tb_hyperelastic_create": (C.c_int, [vp, C.c_int, C.POINTER(tb_material), C.POINTER(vp)]),
+    "tb_residual": (C.c_int, [vp, C.c_int, vp, C.c_double, vp]),
+    "tb_linearize": (C.c_int, [vp, vp, C.c_int, vp, C.c_double, vp, vp]),
+    "tb_host_material_eval": (C.c_int, [C.POINTER(tb_material), c_dp, c_dp, c_dp, c_dp]),
     "tb_reaction_step": (C.c_int, [vp, C.c_int, c_dp, C.c_int, vp, vp, C.c_int64, C.c_int, C.c_int, C.c_double,
                                    C.c_double, C.c_int, C.c_double]),
     "tb_cell_model_info": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -533,6 +533,8 @@ def setup_operator(strategy, integrator, dh, pattern=None):
     """setup_operator(strategy, integrator, [solver,] dh) (src/solver/interface.jl:17-94)."""
     if isinstance(integrator, LinearIntegrator):
         return LinearOperator(strategy, integrator, dh)
+    if isinstance(integrator, QuasiStaticModel):
+        return NonlinearOperator(strategy, integrator, dh, pattern or allocate_matrix(dh))
     if pattern is None:
         pattern = allocate_matrix(dh)
     return BilinearOperator(strategy, integrator, dh, pattern)
@@ -698,3 +700,81 @@ def reaction_rate_max(device, f, cache):
         base = cache.du.data_ptr() + 8 * m.phi_index
         check(lib().tb_absmax(device.h, f.npoints, C.c_void_p(base), m.nstates, C.byref(out)))
     return out.value
+
+
+# --------------------------------------------------------------------------------------- quasi-static mechanics
+class HolzapfelOgden2009Model:
+    """HolzapfelOgden2009Model(; a, b, aᶠ, bᶠ, aˢ, bˢ, aᶠˢ, bᶠˢ, mpU = SimpleCompressionPenalty(β)) (energies.jl:136-168)."""
+    names = ["a", "b", "af", "bf", "as_", "bs", "afs", "bfs", "beta"]
+
+    def __init__(self, a=0.059, b=8.023, af=18.472, bf=16.026, as_=2.581, bs=11.120, afs=0.216, bfs=11.436, beta=1.0):
+        self.p = np.array([a, b, af, bf, as_, bs, afs, bfs, beta], dtype=np.float64)
+
+
+class PK1Model:
+    """PK1Model(material, coefficient_field) with a constant OrthotropicMicrostructure (materials.jl:442-453)."""
+
+    def __init__(self, material, microstructure):
+        ms = microstructure.val if isinstance(microstructure, ConstantCoefficient) else microstructure
+        if not isinstance(ms, OrthotropicMicrostructure):
+            raise TypeError("PK1Model: constant OrthotropicMicrostructure expected")
+        self.material, self.microstructure = material, ms
+
+    def lower(self):
+        m = L.tb_material()
+        m.kind = L.TB_MATERIAL_HOLZAPFEL_OGDEN_2009
+        for i, v in enumerate(self.material.p):
+            m.p[i] = v
+        for i in range(3):
+            m.f[i], m.s[i], m.n[i] = self.microstructure.f[i], self.microstructure.s[i], self.microstructure.n[i]
+        return m
+
+
+class QuasiStaticModel:
+    """QuasiStaticModel(:u, constitutive_model, ()) (test/test_elements.jl:99-125)."""
+
+    def __init__(self, sym, constitutive_model, facet_models=()):
+        self.sym, self.constitutive_model = sym, constitutive_model
+
+
+def material_routine(model, F):
+    """Host evaluation of the device material routine: (Ψ, P, 𝔸) with 𝔸[3i+j, 3k+l] = ∂P_ij/∂F_kl."""
+    m = model.lower()
+    F = np.ascontiguousarray(F, dtype=np.float64)
+    psi = C.c_double()
+    P = np.zeros((3, 3))
+    A = np.zeros((9, 9))
+    check(lib().tb_host_material_eval(C.byref(m), F.ctypes.data_as(L.c_dp), C.byref(psi), P.ctypes.data_as(L.c_dp), A.ctypes.data_as(L.c_dp)))
+    return psi.value, P, A
+
+
+class NonlinearOperator:
+    """Operator of a quasi-static problem: `.J` (CSR nzval on device), residual vectors supplied by the caller."""
+
+    def __init__(self, strategy, model, dh, pattern, qorder=0):
+        self.strategy, self.dh = strategy, dh
+        self.dmesh = dh.device_mesh(strategy.device)
+        self.pattern = self.dmesh.pattern(pattern)
+        self._mat = model.constitutive_model.lower()
+        self.form = C.c_void_p()
+        check(lib().tb_hyperelastic_create(self.dmesh.h, qorder, C.byref(self._mat), C.byref(self.form)))
+        self.J = DeviceVector(strategy.device, pattern.nnz)
+
+    def __del__(self):
+        try:
+            if self.form:
+                lib().tb_form_destroy(self.form)
+        except Exception:
+            pass
+
+
+def update_linearization(op, u, t=0.0, residual=None):
+    """update_linearization!(op, residual, u, p) / update_linearization!(op, u, p) (newton_raphson.jl:238)."""
+    check(lib().tb_linearize(op.form, op.pattern.h, op.strategy.code, _ptr(u), float(t), op.J.ptr, _ptr(residual)))
+    return op
+
+
+def residual(op, residual, u, t=0.0):
+    """residual!(op, residual, u, p) (newton_raphson.jl:234)."""
+    check(lib().tb_residual(op.form, op.strategy.code, _ptr(u), float(t), _ptr(residual)))
+    return residual

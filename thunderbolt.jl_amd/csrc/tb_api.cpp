@@ -301,7 +301,7 @@ int tb_pattern_create(tb_mesh *mesh, int64_t n_rows, const int64_t *rowptr, cons
 int tb_pattern_destroy(tb_pattern *p)
 {
     if (!p) return TB_OK;
-    hipFree(p->d_rowptr); hipFree(p->d_colidx); hipFree(p->d_emap);
+    hipFree(p->d_rowptr); hipFree(p->d_colidx); hipFree(p->d_emap); hipFree(p->d_blockpos);
     if (p->patch_mat) { hipFree(p->patch_mat->d_row_desc); hipFree(p->patch_mat->d_elem_rowoff); hipFree(p->patch_mat->d_colpos8); hipFree(p->patch_mat->d_colpos16); }
     delete p;
     return TB_OK;
@@ -402,6 +402,51 @@ int tb_assemble_vector(tb_form *form, int strategy, double t, double *d_b)
     TB_REQUIRE(form->coef.kind != TB_SRC_TABULATED || form->d_table, "tb_assemble_vector: tabulated source without table");
     TB_HIP(hipSetDevice(form->mesh->dev->id));
     return launch_assemble_vector(form, strategy, t, d_b);
+}
+
+// ------------------------------------------------------------------ quasi-static hyperelasticity
+int tb_hyperelastic_create(tb_mesh *mesh, int qorder, const tb_material *material, tb_form **out)
+{
+    TB_REQUIRE(mesh && material && out, "tb_hyperelastic_create: NULL argument");
+    *out = nullptr;
+    TB_REQUIRE(material->kind == TB_MATERIAL_HOLZAPFEL_OGDEN_2009, "tb_hyperelastic_create: unknown material kind %d", material->kind);
+    TB_REQUIRE(mesh->ncomp == 3 && mesh->geom_kind == TB_HEX8, "tb_hyperelastic_create: needs a 3-component field on hexahedra");
+    // the kernels address a node's three dofs as consecutive ids (Ferrite: node-major, component-minor, io.jl:233-238)
+    for (int64_t i = 0; i < mesh->n_cells * mesh->nb; ++i) {
+        const int32_t *d = &mesh->h_cell_dofs[3 * i];
+        TB_REQUIRE(d[1] == d[0] + 1 && d[2] == d[0] + 2, "tb_hyperelastic_create: dofs of a node are not consecutive (cell %lld)", (long long)(i / mesh->nb));
+    }
+    if (qorder == 0) qorder = std::max(2 * kind_order(mesh->field_kind) - 1, 2);
+    auto f = std::make_unique<tb_form>();
+    f->mesh = mesh; f->kind = TB_FORM_HYPERELASTIC; f->qorder = qorder; f->mat = *material;
+    *out = f.release();
+    return TB_OK;
+}
+
+int tb_residual(tb_form *form, int strategy, const double *d_u, double t, double *d_r)
+{
+    (void)t;
+    TB_REQUIRE(form && d_u && d_r, "tb_residual: NULL argument");
+    TB_REQUIRE(form->kind == TB_FORM_HYPERELASTIC, "tb_residual: form is not nonlinear");
+    TB_HIP(hipSetDevice(form->mesh->dev->id));
+    return launch_hyperelastic(form, nullptr, strategy, d_u, nullptr, d_r);
+}
+
+int tb_linearize(tb_form *form, tb_pattern *pat, int strategy, const double *d_u, double t, double *d_nzval, double *d_r)
+{
+    (void)t;
+    TB_REQUIRE(form && pat && d_u && d_nzval, "tb_linearize: NULL argument");
+    TB_REQUIRE(form->kind == TB_FORM_HYPERELASTIC, "tb_linearize: form is not nonlinear");
+    TB_REQUIRE(form->mesh == pat->mesh, "tb_linearize: form and pattern belong to different meshes");
+    TB_HIP(hipSetDevice(form->mesh->dev->id));
+    return launch_hyperelastic(form, pat, strategy, d_u, d_nzval, d_r);
+}
+
+int tb_host_material_eval(const tb_material *material, const double *F, double *psi, double *P, double *A)
+{
+    TB_REQUIRE(material && F, "tb_host_material_eval: NULL argument");
+    TB_REQUIRE(material->kind == TB_MATERIAL_HOLZAPFEL_OGDEN_2009, "tb_host_material_eval: unknown material kind %d", material->kind);
+    return host_material_eval(material, F, psi, P, A);
 }
 
 // ------------------------------------------------------------------ reaction

@@ -128,6 +128,7 @@ struct tb_pattern {
     std::vector<int32_t> h_colidx;
     bool map64 = false;
     void *d_emap = nullptr; // [ndpc*ndpc][n_cells] nz index of (cell,i,j): int32 (nnz < 2^31) or int64
+    uint16_t *d_blockpos = nullptr; // vector fields: per cell and node pair, position of the 3×3 block inside its row
     std::unique_ptr<tb::PatchMatPlan> patch_mat;
 };
 
@@ -140,6 +141,7 @@ struct tb_form {
     double *d_field = nullptr;
     double *d_table = nullptr;
     int64_t table_len = 0;
+    tb_material mat{};
 };
 
 namespace tb {
@@ -154,6 +156,8 @@ int build_patch_mat_plan(tb_pattern *p);
 int ensure_emap(tb_pattern *p);
 int launch_assemble_matrix(tb_form *f, tb_pattern *p, int strategy, double t, double *d_nz);
 int launch_assemble_vector(tb_form *f, int strategy, double t, double *d_b);
+int launch_hyperelastic(tb_form *f, tb_pattern *p, int strategy, const double *d_u, double *d_nz, double *d_r);
+int host_material_eval(const tb_material *mat, const double *F9, double *psi, double *P, double *A);
 int launch_reaction(tb_device *dev, int model, const double *params, int n_params, double *d_u, double *d_du,
                     int64_t n_points, int layout, double t, double dt, int substeps, double thr);
 int launch_heat_matrix(tb_device *dev, int64_t nnz, const double *M, const double *K, double dt, double *A);

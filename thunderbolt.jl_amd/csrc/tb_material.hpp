@@ -1,0 +1,117 @@
+// tb_material.hpp — hand-derived first Piola–Kirchhoff stress P = ∂Ψ/∂F and tangent 𝔸 = ∂²Ψ/∂F² of the
+// Holzapfel–Ogden 2009 energy with SimpleCompressionPenalty.
+//
+// The reference obtains both by forward-mode AD of Ψ(F) (Tensors.gradient / Tensors.hessian,
+// src/modeling/solid/materials.jl:1025-1040) with Ψ from src/modeling/solid/energies.jl:147-168 and
+// U(I₃) = β(I₃ − 1 − 2 log √I₃) from :83-87.  AD types do not exist in device C++, so the derivatives are
+// written out; parity with the AD result is checked against the hyper-dual oracle.
+//
+// Notation: F_ij = ∂x_i/∂X_j, J = det F, C = FᵀF, g = I₃^{-1/3} = J^{-2/3}, Ī₁ = g·tr C,
+//   a = F f₀, b = F s₀, I₄ᶠ = a·a, I₄ˢ = b·b, I₈ = a·b.
+//   ∂J/∂F_ij = J F⁻¹_ji,  ∂F⁻¹_ji/∂F_kl = −F⁻¹_jk F⁻¹_li.
+//   B_ij   = ∂Ī₁/∂F_ij = g (2F_ij − ⅔ tr C · F⁻¹_ji)
+//   ∂²Ī₁   = −⅔ F⁻¹_lk B_ij + g [2 δ_ik δ_jl − 4/3 F_kl F⁻¹_ji + ⅔ tr C · F⁻¹_jk F⁻¹_li]
+//   Ψ₁ = a/(2b)(e^{b(Ī₁−3)} − 1):   P += ½a E₁ B,          𝔸 += ½a E₁ (b B⊗B + ∂²Ī₁)
+//   Ψ₄ = aᶠ/(2bᶠ)(e^{bᶠ(I₄−1)²} − 1) if I₄ ≥ 1:  w₁ = aᶠ(I₄−1)E₄, w₂ = aᶠE₄(1 + 2bᶠ(I₄−1)²)
+//        P += w₁·2 a⊗f₀,   𝔸_ijkl += 4 w₂ a_i f_j a_k f_l + 2 w₁ δ_ik f_j f_l        (same for s₀)
+//   Ψ₈ = aᶠˢ/(2bᶠˢ)(e^{bᶠˢ I₈²} − 1):  M = b⊗f₀ + a⊗s₀, v₁ = aᶠˢ I₈ E₈, v₂ = aᶠˢ E₈ (1 + 2bᶠˢ I₈²)
+//        P += v₁ M,         𝔸_ijkl += v₂ M_ij M_kl + v₁ δ_ik (s_j f_l + f_j s_l)
+//   U  = β(J² − 1 − 2 ln J):  P += 2β(J²−1) F⁻ᵀ,  𝔸_ijkl += 4βJ² F⁻¹_ji F⁻¹_lk − 2β(J²−1) F⁻¹_jk F⁻¹_li
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+namespace tbk {
+
+#ifndef TB_HD
+#define TB_HD __host__ __device__ __forceinline__
+#endif
+
+struct HOParams {
+    double a, b, af, bf, as, bs, afs, bfs, beta; // struct field order of HolzapfelOgden2009Model, energies.jl:136-146
+    double f[3], s[3], n[3];                     // microstructure frame (ConstantCoefficient(OrthotropicMicrostructure))
+};
+
+// returns Ψ; P[3i+j], A[9(3i+j) + 3k+l] (A only when NEED_A)
+template <bool NEED_A>
+TB_HD double ho_stress_tangent(const HOParams &m, const double (&F)[3][3], double (&P)[9], double *A)
+{
+    // J, F⁻¹
+    const double c00 = F[1][1] * F[2][2] - F[1][2] * F[2][1];
+    const double c01 = F[1][2] * F[2][0] - F[1][0] * F[2][2];
+    const double c02 = F[1][0] * F[2][1] - F[1][1] * F[2][0];
+    const double J = F[0][0] * c00 + F[0][1] * c01 + F[0][2] * c02;
+    const double iJ = 1.0 / J;
+    double Fi[3][3];
+    Fi[0][0] = c00 * iJ; Fi[0][1] = (F[0][2] * F[2][1] - F[0][1] * F[2][2]) * iJ; Fi[0][2] = (F[0][1] * F[1][2] - F[0][2] * F[1][1]) * iJ;
+    Fi[1][0] = c01 * iJ; Fi[1][1] = (F[0][0] * F[2][2] - F[0][2] * F[2][0]) * iJ; Fi[1][2] = (F[0][2] * F[1][0] - F[0][0] * F[1][2]) * iJ;
+    Fi[2][0] = c02 * iJ; Fi[2][1] = (F[0][1] * F[2][0] - F[0][0] * F[2][1]) * iJ; Fi[2][2] = (F[0][0] * F[1][1] - F[0][1] * F[1][0]) * iJ;
+    const double J2 = J * J;
+    double trC = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) trC += F[i][j] * F[i][j];
+    const double g = 1.0 / cbrt(J2);
+    const double I1b = trC * g;
+    // fibre kinematics
+    double av[3], bv[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        av[i] = F[i][0] * m.f[0] + F[i][1] * m.f[1] + F[i][2] * m.f[2];
+        bv[i] = F[i][0] * m.s[0] + F[i][1] * m.s[1] + F[i][2] * m.s[2];
+    }
+    const double I4f = av[0] * av[0] + av[1] * av[1] + av[2] * av[2];
+    const double I4s = bv[0] * bv[0] + bv[1] * bv[1] + bv[2] * bv[2];
+    const double I8 = av[0] * bv[0] + av[1] * bv[1] + av[2] * bv[2];
+
+    const double E1 = exp(m.b * (I1b - 3.0));
+    const double E8 = exp(m.bfs * I8 * I8);
+    const bool onf = I4f >= 1.0, ons = I4s >= 1.0;
+    const double df = I4f - 1.0, ds = I4s - 1.0;
+    const double E4f = onf ? exp(m.bf * df * df) : 1.0;
+    const double E4s = ons ? exp(m.bs * ds * ds) : 1.0;
+    double psi = m.a / (2.0 * m.b) * (E1 - 1.0) + m.afs / (2.0 * m.bfs) * (E8 - 1.0) + m.beta * (J2 - 1.0 - 2.0 * log(J));
+    if (onf) psi += m.af / (2.0 * m.bf) * (E4f - 1.0);
+    if (ons) psi += m.as / (2.0 * m.bs) * (E4s - 1.0);
+
+    const double h1 = 0.5 * m.a * E1;
+    const double w1f = onf ? m.af * df * E4f : 0.0, w2f = onf ? m.af * E4f * (1.0 + 2.0 * m.bf * df * df) : 0.0;
+    const double w1s = ons ? m.as * ds * E4s : 0.0, w2s = ons ? m.as * E4s * (1.0 + 2.0 * m.bs * ds * ds) : 0.0;
+    const double v1 = m.afs * I8 * E8, v2 = m.afs * E8 * (1.0 + 2.0 * m.bfs * I8 * I8);
+    const double u1 = 2.0 * m.beta * (J2 - 1.0), u2 = 4.0 * m.beta * J2;
+
+    double B[3][3], M[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            B[i][j] = g * (2.0 * F[i][j] - (2.0 / 3.0) * trC * Fi[j][i]);
+            M[i][j] = bv[i] * m.f[j] + av[i] * m.s[j];
+            P[3 * i + j] = h1 * B[i][j] + 2.0 * w1f * av[i] * m.f[j] + 2.0 * w1s * bv[i] * m.s[j] + v1 * M[i][j] + u1 * Fi[j][i];
+        }
+    if constexpr (NEED_A) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int l = 0; l < 3; ++l) {
+                        const double dik = i == k ? 1.0 : 0.0, djl = j == l ? 1.0 : 0.0;
+                        const double d2I1 = -(2.0 / 3.0) * Fi[l][k] * B[i][j] +
+                                            g * (2.0 * dik * djl - (4.0 / 3.0) * F[k][l] * Fi[j][i] + (2.0 / 3.0) * trC * Fi[j][k] * Fi[l][i]);
+                        double t = h1 * (m.b * B[i][j] * B[k][l] + d2I1);
+                        t += 4.0 * w2f * av[i] * m.f[j] * av[k] * m.f[l] + 2.0 * w1f * dik * m.f[j] * m.f[l];
+                        t += 4.0 * w2s * bv[i] * m.s[j] * bv[k] * m.s[l] + 2.0 * w1s * dik * m.s[j] * m.s[l];
+                        t += v2 * M[i][j] * M[k][l] + v1 * dik * (m.s[j] * m.f[l] + m.f[j] * m.s[l]);
+                        t += u2 * Fi[j][i] * Fi[l][k] - u1 * Fi[j][k] * Fi[l][i];
+                        A[9 * (3 * i + j) + 3 * k + l] = t;
+                    }
+    }
+    return psi;
+}
+
+} // namespace tbk

@@ -1,0 +1,349 @@
+// tb_mechanics.hip — quasi-static hyperelastic residual / tangent element kernels (Holzapfel–Ogden 2009),
+// vector-valued Q1 and Q2 Lagrange fields on trilinear hexahedra.
+//
+// Restates src/modeling/solid/elements.jl:177-225 (K and r), :227-273 (K), :275-313 (r):
+//   per quadrature point  ∇u = Σ uₑᵢ ∇δuᵢ,  F = I + ∇u,  (P, 𝔸) = material_routine(F)   (materials.jl:442-453,1025-1040)
+//   rₑ[i] += ∇δuᵢ ⊡ P dΩ,   Kₑ[i,j] += (∇δuᵢ ⊡ 𝔸) ⊡ ∇δuⱼ dΩ,   dof i = 3a + c ↔ ∇δuᵢ = e_c ⊗ ∇Nₐ.
+// The cell loop / load_element_unknowns! / assemble! belong to FerriteOperators (third party); call sites
+// src/solver/nonlinear/newton_raphson.jl:234-238, src/solver/time/homotopy.jl:61-67.
+//
+// One workgroup per cell.  Kₑ never exists as a whole: thread (a, b-group) keeps the 3×3 blocks of its node
+// pairs in registers while the workgroup sweeps the quadrature points; per point the tangent is first
+// contracted with ∇Nₐ once (T[a][c][d][l] = Σ_k ∇Nₐ[k] 𝔸[c][k][d][l], staged in LDS, double-buffered) and then
+// with ∇N_b — 27·NB² FMAs per point instead of 81·NB².  FP64 MFMA equals the FP64 vector rate on CDNA4 and the
+// per-point B-matrices are 3-sparse, so the contraction stays on the VALU.
+#include <hip/hip_runtime.h>
+
+#include "tb_internal.h"
+#include "tb_material.hpp"
+
+namespace tb {
+using namespace tbk;
+
+// ---- reference-element tables for the two supported vector fields (geometry: trilinear hexahedron) ----
+struct G3 {
+    __host__ __device__ static constexpr double x(int i) { return i == 0 ? -0.7745966692414834 : i == 1 ? 0.0 : 0.7745966692414834; }
+    __host__ __device__ static constexpr double w(int i) { return i == 1 ? 0.8888888888888888 : 0.5555555555555556; }
+};
+struct G2 {
+    __host__ __device__ static constexpr double x(int i) { return i == 0 ? -0.5773502691896258 : 0.5773502691896258; }
+    __host__ __device__ static constexpr double w(int) { return 1.0; }
+};
+
+__host__ __device__ constexpr int hex_sgn(int a, int d)
+{
+    constexpr int S[3][8] = {{-1, 1, 1, -1, -1, 1, 1, -1}, {-1, -1, 1, 1, -1, -1, 1, 1}, {-1, -1, -1, -1, 1, 1, 1, 1}};
+    return S[d][a];
+}
+// Ferrite Lagrange{RefHexahedron,2} local numbering: vertices, edges, faces, volume → tensor index per direction
+__host__ __device__ constexpr int hex27_tix(int a, int d)
+{
+    constexpr int T[27][3] = {{0, 0, 0}, {2, 0, 0}, {2, 2, 0}, {0, 2, 0}, {0, 0, 2}, {2, 0, 2}, {2, 2, 2}, {0, 2, 2}, {1, 0, 0},
+                              {2, 1, 0}, {1, 2, 0}, {0, 1, 0}, {1, 0, 2}, {2, 1, 2}, {1, 2, 2}, {0, 1, 2}, {0, 0, 1}, {2, 0, 1},
+                              {2, 2, 1}, {0, 2, 1}, {1, 1, 0}, {1, 0, 1}, {2, 1, 1}, {1, 2, 1}, {0, 1, 1}, {1, 1, 2}, {1, 1, 1}};
+    return T[a][d];
+}
+__host__ __device__ constexpr double quad1d(int i, double x) { return i == 0 ? 0.5 * x * (x - 1.0) : i == 1 ? (1.0 - x * x) : 0.5 * x * (x + 1.0); }
+__host__ __device__ constexpr double dquad1d(int i, double x) { return i == 0 ? x - 0.5 : i == 1 ? -2.0 * x : x + 0.5; }
+
+template <int NB_, int NQ1D_, int PB_, int THREADS_> struct VecField {
+    static constexpr int NB = NB_, NQ1D = NQ1D_, NQ = NQ1D_ * NQ1D_ * NQ1D_, PB = PB_, THREADS = THREADS_, ND = 3 * NB_;
+    __host__ __device__ static constexpr double gx(int i) { return NQ1D == 2 ? G2::x(i) : G3::x(i); }
+    __host__ __device__ static constexpr double gw(int i) { return NQ1D == 2 ? G2::w(i) : G3::w(i); }
+    __host__ __device__ static constexpr double xi(int q, int d) { return gx(d == 0 ? q % NQ1D : d == 1 ? (q / NQ1D) % NQ1D : q / (NQ1D * NQ1D)); }
+    __host__ __device__ static constexpr double w(int q) { return gw(q % NQ1D) * gw((q / NQ1D) % NQ1D) * gw(q / (NQ1D * NQ1D)); }
+    __host__ __device__ static constexpr double dM(int q, int a, int d) // trilinear geometry
+    {
+        return 0.125 * (d == 0 ? hex_sgn(a, 0) : 1.0 + hex_sgn(a, 0) * xi(q, 0)) * (d == 1 ? hex_sgn(a, 1) : 1.0 + hex_sgn(a, 1) * xi(q, 1)) *
+               (d == 2 ? hex_sgn(a, 2) : 1.0 + hex_sgn(a, 2) * xi(q, 2));
+    }
+    __host__ __device__ static constexpr double dN(int q, int a, int d)
+    {
+        if (NB == 8) return dM(q, a, d);
+        return (d == 0 ? dquad1d(hex27_tix(a, 0), xi(q, 0)) : quad1d(hex27_tix(a, 0), xi(q, 0))) *
+               (d == 1 ? dquad1d(hex27_tix(a, 1), xi(q, 1)) : quad1d(hex27_tix(a, 1), xi(q, 1))) *
+               (d == 2 ? dquad1d(hex27_tix(a, 2), xi(q, 2)) : quad1d(hex27_tix(a, 2), xi(q, 2)));
+    }
+};
+using Q1Vec = VecField<8, 2, 1, 64>;    // 64 threads: one per node pair
+using Q2Vec = VecField<27, 3, 3, 256>;  // 243 threads: node a × 9 groups of 3 nodes b
+
+template <class FE> struct MechTables {
+    double dN[FE::NQ][FE::NB][3];
+    double dM[FE::NQ][8][3];
+    double w[FE::NQ];
+};
+template <class FE> constexpr MechTables<FE> make_mech_tables()
+{
+    MechTables<FE> t{};
+    for (int q = 0; q < FE::NQ; ++q) {
+        t.w[q] = FE::w(q);
+        for (int a = 0; a < FE::NB; ++a)
+            for (int d = 0; d < 3; ++d) t.dN[q][a][d] = FE::dN(q, a, d);
+        for (int a = 0; a < 8; ++a)
+            for (int d = 0; d < 3; ++d) t.dM[q][a][d] = FE::dM(q, a, d);
+    }
+    return t;
+}
+template <class FE> __constant__ MechTables<FE> g_mech_tables = make_mech_tables<FE>();
+
+struct MechMesh {
+    const double *xyz;
+    const int32_t *conn;
+    const int32_t *cell_dofs;
+};
+
+// position of column dof(b,0) inside row dof(a,0), per cell and node pair (the three component rows of a node
+// share one column set, so the same position serves rows +1, +2 and columns +1, +2)
+__global__ void k_build_blockpos(const int32_t *__restrict__ cell_dofs, int64_t n_cells, int nb, const int64_t *__restrict__ rowptr,
+                                 const int32_t *__restrict__ colidx, uint16_t *__restrict__ pos, Status *st)
+{
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= n_cells * nb * nb) return;
+    const int64_t cell = tid / (nb * nb);
+    const int a = (int)(tid % (nb * nb)) / nb, b = (int)(tid % nb);
+    const int32_t *d = cell_dofs + cell * 3 * nb;
+    const int32_t row = d[3 * a], col = d[3 * b];
+    const int64_t lo0 = rowptr[row], hi0 = rowptr[row + 1];
+    int64_t lo = lo0, hi = hi0;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (colidx[mid] < col) lo = mid + 1; else hi = mid;
+    }
+    if (lo >= hi0 || colidx[lo] != col || lo - lo0 > 0xFFFF) { st->pattern_missing = 1; st->cell = cell; lo = lo0; }
+    pos[tid] = (uint16_t)(lo - lo0);
+}
+
+template <class FE, bool NEED_K, bool NEED_R>
+__global__ void __launch_bounds__(FE::THREADS)
+k_hyperelastic(MechMesh m, HOParams mat, const int32_t *__restrict__ list, const double *__restrict__ u, double *__restrict__ nz,
+               double *__restrict__ r, const int64_t *__restrict__ rowptr, const uint16_t *__restrict__ blockpos, int atomic, Status *st)
+{
+    constexpr int NB = FE::NB, NQ = FE::NQ, ND = FE::ND, PB = FE::PB, T = FE::THREADS, NG = NB / PB;
+    const MechTables<FE> &tb = g_mech_tables<FE>;
+    const int64_t cell = list ? list[blockIdx.x] : blockIdx.x;
+    const int tid = threadIdx.x;
+    __shared__ double s_ue[ND], s_x[24], s_JI[NQ][10], s_G[NQ][NB][3], s_P[NQ][9];
+    __shared__ double s_A[NEED_K ? NQ : 1][81], s_T[NEED_K ? 2 : 1][NEED_K ? NB : 1][27];
+    __shared__ int32_t s_dof[ND];
+
+    // load_element_unknowns! (elements.jl:125-132) + cell coordinates
+    for (int i = tid; i < ND; i += T) {
+        const int32_t d = m.cell_dofs[cell * ND + i];
+        s_dof[i] = d;
+        s_ue[i] = u[d];
+    }
+    for (int i = tid; i < 24; i += T) s_x[i] = m.xyz[3 * (int64_t)m.conn[cell * 8 + i / 3] + i % 3];
+    __syncthreads();
+
+    // A1: J, J⁻¹, dΩ per point (PR883.jl:253-263,367-387)
+    if (tid < NQ) {
+        const int q = tid;
+        double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) J[i][k] += s_x[3 * a + i] * tb.dM[q][a][k];
+        const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1], c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2], c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+        const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02, id = 1.0 / det;
+        double *o = s_JI[q];
+        o[0] = c00 * id; o[1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * id; o[2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * id;
+        o[3] = c01 * id; o[4] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * id; o[5] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * id;
+        o[6] = c02 * id; o[7] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * id; o[8] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * id;
+        o[9] = det * tb.w[q];
+        if (!(o[9] > 0.0)) { st->neg_detj = 1; st->cell = cell; }
+    }
+    __syncthreads();
+    // A2: mapped gradients ∇Nₐ = ∂Nₐ/∂ξ · J⁻¹ for every (point, node)
+    for (int idx = tid; idx < NQ * NB; idx += T) {
+        const int q = idx / NB, a = idx % NB;
+        const double *ji = s_JI[q];
+        const double d0 = tb.dN[q][a][0], d1 = tb.dN[q][a][1], d2 = tb.dN[q][a][2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s_G[q][a][k] = d0 * ji[k] + d1 * ji[3 + k] + d2 * ji[6 + k];
+    }
+    __syncthreads();
+    // A3: F = I + ∇u, stress and tangent, pre-multiplied by dΩ
+    if (tid < NQ) {
+        const int q = tid;
+        double F[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+        for (int a = 0; a < NB; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double uc = s_ue[3 * a + c];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) F[c][k] += uc * s_G[q][a][k];
+            }
+        const double dO = s_JI[q][9];
+        double P[9];
+        if constexpr (NEED_K) {
+            double A[81];
+            ho_stress_tangent<true>(mat, F, P, A);
+#pragma unroll
+            for (int e = 0; e < 81; ++e) s_A[q][e] = A[e] * dO;
+        } else {
+            ho_stress_tangent<false>(mat, F, P, nullptr);
+        }
+#pragma unroll
+        for (int e = 0; e < 9; ++e) s_P[q][e] = P[e] * dO;
+    }
+    __syncthreads();
+
+    // B: sweep the points
+    const int a_own = tid / NG, bg = tid % NG;
+    const bool pair_thread = tid < NB * NG;
+    double Kacc[NEED_K ? PB : 1][9];
+#pragma unroll
+    for (int pb = 0; pb < (NEED_K ? PB : 1); ++pb)
+#pragma unroll
+        for (int e = 0; e < 9; ++e) Kacc[pb][e] = 0.0;
+    double racc = 0.0;
+    auto stage_T = [&](int q, int buf) {
+        for (int idx = tid; idx < NB * 27; idx += T) {
+            const int a = idx / 27, e = idx % 27, c = e / 9, dl = e % 9; // T[a][c][d][l], dl = 3d + l
+            const double *g = s_G[q][a];
+            s_T[buf][a][e] = g[0] * s_A[q][9 * (3 * c + 0) + dl] + g[1] * s_A[q][9 * (3 * c + 1) + dl] + g[2] * s_A[q][9 * (3 * c + 2) + dl];
+        }
+    };
+    if constexpr (NEED_K) { stage_T(0, 0); __syncthreads(); }
+    for (int q = 0; q < NQ; ++q) {
+        if constexpr (NEED_K) {
+            if (q + 1 < NQ) stage_T(q + 1, (q + 1) & 1);
+            if (pair_thread) {
+                double Ta[27];
+#pragma unroll
+                for (int e = 0; e < 27; ++e) Ta[e] = s_T[q & 1][a_own][e];
+#pragma unroll
+                for (int pb = 0; pb < PB; ++pb) {
+                    const double *gb = s_G[q][bg * PB + pb];
+                    const double g0 = gb[0], g1 = gb[1], g2 = gb[2];
+#pragma unroll
+                    for (int cd = 0; cd < 9; ++cd) Kacc[pb][cd] += Ta[3 * cd] * g0 + Ta[3 * cd + 1] * g1 + Ta[3 * cd + 2] * g2;
+                }
+            }
+        }
+        if constexpr (NEED_R) {
+            if (tid < ND) {
+                const double *g = s_G[q][tid / 3];
+                const double *p = s_P[q] + 3 * (tid % 3);
+                racc += g[0] * p[0] + g[1] * p[1] + g[2] * p[2];
+            }
+        }
+        if constexpr (NEED_K) __syncthreads();
+    }
+
+    // C: assemble!(assembler, dofs, Kₑ, rₑ)
+    if constexpr (NEED_K) {
+        if (pair_thread) {
+            const int32_t row0 = s_dof[3 * a_own];
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) {
+                const int b = bg * PB + pb;
+                const int64_t pos = blockpos[cell * (NB * NB) + a_own * NB + b];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    double *dst = nz + rowptr[row0 + c] + pos;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) {
+                        if (atomic) unsafeAtomicAdd(dst + d, Kacc[pb][3 * c + d]); else dst[d] += Kacc[pb][3 * c + d];
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (NEED_R) {
+        if (tid < ND) {
+            if (atomic) unsafeAtomicAdd(r + s_dof[tid], racc); else r[s_dof[tid]] += racc;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static HOParams make_params(const tb_form *f)
+{
+    HOParams p{};
+    const double *q = f->mat.p;
+    p.a = q[0]; p.b = q[1]; p.af = q[2]; p.bf = q[3]; p.as = q[4]; p.bs = q[5]; p.afs = q[6]; p.bfs = q[7]; p.beta = q[8];
+    for (int i = 0; i < 3; ++i) { p.f[i] = f->mat.f[i]; p.s[i] = f->mat.s[i]; p.n[i] = f->mat.n[i]; }
+    return p;
+}
+
+int host_material_eval(const tb_material *mat, const double *F9, double *psi, double *P, double *A)
+{
+    tb_form tmp;
+    tmp.mat = *mat;
+    const HOParams p = make_params(&tmp);
+    double F[3][3], Pl[9], Al[81];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) F[i][j] = F9[3 * i + j];
+    const double v = ho_stress_tangent<true>(p, F, Pl, Al);
+    if (psi) *psi = v;
+    if (P) for (int i = 0; i < 9; ++i) P[i] = Pl[i];
+    if (A) for (int i = 0; i < 81; ++i) A[i] = Al[i];
+    return TB_OK;
+}
+
+static int ensure_blockpos(tb_pattern *p)
+{
+    if (p->d_blockpos) return TB_OK;
+    tb_mesh *m = p->mesh;
+    const int64_t n = m->n_cells * m->nb * m->nb;
+    TB_HIP(hipMalloc((void **)&p->d_blockpos, sizeof(uint16_t) * n));
+    hipLaunchKernelGGL(k_build_blockpos, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, m->dev->stream, m->d_cell_dofs, m->n_cells, m->nb,
+                       p->d_rowptr, p->d_colidx, p->d_blockpos, m->dev->d_status);
+    TB_HIP(hipGetLastError());
+    return TB_OK;
+}
+
+template <class FE, bool NEED_K, bool NEED_R>
+static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, double *d_nz, double *d_r)
+{
+    tb_mesh *m = f->mesh;
+    tb_device *dev = m->dev;
+    const MechMesh mm{m->d_xyz, m->d_conn, m->d_cell_dofs};
+    const HOParams hp = make_params(f);
+    if (NEED_K) {
+        int rc = ensure_blockpos(p);
+        if (rc) return rc;
+        TB_HIP(hipMemsetAsync(d_nz, 0, (size_t)p->nnz * sizeof(double), dev->stream));
+    }
+    if (NEED_R) TB_HIP(hipMemsetAsync(d_r, 0, (size_t)m->ndofs * sizeof(double), dev->stream));
+    const int64_t *rowptr = p ? p->d_rowptr : nullptr;
+    const uint16_t *bp = p ? p->d_blockpos : nullptr;
+    auto go = [&](const int32_t *list, int64_t n, int atomic) -> int {
+        if (!n) return TB_OK;
+        hipLaunchKernelGGL((k_hyperelastic<FE, NEED_K, NEED_R>), dim3((unsigned)n), dim3(FE::THREADS), 0, dev->stream, mm, hp, list, d_u, d_nz, d_r,
+                           rowptr, bp, atomic, dev->d_status);
+        TB_HIP(hipGetLastError());
+        return TB_OK;
+    };
+    if (strategy == TB_STRATEGY_PER_COLOR) {
+        if (!m->colors) { int rc = build_color_plan(m); if (rc) return rc; }
+        for (int c = 0; c < m->colors->ncolors; ++c) {
+            int rc = go(m->colors->d_cells + m->colors->offsets[c], m->colors->offsets[c + 1] - m->colors->offsets[c], 0);
+            if (rc) return rc;
+        }
+        return TB_OK;
+    }
+    if (strategy == TB_STRATEGY_ATOMIC || strategy == TB_STRATEGY_PATCH) return go(nullptr, m->n_cells, 1);
+    set_error("hyperelastic assembly: strategy %d not supported (use ATOMIC or PER_COLOR)", strategy);
+    return TB_ERR_UNSUPPORTED;
+}
+
+int launch_hyperelastic(tb_form *f, tb_pattern *p, int strategy, const double *d_u, double *d_nz, double *d_r)
+{
+    tb_mesh *m = f->mesh;
+    int rc = reset_status(m->dev);
+    if (rc) return rc;
+    const bool q2 = m->field_kind == TB_HEX27;
+    if (!q2 && !(m->field_kind == TB_HEX8 && f->qorder == 2)) { set_error("hyperelastic: Q1 field needs quadrature order 2"); return TB_ERR_UNSUPPORTED; }
+    if (q2 && f->qorder != 3) { set_error("hyperelastic: Q2 field needs quadrature order 3"); return TB_ERR_UNSUPPORTED; }
+    if (d_nz && d_r) rc = q2 ? run<Q2Vec, true, true>(f, p, strategy, d_u, d_nz, d_r) : run<Q1Vec, true, true>(f, p, strategy, d_u, d_nz, d_r);
+    else if (d_nz) rc = q2 ? run<Q2Vec, true, false>(f, p, strategy, d_u, d_nz, d_r) : run<Q1Vec, true, false>(f, p, strategy, d_u, d_nz, d_r);
+    else rc = q2 ? run<Q2Vec, false, true>(f, p, strategy, d_u, d_nz, d_r) : run<Q1Vec, false, true>(f, p, strategy, d_u, d_nz, d_r);
+    if (rc) return rc;
+    return check_status(m->dev);
+}
+
+} // namespace tb
