@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""BASELINE config 4: quasi-static Holzapfel–Ogden mechanics, Q2 displacement on an n³ hex mesh, Newton
+residual / tangent assembly on one MI355X.  Prints one JSON line (element-integrations/s for
+update_linearization! and residual!)."""
+import argparse, json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=40)
+ap.add_argument("--order", type=int, default=2)
+ap.add_argument("--steps", type=int, default=3)
+ap.add_argument("--strategy", default="atomic", choices=["atomic", "color"])
+ap.add_argument("--cpu-n", type=int, default=8)
+args = ap.parse_args()
+import thunderbolt_jl_amd as tb
+dev = tb.MI355XDevice(0)
+t0 = time.time()
+g = tb.generate_mesh(tb.Hexahedron, (args.n,) * 3, (0, 0, 0), (1, 1, 1), perturb=0.1)
+dh = tb.DofHandler(g, tb.LagrangeCollection(args.order) ** 3)
+sp = tb.allocate_matrix(dh)
+t_setup = time.time() - t0
+model = tb.QuasiStaticModel("u", tb.PK1Model(tb.HolzapfelOgden2009Model(), tb.ConstantCoefficient(tb.OrthotropicMicrostructure([1, 0, 0], [0, 1, 0], [0, 0, 1]))))
+st = (tb.AtomicAssemblyStrategy if args.strategy == "atomic" else tb.PerColorAssemblyStrategy)(dev)
+op = tb.setup_operator(st, model, dh, sp)
+xyz_dof = np.zeros(dh.ndofs)
+u = 1e-2 * np.sin(np.pi * np.arange(dh.ndofs) / dh.ndofs)   # smooth small displacement state
+du, res = dev.to_device(u), dev.zeros(dh.ndofs)
+tb.update_linearization(op, du, 0.0, residual=res)          # warm-up (builds block positions / colours)
+tb.residual(op, res, du, 0.0)
+e = [dev.event() for _ in range(3)]
+tl = tr = 0.0
+for _ in range(args.steps):
+    e[0].record(); tb.update_linearization(op, du, 0.0, residual=res)
+    e[1].record(); tb.residual(op, res, du, 0.0)
+    e[2].record()
+    tl += e[0].elapsed_ms(e[1]); tr += e[1].elapsed_ms(e[2])
+tl /= args.steps; tr /= args.steps
+out = {"workload": "HO2009 quasi-static, Q%d displacement, %d^3 hex (%d cells, %d dofs, nnz %d), %s scatter" % (args.order, args.n, g.n_cells, dh.ndofs, sp.nnz, args.strategy),
+       "linearize_ms": tl, "residual_ms": tr, "linearize_cells_per_s": g.n_cells / (tl * 1e-3), "residual_cells_per_s": g.n_cells / (tr * 1e-3),
+       "host_setup_s": t_setup}
+# CPU oracle ("port", C restatement with hyper-dual AD — not Julia) on a bounded sample
+from oracle import oracle as o
+n = args.cpu_n
+xyz, conn = o.generate_grid_hex(n, n, n, (0, 0, 0), (1, 1, 1))
+kind, q = (o.HEX27, 3) if args.order == 2 else (o.HEX8, 2)
+cd, nd = o.close_dofs(kind, 3, conn, len(xyz))
+rp, ci = o.build_pattern(cd, nd)
+col, nc = o.color_cells(cd, nd)
+m = o.Mesh(kind, q, xyz, conn, cd)
+uu = 1e-2 * np.sin(np.pi * np.arange(nd) / nd)
+th = min(32, len(os.sched_getaffinity(0)))
+t0 = time.perf_counter(); o.assemble_hyperelastic(m, uu, rp, ci, nthreads=th, color=col, ncolors=nc); t1 = time.perf_counter()
+out["cpu_baseline"] = {"value": n ** 3 / (t1 - t0), "unit": "element-integrations/s (K+r)", "cores": th, "kind": "port", "sample": "%d^3 cells" % n}
+print(json.dumps(out))

@@ -338,6 +338,11 @@ k_matrix_patch(MeshView m, FormArgs fa, PatchView pv, double *__restrict__ nz, S
     const int nrows = (int)(r1 - r0);
     const RowDesc last = pv.row_desc[r1 - 1];
     const int nacc = (int)(last.off + last.len);
+    // first cell's connectivity / coordinates are requested before the LDS set-up so their latency hides behind it
+    int64_t e = e0 + threadIdx.x;
+    int64_t cell = 0;
+    double x[E::NV][3];
+    if (e < e1) { cell = pv.elem_cell[e]; load_coords<E>(m, cell, x); }
     // row descriptors live behind the accumulators: nz0[max_rows] (int64) then {off,len}[max_rows]
     int64_t *dnz = (int64_t *)(acc + pv.lds_entries);
     uint2 *dol = (uint2 *)(dnz + pv.max_rows);
@@ -349,9 +354,14 @@ k_matrix_patch(MeshView m, FormArgs fa, PatchView pv, double *__restrict__ nz, S
     }
     __syncthreads();
 
-    for (int64_t e = e0 + threadIdx.x; e < e1; e += T) {
-        const int64_t cell = pv.elem_cell[e];
-        // scatter metadata first: independent of the arithmetic, so its latency hides behind it
+    while (e < e1) {
+        // software pipeline: the next cell's coordinates travel while this one is integrated
+        const int64_t en = e + T;
+        const bool more = en < e1;
+        int64_t celln = 0;
+        double xn[E::NV][3];
+        if (more) { celln = pv.elem_cell[en]; load_coords<E>(m, celln, xn); }
+        // scatter metadata: independent of the arithmetic, so its latency hides behind it too
         uint16_t ro[NB];
         PosT cp[NB * NB];
         {
@@ -362,13 +372,11 @@ k_matrix_patch(MeshView m, FormArgs fa, PatchView pv, double *__restrict__ nz, S
 #pragma unroll
             for (int k = 0; k < NB * NB; ++k) cp[k] = cpp[k];
         }
-        double x[E::NV][3];
-        load_coords<E>(m, cell, x);
         double Ke[SYM ? NB * (NB + 1) / 2 : NB * NB];
 #pragma unroll
         for (int k = 0; k < (SYM ? NB * (NB + 1) / 2 : NB * NB); ++k) Ke[k] = 0.0;
         if (!(fa.debug & 4)) { if (!element_matrix<E, FORM, FIELD, SYM>(x, fa, cell, Ke)) flag_neg_detj(st, cell); }
-        else { Ke[0] = x[0][0] + x[7][2]; }
+        else { Ke[0] = x[0][0] + x[E::NV - 1][2]; }
         if (!(fa.debug & 1))
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -377,6 +385,10 @@ k_matrix_patch(MeshView m, FormArgs fa, PatchView pv, double *__restrict__ nz, S
 #pragma unroll
             for (int j = 0; j < NB; ++j) unsafeAtomicAdd(row + cp[i * NB + j], Ke[SYM ? sym_idx<NB>(i, j) : i * NB + j]);
         }
+        if (!more) break;
+        e = en; cell = celln;
+#pragma unroll
+        for (int a_ = 0; a_ < E::NV; ++a_) { x[a_][0] = xn[a_][0]; x[a_][1] = xn[a_][1]; x[a_][2] = xn[a_][2]; }
     }
     __syncthreads();
 
@@ -403,16 +415,22 @@ k_vector_patch(MeshView m, FormArgs fa, PatchView pv, double *__restrict__ b, St
     const int64_t e0 = pv.elem_ptr[p], e1 = pv.elem_ptr[p + 1];
     const int64_t r0 = pv.row_ptr[p], r1 = pv.row_ptr[p + 1];
     const int nrows = (int)(r1 - r0);
+    int64_t e = e0 + threadIdx.x;
+    int64_t cell = 0;
+    double x[E::NV][3];
+    if (e < e1) { cell = pv.elem_cell[e]; load_coords<E>(m, cell, x); }
     for (int k = threadIdx.x; k < nrows; k += T) acc[k] = 0.0;
     __syncthreads();
-    for (int64_t e = e0 + threadIdx.x; e < e1; e += T) {
-        const int64_t cell = pv.elem_cell[e];
+    while (e < e1) {
+        const int64_t en = e + T;
+        const bool more = en < e1;
+        int64_t celln = 0;
+        double xn[E::NV][3];
+        if (more) { celln = pv.elem_cell[en]; load_coords<E>(m, celln, xn); }
         uint16_t lr[E::NB];
         const uint16_t *lp = pv.elem_lrow + e * E::NB;
 #pragma unroll
         for (int j = 0; j < E::NB; ++j) lr[j] = lp[j];
-        double x[E::NV][3];
-        load_coords<E>(m, cell, x);
         double be[E::NB];
 #pragma unroll
         for (int j = 0; j < E::NB; ++j) be[j] = 0.0;
@@ -420,6 +438,10 @@ k_vector_patch(MeshView m, FormArgs fa, PatchView pv, double *__restrict__ b, St
 #pragma unroll
         for (int j = 0; j < E::NB; ++j)
             if (lr[j] != 0xFFFF) unsafeAtomicAdd(&acc[lr[j]], be[j]);
+        if (!more) break;
+        e = en; cell = celln;
+#pragma unroll
+        for (int a_ = 0; a_ < E::NV; ++a_) { x[a_][0] = xn[a_][0]; x[a_][1] = xn[a_][1]; x[a_][2] = xn[a_][2]; }
     }
     __syncthreads();
     for (int s = threadIdx.x; s < nrows; s += T) b[pv.row_dof[r0 + s]] = acc[s];
