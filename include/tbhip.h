@@ -209,6 +209,11 @@ int tb_cell_model_defaults(int model, double *params, double *u0);
 int tb_heat_matrix(tb_device *dev, int64_t nnz, const double *d_Mnz, const double *d_Knz, double dt, double *d_Anz);
 /* y = α·A·x + β·y, CSR (src/utils.jl:185-231; `b = M uₙ₋₁`, src/solver/time/euler.jl:85) */
 int tb_spmv_csr(tb_pattern *pat, const double *d_nzval, const double *d_x, double alpha, double beta, double *d_y);
+/* Jacobi-preconditioned CG for the heat step A uₙ = b, A = M − Δt·K SPD (src/solver/time/euler.jl:94-100; the tutorials
+ * configure KrylovJL_CG(atol = 1e-6, rtol = 1e-5)).  d_x holds the initial guess (uₙ₋₁) and the solution.
+ * Stops when ‖r‖₂ ≤ atol + rtol·‖r₀‖₂ or after maxiter iterations; reports iterations and the final ‖r‖₂. */
+int tb_cg_solve(tb_pattern *pat, const double *d_Anz, const double *d_b, double *d_x, double rtol, double atol, int maxiter,
+                int jacobi, int *iters, double *resnorm);
 /* y += x (add!(b, source), src/solver/time/euler.jl:90) and max |x[i]| over a strided slice
  * (RTC reads max(dumat[:,φₘidx]), src/solver/time/rtc.jl:64-73) */
 int tb_axpy(tb_device *dev, int64_t n, double a, const double *d_x, double *d_y);

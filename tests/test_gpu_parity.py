@@ -416,3 +416,52 @@ def test_hyperelastic_negative_jacobian_and_bad_field(tb, device):
     assert e.value.code == tb._lib.TB_ERR_NEG_DETJ
     with pytest.raises(tb.TBError):  # scalar field cannot carry the mechanics form
         tb.setup_operator(tb.AtomicAssemblyStrategy(device), model, tb.DofHandler(g))
+
+
+# ------------------------------------------------------------------------------------------- heat step + splitting
+def test_monodomain_operator_splitting_steps(tb, oracle, device):
+    """LieTrotterGodunov((BackwardEuler, ForwardEulerCell)) on FHN (config 2 at toy size) against the same scheme done
+    with oracle operators and an exact sparse solve; CG at rtol 1e-12 so only the linear-solver tolerance differs."""
+    import scipy.sparse as sps
+    import scipy.sparse.linalg as spla
+    g, dh, sp, om = make_problem(tb, oracle, nel=(6, 5, 4), perturb=0.2, left=(0, 0, 0), right=(2.5, 2.0, 1.5))
+    kap = np.diag([4.5e-2, 2.0e-2, 2.0e-2])
+    D = tb.ConductivityToDiffusivityCoefficient(tb.ConstantCoefficient(kap), tb.ConstantCoefficient(1.0), tb.ConstantCoefficient(1.0))
+    src = tb.LinearIntegrator(tb.AnalyticalCoefficient("cos_exp"), nonzero_intervals=[(0.0, 0.25)])
+    st = tb.PatchAssemblyStrategy(device)
+    heat = tb.BackwardEulerStage(tb.BackwardEulerSolver(rtol=1e-12, atol=1e-14), st, dh, D, src, sp)
+    model = tb.FHNModel()
+    n = dh.ndofs
+    n2d = tb.distributed.node_to_dof(dh)
+    X = np.empty((n, 3)); X[n2d] = g.xyz
+    u0 = np.zeros((2, n))
+    u0[0] = (X[:, 0] < 1.25).astype(float)          # φ = 1 on part of the domain, s = 0.1 elsewhere (ep01:113-118 style)
+    u0[1] = 0.1 * (X[:, 1] > 1.0)
+    f = tb.PointwiseODEFunction(n, model)
+    cache = tb.setup_solver_cache(f, tb.ForwardEulerCellSolver(device), u=device.to_device(u0.ravel()))
+    ltg = tb.LieTrotterGodunov(heat, f, cache)
+    # reference: same scheme with oracle operators
+    Mh = oracle.assemble_matrix(om, 0, oracle.Coef(oracle.COEF_CONST_SCALAR, [1.0]), sp.rowptr, sp.colidx)
+    Kh = oracle.assemble_matrix(om, 1, oracle.Coef(oracle.COEF_CONST_TENSOR, kap.ravel(), Cm=1.0, chi=1.0, wrap=True), sp.rowptr, sp.colidx)
+    csr = lambda nz: sps.csr_matrix((nz, sp.colidx, sp.rowptr), shape=(n, n))  # noqa: E731
+    ref = u0.ravel().copy()
+    dt, t = 0.1, 0.0
+    for step in range(5):
+        assert ltg.step(t, dt)
+        A = csr(oracle.heat_matrix(Mh, Kh, dt))
+        b = csr(Mh) @ ref[:n]
+        if 0.0 <= t + dt <= 0.25:
+            fsrc = oracle.assemble_source(om, oracle.SRC_COS_EXP, t=t + dt)
+        b = b + fsrc                                  # stale source is kept when not updated (euler.jl:118-120, add!)
+        ref[:n] = spla.spsolve(A.tocsc(), b)
+        oracle.reaction_step(oracle.CELL_FHN, model.params, ref, n, oracle.LAYOUT_SOA, t=t, dt=dt)
+        t += dt
+    got = cache.un.to_host()
+    assert heat.last_iters > 0
+    assert rel_err(got, ref) < 1e-9
+    # pure Neumann diffusion keeps u ≡ 1 (test/test_time_integrator.jl:29-41)
+    heat2 = tb.BackwardEulerStage(tb.BackwardEulerSolver(rtol=1e-12, atol=1e-14), st, dh, D, None, sp)
+    one = device.to_device(np.ones(n))
+    for _ in range(3):
+        assert heat2.perform_step(one, 0.0, 0.5)
+    np.testing.assert_allclose(one.to_host(), 1.0, rtol=1e-10)

@@ -80,6 +80,7 @@ SIGNATURES = {
     "tb_cell_model_defaults": (C.c_int, [C.c_int, c_dp, c_dp]),
     "tb_heat_matrix": (C.c_int, [vp, C.c_int64, vp, vp, C.c_double, vp]),
     "tb_spmv_csr": (C.c_int, [vp, vp, vp, C.c_double, C.c_double, vp]),
+    "tb_cg_solve": (C.c_int, [vp, vp, vp, vp, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "tb_axpy": (C.c_int, [vp, C.c_int64, C.c_double, vp, vp]),
     "tb_absmax": (C.c_int, [vp, C.c_int64, vp, C.c_int64, C.POINTER(C.c_double)]),
     "tb_host_generate_grid_hex": (C.c_int, [C.c_int, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_i32p]),

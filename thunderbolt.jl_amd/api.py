@@ -123,6 +123,14 @@ class DeviceVector:
         v._owner = tensor
         return v
 
+    def view(self, offset, n):
+        """Non-owning sub-vector (e.g. the φₘ block `u[heat_dofrange]` of the split problem, fem.jl:399-408)."""
+        v = DeviceVector.__new__(DeviceVector)
+        v.dev, v.n, v.dtype = self.dev, int(n), self.dtype
+        v.ptr = C.c_void_p(self.data_ptr() + int(offset) * self.dtype.itemsize)
+        v._owner = self
+        return v
+
     @property
     def nbytes(self):
         return self.n * self.dtype.itemsize
@@ -778,3 +786,67 @@ def residual(op, residual, u, t=0.0):
     """residual!(op, residual, u, p) (newton_raphson.jl:234)."""
     check(lib().tb_residual(op.form, op.strategy.code, _ptr(u), float(t), _ptr(residual)))
     return residual
+
+
+# --------------------------------------------------------------------------------------- heat step + operator splitting
+def cg_solve(pattern, A, b, x, rtol=1e-5, atol=1e-6, maxiter=1000, jacobi=True):
+    """LinearSolve.solve!(linear_solver) with KrylovJL_CG(atol, rtol) (euler.jl:94-100, ep01_spiral-wave.jl:126-128)."""
+    it, res = C.c_int(), C.c_double()
+    check(lib().tb_cg_solve(pattern.h, _ptr(A), _ptr(b), _ptr(x), float(rtol), float(atol), int(maxiter), int(jacobi),
+                            C.byref(it), C.byref(res)))
+    return it.value, res.value
+
+
+class BackwardEulerSolver:
+    """BackwardEulerSolver(; inner_solver = KrylovJL_CG(atol, rtol)) for an AffineODEFunction (euler.jl:4-15)."""
+
+    def __init__(self, rtol=1e-5, atol=1e-6, maxiter=1000, jacobi=True):
+        self.rtol, self.atol, self.maxiter, self.jacobi = rtol, atol, maxiter, jacobi
+
+
+class BackwardEulerStage:
+    """BackwardEulerSolverCache + BackwardEulerAffineODEStage (euler.jl:44-69): M, K, source, A, b, Δt_last;
+    setup assembles all operators once at t₀ (euler.jl:143-176)."""
+
+    def __init__(self, solver, strategy, dh, diffusion, source=None, pattern=None, t0=0.0):
+        self.solver, self.device = solver, strategy.device
+        self.sp = pattern or allocate_matrix(dh)
+        self.M = update_operator(setup_operator(strategy, BilinearMassIntegrator(ConstantCoefficient(1.0)), dh, self.sp), t0)
+        self.K = update_operator(setup_operator(strategy, BilinearDiffusionIntegrator(diffusion), dh, self.sp), t0)
+        self.source = None if source is None else update_operator(setup_operator(strategy, source, dh), t0)
+        self.A = DeviceVector(self.device, self.sp.nnz)
+        self.b = DeviceVector(self.device, dh.ndofs)
+        self.dt_last = None
+        self.last_iters = 0
+
+    def perform_step(self, u, t, dt):
+        """perform_backward_euler_step!(f, cache, stage, t, Δt) (euler.jl:71-101): True on success."""
+        if self.dt_last is None or abs(dt - self.dt_last) > 1e-14 * abs(dt):
+            heat_system_matrix(self.device, self.M, self.K, dt, self.A)         # euler.jl:104-116
+            self.dt_last = dt
+        self.M.mul(self.b, u)                                                   # b = M uₙ₋₁
+        if self.source is not None:
+            if needs_update(self.source, t + dt):                               # euler.jl:118-120
+                update_operator(self.source, t + dt)
+            add(self.b, self.source, self.device)
+        its, res = cg_solve(self.M.pattern, self.A, self.b, u, self.solver.rtol, self.solver.atol, self.solver.maxiter,
+                            self.solver.jacobi)
+        self.last_iters = its
+        return its < self.solver.maxiter or res <= self.solver.atol
+
+
+class LieTrotterGodunov:
+    """LieTrotterGodunov((BackwardEulerSolver(), ForwardEulerCellSolver())) on the monodomain split
+    (OrdinaryDiffEqOperatorSplitting, third party; sequencing per integrator/operatorsplitting-interface.jl):
+    heat step on u[heat_dofrange] (the φₘ block of the SoA state, fem.jl:399-408), then the reaction step."""
+
+    def __init__(self, heat_stage, odefun, cell_cache):
+        self.heat, self.f, self.cell = heat_stage, odefun, cell_cache
+        m = odefun.ode
+        if odefun.layout.code != L.TB_LAYOUT_SOA:
+            raise NotImplementedError("the split problem stores its state StateBlocked (SoA)")
+        self.phi = cell_cache.un.view(m.phi_index * odefun.npoints, odefun.npoints)
+
+    def step(self, t, dt):
+        ok = self.heat.perform_step(self.phi, t, dt)
+        return ok and perform_step(self.f, self.cell, t, dt)

@@ -5,6 +5,7 @@
 //   max |x[i·stride]|                 RTC controller input, src/solver/time/rtc.jl:64-73
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstring>
 
 #include "tb_internal.h"
@@ -110,6 +111,139 @@ int launch_absmax(tb_device *dev, int64_t n, const double *x, int64_t stride, do
     TB_HIP(hipMemcpyAsync(&bits, d_out, sizeof bits, hipMemcpyDeviceToHost, dev->stream));
     TB_HIP(hipStreamSynchronize(dev->stream));
     memcpy(result, &bits, sizeof bits);
+    return TB_OK;
+}
+
+} // namespace tb
+
+// ------------------------------------------------------------------------------------------------
+// Preconditioned conjugate gradients for the heat step  (M − Δt K) uₙ = M uₙ₋₁ + f
+// (src/solver/time/euler.jl:94-100; the tutorials use KrylovJL_CG(atol = 1e-6, rtol = 1e-5),
+// docs/src/literate-tutorials/ep01_spiral-wave.jl:126-128).  Adjacent component: the
+// Krylov method itself is third party (Krylov.jl) in the reference, so this is a plain textbook PCG
+// with a Jacobi preconditioner; stopping test ‖r‖₂ ≤ atol + rtol·‖r₀‖₂ like Krylov.jl's cg.
+// ------------------------------------------------------------------------------------------------
+namespace tb {
+
+__global__ void __launch_bounds__(256)
+k_extract_diag(int64_t nrows, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const double *__restrict__ nz,
+               double *__restrict__ dinv)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    double d = 1.0;
+    for (int64_t k = rowptr[r]; k < rowptr[r + 1]; ++k)
+        if (colidx[k] == r) { d = nz[k]; break; }
+    dinv[r] = 1.0 / d;
+}
+
+__device__ __forceinline__ void block_sum_to(double v, double *out)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __shared__ double sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(out, sm[0] + sm[1] + sm[2] + sm[3]);
+}
+
+// r = b − Ax (Ax given), z = D⁻¹ r, p = z;  out[0] += r·z, out[1] += r·r
+__global__ void __launch_bounds__(256)
+k_cg_init(int64_t n, const double *__restrict__ b, const double *__restrict__ Ax, const double *__restrict__ dinv, double *__restrict__ r,
+          double *__restrict__ p, double *__restrict__ out)
+{
+    double rz = 0.0, rr = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double ri = b[i] - Ax[i];
+        const double zi = dinv ? dinv[i] * ri : ri;
+        r[i] = ri; p[i] = zi;
+        rz += ri * zi; rr += ri * ri;
+    }
+    block_sum_to(rz, out);
+    __syncthreads();
+    block_sum_to(rr, out + 1);
+}
+
+__global__ void __launch_bounds__(256) k_dot(int64_t n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ out)
+{
+    double s = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) s += a[i] * b[i];
+    block_sum_to(s, out);
+}
+
+// x += α p, r −= α Ap;  out[0] += r·(D⁻¹r), out[1] += r·r
+__global__ void __launch_bounds__(256)
+k_cg_update(int64_t n, double alpha, const double *__restrict__ p, const double *__restrict__ Ap, const double *__restrict__ dinv,
+            double *__restrict__ x, double *__restrict__ r, double *__restrict__ out)
+{
+    double rz = 0.0, rr = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        x[i] += alpha * p[i];
+        const double ri = r[i] - alpha * Ap[i];
+        r[i] = ri;
+        rz += ri * (dinv ? dinv[i] * ri : ri);
+        rr += ri * ri;
+    }
+    block_sum_to(rz, out);
+    __syncthreads();
+    block_sum_to(rr, out + 1);
+}
+
+// p = D⁻¹ r + β p
+__global__ void __launch_bounds__(256)
+k_cg_direction(int64_t n, double beta, const double *__restrict__ r, const double *__restrict__ dinv, double *__restrict__ p)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = (dinv ? dinv[i] * r[i] : r[i]) + beta * p[i];
+}
+
+int launch_cg(tb_pattern *pat, const double *A, const double *b, double *x, double rtol, double atol, int maxiter, int jacobi, int *iters,
+              double *resnorm)
+{
+    tb_device *dev = pat->mesh->dev;
+    const int64_t n = pat->n_rows;
+    if (!pat->d_cg_ws) TB_HIP(hipMalloc((void **)&pat->d_cg_ws, sizeof(double) * (4 * n + 2)));
+    double *r = pat->d_cg_ws, *p = r + n, *Ap = p + n, *dinv = Ap + n, *scal = dinv + n;
+    const unsigned g = grid_for(dev, n, 256);
+    auto read2 = [&](double *h) -> int {
+        TB_HIP(hipMemcpyAsync(h, scal, 2 * sizeof(double), hipMemcpyDeviceToHost, dev->stream));
+        TB_HIP(hipStreamSynchronize(dev->stream));
+        return TB_OK;
+    };
+    if (jacobi) hipLaunchKernelGGL(k_extract_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, dev->stream, n, pat->d_rowptr, pat->d_colidx, A, dinv);
+    const double *dp = jacobi ? dinv : nullptr;
+    int rc = launch_spmv(pat, A, x, 1.0, 0.0, Ap);
+    if (rc) return rc;
+    TB_HIP(hipMemsetAsync(scal, 0, 2 * sizeof(double), dev->stream));
+    hipLaunchKernelGGL(k_cg_init, dim3(g), dim3(256), 0, dev->stream, n, b, Ap, dp, r, p, scal);
+    double h[2];
+    if ((rc = read2(h))) return rc;
+    double rz = h[0], rnorm = std::sqrt(h[1]);
+    const double tol = atol + rtol * rnorm;
+    int it = 0;
+    while (rnorm > tol && it < maxiter) {
+        if ((rc = launch_spmv(pat, A, p, 1.0, 0.0, Ap))) return rc;
+        TB_HIP(hipMemsetAsync(scal, 0, 2 * sizeof(double), dev->stream));
+        hipLaunchKernelGGL(k_dot, dim3(g), dim3(256), 0, dev->stream, n, p, Ap, scal);
+        if ((rc = read2(h))) return rc;
+        const double pAp = h[0];
+        if (!(pAp > 0.0)) { set_error("tb_cg_solve: matrix is not positive definite (pᵀAp = %g)", pAp); return TB_ERR_BAD_ARG; }
+        const double alpha = rz / pAp;
+        TB_HIP(hipMemsetAsync(scal, 0, 2 * sizeof(double), dev->stream));
+        hipLaunchKernelGGL(k_cg_update, dim3(g), dim3(256), 0, dev->stream, n, alpha, p, Ap, dp, x, r, scal);
+        if ((rc = read2(h))) return rc;
+        const double rz_new = h[0];
+        rnorm = std::sqrt(h[1]);
+        hipLaunchKernelGGL(k_cg_direction, dim3(g), dim3(256), 0, dev->stream, n, rz_new / rz, r, dp, p);
+        rz = rz_new;
+        ++it;
+    }
+    TB_HIP(hipGetLastError());
+    if (iters) *iters = it;
+    if (resnorm) *resnorm = rnorm;
     return TB_OK;
 }
 

@@ -301,7 +301,7 @@ int tb_pattern_create(tb_mesh *mesh, int64_t n_rows, const int64_t *rowptr, cons
 int tb_pattern_destroy(tb_pattern *p)
 {
     if (!p) return TB_OK;
-    hipFree(p->d_rowptr); hipFree(p->d_colidx); hipFree(p->d_emap); hipFree(p->d_blockpos);
+    hipFree(p->d_rowptr); hipFree(p->d_colidx); hipFree(p->d_emap); hipFree(p->d_blockpos); hipFree(p->d_cg_ws);
     if (p->patch_mat) { hipFree(p->patch_mat->d_row_desc); hipFree(p->patch_mat->d_elem_rowoff); hipFree(p->patch_mat->d_colpos8); hipFree(p->patch_mat->d_colpos16); }
     delete p;
     return TB_OK;
@@ -532,6 +532,15 @@ int tb_spmv_csr(tb_pattern *pat, const double *d_nzval, const double *d_x, doubl
     TB_REQUIRE(pat && d_nzval && d_x && d_y, "tb_spmv_csr: NULL argument");
     TB_REQUIRE(d_x != d_y, "tb_spmv_csr: x and y alias");
     return launch_spmv(pat, d_nzval, d_x, alpha, beta, d_y);
+}
+
+int tb_cg_solve(tb_pattern *pat, const double *d_Anz, const double *d_b, double *d_x, double rtol, double atol, int maxiter, int jacobi,
+                int *iters, double *resnorm)
+{
+    TB_REQUIRE(pat && d_Anz && d_b && d_x, "tb_cg_solve: NULL argument");
+    TB_REQUIRE(rtol >= 0 && atol >= 0 && maxiter >= 0, "tb_cg_solve: negative tolerance or iteration limit");
+    TB_HIP(hipSetDevice(pat->mesh->dev->id));
+    return launch_cg(pat, d_Anz, d_b, d_x, rtol, atol, maxiter, jacobi, iters, resnorm);
 }
 
 int tb_axpy(tb_device *dev, int64_t n, double a, const double *d_x, double *d_y)

@@ -128,6 +128,7 @@ struct tb_pattern {
     std::vector<int32_t> h_colidx;
     bool map64 = false;
     void *d_emap = nullptr; // [ndpc*ndpc][n_cells] nz index of (cell,i,j): int32 (nnz < 2^31) or int64
+    double *d_cg_ws = nullptr;      // CG workspace (r, p, Ap, D⁻¹, 2 scalars)
     uint16_t *d_blockpos = nullptr; // vector fields: per cell and node pair, position of the 3×3 block inside its row
     std::unique_ptr<tb::PatchMatPlan> patch_mat;
 };
@@ -162,6 +163,8 @@ int launch_reaction(tb_device *dev, int model, const double *params, int n_param
                     int64_t n_points, int layout, double t, double dt, int substeps, double thr);
 int launch_heat_matrix(tb_device *dev, int64_t nnz, const double *M, const double *K, double dt, double *A);
 int launch_spmv(tb_pattern *p, const double *nz, const double *x, double alpha, double beta, double *y);
+int launch_cg(tb_pattern *pat, const double *A, const double *b, double *x, double rtol, double atol, int maxiter, int jacobi, int *iters,
+              double *resnorm);
 int launch_axpy(tb_device *dev, int64_t n, double a, const double *x, double *y);
 int launch_absmax(tb_device *dev, int64_t n, const double *x, int64_t stride, double *result);
 
