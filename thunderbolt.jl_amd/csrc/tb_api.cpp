@@ -241,10 +241,7 @@ int tb_mesh_destroy(tb_mesh *m)
     hipFree(m->d_xyz); hipFree(m->d_conn); hipFree(m->d_cell_dofs);
     if (m->colors) hipFree(m->colors->d_cells);
     if (m->ea) { hipFree(m->ea->d_ptr); hipFree(m->ea->d_src); hipFree(m->ea->d_ea); }
-    if (m->patches) {
-        hipFree(m->patches->d_elem_ptr); hipFree(m->patches->d_row_ptr); hipFree(m->patches->d_elem_cell);
-        hipFree(m->patches->d_elem_lrow); hipFree(m->patches->d_row_dof);
-    }
+    free_patch_plan(m);
     delete m;
     return TB_OK;
 }
@@ -302,7 +299,7 @@ int tb_pattern_destroy(tb_pattern *p)
 {
     if (!p) return TB_OK;
     hipFree(p->d_rowptr); hipFree(p->d_colidx); hipFree(p->d_emap); hipFree(p->d_blockpos); hipFree(p->d_cg_ws);
-    if (p->patch_mat) { hipFree(p->patch_mat->d_row_desc); hipFree(p->patch_mat->d_elem_rowoff); hipFree(p->patch_mat->d_colpos8); hipFree(p->patch_mat->d_colpos16); }
+    free_patch_mat_plan(p);
     delete p;
     return TB_OK;
 }

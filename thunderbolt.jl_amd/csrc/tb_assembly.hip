@@ -517,8 +517,7 @@ static int run_matrix(tb_form *f, tb_pattern *p, int strategy, double t, double 
     const MeshView mv = make_view(m);
     const FormArgs fa = make_args(f, t);
     if (strategy == TB_STRATEGY_PATCH) {
-        if (!m->patches) { int rc = build_patch_plan(m, 0); if (rc) return rc; }
-        if (!p->patch_mat) { int rc = build_patch_mat_plan(p); if (rc) return rc; }
+        { int rc = ensure_patch_plans(m, p); if (rc) return rc; }
         const PatchView pv = make_patch_view(m, p);
         const size_t lds = (size_t)p->patch_mat->max_lds_entries * sizeof(double) + (size_t)m->patches->max_rows * 16;
         const int T = m->patches->threads;
@@ -598,7 +597,7 @@ static int run_vector(tb_form *f, int strategy, double t, double *d_b)
     const MeshView mv = make_view(m);
     const FormArgs fa = make_args(f, t);
     if (strategy == TB_STRATEGY_PATCH) {
-        if (!m->patches) { int rc = build_patch_plan(m, 0); if (rc) return rc; }
+        { int rc = ensure_patch_plans(m, nullptr); if (rc) return rc; }
         const PatchView pv = make_patch_view(m, nullptr);
         const int T = m->patches->threads;
         hipLaunchKernelGGL((k_vector_patch<E>), dim3((unsigned)m->patches->n_patches), dim3(T),

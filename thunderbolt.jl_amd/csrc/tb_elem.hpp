@@ -9,6 +9,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 namespace tbk {
 
 #define TB_HD __host__ __device__ __forceinline__
@@ -161,10 +163,28 @@ __device__ __forceinline__ void geo_prepare(const double (&x)[8][3], GeoCoeffs<H
         g.c[4][i] = 0.125 * (dd1 + dd0); g.c[7][i] = 0.125 * (dd1 - dd0);
     }
 }
+// Gauss coordinates of point q.  For the 2-point rule they are ±1/√3 selected by the bits of q — pure scalar
+// arithmetic, so the geometry stage of a point does not wait for the scalar loads of the ∂N/∂ξ table.
+template <int ORDER>
+__device__ __forceinline__ void gauss_coords(const Tables<Hex8<ORDER>> &tb, int q, double (&c)[6])
+{
+    if constexpr (ORDER == 2) {
+        constexpr double G = 0.5773502691896258, G2 = G * G;
+        c[0] = (q & 1) ? G : -G; c[1] = (q & 2) ? G : -G; c[2] = (q & 4) ? G : -G;
+        c[3] = (((q >> 1) ^ (q >> 2)) & 1) ? -G2 : G2;
+        c[4] = (((q >> 2) ^ q) & 1) ? -G2 : G2;
+        c[5] = ((q ^ (q >> 1)) & 1) ? -G2 : G2;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c[k] = tb.xi[q][k];
+    }
+}
 template <int ORDER>
 __device__ __forceinline__ void geo_jacobian(const GeoCoeffs<Hex8<ORDER>> &g, const Tables<Hex8<ORDER>> &tb, int q, double (&J)[3][3])
 {
-    const double xi = tb.xi[q][0], eta = tb.xi[q][1], zeta = tb.xi[q][2], ez = tb.xi[q][3], zx = tb.xi[q][4], xe = tb.xi[q][5];
+    double c[6];
+    gauss_coords(tb, q, c);
+    const double xi = c[0], eta = c[1], zeta = c[2], ez = c[3], zx = c[4], xe = c[5];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         J[i][0] = g.c[1][i] + g.c[4][i] * eta + g.c[6][i] * zeta + g.c[7][i] * ez;
@@ -175,7 +195,9 @@ __device__ __forceinline__ void geo_jacobian(const GeoCoeffs<Hex8<ORDER>> &g, co
 template <int ORDER>
 __device__ __forceinline__ void geo_position(const GeoCoeffs<Hex8<ORDER>> &g, const Tables<Hex8<ORDER>> &tb, int q, double (&xq)[3])
 {
-    const double xi = tb.xi[q][0], eta = tb.xi[q][1], zeta = tb.xi[q][2], ez = tb.xi[q][3], zx = tb.xi[q][4], xe = tb.xi[q][5];
+    double c[6];
+    gauss_coords(tb, q, c);
+    const double xi = c[0], eta = c[1], zeta = c[2], ez = c[3], zx = c[4], xe = c[5];
     const double xez = xi * ez;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -218,7 +240,8 @@ __device__ __forceinline__ void geometry_rt(const Tables<E> &tb, int q, const Ge
     g.Jinv[0][0] = c00 * id; g.Jinv[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * id; g.Jinv[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * id;
     g.Jinv[1][0] = c01 * id; g.Jinv[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * id; g.Jinv[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * id;
     g.Jinv[2][0] = c02 * id; g.Jinv[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * id; g.Jinv[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * id;
-    g.dOmega = det * tb.w[q];
+    if constexpr (std::is_same<E, Hex8<2>>::value) g.dOmega = det; // Gauss weights of the 2-point rule are all 1
+    else g.dOmega = det * tb.w[q];
 }
 
 // compile-time loop over quadrature points

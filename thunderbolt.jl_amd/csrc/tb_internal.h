@@ -60,6 +60,8 @@ struct EAPlan {                // dof → contributing (cell, local) slots, cell
 // patch, which (re)computes all cells touching its rows, accumulates in LDS and stores once.
 struct PatchPlan {
     int cells_per_patch = 0;
+    int version = 0;   // bumped when the plan is rebuilt (LDS-fit retry); matrix extensions remember theirs
+    int shrink = 0;    // tile reductions applied so far
     int64_t n_patches = 0;
     int max_elems = 0, max_rows = 0, threads = 256; // threads: workgroup size used by the patch kernels
     int64_t total_elems = 0, total_rows = 0;
@@ -84,6 +86,7 @@ struct RowDesc {      // one owned row of a patch
 };
 
 struct PatchMatPlan {
+    int version = 0;
     int max_lds_entries = 0;           // max over patches of Σ rowlen of owned rows
     RowDesc *d_row_desc = nullptr;     // per owned row
     uint16_t *d_elem_rowoff = nullptr; // per element instance × local dof: LDS offset of that row, 0xFFFF = not owned here
@@ -152,6 +155,9 @@ int build_color_plan(tb_mesh *m);
 int build_ea_plan(tb_mesh *m);
 int build_patch_plan(tb_mesh *m, int cells_per_patch);
 int build_patch_mat_plan(tb_pattern *p);
+int ensure_patch_plans(tb_mesh *m, tb_pattern *p); // builds / refits both so the LDS block allows two workgroups per CU
+void free_patch_plan(tb_mesh *m);
+void free_patch_mat_plan(tb_pattern *p);
 
 // ---- kernel launchers (tb_assembly.hip / tb_reaction.hip / tb_algebra.hip) ----
 int ensure_emap(tb_pattern *p);

@@ -2,6 +2,7 @@
 // setup_operator, src/solver/interface.jl:17-94: colouring, element-assembly maps, patch decomposition).
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
@@ -85,7 +86,21 @@ static inline uint64_t spread21(uint64_t v)
 // order) that touches it; a patch's element list = every cell touching one of its rows.
 int build_patch_plan(tb_mesh *m, int cells_per_patch)
 {
-    if (cells_per_patch <= 0) {
+    // Patch shape.  Default: tiles of 7×7×7 bucket cells — 343 owned rows (≈80 KB of LDS accumulators, two
+    // workgroups per CU) and 8³ = 512 cell instances = exactly two full 256-thread sweeps.  TB_PATCH_TILE="tx,ty,tz"
+    // overrides; TB_PATCH_CELLS=n (or the argument) selects Morton runs of n cells instead.
+    int tile[3] = {7, 7, 7};
+    bool use_tiles = cells_per_patch <= 0 && !getenv("TB_PATCH_CELLS");
+    if (const char *e = getenv("TB_PATCH_TILE")) {
+        int a, b, c;
+        if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a > 0 && b > 0 && c > 0) { tile[0] = a; tile[1] = b; tile[2] = c; use_tiles = cells_per_patch <= 0; }
+    }
+    if (cells_per_patch < 0) { // shrink request from the LDS-fit retry loop: −k → k-th reduction of the tile
+        for (int k = 0; k < -cells_per_patch; ++k) { int d = 0; for (int j = 1; j < 3; ++j) if (tile[j] > tile[d]) d = j; if (tile[d] > 1) --tile[d]; }
+        cells_per_patch = 0;
+    }
+    if (use_tiles) cells_per_patch = tile[0] * tile[1] * tile[2];
+    else if (cells_per_patch <= 0) {
         const char *e = getenv("TB_PATCH_CELLS");
         cells_per_patch = e ? atoi(e) : 256;
         if (cells_per_patch <= 0) cells_per_patch = 256;
@@ -124,15 +139,21 @@ int build_patch_plan(tb_mesh *m, int cells_per_patch)
             for (int64_t r = 0; r < nc; ++r) bucket[3 * (size_t)byc[r].second + d] = (uint32_t)((r * R) / nc);
         }
 #pragma omp parallel for schedule(static)
-        for (int64_t c = 0; c < nc; ++c)
-            keyed[c] = {spread21(bucket[3 * c]) | spread21(bucket[3 * c + 1]) << 1 | spread21(bucket[3 * c + 2]) << 2, (int32_t)c};
+        for (int64_t c = 0; c < nc; ++c) {
+            if (use_tiles) { // tile id (z-major), 21 bits per axis
+                const uint64_t ti = bucket[3 * c] / tile[0], tj = bucket[3 * c + 1] / tile[1], tk = bucket[3 * c + 2] / tile[2];
+                keyed[c] = {(tk << 42) | (tj << 21) | ti, (int32_t)c};
+            } else {
+                keyed[c] = {spread21(bucket[3 * c]) | spread21(bucket[3 * c + 1]) << 1 | spread21(bucket[3 * c + 2]) << 2, (int32_t)c};
+            }
+        }
     }
     std::sort(keyed.begin(), keyed.end());
 
     // 2. patch boundaries + row ownership by first touch, in Morton order.  A patch closes after `cells_per_patch`
     //    cells or when it would own more than 9/8 of that many rows (domain-boundary patches own the extra
     //    boundary layers), which bounds the LDS accumulator block of every workgroup.
-    const int max_rows_cfg = cells_per_patch + cells_per_patch / 8;
+    const int max_rows_cfg = use_tiles ? cells_per_patch + 8 : cells_per_patch + cells_per_patch / 8;
     std::vector<int32_t> owner(m->ndofs, -1);
     std::vector<int64_t> pstart(1, 0);
     {
@@ -141,7 +162,8 @@ int build_patch_plan(tb_mesh *m, int cells_per_patch)
             const int32_t c = keyed[k].second;
             int newrows = 0;
             for (int l = 0; l < ndpc; ++l) newrows += owner[m->h_cell_dofs[(int64_t)c * ndpc + l]] < 0;
-            if (cells_in == cells_per_patch || (cells_in > 0 && rows_in + newrows > max_rows_cfg)) {
+            const bool new_tile = use_tiles && k > 0 && keyed[k].first != keyed[k - 1].first;
+            if (cells_in == cells_per_patch || new_tile || (cells_in > 0 && rows_in + newrows > max_rows_cfg)) {
                 pstart.push_back(k);
                 rows_in = 0; cells_in = 0;
             }
@@ -228,6 +250,7 @@ int build_patch_plan(tb_mesh *m, int cells_per_patch)
     // overlaps the other's arithmetic); measured best on MI355X among 64…512
     plan->threads = std::min(256, std::max(64, (plan->max_elems + 63) / 64 * 64));
     if (const char *e = getenv("TB_PATCH_THREADS")) { const int t = atoi(e); if (t >= 64 && t <= 512 && t % 64 == 0) plan->threads = t; }
+    plan->version = m->patches ? m->patches->version + 1 : 1;
     plan->total_elems = (int64_t)plan->h_elem_cell.size();
     plan->total_rows = (int64_t)plan->h_row_dof.size();
     if (plan->total_rows != m->ndofs) { set_error("patch plan: %lld rows owned, %lld dofs", (long long)plan->total_rows, (long long)m->ndofs); return TB_ERR_BAD_ARG; }
@@ -263,11 +286,13 @@ int build_patch_mat_plan(tb_pattern *p)
         }
         max_entries = std::max<int64_t>(max_entries, (int64_t)off);
     }
+    plan->max_lds_entries = (int)max_entries;
+    plan->version = pp->version;
     if (max_entries * 8 + (int64_t)pp->max_rows * 16 > 160 * 1024 || max_entries >= 0xFFFF) {
-        set_error("patch plan needs %lld B of LDS per patch (>160 KiB): lower TB_PATCH_CELLS", (long long)(max_entries * 8));
+        set_error("patch plan needs %lld B of LDS per patch (>160 KiB): lower TB_PATCH_TILE / TB_PATCH_CELLS", (long long)(max_entries * 8));
+        p->patch_mat = std::move(plan); // keeps the size for the refit loop
         return TB_ERR_UNSUPPORTED;
     }
-    plan->max_lds_entries = (int)max_entries;
     const bool wide = maxlen > 255;
     std::vector<uint8_t> cp8;
     std::vector<uint16_t> cp16;
@@ -305,6 +330,51 @@ int build_patch_mat_plan(tb_pattern *p)
     else { if ((rc = upload(m->dev, cp8, &plan->d_colpos8))) return rc; }
     p->patch_mat = std::move(plan);
     return TB_OK;
+}
+
+} // namespace tb
+
+namespace tb {
+
+void free_patch_plan(tb_mesh *m)
+{
+    if (!m->patches) return;
+    hipFree(m->patches->d_elem_ptr); hipFree(m->patches->d_row_ptr); hipFree(m->patches->d_elem_cell);
+    hipFree(m->patches->d_elem_lrow); hipFree(m->patches->d_row_dof);
+    m->patches.reset();
+}
+
+void free_patch_mat_plan(tb_pattern *p)
+{
+    if (!p->patch_mat) return;
+    hipFree(p->patch_mat->d_row_desc); hipFree(p->patch_mat->d_elem_rowoff); hipFree(p->patch_mat->d_colpos8); hipFree(p->patch_mat->d_colpos16);
+    p->patch_mat.reset();
+}
+
+// Build the patch plan and (when a pattern is given) its matrix extension; shrink the tile until one patch's
+// LDS block (row accumulators + descriptors) is ≤ 80 KiB, i.e. two workgroups fit a CU's 160 KiB.
+int ensure_patch_plans(tb_mesh *m, tb_pattern *p)
+{
+    if (!m->patches) { int rc = build_patch_plan(m, 0); if (rc) return rc; }
+    if (!p) return TB_OK;
+    if (p->patch_mat && p->patch_mat->version == m->patches->version) return TB_OK;
+    const bool fixed = getenv("TB_PATCH_CELLS") || getenv("TB_PATCH_TILE");
+    for (int attempt = 0; attempt < 12; ++attempt) {
+        free_patch_mat_plan(p);
+        int rc = build_patch_mat_plan(p);
+        const int64_t bytes = p->patch_mat ? (int64_t)p->patch_mat->max_lds_entries * 8 + (int64_t)m->patches->max_rows * 16 : 0;
+        if (rc == TB_OK && (fixed || bytes <= 80 * 1024)) return TB_OK;
+        if (rc != TB_OK && rc != TB_ERR_UNSUPPORTED) return rc;
+        if (fixed) return rc;
+        const int shrink = m->patches->shrink + 1, version = m->patches->version;
+        free_patch_plan(m);
+        rc = build_patch_plan(m, -shrink);
+        if (rc) return rc;
+        m->patches->shrink = shrink;
+        m->patches->version = version + 1;
+    }
+    set_error("patch plan: could not fit the LDS budget");
+    return TB_ERR_UNSUPPORTED;
 }
 
 } // namespace tb
