@@ -30,7 +30,7 @@ FP64_VECTOR_TFLOPS = 78.6      # AMD spec sheet; FP64 MFMA runs at the same rate
 BYTES_PER_CELL_MATRIX = 272.0  # 32 B conn + 24 B coords + 27 nz × 8 B
 BYTES_PER_CELL_VECTOR = 64.0   # 32 + 24 + 8
 BYTES_PER_DOF_UPDATE = 16.0    # in place; 24 when du is materialised
-FLOP_PER_CELL_DIFFUSION = 6000.0  # ≈3000 FP64 instructions per cell counted as FMAs (ISA count)
+FLOP_PER_CELL_DIFFUSION = 4300.0  # useful FP64 flops per cell: ≈8×(208 FMA + 100 mul/add) + 200 (ISA count); halo recompute not counted
 
 
 def parse():
