@@ -70,3 +70,60 @@ def halo_sum(vec, lower_idx, upper_idx, rank, world_size, dist):
     for idx, recv in bufs:
         vec[idx] += recv
     return vec
+
+
+class DistributedCG:
+    """Jacobi-preconditioned CG on sub-domain (interface-unassembled) matrices A = Σ_p R_pᵀ A_p R_p.
+
+    Vectors are torch tensors holding every dof of the slab (owned + interface); solution-type vectors are kept
+    *consistent* (both neighbours hold the same interface value), operator results are summed over the interface
+    with `halo_sum`.  Dot products weight interface dofs by 1/multiplicity and are all-reduced (one scalar
+    all-reduce — RCCL on GPU).  `local_spmv(x) -> y` applies the rank's own A_p (tb_spmv_csr on device; any callable
+    in tests).  New work: the reference has no distributed solver (README.md:7)."""
+
+    def __init__(self, local_spmv, local_diag, lower_idx, upper_idx, rank, world_size, dist):
+        import torch
+        self.torch, self.dist = torch, dist
+        self.spmv, self.rank, self.world = local_spmv, rank, world_size
+        self.lo, self.up = lower_idx, upper_idx
+        d = local_diag.clone()
+        halo_sum(d, self.lo, self.up, rank, world_size, dist)      # assembled diagonal
+        self.dinv = 1.0 / d
+        w = torch.ones_like(d)
+        for idx in (self.lo, self.up):
+            if idx is not None:
+                w[idx] = 0.5                                      # slab interfaces are shared by exactly two ranks
+        self.w = w
+
+    def dot(self, a, b):
+        s = (self.w * a * b).sum().reshape(1)
+        if self.world > 1:
+            self.dist.all_reduce(s)
+        return float(s.item())
+
+    def apply(self, x):
+        y = self.spmv(x)
+        halo_sum(y, self.lo, self.up, self.rank, self.world, self.dist)
+        return y
+
+    def solve(self, b, x, rtol=1e-5, atol=1e-6, maxiter=1000):
+        """b: ASSEMBLED right-hand side (consistent), x: initial guess (consistent); returns (x, iterations, ‖r‖)."""
+        r = b - self.apply(x)
+        z = self.dinv * r
+        p = z.clone()
+        rz = self.dot(r, z)
+        rn = self.dot(r, r) ** 0.5
+        tol = atol + rtol * rn
+        it = 0
+        while rn > tol and it < maxiter:
+            Ap = self.apply(p)
+            alpha = rz / self.dot(p, Ap)
+            x += alpha * p
+            r -= alpha * Ap
+            z = self.dinv * r
+            rz_new = self.dot(r, z)
+            rn = self.dot(r, r) ** 0.5
+            p = z + (rz_new / rz) * p
+            rz = rz_new
+            it += 1
+        return x, it, rn
