@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=64, help="edge of the CPU-baseline sample mesh")
     ap.add_argument("--keep-du", action="store_true", help="materialise du (dumat) in the reaction step")
+    ap.add_argument("--ionic", default="pcg2019", choices=["pcg2019", "tt06", "fhn"],
+                    help="ionic model of the reaction step (pcg2019 = reference-pinned 7-state model; tt06 = 19-state extension)")
     return ap.parse_args()
 
 
@@ -125,10 +127,12 @@ def main():
         lo_idx = None if lo is None else torch.from_numpy(n2d[lo]).cuda()
         up_idx = None if up is None else torch.from_numpy(n2d[up]).cuda()
 
-    model = tb.PCG2019()
+    model = {"pcg2019": tb.PCG2019, "tt06": tb.TT06, "fhn": tb.FHNModel}[args.ionic]()
+    ns = model.nstates
+    rdt = {"pcg2019": 0.01, "tt06": 0.001, "fhn": 0.1}[args.ionic]   # forward-Euler-stable reaction step sizes
     npts = dh.ndofs
     u0 = np.tile(model.default_initial_state(), (npts, 1))
-    u0[:, 0] += np.linspace(0.0, 60.0, npts)
+    u0[:, model.phi_index] += np.linspace(0.0, 60.0 if ns > 2 else 1.0, npts)
     u = torch.from_numpy(np.ascontiguousarray(u0.T).ravel()).cuda()
     f = tb.PointwiseODEFunction(npts, model)
     cache = tb.setup_solver_cache(f, tb.ForwardEulerCellSolver(dev), u=u, keep_du=args.keep_du)
@@ -144,7 +148,7 @@ def main():
         ev[3].record()
         if world > 1:
             tb.distributed.halo_sum(b, lo_idx, up_idx, rank, world, dist)
-        ev[4].record(); tb.perform_step(f, cache, t, 0.01)
+        ev[4].record(); tb.perform_step(f, cache, t, rdt)
         ev[5].record()
         if timed:
             for k, name in enumerate(phase):
@@ -179,21 +183,21 @@ def main():
             "value": 3 * cells_total * K_ / elapsed, "unit": "element-integrations/s",
             "n_gpus": world, "steps": K_, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "monodomain hot path on %d^3 hex Q1 per GPU (%d cells, %d dofs): assemble M + K + b (%s scatter)%s + PCG2019 forward-Euler reaction step"
-                                   % (n, g.n_cells, npts, args.strategy, " + neighbour halo sum of b" if world > 1 else ""),
-                       "cells_per_gpu": g.n_cells, "dofs_per_gpu": npts, "nnz_per_gpu": sp.nnz, "ionic_states": 7,
+            "config": {"workload": "monodomain hot path on %d^3 hex Q1 per GPU (%d cells, %d dofs): assemble M + K + b (%s scatter)%s + %s forward-Euler reaction step"
+                                   % (n, g.n_cells, npts, args.strategy, " + neighbour halo sum of b" if world > 1 else "", args.ionic.upper()),
+                       "cells_per_gpu": g.n_cells, "dofs_per_gpu": npts, "nnz_per_gpu": sp.nnz, "ionic_model": args.ionic, "ionic_states": ns,
                        "partition": "z-slabs"},
-            "dof_updates_per_s": 7 * dofs_total * K_ / elapsed,
+            "dof_updates_per_s": ns * dofs_total * K_ / elapsed,
             "phase_ms": {k: v / K_ for k, v in phase.items()},
             "phase_rates": {"mass_cells_per_s": g.n_cells / (phase["mass"] / K_ * 1e-3),
                             "diffusion_cells_per_s": g.n_cells / (k_ms * 1e-3),
                             "source_cells_per_s": g.n_cells / (phase["source"] / K_ * 1e-3),
-                            "reaction_dof_updates_per_s": 7 * npts / (phase["reaction"] / K_ * 1e-3)},
+                            "reaction_dof_updates_per_s": ns * npts / (phase["reaction"] / K_ * 1e-3)},
             "roofline": {"kernel": "k_matrix_patch<Hex8<2>,DIFFUSION>" if args.strategy == "patch" else "k_matrix_direct<Hex8<2>,DIFFUSION>",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None,
                          "note": "algorithmic 272 B/cell; the kernel is FP64-VALU-bound (≈5 kflop/cell, FP64 MFMA = vector rate on CDNA4), see DESIGN.md",
-                         "reaction": {"bound": "hbm", "achieved": (BYTES_PER_DOF_UPDATE + (8 if args.keep_du else 0)) * 7 * npts / (phase["reaction"] / K_ * 1e-3) / 1e9,
+                         "reaction": {"bound": "hbm", "achieved": (BYTES_PER_DOF_UPDATE + (8 if args.keep_du else 0)) * ns * npts / (phase["reaction"] / K_ * 1e-3) / 1e9,
                                       "peak": HBM_PEAK_GBS, "unit": "GB/s"}},
         }
         out["roofline"]["reaction"]["frac"] = out["roofline"]["reaction"]["achieved"] / HBM_PEAK_GBS

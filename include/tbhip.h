@@ -103,7 +103,10 @@ typedef struct tb_material {
 } tb_material;
 
 /* ionic models (src/modeling/cells/{fhn,aliev-panfilov,pcg2019}.jl) and state layouts (src/modeling/solution_variables.jl:40-68) */
-enum { TB_CELL_FHN = 0, TB_CELL_ALIEV_PANFILOV = 1, TB_CELL_PCG2019 = 2 };
+enum {
+    TB_CELL_FHN = 0, TB_CELL_ALIEV_PANFILOV = 1, TB_CELL_PCG2019 = 2,
+    TB_CELL_TT06 = 3 /* ten Tusscher–Panfilov 2006 (epi): EXTENSION, not in the reference (BASELINE config 3 names it) */
+};
 enum {
     TB_LAYOUT_SOA = 0, /* StateBlockedLayout: u[k + s·npoints]  */
     TB_LAYOUT_AOS = 1  /* PointBlockedLayout: u[k·nstates + s]  */

@@ -751,8 +751,8 @@ int orc_assemble_source(const orc_mesh *m, int src_kind, const double *p, const 
 /* ionic models                                                                                */
 /* ------------------------------------------------------------------------------------------ */
 
-int orc_cell_nstates(int model) { return model == ORC_CELL_PCG2019 ? 7 : (model == ORC_CELL_FHN || model == ORC_CELL_ALIEV_PANFILOV) ? 2 : -1; }
-int orc_cell_nparams(int model) { return model == ORC_CELL_PCG2019 ? 36 : (model == ORC_CELL_FHN || model == ORC_CELL_ALIEV_PANFILOV) ? 6 : -1; }
+int orc_cell_nstates(int model) { return model == ORC_CELL_TT06 ? 19 : model == ORC_CELL_PCG2019 ? 7 : (model == ORC_CELL_FHN || model == ORC_CELL_ALIEV_PANFILOV) ? 2 : -1; }
+int orc_cell_nparams(int model) { return model == ORC_CELL_TT06 ? 48 : model == ORC_CELL_PCG2019 ? 36 : (model == ORC_CELL_FHN || model == ORC_CELL_ALIEV_PANFILOV) ? 6 : -1; }
 
 /* PCG2019 parameter order = struct field order, src/modeling/cells/pcg2019.jl:4-48 */
 enum { P_gNa, P_Em, P_km, P_taum, P_Eh, P_kh, P_dh, P_tauh0, P_gK1, P_Ez, P_kz, P_gto, P_Er, P_kr, P_Es, P_ks,
@@ -776,6 +776,12 @@ void orc_cell_default_params(int model, double *p)
                               0.008, 24.6, 12.1, 628.0,
                               65.0, -85.0, 50.0};
         memcpy(p, d, sizeof d);
+    } else if (model == ORC_CELL_TT06) { /* ten Tusscher & Panfilov 2006, epicardial cell (EXTENSION: not in the reference) */
+        const double d[48] = {14.838, 5.405, 0.153, 0.392, 0.294, 3.98e-5, 0.00029, 0.000592, 0.1238, 0.0146, 2.724, 1000.0,
+                              5.4, 2.0, 140.0, 0.016404, 0.001094, 0.00005468, 0.2, 0.001, 10.0, 0.3, 0.4, 0.00025,
+                              0.006375, 0.00025, 0.102, 0.15, 0.045, 0.060, 0.005, 1.5, 2.5, 1.0, 0.00036, 0.0038,
+                              0.185, 0.03, 1.0, 40.0, 87.5, 1.38, 0.1, 0.35, 0.0005, 8314.472, 310.0, 96485.3415};
+        memcpy(p, d, sizeof d);
     }
 }
 
@@ -784,6 +790,11 @@ static double sigmoid(double phi, double E, double k, double sign) { return 1.0 
 /* cells/pcg2019.jl:137-152; FHN / AP default to zeros (fhn.jl:19, aliev-panfilov.jl:15) */
 void orc_cell_default_state(int model, const double *p, double *u0)
 {
+    if (model == ORC_CELL_TT06) { /* resting state of the authors' reference implementation */
+        const double d[19] = {-86.2, 0.00007, 1.3, 0.00007, 7.67, 138.3, 0.0, 0.75, 0.75, 0.0, 1.0, 0.0, 0.0, 1.0, 0.0, 1.0, 1.0, 1.0, 1.0};
+        memcpy(u0, d, sizeof d);
+        return;
+    }
     if (model != ORC_CELL_PCG2019) { u0[0] = u0[1] = 0.0; return; }
     u0[0] = p[P_EK];
     u0[1] = sigmoid(u0[0], p[P_Eh], p[P_kh], 1.0);
@@ -794,9 +805,95 @@ void orc_cell_default_state(int model, const double *p, double *u0)
     u0[6] = sigmoid(u0[0], p[P_Exr], p[P_kxr], -1.0);
 }
 
+
+/* ten Tusscher & Panfilov 2006 (Am J Physiol 291:H1088), epicardial parameter set, ODE form of the published
+ * equations; states (V, Ca_i, Ca_SR, Ca_ss, Na_i, K_i, m, h, j, xr1, xr2, xs, r, s, d, f, f2, fCass, R̄).
+ * EXTENSION: the reference has no TT06 — parity unpinned, checked GPU-vs-this only. */
+static void tt06_rhs(const double *p, const double *u, double *du)
+{
+    const double GNa = p[0], GK1 = p[1], GKr = p[2], GKs = p[3], Gto = p[4], GCaL = p[5], GbNa = p[6], GbCa = p[7], GpCa = p[8],
+                 GpK = p[9], knak = p[10], knaca = p[11], Ko = p[12], Cao = p[13], Nao = p[14], Vc = p[15], Vsr = p[16], Vss = p[17],
+                 Bufc = p[18], Kbufc = p[19], Bufsr = p[20], Kbufsr = p[21], Bufss = p[22], Kbufss = p[23], Vmaxup = p[24], Kup = p[25],
+                 Vrel = p[26], k1p = p[27], k2p = p[28], k3 = p[29], k4 = p[30], EC = p[31], maxsr = p[32], minsr = p[33],
+                 Vleak = p[34], Vxfer = p[35], Cm = p[36], pKNa = p[37], KmK = p[38], KmNa = p[39], KmNai = p[40], KmCa = p[41],
+                 ksat = p[42], nn = p[43], KpCa = p[44], R = p[45], T = p[46], F = p[47];
+    const double V = u[0], Cai = u[1], CaSR = u[2], CaSS = u[3], Nai = u[4], Ki = u[5], m = u[6], h = u[7], j = u[8], xr1 = u[9],
+                 xr2 = u[10], xs = u[11], r = u[12], s = u[13], d = u[14], f = u[15], f2 = u[16], fCass = u[17], RR = u[18];
+    const double RTONF = R * T / F, FoRT = F / (R * T);
+    const double Ek = RTONF * log(Ko / Ki), Ena = RTONF * log(Nao / Nai);
+    const double Eks = RTONF * log((Ko + pKNa * Nao) / (Ki + pKNa * Nai)), Eca = 0.5 * RTONF * log(Cao / Cai);
+    const double Ak1 = 0.1 / (1.0 + exp(0.06 * (V - Ek - 200.0)));
+    const double Bk1 = (3.0 * exp(0.0002 * (V - Ek + 100.0)) + exp(0.1 * (V - Ek - 10.0))) / (1.0 + exp(-0.5 * (V - Ek)));
+    const double rec_iK1 = Ak1 / (Ak1 + Bk1);
+    const double rec_iNaK = 1.0 / (1.0 + 0.1245 * exp(-0.1 * V * FoRT) + 0.0353 * exp(-V * FoRT));
+    const double rec_ipK = 1.0 / (1.0 + exp((25.0 - V) / 5.98));
+    const double INa = GNa * m * m * m * h * j * (V - Ena);
+    const double e2 = exp(2.0 * (V - 15.0) * FoRT);
+    const double ICaL = GCaL * d * f * f2 * fCass * 4.0 * (V - 15.0) * (F * FoRT) * (0.25 * e2 * CaSS - Cao) / (e2 - 1.0);
+    const double Ito = Gto * r * s * (V - Ek);
+    const double IKr = GKr * sqrt(Ko / 5.4) * xr1 * xr2 * (V - Ek);
+    const double IKs = GKs * xs * xs * (V - Eks);
+    const double IK1 = GK1 * rec_iK1 * (V - Ek);
+    const double en = exp(nn * V * FoRT), en1 = exp((nn - 1.0) * V * FoRT);
+    const double INaCa = knaca * (1.0 / (KmNai * KmNai * KmNai + Nao * Nao * Nao)) * (1.0 / (KmCa + Cao)) * (1.0 / (1.0 + ksat * en1)) *
+                         (en * Nai * Nai * Nai * Cao - en1 * Nao * Nao * Nao * Cai * 2.5);
+    const double INaK = knak * (Ko / (Ko + KmK)) * (Nai / (Nai + KmNa)) * rec_iNaK;
+    const double IpCa = GpCa * Cai / (KpCa + Cai);
+    const double IpK = GpK * rec_ipK * (V - Ek);
+    const double IbNa = GbNa * (V - Ena), IbCa = GbCa * (V - Eca);
+    du[0] = -(IKr + IKs + IK1 + Ito + INa + IbNa + ICaL + IbCa + INaK + INaCa + IpCa + IpK);
+    /* calcium handling */
+    const double kCaSR = maxsr - (maxsr - minsr) / (1.0 + (EC / CaSR) * (EC / CaSR));
+    const double k1 = k1p / kCaSR, k2 = k2p * kCaSR;
+    du[18] = k4 * (1.0 - RR) - k2 * CaSS * RR;
+    const double O = k1 * CaSS * CaSS * RR / (k3 + k1 * CaSS * CaSS);
+    const double Irel = Vrel * O * (CaSR - CaSS), Ileak = Vleak * (CaSR - Cai);
+    const double Iup = Vmaxup / (1.0 + (Kup * Kup) / (Cai * Cai)), Ixfer = Vxfer * (CaSS - Cai);
+    const double bc = 1.0 / (1.0 + Bufc * Kbufc / ((Cai + Kbufc) * (Cai + Kbufc)));
+    const double bsr = 1.0 / (1.0 + Bufsr * Kbufsr / ((CaSR + Kbufsr) * (CaSR + Kbufsr)));
+    const double bss = 1.0 / (1.0 + Bufss * Kbufss / ((CaSS + Kbufss) * (CaSS + Kbufss)));
+    du[1] = bc * ((Ileak - Iup) * Vsr / Vc + Ixfer - (IbCa + IpCa - 2.0 * INaCa) * Cm / (2.0 * Vc * F));
+    du[2] = bsr * (Iup - Irel - Ileak);
+    du[3] = bss * (-ICaL * Cm / (2.0 * Vss * F) + Irel * Vsr / Vss - Ixfer * Vc / Vss);
+    du[4] = -(INa + IbNa + 3.0 * INaK + 3.0 * INaCa) * Cm / (Vc * F);
+    du[5] = -(IK1 + Ito + IKr + IKs - 2.0 * INaK + IpK) * Cm / (Vc * F);
+    /* gates */
+    const double AM = 1.0 / (1.0 + exp((-60.0 - V) / 5.0));
+    const double BM = 0.1 / (1.0 + exp((V + 35.0) / 5.0)) + 0.1 / (1.0 + exp((V - 50.0) / 200.0));
+    const double mrt = 1.0 + exp((-56.86 - V) / 9.03);
+    du[6] = (1.0 / (mrt * mrt) - m) / (AM * BM);
+    const double hrt = 1.0 + exp((V + 71.55) / 7.43);
+    const double hinf = 1.0 / (hrt * hrt);
+    double AH, BH, AJ, BJ;
+    if (V >= -40.0) {
+        AH = 0.0; BH = 0.77 / (0.13 * (1.0 + exp(-(V + 10.66) / 11.1)));
+        AJ = 0.0; BJ = 0.6 * exp(0.057 * V) / (1.0 + exp(-0.1 * (V + 32.0)));
+    } else {
+        AH = 0.057 * exp(-(V + 80.0) / 6.8); BH = 2.7 * exp(0.079 * V) + 3.1e5 * exp(0.3485 * V);
+        AJ = ((-2.5428e4) * exp(0.2444 * V) - 6.948e-6 * exp(-0.04391 * V)) * (V + 37.78) / (1.0 + exp(0.311 * (V + 79.23)));
+        BJ = 0.02424 * exp(-0.01052 * V) / (1.0 + exp(-0.1378 * (V + 40.14)));
+    }
+    du[7] = (hinf - h) * (AH + BH);
+    du[8] = (hinf - j) * (AJ + BJ);
+    du[9] = (1.0 / (1.0 + exp((-26.0 - V) / 7.0)) - xr1) / ((450.0 / (1.0 + exp((-45.0 - V) / 10.0))) * (6.0 / (1.0 + exp((V + 30.0) / 11.5))));
+    du[10] = (1.0 / (1.0 + exp((V + 88.0) / 24.0)) - xr2) / ((3.0 / (1.0 + exp((-60.0 - V) / 20.0))) * (1.12 / (1.0 + exp((V - 60.0) / 20.0))));
+    du[11] = (1.0 / (1.0 + exp((-5.0 - V) / 14.0)) - xs) / ((1400.0 / sqrt(1.0 + exp((5.0 - V) / 6.0))) * (1.0 / (1.0 + exp((V - 35.0) / 15.0))) + 80.0);
+    du[12] = (1.0 / (1.0 + exp((20.0 - V) / 6.0)) - r) / (9.5 * exp(-(V + 40.0) * (V + 40.0) / 1800.0) + 0.8);
+    du[13] = (1.0 / (1.0 + exp((V + 20.0) / 5.0)) - s) / (85.0 * exp(-(V + 45.0) * (V + 45.0) / 320.0) + 5.0 / (1.0 + exp((V - 20.0) / 5.0)) + 3.0);
+    du[14] = (1.0 / (1.0 + exp((-8.0 - V) / 7.5)) - d) /
+             ((1.4 / (1.0 + exp((-35.0 - V) / 13.0)) + 0.25) * (1.4 / (1.0 + exp((V + 5.0) / 5.0))) + 1.0 / (1.0 + exp((50.0 - V) / 20.0)));
+    du[15] = (1.0 / (1.0 + exp((V + 20.0) / 7.0)) - f) /
+             (1102.5 * exp(-(V + 27.0) * (V + 27.0) / 225.0) + 200.0 / (1.0 + exp((13.0 - V) / 10.0)) + 180.0 / (1.0 + exp((V + 30.0) / 10.0)) + 20.0);
+    du[16] = (0.67 / (1.0 + exp((V + 35.0) / 7.0)) + 0.33 - f2) /
+             (600.0 * exp(-(V + 25.0) * (V + 25.0) / 170.0) + 31.0 / (1.0 + exp((25.0 - V) / 10.0)) + 16.0 / (1.0 + exp((V + 30.0) / 10.0)));
+    const double cq = 1.0 + (CaSS / 0.05) * (CaSS / 0.05);
+    du[17] = (0.6 / cq + 0.4 - fCass) / (80.0 / cq + 2.0);
+}
+
 void orc_cell_rhs(int model, const double *p, const double *u, double t, double *du)
 {
     (void)t;
+    if (model == ORC_CELL_TT06) { tt06_rhs(p, u, du); return; }
     if (model == ORC_CELL_FHN) { /* cells/fhn.jl:21-34 */
         double a = p[0], b = p[1], c = p[2], d = p[3], e = p[4], f = p[5];
         double phi = u[0], s = u[1];
@@ -877,7 +974,7 @@ int orc_reaction_step(int model, const double *p, double *u, double *du, int64_t
 #endif
 #pragma omp parallel for schedule(static) if (nthreads > 1)
     for (int64_t i = 0; i < npoints; ++i) {
-        double ul[8], dul[8];
+        double ul[32], dul[32];
         for (int j = 0; j < ns; ++j) ul[j] = layout == ORC_LAYOUT_SOA ? u[i + j * npoints] : u[i * ns + j];
         point_step(model, p, ul, dul, ns, t, dt, substeps, threshold);
         for (int j = 0; j < ns; ++j) {

@@ -44,7 +44,7 @@ enum {
     ORC_SRC_TABULATED = 3          /* table[q + nq*cell] (host-evaluated closure) */
 };
 
-enum { ORC_CELL_FHN = 0, ORC_CELL_ALIEV_PANFILOV = 1, ORC_CELL_PCG2019 = 2 };
+enum { ORC_CELL_FHN = 0, ORC_CELL_ALIEV_PANFILOV = 1, ORC_CELL_PCG2019 = 2, ORC_CELL_TT06 = 3 /* extension, not in the reference */ };
 enum { ORC_LAYOUT_SOA = 0, ORC_LAYOUT_AOS = 1 };
 
 /* ---- FE substrate (Ferrite conventions restated; UNPINNED where SURVEY §8c says so) ---- */

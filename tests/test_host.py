@@ -91,7 +91,7 @@ def test_error_channel_without_gpu(tb):
 
 def test_cell_model_defaults_match_oracle(tb, oracle):
     for cls, oid in ((tb.FHNModel, oracle.CELL_FHN), (tb.AlievPanfilovModel, oracle.CELL_ALIEV_PANFILOV),
-                     (tb.PCG2019, oracle.CELL_PCG2019)):
+                     (tb.PCG2019, oracle.CELL_PCG2019), (tb.TT06, oracle.CELL_TT06)):
         m = cls()
         np.testing.assert_array_equal(m.params, oracle.cell_default_params(oid))
         np.testing.assert_allclose(m.default_initial_state(), oracle.cell_default_state(oid), rtol=1e-15)

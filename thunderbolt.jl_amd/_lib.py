@@ -17,7 +17,7 @@ TB_MATERIAL_HOLZAPFEL_OGDEN_2009 = 0
 TB_COEF_CONST_SCALAR, TB_COEF_CONST_TENSOR, TB_COEF_FIELD_SCALAR = 0, 1, 2
 TB_COEF_SPECTRAL_CONST, TB_COEF_SPECTRAL_FIELD, TB_COEF_TRANSVERSE_CONST = 3, 4, 5
 TB_SRC_CONST, TB_SRC_NORM_PLUS_T, TB_SRC_COS_EXP, TB_SRC_TABULATED = 0, 1, 2, 3
-TB_CELL_FHN, TB_CELL_ALIEV_PANFILOV, TB_CELL_PCG2019 = 0, 1, 2
+TB_CELL_FHN, TB_CELL_ALIEV_PANFILOV, TB_CELL_PCG2019, TB_CELL_TT06 = 0, 1, 2, 3
 TB_LAYOUT_SOA, TB_LAYOUT_AOS = 0, 1
 
 c_dp = C.POINTER(C.c_double)

@@ -636,6 +636,16 @@ class PCG2019(_IonicModel):
     state_symbols = ("φₘ", "h", "m", "f", "s", "xs", "xr")
 
 
+class TT06(_IonicModel):
+    """ten Tusscher–Panfilov 2006 epicardial cell — extension (the reference has no TT06)."""
+    model_id = L.TB_CELL_TT06
+    param_names = ["G_Na", "G_K1", "G_Kr", "G_Ks", "G_to", "G_CaL", "G_bNa", "G_bCa", "G_pCa", "G_pK", "k_NaK", "k_NaCa", "K_o", "Ca_o",
+                   "Na_o", "V_c", "V_sr", "V_ss", "Buf_c", "K_bufc", "Buf_sr", "K_bufsr", "Buf_ss", "K_bufss", "V_maxup", "K_up", "V_rel",
+                   "k1p", "k2p", "k3", "k4", "EC", "max_sr", "min_sr", "V_leak", "V_xfer", "C_m", "p_KNa", "K_mK", "K_mNa", "K_mNai", "K_mCa",
+                   "k_sat", "n", "K_pCa", "R", "T", "F"]
+    state_symbols = ("φₘ", "Ca_i", "Ca_SR", "Ca_ss", "Na_i", "K_i", "m", "h", "j", "xr1", "xr2", "xs", "r", "s", "d", "f", "f2", "fCass", "R̄")
+
+
 class StateBlockedLayout:
     code = L.TB_LAYOUT_SOA
 

@@ -454,6 +454,7 @@ int tb_cell_model_info(int model, int *n_states, int *n_params, int *phi_index)
     case TB_CELL_FHN: ns = 2; np = 6; break;
     case TB_CELL_ALIEV_PANFILOV: ns = 2; np = 6; pi = 1; break; // state order (s, φₘ): aliev-panfilov.jl:13
     case TB_CELL_PCG2019: ns = 7; np = 36; break;
+    case TB_CELL_TT06: ns = 19; np = 48; break;
     default: set_error("unknown cell model %d", model); return TB_ERR_BAD_ARG;
     }
     if (n_states) *n_states = ns;
@@ -492,6 +493,18 @@ int tb_cell_model_defaults(int model, double *params, double *u0)
             u0[4] = sig(u0[0], d[14], d[15], 1.0);  // s
             u0[5] = sig(u0[0], d[30], d[31], -1.0); // xs
             u0[6] = sig(u0[0], d[24], d[25], -1.0); // xr
+        }
+        return TB_OK;
+    }
+    case TB_CELL_TT06: { // ten Tusscher & Panfilov 2006, epicardial set; resting state of the authors' implementation
+        const double d[48] = {14.838, 5.405, 0.153, 0.392, 0.294, 3.98e-5, 0.00029, 0.000592, 0.1238, 0.0146, 2.724, 1000.0,
+                              5.4, 2.0, 140.0, 0.016404, 0.001094, 0.00005468, 0.2, 0.001, 10.0, 0.3, 0.4, 0.00025,
+                              0.006375, 0.00025, 0.102, 0.15, 0.045, 0.060, 0.005, 1.5, 2.5, 1.0, 0.00036, 0.0038,
+                              0.185, 0.03, 1.0, 40.0, 87.5, 1.38, 0.1, 0.35, 0.0005, 8314.472, 310.0, 96485.3415};
+        memcpy(params, d, sizeof d);
+        if (u0) {
+            const double s[19] = {-86.2, 0.00007, 1.3, 0.00007, 7.67, 138.3, 0.0, 0.75, 0.75, 0.0, 1.0, 0.0, 0.0, 1.0, 0.0, 1.0, 1.0, 1.0, 1.0};
+            memcpy(u0, s, sizeof s);
         }
         return TB_OK;
     }

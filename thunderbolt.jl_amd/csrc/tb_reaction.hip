@@ -15,7 +15,7 @@
 namespace tb {
 
 struct CellParams {
-    double p[36];
+    double p[48];
 };
 
 template <int MODEL> struct CellModel;
@@ -79,6 +79,96 @@ template <> struct CellModel<TB_CELL_PCG2019> {
     }
 };
 
+
+// ten Tusscher & Panfilov 2006 human ventricular model, epicardial parameters (Am J Physiol 291:H1088) — BASELINE.json's
+// config 3 names it, the reference does not have it: an EXTENSION whose parity is pinned only against this
+// repository's own oracle.  Plain ODE right-hand side for cell_rhs!-style explicit stepping; the m gate (τ ≈ 1 µs·10³ at
+// rest) needs Δt ≲ 2·10⁻³ ms under forward Euler — use the sub-stepper.
+template <> struct CellModel<TB_CELL_TT06> {
+    static constexpr int NS = 19, PHI = 0;
+    __device__ __forceinline__ static double sg(double x) { return 1.0 / (1.0 + exp(x)); } // 1/(1+eˣ)
+    __device__ __forceinline__ static void rhs(const CellParams &P, const double (&u)[NS], double, double (&du)[NS])
+    {
+        const double *p = P.p;
+        const double GNa = p[0], GK1 = p[1], GKr = p[2], GKs = p[3], Gto = p[4], GCaL = p[5], GbNa = p[6], GbCa = p[7], GpCa = p[8],
+                     GpK = p[9], knak = p[10], knaca = p[11], Ko = p[12], Cao = p[13], Nao = p[14], Vc = p[15], Vsr = p[16], Vss = p[17],
+                     Bufc = p[18], Kbufc = p[19], Bufsr = p[20], Kbufsr = p[21], Bufss = p[22], Kbufss = p[23], Vmaxup = p[24], Kup = p[25],
+                     Vrel = p[26], k1p = p[27], k2p = p[28], k3 = p[29], k4 = p[30], EC = p[31], maxsr = p[32], minsr = p[33],
+                     Vleak = p[34], Vxfer = p[35], Cm = p[36], pKNa = p[37], KmK = p[38], KmNa = p[39], KmNai = p[40], KmCa = p[41],
+                     ksat = p[42], nn = p[43], KpCa = p[44], R = p[45], T = p[46], F = p[47];
+        const double V = u[0], Cai = u[1], CaSR = u[2], CaSS = u[3], Nai = u[4], Ki = u[5], m = u[6], h = u[7], j = u[8], xr1 = u[9],
+                     xr2 = u[10], xs = u[11], r = u[12], s = u[13], d = u[14], f = u[15], f2 = u[16], fCass = u[17], RR = u[18];
+        const double RTONF = R * T / F, FoRT = F / (R * T);
+        // reversal potentials
+        const double Ek = RTONF * log(Ko / Ki), Ena = RTONF * log(Nao / Nai);
+        const double Eks = RTONF * log((Ko + pKNa * Nao) / (Ki + pKNa * Nai)), Eca = 0.5 * RTONF * log(Cao / Cai);
+        // currents
+        const double Ak1 = 0.1 * sg(0.06 * (V - Ek - 200.0));
+        const double Bk1 = (3.0 * exp(0.0002 * (V - Ek + 100.0)) + exp(0.1 * (V - Ek - 10.0))) * sg(-0.5 * (V - Ek));
+        const double INa = GNa * m * m * m * h * j * (V - Ena);
+        const double e2 = exp(2.0 * (V - 15.0) * FoRT);
+        const double ICaL = GCaL * d * f * f2 * fCass * 4.0 * (V - 15.0) * (F * FoRT) * (0.25 * e2 * CaSS - Cao) / (e2 - 1.0);
+        const double Ito = Gto * r * s * (V - Ek);
+        const double IKr = GKr * sqrt(Ko / 5.4) * xr1 * xr2 * (V - Ek);
+        const double IKs = GKs * xs * xs * (V - Eks);
+        const double IK1 = GK1 * (Ak1 / (Ak1 + Bk1)) * (V - Ek);
+        const double en = exp(nn * V * FoRT), en1 = exp((nn - 1.0) * V * FoRT);
+        const double INaCa = knaca * (1.0 / (KmNai * KmNai * KmNai + Nao * Nao * Nao)) * (1.0 / (KmCa + Cao)) * (1.0 / (1.0 + ksat * en1)) *
+                             (en * Nai * Nai * Nai * Cao - en1 * Nao * Nao * Nao * Cai * 2.5);
+        const double INaK = knak * (Ko / (Ko + KmK)) * (Nai / (Nai + KmNa)) / (1.0 + 0.1245 * exp(-0.1 * V * FoRT) + 0.0353 * exp(-V * FoRT));
+        const double IpCa = GpCa * Cai / (KpCa + Cai);
+        const double IpK = GpK * sg((25.0 - V) / 5.98) * (V - Ek);
+        const double IbNa = GbNa * (V - Ena), IbCa = GbCa * (V - Eca);
+        du[0] = -(IKr + IKs + IK1 + Ito + INa + IbNa + ICaL + IbCa + INaK + INaCa + IpCa + IpK);
+        // calcium handling
+        const double ecs = EC / CaSR;
+        const double kCaSR = maxsr - (maxsr - minsr) / (1.0 + ecs * ecs);
+        const double k1 = k1p / kCaSR, k2 = k2p * kCaSR;
+        du[18] = k4 * (1.0 - RR) - k2 * CaSS * RR;
+        const double O = k1 * CaSS * CaSS * RR / (k3 + k1 * CaSS * CaSS);
+        const double Irel = Vrel * O * (CaSR - CaSS), Ileak = Vleak * (CaSR - Cai);
+        const double Iup = Vmaxup / (1.0 + (Kup * Kup) / (Cai * Cai)), Ixfer = Vxfer * (CaSS - Cai);
+        const double bc = 1.0 / (1.0 + Bufc * Kbufc / ((Cai + Kbufc) * (Cai + Kbufc)));
+        const double bsr = 1.0 / (1.0 + Bufsr * Kbufsr / ((CaSR + Kbufsr) * (CaSR + Kbufsr)));
+        const double bss = 1.0 / (1.0 + Bufss * Kbufss / ((CaSS + Kbufss) * (CaSS + Kbufss)));
+        du[1] = bc * ((Ileak - Iup) * Vsr / Vc + Ixfer - (IbCa + IpCa - 2.0 * INaCa) * Cm / (2.0 * Vc * F));
+        du[2] = bsr * (Iup - Irel - Ileak);
+        du[3] = bss * (-ICaL * Cm / (2.0 * Vss * F) + Irel * Vsr / Vss - Ixfer * Vc / Vss);
+        du[4] = -(INa + IbNa + 3.0 * INaK + 3.0 * INaCa) * Cm / (Vc * F);
+        du[5] = -(IK1 + Ito + IKr + IKs - 2.0 * INaK + IpK) * Cm / (Vc * F);
+        // gates: dy/dt = (y∞ − y)/τ
+        const double AM = sg((-60.0 - V) / 5.0);
+        const double BM = 0.1 * sg((V + 35.0) / 5.0) + 0.1 * sg((V - 50.0) / 200.0);
+        const double mr = sg((-56.86 - V) / 9.03);
+        du[6] = (mr * mr - m) / (AM * BM);
+        const double hr = sg((V + 71.55) / 7.43);
+        const double hinf = hr * hr;
+        double ABH, ABJ; // αh + βh, αj + βj
+        if (V >= -40.0) {
+            ABH = 0.77 / (0.13 * (1.0 + exp(-(V + 10.66) / 11.1)));
+            ABJ = 0.6 * exp(0.057 * V) * sg(-0.1 * (V + 32.0));
+        } else {
+            ABH = 0.057 * exp(-(V + 80.0) / 6.8) + 2.7 * exp(0.079 * V) + 3.1e5 * exp(0.3485 * V);
+            ABJ = ((-2.5428e4) * exp(0.2444 * V) - 6.948e-6 * exp(-0.04391 * V)) * (V + 37.78) * sg(0.311 * (V + 79.23)) +
+                  0.02424 * exp(-0.01052 * V) * sg(-0.1378 * (V + 40.14));
+        }
+        du[7] = (hinf - h) * ABH;
+        du[8] = (hinf - j) * ABJ;
+        du[9] = (sg((-26.0 - V) / 7.0) - xr1) / ((450.0 * sg((-45.0 - V) / 10.0)) * (6.0 * sg((V + 30.0) / 11.5)));
+        du[10] = (sg((V + 88.0) / 24.0) - xr2) / ((3.0 * sg((-60.0 - V) / 20.0)) * (1.12 * sg((V - 60.0) / 20.0)));
+        du[11] = (sg((-5.0 - V) / 14.0) - xs) / ((1400.0 / sqrt(1.0 + exp((5.0 - V) / 6.0))) * sg((V - 35.0) / 15.0) + 80.0);
+        du[12] = (sg((20.0 - V) / 6.0) - r) / (9.5 * exp(-(V + 40.0) * (V + 40.0) / 1800.0) + 0.8);
+        du[13] = (sg((V + 20.0) / 5.0) - s) / (85.0 * exp(-(V + 45.0) * (V + 45.0) / 320.0) + 5.0 * sg((V - 20.0) / 5.0) + 3.0);
+        du[14] = (sg((-8.0 - V) / 7.5) - d) / ((1.4 * sg((-35.0 - V) / 13.0) + 0.25) * (1.4 * sg((V + 5.0) / 5.0)) + sg((50.0 - V) / 20.0));
+        du[15] = (sg((V + 20.0) / 7.0) - f) /
+                 (1102.5 * exp(-(V + 27.0) * (V + 27.0) / 225.0) + 200.0 * sg((13.0 - V) / 10.0) + 180.0 * sg((V + 30.0) / 10.0) + 20.0);
+        du[16] = (0.67 * sg((V + 35.0) / 7.0) + 0.33 - f2) /
+                 (600.0 * exp(-(V + 25.0) * (V + 25.0) / 170.0) + 31.0 * sg((25.0 - V) / 10.0) + 16.0 * sg((V + 30.0) / 10.0));
+        const double cq = 1.0 + (CaSS / 0.05) * (CaSS / 0.05);
+        du[17] = (0.6 / cq + 0.4 - fCass) / (80.0 / cq + 2.0);
+    }
+};
+
 template <int MODEL, int LAYOUT, bool WRITE_DU>
 __global__ void __launch_bounds__(256)
 k_reaction(CellParams P, double *__restrict__ u, double *__restrict__ du_out, int64_t n, double t, double dt, int substeps,
@@ -135,11 +225,12 @@ int launch_reaction(tb_device *dev, int model, const double *params, int n_param
                     int layout, double t, double dt, int substeps, double thr)
 {
     CellParams P{};
-    for (int i = 0; i < n_params && i < 36; ++i) P.p[i] = params[i];
+    for (int i = 0; i < n_params && i < 48; ++i) P.p[i] = params[i];
     switch (model) {
     case TB_CELL_FHN: return run<TB_CELL_FHN>(dev, P, d_u, d_du, n_points, layout, t, dt, substeps, thr);
     case TB_CELL_ALIEV_PANFILOV: return run<TB_CELL_ALIEV_PANFILOV>(dev, P, d_u, d_du, n_points, layout, t, dt, substeps, thr);
     case TB_CELL_PCG2019: return run<TB_CELL_PCG2019>(dev, P, d_u, d_du, n_points, layout, t, dt, substeps, thr);
+    case TB_CELL_TT06: return run<TB_CELL_TT06>(dev, P, d_u, d_du, n_points, layout, t, dt, substeps, thr);
     }
     set_error("unknown cell model %d", model);
     return TB_ERR_BAD_ARG;
