@@ -234,22 +234,25 @@ k_hyperelastic(MechMesh m, HOParams mat, const int32_t *__restrict__ list, const
         if constexpr (NEED_K) __syncthreads();
     }
 
-    // C: assemble!(assembler, dofs, Kₑ, rₑ)
+    // C: assemble!(assembler, dofs, Kₑ, rₑ).  The 3×3 node-pair blocks are re-dealt through LDS one component row c at a
+    // time so that three consecutive lanes write the three consecutive columns (d = 0,1,2) of a block row: a
+    // wave-instruction then touches 21 24-byte segments instead of 63 scattered doubles (3× fewer memory-side requests).
     if constexpr (NEED_K) {
-        if (pair_thread) {
-            const int32_t row0 = s_dof[3 * a_own];
+        double *kbuf = &s_A[0][0]; // 𝔸 is dead after the sweep; NB·NB·3 ≤ NQ·81 doubles
 #pragma unroll
-            for (int pb = 0; pb < PB; ++pb) {
-                const int b = bg * PB + pb;
-                const int64_t pos = blockpos[cell * (NB * NB) + a_own * NB + b];
+        for (int c = 0; c < 3; ++c) {
+            __syncthreads();
+            if (pair_thread) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    double *dst = nz + rowptr[row0 + c] + pos;
+                for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) {
-                        if (atomic) unsafeAtomicAdd(dst + d, Kacc[pb][3 * c + d]); else dst[d] += Kacc[pb][3 * c + d];
-                    }
-                }
+                    for (int d = 0; d < 3; ++d) kbuf[(a_own * NB + bg * PB + pb) * 3 + d] = Kacc[pb][3 * c + d];
+            }
+            __syncthreads();
+            for (int idx = tid; idx < NB * NB * 3; idx += T) {
+                const int d = idx % 3, ab = idx / 3, a = ab / NB;
+                const int64_t k = rowptr[s_dof[3 * a] + c] + blockpos[cell * (NB * NB) + ab] + d;
+                if (atomic) unsafeAtomicAdd(nz + k, kbuf[idx]); else nz[k] += kbuf[idx];
             }
         }
     }
