@@ -9,7 +9,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=40)
 ap.add_argument("--order", type=int, default=2)
 ap.add_argument("--steps", type=int, default=3)
-ap.add_argument("--strategy", default="atomic", choices=["atomic", "color"])
+ap.add_argument("--strategy", default="element", choices=["atomic", "color", "element"])
 ap.add_argument("--cpu-n", type=int, default=8)
 args = ap.parse_args()
 import thunderbolt_jl_amd as tb
@@ -20,7 +20,7 @@ dh = tb.DofHandler(g, tb.LagrangeCollection(args.order) ** 3)
 sp = tb.allocate_matrix(dh)
 t_setup = time.time() - t0
 model = tb.QuasiStaticModel("u", tb.PK1Model(tb.HolzapfelOgden2009Model(), tb.ConstantCoefficient(tb.OrthotropicMicrostructure([1, 0, 0], [0, 1, 0], [0, 0, 1]))))
-st = (tb.AtomicAssemblyStrategy if args.strategy == "atomic" else tb.PerColorAssemblyStrategy)(dev)
+st = {"atomic": tb.AtomicAssemblyStrategy, "color": tb.PerColorAssemblyStrategy, "element": tb.ElementAssemblyStrategy}[args.strategy](dev)
 op = tb.setup_operator(st, model, dh, sp)
 xyz_dof = np.zeros(dh.ndofs)
 u = 1e-2 * np.sin(np.pi * np.arange(dh.ndofs) / dh.ndofs)   # smooth small displacement state

@@ -393,7 +393,7 @@ def test_hyperelastic_residual_and_tangent_parity(tb, oracle, device, order, nel
     u = rng.uniform(-1e-2, 1e-2, dh.ndofs)            # SURVEY §8d value distribution
     Kref, rref = oracle.assemble_hyperelastic(om, u, sp.rowptr, sp.colidx, fsn=np.stack([f, s, n]))
     du = device.to_device(u)
-    for st in (tb.AtomicAssemblyStrategy(device), tb.PerColorAssemblyStrategy(device)):
+    for st in (tb.AtomicAssemblyStrategy(device), tb.PerColorAssemblyStrategy(device), tb.ElementAssemblyStrategy(device)):
         op = tb.setup_operator(st, model, dh, sp)
         res = device.zeros(dh.ndofs)
         tb.update_linearization(op, du, 0.0, residual=res)

@@ -238,7 +238,7 @@ int tb_mesh_create(tb_device *dev, int geom_kind, int64_t n_nodes, const double 
 int tb_mesh_destroy(tb_mesh *m)
 {
     if (!m) return TB_OK;
-    hipFree(m->d_xyz); hipFree(m->d_conn); hipFree(m->d_cell_dofs);
+    hipFree(m->d_xyz); hipFree(m->d_conn); hipFree(m->d_cell_dofs); hipFree(m->d_node_dof0);
     if (m->colors) hipFree(m->colors->d_cells);
     if (m->ea) { hipFree(m->ea->d_ptr); hipFree(m->ea->d_src); hipFree(m->ea->d_ea); }
     free_patch_plan(m);
@@ -298,7 +298,7 @@ int tb_pattern_create(tb_mesh *mesh, int64_t n_rows, const int64_t *rowptr, cons
 int tb_pattern_destroy(tb_pattern *p)
 {
     if (!p) return TB_OK;
-    hipFree(p->d_rowptr); hipFree(p->d_colidx); hipFree(p->d_emap); hipFree(p->d_blockpos); hipFree(p->d_cg_ws);
+    hipFree(p->d_rowptr); hipFree(p->d_colidx); hipFree(p->d_emap); hipFree(p->d_blockpos); hipFree(p->d_cg_ws); hipFree(p->d_kebuf);
     free_patch_mat_plan(p);
     delete p;
     return TB_OK;

@@ -115,6 +115,8 @@ struct tb_mesh {
     double *d_xyz = nullptr;
     int32_t *d_conn = nullptr;
     int32_t *d_cell_dofs = nullptr;
+    int32_t *d_node_dof0 = nullptr; // vector fields: first dof of every field node
+    int64_t n_nodes_field = 0;
     std::vector<double> h_xyz;
     std::vector<int32_t> h_conn, h_cell_dofs;
     std::unique_ptr<tb::ColorPlan> colors;
@@ -132,6 +134,8 @@ struct tb_pattern {
     bool map64 = false;
     void *d_emap = nullptr; // [ndpc*ndpc][n_cells] nz index of (cell,i,j): int32 (nnz < 2^31) or int64
     double *d_cg_ws = nullptr;      // CG workspace (r, p, Ap, D⁻¹, 2 scalars)
+    double *d_kebuf = nullptr;      // element-matrix buffer of the ElementAssemblyStrategy (vector fields)
+    int64_t max_row_len = 0;
     uint16_t *d_blockpos = nullptr; // vector fields: per cell and node pair, position of the 3×3 block inside its row
     std::unique_ptr<tb::PatchMatPlan> patch_mat;
 };

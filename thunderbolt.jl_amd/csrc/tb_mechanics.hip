@@ -14,6 +14,8 @@
 // per-point B-matrices are 3-sparse, so the contraction stays on the VALU.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "tb_internal.h"
 #include "tb_material.hpp"
 
@@ -117,7 +119,8 @@ __global__ void k_build_blockpos(const int32_t *__restrict__ cell_dofs, int64_t 
 template <class FE, bool NEED_K, bool NEED_R>
 __global__ void __launch_bounds__(FE::THREADS)
 k_hyperelastic(MechMesh m, HOParams mat, const int32_t *__restrict__ list, const double *__restrict__ u, double *__restrict__ nz,
-               double *__restrict__ r, const int64_t *__restrict__ rowptr, const uint16_t *__restrict__ blockpos, int atomic, Status *st)
+               double *__restrict__ r, const int64_t *__restrict__ rowptr, const uint16_t *__restrict__ blockpos, int atomic /*0 rmw, 1 atomic, 2 store Kₑ/rₑ*/,
+               double *__restrict__ ke, double *__restrict__ re, Status *st)
 {
     constexpr int NB = FE::NB, NQ = FE::NQ, ND = FE::ND, PB = FE::PB, T = FE::THREADS, NG = NB / PB;
     const MechTables<FE> &tb = g_mech_tables<FE>;
@@ -249,17 +252,72 @@ k_hyperelastic(MechMesh m, HOParams mat, const int32_t *__restrict__ list, const
                     for (int d = 0; d < 3; ++d) kbuf[(a_own * NB + bg * PB + pb) * 3 + d] = Kacc[pb][3 * c + d];
             }
             __syncthreads();
-            for (int idx = tid; idx < NB * NB * 3; idx += T) {
-                const int d = idx % 3, ab = idx / 3, a = ab / NB;
-                const int64_t k = rowptr[s_dof[3 * a] + c] + blockpos[cell * (NB * NB) + ab] + d;
-                if (atomic) unsafeAtomicAdd(nz + k, kbuf[idx]); else nz[k] += kbuf[idx];
+            if (atomic == 2) { // element assembly: Kₑ rows leave as contiguous ND-long runs
+                for (int idx = tid; idx < NB * NB * 3; idx += T) {
+                    const int a = idx / ND, j = idx % ND;
+                    ke[((int64_t)cell * ND + 3 * a + c) * ND + j] = kbuf[idx];
+                }
+            } else {
+                for (int idx = tid; idx < NB * NB * 3; idx += T) {
+                    const int d = idx % 3, ab = idx / 3, a = ab / NB;
+                    const int64_t k = rowptr[s_dof[3 * a] + c] + blockpos[cell * (NB * NB) + ab] + d;
+                    if (atomic) unsafeAtomicAdd(nz + k, kbuf[idx]); else nz[k] += kbuf[idx];
+                }
             }
         }
     }
     if constexpr (NEED_R) {
         if (tid < ND) {
-            if (atomic) unsafeAtomicAdd(r + s_dof[tid], racc); else r[s_dof[tid]] += racc;
+            if (atomic == 2) re[cell * ND + tid] = racc;
+            else if (atomic) unsafeAtomicAdd(r + s_dof[tid], racc);
+            else r[s_dof[tid]] += racc;
         }
+    }
+}
+
+
+// ElementAssemblyStrategy for the tangent: second pass, one wave per node.  The node's three rows are summed in LDS
+// from the ≤8 element matrices that touch it — each contribution is a contiguous ND-long run of Kₑ, added in cell
+// order with plain read-modify-writes (bit-reproducible) — and every row is stored once, coalesced.
+template <int NB>
+__global__ void __launch_bounds__(256)
+k_gather_node_rows(const int32_t *__restrict__ node_dof0, int64_t n_nodes, const int64_t *__restrict__ ea_ptr, const int32_t *__restrict__ ea_src,
+                   const double *__restrict__ ke, const uint16_t *__restrict__ blockpos, const int64_t *__restrict__ rowptr, double *__restrict__ nz,
+                   const double *__restrict__ re, double *__restrict__ r, int max_len)
+{
+    constexpr int ND = 3 * NB;
+    extern __shared__ double s_rows[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t node = (int64_t)blockIdx.x * (blockDim.x >> 6) + wv;
+    if (node >= n_nodes) return;
+    double *acc = s_rows + (size_t)wv * 3 * max_len;
+    const int32_t dof0 = node_dof0[node];
+    const int64_t g0 = rowptr[dof0];
+    const int L = (int)(rowptr[dof0 + 1] - g0);
+    const int64_t k0 = ea_ptr[dof0], k1 = ea_ptr[dof0 + 1];
+    if (nz) {
+        for (int k = lane; k < 3 * L; k += 64) acc[k] = 0.0;
+        for (int64_t k = k0; k < k1; ++k) {
+            const int32_t slot = ea_src[k];
+            const int64_t cell = slot / ND;
+            const int a = (slot % ND) / 3;
+            const double *src = ke + ((int64_t)cell * ND + 3 * a) * ND;
+            const uint16_t *bp = blockpos + cell * (NB * NB) + a * NB;
+            for (int idx = lane; idx < 3 * ND; idx += 64) {
+                const int c = idx / ND, j = idx % ND;
+                acc[c * L + bp[j / 3] + j % 3] += src[(int64_t)c * ND + j];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        for (int c = 0; c < 3; ++c) {
+            double *dst = nz + rowptr[dof0 + c];
+            for (int k = lane; k < L; k += 64) dst[k] = acc[c * L + k];
+        }
+    }
+    if (r && lane < 3) {
+        double s = 0.0;
+        for (int64_t k = k0; k < k1; ++k) s += re[ea_src[k] + lane];
+        r[dof0 + lane] = s;
     }
 }
 
@@ -287,6 +345,21 @@ int host_material_eval(const tb_material *mat, const double *F9, double *psi, do
     return TB_OK;
 }
 
+// first-component dof of every node of the vector field (rows of a node are dof0, dof0+1, dof0+2)
+static int build_node_list(tb_mesh *m)
+{
+    std::vector<int32_t> d0;
+    d0.reserve((size_t)m->ndofs / 3);
+    std::vector<uint8_t> seen(m->ndofs, 0);
+    for (int64_t i = 0; i < m->n_cells * m->nb; ++i) {
+        const int32_t d = m->h_cell_dofs[3 * i];
+        if (!seen[d]) { seen[d] = 1; d0.push_back(d); }
+    }
+    std::sort(d0.begin(), d0.end());
+    m->n_nodes_field = (int64_t)d0.size();
+    return upload(m->dev, d0, &m->d_node_dof0);
+}
+
 static int ensure_blockpos(tb_pattern *p)
 {
     if (p->d_blockpos) return TB_OK;
@@ -306,21 +379,48 @@ static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, doubl
     tb_device *dev = m->dev;
     const MechMesh mm{m->d_xyz, m->d_conn, m->d_cell_dofs};
     const HOParams hp = make_params(f);
+    const bool ea = strategy == TB_STRATEGY_ELEMENT || strategy == TB_STRATEGY_PATCH;
     if (NEED_K) {
         int rc = ensure_blockpos(p);
         if (rc) return rc;
-        TB_HIP(hipMemsetAsync(d_nz, 0, (size_t)p->nnz * sizeof(double), dev->stream));
+        if (!ea) TB_HIP(hipMemsetAsync(d_nz, 0, (size_t)p->nnz * sizeof(double), dev->stream));
     }
-    if (NEED_R) TB_HIP(hipMemsetAsync(d_r, 0, (size_t)m->ndofs * sizeof(double), dev->stream));
+    if (NEED_R && !ea) TB_HIP(hipMemsetAsync(d_r, 0, (size_t)m->ndofs * sizeof(double), dev->stream));
     const int64_t *rowptr = p ? p->d_rowptr : nullptr;
     const uint16_t *bp = p ? p->d_blockpos : nullptr;
+    double *kebuf = nullptr, *rebuf = nullptr;
     auto go = [&](const int32_t *list, int64_t n, int atomic) -> int {
         if (!n) return TB_OK;
         hipLaunchKernelGGL((k_hyperelastic<FE, NEED_K, NEED_R>), dim3((unsigned)n), dim3(FE::THREADS), 0, dev->stream, mm, hp, list, d_u, d_nz, d_r,
-                           rowptr, bp, atomic, dev->d_status);
+                           rowptr, bp, atomic, kebuf, rebuf, dev->d_status);
         TB_HIP(hipGetLastError());
         return TB_OK;
     };
+    if (ea) {
+        // ElementAssemblyStrategy (default for mechanics): Kₑ / rₑ stored per cell, then gathered per node row
+        if (!m->ea) { int rc = build_ea_plan(m); if (rc) return rc; }
+        if (!m->d_node_dof0) { int rc = build_node_list(m); if (rc) return rc; }
+        rebuf = m->ea->d_ea;
+        if (NEED_K) {
+            if (!p->d_kebuf) {
+                hipError_t e = hipMalloc((void **)&p->d_kebuf, sizeof(double) * (size_t)m->n_cells * FE::ND * FE::ND);
+                if (e != hipSuccess) { set_error("element-matrix buffer (%zu B): %s", sizeof(double) * (size_t)m->n_cells * FE::ND * FE::ND, hipGetErrorString(e)); return TB_ERR_NOMEM; }
+            }
+            kebuf = p->d_kebuf;
+        }
+        int rc = go(nullptr, m->n_cells, 2);
+        if (rc) return rc;
+        int max_len = 1;
+        if (NEED_K) { if (!p->max_row_len) for (int64_t r = 0; r < p->n_rows; ++r) p->max_row_len = std::max<int64_t>(p->max_row_len, p->h_rowptr[r + 1] - p->h_rowptr[r]); max_len = (int)p->max_row_len; }
+        const size_t lds = (size_t)4 * 3 * max_len * sizeof(double);
+        if (lds > 160 * 1024) { set_error("element assembly gather: rows of %d entries do not fit LDS", max_len); return TB_ERR_UNSUPPORTED; }
+        auto k = k_gather_node_rows<FE::NB>;
+        TB_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, dim3((unsigned)((m->n_nodes_field + 3) / 4)), dim3(256), lds, dev->stream, m->d_node_dof0, m->n_nodes_field, m->ea->d_ptr,
+                           m->ea->d_src, kebuf, bp, rowptr, NEED_K ? d_nz : (double *)nullptr, rebuf, NEED_R ? d_r : (double *)nullptr, max_len);
+        TB_HIP(hipGetLastError());
+        return TB_OK;
+    }
     if (strategy == TB_STRATEGY_PER_COLOR) {
         if (!m->colors) { int rc = build_color_plan(m); if (rc) return rc; }
         for (int c = 0; c < m->colors->ncolors; ++c) {
@@ -329,8 +429,8 @@ static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, doubl
         }
         return TB_OK;
     }
-    if (strategy == TB_STRATEGY_ATOMIC || strategy == TB_STRATEGY_PATCH) return go(nullptr, m->n_cells, 1);
-    set_error("hyperelastic assembly: strategy %d not supported (use ATOMIC or PER_COLOR)", strategy);
+    if (strategy == TB_STRATEGY_ATOMIC) return go(nullptr, m->n_cells, 1);
+    set_error("hyperelastic assembly: unknown strategy %d", strategy);
     return TB_ERR_UNSUPPORTED;
 }
 
