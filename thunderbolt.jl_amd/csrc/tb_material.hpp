@@ -34,8 +34,9 @@ struct HOParams {
 };
 
 // returns Ψ; P[3i+j], A[9(3i+j) + 3k+l] (A only when NEED_A)
+// `scale` multiplies P and A on output (the kernels pass dΩ and point A straight at LDS)
 template <bool NEED_A>
-TB_HD double ho_stress_tangent(const HOParams &m, const double (&F)[3][3], double (&P)[9], double *A)
+TB_HD double ho_stress_tangent(const HOParams &m, const double (&F)[3][3], double (&P)[9], double *A, double scale = 1.0)
 {
     // J, F⁻¹
     const double c00 = F[1][1] * F[2][2] - F[1][2] * F[2][1];
@@ -89,7 +90,7 @@ TB_HD double ho_stress_tangent(const HOParams &m, const double (&F)[3][3], doubl
         for (int j = 0; j < 3; ++j) {
             B[i][j] = g * (2.0 * F[i][j] - (2.0 / 3.0) * trC * Fi[j][i]);
             M[i][j] = bv[i] * m.f[j] + av[i] * m.s[j];
-            P[3 * i + j] = h1 * B[i][j] + 2.0 * w1f * av[i] * m.f[j] + 2.0 * w1s * bv[i] * m.s[j] + v1 * M[i][j] + u1 * Fi[j][i];
+            P[3 * i + j] = scale * (h1 * B[i][j] + 2.0 * w1f * av[i] * m.f[j] + 2.0 * w1s * bv[i] * m.s[j] + v1 * M[i][j] + u1 * Fi[j][i]);
         }
     if constexpr (NEED_A) {
 #pragma unroll
@@ -108,7 +109,7 @@ TB_HD double ho_stress_tangent(const HOParams &m, const double (&F)[3][3], doubl
                         t += 4.0 * w2s * bv[i] * m.s[j] * bv[k] * m.s[l] + 2.0 * w1s * dik * m.s[j] * m.s[l];
                         t += v2 * M[i][j] * M[k][l] + v1 * dik * (m.s[j] * m.f[l] + m.f[j] * m.s[l]);
                         t += u2 * Fi[j][i] * Fi[l][k] - u1 * Fi[j][k] * Fi[l][i];
-                        A[9 * (3 * i + j) + 3 * k + l] = t;
+                        A[9 * (3 * i + j) + 3 * k + l] = scale * t;
                     }
     }
     return psi;

@@ -48,8 +48,9 @@ __host__ __device__ constexpr int hex27_tix(int a, int d)
 __host__ __device__ constexpr double quad1d(int i, double x) { return i == 0 ? 0.5 * x * (x - 1.0) : i == 1 ? (1.0 - x * x) : 0.5 * x * (x + 1.0); }
 __host__ __device__ constexpr double dquad1d(int i, double x) { return i == 0 ? x - 0.5 : i == 1 ? -2.0 * x : x + 0.5; }
 
-template <int NB_, int NQ1D_, int PB_, int THREADS_> struct VecField {
+template <int NB_, int NQ1D_, int PB_, int THREADS_, int WAVES_> struct VecField {
     static constexpr int NB = NB_, NQ1D = NQ1D_, NQ = NQ1D_ * NQ1D_ * NQ1D_, PB = PB_, THREADS = THREADS_, ND = 3 * NB_;
+    static constexpr int WAVES = WAVES_; // min waves per SIMD the register allocator must leave room for (measured best)
     __host__ __device__ static constexpr double gx(int i) { return NQ1D == 2 ? G2::x(i) : G3::x(i); }
     __host__ __device__ static constexpr double gw(int i) { return NQ1D == 2 ? G2::w(i) : G3::w(i); }
     __host__ __device__ static constexpr double xi(int q, int d) { return gx(d == 0 ? q % NQ1D : d == 1 ? (q / NQ1D) % NQ1D : q / (NQ1D * NQ1D)); }
@@ -67,8 +68,8 @@ template <int NB_, int NQ1D_, int PB_, int THREADS_> struct VecField {
                (d == 2 ? dquad1d(hex27_tix(a, 2), xi(q, 2)) : quad1d(hex27_tix(a, 2), xi(q, 2)));
     }
 };
-using Q1Vec = VecField<8, 2, 1, 64>;    // 64 threads: one per node pair
-using Q2Vec = VecField<27, 3, 3, 256>;  // 243 threads: node a × 9 groups of 3 nodes b
+using Q1Vec = VecField<8, 2, 1, 64, 2>;    // 64 threads: one per node pair
+using Q2Vec = VecField<27, 3, 3, 256, 3>;  // 243 threads: node a × 9 groups of 3 nodes b
 
 template <class FE> struct MechTables {
     double dN[FE::NQ][FE::NB][3];
@@ -117,7 +118,7 @@ __global__ void k_build_blockpos(const int32_t *__restrict__ cell_dofs, int64_t 
 }
 
 template <class FE, bool NEED_K, bool NEED_R>
-__global__ void __launch_bounds__(FE::THREADS)
+__global__ void __launch_bounds__(FE::THREADS, FE::WAVES)
 k_hyperelastic(MechMesh m, HOParams mat, const int32_t *__restrict__ list, const double *__restrict__ u, double *__restrict__ nz,
                double *__restrict__ r, const int64_t *__restrict__ rowptr, const uint16_t *__restrict__ blockpos, int atomic /*0 rmw, 1 atomic, 2 store Kₑ/rₑ*/,
                double *__restrict__ ke, double *__restrict__ re, Status *st)
@@ -181,16 +182,10 @@ k_hyperelastic(MechMesh m, HOParams mat, const int32_t *__restrict__ list, const
             }
         const double dO = s_JI[q][9];
         double P[9];
-        if constexpr (NEED_K) {
-            double A[81];
-            ho_stress_tangent<true>(mat, F, P, A);
+        if constexpr (NEED_K) ho_stress_tangent<true>(mat, F, P, s_A[q], dO); // 𝔸·dΩ goes straight to LDS
+        else ho_stress_tangent<false>(mat, F, P, nullptr, dO);
 #pragma unroll
-            for (int e = 0; e < 81; ++e) s_A[q][e] = A[e] * dO;
-        } else {
-            ho_stress_tangent<false>(mat, F, P, nullptr);
-        }
-#pragma unroll
-        for (int e = 0; e < 9; ++e) s_P[q][e] = P[e] * dO;
+        for (int e = 0; e < 9; ++e) s_P[q][e] = P[e];
     }
     __syncthreads();
 
