@@ -116,3 +116,101 @@ TB_HD double ho_stress_tangent(const HOParams &m, const double (&F)[3][3], doubl
 }
 
 } // namespace tbk
+
+// ---- split evaluation for the kernels: per-point common block, then one (i,j) row of P / 𝔸 per lane ----
+// ho_stress_tangent keeps a whole 9×9 tangent in registers on ONE lane per Gauss point; inside a workgroup that is
+// the critical path.  The kernels instead compute the ~46 shared quantities once per point (ho_common → LDS) and let
+// 9 lanes per point build one row (i,j) of 𝔸 each (ho_row): same arithmetic, 4× shorter critical path.
+namespace tbk {
+
+enum { HOC_FI = 0, HOC_B = 9, HOC_M = 18, HOC_AV = 27, HOC_BV = 30, HOC_H1 = 33, HOC_H1B, HOC_W1F2, HOC_W2F4, HOC_W1S2, HOC_W2S4,
+       HOC_V1, HOC_V2, HOC_U1, HOC_U2, HOC_G, HOC_TRC, HOC_PSI, HOC_SIZE = 48 };
+
+TB_HD void ho_common(const HOParams &m, const double (&F)[3][3], double *C)
+{
+    const double c00 = F[1][1] * F[2][2] - F[1][2] * F[2][1];
+    const double c01 = F[1][2] * F[2][0] - F[1][0] * F[2][2];
+    const double c02 = F[1][0] * F[2][1] - F[1][1] * F[2][0];
+    const double J = F[0][0] * c00 + F[0][1] * c01 + F[0][2] * c02;
+    const double iJ = 1.0 / J;
+    double Fi[3][3];
+    Fi[0][0] = c00 * iJ; Fi[0][1] = (F[0][2] * F[2][1] - F[0][1] * F[2][2]) * iJ; Fi[0][2] = (F[0][1] * F[1][2] - F[0][2] * F[1][1]) * iJ;
+    Fi[1][0] = c01 * iJ; Fi[1][1] = (F[0][0] * F[2][2] - F[0][2] * F[2][0]) * iJ; Fi[1][2] = (F[0][2] * F[1][0] - F[0][0] * F[1][2]) * iJ;
+    Fi[2][0] = c02 * iJ; Fi[2][1] = (F[0][1] * F[2][0] - F[0][0] * F[2][1]) * iJ; Fi[2][2] = (F[0][0] * F[1][1] - F[0][1] * F[1][0]) * iJ;
+    const double J2 = J * J;
+    double trC = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) trC += F[i][j] * F[i][j];
+    const double g = 1.0 / cbrt(J2);
+    double av[3], bv[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        av[i] = F[i][0] * m.f[0] + F[i][1] * m.f[1] + F[i][2] * m.f[2];
+        bv[i] = F[i][0] * m.s[0] + F[i][1] * m.s[1] + F[i][2] * m.s[2];
+    }
+    const double I4f = av[0] * av[0] + av[1] * av[1] + av[2] * av[2];
+    const double I4s = bv[0] * bv[0] + bv[1] * bv[1] + bv[2] * bv[2];
+    const double I8 = av[0] * bv[0] + av[1] * bv[1] + av[2] * bv[2];
+    const double E1 = exp(m.b * (trC * g - 3.0));
+    const double E8 = exp(m.bfs * I8 * I8);
+    const bool onf = I4f >= 1.0, ons = I4s >= 1.0;
+    const double df = I4f - 1.0, ds = I4s - 1.0;
+    const double E4f = onf ? exp(m.bf * df * df) : 1.0;
+    const double E4s = ons ? exp(m.bs * ds * ds) : 1.0;
+    double psi = m.a / (2.0 * m.b) * (E1 - 1.0) + m.afs / (2.0 * m.bfs) * (E8 - 1.0) + m.beta * (J2 - 1.0 - 2.0 * log(J));
+    if (onf) psi += m.af / (2.0 * m.bf) * (E4f - 1.0);
+    if (ons) psi += m.as / (2.0 * m.bs) * (E4s - 1.0);
+    const double h1 = 0.5 * m.a * E1;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            C[HOC_FI + 3 * i + j] = Fi[i][j];
+            C[HOC_B + 3 * i + j] = g * (2.0 * F[i][j] - (2.0 / 3.0) * trC * Fi[j][i]);
+            C[HOC_M + 3 * i + j] = bv[i] * m.f[j] + av[i] * m.s[j];
+        }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { C[HOC_AV + i] = av[i]; C[HOC_BV + i] = bv[i]; }
+    C[HOC_H1] = h1; C[HOC_H1B] = h1 * m.b;
+    C[HOC_W1F2] = onf ? 2.0 * m.af * df * E4f : 0.0; C[HOC_W2F4] = onf ? 4.0 * m.af * E4f * (1.0 + 2.0 * m.bf * df * df) : 0.0;
+    C[HOC_W1S2] = ons ? 2.0 * m.as * ds * E4s : 0.0; C[HOC_W2S4] = ons ? 4.0 * m.as * E4s * (1.0 + 2.0 * m.bs * ds * ds) : 0.0;
+    C[HOC_V1] = m.afs * I8 * E8; C[HOC_V2] = m.afs * E8 * (1.0 + 2.0 * m.bfs * I8 * I8);
+    C[HOC_U1] = 2.0 * m.beta * (J2 - 1.0); C[HOC_U2] = 4.0 * m.beta * J2;
+    C[HOC_G] = g; C[HOC_TRC] = trC; C[HOC_PSI] = psi;
+}
+
+TB_HD double sel3(int k, double a, double b, double c) { return k == 0 ? a : (k == 1 ? b : c); }
+
+// row (i,j) of P and 𝔸 from the common block (C and F may live in LDS; i, j may differ per lane)
+template <bool NEED_A>
+TB_HD void ho_row(const HOParams &m, const double *C, const double *F, int i, int j, double scale, double &P_ij, double *Arow)
+{
+    const double Bij = C[HOC_B + 3 * i + j], Mij = C[HOC_M + 3 * i + j], Fiji = C[HOC_FI + 3 * j + i];
+    const double avi = C[HOC_AV + i], bvi = C[HOC_BV + i];
+    const double fj = sel3(j, m.f[0], m.f[1], m.f[2]), sj = sel3(j, m.s[0], m.s[1], m.s[2]);
+    const double h1 = C[HOC_H1], h1b = C[HOC_H1B], w1f2 = C[HOC_W1F2], w2f4 = C[HOC_W2F4], w1s2 = C[HOC_W1S2], w2s4 = C[HOC_W2S4];
+    const double v1 = C[HOC_V1], v2 = C[HOC_V2], u1 = C[HOC_U1], u2 = C[HOC_U2], g = C[HOC_G], trC = C[HOC_TRC];
+    P_ij = scale * (h1 * Bij + w1f2 * avi * fj + w1s2 * bvi * sj + v1 * Mij + u1 * Fiji);
+    if constexpr (NEED_A) {
+        const double Fij_[3] = {C[HOC_FI + 3 * j + 0], C[HOC_FI + 3 * j + 1], C[HOC_FI + 3 * j + 2]}; // F⁻¹[j][k]
+        const double Fi_i[3] = {C[HOC_FI + 0 + i], C[HOC_FI + 3 + i], C[HOC_FI + 6 + i]};             // F⁻¹[l][i]
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+                const double dik = i == k ? 1.0 : 0.0, djl = j == l ? 1.0 : 0.0;
+                const double Filk = C[HOC_FI + 3 * l + k], Bkl = C[HOC_B + 3 * k + l], Mkl = C[HOC_M + 3 * k + l];
+                const double d2I1 = -(2.0 / 3.0) * Filk * Bij + g * (2.0 * dik * djl - (4.0 / 3.0) * F[3 * k + l] * Fiji + (2.0 / 3.0) * trC * Fij_[k] * Fi_i[l]);
+                double t = h1 * d2I1 + h1b * Bij * Bkl;
+                t += w2f4 * avi * fj * C[HOC_AV + k] * m.f[l] + w1f2 * dik * fj * m.f[l];
+                t += w2s4 * bvi * sj * C[HOC_BV + k] * m.s[l] + w1s2 * dik * sj * m.s[l];
+                t += v2 * Mij * Mkl + v1 * dik * (sj * m.f[l] + fj * m.s[l]);
+                t += u2 * Fiji * Filk - u1 * Fij_[k] * Fi_i[l];
+                Arow[3 * k + l] = scale * t;
+            }
+    }
+}
+
+} // namespace tbk

@@ -128,7 +128,13 @@ k_hyperelastic(MechMesh m, HOParams mat, const int32_t *__restrict__ list, const
     const int64_t cell = list ? list[blockIdx.x] : blockIdx.x;
     const int tid = threadIdx.x;
     __shared__ double s_ue[ND], s_x[24], s_JI[NQ][10], s_G[NQ][NB][3], s_P[NQ][9];
-    __shared__ double s_A[NEED_K ? NQ : 1][81], s_T[NEED_K ? 2 : 1][NEED_K ? NB : 1][27];
+    __shared__ double s_A[NEED_K ? NQ : 1][81];
+    // phase A scratch (common blocks + F) and phase B's double-buffered T share one region
+    constexpr int TC_SIZE = (NEED_K && 2 * NB * 27 > NQ * (HOC_SIZE + 9)) ? 2 * NB * 27 : NQ * (HOC_SIZE + 9);
+    __shared__ double s_TC[TC_SIZE];
+    double (*s_T)[NB][27] = reinterpret_cast<double (*)[NB][27]>(s_TC);
+    double (*s_C)[HOC_SIZE] = reinterpret_cast<double (*)[HOC_SIZE]>(s_TC);
+    double (*s_F)[9] = reinterpret_cast<double (*)[9]>(s_TC + NQ * HOC_SIZE);
     __shared__ int32_t s_dof[ND];
 
     // load_element_unknowns! (elements.jl:125-132) + cell coordinates
@@ -169,23 +175,35 @@ k_hyperelastic(MechMesh m, HOParams mat, const int32_t *__restrict__ list, const
         for (int k = 0; k < 3; ++k) s_G[q][a][k] = d0 * ji[k] + d1 * ji[3 + k] + d2 * ji[6 + k];
     }
     __syncthreads();
-    // A3: F = I + ∇u, stress and tangent, pre-multiplied by dΩ
+    // A3a: F = I + ∇u, one lane per (point, component c, direction k)
+    for (int t = tid; t < NQ * 9; t += T) {
+        const int q = t / 9, ck = t % 9, c = ck / 3, k = ck % 3;
+        double v = c == k ? 1.0 : 0.0;
+        for (int a = 0; a < NB; ++a) v += s_ue[3 * a + c] * s_G[q][a][k];
+        s_F[q][ck] = v;
+    }
+    __syncthreads();
+    // A3b: the quantities shared by all entries of P and 𝔸 at a point (one lane per point)
     if (tid < NQ) {
-        const int q = tid;
-        double F[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-        for (int a = 0; a < NB; ++a)
+        double F[3][3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const double uc = s_ue[3 * a + c];
+        for (int e = 0; e < 9; ++e) F[e / 3][e % 3] = s_F[tid][e];
+        ho_common(mat, F, s_C[tid]);
+    }
+    __syncthreads();
+    // A3c: one lane per (point, i, j): row (i,j) of P·dΩ and 𝔸·dΩ
+    for (int t = tid; t < NQ * 9; t += T) {
+        const int q = t / 9, ij = t % 9;
+        double Pij;
+        if constexpr (NEED_K) {
+            double row[9];
+            ho_row<true>(mat, s_C[q], s_F[q], ij / 3, ij % 3, s_JI[q][9], Pij, row);
 #pragma unroll
-                for (int k = 0; k < 3; ++k) F[c][k] += uc * s_G[q][a][k];
-            }
-        const double dO = s_JI[q][9];
-        double P[9];
-        if constexpr (NEED_K) ho_stress_tangent<true>(mat, F, P, s_A[q], dO); // 𝔸·dΩ goes straight to LDS
-        else ho_stress_tangent<false>(mat, F, P, nullptr, dO);
-#pragma unroll
-        for (int e = 0; e < 9; ++e) s_P[q][e] = P[e];
+            for (int e = 0; e < 9; ++e) s_A[q][9 * ij + e] = row[e];
+        } else {
+            ho_row<false>(mat, s_C[q], s_F[q], ij / 3, ij % 3, s_JI[q][9], Pij, nullptr);
+        }
+        s_P[q][ij] = Pij;
     }
     __syncthreads();
 
@@ -333,7 +351,11 @@ int host_material_eval(const tb_material *mat, const double *F9, double *psi, do
     const HOParams p = make_params(&tmp);
     double F[3][3], Pl[9], Al[81];
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) F[i][j] = F9[3 * i + j];
-    const double v = ho_stress_tangent<true>(p, F, Pl, Al);
+    // evaluated through the same split routines the kernels use (ho_common + ho_row)
+    double C[HOC_SIZE];
+    ho_common(p, F, C);
+    for (int ij = 0; ij < 9; ++ij) ho_row<true>(p, C, F9, ij / 3, ij % 3, 1.0, Pl[ij], Al + 9 * ij);
+    const double v = C[HOC_PSI];
     if (psi) *psi = v;
     if (P) for (int i = 0; i < 9; ++i) P[i] = Pl[i];
     if (A) for (int i = 0; i < 81; ++i) A[i] = Al[i];
