@@ -100,6 +100,10 @@ typedef struct tb_material {
     int32_t reserved;
     double p[16];               /* HO2009: a, b, aᶠ, bᶠ, aˢ, bˢ, aᶠˢ, bᶠˢ, β (struct field order) */
     double f[3], s[3], n[3];    /* ConstantCoefficient(OrthotropicMicrostructure(f, s, n)) */
+    const double *fsn_field;    /* optional HOST pointer: nodal frames of an OrthotropicMicrostructureModel of FieldCoefficients
+                                   (microstructure.jl:145-187), [cell][geometry node 0..7][f|s|n][3]; interpolated with the
+                                   first-order shape functions, normalised and Gram–Schmidt-orthogonalised per point; NULL → f,s,n */
+    int64_t fsn_field_len;      /* n_cells·8·9 */
 } tb_material;
 
 /* ionic models (src/modeling/cells/{fhn,aliev-panfilov,pcg2019}.jl) and state layouts (src/modeling/solution_variables.jl:40-68) */

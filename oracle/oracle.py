@@ -299,6 +299,16 @@ def ho_energy(F, p=HO_DEFAULTS, fsn=np.eye(3)):
     return psi, P, A
 
 
+def set_microstructure_field(field):
+    """field: (n_cells, 8, 3, 3) nodal f,s,n or None (constant frame)."""
+    global _FSN_KEEP
+    _FSN_KEEP = None if field is None else _f64(field)
+    lib().orc_set_microstructure_field(_d(_FSN_KEEP))
+
+
+_FSN_KEEP = None
+
+
 def element_hyperelastic(mesh, cell, ue, p=HO_DEFAULTS, fsn=np.eye(3), want_K=True, want_r=True):
     nd = mesh.cell_dofs.shape[1]
     Ke = np.zeros((nd, nd)) if want_K else None

@@ -1102,8 +1102,14 @@ double orc_ho_energy(const double *p, const double *fsn, const double *F, double
 
 /* src/modeling/solid/elements.jl:177-313.  Vector-valued shape functions: dof 3a+c ↔ e_c ⊗ ∇N_a
  * (node-major, component-minor: src/ferrite-addons/io.jl:233-238). */
+/* nodal microstructure field (OrthotropicMicrostructureModel of FieldCoefficients, microstructure.jl:145-187): per cell
+ * and geometric node f,s,n (9 doubles); interpolated with the first-order shape functions, normalised and
+ * Gram–Schmidt-orthogonalised at the quadrature point (utils.jl:131-139).  NULL → constant frame `fsn`. */
+static const double *g_fsn_field = NULL;
+void orc_set_microstructure_field(const double *field) { g_fsn_field = field; }
+
 static int element_hyperelastic_cv(const orc_mesh *m, const cellvalues *cv, int64_t cell, const double *p,
-                                   const double *fsn, const double *ue, double *Ke, double *re)
+                                   const double *fsn_const, const double *ue, double *Ke, double *re)
 {
     double x[24], dNdx[3 * MAXNB], P[9], A[81];
     int nb = cv->nb, nd = 3 * nb;
@@ -1116,6 +1122,18 @@ static int element_hyperelastic_cv(const orc_mesh *m, const cellvalues *cv, int6
         for (int a = 0; a < nb; ++a)
             for (int c = 0; c < 3; ++c)
                 for (int k = 0; k < 3; ++k) F[3 * c + k] += ue[3 * a + c] * dNdx[3 * a + k];
+        double frame[9];
+        const double *fsn = fsn_const;
+        if (g_fsn_field) {
+            const double *base = g_fsn_field + (int64_t)cell * cv->ngeo * 9;
+            double tmp[24];
+            for (int which = 0; which < 3; ++which) {
+                for (int a = 0; a < cv->ngeo; ++a) for (int d = 0; d < 3; ++d) tmp[3 * a + d] = base[9 * a + 3 * which + d];
+                orc_eval_field(cv->ngeo, 3, cv->M[q], tmp, frame + 3 * which);
+            }
+            orc_orthogonalize(3, frame, frame + 3, frame + 6);
+            fsn = frame;
+        }
         orc_ho_energy(p, fsn, F, P, Ke ? A : NULL);
         for (int i = 0; i < nd; ++i) {
             int a = i / 3, c = i % 3;

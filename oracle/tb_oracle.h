@@ -163,6 +163,8 @@ int orc_element_hyperelastic(const orc_mesh *m, int64_t cell, const double *p, c
 /* update_linearization!(op, residual, u, p) / residual!(op, residual, u, p) call sites
  * src/solver/nonlinear/newton_raphson.jl:234-238: zero-fill, cell loop, load_element_unknowns!
  * (elements.jl:125-132), element kernel, assemble!.  nzval and/or r may be NULL. */
+/* nodal f,s,n field for the hyperelastic routines ([cell][geometry node][f|s|n][3]); NULL restores the constant frame */
+void orc_set_microstructure_field(const double *field);
 int orc_assemble_hyperelastic(const orc_mesh *m, const double *p, const double *fsn, const double *u,
                               const int64_t *rowptr, const int32_t *colidx, double *nzval, double *r, int nthreads,
                               const int32_t *color, int ncolors);

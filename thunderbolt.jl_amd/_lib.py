@@ -33,7 +33,7 @@ class tb_coef(C.Structure):
 
 class tb_material(C.Structure):
     _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("p", C.c_double * 16), ("f", C.c_double * 3),
-                ("s", C.c_double * 3), ("n", C.c_double * 3)]
+                ("s", C.c_double * 3), ("n", C.c_double * 3), ("fsn_field", c_dp), ("fsn_field_len", C.c_int64)]
 
 
 # name -> (restype, argtypes): every symbol include/tbhip.h declares

@@ -734,8 +734,8 @@ class PK1Model:
 
     def __init__(self, material, microstructure):
         ms = microstructure.val if isinstance(microstructure, ConstantCoefficient) else microstructure
-        if not isinstance(ms, OrthotropicMicrostructure):
-            raise TypeError("PK1Model: constant OrthotropicMicrostructure expected")
+        if not isinstance(ms, (OrthotropicMicrostructure, OrthotropicMicrostructureModel)):
+            raise TypeError("PK1Model: OrthotropicMicrostructure (constant) or OrthotropicMicrostructureModel (nodal fields) expected")
         self.material, self.microstructure = material, ms
 
     def lower(self):
@@ -743,8 +743,14 @@ class PK1Model:
         m.kind = L.TB_MATERIAL_HOLZAPFEL_OGDEN_2009
         for i, v in enumerate(self.material.p):
             m.p[i] = v
-        for i in range(3):
-            m.f[i], m.s[i], m.n[i] = self.microstructure.f[i], self.microstructure.s[i], self.microstructure.n[i]
+        if isinstance(self.microstructure, OrthotropicMicrostructureModel):
+            self._keep = self.microstructure.fsn           # [cell][node][f|s|n][3]
+            m.fsn_field = self._keep.ctypes.data_as(L.c_dp)
+            m.fsn_field_len = self._keep.size
+            m.f[0], m.s[1], m.n[2] = 1.0, 1.0, 1.0
+        else:
+            for i in range(3):
+                m.f[i], m.s[i], m.n[i] = self.microstructure.f[i], self.microstructure.s[i], self.microstructure.n[i]
         return m
 
 

@@ -416,6 +416,15 @@ int tb_hyperelastic_create(tb_mesh *mesh, int qorder, const tb_material *materia
     if (qorder == 0) qorder = std::max(2 * kind_order(mesh->field_kind) - 1, 2);
     auto f = std::make_unique<tb_form>();
     f->mesh = mesh; f->kind = TB_FORM_HYPERELASTIC; f->qorder = qorder; f->mat = *material;
+    f->mat.fsn_field = nullptr;
+    if (material->fsn_field) {
+        const int64_t need = mesh->n_cells * 72;
+        TB_REQUIRE(material->fsn_field_len == need, "tb_hyperelastic_create: microstructure field needs %lld values, got %lld", (long long)need,
+                   (long long)material->fsn_field_len);
+        TB_HIP(hipMalloc((void **)&f->d_field, sizeof(double) * need));
+        TB_HIP(hipMemcpyAsync(f->d_field, material->fsn_field, sizeof(double) * need, hipMemcpyHostToDevice, mesh->dev->stream));
+        TB_HIP(hipStreamSynchronize(mesh->dev->stream));
+    }
     *out = f.release();
     return TB_OK;
 }

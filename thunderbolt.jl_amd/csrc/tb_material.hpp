@@ -124,7 +124,7 @@ TB_HD double ho_stress_tangent(const HOParams &m, const double (&F)[3][3], doubl
 namespace tbk {
 
 enum { HOC_FI = 0, HOC_B = 9, HOC_M = 18, HOC_AV = 27, HOC_BV = 30, HOC_H1 = 33, HOC_H1B, HOC_W1F2, HOC_W2F4, HOC_W1S2, HOC_W2S4,
-       HOC_V1, HOC_V2, HOC_U1, HOC_U2, HOC_G, HOC_TRC, HOC_PSI, HOC_SIZE = 48 };
+       HOC_V1, HOC_V2, HOC_U1, HOC_U2, HOC_G, HOC_TRC, HOC_PSI, HOC_FV, HOC_SV = HOC_FV + 3, HOC_SIZE = 52 };
 
 TB_HD void ho_common(const HOParams &m, const double (&F)[3][3], double *C)
 {
@@ -179,9 +179,26 @@ TB_HD void ho_common(const HOParams &m, const double (&F)[3][3], double *C)
     C[HOC_V1] = m.afs * I8 * E8; C[HOC_V2] = m.afs * E8 * (1.0 + 2.0 * m.bfs * I8 * I8);
     C[HOC_U1] = 2.0 * m.beta * (J2 - 1.0); C[HOC_U2] = 4.0 * m.beta * J2;
     C[HOC_G] = g; C[HOC_TRC] = trC; C[HOC_PSI] = psi;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { C[HOC_FV + i] = m.f[i]; C[HOC_SV + i] = m.s[i]; }
 }
 
-TB_HD double sel3(int k, double a, double b, double c) { return k == 0 ? a : (k == 1 ? b : c); }
+// orthogonalize_system(f,s,n): normalise, then Gram–Schmidt without renormalising w₂ (src/utils.jl:131-139)
+TB_HD void ho_orthonormal_frame(double (&f)[3], double (&s)[3], double (&n)[3])
+{
+    const double rf = 1.0 / sqrt(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]);
+    const double rs = 1.0 / sqrt(s[0] * s[0] + s[1] * s[1] + s[2] * s[2]);
+    const double rn = 1.0 / sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { f[d] *= rf; s[d] *= rs; n[d] *= rn; }
+    const double fs = f[0] * s[0] + f[1] * s[1] + f[2] * s[2];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) s[d] -= fs * f[d];
+    const double fn = f[0] * n[0] + f[1] * n[1] + f[2] * n[2];
+    const double sn = s[0] * n[0] + s[1] * n[1] + s[2] * n[2];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) n[d] = n[d] - fn * f[d] - sn * s[d];
+}
 
 // row (i,j) of P and 𝔸 from the common block (C and F may live in LDS; i, j may differ per lane)
 template <bool NEED_A>
@@ -189,7 +206,7 @@ TB_HD void ho_row(const HOParams &m, const double *C, const double *F, int i, in
 {
     const double Bij = C[HOC_B + 3 * i + j], Mij = C[HOC_M + 3 * i + j], Fiji = C[HOC_FI + 3 * j + i];
     const double avi = C[HOC_AV + i], bvi = C[HOC_BV + i];
-    const double fj = sel3(j, m.f[0], m.f[1], m.f[2]), sj = sel3(j, m.s[0], m.s[1], m.s[2]);
+    const double fj = C[HOC_FV + j], sj = C[HOC_SV + j]; // frame of THIS point (constant or interpolated nodal field)
     const double h1 = C[HOC_H1], h1b = C[HOC_H1B], w1f2 = C[HOC_W1F2], w2f4 = C[HOC_W2F4], w1s2 = C[HOC_W1S2], w2s4 = C[HOC_W2S4];
     const double v1 = C[HOC_V1], v2 = C[HOC_V2], u1 = C[HOC_U1], u2 = C[HOC_U2], g = C[HOC_G], trC = C[HOC_TRC];
     P_ij = scale * (h1 * Bij + w1f2 * avi * fj + w1s2 * bvi * sj + v1 * Mij + u1 * Fiji);
@@ -204,9 +221,10 @@ TB_HD void ho_row(const HOParams &m, const double *C, const double *F, int i, in
                 const double Filk = C[HOC_FI + 3 * l + k], Bkl = C[HOC_B + 3 * k + l], Mkl = C[HOC_M + 3 * k + l];
                 const double d2I1 = -(2.0 / 3.0) * Filk * Bij + g * (2.0 * dik * djl - (4.0 / 3.0) * F[3 * k + l] * Fiji + (2.0 / 3.0) * trC * Fij_[k] * Fi_i[l]);
                 double t = h1 * d2I1 + h1b * Bij * Bkl;
-                t += w2f4 * avi * fj * C[HOC_AV + k] * m.f[l] + w1f2 * dik * fj * m.f[l];
-                t += w2s4 * bvi * sj * C[HOC_BV + k] * m.s[l] + w1s2 * dik * sj * m.s[l];
-                t += v2 * Mij * Mkl + v1 * dik * (sj * m.f[l] + fj * m.s[l]);
+                const double fl = C[HOC_FV + l], sl = C[HOC_SV + l];
+                t += w2f4 * avi * fj * C[HOC_AV + k] * fl + w1f2 * dik * fj * fl;
+                t += w2s4 * bvi * sj * C[HOC_BV + k] * sl + w1s2 * dik * sj * sl;
+                t += v2 * Mij * Mkl + v1 * dik * (sj * fl + fj * sl);
                 t += u2 * Fiji * Filk - u1 * Fij_[k] * Fi_i[l];
                 Arow[3 * k + l] = scale * t;
             }

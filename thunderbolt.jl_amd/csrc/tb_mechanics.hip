@@ -74,6 +74,7 @@ using Q2Vec = VecField<27, 3, 3, 256, 3>;  // 243 threads: node a × 9 groups of
 template <class FE> struct MechTables {
     double dN[FE::NQ][FE::NB][3];
     double dM[FE::NQ][8][3];
+    double M[FE::NQ][8]; // first-order shape values (nodal microstructure fields)
     double w[FE::NQ];
 };
 template <class FE> constexpr MechTables<FE> make_mech_tables()
@@ -83,8 +84,10 @@ template <class FE> constexpr MechTables<FE> make_mech_tables()
         t.w[q] = FE::w(q);
         for (int a = 0; a < FE::NB; ++a)
             for (int d = 0; d < 3; ++d) t.dN[q][a][d] = FE::dN(q, a, d);
-        for (int a = 0; a < 8; ++a)
+        for (int a = 0; a < 8; ++a) {
+            t.M[q][a] = 0.125 * (1.0 + hex_sgn(a, 0) * FE::xi(q, 0)) * (1.0 + hex_sgn(a, 1) * FE::xi(q, 1)) * (1.0 + hex_sgn(a, 2) * FE::xi(q, 2));
             for (int d = 0; d < 3; ++d) t.dM[q][a][d] = FE::dM(q, a, d);
+        }
     }
     return t;
 }
@@ -94,6 +97,7 @@ struct MechMesh {
     const double *xyz;
     const int32_t *conn;
     const int32_t *cell_dofs;
+    const double *fsn_field; // per cell and geometric node: f,s,n (9 doubles); NULL → constant frame of the material
 };
 
 // position of column dof(b,0) inside row dof(a,0), per cell and node pair (the three component rows of a node
@@ -130,11 +134,10 @@ k_hyperelastic(MechMesh m, HOParams mat, const int32_t *__restrict__ list, const
     __shared__ double s_ue[ND], s_x[24], s_JI[NQ][10], s_G[NQ][NB][3], s_P[NQ][9];
     __shared__ double s_A[NEED_K ? NQ : 1][81];
     // phase A scratch (common blocks + F) and phase B's double-buffered T share one region
-    constexpr int TC_SIZE = (NEED_K && 2 * NB * 27 > NQ * (HOC_SIZE + 9)) ? 2 * NB * 27 : NQ * (HOC_SIZE + 9);
+    constexpr int TC_SIZE = (NEED_K && 2 * NB * 27 > NQ * HOC_SIZE) ? 2 * NB * 27 : NQ * HOC_SIZE;
     __shared__ double s_TC[TC_SIZE];
     double (*s_T)[NB][27] = reinterpret_cast<double (*)[NB][27]>(s_TC);
     double (*s_C)[HOC_SIZE] = reinterpret_cast<double (*)[HOC_SIZE]>(s_TC);
-    double (*s_F)[9] = reinterpret_cast<double (*)[9]>(s_TC + NQ * HOC_SIZE);
     __shared__ int32_t s_dof[ND];
 
     // load_element_unknowns! (elements.jl:125-132) + cell coordinates
@@ -180,15 +183,28 @@ k_hyperelastic(MechMesh m, HOParams mat, const int32_t *__restrict__ list, const
         const int q = t / 9, ck = t % 9, c = ck / 3, k = ck % 3;
         double v = c == k ? 1.0 : 0.0;
         for (int a = 0; a < NB; ++a) v += s_ue[3 * a + c] * s_G[q][a][k];
-        s_F[q][ck] = v;
+        s_JI[q][ck] = v; // J⁻¹ is dead after A2: its slots carry F from here on
     }
     __syncthreads();
     // A3b: the quantities shared by all entries of P and 𝔸 at a point (one lane per point)
     if (tid < NQ) {
         double F[3][3];
 #pragma unroll
-        for (int e = 0; e < 9; ++e) F[e / 3][e % 3] = s_F[tid][e];
-        ho_common(mat, F, s_C[tid]);
+        for (int e = 0; e < 9; ++e) F[e / 3][e % 3] = s_JI[tid][e];
+        HOParams mq = mat;
+        if (m.fsn_field) { // interpolate the nodal frame, normalise, Gram–Schmidt (microstructure.jl:176-187)
+            double f[3] = {0, 0, 0}, s[3] = {0, 0, 0}, n[3] = {0, 0, 0};
+            const double *fc = m.fsn_field + cell * 72;
+            for (int a = 0; a < 8; ++a) {
+                const double Na = tb.M[tid][a];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) { f[d] += Na * fc[9 * a + d]; s[d] += Na * fc[9 * a + 3 + d]; n[d] += Na * fc[9 * a + 6 + d]; }
+            }
+            ho_orthonormal_frame(f, s, n);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { mq.f[d] = f[d]; mq.s[d] = s[d]; mq.n[d] = n[d]; }
+        }
+        ho_common(mq, F, s_C[tid]);
     }
     __syncthreads();
     // A3c: one lane per (point, i, j): row (i,j) of P·dΩ and 𝔸·dΩ
@@ -197,11 +213,11 @@ k_hyperelastic(MechMesh m, HOParams mat, const int32_t *__restrict__ list, const
         double Pij;
         if constexpr (NEED_K) {
             double row[9];
-            ho_row<true>(mat, s_C[q], s_F[q], ij / 3, ij % 3, s_JI[q][9], Pij, row);
+            ho_row<true>(mat, s_C[q], s_JI[q], ij / 3, ij % 3, s_JI[q][9], Pij, row);
 #pragma unroll
             for (int e = 0; e < 9; ++e) s_A[q][9 * ij + e] = row[e];
         } else {
-            ho_row<false>(mat, s_C[q], s_F[q], ij / 3, ij % 3, s_JI[q][9], Pij, nullptr);
+            ho_row<false>(mat, s_C[q], s_JI[q], ij / 3, ij % 3, s_JI[q][9], Pij, nullptr);
         }
         s_P[q][ij] = Pij;
     }
@@ -394,7 +410,7 @@ static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, doubl
 {
     tb_mesh *m = f->mesh;
     tb_device *dev = m->dev;
-    const MechMesh mm{m->d_xyz, m->d_conn, m->d_cell_dofs};
+    const MechMesh mm{m->d_xyz, m->d_conn, m->d_cell_dofs, f->d_field};
     const HOParams hp = make_params(f);
     const bool ea = strategy == TB_STRATEGY_ELEMENT || strategy == TB_STRATEGY_PATCH;
     if (NEED_K) {

@@ -10,6 +10,8 @@
 // (SGPRs / scalar cache), never through global memory.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "tb_internal.h"
 
 namespace tb {
@@ -210,7 +212,8 @@ static int run(tb_device *dev, const CellParams &P, double *u, double *du, int64
 {
     const int bs = 256;
     int64_t nb = (n + bs - 1) / bs;
-    const int64_t cap = (int64_t)dev->n_cu * 16;
+    static const int per_cu = getenv("TB_REACTION_BLOCKS_PER_CU") ? atoi(getenv("TB_REACTION_BLOCKS_PER_CU")) : 16;
+    const int64_t cap = per_cu > 0 ? (int64_t)dev->n_cu * per_cu : nb;
     if (nb > cap) nb = cap;
     const dim3 grid((unsigned)nb), block(bs);
 #define TB_LAUNCH(L, W) hipLaunchKernelGGL((k_reaction<MODEL, L, W>), grid, block, 0, dev->stream, P, u, du, n, t, dt, substeps, thr)
