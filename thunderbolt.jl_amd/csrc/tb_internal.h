@@ -117,6 +117,7 @@ struct tb_mesh {
     int32_t *d_cell_dofs = nullptr;
     int32_t *d_node_dof0 = nullptr; // vector fields: first dof of every field node
     int64_t n_nodes_field = 0;
+    std::vector<int32_t> h_node_dof0;
     std::vector<double> h_xyz;
     std::vector<int32_t> h_conn, h_cell_dofs;
     std::unique_ptr<tb::ColorPlan> colors;
@@ -155,6 +156,7 @@ struct tb_form {
 namespace tb {
 
 // ---- plan builders (tb_plans.cpp) ----
+void dof_slots(const tb_mesh *m, std::vector<int64_t> &ptr, std::vector<int32_t> &src); // dof → (cell·ndpc + local) slots, cell-ordered
 int build_color_plan(tb_mesh *m);
 int build_ea_plan(tb_mesh *m);
 int build_patch_plan(tb_mesh *m, int cells_per_patch);

@@ -7,11 +7,14 @@
 // The cell loop / load_element_unknowns! / assemble! belong to FerriteOperators (third party); call sites
 // src/solver/nonlinear/newton_raphson.jl:234-238, src/solver/time/homotopy.jl:61-67.
 //
-// One workgroup per cell.  Kₑ never exists as a whole: thread (a, b-group) keeps the 3×3 blocks of its node
-// pairs in registers while the workgroup sweeps the quadrature points; per point the tangent is first
-// contracted with ∇Nₐ once (T[a][c][d][l] = Σ_k ∇Nₐ[k] 𝔸[c][k][d][l], staged in LDS, double-buffered) and then
-// with ∇N_b — 27·NB² FMAs per point instead of 81·NB².  FP64 MFMA equals the FP64 vector rate on CDNA4 and the
-// per-point B-matrices are 3-sparse, so the contraction stays on the VALU.
+// One workgroup per cell.  The tangent is contracted in two steps, T[a][c][d][l] = Σ_k ∇Nₐ[k] 𝔸[c][k][d][l] and then
+// Kₑ[(a,c)][(b,d)] += Σ_l T[a][c][d][l] ∇N_b[l] — 27·NB² FMAs per point instead of 81·NB².
+//  * Q2 (default): the second step is a GEMM per component d, C_d[(a,c)][b] = Σ_(q,l) T_d[(a,c)][(q,l)] · ∇N[(q,l)][b]
+//    (M = 81, N = 27, K = 81), run on v_mfma_f64_16x16x4_f64: 6×2 tiles × 3 d, 21 k-steps.  The A operand (one T entry
+//    per lane) is formed in registers from 𝔸 and ∇N straight out of LDS, so T is never staged.  FP64 MFMA is not faster
+//    than FP64 vector FMAs on CDNA4 (measured 48 vs 70 TFLOP/s, scripts/microbench/mfma_f64.hip) — the point is operand
+//    reuse: the vector version needs one LDS double per 2.25 FMAs and is LDS-bandwidth-bound at ≈20 % of peak.
+//  * Q1 and the comparison build (TB_MECH_MFMA=0): thread (a, b-group) keeps 3×3 blocks in registers, T staged in LDS.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -121,7 +124,13 @@ __global__ void k_build_blockpos(const int32_t *__restrict__ cell_dofs, int64_t 
     pos[tid] = (uint16_t)(lo - lo0);
 }
 
-template <class FE, bool NEED_K, bool NEED_R>
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+#ifndef TB_KE_DMAJOR
+#define TB_KE_DMAJOR 0
+#endif
+constexpr bool KE_DMAJOR = TB_KE_DMAJOR; // stored-Kₑ row layout of the matrix-core kernel: [d][b] or [b][d]
+
+template <class FE, bool NEED_K, bool NEED_R, bool MFMA>
 __global__ void __launch_bounds__(FE::THREADS, FE::WAVES)
 k_hyperelastic(MechMesh m, HOParams mat, const int32_t *__restrict__ list, const double *__restrict__ u, double *__restrict__ nz,
                double *__restrict__ r, const int64_t *__restrict__ rowptr, const uint16_t *__restrict__ blockpos, int atomic /*0 rmw, 1 atomic, 2 store Kₑ/rₑ*/,
@@ -134,7 +143,7 @@ k_hyperelastic(MechMesh m, HOParams mat, const int32_t *__restrict__ list, const
     __shared__ double s_ue[ND], s_x[24], s_JI[NQ][10], s_G[NQ][NB][3], s_P[NQ][9];
     __shared__ double s_A[NEED_K ? NQ : 1][81];
     // phase A scratch (common blocks + F) and phase B's double-buffered T share one region
-    constexpr int TC_SIZE = (NEED_K && 2 * NB * 27 > NQ * HOC_SIZE) ? 2 * NB * 27 : NQ * HOC_SIZE;
+    constexpr int TC_SIZE = (NEED_K && !MFMA && 2 * NB * 27 > NQ * HOC_SIZE) ? 2 * NB * 27 : NQ * HOC_SIZE;
     __shared__ double s_TC[TC_SIZE];
     double (*s_T)[NB][27] = reinterpret_cast<double (*)[NB][27]>(s_TC);
     double (*s_C)[HOC_SIZE] = reinterpret_cast<double (*)[HOC_SIZE]>(s_TC);
@@ -223,6 +232,79 @@ k_hyperelastic(MechMesh m, HOParams mat, const int32_t *__restrict__ list, const
     }
     __syncthreads();
 
+    double racc = 0.0;
+    if constexpr (NEED_K && MFMA) {
+        // B (matrix cores): wave w owns nine of the 36 output tiles (M-tile mt, component d, N-tile nt): four A-operand
+        // kinds (mt,d) with both N-tiles and one more with a single N-tile.  Rows ≥ ND / columns ≥ NB of the padded tiles
+        // hold finite garbage that is never stored; only the K padding (kk ≥ 3·NQ) must vanish, which the B operand does.
+        static_assert(T == 256 && ND <= 96 && NB <= 32, "tile assignment below is for 6×2×3 tiles on four waves");
+        constexpr int KS = (3 * NQ + 3) / 4;
+        const int lane = tid & 63, wv = tid >> 6, lr = lane & 15, g = lane >> 4;
+        int offG[5], offA[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int kind = i < 4 ? 4 * wv + i : 16 + (wv >> 1), mt = kind / 3, d = kind % 3;
+            const int R = 16 * mt + lr, Rc = R < ND ? R : 0;
+            offG[i] = 3 * (Rc / 3);
+            offA[i] = 27 * (Rc % 3) + 3 * d;
+        }
+        const int b1 = 16 + lr < NB ? 16 + lr : 0;
+        const bool odd = wv & 1;
+        mfma_d4 acc[4][2], acc4 = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc[i][0] = mfma_d4{0, 0, 0, 0}; acc[i][1] = mfma_d4{0, 0, 0, 0}; }
+        const double *sG = &s_G[0][0][0], *sA = &s_A[0][0];
+#pragma unroll 3
+        for (int s = 0; s < KS; ++s) {
+            const int kk = 4 * s + g;
+            const bool kv = kk < 3 * NQ;
+            const int kc = kv ? kk : 0, q = kc / 3, l = kc - 3 * q;
+            const double *gq = sG + q * (NB * 3), *aq = sA + q * 81 + l;
+            double B0 = gq[3 * lr + l], B1 = gq[3 * b1 + l];
+            if (!kv) { B0 = 0.0; B1 = 0.0; }
+            double Aop[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const double *gg = gq + offG[i], *aa = aq + offA[i];
+                Aop[i] = gg[0] * aa[0] + gg[1] * aa[9] + gg[2] * aa[18];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop[i], B0, acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop[i], B1, acc[i][1], 0, 0, 0);
+            }
+            acc4 = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop[4], odd ? B1 : B0, acc4, 0, 0, 0);
+        }
+        if constexpr (NEED_R) {
+            if (tid < ND) {
+                for (int q = 0; q < NQ; ++q) {
+                    const double *gr = s_G[q][tid / 3];
+                    const double *p = s_P[q] + 3 * (tid % 3);
+                    racc += gr[0] * p[0] + gr[1] * p[1] + gr[2] * p[2];
+                }
+            }
+        }
+        // C: D[row = g + 4·reg][col = lr] of tile (mt, d, nt) is Kₑ[(a,c) = 16·mt + row][(b,d), b = 16·nt + col]
+        auto emit = [&](const mfma_d4 &v, int kind, int nt) {
+            const int mt = kind / 3, d = kind % 3, b = 16 * nt + lr;
+            if (b >= NB) return;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int R = 16 * mt + g + 4 * rg;
+                if (R >= ND) continue;
+                if (atomic == 2) { // element assembly: row R of Kₑ leaves as three runs (d) of NB consecutive doubles
+                    ke[((int64_t)cell * ND + R) * ND + (KE_DMAJOR ? d * NB + b : 3 * b + d)] = v[rg];
+                } else {
+                    const int a = R / 3, c = R - 3 * a;
+                    const int64_t k = rowptr[s_dof[3 * a] + c] + blockpos[cell * (NB * NB) + a * NB + b] + d;
+                    if (atomic) unsafeAtomicAdd(nz + k, v[rg]); else nz[k] += v[rg];
+                }
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { emit(acc[i][0], 4 * wv + i, 0); emit(acc[i][1], 4 * wv + i, 1); }
+        emit(acc4, 16 + (wv >> 1), odd ? 1 : 0);
+    } else {
     // B: sweep the points
     const int a_own = tid / NG, bg = tid % NG;
     const bool pair_thread = tid < NB * NG;
@@ -231,7 +313,6 @@ k_hyperelastic(MechMesh m, HOParams mat, const int32_t *__restrict__ list, const
     for (int pb = 0; pb < (NEED_K ? PB : 1); ++pb)
 #pragma unroll
         for (int e = 0; e < 9; ++e) Kacc[pb][e] = 0.0;
-    double racc = 0.0;
     auto stage_T = [&](int q, int buf) {
         for (int idx = tid; idx < NB * 27; idx += T) {
             const int a = idx / 27, e = idx % 27, c = e / 9, dl = e % 9; // T[a][c][d][l], dl = 3d + l
@@ -295,6 +376,7 @@ k_hyperelastic(MechMesh m, HOParams mat, const int32_t *__restrict__ list, const
             }
         }
     }
+    }
     if constexpr (NEED_R) {
         if (tid < ND) {
             if (atomic == 2) re[cell * ND + tid] = racc;
@@ -305,49 +387,89 @@ k_hyperelastic(MechMesh m, HOParams mat, const int32_t *__restrict__ list, const
 }
 
 
-// ElementAssemblyStrategy for the tangent: second pass, one wave per node.  The node's three rows are summed in LDS
-// from the ≤8 element matrices that touch it — each contribution is a contiguous ND-long run of Kₑ, added in cell
-// order with plain read-modify-writes (bit-reproducible) — and every row is stored once, coalesced.
-template <int NB>
+// ElementAssemblyStrategy for the tangent: second pass, one wave per node.  A lane owns *positions* of the node's three
+// CSR rows, not source entries: per cell touching the node a byte map "neighbour-node slot of the row → local node b" is
+// built in LDS from blockpos (27 byte stores), then every lane sums its entry over the ≤8 element matrices in cell order —
+// independent loads, all in flight together, no accumulator in LDS, each nz stored once (bit-reproducible like the
+// reference's EA strategy).  DMAJOR: row layout of the stored Kₑ is [d][b] instead of [b][d].
+template <int NB, bool DMAJOR, int NK>
+__device__ __forceinline__ void gather_rows(const double *const (&rowk)[8], const uint8_t *inv, int nbr_max, int L, int lane, double *dst0, bool first)
+{
+    constexpr int ND = 3 * NB;
+    for (int c = 0; c < 3; ++c) {
+        double *dst = dst0 + (int64_t)c * L;
+        for (int p = lane; p < L; p += 64) {
+            const int nbr = p / 3, d = p - 3 * nbr;
+            double v[NK];
+            bool ok[NK];
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const int b = inv[k * nbr_max + nbr];
+                ok[k] = b != 0xFF;
+                const int bb = ok[k] ? b : 0;
+                v[k] = rowk[k][c * ND + (DMAJOR ? d * NB + bb : 3 * bb + d)];
+            }
+            double sum = 0.0;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) sum += ok[k] ? v[k] : 0.0;
+            if (first) dst[p] = sum; else dst[p] += sum;
+        }
+    }
+}
+
+template <int NB, bool DMAJOR>
 __global__ void __launch_bounds__(256)
 k_gather_node_rows(const int32_t *__restrict__ node_dof0, int64_t n_nodes, const int64_t *__restrict__ ea_ptr, const int32_t *__restrict__ ea_src,
                    const double *__restrict__ ke, const uint16_t *__restrict__ blockpos, const int64_t *__restrict__ rowptr, double *__restrict__ nz,
-                   const double *__restrict__ re, double *__restrict__ r, int max_len)
+                   int nbr_max)
 {
-    constexpr int ND = 3 * NB;
-    extern __shared__ double s_rows[];
+    constexpr int ND = 3 * NB, KC = 8;
+    extern __shared__ uint8_t s_inv[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t node = (int64_t)blockIdx.x * (blockDim.x >> 6) + wv;
     if (node >= n_nodes) return;
-    double *acc = s_rows + (size_t)wv * 3 * max_len;
+    uint8_t *inv = s_inv + (size_t)wv * KC * nbr_max;
     const int32_t dof0 = node_dof0[node];
     const int64_t g0 = rowptr[dof0];
-    const int L = (int)(rowptr[dof0 + 1] - g0);
+    const int L = (int)(rowptr[dof0 + 1] - g0); // rows dof0, dof0+1, dof0+2 are consecutive runs of equal length (checked on the host)
     const int64_t k0 = ea_ptr[dof0], k1 = ea_ptr[dof0 + 1];
-    if (nz) {
-        for (int k = lane; k < 3 * L; k += 64) acc[k] = 0.0;
-        for (int64_t k = k0; k < k1; ++k) {
-            const int32_t slot = ea_src[k];
+    for (int64_t kb = k0; kb < k1; kb += KC) {
+        const int nk = (int)(k1 - kb < KC ? k1 - kb : KC);
+        const int nkp = nk <= 2 ? nk : nk <= 4 ? 4 : 8; // padded slots repeat cell 0 with an all-0xFF map: contribute nothing
+        for (int i = lane; i < nkp * nbr_max / 4; i += 64) reinterpret_cast<uint32_t *>(inv)[i] = 0xFFFFFFFFu;
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < nk * NB; i += 64) {
+            const int k = i / NB, b = i - k * NB;
+            const int32_t slot = ea_src[kb + k];
             const int64_t cell = slot / ND;
             const int a = (slot % ND) / 3;
-            const double *src = ke + ((int64_t)cell * ND + 3 * a) * ND;
-            const uint16_t *bp = blockpos + cell * (NB * NB) + a * NB;
-            for (int idx = lane; idx < 3 * ND; idx += 64) {
-                const int c = idx / ND, j = idx % ND;
-                acc[c * L + bp[j / 3] + j % 3] += src[(int64_t)c * ND + j];
-            }
-            __builtin_amdgcn_wave_barrier();
+            inv[k * nbr_max + blockpos[cell * (NB * NB) + a * NB + b] / 3] = (uint8_t)b;
         }
-        for (int c = 0; c < 3; ++c) {
-            double *dst = nz + rowptr[dof0 + c];
-            for (int k = lane; k < L; k += 64) dst[k] = acc[c * L + k];
+        __builtin_amdgcn_wave_barrier();
+        const double *rowk[8];
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            const int32_t slot = ea_src[kb + (k < nk ? k : 0)];
+            rowk[k] = ke + ((int64_t)(slot / ND) * ND + 3 * ((slot % ND) / 3)) * ND;
         }
+        const bool first = kb == k0;
+        if (nkp == 1) gather_rows<NB, DMAJOR, 1>(rowk, inv, nbr_max, L, lane, nz + g0, first);
+        else if (nkp == 2) gather_rows<NB, DMAJOR, 2>(rowk, inv, nbr_max, L, lane, nz + g0, first);
+        else if (nkp == 4) gather_rows<NB, DMAJOR, 4>(rowk, inv, nbr_max, L, lane, nz + g0, first);
+        else gather_rows<NB, DMAJOR, 8>(rowk, inv, nbr_max, L, lane, nz + g0, first);
+        __builtin_amdgcn_wave_barrier();
     }
-    if (r && lane < 3) {
-        double s = 0.0;
-        for (int64_t k = k0; k < k1; ++k) s += re[ea_src[k] + lane];
-        r[dof0 + lane] = s;
-    }
+}
+
+// element residuals → global residual: r[d] = Σ (in cell order) rₑ slots of dof d
+__global__ void k_gather_residual(const int64_t *__restrict__ ptr, const int32_t *__restrict__ src, const double *__restrict__ re, int64_t ndofs,
+                                  double *__restrict__ r)
+{
+    const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= ndofs) return;
+    double s = 0.0;
+    for (int64_t k = ptr[d]; k < ptr[d + 1]; ++k) s += re[src[k]];
+    r[d] = s;
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -390,7 +512,24 @@ static int build_node_list(tb_mesh *m)
     }
     std::sort(d0.begin(), d0.end());
     m->n_nodes_field = (int64_t)d0.size();
+    m->h_node_dof0 = d0;
     return upload(m->dev, d0, &m->d_node_dof0);
+}
+
+// the gather kernel relies on the three rows of a node being equal-length runs of whole nodes
+static int check_node_rows(tb_pattern *p)
+{
+    if (p->max_row_len) return TB_OK;
+    const tb_mesh *m = p->mesh;
+    for (int32_t d : m->h_node_dof0) {
+        const int64_t L = p->h_rowptr[d + 1] - p->h_rowptr[d];
+        if (L % 3 || L != p->h_rowptr[d + 2] - p->h_rowptr[d + 1] || L != p->h_rowptr[d + 3] - p->h_rowptr[d + 2] || L / 3 > 254) {
+            set_error("element assembly gather: rows of node dof %d are not three equal runs of whole nodes (L = %lld)", d, (long long)L);
+            return TB_ERR_PATTERN;
+        }
+        p->max_row_len = std::max<int64_t>(p->max_row_len, L);
+    }
+    return TB_OK;
 }
 
 static int ensure_blockpos(tb_pattern *p)
@@ -405,7 +544,7 @@ static int ensure_blockpos(tb_pattern *p)
     return TB_OK;
 }
 
-template <class FE, bool NEED_K, bool NEED_R>
+template <class FE, bool NEED_K, bool NEED_R, bool MFMA>
 static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, double *d_nz, double *d_r)
 {
     tb_mesh *m = f->mesh;
@@ -424,7 +563,7 @@ static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, doubl
     double *kebuf = nullptr, *rebuf = nullptr;
     auto go = [&](const int32_t *list, int64_t n, int atomic) -> int {
         if (!n) return TB_OK;
-        hipLaunchKernelGGL((k_hyperelastic<FE, NEED_K, NEED_R>), dim3((unsigned)n), dim3(FE::THREADS), 0, dev->stream, mm, hp, list, d_u, d_nz, d_r,
+        hipLaunchKernelGGL((k_hyperelastic<FE, NEED_K, NEED_R, MFMA>), dim3((unsigned)n), dim3(FE::THREADS), 0, dev->stream, mm, hp, list, d_u, d_nz, d_r,
                            rowptr, bp, atomic, kebuf, rebuf, dev->d_status);
         TB_HIP(hipGetLastError());
         return TB_OK;
@@ -432,7 +571,6 @@ static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, doubl
     if (ea) {
         // ElementAssemblyStrategy (default for mechanics): Kₑ / rₑ stored per cell, then gathered per node row
         if (!m->ea) { int rc = build_ea_plan(m); if (rc) return rc; }
-        if (!m->d_node_dof0) { int rc = build_node_list(m); if (rc) return rc; }
         rebuf = m->ea->d_ea;
         if (NEED_K) {
             if (!p->d_kebuf) {
@@ -443,15 +581,22 @@ static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, doubl
         }
         int rc = go(nullptr, m->n_cells, 2);
         if (rc) return rc;
-        int max_len = 1;
-        if (NEED_K) { if (!p->max_row_len) for (int64_t r = 0; r < p->n_rows; ++r) p->max_row_len = std::max<int64_t>(p->max_row_len, p->h_rowptr[r + 1] - p->h_rowptr[r]); max_len = (int)p->max_row_len; }
-        const size_t lds = (size_t)4 * 3 * max_len * sizeof(double);
-        if (lds > 160 * 1024) { set_error("element assembly gather: rows of %d entries do not fit LDS", max_len); return TB_ERR_UNSUPPORTED; }
-        auto k = k_gather_node_rows<FE::NB>;
-        TB_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k, dim3((unsigned)((m->n_nodes_field + 3) / 4)), dim3(256), lds, dev->stream, m->d_node_dof0, m->n_nodes_field, m->ea->d_ptr,
-                           m->ea->d_src, kebuf, bp, rowptr, NEED_K ? d_nz : (double *)nullptr, rebuf, NEED_R ? d_r : (double *)nullptr, max_len);
-        TB_HIP(hipGetLastError());
+        if (NEED_K) {
+            if (!m->d_node_dof0) { rc = build_node_list(m); if (rc) return rc; }
+            rc = check_node_rows(p);
+            if (rc) return rc;
+            const int nbr_max = (((int)p->max_row_len / 3) + 3) & ~3;
+            const size_t lds = (size_t)4 * 8 * nbr_max;
+            auto k = k_gather_node_rows<FE::NB, MFMA && KE_DMAJOR>;
+            hipLaunchKernelGGL(k, dim3((unsigned)((m->n_nodes_field + 3) / 4)), dim3(256), lds, dev->stream, m->d_node_dof0, m->n_nodes_field,
+                               m->ea->d_ptr, m->ea->d_src, kebuf, bp, rowptr, d_nz, nbr_max);
+            TB_HIP(hipGetLastError());
+        }
+        if (NEED_R) {
+            hipLaunchKernelGGL(k_gather_residual, dim3((unsigned)((m->ndofs + 255) / 256)), dim3(256), 0, dev->stream, m->ea->d_ptr, m->ea->d_src,
+                               rebuf, m->ndofs, d_r);
+            TB_HIP(hipGetLastError());
+        }
         return TB_OK;
     }
     if (strategy == TB_STRATEGY_PER_COLOR) {
@@ -475,9 +620,13 @@ int launch_hyperelastic(tb_form *f, tb_pattern *p, int strategy, const double *d
     const bool q2 = m->field_kind == TB_HEX27;
     if (!q2 && !(m->field_kind == TB_HEX8 && f->qorder == 2)) { set_error("hyperelastic: Q1 field needs quadrature order 2"); return TB_ERR_UNSUPPORTED; }
     if (q2 && f->qorder != 3) { set_error("hyperelastic: Q2 field needs quadrature order 3"); return TB_ERR_UNSUPPORTED; }
-    if (d_nz && d_r) rc = q2 ? run<Q2Vec, true, true>(f, p, strategy, d_u, d_nz, d_r) : run<Q1Vec, true, true>(f, p, strategy, d_u, d_nz, d_r);
-    else if (d_nz) rc = q2 ? run<Q2Vec, true, false>(f, p, strategy, d_u, d_nz, d_r) : run<Q1Vec, true, false>(f, p, strategy, d_u, d_nz, d_r);
-    else rc = q2 ? run<Q2Vec, false, true>(f, p, strategy, d_u, d_nz, d_r) : run<Q1Vec, false, true>(f, p, strategy, d_u, d_nz, d_r);
+    // Q2 tangents run their contraction on the matrix cores; TB_MECH_MFMA=0 selects the vector-FMA build (comparison)
+    static const bool mfma = !(getenv("TB_MECH_MFMA") && atoi(getenv("TB_MECH_MFMA")) == 0);
+    if (d_nz && d_r) rc = !q2 ? run<Q1Vec, true, true, false>(f, p, strategy, d_u, d_nz, d_r)
+                         : mfma ? run<Q2Vec, true, true, true>(f, p, strategy, d_u, d_nz, d_r) : run<Q2Vec, true, true, false>(f, p, strategy, d_u, d_nz, d_r);
+    else if (d_nz) rc = !q2 ? run<Q1Vec, true, false, false>(f, p, strategy, d_u, d_nz, d_r)
+                        : mfma ? run<Q2Vec, true, false, true>(f, p, strategy, d_u, d_nz, d_r) : run<Q2Vec, true, false, false>(f, p, strategy, d_u, d_nz, d_r);
+    else rc = q2 ? run<Q2Vec, false, true, false>(f, p, strategy, d_u, d_nz, d_r) : run<Q1Vec, false, true, false>(f, p, strategy, d_u, d_nz, d_r);
     if (rc) return rc;
     return check_status(m->dev);
 }

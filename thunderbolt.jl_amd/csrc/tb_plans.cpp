@@ -12,7 +12,7 @@
 namespace tb {
 
 // dof → contributing element-vector slots (cell*ndpc + local), ordered by cell
-static void dof_slots(const tb_mesh *m, std::vector<int64_t> &ptr, std::vector<int32_t> &src)
+void dof_slots(const tb_mesh *m, std::vector<int64_t> &ptr, std::vector<int32_t> &src)
 {
     const int64_t n = m->n_cells * m->ndpc;
     ptr.assign(m->ndofs + 1, 0);
