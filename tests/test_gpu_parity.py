@@ -504,3 +504,54 @@ def test_hyperelastic_nodal_fibre_field_parity(tb, oracle, device):
     # and it really differs from the constant-frame result
     Kc, _ = oracle.assemble_hyperelastic(om, u, sp.rowptr, sp.colidx)
     assert rel_err(Kc, Kref) > 1e-3
+
+
+def test_empty_and_ragged_inputs(tb, oracle, device):
+    """Edge shapes: a mesh without cells, zero / one reaction points, and an 'unstructured' presentation of a mesh
+    (cells shuffled, dofs randomly renumbered, two disconnected blocks of very different cell size)."""
+    rng = np.random.default_rng(7)
+    # --- no cells: operators exist, assemble to nothing
+    g1 = tb.generate_mesh(tb.Hexahedron, (1, 1, 1))
+    empty = tb.Grid(tb.Hexahedron, g1.xyz, g1.conn[:0])
+    dh = tb.DofHandler(empty, cell_dofs=np.zeros((0, 8), dtype=np.int32), ndofs=len(g1.xyz))
+    sp = tb.SparsityPattern(np.zeros(len(g1.xyz) + 1, dtype=np.int64), np.zeros(0, dtype=np.int32))
+    for st in strategies(tb, device, matrix=False):
+        b = tb.update_operator(tb.setup_operator(st, tb.LinearIntegrator(tb.AnalyticalCoefficient("const", 1.0)), dh), 0.0)
+        np.testing.assert_array_equal(b.b.to_host(), np.zeros(len(g1.xyz)))
+    for st in strategies(tb, device):
+        K = tb.update_operator(tb.setup_operator(st, tb.BilinearDiffusionIntegrator(tb.ConstantCoefficient(1.0)), dh, sp), 0.0)
+        assert K.A.to_host().size == 0
+    # --- zero and one reaction points
+    model = tb.FHNModel()
+    for npts in (0, 1):
+        f = tb.PointwiseODEFunction(npts, model)
+        host = np.tile(model.default_initial_state(), (npts, 1)).T.ravel().copy()
+        cache = tb.setup_solver_cache(f, tb.ForwardEulerCellSolver(device), u=device.to_device(host) if npts else None)
+        assert tb.perform_step(f, cache, 0.0, 0.1) is True
+        if npts:
+            ref = host.copy()
+            oracle.reaction_step(oracle.CELL_FHN, model.params, ref, npts, oracle.LAYOUT_SOA, t=0.0, dt=0.1)
+            assert rel_err(cache.un.to_host(), ref) < TOL
+    # --- ragged: two disconnected blocks (cell size ratio 20), shuffled cells, permuted dof ids
+    ga = tb.generate_mesh(tb.Hexahedron, (5, 4, 3), (0, 0, 0), (1, 1, 1), perturb=0.2)
+    gb = tb.generate_mesh(tb.Hexahedron, (3, 3, 3), (5, 5, 5), (5.05, 5.05, 5.05), perturb=0.1)
+    xyz = np.vstack([ga.xyz, gb.xyz])
+    conn = np.vstack([ga.conn, gb.conn + len(ga.xyz)])
+    conn = conn[rng.permutation(len(conn))]
+    perm = rng.permutation(len(xyz)).astype(np.int32)
+    cd = perm[conn]
+    g = tb.Grid(tb.Hexahedron, xyz, conn)
+    dh = tb.DofHandler(g, cell_dofs=cd, ndofs=len(xyz))
+    sp = tb.allocate_matrix(dh)
+    rp, ci = oracle.build_pattern(cd, len(xyz))
+    np.testing.assert_array_equal(sp.colidx, ci)
+    om = oracle.Mesh(oracle.HEX8, 2, xyz, conn, cd)
+    D = np.array([[2.0, 0.3, 0.1], [0.3, 1.5, -0.2], [0.1, -0.2, 1.0]])
+    refK = oracle.assemble_matrix(om, 1, oracle.Coef(oracle.COEF_CONST_TENSOR, D.ravel()), rp, ci)
+    refb = oracle.assemble_source(om, oracle.SRC_NORM_PLUS_T, t=0.4)
+    for st in strategies(tb, device):
+        K = tb.update_operator(tb.setup_operator(st, tb.BilinearDiffusionIntegrator(tb.ConstantCoefficient(D)), dh, sp), 0.0)
+        assert rel_err(K.A.to_host(), refK) < TOL, type(st).__name__
+    for st in strategies(tb, device, matrix=False):
+        b = tb.update_operator(tb.setup_operator(st, tb.LinearIntegrator(tb.AnalyticalCoefficient("norm_plus_t")), dh), 0.4)
+        assert rel_err(b.b.to_host(), refb) < TOL, type(st).__name__

@@ -384,11 +384,16 @@ int tb_form_set_table(tb_form *f, const double *values, int64_t n)
 // ------------------------------------------------------------------ assembly
 int tb_assemble_matrix(tb_form *form, tb_pattern *pat, int strategy, double t, double *d_nzval)
 {
-    TB_REQUIRE(form && pat && d_nzval, "tb_assemble_matrix: NULL argument");
+    TB_REQUIRE(form && pat && (d_nzval || pat->nnz == 0), "tb_assemble_matrix: NULL argument");
     TB_REQUIRE(form->mesh == pat->mesh, "tb_assemble_matrix: form and pattern belong to different meshes");
     TB_REQUIRE(form->kind == TB_FORM_MASS || form->kind == TB_FORM_DIFFUSION, "tb_assemble_matrix: form is not bilinear");
     TB_REQUIRE(form->mesh->ncomp == 1, "tb_assemble_matrix: scalar fields only");
+    TB_REQUIRE(strategy >= TB_STRATEGY_ATOMIC && strategy <= TB_STRATEGY_PATCH, "tb_assemble_matrix: unknown strategy %d", strategy);
     TB_HIP(hipSetDevice(form->mesh->dev->id));
+    if (form->mesh->n_cells == 0) { // nothing to integrate: the operator is the zero matrix (outputs are overwritten)
+        if (pat->nnz) TB_HIP(hipMemsetAsync(d_nzval, 0, sizeof(double) * (size_t)pat->nnz, form->mesh->dev->stream));
+        return TB_OK;
+    }
     return launch_assemble_matrix(form, pat, strategy, t, d_nzval);
 }
 
@@ -397,7 +402,12 @@ int tb_assemble_vector(tb_form *form, int strategy, double t, double *d_b)
     TB_REQUIRE(form && d_b, "tb_assemble_vector: NULL argument");
     TB_REQUIRE(form->kind == TB_FORM_SOURCE, "tb_assemble_vector: form is not linear");
     TB_REQUIRE(form->coef.kind != TB_SRC_TABULATED || form->d_table, "tb_assemble_vector: tabulated source without table");
+    TB_REQUIRE(strategy >= TB_STRATEGY_ATOMIC && strategy <= TB_STRATEGY_PATCH, "tb_assemble_vector: unknown strategy %d", strategy);
     TB_HIP(hipSetDevice(form->mesh->dev->id));
+    if (form->mesh->n_cells == 0) {
+        TB_HIP(hipMemsetAsync(d_b, 0, sizeof(double) * (size_t)form->mesh->ndofs, form->mesh->dev->stream));
+        return TB_OK;
+    }
     return launch_assemble_vector(form, strategy, t, d_b);
 }
 
@@ -435,16 +445,25 @@ int tb_residual(tb_form *form, int strategy, const double *d_u, double t, double
     TB_REQUIRE(form && d_u && d_r, "tb_residual: NULL argument");
     TB_REQUIRE(form->kind == TB_FORM_HYPERELASTIC, "tb_residual: form is not nonlinear");
     TB_HIP(hipSetDevice(form->mesh->dev->id));
+    if (form->mesh->n_cells == 0) {
+        TB_HIP(hipMemsetAsync(d_r, 0, sizeof(double) * (size_t)form->mesh->ndofs, form->mesh->dev->stream));
+        return TB_OK;
+    }
     return launch_hyperelastic(form, nullptr, strategy, d_u, nullptr, d_r);
 }
 
 int tb_linearize(tb_form *form, tb_pattern *pat, int strategy, const double *d_u, double t, double *d_nzval, double *d_r)
 {
     (void)t;
-    TB_REQUIRE(form && pat && d_u && d_nzval, "tb_linearize: NULL argument");
+    TB_REQUIRE(form && pat && d_u && (d_nzval || pat->nnz == 0), "tb_linearize: NULL argument");
     TB_REQUIRE(form->kind == TB_FORM_HYPERELASTIC, "tb_linearize: form is not nonlinear");
     TB_REQUIRE(form->mesh == pat->mesh, "tb_linearize: form and pattern belong to different meshes");
     TB_HIP(hipSetDevice(form->mesh->dev->id));
+    if (form->mesh->n_cells == 0) {
+        if (pat->nnz) TB_HIP(hipMemsetAsync(d_nzval, 0, sizeof(double) * (size_t)pat->nnz, form->mesh->dev->stream));
+        if (d_r) TB_HIP(hipMemsetAsync(d_r, 0, sizeof(double) * (size_t)form->mesh->ndofs, form->mesh->dev->stream));
+        return TB_OK;
+    }
     return launch_hyperelastic(form, pat, strategy, d_u, d_nzval, d_r);
 }
 
@@ -525,7 +544,7 @@ int tb_cell_model_defaults(int model, double *params, double *u0)
 int tb_reaction_step(tb_device *dev, int model, const double *params, int n_params, double *d_u, double *d_du,
                      int64_t n_points, int n_states, int layout, double t, double dt, int substeps, double threshold)
 {
-    TB_REQUIRE(dev && params && d_u, "tb_reaction_step: NULL argument");
+    TB_REQUIRE(dev && params && (d_u || n_points == 0), "tb_reaction_step: NULL argument");
     int ns, np;
     int rc = tb_cell_model_info(model, &ns, &np, nullptr);
     if (rc) return rc;
