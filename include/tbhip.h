@@ -208,6 +208,12 @@ int tb_host_material_eval(const tb_material *material, const double *F, double *
 int tb_reaction_step(tb_device *dev, int model, const double *params, int n_params, double *d_u, double *d_du,
                      int64_t n_points, int n_states, int layout, double t, double dt, int substeps,
                      double threshold);
+/* Same step with the reaction tangent fused in: *rmax receives max over points of the φₘ component of the last right-hand
+ * side evaluated at each point — what ReactionTangentController reads from `dumat` after the step (src/solver/time/rtc.jl:55-73)
+ * — without `du` having to be written (d_du may be NULL): 16 instead of 24 bytes per DoF-update. */
+int tb_reaction_step_rtc(tb_device *dev, int model, const double *params, int n_params, double *d_u, double *d_du,
+                         int64_t n_points, int n_states, int layout, double t, double dt, int substeps, double threshold,
+                         double *rmax);
 int tb_cell_model_info(int model, int *n_states, int *n_params, int *phi_index);
 int tb_cell_model_defaults(int model, double *params, double *u0);
 
@@ -225,6 +231,9 @@ int tb_cg_solve(tb_pattern *pat, const double *d_Anz, const double *d_b, double 
  * (RTC reads max(dumat[:,φₘidx]), src/solver/time/rtc.jl:64-73) */
 int tb_axpy(tb_device *dev, int64_t n, double a, const double *d_x, double *d_y);
 int tb_absmax(tb_device *dev, int64_t n, const double *d_x, int64_t stride, double *result);
+/* signed maximum of a strided slice: exactly `maximum(@view dumat[:, φₘidx])` of get_reaction_tangent
+ * (src/solver/time/rtc.jl:64-73 — no absolute value there).  n == 0 yields −∞. */
+int tb_max(tb_device *dev, int64_t n, const double *d_x, int64_t stride, double *result);
 
 /* ------------------------------------------------------------------ host-side generators (no GPU needed)
  * Ferrite-convention synthetic inputs for benchmarks and tests: generate_grid (src/mesh/generators.jl:942),

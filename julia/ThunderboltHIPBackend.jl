@@ -153,5 +153,13 @@ function _pointwise_step_outer_kernel!(f::PointwiseODEFunction, t::Real, Δt::Re
     return rc == 0
 end
 
+# reaction tangent of the RTC controller: `maximum(@view cache.dumat[:, φₘidx])` (src/solver/time/rtc.jl:64-73) on the device
+function reaction_tangent(dev::MI355XDevice, dumat_phi::Ptr{Float64}, npoints::Integer, stride::Integer = 1)
+    R = Ref{Float64}()
+    check(ccall((:tb_max, libtbhip), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}, Int64, Ref{Float64}), dev.handle, npoints, dumat_phi, stride, R))
+    return R[]
+end
+# … or fused into the step itself (no dumat needed): tb_reaction_step_rtc(..., rmax::Ref{Float64})
+
 # heat-step algebra (src/solver/time/euler.jl:85,90,110-116): tb_heat_matrix, tb_spmv_csr, tb_axpy
 end # module

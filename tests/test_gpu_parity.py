@@ -555,3 +555,51 @@ def test_empty_and_ragged_inputs(tb, oracle, device):
     for st in strategies(tb, device, matrix=False):
         b = tb.update_operator(tb.setup_operator(st, tb.LinearIntegrator(tb.AnalyticalCoefficient("norm_plus_t")), dh), 0.4)
         assert rel_err(b.b.to_host(), refb) < TOL, type(st).__name__
+
+
+@pytest.mark.parametrize("layout", ["SOA", "AOS"])
+def test_reaction_tangent_fused_and_signed(tb, oracle, device, layout):
+    """get_reaction_tangent is the *signed* maximum of dumat[:, φₘ] (src/solver/time/rtc.jl:64-73); the fused kernel
+    reduction (tb_reaction_step_rtc) returns the same number without dumat, and leaves the states identical."""
+    model = tb.FHNModel()
+    n = 4099
+    rng = np.random.default_rng(3)
+    pts = np.tile(model.default_initial_state(), (n, 1)) + rng.uniform(0.0, 1.0, size=(n, 2))
+    pts[:, 0] += 1.5                                             # φ > 1: every φ-rate is negative → signed max ≠ abs max
+    host = (np.ascontiguousarray(pts.T) if layout == "SOA" else pts).ravel().copy()
+    lay = tb.StateBlockedLayout() if layout == "SOA" else tb.PointBlockedLayout()
+    f = tb.PointwiseODEFunction(n, model, layout=lay)
+    for solver in (tb.ForwardEulerCellSolver(device), tb.AdaptiveForwardEulerSubstepper(device, substeps=5, reaction_threshold=0.5)):
+        c1 = tb.setup_solver_cache(f, solver, u=device.to_device(host))
+        c2 = tb.setup_solver_cache(f, solver, u=device.to_device(host), keep_du=False)
+        ref = host.copy()
+        du_ref = oracle.reaction_step(oracle.CELL_FHN, model.params, ref, n, getattr(oracle, "LAYOUT_" + layout), t=0.0, dt=0.1,
+                                      substeps=solver.substeps, threshold=solver.reaction_threshold)
+        sl = du_ref.reshape(2, n)[0] if layout == "SOA" else du_ref.reshape(n, 2)[:, 0]
+        assert sl.max() < 0 < np.abs(sl).max()
+        tb.perform_step(f, c1, 0.0, 0.1)
+        ok, R = tb.perform_step_with_reaction_tangent(f, c2, 0.0, 0.1)
+        assert ok is True
+        np.testing.assert_allclose(tb.get_reaction_tangent(device, f, c1), sl.max(), rtol=1e-12)
+        np.testing.assert_allclose(R, sl.max(), rtol=1e-12)
+        np.testing.assert_allclose(tb.reaction_rate_max(device, f, c1), np.abs(sl).max(), rtol=1e-12)
+        np.testing.assert_array_equal(c1.un.to_host(), c2.un.to_host())
+        assert rel_err(c1.un.to_host(), ref) < TOL
+    # RTC on the split monodomain problem: dt follows σ(R) of the last step and stays inside its bounds
+    g = tb.generate_mesh(tb.Hexahedron, (6, 6, 6), (0, 0, 0), (1, 1, 1))
+    dh = tb.DofHandler(g)
+    nd = dh.ndofs
+    X = np.empty((nd, 3)); X[tb.distributed.node_to_dof(dh)] = g.xyz
+    u0 = np.zeros((2, nd))
+    u0[0] = (X[:, 0] < 0.5).astype(float)
+    u0[1] = 0.1 * (X[:, 1] > 0.5)
+    fm = tb.PointwiseODEFunction(nd, model)
+    cell = tb.setup_solver_cache(fm, tb.ForwardEulerCellSolver(device), u=device.to_device(u0.ravel()), keep_du=False)
+    heat = tb.BackwardEulerStage(tb.BackwardEulerSolver(), tb.PatchAssemblyStrategy(device), dh,
+                                 tb.ConstantCoefficient(np.diag([4.5e-3, 2.0e-3, 2.0e-3])))
+    rtc = tb.ReactionTangentController(tb.LieTrotterGodunov(heat, fm, cell), 0.5, 1.0, (0.05, 0.4))
+    hist = rtc.solve(0.0, 2.0, 0.1)
+    assert abs(hist[-1][0] + hist[-1][1] - 2.0) < 1e-12 and len(hist) >= 5
+    assert all(0.05 - 1e-15 <= h <= 0.4 + 1e-15 for _, h in hist[1:-1])
+    assert rtc.dt_cache == pytest.approx(rtc.stepsize(rtc.R))
+    assert np.isfinite(cell.un.to_host()).all()

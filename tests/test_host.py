@@ -111,3 +111,20 @@ def test_slab_partition(tb):
     assert p.local_nel() == (4, 4, 4) and p.left[2] == 1.0 and p.right[2] == 2
     lo, up = p.interface_nodes()
     assert up is None and len(lo) == 25
+
+
+def test_reaction_tangent_controller_stepsize_known_answers(tb):
+    """σ(R) of the ReactionTangentController at the values the reference pins (test/test_os_gearing.jl:250-296):
+    R = 0.5 with σ_s = 0.5, σ_c = 1 on Δt ∈ (0.05π, 0.2π), and the σ_s = ∞ step function incl. the boundary R = σ_c."""
+    dt = 0.1 * np.pi
+    bounds = (dt * 0.5, dt * 2)
+    rtc = tb.ReactionTangentController(None, 0.5, 1.0, bounds)
+    expected = (1 - 1 / (1 + np.exp((1.0 - 0.5) * 0.5))) * (bounds[1] - bounds[0]) + bounds[0]
+    assert rtc.stepsize(0.5) == pytest.approx(expected, rel=1e-15)
+    assert bounds[0] < rtc.stepsize(0.5) < bounds[1]
+    for sigma_c, want in ((0.75, bounds[1]), (0.5, bounds[1]), (0.25, bounds[0])):
+        assert tb.ReactionTangentController(None, np.inf, sigma_c, bounds).stepsize(0.5) == want
+    # monotone: faster reactions → shorter steps
+    rs = np.linspace(-2, 5, 50)
+    dts = [rtc.stepsize(r) for r in rs]
+    assert all(a >= b for a, b in zip(dts, dts[1:]))

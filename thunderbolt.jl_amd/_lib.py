@@ -76,6 +76,8 @@ SIGNATURES = {
     "tb_host_material_eval": (C.c_int, [C.POINTER(tb_material), c_dp, c_dp, c_dp, c_dp]),
     "tb_reaction_step": (C.c_int, [vp, C.c_int, c_dp, C.c_int, vp, vp, C.c_int64, C.c_int, C.c_int, C.c_double,
                                    C.c_double, C.c_int, C.c_double]),
+    "tb_reaction_step_rtc": (C.c_int, [vp, C.c_int, c_dp, C.c_int, vp, vp, C.c_int64, C.c_int, C.c_int, C.c_double,
+                                       C.c_double, C.c_int, C.c_double, c_dp]),
     "tb_cell_model_info": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "tb_cell_model_defaults": (C.c_int, [C.c_int, c_dp, c_dp]),
     "tb_heat_matrix": (C.c_int, [vp, C.c_int64, vp, vp, C.c_double, vp]),
@@ -83,6 +85,7 @@ SIGNATURES = {
     "tb_cg_solve": (C.c_int, [vp, vp, vp, vp, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "tb_axpy": (C.c_int, [vp, C.c_int64, C.c_double, vp, vp]),
     "tb_absmax": (C.c_int, [vp, C.c_int64, vp, C.c_int64, C.POINTER(C.c_double)]),
+    "tb_max": (C.c_int, [vp, C.c_int64, vp, C.c_int64, C.POINTER(C.c_double)]),
     "tb_host_generate_grid_hex": (C.c_int, [C.c_int, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_i32p]),
     "tb_host_perturb_nodes": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, c_dp]),
     "tb_host_close_dofs": (C.c_int64, [C.c_int, C.c_int, C.c_int64, C.c_int64, c_i32p, c_i32p]),

@@ -707,17 +707,39 @@ def perform_step(f, cache, t, dt):
     return pointwise_step_outer_kernel(f, t, dt, cache)
 
 
+def _phi_slice(f, cache):
+    m = f.ode
+    if f.layout.code == L.TB_LAYOUT_SOA:
+        return C.c_void_p(cache.du.data_ptr() + 8 * m.phi_index * f.npoints), 1
+    return C.c_void_p(cache.du.data_ptr() + 8 * m.phi_index), m.nstates
+
+
+def get_reaction_tangent(device, f, cache):
+    """R = maximum(@view dumat[:, φₘidx]) — the *signed* maximum, as get_reaction_tangent reads it
+    (src/solver/time/rtc.jl:55-73)."""
+    base, stride = _phi_slice(f, cache)
+    out = C.c_double()
+    check(lib().tb_max(device.h, f.npoints, base, stride, C.byref(out)))
+    return out.value
+
+
 def reaction_rate_max(device, f, cache):
-    """max |dumat[:, φₘidx]| as the RTC controller reads it (src/solver/time/rtc.jl:64-73)."""
+    """max |dumat[:, φₘidx]| (diagnostic; the controller itself uses get_reaction_tangent)."""
+    base, stride = _phi_slice(f, cache)
+    out = C.c_double()
+    check(lib().tb_absmax(device.h, f.npoints, base, stride, C.byref(out)))
+    return out.value
+
+
+def perform_step_with_reaction_tangent(f, cache, t, dt):
+    """One pointwise step with the reaction tangent reduced inside the kernel (tb_reaction_step_rtc): returns
+    (ok, R) with R as get_reaction_tangent would give after the step; `cache.du` may be None."""
     m = f.ode
     out = C.c_double()
-    if f.layout.code == L.TB_LAYOUT_SOA:
-        base = cache.du.data_ptr() + 8 * m.phi_index * f.npoints
-        check(lib().tb_absmax(device.h, f.npoints, C.c_void_p(base), 1, C.byref(out)))
-    else:
-        base = cache.du.data_ptr() + 8 * m.phi_index
-        check(lib().tb_absmax(device.h, f.npoints, C.c_void_p(base), m.nstates, C.byref(out)))
-    return out.value
+    check(lib().tb_reaction_step_rtc(cache.solver.device.h, m.model_id, m.params.ctypes.data_as(L.c_dp), len(m.params),
+                                     _ptr(cache.un), _ptr(cache.du), f.npoints, m.nstates, f.layout.code, float(t),
+                                     float(dt), int(cache.substeps), float(cache.reaction_threshold), C.byref(out)))
+    return True, out.value
 
 
 # --------------------------------------------------------------------------------------- quasi-static mechanics
@@ -866,3 +888,43 @@ class LieTrotterGodunov:
     def step(self, t, dt):
         ok = self.heat.perform_step(self.phi, t, dt)
         return ok and perform_step(self.f, self.cell, t, dt)
+
+
+class ReactionTangentController:
+    """ReactionTangentController(ltg, σ_s, σ_c, Δt_bounds) (src/solver/time/rtc.jl:1-125): steps exactly like
+    LieTrotterGodunov; after every (always accepted) step the next Δt is σ(R) of the reaction tangent R of the
+    pointwise sub-problem.  R comes out of the reaction kernel itself (fused reduction), so `dumat` need not exist."""
+
+    def __init__(self, ltg, sigma_s, sigma_c, dt_bounds):
+        self.ltg, self.sigma_s, self.sigma_c = ltg, float(sigma_s), float(sigma_c)
+        self.dt_bounds = (float(dt_bounds[0]), float(dt_bounds[1]))
+        self.R = 0.0
+
+    def stepsize(self, R):
+        """step_accept_controller! (rtc.jl:104-120)."""
+        lo, hi = self.dt_bounds
+        if np.isinf(self.sigma_s):
+            return lo if R > self.sigma_c else hi
+        return (1.0 - 1.0 / (1.0 + np.exp((self.sigma_c - R) * self.sigma_s))) * (hi - lo) + lo
+
+    def step(self, t, dt):
+        """One LTG step of length dt; returns (ok, next dt)."""
+        ok = self.ltg.heat.perform_step(self.ltg.phi, t, dt)
+        if not ok:
+            return False, dt
+        ok, self.R = perform_step_with_reaction_tangent(self.ltg.f, self.ltg.cell, t, dt)
+        return ok, self.stepsize(self.R)
+
+    def solve(self, t0, t1, dt):
+        """Advance from t0 to t1 (the last step is clipped to land on t1); returns the list of accepted (t, dt)."""
+        t, hist = float(t0), []
+        while t < t1 - 1e-14 * max(1.0, abs(t1)):
+            h = min(dt, t1 - t)
+            ok, dt_next = self.step(t, h)
+            if not ok:
+                raise RuntimeError("RTC: inner step failed at t = %g" % t)
+            hist.append((t, h))
+            t += h
+            dt = dt_next
+        self.dt_cache = dt
+        return hist

@@ -77,6 +77,24 @@ k_absmax(int64_t n, const double *__restrict__ x, int64_t stride_x, unsigned lon
     }
 }
 
+// order-preserving map double → uint64 (total order of finite values and ±∞), so atomicMax works on signed values
+__device__ __forceinline__ unsigned long long ordered_key(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+__global__ void __launch_bounds__(256)
+k_max(int64_t n, const double *__restrict__ x, int64_t stride_x, unsigned long long *__restrict__ out)
+{
+    double m = -__builtin_huge_val();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) m = fmax(m, x[i * stride_x]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, ordered_key(m));
+}
+
 int launch_heat_matrix(tb_device *dev, int64_t nnz, const double *M, const double *K, double dt, double *A)
 {
     hipLaunchKernelGGL(k_heat_matrix, dim3(grid_for(dev, (nnz + 1) / 2, 256)), dim3(256), 0, dev->stream, nnz, M, K, dt, A);
@@ -111,6 +129,29 @@ int launch_absmax(tb_device *dev, int64_t n, const double *x, int64_t stride, do
     TB_HIP(hipMemcpyAsync(&bits, d_out, sizeof bits, hipMemcpyDeviceToHost, dev->stream));
     TB_HIP(hipStreamSynchronize(dev->stream));
     memcpy(result, &bits, sizeof bits);
+    return TB_OK;
+}
+
+double decode_ordered_key(unsigned long long k)
+{
+    const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    double v;
+    memcpy(&v, &b, sizeof v);
+    return v;
+}
+
+int launch_max(tb_device *dev, int64_t n, const double *x, int64_t stride, double *result)
+{
+    unsigned long long *d_out = (unsigned long long *)&dev->d_status->cell; // 8-byte scratch inside the status block
+    TB_HIP(hipMemsetAsync(d_out, 0, sizeof(unsigned long long), dev->stream)); // key 0 < key(−∞)
+    if (n > 0) {
+        hipLaunchKernelGGL(k_max, dim3(grid_for(dev, n, 256)), dim3(256), 0, dev->stream, n, x, stride, d_out);
+        TB_HIP(hipGetLastError());
+    }
+    unsigned long long bits = 0;
+    TB_HIP(hipMemcpyAsync(&bits, d_out, sizeof bits, hipMemcpyDeviceToHost, dev->stream));
+    TB_HIP(hipStreamSynchronize(dev->stream));
+    *result = bits ? decode_ordered_key(bits) : -__builtin_huge_val();
     return TB_OK;
 }
 

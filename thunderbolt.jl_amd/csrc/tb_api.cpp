@@ -541,20 +541,34 @@ int tb_cell_model_defaults(int model, double *params, double *u0)
     return TB_ERR_BAD_ARG;
 }
 
-int tb_reaction_step(tb_device *dev, int model, const double *params, int n_params, double *d_u, double *d_du,
-                     int64_t n_points, int n_states, int layout, double t, double dt, int substeps, double threshold)
+static int reaction_step(const char *who, tb_device *dev, int model, const double *params, int n_params, double *d_u, double *d_du,
+                         int64_t n_points, int n_states, int layout, double t, double dt, int substeps, double threshold, double *rmax)
 {
-    TB_REQUIRE(dev && params && (d_u || n_points == 0), "tb_reaction_step: NULL argument");
+    TB_REQUIRE(dev && params && (d_u || n_points == 0), "%s: NULL argument", who);
     int ns, np;
     int rc = tb_cell_model_info(model, &ns, &np, nullptr);
     if (rc) return rc;
-    TB_REQUIRE(n_states == ns, "tb_reaction_step: model has %d states, caller says %d", ns, n_states);
-    TB_REQUIRE(n_params == np, "tb_reaction_step: model has %d parameters, caller passed %d", np, n_params);
-    TB_REQUIRE(layout == TB_LAYOUT_SOA || layout == TB_LAYOUT_AOS, "tb_reaction_step: unknown layout %d", layout);
-    TB_REQUIRE(n_points >= 0, "tb_reaction_step: negative point count");
-    if (n_points == 0) return TB_OK;
+    TB_REQUIRE(n_states == ns, "%s: model has %d states, caller says %d", who, ns, n_states);
+    TB_REQUIRE(n_params == np, "%s: model has %d parameters, caller passed %d", who, np, n_params);
+    TB_REQUIRE(layout == TB_LAYOUT_SOA || layout == TB_LAYOUT_AOS, "%s: unknown layout %d", who, layout);
+    TB_REQUIRE(n_points >= 0, "%s: negative point count", who);
+    if (n_points == 0) { if (rmax) *rmax = -__builtin_huge_val(); return TB_OK; }
     TB_HIP(hipSetDevice(dev->id));
-    return launch_reaction(dev, model, params, n_params, d_u, d_du, n_points, layout, t, dt, substeps, threshold);
+    return launch_reaction(dev, model, params, n_params, d_u, d_du, n_points, layout, t, dt, substeps, threshold, rmax);
+}
+
+int tb_reaction_step(tb_device *dev, int model, const double *params, int n_params, double *d_u, double *d_du,
+                     int64_t n_points, int n_states, int layout, double t, double dt, int substeps, double threshold)
+{
+    return reaction_step("tb_reaction_step", dev, model, params, n_params, d_u, d_du, n_points, n_states, layout, t, dt, substeps, threshold, nullptr);
+}
+
+int tb_reaction_step_rtc(tb_device *dev, int model, const double *params, int n_params, double *d_u, double *d_du,
+                         int64_t n_points, int n_states, int layout, double t, double dt, int substeps, double threshold,
+                         double *rmax)
+{
+    TB_REQUIRE(rmax, "tb_reaction_step_rtc: NULL rmax");
+    return reaction_step("tb_reaction_step_rtc", dev, model, params, n_params, d_u, d_du, n_points, n_states, layout, t, dt, substeps, threshold, rmax);
 }
 
 // ------------------------------------------------------------------ algebra
@@ -593,6 +607,12 @@ int tb_absmax(tb_device *dev, int64_t n, const double *d_x, int64_t stride, doub
     TB_REQUIRE(dev && d_x && result && n >= 0 && stride >= 1, "tb_absmax: bad argument");
     if (!n) { *result = 0.0; return TB_OK; }
     return launch_absmax(dev, n, d_x, stride, result);
+}
+
+int tb_max(tb_device *dev, int64_t n, const double *d_x, int64_t stride, double *result)
+{
+    TB_REQUIRE(dev && (d_x || n == 0) && result && n >= 0 && stride >= 1, "tb_max: bad argument");
+    return launch_max(dev, n, d_x, stride, result);
 }
 
 } // extern "C"

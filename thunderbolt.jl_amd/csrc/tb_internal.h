@@ -172,13 +172,15 @@ int launch_assemble_vector(tb_form *f, int strategy, double t, double *d_b);
 int launch_hyperelastic(tb_form *f, tb_pattern *p, int strategy, const double *d_u, double *d_nz, double *d_r);
 int host_material_eval(const tb_material *mat, const double *F9, double *psi, double *P, double *A);
 int launch_reaction(tb_device *dev, int model, const double *params, int n_params, double *d_u, double *d_du,
-                    int64_t n_points, int layout, double t, double dt, int substeps, double thr);
+                    int64_t n_points, int layout, double t, double dt, int substeps, double thr, double *rmax /*nullable, host*/);
 int launch_heat_matrix(tb_device *dev, int64_t nnz, const double *M, const double *K, double dt, double *A);
 int launch_spmv(tb_pattern *p, const double *nz, const double *x, double alpha, double beta, double *y);
 int launch_cg(tb_pattern *pat, const double *A, const double *b, double *x, double rtol, double atol, int maxiter, int jacobi, int *iters,
               double *resnorm);
 int launch_axpy(tb_device *dev, int64_t n, double a, const double *x, double *y);
 int launch_absmax(tb_device *dev, int64_t n, const double *x, int64_t stride, double *result);
+int launch_max(tb_device *dev, int64_t n, const double *x, int64_t stride, double *result);
+double decode_ordered_key(unsigned long long k);
 
 int check_status(tb_device *dev);
 int reset_status(tb_device *dev);

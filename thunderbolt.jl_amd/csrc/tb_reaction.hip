@@ -174,11 +174,12 @@ template <> struct CellModel<TB_CELL_TT06> {
 template <int MODEL, int LAYOUT, bool WRITE_DU>
 __global__ void __launch_bounds__(256)
 k_reaction(CellParams P, double *__restrict__ u, double *__restrict__ du_out, int64_t n, double t, double dt, int substeps,
-           double threshold)
+           double threshold, unsigned long long *__restrict__ rmax_key)
 {
     using M = CellModel<MODEL>;
     constexpr int NS = M::NS;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    double rm = -__builtin_huge_val(); // reaction tangent: max of the φₘ rate of the last evaluation (rtc.jl:64-73)
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         double ul[NS], dul[NS];
 #pragma unroll
@@ -203,12 +204,21 @@ k_reaction(CellParams P, double *__restrict__ u, double *__restrict__ du_out, in
             u[k] = ul[j];
             if (WRITE_DU) du_out[k] = dul[j];
         }
+        rm = fmax(rm, dul[M::PHI]);
+    }
+    if (rmax_key) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) rm = fmax(rm, __shfl_xor(rm, o, 64));
+        if ((threadIdx.x & 63) == 0) {
+            const unsigned long long b = (unsigned long long)__double_as_longlong(rm);
+            atomicMax(rmax_key, (b >> 63) ? ~b : (b | 0x8000000000000000ull)); // order-preserving key, see tb_algebra.hip
+        }
     }
 }
 
 template <int MODEL>
 static int run(tb_device *dev, const CellParams &P, double *u, double *du, int64_t n, int layout, double t, double dt, int substeps,
-               double thr)
+               double thr, unsigned long long *rmax_key)
 {
     const int bs = 256;
     int64_t nb = (n + bs - 1) / bs;
@@ -216,7 +226,7 @@ static int run(tb_device *dev, const CellParams &P, double *u, double *du, int64
     const int64_t cap = per_cu > 0 ? (int64_t)dev->n_cu * per_cu : nb;
     if (nb > cap) nb = cap;
     const dim3 grid((unsigned)nb), block(bs);
-#define TB_LAUNCH(L, W) hipLaunchKernelGGL((k_reaction<MODEL, L, W>), grid, block, 0, dev->stream, P, u, du, n, t, dt, substeps, thr)
+#define TB_LAUNCH(L, W) hipLaunchKernelGGL((k_reaction<MODEL, L, W>), grid, block, 0, dev->stream, P, u, du, n, t, dt, substeps, thr, rmax_key)
     if (layout == TB_LAYOUT_SOA) { if (du) TB_LAUNCH(TB_LAYOUT_SOA, true); else TB_LAUNCH(TB_LAYOUT_SOA, false); }
     else { if (du) TB_LAUNCH(TB_LAYOUT_AOS, true); else TB_LAUNCH(TB_LAYOUT_AOS, false); }
 #undef TB_LAUNCH
@@ -225,18 +235,29 @@ static int run(tb_device *dev, const CellParams &P, double *u, double *du, int64
 }
 
 int launch_reaction(tb_device *dev, int model, const double *params, int n_params, double *d_u, double *d_du, int64_t n_points,
-                    int layout, double t, double dt, int substeps, double thr)
+                    int layout, double t, double dt, int substeps, double thr, double *rmax)
 {
     CellParams P{};
     for (int i = 0; i < n_params && i < 48; ++i) P.p[i] = params[i];
-    switch (model) {
-    case TB_CELL_FHN: return run<TB_CELL_FHN>(dev, P, d_u, d_du, n_points, layout, t, dt, substeps, thr);
-    case TB_CELL_ALIEV_PANFILOV: return run<TB_CELL_ALIEV_PANFILOV>(dev, P, d_u, d_du, n_points, layout, t, dt, substeps, thr);
-    case TB_CELL_PCG2019: return run<TB_CELL_PCG2019>(dev, P, d_u, d_du, n_points, layout, t, dt, substeps, thr);
-    case TB_CELL_TT06: return run<TB_CELL_TT06>(dev, P, d_u, d_du, n_points, layout, t, dt, substeps, thr);
+    unsigned long long *key = nullptr;
+    if (rmax) {
+        key = (unsigned long long *)&dev->d_status->cell; // 8-byte scratch inside the status block
+        TB_HIP(hipMemsetAsync(key, 0, sizeof *key, dev->stream));
     }
-    set_error("unknown cell model %d", model);
-    return TB_ERR_BAD_ARG;
+    int rc = TB_ERR_BAD_ARG;
+    switch (model) {
+    case TB_CELL_FHN: rc = run<TB_CELL_FHN>(dev, P, d_u, d_du, n_points, layout, t, dt, substeps, thr, key); break;
+    case TB_CELL_ALIEV_PANFILOV: rc = run<TB_CELL_ALIEV_PANFILOV>(dev, P, d_u, d_du, n_points, layout, t, dt, substeps, thr, key); break;
+    case TB_CELL_PCG2019: rc = run<TB_CELL_PCG2019>(dev, P, d_u, d_du, n_points, layout, t, dt, substeps, thr, key); break;
+    case TB_CELL_TT06: rc = run<TB_CELL_TT06>(dev, P, d_u, d_du, n_points, layout, t, dt, substeps, thr, key); break;
+    default: set_error("unknown cell model %d", model); return TB_ERR_BAD_ARG;
+    }
+    if (rc || !rmax) return rc;
+    unsigned long long bits = 0;
+    TB_HIP(hipMemcpyAsync(&bits, key, sizeof bits, hipMemcpyDeviceToHost, dev->stream));
+    TB_HIP(hipStreamSynchronize(dev->stream));
+    *rmax = bits ? decode_ordered_key(bits) : -__builtin_huge_val();
+    return TB_OK;
 }
 
 } // namespace tb
