@@ -6,3 +6,4 @@ from . import _lib
 from ._lib import TBError, build_library, lib  # noqa: F401
 from .api import *  # noqa: F401,F403
 from . import distributed  # noqa: F401
+from . import meshio  # noqa: F401
