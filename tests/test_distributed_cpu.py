@@ -165,3 +165,98 @@ def test_two_rank_heat_solve_equals_single_domain():
     for rank, gnode, x, its in res:
         assert 0 < its < 200
         np.testing.assert_allclose(x, ref[gnode], rtol=1e-9, atol=1e-12)
+
+
+def _unstructured_problem(tb):
+    """A perturbed box presented as an unstructured mesh: cells shuffled, nodes renumbered at random."""
+    rng = np.random.default_rng(11)
+    g0 = tb.generate_mesh(tb.Hexahedron, (5, 4, 6), (0.0, 0.0, 0.0), (1.0, 0.8, 1.4), perturb=0.2)
+    perm = rng.permutation(g0.n_nodes)
+    xyz = np.empty_like(g0.xyz)
+    xyz[perm] = g0.xyz
+    conn = perm[g0.conn][rng.permutation(g0.n_cells)].astype(np.int32)
+    return xyz, conn
+
+
+def _general_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import thunderbolt_jl_amd as tb
+    from oracle import oracle as o
+    D = tb.distributed
+    xyz, conn = _unstructured_problem(tb)
+    part = D.partition_cells_rcb(xyz[conn].mean(axis=1), world)
+    gp = D.GeneralPartition(conn, part, rank)
+    lx = xyz[gp.global_nodes]
+    cd, nd = o.close_dofs(o.HEX8, 1, gp.conn, len(lx))
+    rp, ci = o.build_pattern(cd, nd)
+    om = o.Mesh(o.HEX8, 2, lx, gp.conn, cd)
+    n2d = np.full(len(lx), -1, dtype=np.int64)
+    n2d[gp.conn.ravel()] = cd.ravel()
+    nb = [(peer, torch.from_numpy(n2d[idx])) for peer, idx in gp.neighbours]
+    b = torch.from_numpy(o.assemble_source(om, o.SRC_COS_EXP, t=0.1))
+    D.exchange_sum(b, nb, dist)
+    kap = np.diag([4.5e-2, 2.0e-2, 2.0e-2])
+    Mp = o.assemble_matrix(om, 0, o.Coef(o.COEF_CONST_SCALAR, [1.0]), rp, ci)
+    Kp = o.assemble_matrix(om, 1, o.Coef(o.COEF_CONST_TENSOR, kap.ravel()), rp, ci)
+    Ap = o.heat_matrix(Mp, Kp, 0.5)
+    diag = np.array([Ap[rp[r] + np.searchsorted(ci[rp[r]:rp[r + 1]], r)] for r in range(nd)])
+    cg = D.DistributedCG(lambda x: torch.from_numpy(o.spmv_csr(rp, ci, Ap, x.numpy())), torch.from_numpy(diag), None, None, rank, world, dist,
+                         neighbours=nb)
+    u0 = np.empty(nd)
+    u0[n2d] = np.cos(2 * lx[:, 0]) * (1 + lx[:, 2])
+    rhs = torch.from_numpy(o.spmv_csr(rp, ci, Mp, u0))
+    D.exchange_sum(rhs, nb, dist)
+    x, its, rn = cg.solve(rhs, torch.from_numpy(u0.copy()), rtol=1e-12, atol=1e-14)
+    q.put((rank, gp.global_nodes, b.numpy()[n2d], x.numpy()[n2d], len(gp.cells), gp.multiplicity()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_general_partition_equals_single_domain(world):
+    """Unstructured presentation, recursive-coordinate-bisection parts (3 parts: some nodes are held by three ranks):
+    assembled source vector and the backward-Euler heat solve equal the single-domain result."""
+    import scipy.sparse as sps
+    import scipy.sparse.linalg as spla
+    from oracle import oracle as o
+    import thunderbolt_jl_amd as tb
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_general_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    xyz, conn = _unstructured_problem(tb)
+    cd, nd = o.close_dofs(o.HEX8, 1, conn, len(xyz))
+    rp, ci = o.build_pattern(cd, nd)
+    om = o.Mesh(o.HEX8, 2, xyz, conn, cd)
+    n2d = np.full(len(xyz), -1, dtype=np.int64)
+    n2d[conn.ravel()] = cd.ravel()
+    bref = o.assemble_source(om, o.SRC_COS_EXP, t=0.1)[n2d]
+    M = o.assemble_matrix(om, 0, o.Coef(o.COEF_CONST_SCALAR, [1.0]), rp, ci)
+    K = o.assemble_matrix(om, 1, o.Coef(o.COEF_CONST_TENSOR, np.diag([4.5e-2, 2.0e-2, 2.0e-2]).ravel()), rp, ci)
+    A = sps.csr_matrix((o.heat_matrix(M, K, 0.5), ci, rp), shape=(nd, nd))
+    u0 = np.empty(nd)
+    u0[n2d] = np.cos(2 * xyz[:, 0]) * (1 + xyz[:, 2])
+    xref = spla.spsolve(A.tocsc(), sps.csr_matrix((M, ci, rp), shape=(nd, nd)) @ u0)[n2d]
+    held = np.zeros(len(xyz), dtype=int)
+    ncells = 0
+    for rank, gnodes, b, x, nc, mult in res:
+        np.testing.assert_allclose(b, bref[gnodes], rtol=1e-12, atol=1e-18)
+        np.testing.assert_allclose(x, xref[gnodes], rtol=1e-9, atol=1e-12)
+        held[gnodes] += 1
+        ncells += nc
+    assert ncells == len(conn) and held.min() == 1
+    for rank, gnodes, b, x, nc, mult in res:
+        np.testing.assert_array_equal(mult, held[gnodes])          # each rank knows how many ranks hold each of its nodes
+    if world == 3:
+        assert held.max() == 3
+    sizes = sorted(r[4] for r in res)
+    assert sizes[-1] - sizes[0] <= 1                               # balanced parts

@@ -1,9 +1,10 @@
 """Multi-GPU sharding of the hot path (new work: the reference is shared-memory only, README.md:7).
 
-Cells are partitioned into P contiguous z-slabs (structured boxes); every rank assembles its own
-sub-domain operators with NO communication; the only exchange is the sum of vector entries on the
-interface planes shared by neighbouring slabs (chain topology → neighbour send/recv, or one
-all-reduce of the packed interface vector).  The reaction step owns its points and never communicates.
+Cells are partitioned into P contiguous z-slabs (structured boxes) or, for general meshes, by recursive
+coordinate bisection of the cell centroids; every rank assembles its own sub-domain operators with NO
+communication; the only exchange is the sum of vector entries on the dofs shared with neighbouring parts
+(neighbour send/recv — chain topology for slabs, an arbitrary neighbour set for general parts).  The reaction
+step owns its points and never communicates.
 """
 import numpy as np
 
@@ -41,6 +42,78 @@ class SlabPartition:
         return lower, upper
 
 
+def partition_cells_rcb(centroids, nparts):
+    """Recursive coordinate bisection: part id per cell.  Splits along the longest extent, proportionally when the
+    number of parts is odd, so every part receives ⌊n/P⌋ or ⌈n/P⌉ cells.  Deterministic (stable sorts)."""
+    centroids = np.asarray(centroids, dtype=np.float64)
+    part = np.zeros(len(centroids), dtype=np.int32)
+
+    def split(idx, p0, np_):
+        if np_ == 1 or len(idx) == 0:
+            part[idx] = p0
+            return
+        c = centroids[idx]
+        axis = int(np.argmax(c.max(axis=0) - c.min(axis=0)))
+        order = idx[np.argsort(c[:, axis], kind="stable")]
+        nl = np_ // 2
+        cut = (len(idx) * nl) // np_
+        split(order[:cut], p0, nl)
+        split(order[cut:], p0 + nl, np_ - nl)
+
+    split(np.arange(len(centroids)), 0, int(nparts))
+    return part
+
+
+class GeneralPartition:
+    """One rank's share of an arbitrary mesh: the cells with part id == rank, their nodes renumbered locally (first
+    visit), and for every other rank the nodes shared with it — both sides list them in ascending *global* node id,
+    so the packed exchange buffers line up without any negotiation."""
+
+    def __init__(self, conn, part, rank):
+        conn, part = np.asarray(conn), np.asarray(part)
+        self.rank = int(rank)
+        self.cells = np.flatnonzero(part == rank)
+        gl = conn[self.cells]
+        self.global_nodes, first = np.unique(gl.ravel(), return_index=True)
+        order = np.argsort(first, kind="stable")                    # local ids by first visit
+        self.global_nodes = self.global_nodes[order]
+        lookup = {int(g): i for i, g in enumerate(self.global_nodes)}
+        self.conn = np.vectorize(lookup.__getitem__, otypes=[np.int32])(gl) if gl.size else gl.astype(np.int32)
+        mine = set(lookup)
+        self.neighbours = []                                        # [(peer rank, local node ids)], peers ascending
+        for q in sorted(set(part.tolist()) - {self.rank}):
+            shared = sorted(mine.intersection(np.unique(conn[part == q]).tolist()))
+            if shared:
+                self.neighbours.append((int(q), np.array([lookup[g] for g in shared], dtype=np.int64)))
+
+    def multiplicity(self):
+        m = np.ones(len(self.global_nodes))
+        for _, idx in self.neighbours:
+            m[idx] += 1.0
+        return m
+
+
+def exchange_sum(vec, neighbours, dist):
+    """Sum the entries of `vec` (torch tensor, any device) shared with each neighbour, in place: every rank sends its
+    own *partial* values of the shared dofs to each sharing peer and adds what it receives, so a dof held by k ranks
+    ends up with the sum of all k partials on each of them.  neighbours = [(peer, index tensor)]."""
+    import torch
+
+    ops, bufs = [], []
+    for peer, idx in neighbours:
+        send = vec[idx].contiguous()                                # partials, taken before anything is added
+        recv = torch.empty_like(send)
+        ops.append(dist.P2POp(dist.isend, send, peer))
+        ops.append(dist.P2POp(dist.irecv, recv, peer))
+        bufs.append((idx, recv, send))
+    if ops:
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+    for idx, recv, _ in bufs:
+        vec[idx] += recv
+    return vec
+
+
 def node_to_dof(dh):
     """dof id of every mesh node for a first-order scalar field (dof id ≠ node id in Ferrite numbering)."""
     n2d = np.full(dh.grid.n_nodes, -1, dtype=np.int64)
@@ -53,23 +126,9 @@ def halo_sum(vec, lower_idx, upper_idx, rank, world_size, dist):
 
     After the call every rank holds the globally assembled value on its interface dofs.  Uses
     neighbour isend/irecv (RCCL over xGMI on GPU, gloo on CPU)."""
-    import torch
-
-    ops, bufs = [], []
-    for idx, peer in ((lower_idx, rank - 1), (upper_idx, rank + 1)):
-        if idx is None or peer < 0 or peer >= world_size:
-            continue
-        send = vec[idx].contiguous()
-        recv = torch.empty_like(send)
-        ops.append(dist.P2POp(dist.isend, send, peer))
-        ops.append(dist.P2POp(dist.irecv, recv, peer))
-        bufs.append((idx, recv))
-    if ops:
-        for r in dist.batch_isend_irecv(ops):
-            r.wait()
-    for idx, recv in bufs:
-        vec[idx] += recv
-    return vec
+    nb = [(peer, idx) for idx, peer in ((lower_idx, rank - 1), (upper_idx, rank + 1))
+          if idx is not None and 0 <= peer < world_size]
+    return exchange_sum(vec, nb, dist)
 
 
 class DistributedCG:
@@ -81,19 +140,20 @@ class DistributedCG:
     all-reduce — RCCL on GPU).  `local_spmv(x) -> y` applies the rank's own A_p (tb_spmv_csr on device; any callable
     in tests).  New work: the reference has no distributed solver (README.md:7)."""
 
-    def __init__(self, local_spmv, local_diag, lower_idx, upper_idx, rank, world_size, dist):
+    def __init__(self, local_spmv, local_diag, lower_idx, upper_idx, rank, world_size, dist, neighbours=None):
         import torch
         self.torch, self.dist = torch, dist
         self.spmv, self.rank, self.world = local_spmv, rank, world_size
-        self.lo, self.up = lower_idx, upper_idx
+        # slab partitions pass (lower, upper); general partitions pass neighbours = [(peer, index tensor)]
+        self.nb = neighbours if neighbours is not None else [
+            (peer, idx) for idx, peer in ((lower_idx, rank - 1), (upper_idx, rank + 1)) if idx is not None and 0 <= peer < world_size]
         d = local_diag.clone()
-        halo_sum(d, self.lo, self.up, rank, world_size, dist)      # assembled diagonal
+        exchange_sum(d, self.nb, dist)                              # assembled diagonal
         self.dinv = 1.0 / d
-        w = torch.ones_like(d)
-        for idx in (self.lo, self.up):
-            if idx is not None:
-                w[idx] = 0.5                                      # slab interfaces are shared by exactly two ranks
-        self.w = w
+        mult = torch.ones_like(d)
+        for _, idx in self.nb:
+            mult[idx] += 1.0
+        self.w = 1.0 / mult                                         # a dof held by k ranks counts 1/k in every dot product
 
     def dot(self, a, b):
         s = (self.w * a * b).sum().reshape(1)
@@ -103,7 +163,7 @@ class DistributedCG:
 
     def apply(self, x):
         y = self.spmv(x)
-        halo_sum(y, self.lo, self.up, self.rank, self.world, self.dist)
+        exchange_sum(y, self.nb, self.dist)
         return y
 
     def solve(self, b, x, rtol=1e-5, atol=1e-6, maxiter=1000):
