@@ -231,6 +231,16 @@ int tb_cg_solve(tb_pattern *pat, const double *d_Anz, const double *d_b, double 
  * (RTC reads max(dumat[:,φₘidx]), src/solver/time/rtc.jl:64-73) */
 int tb_axpy(tb_device *dev, int64_t n, double a, const double *d_x, double *d_y);
 int tb_absmax(tb_device *dev, int64_t n, const double *d_x, int64_t stride, double *result);
+/* x·y (norms of residuals / increments in the Newton loop, src/solver/nonlinear/newton_raphson.jl:246-290) */
+int tb_dot(tb_device *dev, int64_t n, const double *d_x, const double *d_y, double *result);
+/* apply_zero!(K, f, ch) on the device CSR matrix (Ferrite.apply_zero!; CSR method src/utils.jl:263-278; used by
+ * eliminate_constraints_from_linearization! / _residual! / _increment!, src/solver/nonlinear/nlsolve_common.jl:12-26):
+ * d_prescribed is one byte per dof (1 = Dirichlet dof).  Rows and columns of prescribed dofs are zeroed, their diagonal
+ * entry becomes `diag` (pass tb_meandiag like Ferrite does, or 1), and f is zeroed at those dofs.  d_nzval or d_f may be
+ * NULL (vector-only: apply_zero!(f, ch)). */
+int tb_apply_zero_csr(tb_pattern *pat, double *d_nzval, double *d_f, const uint8_t *d_prescribed, double diag);
+/* mean |diagonal| (Ferrite.meandiag) */
+int tb_meandiag(tb_pattern *pat, const double *d_nzval, double *result);
 /* signed maximum of a strided slice: exactly `maximum(@view dumat[:, φₘidx])` of get_reaction_tangent
  * (src/solver/time/rtc.jl:64-73 — no absolute value there).  n == 0 yields −∞. */
 int tb_max(tb_device *dev, int64_t n, const double *d_x, int64_t stride, double *result);

@@ -603,3 +603,74 @@ def test_reaction_tangent_fused_and_signed(tb, oracle, device, layout):
     assert all(0.05 - 1e-15 <= h <= 0.4 + 1e-15 for _, h in hist[1:-1])
     assert rtc.dt_cache == pytest.approx(rtc.stepsize(rtc.R))
     assert np.isfinite(cell.un.to_host()).all()
+
+
+HEX27_TIX = [(0, 0, 0), (2, 0, 0), (2, 2, 0), (0, 2, 0), (0, 0, 2), (2, 0, 2), (2, 2, 2), (0, 2, 2), (1, 0, 0), (2, 1, 0), (1, 2, 0), (0, 1, 0), (1, 0, 2),
+             (2, 1, 2), (1, 2, 2), (0, 1, 2), (0, 0, 1), (2, 0, 1), (2, 2, 1), (0, 2, 1), (1, 1, 0), (1, 0, 1), (2, 1, 1), (1, 2, 1), (0, 1, 1), (1, 1, 2), (1, 1, 1)]
+HEX8_SGN = np.array([[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, -1, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1]], dtype=float)
+
+
+def vector_dof_positions(g, dh, order):
+    """position of the node carrying each displacement dof (trilinear geometry; Q2 nodes through the reference map)."""
+    xi = HEX8_SGN if order == 1 else np.array(HEX27_TIX, dtype=float) - 1.0
+    N = 0.125 * np.prod(1.0 + HEX8_SGN[None, :, :] * xi[:, None, :], axis=2)        # (nb, 8)
+    X = np.empty((dh.ndofs, 3))
+    pos = np.einsum("ba,cak->cbk", N, g.xyz[g.conn])                                 # (cells, nb, 3)
+    for c in range(3):
+        X[dh.cell_dofs[:, c::3].ravel()] = pos.reshape(-1, 3)
+    return X
+
+
+@pytest.mark.parametrize("order,nel", [(1, (4, 3, 3)), (2, (2, 2, 2))])
+def test_newton_raphson_with_dirichlet_elimination(tb, oracle, device, order, nel):
+    """Quasi-static stretch test: clamp x = 0, pull the x = 1 face by 5 %, Newton–Raphson (newton_raphson.jl:215-320) with
+    device-side apply_zero! and Jacobi-CG against the same Newton iteration done with oracle operators and a direct solve."""
+    import scipy.sparse as sps
+    import scipy.sparse.linalg as spla
+    g, dh, sp, om = mech_problem(tb, oracle, nel, order, perturb=0.1)
+    X = vector_dof_positions(g, dh, order)
+    comp = np.empty(dh.ndofs, dtype=int)
+    for c in range(3):
+        comp[dh.cell_dofs[:, c::3].ravel()] = c
+    left, right = np.flatnonzero(X[:, 0] < 1e-12), np.flatnonzero(X[:, 0] > 1.0 - 1e-12)
+    pres = np.concatenate([left, right])
+    vals = np.concatenate([np.zeros(len(left)), np.where(comp[right] == 0, 0.05, 0.0)])
+    ch = tb.ConstraintHandler(dh, pres, vals)
+    order_ix = np.argsort(pres)
+    np.testing.assert_array_equal(ch.prescribed_dofs, pres[order_ix])
+    ch.values = vals[order_ix]
+    fsn = np.eye(3)
+    model = tb.QuasiStaticModel("u", tb.PK1Model(tb.HolzapfelOgden2009Model(), tb.ConstantCoefficient(tb.OrthotropicMicrostructure(*fsn))))
+    op = tb.setup_operator(tb.ElementAssemblyStrategy(device), model, dh, sp)
+    u = device.zeros(dh.ndofs)
+    tb.apply(u, ch)
+    solver = tb.NewtonRaphsonSolver(max_iter=20, tol=1e-10, inner_rtol=1e-13)
+    assert tb.nlsolve(u, op, ch, solver) is True
+    assert 2 <= solver.iter <= 12
+    assert solver.residual_norms[-1] < 1e-10 and solver.residual_norms[-1] < 1e-8 * solver.residual_norms[0]
+    # reference Newton: oracle operators, Ferrite-style elimination, sparse direct solve
+    n = dh.ndofs
+    free = ch.free_dofs()
+    uref = np.zeros(n)
+    uref[ch.prescribed_dofs] = ch.values
+    for it in range(20):
+        K, r = oracle.assemble_hyperelastic(om, uref, sp.rowptr, sp.colidx, fsn=fsn)
+        A = sps.csr_matrix((K, sp.colidx, sp.rowptr), shape=(n, n))[free][:, free]
+        if np.linalg.norm(r[free]) < 1e-11 and it > 0:
+            break
+        uref[free] -= spla.spsolve(A.tocsc(), r[free])
+    got = u.to_host()
+    np.testing.assert_allclose(got[ch.prescribed_dofs], ch.values, rtol=0, atol=0)   # Dirichlet values untouched
+    assert np.abs(got - uref).max() < 1e-9 * np.abs(uref).max()
+    # apply_zero! semantics on the tangent: rows/cols of prescribed dofs are zero except the mean diagonal
+    tb.update_linearization(op, u, 0.0)
+    md = tb.meandiag(op, op.J)
+    J0 = op.J.to_host()
+    d = np.array([J0[sp.rowptr[i] + np.searchsorted(sp.colidx[sp.rowptr[i]:sp.rowptr[i + 1]], i)] for i in range(n)])
+    assert md == pytest.approx(np.abs(d).mean(), rel=1e-13)
+    tb.apply_zero(op.J, None, ch, pattern=op.pattern, diag=md)
+    A = sps.csr_matrix((op.J.to_host(), sp.colidx, sp.rowptr), shape=(n, n)).toarray()
+    flag = np.zeros(n, dtype=bool); flag[ch.prescribed_dofs] = True
+    assert np.all(A[flag][:, ~flag] == 0) and np.all(A[~flag][:, flag] == 0)
+    np.testing.assert_array_equal(A[flag][:, flag], md * np.eye(flag.sum()))
+    np.testing.assert_array_equal(A[~flag][:, ~flag], sps.csr_matrix((J0, sp.colidx, sp.rowptr), shape=(n, n)).toarray()[~flag][:, ~flag])

@@ -85,6 +85,9 @@ SIGNATURES = {
     "tb_cg_solve": (C.c_int, [vp, vp, vp, vp, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "tb_axpy": (C.c_int, [vp, C.c_int64, C.c_double, vp, vp]),
     "tb_absmax": (C.c_int, [vp, C.c_int64, vp, C.c_int64, C.POINTER(C.c_double)]),
+    "tb_dot": (C.c_int, [vp, C.c_int64, vp, vp, C.POINTER(C.c_double)]),
+    "tb_apply_zero_csr": (C.c_int, [vp, vp, vp, vp, C.c_double]),
+    "tb_meandiag": (C.c_int, [vp, vp, C.POINTER(C.c_double)]),
     "tb_max": (C.c_int, [vp, C.c_int64, vp, C.c_int64, C.POINTER(C.c_double)]),
     "tb_host_generate_grid_hex": (C.c_int, [C.c_int, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_i32p]),
     "tb_host_perturb_nodes": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, c_dp]),

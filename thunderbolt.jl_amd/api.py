@@ -826,6 +826,112 @@ def residual(op, residual, u, t=0.0):
     return residual
 
 
+# --------------------------------------------------------------------------------------- constraints + Newton–Raphson
+class ConstraintHandler:
+    """ConstraintHandler(dh) with Dirichlet conditions on whole dofs (Ferrite, third party; used through apply_zero! /
+    apply!).  `prescribed_dofs`: dof ids; `values`: their prescribed values (inhomogeneities; default 0)."""
+
+    def __init__(self, dh, prescribed_dofs, values=None):
+        self.dh = dh
+        self.prescribed_dofs = np.unique(np.asarray(prescribed_dofs, dtype=np.int64))
+        self.values = np.zeros(len(self.prescribed_dofs)) if values is None else np.asarray(values, dtype=np.float64)
+        self._flags = {}
+
+    def flags(self, device):
+        key = id(device)
+        if key not in self._flags:
+            f = np.zeros(self.dh.ndofs, dtype=np.uint8)
+            f[self.prescribed_dofs] = 1
+            self._flags[key] = device.to_device(f)
+        return self._flags[key]
+
+    def free_dofs(self):
+        return np.setdiff1d(np.arange(self.dh.ndofs), self.prescribed_dofs)
+
+
+def apply(u, ch):
+    """apply!(u, ch): write the prescribed values into a solution vector (host round trip: setup-time operation)."""
+    h = u.to_host()
+    h[ch.prescribed_dofs] = ch.values
+    u.copy_from_host(h)
+    return u
+
+
+def meandiag(op_or_pattern, nz):
+    pat = getattr(op_or_pattern, "pattern", op_or_pattern)
+    out = C.c_double()
+    check(lib().tb_meandiag(pat.h, _ptr(nz), C.byref(out)))
+    return out.value
+
+
+def apply_zero(K, f, ch, pattern=None, diag=None):
+    """apply_zero!(K, f, ch) / apply_zero!(f, ch) on the device (src/utils.jl:263-278, nlsolve_common.jl:12-26).
+    K: CSR nzval DeviceVector (or None), f: DeviceVector (or None)."""
+    dev = (K if K is not None else f).dev
+    if K is not None and diag is None:
+        diag = meandiag(pattern, K)
+    check(lib().tb_apply_zero_csr(pattern.h, _ptr(K), _ptr(f), ch.flags(dev).ptr, float(diag if diag is not None else 1.0)))
+
+
+def dot(x, y):
+    out = C.c_double()
+    check(lib().tb_dot(x.dev.h, x.n, x.ptr, y.ptr, C.byref(out)))
+    return out.value
+
+
+def norm(x):
+    return float(np.sqrt(dot(x, x)))
+
+
+class NewtonRaphsonSolver:
+    """NewtonRaphsonSolver(; max_iter, tol, inner_solver) (src/solver/nonlinear/newton_raphson.jl:1-60); nlsolve!
+    follows :215-320 — update_linearization!, eliminate constraints, residual norm over the free dofs, linear solve,
+    eliminate the increment, u .-= Δu, Θₖ contraction monitor, early exits — with Jacobi-CG as inner solver."""
+
+    def __init__(self, max_iter=100, tol=1e-4, inner_rtol=1e-8, inner_atol=1e-14, inner_maxiter=5000, enforce_monotonic_convergence=True):
+        self.max_iter, self.tol = max_iter, tol
+        self.inner_rtol, self.inner_atol, self.inner_maxiter = inner_rtol, inner_atol, inner_maxiter
+        self.enforce_monotonic_convergence = enforce_monotonic_convergence
+        self.iter, self.theta, self.residual_norms, self.linear_iters = -1, [], [], []
+
+
+def nlsolve(u, op, ch, solver, t=0.0):
+    """nlsolve!(u, stage, cache, t) → Bool.  `u` must already satisfy the Dirichlet values (apply!(u, ch))."""
+    dev = u.dev
+    res = DeviceVector(dev, u.n)
+    du = DeviceVector(dev, u.n)
+    solver.iter, solver.theta, solver.residual_norms, solver.linear_iters = -1, [], [], []
+    rprev = iprev = 0.0
+    eps = np.finfo(np.float64).eps
+    while True:
+        solver.iter += 1
+        update_linearization(op, u, t, residual=res)
+        apply_zero(op.J, res, ch, pattern=op.pattern)
+        rnorm = norm(res)                                     # prescribed entries are zero: this is the norm over the free dofs
+        solver.residual_norms.append(rnorm)
+        if rnorm < solver.tol and solver.iter > 0:
+            solver.theta.append(0.0)
+            break
+        if solver.iter > solver.max_iter or not np.isfinite(rnorm):
+            solver.theta.append(np.inf)
+            return False
+        du.fill_zero()
+        its, _ = cg_solve(op.pattern, op.J, res, du, solver.inner_rtol, solver.inner_atol, solver.inner_maxiter, True)
+        solver.linear_iters.append(its)
+        apply_zero(None, du, ch, pattern=op.pattern)          # eliminate_constraints_from_increment!
+        check(lib().tb_axpy(dev.h, u.n, -1.0, du.ptr, u.ptr))  # u .-= Δu
+        inorm = norm(du)
+        if solver.iter > 0:
+            theta = min(rnorm / rprev, inorm / iprev) if rprev > 0.0 and iprev > 0.0 else 0.0
+            solver.theta.append(theta)
+            if rnorm < eps or inorm < eps:
+                break
+            if solver.enforce_monotonic_convergence and theta >= 1.0:
+                return False
+        rprev, iprev = rnorm, inorm
+    return True
+
+
 # --------------------------------------------------------------------------------------- heat step + operator splitting
 def cg_solve(pattern, A, b, x, rtol=1e-5, atol=1e-6, maxiter=1000, jacobi=True):
     """LinearSolve.solve!(linear_solver) with KrylovJL_CG(atol, rtol) (euler.jl:94-100, ep01_spiral-wave.jl:126-128)."""

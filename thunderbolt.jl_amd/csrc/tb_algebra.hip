@@ -288,4 +288,86 @@ int launch_cg(tb_pattern *pat, const double *A, const double *b, double *x, doub
     return TB_OK;
 }
 
+// apply_zero!(K, f, ch) on device CSR (Ferrite.apply_zero!; CSR method src/utils.jl:263-278, call sites
+// src/solver/nonlinear/nlsolve_common.jl:12-26): rows and columns of prescribed dofs are zeroed, their diagonal entry is set
+// to `diag` (Ferrite uses the mean diagonal so the conditioning survives), f is zeroed there.  8 lanes per row.
+__global__ void __launch_bounds__(256)
+k_apply_zero_csr(int64_t nrows, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const uint8_t *__restrict__ flags,
+                 double diag, double *__restrict__ nz, double *__restrict__ f)
+{
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    const int sub = threadIdx.x & 7;
+    if (r >= nrows) return;
+    const bool pr = flags[r];
+    if (nz)
+        for (int64_t k = rowptr[r] + sub; k < rowptr[r + 1]; k += 8) {
+            const int32_t c = colidx[k];
+            if (pr) nz[k] = c == r ? diag : 0.0;
+            else if (flags[c]) nz[k] = 0.0;
+        }
+    if (f && pr && sub == 0) f[r] = 0.0;
+}
+
+// Σ |diag| / n (Ferrite.meandiag)
+__global__ void __launch_bounds__(256)
+k_sum_absdiag(int64_t nrows, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const double *__restrict__ nz, double *__restrict__ out)
+{
+    double s = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += stride)
+        for (int64_t k = rowptr[r]; k < rowptr[r + 1]; ++k)
+            if (colidx[k] == r) { s += fabs(nz[k]); break; }
+    block_sum_to(s, out);
+}
+
+static int scratch2(tb_pattern *pat, double **scal)
+{
+    const int64_t n = pat->n_rows;
+    if (!pat->d_cg_ws) TB_HIP(hipMalloc((void **)&pat->d_cg_ws, sizeof(double) * (4 * n + 2)));
+    *scal = pat->d_cg_ws + 4 * n;
+    return TB_OK;
+}
+
+int launch_apply_zero(tb_pattern *pat, double *nz, double *f, const uint8_t *flags, double diag)
+{
+    tb_device *dev = pat->mesh->dev;
+    const int64_t n = pat->n_rows;
+    if (!n) return TB_OK;
+    hipLaunchKernelGGL(k_apply_zero_csr, dim3((unsigned)((n * 8 + 255) / 256)), dim3(256), 0, dev->stream, n, pat->d_rowptr, pat->d_colidx, flags, diag, nz, f);
+    TB_HIP(hipGetLastError());
+    return TB_OK;
+}
+
+int launch_meandiag(tb_pattern *pat, const double *nz, double *result)
+{
+    tb_device *dev = pat->mesh->dev;
+    const int64_t n = pat->n_rows;
+    *result = 0.0;
+    if (!n) return TB_OK;
+    double *scal;
+    int rc = scratch2(pat, &scal);
+    if (rc) return rc;
+    TB_HIP(hipMemsetAsync(scal, 0, 2 * sizeof(double), dev->stream));
+    hipLaunchKernelGGL(k_sum_absdiag, dim3(grid_for(dev, n, 256)), dim3(256), 0, dev->stream, n, pat->d_rowptr, pat->d_colidx, nz, scal);
+    TB_HIP(hipGetLastError());
+    double h = 0.0;
+    TB_HIP(hipMemcpyAsync(&h, scal, sizeof h, hipMemcpyDeviceToHost, dev->stream));
+    TB_HIP(hipStreamSynchronize(dev->stream));
+    *result = h / (double)n;
+    return TB_OK;
+}
+
+int launch_dot(tb_device *dev, int64_t n, const double *a, const double *b, double *result)
+{
+    double *scal = (double *)&dev->d_status->cell; // 8-byte scratch inside the status block
+    TB_HIP(hipMemsetAsync(scal, 0, sizeof(double), dev->stream));
+    if (n > 0) {
+        hipLaunchKernelGGL(k_dot, dim3(grid_for(dev, n, 256)), dim3(256), 0, dev->stream, n, a, b, scal);
+        TB_HIP(hipGetLastError());
+    }
+    TB_HIP(hipMemcpyAsync(result, scal, sizeof(double), hipMemcpyDeviceToHost, dev->stream));
+    TB_HIP(hipStreamSynchronize(dev->stream));
+    return TB_OK;
+}
+
 } // namespace tb

@@ -602,6 +602,26 @@ int tb_axpy(tb_device *dev, int64_t n, double a, const double *d_x, double *d_y)
     return launch_axpy(dev, n, a, d_x, d_y);
 }
 
+int tb_dot(tb_device *dev, int64_t n, const double *d_x, const double *d_y, double *result)
+{
+    TB_REQUIRE(dev && result && n >= 0 && ((d_x && d_y) || n == 0), "tb_dot: bad argument");
+    return launch_dot(dev, n, d_x, d_y, result);
+}
+
+int tb_apply_zero_csr(tb_pattern *pat, double *d_nzval, double *d_f, const uint8_t *d_prescribed, double diag)
+{
+    TB_REQUIRE(pat && d_prescribed && (d_nzval || d_f), "tb_apply_zero_csr: NULL argument");
+    TB_HIP(hipSetDevice(pat->mesh->dev->id));
+    return launch_apply_zero(pat, d_nzval, d_f, d_prescribed, diag);
+}
+
+int tb_meandiag(tb_pattern *pat, const double *d_nzval, double *result)
+{
+    TB_REQUIRE(pat && d_nzval && result, "tb_meandiag: NULL argument");
+    TB_HIP(hipSetDevice(pat->mesh->dev->id));
+    return launch_meandiag(pat, d_nzval, result);
+}
+
 int tb_absmax(tb_device *dev, int64_t n, const double *d_x, int64_t stride, double *result)
 {
     TB_REQUIRE(dev && d_x && result && n >= 0 && stride >= 1, "tb_absmax: bad argument");

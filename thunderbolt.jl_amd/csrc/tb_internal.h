@@ -179,6 +179,9 @@ int launch_cg(tb_pattern *pat, const double *A, const double *b, double *x, doub
               double *resnorm);
 int launch_axpy(tb_device *dev, int64_t n, double a, const double *x, double *y);
 int launch_absmax(tb_device *dev, int64_t n, const double *x, int64_t stride, double *result);
+int launch_apply_zero(tb_pattern *pat, double *nz, double *f, const uint8_t *flags, double diag);
+int launch_meandiag(tb_pattern *pat, const double *nz, double *result);
+int launch_dot(tb_device *dev, int64_t n, const double *a, const double *b, double *result);
 int launch_max(tb_device *dev, int64_t n, const double *x, int64_t stride, double *result);
 double decode_ordered_key(unsigned long long k);
 
