@@ -196,7 +196,7 @@ def main():
             "roofline": {"kernel": "k_matrix_patch<Hex8<2>,DIFFUSION>" if args.strategy == "patch" else "k_matrix_direct<Hex8<2>,DIFFUSION>",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None,
-                         "note": "algorithmic 272 B/cell; the kernel is FP64-VALU-bound (≈5 kflop/cell, FP64 MFMA = vector rate on CDNA4), see DESIGN.md",
+                         "note": "algorithmic 272 B/cell; the kernel is FP64-VALU-bound (≈5 kflop/cell; FP64 MFMA is no faster than FP64 FMA on CDNA4: 48 vs 70 TF measured), see DESIGN.md",
                          "reaction": {"bound": "hbm", "achieved": (BYTES_PER_DOF_UPDATE + (8 if args.keep_du else 0)) * ns * npts / (phase["reaction"] / K_ * 1e-3) / 1e9,
                                       "peak": HBM_PEAK_GBS, "unit": "GB/s"}},
         }
