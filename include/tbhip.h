@@ -63,6 +63,7 @@ enum {
     TB_FORM_MASS = 0,      /* Mₑ[i,j] += ρ NᵢNⱼ dΩ          src/modeling/core/mass.jl:28-43       */
     TB_FORM_DIFFUSION = 1, /* Kₑ[i,j] -= ∇Nⱼ·D·∇Nᵢ dΩ       src/modeling/core/diffusion.jl:28-50  */
     TB_FORM_SOURCE = 2,    /* bₑ[j]  += f(x_q,t) Nⱼ dΩ      src/modeling/core/analytical_coefficient.jl:80-101 */
+    TB_FORM_FACET = 4,       /* weak boundary conditions on hexahedron facets   src/modeling/core/weak_boundary_conditions.jl */
     TB_FORM_HYPERELASTIC = 3 /* rₑ[i] += ∇δuᵢ⊡P dΩ, Kₑ[i,j] += (∇δuᵢ⊡𝔸)⊡∇δuⱼ dΩ   src/modeling/solid/elements.jl:177-313 */
 };
 
@@ -197,6 +198,17 @@ int tb_residual(tb_form *form, int strategy, const double *d_u, double t, double
  * elimination is NOT part of it (applied afterwards on the host: src/solver/nonlinear/nlsolve_common.jl:12-26). */
 int tb_linearize(tb_form *form, tb_pattern *pat, int strategy, const double *d_u, double t, double *d_nzval, double *d_r);
 /* host evaluation of the device material routine (Ψ, P = ∂Ψ/∂F, 𝔸 = ∂²Ψ/∂F²; row-major F[3i+j], A[9(3i+j)+3k+l]) */
+/* Weak boundary conditions of a quasi-static problem (src/modeling/core/weak_boundary_conditions.jl): RobinBC
+ * Ψ = α u·u (:102-198), NormalSpringBC Ψ = ½ kₛ (u·N)² (:200-300), ConstantPressureBC follower load p·J·F⁻ᵀ·n₀ with its
+ * consistent tangent (:419-515).  `facets` lists n_facets pairs (cell, local facet) — Ferrite's FacetIndex, local facets of
+ * the hexahedron numbered as Ferrite.reference_facets(RefHexahedron); `facet_qpoints` = Gauss points per direction on the
+ * facet (the reference uses the interpolation order, src/discretization/fem.jl:80-90; 0 selects that).
+ * tb_facet_assemble ADDS to d_nzval / d_r (either may be NULL): the reference accumulates surface terms into the same
+ * Kₑ / rₑ as the volume term (call it after tb_linearize / tb_residual).  Vector field on hexahedra only. */
+enum { TB_BC_ROBIN = 0, TB_BC_NORMAL_SPRING = 1, TB_BC_PRESSURE = 2 };
+int tb_facet_form_create(tb_mesh *mesh, int bc_kind, double param, int facet_qpoints, const int32_t *facets, int64_t n_facets,
+                         int index_base, tb_form **out);
+int tb_facet_assemble(tb_form *form, tb_pattern *pat, const double *d_u, double t, double *d_nzval, double *d_r);
 int tb_host_material_eval(const tb_material *material, const double *F, double *psi, double *P, double *A);
 
 /* ------------------------------------------------------------------ pointwise reaction step

@@ -318,6 +318,34 @@ def element_hyperelastic(mesh, cell, ue, p=HO_DEFAULTS, fsn=np.eye(3), want_K=Tr
     return Ke, re
 
 
+BC_ROBIN, BC_NORMAL_SPRING, BC_PRESSURE = 0, 1, 2
+
+
+def element_facet(mesh, cell, local_facet, kind, param, fq, ue, want_K=True, want_r=True):
+    """assemble_facet! of one (cell, local facet 0…5) (weak_boundary_conditions.jl): returns (Ke, re) contributions."""
+    nd = mesh.cell_dofs.shape[1]
+    Ke = np.zeros((nd, nd)) if want_K else None
+    re = np.zeros(nd) if want_r else None
+    rc = lib().orc_element_facet(C.byref(mesh.c), C.c_int64(cell), int(local_facet), int(kind), C.c_double(param), int(fq), _d(_f64(ue)),
+                                 _d(Ke), _d(re))
+    assert rc == 0, rc
+    return Ke, re
+
+
+def assemble_facets(mesh, kind, param, fq, facets, u, rowptr=None, colidx=None, nz=None, r=None):
+    """Adds the facet integrals of `facets` ((cell, local facet) pairs) to nz / r (created zeroed when None is passed
+    together with a pattern / as r=True)."""
+    facets = np.ascontiguousarray(facets, dtype=np.int32).reshape(-1, 2)
+    if nz is None and rowptr is not None:
+        nz = np.zeros(int(rowptr[-1]))
+    if r is None or r is True:
+        r = np.zeros(mesh.ndofs)
+    rc = lib().orc_assemble_facets(C.byref(mesh.c), int(kind), C.c_double(param), int(fq), _i32(facets), C.c_int64(len(facets)), _d(_f64(u)),
+                                   _i64(rowptr), _i32(colidx), _d(nz), _d(r))
+    assert rc == 0, rc
+    return nz, r
+
+
 def assemble_hyperelastic(mesh, u, rowptr=None, colidx=None, p=HO_DEFAULTS, fsn=np.eye(3), want_K=True, want_r=True,
                           nthreads=1, color=None, ncolors=0):
     nz = np.zeros(int(rowptr[-1])) if want_K else None

@@ -1204,3 +1204,129 @@ int orc_assemble_hyperelastic(const orc_mesh *m, const double *p, const double *
     }
     return err ? -1 : 0;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* weak boundary conditions (facet integrals)                                                  */
+/* ------------------------------------------------------------------------------------------ */
+
+/* facet lf of the reference hexahedron: fixed coordinate, its value, and the two in-facet directions (s, t) ordered so
+ * that ∂x/∂s × ∂x/∂t points outwards (vertex cycles (1,4,3,2),(1,2,6,5),(2,3,7,6),(3,4,8,7),(1,5,8,4),(5,6,7,8)) */
+static const int FACET_FIX[6] = {2, 1, 0, 1, 0, 2};
+static const double FACET_VAL[6] = {-1, -1, 1, 1, -1, 1};
+static const int FACET_S[6] = {1, 0, 1, 2, 2, 0};
+static const int FACET_T[6] = {0, 2, 2, 0, 1, 1};
+
+int orc_element_facet(const orc_mesh *m, int64_t cell, int lf, int kind, double param, int fq, const double *ue, double *Ke, double *re)
+{
+    if (m->kind != ORC_HEX8 && m->kind != ORC_HEX27) return -2;
+    if (lf < 0 || lf > 5 || fq < 1 || fq > 3) return -2;
+    int dim, nb;
+    orc_elem_info(m->kind, &dim, &nb);
+    const int nd = 3 * nb;
+    double x[24];
+    for (int a = 0; a < 8; ++a) for (int d = 0; d < 3; ++d) x[3 * a + d] = m->xyz[3 * (int64_t)m->conn[cell * 8 + a] + d];
+    double g1[3], w1[3];
+    orc_quadrature(ORC_LINE2, fq, g1, w1);
+    for (int qt = 0; qt < fq; ++qt)
+        for (int qs = 0; qs < fq; ++qs) {
+            double xi[3];
+            xi[FACET_FIX[lf]] = FACET_VAL[lf];
+            xi[FACET_S[lf]] = g1[qs];
+            xi[FACET_T[lf]] = g1[qt];
+            double N[27], dN[81], M[8], dM[24], J[9], Jinv[9], det;
+            orc_shape(m->kind, xi, N, dN);
+            orc_shape(ORC_HEX8, xi, M, dM);
+            if (orc_mapping(3, 8, x, dM, J, &det, Jinv)) return -1;
+            /* weighted normal = ∂x/∂s × ∂x/∂t (columns of J) */
+            const int cs = FACET_S[lf], ct = FACET_T[lf];
+            const double a[3] = {J[0 + cs], J[3 + cs], J[6 + cs]}, b[3] = {J[0 + ct], J[3 + ct], J[6 + ct]};
+            double nw[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+            const double len = sqrt(nw[0] * nw[0] + nw[1] * nw[1] + nw[2] * nw[2]);
+            const double dG = len * w1[qs] * w1[qt];
+            const double n0[3] = {nw[0] / len, nw[1] / len, nw[2] / len};
+            /* u_q = Σ N_a u_a (function_value), ∇u = Σ u_a ⊗ ∇N_a (function_gradient) */
+            double uq[3] = {0, 0, 0}, dNdx[81], F[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+            for (int aa = 0; aa < nb; ++aa)
+                for (int k = 0; k < 3; ++k) {
+                    double sgr = 0;
+                    for (int mm = 0; mm < 3; ++mm) sgr += dN[3 * aa + mm] * Jinv[3 * mm + k];
+                    dNdx[3 * aa + k] = sgr;
+                }
+            for (int aa = 0; aa < nb; ++aa)
+                for (int c = 0; c < 3; ++c) {
+                    uq[c] += N[aa] * ue[3 * aa + c];
+                    for (int k = 0; k < 3; ++k) F[3 * c + k] += ue[3 * aa + c] * dNdx[3 * aa + k];
+                }
+            if (kind == ORC_BC_ROBIN || kind == ORC_BC_NORMAL_SPRING) {
+                double grad[3], H[9];
+                if (kind == ORC_BC_ROBIN) { /* Ψ = α u·u */
+                    for (int c = 0; c < 3; ++c) grad[c] = 2.0 * param * uq[c];
+                    for (int c = 0; c < 3; ++c) for (int d = 0; d < 3; ++d) H[3 * c + d] = c == d ? 2.0 * param : 0.0;
+                } else { /* Ψ = ½ kₛ (u·N)² */
+                    const double un = uq[0] * n0[0] + uq[1] * n0[1] + uq[2] * n0[2];
+                    for (int c = 0; c < 3; ++c) grad[c] = param * un * n0[c];
+                    for (int c = 0; c < 3; ++c) for (int d = 0; d < 3; ++d) H[3 * c + d] = param * n0[c] * n0[d];
+                }
+                for (int i = 0; i < nd; ++i) { /* δuᵢ = N_a e_c */
+                    const int ai = i / 3, ci = i % 3;
+                    if (re) re[i] += N[ai] * grad[ci] * dG;
+                    if (Ke)
+                        for (int j = 0; j < nd; ++j) Ke[(size_t)i * nd + j] += N[ai] * H[3 * ci + (j % 3)] * N[j / 3] * dG;
+                }
+            } else if (kind == ORC_BC_PRESSURE) {
+                double Fi[9], Jf;
+                {   /* invF, J = det F */
+                    const double c00 = F[4] * F[8] - F[5] * F[7], c01 = F[5] * F[6] - F[3] * F[8], c02 = F[3] * F[7] - F[4] * F[6];
+                    Jf = F[0] * c00 + F[1] * c01 + F[2] * c02;
+                    const double id = 1.0 / Jf;
+                    Fi[0] = c00 * id; Fi[1] = (F[2] * F[7] - F[1] * F[8]) * id; Fi[2] = (F[1] * F[5] - F[2] * F[4]) * id;
+                    Fi[3] = c01 * id; Fi[4] = (F[0] * F[8] - F[2] * F[6]) * id; Fi[5] = (F[2] * F[3] - F[0] * F[5]) * id;
+                    Fi[6] = c02 * id; Fi[7] = (F[1] * F[6] - F[0] * F[7]) * id; Fi[8] = (F[0] * F[4] - F[1] * F[3]) * id;
+                }
+                double cn[3]; /* cofF·n₀ = F⁻ᵀ n₀ */
+                for (int c = 0; c < 3; ++c) cn[c] = Fi[0 + c] * n0[0] + Fi[3 + c] * n0[1] + Fi[6 + c] * n0[2];
+                for (int i = 0; i < nd; ++i) {
+                    const int ai = i / 3, ci = i % 3;
+                    if (re) re[i] += param * Jf * cn[ci] * N[ai] * dG;
+                    if (!Ke) continue;
+                    for (int j = 0; j < nd; ++j) {
+                        const int bj = j / 3, dj = j % 3;
+                        /* ∇δuⱼ = e_d ⊗ ∇N_b;  A = invF·∇δuⱼ·invF;  δcofF = −Aᵀ;  δJ = J tr(∇δuⱼ·invF) */
+                        double gF[3]; /* (∇N_b)ᵀ·invF : row vector */
+                        for (int k = 0; k < 3; ++k) gF[k] = dNdx[3 * bj + 0] * Fi[0 + k] + dNdx[3 * bj + 1] * Fi[3 + k] + dNdx[3 * bj + 2] * Fi[6 + k];
+                        const double dJ = Jf * gF[dj];
+                        /* A[r][k] = invF[r][d] gF[k];  (δcofF·n₀)[c] = −Σ_r A[r][c] n₀[r] = −gF[c] Σ_r invF[r][d] n₀[r] */
+                        const double fin = Fi[0 + dj] * n0[0] + Fi[3 + dj] * n0[1] + Fi[6 + dj] * n0[2];
+                        const double v = dJ * cn[ci] + Jf * (-gF[ci] * fin);
+                        Ke[(size_t)i * nd + j] += param * v * N[ai] * dG;
+                    }
+                }
+            } else return -2;
+        }
+    return 0;
+}
+
+int orc_assemble_facets(const orc_mesh *m, int kind, double param, int fq, const int32_t *facets, int64_t nf, const double *u,
+                        const int64_t *rowptr, const int32_t *colidx, double *nzval, double *r)
+{
+    int dim, nb;
+    if (orc_elem_info(m->kind, &dim, &nb)) return -2;
+    const int nd = 3 * nb;
+    double *Ke = nzval ? (double *)malloc(sizeof(double) * nd * nd) : NULL;
+    int err = 0;
+    for (int64_t f = 0; f < nf && !err; ++f) {
+        const int64_t cell = facets[2 * f];
+        const int32_t *dofs = m->cell_dofs + cell * nd;
+        double ue[81], re[81];
+        for (int i = 0; i < nd; ++i) { ue[i] = u[dofs[i]]; re[i] = 0.0; }
+        if (Ke) memset(Ke, 0, sizeof(double) * nd * nd);
+        err = orc_element_facet(m, cell, facets[2 * f + 1], kind, param, fq, ue, Ke, r ? re : NULL);
+        if (!err && nzval) {
+            /* add: scatter_matrix accumulates */
+            err = scatter_matrix(nd, dofs, Ke, rowptr, colidx, nzval);
+        }
+        if (!err && r) for (int i = 0; i < nd; ++i) r[dofs[i]] += re[i];
+    }
+    free(Ke);
+    return err;
+}

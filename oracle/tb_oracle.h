@@ -168,6 +168,22 @@ void orc_set_microstructure_field(const double *field);
 int orc_assemble_hyperelastic(const orc_mesh *m, const double *p, const double *fsn, const double *u,
                               const int64_t *rowptr, const int32_t *colidx, double *nzval, double *r, int nthreads,
                               const int32_t *color, int ncolors);
+
+/* ---- weak boundary conditions on hexahedron facets (src/modeling/core/weak_boundary_conditions.jl) ----
+ * kind: RobinBC Ψ = α u·u (:102-168), NormalSpringBC Ψ = ½ kₛ (u·N)² (:200-300), ConstantPressureBC follower load
+ * p·J·F⁻ᵀ·n₀ with its tangent (:419-515).  FacetValues conventions are Ferrite's [UNPINNED]: reference facets of
+ * RefHexahedron (1,4,3,2),(1,2,6,5),(2,3,7,6),(3,4,8,7),(1,5,8,4),(5,6,7,8); Gauss–Legendre tensor rule with `fq` points
+ * per direction on the facet (FacetQuadratureRuleCollection(interpolation order), src/discretization/fem.jl:80-90);
+ * dΓ·n₀ = ∂x/∂s × ∂x/∂t · w, oriented outwards.  facets: nf pairs (cell, local facet 0…5).
+ * Contributions are ADDED to nzval / r (the reference accumulates them into the same Kₑ / rₑ as the volume term). */
+#define ORC_BC_ROBIN 0
+#define ORC_BC_NORMAL_SPRING 1
+#define ORC_BC_PRESSURE 2
+int orc_element_facet(const orc_mesh *m, int64_t cell, int local_facet, int kind, double param, int fq, const double *ue,
+                      double *Ke /* nd×nd or NULL, accumulated */, double *re /* nd or NULL, accumulated */);
+int orc_assemble_facets(const orc_mesh *m, int kind, double param, int fq, const int32_t *facets, int64_t nf, const double *u,
+                        const int64_t *rowptr, const int32_t *colidx, double *nzval, double *r);
+
 #ifdef __cplusplus
 }
 #endif

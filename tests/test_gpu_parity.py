@@ -674,3 +674,36 @@ def test_newton_raphson_with_dirichlet_elimination(tb, oracle, device, order, ne
     assert np.all(A[flag][:, ~flag] == 0) and np.all(A[~flag][:, flag] == 0)
     np.testing.assert_array_equal(A[flag][:, flag], md * np.eye(flag.sum()))
     np.testing.assert_array_equal(A[~flag][:, ~flag], sps.csr_matrix((J0, sp.colidx, sp.rowptr), shape=(n, n)).toarray()[~flag][:, ~flag])
+
+
+@pytest.mark.parametrize("order,nel", [(1, (3, 2, 2)), (2, (2, 2, 1))])
+def test_weak_boundary_conditions_parity(tb, oracle, device, order, nel):
+    """RobinBC / NormalSpringBC / ConstantPressureBC facet terms (weak_boundary_conditions.jl) added to the volume term,
+    against the oracle; update_linearization!, K-only and residual! variants agree."""
+    g, dh, sp, om = mech_problem(tb, oracle, nel, order, perturb=0.1)
+    rng = np.random.default_rng(4)
+    u = rng.uniform(-1e-2, 1e-2, dh.ndofs)
+    fsn = np.eye(3)
+    bcs = [tb.RobinBC(0.3, "left"), tb.NormalSpringBC(2.0, "top"), tb.ConstantPressureBC(0.05, "right"), tb.ConstantPressureBC(-0.02, "front")]
+    okind = {tb.RobinBC: oracle.BC_ROBIN, tb.NormalSpringBC: oracle.BC_NORMAL_SPRING, tb.ConstantPressureBC: oracle.BC_PRESSURE}
+    Kref, rref = oracle.assemble_hyperelastic(om, u, sp.rowptr, sp.colidx, fsn=fsn)
+    Kvol = Kref.copy()
+    for bc in bcs:
+        oracle.assemble_facets(om, okind[type(bc)], bc.param, order, g.facetset(bc.boundary_name), u, sp.rowptr, sp.colidx, nz=Kref, r=rref)
+    assert np.abs(Kref - Kvol).max() > 1e-4 * np.abs(Kvol).max()          # the surface terms are not negligible here
+    model = tb.QuasiStaticModel("u", tb.PK1Model(tb.HolzapfelOgden2009Model(), tb.ConstantCoefficient(tb.OrthotropicMicrostructure(*fsn))), bcs)
+    du = device.to_device(u)
+    for st in (tb.ElementAssemblyStrategy(device), tb.AtomicAssemblyStrategy(device)):
+        op = tb.setup_operator(st, model, dh, sp)
+        res = device.zeros(dh.ndofs)
+        tb.update_linearization(op, du, 0.0, residual=res)
+        assert rel_err(op.J.to_host(), Kref) < 1e-11
+        assert rel_err(res.to_host(), rref) < 1e-11
+        res2 = device.zeros(dh.ndofs)
+        tb.residual(op, res2, du, 0.0)
+        assert rel_err(res2.to_host(), rref) < 1e-11
+        tb.update_linearization(op, du, 0.0)
+        assert rel_err(op.J.to_host(), Kref) < 1e-11
+    # facet index validation
+    with pytest.raises(tb.TBError):
+        tb.setup_operator(tb.AtomicAssemblyStrategy(device), tb.QuasiStaticModel("u", model.constitutive_model, [tb.RobinBC(1.0, np.array([[0, 6]]))]), dh, sp)

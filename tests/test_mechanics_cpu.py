@@ -88,3 +88,61 @@ def test_threaded_hyperelastic_assembly(oracle):
     K2, r2 = oracle.assemble_hyperelastic(m, u, rp, ci, nthreads=4, color=col, ncolors=nc)
     np.testing.assert_allclose(K2, K, rtol=1e-12, atol=1e-14)
     np.testing.assert_allclose(r2, r, rtol=1e-12, atol=1e-16)
+
+
+# ------------------------------------------------------------------------------------------- weak boundary conditions
+def _one_hex(oracle, order, distort=0.0, seed=0):
+    rng = np.random.default_rng(seed)
+    xyz, conn = oracle.generate_grid_hex(1, 1, 1, (0, 0, 0), (1.0, 1.0, 1.0))
+    xyz = xyz + distort * rng.uniform(-1, 1, xyz.shape)
+    kind, q = (oracle.HEX8, 2) if order == 1 else (oracle.HEX27, 3)
+    cd, nd = oracle.close_dofs(kind, 3, conn, len(xyz))
+    return oracle.Mesh(kind, q, xyz, conn, cd), nd
+
+
+@pytest.mark.parametrize("order", [1, 2])
+def test_facet_terms_closed_forms(oracle, order):
+    """Closed forms on the unit cube (weak_boundary_conditions.jl): Robin r = 2α·M_Γ·u and K = 2α·M_Γ (Σ = 2α·area per
+    component); pressure at u = 0 pushes with p·area·n₀ in total; on a closed surface the follower load has no resultant."""
+    m, nd = _one_hex(oracle, order)
+    fq = order + 1
+    normals = np.array([[0, 0, -1], [0, -1, 0], [1, 0, 0], [0, 1, 0], [-1, 0, 0], [0, 0, 1]], dtype=float)
+    u0 = np.zeros(nd)
+    for lf in range(6):
+        Ke, re = oracle.element_facet(m, 0, lf, oracle.BC_ROBIN, 0.7, fq, np.tile([1.0, -2.0, 0.5], nd // 3))
+        assert Ke.sum() == pytest.approx(3 * 2 * 0.7 * 1.0, rel=1e-13)
+        np.testing.assert_allclose(re.reshape(-1, 3).sum(axis=0), 2 * 0.7 * np.array([1.0, -2.0, 0.5]), rtol=1e-13)
+        np.testing.assert_allclose(Ke, Ke.T, atol=1e-15)
+        _, rp = oracle.element_facet(m, 0, lf, oracle.BC_PRESSURE, 3.0, fq, u0)
+        np.testing.assert_allclose(rp.reshape(-1, 3).sum(axis=0), 3.0 * normals[lf], atol=1e-14)
+        Kn, rn = oracle.element_facet(m, 0, lf, oracle.BC_NORMAL_SPRING, 2.0, fq, np.tile([1.0, -2.0, 0.5], nd // 3))
+        un = np.array([1.0, -2.0, 0.5]) @ normals[lf]
+        np.testing.assert_allclose(rn.reshape(-1, 3).sum(axis=0), 2.0 * un * normals[lf], atol=1e-13)
+    rng = np.random.default_rng(1)
+    md, nd = _one_hex(oracle, order, distort=0.1, seed=3)
+    u = rng.uniform(-0.05, 0.05, nd)
+    tot = np.zeros(3)
+    for lf in range(6):
+        _, rp = oracle.element_facet(md, 0, lf, oracle.BC_PRESSURE, 1.3, fq + 1 if fq < 3 else 3, u)
+        tot += rp.reshape(-1, 3).sum(axis=0)
+    if order == 1:  # exact only when the rule integrates the (tri-quadratic) integrand: Q1 with 3 points
+        assert np.abs(tot).max() < 1e-13
+
+
+@pytest.mark.parametrize("order", [1, 2])
+@pytest.mark.parametrize("kind", ["BC_ROBIN", "BC_NORMAL_SPRING", "BC_PRESSURE"])
+def test_facet_tangent_is_derivative_of_residual(oracle, order, kind):
+    m, nd = _one_hex(oracle, order, distort=0.12, seed=5)
+    rng = np.random.default_rng(2)
+    u = rng.uniform(-0.05, 0.05, nd)
+    k = getattr(oracle, kind)
+    for lf in (0, 3, 4):
+        Ke, _ = oracle.element_facet(m, 0, lf, k, 1.7, order + 1, u)
+        fd = np.zeros_like(Ke)
+        h = 1e-6
+        for j in range(nd):
+            e = np.zeros(nd); e[j] = h
+            _, rp = oracle.element_facet(m, 0, lf, k, 1.7, order + 1, u + e, want_K=False)
+            _, rm = oracle.element_facet(m, 0, lf, k, 1.7, order + 1, u - e, want_K=False)
+            fd[:, j] = (rp - rm) / (2 * h)
+        assert np.abs(Ke - fd).max() < 1e-8 * max(1.0, np.abs(Ke).max())

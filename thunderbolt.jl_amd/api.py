@@ -216,6 +216,18 @@ class Grid:
     def n_nodes(self):
         return self.xyz.shape[0]
 
+    def facetset(self, name):
+        """getfacetset(grid, name) of a generated box: left/right (x), front/back (y), bottom/top (z), as (cell, local
+        facet) pairs, 0-based (Ferrite generate_grid facetsets; local facets as Ferrite.reference_facets(RefHexahedron))."""
+        if self.dims is None or self.cell_kind != Hexahedron:
+            raise KeyError("facetsets exist on generated hexahedral boxes only; pass explicit (cell, facet) pairs otherwise")
+        nx, ny, nz = self.dims
+        c = np.arange(nx * ny * nz).reshape(nz, ny, nx)
+        sel, lf = {"left": (c[:, :, 0], 4), "right": (c[:, :, -1], 2), "front": (c[:, 0, :], 1), "back": (c[:, -1, :], 3),
+                   "bottom": (c[0, :, :], 0), "top": (c[-1, :, :], 5)}[name]
+        cells = sel.ravel()
+        return np.stack([cells, np.full_like(cells, lf)], axis=1).astype(np.int32)
+
 
 def generate_mesh(cell_kind, nel, left=(-1.0, -1.0, -1.0), right=(1.0, 1.0, 1.0), perturb=0.0):
     """generate_mesh(Hexahedron, (nx,ny,nz), left, right) — Ferrite generate_grid conventions."""
@@ -776,11 +788,35 @@ class PK1Model:
         return m
 
 
+class RobinBC:
+    """RobinBC(α, boundary_name): P·n₀ = −α u (weak_boundary_conditions.jl:23-26; energy α u·u)."""
+    kind = L.TB_BC_ROBIN
+
+    def __init__(self, alpha, boundary_name):
+        self.param, self.boundary_name = float(alpha), boundary_name
+
+
+class NormalSpringBC:
+    """NormalSpringBC(kₛ, boundary_name): energy ½ kₛ (u·N)² (weak_boundary_conditions.jl:35-38)."""
+    kind = L.TB_BC_NORMAL_SPRING
+
+    def __init__(self, ks, boundary_name):
+        self.param, self.boundary_name = float(ks), boundary_name
+
+
+class ConstantPressureBC:
+    """ConstantPressureBC(p, boundary_name): follower load p·J·F⁻ᵀ·n₀ (weak_boundary_conditions.jl:59-62,419-515)."""
+    kind = L.TB_BC_PRESSURE
+
+    def __init__(self, p, boundary_name):
+        self.param, self.boundary_name = float(p), boundary_name
+
+
 class QuasiStaticModel:
-    """QuasiStaticModel(:u, constitutive_model, ()) (test/test_elements.jl:99-125)."""
+    """QuasiStaticModel(:u, constitutive_model, facet_models) (test/test_elements.jl:99-125, fem.jl:597-623)."""
 
     def __init__(self, sym, constitutive_model, facet_models=()):
-        self.sym, self.constitutive_model = sym, constitutive_model
+        self.sym, self.constitutive_model, self.facet_models = sym, constitutive_model, tuple(facet_models)
 
 
 def material_routine(model, F):
@@ -805,9 +841,19 @@ class NonlinearOperator:
         self.form = C.c_void_p()
         check(lib().tb_hyperelastic_create(self.dmesh.h, qorder, C.byref(self._mat), C.byref(self.form)))
         self.J = DeviceVector(strategy.device, pattern.nnz)
+        # surface terms: one facet form per weak boundary condition (setup_boundary_cache, weak_boundary_conditions.jl:1-7)
+        self.facet_forms = []
+        for bc in getattr(model, "facet_models", ()):
+            fs = bc.boundary_name if not isinstance(bc.boundary_name, str) else dh.grid.facetset(bc.boundary_name)
+            fs = np.ascontiguousarray(fs, dtype=np.int32).reshape(-1, 2)
+            h = C.c_void_p()
+            check(lib().tb_facet_form_create(self.dmesh.h, bc.kind, bc.param, 0, fs.ctypes.data_as(L.c_i32p), len(fs), 0, C.byref(h)))
+            self.facet_forms.append(h)
 
     def __del__(self):
         try:
+            for h in self.facet_forms:
+                lib().tb_form_destroy(h)
             if self.form:
                 lib().tb_form_destroy(self.form)
         except Exception:
@@ -815,14 +861,19 @@ class NonlinearOperator:
 
 
 def update_linearization(op, u, t=0.0, residual=None):
-    """update_linearization!(op, residual, u, p) / update_linearization!(op, u, p) (newton_raphson.jl:238)."""
+    """update_linearization!(op, residual, u, p) / update_linearization!(op, u, p) (newton_raphson.jl:238): volume term,
+    then the surface terms are accumulated into the same J / residual."""
     check(lib().tb_linearize(op.form, op.pattern.h, op.strategy.code, _ptr(u), float(t), op.J.ptr, _ptr(residual)))
+    for h in op.facet_forms:
+        check(lib().tb_facet_assemble(h, op.pattern.h, _ptr(u), float(t), op.J.ptr, _ptr(residual)))
     return op
 
 
 def residual(op, residual, u, t=0.0):
     """residual!(op, residual, u, p) (newton_raphson.jl:234)."""
     check(lib().tb_residual(op.form, op.strategy.code, _ptr(u), float(t), _ptr(residual)))
+    for h in op.facet_forms:
+        check(lib().tb_facet_assemble(h, None, _ptr(u), float(t), None, _ptr(residual)))
     return residual
 
 

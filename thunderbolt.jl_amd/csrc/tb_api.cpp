@@ -363,7 +363,7 @@ int tb_form_create(tb_mesh *mesh, int form_kind, int qorder, const tb_coef *coef
 int tb_form_destroy(tb_form *f)
 {
     if (!f) return TB_OK;
-    hipFree(f->d_field); hipFree(f->d_table);
+    hipFree(f->d_field); hipFree(f->d_table); hipFree(f->d_facets);
     delete f;
     return TB_OK;
 }
@@ -465,6 +465,47 @@ int tb_linearize(tb_form *form, tb_pattern *pat, int strategy, const double *d_u
         return TB_OK;
     }
     return launch_hyperelastic(form, pat, strategy, d_u, d_nzval, d_r);
+}
+
+int tb_facet_form_create(tb_mesh *mesh, int bc_kind, double param, int facet_qpoints, const int32_t *facets, int64_t n_facets,
+                         int index_base, tb_form **out)
+{
+    TB_REQUIRE(mesh && out && (facets || n_facets == 0), "tb_facet_form_create: NULL argument");
+    *out = nullptr;
+    TB_REQUIRE(bc_kind >= TB_BC_ROBIN && bc_kind <= TB_BC_PRESSURE, "tb_facet_form_create: unknown boundary condition %d", bc_kind);
+    TB_REQUIRE(mesh->ncomp == 3 && mesh->geom_kind == TB_HEX8, "tb_facet_form_create: needs a 3-component field on hexahedra");
+    TB_REQUIRE(index_base == 0 || index_base == 1, "tb_facet_form_create: index_base must be 0 or 1");
+    TB_REQUIRE(n_facets >= 0, "tb_facet_form_create: negative facet count");
+    if (facet_qpoints == 0) facet_qpoints = kind_order(mesh->field_kind);
+    TB_REQUIRE(facet_qpoints >= 1 && facet_qpoints <= 3, "tb_facet_form_create: 1…3 Gauss points per facet direction (got %d)", facet_qpoints);
+    for (int64_t i = 0; i < mesh->n_cells * mesh->nb; ++i) {
+        const int32_t *d = &mesh->h_cell_dofs[3 * i];
+        TB_REQUIRE(d[1] == d[0] + 1 && d[2] == d[0] + 2, "tb_facet_form_create: dofs of a node are not consecutive (cell %lld)", (long long)(i / mesh->nb));
+    }
+    std::vector<int32_t> fl((size_t)2 * n_facets);
+    for (int64_t i = 0; i < n_facets; ++i) {
+        const int32_t c = facets[2 * i] - index_base, lf = facets[2 * i + 1] - index_base;
+        TB_REQUIRE(c >= 0 && c < mesh->n_cells && lf >= 0 && lf < 6, "tb_facet_form_create: facet %lld = (%d, %d) out of range", (long long)i, facets[2 * i], facets[2 * i + 1]);
+        fl[2 * i] = c; fl[2 * i + 1] = lf;
+    }
+    auto f = std::make_unique<tb_form>();
+    f->mesh = mesh; f->kind = TB_FORM_FACET; f->bc_kind = bc_kind; f->bc_param = param; f->facet_q = facet_qpoints; f->n_facets = n_facets;
+    TB_HIP(hipSetDevice(mesh->dev->id));
+    int rc = upload(mesh->dev, fl, &f->d_facets);
+    if (rc) return rc;
+    *out = f.release();
+    return TB_OK;
+}
+
+int tb_facet_assemble(tb_form *form, tb_pattern *pat, const double *d_u, double t, double *d_nzval, double *d_r)
+{
+    (void)t;
+    TB_REQUIRE(form && d_u && (d_nzval || d_r), "tb_facet_assemble: NULL argument");
+    TB_REQUIRE(form->kind == TB_FORM_FACET, "tb_facet_assemble: form is not a weak boundary condition");
+    TB_REQUIRE(!d_nzval || (pat && pat->mesh == form->mesh), "tb_facet_assemble: the tangent needs the pattern of the form's mesh");
+    if (form->n_facets == 0) return TB_OK;
+    TB_HIP(hipSetDevice(form->mesh->dev->id));
+    return launch_facets(form, pat, d_u, d_nzval, d_r);
 }
 
 int tb_host_material_eval(const tb_material *material, const double *F, double *psi, double *P, double *A)

@@ -151,6 +151,11 @@ struct tb_form {
     double *d_table = nullptr;
     int64_t table_len = 0;
     tb_material mat{};
+    // weak boundary conditions (TB_FORM_FACET)
+    int bc_kind = 0, facet_q = 0;
+    double bc_param = 0.0;
+    int32_t *d_facets = nullptr; // (cell, local facet) pairs, 0-based
+    int64_t n_facets = 0;
 };
 
 namespace tb {
@@ -179,6 +184,8 @@ int launch_cg(tb_pattern *pat, const double *A, const double *b, double *x, doub
               double *resnorm);
 int launch_axpy(tb_device *dev, int64_t n, double a, const double *x, double *y);
 int launch_absmax(tb_device *dev, int64_t n, const double *x, int64_t stride, double *result);
+int launch_facets(tb_form *f, tb_pattern *p, const double *d_u, double *d_nz, double *d_r);
+int ensure_blockpos(tb_pattern *p);
 int launch_apply_zero(tb_pattern *pat, double *nz, double *f, const uint8_t *flags, double diag);
 int launch_meandiag(tb_pattern *pat, const double *nz, double *result);
 int launch_dot(tb_device *dev, int64_t n, const double *a, const double *b, double *result);

@@ -532,7 +532,7 @@ static int check_node_rows(tb_pattern *p)
     return TB_OK;
 }
 
-static int ensure_blockpos(tb_pattern *p)
+int ensure_blockpos(tb_pattern *p)
 {
     if (p->d_blockpos) return TB_OK;
     tb_mesh *m = p->mesh;
@@ -629,6 +629,172 @@ int launch_hyperelastic(tb_form *f, tb_pattern *p, int strategy, const double *d
     else rc = q2 ? run<Q2Vec, false, true, false>(f, p, strategy, d_u, d_nz, d_r) : run<Q1Vec, false, true, false>(f, p, strategy, d_u, d_nz, d_r);
     if (rc) return rc;
     return check_status(m->dev);
+}
+
+
+// ------------------------------------------------------------------------------------------------ weak boundary conditions
+// Facet integrals of src/modeling/core/weak_boundary_conditions.jl (RobinBC :102-198, NormalSpringBC :200-300, pressure
+// follower load :419-515).  One 64-thread workgroup per (cell, local facet): per facet Gauss point the shape values,
+// mapped gradients and the few tensors the integrand needs are parked in LDS, then every thread sums its (i, j) pairs over
+// the points and adds the result to the CSR entry / residual entry with one atomic each (surface terms are O(n²) work, the
+// volume term O(n³): this kernel is not on the critical path).  FacetValues conventions are Ferrite's (tbhip.h).
+__host__ __device__ constexpr int facet_fix(int lf) { constexpr int v[6] = {2, 1, 0, 1, 0, 2}; return v[lf]; }
+__host__ __device__ constexpr double facet_val(int lf) { constexpr double v[6] = {-1, -1, 1, 1, -1, 1}; return v[lf]; }
+__host__ __device__ constexpr int facet_s(int lf) { constexpr int v[6] = {1, 0, 1, 2, 2, 0}; return v[lf]; }
+__host__ __device__ constexpr int facet_t(int lf) { constexpr int v[6] = {0, 2, 2, 0, 1, 1}; return v[lf]; }
+
+template <int NB>
+__device__ inline void shape_at(int a, const double (&xi)[3], double &N, double (&dN)[3])
+{
+    if (NB == 8) {
+        const double f[3] = {1.0 + hex_sgn(a, 0) * xi[0], 1.0 + hex_sgn(a, 1) * xi[1], 1.0 + hex_sgn(a, 2) * xi[2]};
+        N = 0.125 * f[0] * f[1] * f[2];
+        dN[0] = 0.125 * hex_sgn(a, 0) * f[1] * f[2];
+        dN[1] = 0.125 * f[0] * hex_sgn(a, 1) * f[2];
+        dN[2] = 0.125 * f[0] * f[1] * hex_sgn(a, 2);
+    } else {
+        double v[3], d[3];
+        for (int k = 0; k < 3; ++k) { v[k] = quad1d(hex27_tix(a, k), xi[k]); d[k] = dquad1d(hex27_tix(a, k), xi[k]); }
+        N = v[0] * v[1] * v[2];
+        dN[0] = d[0] * v[1] * v[2];
+        dN[1] = v[0] * d[1] * v[2];
+        dN[2] = v[0] * v[1] * d[2];
+    }
+}
+
+template <int NB>
+__global__ void __launch_bounds__(64)
+k_facets(MechMesh m, const int32_t *__restrict__ facets, int bc, double param, int fq, const double *__restrict__ u, double *__restrict__ nz,
+         double *__restrict__ r, const int64_t *__restrict__ rowptr, const uint16_t *__restrict__ blockpos, Status *st)
+{
+    constexpr int ND = 3 * NB, MAXQ = 9;
+    const int tid = threadIdx.x;
+    const int64_t cell = facets[2 * blockIdx.x];
+    const int lf = facets[2 * blockIdx.x + 1];
+    __shared__ double s_ue[ND], s_x[24], s_N[MAXQ][NB], s_G[MAXQ][NB][3];
+    __shared__ double s_q[MAXQ][32]; // per point: dΓ, n₀[3], grad[3] (Robin / spring) or J·cofF·n₀ [3], H[9] / invF[9], J, invFᵀ… (see below)
+    __shared__ int32_t s_dof[ND];
+    for (int i = tid; i < ND; i += 64) { const int32_t d = m.cell_dofs[cell * ND + i]; s_dof[i] = d; s_ue[i] = u[d]; }
+    for (int i = tid; i < 24; i += 64) s_x[i] = m.xyz[3 * (int64_t)m.conn[cell * 8 + i / 3] + i % 3];
+    __syncthreads();
+    const int nq = fq * fq;
+    const double gx[3][3] = {{0.0, 0.0, 0.0}, {-0.5773502691896258, 0.5773502691896258, 0.0}, {-0.7745966692414834, 0.0, 0.7745966692414834}};
+    const double gw[3][3] = {{2.0, 0.0, 0.0}, {1.0, 1.0, 0.0}, {0.5555555555555556, 0.8888888888888888, 0.5555555555555556}};
+    // geometry + shape values per point: thread (q, a)
+    for (int idx = tid; idx < nq * NB; idx += 64) {
+        const int q = idx / NB, a = idx % NB;
+        double xi[3];
+        xi[facet_fix(lf)] = facet_val(lf);
+        xi[facet_s(lf)] = gx[fq - 1][q % fq];
+        xi[facet_t(lf)] = gx[fq - 1][q / fq];
+        double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        for (int v = 0; v < 8; ++v) {
+            double Mv, dM[3];
+            shape_at<8>(v, xi, Mv, dM);
+            for (int i = 0; i < 3; ++i) for (int k = 0; k < 3; ++k) J[i][k] += s_x[3 * v + i] * dM[k];
+        }
+        const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1], c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2], c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+        const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02, id = 1.0 / det;
+        const double Ji[3][3] = {{c00 * id, (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * id, (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * id},
+                                 {c01 * id, (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * id, (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * id},
+                                 {c02 * id, (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * id, (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * id}};
+        double Na, dNa[3];
+        shape_at<NB>(a, xi, Na, dNa);
+        s_N[q][a] = Na;
+        for (int k = 0; k < 3; ++k) s_G[q][a][k] = dNa[0] * Ji[0][k] + dNa[1] * Ji[1][k] + dNa[2] * Ji[2][k];
+        if (a == 0) {
+            if (!(det > 0.0)) { st->neg_detj = 1; st->cell = cell; }
+            const int cs = facet_s(lf), ct = facet_t(lf);
+            const double av[3] = {J[0][cs], J[1][cs], J[2][cs]}, bv[3] = {J[0][ct], J[1][ct], J[2][ct]};
+            const double nw[3] = {av[1] * bv[2] - av[2] * bv[1], av[2] * bv[0] - av[0] * bv[2], av[0] * bv[1] - av[1] * bv[0]};
+            const double len = sqrt(nw[0] * nw[0] + nw[1] * nw[1] + nw[2] * nw[2]);
+            s_q[q][0] = len * gw[fq - 1][q % fq] * gw[fq - 1][q / fq];
+            for (int k = 0; k < 3; ++k) s_q[q][1 + k] = nw[k] / len;
+        }
+    }
+    __syncthreads();
+    // field values per point (one thread per point): u_q, F, and the tensors of the integrand
+    //   slots: [4..6] g = residual vector density (δuᵢ·g), [7..15] H (Robin / spring: Hessian; pressure: invF), [16] J, [17..19] cofF·n₀,
+    //          [20..22] invFᵀ-weighted normal  fin[d] = Σ_r invF[r][d] n₀[r]
+    if (tid < nq) {
+        const int q = tid;
+        double uq[3] = {0, 0, 0}, F[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+        for (int a = 0; a < NB; ++a)
+            for (int c = 0; c < 3; ++c) {
+                uq[c] += s_N[q][a] * s_ue[3 * a + c];
+                for (int k = 0; k < 3; ++k) F[c][k] += s_ue[3 * a + c] * s_G[q][a][k];
+            }
+        const double *n0 = &s_q[q][1];
+        double *o = s_q[q];
+        if (bc == TB_BC_ROBIN) {
+            for (int c = 0; c < 3; ++c) o[4 + c] = 2.0 * param * uq[c];
+            for (int e = 0; e < 9; ++e) o[7 + e] = (e % 4 == 0) ? 2.0 * param : 0.0;
+        } else if (bc == TB_BC_NORMAL_SPRING) {
+            const double un = uq[0] * n0[0] + uq[1] * n0[1] + uq[2] * n0[2];
+            for (int c = 0; c < 3; ++c) o[4 + c] = param * un * n0[c];
+            for (int c = 0; c < 3; ++c) for (int d = 0; d < 3; ++d) o[7 + 3 * c + d] = param * n0[c] * n0[d];
+        } else {
+            const double c00 = F[1][1] * F[2][2] - F[1][2] * F[2][1], c01 = F[1][2] * F[2][0] - F[1][0] * F[2][2], c02 = F[1][0] * F[2][1] - F[1][1] * F[2][0];
+            const double Jf = F[0][0] * c00 + F[0][1] * c01 + F[0][2] * c02, id = 1.0 / Jf;
+            const double Fi[9] = {c00 * id, (F[0][2] * F[2][1] - F[0][1] * F[2][2]) * id, (F[0][1] * F[1][2] - F[0][2] * F[1][1]) * id,
+                                  c01 * id, (F[0][0] * F[2][2] - F[0][2] * F[2][0]) * id, (F[0][2] * F[1][0] - F[0][0] * F[1][2]) * id,
+                                  c02 * id, (F[0][1] * F[2][0] - F[0][0] * F[2][1]) * id, (F[0][0] * F[1][1] - F[0][1] * F[1][0]) * id};
+            for (int e = 0; e < 9; ++e) o[7 + e] = Fi[e];
+            o[16] = Jf;
+            for (int c = 0; c < 3; ++c) {
+                const double cn = Fi[0 + c] * n0[0] + Fi[3 + c] * n0[1] + Fi[6 + c] * n0[2]; // (F⁻ᵀ n₀)[c] — also fin[c]
+                o[17 + c] = cn;
+                o[4 + c] = param * Jf * cn;
+            }
+        }
+    }
+    __syncthreads();
+    // residual: rₑ[i] += δuᵢ·g dΓ
+    if (r)
+        for (int i = tid; i < ND; i += 64) {
+            const int a = i / 3, c = i % 3;
+            double v = 0.0;
+            for (int q = 0; q < nq; ++q) v += s_N[q][a] * s_q[q][4 + c] * s_q[q][0];
+            if (v != 0.0) unsafeAtomicAdd(r + s_dof[i], v);
+        }
+    // tangent
+    if (nz)
+        for (int ij = tid; ij < ND * ND; ij += 64) {
+            const int i = ij / ND, j = ij % ND, a = i / 3, c = i % 3, b = j / 3, d = j % 3;
+            double v = 0.0;
+            if (bc != TB_BC_PRESSURE) {
+                for (int q = 0; q < nq; ++q) v += s_N[q][a] * s_q[q][7 + 3 * c + d] * s_N[q][b] * s_q[q][0];
+            } else {
+                for (int q = 0; q < nq; ++q) {
+                    const double *o = s_q[q], *Fi = o + 7, *g = s_G[q][b];
+                    double gF[3];
+                    for (int k = 0; k < 3; ++k) gF[k] = g[0] * Fi[0 + k] + g[1] * Fi[3 + k] + g[2] * Fi[6 + k];
+                    // δJ·cofF·n₀ + J·δcofF·n₀ for δF = e_d ⊗ ∇N_b
+                    v += param * o[16] * (gF[d] * o[17 + c] - gF[c] * o[17 + d]) * s_N[q][a] * o[0];
+                }
+            }
+            if (v != 0.0) unsafeAtomicAdd(nz + rowptr[s_dof[3 * a] + c] + blockpos[cell * (NB * NB) + a * NB + b] + d, v);
+        }
+}
+
+int launch_facets(tb_form *f, tb_pattern *p, const double *d_u, double *d_nz, double *d_r)
+{
+    tb_mesh *m = f->mesh;
+    tb_device *dev = m->dev;
+    int rc = reset_status(dev);
+    if (rc) return rc;
+    if (d_nz) { rc = ensure_blockpos(p); if (rc) return rc; }
+    const MechMesh mm{m->d_xyz, m->d_conn, m->d_cell_dofs, nullptr};
+    const int64_t *rowptr = p ? p->d_rowptr : nullptr;
+    const uint16_t *bp = p ? p->d_blockpos : nullptr;
+    if (m->field_kind == TB_HEX27)
+        hipLaunchKernelGGL((k_facets<27>), dim3((unsigned)f->n_facets), dim3(64), 0, dev->stream, mm, f->d_facets, f->bc_kind, f->bc_param, f->facet_q,
+                           d_u, d_nz, d_r, rowptr, bp, dev->d_status);
+    else
+        hipLaunchKernelGGL((k_facets<8>), dim3((unsigned)f->n_facets), dim3(64), 0, dev->stream, mm, f->d_facets, f->bc_kind, f->bc_param, f->facet_q,
+                           d_u, d_nz, d_r, rowptr, bp, dev->d_status);
+    TB_HIP(hipGetLastError());
+    return check_status(dev);
 }
 
 } // namespace tb
