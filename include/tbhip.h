@@ -198,6 +198,12 @@ int tb_residual(tb_form *form, int strategy, const double *d_u, double t, double
  * elimination is NOT part of it (applied afterwards on the host: src/solver/nonlinear/nlsolve_common.jl:12-26). */
 int tb_linearize(tb_form *form, tb_pattern *pat, int strategy, const double *d_u, double t, double *d_nzval, double *d_r);
 /* host evaluation of the device material routine (Ψ, P = ∂Ψ/∂F, 𝔸 = ∂²Ψ/∂F²; row-major F[3i+j], A[9(3i+j)+3k+l]) */
+/* Active stress (ActiveStressModel, src/modeling/solid/materials.jl:1200-1266, with SimpleActiveStress, src/modeling/solid/active.jl:100-113,
+ * over a steady-state sarcomere model driven by a calcium field, src/modeling/solid/contraction.jl:103-105,166-175):
+ * P += Ta·(F·f₀)⊗f₀/‖F·f₀‖ with its consistent tangent, Ta(x_q) = tension · Σₐ Mₐ(ξ_q)·state[cell][a] (first-order nodal data
+ * per cell, n_cells×8 host values copied to the device) or Ta = tension when state_field is NULL.  tb_material.p[9] is the
+ * initial uniform tension.  Call again whenever the calcium transient advances (host values → device, O(cells)). */
+int tb_hyperelastic_set_active_tension(tb_form *form, double tension, const double *state_field, int64_t len);
 /* Weak boundary conditions of a quasi-static problem (src/modeling/core/weak_boundary_conditions.jl): RobinBC
  * Ψ = α u·u (:102-198), NormalSpringBC Ψ = ½ kₛ (u·N)² (:200-300), ConstantPressureBC follower load p·J·F⁻ᵀ·n₀ with its
  * consistent tangent (:419-515).  `facets` lists n_facets pairs (cell, local facet) — Ferrite's FacetIndex, local facets of

@@ -320,6 +320,18 @@ def element_hyperelastic(mesh, cell, ue, p=HO_DEFAULTS, fsn=np.eye(3), want_K=Tr
 
 BC_ROBIN, BC_NORMAL_SPRING, BC_PRESSURE = 0, 1, 2
 
+_ACT_KEEP = [None]
+
+
+def set_active_tension(tension, field=None):
+    """ActiveStressModel + SimpleActiveStress: Ta = tension·(nodal calcium field per cell, or 1).  Global state of the
+    oracle (like set_microstructure_field); reset with set_active_tension(0.0)."""
+    f = None if field is None else np.ascontiguousarray(field, dtype=np.float64)
+    _ACT_KEEP[0] = f
+    lib().orc_set_active_tension.restype = None
+    lib().orc_set_active_tension(C.c_double(tension), _d(f))
+
+
 
 def element_facet(mesh, cell, local_facet, kind, param, fq, ue, want_K=True, want_r=True):
     """assemble_facet! of one (cell, local facet 0…5) (weak_boundary_conditions.jl): returns (Ke, re) contributions."""

@@ -1052,6 +1052,7 @@ static hd hd_cbrt(hd u) { double c = cbrt(u.v); return hd_chain(u, c, c / (3.0 *
 static hd hd_inv(hd u) { return hd_chain(u, 1.0 / u.v, -1.0 / (u.v * u.v), 2.0 / (u.v * u.v * u.v)); }
 
 /* Ψ of HolzapfelOgden2009Model with SimpleCompressionPenalty, src/modeling/solid/energies.jl:147-168 and :83-87 */
+static _Thread_local double g_active_tension = 0.0; /* Ta = Tmax·𝓝 at the point being evaluated (set by the element routine) */
 static hd ho_psi(const double *p, const double *fsn, hd F[3][3])
 {
     const double a = p[0], b = p[1], af = p[2], bf = p[3], as = p[4], bs = p[5], afs = p[6], bfs = p[7], beta = p[8];
@@ -1087,6 +1088,10 @@ static hd ho_psi(const double *p, const double *fsn, hd F[3][3])
         hd d = hd_addc(I4s, -1.0);
         psi = hd_add(psi, hd_scale(hd_addc(hd_exp(hd_scale(hd_mul(d, d), bs)), -1.0), as / (2.0 * bs)));
     }
+    /* ActiveStressModel (materials.jl:1200-1266) with SimpleActiveStress (active.jl:100-113): P += 𝓝·Tmax·(F·f₀)⊗f₀/‖F·f₀‖,
+     * differentiated once more by AD for the tangent.  That stress is the F-gradient of 𝓝·Tmax·‖F·f₀‖ = Ta·√I₄ᶠ, so it is
+     * taken through the same hyper-dual pass (𝓝 does not depend on F for steady-state sarcomere models, contraction.jl:103-105). */
+    if (g_active_tension != 0.0) psi = hd_add(psi, hd_scale(hd_sqrt(I4f), g_active_tension));
     return psi;
 }
 
@@ -1107,6 +1112,12 @@ double orc_ho_energy(const double *p, const double *fsn, const double *F, double
  * Gram–Schmidt-orthogonalised at the quadrature point (utils.jl:131-139).  NULL → constant frame `fsn`. */
 static const double *g_fsn_field = NULL;
 void orc_set_microstructure_field(const double *field) { g_fsn_field = field; }
+/* active tension Ta(x_q) = tension · (field ? Σₐ Mₐ(ξ_q)·field[cell][a] : 1): Tmax times the calcium-driven state of a
+ * CaDrivenInternalSarcomereModel over a steady-state sarcomere model (contraction.jl:103-105,166-175); the calcium field is
+ * first-order nodal data per cell like every FieldCoefficient (coefficients.jl:85-99). */
+static double g_act_scale = 0.0;
+static const double *g_act_field = NULL;
+void orc_set_active_tension(double tension, const double *field) { g_act_scale = tension; g_act_field = field; }
 
 static int element_hyperelastic_cv(const orc_mesh *m, const cellvalues *cv, int64_t cell, const double *p,
                                    const double *fsn_const, const double *ue, double *Ke, double *re)
@@ -1134,7 +1145,14 @@ static int element_hyperelastic_cv(const orc_mesh *m, const cellvalues *cv, int6
             orc_orthogonalize(3, frame, frame + 3, frame + 6);
             fsn = frame;
         }
+        g_active_tension = g_act_scale;
+        if (g_act_field && g_act_scale != 0.0) {
+            double ca = 0.0;
+            for (int a = 0; a < cv->ngeo; ++a) ca += cv->M[q][a] * g_act_field[(int64_t)cell * cv->ngeo + a];
+            g_active_tension = g_act_scale * ca;
+        }
         orc_ho_energy(p, fsn, F, P, Ke ? A : NULL);
+        g_active_tension = 0.0;
         for (int i = 0; i < nd; ++i) {
             int a = i / 3, c = i % 3;
             /* residualₑ[i] += ∇δui ⊡ P * dΩ */

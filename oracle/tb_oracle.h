@@ -179,6 +179,7 @@ int orc_assemble_hyperelastic(const orc_mesh *m, const double *p, const double *
 #define ORC_BC_ROBIN 0
 #define ORC_BC_NORMAL_SPRING 1
 #define ORC_BC_PRESSURE 2
+void orc_set_active_tension(double tension, const double *field_per_cell_node /* n_cells×8 or NULL */);
 int orc_element_facet(const orc_mesh *m, int64_t cell, int local_facet, int kind, double param, int fq, const double *ue,
                       double *Ke /* nd×nd or NULL, accumulated */, double *re /* nd or NULL, accumulated */);
 int orc_assemble_facets(const orc_mesh *m, int kind, double param, int fq, const int32_t *facets, int64_t nf, const double *u,

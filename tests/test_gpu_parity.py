@@ -707,3 +707,38 @@ def test_weak_boundary_conditions_parity(tb, oracle, device, order, nel):
     # facet index validation
     with pytest.raises(tb.TBError):
         tb.setup_operator(tb.AtomicAssemblyStrategy(device), tb.QuasiStaticModel("u", model.constitutive_model, [tb.RobinBC(1.0, np.array([[0, 6]]))]), dh, sp)
+
+
+@pytest.mark.parametrize("order,nel", [(1, (3, 2, 2)), (2, (2, 1, 2))])
+def test_active_stress_parity(tb, oracle, device, order, nel):
+    """ActiveStressModel(HO2009, SimpleActiveStress, CaDrivenInternalSarcomereModel(PSL1995, Ca)) — uniform calcium transient
+    Ca(t) and nodal calcium per cell — against the oracle (AD of Ψ_passive + Ta‖F f₀‖)."""
+    g, dh, sp, om = mech_problem(tb, oracle, nel, order, perturb=0.1)
+    rng = np.random.default_rng(6)
+    u = rng.uniform(-1e-2, 1e-2, dh.ndofs)
+    du = device.to_device(u)
+    f, s, n = np.array([1, 1, 0.0]) / np.sqrt(2), np.array([-1, 1, 0.0]) / np.sqrt(2), np.array([0, 0, 1.0])
+    fsn = np.stack([f, s, n])
+    ms = tb.ConstantCoefficient(tb.OrthotropicMicrostructure(f, s, n))
+    nodal = rng.uniform(0.1, 1.0, (g.n_cells, 8))
+    cases = [(tb.CaDrivenInternalSarcomereModel(tb.PelceSunLangeveld1995Model(), lambda t: 0.2 + t), 0.5, (2.5 * 0.7, None)),
+             (tb.CaDrivenInternalSarcomereModel(tb.PelceSunLangeveld1995Model(), nodal), 0.0, (2.5, nodal))]
+    try:
+        for sarc, t, (scale, field) in cases:
+            oracle.set_active_tension(scale, field)
+            Kref, rref = oracle.assemble_hyperelastic(om, u, sp.rowptr, sp.colidx, fsn=fsn)
+            oracle.set_active_tension(0.0)
+            Kp, rp = oracle.assemble_hyperelastic(om, u, sp.rowptr, sp.colidx, fsn=fsn)
+            assert np.abs(rref - rp).max() > 1e-3 * np.abs(rp).max()
+            model = tb.QuasiStaticModel("u", tb.ActiveStressModel(tb.HolzapfelOgden2009Model(), tb.SimpleActiveStress(Tmax=2.5), sarc, ms))
+            for st in (tb.ElementAssemblyStrategy(device), tb.PerColorAssemblyStrategy(device)):
+                op = tb.setup_operator(st, model, dh, sp)
+                res = device.zeros(dh.ndofs)
+                tb.update_linearization(op, du, t, residual=res)
+                assert rel_err(op.J.to_host(), Kref) < 1e-11
+                assert rel_err(res.to_host(), rref) < 1e-11
+                res2 = device.zeros(dh.ndofs)
+                tb.residual(op, res2, du, t)
+                assert rel_err(res2.to_host(), rref) < 1e-11
+    finally:
+        oracle.set_active_tension(0.0)

@@ -146,3 +146,50 @@ def test_facet_tangent_is_derivative_of_residual(oracle, order, kind):
             _, rm = oracle.element_facet(m, 0, lf, k, 1.7, order + 1, u - e, want_K=False)
             fd[:, j] = (rp - rm) / (2 * h)
         assert np.abs(Ke - fd).max() < 1e-8 * max(1.0, np.abs(Ke).max())
+
+
+def test_active_stress_material_routine_matches_ad_oracle(tb, oracle):
+    """ActiveStressModel + SimpleActiveStress (materials.jl:1200-1266, active.jl:100-113): the device routine's P and 𝔸
+    (evaluated on the host through the same inline code) against the hyper-dual derivative of Ψ_passive + Ta·‖F f₀‖, and the
+    stress increment against its closed form Ta·(F f₀)⊗f₀/‖F f₀‖."""
+    rng = np.random.default_rng(8)
+    f, s, n = np.linalg.qr(rng.normal(size=(3, 3)))[0].T
+    for Ta in (0.0, 0.7, 25.0):
+        for _ in range(4):
+            F = np.eye(3) + 0.15 * rng.normal(size=(3, 3))
+            model = tb.ActiveStressModel(tb.HolzapfelOgden2009Model(), tb.SimpleActiveStress(Tmax=Ta), tb.CaDrivenInternalSarcomereModel(tb.PelceSunLangeveld1995Model(), 1.0),
+                                         tb.ConstantCoefficient(tb.OrthotropicMicrostructure(f, s, n)))
+            psi, P, A = tb.material_routine(model, F)
+            oracle.set_active_tension(0.0)
+            psi0, P0, A0 = oracle.ho_energy(F, fsn=np.stack([f, s, n]))
+            Ff = F @ f
+            lam = np.linalg.norm(Ff)
+            np.testing.assert_allclose(P - P0, Ta * np.outer(Ff, f) / lam, rtol=1e-11, atol=1e-12 * np.abs(P).max())
+            # second derivative of Ta·‖F f₀‖ by its closed form
+            dA = Ta * (np.einsum("ik,j,l->ijkl", np.eye(3), f, f) / lam - np.einsum("i,j,k,l->ijkl", Ff, f, Ff, f) / lam ** 3)
+            np.testing.assert_allclose((A - A0).reshape(3, 3, 3, 3), dA, rtol=1e-10, atol=1e-12 * np.abs(A).max())
+            assert psi - psi0 == pytest.approx(Ta * lam, rel=1e-11, abs=1e-12 * max(1.0, abs(psi)))
+    # PelceSunLangeveld1995: compute_λᵃ (contraction.jl:307-311) — used by the active *strain* models, 𝓝 ignores it
+    m = tb.PelceSunLangeveld1995Model()
+    assert m.compute_lambda_a(0.0) == 1.0 and m.compute_lambda_a(1.0) == pytest.approx(1.0 / (1.0 + 0.5 * (1 / 0.7 - 1)))
+
+
+def test_active_stress_element_through_the_oracle(oracle):
+    """The oracle's element routine with an active tension: K = ∂r/∂u by central differences, nodal calcium interpolated."""
+    m, nd = _one_hex(oracle, 1, distort=0.1, seed=2)
+    rng = np.random.default_rng(3)
+    u = rng.uniform(-0.03, 0.03, nd)
+    ca = rng.uniform(0.2, 1.0, (1, 8))
+    oracle.set_active_tension(3.0, ca)
+    try:
+        Ke, re = oracle.element_hyperelastic(m, 0, u)
+        fd = np.zeros_like(Ke)
+        for j in range(nd):
+            e = np.zeros(nd); e[j] = 1e-6
+            fd[:, j] = (oracle.element_hyperelastic(m, 0, u + e, want_K=False)[1] - oracle.element_hyperelastic(m, 0, u - e, want_K=False)[1]) / 2e-6
+        assert np.abs(Ke - fd).max() < 1e-7 * np.abs(Ke).max()
+        oracle.set_active_tension(0.0)
+        K0, r0 = oracle.element_hyperelastic(m, 0, u)
+        assert np.abs(re - r0).max() > 1e-3
+    finally:
+        oracle.set_active_tension(0.0)

@@ -788,6 +788,65 @@ class PK1Model:
         return m
 
 
+class SimpleActiveStress:
+    """SimpleActiveStress(; Tmax): Tᵃ = Tmax·[Caᵢ]·(F·f₀)⊗f₀/‖F·f₀‖ (src/modeling/solid/active.jl:100-113)."""
+
+    def __init__(self, Tmax=1.0):
+        self.Tmax = float(Tmax)
+
+
+class PelceSunLangeveld1995Model:
+    """PelceSunLangeveld1995Model(; β, λᵃₘₐₓ): steady-state sarcomere model (contraction.jl:302-311); in the active
+    *stress* framework 𝓝(state, …) = state for every steady-state model (contraction.jl:103-105)."""
+
+    def __init__(self, beta=3.0, lambda_a_max=0.7):
+        self.beta, self.lambda_a_max = beta, lambda_a_max
+
+    def compute_lambda_a(self, Ca):
+        f = 0.5 + np.arctan(self.beta * np.log(Ca)) / np.pi if Ca > 0.0 else 0.0
+        return 1.0 / (1.0 + f * (1.0 / self.lambda_a_max - 1.0))
+
+
+class ConstantStretchModel:
+    def __init__(self, lam=1.0):
+        self.lam = lam
+
+
+class CaDrivenInternalSarcomereModel:
+    """CaDrivenInternalSarcomereModel(model, calcium_field) (contraction.jl:166-175).  calcium_field: a number, a callable
+    Ca(t) (spatially uniform transient) or nodal values per cell, shape (n_cells, 8) / callable t ↦ such an array."""
+
+    def __init__(self, model, calcium_field):
+        self.model, self.calcium_field = model, calcium_field
+
+    def state(self, t):
+        ca = self.calcium_field(t) if callable(self.calcium_field) else self.calcium_field
+        return ca
+
+
+class ActiveStressModel:
+    """ActiveStressModel(material_model, active_stress_model, contraction_model, microstructure_model)
+    (src/modeling/solid/materials.jl:1200-1266): P = ∂Ψ_passive/∂F + 𝓝·active_stress(F, f₀)."""
+
+    def __init__(self, material_model, active_stress_model, contraction_model, microstructure_model):
+        self.passive = PK1Model(material_model, microstructure_model)
+        self.active_stress_model, self.contraction_model = active_stress_model, contraction_model
+        self.material, self.microstructure = self.passive.material, self.passive.microstructure
+
+    def tension(self, t):
+        """(scale, nodal field or None) of Ta = Tmax·𝓝 at time t"""
+        st = self.contraction_model.state(t) if hasattr(self.contraction_model, "state") else 1.0
+        if np.ndim(st) == 0:
+            return self.active_stress_model.Tmax * float(st), None
+        return self.active_stress_model.Tmax, np.ascontiguousarray(st, dtype=np.float64)
+
+    def lower(self, t=0.0):
+        m = self.passive.lower()
+        scale, field = self.tension(t)
+        m.p[9] = scale if field is None else 0.0
+        return m
+
+
 class RobinBC:
     """RobinBC(α, boundary_name): P·n₀ = −α u (weak_boundary_conditions.jl:23-26; energy α u·u)."""
     kind = L.TB_BC_ROBIN
@@ -834,7 +893,7 @@ class NonlinearOperator:
     """Operator of a quasi-static problem: `.J` (CSR nzval on device), residual vectors supplied by the caller."""
 
     def __init__(self, strategy, model, dh, pattern, qorder=0):
-        self.strategy, self.dh = strategy, dh
+        self.strategy, self.dh, self.model = strategy, dh, model
         self.dmesh = dh.device_mesh(strategy.device)
         self.pattern = self.dmesh.pattern(pattern)
         self._mat = model.constitutive_model.lower()
@@ -860,9 +919,18 @@ class NonlinearOperator:
             pass
 
 
+def _sync_active_tension(op, t):
+    cm = op.model.constitutive_model
+    if isinstance(cm, ActiveStressModel):
+        scale, field = cm.tension(t)
+        check(lib().tb_hyperelastic_set_active_tension(op.form, float(scale), None if field is None else field.ctypes.data_as(L.c_dp),
+                                                       0 if field is None else field.size))
+
+
 def update_linearization(op, u, t=0.0, residual=None):
     """update_linearization!(op, residual, u, p) / update_linearization!(op, u, p) (newton_raphson.jl:238): volume term,
     then the surface terms are accumulated into the same J / residual."""
+    _sync_active_tension(op, t)
     check(lib().tb_linearize(op.form, op.pattern.h, op.strategy.code, _ptr(u), float(t), op.J.ptr, _ptr(residual)))
     for h in op.facet_forms:
         check(lib().tb_facet_assemble(h, op.pattern.h, _ptr(u), float(t), op.J.ptr, _ptr(residual)))
@@ -871,6 +939,7 @@ def update_linearization(op, u, t=0.0, residual=None):
 
 def residual(op, residual, u, t=0.0):
     """residual!(op, residual, u, p) (newton_raphson.jl:234)."""
+    _sync_active_tension(op, t)
     check(lib().tb_residual(op.form, op.strategy.code, _ptr(u), float(t), _ptr(residual)))
     for h in op.facet_forms:
         check(lib().tb_facet_assemble(h, None, _ptr(u), float(t), None, _ptr(residual)))

@@ -363,7 +363,7 @@ int tb_form_create(tb_mesh *mesh, int form_kind, int qorder, const tb_coef *coef
 int tb_form_destroy(tb_form *f)
 {
     if (!f) return TB_OK;
-    hipFree(f->d_field); hipFree(f->d_table); hipFree(f->d_facets);
+    hipFree(f->d_field); hipFree(f->d_table); hipFree(f->d_facets); hipFree(f->d_act_field);
     delete f;
     return TB_OK;
 }
@@ -427,6 +427,7 @@ int tb_hyperelastic_create(tb_mesh *mesh, int qorder, const tb_material *materia
     auto f = std::make_unique<tb_form>();
     f->mesh = mesh; f->kind = TB_FORM_HYPERELASTIC; f->qorder = qorder; f->mat = *material;
     f->mat.fsn_field = nullptr;
+    f->act_tension = material->p[9];
     if (material->fsn_field) {
         const int64_t need = mesh->n_cells * 72;
         TB_REQUIRE(material->fsn_field_len == need, "tb_hyperelastic_create: microstructure field needs %lld values, got %lld", (long long)need,
@@ -436,6 +437,22 @@ int tb_hyperelastic_create(tb_mesh *mesh, int qorder, const tb_material *materia
         TB_HIP(hipStreamSynchronize(mesh->dev->stream));
     }
     *out = f.release();
+    return TB_OK;
+}
+
+int tb_hyperelastic_set_active_tension(tb_form *form, double tension, const double *state_field, int64_t len)
+{
+    TB_REQUIRE(form && form->kind == TB_FORM_HYPERELASTIC, "tb_hyperelastic_set_active_tension: not a hyperelastic form");
+    tb_mesh *m = form->mesh;
+    form->act_tension = tension;
+    if (!state_field) { hipFree(form->d_act_field); form->d_act_field = nullptr; return TB_OK; }
+    TB_REQUIRE(len == m->n_cells * 8, "tb_hyperelastic_set_active_tension: state field needs %lld values (cells × 8), got %lld", (long long)(m->n_cells * 8), (long long)len);
+    TB_HIP(hipSetDevice(m->dev->id));
+    if (!form->d_act_field && len) TB_HIP(hipMalloc((void **)&form->d_act_field, sizeof(double) * len));
+    if (len) {
+        TB_HIP(hipMemcpyAsync(form->d_act_field, state_field, sizeof(double) * len, hipMemcpyHostToDevice, m->dev->stream));
+        TB_HIP(hipStreamSynchronize(m->dev->stream));
+    }
     return TB_OK;
 }
 

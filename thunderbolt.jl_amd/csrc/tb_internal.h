@@ -151,6 +151,9 @@ struct tb_form {
     double *d_table = nullptr;
     int64_t table_len = 0;
     tb_material mat{};
+    // active stress (TB_FORM_HYPERELASTIC): Ta = act_tension · (nodal field per cell, or 1)
+    double act_tension = 0.0;
+    double *d_act_field = nullptr;
     // weak boundary conditions (TB_FORM_FACET)
     int bc_kind = 0, facet_q = 0;
     double bc_param = 0.0;

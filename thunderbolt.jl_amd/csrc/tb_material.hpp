@@ -17,6 +17,8 @@
 //   Ψ₈ = aᶠˢ/(2bᶠˢ)(e^{bᶠˢ I₈²} − 1):  M = b⊗f₀ + a⊗s₀, v₁ = aᶠˢ I₈ E₈, v₂ = aᶠˢ E₈ (1 + 2bᶠˢ I₈²)
 //        P += v₁ M,         𝔸_ijkl += v₂ M_ij M_kl + v₁ δ_ik (s_j f_l + f_j s_l)
 //   U  = β(J² − 1 − 2 ln J):  P += 2β(J²−1) F⁻ᵀ,  𝔸_ijkl += 4βJ² F⁻¹_ji F⁻¹_lk − 2β(J²−1) F⁻¹_jk F⁻¹_li
+//   active stress (ActiveStressModel, materials.jl:1200-1266; SimpleActiveStress, active.jl:100-113):
+//        Pᵃ = Ta (F f₀)⊗f₀/‖F f₀‖ = ∂(Ta √I₄ᶠ)/∂F — the Ψ₄ pattern with w₁ = Ta/(2√I₄ᶠ), w₂ = −Ta/(4 I₄ᶠ^{3/2})
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -31,6 +33,7 @@ namespace tbk {
 struct HOParams {
     double a, b, af, bf, as, bs, afs, bfs, beta; // struct field order of HolzapfelOgden2009Model, energies.jl:136-146
     double f[3], s[3], n[3];                     // microstructure frame (ConstantCoefficient(OrthotropicMicrostructure))
+    double Ta;                                   // active tension Tmax·𝓝 at the point (ActiveStressModel + SimpleActiveStress); 0 = passive
 };
 
 // returns Ψ; P[3i+j], A[9(3i+j) + 3k+l] (A only when NEED_A)
@@ -78,7 +81,9 @@ TB_HD double ho_stress_tangent(const HOParams &m, const double (&F)[3][3], doubl
     if (ons) psi += m.as / (2.0 * m.bs) * (E4s - 1.0);
 
     const double h1 = 0.5 * m.a * E1;
-    const double w1f = onf ? m.af * df * E4f : 0.0, w2f = onf ? m.af * E4f * (1.0 + 2.0 * m.bf * df * df) : 0.0;
+    const double lamf = sqrt(I4f);
+    const double w1f = (onf ? m.af * df * E4f : 0.0) + 0.5 * m.Ta / lamf, w2f = (onf ? m.af * E4f * (1.0 + 2.0 * m.bf * df * df) : 0.0) - 0.25 * m.Ta / (lamf * I4f);
+    psi += m.Ta * lamf;
     const double w1s = ons ? m.as * ds * E4s : 0.0, w2s = ons ? m.as * E4s * (1.0 + 2.0 * m.bs * ds * ds) : 0.0;
     const double v1 = m.afs * I8 * E8, v2 = m.afs * E8 * (1.0 + 2.0 * m.bfs * I8 * I8);
     const double u1 = 2.0 * m.beta * (J2 - 1.0), u2 = 4.0 * m.beta * J2;
@@ -174,7 +179,10 @@ TB_HD void ho_common(const HOParams &m, const double (&F)[3][3], double *C)
 #pragma unroll
     for (int i = 0; i < 3; ++i) { C[HOC_AV + i] = av[i]; C[HOC_BV + i] = bv[i]; }
     C[HOC_H1] = h1; C[HOC_H1B] = h1 * m.b;
-    C[HOC_W1F2] = onf ? 2.0 * m.af * df * E4f : 0.0; C[HOC_W2F4] = onf ? 4.0 * m.af * E4f * (1.0 + 2.0 * m.bf * df * df) : 0.0;
+    const double lamf = sqrt(I4f);
+    psi += m.Ta * lamf;
+    C[HOC_W1F2] = (onf ? 2.0 * m.af * df * E4f : 0.0) + m.Ta / lamf;
+    C[HOC_W2F4] = (onf ? 4.0 * m.af * E4f * (1.0 + 2.0 * m.bf * df * df) : 0.0) - m.Ta / (lamf * I4f);
     C[HOC_W1S2] = ons ? 2.0 * m.as * ds * E4s : 0.0; C[HOC_W2S4] = ons ? 4.0 * m.as * E4s * (1.0 + 2.0 * m.bs * ds * ds) : 0.0;
     C[HOC_V1] = m.afs * I8 * E8; C[HOC_V2] = m.afs * E8 * (1.0 + 2.0 * m.bfs * I8 * I8);
     C[HOC_U1] = 2.0 * m.beta * (J2 - 1.0); C[HOC_U2] = 4.0 * m.beta * J2;

@@ -101,6 +101,7 @@ struct MechMesh {
     const int32_t *conn;
     const int32_t *cell_dofs;
     const double *fsn_field; // per cell and geometric node: f,s,n (9 doubles); NULL → constant frame of the material
+    const double *act_field; // per cell and geometric node: calcium-driven state multiplying the active tension; NULL → 1
 };
 
 // position of column dof(b,0) inside row dof(a,0), per cell and node pair (the three component rows of a node
@@ -201,6 +202,11 @@ k_hyperelastic(MechMesh m, HOParams mat, const int32_t *__restrict__ list, const
 #pragma unroll
         for (int e = 0; e < 9; ++e) F[e / 3][e % 3] = s_JI[tid][e];
         HOParams mq = mat;
+        if (m.act_field) { // Ta(x_q) = Tmax·Σₐ Mₐ(ξ_q)·state[cell][a] (coefficients.jl:85-99, contraction.jl:166-175)
+            double ca = 0.0;
+            for (int a = 0; a < 8; ++a) ca += tb.M[tid][a] * m.act_field[cell * 8 + a];
+            mq.Ta = mat.Ta * ca;
+        }
         if (m.fsn_field) { // interpolate the nodal frame, normalise, Gram–Schmidt (microstructure.jl:176-187)
             double f[3] = {0, 0, 0}, s[3] = {0, 0, 0}, n[3] = {0, 0, 0};
             const double *fc = m.fsn_field + cell * 72;
@@ -479,6 +485,7 @@ static HOParams make_params(const tb_form *f)
     const double *q = f->mat.p;
     p.a = q[0]; p.b = q[1]; p.af = q[2]; p.bf = q[3]; p.as = q[4]; p.bs = q[5]; p.afs = q[6]; p.bfs = q[7]; p.beta = q[8];
     for (int i = 0; i < 3; ++i) { p.f[i] = f->mat.f[i]; p.s[i] = f->mat.s[i]; p.n[i] = f->mat.n[i]; }
+    p.Ta = f->act_tension;
     return p;
 }
 
@@ -486,6 +493,7 @@ int host_material_eval(const tb_material *mat, const double *F9, double *psi, do
 {
     tb_form tmp;
     tmp.mat = *mat;
+    tmp.act_tension = mat->p[9];
     const HOParams p = make_params(&tmp);
     double F[3][3], Pl[9], Al[81];
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) F[i][j] = F9[3 * i + j];
@@ -549,7 +557,7 @@ static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, doubl
 {
     tb_mesh *m = f->mesh;
     tb_device *dev = m->dev;
-    const MechMesh mm{m->d_xyz, m->d_conn, m->d_cell_dofs, f->d_field};
+    const MechMesh mm{m->d_xyz, m->d_conn, m->d_cell_dofs, f->d_field, f->d_act_field};
     const HOParams hp = make_params(f);
     const bool ea = strategy == TB_STRATEGY_ELEMENT || strategy == TB_STRATEGY_PATCH;
     if (NEED_K) {
@@ -784,7 +792,7 @@ int launch_facets(tb_form *f, tb_pattern *p, const double *d_u, double *d_nz, do
     int rc = reset_status(dev);
     if (rc) return rc;
     if (d_nz) { rc = ensure_blockpos(p); if (rc) return rc; }
-    const MechMesh mm{m->d_xyz, m->d_conn, m->d_cell_dofs, nullptr};
+    const MechMesh mm{m->d_xyz, m->d_conn, m->d_cell_dofs, nullptr, nullptr};
     const int64_t *rowptr = p ? p->d_rowptr : nullptr;
     const uint16_t *bp = p ? p->d_blockpos : nullptr;
     if (m->field_kind == TB_HEX27)
