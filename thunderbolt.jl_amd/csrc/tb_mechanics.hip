@@ -240,25 +240,36 @@ k_hyperelastic(MechMesh m, HOParams mat, const int32_t *__restrict__ list, const
 
     double racc = 0.0;
     if constexpr (NEED_K && MFMA) {
-        // B (matrix cores): wave w owns nine of the 36 output tiles (M-tile mt, component d, N-tile nt): four A-operand
-        // kinds (mt,d) with both N-tiles and one more with a single N-tile.  Rows ≥ ND / columns ≥ NB of the padded tiles
-        // hold finite garbage that is never stored; only the K padding (kk ≥ 3·NQ) must vanish, which the B operand does.
-        static_assert(T == 256 && ND <= 96 && NB <= 32, "tile assignment below is for 6×2×3 tiles on four waves");
+        // B (matrix cores).  Kₑ is symmetric (𝔸 has major symmetry), so of the 6×3×2 tiles (M-tile mt, component d, N-tile nt)
+        // the nine with mt ≥ 3, nt = 0 — rows (a ≥ 16, c), columns (b < 16, d): strictly below the block diagonal — are not
+        // computed; the epilogue mirrors them from the tiles (mt ≤ 2, ·, nt = 1).  27 tiles on four waves (7, 7, 7, 6):
+        //   A-operand kinds k = 3·mt + d;  k < 9: both N-tiles;  k ≥ 9: nt = 1 only
+        //   wave 0: kinds 0, 4, 8 (both) + 9      wave 1: 1, 5 (both) + 10, 11, 12
+        //   wave 2: 2, 6 (both) + 13, 14, 15      wave 3: 3, 7 (both) + 16, 17
+        // Rows ≥ ND / columns ≥ NB of the padded tiles hold finite garbage that is never stored; only the K padding
+        // (kk ≥ 3·NQ) must vanish, which the B operand does.
+        static_assert(T == 256 && ND == 81 && NB == 27, "tile assignment below is for 6×2×3 tiles on four waves");
         constexpr int KS = (3 * NQ + 3) / 4;
         const int lane = tid & 63, wv = tid >> 6, lr = lane & 15, g = lane >> 4;
+        // entries: e0, e1 → both N-tiles; e2, e3 → nt = 1; e4 → nt = 1 (waves 1, 2);  wave 0 additionally runs e2 on nt = 0
+        int kind[5];
+        kind[0] = wv; kind[1] = wv + 4;
+        kind[2] = wv == 0 ? 8 : wv == 1 ? 10 : wv == 2 ? 13 : 16;
+        kind[3] = wv == 0 ? 9 : wv == 1 ? 11 : wv == 2 ? 14 : 17;
+        kind[4] = wv == 1 ? 12 : wv == 2 ? 15 : 17; // unused on waves 0 and 3
+        const bool has_e4 = wv == 1 || wv == 2, e2_both = wv == 0;
         int offG[5], offA[5];
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
-            const int kind = i < 4 ? 4 * wv + i : 16 + (wv >> 1), mt = kind / 3, d = kind % 3;
+            const int mt = kind[i] / 3, d = kind[i] % 3;
             const int R = 16 * mt + lr, Rc = R < ND ? R : 0;
             offG[i] = 3 * (Rc / 3);
             offA[i] = 27 * (Rc % 3) + 3 * d;
         }
         const int b1 = 16 + lr < NB ? 16 + lr : 0;
-        const bool odd = wv & 1;
-        mfma_d4 acc[4][2], acc4 = {0, 0, 0, 0};
+        mfma_d4 acc[7];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { acc[i][0] = mfma_d4{0, 0, 0, 0}; acc[i][1] = mfma_d4{0, 0, 0, 0}; }
+        for (int i = 0; i < 7; ++i) acc[i] = mfma_d4{0, 0, 0, 0};
         const double *sG = &s_G[0][0][0], *sA = &s_A[0][0];
 #pragma unroll 3
         for (int s = 0; s < KS; ++s) {
@@ -274,12 +285,14 @@ k_hyperelastic(MechMesh m, HOParams mat, const int32_t *__restrict__ list, const
                 const double *gg = gq + offG[i], *aa = aq + offA[i];
                 Aop[i] = gg[0] * aa[0] + gg[1] * aa[9] + gg[2] * aa[18];
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop[i], B0, acc[i][0], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop[i], B1, acc[i][1], 0, 0, 0);
-            }
-            acc4 = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop[4], odd ? B1 : B0, acc4, 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop[0], B0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop[0], B1, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop[1], B0, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop[1], B1, acc[3], 0, 0, 0);
+            acc[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop[2], B1, acc[4], 0, 0, 0);
+            acc[5] = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop[3], B1, acc[5], 0, 0, 0);
+            if (e2_both) acc[6] = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop[2], B0, acc[6], 0, 0, 0);
+            else if (has_e4) acc[6] = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop[4], B1, acc[6], 0, 0, 0);
         }
         if constexpr (NEED_R) {
             if (tid < ND) {
@@ -290,26 +303,33 @@ k_hyperelastic(MechMesh m, HOParams mat, const int32_t *__restrict__ list, const
                 }
             }
         }
-        // C: D[row = g + 4·reg][col = lr] of tile (mt, d, nt) is Kₑ[(a,c) = 16·mt + row][(b,d), b = 16·nt + col]
-        auto emit = [&](const mfma_d4 &v, int kind, int nt) {
-            const int mt = kind / 3, d = kind % 3, b = 16 * nt + lr;
+        // C: D[row = g + 4·reg][col = lr] of tile (mt, d, nt) is Kₑ[(a,c) = 16·mt + row][(b,d), b = 16·nt + col]; tiles
+        // (mt ≤ 2, nt = 1) also supply the mirrored entries Kₑ[(b,d)][(a,c)] of the tiles that were skipped
+        auto put = [&](int R, int b, int d, double v) { // Kₑ[R][(b,d)]
+            if (atomic == 2) { // element assembly: the stored Kₑ row
+                ke[((int64_t)cell * ND + R) * ND + (KE_DMAJOR ? d * NB + b : 3 * b + d)] = v;
+            } else {
+                const int a = R / 3, c = R - 3 * a;
+                const int64_t k = rowptr[s_dof[3 * a] + c] + blockpos[cell * (NB * NB) + a * NB + b] + d;
+                if (atomic) unsafeAtomicAdd(nz + k, v); else nz[k] += v;
+            }
+        };
+        auto emit = [&](const mfma_d4 &v, int knd, int nt) {
+            const int mt = knd / 3, d = knd % 3, b = 16 * nt + lr;
             if (b >= NB) return;
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const int R = 16 * mt + g + 4 * rg;
                 if (R >= ND) continue;
-                if (atomic == 2) { // element assembly: row R of Kₑ leaves as three runs (d) of NB consecutive doubles
-                    ke[((int64_t)cell * ND + R) * ND + (KE_DMAJOR ? d * NB + b : 3 * b + d)] = v[rg];
-                } else {
-                    const int a = R / 3, c = R - 3 * a;
-                    const int64_t k = rowptr[s_dof[3 * a] + c] + blockpos[cell * (NB * NB) + a * NB + b] + d;
-                    if (atomic) unsafeAtomicAdd(nz + k, v[rg]); else nz[k] += v[rg];
-                }
+                put(R, b, d, v[rg]);
+                if (nt == 1 && mt <= 2) put(3 * b + d, R / 3, R % 3, v[rg]); // transpose: row (b,d), column (a,c) = R
             }
         };
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { emit(acc[i][0], 4 * wv + i, 0); emit(acc[i][1], 4 * wv + i, 1); }
-        emit(acc4, 16 + (wv >> 1), odd ? 1 : 0);
+        emit(acc[0], kind[0], 0); emit(acc[1], kind[0], 1);
+        emit(acc[2], kind[1], 0); emit(acc[3], kind[1], 1);
+        emit(acc[4], kind[2], 1); emit(acc[5], kind[3], 1);
+        if (e2_both) emit(acc[6], kind[2], 0);
+        else if (has_e4) emit(acc[6], kind[4], 1);
     } else {
     // B: sweep the points
     const int a_own = tid / NG, bg = tid % NG;
