@@ -241,45 +241,92 @@ k_cg_direction(int64_t n, double beta, const double *__restrict__ r, const doubl
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = (dinv ? dinv[i] * r[i] : r[i]) + beta * p[i];
 }
 
+// ---- device-resident CG scalars: the host only reads (pᵀAp, rᵀr) once per iteration to decide whether to go on ----
+// scal[0..2]: r·z of the current / next / retired iteration (rotating), scal[3] = pᵀAp, scal[4] = rᵀr
+template <int LANES>
+__global__ void __launch_bounds__(256)
+k_spmv_dot(int64_t nrows, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const double *__restrict__ nz,
+           const double *__restrict__ x, double *__restrict__ y, double *__restrict__ xy)
+{
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int sub = threadIdx.x % LANES;
+    const int64_t nsub = ((int64_t)gridDim.x * blockDim.x) / LANES;
+    double acc = 0.0;
+    for (int64_t r = gid / LANES; r < nrows; r += nsub) {
+        const int64_t k0 = rowptr[r], k1 = rowptr[r + 1];
+        double v = 0.0;
+        for (int64_t k = k0 + sub; k < k1; k += LANES) v += nz[k] * x[colidx[k]];
+#pragma unroll
+        for (int o = LANES / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, LANES);
+        if (sub == 0) { y[r] = v; acc += x[r] * v; }
+    }
+    block_sum_to(acc, xy);
+}
+
+__global__ void __launch_bounds__(256)
+k_cg_update_dev(int64_t n, const double *__restrict__ rz, const double *__restrict__ pAp, const double *__restrict__ p, const double *__restrict__ Ap,
+                const double *__restrict__ dinv, double *__restrict__ x, double *__restrict__ r, double *__restrict__ rz_next, double *__restrict__ rr)
+{
+    const double alpha = *rz / *pAp;
+    double a = 0.0, c = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        x[i] += alpha * p[i];
+        const double ri = r[i] - alpha * Ap[i];
+        r[i] = ri;
+        a += ri * (dinv ? dinv[i] * ri : ri);
+        c += ri * ri;
+    }
+    block_sum_to(a, rz_next);
+    __syncthreads();
+    block_sum_to(c, rr);
+}
+
+// p = D⁻¹ r + (rz_next / rz) p; one thread retires the scalars the next iteration accumulates into
+__global__ void __launch_bounds__(256)
+k_cg_direction_dev(int64_t n, const double *__restrict__ rz, const double *__restrict__ rz_next, double *__restrict__ retired, double *__restrict__ pAp_rr,
+                   const double *__restrict__ r, const double *__restrict__ dinv, double *__restrict__ p)
+{
+    const double beta = *rz_next / *rz;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = (dinv ? dinv[i] * r[i] : r[i]) + beta * p[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *retired = 0.0; pAp_rr[0] = 0.0; pAp_rr[1] = 0.0; }
+}
+
 int launch_cg(tb_pattern *pat, const double *A, const double *b, double *x, double rtol, double atol, int maxiter, int jacobi, int *iters,
               double *resnorm)
 {
     tb_device *dev = pat->mesh->dev;
     const int64_t n = pat->n_rows;
-    if (!pat->d_cg_ws) TB_HIP(hipMalloc((void **)&pat->d_cg_ws, sizeof(double) * (4 * n + 2)));
+    if (!pat->d_cg_ws) TB_HIP(hipMalloc((void **)&pat->d_cg_ws, sizeof(double) * (4 * n + 8)));
     double *r = pat->d_cg_ws, *p = r + n, *Ap = p + n, *dinv = Ap + n, *scal = dinv + n;
     const unsigned g = grid_for(dev, n, 256);
-    auto read2 = [&](double *h) -> int {
-        TB_HIP(hipMemcpyAsync(h, scal, 2 * sizeof(double), hipMemcpyDeviceToHost, dev->stream));
-        TB_HIP(hipStreamSynchronize(dev->stream));
-        return TB_OK;
-    };
+    constexpr int LANES = 8;
+    const unsigned gs = grid_for(dev, n * LANES, 256);
     if (jacobi) hipLaunchKernelGGL(k_extract_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, dev->stream, n, pat->d_rowptr, pat->d_colidx, A, dinv);
     const double *dp = jacobi ? dinv : nullptr;
     int rc = launch_spmv(pat, A, x, 1.0, 0.0, Ap);
     if (rc) return rc;
-    TB_HIP(hipMemsetAsync(scal, 0, 2 * sizeof(double), dev->stream));
+    TB_HIP(hipMemsetAsync(scal, 0, 5 * sizeof(double), dev->stream));
+    // k_cg_init writes r·z to out[0] and r·r to out[1]: point it at (scal[0], scal[1]) and move r·r to its slot afterwards
     hipLaunchKernelGGL(k_cg_init, dim3(g), dim3(256), 0, dev->stream, n, b, Ap, dp, r, p, scal);
     double h[2];
-    if ((rc = read2(h))) return rc;
-    double rz = h[0], rnorm = std::sqrt(h[1]);
+    TB_HIP(hipMemcpyAsync(h, scal, 2 * sizeof(double), hipMemcpyDeviceToHost, dev->stream));
+    TB_HIP(hipStreamSynchronize(dev->stream));
+    TB_HIP(hipMemsetAsync(scal + 1, 0, sizeof(double), dev->stream)); // slot 1 becomes the "next r·z" accumulator
+    double rnorm = std::sqrt(h[1]);
     const double tol = atol + rtol * rnorm;
-    int it = 0;
+    int it = 0, cur = 0;
     while (rnorm > tol && it < maxiter) {
-        if ((rc = launch_spmv(pat, A, p, 1.0, 0.0, Ap))) return rc;
-        TB_HIP(hipMemsetAsync(scal, 0, 2 * sizeof(double), dev->stream));
-        hipLaunchKernelGGL(k_dot, dim3(g), dim3(256), 0, dev->stream, n, p, Ap, scal);
-        if ((rc = read2(h))) return rc;
-        const double pAp = h[0];
-        if (!(pAp > 0.0)) { set_error("tb_cg_solve: matrix is not positive definite (pᵀAp = %g)", pAp); return TB_ERR_BAD_ARG; }
-        const double alpha = rz / pAp;
-        TB_HIP(hipMemsetAsync(scal, 0, 2 * sizeof(double), dev->stream));
-        hipLaunchKernelGGL(k_cg_update, dim3(g), dim3(256), 0, dev->stream, n, alpha, p, Ap, dp, x, r, scal);
-        if ((rc = read2(h))) return rc;
-        const double rz_new = h[0];
+        const int nxt = (cur + 1) % 3, ret = (cur + 2) % 3;
+        hipLaunchKernelGGL(k_spmv_dot<LANES>, dim3(gs), dim3(256), 0, dev->stream, n, pat->d_rowptr, pat->d_colidx, A, p, Ap, scal + 3);
+        hipLaunchKernelGGL(k_cg_update_dev, dim3(g), dim3(256), 0, dev->stream, n, scal + cur, scal + 3, p, Ap, dp, x, r, scal + nxt, scal + 4);
+        TB_HIP(hipMemcpyAsync(h, scal + 3, 2 * sizeof(double), hipMemcpyDeviceToHost, dev->stream));
+        hipLaunchKernelGGL(k_cg_direction_dev, dim3(g), dim3(256), 0, dev->stream, n, scal + cur, scal + nxt, scal + ret, scal + 3, r, dp, p);
+        TB_HIP(hipStreamSynchronize(dev->stream));
+        if (!(h[0] > 0.0)) { set_error("tb_cg_solve: matrix is not positive definite (pᵀAp = %g)", h[0]); return TB_ERR_BAD_ARG; }
         rnorm = std::sqrt(h[1]);
-        hipLaunchKernelGGL(k_cg_direction, dim3(g), dim3(256), 0, dev->stream, n, rz_new / rz, r, dp, p);
-        rz = rz_new;
+        cur = nxt;
         ++it;
     }
     TB_HIP(hipGetLastError());
@@ -323,7 +370,7 @@ k_sum_absdiag(int64_t nrows, const int64_t *__restrict__ rowptr, const int32_t *
 static int scratch2(tb_pattern *pat, double **scal)
 {
     const int64_t n = pat->n_rows;
-    if (!pat->d_cg_ws) TB_HIP(hipMalloc((void **)&pat->d_cg_ws, sizeof(double) * (4 * n + 2)));
+    if (!pat->d_cg_ws) TB_HIP(hipMalloc((void **)&pat->d_cg_ws, sizeof(double) * (4 * n + 8)));
     *scal = pat->d_cg_ws + 4 * n;
     return TB_OK;
 }
