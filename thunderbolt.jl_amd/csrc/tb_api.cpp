@@ -363,7 +363,7 @@ int tb_form_create(tb_mesh *mesh, int form_kind, int qorder, const tb_coef *coef
 int tb_form_destroy(tb_form *f)
 {
     if (!f) return TB_OK;
-    hipFree(f->d_field); hipFree(f->d_table); hipFree(f->d_facets); hipFree(f->d_act_field);
+    hipFree(f->d_field); hipFree(f->d_dtab); hipFree(f->d_table); hipFree(f->d_facets); hipFree(f->d_act_field);
     delete f;
     return TB_OK;
 }

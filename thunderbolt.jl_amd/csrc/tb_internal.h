@@ -148,6 +148,7 @@ struct tb_form {
     double Dconst[9] = {0}; // folded constant tensor (incl. κ/(Cₘχ))
     bool field = false, symmetric = true;
     double *d_field = nullptr;
+    double *d_dtab = nullptr;  // diffusion tensor at the quadrature points (built from d_field at the first assembly)
     double *d_table = nullptr;
     int64_t table_len = 0;
     tb_material mat{};
