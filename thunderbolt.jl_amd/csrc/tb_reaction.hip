@@ -16,6 +16,35 @@
 
 namespace tb {
 
+// exp for bounded arguments (|x| ≲ 700; ionic-model arguments stay within ±100): k = rint(x·log₂e), r = x − k·ln2 in two
+// pieces (|r| ≤ 0.347), degree-13 Taylor polynomial (truncation 2·10⁻¹⁸ relative), one ldexp.  ≈21 instructions against ≈40 of
+// the library routine, which spends the rest on special cases that cannot occur here; agreement with libm ≤ 2 ulp
+// (tests/test_gpu_parity.py compares whole trajectories at 1e-12).  The reaction kernels are exp-bound, not HBM-bound.
+__device__ __forceinline__ double exp_b(double x)
+{
+    x = fmin(fmax(x, -700.0), 700.0);
+    const double kf = rint(x * 1.4426950408889634);
+    double r = fma(kf, -6.93147180369123816490e-01, x);
+    r = fma(kf, -1.90821492927058770002e-10, r);
+    const double c[12] = {1.6059043836821613e-10, 2.08767569878681e-09, 2.505210838544172e-08, 2.755731922398589e-07, 2.7557319223985893e-06, 2.48015873015873e-05, 0.0001984126984126984, 0.001388888888888889, 0.008333333333333333, 0.041666666666666664, 0.16666666666666666, 0.5};
+    double q = c[0];
+#pragma unroll
+    for (int i = 1; i < 12; ++i) q = fma(q, r, c[i]);
+    q = fma(q, r, 1.0); // … + r
+    q = fma(q, r, 1.0); // 1 + r·(…)
+    return ldexp(q, (int)kf);
+}
+
+// 1/y for well-scaled arguments: hardware reciprocal refined by two Newton steps (≤ 1–2 ulp), 5 instructions against the
+// ≈12 of the IEEE division sequence (no scaling / fix-up: gate and buffer denominators are O(1) numbers)
+__device__ __forceinline__ double rcp_b(double y)
+{
+    double r = __builtin_amdgcn_rcp(y);
+    r = fma(fma(-y, r, 1.0), r, r);
+    r = fma(fma(-y, r, 1.0), r, r);
+    return r;
+}
+
 struct CellParams {
     double p[48];
 };
@@ -52,7 +81,7 @@ template <> struct CellModel<TB_CELL_PCG2019> {
            gKr, Exr, kxr, tauxr, Ey, ky, gKs, Exs, kxs, tauxs, ENa, EK, ECa };
     __device__ __forceinline__ static double sigmoid(double phi, double E, double k, double sign)
     {
-        return 1.0 / (1.0 + exp(sign * (phi - E) / k));
+        return 1.0 / (1.0 + exp_b(sign * (phi - E) / k));
     }
     __device__ __forceinline__ static void rhs(const CellParams &P, const double (&u)[NS], double, double (&du)[NS])
     {
@@ -69,8 +98,8 @@ template <> struct CellModel<TB_CELL_PCG2019> {
         const double I_Kr = p[gKr] * xr * yinf * (phi - p[EK]);
         const double I_Ks = p[gKs] * xs * (phi - p[EK]);
         du[0] = -(I_Na + I_K1 + I_to + I_CaL + I_Kr + I_Ks); // C_m = 1, pcg2019.jl:55
-        const double eh = exp((phi - p[Eh]) / p[kh]);
-        const double tau_h = (2.0 * p[tauh0] * exp(p[dh] * (phi - p[Eh]) / p[kh])) / (1.0 + eh);
+        const double eh = exp_b((phi - p[Eh]) / p[kh]);
+        const double tau_h = (2.0 * p[tauh0] * exp_b(p[dh] * (phi - p[Eh]) / p[kh])) / (1.0 + eh);
         const double hinf = 1.0 / (1.0 + eh);
         du[1] = (hinf - h) / tau_h;
         du[2] = (sigmoid(phi, p[Em], p[km], -1.0) - m) / p[taum];
@@ -89,12 +118,12 @@ template <> struct CellModel<TB_CELL_PCG2019> {
 template <> struct CellModel<TB_CELL_TT06> {
     static constexpr int NS = 19, PHI = 0;
     // The ≈50 exponentials of the published right-hand side are affine in V with only a handful of distinct slopes:
-    // exp((V + c)/k) = exp(V/k)·exp(c/k), exp(−x) = 1/exp(x).  One exp per slope plus constant factors (folded at compile
+    // exp_b((V + c)/k) = exp_b(V/k)·exp_b(c/k), exp_b(−x) = 1/exp_b(x).  One exp per slope plus constant factors (folded at compile
     // time) and a reciprocal replaces 3–5 library calls each; the kernel is exp-bound (FP64 exp ≈ 40 instructions), so this
     // is where its time goes.  Divisions by literal constants are written as multiplications by the (compile-time) reciprocal
     // for the same reason (an IEEE FP64 division is ≈15 instructions).  Rounding differs from the literal form by a few ulp
     // (parity tolerance 1e-12).
-    __device__ __forceinline__ static double sgm(double e) { return 1.0 / (1.0 + e); } // 1/(1+e), e = exp(x) given
+    __device__ __forceinline__ static double sgm(double e) { return rcp_b(1.0 + e); } // 1/(1+e), e = exp_b(x) given
     __device__ __forceinline__ static void rhs(const CellParams &P, const double (&u)[NS], double, double (&du)[NS])
     {
         const double *p = P.p;
@@ -110,31 +139,31 @@ template <> struct CellModel<TB_CELL_TT06> {
         // reversal potentials
         const double Ek = RTONF * log(Ko / Ki), Ena = RTONF * log(Nao / Nai);
         const double Eks = RTONF * log((Ko + pKNa * Nao) / (Ki + pKNa * Nai)), Eca = 0.5 * RTONF * log(Cao / Cai);
-        // shared exponentials of V (p = exp(V/k), q = 1/p)
-        const double p5 = exp(V * (1.0 / 5.0)), q5 = 1.0 / p5;
-        const double p10 = exp(V * (1.0 / 10.0)), q10 = 1.0 / p10;
-        const double p20 = exp(V * (1.0 / 20.0)), q20 = 1.0 / p20;
-        const double p7 = exp(V * (1.0 / 7.0)), q7 = 1.0 / p7;
-        const double q6 = exp(-V * (1.0 / 6.0));
-        const double w = exp(V * FoRT), iw = 1.0 / w; // exp(±V F/RT)
+        // shared exponentials of V (p = exp_b(V/k), q = 1/p)
+        const double p5 = exp_b(V * (1.0 / 5.0)), q5 = rcp_b(p5);
+        const double p10 = exp_b(V * (1.0 / 10.0)), q10 = rcp_b(p10);
+        const double p20 = exp_b(V * (1.0 / 20.0)), q20 = rcp_b(p20);
+        const double p7 = exp_b(V * (1.0 / 7.0)), q7 = rcp_b(p7);
+        const double q6 = exp_b(-V * (1.0 / 6.0));
+        const double w = exp_b(V * FoRT), iw = rcp_b(w); // exp_b(±V F/RT)
         // currents
         const double vk = V - Ek;
-        const double Ak1 = 0.1 * sgm(exp(0.06 * (vk - 200.0)));
-        const double eh = exp(-0.5 * vk);
-        const double Bk1 = (3.0 * exp(0.0002 * (vk + 100.0)) + exp(0.1 * (vk - 10.0))) * sgm(eh);
+        const double Ak1 = 0.1 * sgm(exp_b(0.06 * (vk - 200.0)));
+        const double eh = exp_b(-0.5 * vk);
+        const double Bk1 = (3.0 * exp_b(0.0002 * (vk + 100.0)) + exp_b(0.1 * (vk - 10.0))) * sgm(eh);
         const double INa = GNa * m * m * m * h * j * (V - Ena);
-        const double e2 = w * w * exp(-30.0 * FoRT); // exp(2 (V − 15) F/RT)
+        const double e2 = w * w * exp_b(-30.0 * FoRT); // exp_b(2 (V − 15) F/RT)
         const double ICaL = GCaL * d * f * f2 * fCass * 4.0 * (V - 15.0) * (F * FoRT) * (0.25 * e2 * CaSS - Cao) / (e2 - 1.0);
         const double Ito = Gto * r * s * vk;
         const double IKr = GKr * sqrt(Ko * (1.0 / 5.4)) * xr1 * xr2 * vk;
         const double IKs = GKs * xs * xs * (V - Eks);
         const double IK1 = GK1 * (Ak1 / (Ak1 + Bk1)) * vk;
-        const double en = exp(nn * V * FoRT), en1 = en * iw; // exp((γ − 1) V F/RT)
+        const double en = exp_b(nn * V * FoRT), en1 = en * iw; // exp_b((γ − 1) V F/RT)
         const double INaCa = knaca * (1.0 / (KmNai * KmNai * KmNai + Nao * Nao * Nao)) * (1.0 / (KmCa + Cao)) * (1.0 / (1.0 + ksat * en1)) *
                              (en * Nai * Nai * Nai * Cao - en1 * Nao * Nao * Nao * Cai * 2.5);
-        const double INaK = knak * (Ko / (Ko + KmK)) * (Nai / (Nai + KmNa)) / (1.0 + 0.1245 * exp(-0.1 * V * FoRT) + 0.0353 * iw);
+        const double INaK = knak * (Ko / (Ko + KmK)) * (Nai / (Nai + KmNa)) / (1.0 + 0.1245 * exp_b(-0.1 * V * FoRT) + 0.0353 * iw);
         const double IpCa = GpCa * Cai / (KpCa + Cai);
-        const double IpK = GpK * sgm(exp((25.0 - V) * (1.0 / 5.98))) * vk;
+        const double IpK = GpK * sgm(exp_b((25.0 - V) * (1.0 / 5.98))) * vk;
         const double IbNa = GbNa * (V - Ena), IbCa = GbCa * (V - Eca);
         du[0] = -(IKr + IKs + IK1 + Ito + INa + IbNa + ICaL + IbCa + INaK + INaCa + IpCa + IpK);
         // calcium handling
@@ -153,36 +182,36 @@ template <> struct CellModel<TB_CELL_TT06> {
         du[3] = bss * (-ICaL * Cm / (2.0 * Vss * F) + Irel * Vsr / Vss - Ixfer * Vc / Vss);
         du[4] = -(INa + IbNa + 3.0 * INaK + 3.0 * INaCa) * Cm / (Vc * F);
         du[5] = -(IK1 + Ito + IKr + IKs - 2.0 * INaK + IpK) * Cm / (Vc * F);
-        // gates: dy/dt = (y∞ − y)/τ.  Constants below are exp(c/k) of the published arguments (V + c)/k, folded by the compiler.
-        const double AM = sgm(q5 * 6.14421235332821e-06 /* exp(-60.0 * (1.0 / 5.0)) */);
-        const double BM = 0.1 * sgm(p5 * 1096.6331584284585 /* exp(35.0 * (1.0 / 5.0)) */) + 0.1 * sgm(exp((V - 50.0) * (1.0 / 200.0)));
-        const double mr = sgm(exp((-56.86 - V) * (1.0 / 9.03)));
-        du[6] = (mr * mr - m) / (AM * BM);
-        const double hr = sgm(exp((V + 71.55) * (1.0 / 7.43)));
+        // gates: dy/dt = (y∞ − y)/τ.  Constants below are exp_b(c/k) of the published arguments (V + c)/k, folded by the compiler.
+        const double AM = sgm(q5 * 6.14421235332821e-06 /* exp_b(-60.0 * (1.0 / 5.0)) */);
+        const double BM = 0.1 * sgm(p5 * 1096.6331584284585 /* exp_b(35.0 * (1.0 / 5.0)) */) + 0.1 * sgm(exp_b((V - 50.0) * (1.0 / 200.0)));
+        const double mr = sgm(exp_b((-56.86 - V) * (1.0 / 9.03)));
+        du[6] = (mr * mr - m) * rcp_b(AM * BM);
+        const double hr = sgm(exp_b((V + 71.55) * (1.0 / 7.43)));
         const double hinf = hr * hr;
         double ABH, ABJ; // αh + βh, αj + βj
         if (V >= -40.0) {
-            ABH = 0.77 / (0.13 * (1.0 + exp(-(V + 10.66) * (1.0 / 11.1))));
-            ABJ = 0.6 * exp(0.057 * V) * sgm(q10 * 0.04076220397836621 /* exp(-3.2) */);
+            ABH = 0.77 / (0.13 * (1.0 + exp_b(-(V + 10.66) * (1.0 / 11.1))));
+            ABJ = 0.6 * exp_b(0.057 * V) * sgm(q10 * 0.04076220397836621 /* exp_b(-3.2) */);
         } else {
-            ABH = 0.057 * exp(-(V + 80.0) * (1.0 / 6.8)) + 2.7 * exp(0.079 * V) + 3.1e5 * exp(0.3485 * V);
-            ABJ = ((-2.5428e4) * exp(0.2444 * V) - 6.948e-6 * exp(-0.04391 * V)) * (V + 37.78) * sgm(exp(0.311 * (V + 79.23))) +
-                  0.02424 * exp(-0.01052 * V) * sgm(exp(-0.1378 * (V + 40.14)));
+            ABH = 0.057 * exp_b(-(V + 80.0) * (1.0 / 6.8)) + 2.7 * exp_b(0.079 * V) + 3.1e5 * exp_b(0.3485 * V);
+            ABJ = ((-2.5428e4) * exp_b(0.2444 * V) - 6.948e-6 * exp_b(-0.04391 * V)) * (V + 37.78) * sgm(exp_b(0.311 * (V + 79.23))) +
+                  0.02424 * exp_b(-0.01052 * V) * sgm(exp_b(-0.1378 * (V + 40.14)));
         }
         du[7] = (hinf - h) * ABH;
         du[8] = (hinf - j) * ABJ;
-        du[9] = (sgm(q7 * 0.02437284407327961 /* exp(-26.0 * (1.0 / 7.0)) */) - xr1) / ((450.0 * sgm(q10 * 0.011108996538242306 /* exp(-4.5) */)) * (6.0 * sgm(exp((V + 30.0) * (1.0 / 11.5)))));
-        du[10] = (sgm(exp((V + 88.0) * (1.0 / 24.0))) - xr2) / ((3.0 * sgm(q20 * 0.049787068367863944 /* exp(-3.0) */)) * (1.12 * sgm(p20 * 0.049787068367863944 /* exp(-3.0) */)));
-        du[11] = (sgm(exp((-5.0 - V) * (1.0 / 14.0))) - xs) / ((1400.0 / sqrt(1.0 + q6 * 2.3009758908928246 /* exp(5.0 * (1.0 / 6.0)) */)) * sgm(exp((V - 35.0) * (1.0 / 15.0))) + 80.0);
-        du[12] = (sgm(q6 * 28.031624894526125 /* exp(20.0 * (1.0 / 6.0)) */) - r) / (9.5 * exp(-(V + 40.0) * (V + 40.0) * (1.0 / 1800.0)) + 0.8);
-        du[13] = (sgm(p5 * 54.598150033144236 /* exp(4.0) */) - s) / (85.0 * exp(-(V + 45.0) * (V + 45.0) * (1.0 / 320.0)) + 5.0 * sgm(p5 * 0.01831563888873418 /* exp(-4.0) */) + 3.0);
-        du[14] = (sgm(exp((-8.0 - V) * (1.0 / 7.5))) - d) / ((1.4 * sgm(exp((-35.0 - V) * (1.0 / 13.0))) + 0.25) * (1.4 * sgm(p5 * 2.718281828459045 /* exp(1.0) */)) + sgm(q20 * 12.182493960703473 /* exp(2.5) */));
-        du[15] = (sgm(p7 * 17.411708063327644 /* exp(20.0 * (1.0 / 7.0)) */) - f) /
-                 (1102.5 * exp(-(V + 27.0) * (V + 27.0) * (1.0 / 225.0)) + 200.0 * sgm(q10 * 3.6692966676192444 /* exp(1.3) */) + 180.0 * sgm(p10 * 20.085536923187668 /* exp(3.0) */) + 20.0);
-        du[16] = (0.67 * sgm(p7 * 148.4131591025766 /* exp(5.0) */) + 0.33 - f2) /
-                 (600.0 * exp(-(V + 25.0) * (V + 25.0) * (1.0 / 170.0)) + 31.0 * sgm(q10 * 12.182493960703473 /* exp(2.5) */) + 16.0 * sgm(p10 * 20.085536923187668 /* exp(3.0) */));
+        du[9] = (sgm(q7 * 0.02437284407327961 /* exp_b(-26.0 * (1.0 / 7.0)) */) - xr1) * rcp_b((450.0 * sgm(q10 * 0.011108996538242306 /* exp_b(-4.5) */)) * (6.0 * sgm(exp_b((V + 30.0) * (1.0 / 11.5)))));
+        du[10] = (sgm(exp_b((V + 88.0) * (1.0 / 24.0))) - xr2) * rcp_b((3.0 * sgm(q20 * 0.049787068367863944 /* exp_b(-3.0) */)) * (1.12 * sgm(p20 * 0.049787068367863944 /* exp_b(-3.0) */)));
+        du[11] = (sgm(exp_b((-5.0 - V) * (1.0 / 14.0))) - xs) * rcp_b((1400.0 / sqrt(1.0 + q6 * 2.3009758908928246 /* exp_b(5.0 * (1.0 / 6.0)) */)) * sgm(exp_b((V - 35.0) * (1.0 / 15.0))) + 80.0);
+        du[12] = (sgm(q6 * 28.031624894526125 /* exp_b(20.0 * (1.0 / 6.0)) */) - r) * rcp_b(9.5 * exp_b(-(V + 40.0) * (V + 40.0) * (1.0 / 1800.0)) + 0.8);
+        du[13] = (sgm(p5 * 54.598150033144236 /* exp_b(4.0) */) - s) * rcp_b(85.0 * exp_b(-(V + 45.0) * (V + 45.0) * (1.0 / 320.0)) + 5.0 * sgm(p5 * 0.01831563888873418 /* exp_b(-4.0) */) + 3.0);
+        du[14] = (sgm(exp_b((-8.0 - V) * (1.0 / 7.5))) - d) * rcp_b((1.4 * sgm(exp_b((-35.0 - V) * (1.0 / 13.0))) + 0.25) * (1.4 * sgm(p5 * 2.718281828459045 /* exp_b(1.0) */)) + sgm(q20 * 12.182493960703473 /* exp_b(2.5) */));
+        du[15] = (sgm(p7 * 17.411708063327644 /* exp_b(20.0 * (1.0 / 7.0)) */) - f) *
+                 rcp_b((1102.5 * exp_b(-(V + 27.0) * (V + 27.0) * (1.0 / 225.0)) + 200.0 * sgm(q10 * 3.6692966676192444 /* exp_b(1.3) */) + 180.0 * sgm(p10 * 20.085536923187668 /* exp_b(3.0) */) + 20.0));
+        du[16] = (0.67 * sgm(p7 * 148.4131591025766 /* exp_b(5.0) */) + 0.33 - f2) *
+                 rcp_b((600.0 * exp_b(-(V + 25.0) * (V + 25.0) * (1.0 / 170.0)) + 31.0 * sgm(q10 * 12.182493960703473 /* exp_b(2.5) */) + 16.0 * sgm(p10 * 20.085536923187668 /* exp_b(3.0) */)));
         const double cq = 1.0 + (CaSS * (1.0 / 0.05)) * (CaSS * (1.0 / 0.05));
-        du[17] = (0.6 / cq + 0.4 - fCass) / (80.0 / cq + 2.0);
+        du[17] = (0.6 / cq + 0.4 - fCass) * rcp_b(80.0 / cq + 2.0);
     }
 };
 
