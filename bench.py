@@ -235,8 +235,13 @@ def main():
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             if tj["cells"] == g.n_cells and args.strategy == "patch":
                 kk = [v for k, v in tj["kernels"].items() if "k_matrix_patch" in k and ", 1," in k][0]
-                out["roofline"]["traffic"] = kk["fetch_bytes"] + kk["write_bytes"]
-                out["roofline"]["traffic_note"] = "bytes per launch, " + tj["source"] + "; FETCH_SIZE uncorrected (lower bound, see profiles/traffic.json)"
+                if "read_bytes_by_request_size" in kk:   # FETCH_SIZE corrected for gfx950: 128-B requests counted as 128 B
+                    out["roofline"]["traffic"] = kk["read_bytes_by_request_size"] + kk["write_bytes"]
+                    out["roofline"]["traffic_note"] = ("bytes per launch: reads = 32/64/128-byte TCC_EA0_RDREQ counts x their sizes (FETCH_SIZE tallies 128-B requests "
+                                                       "at 64 B on gfx950), writes = WRITE_SIZE; separate rocprofv3 --pmc passes of python3 bench.py, " + tj["source"])
+                else:
+                    out["roofline"]["traffic"] = kk["fetch_bytes"] + kk["write_bytes"]
+                    out["roofline"]["traffic_note"] = "bytes per launch, " + tj["source"] + "; FETCH_SIZE uncorrected (lower bound, see profiles/traffic.json)"
         except Exception:
             pass
         if world == 1 and not args.no_cpu_baseline:
