@@ -500,6 +500,13 @@ static void eval_tensor_coef(const orc_coef *c, const cellvalues *cv, int q, int
     case ORC_COEF_TRANSVERSE_CONST:
         orc_eval_spectral(dim, 1, c->p, c->p + dim, k);
         break;
+    case ORC_COEF_FIELD_SCALAR: { /* FieldCoefficient of a scalar conductivity (coefficients.jl:85-99): κ(x_q)·I */
+        double v;
+        orc_eval_field(nb, 1, cv->N[q], c->field + (int64_t)cell * nb, &v);
+        for (int i = 0; i < dim * dim; ++i) k[i] = 0;
+        for (int i = 0; i < dim; ++i) k[dim * i + i] = v;
+        break;
+    }
     case ORC_COEF_SPECTRAL_FIELD: {
         /* microstructure.jl:176-187: interpolate f,s,n (coefficients.jl:85-99), orthogonalise */
         double v[9];

@@ -40,6 +40,7 @@ def coef_cases(tb, oracle, g, rng):
     sfield = rng.normal(size=(nc, 8, 3)) * 0.3 + np.array([0, 2.0, 0])
     nfield = rng.normal(size=(nc, 8, 3)) * 0.3 + np.array([0, 0, 2.0])
     fsn = np.stack([ffield, sfield, nfield], axis=2)
+    kfield = rng.uniform(0.2, 3.0, size=(nc, 8))                 # heterogeneous isotropic conductivity (e.g. scar), nodal per cell
     T, O = tb, oracle
     return [
         ("iso", T.ConstantCoefficient(1.0), O.Coef(O.COEF_CONST_SCALAR, [1.0])),
@@ -58,6 +59,8 @@ def coef_cases(tb, oracle, g, rng):
             T.SpectralTensorCoefficient(T.OrthotropicMicrostructureModel(ffield, sfield, nfield), T.ConstantCoefficient(lam)),
             T.ConstantCoefficient(1.3), T.ConstantCoefficient(0.9)),
          O.Coef(O.COEF_SPECTRAL_FIELD, lam, field=fsn, Cm=1.3, chi=0.9, wrap=True)),
+        ("iso_field", T.ConductivityToDiffusivityCoefficient(T.FieldCoefficient(kfield), T.ConstantCoefficient(1.1), T.ConstantCoefficient(0.8)),
+         O.Coef(O.COEF_FIELD_SCALAR, [0.0], field=kfield, Cm=1.1, chi=0.8, wrap=True)),
     ]
 
 

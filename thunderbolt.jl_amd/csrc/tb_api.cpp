@@ -341,6 +341,7 @@ int tb_form_create(tb_mesh *mesh, int form_kind, int qorder, const tb_coef *coef
                 }
             break;
         case TB_COEF_SPECTRAL_FIELD: f->field = true; need_field = mesh->n_cells * nb * 9; break;
+        case TB_COEF_FIELD_SCALAR: f->field = true; need_field = mesh->n_cells * nb; break; // κ(x)·I, FieldCoefficient (coefficients.jl:85-99)
         default: set_error("diffusion form: coefficient kind %d", coef->kind); return TB_ERR_BAD_ARG;
         }
         const double den = coef->Cm * coef->chi;

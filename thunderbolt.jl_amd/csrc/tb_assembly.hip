@@ -199,6 +199,28 @@ k_tabulate_spectral(const double *__restrict__ field, int64_t n_cells, double l0
     }
 }
 
+// same table for an isotropic heterogeneous conductivity κ(x)·I given as first-order nodal data per cell (FieldCoefficient)
+template <class E>
+__global__ void __launch_bounds__(256)
+k_tabulate_isotropic(const double *__restrict__ field, int64_t n_cells, double scale, double *__restrict__ dtab)
+{
+    const int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= n_cells) return;
+    constexpr int NB = E::NB;
+    const Tables<E> &tb = g_tables<E>;
+    double fc[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) fc[k] = field[cell * NB + k];
+    for (int q = 0; q < E::NQ; ++q) {
+        double v = 0.0;
+#pragma unroll
+        for (int a = 0; a < NB; ++a) v += tb.N[q][a] * fc[a];
+        v *= scale;
+        double *o = dtab + (cell * E::NQ + q) * 6;
+        o[0] = v; o[1] = 0.0; o[2] = 0.0; o[3] = v; o[4] = 0.0; o[5] = v;
+    }
+}
+
 __device__ __forceinline__ double eval_source(const FormArgs &fa, const double (&xq)[3], int64_t cell, int q, int nq)
 {
     switch (fa.src_kind) {
@@ -601,8 +623,11 @@ static int run_matrix_coef(tb_form *f, tb_pattern *p, int strategy, double t, do
         hipError_t e = hipMalloc((void **)&f->d_dtab, bytes);
         if (e != hipSuccess) { set_error("diffusion tensor table (%zu B): %s", bytes, hipGetErrorString(e)); return TB_ERR_NOMEM; }
         const double sc = f->coef.wrap ? 1.0 / (f->coef.Cm * f->coef.chi) : 1.0;
-        hipLaunchKernelGGL((k_tabulate_spectral<E>), dim3(nblocks(m->n_cells, 256)), dim3(256), 0, m->dev->stream, f->d_field, m->n_cells, f->coef.p[0],
-                           f->coef.p[1], f->coef.p[2], sc, f->d_dtab);
+        if (f->coef.kind == TB_COEF_FIELD_SCALAR)
+            hipLaunchKernelGGL((k_tabulate_isotropic<E>), dim3(nblocks(m->n_cells, 256)), dim3(256), 0, m->dev->stream, f->d_field, m->n_cells, sc, f->d_dtab);
+        else
+            hipLaunchKernelGGL((k_tabulate_spectral<E>), dim3(nblocks(m->n_cells, 256)), dim3(256), 0, m->dev->stream, f->d_field, m->n_cells, f->coef.p[0],
+                               f->coef.p[1], f->coef.p[2], sc, f->d_dtab);
         TB_HIP(hipGetLastError());
         TB_HIP(hipStreamSynchronize(m->dev->stream));
         (void)hipFree(f->d_field); f->d_field = nullptr; // the nodal frames are not needed any more (5.8 GB at 10 M cells)
