@@ -45,7 +45,8 @@ enum {
 };
 
 /* cell kinds (Ferrite reference shapes; local vertex order as src/mesh/generators.jl:62-79) */
-enum { TB_HEX8 = 3, TB_TET4 = 4, TB_HEX27 = 5 /* Q2 field on trilinear HEX8 geometry */ };
+enum { TB_QUAD4 = 2 /* bilinear quadrilateral in the plane z = 0 (2-D problems; xyz still n×3) */, TB_HEX8 = 3, TB_TET4 = 4,
+       TB_HEX27 = 5 /* Q2 field on trilinear HEX8 geometry */ };
 
 /* assembly strategies — device analogues of the FerriteOperators strategies Thunderbolt re-exports
  * (src/Thunderbolt.jl:22-32; selected via FiniteElementDiscretization(; assembly_strategy), src/discretization/fem.jl:38-46) */
@@ -150,7 +151,9 @@ int tb_event_destroy(void *event);
  * dh.cell_dofs / dh.cell_dofs_offset).  The host supplies Ferrite's own node coordinates, cell
  * connectivity and dof table, so DoF indexing is inherited bit-exactly, never re-derived.
  *   xyz        n_nodes×3 (AoS);  conn  n_cells×nverts;  cell_dofs  n_cells×(nbasis·ncomp)
- *   field_kind TB_HEX8 | TB_TET4 | TB_HEX27 (must match geom_kind's shape); ncomp 1 (scalar) or 3 */
+ *   field_kind TB_QUAD4 | TB_HEX8 | TB_TET4 | TB_HEX27 (must match geom_kind's shape); ncomp 1 (scalar) or 3.
+ *   TB_QUAD4: two-dimensional meshes (the reference's GPU tests and the spiral-wave tutorial run on generate_grid(Quadrilateral, …)):
+ *   coordinates are passed as n×3 with z = 0 and diffusion tensors as 3×3 with the 2×2 tensor in the upper-left block. */
 int tb_mesh_create(tb_device *dev, int geom_kind, int64_t n_nodes, const double *xyz, int64_t n_cells,
                    const int32_t *conn, int field_kind, int ncomp, const int32_t *cell_dofs, int64_t ndofs,
                    int index_base, tb_mesh **out);
@@ -269,6 +272,8 @@ int tb_max(tb_device *dev, int64_t n, const double *d_x, int64_t stride, double 
  * third-party behaviour; at run time the Julia host passes Ferrite's own arrays instead). */
 int tb_host_generate_grid_hex(int nx, int ny, int nz, const double *left, const double *right,
                               double *xyz, int32_t *conn);
+/* generate_grid(Quadrilateral, (nx, ny), left, right): nodes x-fastest, xyz n×3 with z = 0, counter-clockwise cells */
+int tb_host_generate_grid_quad(int nx, int ny, const double *left, const double *right, double *xyz, int32_t *conn);
 int tb_host_perturb_nodes(int nx, int ny, int nz, double amplitude_rel, double *xyz);
 int64_t tb_host_close_dofs(int field_kind, int ncomp, int64_t n_cells, int64_t n_nodes, const int32_t *conn,
                            int32_t *cell_dofs);

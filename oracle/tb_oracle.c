@@ -335,7 +335,8 @@ int64_t orc_close_dofs(int kind, int ncomp, int64_t n_cells, int64_t n_nodes, co
 {
     static const int E[12][2] = {{0,1},{1,2},{2,3},{3,0},{4,5},{5,6},{6,7},{7,4},{0,4},{1,5},{2,6},{3,7}};
     static const int F[6][4] = {{0,3,2,1},{0,1,5,4},{1,2,6,5},{2,3,7,6},{0,4,7,3},{4,5,6,7}};
-    int nverts = (kind == ORC_TET4) ? 4 : 8;
+    int refdim, nverts;
+    if (orc_elem_info(kind == ORC_HEX27 ? ORC_HEX8 : kind, &refdim, &nverts)) return -1; /* LINE2 2, QUAD4 4, TET4 4, HEX8 8 */
     int nb = (kind == ORC_HEX27) ? 27 : nverts;
     int32_t *vdof = (int32_t *)malloc(sizeof(int32_t) * n_nodes);
     for (int64_t i = 0; i < n_nodes; ++i) vdof[i] = -1;

@@ -745,3 +745,82 @@ def test_active_stress_parity(tb, oracle, device, order, nel):
                 assert rel_err(res2.to_host(), rref) < 1e-11
     finally:
         oracle.set_active_tension(0.0)
+
+
+# ------------------------------------------------------------------------------------------- the reference's own GPU tests
+def quad_problem(tb, oracle, nel, left, right):
+    g = tb.generate_mesh(tb.Quadrilateral, nel, left, right)
+    dh = tb.DofHandler(g)
+    sp = tb.allocate_matrix(dh)
+    xy = np.ascontiguousarray(g.xyz[:, :2])
+    om = oracle.Mesh(oracle.QUAD4, 2, xy, g.conn, dh.cell_dofs)
+    return g, dh, sp, om
+
+
+def test_reference_gpu_operator_api_pattern(tb, oracle, device):
+    """test/gpu/test_operators.jl: generate_grid(Quadrilateral, (287, 1), (-1,-1), (1,1)); linear form with
+    AnalyticalCoefficient((x, t) -> cos(2π t)·exp(−‖x‖²)) active on [0, 1]; ElementAssemblyStrategy on the device against
+    the sequential CPU operator at t = 0 (`Vector(cuda_op.b) ≈ linop.b`)."""
+    g, dh, sp, om = quad_problem(tb, oracle, (287, 1), (-1.0, -1.0), (1.0, 1.0))
+    assert g.n_cells == 287 and dh.ndofs == 288 * 2
+    ref = oracle.assemble_source(om, oracle.SRC_COS_EXP, t=0.0)
+    assert np.abs(ref).max() > 1e-3
+    linint = tb.LinearIntegrator(tb.AnalyticalCoefficient("cos_exp"), nonzero_intervals=[(0.0, 1.0)])
+    for st in strategies(tb, device, matrix=False):
+        op = tb.setup_operator(st, linint, dh)
+        assert tb.needs_update(op, 0.0)
+        tb.update_operator(op, 0.0)
+        assert rel_err(op.b.to_host(), ref) < TOL, type(st).__name__
+    # quadrilateral matrices (2-D tensor in the upper-left block) against the oracle's 2-D elements
+    kap = np.array([[4.5e-5, 0.0], [0.0, 2.0e-5]])
+    for st in strategies(tb, device):
+        K = tb.update_operator(tb.setup_operator(st, tb.BilinearDiffusionIntegrator(tb.ConstantCoefficient(kap)), dh, sp), 0.0)
+        assert rel_err(K.A.to_host(), oracle.assemble_matrix(om, 1, oracle.Coef(oracle.COEF_CONST_TENSOR, kap.ravel()), sp.rowptr, sp.colidx)) < TOL
+        M = tb.update_operator(tb.setup_operator(st, tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.0)), dh, sp), 0.0)
+        assert rel_err(M.A.to_host(), oracle.assemble_matrix(om, 0, oracle.Coef(oracle.COEF_CONST_SCALAR, [1.0]), sp.rowptr, sp.colidx)) < TOL
+
+
+def test_reference_gpu_diffusion_pattern(tb, oracle, device):
+    """test/gpu/diffusion-test.jl: TransientDiffusionModel with κ = diag(4.5e-5, 2e-5) on generate_mesh(Quadrilateral, (2⁷, 2⁷),
+    (0,0), (2.5,2.5)), random u₀, BackwardEulerSolver with Δt₀ = 0.1 over tspan (0, 10) — the device integrator must end where
+    the CPU one does (`Vector(gpuintegrator.u) ≈ cpuintegrator.u`) and move away from u₀.  CPU side: oracle operators + sparse LU."""
+    import scipy.sparse as sps
+    import scipy.sparse.linalg as spla
+    n = 2 ** 7
+    g, dh, sp, om = quad_problem(tb, oracle, (n, n), (0.0, 0.0), (2.5, 2.5))
+    kap = np.array([[4.5e-5, 0.0], [0.0, 2.0e-5]])
+    heat = tb.BackwardEulerStage(tb.BackwardEulerSolver(rtol=1e-13, atol=1e-15), tb.PatchAssemblyStrategy(device), dh, tb.ConstantCoefficient(kap), None, sp)
+    rng = np.random.default_rng(0)
+    u0 = rng.random(dh.ndofs)
+    u = device.to_device(u0)
+    dt, nsteps = 0.1, 100
+    for s in range(nsteps):
+        assert heat.perform_step(u, s * dt, dt)
+    Mh = oracle.assemble_matrix(om, 0, oracle.Coef(oracle.COEF_CONST_SCALAR, [1.0]), sp.rowptr, sp.colidx)
+    Kh = oracle.assemble_matrix(om, 1, oracle.Coef(oracle.COEF_CONST_TENSOR, kap.ravel()), sp.rowptr, sp.colidx)
+    nd = dh.ndofs
+    A = sps.csr_matrix((oracle.heat_matrix(Mh, Kh, dt), sp.colidx, sp.rowptr), shape=(nd, nd)).tocsc()
+    Mm = sps.csr_matrix((Mh, sp.colidx, sp.rowptr), shape=(nd, nd))
+    lu = spla.splu(A)
+    ref = u0.copy()
+    for s in range(nsteps):
+        ref = lu.solve(Mm @ ref)
+    got = u.to_host()
+    assert not np.allclose(got, u0)
+    np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-12)
+
+
+def test_reference_gpu_ensemble_pattern(tb, oracle, device):
+    """test/gpu/ensemble-test.jl: a 256-point FitzHugh–Nagumo ensemble advanced 100 forward-Euler steps on the device equals the
+    CPU ensemble."""
+    model = tb.FHNModel()
+    n = 256
+    rng = np.random.default_rng(1)
+    host = np.ascontiguousarray((np.tile(model.default_initial_state(), (n, 1)) + rng.uniform(0, 1, (n, 2))).T).ravel().copy()
+    f = tb.PointwiseODEFunction(n, model)
+    cache = tb.setup_solver_cache(f, tb.ForwardEulerCellSolver(device), u=device.to_device(host))
+    ref = host.copy()
+    for s in range(100):
+        assert tb.perform_step(f, cache, 0.1 * s, 0.1) is True
+        oracle.reaction_step(oracle.CELL_FHN, model.params, ref, n, oracle.LAYOUT_SOA, t=0.1 * s, dt=0.1)
+    assert rel_err(cache.un.to_host(), ref) < 1e-11

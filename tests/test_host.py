@@ -128,3 +128,30 @@ def test_reaction_tangent_controller_stepsize_known_answers(tb):
     rs = np.linspace(-2, 5, 50)
     dts = [rtc.stepsize(r) for r in rs]
     assert all(a >= b for a, b in zip(dts, dts[1:]))
+
+
+def test_quadrilateral_grid_conventions(tb, oracle):
+    """generate_grid(Quadrilateral, (nx, ny), left, right): nodes x-fastest on the lattice, counter-clockwise cells, z = 0;
+    first-visit dof numbering and the sparsity graph equal the oracle's on the same connectivity."""
+    g = tb.generate_mesh(tb.Quadrilateral, (3, 2), (-1.0, -1.0), (1.0, 1.0))
+    assert g.xyz.shape == (12, 3) and g.conn.shape == (6, 4) and np.all(g.xyz[:, 2] == 0)
+    np.testing.assert_array_equal(g.conn[0], [0, 1, 5, 4])
+    np.testing.assert_allclose(g.xyz[5], [-1 + 2 / 3, 0.0, 0.0])
+    x = g.xyz[g.conn]                                           # positive orientation everywhere
+    a, b = x[:, 1, :2] - x[:, 0, :2], x[:, 3, :2] - x[:, 0, :2]
+    area2 = a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0]
+    assert np.all(area2 > 0)
+    dh = tb.DofHandler(g)
+    cd, nd = oracle.close_dofs(oracle.QUAD4, 1, g.conn, g.n_nodes)
+    np.testing.assert_array_equal(dh.cell_dofs, cd)
+    assert dh.ndofs == nd == 12
+    sp = tb.allocate_matrix(dh)
+    rp, ci = oracle.build_pattern(cd, nd)
+    np.testing.assert_array_equal(sp.rowptr, rp)
+    np.testing.assert_array_equal(sp.colidx, ci)
+    # the oracle's 2-D element on this mesh: Σ M = area, K·1 = 0
+    om = oracle.Mesh(oracle.QUAD4, 2, np.ascontiguousarray(g.xyz[:, :2]), g.conn, cd)
+    M = oracle.assemble_matrix(om, 0, oracle.Coef(oracle.COEF_CONST_SCALAR, [1.0]), rp, ci)
+    assert M.sum() == pytest.approx(4.0, rel=1e-14)
+    K = oracle.assemble_matrix(om, 1, oracle.Coef(oracle.COEF_CONST_TENSOR, [2.0, 0.3, 0.3, 1.0]), rp, ci)
+    assert np.abs(oracle.spmv_csr(rp, ci, K, np.ones(nd))).max() < 1e-14

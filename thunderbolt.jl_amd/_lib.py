@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "libtbhip.so")
 # enums of include/tbhip.h
 TB_OK = 0
 TB_ERR_BAD_ARG, TB_ERR_HIP, TB_ERR_NEG_DETJ, TB_ERR_PATTERN, TB_ERR_UNSUPPORTED, TB_ERR_NOMEM = -1, -2, -3, -4, -5, -6
-TB_HEX8, TB_TET4, TB_HEX27 = 3, 4, 5
+TB_QUAD4, TB_HEX8, TB_TET4, TB_HEX27 = 2, 3, 4, 5
 TB_STRATEGY_ATOMIC, TB_STRATEGY_PER_COLOR, TB_STRATEGY_ELEMENT, TB_STRATEGY_PATCH = 0, 1, 2, 3
 TB_FORM_MASS, TB_FORM_DIFFUSION, TB_FORM_SOURCE, TB_FORM_HYPERELASTIC = 0, 1, 2, 3
 TB_MATERIAL_HOLZAPFEL_OGDEN_2009 = 0
@@ -94,6 +94,7 @@ SIGNATURES = {
     "tb_meandiag": (C.c_int, [vp, vp, C.POINTER(C.c_double)]),
     "tb_max": (C.c_int, [vp, C.c_int64, vp, C.c_int64, C.POINTER(C.c_double)]),
     "tb_host_generate_grid_hex": (C.c_int, [C.c_int, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_i32p]),
+    "tb_host_generate_grid_quad": (C.c_int, [C.c_int, C.c_int, c_dp, c_dp, c_dp, c_i32p]),
     "tb_host_perturb_nodes": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, c_dp]),
     "tb_host_close_dofs": (C.c_int64, [C.c_int, C.c_int, C.c_int64, C.c_int64, c_i32p, c_i32p]),
     "tb_host_build_pattern": (C.c_int64, [C.c_int64, C.c_int, c_i32p, C.c_int64, c_i64p, c_i32p]),

@@ -188,7 +188,7 @@ class PatchAssemblyStrategy(_Strategy):
 
 
 # --------------------------------------------------------------------------------------- mesh / dofs
-Hexahedron, Tetrahedron = L.TB_HEX8, L.TB_TET4
+Hexahedron, Tetrahedron, Quadrilateral = L.TB_HEX8, L.TB_TET4, L.TB_QUAD4
 
 
 class LagrangeCollection:
@@ -204,6 +204,9 @@ class LagrangeCollection:
 class Grid:
     def __init__(self, cell_kind, xyz, conn, dims=None):
         self.cell_kind = cell_kind
+        xyz = np.asarray(xyz, dtype=np.float64)
+        if xyz.ndim == 2 and xyz.shape[1] == 2:   # 2-D meshes travel with z = 0 (tbhip.h, TB_QUAD4)
+            xyz = np.hstack([xyz, np.zeros((len(xyz), 1))])
         self.xyz = np.ascontiguousarray(xyz, dtype=np.float64)
         self.conn = np.ascontiguousarray(conn, dtype=np.int32)
         self.dims = dims
@@ -230,9 +233,18 @@ class Grid:
 
 
 def generate_mesh(cell_kind, nel, left=(-1.0, -1.0, -1.0), right=(1.0, 1.0, 1.0), perturb=0.0):
-    """generate_mesh(Hexahedron, (nx,ny,nz), left, right) — Ferrite generate_grid conventions."""
+    """generate_mesh(Hexahedron, (nx,ny,nz), left, right) / generate_mesh(Quadrilateral, (nx,ny), left, right) — Ferrite
+    generate_grid conventions."""
+    if cell_kind == Quadrilateral:
+        nx, ny = nel
+        xyz = np.empty(((nx + 1) * (ny + 1), 3))
+        conn = np.empty((nx * ny, 4), dtype=np.int32)
+        le, ri = np.asarray(left, dtype=np.float64)[:2].copy(), np.asarray(right, dtype=np.float64)[:2].copy()
+        check(lib().tb_host_generate_grid_quad(nx, ny, le.ctypes.data_as(L.c_dp), ri.ctypes.data_as(L.c_dp),
+                                              xyz.ctypes.data_as(L.c_dp), conn.ctypes.data_as(L.c_i32p)))
+        return Grid(cell_kind, xyz, conn, dims=(nx, ny))
     if cell_kind != Hexahedron:
-        raise NotImplementedError("generate_mesh: only Hexahedron boxes are generated; pass your own Grid for others")
+        raise NotImplementedError("generate_mesh: Hexahedron boxes and Quadrilateral rectangles are generated; pass your own Grid for others")
     nx, ny, nz = nel
     nn = (nx + 1) * (ny + 1) * (nz + 1)
     xyz = np.empty((nn, 3))
@@ -255,9 +267,9 @@ class DofHandler:
             self.field_kind = L.TB_HEX8 if ip.order == 1 else L.TB_HEX27
         else:
             if ip.order != 1:
-                raise NotImplementedError("only first-order tetrahedra")
-            self.field_kind = L.TB_TET4
-        nb = {L.TB_HEX8: 8, L.TB_HEX27: 27, L.TB_TET4: 4}[self.field_kind]
+                raise NotImplementedError("only first-order tetrahedra / quadrilaterals")
+            self.field_kind = grid.cell_kind
+        nb = {L.TB_HEX8: 8, L.TB_HEX27: 27, L.TB_TET4: 4, L.TB_QUAD4: 4}[self.field_kind]
         self.ndofs_per_cell = nb * ip.ncomp
         if cell_dofs is None:  # close!(dh)
             cd = np.empty((grid.n_cells, self.ndofs_per_cell), dtype=np.int32)
@@ -413,6 +425,8 @@ def _lower_coef(coef, wrap=False, Cm=1.0, chi=1.0):
             c.kind = L.TB_COEF_CONST_SCALAR
             c.p[0] = float(v)
         else:
+            if v.shape == (2, 2):                   # 2-D tensor: upper-left block of the 3×3 the ABI carries
+                v = np.block([[v, np.zeros((2, 1))], [np.zeros((1, 2)), np.ones((1, 1))]])
             assert v.shape == (3, 3)
             c.kind = L.TB_COEF_CONST_TENSOR
             for i, x in enumerate(v.ravel()):

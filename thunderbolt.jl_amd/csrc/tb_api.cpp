@@ -209,7 +209,7 @@ int tb_mesh_create(tb_device *dev, int geom_kind, int64_t n_nodes, const double 
 {
     TB_REQUIRE(dev && out && xyz && conn && cell_dofs, "tb_mesh_create: NULL argument");
     *out = nullptr;
-    TB_REQUIRE(geom_kind == TB_HEX8 || geom_kind == TB_TET4, "tb_mesh_create: geometry kind %d (need TB_HEX8 or TB_TET4)", geom_kind);
+    TB_REQUIRE(geom_kind == TB_HEX8 || geom_kind == TB_TET4 || geom_kind == TB_QUAD4, "tb_mesh_create: geometry kind %d (need TB_QUAD4, TB_HEX8 or TB_TET4)", geom_kind);
     TB_REQUIRE(field_kind == geom_kind || (geom_kind == TB_HEX8 && field_kind == TB_HEX27),
                "tb_mesh_create: field kind %d does not live on geometry kind %d", field_kind, geom_kind);
     TB_REQUIRE(ncomp == 1 || ncomp == 3, "tb_mesh_create: ncomp must be 1 or 3 (got %d)", ncomp);

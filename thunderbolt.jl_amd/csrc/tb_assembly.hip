@@ -651,6 +651,7 @@ int launch_assemble_matrix(tb_form *f, tb_pattern *p, int strategy, double t, do
     if (rc) return rc;
     if (m->field_kind == TB_HEX8 && f->qorder == 2) rc = run_matrix_form<Hex8<2>>(f, p, strategy, t, d_nz);
     else if (m->field_kind == TB_TET4 && f->qorder == 2) rc = run_matrix_form<Tet4<2>>(f, p, strategy, t, d_nz);
+    else if (m->field_kind == TB_QUAD4 && f->qorder == 2) rc = run_matrix_form<Quad4<2>>(f, p, strategy, t, d_nz);
     else {
         set_error("matrix assembly: field kind %d with quadrature order %d not implemented", m->field_kind, f->qorder);
         return TB_ERR_UNSUPPORTED;
@@ -716,6 +717,7 @@ int launch_assemble_vector(tb_form *f, int strategy, double t, double *d_b)
     if (m->field_kind == TB_HEX8 && f->qorder == 2) rc = run_vector<Hex8<2>>(f, strategy, t, d_b);
     else if (m->field_kind == TB_HEX8 && f->qorder == 3) rc = run_vector<Hex8<3>>(f, strategy, t, d_b);
     else if (m->field_kind == TB_TET4 && f->qorder == 2) rc = run_vector<Tet4<2>>(f, strategy, t, d_b);
+    else if (m->field_kind == TB_QUAD4 && f->qorder == 2) rc = run_vector<Quad4<2>>(f, strategy, t, d_b);
     else {
         set_error("vector assembly: field kind %d with quadrature order %d not implemented", m->field_kind, f->qorder);
         return TB_ERR_UNSUPPORTED;

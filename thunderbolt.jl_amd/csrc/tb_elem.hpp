@@ -69,6 +69,29 @@ template <int ORDER> struct Tet4 {
     TB_HD static constexpr double dM(int q, int a, int d) { return dN(q, a, d); }
 };
 
+// bilinear quadrilateral in the plane z = 0, vertices (-,-),(+,-),(+,+),(-,+) (Ferrite RefQuadrilateral).  The element is
+// carried through the 3-D code with a trivial third reference direction: ∂x/∂ζ = e_z, ∂N/∂ζ = 0 — the Jacobian is
+// block-diagonal, detJ is the 2-D determinant and the third row / column of the coefficient tensor never contributes.
+template <int ORDER> struct Quad4 {
+    static constexpr int NV = 4, NB = 4, NQ = ORDER * ORDER;
+    TB_HD static constexpr int sgn(int a, int d)
+    {
+        constexpr int S[2][4] = {{-1, 1, 1, -1}, {-1, -1, 1, 1}};
+        return S[d][a];
+    }
+    TB_HD static constexpr int qi(int q, int d) { return d == 0 ? q % ORDER : q / ORDER; }
+    TB_HD static constexpr double xi(int q, int d) { return d < 2 ? Gauss<ORDER>::x(qi(q, d)) : 0.0; }
+    TB_HD static constexpr double w(int q) { return Gauss<ORDER>::w(qi(q, 0)) * Gauss<ORDER>::w(qi(q, 1)); }
+    TB_HD static constexpr double fac(int q, int a, int d) { return 1.0 + sgn(a, d) * xi(q, d); }
+    TB_HD static constexpr double N(int q, int a) { return 0.25 * fac(q, a, 0) * fac(q, a, 1); }
+    TB_HD static constexpr double dN(int q, int a, int d)
+    {
+        return d == 2 ? 0.0 : 0.25 * (d == 0 ? sgn(a, 0) : fac(q, a, 0)) * (d == 1 ? sgn(a, 1) : fac(q, a, 1));
+    }
+    TB_HD static constexpr double M(int q, int a) { return N(q, a); }
+    TB_HD static constexpr double dM(int q, int a, int d) { return dN(q, a, d); }
+};
+
 struct Geom {
     double dOmega;  // detJ · w
     double Jinv[3][3];
@@ -224,6 +247,37 @@ __device__ __forceinline__ void geo_position(const GeoCoeffs<Tet4<ORDER>> &g, co
 {
 #pragma unroll
     for (int i = 0; i < 3; ++i) xq[i] = g.c[0][i] + g.c[1][i] * tb.xi[q][0] + g.c[2][i] * tb.xi[q][1] + g.c[3][i] * tb.xi[q][2];
+}
+
+// Quadrilateral: x(ξ,η) = c0 + c1 ξ + c2 η + c3 ξη
+template <int ORDER>
+__device__ __forceinline__ void geo_prepare(const double (&x)[4][3], GeoCoeffs<Quad4<ORDER>> &g)
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double s0 = x[1][i] + x[0][i], d0 = x[1][i] - x[0][i]; // y = −
+        const double s1 = x[2][i] + x[3][i], d1 = x[2][i] - x[3][i]; // y = +
+        g.c[0][i] = 0.25 * (s1 + s0); g.c[2][i] = 0.25 * (s1 - s0);
+        g.c[1][i] = 0.25 * (d1 + d0); g.c[3][i] = 0.25 * (d1 - d0);
+    }
+}
+template <int ORDER>
+__device__ __forceinline__ void geo_jacobian(const GeoCoeffs<Quad4<ORDER>> &g, const Tables<Quad4<ORDER>> &tb, int q, double (&J)[3][3])
+{
+    const double xi = tb.xi[q][0], eta = tb.xi[q][1];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        J[i][0] = g.c[1][i] + g.c[3][i] * eta;
+        J[i][1] = g.c[2][i] + g.c[3][i] * xi;
+        J[i][2] = i == 2 ? 1.0 : 0.0;
+    }
+}
+template <int ORDER>
+__device__ __forceinline__ void geo_position(const GeoCoeffs<Quad4<ORDER>> &g, const Tables<Quad4<ORDER>> &tb, int q, double (&xq)[3])
+{
+    const double xi = tb.xi[q][0], eta = tb.xi[q][1];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xq[i] = g.c[0][i] + g.c[1][i] * xi + g.c[2][i] * eta + g.c[3][i] * (xi * eta);
 }
 
 // J, detJ·w, J⁻¹ at run-time quadrature point q (geometry interpolation == field interpolation, first-order cells)

@@ -83,10 +83,32 @@ int tb_host_perturb_nodes(int nx, int ny, int nz, double amplitude_rel, double *
     return TB_OK;
 }
 
+int tb_host_generate_grid_quad(int nx, int ny, const double *left, const double *right, double *xyz, int32_t *conn)
+{
+    if (!(nx > 0 && ny > 0 && left && right && xyz && conn)) { set_error("tb_host_generate_grid_quad: bad argument"); return TB_ERR_BAD_ARG; }
+    const int px = nx + 1, py = ny + 1;
+    // node lattice by corner interpolation like Ferrite's generate_grid (x fastest)
+    for (int j = 0; j < py; ++j)
+        for (int i = 0; i < px; ++i) {
+            const double tx = (double)i / nx, ty = (double)j / ny;
+            double *p = xyz + 3 * ((int64_t)j * px + i);
+            p[0] = left[0] + (right[0] - left[0]) * tx;
+            p[1] = left[1] + (right[1] - left[1]) * ty;
+            p[2] = 0.0;
+        }
+    for (int j = 0; j < ny; ++j)
+        for (int i = 0; i < nx; ++i) {
+            int32_t *c = conn + 4 * ((int64_t)j * nx + i);
+            const int32_t n0 = (int32_t)(j * px + i);
+            c[0] = n0; c[1] = n0 + 1; c[2] = n0 + 1 + px; c[3] = n0 + px;
+        }
+    return TB_OK;
+}
+
 int64_t tb_host_close_dofs(int field_kind, int ncomp, int64_t n_cells, int64_t n_nodes, const int32_t *conn, int32_t *cell_dofs)
 {
     if (!(conn && cell_dofs && n_cells >= 0 && n_nodes > 0 && ncomp >= 1) ||
-        !(field_kind == TB_HEX8 || field_kind == TB_TET4 || field_kind == TB_HEX27)) {
+        !(field_kind == TB_HEX8 || field_kind == TB_TET4 || field_kind == TB_HEX27 || field_kind == TB_QUAD4)) {
         set_error("tb_host_close_dofs: bad argument");
         return TB_ERR_BAD_ARG;
     }

@@ -39,8 +39,8 @@ struct Status {
     long long cell;      // one offending cell (0-based)
 };
 
-inline int kind_nverts(int kind) { return kind == TB_TET4 ? 4 : 8; }
-inline int kind_nbasis(int kind) { return kind == TB_TET4 ? 4 : kind == TB_HEX27 ? 27 : 8; }
+inline int kind_nverts(int kind) { return kind == TB_TET4 || kind == TB_QUAD4 ? 4 : 8; }
+inline int kind_nbasis(int kind) { return kind == TB_TET4 || kind == TB_QUAD4 ? 4 : kind == TB_HEX27 ? 27 : 8; }
 inline int kind_order(int kind) { return kind == TB_HEX27 ? 2 : 1; }
 
 // ---- assembly plans (built lazily on the host, cached on the mesh / pattern) ----
