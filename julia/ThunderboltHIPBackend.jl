@@ -72,11 +72,13 @@ end
 function DeviceMesh(dev::MI355XDevice, dh::DofHandler)
     grid = Ferrite.get_grid(dh)
     sdh = only(dh.subdofhandlers)                       # one subdomain, one field (SURVEY §8b)
-    xyz = reinterpret(Float64, [n.x for n in grid.nodes])         # AoS, 3 per node
+    sdim = Ferrite.getspatialdim(grid)
+    xyz = sdim == 3 ? collect(reinterpret(Float64, [n.x for n in grid.nodes])) :        # AoS, 3 per node
+          Float64[i <= 2 ? n.x[i] : 0.0 for n in grid.nodes for i in 1:3]               # 2-D meshes travel with z = 0 (TB_QUAD4)
     conn = Int32[v for c in grid.cells for v in c.nodes]          # 1-based
     ndpc = Ferrite.ndofs_per_cell(sdh)
     celldofs = Int32.(dh.cell_dofs)                               # dh.cell_dofs / cell_dofs_offset, src/utils.jl:52-56
-    kind = grid.cells[1] isa Hexahedron ? Cint(3) : Cint(4)       # TB_HEX8 / TB_TET4
+    kind = grid.cells[1] isa Quadrilateral ? Cint(2) : grid.cells[1] isa Hexahedron ? Cint(3) : Cint(4)   # TB_QUAD4 / TB_HEX8 / TB_TET4
     order = Ferrite.getorder(Ferrite.getfieldinterpolation(sdh, first(sdh.field_names)))
     fkind = (kind == 3 && order == 2) ? Cint(5) : kind            # TB_HEX27
     ncomp = Ferrite.n_components(Ferrite.getfieldinterpolation(sdh, first(sdh.field_names)))
