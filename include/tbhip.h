@@ -235,6 +235,12 @@ int tb_reaction_step(tb_device *dev, int model, const double *params, int n_para
 int tb_reaction_step_rtc(tb_device *dev, int model, const double *params, int n_params, double *d_u, double *d_du,
                          int64_t n_points, int n_states, int layout, double t, double dt, int substeps, double threshold,
                          double *rmax);
+/* Rush–Larsen step (SURVEY §8 f4 — the reference carries only the reaction_rhs!/state_rhs! hooks for it, src/modeling/cells/fhn.jl:36-60):
+ * Hodgkin–Huxley-type gates are advanced with the exact solution of their linear ODE for frozen φₘ, every other state by forward
+ * Euler.  Lifts the fast-gate stability limit of forward Euler (TT06: Δt = 0.02 ms in one evaluation instead of twenty sub-steps).
+ * TB_CELL_TT06 only; other models return TB_ERR_UNSUPPORTED. */
+int tb_reaction_step_rl(tb_device *dev, int model, const double *params, int n_params, double *d_u, int64_t n_points, int n_states,
+                        int layout, double t, double dt);
 int tb_cell_model_info(int model, int *n_states, int *n_params, int *phi_index);
 int tb_cell_model_defaults(int model, double *params, double *u0);
 

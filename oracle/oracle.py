@@ -271,6 +271,14 @@ def reaction_step(model, p, u, npoints, layout=LAYOUT_SOA, t=0.0, dt=1.0, subste
     return du
 
 
+def reaction_step_rl(model, p, u, npoints, layout=LAYOUT_SOA, t=0.0, dt=1.0, nthreads=1):
+    """Rush–Larsen step, in place on `u` (TT06 only)."""
+    assert u.dtype == np.float64 and u.flags.c_contiguous
+    p = _f64(p)
+    rc = lib().orc_reaction_step_rl(model, _d(p), _d(u), C.c_int64(npoints), layout, C.c_double(t), C.c_double(dt), nthreads)
+    assert rc == 0, rc
+
+
 # ---------------------------------------------------------------- heat-step algebra
 def heat_matrix(Mnz, Knz, dt):
     A = np.zeros_like(Mnz)

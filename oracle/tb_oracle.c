@@ -817,8 +817,12 @@ void orc_cell_default_state(int model, const double *p, double *u0)
 /* ten Tusscher & Panfilov 2006 (Am J Physiol 291:H1088), epicardial parameter set, ODE form of the published
  * equations; states (V, Ca_i, Ca_SR, Ca_ss, Na_i, K_i, m, h, j, xr1, xr2, xs, r, s, d, f, f2, fCass, R̄).
  * EXTENSION: the reference has no TT06 — parity unpinned, checked GPU-vs-this only. */
-static void tt06_rhs(const double *p, const double *u, double *du)
+/* rate: NULL, or 19 slots receiving 1/τ of the Hodgkin–Huxley-type gates (0 for the other states) — for the Rush–Larsen step */
+static void tt06_rhs_rates(const double *p, const double *u, double *du, double *rate)
 {
+    double rloc[19];
+    if (!rate) rate = rloc;
+    for (int k = 0; k < 19; ++k) rate[k] = 0.0;
     const double GNa = p[0], GK1 = p[1], GKr = p[2], GKs = p[3], Gto = p[4], GCaL = p[5], GbNa = p[6], GbCa = p[7], GpCa = p[8],
                  GpK = p[9], knak = p[10], knaca = p[11], Ko = p[12], Cao = p[13], Nao = p[14], Vc = p[15], Vsr = p[16], Vss = p[17],
                  Bufc = p[18], Kbufc = p[19], Bufsr = p[20], Kbufsr = p[21], Bufss = p[22], Kbufss = p[23], Vmaxup = p[24], Kup = p[25],
@@ -869,6 +873,7 @@ static void tt06_rhs(const double *p, const double *u, double *du)
     const double AM = 1.0 / (1.0 + exp((-60.0 - V) / 5.0));
     const double BM = 0.1 / (1.0 + exp((V + 35.0) / 5.0)) + 0.1 / (1.0 + exp((V - 50.0) / 200.0));
     const double mrt = 1.0 + exp((-56.86 - V) / 9.03);
+    rate[6] = 1.0 / (AM * BM);
     du[6] = (1.0 / (mrt * mrt) - m) / (AM * BM);
     const double hrt = 1.0 + exp((V + 71.55) / 7.43);
     const double hinf = 1.0 / (hrt * hrt);
@@ -881,22 +886,41 @@ static void tt06_rhs(const double *p, const double *u, double *du)
         AJ = ((-2.5428e4) * exp(0.2444 * V) - 6.948e-6 * exp(-0.04391 * V)) * (V + 37.78) / (1.0 + exp(0.311 * (V + 79.23)));
         BJ = 0.02424 * exp(-0.01052 * V) / (1.0 + exp(-0.1378 * (V + 40.14)));
     }
+    rate[7] = AH + BH;
     du[7] = (hinf - h) * (AH + BH);
+    rate[8] = AJ + BJ;
     du[8] = (hinf - j) * (AJ + BJ);
-    du[9] = (1.0 / (1.0 + exp((-26.0 - V) / 7.0)) - xr1) / ((450.0 / (1.0 + exp((-45.0 - V) / 10.0))) * (6.0 / (1.0 + exp((V + 30.0) / 11.5))));
-    du[10] = (1.0 / (1.0 + exp((V + 88.0) / 24.0)) - xr2) / ((3.0 / (1.0 + exp((-60.0 - V) / 20.0))) * (1.12 / (1.0 + exp((V - 60.0) / 20.0))));
-    du[11] = (1.0 / (1.0 + exp((-5.0 - V) / 14.0)) - xs) / ((1400.0 / sqrt(1.0 + exp((5.0 - V) / 6.0))) * (1.0 / (1.0 + exp((V - 35.0) / 15.0))) + 80.0);
-    du[12] = (1.0 / (1.0 + exp((20.0 - V) / 6.0)) - r) / (9.5 * exp(-(V + 40.0) * (V + 40.0) / 1800.0) + 0.8);
-    du[13] = (1.0 / (1.0 + exp((V + 20.0) / 5.0)) - s) / (85.0 * exp(-(V + 45.0) * (V + 45.0) / 320.0) + 5.0 / (1.0 + exp((V - 20.0) / 5.0)) + 3.0);
-    du[14] = (1.0 / (1.0 + exp((-8.0 - V) / 7.5)) - d) /
-             ((1.4 / (1.0 + exp((-35.0 - V) / 13.0)) + 0.25) * (1.4 / (1.0 + exp((V + 5.0) / 5.0))) + 1.0 / (1.0 + exp((50.0 - V) / 20.0)));
-    du[15] = (1.0 / (1.0 + exp((V + 20.0) / 7.0)) - f) /
-             (1102.5 * exp(-(V + 27.0) * (V + 27.0) / 225.0) + 200.0 / (1.0 + exp((13.0 - V) / 10.0)) + 180.0 / (1.0 + exp((V + 30.0) / 10.0)) + 20.0);
-    du[16] = (0.67 / (1.0 + exp((V + 35.0) / 7.0)) + 0.33 - f2) /
-             (600.0 * exp(-(V + 25.0) * (V + 25.0) / 170.0) + 31.0 / (1.0 + exp((25.0 - V) / 10.0)) + 16.0 / (1.0 + exp((V + 30.0) / 10.0)));
+    { const double tau_ = (450.0 / (1.0 + exp((-45.0 - V) / 10.0))) * (6.0 / (1.0 + exp((V + 30.0) / 11.5)));
+      rate[9] = 1.0 / tau_;
+      du[9] = (1.0 / (1.0 + exp((-26.0 - V) / 7.0)) - xr1) / tau_; }
+    { const double tau_ = (3.0 / (1.0 + exp((-60.0 - V) / 20.0))) * (1.12 / (1.0 + exp((V - 60.0) / 20.0)));
+      rate[10] = 1.0 / tau_;
+      du[10] = (1.0 / (1.0 + exp((V + 88.0) / 24.0)) - xr2) / tau_; }
+    { const double tau_ = (1400.0 / sqrt(1.0 + exp((5.0 - V) / 6.0))) * (1.0 / (1.0 + exp((V - 35.0) / 15.0))) + 80.0;
+      rate[11] = 1.0 / tau_;
+      du[11] = (1.0 / (1.0 + exp((-5.0 - V) / 14.0)) - xs) / tau_; }
+    { const double tau_ = 9.5 * exp(-(V + 40.0) * (V + 40.0) / 1800.0) + 0.8;
+      rate[12] = 1.0 / tau_;
+      du[12] = (1.0 / (1.0 + exp((20.0 - V) / 6.0)) - r) / tau_; }
+    { const double tau_ = 85.0 * exp(-(V + 45.0) * (V + 45.0) / 320.0) + 5.0 / (1.0 + exp((V - 20.0) / 5.0)) + 3.0;
+      rate[13] = 1.0 / tau_;
+      du[13] = (1.0 / (1.0 + exp((V + 20.0) / 5.0)) - s) / tau_; }
+    { const double tau_ = (1.4 / (1.0 + exp((-35.0 - V) / 13.0)) + 0.25) * (1.4 / (1.0 + exp((V + 5.0) / 5.0))) + 1.0 / (1.0 + exp((50.0 - V) / 20.0));
+      rate[14] = 1.0 / tau_;
+      du[14] = (1.0 / (1.0 + exp((-8.0 - V) / 7.5)) - d) / tau_; }
+    { const double tau_ = 1102.5 * exp(-(V + 27.0) * (V + 27.0) / 225.0) + 200.0 / (1.0 + exp((13.0 - V) / 10.0)) + 180.0 / (1.0 + exp((V + 30.0) / 10.0)) + 20.0;
+      rate[15] = 1.0 / tau_;
+      du[15] = (1.0 / (1.0 + exp((V + 20.0) / 7.0)) - f) / tau_; }
+    { const double tau_ = 600.0 * exp(-(V + 25.0) * (V + 25.0) / 170.0) + 31.0 / (1.0 + exp((25.0 - V) / 10.0)) + 16.0 / (1.0 + exp((V + 30.0) / 10.0));
+      rate[16] = 1.0 / tau_;
+      du[16] = (0.67 / (1.0 + exp((V + 35.0) / 7.0)) + 0.33 - f2) / tau_; }
     const double cq = 1.0 + (CaSS / 0.05) * (CaSS / 0.05);
-    du[17] = (0.6 / cq + 0.4 - fCass) / (80.0 / cq + 2.0);
+    { const double tau_ = 80.0 / cq + 2.0;
+      rate[17] = 1.0 / tau_;
+      du[17] = (0.6 / cq + 0.4 - fCass) / tau_; }
 }
+
+static void tt06_rhs(const double *p, const double *u, double *du) { tt06_rhs_rates(p, u, du, NULL); }
 
 void orc_cell_rhs(int model, const double *p, const double *u, double t, double *du)
 {
@@ -989,6 +1013,30 @@ int orc_reaction_step(int model, const double *p, double *u, double *du, int64_t
             int64_t k = layout == ORC_LAYOUT_SOA ? i + j * npoints : i * ns + j;
             u[k] = ul[j];
             if (du) du[k] = dul[j];
+        }
+    }
+    return 0;
+}
+
+/* Rush–Larsen step (the reference only has the reaction_rhs!/state_rhs! hooks, cells/fhn.jl:36-60): gates by
+ * the exact solution of their linear ODE for frozen V, y ← y + du·(1 − e^{−Δt·rate})/rate; other states forward Euler.
+ * TT06 only (returns −2 otherwise). */
+int orc_reaction_step_rl(int model, const double *p, double *u, int64_t npoints, int layout, double t, double dt, int nthreads)
+{
+    (void)t;
+    if (model != ORC_CELL_TT06) return -2;
+    const int ns = 19;
+#ifdef _OPENMP
+    if (nthreads > 1) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(static) if (nthreads > 1)
+    for (int64_t i = 0; i < npoints; ++i) {
+        double ul[19], dul[19], rate[19];
+        for (int j = 0; j < ns; ++j) ul[j] = layout == ORC_LAYOUT_SOA ? u[i + j * npoints] : u[i * ns + j];
+        tt06_rhs_rates(p, ul, dul, rate);
+        for (int j = 0; j < ns; ++j) {
+            const double h = rate[j] != 0.0 ? -expm1(-dt * rate[j]) / rate[j] : dt;
+            u[layout == ORC_LAYOUT_SOA ? i + j * npoints : i * ns + j] = ul[j] + h * dul[j];
         }
     }
     return 0;

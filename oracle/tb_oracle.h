@@ -133,6 +133,8 @@ void orc_cell_rhs(int model, const double *p, const double *u, double t, double 
 int orc_reaction_step(int model, const double *p, double *u, double *du, int64_t npoints, int layout,
                       double t, double dt, int substeps, double threshold, int nthreads);
 
+int orc_reaction_step_rl(int model, const double *p, double *u, int64_t npoints, int layout, double t, double dt, int nthreads);
+
 /* ---- heat-step algebra ---- */
 /* euler.jl:110-116 */
 void orc_heat_matrix(int64_t nnz, const double *Mnz, const double *Knz, double dt, double *Anz);

@@ -824,3 +824,42 @@ def test_reference_gpu_ensemble_pattern(tb, oracle, device):
         assert tb.perform_step(f, cache, 0.1 * s, 0.1) is True
         oracle.reaction_step(oracle.CELL_FHN, model.params, ref, n, oracle.LAYOUT_SOA, t=0.1 * s, dt=0.1)
     assert rel_err(cache.un.to_host(), ref) < 1e-11
+
+
+@pytest.mark.parametrize("layout", ["SOA", "AOS"])
+def test_rush_larsen_tt06(tb, oracle, device, layout):
+    """Rush–Larsen step for TT06 (extension): device vs oracle over 50 steps at Δt = 0.02 ms, and agreement with a
+    finely sub-stepped forward-Euler trajectory: the error is small and halves with Δt (first order), while plain forward Euler is
+    unstable at this Δt."""
+    model = tb.TT06()
+    n = 512 + 19
+    rng = np.random.default_rng(5)
+    pts = initial_points(tb, model, n, rng)
+    host = (np.ascontiguousarray(pts.T) if layout == "SOA" else pts).ravel().copy()
+    lay = tb.StateBlockedLayout() if layout == "SOA" else tb.PointBlockedLayout()
+    f = tb.PointwiseODEFunction(n, model, layout=lay)
+    cache = tb.setup_solver_cache(f, tb.RushLarsenCellSolver(device), u=device.to_device(host), keep_du=False)
+    ref = host.copy()
+    dt = 0.02
+    for s in range(50):
+        assert tb.perform_step(f, cache, s * dt, dt) is True
+        oracle.reaction_step_rl(oracle.CELL_TT06, model.params, ref, n, getattr(oracle, "LAYOUT_" + layout), t=s * dt, dt=dt)
+    got = cache.un.to_host()
+    assert np.isfinite(got).all()
+    assert rel_err(got, ref) < 1e-11
+    # fine forward Euler (Δt = 0.0005, 40 sub-steps per step) from the same start
+    fe = host.copy()
+    for s in range(50):
+        oracle.reaction_step(oracle.CELL_TT06, model.params, fe, n, getattr(oracle, "LAYOUT_" + layout), t=s * dt, dt=dt, substeps=40, threshold=0.0,
+                             want_du=False)
+    V = lambda a: a.reshape(19, n)[0] if layout == "SOA" else a.reshape(n, 19)[:, 0]  # noqa: E731
+    half = host.copy()                                            # same scheme at Δt/2 (oracle): the error halves — first order
+    for s in range(100):
+        oracle.reaction_step_rl(oracle.CELL_TT06, model.params, half, n, getattr(oracle, "LAYOUT_" + layout), t=s * dt / 2, dt=dt / 2)
+    e1, e2 = np.median(np.abs(V(got) - V(fe))), np.median(np.abs(V(half) - V(fe)))
+    assert e1 < 2.0 and 1.6 < e1 / e2 < 2.6, (e1, e2)            # mV; points near threshold differ most, hence the median
+    # models without gates are refused
+    fh = tb.PointwiseODEFunction(4, tb.FHNModel())
+    with pytest.raises(tb.TBError) as e:
+        tb.perform_step(fh, tb.setup_solver_cache(fh, tb.RushLarsenCellSolver(device), u=device.zeros(8), keep_du=False), 0.0, 0.1)
+    assert e.value.code == tb._lib.TB_ERR_UNSUPPORTED

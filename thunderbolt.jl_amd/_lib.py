@@ -82,6 +82,7 @@ SIGNATURES = {
                                    C.c_double, C.c_int, C.c_double]),
     "tb_reaction_step_rtc": (C.c_int, [vp, C.c_int, c_dp, C.c_int, vp, vp, C.c_int64, C.c_int, C.c_int, C.c_double,
                                        C.c_double, C.c_int, C.c_double, c_dp]),
+    "tb_reaction_step_rl": (C.c_int, [vp, C.c_int, c_dp, C.c_int, vp, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double]),
     "tb_cell_model_info": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "tb_cell_model_defaults": (C.c_int, [C.c_int, c_dp, c_dp]),
     "tb_heat_matrix": (C.c_int, [vp, C.c_int64, vp, vp, C.c_double, vp]),

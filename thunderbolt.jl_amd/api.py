@@ -704,6 +704,16 @@ class AdaptiveForwardEulerSubstepper:
         self.batch_size_hint = batch_size_hint
 
 
+class RushLarsenCellSolver:
+    """Rush–Larsen stepper for gate-type ionic models (extension; the reference has the reaction_rhs! / state_rhs!
+    hooks only): gates exactly for frozen φₘ, the rest forward Euler."""
+
+    def __init__(self, device, batch_size_hint=32):
+        self.device, self.batch_size_hint = device, batch_size_hint
+        self.substeps, self.reaction_threshold = 1, 0.0
+        self.rush_larsen = True
+
+
 class PointwiseSolverCache:
     """ForwardEulerCellSolverCache / AdaptiveForwardEulerSubstepperCache (partitioned_solver.jl:63-77,178-194):
     `du` is materialised (dumat), `un` is advanced in place."""
@@ -722,6 +732,10 @@ def setup_solver_cache(f, solver, t0=0.0, u=None, keep_du=True):
 def pointwise_step_outer_kernel(f, t, dt, cache):
     """_pointwise_step_outer_kernel!(f, t, Δt, cache, ::DeviceVector) → Bool (partitioned_solver.jl:38-52)."""
     m = f.ode
+    if getattr(cache.solver, "rush_larsen", False):
+        check(lib().tb_reaction_step_rl(cache.solver.device.h, m.model_id, m.params.ctypes.data_as(L.c_dp), len(m.params),
+                                        _ptr(cache.un), f.npoints, m.nstates, f.layout.code, float(t), float(dt)))
+        return True
     check(lib().tb_reaction_step(cache.solver.device.h, m.model_id, m.params.ctypes.data_as(L.c_dp), len(m.params),
                                  _ptr(cache.un), _ptr(cache.du), f.npoints, m.nstates, f.layout.code, float(t),
                                  float(dt), int(cache.substeps), float(cache.reaction_threshold)))

@@ -630,6 +630,21 @@ int tb_reaction_step_rtc(tb_device *dev, int model, const double *params, int n_
     return reaction_step("tb_reaction_step_rtc", dev, model, params, n_params, d_u, d_du, n_points, n_states, layout, t, dt, substeps, threshold, rmax);
 }
 
+int tb_reaction_step_rl(tb_device *dev, int model, const double *params, int n_params, double *d_u, int64_t n_points, int n_states,
+                        int layout, double t, double dt)
+{
+    TB_REQUIRE(dev && params && (d_u || n_points == 0), "tb_reaction_step_rl: NULL argument");
+    int ns, np;
+    int rc = tb_cell_model_info(model, &ns, &np, nullptr);
+    if (rc) return rc;
+    TB_REQUIRE(n_states == ns && n_params == np, "tb_reaction_step_rl: model has %d states / %d parameters, caller says %d / %d", ns, np, n_states, n_params);
+    TB_REQUIRE(layout == TB_LAYOUT_SOA || layout == TB_LAYOUT_AOS, "tb_reaction_step_rl: unknown layout %d", layout);
+    TB_REQUIRE(n_points >= 0, "tb_reaction_step_rl: negative point count");
+    if (n_points == 0) return model == TB_CELL_TT06 ? TB_OK : launch_reaction_rl(dev, model, params, n_params, d_u, 0, layout, t, dt);
+    TB_HIP(hipSetDevice(dev->id));
+    return launch_reaction_rl(dev, model, params, n_params, d_u, n_points, layout, t, dt);
+}
+
 // ------------------------------------------------------------------ algebra
 int tb_heat_matrix(tb_device *dev, int64_t nnz, const double *d_Mnz, const double *d_Knz, double dt, double *d_Anz)
 {

@@ -53,6 +53,7 @@ template <int MODEL> struct CellModel;
 
 template <> struct CellModel<TB_CELL_FHN> {
     static constexpr int NS = 2, PHI = 0;
+    static constexpr bool HAS_GATES = false;
     __device__ __forceinline__ static void rhs(const CellParams &P, const double (&u)[NS], double, double (&du)[NS])
     {
         const double a = P.p[0], b = P.p[1], c = P.p[2], d = P.p[3], e = P.p[4], f = P.p[5];
@@ -63,7 +64,8 @@ template <> struct CellModel<TB_CELL_FHN> {
 };
 
 template <> struct CellModel<TB_CELL_ALIEV_PANFILOV> {
-    static constexpr int NS = 2, PHI = 1; // state order (s, φₘ)
+    static constexpr int NS = 2, PHI = 1;
+    static constexpr bool HAS_GATES = false; // state order (s, φₘ)
     __device__ __forceinline__ static void rhs(const CellParams &P, const double (&u)[NS], double, double (&du)[NS])
     {
         const double ct = P.p[0], k = P.p[1], a = P.p[2], e0 = P.p[3], mu1 = P.p[4], mu2 = P.p[5];
@@ -76,6 +78,7 @@ template <> struct CellModel<TB_CELL_ALIEV_PANFILOV> {
 
 template <> struct CellModel<TB_CELL_PCG2019> {
     static constexpr int NS = 7, PHI = 0;
+    static constexpr bool HAS_GATES = false;
     // parameter slots follow the struct field order of pcg2019.jl:4-48
     enum { gNa, Em, km, taum, Eh, kh, dh, tauh0, gK1, Ez, kz, gto, Er, kr, Es, ks, taus, gCaL, Ed, kd, Ef, kf, tauf,
            gKr, Exr, kxr, tauxr, Ey, ky, gKs, Exs, kxs, tauxs, ENa, EK, ECa };
@@ -124,8 +127,18 @@ template <> struct CellModel<TB_CELL_TT06> {
     // for the same reason (an IEEE FP64 division is ≈15 instructions).  Rounding differs from the literal form by a few ulp
     // (parity tolerance 1e-12).
     __device__ __forceinline__ static double sgm(double e) { return rcp_b(1.0 + e); } // 1/(1+e), e = exp_b(x) given
-    __device__ __forceinline__ static void rhs(const CellParams &P, const double (&u)[NS], double, double (&du)[NS])
+    static constexpr bool HAS_GATES = true;
+    // rate[k] = 1/τ_k for the Hodgkin–Huxley-type gates (dy/dt = (y∞ − y)/τ, y∞ and τ functions of V / Ca only), 0 otherwise:
+    // what a Rush–Larsen step needs besides du (see k_reaction_rl)
+    __device__ __forceinline__ static void rhs(const CellParams &P, const double (&u)[NS], double t, double (&du)[NS])
     {
+        double rate[NS];
+        rhs_rates(P, u, t, du, rate);
+    }
+    __device__ __forceinline__ static void rhs_rates(const CellParams &P, const double (&u)[NS], double, double (&du)[NS], double (&rate)[NS])
+    {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) rate[k] = 0.0;
         const double *p = P.p;
         const double GNa = p[0], GK1 = p[1], GKr = p[2], GKs = p[3], Gto = p[4], GCaL = p[5], GbNa = p[6], GbCa = p[7], GpCa = p[8],
                      GpK = p[9], knak = p[10], knaca = p[11], Ko = p[12], Cao = p[13], Nao = p[14], Vc = p[15], Vsr = p[16], Vss = p[17],
@@ -186,7 +199,8 @@ template <> struct CellModel<TB_CELL_TT06> {
         const double AM = sgm(q5 * 6.14421235332821e-06 /* exp_b(-60.0 * (1.0 / 5.0)) */);
         const double BM = 0.1 * sgm(p5 * 1096.6331584284585 /* exp_b(35.0 * (1.0 / 5.0)) */) + 0.1 * sgm(exp_b((V - 50.0) * (1.0 / 200.0)));
         const double mr = sgm(exp_b((-56.86 - V) * (1.0 / 9.03)));
-        du[6] = (mr * mr - m) * rcp_b(AM * BM);
+        rate[6] = rcp_b(AM * BM);
+        du[6] = (mr * mr - m) * rate[6];
         const double hr = sgm(exp_b((V + 71.55) * (1.0 / 7.43)));
         const double hinf = hr * hr;
         double ABH, ABJ; // αh + βh, αj + βj
@@ -198,20 +212,29 @@ template <> struct CellModel<TB_CELL_TT06> {
             ABJ = ((-2.5428e4) * exp_b(0.2444 * V) - 6.948e-6 * exp_b(-0.04391 * V)) * (V + 37.78) * sgm(exp_b(0.311 * (V + 79.23))) +
                   0.02424 * exp_b(-0.01052 * V) * sgm(exp_b(-0.1378 * (V + 40.14)));
         }
+        rate[7] = ABH;
         du[7] = (hinf - h) * ABH;
+        rate[8] = ABJ;
         du[8] = (hinf - j) * ABJ;
-        du[9] = (sgm(q7 * 0.02437284407327961 /* exp_b(-26.0 * (1.0 / 7.0)) */) - xr1) * rcp_b((450.0 * sgm(q10 * 0.011108996538242306 /* exp_b(-4.5) */)) * (6.0 * sgm(exp_b((V + 30.0) * (1.0 / 11.5)))));
-        du[10] = (sgm(exp_b((V + 88.0) * (1.0 / 24.0))) - xr2) * rcp_b((3.0 * sgm(q20 * 0.049787068367863944 /* exp_b(-3.0) */)) * (1.12 * sgm(p20 * 0.049787068367863944 /* exp_b(-3.0) */)));
-        du[11] = (sgm(exp_b((-5.0 - V) * (1.0 / 14.0))) - xs) * rcp_b((1400.0 / sqrt(1.0 + q6 * 2.3009758908928246 /* exp_b(5.0 * (1.0 / 6.0)) */)) * sgm(exp_b((V - 35.0) * (1.0 / 15.0))) + 80.0);
-        du[12] = (sgm(q6 * 28.031624894526125 /* exp_b(20.0 * (1.0 / 6.0)) */) - r) * rcp_b(9.5 * exp_b(-(V + 40.0) * (V + 40.0) * (1.0 / 1800.0)) + 0.8);
-        du[13] = (sgm(p5 * 54.598150033144236 /* exp_b(4.0) */) - s) * rcp_b(85.0 * exp_b(-(V + 45.0) * (V + 45.0) * (1.0 / 320.0)) + 5.0 * sgm(p5 * 0.01831563888873418 /* exp_b(-4.0) */) + 3.0);
-        du[14] = (sgm(exp_b((-8.0 - V) * (1.0 / 7.5))) - d) * rcp_b((1.4 * sgm(exp_b((-35.0 - V) * (1.0 / 13.0))) + 0.25) * (1.4 * sgm(p5 * 2.718281828459045 /* exp_b(1.0) */)) + sgm(q20 * 12.182493960703473 /* exp_b(2.5) */));
-        du[15] = (sgm(p7 * 17.411708063327644 /* exp_b(20.0 * (1.0 / 7.0)) */) - f) *
-                 rcp_b((1102.5 * exp_b(-(V + 27.0) * (V + 27.0) * (1.0 / 225.0)) + 200.0 * sgm(q10 * 3.6692966676192444 /* exp_b(1.3) */) + 180.0 * sgm(p10 * 20.085536923187668 /* exp_b(3.0) */) + 20.0));
-        du[16] = (0.67 * sgm(p7 * 148.4131591025766 /* exp_b(5.0) */) + 0.33 - f2) *
-                 rcp_b((600.0 * exp_b(-(V + 25.0) * (V + 25.0) * (1.0 / 170.0)) + 31.0 * sgm(q10 * 12.182493960703473 /* exp_b(2.5) */) + 16.0 * sgm(p10 * 20.085536923187668 /* exp_b(3.0) */)));
+        rate[9] = rcp_b((450.0 * sgm(q10 * 0.011108996538242306 /* exp_b(-4.5) */)) * (6.0 * sgm(exp_b((V + 30.0) * (1.0 / 11.5)))));
+        du[9] = (sgm(q7 * 0.02437284407327961 /* exp_b(-26.0 * (1.0 / 7.0)) */) - xr1) * rate[9];
+        rate[10] = rcp_b((3.0 * sgm(q20 * 0.049787068367863944 /* exp_b(-3.0) */)) * (1.12 * sgm(p20 * 0.049787068367863944 /* exp_b(-3.0) */)));
+        du[10] = (sgm(exp_b((V + 88.0) * (1.0 / 24.0))) - xr2) * rate[10];
+        rate[11] = rcp_b((1400.0 / sqrt(1.0 + q6 * 2.3009758908928246 /* exp_b(5.0 * (1.0 / 6.0)) */)) * sgm(exp_b((V - 35.0) * (1.0 / 15.0))) + 80.0);
+        du[11] = (sgm(exp_b((-5.0 - V) * (1.0 / 14.0))) - xs) * rate[11];
+        rate[12] = rcp_b(9.5 * exp_b(-(V + 40.0) * (V + 40.0) * (1.0 / 1800.0)) + 0.8);
+        du[12] = (sgm(q6 * 28.031624894526125 /* exp_b(20.0 * (1.0 / 6.0)) */) - r) * rate[12];
+        rate[13] = rcp_b(85.0 * exp_b(-(V + 45.0) * (V + 45.0) * (1.0 / 320.0)) + 5.0 * sgm(p5 * 0.01831563888873418 /* exp_b(-4.0) */) + 3.0);
+        du[13] = (sgm(p5 * 54.598150033144236 /* exp_b(4.0) */) - s) * rate[13];
+        rate[14] = rcp_b((1.4 * sgm(exp_b((-35.0 - V) * (1.0 / 13.0))) + 0.25) * (1.4 * sgm(p5 * 2.718281828459045 /* exp_b(1.0) */)) + sgm(q20 * 12.182493960703473 /* exp_b(2.5) */));
+        du[14] = (sgm(exp_b((-8.0 - V) * (1.0 / 7.5))) - d) * rate[14];
+        rate[15] = rcp_b((1102.5 * exp_b(-(V + 27.0) * (V + 27.0) * (1.0 / 225.0)) + 200.0 * sgm(q10 * 3.6692966676192444 /* exp_b(1.3) */) + 180.0 * sgm(p10 * 20.085536923187668 /* exp_b(3.0) */) + 20.0));
+        du[15] = (sgm(p7 * 17.411708063327644 /* exp_b(20.0 * (1.0 / 7.0)) */) - f) * rate[15];
+        rate[16] = rcp_b((600.0 * exp_b(-(V + 25.0) * (V + 25.0) * (1.0 / 170.0)) + 31.0 * sgm(q10 * 12.182493960703473 /* exp_b(2.5) */) + 16.0 * sgm(p10 * 20.085536923187668 /* exp_b(3.0) */)));
+        du[16] = (0.67 * sgm(p7 * 148.4131591025766 /* exp_b(5.0) */) + 0.33 - f2) * rate[16];
         const double cq = 1.0 + (CaSS * (1.0 / 0.05)) * (CaSS * (1.0 / 0.05));
-        du[17] = (0.6 / cq + 0.4 - fCass) * rcp_b(80.0 / cq + 2.0);
+        rate[17] = rcp_b(80.0 / cq + 2.0);
+        du[17] = (0.6 / cq + 0.4 - fCass) * rate[17];
     }
 };
 
@@ -258,6 +281,61 @@ k_reaction(CellParams P, double *__restrict__ u, double *__restrict__ du_out, in
             atomicMax(rmax_key, (b >> 63) ? ~b : (b | 0x8000000000000000ull)); // order-preserving key, see tb_algebra.hip
         }
     }
+}
+
+// expm1 for the Rush–Larsen factor: series for small arguments (no cancellation), exp − 1 otherwise
+__device__ __forceinline__ double expm1_b(double z)
+{
+    if (fabs(z) < 0.3) {
+        double q = 1.6059043836821613e-10;
+        const double c[11] = {2.08767569878681e-09, 2.505210838544172e-08, 2.755731922398589e-07, 2.7557319223985893e-06, 2.48015873015873e-05,
+                              0.0001984126984126984, 0.001388888888888889, 0.008333333333333333, 0.041666666666666664, 0.16666666666666666, 0.5};
+#pragma unroll
+        for (int i = 0; i < 11; ++i) q = fma(q, z, c[i]);
+        q = fma(q, z, 1.0);
+        return q * z;
+    }
+    return exp_b(z) - 1.0;
+}
+
+// Rush–Larsen step (the splitting SURVEY §8 f4 names; the reference only carries the reaction_rhs!/state_rhs! hooks for it,
+// src/modeling/cells/fhn.jl:36-60): gates are advanced with the exact solution of their linear ODE for frozen V,
+//   y ← y∞ + (y − y∞) e^{−Δt/τ}  =  y + du · (1 − e^{−Δt·rate}) / rate,
+// every other state by forward Euler.  Removes the fast sodium gate's µs-scale stability limit: TT06 runs at Δt = 0.02 ms
+// in one evaluation instead of twenty forward-Euler sub-steps.
+template <int MODEL, int LAYOUT>
+__global__ void __launch_bounds__(256)
+k_reaction_rl(CellParams P, double *__restrict__ u, int64_t n, double t, double dt)
+{
+    using M = CellModel<MODEL>;
+    constexpr int NS = M::NS;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        double ul[NS], dul[NS], rate[NS];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) ul[j] = LAYOUT == TB_LAYOUT_SOA ? u[i + j * n] : u[i * NS + j];
+        M::rhs_rates(P, ul, t, dul, rate);
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const double h = rate[j] != 0.0 ? -expm1_b(-dt * rate[j]) * rcp_b(rate[j]) : dt;
+            const int64_t k = LAYOUT == TB_LAYOUT_SOA ? i + j * n : i * NS + j;
+            u[k] = ul[j] + h * dul[j];
+        }
+    }
+}
+
+int launch_reaction_rl(tb_device *dev, int model, const double *params, int n_params, double *d_u, int64_t n, int layout, double t, double dt)
+{
+    if (model != TB_CELL_TT06) { set_error("Rush–Larsen step: cell model %d has no gate decomposition (only TB_CELL_TT06)", model); return TB_ERR_UNSUPPORTED; }
+    CellParams P{};
+    for (int i = 0; i < n_params && i < 48; ++i) P.p[i] = params[i];
+    int64_t nb = (n + 255) / 256;
+    const int64_t cap = (int64_t)dev->n_cu * 16;
+    if (nb > cap) nb = cap;
+    if (layout == TB_LAYOUT_SOA) hipLaunchKernelGGL((k_reaction_rl<TB_CELL_TT06, TB_LAYOUT_SOA>), dim3((unsigned)nb), dim3(256), 0, dev->stream, P, d_u, n, t, dt);
+    else hipLaunchKernelGGL((k_reaction_rl<TB_CELL_TT06, TB_LAYOUT_AOS>), dim3((unsigned)nb), dim3(256), 0, dev->stream, P, d_u, n, t, dt);
+    TB_HIP(hipGetLastError());
+    return TB_OK;
 }
 
 template <int MODEL>
