@@ -863,3 +863,18 @@ def test_rush_larsen_tt06(tb, oracle, device, layout):
     with pytest.raises(tb.TBError) as e:
         tb.perform_step(fh, tb.setup_solver_cache(fh, tb.RushLarsenCellSolver(device), u=device.zeros(8), keep_du=False), 0.0, 0.1)
     assert e.value.code == tb._lib.TB_ERR_UNSUPPORTED
+
+
+def test_reference_backward_euler_on_a_steady_state(tb, device):
+    """test/test_time_integrator.jl:14-41: pure Neumann diffusion (κ = I) on generate_mesh(Quadrilateral, (4, 4), (0,0), (1,1)) without a
+    source — the constant state is a steady state, so u ≡ u₀ ≡ 1 for every t and Δt; BackwardEulerSolver() defaults, Δt = 0.1, tspan
+    (0, 1); `integrator.u ≈ u₀ atol = 1e-4` after one step and at the end."""
+    g = tb.generate_mesh(tb.Quadrilateral, (4, 4), (0.0, 0.0), (1.0, 1.0))
+    dh = tb.DofHandler(g)
+    heat = tb.BackwardEulerStage(tb.BackwardEulerSolver(), tb.PatchAssemblyStrategy(device), dh, tb.ConstantCoefficient(np.eye(2)))
+    u = device.to_device(np.ones(dh.ndofs))
+    assert heat.perform_step(u, 0.0, 0.1)
+    np.testing.assert_allclose(u.to_host(), 1.0, atol=1e-4)
+    for s in range(1, 10):
+        assert heat.perform_step(u, 0.1 * s, 0.1)
+    np.testing.assert_allclose(u.to_host(), 1.0, atol=1e-4)
