@@ -214,7 +214,11 @@ int tb_hyperelastic_set_active_tension(tb_form *form, double tension, const doub
  * facet (the reference uses the interpolation order, src/discretization/fem.jl:80-90; 0 selects that).
  * tb_facet_assemble ADDS to d_nzval / d_r (either may be NULL): the reference accumulates surface terms into the same
  * Kₑ / rₑ as the volume term (call it after tb_linearize / tb_residual).  Vector field on hexahedra only. */
-enum { TB_BC_ROBIN = 0, TB_BC_NORMAL_SPRING = 1, TB_BC_PRESSURE = 2 };
+enum { TB_BC_ROBIN = 0, TB_BC_NORMAL_SPRING = 1, TB_BC_PRESSURE = 2,
+       TB_BC_BENDING_SPRING = 3, /* BendingSpringBC: energy ½ kᵇ |F⁻ᵀN − N|² (:47-57, :301-415) */
+       TB_BC_PRESSURE_FIELD = 4  /* PressureFieldBC: p(x) = param · first-order nodal data per cell (tb_facet_form_set_field; NULL → param) */ };
+/* nodal data of a PressureFieldBC: n_cells×8 host values (per cell and geometry node), copied to the device */
+int tb_facet_form_set_field(tb_form *form, const double *field, int64_t len);
 int tb_facet_form_create(tb_mesh *mesh, int bc_kind, double param, int facet_qpoints, const int32_t *facets, int64_t n_facets,
                          int index_base, tb_form **out);
 int tb_facet_assemble(tb_form *form, tb_pattern *pat, const double *d_u, double t, double *d_nzval, double *d_r);

@@ -326,7 +326,16 @@ def element_hyperelastic(mesh, cell, ue, p=HO_DEFAULTS, fsn=np.eye(3), want_K=Tr
     return Ke, re
 
 
-BC_ROBIN, BC_NORMAL_SPRING, BC_PRESSURE = 0, 1, 2
+BC_ROBIN, BC_NORMAL_SPRING, BC_PRESSURE, BC_BENDING_SPRING, BC_PRESSURE_FIELD = 0, 1, 2, 3, 4
+_PF_KEEP = [None]
+
+
+def set_facet_pressure_field(field=None):
+    f = None if field is None else np.ascontiguousarray(field, dtype=np.float64)
+    _PF_KEEP[0] = f
+    lib().orc_set_facet_pressure_field.restype = None
+    lib().orc_set_facet_pressure_field(_d(f))
+
 
 _ACT_KEEP = [None]
 

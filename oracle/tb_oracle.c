@@ -1290,6 +1290,36 @@ static const double FACET_VAL[6] = {-1, -1, 1, 1, -1, 1};
 static const int FACET_S[6] = {1, 0, 1, 2, 2, 0};
 static const int FACET_T[6] = {0, 2, 2, 0, 1, 1};
 
+/* nodal pressure data of a PressureFieldBC (first-order, per cell and geometry node, n_cells×8); NULL → 1 (then p = param) */
+static const double *g_facet_pressure_field = NULL;
+void orc_set_facet_pressure_field(const double *field) { g_facet_pressure_field = field; }
+
+/* BendingSpringBC energy ½ kᵇ |F⁻ᵀN − N|² with first and second F-derivatives by the hyper-dual pass (the reference uses
+ * Tensors.hessian on exactly this expression, weak_boundary_conditions.jl:319-326) */
+static double bending_energy(double kb, const double *N, const double *F, double *P, double *A)
+{
+    hd Fd[3][3], cof[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Fd[i][j] = hd_var(F[3 * i + j], 3 * i + j);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) { /* cofactor C_ij */
+            const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+            cof[i][j] = hd_sub(hd_mul(Fd[i1][j1], Fd[i2][j2]), hd_mul(Fd[i1][j2], Fd[i2][j1]));
+        }
+    hd det = hd_add(hd_add(hd_mul(Fd[0][0], cof[0][0]), hd_mul(Fd[0][1], cof[0][1])), hd_mul(Fd[0][2], cof[0][2]));
+    hd idet = hd_inv(det);
+    hd psi = hd_const(0.0);
+    for (int a = 0; a < 3; ++a) { /* (F⁻ᵀN)_a = Σ_b F⁻¹_ba N_b = Σ_b cof_ab N_b / det */
+        hd va = hd_const(0.0);
+        for (int b = 0; b < 3; ++b) va = hd_add(va, hd_scale(cof[a][b], N[b]));
+        hd wa = hd_addc(hd_mul(va, idet), -N[a]);
+        psi = hd_add(psi, hd_mul(wa, wa));
+    }
+    psi = hd_scale(psi, 0.5 * kb);
+    for (int i = 0; i < 9; ++i) P[i] = psi.g[i];
+    if (A) for (int i = 0; i < 9; ++i) for (int j = 0; j < 9; ++j) A[9 * i + j] = psi.h[hidx(i, j)];
+    return psi.v;
+}
+
 int orc_element_facet(const orc_mesh *m, int64_t cell, int lf, int kind, double param, int fq, const double *ue, double *Ke, double *re)
 {
     if (m->kind != ORC_HEX8 && m->kind != ORC_HEX27) return -2;
@@ -1347,7 +1377,28 @@ int orc_element_facet(const orc_mesh *m, int64_t cell, int lf, int kind, double 
                     if (Ke)
                         for (int j = 0; j < nd; ++j) Ke[(size_t)i * nd + j] += N[ai] * H[3 * ci + (j % 3)] * N[j / 3] * dG;
                 }
-            } else if (kind == ORC_BC_PRESSURE) {
+            } else if (kind == ORC_BC_BENDING_SPRING) {
+                double P[9], A[81];
+                bending_energy(param, n0, F, P, Ke ? A : NULL);
+                for (int i = 0; i < nd; ++i) {
+                    const int ai = i / 3, ci = i % 3;
+                    if (re) { double sres = 0; for (int k = 0; k < 3; ++k) sres += dNdx[3 * ai + k] * P[3 * ci + k]; re[i] += sres * dG; }
+                    if (!Ke) continue;
+                    double T[9];
+                    for (int dl = 0; dl < 9; ++dl) { double sT = 0; for (int k = 0; k < 3; ++k) sT += dNdx[3 * ai + k] * A[9 * (3 * ci + k) + dl]; T[dl] = sT; }
+                    for (int j = 0; j < nd; ++j) {
+                        const int bj = j / 3, dj = j % 3;
+                        double sK = 0;
+                        for (int l = 0; l < 3; ++l) sK += T[3 * dj + l] * dNdx[3 * bj + l];
+                        Ke[(size_t)i * nd + j] += sK * dG;
+                    }
+                }
+            } else if (kind == ORC_BC_PRESSURE || kind == ORC_BC_PRESSURE_FIELD) {
+                double pq = param;
+                if (kind == ORC_BC_PRESSURE_FIELD && g_facet_pressure_field) { /* evaluate_coefficient(pc, cell, qp, t): nodal data × M_a(ξ_q) */
+                    double v = 0; for (int a2 = 0; a2 < 8; ++a2) v += M[a2] * g_facet_pressure_field[cell * 8 + a2];
+                    pq = param * v;
+                }
                 double Fi[9], Jf;
                 {   /* invF, J = det F */
                     const double c00 = F[4] * F[8] - F[5] * F[7], c01 = F[5] * F[6] - F[3] * F[8], c02 = F[3] * F[7] - F[4] * F[6];
@@ -1361,7 +1412,7 @@ int orc_element_facet(const orc_mesh *m, int64_t cell, int lf, int kind, double 
                 for (int c = 0; c < 3; ++c) cn[c] = Fi[0 + c] * n0[0] + Fi[3 + c] * n0[1] + Fi[6 + c] * n0[2];
                 for (int i = 0; i < nd; ++i) {
                     const int ai = i / 3, ci = i % 3;
-                    if (re) re[i] += param * Jf * cn[ci] * N[ai] * dG;
+                    if (re) re[i] += pq * Jf * cn[ci] * N[ai] * dG;
                     if (!Ke) continue;
                     for (int j = 0; j < nd; ++j) {
                         const int bj = j / 3, dj = j % 3;
@@ -1372,7 +1423,7 @@ int orc_element_facet(const orc_mesh *m, int64_t cell, int lf, int kind, double 
                         /* A[r][k] = invF[r][d] gF[k];  (δcofF·n₀)[c] = −Σ_r A[r][c] n₀[r] = −gF[c] Σ_r invF[r][d] n₀[r] */
                         const double fin = Fi[0 + dj] * n0[0] + Fi[3 + dj] * n0[1] + Fi[6 + dj] * n0[2];
                         const double v = dJ * cn[ci] + Jf * (-gF[ci] * fin);
-                        Ke[(size_t)i * nd + j] += param * v * N[ai] * dG;
+                        Ke[(size_t)i * nd + j] += pq * v * N[ai] * dG;
                     }
                 }
             } else return -2;

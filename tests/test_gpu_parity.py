@@ -687,12 +687,17 @@ def test_weak_boundary_conditions_parity(tb, oracle, device, order, nel):
     rng = np.random.default_rng(4)
     u = rng.uniform(-1e-2, 1e-2, dh.ndofs)
     fsn = np.eye(3)
-    bcs = [tb.RobinBC(0.3, "left"), tb.NormalSpringBC(2.0, "top"), tb.ConstantPressureBC(0.05, "right"), tb.ConstantPressureBC(-0.02, "front")]
-    okind = {tb.RobinBC: oracle.BC_ROBIN, tb.NormalSpringBC: oracle.BC_NORMAL_SPRING, tb.ConstantPressureBC: oracle.BC_PRESSURE}
+    pnod = rng.uniform(0.5, 1.5, (g.n_cells, 8))
+    bcs = [tb.RobinBC(0.3, "left"), tb.NormalSpringBC(2.0, "top"), tb.ConstantPressureBC(0.05, "right"), tb.ConstantPressureBC(-0.02, "front"),
+           tb.BendingSpringBC(0.7, "bottom"), tb.PressureFieldBC(tb.FieldCoefficient(0.04 * pnod), "back"), tb.PressureFieldBC(tb.ConstantCoefficient(0.01), "top")]
+    okind = {tb.RobinBC: oracle.BC_ROBIN, tb.NormalSpringBC: oracle.BC_NORMAL_SPRING, tb.ConstantPressureBC: oracle.BC_PRESSURE,
+             tb.BendingSpringBC: oracle.BC_BENDING_SPRING, tb.PressureFieldBC: oracle.BC_PRESSURE_FIELD}
     Kref, rref = oracle.assemble_hyperelastic(om, u, sp.rowptr, sp.colidx, fsn=fsn)
     Kvol = Kref.copy()
     for bc in bcs:
+        oracle.set_facet_pressure_field(getattr(bc, "field", None))
         oracle.assemble_facets(om, okind[type(bc)], bc.param, order, g.facetset(bc.boundary_name), u, sp.rowptr, sp.colidx, nz=Kref, r=rref)
+    oracle.set_facet_pressure_field(None)
     assert np.abs(Kref - Kvol).max() > 1e-4 * np.abs(Kvol).max()          # the surface terms are not negligible here
     model = tb.QuasiStaticModel("u", tb.PK1Model(tb.HolzapfelOgden2009Model(), tb.ConstantCoefficient(tb.OrthotropicMicrostructure(*fsn))), bcs)
     du = device.to_device(u)

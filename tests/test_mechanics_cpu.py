@@ -130,12 +130,13 @@ def test_facet_terms_closed_forms(oracle, order):
 
 
 @pytest.mark.parametrize("order", [1, 2])
-@pytest.mark.parametrize("kind", ["BC_ROBIN", "BC_NORMAL_SPRING", "BC_PRESSURE"])
+@pytest.mark.parametrize("kind", ["BC_ROBIN", "BC_NORMAL_SPRING", "BC_PRESSURE", "BC_BENDING_SPRING", "BC_PRESSURE_FIELD"])
 def test_facet_tangent_is_derivative_of_residual(oracle, order, kind):
     m, nd = _one_hex(oracle, order, distort=0.12, seed=5)
     rng = np.random.default_rng(2)
     u = rng.uniform(-0.05, 0.05, nd)
     k = getattr(oracle, kind)
+    oracle.set_facet_pressure_field(rng.uniform(0.5, 1.5, (1, 8)) if kind == "BC_PRESSURE_FIELD" else None)
     for lf in (0, 3, 4):
         Ke, _ = oracle.element_facet(m, 0, lf, k, 1.7, order + 1, u)
         fd = np.zeros_like(Ke)
@@ -146,6 +147,7 @@ def test_facet_tangent_is_derivative_of_residual(oracle, order, kind):
             _, rm = oracle.element_facet(m, 0, lf, k, 1.7, order + 1, u - e, want_K=False)
             fd[:, j] = (rp - rm) / (2 * h)
         assert np.abs(Ke - fd).max() < 1e-8 * max(1.0, np.abs(Ke).max())
+    oracle.set_facet_pressure_field(None)
 
 
 def test_active_stress_material_routine_matches_ad_oracle(tb, oracle):

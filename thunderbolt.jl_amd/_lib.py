@@ -14,7 +14,7 @@ TB_QUAD4, TB_HEX8, TB_TET4, TB_HEX27 = 2, 3, 4, 5
 TB_STRATEGY_ATOMIC, TB_STRATEGY_PER_COLOR, TB_STRATEGY_ELEMENT, TB_STRATEGY_PATCH = 0, 1, 2, 3
 TB_FORM_MASS, TB_FORM_DIFFUSION, TB_FORM_SOURCE, TB_FORM_HYPERELASTIC = 0, 1, 2, 3
 TB_MATERIAL_HOLZAPFEL_OGDEN_2009 = 0
-TB_BC_ROBIN, TB_BC_NORMAL_SPRING, TB_BC_PRESSURE = 0, 1, 2
+TB_BC_ROBIN, TB_BC_NORMAL_SPRING, TB_BC_PRESSURE, TB_BC_BENDING_SPRING, TB_BC_PRESSURE_FIELD = 0, 1, 2, 3, 4
 TB_COEF_CONST_SCALAR, TB_COEF_CONST_TENSOR, TB_COEF_FIELD_SCALAR = 0, 1, 2
 TB_COEF_SPECTRAL_CONST, TB_COEF_SPECTRAL_FIELD, TB_COEF_TRANSVERSE_CONST = 3, 4, 5
 TB_SRC_CONST, TB_SRC_NORM_PLUS_T, TB_SRC_COS_EXP, TB_SRC_TABULATED = 0, 1, 2, 3
@@ -76,6 +76,7 @@ SIGNATURES = {
     "tb_linearize": (C.c_int, [vp, vp, C.c_int, vp, C.c_double, vp, vp]),
     "tb_hyperelastic_set_active_tension": (C.c_int, [vp, C.c_double, c_dp, C.c_int64]),
     "tb_facet_form_create": (C.c_int, [vp, C.c_int, C.c_double, C.c_int, c_i32p, C.c_int64, C.c_int, C.POINTER(vp)]),
+    "tb_facet_form_set_field": (C.c_int, [vp, c_dp, C.c_int64]),
     "tb_facet_assemble": (C.c_int, [vp, vp, vp, C.c_double, vp, vp]),
     "tb_host_material_eval": (C.c_int, [C.POINTER(tb_material), c_dp, c_dp, c_dp, c_dp]),
     "tb_reaction_step": (C.c_int, [vp, C.c_int, c_dp, C.c_int, vp, vp, C.c_int64, C.c_int, C.c_int, C.c_double,

@@ -899,6 +899,28 @@ class ConstantPressureBC:
         self.param, self.boundary_name = float(p), boundary_name
 
 
+class BendingSpringBC:
+    """BendingSpringBC(kᵇ, boundary_name): energy ½ kᵇ |F⁻ᵀN − N|² (weak_boundary_conditions.jl:47-57,301-415)."""
+    kind = L.TB_BC_BENDING_SPRING
+
+    def __init__(self, kb, boundary_name):
+        self.param, self.boundary_name = float(kb), boundary_name
+
+
+class PressureFieldBC:
+    """PressureFieldBC(pressure_field, boundary_name) (weak_boundary_conditions.jl:71-77,516-632): the follower load of
+    ConstantPressureBC with p = evaluate_coefficient(pc, cell, qp, t); pc: ConstantCoefficient(p) or FieldCoefficient of
+    first-order nodal data per cell, shape (n_cells, 8)."""
+    kind = L.TB_BC_PRESSURE_FIELD
+
+    def __init__(self, pc, boundary_name):
+        self.boundary_name = boundary_name
+        if isinstance(pc, ConstantCoefficient):
+            self.param, self.field = float(pc.val), None
+        else:
+            self.param, self.field = 1.0, np.ascontiguousarray(pc.data, dtype=np.float64)
+
+
 class QuasiStaticModel:
     """QuasiStaticModel(:u, constitutive_model, facet_models) (test/test_elements.jl:99-125, fem.jl:597-623)."""
 
@@ -935,6 +957,8 @@ class NonlinearOperator:
             fs = np.ascontiguousarray(fs, dtype=np.int32).reshape(-1, 2)
             h = C.c_void_p()
             check(lib().tb_facet_form_create(self.dmesh.h, bc.kind, bc.param, 0, fs.ctypes.data_as(L.c_i32p), len(fs), 0, C.byref(h)))
+            if getattr(bc, "field", None) is not None:
+                check(lib().tb_facet_form_set_field(h, bc.field.ctypes.data_as(L.c_dp), bc.field.size))
             self.facet_forms.append(h)
 
     def __del__(self):

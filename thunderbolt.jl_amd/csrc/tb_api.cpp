@@ -490,7 +490,7 @@ int tb_facet_form_create(tb_mesh *mesh, int bc_kind, double param, int facet_qpo
 {
     TB_REQUIRE(mesh && out && (facets || n_facets == 0), "tb_facet_form_create: NULL argument");
     *out = nullptr;
-    TB_REQUIRE(bc_kind >= TB_BC_ROBIN && bc_kind <= TB_BC_PRESSURE, "tb_facet_form_create: unknown boundary condition %d", bc_kind);
+    TB_REQUIRE(bc_kind >= TB_BC_ROBIN && bc_kind <= TB_BC_PRESSURE_FIELD, "tb_facet_form_create: unknown boundary condition %d", bc_kind);
     TB_REQUIRE(mesh->ncomp == 3 && mesh->geom_kind == TB_HEX8, "tb_facet_form_create: needs a 3-component field on hexahedra");
     TB_REQUIRE(index_base == 0 || index_base == 1, "tb_facet_form_create: index_base must be 0 or 1");
     TB_REQUIRE(n_facets >= 0, "tb_facet_form_create: negative facet count");
@@ -512,6 +512,19 @@ int tb_facet_form_create(tb_mesh *mesh, int bc_kind, double param, int facet_qpo
     int rc = upload(mesh->dev, fl, &f->d_facets);
     if (rc) return rc;
     *out = f.release();
+    return TB_OK;
+}
+
+int tb_facet_form_set_field(tb_form *form, const double *field, int64_t len)
+{
+    TB_REQUIRE(form && form->kind == TB_FORM_FACET && form->bc_kind == TB_BC_PRESSURE_FIELD, "tb_facet_form_set_field: not a PressureFieldBC form");
+    tb_mesh *m = form->mesh;
+    if (!field) { hipFree(form->d_field); form->d_field = nullptr; return TB_OK; }
+    TB_REQUIRE(len == m->n_cells * 8, "tb_facet_form_set_field: needs %lld values (cells × 8), got %lld", (long long)(m->n_cells * 8), (long long)len);
+    TB_HIP(hipSetDevice(m->dev->id));
+    if (!form->d_field) TB_HIP(hipMalloc((void **)&form->d_field, sizeof(double) * len));
+    TB_HIP(hipMemcpyAsync(form->d_field, field, sizeof(double) * len, hipMemcpyHostToDevice, m->dev->stream));
+    TB_HIP(hipStreamSynchronize(m->dev->stream));
     return TB_OK;
 }
 

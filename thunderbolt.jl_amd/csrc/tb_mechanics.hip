@@ -692,7 +692,7 @@ __device__ inline void shape_at(int a, const double (&xi)[3], double &N, double 
 
 template <int NB>
 __global__ void __launch_bounds__(64)
-k_facets(MechMesh m, const int32_t *__restrict__ facets, int bc, double param, int fq, const double *__restrict__ u, double *__restrict__ nz,
+k_facets(MechMesh m, const int32_t *__restrict__ facets, int bc, double param, int fq, const double *__restrict__ pfield, const double *__restrict__ u, double *__restrict__ nz,
          double *__restrict__ r, const int64_t *__restrict__ rowptr, const uint16_t *__restrict__ blockpos, Status *st)
 {
     constexpr int ND = 3 * NB, MAXQ = 9;
@@ -762,27 +762,52 @@ k_facets(MechMesh m, const int32_t *__restrict__ facets, int bc, double param, i
             for (int c = 0; c < 3; ++c) o[4 + c] = param * un * n0[c];
             for (int c = 0; c < 3; ++c) for (int d = 0; d < 3; ++d) o[7 + 3 * c + d] = param * n0[c] * n0[d];
         } else {
+            double pq = param;
+            if (bc == TB_BC_PRESSURE_FIELD && pfield) { // evaluate_coefficient(pc, cell, qp, t): nodal data × M_a at the facet point
+                double xi[3];
+                xi[facet_fix(lf)] = facet_val(lf);
+                xi[facet_s(lf)] = gx[fq - 1][q % fq];
+                xi[facet_t(lf)] = gx[fq - 1][q / fq];
+                double v = 0.0;
+                for (int a = 0; a < 8; ++a) { double Ma, dMa[3]; shape_at<8>(a, xi, Ma, dMa); v += Ma * pfield[cell * 8 + a]; }
+                pq = param * v;
+            }
             const double c00 = F[1][1] * F[2][2] - F[1][2] * F[2][1], c01 = F[1][2] * F[2][0] - F[1][0] * F[2][2], c02 = F[1][0] * F[2][1] - F[1][1] * F[2][0];
             const double Jf = F[0][0] * c00 + F[0][1] * c01 + F[0][2] * c02, id = 1.0 / Jf;
             const double Fi[9] = {c00 * id, (F[0][2] * F[2][1] - F[0][1] * F[2][2]) * id, (F[0][1] * F[1][2] - F[0][2] * F[1][1]) * id,
                                   c01 * id, (F[0][0] * F[2][2] - F[0][2] * F[2][0]) * id, (F[0][2] * F[1][0] - F[0][0] * F[1][2]) * id,
                                   c02 * id, (F[0][1] * F[2][0] - F[0][0] * F[2][1]) * id, (F[0][0] * F[1][1] - F[0][1] * F[1][0]) * id};
             for (int e = 0; e < 9; ++e) o[7 + e] = Fi[e];
-            o[16] = Jf;
+            o[16] = bc == TB_BC_BENDING_SPRING ? Jf : pq * Jf;      // pressure: p·J folded here
+            double vv[3];
             for (int c = 0; c < 3; ++c) {
-                const double cn = Fi[0 + c] * n0[0] + Fi[3 + c] * n0[1] + Fi[6 + c] * n0[2]; // (F⁻ᵀ n₀)[c] — also fin[c]
+                const double cn = Fi[0 + c] * n0[0] + Fi[3 + c] * n0[1] + Fi[6 + c] * n0[2]; // v = F⁻ᵀ n₀
+                vv[c] = cn;
                 o[17 + c] = cn;
-                o[4 + c] = param * Jf * cn;
+                o[4 + c] = pq * Jf * cn;
+            }
+            if (bc == TB_BC_BENDING_SPRING) { // w = v − N, z = F⁻¹ w, B = F⁻¹ F⁻ᵀ (slots 20..22, 23..31)
+                const double w[3] = {vv[0] - n0[0], vv[1] - n0[1], vv[2] - n0[2]};
+                for (int j = 0; j < 3; ++j) o[20 + j] = Fi[3 * j + 0] * w[0] + Fi[3 * j + 1] * w[1] + Fi[3 * j + 2] * w[2];
+                for (int j = 0; j < 3; ++j)
+                    for (int l = 0; l < 3; ++l) o[23 + 3 * j + l] = Fi[3 * j + 0] * Fi[3 * l + 0] + Fi[3 * j + 1] * Fi[3 * l + 1] + Fi[3 * j + 2] * Fi[3 * l + 2];
             }
         }
     }
     __syncthreads();
-    // residual: rₑ[i] += δuᵢ·g dΓ
+    // residual: rₑ[i] += δuᵢ·g dΓ   (bending spring: ∇δuᵢ ⊡ P dΓ with P = −kᵇ v ⊗ z)
     if (r)
         for (int i = tid; i < ND; i += 64) {
             const int a = i / 3, c = i % 3;
             double v = 0.0;
-            for (int q = 0; q < nq; ++q) v += s_N[q][a] * s_q[q][4 + c] * s_q[q][0];
+            if (bc == TB_BC_BENDING_SPRING) {
+                for (int q = 0; q < nq; ++q) {
+                    const double *o = s_q[q], *g = s_G[q][a];
+                    v -= param * o[17 + c] * (g[0] * o[20] + g[1] * o[21] + g[2] * o[22]) * o[0];
+                }
+            } else {
+                for (int q = 0; q < nq; ++q) v += s_N[q][a] * s_q[q][4 + c] * s_q[q][0];
+            }
             if (v != 0.0) unsafeAtomicAdd(r + s_dof[i], v);
         }
     // tangent
@@ -790,15 +815,26 @@ k_facets(MechMesh m, const int32_t *__restrict__ facets, int bc, double param, i
         for (int ij = tid; ij < ND * ND; ij += 64) {
             const int i = ij / ND, j = ij % ND, a = i / 3, c = i % 3, b = j / 3, d = j % 3;
             double v = 0.0;
-            if (bc != TB_BC_PRESSURE) {
+            if (bc == TB_BC_ROBIN || bc == TB_BC_NORMAL_SPRING) {
                 for (int q = 0; q < nq; ++q) v += s_N[q][a] * s_q[q][7 + 3 * c + d] * s_N[q][b] * s_q[q][0];
+            } else if (bc == TB_BC_BENDING_SPRING) {
+                // 𝔸[c][k][d][l] = kᵇ [ v_d F⁻¹_lc z_k + v_c (F⁻¹_kd z_l + v_d B_kl) ],  Kₑ += ∇N_a[k] 𝔸 ∇N_b[l] dΓ
+                for (int q = 0; q < nq; ++q) {
+                    const double *o = s_q[q], *Fi = o + 7, *ga = s_G[q][a], *gb = s_G[q][b], *z = o + 20, *B = o + 23;
+                    const double gaz = ga[0] * z[0] + ga[1] * z[1] + ga[2] * z[2], gbz = gb[0] * z[0] + gb[1] * z[1] + gb[2] * z[2];
+                    const double gaFd = ga[0] * Fi[0 + d] + ga[1] * Fi[3 + d] + ga[2] * Fi[6 + d];
+                    const double gbFc = gb[0] * Fi[0 + c] + gb[1] * Fi[3 + c] + gb[2] * Fi[6 + c];
+                    double gaBgb = 0.0;
+                    for (int k = 0; k < 3; ++k) gaBgb += ga[k] * (B[3 * k] * gb[0] + B[3 * k + 1] * gb[1] + B[3 * k + 2] * gb[2]);
+                    v += param * (o[17 + d] * gbFc * gaz + o[17 + c] * (gaFd * gbz + o[17 + d] * gaBgb)) * o[0];
+                }
             } else {
                 for (int q = 0; q < nq; ++q) {
                     const double *o = s_q[q], *Fi = o + 7, *g = s_G[q][b];
                     double gF[3];
                     for (int k = 0; k < 3; ++k) gF[k] = g[0] * Fi[0 + k] + g[1] * Fi[3 + k] + g[2] * Fi[6 + k];
                     // δJ·cofF·n₀ + J·δcofF·n₀ for δF = e_d ⊗ ∇N_b
-                    v += param * o[16] * (gF[d] * o[17 + c] - gF[c] * o[17 + d]) * s_N[q][a] * o[0];
+                    v += o[16] * (gF[d] * o[17 + c] - gF[c] * o[17 + d]) * s_N[q][a] * o[0];
                 }
             }
             if (v != 0.0) unsafeAtomicAdd(nz + rowptr[s_dof[3 * a] + c] + blockpos[cell * (NB * NB) + a * NB + b] + d, v);
@@ -816,10 +852,10 @@ int launch_facets(tb_form *f, tb_pattern *p, const double *d_u, double *d_nz, do
     const int64_t *rowptr = p ? p->d_rowptr : nullptr;
     const uint16_t *bp = p ? p->d_blockpos : nullptr;
     if (m->field_kind == TB_HEX27)
-        hipLaunchKernelGGL((k_facets<27>), dim3((unsigned)f->n_facets), dim3(64), 0, dev->stream, mm, f->d_facets, f->bc_kind, f->bc_param, f->facet_q,
+        hipLaunchKernelGGL((k_facets<27>), dim3((unsigned)f->n_facets), dim3(64), 0, dev->stream, mm, f->d_facets, f->bc_kind, f->bc_param, f->facet_q, f->d_field,
                            d_u, d_nz, d_r, rowptr, bp, dev->d_status);
     else
-        hipLaunchKernelGGL((k_facets<8>), dim3((unsigned)f->n_facets), dim3(64), 0, dev->stream, mm, f->d_facets, f->bc_kind, f->bc_param, f->facet_q,
+        hipLaunchKernelGGL((k_facets<8>), dim3((unsigned)f->n_facets), dim3(64), 0, dev->stream, mm, f->d_facets, f->bc_kind, f->bc_param, f->facet_q, f->d_field,
                            d_u, d_nz, d_r, rowptr, bp, dev->d_status);
     TB_HIP(hipGetLastError());
     return check_status(dev);
