@@ -96,11 +96,24 @@ typedef struct tb_coef {
 } tb_coef;
 
 /* constitutive models for the quasi-static path: PK1Model(material, microstructure) (src/modeling/solid/materials.jl:442-453) */
-enum { TB_MATERIAL_HOLZAPFEL_OGDEN_2009 = 0 /* + SimpleCompressionPenalty, src/modeling/solid/energies.jl:136-168,80-87 */ };
+/* tb_material.kind: the passive energies of src/modeling/solid/energies.jl (parameters p[0…] in the struct field order of the reference) */
+enum { TB_MATERIAL_HOLZAPFEL_OGDEN_2009 = 0, /* a, b, aᶠ, bᶠ, aˢ, bˢ, aᶠˢ, bᶠˢ                                  :136-168 */
+       TB_MATERIAL_NULL = 1,                 /* Ψ = 0                                                            :6-7     */
+       TB_MATERIAL_BIO_NEOHOOKEAN = 2,       /* α                                                                :461-473 */
+       TB_MATERIAL_TI_NEOHOOKEAN = 3,        /* a₁, a₂, α₁, α₂ (TransverseIsotopicNeoHookeanModel)               :93-128  */
+       TB_MATERIAL_LIN_YIN_PASSIVE = 4,      /* C₁…C₄                                                            :178-198 */
+       TB_MATERIAL_LIN_YIN_ACTIVE = 5,       /* C₀…C₅                                                            :207-226 */
+       TB_MATERIAL_HUMPHREY_STRUMPF_YIN = 6, /* C₁…C₄                                                            :235-252 */
+       TB_MATERIAL_LINEAR_SPRING = 7,        /* η                                                                :261-275 */
+       TB_MATERIAL_GUCCIONE_1991 = 8 };      /* C₀, Bᶠᶠ, Bˢˢ, Bⁿⁿ, Bⁿˢ, Bᶠˢ, Bᶠⁿ                                   :284-330 */
+/* tb_material.reserved: the compression penalty U(I₃) (:13-87), parameters p[10] = β, p[11] = a, p[12] = b.  HO2009 with
+ * TB_PENALTY_SIMPLE runs hand-derived stress / tangent routines; every other combination is differentiated on the device by
+ * hyper-dual evaluation, the way the reference differentiates all of them (Tensors.hessian, materials.jl:1025-1040). */
+enum { TB_PENALTY_SIMPLE = 0, TB_PENALTY_NULL = 1, TB_PENALTY_HARTMANN_NEFF_1 = 2, TB_PENALTY_HARTMANN_NEFF_2 = 3, TB_PENALTY_HARTMANN_NEFF_3 = 4 };
 typedef struct tb_material {
     int32_t kind;
-    int32_t reserved;
-    double p[16];               /* HO2009: a, b, aᶠ, bᶠ, aˢ, bˢ, aᶠˢ, bᶠˢ, β (struct field order) */
+    int32_t reserved;           /* TB_PENALTY_* */
+    double p[16];               /* p[0…8] energy parameters (HO2009 + TB_PENALTY_SIMPLE: p[8] = β), p[9] initial active tension, p[10…12] penalty β, a, b */
     double f[3], s[3], n[3];    /* ConstantCoefficient(OrthotropicMicrostructure(f, s, n)) */
     const double *fsn_field;    /* optional HOST pointer: nodal frames of an OrthotropicMicrostructureModel of FieldCoefficients
                                    (microstructure.jl:145-187), [cell][geometry node 0..7][f|s|n][3]; interpolated with the

@@ -326,6 +326,29 @@ def element_hyperelastic(mesh, cell, ue, p=HO_DEFAULTS, fsn=np.eye(3), want_K=Tr
     return Ke, re
 
 
+EN_HO, EN_NULL, EN_BIO_NEOHOOKEAN, EN_TI_NEOHOOKEAN, EN_LIN_YIN_PASSIVE, EN_LIN_YIN_ACTIVE, EN_HSY, EN_LINEAR_SPRING, EN_GUCCIONE = range(9)
+PEN_SIMPLE, PEN_NULL, PEN_HN1, PEN_HN2, PEN_HN3 = range(5)
+
+
+def energy(energy, penalty, p, up, F, fsn=np.eye(3)):
+    """(Ψ, P, 𝔸) of any reference energy by hyper-dual AD."""
+    pp = np.zeros(9); pp[:len(p)] = p
+    uu = np.zeros(3); uu[:len(up)] = up
+    P, A = np.zeros(9), np.zeros(81)
+    lib().orc_energy.restype = C.c_double
+    psi = lib().orc_energy(int(energy), int(penalty), _d(pp), _d(uu), _d(_f64(fsn)), _d(_f64(F)), _d(P), _d(A))
+    return psi, P.reshape(3, 3), A.reshape(9, 9)
+
+
+def set_material(energy=0, penalty=0, p=None, up=None):
+    """material of element_hyperelastic / assemble_hyperelastic (global; set_material() restores HO + SimpleCompressionPenalty)."""
+    pp = np.zeros(9); uu = np.zeros(3)
+    if p is not None: pp[:len(p)] = p
+    if up is not None: uu[:len(up)] = up
+    lib().orc_set_material.restype = None
+    lib().orc_set_material(int(energy), int(penalty), _d(pp), _d(uu))
+
+
 BC_ROBIN, BC_NORMAL_SPRING, BC_PRESSURE, BC_BENDING_SPRING, BC_PRESSURE_FIELD = 0, 1, 2, 3, 4
 _PF_KEEP = [None]
 

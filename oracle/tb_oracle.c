@@ -1161,6 +1161,139 @@ double orc_ho_energy(const double *p, const double *fsn, const double *F, double
     return psi.v;
 }
 
+/* ---- every passive energy of src/modeling/solid/energies.jl through the same hyper-dual pass --------------------------------
+ * energy ids / penalty ids as in thunderbolt.jl_amd/csrc/tb_energy.hpp; p = energy parameters in the reference's struct field order,
+ * up = penalty parameters (β, a, b). */
+static hd hd_pow(hd u, double q)
+{
+    double f = pow(u.v, q);
+    double d1 = q == 0.0 ? 0.0 : q * pow(u.v, q - 1.0);
+    double d2 = (q == 0.0 || q == 1.0) ? 0.0 : q * (q - 1.0) * pow(u.v, q - 2.0);
+    return hd_chain(u, f, d1, d2);
+}
+static hd penalty_U(int penalty, const double *up, hd I3)
+{
+    const double beta = up[0], a = up[1], b = up[2];
+    switch (penalty) {
+    case 1: return hd_scale(I3, 0.0);                                                                   /* NullCompressionPenalty, :13-14 */
+    case 2: return hd_scale(hd_pow(hd_addc(hd_add(hd_pow(I3, b), hd_inv(hd_pow(I3, b))), -2.0), a), beta); /* HartmannNeff 1, :27-35 */
+    case 3: return hd_scale(hd_pow(hd_addc(hd_sqrt(I3), -1.0), a), beta);                                /* HartmannNeff 2, :47-54 */
+    case 4: { hd lj = hd_log(hd_sqrt(I3));                                                               /* HartmannNeff 3, :64-71 */
+              return hd_scale(hd_addc(hd_add(hd_sub(I3, hd_scale(lj, 2.0)), hd_scale(hd_mul(lj, lj), 4.0)), -1.0), beta); }
+    default: return hd_scale(hd_sub(hd_addc(I3, -1.0), hd_scale(hd_log(hd_sqrt(I3)), 2.0)), beta);        /* SimpleCompressionPenalty, :80-87 */
+    }
+}
+static hd quadC(hd C[3][3], const double *x, const double *y)
+{
+    hd r = hd_const(0.0);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r = hd_add(r, hd_scale(C[i][j], x[i] * y[j]));
+    return r;
+}
+static hd psi_generic(int energy, int penalty, const double *p, const double *up, const double *fsn, hd F[3][3])
+{
+    const double *f0 = fsn, *s0 = fsn + 3, *n0 = fsn + 6;
+    hd C[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            hd s = hd_const(0.0);
+            for (int k = 0; k < 3; ++k) s = hd_add(s, hd_mul(F[k][i], F[k][j]));
+            C[i][j] = s;
+        }
+    hd I1 = hd_add(hd_add(C[0][0], C[1][1]), C[2][2]);
+    hd I3 = hd_add(hd_sub(hd_mul(C[0][0], hd_sub(hd_mul(C[1][1], C[2][2]), hd_mul(C[1][2], C[2][1]))),
+                          hd_mul(C[0][1], hd_sub(hd_mul(C[1][0], C[2][2]), hd_mul(C[1][2], C[2][0])))),
+                   hd_mul(C[0][2], hd_sub(hd_mul(C[1][0], C[2][1]), hd_mul(C[1][1], C[2][0]))));
+    hd psi = hd_const(0.0);
+    switch (energy) {
+    case 1: break;                                                                         /* NullEnergyModel */
+    case 2: psi = hd_add(hd_scale(hd_addc(hd_mul(I1, hd_inv(hd_cbrt(I3))), -3.0), p[0]), penalty_U(penalty, up, I3)); break; /* BioNeoHookean */
+    case 3: {                                                                              /* TransverseIsotopicNeoHookeanModel */
+        hd I1b = hd_mul(I1, hd_inv(hd_cbrt(I3)));
+        if (-1e-8 < I1b.v - 3.0 && I1b.v - 3.0 < 0.0) I1b = hd_const(3.0);
+        psi = hd_add(hd_scale(hd_pow(hd_addc(I1b, -3.0), p[0]), p[2]), penalty_U(penalty, up, I3));
+        hd I4 = quadC(C, f0, f0);
+        if (I4.v >= 1.0) psi = hd_add(psi, hd_scale(hd_pow(hd_addc(I4, -1.0), p[1]), p[3]));
+        break;
+    }
+    case 4: {                                                                              /* LinYinPassiveModel */
+        hd i1 = hd_addc(I1, -3.0), i4 = hd_addc(quadC(C, f0, f0), -1.0);
+        hd Q = hd_add(hd_add(hd_scale(hd_mul(i1, i1), p[1]), hd_scale(hd_mul(i1, i4), p[2])), hd_scale(hd_mul(i4, i4), p[3]));
+        psi = hd_add(hd_scale(hd_addc(hd_exp(Q), -1.0), p[0]), penalty_U(penalty, up, I3));
+        break;
+    }
+    case 5: {                                                                              /* LinYinActiveModel */
+        hd i1 = hd_addc(I1, -3.0), i4 = hd_addc(quadC(C, f0, f0), -1.0);
+        psi = hd_addc(hd_scale(hd_mul(i1, i4), p[1]), p[0]);
+        psi = hd_add(psi, hd_scale(hd_mul(i1, i1), p[2]));
+        psi = hd_add(psi, hd_scale(hd_mul(i4, i4), p[3]));
+        psi = hd_add(psi, hd_scale(i1, p[4]));
+        psi = hd_add(psi, hd_scale(i4, p[5]));
+        psi = hd_add(psi, penalty_U(penalty, up, I3));
+        break;
+    }
+    case 6: {                                                                              /* HumphreyStrumpfYinModel */
+        hd l = hd_addc(hd_sqrt(quadC(C, f0, f0)), -1.0), i1 = hd_addc(I1, -3.0);
+        psi = hd_scale(hd_mul(l, l), p[0]);
+        psi = hd_add(psi, hd_scale(hd_mul(hd_mul(l, l), l), p[1]));
+        psi = hd_add(psi, hd_scale(hd_mul(l, i1), p[2]));
+        psi = hd_add(psi, hd_scale(hd_mul(i1, i1), p[3]));
+        psi = hd_add(psi, penalty_U(penalty, up, I3));
+        break;
+    }
+    case 7: { hd i4 = hd_addc(quadC(C, f0, f0), -1.0); psi = hd_scale(hd_mul(i4, i4), 0.5 * p[0]); break; } /* LinearSpringModel */
+    case 8: {                                                                              /* Guccione1991PassiveModel */
+        const double *v[3] = {f0, s0, n0};
+        hd E[3][3];
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) {
+                double dot = v[a][0] * v[b][0] + v[a][1] * v[b][1] + v[a][2] * v[b][2];
+                E[a][b] = hd_scale(hd_addc(quadC(C, v[a], v[b]), -dot), 0.5);
+            }
+        hd Q = hd_scale(hd_mul(E[0][0], E[0][0]), p[1]);
+        Q = hd_add(Q, hd_scale(hd_mul(E[1][1], E[1][1]), p[2]));
+        Q = hd_add(Q, hd_scale(hd_mul(E[2][2], E[2][2]), p[3]));
+        Q = hd_add(Q, hd_scale(hd_add(hd_mul(E[2][1], E[2][1]), hd_mul(E[1][2], E[1][2])), p[4]));
+        Q = hd_add(Q, hd_scale(hd_add(hd_mul(E[0][1], E[0][1]), hd_mul(E[1][0], E[1][0])), p[5]));
+        Q = hd_add(Q, hd_scale(hd_add(hd_mul(E[0][2], E[0][2]), hd_mul(E[2][0], E[2][0])), p[6]));
+        psi = hd_add(hd_scale(hd_exp(Q), 0.5 * p[0]), penalty_U(penalty, up, I3));
+        break;
+    }
+    default: {                                                                             /* HolzapfelOgden2009Model with any penalty */
+        hd I1b = hd_mul(I1, hd_inv(hd_cbrt(I3)));
+        hd I4f = quadC(C, f0, f0), I4s = quadC(C, s0, s0);
+        hd I8 = hd_scale(hd_add(quadC(C, f0, s0), quadC(C, s0, f0)), 0.5);
+        psi = hd_scale(hd_addc(hd_exp(hd_scale(hd_addc(I1b, -3.0), p[1])), -1.0), p[0] / (2.0 * p[1]));
+        psi = hd_add(psi, hd_scale(hd_addc(hd_exp(hd_scale(hd_mul(I8, I8), p[7])), -1.0), p[6] / (2.0 * p[7])));
+        psi = hd_add(psi, penalty_U(penalty, up, I3));
+        if (I4f.v >= 1.0) { hd d = hd_addc(I4f, -1.0); psi = hd_add(psi, hd_scale(hd_addc(hd_exp(hd_scale(hd_mul(d, d), p[3])), -1.0), p[2] / (2.0 * p[3]))); }
+        if (I4s.v >= 1.0) { hd d = hd_addc(I4s, -1.0); psi = hd_add(psi, hd_scale(hd_addc(hd_exp(hd_scale(hd_mul(d, d), p[5])), -1.0), p[4] / (2.0 * p[5]))); }
+    }
+    }
+    if (g_active_tension != 0.0) psi = hd_add(psi, hd_scale(hd_sqrt(quadC(C, f0, f0)), g_active_tension));
+    return psi;
+}
+
+double orc_energy(int energy, int penalty, const double *p, const double *up, const double *fsn, const double *F, double *P, double *A)
+{
+    hd Fd[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Fd[i][j] = hd_var(F[3 * i + j], 3 * i + j);
+    hd psi = psi_generic(energy, penalty, p, up, fsn, Fd);
+    if (P) for (int i = 0; i < 9; ++i) P[i] = psi.g[i];
+    if (A) for (int i = 0; i < 9; ++i) for (int j = 0; j < 9; ++j) A[9 * i + j] = psi.h[hidx(i, j)];
+    return psi.v;
+}
+
+/* material used by the element routines: default (energy 0, penalty 0) = HolzapfelOgden2009 + SimpleCompressionPenalty with the
+ * parameter vector p of the call (p[8] = β); orc_set_material selects another energy / penalty (test infrastructure: global state) */
+static int g_mat_energy = 0, g_mat_penalty = 0;
+static double g_mat_p[9], g_mat_u[3];
+void orc_set_material(int energy, int penalty, const double *p, const double *up)
+{
+    g_mat_energy = energy; g_mat_penalty = penalty;
+    if (p) memcpy(g_mat_p, p, sizeof g_mat_p);
+    if (up) memcpy(g_mat_u, up, sizeof g_mat_u);
+}
+
 /* src/modeling/solid/elements.jl:177-313.  Vector-valued shape functions: dof 3a+c ↔ e_c ⊗ ∇N_a
  * (node-major, component-minor: src/ferrite-addons/io.jl:233-238). */
 /* nodal microstructure field (OrthotropicMicrostructureModel of FieldCoefficients, microstructure.jl:145-187): per cell
@@ -1207,7 +1340,8 @@ static int element_hyperelastic_cv(const orc_mesh *m, const cellvalues *cv, int6
             for (int a = 0; a < cv->ngeo; ++a) ca += cv->M[q][a] * g_act_field[(int64_t)cell * cv->ngeo + a];
             g_active_tension = g_act_scale * ca;
         }
-        orc_ho_energy(p, fsn, F, P, Ke ? A : NULL);
+        if (g_mat_energy == 0 && g_mat_penalty == 0) orc_ho_energy(p, fsn, F, P, Ke ? A : NULL);
+        else orc_energy(g_mat_energy, g_mat_penalty, g_mat_p, g_mat_u, fsn, F, P, Ke ? A : NULL);
         g_active_tension = 0.0;
         for (int i = 0; i < nd; ++i) {
             int a = i / 3, c = i % 3;

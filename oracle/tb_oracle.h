@@ -184,6 +184,9 @@ int orc_assemble_hyperelastic(const orc_mesh *m, const double *p, const double *
 #define ORC_BC_BENDING_SPRING 3 /* ½ kᵇ |F⁻ᵀN − N|² (:47-57, :301-415) */
 #define ORC_BC_PRESSURE_FIELD 4 /* PressureFieldBC: p = param · nodal field (:71-77, :516-632) */
 void orc_set_facet_pressure_field(const double *field_per_cell_node /* n_cells×8 or NULL */);
+/* any energy of src/modeling/solid/energies.jl (ids as in thunderbolt.jl_amd/csrc/tb_energy.hpp) by hyper-dual AD */
+double orc_energy(int energy, int penalty, const double *p, const double *up, const double *fsn, const double *F, double *P, double *A);
+void orc_set_material(int energy, int penalty, const double *p /* 9 */, const double *up /* 3: β, a, b */);
 void orc_set_active_tension(double tension, const double *field_per_cell_node /* n_cells×8 or NULL */);
 int orc_element_facet(const orc_mesh *m, int64_t cell, int local_facet, int kind, double param, int fq, const double *ue,
                       double *Ke /* nd×nd or NULL, accumulated */, double *re /* nd or NULL, accumulated */);

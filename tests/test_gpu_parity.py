@@ -883,3 +883,38 @@ def test_reference_backward_euler_on_a_steady_state(tb, device):
     for s in range(1, 10):
         assert heat.perform_step(u, 0.1 * s, 0.1)
     np.testing.assert_allclose(u.to_host(), 1.0, atol=1e-4)
+
+
+@pytest.mark.parametrize("order,nel", [(1, (3, 2, 2)), (2, (2, 2, 1))])
+@pytest.mark.parametrize("cls,en", [("Guccione1991PassiveModel", "EN_GUCCIONE"), ("TransverseIsotopicNeoHookeanModel", "EN_TI_NEOHOOKEAN"),
+                                    ("LinYinPassiveModel", "EN_LIN_YIN_PASSIVE"), ("HumphreyStrumpfYinModel", "EN_HSY"), ("BioNeoHookean", "EN_BIO_NEOHOOKEAN")])
+def test_other_energies_assemble_like_the_ad_oracle(tb, oracle, device, order, nel, cls, en):
+    """Residual / tangent assembly with the other energies of src/modeling/solid/energies.jl (device-side hyper-dual differentiation,
+    the reference's Tensors.hessian path) against the oracle; nodal fibre frames and an active tension on top for one of them."""
+    g, dh, sp, om = mech_problem(tb, oracle, nel, order, perturb=0.1)
+    rng = np.random.default_rng(9)
+    u = rng.uniform(-1e-2, 1e-2, dh.ndofs)
+    du = device.to_device(u)
+    f, s, n = np.array([1, 1, 0.0]) / np.sqrt(2), np.array([-1, 1, 0.0]) / np.sqrt(2), np.array([0, 0, 1.0])
+    mat = getattr(tb, cls)()
+    active = cls == "Guccione1991PassiveModel"
+    ms = tb.ConstantCoefficient(tb.OrthotropicMicrostructure(f, s, n))
+    const = tb.ActiveStressModel(mat, tb.SimpleActiveStress(Tmax=0.4), tb.CaDrivenInternalSarcomereModel(tb.PelceSunLangeveld1995Model(), 0.5), ms) if active \
+        else tb.PK1Model(mat, ms)
+    oracle.set_material(getattr(oracle, en), mat.mpU.pid, mat.p, mat.mpU.u)
+    oracle.set_active_tension(0.2 if active else 0.0)
+    try:
+        Kref, rref = oracle.assemble_hyperelastic(om, u, sp.rowptr, sp.colidx, fsn=np.stack([f, s, n]))
+    finally:
+        oracle.set_material()
+        oracle.set_active_tension(0.0)
+    model = tb.QuasiStaticModel("u", const)
+    for st in (tb.ElementAssemblyStrategy(device), tb.AtomicAssemblyStrategy(device)):
+        op = tb.setup_operator(st, model, dh, sp)
+        res = device.zeros(dh.ndofs)
+        tb.update_linearization(op, du, 0.0, residual=res)
+        assert rel_err(op.J.to_host(), Kref) < 1e-11, (cls, type(st).__name__, rel_err(op.J.to_host(), Kref))
+        assert rel_err(res.to_host(), rref) < 1e-11
+        res2 = device.zeros(dh.ndofs)
+        tb.residual(op, res2, du, 0.0)
+        assert rel_err(res2.to_host(), rref) < 1e-11

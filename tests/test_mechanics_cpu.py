@@ -195,3 +195,63 @@ def test_active_stress_element_through_the_oracle(oracle):
         assert np.abs(re - r0).max() > 1e-3
     finally:
         oracle.set_active_tension(0.0)
+
+
+ENERGY_CASES = [
+    ("NullEnergyModel", {}, "EN_NULL"),
+    ("BioNeoHookean", {}, "EN_BIO_NEOHOOKEAN"),
+    ("TransverseIsotopicNeoHookeanModel", {}, "EN_TI_NEOHOOKEAN"),
+    ("LinYinPassiveModel", {}, "EN_LIN_YIN_PASSIVE"),
+    ("LinYinActiveModel", {}, "EN_LIN_YIN_ACTIVE"),
+    ("HumphreyStrumpfYinModel", {}, "EN_HSY"),
+    ("LinearSpringModel", {}, "EN_LINEAR_SPRING"),
+    ("Guccione1991PassiveModel", {}, "EN_GUCCIONE"),
+]
+PENALTIES = ["SimpleCompressionPenalty", "NullCompressionPenalty", "HartmannNeffCompressionPenalty1", "HartmannNeffCompressionPenalty2",
+             "HartmannNeffCompressionPenalty3"]
+
+
+@pytest.mark.parametrize("cls,kw,en", ENERGY_CASES)
+def test_every_reference_energy_matches_the_ad_oracle(tb, oracle, cls, kw, en):
+    """All passive energies of src/modeling/solid/energies.jl, with the reference's default parameters and default penalty: the
+    device routine (hyper-dual evaluation per component pair, run on the host through the same inline code) against the oracle's
+    hyper-dual Hessian; Ψ(I) = 0 (or the constant the formula gives) and P(I) = 0 as test/test_type_stability.jl:29-63 checks."""
+    rng = np.random.default_rng(11)
+    f, s, n = np.linalg.qr(rng.normal(size=(3, 3)))[0].T
+    mat = getattr(tb, cls)(**kw)
+    model = tb.PK1Model(mat, tb.ConstantCoefficient(tb.OrthotropicMicrostructure(f, s, n)))
+    eid = getattr(oracle, en)
+    for trial in range(4):
+        F = np.eye(3) + 0.12 * rng.normal(size=(3, 3))
+        psi, P, A = tb.material_routine(model, F)
+        rpsi, rP, rA = oracle.energy(eid, mat.mpU.pid, mat.p, mat.mpU.u, F, fsn=np.stack([f, s, n]))
+        sc = max(1.0, np.abs(rA).max())
+        assert psi == pytest.approx(rpsi, rel=1e-12, abs=1e-13)
+        np.testing.assert_allclose(P, rP, rtol=1e-11, atol=1e-12 * sc)
+        np.testing.assert_allclose(A, rA, rtol=1e-10, atol=1e-12 * sc)
+        np.testing.assert_allclose(A, A.T, atol=1e-12 * sc)
+    psiI, PI, _ = tb.material_routine(model, np.eye(3))
+    if cls != "Guccione1991PassiveModel":          # Ψ(I) = C₀/2 there: the formula has no −1
+        assert abs(psiI) < 1e-14
+    if cls != "LinYinActiveModel":                 # an *active* energy: its linear terms C₄(I₁−3) + C₅(I₄−1) pre-stress the reference state
+        assert np.abs(PI).max() < 1e-12
+
+
+@pytest.mark.parametrize("pen", PENALTIES)
+def test_compression_penalties_with_holzapfel_ogden(tb, oracle, pen):
+    """HolzapfelOgden2009Model(mpU = each penalty of energies.jl:13-87): the Simple penalty takes the hand-derived routines, the
+    others the device AD path; both against the hyper-dual oracle."""
+    rng = np.random.default_rng(12)
+    f, s, n = np.linalg.qr(rng.normal(size=(3, 3)))[0].T
+    mpU = getattr(tb, pen)()
+    if pen == "HartmannNeffCompressionPenalty2":
+        mpU = tb.HartmannNeffCompressionPenalty2(a=2.0)   # the default a = 1.1 has an infinite second derivative at I₃ = 1 and NaNs under compression
+    model = tb.PK1Model(tb.HolzapfelOgden2009Model(mpU=mpU), tb.ConstantCoefficient(tb.OrthotropicMicrostructure(f, s, n)))
+    for trial in range(3):
+        F = np.eye(3) + 0.1 * rng.normal(size=(3, 3))
+        F *= (1.2 / np.linalg.det(F)) ** (1 / 3)                 # J = 1.2 > 1 so that (√I₃ − 1)ᵃ is defined
+        psi, P, A = tb.material_routine(model, F)
+        rpsi, rP, rA = oracle.energy(oracle.EN_HO, mpU.pid, oracle.HO_DEFAULTS[:8], mpU.u, F, fsn=np.stack([f, s, n]))
+        np.testing.assert_allclose(P, rP, rtol=1e-11, atol=1e-12 * np.abs(rA).max())
+        np.testing.assert_allclose(A, rA, rtol=1e-10, atol=1e-12 * np.abs(rA).max())
+        assert psi == pytest.approx(rpsi, rel=1e-12)

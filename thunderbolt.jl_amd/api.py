@@ -787,8 +787,109 @@ class HolzapfelOgden2009Model:
     """HolzapfelOgden2009Model(; a, b, aᶠ, bᶠ, aˢ, bˢ, aᶠˢ, bᶠˢ, mpU = SimpleCompressionPenalty(β)) (energies.jl:136-168)."""
     names = ["a", "b", "af", "bf", "as_", "bs", "afs", "bfs", "beta"]
 
-    def __init__(self, a=0.059, b=8.023, af=18.472, bf=16.026, as_=2.581, bs=11.120, afs=0.216, bfs=11.436, beta=1.0):
+    def __init__(self, a=0.059, b=8.023, af=18.472, bf=16.026, as_=2.581, bs=11.120, afs=0.216, bfs=11.436, beta=1.0, mpU=None):
+        if mpU is not None and mpU.pid == 0:
+            beta = mpU.u[0]
         self.p = np.array([a, b, af, bf, as_, bs, afs, bfs, beta], dtype=np.float64)
+        self.mpU = mpU                       # None / SimpleCompressionPenalty → hand-derived routines; other penalties → device AD
+
+
+# ---- compression penalties U(I₃) and passive energies of src/modeling/solid/energies.jl (defaults = the reference's @kwdef defaults)
+class SimpleCompressionPenalty:
+    pid = 0
+
+    def __init__(self, beta=1.0):
+        self.u = [beta, 0.0, 0.0]
+
+
+class NullCompressionPenalty:
+    pid = 1
+    u = [0.0, 0.0, 0.0]
+
+
+class HartmannNeffCompressionPenalty1:
+    pid = 2
+
+    def __init__(self, a=1, b=2, beta=1.0):
+        self.u = [beta, float(a), float(b)]
+
+
+class HartmannNeffCompressionPenalty2:
+    pid = 3
+
+    def __init__(self, a=1.1, beta=1.0):
+        self.u = [beta, float(a), 0.0]
+
+
+class HartmannNeffCompressionPenalty3:
+    pid = 4
+
+    def __init__(self, beta=1.0):
+        self.u = [beta, 0.0, 0.0]
+
+
+class _Energy:
+    kind = 0
+
+    def __init__(self, p, mpU):
+        self.p = np.array(list(p), dtype=np.float64)
+        self.mpU = mpU
+
+
+class NullEnergyModel(_Energy):
+    kind = 1
+
+    def __init__(self):
+        super().__init__([], NullCompressionPenalty())
+
+
+class BioNeoHookean(_Energy):
+    kind = 2
+
+    def __init__(self, alpha=1.0, mpU=None):
+        super().__init__([alpha], mpU or SimpleCompressionPenalty())
+
+
+class TransverseIsotopicNeoHookeanModel(_Energy):
+    kind = 3
+
+    def __init__(self, a1=2.6, a2=2.82, alpha1=30.48, alpha2=7.25, mpU=None):
+        super().__init__([a1, a2, alpha1, alpha2], mpU or HartmannNeffCompressionPenalty1())
+
+
+class LinYinPassiveModel(_Energy):
+    kind = 4
+
+    def __init__(self, C1=1.05, C2=9.13, C3=2.32, C4=0.08, mpU=None):
+        super().__init__([C1, C2, C3, C4], mpU or SimpleCompressionPenalty())
+
+
+class LinYinActiveModel(_Energy):
+    kind = 5
+
+    def __init__(self, C0=0.0, C1=-13.03, C2=36.65, C3=35.42, C4=15.52, C5=1.62, mpU=None):
+        super().__init__([C0, C1, C2, C3, C4, C5], mpU or SimpleCompressionPenalty())
+
+
+class HumphreyStrumpfYinModel(_Energy):
+    kind = 6
+
+    def __init__(self, C1=15.93, C2=55.85, C3=3.59, C4=30.21, mpU=None):
+        super().__init__([C1, C2, C3, C4], mpU or SimpleCompressionPenalty())
+
+
+class LinearSpringModel(_Energy):
+    kind = 7
+
+    def __init__(self, eta=10.0, mpU=None):
+        super().__init__([eta], mpU or NullCompressionPenalty())
+
+
+class Guccione1991PassiveModel(_Energy):
+    kind = 8
+
+    def __init__(self, C0=0.1, Bff=29.8, Bss=14.9, Bnn=14.9, Bns=9.3, Bfs=19.2, Bfn=14.4, mpU=None):
+        super().__init__([C0, Bff, Bss, Bnn, Bns, Bfs, Bfn], mpU or SimpleCompressionPenalty(50.0))
 
 
 class PK1Model:
@@ -802,9 +903,24 @@ class PK1Model:
 
     def lower(self):
         m = L.tb_material()
-        m.kind = L.TB_MATERIAL_HOLZAPFEL_OGDEN_2009
-        for i, v in enumerate(self.material.p):
-            m.p[i] = v
+        mat = self.material
+        if isinstance(mat, _Energy):                  # any energy + any penalty: differentiated on the device
+            m.kind, m.reserved = mat.kind, mat.mpU.pid
+            for i, v in enumerate(mat.p):
+                m.p[i] = v
+            for i, v in enumerate(mat.mpU.u):
+                m.p[10 + i] = v
+        else:                                         # HolzapfelOgden2009Model(…, mpU = SimpleCompressionPenalty(β)): hand-derived fast path
+            pen = getattr(mat, "mpU", None)
+            m.kind = L.TB_MATERIAL_HOLZAPFEL_OGDEN_2009
+            for i, v in enumerate(mat.p):
+                m.p[i] = v
+            if pen is not None and pen.pid != 0:
+                m.reserved = pen.pid
+                for i, v in enumerate(pen.u):
+                    m.p[10 + i] = v
+            else:
+                m.p[10] = mat.p[8]
         if isinstance(self.microstructure, OrthotropicMicrostructureModel):
             self._keep = self.microstructure.fsn           # [cell][node][f|s|n][3]
             m.fsn_field = self._keep.ctypes.data_as(L.c_dp)

@@ -417,7 +417,8 @@ int tb_hyperelastic_create(tb_mesh *mesh, int qorder, const tb_material *materia
 {
     TB_REQUIRE(mesh && material && out, "tb_hyperelastic_create: NULL argument");
     *out = nullptr;
-    TB_REQUIRE(material->kind == TB_MATERIAL_HOLZAPFEL_OGDEN_2009, "tb_hyperelastic_create: unknown material kind %d", material->kind);
+    TB_REQUIRE(material->kind >= TB_MATERIAL_HOLZAPFEL_OGDEN_2009 && material->kind <= TB_MATERIAL_GUCCIONE_1991, "tb_hyperelastic_create: unknown material kind %d", material->kind);
+    TB_REQUIRE(material->reserved >= TB_PENALTY_SIMPLE && material->reserved <= TB_PENALTY_HARTMANN_NEFF_3, "tb_hyperelastic_create: unknown compression penalty %d", material->reserved);
     TB_REQUIRE(mesh->ncomp == 3 && mesh->geom_kind == TB_HEX8, "tb_hyperelastic_create: needs a 3-component field on hexahedra");
     // the kernels address a node's three dofs as consecutive ids (Ferrite: node-major, component-minor, io.jl:233-238)
     for (int64_t i = 0; i < mesh->n_cells * mesh->nb; ++i) {
@@ -542,7 +543,8 @@ int tb_facet_assemble(tb_form *form, tb_pattern *pat, const double *d_u, double 
 int tb_host_material_eval(const tb_material *material, const double *F, double *psi, double *P, double *A)
 {
     TB_REQUIRE(material && F, "tb_host_material_eval: NULL argument");
-    TB_REQUIRE(material->kind == TB_MATERIAL_HOLZAPFEL_OGDEN_2009, "tb_host_material_eval: unknown material kind %d", material->kind);
+    TB_REQUIRE(material->kind >= TB_MATERIAL_HOLZAPFEL_OGDEN_2009 && material->kind <= TB_MATERIAL_GUCCIONE_1991, "tb_host_material_eval: unknown material kind %d", material->kind);
+    TB_REQUIRE(material->reserved >= TB_PENALTY_SIMPLE && material->reserved <= TB_PENALTY_HARTMANN_NEFF_3, "tb_host_material_eval: unknown compression penalty %d", material->reserved);
     return host_material_eval(material, F, psi, P, A);
 }
 

@@ -1,0 +1,186 @@
+// tb_energy.hpp — the reference's strain-energy functions Ψ(F) (src/modeling/solid/energies.jl) written once over a generic
+// number type, and a scalar hyper-dual number for differentiating them on the device.
+//
+// The reference obtains P = ∂Ψ/∂F and 𝔸 = ∂²Ψ/∂F² of *every* material by forward-mode AD (Tensors.gradient / Tensors.hessian,
+// src/modeling/solid/materials.jl:1025-1040).  The Holzapfel–Ogden model has hand-derived derivatives here (tb_material.hpp, the fast
+// path); all other energies go through the same idea the reference uses, mapped to the GPU: one lane per pair (m, n) of components of
+// F evaluates Ψ on hyper-dual numbers  x = v + a ε₁ + b ε₂ + ab ε₁ε₂  (ε₁² = ε₂² = 0) seeded with ε₁ on F_m and ε₂ on F_n;
+// then Ψ.a = P_m, Ψ.ab = 𝔸_mn = 𝔸_nm.  45 lanes per quadrature point cover the symmetric 9×9 tangent, each carrying four doubles
+// per intermediate — no 9×9 tangent in anybody's registers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+namespace tbk {
+
+#ifndef TB_HD
+#define TB_HD __host__ __device__ __forceinline__
+#endif
+
+struct HD {
+    double v, a, b, ab;
+};
+TB_HD HD hd_c(double c) { return HD{c, 0.0, 0.0, 0.0}; }
+TB_HD HD operator+(HD x, HD y) { return HD{x.v + y.v, x.a + y.a, x.b + y.b, x.ab + y.ab}; }
+TB_HD HD operator-(HD x, HD y) { return HD{x.v - y.v, x.a - y.a, x.b - y.b, x.ab - y.ab}; }
+TB_HD HD operator-(HD x) { return HD{-x.v, -x.a, -x.b, -x.ab}; }
+TB_HD HD operator+(HD x, double c) { x.v += c; return x; }
+TB_HD HD operator-(HD x, double c) { x.v -= c; return x; }
+TB_HD HD operator+(double c, HD x) { x.v += c; return x; }
+TB_HD HD operator-(double c, HD x) { return HD{c - x.v, -x.a, -x.b, -x.ab}; }
+TB_HD HD operator*(HD x, double c) { return HD{x.v * c, x.a * c, x.b * c, x.ab * c}; }
+TB_HD HD operator*(double c, HD x) { return x * c; }
+TB_HD HD operator/(HD x, double c) { return x * (1.0 / c); }
+TB_HD HD operator*(HD x, HD y)
+{
+    return HD{x.v * y.v, x.a * y.v + x.v * y.a, x.b * y.v + x.v * y.b, x.ab * y.v + x.a * y.b + x.b * y.a + x.v * y.ab};
+}
+// f(u) with f, f', f'' given at u.v
+TB_HD HD hd_chain(HD u, double f, double d1, double d2) { return HD{f, d1 * u.a, d1 * u.b, d1 * u.ab + d2 * u.a * u.b}; }
+TB_HD HD exp(HD u) { const double e = ::exp(u.v); return hd_chain(u, e, e, e); }
+TB_HD HD log(HD u) { const double i = 1.0 / u.v; return hd_chain(u, ::log(u.v), i, -i * i); }
+TB_HD HD sqrt(HD u) { const double s = ::sqrt(u.v); return hd_chain(u, s, 0.5 / s, -0.25 / (s * u.v)); }
+TB_HD HD cbrt(HD u) { const double c = ::cbrt(u.v); return hd_chain(u, c, c / (3.0 * u.v), -2.0 * c / (9.0 * u.v * u.v)); }
+TB_HD HD inv(HD u) { const double i = 1.0 / u.v; return hd_chain(u, i, -i * i, 2.0 * i * i * i); }
+TB_HD HD operator/(HD x, HD y) { return x * inv(y); }
+TB_HD HD operator/(double c, HD y) { return inv(y) * c; }
+// u^p for real p (u.v ≥ 0; the derivatives at u.v = 0 are taken as 0 when their exponent is positive, like 0.0^q in Julia)
+TB_HD HD pow(HD u, double p)
+{
+    const double f = ::pow(u.v, p);
+    const double d1 = p == 0.0 ? 0.0 : p * ::pow(u.v, p - 1.0);
+    const double d2 = (p == 0.0 || p == 1.0) ? 0.0 : p * (p - 1.0) * ::pow(u.v, p - 2.0);
+    return hd_chain(u, f, d1, d2);
+}
+// the same vocabulary for plain doubles, so that an energy written once serves both
+TB_HD double hd_value(double x) { return x; }
+TB_HD double hd_value(HD x) { return x.v; }
+TB_HD double inv(double x) { return 1.0 / x; }
+TB_HD double exp(double x) { return ::exp(x); }   // the HD overloads above would otherwise hide the global ones inside tbk
+TB_HD double log(double x) { return ::log(x); }
+TB_HD double sqrt(double x) { return ::sqrt(x); }
+TB_HD double cbrt(double x) { return ::cbrt(x); }
+TB_HD double pow(double x, double p) { return ::pow(x, p); }
+
+// ---- material description that travels by value into the kernels (tb_material of the ABI, lowered) ----
+enum { EN_HOLZAPFEL_OGDEN = 0, EN_NULL = 1, EN_BIO_NEOHOOKEAN = 2, EN_TI_NEOHOOKEAN = 3, EN_LIN_YIN_PASSIVE = 4, EN_LIN_YIN_ACTIVE = 5,
+       EN_HUMPHREY_STRUMPF_YIN = 6, EN_LINEAR_SPRING = 7, EN_GUCCIONE_1991 = 8 };
+enum { PEN_SIMPLE = 0, PEN_NULL = 1, PEN_HARTMANN_NEFF_1 = 2, PEN_HARTMANN_NEFF_2 = 3, PEN_HARTMANN_NEFF_3 = 4 };
+
+struct EnergyParams {
+    int energy, penalty;
+    double p[9];  // energy parameters in the field order of the reference struct
+    double u[3];  // penalty parameters: β, a, b
+    double Ta;    // active tension (ActiveStressModel + SimpleActiveStress): + Ta·‖F f₀‖
+};
+
+// U(I₃), energies.jl:13-87 (I₃ < 0 → NaN there; a cell with detJ ≤ 0 is reported separately)
+template <class T> TB_HD T penalty_U(const EnergyParams &m, T I3)
+{
+    const double beta = m.u[0], a = m.u[1], b = m.u[2];
+    switch (m.penalty) {
+    case PEN_NULL: return I3 * 0.0;
+    case PEN_HARTMANN_NEFF_1: return beta * pow(pow(I3, b) + inv(pow(I3, b)) - 2.0, a);  // β (I₃ᵇ + I₃⁻ᵇ − 2)ᵃ
+    case PEN_HARTMANN_NEFF_2: return beta * pow(sqrt(I3) - 1.0, a);                         // β (√I₃ − 1)ᵃ
+    case PEN_HARTMANN_NEFF_3: { const T lj = log(sqrt(I3)); return beta * (I3 - 2.0 * lj + 4.0 * (lj * lj) - 1.0); }
+    default: return beta * (I3 - 1.0 - 2.0 * log(sqrt(I3)));                                // SimpleCompressionPenalty
+    }
+}
+
+// Ψ(F; f₀, s₀, n₀).  Every branch follows the expression of the reference function it cites.
+template <class T> TB_HD T energy_psi(const EnergyParams &m, const T (&F)[3][3], const double (&f0)[3], const double (&s0)[3], const double (&n0)[3])
+{
+    T C[3][3]; // C = tdot(F) = FᵀF
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = i; j < 3; ++j) { C[i][j] = F[0][i] * F[0][j] + F[1][i] * F[1][j] + F[2][i] * F[2][j]; C[j][i] = C[i][j]; }
+    const T I1 = C[0][0] + C[1][1] + C[2][2];
+    const T I3 = C[0][0] * (C[1][1] * C[2][2] - C[1][2] * C[2][1]) - C[0][1] * (C[1][0] * C[2][2] - C[1][2] * C[2][0]) +
+                 C[0][2] * (C[1][0] * C[2][1] - C[1][1] * C[2][0]);
+    auto quad = [&](const double (&x)[3], const double (&y)[3]) { // x·C·y
+        T r = C[0][0] * (x[0] * y[0]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (i || j) r = r + C[i][j] * (x[i] * y[j]);
+        return r;
+    };
+    const double *p = m.p;
+    T psi = I1 * 0.0;
+    switch (m.energy) {
+    case EN_NULL: break;                                                                          // energies.jl:6-7
+    case EN_BIO_NEOHOOKEAN: psi = p[0] * (I1 * inv(cbrt(I3)) - 3.0) + penalty_U(m, I3); break;    // :461-473
+    case EN_TI_NEOHOOKEAN: {                                                                      // :93-128
+        T I1b = I1 * inv(cbrt(I3));
+        const double dv = hd_value(I1b) - 3.0;
+        if (-1e-8 < dv && dv < 0.0) I1b = I1b * 0.0 + 3.0; // the reference's hotfix: a plain 3.0, derivatives gone
+        psi = p[2] * pow(I1b - 3.0, p[0]) + penalty_U(m, I3);
+        const T I4 = quad(f0, f0);
+        if (hd_value(I4) >= 1.0) psi = psi + p[3] * pow(I4 - 1.0, p[1]);
+        break;
+    }
+    case EN_LIN_YIN_PASSIVE: {                                                                    // :178-198
+        const T i1 = I1 - 3.0, i4 = quad(f0, f0) - 1.0;
+        const T Q = p[1] * (i1 * i1) + p[2] * (i1 * i4) + p[3] * (i4 * i4);
+        psi = p[0] * (exp(Q) - 1.0) + penalty_U(m, I3);
+        break;
+    }
+    case EN_LIN_YIN_ACTIVE: {                                                                     // :207-226
+        const T i1 = I1 - 3.0, i4 = quad(f0, f0) - 1.0;
+        psi = p[0] + p[1] * (i1 * i4) + p[2] * (i1 * i1) + p[3] * (i4 * i4) + p[4] * i1 + p[5] * i4 + penalty_U(m, I3);
+        break;
+    }
+    case EN_HUMPHREY_STRUMPF_YIN: {                                                               // :235-252
+        const T l = sqrt(quad(f0, f0)) - 1.0, i1 = I1 - 3.0;
+        psi = p[0] * (l * l) + p[1] * (l * l * l) + p[2] * (l * i1) + p[3] * (i1 * i1) + penalty_U(m, I3);
+        break;
+    }
+    case EN_LINEAR_SPRING: { const T i4 = quad(f0, f0) - 1.0; psi = (0.5 * p[0]) * (i4 * i4); break; } // :261-275 (mpU not applied there)
+    case EN_GUCCIONE_1991: {                                                                      // :284-330, E = (C − I)/2
+        auto Eq = [&](const double (&x)[3], const double (&y)[3]) { return 0.5 * (quad(x, y) - (x[0] * y[0] + x[1] * y[1] + x[2] * y[2])); };
+        const T Eff = Eq(f0, f0), Ess = Eq(s0, s0), Enn = Eq(n0, n0), Efs = Eq(f0, s0), Esf = Eq(s0, f0), Esn = Eq(s0, n0), Ens = Eq(n0, s0),
+                Efn = Eq(f0, n0), Enf = Eq(n0, f0);
+        const T Q = p[1] * (Eff * Eff) + p[2] * (Ess * Ess) + p[3] * (Enn * Enn) + p[4] * (Ens * Ens + Esn * Esn) + p[5] * (Efs * Efs + Esf * Esf) +
+                    p[6] * (Efn * Efn + Enf * Enf);
+        psi = (0.5 * p[0]) * exp(Q) + penalty_U(m, I3);
+        break;
+    }
+    default: {                                                                                    // Holzapfel–Ogden 2009, :136-168
+        const T I1b = I1 * inv(cbrt(I3));
+        const T I4f = quad(f0, f0), I4s = quad(s0, s0);
+        const T I8 = 0.5 * (quad(f0, s0) + quad(s0, f0));
+        psi = (p[0] / (2.0 * p[1])) * (exp(p[1] * (I1b - 3.0)) - 1.0) + (p[6] / (2.0 * p[7])) * (exp(p[7] * (I8 * I8)) - 1.0) + penalty_U(m, I3);
+        if (hd_value(I4f) >= 1.0) { const T d = I4f - 1.0; psi = psi + (p[2] / (2.0 * p[3])) * (exp(p[3] * (d * d)) - 1.0); }
+        if (hd_value(I4s) >= 1.0) { const T d = I4s - 1.0; psi = psi + (p[4] / (2.0 * p[5])) * (exp(p[5] * (d * d)) - 1.0); }
+    }
+    }
+    if (m.Ta != 0.0) psi = psi + m.Ta * sqrt(quad(f0, f0)); // active stress: ∂(Ta‖F f₀‖)/∂F (materials.jl:1200-1266, active.jl:100-113)
+    return psi;
+}
+
+// pair index pr ∈ [0, 45) ↔ components (mm ≤ nn) of F (row-major 0…8)
+TB_HD void pair_components(int pr, int &mm, int &nn)
+{
+    int r = 0, left = pr;
+    while (left >= 9 - r) { left -= 9 - r; ++r; }
+    mm = r; nn = r + left;
+}
+
+// Ψ, P_mm and 𝔸_(mm,nn) at F by one hyper-dual evaluation
+TB_HD HD energy_pair(const EnergyParams &m, const double *F9, int mm, int nn, const double (&f0)[3], const double (&s0)[3], const double (&n0)[3])
+{
+    HD F[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int e = 3 * i + j;
+            F[i][j] = HD{F9[e], e == mm ? 1.0 : 0.0, e == nn ? 1.0 : 0.0, 0.0};
+        }
+    return energy_psi<HD>(m, F, f0, s0, n0);
+}
+
+} // namespace tbk

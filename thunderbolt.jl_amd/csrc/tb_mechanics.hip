@@ -20,6 +20,7 @@
 #include <algorithm>
 
 #include "tb_internal.h"
+#include "tb_energy.hpp"
 #include "tb_material.hpp"
 
 namespace tb {
@@ -131,9 +132,11 @@ typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 #endif
 constexpr bool KE_DMAJOR = TB_KE_DMAJOR; // stored-Kₑ row layout of the matrix-core kernel: [d][b] or [b][d]
 
-template <class FE, bool NEED_K, bool NEED_R, bool MFMA>
+// AD: the material is any energy of tb_energy.hpp, differentiated per pair of components of F by hyper-dual evaluation (the
+// reference's Tensors.hessian path); !AD: Holzapfel–Ogden 2009 + SimpleCompressionPenalty with the hand-derived routines.
+template <class FE, bool NEED_K, bool NEED_R, bool MFMA, bool AD>
 __global__ void __launch_bounds__(FE::THREADS, FE::WAVES)
-k_hyperelastic(MechMesh m, HOParams mat, const int32_t *__restrict__ list, const double *__restrict__ u, double *__restrict__ nz,
+k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restrict__ list, const double *__restrict__ u, double *__restrict__ nz,
                double *__restrict__ r, const int64_t *__restrict__ rowptr, const uint16_t *__restrict__ blockpos, int atomic /*0 rmw, 1 atomic, 2 store Kₑ/rₑ*/,
                double *__restrict__ ke, double *__restrict__ re, Status *st)
 {
@@ -196,6 +199,43 @@ k_hyperelastic(MechMesh m, HOParams mat, const int32_t *__restrict__ list, const
         s_JI[q][ck] = v; // J⁻¹ is dead after A2: its slots carry F from here on
     }
     __syncthreads();
+    if constexpr (AD) {
+        // A3b': frame and active tension of every point (constant, or interpolated nodal data like OrthotropicMicrostructureModel)
+        if (tid < NQ) {
+            double f[3] = {mat.f[0], mat.f[1], mat.f[2]}, sv[3] = {mat.s[0], mat.s[1], mat.s[2]}, n[3] = {mat.n[0], mat.n[1], mat.n[2]};
+            if (m.fsn_field) {
+                for (int d = 0; d < 3; ++d) { f[d] = 0.0; sv[d] = 0.0; n[d] = 0.0; }
+                const double *fc = m.fsn_field + cell * 72;
+                for (int a = 0; a < 8; ++a) {
+                    const double Na = tb.M[tid][a];
+                    for (int d = 0; d < 3; ++d) { f[d] += Na * fc[9 * a + d]; sv[d] += Na * fc[9 * a + 3 + d]; n[d] += Na * fc[9 * a + 6 + d]; }
+                }
+                ho_orthonormal_frame(f, sv, n);
+            }
+            double ta = en.Ta;
+            if (m.act_field) { double ca = 0.0; for (int a = 0; a < 8; ++a) ca += tb.M[tid][a] * m.act_field[cell * 8 + a]; ta *= ca; }
+            double *o = s_C[tid];
+            for (int d = 0; d < 3; ++d) { o[d] = f[d]; o[3 + d] = sv[d]; o[6 + d] = n[d]; }
+            o[9] = ta;
+        }
+        __syncthreads();
+        // A3c': one lane per (point, pair of components of F): Ψ.a = P_m, Ψ.ab = 𝔸_mn = 𝔸_nm
+        constexpr int NP = NEED_K ? 45 : 9;
+        for (int t = tid; t < NQ * NP; t += T) {
+            const int q = t / NP, pr = t - q * NP;
+            int mm = pr, nn = pr;
+            if constexpr (NEED_K) pair_components(pr, mm, nn);
+            EnergyParams e = en;
+            const double *o = s_C[q];
+            e.Ta = o[9];
+            const double f[3] = {o[0], o[1], o[2]}, sv[3] = {o[3], o[4], o[5]}, n[3] = {o[6], o[7], o[8]};
+            const HD r = energy_pair(e, s_JI[q], mm, nn, f, sv, n);
+            const double dO = s_JI[q][9];
+            if constexpr (NEED_K) { s_A[q][9 * mm + nn] = r.ab * dO; s_A[q][9 * nn + mm] = r.ab * dO; }
+            if (mm == nn) s_P[q][mm] = r.a * dO;
+        }
+        __syncthreads();
+    } else {
     // A3b: the quantities shared by all entries of P and 𝔸 at a point (one lane per point)
     if (tid < NQ) {
         double F[3][3];
@@ -238,6 +278,7 @@ k_hyperelastic(MechMesh m, HOParams mat, const int32_t *__restrict__ list, const
     }
     __syncthreads();
 
+    }
     double racc = 0.0;
     if constexpr (NEED_K && MFMA) {
         // B (matrix cores).  Kₑ is symmetric (𝔸 has major symmetry), so of the 6×3×2 tiles (M-tile mt, component d, N-tile nt)
@@ -509,8 +550,36 @@ static HOParams make_params(const tb_form *f)
     return p;
 }
 
+static bool material_is_fast_path(const tb_material &mat) { return mat.kind == TB_MATERIAL_HOLZAPFEL_OGDEN_2009 && mat.reserved == PEN_SIMPLE; }
+
+static EnergyParams make_energy_params(const tb_form *f)
+{
+    EnergyParams e{};
+    e.energy = f->mat.kind; e.penalty = f->mat.reserved;
+    for (int i = 0; i < 9; ++i) e.p[i] = f->mat.p[i];
+    for (int i = 0; i < 3; ++i) e.u[i] = f->mat.p[10 + i];
+    e.Ta = f->act_tension;
+    return e;
+}
+
 int host_material_eval(const tb_material *mat, const double *F9, double *psi, double *P, double *A)
 {
+    if (!material_is_fast_path(*mat)) { // any energy of tb_energy.hpp: the same hyper-dual evaluation the kernels run, on the host
+        tb_form tmpf;
+        tmpf.mat = *mat;
+        tmpf.act_tension = mat->p[9];
+        const EnergyParams e = make_energy_params(&tmpf);
+        const double f0[3] = {mat->f[0], mat->f[1], mat->f[2]}, s0[3] = {mat->s[0], mat->s[1], mat->s[2]}, n0[3] = {mat->n[0], mat->n[1], mat->n[2]};
+        for (int pr = 0; pr < 45; ++pr) {
+            int mm, nn;
+            pair_components(pr, mm, nn);
+            const HD r = energy_pair(e, F9, mm, nn, f0, s0, n0);
+            if (psi) *psi = r.v;
+            if (P && mm == nn) P[mm] = r.a;
+            if (A) { A[9 * mm + nn] = r.ab; A[9 * nn + mm] = r.ab; }
+        }
+        return TB_OK;
+    }
     tb_form tmp;
     tmp.mat = *mat;
     tmp.act_tension = mat->p[9];
@@ -572,13 +641,14 @@ int ensure_blockpos(tb_pattern *p)
     return TB_OK;
 }
 
-template <class FE, bool NEED_K, bool NEED_R, bool MFMA>
+template <class FE, bool NEED_K, bool NEED_R, bool MFMA, bool AD>
 static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, double *d_nz, double *d_r)
 {
     tb_mesh *m = f->mesh;
     tb_device *dev = m->dev;
     const MechMesh mm{m->d_xyz, m->d_conn, m->d_cell_dofs, f->d_field, f->d_act_field};
     const HOParams hp = make_params(f);
+    const EnergyParams ep = make_energy_params(f);
     const bool ea = strategy == TB_STRATEGY_ELEMENT || strategy == TB_STRATEGY_PATCH;
     if (NEED_K) {
         int rc = ensure_blockpos(p);
@@ -591,7 +661,7 @@ static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, doubl
     double *kebuf = nullptr, *rebuf = nullptr;
     auto go = [&](const int32_t *list, int64_t n, int atomic) -> int {
         if (!n) return TB_OK;
-        hipLaunchKernelGGL((k_hyperelastic<FE, NEED_K, NEED_R, MFMA>), dim3((unsigned)n), dim3(FE::THREADS), 0, dev->stream, mm, hp, list, d_u, d_nz, d_r,
+        hipLaunchKernelGGL((k_hyperelastic<FE, NEED_K, NEED_R, MFMA, AD>), dim3((unsigned)n), dim3(FE::THREADS), 0, dev->stream, mm, hp, ep, list, d_u, d_nz, d_r,
                            rowptr, bp, atomic, kebuf, rebuf, dev->d_status);
         TB_HIP(hipGetLastError());
         return TB_OK;
@@ -650,11 +720,12 @@ int launch_hyperelastic(tb_form *f, tb_pattern *p, int strategy, const double *d
     if (q2 && f->qorder != 3) { set_error("hyperelastic: Q2 field needs quadrature order 3"); return TB_ERR_UNSUPPORTED; }
     // Q2 tangents run their contraction on the matrix cores; TB_MECH_MFMA=0 selects the vector-FMA build (comparison)
     static const bool mfma = !(getenv("TB_MECH_MFMA") && atoi(getenv("TB_MECH_MFMA")) == 0);
-    if (d_nz && d_r) rc = !q2 ? run<Q1Vec, true, true, false>(f, p, strategy, d_u, d_nz, d_r)
-                         : mfma ? run<Q2Vec, true, true, true>(f, p, strategy, d_u, d_nz, d_r) : run<Q2Vec, true, true, false>(f, p, strategy, d_u, d_nz, d_r);
-    else if (d_nz) rc = !q2 ? run<Q1Vec, true, false, false>(f, p, strategy, d_u, d_nz, d_r)
-                        : mfma ? run<Q2Vec, true, false, true>(f, p, strategy, d_u, d_nz, d_r) : run<Q2Vec, true, false, false>(f, p, strategy, d_u, d_nz, d_r);
-    else rc = q2 ? run<Q2Vec, false, true, false>(f, p, strategy, d_u, d_nz, d_r) : run<Q1Vec, false, true, false>(f, p, strategy, d_u, d_nz, d_r);
+    const bool ad = !material_is_fast_path(f->mat);
+#define TB_RUN(FEV, K, R, MF) (ad ? run<FEV, K, R, MF, true>(f, p, strategy, d_u, d_nz, d_r) : run<FEV, K, R, MF, false>(f, p, strategy, d_u, d_nz, d_r))
+    if (d_nz && d_r) rc = !q2 ? TB_RUN(Q1Vec, true, true, false) : (mfma || ad) ? TB_RUN(Q2Vec, true, true, true) : run<Q2Vec, true, true, false, false>(f, p, strategy, d_u, d_nz, d_r);
+    else if (d_nz) rc = !q2 ? TB_RUN(Q1Vec, true, false, false) : (mfma || ad) ? TB_RUN(Q2Vec, true, false, true) : run<Q2Vec, true, false, false, false>(f, p, strategy, d_u, d_nz, d_r);
+    else rc = q2 ? TB_RUN(Q2Vec, false, true, false) : TB_RUN(Q1Vec, false, true, false);
+#undef TB_RUN
     if (rc) return rc;
     return check_status(m->dev);
 }
