@@ -220,6 +220,26 @@ int tb_linearize(tb_form *form, tb_pattern *pat, int strategy, const double *d_u
  * per cell, n_cells×8 host values copied to the device) or Ta = tension when state_field is NULL.  tb_material.p[9] is the
  * initial uniform tension.  Call again whenever the calcium transient advances (host values → device, O(cells)). */
 int tb_hyperelastic_set_active_tension(tb_form *form, double tension, const double *state_field, int64_t len);
+/* Hill-type frameworks (src/modeling/solid/materials.jl:1042-1190): W(F) = W_passive(F) + [𝓝] W_active(F·Fᵃ⁻¹), Fᵃ from an active
+ * deformation gradient model (src/modeling/solid/active.jl:23-96) and the steady-state stretch λᵃ of a calcium-driven sarcomere model
+ * (src/modeling/solid/contraction.jl:166-175,302-320).  framework: generalized (no 𝓝) or extended (𝓝 = calcium-driven state).  The
+ * active spring is ActiveMaterialAdapter(energy) — active_energy = TB_MATERIAL_*, active_p = 9 energy + 3 penalty parameters — or
+ * SimpleActiveSpring (TB_ACTIVE_SIMPLE_SPRING, active_p[0] = aᶠ).  The calcium state reaches the kernels through
+ * tb_hyperelastic_set_active_tension (tension = uniform Ca, or 1 with a nodal Ca field).  Differentiated on the device like the
+ * other energies. */
+enum { TB_HILL_NONE = 0, TB_HILL_GENERALIZED = 1, TB_HILL_EXTENDED = 2 };
+enum { TB_ACTIVE_SIMPLE_SPRING = 100 };
+enum { TB_ADG_GMK = 0, TB_ADG_GMK_INCOMPRESSIBLE = 1, TB_ADG_RLRSQ = 2 };
+enum { TB_SARCOMERE_PELCE_SUN_LANGEVELD_1995 = 0 /* β, λᵃₘₐₓ */, TB_SARCOMERE_CONSTANT_STRETCH = 1 /* λ */ };
+typedef struct {
+    int32_t framework, active_energy, active_penalty, adg_kind, sarcomere_kind;
+    double active_p[12];   /* 9 energy + 3 penalty parameters of the active spring */
+    double sheetlet_part;  /* RLRSQ */
+    double sarcomere_p[2];
+} tb_hill;
+int tb_hyperelastic_set_hill(tb_form *form, const tb_hill *hill); /* NULL or framework = TB_HILL_NONE: plain PK1Model */
+/* host evaluation of the whole constitutive law at one point (the code the kernels run): activation = Ta or the calcium state */
+int tb_host_material_eval_hill(const tb_material *material, const tb_hill *hill, double activation, const double *F, double *psi, double *P, double *A);
 /* Weak boundary conditions of a quasi-static problem (src/modeling/core/weak_boundary_conditions.jl): RobinBC
  * Ψ = α u·u (:102-198), NormalSpringBC Ψ = ½ kₛ (u·N)² (:200-300), ConstantPressureBC follower load p·J·F⁻ᵀ·n₀ with its
  * consistent tangent (:419-515).  `facets` lists n_facets pairs (cell, local facet) — Ferrite's FacetIndex, local facets of
@@ -271,6 +291,11 @@ int tb_spmv_csr(tb_pattern *pat, const double *d_nzval, const double *d_x, doubl
  * Stops when ‖r‖₂ ≤ atol + rtol·‖r₀‖₂ or after maxiter iterations; reports iterations and the final ‖r‖₂. */
 int tb_cg_solve(tb_pattern *pat, const double *d_Anz, const double *d_b, double *d_x, double rtol, double atol, int maxiter,
                 int jacobi, int *iters, double *resnorm);
+/* Restarted GMRES(restart) with right Jacobi preconditioning — the reference's default Newton inner solver
+ * (LinearSolve.KrylovJL_GMRES(), src/solver/nonlinear/newton_raphson.jl:61) — for tangents that are not symmetric positive definite.
+ * Same stopping test as tb_cg_solve on the true residual. */
+int tb_gmres_solve(tb_pattern *pattern, const double *d_Anz, const double *d_b, double *d_x, double rtol, double atol, int maxiter, int restart,
+                   int jacobi, int *iters, double *resnorm);
 /* y += x (add!(b, source), src/solver/time/euler.jl:90) and max |x[i]| over a strided slice
  * (RTC reads max(dumat[:,φₘidx]), src/solver/time/rtc.jl:64-73) */
 int tb_axpy(tb_device *dev, int64_t n, double a, const double *d_x, double *d_y);

@@ -349,6 +349,29 @@ def set_material(energy=0, penalty=0, p=None, up=None):
     lib().orc_set_material(int(energy), int(penalty), _d(pp), _d(uu))
 
 
+HILL_NONE, HILL_GENERALIZED, HILL_EXTENDED = 0, 1, 2
+ACT_SIMPLE_ACTIVE_SPRING = 100
+ADG_GMK, ADG_GMK_INCOMPRESSIBLE, ADG_RLRSQ = 0, 1, 2
+SARC_PSL1995, SARC_CONSTANT_STRETCH = 0, 1
+
+
+def set_hill(framework=0, act_energy=0, act_penalty=0, act_p=None, adg=0, kappa=0.0, sarc=0, sarc_p=(0.0, 0.0)):
+    """Generalized / ExtendedHillModel over the material of set_material (global; set_hill() switches it off).  The calcium
+    state is given with set_active_tension(Ca[, nodal field])."""
+    ap = np.zeros(12)
+    if act_p is not None: ap[:len(act_p)] = act_p
+    sp = np.zeros(2); sp[:len(sarc_p)] = sarc_p
+    lib().orc_set_hill.restype = None
+    lib().orc_set_hill.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p]
+    lib().orc_set_hill(int(framework), int(act_energy), int(act_penalty), ap.ctypes.data, int(adg), float(kappa), int(sarc), sp.ctypes.data)
+
+
+def set_point_activation(a):
+    """activation seen by direct energy() calls: Ta of the active stress or the calcium state of a Hill framework"""
+    lib().orc_set_point_activation.restype = None
+    lib().orc_set_point_activation(C.c_double(float(a)))
+
+
 BC_ROBIN, BC_NORMAL_SPRING, BC_PRESSURE, BC_BENDING_SPRING, BC_PRESSURE_FIELD = 0, 1, 2, 3, 4
 _PF_KEEP = [None]
 

@@ -1108,6 +1108,8 @@ static hd hd_cbrt(hd u) { double c = cbrt(u.v); return hd_chain(u, c, c / (3.0 *
 static hd hd_inv(hd u) { return hd_chain(u, 1.0 / u.v, -1.0 / (u.v * u.v), 2.0 / (u.v * u.v * u.v)); }
 
 /* Ψ of HolzapfelOgden2009Model with SimpleCompressionPenalty, src/modeling/solid/energies.jl:147-168 and :83-87 */
+typedef struct { int framework, act_energy, act_penalty, adg, sarc; double ap[9], au[3], kappa, sp[2]; } hill_desc;
+static hill_desc g_hill; /* test infrastructure: global state like g_mat_* */
 static _Thread_local double g_active_tension = 0.0; /* Ta = Tmax·𝓝 at the point being evaluated (set by the element routine) */
 static hd ho_psi(const double *p, const double *fsn, hd F[3][3])
 {
@@ -1269,15 +1271,96 @@ static hd psi_generic(int energy, int penalty, const double *p, const double *up
         if (I4s.v >= 1.0) { hd d = hd_addc(I4s, -1.0); psi = hd_add(psi, hd_scale(hd_addc(hd_exp(hd_scale(hd_mul(d, d), p[5])), -1.0), p[4] / (2.0 * p[5]))); }
     }
     }
-    if (g_active_tension != 0.0) psi = hd_add(psi, hd_scale(hd_sqrt(quadC(C, f0, f0)), g_active_tension));
+    if (g_active_tension != 0.0 && !g_hill.framework) psi = hd_add(psi, hd_scale(hd_sqrt(quadC(C, f0, f0)), g_active_tension));
     return psi;
 }
+
+/* Hill-type frameworks.  GeneralizedHillModel (materials.jl:1042-1113): Ψ = Ψᵖ(F) + Ψᵃ(F, Fᵃ); ExtendedHillModel
+ * (materials.jl:1119-1190): Ψ = Ψᵖ(F) + 𝓝(state)·Ψᵃ(F, Fᵃ), 𝓝 = state for the steady-state sarcomere models
+ * (contraction.jl:313).  Fᵃ = compute_Fᵃ(state, f₀, s₀, n₀, contraction, adg) (active.jl:23-96) with λᵃ = compute_λᵃ(Ca, …)
+ * (contraction.jl:302-320).  ActiveMaterialAdapter (active.jl:8-21): Ψ(F·Fᵃ⁻¹) in the frame Fᵃf₀/‖Fᵃf₀‖, …;
+ * SimpleActiveSpring (energies.jl:334-347): aᶠ/2 (f₀·Cᵉf₀ − 1)². */
+static void inv3(const double *M, double *Mi)
+{
+    double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
+    double det = M[0] * c00 + M[1] * c01 + M[2] * c02;
+    Mi[0] = c00 / det; Mi[1] = (M[2] * M[7] - M[1] * M[8]) / det; Mi[2] = (M[1] * M[5] - M[2] * M[4]) / det;
+    Mi[3] = c01 / det; Mi[4] = (M[0] * M[8] - M[2] * M[6]) / det; Mi[5] = (M[2] * M[3] - M[0] * M[5]) / det;
+    Mi[6] = c02 / det; Mi[7] = (M[1] * M[6] - M[0] * M[7]) / det; Mi[8] = (M[0] * M[4] - M[1] * M[3]) / det;
+}
+#pragma GCC diagnostic push
+#pragma GCC diagnostic ignored "-Wstringop-overflow" /* gcc 11 false positive on the hd[3][3] argument below */
+__attribute__((noinline)) static hd psi_total(int energy, int penalty, const double *p, const double *up, const double *fsn, hd F[3][3])
+{
+    hd psi = psi_generic(energy, penalty, p, up, fsn, F);
+    if (!g_hill.framework) return psi;
+    const double *f0 = fsn, *s0 = fsn + 3, *n0 = fsn + 6;
+    const double Ca = g_active_tension;
+    double la;
+    if (g_hill.sarc == 1) la = g_hill.sp[0];
+    else {
+        double fr = Ca > 0.0 ? 0.5 + atan(g_hill.sp[0] * log(Ca)) / M_PI : 0.0;
+        la = 1.0 / (1.0 + fr * (1.0 / g_hill.sp[1] - 1.0));
+    }
+    double Fa[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double ff = f0[i] * f0[j], ss = s0[i] * s0[j], nn = n0[i] * n0[j];
+            if (g_hill.adg == 0) Fa[3 * i + j] = (i == j) + (la - 1.0) * ff;
+            else if (g_hill.adg == 1) Fa[3 * i + j] = la * ff + (ss + nn) / sqrt(la);
+            else { double ls = g_hill.kappa * (la - 1.0) + 1.0; Fa[3 * i + j] = la * ff + ls * ss + nn / (ls * la); }
+        }
+    double Fai[9];
+    inv3(Fa, Fai);
+    hd Fe[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            hd a = hd_const(0.0);
+            for (int k = 0; k < 3; ++k) a = hd_add(a, hd_scale(F[i][k], Fai[3 * k + j]));
+            Fe[i][j] = a;
+        }
+    hd pa;
+    if (g_hill.act_energy == 100) {
+        hd i4 = hd_const(0.0);
+        for (int k = 0; k < 3; ++k) {
+            hd v = hd_const(0.0);
+            for (int j = 0; j < 3; ++j) v = hd_add(v, hd_scale(Fe[k][j], f0[j]));
+            i4 = hd_add(i4, hd_mul(v, v));
+        }
+        hd d = hd_addc(i4, -1.0);
+        pa = hd_scale(hd_mul(d, d), 0.5 * g_hill.ap[0]);
+    } else {
+        double fr[9];
+        for (int w = 0; w < 3; ++w) { /* f̃ = Fᵃf₀/‖Fᵃf₀‖, s̃, ñ likewise */
+            double v[3], nv = 0;
+            for (int i = 0; i < 3; ++i) { v[i] = Fa[3 * i] * fsn[3 * w] + Fa[3 * i + 1] * fsn[3 * w + 1] + Fa[3 * i + 2] * fsn[3 * w + 2]; nv += v[i] * v[i]; }
+            for (int i = 0; i < 3; ++i) fr[3 * w + i] = v[i] / sqrt(nv);
+        }
+        double sv = g_active_tension; g_active_tension = 0.0; /* no active-stress term inside the spring */
+        pa = psi_generic(g_hill.act_energy, g_hill.act_penalty, g_hill.ap, g_hill.au, fr, Fe);
+        g_active_tension = sv;
+    }
+    return hd_add(psi, g_hill.framework == 2 ? hd_scale(pa, Ca) : pa);
+}
+#pragma GCC diagnostic pop
+void orc_set_hill(int framework, int act_energy, int act_penalty, const double *act_p, int adg, double kappa, int sarc, const double *sarc_p)
+{
+    memset(&g_hill, 0, sizeof g_hill);
+    g_hill.framework = framework;
+    if (!framework) return;
+    g_hill.act_energy = act_energy; g_hill.act_penalty = act_penalty; g_hill.adg = adg; g_hill.kappa = kappa; g_hill.sarc = sarc;
+    memcpy(g_hill.ap, act_p, 9 * sizeof(double)); memcpy(g_hill.au, act_p + 9, 3 * sizeof(double));
+    g_hill.sp[0] = sarc_p[0]; g_hill.sp[1] = sarc_p[1];
+}
+
+/* point-level activation for direct orc_energy calls (Ta of the active stress, or the calcium state of a Hill framework) */
+void orc_set_point_activation(double a) { g_active_tension = a; }
 
 double orc_energy(int energy, int penalty, const double *p, const double *up, const double *fsn, const double *F, double *P, double *A)
 {
     hd Fd[3][3];
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Fd[i][j] = hd_var(F[3 * i + j], 3 * i + j);
-    hd psi = psi_generic(energy, penalty, p, up, fsn, Fd);
+    hd psi = psi_total(energy, penalty, p, up, fsn, Fd);
     if (P) for (int i = 0; i < 9; ++i) P[i] = psi.g[i];
     if (A) for (int i = 0; i < 9; ++i) for (int j = 0; j < 9; ++j) A[9 * i + j] = psi.h[hidx(i, j)];
     return psi.v;
@@ -1335,12 +1418,13 @@ static int element_hyperelastic_cv(const orc_mesh *m, const cellvalues *cv, int6
             fsn = frame;
         }
         g_active_tension = g_act_scale;
-        if (g_act_field && g_act_scale != 0.0) {
+        if (g_act_field && g_act_scale != 0.0) { /* with a Hill framework the same slot carries the calcium state */
             double ca = 0.0;
             for (int a = 0; a < cv->ngeo; ++a) ca += cv->M[q][a] * g_act_field[(int64_t)cell * cv->ngeo + a];
             g_active_tension = g_act_scale * ca;
         }
-        if (g_mat_energy == 0 && g_mat_penalty == 0) orc_ho_energy(p, fsn, F, P, Ke ? A : NULL);
+        if (g_mat_energy == 0 && g_mat_penalty == 0 && !g_hill.framework) orc_ho_energy(p, fsn, F, P, Ke ? A : NULL);
+        else if (g_mat_energy == 0 && g_mat_penalty == 0) { double up[3] = {p[8], 0, 0}; orc_energy(0, 0, p, up, fsn, F, P, Ke ? A : NULL); }
         else orc_energy(g_mat_energy, g_mat_penalty, g_mat_p, g_mat_u, fsn, F, P, Ke ? A : NULL);
         g_active_tension = 0.0;
         for (int i = 0; i < nd; ++i) {

@@ -186,6 +186,8 @@ int orc_assemble_hyperelastic(const orc_mesh *m, const double *p, const double *
 void orc_set_facet_pressure_field(const double *field_per_cell_node /* n_cells×8 or NULL */);
 /* any energy of src/modeling/solid/energies.jl (ids as in thunderbolt.jl_amd/csrc/tb_energy.hpp) by hyper-dual AD */
 double orc_energy(int energy, int penalty, const double *p, const double *up, const double *fsn, const double *F, double *P, double *A);
+void orc_set_point_activation(double a);
+void orc_set_hill(int framework, int act_energy, int act_penalty, const double *act_p, int adg, double kappa, int sarc, const double *sarc_p);
 void orc_set_material(int energy, int penalty, const double *p /* 9 */, const double *up /* 3: β, a, b */);
 void orc_set_active_tension(double tension, const double *field_per_cell_node /* n_cells×8 or NULL */);
 int orc_element_facet(const orc_mesh *m, int64_t cell, int local_facet, int kind, double param, int fq, const double *ue,

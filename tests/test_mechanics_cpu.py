@@ -255,3 +255,70 @@ def test_compression_penalties_with_holzapfel_ogden(tb, oracle, pen):
         np.testing.assert_allclose(P, rP, rtol=1e-11, atol=1e-12 * np.abs(rA).max())
         np.testing.assert_allclose(A, rA, rtol=1e-10, atol=1e-12 * np.abs(rA).max())
         assert psi == pytest.approx(rpsi, rel=1e-12)
+
+
+def _hill_cases(tb):
+    """The Hill-type material set-ups of the reference's contractile-cuboid integration test
+    (test/integration/test_solid_mechanics.jl:300-360), plus the remaining spring / deformation-gradient / sarcomere variants."""
+    psl = lambda ca: tb.CaDrivenInternalSarcomereModel(tb.PelceSunLangeveld1995Model(), ca)
+    return [
+        ("ExtendedHillModel", tb.HolzapfelOgden2009Model(), tb.ActiveMaterialAdapter(tb.LinearSpringModel()), tb.GMKActiveDeformationGradientModel(), psl),
+        ("GeneralizedHillModel", tb.LinYinPassiveModel(), tb.ActiveMaterialAdapter(tb.LinYinActiveModel()), tb.GMKIncompressibleActiveDeformationGradientModel(), psl),
+        ("GeneralizedHillModel", tb.HumphreyStrumpfYinModel(), tb.ActiveMaterialAdapter(tb.LinearSpringModel()), tb.RLRSQActiveDeformationGradientModel(0.75), psl),
+        ("ExtendedHillModel", tb.HolzapfelOgden2009Model(), tb.SimpleActiveSpring(), tb.RLRSQActiveDeformationGradientModel(0.25), psl),
+        ("GeneralizedHillModel", tb.BioNeoHookean(), tb.SimpleActiveSpring(2.0), tb.GMKActiveDeformationGradientModel(),
+         lambda ca: tb.CaDrivenInternalSarcomereModel(tb.ConstantStretchModel(0.9), ca)),
+    ]
+
+
+def _oracle_hill(oracle, tb, model, ca):
+    h = model.lower_hill()
+    oracle.set_hill(h.framework, h.active_energy, h.active_penalty, list(h.active_p), h.adg_kind, h.sheetlet_part, h.sarcomere_kind, list(h.sarcomere_p))
+    oracle.set_point_activation(ca)
+
+
+@pytest.mark.parametrize("case", range(5))
+@pytest.mark.parametrize("ca", [0.0, 0.35, 1.0])
+def test_hill_frameworks_match_the_ad_oracle(tb, oracle, case, ca):
+    """GeneralizedHillModel / ExtendedHillModel (materials.jl:1042-1190) over every active deformation gradient model (active.jl:23-96)
+    and both steady-state sarcomere models: device routine (run on the host) against the oracle, which forms Fᵃ, inverts it numerically
+    and rotates the frame as ActiveMaterialAdapter does instead of using the closed forms of the kernels."""
+    rng = np.random.default_rng(21 + case)
+    f, s, n = np.linalg.qr(rng.normal(size=(3, 3)))[0].T
+    fw, passive, spring, adg, sarc = _hill_cases(tb)[case]
+    model = getattr(tb, fw)(passive, spring, adg, sarc(ca), tb.ConstantCoefficient(tb.OrthotropicMicrostructure(f, s, n)))
+    pm = tb.PK1Model(passive, tb.ConstantCoefficient(tb.OrthotropicMicrostructure(f, s, n))).lower()
+    try:
+        _oracle_hill(oracle, tb, model, ca)
+        for trial in range(3):
+            F = np.eye(3) + 0.1 * rng.normal(size=(3, 3))
+            psi, P, A = tb.material_routine(model, F)
+            rpsi, rP, rA = oracle.energy(pm.kind, pm.reserved, list(pm.p)[:9], list(pm.p)[10:13], F, fsn=np.stack([f, s, n]))
+            sc = max(1.0, np.abs(rA).max())
+            assert psi == pytest.approx(rpsi, rel=1e-12, abs=1e-13)
+            np.testing.assert_allclose(P, rP, rtol=1e-11, atol=1e-12 * sc)
+            np.testing.assert_allclose(A, rA, rtol=1e-10, atol=1e-12 * sc)
+    finally:
+        oracle.set_hill(); oracle.set_point_activation(0.0)
+
+
+def test_hill_without_calcium_reduces_to_the_springs_at_rest(tb, oracle):
+    """Ca = 0 ⇒ λᵃ = 1 ⇒ Fᵃ = I (contraction.jl:302-311): the generalized model is Ψᵖ(F) + Ψᵃ(F); the extended one (𝓝 = Ca = 0) is
+    the passive spring alone.  With Ca > 0 and the PSL1995 defaults the fibre shortens: P(I)·f₀·f₀ > 0 pulls along f₀."""
+    f, s, n = np.eye(3)
+    ms = tb.ConstantCoefficient(tb.OrthotropicMicrostructure(f, s, n))
+    rng = np.random.default_rng(5)
+    F = np.eye(3) + 0.1 * rng.normal(size=(3, 3))
+    sarc = tb.CaDrivenInternalSarcomereModel(tb.PelceSunLangeveld1995Model(), 0.0)
+    ext = tb.ExtendedHillModel(tb.HolzapfelOgden2009Model(), tb.ActiveMaterialAdapter(tb.LinearSpringModel()), tb.GMKActiveDeformationGradientModel(), sarc, ms)
+    gen = tb.GeneralizedHillModel(tb.HolzapfelOgden2009Model(), tb.ActiveMaterialAdapter(tb.LinearSpringModel()), tb.GMKActiveDeformationGradientModel(), sarc, ms)
+    p0 = tb.material_routine(tb.PK1Model(tb.HolzapfelOgden2009Model(), ms), F)
+    pa = tb.material_routine(tb.PK1Model(tb.LinearSpringModel(), ms), F)
+    pe, pg = tb.material_routine(ext, F), tb.material_routine(gen, F)
+    np.testing.assert_allclose(pe[1], p0[1], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(pg[1], p0[1] + pa[1], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(pg[2], p0[2] + pa[2], rtol=1e-12, atol=1e-13)
+    active = tb.GeneralizedHillModel(tb.HolzapfelOgden2009Model(), tb.ActiveMaterialAdapter(tb.LinearSpringModel()), tb.GMKActiveDeformationGradientModel(),
+                                     tb.CaDrivenInternalSarcomereModel(tb.PelceSunLangeveld1995Model(), 1.0), ms)
+    PI = tb.material_routine(active, np.eye(3))[1]
+    assert PI[0, 0] > 1e-3 and abs(PI[1, 1]) < 1e-12 and abs(PI[0, 1]) < 1e-12

@@ -37,6 +37,16 @@ class tb_material(C.Structure):
                 ("s", C.c_double * 3), ("n", C.c_double * 3), ("fsn_field", c_dp), ("fsn_field_len", C.c_int64)]
 
 
+class tb_hill(C.Structure):
+    _fields_ = [("framework", C.c_int32), ("active_energy", C.c_int32), ("active_penalty", C.c_int32), ("adg_kind", C.c_int32),
+                ("sarcomere_kind", C.c_int32), ("active_p", C.c_double * 12), ("sheetlet_part", C.c_double), ("sarcomere_p", C.c_double * 2)]
+
+
+TB_HILL_NONE, TB_HILL_GENERALIZED, TB_HILL_EXTENDED = 0, 1, 2
+TB_ACTIVE_SIMPLE_SPRING = 100
+TB_ADG_GMK, TB_ADG_GMK_INCOMPRESSIBLE, TB_ADG_RLRSQ = 0, 1, 2
+TB_SARCOMERE_PELCE_SUN_LANGEVELD_1995, TB_SARCOMERE_CONSTANT_STRETCH = 0, 1
+
 # name -> (restype, argtypes): every symbol include/tbhip.h declares
 SIGNATURES = {
     "tb_last_error_string": (C.c_char_p, []),
@@ -75,6 +85,8 @@ SIGNATURES = {
     "tb_residual": (C.c_int, [vp, C.c_int, vp, C.c_double, vp]),
     "tb_linearize": (C.c_int, [vp, vp, C.c_int, vp, C.c_double, vp, vp]),
     "tb_hyperelastic_set_active_tension": (C.c_int, [vp, C.c_double, c_dp, C.c_int64]),
+    "tb_hyperelastic_set_hill": (C.c_int, [vp, vp]),
+    "tb_host_material_eval_hill": (C.c_int, [vp, vp, C.c_double, c_dp, c_dp, c_dp, c_dp]),
     "tb_facet_form_create": (C.c_int, [vp, C.c_int, C.c_double, C.c_int, c_i32p, C.c_int64, C.c_int, C.POINTER(vp)]),
     "tb_facet_form_set_field": (C.c_int, [vp, c_dp, C.c_int64]),
     "tb_facet_assemble": (C.c_int, [vp, vp, vp, C.c_double, vp, vp]),
@@ -89,6 +101,7 @@ SIGNATURES = {
     "tb_heat_matrix": (C.c_int, [vp, C.c_int64, vp, vp, C.c_double, vp]),
     "tb_spmv_csr": (C.c_int, [vp, vp, vp, C.c_double, C.c_double, vp]),
     "tb_cg_solve": (C.c_int, [vp, vp, vp, vp, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "tb_gmres_solve": (C.c_int, [vp, vp, vp, vp, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "tb_axpy": (C.c_int, [vp, C.c_int64, C.c_double, vp, vp]),
     "tb_absmax": (C.c_int, [vp, C.c_int64, vp, C.c_int64, C.POINTER(C.c_double)]),
     "tb_dot": (C.c_int, [vp, C.c_int64, vp, vp, C.POINTER(C.c_double)]),

@@ -991,6 +991,101 @@ class ActiveStressModel:
         return m
 
 
+class ActiveMaterialAdapter:
+    """ActiveMaterialAdapter(mat): Ψᵃ(F, Fᵃ) = Ψ_mat(F·Fᵃ⁻¹) in the frame carried along by Fᵃ (src/modeling/solid/active.jl:8-21)."""
+
+    def __init__(self, mat):
+        self.mat = mat
+
+
+class SimpleActiveSpring:
+    """SimpleActiveSpring(; aᶠ = 1): Ψᵃ = aᶠ/2 (f₀·Cᵉ f₀ − 1)², Cᵉ = Fᵉᵀ Fᵉ, Fᵉ = F·Fᵃ⁻¹ (energies.jl:334-347)."""
+
+    def __init__(self, af=1.0):
+        self.af = float(af)
+
+
+class GMKActiveDeformationGradientModel:
+    """Fᵃ = I + (λᵃ − 1) f₀⊗f₀ (active.jl:23-39)."""
+    adg, sheetlet_part = L.TB_ADG_GMK, 0.0
+
+
+class GMKIncompressibleActiveDeformationGradientModel:
+    """Fᵃ = λᵃ f₀⊗f₀ + λᵃ^(-1/2) (s₀⊗s₀ + n₀⊗n₀) (active.jl:42-62)."""
+    adg, sheetlet_part = L.TB_ADG_GMK_INCOMPRESSIBLE, 0.0
+
+
+class RLRSQActiveDeformationGradientModel:
+    """RLRSQActiveDeformationGradientModel(sheetlet_part): Fᵃ = λᵃ f⊗f + (1 + κ(λᵃ−1)) s⊗s + n⊗n / ((1 + κ(λᵃ−1)) λᵃ) (active.jl:65-96)."""
+    adg = L.TB_ADG_RLRSQ
+
+    def __init__(self, sheetlet_part):
+        self.sheetlet_part = float(sheetlet_part)
+
+
+class _HillModel:
+    framework = L.TB_HILL_NONE
+
+    def __init__(self, passive_spring, active_spring, active_deformation_gradient_model, contraction_model, microstructure_model):
+        self.passive = PK1Model(passive_spring, microstructure_model)
+        self.active_spring, self.adg_model, self.contraction_model = active_spring, active_deformation_gradient_model, contraction_model
+        self.material, self.microstructure = self.passive.material, self.passive.microstructure
+
+    def activation(self, t):
+        """(scale, nodal field or None) of the calcium state at time t"""
+        st = self.contraction_model.state(t) if hasattr(self.contraction_model, "state") else 1.0
+        if np.ndim(st) == 0:
+            return float(st), None
+        return 1.0, np.ascontiguousarray(st, dtype=np.float64)
+
+    tension = activation
+
+    def lower(self, t=0.0):
+        m = self.passive.lower()
+        scale, field = self.activation(t)
+        m.p[9] = scale if field is None else 0.0
+        return m
+
+    def lower_hill(self):
+        h = L.tb_hill()
+        h.framework = self.framework
+        a = self.active_spring
+        if isinstance(a, SimpleActiveSpring):
+            h.active_energy, h.active_penalty = L.TB_ACTIVE_SIMPLE_SPRING, 0
+            h.active_p[0] = a.af
+        elif isinstance(a, ActiveMaterialAdapter):
+            am = PK1Model(a.mat, self.microstructure).lower()
+            h.active_energy, h.active_penalty = am.kind, am.reserved
+            for i in range(9):
+                h.active_p[i] = am.p[i]
+            for i in range(3):
+                h.active_p[9 + i] = am.p[10 + i]
+        else:
+            raise TypeError("active spring: ActiveMaterialAdapter(energy) or SimpleActiveSpring expected")
+        h.adg_kind, h.sheetlet_part = self.adg_model.adg, self.adg_model.sheetlet_part
+        sm = getattr(self.contraction_model, "model", self.contraction_model)
+        if isinstance(sm, PelceSunLangeveld1995Model):
+            h.sarcomere_kind = L.TB_SARCOMERE_PELCE_SUN_LANGEVELD_1995
+            h.sarcomere_p[0], h.sarcomere_p[1] = sm.beta, sm.lambda_a_max
+        elif isinstance(sm, ConstantStretchModel):
+            h.sarcomere_kind = L.TB_SARCOMERE_CONSTANT_STRETCH
+            h.sarcomere_p[0] = sm.lam
+        else:
+            raise TypeError("Hill frameworks: a steady-state sarcomere model (PelceSunLangeveld1995Model, ConstantStretchModel) is expected")
+        return h
+
+
+class GeneralizedHillModel(_HillModel):
+    """GeneralizedHillModel(passive_spring, active_spring, active_deformation_gradient_model, contraction_model,
+    microstructure_model): Ψ = Ψᵖ(F) + Ψᵃ(F, Fᵃ) (src/modeling/solid/materials.jl:1042-1113)."""
+    framework = L.TB_HILL_GENERALIZED
+
+
+class ExtendedHillModel(_HillModel):
+    """ExtendedHillModel(…): Ψ = Ψᵖ(F) + 𝓝(state)·Ψᵃ(F, Fᵃ) (materials.jl:1119-1190)."""
+    framework = L.TB_HILL_EXTENDED
+
+
 class RobinBC:
     """RobinBC(α, boundary_name): P·n₀ = −α u (weak_boundary_conditions.jl:23-26; energy α u·u)."""
     kind = L.TB_BC_ROBIN
@@ -1044,13 +1139,18 @@ class QuasiStaticModel:
         self.sym, self.constitutive_model, self.facet_models = sym, constitutive_model, tuple(facet_models)
 
 
-def material_routine(model, F):
+def material_routine(model, F, t=0.0):
     """Host evaluation of the device material routine: (Ψ, P, 𝔸) with 𝔸[3i+j, 3k+l] = ∂P_ij/∂F_kl."""
-    m = model.lower()
     F = np.ascontiguousarray(F, dtype=np.float64)
     psi = C.c_double()
     P = np.zeros((3, 3))
     A = np.zeros((9, 9))
+    if isinstance(model, _HillModel):
+        m, h = model.lower(t), model.lower_hill()
+        check(lib().tb_host_material_eval_hill(C.byref(m), C.byref(h), m.p[9], F.ctypes.data_as(L.c_dp), C.byref(psi), P.ctypes.data_as(L.c_dp),
+                                               A.ctypes.data_as(L.c_dp)))
+        return psi.value, P, A
+    m = model.lower()
     check(lib().tb_host_material_eval(C.byref(m), F.ctypes.data_as(L.c_dp), C.byref(psi), P.ctypes.data_as(L.c_dp), A.ctypes.data_as(L.c_dp)))
     return psi.value, P, A
 
@@ -1065,6 +1165,9 @@ class NonlinearOperator:
         self._mat = model.constitutive_model.lower()
         self.form = C.c_void_p()
         check(lib().tb_hyperelastic_create(self.dmesh.h, qorder, C.byref(self._mat), C.byref(self.form)))
+        if isinstance(model.constitutive_model, _HillModel):
+            self._hill = model.constitutive_model.lower_hill()
+            check(lib().tb_hyperelastic_set_hill(self.form, C.byref(self._hill)))
         self.J = DeviceVector(strategy.device, pattern.nnz)
         # surface terms: one facet form per weak boundary condition (setup_boundary_cache, weak_boundary_conditions.jl:1-7)
         self.facet_forms = []
@@ -1089,7 +1192,7 @@ class NonlinearOperator:
 
 def _sync_active_tension(op, t):
     cm = op.model.constitutive_model
-    if isinstance(cm, ActiveStressModel):
+    if isinstance(cm, (ActiveStressModel, _HillModel)):
         scale, field = cm.tension(t)
         check(lib().tb_hyperelastic_set_active_tension(op.form, float(scale), None if field is None else field.ctypes.data_as(L.c_dp),
                                                        0 if field is None else field.size))
@@ -1174,9 +1277,16 @@ def norm(x):
 class NewtonRaphsonSolver:
     """NewtonRaphsonSolver(; max_iter, tol, inner_solver) (src/solver/nonlinear/newton_raphson.jl:1-60); nlsolve!
     follows :215-320 — update_linearization!, eliminate constraints, residual norm over the free dofs, linear solve,
-    eliminate the increment, u .-= Δu, Θₖ contraction monitor, early exits — with Jacobi-CG as inner solver."""
+    eliminate the increment, u .-= Δu, Θₖ contraction monitor, early exits.  inner_solver: "cg" (Jacobi-PCG; symmetric positive
+    definite tangents) or "gmres" (restarted, right-Jacobi; the reference's default KrylovJL_GMRES — for indefinite or
+    non-symmetric tangents), or — LinearSolve.jl's pluggability — any callable (pattern, J, residual, Δu) → iterations that leaves the
+    solution of J Δu = residual in Δu (device vectors; the CSR structure is `pattern.sp.rowptr/colidx` on the host, J its values on the device)."""
 
-    def __init__(self, max_iter=100, tol=1e-4, inner_rtol=1e-8, inner_atol=1e-14, inner_maxiter=5000, enforce_monotonic_convergence=True):
+    def __init__(self, max_iter=100, tol=1e-4, inner_rtol=1e-8, inner_atol=1e-14, inner_maxiter=5000, enforce_monotonic_convergence=True,
+                 inner_solver="cg", gmres_restart=50):
+        if inner_solver not in ("cg", "gmres") and not callable(inner_solver):
+            raise ValueError("inner_solver: 'cg', 'gmres' or a callable (pattern, J, residual, Δu) -> linear iterations")
+        self.inner_solver, self.gmres_restart = inner_solver, gmres_restart
         self.max_iter, self.tol = max_iter, tol
         self.inner_rtol, self.inner_atol, self.inner_maxiter = inner_rtol, inner_atol, inner_maxiter
         self.enforce_monotonic_convergence = enforce_monotonic_convergence
@@ -1204,7 +1314,12 @@ def nlsolve(u, op, ch, solver, t=0.0):
             solver.theta.append(np.inf)
             return False
         du.fill_zero()
-        its, _ = cg_solve(op.pattern, op.J, res, du, solver.inner_rtol, solver.inner_atol, solver.inner_maxiter, True)
+        if callable(solver.inner_solver):
+            its = solver.inner_solver(op.pattern, op.J, res, du)
+        elif solver.inner_solver == "gmres":
+            its, _ = gmres_solve(op.pattern, op.J, res, du, solver.inner_rtol, solver.inner_atol, solver.inner_maxiter, solver.gmres_restart, True)
+        else:
+            its, _ = cg_solve(op.pattern, op.J, res, du, solver.inner_rtol, solver.inner_atol, solver.inner_maxiter, True)
         solver.linear_iters.append(its)
         apply_zero(None, du, ch, pattern=op.pattern)          # eliminate_constraints_from_increment!
         check(lib().tb_axpy(dev.h, u.n, -1.0, du.ptr, u.ptr))  # u .-= Δu
@@ -1226,6 +1341,14 @@ def cg_solve(pattern, A, b, x, rtol=1e-5, atol=1e-6, maxiter=1000, jacobi=True):
     it, res = C.c_int(), C.c_double()
     check(lib().tb_cg_solve(pattern.h, _ptr(A), _ptr(b), _ptr(x), float(rtol), float(atol), int(maxiter), int(jacobi),
                             C.byref(it), C.byref(res)))
+    return it.value, res.value
+
+
+def gmres_solve(pattern, A, b, x, rtol=1e-8, atol=1e-14, maxiter=5000, restart=50, jacobi=True):
+    """LinearSolve.solve! with KrylovJL_GMRES (the Newton default, newton_raphson.jl:61): restarted GMRES on the device."""
+    it, res = C.c_int(), C.c_double()
+    check(lib().tb_gmres_solve(pattern.h, _ptr(A), _ptr(b), _ptr(x), float(rtol), float(atol), int(maxiter), int(restart), int(jacobi),
+                               C.byref(it), C.byref(res)))
     return it.value, res.value
 
 

@@ -342,6 +342,143 @@ int launch_cg(tb_pattern *pat, const double *A, const double *b, double *x, doub
     return TB_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Restarted GMRES — the default inner solver of the reference's Newton–Raphson (LinearSolve.KrylovJL_GMRES(),
+// src/solver/nonlinear/newton_raphson.jl:61; Krylov.jl is third party).  Needed where the tangent is not positive definite
+// (non-polyconvex energies, follower loads).  Right Jacobi preconditioning (A D⁻¹ y = b, x = D⁻¹ y: the monitored residual is the
+// true one), classical Gram–Schmidt with one re-orthogonalisation pass so that a whole Arnoldi step is eight launches and one
+// host read: h = Vᵀw and w −= V h are single kernels over all basis vectors.
+// ------------------------------------------------------------------------------------------------
+// out[j] += V[j]·w for j < k (blockIdx.y = j)
+__global__ void __launch_bounds__(256)
+k_multi_dot(int64_t n, const double *__restrict__ V, const double *__restrict__ w, double *__restrict__ out)
+{
+    const double *v = V + (int64_t)blockIdx.y * n;
+    double s = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) s += v[i] * w[i];
+    block_sum_to(s, out + blockIdx.y);
+}
+// w += sign · Σ_{j<k} c[j] V[j];  optionally ww += w·w of the result
+__global__ void __launch_bounds__(256)
+k_multi_axpy(int64_t n, int k, double sign, const double *__restrict__ c, const double *__restrict__ V, double *__restrict__ w, double *__restrict__ ww)
+{
+    double acc = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        double s = 0.0;
+        for (int j = 0; j < k; ++j) s += c[j] * V[(int64_t)j * n + i];
+        const double r = w[i] + sign * s;
+        w[i] = r;
+        acc += r * r;
+    }
+    if (ww) block_sum_to(acc, ww);
+}
+// y = a · (d ? d .* x : x)
+__global__ void __launch_bounds__(256)
+k_scale_diag(int64_t n, double a, const double *__restrict__ d, const double *__restrict__ x, double *__restrict__ y)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = a * (d ? d[i] * x[i] : x[i]);
+}
+// r = b − Ax; rr += r·r
+__global__ void __launch_bounds__(256)
+k_residual(int64_t n, const double *__restrict__ b, const double *__restrict__ Ax, double *__restrict__ r, double *__restrict__ rr)
+{
+    double acc = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) { const double v = b[i] - Ax[i]; r[i] = v; acc += v * v; }
+    block_sum_to(acc, rr);
+}
+// x += d ? d .* t : t
+__global__ void __launch_bounds__(256)
+k_add_diag(int64_t n, const double *__restrict__ d, const double *__restrict__ t, double *__restrict__ x)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) x[i] += d ? d[i] * t[i] : t[i];
+}
+
+int launch_gmres(tb_pattern *pat, const double *A, const double *b, double *x, double rtol, double atol, int maxiter, int restart, int jacobi,
+                 int *iters, double *resnorm)
+{
+    tb_device *dev = pat->mesh->dev;
+    const int64_t n = pat->n_rows;
+    const int m = restart;
+    if (pat->gmres_m < m) {
+        if (pat->d_gmres_ws) TB_HIP(hipFree(pat->d_gmres_ws));
+        pat->d_gmres_ws = nullptr;
+        TB_HIP(hipMalloc((void **)&pat->d_gmres_ws, sizeof(double) * ((size_t)(m + 4) * n + 3 * (size_t)(m + 2))));
+        pat->gmres_m = m;
+    }
+    double *V = pat->d_gmres_ws, *w = V + (size_t)(m + 1) * n, *z = w + n, *dinv = z + n, *sc = dinv + n; // sc: h1[m+2] | h2[m+2] | y[m+2]
+    double *h1 = sc, *h2 = sc + (m + 2), *yd = sc + 2 * (m + 2);
+    const unsigned g = grid_for(dev, n, 256);
+    if (jacobi) hipLaunchKernelGGL(k_extract_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, dev->stream, n, pat->d_rowptr, pat->d_colidx, A, dinv);
+    const double *dp = jacobi ? dinv : nullptr;
+    std::vector<double> H((size_t)(m + 1) * m), cs(m), sn(m), gvec(m + 1), yh(m), hh(2 * (m + 2));
+    int it = 0;
+    double rnorm = 0.0, tol = 0.0;
+    bool first = true;
+    while (true) {
+        // r = b − A x → V[0] = r/‖r‖
+        int rc = launch_spmv(pat, A, x, 1.0, 0.0, z);
+        if (rc) return rc;
+        TB_HIP(hipMemsetAsync(h1, 0, sizeof(double), dev->stream));
+        hipLaunchKernelGGL(k_residual, dim3(g), dim3(256), 0, dev->stream, n, b, z, w, h1);
+        TB_HIP(hipMemcpyAsync(hh.data(), h1, sizeof(double), hipMemcpyDeviceToHost, dev->stream));
+        TB_HIP(hipStreamSynchronize(dev->stream));
+        rnorm = std::sqrt(hh[0]);
+        if (first) { tol = atol + rtol * rnorm; first = false; }
+        if (!(rnorm > tol) || it >= maxiter) break;
+        hipLaunchKernelGGL(k_scale_diag, dim3(g), dim3(256), 0, dev->stream, n, 1.0 / rnorm, (const double *)nullptr, w, V);
+        std::fill(gvec.begin(), gvec.end(), 0.0);
+        gvec[0] = rnorm;
+        int j = 0;
+        double res_est = rnorm;
+        for (; j < m && it < maxiter && res_est > tol; ++j, ++it) {
+            // w = A D⁻¹ v_j
+            hipLaunchKernelGGL(k_scale_diag, dim3(g), dim3(256), 0, dev->stream, n, 1.0, dp, V + (size_t)j * n, z);
+            rc = launch_spmv(pat, A, z, 1.0, 0.0, w);
+            if (rc) return rc;
+            TB_HIP(hipMemsetAsync(sc, 0, sizeof(double) * 2 * (m + 2), dev->stream));
+            hipLaunchKernelGGL(k_multi_dot, dim3(g, j + 1), dim3(256), 0, dev->stream, n, V, w, h1);
+            hipLaunchKernelGGL(k_multi_axpy, dim3(g), dim3(256), 0, dev->stream, n, j + 1, -1.0, h1, V, w, (double *)nullptr);
+            hipLaunchKernelGGL(k_multi_dot, dim3(g, j + 1), dim3(256), 0, dev->stream, n, V, w, h2);
+            hipLaunchKernelGGL(k_multi_axpy, dim3(g), dim3(256), 0, dev->stream, n, j + 1, -1.0, h2, V, w, h2 + (m + 1)); // ‖w‖² in the last slot
+            TB_HIP(hipMemcpyAsync(hh.data(), sc, sizeof(double) * 2 * (m + 2), hipMemcpyDeviceToHost, dev->stream));
+            TB_HIP(hipStreamSynchronize(dev->stream));
+            double *Hj = H.data() + (size_t)j * (m + 1);
+            for (int i = 0; i <= j; ++i) Hj[i] = hh[i] + hh[(m + 2) + i];
+            const double wn = std::sqrt(hh[(m + 2) + (m + 1)]);
+            Hj[j + 1] = wn;
+            if (!std::isfinite(wn)) { set_error("tb_gmres_solve: breakdown (non-finite Arnoldi vector)"); return TB_ERR_BAD_ARG; }
+            for (int i = 0; i < j; ++i) { const double t = cs[i] * Hj[i] + sn[i] * Hj[i + 1]; Hj[i + 1] = -sn[i] * Hj[i] + cs[i] * Hj[i + 1]; Hj[i] = t; }
+            const double den = std::hypot(Hj[j], Hj[j + 1]);
+            cs[j] = den > 0 ? Hj[j] / den : 1.0; sn[j] = den > 0 ? Hj[j + 1] / den : 0.0;
+            Hj[j] = den; Hj[j + 1] = 0.0;
+            gvec[j + 1] = -sn[j] * gvec[j]; gvec[j] = cs[j] * gvec[j];
+            res_est = std::fabs(gvec[j + 1]);
+            if (wn > 0.0 && j + 1 <= m) hipLaunchKernelGGL(k_scale_diag, dim3(g), dim3(256), 0, dev->stream, n, 1.0 / wn, (const double *)nullptr, w, V + (size_t)(j + 1) * n);
+            if (wn == 0.0) { ++j; ++it; break; } // lucky breakdown: the Krylov space is invariant, the solution is exact in it
+        }
+        // y = H⁻¹ g (upper triangular), x += D⁻¹ V y
+        for (int i = j - 1; i >= 0; --i) {
+            double sacc = gvec[i];
+            for (int l = i + 1; l < j; ++l) sacc -= H[(size_t)l * (m + 1) + i] * yh[l];
+            yh[i] = sacc / H[(size_t)i * (m + 1) + i];
+        }
+        TB_HIP(hipMemcpyAsync(yd, yh.data(), sizeof(double) * j, hipMemcpyHostToDevice, dev->stream));
+        TB_HIP(hipMemsetAsync(z, 0, sizeof(double) * n, dev->stream));
+        hipLaunchKernelGGL(k_multi_axpy, dim3(g), dim3(256), 0, dev->stream, n, j, 1.0, yd, V, z, (double *)nullptr);
+        hipLaunchKernelGGL(k_add_diag, dim3(g), dim3(256), 0, dev->stream, n, dp, z, x);
+        TB_HIP(hipStreamSynchronize(dev->stream)); // yh is reused by the next cycle
+    }
+    TB_HIP(hipGetLastError());
+    if (iters) *iters = it;
+    if (resnorm) *resnorm = rnorm;
+    return TB_OK;
+}
+
 // apply_zero!(K, f, ch) on device CSR (Ferrite.apply_zero!; CSR method src/utils.jl:263-278, call sites
 // src/solver/nonlinear/nlsolve_common.jl:12-26): rows and columns of prescribed dofs are zeroed, their diagonal entry is set
 // to `diag` (Ferrite uses the mean diagonal so the conditioning survives), f is zeroed there.  8 lanes per row.

@@ -298,7 +298,7 @@ int tb_pattern_create(tb_mesh *mesh, int64_t n_rows, const int64_t *rowptr, cons
 int tb_pattern_destroy(tb_pattern *p)
 {
     if (!p) return TB_OK;
-    hipFree(p->d_rowptr); hipFree(p->d_colidx); hipFree(p->d_emap); hipFree(p->d_blockpos); hipFree(p->d_cg_ws); hipFree(p->d_kebuf);
+    hipFree(p->d_rowptr); hipFree(p->d_colidx); hipFree(p->d_emap); hipFree(p->d_blockpos); hipFree(p->d_cg_ws); hipFree(p->d_gmres_ws); hipFree(p->d_kebuf);
     free_patch_mat_plan(p);
     delete p;
     return TB_OK;
@@ -456,6 +456,48 @@ int tb_hyperelastic_set_active_tension(tb_form *form, double tension, const doub
         TB_HIP(hipStreamSynchronize(m->dev->stream));
     }
     return TB_OK;
+}
+
+static int validate_hill(const tb_hill *h, const char *who)
+{
+    TB_REQUIRE(h->framework >= TB_HILL_NONE && h->framework <= TB_HILL_EXTENDED, "%s: unknown framework %d", who, h->framework);
+    if (h->framework == TB_HILL_NONE) return TB_OK;
+    TB_REQUIRE(h->active_energy == TB_ACTIVE_SIMPLE_SPRING || (h->active_energy >= TB_MATERIAL_HOLZAPFEL_OGDEN_2009 && h->active_energy <= TB_MATERIAL_GUCCIONE_1991),
+               "%s: unknown active spring %d", who, h->active_energy);
+    TB_REQUIRE(h->active_penalty >= TB_PENALTY_SIMPLE && h->active_penalty <= TB_PENALTY_HARTMANN_NEFF_3, "%s: unknown penalty %d", who, h->active_penalty);
+    TB_REQUIRE(h->adg_kind >= TB_ADG_GMK && h->adg_kind <= TB_ADG_RLRSQ, "%s: unknown active deformation gradient model %d", who, h->adg_kind);
+    TB_REQUIRE(h->sarcomere_kind == TB_SARCOMERE_PELCE_SUN_LANGEVELD_1995 || h->sarcomere_kind == TB_SARCOMERE_CONSTANT_STRETCH,
+               "%s: unknown sarcomere model %d", who, h->sarcomere_kind);
+    return TB_OK;
+}
+static void store_hill(tb_form *form, const tb_hill *h)
+{
+    form->hill = h ? h->framework : 0;
+    if (!form->hill) return;
+    form->act_energy = h->active_energy; form->act_penalty = h->active_penalty; form->adg = h->adg_kind; form->sarc = h->sarcomere_kind;
+    for (int i = 0; i < 12; ++i) form->act_p[i] = h->active_p[i];
+    form->hill_kappa = h->sheetlet_part; form->sarc_p[0] = h->sarcomere_p[0]; form->sarc_p[1] = h->sarcomere_p[1];
+}
+
+int tb_hyperelastic_set_hill(tb_form *form, const tb_hill *hill)
+{
+    TB_REQUIRE(form && form->kind == TB_FORM_HYPERELASTIC, "tb_hyperelastic_set_hill: not a hyperelastic form");
+    if (hill) { int rc = validate_hill(hill, "tb_hyperelastic_set_hill"); if (rc) return rc; }
+    store_hill(form, hill);
+    return TB_OK;
+}
+
+int tb_host_material_eval_hill(const tb_material *material, const tb_hill *hill, double activation, const double *F, double *psi, double *P, double *A)
+{
+    TB_REQUIRE(material && F, "tb_host_material_eval_hill: NULL argument");
+    TB_REQUIRE(material->kind >= TB_MATERIAL_HOLZAPFEL_OGDEN_2009 && material->kind <= TB_MATERIAL_GUCCIONE_1991, "tb_host_material_eval_hill: unknown material kind %d", material->kind);
+    TB_REQUIRE(material->reserved >= TB_PENALTY_SIMPLE && material->reserved <= TB_PENALTY_HARTMANN_NEFF_3, "tb_host_material_eval_hill: unknown compression penalty %d", material->reserved);
+    if (hill) { int rc = validate_hill(hill, "tb_host_material_eval_hill"); if (rc) return rc; }
+    tb_form tmp;
+    tmp.mat = *material;
+    tmp.mat.p[9] = activation;
+    store_hill(&tmp, hill);
+    return host_material_eval_form(&tmp, F, psi, P, A);
 }
 
 int tb_residual(tb_form *form, int strategy, const double *d_u, double t, double *d_r)
@@ -682,6 +724,16 @@ int tb_cg_solve(tb_pattern *pat, const double *d_Anz, const double *d_b, double 
     TB_REQUIRE(rtol >= 0 && atol >= 0 && maxiter >= 0, "tb_cg_solve: negative tolerance or iteration limit");
     TB_HIP(hipSetDevice(pat->mesh->dev->id));
     return launch_cg(pat, d_Anz, d_b, d_x, rtol, atol, maxiter, jacobi, iters, resnorm);
+}
+
+int tb_gmres_solve(tb_pattern *pat, const double *d_Anz, const double *d_b, double *d_x, double rtol, double atol, int maxiter, int restart,
+                   int jacobi, int *iters, double *resnorm)
+{
+    TB_REQUIRE(pat && d_Anz && d_b && d_x, "tb_gmres_solve: NULL argument");
+    TB_REQUIRE(rtol >= 0 && atol >= 0 && maxiter >= 0, "tb_gmres_solve: negative tolerance or iteration limit");
+    TB_REQUIRE(restart >= 1 && restart <= 1000, "tb_gmres_solve: restart must be in 1..1000 (got %d)", restart);
+    TB_HIP(hipSetDevice(pat->mesh->dev->id));
+    return launch_gmres(pat, d_Anz, d_b, d_x, rtol, atol, maxiter, restart, jacobi, iters, resnorm);
 }
 
 int tb_axpy(tb_device *dev, int64_t n, double a, const double *d_x, double *d_y)

@@ -68,11 +68,22 @@ enum { EN_HOLZAPFEL_OGDEN = 0, EN_NULL = 1, EN_BIO_NEOHOOKEAN = 2, EN_TI_NEOHOOK
        EN_HUMPHREY_STRUMPF_YIN = 6, EN_LINEAR_SPRING = 7, EN_GUCCIONE_1991 = 8 };
 enum { PEN_SIMPLE = 0, PEN_NULL = 1, PEN_HARTMANN_NEFF_1 = 2, PEN_HARTMANN_NEFF_2 = 3, PEN_HARTMANN_NEFF_3 = 4 };
 
+enum { HILL_NONE = 0, HILL_GENERALIZED = 1, HILL_EXTENDED = 2 };
+enum { ACT_SIMPLE_ACTIVE_SPRING = 100 };                        // active spring that is not an ActiveMaterialAdapter over an energy
+enum { ADG_GMK = 0, ADG_GMK_INCOMPRESSIBLE = 1, ADG_RLRSQ = 2 }; // active deformation gradient models, active.jl:23-96
+enum { SARC_PELCE_SUN_LANGEVELD = 0, SARC_CONSTANT_STRETCH = 1 };
+
 struct EnergyParams {
     int energy, penalty;
     double p[9];  // energy parameters in the field order of the reference struct
     double u[3];  // penalty parameters: β, a, b
-    double Ta;    // active tension (ActiveStressModel + SimpleActiveStress): + Ta·‖F f₀‖
+    double Ta;    // per point: active tension Tmax·𝓝 (ActiveStressModel + SimpleActiveStress, + Ta·‖F f₀‖) — or, with a Hill framework,
+                  // the calcium-driven state of the sarcomere model
+    // GeneralizedHillModel / ExtendedHillModel (materials.jl:1042-1190): W = W_passive(F) + [𝓝] W_active(F·Fᵃ⁻¹)
+    int hill, act_energy, act_penalty, adg, sarc;
+    double ap[9], au[3]; // active spring: energy + penalty parameters (ACT_SIMPLE_ACTIVE_SPRING: ap[0] = aᶠ)
+    double kappa;        // RLRSQ sheetlet part
+    double sp[2];        // PelceSunLangeveld1995: β, λᵃₘₐₓ; ConstantStretch: λ
 };
 
 // U(I₃), energies.jl:13-87 (I₃ < 0 → NaN there; a cell with detJ ≤ 0 is reported separately)
@@ -157,8 +168,57 @@ template <class T> TB_HD T energy_psi(const EnergyParams &m, const T (&F)[3][3],
         if (hd_value(I4s) >= 1.0) { const T d = I4s - 1.0; psi = psi + (p[4] / (2.0 * p[5])) * (exp(p[5] * (d * d)) - 1.0); }
     }
     }
-    if (m.Ta != 0.0) psi = psi + m.Ta * sqrt(quad(f0, f0)); // active stress: ∂(Ta‖F f₀‖)/∂F (materials.jl:1200-1266, active.jl:100-113)
+    if (m.Ta != 0.0 && m.hill == HILL_NONE) psi = psi + m.Ta * sqrt(quad(f0, f0)); // active stress: ∂(Ta‖F f₀‖)/∂F (materials.jl:1200-1266, active.jl:100-113)
     return psi;
+}
+
+// compute_λᵃ of the steady-state sarcomere models (contraction.jl:302-320)
+TB_HD double sarcomere_lambda_a(const EnergyParams &m, double Ca)
+{
+    if (m.sarc == SARC_CONSTANT_STRETCH) return m.sp[0];
+    const double f = Ca > 0.0 ? 0.5 + atan(m.sp[0] * ::log(Ca)) / 3.141592653589793 : 0.0;
+    return 1.0 / (1.0 + f * (1.0 / m.sp[1] - 1.0));
+}
+
+// Total energy of the material at F: passive part, plus — in the Hill frameworks — the active spring evaluated at Fᵉ = F·Fᵃ⁻¹.
+// All three active deformation gradients of the reference are diagonal in the (orthonormal) frame, Fᵃ = a f⊗f + b s⊗s + c n⊗n, so
+// Fᵃ⁻¹ is known in closed form and ActiveMaterialAdapter's rotated frame Fᵃf₀/‖Fᵃf₀‖ … is the frame itself (active.jl:8-21).
+template <class T> TB_HD T material_psi(const EnergyParams &m, const T (&F)[3][3], const double (&f0)[3], const double (&s0)[3], const double (&n0)[3])
+{
+    T psi = energy_psi<T>(m, F, f0, s0, n0);
+    if (m.hill == HILL_NONE) return psi;
+    const double Ca = m.Ta;
+    const double la = sarcomere_lambda_a(m, Ca);
+    double a = la, b = 1.0, c = 1.0;                                              // GMK: I + (λᵃ − 1) f⊗f
+    if (m.adg == ADG_GMK_INCOMPRESSIBLE) { b = c = 1.0 / ::sqrt(la); }            // λᵃ f⊗f + λᵃ^{-1/2} (s⊗s + n⊗n)
+    else if (m.adg == ADG_RLRSQ) { b = 1.0 + m.kappa * (la - 1.0); c = 1.0 / (b * la); }
+    double Ai[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Ai[i][j] = f0[i] * f0[j] / a + s0[i] * s0[j] / b + n0[i] * n0[j] / c;
+    T Fe[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Fe[i][j] = F[i][0] * Ai[0][j] + F[i][1] * Ai[1][j] + F[i][2] * Ai[2][j];
+    T pa;
+    if (m.act_energy == ACT_SIMPLE_ACTIVE_SPRING) { // aᶠ/2 (f₀·Cᵉ f₀ − 1)², energies.jl:334-347
+        T i4 = F[0][0] * 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const T v = Fe[k][0] * f0[0] + Fe[k][1] * f0[1] + Fe[k][2] * f0[2]; i4 = i4 + v * v; }
+        const T d = i4 - 1.0;
+        pa = (0.5 * m.ap[0]) * (d * d);
+    } else {
+        EnergyParams act{};
+        act.energy = m.act_energy; act.penalty = m.act_penalty;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) act.p[k] = m.ap[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) act.u[k] = m.au[k];
+        pa = energy_psi<T>(act, Fe, f0, s0, n0);
+    }
+    return psi + (m.hill == HILL_EXTENDED ? Ca : 1.0) * pa;                        // 𝓝(state, …) = state for steady-state sarcomeres
 }
 
 // pair index pr ∈ [0, 45) ↔ components (mm ≤ nn) of F (row-major 0…8)
@@ -180,7 +240,7 @@ TB_HD HD energy_pair(const EnergyParams &m, const double *F9, int mm, int nn, co
             const int e = 3 * i + j;
             F[i][j] = HD{F9[e], e == mm ? 1.0 : 0.0, e == nn ? 1.0 : 0.0, 0.0};
         }
-    return energy_psi<HD>(m, F, f0, s0, n0);
+    return material_psi<HD>(m, F, f0, s0, n0);
 }
 
 } // namespace tbk

@@ -135,6 +135,8 @@ struct tb_pattern {
     bool map64 = false;
     void *d_emap = nullptr; // [ndpc*ndpc][n_cells] nz index of (cell,i,j): int32 (nnz < 2^31) or int64
     double *d_cg_ws = nullptr;      // CG workspace (r, p, Ap, D⁻¹, 2 scalars)
+    double *d_gmres_ws = nullptr;   // GMRES workspace: (restart+1) basis vectors + 3 vectors + scalars
+    int gmres_m = 0;
     double *d_kebuf = nullptr;      // element-matrix buffer of the ElementAssemblyStrategy (vector fields)
     int64_t max_row_len = 0;
     uint16_t *d_blockpos = nullptr; // vector fields: per cell and node pair, position of the 3×3 block inside its row
@@ -155,6 +157,9 @@ struct tb_form {
     // active stress (TB_FORM_HYPERELASTIC): Ta = act_tension · (nodal field per cell, or 1)
     double act_tension = 0.0;
     double *d_act_field = nullptr;
+    // Hill frameworks (tb_hyperelastic_set_hill)
+    int hill = 0, act_energy = 0, act_penalty = 0, adg = 0, sarc = 0;
+    double act_p[12] = {0}, hill_kappa = 0.0, sarc_p[2] = {0, 0};
     // weak boundary conditions (TB_FORM_FACET)
     int bc_kind = 0, facet_q = 0;
     double bc_param = 0.0;
@@ -179,12 +184,15 @@ int ensure_emap(tb_pattern *p);
 int launch_assemble_matrix(tb_form *f, tb_pattern *p, int strategy, double t, double *d_nz);
 int launch_assemble_vector(tb_form *f, int strategy, double t, double *d_b);
 int launch_hyperelastic(tb_form *f, tb_pattern *p, int strategy, const double *d_u, double *d_nz, double *d_r);
+int host_material_eval_form(tb_form *form, const double *F9, double *psi, double *P, double *A);
 int host_material_eval(const tb_material *mat, const double *F9, double *psi, double *P, double *A);
 int launch_reaction(tb_device *dev, int model, const double *params, int n_params, double *d_u, double *d_du,
                     int64_t n_points, int layout, double t, double dt, int substeps, double thr, double *rmax /*nullable, host*/);
 int launch_reaction_rl(tb_device *dev, int model, const double *params, int n_params, double *d_u, int64_t n, int layout, double t, double dt);
 int launch_heat_matrix(tb_device *dev, int64_t nnz, const double *M, const double *K, double dt, double *A);
 int launch_spmv(tb_pattern *p, const double *nz, const double *x, double alpha, double beta, double *y);
+int launch_gmres(tb_pattern *pat, const double *A, const double *b, double *x, double rtol, double atol, int maxiter, int restart, int jacobi,
+                 int *iters, double *resnorm);
 int launch_cg(tb_pattern *pat, const double *A, const double *b, double *x, double rtol, double atol, int maxiter, int jacobi, int *iters,
               double *resnorm);
 int launch_axpy(tb_device *dev, int64_t n, double a, const double *x, double *y);

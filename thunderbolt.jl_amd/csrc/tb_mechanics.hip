@@ -551,6 +551,7 @@ static HOParams make_params(const tb_form *f)
 }
 
 static bool material_is_fast_path(const tb_material &mat) { return mat.kind == TB_MATERIAL_HOLZAPFEL_OGDEN_2009 && mat.reserved == PEN_SIMPLE; }
+static bool form_is_fast_path(const tb_form *f) { return material_is_fast_path(f->mat) && f->hill == 0; }
 
 static EnergyParams make_energy_params(const tb_form *f)
 {
@@ -559,16 +560,26 @@ static EnergyParams make_energy_params(const tb_form *f)
     for (int i = 0; i < 9; ++i) e.p[i] = f->mat.p[i];
     for (int i = 0; i < 3; ++i) e.u[i] = f->mat.p[10 + i];
     e.Ta = f->act_tension;
+    e.hill = f->hill; e.act_energy = f->act_energy; e.act_penalty = f->act_penalty; e.adg = f->adg; e.sarc = f->sarc;
+    for (int i = 0; i < 9; ++i) e.ap[i] = f->act_p[i];
+    for (int i = 0; i < 3; ++i) e.au[i] = f->act_p[9 + i];
+    e.kappa = f->hill_kappa; e.sp[0] = f->sarc_p[0]; e.sp[1] = f->sarc_p[1];
     return e;
 }
 
 int host_material_eval(const tb_material *mat, const double *F9, double *psi, double *P, double *A)
 {
-    if (!material_is_fast_path(*mat)) { // any energy of tb_energy.hpp: the same hyper-dual evaluation the kernels run, on the host
-        tb_form tmpf;
-        tmpf.mat = *mat;
-        tmpf.act_tension = mat->p[9];
-        const EnergyParams e = make_energy_params(&tmpf);
+    tb_form tmpf;
+    tmpf.mat = *mat;
+    return host_material_eval_form(&tmpf, F9, psi, P, A);
+}
+
+int host_material_eval_form(tb_form *form, const double *F9, double *psi, double *P, double *A)
+{
+    const tb_material *mat = &form->mat;
+    form->act_tension = mat->p[9];
+    if (!form_is_fast_path(form)) { // any energy of tb_energy.hpp: the same hyper-dual evaluation the kernels run, on the host
+        const EnergyParams e = make_energy_params(form);
         const double f0[3] = {mat->f[0], mat->f[1], mat->f[2]}, s0[3] = {mat->s[0], mat->s[1], mat->s[2]}, n0[3] = {mat->n[0], mat->n[1], mat->n[2]};
         for (int pr = 0; pr < 45; ++pr) {
             int mm, nn;
@@ -580,10 +591,7 @@ int host_material_eval(const tb_material *mat, const double *F9, double *psi, do
         }
         return TB_OK;
     }
-    tb_form tmp;
-    tmp.mat = *mat;
-    tmp.act_tension = mat->p[9];
-    const HOParams p = make_params(&tmp);
+    const HOParams p = make_params(form);
     double F[3][3], Pl[9], Al[81];
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) F[i][j] = F9[3 * i + j];
     // evaluated through the same split routines the kernels use (ho_common + ho_row)
@@ -720,7 +728,7 @@ int launch_hyperelastic(tb_form *f, tb_pattern *p, int strategy, const double *d
     if (q2 && f->qorder != 3) { set_error("hyperelastic: Q2 field needs quadrature order 3"); return TB_ERR_UNSUPPORTED; }
     // Q2 tangents run their contraction on the matrix cores; TB_MECH_MFMA=0 selects the vector-FMA build (comparison)
     static const bool mfma = !(getenv("TB_MECH_MFMA") && atoi(getenv("TB_MECH_MFMA")) == 0);
-    const bool ad = !material_is_fast_path(f->mat);
+    const bool ad = !form_is_fast_path(f);
 #define TB_RUN(FEV, K, R, MF) (ad ? run<FEV, K, R, MF, true>(f, p, strategy, d_u, d_nz, d_r) : run<FEV, K, R, MF, false>(f, p, strategy, d_u, d_nz, d_r))
     if (d_nz && d_r) rc = !q2 ? TB_RUN(Q1Vec, true, true, false) : (mfma || ad) ? TB_RUN(Q2Vec, true, true, true) : run<Q2Vec, true, true, false, false>(f, p, strategy, d_u, d_nz, d_r);
     else if (d_nz) rc = !q2 ? TB_RUN(Q1Vec, true, false, false) : (mfma || ad) ? TB_RUN(Q2Vec, true, false, true) : run<Q2Vec, true, false, false, false>(f, p, strategy, d_u, d_nz, d_r);
