@@ -257,6 +257,23 @@ int tb_facet_form_create(tb_mesh *mesh, int bc_kind, double param, int facet_qpo
 int tb_facet_assemble(tb_form *form, tb_pattern *pat, const double *d_u, double t, double *d_nzval, double *d_r);
 int tb_host_material_eval(const tb_material *material, const double *F, double *psi, double *P, double *A);
 
+/* ------------------------------------------------------------------ pointwise sarcomere dynamics
+ * Sarcomere models with internal state (src/modeling/solid/contraction.jl:337-632).  TB_SARCOMERE_RDQ20MF: 20 states per point
+ * (16 regulatory-unit occupancies, flat index (TL−1) + 2(TC−1) + 4(TR−1) + 8(CC−1); 4 cross-bridge moments), default initial state
+ * (1, 0, …, 0) (default_initial_state!, :371-375); parameters in the field order of RDQ20MFModel (:337-369; 17 values, the last is εᵛ).
+ * tb_sarcomere_step: the StandaloneSarcomereModel protocol (:150-163) — du = sarcomere_rhs!(u, λ, dλ/dt, Ca) — advanced by
+ * `substeps` forward-Euler steps of dt with the inputs held.  State: n_states × n_points, point-fastest.  Inputs per point
+ * (device arrays) or, where the pointer is NULL, the scalar argument.  rate_independent ≠ 0 evaluates at dλ/dt = 0 (AsRateIndependent,
+ * :120-148).  Optional outputs after the step: compute_active_tension / compute_active_stiffness (:616-622) per point.
+ * tb_host_sarcomere_eval: one evaluation of the same inline code on the host (rhs, tension, stiffness; any output may be NULL). */
+enum { TB_SARCOMERE_RDQ20MF = 2 };
+int tb_sarcomere_model_info(int model, int *n_states, int *n_params);
+int tb_sarcomere_step(tb_device *dev, int model, const double *params, int n_params, double *d_state, int64_t n_points,
+                      const double *d_stretch, const double *d_velocity, const double *d_calcium, double stretch, double velocity,
+                      double calcium, double t, double dt, int substeps, int rate_independent, double *d_tension, double *d_stiffness);
+int tb_host_sarcomere_eval(int model, const double *params, int n_params, const double *state, double stretch, double velocity,
+                           double calcium, double *dstate, double *tension, double *stiffness);
+
 /* ------------------------------------------------------------------ pointwise reaction step
  * _pointwise_step_outer_kernel!(f, t, Δt, cache, ::DeviceVector) (src/solver/time/partitioned_solver.jl:38-52,
  * ext/CuThunderboltExt.jl:103-124).  substeps <= 1: ForwardEulerCellSolver (:80-99); substeps > 1:

@@ -429,3 +429,37 @@ def assemble_hyperelastic(mesh, u, rowptr=None, colidx=None, p=HO_DEFAULTS, fsn=
                                          _d(nz), _d(r), nthreads, _i32(color), ncolors)
     assert rc == 0, rc
     return nz, r
+
+
+# ------------------------------------------------------------------------------------------- RDQ20-MF sarcomere model
+# RDQ20MFModel defaults in struct field order (contraction.jl:337-369)
+RDQ20MF_DEFAULTS = np.array([1.25, 1.65, 0.18, 2.2, 2.0, 0.381, -0.571, 10.0, 12.0, 0.1, 0.013, 0.13431, 25.184, 0.032653, 0.000778, 22.894e3, 1.0e-6])
+
+
+def rdq20mf_rhs(u, lam, dlam, ca, p=RDQ20MF_DEFAULTS):
+    du = np.zeros(20)
+    lib().orc_rdq20mf_rhs.restype = None
+    lib().orc_rdq20mf_rhs(_d(_f64(p)), _d(_f64(u)), C.c_double(lam), C.c_double(dlam), C.c_double(ca), _d(du))
+    return du
+
+
+def rdq20mf_tension(u, lam, p=RDQ20MF_DEFAULTS):
+    lib().orc_rdq20mf_tension.restype = C.c_double
+    return lib().orc_rdq20mf_tension(_d(_f64(p)), _d(_f64(u)), C.c_double(lam))
+
+
+def rdq20mf_stiffness(u, lam, p=RDQ20MF_DEFAULTS):
+    lib().orc_rdq20mf_stiffness.restype = C.c_double
+    return lib().orc_rdq20mf_stiffness(_d(_f64(p)), _d(_f64(u)), C.c_double(lam))
+
+
+def rdq20mf_trajectory(u0, dt, lam, dlam, ca, sample, p=RDQ20MF_DEFAULTS):
+    """forward Euler over len(lam) steps; returns (final state, states after the steps flagged in `sample`)"""
+    u = _f64(u0).copy()
+    lam, dlam, ca = _f64(lam), _f64(dlam), _f64(ca)
+    sample = np.ascontiguousarray(sample, dtype=np.uint8)
+    out = np.zeros((int(sample.sum()), 20))
+    lib().orc_rdq20mf_trajectory.restype = None
+    lib().orc_rdq20mf_trajectory(_d(_f64(p)), _d(u), C.c_int64(len(lam)), C.c_double(dt), _d(lam), _d(dlam), _d(ca),
+                                 sample.ctypes.data_as(C.c_void_p), _d(out))
+    return u, out

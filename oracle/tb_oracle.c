@@ -1673,3 +1673,97 @@ int orc_assemble_facets(const orc_mesh *m, int kind, double param, int fq, const
     free(Ke);
     return err;
 }
+
+
+/* =====================================================================================================================
+ * RDQ20-MF sarcomere model — sarcomere_rhs!(du, u, λ, dλdt, Ca, t, p::RDQ20MFModel), src/modeling/solid/contraction.jl:385-453,532-583;
+ * fraction_single_overlap / compute_active_tension / compute_active_stiffness :598-622; smooth_abs src/utils.jl:580.
+ * PINNED by the reference's golden trajectory test/data/trajectories/RDQ20-MF/transient-test.csv under the protocol of
+ * test/test_sarcomere.jl:7-115 (tests/test_sarcomere.py).  p: the 17 struct fields in order
+ * (LA LM LB SL₀ Q Kd₀ αKd μ γ Koff Kbasic r₀ α μ₀_fP μ₁_fP a_XB εᵛ).  Arrays below are [TL][TC][TR][CC], 0-based;
+ * flat state index TL + 2 TC + 4 TR + 8 CC (Julia's column-major reshape(u[1:16], 2,2,2,2)).
+ * ===================================================================================================================== */
+static double ipow(double g, int n) { double r = 1.0; for (int i = 0; i < n; ++i) r *= g; return r; }
+static void rdq20_rates(const double *p, double dT[2][2][2][2])
+{
+    const double Q = p[4], mu = p[7], gamma = p[8], Kbasic = p[10];
+    for (int TL = 0; TL < 2; ++TL) for (int TC = 0; TC < 2; ++TC) for (int TR = 0; TR < 2; ++TR) for (int CC = 0; CC < 2; ++CC) {
+        int nperm = TL + TR; /* (TL+1) + (TR+1) − 2 */
+        if (TC == 1) dT[TL][TC][TR][CC] = Kbasic * ipow(gamma, 2 - nperm);
+        else if (CC == 0) dT[TL][TC][TR][CC] = Q * Kbasic * ipow(gamma, nperm) / mu;
+        else dT[TL][TC][TR][CC] = Q * Kbasic * ipow(gamma, nperm);
+    }
+}
+void orc_rdq20mf_rhs(const double *p, const double *u, double lam, double dlam, double Ca, double *du)
+{
+    const double SL0 = p[3], Kd0 = p[5], aKd = p[6], mu = p[7], Koff = p[9], r0 = p[11], alpha = p[12], mu0 = p[13], mu1 = p[14], epsv = p[16];
+    double U[2][2][2][2], dT[2][2][2][2], PT_C[2][2][2][2], PC_C[2][2][2][2], PT_L[2][2][2][2], PT_R[2][2][2][2];
+    for (int TL = 0; TL < 2; ++TL) for (int TC = 0; TC < 2; ++TC) for (int TR = 0; TR < 2; ++TR) for (int CC = 0; CC < 2; ++CC)
+        U[TL][TC][TR][CC] = u[TL + 2 * TC + 4 * TR + 8 * CC];
+    double SL = SL0 * lam;
+    double dC1 = Koff / (Kd0 - aKd * (2.15 - SL)) * Ca;
+    double dC[2][2] = {{dC1, dC1}, {Koff, Koff / mu}}; /* dC[CC][TC] */
+    rdq20_rates(p, dT);
+    for (int TL = 0; TL < 2; ++TL) for (int TC = 0; TC < 2; ++TC) for (int TR = 0; TR < 2; ++TR) for (int CC = 0; CC < 2; ++CC) {
+        PT_C[TL][TC][TR][CC] = U[TL][TC][TR][CC] * dT[TL][TC][TR][CC];
+        PC_C[TL][TC][TR][CC] = U[TL][TC][TR][CC] * dC[CC][TC];
+    }
+    double dT_L[2][2], dT_R[2][2]; /* built as [TL][TC] and [TR][TC] */
+    for (int TL = 0; TL < 2; ++TL) for (int TC = 0; TC < 2; ++TC) {
+        double flux = 0, prob = 0;
+        for (int TR = 0; TR < 2; ++TR) { flux += PT_C[TL][TC][TR][0] + PT_C[TL][TC][TR][1]; prob += U[TL][TC][TR][0] + U[TL][TC][TR][1]; }
+        dT_L[TL][TC] = prob > 1e-12 ? flux / prob : 0.0;
+    }
+    for (int TR = 0; TR < 2; ++TR) for (int TC = 0; TC < 2; ++TC) {
+        double flux = 0, prob = 0;
+        for (int TL = 0; TL < 2; ++TL) { flux += PT_C[TL][TC][TR][0] + PT_C[TL][TC][TR][1]; prob += U[TL][TC][TR][0] + U[TL][TC][TR][1]; }
+        dT_R[TR][TC] = prob > 1e-12 ? flux / prob : 0.0;
+    }
+    /* used with the indices the other way round, as the reference writes them (:432-436) */
+    for (int TL = 0; TL < 2; ++TL) for (int TC = 0; TC < 2; ++TC) for (int TR = 0; TR < 2; ++TR) for (int CC = 0; CC < 2; ++CC) {
+        PT_L[TL][TC][TR][CC] = U[TL][TC][TR][CC] * dT_L[TC][TL];
+        PT_R[TL][TC][TR][CC] = U[TL][TC][TR][CC] * dT_R[TC][TR];
+    }
+    for (int TL = 0; TL < 2; ++TL) for (int TC = 0; TC < 2; ++TC) for (int TR = 0; TR < 2; ++TR) for (int CC = 0; CC < 2; ++CC)
+        du[TL + 2 * TC + 4 * TR + 8 * CC] = -PT_L[TL][TC][TR][CC] + PT_L[1 - TL][TC][TR][CC] - PT_C[TL][TC][TR][CC] + PT_C[TL][1 - TC][TR][CC] -
+                                            PT_R[TL][TC][TR][CC] + PT_R[TL][TC][1 - TR][CC] - PC_C[TL][TC][TR][CC] + PC_C[TL][TC][TR][1 - CC];
+    double flux_PN = 0, flux_NP = 0, perm = 0;
+    for (int TL = 0; TL < 2; ++TL) for (int TR = 0; TR < 2; ++TR) for (int CC = 0; CC < 2; ++CC) {
+        perm += U[TL][1][TR][CC];
+        flux_PN += U[TL][1][TR][CC] * dT[TL][1][TR][CC];
+        flux_NP += U[TL][0][TR][CC] * dT[TL][0][TR][CC];
+    }
+    double k_PN = perm >= 1e-12 ? flux_PN / perm : 0.0;
+    double k_NP = 1.0 - perm >= 1e-12 ? flux_NP / (1.0 - perm) : 0.0;
+    double r = r0 + alpha * (dlam * dlam / sqrt(dlam * dlam + epsv * epsv));
+    double diag_P = r + k_PN, diag_N = r + k_NP;
+    const double *x = u + 16;
+    double A[4][4] = {{-diag_P, 0, k_NP, 0}, {dlam, -diag_P, 0, k_NP}, {k_PN, 0, -diag_N, 0}, {0, k_PN, dlam, -diag_N}};
+    for (int i = 0; i < 4; ++i) { double s = 0; for (int j = 0; j < 4; ++j) s += A[i][j] * x[j]; du[16 + i] = s; }
+    du[16] += mu0 * perm;
+    du[17] += mu1 * perm;
+}
+double orc_rdq20mf_overlap(const double *p, double lam)
+{
+    double LA = p[0], LM = p[1], LB = p[2], SL = lam * p[3], LMh = (LM - LB) * 0.5;
+    if (SL > LA && SL <= LM) return (SL - LA) / LMh;
+    if (SL > LM && SL <= 2 * LA - LB) return (SL + LM - 2 * LA) * 0.5 / LMh;
+    if (SL > 2 * LA - LB && SL <= 2 * LA + LB) return 1.0;
+    if (SL > 2 * LA + LB && SL <= 2 * LA + LM) return (LM + 2 * LA - SL) * 0.5 / LMh;
+    return 0.0;
+}
+double orc_rdq20mf_tension(const double *p, const double *u, double lam) { return p[15] * (u[17] + u[19]) * orc_rdq20mf_overlap(p, lam); }
+double orc_rdq20mf_stiffness(const double *p, const double *u, double lam) { return p[15] * (u[16] + u[18]) * orc_rdq20mf_overlap(p, lam); }
+/* forward-Euler trajectory under given input series (one entry per step), as the loop of test/test_sarcomere.jl:63-71:
+ * du = rhs(u, inputs at step i); u += dt·du; then the state after step i is recorded where sample[i] != 0 (out: rows of 20). */
+void orc_rdq20mf_trajectory(const double *p, double *u, int64_t n_steps, double dt, const double *lam, const double *dlam, const double *ca,
+                            const unsigned char *sample, double *out)
+{
+    double du[20];
+    int64_t row = 0;
+    for (int64_t i = 0; i < n_steps; ++i) {
+        orc_rdq20mf_rhs(p, u, lam[i], dlam[i], ca[i], du);
+        for (int k = 0; k < 20; ++k) u[k] += dt * du[k];
+        if (sample && sample[i]) { memcpy(out + 20 * row, u, 20 * sizeof(double)); ++row; }
+    }
+}

@@ -197,4 +197,12 @@ int orc_assemble_facets(const orc_mesh *m, int kind, double param, int fq, const
 
 #ifdef __cplusplus
 }
+/* RDQ20-MF sarcomere model (contraction.jl:337-622); pinned by the reference's golden trajectory */
+void orc_rdq20mf_rhs(const double *p, const double *u, double lam, double dlam, double Ca, double *du);
+double orc_rdq20mf_overlap(const double *p, double lam);
+double orc_rdq20mf_tension(const double *p, const double *u, double lam);
+double orc_rdq20mf_stiffness(const double *p, const double *u, double lam);
+void orc_rdq20mf_trajectory(const double *p, double *u, int64_t n_steps, double dt, const double *lam, const double *dlam, const double *ca,
+                            const unsigned char *sample, double *out);
+
 #endif

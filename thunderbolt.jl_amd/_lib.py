@@ -45,7 +45,7 @@ class tb_hill(C.Structure):
 TB_HILL_NONE, TB_HILL_GENERALIZED, TB_HILL_EXTENDED = 0, 1, 2
 TB_ACTIVE_SIMPLE_SPRING = 100
 TB_ADG_GMK, TB_ADG_GMK_INCOMPRESSIBLE, TB_ADG_RLRSQ = 0, 1, 2
-TB_SARCOMERE_PELCE_SUN_LANGEVELD_1995, TB_SARCOMERE_CONSTANT_STRETCH = 0, 1
+TB_SARCOMERE_PELCE_SUN_LANGEVELD_1995, TB_SARCOMERE_CONSTANT_STRETCH, TB_SARCOMERE_RDQ20MF = 0, 1, 2
 
 # name -> (restype, argtypes): every symbol include/tbhip.h declares
 SIGNATURES = {
@@ -85,6 +85,10 @@ SIGNATURES = {
     "tb_residual": (C.c_int, [vp, C.c_int, vp, C.c_double, vp]),
     "tb_linearize": (C.c_int, [vp, vp, C.c_int, vp, C.c_double, vp, vp]),
     "tb_hyperelastic_set_active_tension": (C.c_int, [vp, C.c_double, c_dp, C.c_int64]),
+    "tb_sarcomere_model_info": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "tb_sarcomere_step": (C.c_int, [vp, C.c_int, c_dp, C.c_int, vp, C.c_int64, vp, vp, vp, C.c_double, C.c_double, C.c_double, C.c_double,
+                                    C.c_double, C.c_int, C.c_int, vp, vp]),
+    "tb_host_sarcomere_eval": (C.c_int, [C.c_int, c_dp, C.c_int, c_dp, C.c_double, C.c_double, C.c_double, c_dp, c_dp, c_dp]),
     "tb_hyperelastic_set_hill": (C.c_int, [vp, vp]),
     "tb_host_material_eval_hill": (C.c_int, [vp, vp, C.c_double, c_dp, c_dp, c_dp, c_dp]),
     "tb_facet_form_create": (C.c_int, [vp, C.c_int, C.c_double, C.c_int, c_i32p, C.c_int64, C.c_int, C.POINTER(vp)]),

@@ -1335,6 +1335,137 @@ def nlsolve(u, op, ch, solver, t=0.0):
     return True
 
 
+# --------------------------------------------------------------------------------------- sarcomere models with internal state
+class RDQ20MFModel:
+    """RDQ20MFModel(; …) — mean-field Regazzoni–Dedè–Quarteroni 2020 sarcomere model, 20 states (contraction.jl:337-376); keyword
+    names as the reference's fields (ASCII: SL0, Kd0, alphaKd, mu, gamma, r0, alpha, mu0_fP, mu1_fP, eps_v)."""
+    sid = L.TB_SARCOMERE_RDQ20MF
+    _fields = ("LA", "LM", "LB", "SL0", "Q", "Kd0", "alphaKd", "mu", "gamma", "Koff", "Kbasic", "r0", "alpha", "mu0_fP", "mu1_fP", "a_XB", "eps_v")
+    _defaults = (1.25, 1.65, 0.18, 2.2, 2.0, 0.381, -0.571, 10.0, 12.0, 0.1, 0.013, 0.13431, 25.184, 0.032653, 0.000778, 22.894e3, 1.0e-6)
+
+    def __init__(self, **kw):
+        for n, v in zip(self._fields, self._defaults):
+            setattr(self, n, float(kw.pop(n, v)))
+        if kw:
+            raise TypeError("RDQ20MFModel: unknown parameter(s) %s" % sorted(kw))
+
+    def params(self):
+        return np.array([getattr(self, n) for n in self._fields], dtype=np.float64)
+
+    rate_independent = False
+
+
+class AsRateIndependent:
+    """AsRateIndependent(model): the model evaluated at zero shortening velocity (contraction.jl:107-148)."""
+    rate_independent = True
+
+    def __init__(self, model):
+        self.model = model
+        self.sid = model.sid
+
+    def params(self):
+        return self.model.params()
+
+
+def num_states(model):
+    if isinstance(model, (RDQ20MFModel, AsRateIndependent)):
+        ns = C.c_int()
+        check(lib().tb_sarcomere_model_info(model.sid, C.byref(ns), None))
+        return ns.value
+    return model.num_states
+
+
+def default_initial_state(model, n_points=1):
+    """default_initial_state!(Q, model): Q[1] = 1, the rest 0 (contraction.jl:371-375); shape (n_states, n_points)."""
+    u = np.zeros((num_states(model), n_points))
+    u[0] = 1.0
+    return u
+
+
+def sarcomere_rhs(model, u, stretch, velocity, calcium):
+    """sarcomere_rhs!(du, u, λ, dλdt, Ca, t, model) evaluated on the host by the code the kernel runs → (du, Ta, As)."""
+    p = model.params()
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    du = np.zeros_like(u)
+    Ta, As = C.c_double(), C.c_double()
+    check(lib().tb_host_sarcomere_eval(model.sid, p.ctypes.data_as(L.c_dp), len(p), u.ctypes.data_as(L.c_dp), float(stretch),
+                                       0.0 if model.rate_independent else float(velocity), float(calcium), du.ctypes.data_as(L.c_dp),
+                                       C.byref(Ta), C.byref(As)))
+    return du, Ta.value, As.value
+
+
+def compute_active_tension(model, state, sarcomere_stretch):
+    return sarcomere_rhs(model, state, sarcomere_stretch, 0.0, 0.0)[1]
+
+
+def compute_active_stiffness(model, state, sarcomere_stretch):
+    return sarcomere_rhs(model, state, sarcomere_stretch, 0.0, 0.0)[2]
+
+
+def internal_state_in_bounds(model, Q):
+    """internal_state_in_bounds(::RDQ20MFModel, Q) = all(≥(0), Q[1:16]) (contraction.jl:596)."""
+    return bool(np.all(np.asarray(Q)[:16] >= 0))
+
+
+class SarcomereState:
+    """Internal states of a sarcomere model at n_points points on the device, (n_states, n_points), point-fastest."""
+
+    def __init__(self, device, model, n_points, initial=None):
+        self.device, self.model, self.n_points = device, model, int(n_points)
+        self.n_states = num_states(model)
+        u = default_initial_state(model, self.n_points) if initial is None else np.ascontiguousarray(initial, dtype=np.float64)
+        if u.shape != (self.n_states, self.n_points):
+            raise ValueError("SarcomereState: initial state must have shape (n_states, n_points)")
+        self.u = device.to_device(u.ravel()) if self.n_points else DeviceVector(device, 0)
+
+    def to_host(self):
+        return self.u.to_host().reshape(self.n_states, self.n_points)
+
+
+def _dev_or_scalar(x):
+    if isinstance(x, DeviceVector):
+        return x.ptr, 0.0
+    return None, float(x)
+
+
+def sarcomere_step(state, t, dt, stretch, velocity, calcium, substeps=1, tension=None, stiffness=None):
+    """One forward-Euler step (or `substeps` of them with held inputs) of du = sarcomere_rhs!(u, λ, dλdt, Ca) at every point — the
+    StandaloneSarcomereModel protocol (contraction.jl:150-163).  Inputs: numbers or DeviceVectors of per-point values."""
+    m = state.model
+    p = m.params()
+    ps, s = _dev_or_scalar(stretch)
+    pv, v = _dev_or_scalar(velocity)
+    pc, c = _dev_or_scalar(calcium)
+    check(lib().tb_sarcomere_step(state.device.h, m.sid, p.ctypes.data_as(L.c_dp), len(p), state.u.ptr, state.n_points, ps, pv, pc, s, v, c,
+                                  float(t), float(dt), int(substeps), int(m.rate_independent), _ptr(tension), _ptr(stiffness)))
+
+
+def sarcomere_stepper(state, dt, tension=None, stiffness=None):
+    """A bound single-step call with scalar inputs, step(λ, dλdt, Ca), for launch-rate-bound host loops."""
+    m = state.model
+    p = m.params()
+    fn = lib().tb_sarcomere_step
+    args = (state.device.h, m.sid, p.ctypes.data_as(L.c_dp), len(p), state.u.ptr, state.n_points, None, None, None)
+    tail = (0.0, float(dt), 1, int(m.rate_independent), _ptr(tension), _ptr(stiffness))
+
+    def step(lam, vel, ca):
+        rc = fn(*args, lam, vel, ca, *tail)
+        if rc:
+            check(rc)
+    step._keep = p
+    return step
+
+
+class StandaloneSarcomereModel:
+    """StandaloneSarcomereModel(model, calcium, fiber_stretch, fiber_velocity): inputs as functions of t (contraction.jl:150-163)."""
+
+    def __init__(self, model, calcium, fiber_stretch, fiber_velocity):
+        self.model, self.calcium, self.fiber_stretch, self.fiber_velocity = model, calcium, fiber_stretch, fiber_velocity
+
+    def step(self, state, t, dt, **kw):
+        sarcomere_step(state, t, dt, self.fiber_stretch(t), self.fiber_velocity(t), self.calcium(t), **kw)
+
+
 # --------------------------------------------------------------------------------------- heat step + operator splitting
 def cg_solve(pattern, A, b, x, rtol=1e-5, atol=1e-6, maxiter=1000, jacobi=True):
     """LinearSolve.solve!(linear_solver) with KrylovJL_CG(atol, rtol) (euler.jl:94-100, ep01_spiral-wave.jl:126-128)."""

@@ -590,6 +590,40 @@ int tb_host_material_eval(const tb_material *material, const double *F, double *
     return host_material_eval(material, F, psi, P, A);
 }
 
+// ------------------------------------------------------------------ sarcomere
+int tb_sarcomere_model_info(int model, int *n_states, int *n_params)
+{
+    TB_REQUIRE(model == TB_SARCOMERE_RDQ20MF, "tb_sarcomere_model_info: model %d has no internal state (only TB_SARCOMERE_RDQ20MF)", model);
+    if (n_states) *n_states = 20;
+    if (n_params) *n_params = 17;
+    return TB_OK;
+}
+
+int tb_sarcomere_step(tb_device *dev, int model, const double *params, int n_params, double *d_state, int64_t n_points,
+                      const double *d_stretch, const double *d_velocity, const double *d_calcium, double stretch, double velocity,
+                      double calcium, double t, double dt, int substeps, int rate_independent, double *d_tension, double *d_stiffness)
+{
+    (void)t; // the model is autonomous given its inputs (the reference passes t through and never uses it)
+    TB_REQUIRE(dev && params, "tb_sarcomere_step: NULL argument");
+    TB_REQUIRE(model == TB_SARCOMERE_RDQ20MF, "tb_sarcomere_step: unknown sarcomere model %d", model);
+    TB_REQUIRE(n_params == 17, "tb_sarcomere_step: RDQ20MF takes 17 parameters (got %d)", n_params);
+    TB_REQUIRE(n_points >= 0 && substeps >= 1, "tb_sarcomere_step: n_points must be >= 0 and substeps >= 1");
+    if (n_points == 0) return TB_OK;
+    TB_REQUIRE(d_state, "tb_sarcomere_step: NULL state");
+    TB_HIP(hipSetDevice(dev->id));
+    return launch_sarcomere(dev, params, d_state, n_points, d_stretch, d_velocity, d_calcium, stretch, velocity, calcium, dt, substeps,
+                            rate_independent, d_tension, d_stiffness);
+}
+
+int tb_host_sarcomere_eval(int model, const double *params, int n_params, const double *state, double stretch, double velocity,
+                           double calcium, double *dstate, double *tension, double *stiffness)
+{
+    TB_REQUIRE(params && state, "tb_host_sarcomere_eval: NULL argument");
+    TB_REQUIRE(model == TB_SARCOMERE_RDQ20MF && n_params == 17, "tb_host_sarcomere_eval: RDQ20MF with 17 parameters expected");
+    host_sarcomere_eval(params, state, stretch, velocity, calcium, dstate, tension, stiffness);
+    return TB_OK;
+}
+
 // ------------------------------------------------------------------ reaction
 int tb_cell_model_info(int model, int *n_states, int *n_params, int *phi_index)
 {

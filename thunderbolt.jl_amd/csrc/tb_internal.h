@@ -191,6 +191,11 @@ int launch_reaction(tb_device *dev, int model, const double *params, int n_param
 int launch_reaction_rl(tb_device *dev, int model, const double *params, int n_params, double *d_u, int64_t n, int layout, double t, double dt);
 int launch_heat_matrix(tb_device *dev, int64_t nnz, const double *M, const double *K, double dt, double *A);
 int launch_spmv(tb_pattern *p, const double *nz, const double *x, double alpha, double beta, double *y);
+int launch_sarcomere(tb_device *dev, const double *params, double *d_state, int64_t n, const double *d_stretch, const double *d_velocity,
+                     const double *d_calcium, double stretch, double velocity, double calcium, double dt, int substeps, int rate_independent,
+                     double *d_tension, double *d_stiffness);
+void host_sarcomere_eval(const double *params, const double *u, double stretch, double velocity, double calcium, double *du, double *tension,
+                         double *stiffness);
 int launch_gmres(tb_pattern *pat, const double *A, const double *b, double *x, double rtol, double atol, int maxiter, int restart, int jacobi,
                  int *iters, double *resnorm);
 int launch_cg(tb_pattern *pat, const double *A, const double *b, double *x, double rtol, double atol, int maxiter, int jacobi, int *iters,
