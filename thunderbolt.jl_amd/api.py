@@ -634,6 +634,10 @@ class _IonicModel:
 
 
 def num_states(model):
+    if hasattr(model, "sid"):                  # sarcomere models with internal state
+        ns = C.c_int()
+        check(lib().tb_sarcomere_model_info(model.sid, C.byref(ns), None))
+        return ns.value
     return model.nstates
 
 
@@ -1367,15 +1371,7 @@ class AsRateIndependent:
         return self.model.params()
 
 
-def num_states(model):
-    if isinstance(model, (RDQ20MFModel, AsRateIndependent)):
-        ns = C.c_int()
-        check(lib().tb_sarcomere_model_info(model.sid, C.byref(ns), None))
-        return ns.value
-    return model.num_states
-
-
-def default_initial_state(model, n_points=1):
+def default_sarcomere_state(model, n_points=1):
     """default_initial_state!(Q, model): Q[1] = 1, the rest 0 (contraction.jl:371-375); shape (n_states, n_points)."""
     u = np.zeros((num_states(model), n_points))
     u[0] = 1.0
@@ -1413,7 +1409,7 @@ class SarcomereState:
     def __init__(self, device, model, n_points, initial=None):
         self.device, self.model, self.n_points = device, model, int(n_points)
         self.n_states = num_states(model)
-        u = default_initial_state(model, self.n_points) if initial is None else np.ascontiguousarray(initial, dtype=np.float64)
+        u = default_sarcomere_state(model, self.n_points) if initial is None else np.ascontiguousarray(initial, dtype=np.float64)
         if u.shape != (self.n_states, self.n_points):
             raise ValueError("SarcomereState: initial state must have shape (n_states, n_points)")
         self.u = device.to_device(u.ravel()) if self.n_points else DeviceVector(device, 0)
