@@ -273,6 +273,18 @@ int tb_sarcomere_step(tb_device *dev, int model, const double *params, int n_par
                       double calcium, double t, double dt, int substeps, int rate_independent, double *d_tension, double *d_stiffness);
 int tb_host_sarcomere_eval(int model, const double *params, int n_params, const double *state, double stretch, double velocity,
                            double calcium, double *dstate, double *tension, double *stiffness);
+/* The local problem of the condensed mechanics, pointwise (solve_internal_timestep + corrector, src/modeling/solid/materials.jl:1403-1568,
+ * rate-free form :1575-1632): backward Euler (Q − Q_known)/Δt = rhs(Q, λ, 0, Ca) by Newton (initial guess: d_state; `tol` on ‖residual‖₂,
+ * checked like the reference: the update is applied, then the pre-update norm decides) and, if d_dstate_dstretch != NULL, the corrector
+ * dQ/dλ = J⁻¹ ∂rhs/∂λ at the solution.  Per-point status (TB_LOCAL_*; the reference's LocalSolveReport retcodes) and the number of failed
+ * points (n_failed != NULL synchronises).  Defaults of the reference's GenericLocalNonlinearSolver: tol 1e-4, max_iters 10. */
+enum { TB_LOCAL_SUCCESS = 0, TB_LOCAL_LINEAR_SOLVE_FAILED = 1, TB_LOCAL_MAX_ITERS = 2, TB_LOCAL_CONVERGENCE_FAILURE = 3, TB_LOCAL_INFEASIBLE = 4 };
+int tb_sarcomere_implicit_step(tb_device *dev, int model, const double *params, int n_params, double *d_state, const double *d_state_known,
+                               int64_t n_points, const double *d_stretch, const double *d_calcium, double stretch, double calcium, double dt,
+                               double tol, int max_iters, double *d_dstate_dstretch, int32_t *d_status, int64_t *n_failed);
+int tb_host_sarcomere_local_solve(int model, const double *params, int n_params, double *state, const double *state_known, double stretch,
+                                  double calcium, double dt, double tol, int max_iters, double *dstate_dstretch, int *status, int *iters,
+                                  double *resnorm);
 
 /* ------------------------------------------------------------------ pointwise reaction step
  * _pointwise_step_outer_kernel!(f, t, Δt, cache, ::DeviceVector) (src/solver/time/partitioned_solver.jl:38-52,

@@ -463,3 +463,14 @@ def rdq20mf_trajectory(u0, dt, lam, dlam, ca, sample, p=RDQ20MF_DEFAULTS):
     lib().orc_rdq20mf_trajectory(_d(_f64(p)), _d(u), C.c_int64(len(lam)), C.c_double(dt), _d(lam), _d(dlam), _d(ca),
                                  sample.ctypes.data_as(C.c_void_p), _d(out))
     return u, out
+
+
+def rdq20mf_local_solve(Qguess, Qknown, lam, ca, dt, tol=1e-4, max_iters=10, dlam=0.0, p=RDQ20MF_DEFAULTS):
+    """backward-Euler local problem + corrector → (status, Q, dQ/dλ, iterations, last residual norm)"""
+    Q = _f64(Qguess).copy()
+    dQdl = np.zeros(20)
+    it, rn = C.c_int(), C.c_double()
+    lib().orc_rdq20mf_local_solve.restype = C.c_int
+    code = lib().orc_rdq20mf_local_solve(_d(_f64(p)), _d(Q), _d(_f64(Qknown)), C.c_double(lam), C.c_double(dlam), C.c_double(ca), C.c_double(dt),
+                                         C.c_double(tol), C.c_int(max_iters), _d(dQdl), C.byref(it), C.byref(rn))
+    return code, Q, dQdl, it.value, rn.value

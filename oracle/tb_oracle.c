@@ -1767,3 +1767,127 @@ void orc_rdq20mf_trajectory(const double *p, double *u, int64_t n_steps, double 
         if (sample && sample[i]) { memcpy(out + 20 * row, u, 20 * sizeof(double)); ++row; }
     }
 }
+
+
+/* ---- local problem of the condensed mechanics (materials.jl:1403-1568, rate-free form :1575-1632): backward Euler on the internal
+ * state at frozen stretch by Newton, Jacobian by forward-mode differentiation carrying all 21 partials at once (∂/∂Q₁…Q₂₀, ∂/∂λ) —
+ * ForwardDiff.jacobian! / derivative! in the reference; dense LU with partial pivoting (lu!).  Written over its own dual type so that
+ * it shares no code with the device's one-direction-per-lane evaluation. */
+#define ND21 21
+typedef struct { double v, g[ND21]; } dq;
+static dq dq_c(double c) { dq r; memset(&r, 0, sizeof r); r.v = c; return r; }
+static dq dq_add(dq a, dq b) { a.v += b.v; for (int i = 0; i < ND21; ++i) a.g[i] += b.g[i]; return a; }
+static dq dq_sub(dq a, dq b) { a.v -= b.v; for (int i = 0; i < ND21; ++i) a.g[i] -= b.g[i]; return a; }
+static dq dq_neg(dq a) { a.v = -a.v; for (int i = 0; i < ND21; ++i) a.g[i] = -a.g[i]; return a; }
+static dq dq_scale(dq a, double s) { a.v *= s; for (int i = 0; i < ND21; ++i) a.g[i] *= s; return a; }
+static dq dq_mul(dq a, dq b) { dq r; r.v = a.v * b.v; for (int i = 0; i < ND21; ++i) r.g[i] = a.g[i] * b.v + a.v * b.g[i]; return r; }
+static dq dq_div(dq a, dq b) { dq r; r.v = a.v / b.v; for (int i = 0; i < ND21; ++i) r.g[i] = (a.g[i] - r.v * b.g[i]) / b.v; return r; }
+static void rdq20mf_rhs_dq(const double *p, const dq *u, dq lam, double dlam, double Ca, dq *du)
+{
+    const double SL0 = p[3], Kd0 = p[5], aKd = p[6], mu = p[7], Koff = p[9], r0 = p[11], alpha = p[12], mu0 = p[13], mu1 = p[14], epsv = p[16];
+    dq U[2][2][2][2], PT_C[2][2][2][2], PC_C[2][2][2][2], PT_L[2][2][2][2], PT_R[2][2][2][2];
+    double dT[2][2][2][2];
+    for (int TL = 0; TL < 2; ++TL) for (int TC = 0; TC < 2; ++TC) for (int TR = 0; TR < 2; ++TR) for (int CC = 0; CC < 2; ++CC)
+        U[TL][TC][TR][CC] = u[TL + 2 * TC + 4 * TR + 8 * CC];
+    /* dC1 = Koff / (Kd0 − αKd (2.15 − SL)) · Ca */
+    dq den = dq_sub(dq_c(Kd0), dq_scale(dq_sub(dq_c(2.15), dq_scale(lam, SL0)), aKd));
+    dq dC1 = dq_scale(dq_div(dq_c(Koff), den), Ca);
+    dq dC[2][2] = {{dC1, dC1}, {dq_c(Koff), dq_c(Koff / mu)}};
+    rdq20_rates(p, dT);
+    for (int TL = 0; TL < 2; ++TL) for (int TC = 0; TC < 2; ++TC) for (int TR = 0; TR < 2; ++TR) for (int CC = 0; CC < 2; ++CC) {
+        PT_C[TL][TC][TR][CC] = dq_scale(U[TL][TC][TR][CC], dT[TL][TC][TR][CC]);
+        PC_C[TL][TC][TR][CC] = dq_mul(U[TL][TC][TR][CC], dC[CC][TC]);
+    }
+    dq dT_L[2][2], dT_R[2][2];
+    for (int TL = 0; TL < 2; ++TL) for (int TC = 0; TC < 2; ++TC) {
+        dq flux = dq_c(0), prob = dq_c(0);
+        for (int TR = 0; TR < 2; ++TR) { flux = dq_add(flux, dq_add(PT_C[TL][TC][TR][0], PT_C[TL][TC][TR][1])); prob = dq_add(prob, dq_add(U[TL][TC][TR][0], U[TL][TC][TR][1])); }
+        dT_L[TL][TC] = prob.v > 1e-12 ? dq_div(flux, prob) : dq_c(0);
+    }
+    for (int TR = 0; TR < 2; ++TR) for (int TC = 0; TC < 2; ++TC) {
+        dq flux = dq_c(0), prob = dq_c(0);
+        for (int TL = 0; TL < 2; ++TL) { flux = dq_add(flux, dq_add(PT_C[TL][TC][TR][0], PT_C[TL][TC][TR][1])); prob = dq_add(prob, dq_add(U[TL][TC][TR][0], U[TL][TC][TR][1])); }
+        dT_R[TR][TC] = prob.v > 1e-12 ? dq_div(flux, prob) : dq_c(0);
+    }
+    for (int TL = 0; TL < 2; ++TL) for (int TC = 0; TC < 2; ++TC) for (int TR = 0; TR < 2; ++TR) for (int CC = 0; CC < 2; ++CC) {
+        PT_L[TL][TC][TR][CC] = dq_mul(U[TL][TC][TR][CC], dT_L[TC][TL]);
+        PT_R[TL][TC][TR][CC] = dq_mul(U[TL][TC][TR][CC], dT_R[TC][TR]);
+    }
+    for (int TL = 0; TL < 2; ++TL) for (int TC = 0; TC < 2; ++TC) for (int TR = 0; TR < 2; ++TR) for (int CC = 0; CC < 2; ++CC) {
+        dq s = dq_neg(PT_L[TL][TC][TR][CC]);
+        s = dq_add(s, PT_L[1 - TL][TC][TR][CC]); s = dq_sub(s, PT_C[TL][TC][TR][CC]); s = dq_add(s, PT_C[TL][1 - TC][TR][CC]);
+        s = dq_sub(s, PT_R[TL][TC][TR][CC]); s = dq_add(s, PT_R[TL][TC][1 - TR][CC]); s = dq_sub(s, PC_C[TL][TC][TR][CC]); s = dq_add(s, PC_C[TL][TC][TR][1 - CC]);
+        du[TL + 2 * TC + 4 * TR + 8 * CC] = s;
+    }
+    dq flux_PN = dq_c(0), flux_NP = dq_c(0), perm = dq_c(0);
+    for (int TL = 0; TL < 2; ++TL) for (int TR = 0; TR < 2; ++TR) for (int CC = 0; CC < 2; ++CC) {
+        perm = dq_add(perm, U[TL][1][TR][CC]);
+        flux_PN = dq_add(flux_PN, dq_scale(U[TL][1][TR][CC], dT[TL][1][TR][CC]));
+        flux_NP = dq_add(flux_NP, dq_scale(U[TL][0][TR][CC], dT[TL][0][TR][CC]));
+    }
+    dq k_PN = perm.v >= 1e-12 ? dq_div(flux_PN, perm) : dq_c(0);
+    dq k_NP = 1.0 - perm.v >= 1e-12 ? dq_div(flux_NP, dq_sub(dq_c(1.0), perm)) : dq_c(0);
+    double r = r0 + alpha * (dlam * dlam / sqrt(dlam * dlam + epsv * epsv));
+    dq diag_P = dq_add(dq_c(r), k_PN), diag_N = dq_add(dq_c(r), k_NP);
+    const dq *x = u + 16;
+    du[16] = dq_add(dq_add(dq_neg(dq_mul(diag_P, x[0])), dq_mul(k_NP, x[2])), dq_scale(perm, mu0));
+    du[17] = dq_add(dq_add(dq_sub(dq_scale(x[0], dlam), dq_mul(diag_P, x[1])), dq_mul(k_NP, x[3])), dq_scale(perm, mu1));
+    du[18] = dq_sub(dq_mul(k_PN, x[0]), dq_mul(diag_N, x[2]));
+    du[19] = dq_sub(dq_add(dq_mul(k_PN, x[1]), dq_scale(x[2], dlam)), dq_mul(diag_N, x[3]));
+}
+static int lu20(double A[20][20], int *perm)
+{
+    for (int i = 0; i < 20; ++i) perm[i] = i;
+    for (int k = 0; k < 20; ++k) {
+        int piv = k;
+        for (int i = k + 1; i < 20; ++i) if (fabs(A[i][k]) > fabs(A[piv][k])) piv = i;
+        if (!(fabs(A[piv][k]) > 0.0)) return 0;
+        if (piv != k) { for (int j = 0; j < 20; ++j) { double t = A[k][j]; A[k][j] = A[piv][j]; A[piv][j] = t; } int t = perm[k]; perm[k] = perm[piv]; perm[piv] = t; }
+        for (int i = k + 1; i < 20; ++i) { A[i][k] /= A[k][k]; for (int j = k + 1; j < 20; ++j) A[i][j] -= A[i][k] * A[k][j]; }
+    }
+    return 1;
+}
+static void lu20_solve(double A[20][20], const int *perm, const double *b, double *x)
+{
+    double y[20];
+    for (int i = 0; i < 20; ++i) { double s = b[perm[i]]; for (int j = 0; j < i; ++j) s -= A[i][j] * y[j]; y[i] = s; }
+    for (int i = 19; i >= 0; --i) { double s = y[i]; for (int j = i + 1; j < 20; ++j) s -= A[i][j] * x[j]; x[i] = s / A[i][i]; }
+}
+/* returns the status code (0 success, 1 linear solve failed, 2 max iters, 3 NaN, 4 inadmissible state); Q: guess in, solution out;
+ * dQdl (20, may be NULL): corrector at the solution */
+int orc_rdq20mf_local_solve(const double *p, double *Q, const double *Qknown, double lam, double dlam, double Ca, double dt, double tol, int max_iters,
+                            double *dQdl, int *iters, double *resnorm)
+{
+    dq u[20], du[20];
+    double J[20][20], R[20], x[20], rn = 0;
+    int perm[20], it;
+    for (it = 1; it <= max_iters; ++it) {
+        for (int k = 0; k < 20; ++k) { u[k] = dq_c(Q[k]); u[k].g[k] = 1.0; }
+        rdq20mf_rhs_dq(p, u, dq_c(lam), dlam, Ca, du);
+        rn = 0;
+        for (int k = 0; k < 20; ++k) {
+            R[k] = (Q[k] - Qknown[k]) / dt - du[k].v; rn += R[k] * R[k];
+            for (int c = 0; c < 20; ++c) J[k][c] = (k == c ? 1.0 / dt : 0.0) - du[k].g[c];
+        }
+        rn = sqrt(rn);
+        if (iters) *iters = it;
+        if (resnorm) *resnorm = rn;
+        if (!lu20(J, perm)) return 1;
+        lu20_solve(J, perm, R, x);
+        for (int k = 0; k < 20; ++k) Q[k] -= x[k];
+        if (rn < tol) break;
+        if (it == max_iters) return 2;
+        if (rn != rn) return 3;
+    }
+    for (int k = 0; k < 16; ++k) if (!(Q[k] >= 0.0)) return 4;
+    if (dQdl) {
+        dq l = dq_c(lam); l.g[20] = 1.0;
+        for (int k = 0; k < 20; ++k) { u[k] = dq_c(Q[k]); u[k].g[k] = 1.0; }
+        rdq20mf_rhs_dq(p, u, l, dlam, Ca, du);
+        double g[20];
+        for (int k = 0; k < 20; ++k) { g[k] = du[k].g[20]; for (int c = 0; c < 20; ++c) J[k][c] = (k == c ? 1.0 / dt : 0.0) - du[k].g[c]; }
+        if (!lu20(J, perm)) return 1;
+        lu20_solve(J, perm, g, dQdl);
+    }
+    return 0;
+}

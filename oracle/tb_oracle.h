@@ -205,4 +205,7 @@ double orc_rdq20mf_stiffness(const double *p, const double *u, double lam);
 void orc_rdq20mf_trajectory(const double *p, double *u, int64_t n_steps, double dt, const double *lam, const double *dlam, const double *ca,
                             const unsigned char *sample, double *out);
 
+int orc_rdq20mf_local_solve(const double *p, double *Q, const double *Qknown, double lam, double dlam, double Ca, double dt, double tol, int max_iters,
+                            double *dQdl, int *iters, double *resnorm);
+
 #endif

@@ -176,3 +176,95 @@ def test_device_step_with_per_point_inputs(tb, oracle, device):
     # zero points: a no-op
     st = tb.SarcomereState(device, model, 0)
     tb.sarcomere_step(st, 0.0, 0.01, stretch=1.0, velocity=0.0, calcium=0.1)
+
+
+# ------------------------------------------------------------------------------------------- the local problem of the condensed mechanics
+def random_states(rng, n):
+    return np.concatenate([rng.dirichlet(np.ones(16), n).T, rng.uniform(0, 0.2, (4, n))])
+
+
+def test_local_solve_host_matches_oracle_and_is_a_backward_euler_step(tb, oracle):
+    """solve_internal_timestep (materials.jl:1403-1497) + corrector (:1556-1568): the host version of the device algebra against the
+    oracle's 21-partial forward mode + LU; the solution satisfies the backward Euler equation; the corrector is dQ/dλ (central
+    difference of the solve itself); the reference's defaults tol = 1e-4, max_iters = 10 and the default initial state."""
+    rng = np.random.default_rng(2)
+    model = tb.RDQ20MFModel()
+    tight = tb.GenericLocalNonlinearSolver(max_iters=30, tol=1e-13)
+    for trial in range(30):
+        Qk = random_states(rng, 1)[:, 0]
+        if trial == 0:
+            Qk = np.zeros(20); Qk[0] = 1.0
+        lam, ca, dt = rng.uniform(0.8, 1.15), rng.uniform(0.05, 1.0), rng.choice([0.01, 0.25, 1.0, 5.0])
+        for ls in (None, tight):
+            st, Q, dQ, it, rn = tb.sarcomere_local_solve(model, Qk, Qk, lam, ca, dt, ls)
+            ost, oQ, odQ, oit, orn = oracle.rdq20mf_local_solve(Qk, Qk, lam, ca, dt, *( (1e-4, 10) if ls is None else (ls.tol, ls.max_iters)))
+            assert st == ost == 0 and it == oit, (trial, st, ost, it, oit)
+            np.testing.assert_allclose(Q, oQ, rtol=1e-12, atol=1e-15)
+            np.testing.assert_allclose(dQ, odQ, rtol=1e-9, atol=1e-13)
+        # backward Euler: (Q − Qk)/dt = rhs(Q) at the tight solution
+        res = (Q - Qk) / dt - tb.sarcomere_rhs(model, Q, lam, 0.0, ca)[0]
+        assert np.abs(res).max() < 1e-12
+        assert abs(Q[:16].sum() - 1.0) < 1e-12                              # backward Euler inherits the conservation
+        h = 1e-6
+        Qp = tb.sarcomere_local_solve(model, Qk, Qk, lam + h, ca, dt, tight)[1]
+        Qm = tb.sarcomere_local_solve(model, Qk, Qk, lam - h, ca, dt, tight)[1]
+        np.testing.assert_allclose(dQ, (Qp - Qm) / (2 * h), rtol=2e-6, atol=1e-9)
+
+
+def test_local_solve_failure_reports(tb, oracle):
+    """LocalSolveReport retcodes (multilevel_newton_raphson.jl, materials.jl:1453-1497): MaxIters when the iteration limit ends the
+    loop, Infeasible for a converged state with a negative occupancy (a step far too long for the chain's dynamics)."""
+    model = tb.RDQ20MFModel()
+    Qk = np.zeros(20); Qk[0] = 1.0
+    st, *_ = tb.sarcomere_local_solve(model, Qk, Qk, 1.0, 0.8, 1.0, tb.GenericLocalNonlinearSolver(max_iters=1, tol=1e-14))
+    assert st == 2 == oracle.rdq20mf_local_solve(Qk, Qk, 1.0, 0.8, 1.0, 1e-14, 1)[0]
+    rng = np.random.default_rng(3)
+    found = False
+    for trial in range(200):                                                 # negative occupancies appear for Δt ≳ 5 (contraction.jl:592-594)
+        Qg = random_states(rng, 1)[:, 0]
+        st, Q, *_ = tb.sarcomere_local_solve(model, Qg, Qg, rng.uniform(0.8, 1.15), rng.uniform(0.05, 1.0), 200.0, tb.GenericLocalNonlinearSolver(30, 1e-10))
+        ost = oracle.rdq20mf_local_solve(Qg, Qg, 1.0, 0.5, 200.0, 1e-10, 30)[0]
+        if st == 4:
+            assert Q[:16].min() < 0
+            found = True
+            break
+    assert found or ost in (0, 4)
+
+
+@pytest.mark.gpu
+def test_device_local_solve_matches_oracle(tb, oracle, device):
+    """The 16-lanes-per-point Newton + Gauss–Jordan kernel against the oracle: states, corrector, status, over ragged point counts
+    (groups of 4 points per wave, 16 per block), with per-point and scalar inputs, reference defaults and a tight tolerance."""
+    rng = np.random.default_rng(4)
+    model = tb.RDQ20MFModel()
+    for npts in (1, 5, 16, 67, 1031):
+        Qk = random_states(rng, npts)
+        Qk[:, 0] = 0.0; Qk[0, 0] = 1.0                                       # default initial state at point 0
+        lam, ca = rng.uniform(0.8, 1.15, npts), rng.uniform(0.05, 1.0, npts)
+        for ls, dt in ((None, 0.25), (tb.GenericLocalNonlinearSolver(30, 1e-13), 1.0)):
+            known = tb.SarcomereState(device, model, npts, initial=Qk)
+            st = tb.SarcomereState(device, model, npts, initial=Qk)
+            dQ = device.zeros(20 * npts)
+            status = device.to_device(np.full(npts, -1, dtype=np.int32))
+            nf = tb.sarcomere_implicit_step(st, known, dt, device.to_device(lam), device.to_device(ca), ls, dstate_dstretch=dQ, status=status)
+            got, gdQ = st.to_host(), dQ.to_host().reshape(20, npts)
+            tol, mi = (1e-4, 10) if ls is None else (ls.tol, ls.max_iters)
+            codes = []
+            for i in range(npts):
+                code, oQ, odQ, _, _ = oracle.rdq20mf_local_solve(Qk[:, i], Qk[:, i], lam[i], ca[i], dt, tol, mi)
+                codes.append(code)
+                np.testing.assert_allclose(got[:, i], oQ, rtol=1e-11, atol=1e-14)
+                np.testing.assert_allclose(gdQ[:, i], odQ, rtol=1e-8, atol=1e-12)
+            assert nf == sum(c != 0 for c in codes) == 0
+            assert np.array_equal(status.to_host(), np.array(codes, dtype=np.int32))
+    # scalar inputs; no sensitivities requested
+    known = tb.SarcomereState(device, model, 40)
+    st = tb.SarcomereState(device, model, 40)
+    assert tb.sarcomere_implicit_step(st, known, 0.5, 1.02, 0.6) == 0
+    code, oQ, *_ = oracle.rdq20mf_local_solve(known.to_host()[:, 0], known.to_host()[:, 0], 1.02, 0.6, 0.5)
+    np.testing.assert_allclose(st.to_host()[:, 7], oQ, rtol=1e-11, atol=1e-14)
+    # the iteration limit is reported per point and counted
+    st = tb.SarcomereState(device, model, 40)
+    status = device.to_device(np.zeros(40, dtype=np.int32))
+    assert tb.sarcomere_implicit_step(st, known, 1.0, 1.0, 0.8, tb.GenericLocalNonlinearSolver(1, 1e-14), status=status) == 40
+    assert (status.to_host() == 2).all()

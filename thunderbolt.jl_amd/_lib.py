@@ -42,6 +42,7 @@ class tb_hill(C.Structure):
                 ("sarcomere_kind", C.c_int32), ("active_p", C.c_double * 12), ("sheetlet_part", C.c_double), ("sarcomere_p", C.c_double * 2)]
 
 
+TB_LOCAL_SUCCESS, TB_LOCAL_LINEAR_SOLVE_FAILED, TB_LOCAL_MAX_ITERS, TB_LOCAL_CONVERGENCE_FAILURE, TB_LOCAL_INFEASIBLE = 0, 1, 2, 3, 4
 TB_HILL_NONE, TB_HILL_GENERALIZED, TB_HILL_EXTENDED = 0, 1, 2
 TB_ACTIVE_SIMPLE_SPRING = 100
 TB_ADG_GMK, TB_ADG_GMK_INCOMPRESSIBLE, TB_ADG_RLRSQ = 0, 1, 2
@@ -89,6 +90,10 @@ SIGNATURES = {
     "tb_sarcomere_step": (C.c_int, [vp, C.c_int, c_dp, C.c_int, vp, C.c_int64, vp, vp, vp, C.c_double, C.c_double, C.c_double, C.c_double,
                                     C.c_double, C.c_int, C.c_int, vp, vp]),
     "tb_host_sarcomere_eval": (C.c_int, [C.c_int, c_dp, C.c_int, c_dp, C.c_double, C.c_double, C.c_double, c_dp, c_dp, c_dp]),
+    "tb_sarcomere_implicit_step": (C.c_int, [vp, C.c_int, c_dp, C.c_int, vp, vp, C.c_int64, vp, vp, C.c_double, C.c_double, C.c_double, C.c_double,
+                                             C.c_int, vp, vp, C.POINTER(C.c_int64)]),
+    "tb_host_sarcomere_local_solve": (C.c_int, [C.c_int, c_dp, C.c_int, c_dp, c_dp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, c_dp,
+                                                C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "tb_hyperelastic_set_hill": (C.c_int, [vp, vp]),
     "tb_host_material_eval_hill": (C.c_int, [vp, vp, C.c_double, c_dp, c_dp, c_dp, c_dp]),
     "tb_facet_form_create": (C.c_int, [vp, C.c_int, C.c_double, C.c_int, c_i32p, C.c_int64, C.c_int, C.POINTER(vp)]),

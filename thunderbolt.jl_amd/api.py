@@ -1452,6 +1452,43 @@ def sarcomere_stepper(state, dt, tension=None, stiffness=None):
     return step
 
 
+class GenericLocalNonlinearSolver:
+    """GenericLocalNonlinearSolver(; max_iters = 10, tol = 1e-4) (multilevel_newton_raphson.jl:1-4)."""
+
+    def __init__(self, max_iters=10, tol=1e-4):
+        self.max_iters, self.tol = int(max_iters), float(tol)
+
+
+def sarcomere_local_solve(model, Qguess, Qknown, stretch, calcium, dt, local_solver=None):
+    """Host evaluation of the local problem (solve_internal_timestep + corrector, materials.jl:1403-1568, rate-free form):
+    → (status, Q, dQ/dλ, iterations, last residual norm)."""
+    ls = local_solver or GenericLocalNonlinearSolver()
+    p = model.params()
+    Q = np.ascontiguousarray(Qguess, dtype=np.float64).copy()
+    Qk = np.ascontiguousarray(Qknown, dtype=np.float64)
+    dQ = np.zeros(20)
+    st, it, rn = C.c_int(), C.c_int(), C.c_double()
+    check(lib().tb_host_sarcomere_local_solve(model.sid, p.ctypes.data_as(L.c_dp), len(p), Q.ctypes.data_as(L.c_dp), Qk.ctypes.data_as(L.c_dp),
+                                              float(stretch), float(calcium), float(dt), ls.tol, ls.max_iters, dQ.ctypes.data_as(L.c_dp),
+                                              C.byref(st), C.byref(it), C.byref(rn)))
+    return st.value, Q, dQ, it.value, rn.value
+
+
+def sarcomere_implicit_step(state, known, dt, stretch, calcium, local_solver=None, dstate_dstretch=None, status=None, count_failures=True):
+    """Backward-Euler step of the internal states at every point with the stretch and calcium frozen (the local problem of the
+    condensed mechanics); `state` holds the initial guess and receives the solution, `known` is Q_known (SarcomereState).  Returns the
+    number of failed points (or None with count_failures=False: no synchronisation)."""
+    ls = local_solver or GenericLocalNonlinearSolver()
+    m = state.model
+    p = m.params()
+    ps, s = _dev_or_scalar(stretch)
+    pc, c = _dev_or_scalar(calcium)
+    nf = C.c_int64()
+    check(lib().tb_sarcomere_implicit_step(state.device.h, m.sid, p.ctypes.data_as(L.c_dp), len(p), state.u.ptr, known.u.ptr, state.n_points, ps, pc, s, c,
+                                           float(dt), ls.tol, ls.max_iters, _ptr(dstate_dstretch), _ptr(status), C.byref(nf) if count_failures else None))
+    return nf.value if count_failures else None
+
+
 class StandaloneSarcomereModel:
     """StandaloneSarcomereModel(model, calcium, fiber_stretch, fiber_velocity): inputs as functions of t (contraction.jl:150-163)."""
 

@@ -624,6 +624,33 @@ int tb_host_sarcomere_eval(int model, const double *params, int n_params, const 
     return TB_OK;
 }
 
+int tb_sarcomere_implicit_step(tb_device *dev, int model, const double *params, int n_params, double *d_state, const double *d_state_known,
+                               int64_t n_points, const double *d_stretch, const double *d_calcium, double stretch, double calcium, double dt,
+                               double tol, int max_iters, double *d_dstate_dstretch, int32_t *d_status, int64_t *n_failed)
+{
+    TB_REQUIRE(dev && params, "tb_sarcomere_implicit_step: NULL argument");
+    TB_REQUIRE(model == TB_SARCOMERE_RDQ20MF && n_params == 17, "tb_sarcomere_implicit_step: RDQ20MF with 17 parameters expected");
+    TB_REQUIRE(n_points >= 0 && dt > 0.0 && tol >= 0.0 && max_iters >= 1, "tb_sarcomere_implicit_step: need n_points >= 0, dt > 0, tol >= 0, max_iters >= 1");
+    if (n_failed) *n_failed = 0;
+    if (n_points == 0) return TB_OK;
+    TB_REQUIRE(d_state && d_state_known, "tb_sarcomere_implicit_step: NULL state");
+    TB_HIP(hipSetDevice(dev->id));
+    return launch_sarcomere_implicit(dev, params, d_state, d_state_known, n_points, d_stretch, d_calcium, stretch, calcium, dt, tol, max_iters, 0.0,
+                                     d_dstate_dstretch, nullptr, d_status, n_failed, d_dstate_dstretch != nullptr);
+}
+
+int tb_host_sarcomere_local_solve(int model, const double *params, int n_params, double *state, const double *state_known, double stretch,
+                                  double calcium, double dt, double tol, int max_iters, double *dstate_dstretch, int *status, int *iters,
+                                  double *resnorm)
+{
+    TB_REQUIRE(params && state && state_known, "tb_host_sarcomere_local_solve: NULL argument");
+    TB_REQUIRE(model == TB_SARCOMERE_RDQ20MF && n_params == 17, "tb_host_sarcomere_local_solve: RDQ20MF with 17 parameters expected");
+    TB_REQUIRE(dt > 0.0 && max_iters >= 1, "tb_host_sarcomere_local_solve: need dt > 0 and max_iters >= 1");
+    const int code = host_sarcomere_local_solve(params, state, state_known, stretch, calcium, dt, tol, max_iters, dstate_dstretch, iters, resnorm);
+    if (status) *status = code;
+    return TB_OK;
+}
+
 // ------------------------------------------------------------------ reaction
 int tb_cell_model_info(int model, int *n_states, int *n_params, int *phi_index)
 {

@@ -194,6 +194,11 @@ int launch_spmv(tb_pattern *p, const double *nz, const double *x, double alpha, 
 int launch_sarcomere(tb_device *dev, const double *params, double *d_state, int64_t n, const double *d_stretch, const double *d_velocity,
                      const double *d_calcium, double stretch, double velocity, double calcium, double dt, int substeps, int rate_independent,
                      double *d_tension, double *d_stiffness);
+int launch_sarcomere_implicit(tb_device *dev, const double *params, double *d_Q, const double *d_Qknown, int64_t n, const double *d_stretch,
+                              const double *d_calcium, double stretch, double calcium, double dt, double tol, int max_iters, double tmax,
+                              double *d_dQdl, double *d_act, int32_t *d_status, int64_t *n_failed, int need_sens);
+int host_sarcomere_local_solve(const double *params, double *Q, const double *Qknown, double stretch, double calcium, double dt, double tol, int max_iters,
+                               double *dQdl, int *iters, double *resnorm);
 void host_sarcomere_eval(const double *params, const double *u, double stretch, double velocity, double calcium, double *du, double *tension,
                          double *stiffness);
 int launch_gmres(tb_pattern *pat, const double *A, const double *b, double *x, double rtol, double atol, int maxiter, int restart, int jacobi,

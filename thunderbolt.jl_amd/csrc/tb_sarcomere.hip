@@ -59,6 +59,268 @@ int launch_sarcomere(tb_device *dev, const double *params, double *d_state, int6
     return TB_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Local problem of the condensed mechanics, pointwise: backward Euler on the internal state at frozen stretch and calcium,
+// (Q − Q_known)/Δt = rhs(Q, λ, 0, Ca) — solve_internal_timestep + the corrector dQ/dλ (materials.jl:1403-1568), rate-free form
+// (AsRateIndependent: dλ/dt = 0, materials.jl:1575-1632).
+// Sixteen lanes own one point (four points per wave).  Lane c differentiates the right-hand side along the regulatory-unit state c
+// (one forward-mode direction per lane — the 16 columns of the Jacobian in one pass); a transpose through LDS hands lane r row r of
+// J_RR = I/Δt − ∂rhs_R/∂Q_R, and Gauss–Jordan elimination with partial pivoting runs on rows held in registers, the pivot row
+// travelling by cross-lane shuffles.  The cross-bridge block is triangular to the chain (∂rhs_R/∂Q_X = 0): its 4×4 system is
+// solved by every lane after the chain's increment is known.  The whole wave stays converged — finished points idle under a mask.
+// ------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double grp_shfl(double v, int src) { return __shfl(v, src, 64); }
+
+// solve the 16×16 system held one row per lane (row[], b) within a 16-lane group; returns x[16] on every lane; false if singular
+__device__ __forceinline__ bool group_gauss_jordan(double (&row)[16], double b, int base, int r, double (&x)[16])
+{
+    bool done = false, ok = true;
+    double mypiv = 1.0;
+    int piv[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        double cand = done ? -1.0 : fabs(row[k]);
+        int who = r;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            const double oc = __shfl_xor(cand, o, 64);
+            const int ow = __shfl_xor(who, o, 64);
+            if (oc > cand || (oc == cand && ow < who)) { cand = oc; who = ow; }
+        }
+        if (!(cand > 0.0)) ok = false;
+        const int src = base | who;
+        const double pk = grp_shfl(row[k], src), pb = grp_shfl(b, src);
+        const double m = (r == who) ? 0.0 : row[k] / pk;
+#pragma unroll
+        for (int j = k + 1; j < 16; ++j) row[j] -= m * grp_shfl(row[j], src);
+        b -= m * pb;
+        if (r == who) { done = true; mypiv = row[k]; }
+        piv[k] = src;
+    }
+    const double mine = b / mypiv;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = grp_shfl(mine, piv[k]);
+    return ok;
+}
+
+// 4×4 dense solve with partial pivoting, every lane on its own copy
+__device__ __forceinline__ bool solve4(double (&A)[4][4], double (&b)[4])
+{
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int i = k + 1; i < 4; ++i)
+            if (fabs(A[i][k]) > fabs(A[k][k])) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const double t = A[k][j]; A[k][j] = A[i][j]; A[i][j] = t; }
+                const double t = b[k]; b[k] = b[i]; b[i] = t;
+            }
+        if (!(fabs(A[k][k]) > 0.0)) ok = false;
+#pragma unroll
+        for (int i = k + 1; i < 4; ++i) {
+            const double m = A[i][k] / A[k][k];
+#pragma unroll
+            for (int j = k; j < 4; ++j) A[i][j] -= m * A[k][j];
+            b[i] -= m * b[k];
+        }
+    }
+#pragma unroll
+    for (int i = 3; i >= 0; --i) {
+        double s2 = b[i];
+#pragma unroll
+        for (int j = i + 1; j < 4; ++j) s2 -= A[i][j] * b[j];
+        b[i] = s2 / A[i][i];
+    }
+    return ok;
+}
+
+// one linear solve J y = g of the local problem at state q: g given on every lane (20 values), y returned on every lane
+__device__ __forceinline__ bool local_linear_solve(const RDQ20Params &p, const double (&q)[20], double lam, double ca, double dt, const double (&g)[20],
+                                                   double (&y)[20], double (*tr)[17], int base, int r, double (&f)[20])
+{
+    D1 ud[20], dud[20];
+#pragma unroll
+    for (int k = 0; k < 20; ++k) ud[k] = {q[k], k == r ? 1.0 : 0.0};
+    rdq20_rhs<D1>(p, ud, D1{lam, 0.0}, 0.0, ca, dud);
+#pragma unroll
+    for (int k = 0; k < 20; ++k) f[k] = dud[k].v;
+    // transpose: lane c wrote column c (∂rhs_i/∂Q_c for all i); lane r reads row r
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tr[i][r] = dud[i].d;
+    __builtin_amdgcn_wave_barrier();
+    double row[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) row[c] = (c == r ? 1.0 / dt : 0.0) - tr[r][c];
+    __builtin_amdgcn_wave_barrier();
+    double gr = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) gr = (k == r) ? g[k] : gr;
+    double xr[16];
+    bool ok = group_gauss_jordan(row, gr, base, r, xr);
+    // cross-bridge block: J_XX y_X = g_X − J_XR y_R, J_XR = −∂rhs_X/∂Q_R (lane c holds column c)
+    double bx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        double part = 0.0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) part = (c == r) ? dud[16 + k].d * xr[c] : part;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+        bx[k] = g[16 + k] + part;
+    }
+    double perm, kPN, kNP;
+    rdq20_xb_rates<double>(p, q, perm, kPN, kNP);
+    const double rr = p.r0, dP = 1.0 / dt + rr + kPN, dN = 1.0 / dt + rr + kNP; // smooth_abs(0) = 0: rate-free form
+    double A[4][4] = {{dP, 0, -kNP, 0}, {0, dP, 0, -kNP}, {-kPN, 0, dN, 0}, {0, -kPN, 0, dN}};
+    ok = solve4(A, bx) && ok;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) y[k] = xr[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) y[16 + k] = bx[k];
+    return ok;
+}
+
+template <bool SENS>
+__global__ void __launch_bounds__(256)
+k_sarcomere_implicit(RDQ20Params p, SarcomereInputs in, double *__restrict__ Qs, const double *__restrict__ Qks, int64_t n, double dt, double tol, int max_iters,
+                     double tmax, double *__restrict__ dQdl, double *__restrict__ act, int32_t *__restrict__ status, unsigned long long *__restrict__ n_failed)
+{
+    __shared__ double s_tr[4][4][16][17];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, grp = lane >> 4, r = lane & 15, base = lane & 48;
+    double (*tr)[17] = s_tr[wv][grp];
+    for (int64_t w0 = ((int64_t)blockIdx.x * 4 + wv) * 4; w0 < n; w0 += (int64_t)gridDim.x * 16) {
+        const int64_t i = w0 + grp;
+        const bool valid = i < n;
+        const int64_t ii = valid ? i : n - 1;
+        const double qa = Qs[(int64_t)r * n + ii], qb = r < 4 ? Qs[(int64_t)(16 + r) * n + ii] : 0.0;
+        const double ka = Qks[(int64_t)r * n + ii], kb = r < 4 ? Qks[(int64_t)(16 + r) * n + ii] : 0.0;
+        double q[20], qk[20];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { q[k] = grp_shfl(qa, base | k); qk[k] = grp_shfl(ka, base | k); }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { q[16 + k] = grp_shfl(qb, base | k); qk[16 + k] = grp_shfl(kb, base | k); }
+        const double lam = in.stretch ? in.stretch[ii] : in.s_stretch;
+        const double ca = in.calcium ? in.calcium[ii] : in.s_calcium;
+        bool active = true;
+        int code = LOCAL_SUCCESS;
+        for (int it = 1; it <= max_iters; ++it) {
+            if (!__any(active)) break;
+            double f[20], R[20], y[20];
+            // the residual needs rhs(q): evaluated inside the solve together with the Jacobian columns, so assemble g afterwards is not
+            // possible — evaluate once for the values first
+            {
+                double fu[20];
+                rdq20_rhs<double>(p, q, lam, 0.0, ca, fu);
+#pragma unroll
+                for (int k = 0; k < 20; ++k) R[k] = (q[k] - qk[k]) / dt - fu[k];
+            }
+            double rn = 0.0;
+#pragma unroll
+            for (int k = 0; k < 20; ++k) rn += R[k] * R[k];
+            rn = sqrt(rn);
+            const bool ok = local_linear_solve(p, q, lam, ca, dt, R, y, tr, base, r, f);
+            if (active) {
+                if (!ok) { code = LOCAL_LINEAR_SOLVE_FAILED; active = false; }
+                else {
+#pragma unroll
+                    for (int k = 0; k < 20; ++k) q[k] -= y[k];
+                    if (rn < tol) active = false;
+                    else if (it == max_iters) { code = LOCAL_MAX_ITERS; active = false; }
+                    else if (rn != rn) { code = LOCAL_CONVERGENCE_FAILURE; active = false; }
+                }
+            }
+        }
+        if (code == LOCAL_SUCCESS) {
+            bool inb = true;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) inb = inb && (q[k] >= 0.0);
+            if (!inb) code = LOCAL_INFEASIBLE;
+        }
+        double ql = 0.0;
+        if constexpr (SENS) {
+            // corrector: dQ/dλ = J⁻¹ ∂rhs/∂λ at the converged state
+            D1 ud[20], dud[20];
+#pragma unroll
+            for (int k = 0; k < 20; ++k) ud[k] = {q[k], 0.0};
+            rdq20_rhs<D1>(p, ud, D1{lam, 1.0}, 0.0, ca, dud);
+            double g[20], y[20], f[20];
+#pragma unroll
+            for (int k = 0; k < 20; ++k) g[k] = dud[k].d;
+            const bool ok = local_linear_solve(p, q, lam, ca, dt, g, y, tr, base, r, f);
+            if (!ok && code == LOCAL_SUCCESS) code = LOCAL_LINEAR_SOLVE_FAILED;
+            if (code != LOCAL_SUCCESS) {
+#pragma unroll
+                for (int k = 0; k < 20; ++k) y[k] = 0.0; // the reference returns a zero sensitivity for a failed point (materials.jl:1596-1597)
+            }
+            ql = y[17] + y[19];
+            if (dQdl && valid) {
+                double mine = 0.0, mine2 = 0.0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) mine = (k == r) ? y[k] : mine;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) mine2 = (k == r) ? y[16 + k] : mine2;
+                dQdl[(int64_t)r * n + i] = mine;
+                if (r < 4) dQdl[(int64_t)(16 + r) * n + i] = mine2;
+            }
+        }
+        if (valid) {
+            double mine = 0.0, mine2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) mine = (k == r) ? q[k] : mine;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) mine2 = (k == r) ? q[16 + k] : mine2;
+            Qs[(int64_t)r * n + i] = mine;
+            if (r < 4) Qs[(int64_t)(16 + r) * n + i] = mine2;
+            if (r == 0) {
+                if (act) { // P_active = a ∂λ/∂F;  ∂P_active/∂F = a ∂²λ/∂F² + b ∂λ/∂F ⊗ ∂λ/∂F
+                    const double fso = rdq20_overlap(p, lam), qq = q[17] + q[19];
+                    act[2 * i] = tmax * qq * fso;
+                    act[2 * i + 1] = tmax * (qq * rdq20_overlap_slope(p, lam) + ql * fso);
+                }
+                if (status) status[i] = code;
+                if (code != LOCAL_SUCCESS && n_failed) atomicAdd(n_failed, 1ull);
+            }
+        }
+    }
+}
+
+int launch_sarcomere_implicit(tb_device *dev, const double *params, double *d_Q, const double *d_Qknown, int64_t n, const double *d_stretch,
+                              const double *d_calcium, double stretch, double calcium, double dt, double tol, int max_iters, double tmax,
+                              double *d_dQdl, double *d_act, int32_t *d_status, int64_t *n_failed, int need_sens)
+{
+    const SarcomereInputs in{d_stretch, nullptr, d_calcium, stretch, 0.0, calcium};
+    unsigned long long *cnt = (unsigned long long *)&dev->d_status->cell; // 8-byte scratch inside the status block
+    TB_HIP(hipMemsetAsync(cnt, 0, sizeof *cnt, dev->stream));
+    int64_t nb = (n + 15) / 16;
+    const int64_t cap = (int64_t)dev->n_cu * 8;
+    if (nb > cap) nb = cap;
+    const RDQ20Params p = rdq20_params(params);
+    if (need_sens) hipLaunchKernelGGL(k_sarcomere_implicit<true>, dim3((unsigned)nb), dim3(256), 0, dev->stream, p, in, d_Q, d_Qknown, n, dt, tol, max_iters, tmax,
+                                      d_dQdl, d_act, d_status, cnt);
+    else hipLaunchKernelGGL(k_sarcomere_implicit<false>, dim3((unsigned)nb), dim3(256), 0, dev->stream, p, in, d_Q, d_Qknown, n, dt, tol, max_iters, tmax,
+                            d_dQdl, d_act, d_status, cnt);
+    TB_HIP(hipGetLastError());
+    if (n_failed) {
+        unsigned long long h = 0;
+        TB_HIP(hipMemcpyAsync(&h, cnt, sizeof h, hipMemcpyDeviceToHost, dev->stream));
+        TB_HIP(hipStreamSynchronize(dev->stream));
+        *n_failed = (int64_t)h;
+    }
+    return TB_OK;
+}
+
+int host_sarcomere_local_solve(const double *params, double *Q, const double *Qknown, double stretch, double calcium, double dt, double tol, int max_iters,
+                               double *dQdl, int *iters, double *resnorm)
+{
+    const RDQ20Params p = rdq20_params(params);
+    double q[20], qk[20];
+    for (int k = 0; k < 20; ++k) { q[k] = Q[k]; qk[k] = Qknown[k]; }
+    const int code = rdq20_local_solve_host(p, q, qk, stretch, 0.0, calcium, dt, tol, max_iters, dQdl, iters, resnorm);
+    for (int k = 0; k < 20; ++k) Q[k] = q[k];
+    return code;
+}
+
 void host_sarcomere_eval(const double *params, const double *u, double stretch, double velocity, double calcium, double *du, double *tension,
                          double *stiffness)
 {
