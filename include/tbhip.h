@@ -240,6 +240,21 @@ typedef struct {
 int tb_hyperelastic_set_hill(tb_form *form, const tb_hill *hill); /* NULL or framework = TB_HILL_NONE: plain PK1Model */
 /* host evaluation of the whole constitutive law at one point (the code the kernels run): activation = Ta or the calcium state */
 int tb_host_material_eval_hill(const tb_material *material, const tb_hill *hill, double activation, const double *F, double *psi, double *P, double *A);
+/* Condensed internal variables: ActiveStressModel over a sarcomere model with state (RDQ20MF) whose evolution is solved per quadrature
+ * point inside the assembly — QuasiStaticCondensedElementCache + solve_local_constraint (src/modeling/solid/elements.jl:411-612,
+ * src/modeling/solid/materials.jl:472-502,1403-1632), rate-free local problem (AsRateIndependent: dλ/dt = 0).  With condensation set,
+ * tb_linearize / tb_residual first solve (Q − Q_known)/Δt = rhs(Q, λ(F), 0, Ca) at every quadrature point (λ = ‖F f₀‖; Ca through
+ * tb_hyperelastic_set_active_tension: scale · nodal field or scale) — writing Q back into d_state, which also supplies the initial guess —
+ * then assemble with P = ∂Ψ/∂F + Tmax (Q₁₈+Q₂₀) fso(λ) (F f₀)⊗f₀/λ and the tangent ∂P/∂F|_Q + ∂P/∂Q · dQ/dF (corrector).
+ * State arrays: n_states × n_points on the device, point-fastest, point = cell · n_qp + q (tb_hyperelastic_n_quadrature_points).
+ * tb_hyperelastic_local_solve_report: failures of the last assembly (the reference's check_local_solve_convergence; a step with failed
+ * points must be rejected by the caller).  sarcomere_model < 0 switches condensation off. */
+int tb_hyperelastic_set_condensation(tb_form *form, int sarcomere_model, const double *params, int n_params, double tmax, double local_tol,
+                                     int local_max_iters);
+int tb_hyperelastic_n_quadrature_points(tb_form *form, int64_t *n_points);
+int tb_hyperelastic_set_internal_state(tb_form *form, double *d_state, const double *d_state_known, double dt);
+int tb_hyperelastic_local_solve_report(tb_form *form, int64_t *n_failed, int32_t *status_host, int64_t len);
+
 /* Weak boundary conditions of a quasi-static problem (src/modeling/core/weak_boundary_conditions.jl): RobinBC
  * Ψ = α u·u (:102-198), NormalSpringBC Ψ = ½ kₛ (u·N)² (:200-300), ConstantPressureBC follower load p·J·F⁻ᵀ·n₀ with its
  * consistent tangent (:419-515).  `facets` lists n_facets pairs (cell, local facet) — Ferrite's FacetIndex, local facets of

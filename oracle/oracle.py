@@ -474,3 +474,24 @@ def rdq20mf_local_solve(Qguess, Qknown, lam, ca, dt, tol=1e-4, max_iters=10, dla
     code = lib().orc_rdq20mf_local_solve(_d(_f64(p)), _d(Q), _d(_f64(Qknown)), C.c_double(lam), C.c_double(dlam), C.c_double(ca), C.c_double(dt),
                                          C.c_double(tol), C.c_int(max_iters), _d(dQdl), C.byref(it), C.byref(rn))
     return code, Q, dQdl, it.value, rn.value
+
+
+_COND_KEEP = [None]
+
+
+def set_condensation(Q=None, Qknown=None, dt=1.0, tmax=1.0, tol=1e-4, max_iters=10, p=RDQ20MF_DEFAULTS, status=None):
+    """Condensed RDQ20-MF internal variable in element_hyperelastic / assemble_hyperelastic (global; set_condensation() switches it
+    off).  Q (20 × n_points, point = cell·n_qp + q, C-contiguous float64) is the initial guess and is overwritten with the solution;
+    calcium comes from set_active_tension(scale[, nodal field])."""
+    lib().orc_set_condensation.restype = None
+    lib().orc_set_condensation.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_void_p]
+    if Q is None:
+        _COND_KEEP[0] = None
+        lib().orc_set_condensation(None, 0.0, None, None, 0, 1.0, 0.0, 1, None)
+        return
+    assert Q.flags.c_contiguous and Q.dtype == np.float64 and Q.shape[0] == 20
+    Qk = np.ascontiguousarray(Qknown, dtype=np.float64)
+    pp = _f64(p)
+    _COND_KEEP[0] = (Q, Qk, pp, status)
+    lib().orc_set_condensation(pp.ctypes.data, float(tmax), Q.ctypes.data, Qk.ctypes.data, Q.shape[1], float(dt), float(tol), int(max_iters),
+                               None if status is None else status.ctypes.data)

@@ -1391,6 +1391,55 @@ static double g_act_scale = 0.0;
 static const double *g_act_field = NULL;
 void orc_set_active_tension(double tension, const double *field) { g_act_scale = tension; g_act_field = field; }
 
+/* condensed internal variable (QuasiStaticCondensedElementCache, elements.jl:411-470; material_routine materials.jl:472-502;
+ * solve_local_constraint rate-free :1575-1632; _solve_local_sarcomere_dQdF :1381-1395): global test state like g_mat_* */
+int orc_rdq20mf_local_solve(const double *p, double *Q, const double *Qknown, double lam, double dlam, double Ca, double dt, double tol, int max_iters,
+                            double *dQdl, int *iters, double *resnorm);
+double orc_rdq20mf_overlap(const double *p, double lam);
+static struct { int on; double p[17], tmax, dt, tol; int max_iters; double *Q; const double *Qknown; int64_t n_points; int *status; } g_cond;
+void orc_set_condensation(const double *p, double tmax, double *Q, const double *Qknown, int64_t n_points, double dt, double tol, int max_iters, int *status)
+{
+    memset(&g_cond, 0, sizeof g_cond);
+    if (!p) return;
+    g_cond.on = 1; memcpy(g_cond.p, p, sizeof g_cond.p);
+    g_cond.tmax = tmax; g_cond.Q = Q; g_cond.Qknown = Qknown; g_cond.n_points = n_points; g_cond.dt = dt; g_cond.tol = tol; g_cond.max_iters = max_iters;
+    g_cond.status = status;
+}
+static double overlap_slope_fd(const double *p, double lam)
+{
+    /* slope of the piecewise-linear fso on the branch containing λ: one-sided difference towards the branch interior */
+    double LA = p[0], LM = p[1], LB = p[2], SL0 = p[3], SL = lam * SL0, LMh = (LM - LB) * 0.5;
+    if (SL > LA && SL <= LM) return SL0 / LMh;
+    if (SL > LM && SL <= 2 * LA - LB) return 0.5 * SL0 / LMh;
+    if (SL > 2 * LA + LB && SL <= 2 * LA + LM) return -0.5 * SL0 / LMh;
+    return 0.0;
+}
+/* adds the active part at one point: P += a ∂λ/∂F, A += a ∂²λ/∂F² + b ∂λ/∂F ⊗ ∂λ/∂F after the local solve */
+static void condensed_active_part(int64_t point, const double *F, const double *f0, double Ca, double *P, double *A)
+{
+    double g[3], lam = 0;
+    for (int i = 0; i < 3; ++i) { g[i] = F[3 * i] * f0[0] + F[3 * i + 1] * f0[1] + F[3 * i + 2] * f0[2]; lam += g[i] * g[i]; }
+    lam = sqrt(lam);
+    double Q[20], Qk[20], dQdl[20];
+    for (int k = 0; k < 20; ++k) { Q[k] = g_cond.Q[k * g_cond.n_points + point]; Qk[k] = g_cond.Qknown[k * g_cond.n_points + point]; }
+    int code = orc_rdq20mf_local_solve(g_cond.p, Q, Qk, lam, 0.0, Ca, g_cond.dt, g_cond.tol, g_cond.max_iters, A ? dQdl : NULL, NULL, NULL);
+    if (code != 0) memset(dQdl, 0, sizeof dQdl);
+    for (int k = 0; k < 20; ++k) g_cond.Q[k * g_cond.n_points + point] = Q[k];
+    if (g_cond.status) g_cond.status[point] = code;
+    double fso = orc_rdq20mf_overlap(g_cond.p, lam), qq = Q[17] + Q[19];
+    double a = g_cond.tmax * qq * fso;
+    double dl[9];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) dl[3 * i + j] = g[i] * f0[j] / lam;
+    for (int e = 0; e < 9; ++e) P[e] += a * dl[e];
+    if (A) {
+        double b = g_cond.tmax * (qq * overlap_slope_fd(g_cond.p, lam) + (dQdl[17] + dQdl[19]) * fso);
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) for (int k = 0; k < 3; ++k) for (int l = 0; l < 3; ++l) {
+            double d2 = ((i == k) ? f0[j] * f0[l] / lam : 0.0) - dl[3 * i + j] * dl[3 * k + l] / lam;
+            A[9 * (3 * i + j) + 3 * k + l] += a * d2 + b * dl[3 * i + j] * dl[3 * k + l];
+        }
+    }
+}
+
 static int element_hyperelastic_cv(const orc_mesh *m, const cellvalues *cv, int64_t cell, const double *p,
                                    const double *fsn_const, const double *ue, double *Ke, double *re)
 {
@@ -1418,7 +1467,8 @@ static int element_hyperelastic_cv(const orc_mesh *m, const cellvalues *cv, int6
             fsn = frame;
         }
         g_active_tension = g_act_scale;
-        if (g_act_field && g_act_scale != 0.0) { /* with a Hill framework the same slot carries the calcium state */
+        if (g_cond.on) g_active_tension = 0.0; /* the active part is added after the local solve below */
+        else if (g_act_field && g_act_scale != 0.0) { /* with a Hill framework the same slot carries the calcium state */
             double ca = 0.0;
             for (int a = 0; a < cv->ngeo; ++a) ca += cv->M[q][a] * g_act_field[(int64_t)cell * cv->ngeo + a];
             g_active_tension = g_act_scale * ca;
@@ -1427,6 +1477,11 @@ static int element_hyperelastic_cv(const orc_mesh *m, const cellvalues *cv, int6
         else if (g_mat_energy == 0 && g_mat_penalty == 0) { double up[3] = {p[8], 0, 0}; orc_energy(0, 0, p, up, fsn, F, P, Ke ? A : NULL); }
         else orc_energy(g_mat_energy, g_mat_penalty, g_mat_p, g_mat_u, fsn, F, P, Ke ? A : NULL);
         g_active_tension = 0.0;
+        if (g_cond.on) {
+            double ca = g_act_scale;
+            if (g_act_field) { double sc = 0.0; for (int a = 0; a < cv->ngeo; ++a) sc += cv->M[q][a] * g_act_field[(int64_t)cell * cv->ngeo + a]; ca *= sc; }
+            condensed_active_part((int64_t)cell * cv->nq + q, F, fsn, ca, P, Ke ? A : NULL);
+        }
         for (int i = 0; i < nd; ++i) {
             int a = i / 3, c = i % 3;
             /* residualₑ[i] += ∇δui ⊡ P * dΩ */

@@ -208,4 +208,7 @@ void orc_rdq20mf_trajectory(const double *p, double *u, int64_t n_steps, double 
 int orc_rdq20mf_local_solve(const double *p, double *Q, const double *Qknown, double lam, double dlam, double Ca, double dt, double tol, int max_iters,
                             double *dQdl, int *iters, double *resnorm);
 
+/* condensed internal variable of the hyperelastic element routines (global test state; p = NULL switches it off) */
+void orc_set_condensation(const double *p, double tmax, double *Q, const double *Qknown, int64_t n_points, double dt, double tol, int max_iters, int *status);
+
 #endif

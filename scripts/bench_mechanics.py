@@ -11,6 +11,7 @@ ap.add_argument("--order", type=int, default=2)
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--strategy", default="element", choices=["atomic", "color", "element"])
 ap.add_argument("--cpu-n", type=int, default=8)
+ap.add_argument("--condensed", action="store_true", help="active stress with the RDQ20-MF internal state condensed per quadrature point")
 args = ap.parse_args()
 import thunderbolt_jl_amd as tb
 dev = tb.MI355XDevice(0)
@@ -20,9 +21,14 @@ dh = tb.DofHandler(g, tb.LagrangeCollection(args.order) ** 3)
 sp = tb.allocate_matrix(dh)
 t_setup = time.time() - t0
 model = tb.QuasiStaticModel("u", tb.PK1Model(tb.HolzapfelOgden2009Model(), tb.ConstantCoefficient(tb.OrthotropicMicrostructure([1, 0, 0], [0, 1, 0], [0, 0, 1]))))
+if args.condensed:
+    fsn = tb.ConstantCoefficient(tb.OrthotropicMicrostructure([1, 0, 0], [0, 1, 0], [0, 0, 1]))
+    model = tb.QuasiStaticModel("u", tb.ActiveStressModel(tb.HolzapfelOgden2009Model(), tb.SimpleActiveStress(Tmax=50.0),
+                                                      tb.CaDrivenInternalSarcomereModel(tb.AsRateIndependent(tb.RDQ20MFModel()), 0.6), fsn))
 st = {"atomic": tb.AtomicAssemblyStrategy, "color": tb.PerColorAssemblyStrategy, "element": tb.ElementAssemblyStrategy}[args.strategy](dev)
 op = tb.setup_operator(st, model, dh, sp)
-xyz_dof = np.zeros(dh.ndofs)
+if args.condensed:
+    tb.set_timestep(op, 0.5)
 u = 1e-2 * np.sin(np.pi * np.arange(dh.ndofs) / dh.ndofs)   # smooth small displacement state
 du, res = dev.to_device(u), dev.zeros(dh.ndofs)
 tb.update_linearization(op, du, 0.0, residual=res)          # warm-up (builds block positions / colours)
@@ -35,9 +41,12 @@ for _ in range(args.steps):
     e[2].record()
     tl += e[0].elapsed_ms(e[1]); tr += e[1].elapsed_ms(e[2])
 tl /= args.steps; tr /= args.steps
-out = {"workload": "HO2009 quasi-static, Q%d displacement, %d^3 hex (%d cells, %d dofs, nnz %d), %s scatter" % (args.order, args.n, g.n_cells, dh.ndofs, sp.nnz, args.strategy),
+out = {"workload": ("HO2009 + condensed RDQ20-MF active stress, " if args.condensed else "") + "HO2009 quasi-static, Q%d displacement, %d^3 hex (%d cells, %d dofs, nnz %d), %s scatter" % (args.order, args.n, g.n_cells, dh.ndofs, sp.nnz, args.strategy),
        "linearize_ms": tl, "residual_ms": tr, "linearize_cells_per_s": g.n_cells / (tl * 1e-3), "residual_cells_per_s": g.n_cells / (tr * 1e-3),
        "host_setup_s": t_setup}
+if args.condensed:
+    out["quadrature_points"] = op.internal.n_points
+    print(json.dumps(out)); sys.exit(0)
 # CPU oracle ("port", C restatement with hyper-dual AD — not Julia) on a bounded sample
 from oracle import oracle as o
 n = args.cpu_n

@@ -877,6 +877,113 @@ def test_reference_contracting_cuboid_single_subdomain(tb, device, which):
     assert ux_right.mean() < -1e-4                                                 # contraction along f₀ = e_x
 
 
+@pytest.mark.parametrize("order,nel,passive", [(1, (4, 3, 2), "ho"), (2, (2, 2, 2), "ho"), (1, (3, 3, 2), "guccione")])
+def test_condensed_sarcomere_parity(tb, oracle, device, order, nel, passive):
+    """ActiveStressModel(passive, SimpleActiveStress(Tmax), CaDrivenInternalSarcomereModel(AsRateIndependent(RDQ20MFModel()), Ca)) with
+    the internal state condensed per quadrature point (elements.jl:411-612, materials.jl:472-502,1403-1632): residual, tangent and the
+    solved internal states against the oracle; hand-derived HO path and device-AD path; uniform and nodal calcium; the tangent is the
+    derivative of the residual *including* the local solves (central differences through the device)."""
+    g, dh, sp, om = mech_problem(tb, oracle, nel, order, perturb=0.1)
+    rng = np.random.default_rng(9)
+    u = rng.uniform(-2e-2, 2e-2, dh.ndofs)
+    du = device.to_device(u)
+    f, s, n = np.array([1, 1, 0.0]) / np.sqrt(2), np.array([-1, 1, 0.0]) / np.sqrt(2), np.array([0, 0, 1.0])
+    fsn = np.stack([f, s, n])
+    ms = tb.ConstantCoefficient(tb.OrthotropicMicrostructure(f, s, n))
+    nq = 8 if order == 1 else 27
+    npts = g.n_cells * nq
+    nodal = rng.uniform(0.2, 1.0, (g.n_cells, 8))
+    Q0 = np.concatenate([rng.dirichlet(np.ones(16), npts).T, rng.uniform(0, 0.05, (4, npts))])
+    Tmax, dt = 50.0, 0.5
+    pas = tb.HolzapfelOgden2009Model() if passive == "ho" else tb.Guccione1991PassiveModel()
+    tight = tb.GenericLocalNonlinearSolver(max_iters=30, tol=1e-13)
+    try:
+        for ca, (scale, field) in ((0.6, (0.6, None)), (nodal, (1.0, nodal))):
+            cm = tb.ActiveStressModel(pas, tb.SimpleActiveStress(Tmax=Tmax),
+                                      tb.CaDrivenInternalSarcomereModel(tb.AsRateIndependent(tb.RDQ20MFModel()), ca), ms)
+            pm = cm.passive.lower()
+            oracle.set_material(pm.kind, pm.reserved, list(pm.p)[:9], list(pm.p)[10:13])
+            oracle.set_active_tension(scale, field)
+            for ls, (tol, mi) in ((None, (1e-4, 10)), (tight, (1e-13, 30))):
+                Qref = Q0.copy()
+                oracle.set_condensation(Qref, Q0, dt=dt, tmax=Tmax, tol=tol, max_iters=mi)
+                Kref, rref = oracle.assemble_hyperelastic(om, u, sp.rowptr, sp.colidx, fsn=fsn)
+                oracle.set_condensation()
+                for st in (tb.ElementAssemblyStrategy(device), tb.PerColorAssemblyStrategy(device)):
+                    op = tb.setup_operator(st, tb.QuasiStaticModel("u", cm), dh, sp, local_solver=ls)
+                    op.internal.u.copy_from_host(Q0.ravel()); op.internal_known.u.copy_from_host(Q0.ravel())
+                    tb.set_timestep(op, dt)
+                    res = device.zeros(dh.ndofs)
+                    tb.update_linearization(op, du, 0.0, residual=res)
+                    assert tb.local_solve_failures(op) == 0
+                    np.testing.assert_allclose(op.internal.to_host(), Qref, rtol=1e-10, atol=1e-13)
+                    assert rel_err(res.to_host(), rref) < 1e-10
+                    assert rel_err(op.J.to_host(), Kref) < (1e-9 if ls is tight else 1e-6)     # default tol 1e-4: the corrector sees Q to ~1e-8
+                    res2 = device.zeros(dh.ndofs)
+                    op.internal.u.copy_from_host(Q0.ravel())
+                    tb.residual(op, res2, du, 0.0)
+                    assert rel_err(res2.to_host(), rref) < 1e-10
+            # consistency of the condensed tangent: K·v = d/dε r(u + εv) with the local problems re-solved (tight tolerance)
+            op = tb.setup_operator(tb.ElementAssemblyStrategy(device), tb.QuasiStaticModel("u", cm), dh, sp, local_solver=tight)
+            op.internal_known.u.copy_from_host(Q0.ravel())
+            tb.set_timestep(op, dt)
+
+            def resid(uu):
+                op.internal.u.copy_from_host(Q0.ravel())
+                r = device.zeros(dh.ndofs)
+                tb.residual(op, r, device.to_device(uu), 0.0)
+                return r.to_host()
+            op.internal.u.copy_from_host(Q0.ravel())
+            tb.update_linearization(op, du, 0.0)
+            import scipy.sparse as ssp
+            K = ssp.csr_matrix((op.J.to_host(), sp.colidx, sp.rowptr), shape=(dh.ndofs, dh.ndofs))
+            v = rng.normal(size=dh.ndofs)
+            h = 1e-6
+            fd = (resid(u + h * v) - resid(u - h * v)) / (2 * h)
+            assert np.abs(K @ v - fd).max() < 2e-6 * np.abs(fd).max()
+            # the active part matters and depends on the internal state
+            oracle.set_active_tension(0.0)
+            Kp, rp = oracle.assemble_hyperelastic(om, u, sp.rowptr, sp.colidx, fsn=fsn)
+            assert np.abs(rref - rp).max() > 1e-3 * np.abs(rp).max()
+    finally:
+        oracle.set_condensation(); oracle.set_active_tension(0.0); oracle.set_material()
+
+
+def test_reference_contracting_cuboid_with_internal_sarcomere_state(tb, device):
+    """test/integration/test_solid_mechanics.jl:383-445 (time integrated contracting cuboid): ActiveStressModel(Guccione1991PassiveModel,
+    SimpleActiveStress(Tmax = 220e3), CaDrivenInternalSarcomereModel(AsRateIndependent(RDQ20MFModel()), calcium hat)), the cuboid and
+    boundary conditions of the single-subdomain case, BackwardEulerSolver with the multi-level Newton over tspan (0, 2), Δt = 0.25.
+    Like the reference: every step succeeds and u moved.  Additionally: the internal states stay admissible probabilities, the
+    cross-bridge states leave zero, and the block shortens along the fibre."""
+    g = tb.generate_mesh(tb.Hexahedron, (10, 10, 2), (0.0, 0.0, 0.0), (1.0, 1.0, 0.2))
+    dh = tb.DofHandler(g, tb.LagrangeCollection(1) ** 3)
+    sp = tb.allocate_matrix(dh)
+    ms = tb.ConstantCoefficient(tb.OrthotropicMicrostructure([1.0, 0, 0], [0, 1.0, 0], [0, 0, 1.0]))
+    hat = lambda t: 2.0 * t / 1000.0 if t / 1000.0 < 0.5 else 2.0 - 2.0 * t / 1000.0
+    cm = tb.ActiveStressModel(tb.Guccione1991PassiveModel(), tb.SimpleActiveStress(Tmax=220e3),
+                              tb.CaDrivenInternalSarcomereModel(tb.AsRateIndependent(tb.RDQ20MFModel()), hat), ms)
+    facemodels = (tb.NormalSpringBC(0.0, "right"), tb.ConstantPressureBC(0.0, "back"), tb.PressureFieldBC(tb.ConstantCoefficient(0.0), "top"))
+    op = tb.setup_operator(tb.PerColorAssemblyStrategy(device), tb.QuasiStaticModel("d", cm, facemodels), dh, sp)
+    node_dof0 = np.empty(g.n_nodes, dtype=np.int64)
+    node_dof0[g.conn.ravel()] = dh.cell_dofs[:, 0::3].ravel()
+    X = g.xyz
+    fixed = np.concatenate([node_dof0[X[:, 0] < 1e-12], node_dof0[X[:, 1] < 1e-12] + 1, node_dof0[X[:, 2] < 1e-12] + 2, node_dof0[0] + np.arange(3)])
+    ch = tb.ConstraintHandler(dh, fixed)
+    u = device.zeros(dh.ndofs)
+    solver = tb.NewtonRaphsonSolver(max_iter=10, tol=1e-10, inner_rtol=1e-12, inner_solver="gmres", gmres_restart=100)
+    t, dt = 0.0, 0.25
+    for step in range(8):
+        assert tb.perform_mechanics_step(u, op, ch, solver, t, dt), (step, solver.residual_norms)
+        t += dt
+    uh = u.to_host()
+    Q = op.internal.to_host()
+    assert np.abs(uh).max() > 0.0                                                  # integrator.u ≉ u₀
+    assert Q[:16].min() >= 0.0 and np.abs(Q[:16].sum(axis=0) - 1.0).max() < 1e-10
+    assert Q[16:].max() > 0.0
+    ux_right = uh[node_dof0[X[:, 0] > 1 - 1e-12]]
+    assert ux_right.mean() < 0.0                                                   # active tension shortens the fibre direction
+
+
 # ------------------------------------------------------------------------------------------- the reference's own GPU tests
 def quad_problem(tb, oracle, nel, left, right):
     g = tb.generate_mesh(tb.Quadrilateral, nel, left, right)

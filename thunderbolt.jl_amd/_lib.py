@@ -94,6 +94,10 @@ SIGNATURES = {
                                              C.c_int, vp, vp, C.POINTER(C.c_int64)]),
     "tb_host_sarcomere_local_solve": (C.c_int, [C.c_int, c_dp, C.c_int, c_dp, c_dp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, c_dp,
                                                 C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "tb_hyperelastic_set_condensation": (C.c_int, [vp, C.c_int, c_dp, C.c_int, C.c_double, C.c_double, C.c_int]),
+    "tb_hyperelastic_n_quadrature_points": (C.c_int, [vp, C.POINTER(C.c_int64)]),
+    "tb_hyperelastic_set_internal_state": (C.c_int, [vp, vp, vp, C.c_double]),
+    "tb_hyperelastic_local_solve_report": (C.c_int, [vp, C.POINTER(C.c_int64), vp, C.c_int64]),
     "tb_hyperelastic_set_hill": (C.c_int, [vp, vp]),
     "tb_host_material_eval_hill": (C.c_int, [vp, vp, C.c_double, c_dp, c_dp, c_dp, c_dp]),
     "tb_facet_form_create": (C.c_int, [vp, C.c_int, C.c_double, C.c_int, c_i32p, C.c_int64, C.c_int, C.POINTER(vp)]),

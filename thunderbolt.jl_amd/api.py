@@ -563,12 +563,12 @@ class LinearOperator:
         check(lib().tb_assemble_vector(self.form.h, self.strategy.code, float(t), self.b.ptr))
 
 
-def setup_operator(strategy, integrator, dh, pattern=None):
+def setup_operator(strategy, integrator, dh, pattern=None, local_solver=None):
     """setup_operator(strategy, integrator, [solver,] dh) (src/solver/interface.jl:17-94)."""
     if isinstance(integrator, LinearIntegrator):
         return LinearOperator(strategy, integrator, dh)
     if isinstance(integrator, QuasiStaticModel):
-        return NonlinearOperator(strategy, integrator, dh, pattern or allocate_matrix(dh))
+        return NonlinearOperator(strategy, integrator, dh, pattern or allocate_matrix(dh), local_solver=local_solver)
     if pattern is None:
         pattern = allocate_matrix(dh)
     return BilinearOperator(strategy, integrator, dh, pattern)
@@ -981,12 +981,18 @@ class ActiveStressModel:
         self.active_stress_model, self.contraction_model = active_stress_model, contraction_model
         self.material, self.microstructure = self.passive.material, self.passive.microstructure
 
+    def internal_model(self):
+        """the sarcomere model with internal state behind the contraction model (RDQ20MFModel / AsRateIndependent), or None"""
+        sm = getattr(self.contraction_model, "model", None)
+        return sm if hasattr(sm, "sid") else None
+
     def tension(self, t):
-        """(scale, nodal field or None) of Ta = Tmax·𝓝 at time t"""
+        """(scale, nodal field or None) of Ta = Tmax·𝓝 at time t — with an internal sarcomere model: of the calcium itself"""
         st = self.contraction_model.state(t) if hasattr(self.contraction_model, "state") else 1.0
+        tmax = 1.0 if self.internal_model() is not None else self.active_stress_model.Tmax
         if np.ndim(st) == 0:
-            return self.active_stress_model.Tmax * float(st), None
-        return self.active_stress_model.Tmax, np.ascontiguousarray(st, dtype=np.float64)
+            return tmax * float(st), None
+        return tmax, np.ascontiguousarray(st, dtype=np.float64)
 
     def lower(self, t=0.0):
         m = self.passive.lower()
@@ -1162,7 +1168,7 @@ def material_routine(model, F, t=0.0):
 class NonlinearOperator:
     """Operator of a quasi-static problem: `.J` (CSR nzval on device), residual vectors supplied by the caller."""
 
-    def __init__(self, strategy, model, dh, pattern, qorder=0):
+    def __init__(self, strategy, model, dh, pattern, qorder=0, local_solver=None):
         self.strategy, self.dh, self.model = strategy, dh, model
         self.dmesh = dh.device_mesh(strategy.device)
         self.pattern = self.dmesh.pattern(pattern)
@@ -1172,6 +1178,22 @@ class NonlinearOperator:
         if isinstance(model.constitutive_model, _HillModel):
             self._hill = model.constitutive_model.lower_hill()
             check(lib().tb_hyperelastic_set_hill(self.form, C.byref(self._hill)))
+        # condensed internal variable (QuasiStaticCondensedElementCache): states per quadrature point on the device
+        self.internal = None
+        cm = model.constitutive_model
+        sm = cm.internal_model() if isinstance(cm, ActiveStressModel) else None
+        if sm is not None:
+            if not sm.rate_independent:
+                raise NotImplementedError("rate-coupled internal variables (dλ/dt = ∂λ/∂F : Ḟ, non-symmetric tangent) are not on the device yet: "
+                                          "wrap the sarcomere model in AsRateIndependent")
+            ls = local_solver or GenericLocalNonlinearSolver()
+            pp = sm.params()
+            check(lib().tb_hyperelastic_set_condensation(self.form, sm.sid, pp.ctypes.data_as(L.c_dp), len(pp), cm.active_stress_model.Tmax, ls.tol, ls.max_iters))
+            npts = C.c_int64()
+            check(lib().tb_hyperelastic_n_quadrature_points(self.form, C.byref(npts)))
+            self.internal = SarcomereState(strategy.device, sm, npts.value)        # Q: current iterate / solution
+            self.internal_known = SarcomereState(strategy.device, sm, npts.value)  # Q_known: accepted state of the previous step
+            self.dt = None
         self.J = DeviceVector(strategy.device, pattern.nnz)
         # surface terms: one facet form per weak boundary condition (setup_boundary_cache, weak_boundary_conditions.jl:1-7)
         self.facet_forms = []
@@ -1192,6 +1214,45 @@ class NonlinearOperator:
                 lib().tb_form_destroy(self.form)
         except Exception:
             pass
+
+
+def set_timestep(op, dt):
+    """Δt of the internal variable's backward Euler step (GenericFirstOrderTimeParameters.Δt, euler.jl:490-493)."""
+    op.dt = float(dt)
+    check(lib().tb_hyperelastic_set_internal_state(op.form, op.internal.u.ptr, op.internal_known.u.ptr, op.dt))
+
+
+def accept_internal_state(op):
+    """the time step was accepted: Q_known ← Q"""
+    check(lib().tb_memcpy_d2d(op.strategy.device.h, op.internal_known.u.ptr, op.internal.u.ptr, op.internal.u.nbytes))
+
+
+def reject_internal_state(op):
+    """the time step was rejected: Q ← Q_known (initial guess of the retry)"""
+    check(lib().tb_memcpy_d2d(op.strategy.device.h, op.internal.u.ptr, op.internal_known.u.ptr, op.internal.u.nbytes))
+
+
+def local_solve_failures(op):
+    """number of quadrature points whose local solve failed in the last assembly (check_local_solve_convergence)"""
+    nf = C.c_int64()
+    check(lib().tb_hyperelastic_local_solve_report(op.form, C.byref(nf), None, 0))
+    return nf.value
+
+
+def perform_mechanics_step(u, op, ch, solver, t, dt):
+    """One backward-Euler step t → t + Δt of a quasi-static problem with condensed internal variables: the multi-level Newton of the
+    reference (BackwardEulerSolver(inner_solver = MultiLevelNewtonRaphsonSolver), euler.jl / multilevel_newton_raphson.jl) — global
+    Newton on u, the local problems re-solved inside every assembly from the last iterate, Q_known = the accepted state.  A step with a
+    failed local solve or a diverged global Newton is rejected: u and Q are restored and False is returned."""
+    u0 = u.to_host()
+    set_timestep(op, dt)
+    ok = nlsolve(u, op, ch, solver, t=t + dt)
+    if ok and local_solve_failures(op) == 0:
+        accept_internal_state(op)
+        return True
+    u.copy_from_host(u0)
+    reject_internal_state(op)
+    return False
 
 
 def _sync_active_tension(op, t):

@@ -364,7 +364,7 @@ int tb_form_create(tb_mesh *mesh, int form_kind, int qorder, const tb_coef *coef
 int tb_form_destroy(tb_form *f)
 {
     if (!f) return TB_OK;
-    hipFree(f->d_field); hipFree(f->d_dtab); hipFree(f->d_table); hipFree(f->d_facets); hipFree(f->d_act_field);
+    hipFree(f->d_field); hipFree(f->d_dtab); hipFree(f->d_table); hipFree(f->d_facets); hipFree(f->d_act_field); hipFree(f->d_qp_buf);
     delete f;
     return TB_OK;
 }
@@ -454,6 +454,52 @@ int tb_hyperelastic_set_active_tension(tb_form *form, double tension, const doub
     if (len) {
         TB_HIP(hipMemcpyAsync(form->d_act_field, state_field, sizeof(double) * len, hipMemcpyHostToDevice, m->dev->stream));
         TB_HIP(hipStreamSynchronize(m->dev->stream));
+    }
+    return TB_OK;
+}
+
+int tb_hyperelastic_set_condensation(tb_form *form, int sarcomere_model, const double *params, int n_params, double tmax, double local_tol, int local_max_iters)
+{
+    TB_REQUIRE(form && form->kind == TB_FORM_HYPERELASTIC, "tb_hyperelastic_set_condensation: not a hyperelastic form");
+    if (sarcomere_model < 0) { form->cond_model = 0; return TB_OK; }
+    TB_REQUIRE(sarcomere_model == TB_SARCOMERE_RDQ20MF, "tb_hyperelastic_set_condensation: sarcomere model %d has no internal state (TB_SARCOMERE_RDQ20MF)", sarcomere_model);
+    TB_REQUIRE(params && n_params == 17, "tb_hyperelastic_set_condensation: RDQ20MF takes 17 parameters");
+    TB_REQUIRE(local_tol >= 0.0 && local_max_iters >= 1, "tb_hyperelastic_set_condensation: need tol >= 0 and max_iters >= 1");
+    TB_REQUIRE(form->hill == 0, "tb_hyperelastic_set_condensation: Hill frameworks take steady-state sarcomere models only");
+    form->cond_model = sarcomere_model;
+    for (int i = 0; i < 17; ++i) form->cond_params[i] = params[i];
+    form->cond_tmax = tmax; form->cond_tol = local_tol; form->cond_max_iters = local_max_iters;
+    return TB_OK;
+}
+
+int tb_hyperelastic_n_quadrature_points(tb_form *form, int64_t *n_points)
+{
+    TB_REQUIRE(form && form->kind == TB_FORM_HYPERELASTIC && n_points, "tb_hyperelastic_n_quadrature_points: bad argument");
+    const int nq = form->qorder * form->qorder * form->qorder;
+    *n_points = form->mesh->n_cells * nq;
+    return TB_OK;
+}
+
+int tb_hyperelastic_set_internal_state(tb_form *form, double *d_state, const double *d_state_known, double dt)
+{
+    TB_REQUIRE(form && form->kind == TB_FORM_HYPERELASTIC, "tb_hyperelastic_set_internal_state: not a hyperelastic form");
+    TB_REQUIRE(form->cond_model, "tb_hyperelastic_set_internal_state: the form has no condensed internal variable (tb_hyperelastic_set_condensation)");
+    TB_REQUIRE(d_state && d_state_known, "tb_hyperelastic_set_internal_state: NULL state");
+    TB_REQUIRE(dt > 0.0, "tb_hyperelastic_set_internal_state: the time step must be positive (got %g)", dt);
+    form->d_Q = d_state; form->d_Qknown = d_state_known; form->cond_dt = dt;
+    return TB_OK;
+}
+
+int tb_hyperelastic_local_solve_report(tb_form *form, int64_t *n_failed, int32_t *status_host, int64_t len)
+{
+    TB_REQUIRE(form && form->kind == TB_FORM_HYPERELASTIC && form->cond_model, "tb_hyperelastic_local_solve_report: the form has no condensed internal variable");
+    if (n_failed) *n_failed = form->cond_n_failed;
+    if (status_host) {
+        int64_t npts = 0;
+        tb_hyperelastic_n_quadrature_points(form, &npts);
+        TB_REQUIRE(len == npts, "tb_hyperelastic_local_solve_report: status buffer has %lld entries, expected %lld", (long long)len, (long long)npts);
+        TB_REQUIRE(form->d_qp_buf, "tb_hyperelastic_local_solve_report: no assembly has run yet");
+        TB_HIP(hipMemcpy(status_host, (const int32_t *)(form->d_qp_buf + 4 * npts), sizeof(int32_t) * npts, hipMemcpyDeviceToHost));
     }
     return TB_OK;
 }

@@ -157,6 +157,13 @@ struct tb_form {
     // active stress (TB_FORM_HYPERELASTIC): Ta = act_tension · (nodal field per cell, or 1)
     double act_tension = 0.0;
     double *d_act_field = nullptr;
+    // condensed internal variable (tb_hyperelastic_set_condensation / _set_internal_state)
+    int cond_model = 0, cond_max_iters = 10;
+    double cond_params[17] = {0}, cond_tmax = 0.0, cond_tol = 1e-4, cond_dt = 0.0;
+    double *d_Q = nullptr;
+    const double *d_Qknown = nullptr;
+    double *d_qp_buf = nullptr, *d_qp_act = nullptr; // λ | Ca | (a, b) | status per quadrature point
+    int64_t cond_n_failed = 0;
     // Hill frameworks (tb_hyperelastic_set_hill)
     int hill = 0, act_energy = 0, act_penalty = 0, adg = 0, sarc = 0;
     double act_p[12] = {0}, hill_kappa = 0.0, sarc_p[2] = {0, 0};

@@ -34,6 +34,7 @@ struct HOParams {
     double a, b, af, bf, as, bs, afs, bfs, beta; // struct field order of HolzapfelOgden2009Model, energies.jl:136-146
     double f[3], s[3], n[3];                     // microstructure frame (ConstantCoefficient(OrthotropicMicrostructure))
     double Ta;                                   // active tension Tmax·𝓝 at the point (ActiveStressModel + SimpleActiveStress); 0 = passive
+    double Tb;                                   // condensed internal variable: + Tb ∂λ/∂F ⊗ ∂λ/∂F in the tangent (d𝓝/dλ incl. the local corrector)
 };
 
 // returns Ψ; P[3i+j], A[9(3i+j) + 3k+l] (A only when NEED_A)
@@ -82,7 +83,7 @@ TB_HD double ho_stress_tangent(const HOParams &m, const double (&F)[3][3], doubl
 
     const double h1 = 0.5 * m.a * E1;
     const double lamf = sqrt(I4f);
-    const double w1f = (onf ? m.af * df * E4f : 0.0) + 0.5 * m.Ta / lamf, w2f = (onf ? m.af * E4f * (1.0 + 2.0 * m.bf * df * df) : 0.0) - 0.25 * m.Ta / (lamf * I4f);
+    const double w1f = (onf ? m.af * df * E4f : 0.0) + 0.5 * m.Ta / lamf, w2f = (onf ? m.af * E4f * (1.0 + 2.0 * m.bf * df * df) : 0.0) - 0.25 * m.Ta / (lamf * I4f) + 0.25 * m.Tb / I4f;
     psi += m.Ta * lamf;
     const double w1s = ons ? m.as * ds * E4s : 0.0, w2s = ons ? m.as * E4s * (1.0 + 2.0 * m.bs * ds * ds) : 0.0;
     const double v1 = m.afs * I8 * E8, v2 = m.afs * E8 * (1.0 + 2.0 * m.bfs * I8 * I8);
@@ -182,7 +183,7 @@ TB_HD void ho_common(const HOParams &m, const double (&F)[3][3], double *C)
     const double lamf = sqrt(I4f);
     psi += m.Ta * lamf;
     C[HOC_W1F2] = (onf ? 2.0 * m.af * df * E4f : 0.0) + m.Ta / lamf;
-    C[HOC_W2F4] = (onf ? 4.0 * m.af * E4f * (1.0 + 2.0 * m.bf * df * df) : 0.0) - m.Ta / (lamf * I4f);
+    C[HOC_W2F4] = (onf ? 4.0 * m.af * E4f * (1.0 + 2.0 * m.bf * df * df) : 0.0) - m.Ta / (lamf * I4f) + m.Tb / I4f;
     C[HOC_W1S2] = ons ? 2.0 * m.as * ds * E4s : 0.0; C[HOC_W2S4] = ons ? 4.0 * m.as * E4s * (1.0 + 2.0 * m.bs * ds * ds) : 0.0;
     C[HOC_V1] = m.afs * I8 * E8; C[HOC_V2] = m.afs * E8 * (1.0 + 2.0 * m.bfs * I8 * I8);
     C[HOC_U1] = 2.0 * m.beta * (J2 - 1.0); C[HOC_U2] = 4.0 * m.beta * J2;

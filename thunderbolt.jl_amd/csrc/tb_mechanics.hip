@@ -103,6 +103,7 @@ struct MechMesh {
     const int32_t *cell_dofs;
     const double *fsn_field; // per cell and geometric node: f,s,n (9 doubles); NULL → constant frame of the material
     const double *act_field; // per cell and geometric node: calcium-driven state multiplying the active tension; NULL → 1
+    const double *qp_act;    // condensed internal variable: per quadrature point (a, b) — P += a ∂λ/∂F, 𝔸 += a ∂²λ/∂F² + b ∂λ/∂F ⊗ ∂λ/∂F; NULL → none
 };
 
 // position of column dof(b,0) inside row dof(a,0), per cell and node pair (the three component rows of a node
@@ -217,6 +218,8 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
             double *o = s_C[tid];
             for (int d = 0; d < 3; ++d) { o[d] = f[d]; o[3 + d] = sv[d]; o[6 + d] = n[d]; }
             o[9] = ta;
+            o[10] = 0.0;
+            if (m.qp_act) { o[9] = m.qp_act[2 * (cell * NQ + tid)]; o[10] = m.qp_act[2 * (cell * NQ + tid) + 1]; }
         }
         __syncthreads();
         // A3c': one lane per (point, pair of components of F): Ψ.a = P_m, Ψ.ab = 𝔸_mn = 𝔸_nm
@@ -231,7 +234,17 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
             const double f[3] = {o[0], o[1], o[2]}, sv[3] = {o[3], o[4], o[5]}, n[3] = {o[6], o[7], o[8]};
             const HD r = energy_pair(e, s_JI[q], mm, nn, f, sv, n);
             const double dO = s_JI[q][9];
-            if constexpr (NEED_K) { s_A[q][9 * mm + nn] = r.ab * dO; s_A[q][9 * nn + mm] = r.ab * dO; }
+            if constexpr (NEED_K) {
+                double ab = r.ab;
+                if (o[10] != 0.0) { // condensed internal variable: + b (∂λ/∂F)_m (∂λ/∂F)_n, ∂λ/∂F = (F f₀) ⊗ f₀ / λ
+                    const double *Fq = s_JI[q];
+                    const double g0 = Fq[0] * f[0] + Fq[1] * f[1] + Fq[2] * f[2], g1 = Fq[3] * f[0] + Fq[4] * f[1] + Fq[5] * f[2],
+                                 g2 = Fq[6] * f[0] + Fq[7] * f[1] + Fq[8] * f[2];
+                    const double gv[3] = {g0, g1, g2};
+                    ab += o[10] * (gv[mm / 3] * f[mm % 3]) * (gv[nn / 3] * f[nn % 3]) / (g0 * g0 + g1 * g1 + g2 * g2);
+                }
+                s_A[q][9 * mm + nn] = ab * dO; s_A[q][9 * nn + mm] = ab * dO;
+            }
             if (mm == nn) s_P[q][mm] = r.a * dO;
         }
         __syncthreads();
@@ -247,6 +260,7 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
             for (int a = 0; a < 8; ++a) ca += tb.M[tid][a] * m.act_field[cell * 8 + a];
             mq.Ta = mat.Ta * ca;
         }
+        if (m.qp_act) { mq.Ta = m.qp_act[2 * (cell * NQ + tid)]; mq.Tb = m.qp_act[2 * (cell * NQ + tid) + 1]; }
         if (m.fsn_field) { // interpolate the nodal frame, normalise, Gram–Schmidt (microstructure.jl:176-187)
             double f[3] = {0, 0, 0}, s[3] = {0, 0, 0}, n[3] = {0, 0, 0};
             const double *fc = m.fsn_field + cell * 72;
@@ -546,7 +560,8 @@ static HOParams make_params(const tb_form *f)
     const double *q = f->mat.p;
     p.a = q[0]; p.b = q[1]; p.af = q[2]; p.bf = q[3]; p.as = q[4]; p.bs = q[5]; p.afs = q[6]; p.bfs = q[7]; p.beta = q[8];
     for (int i = 0; i < 3; ++i) { p.f[i] = f->mat.f[i]; p.s[i] = f->mat.s[i]; p.n[i] = f->mat.n[i]; }
-    p.Ta = f->act_tension;
+    p.Ta = f->cond_model ? 0.0 : f->act_tension; // condensed: the per-point (a, b) replace the uniform tension
+    p.Tb = 0.0;
     return p;
 }
 
@@ -559,7 +574,7 @@ static EnergyParams make_energy_params(const tb_form *f)
     e.energy = f->mat.kind; e.penalty = f->mat.reserved;
     for (int i = 0; i < 9; ++i) e.p[i] = f->mat.p[i];
     for (int i = 0; i < 3; ++i) e.u[i] = f->mat.p[10 + i];
-    e.Ta = f->act_tension;
+    e.Ta = f->cond_model ? 0.0 : f->act_tension;
     e.hill = f->hill; e.act_energy = f->act_energy; e.act_penalty = f->act_penalty; e.adg = f->adg; e.sarc = f->sarc;
     for (int i = 0; i < 9; ++i) e.ap[i] = f->act_p[i];
     for (int i = 0; i < 3; ++i) e.au[i] = f->act_p[9 + i];
@@ -654,7 +669,7 @@ static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, doubl
 {
     tb_mesh *m = f->mesh;
     tb_device *dev = m->dev;
-    const MechMesh mm{m->d_xyz, m->d_conn, m->d_cell_dofs, f->d_field, f->d_act_field};
+    const MechMesh mm{m->d_xyz, m->d_conn, m->d_cell_dofs, f->d_field, f->cond_model ? nullptr : f->d_act_field, f->cond_model ? f->d_qp_act : nullptr};
     const HOParams hp = make_params(f);
     const EnergyParams ep = make_energy_params(f);
     const bool ea = strategy == TB_STRATEGY_ELEMENT || strategy == TB_STRATEGY_PATCH;
@@ -718,6 +733,86 @@ static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, doubl
     return TB_ERR_UNSUPPORTED;
 }
 
+// ---- condensed internal variables, stage 0: fibre stretch λ = ‖F f₀‖ and calcium at every quadrature point (the inputs of the local
+// problem; solve_local_constraint, materials.jl:1575-1590).  One workgroup per cell, one lane per quadrature point.
+template <class FE>
+__global__ void __launch_bounds__(64)
+k_fiber_stretch(MechMesh m, HOParams mat, const double *__restrict__ act_field, double act_scale, const double *__restrict__ u, double *__restrict__ lam,
+                double *__restrict__ ca, Status *st)
+{
+    constexpr int NB = FE::NB, NQ = FE::NQ, ND = FE::ND;
+    const MechTables<FE> &tb = g_mech_tables<FE>;
+    const int64_t cell = blockIdx.x;
+    const int tid = threadIdx.x;
+    __shared__ double s_ue[ND], s_x[24];
+    for (int i = tid; i < ND; i += 64) s_ue[i] = u[m.cell_dofs[cell * ND + i]];
+    for (int i = tid; i < 24; i += 64) s_x[i] = m.xyz[3 * (int64_t)m.conn[cell * 8 + i / 3] + i % 3];
+    __syncthreads();
+    if (tid >= NQ) return;
+    const int q = tid;
+    double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) J[i][k] += s_x[3 * a + i] * tb.dM[q][a][k];
+    const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1], c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2], c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+    const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02, id = 1.0 / det;
+    if (!(det > 0.0)) { st->neg_detj = 1; st->cell = cell; }
+    const double ji[9] = {c00 * id, (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * id, (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * id,
+                          c01 * id, (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * id, (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * id,
+                          c02 * id, (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * id, (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * id};
+    double f[3] = {mat.f[0], mat.f[1], mat.f[2]};
+    if (m.fsn_field) {
+        f[0] = f[1] = f[2] = 0.0;
+        const double *fc = m.fsn_field + cell * 72;
+        for (int a = 0; a < 8; ++a) for (int d = 0; d < 3; ++d) f[d] += tb.M[q][a] * fc[9 * a + d];
+        const double nf = sqrt(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]);
+        for (int d = 0; d < 3; ++d) f[d] /= nf;
+    }
+    // F f₀ = f₀ + Σₐ uₐ (∇Nₐ · f₀)
+    double g[3] = {f[0], f[1], f[2]};
+    for (int a = 0; a < NB; ++a) {
+        const double d0 = tb.dN[q][a][0], d1 = tb.dN[q][a][1], d2 = tb.dN[q][a][2];
+        double gf = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gf += (d0 * ji[k] + d1 * ji[3 + k] + d2 * ji[6 + k]) * f[k];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) g[c] += s_ue[3 * a + c] * gf;
+    }
+    double c = act_scale;
+    if (act_field) { double s2 = 0.0; for (int a = 0; a < 8; ++a) s2 += tb.M[q][a] * act_field[cell * 8 + a]; c *= s2; }
+    lam[cell * NQ + q] = sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+    ca[cell * NQ + q] = c;
+}
+
+// stage 0 + stage 1 (the pointwise local solves, tb_sarcomere.hip) ahead of the element kernels
+template <class FE> static int condensed_prepass(tb_form *f, const double *d_u, bool need_tangent)
+{
+    tb_mesh *m = f->mesh;
+    tb_device *dev = m->dev;
+    const int64_t npts = m->n_cells * FE::NQ;
+    if (!f->d_Q || !f->d_Qknown) { set_error("condensed internal variable: no internal state set (tb_hyperelastic_set_internal_state)"); return TB_ERR_BAD_ARG; }
+    if (!(f->cond_dt > 0.0)) { set_error("condensed internal variable: the time step must be positive (got %g)", f->cond_dt); return TB_ERR_BAD_ARG; }
+    if (!f->d_qp_buf) {
+        hipError_t e = hipMalloc((void **)&f->d_qp_buf, sizeof(double) * 4 * (size_t)npts + sizeof(int32_t) * (size_t)npts);
+        if (e != hipSuccess) { set_error("quadrature-point buffers: %s", hipGetErrorString(e)); return TB_ERR_NOMEM; }
+        f->d_qp_act = f->d_qp_buf + 2 * npts;
+    }
+    double *lam = f->d_qp_buf, *ca = f->d_qp_buf + npts;
+    int32_t *status = (int32_t *)(f->d_qp_buf + 4 * npts);
+    const MechMesh mm{m->d_xyz, m->d_conn, m->d_cell_dofs, f->d_field, nullptr, nullptr};
+    hipLaunchKernelGGL(k_fiber_stretch<FE>, dim3((unsigned)m->n_cells), dim3(64), 0, dev->stream, mm, make_params(f), f->d_act_field, f->act_tension, d_u, lam, ca,
+                       dev->d_status);
+    TB_HIP(hipGetLastError());
+    int64_t nfail = 0;
+    int rc = launch_sarcomere_implicit(dev, f->cond_params, f->d_Q, f->d_Qknown, npts, lam, ca, 0.0, 0.0, f->cond_dt, f->cond_tol, f->cond_max_iters, f->cond_tmax,
+                                       nullptr, f->d_qp_act, status, &nfail, need_tangent);
+    f->cond_n_failed = nfail;
+    return rc;
+}
+
 int launch_hyperelastic(tb_form *f, tb_pattern *p, int strategy, const double *d_u, double *d_nz, double *d_r)
 {
     tb_mesh *m = f->mesh;
@@ -729,6 +824,10 @@ int launch_hyperelastic(tb_form *f, tb_pattern *p, int strategy, const double *d
     // Q2 tangents run their contraction on the matrix cores; TB_MECH_MFMA=0 selects the vector-FMA build (comparison)
     static const bool mfma = !(getenv("TB_MECH_MFMA") && atoi(getenv("TB_MECH_MFMA")) == 0);
     const bool ad = !form_is_fast_path(f);
+    if (f->cond_model) {
+        rc = q2 ? condensed_prepass<Q2Vec>(f, d_u, d_nz != nullptr) : condensed_prepass<Q1Vec>(f, d_u, d_nz != nullptr);
+        if (rc) return rc;
+    }
 #define TB_RUN(FEV, K, R, MF) (ad ? run<FEV, K, R, MF, true>(f, p, strategy, d_u, d_nz, d_r) : run<FEV, K, R, MF, false>(f, p, strategy, d_u, d_nz, d_r))
     if (d_nz && d_r) rc = !q2 ? TB_RUN(Q1Vec, true, true, false) : (mfma || ad) ? TB_RUN(Q2Vec, true, true, true) : run<Q2Vec, true, true, false, false>(f, p, strategy, d_u, d_nz, d_r);
     else if (d_nz) rc = !q2 ? TB_RUN(Q1Vec, true, false, false) : (mfma || ad) ? TB_RUN(Q2Vec, true, false, true) : run<Q2Vec, true, false, false, false>(f, p, strategy, d_u, d_nz, d_r);

@@ -135,9 +135,11 @@ __device__ __forceinline__ bool solve4(double (&A)[4][4], double (&b)[4])
     return ok;
 }
 
-// one linear solve J y = g of the local problem at state q: g given on every lane (20 values), y returned on every lane
-__device__ __forceinline__ bool local_linear_solve(const RDQ20Params &p, const double (&q)[20], double lam, double ca, double dt, const double (&g)[20],
-                                                   double (&y)[20], double (*tr)[17], int base, int r, double (&f)[20])
+// Jacobian of the local problem at state q, distributed over the 16 lanes of a group: row r of J_RR in registers, column r of
+// ∂rhs_X/∂Q_R (colX), and rhs(q) itself (f, on every lane)
+struct LocalJacobian { double row[16], colX[4], kPN, kNP; };
+__device__ __forceinline__ void local_jacobian(const RDQ20Params &p, const double (&q)[20], double lam, double ca, double dt, double (*tr)[17], int r,
+                                               LocalJacobian &J, double (&f)[20])
 {
     D1 ud[20], dud[20];
 #pragma unroll
@@ -149,30 +151,40 @@ __device__ __forceinline__ bool local_linear_solve(const RDQ20Params &p, const d
 #pragma unroll
     for (int i = 0; i < 16; ++i) tr[i][r] = dud[i].d;
     __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c = 0; c < 16; ++c) J.row[c] = (c == r ? 1.0 / dt : 0.0) - tr[r][c];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) J.colX[k] = dud[16 + k].d;
+    double perm;
+    rdq20_xb_rates<double>(p, q, perm, J.kPN, J.kNP);
+}
+
+// J y = g: g given on every lane (20 values), y returned on every lane
+__device__ __forceinline__ bool local_linear_solve(const RDQ20Params &p, const LocalJacobian &J, double dt, const double (&g)[20], double (&y)[20], int base, int r)
+{
     double row[16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) row[c] = (c == r ? 1.0 / dt : 0.0) - tr[r][c];
-    __builtin_amdgcn_wave_barrier();
+    for (int c = 0; c < 16; ++c) row[c] = J.row[c];
     double gr = 0.0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) gr = (k == r) ? g[k] : gr;
     double xr[16];
     bool ok = group_gauss_jordan(row, gr, base, r, xr);
     // cross-bridge block: J_XX y_X = g_X − J_XR y_R, J_XR = −∂rhs_X/∂Q_R (lane c holds column c)
+    double mine = 0.0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) mine = (c == r) ? xr[c] : mine;
     double bx[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        double part = 0.0;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) part = (c == r) ? dud[16 + k].d * xr[c] : part;
+        double part = J.colX[k] * mine;
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
         bx[k] = g[16 + k] + part;
     }
-    double perm, kPN, kNP;
-    rdq20_xb_rates<double>(p, q, perm, kPN, kNP);
-    const double rr = p.r0, dP = 1.0 / dt + rr + kPN, dN = 1.0 / dt + rr + kNP; // smooth_abs(0) = 0: rate-free form
-    double A[4][4] = {{dP, 0, -kNP, 0}, {0, dP, 0, -kNP}, {-kPN, 0, dN, 0}, {0, -kPN, 0, dN}};
+    const double rr = p.r0, dP = 1.0 / dt + rr + J.kPN, dN = 1.0 / dt + rr + J.kNP; // smooth_abs(0) = 0: rate-free form
+    double A[4][4] = {{dP, 0, -J.kNP, 0}, {0, dP, 0, -J.kNP}, {-J.kPN, 0, dN, 0}, {0, -J.kPN, 0, dN}};
     ok = solve4(A, bx) && ok;
 #pragma unroll
     for (int k = 0; k < 16; ++k) y[k] = xr[k];
@@ -207,19 +219,13 @@ k_sarcomere_implicit(RDQ20Params p, SarcomereInputs in, double *__restrict__ Qs,
         for (int it = 1; it <= max_iters; ++it) {
             if (!__any(active)) break;
             double f[20], R[20], y[20];
-            // the residual needs rhs(q): evaluated inside the solve together with the Jacobian columns, so assemble g afterwards is not
-            // possible — evaluate once for the values first
-            {
-                double fu[20];
-                rdq20_rhs<double>(p, q, lam, 0.0, ca, fu);
-#pragma unroll
-                for (int k = 0; k < 20; ++k) R[k] = (q[k] - qk[k]) / dt - fu[k];
-            }
+            LocalJacobian J;
+            local_jacobian(p, q, lam, ca, dt, tr, r, J, f);
             double rn = 0.0;
 #pragma unroll
-            for (int k = 0; k < 20; ++k) rn += R[k] * R[k];
+            for (int k = 0; k < 20; ++k) { R[k] = (q[k] - qk[k]) / dt - f[k]; rn += R[k] * R[k]; }
             rn = sqrt(rn);
-            const bool ok = local_linear_solve(p, q, lam, ca, dt, R, y, tr, base, r, f);
+            const bool ok = local_linear_solve(p, J, dt, R, y, base, r);
             if (active) {
                 if (!ok) { code = LOCAL_LINEAR_SOLVE_FAILED; active = false; }
                 else {
@@ -247,7 +253,9 @@ k_sarcomere_implicit(RDQ20Params p, SarcomereInputs in, double *__restrict__ Qs,
             double g[20], y[20], f[20];
 #pragma unroll
             for (int k = 0; k < 20; ++k) g[k] = dud[k].d;
-            const bool ok = local_linear_solve(p, q, lam, ca, dt, g, y, tr, base, r, f);
+            LocalJacobian J;
+            local_jacobian(p, q, lam, ca, dt, tr, r, J, f);
+            const bool ok = local_linear_solve(p, J, dt, g, y, base, r);
             if (!ok && code == LOCAL_SUCCESS) code = LOCAL_LINEAR_SOLVE_FAILED;
             if (code != LOCAL_SUCCESS) {
 #pragma unroll
