@@ -240,6 +240,15 @@ typedef struct {
 int tb_hyperelastic_set_hill(tb_form *form, const tb_hill *hill); /* NULL or framework = TB_HILL_NONE: plain PK1Model */
 /* host evaluation of the whole constitutive law at one point (the code the kernels run): activation = Ta or the calcium state */
 int tb_host_material_eval_hill(const tb_material *material, const tb_hill *hill, double activation, const double *F, double *psi, double *P, double *A);
+/* Subdomains: the reference integrates one material per SubDofHandler / cellset (QuasiStaticModel per subdomain,
+ * test/integration/test_solid_mechanics.jl:96-140; NonlinearMultiDomainIntegrator, src/modeling/core/multi-integrator.jl).  A form with a
+ * cellset integrates over those cells only; with accumulate != 0 tb_linearize / tb_residual add into their outputs instead of
+ * overwriting them, so a multi-domain operator is: first form (overwrite), further forms (accumulate), facet forms (always accumulate).
+ * Subdomain and accumulating forms run with TB_STRATEGY_PER_COLOR (own colouring of the subset) or TB_STRATEGY_ATOMIC. */
+int tb_form_set_cellset(tb_form *form, const int32_t *cells, int64_t n_cells, int index_base);
+int tb_form_clear_cellset(tb_form *form);
+int tb_form_set_accumulate(tb_form *form, int accumulate);
+
 /* Condensed internal variables: ActiveStressModel over a sarcomere model with state (RDQ20MF) whose evolution is solved per quadrature
  * point inside the assembly — QuasiStaticCondensedElementCache + solve_local_constraint (src/modeling/solid/elements.jl:411-612,
  * src/modeling/solid/materials.jl:472-502,1403-1632), rate-free local problem (AsRateIndependent: dλ/dt = 0).  With condensation set,

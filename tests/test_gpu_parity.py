@@ -984,6 +984,80 @@ def test_reference_contracting_cuboid_with_internal_sarcomere_state(tb, device):
     assert ux_right.mean() < 0.0                                                   # active tension shortens the fibre direction
 
 
+def test_reference_passive_structure_with_subdomains(tb, oracle, device):
+    """test/integration/test_solid_mechanics.jl:19-141 ("Passive Structure"): 10×10×2 hexahedra on (−1,−1,−0.2)–(1,1,0.2), three faces
+    clamped in their normal component, node 1 fully, the opposite faces displaced by 0.01 / 0.02 / 0.03, one Newton load step; one
+    domain, then the same mesh split into "inner" (z ≤ 0) and "outer" subdomains.  The reference's assertions: every solve succeeds and
+    moves u; two different materials give a different solution (u₃ ≉ u₁); the same material on both subdomains reproduces the single-
+    domain solution (sort(u₄) ≈ sort(u₁)).  Plus parity of the two-material operator with the oracle (per-subdomain oracle assemblies)."""
+    g = tb.generate_mesh(tb.Hexahedron, (10, 10, 2), (-1.0, -1.0, -0.2), (1.0, 1.0, 0.2))
+    g.addcellset("inner", lambda x: x[2] <= 1.0e-8)
+    g.addcellset("outer", np.setdiff1d(np.arange(g.n_cells), g.getcellset("inner")))
+    g.addcellset("myocardium", lambda x: True)
+    assert len(g.getcellset("inner")) + len(g.getcellset("outer")) == g.n_cells and len(g.getcellset("inner")) == 100
+    dh = tb.DofHandler(g, tb.LagrangeCollection(1) ** 3)
+    sp = tb.allocate_matrix(dh)
+    ms = tb.ConstantCoefficient(tb.OrthotropicMicrostructure([1.0, 0, 0], [0, 1.0, 0], [0, 0, 1.0]))
+    node_dof0 = np.empty(g.n_nodes, dtype=np.int64)
+    node_dof0[g.conn.ravel()] = dh.cell_dofs[:, 0::3].ravel()
+    X = g.xyz
+    lo, hi = X.min(axis=0), X.max(axis=0)
+    pres = {}
+    for c in range(3):
+        for d in node_dof0[np.abs(X[:, c] - lo[c]) < 1e-12] + c: pres[d] = 0.0
+    for d in node_dof0[0] + np.arange(3): pres[d] = 0.0
+    for c, val in ((0, 0.01), (1, 0.02), (2, 0.03)):
+        for d in node_dof0[np.abs(X[:, c] - hi[c]) < 1e-12] + c: pres.setdefault(d, val)
+    dofs = np.array(sorted(pres)); vals = np.array([pres[d] for d in dofs])
+    ch = tb.ConstraintHandler(dh, dofs, vals)
+    ho = lambda: tb.QuasiStaticModel("d", tb.PK1Model(tb.HolzapfelOgden2009Model(), ms))
+    gu = lambda: tb.QuasiStaticModel("d", tb.PK1Model(tb.Guccione1991PassiveModel(), ms))
+
+    def solve(models, strategy):
+        op = tb.setup_operator(strategy, models, dh, sp)
+        u = device.zeros(dh.ndofs)
+        tb.apply(u, ch)
+        # the reference runs NewtonRaphsonSolver(max_iter = 10) with its default inner solver, GMRES (the Guccione tangent is indefinite here)
+        solver = tb.NewtonRaphsonSolver(max_iter=10, tol=1e-8, inner_rtol=1e-12, inner_solver="gmres", gmres_restart=100)
+        assert tb.nlsolve(u, op, ch, solver, t=1.0), solver.residual_norms
+        return u.to_host(), op
+    u1, _ = solve(ho(), tb.PerColorAssemblyStrategy(device))
+    assert np.abs(u1).max() > 1e-3
+    u3, op3 = solve({"inner": ho(), "outer": gu()}, tb.PerColorAssemblyStrategy(device))
+    assert not np.allclose(u3, u1, rtol=1e-6, atol=1e-8)
+    u4, _ = solve({"inner": ho(), "outer": ho()}, tb.AtomicAssemblyStrategy(device))
+    np.testing.assert_allclose(np.sort(u4), np.sort(u1), rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(u4, u1, rtol=1e-7, atol=1e-10)
+    u5, _ = solve({"myocardium": ho()}, tb.PerColorAssemblyStrategy(device))
+    np.testing.assert_allclose(np.sort(u5), np.sort(u1), rtol=1e-7, atol=1e-10)
+    # parity of the two-material operator: oracle assembled per subdomain on the sub-meshes' cells
+    om = oracle.Mesh(oracle.HEX8, 2, g.xyz, g.conn, dh.cell_dofs)
+    rng = np.random.default_rng(10)
+    u = rng.uniform(-1e-2, 1e-2, dh.ndofs)
+    Kref, rref = np.zeros(sp.nnz), np.zeros(dh.ndofs)
+    try:
+        for name, mat in (("inner", None), ("outer", tb.PK1Model(tb.Guccione1991PassiveModel(), ms).lower())):
+            cells = g.getcellset(name)
+            sub = oracle.Mesh(oracle.HEX8, 2, g.xyz, g.conn[cells], dh.cell_dofs[cells])
+            if mat is not None:
+                oracle.set_material(mat.kind, mat.reserved, list(mat.p)[:9], list(mat.p)[10:13])
+            K, r = oracle.assemble_hyperelastic(sub, u, sp.rowptr, sp.colidx, fsn=np.eye(3))
+            Kref += K; rref[:len(r)] += r            # the oracle sizes r by the largest dof of the sub-mesh
+    finally:
+        oracle.set_material()
+    du = device.to_device(u)
+    for st in (tb.PerColorAssemblyStrategy(device), tb.AtomicAssemblyStrategy(device)):
+        op = tb.setup_operator(st, {"inner": ho(), "outer": gu()}, dh, sp)
+        res = device.zeros(dh.ndofs)
+        tb.update_linearization(op, du, 0.0, residual=res)
+        assert rel_err(op.J.to_host(), Kref) < 1e-11 and rel_err(res.to_host(), rref) < 1e-11
+        res2 = device.zeros(dh.ndofs)
+        tb.residual(op, res2, du, 0.0)
+        assert rel_err(res2.to_host(), rref) < 1e-11
+    with pytest.raises(ValueError):
+        tb.setup_operator(tb.ElementAssemblyStrategy(device), {"inner": ho(), "outer": gu()}, dh, sp)
+
+
 # ------------------------------------------------------------------------------------------- the reference's own GPU tests
 def quad_problem(tb, oracle, nel, left, right):
     g = tb.generate_mesh(tb.Quadrilateral, nel, left, right)

@@ -219,6 +219,22 @@ class Grid:
     def n_nodes(self):
         return self.xyz.shape[0]
 
+    def addcellset(self, name, predicate, all=True):
+        """addcellset!(grid, name, x -> Bool; all = true) (Ferrite): cells whose nodes all (any) satisfy the predicate; or pass an
+        explicit array of 0-based cell ids instead of a predicate."""
+        if not hasattr(self, "cellsets"):
+            self.cellsets = {}
+        if callable(predicate):
+            ok = np.array([bool(predicate(x)) for x in self.xyz])[self.conn]
+            cells = np.flatnonzero(ok.all(axis=1) if all else ok.any(axis=1))
+        else:
+            cells = np.asarray(predicate, dtype=np.int64)
+        self.cellsets[name] = cells.astype(np.int32)
+        return self.cellsets[name]
+
+    def getcellset(self, name):
+        return self.cellsets[name]
+
     def facetset(self, name):
         """getfacetset(grid, name) of a generated box: left/right (x), front/back (y), bottom/top (z), as (cell, local
         facet) pairs, 0-based (Ferrite generate_grid facetsets; local facets as Ferrite.reference_facets(RefHexahedron))."""
@@ -567,7 +583,7 @@ def setup_operator(strategy, integrator, dh, pattern=None, local_solver=None):
     """setup_operator(strategy, integrator, [solver,] dh) (src/solver/interface.jl:17-94)."""
     if isinstance(integrator, LinearIntegrator):
         return LinearOperator(strategy, integrator, dh)
-    if isinstance(integrator, QuasiStaticModel):
+    if isinstance(integrator, QuasiStaticModel) or (isinstance(integrator, dict) and all(isinstance(v, QuasiStaticModel) for v in integrator.values())):
         return NonlinearOperator(strategy, integrator, dh, pattern or allocate_matrix(dh), local_solver=local_solver)
     if pattern is None:
         pattern = allocate_matrix(dh)
@@ -1166,52 +1182,71 @@ def material_routine(model, F, t=0.0):
 
 
 class NonlinearOperator:
-    """Operator of a quasi-static problem: `.J` (CSR nzval on device), residual vectors supplied by the caller."""
+    """Operator of a quasi-static problem: `.J` (CSR nzval on device), residual vectors supplied by the caller.  `model`: a
+    QuasiStaticModel, or a dict cellset-name → QuasiStaticModel (one material per subdomain, test_solid_mechanics.jl:96-140): one form
+    per subdomain, the first overwrites J / residual, the others accumulate."""
 
     def __init__(self, strategy, model, dh, pattern, qorder=0, local_solver=None):
         self.strategy, self.dh, self.model = strategy, dh, model
         self.dmesh = dh.device_mesh(strategy.device)
         self.pattern = self.dmesh.pattern(pattern)
-        self._mat = model.constitutive_model.lower()
-        self.form = C.c_void_p()
-        check(lib().tb_hyperelastic_create(self.dmesh.h, qorder, C.byref(self._mat), C.byref(self.form)))
-        if isinstance(model.constitutive_model, _HillModel):
-            self._hill = model.constitutive_model.lower_hill()
-            check(lib().tb_hyperelastic_set_hill(self.form, C.byref(self._hill)))
-        # condensed internal variable (QuasiStaticCondensedElementCache): states per quadrature point on the device
-        self.internal = None
-        cm = model.constitutive_model
-        sm = cm.internal_model() if isinstance(cm, ActiveStressModel) else None
-        if sm is not None:
-            if not sm.rate_independent:
-                raise NotImplementedError("rate-coupled internal variables (dλ/dt = ∂λ/∂F : Ḟ, non-symmetric tangent) are not on the device yet: "
-                                          "wrap the sarcomere model in AsRateIndependent")
-            ls = local_solver or GenericLocalNonlinearSolver()
-            pp = sm.params()
-            check(lib().tb_hyperelastic_set_condensation(self.form, sm.sid, pp.ctypes.data_as(L.c_dp), len(pp), cm.active_stress_model.Tmax, ls.tol, ls.max_iters))
-            npts = C.c_int64()
-            check(lib().tb_hyperelastic_n_quadrature_points(self.form, C.byref(npts)))
-            self.internal = SarcomereState(strategy.device, sm, npts.value)        # Q: current iterate / solution
-            self.internal_known = SarcomereState(strategy.device, sm, npts.value)  # Q_known: accepted state of the previous step
-            self.dt = None
         self.J = DeviceVector(strategy.device, pattern.nnz)
-        # surface terms: one facet form per weak boundary condition (setup_boundary_cache, weak_boundary_conditions.jl:1-7)
-        self.facet_forms = []
-        for bc in getattr(model, "facet_models", ()):
-            fs = bc.boundary_name if not isinstance(bc.boundary_name, str) else dh.grid.facetset(bc.boundary_name)
-            fs = np.ascontiguousarray(fs, dtype=np.int32).reshape(-1, 2)
-            h = C.c_void_p()
-            check(lib().tb_facet_form_create(self.dmesh.h, bc.kind, bc.param, 0, fs.ctypes.data_as(L.c_i32p), len(fs), 0, C.byref(h)))
-            if getattr(bc, "field", None) is not None:
-                check(lib().tb_facet_form_set_field(h, bc.field.ctypes.data_as(L.c_dp), bc.field.size))
-            self.facet_forms.append(h)
+        self.internal = None
+        self.forms, self.facet_forms, self._keep = [], [], []
+        domains = list(model.items()) if isinstance(model, dict) else [(None, model)]
+        if len(domains) > 1 and isinstance(strategy, ElementAssemblyStrategy):
+            raise ValueError("multi-domain operators accumulate: use PerColorAssemblyStrategy or AtomicAssemblyStrategy")
+        for k, (name, qm) in enumerate(domains):
+            cm = qm.constitutive_model
+            mat = cm.lower()
+            form = C.c_void_p()
+            check(lib().tb_hyperelastic_create(self.dmesh.h, qorder, C.byref(mat), C.byref(form)))
+            self.forms.append((form, cm))
+            self._keep.append(mat)
+            if name is not None:
+                cells = np.ascontiguousarray(dh.grid.getcellset(name), dtype=np.int32)
+                check(lib().tb_form_set_cellset(form, cells.ctypes.data_as(L.c_i32p), len(cells), 0))
+            if k > 0:
+                check(lib().tb_form_set_accumulate(form, 1))
+            if isinstance(cm, _HillModel):
+                h = cm.lower_hill()
+                self._keep.append(h)
+                check(lib().tb_hyperelastic_set_hill(form, C.byref(h)))
+            # condensed internal variable (QuasiStaticCondensedElementCache): states per quadrature point on the device
+            sm = cm.internal_model() if isinstance(cm, ActiveStressModel) else None
+            if sm is not None:
+                if len(domains) > 1:
+                    raise NotImplementedError("condensed internal variables on a subdomain are not supported")
+                if not sm.rate_independent:
+                    raise NotImplementedError("rate-coupled internal variables (dλ/dt = ∂λ/∂F : Ḟ, non-symmetric tangent) are not on the device yet: "
+                                              "wrap the sarcomere model in AsRateIndependent")
+                ls = local_solver or GenericLocalNonlinearSolver()
+                pp = sm.params()
+                check(lib().tb_hyperelastic_set_condensation(form, sm.sid, pp.ctypes.data_as(L.c_dp), len(pp), cm.active_stress_model.Tmax, ls.tol, ls.max_iters))
+                npts = C.c_int64()
+                check(lib().tb_hyperelastic_n_quadrature_points(form, C.byref(npts)))
+                self.internal = SarcomereState(strategy.device, sm, npts.value)        # Q: current iterate / solution
+                self.internal_known = SarcomereState(strategy.device, sm, npts.value)  # Q_known: accepted state of the previous step
+                self.dt = None
+            # surface terms: one facet form per weak boundary condition (setup_boundary_cache, weak_boundary_conditions.jl:1-7)
+            for bc in getattr(qm, "facet_models", ()):
+                fs = bc.boundary_name if not isinstance(bc.boundary_name, str) else dh.grid.facetset(bc.boundary_name)
+                fs = np.ascontiguousarray(fs, dtype=np.int32).reshape(-1, 2)
+                if name is not None:                       # the surface terms of a subdomain act on its own cells' facets
+                    fs = fs[np.isin(fs[:, 0], dh.grid.getcellset(name))]
+                h = C.c_void_p()
+                check(lib().tb_facet_form_create(self.dmesh.h, bc.kind, bc.param, 0, fs.ctypes.data_as(L.c_i32p), len(fs), 0, C.byref(h)))
+                if getattr(bc, "field", None) is not None:
+                    check(lib().tb_facet_form_set_field(h, bc.field.ctypes.data_as(L.c_dp), bc.field.size))
+                self.facet_forms.append(h)
+        self.form = self.forms[0][0]
 
     def __del__(self):
         try:
             for h in self.facet_forms:
                 lib().tb_form_destroy(h)
-            if self.form:
-                lib().tb_form_destroy(self.form)
+            for form, _ in self.forms:
+                lib().tb_form_destroy(form)
         except Exception:
             pass
 
@@ -1256,18 +1291,19 @@ def perform_mechanics_step(u, op, ch, solver, t, dt):
 
 
 def _sync_active_tension(op, t):
-    cm = op.model.constitutive_model
-    if isinstance(cm, (ActiveStressModel, _HillModel)):
-        scale, field = cm.tension(t)
-        check(lib().tb_hyperelastic_set_active_tension(op.form, float(scale), None if field is None else field.ctypes.data_as(L.c_dp),
-                                                       0 if field is None else field.size))
+    for form, cm in op.forms:
+        if isinstance(cm, (ActiveStressModel, _HillModel)):
+            scale, field = cm.tension(t)
+            check(lib().tb_hyperelastic_set_active_tension(form, float(scale), None if field is None else field.ctypes.data_as(L.c_dp),
+                                                           0 if field is None else field.size))
 
 
 def update_linearization(op, u, t=0.0, residual=None):
-    """update_linearization!(op, residual, u, p) / update_linearization!(op, u, p) (newton_raphson.jl:238): volume term,
-    then the surface terms are accumulated into the same J / residual."""
+    """update_linearization!(op, residual, u, p) / update_linearization!(op, u, p) (newton_raphson.jl:238): volume terms of every
+    subdomain, then the surface terms, all accumulated into the same J / residual."""
     _sync_active_tension(op, t)
-    check(lib().tb_linearize(op.form, op.pattern.h, op.strategy.code, _ptr(u), float(t), op.J.ptr, _ptr(residual)))
+    for form, _ in op.forms:
+        check(lib().tb_linearize(form, op.pattern.h, op.strategy.code, _ptr(u), float(t), op.J.ptr, _ptr(residual)))
     for h in op.facet_forms:
         check(lib().tb_facet_assemble(h, op.pattern.h, _ptr(u), float(t), op.J.ptr, _ptr(residual)))
     return op
@@ -1276,7 +1312,8 @@ def update_linearization(op, u, t=0.0, residual=None):
 def residual(op, residual, u, t=0.0):
     """residual!(op, residual, u, p) (newton_raphson.jl:234)."""
     _sync_active_tension(op, t)
-    check(lib().tb_residual(op.form, op.strategy.code, _ptr(u), float(t), _ptr(residual)))
+    for form, _ in op.forms:
+        check(lib().tb_residual(form, op.strategy.code, _ptr(u), float(t), _ptr(residual)))
     for h in op.facet_forms:
         check(lib().tb_facet_assemble(h, None, _ptr(u), float(t), None, _ptr(residual)))
     return residual

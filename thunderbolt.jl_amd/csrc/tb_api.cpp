@@ -364,7 +364,7 @@ int tb_form_create(tb_mesh *mesh, int form_kind, int qorder, const tb_coef *coef
 int tb_form_destroy(tb_form *f)
 {
     if (!f) return TB_OK;
-    hipFree(f->d_field); hipFree(f->d_dtab); hipFree(f->d_table); hipFree(f->d_facets); hipFree(f->d_act_field); hipFree(f->d_qp_buf);
+    hipFree(f->d_field); hipFree(f->d_dtab); hipFree(f->d_table); hipFree(f->d_facets); hipFree(f->d_act_field); hipFree(f->d_qp_buf); hipFree(f->d_cellset); if (f->set_colors) hipFree(f->set_colors->d_cells);
     delete f;
     return TB_OK;
 }
@@ -455,6 +455,48 @@ int tb_hyperelastic_set_active_tension(tb_form *form, double tension, const doub
         TB_HIP(hipMemcpyAsync(form->d_act_field, state_field, sizeof(double) * len, hipMemcpyHostToDevice, m->dev->stream));
         TB_HIP(hipStreamSynchronize(m->dev->stream));
     }
+    return TB_OK;
+}
+
+int tb_form_set_cellset(tb_form *form, const int32_t *cells, int64_t n_cells, int index_base)
+{
+    TB_REQUIRE(form && form->kind == TB_FORM_HYPERELASTIC, "tb_form_set_cellset: subdomains are implemented for hyperelastic forms");
+    TB_REQUIRE(index_base == 0 || index_base == 1, "tb_form_set_cellset: index_base must be 0 or 1");
+    TB_REQUIRE(n_cells >= 0 && (cells || n_cells == 0), "tb_form_set_cellset: bad cell list");
+    hipFree(form->d_cellset); form->d_cellset = nullptr;
+    form->set_colors.reset();
+    form->h_cellset.clear();
+    if (!cells && n_cells == 0 && index_base == 0 && !form->has_cellset) return TB_OK;
+    std::vector<uint8_t> seen(form->mesh->n_cells, 0);
+    form->h_cellset.reserve(n_cells);
+    for (int64_t i = 0; i < n_cells; ++i) {
+        const int64_t c = (int64_t)cells[i] - index_base;
+        TB_REQUIRE(c >= 0 && c < form->mesh->n_cells, "tb_form_set_cellset: cell %lld out of range", (long long)cells[i]);
+        TB_REQUIRE(!seen[c], "tb_form_set_cellset: cell %lld listed twice", (long long)cells[i]);
+        seen[c] = 1;
+        form->h_cellset.push_back((int32_t)c);
+    }
+    form->has_cellset = true;
+    form->n_set = n_cells;
+    if (n_cells) {
+        TB_HIP(hipMalloc((void **)&form->d_cellset, sizeof(int32_t) * n_cells));
+        TB_HIP(hipMemcpy(form->d_cellset, form->h_cellset.data(), sizeof(int32_t) * n_cells, hipMemcpyHostToDevice));
+    }
+    return TB_OK;
+}
+
+int tb_form_clear_cellset(tb_form *form)
+{
+    TB_REQUIRE(form, "tb_form_clear_cellset: NULL form");
+    hipFree(form->d_cellset); form->d_cellset = nullptr;
+    form->set_colors.reset(); form->h_cellset.clear(); form->has_cellset = false; form->n_set = 0;
+    return TB_OK;
+}
+
+int tb_form_set_accumulate(tb_form *form, int accumulate)
+{
+    TB_REQUIRE(form && form->kind == TB_FORM_HYPERELASTIC, "tb_form_set_accumulate: implemented for hyperelastic forms");
+    form->accumulate = accumulate != 0;
     return TB_OK;
 }
 

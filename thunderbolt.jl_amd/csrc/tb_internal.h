@@ -157,6 +157,13 @@ struct tb_form {
     // active stress (TB_FORM_HYPERELASTIC): Ta = act_tension · (nodal field per cell, or 1)
     double act_tension = 0.0;
     double *d_act_field = nullptr;
+    // subdomain (tb_form_set_cellset): the cells this form integrates over, and whether it adds to its outputs (tb_form_set_accumulate)
+    bool has_cellset = false;
+    int accumulate = 0;
+    int64_t n_set = 0;
+    int32_t *d_cellset = nullptr;
+    std::unique_ptr<tb::ColorPlan> set_colors;
+    std::vector<int32_t> h_cellset;
     // condensed internal variable (tb_hyperelastic_set_condensation / _set_internal_state)
     int cond_model = 0, cond_max_iters = 10;
     double cond_params[17] = {0}, cond_tmax = 0.0, cond_tol = 1e-4, cond_dt = 0.0;
@@ -179,6 +186,7 @@ namespace tb {
 // ---- plan builders (tb_plans.cpp) ----
 void dof_slots(const tb_mesh *m, std::vector<int64_t> &ptr, std::vector<int32_t> &src); // dof → (cell·ndpc + local) slots, cell-ordered
 int build_color_plan(tb_mesh *m);
+int build_color_plan_subset(tb_mesh *m, const std::vector<int32_t> &cells, std::unique_ptr<ColorPlan> &out);
 int build_ea_plan(tb_mesh *m);
 int build_patch_plan(tb_mesh *m, int cells_per_patch);
 int build_patch_mat_plan(tb_pattern *p);

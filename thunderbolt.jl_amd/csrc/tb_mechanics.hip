@@ -673,12 +673,16 @@ static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, doubl
     const HOParams hp = make_params(f);
     const EnergyParams ep = make_energy_params(f);
     const bool ea = strategy == TB_STRATEGY_ELEMENT || strategy == TB_STRATEGY_PATCH;
+    if (ea && (f->has_cellset || f->accumulate)) {
+        set_error("hyperelastic assembly: subdomain / accumulating forms need TB_STRATEGY_PER_COLOR or TB_STRATEGY_ATOMIC (the element strategy writes whole rows)");
+        return TB_ERR_UNSUPPORTED;
+    }
     if (NEED_K) {
         int rc = ensure_blockpos(p);
         if (rc) return rc;
-        if (!ea) TB_HIP(hipMemsetAsync(d_nz, 0, (size_t)p->nnz * sizeof(double), dev->stream));
+        if (!ea && !f->accumulate) TB_HIP(hipMemsetAsync(d_nz, 0, (size_t)p->nnz * sizeof(double), dev->stream));
     }
-    if (NEED_R && !ea) TB_HIP(hipMemsetAsync(d_r, 0, (size_t)m->ndofs * sizeof(double), dev->stream));
+    if (NEED_R && !ea && !f->accumulate) TB_HIP(hipMemsetAsync(d_r, 0, (size_t)m->ndofs * sizeof(double), dev->stream));
     const int64_t *rowptr = p ? p->d_rowptr : nullptr;
     const uint16_t *bp = p ? p->d_blockpos : nullptr;
     double *kebuf = nullptr, *rebuf = nullptr;
@@ -721,14 +725,21 @@ static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, doubl
         return TB_OK;
     }
     if (strategy == TB_STRATEGY_PER_COLOR) {
-        if (!m->colors) { int rc = build_color_plan(m); if (rc) return rc; }
-        for (int c = 0; c < m->colors->ncolors; ++c) {
-            int rc = go(m->colors->d_cells + m->colors->offsets[c], m->colors->offsets[c + 1] - m->colors->offsets[c], 0);
+        const ColorPlan *cp;
+        if (f->has_cellset) {
+            if (!f->set_colors) { int rc = build_color_plan_subset(m, f->h_cellset, f->set_colors); if (rc) return rc; }
+            cp = f->set_colors.get();
+        } else {
+            if (!m->colors) { int rc = build_color_plan(m); if (rc) return rc; }
+            cp = m->colors.get();
+        }
+        for (int c = 0; c < cp->ncolors; ++c) {
+            int rc = go(cp->d_cells + cp->offsets[c], cp->offsets[c + 1] - cp->offsets[c], 0);
             if (rc) return rc;
         }
         return TB_OK;
     }
-    if (strategy == TB_STRATEGY_ATOMIC) return go(nullptr, m->n_cells, 1);
+    if (strategy == TB_STRATEGY_ATOMIC) return f->has_cellset ? go(f->d_cellset, f->n_set, 1) : go(nullptr, m->n_cells, 1);
     set_error("hyperelastic assembly: unknown strategy %d", strategy);
     return TB_ERR_UNSUPPORTED;
 }
@@ -824,6 +835,7 @@ int launch_hyperelastic(tb_form *f, tb_pattern *p, int strategy, const double *d
     // Q2 tangents run their contraction on the matrix cores; TB_MECH_MFMA=0 selects the vector-FMA build (comparison)
     static const bool mfma = !(getenv("TB_MECH_MFMA") && atoi(getenv("TB_MECH_MFMA")) == 0);
     const bool ad = !form_is_fast_path(f);
+    if (f->cond_model && f->has_cellset) { set_error("condensed internal variables on a subdomain form are not supported"); return TB_ERR_UNSUPPORTED; }
     if (f->cond_model) {
         rc = q2 ? condensed_prepass<Q2Vec>(f, d_u, d_nz != nullptr) : condensed_prepass<Q1Vec>(f, d_u, d_nz != nullptr);
         if (rc) return rc;

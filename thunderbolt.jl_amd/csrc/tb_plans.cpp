@@ -70,6 +70,35 @@ int build_color_plan(tb_mesh *m)
     return TB_OK;
 }
 
+// the same greedy colouring over a subset of the cells (subdomain forms: one integrator per SubDofHandler in the reference)
+int build_color_plan_subset(tb_mesh *m, const std::vector<int32_t> &cells, std::unique_ptr<ColorPlan> &out)
+{
+    std::vector<uint64_t> used(m->ndofs, 0);
+    std::vector<int32_t> color(cells.size());
+    int ncolors = 0;
+    for (size_t i = 0; i < cells.size(); ++i) {
+        const int32_t *d = &m->h_cell_dofs[(int64_t)cells[i] * m->ndpc];
+        uint64_t mask = 0;
+        for (int l = 0; l < m->ndpc; ++l) mask |= used[d[l]];
+        const int col = mask == ~0ull ? 64 : __builtin_ctzll(~mask);
+        if (col >= 64) { set_error("colouring needs more than 64 colours"); return TB_ERR_UNSUPPORTED; }
+        color[i] = col;
+        ncolors = std::max(ncolors, col + 1);
+        for (int l = 0; l < m->ndpc; ++l) used[d[l]] |= 1ull << col;
+    }
+    auto plan = std::make_unique<ColorPlan>();
+    plan->ncolors = ncolors;
+    plan->offsets.assign(ncolors + 1, 0);
+    for (size_t i = 0; i < cells.size(); ++i) plan->offsets[color[i] + 1]++;
+    for (int k = 0; k < ncolors; ++k) plan->offsets[k + 1] += plan->offsets[k];
+    std::vector<int64_t> pos(plan->offsets.begin(), plan->offsets.end() - 1);
+    std::vector<int32_t> grouped(cells.size());
+    for (size_t i = 0; i < cells.size(); ++i) grouped[pos[color[i]]++] = cells[i];
+    if (!grouped.empty()) { int rc = upload(m->dev, grouped, &plan->d_cells); if (rc) return rc; }
+    out = std::move(plan);
+    return TB_OK;
+}
+
 static inline uint64_t spread21(uint64_t v)
 {
     v &= 0x1fffff;
