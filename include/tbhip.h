@@ -240,6 +240,11 @@ typedef struct {
 int tb_hyperelastic_set_hill(tb_form *form, const tb_hill *hill); /* NULL or framework = TB_HILL_NONE: plain PK1Model */
 /* host evaluation of the whole constitutive law at one point (the code the kernels run): activation = Ta or the calcium state */
 int tb_host_material_eval_hill(const tb_material *material, const tb_hill *hill, double activation, const double *F, double *psi, double *P, double *A);
+/* PrestressedMechanicalModel(inner_model, prestress_field) (src/modeling/solid/materials.jl:781-900) with a constant field:
+ * P(F) = Pᵉ(F·F₀⁻¹)·F₀⁻ᵀ, ∂P/∂F_ijkl = 𝔸ᵉ_imkn F₀⁻¹_jm F₀⁻¹_ln.  F0inv: the nine entries of F₀⁻¹ (what the reference's prestress_field
+ * evaluates to), row-major; NULL removes the prestress.  Evaluated through the device AD path (the product F·F₀⁻¹ is differentiated). */
+int tb_hyperelastic_set_prestress(tb_form *form, const double *F0inv);
+
 /* Subdomains: the reference integrates one material per SubDofHandler / cellset (QuasiStaticModel per subdomain,
  * test/integration/test_solid_mechanics.jl:96-140; NonlinearMultiDomainIntegrator, src/modeling/core/multi-integrator.jl).  A form with a
  * cellset integrates over those cells only; with accumulate != 0 tb_linearize / tb_residual add into their outputs instead of

@@ -495,3 +495,14 @@ def set_condensation(Q=None, Qknown=None, dt=1.0, tmax=1.0, tol=1e-4, max_iters=
     _COND_KEEP[0] = (Q, Qk, pp, status)
     lib().orc_set_condensation(pp.ctypes.data, float(tmax), Q.ctypes.data, Qk.ctypes.data, Q.shape[1], float(dt), float(tol), int(max_iters),
                                None if status is None else status.ctypes.data)
+
+
+def set_prestress(F0inv=None):
+    """PrestressedMechanicalModel with a constant field in element_hyperelastic / assemble_hyperelastic (global; set_prestress() removes it)."""
+    lib().orc_set_prestress.restype = None
+    lib().orc_set_prestress.argtypes = [C.c_void_p]
+    if F0inv is None:
+        lib().orc_set_prestress(None)
+    else:
+        G = _f64(F0inv).ravel()
+        lib().orc_set_prestress(G.ctypes.data)

@@ -1391,6 +1391,26 @@ static double g_act_scale = 0.0;
 static const double *g_act_field = NULL;
 void orc_set_active_tension(double tension, const double *field) { g_act_scale = tension; g_act_field = field; }
 
+/* PrestressedMechanicalModel (materials.jl:872-900), as the reference computes it: inner routine at Fᵉ = F·F₀⁻¹, then the pull-back
+ * P = Pᵉ·F₀⁻ᵀ, ∂P∂F = (𝔸ᵉ·F₀⁻ᵀ) contracted once more with F₀⁻¹ on the second index pair: A_ijkl = 𝔸ᵉ_imkn G_jm G_ln */
+static int g_prestressed = 0;
+static double g_prestress_G[9];
+void orc_set_prestress(const double *G) { g_prestressed = G != NULL; if (G) memcpy(g_prestress_G, G, sizeof g_prestress_G); }
+static void prestress_pullback(double *P, double *A)
+{
+    const double *G = g_prestress_G;
+    double Pe[9], Ae[81];
+    memcpy(Pe, P, sizeof Pe);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double s = 0; for (int m = 0; m < 3; ++m) s += Pe[3 * i + m] * G[3 * j + m]; P[3 * i + j] = s; }
+    if (!A) return;
+    memcpy(Ae, A, sizeof Ae);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) for (int k = 0; k < 3; ++k) for (int l = 0; l < 3; ++l) {
+        double s = 0;
+        for (int m = 0; m < 3; ++m) for (int n = 0; n < 3; ++n) s += Ae[9 * (3 * i + m) + 3 * k + n] * G[3 * j + m] * G[3 * l + n];
+        A[9 * (3 * i + j) + 3 * k + l] = s;
+    }
+}
+
 /* condensed internal variable (QuasiStaticCondensedElementCache, elements.jl:411-470; material_routine materials.jl:472-502;
  * solve_local_constraint rate-free :1575-1632; _solve_local_sarcomere_dQdF :1381-1395): global test state like g_mat_* */
 int orc_rdq20mf_local_solve(const double *p, double *Q, const double *Qknown, double lam, double dlam, double Ca, double dt, double tol, int max_iters,
@@ -1473,10 +1493,14 @@ static int element_hyperelastic_cv(const orc_mesh *m, const cellvalues *cv, int6
             for (int a = 0; a < cv->ngeo; ++a) ca += cv->M[q][a] * g_act_field[(int64_t)cell * cv->ngeo + a];
             g_active_tension = g_act_scale * ca;
         }
+        double Fin[9];
+        memcpy(Fin, F, sizeof Fin);
+        if (g_prestressed) for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double sg = 0; for (int k2 = 0; k2 < 3; ++k2) sg += Fin[3 * i + k2] * g_prestress_G[3 * k2 + j]; F[3 * i + j] = sg; }
         if (g_mat_energy == 0 && g_mat_penalty == 0 && !g_hill.framework) orc_ho_energy(p, fsn, F, P, Ke ? A : NULL);
         else if (g_mat_energy == 0 && g_mat_penalty == 0) { double up[3] = {p[8], 0, 0}; orc_energy(0, 0, p, up, fsn, F, P, Ke ? A : NULL); }
         else orc_energy(g_mat_energy, g_mat_penalty, g_mat_p, g_mat_u, fsn, F, P, Ke ? A : NULL);
         g_active_tension = 0.0;
+        if (g_prestressed) { prestress_pullback(P, Ke ? A : NULL); memcpy(F, Fin, sizeof Fin); }
         if (g_cond.on) {
             double ca = g_act_scale;
             if (g_act_field) { double sc = 0.0; for (int a = 0; a < cv->ngeo; ++a) sc += cv->M[q][a] * g_act_field[(int64_t)cell * cv->ngeo + a]; ca *= sc; }

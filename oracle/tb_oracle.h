@@ -211,4 +211,6 @@ int orc_rdq20mf_local_solve(const double *p, double *Q, const double *Qknown, do
 /* condensed internal variable of the hyperelastic element routines (global test state; p = NULL switches it off) */
 void orc_set_condensation(const double *p, double tmax, double *Q, const double *Qknown, int64_t n_points, double dt, double tol, int max_iters, int *status);
 
+void orc_set_prestress(const double *F0inv); /* NULL: none */
+
 #endif

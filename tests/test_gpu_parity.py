@@ -1030,6 +1030,12 @@ def test_reference_passive_structure_with_subdomains(tb, oracle, device):
     np.testing.assert_allclose(u4, u1, rtol=1e-7, atol=1e-10)
     u5, _ = solve({"myocardium": ho()}, tb.PerColorAssemblyStrategy(device))
     np.testing.assert_allclose(np.sort(u5), np.sort(u1), rtol=1e-7, atol=1e-10)
+    # PrestressedMechanicalModel(PK1Model(HO), ConstantCoefficient(Tensor{2,3}((1.1, 0.1, 0.0, 0.2, 0.9, 0.1, -0.1, 0.0, 1.0)))) (:82-92): "the
+    # prestress should force a different solution"
+    G = np.array([1.1, 0.1, 0.0, 0.2, 0.9, 0.1, -0.1, 0.0, 1.0]).reshape(3, 3).T       # Tensors.jl fills column by column
+    pre = lambda: tb.QuasiStaticModel("d", tb.PrestressedMechanicalModel(tb.PK1Model(tb.HolzapfelOgden2009Model(), ms), tb.ConstantCoefficient(G)))
+    u2, _ = solve(pre(), tb.ElementAssemblyStrategy(device))
+    assert not np.allclose(u2, u1, rtol=1e-6, atol=1e-8)
     # parity of the two-material operator: oracle assembled per subdomain on the sub-meshes' cells
     om = oracle.Mesh(oracle.HEX8, 2, g.xyz, g.conn, dh.cell_dofs)
     rng = np.random.default_rng(10)
@@ -1056,6 +1062,19 @@ def test_reference_passive_structure_with_subdomains(tb, oracle, device):
         assert rel_err(res2.to_host(), rref) < 1e-11
     with pytest.raises(ValueError):
         tb.setup_operator(tb.ElementAssemblyStrategy(device), {"inner": ho(), "outer": gu()}, dh, sp)
+    # parity of the prestressed operator: the oracle evaluates the inner routine at F·F₀⁻¹ and pulls P and 𝔸 back like the reference
+    try:
+        oracle.set_prestress(G)
+        Kref, rref = oracle.assemble_hyperelastic(om, u, sp.rowptr, sp.colidx, fsn=np.eye(3))
+    finally:
+        oracle.set_prestress()
+    K0, r0 = oracle.assemble_hyperelastic(om, u, sp.rowptr, sp.colidx, fsn=np.eye(3))
+    assert np.abs(rref - r0).max() > 1e-2 * np.abs(r0).max()
+    for st in (tb.ElementAssemblyStrategy(device), tb.PerColorAssemblyStrategy(device)):
+        op = tb.setup_operator(st, pre(), dh, sp)
+        res = device.zeros(dh.ndofs)
+        tb.update_linearization(op, du, 0.0, residual=res)
+        assert rel_err(op.J.to_host(), Kref) < 1e-11 and rel_err(res.to_host(), rref) < 1e-11
 
 
 # ------------------------------------------------------------------------------------------- the reference's own GPU tests

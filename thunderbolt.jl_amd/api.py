@@ -952,6 +952,21 @@ class PK1Model:
         return m
 
 
+class PrestressedMechanicalModel:
+    """PrestressedMechanicalModel(inner_model, prestress_field) (materials.jl:781-900): P(F) = Pᵉ(F·F₀⁻¹)·F₀⁻ᵀ; prestress_field:
+    ConstantCoefficient of the 3×3 tensor F₀⁻¹ (a numpy array M with M[i, j] = F₀⁻¹_ij — Tensors.jl's Tensor{2,3}((…)) constructor
+    lists the entries column by column)."""
+
+    def __init__(self, inner_model, prestress_field):
+        self.inner_model = inner_model
+        G = prestress_field.val if isinstance(prestress_field, ConstantCoefficient) else prestress_field
+        self.F0inv = np.ascontiguousarray(G, dtype=np.float64).reshape(3, 3)
+        self.material, self.microstructure = inner_model.material, inner_model.microstructure
+
+    def lower(self, *a):
+        return self.inner_model.lower(*a)
+
+
 class SimpleActiveStress:
     """SimpleActiveStress(; Tmax): Tᵃ = Tmax·[Caᵢ]·(F·f₀)⊗f₀/‖F·f₀‖ (src/modeling/solid/active.jl:100-113)."""
 
@@ -1208,6 +1223,10 @@ class NonlinearOperator:
                 check(lib().tb_form_set_cellset(form, cells.ctypes.data_as(L.c_i32p), len(cells), 0))
             if k > 0:
                 check(lib().tb_form_set_accumulate(form, 1))
+            if isinstance(cm, PrestressedMechanicalModel):
+                check(lib().tb_hyperelastic_set_prestress(form, cm.F0inv.ctypes.data_as(L.c_dp)))
+                cm = cm.inner_model
+                self.forms[-1] = (form, cm)
             if isinstance(cm, _HillModel):
                 h = cm.lower_hill()
                 self._keep.append(h)

@@ -458,6 +458,17 @@ int tb_hyperelastic_set_active_tension(tb_form *form, double tension, const doub
     return TB_OK;
 }
 
+int tb_hyperelastic_set_prestress(tb_form *form, const double *F0inv)
+{
+    TB_REQUIRE(form && form->kind == TB_FORM_HYPERELASTIC, "tb_hyperelastic_set_prestress: not a hyperelastic form");
+    form->prestressed = F0inv != nullptr;
+    if (F0inv) {
+        TB_REQUIRE(!form->cond_model, "tb_hyperelastic_set_prestress: not combined with condensed internal variables");
+        for (int i = 0; i < 9; ++i) form->prestress_G[i] = F0inv[i];
+    }
+    return TB_OK;
+}
+
 int tb_form_set_cellset(tb_form *form, const int32_t *cells, int64_t n_cells, int index_base)
 {
     TB_REQUIRE(form && form->kind == TB_FORM_HYPERELASTIC, "tb_form_set_cellset: subdomains are implemented for hyperelastic forms");
@@ -508,6 +519,7 @@ int tb_hyperelastic_set_condensation(tb_form *form, int sarcomere_model, const d
     TB_REQUIRE(params && n_params == 17, "tb_hyperelastic_set_condensation: RDQ20MF takes 17 parameters");
     TB_REQUIRE(local_tol >= 0.0 && local_max_iters >= 1, "tb_hyperelastic_set_condensation: need tol >= 0 and max_iters >= 1");
     TB_REQUIRE(form->hill == 0, "tb_hyperelastic_set_condensation: Hill frameworks take steady-state sarcomere models only");
+    TB_REQUIRE(!form->prestressed, "tb_hyperelastic_set_condensation: not combined with a prestress");
     form->cond_model = sarcomere_model;
     for (int i = 0; i < 17; ++i) form->cond_params[i] = params[i];
     form->cond_tmax = tmax; form->cond_tol = local_tol; form->cond_max_iters = local_max_iters;

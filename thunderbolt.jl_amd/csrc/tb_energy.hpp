@@ -84,6 +84,9 @@ struct EnergyParams {
     double ap[9], au[3]; // active spring: energy + penalty parameters (ACT_SIMPLE_ACTIVE_SPRING: ap[0] = aᶠ)
     double kappa;        // RLRSQ sheetlet part
     double sp[2];        // PelceSunLangeveld1995: β, λᵃₘₐₓ; ConstantStretch: λ
+    // PrestressedMechanicalModel (materials.jl:781-900): W(F) = W_inner(F·F₀⁻¹); G = F₀⁻¹ row-major, used when prestressed != 0
+    int prestressed;
+    double G[9];
 };
 
 // U(I₃), energies.jl:13-87 (I₃ < 0 → NaN there; a cell with detJ ≤ 0 is reported separately)
@@ -240,6 +243,14 @@ TB_HD HD energy_pair(const EnergyParams &m, const double *F9, int mm, int nn, co
             const int e = 3 * i + j;
             F[i][j] = HD{F9[e], e == mm ? 1.0 : 0.0, e == nn ? 1.0 : 0.0, 0.0};
         }
+    if (m.prestressed) { // Fᵉ = F·F₀⁻¹: differentiating through the product gives P = Pᵉ·F₀⁻ᵀ and 𝔸_ijkl = 𝔸ᵉ_imkn G_jm G_ln
+        HD Fe[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) Fe[i][j] = F[i][0] * m.G[j] + F[i][1] * m.G[3 + j] + F[i][2] * m.G[6 + j];
+        return material_psi<HD>(m, Fe, f0, s0, n0);
+    }
     return material_psi<HD>(m, F, f0, s0, n0);
 }
 

@@ -171,6 +171,9 @@ struct tb_form {
     const double *d_Qknown = nullptr;
     double *d_qp_buf = nullptr, *d_qp_act = nullptr; // λ | Ca | (a, b) | status per quadrature point
     int64_t cond_n_failed = 0;
+    // PrestressedMechanicalModel: F₀⁻¹ (tb_hyperelastic_set_prestress)
+    int prestressed = 0;
+    double prestress_G[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     // Hill frameworks (tb_hyperelastic_set_hill)
     int hill = 0, act_energy = 0, act_penalty = 0, adg = 0, sarc = 0;
     double act_p[12] = {0}, hill_kappa = 0.0, sarc_p[2] = {0, 0};

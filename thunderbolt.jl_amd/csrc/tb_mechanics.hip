@@ -566,7 +566,7 @@ static HOParams make_params(const tb_form *f)
 }
 
 static bool material_is_fast_path(const tb_material &mat) { return mat.kind == TB_MATERIAL_HOLZAPFEL_OGDEN_2009 && mat.reserved == PEN_SIMPLE; }
-static bool form_is_fast_path(const tb_form *f) { return material_is_fast_path(f->mat) && f->hill == 0; }
+static bool form_is_fast_path(const tb_form *f) { return material_is_fast_path(f->mat) && f->hill == 0 && !f->prestressed; }
 
 static EnergyParams make_energy_params(const tb_form *f)
 {
@@ -579,6 +579,8 @@ static EnergyParams make_energy_params(const tb_form *f)
     for (int i = 0; i < 9; ++i) e.ap[i] = f->act_p[i];
     for (int i = 0; i < 3; ++i) e.au[i] = f->act_p[9 + i];
     e.kappa = f->hill_kappa; e.sp[0] = f->sarc_p[0]; e.sp[1] = f->sarc_p[1];
+    e.prestressed = f->prestressed;
+    for (int i = 0; i < 9; ++i) e.G[i] = f->prestress_G[i];
     return e;
 }
 
