@@ -267,6 +267,11 @@ int tb_hyperelastic_set_condensation(tb_form *form, int sarcomere_model, const d
                                      int local_max_iters);
 int tb_hyperelastic_n_quadrature_points(tb_form *form, int64_t *n_points);
 int tb_hyperelastic_set_internal_state(tb_form *form, double *d_state, const double *d_state_known, double dt);
+/* Rate-coupled local problem dₜQ = L(F, dₜF, Q) (the unwrapped RDQ20MFModel; QuasiStaticCondensedDAEElementCache, elements.jl:382-400;
+ * solve_local_constraint materials.jl:1664-1750): dλ/dt = ∂λ/∂F : Ḟ with the backward-Euler rate Ḟ = (∇u − ∇u_prev)/Δt.  d_u_prev: the
+ * accepted displacement of the previous step (device, n_dofs); NULL returns to the rate-free problem (AsRateIndependent).  The tangent
+ * gains ∂P/∂Ḟ/Δt and the non-symmetric term ∂P/∂Q · ∂Q/∂λ̇ ⊗ (∂²λ/∂F² : Ḟ): use a general linear solver (tb_gmres_solve). */
+int tb_hyperelastic_set_previous_solution(tb_form *form, const double *d_u_prev);
 int tb_hyperelastic_local_solve_report(tb_form *form, int64_t *n_failed, int32_t *status_host, int64_t len);
 
 /* Weak boundary conditions of a quasi-static problem (src/modeling/core/weak_boundary_conditions.jl): RobinBC
@@ -303,17 +308,19 @@ int tb_sarcomere_step(tb_device *dev, int model, const double *params, int n_par
 int tb_host_sarcomere_eval(int model, const double *params, int n_params, const double *state, double stretch, double velocity,
                            double calcium, double *dstate, double *tension, double *stiffness);
 /* The local problem of the condensed mechanics, pointwise (solve_internal_timestep + corrector, src/modeling/solid/materials.jl:1403-1568,
- * rate-free form :1575-1632): backward Euler (Q − Q_known)/Δt = rhs(Q, λ, 0, Ca) by Newton (initial guess: d_state; `tol` on ‖residual‖₂,
+ * rate-free form :1575-1632, rate-coupled :1664-1750): backward Euler (Q − Q_known)/Δt = rhs(Q, λ, dλ/dt, Ca) by Newton (initial guess: d_state; `tol` on ‖residual‖₂,
  * checked like the reference: the update is applied, then the pre-update norm decides) and, if d_dstate_dstretch != NULL, the corrector
- * dQ/dλ = J⁻¹ ∂rhs/∂λ at the solution.  Per-point status (TB_LOCAL_*; the reference's LocalSolveReport retcodes) and the number of failed
+ * dQ/dλ = J⁻¹ ∂rhs/∂λ at the solution (and dQ/d(dλ/dt) into d_dstate_dvelocity, the second corrector of the rate-coupled form; a
+ * velocity of 0 with d_velocity = NULL is the rate-free problem).  Per-point status (TB_LOCAL_*; the reference's LocalSolveReport retcodes) and the number of failed
  * points (n_failed != NULL synchronises).  Defaults of the reference's GenericLocalNonlinearSolver: tol 1e-4, max_iters 10. */
 enum { TB_LOCAL_SUCCESS = 0, TB_LOCAL_LINEAR_SOLVE_FAILED = 1, TB_LOCAL_MAX_ITERS = 2, TB_LOCAL_CONVERGENCE_FAILURE = 3, TB_LOCAL_INFEASIBLE = 4 };
 int tb_sarcomere_implicit_step(tb_device *dev, int model, const double *params, int n_params, double *d_state, const double *d_state_known,
-                               int64_t n_points, const double *d_stretch, const double *d_calcium, double stretch, double calcium, double dt,
-                               double tol, int max_iters, double *d_dstate_dstretch, int32_t *d_status, int64_t *n_failed);
+                               int64_t n_points, const double *d_stretch, const double *d_velocity, const double *d_calcium, double stretch,
+                               double velocity, double calcium, double dt, double tol, int max_iters, double *d_dstate_dstretch,
+                               double *d_dstate_dvelocity, int32_t *d_status, int64_t *n_failed);
 int tb_host_sarcomere_local_solve(int model, const double *params, int n_params, double *state, const double *state_known, double stretch,
-                                  double calcium, double dt, double tol, int max_iters, double *dstate_dstretch, int *status, int *iters,
-                                  double *resnorm);
+                                  double velocity, double calcium, double dt, double tol, int max_iters, double *dstate_dstretch,
+                                  double *dstate_dvelocity, int *status, int *iters, double *resnorm);
 
 /* ------------------------------------------------------------------ pointwise reaction step
  * _pointwise_step_outer_kernel!(f, t, Δt, cache, ::DeviceVector) (src/solver/time/partitioned_solver.jl:38-52,

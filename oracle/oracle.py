@@ -465,21 +465,21 @@ def rdq20mf_trajectory(u0, dt, lam, dlam, ca, sample, p=RDQ20MF_DEFAULTS):
     return u, out
 
 
-def rdq20mf_local_solve(Qguess, Qknown, lam, ca, dt, tol=1e-4, max_iters=10, dlam=0.0, p=RDQ20MF_DEFAULTS):
-    """backward-Euler local problem + corrector → (status, Q, dQ/dλ, iterations, last residual norm)"""
+def rdq20mf_local_solve(Qguess, Qknown, lam, ca, dt, tol=1e-4, max_iters=10, dlam=0.0, p=RDQ20MF_DEFAULTS, rate=False):
+    """backward-Euler local problem + corrector(s) → (status, Q, dQ/dλ, iterations, last residual norm[, dQ/dλ̇ with rate=True])"""
     Q = _f64(Qguess).copy()
-    dQdl = np.zeros(20)
+    dQdl, dQdv = np.zeros(20), np.zeros(20)
     it, rn = C.c_int(), C.c_double()
-    lib().orc_rdq20mf_local_solve.restype = C.c_int
-    code = lib().orc_rdq20mf_local_solve(_d(_f64(p)), _d(Q), _d(_f64(Qknown)), C.c_double(lam), C.c_double(dlam), C.c_double(ca), C.c_double(dt),
-                                         C.c_double(tol), C.c_int(max_iters), _d(dQdl), C.byref(it), C.byref(rn))
-    return code, Q, dQdl, it.value, rn.value
+    lib().orc_rdq20mf_local_solve_rate.restype = C.c_int
+    code = lib().orc_rdq20mf_local_solve_rate(_d(_f64(p)), _d(Q), _d(_f64(Qknown)), C.c_double(lam), C.c_double(dlam), C.c_double(ca), C.c_double(dt),
+                                              C.c_double(tol), C.c_int(max_iters), _d(dQdl), _d(dQdv) if rate else None, C.byref(it), C.byref(rn))
+    return (code, Q, dQdl, it.value, rn.value, dQdv) if rate else (code, Q, dQdl, it.value, rn.value)
 
 
 _COND_KEEP = [None]
 
 
-def set_condensation(Q=None, Qknown=None, dt=1.0, tmax=1.0, tol=1e-4, max_iters=10, p=RDQ20MF_DEFAULTS, status=None):
+def set_condensation(Q=None, Qknown=None, dt=1.0, tmax=1.0, tol=1e-4, max_iters=10, p=RDQ20MF_DEFAULTS, status=None, u_prev=None):
     """Condensed RDQ20-MF internal variable in element_hyperelastic / assemble_hyperelastic (global; set_condensation() switches it
     off).  Q (20 × n_points, point = cell·n_qp + q, C-contiguous float64) is the initial guess and is overwritten with the solution;
     calcium comes from set_active_tension(scale[, nodal field])."""
@@ -492,9 +492,13 @@ def set_condensation(Q=None, Qknown=None, dt=1.0, tmax=1.0, tol=1e-4, max_iters=
     assert Q.flags.c_contiguous and Q.dtype == np.float64 and Q.shape[0] == 20
     Qk = np.ascontiguousarray(Qknown, dtype=np.float64)
     pp = _f64(p)
-    _COND_KEEP[0] = (Q, Qk, pp, status)
+    up = None if u_prev is None else np.ascontiguousarray(u_prev, dtype=np.float64)
+    _COND_KEEP[0] = (Q, Qk, pp, status, up)
     lib().orc_set_condensation(pp.ctypes.data, float(tmax), Q.ctypes.data, Qk.ctypes.data, Q.shape[1], float(dt), float(tol), int(max_iters),
                                None if status is None else status.ctypes.data)
+    lib().orc_set_condensation_rate.restype = None
+    lib().orc_set_condensation_rate.argtypes = [C.c_void_p]
+    lib().orc_set_condensation_rate(None if up is None else up.ctypes.data)   # rate-coupled form: Ḟ = (∇u − ∇u_prev)/Δt
 
 
 def set_prestress(F0inv=None):

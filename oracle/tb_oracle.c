@@ -1413,10 +1413,12 @@ static void prestress_pullback(double *P, double *A)
 
 /* condensed internal variable (QuasiStaticCondensedElementCache, elements.jl:411-470; material_routine materials.jl:472-502;
  * solve_local_constraint rate-free :1575-1632; _solve_local_sarcomere_dQdF :1381-1395): global test state like g_mat_* */
-int orc_rdq20mf_local_solve(const double *p, double *Q, const double *Qknown, double lam, double dlam, double Ca, double dt, double tol, int max_iters,
-                            double *dQdl, int *iters, double *resnorm);
+int orc_rdq20mf_local_solve_rate(const double *p, double *Q, const double *Qknown, double lam, double dlam, double Ca, double dt, double tol, int max_iters,
+                                 double *dQdl, double *dQdv, int *iters, double *resnorm);
 double orc_rdq20mf_overlap(const double *p, double lam);
-static struct { int on; double p[17], tmax, dt, tol; int max_iters; double *Q; const double *Qknown; int64_t n_points; int *status; } g_cond;
+static struct { int on; double p[17], tmax, dt, tol; int max_iters; double *Q; const double *Qknown; int64_t n_points; int *status; const double *u_prev; } g_cond;
+/* rate-coupled local problem (materials.jl:1664-1750): previous displacement for Ḟ = (∇u − ∇u_prev)/Δt; NULL → rate-free */
+void orc_set_condensation_rate(const double *u_prev) { g_cond.u_prev = u_prev; }
 void orc_set_condensation(const double *p, double tmax, double *Q, const double *Qknown, int64_t n_points, double dt, double tol, int max_iters, int *status)
 {
     memset(&g_cond, 0, sizeof g_cond);
@@ -1435,28 +1437,39 @@ static double overlap_slope_fd(const double *p, double lam)
     return 0.0;
 }
 /* adds the active part at one point: P += a ∂λ/∂F, A += a ∂²λ/∂F² + b ∂λ/∂F ⊗ ∂λ/∂F after the local solve */
-static void condensed_active_part(int64_t point, const double *F, const double *f0, double Ca, double *P, double *A)
+static void condensed_active_part(int64_t point, const double *F, const double *Fprev, const double *f0, double Ca, double *P, double *A)
 {
     double g[3], lam = 0;
     for (int i = 0; i < 3; ++i) { g[i] = F[3 * i] * f0[0] + F[3 * i + 1] * f0[1] + F[3 * i + 2] * f0[2]; lam += g[i] * g[i]; }
     lam = sqrt(lam);
-    double Q[20], Qk[20], dQdl[20];
+    /* ∂λ/∂F and ∂²λ/∂F² written out in full (Tensors.hessian of _fiber_stretch in the reference) */
+    double dl[9], d2l[81];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) dl[3 * i + j] = g[i] * f0[j] / lam;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) for (int k = 0; k < 3; ++k) for (int l = 0; l < 3; ++l)
+        d2l[9 * (3 * i + j) + 3 * k + l] = ((i == k) ? f0[j] * f0[l] / lam : 0.0) - dl[3 * i + j] * dl[3 * k + l] / lam;
+    double dlamdt = 0.0, W[9] = {0};
+    if (Fprev) { /* Ḟ = (F − F_prev)/Δt; dλ/dt = ∂λ/∂F ⊡ Ḟ; ∂dλdt∂F = ∂²λ/∂F² ⊡ Ḟ */
+        double Fd[9];
+        for (int e = 0; e < 9; ++e) { Fd[e] = (F[e] - Fprev[e]) / g_cond.dt; dlamdt += dl[e] * Fd[e]; }
+        for (int e = 0; e < 9; ++e) { double sW = 0; for (int k2 = 0; k2 < 9; ++k2) sW += d2l[9 * e + k2] * Fd[k2]; W[e] = sW; }
+    }
+    double Q[20], Qk[20], dQdl[20], dQdv[20];
     for (int k = 0; k < 20; ++k) { Q[k] = g_cond.Q[k * g_cond.n_points + point]; Qk[k] = g_cond.Qknown[k * g_cond.n_points + point]; }
-    int code = orc_rdq20mf_local_solve(g_cond.p, Q, Qk, lam, 0.0, Ca, g_cond.dt, g_cond.tol, g_cond.max_iters, A ? dQdl : NULL, NULL, NULL);
-    if (code != 0) memset(dQdl, 0, sizeof dQdl);
+    int code = orc_rdq20mf_local_solve_rate(g_cond.p, Q, Qk, lam, dlamdt, Ca, g_cond.dt, g_cond.tol, g_cond.max_iters, A ? dQdl : NULL, A && Fprev ? dQdv : NULL, NULL, NULL);
+    if (code != 0 || !A) { memset(dQdl, 0, sizeof dQdl); memset(dQdv, 0, sizeof dQdv); }
+    if (!Fprev) memset(dQdv, 0, sizeof dQdv);
     for (int k = 0; k < 20; ++k) g_cond.Q[k * g_cond.n_points + point] = Q[k];
     if (g_cond.status) g_cond.status[point] = code;
     double fso = orc_rdq20mf_overlap(g_cond.p, lam), qq = Q[17] + Q[19];
     double a = g_cond.tmax * qq * fso;
-    double dl[9];
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) dl[3 * i + j] = g[i] * f0[j] / lam;
     for (int e = 0; e < 9; ++e) P[e] += a * dl[e];
     if (A) {
-        double b = g_cond.tmax * (qq * overlap_slope_fd(g_cond.p, lam) + (dQdl[17] + dQdl[19]) * fso);
-        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) for (int k = 0; k < 3; ++k) for (int l = 0; l < 3; ++l) {
-            double d2 = ((i == k) ? f0[j] * f0[l] / lam : 0.0) - dl[3 * i + j] * dl[3 * k + l] / lam;
-            A[9 * (3 * i + j) + 3 * k + l] += a * d2 + b * dl[3 * i + j] * dl[3 * k + l];
-        }
+        /* frozen-Q part a ∂²λ + Tmax q fso′ ∂λ⊗∂λ; corrector chains (_solve_local_sarcomere_dQdF, materials.jl:1381-1395):
+         * ∂P∂QdQdF = dfgdQ ⊗ [q_λ ∂λ + q_λ̇ (∂²λ ⊡ Ḟ)], ∂P∂QdQdḞ = q_λ̇ dfgdQ ⊗ ∂λ, folded with ∂Ḟ/∂u = 1/Δt (consistent_tangent) */
+        double ql = dQdl[17] + dQdl[19], qv = dQdv[17] + dQdv[19];
+        double bs = g_cond.tmax * qq * overlap_slope_fd(g_cond.p, lam), dfg = g_cond.tmax * fso;
+        for (int e = 0; e < 9; ++e) for (int k2 = 0; k2 < 9; ++k2)
+            A[9 * e + k2] += a * d2l[9 * e + k2] + bs * dl[e] * dl[k2] + dfg * dl[e] * (ql * dl[k2] + qv * W[k2]) + dfg * qv * dl[e] * dl[k2] / g_cond.dt;
     }
 }
 
@@ -1504,7 +1517,12 @@ static int element_hyperelastic_cv(const orc_mesh *m, const cellvalues *cv, int6
         if (g_cond.on) {
             double ca = g_act_scale;
             if (g_act_field) { double sc = 0.0; for (int a = 0; a < cv->ngeo; ++a) sc += cv->M[q][a] * g_act_field[(int64_t)cell * cv->ngeo + a]; ca *= sc; }
-            condensed_active_part((int64_t)cell * cv->nq + q, F, fsn, ca, P, Ke ? A : NULL);
+            double Fprev[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+            if (g_cond.u_prev) {
+                const int32_t *cd = m->cell_dofs + (int64_t)cell * nd;
+                for (int a = 0; a < nb; ++a) for (int c = 0; c < 3; ++c) for (int k = 0; k < 3; ++k) Fprev[3 * c + k] += g_cond.u_prev[cd[3 * a + c]] * dNdx[3 * a + k];
+            }
+            condensed_active_part((int64_t)cell * cv->nq + q, F, g_cond.u_prev ? Fprev : NULL, fsn, ca, P, Ke ? A : NULL);
         }
         for (int i = 0; i < nd; ++i) {
             int a = i / 3, c = i % 3;
@@ -1852,7 +1870,7 @@ void orc_rdq20mf_trajectory(const double *p, double *u, int64_t n_steps, double 
  * state at frozen stretch by Newton, Jacobian by forward-mode differentiation carrying all 21 partials at once (∂/∂Q₁…Q₂₀, ∂/∂λ) —
  * ForwardDiff.jacobian! / derivative! in the reference; dense LU with partial pivoting (lu!).  Written over its own dual type so that
  * it shares no code with the device's one-direction-per-lane evaluation. */
-#define ND21 21
+#define ND21 22 /* ∂/∂Q₁…Q₂₀, ∂/∂λ, ∂/∂λ̇ */
 typedef struct { double v, g[ND21]; } dq;
 static dq dq_c(double c) { dq r; memset(&r, 0, sizeof r); r.v = c; return r; }
 static dq dq_add(dq a, dq b) { a.v += b.v; for (int i = 0; i < ND21; ++i) a.g[i] += b.g[i]; return a; }
@@ -1861,7 +1879,8 @@ static dq dq_neg(dq a) { a.v = -a.v; for (int i = 0; i < ND21; ++i) a.g[i] = -a.
 static dq dq_scale(dq a, double s) { a.v *= s; for (int i = 0; i < ND21; ++i) a.g[i] *= s; return a; }
 static dq dq_mul(dq a, dq b) { dq r; r.v = a.v * b.v; for (int i = 0; i < ND21; ++i) r.g[i] = a.g[i] * b.v + a.v * b.g[i]; return r; }
 static dq dq_div(dq a, dq b) { dq r; r.v = a.v / b.v; for (int i = 0; i < ND21; ++i) r.g[i] = (a.g[i] - r.v * b.g[i]) / b.v; return r; }
-static void rdq20mf_rhs_dq(const double *p, const dq *u, dq lam, double dlam, double Ca, dq *du)
+static dq dq_sqrt(dq a) { dq r; r.v = sqrt(a.v); for (int i = 0; i < ND21; ++i) r.g[i] = 0.5 * a.g[i] / r.v; return r; }
+static void rdq20mf_rhs_dq(const double *p, const dq *u, dq lam, dq dlam, double Ca, dq *du)
 {
     const double SL0 = p[3], Kd0 = p[5], aKd = p[6], mu = p[7], Koff = p[9], r0 = p[11], alpha = p[12], mu0 = p[13], mu1 = p[14], epsv = p[16];
     dq U[2][2][2][2], PT_C[2][2][2][2], PC_C[2][2][2][2], PT_L[2][2][2][2], PT_R[2][2][2][2];
@@ -1906,13 +1925,14 @@ static void rdq20mf_rhs_dq(const double *p, const dq *u, dq lam, double dlam, do
     }
     dq k_PN = perm.v >= 1e-12 ? dq_div(flux_PN, perm) : dq_c(0);
     dq k_NP = 1.0 - perm.v >= 1e-12 ? dq_div(flux_NP, dq_sub(dq_c(1.0), perm)) : dq_c(0);
-    double r = r0 + alpha * (dlam * dlam / sqrt(dlam * dlam + epsv * epsv));
-    dq diag_P = dq_add(dq_c(r), k_PN), diag_N = dq_add(dq_c(r), k_NP);
+    dq v2 = dq_mul(dlam, dlam);
+    dq r = dq_add(dq_c(r0), dq_scale(dq_div(v2, dq_sqrt(dq_add(v2, dq_c(epsv * epsv)))), alpha)); /* r₀ + α smooth_abs(λ̇, εᵛ) */
+    dq diag_P = dq_add(r, k_PN), diag_N = dq_add(r, k_NP);
     const dq *x = u + 16;
     du[16] = dq_add(dq_add(dq_neg(dq_mul(diag_P, x[0])), dq_mul(k_NP, x[2])), dq_scale(perm, mu0));
-    du[17] = dq_add(dq_add(dq_sub(dq_scale(x[0], dlam), dq_mul(diag_P, x[1])), dq_mul(k_NP, x[3])), dq_scale(perm, mu1));
+    du[17] = dq_add(dq_add(dq_sub(dq_mul(x[0], dlam), dq_mul(diag_P, x[1])), dq_mul(k_NP, x[3])), dq_scale(perm, mu1));
     du[18] = dq_sub(dq_mul(k_PN, x[0]), dq_mul(diag_N, x[2]));
-    du[19] = dq_sub(dq_add(dq_mul(k_PN, x[1]), dq_scale(x[2], dlam)), dq_mul(diag_N, x[3]));
+    du[19] = dq_sub(dq_add(dq_mul(k_PN, x[1]), dq_mul(x[2], dlam)), dq_mul(diag_N, x[3]));
 }
 static int lu20(double A[20][20], int *perm)
 {
@@ -1934,15 +1954,22 @@ static void lu20_solve(double A[20][20], const int *perm, const double *b, doubl
 }
 /* returns the status code (0 success, 1 linear solve failed, 2 max iters, 3 NaN, 4 inadmissible state); Q: guess in, solution out;
  * dQdl (20, may be NULL): corrector at the solution */
+int orc_rdq20mf_local_solve_rate(const double *p, double *Q, const double *Qknown, double lam, double dlam, double Ca, double dt, double tol, int max_iters,
+                                 double *dQdl, double *dQdv, int *iters, double *resnorm);
 int orc_rdq20mf_local_solve(const double *p, double *Q, const double *Qknown, double lam, double dlam, double Ca, double dt, double tol, int max_iters,
                             double *dQdl, int *iters, double *resnorm)
+{
+    return orc_rdq20mf_local_solve_rate(p, Q, Qknown, lam, dlam, Ca, dt, tol, max_iters, dQdl, NULL, iters, resnorm);
+}
+int orc_rdq20mf_local_solve_rate(const double *p, double *Q, const double *Qknown, double lam, double dlam, double Ca, double dt, double tol, int max_iters,
+                                 double *dQdl, double *dQdv, int *iters, double *resnorm)
 {
     dq u[20], du[20];
     double J[20][20], R[20], x[20], rn = 0;
     int perm[20], it;
     for (it = 1; it <= max_iters; ++it) {
         for (int k = 0; k < 20; ++k) { u[k] = dq_c(Q[k]); u[k].g[k] = 1.0; }
-        rdq20mf_rhs_dq(p, u, dq_c(lam), dlam, Ca, du);
+        rdq20mf_rhs_dq(p, u, dq_c(lam), dq_c(dlam), Ca, du);
         rn = 0;
         for (int k = 0; k < 20; ++k) {
             R[k] = (Q[k] - Qknown[k]) / dt - du[k].v; rn += R[k] * R[k];
@@ -1960,13 +1987,14 @@ int orc_rdq20mf_local_solve(const double *p, double *Q, const double *Qknown, do
     }
     for (int k = 0; k < 16; ++k) if (!(Q[k] >= 0.0)) return 4;
     if (dQdl) {
-        dq l = dq_c(lam); l.g[20] = 1.0;
+        dq l = dq_c(lam), vv = dq_c(dlam); l.g[20] = 1.0; vv.g[21] = 1.0;
         for (int k = 0; k < 20; ++k) { u[k] = dq_c(Q[k]); u[k].g[k] = 1.0; }
-        rdq20mf_rhs_dq(p, u, l, dlam, Ca, du);
-        double g[20];
-        for (int k = 0; k < 20; ++k) { g[k] = du[k].g[20]; for (int c = 0; c < 20; ++c) J[k][c] = (k == c ? 1.0 / dt : 0.0) - du[k].g[c]; }
+        rdq20mf_rhs_dq(p, u, l, vv, Ca, du);
+        double g[20], gv[20];
+        for (int k = 0; k < 20; ++k) { g[k] = du[k].g[20]; gv[k] = du[k].g[21]; for (int c = 0; c < 20; ++c) J[k][c] = (k == c ? 1.0 / dt : 0.0) - du[k].g[c]; }
         if (!lu20(J, perm)) return 1;
         lu20_solve(J, perm, g, dQdl);
+        if (dQdv) lu20_solve(J, perm, gv, dQdv);
     }
     return 0;
 }

@@ -213,4 +213,8 @@ void orc_set_condensation(const double *p, double tmax, double *Q, const double 
 
 void orc_set_prestress(const double *F0inv); /* NULL: none */
 
+void orc_set_condensation_rate(const double *u_prev); /* after orc_set_condensation; NULL → rate-free */
+int orc_rdq20mf_local_solve_rate(const double *p, double *Q, const double *Qknown, double lam, double dlam, double Ca, double dt, double tol, int max_iters,
+                                 double *dQdl, double *dQdv, int *iters, double *resnorm);
+
 #endif

@@ -949,10 +949,12 @@ def test_condensed_sarcomere_parity(tb, oracle, device, order, nel, passive):
         oracle.set_condensation(); oracle.set_active_tension(0.0); oracle.set_material()
 
 
-def test_reference_contracting_cuboid_with_internal_sarcomere_state(tb, device):
+@pytest.mark.parametrize("form", ["rate_free", "rate_coupled"])
+def test_reference_contracting_cuboid_with_internal_sarcomere_state(tb, device, form):
     """test/integration/test_solid_mechanics.jl:383-445 (time integrated contracting cuboid): ActiveStressModel(Guccione1991PassiveModel,
     SimpleActiveStress(Tmax = 220e3), CaDrivenInternalSarcomereModel(AsRateIndependent(RDQ20MFModel()), calcium hat)), the cuboid and
-    boundary conditions of the single-subdomain case, BackwardEulerSolver with the multi-level Newton over tspan (0, 2), Δt = 0.25.
+    boundary conditions of the single-subdomain case, BackwardEulerSolver with the multi-level Newton over tspan (0, 2), Δt = 0.25 —
+    and the unwrapped RDQ20MFModel() of :389-405 (rate-coupled local problem, non-symmetric tangent, GMRES).
     Like the reference: every step succeeds and u moved.  Additionally: the internal states stay admissible probabilities, the
     cross-bridge states leave zero, and the block shortens along the fibre."""
     g = tb.generate_mesh(tb.Hexahedron, (10, 10, 2), (0.0, 0.0, 0.0), (1.0, 1.0, 0.2))
@@ -961,9 +963,10 @@ def test_reference_contracting_cuboid_with_internal_sarcomere_state(tb, device):
     ms = tb.ConstantCoefficient(tb.OrthotropicMicrostructure([1.0, 0, 0], [0, 1.0, 0], [0, 0, 1.0]))
     hat = lambda t: 2.0 * t / 1000.0 if t / 1000.0 < 0.5 else 2.0 - 2.0 * t / 1000.0
     cm = tb.ActiveStressModel(tb.Guccione1991PassiveModel(), tb.SimpleActiveStress(Tmax=220e3),
-                              tb.CaDrivenInternalSarcomereModel(tb.AsRateIndependent(tb.RDQ20MFModel()), hat), ms)
+                              tb.CaDrivenInternalSarcomereModel(tb.AsRateIndependent(tb.RDQ20MFModel()) if form == "rate_free" else tb.RDQ20MFModel(), hat), ms)
     facemodels = (tb.NormalSpringBC(0.0, "right"), tb.ConstantPressureBC(0.0, "back"), tb.PressureFieldBC(tb.ConstantCoefficient(0.0), "top"))
     op = tb.setup_operator(tb.PerColorAssemblyStrategy(device), tb.QuasiStaticModel("d", cm, facemodels), dh, sp)
+    assert (op.u_prev is not None) == (form == "rate_coupled")
     node_dof0 = np.empty(g.n_nodes, dtype=np.int64)
     node_dof0[g.conn.ravel()] = dh.cell_dofs[:, 0::3].ravel()
     X = g.xyz
@@ -1075,6 +1078,73 @@ def test_reference_passive_structure_with_subdomains(tb, oracle, device):
         res = device.zeros(dh.ndofs)
         tb.update_linearization(op, du, 0.0, residual=res)
         assert rel_err(op.J.to_host(), Kref) < 1e-11 and rel_err(res.to_host(), rref) < 1e-11
+
+
+@pytest.mark.parametrize("order,nel,passive", [(1, (4, 3, 2), "ho"), (2, (2, 2, 2), "ho"), (1, (3, 3, 2), "guccione"), (2, (2, 2, 1), "guccione")])
+def test_rate_coupled_condensed_sarcomere_parity(tb, oracle, device, order, nel, passive):
+    """The unwrapped RDQ20MFModel in an ActiveStressModel: rate-coupled local problem dₜQ = L(F, dₜF, Q) with the backward-Euler rate
+    Ḟ = (∇u − ∇u_prev)/Δt (QuasiStaticCondensedDAEElementCache, elements.jl:382-400; materials.jl:504-540,1664-1750).  The tangent is no
+    longer symmetric: ∂P/∂Ḟ/Δt and ∂P/∂Q ∂Q/∂λ̇ ⊗ (∂²λ/∂F² : Ḟ).  Residual, tangent and internal states against the oracle (which
+    forms ∂²λ/∂F² in full and contracts it with Ḟ); K·v against central differences of the residual with the local problems re-solved."""
+    g, dh, sp, om = mech_problem(tb, oracle, nel, order, perturb=0.1)
+    rng = np.random.default_rng(11)
+    u = rng.uniform(-2e-2, 2e-2, dh.ndofs)
+    uprev = u + rng.uniform(-4e-3, 4e-3, dh.ndofs)
+    du = device.to_device(u)
+    f, s, n = np.array([1, 1, 0.0]) / np.sqrt(2), np.array([-1, 1, 0.0]) / np.sqrt(2), np.array([0, 0, 1.0])
+    fsn = np.stack([f, s, n])
+    ms = tb.ConstantCoefficient(tb.OrthotropicMicrostructure(f, s, n))
+    nq = 8 if order == 1 else 27
+    npts = g.n_cells * nq
+    Q0 = np.concatenate([rng.dirichlet(np.ones(16), npts).T, rng.uniform(0, 0.05, (4, npts))])
+    Tmax, dt = 50.0, 0.5
+    pas = tb.HolzapfelOgden2009Model() if passive == "ho" else tb.Guccione1991PassiveModel()
+    tight = tb.GenericLocalNonlinearSolver(max_iters=30, tol=1e-13)
+    cm = tb.ActiveStressModel(pas, tb.SimpleActiveStress(Tmax=Tmax), tb.CaDrivenInternalSarcomereModel(tb.RDQ20MFModel(), 0.6), ms)
+    pm = cm.passive.lower()
+    try:
+        oracle.set_material(pm.kind, pm.reserved, list(pm.p)[:9], list(pm.p)[10:13])
+        oracle.set_active_tension(0.6, None)
+        Qref = Q0.copy()
+        oracle.set_condensation(Qref, Q0, dt=dt, tmax=Tmax, tol=tight.tol, max_iters=tight.max_iters, u_prev=uprev)
+        Kref, rref = oracle.assemble_hyperelastic(om, u, sp.rowptr, sp.colidx, fsn=fsn)
+        Qrate = Q0.copy()
+        oracle.set_condensation(Qrate, Q0, dt=dt, tmax=Tmax, tol=tight.tol, max_iters=tight.max_iters)       # rate-free, for comparison
+        K0, r0 = oracle.assemble_hyperelastic(om, u, sp.rowptr, sp.colidx, fsn=fsn)
+        oracle.set_condensation()
+        import scipy.sparse as ssp
+        Km = ssp.csr_matrix((Kref, sp.colidx, sp.rowptr), shape=(dh.ndofs, dh.ndofs))
+        assert abs(Km - Km.T).max() > 1e-6 * np.abs(Kref).max()                     # genuinely non-symmetric
+        assert np.abs(rref - r0).max() > 1e-6 * np.abs(r0).max()                    # the rate changes the state and with it the stress
+        for st in (tb.ElementAssemblyStrategy(device), tb.PerColorAssemblyStrategy(device)):
+            op = tb.setup_operator(st, tb.QuasiStaticModel("u", cm), dh, sp, local_solver=tight)
+            assert op.u_prev is not None
+            op.u_prev.copy_from_host(uprev)
+            op.internal.u.copy_from_host(Q0.ravel()); op.internal_known.u.copy_from_host(Q0.ravel())
+            tb.set_timestep(op, dt)
+            res = device.zeros(dh.ndofs)
+            tb.update_linearization(op, du, 0.0, residual=res)
+            assert tb.local_solve_failures(op) == 0
+            np.testing.assert_allclose(op.internal.to_host(), Qref, rtol=1e-10, atol=1e-13)
+            assert rel_err(res.to_host(), rref) < 1e-10
+            assert rel_err(op.J.to_host(), Kref) < 1e-9
+            res2 = device.zeros(dh.ndofs)
+            op.internal.u.copy_from_host(Q0.ravel())
+            tb.residual(op, res2, du, 0.0)
+            assert rel_err(res2.to_host(), rref) < 1e-10
+
+        def resid(uu):
+            op.internal.u.copy_from_host(Q0.ravel())
+            r = device.zeros(dh.ndofs)
+            tb.residual(op, r, device.to_device(uu), 0.0)
+            return r.to_host()
+        K = ssp.csr_matrix((op.J.to_host(), sp.colidx, sp.rowptr), shape=(dh.ndofs, dh.ndofs))
+        v = rng.normal(size=dh.ndofs)
+        h = 1e-6
+        fd = (resid(u + h * v) - resid(u - h * v)) / (2 * h)
+        assert np.abs(K @ v - fd).max() < 5e-6 * np.abs(fd).max()
+    finally:
+        oracle.set_condensation(); oracle.set_active_tension(0.0); oracle.set_material()
 
 
 # ------------------------------------------------------------------------------------------- the reference's own GPU tests

@@ -268,3 +268,53 @@ def test_device_local_solve_matches_oracle(tb, oracle, device):
     status = device.to_device(np.zeros(40, dtype=np.int32))
     assert tb.sarcomere_implicit_step(st, known, 1.0, 1.0, 0.8, tb.GenericLocalNonlinearSolver(1, 1e-14), status=status) == 40
     assert (status.to_host() == 2).all()
+
+
+def test_rate_coupled_local_solve_host_matches_oracle(tb, oracle):
+    """The rate-coupled local problem dₜQ = L(F, dₜF, Q) (materials.jl:1664-1750): dλ/dt enters the cross-bridge block and a second
+    corrector dQ/d(dλ/dt) appears; host version of the device algebra against the oracle's 22-partial forward mode, and both
+    correctors against central differences of the solve."""
+    rng = np.random.default_rng(5)
+    model = tb.RDQ20MFModel()
+    tight = tb.GenericLocalNonlinearSolver(max_iters=30, tol=1e-13)
+    for trial in range(20):
+        Qk = random_states(rng, 1)[:, 0]
+        lam, ca, dt = rng.uniform(0.8, 1.15), rng.uniform(0.05, 1.0), rng.choice([0.25, 1.0])
+        vel = rng.normal() * 5e-3 if trial else 0.0
+        st, Q, dQ, it, rn, dQv = tb.sarcomere_local_solve(model, Qk, Qk, lam, ca, dt, tight, velocity=vel)
+        ost, oQ, odQ, oit, orn, odQv = oracle.rdq20mf_local_solve(Qk, Qk, lam, ca, dt, tight.tol, tight.max_iters, dlam=vel, rate=True)
+        assert st == ost == 0 and it == oit
+        np.testing.assert_allclose(Q, oQ, rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(dQ, odQ, rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(dQv, odQv, rtol=1e-9, atol=1e-13)
+        assert np.abs(dQv[:16]).max() == 0.0                      # the chain does not see the velocity
+        res = (Q - Qk) / dt - tb.sarcomere_rhs(model, Q, lam, vel, ca)[0]
+        assert np.abs(res).max() < 1e-12
+        if abs(vel) > 1e-4:                                        # away from the regularised kink of |v|
+            h = 1e-7
+            Qp = tb.sarcomere_local_solve(model, Qk, Qk, lam, ca, dt, tight, velocity=vel + h)[1]
+            Qm = tb.sarcomere_local_solve(model, Qk, Qk, lam, ca, dt, tight, velocity=vel - h)[1]
+            np.testing.assert_allclose(dQv, (Qp - Qm) / (2 * h), rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.gpu
+def test_device_rate_coupled_local_solve_matches_oracle(tb, oracle, device):
+    rng = np.random.default_rng(6)
+    model = tb.RDQ20MFModel()
+    tight = tb.GenericLocalNonlinearSolver(30, 1e-13)
+    for npts in (3, 130):
+        Qk = random_states(rng, npts)
+        lam, ca, vel = rng.uniform(0.8, 1.15, npts), rng.uniform(0.05, 1.0, npts), rng.normal(size=npts) * 5e-3
+        known = tb.SarcomereState(device, model, npts, initial=Qk)
+        st = tb.SarcomereState(device, model, npts, initial=Qk)
+        dQ, dQv = device.zeros(20 * npts), device.zeros(20 * npts)
+        nf = tb.sarcomere_implicit_step(st, known, 0.5, device.to_device(lam), device.to_device(ca), tight, dstate_dstretch=dQ,
+                                        velocity=device.to_device(vel), dstate_dvelocity=dQv)
+        assert nf == 0
+        got, gdQ, gdQv = st.to_host(), dQ.to_host().reshape(20, npts), dQv.to_host().reshape(20, npts)
+        for i in range(npts):
+            code, oQ, odQ, _, _, odQv = oracle.rdq20mf_local_solve(Qk[:, i], Qk[:, i], lam[i], ca[i], 0.5, tight.tol, tight.max_iters, dlam=vel[i], rate=True)
+            assert code == 0
+            np.testing.assert_allclose(got[:, i], oQ, rtol=1e-11, atol=1e-14)
+            np.testing.assert_allclose(gdQ[:, i], odQ, rtol=1e-8, atol=1e-12)
+            np.testing.assert_allclose(gdQv[:, i], odQv, rtol=1e-8, atol=1e-12)

@@ -90,10 +90,11 @@ SIGNATURES = {
     "tb_sarcomere_step": (C.c_int, [vp, C.c_int, c_dp, C.c_int, vp, C.c_int64, vp, vp, vp, C.c_double, C.c_double, C.c_double, C.c_double,
                                     C.c_double, C.c_int, C.c_int, vp, vp]),
     "tb_host_sarcomere_eval": (C.c_int, [C.c_int, c_dp, C.c_int, c_dp, C.c_double, C.c_double, C.c_double, c_dp, c_dp, c_dp]),
-    "tb_sarcomere_implicit_step": (C.c_int, [vp, C.c_int, c_dp, C.c_int, vp, vp, C.c_int64, vp, vp, C.c_double, C.c_double, C.c_double, C.c_double,
-                                             C.c_int, vp, vp, C.POINTER(C.c_int64)]),
-    "tb_host_sarcomere_local_solve": (C.c_int, [C.c_int, c_dp, C.c_int, c_dp, c_dp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, c_dp,
-                                                C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "tb_sarcomere_implicit_step": (C.c_int, [vp, C.c_int, c_dp, C.c_int, vp, vp, C.c_int64, vp, vp, vp, C.c_double, C.c_double, C.c_double, C.c_double,
+                                             C.c_double, C.c_int, vp, vp, vp, C.POINTER(C.c_int64)]),
+    "tb_host_sarcomere_local_solve": (C.c_int, [C.c_int, c_dp, C.c_int, c_dp, c_dp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
+                                                c_dp, c_dp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "tb_hyperelastic_set_previous_solution": (C.c_int, [vp, vp]),
     "tb_hyperelastic_set_prestress": (C.c_int, [vp, c_dp]),
     "tb_form_set_cellset": (C.c_int, [vp, c_i32p, C.c_int64, C.c_int]),
     "tb_form_clear_cellset": (C.c_int, [vp]),

@@ -1236,9 +1236,6 @@ class NonlinearOperator:
             if sm is not None:
                 if len(domains) > 1:
                     raise NotImplementedError("condensed internal variables on a subdomain are not supported")
-                if not sm.rate_independent:
-                    raise NotImplementedError("rate-coupled internal variables (dλ/dt = ∂λ/∂F : Ḟ, non-symmetric tangent) are not on the device yet: "
-                                              "wrap the sarcomere model in AsRateIndependent")
                 ls = local_solver or GenericLocalNonlinearSolver()
                 pp = sm.params()
                 check(lib().tb_hyperelastic_set_condensation(form, sm.sid, pp.ctypes.data_as(L.c_dp), len(pp), cm.active_stress_model.Tmax, ls.tol, ls.max_iters))
@@ -1247,6 +1244,10 @@ class NonlinearOperator:
                 self.internal = SarcomereState(strategy.device, sm, npts.value)        # Q: current iterate / solution
                 self.internal_known = SarcomereState(strategy.device, sm, npts.value)  # Q_known: accepted state of the previous step
                 self.dt = None
+                self.u_prev = None
+                if not sm.rate_independent:      # rate-coupled local problem (QuasiStaticCondensedDAEElementCache): Ḟ from the previous displacement
+                    self.u_prev = strategy.device.zeros(dh.ndofs)
+                    check(lib().tb_hyperelastic_set_previous_solution(form, self.u_prev.ptr))
             # surface terms: one facet form per weak boundary condition (setup_boundary_cache, weak_boundary_conditions.jl:1-7)
             for bc in getattr(qm, "facet_models", ()):
                 fs = bc.boundary_name if not isinstance(bc.boundary_name, str) else dh.grid.facetset(bc.boundary_name)
@@ -1300,6 +1301,8 @@ def perform_mechanics_step(u, op, ch, solver, t, dt):
     failed local solve or a diverged global Newton is rejected: u and Q are restored and False is returned."""
     u0 = u.to_host()
     set_timestep(op, dt)
+    if getattr(op, "u_prev", None) is not None:
+        op.u_prev.copy_from_host(u0)                    # backward-Euler rate: Ḟ = (∇u − ∇u_prev)/Δt (AffineVelocity(inv(Δt), uₑprev))
     ok = nlsolve(u, op, ch, solver, t=t + dt)
     if ok and local_solve_failures(op) == 0:
         accept_internal_state(op)
@@ -1576,22 +1579,26 @@ class GenericLocalNonlinearSolver:
         self.max_iters, self.tol = int(max_iters), float(tol)
 
 
-def sarcomere_local_solve(model, Qguess, Qknown, stretch, calcium, dt, local_solver=None):
-    """Host evaluation of the local problem (solve_internal_timestep + corrector, materials.jl:1403-1568, rate-free form):
-    → (status, Q, dQ/dλ, iterations, last residual norm)."""
+def sarcomere_local_solve(model, Qguess, Qknown, stretch, calcium, dt, local_solver=None, velocity=None):
+    """Host evaluation of the local problem (solve_internal_timestep + corrector(s), materials.jl:1403-1568):
+    → (status, Q, dQ/dλ, iterations, last residual norm[, dQ/d(dλ/dt) when a velocity is given: the rate-coupled form])."""
     ls = local_solver or GenericLocalNonlinearSolver()
     p = model.params()
     Q = np.ascontiguousarray(Qguess, dtype=np.float64).copy()
     Qk = np.ascontiguousarray(Qknown, dtype=np.float64)
-    dQ = np.zeros(20)
+    dQ, dQv = np.zeros(20), np.zeros(20)
     st, it, rn = C.c_int(), C.c_int(), C.c_double()
     check(lib().tb_host_sarcomere_local_solve(model.sid, p.ctypes.data_as(L.c_dp), len(p), Q.ctypes.data_as(L.c_dp), Qk.ctypes.data_as(L.c_dp),
-                                              float(stretch), float(calcium), float(dt), ls.tol, ls.max_iters, dQ.ctypes.data_as(L.c_dp),
+                                              float(stretch), 0.0 if velocity is None else float(velocity), float(calcium), float(dt), ls.tol, ls.max_iters,
+                                              dQ.ctypes.data_as(L.c_dp), None if velocity is None else dQv.ctypes.data_as(L.c_dp),
                                               C.byref(st), C.byref(it), C.byref(rn)))
-    return st.value, Q, dQ, it.value, rn.value
+    if velocity is None:
+        return st.value, Q, dQ, it.value, rn.value
+    return st.value, Q, dQ, it.value, rn.value, dQv
 
 
-def sarcomere_implicit_step(state, known, dt, stretch, calcium, local_solver=None, dstate_dstretch=None, status=None, count_failures=True):
+def sarcomere_implicit_step(state, known, dt, stretch, calcium, local_solver=None, dstate_dstretch=None, status=None, count_failures=True,
+                            velocity=None, dstate_dvelocity=None):
     """Backward-Euler step of the internal states at every point with the stretch and calcium frozen (the local problem of the
     condensed mechanics); `state` holds the initial guess and receives the solution, `known` is Q_known (SarcomereState).  Returns the
     number of failed points (or None with count_failures=False: no synchronisation)."""
@@ -1600,9 +1607,11 @@ def sarcomere_implicit_step(state, known, dt, stretch, calcium, local_solver=Non
     p = m.params()
     ps, s = _dev_or_scalar(stretch)
     pc, c = _dev_or_scalar(calcium)
+    pv, v = _dev_or_scalar(0.0 if velocity is None else velocity)
     nf = C.c_int64()
-    check(lib().tb_sarcomere_implicit_step(state.device.h, m.sid, p.ctypes.data_as(L.c_dp), len(p), state.u.ptr, known.u.ptr, state.n_points, ps, pc, s, c,
-                                           float(dt), ls.tol, ls.max_iters, _ptr(dstate_dstretch), _ptr(status), C.byref(nf) if count_failures else None))
+    check(lib().tb_sarcomere_implicit_step(state.device.h, m.sid, p.ctypes.data_as(L.c_dp), len(p), state.u.ptr, known.u.ptr, state.n_points, ps, pv, pc, s, v, c,
+                                           float(dt), ls.tol, ls.max_iters, _ptr(dstate_dstretch), _ptr(dstate_dvelocity), _ptr(status),
+                                           C.byref(nf) if count_failures else None))
     return nf.value if count_failures else None
 
 

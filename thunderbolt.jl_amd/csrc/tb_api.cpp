@@ -544,6 +544,14 @@ int tb_hyperelastic_set_internal_state(tb_form *form, double *d_state, const dou
     return TB_OK;
 }
 
+int tb_hyperelastic_set_previous_solution(tb_form *form, const double *d_u_prev)
+{
+    TB_REQUIRE(form && form->kind == TB_FORM_HYPERELASTIC && form->cond_model, "tb_hyperelastic_set_previous_solution: the form has no condensed internal variable");
+    form->d_u_prev = d_u_prev;
+    if (form->d_qp_buf) { hipFree(form->d_qp_buf); form->d_qp_buf = nullptr; form->d_qp_act = nullptr; } // the per-point layout differs between the two forms
+    return TB_OK;
+}
+
 int tb_hyperelastic_local_solve_report(tb_form *form, int64_t *n_failed, int32_t *status_host, int64_t len)
 {
     TB_REQUIRE(form && form->kind == TB_FORM_HYPERELASTIC && form->cond_model, "tb_hyperelastic_local_solve_report: the form has no condensed internal variable");
@@ -553,7 +561,7 @@ int tb_hyperelastic_local_solve_report(tb_form *form, int64_t *n_failed, int32_t
         tb_hyperelastic_n_quadrature_points(form, &npts);
         TB_REQUIRE(len == npts, "tb_hyperelastic_local_solve_report: status buffer has %lld entries, expected %lld", (long long)len, (long long)npts);
         TB_REQUIRE(form->d_qp_buf, "tb_hyperelastic_local_solve_report: no assembly has run yet");
-        TB_HIP(hipMemcpy(status_host, (const int32_t *)(form->d_qp_buf + 4 * npts), sizeof(int32_t) * npts, hipMemcpyDeviceToHost));
+        TB_HIP(hipMemcpy(status_host, (const int32_t *)(form->d_qp_buf + (form->d_u_prev ? 14 : 4) * npts), sizeof(int32_t) * npts, hipMemcpyDeviceToHost));
     }
     return TB_OK;
 }
@@ -725,28 +733,32 @@ int tb_host_sarcomere_eval(int model, const double *params, int n_params, const 
 }
 
 int tb_sarcomere_implicit_step(tb_device *dev, int model, const double *params, int n_params, double *d_state, const double *d_state_known,
-                               int64_t n_points, const double *d_stretch, const double *d_calcium, double stretch, double calcium, double dt,
-                               double tol, int max_iters, double *d_dstate_dstretch, int32_t *d_status, int64_t *n_failed)
+                               int64_t n_points, const double *d_stretch, const double *d_velocity, const double *d_calcium, double stretch,
+                               double velocity, double calcium, double dt, double tol, int max_iters, double *d_dstate_dstretch,
+                               double *d_dstate_dvelocity, int32_t *d_status, int64_t *n_failed)
 {
     TB_REQUIRE(dev && params, "tb_sarcomere_implicit_step: NULL argument");
     TB_REQUIRE(model == TB_SARCOMERE_RDQ20MF && n_params == 17, "tb_sarcomere_implicit_step: RDQ20MF with 17 parameters expected");
     TB_REQUIRE(n_points >= 0 && dt > 0.0 && tol >= 0.0 && max_iters >= 1, "tb_sarcomere_implicit_step: need n_points >= 0, dt > 0, tol >= 0, max_iters >= 1");
+    TB_REQUIRE(!d_dstate_dvelocity || d_dstate_dstretch, "tb_sarcomere_implicit_step: the velocity corrector is computed together with the stretch corrector");
     if (n_failed) *n_failed = 0;
     if (n_points == 0) return TB_OK;
     TB_REQUIRE(d_state && d_state_known, "tb_sarcomere_implicit_step: NULL state");
     TB_HIP(hipSetDevice(dev->id));
-    return launch_sarcomere_implicit(dev, params, d_state, d_state_known, n_points, d_stretch, d_calcium, stretch, calcium, dt, tol, max_iters, 0.0,
-                                     d_dstate_dstretch, nullptr, d_status, n_failed, d_dstate_dstretch != nullptr);
+    return launch_sarcomere_implicit(dev, params, d_state, d_state_known, n_points, d_stretch, d_velocity, d_calcium, stretch, velocity, calcium, dt, tol,
+                                     max_iters, 0.0, d_dstate_dstretch, d_dstate_dvelocity, nullptr, 2, d_status, n_failed, d_dstate_dstretch != nullptr);
 }
 
 int tb_host_sarcomere_local_solve(int model, const double *params, int n_params, double *state, const double *state_known, double stretch,
-                                  double calcium, double dt, double tol, int max_iters, double *dstate_dstretch, int *status, int *iters,
-                                  double *resnorm)
+                                  double velocity, double calcium, double dt, double tol, int max_iters, double *dstate_dstretch,
+                                  double *dstate_dvelocity, int *status, int *iters, double *resnorm)
 {
     TB_REQUIRE(params && state && state_known, "tb_host_sarcomere_local_solve: NULL argument");
     TB_REQUIRE(model == TB_SARCOMERE_RDQ20MF && n_params == 17, "tb_host_sarcomere_local_solve: RDQ20MF with 17 parameters expected");
     TB_REQUIRE(dt > 0.0 && max_iters >= 1, "tb_host_sarcomere_local_solve: need dt > 0 and max_iters >= 1");
-    const int code = host_sarcomere_local_solve(params, state, state_known, stretch, calcium, dt, tol, max_iters, dstate_dstretch, iters, resnorm);
+    TB_REQUIRE(!dstate_dvelocity || dstate_dstretch, "tb_host_sarcomere_local_solve: the velocity corrector is computed together with the stretch corrector");
+    const int code = host_sarcomere_local_solve(params, state, state_known, stretch, velocity, calcium, dt, tol, max_iters, dstate_dstretch, dstate_dvelocity,
+                                                iters, resnorm);
     if (status) *status = code;
     return TB_OK;
 }

@@ -169,6 +169,7 @@ struct tb_form {
     double cond_params[17] = {0}, cond_tmax = 0.0, cond_tol = 1e-4, cond_dt = 0.0;
     double *d_Q = nullptr;
     const double *d_Qknown = nullptr;
+    const double *d_u_prev = nullptr; // rate-coupled local problem: previous displacement (NULL: rate-free)
     double *d_qp_buf = nullptr, *d_qp_act = nullptr; // λ | Ca | (a, b) | status per quadrature point
     int64_t cond_n_failed = 0;
     // PrestressedMechanicalModel: F₀⁻¹ (tb_hyperelastic_set_prestress)
@@ -213,10 +214,11 @@ int launch_sarcomere(tb_device *dev, const double *params, double *d_state, int6
                      const double *d_calcium, double stretch, double velocity, double calcium, double dt, int substeps, int rate_independent,
                      double *d_tension, double *d_stiffness);
 int launch_sarcomere_implicit(tb_device *dev, const double *params, double *d_Q, const double *d_Qknown, int64_t n, const double *d_stretch,
-                              const double *d_calcium, double stretch, double calcium, double dt, double tol, int max_iters, double tmax,
-                              double *d_dQdl, double *d_act, int32_t *d_status, int64_t *n_failed, int need_sens);
-int host_sarcomere_local_solve(const double *params, double *Q, const double *Qknown, double stretch, double calcium, double dt, double tol, int max_iters,
-                               double *dQdl, int *iters, double *resnorm);
+                              const double *d_velocity, const double *d_calcium, double stretch, double velocity, double calcium, double dt, double tol,
+                              int max_iters, double tmax, double *d_dQdl, double *d_dQdv, double *d_act, int act_stride, int32_t *d_status, int64_t *n_failed,
+                              int need_sens);
+int host_sarcomere_local_solve(const double *params, double *Q, const double *Qknown, double stretch, double velocity, double calcium, double dt, double tol,
+                               int max_iters, double *dQdl, double *dQdv, int *iters, double *resnorm);
 void host_sarcomere_eval(const double *params, const double *u, double stretch, double velocity, double calcium, double *du, double *tension,
                          double *stiffness);
 int launch_gmres(tb_pattern *pat, const double *A, const double *b, double *x, double rtol, double atol, int maxiter, int restart, int jacobi,

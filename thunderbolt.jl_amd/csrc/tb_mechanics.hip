@@ -104,6 +104,7 @@ struct MechMesh {
     const double *fsn_field; // per cell and geometric node: f,s,n (9 doubles); NULL → constant frame of the material
     const double *act_field; // per cell and geometric node: calcium-driven state multiplying the active tension; NULL → 1
     const double *qp_act;    // condensed internal variable: per quadrature point (a, b) — P += a ∂λ/∂F, 𝔸 += a ∂²λ/∂F² + b ∂λ/∂F ⊗ ∂λ/∂F; NULL → none
+    int qp_stride;           // 2, or 5 in the rate-coupled form: (a, b, c·w) with the non-symmetric term 𝔸 += ∂λ/∂F ⊗ (c·w ⊗ f₀), w ⊗ f₀ = ∂²λ/∂F² : Ḟ
 };
 
 // position of column dof(b,0) inside row dof(a,0), per cell and node pair (the three component rows of a node
@@ -219,7 +220,7 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
             for (int d = 0; d < 3; ++d) { o[d] = f[d]; o[3 + d] = sv[d]; o[6 + d] = n[d]; }
             o[9] = ta;
             o[10] = 0.0;
-            if (m.qp_act) { o[9] = m.qp_act[2 * (cell * NQ + tid)]; o[10] = m.qp_act[2 * (cell * NQ + tid) + 1]; }
+            if (m.qp_act) { o[9] = m.qp_act[m.qp_stride * (cell * NQ + tid)]; o[10] = m.qp_act[m.qp_stride * (cell * NQ + tid) + 1]; }
         }
         __syncthreads();
         // A3c': one lane per (point, pair of components of F): Ψ.a = P_m, Ψ.ab = 𝔸_mn = 𝔸_nm
@@ -243,7 +244,17 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
                     const double gv[3] = {g0, g1, g2};
                     ab += o[10] * (gv[mm / 3] * f[mm % 3]) * (gv[nn / 3] * f[nn % 3]) / (g0 * g0 + g1 * g1 + g2 * g2);
                 }
+                if (m.qp_act && m.qp_stride == 5) { // rate-coupled internal variable: the non-symmetric rank-one term, both orderings of the pair
+                    const double *Fq = s_JI[q], *cw = m.qp_act + 5 * (cell * NQ + q) + 2;
+                    const double g0 = Fq[0] * f[0] + Fq[1] * f[1] + Fq[2] * f[2], g1 = Fq[3] * f[0] + Fq[4] * f[1] + Fq[5] * f[2],
+                                 g2 = Fq[6] * f[0] + Fq[7] * f[1] + Fq[8] * f[2];
+                    const double gv[3] = {g0, g1, g2}, il = 1.0 / sqrt(g0 * g0 + g1 * g1 + g2 * g2);
+                    const double amn = gv[mm / 3] * f[mm % 3] * il * cw[nn / 3] * f[nn % 3], anm = gv[nn / 3] * f[nn % 3] * il * cw[mm / 3] * f[mm % 3];
+                    s_A[q][9 * mm + nn] = (ab + amn) * dO;
+                    if (mm != nn) s_A[q][9 * nn + mm] = (ab + anm) * dO;
+                } else {
                 s_A[q][9 * mm + nn] = ab * dO; s_A[q][9 * nn + mm] = ab * dO;
+                }
             }
             if (mm == nn) s_P[q][mm] = r.a * dO;
         }
@@ -260,7 +271,7 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
             for (int a = 0; a < 8; ++a) ca += tb.M[tid][a] * m.act_field[cell * 8 + a];
             mq.Ta = mat.Ta * ca;
         }
-        if (m.qp_act) { mq.Ta = m.qp_act[2 * (cell * NQ + tid)]; mq.Tb = m.qp_act[2 * (cell * NQ + tid) + 1]; }
+        if (m.qp_act) { mq.Ta = m.qp_act[m.qp_stride * (cell * NQ + tid)]; mq.Tb = m.qp_act[m.qp_stride * (cell * NQ + tid) + 1]; }
         if (m.fsn_field) { // interpolate the nodal frame, normalise, Gram–Schmidt (microstructure.jl:176-187)
             double f[3] = {0, 0, 0}, s[3] = {0, 0, 0}, n[3] = {0, 0, 0};
             const double *fc = m.fsn_field + cell * 72;
@@ -283,6 +294,15 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
         if constexpr (NEED_K) {
             double row[9];
             ho_row<true>(mat, s_C[q], s_JI[q], ij / 3, ij % 3, s_JI[q][9], Pij, row);
+            if (m.qp_act && m.qp_stride == 5) { // rate-coupled internal variable: + (∂λ/∂F)_ij (c·w)_k f_l, the only non-symmetric part of the tangent
+                const double *Fq = s_JI[q], *fv = s_C[q] + HOC_FV, *cw = m.qp_act + 5 * (cell * NQ + q) + 2;
+                const int i = ij / 3, j = ij % 3;
+                const double g0 = Fq[0] * fv[0] + Fq[1] * fv[1] + Fq[2] * fv[2], g1 = Fq[3] * fv[0] + Fq[4] * fv[1] + Fq[5] * fv[2],
+                             g2 = Fq[6] * fv[0] + Fq[7] * fv[1] + Fq[8] * fv[2];
+                const double dl = (i == 0 ? g0 : i == 1 ? g1 : g2) * fv[j] / sqrt(g0 * g0 + g1 * g1 + g2 * g2) * s_JI[q][9];
+#pragma unroll
+                for (int e = 0; e < 9; ++e) row[e] += dl * cw[e / 3] * fv[e % 3];
+            }
 #pragma unroll
             for (int e = 0; e < 9; ++e) s_A[q][9 * ij + e] = row[e];
         } else {
@@ -671,7 +691,7 @@ static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, doubl
 {
     tb_mesh *m = f->mesh;
     tb_device *dev = m->dev;
-    const MechMesh mm{m->d_xyz, m->d_conn, m->d_cell_dofs, f->d_field, f->cond_model ? nullptr : f->d_act_field, f->cond_model ? f->d_qp_act : nullptr};
+    const MechMesh mm{m->d_xyz, m->d_conn, m->d_cell_dofs, f->d_field, f->cond_model ? nullptr : f->d_act_field, f->cond_model ? f->d_qp_act : nullptr, f->d_u_prev ? 5 : 2};
     const HOParams hp = make_params(f);
     const EnergyParams ep = make_energy_params(f);
     const bool ea = strategy == TB_STRATEGY_ELEMENT || strategy == TB_STRATEGY_PATCH;
@@ -751,14 +771,14 @@ static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, doubl
 template <class FE>
 __global__ void __launch_bounds__(64)
 k_fiber_stretch(MechMesh m, HOParams mat, const double *__restrict__ act_field, double act_scale, const double *__restrict__ u, double *__restrict__ lam,
-                double *__restrict__ ca, Status *st)
+                double *__restrict__ ca, const double *__restrict__ u_prev, double inv_dt, double *__restrict__ vel, double *__restrict__ wout, Status *st)
 {
     constexpr int NB = FE::NB, NQ = FE::NQ, ND = FE::ND;
     const MechTables<FE> &tb = g_mech_tables<FE>;
     const int64_t cell = blockIdx.x;
     const int tid = threadIdx.x;
-    __shared__ double s_ue[ND], s_x[24];
-    for (int i = tid; i < ND; i += 64) s_ue[i] = u[m.cell_dofs[cell * ND + i]];
+    __shared__ double s_ue[ND], s_x[24], s_up[ND];
+    for (int i = tid; i < ND; i += 64) { const int32_t d = m.cell_dofs[cell * ND + i]; s_ue[i] = u[d]; s_up[i] = u_prev ? u_prev[d] : 0.0; }
     for (int i = tid; i < 24; i += 64) s_x[i] = m.xyz[3 * (int64_t)m.conn[cell * 8 + i / 3] + i % 3];
     __syncthreads();
     if (tid >= NQ) return;
@@ -785,19 +805,37 @@ k_fiber_stretch(MechMesh m, HOParams mat, const double *__restrict__ act_field, 
         for (int d = 0; d < 3; ++d) f[d] /= nf;
     }
     // F f₀ = f₀ + Σₐ uₐ (∇Nₐ · f₀)
-    double g[3] = {f[0], f[1], f[2]};
+    double g[3] = {f[0], f[1], f[2]}, gp[3] = {f[0], f[1], f[2]};
     for (int a = 0; a < NB; ++a) {
         const double d0 = tb.dN[q][a][0], d1 = tb.dN[q][a][1], d2 = tb.dN[q][a][2];
         double gf = 0.0;
 #pragma unroll
         for (int k = 0; k < 3; ++k) gf += (d0 * ji[k] + d1 * ji[3 + k] + d2 * ji[6 + k]) * f[k];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) g[c] += s_ue[3 * a + c] * gf;
+        for (int c = 0; c < 3; ++c) { g[c] += s_ue[3 * a + c] * gf; gp[c] += s_up[3 * a + c] * gf; }
     }
     double c = act_scale;
     if (act_field) { double s2 = 0.0; for (int a = 0; a < 8; ++a) s2 += tb.M[q][a] * act_field[cell * 8 + a]; c *= s2; }
-    lam[cell * NQ + q] = sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+    const double l = sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+    lam[cell * NQ + q] = l;
     ca[cell * NQ + q] = c;
+    if (u_prev) { // rate-coupled: Ḟ f₀ = (F − F_prev) f₀ / Δt; dλ/dt = ∂λ/∂F : Ḟ = g·ġ/λ; ∂²λ/∂F² : Ḟ = w ⊗ f₀, w = ġ/λ − g (g·ġ)/λ³
+        const double gd[3] = {(g[0] - gp[0]) * inv_dt, (g[1] - gp[1]) * inv_dt, (g[2] - gp[2]) * inv_dt};
+        const double ggd = g[0] * gd[0] + g[1] * gd[1] + g[2] * gd[2];
+        vel[cell * NQ + q] = ggd / l;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) wout[3 * (cell * NQ + q) + d] = gd[d] / l - g[d] * ggd / (l * l * l);
+    }
+}
+
+// (a, b, c) of the local solve and w of stage 0 → the (a, b, c·w) records the element kernels read
+__global__ void __launch_bounds__(256) k_pack_rate_terms(int64_t n, const double *__restrict__ abc, const double *__restrict__ w, double *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double c = abc[3 * i + 2];
+    out[5 * i] = abc[3 * i]; out[5 * i + 1] = abc[3 * i + 1];
+    out[5 * i + 2] = c * w[3 * i]; out[5 * i + 3] = c * w[3 * i + 1]; out[5 * i + 4] = c * w[3 * i + 2];
 }
 
 // stage 0 + stage 1 (the pointwise local solves, tb_sarcomere.hip) ahead of the element kernels
@@ -808,20 +846,29 @@ template <class FE> static int condensed_prepass(tb_form *f, const double *d_u, 
     const int64_t npts = m->n_cells * FE::NQ;
     if (!f->d_Q || !f->d_Qknown) { set_error("condensed internal variable: no internal state set (tb_hyperelastic_set_internal_state)"); return TB_ERR_BAD_ARG; }
     if (!(f->cond_dt > 0.0)) { set_error("condensed internal variable: the time step must be positive (got %g)", f->cond_dt); return TB_ERR_BAD_ARG; }
+    const bool rate = f->d_u_prev != nullptr;
+    // layout: λ | Ca | records (2 or 5 per point; rate-free: at 2·npts) | [rate: velocity | w (3) | (a,b,c) (3)] | status
+    const size_t ndbl = rate ? 14 : 4;
     if (!f->d_qp_buf) {
-        hipError_t e = hipMalloc((void **)&f->d_qp_buf, sizeof(double) * 4 * (size_t)npts + sizeof(int32_t) * (size_t)npts);
+        hipError_t e = hipMalloc((void **)&f->d_qp_buf, sizeof(double) * ndbl * (size_t)npts + sizeof(int32_t) * (size_t)npts);
         if (e != hipSuccess) { set_error("quadrature-point buffers: %s", hipGetErrorString(e)); return TB_ERR_NOMEM; }
         f->d_qp_act = f->d_qp_buf + 2 * npts;
     }
     double *lam = f->d_qp_buf, *ca = f->d_qp_buf + npts;
-    int32_t *status = (int32_t *)(f->d_qp_buf + 4 * npts);
-    const MechMesh mm{m->d_xyz, m->d_conn, m->d_cell_dofs, f->d_field, nullptr, nullptr};
+    double *vel = rate ? f->d_qp_buf + 7 * npts : nullptr, *w = rate ? f->d_qp_buf + 8 * npts : nullptr, *abc = rate ? f->d_qp_buf + 11 * npts : nullptr;
+    int32_t *status = (int32_t *)(f->d_qp_buf + (rate ? 14 : 4) * npts);
+    const MechMesh mm{m->d_xyz, m->d_conn, m->d_cell_dofs, f->d_field, nullptr, nullptr, 2};
     hipLaunchKernelGGL(k_fiber_stretch<FE>, dim3((unsigned)m->n_cells), dim3(64), 0, dev->stream, mm, make_params(f), f->d_act_field, f->act_tension, d_u, lam, ca,
-                       dev->d_status);
+                       f->d_u_prev, 1.0 / f->cond_dt, vel, w, dev->d_status);
     TB_HIP(hipGetLastError());
     int64_t nfail = 0;
-    int rc = launch_sarcomere_implicit(dev, f->cond_params, f->d_Q, f->d_Qknown, npts, lam, ca, 0.0, 0.0, f->cond_dt, f->cond_tol, f->cond_max_iters, f->cond_tmax,
-                                       nullptr, f->d_qp_act, status, &nfail, need_tangent);
+    int rc = launch_sarcomere_implicit(dev, f->cond_params, f->d_Q, f->d_Qknown, npts, lam, vel, ca, 0.0, 0.0, 0.0, f->cond_dt, f->cond_tol, f->cond_max_iters,
+                                       f->cond_tmax, nullptr, nullptr, rate ? abc : f->d_qp_act, rate ? 3 : 2, status, &nfail, need_tangent);
+    if (rc) return rc;
+    if (rate) {
+        hipLaunchKernelGGL(k_pack_rate_terms, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, dev->stream, npts, abc, w, f->d_qp_act);
+        TB_HIP(hipGetLastError());
+    }
     f->cond_n_failed = nfail;
     return rc;
 }
@@ -842,9 +889,10 @@ int launch_hyperelastic(tb_form *f, tb_pattern *p, int strategy, const double *d
         rc = q2 ? condensed_prepass<Q2Vec>(f, d_u, d_nz != nullptr) : condensed_prepass<Q1Vec>(f, d_u, d_nz != nullptr);
         if (rc) return rc;
     }
+    const bool nonsym = f->cond_model && f->d_u_prev; // rate-coupled internal variable: the symmetric-tile matrix-core kernel does not apply
 #define TB_RUN(FEV, K, R, MF) (ad ? run<FEV, K, R, MF, true>(f, p, strategy, d_u, d_nz, d_r) : run<FEV, K, R, MF, false>(f, p, strategy, d_u, d_nz, d_r))
-    if (d_nz && d_r) rc = !q2 ? TB_RUN(Q1Vec, true, true, false) : (mfma || ad) ? TB_RUN(Q2Vec, true, true, true) : run<Q2Vec, true, true, false, false>(f, p, strategy, d_u, d_nz, d_r);
-    else if (d_nz) rc = !q2 ? TB_RUN(Q1Vec, true, false, false) : (mfma || ad) ? TB_RUN(Q2Vec, true, false, true) : run<Q2Vec, true, false, false, false>(f, p, strategy, d_u, d_nz, d_r);
+    if (d_nz && d_r) rc = !q2 ? TB_RUN(Q1Vec, true, true, false) : nonsym ? TB_RUN(Q2Vec, true, true, false) : (mfma || ad) ? TB_RUN(Q2Vec, true, true, true) : run<Q2Vec, true, true, false, false>(f, p, strategy, d_u, d_nz, d_r);
+    else if (d_nz) rc = !q2 ? TB_RUN(Q1Vec, true, false, false) : nonsym ? TB_RUN(Q2Vec, true, false, false) : (mfma || ad) ? TB_RUN(Q2Vec, true, false, true) : run<Q2Vec, true, false, false, false>(f, p, strategy, d_u, d_nz, d_r);
     else rc = q2 ? TB_RUN(Q2Vec, false, true, false) : TB_RUN(Q1Vec, false, true, false);
 #undef TB_RUN
     if (rc) return rc;

@@ -137,14 +137,14 @@ __device__ __forceinline__ bool solve4(double (&A)[4][4], double (&b)[4])
 
 // Jacobian of the local problem at state q, distributed over the 16 lanes of a group: row r of J_RR in registers, column r of
 // ∂rhs_X/∂Q_R (colX), and rhs(q) itself (f, on every lane)
-struct LocalJacobian { double row[16], colX[4], kPN, kNP; };
-__device__ __forceinline__ void local_jacobian(const RDQ20Params &p, const double (&q)[20], double lam, double ca, double dt, double (*tr)[17], int r,
+struct LocalJacobian { double row[16], colX[4], kPN, kNP, vel; };
+__device__ __forceinline__ void local_jacobian(const RDQ20Params &p, const double (&q)[20], double lam, double vel, double ca, double dt, double (*tr)[17], int r,
                                                LocalJacobian &J, double (&f)[20])
 {
     D1 ud[20], dud[20];
 #pragma unroll
     for (int k = 0; k < 20; ++k) ud[k] = {q[k], k == r ? 1.0 : 0.0};
-    rdq20_rhs<D1>(p, ud, D1{lam, 0.0}, 0.0, ca, dud);
+    rdq20_rhs<D1>(p, ud, D1{lam, 0.0}, D1{vel, 0.0}, ca, dud);
 #pragma unroll
     for (int k = 0; k < 20; ++k) f[k] = dud[k].v;
     // transpose: lane c wrote column c (∂rhs_i/∂Q_c for all i); lane r reads row r
@@ -158,6 +158,7 @@ __device__ __forceinline__ void local_jacobian(const RDQ20Params &p, const doubl
     for (int k = 0; k < 4; ++k) J.colX[k] = dud[16 + k].d;
     double perm;
     rdq20_xb_rates<double>(p, q, perm, J.kPN, J.kNP);
+    J.vel = vel;
 }
 
 // J y = g: g given on every lane (20 values), y returned on every lane
@@ -183,8 +184,8 @@ __device__ __forceinline__ bool local_linear_solve(const RDQ20Params &p, const L
         for (int o = 8; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
         bx[k] = g[16 + k] + part;
     }
-    const double rr = p.r0, dP = 1.0 / dt + rr + J.kPN, dN = 1.0 / dt + rr + J.kNP; // smooth_abs(0) = 0: rate-free form
-    double A[4][4] = {{dP, 0, -J.kNP, 0}, {0, dP, 0, -J.kNP}, {-J.kPN, 0, dN, 0}, {0, -J.kPN, 0, dN}};
+    const double rr = p.r0 + p.alpha * smooth_abs(J.vel, p.eps_v), dP = 1.0 / dt + rr + J.kPN, dN = 1.0 / dt + rr + J.kNP;
+    double A[4][4] = {{dP, 0, -J.kNP, 0}, {-J.vel, dP, 0, -J.kNP}, {-J.kPN, 0, dN, 0}, {0, -J.kPN, -J.vel, dN}}; // I/Δt − XB_A (contraction.jl:573-578)
     ok = solve4(A, bx) && ok;
 #pragma unroll
     for (int k = 0; k < 16; ++k) y[k] = xr[k];
@@ -196,8 +197,10 @@ __device__ __forceinline__ bool local_linear_solve(const RDQ20Params &p, const L
 template <bool SENS>
 __global__ void __launch_bounds__(256)
 k_sarcomere_implicit(RDQ20Params p, SarcomereInputs in, double *__restrict__ Qs, const double *__restrict__ Qks, int64_t n, double dt, double tol, int max_iters,
-                     double tmax, double *__restrict__ dQdl, double *__restrict__ act, int32_t *__restrict__ status, unsigned long long *__restrict__ n_failed)
+                     double tmax, double *__restrict__ dQdl, double *__restrict__ dQdv, double *__restrict__ act, int act_stride, int32_t *__restrict__ status,
+                     unsigned long long *__restrict__ n_failed)
 {
+    const bool rate = in.velocity != nullptr || in.s_velocity != 0.0 || act_stride == 3 || dQdv != nullptr;
     __shared__ double s_tr[4][4][16][17];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, grp = lane >> 4, r = lane & 15, base = lane & 48;
     double (*tr)[17] = s_tr[wv][grp];
@@ -214,13 +217,14 @@ k_sarcomere_implicit(RDQ20Params p, SarcomereInputs in, double *__restrict__ Qs,
         for (int k = 0; k < 4; ++k) { q[16 + k] = grp_shfl(qb, base | k); qk[16 + k] = grp_shfl(kb, base | k); }
         const double lam = in.stretch ? in.stretch[ii] : in.s_stretch;
         const double ca = in.calcium ? in.calcium[ii] : in.s_calcium;
+        const double vel = in.velocity ? in.velocity[ii] : in.s_velocity; // dλ/dt of the rate-coupled form; 0 in the rate-free one
         bool active = true;
         int code = LOCAL_SUCCESS;
         for (int it = 1; it <= max_iters; ++it) {
             if (!__any(active)) break;
             double f[20], R[20], y[20];
             LocalJacobian J;
-            local_jacobian(p, q, lam, ca, dt, tr, r, J, f);
+            local_jacobian(p, q, lam, vel, ca, dt, tr, r, J, f);
             double rn = 0.0;
 #pragma unroll
             for (int k = 0; k < 20; ++k) { R[k] = (q[k] - qk[k]) / dt - f[k]; rn += R[k] * R[k]; }
@@ -243,18 +247,18 @@ k_sarcomere_implicit(RDQ20Params p, SarcomereInputs in, double *__restrict__ Qs,
             for (int k = 0; k < 16; ++k) inb = inb && (q[k] >= 0.0);
             if (!inb) code = LOCAL_INFEASIBLE;
         }
-        double ql = 0.0;
+        double ql = 0.0, qv = 0.0;
         if constexpr (SENS) {
             // corrector: dQ/dλ = J⁻¹ ∂rhs/∂λ at the converged state
             D1 ud[20], dud[20];
 #pragma unroll
             for (int k = 0; k < 20; ++k) ud[k] = {q[k], 0.0};
-            rdq20_rhs<D1>(p, ud, D1{lam, 1.0}, 0.0, ca, dud);
+            rdq20_rhs<D1>(p, ud, D1{lam, 1.0}, D1{vel, 0.0}, ca, dud);
             double g[20], y[20], f[20];
 #pragma unroll
             for (int k = 0; k < 20; ++k) g[k] = dud[k].d;
             LocalJacobian J;
-            local_jacobian(p, q, lam, ca, dt, tr, r, J, f);
+            local_jacobian(p, q, lam, vel, ca, dt, tr, r, J, f);
             const bool ok = local_linear_solve(p, J, dt, g, y, base, r);
             if (!ok && code == LOCAL_SUCCESS) code = LOCAL_LINEAR_SOLVE_FAILED;
             if (code != LOCAL_SUCCESS) {
@@ -262,6 +266,24 @@ k_sarcomere_implicit(RDQ20Params p, SarcomereInputs in, double *__restrict__ Qs,
                 for (int k = 0; k < 20; ++k) y[k] = 0.0; // the reference returns a zero sensitivity for a failed point (materials.jl:1596-1597)
             }
             ql = y[17] + y[19];
+            if (rate) { // second corrector dQ/d(dλ/dt) (materials.jl:1715-1720): only the cross-bridge rows of ∂rhs/∂v are non-zero, so y_R = 0
+                D1 vd[20], dvd[20];
+#pragma unroll
+                for (int k = 0; k < 20; ++k) vd[k] = {q[k], 0.0};
+                rdq20_rhs<D1>(p, vd, D1{lam, 0.0}, D1{vel, 1.0}, ca, dvd);
+                double bx[4] = {dvd[16].d, dvd[17].d, dvd[18].d, dvd[19].d};
+                const double rr = p.r0 + p.alpha * smooth_abs(vel, p.eps_v), dP = 1.0 / dt + rr + J.kPN, dN = 1.0 / dt + rr + J.kNP;
+                double A[4][4] = {{dP, 0, -J.kNP, 0}, {-vel, dP, 0, -J.kNP}, {-J.kPN, 0, dN, 0}, {0, -J.kPN, -vel, dN}};
+                const bool ok2 = solve4(A, bx);
+                qv = (ok2 && code == LOCAL_SUCCESS) ? bx[1] + bx[3] : 0.0;
+                if (dQdv && valid && r < 4) {
+                    double mine3 = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) mine3 = (k == r) ? bx[k] : mine3;
+                    dQdv[(int64_t)(16 + r) * n + i] = code == LOCAL_SUCCESS ? mine3 : 0.0;
+                }
+                if (dQdv && valid) dQdv[(int64_t)r * n + i] = 0.0;
+            }
             if (dQdl && valid) {
                 double mine = 0.0, mine2 = 0.0;
 #pragma unroll
@@ -281,10 +303,12 @@ k_sarcomere_implicit(RDQ20Params p, SarcomereInputs in, double *__restrict__ Qs,
             Qs[(int64_t)r * n + i] = mine;
             if (r < 4) Qs[(int64_t)(16 + r) * n + i] = mine2;
             if (r == 0) {
-                if (act) { // P_active = a ∂λ/∂F;  ∂P_active/∂F = a ∂²λ/∂F² + b ∂λ/∂F ⊗ ∂λ/∂F
+                if (act) { // P_active = a ∂λ/∂F;  dP_active/du = a ∂²λ/∂F² + b ∂λ/∂F ⊗ ∂λ/∂F + c ∂λ/∂F ⊗ (∂²λ/∂F² : Ḟ)
                     const double fso = rdq20_overlap(p, lam), qq = q[17] + q[19];
-                    act[2 * i] = tmax * qq * fso;
-                    act[2 * i + 1] = tmax * (qq * rdq20_overlap_slope(p, lam) + ql * fso);
+                    act[act_stride * i] = tmax * qq * fso;
+                    // rate-coupled: ∂P/∂Ḟ ∂Ḟ/∂u = q_v fso Tmax/Δt ∂λ⊗∂λ joins the symmetric coefficient (backward Euler: ∂Ḟ/∂u = 1/Δt)
+                    act[act_stride * i + 1] = tmax * (qq * rdq20_overlap_slope(p, lam) + ql * fso) + (rate ? tmax * qv * fso / dt : 0.0);
+                    if (rate) act[act_stride * i + 2] = tmax * qv * fso;
                 }
                 if (status) status[i] = code;
                 if (code != LOCAL_SUCCESS && n_failed) atomicAdd(n_failed, 1ull);
@@ -294,10 +318,11 @@ k_sarcomere_implicit(RDQ20Params p, SarcomereInputs in, double *__restrict__ Qs,
 }
 
 int launch_sarcomere_implicit(tb_device *dev, const double *params, double *d_Q, const double *d_Qknown, int64_t n, const double *d_stretch,
-                              const double *d_calcium, double stretch, double calcium, double dt, double tol, int max_iters, double tmax,
-                              double *d_dQdl, double *d_act, int32_t *d_status, int64_t *n_failed, int need_sens)
+                              const double *d_velocity, const double *d_calcium, double stretch, double velocity, double calcium, double dt, double tol,
+                              int max_iters, double tmax, double *d_dQdl, double *d_dQdv, double *d_act, int act_stride, int32_t *d_status, int64_t *n_failed,
+                              int need_sens)
 {
-    const SarcomereInputs in{d_stretch, nullptr, d_calcium, stretch, 0.0, calcium};
+    const SarcomereInputs in{d_stretch, d_velocity, d_calcium, stretch, velocity, calcium};
     unsigned long long *cnt = (unsigned long long *)&dev->d_status->cell; // 8-byte scratch inside the status block
     TB_HIP(hipMemsetAsync(cnt, 0, sizeof *cnt, dev->stream));
     int64_t nb = (n + 15) / 16;
@@ -305,9 +330,9 @@ int launch_sarcomere_implicit(tb_device *dev, const double *params, double *d_Q,
     if (nb > cap) nb = cap;
     const RDQ20Params p = rdq20_params(params);
     if (need_sens) hipLaunchKernelGGL(k_sarcomere_implicit<true>, dim3((unsigned)nb), dim3(256), 0, dev->stream, p, in, d_Q, d_Qknown, n, dt, tol, max_iters, tmax,
-                                      d_dQdl, d_act, d_status, cnt);
+                                      d_dQdl, d_dQdv, d_act, act_stride, d_status, cnt);
     else hipLaunchKernelGGL(k_sarcomere_implicit<false>, dim3((unsigned)nb), dim3(256), 0, dev->stream, p, in, d_Q, d_Qknown, n, dt, tol, max_iters, tmax,
-                            d_dQdl, d_act, d_status, cnt);
+                            d_dQdl, d_dQdv, d_act, act_stride, d_status, cnt);
     TB_HIP(hipGetLastError());
     if (n_failed) {
         unsigned long long h = 0;
@@ -318,13 +343,13 @@ int launch_sarcomere_implicit(tb_device *dev, const double *params, double *d_Q,
     return TB_OK;
 }
 
-int host_sarcomere_local_solve(const double *params, double *Q, const double *Qknown, double stretch, double calcium, double dt, double tol, int max_iters,
-                               double *dQdl, int *iters, double *resnorm)
+int host_sarcomere_local_solve(const double *params, double *Q, const double *Qknown, double stretch, double velocity, double calcium, double dt, double tol,
+                               int max_iters, double *dQdl, double *dQdv, int *iters, double *resnorm)
 {
     const RDQ20Params p = rdq20_params(params);
     double q[20], qk[20];
     for (int k = 0; k < 20; ++k) { q[k] = Q[k]; qk[k] = Qknown[k]; }
-    const int code = rdq20_local_solve_host(p, q, qk, stretch, 0.0, calcium, dt, tol, max_iters, dQdl, iters, resnorm);
+    const int code = rdq20_local_solve_host(p, q, qk, stretch, velocity, calcium, dt, tol, max_iters, dQdl, iters, resnorm, dQdv);
     for (int k = 0; k < 20; ++k) Q[k] = q[k];
     return code;
 }

@@ -52,6 +52,8 @@ TB_HD D1 operator*(D1 a, double b) { return {a.v * b, a.d * b}; }
 TB_HD D1 operator*(double a, D1 b) { return {a * b.v, a * b.d}; }
 TB_HD D1 operator/(D1 a, double b) { return {a.v / b, a.d / b}; }
 TB_HD D1 operator/(double a, D1 b) { const double q = a / b.v; return {q, -q * b.d / b.v}; }
+TB_HD D1 sqrt(D1 a) { const double r = ::sqrt(a.v); return {r, 0.5 * a.d / r}; }
+TB_HD D1 smooth_abs(D1 x, double e) { return x * x / sqrt(x * x + e * e); }
 TB_HD double val(double x) { return x; }
 TB_HD double val(D1 x) { return x.v; }
 template <class T> TB_HD T num(double c);
@@ -80,7 +82,7 @@ template <class T> TB_HD void rdq20_xb_rates(const RDQ20Params &p, const T (&u)[
 }
 
 template <class T>
-TB_HD void rdq20_rhs(const RDQ20Params &p, const T (&u)[RDQ20_NSTATES], T lam, double dlam, double Ca, T (&du)[RDQ20_NSTATES])
+TB_HD void rdq20_rhs(const RDQ20Params &p, const T (&u)[RDQ20_NSTATES], T lam, T dlam, double Ca, T (&du)[RDQ20_NSTATES])
 {
 #define RU(a, b, c, d) ((a) + 2 * (b) + 4 * (c) + 8 * (d))
     const T SL = p.SL0 * lam;
@@ -136,7 +138,7 @@ TB_HD void rdq20_rhs(const RDQ20Params &p, const T (&u)[RDQ20_NSTATES], T lam, d
     // cross-bridges (contraction.jl:545-583)
     T perm, k_PN, k_NP;
     rdq20_xb_rates(p, u, perm, k_PN, k_NP);
-    const double r = p.r0 + p.alpha * smooth_abs(dlam, p.eps_v);
+    const T r = p.r0 + p.alpha * smooth_abs(dlam, p.eps_v);
     const T dP = r + k_PN, dN = r + k_NP;
     const T x1 = u[16], x2 = u[17], x3 = u[18], x4 = u[19];
     du[16] = -dP * x1 + k_NP * x3 + p.mu0_fP * perm;
@@ -197,13 +199,13 @@ inline void rdq20_local_jacobian(const RDQ20Params &p, const double (&Q)[20], do
     for (int c = 0; c < 20; ++c) {
         D1 u[20], du[20];
         for (int k = 0; k < 20; ++k) u[k] = {Q[k], k == c ? 1.0 : 0.0};
-        rdq20_rhs<D1>(p, u, D1{lam, 0.0}, dlam, Ca, du);
+        rdq20_rhs<D1>(p, u, D1{lam, 0.0}, D1{dlam, 0.0}, Ca, du);
         for (int k = 0; k < 20; ++k) { J[k][c] = (k == c ? 1.0 / dt : 0.0) - du[k].d; rhs[k] = du[k].v; }
     }
 }
 // Q: initial guess in, solution out.  dQdl: dQ/dλ at the solution (may be nullptr).  Returns the status code.
 inline int rdq20_local_solve_host(const RDQ20Params &p, double (&Q)[20], const double (&Qk)[20], double lam, double dlam, double Ca, double dt, double tol,
-                                  int max_iters, double *dQdl, int *iters, double *resnorm)
+                                  int max_iters, double *dQdl, int *iters, double *resnorm, double *dQdv = nullptr)
 {
     double J[20][20], f[20], R[20];
     double rn = 0.0;
@@ -226,11 +228,18 @@ inline int rdq20_local_solve_host(const RDQ20Params &p, double (&Q)[20], const d
         rdq20_local_jacobian(p, Q, lam, dlam, Ca, dt, J, f);
         D1 u[20], du[20];
         for (int k = 0; k < 20; ++k) u[k] = {Q[k], 0.0};
-        rdq20_rhs<D1>(p, u, D1{lam, 1.0}, dlam, Ca, du);
+        rdq20_rhs<D1>(p, u, D1{lam, 1.0}, D1{dlam, 0.0}, Ca, du);
         double g[20];
         for (int k = 0; k < 20; ++k) g[k] = du[k].d;
         if (!dense_solve20(J, g)) return LOCAL_LINEAR_SOLVE_FAILED;
         for (int k = 0; k < 20; ++k) dQdl[k] = g[k];
+        if (dQdv) { // second corrector of the rate-coupled form: dQ/d(dλ/dt) (materials.jl:1715-1720)
+            rdq20_local_jacobian(p, Q, lam, dlam, Ca, dt, J, f);
+            rdq20_rhs<D1>(p, u, D1{lam, 0.0}, D1{dlam, 1.0}, Ca, du);
+            for (int k = 0; k < 20; ++k) g[k] = du[k].d;
+            if (!dense_solve20(J, g)) return LOCAL_LINEAR_SOLVE_FAILED;
+            for (int k = 0; k < 20; ++k) dQdv[k] = g[k];
+        }
     }
     return LOCAL_SUCCESS;
 }
