@@ -12,6 +12,9 @@ ap.add_argument("--n", type=int, default=12)
 ap.add_argument("--order", type=int, default=2)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--tmax", type=float, default=0.5, help="peak active tension")
+ap.add_argument("--sarcomere", default="steady", choices=["steady", "rdq20", "rdq20-rate"],
+                help="steady: Ta = Tmax·Ca(t); rdq20: RDQ20-MF internal state condensed per quadrature point (AsRateIndependent); rdq20-rate: rate-coupled")
+ap.add_argument("--dt", type=float, default=2.0, help="time step of the internal variables [ms] (rdq20 variants)")
 args = ap.parse_args()
 import thunderbolt_jl_amd as tb
 dev = tb.MI355XDevice(0)
@@ -23,6 +26,14 @@ calcium = lambda t: np.sin(0.5 * np.pi * min(t, 1.0)) ** 2                      
 fsn = tb.ConstantCoefficient(tb.OrthotropicMicrostructure([1, 0, 0], [0, 1, 0], [0, 0, 1]))
 material = tb.ActiveStressModel(tb.HolzapfelOgden2009Model(), tb.SimpleActiveStress(Tmax=args.tmax),
                                 tb.CaDrivenInternalSarcomereModel(tb.PelceSunLangeveld1995Model(), calcium), fsn)
+if args.sarcomere != "steady":
+    # calcium transient of the reference's sarcomere test (test/test_sarcomere.jl:25-35), time in ms; Tmax scales the cross-bridge tension
+    c0, cmax, tau1, tau2, tstart = 0.1, 0.9, 20.0, 50.0, 10.0
+    beta = (tau1 / tau2) ** (-1 / (tau1 / tau2 - 1)) - (tau1 / tau2) ** (-1 / (1 - tau2 / tau1))
+    calcium = lambda t: c0 if t < tstart else c0 + (cmax - c0) / beta * (np.exp(-(t - tstart) / tau1) - np.exp(-(t - tstart) / tau2))   # noqa: E731
+    sm = tb.RDQ20MFModel()
+    material = tb.ActiveStressModel(tb.HolzapfelOgden2009Model(), tb.SimpleActiveStress(Tmax=args.tmax),
+                                    tb.CaDrivenInternalSarcomereModel(sm if args.sarcomere == "rdq20-rate" else tb.AsRateIndependent(sm), calcium), fsn)
 model = tb.QuasiStaticModel("u", material, [tb.RobinBC(0.05, "right")])
 t0 = time.perf_counter()
 op = tb.setup_operator(tb.ElementAssemblyStrategy(dev), model, dh, sp)
@@ -40,13 +51,20 @@ ch = tb.ConstraintHandler(dh, np.flatnonzero(X[:, 0] < 1e-12))
 u = dev.zeros(dh.ndofs)
 dev.synchronize()
 t_setup = time.perf_counter() - t0
-solver = tb.NewtonRaphsonSolver(max_iter=25, tol=1e-8, inner_rtol=1e-10)
+solver = tb.NewtonRaphsonSolver(max_iter=25, tol=1e-8, inner_rtol=1e-10, inner_solver="gmres" if args.sarcomere == "rdq20-rate" else "cg")
 hist = []
 t0 = time.perf_counter()
 for s in range(1, args.steps + 1):
-    t = s / args.steps
-    ok = tb.nlsolve(u, op, ch, solver, t=t)
-    hist.append({"t": t, "Ta": args.tmax * calcium(t), "newton_iters": solver.iter, "cg_iters": int(sum(solver.linear_iters)), "residual": solver.residual_norms[-1], "ok": bool(ok)})
+    if args.sarcomere == "steady":
+        t = s / args.steps
+        ok = tb.nlsolve(u, op, ch, solver, t=t)
+        hist.append({"t": t, "Ta": args.tmax * calcium(t), "newton_iters": solver.iter, "cg_iters": int(sum(solver.linear_iters)), "residual": solver.residual_norms[-1], "ok": bool(ok)})
+    else:   # backward Euler on the internal states, multi-level Newton (local problems re-solved inside every assembly)
+        t = (s - 1) * args.dt
+        ok = tb.perform_mechanics_step(u, op, ch, solver, t, args.dt)
+        Q = op.internal.to_host()
+        hist.append({"t": t + args.dt, "Ca": float(calcium(t + args.dt)), "newton_iters": solver.iter, "linear_iters": int(sum(solver.linear_iters)),
+                     "residual": solver.residual_norms[-1], "mean_xb_force_state": float((Q[17] + Q[19]).mean()), "ok": bool(ok)})
     if not ok:
         break
 dev.synchronize()
@@ -55,6 +73,6 @@ uh = u.to_host()
 xdofs = np.zeros(dh.ndofs, dtype=bool)
 xdofs[dh.cell_dofs[:, 0::3].ravel()] = True                                       # x-components
 ux_right = uh[xdofs & (X[:, 0] > 1 - 1e-12)]
-print(json.dumps({"workload": "contracting block, HO2009 + active stress, Q%d, %d^3 cells, %d dofs" % (args.order, n, dh.ndofs),
+print(json.dumps({"workload": "contracting block, HO2009 + active stress (%s), Q%d, %d^3 cells, %d dofs" % (args.sarcomere, args.order, n, dh.ndofs),
                   "setup_s": t_setup, "solve_s": elapsed, "steps": hist, "mean_shortening_x": float(-ux_right.mean()),
                   "all_converged": all(h["ok"] for h in hist)}))

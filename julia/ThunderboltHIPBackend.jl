@@ -163,5 +163,66 @@ function reaction_tangent(dev::MI355XDevice, dumat_phi::Ptr{Float64}, npoints::I
 end
 # … or fused into the step itself (no dumat needed): tb_reaction_step_rtc(..., rmax::Ref{Float64})
 
+
+# ---------------------------------------------------------------- quasi-static mechanics (src/solver/nonlinear/newton_raphson.jl:234-238)
+struct TbMaterial
+    kind::Int32; penalty::Int32; p::NTuple{16, Float64}
+    f::NTuple{3, Float64}; s::NTuple{3, Float64}; n::NTuple{3, Float64}
+    fsn_field::Ptr{Float64}; fsn_field_len::Int64
+end
+struct TbHill
+    framework::Int32; active_energy::Int32; active_penalty::Int32; adg_kind::Int32; sarcomere_kind::Int32
+    active_p::NTuple{12, Float64}; sheetlet_part::Float64; sarcomere_p::NTuple{2, Float64}
+end
+energy_id(::HolzapfelOgden2009Model) = Int32(0); energy_id(::Thunderbolt.NullEnergyModel) = Int32(1)
+energy_id(::Thunderbolt.BioNeoHookean) = Int32(2); energy_id(::Thunderbolt.TransverseIsotopicNeoHookeanModel) = Int32(3)
+energy_id(::Thunderbolt.LinYinPassiveModel) = Int32(4); energy_id(::Thunderbolt.LinYinActiveModel) = Int32(5)
+energy_id(::Thunderbolt.HumphreyStrumpfYinModel) = Int32(6); energy_id(::Thunderbolt.LinearSpringModel) = Int32(7)
+energy_id(::Thunderbolt.Guccione1991PassiveModel) = Int32(8)
+penalty_id(::Thunderbolt.SimpleCompressionPenalty) = Int32(0); penalty_id(::Thunderbolt.NullCompressionPenalty) = Int32(1)
+penalty_id(::Thunderbolt.HartmannNeffCompressionPenalty1) = Int32(2); penalty_id(::Thunderbolt.HartmannNeffCompressionPenalty2) = Int32(3)
+penalty_id(::Thunderbolt.HartmannNeffCompressionPenalty3) = Int32(4)
+# energy parameters = the struct fields before mpU, penalty parameters (β, a, b) in p[11:13]; constant frame or nodal f/s/n field
+
+mutable struct HIPNonlinearOperator{Tv}
+    form::Ptr{Cvoid}; facet_forms::Vector{Ptr{Cvoid}}; pattern::Ptr{Cvoid}; strategy::Cint
+    J::HIPVector{Tv}
+    Q::Union{Nothing, HIPVector{Tv}}; Qknown::Union{Nothing, HIPVector{Tv}}     # condensed internal variables, n_states × (n_cells·n_qp)
+end
+# setup: tb_hyperelastic_create(mesh, 0, Ref(material), form); per weak boundary condition tb_facet_form_create(…);
+#   GeneralizedHillModel / ExtendedHillModel          → tb_hyperelastic_set_hill(form, Ref(TbHill(…)))
+#   PrestressedMechanicalModel(inner, ConstantCoeff.) → tb_hyperelastic_set_prestress(form, vec(Matrix(F₀⁻¹)'))
+#   Dict(cellset => QuasiStaticModel)                  → one form each: tb_form_set_cellset(form, cells, n, 1); tb_form_set_accumulate(form, k > 1)
+#   internal sarcomere model (RDQ20MFModel)            → tb_hyperelastic_set_condensation(form, 2, params, 17, Tmax, tol, max_iters)
+function Thunderbolt.update_linearization!(op::HIPNonlinearOperator, residual::HIPVector, u::HIPVector, p)
+    t = p isa Real ? p : p.t
+    if p isa Thunderbolt.FerriteOperators.GenericFirstOrderTimeParameters && op.Q !== nothing
+        # GenericFirstOrderTimeParameters(p, t, Δt, uprev) (euler.jl:490-493): Δt and the known state of the local problems; the
+        # rate-coupled model additionally reads uprev: tb_hyperelastic_set_previous_solution(op.form, p.uprev.ptr)
+        check(ccall((:tb_hyperelastic_set_internal_state, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Float64),
+            op.form, op.Q.ptr, op.Qknown.ptr, p.Δt))
+    end
+    check(ccall((:tb_linearize, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Float64}, Float64, Ptr{Float64}, Ptr{Float64}),
+        op.form, op.pattern, op.strategy, u.ptr, t, op.J.ptr, residual.ptr))
+    for h in op.facet_forms
+        check(ccall((:tb_facet_assemble, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Float64, Ptr{Float64}, Ptr{Float64}),
+            h, op.pattern, u.ptr, t, op.J.ptr, residual.ptr))
+    end
+end
+function Thunderbolt.residual!(op::HIPNonlinearOperator, residual::HIPVector, u::HIPVector, p)
+    t = p isa Real ? p : p.t
+    check(ccall((:tb_residual, libtbhip), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Float64, Ptr{Float64}), op.form, op.strategy, u.ptr, t, residual.ptr))
+    for h in op.facet_forms
+        check(ccall((:tb_facet_assemble, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Float64, Ptr{Float64}, Ptr{Float64}),
+            h, C_NULL, u.ptr, t, C_NULL, residual.ptr))
+    end
+end
+# check_local_solve_convergence → tb_hyperelastic_local_solve_report(form, n_failed, C_NULL, 0); Newton's linear solve:
+# tb_cg_solve (SPD tangents) or tb_gmres_solve (the reference's default KrylovJL_GMRES; required for the rate-coupled model);
+# apply_zero!(J, r, ch) → tb_apply_zero_csr; norm(r[free]) → tb_dot.
+
+# sarcomere_rhs! under a pointwise explicit step (StandaloneSarcomereModel): tb_sarcomere_step; the local problem alone:
+# tb_sarcomere_implicit_step
+
 # heat-step algebra (src/solver/time/euler.jl:85,90,110-116): tb_heat_matrix, tb_spmv_csr, tb_axpy
 end # module
