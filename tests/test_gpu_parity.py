@@ -1147,6 +1147,47 @@ def test_rate_coupled_condensed_sarcomere_parity(tb, oracle, device, order, nel,
         oracle.set_condensation(); oracle.set_active_tension(0.0); oracle.set_material()
 
 
+@pytest.mark.parametrize("variant", ["front_rate_coupled", "back_rate_free"])
+def test_reference_contracting_cuboid_multiple_subdomains(tb, device, variant):
+    """test/integration/test_solid_mechanics.jl:367-445 ("Multiple subdomains"): cellsets "front" (x ≤ 0.1) and "back" (x ≥ 0.1) of the
+    10×10×2 cuboid; an ActiveStressModel(Guccione1991PassiveModel, SimpleActiveStress(Tmax = 220e3), CaDrivenInternalSarcomereModel(
+    RDQ20MFModel — unwrapped on "front" in the first run, AsRateIndependent on "back" in the second —, calcium hat)) beside a passive
+    PK1Model(Guccione1991PassiveModel) subdomain; BackwardEulerSolver with the multi-level Newton, tspan (0, 2), Δt = 0.25.  Like the
+    reference: every step succeeds and u moved; the internal states of the passive subdomain's points are never touched."""
+    g = tb.generate_mesh(tb.Hexahedron, (10, 10, 2), (0.0, 0.0, 0.0), (1.0, 1.0, 0.2))
+    g.addcellset("front", lambda x: x[0] <= 0.1 + 1e-12)
+    g.addcellset("back", lambda x: x[0] >= 0.1 - 1e-12)
+    assert len(g.getcellset("front")) == 20 and len(g.getcellset("back")) == 180
+    dh = tb.DofHandler(g, tb.LagrangeCollection(1) ** 3)
+    sp = tb.allocate_matrix(dh)
+    ms = tb.ConstantCoefficient(tb.OrthotropicMicrostructure([1.0, 0, 0], [0, 1.0, 0], [0, 0, 1.0]))
+    hat = lambda t: 2.0 * t / 1000.0 if t / 1000.0 < 0.5 else 2.0 - 2.0 * t / 1000.0
+    facemodels = (tb.NormalSpringBC(0.0, "right"), tb.ConstantPressureBC(0.0, "back"), tb.PressureFieldBC(tb.ConstantCoefficient(0.0), "top"))
+    sm = tb.RDQ20MFModel() if variant == "front_rate_coupled" else tb.AsRateIndependent(tb.RDQ20MFModel())
+    active = tb.QuasiStaticModel("d", tb.ActiveStressModel(tb.Guccione1991PassiveModel(), tb.SimpleActiveStress(Tmax=220e3),
+                                                          tb.CaDrivenInternalSarcomereModel(sm, hat), ms), facemodels)
+    passive = tb.QuasiStaticModel("d", tb.PK1Model(tb.Guccione1991PassiveModel(), ms), facemodels)
+    models = {"front": active, "back": passive} if variant == "front_rate_coupled" else {"front": passive, "back": active}
+    act_cells = g.getcellset("front" if variant == "front_rate_coupled" else "back")
+    op = tb.setup_operator(tb.PerColorAssemblyStrategy(device), models, dh, sp)
+    node_dof0 = np.empty(g.n_nodes, dtype=np.int64)
+    node_dof0[g.conn.ravel()] = dh.cell_dofs[:, 0::3].ravel()
+    X = g.xyz
+    fixed = np.concatenate([node_dof0[X[:, 0] < 1e-12], node_dof0[X[:, 1] < 1e-12] + 1, node_dof0[X[:, 2] < 1e-12] + 2, node_dof0[0] + np.arange(3)])
+    ch = tb.ConstraintHandler(dh, fixed)
+    u = device.zeros(dh.ndofs)
+    solver = tb.NewtonRaphsonSolver(max_iter=10, tol=1e-10, inner_rtol=1e-12, inner_solver="gmres", gmres_restart=100)
+    t, dt = 0.0, 0.25
+    for step in range(8):
+        assert tb.perform_mechanics_step(u, op, ch, solver, t, dt), (variant, step, solver.residual_norms)
+        t += dt
+    assert np.abs(u.to_host()).max() > 0.0
+    Q = op.internal.to_host().reshape(20, g.n_cells, 8)
+    inside = np.zeros(g.n_cells, dtype=bool); inside[act_cells] = True
+    assert Q[16:, inside].max() > 0.0 and np.abs(Q[:16, inside].sum(axis=0) - 1.0).max() < 1e-10
+    assert np.abs(Q[16:, ~inside]).max() == 0.0 and (Q[0, ~inside] == 1.0).all()      # default initial state, untouched
+
+
 # ------------------------------------------------------------------------------------------- the reference's own GPU tests
 def quad_problem(tb, oracle, nel, left, right):
     g = tb.generate_mesh(tb.Quadrilateral, nel, left, right)

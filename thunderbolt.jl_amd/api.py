@@ -1234,8 +1234,9 @@ class NonlinearOperator:
             # condensed internal variable (QuasiStaticCondensedElementCache): states per quadrature point on the device
             sm = cm.internal_model() if isinstance(cm, ActiveStressModel) else None
             if sm is not None:
-                if len(domains) > 1:
-                    raise NotImplementedError("condensed internal variables on a subdomain are not supported")
+                if self.internal is not None:
+                    raise NotImplementedError("one subdomain with condensed internal variables per operator")
+                self.internal_form = form
                 ls = local_solver or GenericLocalNonlinearSolver()
                 pp = sm.params()
                 check(lib().tb_hyperelastic_set_condensation(form, sm.sid, pp.ctypes.data_as(L.c_dp), len(pp), cm.active_stress_model.Tmax, ls.tol, ls.max_iters))
@@ -1274,7 +1275,7 @@ class NonlinearOperator:
 def set_timestep(op, dt):
     """Δt of the internal variable's backward Euler step (GenericFirstOrderTimeParameters.Δt, euler.jl:490-493)."""
     op.dt = float(dt)
-    check(lib().tb_hyperelastic_set_internal_state(op.form, op.internal.u.ptr, op.internal_known.u.ptr, op.dt))
+    check(lib().tb_hyperelastic_set_internal_state(op.internal_form, op.internal.u.ptr, op.internal_known.u.ptr, op.dt))
 
 
 def accept_internal_state(op):
@@ -1290,7 +1291,7 @@ def reject_internal_state(op):
 def local_solve_failures(op):
     """number of quadrature points whose local solve failed in the last assembly (check_local_solve_convergence)"""
     nf = C.c_int64()
-    check(lib().tb_hyperelastic_local_solve_report(op.form, C.byref(nf), None, 0))
+    check(lib().tb_hyperelastic_local_solve_report(op.internal_form, C.byref(nf), None, 0))
     return nf.value
 
 

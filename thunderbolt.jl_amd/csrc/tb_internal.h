@@ -216,7 +216,7 @@ int launch_sarcomere(tb_device *dev, const double *params, double *d_state, int6
 int launch_sarcomere_implicit(tb_device *dev, const double *params, double *d_Q, const double *d_Qknown, int64_t n, const double *d_stretch,
                               const double *d_velocity, const double *d_calcium, double stretch, double velocity, double calcium, double dt, double tol,
                               int max_iters, double tmax, double *d_dQdl, double *d_dQdv, double *d_act, int act_stride, int32_t *d_status, int64_t *n_failed,
-                              int need_sens);
+                              int need_sens, const int32_t *d_cells = nullptr, int nq = 1, int64_t n_cells_listed = 0);
 int host_sarcomere_local_solve(const double *params, double *Q, const double *Qknown, double stretch, double velocity, double calcium, double dt, double tol,
                                int max_iters, double *dQdl, double *dQdv, int *iters, double *resnorm);
 void host_sarcomere_eval(const double *params, const double *u, double stretch, double velocity, double calcium, double *du, double *tension,

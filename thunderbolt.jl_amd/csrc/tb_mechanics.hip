@@ -771,11 +771,12 @@ static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, doubl
 template <class FE>
 __global__ void __launch_bounds__(64)
 k_fiber_stretch(MechMesh m, HOParams mat, const double *__restrict__ act_field, double act_scale, const double *__restrict__ u, double *__restrict__ lam,
-                double *__restrict__ ca, const double *__restrict__ u_prev, double inv_dt, double *__restrict__ vel, double *__restrict__ wout, Status *st)
+                double *__restrict__ ca, const double *__restrict__ u_prev, double inv_dt, double *__restrict__ vel, double *__restrict__ wout, Status *st,
+                const int32_t *__restrict__ list)
 {
     constexpr int NB = FE::NB, NQ = FE::NQ, ND = FE::ND;
     const MechTables<FE> &tb = g_mech_tables<FE>;
-    const int64_t cell = blockIdx.x;
+    const int64_t cell = list ? list[blockIdx.x] : blockIdx.x;
     const int tid = threadIdx.x;
     __shared__ double s_ue[ND], s_x[24], s_up[ND];
     for (int i = tid; i < ND; i += 64) { const int32_t d = m.cell_dofs[cell * ND + i]; s_ue[i] = u[d]; s_up[i] = u_prev ? u_prev[d] : 0.0; }
@@ -853,17 +854,21 @@ template <class FE> static int condensed_prepass(tb_form *f, const double *d_u, 
         hipError_t e = hipMalloc((void **)&f->d_qp_buf, sizeof(double) * ndbl * (size_t)npts + sizeof(int32_t) * (size_t)npts);
         if (e != hipSuccess) { set_error("quadrature-point buffers: %s", hipGetErrorString(e)); return TB_ERR_NOMEM; }
         f->d_qp_act = f->d_qp_buf + 2 * npts;
+        TB_HIP(hipMemsetAsync(f->d_qp_buf, 0, sizeof(double) * ndbl * (size_t)npts + sizeof(int32_t) * (size_t)npts, dev->stream)); // points outside a subdomain stay zero / TB_LOCAL_SUCCESS
     }
     double *lam = f->d_qp_buf, *ca = f->d_qp_buf + npts;
     double *vel = rate ? f->d_qp_buf + 7 * npts : nullptr, *w = rate ? f->d_qp_buf + 8 * npts : nullptr, *abc = rate ? f->d_qp_buf + 11 * npts : nullptr;
     int32_t *status = (int32_t *)(f->d_qp_buf + (rate ? 14 : 4) * npts);
     const MechMesh mm{m->d_xyz, m->d_conn, m->d_cell_dofs, f->d_field, nullptr, nullptr, 2};
-    hipLaunchKernelGGL(k_fiber_stretch<FE>, dim3((unsigned)m->n_cells), dim3(64), 0, dev->stream, mm, make_params(f), f->d_act_field, f->act_tension, d_u, lam, ca,
-                       f->d_u_prev, 1.0 / f->cond_dt, vel, w, dev->d_status);
+    const int64_t ncell_work = f->has_cellset ? f->n_set : m->n_cells;
+    if (ncell_work == 0) { f->cond_n_failed = 0; return TB_OK; }
+    hipLaunchKernelGGL(k_fiber_stretch<FE>, dim3((unsigned)ncell_work), dim3(64), 0, dev->stream, mm, make_params(f), f->d_act_field, f->act_tension, d_u, lam, ca,
+                       f->d_u_prev, 1.0 / f->cond_dt, vel, w, dev->d_status, f->has_cellset ? f->d_cellset : nullptr);
     TB_HIP(hipGetLastError());
     int64_t nfail = 0;
     int rc = launch_sarcomere_implicit(dev, f->cond_params, f->d_Q, f->d_Qknown, npts, lam, vel, ca, 0.0, 0.0, 0.0, f->cond_dt, f->cond_tol, f->cond_max_iters,
-                                       f->cond_tmax, nullptr, nullptr, rate ? abc : f->d_qp_act, rate ? 3 : 2, status, &nfail, need_tangent);
+                                       f->cond_tmax, nullptr, nullptr, rate ? abc : f->d_qp_act, rate ? 3 : 2, status, &nfail, need_tangent,
+                                       f->has_cellset ? f->d_cellset : nullptr, FE::NQ, f->n_set);
     if (rc) return rc;
     if (rate) {
         hipLaunchKernelGGL(k_pack_rate_terms, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, dev->stream, npts, abc, w, f->d_qp_act);
@@ -884,7 +889,6 @@ int launch_hyperelastic(tb_form *f, tb_pattern *p, int strategy, const double *d
     // Q2 tangents run their contraction on the matrix cores; TB_MECH_MFMA=0 selects the vector-FMA build (comparison)
     static const bool mfma = !(getenv("TB_MECH_MFMA") && atoi(getenv("TB_MECH_MFMA")) == 0);
     const bool ad = !form_is_fast_path(f);
-    if (f->cond_model && f->has_cellset) { set_error("condensed internal variables on a subdomain form are not supported"); return TB_ERR_UNSUPPORTED; }
     if (f->cond_model) {
         rc = q2 ? condensed_prepass<Q2Vec>(f, d_u, d_nz != nullptr) : condensed_prepass<Q1Vec>(f, d_u, d_nz != nullptr);
         if (rc) return rc;

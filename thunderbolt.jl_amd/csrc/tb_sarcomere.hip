@@ -198,16 +198,19 @@ template <bool SENS>
 __global__ void __launch_bounds__(256)
 k_sarcomere_implicit(RDQ20Params p, SarcomereInputs in, double *__restrict__ Qs, const double *__restrict__ Qks, int64_t n, double dt, double tol, int max_iters,
                      double tmax, double *__restrict__ dQdl, double *__restrict__ dQdv, double *__restrict__ act, int act_stride, int32_t *__restrict__ status,
-                     unsigned long long *__restrict__ n_failed)
+                     unsigned long long *__restrict__ n_failed, const int32_t *__restrict__ cells, int nq, int64_t n_work)
 {
     const bool rate = in.velocity != nullptr || in.s_velocity != 0.0 || act_stride == 3 || dQdv != nullptr;
     __shared__ double s_tr[4][4][16][17];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, grp = lane >> 4, r = lane & 15, base = lane & 48;
     double (*tr)[17] = s_tr[wv][grp];
-    for (int64_t w0 = ((int64_t)blockIdx.x * 4 + wv) * 4; w0 < n; w0 += (int64_t)gridDim.x * 16) {
-        const int64_t i = w0 + grp;
-        const bool valid = i < n;
-        const int64_t ii = valid ? i : n - 1;
+    // n: points the state arrays are laid out for (stride); n_work: points solved — all of them, or the quadrature points of `cells` (subdomain)
+    for (int64_t w0 = ((int64_t)blockIdx.x * 4 + wv) * 4; w0 < n_work; w0 += (int64_t)gridDim.x * 16) {
+        const int64_t wi = w0 + grp;
+        const bool valid = wi < n_work;
+        const int64_t wc = valid ? wi : n_work - 1;
+        const int64_t i = cells ? (int64_t)cells[wc / nq] * nq + wc % nq : wc;
+        const int64_t ii = i;
         const double qa = Qs[(int64_t)r * n + ii], qb = r < 4 ? Qs[(int64_t)(16 + r) * n + ii] : 0.0;
         const double ka = Qks[(int64_t)r * n + ii], kb = r < 4 ? Qks[(int64_t)(16 + r) * n + ii] : 0.0;
         double q[20], qk[20];
@@ -320,19 +323,21 @@ k_sarcomere_implicit(RDQ20Params p, SarcomereInputs in, double *__restrict__ Qs,
 int launch_sarcomere_implicit(tb_device *dev, const double *params, double *d_Q, const double *d_Qknown, int64_t n, const double *d_stretch,
                               const double *d_velocity, const double *d_calcium, double stretch, double velocity, double calcium, double dt, double tol,
                               int max_iters, double tmax, double *d_dQdl, double *d_dQdv, double *d_act, int act_stride, int32_t *d_status, int64_t *n_failed,
-                              int need_sens)
+                              int need_sens, const int32_t *d_cells, int nq, int64_t n_cells_listed)
 {
     const SarcomereInputs in{d_stretch, d_velocity, d_calcium, stretch, velocity, calcium};
+    const int64_t n_work = d_cells ? n_cells_listed * nq : n;
+    if (n_work == 0) { if (n_failed) *n_failed = 0; return TB_OK; }
     unsigned long long *cnt = (unsigned long long *)&dev->d_status->cell; // 8-byte scratch inside the status block
     TB_HIP(hipMemsetAsync(cnt, 0, sizeof *cnt, dev->stream));
-    int64_t nb = (n + 15) / 16;
+    int64_t nb = (n_work + 15) / 16;
     const int64_t cap = (int64_t)dev->n_cu * 8;
     if (nb > cap) nb = cap;
     const RDQ20Params p = rdq20_params(params);
     if (need_sens) hipLaunchKernelGGL(k_sarcomere_implicit<true>, dim3((unsigned)nb), dim3(256), 0, dev->stream, p, in, d_Q, d_Qknown, n, dt, tol, max_iters, tmax,
-                                      d_dQdl, d_dQdv, d_act, act_stride, d_status, cnt);
+                                      d_dQdl, d_dQdv, d_act, act_stride, d_status, cnt, d_cells, nq, n_work);
     else hipLaunchKernelGGL(k_sarcomere_implicit<false>, dim3((unsigned)nb), dim3(256), 0, dev->stream, p, in, d_Q, d_Qknown, n, dt, tol, max_iters, tmax,
-                            d_dQdl, d_dQdv, d_act, act_stride, d_status, cnt);
+                            d_dQdl, d_dQdv, d_act, act_stride, d_status, cnt, d_cells, nq, n_work);
     TB_HIP(hipGetLastError());
     if (n_failed) {
         unsigned long long h = 0;
