@@ -1,0 +1,124 @@
+"""Idealised cardiac geometries (ring, open ring, hexahedral left ventricle): the checks of test/test_mesh.jl:68-95,151-156 — positive
+Jacobians at the quadrature points, centre of mass of the ring — plus facet-set consistency (every named boundary facet is a real
+boundary facet with an outward normal of the expected kind) and the volume of the ring."""
+import numpy as np
+import pytest
+
+SGN = np.array([[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, -1, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1]], dtype=float)
+# Ferrite.reference_facets(RefHexahedron), 0-based vertex ids
+FACETS = [(0, 3, 2, 1), (0, 1, 5, 4), (1, 2, 6, 5), (2, 3, 7, 6), (0, 4, 7, 3), (4, 5, 6, 7)]
+
+
+def detj_and_volume(g):
+    gp = SGN / np.sqrt(3)
+    X = g.xyz[g.conn]
+    dets = []
+    for xi in gp:
+        dN = np.stack([0.125 * SGN[:, d] * np.prod(np.delete(1 + SGN * xi, d, axis=1), axis=1) for d in range(3)], axis=1)
+        dets.append(np.linalg.det(np.einsum("cai,ad->cid", X, dN)))
+    dets = np.array(dets)
+    return dets, dets.sum()
+
+
+def boundary_facet_keys(g):
+    from collections import Counter
+    cnt = Counter()
+    for c in range(g.n_cells):
+        for lf, f in enumerate(FACETS):
+            cnt[tuple(sorted(g.conn[c, list(f)]))] += 1
+    return {k for k, v in cnt.items() if v == 1}
+
+
+def facet_normals(g, fs):
+    """outward normal (area-weighted) and centroid of every facet of a set"""
+    out = []
+    for c, lf in fs:
+        P = g.xyz[g.conn[c, list(FACETS[lf])]]
+        nrm = 0.5 * np.cross(P[2] - P[0], P[3] - P[1])
+        out.append((nrm, P.mean(axis=0), g.xyz[g.conn[c]].mean(axis=0)))
+    return out
+
+
+@pytest.mark.parametrize("make", ["ring", "open_ring", "lv_hex", "lv_hex_fine", "ring_tilted"])
+def test_generated_meshes_are_valid(tb, make):
+    g = {"ring": lambda: tb.generate_ring_mesh(8, 3, 3), "open_ring": lambda: tb.generate_open_ring_mesh(8, 3, 3, np.pi / 4),
+         "lv_hex": lambda: tb.generate_ideal_lv_mesh_hex(8, 4, 4), "lv_hex_fine": lambda: tb.generate_ideal_lv_mesh_hex(16, 3, 6),
+         "ring_tilted": lambda: tb.generate_ring_mesh(12, 2, 4, apicobasal_tilt=0.1)}[make]()
+    dets, vol = detj_and_volume(g)
+    assert dets.min() > 0.0                                                     # test_detJ
+    assert len(np.unique(g.conn)) == g.n_nodes                                  # no orphan nodes
+    bnd = boundary_facet_keys(g)
+    named = set()
+    for name, fs in g.facetsets.items():
+        internal = name in ("RotationalSeam", "SRidgePost", "SRidgeAnt")
+        for (c, lf), (nrm, fc, cc) in zip(fs, facet_normals(g, fs)):
+            key = tuple(sorted(g.conn[c, list(FACETS[lf])]))
+            assert (key in bnd) != internal, (name, c, lf)
+            assert np.dot(nrm, fc - cc) > 0                                      # Ferrite's facet orientation points out of the cell
+            if not internal:
+                named.add(key)
+            if name == "Endocardium" and make.startswith("ring"):
+                assert np.dot(nrm[:2], fc[:2]) < 0                              # faces the cavity
+            if name == "Epicardium" and make.startswith("ring"):
+                assert np.dot(nrm[:2], fc[:2]) > 0
+    assert named == bnd                                                         # the named sets cover the whole boundary exactly
+    for name, nodes in g.nodesets.items():
+        assert all(0 <= n < g.n_nodes for n in nodes)
+
+
+def test_ring_geometry_tools(tb):
+    """test/test_mesh.jl:151-156: centre of mass of the ring and of its endocardial surface at the origin; volume of the polygonal ring."""
+    g = tb.generate_ring_mesh(5, 4, 4)
+    dets, vol = detj_and_volume(g)
+    gp = SGN / np.sqrt(3)
+    X = g.xyz[g.conn]
+    com = np.zeros(3)
+    for q, xi in enumerate(gp):
+        N = 0.125 * np.prod(1 + SGN * xi, axis=1)
+        com += np.einsum("c,ci->i", dets[q], np.einsum("a,cai->ci", N, X))
+    np.testing.assert_allclose(com / vol, 0.0, atol=1e-15)
+    # a ring of 5 straight segments: area of the regular-pentagon annulus × height
+    np.testing.assert_allclose(vol, 0.5 * 5 * np.sin(2 * np.pi / 5) * (1.0 ** 2 - 0.75 ** 2) * 0.4, rtol=1e-12)
+    fs = g.facetsets["Endocardium"]
+    cen = np.sum([np.linalg.norm(n) * fc for n, fc, _ in facet_normals(g, fs)], axis=0) / np.sum([np.linalg.norm(n) for n, _, _ in facet_normals(g, fs)])
+    np.testing.assert_allclose(cen, 0.0, atol=1e-15)
+    # anchors: inner/outer node at angle 0 on the top layer, inner nodes a quarter and three quarters around
+    a1, a2 = g.xyz[g.nodesets["MyocardialAnchor1"][0]], g.xyz[g.nodesets["MyocardialAnchor2"][0]]
+    np.testing.assert_allclose(a1, [0.75, 0, 0.2], atol=1e-15); np.testing.assert_allclose(a2, [1.0, 0, 0.2], atol=1e-15)
+
+
+def test_lv_hex_shape(tb):
+    """The O-grid ventricle: apex node on the axis side of the cap at z ≈ apex_outer, base ring above the equator, endo- and epicardial
+    surfaces closed except at the base (their boundary edges are exactly the base's inner and outer rims)."""
+    g = tb.generate_ideal_lv_mesh_hex(8, 4, 4, septum_flatness=0.0, axis_ratio=1.0)      # surface of revolution
+    apex = g.xyz[g.nodesets["Apex"][0]]
+    np.testing.assert_allclose(apex, [0, 0, 1.5], atol=1e-12)
+    inout = g.xyz[g.nodesets["ApexInOut"]]
+    np.testing.assert_allclose(inout[:, 2], [1.3, 1.5], atol=1e-12)
+    base_nodes = np.unique([g.conn[c, list(FACETS[lf])] for c, lf in g.facetsets["Base"]])
+    assert np.allclose(g.xyz[base_nodes, 2], g.xyz[base_nodes, 2][0]) and g.xyz[base_nodes, 2][0] < 0.0
+    from collections import Counter
+    for name, n_rim in (("Endocardium", 8), ("Epicardium", 8)):
+        edges = Counter()
+        for c, lf in g.facetsets[name]:
+            v = g.conn[c, list(FACETS[lf])]
+            for k in range(4):
+                edges[tuple(sorted((v[k], v[(k + 1) % 4])))] += 1
+        rim = [e for e, k in edges.items() if k == 1]
+        assert len(rim) == n_rim and all(np.allclose(g.xyz[list(e), 2], g.xyz[base_nodes, 2][0]) for e in rim)
+
+
+def test_ideal_lv_microstructure(tb):
+    g = tb.generate_ideal_lv_mesh_hex(8, 3, 4)
+    f, s, n = tb.ideal_lv_microstructure(g)
+    assert f.shape == (g.n_cells, 8, 3)
+    for a, b in ((f, f), (s, s), (n, n)):
+        np.testing.assert_allclose(np.einsum("cai,cai->ca", a, b), 1.0, atol=1e-12)
+    for a, b in ((f, s), (f, n), (s, n)):
+        np.testing.assert_allclose(np.einsum("cai,cai->ca", a, b), 0.0, atol=1e-9)
+    # the sheet normal points across the wall: from endocardial to epicardial facets of the same cell
+    for c, lf in g.facetsets["Epicardium"][:20]:
+        P = g.xyz[g.conn[c, list(FACETS[lf])]]
+        out = np.cross(P[2] - P[0], P[3] - P[1])
+        nn = n[c].mean(axis=0)
+        assert abs(np.dot(out, nn)) / np.linalg.norm(out) > 0.8

@@ -235,11 +235,16 @@ class Grid:
     def getcellset(self, name):
         return self.cellsets[name]
 
+    def getnodeset(self, name):
+        return self.nodesets[name]
+
     def facetset(self, name):
         """getfacetset(grid, name) of a generated box: left/right (x), front/back (y), bottom/top (z), as (cell, local
         facet) pairs, 0-based (Ferrite generate_grid facetsets; local facets as Ferrite.reference_facets(RefHexahedron))."""
+        if getattr(self, "facetsets", None) and name in self.facetsets:      # generated rings / ventricles, loaded meshes
+            return self.facetsets[name]
         if self.dims is None or self.cell_kind != Hexahedron:
-            raise KeyError("facetsets exist on generated hexahedral boxes only; pass explicit (cell, facet) pairs otherwise")
+            raise KeyError("facetset %r: named sets exist on generated meshes only; pass explicit (cell, facet) pairs otherwise" % name)
         nx, ny, nz = self.dims
         c = np.arange(nx * ny * nz).reshape(nz, ny, nx)
         sel, lf = {"left": (c[:, :, 0], 4), "right": (c[:, :, -1], 2), "front": (c[:, 0, :], 1), "back": (c[:, -1, :], 3),
