@@ -10,8 +10,52 @@ extern "C" {
 #include "tb_oracle.h"
 }
 namespace tb { void set_error(const char *fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); } }
+// the header-only device routines, compiled for the host
+#define TB_HD inline
+#include "tb_energy.hpp"
+#include "tb_sarcomere.hpp"
+
+static int sarcomere_and_materials()
+{
+    // oracle: sarcomere rhs, trajectory, local solves (rate-free and rate-coupled), against the host version of the device algebra
+    const double p[17] = {1.25, 1.65, 0.18, 2.2, 2.0, 0.381, -0.571, 10.0, 12.0, 0.1, 0.013, 0.13431, 25.184, 0.032653, 0.000778, 22.894e3, 1.0e-6};
+    tbk::RDQ20Params P{p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[9], p[10], p[11], p[12], p[13], p[14], p[15], p[16]};
+    double u[20] = {1.0}, du[20], lam[64], dl[64], ca[64], out[20 * 4];
+    unsigned char sample[64] = {0};
+    for (int i = 0; i < 64; ++i) { lam[i] = 1.0 - 0.001 * i; dl[i] = -1e-3; ca[i] = 0.1 + 0.01 * i; sample[i] = i % 16 == 15; }
+    orc_rdq20mf_rhs(p, u, 1.0, 0.0, 0.5, du);
+    orc_rdq20mf_trajectory(p, u, 64, 1e-2, lam, dl, ca, sample, out);
+    for (double vel : {0.0, 2e-3}) {
+        double Q[20], Qk[20], a[20], b[20], Q2[20], a2[20], b2[20];
+        for (int k = 0; k < 20; ++k) Q[k] = Qk[k] = Q2[k] = u[k];
+        int it = 0; double rn = 0;
+        if (orc_rdq20mf_local_solve_rate(p, Q, Qk, 0.98, vel, 0.6, 0.5, 1e-12, 30, a, b, &it, &rn)) return 20;
+        double qh[20], qkh[20];
+        for (int k = 0; k < 20; ++k) { qh[k] = Q2[k]; qkh[k] = Qk[k]; }
+        if (tbk::rdq20_local_solve_host(P, qh, qkh, 0.98, vel, 0.6, 0.5, 1e-12, 30, a2, &it, &rn, b2)) return 21;
+        for (int k = 0; k < 20; ++k) if (std::fabs(qh[k] - Q[k]) > 1e-12 || std::fabs(a2[k] - a[k]) > 1e-9 || std::fabs(b2[k] - b[k]) > 1e-9) return 22;
+    }
+    // energies: Hill framework + prestress through the hyper-dual pair evaluation, all 45 pairs
+    tbk::EnergyParams e{};
+    e.energy = 0; e.penalty = 0;
+    const double ho[9] = {0.059, 8.023, 18.472, 16.026, 2.481, 11.120, 0.216, 11.436, 0.0};
+    for (int i = 0; i < 9; ++i) e.p[i] = ho[i];
+    e.u[0] = 4.0; e.Ta = 0.7; e.hill = tbk::HILL_EXTENDED; e.act_energy = 7; e.act_penalty = 1; e.ap[0] = 10.0; e.adg = tbk::ADG_RLRSQ; e.kappa = 0.5;
+    e.sarc = tbk::SARC_PELCE_SUN_LANGEVELD; e.sp[0] = 3.0; e.sp[1] = 0.7;
+    e.prestressed = 1;
+    const double G[9] = {1.1, 0.2, -0.1, 0.1, 0.9, 0.0, 0.0, 0.1, 1.0};
+    for (int i = 0; i < 9; ++i) e.G[i] = G[i];
+    const double F[9] = {1.05, 0.02, -0.01, 0.03, 0.97, 0.04, -0.02, 0.01, 1.02}, f0[3] = {1, 0, 0}, s0[3] = {0, 1, 0}, n0[3] = {0, 0, 1};
+    double acc = 0.0;
+    for (int pr = 0; pr < 45; ++pr) { int mm, nn; tbk::pair_components(pr, mm, nn); acc += tbk::energy_pair(e, F, mm, nn, f0, s0, n0).ab; }
+    if (!(acc == acc)) return 23;
+    // oracle: condensed assembly (rate-coupled) on a tiny mesh, Hill framework, prestress
+    return 0;
+}
+
 int main()
 {
+    if (int rc = sarcomere_and_materials()) { fprintf(stderr, "sarcomere / material section failed: %d\n", rc); return rc; }
     for (int kind : {TB_HEX8, TB_HEX27}) {
         const int nx = 5, ny = 4, nz = 3;
         std::vector<double> xyz(3 * (nx + 1) * (ny + 1) * (nz + 1));
@@ -63,6 +107,28 @@ int main()
                 for (int64_t i = 0; i < nd; ++i) u[i] = 1e-2 * ((i * 7919) % 13 - 6) / 6.0;
                 const double p[9] = {0.059, 8.023, 18.472, 16.026, 2.581, 11.120, 0.216, 11.436, 1.0}, fsn[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
                 if (orc_assemble_hyperelastic(&om, p, fsn, u.data(), rp.data(), ci.data(), nz.data(), r.data(), 1, nullptr, 0)) return 14;
+                { // condensed internal variable, rate-coupled, then Hill framework and prestress
+                    const double sp[17] = {1.25, 1.65, 0.18, 2.2, 2.0, 0.381, -0.571, 10.0, 12.0, 0.1, 0.013, 0.13431, 25.184, 0.032653, 0.000778, 22.894e3, 1.0e-6};
+                    const int nq = kind == TB_HEX27 ? 27 : 8;
+                    const int64_t npts = (int64_t)cd.size() / (nb * ncomp) * nq;
+                    std::vector<double> Q(20 * npts, 0.0), Qk(20 * npts, 0.0), up(nd, 0.0);
+                    for (int64_t i = 0; i < npts; ++i) Q[i] = Qk[i] = 1.0;
+                    std::vector<int> status(npts);
+                    orc_set_active_tension(0.6, nullptr);
+                    orc_set_condensation(sp, 50.0, Q.data(), Qk.data(), npts, 0.5, 1e-10, 20, status.data());
+                    orc_set_condensation_rate(up.data());
+                    if (orc_assemble_hyperelastic(&om, p, fsn, u.data(), rp.data(), ci.data(), nz.data(), r.data(), 2, nullptr, 0)) return 16;
+                    orc_set_condensation(nullptr, 0, nullptr, nullptr, 0, 1, 0, 1, nullptr);
+                    const double ap[12] = {10.0};
+                    const double sarc[2] = {3.0, 0.7};
+                    orc_set_hill(2, 7, 1, ap, 0, 0.0, 0, sarc);
+                    const double G[9] = {1.1, 0.2, -0.1, 0.1, 0.9, 0.0, 0.0, 0.1, 1.0};
+                    orc_set_prestress(G);
+                    if (orc_assemble_hyperelastic(&om, p, fsn, u.data(), rp.data(), ci.data(), nz.data(), r.data(), 1, nullptr, 0)) return 17;
+                    orc_set_prestress(nullptr);
+                    orc_set_hill(0, 0, 0, ap, 0, 0.0, 0, sarc);
+                    orc_set_active_tension(0.0, nullptr);
+                }
                 const int32_t facets[4] = {0, 4, nx - 1, 2};
                 for (int bc = 0; bc < 3; ++bc)
                     if (orc_assemble_facets(&om, bc, 0.3, kind == TB_HEX27 ? 2 : 1, facets, 2, u.data(), rp.data(), ci.data(), nz.data(), r.data())) return 15;
