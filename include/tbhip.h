@@ -318,6 +318,10 @@ int tb_sarcomere_implicit_step(tb_device *dev, int model, const double *params, 
                                int64_t n_points, const double *d_stretch, const double *d_velocity, const double *d_calcium, double stretch,
                                double velocity, double calcium, double dt, double tol, int max_iters, double *d_dstate_dstretch,
                                double *d_dstate_dvelocity, int32_t *d_status, int64_t *n_failed);
+/* ∂rhs/∂state (row-major 20×20), ∂rhs/∂λ, ∂rhs/∂(dλ/dt) and rhs at one point: the hand-derived linearisation the kernels use
+ * (analytic != 0) or forward-mode differentiation of the right-hand side (analytic == 0) — host-side cross-check */
+int tb_host_sarcomere_derivatives(int model, const double *params, int n_params, const double *state, double stretch, double velocity, double calcium,
+                                  int analytic, double *drhs_dstate, double *drhs_dstretch, double *drhs_dvelocity, double *rhs);
 int tb_host_sarcomere_local_solve(int model, const double *params, int n_params, double *state, const double *state_known, double stretch,
                                   double velocity, double calcium, double dt, double tol, int max_iters, double *dstate_dstretch,
                                   double *dstate_dvelocity, int *status, int *iters, double *resnorm);

@@ -92,6 +92,7 @@ SIGNATURES = {
     "tb_host_sarcomere_eval": (C.c_int, [C.c_int, c_dp, C.c_int, c_dp, C.c_double, C.c_double, C.c_double, c_dp, c_dp, c_dp]),
     "tb_sarcomere_implicit_step": (C.c_int, [vp, C.c_int, c_dp, C.c_int, vp, vp, C.c_int64, vp, vp, vp, C.c_double, C.c_double, C.c_double, C.c_double,
                                              C.c_double, C.c_int, vp, vp, vp, C.POINTER(C.c_int64)]),
+    "tb_host_sarcomere_derivatives": (C.c_int, [C.c_int, c_dp, C.c_int, c_dp, C.c_double, C.c_double, C.c_double, C.c_int, c_dp, c_dp, c_dp, c_dp]),
     "tb_host_sarcomere_local_solve": (C.c_int, [C.c_int, c_dp, C.c_int, c_dp, c_dp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
                                                 c_dp, c_dp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "tb_hyperelastic_set_previous_solution": (C.c_int, [vp, vp]),

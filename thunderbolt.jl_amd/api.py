@@ -1578,6 +1578,17 @@ def sarcomere_stepper(state, dt, tension=None, stiffness=None):
     return step
 
 
+def sarcomere_derivatives(model, u, stretch, velocity, calcium, analytic=True):
+    """(∂rhs/∂u [20×20], ∂rhs/∂λ, ∂rhs/∂λ̇, rhs) at one point: the kernels' hand-derived linearisation, or forward mode (analytic=False)"""
+    p = model.params()
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    D, gl, gv, f = np.zeros((20, 20)), np.zeros(20), np.zeros(20), np.zeros(20)
+    check(lib().tb_host_sarcomere_derivatives(model.sid, p.ctypes.data_as(L.c_dp), len(p), u.ctypes.data_as(L.c_dp), float(stretch), float(velocity),
+                                              float(calcium), int(analytic), D.ctypes.data_as(L.c_dp), gl.ctypes.data_as(L.c_dp), gv.ctypes.data_as(L.c_dp),
+                                              f.ctypes.data_as(L.c_dp)))
+    return D, gl, gv, f
+
+
 class GenericLocalNonlinearSolver:
     """GenericLocalNonlinearSolver(; max_iters = 10, tol = 1e-4) (multilevel_newton_raphson.jl:1-4)."""
 

@@ -732,6 +732,15 @@ int tb_host_sarcomere_eval(int model, const double *params, int n_params, const 
     return TB_OK;
 }
 
+int tb_host_sarcomere_derivatives(int model, const double *params, int n_params, const double *state, double stretch, double velocity, double calcium,
+                                  int analytic, double *drhs_dstate, double *drhs_dstretch, double *drhs_dvelocity, double *rhs)
+{
+    TB_REQUIRE(params && state && drhs_dstate && drhs_dstretch && drhs_dvelocity && rhs, "tb_host_sarcomere_derivatives: NULL argument");
+    TB_REQUIRE(model == TB_SARCOMERE_RDQ20MF && n_params == 17, "tb_host_sarcomere_derivatives: RDQ20MF with 17 parameters expected");
+    host_sarcomere_derivatives(params, state, stretch, velocity, calcium, analytic, drhs_dstate, drhs_dstretch, drhs_dvelocity, rhs);
+    return TB_OK;
+}
+
 int tb_sarcomere_implicit_step(tb_device *dev, int model, const double *params, int n_params, double *d_state, const double *d_state_known,
                                int64_t n_points, const double *d_stretch, const double *d_velocity, const double *d_calcium, double stretch,
                                double velocity, double calcium, double dt, double tol, int max_iters, double *d_dstate_dstretch,

@@ -219,6 +219,8 @@ int launch_sarcomere_implicit(tb_device *dev, const double *params, double *d_Q,
                               int need_sens, const int32_t *d_cells = nullptr, int nq = 1, int64_t n_cells_listed = 0);
 int host_sarcomere_local_solve(const double *params, double *Q, const double *Qknown, double stretch, double velocity, double calcium, double dt, double tol,
                                int max_iters, double *dQdl, double *dQdv, int *iters, double *resnorm);
+void host_sarcomere_derivatives(const double *params, const double *u, double stretch, double velocity, double calcium, int analytic, double *D, double *gl,
+                                double *gv, double *rhs);
 void host_sarcomere_eval(const double *params, const double *u, double stretch, double velocity, double calcium, double *du, double *tension,
                          double *stiffness);
 int launch_gmres(tb_pattern *pat, const double *A, const double *b, double *x, double rtol, double atol, int maxiter, int restart, int jacobi,

@@ -70,6 +70,12 @@ int launch_sarcomere(tb_device *dev, const double *params, double *d_state, int6
 // solved by every lane after the chain's increment is known.  The whole wave stays converged — finished points idle under a mask.
 // ------------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double grp_shfl(double v, int src) { return __shfl(v, src, 64); }
+// rotation within a row of 16 lanes on the data-parallel-primitive path (a VALU move, no LDS round trip): row_ror:N = 0x120 + N
+template <int N> __device__ __forceinline__ int row_ror(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x120 + N, 0xF, 0xF, false); }
+template <int N> __device__ __forceinline__ double row_ror(double v)
+{
+    return __hiloint2double(row_ror<N>(__double2hiint(v)), row_ror<N>(__double2loint(v)));
+}
 
 // solve the 16×16 system held one row per lane (row[], b) within a 16-lane group; returns x[16] on every lane; false if singular
 __device__ __forceinline__ bool group_gauss_jordan(double (&row)[16], double b, int base, int r, double (&x)[16])
@@ -81,12 +87,10 @@ __device__ __forceinline__ bool group_gauss_jordan(double (&row)[16], double b, 
     for (int k = 0; k < 16; ++k) {
         double cand = done ? -1.0 : fabs(row[k]);
         int who = r;
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {
-            const double oc = __shfl_xor(cand, o, 64);
-            const int ow = __shfl_xor(who, o, 64);
-            if (oc > cand || (oc == cand && ow < who)) { cand = oc; who = ow; }
-        }
+        // all-reduce (max, lowest lane on ties) over the 16 lanes by rotations: every lane ends with the same (cand, who)
+#define TB_ARGMAX_STEP(N) { const double oc = row_ror<N>(cand); const int ow = row_ror<N>(who); if (oc > cand || (oc == cand && ow < who)) { cand = oc; who = ow; } }
+        TB_ARGMAX_STEP(8) TB_ARGMAX_STEP(4) TB_ARGMAX_STEP(2) TB_ARGMAX_STEP(1)
+#undef TB_ARGMAX_STEP
         if (!(cand > 0.0)) ok = false;
         const int src = base | who;
         const double pk = grp_shfl(row[k], src), pb = grp_shfl(b, src);
@@ -136,29 +140,25 @@ __device__ __forceinline__ bool solve4(double (&A)[4][4], double (&b)[4])
 }
 
 // Jacobian of the local problem at state q, distributed over the 16 lanes of a group: row r of J_RR in registers, column r of
-// ∂rhs_X/∂Q_R (colX), and rhs(q) itself (f, on every lane)
+// ∂rhs_X/∂Q_R (colX), and rhs(q) itself (f, on every lane).  Lane r derives column r by hand (rdq20_rhs_column — the eight neighbour
+// rates and the two cross-bridge exchange rates carry all the nonlinearity), the transpose goes through LDS.
 struct LocalJacobian { double row[16], colX[4], kPN, kNP, vel; };
 __device__ __forceinline__ void local_jacobian(const RDQ20Params &p, const double (&q)[20], double lam, double vel, double ca, double dt, double (*tr)[17], int r,
-                                               LocalJacobian &J, double (&f)[20])
+                                               LocalJacobian &J, double (&f)[20], RDQ20Lin &L)
 {
-    D1 ud[20], dud[20];
+    rdq20_linearise(p, q, lam, vel, ca, L);
+    rdq20_rhs_rows(p, L, q, vel, f);
+    double col[20];
+    rdq20_rhs_column(p, L, q, r, col);
 #pragma unroll
-    for (int k = 0; k < 20; ++k) ud[k] = {q[k], k == r ? 1.0 : 0.0};
-    rdq20_rhs<D1>(p, ud, D1{lam, 0.0}, D1{vel, 0.0}, ca, dud);
-#pragma unroll
-    for (int k = 0; k < 20; ++k) f[k] = dud[k].v;
-    // transpose: lane c wrote column c (∂rhs_i/∂Q_c for all i); lane r reads row r
-#pragma unroll
-    for (int i = 0; i < 16; ++i) tr[i][r] = dud[i].d;
+    for (int i = 0; i < 16; ++i) tr[i][r] = col[i];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int c = 0; c < 16; ++c) J.row[c] = (c == r ? 1.0 / dt : 0.0) - tr[r][c];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int k = 0; k < 4; ++k) J.colX[k] = dud[16 + k].d;
-    double perm;
-    rdq20_xb_rates<double>(p, q, perm, J.kPN, J.kNP);
-    J.vel = vel;
+    for (int k = 0; k < 4; ++k) J.colX[k] = col[16 + k];
+    J.kPN = L.kPN; J.kNP = L.kNP; J.vel = vel;
 }
 
 // J y = g: g given on every lane (20 values), y returned on every lane
@@ -227,7 +227,8 @@ k_sarcomere_implicit(RDQ20Params p, SarcomereInputs in, double *__restrict__ Qs,
             if (!__any(active)) break;
             double f[20], R[20], y[20];
             LocalJacobian J;
-            local_jacobian(p, q, lam, vel, ca, dt, tr, r, J, f);
+            RDQ20Lin L;
+            local_jacobian(p, q, lam, vel, ca, dt, tr, r, J, f, L);
             double rn = 0.0;
 #pragma unroll
             for (int k = 0; k < 20; ++k) { R[k] = (q[k] - qk[k]) / dt - f[k]; rn += R[k] * R[k]; }
@@ -253,15 +254,12 @@ k_sarcomere_implicit(RDQ20Params p, SarcomereInputs in, double *__restrict__ Qs,
         double ql = 0.0, qv = 0.0;
         if constexpr (SENS) {
             // corrector: dQ/dλ = J⁻¹ ∂rhs/∂λ at the converged state
-            D1 ud[20], dud[20];
-#pragma unroll
-            for (int k = 0; k < 20; ++k) ud[k] = {q[k], 0.0};
-            rdq20_rhs<D1>(p, ud, D1{lam, 1.0}, D1{vel, 0.0}, ca, dud);
             double g[20], y[20], f[20];
-#pragma unroll
-            for (int k = 0; k < 20; ++k) g[k] = dud[k].d;
             LocalJacobian J;
-            local_jacobian(p, q, lam, vel, ca, dt, tr, r, J, f);
+            RDQ20Lin L;
+            local_jacobian(p, q, lam, vel, ca, dt, tr, r, J, f, L);
+#pragma unroll
+            for (int k = 0; k < 20; ++k) g[k] = rdq20_rhs_dlam_row(L, q, k);
             const bool ok = local_linear_solve(p, J, dt, g, y, base, r);
             if (!ok && code == LOCAL_SUCCESS) code = LOCAL_LINEAR_SOLVE_FAILED;
             if (code != LOCAL_SUCCESS) {
@@ -270,11 +268,8 @@ k_sarcomere_implicit(RDQ20Params p, SarcomereInputs in, double *__restrict__ Qs,
             }
             ql = y[17] + y[19];
             if (rate) { // second corrector dQ/d(dλ/dt) (materials.jl:1715-1720): only the cross-bridge rows of ∂rhs/∂v are non-zero, so y_R = 0
-                D1 vd[20], dvd[20];
-#pragma unroll
-                for (int k = 0; k < 20; ++k) vd[k] = {q[k], 0.0};
-                rdq20_rhs<D1>(p, vd, D1{lam, 0.0}, D1{vel, 1.0}, ca, dvd);
-                double bx[4] = {dvd[16].d, dvd[17].d, dvd[18].d, dvd[19].d};
+                double bx[4];
+                rdq20_rhs_dvel(L, q, bx);
                 const double rr = p.r0 + p.alpha * smooth_abs(vel, p.eps_v), dP = 1.0 / dt + rr + J.kPN, dN = 1.0 / dt + rr + J.kNP;
                 double A[4][4] = {{dP, 0, -J.kNP, 0}, {-vel, dP, 0, -J.kNP}, {-J.kPN, 0, dN, 0}, {0, -J.kPN, -vel, dN}};
                 const bool ok2 = solve4(A, bx);
@@ -357,6 +352,25 @@ int host_sarcomere_local_solve(const double *params, double *Q, const double *Qk
     const int code = rdq20_local_solve_host(p, q, qk, stretch, velocity, calcium, dt, tol, max_iters, dQdl, iters, resnorm, dQdv);
     for (int k = 0; k < 20; ++k) Q[k] = q[k];
     return code;
+}
+
+// ∂rhs/∂u, ∂rhs/∂λ, ∂rhs/∂(dλ/dt): hand-derived (analytic != 0, what the kernel uses) or by forward mode (analytic == 0)
+void host_sarcomere_derivatives(const double *params, const double *u, double stretch, double velocity, double calcium, int analytic, double *D, double *gl,
+                                double *gv, double *rhs)
+{
+    const RDQ20Params p = rdq20_params(params);
+    double q[20], Dm[20][20], l[20], v[20], f[20];
+    for (int k = 0; k < 20; ++k) q[k] = u[k];
+    if (analytic) rdq20_analytic_derivatives(p, q, stretch, velocity, calcium, Dm, l, v, f);
+    else {
+        for (int c = 0; c < 22; ++c) {
+            D1 ud[20], dud[20];
+            for (int k = 0; k < 20; ++k) ud[k] = {q[k], k == c ? 1.0 : 0.0};
+            rdq20_rhs<D1>(p, ud, D1{stretch, c == 20 ? 1.0 : 0.0}, D1{velocity, c == 21 ? 1.0 : 0.0}, calcium, dud);
+            for (int k = 0; k < 20; ++k) { if (c < 20) Dm[k][c] = dud[k].d; else if (c == 20) l[k] = dud[k].d; else v[k] = dud[k].d; f[k] = dud[k].v; }
+        }
+    }
+    for (int k = 0; k < 20; ++k) { for (int c = 0; c < 20; ++c) D[20 * k + c] = Dm[k][c]; gl[k] = l[k]; gv[k] = v[k]; rhs[k] = f[k]; }
 }
 
 void host_sarcomere_eval(const double *params, const double *u, double stretch, double velocity, double calcium, double *du, double *tension,

@@ -148,6 +148,131 @@ TB_HD void rdq20_rhs(const RDQ20Params &p, const T (&u)[RDQ20_NSTATES], T lam, T
 #undef RU
 }
 
+// ---- the same right-hand side, differentiated by hand: what the 16-lanes-per-point kernel evaluates (one column per lane).
+// The chain's nonlinearity sits in eight neighbour rates (flux / probability of the four (TL,TC) and the four (TR,TC) groups) and the
+// cross-bridge block's in k_PN, k_NP; everything else is linear in the state.  Checked against the forward-mode columns above.
+struct RDQ20Lin {
+    double dT[16];                  // centre-unit transition rate of every state
+    double dC[2][2];                // dC[CC][TC]
+    double ddC1;                    // ∂dC1/∂λ
+    double rateL[2][2], gLden[2][2]; // rateL[TL][TC] and 1/probability of the group (0 where the rate is switched off)
+    double rateR[2][2], gRden[2][2]; // rateR[TR][TC]
+    double perm, kPN, kNP, r, dr;   // cross-bridge block: permissivity, rates, r = r₀ + α|v|_ε and dr/dv
+};
+TB_HD void rdq20_linearise(const RDQ20Params &p, const double (&u)[RDQ20_NSTATES], double lam, double dlam, double Ca, RDQ20Lin &L)
+{
+    const double den = p.Kd0 - p.aKd * (2.15 - p.SL0 * lam);
+    const double dC1 = p.Koff / den * Ca;
+    L.dC[0][0] = dC1; L.dC[0][1] = dC1; L.dC[1][0] = p.Koff; L.dC[1][1] = p.Koff / p.mu;
+    L.ddC1 = -p.Koff * Ca * p.aKd * p.SL0 / (den * den);
+    double su[8], sP[8];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) L.dT[i] = rdq20_dT(p, i & 1, (i >> 1) & 1, (i >> 2) & 1, (i >> 3) & 1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { su[i] = u[i] + u[i + 8]; sP[i] = u[i] * L.dT[i] + u[i + 8] * L.dT[i + 8]; }
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const double fl = sP[a + 2 * b] + sP[a + 2 * b + 4], pr = su[a + 2 * b] + su[a + 2 * b + 4];
+            const bool on = pr > 1e-12;
+            L.rateL[a][b] = on ? fl / pr : 0.0;
+            L.gLden[a][b] = on ? 1.0 / pr : 0.0;
+        }
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const double fl = sP[2 * b + 4 * c] + sP[1 + 2 * b + 4 * c], pr = su[2 * b + 4 * c] + su[1 + 2 * b + 4 * c];
+            const bool on = pr > 1e-12;
+            L.rateR[c][b] = on ? fl / pr : 0.0;
+            L.gRden[c][b] = on ? 1.0 / pr : 0.0;
+        }
+    rdq20_xb_rates<double>(p, u, L.perm, L.kPN, L.kNP);
+    const double e2 = p.eps_v * p.eps_v, x2 = dlam * dlam, sq = ::sqrt(x2 + e2);
+    L.r = p.r0 + p.alpha * (x2 / sq);
+    L.dr = p.alpha * dlam * (x2 + 2.0 * e2) / ((x2 + e2) * sq);   // d/dx [x²/√(x²+ε²)]
+}
+// m[i][j] for run-time i, j without indexing a register array by a run-time value
+TB_HD double pick22(const double (&m)[2][2], int i, int j) { return i ? (j ? m[1][1] : m[1][0]) : (j ? m[0][1] : m[0][0]); }
+// rhs_i for one row i (0…19), given the linearisation data
+TB_HD double rdq20_rhs_row(const RDQ20Params &p, const RDQ20Lin &L, const double (&u)[RDQ20_NSTATES], double dlam, int i)
+{
+    if (i < 16) {
+        const int a = i & 1, b = (i >> 1) & 1, c = (i >> 2) & 1, d = (i >> 3) & 1;
+        return -u[i] * L.rateL[b][a] + u[i ^ 1] * L.rateL[b][1 - a] - u[i] * L.dT[i] + u[i ^ 2] * L.dT[i ^ 2] - u[i] * L.rateR[b][c] + u[i ^ 4] * L.rateR[b][1 - c] -
+               u[i] * L.dC[d][b] + u[i ^ 8] * L.dC[1 - d][b];
+    }
+    const double dP = L.r + L.kPN, dN = L.r + L.kNP, x1 = u[16], x2 = u[17], x3 = u[18], x4 = u[19];
+    if (i == 16) return -dP * x1 + L.kNP * x3 + p.mu0_fP * L.perm;
+    if (i == 17) return dlam * x1 - dP * x2 + L.kNP * x4 + p.mu1_fP * L.perm;
+    if (i == 18) return L.kPN * x1 - dN * x3;
+    return L.kPN * x2 + dlam * x3 - dN * x4;
+}
+// all twenty rows at once (compile-time indices only)
+TB_HD void rdq20_rhs_rows(const RDQ20Params &p, const RDQ20Lin &L, const double (&u)[RDQ20_NSTATES], double dlam, double (&f)[RDQ20_NSTATES])
+{
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int a = i & 1, b = (i >> 1) & 1, c = (i >> 2) & 1, d = (i >> 3) & 1;
+        f[i] = -u[i] * L.rateL[b][a] + u[i ^ 1] * L.rateL[b][1 - a] - u[i] * L.dT[i] + u[i ^ 2] * L.dT[i ^ 2] - u[i] * L.rateR[b][c] + u[i ^ 4] * L.rateR[b][1 - c] -
+               u[i] * L.dC[d][b] + u[i ^ 8] * L.dC[1 - d][b];
+    }
+    const double dP = L.r + L.kPN, dN = L.r + L.kNP, x1 = u[16], x2 = u[17], x3 = u[18], x4 = u[19];
+    f[16] = -dP * x1 + L.kNP * x3 + p.mu0_fP * L.perm;
+    f[17] = dlam * x1 - dP * x2 + L.kNP * x4 + p.mu1_fP * L.perm;
+    f[18] = L.kPN * x1 - dN * x3;
+    f[19] = L.kPN * x2 + dlam * x3 - dN * x4;
+}
+// column c (0…15) of ∂rhs/∂u: col[0…15] chain rows, col[16…19] cross-bridge rows
+TB_HD void rdq20_rhs_column(const RDQ20Params &p, const RDQ20Lin &L, const double (&u)[RDQ20_NSTATES], int c, double (&col)[RDQ20_NSTATES])
+{
+    const int a = c & 1, b = (c >> 1) & 1, cc = (c >> 2) & 1, d = (c >> 3) & 1;
+#pragma unroll
+    for (int i = 0; i < RDQ20_NSTATES; ++i) col[i] = 0.0;
+    const double dTc = rdq20_dT(p, a, b, cc, d);
+    const double rL_ba = pick22(L.rateL, b, a), rR_bc = pick22(L.rateR, b, cc), dC_db = pick22(L.dC, d, b);
+    // explicit occurrences of u_c
+    const double diag = -(rL_ba + dTc + rR_bc + dC_db);
+    const double gL = (dTc - pick22(L.rateL, a, b)) * pick22(L.gLden, a, b);   // ∂ rateL[TL=a][TC=b] / ∂u_c
+    const double gR = (dTc - pick22(L.rateR, cc, b)) * pick22(L.gRden, cc, b); // ∂ rateR[TR=cc][TC=b] / ∂u_c
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int ai = i & 1, bi = (i >> 1) & 1, ci = (i >> 2) & 1;
+        double v = 0.0;
+        v += (i == c) ? diag : 0.0;
+        v += (i == (c ^ 1)) ? rL_ba : 0.0;
+        v += (i == (c ^ 2)) ? dTc : 0.0;
+        v += (i == (c ^ 4)) ? rR_bc : 0.0;
+        v += (i == (c ^ 8)) ? dC_db : 0.0;
+        // through the neighbour rates: row i reads rateL[b_i][a_i] (self) and rateL[b_i][1 − a_i] (flipped left neighbour) …
+        if (bi == a) v += (ai == b) ? -u[i] * gL : u[i ^ 1] * gL;
+        // … and rateR[b_i][c_i] (self), rateR[b_i][1 − c_i] (flipped right neighbour)
+        if (bi == cc) v += (ci == b) ? -u[i] * gR : u[i ^ 4] * gR;
+        col[i] = v;
+    }
+    // cross-bridge rows through the permissivity and the two exchange rates
+    const double dperm = b ? 1.0 : 0.0;
+    const double dkPN = L.perm >= 1e-12 ? ((b ? dTc : 0.0) - L.kPN * dperm) / L.perm : 0.0;
+    const double dkNP = 1.0 - L.perm >= 1e-12 ? ((b ? 0.0 : dTc) + L.kNP * dperm) / (1.0 - L.perm) : 0.0;
+    const double x1 = u[16], x2 = u[17], x3 = u[18], x4 = u[19];
+    col[16] = -dkPN * x1 + dkNP * x3 + p.mu0_fP * dperm;
+    col[17] = -dkPN * x2 + dkNP * x4 + p.mu1_fP * dperm;
+    col[18] = dkPN * x1 - dkNP * x3;
+    col[19] = dkPN * x2 - dkNP * x4;
+}
+// ∂rhs/∂λ (only through the calcium binding rate) and ∂rhs/∂(dλ/dt) (only the cross-bridge rows)
+TB_HD double rdq20_rhs_dlam_row(const RDQ20Lin &L, const double (&u)[RDQ20_NSTATES], int i)
+{
+    if (i >= 16) return 0.0;
+    const int d = (i >> 3) & 1;
+    return d == 0 ? -u[i] * L.ddC1 : u[i ^ 8] * L.ddC1;
+}
+TB_HD void rdq20_rhs_dvel(const RDQ20Lin &L, const double (&u)[RDQ20_NSTATES], double (&g)[4])
+{
+    g[0] = -L.dr * u[16]; g[1] = u[16] - L.dr * u[17]; g[2] = -L.dr * u[18]; g[3] = u[18] - L.dr * u[19];
+}
+
 // fraction_single_overlap (contraction.jl:598-614)
 TB_HD double rdq20_overlap(const RDQ20Params &p, double lam)
 {
@@ -203,6 +328,25 @@ inline void rdq20_local_jacobian(const RDQ20Params &p, const double (&Q)[20], do
         for (int k = 0; k < 20; ++k) { J[k][c] = (k == c ? 1.0 / dt : 0.0) - du[k].d; rhs[k] = du[k].v; }
     }
 }
+// hand-derived counterpart of rdq20_local_jacobian's derivative part: ∂rhs/∂u (20×20), ∂rhs/∂λ, ∂rhs/∂(dλ/dt), and rhs itself
+inline void rdq20_analytic_derivatives(const RDQ20Params &p, const double (&Q)[20], double lam, double dlam, double Ca, double (&D)[20][20], double (&gl)[20],
+                                       double (&gv)[20], double (&rhs)[20])
+{
+    RDQ20Lin L;
+    rdq20_linearise(p, Q, lam, dlam, Ca, L);
+    for (int c = 0; c < 16; ++c) {
+        double col[20];
+        rdq20_rhs_column(p, L, Q, c, col);
+        for (int k = 0; k < 20; ++k) D[k][c] = col[k];
+    }
+    const double dP = L.r + L.kPN, dN = L.r + L.kNP;
+    const double XB[4][4] = {{-dP, 0, L.kNP, 0}, {dlam, -dP, 0, L.kNP}, {L.kPN, 0, -dN, 0}, {0, L.kPN, dlam, -dN}};
+    for (int k = 0; k < 20; ++k) for (int c = 16; c < 20; ++c) D[k][c] = k >= 16 ? XB[k - 16][c - 16] : 0.0;
+    double g4[4];
+    rdq20_rhs_dvel(L, Q, g4);
+    for (int k = 0; k < 20; ++k) { gl[k] = rdq20_rhs_dlam_row(L, Q, k); gv[k] = k >= 16 ? g4[k - 16] : 0.0; rhs[k] = rdq20_rhs_row(p, L, Q, dlam, k); }
+}
+
 // Q: initial guess in, solution out.  dQdl: dQ/dλ at the solution (may be nullptr).  Returns the status code.
 inline int rdq20_local_solve_host(const RDQ20Params &p, double (&Q)[20], const double (&Qk)[20], double lam, double dlam, double Ca, double dt, double tol,
                                   int max_iters, double *dQdl, int *iters, double *resnorm, double *dQdv = nullptr)
