@@ -77,6 +77,14 @@ template <int N> __device__ __forceinline__ double row_ror(double v)
     return __hiloint2double(row_ror<N>(__double2hiint(v)), row_ror<N>(__double2loint(v)));
 }
 
+__device__ __forceinline__ double rcp_fast(double y) // hardware reciprocal + two Newton steps (≤ 2 ulp) instead of the IEEE division sequence
+{
+    double r = __builtin_amdgcn_rcp(y);
+    r = fma(fma(-y, r, 1.0), r, r);
+    r = fma(fma(-y, r, 1.0), r, r);
+    return r;
+}
+
 // solve the 16×16 system held one row per lane (row[], b) within a 16-lane group; returns x[16] on every lane; false if singular
 __device__ __forceinline__ bool group_gauss_jordan(double (&row)[16], double b, int base, int r, double (&x)[16])
 {
@@ -94,14 +102,14 @@ __device__ __forceinline__ bool group_gauss_jordan(double (&row)[16], double b, 
         if (!(cand > 0.0)) ok = false;
         const int src = base | who;
         const double pk = grp_shfl(row[k], src), pb = grp_shfl(b, src);
-        const double m = (r == who) ? 0.0 : row[k] / pk;
+        const double m = (r == who) ? 0.0 : row[k] * rcp_fast(pk);
 #pragma unroll
         for (int j = k + 1; j < 16; ++j) row[j] -= m * grp_shfl(row[j], src);
         b -= m * pb;
         if (r == who) { done = true; mypiv = row[k]; }
         piv[k] = src;
     }
-    const double mine = b / mypiv;
+    const double mine = b * rcp_fast(mypiv);
 #pragma unroll
     for (int k = 0; k < 16; ++k) x[k] = grp_shfl(mine, piv[k]);
     return ok;
@@ -121,9 +129,10 @@ __device__ __forceinline__ bool solve4(double (&A)[4][4], double (&b)[4])
                 const double t = b[k]; b[k] = b[i]; b[i] = t;
             }
         if (!(fabs(A[k][k]) > 0.0)) ok = false;
+        const double inv = rcp_fast(A[k][k]);
 #pragma unroll
         for (int i = k + 1; i < 4; ++i) {
-            const double m = A[i][k] / A[k][k];
+            const double m = A[i][k] * inv;
 #pragma unroll
             for (int j = k; j < 4; ++j) A[i][j] -= m * A[k][j];
             b[i] -= m * b[k];
@@ -134,7 +143,7 @@ __device__ __forceinline__ bool solve4(double (&A)[4][4], double (&b)[4])
         double s2 = b[i];
 #pragma unroll
         for (int j = i + 1; j < 4; ++j) s2 -= A[i][j] * b[j];
-        b[i] = s2 / A[i][i];
+        b[i] = s2 * rcp_fast(A[i][i]);
     }
     return ok;
 }
