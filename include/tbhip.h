@@ -360,6 +360,15 @@ int tb_spmv_csr(tb_pattern *pat, const double *d_nzval, const double *d_x, doubl
  * Stops when ‖r‖₂ ≤ atol + rtol·‖r₀‖₂ or after maxiter iterations; reports iterations and the final ‖r‖₂. */
 int tb_cg_solve(tb_pattern *pat, const double *d_Anz, const double *d_b, double *d_x, double rtol, double atol, int maxiter,
                 int jacobi, int *iters, double *resnorm);
+/* Preconditioned CG with a choice of preconditioner.  TB_PRECOND_L1GS: ℓ₁ Gauss–Seidel, symmetric sweep, partitions of `partsize`
+ * consecutive rows (the preconditioner the reference documents for its Krylov solves — Thunderbolt.Preconditioners.L1GSPrecBuilder /
+ * SymmetricSweep, docs/src/api-reference/solver.md:13-22; Baker–Falgout–Kolev–Yang 2011): M = (D̃ + L_p) D̃⁻¹ (D̃ + U_p) with
+ * D̃_ii = a_ii + Σ_{j outside the partition} |a_ij|.  tb_l1gs_apply: one application z = M⁻¹ r (forward or symmetric sweep). */
+enum { TB_PRECOND_NONE = 0, TB_PRECOND_JACOBI = 1, TB_PRECOND_L1GS = 2 };
+enum { TB_SWEEP_FORWARD = 0, TB_SWEEP_SYMMETRIC = 2 };
+int tb_pcg_solve(tb_pattern *pat, const double *d_Anz, const double *d_b, double *d_x, double rtol, double atol, int maxiter, int precond,
+                 int partsize, int *iters, double *resnorm);
+int tb_l1gs_apply(tb_pattern *pat, const double *d_Anz, int partsize, int sweep, const double *d_r, double *d_z);
 /* Restarted GMRES(restart) with right Jacobi preconditioning — the reference's default Newton inner solver
  * (LinearSolve.KrylovJL_GMRES(), src/solver/nonlinear/newton_raphson.jl:61) — for tangents that are not symmetric positive definite.
  * Same stopping test as tb_cg_solve on the true residual. */

@@ -42,6 +42,8 @@ class tb_hill(C.Structure):
                 ("sarcomere_kind", C.c_int32), ("active_p", C.c_double * 12), ("sheetlet_part", C.c_double), ("sarcomere_p", C.c_double * 2)]
 
 
+TB_PRECOND_NONE, TB_PRECOND_JACOBI, TB_PRECOND_L1GS = 0, 1, 2
+TB_SWEEP_FORWARD, TB_SWEEP_SYMMETRIC = 0, 2
 TB_LOCAL_SUCCESS, TB_LOCAL_LINEAR_SOLVE_FAILED, TB_LOCAL_MAX_ITERS, TB_LOCAL_CONVERGENCE_FAILURE, TB_LOCAL_INFEASIBLE = 0, 1, 2, 3, 4
 TB_HILL_NONE, TB_HILL_GENERALIZED, TB_HILL_EXTENDED = 0, 1, 2
 TB_ACTIVE_SIMPLE_SPRING = 100
@@ -120,6 +122,8 @@ SIGNATURES = {
     "tb_heat_matrix": (C.c_int, [vp, C.c_int64, vp, vp, C.c_double, vp]),
     "tb_spmv_csr": (C.c_int, [vp, vp, vp, C.c_double, C.c_double, vp]),
     "tb_cg_solve": (C.c_int, [vp, vp, vp, vp, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "tb_pcg_solve": (C.c_int, [vp, vp, vp, vp, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "tb_l1gs_apply": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
     "tb_gmres_solve": (C.c_int, [vp, vp, vp, vp, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "tb_axpy": (C.c_int, [vp, C.c_int64, C.c_double, vp, vp]),
     "tb_absmax": (C.c_int, [vp, C.c_int64, vp, C.c_int64, C.POINTER(C.c_double)]),

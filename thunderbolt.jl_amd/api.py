@@ -1413,10 +1413,11 @@ class NewtonRaphsonSolver:
     solution of J Δu = residual in Δu (device vectors; the CSR structure is `pattern.sp.rowptr/colidx` on the host, J its values on the device)."""
 
     def __init__(self, max_iter=100, tol=1e-4, inner_rtol=1e-8, inner_atol=1e-14, inner_maxiter=5000, enforce_monotonic_convergence=True,
-                 inner_solver="cg", gmres_restart=50):
+                 inner_solver="cg", gmres_restart=50, inner_precond=None):
         if inner_solver not in ("cg", "gmres") and not callable(inner_solver):
             raise ValueError("inner_solver: 'cg', 'gmres' or a callable (pattern, J, residual, Δu) -> linear iterations")
         self.inner_solver, self.gmres_restart = inner_solver, gmres_restart
+        self.inner_precond = inner_precond          # None (Jacobi, device-scalar CG) or L1GSPrecBuilder(partsize)
         self.max_iter, self.tol = max_iter, tol
         self.inner_rtol, self.inner_atol, self.inner_maxiter = inner_rtol, inner_atol, inner_maxiter
         self.enforce_monotonic_convergence = enforce_monotonic_convergence
@@ -1446,6 +1447,8 @@ def nlsolve(u, op, ch, solver, t=0.0):
         du.fill_zero()
         if callable(solver.inner_solver):
             its = solver.inner_solver(op.pattern, op.J, res, du)
+        elif solver.inner_solver == "cg" and solver.inner_precond is not None:
+            its, _ = pcg_solve(op.pattern, op.J, res, du, solver.inner_rtol, solver.inner_atol, solver.inner_maxiter, solver.inner_precond)
         elif solver.inner_solver == "gmres":
             its, _ = gmres_solve(op.pattern, op.J, res, du, solver.inner_rtol, solver.inner_atol, solver.inner_maxiter, solver.gmres_restart, True)
         else:
@@ -1649,6 +1652,28 @@ def cg_solve(pattern, A, b, x, rtol=1e-5, atol=1e-6, maxiter=1000, jacobi=True):
     check(lib().tb_cg_solve(pattern.h, _ptr(A), _ptr(b), _ptr(x), float(rtol), float(atol), int(maxiter), int(jacobi),
                             C.byref(it), C.byref(res)))
     return it.value, res.value
+
+
+class L1GSPrecBuilder:
+    """L1GSPrecBuilder(partsize) (Thunderbolt.Preconditioners, docs/src/api-reference/solver.md:13-22): ℓ₁ Gauss–Seidel with a symmetric
+    sweep over partitions of `partsize` consecutive rows, as a preconditioner of cg_solve / the Newton inner solver."""
+
+    def __init__(self, partsize=64):
+        self.partsize = int(partsize)
+
+
+def pcg_solve(pattern, A, b, x, rtol=1e-5, atol=1e-6, maxiter=1000, precond="jacobi"):
+    """CG with precond = None | "jacobi" | L1GSPrecBuilder(partsize)"""
+    kind, ps = (L.TB_PRECOND_NONE, 1) if precond is None else (L.TB_PRECOND_JACOBI, 1) if precond == "jacobi" else (L.TB_PRECOND_L1GS, precond.partsize)
+    it, res = C.c_int(), C.c_double()
+    check(lib().tb_pcg_solve(pattern.h, _ptr(A), _ptr(b), _ptr(x), float(rtol), float(atol), int(maxiter), kind, ps, C.byref(it), C.byref(res)))
+    return it.value, res.value
+
+
+def l1gs_apply(pattern, A, r, z, partsize=64, sweep="symmetric"):
+    """z = M⁻¹ r of the ℓ₁ Gauss–Seidel preconditioner (ForwardSweep / SymmetricSweep)"""
+    check(lib().tb_l1gs_apply(pattern.h, _ptr(A), int(partsize), L.TB_SWEEP_SYMMETRIC if sweep == "symmetric" else L.TB_SWEEP_FORWARD, _ptr(r), _ptr(z)))
+    return z
 
 
 def gmres_solve(pattern, A, b, x, rtol=1e-8, atol=1e-14, maxiter=5000, restart=50, jacobi=True):

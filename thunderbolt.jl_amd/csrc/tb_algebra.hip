@@ -479,6 +479,144 @@ int launch_gmres(tb_pattern *pat, const double *A, const double *b, double *x, d
     return TB_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// ℓ₁ Gauss–Seidel preconditioner (Baker, Falgout, Kolev, Yang, "Multigrid smoothers for ultraparallel computing", SIAM J. Sci. Comput.
+// 33 (2011), §6) — the preconditioner the reference's documentation lists for its Krylov solves (Thunderbolt.Preconditioners.L1GSPrecBuilder
+// with ForwardSweep / BackwardSweep / SymmetricSweep, docs/src/api-reference/solver.md:13-22; its source is not part of the reference
+// checkout, so this restates the published algorithm: parity unpinned).  Rows are cut into partitions of `ps` consecutive rows; inside a
+// partition the sweep is exact Gauss–Seidel, couplings that leave the partition are moved onto the diagonal by their ℓ₁ norm:
+//   D̃_ii = a_ii + Σ_{j ∉ part(i)} |a_ij|;  forward: (D̃ + L_p) y = r;  symmetric: then (D̃ + U_p) z = D̃ y,
+// i.e. M = (D̃ + L_p) D̃⁻¹ (D̃ + U_p), symmetric positive definite whenever A is.  One wavefront per partition: the rows are visited in
+// order, the lanes share a row's entries; the partition's part of the iterate lives in LDS.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_l1gs_diag(int64_t n, int ps, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const double *__restrict__ nz, double *__restrict__ dt)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int64_t lo = r / ps * ps, hi = lo + ps;
+    double d = 0.0;
+    for (int64_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+        const int32_t c = colidx[k];
+        if (c == r) d += nz[k];
+        else if (c < lo || c >= hi) d += fabs(nz[k]);
+    }
+    dt[r] = d;
+}
+
+template <bool SYMMETRIC>
+__global__ void __launch_bounds__(256)
+k_l1gs_apply(int64_t n, int ps, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const double *__restrict__ nz,
+             const double *__restrict__ dt, const double *__restrict__ r, double *__restrict__ z)
+{
+    extern __shared__ double s_y[]; // [waves per block][ps]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t part = (int64_t)blockIdx.x * (blockDim.x >> 6) + wv;
+    const int64_t lo = part * ps;
+    if (lo >= n) return;
+    const int64_t hi = lo + ps < n ? lo + ps : n;
+    double *y = s_y + (size_t)wv * ps;
+    for (int64_t i = lo; i < hi; ++i) { // forward sweep
+        double acc = 0.0;
+        for (int64_t k = rowptr[i] + lane; k < rowptr[i + 1]; k += 64) {
+            const int32_t c = colidx[k];
+            if (c >= lo && c < i) acc += nz[k] * y[c - lo];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (lane == 0) y[i - lo] = (r[i] - acc) / dt[i];
+        __builtin_amdgcn_wave_barrier();
+    }
+    if constexpr (SYMMETRIC) {
+        for (int64_t i = hi - 1; i >= lo; --i) { // backward sweep: z_i = y_i − Σ_{j > i in the partition} a_ij z_j / D̃_ii, in place
+            double acc = 0.0;
+            for (int64_t k = rowptr[i] + lane; k < rowptr[i + 1]; k += 64) {
+                const int32_t c = colidx[k];
+                if (c > i && c < hi) acc += nz[k] * y[c - lo];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+            if (lane == 0) y[i - lo] -= acc / dt[i];
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    for (int64_t i = lo + lane; i < hi; i += 64) z[i] = y[i - lo];
+}
+
+int launch_l1gs_setup(tb_pattern *pat, const double *A, int ps, double *d_dtilde)
+{
+    tb_device *dev = pat->mesh->dev;
+    const int64_t n = pat->n_rows;
+    hipLaunchKernelGGL(k_l1gs_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, dev->stream, n, ps, pat->d_rowptr, pat->d_colidx, A, d_dtilde);
+    TB_HIP(hipGetLastError());
+    return TB_OK;
+}
+
+int launch_l1gs_apply(tb_pattern *pat, const double *A, const double *d_dtilde, int ps, int symmetric, const double *r, double *z)
+{
+    tb_device *dev = pat->mesh->dev;
+    const int64_t n = pat->n_rows, nparts = (n + ps - 1) / ps;
+    const size_t lds = sizeof(double) * 4 * (size_t)ps;
+    const dim3 grid((unsigned)((nparts + 3) / 4)), block(256);
+    if (symmetric) hipLaunchKernelGGL(k_l1gs_apply<true>, grid, block, lds, dev->stream, n, ps, pat->d_rowptr, pat->d_colidx, A, d_dtilde, r, z);
+    else hipLaunchKernelGGL(k_l1gs_apply<false>, grid, block, lds, dev->stream, n, ps, pat->d_rowptr, pat->d_colidx, A, d_dtilde, r, z);
+    TB_HIP(hipGetLastError());
+    return TB_OK;
+}
+
+// preconditioned CG with a general preconditioner application (two host reads per iteration): z = M⁻¹ r by ℓ₁ Gauss–Seidel
+int launch_pcg_l1gs(tb_pattern *pat, const double *A, const double *b, double *x, double rtol, double atol, int maxiter, int ps, int *iters, double *resnorm)
+{
+    tb_device *dev = pat->mesh->dev;
+    const int64_t n = pat->n_rows;
+    if (!pat->d_pcg_ws) TB_HIP(hipMalloc((void **)&pat->d_pcg_ws, sizeof(double) * (5 * n + 8)));
+    double *r = pat->d_pcg_ws, *z = r + n, *p = z + n, *Ap = p + n, *dtl = Ap + n, *scal = dtl + n;
+    const unsigned g = grid_for(dev, n, 256);
+    int rc = launch_l1gs_setup(pat, A, ps, dtl);
+    if (rc) return rc;
+    rc = launch_spmv(pat, A, x, 1.0, 0.0, Ap);
+    if (rc) return rc;
+    double h[2];
+    TB_HIP(hipMemsetAsync(scal, 0, 2 * sizeof(double), dev->stream));
+    hipLaunchKernelGGL(k_residual, dim3(g), dim3(256), 0, dev->stream, n, b, Ap, r, scal);
+    TB_HIP(hipMemcpyAsync(h, scal, sizeof(double), hipMemcpyDeviceToHost, dev->stream));
+    TB_HIP(hipStreamSynchronize(dev->stream));
+    double rnorm = std::sqrt(h[0]);
+    const double tol = atol + rtol * rnorm;
+    int it = 0;
+    double rz = 0.0;
+    while (rnorm > tol && it < maxiter) {
+        rc = launch_l1gs_apply(pat, A, dtl, ps, 1, r, z);
+        if (rc) return rc;
+        TB_HIP(hipMemsetAsync(scal, 0, 2 * sizeof(double), dev->stream));
+        hipLaunchKernelGGL(k_dot, dim3(g), dim3(256), 0, dev->stream, n, r, z, scal);
+        TB_HIP(hipMemcpyAsync(h, scal, sizeof(double), hipMemcpyDeviceToHost, dev->stream));
+        TB_HIP(hipStreamSynchronize(dev->stream));
+        const double rz_new = h[0];
+        if (it == 0) TB_HIP(hipMemcpyAsync(p, z, sizeof(double) * n, hipMemcpyDeviceToDevice, dev->stream));
+        else hipLaunchKernelGGL(k_cg_direction, dim3(g), dim3(256), 0, dev->stream, n, rz_new / rz, z, (const double *)nullptr, p);
+        rz = rz_new;
+        rc = launch_spmv(pat, A, p, 1.0, 0.0, Ap);
+        if (rc) return rc;
+        TB_HIP(hipMemsetAsync(scal, 0, 2 * sizeof(double), dev->stream));
+        hipLaunchKernelGGL(k_dot, dim3(g), dim3(256), 0, dev->stream, n, p, Ap, scal);
+        TB_HIP(hipMemcpyAsync(h, scal, sizeof(double), hipMemcpyDeviceToHost, dev->stream));
+        TB_HIP(hipStreamSynchronize(dev->stream));
+        if (!(h[0] > 0.0)) { set_error("tb_pcg_solve: matrix is not positive definite (pᵀAp = %g)", h[0]); return TB_ERR_BAD_ARG; }
+        const double alpha = rz / h[0];
+        TB_HIP(hipMemsetAsync(scal, 0, 2 * sizeof(double), dev->stream));
+        hipLaunchKernelGGL(k_cg_update, dim3(g), dim3(256), 0, dev->stream, n, alpha, p, Ap, (const double *)nullptr, x, r, scal);
+        TB_HIP(hipMemcpyAsync(h, scal, 2 * sizeof(double), hipMemcpyDeviceToHost, dev->stream));
+        TB_HIP(hipStreamSynchronize(dev->stream));
+        rnorm = std::sqrt(h[1]);
+        ++it;
+    }
+    TB_HIP(hipGetLastError());
+    if (iters) *iters = it;
+    if (resnorm) *resnorm = rnorm;
+    return TB_OK;
+}
+
 // apply_zero!(K, f, ch) on device CSR (Ferrite.apply_zero!; CSR method src/utils.jl:263-278, call sites
 // src/solver/nonlinear/nlsolve_common.jl:12-26): rows and columns of prescribed dofs are zeroed, their diagonal entry is set
 // to `diag` (Ferrite uses the mean diagonal so the conditioning survives), f is zeroed there.  8 lanes per row.

@@ -298,7 +298,7 @@ int tb_pattern_create(tb_mesh *mesh, int64_t n_rows, const int64_t *rowptr, cons
 int tb_pattern_destroy(tb_pattern *p)
 {
     if (!p) return TB_OK;
-    hipFree(p->d_rowptr); hipFree(p->d_colidx); hipFree(p->d_emap); hipFree(p->d_blockpos); hipFree(p->d_cg_ws); hipFree(p->d_gmres_ws); hipFree(p->d_kebuf);
+    hipFree(p->d_rowptr); hipFree(p->d_colidx); hipFree(p->d_emap); hipFree(p->d_blockpos); hipFree(p->d_cg_ws); hipFree(p->d_gmres_ws); hipFree(p->d_pcg_ws); hipFree(p->d_kebuf);
     free_patch_mat_plan(p);
     delete p;
     return TB_OK;
@@ -906,6 +906,31 @@ int tb_cg_solve(tb_pattern *pat, const double *d_Anz, const double *d_b, double 
     TB_REQUIRE(rtol >= 0 && atol >= 0 && maxiter >= 0, "tb_cg_solve: negative tolerance or iteration limit");
     TB_HIP(hipSetDevice(pat->mesh->dev->id));
     return launch_cg(pat, d_Anz, d_b, d_x, rtol, atol, maxiter, jacobi, iters, resnorm);
+}
+
+int tb_pcg_solve(tb_pattern *pat, const double *d_Anz, const double *d_b, double *d_x, double rtol, double atol, int maxiter, int precond, int partsize,
+                 int *iters, double *resnorm)
+{
+    TB_REQUIRE(pat && d_Anz && d_b && d_x, "tb_pcg_solve: NULL argument");
+    TB_REQUIRE(rtol >= 0 && atol >= 0 && maxiter >= 0, "tb_pcg_solve: negative tolerance or iteration limit");
+    TB_REQUIRE(precond >= TB_PRECOND_NONE && precond <= TB_PRECOND_L1GS, "tb_pcg_solve: unknown preconditioner %d", precond);
+    TB_HIP(hipSetDevice(pat->mesh->dev->id));
+    if (precond != TB_PRECOND_L1GS) return launch_cg(pat, d_Anz, d_b, d_x, rtol, atol, maxiter, precond == TB_PRECOND_JACOBI, iters, resnorm);
+    TB_REQUIRE(partsize >= 1 && partsize <= 1024, "tb_pcg_solve: partition size must be in 1..1024 (got %d)", partsize);
+    return launch_pcg_l1gs(pat, d_Anz, d_b, d_x, rtol, atol, maxiter, partsize, iters, resnorm);
+}
+
+int tb_l1gs_apply(tb_pattern *pat, const double *d_Anz, int partsize, int sweep, const double *d_r, double *d_z)
+{
+    TB_REQUIRE(pat && d_Anz && d_r && d_z, "tb_l1gs_apply: NULL argument");
+    TB_REQUIRE(partsize >= 1 && partsize <= 1024, "tb_l1gs_apply: partition size must be in 1..1024 (got %d)", partsize);
+    TB_REQUIRE(sweep == TB_SWEEP_FORWARD || sweep == TB_SWEEP_SYMMETRIC, "tb_l1gs_apply: sweep must be TB_SWEEP_FORWARD or TB_SWEEP_SYMMETRIC");
+    TB_HIP(hipSetDevice(pat->mesh->dev->id));
+    if (!pat->d_pcg_ws) TB_HIP(hipMalloc((void **)&pat->d_pcg_ws, sizeof(double) * (5 * pat->n_rows + 8)));
+    double *dtl = pat->d_pcg_ws + 4 * pat->n_rows;
+    int rc = launch_l1gs_setup(pat, d_Anz, partsize, dtl);
+    if (rc) return rc;
+    return launch_l1gs_apply(pat, d_Anz, dtl, partsize, sweep == TB_SWEEP_SYMMETRIC, d_r, d_z);
 }
 
 int tb_gmres_solve(tb_pattern *pat, const double *d_Anz, const double *d_b, double *d_x, double rtol, double atol, int maxiter, int restart,

@@ -135,6 +135,7 @@ struct tb_pattern {
     bool map64 = false;
     void *d_emap = nullptr; // [ndpc*ndpc][n_cells] nz index of (cell,i,j): int32 (nnz < 2^31) or int64
     double *d_cg_ws = nullptr;      // CG workspace (r, p, Ap, D⁻¹, 2 scalars)
+    double *d_pcg_ws = nullptr;     // general-preconditioner PCG workspace (r, z, p, Ap, D̃, scalars)
     double *d_gmres_ws = nullptr;   // GMRES workspace: (restart+1) basis vectors + 3 vectors + scalars
     int gmres_m = 0;
     double *d_kebuf = nullptr;      // element-matrix buffer of the ElementAssemblyStrategy (vector fields)
@@ -223,6 +224,9 @@ void host_sarcomere_derivatives(const double *params, const double *u, double st
                                 double *gv, double *rhs);
 void host_sarcomere_eval(const double *params, const double *u, double stretch, double velocity, double calcium, double *du, double *tension,
                          double *stiffness);
+int launch_l1gs_setup(tb_pattern *pat, const double *A, int ps, double *d_dtilde);
+int launch_l1gs_apply(tb_pattern *pat, const double *A, const double *d_dtilde, int ps, int symmetric, const double *r, double *z);
+int launch_pcg_l1gs(tb_pattern *pat, const double *A, const double *b, double *x, double rtol, double atol, int maxiter, int ps, int *iters, double *resnorm);
 int launch_gmres(tb_pattern *pat, const double *A, const double *b, double *x, double rtol, double atol, int maxiter, int restart, int jacobi,
                  int *iters, double *resnorm);
 int launch_cg(tb_pattern *pat, const double *A, const double *b, double *x, double rtol, double atol, int maxiter, int jacobi, int *iters,
