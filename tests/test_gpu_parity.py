@@ -171,6 +171,81 @@ def test_error_codes(tb, oracle, device):
                           tb.SparsityPattern(sp.rowptr[:-1], sp.colidx))
 
 
+def test_argument_checks_of_the_mechanics_and_sarcomere_entry_points(tb, device):
+    """Every misuse is an error code with a message, never a crash or a silent no-op: the failure behaviour the drop-in boundary
+    promises, for the entry points added around the mechanics path."""
+    import ctypes as C
+    L = tb._lib
+    lib = tb.lib()
+    g = tb.generate_mesh(tb.Hexahedron, (2, 2, 2))
+    dh = tb.DofHandler(g, tb.LagrangeCollection(1) ** 3)
+    sp = tb.allocate_matrix(dh)
+    ms = tb.ConstantCoefficient(tb.OrthotropicMicrostructure([1.0, 0, 0], [0, 1.0, 0], [0, 0, 1.0]))
+    op = tb.setup_operator(tb.PerColorAssemblyStrategy(device), tb.QuasiStaticModel("u", tb.PK1Model(tb.HolzapfelOgden2009Model(), ms)), dh, sp)
+    form = op.form
+    p17 = tb.RDQ20MFModel().params()
+    dp = p17.ctypes.data_as(L.c_dp)
+
+    def bad(rc):
+        assert rc != 0 and len(lib.tb_last_error_string()) > 0
+    # condensation: wrong model id / parameter count / tolerances; internal state without condensation; zero or negative Δt
+    bad(lib.tb_hyperelastic_set_condensation(form, 0, dp, 17, 1.0, 1e-4, 10))
+    bad(lib.tb_hyperelastic_set_condensation(form, L.TB_SARCOMERE_RDQ20MF, dp, 16, 1.0, 1e-4, 10))
+    bad(lib.tb_hyperelastic_set_condensation(form, L.TB_SARCOMERE_RDQ20MF, dp, 17, 1.0, -1.0, 10))
+    bad(lib.tb_hyperelastic_set_condensation(form, L.TB_SARCOMERE_RDQ20MF, dp, 17, 1.0, 1e-4, 0))
+    q = device.zeros(20 * g.n_cells * 8)
+    bad(lib.tb_hyperelastic_set_internal_state(form, q.ptr, q.ptr, 0.5))
+    bad(lib.tb_hyperelastic_set_previous_solution(form, q.ptr))
+    bad(lib.tb_hyperelastic_local_solve_report(form, None, None, 0))
+    assert lib.tb_hyperelastic_set_condensation(form, L.TB_SARCOMERE_RDQ20MF, dp, 17, 1.0, 1e-4, 10) == 0
+    bad(lib.tb_hyperelastic_set_internal_state(form, q.ptr, q.ptr, 0.0))
+    bad(lib.tb_hyperelastic_set_internal_state(form, None, q.ptr, 0.5))
+    u, r = device.zeros(dh.ndofs), device.zeros(dh.ndofs)
+    bad(lib.tb_residual(form, op.strategy.code, u.ptr, 0.0, r.ptr))                     # condensed but no internal state given yet
+    # a prestress and a Hill framework exclude the condensed state
+    G = np.eye(3).ravel()
+    bad(lib.tb_hyperelastic_set_prestress(form, G.ctypes.data_as(L.c_dp)))
+    assert lib.tb_hyperelastic_set_condensation(form, -1, None, 0, 0.0, 0.0, 1) == 0      # off again
+    assert lib.tb_hyperelastic_set_prestress(form, G.ctypes.data_as(L.c_dp)) == 0
+    bad(lib.tb_hyperelastic_set_condensation(form, L.TB_SARCOMERE_RDQ20MF, dp, 17, 1.0, 1e-4, 10))
+    assert lib.tb_hyperelastic_set_prestress(form, None) == 0
+    h = L.tb_hill()
+    h.framework = 7
+    bad(lib.tb_hyperelastic_set_hill(form, C.byref(h)))
+    h.framework, h.active_energy = L.TB_HILL_EXTENDED, 55
+    bad(lib.tb_hyperelastic_set_hill(form, C.byref(h)))
+    h.active_energy, h.adg_kind = 7, 9
+    bad(lib.tb_hyperelastic_set_hill(form, C.byref(h)))
+    # cell sets: out of range, duplicates, wrong base; the element strategy refuses subdomain / accumulating forms
+    cells = np.array([0, 1, 99], dtype=np.int32)
+    bad(lib.tb_form_set_cellset(form, cells.ctypes.data_as(L.c_i32p), 3, 0))
+    cells = np.array([0, 1, 1], dtype=np.int32)
+    bad(lib.tb_form_set_cellset(form, cells.ctypes.data_as(L.c_i32p), 3, 0))
+    bad(lib.tb_form_set_cellset(form, cells.ctypes.data_as(L.c_i32p), 2, 5))
+    cells = np.array([0, 3], dtype=np.int32)
+    assert lib.tb_form_set_cellset(form, cells.ctypes.data_as(L.c_i32p), 2, 0) == 0
+    rc = lib.tb_residual(form, L.TB_STRATEGY_ELEMENT, u.ptr, 0.0, r.ptr)
+    assert rc == L.TB_ERR_UNSUPPORTED
+    assert lib.tb_residual(form, L.TB_STRATEGY_ATOMIC, u.ptr, 0.0, r.ptr) == 0
+    assert lib.tb_form_clear_cellset(form) == 0 and lib.tb_residual(form, L.TB_STRATEGY_ELEMENT, u.ptr, 0.0, r.ptr) == 0
+    # sarcomere kernels
+    st = device.zeros(20 * 8)
+    bad(lib.tb_sarcomere_step(device.h, 7, dp, 17, st.ptr, 8, None, None, None, 1.0, 0.0, 0.5, 0.0, 0.01, 1, 0, None, None))
+    bad(lib.tb_sarcomere_step(device.h, L.TB_SARCOMERE_RDQ20MF, dp, 12, st.ptr, 8, None, None, None, 1.0, 0.0, 0.5, 0.0, 0.01, 1, 0, None, None))
+    bad(lib.tb_sarcomere_step(device.h, L.TB_SARCOMERE_RDQ20MF, dp, 17, st.ptr, 8, None, None, None, 1.0, 0.0, 0.5, 0.0, 0.01, 0, 0, None, None))
+    bad(lib.tb_sarcomere_step(device.h, L.TB_SARCOMERE_RDQ20MF, dp, 17, None, 8, None, None, None, 1.0, 0.0, 0.5, 0.0, 0.01, 1, 0, None, None))
+    nf = C.c_int64()
+    bad(lib.tb_sarcomere_implicit_step(device.h, L.TB_SARCOMERE_RDQ20MF, dp, 17, st.ptr, st.ptr, 8, None, None, None, 1.0, 0.0, 0.5, -1.0, 1e-4, 10, None, None, None, C.byref(nf)))
+    bad(lib.tb_sarcomere_implicit_step(device.h, L.TB_SARCOMERE_RDQ20MF, dp, 17, st.ptr, st.ptr, 8, None, None, None, 1.0, 0.0, 0.5, 0.5, 1e-4, 10, None, st.ptr, None, C.byref(nf)))
+    # linear solvers
+    x, b = device.zeros(dh.ndofs), device.zeros(dh.ndofs)
+    it, res = C.c_int(), C.c_double()
+    bad(lib.tb_pcg_solve(op.pattern.h, op.J.ptr, b.ptr, x.ptr, 1e-8, 0.0, 10, 9, 64, C.byref(it), C.byref(res)))
+    bad(lib.tb_pcg_solve(op.pattern.h, op.J.ptr, b.ptr, x.ptr, 1e-8, 0.0, 10, L.TB_PRECOND_L1GS, 0, C.byref(it), C.byref(res)))
+    bad(lib.tb_gmres_solve(op.pattern.h, op.J.ptr, b.ptr, x.ptr, 1e-8, 0.0, 10, 0, 1, C.byref(it), C.byref(res)))
+    bad(lib.tb_l1gs_apply(op.pattern.h, op.J.ptr, 64, 1, b.ptr, x.ptr))
+
+
 # ------------------------------------------------------------------------------------------- reaction
 MODELS = [("FHNModel", "CELL_FHN"), ("AlievPanfilovModel", "CELL_ALIEV_PANFILOV"), ("PCG2019", "CELL_PCG2019"), ("TT06", "CELL_TT06")]
 
