@@ -246,6 +246,57 @@ def test_argument_checks_of_the_mechanics_and_sarcomere_entry_points(tb, device)
     bad(lib.tb_l1gs_apply(op.pattern.h, op.J.ptr, 64, 1, b.ptr, x.ptr))
 
 
+def test_q2_scalar_forms_parity(tb, oracle, device):
+    """Mass, diffusion and linear forms on the triquadratic scalar field (LagrangeCollection{2} on hexahedra: 27×27 element matrices,
+    mass.jl:28-43, diffusion.jl:28-50, analytical_coefficient.jl:80-101) against the oracle on a distorted mesh; K·1 = 0, Σ M = volume;
+    strategies and coefficient kinds that are not implemented for this field are refused, not approximated."""
+    g = tb.generate_mesh(tb.Hexahedron, (4, 3, 3), (0, 0, 0), (1.0, 0.7, 0.5), perturb=0.15)
+    dh = tb.DofHandler(g, tb.LagrangeCollection(2))
+    assert dh.cell_dofs.shape[1] == 27
+    sp = tb.allocate_matrix(dh)
+    om = oracle.Mesh(oracle.HEX27, 3, g.xyz, g.conn, dh.cell_dofs)
+    full = np.array([[2.0, 0.3, 0.1], [0.3, 1.5, -0.2], [0.1, -0.2, 1.0]])
+    nonsym = np.array([[2.0, 0.5, 0.0], [-0.1, 1.5, 0.2], [0.3, 0.0, 1.0]])
+    import scipy.sparse as ssp
+    for st in (tb.AtomicAssemblyStrategy(device), tb.PerColorAssemblyStrategy(device)):
+        M = tb.update_operator(tb.setup_operator(st, tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.7)), dh, sp), 0.0)
+        Mref = oracle.assemble_matrix(om, 0, oracle.Coef(oracle.COEF_CONST_SCALAR, [1.7]), sp.rowptr, sp.colidx)
+        assert rel_err(M.A.to_host(), Mref) < TOL
+        np.testing.assert_allclose(M.A.to_host().sum(), 1.7 * 1.0 * 0.7 * 0.5, rtol=1e-12)
+        for D in (full, nonsym):
+            K = tb.update_operator(tb.setup_operator(st, tb.BilinearDiffusionIntegrator(tb.ConstantCoefficient(D)), dh, sp), 0.0)
+            Kref = oracle.assemble_matrix(om, 1, oracle.Coef(oracle.COEF_CONST_TENSOR, D.ravel()), sp.rowptr, sp.colidx)
+            assert rel_err(K.A.to_host(), Kref) < TOL
+            Km = ssp.csr_matrix((K.A.to_host(), sp.colidx, sp.rowptr), shape=(dh.ndofs, dh.ndofs))
+            assert np.abs(Km @ np.ones(dh.ndofs)).max() < 1e-12 * np.abs(Kref).max()
+        Kw = tb.update_operator(tb.setup_operator(st, tb.BilinearDiffusionIntegrator(
+            tb.ConductivityToDiffusivityCoefficient(tb.ConstantCoefficient(full), tb.ConstantCoefficient(2.0), tb.ConstantCoefficient(0.5))), dh, sp), 0.0)
+        Kwref = oracle.assemble_matrix(om, 1, oracle.Coef(oracle.COEF_CONST_TENSOR, full.ravel(), Cm=2.0, chi=0.5, wrap=True), sp.rowptr, sp.colidx)
+        assert rel_err(Kw.A.to_host(), Kwref) < TOL
+        for name, oid, t in (("cos_exp", oracle.SRC_COS_EXP, 0.1), ("norm_plus_t", oracle.SRC_NORM_PLUS_T, 0.3)):
+            b = tb.update_operator(tb.setup_operator(st, tb.LinearIntegrator(tb.AnalyticalCoefficient(name)), dh), t)
+            assert rel_err(b.b.to_host(), oracle.assemble_source(om, oid, t=t)) < TOL
+        one = tb.update_operator(tb.setup_operator(st, tb.LinearIntegrator(tb.AnalyticalCoefficient("const", 1.0)), dh), 0.0)
+        Mu = tb.update_operator(tb.setup_operator(st, tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.0)), dh, sp), 0.0)
+        Mm = ssp.csr_matrix((Mu.A.to_host(), sp.colidx, sp.rowptr), shape=(dh.ndofs, dh.ndofs))
+        np.testing.assert_allclose(one.b.to_host(), Mm @ np.ones(dh.ndofs), rtol=1e-11, atol=1e-15)        # ∫ 1·Nⱼ = (M·1)ⱼ
+    with pytest.raises(tb.TBError) as e:
+        tb.update_operator(tb.setup_operator(tb.PatchAssemblyStrategy(device), tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.0)), dh, sp), 0.0)
+    assert e.value.code == tb._lib.TB_ERR_UNSUPPORTED
+    # a heat step on the quadratic field: A = M − Δt K is symmetric positive definite, CG converges to scipy's solution
+    import scipy.sparse.linalg as sla
+    st = tb.PerColorAssemblyStrategy(device)
+    M = tb.update_operator(tb.setup_operator(st, tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.0)), dh, sp), 0.0)
+    K = tb.update_operator(tb.setup_operator(st, tb.BilinearDiffusionIntegrator(tb.ConstantCoefficient(full * 1e-2)), dh, sp), 0.0)
+    A = device.zeros(sp.nnz)
+    tb.check(tb.lib().tb_heat_matrix(device.h, sp.nnz, M.A.ptr, K.A.ptr, 0.5, A.ptr))
+    rhs = np.random.default_rng(3).normal(size=dh.ndofs)
+    x = device.zeros(dh.ndofs)
+    tb.cg_solve(M.pattern, A, device.to_device(rhs), x, rtol=1e-12, atol=0.0, maxiter=2000)
+    xref = sla.spsolve(ssp.csr_matrix((A.to_host(), sp.colidx, sp.rowptr), shape=(dh.ndofs, dh.ndofs)).tocsc(), rhs)
+    assert np.abs(x.to_host() - xref).max() < 1e-9 * np.abs(xref).max()
+
+
 # ------------------------------------------------------------------------------------------- reaction
 MODELS = [("FHNModel", "CELL_FHN"), ("AlievPanfilovModel", "CELL_ALIEV_PANFILOV"), ("PCG2019", "CELL_PCG2019"), ("TT06", "CELL_TT06")]
 

@@ -644,6 +644,189 @@ static int run_matrix_form(tb_form *f, tb_pattern *p, int strategy, double t, do
     return run_matrix_coef<E, TB_FORM_DIFFUSION>(f, p, strategy, t, d_nz);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Scalar forms on the triquadratic field (Lagrange order 2 on hexahedra, 27 dofs and 27 Gauss points per cell): Mₑ, Kₑ are 27×27 —
+// too large for the one-thread-per-cell register kernels above, so one workgroup integrates one cell: geometry per point, mapped
+// gradients and D·∇N in LDS, then every lane sums its (i, j) entries over the points and adds them through a per-cell table of row
+// positions.  Constant coefficients (the reference's mass.jl:28-43 / diffusion.jl:28-50 with ConstantCoefficient); sources as above.
+// ------------------------------------------------------------------------------------------------
+struct Q2Tables { double N[27][27], dN[27][27][3], dM[27][8][3], M[27][8], w[27]; };
+constexpr Q2Tables make_q2_tables()
+{
+    Q2Tables t{};
+    for (int q = 0; q < 27; ++q) {
+        t.w[q] = Hex27::w(q);
+        for (int a = 0; a < 27; ++a) { t.N[q][a] = Hex27::N(q, a); for (int d = 0; d < 3; ++d) t.dN[q][a][d] = Hex27::dN(q, a, d); }
+        for (int a = 0; a < 8; ++a) { t.M[q][a] = Hex27::M(q, a); for (int d = 0; d < 3; ++d) t.dM[q][a][d] = Hex27::dM(q, a, d); }
+    }
+    return t;
+}
+__constant__ Q2Tables g_q2_tables = make_q2_tables();
+
+// position of column dof(j) inside row dof(i), per cell and pair (cell-major: one coalesced 729-entry read per workgroup)
+__global__ void k_build_q2pos(const int32_t *__restrict__ cell_dofs, int64_t n_cells, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+                              uint16_t *__restrict__ pos, Status *st)
+{
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= n_cells * 729) return;
+    const int64_t cell = tid / 729;
+    const int i = (int)(tid % 729) / 27, j = (int)(tid % 27);
+    const int32_t *d = cell_dofs + cell * 27;
+    const int32_t row = d[i], col = d[j];
+    const int64_t lo0 = rowptr[row], hi0 = rowptr[row + 1];
+    int64_t lo = lo0, hi = hi0;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (colidx[mid] < col) lo = mid + 1; else hi = mid;
+    }
+    if (lo >= hi0 || colidx[lo] != col || lo - lo0 > 0xFFFF) { st->pattern_missing = 1; st->cell = cell; lo = lo0; }
+    pos[tid] = (uint16_t)(lo - lo0);
+}
+
+// geometry of the 27 points of a cell: J⁻¹ (9) and dΩ into s_geo[q][0..9]; x_q into s_xq when asked for
+__device__ __forceinline__ void q2_geometry(const double *s_x, int q, double *geo, double *xq, int64_t cell, Status *st)
+{
+    const Q2Tables &tb = g_q2_tables;
+    double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) J[i][k] += s_x[3 * a + i] * tb.dM[q][a][k];
+    const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1], c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2], c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+    const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02, id = 1.0 / det;
+    geo[0] = c00 * id; geo[1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * id; geo[2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * id;
+    geo[3] = c01 * id; geo[4] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * id; geo[5] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * id;
+    geo[6] = c02 * id; geo[7] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * id; geo[8] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * id;
+    geo[9] = det * tb.w[q];
+    if (!(geo[9] > 0.0)) { st->neg_detj = 1; st->cell = cell; }
+    if (xq) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { double v = 0.0; for (int a = 0; a < 8; ++a) v += tb.M[q][a] * s_x[3 * a + i]; xq[i] = v; }
+    }
+}
+
+template <int FORM>
+__global__ void __launch_bounds__(256)
+k_matrix_q2(MeshView m, FormArgs fa, const int32_t *__restrict__ list, const int64_t *__restrict__ rowptr, const uint16_t *__restrict__ pos, double *__restrict__ nz,
+            int atomic, Status *st)
+{
+    const Q2Tables &tb = g_q2_tables;
+    const int64_t cell = list ? list[blockIdx.x] : blockIdx.x;
+    const int tid = threadIdx.x;
+    __shared__ double s_x[24], s_geo[27][10];
+    __shared__ double s_G[FORM == TB_FORM_DIFFUSION ? 27 : 1][27][3], s_T[FORM == TB_FORM_DIFFUSION ? 27 : 1][27][3];
+    __shared__ double s_N[FORM == TB_FORM_MASS ? 27 : 1][27];
+    __shared__ int32_t s_dof[27];
+    if (tid < 27) s_dof[tid] = m.cell_dofs[cell * 27 + tid];
+    for (int i = tid; i < 24; i += 256) s_x[i] = m.xyz[3 * (int64_t)m.conn[cell * 8 + i / 3] + i % 3];
+    if constexpr (FORM == TB_FORM_MASS) for (int i = tid; i < 729; i += 256) s_N[i / 27][i % 27] = tb.N[i / 27][i % 27];
+    __syncthreads();
+    if (tid < 27) q2_geometry(s_x, tid, s_geo[tid], nullptr, cell, st);
+    __syncthreads();
+    if constexpr (FORM == TB_FORM_DIFFUSION) {
+        // ∇Nₐ = ∂Nₐ/∂ξ · J⁻¹ and T = dΩ · D · ∇Nₐ for every (point, node)
+        for (int idx = tid; idx < 729; idx += 256) {
+            const int q = idx / 27, a = idx % 27;
+            const double *ji = s_geo[q];
+            const double d0 = tb.dN[q][a][0], d1 = tb.dN[q][a][1], d2 = tb.dN[q][a][2];
+            double gk[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) gk[k] = d0 * ji[k] + d1 * ji[3 + k] + d2 * ji[6 + k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                s_G[q][a][k] = gk[k];
+                s_T[q][a][k] = ji[9] * (fa.D[3 * k] * gk[0] + fa.D[3 * k + 1] * gk[1] + fa.D[3 * k + 2] * gk[2]);
+            }
+        }
+        __syncthreads();
+    }
+    const int64_t pbase = cell * 729;
+    for (int e = tid; e < 729; e += 256) {
+        const int i = e / 27, j = e % 27;
+        double v = 0.0;
+        if constexpr (FORM == TB_FORM_MASS) {
+            // Mₑ[i,j] += ρ·Nᵢ·Nⱼ·dΩ  (mass.jl:32-42)
+            for (int q = 0; q < 27; ++q) v += fa.rho * s_geo[q][9] * s_N[q][i] * s_N[q][j];
+        } else {
+            // Kₑ[i,j] −= (∇Nⱼ·D·∇Nᵢ)·dΩ  (diffusion.jl:38-49; argument order of _inner_product_helper, utils.jl:409-410)
+            for (int q = 0; q < 27; ++q) v -= s_G[q][j][0] * s_T[q][i][0] + s_G[q][j][1] * s_T[q][i][1] + s_G[q][j][2] * s_T[q][i][2];
+        }
+        const int64_t k = rowptr[s_dof[i]] + pos[pbase + e];
+        if (atomic) unsafeAtomicAdd(nz + k, v); else nz[k] += v;
+    }
+}
+
+__global__ void __launch_bounds__(64)
+k_vector_q2(MeshView m, FormArgs fa, const int32_t *__restrict__ list, double *__restrict__ b, int atomic, Status *st)
+{
+    const Q2Tables &tb = g_q2_tables;
+    const int64_t cell = list ? list[blockIdx.x] : blockIdx.x;
+    const int tid = threadIdx.x;
+    __shared__ double s_x[24], s_fw[27];
+    for (int i = tid; i < 24; i += 64) s_x[i] = m.xyz[3 * (int64_t)m.conn[cell * 8 + i / 3] + i % 3];
+    __syncthreads();
+    if (tid < 27) {
+        double geo[10], xq[3];
+        q2_geometry(s_x, tid, geo, xq, cell, st);
+        s_fw[tid] = eval_source(fa, xq, cell, tid, 27) * geo[9];
+    }
+    __syncthreads();
+    if (tid < 27) { // bₑ[j] += f(x_q,t)·Nⱼ·dΩ  (analytical_coefficient.jl:89-99)
+        double v = 0.0;
+        for (int q = 0; q < 27; ++q) v += s_fw[q] * tb.N[q][tid];
+        const int32_t d = m.cell_dofs[cell * 27 + tid];
+        if (atomic) unsafeAtomicAdd(b + d, v); else b[d] += v;
+    }
+}
+
+static int ensure_q2pos(tb_pattern *p)
+{
+    if (p->d_q2pos) return TB_OK;
+    tb_mesh *m = p->mesh;
+    const int64_t n = m->n_cells * 729;
+    TB_HIP(hipMalloc((void **)&p->d_q2pos, sizeof(uint16_t) * n));
+    int rc = reset_status(m->dev);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_build_q2pos, dim3(nblocks(n, 256)), dim3(256), 0, m->dev->stream, m->d_cell_dofs, m->n_cells, p->d_rowptr, p->d_colidx, p->d_q2pos,
+                       m->dev->d_status);
+    TB_HIP(hipGetLastError());
+    return check_status(m->dev);
+}
+
+static int run_q2(tb_form *f, tb_pattern *p, int strategy, double t, double *d_nz, double *d_b)
+{
+    tb_mesh *m = f->mesh;
+    tb_device *dev = m->dev;
+    if (f->field) { set_error("Q2 scalar forms take constant coefficients (field coefficients are implemented for first-order fields)"); return TB_ERR_UNSUPPORTED; }
+    const MeshView mv = make_view(m);
+    const FormArgs fa = make_args(f, t);
+    if (d_nz) { int rc = ensure_q2pos(p); if (rc) return rc; TB_HIP(hipMemsetAsync(d_nz, 0, (size_t)p->nnz * sizeof(double), dev->stream)); }
+    else TB_HIP(hipMemsetAsync(d_b, 0, (size_t)m->ndofs * sizeof(double), dev->stream));
+    auto go = [&](const int32_t *list, int64_t n, int atomic) -> int {
+        if (n == 0) return TB_OK;
+        if (d_nz && f->kind == TB_FORM_MASS)
+            hipLaunchKernelGGL(k_matrix_q2<TB_FORM_MASS>, dim3((unsigned)n), dim3(256), 0, dev->stream, mv, fa, list, p->d_rowptr, p->d_q2pos, d_nz, atomic, dev->d_status);
+        else if (d_nz)
+            hipLaunchKernelGGL(k_matrix_q2<TB_FORM_DIFFUSION>, dim3((unsigned)n), dim3(256), 0, dev->stream, mv, fa, list, p->d_rowptr, p->d_q2pos, d_nz, atomic, dev->d_status);
+        else hipLaunchKernelGGL(k_vector_q2, dim3((unsigned)n), dim3(64), 0, dev->stream, mv, fa, list, d_b, atomic, dev->d_status);
+        TB_HIP(hipGetLastError());
+        return TB_OK;
+    };
+    if (strategy == TB_STRATEGY_ATOMIC) return go(nullptr, m->n_cells, 1);
+    if (strategy == TB_STRATEGY_PER_COLOR) {
+        if (!m->colors) { int rc = build_color_plan(m); if (rc) return rc; }
+        for (int c = 0; c < m->colors->ncolors; ++c) {
+            int rc = go(m->colors->d_cells + m->colors->offsets[c], m->colors->offsets[c + 1] - m->colors->offsets[c], 0);
+            if (rc) return rc;
+        }
+        return TB_OK;
+    }
+    set_error("Q2 scalar forms: strategy %d not supported (use TB_STRATEGY_ATOMIC or TB_STRATEGY_PER_COLOR)", strategy);
+    return TB_ERR_UNSUPPORTED;
+}
+
 int launch_assemble_matrix(tb_form *f, tb_pattern *p, int strategy, double t, double *d_nz)
 {
     tb_mesh *m = f->mesh;
@@ -652,6 +835,7 @@ int launch_assemble_matrix(tb_form *f, tb_pattern *p, int strategy, double t, do
     if (m->field_kind == TB_HEX8 && f->qorder == 2) rc = run_matrix_form<Hex8<2>>(f, p, strategy, t, d_nz);
     else if (m->field_kind == TB_TET4 && f->qorder == 2) rc = run_matrix_form<Tet4<2>>(f, p, strategy, t, d_nz);
     else if (m->field_kind == TB_QUAD4 && f->qorder == 2) rc = run_matrix_form<Quad4<2>>(f, p, strategy, t, d_nz);
+    else if (m->field_kind == TB_HEX27 && f->qorder == 3) rc = run_q2(f, p, strategy, t, d_nz, nullptr);
     else {
         set_error("matrix assembly: field kind %d with quadrature order %d not implemented", m->field_kind, f->qorder);
         return TB_ERR_UNSUPPORTED;
@@ -718,6 +902,7 @@ int launch_assemble_vector(tb_form *f, int strategy, double t, double *d_b)
     else if (m->field_kind == TB_HEX8 && f->qorder == 3) rc = run_vector<Hex8<3>>(f, strategy, t, d_b);
     else if (m->field_kind == TB_TET4 && f->qorder == 2) rc = run_vector<Tet4<2>>(f, strategy, t, d_b);
     else if (m->field_kind == TB_QUAD4 && f->qorder == 2) rc = run_vector<Quad4<2>>(f, strategy, t, d_b);
+    else if (m->field_kind == TB_HEX27 && f->qorder == 3) rc = run_q2(f, nullptr, strategy, t, nullptr, d_b);
     else {
         set_error("vector assembly: field kind %d with quadrature order %d not implemented", m->field_kind, f->qorder);
         return TB_ERR_UNSUPPORTED;

@@ -52,6 +52,32 @@ template <int ORDER> struct Hex8 {
     TB_HD static constexpr double dM(int q, int a, int d) { return dN(q, a, d); }
 };
 
+// ---- Hex27: triquadratic Lagrange field on the trilinear hexahedron, 3×3×3 Gauss points.  Ferrite Lagrange{RefHexahedron,2} local
+// numbering: vertices, edges, faces, volume (the tensor index per direction below).  Used by the scalar Q2 forms (block-per-cell kernels).
+struct Hex27 {
+    static constexpr int NB = 27, NQ = 27, NV = 8;
+    TB_HD static constexpr int tix(int a, int d)
+    {
+        constexpr int T[27][3] = {{0, 0, 0}, {2, 0, 0}, {2, 2, 0}, {0, 2, 0}, {0, 0, 2}, {2, 0, 2}, {2, 2, 2}, {0, 2, 2}, {1, 0, 0},
+                                  {2, 1, 0}, {1, 2, 0}, {0, 1, 0}, {1, 0, 2}, {2, 1, 2}, {1, 2, 2}, {0, 1, 2}, {0, 0, 1}, {2, 0, 1},
+                                  {2, 2, 1}, {0, 2, 1}, {1, 1, 0}, {1, 0, 1}, {2, 1, 1}, {1, 2, 1}, {0, 1, 1}, {1, 1, 2}, {1, 1, 1}};
+        return T[a][d];
+    }
+    TB_HD static constexpr double q1(int i, double x) { return i == 0 ? 0.5 * x * (x - 1.0) : i == 1 ? (1.0 - x * x) : 0.5 * x * (x + 1.0); }
+    TB_HD static constexpr double dq1(int i, double x) { return i == 0 ? x - 0.5 : i == 1 ? -2.0 * x : x + 0.5; }
+    TB_HD static constexpr int qi(int q, int d) { return d == 0 ? q % 3 : d == 1 ? (q / 3) % 3 : q / 9; }
+    TB_HD static constexpr double xi(int q, int d) { return Gauss<3>::x(qi(q, d)); }
+    TB_HD static constexpr double w(int q) { return Gauss<3>::w(qi(q, 0)) * Gauss<3>::w(qi(q, 1)) * Gauss<3>::w(qi(q, 2)); }
+    TB_HD static constexpr double N(int q, int a) { return q1(tix(a, 0), xi(q, 0)) * q1(tix(a, 1), xi(q, 1)) * q1(tix(a, 2), xi(q, 2)); }
+    TB_HD static constexpr double dN(int q, int a, int d)
+    {
+        return (d == 0 ? dq1(tix(a, 0), xi(q, 0)) : q1(tix(a, 0), xi(q, 0))) * (d == 1 ? dq1(tix(a, 1), xi(q, 1)) : q1(tix(a, 1), xi(q, 1))) *
+               (d == 2 ? dq1(tix(a, 2), xi(q, 2)) : q1(tix(a, 2), xi(q, 2)));
+    }
+    TB_HD static constexpr double M(int q, int a) { return Hex8<3>::N(q, a); }       // trilinear geometry at the same points
+    TB_HD static constexpr double dM(int q, int a, int d) { return Hex8<3>::dN(q, a, d); }
+};
+
 // linear tetrahedron on the unit simplex; ORDER 1 → 1 point, ORDER 2 → 4-point degree-2 rule
 template <int ORDER> struct Tet4 {
     static constexpr int NV = 4, NB = 4, NQ = ORDER == 1 ? 1 : 4;
