@@ -260,3 +260,84 @@ def test_general_partition_equals_single_domain(world):
         assert held.max() == 3
     sizes = sorted(r[4] for r in res)
     assert sizes[-1] - sizes[0] <= 1                               # balanced parts
+
+
+def _mechanics_field(x):
+    """a smooth displacement as a function of position, so that every rank evaluates the same field on its own nodes"""
+    return 1e-2 * np.stack([np.sin(2 * x[:, 1]) * x[:, 2], np.cos(x[:, 0]) * x[:, 1], x[:, 0] * x[:, 1] - 0.5 * x[:, 2]], axis=1)
+
+
+def _mechanics_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import thunderbolt_jl_amd as tb
+    from oracle import oracle as o
+    D = tb.distributed
+    xyz, conn = _unstructured_problem(tb)
+    part = D.partition_cells_rcb(xyz[conn].mean(axis=1), world)
+    gp = D.GeneralPartition(conn, part, rank)
+    lx = xyz[gp.global_nodes]
+    cd, nd = o.close_dofs(o.HEX8, 3, gp.conn, len(lx))           # three displacement dofs per node, node-major
+    rp, ci = o.build_pattern(cd, nd)
+    om = o.Mesh(o.HEX8, 2, lx, gp.conn, cd)
+    n2d0 = np.full(len(lx), -1, dtype=np.int64)
+    n2d0[gp.conn.ravel()] = cd[:, 0::3].ravel()
+    u = np.empty(nd)
+    uf = _mechanics_field(lx)
+    for c in range(3):
+        u[n2d0 + c] = uf[:, c]
+    fsn = np.eye(3)
+    K, r = o.assemble_hyperelastic(om, u, rp, ci, fsn=fsn)
+    # the interface exchange of a vector field: the three dofs of every shared node, in the shared order of the nodes
+    nb = [(peer, torch.from_numpy((n2d0[idx][:, None] + np.arange(3)).ravel())) for peer, idx in gp.neighbours]
+    rt = torch.from_numpy(r.copy())
+    D.exchange_sum(rt, nb, dist)
+    # K·v with a global v: local product, then the same exchange (sub-domain matrices are never summed across ranks)
+    v = np.empty(nd)
+    vf = np.stack([np.cos(3 * lx[:, 0]), lx[:, 1] ** 2, np.sin(lx[:, 2] + lx[:, 0])], axis=1)
+    for c in range(3):
+        v[n2d0 + c] = vf[:, c]
+    Kv = torch.from_numpy(o.spmv_csr(rp, ci, K, v))
+    D.exchange_sum(Kv, nb, dist)
+    q.put((rank, gp.global_nodes, np.stack([rt.numpy()[n2d0 + c] for c in range(3)], axis=1), np.stack([Kv.numpy()[n2d0 + c] for c in range(3)], axis=1)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_mechanics_residual_and_tangent_action(world):
+    """SURVEY §8e for the mechanics path: cells partitioned by recursive bisection, every rank assembles the hyperelastic residual and
+    tangent of its own cells only, one interface sum over the three dofs of every shared node — the residual and the action K·v equal
+    the single-domain ones to 1e-12 (only the summation order on interface dofs differs)."""
+    from oracle import oracle as o
+    import thunderbolt_jl_amd as tb
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mechanics_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    xyz, conn = _unstructured_problem(tb)
+    cd, nd = o.close_dofs(o.HEX8, 3, conn, len(xyz))
+    rp, ci = o.build_pattern(cd, nd)
+    om = o.Mesh(o.HEX8, 2, xyz, conn, cd)
+    n2d0 = np.full(len(xyz), -1, dtype=np.int64)
+    n2d0[conn.ravel()] = cd[:, 0::3].ravel()
+    u, v = np.empty(nd), np.empty(nd)
+    uf = _mechanics_field(xyz)
+    vf = np.stack([np.cos(3 * xyz[:, 0]), xyz[:, 1] ** 2, np.sin(xyz[:, 2] + xyz[:, 0])], axis=1)
+    for c in range(3):
+        u[n2d0 + c] = uf[:, c]; v[n2d0 + c] = vf[:, c]
+    K, r = o.assemble_hyperelastic(om, u, rp, ci, fsn=np.eye(3))
+    Kv = o.spmv_csr(rp, ci, K, v)
+    rref = np.stack([r[n2d0 + c] for c in range(3)], axis=1)
+    Kvref = np.stack([Kv[n2d0 + c] for c in range(3)], axis=1)
+    for rank, gnodes, rr, kk in res:
+        np.testing.assert_allclose(rr, rref[gnodes], rtol=1e-11, atol=1e-12 * np.abs(rref).max())
+        np.testing.assert_allclose(kk, Kvref[gnodes], rtol=1e-11, atol=1e-12 * np.abs(Kvref).max())
