@@ -24,7 +24,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib as L
-from ._lib import check, lib
+from ._lib import TBError, check, lib
 
 
 def _ptr(x):
@@ -1422,6 +1422,7 @@ class NewtonRaphsonSolver:
         self.inner_rtol, self.inner_atol, self.inner_maxiter = inner_rtol, inner_atol, inner_maxiter
         self.enforce_monotonic_convergence = enforce_monotonic_convergence
         self.iter, self.theta, self.residual_norms, self.linear_iters = -1, [], [], []
+        self.linear_failure = None
 
 
 def nlsolve(u, op, ch, solver, t=0.0):
@@ -1445,14 +1446,21 @@ def nlsolve(u, op, ch, solver, t=0.0):
             solver.theta.append(np.inf)
             return False
         du.fill_zero()
-        if callable(solver.inner_solver):
-            its = solver.inner_solver(op.pattern, op.J, res, du)
-        elif solver.inner_solver == "cg" and solver.inner_precond is not None:
-            its, _ = pcg_solve(op.pattern, op.J, res, du, solver.inner_rtol, solver.inner_atol, solver.inner_maxiter, solver.inner_precond)
-        elif solver.inner_solver == "gmres":
-            its, _ = gmres_solve(op.pattern, op.J, res, du, solver.inner_rtol, solver.inner_atol, solver.inner_maxiter, solver.gmres_restart, True)
-        else:
-            its, _ = cg_solve(op.pattern, op.J, res, du, solver.inner_rtol, solver.inner_atol, solver.inner_maxiter, True)
+        try:
+            if callable(solver.inner_solver):
+                its = solver.inner_solver(op.pattern, op.J, res, du)
+            elif solver.inner_solver == "cg" and solver.inner_precond is not None:
+                its, _ = pcg_solve(op.pattern, op.J, res, du, solver.inner_rtol, solver.inner_atol, solver.inner_maxiter, solver.inner_precond)
+            elif solver.inner_solver == "gmres":
+                its, _ = gmres_solve(op.pattern, op.J, res, du, solver.inner_rtol, solver.inner_atol, solver.inner_maxiter, solver.gmres_restart, True)
+            else:
+                its, _ = cg_solve(op.pattern, op.J, res, du, solver.inner_rtol, solver.inner_atol, solver.inner_maxiter, True)
+        except TBError as e:
+            # a failed inner linear solve fails the nonlinear solve (newton_raphson.jl:262-270: `solve_inner_linear_system!` → false) — e.g. CG
+            # meeting an indefinite tangent after too large a load step; the caller retries with a smaller step or another inner solver
+            solver.linear_failure = str(e)
+            solver.theta.append(np.inf)
+            return False
         solver.linear_iters.append(its)
         apply_zero(None, du, ch, pattern=op.pattern)          # eliminate_constraints_from_increment!
         check(lib().tb_axpy(dev.h, u.n, -1.0, du.ptr, u.ptr))  # u .-= Δu
