@@ -958,12 +958,11 @@ def test_reference_contracting_cuboid_single_subdomain(tb, device, which):
     """test/integration/test_solid_mechanics.jl:287-365 ("Contracting cuboid", single subdomain), the three constitutive models the
     reference runs: 10×10×2 hexahedra on (0,0,0)–(1,1,0.2), left/front/bottom faces clamped in their normal component and node 1
     fully, facet models NormalSpringBC(0,"right"), ConstantPressureBC(0,"back"), PressureFieldBC(0,"top"), calcium hat
-    Ca(t) = 2t/1000, load steps t = 100, 200, 300 with Newton (tol 1e-10, max_iter 10).  Like the reference: every step
-    converges and u moved; additionally the block shortens along the fibre (x).
-    Deviation: the reference's third set-up wraps HumphreyStrumpfYinModel, whose tangent at rest has no shear stiffness (λmin(K) = 1e-14
-    on this mesh, measured) — Newton from u = 0 with fixed load steps does not converge on it with any linear solver; the reference
-    relies on its adaptive path following there.  The replay uses the passive spring of the reference's other active-stress block
-    (Guccione1991PassiveModel, :392-410) instead; HSY itself is covered by the energy parity tests."""
+    Ca(t) = 2t/1000, HomotopyPathSolver(NewtonRaphsonSolver(max_iter = 10, tol = 1e-10)) over tspan (0, 300) with Δt = 100, adaptive.
+    Like the reference: the solve succeeds and u moved; additionally the block shortens along the fibre (x).  The third set-up
+    (HumphreyStrumpfYinModel) has no shear stiffness at rest (λmin(K) = 1e-14 on this mesh, measured): Newton from u = 0 fails for the
+    first load increments with any linear solver, and it is the adaptive path following — rejected steps retried with half the
+    increment — that gets it through, here as in the reference."""
     g = tb.generate_mesh(tb.Hexahedron, (10, 10, 2), (0.0, 0.0, 0.0), (1.0, 1.0, 0.2))
     dh = tb.DofHandler(g, tb.LagrangeCollection(1) ** 3)
     sp = tb.allocate_matrix(dh)
@@ -974,7 +973,7 @@ def test_reference_contracting_cuboid_single_subdomain(tb, device, which):
                                                         tb.GMKActiveDeformationGradientModel(), sarc, ms),
           "generalized_hill": lambda: tb.GeneralizedHillModel(tb.LinYinPassiveModel(), tb.ActiveMaterialAdapter(tb.LinYinActiveModel()),
                                                               tb.GMKIncompressibleActiveDeformationGradientModel(), sarc, ms),
-          "active_stress": lambda: tb.ActiveStressModel(tb.Guccione1991PassiveModel(), tb.SimpleActiveStress(), sarc, ms)}[which]()
+          "active_stress": lambda: tb.ActiveStressModel(tb.HumphreyStrumpfYinModel(), tb.SimpleActiveStress(), sarc, ms)}[which]()
     facemodels = (tb.NormalSpringBC(0.0, "right"), tb.ConstantPressureBC(0.0, "back"), tb.PressureFieldBC(tb.ConstantCoefficient(0.0), "top"))
     op = tb.setup_operator(tb.PerColorAssemblyStrategy(device), tb.QuasiStaticModel("d", cm, facemodels), dh, sp)
     node_dof0 = np.empty(g.n_nodes, dtype=np.int64)
@@ -995,8 +994,11 @@ def test_reference_contracting_cuboid_single_subdomain(tb, device, which):
         return 1
     inner = {"extended_hill": "cg", "generalized_hill": "gmres", "active_stress": sparse_lu}[which]
     solver = tb.NewtonRaphsonSolver(max_iter=10, tol=1e-10, inner_rtol=1e-12, inner_solver=inner, gmres_restart=100)
-    for t in (100.0, 200.0, 300.0):
-        assert tb.nlsolve(u, op, ch, solver, t=t), (which, t, solver.residual_norms)
+    path = tb.HomotopyPathSolver(solver)
+    assert path.solve(u, op, ch, (0.0, 300.0), 100.0, adaptive=True), (which, path.steps)
+    assert path.steps[-1][0] == 300.0 and path.steps[-1][3]
+    if which == "active_stress":
+        assert not path.steps[0][3]                                                 # the first increment is rejected on the singular tangent
     uh = u.to_host()
     assert np.abs(uh).max() > 1e-4                                                 # integrator.u ≉ u₀
     ux_right = uh[node_dof0[X[:, 0] > 1 - 1e-12]]

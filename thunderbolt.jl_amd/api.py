@@ -1300,6 +1300,37 @@ def local_solve_failures(op):
     return nf.value
 
 
+class HomotopyPathSolver:
+    """HomotopyPathSolver(inner_solver) (src/solver/time/homotopy.jl): solve F(u, t) = 0 along the pseudo-time t with a Newton solve per
+    load step; `solve` mirrors the adaptive integrator around it — a failed step is rejected (u restored) and retried with half the
+    increment, an easy one (few Newton iterations) lets the increment grow back."""
+
+    def __init__(self, inner_solver):
+        self.inner_solver = inner_solver
+        self.steps = []                      # (t, dt, newton iterations, accepted)
+
+    def solve(self, u, op, ch, tspan, dt, adaptive=True, dtmin=1e-6, maxiters=200):
+        t, t_end = float(tspan[0]), float(tspan[1])
+        self.steps = []
+        while t < t_end - 1e-12 * max(1.0, abs(t_end)):
+            if len(self.steps) >= maxiters:
+                return False
+            h = min(dt, t_end - t)
+            u0 = u.to_host()
+            ok = nlsolve(u, op, ch, self.inner_solver, t=t + h)
+            self.steps.append((t + h, h, self.inner_solver.iter, bool(ok)))
+            if ok:
+                t += h
+                if adaptive and self.inner_solver.iter <= 3:
+                    dt = min(2.0 * dt, t_end - tspan[0])
+            else:
+                u.copy_from_host(u0)
+                if not adaptive or 0.5 * h < dtmin:
+                    return False
+                dt = 0.5 * h
+        return True
+
+
 def perform_mechanics_step(u, op, ch, solver, t, dt):
     """One backward-Euler step t → t + Δt of a quasi-static problem with condensed internal variables: the multi-level Newton of the
     reference (BackwardEulerSolver(inner_solver = MultiLevelNewtonRaphsonSolver), euler.jl / multilevel_newton_raphson.jl) — global
