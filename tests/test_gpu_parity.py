@@ -1322,7 +1322,7 @@ def test_reference_contracting_ideal_lv(tb, device, which):
     (the reference runs it on the wedge-capped mesh, whose apex cells the device kernels do not integrate): anchors MyocardialAnchor1
     (all components), 2 (y, z), 3 and 4 (z); RobinBC(0.1, "Epicardium"), NormalSpringBC(1.0, "Base"), PressureFieldBC(0.01,
     "Endocardium"); a rule-based nodal fibre field (helix +80° endo … −65° epi, the angles of the reference's ODB25LT set-up); calcium
-    hat; load steps t = 100, 200, 300 with Newton (tol 1e-10, max_iter 10) and a sparse LU inner solver (UMFPACK in the reference).
+    hat; HomotopyPathSolver(Newton(tol 1e-10, max_iter 10)) to t = 300 with Δt = 100, adaptive, sparse LU inner solver (UMFPACK in the reference).
     Like the reference: every step succeeds and u moved.  Additionally: the cavity pressure and the contraction act against each
     other as they should — the apex moves towards the base under activation."""
     g = tb.generate_ideal_lv_mesh_hex(8, 2, 3)
@@ -1335,7 +1335,7 @@ def test_reference_contracting_ideal_lv(tb, device, which):
                                                         tb.GMKActiveDeformationGradientModel(), sarc, ms),
           "generalized_hill": lambda: tb.GeneralizedHillModel(tb.LinYinPassiveModel(), tb.ActiveMaterialAdapter(tb.LinYinActiveModel()),
                                                               tb.GMKIncompressibleActiveDeformationGradientModel(), sarc, ms),
-          "active_stress": lambda: tb.ActiveStressModel(tb.Guccione1991PassiveModel(), tb.SimpleActiveStress(), sarc, ms)}[which]()
+          "active_stress": lambda: tb.ActiveStressModel(tb.HumphreyStrumpfYinModel(), tb.SimpleActiveStress(), sarc, ms)}[which]()
     facemodels = (tb.RobinBC(0.1, "Epicardium"), tb.NormalSpringBC(1.0, "Base"), tb.PressureFieldBC(tb.ConstantCoefficient(0.01), "Endocardium"))
     op = tb.setup_operator(tb.PerColorAssemblyStrategy(device), tb.QuasiStaticModel("d", cm, facemodels), dh, sp)
     node_dof0 = np.empty(g.n_nodes, dtype=np.int64)
@@ -1353,14 +1353,14 @@ def test_reference_contracting_ideal_lv(tb, device, which):
         return 1
     u = device.zeros(dh.ndofs)
     solver = tb.NewtonRaphsonSolver(max_iter=10, tol=1e-10, inner_solver=sparse_lu)
-    uz_apex = []
     apex = g.getnodeset("Apex")[0]
-    for t in (100.0, 200.0, 300.0):
-        assert tb.nlsolve(u, op, ch, solver, t=t), (which, t, solver.residual_norms)
-        uz_apex.append(u.to_host()[node_dof0[apex] + 2])
+    path = tb.HomotopyPathSolver(solver)
+    assert path.solve(u, op, ch, (0.0, 100.0), 100.0, adaptive=True), (which, path.steps)
+    uz100 = u.to_host()[node_dof0[apex] + 2]
+    assert path.solve(u, op, ch, (100.0, 300.0), 100.0, adaptive=True), (which, path.steps)
     uh = u.to_host()
     assert np.abs(uh).max() > 1e-4                                                 # integrator.u ≉ u₀
-    assert uz_apex[-1] < uz_apex[0]                                                # the apex (z = +1.5) is pulled towards the base as Ca rises
+    assert uh[node_dof0[apex] + 2] < uz100                                         # the apex (z = +1.5) is pulled towards the base as Ca rises
 
 
 def l1gs_reference(A, r, ps, symmetric=True):
