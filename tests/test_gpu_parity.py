@@ -1442,6 +1442,50 @@ def test_l1_gauss_seidel_preconditioner(tb, oracle, device):
     assert itm["l1gs"] < itm["jacobi"], itm
 
 
+def test_reference_ideal_lv_load_path_properties(tb, device):
+    """The load-path checks of the reference's idealised-LV testsets (test/integration/test_solid_mechanics.jl:659-765), HumphreyStrumpfYin
+    active stress on the hexahedral ventricle: adaptive and fixed load steps reach the same state ("Adaptivity does not change the
+    result", atol 1e-4); two different calcium histories give different states at the same pseudo-time when their calcium differs
+    ("The load path is actually different") and the same state when it agrees ("Check path independence" — the model has no memory)."""
+    g = tb.generate_ideal_lv_mesh_hex(8, 2, 3)
+    dh = tb.DofHandler(g, tb.LagrangeCollection(1) ** 3)
+    sp = tb.allocate_matrix(dh)
+    ms = tb.OrthotropicMicrostructureModel(*tb.ideal_lv_microstructure(g, np.deg2rad(80.0), np.deg2rad(-65.0)))
+    hat = lambda t: 2.0 * t / 1000.0 if t / 1000.0 < 0.5 else 2.0 - 2.0 * t / 1000.0                       # TestCalciumHatField
+    qhat = lambda t: (2.0 * t / 1000.0) ** 2 if t / 1000.0 < 0.5 else 2.0 - (2.0 * t / 1000.0) ** 2        # TestCalciumQuadraticHatField
+    facemodels = (tb.RobinBC(0.1, "Epicardium"), tb.NormalSpringBC(1.0, "Base"), tb.PressureFieldBC(tb.ConstantCoefficient(0.01), "Endocardium"))
+    node_dof0 = np.empty(g.n_nodes, dtype=np.int64)
+    node_dof0[g.conn.ravel()] = dh.cell_dofs[:, 0::3].ravel()
+    a = [g.getnodeset("MyocardialAnchor%d" % k)[0] for k in (1, 2, 3, 4)]
+    ch = tb.ConstraintHandler(dh, np.concatenate([node_dof0[a[0]] + np.arange(3), node_dof0[a[1]] + np.array([1, 2]), [node_dof0[a[2]] + 2], [node_dof0[a[3]] + 2]]))
+
+    def sparse_lu(pattern, J, res, du):
+        import scipy.sparse as ssp
+        import scipy.sparse.linalg as sla
+        n = len(pattern.sp.rowptr) - 1
+        A = ssp.csr_matrix((J.to_host(), pattern.sp.colidx, pattern.sp.rowptr), shape=(n, n))
+        du.copy_from_host(sla.splu(A.tocsc()).solve(res.to_host()))
+        return 1
+
+    def run(ca, tmax, dt, adaptive):
+        cm = tb.ActiveStressModel(tb.HumphreyStrumpfYinModel(), tb.SimpleActiveStress(), tb.CaDrivenInternalSarcomereModel(tb.PelceSunLangeveld1995Model(), ca), ms)
+        op = tb.setup_operator(tb.PerColorAssemblyStrategy(device), tb.QuasiStaticModel("d", cm, facemodels), dh, sp)
+        u = device.zeros(dh.ndofs)
+        path = tb.HomotopyPathSolver(tb.NewtonRaphsonSolver(max_iter=10, tol=1e-10, inner_solver=sparse_lu))
+        assert path.solve(u, op, ch, (0.0, tmax), dt, adaptive=adaptive, maxiters=400), path.steps[-5:]
+        return u.to_host(), path
+    u1, p1 = run(qhat, 10.0, 1.0, True)
+    u2, p2 = run(qhat, 10.0, 1.0, False)
+    assert len(p1.steps) < len(p2.steps)                                          # the adaptive run really took other steps
+    np.testing.assert_allclose(u1, u2, rtol=0, atol=1e-4)
+    v1, _ = run(hat, 100.0, 100.0, True)
+    v2, _ = run(qhat, 100.0, 100.0, True)
+    assert not np.allclose(v1, v2, rtol=0, atol=1e-4)                              # Ca(100) = 0.2 vs 0.04
+    w1, _ = run(hat, 500.0, 100.0, True)
+    w2, _ = run(qhat, 500.0, 100.0, True)
+    np.testing.assert_allclose(w1, w2, rtol=0, atol=1e-4)                          # Ca(500) = 1 on both paths
+
+
 # ------------------------------------------------------------------------------------------- the reference's own GPU tests
 def quad_problem(tb, oracle, nel, left, right):
     g = tb.generate_mesh(tb.Quadrilateral, nel, left, right)
