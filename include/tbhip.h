@@ -288,6 +288,9 @@ enum { TB_BC_ROBIN = 0, TB_BC_NORMAL_SPRING = 1, TB_BC_PRESSURE = 2,
 int tb_facet_form_set_field(tb_form *form, const double *field, int64_t len);
 int tb_facet_form_create(tb_mesh *mesh, int bc_kind, double param, int facet_qpoints, const int32_t *facets, int64_t n_facets,
                          int index_base, tb_form **out);
+/* new value of the boundary condition's parameter (α, kₛ, kᵇ, p, or the scale of the nodal pressure field): time-dependent loads such as
+ * the reference's ramped PressureFieldBC (test/integration/test_solid_mechanics.jl:571-590) set it before every assembly */
+int tb_facet_form_set_param(tb_form *form, double param);
 int tb_facet_assemble(tb_form *form, tb_pattern *pat, const double *d_u, double t, double *d_nzval, double *d_r);
 int tb_host_material_eval(const tb_material *material, const double *F, double *psi, double *P, double *A);
 

@@ -1486,6 +1486,34 @@ def test_reference_ideal_lv_load_path_properties(tb, device):
     np.testing.assert_allclose(w1, w2, rtol=0, atol=1e-4)                          # Ca(500) = 1 on both paths
 
 
+def test_reference_weak_bc_on_subdomains_without_matching_facetset(tb, device):
+    """test/integration/test_solid_mechanics.jl:560-590: subdomains "inner" / "outer" (no facetset carries those names), the *only* load a
+    ramped PressureFieldBC(0.01·t, "top") on both — if the surface terms of a subdomain were dropped the body would not deform:
+    norm(u) > 1e-8 after the homotopy solve to t = 300."""
+    g = tb.generate_mesh(tb.Hexahedron, (10, 10, 2), (0.0, 0.0, 0.0), (1.0, 1.0, 0.2))
+    g.addcellset("inner", lambda x: x[2] <= 0.1 + 1e-12)
+    g.addcellset("outer", lambda x: x[2] >= 0.1 - 1e-12)
+    dh = tb.DofHandler(g, tb.LagrangeCollection(1) ** 3)
+    sp = tb.allocate_matrix(dh)
+    ms = tb.ConstantCoefficient(tb.OrthotropicMicrostructure([1.0, 0, 0], [0, 1.0, 0], [0, 0, 1.0]))
+    load = (tb.PressureFieldBC(lambda t: 0.01 * t, "top"),)
+    models = {k: tb.QuasiStaticModel("d", tb.PK1Model(tb.Guccione1991PassiveModel(), ms), load) for k in ("inner", "outer")}
+    op = tb.setup_operator(tb.PerColorAssemblyStrategy(device), models, dh, sp)
+    assert len(op.facet_forms) == 2                     # "top" facets belong to the outer cells: one of the two forms is empty, none is lost
+    node_dof0 = np.empty(g.n_nodes, dtype=np.int64)
+    node_dof0[g.conn.ravel()] = dh.cell_dofs[:, 0::3].ravel()
+    X = g.xyz
+    fixed = np.concatenate([node_dof0[X[:, 0] < 1e-12], node_dof0[X[:, 1] < 1e-12] + 1, node_dof0[X[:, 2] < 1e-12] + 2, node_dof0[0] + np.arange(3)])
+    ch = tb.ConstraintHandler(dh, fixed)
+    u = device.zeros(dh.ndofs)
+    path = tb.HomotopyPathSolver(tb.NewtonRaphsonSolver(max_iter=10, tol=1e-10, inner_rtol=1e-12, inner_solver="gmres", gmres_restart=100))
+    assert path.solve(u, op, ch, (0.0, 300.0), 100.0, adaptive=True), path.steps
+    uh = u.to_host()
+    assert np.linalg.norm(uh) > 1.0e-8
+    top = node_dof0[X[:, 2] > 0.2 - 1e-12] + 2
+    assert uh[top].mean() < 0.0                          # a positive pressure pushes the top face down (−z)
+
+
 # ------------------------------------------------------------------------------------------- the reference's own GPU tests
 def quad_problem(tb, oracle, nel, left, right):
     g = tb.generate_mesh(tb.Quadrilateral, nel, left, right)

@@ -110,6 +110,7 @@ SIGNATURES = {
     "tb_host_material_eval_hill": (C.c_int, [vp, vp, C.c_double, c_dp, c_dp, c_dp, c_dp]),
     "tb_facet_form_create": (C.c_int, [vp, C.c_int, C.c_double, C.c_int, c_i32p, C.c_int64, C.c_int, C.POINTER(vp)]),
     "tb_facet_form_set_field": (C.c_int, [vp, c_dp, C.c_int64]),
+    "tb_facet_form_set_param": (C.c_int, [vp, C.c_double]),
     "tb_facet_assemble": (C.c_int, [vp, vp, vp, C.c_double, vp, vp]),
     "tb_host_material_eval": (C.c_int, [C.POINTER(tb_material), c_dp, c_dp, c_dp, c_dp]),
     "tb_reaction_step": (C.c_int, [vp, C.c_int, c_dp, C.c_int, vp, vp, C.c_int64, C.c_int, C.c_int, C.c_double,

@@ -1172,7 +1172,10 @@ class PressureFieldBC:
 
     def __init__(self, pc, boundary_name):
         self.boundary_name = boundary_name
-        if isinstance(pc, ConstantCoefficient):
+        self.param_of_t = None
+        if callable(pc):                       # spatially uniform, time-dependent pressure p(t) (e.g. the reference's TestRampField)
+            self.param, self.field, self.param_of_t = float(pc(0.0)), None, pc
+        elif isinstance(pc, ConstantCoefficient):
             self.param, self.field = float(pc.val), None
         else:
             self.param, self.field = 1.0, np.ascontiguousarray(pc.data, dtype=np.float64)
@@ -1212,7 +1215,7 @@ class NonlinearOperator:
         self.pattern = self.dmesh.pattern(pattern)
         self.J = DeviceVector(strategy.device, pattern.nnz)
         self.internal = None
-        self.forms, self.facet_forms, self._keep = [], [], []
+        self.forms, self.facet_forms, self._keep, self._facet_bcs = [], [], [], []
         domains = list(model.items()) if isinstance(model, dict) else [(None, model)]
         if len(domains) > 1 and isinstance(strategy, ElementAssemblyStrategy):
             raise ValueError("multi-domain operators accumulate: use PerColorAssemblyStrategy or AtomicAssemblyStrategy")
@@ -1265,6 +1268,7 @@ class NonlinearOperator:
                 if getattr(bc, "field", None) is not None:
                     check(lib().tb_facet_form_set_field(h, bc.field.ctypes.data_as(L.c_dp), bc.field.size))
                 self.facet_forms.append(h)
+                self._facet_bcs.append(bc)
         self.form = self.forms[0][0]
 
     def __del__(self):
@@ -1350,6 +1354,9 @@ def perform_mechanics_step(u, op, ch, solver, t, dt):
 
 
 def _sync_active_tension(op, t):
+    for h, bc in zip(op.facet_forms, op._facet_bcs):
+        if getattr(bc, "param_of_t", None) is not None:
+            check(lib().tb_facet_form_set_param(h, float(bc.param_of_t(t))))
     for form, cm in op.forms:
         if isinstance(cm, (ActiveStressModel, _HillModel)):
             scale, field = cm.tension(t)

@@ -679,6 +679,13 @@ int tb_facet_form_set_field(tb_form *form, const double *field, int64_t len)
     return TB_OK;
 }
 
+int tb_facet_form_set_param(tb_form *form, double param)
+{
+    TB_REQUIRE(form && form->kind == TB_FORM_FACET, "tb_facet_form_set_param: not a facet form");
+    form->bc_param = param;
+    return TB_OK;
+}
+
 int tb_facet_assemble(tb_form *form, tb_pattern *pat, const double *d_u, double t, double *d_nzval, double *d_r)
 {
     (void)t;
