@@ -1514,6 +1514,70 @@ def test_reference_weak_bc_on_subdomains_without_matching_facetset(tb, device):
     assert uh[top].mean() < 0.0                          # a positive pressure pushes the top face down (−z)
 
 
+def _strong_activation_problem(tb, device, nel):
+    g = tb.generate_mesh(tb.Hexahedron, nel, (0.0, 0.0, 0.0), (1.0, 1.0, 0.2))
+    dh = tb.DofHandler(g, tb.LagrangeCollection(1) ** 3)
+    sp = tb.allocate_matrix(dh)
+    ms = tb.ConstantCoefficient(tb.OrthotropicMicrostructure([1.0, 0, 0], [0, 1.0, 0], [0, 0, 1.0]))
+    cm = tb.ActiveStressModel(tb.Guccione1991PassiveModel(), tb.SimpleActiveStress(Tmax=220e3),
+                              tb.CaDrivenInternalSarcomereModel(tb.RDQ20MFModel(), 1.0), ms)
+    op = tb.setup_operator(tb.PerColorAssemblyStrategy(device), tb.QuasiStaticModel("d", cm, ()), dh, sp)
+    node_dof0 = np.empty(g.n_nodes, dtype=np.int64)
+    node_dof0[g.conn.ravel()] = dh.cell_dofs[:, 0::3].ravel()
+    X = g.xyz
+    fixed = np.concatenate([node_dof0[X[:, 0] < 1e-12], node_dof0[X[:, 1] < 1e-12] + 1, node_dof0[X[:, 2] < 1e-12] + 2, node_dof0[0] + np.arange(3)])
+
+    def sparse_lu(pattern, J, res, du):
+        import scipy.sparse as ssp
+        import scipy.sparse.linalg as sla
+        n = len(pattern.sp.rowptr) - 1
+        A = ssp.csr_matrix((J.to_host(), pattern.sp.colidx, pattern.sp.rowptr), shape=(n, n))
+        du.copy_from_host(sla.splu(A.tocsc()).solve(res.to_host()))
+        return 1
+    solver = tb.NewtonRaphsonSolver(max_iter=10, tol=1e-8, inner_solver=sparse_lu)
+    return g, dh, op, tb.ConstraintHandler(dh, fixed), solver, node_dof0
+
+
+def test_reference_condensed_sarcomere_under_strong_activation(tb, device):
+    """test/integration/test_solid_mechanics.jl:850-903: the regression test that pins the condensation contribution ∂P/∂Q ⊗ ∂Q/∂λ ⊗ ∂λ/∂F
+    to the tangent — unwrapped RDQ20MFModel at full activation (Ca = 1, Tmax = 220e3) on a 2×2×1 cuboid, backward Euler with Δt = 2.5
+    over (0, 5), Newton tol 1e-8 within 10 iterations and a direct inner solve.  With a wrong sign or a missing rate term the global
+    Newton diverges within two steps; here both steps converge, quadratically at the end."""
+    g, dh, op, ch, solver, node_dof0 = _strong_activation_problem(tb, device, (2, 2, 1))
+    u = device.zeros(dh.ndofs)
+    for step in range(2):
+        assert tb.perform_mechanics_step(u, op, ch, solver, 2.5 * step, 2.5), (step, solver.residual_norms)
+        rn = solver.residual_norms
+        assert solver.iter <= 10 and rn[-1] < 1e-8
+        if len(rn) >= 4:
+            assert rn[-1] < 1e-2 * rn[-2]                                           # the consistent tangent gives super-linear convergence at the end
+    uh = u.to_host()
+    assert uh[node_dof0[g.xyz[:, 0] > 1 - 1e-12]].mean() < -1e-3                    # strong shortening along the fibre
+    Q = op.internal.to_host()
+    assert Q[:16].min() >= 0.0 and (Q[17] + Q[19]).min() > 0.0
+
+
+def test_reference_step_too_long_for_the_sarcomere_fails_cleanly(tb, device):
+    """test/integration/test_solid_mechanics.jl:905-958: Δt = 20 outruns the Markov chain's own dynamics — occupancies leave [0, 1], the
+    local solves report it per quadrature point, the step is rejected (retcode ConvergenceFailure, integrator.t == 0): no exception,
+    nothing accepted, u and the internal states exactly as before."""
+    g, dh, op, ch, solver, _ = _strong_activation_problem(tb, device, (1, 1, 1))
+    u = device.zeros(dh.ndofs)
+    Q0 = op.internal.to_host().copy()
+    ok = tb.perform_mechanics_step(u, op, ch, solver, 0.0, 20.0)
+    assert ok is False
+    assert tb.local_solve_failures(op) > 0
+    status = np.zeros(op.internal.n_points, dtype=np.int32)
+    nf = __import__("ctypes").c_int64()
+    tb.check(tb.lib().tb_hyperelastic_local_solve_report(op.internal_form, nf, status.ctypes.data, len(status)))
+    assert nf.value == (status != 0).sum() > 0 and set(status[status != 0]) <= {tb._lib.TB_LOCAL_INFEASIBLE, tb._lib.TB_LOCAL_MAX_ITERS}
+    assert np.abs(u.to_host()).max() == 0.0
+    np.testing.assert_array_equal(op.internal.to_host(), Q0)
+    np.testing.assert_array_equal(op.internal_known.to_host(), Q0)
+    # the same problem at a step the chain can follow goes through afterwards
+    assert tb.perform_mechanics_step(u, op, ch, solver, 0.0, 2.5)
+
+
 # ------------------------------------------------------------------------------------------- the reference's own GPU tests
 def quad_problem(tb, oracle, nel, left, right):
     g = tb.generate_mesh(tb.Quadrilateral, nel, left, right)
