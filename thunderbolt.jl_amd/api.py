@@ -1314,6 +1314,10 @@ class HomotopyPathSolver:
         self.steps = []                      # (t, dt, newton iterations, accepted)
 
     def solve(self, u, op, ch, tspan, dt, adaptive=True, dtmin=1e-6, maxiters=200):
+        if getattr(op, "internal", None) is not None:
+            # check_internal_variables_are_rate_free (homotopy.jl:22-58): continuation has neither a previous solution nor a timestep
+            raise ValueError("the material carries an internal variable with a time derivative, which HomotopyPathSolver cannot integrate: "
+                             "continuation supplies neither a previous solution nor a timestep. Use perform_mechanics_step (backward Euler) instead")
         t, t_end = float(tspan[0]), float(tspan[1])
         self.steps = []
         while t < t_end - 1e-12 * max(1.0, abs(t_end)):
@@ -1442,8 +1446,31 @@ def norm(x):
     return float(np.sqrt(dot(x, x)))
 
 
+class EisenstatWalkerForcing:
+    """EisenstatWalkerForcing(; η₀ = 0.5, ηₘₐₓ = 0.9, γ = 0.9, α = 2, safeguard = true, safeguard_threshold = 0.1)
+    (newton_raphson.jl:1-41,158-178): ηₖ = γ (‖rₖ‖/‖rₖ₋₁‖)^α becomes the relative tolerance of the k-th inner Krylov solve."""
+
+    def __init__(self, eta0=0.5, eta_max=0.9, gamma=0.9, alpha=2.0, safeguard=True, safeguard_threshold=0.1):
+        self.eta0, self.eta_max, self.gamma, self.alpha = eta0, eta_max, gamma, alpha
+        self.safeguard, self.safeguard_threshold = safeguard, safeguard_threshold
+        self.eta, self.rnorm = eta0, 0.0
+
+    def prestep(self, residualnorm, it):
+        if it == 0:
+            self.eta = min(self.eta0, self.eta_max)
+        else:
+            eta = self.gamma * (residualnorm / self.rnorm) ** self.alpha
+            if self.safeguard:
+                sg = self.gamma * self.eta ** self.alpha
+                if sg > self.safeguard_threshold and sg > eta:
+                    eta = sg
+            self.eta = min(max(eta, 0.0), self.eta_max)
+        self.rnorm = residualnorm
+        return self.eta
+
+
 class NewtonRaphsonSolver:
-    """NewtonRaphsonSolver(; max_iter, tol, inner_solver) (src/solver/nonlinear/newton_raphson.jl:1-60); nlsolve!
+    """NewtonRaphsonSolver(; max_iter, tol, inner_solver, forcing, simplified_newton) (src/solver/nonlinear/newton_raphson.jl:1-60); nlsolve!
     follows :215-320 — update_linearization!, eliminate constraints, residual norm over the free dofs, linear solve,
     eliminate the increment, u .-= Δu, Θₖ contraction monitor, early exits.  inner_solver: "cg" (Jacobi-PCG; symmetric positive
     definite tangents) or "gmres" (restarted, right-Jacobi; the reference's default KrylovJL_GMRES — for indefinite or
@@ -1451,11 +1478,14 @@ class NewtonRaphsonSolver:
     solution of J Δu = residual in Δu (device vectors; the CSR structure is `pattern.sp.rowptr/colidx` on the host, J its values on the device)."""
 
     def __init__(self, max_iter=100, tol=1e-4, inner_rtol=1e-8, inner_atol=1e-14, inner_maxiter=5000, enforce_monotonic_convergence=True,
-                 inner_solver="cg", gmres_restart=50, inner_precond=None):
+                 inner_solver="cg", gmres_restart=50, inner_precond=None, simplified_newton=False, forcing=None):
         if inner_solver not in ("cg", "gmres") and not callable(inner_solver):
             raise ValueError("inner_solver: 'cg', 'gmres' or a callable (pattern, J, residual, Δu) -> linear iterations")
         self.inner_solver, self.gmres_restart = inner_solver, gmres_restart
         self.inner_precond = inner_precond          # None (Jacobi, device-scalar CG) or L1GSPrecBuilder(partsize)
+        # simplified_newton: the tangent of the first iteration is reused, later iterations assemble the residual only (residual!);
+        # forcing: EisenstatWalkerForcing() adapts the inner Krylov tolerance (ignored by callable inner solvers, as by direct ones)
+        self.simplified_newton, self.forcing = bool(simplified_newton), forcing
         self.max_iter, self.tol = max_iter, tol
         self.inner_rtol, self.inner_atol, self.inner_maxiter = inner_rtol, inner_atol, inner_maxiter
         self.enforce_monotonic_convergence = enforce_monotonic_convergence
@@ -1473,8 +1503,13 @@ def nlsolve(u, op, ch, solver, t=0.0):
     eps = np.finfo(np.float64).eps
     while True:
         solver.iter += 1
-        update_linearization(op, u, t, residual=res)
-        apply_zero(op.J, res, ch, pattern=op.pattern)
+        if solver.simplified_newton and solver.iter > 0:
+            residual(op, res, u, t)                            # the eliminated tangent of iteration 0 stays in op.J
+            apply_zero(None, res, ch, pattern=op.pattern)
+        else:
+            update_linearization(op, u, t, residual=res)
+            apply_zero(op.J, res, ch, pattern=op.pattern)
+        solver.jacobian_is_fresh = not (solver.simplified_newton and solver.iter > 0)
         rnorm = norm(res)                                     # prescribed entries are zero: this is the norm over the free dofs
         solver.residual_norms.append(rnorm)
         if rnorm < solver.tol and solver.iter > 0:
@@ -1484,15 +1519,16 @@ def nlsolve(u, op, ch, solver, t=0.0):
             solver.theta.append(np.inf)
             return False
         du.fill_zero()
+        inner_rtol = solver.inner_rtol if solver.forcing is None else solver.forcing.prestep(rnorm, solver.iter)
         try:
             if callable(solver.inner_solver):
                 its = solver.inner_solver(op.pattern, op.J, res, du)
             elif solver.inner_solver == "cg" and solver.inner_precond is not None:
-                its, _ = pcg_solve(op.pattern, op.J, res, du, solver.inner_rtol, solver.inner_atol, solver.inner_maxiter, solver.inner_precond)
+                its, _ = pcg_solve(op.pattern, op.J, res, du, inner_rtol, solver.inner_atol, solver.inner_maxiter, solver.inner_precond)
             elif solver.inner_solver == "gmres":
-                its, _ = gmres_solve(op.pattern, op.J, res, du, solver.inner_rtol, solver.inner_atol, solver.inner_maxiter, solver.gmres_restart, True)
+                its, _ = gmres_solve(op.pattern, op.J, res, du, inner_rtol, solver.inner_atol, solver.inner_maxiter, solver.gmres_restart, True)
             else:
-                its, _ = cg_solve(op.pattern, op.J, res, du, solver.inner_rtol, solver.inner_atol, solver.inner_maxiter, True)
+                its, _ = cg_solve(op.pattern, op.J, res, du, inner_rtol, solver.inner_atol, solver.inner_maxiter, True)
         except TBError as e:
             # a failed inner linear solve fails the nonlinear solve (newton_raphson.jl:262-270: `solve_inner_linear_system!` → false) — e.g. CG
             # meeting an indefinite tangent after too large a load step; the caller retries with a smaller step or another inner solver
