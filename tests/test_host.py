@@ -155,3 +155,48 @@ def test_quadrilateral_grid_conventions(tb, oracle):
     assert M.sum() == pytest.approx(4.0, rel=1e-14)
     K = oracle.assemble_matrix(om, 1, oracle.Coef(oracle.COEF_CONST_TENSOR, [2.0, 0.3, 0.3, 1.0]), rp, ci)
     assert np.abs(oracle.spmv_csr(rp, ci, K, np.ones(nd))).max() < 1e-14
+
+
+def test_deuflhard_continuation_controllers(tb):
+    """test/test_time_integrator.jl:315-398: the three load-path step controllers are pure functions of Newton's contraction history, so
+    prescribed Θₖ pin their laws exactly — acceptance, the shrink on rejection, and the predictor with its three denominators
+    (2Θ₀, g(Θ₀), the mean); g(x) = √(1 + 4x) − 1."""
+    g = lambda x: np.sqrt(1 + 4 * x) - 1                                          # noqa: E731
+    ctrls = (tb.Deuflhard2004DiscreteContinuationController(theta_min=1 / 8, p=1),
+             tb.Deuflhard2004_B_DiscreteContinuationControllerVariant(theta_min=1 / 8, p=1),
+             tb.ExperimentalDiscreteContinuationController(theta_min=1 / 8, p=1))
+    for c in ctrls:
+        assert c.should_accept_step([0.1, 0.2])
+        assert not c.should_accept_step([0.1, c.theta_reject + 0.01])
+        assert c.should_accept_step([10.0], enforce_monotonic_convergence=False)     # without monotonicity only finiteness matters
+        assert not c.should_accept_step([0.1, np.nan], enforce_monotonic_convergence=False)
+    c = ctrls[0]
+    clamp = lambda q, c: min(max(q, c.qmin), c.qmax)                               # noqa: E731
+    dt = c.reject_step(0.4, [0.1, 2.0])
+    assert dt == pytest.approx(clamp(c.gamma * (g(c.theta_bar) / g(2.0)) ** (1 / c.p), c) * 0.4) and dt < 0.4
+    assert c.reject_step(0.4, [0.1, 0.2]) == 0.4                                    # nothing above the threshold: dt untouched
+    th = [0.3, 0.4]
+    t0 = max(th[0], c.theta_min)
+    assert ctrls[0].adapt_dt(0.4, th) == pytest.approx(clamp(c.gamma * (g(c.theta_bar) / (2 * t0)) ** (1 / c.p), c) * 0.4)
+    assert ctrls[1].adapt_dt(0.4, th) == pytest.approx(clamp(c.gamma * (g(c.theta_bar) / g(t0)) ** (1 / c.p), c) * 0.4)
+    e = ctrls[2]
+    t0e = max(sum(th) / len(th), e.theta_min)
+    assert e.adapt_dt(0.4, th) == pytest.approx(clamp(e.gamma * (g(e.theta_bar) / (2 * t0e)) ** (1 / e.p), e) * 0.4)
+    assert ctrls[0].adapt_dt(0.4, []) == pytest.approx(clamp(c.gamma * (g(c.theta_bar) / (2 * c.theta_min)) ** (1 / c.p), c) * 0.4)   # empty history → Θmin
+    assert (e.theta_reject, e.theta_bar) == (0.9, 0.75) and (c.theta_reject, c.theta_bar, c.gamma, c.qmin, c.qmax) == (0.95, 0.5, 0.95, 0.2, 5.0)
+
+
+def test_eisenstat_walker_forcing_law(tb):
+    """newton_raphson.jl:158-178: η₀ on the first step, then γ (‖rₖ‖/‖rₖ₋₁‖)^α with the safeguard γ ηₖ₋₁^α when that exceeds the threshold,
+    clamped to [0, ηmax]."""
+    f = tb.EisenstatWalkerForcing()
+    assert f.prestep(1.0, 0) == 0.5
+    assert f.prestep(0.5, 1) == pytest.approx(max(0.9 * 0.25, 0.9 * 0.5 ** 2))      # both 0.225: safeguard 0.225 > 0.1 and not larger
+    eta2 = f.prestep(0.05, 2)                                                       # fast drop: γ·0.01 = 0.009, safeguard γ·0.225² = 0.0456 < 0.1 → not applied
+    assert eta2 == pytest.approx(0.009)
+    f = tb.EisenstatWalkerForcing()
+    f.prestep(1.0, 0)
+    assert f.prestep(2.0, 1) == 0.9                                                 # growth of the residual saturates at ηmax
+    f = tb.EisenstatWalkerForcing(safeguard=False)
+    f.prestep(1.0, 0)
+    assert f.prestep(0.1, 1) == pytest.approx(0.009)

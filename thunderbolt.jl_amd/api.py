@@ -1304,13 +1304,76 @@ def local_solve_failures(op):
     return nf.value
 
 
+def _g_deuflhard(x):
+    return np.sqrt(1.0 + 4.0 * x) - 1.0
+
+
+class Deuflhard2004DiscreteContinuationController:
+    """Deuflhard2004DiscreteContinuationController(; Θmin, p, Θreject = 0.95, Θbar = 0.5, γ = 0.95, qmin = 1/5, qmax = 5)
+    (src/solver/time/homotopy.jl:204-281): step-size control of the load path from Newton's contraction history Θₖ — accept when every
+    Θₖ ≤ Θreject (only finiteness without monotonicity enforcement); on rejection dt ← clamp(γ (g(Θ̄)/g(Θₖ))^(1/p)) dt for the first
+    offending Θₖ; after an accepted step dt ← clamp(γ (g(Θ̄)/(2Θ₀))^(1/p)) dt with Θ₀ = max(Θ₁, Θmin); g(x) = √(1+4x) − 1."""
+    variant = "A"
+
+    def __init__(self, theta_min=1.0 / 8.0, p=1, theta_reject=0.95, theta_bar=0.5, gamma=0.95, qmin=0.2, qmax=5.0):
+        self.theta_min, self.p, self.theta_reject, self.theta_bar = theta_min, p, theta_reject, theta_bar
+        self.gamma, self.qmin, self.qmax = gamma, qmin, qmax
+
+    def _clamp(self, q):
+        return min(max(q, self.qmin), self.qmax)
+
+    def should_accept_step(self, thetas, enforce_monotonic_convergence=True):
+        th = np.asarray(thetas, dtype=np.float64)
+        return bool(np.all(th <= self.theta_reject)) if enforce_monotonic_convergence else bool(np.all(np.isfinite(th)))
+
+    def reject_step(self, dt, thetas):
+        for th in thetas:
+            if th > self.theta_reject:
+                return self._clamp(self.gamma * (_g_deuflhard(self.theta_bar) / _g_deuflhard(th)) ** (1.0 / self.p)) * dt
+        return dt
+
+    def _theta0(self, thetas):
+        return max(thetas[0], self.theta_min) if len(thetas) else self.theta_min
+
+    def _denominator(self, theta0):
+        return 2.0 * theta0
+
+    def adapt_dt(self, dt, thetas):
+        return self._clamp(self.gamma * (_g_deuflhard(self.theta_bar) / self._denominator(self._theta0(thetas))) ** (1.0 / self.p)) * dt
+
+
+class Deuflhard2004_B_DiscreteContinuationControllerVariant(Deuflhard2004DiscreteContinuationController):
+    """the variant with g(Θ₀) in the denominator of the predictor (homotopy.jl:283-342) — the default controller of HomotopyPathSolver (:406-408)"""
+    variant = "B"
+
+    def _denominator(self, theta0):
+        return _g_deuflhard(theta0)
+
+
+class ExperimentalDiscreteContinuationController(Deuflhard2004DiscreteContinuationController):
+    """ExperimentalDiscreteContinuationController(; Θmin, p, Θreject = 0.9, Θbar = 0.75, …) (homotopy.jl:344-400): the mean contraction rate
+    drives the predictor, the largest one the rejection."""
+    variant = "experimental"
+
+    def __init__(self, theta_min=1.0 / 8.0, p=1, theta_reject=0.9, theta_bar=0.75, gamma=0.95, qmin=0.2, qmax=5.0):
+        super().__init__(theta_min, p, theta_reject, theta_bar, gamma, qmin, qmax)
+
+    def reject_step(self, dt, thetas):
+        return self._clamp(self.gamma * (_g_deuflhard(self.theta_bar) / _g_deuflhard(max(thetas))) ** (1.0 / self.p)) * dt
+
+    def _theta0(self, thetas):
+        return max(float(np.mean(thetas)), self.theta_min) if len(thetas) else self.theta_min
+
+
 class HomotopyPathSolver:
     """HomotopyPathSolver(inner_solver) (src/solver/time/homotopy.jl): solve F(u, t) = 0 along the pseudo-time t with a Newton solve per
-    load step; `solve` mirrors the adaptive integrator around it — a failed step is rejected (u restored) and retried with half the
-    increment, an easy one (few Newton iterations) lets the increment grow back."""
+    load step; `solve` mirrors the adaptive integrator around it: the controller (default Deuflhard2004_B…Variant(Θmin = 1/8, p = 1))
+    judges Newton's contraction history, a rejected or failed step is rolled back (u restored) and retried with a shorter increment
+    (controller law for a poor contraction rate; failfactor 1/2 for a failed solve), an accepted one adapts the next increment."""
 
-    def __init__(self, inner_solver):
+    def __init__(self, inner_solver, controller=None):
         self.inner_solver = inner_solver
+        self.controller = controller or Deuflhard2004_B_DiscreteContinuationControllerVariant()
         self.steps = []                      # (t, dt, newton iterations, accepted)
 
     def solve(self, u, op, ch, tspan, dt, adaptive=True, dtmin=1e-6, maxiters=200):
@@ -1320,22 +1383,30 @@ class HomotopyPathSolver:
                              "continuation supplies neither a previous solution nor a timestep. Use perform_mechanics_step (backward Euler) instead")
         t, t_end = float(tspan[0]), float(tspan[1])
         self.steps = []
+        ns = self.inner_solver
         while t < t_end - 1e-12 * max(1.0, abs(t_end)):
             if len(self.steps) >= maxiters:
                 return False
             h = min(dt, t_end - t)
             u0 = u.to_host()
-            ok = nlsolve(u, op, ch, self.inner_solver, t=t + h)
-            self.steps.append((t + h, h, self.inner_solver.iter, bool(ok)))
+            solved = nlsolve(u, op, ch, ns, t=t + h)
+            thetas = [th for th in ns.theta if np.isfinite(th)] if solved else list(ns.theta)
+            ok = solved and (not adaptive or self.controller.should_accept_step(thetas, ns.enforce_monotonic_convergence))
+            self.steps.append((t + h, h, ns.iter, bool(ok)))
             if ok:
                 t += h
-                if adaptive and self.inner_solver.iter <= 3:
-                    dt = min(2.0 * dt, t_end - tspan[0])
+                if adaptive:
+                    dt = self.controller.adapt_dt(h, thetas)
             else:
-                u.copy_from_host(u0)
-                if not adaptive or 0.5 * h < dtmin:
+                u.copy_from_host(u0)                           # rollback_state!
+                if not adaptive:
                     return False
-                dt = 0.5 * h
+                dt = 0.5 * h if not solved else self.controller.reject_step(h, thetas)
+                if dt < dtmin or dt >= h:
+                    if dt >= h:
+                        dt = 0.5 * h
+                    if dt < dtmin:
+                        return False
         return True
 
 
