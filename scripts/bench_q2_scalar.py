@@ -14,7 +14,7 @@ dh = tb.DofHandler(g, tb.LagrangeCollection(2))
 sp = tb.allocate_matrix(dh)
 out = {"workload": "scalar Q2, %d^3 hex (%d cells, %d dofs, nnz %d)" % (args.n, g.n_cells, dh.ndofs, sp.nnz)}
 D = np.array([[2.0, 0.3, 0.1], [0.3, 1.5, -0.2], [0.1, -0.2, 1.0]])
-for sname, st in (("atomic", tb.AtomicAssemblyStrategy(dev)), ("color", tb.PerColorAssemblyStrategy(dev))):
+for sname, st in (("atomic", tb.AtomicAssemblyStrategy(dev)), ("color", tb.PerColorAssemblyStrategy(dev)), ("element", tb.ElementAssemblyStrategy(dev))):
     ops = {"mass": tb.setup_operator(st, tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.0)), dh, sp),
            "diffusion": tb.setup_operator(st, tb.BilinearDiffusionIntegrator(tb.ConstantCoefficient(D)), dh, sp),
            "source": tb.setup_operator(st, tb.LinearIntegrator(tb.AnalyticalCoefficient("cos_exp")), dh)}

@@ -258,7 +258,7 @@ def test_q2_scalar_forms_parity(tb, oracle, device):
     full = np.array([[2.0, 0.3, 0.1], [0.3, 1.5, -0.2], [0.1, -0.2, 1.0]])
     nonsym = np.array([[2.0, 0.5, 0.0], [-0.1, 1.5, 0.2], [0.3, 0.0, 1.0]])
     import scipy.sparse as ssp
-    for st in (tb.AtomicAssemblyStrategy(device), tb.PerColorAssemblyStrategy(device)):
+    for st in (tb.AtomicAssemblyStrategy(device), tb.PerColorAssemblyStrategy(device), tb.ElementAssemblyStrategy(device)):
         M = tb.update_operator(tb.setup_operator(st, tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.7)), dh, sp), 0.0)
         Mref = oracle.assemble_matrix(om, 0, oracle.Coef(oracle.COEF_CONST_SCALAR, [1.7]), sp.rowptr, sp.colidx)
         assert rel_err(M.A.to_host(), Mref) < TOL

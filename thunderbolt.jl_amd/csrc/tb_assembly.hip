@@ -710,7 +710,7 @@ __device__ __forceinline__ void q2_geometry(const double *s_x, int q, double *ge
 template <int FORM>
 __global__ void __launch_bounds__(256)
 k_matrix_q2(MeshView m, FormArgs fa, const int32_t *__restrict__ list, const int64_t *__restrict__ rowptr, const uint16_t *__restrict__ pos, double *__restrict__ nz,
-            int atomic, Status *st)
+            int atomic /*0 rmw, 1 atomic, 2 store Kₑ*/, double *__restrict__ ke, Status *st)
 {
     const Q2Tables &tb = g_q2_tables;
     const int64_t cell = list ? list[blockIdx.x] : blockIdx.x;
@@ -743,6 +743,30 @@ k_matrix_q2(MeshView m, FormArgs fa, const int32_t *__restrict__ list, const int
         __syncthreads();
     }
     const int64_t pbase = cell * 729;
+    if (atomic == 2) {
+        // element strategy: Kₑ leaves as one contiguous 729-entry run (gathered per row by k_gather_rows_q2).  Lane t < 243 owns row
+        // i = t / 9 and the three columns 3·(t % 9) …: one LDS read of the row's factor serves three entries.
+        if (tid < 243) {
+            const int i = tid / 9, j0 = 3 * (tid % 9);
+            double v[3] = {0.0, 0.0, 0.0};
+            if constexpr (FORM == TB_FORM_MASS) {
+                for (int q = 0; q < 27; ++q) {
+                    const double wi = fa.rho * s_geo[q][9] * s_N[q][i];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) v[c] += wi * s_N[q][j0 + c];
+                }
+            } else {
+                for (int q = 0; q < 27; ++q) {
+                    const double t0 = s_T[q][i][0], t1 = s_T[q][i][1], t2 = s_T[q][i][2];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) v[c] -= s_G[q][j0 + c][0] * t0 + s_G[q][j0 + c][1] * t1 + s_G[q][j0 + c][2] * t2;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) ke[pbase + 27 * i + j0 + c] = v[c];
+        }
+        return;
+    }
     for (int e = tid; e < 729; e += 256) {
         const int i = e / 27, j = e % 27;
         double v = 0.0;
@@ -756,6 +780,29 @@ k_matrix_q2(MeshView m, FormArgs fa, const int32_t *__restrict__ list, const int
         const int64_t k = rowptr[s_dof[i]] + pos[pbase + e];
         if (atomic) unsafeAtomicAdd(nz + k, v); else nz[k] += v;
     }
+}
+
+// ElementAssemblyStrategy for the quadratic scalar field, second pass: one wavefront per row sums the rows of the ≤ 8 element matrices that
+// touch its dof into an LDS copy of the CSR row (27 lanes, one entry each, cell after cell: no conflicts) and stores the row once.
+__global__ void __launch_bounds__(256)
+k_gather_rows_q2(int64_t n_rows, const int64_t *__restrict__ ea_ptr, const int32_t *__restrict__ ea_src, const double *__restrict__ ke,
+                 const uint16_t *__restrict__ pos, const int64_t *__restrict__ rowptr, double *__restrict__ nz, int max_row)
+{
+    extern __shared__ double s_rows[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + wv;
+    if (r >= n_rows) return;
+    double *row = s_rows + (size_t)wv * max_row;
+    const int64_t g0 = rowptr[r];
+    const int len = (int)(rowptr[r + 1] - g0);
+    for (int p = lane; p < len; p += 64) row[p] = 0.0;
+    __builtin_amdgcn_wave_barrier();
+    for (int64_t k = ea_ptr[r]; k < ea_ptr[r + 1]; ++k) {
+        const int64_t slot = ea_src[k]; // cell · 27 + local row
+        if (lane < 27) row[pos[slot * 27 + lane]] += ke[slot * 27 + lane];
+        __builtin_amdgcn_wave_barrier();
+    }
+    for (int p = lane; p < len; p += 64) nz[g0 + p] = row[p];
 }
 
 __global__ void __launch_bounds__(64)
@@ -802,19 +849,39 @@ static int run_q2(tb_form *f, tb_pattern *p, int strategy, double t, double *d_n
     if (f->field) { set_error("Q2 scalar forms take constant coefficients (field coefficients are implemented for first-order fields)"); return TB_ERR_UNSUPPORTED; }
     const MeshView mv = make_view(m);
     const FormArgs fa = make_args(f, t);
-    if (d_nz) { int rc = ensure_q2pos(p); if (rc) return rc; TB_HIP(hipMemsetAsync(d_nz, 0, (size_t)p->nnz * sizeof(double), dev->stream)); }
+    const bool ea = d_nz && (strategy == TB_STRATEGY_ELEMENT);
+    if (d_nz) { int rc = ensure_q2pos(p); if (rc) return rc; if (!ea) TB_HIP(hipMemsetAsync(d_nz, 0, (size_t)p->nnz * sizeof(double), dev->stream)); }
     else TB_HIP(hipMemsetAsync(d_b, 0, (size_t)m->ndofs * sizeof(double), dev->stream));
+    double *kebuf = nullptr;
+    if (ea) {
+        if (!m->ea) { int rc = build_ea_plan(m); if (rc) return rc; }
+        if (!p->d_kebuf) {
+            hipError_t e = hipMalloc((void **)&p->d_kebuf, sizeof(double) * (size_t)m->n_cells * 729);
+            if (e != hipSuccess) { set_error("element-matrix buffer (%zu B): %s", sizeof(double) * (size_t)m->n_cells * 729, hipGetErrorString(e)); return TB_ERR_NOMEM; }
+        }
+        kebuf = p->d_kebuf;
+    }
     auto go = [&](const int32_t *list, int64_t n, int atomic) -> int {
         if (n == 0) return TB_OK;
         if (d_nz && f->kind == TB_FORM_MASS)
-            hipLaunchKernelGGL(k_matrix_q2<TB_FORM_MASS>, dim3((unsigned)n), dim3(256), 0, dev->stream, mv, fa, list, p->d_rowptr, p->d_q2pos, d_nz, atomic, dev->d_status);
+            hipLaunchKernelGGL(k_matrix_q2<TB_FORM_MASS>, dim3((unsigned)n), dim3(256), 0, dev->stream, mv, fa, list, p->d_rowptr, p->d_q2pos, d_nz, atomic, kebuf, dev->d_status);
         else if (d_nz)
-            hipLaunchKernelGGL(k_matrix_q2<TB_FORM_DIFFUSION>, dim3((unsigned)n), dim3(256), 0, dev->stream, mv, fa, list, p->d_rowptr, p->d_q2pos, d_nz, atomic, dev->d_status);
+            hipLaunchKernelGGL(k_matrix_q2<TB_FORM_DIFFUSION>, dim3((unsigned)n), dim3(256), 0, dev->stream, mv, fa, list, p->d_rowptr, p->d_q2pos, d_nz, atomic, kebuf, dev->d_status);
         else hipLaunchKernelGGL(k_vector_q2, dim3((unsigned)n), dim3(64), 0, dev->stream, mv, fa, list, d_b, atomic, dev->d_status);
         TB_HIP(hipGetLastError());
         return TB_OK;
     };
-    if (strategy == TB_STRATEGY_ATOMIC) return go(nullptr, m->n_cells, 1);
+    if (ea) {
+        int rc = go(nullptr, m->n_cells, 2);
+        if (rc) return rc;
+        if (!p->max_row_len) for (int64_t r = 0; r < p->n_rows; ++r) p->max_row_len = std::max<int64_t>(p->max_row_len, p->h_rowptr[r + 1] - p->h_rowptr[r]);
+        const int max_row = (int)p->max_row_len;
+        hipLaunchKernelGGL(k_gather_rows_q2, dim3((unsigned)((m->ndofs + 3) / 4)), dim3(256), sizeof(double) * 4 * (size_t)max_row, dev->stream, m->ndofs,
+                           m->ea->d_ptr, m->ea->d_src, kebuf, p->d_q2pos, p->d_rowptr, d_nz, max_row);
+        TB_HIP(hipGetLastError());
+        return TB_OK;
+    }
+    if (strategy == TB_STRATEGY_ATOMIC || (strategy == TB_STRATEGY_ELEMENT && !d_nz)) return go(nullptr, m->n_cells, 1);
     if (strategy == TB_STRATEGY_PER_COLOR) {
         if (!m->colors) { int rc = build_color_plan(m); if (rc) return rc; }
         for (int c = 0; c < m->colors->ncolors; ++c) {
@@ -823,7 +890,7 @@ static int run_q2(tb_form *f, tb_pattern *p, int strategy, double t, double *d_n
         }
         return TB_OK;
     }
-    set_error("Q2 scalar forms: strategy %d not supported (use TB_STRATEGY_ATOMIC or TB_STRATEGY_PER_COLOR)", strategy);
+    set_error("Q2 scalar forms: strategy %d not supported (use TB_STRATEGY_ELEMENT, TB_STRATEGY_ATOMIC or TB_STRATEGY_PER_COLOR)", strategy);
     return TB_ERR_UNSUPPORTED;
 }
 
