@@ -1676,6 +1676,57 @@ def test_reference_simplified_newton_and_forcing_on_the_prestressed_sheet(tb, de
     assert kr_e < kr_g and it_e >= it_g, (kr_e, kr_g, it_e, it_g)
 
 
+def test_reference_validation_land2015_benchmark_problem_1(tb, device):
+    """test/validation/land2015.jl (Land et al. 2015, cardiac mechanics verification benchmark, problem 1: deforming beam): 10×1×1 beam,
+    25×3×3 hexahedra with a quadratic displacement field, Guccione material C₀ = 2, Bᶠᶠ = 8, Bˢˢ = Bⁿⁿ = 2, Bⁿˢ = 1, Bᶠˢ = Bᶠⁿ = 2 with
+    SimpleCompressionPenalty(100), fibres along x, the x = 0 face clamped, a pressure ramped to 0.004 on the bottom face, load path in
+    steps of 0.2 with Newton (tol 1e-4, max_iter 10) and a direct inner solve.  The reference's assertion — a published number, the one
+    external known answer the mechanics path has: the z-deflection of the point (10, 0.5, 1) is 3.17 ± 0.02."""
+    import scipy.sparse as ssp
+    import scipy.sparse.linalg as sla
+    g = tb.generate_mesh(tb.Hexahedron, (25, 3, 3), (0.0, 0.0, 0.0), (10.0, 1.0, 1.0))
+    dh = tb.DofHandler(g, tb.LagrangeCollection(2) ** 3)
+    sp = tb.allocate_matrix(dh)
+    mat = tb.Guccione1991PassiveModel(C0=2.0, Bff=8.0, Bss=2.0, Bnn=2.0, Bns=1.0, Bfs=2.0, Bfn=2.0, mpU=tb.SimpleCompressionPenalty(100.0))
+    ms = tb.ConstantCoefficient(tb.OrthotropicMicrostructure([1.0, 0, 0], [0, 1.0, 0], [0, 0, 1.0]))
+    load = (tb.PressureFieldBC(lambda t: min(t, 1.0) * 0.004, "bottom"),)
+    op = tb.setup_operator(tb.ElementAssemblyStrategy(device), tb.QuasiStaticModel("displacement", tb.PK1Model(mat, ms), load), dh, sp)
+    # positions of the Q2 nodes through the trilinear map (the mesh is a box: affine)
+    sgn = np.array([[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, -1, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1]], dtype=float)
+    tix = np.array([(0, 0, 0), (2, 0, 0), (2, 2, 0), (0, 2, 0), (0, 0, 2), (2, 0, 2), (2, 2, 2), (0, 2, 2), (1, 0, 0), (2, 1, 0), (1, 2, 0), (0, 1, 0), (1, 0, 2),
+                    (2, 1, 2), (1, 2, 2), (0, 1, 2), (0, 0, 1), (2, 0, 1), (2, 2, 1), (0, 2, 1), (1, 1, 0), (1, 0, 1), (2, 1, 1), (1, 2, 1), (0, 1, 1), (1, 1, 2), (1, 1, 1)],
+                   dtype=float) - 1.0
+    N = 0.125 * np.prod(1.0 + sgn[None, :, :] * tix[:, None, :], axis=2)
+    pos = np.einsum("ba,cak->cbk", N, g.xyz[g.conn])
+    X = np.empty((dh.ndofs, 3))
+    for c in range(3):
+        X[dh.cell_dofs[:, c::3].ravel()] = pos.reshape(-1, 3)
+    ch = tb.ConstraintHandler(dh, np.flatnonzero(X[:, 0] < 1e-12))
+    lu = {}
+
+    def sparse_lu(pattern, J, res, du):
+        n = len(pattern.sp.rowptr) - 1
+        A = ssp.csr_matrix((J.to_host(), pattern.sp.colidx, pattern.sp.rowptr), shape=(n, n))
+        du.copy_from_host(sla.splu(A.tocsc()).solve(res.to_host()))
+        return 1
+    u = device.zeros(dh.ndofs)
+    newton = tb.NewtonRaphsonSolver(tol=1e-4, max_iter=10, inner_solver=sparse_lu)
+    path = tb.HomotopyPathSolver(newton)
+    # dt = 0.2, dtmax = 0.2, adaptive: the controller may only shorten the increment
+    t, dt = 0.0, 0.2
+    while t < 1.0 - 1e-12:
+        h = min(dt, 0.2, 1.0 - t)
+        assert path.solve(u, op, ch, (t, t + h), h, adaptive=True, maxiters=100), path.steps
+        t += h
+    uh = u.to_host()
+    tip = np.flatnonzero((np.abs(X[:, 0] - 10.0) < 1e-9) & (np.abs(X[:, 1] - 0.5) < 1e-9) & (np.abs(X[:, 2] - 1.0) < 1e-9))
+    zdofs = [d for d in tip if d in set(dh.cell_dofs[:, 2::3].ravel())]
+    assert len(zdofs) == 1
+    deflection = uh[zdofs[0]]
+    print("Land 2015 problem 1: tip deflection %.4f (reference asserts 3.17 ± 0.02), %d load steps" % (deflection, len(path.steps)))
+    assert abs(deflection - 3.17) <= 0.02, deflection
+
+
 # ------------------------------------------------------------------------------------------- the reference's own GPU tests
 def quad_problem(tb, oracle, nel, left, right):
     g = tb.generate_mesh(tb.Quadrilateral, nel, left, right)
