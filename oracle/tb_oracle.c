@@ -485,7 +485,10 @@ static int reinit_qp(const cellvalues *cv, int q, const double *x, double *dOmeg
 /* evaluate a (tensor-valued) diffusion coefficient at quadrature point q of `cell` */
 static void eval_tensor_coef(const orc_coef *c, const cellvalues *cv, int q, int64_t cell, double *D)
 {
-    int dim = cv->dim, nb = cv->nb;
+    /* field coefficients carry first-order nodal data per cell (FieldCoefficient with its own LagrangeCollection{1}, coefficients.jl:85-99):
+     * the cell's basis for first-order fields, the geometry nodes and their shape values for the quadratic field */
+    int dim = cv->dim, nb = cv->nb == cv->ngeo ? cv->nb : cv->ngeo;
+    const double *Nq = cv->nb == cv->ngeo ? cv->N[q] : cv->M[q];
     double k[9];
     switch (c->kind) {
     case ORC_COEF_CONST_SCALAR:
@@ -503,7 +506,7 @@ static void eval_tensor_coef(const orc_coef *c, const cellvalues *cv, int q, int
         break;
     case ORC_COEF_FIELD_SCALAR: { /* FieldCoefficient of a scalar conductivity (coefficients.jl:85-99): κ(x_q)·I */
         double v;
-        orc_eval_field(nb, 1, cv->N[q], c->field + (int64_t)cell * nb, &v);
+        orc_eval_field(nb, 1, Nq, c->field + (int64_t)cell * nb, &v);
         for (int i = 0; i < dim * dim; ++i) k[i] = 0;
         for (int i = 0; i < dim; ++i) k[dim * i + i] = v;
         break;
@@ -515,7 +518,7 @@ static void eval_tensor_coef(const orc_coef *c, const cellvalues *cv, int q, int
         double tmp[3 * MAXNB];
         for (int which = 0; which < 3; ++which) {
             for (int a = 0; a < nb; ++a) for (int d = 0; d < 3; ++d) tmp[3 * a + d] = base[9 * a + 3 * which + d];
-            orc_eval_field(nb, 3, cv->N[q], tmp, v + 3 * which);
+            orc_eval_field(nb, 3, Nq, tmp, v + 3 * which);
         }
         orc_orthogonalize(3, v, v + 3, v + 6);
         orc_eval_spectral(3, 3, v, c->p, k);
@@ -532,7 +535,8 @@ static double eval_scalar_coef(const orc_coef *c, const cellvalues *cv, int q, i
 {
     if (c->kind == ORC_COEF_FIELD_SCALAR) {
         double v;
-        orc_eval_field(cv->nb, 1, cv->N[q], c->field + (int64_t)cell * cv->nb, &v);
+        if (cv->nb == cv->ngeo) orc_eval_field(cv->nb, 1, cv->N[q], c->field + (int64_t)cell * cv->nb, &v);
+        else orc_eval_field(cv->ngeo, 1, cv->M[q], c->field + (int64_t)cell * cv->ngeo, &v);
         return v;
     }
     return c->p[0];

@@ -249,7 +249,7 @@ def test_argument_checks_of_the_mechanics_and_sarcomere_entry_points(tb, device)
 def test_q2_scalar_forms_parity(tb, oracle, device):
     """Mass, diffusion and linear forms on the triquadratic scalar field (LagrangeCollection{2} on hexahedra: 27×27 element matrices,
     mass.jl:28-43, diffusion.jl:28-50, analytical_coefficient.jl:80-101) against the oracle on a distorted mesh; K·1 = 0, Σ M = volume;
-    strategies and coefficient kinds that are not implemented for this field are refused, not approximated."""
+    constant and heterogeneous (first-order nodal) coefficients; the patch strategy is refused for this field, not approximated."""
     g = tb.generate_mesh(tb.Hexahedron, (4, 3, 3), (0, 0, 0), (1.0, 0.7, 0.5), perturb=0.15)
     dh = tb.DofHandler(g, tb.LagrangeCollection(2))
     assert dh.cell_dofs.shape[1] == 27
@@ -283,6 +283,27 @@ def test_q2_scalar_forms_parity(tb, oracle, device):
     with pytest.raises(tb.TBError) as e:
         tb.update_operator(tb.setup_operator(tb.PatchAssemblyStrategy(device), tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.0)), dh, sp), 0.0)
     assert e.value.code == tb._lib.TB_ERR_UNSUPPORTED
+    # heterogeneous coefficients: first-order nodal data per cell — fibre frames (spectral tensor, κ/(Cₘχ) wrap), isotropic conductivity, density
+    rng = np.random.default_rng(5)
+    nc = g.n_cells
+    ffield = rng.normal(size=(nc, 8, 3)) * 0.3 + np.array([2.0, 0, 0])
+    sfield = rng.normal(size=(nc, 8, 3)) * 0.3 + np.array([0, 2.0, 0])
+    nfield = rng.normal(size=(nc, 8, 3)) * 0.3 + np.array([0, 0, 2.0])
+    lam = np.array([3.0, 1.2, 0.4])
+    kfield = rng.uniform(0.2, 3.0, size=(nc, 8))
+    for st in (tb.PerColorAssemblyStrategy(device), tb.ElementAssemblyStrategy(device)):
+        Kf = tb.update_operator(tb.setup_operator(st, tb.BilinearDiffusionIntegrator(tb.ConductivityToDiffusivityCoefficient(
+            tb.SpectralTensorCoefficient(tb.OrthotropicMicrostructureModel(ffield, sfield, nfield), tb.ConstantCoefficient(lam)),
+            tb.ConstantCoefficient(1.3), tb.ConstantCoefficient(0.9))), dh, sp), 0.0)
+        Kfref = oracle.assemble_matrix(om, 1, oracle.Coef(oracle.COEF_SPECTRAL_FIELD, lam, field=np.stack([ffield, sfield, nfield], axis=2), Cm=1.3, chi=0.9, wrap=True),
+                                       sp.rowptr, sp.colidx)
+        assert rel_err(Kf.A.to_host(), Kfref) < TOL
+        Ki = tb.update_operator(tb.setup_operator(st, tb.BilinearDiffusionIntegrator(tb.FieldCoefficient(kfield)), dh, sp), 0.0)
+        Kiref = oracle.assemble_matrix(om, 1, oracle.Coef(oracle.COEF_FIELD_SCALAR, [0.0], field=kfield), sp.rowptr, sp.colidx)
+        assert rel_err(Ki.A.to_host(), Kiref) < TOL
+        Mf = tb.update_operator(tb.setup_operator(st, tb.BilinearMassIntegrator(tb.FieldCoefficient(kfield)), dh, sp), 0.0)
+        Mfref = oracle.assemble_matrix(om, 0, oracle.Coef(oracle.COEF_FIELD_SCALAR, [0.0], field=kfield), sp.rowptr, sp.colidx)
+        assert rel_err(Mf.A.to_host(), Mfref) < TOL
     # a heat step on the quadratic field: A = M − Δt K is symmetric positive definite, CG converges to scipy's solution
     import scipy.sparse.linalg as sla
     st = tb.PerColorAssemblyStrategy(device)

@@ -318,7 +318,9 @@ int tb_form_create(tb_mesh *mesh, int form_kind, int qorder, const tb_coef *coef
     if (qorder == 0) qorder = std::max(2 * kind_order(mesh->field_kind) - 1, 2); // src/discretization/fem.jl:52-55
     auto f = std::make_unique<tb_form>();
     f->mesh = mesh; f->kind = form_kind; f->qorder = qorder; f->coef = *coef; f->coef.field = nullptr;
-    const int nb = mesh->nb;
+    // field coefficients are first-order nodal data per cell (coefficients.jl:85-99): the cell's own basis for first-order fields, the
+    // eight geometry nodes for the quadratic field
+    const int nb = mesh->field_kind == TB_HEX27 ? 8 : mesh->nb;
     int64_t need_field = 0;
     if (form_kind == TB_FORM_MASS) {
         TB_REQUIRE(coef->kind == TB_COEF_CONST_SCALAR || coef->kind == TB_COEF_FIELD_SCALAR, "mass form: coefficient kind %d", coef->kind);

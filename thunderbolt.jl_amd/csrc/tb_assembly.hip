@@ -707,7 +707,7 @@ __device__ __forceinline__ void q2_geometry(const double *s_x, int q, double *ge
     }
 }
 
-template <int FORM>
+template <int FORM, bool FIELD>
 __global__ void __launch_bounds__(256)
 k_matrix_q2(MeshView m, FormArgs fa, const int32_t *__restrict__ list, const int64_t *__restrict__ rowptr, const uint16_t *__restrict__ pos, double *__restrict__ nz,
             int atomic /*0 rmw, 1 atomic, 2 store Kₑ*/, double *__restrict__ ke, Status *st)
@@ -723,7 +723,14 @@ k_matrix_q2(MeshView m, FormArgs fa, const int32_t *__restrict__ list, const int
     for (int i = tid; i < 24; i += 256) s_x[i] = m.xyz[3 * (int64_t)m.conn[cell * 8 + i / 3] + i % 3];
     if constexpr (FORM == TB_FORM_MASS) for (int i = tid; i < 729; i += 256) s_N[i / 27][i % 27] = tb.N[i / 27][i % 27];
     __syncthreads();
-    if (tid < 27) q2_geometry(s_x, tid, s_geo[tid], nullptr, cell, st);
+    if (tid < 27) {
+        q2_geometry(s_x, tid, s_geo[tid], nullptr, cell, st);
+        if constexpr (FORM == TB_FORM_MASS) { // ρ·dΩ: constant density, or first-order nodal data per cell interpolated at the point
+            double rho = fa.rho;
+            if constexpr (FIELD) { rho = 0.0; for (int a = 0; a < 8; ++a) rho += tb.M[tid][a] * fa.field[cell * 8 + a]; }
+            s_geo[tid][9] *= rho;
+        }
+    }
     __syncthreads();
     if constexpr (FORM == TB_FORM_DIFFUSION) {
         // ∇Nₐ = ∂Nₐ/∂ξ · J⁻¹ and T = dΩ · D · ∇Nₐ for every (point, node)
@@ -734,10 +741,18 @@ k_matrix_q2(MeshView m, FormArgs fa, const int32_t *__restrict__ list, const int
             double gk[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) gk[k] = d0 * ji[k] + d1 * ji[3 + k] + d2 * ji[6 + k];
+            double D[9];
+            if constexpr (FIELD) { // tensor tabulated at the 27 points of the cell (k_tabulate_spectral / _isotropic over Hex8<3>: same point order)
+                const double *dq = fa.dtab + (cell * 27 + q) * 6;
+                D[0] = dq[0]; D[1] = D[3] = dq[1]; D[2] = D[6] = dq[2]; D[4] = dq[3]; D[5] = D[7] = dq[4]; D[8] = dq[5];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 9; ++e) D[e] = fa.D[e];
+            }
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 s_G[q][a][k] = gk[k];
-                s_T[q][a][k] = ji[9] * (fa.D[3 * k] * gk[0] + fa.D[3 * k + 1] * gk[1] + fa.D[3 * k + 2] * gk[2]);
+                s_T[q][a][k] = ji[9] * (D[3 * k] * gk[0] + D[3 * k + 1] * gk[1] + D[3 * k + 2] * gk[2]);
             }
         }
         __syncthreads();
@@ -751,7 +766,7 @@ k_matrix_q2(MeshView m, FormArgs fa, const int32_t *__restrict__ list, const int
             double v[3] = {0.0, 0.0, 0.0};
             if constexpr (FORM == TB_FORM_MASS) {
                 for (int q = 0; q < 27; ++q) {
-                    const double wi = fa.rho * s_geo[q][9] * s_N[q][i];
+                    const double wi = s_geo[q][9] * s_N[q][i];
 #pragma unroll
                     for (int c = 0; c < 3; ++c) v[c] += wi * s_N[q][j0 + c];
                 }
@@ -772,7 +787,7 @@ k_matrix_q2(MeshView m, FormArgs fa, const int32_t *__restrict__ list, const int
         double v = 0.0;
         if constexpr (FORM == TB_FORM_MASS) {
             // Mₑ[i,j] += ρ·Nᵢ·Nⱼ·dΩ  (mass.jl:32-42)
-            for (int q = 0; q < 27; ++q) v += fa.rho * s_geo[q][9] * s_N[q][i] * s_N[q][j];
+            for (int q = 0; q < 27; ++q) v += s_geo[q][9] * s_N[q][i] * s_N[q][j];
         } else {
             // Kₑ[i,j] −= (∇Nⱼ·D·∇Nᵢ)·dΩ  (diffusion.jl:38-49; argument order of _inner_product_helper, utils.jl:409-410)
             for (int q = 0; q < 27; ++q) v -= s_G[q][j][0] * s_T[q][i][0] + s_G[q][j][1] * s_T[q][i][1] + s_G[q][j][2] * s_T[q][i][2];
@@ -846,7 +861,20 @@ static int run_q2(tb_form *f, tb_pattern *p, int strategy, double t, double *d_n
 {
     tb_mesh *m = f->mesh;
     tb_device *dev = m->dev;
-    if (f->field) { set_error("Q2 scalar forms take constant coefficients (field coefficients are implemented for first-order fields)"); return TB_ERR_UNSUPPORTED; }
+    if (f->field && f->kind == TB_FORM_DIFFUSION && !f->d_dtab) { // first assembly: tabulate the tensor at the 27 points from the first-order nodal data
+        const size_t bytes = sizeof(double) * (size_t)m->n_cells * 27 * 6;
+        hipError_t e = hipMalloc((void **)&f->d_dtab, bytes);
+        if (e != hipSuccess) { set_error("diffusion tensor table (%zu B): %s", bytes, hipGetErrorString(e)); return TB_ERR_NOMEM; }
+        const double sc = f->coef.wrap ? 1.0 / (f->coef.Cm * f->coef.chi) : 1.0;
+        if (f->coef.kind == TB_COEF_FIELD_SCALAR)
+            hipLaunchKernelGGL((k_tabulate_isotropic<Hex8<3>>), dim3(nblocks(m->n_cells, 256)), dim3(256), 0, dev->stream, f->d_field, m->n_cells, sc, f->d_dtab);
+        else
+            hipLaunchKernelGGL((k_tabulate_spectral<Hex8<3>>), dim3(nblocks(m->n_cells, 256)), dim3(256), 0, dev->stream, f->d_field, m->n_cells, f->coef.p[0],
+                               f->coef.p[1], f->coef.p[2], sc, f->d_dtab);
+        TB_HIP(hipGetLastError());
+        TB_HIP(hipStreamSynchronize(dev->stream));
+        (void)hipFree(f->d_field); f->d_field = nullptr;
+    }
     const MeshView mv = make_view(m);
     const FormArgs fa = make_args(f, t);
     const bool ea = d_nz && (strategy == TB_STRATEGY_ELEMENT);
@@ -863,10 +891,10 @@ static int run_q2(tb_form *f, tb_pattern *p, int strategy, double t, double *d_n
     }
     auto go = [&](const int32_t *list, int64_t n, int atomic) -> int {
         if (n == 0) return TB_OK;
-        if (d_nz && f->kind == TB_FORM_MASS)
-            hipLaunchKernelGGL(k_matrix_q2<TB_FORM_MASS>, dim3((unsigned)n), dim3(256), 0, dev->stream, mv, fa, list, p->d_rowptr, p->d_q2pos, d_nz, atomic, kebuf, dev->d_status);
-        else if (d_nz)
-            hipLaunchKernelGGL(k_matrix_q2<TB_FORM_DIFFUSION>, dim3((unsigned)n), dim3(256), 0, dev->stream, mv, fa, list, p->d_rowptr, p->d_q2pos, d_nz, atomic, kebuf, dev->d_status);
+#define TB_Q2(FORM, FIELD) hipLaunchKernelGGL((k_matrix_q2<FORM, FIELD>), dim3((unsigned)n), dim3(256), 0, dev->stream, mv, fa, list, p->d_rowptr, p->d_q2pos, d_nz, atomic, kebuf, dev->d_status)
+        if (d_nz && f->kind == TB_FORM_MASS) { if (f->field) TB_Q2(TB_FORM_MASS, true); else TB_Q2(TB_FORM_MASS, false); }
+        else if (d_nz) { if (f->field) TB_Q2(TB_FORM_DIFFUSION, true); else TB_Q2(TB_FORM_DIFFUSION, false); }
+#undef TB_Q2
         else hipLaunchKernelGGL(k_vector_q2, dim3((unsigned)n), dim3(64), 0, dev->stream, mv, fa, list, d_b, atomic, dev->d_status);
         TB_HIP(hipGetLastError());
         return TB_OK;
