@@ -272,9 +272,14 @@ k_spmv_dot(int64_t nrows, const int64_t *__restrict__ rowptr, const int32_t *__r
 
 __global__ void __launch_bounds__(256)
 k_cg_update_dev(int64_t n, const double *__restrict__ rz, const double *__restrict__ pAp, const double *__restrict__ p, const double *__restrict__ Ap,
-                const double *__restrict__ dinv, double *__restrict__ x, double *__restrict__ r, double *__restrict__ rz_next, double *__restrict__ rr)
+                const double *__restrict__ dinv, double *__restrict__ x, double *__restrict__ r, double *__restrict__ rz_next, double *__restrict__ rr,
+                double *__restrict__ flag)
 {
-    const double alpha = *rz / *pAp;
+    // pᵀAp ≤ 0 with a non-zero residual: the matrix is not positive definite — remembered in a sticky flag the host reads at its next
+    // convergence check; at exact convergence (r = 0 ⇒ p = 0) the step is simply empty
+    const double pap = *pAp;
+    const double alpha = pap > 0.0 ? *rz / pap : 0.0;
+    if (!(pap > 0.0) && *rz != 0.0 && blockIdx.x == 0 && threadIdx.x == 0) *flag = pap == 0.0 ? -1e-300 : pap;
     double a = 0.0, c = 0.0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -294,7 +299,7 @@ __global__ void __launch_bounds__(256)
 k_cg_direction_dev(int64_t n, const double *__restrict__ rz, const double *__restrict__ rz_next, double *__restrict__ retired, double *__restrict__ pAp_rr,
                    const double *__restrict__ r, const double *__restrict__ dinv, double *__restrict__ p)
 {
-    const double beta = *rz_next / *rz;
+    const double beta = *rz > 0.0 ? *rz_next / *rz : 0.0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = (dinv ? dinv[i] * r[i] : r[i]) + beta * p[i];
     if (blockIdx.x == 0 && threadIdx.x == 0) { *retired = 0.0; pAp_rr[0] = 0.0; pAp_rr[1] = 0.0; }
@@ -314,27 +319,33 @@ int launch_cg(tb_pattern *pat, const double *A, const double *b, double *x, doub
     const double *dp = jacobi ? dinv : nullptr;
     int rc = launch_spmv(pat, A, x, 1.0, 0.0, Ap);
     if (rc) return rc;
-    TB_HIP(hipMemsetAsync(scal, 0, 5 * sizeof(double), dev->stream));
+    TB_HIP(hipMemsetAsync(scal, 0, 6 * sizeof(double), dev->stream)); // scal[5]: sticky "pᵀAp ≤ 0" flag
     // k_cg_init writes r·z to out[0] and r·r to out[1]: point it at (scal[0], scal[1]) and move r·r to its slot afterwards
     hipLaunchKernelGGL(k_cg_init, dim3(g), dim3(256), 0, dev->stream, n, b, Ap, dp, r, p, scal);
-    double h[2];
+    double h[3];
     TB_HIP(hipMemcpyAsync(h, scal, 2 * sizeof(double), hipMemcpyDeviceToHost, dev->stream));
     TB_HIP(hipStreamSynchronize(dev->stream));
     TB_HIP(hipMemsetAsync(scal + 1, 0, sizeof(double), dev->stream)); // slot 1 becomes the "next r·z" accumulator
     double rnorm = std::sqrt(h[1]);
     const double tol = atol + rtol * rnorm;
+    // The host looks at (‖r‖², flag) once per `check` iterations: small systems are bound by the host round trip, not by the kernels, so they
+    // run a few iterations between looks (at most check − 1 iterations past the tolerance); large ones look every iteration.
+    static const int check_env = getenv("TB_CG_CHECK_EVERY") ? atoi(getenv("TB_CG_CHECK_EVERY")) : 0;
+    const int check = check_env > 0 ? check_env : (n >= 262144 ? 1 : 4);
     int it = 0, cur = 0;
     while (rnorm > tol && it < maxiter) {
         const int nxt = (cur + 1) % 3, ret = (cur + 2) % 3;
         hipLaunchKernelGGL(k_spmv_dot<LANES>, dim3(gs), dim3(256), 0, dev->stream, n, pat->d_rowptr, pat->d_colidx, A, p, Ap, scal + 3);
-        hipLaunchKernelGGL(k_cg_update_dev, dim3(g), dim3(256), 0, dev->stream, n, scal + cur, scal + 3, p, Ap, dp, x, r, scal + nxt, scal + 4);
-        TB_HIP(hipMemcpyAsync(h, scal + 3, 2 * sizeof(double), hipMemcpyDeviceToHost, dev->stream));
+        hipLaunchKernelGGL(k_cg_update_dev, dim3(g), dim3(256), 0, dev->stream, n, scal + cur, scal + 3, p, Ap, dp, x, r, scal + nxt, scal + 4, scal + 5);
+        const bool look = (it + 1) % check == 0 || it + 1 == maxiter;
+        if (look) TB_HIP(hipMemcpyAsync(h, scal + 3, 3 * sizeof(double), hipMemcpyDeviceToHost, dev->stream));
         hipLaunchKernelGGL(k_cg_direction_dev, dim3(g), dim3(256), 0, dev->stream, n, scal + cur, scal + nxt, scal + ret, scal + 3, r, dp, p);
-        TB_HIP(hipStreamSynchronize(dev->stream));
-        if (!(h[0] > 0.0)) { set_error("tb_cg_solve: matrix is not positive definite (pᵀAp = %g)", h[0]); return TB_ERR_BAD_ARG; }
-        rnorm = std::sqrt(h[1]);
         cur = nxt;
         ++it;
+        if (!look) continue;
+        TB_HIP(hipStreamSynchronize(dev->stream));
+        if (h[2] != 0.0) { set_error("tb_cg_solve: matrix is not positive definite (pᵀAp = %g)", h[2] == -1e-300 ? 0.0 : h[2]); return TB_ERR_BAD_ARG; }
+        rnorm = std::sqrt(h[1]);
     }
     TB_HIP(hipGetLastError());
     if (iters) *iters = it;
