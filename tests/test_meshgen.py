@@ -122,3 +122,20 @@ def test_ideal_lv_microstructure(tb):
         out = np.cross(P[2] - P[0], P[3] - P[1])
         nn = n[c].mean(axis=0)
         assert abs(np.dot(out, nn)) / np.linalg.norm(out) > 0.8
+
+
+def test_generated_box_sets_match_predicates(tb):
+    """test/test_mesh.jl:36-57: the named facet sets of a generated box are the facets picked by the coordinate predicates
+    (addfacetset!(grid, "right_new", x -> x[1] ≈ 1) == getfacetset(grid, "right"), …), cell sets by addcellset!."""
+    g = tb.generate_mesh(tb.Hexahedron, (3, 4, 2), (-1.0, -1.0, -1.0), (1.0, 1.0, 1.0))
+    as_set = lambda a: set(map(tuple, np.asarray(a).tolist()))                          # noqa: E731
+    for name, axis, val in (("right", 0, 1.0), ("left", 0, -1.0), ("top", 2, 1.0), ("bottom", 2, -1.0), ("front", 1, -1.0), ("back", 1, 1.0)):
+        new = g.addfacetset(name + "_new", lambda x, axis=axis, val=val: abs(x[axis] - val) < 1e-12)
+        assert as_set(new) == as_set(g.facetset(name)) and len(new) > 0
+    right = g.addcellset("right_cells", lambda x: x[0] >= 0.0 - 1e-12)
+    left = g.addcellset("left_cells", lambda x: x[0] <= 0.0 + 1e-12)
+    assert len(right) + len(left) >= g.n_cells - 4 * 2 and set(right).isdisjoint(set(left))   # nx = 3: the middle column belongs to neither
+    # a generated ring: the endocardium picked by radius
+    ring = tb.generate_ring_mesh(8, 2, 2)
+    endo = ring.addfacetset("endo_new", lambda x: np.hypot(x[0], x[1]) < 0.75 + 1e-9)
+    assert as_set(endo) == as_set(ring.facetset("Endocardium"))

@@ -235,6 +235,33 @@ class Grid:
     def getcellset(self, name):
         return self.cellsets[name]
 
+    # Ferrite.reference_facets(RefHexahedron), 0-based vertex ids, in Ferrite's facet order
+    HEX_FACETS = ((0, 3, 2, 1), (0, 1, 5, 4), (1, 2, 6, 5), (2, 3, 7, 6), (0, 4, 7, 3), (4, 5, 6, 7))
+
+    def addfacetset(self, name, predicate, all=True, boundary_only=True):
+        """addfacetset!(grid, name, x -> Bool; all = true) (Ferrite): the (cell, local facet) pairs — 0-based — whose nodes all (any)
+        satisfy the predicate; boundary facets only, like Ferrite's default use on generated grids (boundary_only=False: internal ones too)."""
+        if self.cell_kind != Hexahedron:
+            raise NotImplementedError("addfacetset: hexahedral grids")
+        if getattr(self, "facetsets", None) is None:
+            self.facetsets = {}
+        ok = np.array([bool(predicate(x)) for x in self.xyz])
+        out = []
+        count = {}
+        if boundary_only:
+            for c in range(self.n_cells):
+                for f in self.HEX_FACETS:
+                    key = tuple(sorted(self.conn[c, list(f)].tolist()))
+                    count[key] = count.get(key, 0) + 1
+        for c in range(self.n_cells):
+            for lf, f in enumerate(self.HEX_FACETS):
+                nodes = self.conn[c, list(f)]
+                hit = ok[nodes].all() if all else ok[nodes].any()
+                if hit and (not boundary_only or count[tuple(sorted(nodes.tolist()))] == 1):
+                    out.append((c, lf))
+        self.facetsets[name] = np.array(out, dtype=np.int32).reshape(-1, 2)
+        return self.facetsets[name]
+
     def getnodeset(self, name):
         return self.nodesets[name]
 
