@@ -139,3 +139,25 @@ def test_generated_box_sets_match_predicates(tb):
     ring = tb.generate_ring_mesh(8, 2, 2)
     endo = ring.addfacetset("endo_new", lambda x: np.hypot(x[0], x[1]) < 0.75 + 1e-9)
     assert as_set(endo) == as_set(ring.facetset("Endocardium"))
+
+
+@pytest.mark.parametrize("make", ["box", "ring", "lv_hex"])
+def test_uniform_refinement(tb, make):
+    """test/test_mesh.jl:60-65: eight times the cells, all hexahedra, positive Jacobians; plus: the volume is that of the coarse mesh's
+    trilinear cells refined (equal for the box), nodes are shared between neighbours (no duplicates), the refined box is the box."""
+    g = {"box": lambda: tb.generate_mesh(tb.Hexahedron, (3, 2, 2), (0, 0, 0), (1.0, 0.7, 0.5), perturb=0.1), "ring": lambda: tb.generate_ring_mesh(8, 2, 2),
+         "lv_hex": lambda: tb.generate_ideal_lv_mesh_hex(8, 2, 3)}[make]()
+    f = tb.uniform_refinement(g)
+    assert f.n_cells == 8 * g.n_cells
+    dets, vol = detj_and_volume(f)
+    assert dets.min() > 0.0
+    assert len(np.unique(np.round(f.xyz, 12), axis=0)) == f.n_nodes and len(np.unique(f.conn)) == f.n_nodes
+    _, vol0 = detj_and_volume(g)
+    if make == "box":
+        assert len(boundary_facet_keys(f)) == 4 * len(boundary_facet_keys(g))
+    assert abs(vol - vol0) < 0.05 * vol0                                               # distorted trilinear cells are not reproduced exactly by their eight children
+    g0 = tb.generate_mesh(tb.Hexahedron, (2, 2, 2), (0, 0, 0), (1.0, 1.0, 1.0))
+    f0 = tb.uniform_refinement(g0)
+    np.testing.assert_allclose(detj_and_volume(f0)[1], 1.0, rtol=1e-13)
+    ref = tb.generate_mesh(tb.Hexahedron, (4, 4, 4), (0, 0, 0), (1.0, 1.0, 1.0))
+    assert {tuple(np.round(x, 12)) for x in f0.xyz} == {tuple(np.round(x, 12)) for x in ref.xyz}

@@ -229,3 +229,46 @@ def ideal_lv_microstructure(g, alpha_endo=np.deg2rad(80.0), alpha_epi=np.deg2rad
     s = np.cross(nrm, f)
     return f[g.conn], s[g.conn], nrm[g.conn]
 
+
+
+def uniform_refinement(g):
+    """uniform_refinement(grid) for hexahedral grids (src/mesh/tools.jl:257-300): every hexahedron is cut into eight by its edge, face
+    and cell centres; new nodes are appended after the old ones — edge centres, face centres, cell centres — shared between
+    neighbouring cells.  Sets are not transferred (the reference leaves that as a TODO as well)."""
+    if g.cell_kind != Hexahedron:
+        raise NotImplementedError("uniform_refinement: hexahedral grids")
+    conn = g.conn.astype(np.int64)
+    nc = len(conn)
+    # Ferrite's reference edges / faces of the hexahedron, 0-based vertex ids
+    E = ((0, 1), (1, 2), (2, 3), (3, 0), (4, 5), (5, 6), (6, 7), (7, 4), (0, 4), (1, 5), (2, 6), (3, 7))
+    F = ((0, 3, 2, 1), (0, 1, 5, 4), (1, 2, 6, 5), (2, 3, 7, 6), (0, 4, 7, 3), (4, 5, 6, 7))
+    ekeys = np.sort(np.stack([conn[:, list(e)] for e in E], axis=1), axis=2).reshape(-1, 2)
+    eu, einv = np.unique(ekeys, axis=0, return_inverse=True)
+    fkeys = np.sort(np.stack([conn[:, list(f)] for f in F], axis=1), axis=2).reshape(-1, 4)
+    fu, finv = np.unique(fkeys, axis=0, return_inverse=True)
+    n0 = g.n_nodes
+    edge_id = n0 + einv.reshape(nc, 12)
+    face_id = n0 + len(eu) + finv.reshape(nc, 6)
+    cell_id = n0 + len(eu) + len(fu) + np.arange(nc)
+    xyz = np.concatenate([g.xyz, g.xyz[eu].mean(axis=1), g.xyz[fu].mean(axis=1), g.xyz[conn].mean(axis=1)])
+    # the 27 points of a cell on the 3×3×3 lattice (index 0, 1, 2 per direction = vertex, centre, vertex)
+    lat = np.empty((nc, 3, 3, 3), dtype=np.int64)
+    vpos = ((0, 0, 0), (2, 0, 0), (2, 2, 0), (0, 2, 0), (0, 0, 2), (2, 0, 2), (2, 2, 2), (0, 2, 2))
+    for v, (i, j, k) in enumerate(vpos):
+        lat[:, i, j, k] = conn[:, v]
+    for e, (a, b) in enumerate(E):
+        i, j, k = [(vpos[a][d] + vpos[b][d]) // 2 for d in range(3)]
+        lat[:, i, j, k] = edge_id[:, e]
+    for f, vs in enumerate(F):
+        i, j, k = [sum(vpos[v][d] for v in vs) // 4 for d in range(3)]
+        lat[:, i, j, k] = face_id[:, f]
+    lat[:, 1, 1, 1] = cell_id
+    new = np.empty((nc, 8, 8), dtype=np.int32)
+    sub = 0
+    for k in range(2):
+        for j in range(2):
+            for i in range(2):
+                for v, (a, b, c) in enumerate(((0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 1, 1))):
+                    new[:, sub, v] = lat[:, i + a, j + b, k + c]
+                sub += 1
+    return Grid(Hexahedron, xyz, new.reshape(-1, 8))
