@@ -88,8 +88,22 @@ for k in range(nsteps):
         un = cache.un.to_host().reshape(model.nstates, npts)
         ca_node = np.empty(g.n_nodes); ca_node = un[ica][n2d]
         # normalised calcium transient in [0, 1]: rest → 0, systolic peak (≈ 1 µM for TT06) → 1
-        calcium["field"] = np.clip((ca_node[g.conn] - ca_rest) / (1.0e-3 - ca_rest), 0.0, 1.0)
-        ok = tb.nlsolve(u, op, ch, newton, t=t + args.dt)
+        ca_new = np.clip((ca_node[g.conn] - ca_rest) / (1.0e-3 - ca_rest), 0.0, 1.0)
+        # the calcium field is the load parameter of this solve: walk from the previous field to the new one, halving the increment when Newton
+        # fails (a coarse mesh does not take a large activation jump in one step)
+        ca_old, frac, inc, ok = calcium["field"].copy(), 0.0, 1.0, True
+        while frac < 1.0 - 1e-12:
+            trial = min(1.0, frac + inc)
+            calcium["field"] = ca_old + trial * (ca_new - ca_old)
+            ub = u.to_host()
+            if tb.nlsolve(u, op, ch, newton, t=t + args.dt):
+                frac = trial
+            else:
+                u.copy_from_host(ub)
+                inc *= 0.5
+                if inc < 1.0 / 64:
+                    ok = False
+                    break
         dev.synchronize()
         mech_s += time.perf_counter() - t1
         phi = un[model.phi_index]
