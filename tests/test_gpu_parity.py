@@ -1785,6 +1785,57 @@ def test_reference_validation_land2015_benchmark_problem_1(tb, device):
     assert abs(deflection - 3.17) <= 0.02, deflection
 
 
+def test_lv_coordinate_system_by_device_laplace_solves(tb, oracle, device):
+    """The reference's use of its sequential assembly loop (`_assemble_laplacian`, `_solve_dirichlet_laplace`,
+    `_lumped_gradient`, coordinate_systems.jl:145-233) on the device path: the Laplacian equals the oracle's (K = +∇N·∇N), the harmonic
+    coordinates attain 0 and 1 exactly on their surfaces and lie strictly in between elsewhere (test/test_coordinate_systems.jl:181-182),
+    the solve satisfies the discrete equations on the free dofs, and the rule-based fibres built from the coordinates agree with the
+    analytic field of the same ellipsoid."""
+    g = tb.generate_ideal_lv_mesh_hex(16, 4, 8, septum_flatness=0.0, axis_ratio=1.0)
+    cs = tb.compute_lv_coordinate_system(g, device)
+    dh = cs.dh
+    sp = tb.allocate_matrix(dh)
+    K = tb.coordinates.assemble_laplacian(tb.PerColorAssemblyStrategy(device), dh, sp)
+    om = oracle.Mesh(oracle.HEX8, 2, g.xyz, g.conn, dh.cell_dofs)
+    Kref = -oracle.assemble_matrix(om, 1, oracle.Coef(oracle.COEF_CONST_TENSOR, np.eye(3).ravel()), sp.rowptr, sp.colidx)
+    assert rel_err(K.A.to_host(), Kref) < TOL
+    import scipy.sparse as ssp
+    Km = ssp.csr_matrix((Kref, sp.colidx, sp.rowptr), shape=(dh.ndofs, dh.ndofs))
+    endo, n2d = tb.coordinates._facet_dofs(g, dh, "Endocardium")
+    epi, _ = tb.coordinates._facet_dofs(g, dh, "Epicardium")
+    base, _ = tb.coordinates._facet_dofs(g, dh, "Base")
+    apex = n2d[g.getnodeset("Apex")]
+    t, a = cs.u_transmural, cs.u_apicobasal
+    assert np.all(t[endo] == 0.0) and np.all(t[epi] == 1.0) and np.all(a[apex] == 0.0) and np.all(a[base] == 1.0)
+    free_t = np.setdiff1d(np.arange(dh.ndofs), np.concatenate([endo, epi]))
+    free_a = np.setdiff1d(np.arange(dh.ndofs), np.concatenate([apex, base]))
+    assert t[free_t].min() > 0.0 and t[free_t].max() < 1.0 and a[free_a].min() > 0.0 and a[free_a].max() < 1.0
+    assert np.abs((Km @ t)[free_t]).max() < 1e-9 * np.abs(Kref).max() and np.abs((Km @ a)[free_a]).max() < 1e-9 * np.abs(Kref).max()
+    # the transmural coordinate follows the wall fraction of the parametrisation (harmonic in a thick shell: close to, not equal to, linear)
+    rp = np.empty(dh.ndofs); rp[n2d] = g.parametric[:, 2]
+    assert np.abs(t - rp).max() < 0.12
+    th = np.empty(dh.ndofs); th[n2d] = g.parametric[:, 0]
+    from scipy.stats import spearmanr
+    assert spearmanr(a, th)[0] > 0.9                                            # apicobasal grows monotonically from the apex (a point condition: steep near it) to the base
+    # fibres: compare with the analytic helix field away from the apical cap
+    f1, s1, n1 = tb.create_microstructure_model(cs, np.deg2rad(60.0), np.deg2rad(-60.0))
+    f0, s0, n0 = tb.ideal_lv_microstructure(g, np.deg2rad(60.0), np.deg2rad(-60.0))
+    for v in (f1, s1, n1):
+        np.testing.assert_allclose(np.einsum("cai,cai->ca", v, v), 1.0, atol=1e-10)
+    np.testing.assert_allclose(np.einsum("cai,cai->ca", f1, n1), 0.0, atol=1e-10)
+    wall = (g.parametric[g.conn][..., 0] > 0.35 * np.pi / 2)                    # nodes above the apical region
+    cosang = np.abs(np.einsum("cai,cai->ca", f1, f0))[wall]
+    assert np.median(np.degrees(np.arccos(np.clip(cosang, 0, 1)))) < 8.0
+    # and the field drives the mechanics kernels like any other nodal microstructure
+    dhv = tb.DofHandler(g, tb.LagrangeCollection(1) ** 3)
+    spv = tb.allocate_matrix(dhv)
+    op = tb.setup_operator(tb.ElementAssemblyStrategy(device), tb.QuasiStaticModel("d", tb.PK1Model(tb.HolzapfelOgden2009Model(),
+                           tb.OrthotropicMicrostructureModel(f1, s1, n1))), dhv, spv)
+    res = device.zeros(dhv.ndofs)
+    tb.update_linearization(op, device.zeros(dhv.ndofs), 0.0, residual=res)
+    assert np.abs(res.to_host()).max() < 1e-12                                  # stress-free at rest with any frame
+
+
 # ------------------------------------------------------------------------------------------- the reference's own GPU tests
 def quad_problem(tb, oracle, nel, left, right):
     g = tb.generate_mesh(tb.Quadrilateral, nel, left, right)

@@ -7,4 +7,6 @@ from ._lib import TBError, build_library, lib  # noqa: F401
 from .api import *  # noqa: F401,F403
 from . import distributed  # noqa: F401
 from . import meshio  # noqa: F401
+from . import coordinates  # noqa: F401
+from .coordinates import compute_lv_coordinate_system, create_microstructure_model  # noqa: F401
 from .meshgen import generate_ring_mesh, generate_open_ring_mesh, generate_ideal_lv_mesh_hex, ideal_lv_microstructure, uniform_refinement  # noqa: F401
