@@ -1818,7 +1818,7 @@ def test_lv_coordinate_system_by_device_laplace_solves(tb, oracle, device):
     from scipy.stats import spearmanr
     assert spearmanr(a, th)[0] > 0.9                                            # apicobasal grows monotonically from the apex (a point condition: steep near it) to the base
     # fibres: compare with the analytic helix field away from the apical cap
-    f1, s1, n1 = tb.create_microstructure_model(cs, np.deg2rad(60.0), np.deg2rad(-60.0))
+    f1, s1, n1 = tb.create_lumped_microstructure_model(cs, np.deg2rad(60.0), np.deg2rad(-60.0))
     f0, s0, n0 = tb.ideal_lv_microstructure(g, np.deg2rad(60.0), np.deg2rad(-60.0))
     for v in (f1, s1, n1):
         np.testing.assert_allclose(np.einsum("cai,cai->ca", v, v), 1.0, atol=1e-10)
@@ -1834,6 +1834,42 @@ def test_lv_coordinate_system_by_device_laplace_solves(tb, oracle, device):
     res = device.zeros(dhv.ndofs)
     tb.update_linearization(op, device.zeros(dhv.ndofs), 0.0, residual=res)
     assert np.abs(res.to_host()).max() < 1e-12                                  # stress-free at rest with any frame
+
+
+def test_ring_microstructure_from_device_coordinate_system(tb, oracle, device):
+    """test/test_microstructures.jl:1-73 through the device path: compute_midmyocardial_section_coordinate_system (transmural coordinate by a
+    device Laplace solve) on generate_ring_mesh(80,1,1), its value at every quadrature point ≈ 4(r − 0.75) to 0.01, and the ODB25LT generator
+    with all angles zero: sheetlets exactly −z, normals radial, fibres s × n (to 0.05) — evaluated at the quadrature points the way a
+    FieldCoefficient is.  The generated frame then feeds the device diffusion kernel (spectral tensor of the nodal field) against the oracle."""
+    g = tb.generate_ring_mesh(80, 1, 1)
+    cs = tb.compute_midmyocardial_section_coordinate_system(g, device)
+    X = g.xyz[g.conn]
+    SG = np.array([[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, -1, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1]], dtype=float)
+    fn, sn, nn = tb.create_microstructure_model(cs, tb.ODB25LTMicrostructureParameters(0.0, 0.0, 0.0, 0.0, 0.0, 0.0))
+    assert cs.u_transmural.min() == 0.0 and cs.u_transmural.max() == 1.0
+    assert abs(cs.u_apicobasal.min() - 0.4) < 1e-15 and abs(cs.u_apicobasal.max() - 0.6) < 1e-15
+    for xi in SG / np.sqrt(3):
+        N = 0.125 * np.prod(1 + SG * xi, axis=1)
+        x = np.einsum("a,cai->ci", N, X)
+        tm = tb.evaluate_coordinate(cs, xi)[0]
+        assert np.abs(tm - 4 * (np.hypot(x[:, 0], x[:, 1]) - 0.75)).max() < 0.01
+        ndir = x * [1, 1, 0]
+        ndir /= np.linalg.norm(ndir, axis=1, keepdims=True)
+        sdir = np.broadcast_to([0.0, 0.0, -1.0], ndir.shape)
+        f, s, n = (np.einsum("a,cai->ci", N, v) for v in (fn, sn, nn))
+        assert np.abs(s - sdir).max() < 1e-10
+        assert np.abs(f - np.cross(sdir, ndir)).max() < 0.05 and np.abs(n - ndir).max() < 0.05
+    # default ±60° helix field as the eigenvectors of the conductivity tensor on the device
+    f, s, n = tb.create_microstructure_model(cs)
+    dh = cs.dh
+    sp = tb.allocate_matrix(dh)
+    lam = np.array([4.5e-5, 2.0e-5, 1.0e-5])
+    om = oracle.Mesh(oracle.HEX8, 2, g.xyz, g.conn, dh.cell_dofs)
+    Kref = oracle.assemble_matrix(om, 1, oracle.Coef(oracle.COEF_SPECTRAL_FIELD, lam, field=np.stack([f, s, n], axis=2)), sp.rowptr, sp.colidx)
+    for st in (tb.PerColorAssemblyStrategy(device), tb.PatchAssemblyStrategy(device), tb.AtomicAssemblyStrategy(device)):
+        K = tb.update_operator(tb.setup_operator(st, tb.BilinearDiffusionIntegrator(
+            tb.SpectralTensorCoefficient(tb.OrthotropicMicrostructureModel(f, s, n), tb.ConstantCoefficient(lam))), dh, sp), 0.0)
+        assert rel_err(K.A.to_host(), Kref) < TOL
 
 
 # ------------------------------------------------------------------------------------------- the reference's own GPU tests

@@ -161,3 +161,95 @@ def test_uniform_refinement(tb, make):
     np.testing.assert_allclose(detj_and_volume(f0)[1], 1.0, rtol=1e-13)
     ref = tb.generate_mesh(tb.Hexahedron, (4, 4, 4), (0, 0, 0), (1.0, 1.0, 1.0))
     assert {tuple(np.round(x, 12)) for x in f0.xyz} == {tuple(np.round(x, 12)) for x in ref.xyz}
+
+
+def _ring_cs(tb, g):
+    """coordinate system of a ring with closed-form nodal fields (no Laplace solve: host logic only)"""
+    from importlib import import_module
+    C = import_module("thunderbolt.jl_amd.coordinates".replace("thunderbolt.jl_amd", tb.__name__))
+    dh = tb.DofHandler(g)
+    n2d = np.full(g.n_nodes, -1, dtype=np.int64)
+    n2d[g.conn.ravel()] = dh.cell_dofs.ravel()
+    r = np.hypot(g.xyz[:, 0], g.xyz[:, 1])
+    transmural, apicobasal = np.zeros(dh.ndofs), np.zeros(dh.ndofs)
+    transmural[n2d] = 4 * (r - 0.75)
+    z = g.xyz[:, 2]
+    apicobasal[n2d] = 0.4 + 0.2 * (z - z.min()) / (z.max() - z.min())
+    origin = g.xyz.mean(axis=0)
+    zero = C._sheet_direction(g, "RotationalSeam", origin, np.array([0.0, 0.0, 1.0]))
+    rot = C.rotational_from_azimuth(g, origin, [0.0, 0.0, 1.0], zero)
+    return C, C.LVCoordinateSystem(g, dh, transmural, apicobasal, rot)
+
+
+def test_midmyocardial_rotational_coordinate(tb):
+    """test/test_coordinate_systems.jl:398-420: the azimuthal chart on a ring — every element spans exactly 1/num_c of a turn (the branch cut
+    never falls inside an element) and the coordinate is the polar angle"""
+    num_c = 40
+    g = tb.generate_ring_mesh(num_c, 2, 2)
+    C, cs = _ring_cs(tb, g)
+    assert np.isfinite(cs.u_rotational).all()
+    spread = (cs.u_rotational.max(axis=1) - cs.u_rotational.min(axis=1)).max()
+    assert abs(spread - 1 / num_c) < 1e-8
+    X = g.xyz[g.conn]
+    exact = np.mod(np.arctan2(X[..., 1], X[..., 0]), 2 * np.pi) / (2 * np.pi)
+    d = np.abs(C.wrap_rotational(cs.u_rotational) - exact)
+    assert np.minimum(d, 1 - d).max() < 1e-12
+    # values at interior points of the cells stay in [0, 1)
+    for xi in SGN / np.sqrt(3):
+        rr = C.evaluate_coordinate(cs, xi)[2]
+        assert (0.0 <= rr).all() and (rr < 1.0).all()
+    with pytest.raises(ValueError):
+        C.rotational_from_azimuth(g, g.xyz.mean(axis=0), [0, 0, 1.0], [0, 0, 2.0])
+
+
+def test_local_coordinate_axes_are_a_right_handed_frame(tb):
+    """test/test_coordinate_systems.jl:422-470: orthonormal, right-handed (transmural × apicobasal = rotational), transmural pointing away
+    from the long axis"""
+    g = tb.generate_ring_mesh(24, 2, 2)
+    C, cs = _ring_cs(tb, g)
+    X = g.xyz[g.conn]
+    for xi in SGN / np.sqrt(3):
+        t, a, r = C.evaluate_coordinate_axes(cs, xi)
+        for v in (t, a, r):
+            assert np.allclose(np.linalg.norm(v, axis=1), 1.0, atol=1e-13)
+        assert np.abs(np.einsum("ci,ci->c", t, a)).max() < 1e-12 and np.abs(np.einsum("ci,ci->c", t, r)).max() < 1e-12
+        assert np.abs(np.einsum("ci,ci->c", a, r)).max() < 1e-12
+        assert np.linalg.norm(np.cross(t, a) - r, axis=1).max() < 1e-12
+        N = 0.125 * np.prod(1 + SGN * xi, axis=1)
+        x = np.einsum("a,cai->ci", N, X)
+        radial = x * [1, 1, 0]
+        assert (np.einsum("ci,ci->c", t, radial) > 0).all()
+
+
+def test_odb25lt_rule(tb):
+    """microstructure.jl:208-245 and test/test_microstructures.jl:45-71: with all angles zero the sheetlets point in −z, the normals radially
+    outwards and f = s × n; with a helix angle the fibres tilt by exactly that angle out of the circumferential direction, and the triad
+    stays orthonormal for any (α, β, γ)"""
+    g = tb.generate_ring_mesh(80, 1, 1)
+    C, cs = _ring_cs(tb, g)
+    P = C.ODB25LTMicrostructureParameters
+    f, s, n = C.create_microstructure_model(cs, P(0.0, 0.0, 0.0, 0.0, 0.0, 0.0))
+    X = g.xyz[g.conn]
+    ndir = X * [1, 1, 0]
+    ndir /= np.linalg.norm(ndir, axis=2, keepdims=True)
+    sdir = np.broadcast_to([0.0, 0.0, -1.0], ndir.shape)
+    assert np.abs(s - sdir).max() < 1e-12
+    assert np.abs(n - ndir).max() < 0.05 and np.abs(f - np.cross(sdir, ndir)).max() < 0.05
+    # default helix angles ±60°: angle between f and the local circumferential axis is α(transmural), rotation about the transmural axis
+    p = P()
+    f, s, n = C.create_microstructure_model(cs, p)
+    for a in range(8):
+        t_dir, a_dir, c_dir = C.evaluate_coordinate_axes(cs, SGN[a])
+        x = cs.u_transmural[cs.dh.cell_dofs[:, a]]
+        alpha = (1 - x) * p.αendo + x * p.αepi
+        assert np.abs(np.einsum("ci,ci->c", f[:, a], c_dir) - np.cos(alpha)).max() < 1e-12
+        # Rodrigues about the transmural axis: c cos α + (t × c) sin α with t × c = t × (t × a) = −a
+        assert np.abs(np.einsum("ci,ci->c", f[:, a], a_dir) + np.sin(alpha)).max() < 1e-12
+        assert np.abs(np.einsum("ci,ci->c", f[:, a], t_dir)).max() < 1e-12
+    rng = np.random.default_rng(0)
+    f, s, n = C.create_microstructure_model(cs, P(*rng.uniform(-1.2, 1.2, 6)))
+    for u, v in ((f, f), (s, s), (n, n)):
+        assert np.abs(np.einsum("cai,cai->ca", u, v) - 1).max() < 1e-12
+    for u, v in ((f, s), (f, n), (s, n)):
+        assert np.abs(np.einsum("cai,cai->ca", u, v)).max() < 1e-12
+    assert np.abs(np.cross(f, s) - n).max() < 1e-12

@@ -2,8 +2,10 @@
 of its sequential assembly loop (`_assemble_laplacian`, `_solve_dirichlet_laplace`, `_lumped_gradient`, src/modeling/core/coordinate_systems.jl:
 145-233).  The Laplacian is the device diffusion form with D = −I (so that Kₑ[i,j] = +∇Nᵢ·∇Nⱼ dΩ), the Dirichlet data are
 eliminated on the device CSR arrays, the solve is the device Jacobi-CG; the lumped gradient recovery is a host (numpy) setup step.
-Transmural (endocardium 0 → epicardium 1) and apicobasal (apex 0 → base 1) coordinates; the rotational coordinate of the reference
-(discontinuous interpolation across the ridge sheets) is not built."""
+Transmural (endocardium 0 → epicardium 1) and apicobasal (apex 0 → base 1) coordinates; the rotational coordinate is built in its
+azimuthal chart (element-wise discontinuous values, `_compute_rotational_from_azimuth!`), not in the ridge-based chart of a bi-ventricular mesh.
+`create_microstructure_model` is the reference's generator: local axes from the in-cell gradients at the cell's nodes and the ODB25LT angle rule."""
+from dataclasses import dataclass
 import numpy as np
 
 from . import api as tb
@@ -66,8 +68,9 @@ class LVCoordinateSystem:
     """nodal transmural and apicobasal coordinates (dof order of `dh`) of a ventricle with "Endocardium", "Epicardium", "Base" facet sets
     and an "Apex" node set"""
 
-    def __init__(self, grid, dh, transmural, apicobasal):
+    def __init__(self, grid, dh, transmural, apicobasal, rotational=None):
         self.grid, self.dh, self.u_transmural, self.u_apicobasal = grid, dh, transmural, apicobasal
+        self.u_rotational = rotational                                  # (cells, 8): one value per cell-node (DiscontinuousLagrange{1}), or None
 
 
 def _facet_dofs(g, dh, name):
@@ -92,9 +95,172 @@ def compute_lv_coordinate_system(grid, device, strategy=None):
     return LVCoordinateSystem(grid, dh, transmural, apicobasal)
 
 
-def create_microstructure_model(cs, alpha_endo=np.deg2rad(80.0), alpha_epi=np.deg2rad(-65.0)):
-    """Rule-based fibres from the harmonic coordinates, in the spirit of the reference's create_microstructure_model(cs, …, ODB25LT…)
-    (microstructure.jl; simplified: helix angle linear in the transmural coordinate, no transverse or sheet angle): the transmural direction
+def _orthogonal_to(axis):
+    e = np.eye(3)[np.argmin(np.abs(axis))]
+    e = e - (e @ axis) * axis
+    return e / np.linalg.norm(e)
+
+
+def wrap_rotational(r):
+    return np.mod(r, 1.0)
+
+
+def rotational_from_azimuth(grid, origin, axis, zero_direction):
+    """_compute_rotational_from_azimuth! + _unwrap_cell_angles! (coordinate_systems.jl:515-590): r = θ/2π around `axis` per cell-node, each
+    cell unwrapped so that the branch cut falls outside of it and placed on the turn of its mean"""
+    l = np.asarray(axis, dtype=float) / np.linalg.norm(axis)
+    e1 = np.asarray(zero_direction, dtype=float)
+    e1 = e1 - (e1 @ l) * l
+    if np.linalg.norm(e1) < np.sqrt(np.finfo(float).eps):
+        raise ValueError("The azimuth reference direction must not be collinear with the long axis.")
+    e1 /= np.linalg.norm(e1)
+    e2 = np.cross(l, e1)
+    X = grid.xyz[grid.conn]                                             # (cells, 8, 3)
+    d = X - np.asarray(origin, dtype=float)
+    d = d - (d @ l)[..., None] * l
+    tol = 1e-6 * np.linalg.norm(X - X[:, :1], axis=2).max(axis=1)
+    defined = np.linalg.norm(d, axis=2) > tol[:, None]
+    ang = np.where(defined, np.mod(np.arctan2(d @ e2, d @ e1), 2 * np.pi) / (2 * np.pi), 0.0)
+    first = np.argmax(defined, axis=1)
+    ref = np.take_along_axis(ang, first[:, None], axis=1)
+    delta = ang - ref
+    ang = ref + (delta - np.round(delta))                               # rem(·, 1, RoundNearest)
+    cnt = defined.sum(axis=1)
+    mean = np.where(cnt > 0, (ang * defined).sum(axis=1) / np.maximum(cnt, 1), 0.0)
+    turn = np.floor(mean)
+    out = np.where(defined, ang - turn[:, None], (mean - turn)[:, None])
+    out[cnt == 0] = 0.0
+    return out
+
+
+def _sheet_direction(grid, name, origin, axis):
+    """mean radial direction of the facets of `name` (coordinate_systems.jl:341-352), or None"""
+    if name not in grid.facetsets:
+        return None
+    nodes = np.unique(np.concatenate([grid.conn[c, list(tb.Grid.HEX_FACETS[lf])] for c, lf in grid.facetset(name)]))
+    d = grid.xyz[nodes] - origin
+    d = d - (d @ axis)[:, None] * axis
+    nrm = np.linalg.norm(d, axis=1)
+    keep = nrm >= np.finfo(float).eps
+    direction = (d[keep] / nrm[keep, None]).sum(axis=0)
+    if np.linalg.norm(direction) < 0.5:
+        return None
+    return direction / np.linalg.norm(direction)
+
+
+def compute_midmyocardial_section_coordinate_system(grid, device, up=(0.0, 0.0, 1.0), apicobasal_lower=0.4, apicobasal_upper=0.6,
+                                                    epicardium_name="Epicardium", endocardium_name="Endocardium",
+                                                    rotational_zero_direction=None, strategy=None):
+    """compute_midmyocardial_section_coordinate_system(mesh; ridge_anterior = nothing, ridge_posterior = nothing)
+    (coordinate_systems.jl:971-1027): transmural coordinate by a Dirichlet–Laplace solve on the device (clamped to [0,1] as the reference
+    does after its Krylov solve), apicobasal = height along `up` rescaled into [lower, upper], rotational = azimuth around `up` through the
+    node centroid, zero on the "RotationalSeam" sheet if the mesh has one."""
+    dh = tb.DofHandler(grid)
+    sp = tb.allocate_matrix(dh)
+    K = assemble_laplacian(strategy or tb.PerColorAssemblyStrategy(device), dh, sp)
+    endo, n2d = _facet_dofs(grid, dh, endocardium_name)
+    epi, _ = _facet_dofs(grid, dh, epicardium_name)
+    transmural, _ = solve_dirichlet_laplace(K, dh, [(endo, 0.0), (epi, 1.0)])
+    transmural = np.clip(transmural, 0.0, 1.0)
+    up = np.asarray(up, dtype=float)
+    apicobasal = np.zeros(dh.ndofs)
+    apicobasal[n2d[np.arange(grid.n_nodes)]] = grid.xyz @ up
+    apicobasal -= apicobasal.min()
+    apicobasal /= apicobasal.max()
+    apicobasal = apicobasal * (apicobasal_upper - apicobasal_lower) + apicobasal_lower
+    l = up / np.linalg.norm(up)
+    origin = grid.xyz.sum(axis=0) / grid.n_nodes
+    zero = None if rotational_zero_direction is None else np.asarray(rotational_zero_direction, dtype=float)
+    if zero is None:
+        zero = _sheet_direction(grid, "RotationalSeam", origin, l)
+    if zero is None:
+        zero = _orthogonal_to(l)
+    return LVCoordinateSystem(grid, dh, transmural, apicobasal, rotational_from_azimuth(grid, origin, l, zero))
+
+
+def _shape_gradients(X, xi):
+    """∂Nₐ/∂x of the trilinear hexahedron at reference point ξ for every cell: (cells, 8, 3)"""
+    f = 1 + _SGN * np.asarray(xi, dtype=float)
+    dN = np.stack([0.125 * _SGN[:, d] * np.prod(np.delete(f, d, axis=1), axis=1) for d in range(3)], axis=1)
+    J = np.einsum("cai,ad->cid", X, dN)
+    return np.einsum("ad,cdi->cai", dN, np.linalg.inv(J)), 0.125 * np.prod(f, axis=1)
+
+
+def evaluate_coordinate_axes(cs, xi):
+    """evaluate_coordinate_axes + _local_axes (coefficients.jl:427-446, coordinate_systems.jl:30-36) at reference point ξ of every cell:
+    transmural = ∇φ_t/|∇φ_t|, apicobasal = ∇φ_ab made orthogonal to it, rotational = transmural × apicobasal"""
+    dNdx, _ = _shape_gradients(cs.grid.xyz[cs.grid.conn], xi)
+    gt = np.einsum("ca,cai->ci", cs.u_transmural[cs.dh.cell_dofs], dNdx)
+    ga = np.einsum("ca,cai->ci", cs.u_apicobasal[cs.dh.cell_dofs], dNdx)
+    t = gt / np.linalg.norm(gt, axis=1, keepdims=True)
+    a = ga / np.linalg.norm(ga, axis=1, keepdims=True)
+    a = a - np.einsum("ci,ci->c", a, t)[:, None] * t
+    a /= np.linalg.norm(a, axis=1, keepdims=True)
+    r = np.cross(t, a)
+    return t, a, r / np.linalg.norm(r, axis=1, keepdims=True)
+
+
+def evaluate_coordinate(cs, xi):
+    """evaluate_coefficient(::LVCoordinateSystem…) at ξ of every cell: (transmural, apicobasal[, rotational])"""
+    N = 0.125 * np.prod(1 + _SGN * np.asarray(xi, dtype=float), axis=1)
+    out = [cs.u_transmural[cs.dh.cell_dofs] @ N, cs.u_apicobasal[cs.dh.cell_dofs] @ N]
+    if cs.u_rotational is not None:
+        out.append(wrap_rotational(cs.u_rotational @ N))
+    return tuple(out)
+
+
+@dataclass
+class ODB25LTMicrostructureParameters:
+    """ODB25LTMicrostructureParameters (microstructure.jl:192-199): helix α, transversal β and sheetlet γ angles, linear across the wall"""
+    αendo: float = np.deg2rad(60.0)
+    αepi: float = np.deg2rad(-60.0)
+    βendo: float = 0.0
+    βepi: float = 0.0
+    γendo: float = 0.0
+    γepi: float = 0.0
+
+
+def _rotate_around(v, a, theta):
+    """Rodrigues rotation of v around the unit axis a (utils.jl:98-102)"""
+    c, s = np.cos(theta)[..., None], np.sin(theta)[..., None]
+    return v * c + np.cross(a, v) * s + a * np.einsum("...i,...i->...", a, v)[..., None] * (1 - c)
+
+
+def _unit(v):
+    return v / np.linalg.norm(v, axis=-1, keepdims=True)
+
+
+def compute_local_microstructure(p, transmural, axes):
+    """compute_local_microstructure(::ODB25LTMicrostructureParameters, x, axes) (microstructure.jl:208-245)"""
+    t_dir, a_dir, c_dir = axes
+    x = np.asarray(transmural, dtype=float)
+    alpha = (1 - x) * p.αendo + x * p.αepi
+    beta = (1 - x) * p.βendo + x * p.βepi
+    gamma = (1 - x) * p.γendo + x * p.γepi
+    f = _unit(_rotate_around(c_dir, t_dir, alpha))
+    f = _unit(_rotate_around(f, a_dir, -beta))
+    s = _unit(_rotate_around(c_dir, t_dir, alpha + np.pi / 2.0))
+    s = _unit(s - np.einsum("...i,...i->...", s, f)[..., None] * f)
+    s = _unit(_rotate_around(s, f, -gamma))
+    return f, s, _unit(np.cross(f, s))
+
+
+def create_microstructure_model(cs, parameters=None):
+    """create_microstructure_model(coordinate_system, ip_collection, parameters) (microstructure.jl:279-333): the rule evaluated at the nodal
+    quadrature points of every cell (the cell's own gradients there, not a recovered nodal gradient); returns (f, s, n), each (cells, 8, 3)
+    in the [basis, cell] layout a FieldCoefficient / OrthotropicMicrostructureModel takes."""
+    p = parameters or ODB25LTMicrostructureParameters()
+    nc = cs.grid.n_cells
+    f, s, n = (np.zeros((nc, 8, 3)) for _ in range(3))
+    for a in range(8):
+        axes = evaluate_coordinate_axes(cs, _SGN[a])
+        f[:, a], s[:, a], n[:, a] = compute_local_microstructure(p, cs.u_transmural[cs.dh.cell_dofs[:, a]], axes)
+    return f, s, n
+
+
+def create_lumped_microstructure_model(cs, alpha_endo=np.deg2rad(80.0), alpha_epi=np.deg2rad(-65.0)):
+    """Helix-angle rule on *recovered nodal* gradients (`_lumped_gradient`), a continuous variant of create_microstructure_model that stays
+    defined at the apex, where the in-cell gradients of the two coordinates become parallel: the transmural direction
     is ∇φ_t, the longitudinal one ∇φ_ab made orthogonal to it, the circumferential one their cross product; f = cos α c + sin α l,
     n = transmural, s = n × f.  Returns nodal (f, s, n) per cell for OrthotropicMicrostructureModel."""
     g, dh = cs.grid, cs.dh
