@@ -59,6 +59,53 @@ k_spmv(int64_t nrows, const int64_t *__restrict__ rowptr, const int32_t *__restr
     }
 }
 
+__device__ __forceinline__ void block_sum_to(double v, double *out);
+
+// CSR "stream" SpMV: a workgroup owns a run of consecutive rows holding ≤ CAP non-zeros.  Phase 1 streams nzval / colidx of the whole run with
+// every lane busy and fully coalesced (lane i takes entry i, whatever row it belongs to), gathers x and parks the products in LDS; phase 2 sums
+// each row's segment with 8 lanes.  Against the lanes-per-row kernel (27-entry rows fill 27 of 32 lane slots and issue two dependent passes)
+// this keeps CAP/256 independent loads in flight per lane.  DOT: also accumulates xᵀy (the pᵀAp of CG) into *xy.
+template <int CAP, bool DOT>
+__global__ void __launch_bounds__(256)
+k_spmv_stream(int n_blk, const int32_t *__restrict__ blkrow, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const double *__restrict__ nz,
+              const double *__restrict__ x, double alpha, double beta, double *__restrict__ y, double *__restrict__ xy)
+{
+    __shared__ double s[CAP];
+    constexpr int LN = 8;
+    const int sub = threadIdx.x % LN;
+    double acc = 0.0;
+    for (int b = blockIdx.x; b < n_blk; b += gridDim.x) {
+        const int r0 = blkrow[b], r1 = blkrow[b + 1];
+        const int64_t k0 = rowptr[r0];
+        const int len = (int)(rowptr[r1] - k0);
+        const double *nzb = nz + k0;
+        const int32_t *cb = colidx + k0;
+#pragma unroll
+        for (int u = 0; u < CAP / 256; ++u) {
+            const int i = threadIdx.x + u * 256;
+#ifdef TB_SPMV_NT
+            if (i < len) s[i] = __builtin_nontemporal_load(nzb + i) * x[__builtin_nontemporal_load(cb + i)];
+#else
+            if (i < len) s[i] = nzb[i] * x[cb[i]];
+#endif
+        }
+        __syncthreads();
+        for (int r = r0 + threadIdx.x / LN; r < r1; r += 256 / LN) {
+            const int a = (int)(rowptr[r] - k0), e = (int)(rowptr[r + 1] - k0);
+            double v = 0.0;
+            for (int i = a + sub; i < e; i += LN) v += s[i];
+#pragma unroll
+            for (int o = LN / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, LN);
+            if (sub == 0) {
+                if constexpr (DOT) { y[r] = v; acc += x[r] * v; }
+                else y[r] = beta == 0.0 ? alpha * v : alpha * v + beta * y[r];
+            }
+        }
+        __syncthreads();
+    }
+    if constexpr (DOT) block_sum_to(acc, xy);
+}
+
 __global__ void __launch_bounds__(256)
 k_absmax(int64_t n, const double *__restrict__ x, int64_t stride_x, unsigned long long *__restrict__ out)
 {
@@ -109,17 +156,51 @@ int launch_axpy(tb_device *dev, int64_t n, double a, const double *x, double *y)
     return TB_OK;
 }
 
+// row runs of the stream SpMV: greedy cuts of the row sequence at ≤ SPMV_CAP non-zeros; n_blk = −1 (lanes-per-row kernel instead) if a single
+// row exceeds the capacity
+#ifndef TB_SPMV_CAP
+#define TB_SPMV_CAP 2048
+#endif
+constexpr int SPMV_CAP = TB_SPMV_CAP;
+static int stream_plan(tb_pattern *p)
+{
+    if (p->n_blk != 0) return TB_OK;
+    std::vector<int32_t> cut{0};
+    int64_t start = 0;
+    for (int64_t r = 0; r < p->n_rows; ++r) {
+        if (p->h_rowptr[r + 1] - p->h_rowptr[r] > SPMV_CAP) { p->n_blk = -1; return TB_OK; }
+        if (p->h_rowptr[r + 1] - p->h_rowptr[start] > SPMV_CAP) { cut.push_back((int32_t)r); start = r; }
+    }
+    cut.push_back((int32_t)p->n_rows);
+    TB_HIP(hipMalloc((void **)&p->d_blkrow, cut.size() * sizeof(int32_t)));
+    TB_HIP(hipMemcpy(p->d_blkrow, cut.data(), cut.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    p->n_blk = (int64_t)cut.size() - 1;
+    return TB_OK;
+}
+
+static unsigned stream_grid(const tb_pattern *p)
+{
+    static const int64_t cap = getenv("TB_SPMV_GRID") ? atoi(getenv("TB_SPMV_GRID")) : 2048; // 256 CUs × 8 resident workgroups
+    return (unsigned)std::min<int64_t>(p->n_blk, cap);
+}
+
 int launch_spmv(tb_pattern *p, const double *nz, const double *x, double alpha, double beta, double *y)
 {
     tb_device *dev = p->mesh->dev;
-    static const int lanes = getenv("TB_SPMV_LANES") ? atoi(getenv("TB_SPMV_LANES")) : 16;
+    static const int lanes = getenv("TB_SPMV_LANES") ? atoi(getenv("TB_SPMV_LANES")) : 0;
+    if (lanes == 0 && stream_plan(p) == TB_OK && p->n_blk > 0) {
+        hipLaunchKernelGGL((k_spmv_stream<SPMV_CAP, false>), dim3(stream_grid(p)), dim3(256), 0, dev->stream, (int)p->n_blk, p->d_blkrow, p->d_rowptr, p->d_colidx, nz,
+                           x, alpha, beta, y, (double *)nullptr);
+        TB_HIP(hipGetLastError());
+        return TB_OK;
+    }
 #define TB_SPMV(LN) hipLaunchKernelGGL(k_spmv<LN>, dim3(grid_for(dev, p->n_rows * LN, 256)), dim3(256), 0, dev->stream, p->n_rows, p->d_rowptr, p->d_colidx, nz, x, alpha, beta, y)
     switch (lanes) {
     case 2: TB_SPMV(2); break;
     case 4: TB_SPMV(4); break;
-    case 16: TB_SPMV(16); break;
+    case 8: TB_SPMV(8); break;
     case 32: TB_SPMV(32); break;
-    default: TB_SPMV(8);
+    default: TB_SPMV(16);
     }
 #undef TB_SPMV
     TB_HIP(hipGetLastError());
@@ -335,7 +416,11 @@ int launch_cg(tb_pattern *pat, const double *A, const double *b, double *x, doub
     int it = 0, cur = 0;
     while (rnorm > tol && it < maxiter) {
         const int nxt = (cur + 1) % 3, ret = (cur + 2) % 3;
-        hipLaunchKernelGGL(k_spmv_dot<LANES>, dim3(gs), dim3(256), 0, dev->stream, n, pat->d_rowptr, pat->d_colidx, A, p, Ap, scal + 3);
+        if (pat->n_blk > 0)
+            hipLaunchKernelGGL((k_spmv_stream<SPMV_CAP, true>), dim3(stream_grid(pat)), dim3(256), 0, dev->stream, (int)pat->n_blk, pat->d_blkrow, pat->d_rowptr,
+                               pat->d_colidx, A, p, 1.0, 0.0, Ap, scal + 3);
+        else
+            hipLaunchKernelGGL(k_spmv_dot<LANES>, dim3(gs), dim3(256), 0, dev->stream, n, pat->d_rowptr, pat->d_colidx, A, p, Ap, scal + 3);
         hipLaunchKernelGGL(k_cg_update_dev, dim3(g), dim3(256), 0, dev->stream, n, scal + cur, scal + 3, p, Ap, dp, x, r, scal + nxt, scal + 4, scal + 5);
         const bool look = (it + 1) % check == 0 || it + 1 == maxiter;
         if (look) TB_HIP(hipMemcpyAsync(h, scal + 3, 3 * sizeof(double), hipMemcpyDeviceToHost, dev->stream));
