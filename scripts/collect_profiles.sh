@@ -21,6 +21,10 @@ rocprofv3 --kernel-trace --stats -d "$out/ktm" -o ktm -- python3 scripts/bench_m
 python3 scripts/rocpd_summary.py "$out/ktm/ktm_results.db" --json "$out/mechanics_kernel_stats.json" > "$out/mechanics_kernel_stats.txt"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT -d "$out/pmcm" -o pmcm -- python3 scripts/bench_mechanics.py --n 40 --cpu-n 2 > /dev/null 2>&1
 python3 scripts/rocpd_summary.py "$out/pmcm/pmcm_results.db" --json "$out/mechanics_pmc_40.json" > /dev/null
+# monodomain simulation (config 3 as a time loop): the stream SpMV + CG kernels next to the reaction step
+rocprofv3 --kernel-trace --stats -d "$out/kte" -o kte -- python3 examples/monodomain_fhn.py --ionic tt06 --n 216 > "$out/monodomain_tt06_216.json" 2>/dev/null
+python3 scripts/rocpd_summary.py "$out/kte/kte_results.db" --json "$out/monodomain_kernel_stats.json" > "$out/monodomain_kernel_stats.txt"
+rm -rf "$out"/kte
 rm -rf "$out"/kt "$out"/pmc1 "$out"/pmc2 "$out"/pmc3 "$out"/ktm "$out"/pmcm
 ./scripts/microbench/mfma_f64.bin > "$out/mfma_f64_microbench.txt" 2>&1
 tail -c 600 "$out/bench_216.json"; cat "$out/mechanics_80_q2.json" | cut -c1-300; head -5 "$out/kernel_stats.txt"

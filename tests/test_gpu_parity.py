@@ -1872,6 +1872,53 @@ def test_ring_microstructure_from_device_coordinate_system(tb, oracle, device):
         assert rel_err(K.A.to_host(), Kref) < TOL
 
 
+@pytest.mark.parametrize("long_row", [False, True])
+def test_spmv_and_cg_on_ragged_superset_patterns(tb, device, long_row):
+    """The stream SpMV cuts the row sequence into runs of ≤ 2048 non-zeros; a pattern with extra couplings (ragged rows of 8…400 entries, cuts
+    falling anywhere) must give the same product as scipy, assembly into it must leave the extra entries zero, and CG must converge on it.  A row
+    longer than the capacity makes the whole pattern fall back to the lanes-per-row kernel — same answers."""
+    import scipy.sparse as ssp
+    g = tb.generate_mesh(tb.Hexahedron, (16, 15, 14), perturb=0.2)
+    dh = tb.DofHandler(g)
+    base = tb.allocate_matrix(dh)
+    n = dh.ndofs
+    rng = np.random.default_rng(11)
+    P = ssp.csr_matrix((np.ones(base.nnz), base.colidx, base.rowptr), shape=(n, n))
+    rows = rng.integers(0, n, 40)
+    extra = ssp.lil_matrix((n, n))
+    for r in rows:
+        extra[r, rng.choice(n, rng.integers(1, 380), replace=False)] = 1.0
+    if long_row:
+        extra[n // 2, rng.choice(n, 2500, replace=False)] = 1.0
+    S = (P + extra.tocsr() + extra.tocsr().T).tocsr()                           # structurally symmetric superset
+    S.sort_indices()
+    sp = tb.SparsityPattern(S.indptr.astype(np.int64), S.indices.astype(np.int32))
+    if long_row:
+        assert np.diff(sp.rowptr).max() > 2048
+    M = tb.update_operator(tb.setup_operator(tb.PerColorAssemblyStrategy(device), tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.0)), dh, sp), 0.0)
+    Mh = ssp.csr_matrix((M.A.to_host(), sp.colidx, sp.rowptr), shape=(n, n))
+    Mb = tb.update_operator(tb.setup_operator(tb.PerColorAssemblyStrategy(device), tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.0)), dh, base), 0.0)
+    Mbh = ssp.csr_matrix((Mb.A.to_host(), base.colidx, base.rowptr), shape=(n, n))
+    assert abs(Mh - Mbh).max() == 0.0                                           # extras stay zero, the rest is bit-identical
+    # arbitrary values on the whole pattern: the product itself
+    vals = rng.normal(size=sp.nnz)
+    A = device.to_device(vals)
+    xh = rng.normal(size=n)
+    y = device.to_device(rng.normal(size=n))
+    y0 = y.to_host()
+    tb.check(tb.lib().tb_spmv_csr(M.pattern.h, A.ptr, device.to_device(xh).ptr, 1.0, 0.0, y.ptr))
+    ref = ssp.csr_matrix((vals, sp.colidx, sp.rowptr), shape=(n, n)) @ xh
+    assert rel_err(y.to_host(), ref) < TOL
+    y = device.to_device(y0)
+    tb.check(tb.lib().tb_spmv_csr(M.pattern.h, A.ptr, device.to_device(xh).ptr, -0.5, 2.0, y.ptr))
+    assert rel_err(y.to_host(), -0.5 * ref + 2.0 * y0) < TOL
+    # CG on the SPD mass matrix stored in the superset pattern
+    b = device.to_device(Mh @ xh)
+    u = device.zeros(n)
+    its, res = tb.cg_solve(M.pattern, M.A, b, u, rtol=1e-12, atol=0.0, maxiter=400)
+    assert its < 400 and np.abs(u.to_host() - xh).max() < 1e-8
+
+
 # ------------------------------------------------------------------------------------------- the reference's own GPU tests
 def quad_problem(tb, oracle, nel, left, right):
     g = tb.generate_mesh(tb.Quadrilateral, nel, left, right)

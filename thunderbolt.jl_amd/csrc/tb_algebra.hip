@@ -254,16 +254,31 @@ int launch_max(tb_device *dev, int64_t n, const double *x, int64_t stride, doubl
 // ------------------------------------------------------------------------------------------------
 namespace tb {
 
+// D⁻¹ for the Jacobi preconditioner: the position of each row's diagonal entry is a property of the pattern, found once on the host
+// (scanning the rows on the device, one thread per row, cost 1.7 ms per solve at 216³ — more than a CG iteration); −1 = no diagonal stored
 __global__ void __launch_bounds__(256)
-k_extract_diag(int64_t nrows, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const double *__restrict__ nz,
-               double *__restrict__ dinv)
+k_extract_diag(int64_t nrows, const int64_t *__restrict__ diagpos, const double *__restrict__ nz, double *__restrict__ dinv)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nrows) return;
-    double d = 1.0;
-    for (int64_t k = rowptr[r]; k < rowptr[r + 1]; ++k)
-        if (colidx[k] == r) { d = nz[k]; break; }
-    dinv[r] = 1.0 / d;
+    const int64_t k = diagpos[r];
+    dinv[r] = 1.0 / (k >= 0 ? nz[k] : 1.0);
+}
+
+static int launch_extract_diag(tb_pattern *p, const double *nz, double *dinv)
+{
+    tb_device *dev = p->mesh->dev;
+    if (!p->d_diagpos) {
+        std::vector<int64_t> pos((size_t)p->n_rows, -1);
+        for (int64_t r = 0; r < p->n_rows; ++r)
+            for (int64_t k = p->h_rowptr[r]; k < p->h_rowptr[r + 1]; ++k)
+                if (p->h_colidx[k] == r) { pos[r] = k; break; }
+        TB_HIP(hipMalloc((void **)&p->d_diagpos, pos.size() * sizeof(int64_t)));
+        TB_HIP(hipMemcpy(p->d_diagpos, pos.data(), pos.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    }
+    hipLaunchKernelGGL(k_extract_diag, dim3((unsigned)((p->n_rows + 255) / 256)), dim3(256), 0, dev->stream, p->n_rows, p->d_diagpos, nz, dinv);
+    TB_HIP(hipGetLastError());
+    return TB_OK;
 }
 
 __device__ __forceinline__ void block_sum_to(double v, double *out)
@@ -396,7 +411,7 @@ int launch_cg(tb_pattern *pat, const double *A, const double *b, double *x, doub
     const unsigned g = grid_for(dev, n, 256);
     constexpr int LANES = 16; // 16 lanes per row measured best for 27-entry rows (0.96 vs 1.03 ms at 216³ with 8)
     const unsigned gs = grid_for(dev, n * LANES, 256);
-    if (jacobi) hipLaunchKernelGGL(k_extract_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, dev->stream, n, pat->d_rowptr, pat->d_colidx, A, dinv);
+    if (jacobi) { const int rcd = launch_extract_diag(pat, A, dinv); if (rcd) return rcd; }
     const double *dp = jacobi ? dinv : nullptr;
     int rc = launch_spmv(pat, A, x, 1.0, 0.0, Ap);
     if (rc) return rc;
@@ -509,7 +524,7 @@ int launch_gmres(tb_pattern *pat, const double *A, const double *b, double *x, d
     double *V = pat->d_gmres_ws, *w = V + (size_t)(m + 1) * n, *z = w + n, *dinv = z + n, *sc = dinv + n; // sc: h1[m+2] | h2[m+2] | y[m+2]
     double *h1 = sc, *h2 = sc + (m + 2), *yd = sc + 2 * (m + 2);
     const unsigned g = grid_for(dev, n, 256);
-    if (jacobi) hipLaunchKernelGGL(k_extract_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, dev->stream, n, pat->d_rowptr, pat->d_colidx, A, dinv);
+    if (jacobi) { const int rcd = launch_extract_diag(pat, A, dinv); if (rcd) return rcd; }
     const double *dp = jacobi ? dinv : nullptr;
     std::vector<double> H((size_t)(m + 1) * m), cs(m), sn(m), gvec(m + 1), yh(m), hh(2 * (m + 2));
     int it = 0;
