@@ -135,6 +135,8 @@ struct tb_pattern {
     bool map64 = false;
     void *d_emap = nullptr; // [ndpc*ndpc][n_cells] nz index of (cell,i,j): int32 (nnz < 2^31) or int64
     double *d_cg_ws = nullptr;      // CG workspace (r, p, Ap, D⁻¹, 2 scalars)
+    int32_t *d_bcol = nullptr;      // block SpMV of 3-dof-per-node patterns: one column (node) index per 3×3 block
+    int b3 = 0, b3_lanes = 16;      // b3: 0 = not examined, 1 = CSR of 3×3 blocks, −1 = not
     int64_t *d_diagpos = nullptr;   // nz index of each row's diagonal entry (−1 if absent), built at the first Jacobi-preconditioned solve
     int32_t *d_blkrow = nullptr;    // stream SpMV: first row of each workgroup's run of rows (n_blk + 1 entries)
     int64_t n_blk = 0;              // 0 = not planned yet, −1 = a row exceeds the capacity (lanes-per-row kernel)
