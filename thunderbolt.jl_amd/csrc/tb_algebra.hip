@@ -226,7 +226,8 @@ static int block3_plan(tb_pattern *p)
     TB_HIP(hipMalloc((void **)&p->d_bcol, bcol.size() * sizeof(int32_t)));
     TB_HIP(hipMemcpy(p->d_bcol, bcol.data(), bcol.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     const double avg = (double)bcol.size() / (double)nbr; // blocks per node row: 27 for Q1, 64…125 for Q2
-    p->b3_lanes = avg > 80 ? 64 : avg > 36 ? 32 : 16;
+    static const int lanes_env = getenv("TB_SPMV_B3_LANES") ? atoi(getenv("TB_SPMV_B3_LANES")) : 0;
+    p->b3_lanes = lanes_env ? lanes_env : (avg > 36 ? 32 : 16); // measured: 16 ≈ 32 > 64 on Q2 (24³ contraction solve 4.7 / 4.7 / 5.2 s), 16 best on Q1
     p->b3 = 1;
     return TB_OK;
 }
