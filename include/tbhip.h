@@ -363,6 +363,11 @@ int tb_spmv_csr(tb_pattern *pat, const double *d_nzval, const double *d_x, doubl
  * Stops when ‖r‖₂ ≤ atol + rtol·‖r₀‖₂ or after maxiter iterations; reports iterations and the final ‖r‖₂. */
 int tb_cg_solve(tb_pattern *pat, const double *d_Anz, const double *d_b, double *d_x, double rtol, double atol, int maxiter,
                 int jacobi, int *iters, double *resnorm);
+/* The same solve started from a known initial residual: d_r0 = b − A·x₀ supplied by the caller, so neither b nor the product A·x₀ is
+ * formed.  In the backward-Euler heat step (euler.jl:71-101: A = M − Δt·K, b = M·uₙ₋₁, initial guess uₙ₋₁) the residual is
+ * r₀ = Δt·K·uₙ₋₁ (+ source): one SpMV with K replaces the two with M and A. */
+int tb_cg_solve_from_residual(tb_pattern *pat, const double *d_Anz, const double *d_r0, double *d_x, double rtol, double atol, int maxiter,
+                              int jacobi, int *iters, double *resnorm);
 /* Preconditioned CG with a choice of preconditioner.  TB_PRECOND_L1GS: ℓ₁ Gauss–Seidel, symmetric sweep, partitions of `partsize`
  * consecutive rows (the preconditioner the reference documents for its Krylov solves — Thunderbolt.Preconditioners.L1GSPrecBuilder /
  * SymmetricSweep, docs/src/api-reference/solver.md:13-22; Baker–Falgout–Kolev–Yang 2011): M = (D̃ + L_p) D̃⁻¹ (D̃ + U_p) with

@@ -1964,6 +1964,40 @@ def test_block_spmv_of_vector_field_patterns(tb, device, order):
             assert its < 500 and np.abs(u.to_host() - xh).max() < 1e-9
 
 
+def test_cg_from_initial_residual_matches_the_plain_solve(tb, device):
+    """tb_cg_solve_from_residual: handing CG the initial residual r₀ = b − A·x₀ gives the iterates of the plain solve (same count, same answer
+    to rounding); in the heat step that residual is Δt·K·uₙ₋₁, which the backward-Euler stage now uses (euler.jl:71-101)."""
+    g = tb.generate_mesh(tb.Hexahedron, (12, 11, 10), perturb=0.2)
+    dh = tb.DofHandler(g)
+    sp = tb.allocate_matrix(dh)
+    st = tb.PatchAssemblyStrategy(device)
+    M = tb.update_operator(tb.setup_operator(st, tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.0)), dh, sp), 0.0)
+    K = tb.update_operator(tb.setup_operator(st, tb.BilinearDiffusionIntegrator(tb.ConstantCoefficient(np.diag([3e-2, 1e-2, 2e-2]))), dh, sp), 0.0)
+    dt = 0.7
+    A = device.zeros(sp.nnz)
+    tb.heat_system_matrix(device, M, K, dt, A)
+    rng = np.random.default_rng(2)
+    u0 = rng.normal(size=dh.ndofs)
+    b = device.zeros(dh.ndofs)
+    M.mul(b, device.to_device(u0))
+    x1 = device.to_device(u0)
+    it1, res1 = tb.cg_solve(M.pattern, A, b, x1, rtol=1e-10, atol=0.0, maxiter=300)
+    r0 = device.zeros(dh.ndofs)
+    uu = device.to_device(u0)
+    tb.check(tb.lib().tb_spmv_csr(K.pattern.h, K.A.ptr, uu.ptr, dt, 0.0, r0.ptr))
+    x2 = device.to_device(u0)
+    it2, res2 = tb.cg_solve(M.pattern, A, r0, x2, rtol=1e-10, atol=0.0, maxiter=300, b_is_residual=True)
+    assert it1 == it2 and 0 < it1 < 300
+    assert np.abs(x1.to_host() - x2.to_host()).max() < 1e-11 * np.abs(u0).max()
+    import scipy.sparse as ssp
+    import scipy.sparse.linalg as sla
+    Ah = ssp.csr_matrix((A.to_host(), sp.colidx, sp.rowptr), shape=(dh.ndofs,) * 2)
+    ref = sla.spsolve(Ah.tocsc(), b.to_host())
+    assert np.abs(x2.to_host() - ref).max() < 1e-8 * np.abs(ref).max()
+    with pytest.raises(tb.TBError):
+        tb.check(tb.lib().tb_cg_solve_from_residual(M.pattern.h, A.ptr, None, x2.ptr, 1e-8, 0.0, 10, 1, None, None))
+
+
 # ------------------------------------------------------------------------------------------- the reference's own GPU tests
 def quad_problem(tb, oracle, nel, left, right):
     g = tb.generate_mesh(tb.Quadrilateral, nel, left, right)

@@ -1826,10 +1826,11 @@ class StandaloneSarcomereModel:
 
 
 # --------------------------------------------------------------------------------------- heat step + operator splitting
-def cg_solve(pattern, A, b, x, rtol=1e-5, atol=1e-6, maxiter=1000, jacobi=True):
-    """LinearSolve.solve!(linear_solver) with KrylovJL_CG(atol, rtol) (euler.jl:94-100, ep01_spiral-wave.jl:126-128)."""
+def cg_solve(pattern, A, b, x, rtol=1e-5, atol=1e-6, maxiter=1000, jacobi=True, b_is_residual=False):
+    """LinearSolve.solve!(linear_solver) with KrylovJL_CG(atol, rtol) (euler.jl:94-100, ep01_spiral-wave.jl:126-128).  b_is_residual: `b`
+    already holds b − A·x₀ for the initial guess in `x` (tb_cg_solve_from_residual)."""
     it, res = C.c_int(), C.c_double()
-    check(lib().tb_cg_solve(pattern.h, _ptr(A), _ptr(b), _ptr(x), float(rtol), float(atol), int(maxiter), int(jacobi),
+    check((lib().tb_cg_solve_from_residual if b_is_residual else lib().tb_cg_solve)(pattern.h, _ptr(A), _ptr(b), _ptr(x), float(rtol), float(atol), int(maxiter), int(jacobi),
                             C.byref(it), C.byref(res)))
     return it.value, res.value
 
@@ -1891,13 +1892,15 @@ class BackwardEulerStage:
         if self.dt_last is None or abs(dt - self.dt_last) > 1e-14 * abs(dt):
             heat_system_matrix(self.device, self.M, self.K, dt, self.A)         # euler.jl:104-116
             self.dt_last = dt
-        self.M.mul(self.b, u)                                                   # b = M uₙ₋₁
+        # A uₙ = b with b = M uₙ₋₁ (+ f) and the initial guess uₙ₋₁ (euler.jl:85-100): the initial residual b − A uₙ₋₁ is Δt·K·uₙ₋₁ (+ f),
+        # so one product with K stands for the two with M and A
+        check(lib().tb_spmv_csr(self.K.pattern.h, self.K.A.ptr, _ptr(u), float(dt), 0.0, self.b.ptr))
         if self.source is not None:
             if needs_update(self.source, t + dt):                               # euler.jl:118-120
                 update_operator(self.source, t + dt)
             add(self.b, self.source, self.device)
         its, res = cg_solve(self.M.pattern, self.A, self.b, u, self.solver.rtol, self.solver.atol, self.solver.maxiter,
-                            self.solver.jacobi)
+                            self.solver.jacobi, b_is_residual=True)
         self.last_iters = its
         return its < self.solver.maxiter or res <= self.solver.atol
 

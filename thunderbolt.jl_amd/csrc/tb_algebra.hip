@@ -495,7 +495,7 @@ k_cg_direction_dev(int64_t n, const double *__restrict__ rz, const double *__res
 }
 
 int launch_cg(tb_pattern *pat, const double *A, const double *b, double *x, double rtol, double atol, int maxiter, int jacobi, int *iters,
-              double *resnorm)
+              double *resnorm, bool b_is_residual)
 {
     tb_device *dev = pat->mesh->dev;
     const int64_t n = pat->n_rows;
@@ -506,8 +506,9 @@ int launch_cg(tb_pattern *pat, const double *A, const double *b, double *x, doub
     const unsigned gs = grid_for(dev, n * LANES, 256);
     if (jacobi) { const int rcd = launch_extract_diag(pat, A, dinv); if (rcd) return rcd; }
     const double *dp = jacobi ? dinv : nullptr;
-    int rc = launch_spmv(pat, A, x, 1.0, 0.0, Ap);
-    if (rc) return rc;
+    if (b_is_residual) TB_HIP(hipMemsetAsync(Ap, 0, sizeof(double) * n, dev->stream)); // r₀ = b given: nothing to subtract
+    else { const int rc = launch_spmv(pat, A, x, 1.0, 0.0, Ap); if (rc) return rc; }
+    if (b_is_residual && block3_plan(pat) == TB_OK && pat->b3 <= 0) stream_plan(pat); // the loop below picks its SpMV kernel from these plans
     TB_HIP(hipMemsetAsync(scal, 0, 6 * sizeof(double), dev->stream)); // scal[5]: sticky "pᵀAp ≤ 0" flag
     // k_cg_init writes r·z to out[0] and r·r to out[1]: point it at (scal[0], scal[1]) and move r·r to its slot afterwards
     hipLaunchKernelGGL(k_cg_init, dim3(g), dim3(256), 0, dev->stream, n, b, Ap, dp, r, p, scal);

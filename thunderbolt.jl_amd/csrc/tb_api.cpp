@@ -917,6 +917,15 @@ int tb_cg_solve(tb_pattern *pat, const double *d_Anz, const double *d_b, double 
     return launch_cg(pat, d_Anz, d_b, d_x, rtol, atol, maxiter, jacobi, iters, resnorm);
 }
 
+int tb_cg_solve_from_residual(tb_pattern *pat, const double *d_Anz, const double *d_r0, double *d_x, double rtol, double atol, int maxiter, int jacobi,
+                              int *iters, double *resnorm)
+{
+    TB_REQUIRE(pat && d_Anz && d_r0 && d_x, "tb_cg_solve_from_residual: NULL argument");
+    TB_REQUIRE(rtol >= 0 && atol >= 0 && maxiter >= 0, "tb_cg_solve_from_residual: negative tolerance or iteration limit");
+    TB_HIP(hipSetDevice(pat->mesh->dev->id));
+    return launch_cg(pat, d_Anz, d_r0, d_x, rtol, atol, maxiter, jacobi, iters, resnorm, true);
+}
+
 int tb_pcg_solve(tb_pattern *pat, const double *d_Anz, const double *d_b, double *d_x, double rtol, double atol, int maxiter, int precond, int partsize,
                  int *iters, double *resnorm)
 {

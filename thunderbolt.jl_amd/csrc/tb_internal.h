@@ -236,7 +236,7 @@ int launch_pcg_l1gs(tb_pattern *pat, const double *A, const double *b, double *x
 int launch_gmres(tb_pattern *pat, const double *A, const double *b, double *x, double rtol, double atol, int maxiter, int restart, int jacobi,
                  int *iters, double *resnorm);
 int launch_cg(tb_pattern *pat, const double *A, const double *b, double *x, double rtol, double atol, int maxiter, int jacobi, int *iters,
-              double *resnorm);
+              double *resnorm, bool b_is_residual = false);
 int launch_axpy(tb_device *dev, int64_t n, double a, const double *x, double *y);
 int launch_absmax(tb_device *dev, int64_t n, const double *x, int64_t stride, double *result);
 int launch_facets(tb_form *f, tb_pattern *p, const double *d_u, double *d_nz, double *d_r);
