@@ -225,4 +225,14 @@ end
 # tb_sarcomere_implicit_step
 
 # heat-step algebra (src/solver/time/euler.jl:85,90,110-116): tb_heat_matrix, tb_spmv_csr, tb_axpy
+# perform_backward_euler_step! (euler.jl:71-101) for device vectors: the initial guess is uₙ₋₁, so b − A·uₙ₋₁ = Δt·K·uₙ₋₁ (+ source) and CG can
+# start from that residual — one SpMV with K instead of mul!(b, M, uₙ₋₁) and the solver's own A·x₀:
+function backward_euler_heat_step!(pat, Anz::Ptr{Float64}, Knz::Ptr{Float64}, u::Ptr{Float64}, r0::Ptr{Float64}, Δt; rtol = 1e-5, atol = 1e-6, maxiter = 1000)
+    check(ccall((:tb_spmv_csr, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Cdouble, Cdouble, Ptr{Float64}), pat, Knz, u, Δt, 0.0, r0))
+    iters = Ref{Cint}(0); res = Ref{Cdouble}(0.0)
+    check(ccall((:tb_cg_solve_from_residual, libtbhip), Cint,
+                (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cdouble, Cdouble, Cint, Cint, Ref{Cint}, Ref{Cdouble}),
+                pat, Anz, r0, u, rtol, atol, maxiter, 1, iters, res))
+    return iters[] < maxiter || res[] <= atol
+end
 end # module
