@@ -1810,13 +1810,39 @@ def test_lv_coordinate_system_by_device_laplace_solves(tb, oracle, device):
     free_t = np.setdiff1d(np.arange(dh.ndofs), np.concatenate([endo, epi]))
     free_a = np.setdiff1d(np.arange(dh.ndofs), np.concatenate([apex, base]))
     assert t[free_t].min() > 0.0 and t[free_t].max() < 1.0 and a[free_a].min() > 0.0 and a[free_a].max() < 1.0
-    assert np.abs((Km @ t)[free_t]).max() < 1e-9 * np.abs(Kref).max() and np.abs((Km @ a)[free_a]).max() < 1e-9 * np.abs(Kref).max()
+    al = cs.u_apicobasal_laplace                                                # the raw harmonic field; `a` is its arc-length recalibration
+    assert np.abs((Km @ t)[free_t]).max() < 1e-9 * np.abs(Kref).max() and np.abs((Km @ al)[free_a]).max() < 1e-9 * np.abs(Kref).max()
+    order = np.argsort(al, kind="stable")
+    assert np.all(np.diff(a[order]) >= 0.0)                                     # monotone in the Laplace field: ∇ab ∥ ∇u, the chart cannot reverse
+    # test/test_coordinate_systems.jl:136-160: along an epicardial meridian the recalibrated coordinate is far closer to normalised arc length
+    # than the raw field, which is pinned at one node and spends most of its range next to the apex
+    par = g.parametric
+    mer = np.where((np.abs(par[:, 2] - 1.0) < 1e-12) & (np.abs(g.xyz[:, 1]) < 1e-9) & (g.xyz[:, 0] > 1e-9))[0]   # epicardial nodes in the half plane y = 0, x > 0
+    mer = mer[np.argsort(par[mer, 0])]
+    pts = np.vstack([g.xyz[g.getnodeset("Apex")[0]], g.xyz[mer]])
+    sarc = np.concatenate([[0.0], np.cumsum(np.linalg.norm(np.diff(pts, axis=0), axis=1))])
+    sarc /= sarc[-1]
+    ids = np.concatenate([[g.getnodeset("Apex")[0]], mer])
+    err_recal, err_raw = np.abs(a[n2d[ids]] - sarc).max(), np.abs(al[n2d[ids]] - sarc).max()
+    assert len(mer) > 8 and err_recal < 0.15 and err_recal < 0.5 * err_raw, (err_recal, err_raw)
+    # pinning an apical cap (positive capacity) instead of the node gives a measurably different coordinate with the same exact ends (:125-133)
+    cap = tb.compute_lv_coordinate_system(g, device, apical_cap_fraction=0.15)
+    assert np.all(cap.u_apicobasal[apex] == 0.0) and np.all(cap.u_apicobasal[base] == 1.0)
+    assert np.abs(cap.u_apicobasal - a).max() > 0.01 and (cap.u_apicobasal_laplace == 0.0).sum() > len(apex)
+    # recalibration known answer (:74-91): a ring pinned on its two flat faces has a Laplace field linear in z — the recalibration is the identity
+    ring = tb.generate_ring_mesh(16, 2, 6)
+    rdh = tb.DofHandler(ring)
+    rK = tb.coordinates.assemble_laplacian(tb.PerColorAssemblyStrategy(device), rdh, tb.allocate_matrix(rdh))
+    bot, _ = tb.coordinates._facet_dofs(ring, rdh, "Myocardium")
+    top, _ = tb.coordinates._facet_dofs(ring, rdh, "Base")
+    ur, _ = tb.coordinates.solve_dirichlet_laplace(rK, rdh, [(bot, 0.0), (top, 1.0)])
+    np.testing.assert_allclose(tb.apicobasal_from_laplace(ring, rdh, ur), np.clip(ur, 0.0, 1.0), atol=5e-3)
     # the transmural coordinate follows the wall fraction of the parametrisation (harmonic in a thick shell: close to, not equal to, linear)
     rp = np.empty(dh.ndofs); rp[n2d] = g.parametric[:, 2]
     assert np.abs(t - rp).max() < 0.12
     th = np.empty(dh.ndofs); th[n2d] = g.parametric[:, 0]
     from scipy.stats import spearmanr
-    assert spearmanr(a, th)[0] > 0.9                                            # apicobasal grows monotonically from the apex (a point condition: steep near it) to the base
+    assert spearmanr(a, th)[0] > 0.9                                            # apicobasal grows monotonically from the apex to the base
     # fibres: compare with the analytic helix field away from the apical cap
     f1, s1, n1 = tb.create_lumped_microstructure_model(cs, np.deg2rad(60.0), np.deg2rad(-60.0))
     f0, s0, n0 = tb.ideal_lv_microstructure(g, np.deg2rad(60.0), np.deg2rad(-60.0))

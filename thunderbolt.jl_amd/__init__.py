@@ -10,5 +10,5 @@ from . import meshio  # noqa: F401
 from . import coordinates  # noqa: F401
 from .coordinates import (compute_lv_coordinate_system, compute_midmyocardial_section_coordinate_system, create_microstructure_model,  # noqa: F401
                           create_lumped_microstructure_model, ODB25LTMicrostructureParameters, evaluate_coordinate_axes, evaluate_coordinate,
-                          wrap_rotational)
+                          wrap_rotational, apicobasal_from_laplace)
 from .meshgen import generate_ring_mesh, generate_open_ring_mesh, generate_ideal_lv_mesh_hex, ideal_lv_microstructure, uniform_refinement  # noqa: F401

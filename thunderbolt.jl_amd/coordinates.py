@@ -81,18 +81,83 @@ def _facet_dofs(g, dh, name):
     return n2d[nodes], n2d
 
 
-def compute_lv_coordinate_system(grid, device, strategy=None):
-    """compute_lv_coordinate_system(mesh) (coordinate_systems.jl): two harmonic coordinates by Dirichlet–Laplace solves on the device"""
+def apicobasal_from_laplace(grid, dh, u_laplace, nbins=200):
+    """apicobasal_from_laplace(dh, ip, u; nbins) (coordinate_systems.jl:238-300): recalibrate the apicobasal Laplace field to arc length along its
+    own trajectories, ab = 1 − F(u)/F(0) with F(u) = ∫ᵤ¹ dū/⟨‖∇u‖⟩(ū), the level-set average ⟨‖∇u‖⟩ taken per bin with the lumped weights of
+    `_lumped_gradient`; exactly 0 / 1 on the two Dirichlet sets, monotone in u"""
+    u = np.clip(np.asarray(u_laplace, dtype=float), 0.0, 1.0)
+    grad, weight = lumped_gradient(grid, dh, u)
+    gradnorm = np.linalg.norm(grad, axis=1)
+    edges = np.linspace(0.0, 1.0, nbins + 1)
+    du = 1.0 / nbins
+    b = np.clip(np.searchsorted(edges, u, side="right"), 1, nbins) - 1   # searchsortedlast, 0-based
+    num = np.bincount(b, weights=weight * gradnorm, minlength=nbins)
+    den = np.bincount(b, weights=weight, minlength=nbins)
+    gbar = np.where(den > 0, num / np.where(den > 0, den, 1.0), 0.0)
+    for k in range(1, nbins):                                            # empty bins inherit a populated neighbour, both ways
+        if gbar[k] == 0:
+            gbar[k] = gbar[k - 1]
+    for k in range(nbins - 2, -1, -1):
+        if gbar[k] == 0:
+            gbar[k] = gbar[k + 1]
+    F = np.zeros(nbins + 1)
+    for k in range(nbins - 1, -1, -1):
+        F[k] = F[k + 1] + du / max(gbar[k], np.finfo(float).eps)
+    if not F[0] > 0:
+        return np.zeros_like(u)
+    lam = (u - edges[b]) / du
+    return np.clip(1.0 - (F[b] + lam * (F[b + 1] - F[b])) / F[0], 0.0, 1.0)
+
+
+def _apical_cap_facets(grid, apex, longitudinal, height, surface_names):
+    """_apical_cap_facets (coordinate_systems.jl:752-783): facets of the named surfaces whose nodes all lie within `height` of the apex along the
+    long axis — a Dirichlet set of positive capacity for the apical end of the apicobasal problem"""
+    below = (grid.xyz - apex) @ longitudinal <= height
+    cap = []
+    for name in surface_names:
+        if name not in grid.facetsets:
+            continue
+        for c, lf in grid.facetset(name):
+            if below[grid.conn[c, list(tb.Grid.HEX_FACETS[lf])]].all():
+                cap.append((c, lf))
+    return cap
+
+
+def compute_lv_coordinate_system(grid, device, strategy=None, apex_nodeset="Apex", apex_facetset=None, apical_cap_fraction=0.0,
+                                 apicobasal_bins=200, recalibrate=True):
+    """compute_lv_coordinate_system(mesh; apex_nodeset, apex_facetset, apical_cap_fraction, apicobasal_bins) (coordinate_systems.jl:886-952):
+    transmural and apicobasal coordinates by Dirichlet–Laplace solves on the device; the apical end is pinned on a named facet set, on the
+    apical cap cut off by a plane at `apical_cap_fraction` of the chamber length, or (the default, as in the reference) on the apex node set;
+    the apicobasal Laplace field is then recalibrated to arc length (apicobasal_from_laplace).  The long axis runs from the apex node to the
+    centroid of the base nodes (the reference's compute_lv_axes fits it to the basal plane).  `u_apicobasal_laplace` keeps the raw field."""
     dh = tb.DofHandler(grid)
     sp = tb.allocate_matrix(dh)
     K = assemble_laplacian(strategy or tb.PerColorAssemblyStrategy(device), dh, sp)
     endo, n2d = _facet_dofs(grid, dh, "Endocardium")
     epi, _ = _facet_dofs(grid, dh, "Epicardium")
     base, _ = _facet_dofs(grid, dh, "Base")
-    apex = n2d[np.asarray(grid.getnodeset("Apex"))]
     transmural, _ = solve_dirichlet_laplace(K, dh, [(endo, 0.0), (epi, 1.0)])
-    apicobasal, _ = solve_dirichlet_laplace(K, dh, [(apex, 0.0), (base, 1.0)])
-    return LVCoordinateSystem(grid, dh, transmural, apicobasal)
+    transmural = np.clip(transmural, 0.0, 1.0)
+    apex_nodes = np.asarray(grid.getnodeset(apex_nodeset))
+    apical = n2d[apex_nodes]
+    if apex_facetset is not None:
+        if apex_facetset not in grid.facetsets:
+            raise ValueError('No facetset "%s" on this mesh.' % apex_facetset)
+        apical, _ = _facet_dofs(grid, dh, apex_facetset)
+    elif apical_cap_fraction > 0:
+        apex = grid.xyz[apex_nodes].mean(axis=0)
+        d2n = np.empty(dh.ndofs, dtype=np.int64)
+        d2n[n2d] = np.arange(grid.n_nodes)
+        base_center = grid.xyz[d2n[base]].mean(axis=0)
+        l = (base_center - apex) / np.linalg.norm(base_center - apex)
+        cap = _apical_cap_facets(grid, apex, l, apical_cap_fraction * abs((base_center - apex) @ l), ("Endocardium", "Epicardium"))
+        if cap:
+            apical = n2d[np.unique(np.concatenate([grid.conn[c, list(tb.Grid.HEX_FACETS[lf])] for c, lf in cap]))]
+    laplace, _ = solve_dirichlet_laplace(K, dh, [(apical, 0.0), (base, 1.0)])
+    apicobasal = apicobasal_from_laplace(grid, dh, laplace, apicobasal_bins) if recalibrate else laplace
+    cs = LVCoordinateSystem(grid, dh, transmural, apicobasal)
+    cs.u_apicobasal_laplace = laplace
+    return cs
 
 
 def _orthogonal_to(axis):
