@@ -360,7 +360,10 @@ int tb_heat_matrix(tb_device *dev, int64_t nnz, const double *d_Mnz, const doubl
 int tb_spmv_csr(tb_pattern *pat, const double *d_nzval, const double *d_x, double alpha, double beta, double *d_y);
 /* Jacobi-preconditioned CG for the heat step A uₙ = b, A = M − Δt·K SPD (src/solver/time/euler.jl:94-100; the tutorials
  * configure KrylovJL_CG(atol = 1e-6, rtol = 1e-5)).  d_x holds the initial guess (uₙ₋₁) and the solution.
- * Stops when ‖r‖₂ ≤ atol + rtol·‖r₀‖₂ or after maxiter iterations; reports iterations and the final ‖r‖₂. */
+ * Stops when ‖r‖₂ ≤ atol + rtol·‖r₀‖₂ or after maxiter iterations; reports iterations and the final ‖r‖₂.
+ * jacobi: 0 = no preconditioner, 1 = Jacobi (D⁻¹ read from d_Anz), TB_JACOBI_REUSE = Jacobi with the D⁻¹ of the previous solve on this pattern
+ * (the time loop solves with one matrix step after step; a stale diagonal is still a valid SPD preconditioner, only a slower one). */
+enum { TB_JACOBI_REUSE = 2 };
 int tb_cg_solve(tb_pattern *pat, const double *d_Anz, const double *d_b, double *d_x, double rtol, double atol, int maxiter,
                 int jacobi, int *iters, double *resnorm);
 /* The same solve started from a known initial residual: d_r0 = b − A·x₀ supplied by the caller, so neither b nor the product A·x₀ is

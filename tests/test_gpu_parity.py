@@ -2022,6 +2022,12 @@ def test_cg_from_initial_residual_matches_the_plain_solve(tb, device):
     assert np.abs(x2.to_host() - ref).max() < 1e-8 * np.abs(ref).max()
     with pytest.raises(tb.TBError):
         tb.check(tb.lib().tb_cg_solve_from_residual(M.pattern.h, A.ptr, None, x2.ptr, 1e-8, 0.0, 10, 1, None, None))
+    with pytest.raises(tb.TBError):
+        tb.check(tb.lib().tb_cg_solve(M.pattern.h, A.ptr, b.ptr, x2.ptr, 1e-8, 0.0, 10, 3, None, None))
+    # TB_JACOBI_REUSE: the D⁻¹ of the previous solve on this pattern — same matrix, same iterates
+    x3 = device.to_device(u0)
+    it3, _ = tb.cg_solve(M.pattern, A, b, x3, rtol=1e-10, atol=0.0, maxiter=300, jacobi=2)
+    assert it3 == it1 and np.abs(x3.to_host() - x1.to_host()).max() < 1e-12 * np.abs(u0).max()
 
 
 # ------------------------------------------------------------------------------------------- the reference's own GPU tests

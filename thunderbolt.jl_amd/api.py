@@ -1889,7 +1889,8 @@ class BackwardEulerStage:
 
     def perform_step(self, u, t, dt):
         """perform_backward_euler_step!(f, cache, stage, t, Δt) (euler.jl:71-101): True on success."""
-        if self.dt_last is None or abs(dt - self.dt_last) > 1e-14 * abs(dt):
+        rebuilt = self.dt_last is None or abs(dt - self.dt_last) > 1e-14 * abs(dt)
+        if rebuilt:
             heat_system_matrix(self.device, self.M, self.K, dt, self.A)         # euler.jl:104-116
             self.dt_last = dt
         # A uₙ = b with b = M uₙ₋₁ (+ f) and the initial guess uₙ₋₁ (euler.jl:85-100): the initial residual b − A uₙ₋₁ is Δt·K·uₙ₋₁ (+ f),
@@ -1900,7 +1901,7 @@ class BackwardEulerStage:
                 update_operator(self.source, t + dt)
             add(self.b, self.source, self.device)
         its, res = cg_solve(self.M.pattern, self.A, self.b, u, self.solver.rtol, self.solver.atol, self.solver.maxiter,
-                            self.solver.jacobi, b_is_residual=True)
+                            (1 if rebuilt else 2) if self.solver.jacobi else 0, b_is_residual=True)     # 2 = TB_JACOBI_REUSE: same A as last step
         self.last_iters = its
         return its < self.solver.maxiter or res <= self.solver.atol
 

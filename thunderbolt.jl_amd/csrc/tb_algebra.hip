@@ -504,7 +504,9 @@ int launch_cg(tb_pattern *pat, const double *A, const double *b, double *x, doub
     const unsigned g = grid_for(dev, n, 256);
     constexpr int LANES = 16; // 16 lanes per row measured best for 27-entry rows (0.96 vs 1.03 ms at 216³ with 8)
     const unsigned gs = grid_for(dev, n * LANES, 256);
-    if (jacobi) { const int rcd = launch_extract_diag(pat, A, dinv); if (rcd) return rcd; }
+    const bool fresh_ws = !pat->cg_dinv_valid;
+    if (jacobi == 1 || (jacobi == 2 && fresh_ws)) { const int rcd = launch_extract_diag(pat, A, dinv); if (rcd) return rcd; } // 2: D⁻¹ of the previous solve is still valid
+    if (jacobi) pat->cg_dinv_valid = true;
     const double *dp = jacobi ? dinv : nullptr;
     if (b_is_residual) TB_HIP(hipMemsetAsync(Ap, 0, sizeof(double) * n, dev->stream)); // r₀ = b given: nothing to subtract
     else { const int rc = launch_spmv(pat, A, x, 1.0, 0.0, Ap); if (rc) return rc; }

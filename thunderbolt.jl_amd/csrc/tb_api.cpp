@@ -913,6 +913,7 @@ int tb_cg_solve(tb_pattern *pat, const double *d_Anz, const double *d_b, double 
 {
     TB_REQUIRE(pat && d_Anz && d_b && d_x, "tb_cg_solve: NULL argument");
     TB_REQUIRE(rtol >= 0 && atol >= 0 && maxiter >= 0, "tb_cg_solve: negative tolerance or iteration limit");
+    TB_REQUIRE(jacobi >= 0 && jacobi <= TB_JACOBI_REUSE, "tb_cg_solve: jacobi must be 0, 1 or TB_JACOBI_REUSE");
     TB_HIP(hipSetDevice(pat->mesh->dev->id));
     return launch_cg(pat, d_Anz, d_b, d_x, rtol, atol, maxiter, jacobi, iters, resnorm);
 }
@@ -922,6 +923,7 @@ int tb_cg_solve_from_residual(tb_pattern *pat, const double *d_Anz, const double
 {
     TB_REQUIRE(pat && d_Anz && d_r0 && d_x, "tb_cg_solve_from_residual: NULL argument");
     TB_REQUIRE(rtol >= 0 && atol >= 0 && maxiter >= 0, "tb_cg_solve_from_residual: negative tolerance or iteration limit");
+    TB_REQUIRE(jacobi >= 0 && jacobi <= TB_JACOBI_REUSE, "tb_cg_solve_from_residual: jacobi must be 0, 1 or TB_JACOBI_REUSE");
     TB_HIP(hipSetDevice(pat->mesh->dev->id));
     return launch_cg(pat, d_Anz, d_r0, d_x, rtol, atol, maxiter, jacobi, iters, resnorm, true);
 }
