@@ -2,9 +2,14 @@
 """Benchmark of the hot path on N MI355X (one process per GPU).
 
 A "step" is one pass of the hot path over one synthetic batch: the three monodomain element
-integrations over the whole mesh — mass matrix M, diffusion matrix K (κ/(Cₘχ)), source vector b —
+integrations over the whole mesh — mass matrix M and diffusion matrix K (κ/(Cₘχ)) in one fused pass
+(tb_assemble_matrix_pair: the heat stage assembles them back to back, euler.jl:172-176), source vector b —
 then the halo sum of b over the slab interfaces (N > 1) and one forward-Euler reaction step of the
-ionic model on every dof.  Workload at N = 1: BASELINE.json's metric configuration, the 10M-hex Q1
+ionic model on every dof.
+
+`python bench.py --gpus N` (N > 1) starts its own N ranks: the parent never touches the GPU, it runs
+`python -m torch.distributed.run --nproc-per-node N … bench.py` as a child process and exits with its code.
+Under torchrun (RANK / WORLD_SIZE set) WORLD_SIZE must equal --gpus.  Workload at N = 1: BASELINE.json's metric configuration, the 10M-hex Q1
 monodomain mesh (216³ = 10 077 696 hexahedra, 10 218 313 dofs) with the ten Tusscher–Panfilov 2006 ionic
 model that configuration names (19 states; the reference itself has no TT06 — SURVEY F6 — so its parity is
 pinned against this repository's oracle only; `--ionic pcg2019` runs the reference's own 7-state model, and
@@ -32,7 +37,6 @@ FP64_VECTOR_TFLOPS = 78.6      # AMD spec sheet; FP64 MFMA runs at the same rate
 BYTES_PER_CELL_MATRIX = 272.0  # 32 B conn + 24 B coords + 27 nz × 8 B
 BYTES_PER_CELL_VECTOR = 64.0   # 32 + 24 + 8
 BYTES_PER_DOF_UPDATE = 16.0    # in place; 24 when du is materialised
-FLOP_PER_CELL_DIFFUSION = 4300.0  # useful FP64 flops per cell: ≈8×(208 FMA + 100 mul/add) + 200 (ISA count); halo recompute not counted
 
 
 def parse():
@@ -45,6 +49,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=64, help="edge of the CPU-baseline sample mesh")
     ap.add_argument("--keep-du", action="store_true", help="materialise du (dumat) in the reaction step")
+    ap.add_argument("--separate", action="store_true", help="assemble M and K with two launches instead of the fused pass")
     ap.add_argument("--ionic", default="tt06", choices=["pcg2019", "tt06", "fhn"],
                     help="ionic model of the reaction step (tt06 = the 19-state model BASELINE's 10M-hex configuration names; "
                          "pcg2019 = the reference's own 7-state model)")
@@ -95,11 +100,40 @@ def cpu_baseline(n, kap, threads, ionic="tt06"):
             "dof_updates_per_s": nstates * nd / best_rx, "ionic_model": ionic}
 
 
+def spawn_ranks(args):
+    """--gpus N without a launcher: start N ranks as a child torchrun (this process has not initialised the GPU and does not
+    re-exec; it waits and returns the child's exit code)."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()    # counts devices without creating a context
+    if have < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d requested but %d GPU(s) visible\n" % (args.gpus, have))
+        return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        sys.stderr.write("bench.py: --gpus must be >= 1\n")
+        return 2
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if not launched and args.gpus > 1:
+        return spawn_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: WORLD_SIZE=%d but --gpus %d — refusing to print a line for the wrong job size\n" % (world, args.gpus))
+        return 2
     import torch
     import torch.distributed as dist
     import thunderbolt_jl_amd as tb
@@ -108,6 +142,7 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
     dev = tb.MI355XDevice(local_rank)
     dev.set_stream(torch.cuda.current_stream().cuda_stream)
 
@@ -145,13 +180,20 @@ def main():
     f = tb.PointwiseODEFunction(npts, model)
     cache = tb.setup_solver_cache(f, tb.ForwardEulerCellSolver(dev), u=u, keep_du=args.keep_du)
 
+    fused = args.strategy == "patch" and not args.separate
     ev = [dev.event() for _ in range(6)]
-    phase = {"mass": 0.0, "diffusion": 0.0, "source": 0.0, "halo": 0.0, "reaction": 0.0}
+    phase = {"mass": 0.0, "diffusion": 0.0, "source": 0.0, "halo": 0.0, "reaction": 0.0}   # fused: "diffusion" holds the M + K pass, "mass" stays 0
 
     def step(i, timed):
         t = 0.01 * i
-        ev[0].record(); tb.update_operator(M, t)
-        ev[1].record(); tb.update_operator(K, t)
+        ev[0].record()
+        if not fused:
+            tb.update_operator(M, t)
+        ev[1].record()
+        if fused:
+            tb.update_operators(M, K, t)
+        else:
+            tb.update_operator(K, t)
         ev[2].record(); tb.update_operator(src, t)
         ev[3].record()
         if world > 1:
@@ -203,45 +245,53 @@ def main():
         cells_total = g.n_cells * world
         dofs_total = npts * world
         ms = elapsed / K_ * 1e3
-        k_ms = phase["diffusion"] / K_
-        achieved = BYTES_PER_CELL_MATRIX * g.n_cells / (k_ms * 1e-3) / 1e9
+        k_ms = phase["diffusion"] / K_            # fused: the one M + K launch
+        # algorithmic bytes of the dominant launch, each datum once: connectivity 32 B + coordinates 24 B per cell, 27 nz × 8 B per
+        # cell and matrix written once — 272 B/cell for one matrix, 488 B/cell for the fused pair (2 × 272 = 544 B/cell if each of the two
+        # element-integrations were charged its own mesh read: reported as frac_per_integration)
+        bytes_per_cell = (BYTES_PER_CELL_MATRIX + 216.0) if fused else BYTES_PER_CELL_MATRIX
+        achieved = bytes_per_cell * g.n_cells / (k_ms * 1e-3) / 1e9
+        if args.strategy == "patch":
+            kname = "k_patch_hex8<K+M>" if fused else "k_patch_hex8<K>"
+        else:
+            kname = "k_matrix_direct<Hex8<2>,DIFFUSION>"
+        mk_ms = k_ms + phase["mass"] / K_
         out = {
             "metric": "element-integrations/sec + DoF-updates/sec, 10M-hex Q1 monodomain",
             "value": 3 * cells_total * K_ / elapsed, "unit": "element-integrations/s",
             "n_gpus": world, "steps": K_, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "monodomain hot path on %d^3 hex Q1 per GPU (%d cells, %d dofs): assemble M + K (%s scatter) + b (atomic scatter)%s + %s forward-Euler reaction step"
-                                   % (n, g.n_cells, npts, args.strategy, " + neighbour halo sum of b" if world > 1 else "", args.ionic.upper()),
+            "config": {"workload": "monodomain hot path on %d^3 hex Q1 per GPU (%d cells, %d dofs): assemble M + K (%s scatter, %s) + b (atomic scatter)%s + %s forward-Euler reaction step"
+                                   % (n, g.n_cells, npts, args.strategy, "one fused pass" if fused else "two launches",
+                                      " + neighbour halo sum of b" if world > 1 else "", args.ionic.upper()),
                        "cells_per_gpu": g.n_cells, "dofs_per_gpu": npts, "nnz_per_gpu": sp.nnz, "ionic_model": args.ionic, "ionic_states": ns,
                        "partition": "z-slabs"},
             "dof_updates_per_s": ns * dofs_total * K_ / elapsed,
-            "phase_ms": {k: v / K_ for k, v in phase.items()},
-            "phase_rates": {"mass_cells_per_s": g.n_cells / (phase["mass"] / K_ * 1e-3),
-                            "diffusion_cells_per_s": g.n_cells / (k_ms * 1e-3),
+            "phase_ms": ({"mass+diffusion": k_ms} if fused else {"mass": phase["mass"] / K_, "diffusion": k_ms}) | {k: phase[k] / K_ for k in ("source", "halo", "reaction")},
+            "phase_rates": {"matrix_integrations_per_s": 2 * g.n_cells / (mk_ms * 1e-3),
                             "source_cells_per_s": g.n_cells / (phase["source"] / K_ * 1e-3),
                             "reaction_dof_updates_per_s": ns * npts / (phase["reaction"] / K_ * 1e-3)},
-            "roofline": {"kernel": "k_matrix_patch<Hex8<2>,DIFFUSION>" if args.strategy == "patch" else "k_matrix_direct<Hex8<2>,DIFFUSION>",
-                         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None,
-                         "note": "algorithmic 272 B/cell; the kernel is FP64-VALU-bound (≈5 kflop/cell; FP64 MFMA is no faster than FP64 FMA on CDNA4: 48 vs 70 TF measured), see DESIGN.md",
+            "roofline": {"kernel": kname, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "algorithmic_bytes_per_cell": bytes_per_cell, "launch_ms": k_ms,
+                         "frac_per_integration": BYTES_PER_CELL_MATRIX * 2 * g.n_cells / (mk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "reaction": {"bound": "hbm", "achieved": (BYTES_PER_DOF_UPDATE + (8 if args.keep_du else 0)) * ns * npts / (phase["reaction"] / K_ * 1e-3) / 1e9,
-                                      "peak": HBM_PEAK_GBS, "unit": "GB/s"}},
+                                      "peak": HBM_PEAK_GBS, "unit": "GB/s"},
+                         "source": {"bound": "hbm", "achieved": BYTES_PER_CELL_VECTOR * g.n_cells / (phase["source"] / K_ * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}},
         }
-        out["roofline"]["reaction"]["frac"] = out["roofline"]["reaction"]["achieved"] / HBM_PEAK_GBS
+        for k in ("reaction", "source"):
+            out["roofline"][k]["frac"] = out["roofline"][k]["achieved"] / HBM_PEAK_GBS
         if ref_rx is not None:
             out["reference_model_reaction"] = ref_rx
-        out["roofline"]["fp64_frac"] = FLOP_PER_CELL_DIFFUSION * g.n_cells / (k_ms * 1e-3) / (FP64_VECTOR_TFLOPS * 1e12)
-        try:  # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)
+        try:  # HBM bytes per launch from this round's PMC passes (rocprofv3 cannot run inside this process): scripts/collect_profiles.sh writes the file
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             if tj["cells"] == g.n_cells and args.strategy == "patch":
-                kk = [v for k, v in tj["kernels"].items() if "k_matrix_patch" in k and ", 1," in k][0]
-                if "read_bytes_by_request_size" in kk:   # FETCH_SIZE corrected for gfx950: 128-B requests counted as 128 B
-                    out["roofline"]["traffic"] = kk["read_bytes_by_request_size"] + kk["write_bytes"]
+                kk = tj["kernels"].get("fused" if fused else "diffusion")
+                if kk:
+                    out["roofline"]["traffic"] = kk["read_bytes"] + kk["write_bytes"]
+                    out["roofline"]["traffic_read"] = kk["read_bytes"]
+                    out["roofline"]["traffic_write"] = kk["write_bytes"]
                     out["roofline"]["traffic_note"] = ("bytes per launch: reads = 32/64/128-byte TCC_EA0_RDREQ counts x their sizes (FETCH_SIZE tallies 128-B requests "
                                                        "at 64 B on gfx950), writes = WRITE_SIZE; separate rocprofv3 --pmc passes of python3 bench.py, " + tj["source"])
-                else:
-                    out["roofline"]["traffic"] = kk["fetch_bytes"] + kk["write_bytes"]
-                    out["roofline"]["traffic_note"] = "bytes per launch, " + tj["source"] + "; FETCH_SIZE uncorrected (lower bound, see profiles/traffic.json)"
         except Exception:
             pass
         if world == 1 and not args.no_cpu_baseline:
@@ -252,4 +302,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -198,6 +198,12 @@ int tb_form_set_table(tb_form *form, const double *values, int64_t n);
  * update_operator!(op, t) for bilinear operators → fills op.A's nzval
  * (src/solver/time/euler.jl:172-176; canonical loop src/modeling/core/coordinate_systems.jl:145-171) */
 int tb_assemble_matrix(tb_form *form, tb_pattern *pat, int strategy, double t, double *d_nzval);
+/* The heat stage's set-up assembles the mass and the diffusion operator of one DofHandler back to back on the shared
+ * sparsity pattern (update_operator!(cache.M, t); update_operator!(cache.K, t), src/solver/time/euler.jl:172-176, pattern
+ * sharing :110-116): one pass over the mesh fills both nzval arrays (geometry and scatter metadata read once).  Results are
+ * those of two tb_assemble_matrix calls; combinations the fused kernel does not cover fall back to exactly those two calls. */
+int tb_assemble_matrix_pair(tb_form *mass, tb_form *diffusion, tb_pattern *pat, int strategy, double t, double *d_nzval_mass,
+                            double *d_nzval_diffusion);
 /* update_operator!(op, t) for linear operators → fills op.b (src/solver/time/euler.jl:119,176;
  * test/gpu/test_operators.jl:24-30) */
 int tb_assemble_vector(tb_form *form, int strategy, double t, double *d_b);

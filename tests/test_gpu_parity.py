@@ -431,16 +431,41 @@ def test_heat_algebra_parity(tb, oracle, device):
 
 
 # ------------------------------------------------------------------------------------------- BASELINE sizes
-def _property_checks(tb, oracle, device, n, sample=200):
-    """Size-independent properties at BASELINE sizes (the oracle checks a random sample of rows exactly)."""
+def _sampled_rows_error(oracle, om, form, oc, sp, cell_dofs, nz, rows):
+    """max |nz − oracle| over every entry of the given rows, the oracle summing its element matrices of the cells around them"""
+    sel = np.isin(cell_dofs, rows)
+    acc = {}
+    for c in np.nonzero(sel.any(axis=1))[0]:
+        Ke = oracle.element_matrix(om, form, oc, int(c))
+        d = cell_dofs[c]
+        for i in range(8):
+            if sel[c, i]:
+                for j in range(8):
+                    acc[(d[i], d[j])] = acc.get((d[i], d[j]), 0.0) + Ke[i, j]
+    worst = 0.0
+    for (r, c_), v in acc.items():
+        k0, k1 = sp.rowptr[r], sp.rowptr[r + 1]
+        k = k0 + np.searchsorted(sp.colidx[k0:k1], c_)
+        worst = max(worst, abs(nz[k] - v))
+    return worst
+
+
+def _property_checks(tb, oracle, device, n, sample=200, fused=False):
+    """Size-independent properties at BASELINE sizes (the oracle checks a random sample of rows exactly).
+    fused: M and K come from the one-pass pair assembly (tb_assemble_matrix_pair), as bench.py runs them."""
     g = tb.generate_mesh(tb.Hexahedron, (n, n, n), (0, 0, 0), (1, 1, 1), perturb=0.2)
     dh = tb.DofHandler(g)
     sp = tb.allocate_matrix(dh)
     assert g.n_cells == n ** 3 and dh.ndofs == (n + 1) ** 3 and sp.nnz == (3 * n + 1) ** 3
     st = tb.PatchAssemblyStrategy(device)
     kap = np.array([[4.5e-5, 1e-5, 0], [1e-5, 2.0e-5, 0], [0, 0, 2.0e-5]])
-    M = tb.update_operator(tb.setup_operator(st, tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.0)), dh, sp), 0.0)
-    K = tb.update_operator(tb.setup_operator(st, tb.BilinearDiffusionIntegrator(tb.ConstantCoefficient(kap)), dh, sp), 0.0)
+    M = tb.setup_operator(st, tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.0)), dh, sp)
+    K = tb.setup_operator(st, tb.BilinearDiffusionIntegrator(tb.ConstantCoefficient(kap)), dh, sp)
+    if fused:
+        tb.update_operators(M, K, 0.0)
+    else:
+        tb.update_operator(M, 0.0)
+        tb.update_operator(K, 0.0)
     b1 = tb.update_operator(tb.setup_operator(st, tb.LinearIntegrator(tb.AnalyticalCoefficient("const", 1.0)), dh), 0.0)
     one = device.to_device(np.ones(dh.ndofs))
     y = device.zeros(dh.ndofs)
@@ -464,24 +489,11 @@ def _property_checks(tb, oracle, device, n, sample=200):
     om = oracle.Mesh(oracle.HEX8, 2, g.xyz, g.conn, dh.cell_dofs)
     oc = oracle.Coef(oracle.COEF_CONST_TENSOR, kap.ravel())
     rows = rng.choice(dh.ndofs, size=sample, replace=False)
-    n2d_cells = {}
-    flat = dh.cell_dofs
-    sel = np.isin(flat, rows)
-    cells = np.nonzero(sel.any(axis=1))[0]
-    acc = {}
-    for c in cells:
-        Ke = oracle.element_matrix(om, 1, oc, int(c))
-        d = flat[c]
-        for i in range(8):
-            if sel[c, i]:
-                for j in range(8):
-                    acc[(d[i], d[j])] = acc.get((d[i], d[j]), 0.0) + Ke[i, j]
-    worst = 0.0
-    for (r, c_), v in acc.items():
-        k0, k1 = sp.rowptr[r], sp.rowptr[r + 1]
-        k = k0 + np.searchsorted(sp.colidx[k0:k1], c_)
-        worst = max(worst, abs(Kh[k] - v))
+    worst = _sampled_rows_error(oracle, om, 1, oc, sp, dh.cell_dofs, Kh, rows)
     assert worst < 1e-12 * np.abs(Kh).max()
+    Mh = M.A.to_host()
+    assert _sampled_rows_error(oracle, om, 0, oracle.Coef(oracle.COEF_CONST_SCALAR, [1.0]), sp, dh.cell_dofs, Mh, rows) < 1e-12 * np.abs(Mh).max()
+    del Mh
     # strategies agree with each other at size
     Ka = tb.update_operator(tb.setup_operator(tb.AtomicAssemblyStrategy(device), tb.BilinearDiffusionIntegrator(tb.ConstantCoefficient(kap)), dh, sp), 0.0)
     Kah = Ka.A.to_host()
@@ -500,6 +512,35 @@ def test_properties_64_cubed(tb, oracle, device):
 
 def test_properties_100_cubed(tb, oracle, device):
     assert _property_checks(tb, oracle, device, 100) == 1000000
+
+
+def test_properties_216_cubed(tb, oracle, device):
+    """BASELINE's metric configuration (10 077 696 hexahedra, 273 359 449 non-zeros) through the fused M + K pass of bench.py:
+    K·1 = 0, Σ M = volume, ∫1·Nⱼ = (M·1)ⱼ, symmetry, definiteness, sampled rows of K and M against oracle element matrices,
+    atomic == patch.  Covers the Int32 / size effects the smaller property tests cannot."""
+    assert _property_checks(tb, oracle, device, 216, sample=300, fused=True) == 10077696
+
+
+def test_fused_mass_diffusion_pair_parity(tb, oracle, device):
+    """tb_assemble_matrix_pair (one pass, both matrices) == the oracle, for constant and nodal-field coefficients, on a mesh of several
+    patches with ragged boundary tiles; second call overwrites."""
+    g, dh, sp, om = make_problem(tb, oracle, nel=(13, 11, 9), perturb=0.25)
+    rng = np.random.default_rng(11)
+    rho_field = rng.uniform(0.5, 2.0, size=(g.n_cells, 8))
+    cases = {n_: (tc, oc) for n_, tc, oc in coef_cases(tb, oracle, g, rng)}
+    st = tb.PatchAssemblyStrategy(device)
+    for mname, mt, mo in (("const", tb.ConstantCoefficient(1.7), oracle.Coef(oracle.COEF_CONST_SCALAR, [1.7])),
+                          ("field", tb.FieldCoefficient(rho_field), oracle.Coef(oracle.COEF_FIELD_SCALAR, field=rho_field))):
+        refM = oracle.assemble_matrix(om, 0, mo, sp.rowptr, sp.colidx)
+        for kname in ("diag", "full", "monodomain", "fibre_field", "iso_field", "nonsym"):
+            kt, ko = cases[kname]
+            refK = oracle.assemble_matrix(om, 1, ko, sp.rowptr, sp.colidx)
+            M = tb.setup_operator(st, tb.BilinearMassIntegrator(mt), dh, sp)
+            K = tb.setup_operator(st, tb.BilinearDiffusionIntegrator(kt), dh, sp)
+            for rep in range(2):
+                tb.update_operators(M, K, 0.1 * rep)
+                assert rel_err(M.A.to_host(), refM) < TOL, (mname, kname, rep)
+                assert rel_err(K.A.to_host(), refK) < TOL, (mname, kname, rep)
 
 
 def test_reaction_full_size_roundtrip(tb, oracle, device):

@@ -5,7 +5,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtbhip.so")
+LIB_PATH = os.environ.get("TB_LIBTBHIP") or os.path.join(_HERE, "libtbhip.so")   # TB_LIBTBHIP: a profiling build (make ablation)
 
 # enums of include/tbhip.h
 TB_OK = 0
@@ -83,6 +83,7 @@ SIGNATURES = {
     "tb_form_destroy": (C.c_int, [vp]),
     "tb_form_set_table": (C.c_int, [vp, c_dp, C.c_int64]),
     "tb_assemble_matrix": (C.c_int, [vp, vp, C.c_int, C.c_double, vp]),
+    "tb_assemble_matrix_pair": (C.c_int, [vp, vp, vp, C.c_int, C.c_double, vp, vp]),
     "tb_assemble_vector": (C.c_int, [vp, C.c_int, C.c_double, vp]),
     "tb_hyperelastic_create": (C.c_int, [vp, C.c_int, C.POINTER(tb_material), C.POINTER(vp)]),
     "tb_residual": (C.c_int, [vp, C.c_int, vp, C.c_double, vp]),

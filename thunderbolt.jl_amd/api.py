@@ -628,6 +628,18 @@ def update_operator(op, t):
     return op
 
 
+def update_operators(M, K, t):
+    """update_operator!(cache.M, t); update_operator!(cache.K, t) of the heat stage (src/solver/time/euler.jl:172-176) in one pass
+    over the mesh: M a mass operator, K a diffusion operator of the same DofHandler / pattern / strategy."""
+    if (isinstance(M, BilinearOperator) and isinstance(K, BilinearOperator) and M.pattern is K.pattern and M.strategy.code == K.strategy.code
+            and M.integrator.form == L.TB_FORM_MASS and K.integrator.form == L.TB_FORM_DIFFUSION):
+        check(lib().tb_assemble_matrix_pair(M.form.h, K.form.h, M.pattern.h, M.strategy.code, float(t), M.A.ptr, K.A.ptr))
+    else:
+        M.update(t)
+        K.update(t)
+    return M, K
+
+
 def needs_update(op, t):
     """needs_update(op::LinearOperator, t) (src/discretization/operator.jl:17-26): closed-interval test."""
     iv = getattr(op.integrator, "nonzero_intervals", None)

@@ -300,6 +300,7 @@ int tb_pattern_destroy(tb_pattern *p)
     if (!p) return TB_OK;
     hipFree(p->d_rowptr); hipFree(p->d_colidx); hipFree(p->d_blkrow); hipFree(p->d_bcol); hipFree(p->d_diagpos); hipFree(p->d_emap); hipFree(p->d_blockpos); hipFree(p->d_cg_ws); hipFree(p->d_gmres_ws); hipFree(p->d_pcg_ws); hipFree(p->d_q2pos); hipFree(p->d_kebuf);
     free_patch_mat_plan(p);
+    free_patch_fused_plan(p);
     delete p;
     return TB_OK;
 }
@@ -398,6 +399,22 @@ int tb_assemble_matrix(tb_form *form, tb_pattern *pat, int strategy, double t, d
         return TB_OK;
     }
     return launch_assemble_matrix(form, pat, strategy, t, d_nzval);
+}
+
+int tb_assemble_matrix_pair(tb_form *mass, tb_form *diffusion, tb_pattern *pat, int strategy, double t, double *d_nzval_mass, double *d_nzval_diffusion)
+{
+    TB_REQUIRE(mass && diffusion && pat && ((d_nzval_mass && d_nzval_diffusion) || pat->nnz == 0), "tb_assemble_matrix_pair: NULL argument");
+    TB_REQUIRE(mass->kind == TB_FORM_MASS && diffusion->kind == TB_FORM_DIFFUSION, "tb_assemble_matrix_pair: expects (mass form, diffusion form)");
+    TB_REQUIRE(mass->mesh == pat->mesh && diffusion->mesh == pat->mesh, "tb_assemble_matrix_pair: forms and pattern belong to different meshes");
+    TB_REQUIRE(d_nzval_mass != d_nzval_diffusion || pat->nnz == 0, "tb_assemble_matrix_pair: the two outputs alias");
+    if (strategy == TB_STRATEGY_PATCH && mass->mesh->n_cells > 0 && hex8_patch_applicable(mass, pat) && hex8_patch_applicable(diffusion, pat)) {
+        TB_HIP(hipSetDevice(mass->mesh->dev->id));
+        const int rc = launch_assemble_hex8_patch(diffusion, mass, pat, t, d_nzval_diffusion, d_nzval_mass);
+        if (rc != TB_ERR_UNSUPPORTED) return rc;
+    }
+    int rc = tb_assemble_matrix(mass, pat, strategy, t, d_nzval_mass);
+    if (rc) return rc;
+    return tb_assemble_matrix(diffusion, pat, strategy, t, d_nzval_diffusion);
 }
 
 int tb_assemble_vector(tb_form *form, int strategy, double t, double *d_b)

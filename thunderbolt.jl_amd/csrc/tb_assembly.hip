@@ -22,32 +22,11 @@
 #include <type_traits>
 
 #include "tb_elem.hpp"
+#include "tb_forms.hpp"
 #include "tb_internal.h"
 
 namespace tb {
 using namespace tbk;
-
-struct MeshView {
-    const double *xyz;
-    const int32_t *conn;
-    const int32_t *cell_dofs;
-    int64_t n_cells;
-};
-
-struct FormArgs {
-    double D[9];      // constant tensor (already divided by Cₘ·χ when wrapped)
-    double rho;       // constant density
-    double lambda[3]; // eigenvalues for the spectral field coefficient
-    double scale;     // 1/(Cₘ·χ) for field coefficients (1 when not wrapped)
-    const double *field;
-    const double *dtab; // diffusion with a fibre field: the tensor at every quadrature point, 6 doubles (xx,xy,xz,yy,yz,zz) per (cell, q)
-    // source
-    int src_kind;
-    double p0;
-    const double *table;
-    double t, ct;
-    int debug; // diagnostic ablation bits (TB_DEBUG_FLAGS): 1 skip LDS adds, 2 skip write-out, 4 skip arithmetic
-};
 
 template <int NB> __host__ __device__ constexpr int sym_idx(int i, int j)
 {
@@ -428,9 +407,13 @@ k_matrix_patch(MeshView m, FormArgs fa, PatchView pv, double *__restrict__ nz, S
         double Ke[SYM ? NB * (NB + 1) / 2 : NB * NB];
 #pragma unroll
         for (int k = 0; k < (SYM ? NB * (NB + 1) / 2 : NB * NB); ++k) Ke[k] = 0.0;
-        if (!(fa.debug & 4)) { if (!element_matrix<E, FORM, FIELD, SYM>(x, fa, cell, Ke)) flag_neg_detj(st, cell); }
-        else { Ke[0] = x[0][0] + x[E::NV - 1][2]; }
+#ifdef TB_ABLATION
+        if (fa.debug & 4) Ke[0] = x[0][0] + x[E::NV - 1][2]; else
+#endif
+        if (!element_matrix<E, FORM, FIELD, SYM>(x, fa, cell, Ke)) flag_neg_detj(st, cell);
+#ifdef TB_ABLATION
         if (!(fa.debug & 1))
+#endif
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             if (ro[i] == 0xFFFF) continue;
@@ -445,8 +428,10 @@ k_matrix_patch(MeshView m, FormArgs fa, PatchView pv, double *__restrict__ nz, S
     }
     __syncthreads();
 
+#ifdef TB_ABLATION
     if (fa.debug & 1) { if (threadIdx.x == 0) nz[p] = acc[0] + Ke_sink(); }
     if (fa.debug & 2) return;
+#endif
     // write-out: one row per half-wave, descriptors from LDS, several rows in flight per wave
     const int half = threadIdx.x >> 5, hl = threadIdx.x & 31, nhalves = T >> 5;
 #pragma unroll 4
@@ -526,27 +511,6 @@ int ensure_emap(tb_pattern *p)
     return check_status(dev);
 }
 
-static FormArgs make_args(const tb_form *f, double t)
-{
-    FormArgs a{};
-    for (int i = 0; i < 9; ++i) a.D[i] = f->Dconst[i];
-    a.rho = f->coef.p[0];
-    a.lambda[0] = f->coef.p[0]; a.lambda[1] = f->coef.p[1]; a.lambda[2] = f->coef.p[2];
-    a.scale = f->coef.wrap ? 1.0 / (f->coef.Cm * f->coef.chi) : 1.0;
-    a.field = f->d_field;
-    a.dtab = f->d_dtab;
-    a.src_kind = f->coef.kind;
-    a.p0 = f->coef.p[0];
-    a.table = f->d_table;
-    a.t = t;
-    a.ct = std::cos(2.0 * 3.141592653589793 * t);
-    static const int dbg = getenv("TB_DEBUG_FLAGS") ? atoi(getenv("TB_DEBUG_FLAGS")) : 0;
-    a.debug = dbg;
-    return a;
-}
-
-static MeshView make_view(const tb_mesh *m) { return MeshView{m->d_xyz, m->d_conn, m->d_cell_dofs, m->n_cells}; }
-
 static PatchView make_patch_view(const tb_mesh *m, const tb_pattern *p)
 {
     const PatchPlan *pp = m->patches.get();
@@ -614,24 +578,32 @@ static int run_matrix(tb_form *f, tb_pattern *p, int strategy, double t, double 
     return TB_ERR_UNSUPPORTED;
 }
 
+// first assembly of a diffusion form with a nodal coefficient field: tabulate the tensor at the quadrature points (the microstructure
+// is data of the form, fixed at tb_form_create) and drop the nodal frames (5.8 GB at 10 M cells)
+template <class E>
+static int tabulate_diffusion_field_t(tb_form *f)
+{
+    tb_mesh *m = f->mesh;
+    const size_t bytes = sizeof(double) * (size_t)m->n_cells * E::NQ * 6;
+    hipError_t e = hipMalloc((void **)&f->d_dtab, bytes);
+    if (e != hipSuccess) { set_error("diffusion tensor table (%zu B): %s", bytes, hipGetErrorString(e)); return TB_ERR_NOMEM; }
+    const double sc = f->coef.wrap ? 1.0 / (f->coef.Cm * f->coef.chi) : 1.0;
+    if (f->coef.kind == TB_COEF_FIELD_SCALAR)
+        hipLaunchKernelGGL((k_tabulate_isotropic<E>), dim3(nblocks(m->n_cells, 256)), dim3(256), 0, m->dev->stream, f->d_field, m->n_cells, sc, f->d_dtab);
+    else
+        hipLaunchKernelGGL((k_tabulate_spectral<E>), dim3(nblocks(m->n_cells, 256)), dim3(256), 0, m->dev->stream, f->d_field, m->n_cells, f->coef.p[0],
+                           f->coef.p[1], f->coef.p[2], sc, f->d_dtab);
+    TB_HIP(hipGetLastError());
+    TB_HIP(hipStreamSynchronize(m->dev->stream));
+    (void)hipFree(f->d_field); f->d_field = nullptr;
+    return TB_OK;
+}
+int tabulate_diffusion_field(tb_form *f) { return tabulate_diffusion_field_t<Hex8<2>>(f); } // for tb_patch_fused.hip
+
 template <class E, int FORM>
 static int run_matrix_coef(tb_form *f, tb_pattern *p, int strategy, double t, double *d_nz)
 {
-    if (f->field && FORM == TB_FORM_DIFFUSION && !f->d_dtab) { // first assembly: tabulate the tensor at the quadrature points
-        tb_mesh *m = f->mesh;
-        const size_t bytes = sizeof(double) * (size_t)m->n_cells * E::NQ * 6;
-        hipError_t e = hipMalloc((void **)&f->d_dtab, bytes);
-        if (e != hipSuccess) { set_error("diffusion tensor table (%zu B): %s", bytes, hipGetErrorString(e)); return TB_ERR_NOMEM; }
-        const double sc = f->coef.wrap ? 1.0 / (f->coef.Cm * f->coef.chi) : 1.0;
-        if (f->coef.kind == TB_COEF_FIELD_SCALAR)
-            hipLaunchKernelGGL((k_tabulate_isotropic<E>), dim3(nblocks(m->n_cells, 256)), dim3(256), 0, m->dev->stream, f->d_field, m->n_cells, sc, f->d_dtab);
-        else
-            hipLaunchKernelGGL((k_tabulate_spectral<E>), dim3(nblocks(m->n_cells, 256)), dim3(256), 0, m->dev->stream, f->d_field, m->n_cells, f->coef.p[0],
-                               f->coef.p[1], f->coef.p[2], sc, f->d_dtab);
-        TB_HIP(hipGetLastError());
-        TB_HIP(hipStreamSynchronize(m->dev->stream));
-        (void)hipFree(f->d_field); f->d_field = nullptr; // the nodal frames are not needed any more (5.8 GB at 10 M cells)
-    }
+    if (f->field && FORM == TB_FORM_DIFFUSION && !f->d_dtab) { int rc = tabulate_diffusion_field_t<E>(f); if (rc) return rc; }
     if (f->field) return run_matrix<E, FORM, true, true>(f, p, strategy, t, d_nz);
     if (FORM == TB_FORM_DIFFUSION && !f->symmetric) return run_matrix<E, FORM, false, false>(f, p, strategy, t, d_nz);
     return run_matrix<E, FORM, false, true>(f, p, strategy, t, d_nz);
@@ -927,6 +899,12 @@ int launch_assemble_matrix(tb_form *f, tb_pattern *p, int strategy, double t, do
     tb_mesh *m = f->mesh;
     int rc = reset_status(m->dev);
     if (rc) return rc;
+    if (strategy == TB_STRATEGY_PATCH && hex8_patch_applicable(f, p)) {
+        rc = f->kind == TB_FORM_DIFFUSION ? launch_assemble_hex8_patch(f, nullptr, p, t, d_nz, nullptr) : launch_assemble_hex8_patch(nullptr, f, p, t, nullptr, d_nz);
+        if (rc != TB_ERR_UNSUPPORTED) return rc; // e.g. rows longer than 255 entries: the general patch kernel below
+        rc = reset_status(m->dev);
+        if (rc) return rc;
+    }
     if (m->field_kind == TB_HEX8 && f->qorder == 2) rc = run_matrix_form<Hex8<2>>(f, p, strategy, t, d_nz);
     else if (m->field_kind == TB_TET4 && f->qorder == 2) rc = run_matrix_form<Tet4<2>>(f, p, strategy, t, d_nz);
     else if (m->field_kind == TB_QUAD4 && f->qorder == 2) rc = run_matrix_form<Quad4<2>>(f, p, strategy, t, d_nz);

@@ -94,6 +94,22 @@ struct PatchMatPlan {
     uint16_t *d_colpos16 = nullptr;    // same, 16-bit, when some row is longer
 };
 
+// Plan of the sum-factorised hexahedron patch kernel (tb_patch_fused.hip): per patch the list of the nodes its cell
+// instances touch (owned rows first, in row-slot order), per instance 8 patch-local node indices (16 B: they select both
+// the coordinates and the row accumulators) and the index of the cell's 64-byte signature "position of column dof(j) in row
+// dof(i)" in a de-duplicated table (structured regions share a handful of signatures; an unstructured mesh keeps one per cell).
+struct PatchFusedPlan {
+    int version = 0;
+    int max_lds_entries = 0, max_nodes = 0;
+    int64_t nsig = 0;
+    int64_t *d_node_ptr = nullptr; // n_patches+1
+    int32_t *d_pnode = nullptr;    // global node ids
+    uint16_t *d_elem_ln = nullptr; // 8 per instance
+    uint32_t *d_elem_sig = nullptr;
+    uint8_t *d_sigtab = nullptr;   // nsig × 64
+    RowDesc *d_row_desc = nullptr;
+};
+
 } // namespace tb
 
 struct tb_device {
@@ -149,6 +165,7 @@ struct tb_pattern {
     int64_t max_row_len = 0;
     uint16_t *d_blockpos = nullptr; // vector fields: per cell and node pair, position of the 3×3 block inside its row
     std::unique_ptr<tb::PatchMatPlan> patch_mat;
+    std::unique_ptr<tb::PatchFusedPlan> patch_fused;
 };
 
 struct tb_form {
@@ -205,6 +222,10 @@ int build_patch_mat_plan(tb_pattern *p);
 int ensure_patch_plans(tb_mesh *m, tb_pattern *p); // builds / refits both so the LDS block allows two workgroups per CU
 void free_patch_plan(tb_mesh *m);
 void free_patch_mat_plan(tb_pattern *p);
+int ensure_patch_fused(tb_mesh *m, tb_pattern *p, int nregions); // plan of the sum-factorised hexahedron kernel; nregions accumulator blocks must fit 80 KiB of LDS
+void free_patch_fused_plan(tb_pattern *p);
+int launch_assemble_hex8_patch(tb_form *fK, tb_form *fM, tb_pattern *p, double t, double *d_nzK, double *d_nzM); // either form may be NULL
+bool hex8_patch_applicable(const tb_form *f, const tb_pattern *p);
 
 // ---- kernel launchers (tb_assembly.hip / tb_reaction.hip / tb_algebra.hip) ----
 int ensure_emap(tb_pattern *p);

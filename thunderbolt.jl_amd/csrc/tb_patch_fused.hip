@@ -1,0 +1,248 @@
+// tb_patch_fused.hip — PATCH-strategy assembly of the mass and diffusion matrices on trilinear hexahedra (2×2×2 Gauss rule),
+// either one of them or BOTH in one pass over the mesh.
+//
+// Reference call sites: the backward-Euler heat stage assembles the mass and the diffusion operator of one DofHandler back to
+// back on the same sparsity pattern (src/solver/time/euler.jl:172-176, pattern sharing :110-116); element routines
+// src/modeling/core/mass.jl:28-43, src/modeling/core/diffusion.jl:28-50, geometry src/ferrite-addons/PR883.jl:253-291,367-387.
+//
+// One workgroup per patch (tb_plans.cpp): a thread integrates one cell instance with the sum-factorised element routine
+// (tb_hex8_sumfac.hpp: geometry once for both forms, ≈1 400 FP64 instructions per cell for Kₑ and Mₑ together), adds the
+// entries of the rows its patch owns into LDS row accumulators (ds_add_f64; one block of accumulators per matrix) and every
+// row leaves as one contiguous store per matrix: each nz is written exactly once, no zero-fill pass, no global atomics.
+// Per-instance metadata is 20 B (8 patch-local node indices + signature index); the 64 positions "column dof(j) in row
+// dof(i)" of a cell come from a de-duplicated signature table; coordinates are gathered through the patch's node list in LDS.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "tb_elem.hpp"
+#include "tb_forms.hpp"
+#include "tb_hex8_sumfac.hpp"
+#include "tb_internal.h"
+
+namespace tb {
+using namespace tbk;
+
+struct FusedView {
+    const int64_t *elem_ptr, *row_ptr, *node_ptr;
+    const int32_t *elem_cell;
+    const uint16_t *elem_ln;
+    const uint32_t *elem_sig;
+    const uint8_t *sigtab;
+    const int32_t *pnode;
+    const RowDesc *row_desc;
+    int kcap, max_rows, max_nodes;
+};
+
+template <bool WK, bool WM, bool FK, bool FM>
+__global__ void __launch_bounds__(256, 2)
+k_patch_hex8(MeshView m, FormArgs faK, FormArgs faM, FusedView pv, double *__restrict__ nzK, double *__restrict__ nzM, Status *st)
+{
+    extern __shared__ double lds[];
+    const int T = blockDim.x, tid = threadIdx.x;
+    const int64_t p = blockIdx.x;
+    const int64_t e0 = pv.elem_ptr[p], e1 = pv.elem_ptr[p + 1];
+    const int64_t r0 = pv.row_ptr[p];
+    const int nrows = (int)(pv.row_ptr[p + 1] - r0);
+    if (nrows == 0) return; // a patch whose dofs all belong to earlier patches writes nothing
+    const int64_t n0 = pv.node_ptr[p];
+    const int nnodes = (int)(pv.node_ptr[p + 1] - n0);
+    double *accK = lds;
+    double *accM = lds + (WK && WM ? pv.kcap : 0);
+    RowDesc *desc = (RowDesc *)(lds + (WK && WM ? 2 : 1) * pv.kcap);
+    int32_t *nid = (int32_t *)(desc + pv.max_rows);
+
+    // the first instance's metadata travels while the LDS block is set up
+    int64_t e = e0 + tid;
+    uint4 lnv = make_uint4(0, 0, 0, 0);
+    uint32_t sig = 0;
+    if (e < e1) { lnv = ((const uint4 *)pv.elem_ln)[e]; sig = pv.elem_sig[e]; }
+    const RowDesc last = pv.row_desc[r0 + nrows - 1];
+    const int nacc2 = (int)((last.off + last.len + 1) >> 1);
+    for (int k = tid; k < nnodes; k += T) nid[k] = pv.pnode[n0 + k];
+    for (int s = tid; s < nrows; s += T) desc[s] = pv.row_desc[r0 + s];
+    {
+        double2 *zK = (double2 *)accK, *zM = (double2 *)accM;
+        for (int k = tid; k < nacc2; k += T) {
+            zK[k] = make_double2(0.0, 0.0);
+            if (WK && WM) zM[k] = make_double2(0.0, 0.0);
+        }
+    }
+    __syncthreads();
+
+    while (e < e1) {
+        const int64_t en = e + T;
+        uint4 lnn = make_uint4(0, 0, 0, 0);
+        uint32_t sign = 0;
+        if (en < e1) { lnn = ((const uint4 *)pv.elem_ln)[en]; sign = pv.elem_sig[en]; }
+        uint32_t ln[8] = {lnv.x & 0xffffu, lnv.x >> 16, lnv.y & 0xffffu, lnv.y >> 16, lnv.z & 0xffffu, lnv.z >> 16, lnv.w & 0xffffu, lnv.w >> 16};
+        double x[8][3];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            const double *px = m.xyz + 3 * (int64_t)nid[ln[a]];
+            x[a][0] = px[0]; x[a][1] = px[1]; x[a][2] = px[2];
+        }
+        uint4 cp[4];
+        {
+            const uint4 *cpp = (const uint4 *)(pv.sigtab + (size_t)sig * 64);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cp[k] = cpp[k];
+        }
+        uint32_t ro[8]; // entry offset of row i in the accumulator block; 0xFFFFFFFF = row not owned by this patch
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ro[i] = ln[i] < (uint32_t)nrows ? desc[ln[i]].off : 0xFFFFFFFFu;
+        int64_t cell = 0;
+        if constexpr (FK || FM) cell = pv.elem_cell[e];
+
+        double G[8][6], dq[8];
+        auto Dq = [&](int q, double(&D)[6]) {
+            if constexpr (FK) {
+                const double *dp = faK.dtab + (cell * 8 + q) * 6;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) D[k] = dp[k];
+            } else {
+                D[0] = faK.D[0]; D[1] = faK.D[1]; D[2] = faK.D[2]; D[3] = faK.D[4]; D[4] = faK.D[5]; D[5] = faK.D[8];
+            }
+        };
+#ifdef TB_ABLATION
+        if (faK.debug & 4) { // no arithmetic: keep the loads alive, feed the scatter with trivial values
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { dq[q] = x[q][0] + x[q][1] + x[q][2]; for (int k = 0; k < 6; ++k) G[q][k] = dq[q]; }
+        } else
+#endif
+        if (!hex8_sf_geometry<WK, FK>(x, Dq, G, dq)) { st->neg_detj = 1; st->cell = pv.elem_cell[e]; }
+        bool own[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) own[i] = ro[i] != 0xFFFFFFFFu;
+#ifdef TB_ABLATION
+        if (faK.debug & 1) { // no LDS adds: one add per thread keeps the values alive
+#pragma unroll
+            for (int i = 1; i < 8; ++i) own[i] = false;
+            own[0] = own[0] && (G[0][0] + dq[0] == 1.2345);
+        }
+#endif
+        // positions: byte i*8+j of the 64-byte signature; dwords 2i, 2i+1 hold row i
+        auto pos = [&](int i, int j) -> uint32_t {
+            const uint4 &c4 = cp[i >> 1];
+            const uint32_t w = (i & 1) ? (j < 4 ? c4.z : c4.w) : (j < 4 ? c4.x : c4.y);
+            return (w >> (8 * (j & 3))) & 0xffu;
+        };
+        if constexpr (WK) {
+            Hex8SFK c;
+            hex8_sf_contract(G, c);
+            // every entry goes to LDS as soon as it is formed (rows i and j of the symmetric pair): Kₑ is never held as a whole
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = i; j < 8; ++j) {
+                    const double v = hex8_sf_entry(c, i, j);
+                    if (own[i]) unsafeAtomicAdd(accK + (ro[i] + pos(i, j)), v);
+                    if (j > i && own[j]) unsafeAtomicAdd(accK + (ro[j] + pos(j, i)), v);
+                }
+        }
+        if constexpr (WM) {
+            if constexpr (FM) { // ρ at the Gauss points from first-order nodal data per cell (FieldCoefficient, coefficients.jl:85-99)
+                double rn[8];
+#pragma unroll
+                for (int a = 0; a < 8; ++a) rn[a] = faM.field[cell * 8 + a];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    double r = 0.0;
+#pragma unroll
+                    for (int a = 0; a < 8; ++a) r += Hex8<2>::N(q, a) * rn[a];
+                    dq[q] *= r;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) dq[q] *= faM.rho;
+            }
+            double Z[3][3][3];
+            hex8_sf_mass(dq, Z);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (own[i]) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) unsafeAtomicAdd(accM + (ro[i] + pos(i, j)), Z[SF::ty(i, j, 0)][SF::ty(i, j, 1)][SF::ty(i, j, 2)]);
+                }
+        }
+        e = en; lnv = lnn; sig = sign;
+    }
+    __syncthreads();
+#ifdef TB_ABLATION
+    if (faK.debug & 2) { if (tid == 0 && accK[0] + accM[1] == 1.2345) nzK[p] = 0.0; return; }
+#endif
+
+    // write-out: one row per half-wave, each matrix's row as one contiguous run
+    const int half = tid >> 5, hl = tid & 31, nhalves = T >> 5;
+#pragma unroll 2
+    for (int s = half; s < nrows; s += nhalves) {
+        const RowDesc d = desc[s];
+        for (uint32_t k = hl; k < d.len; k += 32) {
+            if constexpr (WK) nzK[d.nz0 + k] = accK[d.off + k];
+            if constexpr (WM) nzM[d.nz0 + k] = accM[d.off + k];
+        }
+    }
+}
+
+bool hex8_patch_applicable(const tb_form *f, const tb_pattern *p)
+{
+    static const bool legacy = getenv("TB_PATCH_KERNEL") && !strcmp(getenv("TB_PATCH_KERNEL"), "legacy");
+    if (legacy) return false;
+    const tb_mesh *m = f->mesh;
+    if (m->field_kind != TB_HEX8 || m->geom_kind != TB_HEX8 || m->ncomp != 1 || f->qorder != 2) return false;
+    if (f->kind == TB_FORM_DIFFUSION && !f->symmetric) return false;
+    if (f->kind != TB_FORM_DIFFUSION && f->kind != TB_FORM_MASS) return false;
+    if (f->has_cellset) return false;
+    (void)p;
+    return true;
+}
+
+int tabulate_diffusion_field(tb_form *f); // tb_assembly.hip
+
+int launch_assemble_hex8_patch(tb_form *fK, tb_form *fM, tb_pattern *p, double t, double *d_nzK, double *d_nzM)
+{
+    tb_form *any = fK ? fK : fM;
+    tb_mesh *m = any->mesh;
+    tb_device *dev = m->dev;
+    int rc = reset_status(dev);
+    if (rc) return rc;
+    if (fK && fK->field && !fK->d_dtab) { rc = tabulate_diffusion_field(fK); if (rc) return rc; }
+    const int nreg = fK && fM ? 2 : 1;
+    rc = ensure_patch_fused(m, p, nreg);
+    if (rc) return rc;
+    const PatchPlan *pp = m->patches.get();
+    const PatchFusedPlan *pf = p->patch_fused.get();
+    FusedView pv{};
+    pv.elem_ptr = pp->d_elem_ptr; pv.row_ptr = pp->d_row_ptr; pv.node_ptr = pf->d_node_ptr; pv.elem_cell = pp->d_elem_cell;
+    pv.elem_ln = pf->d_elem_ln; pv.elem_sig = pf->d_elem_sig; pv.sigtab = pf->d_sigtab; pv.pnode = pf->d_pnode; pv.row_desc = pf->d_row_desc;
+    pv.kcap = pf->max_lds_entries; pv.max_rows = pp->max_rows; pv.max_nodes = pf->max_nodes;
+    const size_t lds = (size_t)nreg * pv.kcap * sizeof(double) + (size_t)pv.max_rows * sizeof(RowDesc) + (size_t)pv.max_nodes * sizeof(int32_t);
+    const MeshView mv = make_view(m);
+    FormArgs aK = fK ? make_args(fK, t) : FormArgs{};
+    const FormArgs aM = fM ? make_args(fM, t) : FormArgs{};
+#ifdef TB_ABLATION
+    aK.debug = aM.debug | aK.debug;
+#endif
+    const int T = pp->threads;
+    auto launch = [&](auto k) -> int {
+        TB_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, dim3((unsigned)pp->n_patches), dim3(T), lds, dev->stream, mv, aK, aM, pv, d_nzK, d_nzM, dev->d_status);
+        return TB_OK;
+    };
+    const bool fk = fK && fK->field, fm = fM && fM->field;
+    if (fK && fM) {
+        if (fk && fm) rc = launch(k_patch_hex8<true, true, true, true>);
+        else if (fk) rc = launch(k_patch_hex8<true, true, true, false>);
+        else if (fm) rc = launch(k_patch_hex8<true, true, false, true>);
+        else rc = launch(k_patch_hex8<true, true, false, false>);
+    } else if (fK) {
+        rc = fk ? launch(k_patch_hex8<true, false, true, false>) : launch(k_patch_hex8<true, false, false, false>);
+    } else {
+        rc = fm ? launch(k_patch_hex8<false, true, false, true>) : launch(k_patch_hex8<false, true, false, false>);
+    }
+    if (rc) return rc;
+    TB_HIP(hipGetLastError());
+    return check_status(dev);
+}
+
+} // namespace tb

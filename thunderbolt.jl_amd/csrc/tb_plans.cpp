@@ -407,3 +407,174 @@ int ensure_patch_plans(tb_mesh *m, tb_pattern *p)
 }
 
 } // namespace tb
+
+namespace tb {
+
+void free_patch_fused_plan(tb_pattern *p)
+{
+    if (!p->patch_fused) return;
+    PatchFusedPlan *f = p->patch_fused.get();
+    hipFree(f->d_node_ptr); hipFree(f->d_pnode); hipFree(f->d_elem_ln); hipFree(f->d_elem_sig); hipFree(f->d_sigtab); hipFree(f->d_row_desc);
+    p->patch_fused.reset();
+}
+
+static inline uint64_t mix64(uint64_t h, uint64_t v)
+{
+    h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+    h *= 0xff51afd7ed558ccdull;
+    return h ^ (h >> 33);
+}
+
+// Fused-kernel extension of the patch plan (see PatchFusedPlan).  Needs a scalar first-order field whose local dof a sits on
+// local vertex a (Ferrite: vertex dofs in vertex order), i.e. a one-to-one node ↔ dof relation; rows of at most 255 entries.
+static int build_patch_fused_plan(tb_pattern *p, int64_t *lds_need, int nregions)
+{
+    tb_mesh *m = p->mesh;
+    const PatchPlan *pp = m->patches.get();
+    const int ndpc = m->ndpc;
+    if (ndpc != 8 || m->nverts != 8 || m->ncomp != 1) { set_error("fused patch plan: needs a scalar trilinear hexahedron field"); return TB_ERR_UNSUPPORTED; }
+    auto plan = std::make_unique<PatchFusedPlan>();
+    plan->version = pp->version;
+    // 1. row descriptors and the LDS need
+    std::vector<RowDesc> row_desc(pp->total_rows);
+    int64_t maxlen = 0, max_entries = 0;
+    for (int64_t q = 0; q < pp->n_patches; ++q) {
+        uint64_t off = 0;
+        for (int64_t r = pp->h_row_ptr[q]; r < pp->h_row_ptr[q + 1]; ++r) {
+            const int32_t d = pp->h_row_dof[r];
+            const int64_t len = p->h_rowptr[d + 1] - p->h_rowptr[d];
+            row_desc[r] = RowDesc{p->h_rowptr[d], (uint32_t)off, (uint32_t)len};
+            off += (uint64_t)len;
+            maxlen = std::max(maxlen, len);
+        }
+        max_entries = std::max<int64_t>(max_entries, (int64_t)off);
+    }
+    if (maxlen > 255) { set_error("fused patch plan: a row has %lld entries (> 255)", (long long)maxlen); return TB_ERR_UNSUPPORTED; }
+    plan->max_lds_entries = (int)((max_entries + 1) & ~(int64_t)1);
+    // 2. per-patch node lists and patch-local node indices of every instance
+    std::vector<int64_t> node_ptr(pp->n_patches + 1, 0);
+    std::vector<int32_t> pnode;
+    pnode.reserve((size_t)(m->n_nodes * 2.2) + 1024);
+    std::vector<uint16_t> ln((size_t)pp->total_elems * 8);
+    std::vector<int32_t> local_of(m->n_nodes, -1);
+    bool bad = false;
+    int max_nodes = 0;
+    for (int64_t q = 0; q < pp->n_patches; ++q) {
+        const int64_t r0 = pp->h_row_ptr[q], nrows = pp->h_row_ptr[q + 1] - r0;
+        const size_t base = pnode.size();
+        pnode.resize(base + nrows, -1);
+        for (int64_t e = pp->h_elem_ptr[q]; e < pp->h_elem_ptr[q + 1]; ++e) { // owned slots first
+            const int32_t c = pp->h_elem_cell[e];
+            for (int a = 0; a < 8; ++a) {
+                const uint16_t slot = pp->h_elem_lrow[e * 8 + a];
+                if (slot == 0xFFFF) continue;
+                const int32_t node = m->h_conn[(int64_t)c * 8 + a];
+                int32_t &dst = pnode[base + slot];
+                if (dst < 0) { dst = node; local_of[node] = slot; }
+                else if (dst != node) bad = true;
+            }
+        }
+        for (int64_t e = pp->h_elem_ptr[q]; e < pp->h_elem_ptr[q + 1]; ++e) {
+            const int32_t c = pp->h_elem_cell[e];
+            for (int a = 0; a < 8; ++a) {
+                const int32_t node = m->h_conn[(int64_t)c * 8 + a];
+                if (local_of[node] < 0) { local_of[node] = (int32_t)(pnode.size() - base); pnode.push_back(node); }
+                else if (pp->h_elem_lrow[e * 8 + a] == 0xFFFF && local_of[node] < nrows) bad = true; // an owned node reached through a dof the patch does not own
+                ln[(size_t)e * 8 + a] = (uint16_t)local_of[node];
+            }
+        }
+        const size_t nn = pnode.size() - base;
+        if (nn >= 0xFFFF) { set_error("fused patch plan: a patch touches %zu nodes", nn); return TB_ERR_UNSUPPORTED; }
+        max_nodes = std::max(max_nodes, (int)nn);
+        for (size_t k = base; k < pnode.size(); ++k) if (pnode[k] >= 0) local_of[pnode[k]] = -1; else bad = true;
+        node_ptr[q + 1] = (int64_t)pnode.size();
+    }
+    if (bad) { set_error("fused patch plan: dofs and vertices of the field are not in one-to-one correspondence"); return TB_ERR_UNSUPPORTED; }
+    plan->max_nodes = max_nodes;
+    *lds_need = (int64_t)nregions * plan->max_lds_entries * 8 + (int64_t)pp->max_rows * 16 + (int64_t)max_nodes * 4;
+    if (*lds_need > 80 * 1024) { p->patch_fused = std::move(plan); return TB_ERR_UNSUPPORTED; } // caller shrinks the tile and retries
+    // 3. signatures: position of column dof(j) inside row dof(i) for every pair of a cell, de-duplicated
+    const int64_t nc = m->n_cells;
+    std::vector<uint8_t> sig((size_t)nc * 64);
+    std::vector<uint64_t> hash(nc);
+    bool missing = false;
+#pragma omp parallel for schedule(static) reduction(|| : missing)
+    for (int64_t c = 0; c < nc; ++c) {
+        const int32_t *d = &m->h_cell_dofs[c * 8];
+        uint8_t *sg = &sig[(size_t)c * 64];
+        for (int i = 0; i < 8; ++i) {
+            const int32_t *b = &p->h_colidx[p->h_rowptr[d[i]]];
+            const int32_t *en = &p->h_colidx[p->h_rowptr[d[i] + 1]];
+            for (int j = 0; j < 8; ++j) {
+                const int32_t *it = std::lower_bound(b, en, d[j]);
+                if (it == en || *it != d[j]) { missing = true; sg[i * 8 + j] = 0; continue; }
+                sg[i * 8 + j] = (uint8_t)(it - b);
+            }
+        }
+        uint64_t h = 0x243f6a8885a308d3ull;
+        for (int k = 0; k < 8; ++k) { uint64_t v; memcpy(&v, sg + 8 * k, 8); h = mix64(h, v); }
+        hash[c] = h;
+    }
+    if (missing) { set_error("patch plan: a cell coupling is missing from the CSR pattern"); return TB_ERR_PATTERN; }
+    std::vector<int32_t> order(nc);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+        if (hash[a] != hash[b]) return hash[a] < hash[b];
+        const int r = memcmp(&sig[(size_t)a * 64], &sig[(size_t)b * 64], 64);
+        return r != 0 ? r < 0 : a < b;
+    });
+    std::vector<uint32_t> cell_sig(nc);
+    std::vector<uint8_t> sigtab;
+    int64_t nsig = 0;
+    for (int64_t k = 0; k < nc; ++k) {
+        const int32_t c = order[k];
+        if (k == 0 || memcmp(&sig[(size_t)c * 64], &sig[(size_t)order[k - 1] * 64], 64) != 0) {
+            sigtab.insert(sigtab.end(), &sig[(size_t)c * 64], &sig[(size_t)c * 64] + 64);
+            ++nsig;
+        }
+        cell_sig[c] = (uint32_t)(nsig - 1);
+    }
+    plan->nsig = nsig;
+    std::vector<uint32_t> elem_sig(pp->total_elems);
+#pragma omp parallel for schedule(static)
+    for (int64_t e = 0; e < pp->total_elems; ++e) elem_sig[e] = cell_sig[pp->h_elem_cell[e]];
+    int rc;
+    if ((rc = upload(m->dev, node_ptr, &plan->d_node_ptr))) return rc;
+    if ((rc = upload(m->dev, pnode, &plan->d_pnode))) return rc;
+    if ((rc = upload(m->dev, ln, &plan->d_elem_ln))) return rc;
+    if ((rc = upload(m->dev, elem_sig, &plan->d_elem_sig))) return rc;
+    if ((rc = upload(m->dev, sigtab, &plan->d_sigtab))) return rc;
+    if ((rc = upload(m->dev, row_desc, &plan->d_row_desc))) return rc;
+    p->patch_fused = std::move(plan);
+    return TB_OK;
+}
+
+// Build (or refit) the mesh's patch plan and the pattern's fused extension so that `nregions` blocks of row accumulators, the
+// row descriptors and the node list of any patch fit 80 KiB of LDS — two workgroups per CU.
+int ensure_patch_fused(tb_mesh *m, tb_pattern *p, int nregions)
+{
+    if (!m->patches) { int rc = build_patch_plan(m, 0); if (rc) return rc; }
+    auto need = [&](const PatchFusedPlan *f) { return (int64_t)nregions * f->max_lds_entries * 8 + (int64_t)m->patches->max_rows * 16 + (int64_t)f->max_nodes * 4; };
+    if (p->patch_fused && p->patch_fused->version == m->patches->version && p->patch_fused->d_row_desc && need(p->patch_fused.get()) <= 80 * 1024) return TB_OK;
+    const bool fixed = getenv("TB_PATCH_CELLS") || getenv("TB_PATCH_TILE");
+    for (int attempt = 0; attempt < 16; ++attempt) {
+        free_patch_fused_plan(p);
+        int64_t bytes = 0;
+        int rc = build_patch_fused_plan(p, &bytes, nregions);
+        if (rc == TB_OK) return TB_OK;
+        const bool too_big = rc == TB_ERR_UNSUPPORTED && p->patch_fused; // the builder leaves the size-only plan behind in that case
+        free_patch_fused_plan(p);
+        if (!too_big) return rc;
+        if (fixed) { set_error("patch plan needs %lld B of LDS per patch (> 80 KiB): lower TB_PATCH_TILE / TB_PATCH_CELLS", (long long)bytes); return TB_ERR_UNSUPPORTED; }
+        const int shrink = m->patches->shrink + 1, version = m->patches->version;
+        free_patch_plan(m);
+        rc = build_patch_plan(m, -shrink);
+        if (rc) return rc;
+        m->patches->shrink = shrink;
+        m->patches->version = version + 1;
+    }
+    set_error("patch plan: could not fit the LDS budget");
+    return TB_ERR_UNSUPPORTED;
+}
+
+} // namespace tb
