@@ -108,6 +108,9 @@ struct PatchFusedPlan {
     uint32_t *d_elem_sig = nullptr;
     uint8_t *d_sigtab = nullptr;   // nsig × 64
     RowDesc *d_row_desc = nullptr;
+    // persistent kernel (every patch ≤ 256 instances / rows / nodes): packed patch headers and pre-gathered vertex coordinates
+    uint32_t *d_hdr = nullptr;     // 4 per patch: e0, r0, n0, nrows | nnodes << 10 | ne << 21 (NULL when some count does not fit)
+    double *d_pcoord = nullptr;    // 3 per patch node
 };
 
 } // namespace tb

@@ -414,7 +414,7 @@ void free_patch_fused_plan(tb_pattern *p)
 {
     if (!p->patch_fused) return;
     PatchFusedPlan *f = p->patch_fused.get();
-    hipFree(f->d_node_ptr); hipFree(f->d_pnode); hipFree(f->d_elem_ln); hipFree(f->d_elem_sig); hipFree(f->d_sigtab); hipFree(f->d_row_desc);
+    hipFree(f->d_node_ptr); hipFree(f->d_pnode); hipFree(f->d_elem_ln); hipFree(f->d_elem_sig); hipFree(f->d_sigtab); hipFree(f->d_row_desc); hipFree(f->d_hdr); hipFree(f->d_pcoord);
     p->patch_fused.reset();
 }
 
@@ -491,7 +491,7 @@ static int build_patch_fused_plan(tb_pattern *p, int64_t *lds_need, int nregions
     }
     if (bad) { set_error("fused patch plan: dofs and vertices of the field are not in one-to-one correspondence"); return TB_ERR_UNSUPPORTED; }
     plan->max_nodes = max_nodes;
-    *lds_need = (int64_t)nregions * plan->max_lds_entries * 8 + (int64_t)pp->max_rows * 16 + (int64_t)max_nodes * 4;
+    *lds_need = (int64_t)nregions * plan->max_lds_entries * 8 + (int64_t)pp->max_rows * 16 + (int64_t)max_nodes * 24; // coordinates of the patch's nodes in LDS (persistent kernel)
     if (*lds_need > 80 * 1024) { p->patch_fused = std::move(plan); return TB_ERR_UNSUPPORTED; } // caller shrinks the tile and retries
     // 3. signatures: position of column dof(j) inside row dof(i) for every pair of a cell, de-duplicated
     const int64_t nc = m->n_cells;
@@ -535,6 +535,10 @@ static int build_patch_fused_plan(tb_pattern *p, int64_t *lds_need, int nregions
         cell_sig[c] = (uint32_t)(nsig - 1);
     }
     plan->nsig = nsig;
+    if (getenv("TB_PLAN_VERBOSE"))
+        fprintf(stderr, "[tbhip] fused patch plan: %lld patches, %lld instances (%.3f per cell), max instances/rows/nodes per patch %d/%d/%d, %lld signatures, LDS %lld B for %d block(s)\n",
+                (long long)pp->n_patches, (long long)pp->total_elems, (double)pp->total_elems / (double)std::max<int64_t>(nc, 1), pp->max_elems, pp->max_rows, max_nodes,
+                (long long)nsig, (long long)*lds_need, nregions);
     std::vector<uint32_t> elem_sig(pp->total_elems);
 #pragma omp parallel for schedule(static)
     for (int64_t e = 0; e < pp->total_elems; ++e) elem_sig[e] = cell_sig[pp->h_elem_cell[e]];
@@ -545,6 +549,22 @@ static int build_patch_fused_plan(tb_pattern *p, int64_t *lds_need, int nregions
     if ((rc = upload(m->dev, elem_sig, &plan->d_elem_sig))) return rc;
     if ((rc = upload(m->dev, sigtab, &plan->d_sigtab))) return rc;
     if ((rc = upload(m->dev, row_desc, &plan->d_row_desc))) return rc;
+    if (pp->max_rows < 1024 && max_nodes < 2048 && pp->max_elems < 2048 && pp->total_elems < (int64_t)0x7fffffff && (int64_t)pnode.size() < (int64_t)0x7fffffff) {
+        // inputs of the persistent kernel: packed headers, pre-gathered coordinates
+        std::vector<uint32_t> hdr((size_t)pp->n_patches * 4);
+        for (int64_t q = 0; q < pp->n_patches; ++q) {
+            hdr[4 * q] = (uint32_t)pp->h_elem_ptr[q]; hdr[4 * q + 1] = (uint32_t)pp->h_row_ptr[q]; hdr[4 * q + 2] = (uint32_t)node_ptr[q];
+            const uint32_t ne = (uint32_t)(pp->h_elem_ptr[q + 1] - pp->h_elem_ptr[q]), nr = (uint32_t)(pp->h_row_ptr[q + 1] - pp->h_row_ptr[q]),
+                           nn = (uint32_t)(node_ptr[q + 1] - node_ptr[q]);
+            hdr[4 * q + 3] = nr | nn << 10 | ne << 21;
+        }
+        std::vector<double> pcoord(pnode.size() * 3);
+#pragma omp parallel for schedule(static)
+        for (int64_t k = 0; k < (int64_t)pnode.size(); ++k)
+            for (int d = 0; d < 3; ++d) pcoord[3 * k + d] = m->h_xyz[3 * (int64_t)pnode[k] + d];
+        if ((rc = upload(m->dev, hdr, &plan->d_hdr))) return rc;
+        if ((rc = upload(m->dev, pcoord, &plan->d_pcoord))) return rc;
+    }
     p->patch_fused = std::move(plan);
     return TB_OK;
 }
@@ -554,7 +574,7 @@ static int build_patch_fused_plan(tb_pattern *p, int64_t *lds_need, int nregions
 int ensure_patch_fused(tb_mesh *m, tb_pattern *p, int nregions)
 {
     if (!m->patches) { int rc = build_patch_plan(m, 0); if (rc) return rc; }
-    auto need = [&](const PatchFusedPlan *f) { return (int64_t)nregions * f->max_lds_entries * 8 + (int64_t)m->patches->max_rows * 16 + (int64_t)f->max_nodes * 4; };
+    auto need = [&](const PatchFusedPlan *f) { return (int64_t)nregions * f->max_lds_entries * 8 + (int64_t)m->patches->max_rows * 16 + (int64_t)f->max_nodes * 24; };
     if (p->patch_fused && p->patch_fused->version == m->patches->version && p->patch_fused->d_row_desc && need(p->patch_fused.get()) <= 80 * 1024) return TB_OK;
     const bool fixed = getenv("TB_PATCH_CELLS") || getenv("TB_PATCH_TILE");
     for (int attempt = 0; attempt < 16; ++attempt) {
