@@ -141,6 +141,10 @@ int tb_device_create(int hip_device_id, tb_device **out);
 int tb_device_destroy(tb_device *dev);
 /* adopt an external hipStream_t (e.g. the host framework's current stream); NULL → library-owned stream */
 int tb_device_set_stream(tb_device *dev, void *hip_stream);
+/* run on the legacy default (null) stream — the stream a host framework uses when it has not created one (torch.cuda.current_stream() of a
+ * fresh process): kernels are then ordered with that framework's own work and collectives without events.  tb_device_set_stream(dev, NULL)
+ * means "give the device its own non-blocking stream back". */
+int tb_device_use_null_stream(tb_device *dev);
 int tb_device_synchronize(tb_device *dev);
 int tb_device_info(tb_device *dev, char *name, size_t name_len, int *n_cu, size_t *hbm_bytes);
 
@@ -397,6 +401,17 @@ int tb_axpy(tb_device *dev, int64_t n, double a, const double *d_x, double *d_y)
 int tb_absmax(tb_device *dev, int64_t n, const double *d_x, int64_t stride, double *result);
 /* x·y (norms of residuals / increments in the Newton loop, src/solver/nonlinear/newton_raphson.jl:246-290) */
 int tb_dot(tb_device *dev, int64_t n, const double *d_x, const double *d_y, double *result);
+/* Building blocks of a Jacobi-CG on sub-domain (interface-unassembled) matrices spread over several devices — new work, the reference is
+ * shared-memory only (README.md:7); its single-device counterpart is the CG of the heat stage (src/solver/time/euler.jl:94-100).  d_w weights a
+ * dof held by k ranks with 1/k (NULL: 1); every scalar lives in caller-owned device memory, so the caller sums them over the ranks (RCCL
+ * all-reduce) and no kernel waits for the host:
+ *   tb_cgd_dot        *d_out      += Σ w·a·b
+ *   tb_cgd_update     α = *d_rz / *d_pAp;  x += α p;  r −= α Ap;  d_out2[0] += Σ w·r·(D⁻¹r);  d_out2[1] += Σ w·r·r
+ *   tb_cgd_direction  β = *d_rz_new / *d_rz;  p = D⁻¹ r + β p                                   (d_dinv NULL: no preconditioner) */
+int tb_cgd_dot(tb_device *dev, int64_t n, const double *d_w, const double *d_a, const double *d_b, double *d_out);
+int tb_cgd_update(tb_device *dev, int64_t n, const double *d_w, const double *d_dinv, const double *d_p, const double *d_Ap, double *d_x, double *d_r,
+                  const double *d_rz, const double *d_pAp, double *d_out2);
+int tb_cgd_direction(tb_device *dev, int64_t n, const double *d_dinv, const double *d_r, double *d_p, const double *d_rz, const double *d_rz_new);
 /* apply_zero!(K, f, ch) on the device CSR matrix (Ferrite.apply_zero!; CSR method src/utils.jl:263-278; used by
  * eliminate_constraints_from_linearization! / _residual! / _increment!, src/solver/nonlinear/nlsolve_common.jl:12-26):
  * d_prescribed is one byte per dof (1 = Dirichlet dof).  Rows and columns of prescribed dofs are zeroed, their diagonal

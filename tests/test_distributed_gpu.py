@@ -1,0 +1,160 @@
+"""N>1 path with device-assembled operators: two ranks, both on cuda:0, `gloo` backend with halo buffers staged through the host (the box has
+one GPU; RCCL needs one device per rank).  Every rank assembles b, M and K of its z-slab with the HIP kernels (the fused M + K pass and the
+vector scatter bench.py runs), and the partition / interface bookkeeping / exchange / distributed Jacobi-CG under test are the shipped ones
+(thunderbolt.jl_amd/distributed.py, device path: tb_spmv_csr + tb_cgd_* with device-resident scalars).  The reference is shared-memory only
+(README.md:7): correctness is "P-rank result == 1-rank result" (SURVEY §8e), here against the 1-rank HIP result."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NEL = (12, 10, 16)
+LEFT, RIGHT = (0.0, 0.0, 0.0), (1.0, 1.0, 2.0)
+KAPPA = np.diag([4.5e-2, 2.0e-2, 2.0e-2])
+DT = 0.5
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _warp(xyz):
+    """smooth distortion of the global lattice as a function of position only, so slabs and the whole box see the same non-affine cells"""
+    x, y, z = xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy()
+    s = 0.012 * np.sin(2 * np.pi * x) * np.sin(2 * np.pi * y) * np.sin(np.pi * z)
+    xyz[:, 0] += s
+    xyz[:, 1] -= 0.7 * s
+    xyz[:, 2] += 0.5 * s
+    return xyz
+
+
+def _field(X):
+    return np.cos(2 * X[:, 0]) * (1 + X[:, 2]) + X[:, 1] ** 2
+
+
+def _assemble(tb, dev, g):
+    import torch
+    dh = tb.DofHandler(g)
+    sp = tb.allocate_matrix(dh)
+    st = tb.PatchAssemblyStrategy(dev)
+    M = tb.setup_operator(st, tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.0)), dh, sp)
+    K = tb.setup_operator(st, tb.BilinearDiffusionIntegrator(tb.ConstantCoefficient(KAPPA)), dh, sp)
+    tb.update_operators(M, K, 0.0)
+    src = tb.setup_operator(tb.AtomicAssemblyStrategy(dev), tb.LinearIntegrator(tb.AnalyticalCoefficient("cos_exp")), dh)
+    b = torch.zeros(dh.ndofs, dtype=torch.float64, device="cuda")
+    src.b = tb.DeviceVector.wrap(dev, b)
+    tb.update_operator(src, 0.1)
+    A = tb.heat_system_matrix(dev, M, K, DT)
+    return dh, sp, M, K, A, b
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import thunderbolt_jl_amd as tb
+    D = tb.distributed
+    torch.cuda.set_device(0)
+    dev = tb.MI355XDevice(0)
+    dev.set_stream(torch.cuda.current_stream().cuda_stream)
+    part = D.SlabPartition(NEL, LEFT, RIGHT, world, rank)
+    g = tb.generate_mesh(tb.Hexahedron, part.local_nel(), part.left, part.right)
+    _warp(g.xyz)
+    dh, sp, M, K, A, b = _assemble(tb, dev, g)
+    n2d = D.node_to_dof(dh)
+    lo, up = part.interface_nodes()
+    lo_idx = None if lo is None else torch.from_numpy(n2d[lo]).cuda()
+    up_idx = None if up is None else torch.from_numpy(n2d[up]).cuda()
+    torch.cuda.synchronize()
+    D.halo_sum(b, lo_idx, up_idx, rank, world, dist)
+    # operator action with the sub-domain matrix: device SpMV + exchange
+    xl = np.empty(dh.ndofs)
+    xl[n2d] = _field(g.xyz)
+    x = torch.from_numpy(xl).cuda()
+    y = torch.zeros_like(x)
+    K.mul(tb.DeviceVector.wrap(dev, y), tb.DeviceVector.wrap(dev, x))
+    D.halo_sum(y, lo_idx, up_idx, rank, world, dist)
+    # backward-Euler heat step (M − Δt K) u = M u₀ by the distributed device CG
+    Ah = A.to_host()
+    diag = np.array([Ah[sp.rowptr[r] + np.searchsorted(sp.colidx[sp.rowptr[r]:sp.rowptr[r + 1]], r)] for r in range(dh.ndofs)])
+
+    def spmv(v):
+        out = torch.zeros_like(v)
+        tb._lib.check(tb.lib().tb_spmv_csr(K.pattern.h, A.ptr, v.data_ptr(), 1.0, 0.0, out.data_ptr()))
+        return out
+
+    rhs = torch.zeros_like(x)
+    M.mul(tb.DeviceVector.wrap(dev, rhs), tb.DeviceVector.wrap(dev, x))
+    D.halo_sum(rhs, lo_idx, up_idx, rank, world, dist)
+    cg = D.DistributedCG(spmv, torch.from_numpy(diag).cuda(), lo_idx, up_idx, rank, world, dist, device=dev, look=4)
+    u, its, rn = cg.solve(rhs, x.clone(), rtol=1e-13, atol=1e-15, maxiter=400)
+    torch.cuda.synchronize()
+    plane = (NEL[0] + 1) * (NEL[1] + 1)
+    gnode = np.arange(g.n_nodes) + part.z0 * plane
+    q.put((rank, gnode, b.cpu().numpy()[n2d], y.cpu().numpy()[n2d], u.cpu().numpy()[n2d], its))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_hip_assembly_halo_and_cg_equal_single_rank(tb, device):
+    import torch
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # single-rank HIP reference on the whole box
+    g = tb.generate_mesh(tb.Hexahedron, NEL, LEFT, RIGHT)
+    _warp(g.xyz)
+    dh, sp, M, K, A, b = _assemble(tb, device, g)
+    n2d = tb.distributed.node_to_dof(dh)
+    bref = b.cpu().numpy()[n2d]
+    xl = np.empty(dh.ndofs)
+    xl[n2d] = _field(g.xyz)
+    x = device.to_device(xl)
+    y = device.zeros(dh.ndofs)
+    K.mul(y, x)
+    yref = y.to_host()[n2d]
+    rhs = device.zeros(dh.ndofs)
+    M.mul(rhs, x)
+    u = device.to_device(xl)
+    its, _ = tb.cg_solve(K.pattern, A, rhs, u, rtol=1e-13, atol=1e-15, maxiter=400)
+    uref = u.to_host()[n2d]
+    seen = np.zeros(g.n_nodes, dtype=int)
+    for rank, gnode, bb, yy, uu, it in res:
+        np.testing.assert_allclose(bb, bref[gnode], rtol=1e-12, atol=1e-12 * np.abs(bref).max())
+        np.testing.assert_allclose(yy, yref[gnode], rtol=0, atol=1e-12 * np.abs(yref).max())
+        np.testing.assert_allclose(uu, uref[gnode], rtol=0, atol=1e-9 * np.abs(uref).max())
+        assert 0 < it <= 400
+        seen[gnode] += 1
+    plane = (NEL[0] + 1) * (NEL[1] + 1)
+    assert seen.min() == 1 and (seen == 2).sum() == plane
+
+
+def test_bench_refuses_wrong_job_size():
+    """`python bench.py --gpus 2` on a one-GPU box must fail loudly instead of printing an n_gpus: 1 line."""
+    import subprocess
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than 2 GPUs")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "n_gpus" not in r.stdout

@@ -200,3 +200,18 @@ def test_eisenstat_walker_forcing_law(tb):
     f = tb.EisenstatWalkerForcing(safeguard=False)
     f.prestep(1.0, 0)
     assert f.prestep(0.1, 1) == pytest.approx(0.009)
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    """bench.py under a launcher whose WORLD_SIZE differs from --gpus must exit non-zero without printing a result line (the
+    argument used to be ignored and a driver scaling run would have recorded n_gpus: 1 eight times)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode != 0 and "n_gpus" not in r.stdout and "WORLD_SIZE" in r.stderr
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode != 0 and "n_gpus" not in r.stdout           # more ranks than visible GPUs: refused before anything is launched

@@ -57,6 +57,7 @@ SIGNATURES = {
     "tb_device_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
     "tb_device_destroy": (C.c_int, [vp]),
     "tb_device_set_stream": (C.c_int, [vp, vp]),
+    "tb_device_use_null_stream": (C.c_int, [vp]),
     "tb_device_synchronize": (C.c_int, [vp]),
     "tb_device_info": (C.c_int, [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
     "tb_malloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
@@ -131,6 +132,9 @@ SIGNATURES = {
     "tb_axpy": (C.c_int, [vp, C.c_int64, C.c_double, vp, vp]),
     "tb_absmax": (C.c_int, [vp, C.c_int64, vp, C.c_int64, C.POINTER(C.c_double)]),
     "tb_dot": (C.c_int, [vp, C.c_int64, vp, vp, C.POINTER(C.c_double)]),
+    "tb_cgd_dot": (C.c_int, [vp, C.c_int64, vp, vp, vp, vp]),
+    "tb_cgd_update": (C.c_int, [vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "tb_cgd_direction": (C.c_int, [vp, C.c_int64, vp, vp, vp, vp, vp]),
     "tb_apply_zero_csr": (C.c_int, [vp, vp, vp, vp, C.c_double]),
     "tb_meandiag": (C.c_int, [vp, vp, C.POINTER(C.c_double)]),
     "tb_max": (C.c_int, [vp, C.c_int64, vp, C.c_int64, C.POINTER(C.c_double)]),

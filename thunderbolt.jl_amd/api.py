@@ -51,7 +51,14 @@ class MI355XDevice:
         self.device_id = device_id
 
     def set_stream(self, hip_stream):
-        check(lib().tb_device_set_stream(self.h, C.c_void_p(hip_stream) if hip_stream else None))
+        """hip_stream: a hipStream_t handle (int); 0 = the legacy default stream (what torch.cuda.current_stream().cuda_stream is in a
+        fresh process: the device's kernels are then ordered with torch's own work and its collectives); None = a private non-blocking stream."""
+        if hip_stream is None:
+            check(lib().tb_device_set_stream(self.h, None))
+        elif int(hip_stream) == 0:
+            check(lib().tb_device_use_null_stream(self.h))
+        else:
+            check(lib().tb_device_set_stream(self.h, C.c_void_p(int(hip_stream))))
 
     def synchronize(self):
         check(lib().tb_device_synchronize(self.h))

@@ -899,6 +899,68 @@ int launch_meandiag(tb_pattern *pat, const double *nz, double *result)
     return TB_OK;
 }
 
+// ---- sub-structured CG over several devices: weighted sums (a dof held by k ranks counts 1/k), every scalar in caller-owned device memory ----
+__global__ void __launch_bounds__(256)
+k_cgd_dot(int64_t n, const double *__restrict__ w, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ out)
+{
+    double s = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) s += (w ? w[i] : 1.0) * a[i] * b[i];
+    block_sum_to(s, out);
+}
+
+// α = rz / pAp (device scalars, already summed over the ranks); x += α p, r −= α Ap; out[0] += Σ w r·(D⁻¹r), out[1] += Σ w r·r
+__global__ void __launch_bounds__(256)
+k_cgd_update(int64_t n, const double *__restrict__ w, const double *__restrict__ dinv, const double *__restrict__ p, const double *__restrict__ Ap,
+             double *__restrict__ x, double *__restrict__ r, const double *__restrict__ rz, const double *__restrict__ pAp, double *__restrict__ out)
+{
+    const double pap = *pAp;
+    const double alpha = pap > 0.0 ? *rz / pap : 0.0;
+    double a = 0.0, c = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        x[i] += alpha * p[i];
+        const double ri = r[i] - alpha * Ap[i];
+        r[i] = ri;
+        const double wi = w ? w[i] : 1.0;
+        a += wi * ri * (dinv ? dinv[i] * ri : ri);
+        c += wi * ri * ri;
+    }
+    block_sum_to(a, out);
+    __syncthreads();
+    block_sum_to(c, out + 1);
+}
+
+// β = rz_new / rz (device scalars); p = D⁻¹ r + β p
+__global__ void __launch_bounds__(256)
+k_cgd_direction(int64_t n, const double *__restrict__ dinv, const double *__restrict__ r, double *__restrict__ p, const double *__restrict__ rz,
+                const double *__restrict__ rz_new)
+{
+    const double beta = *rz > 0.0 ? *rz_new / *rz : 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = (dinv ? dinv[i] * r[i] : r[i]) + beta * p[i];
+}
+
+int launch_cgd_dot(tb_device *dev, int64_t n, const double *w, const double *a, const double *b, double *d_out)
+{
+    if (n > 0) hipLaunchKernelGGL(k_cgd_dot, dim3(grid_for(dev, n, 256)), dim3(256), 0, dev->stream, n, w, a, b, d_out);
+    TB_HIP(hipGetLastError());
+    return TB_OK;
+}
+int launch_cgd_update(tb_device *dev, int64_t n, const double *w, const double *dinv, const double *p, const double *Ap, double *x, double *r,
+                      const double *d_rz, const double *d_pAp, double *d_out2)
+{
+    if (n > 0) hipLaunchKernelGGL(k_cgd_update, dim3(grid_for(dev, n, 256)), dim3(256), 0, dev->stream, n, w, dinv, p, Ap, x, r, d_rz, d_pAp, d_out2);
+    TB_HIP(hipGetLastError());
+    return TB_OK;
+}
+int launch_cgd_direction(tb_device *dev, int64_t n, const double *dinv, const double *r, double *p, const double *d_rz, const double *d_rz_new)
+{
+    if (n > 0) hipLaunchKernelGGL(k_cgd_direction, dim3(grid_for(dev, n, 256)), dim3(256), 0, dev->stream, n, dinv, r, p, d_rz, d_rz_new);
+    TB_HIP(hipGetLastError());
+    return TB_OK;
+}
+
 int launch_dot(tb_device *dev, int64_t n, const double *a, const double *b, double *result)
 {
     double *scal = (double *)&dev->d_status->cell; // 8-byte scratch inside the status block

@@ -107,6 +107,16 @@ int tb_device_set_stream(tb_device *dev, void *hip_stream)
     return TB_OK;
 }
 
+int tb_device_use_null_stream(tb_device *dev)
+{
+    TB_REQUIRE(dev, "tb_device_use_null_stream: dev is NULL");
+    TB_HIP(hipStreamSynchronize(dev->stream));
+    if (dev->own_stream && dev->stream) TB_HIP(hipStreamDestroy(dev->stream));
+    dev->stream = nullptr; // the legacy default stream: ordered with every blocking stream of the process (a host framework's default stream is this one)
+    dev->own_stream = false;
+    return TB_OK;
+}
+
 int tb_device_synchronize(tb_device *dev)
 {
     TB_REQUIRE(dev, "tb_device_synchronize: dev is NULL");
@@ -991,6 +1001,28 @@ int tb_dot(tb_device *dev, int64_t n, const double *d_x, const double *d_y, doub
 {
     TB_REQUIRE(dev && result && n >= 0 && ((d_x && d_y) || n == 0), "tb_dot: bad argument");
     return launch_dot(dev, n, d_x, d_y, result);
+}
+
+int tb_cgd_dot(tb_device *dev, int64_t n, const double *d_w, const double *d_a, const double *d_b, double *d_out)
+{
+    TB_REQUIRE(dev && d_out && n >= 0 && ((d_a && d_b) || n == 0), "tb_cgd_dot: bad argument");
+    TB_HIP(hipSetDevice(dev->id));
+    return launch_cgd_dot(dev, n, d_w, d_a, d_b, d_out);
+}
+
+int tb_cgd_update(tb_device *dev, int64_t n, const double *d_w, const double *d_dinv, const double *d_p, const double *d_Ap, double *d_x, double *d_r,
+                  const double *d_rz, const double *d_pAp, double *d_out2)
+{
+    TB_REQUIRE(dev && d_rz && d_pAp && d_out2 && n >= 0 && ((d_p && d_Ap && d_x && d_r) || n == 0), "tb_cgd_update: bad argument");
+    TB_HIP(hipSetDevice(dev->id));
+    return launch_cgd_update(dev, n, d_w, d_dinv, d_p, d_Ap, d_x, d_r, d_rz, d_pAp, d_out2);
+}
+
+int tb_cgd_direction(tb_device *dev, int64_t n, const double *d_dinv, const double *d_r, double *d_p, const double *d_rz, const double *d_rz_new)
+{
+    TB_REQUIRE(dev && d_rz && d_rz_new && n >= 0 && ((d_r && d_p) || n == 0), "tb_cgd_direction: bad argument");
+    TB_HIP(hipSetDevice(dev->id));
+    return launch_cgd_direction(dev, n, d_dinv, d_r, d_p, d_rz, d_rz_new);
 }
 
 int tb_apply_zero_csr(tb_pattern *pat, double *d_nzval, double *d_f, const uint8_t *d_prescribed, double diag)

@@ -269,6 +269,10 @@ int ensure_blockpos(tb_pattern *p);
 int launch_apply_zero(tb_pattern *pat, double *nz, double *f, const uint8_t *flags, double diag);
 int launch_meandiag(tb_pattern *pat, const double *nz, double *result);
 int launch_dot(tb_device *dev, int64_t n, const double *a, const double *b, double *result);
+int launch_cgd_dot(tb_device *dev, int64_t n, const double *w, const double *a, const double *b, double *d_out);
+int launch_cgd_update(tb_device *dev, int64_t n, const double *w, const double *dinv, const double *p, const double *Ap, double *x, double *r,
+                      const double *d_rz, const double *d_pAp, double *d_out2);
+int launch_cgd_direction(tb_device *dev, int64_t n, const double *dinv, const double *r, double *p, const double *d_rz, const double *d_rz_new);
 int launch_max(tb_device *dev, int64_t n, const double *x, int64_t stride, double *result);
 double decode_ordered_key(unsigned long long k);
 

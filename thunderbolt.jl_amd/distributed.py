@@ -93,15 +93,24 @@ class GeneralPartition:
         return m
 
 
+def _host_staged(vec, dist):
+    """gloo moves host buffers only: device tensors are staged through the host (the CPU-backend test configuration; RCCL sends device
+    buffers directly)."""
+    return vec.is_cuda and dist.get_backend() == "gloo"
+
+
 def exchange_sum(vec, neighbours, dist):
     """Sum the entries of `vec` (torch tensor, any device) shared with each neighbour, in place: every rank sends its
     own *partial* values of the shared dofs to each sharing peer and adds what it receives, so a dof held by k ranks
     ends up with the sum of all k partials on each of them.  neighbours = [(peer, index tensor)]."""
     import torch
 
+    staged = _host_staged(vec, dist)
     ops, bufs = [], []
     for peer, idx in neighbours:
         send = vec[idx].contiguous()                                # partials, taken before anything is added
+        if staged:
+            send = send.cpu()
         recv = torch.empty_like(send)
         ops.append(dist.P2POp(dist.isend, send, peer))
         ops.append(dist.P2POp(dist.irecv, recv, peer))
@@ -110,8 +119,19 @@ def exchange_sum(vec, neighbours, dist):
         for r in dist.batch_isend_irecv(ops):
             r.wait()
     for idx, recv, _ in bufs:
-        vec[idx] += recv
+        vec[idx] += recv.to(vec.device) if staged else recv
     return vec
+
+
+def all_reduce_sum(t, dist):
+    """Sum a (small) tensor over the ranks in place; device tensors go through the host under gloo."""
+    if _host_staged(t, dist):
+        h = t.cpu()
+        dist.all_reduce(h)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t)
+    return t
 
 
 def node_to_dof(dh):
@@ -134,16 +154,22 @@ def halo_sum(vec, lower_idx, upper_idx, rank, world_size, dist):
 class DistributedCG:
     """Jacobi-preconditioned CG on sub-domain (interface-unassembled) matrices A = Σ_p R_pᵀ A_p R_p.
 
-    Vectors are torch tensors holding every dof of the slab (owned + interface); solution-type vectors are kept
-    *consistent* (both neighbours hold the same interface value), operator results are summed over the interface
-    with `halo_sum`.  Dot products weight interface dofs by 1/multiplicity and are all-reduced (one scalar
-    all-reduce — RCCL on GPU).  `local_spmv(x) -> y` applies the rank's own A_p (tb_spmv_csr on device; any callable
-    in tests).  New work: the reference has no distributed solver (README.md:7)."""
+    Vectors are torch tensors holding every dof of the part (owned + interface); solution-type vectors are kept
+    *consistent* (all sharing ranks hold the same interface value), operator results are summed over the interface
+    with `exchange_sum`.  Dot products weight interface dofs by 1/multiplicity and are all-reduced.
+    `local_spmv(x) -> y` applies the rank's own A_p.  New work: the reference has no distributed solver (README.md:7).
 
-    def __init__(self, local_spmv, local_diag, lower_idx, upper_idx, rank, world_size, dist, neighbours=None):
+    Two execution paths with the same arithmetic:
+      * device=<MI355XDevice>, device tensors: the vector work runs in libtbhip (tb_cgd_dot / tb_cgd_update / tb_cgd_direction, local SpMV by
+        tb_spmv_csr through `local_spmv`), α and β are formed on the device from all-reduced device scalars, and the host reads one number
+        (‖r‖²) per look — every `look` iterations — like tb_cg_solve on one device;
+      * device=None: plain torch ops on whatever device the tensors live on (CPU in the gloo tests, where the oracle assembles)."""
+
+    def __init__(self, local_spmv, local_diag, lower_idx, upper_idx, rank, world_size, dist, neighbours=None, device=None, look=1):
         import torch
         self.torch, self.dist = torch, dist
         self.spmv, self.rank, self.world = local_spmv, rank, world_size
+        self.dev, self.look = device, max(1, int(look))
         # slab partitions pass (lower, upper); general partitions pass neighbours = [(peer, index tensor)]
         self.nb = neighbours if neighbours is not None else [
             (peer, idx) for idx, peer in ((lower_idx, rank - 1), (upper_idx, rank + 1)) if idx is not None and 0 <= peer < world_size]
@@ -158,7 +184,7 @@ class DistributedCG:
     def dot(self, a, b):
         s = (self.w * a * b).sum().reshape(1)
         if self.world > 1:
-            self.dist.all_reduce(s)
+            all_reduce_sum(s, self.dist)
         return float(s.item())
 
     def apply(self, x):
@@ -168,6 +194,8 @@ class DistributedCG:
 
     def solve(self, b, x, rtol=1e-5, atol=1e-6, maxiter=1000):
         """b: ASSEMBLED right-hand side (consistent), x: initial guess (consistent); returns (x, iterations, ‖r‖)."""
+        if self.dev is not None and x.is_cuda:
+            return self._solve_device(b, x, rtol, atol, maxiter)
         r = b - self.apply(x)
         z = self.dinv * r
         p = z.clone()
@@ -186,4 +214,36 @@ class DistributedCG:
             p = z + (rz_new / rz) * p
             rz = rz_new
             it += 1
+        return x, it, rn
+
+    def _solve_device(self, b, x, rtol, atol, maxiter):
+        import ctypes as C
+        from ._lib import check, lib
+        torch, dist, dev, n = self.torch, self.dist, self.dev, x.numel()
+        L = lib()
+        ptr = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        S = torch.zeros(4, dtype=torch.float64, device=x.device)    # rz | pAp | rz_new, rr  (device-resident scalars)
+        r = b - self.apply(x)
+        p = self.dinv * r
+        check(L.tb_cgd_dot(dev.h, n, ptr(self.w), ptr(r), ptr(p), ptr(S[0:1])))
+        check(L.tb_cgd_dot(dev.h, n, ptr(self.w), ptr(r), ptr(r), ptr(S[3:4])))
+        if self.world > 1:
+            all_reduce_sum(S, dist)
+        rn = float(S[3].item()) ** 0.5
+        tol = atol + rtol * rn
+        it = 0
+        while rn > tol and it < maxiter:
+            for _ in range(min(self.look, maxiter - it)):
+                Ap = self.apply(p)                                   # local SpMV (tb_spmv_csr) + neighbour exchange
+                S[1:].zero_()
+                check(L.tb_cgd_dot(dev.h, n, ptr(self.w), ptr(p), ptr(Ap), ptr(S[1:2])))
+                if self.world > 1:
+                    all_reduce_sum(S[1:2], dist)
+                check(L.tb_cgd_update(dev.h, n, ptr(self.w), ptr(self.dinv), ptr(p), ptr(Ap), ptr(x), ptr(r), ptr(S[0:1]), ptr(S[1:2]), ptr(S[2:4])))
+                if self.world > 1:
+                    all_reduce_sum(S[2:4], dist)
+                check(L.tb_cgd_direction(dev.h, n, ptr(self.dinv), ptr(r), ptr(p), ptr(S[0:1]), ptr(S[2:3])))
+                S[0:1].copy_(S[2:3])
+                it += 1
+            rn = float(S[3].item()) ** 0.5                           # the one host read of the look
         return x, it, rn
