@@ -371,9 +371,14 @@ int tb_spmv_csr(tb_pattern *pat, const double *d_nzval, const double *d_x, doubl
 /* Jacobi-preconditioned CG for the heat step A uₙ = b, A = M − Δt·K SPD (src/solver/time/euler.jl:94-100; the tutorials
  * configure KrylovJL_CG(atol = 1e-6, rtol = 1e-5)).  d_x holds the initial guess (uₙ₋₁) and the solution.
  * Stops when ‖r‖₂ ≤ atol + rtol·‖r₀‖₂ or after maxiter iterations; reports iterations and the final ‖r‖₂.
- * jacobi: 0 = no preconditioner, 1 = Jacobi (D⁻¹ read from d_Anz), TB_JACOBI_REUSE = Jacobi with the D⁻¹ of the previous solve on this pattern
- * (the time loop solves with one matrix step after step; a stale diagonal is still a valid SPD preconditioner, only a slower one). */
+ * jacobi: 0 = no preconditioner, 1 = Jacobi (D⁻¹ read from d_Anz), TB_JACOBI_REUSE = Jacobi with the D⁻¹ extracted at the previous Jacobi solve
+ * with this same d_Anz array, the caller vouching that its values are unchanged (the time loop solves with one matrix step after step); if another
+ * array was solved with on this pattern in between, D⁻¹ is extracted again. */
 enum { TB_JACOBI_REUSE = 2 };
+/* the stopping threshold atol + rtol·‖r₀‖₂ of the latest tb_cg_solve / tb_cg_solve_from_residual / tb_pcg_solve / tb_gmres_solve on this pattern:
+ * a solve has converged iff its reported resnorm ≤ this value (the reference fails a step whose linear solve ran into MaxIters,
+ * src/solver/nonlinear/newton_raphson.jl: `solve_succeeded || return false`) */
+int tb_solver_last_tolerance(const tb_pattern *pat, double *tol);
 int tb_cg_solve(tb_pattern *pat, const double *d_Anz, const double *d_b, double *d_x, double rtol, double atol, int maxiter,
                 int jacobi, int *iters, double *resnorm);
 /* The same solve started from a known initial residual: d_r0 = b − A·x₀ supplied by the caller, so neither b nor the product A·x₀ is

@@ -1,30 +1,36 @@
 #!/bin/bash
-# Run on the GPU box (gpurun -- 'bash scripts/collect_profiles.sh <tag>'): rocprofv3 evidence for profiles/<tag>/.
-# Kernel-trace and each PMC group are separate passes (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950).
-tag=${1:-r01_v4}
+# Run on the GPU box (gpurun -- 'bash scripts/collect_profiles.sh <tag>'): rocprofv3 evidence for profiles/<tag>/ and profiles/traffic.json.
+# Kernel trace and every PMC group are separate passes (no PMC together with tracing domains; TCC read- and write-side counters do not fit one pass).
+tag=${1:-r02_v1}
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 out=gpurun_out/$tag
 mkdir -p "$out"
+# micro-benchmarks are built here (binaries are not tracked)
+for mb in mfma_f64 lds_atomic wg_launch; do
+  [ -f scripts/microbench/$mb.hip ] && hipcc --offload-arch=gfx950 -O3 scripts/microbench/$mb.hip -o scripts/microbench/$mb.bin 2>/dev/null
+done
 python3 bench.py > "$out/bench_216.json" 2> "$out/bench_216.err"
 rocprofv3 --kernel-trace --stats -d "$out/kt" -o kt -- python3 bench.py --no-cpu-baseline > "$out/bench_under_rocprof.json" 2>/dev/null
 python3 scripts/rocpd_summary.py "$out/kt/kt_results.db" --json "$out/kernel_stats.json" > "$out/kernel_stats.txt"
 i=0
-for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT"; do
+for grp in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum" "WRITE_SIZE" "FETCH_SIZE" \
+           "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp -d "$out/pmc$i" -o pmc -- python3 bench.py --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --pmc $grp -d "$out/pmc$i" -o pmc -- python3 bench.py --no-cpu-baseline --steps 5 > /dev/null 2>&1
   python3 scripts/rocpd_summary.py "$out/pmc$i/pmc_results.db" --json "$out/pmc$i.json" > /dev/null
 done
-# mechanics (BASELINE config 4)
-python3 scripts/bench_mechanics.py --n 80 > "$out/mechanics_80_q2.json" 2>/dev/null
-rocprofv3 --kernel-trace --stats -d "$out/ktm" -o ktm -- python3 scripts/bench_mechanics.py --n 80 --cpu-n 2 > /dev/null 2>&1
-python3 scripts/rocpd_summary.py "$out/ktm/ktm_results.db" --json "$out/mechanics_kernel_stats.json" > "$out/mechanics_kernel_stats.txt"
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT -d "$out/pmcm" -o pmcm -- python3 scripts/bench_mechanics.py --n 40 --cpu-n 2 > /dev/null 2>&1
-python3 scripts/rocpd_summary.py "$out/pmcm/pmcm_results.db" --json "$out/mechanics_pmc_40.json" > /dev/null
-# monodomain simulation (config 3 as a time loop): the stream SpMV + CG kernels next to the reaction step
-rocprofv3 --kernel-trace --stats -d "$out/kte" -o kte -- python3 examples/monodomain_fhn.py --ionic tt06 --n 216 > "$out/monodomain_tt06_216.json" 2>/dev/null
-python3 scripts/rocpd_summary.py "$out/kte/kte_results.db" --json "$out/monodomain_kernel_stats.json" > "$out/monodomain_kernel_stats.txt"
-rm -rf "$out"/kte
-rm -rf "$out"/kt "$out"/pmc1 "$out"/pmc2 "$out"/pmc3 "$out"/ktm "$out"/pmcm
-./scripts/microbench/mfma_f64.bin > "$out/mfma_f64_microbench.txt" 2>&1
-tail -c 600 "$out/bench_216.json"; cat "$out/mechanics_80_q2.json" | cut -c1-300; head -5 "$out/kernel_stats.txt"
+python3 scripts/make_traffic_json.py "$out" "$tag" > "$out/traffic.json"
+if [ "$2" != "bench-only" ]; then
+  # mechanics (BASELINE config 4)
+  python3 scripts/bench_mechanics.py --n 80 > "$out/mechanics_80_q2.json" 2>/dev/null
+  rocprofv3 --kernel-trace --stats -d "$out/ktm" -o ktm -- python3 scripts/bench_mechanics.py --n 80 --cpu-n 2 > /dev/null 2>&1
+  python3 scripts/rocpd_summary.py "$out/ktm/ktm_results.db" --json "$out/mechanics_kernel_stats.json" > "$out/mechanics_kernel_stats.txt"
+  # monodomain simulation (config 3 as a time loop)
+  rocprofv3 --kernel-trace --stats -d "$out/kte" -o kte -- python3 examples/monodomain_fhn.py --ionic tt06 --n 216 > "$out/monodomain_tt06_216.json" 2>/dev/null
+  python3 scripts/rocpd_summary.py "$out/kte/kte_results.db" --json "$out/monodomain_kernel_stats.json" > "$out/monodomain_kernel_stats.txt"
+  [ -x scripts/microbench/mfma_f64.bin ] && ./scripts/microbench/mfma_f64.bin > "$out/mfma_f64_microbench.txt" 2>&1
+  [ -x scripts/microbench/wg_launch.bin ] && ./scripts/microbench/wg_launch.bin > "$out/wg_launch_microbench.txt" 2>&1
+fi
+rm -rf "$out"/kt "$out"/pmc1 "$out"/pmc2 "$out"/pmc3 "$out"/pmc4 "$out"/ktm "$out"/kte
+tail -c 700 "$out/bench_216.json"; head -6 "$out/kernel_stats.txt"; cat "$out/traffic.json" | head -30

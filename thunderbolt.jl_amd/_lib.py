@@ -129,6 +129,7 @@ SIGNATURES = {
     "tb_pcg_solve": (C.c_int, [vp, vp, vp, vp, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "tb_l1gs_apply": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
     "tb_gmres_solve": (C.c_int, [vp, vp, vp, vp, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "tb_solver_last_tolerance": (C.c_int, [vp, C.POINTER(C.c_double)]),
     "tb_axpy": (C.c_int, [vp, C.c_int64, C.c_double, vp, vp]),
     "tb_absmax": (C.c_int, [vp, C.c_int64, vp, C.c_int64, C.POINTER(C.c_double)]),
     "tb_dot": (C.c_int, [vp, C.c_int64, vp, vp, C.POINTER(C.c_double)]),

@@ -1641,11 +1641,17 @@ def nlsolve(u, op, ch, solver, t=0.0):
             if callable(solver.inner_solver):
                 its = solver.inner_solver(op.pattern, op.J, res, du)
             elif solver.inner_solver == "cg" and solver.inner_precond is not None:
-                its, _ = pcg_solve(op.pattern, op.J, res, du, inner_rtol, solver.inner_atol, solver.inner_maxiter, solver.inner_precond)
+                its, lres = pcg_solve(op.pattern, op.J, res, du, inner_rtol, solver.inner_atol, solver.inner_maxiter, solver.inner_precond)
             elif solver.inner_solver == "gmres":
-                its, _ = gmres_solve(op.pattern, op.J, res, du, inner_rtol, solver.inner_atol, solver.inner_maxiter, solver.gmres_restart, True)
+                its, lres = gmres_solve(op.pattern, op.J, res, du, inner_rtol, solver.inner_atol, solver.inner_maxiter, solver.gmres_restart, True)
             else:
-                its, _ = cg_solve(op.pattern, op.J, res, du, inner_rtol, solver.inner_atol, solver.inner_maxiter, True)
+                its, lres = cg_solve(op.pattern, op.J, res, du, inner_rtol, solver.inner_atol, solver.inner_maxiter, True)
+            if not callable(solver.inner_solver) and not solve_converged(op.pattern, lres):
+                # newton_raphson.jl: `solve_succeeded || return false` — an inner solve that ran into its iteration limit fails the step
+                solver.linear_failure = "inner linear solve stopped at %d iterations with residual %.3e above its tolerance" % (its, lres)
+                solver.linear_iters.append(its)
+                solver.theta.append(np.inf)
+                return False
         except TBError as e:
             # a failed inner linear solve fails the nonlinear solve (newton_raphson.jl:262-270: `solve_inner_linear_system!` → false) — e.g. CG
             # meeting an indefinite tangent after too large a load step; the caller retries with a smaller step or another inner solver
@@ -1845,6 +1851,14 @@ class StandaloneSarcomereModel:
 
 
 # --------------------------------------------------------------------------------------- heat step + operator splitting
+def solve_converged(pattern, resnorm):
+    """True iff the latest Krylov solve on `pattern` met its stopping test ‖r‖ ≤ atol + rtol·‖r₀‖ (tb_solver_last_tolerance) — also when it
+    did so exactly at the iteration limit; the reference fails a step whose linear solve hit MaxIters (newton_raphson.jl)."""
+    tol = C.c_double()
+    check(lib().tb_solver_last_tolerance(pattern.h, C.byref(tol)))
+    return resnorm <= tol.value
+
+
 def cg_solve(pattern, A, b, x, rtol=1e-5, atol=1e-6, maxiter=1000, jacobi=True, b_is_residual=False):
     """LinearSolve.solve!(linear_solver) with KrylovJL_CG(atol, rtol) (euler.jl:94-100, ep01_spiral-wave.jl:126-128).  b_is_residual: `b`
     already holds b − A·x₀ for the initial guess in `x` (tb_cg_solve_from_residual)."""
@@ -1922,7 +1936,7 @@ class BackwardEulerStage:
         its, res = cg_solve(self.M.pattern, self.A, self.b, u, self.solver.rtol, self.solver.atol, self.solver.maxiter,
                             (1 if rebuilt else 2) if self.solver.jacobi else 0, b_is_residual=True)     # 2 = TB_JACOBI_REUSE: same A as last step
         self.last_iters = its
-        return its < self.solver.maxiter or res <= self.solver.atol
+        return solve_converged(self.M.pattern, res)
 
 
 class LieTrotterGodunov:

@@ -504,9 +504,10 @@ int launch_cg(tb_pattern *pat, const double *A, const double *b, double *x, doub
     const unsigned g = grid_for(dev, n, 256);
     constexpr int LANES = 16; // 16 lanes per row measured best for 27-entry rows (0.96 vs 1.03 ms at 216³ with 8)
     const unsigned gs = grid_for(dev, n * LANES, 256);
-    const bool fresh_ws = !pat->cg_dinv_valid;
-    if (jacobi == 1 || (jacobi == 2 && fresh_ws)) { const int rcd = launch_extract_diag(pat, A, dinv); if (rcd) return rcd; } // 2: D⁻¹ of the previous solve is still valid
-    if (jacobi) pat->cg_dinv_valid = true;
+    // TB_JACOBI_REUSE keeps D⁻¹ only when the slot holds the diagonal of THIS nz array (another operator of the pattern, a mass projection or a
+    // Newton solve may have run in between): validity is tied to the array, the caller vouches that its values are unchanged
+    if (jacobi == 1 || (jacobi == 2 && pat->cg_dinv_of != A)) { const int rcd = launch_extract_diag(pat, A, dinv); if (rcd) return rcd; }
+    if (jacobi) pat->cg_dinv_of = A;
     const double *dp = jacobi ? dinv : nullptr;
     if (b_is_residual) TB_HIP(hipMemsetAsync(Ap, 0, sizeof(double) * n, dev->stream)); // r₀ = b given: nothing to subtract
     else { const int rc = launch_spmv(pat, A, x, 1.0, 0.0, Ap); if (rc) return rc; }
@@ -641,7 +642,7 @@ int launch_gmres(tb_pattern *pat, const double *A, const double *b, double *x, d
         TB_HIP(hipMemcpyAsync(hh.data(), h1, sizeof(double), hipMemcpyDeviceToHost, dev->stream));
         TB_HIP(hipStreamSynchronize(dev->stream));
         rnorm = std::sqrt(hh[0]);
-        if (first) { tol = atol + rtol * rnorm; first = false; }
+        if (first) { tol = atol + rtol * rnorm; pat->last_tol = tol; first = false; }
         if (!(rnorm > tol) || it >= maxiter) break;
         hipLaunchKernelGGL(k_scale_diag, dim3(g), dim3(256), 0, dev->stream, n, 1.0 / rnorm, (const double *)nullptr, w, V);
         std::fill(gvec.begin(), gvec.end(), 0.0);
@@ -796,6 +797,7 @@ int launch_pcg_l1gs(tb_pattern *pat, const double *A, const double *b, double *x
     TB_HIP(hipStreamSynchronize(dev->stream));
     double rnorm = std::sqrt(h[0]);
     const double tol = atol + rtol * rnorm;
+    pat->last_tol = tol;
     int it = 0;
     double rz = 0.0;
     while (rnorm > tol && it < maxiter) {

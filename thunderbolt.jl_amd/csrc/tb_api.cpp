@@ -67,7 +67,7 @@ int tb_device_create(int hip_device_id, tb_device **out)
     TB_HIP(hipGetDeviceCount(&n));
     TB_REQUIRE(hip_device_id >= 0 && hip_device_id < n, "tb_device_create: device %d of %d", hip_device_id, n);
     TB_HIP(hipSetDevice(hip_device_id));
-    auto dev = std::make_unique<tb_device>();
+    std::unique_ptr<tb_device, int (*)(tb_device *)> dev(new tb_device, tb_device_destroy); // a failure below releases what was created so far
     dev->id = hip_device_id;
     hipDeviceProp_t prop;
     TB_HIP(hipGetDeviceProperties(&prop, hip_device_id));
@@ -226,7 +226,7 @@ int tb_mesh_create(tb_device *dev, int geom_kind, int64_t n_nodes, const double 
     TB_REQUIRE(index_base == 0 || index_base == 1, "tb_mesh_create: index_base must be 0 or 1");
     TB_REQUIRE(n_nodes > 0 && n_cells >= 0 && ndofs > 0 && n_nodes < 0x7fffffff && ndofs < 0x7fffffff,
                "tb_mesh_create: sizes out of range (nodes %lld, cells %lld, dofs %lld)", (long long)n_nodes, (long long)n_cells, (long long)ndofs);
-    auto m = std::make_unique<tb_mesh>();
+    std::unique_ptr<tb_mesh, int (*)(tb_mesh *)> m(new tb_mesh, tb_mesh_destroy); // a failed upload releases the earlier device arrays
     m->dev = dev;
     m->geom_kind = geom_kind; m->field_kind = field_kind; m->ncomp = ncomp;
     m->nverts = kind_nverts(geom_kind); m->nb = kind_nbasis(field_kind); m->ndpc = m->nb * ncomp;
@@ -267,7 +267,7 @@ int tb_pattern_create(tb_mesh *mesh, int64_t n_rows, const int64_t *rowptr, cons
     *out = nullptr;
     TB_REQUIRE(n_rows == mesh->ndofs, "tb_pattern_create: %lld rows but the dof table has %lld dofs", (long long)n_rows, (long long)mesh->ndofs);
     TB_REQUIRE(index_base == 0 || index_base == 1, "tb_pattern_create: index_base must be 0 or 1");
-    auto p = std::make_unique<tb_pattern>();
+    std::unique_ptr<tb_pattern, int (*)(tb_pattern *)> p(new tb_pattern, tb_pattern_destroy); // error returns free the device arrays too
     p->mesh = mesh;
     p->n_rows = n_rows;
     copy_rebased(p->h_rowptr, rowptr, (size_t)n_rows + 1, index_base);
@@ -280,11 +280,7 @@ int tb_pattern_create(tb_mesh *mesh, int64_t n_rows, const int64_t *rowptr, cons
             TB_REQUIRE(p->h_colidx[k] >= 0 && p->h_colidx[k] < n_rows, "tb_pattern_create: column out of range in row %lld", (long long)r);
             TB_REQUIRE(k == p->h_rowptr[r] || p->h_colidx[k] > p->h_colidx[k - 1], "tb_pattern_create: columns of row %lld not sorted", (long long)r);
         }
-    TB_HIP(hipSetDevice(mesh->dev->id));
-    int rc;
-    if ((rc = upload(mesh->dev, p->h_rowptr, &p->d_rowptr))) return rc;
-    if ((rc = upload(mesh->dev, p->h_colidx, &p->d_colidx))) return rc;
-    // every cell coupling must exist in the pattern (host check; the device scatter map is built lazily)
+    // every cell coupling must exist in the pattern (host check, before anything is allocated on the device; the scatter maps are built lazily)
     {
         const int ndpc = mesh->ndpc;
         bool missing = false;
@@ -301,6 +297,10 @@ int tb_pattern_create(tb_mesh *mesh, int64_t n_rows, const int64_t *rowptr, cons
         }
         if (missing) { set_error("tb_pattern_create: a cell coupling is missing from the CSR pattern"); return TB_ERR_PATTERN; }
     }
+    TB_HIP(hipSetDevice(mesh->dev->id));
+    int rc;
+    if ((rc = upload(mesh->dev, p->h_rowptr, &p->d_rowptr))) return rc;
+    if ((rc = upload(mesh->dev, p->h_colidx, &p->d_colidx))) return rc;
     *out = p.release();
     return TB_OK;
 }
@@ -988,6 +988,13 @@ int tb_gmres_solve(tb_pattern *pat, const double *d_Anz, const double *d_b, doub
     TB_REQUIRE(restart >= 1 && restart <= 1000, "tb_gmres_solve: restart must be in 1..1000 (got %d)", restart);
     TB_HIP(hipSetDevice(pat->mesh->dev->id));
     return launch_gmres(pat, d_Anz, d_b, d_x, rtol, atol, maxiter, restart, jacobi, iters, resnorm);
+}
+
+int tb_solver_last_tolerance(const tb_pattern *pat, double *tol)
+{
+    TB_REQUIRE(pat && tol, "tb_solver_last_tolerance: NULL argument");
+    *tol = pat->last_tol;
+    return TB_OK;
 }
 
 int tb_axpy(tb_device *dev, int64_t n, double a, const double *d_x, double *d_y)

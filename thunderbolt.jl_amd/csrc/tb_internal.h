@@ -154,7 +154,8 @@ struct tb_pattern {
     bool map64 = false;
     void *d_emap = nullptr; // [ndpc*ndpc][n_cells] nz index of (cell,i,j): int32 (nnz < 2^31) or int64
     double *d_cg_ws = nullptr;      // CG workspace (r, p, Ap, D⁻¹, 2 scalars)
-    bool cg_dinv_valid = false;     // the D⁻¹ slot of d_cg_ws holds the diagonal of some earlier solve (TB_JACOBI_REUSE)
+    const double *cg_dinv_of = nullptr; // the nz array whose diagonal the D⁻¹ slot of d_cg_ws holds (TB_JACOBI_REUSE re-extracts for any other)
+    double last_tol = 0.0;          // atol + rtol·‖r₀‖ of the latest Krylov solve on this pattern (tb_solver_last_tolerance)
     int32_t *d_bcol = nullptr;      // block SpMV of 3-dof-per-node patterns: one column (node) index per 3×3 block
     int b3 = 0, b3_lanes = 16;      // b3: 0 = not examined, 1 = CSR of 3×3 blocks, −1 = not
     int64_t *d_diagpos = nullptr;   // nz index of each row's diagonal entry (−1 if absent), built at the first Jacobi-preconditioned solve

@@ -393,8 +393,8 @@ int ensure_patch_plans(tb_mesh *m, tb_pattern *p)
         int rc = build_patch_mat_plan(p);
         const int64_t bytes = p->patch_mat ? (int64_t)p->patch_mat->max_lds_entries * 8 + (int64_t)m->patches->max_rows * 16 : 0;
         if (rc == TB_OK && (fixed || bytes <= 80 * 1024)) return TB_OK;
-        if (rc != TB_OK && rc != TB_ERR_UNSUPPORTED) return rc;
-        if (fixed) return rc;
+        if (rc != TB_OK && rc != TB_ERR_UNSUPPORTED) { free_patch_mat_plan(p); return rc; }
+        if (fixed) { free_patch_mat_plan(p); return rc; } // no half-built plan is left behind: the next call builds (and reports) again
         const int shrink = m->patches->shrink + 1, version = m->patches->version;
         free_patch_plan(m);
         rc = build_patch_plan(m, -shrink);
