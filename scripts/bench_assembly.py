@@ -50,4 +50,8 @@ for what in order:
         out["fused_ms"] = timeit(lambda: tb.update_operators(M, K, 0.0))
         if a.check and "mass_ms" in out:
             out["fused_vs_sep"] = [float(np.abs(M.A.to_host() - Mh).max() / np.abs(Mh).max()), float(np.abs(K.A.to_host() - Kh).max() / np.abs(Kh).max())]
+if "vec" in order:
+    for name, st_ in (("atomic", tb.AtomicAssemblyStrategy(dev)), ("patch", tb.PatchAssemblyStrategy(dev))):
+        src = tb.setup_operator(st_, tb.LinearIntegrator(tb.AnalyticalCoefficient("cos_exp")), dh)
+        out["source_%s_ms" % name] = timeit(lambda: tb.update_operator(src, 0.1))
 print(json.dumps(out))

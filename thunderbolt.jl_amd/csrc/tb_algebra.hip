@@ -521,6 +521,7 @@ int launch_cg(tb_pattern *pat, const double *A, const double *b, double *x, doub
     TB_HIP(hipMemsetAsync(scal + 1, 0, sizeof(double), dev->stream)); // slot 1 becomes the "next r·z" accumulator
     double rnorm = std::sqrt(h[1]);
     const double tol = atol + rtol * rnorm;
+    pat->last_tol = tol;
     // The host looks at (‖r‖², flag) once per `check` iterations: small systems are bound by the host round trip, not by the kernels, so they
     // run a few iterations between looks (at most check − 1 iterations past the tolerance); large ones look every iteration.
     static const int check_env = getenv("TB_CG_CHECK_EVERY") ? atoi(getenv("TB_CG_CHECK_EVERY")) : 0;

@@ -252,6 +252,7 @@ int tb_mesh_destroy(tb_mesh *m)
     if (m->colors) hipFree(m->colors->d_cells);
     if (m->ea) { hipFree(m->ea->d_ptr); hipFree(m->ea->d_src); hipFree(m->ea->d_ea); }
     free_patch_plan(m);
+    free_vec_patch_plans(m);
     delete m;
     return TB_OK;
 }

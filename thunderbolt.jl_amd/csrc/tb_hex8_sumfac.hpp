@@ -156,6 +156,76 @@ __device__ __forceinline__ void hex8_sf_cross(const double (&G)[8][6], double (&
         }
 }
 
+// Linear form bₑ[j] = Σ_q f(x_q) Nⱼ(ξ_q) detJ_q (src/modeling/core/analytical_coefficient.jl:89-99) by the same factorisation: Jacobian columns and
+// Gauss-point positions from the modal geometry (4 and 8 distinct values per component instead of 8 × 8 products), the 8 weighted values
+// f·detJ contracted to the 8 nodes direction by direction.  F(q, xq) evaluates the source at Gauss point q.  ≈ 330 FP64 instructions per cell
+// plus 8 source evaluations (the 8-point loop of tb_assembly.hip: ≈ 900).  Returns false when some detJ ≤ 0.
+template <class FFn>
+__device__ __forceinline__ bool hex8_sf_source(const double (&x)[8][3], FFn &&F, double (&be)[8])
+{
+    GeoCoeffs<Hex8<2>> gc;
+    geo_prepare(x, gc);
+    constexpr double gg = SF::g;
+    double c0[4][3], c1[4][3], c2[4][3], xq[8][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const double sb = b ? gg : -gg;
+            const double a0 = fma(gc.c[6][i], sb, gc.c[1][i]), a1 = fma(gc.c[7][i], sb, gc.c[4][i]);
+            c0[0 + 2 * b][i] = fma(a1, -gg, a0); c0[1 + 2 * b][i] = fma(a1, gg, a0);
+            const double b0 = fma(gc.c[5][i], sb, gc.c[2][i]);
+            c1[0 + 2 * b][i] = fma(a1, -gg, b0); c1[1 + 2 * b][i] = fma(a1, gg, b0);
+            const double d0 = fma(gc.c[5][i], sb, gc.c[3][i]), d1 = fma(gc.c[7][i], sb, gc.c[6][i]);
+            c2[0 + 2 * b][i] = fma(d1, -gg, d0); c2[1 + 2 * b][i] = fma(d1, gg, d0);
+            // position: x = (c0 + c3 ζ) + η (c2 + c5 ζ) + ξ [(c1 + c6 ζ) + η (c4 + c7 ζ)], b = bit of ζ
+            const double p0 = fma(gc.c[3][i], sb, gc.c[0][i]);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) { // bit of η
+                const double se = e ? gg : -gg;
+                const double r0 = fma(b0, se, p0), r1 = fma(a1, se, a0);
+                xq[0 + 2 * e + 4 * b][i] = fma(r1, -gg, r0);
+                xq[1 + 2 * e + 4 * b][i] = fma(r1, gg, r0);
+            }
+        }
+    }
+    bool ok = true;
+    double fw[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int q1 = q & 1, q2 = (q >> 1) & 1, q3 = q >> 2;
+        const double(&u)[3] = c0[q2 + 2 * q3];
+        const double(&v)[3] = c1[q1 + 2 * q3];
+        const double(&z)[3] = c2[q1 + 2 * q2];
+        const double det = u[0] * (v[1] * z[2] - z[1] * v[2]) + u[1] * (z[0] * v[2] - v[0] * z[2]) + u[2] * (v[0] * z[1] - z[0] * v[1]);
+        ok = ok && (det > 0.0);
+        fw[q] = F(q, xq[q]) * det;
+    }
+    double A1[2][2][2]; // [b1][q2][q3]
+#pragma unroll
+    for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+        for (int q3 = 0; q3 < 2; ++q3) {
+            const double f0 = fw[2 * q2 + 4 * q3], f1 = fw[1 + 2 * q2 + 4 * q3];
+            A1[0][q2][q3] = fma(SF::f(0, 1), f1, SF::f(0, 0) * f0);
+            A1[1][q2][q3] = fma(SF::f(1, 1), f1, SF::f(1, 0) * f0);
+        }
+    double B1[2][2][2]; // [b1][b2][q3]
+#pragma unroll
+    for (int b1 = 0; b1 < 2; ++b1)
+#pragma unroll
+        for (int q3 = 0; q3 < 2; ++q3) {
+            B1[b1][0][q3] = fma(SF::f(0, 1), A1[b1][1][q3], SF::f(0, 0) * A1[b1][0][q3]);
+            B1[b1][1][q3] = fma(SF::f(1, 1), A1[b1][1][q3], SF::f(1, 0) * A1[b1][0][q3]);
+        }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int b1 = SF::bit(j, 0), b2 = SF::bit(j, 1), b3 = SF::bit(j, 2);
+        be[j] = fma(SF::f(b3, 1), B1[b1][b2][1], SF::f(b3, 0) * B1[b1][b2][0]);
+    }
+    return ok;
+}
+
 struct Hex8SFK {
     double Y11[3][3], Y22[3][3], Y33[3][3]; // [type lower dir][type higher dir] of the two remaining directions
     double X12[2][2][3], X13[2][2][3], X23[2][2][3];

@@ -113,6 +113,21 @@ struct PatchFusedPlan {
     double *d_pcoord = nullptr;    // 3 per patch node
 };
 
+// Patch plan of the linear-form (vector) kernels on trilinear hexahedra (tb_assembly.hip: k_vector_hex8_patch).  Row accumulators of a vector
+// are one double per node, so patches are large (8×8×8 tiles).  halo = true: rows owned by first touch, the patch re-integrates the halo cells
+// and stores each owned dof once (deterministic, PATCH strategy); halo = false: own cells only, every touched node is added to the zeroed
+// vector with one global atomic per patch node (ATOMIC strategy: 1.4 atomics per cell instead of 8).
+struct VecPatchPlan {
+    bool halo = false;
+    int64_t n_patches = 0, total_elems = 0, total_nodes = 0;
+    int max_nodes = 0, max_elems = 0;
+    uint32_t *d_hdr = nullptr;      // 4 per patch: e0, n0, nrows | nnodes << 16, ne
+    uint16_t *d_elem_ln = nullptr;  // 8 patch-local node indices per instance
+    int32_t *d_elem_cell = nullptr; // global cell of every instance (tabulated sources, error reports)
+    double *d_pcoord = nullptr;     // 3 per patch node
+    int32_t *d_pdof = nullptr;      // global dof of every patch node
+};
+
 } // namespace tb
 
 struct tb_device {
@@ -142,6 +157,7 @@ struct tb_mesh {
     std::unique_ptr<tb::ColorPlan> colors;
     std::unique_ptr<tb::EAPlan> ea;
     std::unique_ptr<tb::PatchPlan> patches;
+    std::unique_ptr<tb::VecPatchPlan> vpatches[2]; // [halo]
 };
 
 struct tb_pattern {
@@ -226,6 +242,8 @@ int build_patch_mat_plan(tb_pattern *p);
 int ensure_patch_plans(tb_mesh *m, tb_pattern *p); // builds / refits both so the LDS block allows two workgroups per CU
 void free_patch_plan(tb_mesh *m);
 void free_patch_mat_plan(tb_pattern *p);
+int ensure_vec_patch_plan(tb_mesh *m, bool halo);
+void free_vec_patch_plans(tb_mesh *m);
 int ensure_patch_fused(tb_mesh *m, tb_pattern *p, int nregions); // plan of the sum-factorised hexahedron kernel; nregions accumulator blocks must fit 80 KiB of LDS
 void free_patch_fused_plan(tb_pattern *p);
 int launch_assemble_hex8_patch(tb_form *fK, tb_form *fM, tb_pattern *p, double t, double *d_nzK, double *d_nzM); // either form may be NULL

@@ -598,3 +598,170 @@ int ensure_patch_fused(tb_mesh *m, tb_pattern *p, int nregions)
 }
 
 } // namespace tb
+
+namespace tb {
+
+void free_vec_patch_plans(tb_mesh *m)
+{
+    for (auto &v : m->vpatches) {
+        if (!v) continue;
+        hipFree(v->d_hdr); hipFree(v->d_elem_ln); hipFree(v->d_elem_cell); hipFree(v->d_pcoord); hipFree(v->d_pdof);
+        v.reset();
+    }
+}
+
+// Tiles of 8×8×8 bucket cells (TB_VPATCH_TILE="tx,ty,tz" overrides), cells ordered lexicographically inside a tile — the same bucket construction
+// as build_patch_plan (quantile buckets per axis: exact layers on structured boxes, density-adaptive on unstructured meshes).
+int ensure_vec_patch_plan(tb_mesh *m, bool halo)
+{
+    if (m->vpatches[halo]) return TB_OK;
+    if (m->ndpc != 8 || m->nverts != 8 || m->ncomp != 1) { set_error("vector patch plan: needs a scalar trilinear hexahedron field"); return TB_ERR_UNSUPPORTED; }
+    int tile[3] = {8, 8, 8};
+    if (const char *e = getenv("TB_VPATCH_TILE")) {
+        int a, b, c;
+        if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a > 0 && b > 0 && c > 0) { tile[0] = a; tile[1] = b; tile[2] = c; }
+    }
+    const int64_t nc = m->n_cells;
+    std::vector<uint32_t> bucket((size_t)nc * 3);
+    std::vector<std::pair<uint64_t, int32_t>> keyed(nc);
+    {
+        std::vector<double> cen((size_t)nc * 3);
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, hsum[3] = {0, 0, 0};
+#pragma omp parallel for schedule(static) reduction(min : lo[:3]) reduction(max : hi[:3]) reduction(+ : hsum[:3])
+        for (int64_t c = 0; c < nc; ++c) {
+            double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300}, sum[3] = {0, 0, 0};
+            for (int a = 0; a < 8; ++a)
+                for (int d = 0; d < 3; ++d) {
+                    const double v = m->h_xyz[3 * (int64_t)m->h_conn[c * 8 + a] + d];
+                    sum[d] += v; mn[d] = std::min(mn[d], v); mx[d] = std::max(mx[d], v);
+                }
+            for (int d = 0; d < 3; ++d) {
+                cen[3 * c + d] = sum[d] / 8;
+                lo[d] = std::min(lo[d], mn[d]); hi[d] = std::max(hi[d], mx[d]); hsum[d] += mx[d] - mn[d];
+            }
+        }
+#pragma omp parallel for schedule(static, 1) num_threads(3)
+        for (int d = 0; d < 3; ++d) {
+            const double hmean = hsum[d] / (double)std::max<int64_t>(nc, 1);
+            int64_t R = hmean > 0 ? (int64_t)std::llround((hi[d] - lo[d]) / hmean) : 1;
+            R = std::min<int64_t>(std::max<int64_t>(R, 1), 1 << 21);
+            std::vector<std::pair<double, int32_t>> byc(nc);
+            for (int64_t c = 0; c < nc; ++c) byc[c] = {cen[3 * c + d], (int32_t)c};
+            std::sort(byc.begin(), byc.end());
+            for (int64_t r = 0; r < nc; ++r) bucket[3 * (size_t)byc[r].second + d] = (uint32_t)((r * R) / nc);
+        }
+#pragma omp parallel for schedule(static)
+        for (int64_t c = 0; c < nc; ++c) {
+            const uint64_t ti = bucket[3 * c] / tile[0], tj = bucket[3 * c + 1] / tile[1], tk = bucket[3 * c + 2] / tile[2];
+            keyed[c] = {(tk << 42) | (tj << 21) | ti, (int32_t)c};
+        }
+    }
+    auto lex_less = [&](int32_t a, int32_t b) {
+        const uint32_t *A = &bucket[3 * (size_t)a], *B = &bucket[3 * (size_t)b];
+        if (A[2] != B[2]) return A[2] < B[2];
+        if (A[1] != B[1]) return A[1] < B[1];
+        if (A[0] != B[0]) return A[0] < B[0];
+        return a < b;
+    };
+    std::sort(keyed.begin(), keyed.end(), [&](const std::pair<uint64_t, int32_t> &a, const std::pair<uint64_t, int32_t> &b) {
+        return a.first != b.first ? a.first < b.first : lex_less(a.second, b.second);
+    });
+    // patches: one per tile, cut further so that no patch exceeds 1000 cells (16-bit local node indices, LDS)
+    const int cap = std::min(1000, tile[0] * tile[1] * tile[2]);
+    std::vector<int64_t> pstart(1, 0);
+    for (int64_t k = 1; k < nc; ++k)
+        if (keyed[k].first != keyed[k - 1].first || k - pstart.back() >= cap) pstart.push_back(k);
+    if (nc > 0) pstart.push_back(nc);
+    const int64_t np = (int64_t)pstart.size() - 1;
+    // first-touch ownership (halo variant)
+    std::vector<int32_t> owner;
+    std::vector<int64_t> sptr;
+    std::vector<int32_t> ssrc;
+    if (halo) {
+        owner.assign(m->ndofs, -1);
+        for (int64_t q = 0; q < np; ++q)
+            for (int64_t k = pstart[q]; k < pstart[q + 1]; ++k)
+                for (int l = 0; l < 8; ++l) {
+                    int32_t &o = owner[m->h_cell_dofs[(int64_t)keyed[k].second * 8 + l]];
+                    if (o < 0) o = (int32_t)q;
+                }
+        dof_slots(m, sptr, ssrc);
+    }
+    auto plan = std::make_unique<VecPatchPlan>();
+    plan->halo = halo;
+    plan->n_patches = np;
+    std::vector<uint32_t> hdr((size_t)np * 4);
+    std::vector<uint16_t> ln;
+    std::vector<int32_t> ecell, pdof, pnode;
+    ln.reserve((size_t)nc * 8 * (halo ? 3 : 2) / 2);
+    ecell.reserve((size_t)nc * (halo ? 3 : 2) / 2);
+    std::vector<int32_t> local_of(m->n_nodes, -1), cell_stamp(halo ? nc : 0, -1);
+    std::vector<int32_t> cells;
+    bool bad = false;
+    for (int64_t q = 0; q < np; ++q) {
+        cells.clear();
+        for (int64_t k = pstart[q]; k < pstart[q + 1]; ++k) cells.push_back(keyed[k].second);
+        const size_t nbase = pnode.size();
+        if (halo) { // owned nodes first (slot order = first touch inside the patch), then the halo cells
+            for (int32_t c : cells) {
+                cell_stamp[c] = (int32_t)q;
+                for (int a = 0; a < 8; ++a) {
+                    const int32_t d = m->h_cell_dofs[(int64_t)c * 8 + a], node = m->h_conn[(int64_t)c * 8 + a];
+                    if (owner[d] == q && local_of[node] < 0) { local_of[node] = (int32_t)(pnode.size() - nbase); pnode.push_back(node); pdof.push_back(d); }
+                }
+            }
+            const size_t nown = pnode.size() - nbase;
+            const size_t nown_cells = cells.size();
+            for (size_t r = 0; r < nown; ++r) {
+                const int32_t d = pdof[nbase + r];
+                for (int64_t s2 = sptr[d]; s2 < sptr[d + 1]; ++s2) {
+                    const int32_t c = ssrc[s2] / 8;
+                    if (cell_stamp[c] != q) { cell_stamp[c] = (int32_t)q; cells.push_back(c); }
+                }
+            }
+            std::sort(cells.begin() + nown_cells, cells.end(), lex_less);
+            hdr[4 * q + 2] = (uint32_t)nown;
+        }
+        for (int32_t c : cells)
+            for (int a = 0; a < 8; ++a) {
+                const int32_t d = m->h_cell_dofs[(int64_t)c * 8 + a], node = m->h_conn[(int64_t)c * 8 + a];
+                if (local_of[node] < 0) { local_of[node] = (int32_t)(pnode.size() - nbase); pnode.push_back(node); pdof.push_back(d); }
+                else if (pdof[nbase + local_of[node]] != d) bad = true;
+                ln.push_back((uint16_t)local_of[node]);
+            }
+        for (int32_t c : cells) ecell.push_back(c);
+        const size_t nn = pnode.size() - nbase;
+        if (nn >= 0xFFFF || cells.size() >= 0xFFFF) { set_error("vector patch plan: patch too large (%zu nodes)", nn); return TB_ERR_UNSUPPORTED; }
+        hdr[4 * q] = (uint32_t)(ecell.size() - cells.size());
+        hdr[4 * q + 1] = (uint32_t)nbase;
+        if (!halo) hdr[4 * q + 2] = (uint32_t)nn; // every touched node is accumulated and added
+        hdr[4 * q + 2] |= (uint32_t)nn << 16;
+        hdr[4 * q + 3] = (uint32_t)cells.size();
+        plan->max_nodes = std::max(plan->max_nodes, (int)nn);
+        plan->max_elems = std::max(plan->max_elems, (int)cells.size());
+        for (size_t k = nbase; k < pnode.size(); ++k) local_of[pnode[k]] = -1;
+    }
+    if (bad) { set_error("vector patch plan: dofs and vertices of the field are not in one-to-one correspondence"); return TB_ERR_UNSUPPORTED; }
+    if ((int64_t)ecell.size() >= (int64_t)0x7fffffff || (int64_t)pnode.size() >= (int64_t)0x7fffffff) { set_error("vector patch plan: too many instances for 32-bit offsets"); return TB_ERR_UNSUPPORTED; }
+    plan->total_elems = (int64_t)ecell.size();
+    plan->total_nodes = (int64_t)pnode.size();
+    std::vector<double> pcoord(pnode.size() * 3);
+#pragma omp parallel for schedule(static)
+    for (int64_t k = 0; k < (int64_t)pnode.size(); ++k)
+        for (int d = 0; d < 3; ++d) pcoord[3 * k + d] = m->h_xyz[3 * (int64_t)pnode[k] + d];
+    if (getenv("TB_PLAN_VERBOSE"))
+        fprintf(stderr, "[tbhip] vector patch plan (%s): %lld patches, %.3f instances per cell, %.3f patch nodes per dof, max %d instances / %d nodes per patch\n",
+                halo ? "halo" : "own cells", (long long)np, (double)ecell.size() / (double)std::max<int64_t>(nc, 1), (double)pnode.size() / (double)std::max<int64_t>(m->ndofs, 1),
+                plan->max_elems, plan->max_nodes);
+    int rc = TB_OK;
+    if (!rc) rc = upload(m->dev, hdr, &plan->d_hdr);
+    if (!rc) rc = upload(m->dev, ln, &plan->d_elem_ln);
+    if (!rc) rc = upload(m->dev, ecell, &plan->d_elem_cell);
+    if (!rc) rc = upload(m->dev, pcoord, &plan->d_pcoord);
+    if (!rc) rc = upload(m->dev, pdof, &plan->d_pdof);
+    if (rc) { hipFree(plan->d_hdr); hipFree(plan->d_elem_ln); hipFree(plan->d_elem_cell); hipFree(plan->d_pcoord); hipFree(plan->d_pdof); return rc; }
+    m->vpatches[halo] = std::move(plan);
+    return TB_OK;
+}
+
+} // namespace tb
