@@ -124,7 +124,9 @@ typedef struct tb_material {
 /* ionic models (src/modeling/cells/{fhn,aliev-panfilov,pcg2019}.jl) and state layouts (src/modeling/solution_variables.jl:40-68) */
 enum {
     TB_CELL_FHN = 0, TB_CELL_ALIEV_PANFILOV = 1, TB_CELL_PCG2019 = 2,
-    TB_CELL_TT06 = 3 /* ten Tusscher–Panfilov 2006 (epi): EXTENSION, not in the reference (BASELINE config 3 names it) */
+    TB_CELL_TT06 = 3, /* ten Tusscher–Panfilov 2006 (epi): EXTENSION, not in the reference (BASELINE config 3 names it) */
+    TB_CELL_FHN_HETEROGENEOUS = 4 /* HeterogeneousFHNModel of docs/src/literate-howto/custom-ep-cell-model.jl:8-56 with the recovery rate an affine
+                                     function of the point coordinate, e(x) = e0 + g·x: parameters (a, b, c, d, e0, gx, gy, gz); needs d_x */
 };
 enum {
     TB_LAYOUT_SOA = 0, /* StateBlockedLayout: u[k + s·npoints]  */
@@ -348,6 +350,13 @@ int tb_host_sarcomere_local_solve(int model, const double *params, int n_params,
 int tb_reaction_step(tb_device *dev, int model, const double *params, int n_params, double *d_u, double *d_du,
                      int64_t n_points, int n_states, int layout, double t, double dt, int substeps,
                      double threshold);
+/* The same step with the per-point coordinate the reference hands to cell_rhs!(du, u, x, t, p): x = getcoordinate(cache, i)
+ * (src/solver/time/partitioned_solver.jl:88-92; cache field `xs`, :63-77; Vec{sdim, Float32}, src/modeling/core/coordinate_systems.jl:43-49).
+ * d_x: n_points × sdim Float32 values, point-major, or NULL ("x === nothing"); sdim 1…3.  Models that read x (TB_CELL_FHN_HETEROGENEOUS)
+ * return TB_ERR_BAD_ARG without it; the others ignore it. */
+int tb_reaction_step_x(tb_device *dev, int model, const double *params, int n_params, double *d_u, double *d_du,
+                       int64_t n_points, int n_states, int layout, const float *d_x, int sdim, double t, double dt, int substeps,
+                       double threshold);
 /* Same step with the reaction tangent fused in: *rmax receives max over points of the φₘ component of the last right-hand
  * side evaluated at each point — what ReactionTangentController reads from `dumat` after the step (src/solver/time/rtc.jl:55-73)
  * — without `du` having to be written (d_du may be NULL): 16 instead of 24 bytes per DoF-update. */
@@ -357,7 +366,8 @@ int tb_reaction_step_rtc(tb_device *dev, int model, const double *params, int n_
 /* Rush–Larsen step (SURVEY §8 f4 — the reference carries only the reaction_rhs!/state_rhs! hooks for it, src/modeling/cells/fhn.jl:36-60):
  * Hodgkin–Huxley-type gates are advanced with the exact solution of their linear ODE for frozen φₘ, every other state by forward
  * Euler.  Lifts the fast-gate stability limit of forward Euler (TT06: Δt = 0.02 ms in one evaluation instead of twenty sub-steps).
- * TB_CELL_TT06 only; other models return TB_ERR_UNSUPPORTED. */
+ * TB_CELL_TT06 and TB_CELL_PCG2019 (whose six gates relax as (g∞ − g)/τ_g, src/modeling/cells/pcg2019.jl:96-118); other models return
+ * TB_ERR_UNSUPPORTED. */
 int tb_reaction_step_rl(tb_device *dev, int model, const double *params, int n_params, double *d_u, int64_t n_points, int n_states,
                         int layout, double t, double dt);
 int tb_cell_model_info(int model, int *n_states, int *n_params, int *phi_index);

@@ -17,7 +17,7 @@ LINE2, QUAD4, HEX8, TET4, HEX27 = 1, 2, 3, 4, 5
 COEF_CONST_SCALAR, COEF_CONST_TENSOR, COEF_FIELD_SCALAR = 0, 1, 2
 COEF_SPECTRAL_CONST, COEF_SPECTRAL_FIELD, COEF_TRANSVERSE_CONST = 3, 4, 5
 SRC_CONST, SRC_NORM_PLUS_T, SRC_COS_EXP, SRC_TABULATED = 0, 1, 2, 3
-CELL_FHN, CELL_ALIEV_PANFILOV, CELL_PCG2019, CELL_TT06 = 0, 1, 2, 3
+CELL_FHN, CELL_ALIEV_PANFILOV, CELL_PCG2019, CELL_TT06, CELL_FHN_HETEROGENEOUS = 0, 1, 2, 3, 4
 LAYOUT_SOA, LAYOUT_AOS = 0, 1
 
 _dp = C.POINTER(C.c_double)
@@ -271,8 +271,22 @@ def reaction_step(model, p, u, npoints, layout=LAYOUT_SOA, t=0.0, dt=1.0, subste
     return du
 
 
+def reaction_step_x(model, p, u, npoints, xs, layout=LAYOUT_SOA, t=0.0, dt=1.0, substeps=1, threshold=0.1, want_du=True):
+    """reaction_step with the point coordinates xs (npoints × sdim, Float32) handed to cell_rhs! — in place on `u`; returns du (or None)."""
+    assert u.dtype == np.float64 and u.flags.c_contiguous
+    p = _f64(p)
+    xs = np.ascontiguousarray(np.asarray(xs, dtype=np.float32).reshape(npoints, -1))
+    du = np.zeros_like(u) if want_du else None
+    f = lib().orc_reaction_step_x
+    f.restype = C.c_int
+    rc = f(C.c_int(model), _d(p), _d(u), _d(du), C.c_int64(npoints), C.c_int(layout), xs.ctypes.data_as(C.POINTER(C.c_float)), C.c_int(xs.shape[1]),
+           C.c_double(t), C.c_double(dt), C.c_int(substeps), C.c_double(threshold), C.c_int(1))
+    assert rc == 0, rc
+    return du
+
+
 def reaction_step_rl(model, p, u, npoints, layout=LAYOUT_SOA, t=0.0, dt=1.0, nthreads=1):
-    """Rush–Larsen step, in place on `u` (TT06 only)."""
+    """Rush–Larsen step, in place on `u` (TT06 and PCG2019)."""
     assert u.dtype == np.float64 and u.flags.c_contiguous
     p = _f64(p)
     rc = lib().orc_reaction_step_rl(model, _d(p), _d(u), C.c_int64(npoints), layout, C.c_double(t), C.c_double(dt), nthreads)

@@ -763,8 +763,8 @@ int orc_assemble_source(const orc_mesh *m, int src_kind, const double *p, const 
 /* ionic models                                                                                */
 /* ------------------------------------------------------------------------------------------ */
 
-int orc_cell_nstates(int model) { return model == ORC_CELL_TT06 ? 19 : model == ORC_CELL_PCG2019 ? 7 : (model == ORC_CELL_FHN || model == ORC_CELL_ALIEV_PANFILOV) ? 2 : -1; }
-int orc_cell_nparams(int model) { return model == ORC_CELL_TT06 ? 48 : model == ORC_CELL_PCG2019 ? 36 : (model == ORC_CELL_FHN || model == ORC_CELL_ALIEV_PANFILOV) ? 6 : -1; }
+int orc_cell_nstates(int model) { return model == ORC_CELL_TT06 ? 19 : model == ORC_CELL_PCG2019 ? 7 : (model == ORC_CELL_FHN || model == ORC_CELL_ALIEV_PANFILOV || model == ORC_CELL_FHN_HETEROGENEOUS) ? 2 : -1; }
+int orc_cell_nparams(int model) { return model == ORC_CELL_TT06 ? 48 : model == ORC_CELL_PCG2019 ? 36 : model == ORC_CELL_FHN_HETEROGENEOUS ? 8 : (model == ORC_CELL_FHN || model == ORC_CELL_ALIEV_PANFILOV) ? 6 : -1; }
 
 /* PCG2019 parameter order = struct field order, src/modeling/cells/pcg2019.jl:4-48 */
 enum { P_gNa, P_Em, P_km, P_taum, P_Eh, P_kh, P_dh, P_tauh0, P_gK1, P_Ez, P_kz, P_gto, P_Er, P_kr, P_Es, P_ks,
@@ -787,6 +787,9 @@ void orc_cell_default_params(int model, double *p)
                               0.056, -26.6, 6.5, 334.0, -49.6, 23.5,
                               0.008, 24.6, 12.1, 628.0,
                               65.0, -85.0, 50.0};
+        memcpy(p, d, sizeof d);
+    } else if (model == ORC_CELL_FHN_HETEROGENEOUS) { /* docs/src/literate-howto/custom-ep-cell-model.jl:8-15, e ≡ 0.01 (no gradient) */
+        const double d[8] = {0.1, 0.5, 1.0, 0.0, 0.01, 0.0, 0.0, 0.0};
         memcpy(p, d, sizeof d);
     } else if (model == ORC_CELL_TT06) { /* ten Tusscher & Panfilov 2006, epicardial cell (EXTENSION: not in the reference) */
         const double d[48] = {14.838, 5.405, 0.153, 0.392, 0.294, 3.98e-5, 0.00029, 0.000592, 0.1238, 0.0146, 2.724, 1000.0,
@@ -977,6 +980,53 @@ void orc_cell_rhs(int model, const double *p, const double *u, double t, double 
 static int phi_index(int model) { return model == ORC_CELL_ALIEV_PANFILOV ? 1 : 0; }
 
 /* src/solver/time/partitioned_solver.jl:80-99 (FE) and :196-234 (adaptive) for one point */
+/* cell_rhs!(du, u, x, t, p) of the how-to's HeterogeneousFHNModel (docs/src/literate-howto/custom-ep-cell-model.jl:43-56) with the closure
+ * e(x,t) restated as the affine field e0 + g·x; every other model ignores x (they are called with `x` and never read it) */
+static void cell_rhs_x(int model, const double *p, const double *u, const float *x, int sdim, double t, double *du)
+{
+    if (model != ORC_CELL_FHN_HETEROGENEOUS) { orc_cell_rhs(model, p, u, t, du); return; }
+    double e = p[4];
+    for (int d = 0; d < sdim && x; ++d) e += p[5 + d] * (double)x[d];
+    const double phi = u[0], s = u[1];
+    du[0] = phi * (1.0 - phi) * (phi - p[0]) - s;
+    du[1] = e * (p[1] * phi - p[2] * s - p[3]);
+}
+
+static void point_step_x(int model, const double *p, double *ul, double *dul, int ns, const float *x, int sdim, double t, double dt,
+                         int substeps, double threshold)
+{
+    cell_rhs_x(model, p, ul, x, sdim, t, dul);
+    if (substeps <= 1 || fabs(dul[model == ORC_CELL_ALIEV_PANFILOV ? 1 : 0]) < threshold) {
+        for (int j = 0; j < ns; ++j) ul[j] += dt * dul[j];
+        return;
+    }
+    const double dts = dt / substeps;
+    for (int j = 0; j < ns; ++j) ul[j] += dts * dul[j];
+    for (int s = 2; s <= substeps; ++s) {
+        cell_rhs_x(model, p, ul, x, sdim, t + (s - 1) * dts, dul);
+        for (int j = 0; j < ns; ++j) ul[j] += dts * dul[j];
+    }
+}
+
+int orc_reaction_step_x(int model, const double *p, double *u, double *du, int64_t npoints, int layout, const float *xs, int sdim,
+                        double t, double dt, int substeps, double threshold, int nthreads)
+{
+    int ns = orc_cell_nstates(model);
+    if (ns < 0) return -1;
+    (void)nthreads;
+    for (int64_t i = 0; i < npoints; ++i) {
+        double ul[32], dul[32];
+        for (int j = 0; j < ns; ++j) ul[j] = layout == ORC_LAYOUT_SOA ? u[i + j * npoints] : u[i * ns + j];
+        point_step_x(model, p, ul, dul, ns, xs ? xs + i * sdim : NULL, sdim, t, dt, substeps, threshold);
+        for (int j = 0; j < ns; ++j) {
+            int64_t k = layout == ORC_LAYOUT_SOA ? i + j * npoints : i * ns + j;
+            u[k] = ul[j];
+            if (du) du[k] = dul[j];
+        }
+    }
+    return 0;
+}
+
 static void point_step(int model, const double *p, double *ul, double *dul, int ns, double t, double dt,
                        int substeps, double threshold)
 {
@@ -1028,6 +1078,22 @@ int orc_reaction_step(int model, const double *p, double *u, double *du, int64_t
 int orc_reaction_step_rl(int model, const double *p, double *u, int64_t npoints, int layout, double t, double dt, int nthreads)
 {
     (void)t;
+    if (model == ORC_CELL_PCG2019) { /* gates relax as (g∞ − g)/τ_g (pcg2019.jl:96-118): rate = 1/τ_g, τ_h from :88 */
+        for (int64_t i = 0; i < npoints; ++i) {
+            double ul[7], dul[7], rate[7];
+            for (int j = 0; j < 7; ++j) ul[j] = layout == ORC_LAYOUT_SOA ? u[i + j * npoints] : u[i * 7 + j];
+            orc_cell_rhs(model, p, ul, t, dul);
+            const double eh = exp((ul[0] - p[P_Eh]) / p[P_kh]);
+            rate[0] = 0.0;
+            rate[1] = (1.0 + eh) / (2.0 * p[P_tauh0] * exp(p[P_dh] * (ul[0] - p[P_Eh]) / p[P_kh]));
+            rate[2] = 1.0 / p[P_taum]; rate[3] = 1.0 / p[P_tauf]; rate[4] = 1.0 / p[P_taus]; rate[5] = 1.0 / p[P_tauxs]; rate[6] = 1.0 / p[P_tauxr];
+            for (int j = 0; j < 7; ++j) {
+                const double h = rate[j] != 0.0 ? -expm1(-dt * rate[j]) / rate[j] : dt;
+                u[layout == ORC_LAYOUT_SOA ? i + j * npoints : i * 7 + j] = ul[j] + h * dul[j];
+            }
+        }
+        return 0;
+    }
     if (model != ORC_CELL_TT06) return -2;
     const int ns = 19;
 #ifdef _OPENMP

@@ -44,7 +44,8 @@ enum {
     ORC_SRC_TABULATED = 3          /* table[q + nq*cell] (host-evaluated closure) */
 };
 
-enum { ORC_CELL_FHN = 0, ORC_CELL_ALIEV_PANFILOV = 1, ORC_CELL_PCG2019 = 2, ORC_CELL_TT06 = 3 /* extension, not in the reference */ };
+enum { ORC_CELL_FHN = 0, ORC_CELL_ALIEV_PANFILOV = 1, ORC_CELL_PCG2019 = 2, ORC_CELL_TT06 = 3 /* extension, not in the reference */,
+       ORC_CELL_FHN_HETEROGENEOUS = 4 /* docs/src/literate-howto/custom-ep-cell-model.jl:8-56 with e(x) = e0 + g·x */ };
 enum { ORC_LAYOUT_SOA = 0, ORC_LAYOUT_AOS = 1 };
 
 /* ---- FE substrate (Ferrite conventions restated; UNPINNED where SURVEY §8c says so) ---- */
@@ -133,6 +134,9 @@ void orc_cell_rhs(int model, const double *p, const double *u, double t, double 
 int orc_reaction_step(int model, const double *p, double *u, double *du, int64_t npoints, int layout,
                       double t, double dt, int substeps, double threshold, int nthreads);
 
+/* the same outer loop with the point coordinate handed to cell_rhs! (partitioned_solver.jl:88-92): xs = npoints × sdim Float32, or NULL */
+int orc_reaction_step_x(int model, const double *p, double *u, double *du, int64_t npoints, int layout, const float *xs, int sdim,
+                        double t, double dt, int substeps, double threshold, int nthreads);
 int orc_reaction_step_rl(int model, const double *p, double *u, int64_t npoints, int layout, double t, double dt, int nthreads);
 
 /* ---- heat-step algebra ---- */

@@ -1249,7 +1249,7 @@ def test_reference_passive_structure_with_subdomains(tb, oracle, device):
         tb.apply(u, ch)
         # the reference runs NewtonRaphsonSolver(max_iter = 10) with its default inner solver, GMRES (the Guccione tangent is indefinite here)
         solver = tb.NewtonRaphsonSolver(max_iter=10, tol=1e-8, inner_rtol=1e-12, inner_solver="gmres", gmres_restart=100)
-        assert tb.nlsolve(u, op, ch, solver, t=1.0), solver.residual_norms
+        assert tb.nlsolve(u, op, ch, solver, t=1.0), (solver.residual_norms, getattr(solver, "linear_failure", None))
         return u.to_host(), op
     u1, _ = solve(ho(), tb.PerColorAssemblyStrategy(device))
     assert np.abs(u1).max() > 1e-3
@@ -2237,3 +2237,65 @@ def test_other_energies_assemble_like_the_ad_oracle(tb, oracle, device, order, n
         res2 = device.zeros(dh.ndofs)
         tb.residual(op, res2, du, 0.0)
         assert rel_err(res2.to_host(), rref) < 1e-11
+
+
+# ------------------------------------------------------------------------------------------- cell models that read the point coordinate; Rush–Larsen
+@pytest.mark.parametrize("layout", ["SOA", "AOS"])
+@pytest.mark.parametrize("sdim", [2, 3])
+def test_reaction_reads_point_coordinates(tb, oracle, device, layout, sdim):
+    """cell_rhs!(du, u, x, t, p) with x = getcoordinate(cache, i) (partitioned_solver.jl:88-92): the how-to's HeterogeneousFHNModel
+    (custom-ep-cell-model.jl:43-56, e(x) = e0 + g·x) through tb_reaction_step_x, forward Euler and the adaptive sub-stepper, against the oracle;
+    models that do not read x give the same states with and without it; a model that needs x refuses to run without."""
+    n = 700 + 13
+    rng = np.random.default_rng(12)
+    model = tb.HeterogeneousFHNModel(e0=0.02, gx=0.03, gy=-0.01, gz=0.02 if sdim == 3 else 0.0)
+    xs = rng.uniform(-1, 1, size=(n, sdim)).astype(np.float32)
+    pts = rng.uniform(-0.2, 1.0, size=(n, 2))
+    host = (np.ascontiguousarray(pts.T) if layout == "SOA" else pts).ravel().copy()
+    lay = tb.StateBlockedLayout() if layout == "SOA" else tb.PointBlockedLayout()
+    f = tb.PointwiseODEFunction(n, model, x=xs, layout=lay)
+    for solver in (tb.ForwardEulerCellSolver(device), tb.AdaptiveForwardEulerSubstepper(device, substeps=5, reaction_threshold=0.05)):
+        cache = tb.setup_solver_cache(f, solver, u=device.to_device(host))
+        ref = host.copy()
+        for step in range(30):
+            assert tb.perform_step(f, cache, 0.1 * step, 0.1) is True
+            du_ref = oracle.reaction_step_x(oracle.CELL_FHN_HETEROGENEOUS, model.params, ref, n, xs, getattr(oracle, "LAYOUT_" + layout), t=0.1 * step, dt=0.1,
+                                            substeps=solver.substeps, threshold=solver.reaction_threshold)
+        assert rel_err(cache.un.to_host(), ref) < TOL
+        assert rel_err(cache.du.to_host(), du_ref) < 1e-10
+    # the gradient matters (the test would pass trivially otherwise)
+    flat = tb.HeterogeneousFHNModel(e0=0.02)
+    c2 = tb.setup_solver_cache(tb.PointwiseODEFunction(n, flat, x=xs, layout=lay), tb.ForwardEulerCellSolver(device), u=device.to_device(host))
+    for step in range(30):
+        tb.perform_step(tb.PointwiseODEFunction(n, flat, x=xs, layout=lay), c2, 0.1 * step, 0.1)
+    assert rel_err(c2.un.to_host(), ref) > 1e-4
+    # x is ignored by the models that do not read it
+    m = tb.FHNModel()
+    fa, fb = tb.PointwiseODEFunction(n, m, layout=lay), tb.PointwiseODEFunction(n, m, x=xs, layout=lay)
+    ca = tb.setup_solver_cache(fa, tb.ForwardEulerCellSolver(device), u=device.to_device(host))
+    cb = tb.setup_solver_cache(fb, tb.ForwardEulerCellSolver(device), u=device.to_device(host))
+    for step in range(5):
+        tb.perform_step(fa, ca, 0.1 * step, 0.1)
+        tb.perform_step(fb, cb, 0.1 * step, 0.1)
+    np.testing.assert_array_equal(ca.un.to_host(), cb.un.to_host())
+    with pytest.raises(tb.TBError):
+        tb.perform_step(tb.PointwiseODEFunction(n, model, layout=lay), tb.setup_solver_cache(tb.PointwiseODEFunction(n, model, layout=lay), tb.ForwardEulerCellSolver(device), u=device.to_device(host)), 0.0, 0.1)
+
+
+@pytest.mark.parametrize("layout", ["SOA", "AOS"])
+def test_rush_larsen_pcg2019_parity(tb, oracle, device, layout):
+    """Rush–Larsen step of the reference's own 7-state model (gates (g∞ − g)/τ_g, pcg2019.jl:96-118) against the oracle; stable at a step
+    where forward Euler is not needed to sub-step (Δt = 0.05 ms)."""
+    model = tb.PCG2019()
+    n = 600 + 7
+    rng = np.random.default_rng(21)
+    pts = initial_points(tb, model, n, rng)
+    host = (np.ascontiguousarray(pts.T) if layout == "SOA" else pts).ravel().copy()
+    f = tb.PointwiseODEFunction(n, model, layout=tb.StateBlockedLayout() if layout == "SOA" else tb.PointBlockedLayout())
+    cache = tb.setup_solver_cache(f, tb.RushLarsenCellSolver(device), u=device.to_device(host), keep_du=False)
+    ref = host.copy()
+    for step in range(40):
+        tb.perform_step(f, cache, 0.05 * step, 0.05)
+        oracle.reaction_step_rl(oracle.CELL_PCG2019, model.params, ref, n, getattr(oracle, "LAYOUT_" + layout), t=0.05 * step, dt=0.05)
+    assert np.isfinite(ref).all()
+    assert rel_err(cache.un.to_host(), ref) < 1e-11

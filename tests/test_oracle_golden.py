@@ -257,3 +257,50 @@ def test_q2_tables(oracle):
         xp, xm = np.array(xi), np.array(xi)
         xp[d] += e; xm[d] -= e
         np.testing.assert_allclose((o.shape(o.HEX27, xp)[0] - o.shape(o.HEX27, xm)[0]) / (2 * e), dN[:, d], atol=1e-8)
+
+
+def test_heterogeneous_fhn_reduces_to_fhn_and_reads_x(oracle):
+    """HeterogeneousFHNModel of the reference's how-to (docs/src/literate-howto/custom-ep-cell-model.jl:43-56): with a constant e it is the FHN
+    right-hand side (cells/fhn.jl:21-34, f = 1) bit for bit; with a gradient only du[2] changes, by g·x·(bφ − cs − d)."""
+    o = oracle
+    rng = np.random.default_rng(3)
+    n = 17
+    u = rng.uniform(-0.2, 1.0, size=2 * n)
+    xs = rng.uniform(-1, 1, size=(n, 3)).astype(np.float32)
+    pf = o.cell_default_params(o.CELL_FHN)
+    ph = o.cell_default_params(o.CELL_FHN_HETEROGENEOUS)
+    a, b = u.copy(), u.copy()
+    da = o.reaction_step(o.CELL_FHN, pf, a, n, o.LAYOUT_SOA, t=0.3, dt=0.05)
+    db = o.reaction_step_x(o.CELL_FHN_HETEROGENEOUS, ph, b, n, xs, o.LAYOUT_SOA, t=0.3, dt=0.05)
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(da, db)
+    ph[5:8] = [0.02, -0.01, 0.005]
+    c = u.copy()
+    dc = o.reaction_step_x(o.CELL_FHN_HETEROGENEOUS, ph, c, n, xs, o.LAYOUT_SOA, t=0.3, dt=0.05)
+    phi, s = u[:n], u[n:]
+    np.testing.assert_array_equal(dc[:n], da[:n])
+    np.testing.assert_allclose(dc[n:] - da[n:], (xs.astype(float) @ ph[5:8]) * (0.5 * phi - 1.0 * s - 0.0), rtol=1e-12, atol=1e-16)
+
+
+def test_pcg2019_rush_larsen_is_exact_for_gates_and_first_order(oracle):
+    """Rush–Larsen for the reference's PCG2019 (gates relax as (g∞ − g)/τ_g, cells/pcg2019.jl:96-118): a gate with frozen φₘ follows
+    g∞ + (g − g∞)e^{−Δt/τ}; for Δt → 0 the step tends to forward Euler at second order in Δt."""
+    o = oracle
+    p = o.cell_default_params(o.CELL_PCG2019)
+    u0 = o.cell_default_state(o.CELL_PCG2019, p)
+    u0 = u0 + np.array([25.0, -0.1, 0.2, -0.1, 0.05, 0.1, 0.2])
+    du = o.cell_rhs(o.CELL_PCG2019, p, u0)
+    dt = 0.5
+    u = u0.copy()
+    o.reaction_step_rl(o.CELL_PCG2019, p, u, 1, o.LAYOUT_SOA, dt=dt)
+    tau_m = p[3]
+    m_inf = u0[2] + du[2] * tau_m
+    np.testing.assert_allclose(u[2], m_inf + (u0[2] - m_inf) * np.exp(-dt / tau_m), rtol=1e-13)
+    np.testing.assert_allclose(u[0], u0[0] + dt * du[0], rtol=1e-15)        # φₘ by forward Euler
+    errs = []
+    for h in (1e-2, 5e-3):
+        a, b = u0.copy(), u0.copy()
+        o.reaction_step_rl(o.CELL_PCG2019, p, a, 1, o.LAYOUT_SOA, dt=h)
+        o.reaction_step(o.CELL_PCG2019, p, b, 1, o.LAYOUT_SOA, dt=h, want_du=False)
+        errs.append(np.abs(a - b).max())
+    assert errs[1] < 0.3 * errs[0]

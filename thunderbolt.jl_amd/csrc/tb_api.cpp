@@ -818,6 +818,7 @@ int tb_cell_model_info(int model, int *n_states, int *n_params, int *phi_index)
     case TB_CELL_ALIEV_PANFILOV: ns = 2; np = 6; pi = 1; break; // state order (s, φₘ): aliev-panfilov.jl:13
     case TB_CELL_PCG2019: ns = 7; np = 36; break;
     case TB_CELL_TT06: ns = 19; np = 48; break;
+    case TB_CELL_FHN_HETEROGENEOUS: ns = 2; np = 8; break;
     default: set_error("unknown cell model %d", model); return TB_ERR_BAD_ARG;
     }
     if (n_states) *n_states = ns;
@@ -832,6 +833,12 @@ int tb_cell_model_defaults(int model, double *params, double *u0)
     switch (model) {
     case TB_CELL_FHN: { // src/modeling/cells/fhn.jl:6-13
         const double d[6] = {0.1, 0.5, 1.0, 0.0, 0.01, 1.0};
+        memcpy(params, d, sizeof d);
+        if (u0) u0[0] = u0[1] = 0.0;
+        return TB_OK;
+    }
+    case TB_CELL_FHN_HETEROGENEOUS: { // docs/src/literate-howto/custom-ep-cell-model.jl:8-15: a, b, c, d, e ≡ 0.01 (no gradient)
+        const double d[8] = {0.1, 0.5, 1.0, 0.0, 0.01, 0.0, 0.0, 0.0};
         memcpy(params, d, sizeof d);
         if (u0) u0[0] = u0[1] = 0.0;
         return TB_OK;
@@ -877,8 +884,11 @@ int tb_cell_model_defaults(int model, double *params, double *u0)
 }
 
 static int reaction_step(const char *who, tb_device *dev, int model, const double *params, int n_params, double *d_u, double *d_du,
-                         int64_t n_points, int n_states, int layout, double t, double dt, int substeps, double threshold, double *rmax)
+                         int64_t n_points, int n_states, int layout, double t, double dt, int substeps, double threshold, double *rmax,
+                         const float *d_x = nullptr, int sdim = 0)
 {
+    TB_REQUIRE(model != TB_CELL_FHN_HETEROGENEOUS || d_x || n_points == 0, "%s: this cell model reads the point coordinate — pass d_x (tb_reaction_step_x)", who);
+    TB_REQUIRE(!d_x || (sdim >= 1 && sdim <= 3), "%s: sdim must be 1, 2 or 3 (got %d)", who, sdim);
     TB_REQUIRE(dev && params && (d_u || n_points == 0), "%s: NULL argument", who);
     int ns, np;
     int rc = tb_cell_model_info(model, &ns, &np, nullptr);
@@ -889,7 +899,13 @@ static int reaction_step(const char *who, tb_device *dev, int model, const doubl
     TB_REQUIRE(n_points >= 0, "%s: negative point count", who);
     if (n_points == 0) { if (rmax) *rmax = -__builtin_huge_val(); return TB_OK; }
     TB_HIP(hipSetDevice(dev->id));
-    return launch_reaction(dev, model, params, n_params, d_u, d_du, n_points, layout, t, dt, substeps, threshold, rmax);
+    return launch_reaction(dev, model, params, n_params, d_u, d_du, n_points, layout, t, dt, substeps, threshold, rmax, d_x, sdim);
+}
+
+int tb_reaction_step_x(tb_device *dev, int model, const double *params, int n_params, double *d_u, double *d_du, int64_t n_points, int n_states,
+                       int layout, const float *d_x, int sdim, double t, double dt, int substeps, double threshold)
+{
+    return reaction_step("tb_reaction_step_x", dev, model, params, n_params, d_u, d_du, n_points, n_states, layout, t, dt, substeps, threshold, nullptr, d_x, sdim);
 }
 
 int tb_reaction_step(tb_device *dev, int model, const double *params, int n_params, double *d_u, double *d_du,
@@ -916,7 +932,7 @@ int tb_reaction_step_rl(tb_device *dev, int model, const double *params, int n_p
     TB_REQUIRE(n_states == ns && n_params == np, "tb_reaction_step_rl: model has %d states / %d parameters, caller says %d / %d", ns, np, n_states, n_params);
     TB_REQUIRE(layout == TB_LAYOUT_SOA || layout == TB_LAYOUT_AOS, "tb_reaction_step_rl: unknown layout %d", layout);
     TB_REQUIRE(n_points >= 0, "tb_reaction_step_rl: negative point count");
-    if (n_points == 0) return model == TB_CELL_TT06 ? TB_OK : launch_reaction_rl(dev, model, params, n_params, d_u, 0, layout, t, dt);
+    if (n_points == 0) return launch_reaction_rl(dev, model, params, n_params, d_u, 0, layout, t, dt);
     TB_HIP(hipSetDevice(dev->id));
     return launch_reaction_rl(dev, model, params, n_params, d_u, n_points, layout, t, dt);
 }

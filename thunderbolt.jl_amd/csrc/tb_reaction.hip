@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "tb_internal.h"
 #include "tb_math.hpp"
@@ -50,7 +51,7 @@ template <> struct CellModel<TB_CELL_ALIEV_PANFILOV> {
 
 template <> struct CellModel<TB_CELL_PCG2019> {
     static constexpr int NS = 7, PHI = 0;
-    static constexpr bool HAS_GATES = false;
+    static constexpr bool HAS_GATES = true; // every state but φₘ relaxes as (g∞ − g)/τ_g (pcg2019.jl:96-118)
     // parameter slots follow the struct field order of pcg2019.jl:4-48
     enum { gNa, Em, km, taum, Eh, kh, dh, tauh0, gK1, Ez, kz, gto, Er, kr, Es, ks, taus, gCaL, Ed, kd, Ef, kf, tauf,
            gKr, Exr, kxr, tauxr, Ey, ky, gKs, Exs, kxs, tauxs, ENa, EK, ECa };
@@ -58,7 +59,13 @@ template <> struct CellModel<TB_CELL_PCG2019> {
     {
         return 1.0 / (1.0 + exp_b(sign * (phi - E) / k));
     }
-    __device__ __forceinline__ static void rhs(const CellParams &P, const double (&u)[NS], double, double (&du)[NS])
+    __device__ __forceinline__ static void rhs(const CellParams &P, const double (&u)[NS], double t, double (&du)[NS])
+    {
+        double rate[NS];
+        rhs_rates(P, u, t, du, rate);
+    }
+    // rate[k] = 1/τ of gate k (0 for φₘ): the Rush–Larsen step advances gates with the exact solution of their linear ODE for frozen φₘ
+    __device__ __forceinline__ static void rhs_rates(const CellParams &P, const double (&u)[NS], double, double (&du)[NS], double (&rate)[NS])
     {
         const double *p = P.p;
         const double phi = u[0], h = u[1], m = u[2], f = u[3], s = u[4], xs = u[5], xr = u[6];
@@ -82,6 +89,23 @@ template <> struct CellModel<TB_CELL_PCG2019> {
         du[4] = (sigmoid(phi, p[Es], p[ks], 1.0) - s) / p[taus];
         du[5] = (sigmoid(phi, p[Exs], p[kxs], -1.0) - xs) / p[tauxs];
         du[6] = (sigmoid(phi, p[Exr], p[kxr], -1.0) - xr) / p[tauxr];
+        rate[0] = 0.0; rate[1] = 1.0 / tau_h; rate[2] = 1.0 / p[taum]; rate[3] = 1.0 / p[tauf]; rate[4] = 1.0 / p[taus]; rate[5] = 1.0 / p[tauxs]; rate[6] = 1.0 / p[tauxr];
+    }
+};
+
+// HeterogeneousFHNModel of the reference's how-to (docs/src/literate-howto/custom-ep-cell-model.jl:8-56): FitzHugh–Nagumo whose recovery rate e
+// depends on the point's coordinate x — there a Julia closure e(x,t); closures cannot cross a C ABI, so the bound form is the
+// affine field e(x) = e₀ + g·x (parameters a, b, c, d, e₀, gₓ, g_y, g_z).  The one built-in model that reads `x` (partitioned_solver.jl:88-92).
+template <> struct CellModel<TB_CELL_FHN_HETEROGENEOUS> {
+    static constexpr int NS = 2, PHI = 0;
+    static constexpr bool HAS_GATES = false, USES_X = true;
+    __device__ __forceinline__ static void rhs_x(const CellParams &P, const double (&u)[NS], const float (&x)[3], double, double (&du)[NS])
+    {
+        const double a = P.p[0], b = P.p[1], c = P.p[2], d = P.p[3];
+        const double e = P.p[4] + P.p[5] * (double)x[0] + P.p[6] * (double)x[1] + P.p[7] * (double)x[2];
+        const double phi = u[0], s = u[1];
+        du[0] = phi * (1.0 - phi) * (phi - a) - s;
+        du[1] = e * (b * phi - c * s - d);
     }
 };
 
@@ -210,10 +234,22 @@ template <> struct CellModel<TB_CELL_TT06> {
     }
 };
 
+template <class M, class = void> struct uses_x : std::false_type {};
+template <class M> struct uses_x<M, std::enable_if_t<M::USES_X>> : std::true_type {};
+
+// cell_rhs!(du, u, x, t, p) (partitioned_solver.jl:88-92): x = the point's coordinate (Vec{sdim, Float32}, coordinate_systems.jl:43-49) for the
+// models that read it, nothing for the others
+template <class M>
+__device__ __forceinline__ void cell_rhs(const CellParams &P, const double (&u)[M::NS], const float (&x)[3], double t, double (&du)[M::NS])
+{
+    if constexpr (uses_x<M>::value) M::rhs_x(P, u, x, t, du);
+    else M::rhs(P, u, t, du);
+}
+
 template <int MODEL, int LAYOUT, bool WRITE_DU>
 __global__ void __launch_bounds__(256)
 k_reaction(CellParams P, double *__restrict__ u, double *__restrict__ du_out, int64_t n, double t, double dt, int substeps,
-           double threshold, unsigned long long *__restrict__ rmax_key)
+           double threshold, unsigned long long *__restrict__ rmax_key, const float *__restrict__ xs, int sdim)
 {
     using M = CellModel<MODEL>;
     constexpr int NS = M::NS;
@@ -223,7 +259,11 @@ k_reaction(CellParams P, double *__restrict__ u, double *__restrict__ du_out, in
         double ul[NS], dul[NS];
 #pragma unroll
         for (int j = 0; j < NS; ++j) ul[j] = LAYOUT == TB_LAYOUT_SOA ? u[i + j * n] : u[i * NS + j];
-        M::rhs(P, ul, t, dul);
+        float xp[3] = {0.0f, 0.0f, 0.0f};
+        if constexpr (uses_x<M>::value) {
+            if (xs) for (int d = 0; d < sdim; ++d) xp[d] = xs[i * sdim + d];
+        }
+        cell_rhs<M>(P, ul, xp, t, dul);
         if (substeps <= 1 || fabs(dul[M::PHI]) < threshold) {
 #pragma unroll
             for (int j = 0; j < NS; ++j) ul[j] += dt * dul[j];
@@ -232,7 +272,7 @@ k_reaction(CellParams P, double *__restrict__ u, double *__restrict__ du_out, in
 #pragma unroll
             for (int j = 0; j < NS; ++j) ul[j] += dts * dul[j];
             for (int s = 2; s <= substeps; ++s) {
-                M::rhs(P, ul, t + (s - 1) * dts, dul);
+                cell_rhs<M>(P, ul, xp, t + (s - 1) * dts, dul);
 #pragma unroll
                 for (int j = 0; j < NS; ++j) ul[j] += dts * dul[j];
             }
@@ -298,21 +338,27 @@ k_reaction_rl(CellParams P, double *__restrict__ u, int64_t n, double t, double 
 
 int launch_reaction_rl(tb_device *dev, int model, const double *params, int n_params, double *d_u, int64_t n, int layout, double t, double dt)
 {
-    if (model != TB_CELL_TT06) { set_error("Rush–Larsen step: cell model %d has no gate decomposition (only TB_CELL_TT06)", model); return TB_ERR_UNSUPPORTED; }
+    if (model != TB_CELL_TT06 && model != TB_CELL_PCG2019) {
+        set_error("Rush–Larsen step: cell model %d has no gate decomposition (TB_CELL_TT06 and TB_CELL_PCG2019 have)", model);
+        return TB_ERR_UNSUPPORTED;
+    }
     CellParams P{};
     for (int i = 0; i < n_params && i < 48; ++i) P.p[i] = params[i];
     int64_t nb = (n + 255) / 256;
     const int64_t cap = (int64_t)dev->n_cu * 16;
     if (nb > cap) nb = cap;
-    if (layout == TB_LAYOUT_SOA) hipLaunchKernelGGL((k_reaction_rl<TB_CELL_TT06, TB_LAYOUT_SOA>), dim3((unsigned)nb), dim3(256), 0, dev->stream, P, d_u, n, t, dt);
-    else hipLaunchKernelGGL((k_reaction_rl<TB_CELL_TT06, TB_LAYOUT_AOS>), dim3((unsigned)nb), dim3(256), 0, dev->stream, P, d_u, n, t, dt);
+    if (n == 0) return TB_OK;
+#define TB_RL(MODEL) do { if (layout == TB_LAYOUT_SOA) hipLaunchKernelGGL((k_reaction_rl<MODEL, TB_LAYOUT_SOA>), dim3((unsigned)nb), dim3(256), 0, dev->stream, P, d_u, n, t, dt); \
+                          else hipLaunchKernelGGL((k_reaction_rl<MODEL, TB_LAYOUT_AOS>), dim3((unsigned)nb), dim3(256), 0, dev->stream, P, d_u, n, t, dt); } while (0)
+    if (model == TB_CELL_TT06) TB_RL(TB_CELL_TT06); else TB_RL(TB_CELL_PCG2019);
+#undef TB_RL
     TB_HIP(hipGetLastError());
     return TB_OK;
 }
 
 template <int MODEL>
 static int run(tb_device *dev, const CellParams &P, double *u, double *du, int64_t n, int layout, double t, double dt, int substeps,
-               double thr, unsigned long long *rmax_key)
+               double thr, unsigned long long *rmax_key, const float *xs, int sdim)
 {
     const int bs = 256;
     int64_t nb = (n + bs - 1) / bs;
@@ -320,7 +366,7 @@ static int run(tb_device *dev, const CellParams &P, double *u, double *du, int64
     const int64_t cap = per_cu > 0 ? (int64_t)dev->n_cu * per_cu : nb;
     if (nb > cap) nb = cap;
     const dim3 grid((unsigned)nb), block(bs);
-#define TB_LAUNCH(L, W) hipLaunchKernelGGL((k_reaction<MODEL, L, W>), grid, block, 0, dev->stream, P, u, du, n, t, dt, substeps, thr, rmax_key)
+#define TB_LAUNCH(L, W) hipLaunchKernelGGL((k_reaction<MODEL, L, W>), grid, block, 0, dev->stream, P, u, du, n, t, dt, substeps, thr, rmax_key, xs, sdim)
     if (layout == TB_LAYOUT_SOA) { if (du) TB_LAUNCH(TB_LAYOUT_SOA, true); else TB_LAUNCH(TB_LAYOUT_SOA, false); }
     else { if (du) TB_LAUNCH(TB_LAYOUT_AOS, true); else TB_LAUNCH(TB_LAYOUT_AOS, false); }
 #undef TB_LAUNCH
@@ -329,7 +375,7 @@ static int run(tb_device *dev, const CellParams &P, double *u, double *du, int64
 }
 
 int launch_reaction(tb_device *dev, int model, const double *params, int n_params, double *d_u, double *d_du, int64_t n_points,
-                    int layout, double t, double dt, int substeps, double thr, double *rmax)
+                    int layout, double t, double dt, int substeps, double thr, double *rmax, const float *d_x, int sdim)
 {
     CellParams P{};
     for (int i = 0; i < n_params && i < 48; ++i) P.p[i] = params[i];
@@ -340,10 +386,11 @@ int launch_reaction(tb_device *dev, int model, const double *params, int n_param
     }
     int rc = TB_ERR_BAD_ARG;
     switch (model) {
-    case TB_CELL_FHN: rc = run<TB_CELL_FHN>(dev, P, d_u, d_du, n_points, layout, t, dt, substeps, thr, key); break;
-    case TB_CELL_ALIEV_PANFILOV: rc = run<TB_CELL_ALIEV_PANFILOV>(dev, P, d_u, d_du, n_points, layout, t, dt, substeps, thr, key); break;
-    case TB_CELL_PCG2019: rc = run<TB_CELL_PCG2019>(dev, P, d_u, d_du, n_points, layout, t, dt, substeps, thr, key); break;
-    case TB_CELL_TT06: rc = run<TB_CELL_TT06>(dev, P, d_u, d_du, n_points, layout, t, dt, substeps, thr, key); break;
+    case TB_CELL_FHN: rc = run<TB_CELL_FHN>(dev, P, d_u, d_du, n_points, layout, t, dt, substeps, thr, key, d_x, sdim); break;
+    case TB_CELL_ALIEV_PANFILOV: rc = run<TB_CELL_ALIEV_PANFILOV>(dev, P, d_u, d_du, n_points, layout, t, dt, substeps, thr, key, d_x, sdim); break;
+    case TB_CELL_PCG2019: rc = run<TB_CELL_PCG2019>(dev, P, d_u, d_du, n_points, layout, t, dt, substeps, thr, key, d_x, sdim); break;
+    case TB_CELL_TT06: rc = run<TB_CELL_TT06>(dev, P, d_u, d_du, n_points, layout, t, dt, substeps, thr, key, d_x, sdim); break;
+    case TB_CELL_FHN_HETEROGENEOUS: rc = run<TB_CELL_FHN_HETEROGENEOUS>(dev, P, d_u, d_du, n_points, layout, t, dt, substeps, thr, key, d_x, sdim); break;
     default: set_error("unknown cell model %d", model); return TB_ERR_BAD_ARG;
     }
     if (rc || !rmax) return rc;
