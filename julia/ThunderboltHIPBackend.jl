@@ -1,22 +1,27 @@
-# ThunderboltHIPBackend.jl — the reference-side binding a Thunderbolt.jl maintainer would add (as a package
-# extension next to ext/CuThunderboltExt.jl) to use libtbhip.so as an `AbstractGPUDevice` backend.
+# ThunderboltHIPBackend.jl — the reference-side binding a Thunderbolt.jl maintainer would add (as a package extension next to
+# ext/CuThunderboltExt.jl) to use libtbhip.so as an `AbstractGPUDevice` backend for the assembly + reaction hot path.
 #
-# NOT executed in the build container (no Julia toolchain there).  It is kept thin on purpose and mirrors
-# thunderbolt.jl_amd/api.py call for call; every `ccall` below targets a symbol declared in include/tbhip.h.
+# NOT executed in the build container (no Julia toolchain there; stated in DESIGN.md and INTEGRATION.md).  Every `ccall` targets a symbol
+# declared in include/tbhip.h with the argument order of that header; tests/abi_driver.c exercises the same entry points in the same order
+# from C, and thunderbolt.jl_amd/api.py is the executable mirror.
 module ThunderboltHIPBackend
 
-using Thunderbolt, Ferrite, SparseArrays, SparseMatricesCSR
-import Thunderbolt: AbstractGPUDevice, AbstractAssemblyStrategy, setup_operator, update_operator!,
-    _pointwise_step_outer_kernel!, create_system_vector, create_system_matrix, value_type, index_type,
-    AbstractPointwiseSolverCache, PointwiseODEFunction, num_states, BilinearMassIntegrator,
-    BilinearDiffusionIntegrator, LinearIntegrator
+using Thunderbolt, Ferrite, Tensors, SparseArrays, SparseMatricesCSR, LinearAlgebra
+import LinearAlgebra: mul!
+import Thunderbolt: AbstractGPUDevice, AbstractAssemblyStrategy, AbstractSolver, AbstractSemidiscreteFunction, setup_operator,
+    update_operator!, update_linearization!, residual!, add!, needs_update, _pointwise_step_outer_kernel!, create_system_vector,
+    create_system_matrix, __add_to_vector!, adapt_vector_type, value_type, index_type, solution_size, AbstractPointwiseSolverCache,
+    AbstractPointwiseFunction, num_states, BilinearMassIntegrator, BilinearDiffusionIntegrator, LinearIntegrator, ConstantCoefficient,
+    FieldCoefficient, ConductivityToDiffusivityCoefficient, SpectralTensorCoefficient, OrthotropicMicrostructure,
+    TransverselyIsotropicMicrostructure, OrthotropicMicrostructureModel, PerColorAssemblyStrategy, ElementAssemblyStrategy,
+    QuasiStaticModel, PK1Model, HolzapfelOgden2009Model
 
 const libtbhip = get(ENV, "TBHIP_LIBRARY", "libtbhip.so")
 
 check(rc::Cint) = rc == 0 ? nothing :
     error("libtbhip error $rc: " * unsafe_string(ccall((:tb_last_error_string, libtbhip), Cstring, ())))
 
-# ---------------------------------------------------------------- device (replaces FerriteOperators.CudaDevice)
+# ---------------------------------------------------------------- device (replaces FerriteOperators.CudaDevice, ext/CuThunderboltExt.jl:48-49)
 mutable struct MI355XDevice{Tv, Ti} <: AbstractGPUDevice
     handle::Ptr{Cvoid}
     function MI355XDevice{Tv, Ti}(id::Integer = 0) where {Tv, Ti}
@@ -31,22 +36,36 @@ MI355XDevice(id = 0) = MI355XDevice{Float64, Int32}(id)
 value_type(::MI355XDevice{Tv}) where {Tv} = Tv
 index_type(::MI355XDevice{Tv, Ti}) where {Tv, Ti} = Ti
 
-# device vector: GC-managed wrapper, finaliser calls tb_free
-mutable struct HIPVector{T} <: AbstractVector{T}
+# ---------------------------------------------------------------- vectors: an opaque, GC-managed device buffer (finaliser → tb_free).
+# Deliberately NOT an AbstractVector: there is no scalar indexing on the device, and the solvers that consume it are the library's own
+# (tb_cg_solve …), reached through the methods below — not LinearSolve's generic fallbacks.
+mutable struct HIPVector{T}
     dev::MI355XDevice
     ptr::Ptr{T}
     n::Int
-    function HIPVector{T}(dev, n) where {T}
+    function HIPVector{T}(dev::MI355XDevice, n::Integer) where {T}
         p = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:tb_malloc, libtbhip), Cint, (Ptr{Cvoid}, Csize_t, Ref{Ptr{Cvoid}}), dev.handle, n * sizeof(T), p))
         v = new{T}(dev, Ptr{T}(p[]), n)
         finalizer(x -> ccall((:tb_free, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), x.dev.handle, x.ptr), v)
-        return v
+        return fill!(v, zero(T))
     end
 end
-Base.size(v::HIPVector) = (v.n,)
+Base.length(v::HIPVector) = v.n
+Base.eltype(::HIPVector{T}) where {T} = T
+Base.similar(v::HIPVector{T}) where {T} = HIPVector{T}(v.dev, v.n)
+function Base.fill!(v::HIPVector{T}, x) where {T}
+    iszero(x) || error("HIPVector: only zero-fill is provided")
+    check(ccall((:tb_memset, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Csize_t), v.dev.handle, v.ptr, 0, v.n * sizeof(T)))
+    return v
+end
 function Base.copyto!(v::HIPVector{T}, a::Vector{T}) where {T}
+    length(a) == v.n || throw(DimensionMismatch())
     check(ccall((:tb_memcpy_h2d, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), v.dev.handle, v.ptr, a, sizeof(a)))
+    return v
+end
+function Base.copyto!(v::HIPVector{T}, w::HIPVector{T}) where {T}
+    check(ccall((:tb_memcpy_d2d, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), v.dev.handle, v.ptr, w.ptr, v.n * sizeof(T)))
     return v
 end
 function Base.Vector(v::HIPVector{T}) where {T}
@@ -54,47 +73,92 @@ function Base.Vector(v::HIPVector{T}) where {T}
     check(ccall((:tb_memcpy_d2h, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), v.dev.handle, a, v.ptr, sizeof(a)))
     return a
 end
-# ext/CuThunderboltExt.jl:126-127
-create_system_vector(::Type{<:HIPVector{T}}, dev::MI355XDevice, n::Integer) where {T} = HIPVector{T}(dev, n)
+HIPVector(dev::MI355XDevice, a::Vector{T}) where {T} = copyto!(HIPVector{T}(dev, length(a)), a)
 
-# ---------------------------------------------------------------- strategies (src/Thunderbolt.jl:22-32)
+# the device a vector type lives on: one process drives one GPU (one rank per GPU under torch.distributed / MPI)
+const CURRENT_DEVICE = Ref{Union{Nothing, MI355XDevice}}(nothing)
+current_device() = something(CURRENT_DEVICE[], (CURRENT_DEVICE[] = MI355XDevice(); CURRENT_DEVICE[]))
+
+# ext/CuThunderboltExt.jl:126-127
+create_system_vector(::Type{<:HIPVector{T}}, f::AbstractSemidiscreteFunction) where {T} = HIPVector{T}(current_device(), solution_size(f))
+create_system_vector(::Type{<:HIPVector{T}}, dh::DofHandler) where {T} = HIPVector{T}(current_device(), ndofs(dh))
+# ext/CuThunderboltExt.jl:141-146
+__add_to_vector!(b::Vector, a::HIPVector) = b .+= Vector(a)
+function __add_to_vector!(b::HIPVector{T}, a::Vector{T}) where {T}
+    tmp = HIPVector(b.dev, a)
+    check(ccall((:tb_axpy, libtbhip), Cint, (Ptr{Cvoid}, Int64, Cdouble, Ptr{T}, Ptr{T}), b.dev.handle, b.n, 1.0, tmp.ptr, b.ptr))
+    return b
+end
+adapt_vector_type(::Type{<:HIPVector}, v::Vector) = HIPVector(current_device(), v)
+
+# ---------------------------------------------------------------- strategies (src/Thunderbolt.jl:22-32): the reference's own strategy types carry the
+# device; the patch strategy is this backend's addition
 struct PatchAssemblyStrategy{D <: MI355XDevice} <: AbstractAssemblyStrategy
     device::D
 end
-strategy_code(::Thunderbolt.PerColorAssemblyStrategy) = Cint(1)
-strategy_code(::Thunderbolt.ElementAssemblyStrategy) = Cint(2)
-strategy_code(::PatchAssemblyStrategy) = Cint(3)
+const HIPStrategy = Union{PatchAssemblyStrategy, PerColorAssemblyStrategy{<:MI355XDevice}, ElementAssemblyStrategy{<:MI355XDevice}}
+strategy_code(::PerColorAssemblyStrategy) = Cint(1)      # TB_STRATEGY_PER_COLOR
+strategy_code(::ElementAssemblyStrategy) = Cint(2)       # TB_STRATEGY_ELEMENT
+strategy_code(::PatchAssemblyStrategy) = Cint(3)         # TB_STRATEGY_PATCH
 
-# ---------------------------------------------------------------- mesh + dof table: Ferrite's own arrays go over as they are
-struct DeviceMesh
-    handle::Ptr{Cvoid}
+# ---------------------------------------------------------------- mesh, dof table, pattern: Ferrite's own arrays go over as they are, once per DofHandler
+# (all operators of one DofHandler share one sparsity pattern, src/solver/time/euler.jl:110-116, newmark.jl:105-110)
+mutable struct DeviceDofHandler
+    dev::MI355XDevice
+    mesh::Ptr{Cvoid}
+    pattern::Ptr{Cvoid}
+    nnz::Int
+    size::Tuple{Int, Int}
+    cpu_pattern::SparseMatrixCSR{1, Float64, Int64}   # kept for hosts that want rowptr / colval on the CPU side
 end
-function DeviceMesh(dev::MI355XDevice, dh::DofHandler)
+const DOFHANDLERS = IdDict{Any, DeviceDofHandler}()
+
+function DeviceDofHandler(dev::MI355XDevice, dh::DofHandler)
+    haskey(DOFHANDLERS, dh) && return DOFHANDLERS[dh]
     grid = Ferrite.get_grid(dh)
     sdh = only(dh.subdofhandlers)                       # one subdomain, one field (SURVEY §8b)
     sdim = Ferrite.getspatialdim(grid)
-    xyz = sdim == 3 ? collect(reinterpret(Float64, [n.x for n in grid.nodes])) :        # AoS, 3 per node
-          Float64[i <= 2 ? n.x[i] : 0.0 for n in grid.nodes for i in 1:3]               # 2-D meshes travel with z = 0 (TB_QUAD4)
-    conn = Int32[v for c in grid.cells for v in c.nodes]          # 1-based
-    ndpc = Ferrite.ndofs_per_cell(sdh)
-    celldofs = Int32.(dh.cell_dofs)                               # dh.cell_dofs / cell_dofs_offset, src/utils.jl:52-56
+    xyz = Float64[i <= sdim ? n.x[i] : 0.0 for n in grid.nodes for i in 1:3]           # AoS, 3 per node; 2-D meshes travel with z = 0 (TB_QUAD4)
+    conn = Int32[v for c in grid.cells for v in c.nodes]                                # 1-based
+    celldofs = Int32.(dh.cell_dofs)                                                     # dh.cell_dofs / cell_dofs_offset, src/utils.jl:52-56
     kind = grid.cells[1] isa Quadrilateral ? Cint(2) : grid.cells[1] isa Hexahedron ? Cint(3) : Cint(4)   # TB_QUAD4 / TB_HEX8 / TB_TET4
-    order = Ferrite.getorder(Ferrite.getfieldinterpolation(sdh, first(sdh.field_names)))
-    fkind = (kind == 3 && order == 2) ? Cint(5) : kind            # TB_HEX27
-    ncomp = Ferrite.n_components(Ferrite.getfieldinterpolation(sdh, first(sdh.field_names)))
-    h = Ref{Ptr{Cvoid}}(C_NULL)
+    ip = Ferrite.getfieldinterpolation(sdh, first(sdh.field_names))
+    fkind = (kind == 3 && Ferrite.getorder(ip) == 2) ? Cint(5) : kind                  # TB_HEX27
+    ncomp = Ferrite.n_components(ip)
+    mesh = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:tb_mesh_create, libtbhip), Cint,
         (Ptr{Cvoid}, Cint, Int64, Ptr{Float64}, Int64, Ptr{Int32}, Cint, Cint, Ptr{Int32}, Int64, Cint, Ref{Ptr{Cvoid}}),
-        dev.handle, kind, length(grid.nodes), xyz, length(grid.cells), conn, fkind, ncomp, celldofs, ndofs(dh), 1, h))
-    return DeviceMesh(h[])
+        dev.handle, kind, length(grid.nodes), xyz, length(grid.cells), conn, fkind, ncomp, celldofs, ndofs(dh), 1, mesh))
+    A = SparseMatrixCSR(transpose(allocate_matrix(dh)))                                 # src/solver/interface.jl:162-168
+    pat = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:tb_pattern_create, libtbhip), Cint, (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int32}, Cint, Ref{Ptr{Cvoid}}),
+        mesh[], size(A, 1), Int64.(A.rowptr), Int32.(A.colval), 1, pat))
+    ddh = DeviceDofHandler(dev, mesh[], pat[], nnz(A), size(A), A)
+    finalizer(ddh) do d
+        ccall((:tb_pattern_destroy, libtbhip), Cint, (Ptr{Cvoid},), d.pattern)
+        ccall((:tb_mesh_destroy, libtbhip), Cint, (Ptr{Cvoid},), d.mesh)
+    end
+    return DOFHANDLERS[dh] = ddh
 end
 
-# CSR pattern of transpose(allocate_matrix(dh)) (src/solver/interface.jl:162-168)
-function device_pattern(mesh::DeviceMesh, A::SparseMatrixCSR{1, Tv, Ti}) where {Tv, Ti}
-    h = Ref{Ptr{Cvoid}}(C_NULL)
-    check(ccall((:tb_pattern_create, libtbhip), Cint, (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int32}, Cint, Ref{Ptr{Cvoid}}),
-        mesh.handle, size(A, 1), Int64.(A.rowptr), Int32.(A.colval), 1, h))
-    return h[]
+# device CSR matrix: the shared pattern + one nzval vector (rowptr / colval stay inside the library: tb_pattern_{rowptr,colidx}_device)
+struct HIPSparseMatrixCSR{Tv}
+    ddh::DeviceDofHandler
+    nzval::HIPVector{Tv}
+end
+Base.size(A::HIPSparseMatrixCSR) = A.ddh.size
+SparseArrays.nnz(A::HIPSparseMatrixCSR) = A.ddh.nnz
+SparseArrays.nonzeros(A::HIPSparseMatrixCSR) = A.nzval
+# ext/CuThunderboltExt.jl:129-139
+function create_system_matrix(::Type{<:HIPSparseMatrixCSR{Tv}}, dh::DofHandler) where {Tv}
+    ddh = DeviceDofHandler(current_device(), dh)
+    return HIPSparseMatrixCSR{Tv}(ddh, HIPVector{Tv}(ddh.dev, ddh.nnz))
+end
+# y = α·A·x + β·y (src/utils.jl:185-231)
+function mul!(y::HIPVector{Tv}, A::HIPSparseMatrixCSR{Tv}, x::HIPVector{Tv}, α::Number = true, β::Number = false) where {Tv}
+    check(ccall((:tb_spmv_csr, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Tv}, Ptr{Tv}, Cdouble, Cdouble, Ptr{Tv}),
+        A.ddh.pattern, A.nzval.ptr, x.ptr, α, β, y.ptr))
+    return y
 end
 
 # ---------------------------------------------------------------- coefficients → tb_coef (closures cannot cross the ABI, SURVEY F10)
@@ -103,37 +167,130 @@ struct TbCoef
     p::NTuple{16, Float64}; field::Ptr{Float64}; field_len::Int64
 end
 pad16(v) = ntuple(i -> i <= length(v) ? Float64(v[i]) : 0.0, 16)
-lower(c::ConstantCoefficient{<:Real}) = TbCoef(0, 0, 1.0, 1.0, pad16((c.val,)), C_NULL, 0)
-lower(c::ConstantCoefficient{<:Tensors.AbstractTensor{2, 3}}) = TbCoef(1, 0, 1.0, 1.0, pad16(vec(Matrix(c.val)')), C_NULL, 0)
-function lower(c::Thunderbolt.ConductivityToDiffusivityCoefficient)       # κ/(Cₘχ), coefficients.jl:152-162
-    k = lower(c.conductivity_tensor_coefficient)
-    return TbCoef(k.kind, 1, c.capacitance_coefficient.val, c.χ_coefficient.val, k.p, k.field, k.field_len)
+v3(x::Vec{3}) = (x[1], x[2], x[3])
+v3(x::Vec{2}) = (x[1], x[2], 0.0)
+# returns (TbCoef, keepalive): the field array must outlive tb_form_create, which copies it
+lower(c::ConstantCoefficient{<:Real}) = (TbCoef(0, 0, 1.0, 1.0, pad16((c.val,)), C_NULL, 0), nothing)                     # TB_COEF_CONST_SCALAR
+function lower(c::ConstantCoefficient{<:Tensors.SecondOrderTensor})                                                         # TB_COEF_CONST_TENSOR, row-major 3×3
+    D = zeros(3, 3); d = size(c.val, 1); D[1:d, 1:d] .= Matrix(c.val)
+    return (TbCoef(1, 0, 1.0, 1.0, pad16(vec(permutedims(D))), C_NULL, 0), nothing)
 end
-# SpectralTensorCoefficient of constant / nodal f,s,n: kinds 3, 4, 5 — same lowering as thunderbolt.jl_amd/api.py:_lower_coef
+function lower(c::FieldCoefficient)                                                                                         # TB_COEF_FIELD_SCALAR, field[basis + nb·cell]
+    data = Float64.(vec(c.elementwise_data.data))
+    return (TbCoef(2, 0, 1.0, 1.0, pad16(()), pointer(data), length(data)), data)
+end
+function lower(c::SpectralTensorCoefficient)
+    λ = c.eigenvalues isa ConstantCoefficient ? Tuple(c.eigenvalues.val) : error("spectral coefficient: constant eigenvalues only")
+    ev = c.eigenvectors
+    if ev isa ConstantCoefficient{<:OrthotropicMicrostructure}                                                              # TB_COEF_SPECTRAL_CONST: f, s, n, λ
+        m = ev.val
+        return (TbCoef(3, 0, 1.0, 1.0, pad16((v3(m.f)..., v3(m.s)..., v3(m.n)..., λ...)), C_NULL, 0), nothing)
+    elseif ev isa ConstantCoefficient{<:TransverselyIsotropicMicrostructure}                                                # TB_COEF_TRANSVERSE_CONST: f, λ₁, λ₂
+        return (TbCoef(5, 0, 1.0, 1.0, pad16((v3(ev.val.f)..., λ[1], λ[2])), C_NULL, 0), nothing)
+    elseif ev isa OrthotropicMicrostructureModel                                                                            # TB_COEF_SPECTRAL_FIELD: per cell, per basis f, s, n
+        f, s, n = ev.fiber_coefficient.elementwise_data.data, ev.sheetlet_coefficient.elementwise_data.data, ev.normal_coefficient.elementwise_data.data
+        data = Float64[x for k in eachindex(f) for vec3 in (f[k], s[k], n[k]) for x in v3(vec3)]                            # cell-major (ElementwiseData, collections.jl:195-233)
+        return (TbCoef(4, 0, 1.0, 1.0, pad16(λ), pointer(data), length(data)), data)
+    end
+    error("spectral coefficient over $(typeof(ev)) is not lowered")
+end
+function lower(c::ConductivityToDiffusivityCoefficient)                                                                     # κ/(Cₘχ), coefficients.jl:152-162
+    k, keep = lower(c.conductivity_tensor_coefficient)
+    return (TbCoef(k.kind, 1, c.capacitance_coefficient.val, c.χ_coefficient.val, k.p, k.field, k.field_len), keep)
+end
 
-# ---------------------------------------------------------------- operators (src/solver/interface.jl:17-94, euler.jl:172-176)
+# ---------------------------------------------------------------- operators (src/solver/interface.jl:17-94, euler.jl:143-176)
 mutable struct HIPBilinearOperator{Tv}
-    form::Ptr{Cvoid}; pattern::Ptr{Cvoid}; strategy::Cint
-    A::HIPVector{Tv}                    # nzval of op.A; rowptr/colval via tb_pattern_{rowptr,colidx}_device
+    form::Ptr{Cvoid}
+    strategy::Cint
+    A::HIPSparseMatrixCSR{Tv}            # op.A (euler.jl:112-114)
+    is_mass::Bool
 end
-function setup_operator(strategy::Union{PatchAssemblyStrategy, Thunderbolt.PerColorAssemblyStrategy{<:MI355XDevice}},
-        integrator::Union{BilinearMassIntegrator, BilinearDiffusionIntegrator}, dh::DofHandler)
-    dev = strategy.device
-    mesh = DeviceMesh(dev, dh)
-    A = SparseMatrixCSR(transpose(allocate_matrix(dh)))
-    pat = device_pattern(mesh, A)
-    coef = Ref(lower(integrator isa BilinearMassIntegrator ? integrator.ρ : integrator.D))
+function setup_operator(strategy::HIPStrategy, integrator::Union{BilinearMassIntegrator, BilinearDiffusionIntegrator}, dh::DofHandler)
+    ddh = DeviceDofHandler(strategy.device, dh)
+    coef, keep = lower(integrator isa BilinearMassIntegrator ? integrator.ρ : integrator.D)
     form = Ref{Ptr{Cvoid}}(C_NULL)
-    check(ccall((:tb_form_create, libtbhip), Cint, (Ptr{Cvoid}, Cint, Cint, Ref{TbCoef}, Ref{Ptr{Cvoid}}),
-        mesh.handle, integrator isa BilinearMassIntegrator ? 0 : 1, 0, coef, form))
-    return HIPBilinearOperator{Float64}(form[], pat, strategy_code(strategy), HIPVector{Float64}(dev, nnz(A)))
+    GC.@preserve keep check(ccall((:tb_form_create, libtbhip), Cint, (Ptr{Cvoid}, Cint, Cint, Ref{TbCoef}, Ref{Ptr{Cvoid}}),
+        ddh.mesh, integrator isa BilinearMassIntegrator ? 0 : 1, 0, Ref(coef), form))
+    Tv = value_type(strategy.device)
+    op = HIPBilinearOperator{Tv}(form[], strategy_code(strategy), HIPSparseMatrixCSR{Tv}(ddh, HIPVector{Tv}(ddh.dev, ddh.nnz)), integrator isa BilinearMassIntegrator)
+    finalizer(o -> ccall((:tb_form_destroy, libtbhip), Cint, (Ptr{Cvoid},), o.form), op)
+    return op
 end
+# the 4-argument form the solvers call (interface.jl:66-94): the solver's system_matrix_type is this backend's CSR type already
+setup_operator(strategy::HIPStrategy, integrator::Union{BilinearMassIntegrator, BilinearDiffusionIntegrator}, ::AbstractSolver, dh::DofHandler) =
+    setup_operator(strategy, integrator, dh)
+
 update_operator!(op::HIPBilinearOperator, t) =
     check(ccall((:tb_assemble_matrix, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Float64, Ptr{Float64}),
-        op.form, op.pattern, op.strategy, t, op.A.ptr))
-# linear operators: tb_form_create(kind = 2, TB_SRC_* id or TB_SRC_TABULATED + tb_form_set_table(f.(x_q, t))) and
-# update_operator!(op, t) = tb_assemble_vector(form, strategy, t, op.b.ptr); needs_update stays host-side
-# (src/discretization/operator.jl:17-26).
+        op.form, op.A.ddh.pattern, op.strategy, t, op.A.nzval.ptr))
+# update_operator!(mass, t); update_operator!(diffusion, t) of the heat stage's set-up (euler.jl:172-176) in one pass over the mesh
+function update_operators!(M::HIPBilinearOperator, K::HIPBilinearOperator, t)
+    (M.is_mass && !K.is_mass && M.A.ddh === K.A.ddh) || (update_operator!(M, t); update_operator!(K, t); return nothing)
+    check(ccall((:tb_assemble_matrix_pair, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Float64, Ptr{Float64}, Ptr{Float64}),
+        M.form, K.form, M.A.ddh.pattern, M.strategy, t, M.A.nzval.ptr, K.A.nzval.ptr))
+end
+mul!(y::HIPVector, op::HIPBilinearOperator, x::HIPVector, α::Number = true, β::Number = false) = mul!(y, op.A, x, α, β)   # mul!(b, M, uₙ₋₁), euler.jl:85
+
+# linear operators: the source closure f(x, t) is evaluated on the host at every quadrature point and uploaded (TB_SRC_TABULATED)
+mutable struct HIPLinearOperator{Tv, F, IV}
+    form::Ptr{Cvoid}
+    strategy::Cint
+    b::HIPVector{Tv}                     # op.b (test/gpu/test_operators.jl:30)
+    f::F                                 # (x, t) -> value
+    nonzero_intervals::IV
+    xq::Vector{Vec{3, Float64}}          # quadrature-point coordinates, [q + nq·(cell − 1)]
+end
+function setup_operator(strategy::HIPStrategy, integrator::LinearIntegrator, dh::DofHandler)
+    ddh = DeviceDofHandler(strategy.device, dh)
+    protocol = integrator.integrand                      # AnalyticalTransmembraneStimulationProtocol(f, nonzero_intervals), electrophysiology.jl:260-283
+    sdh = only(dh.subdofhandlers)
+    ip = Ferrite.getfieldinterpolation(sdh, first(sdh.field_names))
+    qr = QuadratureRule{Ferrite.getrefshape(ip)}(max(2 * Ferrite.getorder(ip) - 1, 2))                 # fem.jl:52-55
+    gip = Ferrite.geometric_interpolation(typeof(Ferrite.get_grid(dh).cells[1]))
+    xq = Vec{3, Float64}[]
+    for cell in CellIterator(sdh)
+        X = getcoordinates(cell)
+        for ξ in Ferrite.getpoints(qr)
+            x = sum(Ferrite.reference_shape_value(gip, ξ, a) * X[a] for a in 1:length(X))
+            push!(xq, Vec{3, Float64}(i -> i <= length(x) ? x[i] : 0.0))
+        end
+    end
+    coef = TbCoef(3, 0, 1.0, 1.0, pad16(()), C_NULL, 0)                                                # TB_SRC_TABULATED
+    form = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:tb_form_create, libtbhip), Cint, (Ptr{Cvoid}, Cint, Cint, Ref{TbCoef}, Ref{Ptr{Cvoid}}), ddh.mesh, 2, 0, Ref(coef), form))
+    Tv = value_type(strategy.device)
+    op = HIPLinearOperator(form[], strategy_code(strategy), HIPVector{Tv}(ddh.dev, ndofs(dh)), protocol.f.f, protocol.nonzero_intervals, xq)
+    finalizer(o -> ccall((:tb_form_destroy, libtbhip), Cint, (Ptr{Cvoid},), o.form), op)
+    return op
+end
+setup_operator(strategy::HIPStrategy, integrator::LinearIntegrator, ::AbstractSolver, dh::DofHandler) = setup_operator(strategy, integrator, dh)
+needs_update(op::HIPLinearOperator, t) = any(iv -> iv[1] <= t <= iv[2], op.nonzero_intervals)          # src/discretization/operator.jl:17-26
+function update_operator!(op::HIPLinearOperator, t)
+    table = Float64[op.f(x, t) for x in op.xq]
+    check(ccall((:tb_form_set_table, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64), op.form, table, length(table)))
+    check(ccall((:tb_assemble_vector, libtbhip), Cint, (Ptr{Cvoid}, Cint, Float64, Ptr{Float64}), op.form, op.strategy, t, op.b.ptr))
+end
+function add!(b::HIPVector{Tv}, op::HIPLinearOperator{Tv}) where {Tv}                                   # add!(b, source), euler.jl:90
+    check(ccall((:tb_axpy, libtbhip), Cint, (Ptr{Cvoid}, Int64, Cdouble, Ptr{Tv}, Ptr{Tv}), b.dev.handle, b.n, 1.0, op.b.ptr, b.ptr))
+    return b
+end
+
+# ---------------------------------------------------------------- heat stage algebra and solve (euler.jl:71-116)
+# _implicit_euler_heat_solver_update_system_matrix!: Anz = Mnz − Δt·Knz
+function Thunderbolt._implicit_euler_heat_solver_update_system_matrix!(A::HIPSparseMatrixCSR, M::HIPBilinearOperator, K::HIPBilinearOperator, Δt)
+    check(ccall((:tb_heat_matrix, libtbhip), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Cdouble, Ptr{Float64}),
+        A.ddh.dev.handle, A.ddh.nnz, M.A.nzval.ptr, K.A.nzval.ptr, Δt, A.nzval.ptr))
+end
+# the linear solve of the stage for device matrices: Jacobi-CG inside the library (KrylovJL_CG(atol, rtol) in the tutorials); converged iff the
+# residual met the solver's own stopping threshold
+function solve_heat_system!(u::HIPVector, A::HIPSparseMatrixCSR, b::HIPVector; rtol = 1e-5, atol = 1e-6, maxiter = 1000, reuse_diagonal = false)
+    iters = Ref{Cint}(0); res = Ref{Cdouble}(0.0); tol = Ref{Cdouble}(0.0)
+    check(ccall((:tb_cg_solve, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cdouble, Cdouble, Cint, Cint, Ref{Cint}, Ref{Cdouble}),
+        A.ddh.pattern, A.nzval.ptr, b.ptr, u.ptr, rtol, atol, maxiter, reuse_diagonal ? 2 : 1, iters, res))
+    check(ccall((:tb_solver_last_tolerance, libtbhip), Cint, (Ptr{Cvoid}, Ref{Cdouble}), A.ddh.pattern, tol))
+    return res[] <= tol[], Int(iters[])
+end
 
 # ---------------------------------------------------------------- pointwise reaction step, dispatched on the vector type
 # (src/solver/time/partitioned_solver.jl:38-44, ext/CuThunderboltExt.jl:111-117)
@@ -142,16 +299,22 @@ model_id(::Thunderbolt.ParametrizedAlievPanfilovModel) = Cint(1)
 model_id(::Thunderbolt.ParametrizedPCG2019Model) = Cint(2)
 params(m) = Float64[getfield(m, f) for f in fieldnames(typeof(m))]      # struct field order == ABI parameter order
 
-function _pointwise_step_outer_kernel!(f::PointwiseODEFunction, t::Real, Δt::Real,
-        cache::AbstractPointwiseSolverCache, u::HIPVector)
+function _pointwise_step_outer_kernel!(f::AbstractPointwiseFunction, t::Real, Δt::Real, cache::AbstractPointwiseSolverCache, u::HIPVector)
     p = params(f.ode)
-    npoints = length(f.associated_states) ÷ num_states(f.ode)
     substeps = hasproperty(cache, :substeps) ? cache.substeps : 1
     threshold = hasproperty(cache, :reaction_threshold) ? cache.reaction_threshold : 0.0
-    rc = ccall((:tb_reaction_step, libtbhip), Cint,
-        (Ptr{Cvoid}, Cint, Ptr{Float64}, Cint, Ptr{Float64}, Ptr{Float64}, Int64, Cint, Cint, Float64, Float64, Cint, Float64),
-        u.dev.handle, model_id(f.ode), p, length(p), cache.uₙ.ptr, cache.du.ptr, npoints, num_states(f.ode),
-        0 #= StateBlockedLayout, fem.jl:385-408 =#, t, Δt, substeps, threshold)
+    du = cache.du === nothing ? Ptr{Float64}(C_NULL) : cache.du.ptr
+    xs = cache.xs                                                        # Vector{Vec{sdim, Float32}} uploaded as an HIPVector{Float32}, or nothing
+    if xs === nothing
+        rc = ccall((:tb_reaction_step, libtbhip), Cint,
+            (Ptr{Cvoid}, Cint, Ptr{Float64}, Cint, Ptr{Float64}, Ptr{Float64}, Int64, Cint, Cint, Float64, Float64, Cint, Float64),
+            u.dev.handle, model_id(f.ode), p, length(p), cache.uₙ.ptr, du, f.npoints, num_states(f.ode),
+            0 #= StateBlockedLayout, fem.jl:385-408 =#, t, Δt, substeps, threshold)
+    else
+        rc = ccall((:tb_reaction_step_x, libtbhip), Cint,
+            (Ptr{Cvoid}, Cint, Ptr{Float64}, Cint, Ptr{Float64}, Ptr{Float64}, Int64, Cint, Cint, Ptr{Float32}, Cint, Float64, Float64, Cint, Float64),
+            u.dev.handle, model_id(f.ode), p, length(p), cache.uₙ.ptr, du, f.npoints, num_states(f.ode), 0, xs.ptr, xs.n ÷ f.npoints, t, Δt, substeps, threshold)
+    end
     return rc == 0
 end
 
@@ -161,18 +324,12 @@ function reaction_tangent(dev::MI355XDevice, dumat_phi::Ptr{Float64}, npoints::I
     check(ccall((:tb_max, libtbhip), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}, Int64, Ref{Float64}), dev.handle, npoints, dumat_phi, stride, R))
     return R[]
 end
-# … or fused into the step itself (no dumat needed): tb_reaction_step_rtc(..., rmax::Ref{Float64})
-
 
 # ---------------------------------------------------------------- quasi-static mechanics (src/solver/nonlinear/newton_raphson.jl:234-238)
 struct TbMaterial
     kind::Int32; penalty::Int32; p::NTuple{16, Float64}
     f::NTuple{3, Float64}; s::NTuple{3, Float64}; n::NTuple{3, Float64}
     fsn_field::Ptr{Float64}; fsn_field_len::Int64
-end
-struct TbHill
-    framework::Int32; active_energy::Int32; active_penalty::Int32; adg_kind::Int32; sarcomere_kind::Int32
-    active_p::NTuple{12, Float64}; sheetlet_part::Float64; sarcomere_p::NTuple{2, Float64}
 end
 energy_id(::HolzapfelOgden2009Model) = Int32(0); energy_id(::Thunderbolt.NullEnergyModel) = Int32(1)
 energy_id(::Thunderbolt.BioNeoHookean) = Int32(2); energy_id(::Thunderbolt.TransverseIsotopicNeoHookeanModel) = Int32(3)
@@ -182,57 +339,54 @@ energy_id(::Thunderbolt.Guccione1991PassiveModel) = Int32(8)
 penalty_id(::Thunderbolt.SimpleCompressionPenalty) = Int32(0); penalty_id(::Thunderbolt.NullCompressionPenalty) = Int32(1)
 penalty_id(::Thunderbolt.HartmannNeffCompressionPenalty1) = Int32(2); penalty_id(::Thunderbolt.HartmannNeffCompressionPenalty2) = Int32(3)
 penalty_id(::Thunderbolt.HartmannNeffCompressionPenalty3) = Int32(4)
-# energy parameters = the struct fields before mpU, penalty parameters (β, a, b) in p[11:13]; constant frame or nodal f/s/n field
+# energy parameters = the Float fields of the energy struct in field order (p[1:9]); penalty parameters (β, a, b) in p[11:13]
+function lower(m::PK1Model)
+    ψ = m.material
+    ep = Float64[getfield(ψ, f) for f in fieldnames(typeof(ψ)) if getfield(ψ, f) isa Real]
+    pen = hasproperty(ψ, :mpU) ? ψ.mpU : Thunderbolt.NullCompressionPenalty()
+    pp = Float64[getfield(pen, f) for f in fieldnames(typeof(pen)) if getfield(pen, f) isa Real]
+    p = zeros(16); p[1:length(ep)] .= ep; p[11:10 + length(pp)] .= pp
+    energy_id(ψ) == 0 && penalty_id(pen) == 0 && (p[9] = isempty(pp) ? 1.0 : pp[1])       # HO2009 + SimpleCompressionPenalty: β also in p[9] (fast path)
+    ms = m.coefficient isa ConstantCoefficient ? m.coefficient.val : error("mechanics: constant microstructure frames only in this binding")
+    return TbMaterial(energy_id(ψ), penalty_id(pen), Tuple(p), v3(ms.f), v3(ms.s), v3(ms.n), C_NULL, 0)
+end
 
 mutable struct HIPNonlinearOperator{Tv}
-    form::Ptr{Cvoid}; facet_forms::Vector{Ptr{Cvoid}}; pattern::Ptr{Cvoid}; strategy::Cint
-    J::HIPVector{Tv}
-    Q::Union{Nothing, HIPVector{Tv}}; Qknown::Union{Nothing, HIPVector{Tv}}     # condensed internal variables, n_states × (n_cells·n_qp)
+    form::Ptr{Cvoid}
+    strategy::Cint
+    J::HIPSparseMatrixCSR{Tv}            # op.J (src/solver/interface.jl:9)
 end
-# setup: tb_hyperelastic_create(mesh, 0, Ref(material), form); per weak boundary condition tb_facet_form_create(…);
-#   GeneralizedHillModel / ExtendedHillModel          → tb_hyperelastic_set_hill(form, Ref(TbHill(…)))
-#   PrestressedMechanicalModel(inner, ConstantCoeff.) → tb_hyperelastic_set_prestress(form, vec(Matrix(F₀⁻¹)'))
-#   Dict(cellset => QuasiStaticModel)                  → one form each: tb_form_set_cellset(form, cells, n, 1); tb_form_set_accumulate(form, k > 1)
-#   internal sarcomere model (RDQ20MFModel)            → tb_hyperelastic_set_condensation(form, 2, params, 17, Tmax, tol, max_iters)
-function Thunderbolt.update_linearization!(op::HIPNonlinearOperator, residual::HIPVector, u::HIPVector, p)
-    t = p isa Real ? p : p.t
-    if p isa Thunderbolt.FerriteOperators.GenericFirstOrderTimeParameters && op.Q !== nothing
-        # GenericFirstOrderTimeParameters(p, t, Δt, uprev) (euler.jl:490-493): Δt and the known state of the local problems; the
-        # rate-coupled model additionally reads uprev: tb_hyperelastic_set_previous_solution(op.form, p.uprev.ptr)
-        check(ccall((:tb_hyperelastic_set_internal_state, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Float64),
-            op.form, op.Q.ptr, op.Qknown.ptr, p.Δt))
-    end
+function setup_operator(strategy::HIPStrategy, model::QuasiStaticModel, ::AbstractSolver, dh::DofHandler)
+    ddh = DeviceDofHandler(strategy.device, dh)
+    form = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:tb_hyperelastic_create, libtbhip), Cint, (Ptr{Cvoid}, Cint, Ref{TbMaterial}, Ref{Ptr{Cvoid}}), ddh.mesh, 0, Ref(lower(model.material_model)), form))
+    Tv = value_type(strategy.device)
+    op = HIPNonlinearOperator{Tv}(form[], strategy_code(strategy), HIPSparseMatrixCSR{Tv}(ddh, HIPVector{Tv}(ddh.dev, ddh.nnz)))
+    finalizer(o -> ccall((:tb_form_destroy, libtbhip), Cint, (Ptr{Cvoid},), o.form), op)
+    return op
+end
+gettime(p::Real) = p
+gettime(p) = p.t                                                         # GenericFirstOrderTimeParameters(p, t, Δt, uprev), euler.jl:490-493
+function update_linearization!(op::HIPNonlinearOperator, residual::HIPVector, u::HIPVector, p)
     check(ccall((:tb_linearize, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Float64}, Float64, Ptr{Float64}, Ptr{Float64}),
-        op.form, op.pattern, op.strategy, u.ptr, t, op.J.ptr, residual.ptr))
-    for h in op.facet_forms
-        check(ccall((:tb_facet_assemble, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Float64, Ptr{Float64}, Ptr{Float64}),
-            h, op.pattern, u.ptr, t, op.J.ptr, residual.ptr))
-    end
+        op.form, op.J.ddh.pattern, op.strategy, u.ptr, gettime(p), op.J.nzval.ptr, residual.ptr))
 end
-function Thunderbolt.residual!(op::HIPNonlinearOperator, residual::HIPVector, u::HIPVector, p)
-    t = p isa Real ? p : p.t
-    check(ccall((:tb_residual, libtbhip), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Float64, Ptr{Float64}), op.form, op.strategy, u.ptr, t, residual.ptr))
-    for h in op.facet_forms
-        check(ccall((:tb_facet_assemble, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Float64, Ptr{Float64}, Ptr{Float64}),
-            h, C_NULL, u.ptr, t, C_NULL, residual.ptr))
-    end
+function update_linearization!(op::HIPNonlinearOperator, u::HIPVector, p)
+    check(ccall((:tb_linearize, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Float64}, Float64, Ptr{Float64}, Ptr{Float64}),
+        op.form, op.J.ddh.pattern, op.strategy, u.ptr, gettime(p), op.J.nzval.ptr, C_NULL))
 end
-# check_local_solve_convergence → tb_hyperelastic_local_solve_report(form, n_failed, C_NULL, 0); Newton's linear solve:
-# tb_cg_solve (SPD tangents) or tb_gmres_solve (the reference's default KrylovJL_GMRES; required for the rate-coupled model);
-# apply_zero!(J, r, ch) → tb_apply_zero_csr; norm(r[free]) → tb_dot.
+function residual!(op::HIPNonlinearOperator, residual::HIPVector, u::HIPVector, p)
+    check(ccall((:tb_residual, libtbhip), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Float64, Ptr{Float64}), op.form, op.strategy, u.ptr, gettime(p), residual.ptr))
+end
+# apply_zero!(J, r, ch) on the device CSR matrix (src/solver/nonlinear/nlsolve_common.jl:12-26, src/utils.jl:263-278): flags = one byte per dof
+function Ferrite.apply_zero!(J::HIPSparseMatrixCSR, r::HIPVector, prescribed_flags::HIPVector{UInt8}, diag::Real)
+    check(ccall((:tb_apply_zero_csr, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{UInt8}, Cdouble), J.ddh.pattern, J.nzval.ptr, r.ptr, prescribed_flags.ptr, diag))
+end
+function LinearAlgebra.dot(a::HIPVector{Float64}, b::HIPVector{Float64})
+    r = Ref{Cdouble}(0.0)
+    check(ccall((:tb_dot, libtbhip), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ref{Cdouble}), a.dev.handle, a.n, a.ptr, b.ptr, r))
+    return r[]
+end
+LinearAlgebra.norm(a::HIPVector{Float64}) = sqrt(dot(a, a))
 
-# sarcomere_rhs! under a pointwise explicit step (StandaloneSarcomereModel): tb_sarcomere_step; the local problem alone:
-# tb_sarcomere_implicit_step
-
-# heat-step algebra (src/solver/time/euler.jl:85,90,110-116): tb_heat_matrix, tb_spmv_csr, tb_axpy
-# perform_backward_euler_step! (euler.jl:71-101) for device vectors: the initial guess is uₙ₋₁, so b − A·uₙ₋₁ = Δt·K·uₙ₋₁ (+ source) and CG can
-# start from that residual — one SpMV with K instead of mul!(b, M, uₙ₋₁) and the solver's own A·x₀:
-function backward_euler_heat_step!(pat, Anz::Ptr{Float64}, Knz::Ptr{Float64}, u::Ptr{Float64}, r0::Ptr{Float64}, Δt; rtol = 1e-5, atol = 1e-6, maxiter = 1000)
-    check(ccall((:tb_spmv_csr, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Cdouble, Cdouble, Ptr{Float64}), pat, Knz, u, Δt, 0.0, r0))
-    iters = Ref{Cint}(0); res = Ref{Cdouble}(0.0)
-    check(ccall((:tb_cg_solve_from_residual, libtbhip), Cint,
-                (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cdouble, Cdouble, Cint, Cint, Ref{Cint}, Ref{Cdouble}),
-                pat, Anz, r0, u, rtol, atol, maxiter, 1, iters, res))
-    return iters[] < maxiter || res[] <= atol
-end
 end # module
