@@ -15,7 +15,7 @@ ap.add_argument("--tend", type=float, default=120.0, help="ms")
 ap.add_argument("--dt", type=float, default=0.05, help="electrophysiology time step [ms]")
 ap.add_argument("--mech-every", type=float, default=5.0, help="mechanics solve interval [ms]")
 ap.add_argument("--tmax", type=float, default=20.0, help="peak active tension")
-ap.add_argument("--inner", default="lu", choices=["lu", "gmres"], help="linear solver of the Newton steps: host sparse LU (the follower pressure makes the tangent\n                non-symmetric and the anchored ventricle is badly conditioned) or device GMRES")
+# the follower pressure makes the tangent non-symmetric: the Newton steps are solved by restarted GMRES with a Jacobi preconditioner on the device
 args = ap.parse_args()
 import thunderbolt_jl_amd as tb
 dev = tb.MI355XDevice(0)
@@ -53,17 +53,9 @@ nd0 = np.empty(g.n_nodes, dtype=np.int64)
 nd0[g.conn.ravel()] = dhv.cell_dofs[:, 0::3].ravel()
 a = [g.getnodeset("MyocardialAnchor%d" % k)[0] for k in (1, 2, 3, 4)]
 ch = tb.ConstraintHandler(dhv, np.concatenate([nd0[a[0]] + np.arange(3), nd0[a[1]] + np.array([1, 2]), [nd0[a[2]] + 2], [nd0[a[3]] + 2]]))
-def sparse_lu(pattern, J, res, du):
-    import scipy.sparse as ssp
-    import scipy.sparse.linalg as sla
-    nn = len(pattern.sp.rowptr) - 1
-    du.copy_from_host(sla.splu(ssp.csr_matrix((J.to_host(), pattern.sp.colidx, pattern.sp.rowptr), shape=(nn, nn)).tocsc()).solve(res.to_host()))
-    return 1
-
-
 # the first increment after a change of the calcium field may raise the residual once before quadratic convergence takes over (the reference
 # makes the same remark about its condensed cuboid): no monotonicity enforcement
-newton = tb.NewtonRaphsonSolver(max_iter=30, tol=1e-8, inner_rtol=1e-10, inner_maxiter=20000, inner_solver=sparse_lu if args.inner == "lu" else "gmres",
+newton = tb.NewtonRaphsonSolver(max_iter=30, tol=1e-8, inner_rtol=1e-10, inner_maxiter=20000, inner_solver="gmres",
                                 gmres_restart=200, enforce_monotonic_convergence=False)
 u = dev.zeros(dhv.ndofs)
 # passive inflation to the cavity pressure before the beat starts (calcium at rest): a short load path from the unloaded state

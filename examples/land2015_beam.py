@@ -2,15 +2,15 @@
 """Land et al. 2015, cardiac mechanics verification benchmark, problem 1 (the reference's test/validation/land2015.jl) on one MI355X:
 a 10×1×1 Guccione beam clamped at x = 0 under a follower pressure of 0.004 on its bottom face, quadratic hexahedra, load path in steps of
 0.2 with Newton; reports the z-deflection of the point (10, 0.5, 1) — 3.17 ± 0.02 in the reference's assertion — and timings.
---refine r uses (25r)×(3r)×(3r) cells; --inner picks the linear solver of the Newton steps: device Jacobi-CG (default; 3.155 in 35 Newton
-iterations, 14 s at r = 1 — the slender beam is badly conditioned), a host sparse LU (3.155, 3.5 s), or device GMRES(200), which stagnates on
-this bending problem with a Jacobi preconditioner and is kept only to show it."""
+--refine r uses (25r)×(3r)×(3r) cells; --inner picks the linear solver of the Newton steps, all on the device: CG with the Chebyshev polynomial
+preconditioner (default: the slender beam is badly conditioned — Jacobi-CG needs thousands of iterations per Newton step, degree-24 Chebyshev
+about twenty times fewer), Jacobi-CG, or GMRES(200), which stagnates on this bending problem with a Jacobi preconditioner and is kept only to show it."""
 import argparse, json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ap = argparse.ArgumentParser()
 ap.add_argument("--refine", type=int, default=1)
-ap.add_argument("--inner", default="cg", choices=["gmres", "cg", "lu"])
+ap.add_argument("--inner", default="chebyshev", choices=["chebyshev", "cg", "gmres"])
 args = ap.parse_args()
 import thunderbolt_jl_amd as tb
 dev = tb.MI355XDevice(0)
@@ -36,16 +36,11 @@ ch = tb.ConstraintHandler(dh, np.flatnonzero(X[:, 0] < 1e-12))
 setup_s = time.perf_counter() - t0
 
 
-def sparse_lu(pattern, J, res, du):
-    import scipy.sparse as ssp
-    import scipy.sparse.linalg as sla
-    n = len(pattern.sp.rowptr) - 1
-    du.copy_from_host(sla.splu(ssp.csr_matrix((J.to_host(), pattern.sp.colidx, pattern.sp.rowptr), shape=(n, n)).tocsc()).solve(res.to_host()))
-    return 1
-
-
-inner = sparse_lu if args.inner == "lu" else args.inner
-newton = tb.NewtonRaphsonSolver(tol=1e-4, max_iter=10, inner_solver=inner, inner_rtol=1e-8, inner_maxiter=20000, gmres_restart=200)
+if args.inner == "chebyshev":
+    inner, precond = "cg", tb.ChebyshevPrecBuilder(24)
+else:
+    inner, precond = args.inner, None
+newton = tb.NewtonRaphsonSolver(tol=1e-4, max_iter=10, inner_solver=inner, inner_precond=precond, inner_rtol=1e-8, inner_maxiter=20000, gmres_restart=200)
 path = tb.HomotopyPathSolver(newton)
 u = dev.zeros(dh.ndofs)
 dev.synchronize()

@@ -400,7 +400,10 @@ int tb_cg_solve_from_residual(tb_pattern *pat, const double *d_Anz, const double
  * consecutive rows (the preconditioner the reference documents for its Krylov solves — Thunderbolt.Preconditioners.L1GSPrecBuilder /
  * SymmetricSweep, docs/src/api-reference/solver.md:13-22; Baker–Falgout–Kolev–Yang 2011): M = (D̃ + L_p) D̃⁻¹ (D̃ + U_p) with
  * D̃_ii = a_ii + Σ_{j outside the partition} |a_ij|.  tb_l1gs_apply: one application z = M⁻¹ r (forward or symmetric sweep). */
-enum { TB_PRECOND_NONE = 0, TB_PRECOND_JACOBI = 1, TB_PRECOND_L1GS = 2 };
+enum { TB_PRECOND_NONE = 0, TB_PRECOND_JACOBI = 1, TB_PRECOND_L1GS = 2,
+       TB_PRECOND_CHEBYSHEV = 3 /* M⁻¹ = p_m(D⁻¹A)·D⁻¹, Chebyshev polynomial of degree m = `partsize` on [λmax/(1.8 m²), λmax] of D⁻¹A (the smoother of the
+                                   reference's multigrid extension, src/solver/linear/multigrid.jl:28-33, used as a preconditioner of its own): SpMVs and one
+                                   fused vector kernel per degree, no inner products; λmax by 24 Lanczos steps capped by the Gershgorin bound */ };
 enum { TB_SWEEP_FORWARD = 0, TB_SWEEP_SYMMETRIC = 2 };
 int tb_pcg_solve(tb_pattern *pat, const double *d_Anz, const double *d_b, double *d_x, double rtol, double atol, int maxiter, int precond,
                  int partsize, int *iters, double *resnorm);

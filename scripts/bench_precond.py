@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Jacobi vs ℓ₁ Gauss–Seidel preconditioned CG on the device: the heat matrix M − Δt·K of an n³ mesh and a Q2 mechanics tangent."""
+"""Jacobi vs ℓ₁ Gauss–Seidel vs Chebyshev-polynomial preconditioned CG on the device: the heat matrix M − Δt·K of an n³ mesh and a Q2 mechanics tangent."""
 import argparse, json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,7 +24,7 @@ tb.check(tb.lib().tb_heat_matrix(dev.h, sp.nnz, M.A.ptr, K.A.ptr, args.dt, A.ptr
 rng = np.random.default_rng(0)
 b = dev.to_device(rng.normal(size=dh.ndofs))
 pat = M.pattern
-for name, pc in (("jacobi", "jacobi"), ("l1gs_64", tb.L1GSPrecBuilder(64)), ("l1gs_256", tb.L1GSPrecBuilder(256))):
+for name, pc in (("jacobi", "jacobi"), ("l1gs_64", tb.L1GSPrecBuilder(64)), ("chebyshev_4", tb.ChebyshevPrecBuilder(4)), ("chebyshev_8", tb.ChebyshevPrecBuilder(8))):
     x = dev.zeros(dh.ndofs)
     tb.pcg_solve(pat, A, b, x, rtol=1e-8, atol=0.0, maxiter=3, precond=pc)
     x = dev.zeros(dh.ndofs); dev.synchronize()
@@ -53,10 +53,11 @@ for c in range(3):
 ch = tb.ConstraintHandler(dhm, np.flatnonzero(X[:, 0] < 1e-12))
 tb.apply_zero(op.J, r, ch, pattern=op.pattern)
 bm = dev.to_device(rng.normal(size=dhm.ndofs) * (X[:, 0] > 1e-12))
-for name, pc in (("jacobi", "jacobi"), ("l1gs_96", tb.L1GSPrecBuilder(96)), ("l1gs_243", tb.L1GSPrecBuilder(243))):
+for name, pc in (("jacobi", "jacobi"), ("l1gs_96", tb.L1GSPrecBuilder(96)), ("chebyshev_8", tb.ChebyshevPrecBuilder(8)), ("chebyshev_16", tb.ChebyshevPrecBuilder(16)),
+                 ("chebyshev_24", tb.ChebyshevPrecBuilder(24))):
     x = dev.zeros(dhm.ndofs); dev.synchronize()
     t0 = time.perf_counter()
-    its, res = tb.pcg_solve(op.pattern, op.J, bm, x, rtol=1e-8, atol=0.0, maxiter=20000, precond=pc)
+    its, res = tb.pcg_solve(op.pattern, op.J, bm, x, rtol=1e-8, atol=0.0, maxiter=6000, precond=pc)
     dev.synchronize()
     out["mechanics_Q2_%d^3_%s" % (n, name)] = {"iterations": its, "ms": (time.perf_counter() - t0) * 1e3, "dofs": dhm.ndofs}
 print(json.dumps(out))

@@ -1507,11 +1507,14 @@ def test_l1_gauss_seidel_preconditioner(tb, oracle, device):
     b = rng.normal(size=dh.ndofs)
     xref = sla.spsolve(A.tocsc(), b)
     its = {}
-    for name, pc in (("jacobi", "jacobi"), ("l1gs", tb.L1GSPrecBuilder(64)), ("none", None)):
+    for name, pc in (("jacobi", "jacobi"), ("l1gs", tb.L1GSPrecBuilder(64)), ("none", None), ("cheb4", tb.ChebyshevPrecBuilder(4)), ("cheb1", tb.ChebyshevPrecBuilder(1))):
         x = device.zeros(dh.ndofs)
         its[name], res = tb.pcg_solve(pat, dA, device.to_device(b), x, rtol=1e-11, atol=0.0, maxiter=2000, precond=pc)
         assert np.abs(x.to_host() - xref).max() < 1e-8 * np.abs(xref).max(), name
+        assert tb.solve_converged(pat, res), name
     assert its["l1gs"] < its["jacobi"] <= its["none"], its
+    # the Chebyshev polynomial preconditioner: degree 1 is (scaled) Jacobi, degree 4 needs clearly fewer outer iterations
+    assert abs(its["cheb1"] - its["jacobi"]) <= 2 and its["cheb4"] <= 0.6 * its["jacobi"], its
     # a mechanics tangent (Q1 Holzapfel–Ogden at a small random displacement, one face clamped)
     gm, dhm, spm, omm = mech_problem(tb, oracle, (5, 4, 3), 1, perturb=0.1)
     u = rng.uniform(-5e-3, 5e-3, dhm.ndofs)
@@ -1534,11 +1537,12 @@ def test_l1_gauss_seidel_preconditioner(tb, oracle, device):
     bm = rng.normal(size=dhm.ndofs); bm[fixed] = 0.0
     xrefm = sla.spsolve(ssp.csr_matrix((vals, spm.colidx, spm.rowptr), shape=At.shape).tocsc(), bm)
     itm = {}
-    for name, pc in (("jacobi", "jacobi"), ("l1gs", tb.L1GSPrecBuilder(96))):
+    for name, pc in (("jacobi", "jacobi"), ("l1gs", tb.L1GSPrecBuilder(96)), ("cheb8", tb.ChebyshevPrecBuilder(8))):
         x = device.zeros(dhm.ndofs)
         itm[name], res = tb.pcg_solve(patm, device.to_device(vals), device.to_device(bm), x, rtol=1e-10, atol=0.0, maxiter=5000, precond=pc)
         assert np.abs(x.to_host() - xrefm).max() < 1e-6 * np.abs(xrefm).max(), name
     assert itm["l1gs"] < itm["jacobi"], itm
+    assert itm["cheb8"] <= 0.3 * itm["jacobi"], itm
 
 
 def test_reference_ideal_lv_load_path_properties(tb, device):

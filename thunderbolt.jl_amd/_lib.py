@@ -42,7 +42,7 @@ class tb_hill(C.Structure):
                 ("sarcomere_kind", C.c_int32), ("active_p", C.c_double * 12), ("sheetlet_part", C.c_double), ("sarcomere_p", C.c_double * 2)]
 
 
-TB_PRECOND_NONE, TB_PRECOND_JACOBI, TB_PRECOND_L1GS = 0, 1, 2
+TB_PRECOND_NONE, TB_PRECOND_JACOBI, TB_PRECOND_L1GS, TB_PRECOND_CHEBYSHEV = 0, 1, 2, 3
 TB_SWEEP_FORWARD, TB_SWEEP_SYMMETRIC = 0, 2
 TB_LOCAL_SUCCESS, TB_LOCAL_LINEAR_SOLVE_FAILED, TB_LOCAL_MAX_ITERS, TB_LOCAL_CONVERGENCE_FAILURE, TB_LOCAL_INFEASIBLE = 0, 1, 2, 3, 4
 TB_HILL_NONE, TB_HILL_GENERALIZED, TB_HILL_EXTENDED = 0, 1, 2

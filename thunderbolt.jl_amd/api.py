@@ -1619,7 +1619,7 @@ class NewtonRaphsonSolver:
         if inner_solver not in ("cg", "gmres") and not callable(inner_solver):
             raise ValueError("inner_solver: 'cg', 'gmres' or a callable (pattern, J, residual, Δu) -> linear iterations")
         self.inner_solver, self.gmres_restart = inner_solver, gmres_restart
-        self.inner_precond = inner_precond          # None (Jacobi, device-scalar CG) or L1GSPrecBuilder(partsize)
+        self.inner_precond = inner_precond          # None (Jacobi, device-scalar CG), L1GSPrecBuilder(partsize) or ChebyshevPrecBuilder(degree)
         # simplified_newton: the tangent of the first iteration is reused, later iterations assemble the residual only (residual!);
         # forcing: EisenstatWalkerForcing() adapts the inner Krylov tolerance (ignored by callable inner solvers, as by direct ones)
         self.simplified_newton, self.forcing = bool(simplified_newton), forcing
@@ -1899,9 +1899,21 @@ class L1GSPrecBuilder:
         self.partsize = int(partsize)
 
 
+class ChebyshevPrecBuilder:
+    """Chebyshev polynomial preconditioner of degree `degree` over Jacobi scaling (TB_PRECOND_CHEBYSHEV): the smoother of the reference's
+    multigrid extension (src/solver/linear/multigrid.jl:28-33) used as a preconditioner of its own — for the elasticity tangents, where
+    Jacobi-CG needs thousands of iterations, it cuts the outer iterations (and with them the inner products and host looks) about degree-fold."""
+
+    def __init__(self, degree=16):
+        self.degree = int(degree)
+
+
 def pcg_solve(pattern, A, b, x, rtol=1e-5, atol=1e-6, maxiter=1000, precond="jacobi"):
-    """CG with precond = None | "jacobi" | L1GSPrecBuilder(partsize)"""
-    kind, ps = (L.TB_PRECOND_NONE, 1) if precond is None else (L.TB_PRECOND_JACOBI, 1) if precond == "jacobi" else (L.TB_PRECOND_L1GS, precond.partsize)
+    """CG with precond = None | "jacobi" | L1GSPrecBuilder(partsize) | ChebyshevPrecBuilder(degree)"""
+    if isinstance(precond, ChebyshevPrecBuilder):
+        kind, ps = L.TB_PRECOND_CHEBYSHEV, precond.degree
+    else:
+        kind, ps = (L.TB_PRECOND_NONE, 1) if precond is None else (L.TB_PRECOND_JACOBI, 1) if precond == "jacobi" else (L.TB_PRECOND_L1GS, precond.partsize)
     it, res = C.c_int(), C.c_double()
     check(lib().tb_pcg_solve(pattern.h, _ptr(A), _ptr(b), _ptr(x), float(rtol), float(atol), int(maxiter), kind, ps, C.byref(it), C.byref(res)))
     return it.value, res.value

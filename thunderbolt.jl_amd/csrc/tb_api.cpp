@@ -309,7 +309,7 @@ int tb_pattern_create(tb_mesh *mesh, int64_t n_rows, const int64_t *rowptr, cons
 int tb_pattern_destroy(tb_pattern *p)
 {
     if (!p) return TB_OK;
-    hipFree(p->d_rowptr); hipFree(p->d_colidx); hipFree(p->d_blkrow); hipFree(p->d_bcol); hipFree(p->d_diagpos); hipFree(p->d_emap); hipFree(p->d_blockpos); hipFree(p->d_cg_ws); hipFree(p->d_gmres_ws); hipFree(p->d_pcg_ws); hipFree(p->d_q2pos); hipFree(p->d_kebuf);
+    hipFree(p->d_rowptr); hipFree(p->d_colidx); hipFree(p->d_blkrow); hipFree(p->d_bcol); hipFree(p->d_diagpos); hipFree(p->d_emap); hipFree(p->d_blockpos); hipFree(p->d_cg_ws); hipFree(p->d_gmres_ws); hipFree(p->d_pcg_ws); hipFree(p->d_cheb_ws); hipFree(p->d_q2pos); hipFree(p->d_kebuf);
     free_patch_mat_plan(p);
     free_patch_fused_plan(p);
     delete p;
@@ -977,8 +977,12 @@ int tb_pcg_solve(tb_pattern *pat, const double *d_Anz, const double *d_b, double
 {
     TB_REQUIRE(pat && d_Anz && d_b && d_x, "tb_pcg_solve: NULL argument");
     TB_REQUIRE(rtol >= 0 && atol >= 0 && maxiter >= 0, "tb_pcg_solve: negative tolerance or iteration limit");
-    TB_REQUIRE(precond >= TB_PRECOND_NONE && precond <= TB_PRECOND_L1GS, "tb_pcg_solve: unknown preconditioner %d", precond);
+    TB_REQUIRE(precond >= TB_PRECOND_NONE && precond <= TB_PRECOND_CHEBYSHEV, "tb_pcg_solve: unknown preconditioner %d", precond);
     TB_HIP(hipSetDevice(pat->mesh->dev->id));
+    if (precond == TB_PRECOND_CHEBYSHEV) {
+        TB_REQUIRE(partsize >= 1 && partsize <= 64, "tb_pcg_solve: Chebyshev degree must be in 1..64 (got %d)", partsize);
+        return launch_pcg_chebyshev(pat, d_Anz, d_b, d_x, rtol, atol, maxiter, partsize, iters, resnorm);
+    }
     if (precond != TB_PRECOND_L1GS) return launch_cg(pat, d_Anz, d_b, d_x, rtol, atol, maxiter, precond == TB_PRECOND_JACOBI, iters, resnorm);
     TB_REQUIRE(partsize >= 1 && partsize <= 1024, "tb_pcg_solve: partition size must be in 1..1024 (got %d)", partsize);
     return launch_pcg_l1gs(pat, d_Anz, d_b, d_x, rtol, atol, maxiter, partsize, iters, resnorm);

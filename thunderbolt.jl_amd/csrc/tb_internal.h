@@ -179,6 +179,7 @@ struct tb_pattern {
     int64_t n_blk = 0;              // 0 = not planned yet, −1 = a row exceeds the capacity (lanes-per-row kernel)
     uint16_t *d_q2pos = nullptr;    // scalar Q2 forms: position of col dof(j) in row dof(i), per cell and pair
     double *d_pcg_ws = nullptr;     // general-preconditioner PCG workspace (r, z, p, Ap, D̃, scalars)
+    double *d_cheb_ws = nullptr;    // Chebyshev-preconditioned CG workspace (r, z, p, Ap, D⁻¹, d, w, scalars)
     double *d_gmres_ws = nullptr;   // GMRES workspace: (restart+1) basis vectors + 3 vectors + scalars
     int gmres_m = 0;
     double *d_kebuf = nullptr;      // element-matrix buffer of the ElementAssemblyStrategy (vector fields)
@@ -277,6 +278,7 @@ void host_sarcomere_eval(const double *params, const double *u, double stretch, 
                          double *stiffness);
 int launch_l1gs_setup(tb_pattern *pat, const double *A, int ps, double *d_dtilde);
 int launch_l1gs_apply(tb_pattern *pat, const double *A, const double *d_dtilde, int ps, int symmetric, const double *r, double *z);
+int launch_pcg_chebyshev(tb_pattern *pat, const double *A, const double *b, double *x, double rtol, double atol, int maxiter, int degree, int *iters, double *resnorm);
 int launch_pcg_l1gs(tb_pattern *pat, const double *A, const double *b, double *x, double rtol, double atol, int maxiter, int ps, int *iters, double *resnorm);
 int launch_gmres(tb_pattern *pat, const double *A, const double *b, double *x, double rtol, double atol, int maxiter, int restart, int jacobi,
                  int *iters, double *resnorm);
