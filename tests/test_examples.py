@@ -27,7 +27,7 @@ def test_examples_run():
     assert d["all_converged"] and d["mean_shortening_x"] > 0
     d = run("mechanics_contraction.py", "--n", "4", "--order", "1", "--steps", "10", "--sarcomere", "rdq20", "--tmax", "60")
     assert d["all_converged"]
-    d = run("land2015_beam.py", "--inner", "lu")
+    d = run("land2015_beam.py")                                  # Newton + Chebyshev-preconditioned CG, all on the device
     assert d["converged"] and abs(d["tip_deflection_z"] - 3.17) <= 0.02
     d = run("electromechanics_lv.py", "--nc", "8", "--nr", "2", "--nl", "4", "--tend", "20", "--mech-every", "5")
     assert d["all_converged"] and d["mechanics_solves"] == 4 and d["final"]["activated_fraction"] > 0.2
