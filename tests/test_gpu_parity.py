@@ -2303,3 +2303,40 @@ def test_rush_larsen_pcg2019_parity(tb, oracle, device, layout):
         oracle.reaction_step_rl(oracle.CELL_PCG2019, model.params, ref, n, getattr(oracle, "LAYOUT_" + layout), t=0.05 * step, dt=0.05)
     assert np.isfinite(ref).all()
     assert rel_err(cache.un.to_host(), ref) < 1e-11
+
+
+@pytest.mark.parametrize("mesh", ["ideal_lv", "ring", "shuffled_box"])
+def test_patch_kernels_on_unstructured_hexahedral_meshes(tb, oracle, device, mesh):
+    """The sum-factorised patch kernels (matrices alone and fused, vector kernels with and without halo) on meshes that are not lexicographic
+    boxes: the all-hexahedral ideal ventricle (O-grid apex: nodes of valence ≠ 8, rows that do not have 27 entries), the ring, and a box whose
+    cells and nodes are randomly renumbered (patch tiles come from centroid buckets, never from the numbering)."""
+    rng = np.random.default_rng(31)
+    if mesh == "ideal_lv":
+        g = tb.generate_ideal_lv_mesh_hex(16, 4, 8)
+    elif mesh == "ring":
+        g = tb.generate_ring_mesh(24, 3, 5)
+    else:
+        g0 = tb.generate_mesh(tb.Hexahedron, (9, 8, 7), (0, 0, 0), (1.0, 0.9, 0.8), perturb=0.25)
+        pn, pc = rng.permutation(g0.n_nodes), rng.permutation(g0.n_cells)
+        inv = np.empty_like(pn); inv[pn] = np.arange(g0.n_nodes)
+        g = tb.Grid(tb.Hexahedron, g0.xyz[pn], inv[g0.conn[pc]].astype(np.int32))
+    cd, nd = oracle.close_dofs(oracle.HEX8, 1, g.conn, g.n_nodes)
+    dh = tb.DofHandler(g, cell_dofs=cd, ndofs=nd)
+    sp = tb.allocate_matrix(dh)
+    om = oracle.Mesh(oracle.HEX8, 2, g.xyz, g.conn, dh.cell_dofs)
+    D = np.array([[2.0, 0.3, 0.1], [0.3, 1.5, -0.2], [0.1, -0.2, 1.0]])
+    rho = rng.uniform(0.5, 2.0, size=(g.n_cells, 8))
+    refM = oracle.assemble_matrix(om, 0, oracle.Coef(oracle.COEF_FIELD_SCALAR, field=rho), sp.rowptr, sp.colidx)
+    refK = oracle.assemble_matrix(om, 1, oracle.Coef(oracle.COEF_CONST_TENSOR, D.ravel()), sp.rowptr, sp.colidx)
+    st = tb.PatchAssemblyStrategy(device)
+    M = tb.setup_operator(st, tb.BilinearMassIntegrator(tb.FieldCoefficient(rho)), dh, sp)
+    K = tb.setup_operator(st, tb.BilinearDiffusionIntegrator(tb.ConstantCoefficient(D)), dh, sp)
+    tb.update_operator(M, 0.0); tb.update_operator(K, 0.0)
+    assert rel_err(M.A.to_host(), refM) < TOL and rel_err(K.A.to_host(), refK) < TOL
+    M.A.fill_zero(); K.A.fill_zero()
+    tb.update_operators(M, K, 0.0)
+    assert rel_err(M.A.to_host(), refM) < TOL and rel_err(K.A.to_host(), refK) < TOL
+    refb = oracle.assemble_source(om, oracle.SRC_NORM_PLUS_T, t=0.4)
+    for s_ in (tb.PatchAssemblyStrategy(device), tb.AtomicAssemblyStrategy(device)):
+        b = tb.update_operator(tb.setup_operator(s_, tb.LinearIntegrator(tb.AnalyticalCoefficient("norm_plus_t")), dh), 0.4)
+        assert rel_err(b.b.to_host(), refb) < TOL, type(s_).__name__
