@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=216)
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--check", action="store_true", help="compare fused vs separate results")
+ap.add_argument("--fibre", action="store_true", help="diffusion with a nodal fibre field (SpectralTensorCoefficient over OrthotropicMicrostructureModel)")
 a = ap.parse_args()
 dev = tb.MI355XDevice(0)
 g = tb.generate_mesh(tb.Hexahedron, (a.n,) * 3, (0, 0, 0), (1, 1, 1), perturb=0.2)
@@ -23,6 +24,12 @@ sp = tb.allocate_matrix(dh)
 st = tb.PatchAssemblyStrategy(dev)
 kap = np.diag([4.5e-5, 2.0e-5, 2.0e-5])
 D = tb.ConductivityToDiffusivityCoefficient(tb.ConstantCoefficient(kap), tb.ConstantCoefficient(1.0), tb.ConstantCoefficient(1.0))
+if a.fibre:
+    rng = np.random.default_rng(0)
+    nc = g.n_cells
+    f = rng.normal(size=(nc, 8, 3)) * 0.2 + np.array([2.0, 0, 0]); s_ = rng.normal(size=(nc, 8, 3)) * 0.2 + np.array([0, 2.0, 0]); n_ = rng.normal(size=(nc, 8, 3)) * 0.2 + np.array([0, 0, 2.0])
+    D = tb.ConductivityToDiffusivityCoefficient(tb.SpectralTensorCoefficient(tb.OrthotropicMicrostructureModel(f, s_, n_), tb.ConstantCoefficient(np.array([4.5e-5, 2.0e-5, 1.0e-5]))),
+                                                tb.ConstantCoefficient(1.0), tb.ConstantCoefficient(1.0))
 M = tb.setup_operator(st, tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.0)), dh, sp)
 K = tb.setup_operator(st, tb.BilinearDiffusionIntegrator(D), dh, sp)
 

@@ -378,7 +378,7 @@ int tb_form_create(tb_mesh *mesh, int form_kind, int qorder, const tb_coef *coef
 int tb_form_destroy(tb_form *f)
 {
     if (!f) return TB_OK;
-    hipFree(f->d_field); hipFree(f->d_dtab); hipFree(f->d_table); hipFree(f->d_facets); hipFree(f->d_act_field); hipFree(f->d_qp_buf); hipFree(f->d_cellset); if (f->set_colors) hipFree(f->set_colors->d_cells);
+    hipFree(f->d_field); hipFree(f->d_dtab); hipFree(f->d_gtab); hipFree(f->d_table); hipFree(f->d_facets); hipFree(f->d_act_field); hipFree(f->d_qp_buf); hipFree(f->d_cellset); if (f->set_colors) hipFree(f->set_colors->d_cells);
     delete f;
     return TB_OK;
 }

@@ -20,6 +20,7 @@ struct FormArgs {
     double lambda[3]; // eigenvalues for the spectral field coefficient
     double scale;     // 1/(Cₘ·χ) for field coefficients (1 when not wrapped)
     const double *field;
+    const double *gtab; // hexahedron patch kernel with a field tensor: 7 doubles per (cell, q): G_q (xx,xy,xz,yy,yz,zz) and detJ_q
     const double *dtab; // diffusion with a fibre field: the tensor at every quadrature point, 6 doubles (xx,xy,xz,yy,yz,zz) per (cell, q)
     // source
     int src_kind;
@@ -40,6 +41,7 @@ inline FormArgs make_args(const tb_form *f, double t)
     a.scale = f->coef.wrap ? 1.0 / (f->coef.Cm * f->coef.chi) : 1.0;
     a.field = f->d_field;
     a.dtab = f->d_dtab;
+    a.gtab = f->d_gtab;
     a.src_kind = f->coef.kind;
     a.p0 = f->coef.p[0];
     a.table = f->d_table;

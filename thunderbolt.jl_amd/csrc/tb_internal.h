@@ -197,6 +197,7 @@ struct tb_form {
     bool field = false, symmetric = true;
     double *d_field = nullptr;
     double *d_dtab = nullptr;  // diffusion tensor at the quadrature points (built from d_field at the first assembly)
+    double *d_gtab = nullptr;  // trilinear hexahedra, field tensors: G_q = −¼/detJ·A·D_q·Aᵀ (6) and detJ_q per (cell, point) — mesh and field are fixed, so is G
     double *d_table = nullptr;
     int64_t table_len = 0;
     tb_material mat{};

@@ -46,27 +46,31 @@ struct FusedView {
 // accumulators.  x: vertex coordinates, cp: the cell's 64 positions (byte i*8+j; dwords 2i, 2i+1 hold row i), ro[i]: entry offset of row i
 // in the accumulator block or 0xFFFFFFFF when the patch does not own it.
 // mid(): called once between the Kₑ and the Mₑ part, where few registers are live (the persistent kernel issues its prefetch there).
-template <bool WK, bool WM, bool FK, bool FM, class Mid>
+template <bool WK, bool WM, bool FK, bool FM, bool DIAG = false, class Mid>
 __device__ __forceinline__ void hex8_instance(const double (&x)[8][3], const uint4 (&cp)[4], const uint32_t (&ro)[8], int64_t cell, const FormArgs &faK,
                                               const FormArgs &faM, double *accK, double *accM, Status *st, const int32_t *elem_cell, int64_t e, Mid &&mid)
 {
     double G[8][6], dq[8];
-    auto Dq = [&](int q, double(&D)[6]) {
-        if constexpr (FK) {
-            const double *dp = faK.dtab + (cell * 8 + q) * 6;
+    if constexpr (FK) {
+        // field tensors: mesh and coefficient field are fixed, so G_q and detJ_q were tabulated once (k_tabulate_g_hex8: the same
+        // hex8_sf_geometry, detJ ≤ 0 reported there) — the cell needs no geometry stage and no coordinates, only its 56 numbers
+        const double *gp = faK.gtab + cell * 56;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) D[k] = dp[k];
-        } else {
-            D[0] = faK.D[0]; D[1] = faK.D[1]; D[2] = faK.D[2]; D[3] = faK.D[4]; D[4] = faK.D[5]; D[5] = faK.D[8];
+        for (int q = 0; q < 8; ++q) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) G[q][k] = gp[7 * q + k];
+            dq[q] = gp[7 * q + 6];
         }
-    };
+    } else {
+        auto Dq = [&](int, double(&D)[6]) { D[0] = faK.D[0]; D[1] = faK.D[1]; D[2] = faK.D[2]; D[3] = faK.D[4]; D[4] = faK.D[5]; D[5] = faK.D[8]; };
 #ifdef TB_ABLATION
-    if (faK.debug & 4) { // no arithmetic: keep the loads alive, feed the scatter with trivial values
+        if (faK.debug & 4) { // no arithmetic: keep the loads alive, feed the scatter with trivial values
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { dq[q] = x[q][0] + x[q][1] + x[q][2]; for (int k = 0; k < 6; ++k) G[q][k] = dq[q]; }
-    } else
+            for (int q = 0; q < 8; ++q) { dq[q] = x[q][0] + x[q][1] + x[q][2]; for (int k = 0; k < 6; ++k) G[q][k] = dq[q]; }
+        } else
 #endif
-    if (!hex8_sf_geometry<WK, FK>(x, Dq, G, dq)) { st->neg_detj = 1; st->cell = elem_cell[e]; }
+        if (!hex8_sf_geometry<WK, false, DIAG>(x, Dq, G, dq)) { st->neg_detj = 1; st->cell = elem_cell[e]; }
+    }
     bool own[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) own[i] = ro[i] != 0xFFFFFFFFu;
@@ -120,6 +124,34 @@ __device__ __forceinline__ void hex8_instance(const double (&x)[8][3], const uin
 #pragma unroll
                 for (int j = 0; j < 8; ++j) unsafeAtomicAdd(accM + (ro[i] + pos(i, j)), Z[SF::ty(i, j, 0)][SF::ty(i, j, 1)][SF::ty(i, j, 2)]);
             }
+    }
+}
+
+// G_q and detJ_q of every cell for a diffusion form with a field tensor (tabulated D_q in, 7 doubles per point out)
+__global__ void __launch_bounds__(256)
+k_tabulate_g_hex8(MeshView m, const double *__restrict__ dtab, double *__restrict__ gtab, Status *st)
+{
+    const int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= m.n_cells) return;
+    double x[8][3];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        const double *px = m.xyz + 3 * (int64_t)m.conn[cell * 8 + a];
+        x[a][0] = px[0]; x[a][1] = px[1]; x[a][2] = px[2];
+    }
+    double G[8][6], dq[8];
+    auto Dq = [&](int q, double(&D)[6]) {
+        const double *dp = dtab + (cell * 8 + q) * 6;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) D[k] = dp[k];
+    };
+    if (!hex8_sf_geometry<true, false>(x, Dq, G, dq)) { st->neg_detj = 1; st->cell = cell; }
+    double *gp = gtab + cell * 56;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) gp[7 * q + k] = G[q][k];
+        gp[7 * q + 6] = dq[q];
     }
 }
 
@@ -206,7 +238,7 @@ k_patch_hex8(MeshView m, FormArgs faK, FormArgs faM, FusedView pv, double *__res
 // Default form: one workgroup per patch.  The patch header is one 16-byte scalar load; instance metadata, row descriptors and the
 // pre-gathered vertex coordinates of the patch's nodes (contiguous, coalesced) are all requested at once right behind it, so a patch costs two
 // dependent trips to memory (header → inputs) instead of four (pointers → last row descriptor → node ids → coordinate gather).
-template <bool WK, bool WM, bool FK, bool FM>
+template <bool WK, bool WM, bool FK, bool FM, bool DIAG = false>
 __global__ void __launch_bounds__(256, 2)
 k_patch_hex8_staged(FormArgs faK, FormArgs faM, FusedView pv, const uint4 *__restrict__ hdrs, const double *__restrict__ pcoord, double *__restrict__ nzK,
                     double *__restrict__ nzM, Status *st)
@@ -279,7 +311,7 @@ k_patch_hex8_staged(FormArgs faK, FormArgs faM, FusedView pv, const uint4 *__res
         for (int i = 0; i < 8; ++i) ro[i] = ln[i] < (uint32_t)nrows ? desc[ln[i]].off : 0xFFFFFFFFu;
         int64_t cell = 0;
         if constexpr (FK || FM) cell = pv.elem_cell[e0 + ei];
-        hex8_instance<WK, WM, FK, FM>(x, cp, ro, cell, faK, faM, accK, accM, st, pv.elem_cell, e0 + ei, [] {});
+        hex8_instance<WK, WM, FK, FM, DIAG>(x, cp, ro, cell, faK, faM, accK, accM, st, pv.elem_cell, e0 + ei, [] {});
     }
     TB_ST(3);
     __syncthreads();
@@ -344,6 +376,15 @@ int launch_assemble_hex8_patch(tb_form *fK, tb_form *fM, tb_pattern *p, double t
     int rc = reset_status(dev);
     if (rc) return rc;
     if (fK && fK->field && !fK->d_dtab) { rc = tabulate_diffusion_field(fK); if (rc) return rc; }
+    if (fK && fK->field && !fK->d_gtab) {
+        const size_t bytes = sizeof(double) * 56 * (size_t)m->n_cells;
+        hipError_t e = hipMalloc((void **)&fK->d_gtab, bytes);
+        if (e != hipSuccess) { set_error("G table of the hexahedron patch kernel (%zu B): %s", bytes, hipGetErrorString(e)); return TB_ERR_NOMEM; }
+        hipLaunchKernelGGL(k_tabulate_g_hex8, dim3((unsigned)((m->n_cells + 255) / 256)), dim3(256), 0, dev->stream, make_view(m), fK->d_dtab, fK->d_gtab, dev->d_status);
+        TB_HIP(hipGetLastError());
+        rc = check_status(dev);
+        if (rc) { (void)hipFree(fK->d_gtab); fK->d_gtab = nullptr; return rc; }
+    }
     const int nreg = fK && fM ? 2 : 1;
     rc = ensure_patch_fused(m, p, nreg);
     if (rc) return rc;
@@ -380,10 +421,14 @@ int launch_assemble_hex8_patch(tb_form *fK, tb_form *fM, tb_pattern *p, double t
         return TB_OK;
     };
 #define TB_PL(a, b, c, d) rc = launch(k_patch_hex8_staged<a, b, c, d>, k_patch_hex8<a, b, c, d>)
-    if (fK && fM) { if (fk && fm) TB_PL(true, true, true, true); else if (fk) TB_PL(true, true, true, false); else if (fm) TB_PL(true, true, false, true); else TB_PL(true, true, false, false); }
-    else if (fK) { if (fk) TB_PL(true, false, true, false); else TB_PL(true, false, false, false); }
+#define TB_PLD(a, b, c, d) rc = launch(k_patch_hex8_staged<a, b, c, d, true>, k_patch_hex8<a, b, c, d>)
+    // constant diagonal tensors (isotropic / axis-aligned conductivities) take the variant with the cheaper A·D product
+    const bool diag = fK && !fk && aK.D[1] == 0.0 && aK.D[2] == 0.0 && aK.D[5] == 0.0 && aK.D[3] == 0.0 && aK.D[6] == 0.0 && aK.D[7] == 0.0;
+    if (fK && fM) { if (fk && fm) TB_PL(true, true, true, true); else if (fk) TB_PL(true, true, true, false); else if (fm) { if (diag) TB_PLD(true, true, false, true); else TB_PL(true, true, false, true); } else { if (diag) TB_PLD(true, true, false, false); else TB_PL(true, true, false, false); } }
+    else if (fK) { if (fk) TB_PL(true, false, true, false); else if (diag) TB_PLD(true, false, false, false); else TB_PL(true, false, false, false); }
     else { if (fm) TB_PL(false, true, false, true); else TB_PL(false, true, false, false); }
 #undef TB_PL
+#undef TB_PLD
     if (rc) return rc;
     TB_HIP(hipGetLastError());
 #ifdef TB_ABLATION
