@@ -45,10 +45,11 @@ struct FusedView {
 // One cell instance: geometry of the 8 points (once for both forms), sum-factorised Kₑ / Mₑ, entries of owned rows added to the LDS row
 // accumulators.  x: vertex coordinates, cp: the cell's 64 positions (byte i*8+j; dwords 2i, 2i+1 hold row i), ro[i]: entry offset of row i
 // in the accumulator block or 0xFFFFFFFF when the patch does not own it.
-// mid(): called once between the Kₑ and the Mₑ part, where few registers are live (the persistent kernel issues its prefetch there).
-template <bool WK, bool WM, bool FK, bool FM, bool DIAG = false, class Mid>
-__device__ __forceinline__ void hex8_instance(const double (&x)[8][3], const uint4 (&cp)[4], const uint32_t (&ro)[8], int64_t cell, const FormArgs &faK,
-                                              const FormArgs &faM, double *accK, double *accM, Status *st, const int32_t *elem_cell, int64_t e, Mid &&mid)
+// meta(cp, ro) delivers the scatter metadata when the scatter starts (the streaming kernel reads them from LDS only then: held from the start, they
+// cost 24 registers through the contraction).
+template <bool WK, bool WM, bool FK, bool FM, bool DIAG = false, class Meta>
+__device__ __forceinline__ void hex8_instance(const double (&x)[8][3], Meta &&meta, int64_t cell, const FormArgs &faK,
+                                              const FormArgs &faM, double *accK, double *accM, Status *st, const int32_t *elem_cell, int64_t e)
 {
     double G[8][6], dq[8];
     if constexpr (FK) {
@@ -71,6 +72,11 @@ __device__ __forceinline__ void hex8_instance(const double (&x)[8][3], const uin
 #endif
         if (!hex8_sf_geometry<WK, false, DIAG>(x, Dq, G, dq)) { st->neg_detj = 1; st->cell = elem_cell[e]; }
     }
+    Hex8SFK c;
+    if constexpr (WK) hex8_sf_contract(G, c);
+    uint4 cp[4];
+    uint32_t ro[8];
+    meta(cp, ro);
     bool own[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) own[i] = ro[i] != 0xFFFFFFFFu;
@@ -87,8 +93,6 @@ __device__ __forceinline__ void hex8_instance(const double (&x)[8][3], const uin
         return (w >> (8 * (j & 3))) & 0xffu;
     };
     if constexpr (WK) {
-        Hex8SFK c;
-        hex8_sf_contract(G, c);
         // every entry goes to LDS as soon as it is formed (rows i and j of the symmetric pair): Kₑ is never held as a whole
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -99,7 +103,6 @@ __device__ __forceinline__ void hex8_instance(const double (&x)[8][3], const uin
                 if (j > i && own[j]) unsafeAtomicAdd(accK + (ro[j] + pos(j, i)), v);
             }
     }
-    mid();
     if constexpr (WM) {
         if constexpr (FM) { // ρ at the Gauss points from first-order nodal data per cell (FieldCoefficient, coefficients.jl:85-99)
             double rn[8];
@@ -215,7 +218,7 @@ k_patch_hex8(MeshView m, FormArgs faK, FormArgs faM, FusedView pv, double *__res
         for (int i = 0; i < 8; ++i) ro[i] = ln[i] < (uint32_t)nrows ? desc[ln[i]].off : 0xFFFFFFFFu;
         int64_t cell = 0;
         if constexpr (FK || FM) cell = pv.elem_cell[e];
-        hex8_instance<WK, WM, FK, FM>(x, cp, ro, cell, faK, faM, accK, accM, st, pv.elem_cell, e, [] {});
+        hex8_instance<WK, WM, FK, FM>(x, [&](uint4(&c4)[4], uint32_t(&r8)[8]) { for (int k = 0; k < 4; ++k) c4[k] = cp[k]; for (int k = 0; k < 8; ++k) r8[k] = ro[k]; }, cell, faK, faM, accK, accM, st, pv.elem_cell, e);
         e = en; lnv = lnn; sig = sign;
     }
     __syncthreads();
@@ -311,7 +314,7 @@ k_patch_hex8_staged(FormArgs faK, FormArgs faM, FusedView pv, const uint4 *__res
         for (int i = 0; i < 8; ++i) ro[i] = ln[i] < (uint32_t)nrows ? desc[ln[i]].off : 0xFFFFFFFFu;
         int64_t cell = 0;
         if constexpr (FK || FM) cell = pv.elem_cell[e0 + ei];
-        hex8_instance<WK, WM, FK, FM, DIAG>(x, cp, ro, cell, faK, faM, accK, accM, st, pv.elem_cell, e0 + ei, [] {});
+        hex8_instance<WK, WM, FK, FM, DIAG>(x, [&](uint4(&c4)[4], uint32_t(&r8)[8]) { for (int k = 0; k < 4; ++k) c4[k] = cp[k]; for (int k = 0; k < 8; ++k) r8[k] = ro[k]; }, cell, faK, faM, accK, accM, st, pv.elem_cell, e0 + ei);
     }
     TB_ST(3);
     __syncthreads();
