@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=64)
 ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--strategies", default="atomic,color,element")
 args = ap.parse_args()
 import thunderbolt_jl_amd as tb
 dev = tb.MI355XDevice(0)
@@ -15,6 +16,8 @@ sp = tb.allocate_matrix(dh)
 out = {"workload": "scalar Q2, %d^3 hex (%d cells, %d dofs, nnz %d)" % (args.n, g.n_cells, dh.ndofs, sp.nnz)}
 D = np.array([[2.0, 0.3, 0.1], [0.3, 1.5, -0.2], [0.1, -0.2, 1.0]])
 for sname, st in (("atomic", tb.AtomicAssemblyStrategy(dev)), ("color", tb.PerColorAssemblyStrategy(dev)), ("element", tb.ElementAssemblyStrategy(dev))):
+    if sname not in args.strategies.split(","):
+        continue
     ops = {"mass": tb.setup_operator(st, tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.0)), dh, sp),
            "diffusion": tb.setup_operator(st, tb.BilinearDiffusionIntegrator(tb.ConstantCoefficient(D)), dh, sp),
            "source": tb.setup_operator(st, tb.LinearIntegrator(tb.AnalyticalCoefficient("cos_exp")), dh)}

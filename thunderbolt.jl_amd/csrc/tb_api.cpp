@@ -248,9 +248,9 @@ int tb_mesh_create(tb_device *dev, int geom_kind, int64_t n_nodes, const double 
 int tb_mesh_destroy(tb_mesh *m)
 {
     if (!m) return TB_OK;
-    hipFree(m->d_xyz); hipFree(m->d_conn); hipFree(m->d_cell_dofs); hipFree(m->d_node_dof0);
+    hipFree(m->d_xyz); hipFree(m->d_conn); hipFree(m->d_cell_dofs); hipFree(m->d_node_dof0); hipFree(m->d_cell_xyz);
     if (m->colors) hipFree(m->colors->d_cells);
-    if (m->ea) { hipFree(m->ea->d_ptr); hipFree(m->ea->d_src); hipFree(m->ea->d_ea); }
+    if (m->ea) { hipFree(m->ea->d_ptr); hipFree(m->ea->d_src); hipFree(m->ea->d_ea); hipFree(m->ea->d_ell); }
     free_patch_plan(m);
     free_vec_patch_plans(m);
     delete m;

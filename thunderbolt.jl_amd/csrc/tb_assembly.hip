@@ -760,117 +760,291 @@ __device__ __forceinline__ void q2_geometry(const double *s_x, int q, double *ge
     }
 }
 
-template <int FORM, bool FIELD>
-__global__ void __launch_bounds__(256)
-k_matrix_q2(MeshView m, FormArgs fa, const int32_t *__restrict__ list, const int64_t *__restrict__ rowptr, const uint16_t *__restrict__ pos, double *__restrict__ nz,
-            int atomic /*0 rmw, 1 atomic, 2 store Kₑ*/, double *__restrict__ ke, Status *st)
+// Element matrices of the quadratic field on the matrix cores.  Both forms are one small GEMM per cell,
+//   Kₑ[i][j] = −Σ_(q,k) T[(q,k)][i]·G[(q,k)][j]   (T = dΩ·D·∇N, G = ∇N: 27 × 27 × 81)      Mₑ[i][j] = Σ_q (ρ dΩ N)[q][i]·N[q][j]   (27 × 27 × 27),
+// i.e. 2 × 2 tiles of v_mfma_f64_16x16x4_f64 with 21 / 7 k-steps.  The previous form (every lane summing its entries over the points out of LDS) was
+// bound by LDS bandwidth — six doubles read per three FMAs, 0.95 MB of LDS traffic per cell; an MFMA reads two doubles per lane for sixteen FMAs.
+// The four waves split the k-steps (each runs its share on every tile) and the partial tiles are summed through LDS in a fixed order, so the lower-left
+// tile of a symmetric form is never computed (SYM: 3 tiles instead of 4) and the stores of the element strategy are 729 consecutive doubles.
+// Reference-element values are formed from the 1-D factors in registers (no table loads); geometry per point as in q2_geometry.
+typedef double q2_d4 __attribute__((ext_vector_type(4)));
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. waits for every global store and prefetch load in flight
+__device__ __forceinline__ void lds_barrier()
 {
-    const Q2Tables &tb = g_q2_tables;
-    const int64_t cell = list ? list[blockIdx.x] : blockIdx.x;
-    const int tid = threadIdx.x;
-    __shared__ double s_x[24], s_geo[27][10];
-    __shared__ double s_G[FORM == TB_FORM_DIFFUSION ? 27 : 1][27][3], s_T[FORM == TB_FORM_DIFFUSION ? 27 : 1][27][3];
-    __shared__ double s_N[FORM == TB_FORM_MASS ? 27 : 1][27];
-    __shared__ int32_t s_dof[27];
-    if (tid < 27) s_dof[tid] = m.cell_dofs[cell * 27 + tid];
-    for (int i = tid; i < 24; i += 256) s_x[i] = m.xyz[3 * (int64_t)m.conn[cell * 8 + i / 3] + i % 3];
-    if constexpr (FORM == TB_FORM_MASS) for (int i = tid; i < 729; i += 256) s_N[i / 27][i % 27] = tb.N[i / 27][i % 27];
-    __syncthreads();
-    if (tid < 27) {
-        q2_geometry(s_x, tid, s_geo[tid], nullptr, cell, st);
-        if constexpr (FORM == TB_FORM_MASS) { // ρ·dΩ: constant density, or first-order nodal data per cell interpolated at the point
-            double rho = fa.rho;
-            if constexpr (FIELD) { rho = 0.0; for (int a = 0; a < 8; ++a) rho += tb.M[tid][a] * fa.field[cell * 8 + a]; }
-            s_geo[tid][9] *= rho;
-        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+__constant__ uint8_t g_q2_tix[27] = {
+    0 | 0 << 2 | 0 << 4, 2 | 0 << 2 | 0 << 4, 2 | 2 << 2 | 0 << 4, 0 | 2 << 2 | 0 << 4, 0 | 0 << 2 | 2 << 4, 2 | 0 << 2 | 2 << 4, 2 | 2 << 2 | 2 << 4,
+    0 | 2 << 2 | 2 << 4, 1 | 0 << 2 | 0 << 4, 2 | 1 << 2 | 0 << 4, 1 | 2 << 2 | 0 << 4, 0 | 1 << 2 | 0 << 4, 1 | 0 << 2 | 2 << 4, 2 | 1 << 2 | 2 << 4,
+    1 | 2 << 2 | 2 << 4, 0 | 1 << 2 | 2 << 4, 0 | 0 << 2 | 1 << 4, 2 | 0 << 2 | 1 << 4, 2 | 2 << 2 | 1 << 4, 0 | 2 << 2 | 1 << 4, 1 | 1 << 2 | 0 << 4,
+    1 | 0 << 2 | 1 << 4, 2 | 1 << 2 | 1 << 4, 1 | 2 << 2 | 1 << 4, 0 | 1 << 2 | 1 << 4, 1 | 1 << 2 | 2 << 4, 1 | 1 << 2 | 1 << 4};
+
+// 1-D quadratic Lagrange factor t ∈ {0: ξ = −1, 1: ξ = 0, 2: ξ = +1} and its derivative at x (tb_elem.hpp Hex27::q1 / dq1)
+__device__ __forceinline__ double q2_l(int t, double x) { return t == 0 ? 0.5 * x * (x - 1.0) : t == 1 ? (1.0 - x * x) : 0.5 * x * (x + 1.0); }
+__device__ __forceinline__ double q2_dl(int t, double x) { return t == 0 ? x - 0.5 : t == 1 ? -2.0 * x : x + 0.5; }
+
+// geometry of point q = lane of the cell whose vertex coordinates sit in sx: J = Σ xₐ ⊗ ∂Mₐ/∂ξ of the trilinear map (tensor rule, first coordinate
+// fastest).  Mass: out[0] = ρ·detJ·w.  Diffusion: out[0..8] = S = −dΩ · J⁻¹ D J⁻ᵀ, the coefficient pulled back to the reference cell, so that
+// Kₑ[i][j] = Σ_q ∂Nᵢ/∂ξ · S_q · ∂Nⱼ/∂ξ with Kₑ[i,j] −= (∇Nⱼ·D·∇Nᵢ)·dΩ  (diffusion.jl:38-49; argument order of _inner_product_helper, utils.jl:409-410).
+template <bool DIFF, bool MASS_FIELD>
+__device__ __forceinline__ void q2_point_geometry(const double *sx, int q, double *out, double rho_c, const double *rho_nodes, const double *D, int64_t cell, Status *st)
+{
+    constexpr double GX = 0.7745966692414834, W0 = 0.5555555555555556, W1 = 0.8888888888888888;
+    const int q0 = q % 3, q1 = (q / 3) % 3, q2 = q / 9;
+    const double xi[3] = {GX * (q0 - 1), GX * (q1 - 1), GX * (q2 - 1)};
+    const double wq = (q0 == 1 ? W1 : W0) * (q1 == 1 ? W1 : W0) * (q2 == 1 ? W1 : W0);
+    double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, rho = 0.0;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        const double f0 = 1.0 + Hex8<3>::sgn(a, 0) * xi[0], f1 = 1.0 + Hex8<3>::sgn(a, 1) * xi[1], f2 = 1.0 + Hex8<3>::sgn(a, 2) * xi[2];
+        const double d[3] = {0.125 * Hex8<3>::sgn(a, 0) * f1 * f2, 0.125 * f0 * Hex8<3>::sgn(a, 1) * f2, 0.125 * f0 * f1 * Hex8<3>::sgn(a, 2)};
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) J[i][k] += sx[3 * a + i] * d[k];
+        if constexpr (MASS_FIELD) rho += 0.125 * f0 * f1 * f2 * rho_nodes[a];
     }
-    __syncthreads();
-    if constexpr (FORM == TB_FORM_DIFFUSION) {
-        // ∇Nₐ = ∂Nₐ/∂ξ · J⁻¹ and T = dΩ · D · ∇Nₐ for every (point, node)
-        for (int idx = tid; idx < 729; idx += 256) {
-            const int q = idx / 27, a = idx % 27;
-            const double *ji = s_geo[q];
-            const double d0 = tb.dN[q][a][0], d1 = tb.dN[q][a][1], d2 = tb.dN[q][a][2];
-            double gk[3];
+    const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1], c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2], c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+    const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+    const double dO = det * wq;
+    if (!(dO > 0.0)) { st->neg_detj = 1; st->cell = cell; }
+    if constexpr (!DIFF) { out[0] = dO * (MASS_FIELD ? rho : rho_c); return; }
+    const double id = 1.0 / det;
+    // ji[m][k] = ∂ξ_m/∂x_k
+    const double ji[3][3] = {{c00 * id, (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * id, (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * id},
+                             {c01 * id, (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * id, (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * id},
+                             {c02 * id, (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * id, (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * id}};
+    // ∇Nₐ[k] = Σ_m ∂Nₐ/∂ξ_m · ji[m][k];  S[m][n] = −dΩ Σ_kl ji[n][k] D[k][l] ji[m][l]   (m pairs with Nᵢ, n with Nⱼ: −∇Nⱼ·D·∇Nᵢ)
+    double E[3][3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) gk[k] = d0 * ji[k] + d1 * ji[3 + k] + d2 * ji[6 + k];
-            double D[9];
-            if constexpr (FIELD) { // tensor tabulated at the 27 points of the cell (k_tabulate_spectral / _isotropic over Hex8<3>: same point order)
-                const double *dq = fa.dtab + (cell * 27 + q) * 6;
-                D[0] = dq[0]; D[1] = D[3] = dq[1]; D[2] = D[6] = dq[2]; D[4] = dq[3]; D[5] = D[7] = dq[4]; D[8] = dq[5];
-            } else {
+    for (int m = 0; m < 3; ++m)
 #pragma unroll
-                for (int e = 0; e < 9; ++e) D[e] = fa.D[e];
-            }
+        for (int k = 0; k < 3; ++k) E[m][k] = -dO * (D[3 * k] * ji[m][0] + D[3 * k + 1] * ji[m][1] + D[3 * k + 2] * ji[m][2]); // −dΩ (D ∇ξ_m)[k]
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                s_G[q][a][k] = gk[k];
-                s_T[q][a][k] = ji[9] * (D[3 * k] * gk[0] + D[3 * k + 1] * gk[1] + D[3 * k + 2] * gk[2]);
-            }
-        }
-        __syncthreads();
-    }
-    const int64_t pbase = cell * 729;
-    if (atomic == 2) {
-        // element strategy: Kₑ leaves as one contiguous 729-entry run (gathered per row by k_gather_rows_q2).  Lane t < 243 owns row
-        // i = t / 9 and the three columns 3·(t % 9) …: one LDS read of the row's factor serves three entries.
-        if (tid < 243) {
-            const int i = tid / 9, j0 = 3 * (tid % 9);
-            double v[3] = {0.0, 0.0, 0.0};
-            if constexpr (FORM == TB_FORM_MASS) {
-                for (int q = 0; q < 27; ++q) {
-                    const double wi = s_geo[q][9] * s_N[q][i];
+    for (int m = 0; m < 3; ++m)
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) v[c] += wi * s_N[q][j0 + c];
-                }
-            } else {
-                for (int q = 0; q < 27; ++q) {
-                    const double t0 = s_T[q][i][0], t1 = s_T[q][i][1], t2 = s_T[q][i][2];
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) v[c] -= s_G[q][j0 + c][0] * t0 + s_G[q][j0 + c][1] * t1 + s_G[q][j0 + c][2] * t2;
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < 3; ++c) ke[pbase + 27 * i + j0 + c] = v[c];
-        }
-        return;
-    }
-    for (int e = tid; e < 729; e += 256) {
-        const int i = e / 27, j = e % 27;
-        double v = 0.0;
-        if constexpr (FORM == TB_FORM_MASS) {
-            // Mₑ[i,j] += ρ·Nᵢ·Nⱼ·dΩ  (mass.jl:32-42)
-            for (int q = 0; q < 27; ++q) v += s_geo[q][9] * s_N[q][i] * s_N[q][j];
-        } else {
-            // Kₑ[i,j] −= (∇Nⱼ·D·∇Nᵢ)·dΩ  (diffusion.jl:38-49; argument order of _inner_product_helper, utils.jl:409-410)
-            for (int q = 0; q < 27; ++q) v -= s_G[q][j][0] * s_T[q][i][0] + s_G[q][j][1] * s_T[q][i][1] + s_G[q][j][2] * s_T[q][i][2];
-        }
-        const int64_t k = rowptr[s_dof[i]] + pos[pbase + e];
-        if (atomic) unsafeAtomicAdd(nz + k, v); else nz[k] += v;
-    }
+        for (int n = 0; n < 3; ++n) out[3 * m + n] = E[m][0] * ji[n][0] + E[m][1] * ji[n][1] + E[m][2] * ji[n][2];
 }
 
-// ElementAssemblyStrategy for the quadratic scalar field, second pass: one wavefront per row sums the rows of the ≤ 8 element matrices that
-// touch its dof into an LDS copy of the CSR row (27 lanes, one entry each, cell after cell: no conflicts) and stores the row once.
+// The workgroup is persistent (cells blockIdx.x, + gridDim.x, …) and pipelined over two barriers per cell: while waves 0–2 run the tiles of cell c
+// (tile 0: i, j < 16; tile 1: i < 16 ≤ j; tile 2: i, j ≥ 16; the lower-left tile of a symmetric form is the mirror of tile 1 and is stored from it),
+// wave 3 computes the point geometry of cell c + 1 and requests the vertex coordinates of cell c + 2, so neither the two dependent loads
+// (connectivity → coordinates) nor the 27-lane geometry phase sit on the critical path.  Non-symmetric tensors (SYM = false): wave 3 runs the
+// fourth tile before the geometry.  With the coefficient pulled back (S_q above) the B operand — reference gradients ∂Nⱼ/∂ξ (mass: Nⱼ) at the
+// points — is the same for every cell: each lane keeps its 21 (7) values in registers, as it keeps the reference gradients of the three
+// (point, node) pairs whose A entries  A[(q,n)][i] = Σ_m ∂Nᵢ/∂ξ_m S_q[m][n]  (mass: ρ dΩ_q Nᵢ) it forms per cell: 9 FMAs per pair and one LDS
+// operand buffer.  Tiles leave from the accumulator registers: 16 lanes store 16 consecutive doubles of an element-matrix row.
+template <int FORM, bool FIELD, bool SYM>
+__global__ void __launch_bounds__(256, 3)
+k_matrix_q2(MeshView m, FormArgs fa, const double *__restrict__ cell_xyz, const int32_t *__restrict__ list, int64_t n_list, const int64_t *__restrict__ rowptr,
+            const uint16_t *__restrict__ pos, double *__restrict__ nz, int atomic /*0 rmw, 1 atomic, 2 store Kₑ*/, double *__restrict__ ke, int rot, Status *st)
+{
+    constexpr bool DIFF = FORM == TB_FORM_DIFFUSION;
+    constexpr int KD = DIFF ? 81 : 27, KS = (KD + 3) / 4, LD = 27, NS = DIFF ? 9 : 1;
+    constexpr double GX = 0.7745966692414834;
+    // wave roles rotate with the workgroup so that the producer waves (no matrix-core work) do not all sit on the same SIMD
+    const int lane = threadIdx.x & 63, wv = ((threadIdx.x >> 6) + (blockIdx.x >> 3) + blockIdx.x / rot) & 3, tid = 64 * wv + lane, lr = lane & 15, g = lane >> 4;
+    __shared__ double s_x[2][24], s_rho[2][8], s_S[2][27][NS], sA[KD * LD], s_out[729];
+    __shared__ int32_t s_dof[27];
+    auto cell_of = [&](int64_t it) -> int64_t { return list ? (int64_t)list[it] : it; };
+    int64_t it = blockIdx.x;
+    if (it >= n_list) return;
+    // reference values at (point q, node a): N and ∂N/∂ξ from the 1-D factors (tb_elem.hpp Hex27)
+    auto ref = [&](int q, int a, double &n, double (&d)[3]) {
+        const int tx = g_q2_tix[a], t0 = tx & 3, t1 = (tx >> 2) & 3, t2 = tx >> 4;
+        const double x0 = GX * (q % 3 - 1), x1 = GX * ((q / 3) % 3 - 1), x2 = GX * (q / 9 - 1);
+        const double l0 = q2_l(t0, x0), l1 = q2_l(t1, x1), l2 = q2_l(t2, x2);
+        n = l0 * l1 * l2;
+        d[0] = q2_dl(t0, x0) * l1 * l2; d[1] = l0 * q2_dl(t1, x1) * l2; d[2] = l0 * l1 * q2_dl(t2, x2);
+    };
+    // the (q, a) pairs this lane forms A entries for: the operand phase runs on the tile waves only (192 lanes of a symmetric form: wave 3 is the
+    // producer of the next cell's geometry and shares no registers with the tile code path)
+    constexpr int NC = SYM ? 192 : 256, NR = (729 + NC - 1) / NC;
+    double rn[NR], rd[NR][3];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int idx = tid + NC * r < 729 ? tid + NC * r : 728;
+        ref(idx / 27, idx % 27, rn[r], rd[r]);
+    }
+    // this lane's B operand: B[kk = 4s + g][j = 16·tj + lr];  kk = 3q + n (mass: kk = q) — the table goes through the (still unused) operand buffer once
+    const int ti = wv == 0 || wv == 1 ? 0 : 1, tj = wv == 1 || wv == 2 ? 1 : 0;
+    const int ra = 16 * ti + lr < 27 ? 16 * ti + lr : 26, cb = 16 * tj + lr < 27 ? 16 * tj + lr : 26;
+    if (tid < NC) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int idx = tid + NC * r;
+            if (idx < 729) {
+                const int q = idx / 27, a = idx - 27 * q;
+                if constexpr (!DIFF) sA[q * LD + a] = rn[r];
+                else {
+#pragma unroll
+                    for (int n = 0; n < 3; ++n) sA[(3 * q + n) * LD + a] = rd[r][n];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    double Bv[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int kk = 4 * s + g;
+        Bv[s] = sA[(kk < KD ? kk : KD - 1) * LD + cb];
+    }
+    // producer: inputs of later cells in flight (lane < 24: a vertex coordinate; 32..39: nodal density; lane = point: the tensor there).  Two sets,
+    // used alternately: a set is requested two iterations before it is parked, so the load latency never sits on the critical path
+    struct Pre { double x = 0.0, r = 0.0, d[6] = {0, 0, 0, 0, 0, 0}; };
+    Pre PA, PB;
+    auto request = [&](Pre &P, int64_t itn) {
+        if (itn >= n_list) return;
+        const int64_t c = cell_of(itn);
+        if (lane < 24) P.x = cell_xyz[c * 24 + lane];
+        if constexpr (!DIFF && FIELD) if (lane >= 32 && lane < 40) P.r = fa.field[c * 8 + lane - 32];
+        if constexpr (DIFF && FIELD) if (lane < 27) { // tensor tabulated at the 27 points of the cell (k_tabulate_spectral / _isotropic over Hex8<3>: same point order)
+#pragma unroll
+            for (int e = 0; e < 6; ++e) P.d[e] = fa.dtab[(c * 27 + lane) * 6 + e];
+        }
+    };
+    double Dq[6] = {0, 0, 0, 0, 0, 0};
+    auto park = [&](const Pre &P, int b) { // coordinates / densities to LDS; the tensor stays in this lane's registers
+        if (lane < 24) s_x[b][lane] = P.x;
+        if constexpr (!DIFF && FIELD) if (lane >= 32 && lane < 40) s_rho[b][lane - 32] = P.r;
+        if constexpr (DIFF && FIELD) {
+#pragma unroll
+            for (int e = 0; e < 6; ++e) Dq[e] = P.d[e];
+        }
+    };
+    auto geometry = [&](int b, int64_t itn) {
+        double D[9];
+        if constexpr (DIFF && FIELD) { D[0] = Dq[0]; D[1] = D[3] = Dq[1]; D[2] = D[6] = Dq[2]; D[4] = Dq[3]; D[5] = D[7] = Dq[4]; D[8] = Dq[5]; }
+        else {
+#pragma unroll
+            for (int e = 0; e < 9; ++e) D[e] = DIFF ? fa.D[e] : 0.0;
+        }
+        if (lane < 27) q2_point_geometry<DIFF, !DIFF && FIELD>(s_x[b], lane, s_S[b][lane], fa.rho, s_rho[b], D, cell_of(itn), st);
+    };
+    const int64_t G = gridDim.x;
+    if (wv == 3) { // prologue: geometry of the first cell; sets A and B hold the inputs of the second and third
+        request(PA, it);
+        park(PA, 0);
+        __builtin_amdgcn_wave_barrier();
+        geometry(0, it);
+        request(PA, it + G);
+        request(PB, it + 2 * G);
+    }
+    // one cell; PROD: this wave parks / requests / computes the next geometry, TILE: it forms operands and runs its tile
+    auto iteration = [&](auto prod, auto tile, int buf, Pre &P) __attribute__((always_inline)) {
+        constexpr bool PROD = decltype(prod)::value, TILE = decltype(tile)::value;
+        const int64_t cell = cell_of(it);
+        lds_barrier(); // S of this cell is in s_S[buf]; the operand buffer is free
+        if constexpr (TILE) {
+            if (tid < 27 && atomic != 2) s_dof[tid] = m.cell_dofs[cell * 27 + tid];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int idx = tid + NC * r;
+                if (idx < 729) {
+                    const int q = idx / 27, a = idx - 27 * q;
+                    const double *S = s_S[buf][q];
+                    if constexpr (!DIFF) sA[q * LD + a] = S[0] * rn[r];          // Mₑ[i,j] += ρ·Nᵢ·Nⱼ·dΩ  (mass.jl:32-42)
+                    else {
+#pragma unroll
+                        for (int n = 0; n < 3; ++n) sA[(3 * q + n) * LD + a] = rd[r][0] * S[n] + rd[r][1] * S[3 + n] + rd[r][2] * S[6 + n];
+                    }
+                }
+            }
+        }
+        if constexpr (PROD) { park(P, buf ^ 1); request(P, it + 3 * G); } // next cell's inputs (requested two iterations ago) → LDS; the set is free again
+        lds_barrier(); // operands complete
+        if constexpr (TILE) {
+            // lane (lr, g) feeds A[row lr][k g] and B[k g][col lr]; rows / columns ≥ 27 are clamped (never stored); the k-padding vanishes through A
+            q2_d4 acc = q2_d4{0, 0, 0, 0};
+            double av[KS]; // all A reads in flight before the first product
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int kk = 4 * s + g;
+                av[s] = sA[(kk < KD ? kk : KD - 1) * LD + ra];
+            }
+            if (4 * (KS - 1) + g >= KD) av[KS - 1] = 0.0;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], Bv[s], acc, 0, 0, 0);
+            // D[row g + 4·reg][col lr]: the element strategy stores its tile straight into the contiguous Kₑ (gathered per row by k_gather_rows_q2); the
+            // scattering strategies pass it through LDS so that the position table is read, and the row pointers are looked up, in entry order
+            const int64_t pbase = cell * 729;
+            const int j = 16 * tj + lr;
+            if (j < 27) {
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int i = 16 * ti + g + 4 * rg;
+                    if (i >= 27) continue;
+                    if (atomic == 2) {
+                        ke[pbase + 27 * i + j] = acc[rg];
+                        if (SYM && wv == 1) ke[pbase + 27 * j + i] = acc[rg];
+                    } else {
+                        s_out[27 * i + j] = acc[rg];
+                        if (SYM && wv == 1) s_out[27 * j + i] = acc[rg];
+                    }
+                }
+            }
+        }
+        if (atomic != 2) { // uniform over the workgroup
+            lds_barrier();
+            if constexpr (TILE) {
+                const int64_t pbase = cell * 729;
+                for (int e = tid; e < 729; e += NC) {
+                    const int64_t k = rowptr[s_dof[e / 27]] + pos[pbase + e];
+                    if (atomic) unsafeAtomicAdd(nz + k, s_out[e]); else nz[k] += s_out[e];
+                }
+            }
+        }
+        if constexpr (PROD) if (it + G < n_list) geometry(buf ^ 1, it + G);
+    };
+    auto run = [&](auto prod, auto tile) __attribute__((always_inline)) {
+        for (;;) {
+            iteration(prod, tile, 0, PA);
+            it += G;
+            if (it >= n_list) break;
+            iteration(prod, tile, 1, PB);
+            it += G;
+            if (it >= n_list) break;
+        }
+    };
+    if (wv == 3) run(std::true_type{}, std::integral_constant<bool, !SYM>{});
+    else run(std::false_type{}, std::true_type{});
+}
+
+// ElementAssemblyStrategy for the quadratic scalar field, second pass: a half-wave per row sums the rows of the element matrices that touch its dof
+// (27 lanes, an LDS copy of the CSR row, cells in ascending order: bit-reproducible) and stores the CSR row once.  The contributing (cell, local row)
+// slots come from a fixed-width table (W per row, −1 padded: one load, no pointer chase) and the index and value loads of eight cells are all in
+// flight before the first addition.
 __global__ void __launch_bounds__(256)
-k_gather_rows_q2(int64_t n_rows, const int64_t *__restrict__ ea_ptr, const int32_t *__restrict__ ea_src, const double *__restrict__ ke,
-                 const uint16_t *__restrict__ pos, const int64_t *__restrict__ rowptr, double *__restrict__ nz, int max_row)
+k_gather_rows_q2(int64_t n_rows, const int32_t *__restrict__ ell, int W, const double *__restrict__ ke, const uint16_t *__restrict__ pos,
+                 const int64_t *__restrict__ rowptr, double *__restrict__ nz, int max_row)
 {
     extern __shared__ double s_rows[];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + wv;
+    const int hw = threadIdx.x >> 5, l = threadIdx.x & 31;
+    const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 5) + hw;
     if (r >= n_rows) return;
-    double *row = s_rows + (size_t)wv * max_row;
+    double *row = s_rows + (size_t)hw * max_row;
     const int64_t g0 = rowptr[r];
     const int len = (int)(rowptr[r + 1] - g0);
-    for (int p = lane; p < len; p += 64) row[p] = 0.0;
-    __builtin_amdgcn_wave_barrier();
-    for (int64_t k = ea_ptr[r]; k < ea_ptr[r + 1]; ++k) {
-        const int64_t slot = ea_src[k]; // cell · 27 + local row
-        if (lane < 27) row[pos[slot * 27 + lane]] += ke[slot * 27 + lane];
-        __builtin_amdgcn_wave_barrier();
+    for (int p = l; p < len; p += 32) row[p] = 0.0;
+    for (int kb = 0; kb < W; kb += 8) {
+        int slot[8], pp[8];
+        double vv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) slot[k] = ell[r * W + kb + k]; // cell · 27 + local row
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const bool on = slot[k] >= 0 && l < 27;
+            pp[k] = on ? pos[(int64_t)slot[k] * 27 + l] : -1;
+            vv[k] = on ? ke[(int64_t)slot[k] * 27 + l] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (pp[k] >= 0) row[pp[k]] += vv[k];
     }
-    for (int p = lane; p < len; p += 64) nz[g0 + p] = row[p];
+    for (int p = l; p < len; p += 32) nz[g0 + p] = row[p];
 }
 
 __global__ void __launch_bounds__(64)
@@ -894,6 +1068,22 @@ k_vector_q2(MeshView m, FormArgs fa, const int32_t *__restrict__ list, double *_
         const int32_t d = m.cell_dofs[cell * 27 + tid];
         if (atomic) unsafeAtomicAdd(b + d, v); else b[d] += v;
     }
+}
+
+__global__ void k_cell_xyz(const int32_t *__restrict__ conn, const double *__restrict__ xyz, int64_t n, int nverts, double *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; // (cell, vertex, component)
+    if (i < n * nverts * 3) out[i] = xyz[3 * (int64_t)conn[i / 3] + i % 3];
+}
+
+static int ensure_cell_xyz(tb_mesh *m)
+{
+    if (m->d_cell_xyz) return TB_OK;
+    const int64_t n = m->n_cells * m->nverts * 3;
+    TB_HIP(hipMalloc((void **)&m->d_cell_xyz, sizeof(double) * n));
+    hipLaunchKernelGGL(k_cell_xyz, dim3(nblocks(n, 256)), dim3(256), 0, m->dev->stream, m->d_conn, m->d_xyz, m->n_cells, m->nverts, m->d_cell_xyz);
+    TB_HIP(hipGetLastError());
+    return TB_OK;
 }
 
 static int ensure_q2pos(tb_pattern *p)
@@ -931,7 +1121,7 @@ static int run_q2(tb_form *f, tb_pattern *p, int strategy, double t, double *d_n
     const MeshView mv = make_view(m);
     const FormArgs fa = make_args(f, t);
     const bool ea = d_nz && (strategy == TB_STRATEGY_ELEMENT);
-    if (d_nz) { int rc = ensure_q2pos(p); if (rc) return rc; if (!ea) TB_HIP(hipMemsetAsync(d_nz, 0, (size_t)p->nnz * sizeof(double), dev->stream)); }
+    if (d_nz) { int rc = ensure_q2pos(p); if (rc) return rc; rc = ensure_cell_xyz(m); if (rc) return rc; if (!ea) TB_HIP(hipMemsetAsync(d_nz, 0, (size_t)p->nnz * sizeof(double), dev->stream)); }
     else TB_HIP(hipMemsetAsync(d_b, 0, (size_t)m->ndofs * sizeof(double), dev->stream));
     double *kebuf = nullptr;
     if (ea) {
@@ -944,9 +1134,15 @@ static int run_q2(tb_form *f, tb_pattern *p, int strategy, double t, double *d_n
     }
     auto go = [&](const int32_t *list, int64_t n, int atomic) -> int {
         if (n == 0) return TB_OK;
-#define TB_Q2(FORM, FIELD) hipLaunchKernelGGL((k_matrix_q2<FORM, FIELD>), dim3((unsigned)n), dim3(256), 0, dev->stream, mv, fa, list, p->d_rowptr, p->d_q2pos, d_nz, atomic, kebuf, dev->d_status)
-        if (d_nz && f->kind == TB_FORM_MASS) { if (f->field) TB_Q2(TB_FORM_MASS, true); else TB_Q2(TB_FORM_MASS, false); }
-        else if (d_nz) { if (f->field) TB_Q2(TB_FORM_DIFFUSION, true); else TB_Q2(TB_FORM_DIFFUSION, false); }
+        // persistent workgroups: three per CU (≤ 168 VGPRs)
+        const unsigned wgs = (unsigned)std::min<int64_t>(n, (int64_t)dev->n_cu * 3);
+#define TB_Q2(FORM, FIELD, SYM) hipLaunchKernelGGL((k_matrix_q2<FORM, FIELD, SYM>), dim3(wgs), dim3(256), 0, dev->stream, mv, fa, m->d_cell_xyz, list, n, p->d_rowptr, p->d_q2pos, d_nz, atomic, kebuf, dev->n_cu, dev->d_status)
+        if (d_nz && f->kind == TB_FORM_MASS) { if (f->field) TB_Q2(TB_FORM_MASS, true, true); else TB_Q2(TB_FORM_MASS, false, true); }
+        else if (d_nz) {
+            // a non-symmetric constant tensor gives a non-symmetric Kₑ: all four tiles
+            const bool sym = f->field || (fa.D[1] == fa.D[3] && fa.D[2] == fa.D[6] && fa.D[5] == fa.D[7]);
+            if (f->field) TB_Q2(TB_FORM_DIFFUSION, true, true); else if (sym) TB_Q2(TB_FORM_DIFFUSION, false, true); else TB_Q2(TB_FORM_DIFFUSION, false, false);
+        }
 #undef TB_Q2
         else hipLaunchKernelGGL(k_vector_q2, dim3((unsigned)n), dim3(64), 0, dev->stream, mv, fa, list, d_b, atomic, dev->d_status);
         TB_HIP(hipGetLastError());
@@ -957,8 +1153,10 @@ static int run_q2(tb_form *f, tb_pattern *p, int strategy, double t, double *d_n
         if (rc) return rc;
         if (!p->max_row_len) for (int64_t r = 0; r < p->n_rows; ++r) p->max_row_len = std::max<int64_t>(p->max_row_len, p->h_rowptr[r + 1] - p->h_rowptr[r]);
         const int max_row = (int)p->max_row_len;
-        hipLaunchKernelGGL(k_gather_rows_q2, dim3((unsigned)((m->ndofs + 3) / 4)), dim3(256), sizeof(double) * 4 * (size_t)max_row, dev->stream, m->ndofs,
-                           m->ea->d_ptr, m->ea->d_src, kebuf, p->d_q2pos, p->d_rowptr, d_nz, max_row);
+        rc = ensure_ea_ell(m);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_gather_rows_q2, dim3((unsigned)((m->ndofs + 7) / 8)), dim3(256), sizeof(double) * 8 * (size_t)max_row, dev->stream, m->ndofs,
+                           m->ea->d_ell, m->ea->ell_w, kebuf, p->d_q2pos, p->d_rowptr, d_nz, max_row);
         TB_HIP(hipGetLastError());
         return TB_OK;
     }

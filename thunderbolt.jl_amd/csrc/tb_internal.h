@@ -54,6 +54,8 @@ struct EAPlan {                // dof → contributing (cell, local) slots, cell
     int64_t *d_ptr = nullptr;  // ndofs+1
     int32_t *d_src = nullptr;  // n_cells*ndpc indices into the element-vector buffer
     double *d_ea = nullptr;    // n_cells*ndpc element vectors
+    int32_t *d_ell = nullptr;  // the same slots as a fixed-width table (ell_w per dof, −1 padded), built on first use by ensure_ea_ell
+    int ell_w = 0;
 };
 
 // Patch plan: cells in Morton order are cut into patches; every dof (row) is owned by exactly one
@@ -150,6 +152,7 @@ struct tb_mesh {
     int32_t *d_conn = nullptr;
     int32_t *d_cell_dofs = nullptr;
     int32_t *d_node_dof0 = nullptr; // vector fields: first dof of every field node
+    double *d_cell_xyz = nullptr;   // vertex coordinates per cell (nverts × 3, cell-major), built on first use by the block-per-cell kernels
     int64_t n_nodes_field = 0;
     std::vector<int32_t> h_node_dof0;
     std::vector<double> h_xyz;
@@ -239,6 +242,7 @@ void dof_slots(const tb_mesh *m, std::vector<int64_t> &ptr, std::vector<int32_t>
 int build_color_plan(tb_mesh *m);
 int build_color_plan_subset(tb_mesh *m, const std::vector<int32_t> &cells, std::unique_ptr<ColorPlan> &out);
 int build_ea_plan(tb_mesh *m);
+int ensure_ea_ell(tb_mesh *m);
 int build_patch_plan(tb_mesh *m, int cells_per_patch);
 int build_patch_mat_plan(tb_pattern *p);
 int ensure_patch_plans(tb_mesh *m, tb_pattern *p); // builds / refits both so the LDS block allows two workgroups per CU

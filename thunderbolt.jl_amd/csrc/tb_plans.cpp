@@ -39,6 +39,25 @@ int build_ea_plan(tb_mesh *m)
     return TB_OK;
 }
 
+// fixed-width form of the slot lists (width = the largest number of cells at a dof, rounded up to a multiple of 8)
+int ensure_ea_ell(tb_mesh *m)
+{
+    if (!m->ea) { int rc = build_ea_plan(m); if (rc) return rc; }
+    if (m->ea->d_ell) return TB_OK;
+    std::vector<int64_t> ptr;
+    std::vector<int32_t> src;
+    dof_slots(m, ptr, src);
+    int64_t w = 0;
+    for (int64_t d = 0; d < m->ndofs; ++d) w = std::max(w, ptr[d + 1] - ptr[d]);
+    w = (w + 7) / 8 * 8;
+    std::vector<int32_t> ell((size_t)m->ndofs * w, -1);
+    for (int64_t d = 0; d < m->ndofs; ++d) std::copy(src.begin() + ptr[d], src.begin() + ptr[d + 1], ell.begin() + d * w);
+    int rc = upload(m->dev, ell, &m->ea->d_ell);
+    if (rc) return rc;
+    m->ea->ell_w = (int)w;
+    return TB_OK;
+}
+
 // Greedy colouring of the cell conflict graph (two cells conflict iff they share a dof): smallest
 // colour not used by any neighbour, neighbours found through a per-dof colour bitmask.
 int build_color_plan(tb_mesh *m)
