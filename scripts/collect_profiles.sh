@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 out=gpurun_out/$tag
 mkdir -p "$out"
 # micro-benchmarks are built here (binaries are not tracked)
-for mb in mfma_f64 lds_atomic wg_launch; do
+for mb in mfma_f64 mfma_f64_4x4 lds_atomic wg_launch; do
   [ -f scripts/microbench/$mb.hip ] && hipcc --offload-arch=gfx950 -O3 scripts/microbench/$mb.hip -o scripts/microbench/$mb.bin 2>/dev/null
 done
 python3 bench.py > "$out/bench_216.json" 2> "$out/bench_216.err"
@@ -31,6 +31,11 @@ if [ "$2" != "bench-only" ]; then
   python3 scripts/rocpd_summary.py "$out/kte/kte_results.db" --json "$out/monodomain_kernel_stats.json" > "$out/monodomain_kernel_stats.txt"
   [ -x scripts/microbench/mfma_f64.bin ] && ./scripts/microbench/mfma_f64.bin > "$out/mfma_f64_microbench.txt" 2>&1
   [ -x scripts/microbench/wg_launch.bin ] && ./scripts/microbench/wg_launch.bin > "$out/wg_launch_microbench.txt" 2>&1
+  [ -x scripts/microbench/mfma_f64_4x4.bin ] && ./scripts/microbench/mfma_f64_4x4.bin > "$out/mfma_f64_4x4_microbench.txt" 2>&1
+  # scalar forms on the quadratic field
+  python3 scripts/bench_q2_scalar.py --n 64 > "$out/q2_scalar_64.json" 2>/dev/null
+  rocprofv3 --kernel-trace --stats -d "$out/ktq" -o ktq -- python3 scripts/bench_q2_scalar.py --n 64 --strategies element > /dev/null 2>&1
+  python3 scripts/rocpd_summary.py "$out/ktq/ktq_results.db" --json "$out/q2_scalar_kernel_stats.json" > "$out/q2_scalar_kernel_stats.txt"
 fi
-rm -rf "$out"/kt "$out"/pmc1 "$out"/pmc2 "$out"/pmc3 "$out"/pmc4 "$out"/ktm "$out"/kte
+rm -rf "$out"/kt "$out"/pmc1 "$out"/pmc2 "$out"/pmc3 "$out"/pmc4 "$out"/ktm "$out"/kte "$out"/ktq
 tail -c 700 "$out/bench_216.json"; head -6 "$out/kernel_stats.txt"; cat "$out/traffic.json" | head -30

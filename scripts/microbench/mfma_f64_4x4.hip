@@ -22,6 +22,24 @@ __global__ void __launch_bounds__(256) k_4x4(double *out, int iters, double a0, 
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// the same with NC dependent chains per wave (each product waits for the previous one of its chain)
+template <int NC>
+__global__ void __launch_bounds__(256) k_4x4_chains(double *out, int iters, double a0, double b0)
+{
+    double acc[NC];
+    for (int i = 0; i < NC; ++i) acc[i] = 0.0;
+    double a = a0 + threadIdx.x, b = b0 - threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 16 / NC; ++r)
+#pragma unroll
+            for (int i = 0; i < NC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0;
+    for (int i = 0; i < NC; ++i) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 __global__ void __launch_bounds__(256) k_16(double *out, int iters, double a0, double b0)
 {
     double4_t acc[8];
@@ -59,6 +77,17 @@ int main()
         hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
         const double n16 = (double)blocks * 4 * iters * 8;
         printf("mfma_f64_16x16x4:  %.3f ms  %.1f TFLOP/s  (%.1f cycles per instruction per SIMD at 2.4 GHz)\n", ms, n16 * 2048 / ms * 1e-9, ms * 1e-3 * 2.4e9 / (n16 / 1024));
+    }
+    {   // dependent chains, one wave per SIMD (256 threads per CU): issue interval of a chained product
+        float ms;
+        const int b1 = 256;
+        auto run = [&](auto kern, int nc) {
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(kern, dim3(b1), dim3(256), 0, 0, d, iters, 1.0, 2.0);
+            hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+            printf("4x4x4_4b, %2d chain(s), one wave per SIMD: %.1f cycles per instruction at 2.4 GHz\n", nc, ms * 1e-3 * 2.4e9 / ((double)iters * 16));
+        };
+        run(k_4x4_chains<1>, 1); run(k_4x4_chains<1>, 1); run(k_4x4_chains<2>, 2); run(k_4x4_chains<4>, 4); run(k_4x4_chains<8>, 8); run(k_4x4_chains<16>, 16);
     }
     // layout: random integers, all candidate maps
     double ha[64], hb[64], hd[64], *da, *db, *dd;
