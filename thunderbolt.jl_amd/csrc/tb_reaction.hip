@@ -146,8 +146,9 @@ template <> struct CellModel<TB_CELL_TT06> {
                      xr2 = u[10], xs = u[11], r = u[12], s = u[13], d = u[14], f = u[15], f2 = u[16], fCass = u[17], RR = u[18];
         const double RTONF = R * T / F, FoRT = F / (R * T);
         // reversal potentials
-        const double Ek = RTONF * log(Ko / Ki), Ena = RTONF * log(Nao / Nai);
-        const double Eks = RTONF * log((Ko + pKNa * Nao) / (Ki + pKNa * Nai)), Eca = 0.5 * RTONF * log(Cao / Cai);
+        // log(a/b) = log a − log b: the numerators are parameters (their logarithms are loop invariants), the state-dependent ones take the bounded form
+        const double Ek = RTONF * (log(Ko) - log_b(Ki)), Ena = RTONF * (log(Nao) - log_b(Nai));
+        const double Eks = RTONF * (log(Ko + pKNa * Nao) - log_b(Ki + pKNa * Nai)), Eca = 0.5 * RTONF * (log(Cao) - log_b(Cai));
         // shared exponentials of V (p = exp_b(V/k), q = 1/p)
         const double p5 = exp_b(V * (1.0 / 5.0)), q5 = rcp_b(p5);
         const double p10 = exp_b(V * (1.0 / 10.0)), q10 = rcp_b(p10);
@@ -162,30 +163,30 @@ template <> struct CellModel<TB_CELL_TT06> {
         const double Bk1 = (3.0 * exp_b(0.0002 * (vk + 100.0)) + exp_b(0.1 * (vk - 10.0))) * sgm(eh);
         const double INa = GNa * m * m * m * h * j * (V - Ena);
         const double e2 = w * w * exp_b(-30.0 * FoRT); // exp_b(2 (V − 15) F/RT)
-        const double ICaL = GCaL * d * f * f2 * fCass * 4.0 * (V - 15.0) * (F * FoRT) * (0.25 * e2 * CaSS - Cao) / (e2 - 1.0);
+        const double ICaL = GCaL * d * f * f2 * fCass * 4.0 * (V - 15.0) * (F * FoRT) * (0.25 * e2 * CaSS - Cao) * rcp_b(e2 - 1.0);
         const double Ito = Gto * r * s * vk;
         const double IKr = GKr * sqrt(Ko * (1.0 / 5.4)) * xr1 * xr2 * vk;
         const double IKs = GKs * xs * xs * (V - Eks);
-        const double IK1 = GK1 * (Ak1 / (Ak1 + Bk1)) * vk;
+        const double IK1 = GK1 * (Ak1 * rcp_b(Ak1 + Bk1)) * vk;
         const double en = exp_b(nn * V * FoRT), en1 = en * iw; // exp_b((γ − 1) V F/RT)
-        const double INaCa = knaca * (1.0 / (KmNai * KmNai * KmNai + Nao * Nao * Nao)) * (1.0 / (KmCa + Cao)) * (1.0 / (1.0 + ksat * en1)) *
+        const double INaCa = knaca * (1.0 / (KmNai * KmNai * KmNai + Nao * Nao * Nao)) * (1.0 / (KmCa + Cao)) * rcp_b(1.0 + ksat * en1) *
                              (en * Nai * Nai * Nai * Cao - en1 * Nao * Nao * Nao * Cai * 2.5);
-        const double INaK = knak * (Ko / (Ko + KmK)) * (Nai / (Nai + KmNa)) / (1.0 + 0.1245 * exp_b(-0.1 * V * FoRT) + 0.0353 * iw);
-        const double IpCa = GpCa * Cai / (KpCa + Cai);
+        const double INaK = knak * (Ko / (Ko + KmK)) * (Nai * rcp_b(Nai + KmNa)) * rcp_b(1.0 + 0.1245 * exp_b(-0.1 * V * FoRT) + 0.0353 * iw);
+        const double IpCa = GpCa * Cai * rcp_b(KpCa + Cai);
         const double IpK = GpK * sgm(exp_b((25.0 - V) * (1.0 / 5.98))) * vk;
         const double IbNa = GbNa * (V - Ena), IbCa = GbCa * (V - Eca);
         du[0] = -(IKr + IKs + IK1 + Ito + INa + IbNa + ICaL + IbCa + INaK + INaCa + IpCa + IpK);
         // calcium handling
-        const double ecs = EC / CaSR;
-        const double kCaSR = maxsr - (maxsr - minsr) / (1.0 + ecs * ecs);
-        const double k1 = k1p / kCaSR, k2 = k2p * kCaSR;
+        const double ecs = EC * rcp_b(CaSR);
+        const double kCaSR = maxsr - (maxsr - minsr) * rcp_b(1.0 + ecs * ecs);
+        const double k1 = k1p * rcp_b(kCaSR), k2 = k2p * kCaSR;
         du[18] = k4 * (1.0 - RR) - k2 * CaSS * RR;
-        const double O = k1 * CaSS * CaSS * RR / (k3 + k1 * CaSS * CaSS);
+        const double O = k1 * CaSS * CaSS * RR * rcp_b(k3 + k1 * CaSS * CaSS);
         const double Irel = Vrel * O * (CaSR - CaSS), Ileak = Vleak * (CaSR - Cai);
-        const double Iup = Vmaxup / (1.0 + (Kup * Kup) / (Cai * Cai)), Ixfer = Vxfer * (CaSS - Cai);
-        const double bc = 1.0 / (1.0 + Bufc * Kbufc / ((Cai + Kbufc) * (Cai + Kbufc)));
-        const double bsr = 1.0 / (1.0 + Bufsr * Kbufsr / ((CaSR + Kbufsr) * (CaSR + Kbufsr)));
-        const double bss = 1.0 / (1.0 + Bufss * Kbufss / ((CaSS + Kbufss) * (CaSS + Kbufss)));
+        // 1/(1 + a/x²) = x²/(x² + a): one reciprocal each
+        const double Iup = Vmaxup * (Cai * Cai) * rcp_b(Cai * Cai + Kup * Kup), Ixfer = Vxfer * (CaSS - Cai);
+        const double sc = (Cai + Kbufc) * (Cai + Kbufc), ssr = (CaSR + Kbufsr) * (CaSR + Kbufsr), sss = (CaSS + Kbufss) * (CaSS + Kbufss);
+        const double bc = sc * rcp_b(sc + Bufc * Kbufc), bsr = ssr * rcp_b(ssr + Bufsr * Kbufsr), bss = sss * rcp_b(sss + Bufss * Kbufss);
         du[1] = bc * ((Ileak - Iup) * Vsr / Vc + Ixfer - (IbCa + IpCa - 2.0 * INaCa) * Cm / (2.0 * Vc * F));
         du[2] = bsr * (Iup - Irel - Ileak);
         du[3] = bss * (-ICaL * Cm / (2.0 * Vss * F) + Irel * Vsr / Vss - Ixfer * Vc / Vss);
@@ -201,7 +202,7 @@ template <> struct CellModel<TB_CELL_TT06> {
         const double hinf = hr * hr;
         double ABH, ABJ; // αh + βh, αj + βj
         if (V >= -40.0) {
-            ABH = 0.77 / (0.13 * (1.0 + exp_b(-(V + 10.66) * (1.0 / 11.1))));
+            ABH = (0.77 / 0.13) * sgm(exp_b(-(V + 10.66) * (1.0 / 11.1)));
             ABJ = 0.6 * exp_b(0.057 * V) * sgm(q10 * 0.04076220397836621 /* exp_b(-3.2) */);
         } else {
             ABH = 0.057 * exp_b(-(V + 80.0) * (1.0 / 6.8)) + 2.7 * exp_b(0.079 * V) + 3.1e5 * exp_b(0.3485 * V);
@@ -229,8 +230,9 @@ template <> struct CellModel<TB_CELL_TT06> {
         rate[16] = rcp_b((600.0 * exp_b(-(V + 25.0) * (V + 25.0) * (1.0 / 170.0)) + 31.0 * sgm(q10 * 12.182493960703473 /* exp_b(2.5) */) + 16.0 * sgm(p10 * 20.085536923187668 /* exp_b(3.0) */)));
         du[16] = (0.67 * sgm(p7 * 148.4131591025766 /* exp_b(5.0) */) + 0.33 - f2) * rate[16];
         const double cq = 1.0 + (CaSS * (1.0 / 0.05)) * (CaSS * (1.0 / 0.05));
-        rate[17] = rcp_b(80.0 / cq + 2.0);
-        du[17] = (0.6 / cq + 0.4 - fCass) * rate[17];
+        const double icq = rcp_b(cq);
+        rate[17] = rcp_b(80.0 * icq + 2.0);
+        du[17] = (0.6 * icq + 0.4 - fCass) * rate[17];
     }
 };
 
