@@ -55,9 +55,11 @@ template <> struct CellModel<TB_CELL_PCG2019> {
     // parameter slots follow the struct field order of pcg2019.jl:4-48
     enum { gNa, Em, km, taum, Eh, kh, dh, tauh0, gK1, Ez, kz, gto, Er, kr, Es, ks, taus, gCaL, Ed, kd, Ef, kf, tauf,
            gKr, Exr, kxr, tauxr, Ey, ky, gKs, Exs, kxs, tauxs, ENa, EK, ECa };
-    __device__ __forceinline__ static double sigmoid(double phi, double E, double k, double sign)
+    // 1/(1 + exp(±(φ − E)/k)).  Divisions by parameters are multiplications by their reciprocals (loop invariants of the point loop; an IEEE FP64
+    // division is ≈ 15 instructions, and there were 18 of them per evaluation besides the 12 exponentials), 1/(1 + e) is a refined hardware reciprocal
+    __device__ __forceinline__ static double sigmoid(double phi, double E, double ik, double sign)
     {
-        return 1.0 / (1.0 + exp_b(sign * (phi - E) / k));
+        return rcp_b(1.0 + exp_b(sign * (phi - E) * ik));
     }
     __device__ __forceinline__ static void rhs(const CellParams &P, const double (&u)[NS], double t, double (&du)[NS])
     {
@@ -69,10 +71,10 @@ template <> struct CellModel<TB_CELL_PCG2019> {
     {
         const double *p = P.p;
         const double phi = u[0], h = u[1], m = u[2], f = u[3], s = u[4], xs = u[5], xr = u[6];
-        const double rinf = sigmoid(phi, p[Er], p[kr], -1.0);
-        const double dinf = sigmoid(phi, p[Ed], p[kd], -1.0);
-        const double zinf = sigmoid(phi, p[Ez], p[kz], 1.0);
-        const double yinf = sigmoid(phi, p[Ey], p[ky], 1.0);
+        const double rinf = sigmoid(phi, p[Er], 1.0 / p[kr], -1.0);
+        const double dinf = sigmoid(phi, p[Ed], 1.0 / p[kd], -1.0);
+        const double zinf = sigmoid(phi, p[Ez], 1.0 / p[kz], 1.0);
+        const double yinf = sigmoid(phi, p[Ey], 1.0 / p[ky], 1.0);
         const double I_Na = p[gNa] * m * m * m * h * h * (phi - p[ENa]);
         const double I_K1 = p[gK1] * zinf * (phi - p[EK]);
         const double I_to = p[gto] * rinf * s * (phi - p[EK]);
@@ -80,16 +82,18 @@ template <> struct CellModel<TB_CELL_PCG2019> {
         const double I_Kr = p[gKr] * xr * yinf * (phi - p[EK]);
         const double I_Ks = p[gKs] * xs * (phi - p[EK]);
         du[0] = -(I_Na + I_K1 + I_to + I_CaL + I_Kr + I_Ks); // C_m = 1, pcg2019.jl:55
-        const double eh = exp_b((phi - p[Eh]) / p[kh]);
-        const double tau_h = (2.0 * p[tauh0] * exp_b(p[dh] * (phi - p[Eh]) / p[kh])) / (1.0 + eh);
-        const double hinf = 1.0 / (1.0 + eh);
-        du[1] = (hinf - h) / tau_h;
-        du[2] = (sigmoid(phi, p[Em], p[km], -1.0) - m) / p[taum];
-        du[3] = (sigmoid(phi, p[Ef], p[kf], 1.0) - f) / p[tauf];
-        du[4] = (sigmoid(phi, p[Es], p[ks], 1.0) - s) / p[taus];
-        du[5] = (sigmoid(phi, p[Exs], p[kxs], -1.0) - xs) / p[tauxs];
-        du[6] = (sigmoid(phi, p[Exr], p[kxr], -1.0) - xr) / p[tauxr];
-        rate[0] = 0.0; rate[1] = 1.0 / tau_h; rate[2] = 1.0 / p[taum]; rate[3] = 1.0 / p[tauf]; rate[4] = 1.0 / p[taus]; rate[5] = 1.0 / p[tauxs]; rate[6] = 1.0 / p[tauxr];
+        const double xh = (phi - p[Eh]) * (1.0 / p[kh]);
+        const double eh = exp_b(xh);
+        const double hinf = rcp_b(1.0 + eh);
+        // τ_h = 2 τ_h0 exp(δ_h x)/(1 + e^x)  →  1/τ_h = (1 + e^x)·exp(−δ_h x)/(2 τ_h0)
+        rate[0] = 0.0; rate[1] = (1.0 + eh) * exp_b(-p[dh] * xh) * (0.5 / p[tauh0]); rate[2] = 1.0 / p[taum]; rate[3] = 1.0 / p[tauf]; rate[4] = 1.0 / p[taus];
+        rate[5] = 1.0 / p[tauxs]; rate[6] = 1.0 / p[tauxr];
+        du[1] = (hinf - h) * rate[1];
+        du[2] = (sigmoid(phi, p[Em], 1.0 / p[km], -1.0) - m) * rate[2];
+        du[3] = (sigmoid(phi, p[Ef], 1.0 / p[kf], 1.0) - f) * rate[3];
+        du[4] = (sigmoid(phi, p[Es], 1.0 / p[ks], 1.0) - s) * rate[4];
+        du[5] = (sigmoid(phi, p[Exs], 1.0 / p[kxs], -1.0) - xs) * rate[5];
+        du[6] = (sigmoid(phi, p[Exr], 1.0 / p[kxr], -1.0) - xr) * rate[6];
     }
 };
 
