@@ -839,13 +839,12 @@ __device__ __forceinline__ void q2_point_geometry(const double *sx, int q, doubl
 template <int FORM, bool FIELD, bool SYM>
 __global__ void __launch_bounds__(256, 3)
 k_matrix_q2(MeshView m, FormArgs fa, const double *__restrict__ cell_xyz, const int32_t *__restrict__ list, int64_t n_list, const int64_t *__restrict__ rowptr,
-            const uint16_t *__restrict__ pos, double *__restrict__ nz, int atomic /*0 rmw, 1 atomic, 2 store Kₑ*/, double *__restrict__ ke, int rot, Status *st)
+            const uint16_t *__restrict__ pos, double *__restrict__ nz, int atomic /*0 rmw, 1 atomic, 2 store Kₑ*/, double *__restrict__ ke, Status *st)
 {
     constexpr bool DIFF = FORM == TB_FORM_DIFFUSION;
     constexpr int KD = DIFF ? 81 : 27, KS = (KD + 3) / 4, LD = 27, NS = DIFF ? 9 : 1;
     constexpr double GX = 0.7745966692414834;
-    // wave roles rotate with the workgroup so that the producer waves (no matrix-core work) do not all sit on the same SIMD
-    const int lane = threadIdx.x & 63, wv = ((threadIdx.x >> 6) + (blockIdx.x >> 3) + blockIdx.x / rot) & 3, tid = 64 * wv + lane, lr = lane & 15, g = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lr = lane & 15, g = lane >> 4; // wave = role (re-labelling the roles per workgroup, by block index or by hardware SIMD id, changes nothing: DESIGN §8)
     __shared__ double s_x[2][24], s_rho[2][8], s_S[2][27][NS], sA[KD * LD], s_out[729];
     __shared__ int32_t s_dof[27];
     auto cell_of = [&](int64_t it) -> int64_t { return list ? (int64_t)list[it] : it; };
@@ -1136,7 +1135,7 @@ static int run_q2(tb_form *f, tb_pattern *p, int strategy, double t, double *d_n
         if (n == 0) return TB_OK;
         // persistent workgroups: three per CU (≤ 168 VGPRs)
         const unsigned wgs = (unsigned)std::min<int64_t>(n, (int64_t)dev->n_cu * 3);
-#define TB_Q2(FORM, FIELD, SYM) hipLaunchKernelGGL((k_matrix_q2<FORM, FIELD, SYM>), dim3(wgs), dim3(256), 0, dev->stream, mv, fa, m->d_cell_xyz, list, n, p->d_rowptr, p->d_q2pos, d_nz, atomic, kebuf, dev->n_cu, dev->d_status)
+#define TB_Q2(FORM, FIELD, SYM) hipLaunchKernelGGL((k_matrix_q2<FORM, FIELD, SYM>), dim3(wgs), dim3(256), 0, dev->stream, mv, fa, m->d_cell_xyz, list, n, p->d_rowptr, p->d_q2pos, d_nz, atomic, kebuf, dev->d_status)
         if (d_nz && f->kind == TB_FORM_MASS) { if (f->field) TB_Q2(TB_FORM_MASS, true, true); else TB_Q2(TB_FORM_MASS, false, true); }
         else if (d_nz) {
             // a non-symmetric constant tensor gives a non-symmetric Kₑ: all four tiles
