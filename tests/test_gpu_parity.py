@@ -608,6 +608,52 @@ def test_hyperelastic_residual_and_tangent_parity(tb, oracle, device, order, nel
     assert np.abs(y).max() < 1e-10 * np.abs(op.J.to_host()).max()
 
 
+def test_mechanics_properties_80_cubed(tb, oracle, device):
+    """BASELINE config 4 at its own size (512 000 Q2 hexahedra, 12.5 M dofs, 2.37·10⁹ nz: the Int32 / size effects the small parity cases cannot see):
+    residual and tangent of the element strategy — a sample of rows against the oracle's assembly of the cells around them, rigid translations in
+    the kernel of the tangent, zero residual at u = 0.  The matrix stays on the device; rows are read back through views."""
+    import ctypes as C
+    n = 80
+    g = tb.generate_mesh(tb.Hexahedron, (n, n, n), (0, 0, 0), (1.0, 1.0, 1.0), perturb=0.1)
+    dh = tb.DofHandler(g, tb.LagrangeCollection(2) ** 3)
+    sp = tb.allocate_matrix(dh)
+    assert g.n_cells == 512000 and dh.ndofs == 3 * 161 ** 3 and sp.nnz == 2370372489
+    f, s_, nn = np.array([1, 1, 0.0]) / np.sqrt(2), np.array([-1, 1, 0.0]) / np.sqrt(2), np.array([0, 0, 1.0])
+    model = tb.QuasiStaticModel("u", tb.PK1Model(tb.HolzapfelOgden2009Model(), tb.ConstantCoefficient(tb.OrthotropicMicrostructure(f, s_, nn))))
+    op = tb.setup_operator(tb.ElementAssemblyStrategy(device), model, dh, sp)
+    u = 1e-2 * np.sin(np.pi * np.arange(dh.ndofs) / dh.ndofs)
+    res = device.zeros(dh.ndofs)
+    tb.update_linearization(op, device.to_device(u), 0.0, residual=res)
+    rh = res.to_host()
+    # sampled rows: the oracle assembles the sub-mesh of the cells that touch them (every contribution to these rows lives there)
+    rng = np.random.default_rng(9)
+    rows = np.concatenate([rng.choice(dh.ndofs, 24, replace=False), [0, dh.ndofs - 1]])
+    cells = np.nonzero(np.isin(dh.cell_dofs, rows).any(axis=1))[0]
+    sub_dofs, inv = np.unique(dh.cell_dofs[cells], return_inverse=True)
+    cd = inv.reshape(len(cells), -1).astype(np.int32)
+    rp, ci = oracle.build_pattern(cd, len(sub_dofs))
+    om = oracle.Mesh(oracle.HEX27, 3, g.xyz, np.ascontiguousarray(g.conn[cells]), cd)
+    Ks, rs = oracle.assemble_hyperelastic(om, u[sub_dofs], rp, ci, fsn=np.stack([f, s_, nn]))
+    scale = np.abs(Ks).max()
+    for d in rows:
+        l = int(np.searchsorted(sub_dofs, d))
+        k0, k1 = int(sp.rowptr[d]), int(sp.rowptr[d + 1])
+        dev_row = op.J.view(k0, k1 - k0).to_host()
+        cols = sp.colidx[k0:k1]
+        ref_cols = sub_dofs[ci[rp[l]:rp[l + 1]]]
+        np.testing.assert_array_equal(cols, ref_cols)
+        assert np.abs(dev_row - Ks[rp[l]:rp[l + 1]]).max() < 1e-11 * scale, d
+        assert abs(rh[d] - rs[l]) < 1e-11 * np.abs(rs).max(), d
+    # rigid translations are in the kernel of the tangent (block SpMV on the device)
+    t = device.to_device(np.tile([0.3, -0.2, 0.5], dh.ndofs // 3))
+    y = device.zeros(dh.ndofs)
+    tb._lib.check(tb._lib.lib().tb_spmv_csr(op.pattern.h, op.J.ptr, t.ptr, 1.0, 0.0, y.ptr))
+    assert np.abs(y.to_host()).max() < 1e-9 * scale
+    # stress-free reference configuration
+    tb.residual(op, res, device.zeros(dh.ndofs), 0.0)
+    assert np.abs(res.to_host()).max() < 1e-13
+
+
 def test_hyperelastic_negative_jacobian_and_bad_field(tb, device):
     g = tb.generate_mesh(tb.Hexahedron, (2, 2, 2))
     bad = tb.Grid(tb.Hexahedron, g.xyz, g.conn[:, [0, 3, 2, 1, 4, 7, 6, 5]])
