@@ -146,6 +146,37 @@ def test_tet_mesh_parity(tb, oracle, device):
         assert rel_err(b.b.to_host(), oracle.assemble_source(om, oracle.SRC_NORM_PLUS_T, t=0.4)) < TOL
 
 
+def test_tet_patch_kernel_on_several_patches(tb, oracle, device):
+    """The staged tetrahedron patch kernel (k_patch_tet4) on a mesh of several 5×5×5 tiles with ragged boundary tiles: stiffness (symmetric and
+    non-symmetric tensor), mass (constant and nodal density) and the one-pass pair against the oracle; repeated calls overwrite."""
+    g0 = tb.generate_mesh(tb.Hexahedron, (11, 9, 7), (0, 0, 0), (1.0, 0.8, 0.6), perturb=0.2)
+    tets = hex_to_tets(g0.xyz, g0.conn)
+    cd, nd = oracle.close_dofs(oracle.TET4, 1, tets, len(g0.xyz))
+    g = tb.Grid(tb.Tetrahedron, g0.xyz, tets)
+    dh = tb.DofHandler(g, cell_dofs=cd, ndofs=nd)
+    sp = tb.allocate_matrix(dh)
+    om = oracle.Mesh(oracle.TET4, 2, g.xyz, tets, cd)
+    st = tb.PatchAssemblyStrategy(device)
+    rng = np.random.default_rng(4)
+    rho = rng.uniform(0.5, 2.0, size=(g.n_cells, 4))
+    D = np.array([[2.0, 0.3, 0.1], [0.3, 1.5, -0.2], [0.1, -0.2, 1.0]])
+    N = np.array([[2.0, 0.5, 0.0], [-0.1, 1.5, 0.2], [0.3, 0.0, 1.0]])
+    refM = oracle.assemble_matrix(om, 0, oracle.Coef(oracle.COEF_CONST_SCALAR, [1.3]), sp.rowptr, sp.colidx)
+    refMf = oracle.assemble_matrix(om, 0, oracle.Coef(oracle.COEF_FIELD_SCALAR, field=rho), sp.rowptr, sp.colidx)
+    for Dm in (D, N):
+        refK = oracle.assemble_matrix(om, 1, oracle.Coef(oracle.COEF_CONST_TENSOR, Dm.ravel()), sp.rowptr, sp.colidx)
+        K = tb.setup_operator(st, tb.BilinearDiffusionIntegrator(tb.ConstantCoefficient(Dm)), dh, sp)
+        for rep in range(2):
+            assert rel_err(tb.update_operator(K, 0.1 * rep).A.to_host(), refK) < TOL
+        for mt, mref in ((tb.ConstantCoefficient(1.3), refM), (tb.FieldCoefficient(rho), refMf)):
+            M = tb.setup_operator(st, tb.BilinearMassIntegrator(mt), dh, sp)
+            assert rel_err(tb.update_operator(M, 0.0).A.to_host(), mref) < TOL
+            K2 = tb.setup_operator(st, tb.BilinearDiffusionIntegrator(tb.ConstantCoefficient(Dm)), dh, sp)
+            tb.update_operators(M, K2, 0.0)
+            assert rel_err(M.A.to_host(), mref) < TOL and rel_err(K2.A.to_host(), refK) < TOL
+    np.testing.assert_allclose(refM.sum(), 1.3 * 1.0 * 0.8 * 0.6, rtol=1e-12)
+
+
 def test_error_codes(tb, oracle, device):
     g = tb.generate_mesh(tb.Hexahedron, (2, 2, 2))
     bad = tb.Grid(tb.Hexahedron, g.xyz, g.conn[:, [0, 3, 2, 1, 4, 7, 6, 5]])  # inverted orientation → detJ < 0

@@ -423,6 +423,11 @@ int tb_assemble_matrix_pair(tb_form *mass, tb_form *diffusion, tb_pattern *pat, 
         const int rc = launch_assemble_hex8_patch(diffusion, mass, pat, t, d_nzval_diffusion, d_nzval_mass);
         if (rc != TB_ERR_UNSUPPORTED) return rc;
     }
+    if (strategy == TB_STRATEGY_PATCH && mass->mesh->n_cells > 0 && tet4_patch_applicable(mass, pat) && tet4_patch_applicable(diffusion, pat)) {
+        TB_HIP(hipSetDevice(mass->mesh->dev->id));
+        const int rc = launch_assemble_tet4_patch(diffusion, mass, pat, t, d_nzval_diffusion, d_nzval_mass);
+        if (rc != TB_ERR_UNSUPPORTED) return rc;
+    }
     int rc = tb_assemble_matrix(mass, pat, strategy, t, d_nzval_mass);
     if (rc) return rc;
     return tb_assemble_matrix(diffusion, pat, strategy, t, d_nzval_diffusion);

@@ -1172,6 +1172,193 @@ static int run_q2(tb_form *f, tb_pattern *p, int strategy, double t, double *d_n
     return TB_ERR_UNSUPPORTED;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Patch strategy for linear tetrahedra on the staged layout of the hexahedron kernel (tb_patch_fused.hip): one 16-byte header per patch, the
+// coordinates of the patch's nodes pre-gathered and contiguous, 8 bytes of patch-local node indices and a 4-byte index into the de-duplicated
+// table of 16-byte position signatures per instance.  A tetrahedron carries a 4 × 4 element matrix — 40 B of algorithmic traffic per cell —
+// so the general patch kernel (per instance: cell id, connectivity, coordinate gather, 16 row slots, 16 positions) moved mostly metadata.
+// Mass and stiffness in one pass share geometry and metadata.  Instances are walked 256 at a time (a 5×5×5 tile holds 750 tetrahedra plus halo).
+// The affine geometry is formed once per instance (the generic element routine re-derives it at each of the four points).
+// ------------------------------------------------------------------------------------------------
+struct TetPatchView {
+    const uint16_t *elem_ln;
+    const uint32_t *elem_sig;
+    const uint8_t *sigtab;
+    const RowDesc *row_desc;
+    const int32_t *elem_cell;
+    int kcap, max_rows, max_nodes;
+};
+
+template <bool WK, bool WM, bool FM>
+__global__ void __launch_bounds__(256)
+k_patch_tet4(FormArgs faK, FormArgs faM, TetPatchView pv, const uint4 *__restrict__ hdrs, const double *__restrict__ pcoord, double *__restrict__ nzK,
+             double *__restrict__ nzM, Status *st)
+{
+    extern __shared__ double lds[];
+    constexpr int T = 256;
+    const int tid = threadIdx.x;
+    uint4 h = hdrs[blockIdx.x];
+    h.x = __builtin_amdgcn_readfirstlane(h.x); h.y = __builtin_amdgcn_readfirstlane(h.y); h.z = __builtin_amdgcn_readfirstlane(h.z); h.w = __builtin_amdgcn_readfirstlane(h.w);
+    const int64_t e0 = h.x, r0 = h.y, n0 = h.z;
+    const int nrows = (int)(h.w & 0x3ff), nnodes = (int)((h.w >> 10) & 0x7ff), ne = (int)(h.w >> 21);
+    if (nrows == 0) return; // a patch whose dofs all belong to earlier patches writes nothing
+    constexpr int NREG = (WK && WM) ? 2 : 1;
+    double *accK = lds, *accM = lds + (NREG - 1) * pv.kcap;
+    uint4 *desc = (uint4 *)(lds + NREG * pv.kcap); // RowDesc: nz0 (x, y), off (z), len (w)
+    double *xs = (double *)(desc + pv.max_rows);
+    {
+        const uint4 *gd = (const uint4 *)pv.row_desc + r0;
+        for (int s = tid; s < nrows; s += T) desc[s] = gd[s];
+        const double *gc = pcoord + 3 * n0;
+        for (int k = tid; k < 3 * nnodes; k += T) xs[k] = gc[k];
+        double2 *z = (double2 *)lds;
+        for (int k = tid; k < (NREG * pv.kcap) >> 1; k += T) z[k] = make_double2(0.0, 0.0);
+    }
+    // instance metadata runs two passes ahead of the arithmetic (node indices / signature index / cell id), the signature itself one pass ahead: no pass
+    // waits for a load issued less than a pass ago
+    struct Meta { uint2 l2; uint32_t sig; int32_t cell; };
+    auto fetch = [&](int e) { Meta M{make_uint2(0, 0), 0u, 0}; if (e < ne) { M.l2 = ((const uint2 *)pv.elem_ln)[e0 + e]; M.sig = pv.elem_sig[e0 + e]; M.cell = pv.elem_cell[e0 + e]; } return M; };
+    Meta cur = fetch(tid), nxt = fetch(tid + T);
+    uint4 cpc = ((const uint4 *)pv.sigtab)[cur.sig]; // byte 4i + j: position of column j in row i
+    __syncthreads();
+    for (int e = tid; e < ne; e += T) {
+        const uint4 cpn = ((const uint4 *)pv.sigtab)[nxt.sig];
+        const Meta nn = fetch(e + 2 * T);
+        const uint2 l2 = cur.l2;
+        const uint4 cp = cpc;
+        const int64_t cell = cur.cell;
+        cur = nxt; nxt = nn; cpc = cpn;
+        const uint32_t ln[4] = {l2.x & 0xffffu, l2.x >> 16, l2.y & 0xffffu, l2.y >> 16};
+        const uint32_t cpw[4] = {cp.x, cp.y, cp.z, cp.w};
+        double x[4][3];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const double *px = xs + 3 * ln[a];
+            x[a][0] = px[0]; x[a][1] = px[1]; x[a][2] = px[2];
+        }
+        uint32_t ro[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ro[i] = ln[i] < (uint32_t)nrows ? desc[ln[i]].z : 0xFFFFFFFFu;
+        // geometry of the affine cell, once: J = [x₁−x₀ | x₂−x₀ | x₃−x₀], ∇N₁,₂,₃ = rows of J⁻¹, ∇N₀ = −(∇N₁ + ∇N₂ + ∇N₃); the four points of the
+        // rule share it (the generic element routine of the other strategies re-derives it per point: same numbers to rounding)
+        double gN[4][3], det;
+        {
+            double e[3][3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) e[k][i] = x[k + 1][i] - x[0][i];
+            const double c0[3] = {e[1][1] * e[2][2] - e[1][2] * e[2][1], e[1][2] * e[2][0] - e[1][0] * e[2][2], e[1][0] * e[2][1] - e[1][1] * e[2][0]}; // e₂ × e₃
+            const double c1[3] = {e[2][1] * e[0][2] - e[2][2] * e[0][1], e[2][2] * e[0][0] - e[2][0] * e[0][2], e[2][0] * e[0][1] - e[2][1] * e[0][0]}; // e₃ × e₁
+            const double c2[3] = {e[0][1] * e[1][2] - e[0][2] * e[1][1], e[0][2] * e[1][0] - e[0][0] * e[1][2], e[0][0] * e[1][1] - e[0][1] * e[1][0]}; // e₁ × e₂
+            det = e[0][0] * c0[0] + e[0][1] * c0[1] + e[0][2] * c0[2];
+            if (!(det > 0.0)) flag_neg_detj(st, cell);
+            const double id = 1.0 / det;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                gN[1][i] = c0[i] * id; gN[2][i] = c1[i] * id; gN[3][i] = c2[i] * id;
+                gN[0][i] = -(gN[1][i] + gN[2][i] + gN[3][i]);
+            }
+        }
+        if constexpr (WK) {
+            // Kₑ[i,j] −= (∇Nⱼ·D·∇Nᵢ)·dΩ  (diffusion.jl:38-49), Σ_q dΩ_q = det/6
+            double Ke[16], Dg[4][3];
+            const double mv = -det * (1.0 / 6.0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) Dg[i][k] = mv * (faK.D[3 * k] * gN[i][0] + faK.D[3 * k + 1] * gN[i][1] + faK.D[3 * k + 2] * gN[i][2]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Ke[4 * i + j] = gN[j][0] * Dg[i][0] + gN[j][1] * Dg[i][1] + gN[j][2] * Dg[i][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (ro[i] != 0xFFFFFFFFu) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) unsafeAtomicAdd(accK + (ro[i] + ((cpw[i] >> (8 * j)) & 0xffu)), Ke[4 * i + j]);
+                }
+        }
+        if constexpr (WM) {
+            // Mₑ[i,j] += ρ(x_q)·Nᵢ·Nⱼ·dΩ_q over the four points  (mass.jl:32-42); dΩ_q = det·w
+            double Me[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) Me[k] = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                double r = faM.rho;
+                if constexpr (FM) {
+                    r = 0.0;
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) r += Tet4<2>::N(q, a) * faM.field[cell * 4 + a];
+                }
+                const double rw = r * det * Tet4<2>::w(q);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) Me[4 * i + j] += rw * (Tet4<2>::N(q, i) * Tet4<2>::N(q, j));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (ro[i] != 0xFFFFFFFFu) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) unsafeAtomicAdd(accM + (ro[i] + ((cpw[i] >> (8 * j)) & 0xffu)), Me[4 * i + j]);
+                }
+        }
+    }
+    __syncthreads();
+    // write-out: one row per half-wave (rows of a tetrahedral mesh hold ≈ 15 entries), each matrix's row as one contiguous run
+    const int half = tid >> 5, hl = tid & 31;
+    for (int s = half; s < nrows; s += T / 32) {
+        const uint4 d = desc[s];
+        const int64_t g0 = (int64_t)(((uint64_t)d.y << 32) | d.x);
+        for (uint32_t k = hl; k < d.w; k += 32) {
+            if constexpr (WK) nzK[g0 + k] = accK[d.z + k];
+            if constexpr (WM) nzM[g0 + k] = accM[d.z + k];
+        }
+    }
+}
+
+bool tet4_patch_applicable(const tb_form *f, const tb_pattern *)
+{
+    static const bool legacy = getenv("TB_PATCH_KERNEL") && !strcmp(getenv("TB_PATCH_KERNEL"), "legacy");
+    if (legacy) return false;
+    const tb_mesh *m = f->mesh;
+    if (m->field_kind != TB_TET4 || m->geom_kind != TB_TET4 || m->ncomp != 1 || f->qorder != 2 || f->has_cellset) return false;
+    if (f->kind == TB_FORM_DIFFUSION) return !f->field; // tensor fields stay on the general kernel (their table is built there)
+    return f->kind == TB_FORM_MASS;
+}
+
+int launch_assemble_tet4_patch(tb_form *fK, tb_form *fM, tb_pattern *p, double t, double *d_nzK, double *d_nzM)
+{
+    tb_form *any = fK ? fK : fM;
+    tb_mesh *m = any->mesh;
+    tb_device *dev = m->dev;
+    int rc = reset_status(dev);
+    if (rc) return rc;
+    const int nreg = fK && fM ? 2 : 1;
+    rc = ensure_patch_fused(m, p, nreg);
+    if (rc) return rc;
+    const PatchPlan *pp = m->patches.get();
+    const PatchFusedPlan *pf = p->patch_fused.get();
+    if (!pf->d_hdr) { set_error("tetrahedron patch kernel: a patch exceeds the packed header (1023 rows / 2047 nodes / 2047 instances)"); return TB_ERR_UNSUPPORTED; }
+    TetPatchView pv{pf->d_elem_ln, pf->d_elem_sig, pf->d_sigtab, pf->d_row_desc, pp->d_elem_cell, pf->max_lds_entries, pp->max_rows, pf->max_nodes};
+    const size_t lds = (size_t)nreg * pv.kcap * sizeof(double) + (size_t)pv.max_rows * sizeof(RowDesc) + (size_t)pv.max_nodes * 3 * sizeof(double);
+    const FormArgs aK = fK ? make_args(fK, t) : FormArgs{}, aM = fM ? make_args(fM, t) : FormArgs{};
+    const bool fm = fM && fM->field;
+    auto launch = [&](auto k) -> int {
+        TB_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, dim3((unsigned)pp->n_patches), dim3(256), lds, dev->stream, aK, aM, pv, (const uint4 *)pf->d_hdr, pf->d_pcoord, d_nzK, d_nzM, dev->d_status);
+        return TB_OK;
+    };
+    if (fK && fM) rc = fm ? launch(k_patch_tet4<true, true, true>) : launch(k_patch_tet4<true, true, false>);
+    else if (fK) rc = launch(k_patch_tet4<true, false, false>);
+    else rc = fm ? launch(k_patch_tet4<false, true, true>) : launch(k_patch_tet4<false, true, false>);
+    if (rc) return rc;
+    TB_HIP(hipGetLastError());
+    return check_status(dev);
+}
+
 int launch_assemble_matrix(tb_form *f, tb_pattern *p, int strategy, double t, double *d_nz)
 {
     tb_mesh *m = f->mesh;
@@ -1180,6 +1367,12 @@ int launch_assemble_matrix(tb_form *f, tb_pattern *p, int strategy, double t, do
     if (strategy == TB_STRATEGY_PATCH && hex8_patch_applicable(f, p)) {
         rc = f->kind == TB_FORM_DIFFUSION ? launch_assemble_hex8_patch(f, nullptr, p, t, d_nz, nullptr) : launch_assemble_hex8_patch(nullptr, f, p, t, nullptr, d_nz);
         if (rc != TB_ERR_UNSUPPORTED) return rc; // e.g. rows longer than 255 entries: the general patch kernel below
+        rc = reset_status(m->dev);
+        if (rc) return rc;
+    }
+    if (strategy == TB_STRATEGY_PATCH && tet4_patch_applicable(f, p)) {
+        rc = f->kind == TB_FORM_DIFFUSION ? launch_assemble_tet4_patch(f, nullptr, p, t, d_nz, nullptr) : launch_assemble_tet4_patch(nullptr, f, p, t, nullptr, d_nz);
+        if (rc != TB_ERR_UNSUPPORTED) return rc;
         rc = reset_status(m->dev);
         if (rc) return rc;
     }

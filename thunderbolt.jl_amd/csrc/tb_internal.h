@@ -254,6 +254,8 @@ int ensure_patch_fused(tb_mesh *m, tb_pattern *p, int nregions); // plan of the 
 void free_patch_fused_plan(tb_pattern *p);
 int launch_assemble_hex8_patch(tb_form *fK, tb_form *fM, tb_pattern *p, double t, double *d_nzK, double *d_nzM); // either form may be NULL
 bool hex8_patch_applicable(const tb_form *f, const tb_pattern *p);
+int launch_assemble_tet4_patch(tb_form *fK, tb_form *fM, tb_pattern *p, double t, double *d_nzK, double *d_nzM); // linear tetrahedra; either form may be NULL
+bool tet4_patch_applicable(const tb_form *f, const tb_pattern *p);
 
 // ---- kernel launchers (tb_assembly.hip / tb_reaction.hip / tb_algebra.hip) ----
 int ensure_emap(tb_pattern *p);

@@ -464,7 +464,9 @@ static int build_patch_fused_plan(tb_pattern *p, int64_t *lds_need, int nregions
     tb_mesh *m = p->mesh;
     const PatchPlan *pp = m->patches.get();
     const int ndpc = m->ndpc;
-    if (ndpc != 8 || m->nverts != 8 || m->ncomp != 1) { set_error("fused patch plan: needs a scalar trilinear hexahedron field"); return TB_ERR_UNSUPPORTED; }
+    const bool hex = ndpc == 8 && m->nverts == 8, tet = ndpc == 4 && m->nverts == 4;
+    if (!(hex || tet) || m->ncomp != 1) { set_error("fused patch plan: needs a scalar first-order field on hexahedra or tetrahedra"); return TB_ERR_UNSUPPORTED; }
+    const int NV = ndpc, NS = NV * NV; // nodes per cell, bytes per position signature
     auto plan = std::make_unique<PatchFusedPlan>();
     plan->version = pp->version;
     // 1. row descriptors and the LDS need
@@ -487,7 +489,7 @@ static int build_patch_fused_plan(tb_pattern *p, int64_t *lds_need, int nregions
     std::vector<int64_t> node_ptr(pp->n_patches + 1, 0);
     std::vector<int32_t> pnode;
     pnode.reserve((size_t)(m->n_nodes * 2.2) + 1024);
-    std::vector<uint16_t> ln((size_t)pp->total_elems * 8);
+    std::vector<uint16_t> ln((size_t)pp->total_elems * NV);
     std::vector<int32_t> local_of(m->n_nodes, -1);
     bool bad = false;
     int max_nodes = 0;
@@ -497,10 +499,10 @@ static int build_patch_fused_plan(tb_pattern *p, int64_t *lds_need, int nregions
         pnode.resize(base + nrows, -1);
         for (int64_t e = pp->h_elem_ptr[q]; e < pp->h_elem_ptr[q + 1]; ++e) { // owned slots first
             const int32_t c = pp->h_elem_cell[e];
-            for (int a = 0; a < 8; ++a) {
-                const uint16_t slot = pp->h_elem_lrow[e * 8 + a];
+            for (int a = 0; a < NV; ++a) {
+                const uint16_t slot = pp->h_elem_lrow[e * NV + a];
                 if (slot == 0xFFFF) continue;
-                const int32_t node = m->h_conn[(int64_t)c * 8 + a];
+                const int32_t node = m->h_conn[(int64_t)c * NV + a];
                 int32_t &dst = pnode[base + slot];
                 if (dst < 0) { dst = node; local_of[node] = slot; }
                 else if (dst != node) bad = true;
@@ -508,11 +510,11 @@ static int build_patch_fused_plan(tb_pattern *p, int64_t *lds_need, int nregions
         }
         for (int64_t e = pp->h_elem_ptr[q]; e < pp->h_elem_ptr[q + 1]; ++e) {
             const int32_t c = pp->h_elem_cell[e];
-            for (int a = 0; a < 8; ++a) {
-                const int32_t node = m->h_conn[(int64_t)c * 8 + a];
+            for (int a = 0; a < NV; ++a) {
+                const int32_t node = m->h_conn[(int64_t)c * NV + a];
                 if (local_of[node] < 0) { local_of[node] = (int32_t)(pnode.size() - base); pnode.push_back(node); }
-                else if (pp->h_elem_lrow[e * 8 + a] == 0xFFFF && local_of[node] < nrows) bad = true; // an owned node reached through a dof the patch does not own
-                ln[(size_t)e * 8 + a] = (uint16_t)local_of[node];
+                else if (pp->h_elem_lrow[e * NV + a] == 0xFFFF && local_of[node] < nrows) bad = true; // an owned node reached through a dof the patch does not own
+                ln[(size_t)e * NV + a] = (uint16_t)local_of[node];
             }
         }
         const size_t nn = pnode.size() - base;
@@ -527,24 +529,24 @@ static int build_patch_fused_plan(tb_pattern *p, int64_t *lds_need, int nregions
     if (*lds_need > 80 * 1024) { p->patch_fused = std::move(plan); return TB_ERR_UNSUPPORTED; } // caller shrinks the tile and retries
     // 3. signatures: position of column dof(j) inside row dof(i) for every pair of a cell, de-duplicated
     const int64_t nc = m->n_cells;
-    std::vector<uint8_t> sig((size_t)nc * 64);
+    std::vector<uint8_t> sig((size_t)nc * NS);
     std::vector<uint64_t> hash(nc);
     bool missing = false;
 #pragma omp parallel for schedule(static) reduction(|| : missing)
     for (int64_t c = 0; c < nc; ++c) {
-        const int32_t *d = &m->h_cell_dofs[c * 8];
-        uint8_t *sg = &sig[(size_t)c * 64];
-        for (int i = 0; i < 8; ++i) {
+        const int32_t *d = &m->h_cell_dofs[c * NV];
+        uint8_t *sg = &sig[(size_t)c * NS];
+        for (int i = 0; i < NV; ++i) {
             const int32_t *b = &p->h_colidx[p->h_rowptr[d[i]]];
             const int32_t *en = &p->h_colidx[p->h_rowptr[d[i] + 1]];
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < NV; ++j) {
                 const int32_t *it = std::lower_bound(b, en, d[j]);
-                if (it == en || *it != d[j]) { missing = true; sg[i * 8 + j] = 0; continue; }
-                sg[i * 8 + j] = (uint8_t)(it - b);
+                if (it == en || *it != d[j]) { missing = true; sg[i * NV + j] = 0; continue; }
+                sg[i * NV + j] = (uint8_t)(it - b);
             }
         }
         uint64_t h = 0x243f6a8885a308d3ull;
-        for (int k = 0; k < 8; ++k) { uint64_t v; memcpy(&v, sg + 8 * k, 8); h = mix64(h, v); }
+        for (int k = 0; k < NS / 8; ++k) { uint64_t v; memcpy(&v, sg + 8 * k, 8); h = mix64(h, v); }
         hash[c] = h;
     }
     if (missing) { set_error("patch plan: a cell coupling is missing from the CSR pattern"); return TB_ERR_PATTERN; }
@@ -552,7 +554,7 @@ static int build_patch_fused_plan(tb_pattern *p, int64_t *lds_need, int nregions
     std::iota(order.begin(), order.end(), 0);
     std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
         if (hash[a] != hash[b]) return hash[a] < hash[b];
-        const int r = memcmp(&sig[(size_t)a * 64], &sig[(size_t)b * 64], 64);
+        const int r = memcmp(&sig[(size_t)a * NS], &sig[(size_t)b * NS], NS);
         return r != 0 ? r < 0 : a < b;
     });
     std::vector<uint32_t> cell_sig(nc);
@@ -560,8 +562,8 @@ static int build_patch_fused_plan(tb_pattern *p, int64_t *lds_need, int nregions
     int64_t nsig = 0;
     for (int64_t k = 0; k < nc; ++k) {
         const int32_t c = order[k];
-        if (k == 0 || memcmp(&sig[(size_t)c * 64], &sig[(size_t)order[k - 1] * 64], 64) != 0) {
-            sigtab.insert(sigtab.end(), &sig[(size_t)c * 64], &sig[(size_t)c * 64] + 64);
+        if (k == 0 || memcmp(&sig[(size_t)c * NS], &sig[(size_t)order[k - 1] * NS], NS) != 0) {
+            sigtab.insert(sigtab.end(), &sig[(size_t)c * NS], &sig[(size_t)c * NS] + NS);
             ++nsig;
         }
         cell_sig[c] = (uint32_t)(nsig - 1);
