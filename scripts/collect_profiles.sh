@@ -32,6 +32,7 @@ if [ "$2" != "bench-only" ]; then
   [ -x scripts/microbench/mfma_f64.bin ] && ./scripts/microbench/mfma_f64.bin > "$out/mfma_f64_microbench.txt" 2>&1
   [ -x scripts/microbench/wg_launch.bin ] && ./scripts/microbench/wg_launch.bin > "$out/wg_launch_microbench.txt" 2>&1
   [ -x scripts/microbench/mfma_f64_4x4.bin ] && ./scripts/microbench/mfma_f64_4x4.bin > "$out/mfma_f64_4x4_microbench.txt" 2>&1
+  python3 scripts/bench_tets.py --n 100 > "$out/tets_100.json" 2>/dev/null
   # scalar forms on the quadratic field
   python3 scripts/bench_q2_scalar.py --n 64 > "$out/q2_scalar_64.json" 2>/dev/null
   rocprofv3 --kernel-trace --stats -d "$out/ktq" -o ktq -- python3 scripts/bench_q2_scalar.py --n 64 --strategies element > /dev/null 2>&1
