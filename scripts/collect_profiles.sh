@@ -7,8 +7,8 @@ export TMPDIR=/tmp
 out=gpurun_out/$tag
 mkdir -p "$out"
 # micro-benchmarks are built here (binaries are not tracked)
-for mb in mfma_f64 mfma_f64_4x4 lds_atomic wg_launch; do
-  [ -f scripts/microbench/$mb.hip ] && hipcc --offload-arch=gfx950 -O3 scripts/microbench/$mb.hip -o scripts/microbench/$mb.bin 2>/dev/null
+for mb in mfma_f64 mfma_f64_4x4 lds_atomic wg_launch mall_reuse; do
+  [ -f scripts/microbench/$mb.hip ] && hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics scripts/microbench/$mb.hip -o scripts/microbench/$mb.bin 2>/dev/null
 done
 python3 bench.py > "$out/bench_216.json" 2> "$out/bench_216.err"
 rocprofv3 --kernel-trace --stats -d "$out/kt" -o kt -- python3 bench.py --no-cpu-baseline > "$out/bench_under_rocprof.json" 2>/dev/null
@@ -31,6 +31,7 @@ if [ "$2" != "bench-only" ]; then
   python3 scripts/rocpd_summary.py "$out/kte/kte_results.db" --json "$out/monodomain_kernel_stats.json" > "$out/monodomain_kernel_stats.txt"
   [ -x scripts/microbench/mfma_f64.bin ] && ./scripts/microbench/mfma_f64.bin > "$out/mfma_f64_microbench.txt" 2>&1
   [ -x scripts/microbench/wg_launch.bin ] && ./scripts/microbench/wg_launch.bin > "$out/wg_launch_microbench.txt" 2>&1
+  [ -x scripts/microbench/lds_atomic.bin ] && ./scripts/microbench/lds_atomic.bin > "$out/lds_atomic_microbench.txt" 2>&1
   [ -x scripts/microbench/mfma_f64_4x4.bin ] && ./scripts/microbench/mfma_f64_4x4.bin > "$out/mfma_f64_4x4_microbench.txt" 2>&1
   python3 scripts/bench_tets.py --n 100 > "$out/tets_100.json" 2>/dev/null
   # scalar forms on the quadratic field
