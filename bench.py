@@ -107,14 +107,14 @@ def spawn_ranks(args):
     import subprocess
     import torch
     have = torch.cuda.device_count()    # counts devices without creating a context
-    if have < args.gpus:
+    if have < args.gpus and not os.environ.get("TB_BENCH_SHARE_DEVICE"):
         sys.stderr.write("bench.py: --gpus %d requested but %d GPU(s) visible\n" % (args.gpus, have))
         return 2
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-port", str(port), "--", os.path.abspath(__file__)] + sys.argv[1:]  # "--": the launcher's argparse must not read bench.py's options (--n is a prefix of several of its own)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env)
@@ -138,12 +138,19 @@ def main():
     import torch.distributed as dist
     import thunderbolt_jl_amd as tb
 
-    torch.cuda.set_device(local_rank)
+    # TB_BENCH_SHARE_DEVICE=1 (tests only: a one-GPU box): every rank on cuda:0 with the gloo backend, halo buffers staged through the host — the
+    # same partition / exchange / timing code as the RCCL run, whose line it marks "backend": "gloo (shared device, test)"
+    share = bool(os.environ.get("TB_BENCH_SHARE_DEVICE")) and world > 1
+    device_index = 0 if share else local_rank
+    torch.cuda.set_device(device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
-    dev = tb.MI355XDevice(local_rank)
+    dev = tb.MI355XDevice(device_index)
     dev.set_stream(torch.cuda.current_stream().cuda_stream)
 
     n = args.n
@@ -217,7 +224,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -265,7 +272,7 @@ def main():
                                    % (n, g.n_cells, npts, args.strategy, "one fused pass" if fused else "two launches",
                                       " + neighbour halo sum of b" if world > 1 else "", args.ionic.upper()),
                        "cells_per_gpu": g.n_cells, "dofs_per_gpu": npts, "nnz_per_gpu": sp.nnz, "ionic_model": args.ionic, "ionic_states": ns,
-                       "partition": "z-slabs"},
+                       "partition": "z-slabs", **({"backend": "gloo (shared device, test)"} if share else {})},
             "dof_updates_per_s": ns * dofs_total * K_ / elapsed,
             "phase_ms": ({"mass+diffusion": k_ms} if fused else {"mass": phase["mass"] / K_, "diffusion": k_ms}) | {k: phase[k] / K_ for k in ("source", "halo", "reaction")},
             "phase_rates": {"matrix_integrations_per_s": 2 * g.n_cells / (mk_ms * 1e-3),

@@ -158,3 +158,21 @@ def test_bench_refuses_wrong_job_size():
         pytest.skip("needs a box with fewer than 2 GPUs")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "n_gpus" not in r.stdout
+
+
+def test_bench_two_ranks_end_to_end_on_one_device():
+    """bench.py's own N > 1 path — partition, halo sum of b between the ranks, barrier-bracketed timing, max over ranks, one JSON line from rank 0 —
+    run as the driver runs it (`python bench.py --gpus 2` spawning its ranks), with both ranks on cuda:0 over gloo (TB_BENCH_SHARE_DEVICE, the
+    test-only switch: the box has one GPU and RCCL wants one device per rank)."""
+    import json
+    import subprocess
+    env = dict(os.environ, TB_BENCH_SHARE_DEVICE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--n", "24", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["cells_per_gpu"] == 24 ** 3 and d["config"]["backend"].startswith("gloo")
+    assert d["phase_ms"]["halo"] > 0.0
