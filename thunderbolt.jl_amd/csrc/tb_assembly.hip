@@ -768,13 +768,6 @@ __device__ __forceinline__ void q2_geometry(const double *s_x, int q, double *ge
 // tile of a symmetric form is never computed (SYM: 3 tiles instead of 4) and the stores of the element strategy are 729 consecutive doubles.
 // Reference-element values are formed from the 1-D factors in registers (no table loads); geometry per point as in q2_geometry.
 typedef double q2_d4 __attribute__((ext_vector_type(4)));
-// workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. waits for every global store and prefetch load in flight
-__device__ __forceinline__ void lds_barrier()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
 __constant__ uint8_t g_q2_tix[27] = {
     0 | 0 << 2 | 0 << 4, 2 | 0 << 2 | 0 << 4, 2 | 2 << 2 | 0 << 4, 0 | 2 << 2 | 0 << 4, 0 | 0 << 2 | 2 << 4, 2 | 0 << 2 | 2 << 4, 2 | 2 << 2 | 2 << 4,
     0 | 2 << 2 | 2 << 4, 1 | 0 << 2 | 0 << 4, 2 | 1 << 2 | 0 << 4, 1 | 2 << 2 | 0 << 4, 0 | 1 << 2 | 0 << 4, 1 | 0 << 2 | 2 << 4, 2 | 1 << 2 | 2 << 4,

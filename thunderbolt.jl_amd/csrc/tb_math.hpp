@@ -4,6 +4,14 @@
 
 namespace tb {
 
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. waits for every global store and prefetch load in flight
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // exp for bounded arguments (|x| ≲ 700; ionic-model arguments stay within ±100): k = rint(x·log₂e), r = x − k·ln2 in two
 // pieces (|r| ≤ 0.347), degree-13 Taylor polynomial (truncation 2·10⁻¹⁸ relative), one ldexp.  ≈21 instructions against ≈40 of
 // the library routine, which spends the rest on special cases that cannot occur here; agreement with libm ≤ 2 ulp
