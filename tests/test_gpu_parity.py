@@ -177,6 +177,25 @@ def test_tet_patch_kernel_on_several_patches(tb, oracle, device):
     np.testing.assert_allclose(refM.sum(), 1.3 * 1.0 * 0.8 * 0.6, rtol=1e-12)
 
 
+def test_tet_patch_falls_back_when_a_patch_exceeds_the_packed_header(tb, oracle, device, monkeypatch):
+    """7×7×7 tiles of split hexahedra hold 2 058 tetrahedra plus halo — more instances than the 11-bit count of the staged kernel's patch header:
+    the patch strategy then runs the general patch kernel, same numbers."""
+    monkeypatch.setenv("TB_PATCH_TILE", "7,7,7")
+    g0 = tb.generate_mesh(tb.Hexahedron, (9, 8, 8), (0, 0, 0), (1.0, 0.8, 0.6), perturb=0.15)
+    tets = hex_to_tets(g0.xyz, g0.conn)
+    cd, nd = oracle.close_dofs(oracle.TET4, 1, tets, len(g0.xyz))
+    g = tb.Grid(tb.Tetrahedron, g0.xyz, tets)
+    dh = tb.DofHandler(g, cell_dofs=cd, ndofs=nd)
+    sp = tb.allocate_matrix(dh)
+    om = oracle.Mesh(oracle.TET4, 2, g.xyz, tets, cd)
+    D = np.array([[2.0, 0.3, 0.1], [0.3, 1.5, -0.2], [0.1, -0.2, 1.0]])
+    st = tb.PatchAssemblyStrategy(device)
+    K = tb.update_operator(tb.setup_operator(st, tb.BilinearDiffusionIntegrator(tb.ConstantCoefficient(D)), dh, sp), 0.0)
+    assert rel_err(K.A.to_host(), oracle.assemble_matrix(om, 1, oracle.Coef(oracle.COEF_CONST_TENSOR, D.ravel()), sp.rowptr, sp.colidx)) < TOL
+    M = tb.update_operator(tb.setup_operator(st, tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.0)), dh, sp), 0.0)
+    assert rel_err(M.A.to_host(), oracle.assemble_matrix(om, 0, oracle.Coef(oracle.COEF_CONST_SCALAR, [1.0]), sp.rowptr, sp.colidx)) < TOL
+
+
 def test_error_codes(tb, oracle, device):
     g = tb.generate_mesh(tb.Hexahedron, (2, 2, 2))
     bad = tb.Grid(tb.Hexahedron, g.xyz, g.conn[:, [0, 3, 2, 1, 4, 7, 6, 5]])  # inverted orientation → detJ < 0
