@@ -1040,23 +1040,48 @@ k_gather_rows_q2(int64_t n_rows, const int32_t *__restrict__ ell, int W, const d
 }
 
 __global__ void __launch_bounds__(64)
-k_vector_q2(MeshView m, FormArgs fa, const int32_t *__restrict__ list, double *__restrict__ b, int atomic, Status *st)
+k_vector_q2(MeshView m, FormArgs fa, const double *__restrict__ cell_xyz, const int32_t *__restrict__ list, double *__restrict__ b, int atomic, Status *st)
 {
-    const Q2Tables &tb = g_q2_tables;
+    // one wave per cell: lane q < 27 evaluates f(x_q, t)·dΩ_q, lane j < 27 then sums its dof's row.  Geometry and shape values come from the 1-D
+    // factors in registers (the first version loaded 72 + 27 table entries per lane with lane-varying addresses and inverted J it never used),
+    // vertex coordinates from the cell-major array (one load instead of connectivity → coordinate)
+    constexpr double GX = 0.7745966692414834, W0 = 0.5555555555555556, W1 = 0.8888888888888888;
     const int64_t cell = list ? list[blockIdx.x] : blockIdx.x;
     const int tid = threadIdx.x;
     __shared__ double s_x[24], s_fw[27];
-    for (int i = tid; i < 24; i += 64) s_x[i] = m.xyz[3 * (int64_t)m.conn[cell * 8 + i / 3] + i % 3];
+    if (tid < 24) s_x[tid] = cell_xyz[cell * 24 + tid];
     __syncthreads();
     if (tid < 27) {
-        double geo[10], xq[3];
-        q2_geometry(s_x, tid, geo, xq, cell, st);
-        s_fw[tid] = eval_source(fa, xq, cell, tid, 27) * geo[9];
+        const int q0 = tid % 3, q1 = (tid / 3) % 3, q2 = tid / 9;
+        const double xi[3] = {GX * (q0 - 1), GX * (q1 - 1), GX * (q2 - 1)};
+        double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, xq[3] = {0, 0, 0};
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            const double f0 = 1.0 + Hex8<3>::sgn(a, 0) * xi[0], f1 = 1.0 + Hex8<3>::sgn(a, 1) * xi[1], f2 = 1.0 + Hex8<3>::sgn(a, 2) * xi[2];
+            const double d[3] = {0.125 * Hex8<3>::sgn(a, 0) * f1 * f2, 0.125 * f0 * Hex8<3>::sgn(a, 1) * f2, 0.125 * f0 * f1 * Hex8<3>::sgn(a, 2)};
+            const double Ma = 0.125 * f0 * f1 * f2;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                xq[i] += Ma * s_x[3 * a + i];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) J[i][k] += s_x[3 * a + i] * d[k];
+            }
+        }
+        const double det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) + J[0][1] * (J[1][2] * J[2][0] - J[1][0] * J[2][2]) +
+                           J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+        const double dO = det * (q0 == 1 ? W1 : W0) * (q1 == 1 ? W1 : W0) * (q2 == 1 ? W1 : W0);
+        if (!(dO > 0.0)) { st->neg_detj = 1; st->cell = cell; }
+        s_fw[tid] = eval_source(fa, xq, cell, tid, 27) * dO;
     }
     __syncthreads();
     if (tid < 27) { // bₑ[j] += f(x_q,t)·Nⱼ·dΩ  (analytical_coefficient.jl:89-99)
+        const int tx = g_q2_tix[tid], t0 = tx & 3, t1 = (tx >> 2) & 3, t2 = tx >> 4;
+        double L0[3], L1[3], L2[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const double x = GX * (k - 1); L0[k] = q2_l(t0, x); L1[k] = q2_l(t1, x); L2[k] = q2_l(t2, x); }
         double v = 0.0;
-        for (int q = 0; q < 27; ++q) v += s_fw[q] * tb.N[q][tid];
+#pragma unroll
+        for (int q = 0; q < 27; ++q) v += s_fw[q] * (L0[q % 3] * L1[(q / 3) % 3] * L2[q / 9]);
         const int32_t d = m.cell_dofs[cell * 27 + tid];
         if (atomic) unsafeAtomicAdd(b + d, v); else b[d] += v;
     }
@@ -1114,7 +1139,7 @@ static int run_q2(tb_form *f, tb_pattern *p, int strategy, double t, double *d_n
     const FormArgs fa = make_args(f, t);
     const bool ea = d_nz && (strategy == TB_STRATEGY_ELEMENT);
     if (d_nz) { int rc = ensure_q2pos(p); if (rc) return rc; rc = ensure_cell_xyz(m); if (rc) return rc; if (!ea) TB_HIP(hipMemsetAsync(d_nz, 0, (size_t)p->nnz * sizeof(double), dev->stream)); }
-    else TB_HIP(hipMemsetAsync(d_b, 0, (size_t)m->ndofs * sizeof(double), dev->stream));
+    else { int rc = ensure_cell_xyz(m); if (rc) return rc; TB_HIP(hipMemsetAsync(d_b, 0, (size_t)m->ndofs * sizeof(double), dev->stream)); }
     double *kebuf = nullptr;
     if (ea) {
         if (!m->ea) { int rc = build_ea_plan(m); if (rc) return rc; }
@@ -1136,7 +1161,7 @@ static int run_q2(tb_form *f, tb_pattern *p, int strategy, double t, double *d_n
             if (f->field) TB_Q2(TB_FORM_DIFFUSION, true, true); else if (sym) TB_Q2(TB_FORM_DIFFUSION, false, true); else TB_Q2(TB_FORM_DIFFUSION, false, false);
         }
 #undef TB_Q2
-        else hipLaunchKernelGGL(k_vector_q2, dim3((unsigned)n), dim3(64), 0, dev->stream, mv, fa, list, d_b, atomic, dev->d_status);
+        else hipLaunchKernelGGL(k_vector_q2, dim3((unsigned)n), dim3(64), 0, dev->stream, mv, fa, m->d_cell_xyz, list, d_b, atomic, dev->d_status);
         TB_HIP(hipGetLastError());
         return TB_OK;
     };
