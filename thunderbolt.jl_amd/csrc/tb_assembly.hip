@@ -699,23 +699,10 @@ static int run_matrix_form(tb_form *f, tb_pattern *p, int strategy, double t, do
 
 // ------------------------------------------------------------------------------------------------
 // Scalar forms on the triquadratic field (Lagrange order 2 on hexahedra, 27 dofs and 27 Gauss points per cell): Mₑ, Kₑ are 27×27 —
-// too large for the one-thread-per-cell register kernels above, so one workgroup integrates one cell: geometry per point, mapped
-// gradients and D·∇N in LDS, then every lane sums its (i, j) entries over the points and adds them through a per-cell table of row
-// positions.  Constant coefficients (the reference's mass.jl:28-43 / diffusion.jl:28-50 with ConstantCoefficient); sources as above.
+// too large for the one-thread-per-cell register kernels above, so a workgroup integrates a cell at a time on the matrix cores (k_matrix_q2 below)
+// and the entries reach the CSR arrays through a per-cell table of row positions (k_build_q2pos) — gathered per row, scattered atomically or
+// per colour.  Constant and first-order nodal coefficients (the reference's mass.jl:28-43 / diffusion.jl:28-50); sources: k_vector_q2.
 // ------------------------------------------------------------------------------------------------
-struct Q2Tables { double N[27][27], dN[27][27][3], dM[27][8][3], M[27][8], w[27]; };
-constexpr Q2Tables make_q2_tables()
-{
-    Q2Tables t{};
-    for (int q = 0; q < 27; ++q) {
-        t.w[q] = Hex27::w(q);
-        for (int a = 0; a < 27; ++a) { t.N[q][a] = Hex27::N(q, a); for (int d = 0; d < 3; ++d) t.dN[q][a][d] = Hex27::dN(q, a, d); }
-        for (int a = 0; a < 8; ++a) { t.M[q][a] = Hex27::M(q, a); for (int d = 0; d < 3; ++d) t.dM[q][a][d] = Hex27::dM(q, a, d); }
-    }
-    return t;
-}
-__constant__ Q2Tables g_q2_tables = make_q2_tables();
-
 // position of column dof(j) inside row dof(i), per cell and pair (cell-major: one coalesced 729-entry read per workgroup)
 __global__ void k_build_q2pos(const int32_t *__restrict__ cell_dofs, int64_t n_cells, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
                               uint16_t *__restrict__ pos, Status *st)
@@ -736,37 +723,13 @@ __global__ void k_build_q2pos(const int32_t *__restrict__ cell_dofs, int64_t n_c
     pos[tid] = (uint16_t)(lo - lo0);
 }
 
-// geometry of the 27 points of a cell: J⁻¹ (9) and dΩ into s_geo[q][0..9]; x_q into s_xq when asked for
-__device__ __forceinline__ void q2_geometry(const double *s_x, int q, double *geo, double *xq, int64_t cell, Status *st)
-{
-    const Q2Tables &tb = g_q2_tables;
-    double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-#pragma unroll
-    for (int a = 0; a < 8; ++a)
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) J[i][k] += s_x[3 * a + i] * tb.dM[q][a][k];
-    const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1], c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2], c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
-    const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02, id = 1.0 / det;
-    geo[0] = c00 * id; geo[1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * id; geo[2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * id;
-    geo[3] = c01 * id; geo[4] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * id; geo[5] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * id;
-    geo[6] = c02 * id; geo[7] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * id; geo[8] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * id;
-    geo[9] = det * tb.w[q];
-    if (!(geo[9] > 0.0)) { st->neg_detj = 1; st->cell = cell; }
-    if (xq) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { double v = 0.0; for (int a = 0; a < 8; ++a) v += tb.M[q][a] * s_x[3 * a + i]; xq[i] = v; }
-    }
-}
-
 // Element matrices of the quadratic field on the matrix cores.  Both forms are one small GEMM per cell,
 //   Kₑ[i][j] = −Σ_(q,k) T[(q,k)][i]·G[(q,k)][j]   (T = dΩ·D·∇N, G = ∇N: 27 × 27 × 81)      Mₑ[i][j] = Σ_q (ρ dΩ N)[q][i]·N[q][j]   (27 × 27 × 27),
 // i.e. 2 × 2 tiles of v_mfma_f64_16x16x4_f64 with 21 / 7 k-steps.  The previous form (every lane summing its entries over the points out of LDS) was
 // bound by LDS bandwidth — six doubles read per three FMAs, 0.95 MB of LDS traffic per cell; an MFMA reads two doubles per lane for sixteen FMAs.
 // The four waves split the k-steps (each runs its share on every tile) and the partial tiles are summed through LDS in a fixed order, so the lower-left
 // tile of a symmetric form is never computed (SYM: 3 tiles instead of 4) and the stores of the element strategy are 729 consecutive doubles.
-// Reference-element values are formed from the 1-D factors in registers (no table loads); geometry per point as in q2_geometry.
+// Reference-element values are formed from the 1-D factors in registers (no table loads); geometry per point: q2_point_geometry.
 typedef double q2_d4 __attribute__((ext_vector_type(4)));
 __constant__ uint8_t g_q2_tix[27] = {
     0 | 0 << 2 | 0 << 4, 2 | 0 << 2 | 0 << 4, 2 | 2 << 2 | 0 << 4, 0 | 2 << 2 | 0 << 4, 0 | 0 << 2 | 2 << 4, 2 | 0 << 2 | 2 << 4, 2 | 2 << 2 | 2 << 4,
