@@ -56,48 +56,65 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(n, kap, threads, ionic="tt06"):
-    """Oracle ("port": C restatement of the reference CPU path, NOT Julia) on a bounded sample of the same workload."""
+def cpu_model_string():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(n, kap, threads, ionic="tt06", sizes=(64, 100)):
+    """Oracle ("port": C restatement of the reference CPU path, NOT Julia) on bounded samples of the same workload, as SURVEY §8(d) asks:
+    1 thread and the best multi-thread count, on the 64³ and 100³ meshes, min over repetitions after a warm-up.  `value` is the
+    multi-thread rate on the n³ sample (n = --cpu-n); every other number sits in `table`."""
     from oracle import oracle as o
-    xyz, conn = o.generate_grid_hex(n, n, n, (0, 0, 0), (1, 1, 1))
-    cd, nd = o.close_dofs(o.HEX8, 1, conn, len(xyz))
-    rp, ci = o.build_pattern(cd, nd)
-    col, nc = o.color_cells(cd, nd)
-    m = o.Mesh(o.HEX8, 2, xyz, conn, cd)
-    cM = o.Coef(o.COEF_CONST_SCALAR, [1.0])
-    cK = o.Coef(o.COEF_CONST_TENSOR, kap.ravel(), Cm=1.0, chi=1.0, wrap=True)
     cm = {"pcg2019": o.CELL_PCG2019, "tt06": o.CELL_TT06, "fhn": o.CELL_FHN}[ionic]
     rdt = {"pcg2019": 0.01, "tt06": 0.001, "fhn": 0.1}[ionic]
     p = o.cell_default_params(cm)
-    u = np.ascontiguousarray(np.tile(o.cell_default_state(cm, p), (nd, 1)).T).ravel().copy()
-    nstates = len(u) // nd
-    # the oracle's OpenMP loops stop scaling (and collapse when oversubscribed) well below the box's 256 hardware
-    # threads: pick the fastest of a few thread counts on one diffusion assembly, then time the sample with it
+    cM = o.Coef(o.COEF_CONST_SCALAR, [1.0])
+    cK = o.Coef(o.COEF_CONST_TENSOR, kap.ravel(), Cm=1.0, chi=1.0, wrap=True)
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else threads
-    cands = sorted({t for t in (8, 16, 32, 64) if t <= avail} | {min(avail, 8)})
-    probe = {}
-    for t in cands:
-        t0 = time.perf_counter()
-        o.assemble_matrix(m, 1, cK, rp, ci, nthreads=t, color=col, ncolors=nc)
-        probe[t] = time.perf_counter() - t0
-    threads = min(probe, key=probe.get)
-    best_asm, best_rx = 1e30, 1e30
-    t_end = time.time() + 15.0
-    reps = 0
-    while reps < 2 or (time.time() < t_end and reps < 8):
-        t0 = time.perf_counter()
-        o.assemble_matrix(m, 0, cM, rp, ci, nthreads=threads, color=col, ncolors=nc)
-        o.assemble_matrix(m, 1, cK, rp, ci, nthreads=threads, color=col, ncolors=nc)
-        o.assemble_source(m, o.SRC_COS_EXP, t=0.0, nthreads=threads)
-        t1 = time.perf_counter()
-        o.reaction_step(cm, p, u, nd, o.LAYOUT_SOA, dt=rdt, nthreads=threads, want_du=False)
-        t2 = time.perf_counter()
-        best_asm, best_rx = min(best_asm, t1 - t0), min(best_rx, t2 - t1)
-        reps += 1
-    ncell = n ** 3
-    return {"value": 3 * ncell / best_asm, "unit": "element-integrations/s", "cores": threads, "kind": "port",
-            "sample": "%d^3 hex Q1 mesh (%d cells): M + K + b per-colour/EA OpenMP, min of %d reps; C restatement of the reference CPU path, not Julia" % (n, ncell, reps),
-            "dof_updates_per_s": nstates * nd / best_rx, "ionic_model": ionic}
+    table, chosen = {}, None
+    for nn in sorted(set(sizes) | {n}):
+        xyz, conn = o.generate_grid_hex(nn, nn, nn, (0, 0, 0), (1, 1, 1))
+        cd, nd = o.close_dofs(o.HEX8, 1, conn, len(xyz))
+        rp, ci = o.build_pattern(cd, nd)
+        col, nc = o.color_cells(cd, nd)
+        m = o.Mesh(o.HEX8, 2, xyz, conn, cd)
+        u = np.ascontiguousarray(np.tile(o.cell_default_state(cm, p), (nd, 1)).T).ravel().copy()
+        nstates = len(u) // nd
+        if chosen is None:
+            # the oracle's OpenMP loops stop scaling (and collapse when oversubscribed) well below the box's 256 hardware
+            # threads: pick the fastest of a few thread counts on one diffusion assembly, then time every sample with it
+            cands = sorted({t for t in (8, 16, 32, 64) if t <= avail} | {min(avail, 8)})
+            probe = {}
+            for t in cands:
+                t0 = time.perf_counter()
+                o.assemble_matrix(m, 1, cK, rp, ci, nthreads=t, color=col, ncolors=nc)
+                probe[t] = time.perf_counter() - t0
+            chosen = min(probe, key=probe.get)
+        for th, budget in ((1, 3.0), (chosen, 4.0)):
+            best_asm, best_rx, reps = 1e30, 1e30, 0
+            t_end = time.time() + budget
+            while reps < (1 if th == 1 else 2) or (time.time() < t_end and reps < 6):   # bounded: the slow single-thread legs may get one repetition only
+                t0 = time.perf_counter()
+                o.assemble_matrix(m, 0, cM, rp, ci, nthreads=th, color=col, ncolors=nc)
+                o.assemble_matrix(m, 1, cK, rp, ci, nthreads=th, color=col, ncolors=nc)
+                o.assemble_source(m, o.SRC_COS_EXP, t=0.0, nthreads=th)
+                t1 = time.perf_counter()
+                o.reaction_step(cm, p, u, nd, o.LAYOUT_SOA, dt=rdt, nthreads=th, want_du=False)
+                t2 = time.perf_counter()
+                best_asm, best_rx = min(best_asm, t1 - t0), min(best_rx, t2 - t1)
+                reps += 1
+            table["%d^3/%dt" % (nn, th)] = {"element_integrations_per_s": 3 * nn ** 3 / best_asm, "dof_updates_per_s": nstates * nd / best_rx, "reps": reps}
+    top = table["%d^3/%dt" % (n, chosen)]
+    return {"value": top["element_integrations_per_s"], "unit": "element-integrations/s", "cores": chosen, "kind": "port",
+            "sample": "%d^3 hex Q1 mesh (%d cells): M + K + b per-colour/EA OpenMP, min of %d reps; C restatement of the reference CPU path, not Julia" % (n, n ** 3, top["reps"]),
+            "dof_updates_per_s": top["dof_updates_per_s"], "ionic_model": ionic,
+            "table": table, "threads_available": avail, "threads_chosen": chosen, "cpu_model": cpu_model_string()}
 
 
 def spawn_ranks(args):
@@ -159,8 +176,9 @@ def main():
     dh = tb.DofHandler(g)
     sp = tb.allocate_matrix(dh)
     st = {"patch": tb.PatchAssemblyStrategy, "atomic": tb.AtomicAssemblyStrategy, "color": tb.PerColorAssemblyStrategy}[args.strategy](dev)
-    # linear form: the one-launch atomic scatter (8 f64 atomics per cell, no halo cells to re-integrate) beats the patch
-    # kernel for vectors — 0.57 vs 1.0 ms at 216³ — because the source term is arithmetic-bound (exp, sqrt per point)
+    # linear form: the atomic strategy on hexahedra is the patch-reduced kernel k_vector_hex8_patch<false> — a patch integrates its own cells only
+    # (no halo cells to re-integrate), sums them per node in LDS and adds every touched node to the zeroed vector with one global atomic
+    # (1.4 atomics per cell); the halo flavour (PATCH) stores each dof once but re-integrates 49 % more cells: 0.53 vs 0.34 ms at 216³
     st_vec = tb.AtomicAssemblyStrategy(dev) if args.strategy == "patch" else st
     kap = np.diag([4.5e-5, 2.0e-5, 2.0e-5])  # docs/src/literate-tutorials/ep01_spiral-wave.jl:39-41 style conductivities
     D = tb.ConductivityToDiffusivityCoefficient(tb.ConstantCoefficient(kap), tb.ConstantCoefficient(1.0), tb.ConstantCoefficient(1.0))
@@ -268,7 +286,7 @@ def main():
             "value": 3 * cells_total * K_ / elapsed, "unit": "element-integrations/s",
             "n_gpus": world, "steps": K_, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "monodomain hot path on %d^3 hex Q1 per GPU (%d cells, %d dofs): assemble M + K (%s scatter, %s) + b (atomic scatter)%s + %s forward-Euler reaction step"
+            "config": {"workload": "monodomain hot path on %d^3 hex Q1 per GPU (%d cells, %d dofs): assemble M + K (%s scatter, %s) + b (patch-reduced sums, 1.4 global atomics per cell)%s + %s forward-Euler reaction step"
                                    % (n, g.n_cells, npts, args.strategy, "one fused pass" if fused else "two launches",
                                       " + neighbour halo sum of b" if world > 1 else "", args.ionic.upper()),
                        "cells_per_gpu": g.n_cells, "dofs_per_gpu": npts, "nnz_per_gpu": sp.nnz, "ionic_model": args.ionic, "ionic_states": ns,

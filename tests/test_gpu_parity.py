@@ -500,15 +500,20 @@ def _sampled_rows_error(oracle, om, form, oc, sp, cell_dofs, nz, rows):
     return worst
 
 
-def _property_checks(tb, oracle, device, n, sample=200, fused=False):
+KAPPA_FULL = np.array([[4.5e-5, 1e-5, 0], [1e-5, 2.0e-5, 0], [0, 0, 2.0e-5]])
+KAPPA_BENCH = np.diag([4.5e-5, 2.0e-5, 2.0e-5])   # bench.py's tensor: constant and diagonal → the DIAG instance of the fused kernel
+
+
+def _property_checks(tb, oracle, device, n, sample=200, fused=False, kap=KAPPA_FULL):
     """Size-independent properties at BASELINE sizes (the oracle checks a random sample of rows exactly).
-    fused: M and K come from the one-pass pair assembly (tb_assemble_matrix_pair), as bench.py runs them."""
+    fused: M and K come from the one-pass pair assembly (tb_assemble_matrix_pair), as bench.py runs them.
+    kap: KAPPA_FULL has off-diagonal entries (general-tensor kernel instance), KAPPA_BENCH is bench.py's diagonal tensor
+    (k_patch_hex8_staged<…, DIAG = true>, the instance the headline number is measured on)."""
     g = tb.generate_mesh(tb.Hexahedron, (n, n, n), (0, 0, 0), (1, 1, 1), perturb=0.2)
     dh = tb.DofHandler(g)
     sp = tb.allocate_matrix(dh)
     assert g.n_cells == n ** 3 and dh.ndofs == (n + 1) ** 3 and sp.nnz == (3 * n + 1) ** 3
     st = tb.PatchAssemblyStrategy(device)
-    kap = np.array([[4.5e-5, 1e-5, 0], [1e-5, 2.0e-5, 0], [0, 0, 2.0e-5]])
     M = tb.setup_operator(st, tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.0)), dh, sp)
     K = tb.setup_operator(st, tb.BilinearDiffusionIntegrator(tb.ConstantCoefficient(kap)), dh, sp)
     if fused:
@@ -564,11 +569,20 @@ def test_properties_100_cubed(tb, oracle, device):
     assert _property_checks(tb, oracle, device, 100) == 1000000
 
 
+def test_properties_100_cubed_fused_diagonal_tensor(tb, oracle, device):
+    assert _property_checks(tb, oracle, device, 100, fused=True, kap=KAPPA_BENCH) == 1000000
+
+
 def test_properties_216_cubed(tb, oracle, device):
     """BASELINE's metric configuration (10 077 696 hexahedra, 273 359 449 non-zeros) through the fused M + K pass of bench.py:
     K·1 = 0, Σ M = volume, ∫1·Nⱼ = (M·1)ⱼ, symmetry, definiteness, sampled rows of K and M against oracle element matrices,
-    atomic == patch.  Covers the Int32 / size effects the smaller property tests cannot."""
-    assert _property_checks(tb, oracle, device, 216, sample=300, fused=True) == 10077696
+    atomic == patch.  Covers the Int32 / size effects the smaller property tests cannot.  The tensor is bench.py's own (diagonal), so the
+    kernel instance checked here is the one the bench line is measured on; the general-tensor instance runs in the next test."""
+    assert _property_checks(tb, oracle, device, 216, sample=300, fused=True, kap=KAPPA_BENCH) == 10077696
+
+
+def test_properties_216_cubed_general_tensor(tb, oracle, device):
+    assert _property_checks(tb, oracle, device, 216, sample=300, fused=True, kap=KAPPA_FULL) == 10077696
 
 
 def test_fused_mass_diffusion_pair_parity(tb, oracle, device):
@@ -612,6 +626,32 @@ def test_reaction_full_size_roundtrip(tb, oracle, device):
         oracle.reaction_step(oracle.CELL_PCG2019, model.params, ref, 1024, oracle.LAYOUT_SOA, t=0.01 * step, dt=0.01)
     assert rel_err(out[:, :1024].ravel(), ref) < TOL
     assert np.isfinite(out).all()
+
+
+def test_reaction_full_size_tt06_sample(tb, oracle, device):
+    """10.2 M points × 19 states of the ten Tusscher–Panfilov 2006 model — the reaction kernel and size bench.py times: periodic copies
+    stay identical, a 1024-point sample matches the oracle step for step (forward Euler and Rush–Larsen), everything stays finite."""
+    n = 10218313
+    model = tb.TT06()
+    rng = np.random.default_rng(6)
+    base = initial_points(tb, model, 1024, rng)
+    host = np.ascontiguousarray(np.tile(base, (n // 1024 + 1, 1))[:n].T).ravel()
+    f = tb.PointwiseODEFunction(n, model)
+    dt = 0.001
+    for solver, step_ref in ((tb.ForwardEulerCellSolver(device), lambda u, t: oracle.reaction_step(oracle.CELL_TT06, model.params, u, 1024, oracle.LAYOUT_SOA, t=t, dt=dt)),
+                             (tb.RushLarsenCellSolver(device), lambda u, t: oracle.reaction_step_rl(oracle.CELL_TT06, model.params, u, 1024, oracle.LAYOUT_SOA, t=t, dt=dt))):
+        cache = tb.setup_solver_cache(f, solver, u=device.to_device(host), keep_du=False)
+        for step in range(3):
+            assert tb.perform_step(f, cache, dt * step, dt) is True
+        out = cache.un.to_host().reshape(19, n)
+        np.testing.assert_array_equal(out[:, :1024], out[:, 1024 * 5000:1024 * 5001])
+        np.testing.assert_array_equal(out[:, 1024 * 9978:n], out[:, :n - 1024 * 9978])   # the ragged tail of the last workgroups
+        ref = np.ascontiguousarray(base.T).ravel().copy()
+        for step in range(3):
+            step_ref(ref, dt * step)
+        assert rel_err(out[:, :1024].ravel(), ref) < TOL, type(solver).__name__
+        assert np.isfinite(out).all()
+        del cache, out
 
 
 # ------------------------------------------------------------------------------------------- quasi-static mechanics
