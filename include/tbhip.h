@@ -424,12 +424,28 @@ int tb_dot(tb_device *dev, int64_t n, const double *d_x, const double *d_y, doub
  * dof held by k ranks with 1/k (NULL: 1); every scalar lives in caller-owned device memory, so the caller sums them over the ranks (RCCL
  * all-reduce) and no kernel waits for the host:
  *   tb_cgd_dot        *d_out      += Σ w·a·b
- *   tb_cgd_update     α = *d_rz / *d_pAp;  x += α p;  r −= α Ap;  d_out2[0] += Σ w·r·(D⁻¹r);  d_out2[1] += Σ w·r·r
+ *   tb_cgd_update     α = *d_rz / *d_pAp;  x += α p;  r −= α Ap;  d_out2[0] += Σ w·r·(D⁻¹r);  d_out2[1] += Σ w·r·r;
+ *                     d_out2[2] (a THIRD slot the caller zeroes once) is set to pᵀAp when pᵀAp ≤ 0 with r·z ≠ 0 — breakdown / indefinite
+ *                     operator — and never cleared: the host reads it together with ‖r‖² (the step itself is then empty, α = 0)
  *   tb_cgd_direction  β = *d_rz_new / *d_rz;  p = D⁻¹ r + β p                                   (d_dinv NULL: no preconditioner) */
 int tb_cgd_dot(tb_device *dev, int64_t n, const double *d_w, const double *d_a, const double *d_b, double *d_out);
 int tb_cgd_update(tb_device *dev, int64_t n, const double *d_w, const double *d_dinv, const double *d_p, const double *d_Ap, double *d_x, double *d_r,
                   const double *d_rz, const double *d_pAp, double *d_out2);
 int tb_cgd_direction(tb_device *dev, int64_t n, const double *d_dinv, const double *d_r, double *d_p, const double *d_rz, const double *d_rz_new);
+/* Halo pack / unpack of the multi-GPU path — new work: the reference is shared-memory only (README.md:7); what these stand in for on one device
+ * is the plain indexing of device vectors its GPU extension relies on (ext/CuThunderboltExt.jl:126-170).  Sub-domain vectors hold the dofs
+ * shared with a neighbouring rank at the positions d_idx (0-based Int32, distinct within one call; both sides list the shared dofs in the same
+ * order, e.g. ascending global node id):
+ *   tb_gather_indexed       d_out[k] = d_vec[d_idx[k]]          pack the partial values into the send buffer
+ *   tb_scatter_add_indexed  d_vec[d_idx[k]] += d_in[k]           add what the neighbour sent
+ *   tb_spmv_csr_rows        d_out[k] = Σ_j A[d_rows[k], j]·x[j]   the interface rows of y = A·x straight into the send buffer, before the whole
+ *                                                                product is formed: the exchange overlaps the interior SpMV
+ *   tb_spmv_csr_dot         y = A·x and *d_dot += xᵀ·y           (device scalar) — Σ_ranks xᵀ·A_p·x is pᵀAp of the distributed CG: no halo needed
+ * All asynchronous on the device's stream. */
+int tb_gather_indexed(tb_device *dev, int64_t n, const double *d_vec, const int32_t *d_idx, double *d_out);
+int tb_scatter_add_indexed(tb_device *dev, int64_t n, const double *d_in, const int32_t *d_idx, double *d_vec);
+int tb_spmv_csr_rows(tb_pattern *pat, const double *d_nzval, const double *d_x, int64_t n_rows, const int32_t *d_rows, double *d_out);
+int tb_spmv_csr_dot(tb_pattern *pat, const double *d_nzval, const double *d_x, double *d_y, double *d_dot);
 /* apply_zero!(K, f, ch) on the device CSR matrix (Ferrite.apply_zero!; CSR method src/utils.jl:263-278; used by
  * eliminate_constraints_from_linearization! / _residual! / _increment!, src/solver/nonlinear/nlsolve_common.jl:12-26):
  * d_prescribed is one byte per dof (1 = Dirichlet dof).  Rows and columns of prescribed dofs are zeroed, their diagonal

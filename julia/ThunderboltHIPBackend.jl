@@ -389,4 +389,40 @@ function LinearAlgebra.dot(a::HIPVector{Float64}, b::HIPVector{Float64})
 end
 LinearAlgebra.norm(a::HIPVector{Float64}) = sqrt(dot(a, a))
 
+# ---- multi-device path (new work: the reference is shared-memory only, README.md:7).  One Julia process per GPU (MPI.jl); a sub-domain vector holds
+# the dofs shared with a neighbouring rank at the positions `idx` (0-based Int32 on the device, both sides in the same order).  The exchange is
+# pack → MPI.Isend / MPI.Irecv! on the device buffers (GPU-aware MPI) → unpack; mirrored and tested in thunderbolt.jl_amd/distributed.py (HaloExchange).
+struct HaloNeighbour
+    peer::Int
+    idx::HIPVector{Int32}
+    send::HIPVector{Float64}
+    recv::HIPVector{Float64}
+end
+function halo_pack!(nb::HaloNeighbour, v::HIPVector{Float64})
+    check(ccall((:tb_gather_indexed, libtbhip), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Int32}, Ptr{Float64}), v.dev.handle, nb.idx.n, v.ptr, nb.idx.ptr, nb.send.ptr))
+end
+function halo_unpack_add!(v::HIPVector{Float64}, nb::HaloNeighbour)
+    check(ccall((:tb_scatter_add_indexed, libtbhip), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Int32}, Ptr{Float64}), v.dev.handle, nb.idx.n, nb.recv.ptr, nb.idx.ptr, v.ptr))
+end
+# interface rows of A·x straight into the send buffer (posted before the whole product is formed, so the transfer overlaps it)
+function halo_pack_product_rows!(nb::HaloNeighbour, A::HIPSparseMatrixCSR{Float64}, x::HIPVector{Float64})
+    check(ccall((:tb_spmv_csr_rows, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Int32}, Ptr{Float64}),
+        A.ddh.pattern, A.nzval.ptr, x.ptr, nb.idx.n, nb.idx.ptr, nb.send.ptr))
+end
+# y = A·x and xy[] += xᵀ·y (device scalar): the local quadratic form of the distributed CG
+function mul_dot!(y::HIPVector{Float64}, A::HIPSparseMatrixCSR{Float64}, x::HIPVector{Float64}, xy::HIPVector{Float64})
+    check(ccall((:tb_spmv_csr_dot, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), A.ddh.pattern, A.nzval.ptr, x.ptr, y.ptr, xy.ptr))
+end
+# the vector work of one CG iteration with device-resident scalars S = (rz, pAp, rz_new, rr, flag); the caller all-reduces S[2] and S[3:4] in between
+function cgd_dot!(S::HIPVector{Float64}, slot::Int, w::HIPVector{Float64}, a::HIPVector{Float64}, b::HIPVector{Float64})
+    check(ccall((:tb_cgd_dot, libtbhip), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), a.dev.handle, a.n, w.ptr, a.ptr, b.ptr, S.ptr + 8 * slot))
+end
+function cgd_update!(S::HIPVector{Float64}, w::HIPVector{Float64}, dinv::HIPVector{Float64}, p::HIPVector{Float64}, Ap::HIPVector{Float64}, x::HIPVector{Float64}, r::HIPVector{Float64})
+    check(ccall((:tb_cgd_update, libtbhip), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        x.dev.handle, x.n, w.ptr, dinv.ptr, p.ptr, Ap.ptr, x.ptr, r.ptr, S.ptr, S.ptr + 8, S.ptr + 16))
+end
+function cgd_direction!(S::HIPVector{Float64}, dinv::HIPVector{Float64}, r::HIPVector{Float64}, p::HIPVector{Float64})
+    check(ccall((:tb_cgd_direction, libtbhip), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), r.dev.handle, r.n, dinv.ptr, r.ptr, p.ptr, S.ptr, S.ptr + 16))
+end
+
 end # module

@@ -43,7 +43,11 @@ def _worker(rank, world, port, nel, q):
     up_idx = None if up is None else torch.from_numpy(n2d[up])
     # source vector: local assembly, then halo sum
     b = torch.from_numpy(o.assemble_source(om, o.SRC_COS_EXP, t=0.1))
+    # the persistent-buffer exchange (host tensors: torch index_select / index_add_ on buffers allocated once) equals the plain one bit for bit
+    halo = D.HaloExchange(D.slab_neighbours(lo_idx, up_idx, rank, world), dist, b)
+    b_packed = halo.exchange_sum(b.clone())
     D.halo_sum(b, lo_idx, up_idx, rank, world, dist)
+    assert torch.equal(b, b_packed) and halo.nbytes == 8 * sum(i.numel() for i in (lo_idx, up_idx) if i is not None)
     # operator action y = K x with sub-domain (unassembled-at-the-interface) matrices: local SpMV + halo sum
     kap = np.diag([4.5e-5, 2.0e-5, 2.0e-5])
     Kp = o.assemble_matrix(om, 1, o.Coef(o.COEF_CONST_TENSOR, kap.ravel()), sp.rowptr, sp.colidx)

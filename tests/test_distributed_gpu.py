@@ -1,7 +1,8 @@
 """N>1 path with device-assembled operators: two ranks, both on cuda:0, `gloo` backend with halo buffers staged through the host (the box has
 one GPU; RCCL needs one device per rank).  Every rank assembles b, M and K of its z-slab with the HIP kernels (the fused M + K pass and the
 vector scatter bench.py runs), and the partition / interface bookkeeping / exchange / distributed Jacobi-CG under test are the shipped ones
-(thunderbolt.jl_amd/distributed.py, device path: tb_spmv_csr + tb_cgd_* with device-resident scalars).  The reference is shared-memory only
+(thunderbolt.jl_amd/distributed.py, device path: tb_spmv_csr / tb_spmv_csr_dot / tb_spmv_csr_rows + tb_cgd_* with device-resident scalars, halo pack /
+unpack through tb_gather_indexed / tb_scatter_add_indexed).  The reference is shared-memory only
 (README.md:7): correctness is "P-rank result == 1-rank result" (SURVEY §8e), here against the 1-rank HIP result."""
 import os
 import socket
@@ -78,7 +79,15 @@ def _worker(rank, world, port, q):
     lo_idx = None if lo is None else torch.from_numpy(n2d[lo]).cuda()
     up_idx = None if up is None else torch.from_numpy(n2d[up]).cuda()
     torch.cuda.synchronize()
-    D.halo_sum(b, lo_idx, up_idx, rank, world, dist)
+    # the packed exchange behind the C ABI (persistent buffers, tb_gather_indexed / tb_scatter_add_indexed) against plain torch indexing: bit for bit
+    nb = D.slab_neighbours(lo_idx, up_idx, rank, world)
+    halo = D.HaloExchange(nb, dist, b, dev)
+    b_torch = D.halo_sum(b.clone(), lo_idx, up_idx, rank, world, dist)
+    halo.exchange_sum(b)
+    packed_equal = bool(torch.equal(b, b_torch))
+    b_again = b_torch.clone()
+    halo.exchange_sum(b_again)                                   # the buffers are reused: a second exchange on other data
+    packed_equal = packed_equal and bool(torch.equal(b_again, D.halo_sum(b_torch.clone(), lo_idx, up_idx, rank, world, dist)))
     # operator action with the sub-domain matrix: device SpMV + exchange
     xl = np.empty(dh.ndofs)
     xl[n2d] = _field(g.xyz)
@@ -100,10 +109,31 @@ def _worker(rank, world, port, q):
     D.halo_sum(rhs, lo_idx, up_idx, rank, world, dist)
     cg = D.DistributedCG(spmv, torch.from_numpy(diag).cuda(), lo_idx, up_idx, rank, world, dist, device=dev, look=4)
     u, its, rn = cg.solve(rhs, x.clone(), rtol=1e-13, atol=1e-15, maxiter=400)
+    # the same solve with the iteration ordered for overlap: interface rows of A·p packed first (tb_spmv_csr_rows), exchange posted, whole local
+    # product + local pᵀA_p p behind it (tb_spmv_csr_dot), received partials added (tb_scatter_add_indexed)
+    cg2 = D.DistributedCG(None, torch.from_numpy(diag).cuda(), lo_idx, up_idx, rank, world, dist, device=dev, look=4, operator=(K.pattern, A))
+    u2, its2, rn2 = cg2.solve(rhs, x.clone(), rtol=1e-13, atol=1e-15, maxiter=400)
+    # one product of each form on the same vector: the overlapped form packs rows computed by another kernel (summation order within a row
+    # differs from the stream SpMV's), so agreement is to rounding, not bitwise
+    S = torch.zeros(5, dtype=torch.float64, device="cuda")
+    Ap1, Ap2 = torch.empty_like(x), torch.empty_like(x)
+    cg.device_iteration(x, Ap1, S)
+    pAp1 = float(S[1].item()); S.zero_()
+    cg2.device_iteration(x, Ap2, S)
+    pAp2 = float(S[1].item())
+    prod_err = float((Ap1 - Ap2).abs().max() / Ap1.abs().max())
+    # an indefinite operator must be reported, not iterated to maxiter
+    cgn = D.DistributedCG(lambda v: -spmv(v), torch.from_numpy(diag).cuda(), lo_idx, up_idx, rank, world, dist, device=dev, look=2)
+    try:
+        cgn.solve(rhs, x.clone(), rtol=1e-13, atol=0.0, maxiter=50)
+        breakdown_reported = False
+    except ArithmeticError:
+        breakdown_reported = True
     torch.cuda.synchronize()
     plane = (NEL[0] + 1) * (NEL[1] + 1)
     gnode = np.arange(g.n_nodes) + part.z0 * plane
-    q.put((rank, gnode, b.cpu().numpy()[n2d], y.cpu().numpy()[n2d], u.cpu().numpy()[n2d], its))
+    q.put((rank, gnode, b.cpu().numpy()[n2d], y.cpu().numpy()[n2d], u.cpu().numpy()[n2d], its,
+           {"packed_equal": packed_equal, "u2": u2.cpu().numpy()[n2d], "its2": its2, "prod_err": prod_err, "pAp": (pAp1, pAp2), "breakdown_reported": breakdown_reported}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -140,11 +170,16 @@ def test_two_ranks_hip_assembly_halo_and_cg_equal_single_rank(tb, device):
     its, _ = tb.cg_solve(K.pattern, A, rhs, u, rtol=1e-13, atol=1e-15, maxiter=400)
     uref = u.to_host()[n2d]
     seen = np.zeros(g.n_nodes, dtype=int)
-    for rank, gnode, bb, yy, uu, it in res:
+    for rank, gnode, bb, yy, uu, it, extra in res:
         np.testing.assert_allclose(bb, bref[gnode], rtol=1e-12, atol=1e-12 * np.abs(bref).max())
         np.testing.assert_allclose(yy, yref[gnode], rtol=0, atol=1e-12 * np.abs(yref).max())
         np.testing.assert_allclose(uu, uref[gnode], rtol=0, atol=1e-9 * np.abs(uref).max())
         assert 0 < it <= 400
+        assert extra["packed_equal"], "packed halo exchange (C ABI) differs from the torch-indexing exchange"
+        np.testing.assert_allclose(extra["u2"], uref[gnode], rtol=0, atol=1e-9 * np.abs(uref).max())   # overlapped iteration, same solution
+        assert 0 < extra["its2"] <= 400 and extra["prod_err"] < 1e-13
+        np.testing.assert_allclose(extra["pAp"][0], extra["pAp"][1], rtol=1e-12)
+        assert extra["breakdown_reported"]
         seen[gnode] += 1
     plane = (NEL[0] + 1) * (NEL[1] + 1)
     assert seen.min() == 1 and (seen == 2).sum() == plane

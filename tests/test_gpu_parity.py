@@ -607,6 +607,39 @@ def test_fused_mass_diffusion_pair_parity(tb, oracle, device):
                 assert rel_err(K.A.to_host(), refK) < TOL, (mname, kname, rep)
 
 
+def test_symmetric_accumulator_patch_kernel_parity(tb, oracle, device, monkeypatch):
+    """TB_PATCH_KERNEL=sym (tb_patch_sym.hip: one LDS add per coupling, mirrored write-out, sequential K / M passes on one accumulator block or,
+    TB_SYM_MODE=onepass, one pass over two blocks) == the oracle, on a box of several 7×7×7 tiles with ragged boundary tiles and on an unstructured
+    hexahedral mesh; then back to the default kernel on the same operators (the plan is rebuilt for its tiles)."""
+    meshes = [make_problem(tb, oracle, nel=(17, 15, 9), perturb=0.25)]
+    gl = tb.generate_ideal_lv_mesh_hex(8, 2, 6)
+    dhl = tb.DofHandler(gl)
+    meshes.append((gl, dhl, tb.allocate_matrix(dhl), oracle.Mesh(oracle.HEX8, 2, gl.xyz, gl.conn, dhl.cell_dofs)))
+    rng = np.random.default_rng(3)
+    for g, dh, sp, om in meshes:
+        rho_field = rng.uniform(0.5, 2.0, size=(g.n_cells, 8))
+        cases = {n_: (tc, oc) for n_, tc, oc in coef_cases(tb, oracle, g, rng)}
+        st = tb.PatchAssemblyStrategy(device)
+        for mode in ("seq", "onepass", None):
+            if mode is None:
+                monkeypatch.delenv("TB_PATCH_KERNEL", raising=False)
+            else:
+                monkeypatch.setenv("TB_PATCH_KERNEL", "sym")
+                monkeypatch.setenv("TB_SYM_MODE", mode)
+            for mt, mo in ((tb.ConstantCoefficient(1.7), oracle.Coef(oracle.COEF_CONST_SCALAR, [1.7])),
+                           (tb.FieldCoefficient(rho_field), oracle.Coef(oracle.COEF_FIELD_SCALAR, field=rho_field))):
+                refM = oracle.assemble_matrix(om, 0, mo, sp.rowptr, sp.colidx)
+                for kname in ("diag", "full", "fibre_field"):
+                    kt, ko = cases[kname]
+                    refK = oracle.assemble_matrix(om, 1, ko, sp.rowptr, sp.colidx)
+                    M = tb.setup_operator(st, tb.BilinearMassIntegrator(mt), dh, sp)
+                    K = tb.setup_operator(st, tb.BilinearDiffusionIntegrator(kt), dh, sp)
+                    tb.update_operators(M, K, 0.0)
+                    assert rel_err(M.A.to_host(), refM) < TOL and rel_err(K.A.to_host(), refK) < TOL, (mode, kname, "pair")
+                    assert rel_err(tb.update_operator(K, 0.0).A.to_host(), refK) < TOL, (mode, kname, "K alone")
+                    assert rel_err(tb.update_operator(M, 0.0).A.to_host(), refM) < TOL, (mode, kname, "M alone")
+
+
 def test_reaction_full_size_roundtrip(tb, oracle, device):
     """10M-point PCG2019 (BASELINE config 3 size): identical points evolve identically; a sample matches the oracle."""
     n = 10218313

@@ -49,10 +49,12 @@ class MI355XDevice:
         check(lib().tb_device_create(device_id, C.byref(h)))
         self.h = h
         self.device_id = device_id
+        self.stream_handle = None     # None: the private non-blocking stream tb_device_create made; else the handle given to set_stream
 
     def set_stream(self, hip_stream):
         """hip_stream: a hipStream_t handle (int); 0 = the legacy default stream (what torch.cuda.current_stream().cuda_stream is in a
         fresh process: the device's kernels are then ordered with torch's own work and its collectives); None = a private non-blocking stream."""
+        self.stream_handle = None if hip_stream is None else int(hip_stream)
         if hip_stream is None:
             check(lib().tb_device_set_stream(self.h, None))
         elif int(hip_stream) == 0:
@@ -1615,7 +1617,7 @@ class NewtonRaphsonSolver:
     solution of J Δu = residual in Δu (device vectors; the CSR structure is `pattern.sp.rowptr/colidx` on the host, J its values on the device)."""
 
     def __init__(self, max_iter=100, tol=1e-4, inner_rtol=1e-8, inner_atol=1e-14, inner_maxiter=5000, enforce_monotonic_convergence=True,
-                 inner_solver="cg", gmres_restart=50, inner_precond=None, simplified_newton=False, forcing=None):
+                 inner_solver="cg", gmres_restart=50, inner_precond=None, simplified_newton=False, forcing=None, strict_inner_solve=True):
         if inner_solver not in ("cg", "gmres") and not callable(inner_solver):
             raise ValueError("inner_solver: 'cg', 'gmres' or a callable (pattern, J, residual, Δu) -> linear iterations")
         self.inner_solver, self.gmres_restart = inner_solver, gmres_restart
@@ -1628,6 +1630,11 @@ class NewtonRaphsonSolver:
         self.enforce_monotonic_convergence = enforce_monotonic_convergence
         self.iter, self.theta, self.residual_norms, self.linear_iters = -1, [], [], []
         self.linear_failure = None
+        # strict_inner_solve (default, the reference's behaviour — `solve_succeeded || return false`, newton_raphson.jl:266-269): an inner Krylov
+        # solve that stops above its tolerance fails the nonlinear solve.  False: the increment is applied as an inexact Newton step and the
+        # event is recorded in `linear_failure` (restarted GMRES on an indefinite tangent may stagnate above a tight tolerance while the outer
+        # iteration still contracts); callers opt out explicitly
+        self.strict_inner_solve = bool(strict_inner_solve)
 
 
 def nlsolve(u, op, ch, solver, t=0.0):
@@ -1667,11 +1674,10 @@ def nlsolve(u, op, ch, solver, t=0.0):
             else:
                 its, lres = cg_solve(op.pattern, op.J, res, du, inner_rtol, solver.inner_atol, solver.inner_maxiter, True)
             if not callable(solver.inner_solver) and not solve_converged(op.pattern, lres):
-                # newton_raphson.jl: `solve_succeeded || return false` — an inner solve that ran into its iteration limit fails the step when the
-                # solver is strict about it; otherwise the increment is used as an inexact Newton step (restarted GMRES on an indefinite tangent
-                # may stagnate above a tight tolerance and the outer iteration still contracts) and the event is recorded
+                # newton_raphson.jl:266-269 `solve_succeeded || return false`: an inner solve that ran into its iteration limit fails the step
+                # unless the solver was built with strict_inner_solve=False (inexact Newton step, event recorded)
                 solver.linear_failure = "inner linear solve stopped at %d iterations with residual %.3e above its tolerance" % (its, lres)
-                if getattr(solver, "strict_inner_solve", False):
+                if solver.strict_inner_solve:
                     solver.linear_iters.append(its)
                     solver.theta.append(np.inf)
                     return False

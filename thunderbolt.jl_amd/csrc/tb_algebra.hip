@@ -1149,6 +1149,8 @@ k_cgd_update(int64_t n, const double *__restrict__ w, const double *__restrict__
 {
     const double pap = *pAp;
     const double alpha = pap > 0.0 ? *rz / pap : 0.0;
+    // pᵀAp ≤ 0 while r·z ≠ 0: the operator is not positive definite (or the iteration broke down) — sticky flag in out[2], read by the host with ‖r‖²
+    if (!(pap > 0.0) && *rz != 0.0 && blockIdx.x == 0 && threadIdx.x == 0) out[2] = pap == 0.0 ? -1e-300 : pap;
     double a = 0.0, c = 0.0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -1190,6 +1192,75 @@ int launch_cgd_update(tb_device *dev, int64_t n, const double *w, const double *
 int launch_cgd_direction(tb_device *dev, int64_t n, const double *dinv, const double *r, double *p, const double *d_rz, const double *d_rz_new)
 {
     if (n > 0) hipLaunchKernelGGL(k_cgd_direction, dim3(grid_for(dev, n, 256)), dim3(256), 0, dev->stream, n, dinv, r, p, d_rz, d_rz_new);
+    TB_HIP(hipGetLastError());
+    return TB_OK;
+}
+
+// ---- halo pack / unpack and the packed interface rows of a product (multi-GPU path) ----
+__global__ void __launch_bounds__(256) k_gather_indexed(int64_t n, const double *__restrict__ vec, const int32_t *__restrict__ idx, double *__restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = vec[idx[i]];
+}
+
+__global__ void __launch_bounds__(256) k_scatter_add_indexed(int64_t n, const double *__restrict__ in, const int32_t *__restrict__ idx, double *__restrict__ vec)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) vec[idx[i]] += in[i]; // indices of one call are distinct
+}
+
+// out[k] = Σ_j A[rows[k], j] x[j]: 16 lanes per listed row
+__global__ void __launch_bounds__(256)
+k_spmv_rows(int64_t n, const int32_t *__restrict__ rows, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const double *__restrict__ nz,
+            const double *__restrict__ x, double *__restrict__ out)
+{
+    constexpr int LN = 16;
+    const int sub = threadIdx.x % LN;
+    const int64_t nsub = ((int64_t)gridDim.x * blockDim.x) / LN;
+    for (int64_t k = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LN; k < n; k += nsub) {
+        const int32_t r = rows[k];
+        double v = 0.0;
+        for (int64_t e = rowptr[r] + sub; e < rowptr[r + 1]; e += LN) v += nz[e] * x[colidx[e]];
+#pragma unroll
+        for (int o = LN / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, LN);
+        if (sub == 0) out[k] = v;
+    }
+}
+
+int launch_gather_indexed(tb_device *dev, int64_t n, const double *vec, const int32_t *idx, double *out)
+{
+    if (n > 0) hipLaunchKernelGGL(k_gather_indexed, dim3(grid_for(dev, n, 256)), dim3(256), 0, dev->stream, n, vec, idx, out);
+    TB_HIP(hipGetLastError());
+    return TB_OK;
+}
+int launch_scatter_add_indexed(tb_device *dev, int64_t n, const double *in, const int32_t *idx, double *vec)
+{
+    if (n > 0) hipLaunchKernelGGL(k_scatter_add_indexed, dim3(grid_for(dev, n, 256)), dim3(256), 0, dev->stream, n, in, idx, vec);
+    TB_HIP(hipGetLastError());
+    return TB_OK;
+}
+int launch_spmv_rows(tb_pattern *p, const double *nz, const double *x, int64_t n, const int32_t *rows, double *out)
+{
+    tb_device *dev = p->mesh->dev;
+    if (n > 0) hipLaunchKernelGGL(k_spmv_rows, dim3(grid_for(dev, n * 16, 256)), dim3(256), 0, dev->stream, n, rows, p->d_rowptr, p->d_colidx, nz, x, out);
+    TB_HIP(hipGetLastError());
+    return TB_OK;
+}
+// y = A x and *d_dot += xᵀ y with the kernels of the single-device CG (block / stream / lanes-per-row forms)
+int launch_spmv_dot(tb_pattern *pat, const double *A, const double *x, double *y, double *d_dot)
+{
+    tb_device *dev = pat->mesh->dev;
+    const int64_t n = pat->n_rows;
+    if (n == 0) return TB_OK;
+    static const int lanes_env = getenv("TB_SPMV_LANES") ? atoi(getenv("TB_SPMV_LANES")) : 0;
+    if (lanes_env == 0) { int rc = block3_plan(pat); if (rc) return rc; if (pat->b3 <= 0) { rc = stream_plan(pat); if (rc) return rc; } }
+    if (lanes_env == 0 && pat->b3 > 0)
+        launch_b3<true>(pat, A, x, 1.0, 0.0, y, d_dot);
+    else if (lanes_env == 0 && pat->n_blk > 0)
+        hipLaunchKernelGGL((k_spmv_stream<SPMV_CAP, true>), dim3(stream_grid(pat)), dim3(256), 0, dev->stream, (int)pat->n_blk, pat->d_blkrow, pat->d_rowptr,
+                           pat->d_colidx, A, x, 1.0, 0.0, y, d_dot);
+    else
+        hipLaunchKernelGGL(k_spmv_dot<16>, dim3(grid_for(dev, n * 16, 256)), dim3(256), 0, dev->stream, n, pat->d_rowptr, pat->d_colidx, A, x, y, d_dot);
     TB_HIP(hipGetLastError());
     return TB_OK;
 }

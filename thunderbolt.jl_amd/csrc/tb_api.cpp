@@ -1058,6 +1058,34 @@ int tb_cgd_direction(tb_device *dev, int64_t n, const double *d_dinv, const doub
     return launch_cgd_direction(dev, n, d_dinv, d_r, d_p, d_rz, d_rz_new);
 }
 
+int tb_gather_indexed(tb_device *dev, int64_t n, const double *d_vec, const int32_t *d_idx, double *d_out)
+{
+    TB_REQUIRE(dev && n >= 0 && ((d_vec && d_idx && d_out) || n == 0), "tb_gather_indexed: bad argument");
+    TB_HIP(hipSetDevice(dev->id));
+    return launch_gather_indexed(dev, n, d_vec, d_idx, d_out);
+}
+
+int tb_scatter_add_indexed(tb_device *dev, int64_t n, const double *d_in, const int32_t *d_idx, double *d_vec)
+{
+    TB_REQUIRE(dev && n >= 0 && ((d_vec && d_idx && d_in) || n == 0), "tb_scatter_add_indexed: bad argument");
+    TB_HIP(hipSetDevice(dev->id));
+    return launch_scatter_add_indexed(dev, n, d_in, d_idx, d_vec);
+}
+
+int tb_spmv_csr_rows(tb_pattern *pat, const double *d_nzval, const double *d_x, int64_t n_rows, const int32_t *d_rows, double *d_out)
+{
+    TB_REQUIRE(pat && n_rows >= 0 && ((d_nzval && d_x && d_rows && d_out) || n_rows == 0), "tb_spmv_csr_rows: bad argument");
+    TB_HIP(hipSetDevice(pat->mesh->dev->id));
+    return launch_spmv_rows(pat, d_nzval, d_x, n_rows, d_rows, d_out);
+}
+
+int tb_spmv_csr_dot(tb_pattern *pat, const double *d_nzval, const double *d_x, double *d_y, double *d_dot)
+{
+    TB_REQUIRE(pat && d_nzval && d_x && d_y && d_dot, "tb_spmv_csr_dot: NULL argument");
+    TB_HIP(hipSetDevice(pat->mesh->dev->id));
+    return launch_spmv_dot(pat, d_nzval, d_x, d_y, d_dot);
+}
+
 int tb_apply_zero_csr(tb_pattern *pat, double *d_nzval, double *d_f, const uint8_t *d_prescribed, double diag)
 {
     TB_REQUIRE(pat && d_prescribed && (d_nzval || d_f), "tb_apply_zero_csr: NULL argument");

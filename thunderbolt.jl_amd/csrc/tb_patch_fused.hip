@@ -371,23 +371,41 @@ bool hex8_patch_applicable(const tb_form *f, const tb_pattern *p)
 
 int tabulate_diffusion_field(tb_form *f); // tb_assembly.hip
 
+// G_q = −¼/detJ·A·D_q·Aᵀ and detJ_q of every cell for a diffusion form with a field tensor, built once per form (mesh and field are fixed)
+int tabulate_g_hex8(tb_form *fK)
+{
+    tb_mesh *m = fK->mesh;
+    tb_device *dev = m->dev;
+    int rc;
+    if (!fK->d_dtab) { rc = tabulate_diffusion_field(fK); if (rc) return rc; }
+    if (fK->d_gtab) return TB_OK;
+    const size_t bytes = sizeof(double) * 56 * (size_t)m->n_cells;
+    hipError_t e = hipMalloc((void **)&fK->d_gtab, bytes);
+    if (e != hipSuccess) { set_error("G table of the hexahedron patch kernel (%zu B): %s", bytes, hipGetErrorString(e)); return TB_ERR_NOMEM; }
+    hipLaunchKernelGGL(k_tabulate_g_hex8, dim3((unsigned)((m->n_cells + 255) / 256)), dim3(256), 0, dev->stream, make_view(m), fK->d_dtab, fK->d_gtab, dev->d_status);
+    TB_HIP(hipGetLastError());
+    rc = check_status(dev);
+    if (rc) { (void)hipFree(fK->d_gtab); fK->d_gtab = nullptr; return rc; }
+    return TB_OK;
+}
+
 int launch_assemble_hex8_patch(tb_form *fK, tb_form *fM, tb_pattern *p, double t, double *d_nzK, double *d_nzM)
 {
     tb_form *any = fK ? fK : fM;
     tb_mesh *m = any->mesh;
     tb_device *dev = m->dev;
+    // TB_PATCH_KERNEL=sym selects the symmetric-accumulator kernel (tb_patch_sym.hip: one LDS add per coupling, mirrored write-out, 7×7×7 tiles) — a
+    // measured alternative that is parity-green but slower than this file's kernel on MI355X; it falls back here when its plan cannot be built
+    {
+        const char *kn = getenv("TB_PATCH_KERNEL");
+        if (kn && !strcmp(kn, "sym")) {
+            const int rs = launch_assemble_hex8_sym(fK, fM, p, t, d_nzK, d_nzM);
+            if (rs != TB_ERR_UNSUPPORTED) return rs;
+        }
+    }
     int rc = reset_status(dev);
     if (rc) return rc;
-    if (fK && fK->field && !fK->d_dtab) { rc = tabulate_diffusion_field(fK); if (rc) return rc; }
-    if (fK && fK->field && !fK->d_gtab) {
-        const size_t bytes = sizeof(double) * 56 * (size_t)m->n_cells;
-        hipError_t e = hipMalloc((void **)&fK->d_gtab, bytes);
-        if (e != hipSuccess) { set_error("G table of the hexahedron patch kernel (%zu B): %s", bytes, hipGetErrorString(e)); return TB_ERR_NOMEM; }
-        hipLaunchKernelGGL(k_tabulate_g_hex8, dim3((unsigned)((m->n_cells + 255) / 256)), dim3(256), 0, dev->stream, make_view(m), fK->d_dtab, fK->d_gtab, dev->d_status);
-        TB_HIP(hipGetLastError());
-        rc = check_status(dev);
-        if (rc) { (void)hipFree(fK->d_gtab); fK->d_gtab = nullptr; return rc; }
-    }
+    if (fK && fK->field) { rc = tabulate_g_hex8(fK); if (rc) return rc; }
     const int nreg = fK && fM ? 2 : 1;
     rc = ensure_patch_fused(m, p, nreg);
     if (rc) return rc;

@@ -447,6 +447,7 @@ void free_patch_fused_plan(tb_pattern *p)
     if (!p->patch_fused) return;
     PatchFusedPlan *f = p->patch_fused.get();
     hipFree(f->d_node_ptr); hipFree(f->d_pnode); hipFree(f->d_elem_ln); hipFree(f->d_elem_sig); hipFree(f->d_sigtab); hipFree(f->d_row_desc); hipFree(f->d_hdr); hipFree(f->d_pcoord);
+    hipFree(f->d_elem_ssig); hipFree(f->d_ssigtab); hipFree(f->d_row_sdesc); hipFree(f->d_mirtab);
     p->patch_fused.reset();
 }
 
@@ -457,9 +458,54 @@ static inline uint64_t mix64(uint64_t h, uint64_t v)
     return h ^ (h >> 33);
 }
 
+// De-duplication of fixed- or variable-length byte records by content: open addressing on a 64-bit hash, bytes compared on a hit.
+struct RecordTable {
+    std::vector<int64_t> slot;   // −1 or the offset of the record in `bytes`
+    std::vector<uint64_t> hkey;
+    std::vector<uint8_t> bytes;  // records back to back, each padded to `stride` (fixed) or stored as [len][payload] (variable)
+    int64_t count = 0;
+    RecordTable() { slot.assign(1 << 12, -1); hkey.assign(1 << 12, 0); }
+    static uint64_t hash(const uint8_t *b, size_t n)
+    {
+        uint64_t h = 0x243f6a8885a308d3ull ^ n;
+        size_t k = 0;
+        for (; k + 8 <= n; k += 8) { uint64_t v; memcpy(&v, b + k, 8); h = mix64(h, v); }
+        uint64_t v = 0;
+        if (k < n) { memcpy(&v, b + k, n - k); h = mix64(h, v); }
+        return h;
+    }
+    void grow()
+    {
+        std::vector<int64_t> os(slot.size() * 2, -1);
+        std::vector<uint64_t> ok(slot.size() * 2, 0);
+        const size_t mask = os.size() - 1;
+        for (size_t i = 0; i < slot.size(); ++i)
+            if (slot[i] >= 0) { size_t j = hkey[i] & mask; while (os[j] >= 0) j = (j + 1) & mask; os[j] = slot[i]; ok[j] = hkey[i]; }
+        slot.swap(os); hkey.swap(ok);
+    }
+    // returns the byte offset of the (possibly new) record; `stored` bytes are appended for a new one (≥ n: padding included by the caller)
+    int64_t insert(const uint8_t *b, size_t n, size_t stored)
+    {
+        if ((size_t)count * 2 >= slot.size()) grow();
+        const uint64_t h = hash(b, n);
+        const size_t mask = slot.size() - 1;
+        size_t j = h & mask;
+        while (slot[j] >= 0) {
+            if (hkey[j] == h && (size_t)slot[j] + n <= bytes.size() && memcmp(&bytes[slot[j]], b, n) == 0) return slot[j];
+            j = (j + 1) & mask;
+        }
+        const int64_t at = (int64_t)bytes.size();
+        bytes.insert(bytes.end(), b, b + n);
+        bytes.resize(at + stored, 0);
+        slot[j] = at; hkey[j] = h; ++count;
+        return at;
+    }
+};
+
 // Fused-kernel extension of the patch plan (see PatchFusedPlan).  Needs a scalar first-order field whose local dof a sits on
 // local vertex a (Ferrite: vertex dofs in vertex order), i.e. a one-to-one node ↔ dof relation; rows of at most 255 entries.
-static int build_patch_fused_plan(tb_pattern *p, int64_t *lds_need, int nregions)
+// sym: additionally the symmetric-storage arrays of tb_patch_sym.hip; the LDS need is then counted in symmetric entries.
+static int build_patch_fused_plan_impl(tb_pattern *p, int64_t *lds_need, int nregions, bool sym, std::unique_ptr<PatchFusedPlan> &plan)
 {
     tb_mesh *m = p->mesh;
     const PatchPlan *pp = m->patches.get();
@@ -467,8 +513,8 @@ static int build_patch_fused_plan(tb_pattern *p, int64_t *lds_need, int nregions
     const bool hex = ndpc == 8 && m->nverts == 8, tet = ndpc == 4 && m->nverts == 4;
     if (!(hex || tet) || m->ncomp != 1) { set_error("fused patch plan: needs a scalar first-order field on hexahedra or tetrahedra"); return TB_ERR_UNSUPPORTED; }
     const int NV = ndpc, NS = NV * NV; // nodes per cell, bytes per position signature
-    auto plan = std::make_unique<PatchFusedPlan>();
     plan->version = pp->version;
+    plan->sym = sym;
     // 1. row descriptors and the LDS need
     std::vector<RowDesc> row_desc(pp->total_rows);
     int64_t maxlen = 0, max_entries = 0;
@@ -525,8 +571,38 @@ static int build_patch_fused_plan(tb_pattern *p, int64_t *lds_need, int nregions
     }
     if (bad) { set_error("fused patch plan: dofs and vertices of the field are not in one-to-one correspondence"); return TB_ERR_UNSUPPORTED; }
     plan->max_nodes = max_nodes;
-    *lds_need = (int64_t)nregions * plan->max_lds_entries * 8 + (int64_t)pp->max_rows * 16 + (int64_t)max_nodes * 24; // coordinates of the patch's nodes in LDS (persistent kernel)
-    if (*lds_need > 80 * 1024) { p->patch_fused = std::move(plan); return TB_ERR_UNSUPPORTED; } // caller shrinks the tile and retries
+    // symmetric storage: which patch owns a dof and in which row slot; a row's run keeps column c unless c is an owned row of smaller slot
+    std::vector<int32_t> own_patch, own_slot;
+    std::vector<uint32_t> sym_off; // per owned row: LDS offset of its run
+    if (sym) {
+        own_patch.assign(m->ndofs, -1); own_slot.assign(m->ndofs, -1);
+        for (int64_t q = 0; q < pp->n_patches; ++q)
+            for (int64_t r = pp->h_row_ptr[q]; r < pp->h_row_ptr[q + 1]; ++r) { own_patch[pp->h_row_dof[r]] = (int32_t)q; own_slot[pp->h_row_dof[r]] = (int32_t)(r - pp->h_row_ptr[q]); }
+        sym_off.assign(pp->total_rows, 0);
+        int64_t max_sym = 0;
+        bool too_long = false;
+#pragma omp parallel for schedule(dynamic, 64) reduction(max : max_sym) reduction(|| : too_long)
+        for (int64_t q = 0; q < pp->n_patches; ++q) {
+            uint32_t off = 0;
+            for (int64_t r = pp->h_row_ptr[q]; r < pp->h_row_ptr[q + 1]; ++r) {
+                const int32_t d = pp->h_row_dof[r], s_ = (int32_t)(r - pp->h_row_ptr[q]);
+                int cnt = 0;
+                for (int64_t k = p->h_rowptr[d]; k < p->h_rowptr[d + 1]; ++k) {
+                    const int32_t c = p->h_colidx[k];
+                    cnt += !(own_patch[c] == q && own_slot[c] < s_);
+                }
+                if (cnt > 127) too_long = true;
+                sym_off[r] = off;
+                off += (uint32_t)(cnt | 1); // odd run lengths: consecutive rows start on different banks (stride-14 runs collide two-way)
+            }
+            max_sym = std::max<int64_t>(max_sym, (int64_t)off);
+        }
+        if (too_long) { set_error("symmetric patch plan: a row keeps more than 127 entries"); return TB_ERR_UNSUPPORTED; }
+        plan->max_sym_entries = (int)((max_sym + 1) & ~(int64_t)1);
+    }
+    const int64_t acc_entries = sym ? plan->max_sym_entries : plan->max_lds_entries;
+    *lds_need = (int64_t)nregions * acc_entries * 8 + (int64_t)pp->max_rows * 16 + (int64_t)max_nodes * 24; // + coordinates of the patch's nodes
+    if (*lds_need > 80 * 1024 || acc_entries >= 0x7fff) { plan->d_row_desc = nullptr; return TB_ERR_NOMEM; } // caller shrinks the tile and retries (TB_ERR_NOMEM is this function's private "too big")
     // 3. signatures: position of column dof(j) inside row dof(i) for every pair of a cell, de-duplicated
     const int64_t nc = m->n_cells;
     std::vector<uint8_t> sig((size_t)nc * NS);
@@ -577,6 +653,118 @@ static int build_patch_fused_plan(tb_pattern *p, int64_t *lds_need, int nregions
 #pragma omp parallel for schedule(static)
     for (int64_t e = 0; e < pp->total_elems; ++e) elem_sig[e] = cell_sig[pp->h_elem_cell[e]];
     int rc;
+    if (sym) {
+        // Pair signatures (per instance) and mirror maps (per row), computed patch by patch in parallel chunks and de-duplicated in sequence.
+        //   pair (i ≤ j) of an instance → the row of smaller slot among the owned ones (the kernel takes the same decision from the patch-local
+        //   node indices: owned nodes carry their slot, others a larger number) and the rank of the column inside that row's run;
+        //   CSR entry k of row s (column c) → its LDS entry relative to the run of s: the own rank, or, when c is an owned row t < s,
+        //   run(t) + rank_t(dof of s) − run(s).
+        const int NP = NV * (NV + 1) / 2, SSTRIDE = NV == 8 ? 48 : 16;
+        std::vector<uint32_t> elem_ssig(pp->total_elems);
+        std::vector<uint32_t> sdesc((size_t)pp->total_rows * 4);
+        RecordTable sigs, mirs;
+        const int64_t CH = 2048;
+        std::vector<std::vector<uint8_t>> psig(CH);
+        std::vector<std::vector<int16_t>> pmir(CH);
+        bool overflow = false;
+        for (int64_t q0 = 0; q0 < pp->n_patches; q0 += CH) {
+            const int64_t q1 = std::min(q0 + CH, pp->n_patches);
+#pragma omp parallel for schedule(dynamic, 8) reduction(|| : overflow)
+            for (int64_t q = q0; q < q1; ++q) {
+                const int64_t r0 = pp->h_row_ptr[q], nrows = pp->h_row_ptr[q + 1] - r0;
+                // rank of every CSR entry inside its row's run (0xFF: not kept)
+                std::vector<int64_t> rstart(nrows + 1, 0);
+                for (int64_t s_ = 0; s_ < nrows; ++s_) { const int32_t d = pp->h_row_dof[r0 + s_]; rstart[s_ + 1] = rstart[s_] + (p->h_rowptr[d + 1] - p->h_rowptr[d]); }
+                std::vector<uint8_t> rank(rstart[nrows]);
+                for (int64_t s_ = 0; s_ < nrows; ++s_) {
+                    const int32_t d = pp->h_row_dof[r0 + s_];
+                    int cnt = 0;
+                    for (int64_t k = p->h_rowptr[d]; k < p->h_rowptr[d + 1]; ++k) {
+                        const int32_t c = p->h_colidx[k];
+                        const bool kept = !(own_patch[c] == q && own_slot[c] < s_);
+                        rank[rstart[s_] + (k - p->h_rowptr[d])] = kept ? (uint8_t)cnt : (uint8_t)0xFF;
+                        cnt += kept;
+                    }
+                }
+                auto pos_in_row = [&](int32_t row, int32_t col) -> int64_t {
+                    const int32_t *b = &p->h_colidx[p->h_rowptr[row]], *en = &p->h_colidx[p->h_rowptr[row + 1]];
+                    return std::lower_bound(b, en, col) - b;
+                };
+                // mirror maps
+                std::vector<int16_t> &mir = pmir[q - q0];
+                mir.assign(rstart[nrows], 0);
+                for (int64_t s_ = 0; s_ < nrows; ++s_) {
+                    const int32_t d = pp->h_row_dof[r0 + s_];
+                    for (int64_t k = p->h_rowptr[d]; k < p->h_rowptr[d + 1]; ++k) {
+                        const int32_t c = p->h_colidx[k];
+                        const int64_t at = rstart[s_] + (k - p->h_rowptr[d]);
+                        int64_t delta;
+                        if (rank[at] != 0xFF) delta = rank[at];
+                        else {
+                            const int32_t t = own_slot[c];
+                            const uint8_t rk = rank[rstart[t] + pos_in_row(c, d)]; // symmetric pattern: d is a column of row c, kept there (t < s)
+                            if (rk == 0xFF) overflow = true;
+                            delta = (int64_t)sym_off[r0 + t] + rk - (int64_t)sym_off[r0 + s_];
+                        }
+                        if (delta < -32768 || delta > 32767) overflow = true;
+                        mir[at] = (int16_t)delta;
+                    }
+                }
+                // pair signatures
+                const int64_t e0 = pp->h_elem_ptr[q], ne = pp->h_elem_ptr[q + 1] - e0;
+                std::vector<uint8_t> &sg = psig[q - q0];
+                sg.assign((size_t)ne * NP, 0xFF);
+                for (int64_t e = 0; e < ne; ++e) {
+                    const int32_t c = pp->h_elem_cell[e0 + e];
+                    const int32_t *d = &m->h_cell_dofs[(int64_t)c * NV];
+                    const uint8_t *cs = &sig[(size_t)c * NS];
+                    int32_t slot[8];
+                    for (int a = 0; a < NV; ++a) slot[a] = own_patch[d[a]] == q ? own_slot[d[a]] : 0x7fffffff;
+                    int pr = 0;
+                    for (int i = 0; i < NV; ++i)
+                        for (int j = i; j < NV; ++j, ++pr) {
+                            const int t = slot[i] <= slot[j] ? i : j, o = t == i ? j : i;
+                            if (slot[t] == 0x7fffffff) continue;
+                            sg[(size_t)e * NP + pr] = rank[rstart[slot[t]] + cs[t * NV + o]];
+                            if (sg[(size_t)e * NP + pr] == 0xFF) overflow = true;
+                        }
+                }
+            }
+            if (overflow) break;
+            for (int64_t q = q0; q < q1; ++q) {
+                const int64_t e0 = pp->h_elem_ptr[q], ne = pp->h_elem_ptr[q + 1] - e0;
+                const std::vector<uint8_t> &sg = psig[q - q0];
+                for (int64_t e = 0; e < ne; ++e) elem_ssig[e0 + e] = (uint32_t)(sigs.insert(&sg[(size_t)e * NP], NP, SSTRIDE) / SSTRIDE);
+                const int64_t r0 = pp->h_row_ptr[q], nrows = pp->h_row_ptr[q + 1] - r0;
+                const std::vector<int16_t> &mir = pmir[q - q0];
+                int64_t at = 0;
+                for (int64_t s_ = 0; s_ < nrows; ++s_) {
+                    const int32_t d = pp->h_row_dof[r0 + s_];
+                    const int64_t len = p->h_rowptr[d + 1] - p->h_rowptr[d];
+                    const int64_t moff = mirs.insert((const uint8_t *)&mir[at], (size_t)len * 2, (size_t)len * 2) / 2;
+                    at += len;
+                    const uint64_t nz0 = (uint64_t)p->h_rowptr[d];
+                    if (nz0 >> 40 || moff >> 32) overflow = true;
+                    uint32_t *o = &sdesc[(size_t)(r0 + s_) * 4];
+                    o[0] = (uint32_t)nz0; o[1] = (uint32_t)(nz0 >> 32) | (uint32_t)len << 8; o[2] = sym_off[r0 + s_]; o[3] = (uint32_t)moff;
+                }
+            }
+        }
+        if (overflow) { set_error("symmetric patch plan: an offset does not fit its field"); return TB_ERR_UNSUPPORTED; }
+        plan->nssig = (int64_t)sigs.bytes.size() / SSTRIDE;
+        plan->nmir = (int64_t)mirs.bytes.size() / 2;
+        sigs.bytes.resize(sigs.bytes.size() + 64, 0xFF);  // the kernels fetch whole 16-byte pieces: slack behind the last record
+        mirs.bytes.resize(mirs.bytes.size() + 128, 0);
+        std::vector<int16_t> mirtab(mirs.bytes.size() / 2);
+        memcpy(mirtab.data(), mirs.bytes.data(), mirtab.size() * 2);
+        if (getenv("TB_PLAN_VERBOSE"))
+            fprintf(stderr, "[tbhip] symmetric storage: %d LDS entries per block (full rows: %d), %lld pair signatures, %lld mirror-map entries for %lld non-zeros\n",
+                    plan->max_sym_entries, plan->max_lds_entries, (long long)plan->nssig, (long long)plan->nmir, (long long)p->nnz);
+        if ((rc = upload(m->dev, elem_ssig, &plan->d_elem_ssig))) return rc;
+        if ((rc = upload(m->dev, sigs.bytes, &plan->d_ssigtab))) return rc;
+        if ((rc = upload(m->dev, sdesc, &plan->d_row_sdesc))) return rc;
+        if ((rc = upload(m->dev, mirtab, &plan->d_mirtab))) return rc;
+    }
     if ((rc = upload(m->dev, node_ptr, &plan->d_node_ptr))) return rc;
     if ((rc = upload(m->dev, pnode, &plan->d_pnode))) return rc;
     if ((rc = upload(m->dev, ln, &plan->d_elem_ln))) return rc;
@@ -584,7 +772,7 @@ static int build_patch_fused_plan(tb_pattern *p, int64_t *lds_need, int nregions
     if ((rc = upload(m->dev, sigtab, &plan->d_sigtab))) return rc;
     if ((rc = upload(m->dev, row_desc, &plan->d_row_desc))) return rc;
     if (pp->max_rows < 1024 && max_nodes < 2048 && pp->max_elems < 2048 && pp->total_elems < (int64_t)0x7fffffff && (int64_t)pnode.size() < (int64_t)0x7fffffff) {
-        // inputs of the persistent kernel: packed headers, pre-gathered coordinates
+        // inputs of the staged kernels: packed headers, pre-gathered coordinates
         std::vector<uint32_t> hdr((size_t)pp->n_patches * 4);
         for (int64_t q = 0; q < pp->n_patches; ++q) {
             hdr[4 * q] = (uint32_t)pp->h_elem_ptr[q]; hdr[4 * q + 1] = (uint32_t)pp->h_row_ptr[q]; hdr[4 * q + 2] = (uint32_t)node_ptr[q];
@@ -599,22 +787,37 @@ static int build_patch_fused_plan(tb_pattern *p, int64_t *lds_need, int nregions
         if ((rc = upload(m->dev, hdr, &plan->d_hdr))) return rc;
         if ((rc = upload(m->dev, pcoord, &plan->d_pcoord))) return rc;
     }
+    return TB_OK;
+}
+
+// The plan object is handed to the pattern on every path, so that a failed upload half way leaves nothing behind: the caller's
+// free_patch_fused_plan releases whatever was allocated.  TB_ERR_NOMEM from the builder means "does not fit the LDS budget" (size-only plan).
+static int build_patch_fused_plan(tb_pattern *p, int64_t *lds_need, int nregions, bool sym)
+{
+    auto plan = std::make_unique<PatchFusedPlan>();
+    int rc = build_patch_fused_plan_impl(p, lds_need, nregions, sym, plan);
     p->patch_fused = std::move(plan);
+    if (rc == TB_ERR_NOMEM) return TB_ERR_UNSUPPORTED; // too big: the caller recognises it by the plan left behind without device arrays
+    if (rc != TB_OK) { free_patch_fused_plan(p); return rc; }
     return TB_OK;
 }
 
 // Build (or refit) the mesh's patch plan and the pattern's fused extension so that `nregions` blocks of row accumulators, the
 // row descriptors and the node list of any patch fit 80 KiB of LDS — two workgroups per CU.
-int ensure_patch_fused(tb_mesh *m, tb_pattern *p, int nregions)
+int ensure_patch_fused(tb_mesh *m, tb_pattern *p, int nregions, bool sym)
 {
     if (!m->patches) { int rc = build_patch_plan(m, 0); if (rc) return rc; }
-    auto need = [&](const PatchFusedPlan *f) { return (int64_t)nregions * f->max_lds_entries * 8 + (int64_t)m->patches->max_rows * 16 + (int64_t)f->max_nodes * 24; };
-    if (p->patch_fused && p->patch_fused->version == m->patches->version && p->patch_fused->d_row_desc && need(p->patch_fused.get()) <= 80 * 1024) return TB_OK;
+    auto need = [&](const PatchFusedPlan *f) {
+        return (int64_t)nregions * (sym ? f->max_sym_entries : f->max_lds_entries) * 8 + (int64_t)m->patches->max_rows * 16 + (int64_t)f->max_nodes * 24;
+    };
+    if (p->patch_fused && p->patch_fused->version == m->patches->version && p->patch_fused->d_row_desc && (!sym || p->patch_fused->sym) &&
+        need(p->patch_fused.get()) <= 80 * 1024)
+        return TB_OK;
     const bool fixed = getenv("TB_PATCH_CELLS") || getenv("TB_PATCH_TILE");
     for (int attempt = 0; attempt < 16; ++attempt) {
         free_patch_fused_plan(p);
         int64_t bytes = 0;
-        int rc = build_patch_fused_plan(p, &bytes, nregions);
+        int rc = build_patch_fused_plan(p, &bytes, nregions, sym);
         if (rc == TB_OK) return TB_OK;
         const bool too_big = rc == TB_ERR_UNSUPPORTED && p->patch_fused; // the builder leaves the size-only plan behind in that case
         free_patch_fused_plan(p);

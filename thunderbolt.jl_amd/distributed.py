@@ -102,7 +102,10 @@ def _host_staged(vec, dist):
 def exchange_sum(vec, neighbours, dist):
     """Sum the entries of `vec` (torch tensor, any device) shared with each neighbour, in place: every rank sends its
     own *partial* values of the shared dofs to each sharing peer and adds what it receives, so a dof held by k ranks
-    ends up with the sum of all k partials on each of them.  neighbours = [(peer, index tensor)]."""
+    ends up with the sum of all k partials on each of them.  neighbours = [(peer, index tensor)].
+
+    Plain torch indexing with fresh buffers per call: the statement of the exchange that `HaloExchange` (persistent buffers, pack / unpack
+    through the C ABI) is checked against bit for bit, and the path of host tensors."""
     import torch
 
     staged = _host_staged(vec, dist)
@@ -123,6 +126,94 @@ def exchange_sum(vec, neighbours, dist):
     return vec
 
 
+class HaloExchange:
+    """The neighbour exchange of one sub-domain with persistent buffers, behind the C ABI: per neighbour an Int32 index list on the device, a
+    send and a receive buffer allocated once; pack = tb_gather_indexed (or tb_spmv_csr_rows: the interface rows of a product, computed straight
+    into the send buffer), unpack = tb_scatter_add_indexed.  `start()` posts the sends / receives and returns; `finish(vec)` waits and adds — what
+    is launched in between (the interior SpMV) overlaps the transfer.  Device tensors + an MI355XDevice use libtbhip; host tensors (the gloo
+    tests) use the equivalent torch calls on the same persistent buffers.  Under gloo with device tensors the buffers are staged through pinned
+    host memory (one-GPU test configuration)."""
+
+    def __init__(self, neighbours, dist, like, device=None):
+        import torch
+        self.torch, self.dist, self.dev = torch, dist, device
+        self.cuda = bool(like.is_cuda)
+        if self.cuda and device is None:
+            raise ValueError("HaloExchange: device tensors need the MI355XDevice whose stream orders the pack / unpack kernels")
+        self.staged = self.cuda and dist is not None and dist.is_initialized() and dist.get_backend() == "gloo"
+        self.peers, self.idx, self.idx32, self.send, self.recv, self.send_h, self.recv_h = [], [], [], [], [], [], []
+        for peer, idx in neighbours:
+            idx = torch.as_tensor(idx, dtype=torch.int64, device=like.device)
+            self.peers.append(int(peer))
+            self.idx.append(idx)
+            self.idx32.append(idx.to(torch.int32).contiguous())
+            self.send.append(torch.empty(idx.numel(), dtype=like.dtype, device=like.device))
+            self.recv.append(torch.empty(idx.numel(), dtype=like.dtype, device=like.device))
+            if self.staged:
+                self.send_h.append(torch.empty(idx.numel(), dtype=like.dtype).pin_memory())
+                self.recv_h.append(torch.empty(idx.numel(), dtype=like.dtype).pin_memory())
+        self.reqs = []
+
+    @property
+    def nbytes(self):
+        return sum(b.numel() * b.element_size() for b in self.send)
+
+    def _ptr(self, t):
+        import ctypes as C
+        return C.c_void_p(t.data_ptr())
+
+    def pack(self, vec):
+        """send buffers ← the partial values of the shared dofs"""
+        if self.cuda:
+            from ._lib import check, lib
+            for idx32, send in zip(self.idx32, self.send):
+                check(lib().tb_gather_indexed(self.dev.h, idx32.numel(), self._ptr(vec), self._ptr(idx32), self._ptr(send)))
+        else:
+            for idx, send in zip(self.idx, self.send):
+                self.torch.index_select(vec, 0, idx, out=send)
+
+    def pack_product_rows(self, pattern, nz, x):
+        """send buffers ← the interface rows of A·x (device path only): pattern / nz are the sub-domain CSR operator"""
+        from ._lib import check, lib
+        for idx32, send in zip(self.idx32, self.send):
+            check(lib().tb_spmv_csr_rows(pattern.h, nz.ptr, self._ptr(x), idx32.numel(), self._ptr(idx32), self._ptr(send)))
+
+    def start(self):
+        if not self.peers:
+            return
+        dist, ops = self.dist, []
+        if self.staged:
+            for s, sh in zip(self.send, self.send_h):
+                sh.copy_(s, non_blocking=True)
+            self.torch.cuda.current_stream().synchronize()
+        for k, peer in enumerate(self.peers):
+            ops.append(dist.P2POp(dist.isend, self.send_h[k] if self.staged else self.send[k], peer))
+            ops.append(dist.P2POp(dist.irecv, self.recv_h[k] if self.staged else self.recv[k], peer))
+        self.reqs = dist.batch_isend_irecv(ops)
+
+    def finish(self, vec):
+        """wait for the transfers, then vec[shared dofs] += received partials"""
+        for r in self.reqs:
+            r.wait()
+        self.reqs = []
+        if self.staged:
+            for r_, rh in zip(self.recv, self.recv_h):
+                r_.copy_(rh, non_blocking=True)
+        if self.cuda:
+            from ._lib import check, lib
+            for idx32, recv in zip(self.idx32, self.recv):
+                check(lib().tb_scatter_add_indexed(self.dev.h, idx32.numel(), self._ptr(recv), self._ptr(idx32), self._ptr(vec)))
+        else:
+            for idx, recv in zip(self.idx, self.recv):
+                vec.index_add_(0, idx, recv)
+        return vec
+
+    def exchange_sum(self, vec):
+        self.pack(vec)
+        self.start()
+        return self.finish(vec)
+
+
 def all_reduce_sum(t, dist):
     """Sum a (small) tensor over the ranks in place; device tensors go through the host under gloo."""
     if _host_staged(t, dist):
@@ -141,14 +232,17 @@ def node_to_dof(dh):
     return n2d
 
 
+def slab_neighbours(lower_idx, upper_idx, rank, world_size):
+    """[(peer, index tensor)] of a z-slab: the plane shared with rank − 1 and the one shared with rank + 1"""
+    return [(peer, idx) for idx, peer in ((lower_idx, rank - 1), (upper_idx, rank + 1)) if idx is not None and 0 <= peer < world_size]
+
+
 def halo_sum(vec, lower_idx, upper_idx, rank, world_size, dist):
     """Sum interface entries of `vec` (torch tensor, any device) with both neighbours, in place.
 
     After the call every rank holds the globally assembled value on its interface dofs.  Uses
     neighbour isend/irecv (RCCL over xGMI on GPU, gloo on CPU)."""
-    nb = [(peer, idx) for idx, peer in ((lower_idx, rank - 1), (upper_idx, rank + 1))
-          if idx is not None and 0 <= peer < world_size]
-    return exchange_sum(vec, nb, dist)
+    return exchange_sum(vec, slab_neighbours(lower_idx, upper_idx, rank, world_size), dist)
 
 
 class DistributedCG:
@@ -156,30 +250,42 @@ class DistributedCG:
 
     Vectors are torch tensors holding every dof of the part (owned + interface); solution-type vectors are kept
     *consistent* (all sharing ranks hold the same interface value), operator results are summed over the interface
-    with `exchange_sum`.  Dot products weight interface dofs by 1/multiplicity and are all-reduced.
+    by a `HaloExchange`.  Dot products weight interface dofs by 1/multiplicity and are all-reduced; pᵀAp is the sum over the ranks of the
+    local quadratic forms pᵀA_p p (p is consistent), so it needs no halo.
     `local_spmv(x) -> y` applies the rank's own A_p.  New work: the reference has no distributed solver (README.md:7).
 
-    Two execution paths with the same arithmetic:
-      * device=<MI355XDevice>, device tensors: the vector work runs in libtbhip (tb_cgd_dot / tb_cgd_update / tb_cgd_direction, local SpMV by
-        tb_spmv_csr through `local_spmv`), α and β are formed on the device from all-reduced device scalars, and the host reads one number
-        (‖r‖²) per look — every `look` iterations — like tb_cg_solve on one device;
-      * device=None: plain torch ops on whatever device the tensors live on (CPU in the gloo tests, where the oracle assembles)."""
+    Execution paths with the same arithmetic:
+      * device=<MI355XDevice>, device tensors: the vector work runs in libtbhip (tb_cgd_dot / tb_cgd_update / tb_cgd_direction), α and β are
+        formed on the device from all-reduced device scalars, and the host reads (‖r‖², breakdown flag) once per look — every `look`
+        iterations — like tb_cg_solve on one device.  With operator=(pattern, nz) the iteration is ordered for overlap: the interface rows of
+        A_p·p go straight into the send buffers (tb_spmv_csr_rows), the exchange is posted, the whole local product and its quadratic form
+        follow (tb_spmv_csr_dot) while the transfer is in flight, then the received partials are added (tb_scatter_add_indexed);
+        without it `local_spmv` is called and its result packed afterwards (no overlap).
+      * device=None: plain torch ops on whatever device the tensors live on (CPU in the gloo tests, where the oracle assembles).
 
-    def __init__(self, local_spmv, local_diag, lower_idx, upper_idx, rank, world_size, dist, neighbours=None, device=None, look=1):
+    The device's kernels and torch's work (all-reduces, the staging copies under gloo) must share one stream: the constructor puts the device
+    on torch's current stream and `solve` refuses to run if that has changed."""
+
+    def __init__(self, local_spmv, local_diag, lower_idx, upper_idx, rank, world_size, dist, neighbours=None, device=None, look=1, operator=None):
         import torch
         self.torch, self.dist = torch, dist
         self.spmv, self.rank, self.world = local_spmv, rank, world_size
-        self.dev, self.look = device, max(1, int(look))
+        self.dev, self.look, self.operator = device, max(1, int(look)), operator
+        if device is not None and local_diag.is_cuda:
+            cur = int(torch.cuda.current_stream().cuda_stream)
+            if device.stream_handle != cur:
+                device.set_stream(cur)
         # slab partitions pass (lower, upper); general partitions pass neighbours = [(peer, index tensor)]
-        self.nb = neighbours if neighbours is not None else [
-            (peer, idx) for idx, peer in ((lower_idx, rank - 1), (upper_idx, rank + 1)) if idx is not None and 0 <= peer < world_size]
+        self.nb = neighbours if neighbours is not None else slab_neighbours(lower_idx, upper_idx, rank, world_size)
+        self.halo = HaloExchange(self.nb, dist, local_diag, device if local_diag.is_cuda else None)
         d = local_diag.clone()
-        exchange_sum(d, self.nb, dist)                              # assembled diagonal
+        self.halo.exchange_sum(d)                                   # assembled diagonal
         self.dinv = 1.0 / d
         mult = torch.ones_like(d)
         for _, idx in self.nb:
             mult[idx] += 1.0
         self.w = 1.0 / mult                                         # a dof held by k ranks counts 1/k in every dot product
+        self.breakdown = None
 
     def dot(self, a, b):
         s = (self.w * a * b).sum().reshape(1)
@@ -189,7 +295,7 @@ class DistributedCG:
 
     def apply(self, x):
         y = self.spmv(x)
-        exchange_sum(y, self.nb, self.dist)
+        self.halo.exchange_sum(y)
         return y
 
     def solve(self, b, x, rtol=1e-5, atol=1e-6, maxiter=1000):
@@ -205,7 +311,11 @@ class DistributedCG:
         it = 0
         while rn > tol and it < maxiter:
             Ap = self.apply(p)
-            alpha = rz / self.dot(p, Ap)
+            pAp = self.dot(p, Ap)
+            if not pAp > 0.0:
+                self.breakdown = pAp
+                raise ArithmeticError("DistributedCG: pᵀAp = %g ≤ 0 at iteration %d — the operator is not positive definite" % (pAp, it))
+            alpha = rz / pAp
             x += alpha * p
             r -= alpha * Ap
             z = self.dinv * r
@@ -216,34 +326,59 @@ class DistributedCG:
             it += 1
         return x, it, rn
 
+    def device_iteration(self, p, Ap, S):
+        """One product of the device path: Ap ← assembled A·p, S[1] ← pᵀAp (summed over the ranks).  S: device scalars rz | pAp | rz_new | rr | flag."""
+        import ctypes as C
+        from ._lib import check, lib
+        L, ptr = lib(), (lambda t: C.c_void_p(t.data_ptr()))
+        n = p.numel()
+        if self.operator is not None:
+            pattern, nz = self.operator
+            self.halo.pack_product_rows(pattern, nz, p)              # interface rows first …
+            self.halo.start()                                        # … their exchange in flight …
+            check(L.tb_spmv_csr_dot(pattern.h, nz.ptr, ptr(p), ptr(Ap), ptr(S[1:2])))   # … behind the whole local product + local pᵀA_p p
+            self.halo.finish(Ap)
+        else:
+            y = self.spmv(p)
+            check(L.tb_cgd_dot(self.dev.h, n, None, ptr(p), ptr(y), ptr(S[1:2])))       # local quadratic form, before the halo sum
+            self.halo.exchange_sum(y)
+            Ap.copy_(y)
+        if self.world > 1:
+            all_reduce_sum(S[1:2], self.dist)
+
     def _solve_device(self, b, x, rtol, atol, maxiter):
         import ctypes as C
         from ._lib import check, lib
         torch, dist, dev, n = self.torch, self.dist, self.dev, x.numel()
+        if dev.stream_handle != int(torch.cuda.current_stream().cuda_stream):
+            raise RuntimeError("DistributedCG: the MI355XDevice is not on torch's current stream (device.set_stream(torch.cuda.current_stream().cuda_stream)); "
+                               "its kernels would race with the all-reduces and the exchange")
         L = lib()
         ptr = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-        S = torch.zeros(4, dtype=torch.float64, device=x.device)    # rz | pAp | rz_new, rr  (device-resident scalars)
+        S = torch.zeros(5, dtype=torch.float64, device=x.device)    # rz | pAp | rz_new, rr, breakdown flag  (device-resident scalars)
+        Ap = torch.empty_like(x)
         r = b - self.apply(x)
         p = self.dinv * r
         check(L.tb_cgd_dot(dev.h, n, ptr(self.w), ptr(r), ptr(p), ptr(S[0:1])))
         check(L.tb_cgd_dot(dev.h, n, ptr(self.w), ptr(r), ptr(r), ptr(S[3:4])))
         if self.world > 1:
-            all_reduce_sum(S, dist)
+            all_reduce_sum(S[0:4], dist)
         rn = float(S[3].item()) ** 0.5
         tol = atol + rtol * rn
         it = 0
         while rn > tol and it < maxiter:
             for _ in range(min(self.look, maxiter - it)):
-                Ap = self.apply(p)                                   # local SpMV (tb_spmv_csr) + neighbour exchange
-                S[1:].zero_()
-                check(L.tb_cgd_dot(dev.h, n, ptr(self.w), ptr(p), ptr(Ap), ptr(S[1:2])))
-                if self.world > 1:
-                    all_reduce_sum(S[1:2], dist)
-                check(L.tb_cgd_update(dev.h, n, ptr(self.w), ptr(self.dinv), ptr(p), ptr(Ap), ptr(x), ptr(r), ptr(S[0:1]), ptr(S[1:2]), ptr(S[2:4])))
+                S[1:4].zero_()
+                self.device_iteration(p, Ap, S)
+                check(L.tb_cgd_update(dev.h, n, ptr(self.w), ptr(self.dinv), ptr(p), ptr(Ap), ptr(x), ptr(r), ptr(S[0:1]), ptr(S[1:2]), ptr(S[2:5])))
                 if self.world > 1:
                     all_reduce_sum(S[2:4], dist)
                 check(L.tb_cgd_direction(dev.h, n, ptr(self.dinv), ptr(r), ptr(p), ptr(S[0:1]), ptr(S[2:3])))
                 S[0:1].copy_(S[2:3])
                 it += 1
-            rn = float(S[3].item()) ** 0.5                           # the one host read of the look
+            h = S[3:5].cpu()                                         # the one host read of the look: ‖r‖² and the breakdown flag
+            if float(h[1]) != 0.0:
+                self.breakdown = float(h[1])
+                raise ArithmeticError("DistributedCG: pᵀAp = %g ≤ 0 — the operator is not positive definite (or the iteration broke down)" % self.breakdown)
+            rn = float(h[0]) ** 0.5
         return x, it, rn
