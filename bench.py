@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--n", type=int, default=216, help="cells per edge of each rank's box (216 → 10M hexahedra)")
     ap.add_argument("--strategy", default="patch", choices=["patch", "atomic", "color"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dist-cg", action="store_true", help="skip the (untimed-region) distributed CG iteration measurement")
     ap.add_argument("--cpu-n", type=int, default=64, help="edge of the CPU-baseline sample mesh")
     ap.add_argument("--keep-du", action="store_true", help="materialise du (dumat) in the reaction step")
     ap.add_argument("--separate", action="store_true", help="assemble M and K with two launches instead of the fused pass")
@@ -194,6 +195,9 @@ def main():
         lo, up = part.interface_nodes()
         lo_idx = None if lo is None else torch.from_numpy(n2d[lo]).cuda()
         up_idx = None if up is None else torch.from_numpy(n2d[up]).cuda()
+    # the one data-path exchange: persistent send / receive buffers, pack and unpack through the C ABI (tb_gather_indexed / tb_scatter_add_indexed)
+    nbrs = tb.distributed.slab_neighbours(lo_idx, up_idx, rank, world)
+    halo = tb.distributed.HaloExchange(nbrs, dist if world > 1 else None, b, dev)
 
     model = {"pcg2019": tb.PCG2019, "tt06": tb.TT06, "fhn": tb.FHNModel}[args.ionic]()
     ns = model.nstates
@@ -222,7 +226,7 @@ def main():
         ev[2].record(); tb.update_operator(src, t)
         ev[3].record()
         if world > 1:
-            tb.distributed.halo_sum(b, lo_idx, up_idx, rank, world, dist)
+            halo.exchange_sum(b)
         ev[4].record(); tb.perform_step(f, cache, t, rdt)
         ev[5].record()
         if timed:
@@ -264,6 +268,53 @@ def main():
         ref_rx = {"model": "pcg2019", "states": 7, "ms": ms_ref, "dof_updates_per_s": 7 * npts / (ms_ref * 1e-3),
                   "hbm_frac": BYTES_PER_DOF_UPDATE * 7 * npts / (ms_ref * 1e-3) / 1e9 / HBM_PEAK_GBS}
         del cref, uref
+
+    # outside the timed region as well: what a time step adds to the assembly under a partition — one iteration of the distributed Jacobi-CG on
+    # the heat matrix A = M − Δt·K of this rank's slab: interface rows of A·p packed first (tb_spmv_csr_rows), exchange posted, whole local product
+    # + pᵀA_p p behind it (tb_spmv_csr_dot), received partials added, all-reduce of pᵀAp, update with the two weighted sums, all-reduce, direction
+    dist_cg = None
+    if not args.no_dist_cg:
+        A = tb.heat_system_matrix(dev, M, K, 0.01)
+        diag = torch.empty(npts, dtype=torch.float64, device="cuda")
+        tb._lib.check(tb.lib().tb_extract_diagonal(K.pattern.h, A.ptr, diag.data_ptr()))
+        cg = tb.distributed.DistributedCG(None, diag, lo_idx, up_idx, rank, world, dist if world > 1 else None, device=dev, operator=(K.pattern, A))
+        xs_ = torch.zeros(npts, dtype=torch.float64, device="cuda")
+        rs_ = b.clone() + 1.0
+        ps_ = cg.dinv * rs_
+        Ap_ = torch.empty_like(xs_)
+        S_ = torch.zeros(5, dtype=torch.float64, device="cuda")
+        tb._lib.check(tb.lib().tb_cgd_dot(dev.h, npts, cg.w.data_ptr(), rs_.data_ptr(), ps_.data_ptr(), S_[0:1].data_ptr()))
+        if world > 1:
+            tb.distributed.all_reduce_sum(S_[0:1], dist)
+        for _ in range(3):
+            cg.device_step(xs_, rs_, ps_, Ap_, S_)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        nit = 10
+        ea, eb, ec = dev.event(), dev.event(), dev.event()
+        t0 = time.perf_counter()
+        for _ in range(nit):
+            cg.device_step(xs_, rs_, ps_, Ap_, S_)
+        torch.cuda.synchronize()
+        t_it = (time.perf_counter() - t0) / nit
+        ea.record()
+        for _ in range(nit):
+            cg.device_iteration(ps_, Ap_, S_)                    # product + halo + pᵀAp only
+        eb.record()
+        for _ in range(nit):
+            tb._lib.check(tb.lib().tb_spmv_csr(K.pattern.h, A.ptr, ps_.data_ptr(), 1.0, 0.0, Ap_.data_ptr()))   # the bare local SpMV, for reference
+        ec.record()
+        torch.cuda.synchronize()
+        if world > 1:
+            tt = torch.tensor([t_it], dtype=torch.float64, device="cpu" if share else "cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_it = float(tt.item())
+        dist_cg = {"iteration_ms": t_it * 1e3, "product_halo_dot_ms": ea.elapsed_ms(eb) / nit, "local_spmv_ms": eb.elapsed_ms(ec) / nit,
+                   "halo_bytes_per_rank": halo.nbytes, "rows_per_rank": npts, "nnz_per_rank": sp.nnz,
+                   "note": "one Jacobi-CG iteration on A = M - dt K under the partition (max over ranks, host-timed over %d iterations, device scalars, "
+                           "no host read): interface rows packed first, exchange overlapped with the local SpMV + p'Ap, two all-reduces" % nit}
+        del A, cg, xs_, rs_, ps_, Ap_, diag
 
     if rank == 0:
         K_ = args.steps
@@ -307,6 +358,8 @@ def main():
             out["roofline"][k]["frac"] = out["roofline"][k]["achieved"] / HBM_PEAK_GBS
         if ref_rx is not None:
             out["reference_model_reaction"] = ref_rx
+        if dist_cg is not None:
+            out["distributed_cg"] = dist_cg
         try:  # HBM bytes per launch from this round's PMC passes (rocprofv3 cannot run inside this process): scripts/collect_profiles.sh writes the file
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             if tj["cells"] == g.n_cells and args.strategy == "patch":

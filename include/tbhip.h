@@ -443,6 +443,9 @@ int tb_cgd_direction(tb_device *dev, int64_t n, const double *d_dinv, const doub
  *   tb_spmv_csr_dot         y = A·x and *d_dot += xᵀ·y           (device scalar) — Σ_ranks xᵀ·A_p·x is pᵀAp of the distributed CG: no halo needed
  * All asynchronous on the device's stream. */
 int tb_gather_indexed(tb_device *dev, int64_t n, const double *d_vec, const int32_t *d_idx, double *d_out);
+/* d_diag[r] = A[r, r] (0 where the pattern stores no diagonal entry): the sub-domain diagonal a distributed Jacobi preconditioner sums over the
+ * interface before inverting it (single device: tb_cg_solve does this internally) */
+int tb_extract_diagonal(tb_pattern *pat, const double *d_nzval, double *d_diag);
 int tb_scatter_add_indexed(tb_device *dev, int64_t n, const double *d_in, const int32_t *d_idx, double *d_vec);
 int tb_spmv_csr_rows(tb_pattern *pat, const double *d_nzval, const double *d_x, int64_t n_rows, const int32_t *d_rows, double *d_out);
 int tb_spmv_csr_dot(tb_pattern *pat, const double *d_nzval, const double *d_x, double *d_y, double *d_dot);

@@ -409,6 +409,9 @@ function halo_pack_product_rows!(nb::HaloNeighbour, A::HIPSparseMatrixCSR{Float6
     check(ccall((:tb_spmv_csr_rows, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Int32}, Ptr{Float64}),
         A.ddh.pattern, A.nzval.ptr, x.ptr, nb.idx.n, nb.idx.ptr, nb.send.ptr))
 end
+function diagonal!(d::HIPVector{Float64}, A::HIPSparseMatrixCSR{Float64})
+    check(ccall((:tb_extract_diagonal, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), A.ddh.pattern, A.nzval.ptr, d.ptr))
+end
 # y = A·x and xy[] += xᵀ·y (device scalar): the local quadratic form of the distributed CG
 function mul_dot!(y::HIPVector{Float64}, A::HIPSparseMatrixCSR{Float64}, x::HIPVector{Float64}, xy::HIPVector{Float64})
     check(ccall((:tb_spmv_csr_dot, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), A.ddh.pattern, A.nzval.ptr, x.ptr, y.ptr, xy.ptr))

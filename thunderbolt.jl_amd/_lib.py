@@ -139,6 +139,7 @@ SIGNATURES = {
     "tb_cgd_update": (C.c_int, [vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "tb_cgd_direction": (C.c_int, [vp, C.c_int64, vp, vp, vp, vp, vp]),
     "tb_gather_indexed": (C.c_int, [vp, C.c_int64, vp, vp, vp]),
+    "tb_extract_diagonal": (C.c_int, [vp, vp, vp]),
     "tb_scatter_add_indexed": (C.c_int, [vp, C.c_int64, vp, vp, vp]),
     "tb_spmv_csr_rows": (C.c_int, [vp, vp, vp, C.c_int64, vp, vp]),
     "tb_spmv_csr_dot": (C.c_int, [vp, vp, vp, vp, vp]),

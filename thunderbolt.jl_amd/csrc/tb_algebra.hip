@@ -349,16 +349,18 @@ namespace tb {
 
 // D⁻¹ for the Jacobi preconditioner: the position of each row's diagonal entry is a property of the pattern, found once on the host
 // (scanning the rows on the device, one thread per row, cost 1.7 ms per solve at 216³ — more than a CG iteration); −1 = no diagonal stored
+template <bool INVERT>
 __global__ void __launch_bounds__(256)
 k_extract_diag(int64_t nrows, const int64_t *__restrict__ diagpos, const double *__restrict__ nz, double *__restrict__ dinv)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nrows) return;
     const int64_t k = diagpos[r];
-    dinv[r] = 1.0 / (k >= 0 ? nz[k] : 1.0);
+    if constexpr (INVERT) dinv[r] = 1.0 / (k >= 0 ? nz[k] : 1.0);
+    else dinv[r] = k >= 0 ? nz[k] : 0.0;
 }
 
-static int launch_extract_diag(tb_pattern *p, const double *nz, double *dinv)
+static int launch_extract_diag(tb_pattern *p, const double *nz, double *dinv, bool invert = true)
 {
     tb_device *dev = p->mesh->dev;
     if (!p->d_diagpos) {
@@ -369,10 +371,13 @@ static int launch_extract_diag(tb_pattern *p, const double *nz, double *dinv)
         TB_HIP(hipMalloc((void **)&p->d_diagpos, pos.size() * sizeof(int64_t)));
         TB_HIP(hipMemcpy(p->d_diagpos, pos.data(), pos.size() * sizeof(int64_t), hipMemcpyHostToDevice));
     }
-    hipLaunchKernelGGL(k_extract_diag, dim3((unsigned)((p->n_rows + 255) / 256)), dim3(256), 0, dev->stream, p->n_rows, p->d_diagpos, nz, dinv);
+    if (p->n_rows == 0) return TB_OK;
+    if (invert) hipLaunchKernelGGL(k_extract_diag<true>, dim3((unsigned)((p->n_rows + 255) / 256)), dim3(256), 0, dev->stream, p->n_rows, p->d_diagpos, nz, dinv);
+    else hipLaunchKernelGGL(k_extract_diag<false>, dim3((unsigned)((p->n_rows + 255) / 256)), dim3(256), 0, dev->stream, p->n_rows, p->d_diagpos, nz, dinv);
     TB_HIP(hipGetLastError());
     return TB_OK;
 }
+int launch_extract_diagonal(tb_pattern *p, const double *nz, double *diag) { return launch_extract_diag(p, nz, diag, false); }
 
 __device__ __forceinline__ void block_sum_to(double v, double *out)
 {

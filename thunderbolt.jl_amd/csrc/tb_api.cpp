@@ -248,7 +248,7 @@ int tb_mesh_create(tb_device *dev, int geom_kind, int64_t n_nodes, const double 
 int tb_mesh_destroy(tb_mesh *m)
 {
     if (!m) return TB_OK;
-    hipFree(m->d_xyz); hipFree(m->d_conn); hipFree(m->d_cell_dofs); hipFree(m->d_node_dof0); hipFree(m->d_cell_xyz);
+    hipFree(m->d_xyz); hipFree(m->d_conn); hipFree(m->d_cell_dofs); hipFree(m->d_node_dof0); hipFree(m->d_cell_xyz); hipFree(m->d_rank27);
     if (m->colors) hipFree(m->colors->d_cells);
     if (m->ea) { hipFree(m->ea->d_ptr); hipFree(m->ea->d_src); hipFree(m->ea->d_ea); hipFree(m->ea->d_ell); }
     free_patch_plan(m);
@@ -1056,6 +1056,13 @@ int tb_cgd_direction(tb_device *dev, int64_t n, const double *d_dinv, const doub
     TB_REQUIRE(dev && d_rz && d_rz_new && n >= 0 && ((d_r && d_p) || n == 0), "tb_cgd_direction: bad argument");
     TB_HIP(hipSetDevice(dev->id));
     return launch_cgd_direction(dev, n, d_dinv, d_r, d_p, d_rz, d_rz_new);
+}
+
+int tb_extract_diagonal(tb_pattern *pat, const double *d_nzval, double *d_diag)
+{
+    TB_REQUIRE(pat && ((d_nzval && d_diag) || pat->n_rows == 0), "tb_extract_diagonal: NULL argument");
+    TB_HIP(hipSetDevice(pat->mesh->dev->id));
+    return launch_extract_diagonal(pat, d_nzval, d_diag);
 }
 
 int tb_gather_indexed(tb_device *dev, int64_t n, const double *d_vec, const int32_t *d_idx, double *d_out)

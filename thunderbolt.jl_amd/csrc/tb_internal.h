@@ -163,6 +163,8 @@ struct tb_mesh {
     int32_t *d_conn = nullptr;
     int32_t *d_cell_dofs = nullptr;
     int32_t *d_node_dof0 = nullptr; // vector fields: first dof of every field node
+    uint8_t *d_rank27 = nullptr;    // 27-node vector fields: rank of every node of a cell by global dof (32 bytes per cell), see tb_mechanics.hip
+    int rank27_ok = 0;              // 0 not examined, 1 built, −1 not applicable
     double *d_cell_xyz = nullptr;   // vertex coordinates per cell (nverts × 3, cell-major), built on first use by the block-per-cell kernels
     int64_t n_nodes_field = 0;
     std::vector<int32_t> h_node_dof0;
@@ -197,6 +199,7 @@ struct tb_pattern {
     double *d_gmres_ws = nullptr;   // GMRES workspace: (restart+1) basis vectors + 3 vectors + scalars
     int gmres_m = 0;
     double *d_kebuf = nullptr;      // element-matrix buffer of the ElementAssemblyStrategy (vector fields)
+    size_t kebuf_bytes = 0;
     int64_t max_row_len = 0;
     uint16_t *d_blockpos = nullptr; // vector fields: per cell and node pair, position of the 3×3 block inside its row
     std::unique_ptr<tb::PatchMatPlan> patch_mat;
@@ -318,6 +321,7 @@ int launch_max(tb_device *dev, int64_t n, const double *x, int64_t stride, doubl
 int launch_gather_indexed(tb_device *dev, int64_t n, const double *vec, const int32_t *idx, double *out);
 int launch_scatter_add_indexed(tb_device *dev, int64_t n, const double *in, const int32_t *idx, double *vec);
 int launch_spmv_rows(tb_pattern *p, const double *nz, const double *x, int64_t n, const int32_t *rows, double *out);
+int launch_extract_diagonal(tb_pattern *p, const double *nz, double *diag);
 int launch_spmv_dot(tb_pattern *pat, const double *A, const double *x, double *y, double *d_dot);
 double decode_ordered_key(unsigned long long k);
 

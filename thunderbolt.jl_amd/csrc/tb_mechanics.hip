@@ -17,11 +17,14 @@
 //  * Q1 and the comparison build (TB_MECH_MFMA=0): thread (a, b-group) keeps 3×3 blocks in registers, T staged in LDS.
 #include <hip/hip_runtime.h>
 
+#include <cstring>
+
 #include <algorithm>
 
 #include "tb_internal.h"
 #include "tb_energy.hpp"
 #include "tb_material.hpp"
+#include "tb_math.hpp"
 
 namespace tb {
 using namespace tbk;
@@ -49,6 +52,20 @@ __host__ __device__ constexpr int hex27_tix(int a, int d)
                               {2, 2, 1}, {0, 2, 1}, {1, 1, 0}, {1, 0, 1}, {2, 1, 1}, {1, 2, 1}, {0, 1, 1}, {1, 1, 2}, {1, 1, 1}};
     return T[a][d];
 }
+// inverse of hex27_tix: tensor index t₀ + 3 t₁ + 9 t₂ → Ferrite node
+struct Hex27Nodes { int v[27]; };
+constexpr Hex27Nodes make_hex27_nodes()
+{
+    Hex27Nodes n{};
+    for (int a = 0; a < 27; ++a) n.v[hex27_tix(a, 0) + 3 * hex27_tix(a, 1) + 9 * hex27_tix(a, 2)] = a;
+    return n;
+}
+__constant__ int g_hex27_node[27] = {make_hex27_nodes().v[0], make_hex27_nodes().v[1], make_hex27_nodes().v[2], make_hex27_nodes().v[3], make_hex27_nodes().v[4],
+                                     make_hex27_nodes().v[5], make_hex27_nodes().v[6], make_hex27_nodes().v[7], make_hex27_nodes().v[8], make_hex27_nodes().v[9],
+                                     make_hex27_nodes().v[10], make_hex27_nodes().v[11], make_hex27_nodes().v[12], make_hex27_nodes().v[13], make_hex27_nodes().v[14],
+                                     make_hex27_nodes().v[15], make_hex27_nodes().v[16], make_hex27_nodes().v[17], make_hex27_nodes().v[18], make_hex27_nodes().v[19],
+                                     make_hex27_nodes().v[20], make_hex27_nodes().v[21], make_hex27_nodes().v[22], make_hex27_nodes().v[23], make_hex27_nodes().v[24],
+                                     make_hex27_nodes().v[25], make_hex27_nodes().v[26]};
 __host__ __device__ constexpr double quad1d(int i, double x) { return i == 0 ? 0.5 * x * (x - 1.0) : i == 1 ? (1.0 - x * x) : 0.5 * x * (x + 1.0); }
 __host__ __device__ constexpr double dquad1d(int i, double x) { return i == 0 ? x - 0.5 : i == 1 ? -2.0 * x : x + 0.5; }
 
@@ -129,6 +146,9 @@ __global__ void k_build_blockpos(const int32_t *__restrict__ cell_dofs, int64_t 
 }
 
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+// symmetric-packed element matrix of the 27-node vector field: 378 node blocks (i ≤ j by rank) of 9 doubles
+__host__ __device__ constexpr int symblk(int i, int j) { return i * 27 - i * (i - 1) / 2 + (j - i); }
+constexpr int KE_SYM = 378 * 9;
 #ifndef TB_KE_DMAJOR
 #define TB_KE_DMAJOR 0
 #endif
@@ -136,20 +156,32 @@ constexpr bool KE_DMAJOR = TB_KE_DMAJOR; // stored-Kₑ row layout of the matrix
 
 // AD: the material is any energy of tb_energy.hpp, differentiated per pair of components of F by hyper-dual evaluation (the
 // reference's Tensors.hessian path); !AD: Holzapfel–Ogden 2009 + SimpleCompressionPenalty with the hand-derived routines.
-template <class FE, bool NEED_K, bool NEED_R, bool MFMA, bool AD>
-__global__ void __launch_bounds__(FE::THREADS, FE::WAVES)
+// CT: contraction of the tangent — 0 vector FMAs over the quadrature points (Q1; comparison build), 1 matrix cores (v_mfma_f64_16x16x4,
+// symmetric tiles), 2 sum-factorised over the tensor-product structure of the triquadratic basis and the 3×3×3 Gauss rule (Q2 default)
+template <class FE, bool NEED_K, bool NEED_R, int CT, bool AD>
+__global__ void __launch_bounds__(FE::THREADS, CT == 2 ? 2 : FE::WAVES)
 k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restrict__ list, const double *__restrict__ u, double *__restrict__ nz,
                double *__restrict__ r, const int64_t *__restrict__ rowptr, const uint16_t *__restrict__ blockpos, int atomic /*0 rmw, 1 atomic, 2 store Kₑ/rₑ*/,
-               double *__restrict__ ke, double *__restrict__ re, Status *st)
+               double *__restrict__ ke, double *__restrict__ re, Status *st, const uint8_t *__restrict__ rank27 /*non-NULL: symmetric-packed Kₑ (matrix-core path)*/)
 {
     constexpr int NB = FE::NB, NQ = FE::NQ, ND = FE::ND, PB = FE::PB, T = FE::THREADS, NG = NB / PB;
+    constexpr bool MFMA = CT == 1, SF = CT == 2;
     const MechTables<FE> &tb = g_mech_tables<FE>;
     const int64_t cell = list ? list[blockIdx.x] : blockIdx.x;
     const int tid = threadIdx.x;
-    __shared__ double s_ue[ND], s_x[24], s_JI[NQ][10], s_G[NQ][NB][3], s_P[NQ][9];
-    __shared__ double s_A[NEED_K ? NQ : 1][81];
+    __shared__ double s_ue[ND], s_x[24], s_JI[NQ][10], s_P[NQ][9];
+    // 𝔸·dΩ per point and the mapped gradients share one block: once the contraction is done it stages the symmetric-packed Kₑ for a coalesced store
+    // (dynamic LDS: with the stage buffers of the sum-factorised contraction the kernel's block exceeds the 64 KB a static allocation may have)
+    constexpr int AN = (NEED_K ? NQ : 1) * 81;
+    extern __shared__ double s_AG[];
+    double (*s_A)[81] = reinterpret_cast<double (*)[81]>(s_AG);
+    double (*s_G)[NB][3] = reinterpret_cast<double (*)[NB][3]>(s_AG + AN);
+    __shared__ uint8_t s_rank[32];
     // phase A scratch (common blocks + F) and phase B's double-buffered T share one region
-    constexpr int TC_SIZE = (NEED_K && !MFMA && 2 * NB * 27 > NQ * HOC_SIZE) ? 2 * NB * 27 : NQ * HOC_SIZE;
+    constexpr int SF_Z2 = 3 * 4 * 81 * 3; // stage-2 values of the sum-factorised contraction
+    constexpr int TC_SIZE = (NEED_K && SF) ? (SF_Z2 > NQ * HOC_SIZE ? SF_Z2 : NQ * HOC_SIZE)
+                                           : (NEED_K && !MFMA && 2 * NB * 27 > NQ * HOC_SIZE) ? 2 * NB * 27 : NQ * HOC_SIZE;
+    __shared__ double s_Ji[(NEED_K && SF) ? NQ : 1][9]; // J⁻¹ kept for the pull-back of 𝔸 (the slots of s_JI carry F after A2)
     __shared__ double s_TC[TC_SIZE];
     double (*s_T)[NB][27] = reinterpret_cast<double (*)[NB][27]>(s_TC);
     double (*s_C)[HOC_SIZE] = reinterpret_cast<double (*)[HOC_SIZE]>(s_TC);
@@ -162,6 +194,7 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
         s_ue[i] = u[d];
     }
     for (int i = tid; i < 24; i += T) s_x[i] = m.xyz[3 * (int64_t)m.conn[cell * 8 + i / 3] + i % 3];
+    if (NEED_K && MFMA && rank27 && tid < 32) s_rank[tid] = rank27[cell * 32 + tid];
     __syncthreads();
 
     // A1: J, J⁻¹, dΩ per point (PR883.jl:253-263,367-387)
@@ -182,6 +215,10 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
         o[6] = c02 * id; o[7] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * id; o[8] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * id;
         o[9] = det * tb.w[q];
         if (!(o[9] > 0.0)) { st->neg_detj = 1; st->cell = cell; }
+        if constexpr (NEED_K && SF) {
+#pragma unroll
+            for (int e = 0; e < 9; ++e) s_Ji[q][e] = o[e];
+        }
     }
     __syncthreads();
     // A2: mapped gradients ∇Nₐ = ∂Nₐ/∂ξ · J⁻¹ for every (point, node)
@@ -389,6 +426,24 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
                 if (atomic) unsafeAtomicAdd(nz + k, v); else nz[k] += v;
             }
         };
+        // Symmetric-packed element matrix (rank27 given): the cell's nodes are ranked by their global dof, a 3×3 node block (a, b) is stored once, at
+        // symblk(min rank, max rank), as [c][d] seen from the node of smaller rank — so the gather of a node reads, per cell, ONE contiguous run
+        // (its blocks with all nodes of higher dof) and mirrors them into the rows of those nodes.  Half the bytes of the stored 81 × 81 matrix.
+        // Entries go to the LDS block the operands lived in and leave as one coalesced 27 KB stream.
+        auto put_sym = [&](int R, int b, int d, double v) {
+            const int a = R / 3, c = R - 3 * a;
+            const int ra = s_rank[a], rb = s_rank[b];
+            int slot;
+            if (a == b) slot = symblk(ra, ra) * 9 + 3 * c + d;
+            else {
+                // the entry and its transpose share a slot; the transpose is not computed when it lies in a skipped tile (row ≥ 48, column < 16)
+                const bool partner_computed = !(b >= 16 && a < 16);
+                if (partner_computed && ra > rb) return;
+                slot = ra < rb ? symblk(ra, rb) * 9 + 3 * c + d : symblk(rb, ra) * 9 + 3 * d + c;
+            }
+            s_AG[slot] = v;
+        };
+        const bool sym = atomic == 2 && rank27 != nullptr;
         auto emit = [&](const mfma_d4 &v, int knd, int nt) {
             const int mt = knd / 3, d = knd % 3, b = 16 * nt + lr;
             if (b >= NB) return;
@@ -396,15 +451,171 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
             for (int rg = 0; rg < 4; ++rg) {
                 const int R = 16 * mt + g + 4 * rg;
                 if (R >= ND) continue;
+                if (sym) { put_sym(R, b, d, v[rg]); continue; }
                 put(R, b, d, v[rg]);
                 if (nt == 1 && mt <= 2) put(3 * b + d, R / 3, R % 3, v[rg]); // transpose: row (b,d), column (a,c) = R
             }
         };
+        if (sym) __syncthreads(); // every wave is done reading 𝔸 and ∇N (contraction, residual)
         emit(acc[0], kind[0], 0); emit(acc[1], kind[0], 1);
         emit(acc[2], kind[1], 0); emit(acc[3], kind[1], 1);
         emit(acc[4], kind[2], 1); emit(acc[5], kind[3], 1);
         if (e2_both) emit(acc[6], kind[2], 0);
         else if (has_e4) emit(acc[6], kind[4], 1);
+        if (sym) {
+            __syncthreads();
+            static_assert(KE_SYM % 2 == 0 && KE_SYM <= AN + NQ * NB * 3, "staging block");
+            double2 *dst = reinterpret_cast<double2 *>(ke + (int64_t)cell * KE_SYM);
+            const double2 *src = reinterpret_cast<const double2 *>(s_AG);
+            for (int i = tid; i < KE_SYM / 2; i += T) dst[i] = src[i];
+        }
+    } else if constexpr (NEED_K && SF) {
+        // B (sum factorisation).  Kₑ[(a,c)][(b,d)] = Σ_q Σ_su ∂̂ₛNₐ(ξ_q) Â_q[c][s][d][u] ∂̂ᵤN_b(ξ_q) with the tangent pulled back to the reference cell,
+        // Â_q[c][s][d][u] = Σ_kl J⁻¹[s][k] 𝔸_q[c][k][d][l] J⁻¹[u][l] dΩ.  Basis and Gauss rule are tensor products — node a ↔ (a₀,a₁,a₂), point
+        // q ↔ (q₀,q₁,q₂), ∂̂ₛNₐ(ξ_q) = Π_dim ψ(dim == s)_{a_dim}(q_dim), ψ(false) = φ, ψ(true) = φ′ — so the sum over q is three one-dimensional
+        // contractions.  After direction 1 only "s is 2 or not" (μ) still matters, so the nine (s, u) pairs collapse to four (μ, ν):
+        //   stage 1  Z1[s][d][u][q₁][q₂][a₀][b₀]       = Σ_q₀ ψ(s==0)_{a₀}(q₀) ψ(u==0)_{b₀}(q₀) Â_q[c][s][d][u]
+        //   stage 2  Z2[d][μ][ν][a₀][b₀][a₁][b₁][q₂]   = Σ_{s∈μ} Σ_{u∈ν} Σ_q₁ ψ(s==1)_{a₁}(q₁) ψ(u==1)_{b₁}(q₁) Z1
+        //   stage 3  Kₑ[(a,c)][(b,d)]                  = Σ_μν Σ_q₂ ψ(μ)_{a₂}(q₂) ψ(ν)_{b₂}(q₂) Z2
+        // per row component c: 243 lane-tasks per stage (one per thread), 27 / 108 / 90 multiply-adds each out of 3 / 27 / 12 LDS reads — ≈ 1.6·10⁵
+        // multiply-adds per cell instead of the 1.2·10⁶ of the dense 81 × 27 × 81 products, on the vector ALUs, no symmetry assumed (so the
+        // rate-coupled, non-symmetric tangent runs here too).  Same sums as elements.jl:211-223 in another order (≲ 1e-15 relative).
+        static_assert(T == 256 && NB == 27 && NQ == 27, "sum-factorised contraction: triquadratic field, 3×3×3 Gauss rule");
+        if constexpr (NEED_R) { // the residual reads the mapped gradients, whose block stage 1 reuses
+            if (tid < ND) {
+                for (int q = 0; q < NQ; ++q) {
+                    const double *gr = s_G[q][tid / 3];
+                    const double *pp = s_P[q] + 3 * (tid % 3);
+                    racc += gr[0] * pp[0] + gr[1] * pp[1] + gr[2] * pp[2];
+                }
+            }
+        }
+        // stage 0: 𝔸·dΩ → Â, in place, one lane per (point, c, d)
+        if (tid < NQ * 9) {
+            const int q = tid / 9, cd = tid - 9 * q, c = cd / 3, d = cd - 3 * c;
+            const double *ji = s_Ji[q];
+            double *Aq = s_A[q];
+            double a9[3][3], t9[3][3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int l = 0; l < 3; ++l) a9[k][l] = Aq[9 * (3 * c + k) + 3 * d + l];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int u = 0; u < 3; ++u) t9[k][u] = a9[k][0] * ji[3 * u] + a9[k][1] * ji[3 * u + 1] + a9[k][2] * ji[3 * u + 2];
+#pragma unroll
+            for (int s_ = 0; s_ < 3; ++s_)
+#pragma unroll
+                for (int u = 0; u < 3; ++u) Aq[9 * (3 * c + s_) + 3 * d + u] = ji[3 * s_] * t9[0][u] + ji[3 * s_ + 1] * t9[1][u] + ji[3 * s_ + 2] * t9[2][u];
+        }
+        lds_barrier(); // LDS traffic only: the stores of the previous rows stay in flight
+        double *Z1 = &s_G[0][0][0], *Z2 = s_TC, *outb = &s_G[0][0][0]; // Z1 is dead when stage 3 writes the 27 × 81 rows of this component
+        auto PH = [](int i, int q) constexpr { return quad1d(i, G3::x(q)); };
+        auto DP = [](int i, int q) constexpr { return dquad1d(i, G3::x(q)); };
+        for (int c = 0; c < 3; ++c) {
+            if (tid < 243) { // stage 1: task (s, d, u, q₁, q₂)
+                int t = tid;
+                const int q2 = t % 3; t /= 3;
+                const int q1 = t % 3; t /= 3;
+                const int u = t % 3; t /= 3;
+                const int d = t % 3;
+                const int s_ = t / 3;
+                double in[3], tb0[3][3];
+#pragma unroll
+                for (int q0 = 0; q0 < 3; ++q0) in[q0] = s_A[q0 + 3 * q1 + 9 * q2][9 * (3 * c + s_) + 3 * d + u];
+#pragma unroll
+                for (int b0 = 0; b0 < 3; ++b0)
+#pragma unroll
+                    for (int q0 = 0; q0 < 3; ++q0) tb0[b0][q0] = (u == 0 ? DP(b0, q0) : PH(b0, q0)) * in[q0];
+#pragma unroll
+                for (int a0 = 0; a0 < 3; ++a0)
+#pragma unroll
+                    for (int b0 = 0; b0 < 3; ++b0) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int q0 = 0; q0 < 3; ++q0) v += (s_ == 0 ? DP(a0, q0) : PH(a0, q0)) * tb0[b0][q0];
+                        Z1[9 * tid + 3 * a0 + b0] = v;
+                    }
+            }
+            lds_barrier(); // LDS traffic only: the stores of the previous rows stay in flight
+            if (tid < 243) { // stage 2: task (d, a₀, b₀, q₂, b₁)
+                int t = tid;
+                const int b1 = t % 3; t /= 3;
+                const int q2 = t % 3; t /= 3;
+                const int b0 = t % 3; t /= 3;
+                const int a0 = t % 3;
+                const int d = t / 3;
+                double acc2[2][2][3];
+#pragma unroll
+                for (int e = 0; e < 12; ++e) (&acc2[0][0][0])[e] = 0.0;
+#pragma unroll
+                for (int s_ = 0; s_ < 3; ++s_)
+#pragma unroll
+                    for (int u = 0; u < 3; ++u)
+#pragma unroll
+                        for (int q1 = 0; q1 < 3; ++q1) {
+                            const double pb = u == 1 ? (b1 == 0 ? DP(0, q1) : b1 == 1 ? DP(1, q1) : DP(2, q1)) : (b1 == 0 ? PH(0, q1) : b1 == 1 ? PH(1, q1) : PH(2, q1));
+                            const double z = Z1[9 * (((((s_ * 3 + d) * 3 + u) * 3 + q1) * 3) + q2) + 3 * a0 + b0] * pb;
+#pragma unroll
+                            for (int a1 = 0; a1 < 3; ++a1) acc2[s_ == 2][u == 2][a1] += (s_ == 1 ? DP(a1, q1) : PH(a1, q1)) * z;
+                        }
+#pragma unroll
+                for (int mu = 0; mu < 2; ++mu)
+#pragma unroll
+                    for (int nu = 0; nu < 2; ++nu)
+#pragma unroll
+                        for (int a1 = 0; a1 < 3; ++a1) Z2[((((((d * 2 + mu) * 2 + nu) * 3 + a0) * 3 + b0) * 3 + a1) * 3 + b1) * 3 + q2] = acc2[mu][nu][a1];
+            }
+            lds_barrier(); // LDS traffic only: the stores of the previous rows stay in flight
+            if (tid < 243) { // stage 3: task (d, a₀, b₀, a₁, b₁) → the nine entries (a₂, b₂)
+                int t = tid;
+                const int b1 = t % 3; t /= 3;
+                const int a1 = t % 3; t /= 3;
+                const int b0 = t % 3; t /= 3;
+                const int a0 = t % 3;
+                const int d = t / 3;
+                double z[2][2][3], w[2][3][3]; // w[μ][b₂][q₂] = Σ_ν ψ(ν)_{b₂}(q₂) z[μ][ν][q₂]
+#pragma unroll
+                for (int mu = 0; mu < 2; ++mu)
+#pragma unroll
+                    for (int nu = 0; nu < 2; ++nu)
+#pragma unroll
+                        for (int q2 = 0; q2 < 3; ++q2) z[mu][nu][q2] = Z2[((((((d * 2 + mu) * 2 + nu) * 3 + a0) * 3 + b0) * 3 + a1) * 3 + b1) * 3 + q2];
+#pragma unroll
+                for (int mu = 0; mu < 2; ++mu)
+#pragma unroll
+                    for (int b2 = 0; b2 < 3; ++b2)
+#pragma unroll
+                        for (int q2 = 0; q2 < 3; ++q2) w[mu][b2][q2] = PH(b2, q2) * z[mu][0][q2] + DP(b2, q2) * z[mu][1][q2];
+#pragma unroll
+                for (int a2 = 0; a2 < 3; ++a2) {
+                    const int a = g_hex27_node[a0 + 3 * a1 + 9 * a2];
+#pragma unroll
+                    for (int b2 = 0; b2 < 3; ++b2) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int q2 = 0; q2 < 3; ++q2) v += PH(a2, q2) * w[0][b2][q2] + DP(a2, q2) * w[1][b2][q2];
+                        outb[a * ND + 3 * g_hex27_node[b0 + 3 * b1 + 9 * b2] + d] = v;
+                    }
+                }
+            }
+            lds_barrier(); // LDS traffic only: the stores of the previous rows stay in flight
+            // rows (a, c), a = 0 … 26, of Kₑ: assemble!(assembler, dofs, Kₑ)
+            if (atomic == 2) {
+                for (int idx = tid; idx < NB * ND; idx += T) {
+                    const int a = idx / ND, j = idx - a * ND;
+                    ke[((int64_t)cell * ND + 3 * a + c) * ND + j] = outb[idx];
+                }
+            } else {
+                for (int idx = tid; idx < NB * ND; idx += T) {
+                    const int a = idx / ND, j = idx - a * ND, b = j / 3, d = j - 3 * b;
+                    const int64_t k = rowptr[s_dof[3 * a] + c] + blockpos[cell * (NB * NB) + a * NB + b] + d;
+                    if (atomic) unsafeAtomicAdd(nz + k, outb[idx]); else nz[k] += outb[idx];
+                }
+            }
+            lds_barrier(); // LDS traffic only: the stores of the previous rows stay in flight
+        }
     } else {
     // B: sweep the points
     const int a_own = tid / NG, bg = tid % NG;
@@ -562,6 +773,115 @@ k_gather_node_rows(const int32_t *__restrict__ node_dof0, int64_t n_nodes, const
     }
 }
 
+// Gather of the symmetric-packed element matrices (matrix-core path): one wave per node A.  Per cell around A the wave reads ONE contiguous run —
+// the 3×3 blocks of A with every node of higher dof in that cell — sums the runs of its ≤ KC cells in cell order (bit-reproducible), stores the upper
+// part of A's three rows coalesced, and mirrors every block into the rows of the other node B (rows (B,d), columns (A,0..2): 24-byte pieces; nine lanes
+// hold one block, so a store instruction covers 21 pieces).  Every stored byte is read once and every nz written once: 14 + 14 + 19 GB at 80³ instead of
+// 27 + 27 + 19.  Workgroups are dealt to the XCDs in contiguous chunks of nodes, so that the pieces of one cache line of a row — written by the waves
+// of dof-consecutive nodes — meet in one L2.
+template <int NB>
+__global__ void __launch_bounds__(256)
+k_gather_node_rows_sym(const int32_t *__restrict__ node_dof0, int64_t n_nodes, const int64_t *__restrict__ ea_ptr, const int32_t *__restrict__ ea_src,
+                       const double *__restrict__ ke, const uint16_t *__restrict__ blockpos, const uint8_t *__restrict__ rank27,
+                       const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, double *__restrict__ nz, int nbr_max, int64_t ngroups)
+{
+    constexpr int ND = 3 * NB, KC = 16, CH = 21; // CH neighbours × 3 components = 63 lanes per chunk
+    extern __shared__ uint8_t s_raw[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t chunkg = (ngroups + 7) >> 3;
+    const int64_t grp = (int64_t)(blockIdx.x & 7) * chunkg + (blockIdx.x >> 3);
+    if (grp >= ngroups) return;
+    const int64_t node = grp * 4 + wv;
+    if (node >= n_nodes) return;
+    // per-wave LDS: inv[KC][nbr_max] bytes | posAB[nbr_max] u16 | meta[KC] (cell, a, rank) | vals[63 × 3] doubles | tgt[63] int64
+    const size_t per_wave = (size_t)KC * nbr_max + 2 * (size_t)nbr_max + 16 * KC + 63 * 3 * 8 + 64 * 8;
+    uint8_t *base = s_raw + (size_t)wv * ((per_wave + 15) & ~(size_t)15);
+    int32_t *meta = reinterpret_cast<int32_t *>(base);                       // [KC][4]: cell, a, rank of A, unused
+    double *vals = reinterpret_cast<double *>(base + 16 * KC);
+    long long *tgt = reinterpret_cast<long long *>(base + 16 * KC + 63 * 3 * 8);
+    uint16_t *posAB = reinterpret_cast<uint16_t *>(base + 16 * KC + 63 * 3 * 8 + 64 * 8);
+    uint8_t *inv = base + 16 * KC + 63 * 3 * 8 + 64 * 8 + 2 * (size_t)nbr_max;
+
+    const int32_t dof0 = node_dof0[node];
+    const int64_t g0 = rowptr[dof0];
+    const int L = (int)(rowptr[dof0 + 1] - g0); // rows dof0, dof0+1, dof0+2 are consecutive runs of equal length (checked on the host)
+    const int nn = L / 3;
+    const int64_t k0 = ea_ptr[dof0];
+    const int nk = (int)(ea_ptr[dof0 + 1] - k0); // ≤ KC (checked on the host)
+    if (lane < nk) {
+        const int32_t slot = ea_src[k0 + lane];
+        const int32_t cell = slot / ND, a = (slot % ND) / 3;
+        meta[4 * lane] = cell; meta[4 * lane + 1] = a; meta[4 * lane + 2] = rank27[(int64_t)cell * 32 + a];
+    }
+    for (int i = lane; i < (KC * nbr_max) / 4; i += 64) reinterpret_cast<uint32_t *>(inv)[i] = 0xFFFFFFFFu;
+    __builtin_amdgcn_wave_barrier();
+    const int selfpos = blockpos[(int64_t)meta[0] * (NB * NB) + meta[1] * NB + meta[1]] / 3;
+    const int nu = nn - selfpos; // A itself and its neighbours of higher dof
+    for (int i = lane; i < nk * NB; i += 64) {
+        const int k = i / NB, b = i - k * NB;
+        const int64_t cell = meta[4 * k];
+        const int a = meta[4 * k + 1], ra = meta[4 * k + 2];
+        const int rb = rank27[cell * 32 + b];
+        if (rb >= ra) {
+            const int n = blockpos[cell * (NB * NB) + a * NB + b] / 3 - selfpos;
+            inv[k * nbr_max + n] = (uint8_t)(rb - ra);
+            posAB[n] = blockpos[cell * (NB * NB) + b * NB + a]; // position of column (A,0) in the rows of B: the same from every cell holding both
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    const int ln = lane / 3, d = lane - 3 * ln; // lane 63 idles
+    for (int nc0 = 0; nc0 < nu; nc0 += CH) {
+        const int n = nc0 + ln;
+        const bool valid = lane < 63 && n < nu;
+        // mirror target of this (neighbour, component): row (B, d), column (A, 0) — two dependent loads, issued before the element-matrix reads
+        long long t = -1;
+        if (valid && n > 0) {
+            const int32_t dofB = colidx[g0 + 3 * (selfpos + n)];
+            t = rowptr[dofB + d] + posAB[n];
+        }
+        double sum[3] = {0.0, 0.0, 0.0};
+        for (int kb = 0; kb < nk; kb += 8) {
+            double v[8][3];
+            bool ok[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int kk = kb + k < nk ? kb + k : kb;
+                const int rel = valid ? inv[kk * nbr_max + n] : 0xFF;
+                ok[k] = kb + k < nk && rel != 0xFF;
+                const int ra = meta[4 * kk + 2];
+                const double *src = ke + (int64_t)meta[4 * kk] * KE_SYM + (symblk(ra, ra) + (ok[k] ? rel : 0)) * 9 + d;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v[k][c] = ok[k] ? src[3 * c] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) sum[c] += v[k][c];
+        }
+        if (valid) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) nz[g0 + (int64_t)c * L + 3 * (selfpos + n) + d] = sum[c];
+        }
+        // mirror: the block of (A, B) transposed into rows (B, d); nine consecutive lanes-slots hold one block, three consecutive ones one 24-byte piece
+        if (lane < 63) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) vals[3 * lane + c] = sum[c];
+            tgt[lane] = t;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r_ = 0; r_ < 3; ++r_) {
+            const int q = 64 * r_ + lane;
+            if (q < 189) {
+                const long long tt = tgt[q / 3];
+                if (tt >= 0) nz[tt + (q % 3)] = vals[q];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // element residuals → global residual: r[d] = Σ (in cell order) rₑ slots of dof d
 __global__ void k_gather_residual(const int64_t *__restrict__ ptr, const int32_t *__restrict__ src, const double *__restrict__ re, int64_t ndofs,
                                   double *__restrict__ r)
@@ -674,6 +994,33 @@ static int check_node_rows(tb_pattern *p)
     return TB_OK;
 }
 
+// Per cell: rank of every field node among the cell's nodes by global dof (27 bytes, padded to 32) — the order in which the symmetric-packed
+// element matrix stores its node blocks.  rank27_ok < 0: some node sits in more than 16 cells (the mirroring gather keeps 16 cell maps per wave).
+static int ensure_rank27(tb_mesh *m)
+{
+    if (m->rank27_ok) return TB_OK;
+    const int nb = m->nb;
+    if (nb != 27) { m->rank27_ok = -1; return TB_OK; }
+    std::vector<uint8_t> rk((size_t)m->n_cells * 32, 0);
+    std::vector<uint8_t> cnt((size_t)m->ndofs, 0);
+    bool ok = true;
+#pragma omp parallel for schedule(static)
+    for (int64_t c = 0; c < m->n_cells; ++c) {
+        const int32_t *d = &m->h_cell_dofs[c * 3 * nb];
+        for (int a = 0; a < nb; ++a) {
+            int r = 0;
+            for (int b = 0; b < nb; ++b) r += d[3 * b] < d[3 * a];
+            rk[(size_t)c * 32 + a] = (uint8_t)r;
+        }
+    }
+    for (int64_t i = 0; i < m->n_cells * nb; ++i) { uint8_t &k = cnt[m->h_cell_dofs[3 * i]]; if (k == 255 || ++k > 16) ok = false; }
+    if (!ok) { m->rank27_ok = -1; return TB_OK; }
+    int rc = upload(m->dev, rk, &m->d_rank27);
+    if (rc) return rc;
+    m->rank27_ok = 1;
+    return TB_OK;
+}
+
 int ensure_blockpos(tb_pattern *p)
 {
     if (p->d_blockpos) return TB_OK;
@@ -686,9 +1033,10 @@ int ensure_blockpos(tb_pattern *p)
     return TB_OK;
 }
 
-template <class FE, bool NEED_K, bool NEED_R, bool MFMA, bool AD>
+template <class FE, bool NEED_K, bool NEED_R, int CT, bool AD>
 static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, double *d_nz, double *d_r)
 {
+    constexpr bool MFMA = CT == 1;
     tb_mesh *m = f->mesh;
     tb_device *dev = m->dev;
     const MechMesh mm{m->d_xyz, m->d_conn, m->d_cell_dofs, f->d_field, f->cond_model ? nullptr : f->d_act_field, f->cond_model ? f->d_qp_act : nullptr, f->d_u_prev ? 5 : 2};
@@ -708,10 +1056,14 @@ static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, doubl
     const int64_t *rowptr = p ? p->d_rowptr : nullptr;
     const uint16_t *bp = p ? p->d_blockpos : nullptr;
     double *kebuf = nullptr, *rebuf = nullptr;
+    const uint8_t *rank27 = nullptr;
+    constexpr size_t dyn_lds = sizeof(double) * ((NEED_K ? FE::NQ : 1) * 81 + FE::NQ * FE::NB * 3); // 𝔸·dΩ + mapped gradients (s_AG)
     auto go = [&](const int32_t *list, int64_t n, int atomic) -> int {
         if (!n) return TB_OK;
-        hipLaunchKernelGGL((k_hyperelastic<FE, NEED_K, NEED_R, MFMA, AD>), dim3((unsigned)n), dim3(FE::THREADS), 0, dev->stream, mm, hp, ep, list, d_u, d_nz, d_r,
-                           rowptr, bp, atomic, kebuf, rebuf, dev->d_status);
+        auto kern = k_hyperelastic<FE, NEED_K, NEED_R, CT, AD>;
+        TB_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(FE::THREADS), dyn_lds, dev->stream, mm, hp, ep, list, d_u, d_nz, d_r,
+                           rowptr, bp, atomic, kebuf, rebuf, dev->d_status, rank27);
         TB_HIP(hipGetLastError());
         return TB_OK;
     };
@@ -719,16 +1071,41 @@ static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, doubl
         // ElementAssemblyStrategy (default for mechanics): Kₑ / rₑ stored per cell, then gathered per node row
         if (!m->ea) { int rc = build_ea_plan(m); if (rc) return rc; }
         rebuf = m->ea->d_ea;
+        int rc;
+        // TB_MECH_KE=sym: symmetric-packed element matrices + mirroring gather on the matrix-core path (its tangent is symmetric by construction; meshes
+        // where no node sits in more than 16 cells).  A measured alternative, parity-green, slower on MI355X than the full 81 × 81 storage although it
+        // moves 47 GB instead of 73 GB at 80³: integration 23.2 vs 21.3 ms (the store was never the bound; the LDS staging adds two barriers),
+        // gather 15.2 vs 13.3 ms (24-byte mirror pieces cost more than the halved reads save) — profiles/r03_v1/mechanics_sym_vs_full.txt
+        bool sym = false;
+        if (NEED_K && MFMA) {
+            const char *e = getenv("TB_MECH_KE");
+            if (e && !strcmp(e, "sym")) { rc = ensure_rank27(m); if (rc) return rc; sym = m->rank27_ok > 0; }
+        }
         if (NEED_K) {
+            const size_t need = sizeof(double) * (size_t)m->n_cells * (sym ? (size_t)KE_SYM : (size_t)FE::ND * FE::ND);
+            if (p->d_kebuf && p->kebuf_bytes < need) { (void)hipFree(p->d_kebuf); p->d_kebuf = nullptr; }
             if (!p->d_kebuf) {
-                hipError_t e = hipMalloc((void **)&p->d_kebuf, sizeof(double) * (size_t)m->n_cells * FE::ND * FE::ND);
-                if (e != hipSuccess) { set_error("element-matrix buffer (%zu B): %s", sizeof(double) * (size_t)m->n_cells * FE::ND * FE::ND, hipGetErrorString(e)); return TB_ERR_NOMEM; }
+                hipError_t e = hipMalloc((void **)&p->d_kebuf, need);
+                if (e != hipSuccess) { set_error("element-matrix buffer (%zu B): %s", need, hipGetErrorString(e)); return TB_ERR_NOMEM; }
+                p->kebuf_bytes = need;
             }
             kebuf = p->d_kebuf;
+            if (sym) rank27 = m->d_rank27;
         }
-        int rc = go(nullptr, m->n_cells, 2);
+        rc = go(nullptr, m->n_cells, 2);
         if (rc) return rc;
-        if (NEED_K) {
+        if (NEED_K && sym) {
+            if (!m->d_node_dof0) { rc = build_node_list(m); if (rc) return rc; }
+            rc = check_node_rows(p);
+            if (rc) return rc;
+            const int nbr_max = (((int)p->max_row_len / 3) + 3) & ~3;
+            const size_t per_wave = ((size_t)16 * nbr_max + 2 * (size_t)nbr_max + 16 * 16 + 63 * 3 * 8 + 64 * 8 + 15) & ~(size_t)15;
+            const int64_t ngroups = (m->n_nodes_field + 3) / 4;
+            auto k = k_gather_node_rows_sym<FE::NB>;
+            hipLaunchKernelGGL(k, dim3((unsigned)(8 * ((ngroups + 7) / 8))), dim3(256), 4 * per_wave, dev->stream, m->d_node_dof0, m->n_nodes_field, m->ea->d_ptr,
+                               m->ea->d_src, kebuf, bp, rank27, rowptr, p->d_colidx, d_nz, nbr_max, ngroups);
+            TB_HIP(hipGetLastError());
+        } else if (NEED_K) {
             if (!m->d_node_dof0) { rc = build_node_list(m); if (rc) return rc; }
             rc = check_node_rows(p);
             if (rc) return rc;
@@ -886,18 +1263,22 @@ int launch_hyperelastic(tb_form *f, tb_pattern *p, int strategy, const double *d
     const bool q2 = m->field_kind == TB_HEX27;
     if (!q2 && !(m->field_kind == TB_HEX8 && f->qorder == 2)) { set_error("hyperelastic: Q1 field needs quadrature order 2"); return TB_ERR_UNSUPPORTED; }
     if (q2 && f->qorder != 3) { set_error("hyperelastic: Q2 field needs quadrature order 3"); return TB_ERR_UNSUPPORTED; }
-    // Q2 tangents run their contraction on the matrix cores; TB_MECH_MFMA=0 selects the vector-FMA build (comparison)
-    static const bool mfma = !(getenv("TB_MECH_MFMA") && atoi(getenv("TB_MECH_MFMA")) == 0);
+    // Q2 tangents: sum-factorised contraction (default); TB_MECH_CONTRACT=mfma selects the matrix-core build, =vector the plain FMA sweep over
+    // the points (comparison builds; TB_MECH_MFMA=0 is the older spelling of "vector")
+    const char *ce = getenv("TB_MECH_CONTRACT");
+    const bool old_vec = getenv("TB_MECH_MFMA") && atoi(getenv("TB_MECH_MFMA")) == 0;
+    const int ct2 = (ce && !strcmp(ce, "mfma")) ? 1 : ((ce && !strcmp(ce, "vector")) || old_vec) ? 0 : 2;
     const bool ad = !form_is_fast_path(f);
     if (f->cond_model) {
         rc = q2 ? condensed_prepass<Q2Vec>(f, d_u, d_nz != nullptr) : condensed_prepass<Q1Vec>(f, d_u, d_nz != nullptr);
         if (rc) return rc;
     }
     const bool nonsym = f->cond_model && f->d_u_prev; // rate-coupled internal variable: the symmetric-tile matrix-core kernel does not apply
-#define TB_RUN(FEV, K, R, MF) (ad ? run<FEV, K, R, MF, true>(f, p, strategy, d_u, d_nz, d_r) : run<FEV, K, R, MF, false>(f, p, strategy, d_u, d_nz, d_r))
-    if (d_nz && d_r) rc = !q2 ? TB_RUN(Q1Vec, true, true, false) : nonsym ? TB_RUN(Q2Vec, true, true, false) : (mfma || ad) ? TB_RUN(Q2Vec, true, true, true) : run<Q2Vec, true, true, false, false>(f, p, strategy, d_u, d_nz, d_r);
-    else if (d_nz) rc = !q2 ? TB_RUN(Q1Vec, true, false, false) : nonsym ? TB_RUN(Q2Vec, true, false, false) : (mfma || ad) ? TB_RUN(Q2Vec, true, false, true) : run<Q2Vec, true, false, false, false>(f, p, strategy, d_u, d_nz, d_r);
-    else rc = q2 ? TB_RUN(Q2Vec, false, true, false) : TB_RUN(Q1Vec, false, true, false);
+    const int ct = !q2 ? 0 : (ct2 == 1 && nonsym) ? 0 : ct2;
+#define TB_RUN(FEV, K, R, C) (ad ? run<FEV, K, R, C, true>(f, p, strategy, d_u, d_nz, d_r) : run<FEV, K, R, C, false>(f, p, strategy, d_u, d_nz, d_r))
+    if (d_nz && d_r) rc = !q2 ? TB_RUN(Q1Vec, true, true, 0) : ct == 2 ? TB_RUN(Q2Vec, true, true, 2) : ct == 1 ? TB_RUN(Q2Vec, true, true, 1) : TB_RUN(Q2Vec, true, true, 0);
+    else if (d_nz) rc = !q2 ? TB_RUN(Q1Vec, true, false, 0) : ct == 2 ? TB_RUN(Q2Vec, true, false, 2) : ct == 1 ? TB_RUN(Q2Vec, true, false, 1) : TB_RUN(Q2Vec, true, false, 0);
+    else rc = q2 ? TB_RUN(Q2Vec, false, true, 0) : TB_RUN(Q1Vec, false, true, 0);
 #undef TB_RUN
     if (rc) return rc;
     return check_status(m->dev);

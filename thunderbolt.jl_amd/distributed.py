@@ -294,7 +294,13 @@ class DistributedCG:
         return float(s.item())
 
     def apply(self, x):
-        y = self.spmv(x)
+        if self.spmv is None:                                       # operator=(pattern, nz) given instead of a callable
+            from ._lib import check, lib
+            pattern, nz = self.operator
+            y = self.torch.empty_like(x)
+            check(lib().tb_spmv_csr(pattern.h, nz.ptr, x.data_ptr(), 1.0, 0.0, y.data_ptr()))
+        else:
+            y = self.spmv(x)
         self.halo.exchange_sum(y)
         return y
 
@@ -346,6 +352,21 @@ class DistributedCG:
         if self.world > 1:
             all_reduce_sum(S[1:2], self.dist)
 
+    def device_step(self, x, r, p, Ap, S):
+        """One whole CG iteration of the device path, no host read: product + halo + pᵀAp, update of x and r with the two weighted sums, direction.
+        S: device scalars rz | pAp | rz_new | rr | breakdown flag (bench.py times exactly this)."""
+        import ctypes as C
+        from ._lib import check, lib
+        L, dev, n = lib(), self.dev, x.numel()
+        ptr = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        S[1:4].zero_()
+        self.device_iteration(p, Ap, S)
+        check(L.tb_cgd_update(dev.h, n, ptr(self.w), ptr(self.dinv), ptr(p), ptr(Ap), ptr(x), ptr(r), ptr(S[0:1]), ptr(S[1:2]), ptr(S[2:5])))
+        if self.world > 1:
+            all_reduce_sum(S[2:4], self.dist)
+        check(L.tb_cgd_direction(dev.h, n, ptr(self.dinv), ptr(r), ptr(p), ptr(S[0:1]), ptr(S[2:3])))
+        S[0:1].copy_(S[2:3])
+
     def _solve_device(self, b, x, rtol, atol, maxiter):
         import ctypes as C
         from ._lib import check, lib
@@ -368,13 +389,7 @@ class DistributedCG:
         it = 0
         while rn > tol and it < maxiter:
             for _ in range(min(self.look, maxiter - it)):
-                S[1:4].zero_()
-                self.device_iteration(p, Ap, S)
-                check(L.tb_cgd_update(dev.h, n, ptr(self.w), ptr(self.dinv), ptr(p), ptr(Ap), ptr(x), ptr(r), ptr(S[0:1]), ptr(S[1:2]), ptr(S[2:5])))
-                if self.world > 1:
-                    all_reduce_sum(S[2:4], dist)
-                check(L.tb_cgd_direction(dev.h, n, ptr(self.dinv), ptr(r), ptr(p), ptr(S[0:1]), ptr(S[2:3])))
-                S[0:1].copy_(S[2:3])
+                self.device_step(x, r, p, Ap, S)
                 it += 1
             h = S[3:5].cpu()                                         # the one host read of the look: ‖r‖² and the breakdown flag
             if float(h[1]) != 0.0:
