@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--cpu-n", type=int, default=64, help="edge of the CPU-baseline sample mesh")
     ap.add_argument("--keep-du", action="store_true", help="materialise du (dumat) in the reaction step")
     ap.add_argument("--separate", action="store_true", help="assemble M and K with two launches instead of the fused pass")
-    ap.add_argument("--ionic", default="tt06", choices=["pcg2019", "tt06", "fhn"],
+    ap.add_argument("--ionic", default="tt06", choices=["pcg2019", "tt06", "fhn", "ord"],
                     help="ionic model of the reaction step (tt06 = the 19-state model BASELINE's 10M-hex configuration names; "
                          "pcg2019 = the reference's own 7-state model)")
     return ap.parse_args()
@@ -72,8 +72,8 @@ def cpu_baseline(n, kap, threads, ionic="tt06", sizes=(64, 100)):
     1 thread and the best multi-thread count, on the 64³ and 100³ meshes, min over repetitions after a warm-up.  `value` is the
     multi-thread rate on the n³ sample (n = --cpu-n); every other number sits in `table`."""
     from oracle import oracle as o
-    cm = {"pcg2019": o.CELL_PCG2019, "tt06": o.CELL_TT06, "fhn": o.CELL_FHN}[ionic]
-    rdt = {"pcg2019": 0.01, "tt06": 0.001, "fhn": 0.1}[ionic]
+    cm = {"pcg2019": o.CELL_PCG2019, "tt06": o.CELL_TT06, "fhn": o.CELL_FHN, "ord": o.CELL_ORD11}[ionic]
+    rdt = {"pcg2019": 0.01, "tt06": 0.001, "fhn": 0.1, "ord": 0.002}[ionic]
     p = o.cell_default_params(cm)
     cM = o.Coef(o.COEF_CONST_SCALAR, [1.0])
     cK = o.Coef(o.COEF_CONST_TENSOR, kap.ravel(), Cm=1.0, chi=1.0, wrap=True)
@@ -199,9 +199,9 @@ def main():
     nbrs = tb.distributed.slab_neighbours(lo_idx, up_idx, rank, world)
     halo = tb.distributed.HaloExchange(nbrs, dist if world > 1 else None, b, dev)
 
-    model = {"pcg2019": tb.PCG2019, "tt06": tb.TT06, "fhn": tb.FHNModel}[args.ionic]()
+    model = {"pcg2019": tb.PCG2019, "tt06": tb.TT06, "fhn": tb.FHNModel, "ord": tb.ORd2011}[args.ionic]()
     ns = model.nstates
-    rdt = {"pcg2019": 0.01, "tt06": 0.001, "fhn": 0.1}[args.ionic]   # forward-Euler-stable reaction step sizes
+    rdt = {"pcg2019": 0.01, "tt06": 0.001, "fhn": 0.1, "ord": 0.002}[args.ionic]   # forward-Euler-stable reaction step sizes
     npts = dh.ndofs
     u0 = np.tile(model.default_initial_state(), (npts, 1))
     u0[:, model.phi_index] += np.linspace(0.0, 60.0 if ns > 2 else 1.0, npts)

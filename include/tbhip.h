@@ -53,8 +53,11 @@ enum { TB_QUAD4 = 2 /* bilinear quadrilateral in the plane z = 0 (2-D problems; 
 enum {
     TB_STRATEGY_ATOMIC = 0,    /* one thread per cell, FP64 hardware atomics                                   */
     TB_STRATEGY_PER_COLOR = 1, /* PerColorAssemblyStrategy: colours in sequence, plain read-modify-write       */
-    TB_STRATEGY_ELEMENT = 2,   /* ElementAssemblyStrategy: element vectors stored, gathered per dof (vectors;  */
-                               /* forced for the source term by src/solver/time/euler.jl:148-153)              */
+    TB_STRATEGY_ELEMENT = 2,   /* ElementAssemblyStrategy: element contributions summed per dof / row in cell   */
+                               /* order, no atomics, bit-reproducible (forced for the source term by            */
+                               /* src/solver/time/euler.jl:148-153).  Vectors and quadratic-field matrices store */
+                               /* the element vectors / matrices and gather them; matrices of first-order fields */
+                               /* get the same ordered sums from the patch kernels without the stored copy      */
     TB_STRATEGY_PATCH = 3      /* native: Morton patches of cells, rows accumulated in LDS, each nz / dof      */
                                /* written exactly once with coalesced stores (default, fastest)                */
 };
@@ -126,7 +129,10 @@ enum {
     TB_CELL_FHN = 0, TB_CELL_ALIEV_PANFILOV = 1, TB_CELL_PCG2019 = 2,
     TB_CELL_TT06 = 3, /* ten Tusscher–Panfilov 2006 (epi): EXTENSION, not in the reference (BASELINE config 3 names it) */
     TB_CELL_FHN_HETEROGENEOUS = 4 /* HeterogeneousFHNModel of docs/src/literate-howto/custom-ep-cell-model.jl:8-56 with the recovery rate an affine
-                                     function of the point coordinate, e(x) = e0 + g·x: parameters (a, b, c, d, e0, gx, gy, gz); needs d_x */
+                                     function of the point coordinate, e(x) = e0 + g·x: parameters (a, b, c, d, e0, gx, gy, gz); needs d_x */,
+    TB_CELL_ORD11 = 5 /* O'Hara–Virág–Varró–Rudy 2011 human ventricular model, 41 states: EXTENSION (SURVEY §8 f4 names it; the reference has the
+                         reaction_rhs! / state_rhs! hooks only, src/modeling/cells/fhn.jl:36-60).  17 parameters: scalings of GNa, GNaL, Gto, PCa,
+                         GKr, GKs, GK1, Gncx, Pnak, GKb, PNab, PCab, GpCa (1 = published), nao, cao, ko [mM], cell type (0 endo, 1 epi, 2 M) */
 };
 enum {
     TB_LAYOUT_SOA = 0, /* StateBlockedLayout: u[k + s·npoints]  */
@@ -366,7 +372,7 @@ int tb_reaction_step_rtc(tb_device *dev, int model, const double *params, int n_
 /* Rush–Larsen step (SURVEY §8 f4 — the reference carries only the reaction_rhs!/state_rhs! hooks for it, src/modeling/cells/fhn.jl:36-60):
  * Hodgkin–Huxley-type gates are advanced with the exact solution of their linear ODE for frozen φₘ, every other state by forward
  * Euler.  Lifts the fast-gate stability limit of forward Euler (TT06: Δt = 0.02 ms in one evaluation instead of twenty sub-steps).
- * TB_CELL_TT06 and TB_CELL_PCG2019 (whose six gates relax as (g∞ − g)/τ_g, src/modeling/cells/pcg2019.jl:96-118); other models return
+ * TB_CELL_TT06, TB_CELL_ORD11 and TB_CELL_PCG2019 (whose six gates relax as (g∞ − g)/τ_g, src/modeling/cells/pcg2019.jl:96-118); other models return
  * TB_ERR_UNSUPPORTED. */
 int tb_reaction_step_rl(tb_device *dev, int model, const double *params, int n_params, double *d_u, int64_t n_points, int n_states,
                         int layout, double t, double dt);

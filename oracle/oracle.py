@@ -17,7 +17,7 @@ LINE2, QUAD4, HEX8, TET4, HEX27 = 1, 2, 3, 4, 5
 COEF_CONST_SCALAR, COEF_CONST_TENSOR, COEF_FIELD_SCALAR = 0, 1, 2
 COEF_SPECTRAL_CONST, COEF_SPECTRAL_FIELD, COEF_TRANSVERSE_CONST = 3, 4, 5
 SRC_CONST, SRC_NORM_PLUS_T, SRC_COS_EXP, SRC_TABULATED = 0, 1, 2, 3
-CELL_FHN, CELL_ALIEV_PANFILOV, CELL_PCG2019, CELL_TT06, CELL_FHN_HETEROGENEOUS = 0, 1, 2, 3, 4
+CELL_FHN, CELL_ALIEV_PANFILOV, CELL_PCG2019, CELL_TT06, CELL_FHN_HETEROGENEOUS, CELL_ORD11 = 0, 1, 2, 3, 4, 5
 LAYOUT_SOA, LAYOUT_AOS = 0, 1
 
 _dp = C.POINTER(C.c_double)

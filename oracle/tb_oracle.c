@@ -763,8 +763,8 @@ int orc_assemble_source(const orc_mesh *m, int src_kind, const double *p, const 
 /* ionic models                                                                                */
 /* ------------------------------------------------------------------------------------------ */
 
-int orc_cell_nstates(int model) { return model == ORC_CELL_TT06 ? 19 : model == ORC_CELL_PCG2019 ? 7 : (model == ORC_CELL_FHN || model == ORC_CELL_ALIEV_PANFILOV || model == ORC_CELL_FHN_HETEROGENEOUS) ? 2 : -1; }
-int orc_cell_nparams(int model) { return model == ORC_CELL_TT06 ? 48 : model == ORC_CELL_PCG2019 ? 36 : model == ORC_CELL_FHN_HETEROGENEOUS ? 8 : (model == ORC_CELL_FHN || model == ORC_CELL_ALIEV_PANFILOV) ? 6 : -1; }
+int orc_cell_nstates(int model) { return model == ORC_CELL_ORD11 ? 41 : model == ORC_CELL_TT06 ? 19 : model == ORC_CELL_PCG2019 ? 7 : (model == ORC_CELL_FHN || model == ORC_CELL_ALIEV_PANFILOV || model == ORC_CELL_FHN_HETEROGENEOUS) ? 2 : -1; }
+int orc_cell_nparams(int model) { return model == ORC_CELL_ORD11 ? 17 : model == ORC_CELL_TT06 ? 48 : model == ORC_CELL_PCG2019 ? 36 : model == ORC_CELL_FHN_HETEROGENEOUS ? 8 : (model == ORC_CELL_FHN || model == ORC_CELL_ALIEV_PANFILOV) ? 6 : -1; }
 
 /* PCG2019 parameter order = struct field order, src/modeling/cells/pcg2019.jl:4-48 */
 enum { P_gNa, P_Em, P_km, P_taum, P_Eh, P_kh, P_dh, P_tauh0, P_gK1, P_Ez, P_kz, P_gto, P_Er, P_kr, P_Es, P_ks,
@@ -797,6 +797,9 @@ void orc_cell_default_params(int model, double *p)
                               0.006375, 0.00025, 0.102, 0.15, 0.045, 0.060, 0.005, 1.5, 2.5, 1.0, 0.00036, 0.0038,
                               0.185, 0.03, 1.0, 40.0, 87.5, 1.38, 0.1, 0.35, 0.0005, 8314.472, 310.0, 96485.3415};
         memcpy(p, d, sizeof d);
+    } else if (model == ORC_CELL_ORD11) { /* O'Hara–Rudy 2011: unit conductance scalings, nao / cao / ko of the paper, endocardial cell */
+        const double d[17] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 140.0, 1.8, 5.4, 0.0};
+        memcpy(p, d, sizeof d);
     }
 }
 
@@ -807,6 +810,12 @@ void orc_cell_default_state(int model, const double *p, double *u0)
 {
     if (model == ORC_CELL_TT06) { /* resting state of the authors' reference implementation */
         const double d[19] = {-86.2, 0.00007, 1.3, 0.00007, 7.67, 138.3, 0.0, 0.75, 0.75, 0.0, 1.0, 0.0, 0.0, 1.0, 0.0, 1.0, 1.0, 1.0, 1.0};
+        memcpy(u0, d, sizeof d);
+        return;
+    }
+    if (model == ORC_CELL_ORD11) { /* initial state of the paper's supplement (its published code) */
+        const double d[41] = {-87.0, 7.0, 7.0, 145.0, 145.0, 1.0e-4, 1.0e-4, 1.2, 1.2, 0.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.0, 1.0, 1.0, 0.0, 1.0, 1.0, 0.0, 1.0, 1.0,
+                              0.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0};
         memcpy(u0, d, sizeof d);
         return;
     }
@@ -929,10 +938,247 @@ static void tt06_rhs_rates(const double *p, const double *u, double *du, double 
 
 static void tt06_rhs(const double *p, const double *u, double *du) { tt06_rhs_rates(p, u, du, NULL); }
 
+/* O'Hara, Virág, Varró & Rudy 2011 (PLoS Comput Biol 7(5): e1002061), human ventricular action-potential model, 41 states:
+ *   v, nai, nass, ki, kss, cai, cass, cansr, cajsr, m, hf, hs, j, hsp, jp, mL, hL, hLp, a, iF, iS, ap, iFp, iSp, d, ff, fs, fcaf, fcas, jca, nca,
+ *   ffp, fcafp, xrf, xrs, xs1, xs2, xk1, Jrelnp, Jrelp, CaMKt
+ * Parameters p[0..17): scale factors of the thirteen conductances / permeabilities (GNa, GNaL, Gto, PCa, GKr, GKs, GK1, Gncx, Pnak, GKb, PNab, PCab,
+ * GpCa; 1 = published value), nao, cao, ko [mM], cell type (0 endo, 1 epi, 2 M).  Every other constant is the published one.
+ * EXTENSION (SURVEY §8 f4 names the model; the reference carries only the hooks, src/modeling/cells/fhn.jl:36-60): restated from the paper's
+ * equations and its supplement's initial state, pinned on the paper's endocardial action-potential numbers (tests/test_ord_known_answer.py).
+ * rate: NULL, or 41 slots receiving 1/τ of the Hodgkin–Huxley-type gates (0 for the other states) — for the Rush–Larsen step. */
+static void ord_rhs_rates(const double *p, const double *u, double *du, double *rate)
+{
+    double rloc[41];
+    if (!rate) rate = rloc;
+    for (int k = 0; k < 41; ++k) rate[k] = 0.0;
+    const double nao = p[13], cao = p[14], ko = p[15];
+    const int celltype = (int)p[16];
+    const double R = 8314.0, T = 310.0, F = 96485.0;
+    const double L = 0.01, rad = 0.0011, vcell = 1000 * 3.14 * rad * rad * L, Ageo = 2 * 3.14 * rad * rad + 2 * 3.14 * rad * L, Acap = 2 * Ageo;
+    const double vmyo = 0.68 * vcell, vnsr = 0.0552 * vcell, vjsr = 0.0048 * vcell, vss = 0.02 * vcell;
+    const double v = u[0], nai = u[1], nass = u[2], ki = u[3], kss = u[4], cai = u[5], cass = u[6], cansr = u[7], cajsr = u[8], m = u[9], hf = u[10],
+                 hs = u[11], j = u[12], hsp = u[13], jp = u[14], mL = u[15], hL = u[16], hLp = u[17], a = u[18], iF = u[19], iS = u[20], ap = u[21],
+                 iFp = u[22], iSp = u[23], d = u[24], ff = u[25], fs = u[26], fcaf = u[27], fcas = u[28], jca = u[29], nca = u[30], ffp = u[31],
+                 fcafp = u[32], xrf = u[33], xrs = u[34], xs1 = u[35], xs2 = u[36], xk1 = u[37], Jrelnp = u[38], Jrelp = u[39], CaMKt = u[40];
+    /* CaMK */
+    const double KmCaMK = 0.15, aCaMK = 0.05, bCaMK = 0.00068, CaMKo = 0.05, KmCaM = 0.0015;
+    const double CaMKb = CaMKo * (1.0 - CaMKt) / (1.0 + KmCaM / cass), CaMKa = CaMKb + CaMKt;
+    du[40] = aCaMK * CaMKb * (CaMKb + CaMKt) - bCaMK * CaMKt;
+    const double fp_all = 1.0 / (1.0 + KmCaMK / CaMKa); /* the same phosphorylated fraction enters INa, INaL, Ito, ICaL, Jrel, Jup */
+    /* reversal potentials */
+    const double ENa = (R * T / F) * log(nao / nai), EK = (R * T / F) * log(ko / ki), PKNa = 0.01833;
+    const double EKs = (R * T / F) * log((ko + PKNa * nao) / (ki + PKNa * nai));
+    const double vffrt = v * F * F / (R * T), vfrt = v * F / (R * T);
+    /* INa */
+    const double mss = 1.0 / (1.0 + exp((-(v + 39.57)) / 9.871));
+    const double tm = 1.0 / (6.765 * exp((v + 11.64) / 34.77) + 8.552 * exp(-(v + 77.42) / 5.955));
+    const double hss = 1.0 / (1 + exp((v + 82.90) / 6.086));
+    const double thf = 1.0 / (1.432e-5 * exp(-(v + 1.196) / 6.285) + 6.149 * exp((v + 0.5096) / 20.27));
+    const double ths = 1.0 / (0.009794 * exp(-(v + 17.95) / 28.05) + 0.3343 * exp((v + 5.730) / 56.66));
+    const double Ahf = 0.99, Ahs = 1.0 - Ahf;
+    const double h = Ahf * hf + Ahs * hs;
+    const double jss = hss;
+    const double tj = 2.038 + 1.0 / (0.02136 * exp(-(v + 100.6) / 8.281) + 0.3052 * exp((v + 0.9941) / 38.45));
+    const double hssp = 1.0 / (1 + exp((v + 89.1) / 6.086));
+    const double thsp = 3.0 * ths;
+    const double hp = Ahf * hf + Ahs * hsp;
+    const double tjp = 1.46 * tj;
+    const double GNa = 75.0 * p[0];
+    const double INa = GNa * (v - ENa) * m * m * m * ((1.0 - fp_all) * h * j + fp_all * hp * jp);
+    /* INaL */
+    const double mLss = 1.0 / (1.0 + exp((-(v + 42.85)) / 5.264));
+    const double tmL = tm;
+    const double hLss = 1.0 / (1.0 + exp((v + 87.61) / 7.488));
+    const double thL = 200.0;
+    const double hLssp = 1.0 / (1.0 + exp((v + 93.81) / 7.488));
+    const double thLp = 3.0 * thL;
+    double GNaL = 0.0075 * p[1];
+    if (celltype == 1) GNaL *= 0.6;
+    const double INaL = GNaL * (v - ENa) * mL * ((1.0 - fp_all) * hL + fp_all * hLp);
+    /* Ito */
+    const double ass = 1.0 / (1.0 + exp((-(v - 14.34)) / 14.82));
+    const double ta = 1.0515 / (1.0 / (1.2089 * (1.0 + exp(-(v - 18.4099) / 29.3814))) + 3.5 / (1.0 + exp((v + 100.0) / 29.3814)));
+    const double iss = 1.0 / (1.0 + exp((v + 43.94) / 5.711));
+    const double delta_epi = celltype == 1 ? 1.0 - (0.95 / (1.0 + exp((v + 70.0) / 5.0))) : 1.0;
+    double tiF = 4.562 + 1 / (0.3933 * exp((-(v + 100.0)) / 100.0) + 0.08004 * exp((v + 50.0) / 16.59));
+    double tiS = 23.62 + 1 / (0.001416 * exp((-(v + 96.52)) / 59.05) + 1.780e-8 * exp((v + 114.1) / 8.079));
+    tiF *= delta_epi;
+    tiS *= delta_epi;
+    const double AiF = 1.0 / (1.0 + exp((v - 213.6) / 151.2)), AiS = 1.0 - AiF;
+    const double i_ = AiF * iF + AiS * iS;
+    const double assp = 1.0 / (1.0 + exp((-(v - 24.34)) / 14.82));
+    const double dti_develop = 1.354 + 1.0e-4 / (exp((v - 167.4) / 15.89) + exp(-(v - 12.23) / 0.2154));
+    const double dti_recover = 1.0 - 0.5 / (1.0 + exp((v + 70.0) / 20.0));
+    const double tiFp = dti_develop * dti_recover * tiF, tiSp = dti_develop * dti_recover * tiS;
+    const double ip = AiF * iFp + AiS * iSp;
+    double Gto = 0.02 * p[2];
+    if (celltype == 1 || celltype == 2) Gto *= 4.0;
+    const double Ito = Gto * (v - EK) * ((1.0 - fp_all) * a * i_ + fp_all * ap * ip);
+    /* ICaL, ICaNa, ICaK */
+    const double dss = 1.0 / (1.0 + exp((-(v + 3.940)) / 4.230));
+    const double td = 0.6 + 1.0 / (exp(-0.05 * (v + 6.0)) + exp(0.09 * (v + 14.0)));
+    const double fss = 1.0 / (1.0 + exp((v + 19.58) / 3.696));
+    const double tff = 7.0 + 1.0 / (0.0045 * exp(-(v + 20.0) / 10.0) + 0.0045 * exp((v + 20.0) / 10.0));
+    const double tfs = 1000.0 + 1.0 / (0.000035 * exp(-(v + 5.0) / 4.0) + 0.000035 * exp((v + 5.0) / 6.0));
+    const double Aff = 0.6, Afs = 1.0 - Aff;
+    const double f = Aff * ff + Afs * fs;
+    const double fcass = fss;
+    const double tfcaf = 7.0 + 1.0 / (0.04 * exp(-(v - 4.0) / 7.0) + 0.04 * exp((v - 4.0) / 7.0));
+    const double tfcas = 100.0 + 1.0 / (0.00012 * exp(-v / 3.0) + 0.00012 * exp(v / 7.0));
+    const double Afcaf = 0.3 + 0.6 / (1.0 + exp((v - 10.0) / 10.0)), Afcas = 1.0 - Afcaf;
+    const double fca = Afcaf * fcaf + Afcas * fcas;
+    const double tjca = 75.0;
+    const double tffp = 2.5 * tff;
+    const double fp = Aff * ffp + Afs * fs;
+    const double tfcafp = 2.5 * tfcaf;
+    const double fcap = Afcaf * fcafp + Afcas * fcas;
+    const double Kmn = 0.002, k2n = 1000.0, km2n = jca * 1.0;
+    const double anca = 1.0 / (k2n / km2n + pow(1.0 + Kmn / cass, 4.0));
+    du[30] = anca * k2n - nca * km2n;
+    const double e2 = exp(2.0 * vfrt), e1 = exp(1.0 * vfrt);
+    const double PhiCaL = 4.0 * vffrt * (cass * e2 - 0.341 * cao) / (e2 - 1.0);
+    const double PhiCaNa = 1.0 * vffrt * (0.75 * nass * e1 - 0.75 * nao) / (e1 - 1.0);
+    const double PhiCaK = 1.0 * vffrt * (0.75 * kss * e1 - 0.75 * ko) / (e1 - 1.0);
+    const double zca = 2.0;
+    double PCa = 0.0001 * p[3];
+    if (celltype == 1) PCa *= 1.2;
+    if (celltype == 2) PCa *= 2.5;
+    const double PCap = 1.1 * PCa, PCaNa = 0.00125 * PCa, PCaK = 3.574e-4 * PCa, PCaNap = 0.00125 * PCap, PCaKp = 3.574e-4 * PCap;
+    const double gnp = d * (f * (1.0 - nca) + jca * fca * nca), gp = d * (fp * (1.0 - nca) + jca * fcap * nca);
+    const double ICaL = (1.0 - fp_all) * PCa * PhiCaL * gnp + fp_all * PCap * PhiCaL * gp;
+    const double ICaNa = (1.0 - fp_all) * PCaNa * PhiCaNa * gnp + fp_all * PCaNap * PhiCaNa * gp;
+    const double ICaK = (1.0 - fp_all) * PCaK * PhiCaK * gnp + fp_all * PCaKp * PhiCaK * gp;
+    /* IKr */
+    const double xrss = 1.0 / (1.0 + exp((-(v + 8.337)) / 6.789));
+    const double txrf = 12.98 + 1.0 / (0.3652 * exp((v - 31.66) / 3.869) + 4.123e-5 * exp((-(v - 47.78)) / 20.38));
+    const double txrs = 1.865 + 1.0 / (0.06629 * exp((v - 34.70) / 7.355) + 1.128e-5 * exp((-(v - 29.74)) / 25.94));
+    const double Axrf = 1.0 / (1.0 + exp((v + 54.81) / 38.21)), Axrs = 1.0 - Axrf;
+    const double xr = Axrf * xrf + Axrs * xrs;
+    const double rkr = 1.0 / (1.0 + exp((v + 55.0) / 75.0)) * 1.0 / (1.0 + exp((v - 10.0) / 30.0));
+    double GKr = 0.046 * p[4];
+    if (celltype == 1) GKr *= 1.3;
+    if (celltype == 2) GKr *= 0.8;
+    const double IKr = GKr * sqrt(ko / 5.4) * xr * rkr * (v - EK);
+    /* IKs */
+    const double xs1ss = 1.0 / (1.0 + exp((-(v + 11.60)) / 8.932));
+    const double txs1 = 817.3 + 1.0 / (2.326e-4 * exp((v + 48.28) / 17.80) + 0.001292 * exp((-(v + 210.0)) / 230.0));
+    const double xs2ss = xs1ss;
+    const double txs2 = 1.0 / (0.01 * exp((v - 50.0) / 20.0) + 0.0193 * exp((-(v + 66.54)) / 31.0));
+    const double KsCa = 1.0 + 0.6 / (1.0 + pow(3.8e-5 / cai, 1.4));
+    double GKs = 0.0034 * p[5];
+    if (celltype == 1) GKs *= 1.4;
+    const double IKs = GKs * KsCa * xs1 * xs2 * (v - EKs);
+    /* IK1 */
+    const double xk1ss = 1.0 / (1.0 + exp(-(v + 2.5538 * ko + 144.59) / (1.5692 * ko + 3.8115)));
+    const double txk1 = 122.2 / (exp((-(v + 127.2)) / 20.36) + exp((v + 236.8) / 69.33));
+    const double rk1 = 1.0 / (1.0 + exp((v + 105.8 - 2.6 * ko) / 9.493));
+    double GK1 = 0.1908 * p[6];
+    if (celltype == 1) GK1 *= 1.2;
+    if (celltype == 2) GK1 *= 1.3;
+    const double IK1 = GK1 * sqrt(ko) * rk1 * xk1 * (v - EK);
+    /* INaCa: the same cycle in the myoplasm (80 %) and the subspace (20 %) */
+    const double kna1 = 15.0, kna2 = 5.0, kna3 = 88.12, kasymm = 12.5, wna = 6.0e4, wca = 6.0e4, wnaca = 5.0e3, kcaon = 1.5e6, kcaoff = 5.0e3,
+                 qna = 0.5224, qca = 0.1670, KmCaAct = 150.0e-6, zna = 1.0;
+    const double hca = exp((qca * v * F) / (R * T)), hna = exp((qna * v * F) / (R * T));
+    double Gncx = 0.0008 * p[7];
+    if (celltype == 1) Gncx *= 1.1;
+    if (celltype == 2) Gncx *= 1.4;
+    double INaCa_c[2];
+    for (int w = 0; w < 2; ++w) {
+        const double na = w == 0 ? nai : nass, ca = w == 0 ? cai : cass;
+        const double h1 = 1 + na / kna3 * (1 + hna), h2 = (na * hna) / (kna3 * h1), h3 = 1.0 / h1;
+        const double h4 = 1.0 + na / kna1 * (1 + na / kna2), h5 = na * na / (h4 * kna1 * kna2), h6 = 1.0 / h4;
+        const double h7 = 1.0 + nao / kna3 * (1.0 + 1.0 / hna), h8 = nao / (kna3 * hna * h7), h9 = 1.0 / h7;
+        const double h10 = kasymm + 1.0 + nao / kna1 * (1.0 + nao / kna2), h11 = nao * nao / (h10 * kna1 * kna2), h12 = 1.0 / h10;
+        const double k1 = h12 * cao * kcaon, k2 = kcaoff, k3p = h9 * wca, k3pp = h8 * wnaca, k3 = k3p + k3pp;
+        const double k4p = h3 * wca / hca, k4pp = h2 * wnaca, k4 = k4p + k4pp, k5 = kcaoff, k6 = h6 * ca * kcaon, k7 = h5 * h2 * wna, k8 = h8 * h11 * wna;
+        const double x1 = k2 * k4 * (k7 + k6) + k5 * k7 * (k2 + k3), x2 = k1 * k7 * (k4 + k5) + k4 * k6 * (k1 + k8);
+        const double x3 = k1 * k3 * (k7 + k6) + k8 * k6 * (k2 + k3), x4 = k2 * k8 * (k4 + k5) + k3 * k5 * (k1 + k8);
+        const double xs_ = x1 + x2 + x3 + x4, E1 = x1 / xs_, E2 = x2 / xs_, E3 = x3 / xs_, E4 = x4 / xs_;
+        const double allo = 1.0 / (1.0 + pow(KmCaAct / ca, 2.0));
+        const double JncxNa = 3.0 * (E4 * k7 - E1 * k8) + E3 * k4pp - E2 * k3pp, JncxCa = E2 * k2 - E1 * k1;
+        INaCa_c[w] = (w == 0 ? 0.8 : 0.2) * Gncx * allo * (zna * JncxNa + zca * JncxCa);
+    }
+    const double INaCa_i = INaCa_c[0], INaCa_ss = INaCa_c[1];
+    /* INaK */
+    const double k1p = 949.5, k1m = 182.4, k2p = 687.2, k2m = 39.4, k3p_ = 1899.0, k3m = 79300.0, k4p_ = 639.0, k4m = 40.0, Knai0 = 9.073, Knao0 = 27.78,
+                 delta = -0.1550;
+    const double Knai = Knai0 * exp((delta * v * F) / (3.0 * R * T)), Knao = Knao0 * exp(((1.0 - delta) * v * F) / (3.0 * R * T));
+    const double Kki = 0.5, Kko = 0.3582, MgADP = 0.05, MgATP = 9.8, Kmgatp = 1.698e-7, H = 1.0e-7, eP = 4.2, Khp = 1.698e-7, Knap = 224.0, Kxkur = 292.0;
+    const double P = eP / (1.0 + H / Khp + nai / Knap + ki / Kxkur);
+    const double dni = pow(1.0 + nai / Knai, 3.0) + pow(1.0 + ki / Kki, 2.0) - 1.0, dno = pow(1.0 + nao / Knao, 3.0) + pow(1.0 + ko / Kko, 2.0) - 1.0;
+    const double a1 = (k1p * pow(nai / Knai, 3.0)) / dni, b1 = k1m * MgADP, a2 = k2p, b2 = (k2m * pow(nao / Knao, 3.0)) / dno;
+    const double a3 = (k3p_ * pow(ko / Kko, 2.0)) / dno, b3 = (k3m * P * H) / (1.0 + MgATP / Kmgatp);
+    const double a4 = (k4p_ * MgATP / Kmgatp) / (1.0 + MgATP / Kmgatp), b4 = (k4m * pow(ki / Kki, 2.0)) / dni;
+    const double y1 = a4 * a1 * a2 + b2 * b4 * b3 + a2 * b4 * b3 + b3 * a1 * a2, y2 = b2 * b1 * b4 + a1 * a2 * a3 + a3 * b1 * b4 + a2 * a3 * b4;
+    const double y3 = a2 * a3 * a4 + b3 * b2 * b1 + b2 * b1 * a4 + a3 * a4 * b1, y4 = b4 * b3 * b2 + a3 * a4 * a1 + b2 * a4 * a1 + b3 * b2 * a1;
+    const double ys = y1 + y2 + y3 + y4, F1 = y1 / ys, F2 = y2 / ys, F3 = y3 / ys, F4 = y4 / ys;
+    const double zk = 1.0, JnakNa = 3.0 * (F1 * a3 - F2 * b3), JnakK = 2.0 * (F4 * b1 - F3 * a1);
+    double Pnak = 30 * p[8];
+    if (celltype == 1) Pnak *= 0.9;
+    if (celltype == 2) Pnak *= 0.7;
+    const double INaK = Pnak * (zna * JnakNa + zk * JnakK);
+    /* background currents, sarcolemmal calcium pump */
+    const double xkb = 1.0 / (1.0 + exp(-(v - 14.48) / 18.34));
+    double GKb = 0.003 * p[9];
+    if (celltype == 1) GKb *= 0.6;
+    const double IKb = GKb * xkb * (v - EK);
+    const double PNab = 3.75e-10 * p[10], INab = PNab * vffrt * (nai * e1 - nao) / (e1 - 1.0);
+    const double PCab = 2.5e-8 * p[11], ICab = PCab * 4.0 * vffrt * (cai * e2 - 0.341 * cao) / (e2 - 1.0);
+    const double GpCa = 0.0005 * p[12], IpCa = GpCa * cai / (0.0005 + cai);
+    du[0] = -(INa + INaL + Ito + ICaL + ICaNa + ICaK + IKr + IKs + IK1 + INaCa_i + INaCa_ss + INaK + INab + IKb + IpCa + ICab);
+    /* fluxes */
+    const double JdiffNa = (nass - nai) / 2.0, JdiffK = (kss - ki) / 2.0, Jdiff = (cass - cai) / 0.2;
+    const double bt = 4.75, a_rel = 0.5 * bt;
+    double Jrel_inf = a_rel * (-ICaL) / (1.0 + pow(1.5 / cajsr, 8.0));
+    if (celltype == 2) Jrel_inf *= 1.7;
+    double tau_rel = bt / (1.0 + 0.0123 / cajsr);
+    if (tau_rel < 0.001) tau_rel = 0.001;
+    du[38] = (Jrel_inf - Jrelnp) / tau_rel;
+    const double btp = 1.25 * bt, a_relp = 0.5 * btp;
+    double Jrel_infp = a_relp * (-ICaL) / (1.0 + pow(1.5 / cajsr, 8.0));
+    if (celltype == 2) Jrel_infp *= 1.7;
+    double tau_relp = btp / (1.0 + 0.0123 / cajsr);
+    if (tau_relp < 0.001) tau_relp = 0.001;
+    du[39] = (Jrel_infp - Jrelp) / tau_relp;
+    const double Jrel = (1.0 - fp_all) * Jrelnp + fp_all * Jrelp;
+    double Jupnp = 0.004375 * cai / (cai + 0.00092), Jupp = 2.75 * 0.004375 * cai / (cai + 0.00092 - 0.00017);
+    if (celltype == 1) { Jupnp *= 1.3; Jupp *= 1.3; }
+    const double Jleak = 0.0039375 * cansr / 15.0;
+    const double Jup = (1.0 - fp_all) * Jupnp + fp_all * Jupp - Jleak;
+    const double Jtr = (cansr - cajsr) / 100.0;
+    /* concentrations */
+    du[1] = -(INa + INaL + 3.0 * INaCa_i + 3.0 * INaK + INab) * Acap / (F * vmyo) + JdiffNa * vss / vmyo;
+    du[2] = -(ICaNa + 3.0 * INaCa_ss) * Acap / (F * vss) - JdiffNa;
+    du[3] = -(Ito + IKr + IKs + IK1 + IKb - 2.0 * INaK) * Acap / (F * vmyo) + JdiffK * vss / vmyo;
+    du[4] = -(ICaK)*Acap / (F * vss) - JdiffK;
+    double cmdnmax = 0.05;
+    if (celltype == 1) cmdnmax *= 1.3;
+    const double kmcmdn = 0.00238, trpnmax = 0.07, kmtrpn = 0.0005, BSRmax = 0.047, KmBSR = 0.00087, BSLmax = 1.124, KmBSL = 0.0087, csqnmax = 10.0, kmcsqn = 0.8;
+    const double Bcai = 1.0 / (1.0 + cmdnmax * kmcmdn / pow(kmcmdn + cai, 2.0) + trpnmax * kmtrpn / pow(kmtrpn + cai, 2.0));
+    du[5] = Bcai * (-(IpCa + ICab - 2.0 * INaCa_i) * Acap / (2.0 * F * vmyo) - Jup * vnsr / vmyo + Jdiff * vss / vmyo);
+    const double Bcass = 1.0 / (1.0 + BSRmax * KmBSR / pow(KmBSR + cass, 2.0) + BSLmax * KmBSL / pow(KmBSL + cass, 2.0));
+    du[6] = Bcass * (-(ICaL - 2.0 * INaCa_ss) * Acap / (2.0 * F * vss) + Jrel * vjsr / vss - Jdiff);
+    du[7] = Jup - Jtr * vjsr / vnsr;
+    const double Bcajsr = 1.0 / (1.0 + csqnmax * kmcsqn / pow(kmcsqn + cajsr, 2.0));
+    du[8] = Bcajsr * (Jtr - Jrel);
+    /* gates */
+#define ORD_GATE(k, inf, tau) do { rate[k] = 1.0 / (tau); du[k] = ((inf) - u[k]) / (tau); } while (0)
+    ORD_GATE(9, mss, tm); ORD_GATE(10, hss, thf); ORD_GATE(11, hss, ths); ORD_GATE(12, jss, tj); ORD_GATE(13, hssp, thsp); ORD_GATE(14, jss, tjp);
+    ORD_GATE(15, mLss, tmL); ORD_GATE(16, hLss, thL); ORD_GATE(17, hLssp, thLp);
+    ORD_GATE(18, ass, ta); ORD_GATE(19, iss, tiF); ORD_GATE(20, iss, tiS); ORD_GATE(21, assp, ta); ORD_GATE(22, iss, tiFp); ORD_GATE(23, iss, tiSp);
+    ORD_GATE(24, dss, td); ORD_GATE(25, fss, tff); ORD_GATE(26, fss, tfs); ORD_GATE(27, fcass, tfcaf); ORD_GATE(28, fcass, tfcas); ORD_GATE(29, fcass, tjca);
+    ORD_GATE(31, fss, tffp); ORD_GATE(32, fcass, tfcafp);
+    ORD_GATE(33, xrss, txrf); ORD_GATE(34, xrss, txrs); ORD_GATE(35, xs1ss, txs1); ORD_GATE(36, xs2ss, txs2); ORD_GATE(37, xk1ss, txk1);
+#undef ORD_GATE
+}
+
+
 void orc_cell_rhs(int model, const double *p, const double *u, double t, double *du)
 {
     (void)t;
     if (model == ORC_CELL_TT06) { tt06_rhs(p, u, du); return; }
+    if (model == ORC_CELL_ORD11) { ord_rhs_rates(p, u, du, NULL); return; }
     if (model == ORC_CELL_FHN) { /* cells/fhn.jl:21-34 */
         double a = p[0], b = p[1], c = p[2], d = p[3], e = p[4], f = p[5];
         double phi = u[0], s = u[1];
@@ -1015,7 +1261,7 @@ int orc_reaction_step_x(int model, const double *p, double *u, double *du, int64
     if (ns < 0) return -1;
     (void)nthreads;
     for (int64_t i = 0; i < npoints; ++i) {
-        double ul[32], dul[32];
+        double ul[48], dul[48];
         for (int j = 0; j < ns; ++j) ul[j] = layout == ORC_LAYOUT_SOA ? u[i + j * npoints] : u[i * ns + j];
         point_step_x(model, p, ul, dul, ns, xs ? xs + i * sdim : NULL, sdim, t, dt, substeps, threshold);
         for (int j = 0; j < ns; ++j) {
@@ -1060,7 +1306,7 @@ int orc_reaction_step(int model, const double *p, double *u, double *du, int64_t
 #endif
 #pragma omp parallel for schedule(static) if (nthreads > 1)
     for (int64_t i = 0; i < npoints; ++i) {
-        double ul[32], dul[32];
+        double ul[48], dul[48];
         for (int j = 0; j < ns; ++j) ul[j] = layout == ORC_LAYOUT_SOA ? u[i + j * npoints] : u[i * ns + j];
         point_step(model, p, ul, dul, ns, t, dt, substeps, threshold);
         for (int j = 0; j < ns; ++j) {
@@ -1094,16 +1340,16 @@ int orc_reaction_step_rl(int model, const double *p, double *u, int64_t npoints,
         }
         return 0;
     }
-    if (model != ORC_CELL_TT06) return -2;
-    const int ns = 19;
+    if (model != ORC_CELL_TT06 && model != ORC_CELL_ORD11) return -2;
+    const int ns = model == ORC_CELL_ORD11 ? 41 : 19;
 #ifdef _OPENMP
     if (nthreads > 1) omp_set_num_threads(nthreads);
 #endif
 #pragma omp parallel for schedule(static) if (nthreads > 1)
     for (int64_t i = 0; i < npoints; ++i) {
-        double ul[19], dul[19], rate[19];
+        double ul[41], dul[41], rate[41];
         for (int j = 0; j < ns; ++j) ul[j] = layout == ORC_LAYOUT_SOA ? u[i + j * npoints] : u[i * ns + j];
-        tt06_rhs_rates(p, ul, dul, rate);
+        if (model == ORC_CELL_ORD11) ord_rhs_rates(p, ul, dul, rate); else tt06_rhs_rates(p, ul, dul, rate);
         for (int j = 0; j < ns; ++j) {
             const double h = rate[j] != 0.0 ? -expm1(-dt * rate[j]) / rate[j] : dt;
             u[layout == ORC_LAYOUT_SOA ? i + j * npoints : i * ns + j] = ul[j] + h * dul[j];

@@ -45,7 +45,8 @@ enum {
 };
 
 enum { ORC_CELL_FHN = 0, ORC_CELL_ALIEV_PANFILOV = 1, ORC_CELL_PCG2019 = 2, ORC_CELL_TT06 = 3 /* extension, not in the reference */,
-       ORC_CELL_FHN_HETEROGENEOUS = 4 /* docs/src/literate-howto/custom-ep-cell-model.jl:8-56 with e(x) = e0 + g·x */ };
+       ORC_CELL_FHN_HETEROGENEOUS = 4 /* docs/src/literate-howto/custom-ep-cell-model.jl:8-56 with e(x) = e0 + g·x */,
+       ORC_CELL_ORD11 = 5 /* O'Hara–Virág–Varró–Rudy 2011 human ventricular model, 41 states: extension, pinned on the paper */ };
 enum { ORC_LAYOUT_SOA = 0, ORC_LAYOUT_AOS = 1 };
 
 /* ---- FE substrate (Ferrite conventions restated; UNPINNED where SURVEY §8c says so) ---- */

@@ -23,10 +23,9 @@ def make_problem(tb, oracle, nel=(4, 3, 5), perturb=0.25, left=(0, 0, 0), right=
 
 
 def strategies(tb, device, matrix=True):
-    s = [tb.AtomicAssemblyStrategy(device), tb.PerColorAssemblyStrategy(device), tb.PatchAssemblyStrategy(device)]
-    if not matrix:
-        s.append(tb.ElementAssemblyStrategy(device))
-    return s
+    # the reference exposes every strategy for every operator (src/Thunderbolt.jl:22-32): matrices of first-order fields accept the element
+    # strategy too (ordered per-row sums through the patch kernels)
+    return [tb.AtomicAssemblyStrategy(device), tb.PerColorAssemblyStrategy(device), tb.PatchAssemblyStrategy(device), tb.ElementAssemblyStrategy(device)]
 
 
 def coef_cases(tb, oracle, g, rng):
@@ -369,7 +368,7 @@ def test_q2_scalar_forms_parity(tb, oracle, device):
 
 
 # ------------------------------------------------------------------------------------------- reaction
-MODELS = [("FHNModel", "CELL_FHN"), ("AlievPanfilovModel", "CELL_ALIEV_PANFILOV"), ("PCG2019", "CELL_PCG2019"), ("TT06", "CELL_TT06")]
+MODELS = [("FHNModel", "CELL_FHN"), ("AlievPanfilovModel", "CELL_ALIEV_PANFILOV"), ("PCG2019", "CELL_PCG2019"), ("TT06", "CELL_TT06"), ("ORd2011", "CELL_ORD11")]
 
 
 def initial_points(tb, model, n, rng):
@@ -377,6 +376,14 @@ def initial_points(tb, model, n, rng):
     pts = np.tile(u0, (n, 1))
     if model.nstates == 2:
         pts += rng.uniform(0.0, 1.0, size=pts.shape)
+    elif model.nstates == 41:                                  # O'Hara–Rudy: V from rest to plateau, gates perturbed, concentrations near rest
+        pts[:, 0] += rng.uniform(0.0, 120.0, size=n)
+        pts[:, 1:9] *= rng.uniform(0.9, 1.1, size=(n, 8))
+        pts[:, 9:38] = np.clip(pts[:, 9:38] + rng.uniform(-0.2, 0.2, size=(n, 29)), 0.0, 1.0)
+        pts[:, 29] = np.clip(pts[:, 29], 0.05, 1.0)          # jca is the rate of the nca kinetics (k₋₂ₙ = jca): kept away from 0
+        pts[:, 38:40] = rng.uniform(0.0, 1e-3, size=(n, 2))
+        pts[:, 40] = rng.uniform(0.0, 0.1, size=n)
+        pts[:, 0] += rng.integers(0, 2, size=n) * 1e-9         # V ≠ 0 exactly (the constant-field currents divide by e^{V F/RT} − 1)
     elif model.nstates == 19:                                  # TT06: V from rest to plateau, gates perturbed, ions near rest
         pts[:, 0] += rng.uniform(0.0, 110.0, size=n)
         pts[:, 6:] = np.clip(pts[:, 6:] + rng.uniform(-0.2, 0.2, size=(n, 13)), 0.0, 1.0)
@@ -399,7 +406,7 @@ def test_reaction_forward_euler_parity(tb, oracle, device, cls, oid, layout):
     f = tb.PointwiseODEFunction(n, model, layout=tb.StateBlockedLayout() if layout == "SOA" else tb.PointBlockedLayout())
     cache = tb.setup_solver_cache(f, tb.ForwardEulerCellSolver(device), u=device.to_device(host))
     ref = host.copy()
-    dt = {7: 0.01, 19: 0.001}.get(model.nstates, 0.1)
+    dt = {7: 0.01, 19: 0.001, 41: 0.002}.get(model.nstates, 0.1)
     for step in range(20):
         assert tb.perform_step(f, cache, step * dt, dt) is True
         du_ref = oracle.reaction_step(oid, model.params, ref, n, getattr(oracle, "LAYOUT_" + layout), t=step * dt, dt=dt)
@@ -425,11 +432,11 @@ def test_reaction_adaptive_substepper_parity(tb, oracle, device, cls, oid):
     host = np.ascontiguousarray(pts.T).ravel().copy()
     f = tb.PointwiseODEFunction(n, model)
     thr = 0.05 if model.nstates == 2 else 1.0
-    if model.nstates == 19:
+    if model.nstates in (19, 41):
         thr = 20.0
     cache = tb.setup_solver_cache(f, tb.AdaptiveForwardEulerSubstepper(device, substeps=7, reaction_threshold=thr), u=device.to_device(host))
     ref = host.copy()
-    dt = 0.007 if model.nstates == 19 else 0.05
+    dt = 0.007 if model.nstates in (19, 41) else 0.05
     for step in range(5):
         tb.perform_step(f, cache, step * dt, dt)
         oracle.reaction_step(oid, model.params, ref, n, oracle.LAYOUT_SOA, t=step * dt, dt=dt, substeps=7, threshold=thr)
@@ -2411,6 +2418,24 @@ def test_rush_larsen_tt06(tb, oracle, device, layout):
     with pytest.raises(tb.TBError) as e:
         tb.perform_step(fh, tb.setup_solver_cache(fh, tb.RushLarsenCellSolver(device), u=device.zeros(8), keep_du=False), 0.0, 0.1)
     assert e.value.code == tb._lib.TB_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("layout", ["SOA", "AOS"])
+def test_rush_larsen_ord2011_parity(tb, oracle, device, layout):
+    """Rush–Larsen step of the O'Hara–Rudy model (28 Hodgkin–Huxley-type gates by their exact frozen-V solution, the other 13 states forward Euler):
+    device == oracle over 40 steps at Δt = 0.01 ms."""
+    model = tb.ORd2011()
+    n = 256 + 41
+    pts = initial_points(tb, model, n, np.random.default_rng(9))
+    host = (np.ascontiguousarray(pts.T) if layout == "SOA" else pts).ravel().copy()
+    f = tb.PointwiseODEFunction(n, model, layout=tb.StateBlockedLayout() if layout == "SOA" else tb.PointBlockedLayout())
+    cache = tb.setup_solver_cache(f, tb.RushLarsenCellSolver(device), u=device.to_device(host), keep_du=False)
+    ref = host.copy()
+    for s_ in range(40):
+        assert tb.perform_step(f, cache, s_ * 0.01, 0.01) is True
+        oracle.reaction_step_rl(oracle.CELL_ORD11, model.params, ref, n, getattr(oracle, "LAYOUT_" + layout), t=s_ * 0.01, dt=0.01)
+    got = cache.un.to_host()
+    assert np.isfinite(got).all() and rel_err(got, ref) < 1e-11
 
 
 def test_reference_backward_euler_on_a_steady_state(tb, device):

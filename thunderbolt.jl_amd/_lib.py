@@ -18,7 +18,7 @@ TB_BC_ROBIN, TB_BC_NORMAL_SPRING, TB_BC_PRESSURE, TB_BC_BENDING_SPRING, TB_BC_PR
 TB_COEF_CONST_SCALAR, TB_COEF_CONST_TENSOR, TB_COEF_FIELD_SCALAR = 0, 1, 2
 TB_COEF_SPECTRAL_CONST, TB_COEF_SPECTRAL_FIELD, TB_COEF_TRANSVERSE_CONST = 3, 4, 5
 TB_SRC_CONST, TB_SRC_NORM_PLUS_T, TB_SRC_COS_EXP, TB_SRC_TABULATED = 0, 1, 2, 3
-TB_CELL_FHN, TB_CELL_ALIEV_PANFILOV, TB_CELL_PCG2019, TB_CELL_TT06, TB_CELL_FHN_HETEROGENEOUS = 0, 1, 2, 3, 4
+TB_CELL_FHN, TB_CELL_ALIEV_PANFILOV, TB_CELL_PCG2019, TB_CELL_TT06, TB_CELL_FHN_HETEROGENEOUS, TB_CELL_ORD11 = 0, 1, 2, 3, 4, 5
 TB_LAYOUT_SOA, TB_LAYOUT_AOS = 0, 1
 
 c_dp = C.POINTER(C.c_double)

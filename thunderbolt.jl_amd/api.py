@@ -753,6 +753,17 @@ class TT06(_IonicModel):
     state_symbols = ("φₘ", "Ca_i", "Ca_SR", "Ca_ss", "Na_i", "K_i", "m", "h", "j", "xr1", "xr2", "xs", "r", "s", "d", "f", "f2", "fCass", "R̄")
 
 
+class ORd2011(_IonicModel):
+    """O'Hara–Virág–Varró–Rudy 2011 human ventricular cell (41 states) — extension (SURVEY §8 f4 names it; the reference has the hooks only).
+    Parameters: thirteen conductance scalings (1 = published), extracellular concentrations, cell type (0 endo, 1 epi, 2 M)."""
+    model_id = L.TB_CELL_ORD11
+    param_names = ["s_GNa", "s_GNaL", "s_Gto", "s_PCa", "s_GKr", "s_GKs", "s_GK1", "s_Gncx", "s_Pnak", "s_GKb", "s_PNab", "s_PCab", "s_GpCa",
+                   "nao", "cao", "ko", "celltype"]
+    state_symbols = ("φₘ", "nai", "nass", "ki", "kss", "cai", "cass", "cansr", "cajsr", "m", "hf", "hs", "j", "hsp", "jp", "mL", "hL", "hLp", "a", "iF",
+                     "iS", "ap", "iFp", "iSp", "d", "ff", "fs", "fcaf", "fcas", "jca", "nca", "ffp", "fcafp", "xrf", "xrs", "xs1", "xs2", "xk1",
+                     "Jrelnp", "Jrelp", "CaMKt")
+
+
 class StateBlockedLayout:
     code = L.TB_LAYOUT_SOA
 

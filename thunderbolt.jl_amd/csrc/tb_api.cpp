@@ -824,6 +824,7 @@ int tb_cell_model_info(int model, int *n_states, int *n_params, int *phi_index)
     case TB_CELL_PCG2019: ns = 7; np = 36; break;
     case TB_CELL_TT06: ns = 19; np = 48; break;
     case TB_CELL_FHN_HETEROGENEOUS: ns = 2; np = 8; break;
+    case TB_CELL_ORD11: ns = 41; np = 17; break;
     default: set_error("unknown cell model %d", model); return TB_ERR_BAD_ARG;
     }
     if (n_states) *n_states = ns;
@@ -879,6 +880,16 @@ int tb_cell_model_defaults(int model, double *params, double *u0)
         memcpy(params, d, sizeof d);
         if (u0) {
             const double s[19] = {-86.2, 0.00007, 1.3, 0.00007, 7.67, 138.3, 0.0, 0.75, 0.75, 0.0, 1.0, 0.0, 0.0, 1.0, 0.0, 1.0, 1.0, 1.0, 1.0};
+            memcpy(u0, s, sizeof s);
+        }
+        return TB_OK;
+    }
+    case TB_CELL_ORD11: { // O'Hara–Rudy 2011: unit conductance scalings, the paper's extracellular concentrations, endocardial cell; initial state of its supplement
+        const double d[17] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 140.0, 1.8, 5.4, 0.0};
+        memcpy(params, d, sizeof d);
+        if (u0) {
+            const double s[41] = {-87.0, 7.0, 7.0, 145.0, 145.0, 1.0e-4, 1.0e-4, 1.2, 1.2, 0.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.0, 1.0, 1.0, 0.0, 1.0, 1.0, 0.0, 1.0, 1.0,
+                                  0.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0};
             memcpy(u0, s, sizeof s);
         }
         return TB_OK;

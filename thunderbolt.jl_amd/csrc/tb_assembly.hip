@@ -1345,6 +1345,11 @@ int launch_assemble_matrix(tb_form *f, tb_pattern *p, int strategy, double t, do
     tb_mesh *m = f->mesh;
     int rc = reset_status(m->dev);
     if (rc) return rc;
+    // ElementAssemblyStrategy on first-order fields: what the reference's strategy guarantees for a matrix — element contributions summed per
+    // row in a fixed order, no atomics, bit-reproducible (src/Thunderbolt.jl:22-32; FerriteOperators' element assembly) — is what the patch
+    // kernels do (each non-zero is the ordered sum of its cells' contributions and is stored once), without the stored-Kₑ round trip the
+    // quadratic fields need.  The strategy is accepted and runs them; subdomain forms (not patch-capable) take the per-colour form, deterministic too.
+    if (strategy == TB_STRATEGY_ELEMENT && m->field_kind != TB_HEX27) strategy = f->has_cellset ? TB_STRATEGY_PER_COLOR : TB_STRATEGY_PATCH;
     if (strategy == TB_STRATEGY_PATCH && hex8_patch_applicable(f, p)) {
         rc = f->kind == TB_FORM_DIFFUSION ? launch_assemble_hex8_patch(f, nullptr, p, t, d_nz, nullptr) : launch_assemble_hex8_patch(nullptr, f, p, t, nullptr, d_nz);
         if (rc != TB_ERR_UNSUPPORTED) return rc; // e.g. rows longer than 255 entries: the general patch kernel below

@@ -240,6 +240,220 @@ template <> struct CellModel<TB_CELL_TT06> {
     }
 };
 
+
+// O'Hara, Virág, Varró & Rudy 2011 (PLoS Comput Biol 7(5): e1002061), human ventricular model, 41 states in the order of its published code:
+// v, nai, nass, ki, kss, cai, cass, cansr, cajsr, m, hf, hs, j, hsp, jp, mL, hL, hLp, a, iF, iS, ap, iFp, iSp, d, ff, fs, fcaf, fcas, jca, nca, ffp,
+// fcafp, xrf, xrs, xs1, xs2, xk1, Jrelnp, Jrelp, CaMKt.  EXTENSION (SURVEY §8 f4 names the model, the reference has only the reaction_rhs! /
+// state_rhs! hooks, src/modeling/cells/fhn.jl:36-60); the oracle's restatement is pinned on the paper's endocardial numbers
+// (tests/test_ord_known_answer.py) and this routine on the oracle (1e-12 per step).  Parameters: thirteen conductance scalings (1 = published),
+// nao, cao, ko, cell type.  1/(1 + e^x) are refined hardware reciprocals, x^1.4 = exp(1.4 log x), the integer powers are products.
+template <> struct CellModel<TB_CELL_ORD11> {
+    static constexpr int NS = 41, PHI = 0;
+    static constexpr bool HAS_GATES = true;
+    __device__ __forceinline__ static double sg(double x) { return rcp_b(1.0 + exp_b(x)); } // 1/(1 + e^x)
+    __device__ __forceinline__ static void rhs(const CellParams &P, const double (&u)[NS], double t, double (&du)[NS])
+    {
+        double rate[NS];
+        rhs_rates(P, u, t, du, rate);
+    }
+    __device__ __forceinline__ static void rhs_rates(const CellParams &P, const double (&u)[NS], double, double (&du)[NS], double (&rate)[NS])
+    {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) rate[k] = 0.0;
+        const double *p = P.p;
+        const double nao = p[13], cao = p[14], ko = p[15];
+        const int celltype = (int)p[16];
+        constexpr double R = 8314.0, T = 310.0, F = 96485.0, RTF = R * T / F, FRT = F / (R * T);
+        constexpr double L = 0.01, rad = 0.0011, vcell = 1000 * 3.14 * rad * rad * L, Ageo = 2 * 3.14 * rad * rad + 2 * 3.14 * rad * L, Acap = 2 * Ageo;
+        constexpr double vmyo = 0.68 * vcell, vnsr = 0.0552 * vcell, vjsr = 0.0048 * vcell, vss = 0.02 * vcell;
+        const double v = u[0], nai = u[1], nass = u[2], ki = u[3], kss = u[4], cai = u[5], cass = u[6], cansr = u[7], cajsr = u[8], m = u[9], hf = u[10],
+                     hs = u[11], j = u[12], hsp = u[13], jp = u[14], mL = u[15], hL = u[16], hLp = u[17], a = u[18], iF = u[19], iS = u[20],
+                     ap = u[21], iFp = u[22], iSp = u[23], d = u[24], ff = u[25], fs = u[26], fcaf = u[27], fcas = u[28], jca = u[29], nca = u[30],
+                     ffp = u[31], fcafp = u[32], xrf = u[33], xrs = u[34], xs1 = u[35], xs2 = u[36], xk1 = u[37], Jrelnp = u[38], Jrelp = u[39],
+                     CaMKt = u[40];
+        // CaMK
+        constexpr double KmCaMK = 0.15, aCaMK = 0.05, bCaMK = 0.00068, CaMKo = 0.05, KmCaM = 0.0015;
+        const double CaMKb = CaMKo * (1.0 - CaMKt) * cass * rcp_b(cass + KmCaM), CaMKa = CaMKb + CaMKt;
+        du[40] = aCaMK * CaMKb * (CaMKb + CaMKt) - bCaMK * CaMKt;
+        const double fpa = CaMKa * rcp_b(CaMKa + KmCaMK), fnp = 1.0 - fpa;
+        // reversal potentials
+        const double ENa = RTF * (log(nao) - log(nai)), EK = RTF * (log(ko) - log(ki));
+        const double EKs = RTF * (log(ko + 0.01833 * nao) - log(ki + 0.01833 * nai));
+        const double vfrt = v * FRT, vffrt = vfrt * F;
+        // INa
+        const double mss = sg(-(v + 39.57) * (1.0 / 9.871));
+        const double tm_r = 6.765 * exp_b((v + 11.64) * (1.0 / 34.77)) + 8.552 * exp_b(-(v + 77.42) * (1.0 / 5.955)); // 1/τ_m
+        const double hss = sg((v + 82.90) * (1.0 / 6.086));
+        const double thf_r = 1.432e-5 * exp_b(-(v + 1.196) * (1.0 / 6.285)) + 6.149 * exp_b((v + 0.5096) * (1.0 / 20.27));
+        const double ths_r = 0.009794 * exp_b(-(v + 17.95) * (1.0 / 28.05)) + 0.3343 * exp_b((v + 5.730) * (1.0 / 56.66));
+        constexpr double Ahf = 0.99, Ahs = 1.0 - Ahf;
+        const double h = Ahf * hf + Ahs * hs;
+        const double tj = 2.038 + rcp_b(0.02136 * exp_b(-(v + 100.6) * (1.0 / 8.281)) + 0.3052 * exp_b((v + 0.9941) * (1.0 / 38.45)));
+        const double hssp = sg((v + 89.1) * (1.0 / 6.086));
+        const double hp = Ahf * hf + Ahs * hsp;
+        const double INa = 75.0 * p[0] * (v - ENa) * m * m * m * (fnp * h * j + fpa * hp * jp);
+        // INaL
+        const double mLss = sg(-(v + 42.85) * (1.0 / 5.264));
+        const double hLss = sg((v + 87.61) * (1.0 / 7.488)), hLssp = sg((v + 93.81) * (1.0 / 7.488));
+        const double INaL = 0.0075 * p[1] * (celltype == 1 ? 0.6 : 1.0) * (v - ENa) * mL * (fnp * hL + fpa * hLp);
+        // Ito
+        const double ass = sg(-(v - 14.34) * (1.0 / 14.82));
+        const double ta = 1.0515 * rcp_b(sg(-(v - 18.4099) * (1.0 / 29.3814)) * (1.0 / 1.2089) + 3.5 * sg((v + 100.0) * (1.0 / 29.3814)));
+        const double iss = sg((v + 43.94) * (1.0 / 5.711));
+        const double delta_epi = celltype == 1 ? 1.0 - 0.95 * sg((v + 70.0) * (1.0 / 5.0)) : 1.0;
+        const double tiF = (4.562 + rcp_b(0.3933 * exp_b(-(v + 100.0) * (1.0 / 100.0)) + 0.08004 * exp_b((v + 50.0) * (1.0 / 16.59)))) * delta_epi;
+        const double tiS = (23.62 + rcp_b(0.001416 * exp_b(-(v + 96.52) * (1.0 / 59.05)) + 1.780e-8 * exp_b((v + 114.1) * (1.0 / 8.079)))) * delta_epi;
+        const double AiF = sg((v - 213.6) * (1.0 / 151.2)), AiS = 1.0 - AiF;
+        const double i_ = AiF * iF + AiS * iS;
+        const double assp = sg(-(v - 24.34) * (1.0 / 14.82));
+        const double dti_develop = 1.354 + 1.0e-4 * rcp_b(exp_b((v - 167.4) * (1.0 / 15.89)) + exp_b(-(v - 12.23) * (1.0 / 0.2154)));
+        const double dti_recover = 1.0 - 0.5 * sg((v + 70.0) * (1.0 / 20.0));
+        const double tiFp = dti_develop * dti_recover * tiF, tiSp = dti_develop * dti_recover * tiS;
+        const double ip = AiF * iFp + AiS * iSp;
+        const double Ito = 0.02 * p[2] * (celltype == 0 ? 1.0 : 4.0) * (v - EK) * (fnp * a * i_ + fpa * ap * ip);
+        // ICaL, ICaNa, ICaK
+        const double dss = sg(-(v + 3.940) * (1.0 / 4.230));
+        const double td = 0.6 + rcp_b(exp_b(-0.05 * (v + 6.0)) + exp_b(0.09 * (v + 14.0)));
+        const double fss = sg((v + 19.58) * (1.0 / 3.696));
+        const double e20 = exp_b((v + 20.0) * (1.0 / 10.0));
+        const double tff = 7.0 + rcp_b(0.0045 * rcp_b(e20) + 0.0045 * e20);
+        const double tfs = 1000.0 + rcp_b(0.000035 * exp_b(-(v + 5.0) * (1.0 / 4.0)) + 0.000035 * exp_b((v + 5.0) * (1.0 / 6.0)));
+        constexpr double Aff = 0.6, Afs = 1.0 - Aff;
+        const double f = Aff * ff + Afs * fs;
+        const double e4 = exp_b((v - 4.0) * (1.0 / 7.0));
+        const double tfcaf = 7.0 + rcp_b(0.04 * rcp_b(e4) + 0.04 * e4);
+        const double tfcas = 100.0 + rcp_b(0.00012 * exp_b(-v * (1.0 / 3.0)) + 0.00012 * exp_b(v * (1.0 / 7.0)));
+        const double Afcaf = 0.3 + 0.6 * sg((v - 10.0) * (1.0 / 10.0)), Afcas = 1.0 - Afcaf;
+        const double fca = Afcaf * fcaf + Afcas * fcas;
+        const double fp = Aff * ffp + Afs * fs;
+        const double fcap = Afcaf * fcafp + Afcas * fcas;
+        constexpr double Kmn = 0.002, k2n = 1000.0;
+        const double km2n = jca;
+        const double q1 = 1.0 + Kmn * rcp_b(cass), q2 = q1 * q1;
+        const double anca = rcp_b(k2n * rcp_b(km2n) + q2 * q2);
+        du[30] = anca * k2n - nca * km2n;
+        const double e1 = exp_b(vfrt), e2 = e1 * e1;
+        const double ie1 = rcp_b(e1 - 1.0), ie2 = rcp_b(e2 - 1.0);
+        const double PhiCaL = 4.0 * vffrt * (cass * e2 - 0.341 * cao) * ie2;
+        const double PhiCaNa = vffrt * (0.75 * nass * e1 - 0.75 * nao) * ie1;
+        const double PhiCaK = vffrt * (0.75 * kss * e1 - 0.75 * ko) * ie1;
+        const double PCa = 0.0001 * p[3] * (celltype == 1 ? 1.2 : celltype == 2 ? 2.5 : 1.0), PCap = 1.1 * PCa;
+        const double gnp = d * (f * (1.0 - nca) + jca * fca * nca), gp = d * (fp * (1.0 - nca) + jca * fcap * nca);
+        const double gsum = fnp * PCa * gnp + fpa * PCap * gp; // the permeability ratios PCaNa / PCa, PCaK / PCa are the same for both populations
+        const double ICaL = gsum * PhiCaL, ICaNa = 0.00125 * gsum * PhiCaNa, ICaK = 3.574e-4 * gsum * PhiCaK;
+        // IKr
+        const double xrss = sg(-(v + 8.337) * (1.0 / 6.789));
+        const double txrf = 12.98 + rcp_b(0.3652 * exp_b((v - 31.66) * (1.0 / 3.869)) + 4.123e-5 * exp_b(-(v - 47.78) * (1.0 / 20.38)));
+        const double txrs = 1.865 + rcp_b(0.06629 * exp_b((v - 34.70) * (1.0 / 7.355)) + 1.128e-5 * exp_b(-(v - 29.74) * (1.0 / 25.94)));
+        const double Axrf = sg((v + 54.81) * (1.0 / 38.21)), Axrs = 1.0 - Axrf;
+        const double xr = Axrf * xrf + Axrs * xrs;
+        const double rkr = sg((v + 55.0) * (1.0 / 75.0)) * sg((v - 10.0) * (1.0 / 30.0));
+        const double IKr = 0.046 * p[4] * (celltype == 1 ? 1.3 : celltype == 2 ? 0.8 : 1.0) * sqrt(ko * (1.0 / 5.4)) * xr * rkr * (v - EK);
+        // IKs
+        const double xs1ss = sg(-(v + 11.60) * (1.0 / 8.932));
+        const double txs1 = 817.3 + rcp_b(2.326e-4 * exp_b((v + 48.28) * (1.0 / 17.80)) + 0.001292 * exp_b(-(v + 210.0) * (1.0 / 230.0)));
+        const double txs2_r = 0.01 * exp_b((v - 50.0) * (1.0 / 20.0)) + 0.0193 * exp_b(-(v + 66.54) * (1.0 / 31.0));
+        const double KsCa = 1.0 + 0.6 * rcp_b(1.0 + exp_b(1.4 * (log(3.8e-5) - log(cai))));
+        const double IKs = 0.0034 * p[5] * (celltype == 1 ? 1.4 : 1.0) * KsCa * xs1 * xs2 * (v - EKs);
+        // IK1
+        const double xk1ss = sg(-(v + 2.5538 * ko + 144.59) / (1.5692 * ko + 3.8115));
+        const double txk1_r = (exp_b(-(v + 127.2) * (1.0 / 20.36)) + exp_b((v + 236.8) * (1.0 / 69.33))) * (1.0 / 122.2);
+        const double rk1 = sg((v + 105.8 - 2.6 * ko) * (1.0 / 9.493));
+        const double IK1 = 0.1908 * p[6] * (celltype == 1 ? 1.2 : celltype == 2 ? 1.3 : 1.0) * sqrt(ko) * rk1 * xk1 * (v - EK);
+        // INaCa: the same six-state cycle in the myoplasm (80 %) and in the subspace (20 %)
+        constexpr double kna1 = 15.0, kna2 = 5.0, kna3 = 88.12, kasymm = 12.5, wna = 6.0e4, wca = 6.0e4, wnaca = 5.0e3, kcaon = 1.5e6, kcaoff = 5.0e3,
+                         qna = 0.5224, qca = 0.1670, KmCaAct = 150.0e-6;
+        const double hca = exp_b(qca * vfrt), hna = exp_b(qna * vfrt), ihna = rcp_b(hna);
+        const double Gncx = 0.0008 * p[7] * (celltype == 1 ? 1.1 : celltype == 2 ? 1.4 : 1.0);
+        const double h7 = 1.0 + nao * (1.0 / kna3) * (1.0 + ihna), h8 = nao * ihna * rcp_b(kna3 * h7), h9 = rcp_b(h7);
+        const double h10 = kasymm + 1.0 + nao * (1.0 / kna1) * (1.0 + nao * (1.0 / kna2)), h11 = nao * nao / (h10 * kna1 * kna2), h12 = 1.0 / h10;
+        const double k1 = h12 * cao * kcaon, k3p = h9 * wca, k3pp = h8 * wnaca, k3 = k3p + k3pp, k8 = h8 * h11 * wna;
+        double INaCa_c[2];
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            const double na = w == 0 ? nai : nass, ca = w == 0 ? cai : cass;
+            const double h1 = 1.0 + na * (1.0 / kna3) * (1.0 + hna), h3 = rcp_b(h1), h2 = na * hna * (1.0 / kna3) * h3;
+            const double h4 = 1.0 + na * (1.0 / kna1) * (1.0 + na * (1.0 / kna2)), h6 = rcp_b(h4), h5 = na * na * (1.0 / (kna1 * kna2)) * h6;
+            const double k2 = kcaoff, k4p = h3 * wca * rcp_b(hca), k4pp = h2 * wnaca, k4 = k4p + k4pp, k5 = kcaoff, k6 = h6 * ca * kcaon, k7 = h5 * h2 * wna;
+            const double x1 = k2 * k4 * (k7 + k6) + k5 * k7 * (k2 + k3), x2 = k1 * k7 * (k4 + k5) + k4 * k6 * (k1 + k8);
+            const double x3 = k1 * k3 * (k7 + k6) + k8 * k6 * (k2 + k3), x4 = k2 * k8 * (k4 + k5) + k3 * k5 * (k1 + k8);
+            const double ixs = rcp_b(x1 + x2 + x3 + x4), E1 = x1 * ixs, E2 = x2 * ixs, E3 = x3 * ixs, E4 = x4 * ixs;
+            const double allo = ca * ca * rcp_b(ca * ca + KmCaAct * KmCaAct);
+            const double JncxNa = 3.0 * (E4 * k7 - E1 * k8) + E3 * k4pp - E2 * k3pp, JncxCa = E2 * k2 - E1 * k1;
+            INaCa_c[w] = (w == 0 ? 0.8 : 0.2) * Gncx * allo * (JncxNa + 2.0 * JncxCa);
+        }
+        const double INaCa_i = INaCa_c[0], INaCa_ss = INaCa_c[1];
+        // INaK
+        constexpr double k1p = 949.5, k1m = 182.4, k2p = 687.2, k2m = 39.4, k3p_ = 1899.0, k3m = 79300.0, k4p_ = 639.0, k4m = 40.0, Knai0 = 9.073,
+                         Knao0 = 27.78, delta = -0.1550, Kki = 0.5, Kko = 0.3582, MgADP = 0.05, MgATP = 9.8, Kmgatp = 1.698e-7, H = 1.0e-7, eP = 4.2,
+                         Khp = 1.698e-7, Knap = 224.0, Kxkur = 292.0;
+        const double Knai = Knai0 * exp_b(delta * vfrt * (1.0 / 3.0)), Knao = Knao0 * exp_b((1.0 - delta) * vfrt * (1.0 / 3.0));
+        const double Pp = eP * rcp_b(1.0 + H / Khp + nai * (1.0 / Knap) + ki * (1.0 / Kxkur));
+        const double rni = nai * rcp_b(Knai), rno = nao * rcp_b(Knao), rki = ki * (1.0 / Kki), rko = ko * (1.0 / Kko);
+        const double c3 = [](double x) { return x * x * x; }(1.0 + rni), c3o = [](double x) { return x * x * x; }(1.0 + rno);
+        const double idni = rcp_b(c3 + (1.0 + rki) * (1.0 + rki) - 1.0), idno = rcp_b(c3o + (1.0 + rko) * (1.0 + rko) - 1.0);
+        const double a1 = k1p * rni * rni * rni * idni, b1 = k1m * MgADP, a2 = k2p, b2 = k2m * rno * rno * rno * idno;
+        const double a3 = k3p_ * rko * rko * idno, b3 = (k3m * Pp * H) * (1.0 / (1.0 + MgATP / Kmgatp));
+        constexpr double a4 = (k4p_ * MgATP / Kmgatp) / (1.0 + MgATP / Kmgatp);
+        const double b4 = k4m * rki * rki * idni;
+        const double y1 = a4 * a1 * a2 + b2 * b4 * b3 + a2 * b4 * b3 + b3 * a1 * a2, y2 = b2 * b1 * b4 + a1 * a2 * a3 + a3 * b1 * b4 + a2 * a3 * b4;
+        const double y3 = a2 * a3 * a4 + b3 * b2 * b1 + b2 * b1 * a4 + a3 * a4 * b1, y4 = b4 * b3 * b2 + a3 * a4 * a1 + b2 * a4 * a1 + b3 * b2 * a1;
+        const double iys = rcp_b(y1 + y2 + y3 + y4), F1 = y1 * iys, F2 = y2 * iys, F3 = y3 * iys, F4 = y4 * iys;
+        const double JnakNa = 3.0 * (F1 * a3 - F2 * b3), JnakK = 2.0 * (F4 * b1 - F3 * a1);
+        const double INaK = 30.0 * p[8] * (celltype == 1 ? 0.9 : celltype == 2 ? 0.7 : 1.0) * (JnakNa + JnakK);
+        // background currents, sarcolemmal calcium pump
+        const double xkb = sg(-(v - 14.48) * (1.0 / 18.34));
+        const double IKb = 0.003 * p[9] * (celltype == 1 ? 0.6 : 1.0) * xkb * (v - EK);
+        const double INab = 3.75e-10 * p[10] * vffrt * (nai * e1 - nao) * ie1;
+        const double ICab = 2.5e-8 * p[11] * 4.0 * vffrt * (cai * e2 - 0.341 * cao) * ie2;
+        const double IpCa = 0.0005 * p[12] * cai * rcp_b(0.0005 + cai);
+        du[0] = -(INa + INaL + Ito + ICaL + ICaNa + ICaK + IKr + IKs + IK1 + INaCa_i + INaCa_ss + INaK + INab + IKb + IpCa + ICab);
+        // fluxes
+        const double JdiffNa = (nass - nai) * 0.5, JdiffK = (kss - ki) * 0.5, Jdiff = (cass - cai) * (1.0 / 0.2);
+        constexpr double bt = 4.75, a_rel = 0.5 * bt, btp = 1.25 * bt, a_relp = 0.5 * btp;
+        const double r15 = 1.5 * rcp_b(cajsr), r2 = r15 * r15, r4 = r2 * r2;
+        const double rel_gate = rcp_b(1.0 + r4 * r4) * (celltype == 2 ? 1.7 : 1.0);
+        const double tcj = cajsr * rcp_b(cajsr + 0.0123); // 1/(1 + 0.0123/cajsr)
+        const double tau_rel = fmax(bt * tcj, 0.001), tau_relp = fmax(btp * tcj, 0.001);
+        du[38] = (a_rel * (-ICaL) * rel_gate - Jrelnp) * rcp_b(tau_rel);
+        du[39] = (a_relp * (-ICaL) * rel_gate - Jrelp) * rcp_b(tau_relp);
+        const double Jrel = fnp * Jrelnp + fpa * Jrelp;
+        const double upf = celltype == 1 ? 1.3 : 1.0;
+        const double Jupnp = upf * 0.004375 * cai * rcp_b(cai + 0.00092), Jupp = upf * 2.75 * 0.004375 * cai * rcp_b(cai + 0.00092 - 0.00017);
+        const double Jleak = 0.0039375 * cansr * (1.0 / 15.0);
+        const double Jup = fnp * Jupnp + fpa * Jupp - Jleak;
+        const double Jtr = (cansr - cajsr) * (1.0 / 100.0);
+        // concentrations
+        du[1] = -(INa + INaL + 3.0 * INaCa_i + 3.0 * INaK + INab) * (Acap / (F * vmyo)) + JdiffNa * (vss / vmyo);
+        du[2] = -(ICaNa + 3.0 * INaCa_ss) * (Acap / (F * vss)) - JdiffNa;
+        du[3] = -(Ito + IKr + IKs + IK1 + IKb - 2.0 * INaK) * (Acap / (F * vmyo)) + JdiffK * (vss / vmyo);
+        du[4] = -ICaK * (Acap / (F * vss)) - JdiffK;
+        const double cmdnmax = celltype == 1 ? 0.05 * 1.3 : 0.05;
+        constexpr double kmcmdn = 0.00238, trpnmax = 0.07, kmtrpn = 0.0005, BSRmax = 0.047, KmBSR = 0.00087, BSLmax = 1.124, KmBSL = 0.0087, csqnmax = 10.0,
+                         kmcsqn = 0.8;
+        const double sc1 = (kmcmdn + cai) * (kmcmdn + cai), sc2 = (kmtrpn + cai) * (kmtrpn + cai);
+        const double Bcai = rcp_b(1.0 + cmdnmax * kmcmdn * rcp_b(sc1) + trpnmax * kmtrpn * rcp_b(sc2));
+        du[5] = Bcai * (-(IpCa + ICab - 2.0 * INaCa_i) * (Acap / (2.0 * F * vmyo)) - Jup * (vnsr / vmyo) + Jdiff * (vss / vmyo));
+        const double ss1 = (KmBSR + cass) * (KmBSR + cass), ss2 = (KmBSL + cass) * (KmBSL + cass);
+        const double Bcass = rcp_b(1.0 + BSRmax * KmBSR * rcp_b(ss1) + BSLmax * KmBSL * rcp_b(ss2));
+        du[6] = Bcass * (-(ICaL - 2.0 * INaCa_ss) * (Acap / (2.0 * F * vss)) + Jrel * (vjsr / vss) - Jdiff);
+        du[7] = Jup - Jtr * (vjsr / vnsr);
+        const double sj = (kmcsqn + cajsr) * (kmcsqn + cajsr);
+        du[8] = sj * rcp_b(sj + csqnmax * kmcsqn) * (Jtr - Jrel);
+        // gates: rate = 1/τ
+        auto gate = [&](int k, double inf, double r) { rate[k] = r; du[k] = (inf - u[k]) * r; };
+        gate(9, mss, tm_r); gate(10, hss, thf_r); gate(11, hss, ths_r);
+        const double rtj = rcp_b(tj);
+        gate(12, hss, rtj); gate(13, hssp, ths_r * (1.0 / 3.0)); gate(14, hss, rtj * (1.0 / 1.46));
+        gate(15, mLss, tm_r); gate(16, hLss, 1.0 / 200.0); gate(17, hLssp, 1.0 / 600.0);
+        const double rta = rcp_b(ta);
+        gate(18, ass, rta); gate(19, iss, rcp_b(tiF)); gate(20, iss, rcp_b(tiS)); gate(21, assp, rta); gate(22, iss, rcp_b(tiFp)); gate(23, iss, rcp_b(tiSp));
+        gate(24, dss, rcp_b(td)); gate(25, fss, rcp_b(tff)); gate(26, fss, rcp_b(tfs)); gate(27, fss, rcp_b(tfcaf)); gate(28, fss, rcp_b(tfcas));
+        gate(29, fss, 1.0 / 75.0); gate(31, fss, rcp_b(tff) * (1.0 / 2.5)); gate(32, fss, rcp_b(tfcaf) * (1.0 / 2.5));
+        gate(33, xrss, rcp_b(txrf)); gate(34, xrss, rcp_b(txrs)); gate(35, xs1ss, rcp_b(txs1)); gate(36, xs1ss, txs2_r); gate(37, xk1ss, txk1_r);
+    }
+};
+
 template <class M, class = void> struct uses_x : std::false_type {};
 template <class M> struct uses_x<M, std::enable_if_t<M::USES_X>> : std::true_type {};
 
@@ -344,8 +558,8 @@ k_reaction_rl(CellParams P, double *__restrict__ u, int64_t n, double t, double 
 
 int launch_reaction_rl(tb_device *dev, int model, const double *params, int n_params, double *d_u, int64_t n, int layout, double t, double dt)
 {
-    if (model != TB_CELL_TT06 && model != TB_CELL_PCG2019) {
-        set_error("Rush–Larsen step: cell model %d has no gate decomposition (TB_CELL_TT06 and TB_CELL_PCG2019 have)", model);
+    if (model != TB_CELL_TT06 && model != TB_CELL_PCG2019 && model != TB_CELL_ORD11) {
+        set_error("Rush–Larsen step: cell model %d has no gate decomposition (TB_CELL_TT06, TB_CELL_PCG2019 and TB_CELL_ORD11 have)", model);
         return TB_ERR_UNSUPPORTED;
     }
     CellParams P{};
@@ -356,7 +570,7 @@ int launch_reaction_rl(tb_device *dev, int model, const double *params, int n_pa
     if (n == 0) return TB_OK;
 #define TB_RL(MODEL) do { if (layout == TB_LAYOUT_SOA) hipLaunchKernelGGL((k_reaction_rl<MODEL, TB_LAYOUT_SOA>), dim3((unsigned)nb), dim3(256), 0, dev->stream, P, d_u, n, t, dt); \
                           else hipLaunchKernelGGL((k_reaction_rl<MODEL, TB_LAYOUT_AOS>), dim3((unsigned)nb), dim3(256), 0, dev->stream, P, d_u, n, t, dt); } while (0)
-    if (model == TB_CELL_TT06) TB_RL(TB_CELL_TT06); else TB_RL(TB_CELL_PCG2019);
+    if (model == TB_CELL_TT06) TB_RL(TB_CELL_TT06); else if (model == TB_CELL_ORD11) TB_RL(TB_CELL_ORD11); else TB_RL(TB_CELL_PCG2019);
 #undef TB_RL
     TB_HIP(hipGetLastError());
     return TB_OK;
@@ -397,6 +611,7 @@ int launch_reaction(tb_device *dev, int model, const double *params, int n_param
     case TB_CELL_PCG2019: rc = run<TB_CELL_PCG2019>(dev, P, d_u, d_du, n_points, layout, t, dt, substeps, thr, key, d_x, sdim); break;
     case TB_CELL_TT06: rc = run<TB_CELL_TT06>(dev, P, d_u, d_du, n_points, layout, t, dt, substeps, thr, key, d_x, sdim); break;
     case TB_CELL_FHN_HETEROGENEOUS: rc = run<TB_CELL_FHN_HETEROGENEOUS>(dev, P, d_u, d_du, n_points, layout, t, dt, substeps, thr, key, d_x, sdim); break;
+    case TB_CELL_ORD11: rc = run<TB_CELL_ORD11>(dev, P, d_u, d_du, n_points, layout, t, dt, substeps, thr, key, d_x, sdim); break;
     default: set_error("unknown cell model %d", model); return TB_ERR_BAD_ARG;
     }
     if (rc || !rmax) return rc;
