@@ -159,7 +159,7 @@ constexpr bool KE_DMAJOR = TB_KE_DMAJOR; // stored-Kₑ row layout of the matrix
 // CT: contraction of the tangent — 0 vector FMAs over the quadrature points (Q1; comparison build), 1 matrix cores (v_mfma_f64_16x16x4,
 // symmetric tiles), 2 sum-factorised over the tensor-product structure of the triquadratic basis and the 3×3×3 Gauss rule (Q2 default)
 template <class FE, bool NEED_K, bool NEED_R, int CT, bool AD>
-__global__ void __launch_bounds__(FE::THREADS, CT == 2 ? 2 : FE::WAVES)
+__global__ void __launch_bounds__(FE::THREADS, FE::WAVES)
 k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restrict__ list, const double *__restrict__ u, double *__restrict__ nz,
                double *__restrict__ r, const int64_t *__restrict__ rowptr, const uint16_t *__restrict__ blockpos, int atomic /*0 rmw, 1 atomic, 2 store Kₑ/rₑ*/,
                double *__restrict__ ke, double *__restrict__ re, Status *st, const uint8_t *__restrict__ rank27 /*non-NULL: symmetric-packed Kₑ (matrix-core path)*/)
@@ -178,9 +178,7 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
     double (*s_G)[NB][3] = reinterpret_cast<double (*)[NB][3]>(s_AG + AN);
     __shared__ uint8_t s_rank[32];
     // phase A scratch (common blocks + F) and phase B's double-buffered T share one region
-    constexpr int SF_Z2 = 3 * 4 * 81 * 3; // stage-2 values of the sum-factorised contraction
-    constexpr int TC_SIZE = (NEED_K && SF) ? (SF_Z2 > NQ * HOC_SIZE ? SF_Z2 : NQ * HOC_SIZE)
-                                           : (NEED_K && !MFMA && 2 * NB * 27 > NQ * HOC_SIZE) ? 2 * NB * 27 : NQ * HOC_SIZE;
+    constexpr int TC_SIZE = (NEED_K && CT == 0 && 2 * NB * 27 > NQ * HOC_SIZE) ? 2 * NB * 27 : NQ * HOC_SIZE;
     __shared__ double s_Ji[(NEED_K && SF) ? NQ : 1][9]; // J⁻¹ kept for the pull-back of 𝔸 (the slots of s_JI carry F after A2)
     __shared__ double s_TC[TC_SIZE];
     double (*s_T)[NB][27] = reinterpret_cast<double (*)[NB][27]>(s_TC);
@@ -477,9 +475,10 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
         //   stage 1  Z1[s][d][u][q₁][q₂][a₀][b₀]       = Σ_q₀ ψ(s==0)_{a₀}(q₀) ψ(u==0)_{b₀}(q₀) Â_q[c][s][d][u]
         //   stage 2  Z2[d][μ][ν][a₀][b₀][a₁][b₁][q₂]   = Σ_{s∈μ} Σ_{u∈ν} Σ_q₁ ψ(s==1)_{a₁}(q₁) ψ(u==1)_{b₁}(q₁) Z1
         //   stage 3  Kₑ[(a,c)][(b,d)]                  = Σ_μν Σ_q₂ ψ(μ)_{a₂}(q₂) ψ(ν)_{b₂}(q₂) Z2
-        // per row component c: 243 lane-tasks per stage (one per thread), 27 / 108 / 90 multiply-adds each out of 3 / 27 / 12 LDS reads — ≈ 1.6·10⁵
-        // multiply-adds per cell instead of the 1.2·10⁶ of the dense 81 × 27 × 81 products, on the vector ALUs, no symmetry assumed (so the
-        // rate-coupled, non-symmetric tangent runs here too).  Same sums as elements.jl:211-223 in another order (≲ 1e-15 relative).
+        // per row component c: 243 lane-tasks (one per thread) for stage 1 — 36 multiply-adds out of 3 LDS reads, 9 writes — and 243 for stages 2 + 3
+        // together, in registers — 81 + 90 multiply-adds out of 81 reads (no Z2 in LDS), the nine entries stored straight to Kₑ: ≈ 1.5·10⁵
+        // multiply-adds per cell instead of the 1.2·10⁶ of the dense 81 × 27 × 81 products, on the vector ALUs, 53 KB of LDS (three workgroups per
+        // CU), no symmetry assumed (so the rate-coupled, non-symmetric tangent runs here too).  Same sums as elements.jl:211-223 in another order.
         static_assert(T == 256 && NB == 27 && NQ == 27, "sum-factorised contraction: triquadratic field, 3×3×3 Gauss rule");
         if constexpr (NEED_R) { // the residual reads the mapped gradients, whose block stage 1 reuses
             if (tid < ND) {
@@ -510,9 +509,27 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
                 for (int u = 0; u < 3; ++u) Aq[9 * (3 * c + s_) + 3 * d + u] = ji[3 * s_] * t9[0][u] + ji[3 * s_ + 1] * t9[1][u] + ji[3 * s_ + 2] * t9[2][u];
         }
         lds_barrier(); // LDS traffic only: the stores of the previous rows stay in flight
-        double *Z1 = &s_G[0][0][0], *Z2 = s_TC, *outb = &s_G[0][0][0]; // Z1 is dead when stage 3 writes the 27 × 81 rows of this component
+        double *Z1 = &s_G[0][0][0];
         auto PH = [](int i, int q) constexpr { return quad1d(i, G3::x(q)); };
         auto DP = [](int i, int q) constexpr { return dquad1d(i, G3::x(q)); };
+        // task of stages 2 + 3 (fixed for the three row components): lanes of a wave share (a₀, a₁) where they can — their stores then fall into the
+        // same rows of Kₑ — and the nine lanes (a₁, b₁) of one (d, a₀, b₀) read the same Z1 words (LDS broadcast)
+        int t23 = tid < 243 ? tid : 0;
+        const int tb1 = t23 % 3; t23 /= 3;
+        const int tb0 = t23 % 3; t23 /= 3;
+        const int td = t23 % 3; t23 /= 3;
+        const int ta1 = t23 % 3;
+        const int ta0 = t23 / 3;
+        double c2[2][2][3]; // ψ(s==1)_{a₁}(q₁) · ψ(u==1)_{b₁}(q₁)
+#pragma unroll
+        for (int q1 = 0; q1 < 3; ++q1) {
+            const double pa = ta1 == 0 ? PH(0, q1) : ta1 == 1 ? PH(1, q1) : PH(2, q1), da = ta1 == 0 ? DP(0, q1) : ta1 == 1 ? DP(1, q1) : DP(2, q1);
+            const double pb = tb1 == 0 ? PH(0, q1) : tb1 == 1 ? PH(1, q1) : PH(2, q1), db = tb1 == 0 ? DP(0, q1) : tb1 == 1 ? DP(1, q1) : DP(2, q1);
+            c2[0][0][q1] = pa * pb; c2[0][1][q1] = pa * db; c2[1][0][q1] = da * pb; c2[1][1][q1] = da * db;
+        }
+        int rowa[3], colb[3]; // Ferrite nodes of (a₀, a₁, ·) and (b₀, b₁, ·)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { rowa[k] = g_hex27_node[ta0 + 3 * ta1 + 9 * k]; colb[k] = g_hex27_node[tb0 + 3 * tb1 + 9 * k]; }
         for (int c = 0; c < 3; ++c) {
             if (tid < 243) { // stage 1: task (s, d, u, q₁, q₂)
                 int t = tid;
@@ -521,67 +538,40 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
                 const int u = t % 3; t /= 3;
                 const int d = t % 3;
                 const int s_ = t / 3;
-                double in[3], tb0[3][3];
+                double in[3], tb0_[3][3];
 #pragma unroll
                 for (int q0 = 0; q0 < 3; ++q0) in[q0] = s_A[q0 + 3 * q1 + 9 * q2][9 * (3 * c + s_) + 3 * d + u];
 #pragma unroll
                 for (int b0 = 0; b0 < 3; ++b0)
 #pragma unroll
-                    for (int q0 = 0; q0 < 3; ++q0) tb0[b0][q0] = (u == 0 ? DP(b0, q0) : PH(b0, q0)) * in[q0];
+                    for (int q0 = 0; q0 < 3; ++q0) tb0_[b0][q0] = (u == 0 ? DP(b0, q0) : PH(b0, q0)) * in[q0];
 #pragma unroll
                 for (int a0 = 0; a0 < 3; ++a0)
 #pragma unroll
                     for (int b0 = 0; b0 < 3; ++b0) {
                         double v = 0.0;
 #pragma unroll
-                        for (int q0 = 0; q0 < 3; ++q0) v += (s_ == 0 ? DP(a0, q0) : PH(a0, q0)) * tb0[b0][q0];
+                        for (int q0 = 0; q0 < 3; ++q0) v += (s_ == 0 ? DP(a0, q0) : PH(a0, q0)) * tb0_[b0][q0];
                         Z1[9 * tid + 3 * a0 + b0] = v;
                     }
             }
-            lds_barrier(); // LDS traffic only: the stores of the previous rows stay in flight
-            if (tid < 243) { // stage 2: task (d, a₀, b₀, q₂, b₁)
-                int t = tid;
-                const int b1 = t % 3; t /= 3;
-                const int q2 = t % 3; t /= 3;
-                const int b0 = t % 3; t /= 3;
-                const int a0 = t % 3;
-                const int d = t / 3;
-                double acc2[2][2][3];
+            lds_barrier();
+            if (tid < 243) { // stages 2 + 3 in registers: 81 LDS reads, nine entries (a₂, b₂) of row component c out
+                double z[2][2][3];
 #pragma unroll
-                for (int e = 0; e < 12; ++e) (&acc2[0][0][0])[e] = 0.0;
+                for (int e = 0; e < 12; ++e) (&z[0][0][0])[e] = 0.0;
 #pragma unroll
                 for (int s_ = 0; s_ < 3; ++s_)
 #pragma unroll
                     for (int u = 0; u < 3; ++u)
 #pragma unroll
                         for (int q1 = 0; q1 < 3; ++q1) {
-                            const double pb = u == 1 ? (b1 == 0 ? DP(0, q1) : b1 == 1 ? DP(1, q1) : DP(2, q1)) : (b1 == 0 ? PH(0, q1) : b1 == 1 ? PH(1, q1) : PH(2, q1));
-                            const double z = Z1[9 * (((((s_ * 3 + d) * 3 + u) * 3 + q1) * 3) + q2) + 3 * a0 + b0] * pb;
+                            const double cf = c2[s_ == 1][u == 1][q1];
+                            const double *zp = Z1 + 9 * ((((s_ * 3 + td) * 3 + u) * 3 + q1) * 3) + 3 * ta0 + tb0;
 #pragma unroll
-                            for (int a1 = 0; a1 < 3; ++a1) acc2[s_ == 2][u == 2][a1] += (s_ == 1 ? DP(a1, q1) : PH(a1, q1)) * z;
+                            for (int q2 = 0; q2 < 3; ++q2) z[s_ == 2][u == 2][q2] += cf * zp[9 * q2];
                         }
-#pragma unroll
-                for (int mu = 0; mu < 2; ++mu)
-#pragma unroll
-                    for (int nu = 0; nu < 2; ++nu)
-#pragma unroll
-                        for (int a1 = 0; a1 < 3; ++a1) Z2[((((((d * 2 + mu) * 2 + nu) * 3 + a0) * 3 + b0) * 3 + a1) * 3 + b1) * 3 + q2] = acc2[mu][nu][a1];
-            }
-            lds_barrier(); // LDS traffic only: the stores of the previous rows stay in flight
-            if (tid < 243) { // stage 3: task (d, a₀, b₀, a₁, b₁) → the nine entries (a₂, b₂)
-                int t = tid;
-                const int b1 = t % 3; t /= 3;
-                const int a1 = t % 3; t /= 3;
-                const int b0 = t % 3; t /= 3;
-                const int a0 = t % 3;
-                const int d = t / 3;
-                double z[2][2][3], w[2][3][3]; // w[μ][b₂][q₂] = Σ_ν ψ(ν)_{b₂}(q₂) z[μ][ν][q₂]
-#pragma unroll
-                for (int mu = 0; mu < 2; ++mu)
-#pragma unroll
-                    for (int nu = 0; nu < 2; ++nu)
-#pragma unroll
-                        for (int q2 = 0; q2 < 3; ++q2) z[mu][nu][q2] = Z2[((((((d * 2 + mu) * 2 + nu) * 3 + a0) * 3 + b0) * 3 + a1) * 3 + b1) * 3 + q2];
+                double w[2][3][3]; // w[μ][b₂][q₂] = Σ_ν ψ(ν)_{b₂}(q₂) z[μ][ν][q₂]
 #pragma unroll
                 for (int mu = 0; mu < 2; ++mu)
 #pragma unroll
@@ -589,32 +579,21 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
 #pragma unroll
                         for (int q2 = 0; q2 < 3; ++q2) w[mu][b2][q2] = PH(b2, q2) * z[mu][0][q2] + DP(b2, q2) * z[mu][1][q2];
 #pragma unroll
-                for (int a2 = 0; a2 < 3; ++a2) {
-                    const int a = g_hex27_node[a0 + 3 * a1 + 9 * a2];
+                for (int a2 = 0; a2 < 3; ++a2)
 #pragma unroll
                     for (int b2 = 0; b2 < 3; ++b2) {
                         double v = 0.0;
 #pragma unroll
                         for (int q2 = 0; q2 < 3; ++q2) v += PH(a2, q2) * w[0][b2][q2] + DP(a2, q2) * w[1][b2][q2];
-                        outb[a * ND + 3 * g_hex27_node[b0 + 3 * b1 + 9 * b2] + d] = v;
+                        // assemble!(assembler, dofs, Kₑ): entry ((a, c), (b, d))
+                        if (atomic == 2) ke[((int64_t)cell * ND + 3 * rowa[a2] + c) * ND + 3 * colb[b2] + td] = v;
+                        else {
+                            const int64_t k = rowptr[s_dof[3 * rowa[a2]] + c] + blockpos[cell * (NB * NB) + rowa[a2] * NB + colb[b2]] + td;
+                            if (atomic) unsafeAtomicAdd(nz + k, v); else nz[k] += v;
+                        }
                     }
-                }
             }
-            lds_barrier(); // LDS traffic only: the stores of the previous rows stay in flight
-            // rows (a, c), a = 0 … 26, of Kₑ: assemble!(assembler, dofs, Kₑ)
-            if (atomic == 2) {
-                for (int idx = tid; idx < NB * ND; idx += T) {
-                    const int a = idx / ND, j = idx - a * ND;
-                    ke[((int64_t)cell * ND + 3 * a + c) * ND + j] = outb[idx];
-                }
-            } else {
-                for (int idx = tid; idx < NB * ND; idx += T) {
-                    const int a = idx / ND, j = idx - a * ND, b = j / 3, d = j - 3 * b;
-                    const int64_t k = rowptr[s_dof[3 * a] + c] + blockpos[cell * (NB * NB) + a * NB + b] + d;
-                    if (atomic) unsafeAtomicAdd(nz + k, outb[idx]); else nz[k] += outb[idx];
-                }
-            }
-            lds_barrier(); // LDS traffic only: the stores of the previous rows stay in flight
+            lds_barrier(); // Z1 is rewritten by the next component's stage 1
         }
     } else {
     // B: sweep the points
