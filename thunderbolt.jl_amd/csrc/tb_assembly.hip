@@ -737,6 +737,9 @@ __constant__ uint8_t g_q2_tix[27] = {
     1 | 2 << 2 | 2 << 4, 0 | 1 << 2 | 2 << 4, 0 | 0 << 2 | 1 << 4, 2 | 0 << 2 | 1 << 4, 2 | 2 << 2 | 1 << 4, 0 | 2 << 2 | 1 << 4, 1 | 1 << 2 | 0 << 4,
     1 | 0 << 2 | 1 << 4, 2 | 1 << 2 | 1 << 4, 1 | 2 << 2 | 1 << 4, 0 | 1 << 2 | 1 << 4, 1 | 1 << 2 | 2 << 4, 1 | 1 << 2 | 1 << 4};
 
+// inverse of g_q2_tix: tensor index t₀ + 3 t₁ + 9 t₂ → Ferrite node
+__constant__ uint8_t g_q2_node[27] = {0, 8, 1, 11, 20, 9, 3, 10, 2, 16, 21, 17, 24, 26, 22, 19, 23, 18, 4, 12, 5, 15, 25, 13, 7, 14, 6};
+
 // 1-D quadratic Lagrange factor t ∈ {0: ξ = −1, 1: ξ = 0, 2: ξ = +1} and its derivative at x (tb_elem.hpp Hex27::q1 / dq1)
 __device__ __forceinline__ double q2_l(int t, double x) { return t == 0 ? 0.5 * x * (x - 1.0) : t == 1 ? (1.0 - x * x) : 0.5 * x * (x + 1.0); }
 __device__ __forceinline__ double q2_dl(int t, double x) { return t == 0 ? x - 0.5 : t == 1 ? -2.0 * x : x + 0.5; }
@@ -968,6 +971,193 @@ k_matrix_q2(MeshView m, FormArgs fa, const double *__restrict__ cell_xyz, const 
     else run(std::false_type{}, std::true_type{});
 }
 
+// Sum-factorised form of the same element matrices (default; the matrix-core kernel above stays as the TB_Q2_KERNEL=mfma comparison).  With the
+// coefficient pulled back to the reference cell (S_q above) the sum over the 27 Gauss points is three one-dimensional contractions, because node
+// i ↔ (i₀, i₁, i₂), point q ↔ (q₀, q₁, q₂) and ∂̂ₘNᵢ(ξ_q) = Π_dim ψ(dim == m)_{i_dim}(q_dim), ψ(false) = φ, ψ(true) = φ′:
+//   stage 1  Z1[m][n][q₁][q₂][i₀][j₀] = Σ_q₀ ψ(m==0)_{i₀}(q₀) ψ(n==0)_{j₀}(q₀) S_q[m][n]                     (81 lane-tasks per cell: 36 multiply-adds)
+//   stages 2 + 3 in registers, task (i₀, j₀, i₁, j₁): contract q₁ — after which only "m is 2 or not" matters — then q₂ → the nine entries (i₂, j₂)
+//                                                                                                              (81 tasks: 171 multiply-adds, 81 LDS reads)
+// ≈ 1.7·10⁴ multiply-adds per cell for the stiffness matrix instead of 5.9·10⁴ (mass: 9 + 81 small tasks), on the vector ALUs.  A workgroup takes
+// THREE cells per pass so that the 81-task stages fill 243 of its 256 lanes; 24 KB of LDS, persistent, the vertex coordinates of the next triple
+// requested one pass ahead.  Measured at 64³ (stiffness integration alone): 0.64 ms against 1.07 ms for the matrix-core kernel; a build forced
+// to three waves per SIMD spilled 200 B and took 1.19 ms; a wave-per-cell form without workgroup barriers (81 tasks in two rounds of 64 lanes,
+// geometry on 27 lanes) 0.85 ms — the half-empty second rounds cost more than the barriers.  Same sums as mass.jl:28-43 / diffusion.jl:28-50 in
+// another order (≲ 1e-15 relative); no symmetry assumed, so non-symmetric constant tensors need no variant of their own.
+template <int FORM, bool FIELD>
+__global__ void __launch_bounds__(256, 2)
+k_matrix_q2_sf(MeshView m, FormArgs fa, const double *__restrict__ cell_xyz, const int32_t *__restrict__ list, int64_t n_list, const int64_t *__restrict__ rowptr,
+               const uint16_t *__restrict__ pos, double *__restrict__ nz, int atomic /*0 rmw, 1 atomic, 2 store Kₑ*/, double *__restrict__ ke, Status *st)
+{
+    constexpr bool DIFF = FORM == TB_FORM_DIFFUSION;
+    constexpr int NS = DIFF ? 9 : 1, NZ1 = DIFF ? 729 : 81;
+    constexpr double GX = 0.7745966692414834;
+    __shared__ double s_x[3][24], s_rho[3][8], s_S[3][27][NS], s_Z1[3][NZ1];
+    const int tid = threadIdx.x;
+    auto PH = [](int i, int q) constexpr { return i == 0 ? 0.5 * (GX * (q - 1)) * (GX * (q - 1) - 1.0) : i == 1 ? 1.0 - (GX * (q - 1)) * (GX * (q - 1)) : 0.5 * (GX * (q - 1)) * (GX * (q - 1) + 1.0); };
+    auto DP = [](int i, int q) constexpr { return i == 0 ? GX * (q - 1) - 0.5 : i == 1 ? -2.0 * (GX * (q - 1)) : GX * (q - 1) + 0.5; };
+    auto cell_of = [&](int64_t k) -> int64_t { return list ? (int64_t)list[k] : k; };
+    const int64_t ntrip = (n_list + 2) / 3;
+    // task of stages 2 + 3: cell kc of the triple, (j₁, j₀, i₁, i₀) — fixed for the life of the workgroup
+    const int kc = tid / 81, t81 = tid - 81 * kc;
+    const int tj1 = t81 % 3, tj0 = (t81 / 3) % 3, ti1 = (t81 / 9) % 3, ti0 = t81 / 27;
+    double c2[2][2][3]; // ψ(m==1)_{i₁}(q₁)·ψ(n==1)_{j₁}(q₁)
+#pragma unroll
+    for (int q1 = 0; q1 < 3; ++q1) {
+        const double pa = ti1 == 0 ? PH(0, q1) : ti1 == 1 ? PH(1, q1) : PH(2, q1), da = ti1 == 0 ? DP(0, q1) : ti1 == 1 ? DP(1, q1) : DP(2, q1);
+        const double pb = tj1 == 0 ? PH(0, q1) : tj1 == 1 ? PH(1, q1) : PH(2, q1), db = tj1 == 0 ? DP(0, q1) : tj1 == 1 ? DP(1, q1) : DP(2, q1);
+        c2[0][0][q1] = pa * pb; c2[0][1][q1] = pa * db; c2[1][0][q1] = da * pb; c2[1][1][q1] = da * db;
+    }
+    int rowi[3], colj[3]; // Ferrite nodes of (i₀, i₁, ·), (j₀, j₁, ·)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { rowi[k] = g_q2_node[ti0 + 3 * ti1 + 9 * k]; colj[k] = g_q2_node[tj0 + 3 * tj1 + 9 * k]; }
+    // inputs of a triple: lanes 0–71 one vertex coordinate each, lanes 96–119 one nodal density each
+    auto request = [&](int64_t trip, double &px, double &pr) {
+        px = 0.0; pr = 0.0;
+        if (tid < 72) { const int64_t k = 3 * trip + tid / 24; if (k < n_list) px = cell_xyz[cell_of(k) * 24 + tid % 24]; }
+        if constexpr (!DIFF && FIELD) if (tid >= 96 && tid < 120) { const int64_t k = 3 * trip + (tid - 96) / 8; if (k < n_list) pr = fa.field[cell_of(k) * 8 + (tid - 96) % 8]; }
+    };
+    double px, pr;
+    int64_t trip = blockIdx.x;
+    if (trip >= ntrip) return;
+    request(trip, px, pr);
+    for (; trip < ntrip; trip += gridDim.x) {
+        if (tid < 72) s_x[tid / 24][tid % 24] = px;
+        if constexpr (!DIFF && FIELD) if (tid >= 96 && tid < 120) s_rho[(tid - 96) / 8][(tid - 96) % 8] = pr;
+        lds_barrier();
+        if (trip + gridDim.x < ntrip) request(trip + gridDim.x, px, pr); // next triple's inputs travel during this one's arithmetic
+        const int64_t kcell = 3 * trip + kc;
+        const bool live = tid < 243 && kcell < n_list;
+        const int64_t cell = live ? cell_of(kcell) : 0;
+        // geometry of the 27 points of each cell: lane = (cell of the triple, point)
+        if (tid < 81) {
+            const int k = tid / 27, q = tid - 27 * k;
+            const int64_t kk = 3 * trip + k;
+            if (kk < n_list) {
+                const int64_t c = cell_of(kk);
+                double D[9];
+                if constexpr (DIFF && FIELD) {
+                    const double *dp = fa.dtab + (c * 27 + q) * 6; // tensor tabulated at the 27 points (k_tabulate_spectral / _isotropic over Hex8<3>: same point order)
+                    D[0] = dp[0]; D[1] = D[3] = dp[1]; D[2] = D[6] = dp[2]; D[4] = dp[3]; D[5] = D[7] = dp[4]; D[8] = dp[5];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 9; ++e) D[e] = DIFF ? fa.D[e] : 0.0;
+                }
+                q2_point_geometry<DIFF, !DIFF && FIELD>(s_x[k], q, s_S[k][q], fa.rho, s_rho[k], D, c, st);
+            }
+        }
+        lds_barrier();
+        // stage 1
+        if constexpr (DIFF) {
+            if (tid < 243) { // task (m, n, q₁, q₂) of cell kc
+                int t = t81;
+                const int q2 = t % 3; t /= 3;
+                const int q1 = t % 3; t /= 3;
+                const int n_ = t % 3;
+                const int m_ = t / 3;
+                double in[3], tb0[3][3];
+#pragma unroll
+                for (int q0 = 0; q0 < 3; ++q0) in[q0] = s_S[kc][q0 + 3 * q1 + 9 * q2][3 * m_ + n_];
+#pragma unroll
+                for (int j0 = 0; j0 < 3; ++j0)
+#pragma unroll
+                    for (int q0 = 0; q0 < 3; ++q0) tb0[j0][q0] = (n_ == 0 ? DP(j0, q0) : PH(j0, q0)) * in[q0];
+#pragma unroll
+                for (int i0 = 0; i0 < 3; ++i0)
+#pragma unroll
+                    for (int j0 = 0; j0 < 3; ++j0) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int q0 = 0; q0 < 3; ++q0) v += (m_ == 0 ? DP(i0, q0) : PH(i0, q0)) * tb0[j0][q0];
+                        s_Z1[kc][9 * t81 + 3 * i0 + j0] = v;
+                    }
+            }
+        } else {
+            if (tid < 27) { // task (q₁, q₂) of cell tid / 9
+                const int k = tid / 9, t = tid - 9 * k, q2 = t % 3, q1 = t / 3;
+                double in[3];
+#pragma unroll
+                for (int q0 = 0; q0 < 3; ++q0) in[q0] = s_S[k][q0 + 3 * q1 + 9 * q2][0];
+#pragma unroll
+                for (int i0 = 0; i0 < 3; ++i0)
+#pragma unroll
+                    for (int j0 = 0; j0 < 3; ++j0) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int q0 = 0; q0 < 3; ++q0) v += PH(i0, q0) * PH(j0, q0) * in[q0];
+                        s_Z1[k][9 * t + 3 * i0 + j0] = v;
+                    }
+            }
+        }
+        lds_barrier();
+        // stages 2 + 3
+        if (live) {
+            double out[3][3];
+            if constexpr (DIFF) {
+                double z[2][2][3];
+#pragma unroll
+                for (int e = 0; e < 12; ++e) (&z[0][0][0])[e] = 0.0;
+#pragma unroll
+                for (int m_ = 0; m_ < 3; ++m_)
+#pragma unroll
+                    for (int n_ = 0; n_ < 3; ++n_)
+#pragma unroll
+                        for (int q1 = 0; q1 < 3; ++q1) {
+                            const double cf = c2[m_ == 1][n_ == 1][q1];
+                            const double *zp = &s_Z1[kc][9 * (((m_ * 3 + n_) * 3 + q1) * 3) + 3 * ti0 + tj0];
+#pragma unroll
+                            for (int q2 = 0; q2 < 3; ++q2) z[m_ == 2][n_ == 2][q2] += cf * zp[9 * q2];
+                        }
+                double w[2][3][3];
+#pragma unroll
+                for (int mu = 0; mu < 2; ++mu)
+#pragma unroll
+                    for (int j2 = 0; j2 < 3; ++j2)
+#pragma unroll
+                        for (int q2 = 0; q2 < 3; ++q2) w[mu][j2][q2] = PH(j2, q2) * z[mu][0][q2] + DP(j2, q2) * z[mu][1][q2];
+#pragma unroll
+                for (int i2 = 0; i2 < 3; ++i2)
+#pragma unroll
+                    for (int j2 = 0; j2 < 3; ++j2) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int q2 = 0; q2 < 3; ++q2) v += PH(i2, q2) * w[0][j2][q2] + DP(i2, q2) * w[1][j2][q2];
+                        out[i2][j2] = v;
+                    }
+            } else {
+                double z[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q1 = 0; q1 < 3; ++q1) {
+                    const double *zp = &s_Z1[kc][9 * (q1 * 3) + 3 * ti0 + tj0];
+#pragma unroll
+                    for (int q2 = 0; q2 < 3; ++q2) z[q2] += c2[0][0][q1] * zp[9 * q2];
+                }
+#pragma unroll
+                for (int i2 = 0; i2 < 3; ++i2)
+#pragma unroll
+                    for (int j2 = 0; j2 < 3; ++j2) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int q2 = 0; q2 < 3; ++q2) v += PH(i2, q2) * PH(j2, q2) * z[q2];
+                        out[i2][j2] = v;
+                    }
+            }
+            const int64_t pbase = cell * 729;
+#pragma unroll
+            for (int i2 = 0; i2 < 3; ++i2)
+#pragma unroll
+                for (int j2 = 0; j2 < 3; ++j2) {
+                    const int e = 27 * rowi[i2] + colj[j2];
+                    if (atomic == 2) ke[pbase + e] = out[i2][j2];
+                    else {
+                        const int64_t k = rowptr[m.cell_dofs[cell * 27 + rowi[i2]]] + pos[pbase + e];
+                        if (atomic) unsafeAtomicAdd(nz + k, out[i2][j2]); else nz[k] += out[i2][j2];
+                    }
+                }
+        }
+        lds_barrier(); // the staging arrays are rewritten by the next pass
+    }
+}
+
 // ElementAssemblyStrategy for the quadratic scalar field, second pass: a half-wave per row sums the rows of the element matrices that touch its dof
 // (27 lanes, an LDS copy of the CSR row, cells in ascending order: bit-reproducible) and stores the CSR row once.  The contributing (cell, local row)
 // slots come from a fixed-width table (W per row, −1 padded: one load, no pointer chase) and the index and value loads of eight cells are all in
@@ -1114,6 +1304,16 @@ static int run_q2(tb_form *f, tb_pattern *p, int strategy, double t, double *d_n
     }
     auto go = [&](const int32_t *list, int64_t n, int atomic) -> int {
         if (n == 0) return TB_OK;
+        static const bool q2_mfma = getenv("TB_Q2_KERNEL") && !strcmp(getenv("TB_Q2_KERNEL"), "mfma"); // the matrix-core kernel (comparison)
+        if (d_nz && !q2_mfma && atomic == 2) { // sum-factorised element matrices: three cells per pass, persistent (the scattering strategies keep the matrix-core kernel: it hands its entries over in entry order)
+            const unsigned wg3 = (unsigned)std::min<int64_t>((n + 2) / 3, (int64_t)dev->n_cu * 6);
+#define TB_Q2S(FORM, FIELD) hipLaunchKernelGGL((k_matrix_q2_sf<FORM, FIELD>), dim3(wg3), dim3(256), 0, dev->stream, mv, fa, m->d_cell_xyz, list, n, p->d_rowptr, p->d_q2pos, d_nz, atomic, kebuf, dev->d_status)
+            if (f->kind == TB_FORM_MASS) { if (f->field) TB_Q2S(TB_FORM_MASS, true); else TB_Q2S(TB_FORM_MASS, false); }
+            else { if (f->field) TB_Q2S(TB_FORM_DIFFUSION, true); else TB_Q2S(TB_FORM_DIFFUSION, false); }
+#undef TB_Q2S
+            TB_HIP(hipGetLastError());
+            return TB_OK;
+        }
         // persistent workgroups: three per CU (≤ 168 VGPRs)
         const unsigned wgs = (unsigned)std::min<int64_t>(n, (int64_t)dev->n_cu * 3);
 #define TB_Q2(FORM, FIELD, SYM) hipLaunchKernelGGL((k_matrix_q2<FORM, FIELD, SYM>), dim3(wgs), dim3(256), 0, dev->stream, mv, fa, m->d_cell_xyz, list, n, p->d_rowptr, p->d_q2pos, d_nz, atomic, kebuf, dev->d_status)
