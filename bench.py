@@ -328,7 +328,7 @@ def main():
         bytes_per_cell = (BYTES_PER_CELL_MATRIX + 216.0) if fused else BYTES_PER_CELL_MATRIX
         achieved = bytes_per_cell * g.n_cells / (k_ms * 1e-3) / 1e9
         if args.strategy == "patch":
-            kname = "k_patch_hex8<K+M>" if fused else "k_patch_hex8<K>"
+            kname = "k_patch_hex8_staged<K+M,DIAG>" if fused else "k_patch_hex8_staged<K>"
         else:
             kname = "k_matrix_direct<Hex8<2>,DIFFUSION>"
         mk_ms = k_ms + phase["mass"] / K_
@@ -347,7 +347,12 @@ def main():
             "phase_rates": {"matrix_integrations_per_s": 2 * g.n_cells / (mk_ms * 1e-3),
                             "source_cells_per_s": g.n_cells / (phase["source"] / K_ * 1e-3),
                             "reaction_dof_updates_per_s": ns * npts / (phase["reaction"] / K_ * 1e-3)},
-            "roofline": {"kernel": kname, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            # "bound" names the roofline the kernel is priced against (its algorithmic bytes over the HBM peak); "limiter" what the counters and phase
+            # stamps say holds it there (profiles/r03_v1/sym_kernel_v3.txt): the integration phase of a patch runs at the vector ALU's own
+            # rate (≈ 2 200 instructions per cell instance, 1.70 instances per cell), the staging and write-out phases are latency-bound, and only two
+            # workgroups per CU (254 VGPRs, 77 KB of LDS) overlap them — VALU busy ≈ 50 %, HBM traffic 1.15× the algorithmic bytes
+            "roofline": {"kernel": kname, "bound": "hbm", "limiter": "fp64 vector issue in the integration phase + latency-bound staging / write-out phases at two workgroups per CU (not HBM, not the LDS atomics)" if fused else "see DESIGN.md §5",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "algorithmic_bytes_per_cell": bytes_per_cell, "launch_ms": k_ms,
                          "frac_per_integration": BYTES_PER_CELL_MATRIX * 2 * g.n_cells / (mk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "reaction": {"bound": "hbm", "achieved": (BYTES_PER_DOF_UPDATE + (8 if args.keep_du else 0)) * ns * npts / (phase["reaction"] / K_ * 1e-3) / 1e9,

@@ -979,6 +979,12 @@ int ensure_vec_patch_plan(tb_mesh *m, bool halo)
         for (size_t k = nbase; k < pnode.size(); ++k) local_of[pnode[k]] = -1;
     }
     if (bad) { set_error("vector patch plan: dofs and vertices of the field are not in one-to-one correspondence"); return TB_ERR_UNSUPPORTED; }
+    // the kernel keeps 32 B per patch node in LDS and is built for three workgroups per CU: fragmented patches (quantile buckets on hollow or
+    // strongly graded meshes, a large TB_VPATCH_TILE) that need more than a third of the 160 KiB take the general kernels instead of a launch failure
+    if ((int64_t)plan->max_nodes * 32 > 160 * 1024 / 3) {
+        set_error("vector patch plan: a patch touches %d nodes (%d B of LDS, more than a third of a CU's 160 KiB)", plan->max_nodes, plan->max_nodes * 32);
+        return TB_ERR_UNSUPPORTED;
+    }
     if ((int64_t)ecell.size() >= (int64_t)0x7fffffff || (int64_t)pnode.size() >= (int64_t)0x7fffffff) { set_error("vector patch plan: too many instances for 32-bit offsets"); return TB_ERR_UNSUPPORTED; }
     plan->total_elems = (int64_t)ecell.size();
     plan->total_nodes = (int64_t)pnode.size();
