@@ -487,6 +487,56 @@ def test_heat_algebra_parity(tb, oracle, device):
     np.testing.assert_allclose(out.to_host(), a - 0.3 * b, rtol=0, atol=1e-15)  # FMA vs two roundings
 
 
+@pytest.mark.parametrize("order", [1, 2])
+def test_halo_pack_unpack_and_product_entries_of_the_abi(tb, oracle, device, order):
+    """The multi-GPU building blocks of include/tbhip.h one by one against numpy on an assembled operator (scalar first-order field: stream SpMV;
+    second-order vector field: 3 × 3 block SpMV): tb_gather_indexed, tb_scatter_add_indexed, tb_spmv_csr_rows, tb_spmv_csr_dot, tb_extract_diagonal;
+    argument checks; empty index lists."""
+    import scipy.sparse as ssp
+    lib, check = tb.lib(), tb._lib.check
+    rng = np.random.default_rng(21)
+    if order == 1:
+        g, dh, sp, om = make_problem(tb, oracle, nel=(6, 5, 4))
+        K = tb.update_operator(tb.setup_operator(tb.PatchAssemblyStrategy(device), tb.BilinearDiffusionIntegrator(tb.ConstantCoefficient(np.diag([2.0, 1.0, 0.5]))), dh, sp), 0.0)
+        pattern, nz = K.pattern, K.A
+    else:
+        g, dh, sp, om = mech_problem(tb, oracle, (2, 2, 2), 2)
+        qm = tb.QuasiStaticModel("u", tb.PK1Model(tb.HolzapfelOgden2009Model(), tb.ConstantCoefficient(tb.OrthotropicMicrostructure(*np.eye(3)))))
+        op = tb.setup_operator(tb.ElementAssemblyStrategy(device), qm, dh, sp)
+        tb.update_linearization(op, device.to_device(rng.uniform(-1e-2, 1e-2, dh.ndofs)), 0.0)
+        pattern, nz = op.pattern, op.J
+    n = dh.ndofs
+    A = ssp.csr_matrix((nz.to_host(), sp.colidx, sp.rowptr), shape=(n, n))
+    x = rng.normal(size=n)
+    dx = device.to_device(x)
+    idx = rng.choice(n, size=min(n, 97), replace=False).astype(np.int32)
+    didx = device.to_device(idx)
+    out = device.zeros(len(idx))
+    check(lib.tb_gather_indexed(device.h, len(idx), dx.ptr, didx.ptr, out.ptr))
+    np.testing.assert_array_equal(out.to_host(), x[idx])
+    v = rng.normal(size=n)
+    dv = device.to_device(v)
+    check(lib.tb_scatter_add_indexed(device.h, len(idx), out.ptr, didx.ptr, dv.ptr))
+    ref = v.copy()
+    ref[idx] += x[idx]
+    np.testing.assert_array_equal(dv.to_host(), ref)
+    check(lib.tb_spmv_csr_rows(pattern.h, nz.ptr, dx.ptr, len(idx), didx.ptr, out.ptr))
+    Ax = A @ x
+    assert np.abs(out.to_host() - Ax[idx]).max() < 1e-13 * np.abs(Ax).max()
+    y, dot = device.zeros(n), device.to_device(np.array([0.25]))
+    check(lib.tb_spmv_csr_dot(pattern.h, nz.ptr, dx.ptr, y.ptr, dot.ptr))
+    assert np.abs(y.to_host() - Ax).max() < 1e-13 * np.abs(Ax).max()
+    np.testing.assert_allclose(dot.to_host()[0], 0.25 + x @ Ax, rtol=1e-12)          # accumulates into the device scalar
+    diag = device.zeros(n)
+    check(lib.tb_extract_diagonal(pattern.h, nz.ptr, diag.ptr))
+    np.testing.assert_array_equal(diag.to_host(), A.diagonal())
+    # empty lists are no-ops, NULL arguments are refused
+    assert lib.tb_gather_indexed(device.h, 0, None, None, None) == 0 and lib.tb_scatter_add_indexed(device.h, 0, None, None, None) == 0
+    assert lib.tb_spmv_csr_rows(pattern.h, nz.ptr, dx.ptr, 0, None, None) == 0
+    assert lib.tb_gather_indexed(device.h, 3, dx.ptr, None, out.ptr) == tb._lib.TB_ERR_BAD_ARG
+    assert lib.tb_spmv_csr_dot(pattern.h, nz.ptr, dx.ptr, y.ptr, None) == tb._lib.TB_ERR_BAD_ARG
+
+
 # ------------------------------------------------------------------------------------------- BASELINE sizes
 def _sampled_rows_error(oracle, om, form, oc, sp, cell_dofs, nz, rows):
     """max |nz − oracle| over every entry of the given rows, the oracle summing its element matrices of the cells around them"""
