@@ -467,6 +467,25 @@ int tb_meandiag(tb_pattern *pat, const double *d_nzval, double *result);
  * (src/solver/time/rtc.jl:64-73 — no absolute value there).  n == 0 yields −∞. */
 int tb_max(tb_device *dev, int64_t n, const double *d_x, int64_t stride, double *result);
 
+/* ------------------------------------------------------------------ Float32 value type
+ * The reference types its device path by value_type(device) and its own GPU tests run Float32 (ext/CuThunderboltExt.jl:126-127,
+ * test/gpu/test_operators.jl:20-31, test/gpu/ensemble-test.jl:8-40, test/gpu/diffusion-test.jl).  These entries are the `MI355XDevice{Float32,Int32}`
+ * flavour of the ones above: every caller-visible array is Float32, arithmetic stays Float64 — assembly and the Krylov solve run the Float64 kernels
+ * on a scratch arena owned by the device object and round the result once; the reaction step, SpMV, A = M − Δt·K and axpy convert in registers.
+ * Same argument meaning and error behaviour as their Float64 namesakes; tb_malloc / tb_memcpy_* / tb_free are type-agnostic already. */
+int tb_convert_f64_to_f32(tb_device *dev, int64_t n, const double *d_in, float *d_out);
+int tb_convert_f32_to_f64(tb_device *dev, int64_t n, const float *d_in, double *d_out);
+int tb_assemble_matrix_f32(tb_form *form, tb_pattern *pat, int strategy, double t, float *d_nzval);
+int tb_assemble_matrix_pair_f32(tb_form *mass, tb_form *diffusion, tb_pattern *pat, int strategy, double t, float *d_nzval_mass, float *d_nzval_diffusion);
+int tb_assemble_vector_f32(tb_form *form, int strategy, double t, float *d_b);
+/* d_x NULL: tb_reaction_step; otherwise tb_reaction_step_x */
+int tb_reaction_step_f32(tb_device *dev, int model, const double *params, int n_params, float *d_u, float *d_du, int64_t n_points, int n_states, int layout,
+                         const float *d_x, int sdim, double t, double dt, int substeps, double threshold);
+int tb_spmv_csr_f32(tb_pattern *pat, const float *d_nzval, const float *d_x, double alpha, double beta, float *d_y);
+int tb_heat_matrix_f32(tb_device *dev, int64_t nnz, const float *d_Mnz, const float *d_Knz, double dt, float *d_Anz);
+int tb_axpy_f32(tb_device *dev, int64_t n, double a, const float *d_x, float *d_y);
+int tb_cg_solve_f32(tb_pattern *pat, const float *d_Anz, const float *d_b, float *d_x, double rtol, double atol, int maxiter, int jacobi, int *iters, double *resnorm);
+
 /* ------------------------------------------------------------------ host-side generators (no GPU needed)
  * Ferrite-convention synthetic inputs for benchmarks and tests: generate_grid (src/mesh/generators.jl:942),
  * close!(dh) numbering, allocate_matrix pattern.  Conventions are documented in DESIGN.md (UNPINNED

@@ -389,6 +389,50 @@ function LinearAlgebra.dot(a::HIPVector{Float64}, b::HIPVector{Float64})
 end
 LinearAlgebra.norm(a::HIPVector{Float64}) = sqrt(dot(a, a))
 
+# ---- Float32 value type: MI355XDevice{Float32,Int32} (ext/CuThunderboltExt.jl:126-127 types everything by value_type(device); the reference's GPU
+# tests run Float32).  Storage is Float32, the kernels compute in Float64 and round once (include/tbhip.h, "Float32 value type").
+function update_operator!(op::HIPBilinearOperator{Float32}, t)
+    check(ccall((:tb_assemble_matrix_f32, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Float64, Ptr{Float32}),
+        op.form, op.A.ddh.pattern, op.strategy, Float64(t), op.A.nzval.ptr))
+end
+function update_operators!(mass::HIPBilinearOperator{Float32}, diffusion::HIPBilinearOperator{Float32}, t)
+    check(ccall((:tb_assemble_matrix_pair_f32, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Float64, Ptr{Float32}, Ptr{Float32}),
+        mass.form, diffusion.form, mass.A.ddh.pattern, mass.strategy, Float64(t), mass.A.nzval.ptr, diffusion.A.nzval.ptr))
+end
+function update_operator!(op::HIPLinearOperator{Float32}, t)
+    check(ccall((:tb_assemble_vector_f32, libtbhip), Cint, (Ptr{Cvoid}, Cint, Float64, Ptr{Float32}), op.form, op.strategy, Float64(t), op.b.ptr))
+end
+function LinearAlgebra.mul!(y::HIPVector{Float32}, A::HIPSparseMatrixCSR{Float32}, x::HIPVector{Float32}, α::Number, β::Number)
+    check(ccall((:tb_spmv_csr_f32, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Cdouble, Cdouble, Ptr{Float32}),
+        A.ddh.pattern, A.nzval.ptr, x.ptr, Float64(α), Float64(β), y.ptr))
+    return y
+end
+function heat_system_matrix!(A::HIPSparseMatrixCSR{Float32}, M::HIPSparseMatrixCSR{Float32}, K::HIPSparseMatrixCSR{Float32}, Δt)
+    check(ccall((:tb_heat_matrix_f32, libtbhip), Cint, (Ptr{Cvoid}, Int64, Ptr{Float32}, Ptr{Float32}, Cdouble, Ptr{Float32}),
+        A.nzval.dev.handle, A.nzval.n, M.nzval.ptr, K.nzval.ptr, Float64(Δt), A.nzval.ptr))
+end
+function add!(b::HIPVector{Float32}, x::HIPVector{Float32})
+    check(ccall((:tb_axpy_f32, libtbhip), Cint, (Ptr{Cvoid}, Int64, Cdouble, Ptr{Float32}, Ptr{Float32}), b.dev.handle, b.n, 1.0, x.ptr, b.ptr))
+end
+function cg!(x::HIPVector{Float32}, A::HIPSparseMatrixCSR{Float32}, b::HIPVector{Float32}; rtol = 1e-5, atol = 1e-6, maxiter = 1000)
+    its = Ref{Cint}(0); res = Ref{Cdouble}(0.0)
+    check(ccall((:tb_cg_solve_f32, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Cdouble, Cdouble, Cint, Cint, Ref{Cint}, Ref{Cdouble}),
+        A.ddh.pattern, A.nzval.ptr, b.ptr, x.ptr, rtol, atol, maxiter, 1, its, res))
+    return its[], res[]
+end
+# _pointwise_step_outer_kernel! for Float32 solution vectors (partitioned_solver.jl:38-44 dispatches on the vector type)
+function pointwise_step_f32!(dev, model_id, p::Vector{Float64}, u::HIPVector{Float32}, du, npoints, nstates, xs, sdim, t, Δt, substeps, threshold)
+    check(ccall((:tb_reaction_step_f32, libtbhip), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Float64}, Cint, Ptr{Float32}, Ptr{Float32}, Int64, Cint, Cint, Ptr{Float32}, Cint, Float64, Float64, Cint, Float64),
+        dev.handle, model_id, p, length(p), u.ptr, du === nothing ? C_NULL : du.ptr, npoints, nstates, 0, xs === nothing ? C_NULL : xs.ptr, sdim,
+        Float64(t), Float64(Δt), substeps, Float64(threshold)))
+    return true
+end
+Base.convert(::Type{HIPVector{Float32}}, v::HIPVector{Float64}) = (w = HIPVector{Float32}(v.dev, v.n);
+    check(ccall((:tb_convert_f64_to_f32, libtbhip), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float32}), v.dev.handle, v.n, v.ptr, w.ptr)); w)
+Base.convert(::Type{HIPVector{Float64}}, v::HIPVector{Float32}) = (w = HIPVector{Float64}(v.dev, v.n);
+    check(ccall((:tb_convert_f32_to_f64, libtbhip), Cint, (Ptr{Cvoid}, Int64, Ptr{Float32}, Ptr{Float64}), v.dev.handle, v.n, v.ptr, w.ptr)); w)
+
 # ---- multi-device path (new work: the reference is shared-memory only, README.md:7).  One Julia process per GPU (MPI.jl); a sub-domain vector holds
 # the dofs shared with a neighbouring rank at the positions `idx` (0-based Int32 on the device, both sides in the same order).  The exchange is
 # pack → MPI.Isend / MPI.Irecv! on the device buffers (GPU-aware MPI) → unpack; mirrored and tested in thunderbolt.jl_amd/distributed.py (HaloExchange).

@@ -6,6 +6,7 @@ import ctypes as C
 
 import numpy as np
 import pytest
+from ctypes import byref, c_double as C_double, c_int as C_int
 
 from helpers import hex_to_tets, rel_err
 
@@ -2429,6 +2430,77 @@ def test_reference_gpu_ensemble_pattern(tb, oracle, device):
         assert tb.perform_step(f, cache, 0.1 * s, 0.1) is True
         oracle.reaction_step(oracle.CELL_FHN, model.params, ref, n, oracle.LAYOUT_SOA, t=0.1 * s, dt=0.1)
     assert rel_err(cache.un.to_host(), ref) < 1e-11
+
+
+def test_reference_gpu_tests_in_float32_through_the_f32_entries(tb, oracle, device):
+    """The reference's own GPU tests run with Float32 device vectors (ext/CuThunderboltExt.jl:126-127; test/gpu/test_operators.jl:20-31,
+    ensemble-test.jl, diffusion-test.jl).  The same three set-ups through the *_f32 entries of the ABI (Float32 storage, Float64 arithmetic):
+    results agree with the oracle's Float64 ones to Float32 rounding, the assembled arrays are exactly the rounded Float64 ones."""
+    lib, check = tb.lib(), tb._lib.check
+    f32 = np.float32
+    # (1) linear form on the 287 × 1 quadrilateral mesh
+    g, dh, sp, om = quad_problem(tb, oracle, (287, 1), (-1.0, -1.0), (1.0, 1.0))
+    op = tb.setup_operator(tb.ElementAssemblyStrategy(device), tb.LinearIntegrator(tb.AnalyticalCoefficient("cos_exp"), nonzero_intervals=[(0.0, 1.0)]), dh)
+    b32 = tb.DeviceVector(device, dh.ndofs, dtype=f32)
+    check(lib.tb_assemble_vector_f32(op.form.h, tb._lib.TB_STRATEGY_ELEMENT, 0.0, b32.ptr))
+    ref = oracle.assemble_source(om, oracle.SRC_COS_EXP, t=0.0)
+    np.testing.assert_array_equal(b32.to_host(), tb.update_operator(op, 0.0).b.to_host().astype(f32))
+    np.testing.assert_allclose(b32.to_host(), ref, rtol=2e-7, atol=1e-7 * np.abs(ref).max())
+    # (2) 256-point FitzHugh–Nagumo ensemble, 100 forward-Euler steps, Float32 state
+    model = tb.FHNModel()
+    n = 256
+    rng = np.random.default_rng(1)
+    host = np.ascontiguousarray((np.tile(model.default_initial_state(), (n, 1)) + rng.uniform(0, 1, (n, 2))).T).ravel()
+    u32 = device.to_device(host.astype(f32))
+    refu = host.astype(f32).astype(np.float64)
+    for s_ in range(100):
+        check(lib.tb_reaction_step_f32(device.h, model.model_id, model.params.ctypes.data_as(tb._lib.c_dp), len(model.params), u32.ptr, None, n, 2, 0, None, 0,
+                                       0.1 * s_, 0.1, 1, 0.0))
+        oracle.reaction_step(oracle.CELL_FHN, model.params, refu, n, oracle.LAYOUT_SOA, t=0.1 * s_, dt=0.1)
+    assert np.abs(u32.to_host() - refu).max() < 2e-5 * np.abs(refu).max()      # 100 roundings to Float32 along the way
+    # (3) backward-Euler diffusion on 64 × 64 quadrilaterals, 20 steps: M, K, A, the right-hand side and the solution in Float32
+    g, dh, sp, om = quad_problem(tb, oracle, (64, 64), (0.0, 0.0), (2.5, 2.5))
+    kap = np.array([[4.5e-2, 0.0], [0.0, 2.0e-2]])
+    st = tb.PatchAssemblyStrategy(device)
+    M = tb.setup_operator(st, tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.0)), dh, sp)
+    K = tb.setup_operator(st, tb.BilinearDiffusionIntegrator(tb.ConstantCoefficient(kap)), dh, sp)
+    M32, K32, A32 = (tb.DeviceVector(device, sp.nnz, dtype=f32) for _ in range(3))
+    check(lib.tb_assemble_matrix_pair_f32(M.form.h, K.form.h, M.pattern.h, tb._lib.TB_STRATEGY_PATCH, 0.0, M32.ptr, K32.ptr))
+    tb.update_operators(M, K, 0.0)
+    np.testing.assert_array_equal(M32.to_host(), M.A.to_host().astype(f32))
+    np.testing.assert_array_equal(K32.to_host(), K.A.to_host().astype(f32))
+    check(lib.tb_assemble_matrix_f32(K.form.h, K.pattern.h, tb._lib.TB_STRATEGY_PER_COLOR, 0.0, A32.ptr))
+    assert np.abs(A32.to_host() - K32.to_host()).max() <= 2e-7 * np.abs(K32.to_host()).max()
+    dt = 0.1
+    check(lib.tb_heat_matrix_f32(device.h, sp.nnz, M32.ptr, K32.ptr, dt, A32.ptr))
+    u0 = np.random.default_rng(0).random(dh.ndofs)
+    u = device.to_device(u0.astype(f32))
+    rhs = tb.DeviceVector(device, dh.ndofs, dtype=f32)
+    its, res = C_int(), C_double()
+    for s_ in range(20):
+        check(lib.tb_spmv_csr_f32(M.pattern.h, M32.ptr, u.ptr, 1.0, 0.0, rhs.ptr))
+        check(lib.tb_cg_solve_f32(M.pattern.h, A32.ptr, rhs.ptr, u.ptr, 1e-10, 0.0, 500, 1, byref(its), byref(res)))
+        assert 0 < its.value < 500
+    import scipy.sparse as sps
+    import scipy.sparse.linalg as spla
+    Mh, Kh = M.A.to_host(), K.A.to_host()
+    A = sps.csr_matrix((Mh - dt * Kh, sp.colidx, sp.rowptr), shape=(dh.ndofs, dh.ndofs)).tocsc()
+    Mm = sps.csr_matrix((Mh, sp.colidx, sp.rowptr), shape=(dh.ndofs, dh.ndofs))
+    lu = spla.splu(A)
+    ref = u0.copy()
+    for s_ in range(20):
+        ref = lu.solve(Mm @ ref)
+    got = u.to_host().astype(np.float64)
+    assert not np.allclose(got, u0, atol=1e-3) and np.abs(got - ref).max() < 2e-5 * np.abs(ref).max()
+    y = tb.DeviceVector(device, dh.ndofs, dtype=f32)
+    y.copy_from_host(np.ones(dh.ndofs, dtype=f32))
+    check(lib.tb_axpy_f32(device.h, dh.ndofs, 0.5, u.ptr, y.ptr))
+    np.testing.assert_allclose(y.to_host(), 1.0 + 0.5 * u.to_host(), rtol=2e-7)
+    d64 = device.zeros(dh.ndofs)
+    check(lib.tb_convert_f32_to_f64(device.h, dh.ndofs, u.ptr, d64.ptr))
+    np.testing.assert_array_equal(d64.to_host(), u.to_host().astype(np.float64))
+    check(lib.tb_convert_f64_to_f32(device.h, dh.ndofs, d64.ptr, y.ptr))
+    np.testing.assert_array_equal(y.to_host(), u.to_host())
 
 
 @pytest.mark.parametrize("layout", ["SOA", "AOS"])

@@ -139,6 +139,16 @@ SIGNATURES = {
     "tb_cgd_update": (C.c_int, [vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "tb_cgd_direction": (C.c_int, [vp, C.c_int64, vp, vp, vp, vp, vp]),
     "tb_gather_indexed": (C.c_int, [vp, C.c_int64, vp, vp, vp]),
+    "tb_convert_f64_to_f32": (C.c_int, [vp, C.c_int64, vp, vp]),
+    "tb_convert_f32_to_f64": (C.c_int, [vp, C.c_int64, vp, vp]),
+    "tb_assemble_matrix_f32": (C.c_int, [vp, vp, C.c_int, C.c_double, vp]),
+    "tb_assemble_matrix_pair_f32": (C.c_int, [vp, vp, vp, C.c_int, C.c_double, vp, vp]),
+    "tb_assemble_vector_f32": (C.c_int, [vp, C.c_int, C.c_double, vp]),
+    "tb_reaction_step_f32": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, C.c_int64, C.c_int, C.c_int, vp, C.c_int, C.c_double, C.c_double, C.c_int, C.c_double]),
+    "tb_spmv_csr_f32": (C.c_int, [vp, vp, vp, C.c_double, C.c_double, vp]),
+    "tb_heat_matrix_f32": (C.c_int, [vp, C.c_int64, vp, vp, C.c_double, vp]),
+    "tb_axpy_f32": (C.c_int, [vp, C.c_int64, C.c_double, vp, vp]),
+    "tb_cg_solve_f32": (C.c_int, [vp, vp, vp, vp, C.c_double, C.c_double, C.c_int, C.c_int, vp, vp]),
     "tb_extract_diagonal": (C.c_int, [vp, vp, vp]),
     "tb_scatter_add_indexed": (C.c_int, [vp, C.c_int64, vp, vp, vp]),
     "tb_spmv_csr_rows": (C.c_int, [vp, vp, vp, C.c_int64, vp, vp]),

@@ -88,6 +88,7 @@ int tb_device_destroy(tb_device *dev)
     if (dev->own_stream && dev->stream) hipStreamDestroy(dev->stream);
     if (dev->d_status) hipFree(dev->d_status);
     if (dev->h_status) hipHostFree(dev->h_status);
+    if (dev->d_scratch) hipFree(dev->d_scratch);
     delete dev;
     return TB_OK;
 }

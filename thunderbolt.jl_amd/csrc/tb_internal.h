@@ -152,6 +152,8 @@ struct tb_device {
     std::string name;
     tb::Status *d_status = nullptr;
     tb::Status *h_status = nullptr; // pinned
+    void *d_scratch = nullptr;      // Float64 arena behind the *_f32 entry points (tb_f32.hip), grown on demand
+    size_t scratch_bytes = 0;
 };
 
 struct tb_mesh {
