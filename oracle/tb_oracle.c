@@ -968,7 +968,9 @@ static void ord_rhs_rates(const double *p, const double *u, double *du, double *
     /* reversal potentials */
     const double ENa = (R * T / F) * log(nao / nai), EK = (R * T / F) * log(ko / ki), PKNa = 0.01833;
     const double EKs = (R * T / F) * log((ko + PKNa * nao) / (ki + PKNa * nai));
-    const double vffrt = v * F * F / (R * T), vfrt = v * F / (R * T);
+    /* the constant-field fluxes divide by e^{zVF/RT} − 1: exactly V = 0 (a removable singularity of the published formulas) is moved by 10⁻⁷ mV */
+    const double vg = fabs(v) < 1e-7 ? 1e-7 : v;
+    const double vffrt = vg * F * F / (R * T), vfrt = vg * F / (R * T);
     /* INa */
     const double mss = 1.0 / (1.0 + exp((-(v + 39.57)) / 9.871));
     const double tm = 1.0 / (6.765 * exp((v + 11.64) / 34.77) + 8.552 * exp(-(v + 77.42) / 5.955));

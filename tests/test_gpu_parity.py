@@ -384,7 +384,7 @@ def initial_points(tb, model, n, rng):
         pts[:, 29] = np.clip(pts[:, 29], 0.05, 1.0)          # jca is the rate of the nca kinetics (k₋₂ₙ = jca): kept away from 0
         pts[:, 38:40] = rng.uniform(0.0, 1e-3, size=(n, 2))
         pts[:, 40] = rng.uniform(0.0, 0.1, size=n)
-        pts[:, 0] += rng.integers(0, 2, size=n) * 1e-9         # V ≠ 0 exactly (the constant-field currents divide by e^{V F/RT} − 1)
+        pts[0, 0] = 0.0                                         # one point exactly at V = 0: the removable singularity of the constant-field fluxes is guarded
     elif model.nstates == 19:                                  # TT06: V from rest to plateau, gates perturbed, ions near rest
         pts[:, 0] += rng.uniform(0.0, 110.0, size=n)
         pts[:, 6:] = np.clip(pts[:, 6:] + rng.uniform(-0.2, 0.2, size=(n, 13)), 0.0, 1.0)

@@ -279,7 +279,8 @@ template <> struct CellModel<TB_CELL_ORD11> {
         // reversal potentials
         const double ENa = RTF * (log(nao) - log(nai)), EK = RTF * (log(ko) - log(ki));
         const double EKs = RTF * (log(ko + 0.01833 * nao) - log(ki + 0.01833 * nai));
-        const double vfrt = v * FRT, vffrt = vfrt * F;
+        const double vg = fabs(v) < 1e-7 ? 1e-7 : v; // the constant-field fluxes divide by e^{zVF/RT} − 1: V = 0 exactly is moved by 10⁻⁷ mV (as in the oracle)
+        const double vfrt = vg * FRT, vffrt = vfrt * F;
         // INa
         const double mss = sg(-(v + 39.57) * (1.0 / 9.871));
         const double tm_r = 6.765 * exp_b((v + 11.64) * (1.0 / 34.77)) + 8.552 * exp_b(-(v + 77.42) * (1.0 / 5.955)); // 1/τ_m
