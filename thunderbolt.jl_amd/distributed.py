@@ -137,10 +137,10 @@ class HaloExchange:
     def __init__(self, neighbours, dist, like, device=None):
         import torch
         self.torch, self.dist, self.dev = torch, dist, device
-        self.cuda = bool(like.is_cuda)
-        if self.cuda and device is None:
-            raise ValueError("HaloExchange: device tensors need the MI355XDevice whose stream orders the pack / unpack kernels")
-        self.staged = self.cuda and dist is not None and dist.is_initialized() and dist.get_backend() == "gloo"
+        # device tensors + an MI355XDevice: pack / unpack through libtbhip on the device's stream; device tensors without one (plain torch callers):
+        # the equivalent torch calls on the same persistent buffers, like host tensors
+        self.cuda = bool(like.is_cuda) and device is not None
+        self.staged = bool(like.is_cuda) and dist is not None and dist.is_initialized() and dist.get_backend() == "gloo"
         self.peers, self.idx, self.idx32, self.send, self.recv, self.send_h, self.recv_h = [], [], [], [], [], [], []
         for peer, idx in neighbours:
             idx = torch.as_tensor(idx, dtype=torch.int64, device=like.device)
