@@ -202,6 +202,8 @@ struct tb_pattern {
     int gmres_m = 0;
     double *d_kebuf = nullptr;      // element-matrix buffer of the ElementAssemblyStrategy (vector fields)
     size_t kebuf_bytes = 0;
+    void *d_gnodes = nullptr;       // per field node: {first nz, row length, cell count, ≤ 8 element-matrix run offsets} of the staged gather
+    int gnodes_state = 0;           // 0 not built, 1 built, −1 some node sits in more than 8 cells (direct gather is used)
     int64_t max_row_len = 0;
     uint16_t *d_blockpos = nullptr; // vector fields: per cell and node pair, position of the 3×3 block inside its row
     std::unique_ptr<tb::PatchMatPlan> patch_mat;

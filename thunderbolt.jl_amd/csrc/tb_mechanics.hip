@@ -686,23 +686,28 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
 template <int NB, bool DMAJOR, int NK>
 __device__ __forceinline__ void gather_rows(const double *const (&rowk)[8], const uint8_t *inv, int nbr_max, int L, int lane, double *dst0, bool first)
 {
+    // the three rows of the node share the position → local-node lookup: one pass over the positions with the 3·NK loads of a position in flight
+    // together (constant offsets c·ND from one address), instead of three passes of NK loads each
     constexpr int ND = 3 * NB;
-    for (int c = 0; c < 3; ++c) {
-        double *dst = dst0 + (int64_t)c * L;
-        for (int p = lane; p < L; p += 64) {
-            const int nbr = p / 3, d = p - 3 * nbr;
-            double v[NK];
-            bool ok[NK];
+    for (int p = lane; p < L; p += 64) {
+        const int nbr = p / 3, d = p - 3 * nbr;
+        double v[3][NK];
+        bool ok[NK];
 #pragma unroll
-            for (int k = 0; k < NK; ++k) {
-                const int b = inv[k * nbr_max + nbr];
-                ok[k] = b != 0xFF;
-                const int bb = ok[k] ? b : 0;
-                v[k] = rowk[k][c * ND + (DMAJOR ? d * NB + bb : 3 * bb + d)];
-            }
+        for (int k = 0; k < NK; ++k) {
+            const int b = inv[k * nbr_max + nbr];
+            ok[k] = b != 0xFF;
+            const int bb = ok[k] ? b : 0;
+            const double *src = rowk[k] + (DMAJOR ? d * NB + bb : 3 * bb + d);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c][k] = src[c * ND];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
             double sum = 0.0;
 #pragma unroll
-            for (int k = 0; k < NK; ++k) sum += ok[k] ? v[k] : 0.0;
+            for (int k = 0; k < NK; ++k) sum += ok[k] ? v[c][k] : 0.0;
+            double *dst = dst0 + (int64_t)c * L;
             if (first) dst[p] = sum; else dst[p] += sum;
         }
     }
@@ -749,6 +754,96 @@ k_gather_node_rows(const int32_t *__restrict__ node_dof0, int64_t n_nodes, const
         else if (nkp == 4) gather_rows<NB, DMAJOR, 4>(rowk, inv, nbr_max, L, lane, nz + g0, first);
         else gather_rows<NB, DMAJOR, 8>(rowk, inv, nbr_max, L, lane, nz + g0, first);
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// The same gather with the source rows staged through LDS and the per-node metadata in one record (default when a node's rows hold ≤ 384 positions
+// and no node sits in more than 8 cells).  The kernel above is bound by its chain of dependent trips (dof → row pointers and slot range → slots →
+// block positions → data, then one trip per 64 positions of each row): ≈ 19 µs per node with 24 waves per CU.  Here a wave reads ONE 48-byte record,
+// then — in the same trip — the block positions of its cells and the cells' runs themselves (a node's share of an element matrix is one contiguous run,
+// rows 3a..3a+2 of Kₑ: 3·ND doubles, read coalesced, every line once), parks both in LDS and sums from LDS into registers: a lane owns positions
+// lane + 64·i of the three rows, contributions added in cell order (bit-reproducible); every nz stored once, coalesced.
+struct GatherNode {
+    int64_t g0;      // first nz of row dof0 (rows dof0+1, dof0+2 follow, L entries each)
+    int32_t L, nk;   // row length, number of cells at the node
+    int32_t slot[8]; // cell·ND + 3a: row offset of the node's run in the stored element matrices, cell-ordered
+};
+
+template <int NB, int KC>
+__global__ void __launch_bounds__(256, KC == 4 ? 4 : 2)
+k_gather_node_rows_lds(const GatherNode *__restrict__ gn, int64_t n_nodes, const double *__restrict__ ke, const uint16_t *__restrict__ blockpos,
+                       double *__restrict__ nz, int nbr_pad)
+{
+    constexpr int ND = 3 * NB, RUN = 3 * ND, NJ = (RUN + 63) / 64, NI = 6;
+    extern __shared__ double s_stage[];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t node = (int64_t)blockIdx.x * 4 + wv;
+    if (node >= n_nodes) return; // no workgroup barrier below: waves are independent
+    double *buf = s_stage + (size_t)wv * (KC * RUN + KC * nbr_pad / 8);
+    uint8_t *inv = reinterpret_cast<uint8_t *>(buf + KC * RUN);
+    const GatherNode rec = gn[node];
+    const int L = rec.L;
+    double acc[NI][3];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) acc[i][0] = acc[i][1] = acc[i][2] = 0.0;
+#pragma unroll
+    for (int kb = 0; kb < 8; kb += KC) {
+        if (kb >= rec.nk) break;
+        const int nk = rec.nk - kb < KC ? rec.nk - kb : KC;
+        double r[KC][NJ];
+#pragma unroll
+        for (int k = 0; k < KC; ++k)
+            if (k < nk) {
+                const double *src = ke + (int64_t)rec.slot[kb + k] * ND;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) { const int idx = lane + 64 * j; r[k][j] = idx < RUN ? src[idx] : 0.0; }
+            }
+        for (int i = lane; i < nk * nbr_pad / 4; i += 64) reinterpret_cast<uint32_t *>(inv)[i] = 0xFFFFFFFFu;
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < nk * NB; i += 64) {
+            const int k = i / NB, b = i - k * NB;
+            int32_t slot = rec.slot[kb];
+#pragma unroll
+            for (int kk = 1; kk < KC; ++kk) slot = k == kk ? rec.slot[kb + kk] : slot;
+            const int64_t cell = slot / ND;
+            const int a = (slot - (int32_t)cell * ND) / 3;
+            inv[k * nbr_pad + blockpos[cell * (NB * NB) + a * NB + b] / 3] = (uint8_t)b;
+        }
+#pragma unroll
+        for (int k = 0; k < KC; ++k)
+            if (k < nk) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) { const int idx = lane + 64 * j; if (idx < RUN) buf[k * RUN + idx] = r[k][j]; }
+            }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int p = lane + 64 * i;
+            if (p < L) {
+                const int nbr = p / 3, d = p - 3 * nbr;
+#pragma unroll
+                for (int k = 0; k < KC; ++k)
+                    if (k < nk) {
+                        const int b = inv[k * nbr_pad + nbr];
+                        if (b != 0xFF) {
+                            const double *sv = buf + k * RUN + 3 * b + d;
+                            acc[i][0] += sv[0];
+                            acc[i][1] += sv[ND];
+                            acc[i][2] += sv[2 * ND];
+                        }
+                    }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int p = lane + 64 * i;
+        if (p < L) {
+            nz[rec.g0 + p] = acc[i][0];
+            nz[rec.g0 + L + p] = acc[i][1];
+            nz[rec.g0 + 2 * (int64_t)L + p] = acc[i][2];
+        }
     }
 }
 
@@ -973,6 +1068,36 @@ static int check_node_rows(tb_pattern *p)
     return TB_OK;
 }
 
+// node records of the staged gather (GatherNode): built once per pattern from the host dof table, cells in ascending order like the slot lists
+static int ensure_gather_nodes(tb_pattern *p)
+{
+    if (p->gnodes_state) return TB_OK;
+    const tb_mesh *m = p->mesh;
+    const int nb = m->nb, nd = 3 * nb;
+    const int64_t nn = m->n_nodes_field;
+    if (p->max_row_len > 384 || m->n_cells * (int64_t)nd >= (int64_t)0x7fffffff) { p->gnodes_state = -1; return TB_OK; }
+    std::vector<int32_t> node_of((size_t)m->ndofs, -1);
+    for (int64_t i = 0; i < nn; ++i) node_of[m->h_node_dof0[i]] = (int32_t)i;
+    std::vector<GatherNode> recs((size_t)nn);
+    for (int64_t i = 0; i < nn; ++i) {
+        const int32_t d = m->h_node_dof0[i];
+        recs[i].g0 = p->h_rowptr[d];
+        recs[i].L = (int32_t)(p->h_rowptr[d + 1] - p->h_rowptr[d]);
+        recs[i].nk = 0;
+        for (int k = 0; k < 8; ++k) recs[i].slot[k] = 0;
+    }
+    for (int64_t c = 0; c < m->n_cells; ++c)
+        for (int a = 0; a < nb; ++a) {
+            GatherNode &g = recs[node_of[m->h_cell_dofs[c * nd + 3 * a]]];
+            if (g.nk >= 8) { p->gnodes_state = -1; return TB_OK; }
+            g.slot[g.nk++] = (int32_t)(c * nd + 3 * a);
+        }
+    TB_HIP(hipMalloc(&p->d_gnodes, sizeof(GatherNode) * (size_t)nn));
+    TB_HIP(hipMemcpy(p->d_gnodes, recs.data(), sizeof(GatherNode) * (size_t)nn, hipMemcpyHostToDevice));
+    p->gnodes_state = 1;
+    return TB_OK;
+}
+
 // Per cell: rank of every field node among the cell's nodes by global dof (27 bytes, padded to 32) — the order in which the symmetric-packed
 // element matrix stores its node blocks.  rank27_ok < 0: some node sits in more than 16 cells (the mirroring gather keeps 16 cell maps per wave).
 static int ensure_rank27(tb_mesh *m)
@@ -1089,10 +1214,22 @@ static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, doubl
             rc = check_node_rows(p);
             if (rc) return rc;
             const int nbr_max = (((int)p->max_row_len / 3) + 3) & ~3;
-            const size_t lds = (size_t)4 * 8 * nbr_max;
-            auto k = k_gather_node_rows<FE::NB, MFMA && KE_DMAJOR>;
-            hipLaunchKernelGGL(k, dim3((unsigned)((m->n_nodes_field + 3) / 4)), dim3(256), lds, dev->stream, m->d_node_dof0, m->n_nodes_field,
-                               m->ea->d_ptr, m->ea->d_src, kebuf, bp, rowptr, d_nz, nbr_max);
+            // TB_MECH_GATHER=direct: the trip-bound kernel above, kept as the comparison build (12.8 ms against 9.1 ms at 80³; a variant staging all 8
+            // cells of a vertex node at once was slower still: 66 KB of LDS per workgroup leave 8 waves per CU)
+            static const bool direct = [] { const char *e = getenv("TB_MECH_GATHER"); return e && !strcmp(e, "direct"); }();
+            if (!(MFMA && KE_DMAJOR) && !direct) { rc = ensure_gather_nodes(p); if (rc) return rc; }
+            if (!(MFMA && KE_DMAJOR) && !direct && p->gnodes_state > 0) {
+                const int nbr_pad = (nbr_max + 7) & ~7;
+                const size_t lds = (size_t)4 * 4 * (3 * FE::ND * sizeof(double) + (size_t)nbr_pad);
+                auto k = k_gather_node_rows_lds<FE::NB, 4>;
+                hipLaunchKernelGGL(k, dim3((unsigned)((m->n_nodes_field + 3) / 4)), dim3(256), lds, dev->stream, (const GatherNode *)p->d_gnodes,
+                                   m->n_nodes_field, kebuf, bp, d_nz, nbr_pad);
+            } else {
+                const size_t lds = (size_t)4 * 8 * nbr_max;
+                auto k = k_gather_node_rows<FE::NB, MFMA && KE_DMAJOR>;
+                hipLaunchKernelGGL(k, dim3((unsigned)((m->n_nodes_field + 3) / 4)), dim3(256), lds, dev->stream, m->d_node_dof0, m->n_nodes_field,
+                                   m->ea->d_ptr, m->ea->d_src, kebuf, bp, rowptr, d_nz, nbr_max);
+            }
             TB_HIP(hipGetLastError());
         }
         if (NEED_R) {
