@@ -1246,7 +1246,7 @@ __global__ void k_cell_xyz(const int32_t *__restrict__ conn, const double *__res
     if (i < n * nverts * 3) out[i] = xyz[3 * (int64_t)conn[i / 3] + i % 3];
 }
 
-static int ensure_cell_xyz(tb_mesh *m)
+int ensure_cell_xyz(tb_mesh *m)
 {
     if (m->d_cell_xyz) return TB_OK;
     const int64_t n = m->n_cells * m->nverts * 3;

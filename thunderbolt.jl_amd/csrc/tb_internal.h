@@ -322,6 +322,7 @@ int launch_cgd_update(tb_device *dev, int64_t n, const double *w, const double *
                       const double *d_rz, const double *d_pAp, double *d_out2);
 int launch_cgd_direction(tb_device *dev, int64_t n, const double *dinv, const double *r, double *p, const double *d_rz, const double *d_rz_new);
 int launch_max(tb_device *dev, int64_t n, const double *x, int64_t stride, double *result);
+int ensure_cell_xyz(tb_mesh *m); // tb_assembly.hip: builds tb_mesh::d_cell_xyz on first use
 int launch_gather_indexed(tb_device *dev, int64_t n, const double *vec, const int32_t *idx, double *out);
 int launch_scatter_add_indexed(tb_device *dev, int64_t n, const double *in, const int32_t *idx, double *vec);
 int launch_spmv_rows(tb_pattern *p, const double *nz, const double *x, int64_t n, const int32_t *rows, double *out);

@@ -132,6 +132,8 @@ namespace tbk {
 enum { HOC_FI = 0, HOC_B = 9, HOC_M = 18, HOC_AV = 27, HOC_BV = 30, HOC_H1 = 33, HOC_H1B, HOC_W1F2, HOC_W2F4, HOC_W1S2, HOC_W2S4,
        HOC_V1, HOC_V2, HOC_U1, HOC_U2, HOC_G, HOC_TRC, HOC_PSI, HOC_FV, HOC_SV = HOC_FV + 3, HOC_SIZE = 52 };
 
+// PSI = false (the assembly kernels, which never read HOC_PSI): the energy — a logarithm and four quotients of material constants — is not evaluated
+template <bool PSI = true>
 TB_HD void ho_common(const HOParams &m, const double (&F)[3][3], double *C)
 {
     const double c00 = F[1][1] * F[2][2] - F[1][2] * F[2][1];
@@ -165,9 +167,12 @@ TB_HD void ho_common(const HOParams &m, const double (&F)[3][3], double *C)
     const double df = I4f - 1.0, ds = I4s - 1.0;
     const double E4f = onf ? exp(m.bf * df * df) : 1.0;
     const double E4s = ons ? exp(m.bs * ds * ds) : 1.0;
-    double psi = m.a / (2.0 * m.b) * (E1 - 1.0) + m.afs / (2.0 * m.bfs) * (E8 - 1.0) + m.beta * (J2 - 1.0 - 2.0 * log(J));
-    if (onf) psi += m.af / (2.0 * m.bf) * (E4f - 1.0);
-    if (ons) psi += m.as / (2.0 * m.bs) * (E4s - 1.0);
+    double psi = 0.0;
+    if constexpr (PSI) {
+        psi = m.a / (2.0 * m.b) * (E1 - 1.0) + m.afs / (2.0 * m.bfs) * (E8 - 1.0) + m.beta * (J2 - 1.0 - 2.0 * log(J));
+        if (onf) psi += m.af / (2.0 * m.bf) * (E4f - 1.0);
+        if (ons) psi += m.as / (2.0 * m.bs) * (E4s - 1.0);
+    }
     const double h1 = 0.5 * m.a * E1;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -181,7 +186,7 @@ TB_HD void ho_common(const HOParams &m, const double (&F)[3][3], double *C)
     for (int i = 0; i < 3; ++i) { C[HOC_AV + i] = av[i]; C[HOC_BV + i] = bv[i]; }
     C[HOC_H1] = h1; C[HOC_H1B] = h1 * m.b;
     const double lamf = sqrt(I4f);
-    psi += m.Ta * lamf;
+    if constexpr (PSI) psi += m.Ta * lamf;
     C[HOC_W1F2] = (onf ? 2.0 * m.af * df * E4f : 0.0) + m.Ta / lamf;
     C[HOC_W2F4] = (onf ? 4.0 * m.af * E4f * (1.0 + 2.0 * m.bf * df * df) : 0.0) - m.Ta / (lamf * I4f) + m.Tb / I4f;
     C[HOC_W1S2] = ons ? 2.0 * m.as * ds * E4s : 0.0; C[HOC_W2S4] = ons ? 4.0 * m.as * E4s * (1.0 + 2.0 * m.bs * ds * ds) : 0.0;

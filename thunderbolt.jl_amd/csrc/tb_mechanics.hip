@@ -122,6 +122,10 @@ struct MechMesh {
     const double *act_field; // per cell and geometric node: calcium-driven state multiplying the active tension; NULL → 1
     const double *qp_act;    // condensed internal variable: per quadrature point (a, b) — P += a ∂λ/∂F, 𝔸 += a ∂²λ/∂F² + b ∂λ/∂F ⊗ ∂λ/∂F; NULL → none
     int qp_stride;           // 2, or 5 in the rate-coupled form: (a, b, c·w) with the non-symmetric term 𝔸 += ∂λ/∂F ⊗ (c·w ⊗ f₀), w ⊗ f₀ = ∂²λ/∂F² : Ḟ
+    const double *cell_xyz;  // vertex coordinates per cell (24 doubles, cell-major): the sum-factorised tangent kernel reads them with wave-uniform addresses
+#ifdef TB_ABLATION
+    long long *prof;         // TB_PROF_STAMPS: 16 phase time stamps of every 256th workgroup
+#endif
 };
 
 // position of column dof(b,0) inside row dof(a,0), per cell and node pair (the three component rows of a node
@@ -166,9 +170,19 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
 {
     constexpr int NB = FE::NB, NQ = FE::NQ, ND = FE::ND, PB = FE::PB, T = FE::THREADS, NG = NB / PB;
     constexpr bool MFMA = CT == 1, SF = CT == 2;
+    // sum-factorised tangent: the mapped gradients ∇N = ∂̂N·J⁻¹ are never formed.  ∇u = Ĥ·J⁻¹ with Ĥ[c][s] = Σₐ uₐ[c] ∂̂ₛNₐ (reference gradients from the
+    // 1-D factors in registers, concurrent with the Jacobians), the tangent and the stress are pulled back to the reference cell (stage 0), and the
+    // residual contracts the pulled-back stress with the reference gradients: two barriers and the 729-task gradient pass less per cell
+    constexpr bool REFGRAD = NEED_K && SF;
     const MechTables<FE> &tb = g_mech_tables<FE>;
     const int64_t cell = list ? list[blockIdx.x] : blockIdx.x;
     const int tid = threadIdx.x;
+#ifdef TB_ABLATION
+#define TB_MS(k) do { if (m.prof && tid == 0 && (blockIdx.x & 255) == 7) m.prof[(blockIdx.x >> 8) * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define TB_MS(k) do { } while (0)
+#endif
+    TB_MS(0);
     __shared__ double s_ue[ND], s_x[24], s_JI[NQ][10], s_P[NQ][9];
     // 𝔸·dΩ per point and the mapped gradients share one block: once the contraction is done it stages the symmetric-packed Kₑ for a coalesced store
     // (dynamic LDS: with the stage buffers of the sum-factorised contraction the kernel's block exceeds the 64 KB a static allocation may have)
@@ -185,6 +199,55 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
     double (*s_C)[HOC_SIZE] = reinterpret_cast<double (*)[HOC_SIZE]>(s_TC);
     __shared__ int32_t s_dof[ND];
 
+    __shared__ uint8_t s_node[32], s_tix[32]; // tensor index t₀ + 3t₁ + 9t₂ → Ferrite node and back (LDS copies: a load from the constant table in the
+                                              // middle of the kernel queues behind the element-matrix stores of the other workgroups, ≈ 1.5 µs)
+    if constexpr (REFGRAD) {
+        // load_element_unknowns! (elements.jl:125-132): dofs → u is two dependent trips; the Jacobians of the points are computed inside the second
+        // one — vertex coordinates from the cell-major array with wave-uniform addresses (scalar loads: one trip, no connectivity chase, no LDS
+        // staging), ∂M/∂ξ and the weights from the vertex signs and the 1-D rule in registers (no table loads with lane-varying addresses)
+        static_assert(ND <= T && NB == 27, "one lane per element unknown");
+        int32_t dof = 0;
+        double uv = 0.0;
+        if (tid < ND) { dof = m.cell_dofs[cell * ND + tid]; uv = u[dof]; }
+        if (tid < 27) { const int a = g_hex27_node[tid]; s_node[tid] = (uint8_t)a; s_tix[a] = (uint8_t)tid; }
+        if (tid < NQ) { // A1: J, J⁻¹, dΩ per point (PR883.jl:253-263,367-387)
+            const int q = tid, qd[3] = {q % 3, (q / 3) % 3, q / 9};
+            double mm_[3], pp_[3], wq = 1.0;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const double xi = qd[d] == 0 ? G3::x(0) : qd[d] == 1 ? G3::x(1) : G3::x(2);
+                mm_[d] = 1.0 - xi; pp_[d] = 1.0 + xi;
+                wq *= qd[d] == 1 ? G3::w(1) : G3::w(0);
+            }
+            const double *X = m.cell_xyz + cell * 24;
+            double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {
+                const double f0 = hex_sgn(a, 0) > 0 ? pp_[0] : mm_[0], f1 = hex_sgn(a, 1) > 0 ? pp_[1] : mm_[1], f2 = hex_sgn(a, 2) > 0 ? pp_[2] : mm_[2];
+                const double dm[3] = {0.125 * hex_sgn(a, 0) * f1 * f2, 0.125 * hex_sgn(a, 1) * f0 * f2, 0.125 * hex_sgn(a, 2) * f0 * f1};
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const double xa = X[3 * a + i];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) J[i][k] += xa * dm[k];
+                }
+            }
+            const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1], c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2], c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+            const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02, id = 1.0 / det;
+            double o[10];
+            o[0] = c00 * id; o[1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * id; o[2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * id;
+            o[3] = c01 * id; o[4] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * id; o[5] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * id;
+            o[6] = c02 * id; o[7] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * id; o[8] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * id;
+            o[9] = det * wq;
+            if (!(o[9] > 0.0)) { st->neg_detj = 1; st->cell = cell; }
+#pragma unroll
+            for (int e = 0; e < 9; ++e) s_Ji[q][e] = o[e];
+            s_JI[q][9] = o[9];
+        }
+        if (tid < ND) { s_dof[tid] = dof; s_ue[tid] = uv; }
+        __syncthreads();
+        TB_MS(1);
+    } else {
     // load_element_unknowns! (elements.jl:125-132) + cell coordinates
     for (int i = tid; i < ND; i += T) {
         const int32_t d = m.cell_dofs[cell * ND + i];
@@ -194,9 +257,11 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
     for (int i = tid; i < 24; i += T) s_x[i] = m.xyz[3 * (int64_t)m.conn[cell * 8 + i / 3] + i % 3];
     if (NEED_K && MFMA && rank27 && tid < 32) s_rank[tid] = rank27[cell * 32 + tid];
     __syncthreads();
+    TB_MS(1);
+    }
 
     // A1: J, J⁻¹, dΩ per point (PR883.jl:253-263,367-387)
-    if (tid < NQ) {
+    if (!REFGRAD && tid < NQ) {
         const int q = tid;
         double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
 #pragma unroll
@@ -218,6 +283,36 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
             for (int e = 0; e < 9; ++e) s_Ji[q][e] = o[e];
         }
     }
+    if constexpr (REFGRAD) {
+        // A2': Ĥ[c][s] = Σₐ uₐ[c] ∂̂ₛNₐ(ξ_q), one lane per (point, c, s) — needs the element unknowns only, so it shares the phase with A1
+        if (tid < NQ * 9) {
+            const int q = tid / 9, cs = tid - 9 * q, c = cs / 3, s_ = cs - 3 * c;
+            const int q0 = q % 3, q1 = (q / 3) % 3, q2 = q / 9;
+            auto PHq = [](int i, int qq) { return qq == 0 ? quad1d(i, G3::x(0)) : qq == 1 ? quad1d(i, G3::x(1)) : quad1d(i, G3::x(2)); };
+            auto DPq = [](int i, int qq) { return qq == 0 ? dquad1d(i, G3::x(0)) : qq == 1 ? dquad1d(i, G3::x(1)) : dquad1d(i, G3::x(2)); };
+            double f0[3], f1[3], f2[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                f0[i] = s_ == 0 ? DPq(i, q0) : PHq(i, q0);
+                f1[i] = s_ == 1 ? DPq(i, q1) : PHq(i, q1);
+                f2[i] = s_ == 2 ? DPq(i, q2) : PHq(i, q2);
+            }
+            double h = 0.0;
+#pragma unroll
+            for (int a2 = 0; a2 < 3; ++a2) {
+                double h1 = 0.0;
+#pragma unroll
+                for (int a1 = 0; a1 < 3; ++a1) {
+                    double h0 = 0.0;
+#pragma unroll
+                    for (int a0 = 0; a0 < 3; ++a0) h0 += f0[a0] * s_ue[3 * make_hex27_nodes().v[(a0 + 3 * a1 + 9 * a2) % (NB == 27 ? 27 : 1)] + c];
+                    h1 += f1[a1] * h0;
+                }
+                h += f2[a2] * h1;
+            }
+            s_P[q][cs] = h; // the stress block is free until A3c
+        }
+    } else {
     __syncthreads();
     // A2: mapped gradients ∇Nₐ = ∂Nₐ/∂ξ · J⁻¹ for every (point, node)
     for (int idx = tid; idx < NQ * NB; idx += T) {
@@ -235,10 +330,24 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
         for (int a = 0; a < NB; ++a) v += s_ue[3 * a + c] * s_G[q][a][k];
         s_JI[q][ck] = v; // J⁻¹ is dead after A2: its slots carry F from here on
     }
+    }
     __syncthreads();
+    TB_MS(2);
+    // F = I + Ĥ·J⁻¹ by the lane of the point (the lanes that evaluate the material next), into the slots of s_JI like A3a
+    auto deformation_gradient = [&](int q) {
+        const double *ji = s_Ji[q], *H = s_P[q];
+        double Fv[9];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) Fv[3 * c + k] = (c == k ? 1.0 : 0.0) + H[3 * c] * ji[k] + H[3 * c + 1] * ji[3 + k] + H[3 * c + 2] * ji[6 + k];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) s_JI[q][e] = Fv[e];
+    };
     if constexpr (AD) {
         // A3b': frame and active tension of every point (constant, or interpolated nodal data like OrthotropicMicrostructureModel)
         if (tid < NQ) {
+            if constexpr (REFGRAD) deformation_gradient(tid);
             double f[3] = {mat.f[0], mat.f[1], mat.f[2]}, sv[3] = {mat.s[0], mat.s[1], mat.s[2]}, n[3] = {mat.n[0], mat.n[1], mat.n[2]};
             if (m.fsn_field) {
                 for (int d = 0; d < 3; ++d) { f[d] = 0.0; sv[d] = 0.0; n[d] = 0.0; }
@@ -297,6 +406,7 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
     } else {
     // A3b: the quantities shared by all entries of P and 𝔸 at a point (one lane per point)
     if (tid < NQ) {
+        if constexpr (REFGRAD) deformation_gradient(tid);
         double F[3][3];
 #pragma unroll
         for (int e = 0; e < 9; ++e) F[e / 3][e % 3] = s_JI[tid][e];
@@ -319,9 +429,10 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
 #pragma unroll
             for (int d = 0; d < 3; ++d) { mq.f[d] = f[d]; mq.s[d] = s[d]; mq.n[d] = n[d]; }
         }
-        ho_common(mq, F, s_C[tid]);
+        ho_common<false>(mq, F, s_C[tid]);
     }
     __syncthreads();
+    TB_MS(3);
     // A3c: one lane per (point, i, j): row (i,j) of P·dΩ and 𝔸·dΩ
     for (int t = tid; t < NQ * 9; t += T) {
         const int q = t / 9, ij = t % 9;
@@ -348,6 +459,7 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
     __syncthreads();
 
     }
+    TB_MS(4);
     double racc = 0.0;
     if constexpr (NEED_K && MFMA) {
         // B (matrix cores).  Kₑ is symmetric (𝔸 has major symmetry), so of the 6×3×2 tiles (M-tile mt, component d, N-tile nt)
@@ -480,19 +592,16 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
         // multiply-adds per cell instead of the 1.2·10⁶ of the dense 81 × 27 × 81 products, on the vector ALUs, 53 KB of LDS (three workgroups per
         // CU), no symmetry assumed (so the rate-coupled, non-symmetric tangent runs here too).  Same sums as elements.jl:211-223 in another order.
         static_assert(T == 256 && NB == 27 && NQ == 27, "sum-factorised contraction: triquadratic field, 3×3×3 Gauss rule");
-        if constexpr (NEED_R) { // the residual reads the mapped gradients, whose block stage 1 reuses
-            if (tid < ND) {
-                for (int q = 0; q < NQ; ++q) {
-                    const double *gr = s_G[q][tid / 3];
-                    const double *pp = s_P[q] + 3 * (tid % 3);
-                    racc += gr[0] * pp[0] + gr[1] * pp[1] + gr[2] * pp[2];
-                }
-            }
-        }
-        // stage 0: 𝔸·dΩ → Â, in place, one lane per (point, c, d)
+        // stage 0: 𝔸·dΩ → Â, in place, one lane per (point, c, d); the lanes d = 0 also pull the stress back, P̂[c][s] = Σ_k J⁻¹[s][k] P[c][k]·dΩ
         if (tid < NQ * 9) {
             const int q = tid / 9, cd = tid - 9 * q, c = cd / 3, d = cd - 3 * c;
             const double *ji = s_Ji[q];
+            if (NEED_R && d == 0) {
+                double *pp = s_P[q] + 3 * c;
+                const double p0 = pp[0], p1 = pp[1], p2 = pp[2];
+#pragma unroll
+                for (int s_ = 0; s_ < 3; ++s_) pp[s_] = ji[3 * s_] * p0 + ji[3 * s_ + 1] * p1 + ji[3 * s_ + 2] * p2;
+            }
             double *Aq = s_A[q];
             double a9[3][3], t9[3][3];
 #pragma unroll
@@ -509,9 +618,37 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
                 for (int u = 0; u < 3; ++u) Aq[9 * (3 * c + s_) + 3 * d + u] = ji[3 * s_] * t9[0][u] + ji[3 * s_ + 1] * t9[1][u] + ji[3 * s_ + 2] * t9[2][u];
         }
         lds_barrier(); // LDS traffic only: the stores of the previous rows stay in flight
+        TB_MS(5);
         double *Z1 = &s_G[0][0][0];
         auto PH = [](int i, int q) constexpr { return quad1d(i, G3::x(q)); };
         auto DP = [](int i, int q) constexpr { return dquad1d(i, G3::x(q)); };
+        if constexpr (NEED_R) { // rₑ[(a,c)] = Σ_q Σ_s ∂̂ₛNₐ(ξ_q) P̂_q[c][s], the reference gradients of the lane's node from its 1-D factors
+            if (tid < ND) {
+                const int a = tid / 3, c = tid - 3 * a;
+                double fa[3][3], da[3][3]; // [direction][point]
+                const int ta = s_tix[a];
+#pragma unroll
+                for (int dir = 0; dir < 3; ++dir) {
+                    const int i = dir == 0 ? ta % 3 : dir == 1 ? (ta / 3) % 3 : ta / 9;
+#pragma unroll
+                    for (int qq = 0; qq < 3; ++qq) {
+                        fa[dir][qq] = i == 0 ? PH(0, qq) : i == 1 ? PH(1, qq) : PH(2, qq);
+                        da[dir][qq] = i == 0 ? DP(0, qq) : i == 1 ? DP(1, qq) : DP(2, qq);
+                    }
+                }
+#pragma unroll
+                for (int q2 = 0; q2 < 3; ++q2)
+#pragma unroll
+                    for (int q1 = 0; q1 < 3; ++q1) {
+                        const double m12 = fa[1][q1] * fa[2][q2], d1 = da[1][q1] * fa[2][q2], d2 = fa[1][q1] * da[2][q2];
+#pragma unroll
+                        for (int q0 = 0; q0 < 3; ++q0) {
+                            const double *pp = s_P[q0 + 3 * q1 + 9 * q2] + 3 * c;
+                            racc += da[0][q0] * m12 * pp[0] + fa[0][q0] * (d1 * pp[1] + d2 * pp[2]);
+                        }
+                    }
+            }
+        }
         // task of stages 2 + 3 (fixed for the three row components): lanes of a wave share (a₀, a₁) where they can — their stores then fall into the
         // same rows of Kₑ — and the nine lanes (a₁, b₁) of one (d, a₀, b₀) read the same Z1 words (LDS broadcast)
         int t23 = tid < 243 ? tid : 0;
@@ -529,7 +666,8 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
         }
         int rowa[3], colb[3]; // Ferrite nodes of (a₀, a₁, ·) and (b₀, b₁, ·)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { rowa[k] = g_hex27_node[ta0 + 3 * ta1 + 9 * k]; colb[k] = g_hex27_node[tb0 + 3 * tb1 + 9 * k]; }
+        for (int k = 0; k < 3; ++k) { rowa[k] = s_node[ta0 + 3 * ta1 + 9 * k]; colb[k] = s_node[tb0 + 3 * tb1 + 9 * k]; }
+        TB_MS(6);
         for (int c = 0; c < 3; ++c) {
             if (tid < 243) { // stage 1: task (s, d, u, q₁, q₂)
                 int t = tid;
@@ -556,6 +694,7 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
                     }
             }
             lds_barrier();
+            TB_MS(7 + 2 * c);
             if (tid < 243) { // stages 2 + 3 in registers: 81 LDS reads, nine entries (a₂, b₂) of row component c out
                 double z[2][2][3];
 #pragma unroll
@@ -594,6 +733,7 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
                     }
             }
             lds_barrier(); // Z1 is rewritten by the next component's stage 1
+            TB_MS(8 + 2 * c);
         }
     } else {
     // B: sweep the points
@@ -675,6 +815,10 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
             else r[s_dof[tid]] += racc;
         }
     }
+#ifdef TB_ABLATION
+    if (m.prof) { TB_MS(13); __builtin_amdgcn_s_waitcnt(0); TB_MS(14); }
+#endif
+#undef TB_MS
 }
 
 
@@ -1143,7 +1287,16 @@ static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, doubl
     constexpr bool MFMA = CT == 1;
     tb_mesh *m = f->mesh;
     tb_device *dev = m->dev;
-    const MechMesh mm{m->d_xyz, m->d_conn, m->d_cell_dofs, f->d_field, f->cond_model ? nullptr : f->d_act_field, f->cond_model ? f->d_qp_act : nullptr, f->d_u_prev ? 5 : 2};
+    if (NEED_K && CT == 2) { int rcx = ensure_cell_xyz(m); if (rcx) return rcx; }
+    MechMesh mm{m->d_xyz, m->d_conn, m->d_cell_dofs, f->d_field, f->cond_model ? nullptr : f->d_act_field, f->cond_model ? f->d_qp_act : nullptr, f->d_u_prev ? 5 : 2,
+                m->d_cell_xyz};
+#ifdef TB_ABLATION
+    static long long *d_mprof = nullptr;
+    const int nmprof = (int)(m->n_cells >> 8) + 1;
+    if (!d_mprof && getenv("TB_PROF_STAMPS") && NEED_K) TB_HIP(hipMalloc((void **)&d_mprof, (size_t)nmprof * 16 * sizeof(long long)));
+    if (d_mprof && NEED_K) TB_HIP(hipMemsetAsync(d_mprof, 0, (size_t)nmprof * 16 * sizeof(long long), dev->stream));
+    mm.prof = NEED_K ? d_mprof : nullptr;
+#endif
     const HOParams hp = make_params(f);
     const EnergyParams ep = make_energy_params(f);
     const bool ea = strategy == TB_STRATEGY_ELEMENT || strategy == TB_STRATEGY_PATCH;
@@ -1198,6 +1351,27 @@ static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, doubl
         }
         rc = go(nullptr, m->n_cells, 2);
         if (rc) return rc;
+#ifdef TB_ABLATION
+        if (mm.prof) { // average phase durations of the sampled workgroups (µs; wall clock 100 MHz)
+            std::vector<long long> h((size_t)nmprof * 16);
+            TB_HIP(hipStreamSynchronize(dev->stream));
+            TB_HIP(hipMemcpy(h.data(), mm.prof, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+            double ph[14] = {0};
+            int cnt = 0;
+            for (int w = 0; w < nmprof; ++w) {
+                const long long *a = &h[(size_t)w * 16];
+                if (!a[0] || !a[14]) continue;
+                for (int k = 0; k < 14; ++k) ph[k] += (double)(a[k + 1] - a[k]) * 0.01;
+                ++cnt;
+            }
+            if (cnt) {
+                fprintf(stderr, "[tbhip] mechanics phases (us, n=%d): load %.2f | A1+H %.2f | F+common %.2f | rows %.2f | stage0 %.2f | racc+setup %.2f |", cnt,
+                        ph[0] / cnt, ph[1] / cnt, ph[2] / cnt, ph[3] / cnt, ph[4] / cnt, ph[5] / cnt);
+                for (int c = 0; c < 3; ++c) fprintf(stderr, " c%d: s1 %.2f s23 %.2f |", c, ph[6 + 2 * c] / cnt, ph[7 + 2 * c] / cnt);
+                fprintf(stderr, " tail %.2f | drain %.2f\n", ph[12] / cnt, ph[13] / cnt);
+            }
+        }
+#endif
         if (NEED_K && sym) {
             if (!m->d_node_dof0) { rc = build_node_list(m); if (rc) return rc; }
             rc = check_node_rows(p);
@@ -1352,7 +1526,7 @@ template <class FE> static int condensed_prepass(tb_form *f, const double *d_u, 
     double *lam = f->d_qp_buf, *ca = f->d_qp_buf + npts;
     double *vel = rate ? f->d_qp_buf + 7 * npts : nullptr, *w = rate ? f->d_qp_buf + 8 * npts : nullptr, *abc = rate ? f->d_qp_buf + 11 * npts : nullptr;
     int32_t *status = (int32_t *)(f->d_qp_buf + (rate ? 14 : 4) * npts);
-    const MechMesh mm{m->d_xyz, m->d_conn, m->d_cell_dofs, f->d_field, nullptr, nullptr, 2};
+    const MechMesh mm{m->d_xyz, m->d_conn, m->d_cell_dofs, f->d_field, nullptr, nullptr, 2, nullptr};
     const int64_t ncell_work = f->has_cellset ? f->n_set : m->n_cells;
     if (ncell_work == 0) { f->cond_n_failed = 0; return TB_OK; }
     hipLaunchKernelGGL(k_fiber_stretch<FE>, dim3((unsigned)ncell_work), dim3(64), 0, dev->stream, mm, make_params(f), f->d_act_field, f->act_tension, d_u, lam, ca,
