@@ -404,32 +404,55 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
         }
         __syncthreads();
     } else {
-    // A3b: the quantities shared by all entries of P and 𝔸 at a point (one lane per point)
-    if (tid < NQ) {
-        if constexpr (REFGRAD) deformation_gradient(tid);
-        double F[3][3];
+    // A3b: the quantities shared by all entries of P and 𝔸 at a point.  256-thread workgroups: four independent parts of the block, one per wave
+    // (lane = point), instead of the whole block on one lane per point while three waves wait; 64-thread workgroups: one lane per point
+    {
+        constexpr bool SPLIT = T >= 256;
+        const int part = SPLIT ? tid >> 6 : 0, q = SPLIT ? tid & 63 : tid;
+        if (q < NQ && part < 4) {
+            double F[3][3];
+            if constexpr (REFGRAD) { // F = I + Ĥ·J⁻¹ (every part for itself; part 0 also leaves it in the slots of s_JI, where A3c reads it)
+                const double *ji = s_Ji[q], *H = s_P[q];
 #pragma unroll
-        for (int e = 0; e < 9; ++e) F[e / 3][e % 3] = s_JI[tid][e];
-        HOParams mq = mat;
-        if (m.act_field) { // Ta(x_q) = Tmax·Σₐ Mₐ(ξ_q)·state[cell][a] (coefficients.jl:85-99, contraction.jl:166-175)
-            double ca = 0.0;
-            for (int a = 0; a < 8; ++a) ca += tb.M[tid][a] * m.act_field[cell * 8 + a];
-            mq.Ta = mat.Ta * ca;
-        }
-        if (m.qp_act) { mq.Ta = m.qp_act[m.qp_stride * (cell * NQ + tid)]; mq.Tb = m.qp_act[m.qp_stride * (cell * NQ + tid) + 1]; }
-        if (m.fsn_field) { // interpolate the nodal frame, normalise, Gram–Schmidt (microstructure.jl:176-187)
-            double f[3] = {0, 0, 0}, s[3] = {0, 0, 0}, n[3] = {0, 0, 0};
-            const double *fc = m.fsn_field + cell * 72;
-            for (int a = 0; a < 8; ++a) {
-                const double Na = tb.M[tid][a];
+                for (int c = 0; c < 3; ++c)
 #pragma unroll
-                for (int d = 0; d < 3; ++d) { f[d] += Na * fc[9 * a + d]; s[d] += Na * fc[9 * a + 3 + d]; n[d] += Na * fc[9 * a + 6 + d]; }
+                    for (int k = 0; k < 3; ++k) F[c][k] = (c == k ? 1.0 : 0.0) + H[3 * c] * ji[k] + H[3 * c + 1] * ji[3 + k] + H[3 * c + 2] * ji[6 + k];
+                if (part == 0) {
+#pragma unroll
+                    for (int e = 0; e < 9; ++e) s_JI[q][e] = F[e / 3][e % 3];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 9; ++e) F[e / 3][e % 3] = s_JI[q][e];
             }
-            ho_orthonormal_frame(f, s, n);
+            HOParams mq = mat;
+            if (m.act_field) { // Ta(x_q) = Tmax·Σₐ Mₐ(ξ_q)·state[cell][a] (coefficients.jl:85-99, contraction.jl:166-175)
+                double ca = 0.0;
+                for (int a = 0; a < 8; ++a) ca += tb.M[q][a] * m.act_field[cell * 8 + a];
+                mq.Ta = mat.Ta * ca;
+            }
+            if (m.qp_act) { mq.Ta = m.qp_act[m.qp_stride * (cell * NQ + q)]; mq.Tb = m.qp_act[m.qp_stride * (cell * NQ + q) + 1]; }
+            if (m.fsn_field) { // interpolate the nodal frame, normalise, Gram–Schmidt (microstructure.jl:176-187)
+                double f[3] = {0, 0, 0}, s[3] = {0, 0, 0}, n[3] = {0, 0, 0};
+                const double *fc = m.fsn_field + cell * 72;
+                for (int a = 0; a < 8; ++a) {
+                    const double Na = tb.M[q][a];
 #pragma unroll
-            for (int d = 0; d < 3; ++d) { mq.f[d] = f[d]; mq.s[d] = s[d]; mq.n[d] = n[d]; }
+                    for (int d = 0; d < 3; ++d) { f[d] += Na * fc[9 * a + d]; s[d] += Na * fc[9 * a + 3 + d]; n[d] += Na * fc[9 * a + 6 + d]; }
+                }
+                ho_orthonormal_frame(f, s, n);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) { mq.f[d] = f[d]; mq.s[d] = s[d]; mq.n[d] = n[d]; }
+            }
+            if constexpr (SPLIT) {
+                if (part == 0) ho_common_part<0>(mq, F, s_C[q]);
+                else if (part == 1) ho_common_part<1>(mq, F, s_C[q]);
+                else if (part == 2) ho_common_part<2>(mq, F, s_C[q]);
+                else ho_common_part<3>(mq, F, s_C[q]);
+            } else {
+                ho_common<false>(mq, F, s_C[q]);
+            }
         }
-        ho_common<false>(mq, F, s_C[tid]);
     }
     __syncthreads();
     TB_MS(3);
