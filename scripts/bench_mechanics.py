@@ -12,6 +12,7 @@ ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--strategy", default="element", choices=["atomic", "color", "element"])
 ap.add_argument("--cpu-n", type=int, default=8)
 ap.add_argument("--cell-order", default="lexicographic", choices=["lexicographic", "morton"], help="order of the cells in memory (element matrices of the element strategy are stored in cell order)")
+ap.add_argument("--spmv", action="store_true", help="also time the product J·x with the assembled tangent (the block SpMV of the Krylov solvers)")
 ap.add_argument("--condensed", action="store_true", help="active stress with the RDQ20-MF internal state condensed per quadrature point")
 args = ap.parse_args()
 import thunderbolt_jl_amd as tb
@@ -56,6 +57,19 @@ tl /= args.steps; tr /= args.steps
 out = {"workload": ("HO2009 + condensed RDQ20-MF active stress, " if args.condensed else "") + "HO2009 quasi-static, Q%d displacement, %d^3 hex (%d cells, %d dofs, nnz %d), %s scatter" % (args.order, args.n, g.n_cells, dh.ndofs, sp.nnz, args.strategy),
        "linearize_ms": tl, "residual_ms": tr, "linearize_cells_per_s": g.n_cells / (tl * 1e-3), "residual_cells_per_s": g.n_cells / (tr * 1e-3),
        "host_setup_s": t_setup, "cell_order": args.cell_order}
+if args.spmv:
+    xs, ys = dev.to_device(np.cos(np.arange(dh.ndofs) * 1e-3)), dev.zeros(dh.ndofs)
+    def prod():
+        tb._lib.check(tb.lib().tb_spmv_csr(op.pattern.h, op.J.ptr, xs.ptr, 1.0, 0.0, ys.ptr))
+    prod(); prod()
+    ea, eb = dev.event(), dev.event()
+    ea.record()
+    for _ in range(10):
+        prod()
+    eb.record(); dev.synchronize()
+    ms = ea.elapsed_ms(eb) / 10
+    out["spmv_ms"] = ms
+    out["spmv_TBps_8.4B_per_nz"] = (8.0 + 4.0 / 9.0) * sp.nnz / (ms * 1e-3) / 1e12
 if args.condensed:
     out["quadrature_points"] = op.internal.n_points
     print(json.dumps(out)); sys.exit(0)

@@ -106,6 +106,88 @@ k_spmv_stream(int n_blk, const int32_t *__restrict__ blkrow, const int64_t *__re
     if constexpr (DOT) block_sum_to(acc, xy);
 }
 
+#ifdef TB_ABLATION
+__device__ int g_spmv_nogather = 0;
+#endif
+// The same kernel with the dependent trips of a block cut from five to two.  Above, a block walks block → row range → row pointers → entries → x,
+// and after the barrier every row group loads its two row pointers again: with eight resident workgroups per CU the waves sit in metadata trips four
+// fifths of the time.  Here a block is ONE 16-byte record {first row, rows | entries << 16, first nz} whose load for the NEXT block is issued at the top
+// of the current one, and the row offsets of the first three passes of phase 2 are requested together with the entries (NPRE·32 rows: every row of
+// a 27-entries-per-row block), so a block costs record (hidden) → entries + offsets → x.  What is left is the gather itself: a profiling build that reads x
+// coalesced instead runs at 0.57 instead of 0.81 ms at 216³.  A windowed form (x of the block's ≈ 9 runs of consecutive columns copied into LDS, 16-bit
+// window positions instead of 32-bit columns, 10 B per entry) was built and is correct, but not faster: 0.74–0.75 ms against 0.73 ms on the same box with
+// register staging (run scan by readlane, LDS gather, a third barrier, four workgroups per CU), 0.98 ms with LDS-DMA staging (hipcc 7.2 follows every
+// `global_load_lds` in a loop by `s_waitcnt vmcnt(0)`); removed again.
+template <int CAP, bool DOT>
+__global__ void __launch_bounds__(256)
+k_spmv_stream_rec(int n_blk, const uint4 *__restrict__ blkrec, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const double *__restrict__ nz,
+                  const double *__restrict__ x, double alpha, double beta, double *__restrict__ y, double *__restrict__ xy)
+{
+    __shared__ double s[CAP];
+    constexpr int LN = 8, NG = 256 / LN, NPRE = 3;
+    const int sub = threadIdx.x % LN, g = threadIdx.x / LN;
+    double acc = 0.0;
+    int b = blockIdx.x;
+    uint4 rec = blkrec[b < n_blk ? b : 0];
+    for (; b < n_blk; b += gridDim.x) {
+        const int bn = b + gridDim.x;
+        const uint4 recn = blkrec[bn < n_blk ? bn : b];
+        const int r0 = (int)rec.x, nr = (int)(rec.y & 0xffffu), len = (int)(rec.y >> 16);
+        const int64_t k0 = (int64_t)(((uint64_t)rec.w << 32) | rec.z);
+        // every load below is unconditional (indices clamped into the block): a load inside `if (i < len)` is followed by its own wait, which made the
+        // eight entry / gather pairs of a lane sixteen trips one after the other
+        int64_t pa[NPRE], pe[NPRE];
+#pragma unroll
+        for (int j = 0; j < NPRE; ++j) {
+            const int r = g + NG * j, rc = r < nr ? r : nr - 1;
+            pa[j] = rowptr[r0 + rc]; pe[j] = rowptr[r0 + rc + 1];
+        }
+        const double *nzb = nz + k0;
+        const int32_t *cb = colidx + k0;
+        constexpr int U = CAP / 256;
+        int32_t cj[U];
+        double vj[U], xj[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = threadIdx.x + u * 256, ic = i < len ? i : len - 1;
+            cj[u] = cb[ic]; vj[u] = nzb[ic];
+        }
+#ifdef TB_ABLATION
+        if (g_spmv_nogather) { // profiling build: what the kernel costs without the gather of x (coalesced reads of the same volume instead)
+#pragma unroll
+            for (int u = 0; u < U; ++u) xj[u] = x[(cj[u] & 0) + r0 + ((threadIdx.x + u * 256) & 63)];
+        } else
+#endif
+#pragma unroll
+        for (int u = 0; u < U; ++u) xj[u] = x[cj[u]];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = threadIdx.x + u * 256;
+            if (i < len) s[i] = vj[u] * xj[u];
+        }
+        int ra[NPRE], re[NPRE];
+#pragma unroll
+        for (int j = 0; j < NPRE; ++j) { ra[j] = (int)(pa[j] - k0); re[j] = (int)(pe[j] - k0); }
+        __syncthreads();
+        auto row = [&](int r, int a, int e) {
+            double v = 0.0;
+            for (int i = a + sub; i < e; i += LN) v += s[i];
+#pragma unroll
+            for (int o = LN / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, LN);
+            if (sub == 0) {
+                if constexpr (DOT) { y[r0 + r] = v; acc += x[r0 + r] * v; }
+                else y[r0 + r] = beta == 0.0 ? alpha * v : alpha * v + beta * y[r0 + r];
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < NPRE; ++j) { const int r = g + NG * j; if (r < nr) row(r, ra[j], re[j]); }
+        for (int r = g + NG * NPRE; r < nr; r += NG) row(r, (int)(rowptr[r0 + r] - k0), (int)(rowptr[r0 + r + 1] - k0)); // blocks of short rows
+        __syncthreads();
+        rec = recn;
+    }
+    if constexpr (DOT) block_sum_to(acc, xy);
+}
+
 __global__ void __launch_bounds__(256)
 k_absmax(int64_t n, const double *__restrict__ x, int64_t stride_x, unsigned long long *__restrict__ out)
 {
@@ -257,13 +339,46 @@ static int stream_plan(tb_pattern *p)
     int64_t start = 0;
     for (int64_t r = 0; r < p->n_rows; ++r) {
         if (p->h_rowptr[r + 1] - p->h_rowptr[r] > SPMV_CAP) { p->n_blk = -1; return TB_OK; }
-        if (p->h_rowptr[r + 1] - p->h_rowptr[start] > SPMV_CAP) { cut.push_back((int32_t)r); start = r; }
+        if (p->h_rowptr[r + 1] - p->h_rowptr[start] > SPMV_CAP || r - start >= 60000) { cut.push_back((int32_t)r); start = r; } // (empty rows: the record holds 16 bits of row count)
     }
     cut.push_back((int32_t)p->n_rows);
     TB_HIP(hipMalloc((void **)&p->d_blkrow, cut.size() * sizeof(int32_t)));
     TB_HIP(hipMemcpy(p->d_blkrow, cut.data(), cut.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    // one record per block for k_spmv_stream_rec: first row, rows | entries << 16, first nz (low, high word)
+    static_assert(SPMV_CAP < 65536, "row and entry counts of a block share one 32-bit word");
+    std::vector<uint32_t> rec(4 * (cut.size() - 1));
+    for (size_t b = 0; b + 1 < cut.size(); ++b) {
+        const int64_t k0 = p->h_rowptr[cut[b]], len = p->h_rowptr[cut[b + 1]] - k0;
+        rec[4 * b] = (uint32_t)cut[b];
+        rec[4 * b + 1] = (uint32_t)(cut[b + 1] - cut[b]) | (uint32_t)len << 16;
+        rec[4 * b + 2] = (uint32_t)((uint64_t)k0 & 0xffffffffu);
+        rec[4 * b + 3] = (uint32_t)((uint64_t)k0 >> 32);
+    }
+    TB_HIP(hipMalloc((void **)&p->d_blkrec, rec.size() * sizeof(uint32_t)));
+    TB_HIP(hipMemcpy(p->d_blkrec, rec.data(), rec.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     p->n_blk = (int64_t)cut.size() - 1;
     return TB_OK;
+}
+
+// TB_SPMV_KERNEL=chain: the five-trip kernel, kept as the comparison build
+static bool spmv_chain_kernel()
+{
+    static const bool chain = getenv("TB_SPMV_KERNEL") && !strcmp(getenv("TB_SPMV_KERNEL"), "chain");
+    return chain;
+}
+template <bool DOT>
+static void launch_stream(tb_pattern *p, const double *nz, const double *x, double alpha, double beta, double *y, double *xy, unsigned grid)
+{
+    hipStream_t st = p->mesh->dev->stream;
+#ifdef TB_ABLATION
+    static bool once = false;
+    if (!once) { once = true; const int v = getenv("TB_SPMV_NOGATHER") ? 1 : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_spmv_nogather), &v, sizeof(int)); }
+#endif
+    if (spmv_chain_kernel())
+        hipLaunchKernelGGL((k_spmv_stream<SPMV_CAP, DOT>), dim3(grid), dim3(256), 0, st, (int)p->n_blk, p->d_blkrow, p->d_rowptr, p->d_colidx, nz, x, alpha, beta, y, xy);
+    else
+        hipLaunchKernelGGL((k_spmv_stream_rec<SPMV_CAP, DOT>), dim3(grid), dim3(256), 0, st, (int)p->n_blk, (const uint4 *)p->d_blkrec, p->d_rowptr, p->d_colidx, nz, x,
+                           alpha, beta, y, xy);
 }
 
 static unsigned stream_grid(const tb_pattern *p)
@@ -282,8 +397,7 @@ int launch_spmv(tb_pattern *p, const double *nz, const double *x, double alpha, 
         return TB_OK;
     }
     if (lanes == 0 && stream_plan(p) == TB_OK && p->n_blk > 0) {
-        hipLaunchKernelGGL((k_spmv_stream<SPMV_CAP, false>), dim3(stream_grid(p)), dim3(256), 0, dev->stream, (int)p->n_blk, p->d_blkrow, p->d_rowptr, p->d_colidx, nz,
-                           x, alpha, beta, y, (double *)nullptr);
+        launch_stream<false>(p, nz, x, alpha, beta, y, nullptr, stream_grid(p));
         TB_HIP(hipGetLastError());
         return TB_OK;
     }
@@ -540,8 +654,7 @@ int launch_cg(tb_pattern *pat, const double *A, const double *b, double *x, doub
         if (pat->b3 > 0)
             launch_b3<true>(pat, A, p, 1.0, 0.0, Ap, scal + 3);
         else if (pat->n_blk > 0)
-            hipLaunchKernelGGL((k_spmv_stream<SPMV_CAP, true>), dim3(stream_grid(pat)), dim3(256), 0, dev->stream, (int)pat->n_blk, pat->d_blkrow, pat->d_rowptr,
-                               pat->d_colidx, A, p, 1.0, 0.0, Ap, scal + 3);
+            launch_stream<true>(pat, A, p, 1.0, 0.0, Ap, scal + 3, stream_grid(pat));
         else
             hipLaunchKernelGGL(k_spmv_dot<LANES>, dim3(gs), dim3(256), 0, dev->stream, n, pat->d_rowptr, pat->d_colidx, A, p, Ap, scal + 3);
         hipLaunchKernelGGL(k_cg_update_dev, dim3(g), dim3(256), 0, dev->stream, n, scal + cur, scal + 3, p, Ap, dp, x, r, scal + nxt, scal + 4, scal + 5);
@@ -1262,8 +1375,7 @@ int launch_spmv_dot(tb_pattern *pat, const double *A, const double *x, double *y
     if (lanes_env == 0 && pat->b3 > 0)
         launch_b3<true>(pat, A, x, 1.0, 0.0, y, d_dot);
     else if (lanes_env == 0 && pat->n_blk > 0)
-        hipLaunchKernelGGL((k_spmv_stream<SPMV_CAP, true>), dim3(stream_grid(pat)), dim3(256), 0, dev->stream, (int)pat->n_blk, pat->d_blkrow, pat->d_rowptr,
-                           pat->d_colidx, A, x, 1.0, 0.0, y, d_dot);
+        launch_stream<true>(pat, A, x, 1.0, 0.0, y, d_dot, stream_grid(pat));
     else
         hipLaunchKernelGGL(k_spmv_dot<16>, dim3(grid_for(dev, n * 16, 256)), dim3(256), 0, dev->stream, n, pat->d_rowptr, pat->d_colidx, A, x, y, d_dot);
     TB_HIP(hipGetLastError());

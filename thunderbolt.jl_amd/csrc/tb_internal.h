@@ -194,6 +194,7 @@ struct tb_pattern {
     int b3 = 0, b3_lanes = 16;      // b3: 0 = not examined, 1 = CSR of 3×3 blocks, −1 = not
     int64_t *d_diagpos = nullptr;   // nz index of each row's diagonal entry (−1 if absent), built at the first Jacobi-preconditioned solve
     int32_t *d_blkrow = nullptr;    // stream SpMV: first row of each workgroup's run of rows (n_blk + 1 entries)
+    uint32_t *d_blkrec = nullptr;   // the same runs as 16-byte records {first row, rows | entries << 16, first nz low, high} (k_spmv_stream_rec)
     int64_t n_blk = 0;              // 0 = not planned yet, −1 = a row exceeds the capacity (lanes-per-row kernel)
     uint16_t *d_q2pos = nullptr;    // scalar Q2 forms: position of col dof(j) in row dof(i), per cell and pair
     double *d_pcg_ws = nullptr;     // general-preconditioner PCG workspace (r, z, p, Ap, D̃, scalars)
