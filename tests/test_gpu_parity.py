@@ -789,6 +789,46 @@ def test_hyperelastic_residual_and_tangent_parity(tb, oracle, device, order, nel
     assert np.abs(y).max() < 1e-10 * np.abs(op.J.to_host()).max()
 
 
+def pentagon_prism_mesh(tb, layers=2):
+    """A pentagon cut into five quadrilaterals around its centre, extruded: the centre vertices of the inner layers sit in TEN hexahedra — more than the
+    eight a structured grid ever has (the record-driven gather of the element strategy holds eight cells per node and must hand such meshes to the
+    general kernel; unstructured ventricle meshes have such vertices)."""
+    ang = 2 * np.pi * np.arange(5) / 5 + 0.3
+    p2 = np.stack([np.cos(ang), np.sin(ang)], axis=1)
+    m2 = 0.5 * (p2 + np.roll(p2, -1, axis=0))                    # m[i] between p[i] and p[i+1]
+    pts2 = np.concatenate([[[0.05, -0.03]], p2, m2])             # 0: centre (slightly off), 1..5: corners, 6..10: edge midpoints
+    xyz = np.concatenate([np.column_stack([pts2 + 0.02 * k, np.full(11, 0.45 * k)]) for k in range(layers + 1)])
+    conn = []
+    for k in range(layers):
+        lo, hi = 11 * k, 11 * (k + 1)
+        for i in range(5):
+            quad = [0, 6 + (i - 1) % 5, 1 + i, 6 + i]            # centre, m[i-1], p[i], m[i]: counter-clockwise
+            conn.append([lo + q for q in quad] + [hi + q for q in quad])
+    return tb.Grid(tb.Hexahedron, np.ascontiguousarray(xyz), np.ascontiguousarray(np.array(conn, dtype=np.int32)))
+
+
+@pytest.mark.parametrize("order", [1, 2])
+def test_hyperelastic_tangent_on_a_mesh_with_a_ten_cell_vertex(tb, oracle, device, order):
+    g = pentagon_prism_mesh(tb)
+    dh = tb.DofHandler(g, tb.LagrangeCollection(order) ** 3)
+    sp = tb.allocate_matrix(dh)
+    counts = np.bincount(np.asarray(dh.cell_dofs).ravel())
+    assert counts.max() == 10
+    okind, q = (oracle.HEX8, 2) if order == 1 else (oracle.HEX27, 3)
+    om = oracle.Mesh(okind, q, g.xyz, g.conn, dh.cell_dofs)
+    f, s, n = np.array([1, 0, 0.0]), np.array([0, 1, 0.0]), np.array([0, 0, 1.0])
+    model = tb.QuasiStaticModel("u", tb.PK1Model(tb.HolzapfelOgden2009Model(), tb.ConstantCoefficient(tb.OrthotropicMicrostructure(f, s, n))))
+    u = np.random.default_rng(4).uniform(-1e-2, 1e-2, dh.ndofs)
+    Kref, rref = oracle.assemble_hyperelastic(om, u, sp.rowptr, sp.colidx, fsn=np.stack([f, s, n]))
+    du = device.to_device(u)
+    for st in (tb.ElementAssemblyStrategy(device), tb.AtomicAssemblyStrategy(device), tb.PerColorAssemblyStrategy(device)):
+        op = tb.setup_operator(st, model, dh, sp)
+        res = device.zeros(dh.ndofs)
+        tb.update_linearization(op, du, 0.0, residual=res)
+        assert rel_err(op.J.to_host(), Kref) < 1e-11, (order, type(st).__name__, rel_err(op.J.to_host(), Kref))
+        assert rel_err(res.to_host(), rref) < 1e-11
+
+
 def test_mechanics_properties_80_cubed(tb, oracle, device):
     """BASELINE config 4 at its own size (512 000 Q2 hexahedra, 12.5 M dofs, 2.37·10⁹ nz: the Int32 / size effects the small parity cases cannot see):
     residual and tangent of the element strategy — a sample of rows against the oracle's assembly of the cells around them, rigid translations in

@@ -37,7 +37,6 @@ struct FusedView {
     const int32_t *pnode;
     const RowDesc *row_desc;
     int kcap, max_rows, max_nodes;
-    int nsig_lds; // staged kernel: the signature table (this many entries, ≤ 64) is copied into LDS behind the coordinates; 0 = read from global memory
 #ifdef TB_ABLATION
     long long *prof;
 #endif
@@ -256,10 +255,6 @@ k_patch_hex8_staged(FormArgs faK, FormArgs faM, FusedView pv, const uint4 *__res
 #define TB_ST(k) do { } while (0)
 #endif
     TB_ST(0);
-    // the signature table does not depend on the header: requested first, parked in LDS, read when the scatter starts (from global memory it was a
-    // third dependent trip, header → signature index → table)
-    uint4 sgv = make_uint4(0, 0, 0, 0);
-    if (tid < 4 * pv.nsig_lds) sgv = ((const uint4 *)pv.sigtab)[tid];
     const uint4 h = hdrs[blockIdx.x];
     const int64_t e0 = h.x, r0 = h.y, n0 = h.z;
     const int nrows = (int)(h.w & 0x3ff), nnodes = (int)((h.w >> 10) & 0x7ff), ne = (int)(h.w >> 21);
@@ -268,7 +263,6 @@ k_patch_hex8_staged(FormArgs faK, FormArgs faM, FusedView pv, const uint4 *__res
     double *accM = lds + (WK && WM ? pv.kcap : 0);
     RowDesc *desc = (RowDesc *)(lds + (WK && WM ? 2 : 1) * pv.kcap);
     double *xs = (double *)(desc + pv.max_rows);
-    uint4 *ssig = (uint4 *)(xs + ((3 * pv.max_nodes + 1) & ~1)); // 16-byte aligned: the accumulator blocks hold an even number of doubles
     uint4 lnv = make_uint4(0, 0, 0, 0);
     uint32_t sig = 0;
     if (tid < ne) { lnv = ((const uint4 *)pv.elem_ln)[e0 + tid]; sig = pv.elem_sig[e0 + tid]; }
@@ -292,9 +286,8 @@ k_patch_hex8_staged(FormArgs faK, FormArgs faM, FusedView pv, const uint4 *__res
 #pragma unroll
     for (int j = 0; j < NX; ++j) if (tid + j * T < 3 * nnodes) xs[tid + j * T] = xc[j];
     for (int k = tid + NX * T; k < 3 * nnodes; k += T) xs[k] = pcoord[3 * n0 + k];            // oversize patches only
-    if (tid < 4 * pv.nsig_lds) ssig[tid] = sgv;
     uint4 cp[4];
-    if (!pv.nsig_lds && tid < ne) {
+    if (tid < ne) {
         const uint4 *cpp = (const uint4 *)(pv.sigtab + (size_t)sig * 64);
 #pragma unroll
         for (int k = 0; k < 4; ++k) cp[k] = cpp[k];
@@ -305,12 +298,9 @@ k_patch_hex8_staged(FormArgs faK, FormArgs faM, FusedView pv, const uint4 *__res
     for (int ei = tid; ei < ne; ei += T) {
         if (ei >= T) {
             lnv = ((const uint4 *)pv.elem_ln)[e0 + ei];
-            sig = pv.elem_sig[e0 + ei];
-            if (!pv.nsig_lds) {
-                const uint4 *cpp = (const uint4 *)(pv.sigtab + (size_t)sig * 64);
+            const uint4 *cpp = (const uint4 *)(pv.sigtab + (size_t)pv.elem_sig[e0 + ei] * 64);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) cp[k] = cpp[k];
-            }
+            for (int k = 0; k < 4; ++k) cp[k] = cpp[k];
         }
         const uint32_t ln[8] = {lnv.x & 0xffffu, lnv.x >> 16, lnv.y & 0xffffu, lnv.y >> 16, lnv.z & 0xffffu, lnv.z >> 16, lnv.w & 0xffffu, lnv.w >> 16};
         double x[8][3];
@@ -324,9 +314,7 @@ k_patch_hex8_staged(FormArgs faK, FormArgs faM, FusedView pv, const uint4 *__res
         for (int i = 0; i < 8; ++i) ro[i] = ln[i] < (uint32_t)nrows ? desc[ln[i]].off : 0xFFFFFFFFu;
         int64_t cell = 0;
         if constexpr (FK || FM) cell = pv.elem_cell[e0 + ei];
-        hex8_instance<WK, WM, FK, FM, DIAG>(x, [&](uint4(&c4)[4], uint32_t(&r8)[8]) {
-            if (pv.nsig_lds) { for (int k = 0; k < 4; ++k) c4[k] = ssig[4 * sig + k]; } else { for (int k = 0; k < 4; ++k) c4[k] = cp[k]; }
-            for (int k = 0; k < 8; ++k) r8[k] = ro[k]; }, cell, faK, faM, accK, accM, st, pv.elem_cell, e0 + ei);
+        hex8_instance<WK, WM, FK, FM, DIAG>(x, [&](uint4(&c4)[4], uint32_t(&r8)[8]) { for (int k = 0; k < 4; ++k) c4[k] = cp[k]; for (int k = 0; k < 8; ++k) r8[k] = ro[k]; }, cell, faK, faM, accK, accM, st, pv.elem_cell, e0 + ei);
     }
     TB_ST(3);
     __syncthreads();
@@ -428,10 +416,7 @@ int launch_assemble_hex8_patch(tb_form *fK, tb_form *fM, tb_pattern *p, double t
     pv.elem_ln = pf->d_elem_ln; pv.elem_sig = pf->d_elem_sig; pv.sigtab = pf->d_sigtab; pv.pnode = pf->d_pnode; pv.row_desc = pf->d_row_desc;
     pv.kcap = pf->max_lds_entries; pv.max_rows = pp->max_rows; pv.max_nodes = pf->max_nodes;
     // one LDS size for both kernel forms: accumulator block(s) + row descriptors + 3 doubles per patch node (the general form keeps 4-byte node ids there)
-    size_t lds = (size_t)nreg * pv.kcap * sizeof(double) + (size_t)pv.max_rows * sizeof(RowDesc) + (size_t)pv.max_nodes * 3 * sizeof(double);
-    static const bool sig_global = getenv("TB_PATCH_SIG") && !strcmp(getenv("TB_PATCH_SIG"), "global"); // comparison build: table read from global memory
-    pv.nsig_lds = pf->d_hdr && !sig_global && pv.kcap % 2 == 0 && pf->nsig <= 64 && lds + 8 + (size_t)pf->nsig * 64 <= 80 * 1024 ? (int)pf->nsig : 0;
-    if (pv.nsig_lds) lds += 8 + (size_t)pv.nsig_lds * 64;
+    const size_t lds = (size_t)nreg * pv.kcap * sizeof(double) + (size_t)pv.max_rows * sizeof(RowDesc) + (size_t)pv.max_nodes * 3 * sizeof(double);
     FormArgs aK = fK ? make_args(fK, t) : FormArgs{};
     const FormArgs aM = fM ? make_args(fM, t) : FormArgs{};
 #ifdef TB_ABLATION
