@@ -150,7 +150,8 @@ k_spmv_stream_rec(int n_blk, const uint4 *__restrict__ blkrec, const int64_t *__
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int i = threadIdx.x + u * 256, ic = i < len ? i : len - 1;
-            cj[u] = cb[ic]; vj[u] = nzb[ic];
+            cj[u] = 0; vj[u] = 0.0;
+            if (len > 0) { cj[u] = cb[ic]; vj[u] = nzb[ic]; } // wave-uniform condition (a run of empty rows has no entries to read)
         }
 #ifdef TB_ABLATION
         if (g_spmv_nogather) { // profiling build: what the kernel costs without the gather of x (coalesced reads of the same volume instead)
