@@ -92,14 +92,16 @@ int main()
                     if (orc_assemble_matrix(&om, 1, &ck, 0.0, rp.data(), ci.data(), nz.data(), th, color.data(), ncol)) return 11;
                     if (orc_assemble_source(&om, ORC_SRC_COS_EXP, &one, nullptr, 0.1, b.data(), th)) return 12;
                 }
-                for (int model = 0; model < 4; ++model) {
-                    double p[64], u0[32];
+                for (int model : {0, 1, 2, 3, 5}) { // FHN, Aliev–Panfilov, PCG2019, TT06, O'Hara–Rudy (4 reads point coordinates: covered by the parity tests)
+                    double p[64], u0[48];
                     orc_cell_default_params(model, p);
                     orc_cell_default_state(model, p, u0);
                     const int ns = orc_cell_nstates(model);
                     std::vector<double> u((size_t)ns * 37), du(u.size());
                     for (int s = 0; s < ns; ++s) for (int k = 0; k < 37; ++k) u[s * 37 + k] = u0[s];
                     for (int th : {1, 3}) if (orc_reaction_step(model, p, u.data(), du.data(), 37, 0, 0.0, 1e-3, 4, 0.05, th)) return 13;
+                    if (model == 2 || model == 3 || model == 5) // the gated models also through the Rush–Larsen step
+                        for (int th : {1, 3}) if (orc_reaction_step_rl(model, p, u.data(), 37, 0, 0.0, 1e-3, th)) return 17;
                 }
             }
             if (ncomp == 3) {
