@@ -478,7 +478,8 @@ int tb_convert_f32_to_f64(tb_device *dev, int64_t n, const float *d_in, double *
 int tb_assemble_matrix_f32(tb_form *form, tb_pattern *pat, int strategy, double t, float *d_nzval);
 int tb_assemble_matrix_pair_f32(tb_form *mass, tb_form *diffusion, tb_pattern *pat, int strategy, double t, float *d_nzval_mass, float *d_nzval_diffusion);
 int tb_assemble_vector_f32(tb_form *form, int strategy, double t, float *d_b);
-/* d_x NULL: tb_reaction_step; otherwise tb_reaction_step_x */
+/* d_x NULL: tb_reaction_step; otherwise tb_reaction_step_x.  One pass: the reaction kernels instantiated on Float32 storage (states read as
+ * Float32, stepped in Float64, rounded once on the way out — bit-identical to convert / step / convert back, at half the bytes moved). */
 int tb_reaction_step_f32(tb_device *dev, int model, const double *params, int n_params, float *d_u, float *d_du, int64_t n_points, int n_states, int layout,
                          const float *d_x, int sdim, double t, double dt, int substeps, double threshold);
 int tb_spmv_csr_f32(tb_pattern *pat, const float *d_nzval, const float *d_x, double alpha, double beta, float *d_y);

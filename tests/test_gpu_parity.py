@@ -745,6 +745,29 @@ def test_reaction_full_size_tt06_sample(tb, oracle, device):
         del cache, out
 
 
+@pytest.mark.parametrize("cls,layout", [("PCG2019", 0), ("PCG2019", 1), ("TT06", 0), ("FHNModel", 1)])
+def test_reaction_float32_storage_is_one_rounding_of_the_float64_step(tb, device, cls, layout):
+    """tb_reaction_step_f32 (kernels instantiated on Float32 storage, Float64 arithmetic) against the Float64 entry applied to the same Float32-rounded
+    states and rounded once afterwards: bit for bit, states and rates, sub-stepped and not."""
+    import ctypes as C
+    lib, check = tb.lib(), tb._lib.check
+    model = getattr(tb, cls)()
+    ns, n = model.nstates, 4099
+    rng = np.random.default_rng(12)
+    pts = np.tile(model.default_initial_state(), (n, 1)) * (1.0 + 0.01 * rng.uniform(-1, 1, (n, ns)))
+    pts[:, model.phi_index] += rng.uniform(0.0, 40.0 if ns > 2 else 0.8, n)
+    host = np.ascontiguousarray(pts.T if layout == 0 else pts).ravel().astype(np.float32)
+    par = model.params.ctypes.data_as(tb._lib.c_dp)
+    dt = {"PCG2019": 0.01, "TT06": 0.001, "FHNModel": 0.1}[cls]
+    for substeps, thr in ((1, 0.0), (4, 0.05)):
+        u32, du32 = device.to_device(host.copy()), tb.DeviceVector(device, n * ns, dtype=np.float32)
+        check(lib.tb_reaction_step_f32(device.h, model.model_id, par, len(model.params), u32.ptr, du32.ptr, n, ns, layout, None, 0, 0.0, dt, substeps, thr))
+        u64, du64 = device.to_device(host.astype(np.float64)), device.zeros(n * ns)
+        check(lib.tb_reaction_step(device.h, model.model_id, par, len(model.params), u64.ptr, du64.ptr, n, ns, layout, 0.0, dt, substeps, thr))
+        np.testing.assert_array_equal(u32.to_host(), u64.to_host().astype(np.float32))
+        np.testing.assert_array_equal(du32.to_host(), du64.to_host().astype(np.float32))
+
+
 # ------------------------------------------------------------------------------------------- quasi-static mechanics
 def mech_problem(tb, oracle, nel, order, perturb=0.15):
     g = tb.generate_mesh(tb.Hexahedron, nel, (0, 0, 0), (1.0, 0.7, 0.5), perturb=perturb)

@@ -144,19 +144,19 @@ int tb_assemble_vector_f32(tb_form *form, int strategy, double t, float *d_b)
 int tb_reaction_step_f32(tb_device *dev, int model, const double *params, int n_params, float *d_u, float *d_du, int64_t n_points, int n_states, int layout,
                          const float *d_x, int sdim, double t, double dt, int substeps, double threshold)
 {
+    // one pass: the reaction kernels instantiated on Float32 storage (states read, stepped in Float64, rounded once) — no conversion round trip
     TB_REQUIRE(dev && params && (d_u || n_points == 0) && n_points >= 0 && n_states > 0, "tb_reaction_step_f32: bad argument");
-    const int64_t n = n_points * n_states;
-    double *s = nullptr;
-    int rc = arena(dev, sizeof(double) * (size_t)n * (d_du ? 2 : 1), &s);
+    TB_REQUIRE(model != TB_CELL_FHN_HETEROGENEOUS || d_x || n_points == 0, "tb_reaction_step_f32: this cell model reads the point coordinate — pass d_x");
+    TB_REQUIRE(!d_x || (sdim >= 1 && sdim <= 3), "tb_reaction_step_f32: sdim must be 1, 2 or 3 (got %d)", sdim);
+    int ns, np;
+    int rc = tb_cell_model_info(model, &ns, &np, nullptr);
     if (rc) return rc;
-    rc = up(dev, n, d_u, s);
-    if (rc) return rc;
-    rc = d_x ? tb_reaction_step_x(dev, model, params, n_params, s, d_du ? s + n : nullptr, n_points, n_states, layout, d_x, sdim, t, dt, substeps, threshold)
-             : tb_reaction_step(dev, model, params, n_params, s, d_du ? s + n : nullptr, n_points, n_states, layout, t, dt, substeps, threshold);
-    if (rc) return rc;
-    rc = down(dev, n, s, d_u);
-    if (rc || !d_du) return rc;
-    return down(dev, n, s + n, d_du);
+    TB_REQUIRE(n_states == ns, "tb_reaction_step_f32: model has %d states, caller says %d", ns, n_states);
+    TB_REQUIRE(n_params == np, "tb_reaction_step_f32: model has %d parameters, caller passed %d", np, n_params);
+    TB_REQUIRE(layout == TB_LAYOUT_SOA || layout == TB_LAYOUT_AOS, "tb_reaction_step_f32: unknown layout %d", layout);
+    if (n_points == 0) return TB_OK;
+    TB_HIP(hipSetDevice(dev->id));
+    return launch_reaction_f32(dev, model, params, n_params, d_u, d_du, n_points, layout, t, dt, substeps, threshold, d_x, sdim);
 }
 
 int tb_spmv_csr_f32(tb_pattern *pat, const float *d_nzval, const float *d_x, double alpha, double beta, float *d_y)

@@ -287,6 +287,8 @@ int host_material_eval(const tb_material *mat, const double *F9, double *psi, do
 int launch_reaction(tb_device *dev, int model, const double *params, int n_params, double *d_u, double *d_du,
                     int64_t n_points, int layout, double t, double dt, int substeps, double thr, double *rmax /*nullable, host*/,
                     const float *d_x = nullptr, int sdim = 0);
+int launch_reaction_f32(tb_device *dev, int model, const double *params, int n_params, float *d_u, float *d_du, int64_t n_points, int layout, double t, double dt,
+                        int substeps, double thr, const float *d_x, int sdim);
 int launch_reaction_rl(tb_device *dev, int model, const double *params, int n_params, double *d_u, int64_t n, int layout, double t, double dt);
 int launch_heat_matrix(tb_device *dev, int64_t nnz, const double *M, const double *K, double dt, double *A);
 int launch_spmv(tb_pattern *p, const double *nz, const double *x, double alpha, double beta, double *y);

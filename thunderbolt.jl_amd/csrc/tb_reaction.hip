@@ -467,9 +467,11 @@ __device__ __forceinline__ void cell_rhs(const CellParams &P, const double (&u)[
     else M::rhs(P, u, t, du);
 }
 
-template <int MODEL, int LAYOUT, bool WRITE_DU>
+// TS: storage type of the states (double, or float for the Float32 value type of the boundary: states read and rounded once per call, arithmetic in
+// Float64 — the same result as converting, stepping and converting back, in one pass over half the bytes)
+template <int MODEL, int LAYOUT, bool WRITE_DU, class TS = double>
 __global__ void __launch_bounds__(256)
-k_reaction(CellParams P, double *__restrict__ u, double *__restrict__ du_out, int64_t n, double t, double dt, int substeps,
+k_reaction(CellParams P, TS *__restrict__ u, TS *__restrict__ du_out, int64_t n, double t, double dt, int substeps,
            double threshold, unsigned long long *__restrict__ rmax_key, const float *__restrict__ xs, int sdim)
 {
     using M = CellModel<MODEL>;
@@ -501,8 +503,8 @@ k_reaction(CellParams P, double *__restrict__ u, double *__restrict__ du_out, in
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             const int64_t k = LAYOUT == TB_LAYOUT_SOA ? i + j * n : i * NS + j;
-            u[k] = ul[j];
-            if (WRITE_DU) du_out[k] = dul[j];
+            u[k] = (TS)ul[j];
+            if (WRITE_DU) du_out[k] = (TS)dul[j];
         }
         rm = fmax(rm, dul[M::PHI]);
     }
@@ -577,8 +579,8 @@ int launch_reaction_rl(tb_device *dev, int model, const double *params, int n_pa
     return TB_OK;
 }
 
-template <int MODEL>
-static int run(tb_device *dev, const CellParams &P, double *u, double *du, int64_t n, int layout, double t, double dt, int substeps,
+template <int MODEL, class TS = double>
+static int run(tb_device *dev, const CellParams &P, TS *u, TS *du, int64_t n, int layout, double t, double dt, int substeps,
                double thr, unsigned long long *rmax_key, const float *xs, int sdim)
 {
     const int bs = 256;
@@ -587,12 +589,29 @@ static int run(tb_device *dev, const CellParams &P, double *u, double *du, int64
     const int64_t cap = per_cu > 0 ? (int64_t)dev->n_cu * per_cu : nb;
     if (nb > cap) nb = cap;
     const dim3 grid((unsigned)nb), block(bs);
-#define TB_LAUNCH(L, W) hipLaunchKernelGGL((k_reaction<MODEL, L, W>), grid, block, 0, dev->stream, P, u, du, n, t, dt, substeps, thr, rmax_key, xs, sdim)
+#define TB_LAUNCH(L, W) hipLaunchKernelGGL((k_reaction<MODEL, L, W, TS>), grid, block, 0, dev->stream, P, u, du, n, t, dt, substeps, thr, rmax_key, xs, sdim)
     if (layout == TB_LAYOUT_SOA) { if (du) TB_LAUNCH(TB_LAYOUT_SOA, true); else TB_LAUNCH(TB_LAYOUT_SOA, false); }
     else { if (du) TB_LAUNCH(TB_LAYOUT_AOS, true); else TB_LAUNCH(TB_LAYOUT_AOS, false); }
 #undef TB_LAUNCH
     TB_HIP(hipGetLastError());
     return TB_OK;
+}
+
+// Float32 storage (tb_reaction_step_f32): same kernels with TS = float
+int launch_reaction_f32(tb_device *dev, int model, const double *params, int n_params, float *d_u, float *d_du, int64_t n_points,
+                        int layout, double t, double dt, int substeps, double thr, const float *d_x, int sdim)
+{
+    CellParams P{};
+    for (int i = 0; i < n_params && i < 48; ++i) P.p[i] = params[i];
+    switch (model) {
+    case TB_CELL_FHN: return run<TB_CELL_FHN, float>(dev, P, d_u, d_du, n_points, layout, t, dt, substeps, thr, nullptr, d_x, sdim);
+    case TB_CELL_ALIEV_PANFILOV: return run<TB_CELL_ALIEV_PANFILOV, float>(dev, P, d_u, d_du, n_points, layout, t, dt, substeps, thr, nullptr, d_x, sdim);
+    case TB_CELL_PCG2019: return run<TB_CELL_PCG2019, float>(dev, P, d_u, d_du, n_points, layout, t, dt, substeps, thr, nullptr, d_x, sdim);
+    case TB_CELL_TT06: return run<TB_CELL_TT06, float>(dev, P, d_u, d_du, n_points, layout, t, dt, substeps, thr, nullptr, d_x, sdim);
+    case TB_CELL_FHN_HETEROGENEOUS: return run<TB_CELL_FHN_HETEROGENEOUS, float>(dev, P, d_u, d_du, n_points, layout, t, dt, substeps, thr, nullptr, d_x, sdim);
+    case TB_CELL_ORD11: return run<TB_CELL_ORD11, float>(dev, P, d_u, d_du, n_points, layout, t, dt, substeps, thr, nullptr, d_x, sdim);
+    default: set_error("unknown cell model %d", model); return TB_ERR_BAD_ARG;
+    }
 }
 
 int launch_reaction(tb_device *dev, int model, const double *params, int n_params, double *d_u, double *d_du, int64_t n_points,
