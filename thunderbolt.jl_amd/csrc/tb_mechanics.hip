@@ -173,7 +173,7 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
     // sum-factorised tangent: the mapped gradients ∇N = ∂̂N·J⁻¹ are never formed.  ∇u = Ĥ·J⁻¹ with Ĥ[c][s] = Σₐ uₐ[c] ∂̂ₛNₐ (reference gradients from the
     // 1-D factors in registers, concurrent with the Jacobians), the tangent and the stress are pulled back to the reference cell (stage 0), and the
     // residual contracts the pulled-back stress with the reference gradients: two barriers and the 729-task gradient pass less per cell
-    constexpr bool REFGRAD = NEED_K && SF;
+    constexpr bool REFGRAD = (NEED_K && SF) || (!NEED_K && NEED_R && NB == 27 && NQ == 27 && T == 256); // (the residual-only kernel of the quadratic field too)
     const MechTables<FE> &tb = g_mech_tables<FE>;
     const int64_t cell = list ? list[blockIdx.x] : blockIdx.x;
     const int tid = threadIdx.x;
@@ -193,7 +193,7 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
     __shared__ uint8_t s_rank[32];
     // phase A scratch (common blocks + F) and phase B's double-buffered T share one region
     constexpr int TC_SIZE = (NEED_K && CT == 0 && 2 * NB * 27 > NQ * HOC_SIZE) ? 2 * NB * 27 : NQ * HOC_SIZE;
-    __shared__ double s_Ji[(NEED_K && SF) ? NQ : 1][9]; // J⁻¹ kept for the pull-back of 𝔸 (the slots of s_JI carry F after A2)
+    __shared__ double s_Ji[REFGRAD ? NQ : 1][9]; // J⁻¹ kept for the pull-backs of 𝔸 and P (the slots of s_JI carry F)
     __shared__ double s_TC[TC_SIZE];
     double (*s_T)[NB][27] = reinterpret_cast<double (*)[NB][27]>(s_TC);
     double (*s_C)[HOC_SIZE] = reinterpret_cast<double (*)[HOC_SIZE]>(s_TC);
@@ -484,6 +484,39 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
     }
     TB_MS(4);
     double racc = 0.0;
+    // rₑ[(a,c)] = Σ_q Σ_s ∂̂ₛNₐ(ξ_q) P̂_q[c][s] for the lane's element unknown (reference-gradient path; P̂ = the pulled-back stress in s_P): the reference
+    // gradients of the lane's node come from its 1-D factors
+    auto residual_refgrad = [&]() {
+        auto PHr = [](int i, int q) constexpr { return quad1d(i, G3::x(q)); };
+        auto DPr = [](int i, int q) constexpr { return dquad1d(i, G3::x(q)); };
+        double acc = 0.0;
+        if (tid < ND) {
+            const int a = tid / 3, c = tid - 3 * a;
+            double fa[3][3], da[3][3]; // [direction][point]
+            const int ta = s_tix[a];
+#pragma unroll
+            for (int dir = 0; dir < 3; ++dir) {
+                const int i = dir == 0 ? ta % 3 : dir == 1 ? (ta / 3) % 3 : ta / 9;
+#pragma unroll
+                for (int qq = 0; qq < 3; ++qq) {
+                    fa[dir][qq] = i == 0 ? PHr(0, qq) : i == 1 ? PHr(1, qq) : PHr(2, qq);
+                    da[dir][qq] = i == 0 ? DPr(0, qq) : i == 1 ? DPr(1, qq) : DPr(2, qq);
+                }
+            }
+#pragma unroll
+            for (int q2 = 0; q2 < 3; ++q2)
+#pragma unroll
+                for (int q1 = 0; q1 < 3; ++q1) {
+                    const double m12 = fa[1][q1] * fa[2][q2], d1 = da[1][q1] * fa[2][q2], d2 = fa[1][q1] * da[2][q2];
+#pragma unroll
+                    for (int q0 = 0; q0 < 3; ++q0) {
+                        const double *pp = s_P[(q0 + 3 * q1 + 9 * q2) % NQ] + 3 * c;
+                        acc += da[0][q0] * m12 * pp[0] + fa[0][q0] * (d1 * pp[1] + d2 * pp[2]);
+                    }
+                }
+        }
+        return acc;
+    };
     if constexpr (NEED_K && MFMA) {
         // B (matrix cores).  Kₑ is symmetric (𝔸 has major symmetry), so of the 6×3×2 tiles (M-tile mt, component d, N-tile nt)
         // the nine with mt ≥ 3, nt = 0 — rows (a ≥ 16, c), columns (b < 16, d): strictly below the block diagonal — are not
@@ -645,33 +678,7 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
         double *Z1 = &s_G[0][0][0];
         auto PH = [](int i, int q) constexpr { return quad1d(i, G3::x(q)); };
         auto DP = [](int i, int q) constexpr { return dquad1d(i, G3::x(q)); };
-        if constexpr (NEED_R) { // rₑ[(a,c)] = Σ_q Σ_s ∂̂ₛNₐ(ξ_q) P̂_q[c][s], the reference gradients of the lane's node from its 1-D factors
-            if (tid < ND) {
-                const int a = tid / 3, c = tid - 3 * a;
-                double fa[3][3], da[3][3]; // [direction][point]
-                const int ta = s_tix[a];
-#pragma unroll
-                for (int dir = 0; dir < 3; ++dir) {
-                    const int i = dir == 0 ? ta % 3 : dir == 1 ? (ta / 3) % 3 : ta / 9;
-#pragma unroll
-                    for (int qq = 0; qq < 3; ++qq) {
-                        fa[dir][qq] = i == 0 ? PH(0, qq) : i == 1 ? PH(1, qq) : PH(2, qq);
-                        da[dir][qq] = i == 0 ? DP(0, qq) : i == 1 ? DP(1, qq) : DP(2, qq);
-                    }
-                }
-#pragma unroll
-                for (int q2 = 0; q2 < 3; ++q2)
-#pragma unroll
-                    for (int q1 = 0; q1 < 3; ++q1) {
-                        const double m12 = fa[1][q1] * fa[2][q2], d1 = da[1][q1] * fa[2][q2], d2 = fa[1][q1] * da[2][q2];
-#pragma unroll
-                        for (int q0 = 0; q0 < 3; ++q0) {
-                            const double *pp = s_P[q0 + 3 * q1 + 9 * q2] + 3 * c;
-                            racc += da[0][q0] * m12 * pp[0] + fa[0][q0] * (d1 * pp[1] + d2 * pp[2]);
-                        }
-                    }
-            }
-        }
+        if constexpr (NEED_R) racc = residual_refgrad();
         // task of stages 2 + 3 (fixed for the three row components): lanes of a wave share (a₀, a₁) where they can — their stores then fall into the
         // same rows of Kₑ — and the nine lanes (a₁, b₁) of one (d, a₀, b₀) read the same Z1 words (LDS broadcast)
         int t23 = tid < 243 ? tid : 0;
@@ -758,6 +765,18 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
             lds_barrier(); // Z1 is rewritten by the next component's stage 1
             TB_MS(8 + 2 * c);
         }
+    } else if constexpr (REFGRAD && !NEED_K) {
+        // residual only, reference-gradient path: pull the stress back (one lane per (point, c)), then contract with the reference gradients
+        if (tid < NQ * 3) {
+            const int q = tid / 3, c = tid - 3 * q;
+            const double *ji = s_Ji[q];
+            double *pp = s_P[q] + 3 * c;
+            const double p0 = pp[0], p1 = pp[1], p2 = pp[2];
+#pragma unroll
+            for (int s_ = 0; s_ < 3; ++s_) pp[s_] = ji[3 * s_] * p0 + ji[3 * s_ + 1] * p1 + ji[3 * s_ + 2] * p2;
+        }
+        __syncthreads();
+        racc = residual_refgrad();
     } else {
     // B: sweep the points
     const int a_own = tid / NG, bg = tid % NG;
@@ -1310,7 +1329,8 @@ static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, doubl
     constexpr bool MFMA = CT == 1;
     tb_mesh *m = f->mesh;
     tb_device *dev = m->dev;
-    if (NEED_K && CT == 2) { int rcx = ensure_cell_xyz(m); if (rcx) return rcx; }
+    constexpr bool refgrad_r = !NEED_K && NEED_R && FE::NB == 27 && FE::NQ == 27 && FE::THREADS == 256; // residual-only kernel on the reference-gradient path
+    if ((NEED_K && CT == 2) || refgrad_r) { int rcx = ensure_cell_xyz(m); if (rcx) return rcx; }
     MechMesh mm{m->d_xyz, m->d_conn, m->d_cell_dofs, f->d_field, f->cond_model ? nullptr : f->d_act_field, f->cond_model ? f->d_qp_act : nullptr, f->d_u_prev ? 5 : 2,
                 m->d_cell_xyz};
 #ifdef TB_ABLATION
@@ -1337,7 +1357,7 @@ static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, doubl
     const uint16_t *bp = p ? p->d_blockpos : nullptr;
     double *kebuf = nullptr, *rebuf = nullptr;
     const uint8_t *rank27 = nullptr;
-    constexpr size_t dyn_lds = sizeof(double) * ((NEED_K ? FE::NQ : 1) * 81 + FE::NQ * FE::NB * 3); // 𝔸·dΩ + mapped gradients (s_AG)
+    constexpr size_t dyn_lds = sizeof(double) * ((NEED_K ? FE::NQ : 1) * 81 + (refgrad_r ? 0 : FE::NQ * FE::NB * 3)); // 𝔸·dΩ + mapped gradients (s_AG; no gradient block on the reference-gradient residual path)
     auto go = [&](const int32_t *list, int64_t n, int atomic) -> int {
         if (!n) return TB_OK;
         auto kern = k_hyperelastic<FE, NEED_K, NEED_R, CT, AD>;
