@@ -189,6 +189,81 @@ k_spmv_stream_rec(int n_blk, const uint4 *__restrict__ blkrec, const int64_t *__
     if constexpr (DOT) block_sum_to(acc, xy);
 }
 
+// Row-per-lane form of the same run (default).  In the kernels above lane i takes entry i, so the 64 gathers of x in one instruction follow 2.4 rows
+// through all their columns: ≈ 21 scattered 24-byte pieces, and the texture-address path spends more on them than on the coalesced entry loads
+// (profiling build without the gather: 0.57 instead of 0.81 ms).  Here the entries of the run are parked in LDS as they come (values and columns,
+// coalesced), and the products are taken row-wise: three lanes per row, lane (row, s) the entries s, s + 3, …, so the lanes of a wave — 21 consecutive
+// rows — gather x at three stencil offsets of 21 consecutive rows: a few cache lines per instruction on FE numberings.  Row sums stay in registers
+// (no product array, no second LDS pass), the three partial sums meet by two lane shifts, y is stored by the lanes s = 0.
+template <int CAP, bool DOT>
+__global__ void __launch_bounds__(256)
+k_spmv_stream_rows(int n_blk, const uint4 *__restrict__ blkrec, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, const double *__restrict__ nz,
+                   const double *__restrict__ x, double alpha, double beta, double *__restrict__ y, double *__restrict__ xy)
+{
+    __shared__ double s_v[CAP];
+    __shared__ int32_t s_c[CAP];
+    constexpr int U = CAP / 256, SUB = 3, RW = 21, RP = 4 * RW, NK = 9; // 21 rows per wave (lane 63 idle): no row triple straddles two waves
+    const int tid = threadIdx.x, lane = tid & 63, rl = RW * (tid >> 6) + lane / SUB, sub = lane % SUB;
+    const bool lane_ok = lane < SUB * RW;
+    double acc = 0.0;
+    int b = blockIdx.x;
+    uint4 rec = blkrec[b < n_blk ? b : 0];
+    for (; b < n_blk; b += gridDim.x) {
+        const int bn = b + gridDim.x;
+        const uint4 recn = blkrec[bn < n_blk ? bn : b];
+        const int r0 = (int)rec.x, nr = (int)(rec.y & 0xffffu), len = (int)(rec.y >> 16);
+        const int64_t k0 = (int64_t)(((uint64_t)rec.w << 32) | rec.z);
+        const int rc0 = rl < nr ? rl : nr - 1;
+        const int64_t pa0 = rowptr[r0 + rc0], pe0 = rowptr[r0 + rc0 + 1];
+        const double *nzb = nz + k0;
+        const int32_t *cb = colidx + k0;
+        int32_t cj[U];
+        double vj[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = tid + u * 256, ic = i < len ? i : len - 1;
+            cj[u] = 0; vj[u] = 0.0;
+            if (len > 0) { cj[u] = cb[ic]; vj[u] = nzb[ic]; } // wave-uniform condition
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = tid + u * 256;
+            if (i < len) { s_c[i] = cj[u]; s_v[i] = vj[u]; }
+        }
+        __syncthreads();
+        for (int p0 = 0; p0 < nr; p0 += RP) {
+            const int r = rl + p0;
+            const bool active = lane_ok && r < nr && len > 0;
+            int64_t pa = pa0, pe = pe0;
+            if (p0 > 0) { const int rc = r < nr ? r : nr - 1; pa = rowptr[r0 + rc]; pe = rowptr[r0 + rc + 1]; } // runs of short rows
+            const int a = (int)(pa - k0), e = (int)(pe - k0);
+            int kc[NK], cc[NK];
+            double vv[NK], xx[NK];
+#pragma unroll
+            for (int t_ = 0; t_ < NK; ++t_) {
+                const int k = a + sub + SUB * t_;
+                kc[t_] = active && k < e ? k : -1;
+                const int kk = kc[t_] >= 0 ? kc[t_] : 0;
+                cc[t_] = s_c[kk]; vv[t_] = s_v[kk];
+            }
+#pragma unroll
+            for (int t_ = 0; t_ < NK; ++t_) xx[t_] = len > 0 ? x[cc[t_]] : 0.0;
+            double v = 0.0;
+#pragma unroll
+            for (int t_ = 0; t_ < NK; ++t_) v += kc[t_] >= 0 ? vv[t_] * xx[t_] : 0.0;
+            if (active) for (int k = a + sub + SUB * NK; k < e; k += SUB) v += s_v[k] * x[s_c[k]]; // rows longer than 27 entries
+            v += __shfl_down(v, 1, 64) + __shfl_down(v, 2, 64);
+            if (active && sub == 0) {
+                if constexpr (DOT) { y[r0 + r] = v; acc += x[r0 + r] * v; }
+                else y[r0 + r] = beta == 0.0 ? alpha * v : alpha * v + beta * y[r0 + r];
+            }
+        }
+        __syncthreads();
+        rec = recn;
+    }
+    if constexpr (DOT) block_sum_to(acc, xy);
+}
+
 __global__ void __launch_bounds__(256)
 k_absmax(int64_t n, const double *__restrict__ x, int64_t stride_x, unsigned long long *__restrict__ out)
 {
@@ -375,7 +450,11 @@ static void launch_stream(tb_pattern *p, const double *nz, const double *x, doub
     static bool once = false;
     if (!once) { once = true; const int v = getenv("TB_SPMV_NOGATHER") ? 1 : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_spmv_nogather), &v, sizeof(int)); }
 #endif
-    if (spmv_chain_kernel())
+    static const bool rows_kernel = !(getenv("TB_SPMV_KERNEL") && strcmp(getenv("TB_SPMV_KERNEL"), "rows") != 0); // default; "rec" / "chain": entry-per-lane kernels
+    if (rows_kernel) // 24 KB of LDS per workgroup: six resident per CU
+        hipLaunchKernelGGL((k_spmv_stream_rows<SPMV_CAP, DOT>), dim3(grid > 1536 ? 1536 : grid), dim3(256), 0, st, (int)p->n_blk, (const uint4 *)p->d_blkrec, p->d_rowptr,
+                           p->d_colidx, nz, x, alpha, beta, y, xy);
+    else if (spmv_chain_kernel())
         hipLaunchKernelGGL((k_spmv_stream<SPMV_CAP, DOT>), dim3(grid), dim3(256), 0, st, (int)p->n_blk, p->d_blkrow, p->d_rowptr, p->d_colidx, nz, x, alpha, beta, y, xy);
     else
         hipLaunchKernelGGL((k_spmv_stream_rec<SPMV_CAP, DOT>), dim3(grid), dim3(256), 0, st, (int)p->n_blk, (const uint4 *)p->d_blkrec, p->d_rowptr, p->d_colidx, nz, x,
