@@ -13,9 +13,14 @@ Under torchrun (RANK / WORLD_SIZE set) WORLD_SIZE must equal --gpus.  Workload a
 monodomain mesh (216³ = 10 077 696 hexahedra, 10 218 313 dofs) with the ten Tusscher–Panfilov 2006 ionic
 model that configuration names (19 states; the reference itself has no TT06 — SURVEY F6 — so its parity is
 pinned against this repository's oracle only; `--ionic pcg2019` runs the reference's own 7-state model, and
-its reaction rate is reported as an extra key either way).  N > 1: weak scaling, every rank owns one such
-slab of a box that is N times longer in z; assembly has no data-path collective, the only exchange
-is the neighbour halo sum of shared-node vector entries.
+its reaction rate is reported as an extra key either way).  N > 1 (default `--scaling strong`, BASELINE's configuration: the SAME 10M-hex
+mesh on 1/2/4/8 GPUs, SURVEY §8e): the 216³ box is cut into N z-slabs of 216/N cell layers (27 layers = 1.26 M cells per GPU at N = 8);
+`--scaling weak` gives every rank a whole 216³ slab of a box N times longer in z.  Assembly has no data-path collective, the only exchange
+of the step is the neighbour halo sum of shared-node vector entries; what a partitioned TIME step exchanges besides that — the interface
+sums and the two all-reduces of every CG iteration of the backward-Euler solve — is timed on the same partition (barrier-bracketed, max
+over ranks) and reported as a second rate, `cg_iterations_per_s`, so the line cannot scale by construction.  At N = 1 `slab_sweep` times
+the step and the CG iteration on the 216×216×{108, 54, 27} slabs an N-GPU run gives each rank: t(216) / t(216/N) is the speed-up the
+kernels alone allow (no exchange latency) — the evidence one GPU can give for the 1 → 8 curve.
 
 Prints ONE JSON line (rank 0).  `value` = element-integrations/s of the whole job over the timed
 region (3·cells per step / step time, reaction included in the step time); DoF-updates/s and the
@@ -37,6 +42,11 @@ FP64_VECTOR_TFLOPS = 78.6      # AMD spec sheet; FP64 MFMA runs at the same rate
 BYTES_PER_CELL_MATRIX = 272.0  # 32 B conn + 24 B coords + 27 nz × 8 B
 BYTES_PER_CELL_VECTOR = 64.0   # 32 + 24 + 8
 BYTES_PER_DOF_UPDATE = 16.0    # in place; 24 when du is materialised
+# FP64 flops of one cell instance, counted on the ISA of the shipped kernels (scripts/isa_hist.py; v_mul_f64 / v_add_f64 = 1, v_fma_f64 / v_fmac_f64 = 2)
+FLOP_PER_INSTANCE_FUSED = 430 + 354 + 2 * 465     # k_patch_hex8_staged<K+M,DIAG>
+FLOP_PER_INSTANCE_K = 1400.0                      # k_patch_hex8_staged<K,DIAG> (approximate: the mass part is ≈ 300 of the fused count)
+ROOFLINE_LIMITER = ("fp64 vector issue in the integration phase + latency-bound staging / write-out phases at two workgroups per CU "
+                    "(not HBM, not the LDS atomics)")
 
 
 def parse():
@@ -44,7 +54,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=216, help="cells per edge of each rank's box (216 → 10M hexahedra)")
+    ap.add_argument("--n", type=int, default=216, help="cells per edge of the box (216 → 10M hexahedra)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong = the same n³ mesh cut into N z-slabs (BASELINE's configuration); weak = one n³ slab per rank")
+    ap.add_argument("--no-slab-sweep", action="store_true", help="N = 1: skip the timing of the n×n×{n/2, n/4, n/8} slabs (strong-scaling prediction)")
     ap.add_argument("--strategy", default="patch", choices=["patch", "atomic", "color"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dist-cg", action="store_true", help="skip the (untimed-region) distributed CG iteration measurement")
@@ -161,7 +174,9 @@ def main():
     share = bool(os.environ.get("TB_BENCH_SHARE_DEVICE")) and world > 1
     device_index = 0 if share else local_rank
     torch.cuda.set_device(device_index)
-    if world > 1:
+    # under a launcher the process group is created at every world size, 1 included: the RCCL initialisation, the barrier and the max-over-ranks
+    # all-reduce of the timing then run on a one-GPU box too (tests/test_rccl_world1.py), not for the first time on the 8-GPU node
+    if world > 1 or launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if share:
             dist.init_process_group("gloo")
@@ -172,83 +187,149 @@ def main():
     dev.set_stream(torch.cuda.current_stream().cuda_stream)
 
     n = args.n
-    part = tb.distributed.SlabPartition((n, n, n * world), (0.0, 0.0, 0.0), (1.0, 1.0, float(world)), world, rank)
-    g = tb.generate_mesh(tb.Hexahedron, part.local_nel(), part.left, part.right, perturb=0.2)
-    dh = tb.DofHandler(g)
-    sp = tb.allocate_matrix(dh)
-    st = {"patch": tb.PatchAssemblyStrategy, "atomic": tb.AtomicAssemblyStrategy, "color": tb.PerColorAssemblyStrategy}[args.strategy](dev)
-    # linear form: the atomic strategy on hexahedra is the patch-reduced kernel k_vector_hex8_patch<false> — a patch integrates its own cells only
-    # (no halo cells to re-integrate), sums them per node in LDS and adds every touched node to the zeroed vector with one global atomic
-    # (1.4 atomics per cell); the halo flavour (PATCH) stores each dof once but re-integrates 49 % more cells: 0.53 vs 0.34 ms at 216³
-    st_vec = tb.AtomicAssemblyStrategy(dev) if args.strategy == "patch" else st
+    strong = args.scaling == "strong"
+    if strong and world > n:
+        sys.stderr.write("bench.py: --gpus %d exceeds the %d cell layers of the mesh\n" % (world, n))
+        return 2
+    nz_total = n if strong else n * world
+    part = tb.distributed.SlabPartition((n, n, nz_total), (0.0, 0.0, 0.0), (1.0, 1.0, nz_total / n), world, rank)
     kap = np.diag([4.5e-5, 2.0e-5, 2.0e-5])  # docs/src/literate-tutorials/ep01_spiral-wave.jl:39-41 style conductivities
-    D = tb.ConductivityToDiffusivityCoefficient(tb.ConstantCoefficient(kap), tb.ConstantCoefficient(1.0), tb.ConstantCoefficient(1.0))
-    M = tb.setup_operator(st, tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.0)), dh, sp)
-    K = tb.setup_operator(st, tb.BilinearDiffusionIntegrator(D), dh, sp)
-    src = tb.setup_operator(st_vec, tb.LinearIntegrator(tb.AnalyticalCoefficient("cos_exp")), dh)
-    # source vector lives in a torch tensor so RCCL can exchange its interface entries
-    b = torch.zeros(dh.ndofs, dtype=torch.float64, device="cuda")
-    src.b = tb.DeviceVector.wrap(dev, b)
-    lo_idx = up_idx = None
-    if world > 1:
-        n2d = tb.distributed.node_to_dof(dh)
-        lo, up = part.interface_nodes()
-        lo_idx = None if lo is None else torch.from_numpy(n2d[lo]).cuda()
-        up_idx = None if up is None else torch.from_numpy(n2d[up]).cuda()
-    # the one data-path exchange: persistent send / receive buffers, pack and unpack through the C ABI (tb_gather_indexed / tb_scatter_add_indexed)
-    nbrs = tb.distributed.slab_neighbours(lo_idx, up_idx, rank, world)
-    halo = tb.distributed.HaloExchange(nbrs, dist if world > 1 else None, b, dev)
-
-    model = {"pcg2019": tb.PCG2019, "tt06": tb.TT06, "fhn": tb.FHNModel, "ord": tb.ORd2011}[args.ionic]()
-    ns = model.nstates
     rdt = {"pcg2019": 0.01, "tt06": 0.001, "fhn": 0.1, "ord": 0.002}[args.ionic]   # forward-Euler-stable reaction step sizes
-    npts = dh.ndofs
-    u0 = np.tile(model.default_initial_state(), (npts, 1))
-    u0[:, model.phi_index] += np.linspace(0.0, 60.0 if ns > 2 else 1.0, npts)
-    u = torch.from_numpy(np.ascontiguousarray(u0.T).ravel()).cuda()
-    f = tb.PointwiseODEFunction(npts, model)
-    cache = tb.setup_solver_cache(f, tb.ForwardEulerCellSolver(dev), u=u, keep_du=args.keep_du)
-
     fused = args.strategy == "patch" and not args.separate
-    ev = [dev.event() for _ in range(6)]
-    phase = {"mass": 0.0, "diffusion": 0.0, "source": 0.0, "halo": 0.0, "reaction": 0.0}   # fused: "diffusion" holds the M + K pass, "mass" stays 0
+    gd = dist if dist.is_initialized() else None
+    host_red = "cpu" if share else "cuda"
 
-    def step(i, timed):
-        t = 0.01 * i
-        ev[0].record()
-        if not fused:
-            tb.update_operator(M, t)
-        ev[1].record()
-        if fused:
-            tb.update_operators(M, K, t)
-        else:
-            tb.update_operator(K, t)
-        ev[2].record(); tb.update_operator(src, t)
-        ev[3].record()
-        if world > 1:
-            halo.exchange_sum(b)
-        ev[4].record(); tb.perform_step(f, cache, t, rdt)
-        ev[5].record()
-        if timed:
-            for k, name in enumerate(phase):
-                phase[name] += ev[k].elapsed_ms(ev[k + 1])
+    class Problem:
+        """One rank's share of the workload: mesh slab, operators, source vector, halo exchange, ionic states; `step` is one pass of the hot path."""
 
-    for i in range(args.warmup):
-        step(i, False)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i, True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else "cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        def __init__(self, nel, left, right, rank_, world_, lo_up, dist_):
+            self.world, self.rank, self.dist = world_, rank_, dist_
+            self.g = g = tb.generate_mesh(tb.Hexahedron, nel, left, right, perturb=0.2)
+            self.dh = dh = tb.DofHandler(g)
+            self.sp = sp = tb.allocate_matrix(dh)
+            st = {"patch": tb.PatchAssemblyStrategy, "atomic": tb.AtomicAssemblyStrategy, "color": tb.PerColorAssemblyStrategy}[args.strategy](dev)
+            # linear form: the atomic strategy on hexahedra is the patch-reduced kernel k_vector_hex8_patch<false> — a patch integrates its own cells only
+            # (no halo cells to re-integrate), sums them per node in LDS and adds every touched node to the zeroed vector with one global atomic
+            # (1.4 atomics per cell); the halo flavour (PATCH) stores each dof once but re-integrates 49 % more cells: 0.53 vs 0.34 ms at 216³
+            st_vec = tb.AtomicAssemblyStrategy(dev) if args.strategy == "patch" else st
+            D = tb.ConductivityToDiffusivityCoefficient(tb.ConstantCoefficient(kap), tb.ConstantCoefficient(1.0), tb.ConstantCoefficient(1.0))
+            self.M = tb.setup_operator(st, tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.0)), dh, sp)
+            self.K = tb.setup_operator(st, tb.BilinearDiffusionIntegrator(D), dh, sp)
+            self.src = tb.setup_operator(st_vec, tb.LinearIntegrator(tb.AnalyticalCoefficient("cos_exp")), dh)
+            # source vector lives in a torch tensor so RCCL can exchange its interface entries
+            self.b = torch.zeros(dh.ndofs, dtype=torch.float64, device="cuda")
+            self.src.b = tb.DeviceVector.wrap(dev, self.b)
+            self.lo_idx = self.up_idx = None
+            if world_ > 1:
+                n2d = tb.distributed.node_to_dof(dh)
+                lo, up = lo_up
+                self.lo_idx = None if lo is None else torch.from_numpy(n2d[lo]).cuda()
+                self.up_idx = None if up is None else torch.from_numpy(n2d[up]).cuda()
+            # the one data-path exchange: persistent send / receive buffers, pack and unpack through the C ABI (tb_gather_indexed / tb_scatter_add_indexed)
+            nbrs = tb.distributed.slab_neighbours(self.lo_idx, self.up_idx, rank_, world_)
+            self.halo = tb.distributed.HaloExchange(nbrs, dist_, self.b, dev)
+            self.model = model = {"pcg2019": tb.PCG2019, "tt06": tb.TT06, "fhn": tb.FHNModel, "ord": tb.ORd2011}[args.ionic]()
+            self.ns = model.nstates
+            self.npts = npts = dh.ndofs
+            u0 = np.tile(model.default_initial_state(), (npts, 1))
+            u0[:, model.phi_index] += np.linspace(0.0, 60.0 if self.ns > 2 else 1.0, npts)
+            self.u = torch.from_numpy(np.ascontiguousarray(u0.T).ravel()).cuda()
+            self.f = tb.PointwiseODEFunction(npts, model)
+            self.cache = tb.setup_solver_cache(self.f, tb.ForwardEulerCellSolver(dev), u=self.u, keep_du=args.keep_du)
+            self.ev = [dev.event() for _ in range(6)]
+            self.phase = {"mass": 0.0, "diffusion": 0.0, "source": 0.0, "halo": 0.0, "reaction": 0.0}   # fused: "diffusion" holds the M + K pass, "mass" stays 0
+
+        def step(self, i, timed):
+            t, ev = 0.01 * i, self.ev
+            ev[0].record()
+            if not fused:
+                tb.update_operator(self.M, t)
+            ev[1].record()
+            if fused:
+                tb.update_operators(self.M, self.K, t)
+            else:
+                tb.update_operator(self.K, t)
+            ev[2].record(); tb.update_operator(self.src, t)
+            ev[3].record()
+            if self.world > 1:
+                self.halo.exchange_sum(self.b)
+            ev[4].record(); tb.perform_step(self.f, self.cache, t, rdt)
+            ev[5].record()
+            if timed:
+                for k, name in enumerate(self.phase):
+                    self.phase[name] += ev[k].elapsed_ms(ev[k + 1])
+
+        def sync(self):
+            if self.dist is not None:
+                self.dist.barrier()
+            torch.cuda.synchronize()
+
+        def max_over_ranks(self, x):
+            if self.dist is not None:
+                tt = torch.tensor([x], dtype=torch.float64, device=host_red)
+                self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
+                x = float(tt.item())
+            return x
+
+        def time_steps(self, warmup, steps):
+            """W untimed steps, then exactly K steps bracketed by barrier + synchronize on both sides; the MAX over ranks of the wall time"""
+            for i in range(warmup):
+                self.step(i, False)
+            self.sync()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                self.step(warmup + i, True)
+            torch.cuda.synchronize()
+            if self.dist is not None:
+                self.dist.barrier()
+            return self.max_over_ranks(time.perf_counter() - t0)
+
+        def time_cg(self, nit=10):
+            """What a time step adds to the assembly under a partition — one iteration of the distributed Jacobi-CG on the heat matrix A = M − Δt·K of
+            this rank's slab: interface rows of A·p packed first (tb_spmv_csr_rows), exchange posted, whole local product + pᵀA_p p behind it
+            (tb_spmv_csr_dot), received partials added, all-reduce of pᵀAp, update with the two weighted sums, all-reduce, direction.  Barrier-bracketed,
+            max over ranks, device scalars, no host read."""
+            npts, world_, dist_ = self.npts, self.world, self.dist
+            A = tb.heat_system_matrix(dev, self.M, self.K, 0.01)
+            diag = torch.empty(npts, dtype=torch.float64, device="cuda")
+            tb._lib.check(tb.lib().tb_extract_diagonal(self.K.pattern.h, A.ptr, diag.data_ptr()))
+            cg = tb.distributed.DistributedCG(None, diag, self.lo_idx, self.up_idx, self.rank, world_, dist_, device=dev, operator=(self.K.pattern, A))
+            xs_ = torch.zeros(npts, dtype=torch.float64, device="cuda")
+            rs_ = self.b.clone() + 1.0
+            ps_ = cg.dinv * rs_
+            Ap_ = torch.empty_like(xs_)
+            S_ = torch.zeros(5, dtype=torch.float64, device="cuda")
+            tb._lib.check(tb.lib().tb_cgd_dot(dev.h, npts, cg.w.data_ptr(), rs_.data_ptr(), ps_.data_ptr(), S_[0:1].data_ptr()))
+            if world_ > 1:
+                tb.distributed.all_reduce_sum(S_[0:1], dist_)
+            for _ in range(3):
+                cg.device_step(xs_, rs_, ps_, Ap_, S_)
+            self.sync()
+            ea, eb, ec = dev.event(), dev.event(), dev.event()
+            t0 = time.perf_counter()
+            for _ in range(nit):
+                cg.device_step(xs_, rs_, ps_, Ap_, S_)
+            torch.cuda.synchronize()
+            if dist_ is not None:
+                dist_.barrier()
+            t_it = self.max_over_ranks((time.perf_counter() - t0) / nit)
+            ea.record()
+            for _ in range(nit):
+                cg.device_iteration(ps_, Ap_, S_)                    # product + halo + pᵀAp only
+            eb.record()
+            for _ in range(nit):
+                tb._lib.check(tb.lib().tb_spmv_csr(self.K.pattern.h, A.ptr, ps_.data_ptr(), 1.0, 0.0, Ap_.data_ptr()))   # the bare local SpMV, for reference
+            ec.record()
+            torch.cuda.synchronize()
+            return {"iteration_ms": t_it * 1e3, "product_halo_dot_ms": ea.elapsed_ms(eb) / nit, "local_spmv_ms": eb.elapsed_ms(ec) / nit,
+                    "halo_bytes_per_rank": self.halo.nbytes, "rows_per_rank": npts, "nnz_per_rank": self.sp.nnz,
+                    "note": "one Jacobi-CG iteration on A = M - dt K under the partition (barrier-bracketed, max over ranks, host-timed over %d iterations, device "
+                            "scalars, no host read): interface rows packed first, exchange overlapped with the local SpMV + p'Ap, two all-reduces" % nit}
+
+    pr = Problem(part.local_nel(), part.left, part.right, rank, world, part.interface_nodes(), gd)
+    g, dh, sp, npts, ns = pr.g, pr.dh, pr.sp, pr.npts, pr.ns
+    elapsed = pr.time_steps(args.warmup, args.steps)
+    phase = pr.phase
 
     # outside the timed region: the reference's own 7-state ionic model (PCG2019) on the same points, for the record
     ref_rx = None
@@ -269,57 +350,34 @@ def main():
                   "hbm_frac": BYTES_PER_DOF_UPDATE * 7 * npts / (ms_ref * 1e-3) / 1e9 / HBM_PEAK_GBS}
         del cref, uref
 
-    # outside the timed region as well: what a time step adds to the assembly under a partition — one iteration of the distributed Jacobi-CG on
-    # the heat matrix A = M − Δt·K of this rank's slab: interface rows of A·p packed first (tb_spmv_csr_rows), exchange posted, whole local product
-    # + pᵀA_p p behind it (tb_spmv_csr_dot), received partials added, all-reduce of pᵀAp, update with the two weighted sums, all-reduce, direction
-    dist_cg = None
-    if not args.no_dist_cg:
-        A = tb.heat_system_matrix(dev, M, K, 0.01)
-        diag = torch.empty(npts, dtype=torch.float64, device="cuda")
-        tb._lib.check(tb.lib().tb_extract_diagonal(K.pattern.h, A.ptr, diag.data_ptr()))
-        cg = tb.distributed.DistributedCG(None, diag, lo_idx, up_idx, rank, world, dist if world > 1 else None, device=dev, operator=(K.pattern, A))
-        xs_ = torch.zeros(npts, dtype=torch.float64, device="cuda")
-        rs_ = b.clone() + 1.0
-        ps_ = cg.dinv * rs_
-        Ap_ = torch.empty_like(xs_)
-        S_ = torch.zeros(5, dtype=torch.float64, device="cuda")
-        tb._lib.check(tb.lib().tb_cgd_dot(dev.h, npts, cg.w.data_ptr(), rs_.data_ptr(), ps_.data_ptr(), S_[0:1].data_ptr()))
-        if world > 1:
-            tb.distributed.all_reduce_sum(S_[0:1], dist)
-        for _ in range(3):
-            cg.device_step(xs_, rs_, ps_, Ap_, S_)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        nit = 10
-        ea, eb, ec = dev.event(), dev.event(), dev.event()
-        t0 = time.perf_counter()
-        for _ in range(nit):
-            cg.device_step(xs_, rs_, ps_, Ap_, S_)
-        torch.cuda.synchronize()
-        t_it = (time.perf_counter() - t0) / nit
-        ea.record()
-        for _ in range(nit):
-            cg.device_iteration(ps_, Ap_, S_)                    # product + halo + pᵀAp only
-        eb.record()
-        for _ in range(nit):
-            tb._lib.check(tb.lib().tb_spmv_csr(K.pattern.h, A.ptr, ps_.data_ptr(), 1.0, 0.0, Ap_.data_ptr()))   # the bare local SpMV, for reference
-        ec.record()
-        torch.cuda.synchronize()
-        if world > 1:
-            tt = torch.tensor([t_it], dtype=torch.float64, device="cpu" if share else "cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            t_it = float(tt.item())
-        dist_cg = {"iteration_ms": t_it * 1e3, "product_halo_dot_ms": ea.elapsed_ms(eb) / nit, "local_spmv_ms": eb.elapsed_ms(ec) / nit,
-                   "halo_bytes_per_rank": halo.nbytes, "rows_per_rank": npts, "nnz_per_rank": sp.nnz,
-                   "note": "one Jacobi-CG iteration on A = M - dt K under the partition (max over ranks, host-timed over %d iterations, device scalars, "
-                           "no host read): interface rows packed first, exchange overlapped with the local SpMV + p'Ap, two all-reduces" % nit}
-        del A, cg, xs_, rs_, ps_, Ap_, diag
+    # the second rate of the line: CG iterations of the heat solve on the same partition (its own timed region, barrier-bracketed, max over ranks)
+    dist_cg = None if args.no_dist_cg else pr.time_cg()
+
+    # N = 1: the slabs a strong-scaling run on N GPUs hands each rank, timed one after the other on this GPU (same kernels, same plans, no exchange)
+    slab_sweep = None
+    if world == 1 and not args.no_slab_sweep and n % 8 == 0:
+        slab_sweep = {"layers": {}, "note": "step = M + K + b + %s reaction, cg = one Jacobi-CG iteration on A = M - dt K, each on an %dx%dxL slab of the mesh (the share of one of "
+                                           "N = %d/L GPUs under --scaling strong); predicted_speedup = t(%d layers) / t(L layers): what the kernels alone allow, without the halo "
+                                           "exchange and the two all-reduces of an iteration" % (args.ionic.upper(), n, n, n, n)}
+        base = {"step_ms": elapsed / args.steps * 1e3, "cg_iteration_ms": dist_cg["iteration_ms"] if dist_cg else None}
+        slab_sweep["layers"][str(n)] = dict(base, cells=g.n_cells)
+        for N in (2, 4, 8):
+            L_ = n // N
+            q = Problem((n, n, L_), (0.0, 0.0, 0.0), (1.0, 1.0, L_ / n), 0, 1, (None, None), None)
+            el = q.time_steps(max(2, args.warmup), max(5, args.steps))
+            ent = {"step_ms": el / max(5, args.steps) * 1e3, "cells": q.g.n_cells, "gpus": N}
+            ent["predicted_speedup_step"] = base["step_ms"] / ent["step_ms"]
+            if dist_cg:
+                ent["cg_iteration_ms"] = q.time_cg()["iteration_ms"]
+                ent["predicted_speedup_cg"] = base["cg_iteration_ms"] / ent["cg_iteration_ms"]
+            slab_sweep["layers"][str(L_)] = ent
+            del q
+            torch.cuda.empty_cache()
 
     if rank == 0:
         K_ = args.steps
-        cells_total = g.n_cells * world
-        dofs_total = npts * world
+        cells_total = n * n * nz_total
+        dofs_total = (n + 1) * (n + 1) * (nz_total + 1)          # distinct dofs of the whole mesh (interface dofs, updated on both sides, counted once)
         ms = elapsed / K_ * 1e3
         k_ms = phase["diffusion"] / K_            # fused: the one M + K launch
         # algorithmic bytes of the dominant launch, each datum once: connectivity 32 B + coordinates 24 B per cell, 27 nz × 8 B per
@@ -332,39 +390,55 @@ def main():
         else:
             kname = "k_matrix_direct<Hex8<2>,DIFFUSION>"
         mk_ms = k_ms + phase["mass"] / K_
+        # FP64 side of the same launch (SURVEY §8d asks for both fractions).  Flops per cell instance counted on the ISA of the shipped kernel
+        # (scripts/isa_hist.py on k_patch_hex8_staged<K+M,DIAG>: 430 v_mul_f64 + 354 v_add_f64 + 465 v_fma_f64 → 1 714 flop); a patch re-integrates
+        # the halo cells of its rows, so the kernel executes `instances_per_cell` × that; "useful" charges every cell once.
+        inst_per_cell = pr.K.pattern.patch_stats()["instances_per_cell"] if args.strategy == "patch" else 1.0
+        flop_inst = FLOP_PER_INSTANCE_FUSED if fused else FLOP_PER_INSTANCE_K
+        tf_useful = flop_inst * g.n_cells / (k_ms * 1e-3) / 1e12
         out = {
             "metric": "element-integrations/sec + DoF-updates/sec, 10M-hex Q1 monodomain",
             "value": 3 * cells_total * K_ / elapsed, "unit": "element-integrations/s",
             "n_gpus": world, "steps": K_, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "monodomain hot path on %d^3 hex Q1 per GPU (%d cells, %d dofs): assemble M + K (%s scatter, %s) + b (patch-reduced sums, 1.4 global atomics per cell)%s + %s forward-Euler reaction step"
-                                   % (n, g.n_cells, npts, args.strategy, "one fused pass" if fused else "two launches",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "monodomain hot path on the %dx%dx%d hex Q1 mesh (%d cells) in %d z-slab(s) of %d layers: assemble M + K (%s scatter, %s) + b (patch-reduced sums, 1.4 global atomics per cell)%s + %s forward-Euler reaction step"
+                                   % (n, n, nz_total, cells_total, world, part.nzl, args.strategy, "one fused pass" if fused else "two launches",
                                       " + neighbour halo sum of b" if world > 1 else "", args.ionic.upper()),
-                       "cells_per_gpu": g.n_cells, "dofs_per_gpu": npts, "nnz_per_gpu": sp.nnz, "ionic_model": args.ionic, "ionic_states": ns,
-                       "partition": "z-slabs", **({"backend": "gloo (shared device, test)"} if share else {})},
+                       "cells_total": cells_total, "cells_per_gpu": g.n_cells, "dofs_per_gpu": npts, "nnz_per_gpu": sp.nnz, "ionic_model": args.ionic, "ionic_states": ns,
+                       "partition": "z-slabs", "layers_per_gpu": part.nzl, **({"backend": "gloo (shared device, test)"} if share else ({"backend": "nccl (RCCL)"} if gd is not None else {}))},
             "dof_updates_per_s": ns * dofs_total * K_ / elapsed,
             "phase_ms": ({"mass+diffusion": k_ms} if fused else {"mass": phase["mass"] / K_, "diffusion": k_ms}) | {k: phase[k] / K_ for k in ("source", "halo", "reaction")},
             "phase_rates": {"matrix_integrations_per_s": 2 * g.n_cells / (mk_ms * 1e-3),
                             "source_cells_per_s": g.n_cells / (phase["source"] / K_ * 1e-3),
                             "reaction_dof_updates_per_s": ns * npts / (phase["reaction"] / K_ * 1e-3)},
-            # "bound" names the roofline the kernel is priced against (its algorithmic bytes over the HBM peak); "limiter" what the counters and phase
-            # stamps say holds it there (profiles/r03_v1/sym_kernel_v3.txt): the integration phase of a patch runs at the vector ALU's own
-            # rate (≈ 2 200 instructions per cell instance, 1.70 instances per cell), the staging and write-out phases are latency-bound, and only two
-            # workgroups per CU (254 VGPRs, 77 KB of LDS) overlap them — VALU busy ≈ 50 %, HBM traffic 1.15× the algorithmic bytes
-            "roofline": {"kernel": kname, "bound": "hbm", "limiter": "fp64 vector issue in the integration phase + latency-bound staging / write-out phases at two workgroups per CU (not HBM, not the LDS atomics)" if fused else "see DESIGN.md §5",
+            # "bound" names the roofline `achieved` / `peak` are priced against (algorithmic bytes over the HBM peak, the contract's definition); the FP64
+            # vector roof sits beside it in `fp64` (SURVEY §8d asks for both), `nearest_roof` says which of the two fractions is the larger, and
+            # `limiter` what the counters and phase stamps say holds the kernel below both (profiles/)
+            "roofline": {"kernel": kname, "bound": "hbm", "limiter": ROOFLINE_LIMITER if fused else "see DESIGN.md §5",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "algorithmic_bytes_per_cell": bytes_per_cell, "launch_ms": k_ms,
                          "frac_per_integration": BYTES_PER_CELL_MATRIX * 2 * g.n_cells / (mk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "fp64": {"bound": "fp64-valu", "achieved": tf_useful, "achieved_incl_halo": tf_useful * inst_per_cell, "peak": FP64_VECTOR_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": tf_useful / FP64_VECTOR_TFLOPS, "frac_incl_halo": tf_useful * inst_per_cell / FP64_VECTOR_TFLOPS,
+                                  "flop_per_cell_instance": flop_inst, "instances_per_cell": inst_per_cell,
+                                  "note": "flops counted on the kernel's ISA (v_mul/v_add = 1, v_fma = 2); useful = one instance per cell, incl_halo = what the kernel executes"},
                          "reaction": {"bound": "hbm", "achieved": (BYTES_PER_DOF_UPDATE + (8 if args.keep_du else 0)) * ns * npts / (phase["reaction"] / K_ * 1e-3) / 1e9,
                                       "peak": HBM_PEAK_GBS, "unit": "GB/s"},
                          "source": {"bound": "hbm", "achieved": BYTES_PER_CELL_VECTOR * g.n_cells / (phase["source"] / K_ * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}},
         }
+        rf = out["roofline"]
+        rf["fp64_frac"], rf["fp64_frac_incl_halo"] = rf["fp64"]["frac"], rf["fp64"]["frac_incl_halo"]
+        rf["nearest_roof"] = "fp64-valu" if rf["fp64_frac_incl_halo"] > rf["frac"] else "hbm"
         for k in ("reaction", "source"):
             out["roofline"][k]["frac"] = out["roofline"][k]["achieved"] / HBM_PEAK_GBS
         if ref_rx is not None:
             out["reference_model_reaction"] = ref_rx
         if dist_cg is not None:
             out["distributed_cg"] = dist_cg
+            out["cg_iterations_per_s"] = 1e3 / dist_cg["iteration_ms"]
+            out["cg_dof_iterations_per_s"] = dofs_total * 1e3 / dist_cg["iteration_ms"]
+        if slab_sweep is not None:
+            out["slab_sweep"] = slab_sweep
         try:  # HBM bytes per launch from this round's PMC passes (rocprofv3 cannot run inside this process): scripts/collect_profiles.sh writes the file
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             if tj["cells"] == g.n_cells and args.strategy == "patch":
@@ -380,7 +454,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_n, kap, os.cpu_count() or 1, args.ionic)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -57,7 +57,10 @@ enum {
                                /* order, no atomics, bit-reproducible (forced for the source term by            */
                                /* src/solver/time/euler.jl:148-153).  Vectors and quadratic-field matrices store */
                                /* the element vectors / matrices and gather them; matrices of first-order fields */
-                               /* get the same ordered sums from the patch kernels without the stored copy      */
+                               /* run the per-colour kernels (one contribution per nz and colour, colours in     */
+                               /* sequence: an ordered sum).  Two assemblies of the same form give identical     */
+                               /* bits (tests: test_element_strategy_is_bit_reproducible).  The PATCH kernels    */
+                               /* do NOT promise that: their LDS accumulators add in wave-scheduling order       */
     TB_STRATEGY_PATCH = 3      /* native: Morton patches of cells, rows accumulated in LDS, each nz / dof      */
                                /* written exactly once with coalesced stores (default, fastest)                */
 };
@@ -142,6 +145,11 @@ enum {
 /* ------------------------------------------------------------------ errors */
 const char *tb_last_error_string(void);
 const char *tb_version(void);
+/* Revision of this interface, bumped whenever an existing entry changes what it reads or writes through its pointers (new entries alone do not
+ * bump it).  4: tb_cgd_update writes three doubles (d_out3; revisions ≤ 3 wrote two).  A host binding compares tb_abi_revision() with the
+ * TB_ABI_REVISION it was written against and refuses to run on a mismatch (julia/ThunderboltHIPBackend.jl does, in __init__) */
+#define TB_ABI_REVISION 4
+int tb_abi_revision(void);
 
 /* ------------------------------------------------------------------ device (AbstractGPUDevice, src/devices.jl:3-4;
  * replaces FerriteOperators.CudaDevice as used in ext/CuThunderboltExt.jl:48-49) */
@@ -430,13 +438,13 @@ int tb_dot(tb_device *dev, int64_t n, const double *d_x, const double *d_y, doub
  * dof held by k ranks with 1/k (NULL: 1); every scalar lives in caller-owned device memory, so the caller sums them over the ranks (RCCL
  * all-reduce) and no kernel waits for the host:
  *   tb_cgd_dot        *d_out      += Σ w·a·b
- *   tb_cgd_update     α = *d_rz / *d_pAp;  x += α p;  r −= α Ap;  d_out2[0] += Σ w·r·(D⁻¹r);  d_out2[1] += Σ w·r·r;
- *                     d_out2[2] (a THIRD slot the caller zeroes once) is set to pᵀAp when pᵀAp ≤ 0 with r·z ≠ 0 — breakdown / indefinite
+ *   tb_cgd_update     α = *d_rz / *d_pAp;  x += α p;  r −= α Ap;  d_out3[0] += Σ w·r·(D⁻¹r);  d_out3[1] += Σ w·r·r;
+ *                     d_out3[2] (THREE doubles since ABI revision 4 — TB_ABI_REVISION; a two-double buffer is out of bounds — the caller zeroes it once) is set to pᵀAp when pᵀAp ≤ 0 with r·z ≠ 0 — breakdown / indefinite
  *                     operator — and never cleared: the host reads it together with ‖r‖² (the step itself is then empty, α = 0)
  *   tb_cgd_direction  β = *d_rz_new / *d_rz;  p = D⁻¹ r + β p                                   (d_dinv NULL: no preconditioner) */
 int tb_cgd_dot(tb_device *dev, int64_t n, const double *d_w, const double *d_a, const double *d_b, double *d_out);
 int tb_cgd_update(tb_device *dev, int64_t n, const double *d_w, const double *d_dinv, const double *d_p, const double *d_Ap, double *d_x, double *d_r,
-                  const double *d_rz, const double *d_pAp, double *d_out2);
+                  const double *d_rz, const double *d_pAp, double *d_out3);
 int tb_cgd_direction(tb_device *dev, int64_t n, const double *d_dinv, const double *d_r, double *d_p, const double *d_rz, const double *d_rz_new);
 /* Halo pack / unpack of the multi-GPU path — new work: the reference is shared-memory only (README.md:7); what these stand in for on one device
  * is the plain indexing of device vectors its GPU extension relies on (ext/CuThunderboltExt.jl:126-170).  Sub-domain vectors hold the dofs
@@ -453,6 +461,15 @@ int tb_gather_indexed(tb_device *dev, int64_t n, const double *d_vec, const int3
  * interface before inverting it (single device: tb_cg_solve does this internally) */
 int tb_extract_diagonal(tb_pattern *pat, const double *d_nzval, double *d_diag);
 int tb_scatter_add_indexed(tb_device *dev, int64_t n, const double *d_in, const int32_t *d_idx, double *d_vec);
+/* d_vec[d_idx[i]] = d_in[i] (assignment; indices of one call distinct).  The overlapped product of the distributed CG uses it to replace the
+ * interface rows of the whole-domain product (formed by the stream kernel) by the rows it sent (formed by tb_spmv_csr_rows) before the received
+ * rows are added: both sides of an interface then add the same two numbers and hold the same bits */
+int tb_scatter_indexed(tb_device *dev, int64_t n, const double *d_in, const int32_t *d_idx, double *d_vec);
+/* Work statistics of the PATCH plan of a pattern's mesh (built on first use; no reference counterpart — the reference's strategies carry no
+ * redundancy): out[0] = patches, out[1] = cell instances (a patch re-integrates the halo cells of the rows it owns: instances / cells is the
+ * factor between the flops the patch kernels execute and the flops of one pass over the cells), out[2] = cells, out[3] = largest number of
+ * instances in a patch, out[4] = largest number of rows in a patch, out[5] = LDS bytes of one matrix accumulator block. */
+int tb_pattern_patch_stats(tb_pattern *pat, int64_t *out6);
 int tb_spmv_csr_rows(tb_pattern *pat, const double *d_nzval, const double *d_x, int64_t n_rows, const int32_t *d_rows, double *d_out);
 int tb_spmv_csr_dot(tb_pattern *pat, const double *d_nzval, const double *d_x, double *d_y, double *d_dot);
 /* apply_zero!(K, f, ch) on the device CSR matrix (Ferrite.apply_zero!; CSR method src/utils.jl:263-278; used by

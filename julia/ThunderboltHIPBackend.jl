@@ -18,6 +18,13 @@ import Thunderbolt: AbstractGPUDevice, AbstractAssemblyStrategy, AbstractSolver,
 
 const libtbhip = get(ENV, "TBHIP_LIBRARY", "libtbhip.so")
 
+# revision of include/tbhip.h these ccalls were written against (TB_ABI_REVISION); a library of another revision reads / writes other buffer sizes
+const TB_ABI_REVISION = 4
+function __init__()
+    have = ccall((:tb_abi_revision, libtbhip), Cint, ())
+    have == TB_ABI_REVISION || error("libtbhip ABI revision $have, this binding was written against $TB_ABI_REVISION")
+end
+
 check(rc::Cint) = rc == 0 ? nothing :
     error("libtbhip error $rc: " * unsafe_string(ccall((:tb_last_error_string, libtbhip), Cstring, ())))
 
@@ -448,10 +455,21 @@ end
 function halo_unpack_add!(v::HIPVector{Float64}, nb::HaloNeighbour)
     check(ccall((:tb_scatter_add_indexed, libtbhip), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Int32}, Ptr{Float64}), v.dev.handle, nb.idx.n, nb.recv.ptr, nb.idx.ptr, v.ptr))
 end
+# v[idx] = the rows this rank sent (same kernel as the peer's rows): called before halo_unpack_add! in the overlapped product, so that both sides of an
+# interface add the same two numbers
+function halo_unpack_own!(v::HIPVector{Float64}, nb::HaloNeighbour)
+    check(ccall((:tb_scatter_indexed, libtbhip), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Int32}, Ptr{Float64}), v.dev.handle, nb.idx.n, nb.send.ptr, nb.idx.ptr, v.ptr))
+end
 # interface rows of A·x straight into the send buffer (posted before the whole product is formed, so the transfer overlaps it)
 function halo_pack_product_rows!(nb::HaloNeighbour, A::HIPSparseMatrixCSR{Float64}, x::HIPVector{Float64})
     check(ccall((:tb_spmv_csr_rows, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Int32}, Ptr{Float64}),
         A.ddh.pattern, A.nzval.ptr, x.ptr, nb.idx.n, nb.idx.ptr, nb.send.ptr))
+end
+# work statistics of the patch plan: (patches, cell instances, cells, max instances per patch, max rows per patch, LDS bytes per accumulator block)
+function patch_stats(A::HIPSparseMatrixCSR)
+    out = zeros(Int64, 6)
+    check(ccall((:tb_pattern_patch_stats, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Int64}), A.ddh.pattern, out))
+    return out
 end
 function diagonal!(d::HIPVector{Float64}, A::HIPSparseMatrixCSR{Float64})
     check(ccall((:tb_extract_diagonal, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), A.ddh.pattern, A.nzval.ptr, d.ptr))

@@ -122,6 +122,9 @@ def _worker(rank, world, port, q):
     cg2.device_iteration(x, Ap2, S)
     pAp2 = float(S[1].item())
     prod_err = float((Ap1 - Ap2).abs().max() / Ap1.abs().max())
+    # interface rows of the overlapped product: own rows + received rows, both from tb_spmv_csr_rows → the two sides of the plane hold the same bits
+    ap_lo = None if lo_idx is None else Ap2[lo_idx].cpu().numpy()
+    ap_up = None if up_idx is None else Ap2[up_idx].cpu().numpy()
     # an indefinite operator must be reported, not iterated to maxiter
     cgn = D.DistributedCG(lambda v: -spmv(v), torch.from_numpy(diag).cuda(), lo_idx, up_idx, rank, world, dist, device=dev, look=2)
     try:
@@ -133,7 +136,8 @@ def _worker(rank, world, port, q):
     plane = (NEL[0] + 1) * (NEL[1] + 1)
     gnode = np.arange(g.n_nodes) + part.z0 * plane
     q.put((rank, gnode, b.cpu().numpy()[n2d], y.cpu().numpy()[n2d], u.cpu().numpy()[n2d], its,
-           {"packed_equal": packed_equal, "u2": u2.cpu().numpy()[n2d], "its2": its2, "prod_err": prod_err, "pAp": (pAp1, pAp2), "breakdown_reported": breakdown_reported}))
+           {"packed_equal": packed_equal, "u2": u2.cpu().numpy()[n2d], "its2": its2, "prod_err": prod_err, "pAp": (pAp1, pAp2), "breakdown_reported": breakdown_reported,
+            "ap_lo": ap_lo, "ap_up": ap_up}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -183,6 +187,8 @@ def test_two_ranks_hip_assembly_halo_and_cg_equal_single_rank(tb, device):
         seen[gnode] += 1
     plane = (NEL[0] + 1) * (NEL[1] + 1)
     assert seen.min() == 1 and (seen == 2).sum() == plane
+    by_rank = {rank: extra for rank, _, _, _, _, _, extra in res}
+    np.testing.assert_array_equal(by_rank[0]["ap_up"], by_rank[1]["ap_lo"])       # bitwise consistent across the interface
 
 
 def test_bench_refuses_wrong_job_size():
@@ -208,6 +214,22 @@ def test_bench_two_ranks_end_to_end_on_one_device():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
-    assert d["config"]["cells_per_gpu"] == 24 ** 3 and d["config"]["backend"].startswith("gloo")
+    # default = strong scaling: the SAME 24³ mesh in two z-slabs of 12 layers (BASELINE's 1/2/4/8-GPU configuration)
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["cells_total"] == 24 ** 3 and d["config"]["cells_per_gpu"] == 24 * 24 * 12 and d["config"]["layers_per_gpu"] == 12
+    assert d["config"]["backend"].startswith("gloo")
     assert d["phase_ms"]["halo"] > 0.0
+    assert d["cg_iterations_per_s"] > 0 and d["distributed_cg"]["halo_bytes_per_rank"] == 25 * 25 * 8
+    # value counts the mesh once: 3 element-integrations per cell of the 24³ mesh per step
+    assert abs(d["value"] - 3 * 24 ** 3 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+
+
+def test_bench_two_ranks_weak_mode_still_available():
+    import json
+    import subprocess
+    env = dict(os.environ, TB_BENCH_SHARE_DEVICE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scaling", "weak", "--n", "16", "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-dist-cg"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["scaling"] == "weak" and d["config"]["cells_per_gpu"] == 16 ** 3 and d["config"]["cells_total"] == 2 * 16 ** 3

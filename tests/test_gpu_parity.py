@@ -90,6 +90,34 @@ def test_mass_matrix_parity(tb, oracle, device):
             assert rel_err(op.A.to_host(), ref) < TOL, (name, type(st).__name__)
 
 
+def test_element_strategy_is_bit_reproducible(tb, oracle, device):
+    """ElementAssemblyStrategy promises ordered sums (include/tbhip.h, TB_STRATEGY_ELEMENT): two assemblies of the same form give the same
+    bits — matrices of first-order fields (per-colour kernels: one plain read-modify-write per non-zero and colour, colours in sequence) on a mesh
+    large enough for several workgroups and waves to meet at every row, and the stored-and-gathered vectors.  The oracle fixes the values."""
+    g = tb.generate_mesh(tb.Hexahedron, (21, 19, 17), (0.0, 0.0, 0.0), (1.0, 1.1, 0.9), perturb=0.2)
+    dh = tb.DofHandler(g)
+    sp = tb.allocate_matrix(dh)
+    om = oracle.Mesh(oracle.HEX8, 2, g.xyz, g.conn, dh.cell_dofs)
+    st = tb.ElementAssemblyStrategy(device)
+    kap = np.array([[2.0, 0.3, 0.1], [0.3, 1.5, 0.2], [0.1, 0.2, 1.0]])
+    for integ, okind, oc in ((tb.BilinearDiffusionIntegrator(tb.ConstantCoefficient(kap)), 1, oracle.Coef(oracle.COEF_CONST_TENSOR, kap.ravel())),
+                             (tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.3)), 0, oracle.Coef(oracle.COEF_CONST_SCALAR, [1.3]))):
+        op = tb.setup_operator(st, integ, dh, sp)
+        runs = []
+        for _ in range(3):
+            tb.update_operator(op, 0.0)
+            runs.append(op.A.to_host().copy())
+        np.testing.assert_array_equal(runs[0], runs[1])
+        np.testing.assert_array_equal(runs[0], runs[2])
+        op2 = tb.update_operator(tb.setup_operator(st, integ, dh, sp), 0.0)   # a second operator object: plans rebuilt, same bits
+        np.testing.assert_array_equal(runs[0], op2.A.to_host())
+        assert rel_err(runs[0], oracle.assemble_matrix(om, okind, oc, sp.rowptr, sp.colidx)) < TOL
+    src = tb.setup_operator(st, tb.LinearIntegrator(tb.AnalyticalCoefficient("cos_exp")), dh)
+    b1 = tb.update_operator(src, 0.2).b.to_host().copy()
+    b2 = tb.update_operator(src, 0.2).b.to_host().copy()
+    np.testing.assert_array_equal(b1, b2)
+
+
 def test_source_vector_parity(tb, oracle, device):
     g, dh, sp, om = make_problem(tb, oracle, left=(-1, -1, -1), right=(1, 1, 1))
     for kind, okind, t in (("norm_plus_t", oracle.SRC_NORM_PLUS_T, 0.0), ("norm_plus_t", oracle.SRC_NORM_PLUS_T, 0.7),

@@ -54,6 +54,7 @@ TB_SARCOMERE_PELCE_SUN_LANGEVELD_1995, TB_SARCOMERE_CONSTANT_STRETCH, TB_SARCOME
 SIGNATURES = {
     "tb_last_error_string": (C.c_char_p, []),
     "tb_version": (C.c_char_p, []),
+    "tb_abi_revision": (C.c_int, []),
     "tb_device_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
     "tb_device_destroy": (C.c_int, [vp]),
     "tb_device_set_stream": (C.c_int, [vp, vp]),
@@ -150,7 +151,9 @@ SIGNATURES = {
     "tb_axpy_f32": (C.c_int, [vp, C.c_int64, C.c_double, vp, vp]),
     "tb_cg_solve_f32": (C.c_int, [vp, vp, vp, vp, C.c_double, C.c_double, C.c_int, C.c_int, vp, vp]),
     "tb_extract_diagonal": (C.c_int, [vp, vp, vp]),
+    "tb_pattern_patch_stats": (C.c_int, [vp, vp]),
     "tb_scatter_add_indexed": (C.c_int, [vp, C.c_int64, vp, vp, vp]),
+    "tb_scatter_indexed": (C.c_int, [vp, C.c_int64, vp, vp, vp]),
     "tb_spmv_csr_rows": (C.c_int, [vp, vp, vp, C.c_int64, vp, vp]),
     "tb_spmv_csr_dot": (C.c_int, [vp, vp, vp, vp, vp]),
     "tb_apply_zero_csr": (C.c_int, [vp, vp, vp, vp, C.c_double]),
@@ -182,6 +185,9 @@ def build_library(force=False):
 _lib = None
 
 
+TB_ABI_REVISION = 4   # include/tbhip.h: TB_ABI_REVISION
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -198,6 +204,9 @@ def lib():
             fn = getattr(_lib, name)  # AttributeError if the ABI lost a symbol
             fn.restype = res
             fn.argtypes = args
+        if _lib.tb_abi_revision() != TB_ABI_REVISION:
+            raise ImportError("thunderbolt.jl_amd: %s has ABI revision %d, this binding was written against %d — rebuild (make -C thunderbolt.jl_amd/csrc)"
+                              % (LIB_PATH, _lib.tb_abi_revision(), TB_ABI_REVISION))
     return _lib
 
 

@@ -408,6 +408,13 @@ class DevicePattern:
                                       sp.colidx.ctypes.data_as(L.c_i32p), 0, C.byref(self.h)))
         self.nnz = sp.nnz
 
+    def patch_stats(self):
+        """Work statistics of the PATCH plan (tb_pattern_patch_stats): patches, cell instances, instances per cell, largest patch."""
+        out = np.zeros(6, dtype=np.int64)
+        check(lib().tb_pattern_patch_stats(self.h, out.ctypes.data_as(L.c_i64p)))
+        return {"patches": int(out[0]), "instances": int(out[1]), "cells": int(out[2]), "instances_per_cell": float(out[1]) / max(int(out[2]), 1),
+                "max_instances": int(out[3]), "max_rows": int(out[4]), "lds_bytes_per_block": int(out[5])}
+
     def __del__(self):
         try:
             if self.h:

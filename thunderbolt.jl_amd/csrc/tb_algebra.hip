@@ -1381,9 +1381,9 @@ int launch_cgd_dot(tb_device *dev, int64_t n, const double *w, const double *a, 
     return TB_OK;
 }
 int launch_cgd_update(tb_device *dev, int64_t n, const double *w, const double *dinv, const double *p, const double *Ap, double *x, double *r,
-                      const double *d_rz, const double *d_pAp, double *d_out2)
+                      const double *d_rz, const double *d_pAp, double *d_out3)
 {
-    if (n > 0) hipLaunchKernelGGL(k_cgd_update, dim3(grid_for(dev, n, 256)), dim3(256), 0, dev->stream, n, w, dinv, p, Ap, x, r, d_rz, d_pAp, d_out2);
+    if (n > 0) hipLaunchKernelGGL(k_cgd_update, dim3(grid_for(dev, n, 256)), dim3(256), 0, dev->stream, n, w, dinv, p, Ap, x, r, d_rz, d_pAp, d_out3);
     TB_HIP(hipGetLastError());
     return TB_OK;
 }
@@ -1405,6 +1405,12 @@ __global__ void __launch_bounds__(256) k_scatter_add_indexed(int64_t n, const do
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) vec[idx[i]] += in[i]; // indices of one call are distinct
+}
+
+__global__ void __launch_bounds__(256) k_scatter_indexed(int64_t n, const double *__restrict__ in, const int32_t *__restrict__ idx, double *__restrict__ vec)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) vec[idx[i]] = in[i];
 }
 
 // out[k] = Σ_j A[rows[k], j] x[j]: 16 lanes per listed row
@@ -1434,6 +1440,12 @@ int launch_gather_indexed(tb_device *dev, int64_t n, const double *vec, const in
 int launch_scatter_add_indexed(tb_device *dev, int64_t n, const double *in, const int32_t *idx, double *vec)
 {
     if (n > 0) hipLaunchKernelGGL(k_scatter_add_indexed, dim3(grid_for(dev, n, 256)), dim3(256), 0, dev->stream, n, in, idx, vec);
+    TB_HIP(hipGetLastError());
+    return TB_OK;
+}
+int launch_scatter_indexed(tb_device *dev, int64_t n, const double *in, const int32_t *idx, double *vec)
+{
+    if (n > 0) hipLaunchKernelGGL(k_scatter_indexed, dim3(grid_for(dev, n, 256)), dim3(256), 0, dev->stream, n, in, idx, vec);
     TB_HIP(hipGetLastError());
     return TB_OK;
 }

@@ -57,6 +57,7 @@ extern "C" {
 
 const char *tb_last_error_string(void) { return g_error.c_str(); }
 const char *tb_version(void) { return "thunderbolt.jl_amd 0.1 (gfx950)"; }
+int tb_abi_revision(void) { return TB_ABI_REVISION; }
 
 // ------------------------------------------------------------------ device
 int tb_device_create(int hip_device_id, tb_device **out)
@@ -1056,11 +1057,11 @@ int tb_cgd_dot(tb_device *dev, int64_t n, const double *d_w, const double *d_a, 
 }
 
 int tb_cgd_update(tb_device *dev, int64_t n, const double *d_w, const double *d_dinv, const double *d_p, const double *d_Ap, double *d_x, double *d_r,
-                  const double *d_rz, const double *d_pAp, double *d_out2)
+                  const double *d_rz, const double *d_pAp, double *d_out3)
 {
-    TB_REQUIRE(dev && d_rz && d_pAp && d_out2 && n >= 0 && ((d_p && d_Ap && d_x && d_r) || n == 0), "tb_cgd_update: bad argument");
+    TB_REQUIRE(dev && d_rz && d_pAp && d_out3 && n >= 0 && ((d_p && d_Ap && d_x && d_r) || n == 0), "tb_cgd_update: bad argument");
     TB_HIP(hipSetDevice(dev->id));
-    return launch_cgd_update(dev, n, d_w, d_dinv, d_p, d_Ap, d_x, d_r, d_rz, d_pAp, d_out2);
+    return launch_cgd_update(dev, n, d_w, d_dinv, d_p, d_Ap, d_x, d_r, d_rz, d_pAp, d_out3);
 }
 
 int tb_cgd_direction(tb_device *dev, int64_t n, const double *d_dinv, const double *d_r, double *d_p, const double *d_rz, const double *d_rz_new)
@@ -1077,11 +1078,30 @@ int tb_extract_diagonal(tb_pattern *pat, const double *d_nzval, double *d_diag)
     return launch_extract_diagonal(pat, d_nzval, d_diag);
 }
 
+int tb_pattern_patch_stats(tb_pattern *pat, int64_t *out6)
+{
+    TB_REQUIRE(pat && out6, "tb_pattern_patch_stats: NULL argument");
+    TB_HIP(hipSetDevice(pat->mesh->dev->id));
+    int rc = ensure_patch_plans(pat->mesh, nullptr); // the mesh-level plan as the kernels last (re)fitted it; not the per-pattern extensions
+    if (rc) return rc;
+    const PatchPlan *pp = pat->mesh->patches.get();
+    out6[0] = pp->n_patches; out6[1] = pp->total_elems; out6[2] = pat->mesh->n_cells; out6[3] = pp->max_elems; out6[4] = pp->max_rows;
+    out6[5] = pat->patch_fused ? (int64_t)pat->patch_fused->max_lds_entries * 8 : (pat->patch_mat ? (int64_t)pat->patch_mat->max_lds_entries * 8 : 0);
+    return TB_OK;
+}
+
 int tb_gather_indexed(tb_device *dev, int64_t n, const double *d_vec, const int32_t *d_idx, double *d_out)
 {
     TB_REQUIRE(dev && n >= 0 && ((d_vec && d_idx && d_out) || n == 0), "tb_gather_indexed: bad argument");
     TB_HIP(hipSetDevice(dev->id));
     return launch_gather_indexed(dev, n, d_vec, d_idx, d_out);
+}
+
+int tb_scatter_indexed(tb_device *dev, int64_t n, const double *d_in, const int32_t *d_idx, double *d_vec)
+{
+    TB_REQUIRE(dev && n >= 0 && ((d_vec && d_idx && d_in) || n == 0), "tb_scatter_indexed: bad argument");
+    TB_HIP(hipSetDevice(dev->id));
+    return launch_scatter_indexed(dev, n, d_in, d_idx, d_vec);
 }
 
 int tb_scatter_add_indexed(tb_device *dev, int64_t n, const double *d_in, const int32_t *d_idx, double *d_vec)

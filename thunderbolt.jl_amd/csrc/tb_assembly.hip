@@ -1545,11 +1545,12 @@ int launch_assemble_matrix(tb_form *f, tb_pattern *p, int strategy, double t, do
     tb_mesh *m = f->mesh;
     int rc = reset_status(m->dev);
     if (rc) return rc;
-    // ElementAssemblyStrategy on first-order fields: what the reference's strategy guarantees for a matrix — element contributions summed per
-    // row in a fixed order, no atomics, bit-reproducible (src/Thunderbolt.jl:22-32; FerriteOperators' element assembly) — is what the patch
-    // kernels do (each non-zero is the ordered sum of its cells' contributions and is stored once), without the stored-Kₑ round trip the
-    // quadratic fields need.  The strategy is accepted and runs them; subdomain forms (not patch-capable) take the per-colour form, deterministic too.
-    if (strategy == TB_STRATEGY_ELEMENT && m->field_kind != TB_HEX27) strategy = f->has_cellset ? TB_STRATEGY_PER_COLOR : TB_STRATEGY_PATCH;
+    // ElementAssemblyStrategy on first-order fields: what the reference's strategy guarantees for a matrix is element contributions summed in a
+    // fixed order, no atomics, bit-reproducible (src/Thunderbolt.jl:22-32; FerriteOperators' element assembly).  The patch kernels do not give
+    // that (their LDS row accumulators take the ≤ 8 contributions of a non-zero with ds_add_f64 from four waves: the order follows the wave
+    // scheduling), the per-colour kernels do: cells of one colour share no dof, so every non-zero receives at most one plain read-modify-write per
+    // colour and the colours run in sequence on the stream — the sum of a non-zero is taken in colour order, every time.
+    if (strategy == TB_STRATEGY_ELEMENT && m->field_kind != TB_HEX27) strategy = TB_STRATEGY_PER_COLOR;
     if (strategy == TB_STRATEGY_PATCH && hex8_patch_applicable(f, p)) {
         rc = f->kind == TB_FORM_DIFFUSION ? launch_assemble_hex8_patch(f, nullptr, p, t, d_nz, nullptr) : launch_assemble_hex8_patch(nullptr, f, p, t, nullptr, d_nz);
         if (rc != TB_ERR_UNSUPPORTED) return rc; // e.g. rows longer than 255 entries: the general patch kernel below

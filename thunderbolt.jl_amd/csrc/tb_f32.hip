@@ -58,6 +58,7 @@ k_spmv_f32(int64_t nrows, const int64_t *__restrict__ rowptr, const int32_t *__r
 // scratch arena of the device object (grown on demand, released with the device)
 static int arena(tb_device *dev, size_t bytes, double **out)
 {
+    TB_HIP(hipSetDevice(dev->id)); // every *_f32 entry comes through here first: the arena (and the conversion kernels behind it) belong to this device, whatever the caller's current one
     if (dev->scratch_bytes < bytes) {
         TB_HIP(hipStreamSynchronize(dev->stream));
         if (dev->d_scratch) (void)hipFree(dev->d_scratch);

@@ -322,12 +322,13 @@ int launch_meandiag(tb_pattern *pat, const double *nz, double *result);
 int launch_dot(tb_device *dev, int64_t n, const double *a, const double *b, double *result);
 int launch_cgd_dot(tb_device *dev, int64_t n, const double *w, const double *a, const double *b, double *d_out);
 int launch_cgd_update(tb_device *dev, int64_t n, const double *w, const double *dinv, const double *p, const double *Ap, double *x, double *r,
-                      const double *d_rz, const double *d_pAp, double *d_out2);
+                      const double *d_rz, const double *d_pAp, double *d_out3);
 int launch_cgd_direction(tb_device *dev, int64_t n, const double *dinv, const double *r, double *p, const double *d_rz, const double *d_rz_new);
 int launch_max(tb_device *dev, int64_t n, const double *x, int64_t stride, double *result);
 int ensure_cell_xyz(tb_mesh *m); // tb_assembly.hip: builds tb_mesh::d_cell_xyz on first use
 int launch_gather_indexed(tb_device *dev, int64_t n, const double *vec, const int32_t *idx, double *out);
 int launch_scatter_add_indexed(tb_device *dev, int64_t n, const double *in, const int32_t *idx, double *vec);
+int launch_scatter_indexed(tb_device *dev, int64_t n, const double *in, const int32_t *idx, double *vec);
 int launch_spmv_rows(tb_pattern *p, const double *nz, const double *x, int64_t n, const int32_t *rows, double *out);
 int launch_extract_diagonal(tb_pattern *p, const double *nz, double *diag);
 int launch_spmv_dot(tb_pattern *pat, const double *A, const double *x, double *y, double *d_dot);

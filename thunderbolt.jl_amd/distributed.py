@@ -191,14 +191,24 @@ class HaloExchange:
             ops.append(dist.P2POp(dist.irecv, self.recv_h[k] if self.staged else self.recv[k], peer))
         self.reqs = dist.batch_isend_irecv(ops)
 
-    def finish(self, vec):
-        """wait for the transfers, then vec[shared dofs] += received partials"""
+    def finish(self, vec, own_from_send=False):
+        """wait for the transfers, then vec[shared dofs] += received partials.  own_from_send: first vec[shared dofs] = the send buffers (the
+        overlapped product: the rows this rank sent were formed by tb_spmv_csr_rows, the peer's too — replacing the stream kernel's interface rows
+        by them makes both sides add the same two numbers, so a dof shared by two ranks holds the same bits on both)"""
         for r in self.reqs:
             r.wait()
         self.reqs = []
         if self.staged:
             for r_, rh in zip(self.recv, self.recv_h):
                 r_.copy_(rh, non_blocking=True)
+        if own_from_send:
+            if self.cuda:
+                from ._lib import check, lib
+                for idx32, send in zip(self.idx32, self.send):
+                    check(lib().tb_scatter_indexed(self.dev.h, idx32.numel(), self._ptr(send), self._ptr(idx32), self._ptr(vec)))
+            else:
+                for idx, send in zip(self.idx, self.send):
+                    vec[idx] = send
         if self.cuda:
             from ._lib import check, lib
             for idx32, recv in zip(self.idx32, self.recv):
@@ -250,7 +260,9 @@ class DistributedCG:
 
     Vectors are torch tensors holding every dof of the part (owned + interface); solution-type vectors are kept
     *consistent* (all sharing ranks hold the same interface value), operator results are summed over the interface
-    by a `HaloExchange`.  Dot products weight interface dofs by 1/multiplicity and are all-reduced; pᵀAp is the sum over the ranks of the
+    by a `HaloExchange`.  Consistency is bitwise for dofs shared by two ranks (every slab interface; faces of general partitions): both sides
+    add the same two partials, formed by the same kernel (own + received = received + own); a dof shared by three or more ranks of a general
+    partition receives its partials in peer order, which differs between the ranks — equal to rounding there, not bitwise.  Dot products weight interface dofs by 1/multiplicity and are all-reduced; pᵀAp is the sum over the ranks of the
     local quadratic forms pᵀA_p p (p is consistent), so it needs no halo.
     `local_spmv(x) -> y` applies the rank's own A_p.  New work: the reference has no distributed solver (README.md:7).
 
@@ -343,7 +355,7 @@ class DistributedCG:
             self.halo.pack_product_rows(pattern, nz, p)              # interface rows first …
             self.halo.start()                                        # … their exchange in flight …
             check(L.tb_spmv_csr_dot(pattern.h, nz.ptr, ptr(p), ptr(Ap), ptr(S[1:2])))   # … behind the whole local product + local pᵀA_p p
-            self.halo.finish(Ap)
+            self.halo.finish(Ap, own_from_send=True)                 # interface rows: own (rows kernel) + received (the peer's rows kernel), bitwise symmetric
         else:
             y = self.spmv(p)
             check(L.tb_cgd_dot(self.dev.h, n, None, ptr(p), ptr(y), ptr(S[1:2])))       # local quadratic form, before the halo sum
