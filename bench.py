@@ -36,6 +36,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the CPU baseline runs on all physical cores, pinned (docs/src/vroom.md:3-15 of the reference): libgomp reads these when it is first loaded
+os.environ.setdefault("OMP_PROC_BIND", "close")
+os.environ.setdefault("OMP_PLACES", "cores")
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 FP64_VECTOR_TFLOPS = 78.6      # AMD spec sheet; FP64 MFMA runs at the same rate on CDNA4
@@ -62,6 +65,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dist-cg", action="store_true", help="skip the (untimed-region) distributed CG iteration measurement")
     ap.add_argument("--cpu-n", type=int, default=64, help="edge of the CPU-baseline sample mesh")
+    ap.add_argument("--no-cpu-big", action="store_true", help="skip the one all-cores CPU pass over the GPU run's own mesh")
     ap.add_argument("--keep-du", action="store_true", help="materialise du (dumat) in the reaction step")
     ap.add_argument("--separate", action="store_true", help="assemble M and K with two launches instead of the fused pass")
     ap.add_argument("--ionic", default="tt06", choices=["pcg2019", "tt06", "fhn", "ord"],
@@ -80,55 +84,89 @@ def cpu_model_string():
     return "unknown"
 
 
-def cpu_baseline(n, kap, threads, ionic="tt06", sizes=(64, 100)):
-    """Oracle ("port": C restatement of the reference CPU path, NOT Julia) on bounded samples of the same workload, as SURVEY §8(d) asks:
-    1 thread and the best multi-thread count, on the 64³ and 100³ meshes, min over repetitions after a warm-up.  `value` is the
-    multi-thread rate on the n³ sample (n = --cpu-n); every other number sits in `table`."""
+def physical_cores():
+    """(physical cores, hardware threads) visible to this process, from /proc/cpuinfo (distinct (physical id, core id) pairs among the allowed CPUs)."""
+    allowed = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    cores, cpu, phys = set(), None, None
+    try:
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "processor":
+                cpu, phys = int(v), None
+            elif k == "physical id":
+                phys = int(v)
+            elif k == "core id" and (allowed is None or cpu in allowed):
+                cores.add((phys, int(v)))
+    except OSError:
+        pass
+    nthreads = len(allowed) if allowed is not None else (os.cpu_count() or 1)
+    return (len(cores) or nthreads), nthreads
+
+
+HOST_CORES = physical_cores()
+
+
+def cpu_baseline(n, kap, ionic="tt06", sizes=(64, 100), big=None):
+    """Oracle ("port": C restatement of the reference CPU path, NOT Julia) on bounded samples of the same workload, as SURVEY §8(d) asks: 1 thread and
+    all physical cores (docs/src/vroom.md:3-15: threads = physical cores, pinned — OMP_PROC_BIND / OMP_PLACES are set at the top of this file), on the
+    64³ and 100³ meshes, min over repetitions after a warm-up; the 216³ mesh of the GPU run once on all cores (`big` = its host arrays).  The
+    multi-thread legs run the scaling form of the per-colour loop (oracle.AssemblyPlan: scatter positions looked up once, per-colour cell lists,
+    first-touch zero fill, element routines instantiated for the hexahedron); the 1-thread legs are timed in both forms — that one and the
+    literal sequential loop the parity tests use.  `value` is the all-cores rate on the n³ sample (n = --cpu-n); everything else sits in `table`."""
     from oracle import oracle as o
     cm = {"pcg2019": o.CELL_PCG2019, "tt06": o.CELL_TT06, "fhn": o.CELL_FHN, "ord": o.CELL_ORD11}[ionic]
     rdt = {"pcg2019": 0.01, "tt06": 0.001, "fhn": 0.1, "ord": 0.002}[ionic]
     p = o.cell_default_params(cm)
     cM = o.Coef(o.COEF_CONST_SCALAR, [1.0])
     cK = o.Coef(o.COEF_CONST_TENSOR, kap.ravel(), Cm=1.0, chi=1.0, wrap=True)
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else threads
-    table, chosen = {}, None
-    for nn in sorted(set(sizes) | {n}):
-        xyz, conn = o.generate_grid_hex(nn, nn, nn, (0, 0, 0), (1, 1, 1))
-        cd, nd = o.close_dofs(o.HEX8, 1, conn, len(xyz))
-        rp, ci = o.build_pattern(cd, nd)
-        col, nc = o.color_cells(cd, nd)
-        m = o.Mesh(o.HEX8, 2, xyz, conn, cd)
+    cores, avail = HOST_CORES                                      # counted at import time: once libgomp has pinned the initial thread, its affinity mask is one core
+    table = {}
+
+    def legs(tag, m, rp, ci, nd, ncells, threads_list, literal_1t):
+        col, nc = o.color_cells(m.cell_dofs, nd)
         u = np.ascontiguousarray(np.tile(o.cell_default_state(cm, p), (nd, 1)).T).ravel().copy()
         nstates = len(u) // nd
-        if chosen is None:
-            # the oracle's OpenMP loops stop scaling (and collapse when oversubscribed) well below the box's 256 hardware
-            # threads: pick the fastest of a few thread counts on one diffusion assembly, then time every sample with it
-            cands = sorted({t for t in (8, 16, 32, 64) if t <= avail} | {min(avail, 8)})
-            probe = {}
-            for t in cands:
-                t0 = time.perf_counter()
-                o.assemble_matrix(m, 1, cK, rp, ci, nthreads=t, color=col, ncolors=nc)
-                probe[t] = time.perf_counter() - t0
-            chosen = min(probe, key=probe.get)
-        for th, budget in ((1, 3.0), (chosen, 4.0)):
+        for th in threads_list:
+            plan = o.AssemblyPlan(m, rp, ci, col, nc, th)
+            nzM, nzK = plan.new_values(), plan.new_values()
             best_asm, best_rx, reps = 1e30, 1e30, 0
-            t_end = time.time() + budget
-            while reps < (1 if th == 1 else 2) or (time.time() < t_end and reps < 6):   # bounded: the slow single-thread legs may get one repetition only
+            t_end = time.time() + (3.0 if th == 1 else 4.0)
+            while reps < 2 or (time.time() < t_end and reps < 6):
                 t0 = time.perf_counter()
-                o.assemble_matrix(m, 0, cM, rp, ci, nthreads=th, color=col, ncolors=nc)
-                o.assemble_matrix(m, 1, cK, rp, ci, nthreads=th, color=col, ncolors=nc)
+                plan.assemble(0, cM, nzM)
+                plan.assemble(1, cK, nzK)
                 o.assemble_source(m, o.SRC_COS_EXP, t=0.0, nthreads=th)
                 t1 = time.perf_counter()
                 o.reaction_step(cm, p, u, nd, o.LAYOUT_SOA, dt=rdt, nthreads=th, want_du=False)
                 t2 = time.perf_counter()
-                best_asm, best_rx = min(best_asm, t1 - t0), min(best_rx, t2 - t1)
+                if reps > 0 or th == 1:                            # the first multi-thread pass places the pages
+                    best_asm, best_rx = min(best_asm, t1 - t0), min(best_rx, t2 - t1)
                 reps += 1
-            table["%d^3/%dt" % (nn, th)] = {"element_integrations_per_s": 3 * nn ** 3 / best_asm, "dof_updates_per_s": nstates * nd / best_rx, "reps": reps}
-    top = table["%d^3/%dt" % (n, chosen)]
-    return {"value": top["element_integrations_per_s"], "unit": "element-integrations/s", "cores": chosen, "kind": "port",
-            "sample": "%d^3 hex Q1 mesh (%d cells): M + K + b per-colour/EA OpenMP, min of %d reps; C restatement of the reference CPU path, not Julia" % (n, n ** 3, top["reps"]),
+            table["%s/%dt" % (tag, th)] = {"element_integrations_per_s": 3 * ncells / best_asm, "dof_updates_per_s": nstates * nd / best_rx, "reps": reps}
+            del plan, nzM, nzK
+        if literal_1t:
+            t0 = time.perf_counter()
+            o.assemble_matrix(m, 0, cM, rp, ci)
+            o.assemble_matrix(m, 1, cK, rp, ci)
+            o.assemble_source(m, o.SRC_COS_EXP, t=0.0)
+            table["%s/1t-literal" % tag] = {"element_integrations_per_s": 3 * ncells / (time.perf_counter() - t0), "reps": 1,
+                                            "note": "the sequential loop of coordinate_systems.jl:145-171 as the parity tests run it (generic element instances, search per entry)"}
+
+    for nn in sorted(set(sizes) | {n}):
+        xyz, conn = o.generate_grid_hex(nn, nn, nn, (0, 0, 0), (1, 1, 1))
+        cd, nd = o.close_dofs(o.HEX8, 1, conn, len(xyz))
+        rp, ci = o.build_pattern(cd, nd)
+        legs("%d^3" % nn, o.Mesh(o.HEX8, 2, xyz, conn, cd), rp, ci, nd, nn ** 3, sorted({1, cores}), literal_1t=(nn == min(sizes)))
+    if big is not None:
+        xyz, conn, cd, nd, rp, ci, tag = big
+        legs(tag, o.Mesh(o.HEX8, 2, xyz, conn, cd), rp, ci, nd, conn.shape[0], [cores], literal_1t=False)
+    top = table["%d^3/%dt" % (n, cores)]
+    return {"value": top["element_integrations_per_s"], "unit": "element-integrations/s", "cores": cores, "kind": "port",
+            "sample": "%d^3 hex Q1 mesh (%d cells): M + K per-colour + b element-assembly, OpenMP on all %d physical cores (pinned: OMP_PROC_BIND=%s OMP_PLACES=%s), min of %d reps; "
+                      "C restatement of the reference CPU path, not Julia" % (n, n ** 3, cores, os.environ.get("OMP_PROC_BIND"), os.environ.get("OMP_PLACES"), top["reps"]),
             "dof_updates_per_s": top["dof_updates_per_s"], "ionic_model": ionic,
-            "table": table, "threads_available": avail, "threads_chosen": chosen, "cpu_model": cpu_model_string()}
+            "table": table, "physical_cores": cores, "hardware_threads": avail, "cpu_model": cpu_model_string()}
 
 
 def spawn_ranks(args):
@@ -274,15 +312,21 @@ def main():
         def time_steps(self, warmup, steps):
             """W untimed steps, then exactly K steps bracketed by barrier + synchronize on both sides; the MAX over ranks of the wall time"""
             for i in range(warmup):
-                self.step(i, False)
+                self.step(i, False)                                  # status read after every assembly call: a bad mesh or pattern surfaces here
             self.sync()
+            # the timed steps run with the status deferred (tb_device_defer_status): the mesh is fixed, so the per-call check of the warm-up steps
+            # is what a time loop needs; the steps enqueue back to back and the one status read of the region sits inside it, before the clock stops
+            dev.defer_status(True)
             t0 = time.perf_counter()
             for i in range(steps):
                 self.step(warmup + i, True)
             torch.cuda.synchronize()
+            dev.poll_status()
             if self.dist is not None:
                 self.dist.barrier()
-            return self.max_over_ranks(time.perf_counter() - t0)
+            dt_ = self.max_over_ranks(time.perf_counter() - t0)
+            dev.defer_status(False)
+            return dt_
 
         def time_cg(self, nit=10):
             """What a time step adds to the assembly under a partition — one iteration of the distributed Jacobi-CG on the heat matrix A = M − Δt·K of
@@ -365,7 +409,8 @@ def main():
             L_ = n // N
             q = Problem((n, n, L_), (0.0, 0.0, 0.0), (1.0, 1.0, L_ / n), 0, 1, (None, None), None)
             el = q.time_steps(max(2, args.warmup), max(5, args.steps))
-            ent = {"step_ms": el / max(5, args.steps) * 1e3, "cells": q.g.n_cells, "gpus": N}
+            ent = {"step_ms": el / max(5, args.steps) * 1e3, "cells": q.g.n_cells, "gpus": N,
+                   "phase_ms": {k: v / max(5, args.steps) for k, v in q.phase.items() if v > 0.0}}
             ent["predicted_speedup_step"] = base["step_ms"] / ent["step_ms"]
             if dist_cg:
                 ent["cg_iteration_ms"] = q.time_cg()["iteration_ms"]
@@ -452,7 +497,8 @@ def main():
         except Exception:
             pass
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_n, kap, os.cpu_count() or 1, args.ionic)
+            big = None if args.no_cpu_big else (g.xyz, g.conn, dh.cell_dofs, dh.ndofs, sp.rowptr, sp.colidx, "%dx%dx%d" % (n, n, nz_total))
+            out["cpu_baseline"] = cpu_baseline(args.cpu_n, kap, args.ionic, big=big)
         print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()

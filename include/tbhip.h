@@ -162,6 +162,14 @@ int tb_device_set_stream(tb_device *dev, void *hip_stream);
  * means "give the device its own non-blocking stream back". */
 int tb_device_use_null_stream(tb_device *dev);
 int tb_device_synchronize(tb_device *dev);
+/* Deferred status.  By default every assembly call reads the device's status block (detJ ≤ 0 in a cell, coupling missing from the pattern) before
+ * it returns — one stream synchronisation per call, the analogue of the reference's kernels that cannot throw and a host check after each
+ * (src/ferrite-addons/PR883.jl:359-379).  A time loop on a fixed mesh needs that check once, not per step: with tb_device_defer_status(dev, 1) the
+ * assembly calls only enqueue their kernels and return TB_OK, the flags stay raised in device memory (they are sticky), and
+ * tb_device_poll_status(dev) synchronises, reports the first error raised since the last poll (TB_ERR_NEG_DETJ / TB_ERR_PATTERN, cell in
+ * tb_last_error_string) and clears the block.  The solvers' own reads (CG convergence, local Newton failures) are not affected. */
+int tb_device_defer_status(tb_device *dev, int on);
+int tb_device_poll_status(tb_device *dev);
 int tb_device_info(tb_device *dev, char *name, size_t name_len, int *n_cu, size_t *hbm_bytes);
 
 /* vectors / matrices storage (create_system_vector / create_system_matrix, ext/CuThunderboltExt.jl:126-146) */
@@ -470,6 +478,10 @@ int tb_scatter_indexed(tb_device *dev, int64_t n, const double *d_in, const int3
  * factor between the flops the patch kernels execute and the flops of one pass over the cells), out[2] = cells, out[3] = largest number of
  * instances in a patch, out[4] = largest number of rows in a patch, out[5] = LDS bytes of one matrix accumulator block. */
 int tb_pattern_patch_stats(tb_pattern *pat, int64_t *out6);
+/* Plan of the stream SpMV behind tb_spmv_csr (built with the pattern's first product): out2[0] = row signatures of the index-compressed kernel
+ * (> 0: rows holding the same column offsets relative to their index share one table entry, the kernel reads 4 B per row instead of 4 B per
+ * non-zero; −1: the pattern does not compress — table larger than nnz / 4 — and keeps the CSR kernel), out2[1] = entries of the signature table */
+int tb_pattern_spmv_plan(tb_pattern *pat, int64_t *out2);
 int tb_spmv_csr_rows(tb_pattern *pat, const double *d_nzval, const double *d_x, int64_t n_rows, const int32_t *d_rows, double *d_out);
 int tb_spmv_csr_dot(tb_pattern *pat, const double *d_nzval, const double *d_x, double *d_y, double *d_dot);
 /* apply_zero!(K, f, ch) on the device CSR matrix (Ferrite.apply_zero!; CSR method src/utils.jl:263-278; used by

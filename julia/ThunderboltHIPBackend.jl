@@ -42,6 +42,10 @@ end
 MI355XDevice(id = 0) = MI355XDevice{Float64, Int32}(id)
 value_type(::MI355XDevice{Tv}) where {Tv} = Tv
 index_type(::MI355XDevice{Tv, Ti}) where {Tv, Ti} = Ti
+# deferred status: inside a time loop on a fixed mesh the assembly calls then only enqueue their kernels; `poll_status` synchronises and throws the first
+# assembly error (detJ ≤ 0, coupling missing from the pattern) raised since the last poll
+defer_status!(dev::MI355XDevice, on::Bool = true) = check(ccall((:tb_device_defer_status, libtbhip), Cint, (Ptr{Cvoid}, Cint), dev.handle, on ? 1 : 0))
+poll_status(dev::MI355XDevice) = check(ccall((:tb_device_poll_status, libtbhip), Cint, (Ptr{Cvoid},), dev.handle))
 
 # ---------------------------------------------------------------- vectors: an opaque, GC-managed device buffer (finaliser → tb_free).
 # Deliberately NOT an AbstractVector: there is no scalar indexing on the device, and the solvers that consume it are the library's own

@@ -225,6 +225,41 @@ def assemble_matrix(mesh, form, coef, rowptr, colidx, t=0.0, nthreads=1, color=N
     return nz
 
 
+class AssemblyPlan:
+    """CPU-baseline form of the per-colour loop (bench.py's cpu_baseline): scatter positions looked up once, per-colour cell lists, first-touch zero
+    fill — orc_assembly_plan_*.  `assemble(form, coef, nz)` fills (and returns) nz; pass the same `nz` array every time to keep its pages where the
+    first call put them."""
+
+    def __init__(self, mesh, rowptr, colidx, color, ncolors, nthreads):
+        self.mesh, self.nthreads = mesh, int(nthreads)
+        self.rowptr, self.colidx, self.color = rowptr, colidx, np.ascontiguousarray(color, dtype=np.int32)
+        self.h = C.c_void_p()
+        L = lib()
+        L.orc_assembly_plan_create.restype = C.c_int
+        L.orc_assembly_plan_destroy.restype = None
+        L.orc_assembly_plan_destroy.argtypes = [C.c_void_p]
+        rc = L.orc_assembly_plan_create(C.byref(mesh.c), _i64(rowptr), _i32(colidx), _i32(self.color), int(ncolors), self.nthreads, C.byref(self.h))
+        if rc:
+            raise RuntimeError("orc_assembly_plan_create -> %d" % rc)
+        self.nnz = int(rowptr[-1])
+
+    def new_values(self):
+        return np.empty(self.nnz)                       # untouched pages: the first assembly's zero fill places them
+
+    def assemble(self, form, coef, nz):
+        rc = lib().orc_assemble_matrix_planned(self.h, C.byref(self.mesh.c), int(form), C.byref(coef.c), _d(nz), self.nthreads)
+        if rc:
+            raise RuntimeError("orc_assemble_matrix_planned -> %d" % rc)
+        return nz
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().orc_assembly_plan_destroy(self.h)
+        except Exception:
+            pass
+
+
 def assemble_source(mesh, src_kind, p=None, table=None, t=0.0, nthreads=1):
     b = np.zeros(mesh.ndofs)
     p = _f64(p if p is not None else [0.0])

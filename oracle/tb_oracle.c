@@ -167,7 +167,8 @@ int orc_shape(int kind, const double *xi, double *N, double *dN)
 
 /* src/ferrite-addons/PR883.jl:253-263 (J = Σ xⱼ ⊗ dMⱼ/dξ) and :367-387 (detJ, J⁻¹).
  * x: ngeo*dim, dM: ngeo*dim, J/Jinv: dim*dim row-major. returns -1 when detJ <= 0 (PR883.jl:376). */
-int orc_mapping(int dim, int ngeo, const double *x, const double *dM, double *J, double *detJ, double *Jinv)
+/* the statements of orc_mapping; always inlined so that callers with compile-time dim / ngeo (the hexahedron instances of the CPU baseline) unroll them */
+static inline __attribute__((always_inline)) int mapping_impl(const int dim, const int ngeo, const double *x, const double *dM, double *J, double *detJ, double *Jinv)
 {
     for (int i = 0; i < dim * dim; ++i) J[i] = 0.0;
     for (int a = 0; a < ngeo; ++a)
@@ -190,6 +191,11 @@ int orc_mapping(int dim, int ngeo, const double *x, const double *dM, double *J,
     }
     *detJ = det;
     return det > 0.0 ? 0 : -1;
+}
+
+int orc_mapping(int dim, int ngeo, const double *x, const double *dM, double *J, double *detJ, double *Jinv)
+{
+    return mapping_impl(dim, ngeo, x, dM, J, detJ, Jinv);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -459,21 +465,22 @@ static int cv_setup(cellvalues *cv, int kind, int qorder)
     return 0;
 }
 
-static void gather_coords(const orc_mesh *m, const cellvalues *cv, int64_t cell, double *x)
+static inline __attribute__((always_inline)) void gather_coords_impl(const orc_mesh *m, int64_t cell, double *x, const int dim, const int ngeo)
 {
-    for (int a = 0; a < cv->ngeo; ++a)
-        for (int d = 0; d < cv->dim; ++d) x[cv->dim * a + d] = m->xyz[(int64_t)cv->dim * m->conn[cell * cv->ngeo + a] + d];
+    for (int a = 0; a < ngeo; ++a)
+        for (int d = 0; d < dim; ++d) x[dim * a + d] = m->xyz[(int64_t)dim * m->conn[cell * ngeo + a] + d];
 }
+static void gather_coords(const orc_mesh *m, const cellvalues *cv, int64_t cell, double *x) { gather_coords_impl(m, cell, x, cv->dim, cv->ngeo); }
 
 /* Ferrite reinit!(cv, cell) ≡ PR883.jl:253-291: detJ·w and dNdx = dNdξ ⋅ J⁻¹ at point q */
-static int reinit_qp(const cellvalues *cv, int q, const double *x, double *dOmega, double *dNdx)
+static inline __attribute__((always_inline)) int reinit_qp_impl(const cellvalues *cv, int q, const double *x, double *dOmega, double *dNdx, const int dim, const int ngeo,
+                                                                const int nb)
 {
     double J[9], Jinv[9], det;
-    int dim = cv->dim;
-    if (orc_mapping(dim, cv->ngeo, x, cv->dM[q], J, &det, Jinv)) return -1;
+    if (mapping_impl(dim, ngeo, x, cv->dM[q], J, &det, Jinv)) return -1;
     *dOmega = det * cv->w[q];
     if (dNdx)
-        for (int a = 0; a < cv->nb; ++a)
+        for (int a = 0; a < nb; ++a)
             for (int k = 0; k < dim; ++k) {
                 double s = 0;
                 for (int mm = 0; mm < dim; ++mm) s += cv->dN[q][dim * a + mm] * Jinv[dim * mm + k];
@@ -481,6 +488,7 @@ static int reinit_qp(const cellvalues *cv, int q, const double *x, double *dOmeg
             }
     return 0;
 }
+static int reinit_qp(const cellvalues *cv, int q, const double *x, double *dOmega, double *dNdx) { return reinit_qp_impl(cv, q, x, dOmega, dNdx, cv->dim, cv->ngeo, cv->nb); }
 
 /* evaluate a (tensor-valued) diffusion coefficient at quadrature point q of `cell` */
 static void eval_tensor_coef(const orc_coef *c, const cellvalues *cv, int q, int64_t cell, double *D)
@@ -543,14 +551,14 @@ static double eval_scalar_coef(const orc_coef *c, const cellvalues *cv, int q, i
 }
 
 /* src/modeling/core/mass.jl:28-43 */
-static int element_mass_cv(const orc_mesh *m, const cellvalues *cv, int64_t cell, const orc_coef *rho, double *Me)
+static inline __attribute__((always_inline)) int element_mass_impl(const orc_mesh *m, const cellvalues *cv, int64_t cell, const orc_coef *rho, double *Me, const int nb,
+                                                                   const int dim, const int ngeo, const int nq)
 {
     double x[3 * MAXNB];
-    int nb = cv->nb;
-    gather_coords(m, cv, cell, x);
-    for (int q = 0; q < cv->nq; ++q) {
+    gather_coords_impl(m, cell, x, dim, ngeo);
+    for (int q = 0; q < nq; ++q) {
         double dO;
-        if (reinit_qp(cv, q, x, &dO, NULL)) return -1;
+        if (reinit_qp_impl(cv, q, x, &dO, NULL, dim, ngeo, nb)) return -1;
         double r = eval_scalar_coef(rho, cv, q, cell);
         for (int i = 0; i < nb; ++i) {
             double Ni = cv->N[q][i];
@@ -562,16 +570,20 @@ static int element_mass_cv(const orc_mesh *m, const cellvalues *cv, int64_t cell
     }
     return 0;
 }
+static int element_mass_cv(const orc_mesh *m, const cellvalues *cv, int64_t cell, const orc_coef *rho, double *Me)
+{
+    return element_mass_impl(m, cv, cell, rho, Me, cv->nb, cv->dim, cv->ngeo, cv->nq);
+}
 
 /* src/modeling/core/diffusion.jl:28-50; _inner_product_helper(∇Nⱼ, D, ∇Nᵢ) = (∇Nⱼ⋅D)⋅∇Nᵢ, src/utils.jl:409 */
-static int element_diffusion_cv(const orc_mesh *m, const cellvalues *cv, int64_t cell, const orc_coef *Dc, double *Ke)
+static inline __attribute__((always_inline)) int element_diffusion_impl(const orc_mesh *m, const cellvalues *cv, int64_t cell, const orc_coef *Dc, double *Ke, const int nb,
+                                                                        const int dim, const int ngeo, const int nq)
 {
     double x[3 * MAXNB], dNdx[3 * MAXNB], D[9];
-    int nb = cv->nb, dim = cv->dim;
-    gather_coords(m, cv, cell, x);
-    for (int q = 0; q < cv->nq; ++q) {
+    gather_coords_impl(m, cell, x, dim, ngeo);
+    for (int q = 0; q < nq; ++q) {
         double dO;
-        if (reinit_qp(cv, q, x, &dO, dNdx)) return -1;
+        if (reinit_qp_impl(cv, q, x, &dO, dNdx, dim, ngeo, nb)) return -1;
         eval_tensor_coef(Dc, cv, q, cell, D);
         for (int i = 0; i < nb; ++i) {
             const double *gi = dNdx + dim * i;
@@ -589,6 +601,14 @@ static int element_diffusion_cv(const orc_mesh *m, const cellvalues *cv, int64_t
     }
     return 0;
 }
+static int element_diffusion_cv(const orc_mesh *m, const cellvalues *cv, int64_t cell, const orc_coef *Dc, double *Ke)
+{
+    return element_diffusion_impl(m, cv, cell, Dc, Ke, cv->nb, cv->dim, cv->ngeo, cv->nq);
+}
+/* the same statements instantiated for the trilinear hexahedron with the 2×2×2 rule (nb = ngeo = nq = 8, dim = 3): what a Julia compiler gets from
+ * Ferrite's static sizes; used by the CPU-baseline loop (orc_assemble_matrix_planned), the parity checks keep the generic instances */
+static int element_mass_hex8(const orc_mesh *m, const cellvalues *cv, int64_t cell, const orc_coef *rho, double *Me) { return element_mass_impl(m, cv, cell, rho, Me, 8, 3, 8, 8); }
+static int element_diffusion_hex8(const orc_mesh *m, const cellvalues *cv, int64_t cell, const orc_coef *Dc, double *Ke) { return element_diffusion_impl(m, cv, cell, Dc, Ke, 8, 3, 8, 8); }
 
 static double eval_source(int kind, const double *p, const double *table, int dim, const double *x, double t,
                           int64_t cell, int q, int nq)
@@ -704,6 +724,111 @@ int orc_assemble_matrix(const orc_mesh *m, int form, const orc_coef *c, double t
             int r = form == 0 ? element_mass_cv(m, &cv, cell, c, Ke) : element_diffusion_cv(m, &cv, cell, c, Ke);
             if (!r) r = scatter_matrix(nb, m->cell_dofs + cell * nb, Ke, rowptr, colidx, nzval);
             err = err || (r != 0);
+        }
+    }
+    return err ? -1 : 0;
+}
+
+/* ---- CPU-baseline form of the per-colour loop (bench.py's cpu_baseline only; the parity checks use the canonical loop above) --------------------
+ * Same element routines, same per-colour semantics (colours in sequence, cells of one colour concurrently: PerColorAssemblyStrategy(PolyesterDevice(n)),
+ * docs/src/vroom.md:3-15 — threads = physical cores, pinned), made to scale: the scatter positions of every cell are looked up ONCE (no binary
+ * search per entry and assembly), the cells of each colour sit in one contiguous list in mesh order so that a static schedule hands every thread
+ * the same region of the mesh for every colour, and the non-zeros are zero-filled by the threads that will add to them (first touch). */
+struct orc_assembly_plan {
+    int nb, ncolors;
+    int64_t n_cells, nnz, ndofs;
+    int64_t *color_ptr;   /* ncolors + 1 */
+    int32_t *color_cells; /* cells grouped by colour, ascending inside a colour */
+    int32_t *emap;        /* n_cells × nb × nb positions in nzval (nnz < 2³¹) */
+    int64_t *rowptr;      /* copy: the zero fill partitions rows */
+};
+
+void orc_assembly_plan_destroy(orc_assembly_plan *p)
+{
+    if (!p) return;
+    free(p->color_ptr); free(p->color_cells); free(p->emap); free(p->rowptr); free(p);
+}
+
+int orc_assembly_plan_create(const orc_mesh *m, const int64_t *rowptr, const int32_t *colidx, const int32_t *color, int ncolors, int nthreads,
+                             orc_assembly_plan **out)
+{
+    cellvalues cv;
+    if (cv_setup(&cv, m->kind, m->qorder)) return -2;
+    const int nb = cv.nb;
+    orc_assembly_plan *p = (orc_assembly_plan *)calloc(1, sizeof *p);
+    if (!p) return -4;
+    p->nb = nb; p->ncolors = ncolors; p->n_cells = m->n_cells;
+    int64_t ndofs = 0;
+    for (int64_t i = 0; i < m->n_cells * nb; ++i) if (m->cell_dofs[i] + 1 > ndofs) ndofs = m->cell_dofs[i] + 1;
+    p->ndofs = ndofs; p->nnz = rowptr[ndofs];
+    if (p->nnz >= 2147483647LL) { free(p); return -5; }
+    p->color_ptr = (int64_t *)calloc(ncolors + 1, sizeof(int64_t));
+    p->color_cells = (int32_t *)malloc(sizeof(int32_t) * m->n_cells);
+    p->emap = (int32_t *)malloc(sizeof(int32_t) * m->n_cells * nb * nb);
+    p->rowptr = (int64_t *)malloc(sizeof(int64_t) * (ndofs + 1));
+    if (!p->color_ptr || !p->color_cells || !p->emap || !p->rowptr) { orc_assembly_plan_destroy(p); return -4; }
+    memcpy(p->rowptr, rowptr, sizeof(int64_t) * (ndofs + 1));
+    for (int64_t c = 0; c < m->n_cells; ++c) p->color_ptr[color[c] + 1]++;
+    for (int k = 0; k < ncolors; ++k) p->color_ptr[k + 1] += p->color_ptr[k];
+    {
+        int64_t *pos = (int64_t *)malloc(sizeof(int64_t) * ncolors);
+        for (int k = 0; k < ncolors; ++k) pos[k] = p->color_ptr[k];
+        for (int64_t c = 0; c < m->n_cells; ++c) p->color_cells[pos[color[c]]++] = (int32_t)c;
+        free(pos);
+    }
+    int err = 0;
+#ifdef _OPENMP
+    omp_set_num_threads(nthreads > 0 ? nthreads : 1);
+#endif
+#pragma omp parallel for schedule(static) reduction(|| : err)
+    for (int64_t c = 0; c < m->n_cells; ++c) { /* first touch of a cell's map by the thread range that owns its region */
+        const int32_t *dofs = m->cell_dofs + c * nb;
+        int32_t *em = p->emap + c * nb * nb;
+        for (int i = 0; i < nb; ++i) {
+            const int64_t lo0 = rowptr[dofs[i]], hi0 = rowptr[dofs[i] + 1];
+            for (int j = 0; j < nb; ++j) {
+                int64_t lo = lo0, hi = hi0;
+                const int32_t cj = dofs[j];
+                while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (colidx[mid] < cj) lo = mid + 1; else hi = mid; }
+                if (lo >= hi0 || colidx[lo] != cj) { err = 1; lo = lo0; }
+                em[nb * i + j] = (int32_t)lo;
+            }
+        }
+    }
+    if (err) { orc_assembly_plan_destroy(p); return -3; }
+    *out = p;
+    return 0;
+}
+
+int orc_assemble_matrix_planned(const orc_assembly_plan *p, const orc_mesh *m, int form, const orc_coef *c, double *nzval, int nthreads)
+{
+    cellvalues cv;
+    if (cv_setup(&cv, m->kind, m->qorder)) return -2;
+    const int nb = p->nb;
+    if (nb != cv.nb || p->n_cells != m->n_cells) return -2;
+    const int hex8 = cv.nb == 8 && cv.dim == 3 && cv.ngeo == 8 && cv.nq == 8;
+#ifdef _OPENMP
+    omp_set_num_threads(nthreads > 0 ? nthreads : 1);
+#endif
+    /* zero fill by rows, row r on the thread that owns the matching share of the cells (rows and cells of a generated mesh run in the same order) */
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < p->ndofs; ++r)
+        for (int64_t k = p->rowptr[r]; k < p->rowptr[r + 1]; ++k) nzval[k] = 0.0;
+    int err = 0;
+    for (int col = 0; col < p->ncolors; ++col) {
+        const int32_t *list = p->color_cells + p->color_ptr[col];
+        const int64_t n = p->color_ptr[col + 1] - p->color_ptr[col];
+#pragma omp parallel for schedule(static) reduction(|| : err)
+        for (int64_t k = 0; k < n; ++k) {
+            const int64_t cell = list[k];
+            double Ke[MAXNB * MAXNB];
+            memset(Ke, 0, sizeof(double) * nb * nb);
+            int r;
+            if (hex8) r = form == 0 ? element_mass_hex8(m, &cv, cell, c, Ke) : element_diffusion_hex8(m, &cv, cell, c, Ke);
+            else r = form == 0 ? element_mass_cv(m, &cv, cell, c, Ke) : element_diffusion_cv(m, &cv, cell, c, Ke);
+            err = err || (r != 0);
+            const int32_t *em = p->emap + cell * nb * nb;
+            for (int e = 0; e < nb * nb; ++e) nzval[em[e]] += Ke[e];
         }
     }
     return err ? -1 : 0;

@@ -121,6 +121,12 @@ int orc_element_source(const orc_mesh *m, int64_t cell, int src_kind, const doub
 int orc_assemble_matrix(const orc_mesh *m, int form, const orc_coef *c, double t,
                         const int64_t *rowptr, const int32_t *colidx, double *nzval,
                         int nthreads, const int32_t *color, int ncolors);
+/* CPU-baseline form of the per-colour assembly (bench.py only): precomputed scatter positions, per-colour cell lists, first-touch zero fill */
+typedef struct orc_assembly_plan orc_assembly_plan;
+int orc_assembly_plan_create(const orc_mesh *m, const int64_t *rowptr, const int32_t *colidx, const int32_t *color, int ncolors, int nthreads,
+                             orc_assembly_plan **out);
+void orc_assembly_plan_destroy(orc_assembly_plan *p);
+int orc_assemble_matrix_planned(const orc_assembly_plan *p, const orc_mesh *m, int form, const orc_coef *c, double *nzval, int nthreads);
 int orc_assemble_source(const orc_mesh *m, int src_kind, const double *p, const double *table,
                         double t, double *b, int nthreads);
 

@@ -4,6 +4,8 @@ order and FMA contraction are the only differences); reaction states 1e-12 relat
 integer work (scatter graph) is exact by construction of the comparison (same nz positions)."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 from ctypes import byref, c_double as C_double, c_int as C_int
@@ -25,7 +27,7 @@ def make_problem(tb, oracle, nel=(4, 3, 5), perturb=0.25, left=(0, 0, 0), right=
 
 def strategies(tb, device, matrix=True):
     # the reference exposes every strategy for every operator (src/Thunderbolt.jl:22-32): matrices of first-order fields accept the element
-    # strategy too (ordered per-row sums through the patch kernels)
+    # strategy too (ordered sums through the per-colour kernels)
     return [tb.AtomicAssemblyStrategy(device), tb.PerColorAssemblyStrategy(device), tb.PatchAssemblyStrategy(device), tb.ElementAssemblyStrategy(device)]
 
 
@@ -773,6 +775,101 @@ def test_reaction_full_size_tt06_sample(tb, oracle, device):
         del cache, out
 
 
+def test_config1_linear_form_64_cubed_entry_for_entry(tb, oracle, device):
+    """BASELINE config 1 at its own size: benchmarks/benchmarks-linear-form.jl:16-27 — `generate_grid(Hexahedron, (64, 64, 64))` on Ferrite's default box
+    [−1, 1]³, Q1, 2×2×2 Gauss points, f(x, t) = ‖x‖ + t at t = 0 — every entry of the 274 625-dof vector against the oracle's sequential loop
+    (analytical_coefficient.jl:80-101), all four strategies; then the same on the smoothly perturbed mesh and at another time."""
+    for perturb, t in ((0.0, 0.0), (0.2, 0.7)):
+        g = tb.generate_mesh(tb.Hexahedron, (64, 64, 64), perturb=perturb)          # default box = Ferrite's [−1, 1]³
+        assert np.allclose(g.xyz.min(axis=0), -1.0, atol=0.2 / 32) and np.allclose(g.xyz.max(axis=0), 1.0, atol=0.2 / 32)
+        dh = tb.DofHandler(g)
+        assert g.n_cells == 262144 and dh.ndofs == 274625
+        om = oracle.Mesh(oracle.HEX8, 2, g.xyz, g.conn, dh.cell_dofs)
+        ref = oracle.assemble_source(om, oracle.SRC_NORM_PLUS_T, t=t, nthreads=8)
+        for st in strategies(tb, device, matrix=False):
+            op = tb.setup_operator(st, tb.LinearIntegrator(tb.AnalyticalCoefficient("norm_plus_t")), dh)
+            got = tb.update_operator(op, t).b.to_host()
+            np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max(), err_msg=type(st).__name__)
+            assert rel_err(got, ref) < 1e-13
+
+
+def test_config2_monodomain_fhn_100_cubed_five_steps(tb, oracle, device):
+    """BASELINE config 2 at its own size: monodomain + FitzHugh–Nagumo on the 100³ hex Q1 mesh (10⁶ cells, 1 030 301 dofs), Lie–Trotter–Godunov
+    (backward-Euler heat stage with the device CG, forward-Euler cell stage), χ = Cₘ = 1, κ = diag(4.5e-5, 2e-5, 2e-5), FHN defaults, the
+    spiral-wave initial condition (ep01_spiral-wave.jl:113-118: φ = 1 on x, y ≤ ½L, s = 0.1 on y ≥ ½L), Δt = 1 — five steps.  Reference: the same
+    scheme with the oracle's M and K (sequential-loop restatement) and scipy's CG at 1e-13, the oracle's FHN step on every point; all 2 060 602
+    values compared."""
+    import scipy.sparse as sps
+    import scipy.sparse.linalg as spla
+    n = 100
+    g = tb.generate_mesh(tb.Hexahedron, (n, n, n), (0.0, 0.0, 0.0), (2.5, 2.5, 2.5), perturb=0.2)
+    dh = tb.DofHandler(g)
+    sp = tb.allocate_matrix(dh)
+    nd = dh.ndofs
+    assert g.n_cells == 10 ** 6 and nd == 101 ** 3
+    kap = np.diag([4.5e-5, 2.0e-5, 2.0e-5])
+    D = tb.ConductivityToDiffusivityCoefficient(tb.ConstantCoefficient(kap), tb.ConstantCoefficient(1.0), tb.ConstantCoefficient(1.0))
+    st = tb.PatchAssemblyStrategy(device)
+    heat = tb.BackwardEulerStage(tb.BackwardEulerSolver(rtol=1e-13, atol=1e-15), st, dh, D, None, sp)
+    model = tb.FHNModel()
+    n2d = tb.distributed.node_to_dof(dh)
+    X = np.empty((nd, 3)); X[n2d] = g.xyz
+    u0 = np.zeros((2, nd))
+    u0[0] = ((X[:, 0] <= 1.25) & (X[:, 1] <= 1.25)).astype(float)
+    u0[1] = 0.1 * (X[:, 1] >= 1.25)
+    f = tb.PointwiseODEFunction(nd, model)
+    cache = tb.setup_solver_cache(f, tb.ForwardEulerCellSolver(device), u=device.to_device(u0.ravel()))
+    ltg = tb.LieTrotterGodunov(heat, f, cache)
+    om = oracle.Mesh(oracle.HEX8, 2, g.xyz, g.conn, dh.cell_dofs)
+    col, ncol = oracle.color_cells(dh.cell_dofs, nd)
+    Mh = oracle.assemble_matrix(om, 0, oracle.Coef(oracle.COEF_CONST_SCALAR, [1.0]), sp.rowptr, sp.colidx, nthreads=8, color=col, ncolors=ncol)
+    Kh = oracle.assemble_matrix(om, 1, oracle.Coef(oracle.COEF_CONST_TENSOR, kap.ravel(), Cm=1.0, chi=1.0, wrap=True), sp.rowptr, sp.colidx, nthreads=8, color=col, ncolors=ncol)
+    csr = lambda nz: sps.csr_matrix((nz, sp.colidx, sp.rowptr), shape=(nd, nd))  # noqa: E731
+    dt, t = 1.0, 0.0
+    A, Mc = csr(oracle.heat_matrix(Mh, Kh, dt)), csr(Mh)
+    Dinv = sps.diags(1.0 / A.diagonal())
+    ref = u0.ravel().copy()
+    for step in range(5):
+        assert ltg.step(t, dt)
+        sol, info = spla.cg(A, Mc @ ref[:nd], x0=ref[:nd].copy(), rtol=1e-13, atol=0.0, maxiter=500, M=Dinv)
+        assert info == 0
+        ref[:nd] = sol
+        oracle.reaction_step(oracle.CELL_FHN, model.params, ref, nd, oracle.LAYOUT_SOA, t=t, dt=dt, nthreads=8)
+        t += dt
+    got = cache.un.to_host()
+    assert heat.last_iters > 0
+    assert rel_err(got[:nd], ref[:nd]) < 1e-9 and rel_err(got[nd:], ref[nd:]) < 1e-9
+    assert np.abs(got - ref).max() < 1e-10                       # φ, s = O(1): absolute agreement of every value
+    assert got[:nd].max() > 0.5 and got[:nd].min() < 0.1         # the front is still there: the comparison is not between two constant fields
+
+
+def test_reaction_full_size_ord_sample(tb, oracle, device):
+    """10.2 M points × 41 states of the O'Hara–Rudy 2011 model (`bench.py --ionic ord`): periodic copies stay identical, a 512-point sample matches
+    the oracle step for step (forward Euler and Rush–Larsen), everything stays finite — the size gap of the round-3 review."""
+    n = 10218313
+    model = tb.ORd2011()
+    rng = np.random.default_rng(8)
+    base = initial_points(tb, model, 512, rng)
+    host = np.ascontiguousarray(np.tile(base, (n // 512 + 1, 1))[:n].T).ravel()
+    f = tb.PointwiseODEFunction(n, model)
+    dt = 0.002
+    tail0 = 512 * (n // 512)
+    for solver, step_ref in ((tb.ForwardEulerCellSolver(device), lambda u, t: oracle.reaction_step(oracle.CELL_ORD11, model.params, u, 512, oracle.LAYOUT_SOA, t=t, dt=dt)),
+                             (tb.RushLarsenCellSolver(device), lambda u, t: oracle.reaction_step_rl(oracle.CELL_ORD11, model.params, u, 512, oracle.LAYOUT_SOA, t=t, dt=dt))):
+        cache = tb.setup_solver_cache(f, solver, u=device.to_device(host), keep_du=False)
+        for step in range(2):
+            assert tb.perform_step(f, cache, dt * step, dt) is True
+        out = cache.un.to_host().reshape(41, n)
+        np.testing.assert_array_equal(out[:, :512], out[:, 512 * 9000:512 * 9001])
+        np.testing.assert_array_equal(out[:, tail0:n], out[:, :n - tail0])          # the ragged tail of the last workgroups
+        ref = np.ascontiguousarray(base.T).ravel().copy()
+        for step in range(2):
+            step_ref(ref, dt * step)
+        assert rel_err(out[:, :512].ravel(), ref) < TOL, type(solver).__name__
+        assert np.isfinite(out).all()
+        del cache, out
+
+
 @pytest.mark.parametrize("cls,layout", [("PCG2019", 0), ("PCG2019", 1), ("TT06", 0), ("FHNModel", 1)])
 def test_reaction_float32_storage_is_one_rounding_of_the_float64_step(tb, device, cls, layout):
     """tb_reaction_step_f32 (kernels instantiated on Float32 storage, Float64 arithmetic) against the Float64 entry applied to the same Float32-rounded
@@ -924,6 +1021,33 @@ def test_mechanics_properties_80_cubed(tb, oracle, device):
     # stress-free reference configuration
     tb.residual(op, res, device.zeros(dh.ndofs), 0.0)
     assert np.abs(res.to_host()).max() < 1e-13
+
+
+def test_deferred_status_reports_at_the_poll(tb, device):
+    """tb_device_defer_status: assembly calls enqueue and return TB_OK, the sticky flags are read by tb_device_poll_status (one synchronisation for a whole
+    time loop on a fixed mesh instead of one per call); the poll reports the error, clears the block, and the immediate mode is back afterwards."""
+    g = tb.generate_mesh(tb.Hexahedron, (3, 2, 2))
+    bad = tb.Grid(tb.Hexahedron, g.xyz, g.conn[:, [0, 3, 2, 1, 4, 7, 6, 5]])
+    ok_dh, bad_dh = tb.DofHandler(g), tb.DofHandler(bad)
+    st = tb.PatchAssemblyStrategy(device)
+    good = tb.setup_operator(st, tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.0)), ok_dh, tb.allocate_matrix(ok_dh))
+    badop = tb.setup_operator(st, tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.0)), bad_dh, tb.allocate_matrix(bad_dh))
+    ref = tb.update_operator(good, 0.0).A.to_host().copy()
+    device.defer_status(True)
+    try:
+        tb.update_operator(good, 0.0)
+        device.poll_status()                                         # nothing raised
+        tb.update_operator(badop, 0.0)                               # returns: the flag stays on the device …
+        tb.update_operator(good, 0.0)                                # … through later calls
+        with pytest.raises(tb.TBError) as e:
+            device.poll_status()
+        assert e.value.code == tb._lib.TB_ERR_NEG_DETJ
+        device.poll_status()                                         # cleared by the poll that reported it
+    finally:
+        device.defer_status(False)
+    with pytest.raises(tb.TBError):
+        tb.update_operator(badop, 0.0)                               # immediate mode again
+    assert rel_err(tb.update_operator(good, 0.0).A.to_host(), ref) < 1e-14
 
 
 def test_hyperelastic_negative_jacobian_and_bad_field(tb, device):
@@ -2358,6 +2482,61 @@ def test_spmv_and_cg_on_ragged_superset_patterns(tb, device, long_row):
     u = device.zeros(n)
     its, res = tb.cg_solve(M.pattern, M.A, b, u, rtol=1e-12, atol=0.0, maxiter=400)
     assert its < 400 and np.abs(u.to_host() - xh).max() < 1e-8
+
+
+def test_index_compressed_spmv_is_bit_identical_to_the_csr_kernel(tb, device):
+    """tb_spmv_csr on a finite-element pattern takes the index-compressed kernel (rows that hold the same column offsets share one signature: 4 B per
+    row instead of 4 B per non-zero).  Same lane mapping and summation order as the CSR row kernel, so the products must agree
+    bit for bit — plain, (α, β) and the fused xᵀAx form — on a pattern with the boundary signatures of the first-visit numbering, a few extra long rows
+    (> 27 entries: the tail loop) and their mirrored single entries.  scipy fixes the values."""
+    import scipy.sparse as ssp
+    g = tb.generate_mesh(tb.Hexahedron, (30, 28, 26), perturb=0.2)
+    dh = tb.DofHandler(g)
+    base = tb.allocate_matrix(dh)
+    n = dh.ndofs
+    rng = np.random.default_rng(5)
+    P = ssp.csr_matrix((np.ones(base.nnz), base.colidx, base.rowptr), shape=(n, n))
+    extra = ssp.lil_matrix((n, n))
+    for r in rng.integers(0, n, 3):
+        extra[r, rng.choice(n, 90, replace=False)] = 1.0
+    S = (P + extra.tocsr() + extra.tocsr().T).tocsr()
+    S.sort_indices()
+    sp = tb.SparsityPattern(S.indptr.astype(np.int64), S.indices.astype(np.int32))
+    dm = tb.DeviceMesh(device, dh)
+    old = os.environ.pop("TB_SPMV_KERNEL", None)
+    try:
+        pat_sig = tb.DevicePattern(dm, sp)
+        os.environ["TB_SPMV_KERNEL"] = "rows"
+        pat_csr = tb.DevicePattern(dm, sp)
+        vals = rng.normal(size=sp.nnz)
+        A = device.to_device(vals)
+        xh = rng.normal(size=n)
+        x = device.to_device(xh)
+        y0 = rng.normal(size=n)
+        out = {}
+        for name, pat in (("sig", pat_sig), ("csr", pat_csr)):
+            y = device.zeros(n)
+            tb.check(tb.lib().tb_spmv_csr(pat.h, A.ptr, x.ptr, 1.0, 0.0, y.ptr))        # the first product of a pattern builds its plan (env read here)
+            y2 = device.to_device(y0)
+            tb.check(tb.lib().tb_spmv_csr(pat.h, A.ptr, x.ptr, -0.5, 2.0, y2.ptr))
+            y3, d = device.zeros(n), device.zeros(1)
+            tb.check(tb.lib().tb_spmv_csr_dot(pat.h, A.ptr, x.ptr, y3.ptr, d.ptr))
+            out[name] = (y.to_host(), y2.to_host(), y3.to_host(), d.to_host()[0])
+    finally:
+        if old is None:
+            os.environ.pop("TB_SPMV_KERNEL", None)
+        else:
+            os.environ["TB_SPMV_KERNEL"] = old
+    stats = np.zeros(2, dtype=np.int64)
+    tb.check(tb.lib().tb_pattern_spmv_plan(pat_sig.h, stats.ctypes.data_as(tb._lib.c_i64p)))
+    assert stats[0] > 0 and stats[1] * 4 <= sp.nnz + 128, stats                            # compressed: signatures, table entries ≤ nnz / 4
+    tb.check(tb.lib().tb_pattern_spmv_plan(pat_csr.h, stats.ctypes.data_as(tb._lib.c_i64p)))
+    assert stats[0] == -1
+    for a, b in zip(out["sig"][:3], out["csr"][:3]):
+        np.testing.assert_array_equal(a, b)
+    ref = ssp.csr_matrix((vals, sp.colidx, sp.rowptr), shape=(n, n)) @ xh
+    assert rel_err(out["sig"][0], ref) < TOL and rel_err(out["sig"][1], -0.5 * ref + 2.0 * y0) < TOL
+    assert abs(out["sig"][3] - xh @ ref) <= 1e-11 * abs(xh @ ref) and abs(out["sig"][3] - out["csr"][3]) <= 1e-12 * abs(out["csr"][3])
 
 
 @pytest.mark.parametrize("order", [1, 2])

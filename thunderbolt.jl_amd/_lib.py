@@ -60,6 +60,8 @@ SIGNATURES = {
     "tb_device_set_stream": (C.c_int, [vp, vp]),
     "tb_device_use_null_stream": (C.c_int, [vp]),
     "tb_device_synchronize": (C.c_int, [vp]),
+    "tb_device_defer_status": (C.c_int, [vp, C.c_int]),
+    "tb_device_poll_status": (C.c_int, [vp]),
     "tb_device_info": (C.c_int, [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
     "tb_malloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
     "tb_free": (C.c_int, [vp, vp]),
@@ -152,6 +154,7 @@ SIGNATURES = {
     "tb_cg_solve_f32": (C.c_int, [vp, vp, vp, vp, C.c_double, C.c_double, C.c_int, C.c_int, vp, vp]),
     "tb_extract_diagonal": (C.c_int, [vp, vp, vp]),
     "tb_pattern_patch_stats": (C.c_int, [vp, vp]),
+    "tb_pattern_spmv_plan": (C.c_int, [vp, vp]),
     "tb_scatter_add_indexed": (C.c_int, [vp, C.c_int64, vp, vp, vp]),
     "tb_scatter_indexed": (C.c_int, [vp, C.c_int64, vp, vp, vp]),
     "tb_spmv_csr_rows": (C.c_int, [vp, vp, vp, C.c_int64, vp, vp]),

@@ -65,6 +65,14 @@ class MI355XDevice:
     def synchronize(self):
         check(lib().tb_device_synchronize(self.h))
 
+    def defer_status(self, on=True):
+        """tb_device_defer_status: assembly calls stop reading the status block (no stream synchronisation per call); `poll_status` reads it."""
+        check(lib().tb_device_defer_status(self.h, 1 if on else 0))
+
+    def poll_status(self):
+        """tb_device_poll_status: synchronise, raise the first assembly error (detJ ≤ 0, coupling missing from the pattern) since the last poll, clear."""
+        check(lib().tb_device_poll_status(self.h))
+
     def info(self):
         name = C.create_string_buffer(64)
         ncu, mem = C.c_int(), C.c_size_t()

@@ -5,6 +5,8 @@
 //   max |x[i·stride]|                 RTC controller input, src/solver/time/rtc.jl:64-73
 #include <hip/hip_runtime.h>
 
+#include <unordered_map>
+
 #include <cmath>
 #include <cstring>
 
@@ -264,6 +266,96 @@ k_spmv_stream_rows(int n_blk, const uint4 *__restrict__ blkrec, const int64_t *_
     if constexpr (DOT) block_sum_to(acc, xy);
 }
 
+// Index-compressed form of the row-per-lane run (default when the pattern compresses).  On a finite-element numbering almost every row holds the same
+// column offsets relative to its own index — the 27-point stencil of a hexahedral mesh: one signature covers 97 % of the rows at 216³, the boundary
+// layers of the first-visit numbering add ≈ 10⁵ more — so the 4 B column index per non-zero is redundant: a row carries the position of its
+// signature in a table (4 B per row; the table is a few MB and stays in L2), the kernel streams 8 B per non-zero instead of 12 and parks values
+// only in LDS.  Lane mapping, order of the products and of the partial sums are those of k_spmv_stream_rows: the two kernels give identical bits.
+// Same interface (tb_spmv_csr: the plan is built with the pattern's first product); patterns that do not compress keep the CSR kernel.
+template <int CAP, bool DOT>
+__global__ void __launch_bounds__(256)
+k_spmv_sig_rows(int n_blk, const uint4 *__restrict__ blkrec, const int64_t *__restrict__ rowptr, const uint32_t *__restrict__ rowsig, const int32_t *__restrict__ sigoff,
+                const double *__restrict__ nz, const double *__restrict__ x, double alpha, double beta, double *__restrict__ y, double *__restrict__ xy)
+{
+    __shared__ double s_v[CAP];
+    constexpr int U = CAP / 256, SUB = 3, RW = 21, RP = 4 * RW, NK = 9; // 21 rows per wave (lane 63 idle): no row triple straddles two waves
+    const int tid = threadIdx.x, lane = tid & 63, rl = RW * (tid >> 6) + lane / SUB, sub = lane % SUB;
+    const bool lane_ok = lane < SUB * RW;
+    double acc = 0.0;
+    // column offsets of the wave's current signature, lane (row, sub) holding entries sub, sub + 3, …: re-read from the table only when a pass meets
+    // another signature (97 % of the rows of a hexahedral mesh carry the interior stencil, so almost never)
+    int of[NK];
+    uint32_t cur = 0xFFFFFFFFu;
+#pragma unroll
+    for (int t_ = 0; t_ < NK; ++t_) of[t_] = 0;
+    int b = blockIdx.x;
+    uint4 rec = blkrec[b < n_blk ? b : 0];
+    for (; b < n_blk; b += gridDim.x) {
+        const int bn = b + gridDim.x;
+        const uint4 recn = blkrec[bn < n_blk ? bn : b];
+        const int r0 = (int)rec.x, nr = (int)(rec.y & 0xffffu), len = (int)(rec.y >> 16);
+        const int64_t k0 = (int64_t)(((uint64_t)rec.w << 32) | rec.z);
+        const int rc0 = rl < nr ? rl : nr - 1;
+        const int64_t pa0 = rowptr[r0 + rc0], pe0 = rowptr[r0 + rc0 + 1];
+        const uint32_t sg0 = rowsig[r0 + rc0];
+        const double *nzb = nz + k0;
+        double vj[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = tid + u * 256, ic = i < len ? i : len - 1;
+            vj[u] = len > 0 ? nzb[ic] : 0.0; // wave-uniform condition
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = tid + u * 256;
+            if (i < len) s_v[i] = vj[u];
+        }
+        __syncthreads();
+        for (int p0 = 0; p0 < nr; p0 += RP) {
+            const int r = rl + p0;
+            const bool active = lane_ok && r < nr && len > 0;
+            int64_t pa = pa0, pe = pe0;
+            uint32_t sg = sg0;
+            const int rc = r < nr ? r : nr - 1;
+            if (p0 > 0) { pa = rowptr[r0 + rc]; pe = rowptr[r0 + rc + 1]; sg = rowsig[r0 + rc]; } // runs of short rows
+            const int a = (int)(pa - k0), n = (int)(pe - pa), row = r0 + rc;
+            {
+                const uint32_t sg1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sg);
+                const bool uniform = __ballot(sg != sg1) == 0ull; // every lane carries a valid row's signature (rc is clamped)
+                if (!uniform || sg1 != cur) {
+#pragma unroll
+                    for (int t_ = 0; t_ < NK; ++t_) { const int k = sub + SUB * t_; of[t_] = sigoff[sg + (k < n ? k : 0)]; }
+                    cur = uniform ? sg1 : 0xFFFFFFFFu;
+                }
+            }
+            int kc[NK], cc[NK];
+            double vv[NK], xx[NK];
+#pragma unroll
+            for (int t_ = 0; t_ < NK; ++t_) {
+                const int k = sub + SUB * t_;
+                kc[t_] = active && k < n ? k : -1;
+                const int kk = kc[t_] >= 0 ? kc[t_] : 0;
+                cc[t_] = row + (kc[t_] >= 0 ? of[t_] : 0); // masked entries read x[row]
+                vv[t_] = s_v[a + kk];
+            }
+#pragma unroll
+            for (int t_ = 0; t_ < NK; ++t_) xx[t_] = len > 0 ? x[cc[t_]] : 0.0;
+            double v = 0.0;
+#pragma unroll
+            for (int t_ = 0; t_ < NK; ++t_) v += kc[t_] >= 0 ? vv[t_] * xx[t_] : 0.0;
+            if (active) for (int k = sub + SUB * NK; k < n; k += SUB) v += s_v[a + k] * x[row + sigoff[sg + k]]; // rows longer than 27 entries
+            v += __shfl_down(v, 1, 64) + __shfl_down(v, 2, 64);
+            if (active && sub == 0) {
+                if constexpr (DOT) { y[r0 + r] = v; acc += x[r0 + r] * v; }
+                else y[r0 + r] = beta == 0.0 ? alpha * v : alpha * v + beta * y[r0 + r];
+            }
+        }
+        __syncthreads();
+        rec = recn;
+    }
+    if constexpr (DOT) block_sum_to(acc, xy);
+}
+
 __global__ void __launch_bounds__(256)
 k_absmax(int64_t n, const double *__restrict__ x, int64_t stride_x, unsigned long long *__restrict__ out)
 {
@@ -436,6 +528,66 @@ static int stream_plan(tb_pattern *p)
     return TB_OK;
 }
 
+// Signature plan of the index-compressed SpMV: rows with the same list of column offsets (colidx[k] − row) share one table entry.  Built on the
+// host with the pattern's first product: per row a 64-bit hash (parallel), de-duplication in row order with the neighbouring row as the fast path
+// (consecutive rows of a finite-element numbering nearly always repeat the signature).  The pattern "compresses" when the table is at most a
+// quarter of the column array and every offset list fits the kernel (row length ≤ SPMV_CAP is checked by the stream plan); otherwise n_sig = −1.
+static int sig_plan(tb_pattern *p)
+{
+    if (p->n_sig != 0) return TB_OK;
+    const bool off = getenv("TB_SPMV_KERNEL") && strcmp(getenv("TB_SPMV_KERNEL"), "sig") != 0; // "rows" / "rec" / "chain": the CSR kernels (read per pattern: A/B runs and the bit-identity test build one pattern of each kind in one process)
+    const int64_t n = p->n_rows;
+    if (off || n == 0 || p->nnz >= (int64_t)0xffffffffll) { p->n_sig = -1; return TB_OK; }
+    const int64_t *rp = p->h_rowptr.data();
+    const int32_t *ci = p->h_colidx.data();
+    std::vector<uint64_t> hsh((size_t)n);
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < n; ++r) {
+        uint64_t h = 0x9e3779b97f4a7c15ull ^ (uint64_t)(rp[r + 1] - rp[r]);
+        for (int64_t k = rp[r]; k < rp[r + 1]; ++k) {
+            h ^= (uint64_t)(uint32_t)(ci[k] - (int32_t)r) + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+            h *= 0xff51afd7ed558ccdull; h ^= h >> 33;
+        }
+        hsh[r] = h;
+    }
+    std::vector<uint32_t> rowsig((size_t)n);
+    std::vector<int32_t> tab;
+    std::unordered_map<uint64_t, std::vector<uint32_t>> seen; // hash → positions of the signatures with that hash
+    const int64_t budget = std::max<int64_t>(p->nnz / 4, 64);
+    auto same = [&](uint32_t at, int64_t r) {
+        const int64_t len = rp[r + 1] - rp[r];
+        if ((int64_t)at + len > (int64_t)tab.size()) return false;
+        for (int64_t k = 0; k < len; ++k) if (tab[at + k] != ci[rp[r] + k] - (int32_t)r) return false;
+        return true;
+    };
+    std::vector<int32_t> siglen; // length of the signature starting at a table position is implied by the row: equal hash + equal length + equal offsets
+    std::unordered_map<uint32_t, int32_t> len_at;
+    int64_t nsig = 0;
+    for (int64_t r = 0; r < n; ++r) {
+        const int64_t len = rp[r + 1] - rp[r];
+        if (r > 0 && hsh[r] == hsh[r - 1] && rp[r] - rp[r - 1] == len && same(rowsig[r - 1], r)) { rowsig[r] = rowsig[r - 1]; continue; }
+        auto &cand = seen[hsh[r]];
+        bool found = false;
+        for (uint32_t at : cand) if (len_at[at] == (int32_t)len && same(at, r)) { rowsig[r] = at; found = true; break; }
+        if (found) continue;
+        const uint32_t at = (uint32_t)tab.size();
+        for (int64_t k = 0; k < len; ++k) tab.push_back(ci[rp[r] + k] - (int32_t)r);
+        if (len == 0) tab.push_back(0); // an empty row still owns a (never read) position
+        cand.push_back(at); len_at[at] = (int32_t)len; rowsig[r] = at; ++nsig;
+        if ((int64_t)tab.size() > budget) { p->n_sig = -1; return TB_OK; } // an unstructured numbering: every row its own signature
+    }
+    tab.resize(tab.size() + 32, 0); // the kernel reads offset 0 of a row's signature for its masked entries, and whole triples: slack at the end
+    TB_HIP(hipMalloc((void **)&p->d_rowsig, rowsig.size() * sizeof(uint32_t)));
+    TB_HIP(hipMemcpy(p->d_rowsig, rowsig.data(), rowsig.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    TB_HIP(hipMalloc((void **)&p->d_sigoff, tab.size() * sizeof(int32_t)));
+    TB_HIP(hipMemcpy(p->d_sigoff, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    p->n_sig = nsig; p->sig_entries = (int64_t)tab.size();
+    if (getenv("TB_PLAN_VERBOSE"))
+        fprintf(stderr, "[tbhip] SpMV signature plan: %lld rows, %lld signatures, table %lld entries (%.4f of the column array)\n", (long long)n, (long long)nsig,
+                (long long)tab.size(), (double)tab.size() / (double)std::max<int64_t>(p->nnz, 1));
+    return TB_OK;
+}
+
 // TB_SPMV_KERNEL=chain: the five-trip kernel, kept as the comparison build
 static bool spmv_chain_kernel()
 {
@@ -450,8 +602,11 @@ static void launch_stream(tb_pattern *p, const double *nz, const double *x, doub
     static bool once = false;
     if (!once) { once = true; const int v = getenv("TB_SPMV_NOGATHER") ? 1 : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_spmv_nogather), &v, sizeof(int)); }
 #endif
-    static const bool rows_kernel = !(getenv("TB_SPMV_KERNEL") && strcmp(getenv("TB_SPMV_KERNEL"), "rows") != 0); // default; "rec" / "chain": entry-per-lane kernels
-    if (rows_kernel) // 24 KB of LDS per workgroup: six resident per CU
+    static const bool rows_kernel = !(getenv("TB_SPMV_KERNEL") && strcmp(getenv("TB_SPMV_KERNEL"), "rows") != 0 && strcmp(getenv("TB_SPMV_KERNEL"), "sig") != 0); // "rec" / "chain": entry-per-lane kernels
+    if (rows_kernel && sig_plan(p) == TB_OK && p->n_sig > 0) // default where the pattern compresses: 16 KB of LDS per workgroup
+        hipLaunchKernelGGL((k_spmv_sig_rows<SPMV_CAP, DOT>), dim3(grid > 1536 ? 1536 : grid), dim3(256), 0, st, (int)p->n_blk, (const uint4 *)p->d_blkrec, p->d_rowptr,
+                           p->d_rowsig, p->d_sigoff, nz, x, alpha, beta, y, xy);
+    else if (rows_kernel) // 24 KB of LDS per workgroup: six resident per CU
         hipLaunchKernelGGL((k_spmv_stream_rows<SPMV_CAP, DOT>), dim3(grid > 1536 ? 1536 : grid), dim3(256), 0, st, (int)p->n_blk, (const uint4 *)p->d_blkrec, p->d_rowptr,
                            p->d_colidx, nz, x, alpha, beta, y, xy);
     else if (spmv_chain_kernel())
@@ -465,6 +620,15 @@ static unsigned stream_grid(const tb_pattern *p)
 {
     static const int64_t cap = getenv("TB_SPMV_GRID") ? atoi(getenv("TB_SPMV_GRID")) : 2048; // 256 CUs × 8 resident workgroups
     return (unsigned)std::min<int64_t>(p->n_blk, cap);
+}
+
+int spmv_plans(tb_pattern *p)
+{
+    int rc = block3_plan(p);
+    if (rc || p->b3 > 0) return rc;
+    rc = stream_plan(p);
+    if (rc || p->n_blk <= 0) { if (p->n_sig == 0) p->n_sig = -1; return rc; }
+    return sig_plan(p);
 }
 
 int launch_spmv(tb_pattern *p, const double *nz, const double *x, double alpha, double beta, double *y)

@@ -23,11 +23,19 @@ void set_error(const char *fmt, ...)
 
 int reset_status(tb_device *dev)
 {
+    if (dev->defer_status) return TB_OK; // flags stay raised (they are only ever set) until tb_device_poll_status reads and clears them
     TB_HIP(hipMemsetAsync(dev->d_status, 0, sizeof(Status), dev->stream));
     return TB_OK;
 }
 
+static int read_status(tb_device *dev);
 int check_status(tb_device *dev)
+{
+    if (dev->defer_status) return TB_OK;
+    return read_status(dev);
+}
+
+static int read_status(tb_device *dev)
 {
     TB_HIP(hipMemcpyAsync(dev->h_status, dev->d_status, sizeof(Status), hipMemcpyDeviceToHost, dev->stream));
     TB_HIP(hipStreamSynchronize(dev->stream));
@@ -41,6 +49,8 @@ int check_status(tb_device *dev)
     }
     return TB_OK;
 }
+
+int read_status_public(tb_device *dev) { return read_status(dev); }
 
 template <class T>
 static void copy_rebased(std::vector<T> &dst, const T *src, size_t n, int base)
@@ -117,6 +127,24 @@ int tb_device_use_null_stream(tb_device *dev)
     dev->stream = nullptr; // the legacy default stream: ordered with every blocking stream of the process (a host framework's default stream is this one)
     dev->own_stream = false;
     return TB_OK;
+}
+
+int tb_device_defer_status(tb_device *dev, int on)
+{
+    TB_REQUIRE(dev, "tb_device_defer_status: NULL device");
+    TB_HIP(hipSetDevice(dev->id));
+    if (on && !dev->defer_status) TB_HIP(hipMemsetAsync(dev->d_status, 0, sizeof(Status), dev->stream)); // start from a clean block
+    dev->defer_status = on != 0;
+    return TB_OK;
+}
+
+int tb_device_poll_status(tb_device *dev)
+{
+    TB_REQUIRE(dev, "tb_device_poll_status: NULL device");
+    TB_HIP(hipSetDevice(dev->id));
+    const int rc = tb::read_status_public(dev);
+    TB_HIP(hipMemsetAsync(dev->d_status, 0, sizeof(Status), dev->stream));
+    return rc;
 }
 
 int tb_device_synchronize(tb_device *dev)
@@ -311,7 +339,7 @@ int tb_pattern_create(tb_mesh *mesh, int64_t n_rows, const int64_t *rowptr, cons
 int tb_pattern_destroy(tb_pattern *p)
 {
     if (!p) return TB_OK;
-    hipFree(p->d_rowptr); hipFree(p->d_colidx); hipFree(p->d_blkrow); hipFree(p->d_blkrec); hipFree(p->d_bcol); hipFree(p->d_diagpos); hipFree(p->d_emap); hipFree(p->d_blockpos); hipFree(p->d_cg_ws); hipFree(p->d_gmres_ws); hipFree(p->d_pcg_ws); hipFree(p->d_cheb_ws); hipFree(p->d_q2pos); hipFree(p->d_kebuf); hipFree(p->d_gnodes);
+    hipFree(p->d_rowptr); hipFree(p->d_colidx); hipFree(p->d_blkrow); hipFree(p->d_blkrec); hipFree(p->d_rowsig); hipFree(p->d_sigoff); hipFree(p->d_bcol); hipFree(p->d_diagpos); hipFree(p->d_emap); hipFree(p->d_blockpos); hipFree(p->d_cg_ws); hipFree(p->d_gmres_ws); hipFree(p->d_pcg_ws); hipFree(p->d_cheb_ws); hipFree(p->d_q2pos); hipFree(p->d_kebuf); hipFree(p->d_gnodes);
     free_patch_mat_plan(p);
     free_patch_fused_plan(p);
     delete p;
@@ -1076,6 +1104,16 @@ int tb_extract_diagonal(tb_pattern *pat, const double *d_nzval, double *d_diag)
     TB_REQUIRE(pat && ((d_nzval && d_diag) || pat->n_rows == 0), "tb_extract_diagonal: NULL argument");
     TB_HIP(hipSetDevice(pat->mesh->dev->id));
     return launch_extract_diagonal(pat, d_nzval, d_diag);
+}
+
+int tb_pattern_spmv_plan(tb_pattern *pat, int64_t *out2)
+{
+    TB_REQUIRE(pat && out2, "tb_pattern_spmv_plan: NULL argument");
+    TB_HIP(hipSetDevice(pat->mesh->dev->id));
+    int rc = spmv_plans(pat);
+    if (rc) return rc;
+    out2[0] = pat->n_sig; out2[1] = pat->sig_entries;
+    return TB_OK;
 }
 
 int tb_pattern_patch_stats(tb_pattern *pat, int64_t *out6)

@@ -113,6 +113,11 @@ struct PatchFusedPlan {
     // staged kernels: packed patch headers (limits of the packed word: < 1024 rows, < 2048 nodes, < 2048 instances per patch) and pre-gathered vertex coordinates
     uint32_t *d_hdr = nullptr;     // 4 per patch: e0, r0, n0, nrows | nnodes << 10 | ne << 21 (NULL when some count does not fit)
     double *d_pcoord = nullptr;    // 3 per patch node
+    // one-trip kernel (k_patch_hex8_record): every input of a patch in ONE record at blockIdx × stride, so no load waits for a header —
+    //   [0,16) counts word {nrows | nnodes << 10 | ne << 21, 0, 0, 0} · rec_ne × 16 B local node indices · rec_ne × 4 B signature ids ·
+    //   rec_rm × 16 B row descriptors · rec_nm × 24 B vertex coordinates; zero padding behind the patch's own counts.  Built on first use.
+    uint8_t *d_rec = nullptr;
+    int rec_stride = 0, rec_rm = 0, rec_nm = 0, rec_ne = 0; // rec_ne: instance slots per record (≥ 256, multiple of 64); rec_stride = −1: the patches do not fit the record form (a patch with more than 256 instances)
     // Symmetric-storage extension (tb_patch_sym.hip).  Both matrices are symmetric, so a coupling {n, m} of two rows the patch owns is accumulated
     // once — in the row with the smaller patch-local slot — and mirrored when the rows are written out: a row's accumulator run holds its diagonal,
     // the columns the patch does not own and the owned columns of larger slot (≈ 14 of 27 entries on a hexahedral mesh, padded to an odd
@@ -152,6 +157,7 @@ struct tb_device {
     std::string name;
     tb::Status *d_status = nullptr;
     tb::Status *h_status = nullptr; // pinned
+    bool defer_status = false;      // tb_device_defer_status: assembly calls return without reading the status block; tb_device_poll_status reads it
     void *d_scratch = nullptr;      // Float64 arena behind the *_f32 entry points (tb_f32.hip), grown on demand
     size_t scratch_bytes = 0;
 };
@@ -196,6 +202,12 @@ struct tb_pattern {
     int32_t *d_blkrow = nullptr;    // stream SpMV: first row of each workgroup's run of rows (n_blk + 1 entries)
     uint32_t *d_blkrec = nullptr;   // the same runs as 16-byte records {first row, rows | entries << 16, first nz low, high} (k_spmv_stream_rec)
     int64_t n_blk = 0;              // 0 = not planned yet, −1 = a row exceeds the capacity (lanes-per-row kernel)
+    // index-compressed stream SpMV: rows that hold the same column offsets (colidx[k] − row) share one signature; a row then needs 4 B (the
+    // position of its signature in the table) instead of 4 B per non-zero
+    uint32_t *d_rowsig = nullptr;   // per row: first entry of its signature in d_sigoff
+    int32_t *d_sigoff = nullptr;    // signatures back to back: column offsets relative to the row
+    int64_t n_sig = 0;              // 0 = not planned yet, −1 = the pattern does not compress (CSR kernel), > 0 = signatures in the table
+    int64_t sig_entries = 0;
     uint16_t *d_q2pos = nullptr;    // scalar Q2 forms: position of col dof(j) in row dof(i), per cell and pair
     double *d_pcg_ws = nullptr;     // general-preconditioner PCG workspace (r, z, p, Ap, D̃, scalars)
     double *d_cheb_ws = nullptr;    // Chebyshev-preconditioned CG workspace (r, z, p, Ap, D⁻¹, d, w, scalars)
@@ -264,6 +276,7 @@ int build_ea_plan(tb_mesh *m);
 int ensure_ea_ell(tb_mesh *m);
 int build_patch_plan(tb_mesh *m, int cells_per_patch);
 int build_patch_mat_plan(tb_pattern *p);
+int ensure_patch_records(tb_pattern *p); // one-trip records of the fused plan (after ensure_patch_fused); TB_ERR_UNSUPPORTED when the patches do not fit the form
 int ensure_patch_plans(tb_mesh *m, tb_pattern *p); // builds / refits both so the LDS block allows two workgroups per CU
 void free_patch_plan(tb_mesh *m);
 void free_patch_mat_plan(tb_pattern *p);
@@ -328,6 +341,8 @@ int launch_max(tb_device *dev, int64_t n, const double *x, int64_t stride, doubl
 int ensure_cell_xyz(tb_mesh *m); // tb_assembly.hip: builds tb_mesh::d_cell_xyz on first use
 int launch_gather_indexed(tb_device *dev, int64_t n, const double *vec, const int32_t *idx, double *out);
 int launch_scatter_add_indexed(tb_device *dev, int64_t n, const double *in, const int32_t *idx, double *vec);
+int read_status_public(tb_device *dev); // status block → host, synchronises the stream (what check_status does when the status is not deferred)
+int spmv_plans(tb_pattern *p); // builds the plans tb_spmv_csr would build on its first product
 int launch_scatter_indexed(tb_device *dev, int64_t n, const double *in, const int32_t *idx, double *vec);
 int launch_spmv_rows(tb_pattern *p, const double *nz, const double *x, int64_t n, const int32_t *rows, double *out);
 int launch_extract_diagonal(tb_pattern *p, const double *nz, double *diag);

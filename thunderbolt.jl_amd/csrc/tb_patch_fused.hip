@@ -354,6 +354,133 @@ k_patch_hex8_staged(FormArgs faK, FormArgs faM, FusedView pv, const uint4 *__res
 #ifdef TB_ABLATION
     if (pv.prof) { __builtin_amdgcn_s_waitcnt(0); TB_ST(6); }
 #endif
+#undef TB_ST
+}
+
+// One-trip form (default for constant coefficients): every input of the patch sits in one fixed-stride record (PatchFusedPlan::d_rec), so all
+// of its loads — counts word, node indices, signature ids, row descriptors, coordinates — are addressed from blockIdx alone and issued at once:
+// ONE trip to memory in front of the integration instead of header → inputs (phase stamps of the staged kernel at 216³: 3.4 of a workgroup's
+// 14.2 µs before its first barrier).  The first lines of the record `pf` patches ahead — the one this CU's next workgroup will most likely get —
+// are touched by one dword load per lane, so that workgroup's trip ends in the cache hierarchy instead of behind the store traffic in HBM.
+// Write-out: a half-wave reads ALL its row descriptors, then ALL its accumulators, then stores (one dependent LDS round instead of five).
+template <bool WK, bool WM, bool DIAG, int RPH>
+__global__ void __launch_bounds__(256, 2)
+k_patch_hex8_record(FormArgs faK, FormArgs faM, const uint8_t *__restrict__ rec, int stride, int nem, int rm, int nm, int kcap, const uint8_t *__restrict__ sigtab, int pf,
+                    double *__restrict__ nzK, double *__restrict__ nzM, Status *st
+#ifdef TB_ABLATION
+                    , long long *prof
+#endif
+)
+{
+    extern __shared__ double lds[];
+    constexpr int T = 256;
+    const int tid = threadIdx.x;
+#ifdef TB_ABLATION
+#define TB_ST(k) do { if (prof && tid == 0 && (blockIdx.x & 1023) == 7) prof[(blockIdx.x >> 10) * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define TB_ST(k) do { } while (0)
+#endif
+    TB_ST(0);
+    const uint8_t *r = rec + (size_t)blockIdx.x * (size_t)stride;
+    const uint32_t hw = ((const uint4 *)r)->x; // wave-uniform address: a scalar load, consumed only behind the vector loads below
+    uint32_t pfv = 0;
+    if (pf > 0 && blockIdx.x + (unsigned)pf < gridDim.x && tid * 128 < stride) pfv = *(const uint32_t *)(r + (size_t)pf * (size_t)stride + (size_t)tid * 128);
+    uint4 lnv = ((const uint4 *)(r + 16))[tid];
+    const uint32_t sig = ((const uint32_t *)(r + 16 + (size_t)nem * 16))[tid];
+    const uint8_t *rdp = r + 16 + (size_t)nem * 20;
+    const double *pc = (const double *)(rdp + (size_t)rm * 16);
+    constexpr int NX = 5;
+    uint4 rd = make_uint4(0, 0, 0, 0);
+    double xc[NX];
+    if (tid < rm) rd = ((const uint4 *)rdp)[tid];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) xc[j] = tid + j * T < 3 * nm ? pc[tid + j * T] : 0.0;
+    double *accK = lds;
+    double *accM = lds + (WK && WM ? kcap : 0);
+    RowDesc *desc = (RowDesc *)(lds + (WK && WM ? 2 : 1) * kcap);
+    double *xs = (double *)(desc + rm);
+    {   // zero both accumulator blocks while the loads travel
+        double2 *z = (double2 *)lds;
+        const int n2 = ((WK && WM ? 2 : 1) * kcap) >> 1;
+        for (int k = tid; k < n2; k += T) z[k] = make_double2(0.0, 0.0);
+    }
+    if (tid < rm) ((uint4 *)desc)[tid] = rd;
+#pragma unroll
+    for (int j = 0; j < NX; ++j) if (tid + j * T < 3 * nm) xs[tid + j * T] = xc[j];
+    for (int k = tid + NX * T; k < 3 * nm; k += T) xs[k] = pc[k]; // more than 426 nodes per patch
+    uint4 cp[4];
+    {
+        const uint4 *cpp = (const uint4 *)(sigtab + (size_t)sig * 64); // padding lanes carry signature 0: a valid read
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cp[k] = cpp[k];
+    }
+    const int nrows = (int)(hw & 0x3ff), ne = (int)(hw >> 21);
+    TB_ST(1);
+    __syncthreads();
+    TB_ST(2);
+    for (int ei = tid; ei < ne; ei += T) { // one pass for all but the domain-boundary patches (they own the extra boundary layers: up to ≈ 280 instances)
+        if (ei >= T) {
+            lnv = ((const uint4 *)(r + 16))[ei];
+            const uint4 *cpp = (const uint4 *)(sigtab + (size_t)((const uint32_t *)(r + 16 + (size_t)nem * 16))[ei] * 64);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cp[k] = cpp[k];
+        }
+        const uint32_t ln[8] = {lnv.x & 0xffffu, lnv.x >> 16, lnv.y & 0xffffu, lnv.y >> 16, lnv.z & 0xffffu, lnv.z >> 16, lnv.w & 0xffffu, lnv.w >> 16};
+        double x[8][3];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            const double *px = xs + 3 * ln[a];
+            x[a][0] = px[0]; x[a][1] = px[1]; x[a][2] = px[2];
+        }
+        uint32_t ro[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ro[i] = ln[i] < (uint32_t)nrows ? desc[ln[i]].off : 0xFFFFFFFFu;
+        hex8_instance<WK, WM, false, false, DIAG>(x, [&](uint4(&c4)[4], uint32_t(&r8)[8]) { for (int k = 0; k < 4; ++k) c4[k] = cp[k]; for (int k = 0; k < 8; ++k) r8[k] = ro[k]; }, 0, faK, faM, accK, accM, st,
+                                                  (const int32_t *)nullptr, 0);
+    }
+    TB_ST(3);
+    __syncthreads();
+    TB_ST(4);
+    // write-out: one row per half-wave; all descriptors, then all accumulators, then all stores of the half-wave's rows
+    const int half = tid >> 5, hl = tid & 31;
+    uint4 d[RPH]; // {nz0 lo, nz0 hi, off, len}
+#pragma unroll
+    for (int u = 0; u < RPH; ++u) { const int s = half + u * (T / 32); d[u] = ((const uint4 *)desc)[s < nrows ? s : 0]; if (s >= nrows) d[u].w = 0; }
+    double vK[RPH], vM[RPH];
+#pragma unroll
+    for (int u = 0; u < RPH; ++u) {
+        const uint32_t a_ = d[u].z + (hl < d[u].w ? hl : 0);
+        if constexpr (WK) vK[u] = accK[a_];
+        if constexpr (WM) vM[u] = accM[a_];
+    }
+#pragma unroll
+    for (int u = 0; u < RPH; ++u)
+        if (hl < d[u].w) {
+            const int64_t g0 = (int64_t)(((uint64_t)d[u].y << 32) | d[u].x) + hl;
+            if constexpr (WK) nzK[g0] = vK[u];
+            if constexpr (WM) nzM[g0] = vM[u];
+        }
+    for (int s = half + RPH * (T / 32); s < nrows; s += T / 32) { // patches with more rows than RPH per half-wave
+        const uint4 dd = ((const uint4 *)desc)[s];
+        const int64_t g0 = (int64_t)(((uint64_t)dd.y << 32) | dd.x);
+        for (uint32_t k = hl; k < dd.w; k += 32) {
+            if constexpr (WK) nzK[g0 + k] = accK[dd.z + k];
+            if constexpr (WM) nzM[g0 + k] = accM[dd.z + k];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < RPH; ++u)
+        for (uint32_t k = hl + 32; k < d[u].w; k += 32) { // rows longer than 32 entries (not on hexahedral meshes)
+            const int64_t g0 = (int64_t)(((uint64_t)d[u].y << 32) | d[u].x) + k;
+            if constexpr (WK) nzK[g0] = accK[d[u].z + k];
+            if constexpr (WM) nzM[g0] = accM[d[u].z + k];
+        }
+    TB_ST(5);
+    if (pfv == 0x9e3779b9u && tid == 999) st->cell = -2; // never true: keeps the look-ahead load alive without a wait before this point
+#ifdef TB_ABLATION
+    if (prof) { __builtin_amdgcn_s_waitcnt(0); TB_ST(6); }
+#endif
+#undef TB_ST
 }
 
 bool hex8_patch_applicable(const tb_form *f, const tb_pattern *p)
@@ -430,6 +557,35 @@ int launch_assemble_hex8_patch(tb_form *fK, tb_form *fM, tb_pattern *p, double t
     const bool fk = fK && fK->field, fm = fM && fM->field;
     static const bool general = getenv("TB_PATCH_KERNEL") && !strcmp(getenv("TB_PATCH_KERNEL"), "general"); // measured alternative
     const bool staged = pf->d_hdr && !general;
+    const bool diag = fK && !fk && aK.D[1] == 0.0 && aK.D[2] == 0.0 && aK.D[5] == 0.0 && aK.D[3] == 0.0 && aK.D[6] == 0.0 && aK.D[7] == 0.0;
+    // one-trip record kernel: constant coefficients, patches of ≤ 256 instances (TB_PATCH_KERNEL=staged keeps the two-trip kernel for A/B runs)
+    static const bool no_record = getenv("TB_PATCH_KERNEL") && strcmp(getenv("TB_PATCH_KERNEL"), "record") != 0;
+    static const int pf_ahead = getenv("TB_PATCH_PREFETCH") ? atoi(getenv("TB_PATCH_PREFETCH")) : 512; // look-ahead distance in patches (0 = off); 512 = the resident workgroups
+    if (staged && !no_record && !fk && !fm && ensure_patch_records(p) == TB_OK) {
+        PatchFusedPlan *pr = p->patch_fused.get();
+        const size_t ldsr = (size_t)nreg * pv.kcap * sizeof(double) + (size_t)pr->rec_rm * sizeof(RowDesc) + (size_t)pr->rec_nm * 3 * sizeof(double);
+        if (ldsr <= 80 * 1024) {
+            constexpr int RPH = 20; // rows per half-wave kept in registers at write-out (160 rows per patch; more take the loop)
+            auto launch_rec = [&](auto k) -> int {
+                TB_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr));
+#ifdef TB_ABLATION
+                hipLaunchKernelGGL(k, dim3((unsigned)pp->n_patches), dim3(256), ldsr, dev->stream, aK, aM, (const uint8_t *)pr->d_rec, pr->rec_stride, pr->rec_ne, pr->rec_rm, pr->rec_nm, pv.kcap,
+                                   (const uint8_t *)pf->d_sigtab, pf_ahead, d_nzK, d_nzM, dev->d_status, d_prof);
+#else
+                hipLaunchKernelGGL(k, dim3((unsigned)pp->n_patches), dim3(256), ldsr, dev->stream, aK, aM, (const uint8_t *)pr->d_rec, pr->rec_stride, pr->rec_ne, pr->rec_rm, pr->rec_nm, pv.kcap,
+                                   (const uint8_t *)pf->d_sigtab, pf_ahead, d_nzK, d_nzM, dev->d_status);
+#endif
+                return TB_OK;
+            };
+            if (fK && fM) rc = diag ? launch_rec(k_patch_hex8_record<true, true, true, RPH>) : launch_rec(k_patch_hex8_record<true, true, false, RPH>);
+            else if (fK) rc = diag ? launch_rec(k_patch_hex8_record<true, false, true, RPH>) : launch_rec(k_patch_hex8_record<true, false, false, RPH>);
+            else rc = launch_rec(k_patch_hex8_record<false, true, false, RPH>);
+            if (rc) return rc;
+            TB_HIP(hipGetLastError());
+            goto done;
+        }
+    }
+    {
     const MeshView mv = make_view(m);
     auto launch = [&](auto ks, auto kg) -> int {
         if (staged) {
@@ -444,7 +600,6 @@ int launch_assemble_hex8_patch(tb_form *fK, tb_form *fM, tb_pattern *p, double t
 #define TB_PL(a, b, c, d) rc = launch(k_patch_hex8_staged<a, b, c, d>, k_patch_hex8<a, b, c, d>)
 #define TB_PLD(a, b, c, d) rc = launch(k_patch_hex8_staged<a, b, c, d, true>, k_patch_hex8<a, b, c, d>)
     // constant diagonal tensors (isotropic / axis-aligned conductivities) take the variant with the cheaper A·D product
-    const bool diag = fK && !fk && aK.D[1] == 0.0 && aK.D[2] == 0.0 && aK.D[5] == 0.0 && aK.D[3] == 0.0 && aK.D[6] == 0.0 && aK.D[7] == 0.0;
     if (fK && fM) { if (fk && fm) TB_PL(true, true, true, true); else if (fk) TB_PL(true, true, true, false); else if (fm) { if (diag) TB_PLD(true, true, false, true); else TB_PL(true, true, false, true); } else { if (diag) TB_PLD(true, true, false, false); else TB_PL(true, true, false, false); } }
     else if (fK) { if (fk) TB_PL(true, false, true, false); else if (diag) TB_PLD(true, false, false, false); else TB_PL(true, false, false, false); }
     else { if (fm) TB_PL(false, true, false, true); else TB_PL(false, true, false, false); }
@@ -452,6 +607,8 @@ int launch_assemble_hex8_patch(tb_form *fK, tb_form *fM, tb_pattern *p, double t
 #undef TB_PLD
     if (rc) return rc;
     TB_HIP(hipGetLastError());
+    }
+done:
 #ifdef TB_ABLATION
     if (d_prof && staged) { // average phase durations (µs; wall clock 100 MHz)
         std::vector<long long> h((size_t)nprof * 8);

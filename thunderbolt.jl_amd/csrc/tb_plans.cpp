@@ -447,7 +447,7 @@ void free_patch_fused_plan(tb_pattern *p)
     if (!p->patch_fused) return;
     PatchFusedPlan *f = p->patch_fused.get();
     hipFree(f->d_node_ptr); hipFree(f->d_pnode); hipFree(f->d_elem_ln); hipFree(f->d_elem_sig); hipFree(f->d_sigtab); hipFree(f->d_row_desc); hipFree(f->d_hdr); hipFree(f->d_pcoord);
-    hipFree(f->d_elem_ssig); hipFree(f->d_ssigtab); hipFree(f->d_row_sdesc); hipFree(f->d_mirtab);
+    hipFree(f->d_elem_ssig); hipFree(f->d_ssigtab); hipFree(f->d_row_sdesc); hipFree(f->d_mirtab); hipFree(f->d_rec);
     p->patch_fused.reset();
 }
 
@@ -787,6 +787,53 @@ static int build_patch_fused_plan_impl(tb_pattern *p, int64_t *lds_need, int nre
         if ((rc = upload(m->dev, hdr, &plan->d_hdr))) return rc;
         if ((rc = upload(m->dev, pcoord, &plan->d_pcoord))) return rc;
     }
+    return TB_OK;
+}
+
+// One-trip records (PatchFusedPlan::d_rec): the arrays of the staged kernel copied patch by patch into fixed-stride records, read back from the device
+// copies the plan already holds (the host vectors of the builder are gone by now; this runs once per pattern).
+int ensure_patch_records(tb_pattern *p)
+{
+    PatchFusedPlan *f = p->patch_fused.get();
+    const PatchPlan *pp = p->mesh->patches.get();
+    if (!f || !pp || !f->d_hdr) return TB_ERR_UNSUPPORTED;
+    if (f->d_rec) return TB_OK;
+    if (f->rec_stride < 0 || pp->max_elems > 1024 || pp->max_rows > 256 || f->sym) { f->rec_stride = -1; return TB_ERR_UNSUPPORTED; }
+    const int64_t np = pp->n_patches;
+    const int rm = (pp->max_rows + 3) & ~3, nm = (f->max_nodes + 3) & ~3, nem = std::max(256, (pp->max_elems + 63) & ~63);
+    const size_t o_ln = 16, o_sig = o_ln + (size_t)nem * 16, o_desc = o_sig + (size_t)nem * 4, o_xyz = o_desc + (size_t)rm * 16, raw = o_xyz + (size_t)nm * 24;
+    const size_t stride = (raw + 127) & ~(size_t)127;
+    if (stride * (size_t)np > ((size_t)8 << 30)) { f->rec_stride = -1; return TB_ERR_UNSUPPORTED; } // > 8 GiB of records: keep the compact arrays
+    std::vector<uint32_t> hdr((size_t)np * 4);
+    std::vector<uint16_t> ln((size_t)pp->total_elems * 8);
+    std::vector<uint32_t> sig((size_t)pp->total_elems);
+    std::vector<RowDesc> desc((size_t)pp->total_rows);
+    TB_HIP(hipMemcpy(hdr.data(), f->d_hdr, hdr.size() * 4, hipMemcpyDeviceToHost));
+    TB_HIP(hipMemcpy(ln.data(), f->d_elem_ln, ln.size() * 2, hipMemcpyDeviceToHost));
+    TB_HIP(hipMemcpy(sig.data(), f->d_elem_sig, sig.size() * 4, hipMemcpyDeviceToHost));
+    TB_HIP(hipMemcpy(desc.data(), f->d_row_desc, desc.size() * sizeof(RowDesc), hipMemcpyDeviceToHost));
+    int64_t total_nodes = 0;
+    for (int64_t q = 0; q < np; ++q) total_nodes = std::max<int64_t>(total_nodes, (int64_t)hdr[4 * q + 2] + ((hdr[4 * q + 3] >> 10) & 0x7ff));
+    std::vector<double> xyz((size_t)total_nodes * 3);
+    TB_HIP(hipMemcpy(xyz.data(), f->d_pcoord, xyz.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<uint8_t> rec(stride * (size_t)np, 0);
+#pragma omp parallel for schedule(static)
+    for (int64_t q = 0; q < np; ++q) {
+        uint8_t *r = &rec[stride * (size_t)q];
+        const uint32_t e0 = hdr[4 * q], r0 = hdr[4 * q + 1], n0 = hdr[4 * q + 2], w = hdr[4 * q + 3];
+        const uint32_t nr = w & 0x3ff, nn = (w >> 10) & 0x7ff, ne = w >> 21;
+        const uint32_t h4[4] = {w, 0, 0, 0};
+        memcpy(r, h4, 16);
+        memcpy(r + o_ln, &ln[(size_t)e0 * 8], (size_t)ne * 16);
+        memcpy(r + o_sig, &sig[e0], (size_t)ne * 4);
+        memcpy(r + o_desc, &desc[r0], (size_t)nr * 16);
+        memcpy(r + o_xyz, &xyz[(size_t)n0 * 3], (size_t)nn * 24);
+    }
+    TB_HIP(hipMalloc((void **)&f->d_rec, rec.size()));
+    TB_HIP(hipMemcpy(f->d_rec, rec.data(), rec.size(), hipMemcpyHostToDevice));
+    f->rec_stride = (int)stride; f->rec_rm = rm; f->rec_nm = nm; f->rec_ne = nem;
+    if (getenv("TB_PLAN_VERBOSE"))
+        fprintf(stderr, "[tbhip] one-trip patch records: %lld patches x %zu B (rows <= %d, nodes <= %d), %.2f GB\n", (long long)np, stride, rm, nm, (double)rec.size() / 1e9);
     return TB_OK;
 }
 
