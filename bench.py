@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--n", type=int, default=216, help="cells per edge of the box (216 → 10M hexahedra)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong = the same n³ mesh cut into N z-slabs (BASELINE's configuration); weak = one n³ slab per rank")
+    ap.add_argument("--layers", type=int, default=0, help="N = 1 diagnostics: run on the n×n×LAYERS slab only (the share of one of n/LAYERS GPUs), e.g. under rocprofv3")
     ap.add_argument("--no-slab-sweep", action="store_true", help="N = 1: skip the timing of the n×n×{n/2, n/4, n/8} slabs (strong-scaling prediction)")
     ap.add_argument("--strategy", default="patch", choices=["patch", "atomic", "color"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -230,6 +231,8 @@ def main():
         sys.stderr.write("bench.py: --gpus %d exceeds the %d cell layers of the mesh\n" % (world, n))
         return 2
     nz_total = n if strong else n * world
+    if args.layers > 0 and world == 1:
+        nz_total = args.layers
     part = tb.distributed.SlabPartition((n, n, nz_total), (0.0, 0.0, 0.0), (1.0, 1.0, nz_total / n), world, rank)
     kap = np.diag([4.5e-5, 2.0e-5, 2.0e-5])  # docs/src/literate-tutorials/ep01_spiral-wave.jl:39-41 style conductivities
     rdt = {"pcg2019": 0.01, "tt06": 0.001, "fhn": 0.1, "ord": 0.002}[args.ionic]   # forward-Euler-stable reaction step sizes
@@ -399,7 +402,7 @@ def main():
 
     # N = 1: the slabs a strong-scaling run on N GPUs hands each rank, timed one after the other on this GPU (same kernels, same plans, no exchange)
     slab_sweep = None
-    if world == 1 and not args.no_slab_sweep and n % 8 == 0:
+    if world == 1 and not args.no_slab_sweep and n % 8 == 0 and args.layers == 0:
         slab_sweep = {"layers": {}, "note": "step = M + K + b + %s reaction, cg = one Jacobi-CG iteration on A = M - dt K, each on an %dx%dxL slab of the mesh (the share of one of "
                                            "N = %d/L GPUs under --scaling strong); predicted_speedup = t(%d layers) / t(L layers): what the kernels alone allow, without the halo "
                                            "exchange and the two all-reduces of an iteration" % (args.ionic.upper(), n, n, n, n)}

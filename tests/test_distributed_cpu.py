@@ -345,3 +345,122 @@ def test_distributed_mechanics_residual_and_tangent_action(world):
     for rank, gnodes, rr, kk in res:
         np.testing.assert_allclose(rr, rref[gnodes], rtol=1e-11, atol=1e-12 * np.abs(rref).max())
         np.testing.assert_allclose(kk, Kvref[gnodes], rtol=1e-11, atol=1e-12 * np.abs(Kvref).max())
+
+
+# ----------------------------------------------------------------------------------------------- BASELINE config 5 under a partition
+def _lv_problem(tb):
+    """idealised left ventricle (all-hexahedral, O-grid apex), rule-based fibres, a smooth calcium-like activation field of position"""
+    g = tb.generate_ideal_lv_mesh_hex(16, 2, 8)
+    f, s, n = tb.ideal_lv_microstructure(g, np.deg2rad(60.0), np.deg2rad(-60.0))
+    return g, np.stack([f, s, n], axis=2)                      # fsn[cell][basis][f|s|n][3]
+
+
+def _lv_fields(x):
+    phi = -80.0 + 100.0 * np.exp(-2.0 * ((x[:, 0] - 0.2) ** 2 + x[:, 1] ** 2 + (x[:, 2] + 0.8) ** 2))
+    act = 0.5 + 0.4 * np.sin(2.0 * x[:, 0]) * np.cos(1.5 * x[:, 2])
+    disp = 5e-3 * np.stack([np.sin(2 * x[:, 1]) * x[:, 2], np.cos(x[:, 0]) * x[:, 1], x[:, 0] * x[:, 1] - 0.5 * x[:, 2]], axis=1)
+    return phi, act, disp
+
+
+def _lv_local(o, xyz, conn, fsn, lam, tmax):
+    """the two halves of a coupled step on one (sub-)mesh with the oracle: fibre-aligned K·φ and M·φ, a TT06 Rush–Larsen step of the points, the
+    active-stress residual and tangent action; returns per-NODE arrays"""
+    phi, act, disp = _lv_fields(xyz)
+    cd, nd = o.close_dofs(o.HEX8, 1, conn, len(xyz))
+    rp, ci = o.build_pattern(cd, nd)
+    om = o.Mesh(o.HEX8, 2, xyz, conn, cd)
+    n2d = np.full(len(xyz), -1, dtype=np.int64)
+    n2d[conn.ravel()] = cd.ravel()
+    K = o.assemble_matrix(om, 1, o.Coef(o.COEF_SPECTRAL_FIELD, lam, field=np.ascontiguousarray(fsn), Cm=1.0, chi=1.0, wrap=True), rp, ci)
+    M = o.assemble_matrix(om, 0, o.Coef(o.COEF_CONST_SCALAR, [1.0]), rp, ci)
+    x = np.empty(nd); x[n2d] = phi
+    Kx, Mx = o.spmv_csr(rp, ci, K, x), o.spmv_csr(rp, ci, M, x)
+    # reaction: the points of this (sub-)mesh, SoA
+    p = o.cell_default_params(o.CELL_TT06)
+    u = np.tile(o.cell_default_state(o.CELL_TT06, p), (nd, 1)).T.copy()
+    u[0] = x
+    u = np.ascontiguousarray(u).ravel()
+    o.reaction_step_rl(o.CELL_TT06, p, u, nd, o.LAYOUT_SOA, t=0.0, dt=0.02)
+    un = u.reshape(-1, nd)[:, n2d]                                     # states per node
+    # mechanics: three dofs per node, activation per cell and node
+    cdv, ndv = o.close_dofs(o.HEX8, 3, conn, len(xyz))
+    rpv, civ = o.build_pattern(cdv, ndv)
+    omv = o.Mesh(o.HEX8, 2, xyz, conn, cdv)
+    n2d0 = np.full(len(xyz), -1, dtype=np.int64)
+    n2d0[conn.ravel()] = cdv[:, 0::3].ravel()
+    uv, vv = np.empty(ndv), np.empty(ndv)
+    vf = np.stack([np.cos(3 * xyz[:, 0]), xyz[:, 1] ** 2, np.sin(xyz[:, 2] + xyz[:, 0])], axis=1)
+    for c in range(3):
+        uv[n2d0 + c] = disp[:, c]; vv[n2d0 + c] = vf[:, c]
+    o.set_microstructure_field(np.ascontiguousarray(fsn))
+    o.set_active_tension(tmax, np.ascontiguousarray(act[conn]))
+    try:
+        Kt, r = o.assemble_hyperelastic(omv, uv, rpv, civ)
+    finally:
+        o.set_active_tension(0.0); o.set_microstructure_field(None)
+    Kv = o.spmv_csr(rpv, civ, Kt, vv)
+    return dict(n2d=n2d, n2d0=n2d0, Kx=Kx, Mx=Mx, un=un, r=r, Kv=Kv)
+
+
+def _lv_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import thunderbolt_jl_amd as tb
+    from oracle import oracle as o
+    D = tb.distributed
+    g, fsn = _lv_problem(tb)
+    part = D.partition_cells_rcb(g.xyz[g.conn].mean(axis=1), world)
+    gp = D.GeneralPartition(g.conn, part, rank)
+    lx = g.xyz[gp.global_nodes]
+    L = _lv_local(o, lx, gp.conn, fsn[gp.cells], np.array([0.3, 0.12, 0.12]) * 1e-2, 20.0)
+    nb = [(peer, torch.from_numpy(L["n2d"][idx])) for peer, idx in gp.neighbours]
+    nb3 = [(peer, torch.from_numpy((L["n2d0"][idx][:, None] + np.arange(3)).ravel())) for peer, idx in gp.neighbours]
+    Kx, Mx = torch.from_numpy(L["Kx"].copy()), torch.from_numpy(L["Mx"].copy())
+    D.exchange_sum(Kx, nb, dist); D.exchange_sum(Mx, nb, dist)
+    r, Kv = torch.from_numpy(L["r"].copy()), torch.from_numpy(L["Kv"].copy())
+    D.exchange_sum(r, nb3, dist); D.exchange_sum(Kv, nb3, dist)
+    n2d, n2d0 = L["n2d"], L["n2d0"]
+    q.put((rank, gp.global_nodes, Kx.numpy()[n2d], Mx.numpy()[n2d], L["un"], np.stack([r.numpy()[n2d0 + c] for c in range(3)], axis=1),
+           np.stack([Kv.numpy()[n2d0 + c] for c in range(3)], axis=1), len(gp.cells)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_config5_lv_coupled_step_under_a_partition():
+    """BASELINE config 5 (coupled electromechanics on the ventricle mesh, 8 GPUs) has no reference counterpart; its multi-GPU form is defined as
+    "P-rank result == 1-rank result" (SURVEY §8e).  Two ranks, recursive-coordinate-bisection parts of the idealised LV: every rank assembles the
+    fibre-aligned monodomain operators and the active-stress mechanics residual / tangent of its own cells only (the oracle stands in for the device
+    kernels, as in the tests above), steps the TT06 states of its own points with no communication, and the interface sums (scalar dofs; the three
+    displacement dofs of every shared node) make K·φ, M·φ, the residual and the tangent action equal to the single-domain ones."""
+    from oracle import oracle as o
+    import thunderbolt_jl_amd as tb
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_lv_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g, fsn = _lv_problem(tb)
+    R = _lv_local(o, g.xyz, g.conn, fsn, np.array([0.3, 0.12, 0.12]) * 1e-2, 20.0)
+    n2d, n2d0 = R["n2d"], R["n2d0"]
+    Kx, Mx = R["Kx"][n2d], R["Mx"][n2d]
+    rr = np.stack([R["r"][n2d0 + c] for c in range(3)], axis=1)
+    kv = np.stack([R["Kv"][n2d0 + c] for c in range(3)], axis=1)
+    held = np.zeros(g.n_nodes, dtype=int)
+    ncells = 0
+    for rank, gnodes, kx, mx, un, r3, kv3, nc in res:
+        np.testing.assert_allclose(kx, Kx[gnodes], rtol=1e-11, atol=1e-12 * np.abs(Kx).max())
+        np.testing.assert_allclose(mx, Mx[gnodes], rtol=1e-11, atol=1e-12 * np.abs(Mx).max())
+        np.testing.assert_array_equal(un, R["un"][:, gnodes])                       # the reaction step is pointwise: identical bits on every rank that holds the point
+        np.testing.assert_allclose(r3, rr[gnodes], rtol=1e-10, atol=1e-11 * np.abs(rr).max())
+        np.testing.assert_allclose(kv3, kv[gnodes], rtol=1e-10, atol=1e-11 * np.abs(kv).max())
+        held[gnodes] += 1
+        ncells += nc
+    assert ncells == g.n_cells and held.min() == 1 and held.max() == 2

@@ -5,6 +5,7 @@ integer work (scatter graph) is exact by construction of the comparison (same nz
 import ctypes as C
 
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -12,6 +13,7 @@ from ctypes import byref, c_double as C_double, c_int as C_int
 
 from helpers import hex_to_tets, rel_err
 
+ROOT_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-12
@@ -695,10 +697,12 @@ def test_fused_mass_diffusion_pair_parity(tb, oracle, device):
                 assert rel_err(K.A.to_host(), refK) < TOL, (mname, kname, rep)
 
 
-def test_symmetric_accumulator_patch_kernel_parity(tb, oracle, device, monkeypatch):
-    """TB_PATCH_KERNEL=sym (tb_patch_sym.hip: one LDS add per coupling, mirrored write-out, sequential K / M passes on one accumulator block or,
-    TB_SYM_MODE=onepass, one pass over two blocks) == the oracle, on a box of several 7×7×7 tiles with ragged boundary tiles and on an unstructured
-    hexahedral mesh; then back to the default kernel on the same operators (the plan is rebuilt for its tiles)."""
+def _patch_variant_child():
+    """run in a child process (the kernel switch is read once per process): M, K — as a pair and alone — with the patch kernel selected by
+    TB_PATCH_KERNEL against the oracle, on a box with ragged boundary tiles and on an unstructured hexahedral mesh"""
+    import thunderbolt_jl_amd as tb
+    from oracle import oracle
+    device = tb.MI355XDevice(0)
     meshes = [make_problem(tb, oracle, nel=(17, 15, 9), perturb=0.25)]
     gl = tb.generate_ideal_lv_mesh_hex(8, 2, 6)
     dhl = tb.DofHandler(gl)
@@ -708,24 +712,31 @@ def test_symmetric_accumulator_patch_kernel_parity(tb, oracle, device, monkeypat
         rho_field = rng.uniform(0.5, 2.0, size=(g.n_cells, 8))
         cases = {n_: (tc, oc) for n_, tc, oc in coef_cases(tb, oracle, g, rng)}
         st = tb.PatchAssemblyStrategy(device)
-        for mode in ("seq", "onepass", None):
-            if mode is None:
-                monkeypatch.delenv("TB_PATCH_KERNEL", raising=False)
-            else:
-                monkeypatch.setenv("TB_PATCH_KERNEL", "sym")
-                monkeypatch.setenv("TB_SYM_MODE", mode)
-            for mt, mo in ((tb.ConstantCoefficient(1.7), oracle.Coef(oracle.COEF_CONST_SCALAR, [1.7])),
-                           (tb.FieldCoefficient(rho_field), oracle.Coef(oracle.COEF_FIELD_SCALAR, field=rho_field))):
-                refM = oracle.assemble_matrix(om, 0, mo, sp.rowptr, sp.colidx)
-                for kname in ("diag", "full", "fibre_field"):
-                    kt, ko = cases[kname]
-                    refK = oracle.assemble_matrix(om, 1, ko, sp.rowptr, sp.colidx)
-                    M = tb.setup_operator(st, tb.BilinearMassIntegrator(mt), dh, sp)
-                    K = tb.setup_operator(st, tb.BilinearDiffusionIntegrator(kt), dh, sp)
-                    tb.update_operators(M, K, 0.0)
-                    assert rel_err(M.A.to_host(), refM) < TOL and rel_err(K.A.to_host(), refK) < TOL, (mode, kname, "pair")
-                    assert rel_err(tb.update_operator(K, 0.0).A.to_host(), refK) < TOL, (mode, kname, "K alone")
-                    assert rel_err(tb.update_operator(M, 0.0).A.to_host(), refM) < TOL, (mode, kname, "M alone")
+        for mt, mo in ((tb.ConstantCoefficient(1.7), oracle.Coef(oracle.COEF_CONST_SCALAR, [1.7])),
+                       (tb.FieldCoefficient(rho_field), oracle.Coef(oracle.COEF_FIELD_SCALAR, field=rho_field))):
+            refM = oracle.assemble_matrix(om, 0, mo, sp.rowptr, sp.colidx)
+            for kname in ("diag", "full", "fibre_field"):
+                kt, ko = cases[kname]
+                refK = oracle.assemble_matrix(om, 1, ko, sp.rowptr, sp.colidx)
+                M = tb.setup_operator(st, tb.BilinearMassIntegrator(mt), dh, sp)
+                K = tb.setup_operator(st, tb.BilinearDiffusionIntegrator(kt), dh, sp)
+                tb.update_operators(M, K, 0.0)
+                assert rel_err(M.A.to_host(), refM) < TOL and rel_err(K.A.to_host(), refK) < TOL, (kname, "pair")
+                assert rel_err(tb.update_operator(K, 0.0).A.to_host(), refK) < TOL, (kname, "K alone")
+                assert rel_err(tb.update_operator(M, 0.0).A.to_host(), refM) < TOL, (kname, "M alone")
+    print("PATCH_VARIANT_OK")
+
+
+@pytest.mark.parametrize("kernel,cut", [("record", "balanced"), ("staged", "balanced"), ("general", "balanced"), ("record", "full")])
+def test_patch_kernel_variants_parity(kernel, cut):
+    """Every patch kernel that ships behind a switch — the one-trip record kernel (default for constant coefficients), the two-trip staged kernel (field
+    coefficients, A/B runs), the unstaged general form — and both tile cuts give the oracle's matrices.  The switches are read once per process, so each
+    variant runs in a child (the symmetric-accumulator variant of round 3, measured slower, is gone: DESIGN §8)."""
+    import subprocess
+    env = dict(os.environ, TB_PATCH_KERNEL=kernel, TB_PATCH_CUT=cut)
+    code = "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_parity as t; t._patch_variant_child()" % (ROOT_DIR, os.path.join(ROOT_DIR, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "PATCH_VARIANT_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
 def test_reaction_full_size_roundtrip(tb, oracle, device):
@@ -1021,6 +1032,118 @@ def test_mechanics_properties_80_cubed(tb, oracle, device):
     # stress-free reference configuration
     tb.residual(op, res, device.zeros(dh.ndofs), 0.0)
     assert np.abs(res.to_host()).max() < 1e-13
+
+
+def test_config5_lv_coupled_step(tb, oracle, device):
+    """BASELINE config 5 on one GPU at a size that means something (no reference counterpart, SURVEY F6: the two halves are checked as two kernels on one
+    mesh): the idealised left ventricle with 111 616 hexahedra — an unstructured mesh for the planners (O-grid apex, ring topology) — and one coupled step:
+    fibre-aligned monodomain operators M, K (nodal fibre field of the rule-based microstructure, PATCH strategy), a TT06 Rush–Larsen reaction step on every
+    dof, a backward-Euler heat solve by the device CG, then the active-stress Holzapfel–Ogden linearisation with the calcium of the EP state as the
+    activation.  Oracle: sampled rows of M, K and of the mechanics tangent / residual from the element matrices of the cells around them, a sample of
+    points of the reaction step, and the residual of the heat solve formed with the sampled oracle rows."""
+    g = tb.generate_ideal_lv_mesh_hex(128, 8, 100)
+    assert g.n_cells == 111616
+    f, s_, n_ = tb.ideal_lv_microstructure(g, np.deg2rad(60.0), np.deg2rad(-60.0))
+    fsn = np.stack([f, s_, n_], axis=2)                                          # [cell][basis][f|s|n][3]
+    rng = np.random.default_rng(21)
+    # ---------------- electrophysiology half
+    dhs = tb.DofHandler(g)
+    sps = tb.allocate_matrix(dhs)
+    nd = dhs.ndofs
+    lam = np.array([0.3, 0.12, 0.12]) * 1e-2
+    D = tb.ConductivityToDiffusivityCoefficient(tb.SpectralTensorCoefficient(tb.OrthotropicMicrostructureModel(f, s_, n_), tb.ConstantCoefficient(lam)),
+                                                tb.ConstantCoefficient(1.0), tb.ConstantCoefficient(1.0))
+    st = tb.PatchAssemblyStrategy(device)
+    M = tb.setup_operator(st, tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.0)), dhs, sps)
+    K = tb.setup_operator(st, tb.BilinearDiffusionIntegrator(D), dhs, sps)
+    tb.update_operators(M, K, 0.0)
+    Mh, Kh = M.A.to_host(), K.A.to_host()
+    rows = np.concatenate([rng.choice(nd, 60, replace=False), [0, nd - 1]])
+    cells = np.nonzero(np.isin(dhs.cell_dofs, rows).any(axis=1))[0]
+    sub_dofs, inv = np.unique(dhs.cell_dofs[cells], return_inverse=True)
+    cd = inv.reshape(len(cells), -1).astype(np.int32)
+    rp, ci = oracle.build_pattern(cd, len(sub_dofs))
+    om = oracle.Mesh(oracle.HEX8, 2, g.xyz, np.ascontiguousarray(g.conn[cells]), cd)
+    Ms = oracle.assemble_matrix(om, 0, oracle.Coef(oracle.COEF_CONST_SCALAR, [1.0]), rp, ci)
+    Ks = oracle.assemble_matrix(om, 1, oracle.Coef(oracle.COEF_SPECTRAL_FIELD, lam, field=np.ascontiguousarray(fsn[cells]), Cm=1.0, chi=1.0, wrap=True), rp, ci)
+    for d in rows:
+        l = int(np.searchsorted(sub_dofs, d))
+        k0, k1 = int(sps.rowptr[d]), int(sps.rowptr[d + 1])
+        np.testing.assert_array_equal(sps.colidx[k0:k1], sub_dofs[ci[rp[l]:rp[l + 1]]])
+        assert np.abs(Mh[k0:k1] - Ms[rp[l]:rp[l + 1]]).max() < 1e-12 * np.abs(Ms).max(), d
+        assert np.abs(Kh[k0:k1] - Ks[rp[l]:rp[l + 1]]).max() < 1e-12 * np.abs(Ks).max(), d
+    # reaction: TT06 Rush–Larsen on every dof, a sample of points against the oracle
+    model = tb.TT06()
+    n2d = tb.distributed.node_to_dof(dhs)
+    X = np.empty((nd, 3)); X[n2d] = g.xyz
+    u0 = np.tile(model.default_initial_state(), (nd, 1)).T.copy()
+    apex = g.xyz[g.getnodeset("Apex")[0]]
+    u0[model.phi_index, np.linalg.norm(X - apex, axis=1) < 0.45] = 20.0
+    ica = model.state_symbols.index("Ca_i")
+    u0[ica] *= 1.0 + 4.0 * rng.uniform(0.0, 1.0, nd)                              # a calcium field with structure, so that the activation below is not uniform
+    fode = tb.PointwiseODEFunction(nd, model)
+    cache = tb.setup_solver_cache(fode, tb.RushLarsenCellSolver(device), u=device.to_device(np.ascontiguousarray(u0).ravel()), keep_du=False)
+    dt = 0.05
+    assert tb.perform_step(fode, cache, 0.0, dt) is True
+    un = cache.un.to_host().reshape(model.nstates, nd)
+    pts = rng.choice(nd, 1024, replace=False)
+    ref = np.ascontiguousarray(u0[:, pts]).ravel().copy()
+    oracle.reaction_step_rl(oracle.CELL_TT06, model.params, ref, 1024, oracle.LAYOUT_SOA, t=0.0, dt=dt)
+    assert rel_err(un[:, pts].ravel(), ref) < TOL and np.isfinite(un).all()
+    # heat step (M − Δt K) φ⁺ = M φ by the device CG; checked on the sampled rows with the ORACLE's rows of M and K
+    A = tb.heat_system_matrix(device, M, K, dt)
+    phi_old = un[model.phi_index].copy()
+    b = device.zeros(nd)
+    M.mul(b, device.to_device(phi_old))
+    x = device.to_device(phi_old)
+    its, _ = tb.cg_solve(K.pattern, A, b, x, rtol=1e-12, atol=1e-14, maxiter=500)
+    assert 0 < its < 500
+    phi_new = x.to_host()
+    for d in rows:
+        l = int(np.searchsorted(sub_dofs, d))
+        cols = sub_dofs[ci[rp[l]:rp[l + 1]]]
+        lhs = (Ms[rp[l]:rp[l + 1]] - dt * Ks[rp[l]:rp[l + 1]]) @ phi_new[cols]
+        rhs = Ms[rp[l]:rp[l + 1]] @ phi_old[cols]
+        assert abs(lhs - rhs) < 1e-9 * (np.abs(Ms[rp[l]:rp[l + 1]]) @ np.abs(phi_old[cols]) + 1e-300), d
+    # ---------------- mechanics half on the same mesh: activation = normalised calcium of the EP state, per cell and node
+    ca_node = np.empty(g.n_nodes); ca_node = un[ica][n2d]
+    ca_rest = float(model.default_initial_state()[ica])
+    act = np.clip((ca_node[g.conn] - ca_rest) / (1.0e-3 - ca_rest), 0.0, 1.0)      # [cell][8]
+    assert act.max() > 0.2 and act.std() > 0.02
+    dhv = tb.DofHandler(g, tb.LagrangeCollection(1) ** 3)
+    spv = tb.allocate_matrix(dhv)
+    msm = tb.OrthotropicMicrostructureModel(f, s_, n_)
+    sarc = tb.CaDrivenInternalSarcomereModel(tb.PelceSunLangeveld1995Model(), act)
+    Tmax = 20.0
+    cm = tb.ActiveStressModel(tb.HolzapfelOgden2009Model(), tb.SimpleActiveStress(Tmax=Tmax), sarc, msm)
+    op = tb.setup_operator(tb.ElementAssemblyStrategy(device), tb.QuasiStaticModel("d", cm), dhv, spv)
+    u = 2e-3 * np.sin(7.0 * np.arange(dhv.ndofs) / dhv.ndofs * np.pi)
+    res = device.zeros(dhv.ndofs)
+    tb.update_linearization(op, device.to_device(u), 0.0, residual=res)
+    rh = res.to_host()
+    vrows = np.concatenate([rng.choice(dhv.ndofs, 30, replace=False), [0, dhv.ndofs - 1]])
+    vcells = np.nonzero(np.isin(dhv.cell_dofs, vrows).any(axis=1))[0]
+    vsub, vinv = np.unique(dhv.cell_dofs[vcells], return_inverse=True)
+    vcd = vinv.reshape(len(vcells), -1).astype(np.int32)
+    vrp, vci = oracle.build_pattern(vcd, len(vsub))
+    vom = oracle.Mesh(oracle.HEX8, 2, g.xyz, np.ascontiguousarray(g.conn[vcells]), vcd)
+    oracle.set_microstructure_field(np.ascontiguousarray(msm.fsn[vcells]))
+    oracle.set_active_tension(Tmax, np.ascontiguousarray(act[vcells]))
+    try:
+        Kv, rv = oracle.assemble_hyperelastic(vom, u[vsub], vrp, vci)
+        oracle.set_active_tension(0.0)
+        _, rv_passive = oracle.assemble_hyperelastic(vom, u[vsub], vrp, vci, want_K=False)
+    finally:
+        oracle.set_active_tension(0.0)
+        oracle.set_microstructure_field(None)
+    assert np.abs(rv - rv_passive).max() > 1e-3 * np.abs(rv_passive).max()      # the activation is visible in the sampled rows
+    scale = np.abs(Kv).max()
+    for d in vrows:
+        l = int(np.searchsorted(vsub, d))
+        k0, k1 = int(spv.rowptr[d]), int(spv.rowptr[d + 1])
+        np.testing.assert_array_equal(spv.colidx[k0:k1], vsub[vci[vrp[l]:vrp[l + 1]]])
+        assert np.abs(op.J.view(k0, k1 - k0).to_host() - Kv[vrp[l]:vrp[l + 1]]).max() < 1e-11 * scale, d
+        assert abs(rh[d] - rv[l]) < 1e-11 * np.abs(rv).max(), d
 
 
 def test_deferred_status_reports_at_the_poll(tb, device):
@@ -2504,24 +2627,28 @@ def test_index_compressed_spmv_is_bit_identical_to_the_csr_kernel(tb, device):
     sp = tb.SparsityPattern(S.indptr.astype(np.int64), S.indices.astype(np.int32))
     dm = tb.DeviceMesh(device, dh)
     old = os.environ.pop("TB_SPMV_KERNEL", None)
+    vals = rng.normal(size=sp.nnz)
+    A = device.to_device(vals)
+    xh = rng.normal(size=n)
+    x = device.to_device(xh)
+    y0 = rng.normal(size=n)
+    out = {}
+
+    def products(pat):
+        y = device.zeros(n)
+        tb.check(tb.lib().tb_spmv_csr(pat.h, A.ptr, x.ptr, 1.0, 0.0, y.ptr))            # the first product of a pattern builds its plan: the switch is read here
+        y2 = device.to_device(y0)
+        tb.check(tb.lib().tb_spmv_csr(pat.h, A.ptr, x.ptr, -0.5, 2.0, y2.ptr))
+        y3, d = device.zeros(n), device.zeros(1)
+        tb.check(tb.lib().tb_spmv_csr_dot(pat.h, A.ptr, x.ptr, y3.ptr, d.ptr))
+        return y.to_host(), y2.to_host(), y3.to_host(), d.to_host()[0]
+
     try:
         pat_sig = tb.DevicePattern(dm, sp)
+        out["sig"] = products(pat_sig)
         os.environ["TB_SPMV_KERNEL"] = "rows"
         pat_csr = tb.DevicePattern(dm, sp)
-        vals = rng.normal(size=sp.nnz)
-        A = device.to_device(vals)
-        xh = rng.normal(size=n)
-        x = device.to_device(xh)
-        y0 = rng.normal(size=n)
-        out = {}
-        for name, pat in (("sig", pat_sig), ("csr", pat_csr)):
-            y = device.zeros(n)
-            tb.check(tb.lib().tb_spmv_csr(pat.h, A.ptr, x.ptr, 1.0, 0.0, y.ptr))        # the first product of a pattern builds its plan (env read here)
-            y2 = device.to_device(y0)
-            tb.check(tb.lib().tb_spmv_csr(pat.h, A.ptr, x.ptr, -0.5, 2.0, y2.ptr))
-            y3, d = device.zeros(n), device.zeros(1)
-            tb.check(tb.lib().tb_spmv_csr_dot(pat.h, A.ptr, x.ptr, y3.ptr, d.ptr))
-            out[name] = (y.to_host(), y2.to_host(), y3.to_host(), d.to_host()[0])
+        out["csr"] = products(pat_csr)
     finally:
         if old is None:
             os.environ.pop("TB_SPMV_KERNEL", None)

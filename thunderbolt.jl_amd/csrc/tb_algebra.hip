@@ -275,12 +275,14 @@ k_spmv_stream_rows(int n_blk, const uint4 *__restrict__ blkrec, const int64_t *_
 template <int CAP, bool DOT>
 __global__ void __launch_bounds__(256)
 k_spmv_sig_rows(int n_blk, const uint4 *__restrict__ blkrec, const int64_t *__restrict__ rowptr, const uint32_t *__restrict__ rowsig, const int32_t *__restrict__ sigoff,
-                const double *__restrict__ nz, const double *__restrict__ x, double alpha, double beta, double *__restrict__ y, double *__restrict__ xy)
+                const double *__restrict__ nz, int64_t nnz, const double *__restrict__ x, double alpha, double beta, double *__restrict__ y, double *__restrict__ xy)
 {
-    __shared__ double s_v[CAP];
-    constexpr int U = CAP / 256, SUB = 3, RW = 21, RP = 4 * RW, NK = 9; // 21 rows per wave (lane 63 idle): no row triple straddles two waves
+    __shared__ double2 s_v2[CAP / 2 + 1];
+    double *s_v = (double *)s_v2;
+    constexpr int U = CAP / 512, SUB = 3, RW = 21, RP = 4 * RW, NK = 9; // 21 rows per wave (lane 63 idle): no row triple straddles two waves
     const int tid = threadIdx.x, lane = tid & 63, rl = RW * (tid >> 6) + lane / SUB, sub = lane % SUB;
     const bool lane_ok = lane < SUB * RW;
+    const int G = gridDim.x;
     double acc = 0.0;
     // column offsets of the wave's current signature, lane (row, sub) holding entries sub, sub + 3, …: re-read from the table only when a pass meets
     // another signature (97 % of the rows of a hexahedral mesh carry the interior stencil, so almost never)
@@ -288,29 +290,52 @@ k_spmv_sig_rows(int n_blk, const uint4 *__restrict__ blkrec, const int64_t *__re
     uint32_t cur = 0xFFFFFFFFu;
 #pragma unroll
     for (int t_ = 0; t_ < NK; ++t_) of[t_] = 0;
-    int b = blockIdx.x;
-    uint4 rec = blkrec[b < n_blk ? b : 0];
-    for (; b < n_blk; b += gridDim.x) {
-        const int bn = b + gridDim.x;
-        const uint4 recn = blkrec[bn < n_blk ? bn : b];
-        const int r0 = (int)rec.x, nr = (int)(rec.y & 0xffffu), len = (int)(rec.y >> 16);
-        const int64_t k0 = (int64_t)(((uint64_t)rec.w << 32) | rec.z);
+    // A run costs two dependent trips to memory — its values (+ the row offsets and signatures of its first pass), then the gather of x — and the
+    // kernel is bound by them, not by bytes (8 µs per run and workgroup at 216³ with 12 B or 8 B per non-zero alike).  The values of the NEXT run
+    // are therefore requested while the current one is multiplied: records two runs ahead, values one run ahead (16 bytes per lane from the
+    // 16-byte boundary at or below the run's first entry — 8-byte loads stream at ≈ 0.6 of that rate —, the run then sits in LDS shifted by
+    // o = k0 & 1, its entry e at s_v[e + o]; the launcher guarantees a 16-byte aligned nz and runs of at most CAP − 2 entries; the one pair that
+    // would reach past the array (odd nnz) is read as a single value).
+    auto request = [&](const uint4 &rc, bool live, double2(&v)[U], int64_t &pa, int64_t &pe, uint32_t &sg) {
+        const int r0 = (int)rc.x, nr = (int)(rc.y & 0xffffu), len = (int)(rc.y >> 16);
+        const int64_t k0 = (int64_t)(((uint64_t)rc.w << 32) | rc.z);
         const int rc0 = rl < nr ? rl : nr - 1;
-        const int64_t pa0 = rowptr[r0 + rc0], pe0 = rowptr[r0 + rc0 + 1];
-        const uint32_t sg0 = rowsig[r0 + rc0];
-        const double *nzb = nz + k0;
-        double vj[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = tid + u * 256, ic = i < len ? i : len - 1;
-            vj[u] = len > 0 ? nzb[ic] : 0.0; // wave-uniform condition
-        }
+        pa = pe = 0; sg = 0;
+        if (live) { pa = rowptr[r0 + rc0]; pe = rowptr[r0 + rc0 + 1]; sg = rowsig[r0 + rc0]; }
+        const int64_t ka = k0 - (k0 & 1);
+        const int npairs = (len + (int)(k0 & 1) + 1) >> 1;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int i = tid + u * 256;
-            if (i < len) s_v[i] = vj[u];
+            v[u] = make_double2(0.0, 0.0);
+            if (live && i < npairs) {
+                if (ka + 2 * (int64_t)i + 1 < nnz) v[u] = *(const double2 *)(nz + ka + 2 * (int64_t)i);
+                else v[u].x = nz[ka + 2 * (int64_t)i];
+            }
+        }
+    };
+    int b = blockIdx.x;
+    uint4 rec = blkrec[b < n_blk ? b : 0];
+    uint4 recn = blkrec[b + G < n_blk ? b + G : 0];
+    double2 vj[U];
+    int64_t pa0, pe0;
+    uint32_t sg0;
+    request(rec, b < n_blk, vj, pa0, pe0, sg0);
+    for (; b < n_blk; b += G) {
+        const uint4 recnn = blkrec[b + 2 * G < n_blk ? b + 2 * G : 0];
+        const int r0 = (int)rec.x, nr = (int)(rec.y & 0xffffu), len = (int)(rec.y >> 16);
+        const int64_t k0 = (int64_t)(((uint64_t)rec.w << 32) | rec.z);
+        const int o = (int)(k0 & 1);
+        const int npairs = (len + o + 1) >> 1;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = tid + u * 256;
+            if (i < npairs) s_v2[i] = vj[u];
         }
         __syncthreads();
+        double2 vjn[U];
+        int64_t pa0n = 0, pe0n = 0;
+        uint32_t sg0n = 0;
         for (int p0 = 0; p0 < nr; p0 += RP) {
             const int r = rl + p0;
             const bool active = lane_ok && r < nr && len > 0;
@@ -318,7 +343,7 @@ k_spmv_sig_rows(int n_blk, const uint4 *__restrict__ blkrec, const int64_t *__re
             uint32_t sg = sg0;
             const int rc = r < nr ? r : nr - 1;
             if (p0 > 0) { pa = rowptr[r0 + rc]; pe = rowptr[r0 + rc + 1]; sg = rowsig[r0 + rc]; } // runs of short rows
-            const int a = (int)(pa - k0), n = (int)(pe - pa), row = r0 + rc;
+            const int a = (int)(pa - k0) + o, n = (int)(pe - pa), row = r0 + rc;
             {
                 const uint32_t sg1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sg);
                 const bool uniform = __ballot(sg != sg1) == 0ull; // every lane carries a valid row's signature (rc is clamped)
@@ -340,6 +365,7 @@ k_spmv_sig_rows(int n_blk, const uint4 *__restrict__ blkrec, const int64_t *__re
             }
 #pragma unroll
             for (int t_ = 0; t_ < NK; ++t_) xx[t_] = len > 0 ? x[cc[t_]] : 0.0;
+            if (p0 == 0) request(recn, b + G < n_blk, vjn, pa0n, pe0n, sg0n); // behind the gather in program order: the wait for x does not include these
             double v = 0.0;
 #pragma unroll
             for (int t_ = 0; t_ < NK; ++t_) v += kc[t_] >= 0 ? vv[t_] * xx[t_] : 0.0;
@@ -350,8 +376,12 @@ k_spmv_sig_rows(int n_blk, const uint4 *__restrict__ blkrec, const int64_t *__re
                 else y[r0 + r] = beta == 0.0 ? alpha * v : alpha * v + beta * y[r0 + r];
             }
         }
+        if (nr == 0) request(recn, b + G < n_blk, vjn, pa0n, pe0n, sg0n);
         __syncthreads();
-        rec = recn;
+        rec = recn; recn = recnn;
+#pragma unroll
+        for (int u = 0; u < U; ++u) vj[u] = vjn[u];
+        pa0 = pa0n; pe0 = pe0n; sg0 = sg0n;
     }
     if constexpr (DOT) block_sum_to(acc, xy);
 }
@@ -506,8 +536,9 @@ static int stream_plan(tb_pattern *p)
     std::vector<int32_t> cut{0};
     int64_t start = 0;
     for (int64_t r = 0; r < p->n_rows; ++r) {
-        if (p->h_rowptr[r + 1] - p->h_rowptr[r] > SPMV_CAP) { p->n_blk = -1; return TB_OK; }
-        if (p->h_rowptr[r + 1] - p->h_rowptr[start] > SPMV_CAP || r - start >= 60000) { cut.push_back((int32_t)r); start = r; } // (empty rows: the record holds 16 bits of row count)
+        if (p->h_rowptr[r + 1] - p->h_rowptr[r] > SPMV_CAP - 2) { p->n_blk = -1; return TB_OK; }
+        // − 2: the 16-byte loads of the compressed kernel start one entry early and end one late (empty rows: the record holds 16 bits of row count)
+        if (p->h_rowptr[r + 1] - p->h_rowptr[start] > SPMV_CAP - 2 || r - start >= 60000) { cut.push_back((int32_t)r); start = r; }
     }
     cut.push_back((int32_t)p->n_rows);
     TB_HIP(hipMalloc((void **)&p->d_blkrow, cut.size() * sizeof(int32_t)));
@@ -603,10 +634,17 @@ static void launch_stream(tb_pattern *p, const double *nz, const double *x, doub
     if (!once) { once = true; const int v = getenv("TB_SPMV_NOGATHER") ? 1 : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_spmv_nogather), &v, sizeof(int)); }
 #endif
     static const bool rows_kernel = !(getenv("TB_SPMV_KERNEL") && strcmp(getenv("TB_SPMV_KERNEL"), "rows") != 0 && strcmp(getenv("TB_SPMV_KERNEL"), "sig") != 0); // "rec" / "chain": entry-per-lane kernels
-    if (rows_kernel && sig_plan(p) == TB_OK && p->n_sig > 0) // default where the pattern compresses: 16 KB of LDS per workgroup
-        hipLaunchKernelGGL((k_spmv_sig_rows<SPMV_CAP, DOT>), dim3(grid > 1536 ? 1536 : grid), dim3(256), 0, st, (int)p->n_blk, (const uint4 *)p->d_blkrec, p->d_rowptr,
-                           p->d_rowsig, p->d_sigoff, nz, x, alpha, beta, y, xy);
-    else if (rows_kernel) // 24 KB of LDS per workgroup: six resident per CU
+    if (rows_kernel && ((uintptr_t)nz & 15) == 0 && sig_plan(p) == TB_OK && p->n_sig > 0) { // default where the pattern compresses: 16 KB of LDS per workgroup
+        // persistent: exactly the workgroups that are resident together (the runs are dealt round-robin, every workgroup gets the same share ± 1)
+        static int per_cu = 0;
+        if (!per_cu) {
+            if (getenv("TB_SPMV_WG_PER_CU")) per_cu = atoi(getenv("TB_SPMV_WG_PER_CU"));
+            if (per_cu <= 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_spmv_sig_rows<SPMV_CAP, DOT>, 256, 0) != hipSuccess || per_cu <= 0)) per_cu = 3;
+        }
+        const unsigned gmax = (unsigned)(p->mesh->dev->n_cu * per_cu);
+        hipLaunchKernelGGL((k_spmv_sig_rows<SPMV_CAP, DOT>), dim3(std::min<unsigned>((unsigned)p->n_blk, gmax)), dim3(256), 0, st, (int)p->n_blk, (const uint4 *)p->d_blkrec, p->d_rowptr,
+                           p->d_rowsig, p->d_sigoff, nz, (int64_t)p->nnz, x, alpha, beta, y, xy);
+    } else if (rows_kernel) // 24 KB of LDS per workgroup: six resident per CU
         hipLaunchKernelGGL((k_spmv_stream_rows<SPMV_CAP, DOT>), dim3(grid > 1536 ? 1536 : grid), dim3(256), 0, st, (int)p->n_blk, (const uint4 *)p->d_blkrec, p->d_rowptr,
                            p->d_colidx, nz, x, alpha, beta, y, xy);
     else if (spmv_chain_kernel())
@@ -745,6 +783,18 @@ __device__ __forceinline__ void block_sum_to(double v, double *out)
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
     __syncthreads();
     if (threadIdx.x == 0) unsafeAtomicAdd(out, sm[0] + sm[1] + sm[2] + sm[3]);
+}
+
+// two sums of a 256-thread block with one barrier: out[0] += Σ a, out[1] += Σ c (the two atomics leave from different waves)
+__device__ __forceinline__ void block_sum2_to(double a, double c, double *out)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
+    __shared__ double sm2[8];
+    if ((threadIdx.x & 63) == 0) { sm2[threadIdx.x >> 6] = a; sm2[4 + (threadIdx.x >> 6)] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(out, sm2[0] + sm2[1] + sm2[2] + sm2[3]);
+    if (threadIdx.x == 64) unsafeAtomicAdd(out + 1, sm2[4] + sm2[5] + sm2[6] + sm2[7]);
 }
 
 // r = b − Ax (Ax given), z = D⁻¹ r, p = z;  out[0] += r·z, out[1] += r·r
@@ -1523,9 +1573,7 @@ k_cgd_update(int64_t n, const double *__restrict__ w, const double *__restrict__
         a += wi * ri * (dinv ? dinv[i] * ri : ri);
         c += wi * ri * ri;
     }
-    block_sum_to(a, out);
-    __syncthreads();
-    block_sum_to(c, out + 1);
+    block_sum2_to(a, c, out);
 }
 
 // β = rz_new / rz (device scalars); p = D⁻¹ r + β p
@@ -1547,7 +1595,8 @@ int launch_cgd_dot(tb_device *dev, int64_t n, const double *w, const double *a, 
 int launch_cgd_update(tb_device *dev, int64_t n, const double *w, const double *dinv, const double *p, const double *Ap, double *x, double *r,
                       const double *d_rz, const double *d_pAp, double *d_out3)
 {
-    if (n > 0) hipLaunchKernelGGL(k_cgd_update, dim3(grid_for(dev, n, 256)), dim3(256), 0, dev->stream, n, w, dinv, p, Ap, x, r, d_rz, d_pAp, d_out3);
+    // reductions end in one atomic per block and sum on ONE address: four blocks per CU (1 024 atomics) instead of eight
+    if (n > 0) hipLaunchKernelGGL(k_cgd_update, dim3(std::min<unsigned>(grid_for(dev, n, 256), (unsigned)dev->n_cu * 4)), dim3(256), 0, dev->stream, n, w, dinv, p, Ap, x, r, d_rz, d_pAp, d_out3);
     TB_HIP(hipGetLastError());
     return TB_OK;
 }

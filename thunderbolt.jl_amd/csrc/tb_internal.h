@@ -118,17 +118,6 @@ struct PatchFusedPlan {
     //   rec_rm × 16 B row descriptors · rec_nm × 24 B vertex coordinates; zero padding behind the patch's own counts.  Built on first use.
     uint8_t *d_rec = nullptr;
     int rec_stride = 0, rec_rm = 0, rec_nm = 0, rec_ne = 0; // rec_ne: instance slots per record (≥ 256, multiple of 64); rec_stride = −1: the patches do not fit the record form (a patch with more than 256 instances)
-    // Symmetric-storage extension (tb_patch_sym.hip).  Both matrices are symmetric, so a coupling {n, m} of two rows the patch owns is accumulated
-    // once — in the row with the smaller patch-local slot — and mirrored when the rows are written out: a row's accumulator run holds its diagonal,
-    // the columns the patch does not own and the owned columns of larger slot (≈ 14 of 27 entries on a hexahedral mesh, padded to an odd
-    // count: consecutive rows then start on different LDS banks).
-    bool sym = false;
-    int max_sym_entries = 0;         // LDS entries of the largest patch (sym == true: this, not max_lds_entries, sizes the accumulator block)
-    int64_t nssig = 0, nmir = 0;
-    uint32_t *d_elem_ssig = nullptr; // per instance: index of its pair signature
-    uint8_t *d_ssigtab = nullptr;    // nssig × 48 B (hexahedra: 36 pairs i ≤ j) or × 16 B (tetrahedra: 10): rank of the pair's entry inside the target row's run, 0xFF = no owned row
-    uint32_t *d_row_sdesc = nullptr; // 4 per owned row: nz0 low 32 bits | nz0 >> 32 (8 bits) + row length << 8 | LDS offset of the run | offset of its mirror map
-    int16_t *d_mirtab = nullptr;     // mirror maps, de-duplicated: per CSR entry of a row the LDS entry that holds it, relative to the row's own run
 };
 
 // Patch plan of the linear-form (vector) kernels on trilinear hexahedra (tb_assembly.hip: k_vector_hex8_patch).  Row accumulators of a vector
@@ -282,8 +271,7 @@ void free_patch_plan(tb_mesh *m);
 void free_patch_mat_plan(tb_pattern *p);
 int ensure_vec_patch_plan(tb_mesh *m, bool halo);
 void free_vec_patch_plans(tb_mesh *m);
-int ensure_patch_fused(tb_mesh *m, tb_pattern *p, int nregions, bool sym = false); // plan of the sum-factorised hexahedron kernel; nregions accumulator blocks must fit 80 KiB of LDS
-int launch_assemble_hex8_sym(tb_form *fK, tb_form *fM, tb_pattern *p, double t, double *d_nzK, double *d_nzM); // tb_patch_sym.hip; TB_ERR_UNSUPPORTED → caller falls back
+int ensure_patch_fused(tb_mesh *m, tb_pattern *p, int nregions); // plan of the sum-factorised hexahedron kernel; nregions accumulator blocks must fit 80 KiB of LDS
 void free_patch_fused_plan(tb_pattern *p);
 int launch_assemble_hex8_patch(tb_form *fK, tb_form *fM, tb_pattern *p, double t, double *d_nzK, double *d_nzM); // either form may be NULL
 bool hex8_patch_applicable(const tb_form *f, const tb_pattern *p);

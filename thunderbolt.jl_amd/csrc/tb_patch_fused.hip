@@ -360,12 +360,12 @@ k_patch_hex8_staged(FormArgs faK, FormArgs faM, FusedView pv, const uint4 *__res
 // One-trip form (default for constant coefficients): every input of the patch sits in one fixed-stride record (PatchFusedPlan::d_rec), so all
 // of its loads — counts word, node indices, signature ids, row descriptors, coordinates — are addressed from blockIdx alone and issued at once:
 // ONE trip to memory in front of the integration instead of header → inputs (phase stamps of the staged kernel at 216³: 3.4 of a workgroup's
-// 14.2 µs before its first barrier).  The first lines of the record `pf` patches ahead — the one this CU's next workgroup will most likely get —
-// are touched by one dword load per lane, so that workgroup's trip ends in the cache hierarchy instead of behind the store traffic in HBM.
+// 14.2 µs before its first barrier).  A look-ahead (one dword load per lane into the record `pf` patches ahead, so that the next workgroup's trip would end
+// in the cache hierarchy) is built in and measured slower at every distance tried (1.94 → 2.02–2.05 ms): off unless TB_PATCH_PREFETCH is set.
 // Write-out: a half-wave reads ALL its row descriptors, then ALL its accumulators, then stores (one dependent LDS round instead of five).
 template <bool WK, bool WM, bool DIAG, int RPH>
 __global__ void __launch_bounds__(256, 2)
-k_patch_hex8_record(FormArgs faK, FormArgs faM, const uint8_t *__restrict__ rec, int stride, int nem, int rm, int nm, int kcap, const uint8_t *__restrict__ sigtab, int pf,
+k_patch_hex8_record(FormArgs faK, FormArgs faM, const uint8_t *__restrict__ rec, int stride, int nem, int rm, int nm, int kcap, const uint8_t *__restrict__ sigtab, int pf, int prio,
                     double *__restrict__ nzK, double *__restrict__ nzM, Status *st
 #ifdef TB_ABLATION
                     , long long *prof
@@ -381,6 +381,10 @@ k_patch_hex8_record(FormArgs faK, FormArgs faM, const uint8_t *__restrict__ rec,
 #define TB_ST(k) do { } while (0)
 #endif
     TB_ST(0);
+    // staging and write-out are short, latency-bound instruction streams; the integration is ≈ 2 400 instructions per lane.  With two workgroups per
+    // CU a wave in its staging or write-out phase shares its SIMD with a wave of the other workgroup that may be integrating: raised priority lets
+    // the short phase issue its loads / stores at once instead of waiting behind the other wave's arithmetic (TB_PATCH_PRIO=0 switches it off)
+    if (prio) __builtin_amdgcn_s_setprio(3);
     const uint8_t *r = rec + (size_t)blockIdx.x * (size_t)stride;
     const uint32_t hw = ((const uint4 *)r)->x; // wave-uniform address: a scalar load, consumed only behind the vector loads below
     uint32_t pfv = 0;
@@ -418,6 +422,7 @@ k_patch_hex8_record(FormArgs faK, FormArgs faM, const uint8_t *__restrict__ rec,
     TB_ST(1);
     __syncthreads();
     TB_ST(2);
+    if (prio) __builtin_amdgcn_s_setprio(0);
     for (int ei = tid; ei < ne; ei += T) { // one pass for all but the domain-boundary patches (they own the extra boundary layers: up to ≈ 280 instances)
         if (ei >= T) {
             lnv = ((const uint4 *)(r + 16))[ei];
@@ -441,6 +446,7 @@ k_patch_hex8_record(FormArgs faK, FormArgs faM, const uint8_t *__restrict__ rec,
     TB_ST(3);
     __syncthreads();
     TB_ST(4);
+    if (prio) __builtin_amdgcn_s_setprio(3);
     // write-out: one row per half-wave; all descriptors, then all accumulators, then all stores of the half-wave's rows
     const int half = tid >> 5, hl = tid & 31;
     uint4 d[RPH]; // {nz0 lo, nz0 hi, off, len}
@@ -521,15 +527,6 @@ int launch_assemble_hex8_patch(tb_form *fK, tb_form *fM, tb_pattern *p, double t
     tb_form *any = fK ? fK : fM;
     tb_mesh *m = any->mesh;
     tb_device *dev = m->dev;
-    // TB_PATCH_KERNEL=sym selects the symmetric-accumulator kernel (tb_patch_sym.hip: one LDS add per coupling, mirrored write-out, 7×7×7 tiles) — a
-    // measured alternative that is parity-green but slower than this file's kernel on MI355X; it falls back here when its plan cannot be built
-    {
-        const char *kn = getenv("TB_PATCH_KERNEL");
-        if (kn && !strcmp(kn, "sym")) {
-            const int rs = launch_assemble_hex8_sym(fK, fM, p, t, d_nzK, d_nzM);
-            if (rs != TB_ERR_UNSUPPORTED) return rs;
-        }
-    }
     int rc = reset_status(dev);
     if (rc) return rc;
     if (fK && fK->field) { rc = tabulate_g_hex8(fK); if (rc) return rc; }
@@ -560,7 +557,8 @@ int launch_assemble_hex8_patch(tb_form *fK, tb_form *fM, tb_pattern *p, double t
     const bool diag = fK && !fk && aK.D[1] == 0.0 && aK.D[2] == 0.0 && aK.D[5] == 0.0 && aK.D[3] == 0.0 && aK.D[6] == 0.0 && aK.D[7] == 0.0;
     // one-trip record kernel: constant coefficients, patches of ≤ 256 instances (TB_PATCH_KERNEL=staged keeps the two-trip kernel for A/B runs)
     static const bool no_record = getenv("TB_PATCH_KERNEL") && strcmp(getenv("TB_PATCH_KERNEL"), "record") != 0;
-    static const int pf_ahead = getenv("TB_PATCH_PREFETCH") ? atoi(getenv("TB_PATCH_PREFETCH")) : 512; // look-ahead distance in patches (0 = off); 512 = the resident workgroups
+    static const int wave_prio = getenv("TB_PATCH_PRIO") ? atoi(getenv("TB_PATCH_PRIO")) : 1;
+    static const int pf_ahead = getenv("TB_PATCH_PREFETCH") ? atoi(getenv("TB_PATCH_PREFETCH")) : 0; // look-ahead distance in patches; measured at 216³: 0 → 1.94 ms, 512 → 2.03, 1024 → 2.02, 2048 → 2.05 (off by default)
     if (staged && !no_record && !fk && !fm && ensure_patch_records(p) == TB_OK) {
         PatchFusedPlan *pr = p->patch_fused.get();
         const size_t ldsr = (size_t)nreg * pv.kcap * sizeof(double) + (size_t)pr->rec_rm * sizeof(RowDesc) + (size_t)pr->rec_nm * 3 * sizeof(double);
@@ -570,10 +568,10 @@ int launch_assemble_hex8_patch(tb_form *fK, tb_form *fM, tb_pattern *p, double t
                 TB_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr));
 #ifdef TB_ABLATION
                 hipLaunchKernelGGL(k, dim3((unsigned)pp->n_patches), dim3(256), ldsr, dev->stream, aK, aM, (const uint8_t *)pr->d_rec, pr->rec_stride, pr->rec_ne, pr->rec_rm, pr->rec_nm, pv.kcap,
-                                   (const uint8_t *)pf->d_sigtab, pf_ahead, d_nzK, d_nzM, dev->d_status, d_prof);
+                                   (const uint8_t *)pf->d_sigtab, pf_ahead, wave_prio, d_nzK, d_nzM, dev->d_status, d_prof);
 #else
                 hipLaunchKernelGGL(k, dim3((unsigned)pp->n_patches), dim3(256), ldsr, dev->stream, aK, aM, (const uint8_t *)pr->d_rec, pr->rec_stride, pr->rec_ne, pr->rec_rm, pr->rec_nm, pv.kcap,
-                                   (const uint8_t *)pf->d_sigtab, pf_ahead, d_nzK, d_nzM, dev->d_status);
+                                   (const uint8_t *)pf->d_sigtab, pf_ahead, wave_prio, d_nzK, d_nzM, dev->d_status);
 #endif
                 return TB_OK;
             };

@@ -129,6 +129,35 @@ static inline uint64_t spread21(uint64_t v)
     return v;
 }
 
+// Extent of a hexahedron along the three coordinate axes for the layer count of the bucket construction: per axis the largest component of the
+// three face-centre-to-face-centre vectors.  On a distorted structured grid these average to the layer spacing exactly (they telescope along a
+// grid line), so extent / mean comes out as the number of layers; the bounding box of a sheared cell is larger than the spacing (216 layers of a
+// mesh perturbed by 0.2 h counted as ≈ 200 buckets: tiles then cut through the layers, ragged faces, patches of 270 instances and 158 rows).
+static inline void hex_axis_extents(const double *xyz, const int32_t *cn, double (&ext)[3])
+{
+    static const int lo_hi[3][2][4] = {{{0, 3, 4, 7}, {1, 2, 5, 6}}, {{0, 1, 4, 5}, {3, 2, 7, 6}}, {{0, 1, 2, 3}, {4, 5, 6, 7}}};
+    ext[0] = ext[1] = ext[2] = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        double e[3] = {0, 0, 0};
+        for (int a = 0; a < 4; ++a)
+            for (int d = 0; d < 3; ++d) e[d] += 0.25 * (xyz[3 * (int64_t)cn[lo_hi[k][1][a]] + d] - xyz[3 * (int64_t)cn[lo_hi[k][0][a]] + d]);
+        for (int d = 0; d < 3; ++d) ext[d] = std::max(ext[d], std::fabs(e[d]));
+    }
+}
+
+// Tile of bucket b (0 ≤ b < R) along one axis, for tiles of at most `tile` layers, split evenly instead of cutting full tiles and leaving a sliver:
+//   by_nodes: the R + 1 node layers are dealt to ⌈(R + 1) / tile⌉ tiles in balanced groups and a cell goes with its upper node layer (rows are
+//   owned by first touch, so the tile of cell b owns node layer b + 1 and the first tile node layer 0 as well) — no tile owns more than `tile`
+//   layers of rows, the domain-boundary tiles included (cutting at multiples of `tile` gave the first tile tile + 1 layers: too many rows for the
+//   LDS block, so those patches were split again, and 216 = 43 × 5 + 1 left a one-cell sliver of tiles along two faces);
+//   otherwise the R cell layers are dealt to ⌈R / tile⌉ tiles (patches that own cells, not rows).
+static inline uint64_t balanced_tile(uint32_t b, int64_t R, int tile, bool by_nodes)
+{
+    if (by_nodes) { const int64_t nt = (R + 1 + tile - 1) / tile; return (uint64_t)(((int64_t)b + 1) * nt / (R + 1)); }
+    const int64_t nt = (R + tile - 1) / tile;
+    return (uint64_t)((int64_t)b * nt / R);
+}
+
 // Patch decomposition.  Cells are ordered along a Morton curve through their centroids (works for any
 // unstructured mesh), cut into runs of `cells_per_patch`; a dof is owned by the first patch (in that
 // order) that touches it; a patch's element list = every cell touching one of its rows.
@@ -173,9 +202,11 @@ int build_patch_plan(tb_mesh *m, int cells_per_patch)
                     const double v = m->h_xyz[3 * (int64_t)m->h_conn[c * nv + a] + d];
                     sum[d] += v; mn[d] = std::min(mn[d], v); mx[d] = std::max(mx[d], v);
                 }
+            double ext[3] = {mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]};
+            if (nv == 8) hex_axis_extents(&m->h_xyz[0], &m->h_conn[c * 8], ext);
             for (int d = 0; d < 3; ++d) {
                 cen[3 * c + d] = sum[d] / nv;
-                lo[d] = std::min(lo[d], mn[d]); hi[d] = std::max(hi[d], mx[d]); hsum[d] += mx[d] - mn[d];
+                lo[d] = std::min(lo[d], mn[d]); hi[d] = std::max(hi[d], mx[d]); hsum[d] += ext[d];
             }
         }
 #pragma omp parallel for schedule(static, 1) num_threads(3)
@@ -200,10 +231,12 @@ int build_patch_plan(tb_mesh *m, int cells_per_patch)
                 cells_per_patch = (int)std::min<int64_t>((int64_t)tile[0] * tile[1] * tile[2] * per_bucket, 1 << 20);
             }
         }
+        static const bool legacy_cut = getenv("TB_PATCH_CUT") && !strcmp(getenv("TB_PATCH_CUT"), "full"); // full tiles + sliver (rounds 1–3), for A/B runs
+        auto tile_of = [&](uint32_t b, int d) -> uint64_t { return legacy_cut ? (uint64_t)(b / tile[d]) : balanced_tile(b, Rv[d], tile[d], true); };
 #pragma omp parallel for schedule(static)
         for (int64_t c = 0; c < nc; ++c) {
             if (use_tiles) { // tile id (z-major), 21 bits per axis
-                const uint64_t ti = bucket[3 * c] / tile[0], tj = bucket[3 * c + 1] / tile[1], tk = bucket[3 * c + 2] / tile[2];
+                const uint64_t ti = tile_of(bucket[3 * c], 0), tj = tile_of(bucket[3 * c + 1], 1), tk = tile_of(bucket[3 * c + 2], 2);
                 keyed[c] = {(tk << 42) | (tj << 21) | ti, (int32_t)c};
             } else {
                 keyed[c] = {spread21(bucket[3 * c]) | spread21(bucket[3 * c + 1]) << 1 | spread21(bucket[3 * c + 2]) << 2, (int32_t)c};
@@ -447,7 +480,7 @@ void free_patch_fused_plan(tb_pattern *p)
     if (!p->patch_fused) return;
     PatchFusedPlan *f = p->patch_fused.get();
     hipFree(f->d_node_ptr); hipFree(f->d_pnode); hipFree(f->d_elem_ln); hipFree(f->d_elem_sig); hipFree(f->d_sigtab); hipFree(f->d_row_desc); hipFree(f->d_hdr); hipFree(f->d_pcoord);
-    hipFree(f->d_elem_ssig); hipFree(f->d_ssigtab); hipFree(f->d_row_sdesc); hipFree(f->d_mirtab); hipFree(f->d_rec);
+    hipFree(f->d_rec);
     p->patch_fused.reset();
 }
 
@@ -504,8 +537,7 @@ struct RecordTable {
 
 // Fused-kernel extension of the patch plan (see PatchFusedPlan).  Needs a scalar first-order field whose local dof a sits on
 // local vertex a (Ferrite: vertex dofs in vertex order), i.e. a one-to-one node ↔ dof relation; rows of at most 255 entries.
-// sym: additionally the symmetric-storage arrays of tb_patch_sym.hip; the LDS need is then counted in symmetric entries.
-static int build_patch_fused_plan_impl(tb_pattern *p, int64_t *lds_need, int nregions, bool sym, std::unique_ptr<PatchFusedPlan> &plan)
+static int build_patch_fused_plan_impl(tb_pattern *p, int64_t *lds_need, int nregions, std::unique_ptr<PatchFusedPlan> &plan)
 {
     tb_mesh *m = p->mesh;
     const PatchPlan *pp = m->patches.get();
@@ -514,7 +546,6 @@ static int build_patch_fused_plan_impl(tb_pattern *p, int64_t *lds_need, int nre
     if (!(hex || tet) || m->ncomp != 1) { set_error("fused patch plan: needs a scalar first-order field on hexahedra or tetrahedra"); return TB_ERR_UNSUPPORTED; }
     const int NV = ndpc, NS = NV * NV; // nodes per cell, bytes per position signature
     plan->version = pp->version;
-    plan->sym = sym;
     // 1. row descriptors and the LDS need
     std::vector<RowDesc> row_desc(pp->total_rows);
     int64_t maxlen = 0, max_entries = 0;
@@ -571,36 +602,7 @@ static int build_patch_fused_plan_impl(tb_pattern *p, int64_t *lds_need, int nre
     }
     if (bad) { set_error("fused patch plan: dofs and vertices of the field are not in one-to-one correspondence"); return TB_ERR_UNSUPPORTED; }
     plan->max_nodes = max_nodes;
-    // symmetric storage: which patch owns a dof and in which row slot; a row's run keeps column c unless c is an owned row of smaller slot
-    std::vector<int32_t> own_patch, own_slot;
-    std::vector<uint32_t> sym_off; // per owned row: LDS offset of its run
-    if (sym) {
-        own_patch.assign(m->ndofs, -1); own_slot.assign(m->ndofs, -1);
-        for (int64_t q = 0; q < pp->n_patches; ++q)
-            for (int64_t r = pp->h_row_ptr[q]; r < pp->h_row_ptr[q + 1]; ++r) { own_patch[pp->h_row_dof[r]] = (int32_t)q; own_slot[pp->h_row_dof[r]] = (int32_t)(r - pp->h_row_ptr[q]); }
-        sym_off.assign(pp->total_rows, 0);
-        int64_t max_sym = 0;
-        bool too_long = false;
-#pragma omp parallel for schedule(dynamic, 64) reduction(max : max_sym) reduction(|| : too_long)
-        for (int64_t q = 0; q < pp->n_patches; ++q) {
-            uint32_t off = 0;
-            for (int64_t r = pp->h_row_ptr[q]; r < pp->h_row_ptr[q + 1]; ++r) {
-                const int32_t d = pp->h_row_dof[r], s_ = (int32_t)(r - pp->h_row_ptr[q]);
-                int cnt = 0;
-                for (int64_t k = p->h_rowptr[d]; k < p->h_rowptr[d + 1]; ++k) {
-                    const int32_t c = p->h_colidx[k];
-                    cnt += !(own_patch[c] == q && own_slot[c] < s_);
-                }
-                if (cnt > 127) too_long = true;
-                sym_off[r] = off;
-                off += (uint32_t)(cnt | 1); // odd run lengths: consecutive rows start on different banks (stride-14 runs collide two-way)
-            }
-            max_sym = std::max<int64_t>(max_sym, (int64_t)off);
-        }
-        if (too_long) { set_error("symmetric patch plan: a row keeps more than 127 entries"); return TB_ERR_UNSUPPORTED; }
-        plan->max_sym_entries = (int)((max_sym + 1) & ~(int64_t)1);
-    }
-    const int64_t acc_entries = sym ? plan->max_sym_entries : plan->max_lds_entries;
+    const int64_t acc_entries = plan->max_lds_entries;
     *lds_need = (int64_t)nregions * acc_entries * 8 + (int64_t)pp->max_rows * 16 + (int64_t)max_nodes * 24; // + coordinates of the patch's nodes
     if (*lds_need > 80 * 1024 || acc_entries >= 0x7fff) { plan->d_row_desc = nullptr; return TB_ERR_NOMEM; } // caller shrinks the tile and retries (TB_ERR_NOMEM is this function's private "too big")
     // 3. signatures: position of column dof(j) inside row dof(i) for every pair of a cell, de-duplicated
@@ -653,118 +655,6 @@ static int build_patch_fused_plan_impl(tb_pattern *p, int64_t *lds_need, int nre
 #pragma omp parallel for schedule(static)
     for (int64_t e = 0; e < pp->total_elems; ++e) elem_sig[e] = cell_sig[pp->h_elem_cell[e]];
     int rc;
-    if (sym) {
-        // Pair signatures (per instance) and mirror maps (per row), computed patch by patch in parallel chunks and de-duplicated in sequence.
-        //   pair (i ≤ j) of an instance → the row of smaller slot among the owned ones (the kernel takes the same decision from the patch-local
-        //   node indices: owned nodes carry their slot, others a larger number) and the rank of the column inside that row's run;
-        //   CSR entry k of row s (column c) → its LDS entry relative to the run of s: the own rank, or, when c is an owned row t < s,
-        //   run(t) + rank_t(dof of s) − run(s).
-        const int NP = NV * (NV + 1) / 2, SSTRIDE = NV == 8 ? 48 : 16;
-        std::vector<uint32_t> elem_ssig(pp->total_elems);
-        std::vector<uint32_t> sdesc((size_t)pp->total_rows * 4);
-        RecordTable sigs, mirs;
-        const int64_t CH = 2048;
-        std::vector<std::vector<uint8_t>> psig(CH);
-        std::vector<std::vector<int16_t>> pmir(CH);
-        bool overflow = false;
-        for (int64_t q0 = 0; q0 < pp->n_patches; q0 += CH) {
-            const int64_t q1 = std::min(q0 + CH, pp->n_patches);
-#pragma omp parallel for schedule(dynamic, 8) reduction(|| : overflow)
-            for (int64_t q = q0; q < q1; ++q) {
-                const int64_t r0 = pp->h_row_ptr[q], nrows = pp->h_row_ptr[q + 1] - r0;
-                // rank of every CSR entry inside its row's run (0xFF: not kept)
-                std::vector<int64_t> rstart(nrows + 1, 0);
-                for (int64_t s_ = 0; s_ < nrows; ++s_) { const int32_t d = pp->h_row_dof[r0 + s_]; rstart[s_ + 1] = rstart[s_] + (p->h_rowptr[d + 1] - p->h_rowptr[d]); }
-                std::vector<uint8_t> rank(rstart[nrows]);
-                for (int64_t s_ = 0; s_ < nrows; ++s_) {
-                    const int32_t d = pp->h_row_dof[r0 + s_];
-                    int cnt = 0;
-                    for (int64_t k = p->h_rowptr[d]; k < p->h_rowptr[d + 1]; ++k) {
-                        const int32_t c = p->h_colidx[k];
-                        const bool kept = !(own_patch[c] == q && own_slot[c] < s_);
-                        rank[rstart[s_] + (k - p->h_rowptr[d])] = kept ? (uint8_t)cnt : (uint8_t)0xFF;
-                        cnt += kept;
-                    }
-                }
-                auto pos_in_row = [&](int32_t row, int32_t col) -> int64_t {
-                    const int32_t *b = &p->h_colidx[p->h_rowptr[row]], *en = &p->h_colidx[p->h_rowptr[row + 1]];
-                    return std::lower_bound(b, en, col) - b;
-                };
-                // mirror maps
-                std::vector<int16_t> &mir = pmir[q - q0];
-                mir.assign(rstart[nrows], 0);
-                for (int64_t s_ = 0; s_ < nrows; ++s_) {
-                    const int32_t d = pp->h_row_dof[r0 + s_];
-                    for (int64_t k = p->h_rowptr[d]; k < p->h_rowptr[d + 1]; ++k) {
-                        const int32_t c = p->h_colidx[k];
-                        const int64_t at = rstart[s_] + (k - p->h_rowptr[d]);
-                        int64_t delta;
-                        if (rank[at] != 0xFF) delta = rank[at];
-                        else {
-                            const int32_t t = own_slot[c];
-                            const uint8_t rk = rank[rstart[t] + pos_in_row(c, d)]; // symmetric pattern: d is a column of row c, kept there (t < s)
-                            if (rk == 0xFF) overflow = true;
-                            delta = (int64_t)sym_off[r0 + t] + rk - (int64_t)sym_off[r0 + s_];
-                        }
-                        if (delta < -32768 || delta > 32767) overflow = true;
-                        mir[at] = (int16_t)delta;
-                    }
-                }
-                // pair signatures
-                const int64_t e0 = pp->h_elem_ptr[q], ne = pp->h_elem_ptr[q + 1] - e0;
-                std::vector<uint8_t> &sg = psig[q - q0];
-                sg.assign((size_t)ne * NP, 0xFF);
-                for (int64_t e = 0; e < ne; ++e) {
-                    const int32_t c = pp->h_elem_cell[e0 + e];
-                    const int32_t *d = &m->h_cell_dofs[(int64_t)c * NV];
-                    const uint8_t *cs = &sig[(size_t)c * NS];
-                    int32_t slot[8];
-                    for (int a = 0; a < NV; ++a) slot[a] = own_patch[d[a]] == q ? own_slot[d[a]] : 0x7fffffff;
-                    int pr = 0;
-                    for (int i = 0; i < NV; ++i)
-                        for (int j = i; j < NV; ++j, ++pr) {
-                            const int t = slot[i] <= slot[j] ? i : j, o = t == i ? j : i;
-                            if (slot[t] == 0x7fffffff) continue;
-                            sg[(size_t)e * NP + pr] = rank[rstart[slot[t]] + cs[t * NV + o]];
-                            if (sg[(size_t)e * NP + pr] == 0xFF) overflow = true;
-                        }
-                }
-            }
-            if (overflow) break;
-            for (int64_t q = q0; q < q1; ++q) {
-                const int64_t e0 = pp->h_elem_ptr[q], ne = pp->h_elem_ptr[q + 1] - e0;
-                const std::vector<uint8_t> &sg = psig[q - q0];
-                for (int64_t e = 0; e < ne; ++e) elem_ssig[e0 + e] = (uint32_t)(sigs.insert(&sg[(size_t)e * NP], NP, SSTRIDE) / SSTRIDE);
-                const int64_t r0 = pp->h_row_ptr[q], nrows = pp->h_row_ptr[q + 1] - r0;
-                const std::vector<int16_t> &mir = pmir[q - q0];
-                int64_t at = 0;
-                for (int64_t s_ = 0; s_ < nrows; ++s_) {
-                    const int32_t d = pp->h_row_dof[r0 + s_];
-                    const int64_t len = p->h_rowptr[d + 1] - p->h_rowptr[d];
-                    const int64_t moff = mirs.insert((const uint8_t *)&mir[at], (size_t)len * 2, (size_t)len * 2) / 2;
-                    at += len;
-                    const uint64_t nz0 = (uint64_t)p->h_rowptr[d];
-                    if (nz0 >> 40 || moff >> 32) overflow = true;
-                    uint32_t *o = &sdesc[(size_t)(r0 + s_) * 4];
-                    o[0] = (uint32_t)nz0; o[1] = (uint32_t)(nz0 >> 32) | (uint32_t)len << 8; o[2] = sym_off[r0 + s_]; o[3] = (uint32_t)moff;
-                }
-            }
-        }
-        if (overflow) { set_error("symmetric patch plan: an offset does not fit its field"); return TB_ERR_UNSUPPORTED; }
-        plan->nssig = (int64_t)sigs.bytes.size() / SSTRIDE;
-        plan->nmir = (int64_t)mirs.bytes.size() / 2;
-        sigs.bytes.resize(sigs.bytes.size() + 64, 0xFF);  // the kernels fetch whole 16-byte pieces: slack behind the last record
-        mirs.bytes.resize(mirs.bytes.size() + 128, 0);
-        std::vector<int16_t> mirtab(mirs.bytes.size() / 2);
-        memcpy(mirtab.data(), mirs.bytes.data(), mirtab.size() * 2);
-        if (getenv("TB_PLAN_VERBOSE"))
-            fprintf(stderr, "[tbhip] symmetric storage: %d LDS entries per block (full rows: %d), %lld pair signatures, %lld mirror-map entries for %lld non-zeros\n",
-                    plan->max_sym_entries, plan->max_lds_entries, (long long)plan->nssig, (long long)plan->nmir, (long long)p->nnz);
-        if ((rc = upload(m->dev, elem_ssig, &plan->d_elem_ssig))) return rc;
-        if ((rc = upload(m->dev, sigs.bytes, &plan->d_ssigtab))) return rc;
-        if ((rc = upload(m->dev, sdesc, &plan->d_row_sdesc))) return rc;
-        if ((rc = upload(m->dev, mirtab, &plan->d_mirtab))) return rc;
-    }
     if ((rc = upload(m->dev, node_ptr, &plan->d_node_ptr))) return rc;
     if ((rc = upload(m->dev, pnode, &plan->d_pnode))) return rc;
     if ((rc = upload(m->dev, ln, &plan->d_elem_ln))) return rc;
@@ -798,7 +688,7 @@ int ensure_patch_records(tb_pattern *p)
     const PatchPlan *pp = p->mesh->patches.get();
     if (!f || !pp || !f->d_hdr) return TB_ERR_UNSUPPORTED;
     if (f->d_rec) return TB_OK;
-    if (f->rec_stride < 0 || pp->max_elems > 1024 || pp->max_rows > 256 || f->sym) { f->rec_stride = -1; return TB_ERR_UNSUPPORTED; }
+    if (f->rec_stride < 0 || pp->max_elems > 1024 || pp->max_rows > 256) { f->rec_stride = -1; return TB_ERR_UNSUPPORTED; }
     const int64_t np = pp->n_patches;
     const int rm = (pp->max_rows + 3) & ~3, nm = (f->max_nodes + 3) & ~3, nem = std::max(256, (pp->max_elems + 63) & ~63);
     const size_t o_ln = 16, o_sig = o_ln + (size_t)nem * 16, o_desc = o_sig + (size_t)nem * 4, o_xyz = o_desc + (size_t)rm * 16, raw = o_xyz + (size_t)nm * 24;
@@ -839,10 +729,10 @@ int ensure_patch_records(tb_pattern *p)
 
 // The plan object is handed to the pattern on every path, so that a failed upload half way leaves nothing behind: the caller's
 // free_patch_fused_plan releases whatever was allocated.  TB_ERR_NOMEM from the builder means "does not fit the LDS budget" (size-only plan).
-static int build_patch_fused_plan(tb_pattern *p, int64_t *lds_need, int nregions, bool sym)
+static int build_patch_fused_plan(tb_pattern *p, int64_t *lds_need, int nregions)
 {
     auto plan = std::make_unique<PatchFusedPlan>();
-    int rc = build_patch_fused_plan_impl(p, lds_need, nregions, sym, plan);
+    int rc = build_patch_fused_plan_impl(p, lds_need, nregions, plan);
     p->patch_fused = std::move(plan);
     if (rc == TB_ERR_NOMEM) return TB_ERR_UNSUPPORTED; // too big: the caller recognises it by the plan left behind without device arrays
     if (rc != TB_OK) { free_patch_fused_plan(p); return rc; }
@@ -851,20 +741,20 @@ static int build_patch_fused_plan(tb_pattern *p, int64_t *lds_need, int nregions
 
 // Build (or refit) the mesh's patch plan and the pattern's fused extension so that `nregions` blocks of row accumulators, the
 // row descriptors and the node list of any patch fit 80 KiB of LDS — two workgroups per CU.
-int ensure_patch_fused(tb_mesh *m, tb_pattern *p, int nregions, bool sym)
+int ensure_patch_fused(tb_mesh *m, tb_pattern *p, int nregions)
 {
     if (!m->patches) { int rc = build_patch_plan(m, 0); if (rc) return rc; }
     auto need = [&](const PatchFusedPlan *f) {
-        return (int64_t)nregions * (sym ? f->max_sym_entries : f->max_lds_entries) * 8 + (int64_t)m->patches->max_rows * 16 + (int64_t)f->max_nodes * 24;
+        return (int64_t)nregions * f->max_lds_entries * 8 + (int64_t)m->patches->max_rows * 16 + (int64_t)f->max_nodes * 24;
     };
-    if (p->patch_fused && p->patch_fused->version == m->patches->version && p->patch_fused->d_row_desc && (!sym || p->patch_fused->sym) &&
+    if (p->patch_fused && p->patch_fused->version == m->patches->version && p->patch_fused->d_row_desc &&
         need(p->patch_fused.get()) <= 80 * 1024)
         return TB_OK;
     const bool fixed = getenv("TB_PATCH_CELLS") || getenv("TB_PATCH_TILE");
     for (int attempt = 0; attempt < 16; ++attempt) {
         free_patch_fused_plan(p);
         int64_t bytes = 0;
-        int rc = build_patch_fused_plan(p, &bytes, nregions, sym);
+        int rc = build_patch_fused_plan(p, &bytes, nregions);
         if (rc == TB_OK) return TB_OK;
         const bool too_big = rc == TB_ERR_UNSUPPORTED && p->patch_fused; // the builder leaves the size-only plan behind in that case
         free_patch_fused_plan(p);
@@ -908,6 +798,7 @@ int ensure_vec_patch_plan(tb_mesh *m, bool halo)
     const int64_t nc = m->n_cells;
     std::vector<uint32_t> bucket((size_t)nc * 3);
     std::vector<std::pair<uint64_t, int32_t>> keyed(nc);
+    int64_t Rv[3] = {1, 1, 1};
     {
         std::vector<double> cen((size_t)nc * 3);
         double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, hsum[3] = {0, 0, 0};
@@ -919,9 +810,11 @@ int ensure_vec_patch_plan(tb_mesh *m, bool halo)
                     const double v = m->h_xyz[3 * (int64_t)m->h_conn[c * 8 + a] + d];
                     sum[d] += v; mn[d] = std::min(mn[d], v); mx[d] = std::max(mx[d], v);
                 }
+            double ext[3];
+            hex_axis_extents(&m->h_xyz[0], &m->h_conn[c * 8], ext);
             for (int d = 0; d < 3; ++d) {
                 cen[3 * c + d] = sum[d] / 8;
-                lo[d] = std::min(lo[d], mn[d]); hi[d] = std::max(hi[d], mx[d]); hsum[d] += mx[d] - mn[d];
+                lo[d] = std::min(lo[d], mn[d]); hi[d] = std::max(hi[d], mx[d]); hsum[d] += ext[d];
             }
         }
 #pragma omp parallel for schedule(static, 1) num_threads(3)
@@ -929,15 +822,18 @@ int ensure_vec_patch_plan(tb_mesh *m, bool halo)
             const double hmean = hsum[d] / (double)std::max<int64_t>(nc, 1);
             int64_t R = hmean > 0 ? (int64_t)std::llround((hi[d] - lo[d]) / hmean) : 1;
             R = std::min<int64_t>(std::max<int64_t>(R, 1), 1 << 21);
+            Rv[d] = R;
             std::vector<std::pair<double, int32_t>> byc(nc);
             for (int64_t c = 0; c < nc; ++c) byc[c] = {cen[3 * c + d], (int32_t)c};
             std::sort(byc.begin(), byc.end());
             for (int64_t r = 0; r < nc; ++r) bucket[3 * (size_t)byc[r].second + d] = (uint32_t)((r * R) / nc);
         }
+        static const bool legacy_cut = getenv("TB_PATCH_CUT") && !strcmp(getenv("TB_PATCH_CUT"), "full");
 #pragma omp parallel for schedule(static)
         for (int64_t c = 0; c < nc; ++c) {
-            const uint64_t ti = bucket[3 * c] / tile[0], tj = bucket[3 * c + 1] / tile[1], tk = bucket[3 * c + 2] / tile[2];
-            keyed[c] = {(tk << 42) | (tj << 21) | ti, (int32_t)c};
+            uint64_t t3[3];
+            for (int d = 0; d < 3; ++d) t3[d] = legacy_cut ? (uint64_t)(bucket[3 * c + d] / tile[d]) : balanced_tile(bucket[3 * c + d], Rv[d], tile[d], halo);
+            keyed[c] = {(t3[2] << 42) | (t3[1] << 21) | t3[0], (int32_t)c};
         }
     }
     auto lex_less = [&](int32_t a, int32_t b) {
