@@ -46,8 +46,8 @@ BYTES_PER_CELL_MATRIX = 272.0  # 32 B conn + 24 B coords + 27 nz 
 BYTES_PER_CELL_VECTOR = 64.0   # 32 + 24 + 8
 BYTES_PER_DOF_UPDATE = 16.0    # in place; 24 when du is materialised
 # FP64 flops of one cell instance, counted on the ISA of the shipped kernels (scripts/isa_hist.py; v_mul_f64 / v_add_f64 = 1, v_fma_f64 / v_fmac_f64 = 2)
-FLOP_PER_INSTANCE_FUSED = 430 + 354 + 2 * 465     # k_patch_hex8_staged<K+M,DIAG>
-FLOP_PER_INSTANCE_K = 1400.0                      # k_patch_hex8_staged<K,DIAG> (approximate: the mass part is ≈ 300 of the fused count)
+FLOP_PER_INSTANCE_FUSED = 430 + 354 + 2 * 465     # hex8_instance<K+M,DIAG> inside k_patch_hex8_record / k_patch_hex8_staged
+FLOP_PER_INSTANCE_K = 1400.0                      # hex8_instance<K,DIAG> (approximate: the mass part is ≈ 300 of the fused count)
 ROOFLINE_LIMITER = ("fp64 vector issue in the integration phase + latency-bound staging / write-out phases at two workgroups per CU "
                     "(not HBM, not the LDS atomics)")
 
@@ -130,14 +130,14 @@ def cpu_baseline(n, kap, ionic="tt06", sizes=(64, 100), big=None):
         nstates = len(u) // nd
         for th in threads_list:
             plan = o.AssemblyPlan(m, rp, ci, col, nc, th)
-            nzM, nzK = plan.new_values(), plan.new_values()
+            nzM, nzK, bvec = plan.new_values(), plan.new_values(), np.empty(nd)
             best_asm, best_rx, reps = 1e30, 1e30, 0
             t_end = time.time() + (3.0 if th == 1 else 4.0)
             while reps < 2 or (time.time() < t_end and reps < 6):
                 t0 = time.perf_counter()
                 plan.assemble(0, cM, nzM)
                 plan.assemble(1, cK, nzK)
-                o.assemble_source(m, o.SRC_COS_EXP, t=0.0, nthreads=th)
+                plan.assemble_source(o.SRC_COS_EXP, bvec, t=0.0)
                 t1 = time.perf_counter()
                 o.reaction_step(cm, p, u, nd, o.LAYOUT_SOA, dt=rdt, nthreads=th, want_du=False)
                 t2 = time.perf_counter()
@@ -145,7 +145,7 @@ def cpu_baseline(n, kap, ionic="tt06", sizes=(64, 100), big=None):
                     best_asm, best_rx = min(best_asm, t1 - t0), min(best_rx, t2 - t1)
                 reps += 1
             table["%s/%dt" % (tag, th)] = {"element_integrations_per_s": 3 * ncells / best_asm, "dof_updates_per_s": nstates * nd / best_rx, "reps": reps}
-            del plan, nzM, nzK
+            del plan, nzM, nzK, bvec
         if literal_1t:
             t0 = time.perf_counter()
             o.assemble_matrix(m, 0, cM, rp, ci)
@@ -434,12 +434,12 @@ def main():
         bytes_per_cell = (BYTES_PER_CELL_MATRIX + 216.0) if fused else BYTES_PER_CELL_MATRIX
         achieved = bytes_per_cell * g.n_cells / (k_ms * 1e-3) / 1e9
         if args.strategy == "patch":
-            kname = "k_patch_hex8_staged<K+M,DIAG>" if fused else "k_patch_hex8_staged<K>"
+            kname = "k_patch_hex8_record<K+M,DIAG>" if fused else "k_patch_hex8_record<K,DIAG>"
         else:
             kname = "k_matrix_direct<Hex8<2>,DIFFUSION>"
         mk_ms = k_ms + phase["mass"] / K_
         # FP64 side of the same launch (SURVEY §8d asks for both fractions).  Flops per cell instance counted on the ISA of the shipped kernel
-        # (scripts/isa_hist.py on k_patch_hex8_staged<K+M,DIAG>: 430 v_mul_f64 + 354 v_add_f64 + 465 v_fma_f64 → 1 714 flop); a patch re-integrates
+        # (scripts/isa_hist.py on k_patch_hex8_record<K+M,DIAG>, the same element routine as the staged kernel: 430 v_mul_f64 + 354 v_add_f64 + 465 v_fma_f64 → 1 714 flop); a patch re-integrates
         # the halo cells of its rows, so the kernel executes `instances_per_cell` × that; "useful" charges every cell once.
         inst_per_cell = pr.K.pattern.patch_stats()["instances_per_cell"] if args.strategy == "patch" else 1.0
         flop_inst = FLOP_PER_INSTANCE_FUSED if fused else FLOP_PER_INSTANCE_K

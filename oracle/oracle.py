@@ -252,6 +252,13 @@ class AssemblyPlan:
             raise RuntimeError("orc_assemble_matrix_planned -> %d" % rc)
         return nz
 
+    def assemble_source(self, src_kind, b, p=None, t=0.0):
+        par = _f64(p if p is not None else [0.0])
+        rc = lib().orc_assemble_source_planned(self.h, C.byref(self.mesh.c), int(src_kind), _d(par), None, C.c_double(t), _d(b), self.nthreads)
+        if rc:
+            raise RuntimeError("orc_assemble_source_planned -> %d" % rc)
+        return b
+
     def __del__(self):
         try:
             if self.h:

@@ -741,12 +741,17 @@ struct orc_assembly_plan {
     int32_t *color_cells; /* cells grouped by colour, ascending inside a colour */
     int32_t *emap;        /* n_cells × nb × nb positions in nzval (nnz < 2³¹) */
     int64_t *rowptr;      /* copy: the zero fill partitions rows */
+    /* element-assembly map of the source vector (the strategy the reference forces for it, src/solver/time/euler.jl:148-153): dof → its (cell, local)
+     * slots in cell order, built once; the element vectors live in a buffer the threads that fill it have touched first */
+    int64_t *ea_ptr;      /* ndofs + 1 */
+    int32_t *ea_src;      /* n_cells × nb slots, grouped by dof, ascending cell inside a dof */
+    double *ea;           /* n_cells × nb element-vector entries */
 };
 
 void orc_assembly_plan_destroy(orc_assembly_plan *p)
 {
     if (!p) return;
-    free(p->color_ptr); free(p->color_cells); free(p->emap); free(p->rowptr); free(p);
+    free(p->color_ptr); free(p->color_cells); free(p->emap); free(p->rowptr); free(p->ea_ptr); free(p->ea_src); free(p->ea); free(p);
 }
 
 int orc_assembly_plan_create(const orc_mesh *m, const int64_t *rowptr, const int32_t *colidx, const int32_t *color, int ncolors, int nthreads,
@@ -796,8 +801,49 @@ int orc_assembly_plan_create(const orc_mesh *m, const int64_t *rowptr, const int
         }
     }
     if (err) { orc_assembly_plan_destroy(p); return -3; }
+    if (m->n_cells * nb < 2147483647LL) {
+        p->ea_ptr = (int64_t *)calloc(ndofs + 1, sizeof(int64_t));
+        p->ea_src = (int32_t *)malloc(sizeof(int32_t) * m->n_cells * nb);
+        p->ea = (double *)malloc(sizeof(double) * m->n_cells * nb);
+        if (!p->ea_ptr || !p->ea_src || !p->ea) { orc_assembly_plan_destroy(p); return -4; }
+        for (int64_t i = 0; i < m->n_cells * nb; ++i) p->ea_ptr[m->cell_dofs[i] + 1]++;
+        for (int64_t d = 0; d < ndofs; ++d) p->ea_ptr[d + 1] += p->ea_ptr[d];
+        int64_t *pos = (int64_t *)malloc(sizeof(int64_t) * ndofs);
+        memcpy(pos, p->ea_ptr, sizeof(int64_t) * ndofs);
+        for (int64_t i = 0; i < m->n_cells * nb; ++i) p->ea_src[pos[m->cell_dofs[i]]++] = (int32_t)i;
+        free(pos);
+#pragma omp parallel for schedule(static)
+        for (int64_t c = 0; c < m->n_cells; ++c) for (int j = 0; j < nb; ++j) p->ea[c * nb + j] = 0.0; /* first touch */
+    }
     *out = p;
     return 0;
+}
+
+/* Source vector by element assembly with the plan's map: element vectors of all cells concurrently, then every dof sums its slots in cell order
+ * (the same sums as orc_assemble_source's multi-thread form, without rebuilding the map and the buffer in every call) */
+int orc_assemble_source_planned(const orc_assembly_plan *p, const orc_mesh *m, int src_kind, const double *par, const double *table, double t, double *b, int nthreads)
+{
+    cellvalues cv;
+    if (cv_setup(&cv, m->kind, m->qorder)) return -2;
+    const int nb = p->nb;
+    if (nb != cv.nb || p->n_cells != m->n_cells || !p->ea) return -2;
+#ifdef _OPENMP
+    omp_set_num_threads(nthreads > 0 ? nthreads : 1);
+#endif
+    int err = 0;
+#pragma omp parallel for schedule(static) reduction(|| : err)
+    for (int64_t cell = 0; cell < m->n_cells; ++cell) {
+        double *be = p->ea + cell * nb;
+        memset(be, 0, sizeof(double) * nb);
+        err = err || element_source_cv(m, &cv, cell, src_kind, par, table, t, be);
+    }
+#pragma omp parallel for schedule(static)
+    for (int64_t d = 0; d < p->ndofs; ++d) {
+        double s = 0;
+        for (int64_t k = p->ea_ptr[d]; k < p->ea_ptr[d + 1]; ++k) s += p->ea[p->ea_src[k]];
+        b[d] = s;
+    }
+    return err ? -1 : 0;
 }
 
 int orc_assemble_matrix_planned(const orc_assembly_plan *p, const orc_mesh *m, int form, const orc_coef *c, double *nzval, int nthreads)

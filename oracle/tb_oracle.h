@@ -127,6 +127,7 @@ int orc_assembly_plan_create(const orc_mesh *m, const int64_t *rowptr, const int
                              orc_assembly_plan **out);
 void orc_assembly_plan_destroy(orc_assembly_plan *p);
 int orc_assemble_matrix_planned(const orc_assembly_plan *p, const orc_mesh *m, int form, const orc_coef *c, double *nzval, int nthreads);
+int orc_assemble_source_planned(const orc_assembly_plan *p, const orc_mesh *m, int src_kind, const double *par, const double *table, double t, double *b, int nthreads);
 int orc_assemble_source(const orc_mesh *m, int src_kind, const double *p, const double *table,
                         double t, double *b, int nthreads);
 

@@ -11,13 +11,13 @@ for mb in mfma_f64 mfma_f64_4x4 lds_atomic wg_launch mall_reuse; do
   [ -f scripts/microbench/$mb.hip ] && hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics scripts/microbench/$mb.hip -o scripts/microbench/$mb.bin 2>/dev/null
 done
 python3 bench.py > "$out/bench_216.json" 2> "$out/bench_216.err"
-rocprofv3 --kernel-trace --stats -d "$out/kt" -o kt -- python3 bench.py --no-cpu-baseline > "$out/bench_under_rocprof.json" 2>/dev/null
+rocprofv3 --kernel-trace --stats -d "$out/kt" -o kt -- python3 bench.py --no-cpu-baseline --no-slab-sweep > "$out/bench_under_rocprof.json" 2>/dev/null
 python3 scripts/rocpd_summary.py "$out/kt/kt_results.db" --json "$out/kernel_stats.json" > "$out/kernel_stats.txt"
 i=0
 for grp in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum" "WRITE_SIZE" "FETCH_SIZE" \
            "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp -d "$out/pmc$i" -o pmc -- python3 bench.py --no-cpu-baseline --steps 5 > /dev/null 2>&1
+  rocprofv3 --pmc $grp -d "$out/pmc$i" -o pmc -- python3 bench.py --no-cpu-baseline --no-slab-sweep --steps 5 > /dev/null 2>&1
   python3 scripts/rocpd_summary.py "$out/pmc$i/pmc_results.db" --json "$out/pmc$i.json" > /dev/null
 done
 python3 scripts/make_traffic_json.py "$out" "$tag" > "$out/traffic.json"
@@ -34,10 +34,15 @@ if [ "$2" != "bench-only" ]; then
   [ -x scripts/microbench/lds_atomic.bin ] && ./scripts/microbench/lds_atomic.bin > "$out/lds_atomic_microbench.txt" 2>&1
   [ -x scripts/microbench/mfma_f64_4x4.bin ] && ./scripts/microbench/mfma_f64_4x4.bin > "$out/mfma_f64_4x4_microbench.txt" 2>&1
   python3 scripts/bench_tets.py --n 100 > "$out/tets_100.json" 2>/dev/null
+  # coupled electromechanics on the ideal LV (config 5 as two kernel rates)
+  python3 scripts/bench_electromechanics.py > "$out/electromechanics_lv.json" 2>/dev/null
+  # the 27-layer slab of the strong-scaling split, kernel trace
+  rocprofv3 --kernel-trace --stats -d "$out/kt27" -o kt27 -- python3 bench.py --no-cpu-baseline --layers 27 --steps 50 > /dev/null 2>&1
+  python3 scripts/rocpd_summary.py "$out/kt27/kt27_results.db" --json "$out/slab27_kernel_stats.json" > "$out/slab27_kernel_stats.txt"
   # scalar forms on the quadratic field
   python3 scripts/bench_q2_scalar.py --n 64 > "$out/q2_scalar_64.json" 2>/dev/null
   rocprofv3 --kernel-trace --stats -d "$out/ktq" -o ktq -- python3 scripts/bench_q2_scalar.py --n 64 --strategies element > /dev/null 2>&1
   python3 scripts/rocpd_summary.py "$out/ktq/ktq_results.db" --json "$out/q2_scalar_kernel_stats.json" > "$out/q2_scalar_kernel_stats.txt"
 fi
-rm -rf "$out"/kt "$out"/pmc1 "$out"/pmc2 "$out"/pmc3 "$out"/pmc4 "$out"/ktm "$out"/kte "$out"/ktq
+rm -rf "$out"/kt27 "$out"/kt "$out"/pmc1 "$out"/pmc2 "$out"/pmc3 "$out"/pmc4 "$out"/ktm "$out"/kte "$out"/ktq
 tail -c 700 "$out/bench_216.json"; head -6 "$out/kernel_stats.txt"; cat "$out/traffic.json" | head -30

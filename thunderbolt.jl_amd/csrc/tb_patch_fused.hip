@@ -365,7 +365,7 @@ k_patch_hex8_staged(FormArgs faK, FormArgs faM, FusedView pv, const uint4 *__res
 // Write-out: a half-wave reads ALL its row descriptors, then ALL its accumulators, then stores (one dependent LDS round instead of five).
 template <bool WK, bool WM, bool DIAG, int RPH>
 __global__ void __launch_bounds__(256, 2)
-k_patch_hex8_record(FormArgs faK, FormArgs faM, const uint8_t *__restrict__ rec, int stride, int nem, int rm, int nm, int kcap, const uint8_t *__restrict__ sigtab, int pf, int prio,
+k_patch_hex8_record(FormArgs faK, FormArgs faM, const uint8_t *__restrict__ rec, int stride, int nem, int rm, int nm, int kcap, const uint8_t *__restrict__ sigtab, int pf, int prio, int stagger,
                     double *__restrict__ nzK, double *__restrict__ nzM, Status *st
 #ifdef TB_ABLATION
                     , long long *prof
@@ -385,6 +385,10 @@ k_patch_hex8_record(FormArgs faK, FormArgs faM, const uint8_t *__restrict__ rec,
     // CU a wave in its staging or write-out phase shares its SIMD with a wave of the other workgroup that may be integrating: raised priority lets
     // the short phase issue its loads / stores at once instead of waiting behind the other wave's arithmetic (TB_PATCH_PRIO=0 switches it off)
     if (prio) __builtin_amdgcn_s_setprio(3);
+    // first generation only: the second workgroup of every CU (blocks 256…511 under round-robin dispatch) starts `stagger` × 64 cycles late, so that the
+    // two residents of a CU run their integration phases in turn instead of together (uniform patches keep the offset once it is there)
+    if (stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
+        for (int k = 0; k < stagger; k += 100) __builtin_amdgcn_s_sleep(100);
     const uint8_t *r = rec + (size_t)blockIdx.x * (size_t)stride;
     const uint32_t hw = ((const uint4 *)r)->x; // wave-uniform address: a scalar load, consumed only behind the vector loads below
     uint32_t pfv = 0;
@@ -557,7 +561,8 @@ int launch_assemble_hex8_patch(tb_form *fK, tb_form *fM, tb_pattern *p, double t
     const bool diag = fK && !fk && aK.D[1] == 0.0 && aK.D[2] == 0.0 && aK.D[5] == 0.0 && aK.D[3] == 0.0 && aK.D[6] == 0.0 && aK.D[7] == 0.0;
     // one-trip record kernel: constant coefficients, patches of ≤ 256 instances (TB_PATCH_KERNEL=staged keeps the two-trip kernel for A/B runs)
     static const bool no_record = getenv("TB_PATCH_KERNEL") && strcmp(getenv("TB_PATCH_KERNEL"), "record") != 0;
-    static const int wave_prio = getenv("TB_PATCH_PRIO") ? atoi(getenv("TB_PATCH_PRIO")) : 1;
+    static const int wave_prio = getenv("TB_PATCH_PRIO") ? atoi(getenv("TB_PATCH_PRIO")) : 0; // measured: no effect (1.7007 vs 1.6997 ms)
+    static const int stagger = getenv("TB_PATCH_STAGGER") ? atoi(getenv("TB_PATCH_STAGGER")) : 0;
     static const int pf_ahead = getenv("TB_PATCH_PREFETCH") ? atoi(getenv("TB_PATCH_PREFETCH")) : 0; // look-ahead distance in patches; measured at 216³: 0 → 1.94 ms, 512 → 2.03, 1024 → 2.02, 2048 → 2.05 (off by default)
     if (staged && !no_record && !fk && !fm && ensure_patch_records(p) == TB_OK) {
         PatchFusedPlan *pr = p->patch_fused.get();
@@ -568,10 +573,10 @@ int launch_assemble_hex8_patch(tb_form *fK, tb_form *fM, tb_pattern *p, double t
                 TB_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr));
 #ifdef TB_ABLATION
                 hipLaunchKernelGGL(k, dim3((unsigned)pp->n_patches), dim3(256), ldsr, dev->stream, aK, aM, (const uint8_t *)pr->d_rec, pr->rec_stride, pr->rec_ne, pr->rec_rm, pr->rec_nm, pv.kcap,
-                                   (const uint8_t *)pf->d_sigtab, pf_ahead, wave_prio, d_nzK, d_nzM, dev->d_status, d_prof);
+                                   (const uint8_t *)pf->d_sigtab, pf_ahead, wave_prio, stagger, d_nzK, d_nzM, dev->d_status, d_prof);
 #else
                 hipLaunchKernelGGL(k, dim3((unsigned)pp->n_patches), dim3(256), ldsr, dev->stream, aK, aM, (const uint8_t *)pr->d_rec, pr->rec_stride, pr->rec_ne, pr->rec_rm, pr->rec_nm, pv.kcap,
-                                   (const uint8_t *)pf->d_sigtab, pf_ahead, wave_prio, d_nzK, d_nzM, dev->d_status);
+                                   (const uint8_t *)pf->d_sigtab, pf_ahead, wave_prio, stagger, d_nzK, d_nzM, dev->d_status);
 #endif
                 return TB_OK;
             };
