@@ -345,7 +345,7 @@ def main():
             rs_ = self.b.clone() + 1.0
             ps_ = cg.dinv * rs_
             Ap_ = torch.empty_like(xs_)
-            S_ = torch.zeros(5, dtype=torch.float64, device="cuda")
+            S_ = torch.zeros(6, dtype=torch.float64, device="cuda")
             tb._lib.check(tb.lib().tb_cgd_dot(dev.h, npts, cg.w.data_ptr(), rs_.data_ptr(), ps_.data_ptr(), S_[0:1].data_ptr()))
             if world_ > 1:
                 tb.distributed.all_reduce_sum(S_[0:1], dist_)

@@ -482,7 +482,8 @@ end
 function mul_dot!(y::HIPVector{Float64}, A::HIPSparseMatrixCSR{Float64}, x::HIPVector{Float64}, xy::HIPVector{Float64})
     check(ccall((:tb_spmv_csr_dot, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), A.ddh.pattern, A.nzval.ptr, x.ptr, y.ptr, xy.ptr))
 end
-# the vector work of one CG iteration with device-resident scalars S = (rz, pAp, rz_new, rr, flag); the caller all-reduces S[2] and S[3:4] in between
+# the vector work of one CG iteration with device-resident scalars S = (rz, pAp, rz_new, rr, flag, rr of the last finished iteration) — six doubles; the
+# caller all-reduces S[2] and S[3:4] in between and ends the iteration with cgd_rotate! (rz ← rz_new, rr → S[6], accumulators zeroed)
 function cgd_dot!(S::HIPVector{Float64}, slot::Int, w::HIPVector{Float64}, a::HIPVector{Float64}, b::HIPVector{Float64})
     check(ccall((:tb_cgd_dot, libtbhip), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), a.dev.handle, a.n, w.ptr, a.ptr, b.ptr, S.ptr + 8 * slot))
 end
@@ -492,6 +493,9 @@ function cgd_update!(S::HIPVector{Float64}, w::HIPVector{Float64}, dinv::HIPVect
 end
 function cgd_direction!(S::HIPVector{Float64}, dinv::HIPVector{Float64}, r::HIPVector{Float64}, p::HIPVector{Float64})
     check(ccall((:tb_cgd_direction, libtbhip), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), r.dev.handle, r.n, dinv.ptr, r.ptr, p.ptr, S.ptr, S.ptr + 16))
+end
+function cgd_rotate!(S::HIPVector{Float64})
+    check(ccall((:tb_cgd_rotate, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Float64}), S.dev.handle, S.ptr))
 end
 
 end # module

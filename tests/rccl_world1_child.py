@@ -86,22 +86,24 @@ def main():
     cg = D.DistributedCG(None, diag, None, None, 0, 2, dist, neighbours=nb, device=dev, operator=(K.pattern, A))   # world_size=2 switches the all-reduce branches on
     p = torch.from_numpy(np.cos(np.arange(dh.ndofs) * 0.37)).cuda()
     Ap = torch.empty_like(p)
-    S5 = torch.zeros(5, dtype=torch.float64, device="cuda")
+    S5 = torch.zeros(6, dtype=torch.float64, device="cuda")
     cg.device_iteration(p, Ap, S5)
+    pAp_dev = float(S5[1].item())
+    S5.zero_()
     ref = torch.empty_like(p)
     tb._lib.check(tb.lib().tb_spmv_csr(K.pattern.h, A.ptr, p.data_ptr(), 1.0, 0.0, ref.data_ptr()))
     pAp_ref = float((p * ref).sum().item())
     ref2 = ref.clone(); ref2[lo] += ref[lo]; ref2[up] += ref[up]
     torch.cuda.synchronize()
     res["cg_product_err"] = float((Ap - ref2).abs().max() / ref2.abs().max())
-    res["cg_pAp_rel_err"] = abs(float(S5[1].item()) - pAp_ref) / abs(pAp_ref)
+    res["cg_pAp_rel_err"] = abs(pAp_dev - pAp_ref) / abs(pAp_ref)
     x = torch.zeros_like(p); r = b0.clone() + 1.0; pp = cg.dinv * r
     tb._lib.check(tb.lib().tb_cgd_dot(dev.h, dh.ndofs, cg.w.data_ptr(), r.data_ptr(), pp.data_ptr(), S5[0:1].data_ptr()))
     D.all_reduce_sum(S5[0:1], dist)
     rr = []
     for _ in range(3):
         cg.device_step(x, r, pp, Ap, S5)
-        rr.append(float(S5[3].item()))
+        rr.append(float(S5[5].item()))
     res["cg_steps_rr"] = rr
     res["cg_steps_finite_and_flag_clear"] = bool(np.all(np.isfinite(rr))) and float(S5[4].item()) == 0.0
     dist.barrier()

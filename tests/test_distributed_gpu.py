@@ -115,7 +115,7 @@ def _worker(rank, world, port, q):
     u2, its2, rn2 = cg2.solve(rhs, x.clone(), rtol=1e-13, atol=1e-15, maxiter=400)
     # one product of each form on the same vector: the overlapped form packs rows computed by another kernel (summation order within a row
     # differs from the stream SpMV's), so agreement is to rounding, not bitwise
-    S = torch.zeros(5, dtype=torch.float64, device="cuda")
+    S = torch.zeros(6, dtype=torch.float64, device="cuda")
     Ap1, Ap2 = torch.empty_like(x), torch.empty_like(x)
     cg.device_iteration(x, Ap1, S)
     pAp1 = float(S[1].item()); S.zero_()

@@ -141,6 +141,7 @@ SIGNATURES = {
     "tb_cgd_dot": (C.c_int, [vp, C.c_int64, vp, vp, vp, vp]),
     "tb_cgd_update": (C.c_int, [vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "tb_cgd_direction": (C.c_int, [vp, C.c_int64, vp, vp, vp, vp, vp]),
+    "tb_cgd_rotate": (C.c_int, [vp, vp]),
     "tb_gather_indexed": (C.c_int, [vp, C.c_int64, vp, vp, vp]),
     "tb_convert_f64_to_f32": (C.c_int, [vp, C.c_int64, vp, vp]),
     "tb_convert_f32_to_f64": (C.c_int, [vp, C.c_int64, vp, vp]),

@@ -1586,6 +1586,19 @@ k_cgd_direction(int64_t n, const double *__restrict__ dinv, const double *__rest
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = (dinv ? dinv[i] * r[i] : r[i]) + beta * p[i];
 }
 
+// end of an iteration: rz ← rz_new, ‖r‖² parked in S[5] for the host's next look, the three accumulators (pAp, rz_new, rr) back to zero — one
+// launch for what would be two copies and a fill
+__global__ void k_cgd_rotate(double *__restrict__ S)
+{
+    if (threadIdx.x == 0) { S[0] = S[2]; S[5] = S[3]; S[1] = 0.0; S[2] = 0.0; S[3] = 0.0; }
+}
+int launch_cgd_rotate(tb_device *dev, double *d_S)
+{
+    hipLaunchKernelGGL(k_cgd_rotate, dim3(1), dim3(64), 0, dev->stream, d_S);
+    TB_HIP(hipGetLastError());
+    return TB_OK;
+}
+
 int launch_cgd_dot(tb_device *dev, int64_t n, const double *w, const double *a, const double *b, double *d_out)
 {
     if (n > 0) hipLaunchKernelGGL(k_cgd_dot, dim3(grid_for(dev, n, 256)), dim3(256), 0, dev->stream, n, w, a, b, d_out);

@@ -1099,6 +1099,13 @@ int tb_cgd_direction(tb_device *dev, int64_t n, const double *d_dinv, const doub
     return launch_cgd_direction(dev, n, d_dinv, d_r, d_p, d_rz, d_rz_new);
 }
 
+int tb_cgd_rotate(tb_device *dev, double *d_S)
+{
+    TB_REQUIRE(dev && d_S, "tb_cgd_rotate: NULL argument");
+    TB_HIP(hipSetDevice(dev->id));
+    return launch_cgd_rotate(dev, d_S);
+}
+
 int tb_extract_diagonal(tb_pattern *pat, const double *d_nzval, double *d_diag)
 {
     TB_REQUIRE(pat && ((d_nzval && d_diag) || pat->n_rows == 0), "tb_extract_diagonal: NULL argument");

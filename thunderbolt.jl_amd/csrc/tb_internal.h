@@ -330,6 +330,7 @@ int ensure_cell_xyz(tb_mesh *m); // tb_assembly.hip: builds tb_mesh::d_cell_xyz 
 int launch_gather_indexed(tb_device *dev, int64_t n, const double *vec, const int32_t *idx, double *out);
 int launch_scatter_add_indexed(tb_device *dev, int64_t n, const double *in, const int32_t *idx, double *vec);
 int read_status_public(tb_device *dev); // status block → host, synchronises the stream (what check_status does when the status is not deferred)
+int launch_cgd_rotate(tb_device *dev, double *d_S);
 int spmv_plans(tb_pattern *p); // builds the plans tb_spmv_csr would build on its first product
 int launch_scatter_indexed(tb_device *dev, int64_t n, const double *in, const int32_t *idx, double *vec);
 int launch_spmv_rows(tb_pattern *p, const double *nz, const double *x, int64_t n, const int32_t *rows, double *out);

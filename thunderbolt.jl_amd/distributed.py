@@ -366,18 +366,18 @@ class DistributedCG:
 
     def device_step(self, x, r, p, Ap, S):
         """One whole CG iteration of the device path, no host read: product + halo + pᵀAp, update of x and r with the two weighted sums, direction.
-        S: device scalars rz | pAp | rz_new | rr | breakdown flag (bench.py times exactly this)."""
+        S: SIX device scalars rz | pAp | rz_new | rr | breakdown flag | ‖r‖² of the last finished step; S[1:4] must be zero on entry (they are after
+        every step: tb_cgd_rotate).  bench.py times exactly this."""
         import ctypes as C
         from ._lib import check, lib
         L, dev, n = lib(), self.dev, x.numel()
         ptr = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-        S[1:4].zero_()
-        self.device_iteration(p, Ap, S)
+        self.device_iteration(p, Ap, S)                              # S[1:4] are zero: set by the caller before the first step, by tb_cgd_rotate after every step
         check(L.tb_cgd_update(dev.h, n, ptr(self.w), ptr(self.dinv), ptr(p), ptr(Ap), ptr(x), ptr(r), ptr(S[0:1]), ptr(S[1:2]), ptr(S[2:5])))
         if self.world > 1:
             all_reduce_sum(S[2:4], self.dist)
         check(L.tb_cgd_direction(dev.h, n, ptr(self.dinv), ptr(r), ptr(p), ptr(S[0:1]), ptr(S[2:3])))
-        S[0:1].copy_(S[2:3])
+        check(L.tb_cgd_rotate(dev.h, ptr(S)))                        # rz ← rz_new, ‖r‖² → S[5], accumulators back to zero: one launch
 
     def _solve_device(self, b, x, rtol, atol, maxiter):
         import ctypes as C
@@ -388,7 +388,7 @@ class DistributedCG:
                                "its kernels would race with the all-reduces and the exchange")
         L = lib()
         ptr = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-        S = torch.zeros(5, dtype=torch.float64, device=x.device)    # rz | pAp | rz_new, rr, breakdown flag  (device-resident scalars)
+        S = torch.zeros(6, dtype=torch.float64, device=x.device)    # rz | pAp | rz_new | rr | breakdown flag | ‖r‖² of the last step  (device-resident scalars)
         Ap = torch.empty_like(x)
         r = b - self.apply(x)
         p = self.dinv * r
@@ -397,15 +397,16 @@ class DistributedCG:
         if self.world > 1:
             all_reduce_sum(S[0:4], dist)
         rn = float(S[3].item()) ** 0.5
+        S[1:4].zero_()
         tol = atol + rtol * rn
         it = 0
         while rn > tol and it < maxiter:
             for _ in range(min(self.look, maxiter - it)):
                 self.device_step(x, r, p, Ap, S)
                 it += 1
-            h = S[3:5].cpu()                                         # the one host read of the look: ‖r‖² and the breakdown flag
-            if float(h[1]) != 0.0:
-                self.breakdown = float(h[1])
+            h = S[4:6].cpu()                                         # the one host read of the look: the breakdown flag and ‖r‖²
+            if float(h[0]) != 0.0:
+                self.breakdown = float(h[0])
                 raise ArithmeticError("DistributedCG: pᵀAp = %g ≤ 0 — the operator is not positive definite (or the iteration broke down)" % self.breakdown)
-            rn = float(h[0]) ** 0.5
+            rn = float(h[1]) ** 0.5
         return x, it, rn
