@@ -27,6 +27,8 @@ struct FormArgs {
     double p0;
     const double *table;
     double t, ct;
+    // constant positive definite tensor D = L·Lᵀ, record kernel: coordinates are mapped by L⁻¹ at staging (row-major Linv), iso_scale = −¼·det L
+    double Linv[9], iso_scale;
 #ifdef TB_ABLATION
     int debug; // profiling builds only (make ABLATION=1 → libtbhip_ablation.so): TB_DEBUG_FLAGS bits 1 skip LDS adds, 2 skip write-out, 4 skip arithmetic
 #endif

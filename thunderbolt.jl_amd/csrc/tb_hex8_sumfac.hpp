@@ -42,8 +42,12 @@ __device__ __forceinline__ double sf_rcp(double y)
 // FENCE: keep the points' instruction streams apart (scheduling barrier after each point) — for per-point tensor loads, which
 // the scheduler would otherwise hoist all at once (48 doubles in flight → spills).
 // DIAG: the tensor is diagonal (D[1] = D[2] = D[4] = 0: isotropic or axis-aligned conductivities) — H = A·D is 9 products instead of 27.
-template <bool WANT_K, bool FENCE, bool DIAG = false, class DFn>
-__device__ __forceinline__ bool hex8_sf_geometry(const double (&x)[8][3], DFn &&Dq, double (&G)[8][6], double (&dq)[8])
+// ISO: the coordinates x were mapped by L⁻¹ of the Cholesky factor D = L·Lᵀ of a constant positive definite tensor before the call: in those
+// coordinates the tensor is the identity (anisotropic diffusion = isotropic diffusion in stretched coordinates), J = L·J′ gives
+// A·D·Aᵀ = det L²·A′A′ᵀ and det J = det L·det J′, so G = −¼·det L/det J′ · A′A′ᵀ with no tensor product at all; `sfac` = −¼·det L (−¼ otherwise),
+// dq returns det J′ (the caller folds det L into the density).
+template <bool WANT_K, bool FENCE, bool DIAG = false, bool ISO = false, class DFn>
+__device__ __forceinline__ bool hex8_sf_geometry(const double (&x)[8][3], DFn &&Dq, double (&G)[8][6], double (&dq)[8], double sfac = -0.25)
 {
     GeoCoeffs<Hex8<2>> gc;
     geo_prepare(x, gc);
@@ -78,10 +82,17 @@ __device__ __forceinline__ bool hex8_sf_geometry(const double (&x)[8][3], DFn &&
         const double det = u[0] * A[0][0] + u[1] * A[0][1] + u[2] * A[0][2];
         ok = ok && (det > 0.0);
         dq[q] = det;
-        if constexpr (WANT_K) {
+        if constexpr (WANT_K && ISO) {
+            const double s = sfac * sf_rcp(det);
+            int k = 0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = a; b < 3; ++b) G[q][k++] = s * (A[a][0] * A[b][0] + A[a][1] * A[b][1] + A[a][2] * A[b][2]);
+        } else if constexpr (WANT_K) {
             double D[6];
             Dq(q, D);
-            const double s = -0.25 * sf_rcp(det);
+            const double s = sfac * sf_rcp(det);
             double H[3][3];
 #pragma unroll
             for (int a = 0; a < 3; ++a) {

@@ -114,7 +114,7 @@ struct PatchFusedPlan {
     uint32_t *d_hdr = nullptr;     // 4 per patch: e0, r0, n0, nrows | nnodes << 10 | ne << 21 (NULL when some count does not fit)
     double *d_pcoord = nullptr;    // 3 per patch node
     // one-trip kernel (k_patch_hex8_record): every input of a patch in ONE record at blockIdx × stride, so no load waits for a header —
-    //   [0,16) counts word {nrows | nnodes << 10 | ne << 21, 0, 0, 0} · rec_ne × 16 B local node indices · rec_ne × 4 B signature ids ·
+    //   [0,16) {nrows | nnodes << 10 | ne << 21, first instance, 0, 0} · rec_ne × 16 B local node indices · rec_ne × 4 B signature ids ·
     //   rec_rm × 16 B row descriptors · rec_nm × 24 B vertex coordinates; zero padding behind the patch's own counts.  Built on first use.
     uint8_t *d_rec = nullptr;
     int rec_stride = 0, rec_rm = 0, rec_nm = 0, rec_ne = 0; // rec_ne: instance slots per record (≥ 256, multiple of 64); rec_stride = −1: the patches do not fit the record form (a patch with more than 256 instances)

@@ -47,7 +47,7 @@ struct FusedView {
 // in the accumulator block or 0xFFFFFFFF when the patch does not own it.
 // meta(cp, ro) delivers the scatter metadata when the scatter starts (the streaming kernel reads them from LDS only then: held from the start, they
 // cost 24 registers through the contraction).
-template <bool WK, bool WM, bool FK, bool FM, bool DIAG = false, class Meta>
+template <bool WK, bool WM, bool FK, bool FM, bool DIAG = false, bool ISO = false, class Meta>
 __device__ __forceinline__ void hex8_instance(const double (&x)[8][3], Meta &&meta, int64_t cell, const FormArgs &faK,
                                               const FormArgs &faM, double *accK, double *accM, Status *st, const int32_t *elem_cell, int64_t e)
 {
@@ -70,7 +70,7 @@ __device__ __forceinline__ void hex8_instance(const double (&x)[8][3], Meta &&me
             for (int q = 0; q < 8; ++q) { dq[q] = x[q][0] + x[q][1] + x[q][2]; for (int k = 0; k < 6; ++k) G[q][k] = dq[q]; }
         } else
 #endif
-        if (!hex8_sf_geometry<WK, false, DIAG>(x, Dq, G, dq)) { st->neg_detj = 1; st->cell = elem_cell[e]; }
+        if (!hex8_sf_geometry<WK, false, DIAG, ISO>(x, Dq, G, dq, ISO ? faK.iso_scale : -0.25)) { st->neg_detj = 1; st->cell = elem_cell ? elem_cell[e] : -1; }
     }
     Hex8SFK c;
     if constexpr (WK) hex8_sf_contract(G, c);
@@ -363,9 +363,11 @@ k_patch_hex8_staged(FormArgs faK, FormArgs faM, FusedView pv, const uint4 *__res
 // 14.2 µs before its first barrier).  A look-ahead (one dword load per lane into the record `pf` patches ahead, so that the next workgroup's trip would end
 // in the cache hierarchy) is built in and measured slower at every distance tried (1.94 → 2.02–2.05 ms): off unless TB_PATCH_PREFETCH is set.
 // Write-out: a half-wave reads ALL its row descriptors, then ALL its accumulators, then stores (one dependent LDS round instead of five).
-template <bool WK, bool WM, bool DIAG, int RPH>
+// KOFF > 0: the mass block sits KOFF entries behind the stiffness block (compile-time: the second add of a pair reuses the first one's address register with
+// an immediate offset); KOFF = 0: `kcap` entries behind it (patches with more than KOFF accumulator entries)
+template <bool WK, bool WM, bool DIAG, bool ISO, int RPH, int KOFF = 0>
 __global__ void __launch_bounds__(256, 2)
-k_patch_hex8_record(FormArgs faK, FormArgs faM, const uint8_t *__restrict__ rec, int stride, int nem, int rm, int nm, int kcap, const uint8_t *__restrict__ sigtab, int pf, int prio, int stagger,
+k_patch_hex8_record(FormArgs faK, FormArgs faM, const uint8_t *__restrict__ rec, int stride, int nem, int rm, int nm, int kcap, const uint8_t *__restrict__ sigtab, const int32_t *__restrict__ elem_cell, int pf, int prio, int stagger,
                     double *__restrict__ nzK, double *__restrict__ nzM, Status *st
 #ifdef TB_ABLATION
                     , long long *prof
@@ -390,32 +392,51 @@ k_patch_hex8_record(FormArgs faK, FormArgs faM, const uint8_t *__restrict__ rec,
     if (stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
         for (int k = 0; k < stagger; k += 100) __builtin_amdgcn_s_sleep(100);
     const uint8_t *r = rec + (size_t)blockIdx.x * (size_t)stride;
-    const uint32_t hw = ((const uint4 *)r)->x; // wave-uniform address: a scalar load, consumed only behind the vector loads below
+    const uint4 h4 = *(const uint4 *)r; // wave-uniform address: a scalar load, consumed only behind the vector loads below
+    const uint32_t hw = h4.x;
     uint32_t pfv = 0;
     if (pf > 0 && blockIdx.x + (unsigned)pf < gridDim.x && tid * 128 < stride) pfv = *(const uint32_t *)(r + (size_t)pf * (size_t)stride + (size_t)tid * 128);
     uint4 lnv = ((const uint4 *)(r + 16))[tid];
     const uint32_t sig = ((const uint32_t *)(r + 16 + (size_t)nem * 16))[tid];
     const uint8_t *rdp = r + 16 + (size_t)nem * 20;
     const double *pc = (const double *)(rdp + (size_t)rm * 16);
-    constexpr int NX = 5;
+    constexpr int NX = ISO ? 6 : 5;
     uint4 rd = make_uint4(0, 0, 0, 0);
     double xc[NX];
     if (tid < rm) rd = ((const uint4 *)rdp)[tid];
+    if constexpr (ISO) { // node-wise: lane t takes nodes t and t + 256 whole, so that it can map them (x′ = L⁻¹x) on their way to LDS
 #pragma unroll
-    for (int j = 0; j < NX; ++j) xc[j] = tid + j * T < 3 * nm ? pc[tid + j * T] : 0.0;
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) xc[3 * j + d] = tid + j * T < nm ? pc[3 * (tid + j * T) + d] : 0.0;
+    } else {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) xc[j] = tid + j * T < 3 * nm ? pc[tid + j * T] : 0.0;
+    }
+    const int kblk = KOFF > 0 ? KOFF : kcap;
     double *accK = lds;
-    double *accM = lds + (WK && WM ? kcap : 0);
-    RowDesc *desc = (RowDesc *)(lds + (WK && WM ? 2 : 1) * kcap);
+    double *accM = lds + (WK && WM ? kblk : 0);
+    RowDesc *desc = (RowDesc *)(lds + (WK && WM ? 2 : 1) * kblk);
     double *xs = (double *)(desc + rm);
     {   // zero both accumulator blocks while the loads travel
         double2 *z = (double2 *)lds;
-        const int n2 = ((WK && WM ? 2 : 1) * kcap) >> 1;
+        const int n2 = ((WK && WM ? 2 : 1) * kblk) >> 1;
         for (int k = tid; k < n2; k += T) z[k] = make_double2(0.0, 0.0);
     }
     if (tid < rm) ((uint4 *)desc)[tid] = rd;
+    if constexpr (ISO) {
+        const double *Li = faK.Linv;
+        auto put = [&](int node, double x0, double x1, double x2) {
+            xs[3 * node] = Li[0] * x0 + Li[1] * x1 + Li[2] * x2; xs[3 * node + 1] = Li[3] * x0 + Li[4] * x1 + Li[5] * x2; xs[3 * node + 2] = Li[6] * x0 + Li[7] * x1 + Li[8] * x2;
+        };
 #pragma unroll
-    for (int j = 0; j < NX; ++j) if (tid + j * T < 3 * nm) xs[tid + j * T] = xc[j];
-    for (int k = tid + NX * T; k < 3 * nm; k += T) xs[k] = pc[k]; // more than 426 nodes per patch
+        for (int j = 0; j < 2; ++j) if (tid + j * T < nm) put(tid + j * T, xc[3 * j], xc[3 * j + 1], xc[3 * j + 2]);
+        for (int k = tid + 2 * T; k < nm; k += T) put(k, pc[3 * k], pc[3 * k + 1], pc[3 * k + 2]); // more than 512 nodes per patch
+    } else {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) if (tid + j * T < 3 * nm) xs[tid + j * T] = xc[j];
+        for (int k = tid + NX * T; k < 3 * nm; k += T) xs[k] = pc[k]; // more than 426 nodes per patch
+    }
     uint4 cp[4];
     {
         const uint4 *cpp = (const uint4 *)(sigtab + (size_t)sig * 64); // padding lanes carry signature 0: a valid read
@@ -444,8 +465,8 @@ k_patch_hex8_record(FormArgs faK, FormArgs faM, const uint8_t *__restrict__ rec,
         uint32_t ro[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) ro[i] = ln[i] < (uint32_t)nrows ? desc[ln[i]].off : 0xFFFFFFFFu;
-        hex8_instance<WK, WM, false, false, DIAG>(x, [&](uint4(&c4)[4], uint32_t(&r8)[8]) { for (int k = 0; k < 4; ++k) c4[k] = cp[k]; for (int k = 0; k < 8; ++k) r8[k] = ro[k]; }, 0, faK, faM, accK, accM, st,
-                                                  (const int32_t *)nullptr, 0);
+        hex8_instance<WK, WM, false, false, DIAG, ISO>(x, [&](uint4(&c4)[4], uint32_t(&r8)[8]) { for (int k = 0; k < 4; ++k) c4[k] = cp[k]; for (int k = 0; k < 8; ++k) r8[k] = ro[k]; }, 0, faK, faM, accK, accM, st,
+                                                  elem_cell, (int64_t)h4.y + ei);
     }
     TB_ST(3);
     __syncthreads();
@@ -566,23 +587,56 @@ int launch_assemble_hex8_patch(tb_form *fK, tb_form *fM, tb_pattern *p, double t
     static const int pf_ahead = getenv("TB_PATCH_PREFETCH") ? atoi(getenv("TB_PATCH_PREFETCH")) : 0; // look-ahead distance in patches; measured at 216³: 0 → 1.94 ms, 512 → 2.03, 1024 → 2.02, 2048 → 2.05 (off by default)
     if (staged && !no_record && !fk && !fm && ensure_patch_records(p) == TB_OK) {
         PatchFusedPlan *pr = p->patch_fused.get();
-        const size_t ldsr = (size_t)nreg * pv.kcap * sizeof(double) + (size_t)pr->rec_rm * sizeof(RowDesc) + (size_t)pr->rec_nm * 3 * sizeof(double);
+        constexpr int KOFF = 4096; // fused pair: mass block at a fixed distance when it fits (150 rows of 27 entries = 4 050)
+        const bool fixm = fK && fM && pv.kcap <= KOFF &&
+                          (size_t)2 * KOFF * sizeof(double) + (size_t)pr->rec_rm * sizeof(RowDesc) + (size_t)pr->rec_nm * 3 * sizeof(double) <= 80 * 1024;
+        const size_t ldsr = (size_t)nreg * (fixm ? KOFF : pv.kcap) * sizeof(double) + (size_t)pr->rec_rm * sizeof(RowDesc) + (size_t)pr->rec_nm * 3 * sizeof(double);
         if (ldsr <= 80 * 1024) {
             constexpr int RPH = 20; // rows per half-wave kept in registers at write-out (160 rows per patch; more take the loop)
+            // constant positive definite tensor: D = L·Lᵀ, the kernel integrates in the coordinates x′ = L⁻¹x where the tensor is the identity
+            // (TB_PATCH_ISO=0 keeps the tensor products for A/B runs); anything else — indefinite, or the switch — takes the DIAG / general instances
+            static const bool iso_on = !(getenv("TB_PATCH_ISO") && atoi(getenv("TB_PATCH_ISO")) == 0);
+            bool iso = false;
+            FormArgs aMi = aM;
+            if (fK && iso_on) {
+                const double *D = aK.D;
+                double L[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+                bool pd = D[1] == D[3] && D[2] == D[6] && D[5] == D[7];
+                for (int i = 0; i < 3 && pd; ++i)
+                    for (int j = 0; j <= i; ++j) {
+                        double sum = D[3 * i + j];
+                        for (int k2 = 0; k2 < j; ++k2) sum -= L[i][k2] * L[j][k2];
+                        if (i == j) { if (!(sum > 0.0)) { pd = false; break; } L[i][i] = std::sqrt(sum); }
+                        else L[i][j] = sum / L[j][j];
+                    }
+                if (pd) {
+                    double Li[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}; // inverse of the lower triangle
+                    for (int i = 0; i < 3; ++i) {
+                        Li[i][i] = 1.0 / L[i][i];
+                        for (int j = 0; j < i; ++j) { double sum = 0.0; for (int k2 = j; k2 < i; ++k2) sum -= L[i][k2] * Li[k2][j]; Li[i][j] = sum / L[i][i]; }
+                    }
+                    const double detL = L[0][0] * L[1][1] * L[2][2];
+                    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) aK.Linv[3 * i + j] = Li[i][j];
+                    aK.iso_scale = -0.25 * detL;
+                    aMi.rho = aM.rho * detL; // the kernel's determinants are those of the mapped coordinates: det J = det L · det J′
+                    iso = true;
+                }
+            }
             auto launch_rec = [&](auto k) -> int {
                 TB_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr));
 #ifdef TB_ABLATION
-                hipLaunchKernelGGL(k, dim3((unsigned)pp->n_patches), dim3(256), ldsr, dev->stream, aK, aM, (const uint8_t *)pr->d_rec, pr->rec_stride, pr->rec_ne, pr->rec_rm, pr->rec_nm, pv.kcap,
-                                   (const uint8_t *)pf->d_sigtab, pf_ahead, wave_prio, stagger, d_nzK, d_nzM, dev->d_status, d_prof);
+                hipLaunchKernelGGL(k, dim3((unsigned)pp->n_patches), dim3(256), ldsr, dev->stream, aK, aMi, (const uint8_t *)pr->d_rec, pr->rec_stride, pr->rec_ne, pr->rec_rm, pr->rec_nm, pv.kcap,
+                                   (const uint8_t *)pf->d_sigtab, pp->d_elem_cell, pf_ahead, wave_prio, stagger, d_nzK, d_nzM, dev->d_status, d_prof);
 #else
-                hipLaunchKernelGGL(k, dim3((unsigned)pp->n_patches), dim3(256), ldsr, dev->stream, aK, aM, (const uint8_t *)pr->d_rec, pr->rec_stride, pr->rec_ne, pr->rec_rm, pr->rec_nm, pv.kcap,
-                                   (const uint8_t *)pf->d_sigtab, pf_ahead, wave_prio, stagger, d_nzK, d_nzM, dev->d_status);
+                hipLaunchKernelGGL(k, dim3((unsigned)pp->n_patches), dim3(256), ldsr, dev->stream, aK, aMi, (const uint8_t *)pr->d_rec, pr->rec_stride, pr->rec_ne, pr->rec_rm, pr->rec_nm, pv.kcap,
+                                   (const uint8_t *)pf->d_sigtab, pp->d_elem_cell, pf_ahead, wave_prio, stagger, d_nzK, d_nzM, dev->d_status);
 #endif
                 return TB_OK;
             };
-            if (fK && fM) rc = diag ? launch_rec(k_patch_hex8_record<true, true, true, RPH>) : launch_rec(k_patch_hex8_record<true, true, false, RPH>);
-            else if (fK) rc = diag ? launch_rec(k_patch_hex8_record<true, false, true, RPH>) : launch_rec(k_patch_hex8_record<true, false, false, RPH>);
-            else rc = launch_rec(k_patch_hex8_record<false, true, false, RPH>);
+            if (fK && fM && fixm) rc = iso ? launch_rec(k_patch_hex8_record<true, true, false, true, RPH, KOFF>) : diag ? launch_rec(k_patch_hex8_record<true, true, true, false, RPH, KOFF>) : launch_rec(k_patch_hex8_record<true, true, false, false, RPH, KOFF>);
+            else if (fK && fM) rc = iso ? launch_rec(k_patch_hex8_record<true, true, false, true, RPH>) : diag ? launch_rec(k_patch_hex8_record<true, true, true, false, RPH>) : launch_rec(k_patch_hex8_record<true, true, false, false, RPH>);
+            else if (fK) rc = iso ? launch_rec(k_patch_hex8_record<true, false, false, true, RPH>) : diag ? launch_rec(k_patch_hex8_record<true, false, true, false, RPH>) : launch_rec(k_patch_hex8_record<true, false, false, false, RPH>);
+            else rc = launch_rec(k_patch_hex8_record<false, true, false, false, RPH>);
             if (rc) return rc;
             TB_HIP(hipGetLastError());
             goto done;

@@ -712,7 +712,7 @@ int ensure_patch_records(tb_pattern *p)
         uint8_t *r = &rec[stride * (size_t)q];
         const uint32_t e0 = hdr[4 * q], r0 = hdr[4 * q + 1], n0 = hdr[4 * q + 2], w = hdr[4 * q + 3];
         const uint32_t nr = w & 0x3ff, nn = (w >> 10) & 0x7ff, ne = w >> 21;
-        const uint32_t h4[4] = {w, 0, 0, 0};
+        const uint32_t h4[4] = {w, e0, 0, 0}; // e0: first instance of the patch in the plan's instance arrays (the kernel names the offending cell through it)
         memcpy(r, h4, 16);
         memcpy(r + o_ln, &ln[(size_t)e0 * 8], (size_t)ne * 16);
         memcpy(r + o_sig, &sig[e0], (size_t)ne * 4);
