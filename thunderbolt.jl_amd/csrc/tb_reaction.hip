@@ -256,10 +256,11 @@ template <> struct CellModel<TB_CELL_ORD11> {
         double rate[NS];
         rhs_rates(P, u, t, du, rate);
     }
-    __device__ __forceinline__ static void rhs_rates(const CellParams &P, const double (&u)[NS], double, double (&du)[NS], double (&rate)[NS])
+    // The right-hand side in two parts, so that a kernel can retire the 13 non-gate states before it touches the dynamics of the 28 gates (below):
+    // currents(): everything that reads gate VALUES — the currents, fluxes and the rates of V, the concentrations, nca, Jrel and CaMK (du[0…8], du[30],
+    // du[38…40]); gates(): steady states and rate constants of the gates as functions of V alone, handed one by one to `emit(k, y∞, 1/τ)`.
+    __device__ __forceinline__ static void currents(const CellParams &P, const double (&u)[NS], double (&du)[NS])
     {
-#pragma unroll
-        for (int k = 0; k < NS; ++k) rate[k] = 0.0;
         const double *p = P.p;
         const double nao = p[13], cao = p[14], ko = p[15];
         const int celltype = (int)p[16];
@@ -282,48 +283,20 @@ template <> struct CellModel<TB_CELL_ORD11> {
         const double vg = fabs(v) < 1e-7 ? 1e-7 : v; // the constant-field fluxes divide by e^{zVF/RT} − 1: V = 0 exactly is moved by 10⁻⁷ mV (as in the oracle)
         const double vfrt = vg * FRT, vffrt = vfrt * F;
         // INa
-        const double mss = sg(-(v + 39.57) * (1.0 / 9.871));
-        const double tm_r = 6.765 * exp_b((v + 11.64) * (1.0 / 34.77)) + 8.552 * exp_b(-(v + 77.42) * (1.0 / 5.955)); // 1/τ_m
-        const double hss = sg((v + 82.90) * (1.0 / 6.086));
-        const double thf_r = 1.432e-5 * exp_b(-(v + 1.196) * (1.0 / 6.285)) + 6.149 * exp_b((v + 0.5096) * (1.0 / 20.27));
-        const double ths_r = 0.009794 * exp_b(-(v + 17.95) * (1.0 / 28.05)) + 0.3343 * exp_b((v + 5.730) * (1.0 / 56.66));
         constexpr double Ahf = 0.99, Ahs = 1.0 - Ahf;
         const double h = Ahf * hf + Ahs * hs;
-        const double tj = 2.038 + rcp_b(0.02136 * exp_b(-(v + 100.6) * (1.0 / 8.281)) + 0.3052 * exp_b((v + 0.9941) * (1.0 / 38.45)));
-        const double hssp = sg((v + 89.1) * (1.0 / 6.086));
         const double hp = Ahf * hf + Ahs * hsp;
         const double INa = 75.0 * p[0] * (v - ENa) * m * m * m * (fnp * h * j + fpa * hp * jp);
         // INaL
-        const double mLss = sg(-(v + 42.85) * (1.0 / 5.264));
-        const double hLss = sg((v + 87.61) * (1.0 / 7.488)), hLssp = sg((v + 93.81) * (1.0 / 7.488));
         const double INaL = 0.0075 * p[1] * (celltype == 1 ? 0.6 : 1.0) * (v - ENa) * mL * (fnp * hL + fpa * hLp);
         // Ito
-        const double ass = sg(-(v - 14.34) * (1.0 / 14.82));
-        const double ta = 1.0515 * rcp_b(sg(-(v - 18.4099) * (1.0 / 29.3814)) * (1.0 / 1.2089) + 3.5 * sg((v + 100.0) * (1.0 / 29.3814)));
-        const double iss = sg((v + 43.94) * (1.0 / 5.711));
-        const double delta_epi = celltype == 1 ? 1.0 - 0.95 * sg((v + 70.0) * (1.0 / 5.0)) : 1.0;
-        const double tiF = (4.562 + rcp_b(0.3933 * exp_b(-(v + 100.0) * (1.0 / 100.0)) + 0.08004 * exp_b((v + 50.0) * (1.0 / 16.59)))) * delta_epi;
-        const double tiS = (23.62 + rcp_b(0.001416 * exp_b(-(v + 96.52) * (1.0 / 59.05)) + 1.780e-8 * exp_b((v + 114.1) * (1.0 / 8.079)))) * delta_epi;
         const double AiF = sg((v - 213.6) * (1.0 / 151.2)), AiS = 1.0 - AiF;
         const double i_ = AiF * iF + AiS * iS;
-        const double assp = sg(-(v - 24.34) * (1.0 / 14.82));
-        const double dti_develop = 1.354 + 1.0e-4 * rcp_b(exp_b((v - 167.4) * (1.0 / 15.89)) + exp_b(-(v - 12.23) * (1.0 / 0.2154)));
-        const double dti_recover = 1.0 - 0.5 * sg((v + 70.0) * (1.0 / 20.0));
-        const double tiFp = dti_develop * dti_recover * tiF, tiSp = dti_develop * dti_recover * tiS;
         const double ip = AiF * iFp + AiS * iSp;
         const double Ito = 0.02 * p[2] * (celltype == 0 ? 1.0 : 4.0) * (v - EK) * (fnp * a * i_ + fpa * ap * ip);
         // ICaL, ICaNa, ICaK
-        const double dss = sg(-(v + 3.940) * (1.0 / 4.230));
-        const double td = 0.6 + rcp_b(exp_b(-0.05 * (v + 6.0)) + exp_b(0.09 * (v + 14.0)));
-        const double fss = sg((v + 19.58) * (1.0 / 3.696));
-        const double e20 = exp_b((v + 20.0) * (1.0 / 10.0));
-        const double tff = 7.0 + rcp_b(0.0045 * rcp_b(e20) + 0.0045 * e20);
-        const double tfs = 1000.0 + rcp_b(0.000035 * exp_b(-(v + 5.0) * (1.0 / 4.0)) + 0.000035 * exp_b((v + 5.0) * (1.0 / 6.0)));
         constexpr double Aff = 0.6, Afs = 1.0 - Aff;
         const double f = Aff * ff + Afs * fs;
-        const double e4 = exp_b((v - 4.0) * (1.0 / 7.0));
-        const double tfcaf = 7.0 + rcp_b(0.04 * rcp_b(e4) + 0.04 * e4);
-        const double tfcas = 100.0 + rcp_b(0.00012 * exp_b(-v * (1.0 / 3.0)) + 0.00012 * exp_b(v * (1.0 / 7.0)));
         const double Afcaf = 0.3 + 0.6 * sg((v - 10.0) * (1.0 / 10.0)), Afcas = 1.0 - Afcaf;
         const double fca = Afcaf * fcaf + Afcas * fcas;
         const double fp = Aff * ffp + Afs * fs;
@@ -343,22 +316,14 @@ template <> struct CellModel<TB_CELL_ORD11> {
         const double gsum = fnp * PCa * gnp + fpa * PCap * gp; // the permeability ratios PCaNa / PCa, PCaK / PCa are the same for both populations
         const double ICaL = gsum * PhiCaL, ICaNa = 0.00125 * gsum * PhiCaNa, ICaK = 3.574e-4 * gsum * PhiCaK;
         // IKr
-        const double xrss = sg(-(v + 8.337) * (1.0 / 6.789));
-        const double txrf = 12.98 + rcp_b(0.3652 * exp_b((v - 31.66) * (1.0 / 3.869)) + 4.123e-5 * exp_b(-(v - 47.78) * (1.0 / 20.38)));
-        const double txrs = 1.865 + rcp_b(0.06629 * exp_b((v - 34.70) * (1.0 / 7.355)) + 1.128e-5 * exp_b(-(v - 29.74) * (1.0 / 25.94)));
         const double Axrf = sg((v + 54.81) * (1.0 / 38.21)), Axrs = 1.0 - Axrf;
         const double xr = Axrf * xrf + Axrs * xrs;
         const double rkr = sg((v + 55.0) * (1.0 / 75.0)) * sg((v - 10.0) * (1.0 / 30.0));
         const double IKr = 0.046 * p[4] * (celltype == 1 ? 1.3 : celltype == 2 ? 0.8 : 1.0) * sqrt(ko * (1.0 / 5.4)) * xr * rkr * (v - EK);
         // IKs
-        const double xs1ss = sg(-(v + 11.60) * (1.0 / 8.932));
-        const double txs1 = 817.3 + rcp_b(2.326e-4 * exp_b((v + 48.28) * (1.0 / 17.80)) + 0.001292 * exp_b(-(v + 210.0) * (1.0 / 230.0)));
-        const double txs2_r = 0.01 * exp_b((v - 50.0) * (1.0 / 20.0)) + 0.0193 * exp_b(-(v + 66.54) * (1.0 / 31.0));
         const double KsCa = 1.0 + 0.6 * rcp_b(1.0 + exp_b(1.4 * (log(3.8e-5) - log(cai))));
         const double IKs = 0.0034 * p[5] * (celltype == 1 ? 1.4 : 1.0) * KsCa * xs1 * xs2 * (v - EKs);
         // IK1
-        const double xk1ss = sg(-(v + 2.5538 * ko + 144.59) / (1.5692 * ko + 3.8115));
-        const double txk1_r = (exp_b(-(v + 127.2) * (1.0 / 20.36)) + exp_b((v + 236.8) * (1.0 / 69.33))) * (1.0 / 122.2);
         const double rk1 = sg((v + 105.8 - 2.6 * ko) * (1.0 / 9.493));
         const double IK1 = 0.1908 * p[6] * (celltype == 1 ? 1.2 : celltype == 2 ? 1.3 : 1.0) * sqrt(ko) * rk1 * xk1 * (v - EK);
         // INaCa: the same six-state cycle in the myoplasm (80 %) and in the subspace (20 %)
@@ -441,17 +406,67 @@ template <> struct CellModel<TB_CELL_ORD11> {
         du[7] = Jup - Jtr * (vjsr / vnsr);
         const double sj = (kmcsqn + cajsr) * (kmcsqn + cajsr);
         du[8] = sj * rcp_b(sj + csqnmax * kmcsqn) * (Jtr - Jrel);
-        // gates: rate = 1/τ
-        auto gate = [&](int k, double inf, double r) { rate[k] = r; du[k] = (inf - u[k]) * r; };
-        gate(9, mss, tm_r); gate(10, hss, thf_r); gate(11, hss, ths_r);
+    }
+    template <class Emit>
+    __device__ __forceinline__ static void gates(const CellParams &P, double v, Emit &&emit)
+    {
+        const double ko = P.p[15];
+        const int celltype = (int)P.p[16];
+        const double mss = sg(-(v + 39.57) * (1.0 / 9.871));
+        const double tm_r = 6.765 * exp_b((v + 11.64) * (1.0 / 34.77)) + 8.552 * exp_b(-(v + 77.42) * (1.0 / 5.955)); // 1/τ_m
+        const double hss = sg((v + 82.90) * (1.0 / 6.086));
+        const double thf_r = 1.432e-5 * exp_b(-(v + 1.196) * (1.0 / 6.285)) + 6.149 * exp_b((v + 0.5096) * (1.0 / 20.27));
+        const double ths_r = 0.009794 * exp_b(-(v + 17.95) * (1.0 / 28.05)) + 0.3343 * exp_b((v + 5.730) * (1.0 / 56.66));
+        const double tj = 2.038 + rcp_b(0.02136 * exp_b(-(v + 100.6) * (1.0 / 8.281)) + 0.3052 * exp_b((v + 0.9941) * (1.0 / 38.45)));
+        const double hssp = sg((v + 89.1) * (1.0 / 6.086));
+        const double mLss = sg(-(v + 42.85) * (1.0 / 5.264));
+        const double hLss = sg((v + 87.61) * (1.0 / 7.488)), hLssp = sg((v + 93.81) * (1.0 / 7.488));
+        const double ass = sg(-(v - 14.34) * (1.0 / 14.82));
+        const double ta = 1.0515 * rcp_b(sg(-(v - 18.4099) * (1.0 / 29.3814)) * (1.0 / 1.2089) + 3.5 * sg((v + 100.0) * (1.0 / 29.3814)));
+        const double iss = sg((v + 43.94) * (1.0 / 5.711));
+        const double delta_epi = celltype == 1 ? 1.0 - 0.95 * sg((v + 70.0) * (1.0 / 5.0)) : 1.0;
+        const double tiF = (4.562 + rcp_b(0.3933 * exp_b(-(v + 100.0) * (1.0 / 100.0)) + 0.08004 * exp_b((v + 50.0) * (1.0 / 16.59)))) * delta_epi;
+        const double tiS = (23.62 + rcp_b(0.001416 * exp_b(-(v + 96.52) * (1.0 / 59.05)) + 1.780e-8 * exp_b((v + 114.1) * (1.0 / 8.079)))) * delta_epi;
+        const double assp = sg(-(v - 24.34) * (1.0 / 14.82));
+        const double dti_develop = 1.354 + 1.0e-4 * rcp_b(exp_b((v - 167.4) * (1.0 / 15.89)) + exp_b(-(v - 12.23) * (1.0 / 0.2154)));
+        const double dti_recover = 1.0 - 0.5 * sg((v + 70.0) * (1.0 / 20.0));
+        const double tiFp = dti_develop * dti_recover * tiF, tiSp = dti_develop * dti_recover * tiS;
+        const double dss = sg(-(v + 3.940) * (1.0 / 4.230));
+        const double td = 0.6 + rcp_b(exp_b(-0.05 * (v + 6.0)) + exp_b(0.09 * (v + 14.0)));
+        const double fss = sg((v + 19.58) * (1.0 / 3.696));
+        const double e20 = exp_b((v + 20.0) * (1.0 / 10.0));
+        const double tff = 7.0 + rcp_b(0.0045 * rcp_b(e20) + 0.0045 * e20);
+        const double tfs = 1000.0 + rcp_b(0.000035 * exp_b(-(v + 5.0) * (1.0 / 4.0)) + 0.000035 * exp_b((v + 5.0) * (1.0 / 6.0)));
+        const double e4 = exp_b((v - 4.0) * (1.0 / 7.0));
+        const double tfcaf = 7.0 + rcp_b(0.04 * rcp_b(e4) + 0.04 * e4);
+        const double tfcas = 100.0 + rcp_b(0.00012 * exp_b(-v * (1.0 / 3.0)) + 0.00012 * exp_b(v * (1.0 / 7.0)));
+        const double xrss = sg(-(v + 8.337) * (1.0 / 6.789));
+        const double txrf = 12.98 + rcp_b(0.3652 * exp_b((v - 31.66) * (1.0 / 3.869)) + 4.123e-5 * exp_b(-(v - 47.78) * (1.0 / 20.38)));
+        const double txrs = 1.865 + rcp_b(0.06629 * exp_b((v - 34.70) * (1.0 / 7.355)) + 1.128e-5 * exp_b(-(v - 29.74) * (1.0 / 25.94)));
+        const double xs1ss = sg(-(v + 11.60) * (1.0 / 8.932));
+        const double txs1 = 817.3 + rcp_b(2.326e-4 * exp_b((v + 48.28) * (1.0 / 17.80)) + 0.001292 * exp_b(-(v + 210.0) * (1.0 / 230.0)));
+        const double txs2_r = 0.01 * exp_b((v - 50.0) * (1.0 / 20.0)) + 0.0193 * exp_b(-(v + 66.54) * (1.0 / 31.0));
+        const double xk1ss = sg(-(v + 2.5538 * ko + 144.59) / (1.5692 * ko + 3.8115));
+        const double txk1_r = (exp_b(-(v + 127.2) * (1.0 / 20.36)) + exp_b((v + 236.8) * (1.0 / 69.33))) * (1.0 / 122.2);
+        // rate = 1/τ
+        emit(9, mss, tm_r); emit(10, hss, thf_r); emit(11, hss, ths_r);
         const double rtj = rcp_b(tj);
-        gate(12, hss, rtj); gate(13, hssp, ths_r * (1.0 / 3.0)); gate(14, hss, rtj * (1.0 / 1.46));
-        gate(15, mLss, tm_r); gate(16, hLss, 1.0 / 200.0); gate(17, hLssp, 1.0 / 600.0);
+        emit(12, hss, rtj); emit(13, hssp, ths_r * (1.0 / 3.0)); emit(14, hss, rtj * (1.0 / 1.46));
+        emit(15, mLss, tm_r); emit(16, hLss, 1.0 / 200.0); emit(17, hLssp, 1.0 / 600.0);
         const double rta = rcp_b(ta);
-        gate(18, ass, rta); gate(19, iss, rcp_b(tiF)); gate(20, iss, rcp_b(tiS)); gate(21, assp, rta); gate(22, iss, rcp_b(tiFp)); gate(23, iss, rcp_b(tiSp));
-        gate(24, dss, rcp_b(td)); gate(25, fss, rcp_b(tff)); gate(26, fss, rcp_b(tfs)); gate(27, fss, rcp_b(tfcaf)); gate(28, fss, rcp_b(tfcas));
-        gate(29, fss, 1.0 / 75.0); gate(31, fss, rcp_b(tff) * (1.0 / 2.5)); gate(32, fss, rcp_b(tfcaf) * (1.0 / 2.5));
-        gate(33, xrss, rcp_b(txrf)); gate(34, xrss, rcp_b(txrs)); gate(35, xs1ss, rcp_b(txs1)); gate(36, xs1ss, txs2_r); gate(37, xk1ss, txk1_r);
+        emit(18, ass, rta); emit(19, iss, rcp_b(tiF)); emit(20, iss, rcp_b(tiS)); emit(21, assp, rta); emit(22, iss, rcp_b(tiFp)); emit(23, iss, rcp_b(tiSp));
+        emit(24, dss, rcp_b(td)); emit(25, fss, rcp_b(tff)); emit(26, fss, rcp_b(tfs)); emit(27, fss, rcp_b(tfcaf)); emit(28, fss, rcp_b(tfcas));
+        emit(29, fss, 1.0 / 75.0); emit(31, fss, rcp_b(tff) * (1.0 / 2.5)); emit(32, fss, rcp_b(tfcaf) * (1.0 / 2.5));
+        emit(33, xrss, rcp_b(txrf)); emit(34, xrss, rcp_b(txrs)); emit(35, xs1ss, rcp_b(txs1)); emit(36, xs1ss, txs2_r); emit(37, xk1ss, txk1_r);
+    }
+    static constexpr bool SPLIT_FE = true; // forward Euler without sub-steps runs k_reaction_split: non-gate states retired before the gate pass
+    __device__ __forceinline__ static bool is_gate(int k) { return (k >= 9 && k <= 29) || (k >= 31 && k <= 37); }
+    __device__ __forceinline__ static void rhs_rates(const CellParams &P, const double (&u)[NS], double, double (&du)[NS], double (&rate)[NS])
+    {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) rate[k] = 0.0;
+        currents(P, u, du);
+        gates(P, u[0], [&](int k, double inf, double r) { rate[k] = r; du[k] = (inf - u[k]) * r; });
     }
 };
 
@@ -514,6 +529,58 @@ k_reaction(CellParams P, TS *__restrict__ u, TS *__restrict__ du_out, int64_t n,
         if ((threadIdx.x & 63) == 0) {
             const unsigned long long b = (unsigned long long)__double_as_longlong(rm);
             atomicMax(rmax_key, (b >> 63) ? ~b : (b | 0x8000000000000000ull)); // order-preserving key, see tb_algebra.hip
+        }
+    }
+}
+
+// Forward Euler without sub-steps for the models that split their right-hand side (CellModel::SPLIT_FE: O'Hara–Rudy).  k_reaction holds the 41 states, their 41
+// rates and, until the last line of the RHS, the steady states and rate constants of all 28 gates: 408 registers, one wave per SIMD.  Here the non-gate states
+// are advanced and stored as soon as the currents are known, and the gates follow one by one — steady state, rate, new value, store — so that nothing of a gate
+// outlives its own update: two waves per SIMD.  Same expressions as the generic kernel (same parity against the oracle).
+template <class M, class = void> struct splits_fe : std::false_type {};
+template <class M> struct splits_fe<M, std::enable_if_t<M::SPLIT_FE>> : std::true_type {};
+
+template <int MODEL, int LAYOUT, bool WRITE_DU, class TS = double>
+__global__ void __launch_bounds__(256, 2)
+k_reaction_split(CellParams P, TS *__restrict__ u, TS *__restrict__ du_out, int64_t n, double t, double dt, unsigned long long *__restrict__ rmax_key)
+{
+    using M = CellModel<MODEL>;
+    constexpr int NS = M::NS;
+    // 32-bit point index (the launcher checks n·NS < 2³¹): with the state's array as a wave-uniform base, a load or store needs one offset register
+    // instead of a 64-bit address pair per state — 41 pairs were what pushed the state-blocked layout over its register budget
+    const uint32_t stride = gridDim.x * blockDim.x, n32 = (uint32_t)n;
+    double rm = -__builtin_huge_val();
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n32; i += stride) {
+        auto at = [&](TS *base, int j) -> TS * { return LAYOUT == TB_LAYOUT_SOA ? base + (size_t)j * n + i : base + (size_t)i * NS + j; };
+        double ul[NS], dul[NS];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) ul[j] = *at(u, j);
+        const double v_old = ul[M::PHI];
+        M::currents(P, ul, dul);
+        rm = fmax(rm, dul[M::PHI]);
+#pragma unroll
+        for (int j = 0; j < NS; ++j)
+            if (!M::is_gate(j)) {
+                *at(u, j) = (TS)(ul[j] + dt * dul[j]);
+                if (WRITE_DU) *at(du_out, j) = (TS)dul[j];
+            }
+        __builtin_amdgcn_sched_barrier(0); // the gate pass starts here: none of its exponentials is to be hoisted into the current pass
+        // the gate's own value is read again here (from L2 / the Infinity Cache: this point's line was fetched a few microseconds ago) instead of being held
+        // in a register through the current pass
+        M::gates(P, v_old, [&](int j, double inf, double r) {
+            TS *pj = at(u, j);
+            const double uj = (double)__builtin_nontemporal_load(pj);
+            const double d = (inf - uj) * r;
+            *pj = (TS)(uj + dt * d);
+            if (WRITE_DU) *at(du_out, j) = (TS)d;
+        });
+    }
+    if (rmax_key) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) rm = fmax(rm, __shfl_xor(rm, o, 64));
+        if ((threadIdx.x & 63) == 0) {
+            const unsigned long long b = (unsigned long long)__double_as_longlong(rm);
+            atomicMax(rmax_key, (b >> 63) ? ~b : (b | 0x8000000000000000ull));
         }
     }
 }
@@ -589,6 +656,17 @@ static int run(tb_device *dev, const CellParams &P, TS *u, TS *du, int64_t n, in
     const int64_t cap = per_cu > 0 ? (int64_t)dev->n_cu * per_cu : nb;
     if (nb > cap) nb = (nb + (nb + cap - 1) / cap - 1) / ((nb + cap - 1) / cap); // every thread the same number of points (⌈nb / cap⌉ each): a grid cut at `cap` left some threads 2 and most 1 at 1.3 M points
     const dim3 grid((unsigned)nb), block(bs);
+    if constexpr (splits_fe<CellModel<MODEL>>::value) {
+        static const bool no_split = getenv("TB_REACTION_SPLIT") && atoi(getenv("TB_REACTION_SPLIT")) == 0; // A/B switch
+        if (substeps <= 1 && !no_split && n * CellModel<MODEL>::NS < (int64_t)0x7fffffff) {
+#define TB_LAUNCH_S(L, W) hipLaunchKernelGGL((k_reaction_split<MODEL, L, W, TS>), grid, block, 0, dev->stream, P, u, du, n, t, dt, rmax_key)
+            if (layout == TB_LAYOUT_SOA) { if (du) TB_LAUNCH_S(TB_LAYOUT_SOA, true); else TB_LAUNCH_S(TB_LAYOUT_SOA, false); }
+            else { if (du) TB_LAUNCH_S(TB_LAYOUT_AOS, true); else TB_LAUNCH_S(TB_LAYOUT_AOS, false); }
+#undef TB_LAUNCH_S
+            TB_HIP(hipGetLastError());
+            return TB_OK;
+        }
+    }
 #define TB_LAUNCH(L, W) hipLaunchKernelGGL((k_reaction<MODEL, L, W, TS>), grid, block, 0, dev->stream, P, u, du, n, t, dt, substeps, thr, rmax_key, xs, sdim)
     if (layout == TB_LAYOUT_SOA) { if (du) TB_LAUNCH(TB_LAYOUT_SOA, true); else TB_LAUNCH(TB_LAYOUT_SOA, false); }
     else { if (du) TB_LAUNCH(TB_LAYOUT_AOS, true); else TB_LAUNCH(TB_LAYOUT_AOS, false); }
