@@ -536,7 +536,8 @@ k_reaction(CellParams P, TS *__restrict__ u, TS *__restrict__ du_out, int64_t n,
 // Forward Euler without sub-steps for the models that split their right-hand side (CellModel::SPLIT_FE: O'Hara–Rudy).  k_reaction holds the 41 states, their 41
 // rates and, until the last line of the RHS, the steady states and rate constants of all 28 gates: 408 registers, one wave per SIMD.  Here the non-gate states
 // are advanced and stored as soon as the currents are known, and the gates follow one by one — steady state, rate, new value, store — so that nothing of a gate
-// outlives its own update: two waves per SIMD.  Same expressions as the generic kernel (same parity against the oracle).
+// outlives its own update: two waves per SIMD.  Same expressions as the generic kernel (same parity against the oracle).  Measured SLOWER than the generic
+// kernel (1.90 against 1.71 ms at 10.2 M points: the current pass alone still spills 96 B per lane at 256 registers) — kept opt-in, see run<>().
 template <class M, class = void> struct splits_fe : std::false_type {};
 template <class M> struct splits_fe<M, std::enable_if_t<M::SPLIT_FE>> : std::true_type {};
 
@@ -657,7 +658,9 @@ static int run(tb_device *dev, const CellParams &P, TS *u, TS *du, int64_t n, in
     if (nb > cap) nb = (nb + (nb + cap - 1) / cap - 1) / ((nb + cap - 1) / cap); // every thread the same number of points (⌈nb / cap⌉ each): a grid cut at `cap` left some threads 2 and most 1 at 1.3 M points
     const dim3 grid((unsigned)nb), block(bs);
     if constexpr (splits_fe<CellModel<MODEL>>::value) {
-        static const bool no_split = getenv("TB_REACTION_SPLIT") && atoi(getenv("TB_REACTION_SPLIT")) == 0; // A/B switch
+        // measured at 10.2 M points (O'Hara–Rudy, forward Euler): generic kernel 1.71 ms (408 registers, one wave per SIMD, no scratch), split kernel 1.90 ms (two
+        // waves per SIMD, 96 B of scratch per lane and the gates read twice) — parity-green, slower: opt-in (TB_REACTION_SPLIT=1)
+        static const bool no_split = !(getenv("TB_REACTION_SPLIT") && atoi(getenv("TB_REACTION_SPLIT")) == 1);
         if (substeps <= 1 && !no_split && n * CellModel<MODEL>::NS < (int64_t)0x7fffffff) {
 #define TB_LAUNCH_S(L, W) hipLaunchKernelGGL((k_reaction_split<MODEL, L, W, TS>), grid, block, 0, dev->stream, P, u, du, n, t, dt, rmax_key)
             if (layout == TB_LAYOUT_SOA) { if (du) TB_LAUNCH_S(TB_LAYOUT_SOA, true); else TB_LAUNCH_S(TB_LAYOUT_SOA, false); }
