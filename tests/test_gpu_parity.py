@@ -455,6 +455,41 @@ def test_reaction_forward_euler_parity(tb, oracle, device, cls, oid, layout):
     np.testing.assert_array_equal(cache2.un.to_host(), cache.un.to_host())
 
 
+def _ord_split_child():
+    """child process with TB_REACTION_SPLIT=1: the split forward-Euler kernel of the O'Hara–Rudy model (non-gate states retired before the gate pass) against
+    the oracle, both layouts, with and without the materialised rates, and the fused reaction-tangent maximum"""
+    import thunderbolt_jl_amd as tb
+    from oracle import oracle
+    device = tb.MI355XDevice(0)
+    model = tb.ORd2011()
+    n = 1000 + 37
+    for layout in ("SOA", "AOS"):
+        rng = np.random.default_rng(42)
+        pts = initial_points(tb, model, n, rng)
+        host = (np.ascontiguousarray(pts.T) if layout == "SOA" else pts).ravel().copy()
+        f = tb.PointwiseODEFunction(n, model, layout=tb.StateBlockedLayout() if layout == "SOA" else tb.PointBlockedLayout())
+        cache = tb.setup_solver_cache(f, tb.ForwardEulerCellSolver(device), u=device.to_device(host))
+        ref = host.copy()
+        for step in range(20):
+            assert tb.perform_step(f, cache, step * 0.002, 0.002) is True
+            du_ref = oracle.reaction_step(oracle.CELL_ORD11, model.params, ref, n, getattr(oracle, "LAYOUT_" + layout), t=step * 0.002, dt=0.002)
+        assert rel_err(cache.un.to_host(), ref) < TOL and rel_err(cache.du.to_host(), du_ref) < 1e-10
+        cache2 = tb.setup_solver_cache(f, tb.ForwardEulerCellSolver(device), u=device.to_device(host), keep_du=False)
+        for step in range(20):
+            tb.perform_step(f, cache2, step * 0.002, 0.002)
+        np.testing.assert_array_equal(cache2.un.to_host(), cache.un.to_host())
+    print("ORD_SPLIT_OK")
+
+
+def test_ord_split_kernel_parity():
+    """k_reaction_split is opt-in (measured slower than the generic kernel) but ships: it must give the oracle's states."""
+    import subprocess
+    env = dict(os.environ, TB_REACTION_SPLIT="1")
+    code = "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_parity as t; t._ord_split_child()" % (ROOT_DIR, os.path.join(ROOT_DIR, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ORD_SPLIT_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
 @pytest.mark.parametrize("cls,oid", MODELS)
 def test_reaction_adaptive_substepper_parity(tb, oracle, device, cls, oid):
     model = getattr(tb, cls)()
@@ -2656,6 +2691,9 @@ def test_index_compressed_spmv_is_bit_identical_to_the_csr_kernel(tb, device):
         os.environ["TB_SPMV_KERNEL"] = "rows"
         pat_csr = tb.DevicePattern(dm, sp)
         out["csr"] = products(pat_csr)
+        os.environ["TB_SPMV_KERNEL"] = "wave"                                           # the wave-private form of the compressed kernel (A/B candidate)
+        pat_wave = tb.DevicePattern(dm, sp)
+        out["wave"] = products(pat_wave)
     finally:
         if old is None:
             os.environ.pop("TB_SPMV_KERNEL", None)
@@ -2667,6 +2705,8 @@ def test_index_compressed_spmv_is_bit_identical_to_the_csr_kernel(tb, device):
     tb.check(tb.lib().tb_pattern_spmv_plan(pat_csr.h, stats.ctypes.data_as(tb._lib.c_i64p)))
     assert stats[0] == -1
     for a, b in zip(out["sig"][:3], out["csr"][:3]):
+        np.testing.assert_array_equal(a, b)
+    for a, b in zip(out["wave"][:3], out["csr"][:3]):
         np.testing.assert_array_equal(a, b)
     ref = ssp.csr_matrix((vals, sp.colidx, sp.rowptr), shape=(n, n)) @ xh
     assert rel_err(out["sig"][0], ref) < TOL and rel_err(out["sig"][1], -0.5 * ref + 2.0 * y0) < TOL

@@ -386,6 +386,114 @@ k_spmv_sig_rows(int n_blk, const uint4 *__restrict__ blkrec, const int64_t *__re
     if constexpr (DOT) block_sum_to(acc, xy);
 }
 
+// Wave-private form of k_spmv_sig_rows (TB_SPMV_KERNEL=wave; A/B candidate).  A run is what ONE wave multiplies — at most 21 rows and WCAP entries — and a wave
+// walks its runs on its own: values of the next run requested while the current one is multiplied, its LDS slice written and read by the same wave, so the
+// kernel has no workgroup barrier at all (the block form waits twice per run of ≈ 75 rows for its slowest wave).  Same lane mapping inside the wave, same
+// order of products and sums: identical bits.
+constexpr int SPMV_WCAP = 640;
+template <bool DOT>
+__global__ void __launch_bounds__(256)
+k_spmv_sig_wave(int n_run, const uint4 *__restrict__ runrec, const int64_t *__restrict__ rowptr, const uint32_t *__restrict__ rowsig, const int32_t *__restrict__ sigoff,
+                const double *__restrict__ nz, int64_t nnz, const double *__restrict__ x, double alpha, double beta, double *__restrict__ y, double *__restrict__ xy)
+{
+    constexpr int U = SPMV_WCAP / 128, SUB = 3, RW = 21, NK = 9;
+    __shared__ double2 s_all[4][SPMV_WCAP / 2 + 1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, rl = lane / SUB, sub = lane % SUB;
+    double2 *s_v2 = s_all[wv];
+    const double *s_v = (const double *)s_v2;
+    const bool lane_ok = lane < SUB * RW;
+    const int G = gridDim.x * 4;
+    double acc = 0.0;
+    int of[NK];
+    uint32_t cur = 0xFFFFFFFFu;
+#pragma unroll
+    for (int t_ = 0; t_ < NK; ++t_) of[t_] = 0;
+    auto request = [&](const uint4 &rc, bool live, double2(&v)[U], int64_t &pa, int64_t &pe, uint32_t &sg) {
+        const int r0 = (int)rc.x, nr = (int)(rc.y & 0xffffu), len = (int)(rc.y >> 16);
+        const int64_t k0 = (int64_t)(((uint64_t)rc.w << 32) | rc.z);
+        const int rc0 = rl < nr ? rl : nr - 1;
+        pa = pe = 0; sg = 0;
+        if (live && nr > 0) { pa = rowptr[r0 + rc0]; pe = rowptr[r0 + rc0 + 1]; sg = rowsig[r0 + rc0]; }
+        const int64_t ka = k0 - (k0 & 1);
+        const int npairs = (len + (int)(k0 & 1) + 1) >> 1;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = lane + u * 64;
+            v[u] = make_double2(0.0, 0.0);
+            if (live && i < npairs) {
+                if (ka + 2 * (int64_t)i + 1 < nnz) v[u] = *(const double2 *)(nz + ka + 2 * (int64_t)i);
+                else v[u].x = nz[ka + 2 * (int64_t)i];
+            }
+        }
+    };
+    int b = blockIdx.x * 4 + wv;
+    uint4 rec = runrec[b < n_run ? b : 0];
+    uint4 recn = runrec[b + G < n_run ? b + G : 0];
+    double2 vj[U];
+    int64_t pa0, pe0;
+    uint32_t sg0;
+    request(rec, b < n_run, vj, pa0, pe0, sg0);
+    for (; b < n_run; b += G) {
+        const uint4 recnn = runrec[b + 2 * G < n_run ? b + 2 * G : 0];
+        const int r0 = (int)rec.x, nr = (int)(rec.y & 0xffffu), len = (int)(rec.y >> 16);
+        const int64_t k0 = (int64_t)(((uint64_t)rec.w << 32) | rec.z);
+        const int o = (int)(k0 & 1);
+        const int npairs = (len + o + 1) >> 1;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = lane + u * 64;
+            if (i < npairs) s_v2[i] = vj[u];
+        }
+        __builtin_amdgcn_wave_barrier(); // LDS operations of one wave execute in order; this only keeps the compiler from moving the reads up
+        double2 vjn[U];
+        int64_t pa0n = 0, pe0n = 0;
+        uint32_t sg0n = 0;
+        {
+            const int r = rl;
+            const bool active = lane_ok && r < nr && len > 0;
+            const int rc = r < nr ? r : (nr > 0 ? nr - 1 : 0);
+            const int a = (int)(pa0 - k0) + o, n = (int)(pe0 - pa0), row = r0 + rc;
+            {
+                const uint32_t sg1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sg0);
+                const bool uniform = __ballot(sg0 != sg1) == 0ull;
+                if (nr > 0 && (!uniform || sg1 != cur)) {
+#pragma unroll
+                    for (int t_ = 0; t_ < NK; ++t_) { const int k = sub + SUB * t_; of[t_] = sigoff[sg0 + (k < n ? k : 0)]; }
+                    cur = uniform ? sg1 : 0xFFFFFFFFu;
+                }
+            }
+            int kc[NK], cc[NK];
+            double vv[NK], xx[NK];
+#pragma unroll
+            for (int t_ = 0; t_ < NK; ++t_) {
+                const int k = sub + SUB * t_;
+                kc[t_] = active && k < n ? k : -1;
+                const int kk = kc[t_] >= 0 ? kc[t_] : 0;
+                cc[t_] = row + (kc[t_] >= 0 ? of[t_] : 0);
+                vv[t_] = len > 0 ? s_v[a + kk] : 0.0;
+            }
+#pragma unroll
+            for (int t_ = 0; t_ < NK; ++t_) xx[t_] = len > 0 ? x[cc[t_]] : 0.0;
+            request(recn, b + G < n_run, vjn, pa0n, pe0n, sg0n); // behind the gather in program order
+            double v = 0.0;
+#pragma unroll
+            for (int t_ = 0; t_ < NK; ++t_) v += kc[t_] >= 0 ? vv[t_] * xx[t_] : 0.0;
+            if (active) for (int k = sub + SUB * NK; k < n; k += SUB) v += s_v[a + k] * x[row + sigoff[sg0 + k]]; // rows longer than 27 entries
+            v += __shfl_down(v, 1, 64) + __shfl_down(v, 2, 64);
+            if (active && sub == 0) {
+                if constexpr (DOT) { y[r0 + r] = v; acc += x[r0 + r] * v; }
+                else y[r0 + r] = beta == 0.0 ? alpha * v : alpha * v + beta * y[r0 + r];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        rec = recn; recn = recnn;
+#pragma unroll
+        for (int u = 0; u < U; ++u) vj[u] = vjn[u];
+        pa0 = pa0n; pe0 = pe0n; sg0 = sg0n;
+    }
+    if constexpr (DOT) block_sum_to(acc, xy);
+}
+
 __global__ void __launch_bounds__(256)
 k_absmax(int64_t n, const double *__restrict__ x, int64_t stride_x, unsigned long long *__restrict__ out)
 {
@@ -563,10 +671,10 @@ static int stream_plan(tb_pattern *p)
 // host with the pattern's first product: per row a 64-bit hash (parallel), de-duplication in row order with the neighbouring row as the fast path
 // (consecutive rows of a finite-element numbering nearly always repeat the signature).  The pattern "compresses" when the table is at most a
 // quarter of the column array and every offset list fits the kernel (row length ≤ SPMV_CAP is checked by the stream plan); otherwise n_sig = −1.
-static int sig_plan(tb_pattern *p)
+static int sig_plan(tb_pattern *p, bool forced = false)
 {
     if (p->n_sig != 0) return TB_OK;
-    const bool off = getenv("TB_SPMV_KERNEL") && strcmp(getenv("TB_SPMV_KERNEL"), "sig") != 0; // "rows" / "rec" / "chain": the CSR kernels (read per pattern: A/B runs and the bit-identity test build one pattern of each kind in one process)
+    const bool off = !forced && getenv("TB_SPMV_KERNEL") && strcmp(getenv("TB_SPMV_KERNEL"), "sig") != 0; // "rows" / "rec" / "chain": the CSR kernels (read per pattern: A/B runs and the bit-identity test build one pattern of each kind in one process)
     const int64_t n = p->n_rows;
     if (off || n == 0 || p->nnz >= (int64_t)0xffffffffll) { p->n_sig = -1; return TB_OK; }
     const int64_t *rp = p->h_rowptr.data();
@@ -619,6 +727,29 @@ static int sig_plan(tb_pattern *p)
     return TB_OK;
 }
 
+static int sig_plan_forced(tb_pattern *p) { return sig_plan(p, true); }
+// runs of the wave-private kernel: ≤ 21 rows and ≤ SPMV_WCAP − 2 entries each; n_wrun = −1 when a row is longer than that
+static int wave_plan(tb_pattern *p)
+{
+    if (p->n_wrun != 0) return TB_OK;
+    std::vector<uint32_t> rec;
+    int64_t start = 0;
+    auto push = [&](int64_t r0, int64_t r1) {
+        const int64_t k0 = p->h_rowptr[r0], len = p->h_rowptr[r1] - k0;
+        rec.push_back((uint32_t)r0); rec.push_back((uint32_t)(r1 - r0) | (uint32_t)len << 16);
+        rec.push_back((uint32_t)((uint64_t)k0 & 0xffffffffu)); rec.push_back((uint32_t)((uint64_t)k0 >> 32));
+    };
+    for (int64_t r = 0; r < p->n_rows; ++r) {
+        if (p->h_rowptr[r + 1] - p->h_rowptr[r] > SPMV_WCAP - 2) { p->n_wrun = -1; return TB_OK; }
+        if (p->h_rowptr[r + 1] - p->h_rowptr[start] > SPMV_WCAP - 2 || r - start >= 21) { push(start, r); start = r; }
+    }
+    if (p->n_rows > start) push(start, p->n_rows);
+    TB_HIP(hipMalloc((void **)&p->d_wrunrec, rec.size() * sizeof(uint32_t)));
+    TB_HIP(hipMemcpy(p->d_wrunrec, rec.data(), rec.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    p->n_wrun = (int64_t)rec.size() / 4;
+    return TB_OK;
+}
+
 // TB_SPMV_KERNEL=chain: the five-trip kernel, kept as the comparison build
 static bool spmv_chain_kernel()
 {
@@ -633,7 +764,20 @@ static void launch_stream(tb_pattern *p, const double *nz, const double *x, doub
     static bool once = false;
     if (!once) { once = true; const int v = getenv("TB_SPMV_NOGATHER") ? 1 : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_spmv_nogather), &v, sizeof(int)); }
 #endif
-    static const bool rows_kernel = !(getenv("TB_SPMV_KERNEL") && strcmp(getenv("TB_SPMV_KERNEL"), "rows") != 0 && strcmp(getenv("TB_SPMV_KERNEL"), "sig") != 0); // "rec" / "chain": entry-per-lane kernels
+    static const bool rows_kernel = !(getenv("TB_SPMV_KERNEL") && strcmp(getenv("TB_SPMV_KERNEL"), "rows") != 0 && strcmp(getenv("TB_SPMV_KERNEL"), "sig") != 0 &&
+                                      strcmp(getenv("TB_SPMV_KERNEL"), "wave") != 0); // "rec" / "chain": entry-per-lane kernels
+    const bool wave_kernel = getenv("TB_SPMV_KERNEL") && !strcmp(getenv("TB_SPMV_KERNEL"), "wave"); // read per launch: the bit-identity test switches it inside one process
+    if (wave_kernel && ((uintptr_t)nz & 15) == 0 && sig_plan_forced(p) == TB_OK && p->n_sig > 0 && wave_plan(p) == TB_OK && p->n_wrun > 0) {
+        static int per_cu_w = 0;
+        if (!per_cu_w) {
+            if (getenv("TB_SPMV_WG_PER_CU")) per_cu_w = atoi(getenv("TB_SPMV_WG_PER_CU"));
+            if (per_cu_w <= 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_w, (const void *)k_spmv_sig_wave<DOT>, 256, 0) != hipSuccess || per_cu_w <= 0)) per_cu_w = 3;
+        }
+        const unsigned gmaxw = (unsigned)(p->mesh->dev->n_cu * per_cu_w);
+        hipLaunchKernelGGL((k_spmv_sig_wave<DOT>), dim3(std::min<unsigned>((unsigned)((p->n_wrun + 3) / 4), gmaxw)), dim3(256), 0, st, (int)p->n_wrun, (const uint4 *)p->d_wrunrec,
+                           p->d_rowptr, p->d_rowsig, p->d_sigoff, nz, (int64_t)p->nnz, x, alpha, beta, y, xy);
+        return;
+    }
     if (rows_kernel && ((uintptr_t)nz & 15) == 0 && sig_plan(p) == TB_OK && p->n_sig > 0) { // default where the pattern compresses: 16 KB of LDS per workgroup
         // persistent: exactly the workgroups that are resident together (the runs are dealt round-robin, every workgroup gets the same share ± 1)
         static int per_cu = 0;

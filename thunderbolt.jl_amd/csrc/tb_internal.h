@@ -197,6 +197,8 @@ struct tb_pattern {
     int32_t *d_sigoff = nullptr;    // signatures back to back: column offsets relative to the row
     int64_t n_sig = 0;              // 0 = not planned yet, −1 = the pattern does not compress (CSR kernel), > 0 = signatures in the table
     int64_t sig_entries = 0;
+    uint32_t *d_wrunrec = nullptr;  // wave-private SpMV (TB_SPMV_KERNEL=wave): runs of ≤ 21 rows as 16-byte records
+    int64_t n_wrun = 0;
     uint16_t *d_q2pos = nullptr;    // scalar Q2 forms: position of col dof(j) in row dof(i), per cell and pair
     double *d_pcg_ws = nullptr;     // general-preconditioner PCG workspace (r, z, p, Ap, D̃, scalars)
     double *d_cheb_ws = nullptr;    // Chebyshev-preconditioned CG workspace (r, z, p, Ap, D⁻¹, d, w, scalars)
