@@ -386,7 +386,9 @@ k_spmv_sig_rows(int n_blk, const uint4 *__restrict__ blkrec, const int64_t *__re
     if constexpr (DOT) block_sum_to(acc, xy);
 }
 
-// Wave-private form of k_spmv_sig_rows (TB_SPMV_KERNEL=wave; A/B candidate).  A run is what ONE wave multiplies — at most 21 rows and WCAP entries — and a wave
+// Wave-private form of k_spmv_sig_rows (TB_SPMV_KERNEL=wave; measured: 0.668 against 0.682 ms at 216³, 0.112 against 0.098 ms on the 27-layer slab — not the
+// default; with the values requested TWO runs ahead it took 0.857 ms: gfx9 retires vector-memory operations in order, so the wait for a run's gather of x then
+// includes the value loads issued just before it).  A run is what ONE wave multiplies — at most 21 rows and WCAP entries — and a wave
 // walks its runs on its own: values of the next run requested while the current one is multiplied, its LDS slice written and read by the same wave, so the
 // kernel has no workgroup barrier at all (the block form waits twice per run of ≈ 75 rows for its slowest wave).  Same lane mapping inside the wave, same
 // order of products and sums: identical bits.
