@@ -1,10 +1,7 @@
 #!/bin/bash
-# One gpurun call that replays what the driver does at round end, in its order: the GPU tests, smoke(), the bench line.
-#   /usr/local/graft/bin/gpurun --timeout 3000 -- bash scripts/gpu_check.sh
+# the bench line alone, with its wall time (what the driver's clock sees around `python bench.py`)
 mkdir -p gpurun_out
 {
-python3 -m pytest tests -q -m gpu -x 2>&1 | tail -4
-python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
 t0=$SECONDS
 python3 bench.py 2> gpurun_out/gpu_check_bench.err | tail -1 > gpurun_out/gpu_check_bench.json
 echo "bench.py wall $((SECONDS - t0)) s"
@@ -16,5 +13,5 @@ print('cg', d['cg_iterations_per_s'], d['distributed_cg']['local_spmv_ms'])
 for k,v in d['slab_sweep']['layers'].items(): print('  ', k, {a:(round(b,4) if isinstance(b,float) else b) for a,b in v.items() if a!='phase_ms'})
 print({k:{a:round(b) for a,b in v.items() if a.endswith('per_s')} for k,v in d['cpu_baseline']['table'].items()}, d['cpu_baseline']['physical_cores'])
 PY
-} > gpurun_out/gpu_check.log 2>&1
-tail -c 6000 gpurun_out/gpu_check.log
+} > gpurun_out/gpu_bench_only.log 2>&1
+tail -c 5000 gpurun_out/gpu_bench_only.log

@@ -373,7 +373,8 @@ class DistributedCG:
         L, dev, n = lib(), self.dev, x.numel()
         ptr = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
         self.device_iteration(p, Ap, S)                              # S[1:4] are zero: set by the caller before the first step, by tb_cgd_rotate after every step
-        check(L.tb_cgd_update(dev.h, n, ptr(self.w), ptr(self.dinv), ptr(p), ptr(Ap), ptr(x), ptr(r), ptr(S[0:1]), ptr(S[1:2]), ptr(S[2:5])))
+        w = ptr(self.w) if self.nb else None                         # no shared dofs (one rank, or an isolated part): every weight is 1, the kernel skips the read
+        check(L.tb_cgd_update(dev.h, n, w, ptr(self.dinv), ptr(p), ptr(Ap), ptr(x), ptr(r), ptr(S[0:1]), ptr(S[1:2]), ptr(S[2:5])))
         if self.world > 1:
             all_reduce_sum(S[2:4], self.dist)
         check(L.tb_cgd_direction(dev.h, n, ptr(self.dinv), ptr(r), ptr(p), ptr(S[0:1]), ptr(S[2:3])))
