@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--n", type=int, default=216, help="cells per edge of the box (216 → 10M hexahedra)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong = the same n³ mesh cut into N z-slabs (BASELINE's configuration); weak = one n³ slab per rank")
+    ap.add_argument("--exchange", default="torch", choices=["torch", "abi"],
+                    help="N > 1 data path: torch = torch.distributed over RCCL (batch_isend_irecv / all_reduce); abi = RCCL behind the C ABI (tb_comm_exchange / "
+                         "tb_comm_allreduce, what a Julia host would call) — torch.distributed then only carries the communicator id and the timing barrier")
     ap.add_argument("--layers", type=int, default=0, help="N = 1 diagnostics: run on the n×n×LAYERS slab only (the share of one of n/LAYERS GPUs), e.g. under rocprofv3")
     ap.add_argument("--no-slab-sweep", action="store_true", help="N = 1: skip the timing of the n×n×{n/2, n/4, n/8} slabs (strong-scaling prediction)")
     ap.add_argument("--strategy", default="patch", choices=["patch", "atomic", "color"])
@@ -238,13 +241,17 @@ def main():
     rdt = {"pcg2019": 0.01, "tt06": 0.001, "fhn": 0.1, "ord": 0.002}[args.ionic]   # forward-Euler-stable reaction step sizes
     fused = args.strategy == "patch" and not args.separate
     gd = dist if dist.is_initialized() else None
+    xd = gd                                                          # what the halo exchange and the CG reductions go through
+    if gd is not None and args.exchange == "abi" and not share:
+        xd = tb.distributed.RcclComm.from_torch(dev, dist)
     host_red = "cpu" if share else "cuda"
 
     class Problem:
         """One rank's share of the workload: mesh slab, operators, source vector, halo exchange, ionic states; `step` is one pass of the hot path."""
 
-        def __init__(self, nel, left, right, rank_, world_, lo_up, dist_):
-            self.world, self.rank, self.dist = world_, rank_, dist_
+        def __init__(self, nel, left, right, rank_, world_, lo_up, dist_, xdist_=None):
+            self.world, self.rank, self.dist = world_, rank_, dist_     # dist: barrier / max over ranks of the timings (torch.distributed)
+            self.xdist = xdist_ if xdist_ is not None else dist_        # xdist: halo exchange and CG reductions (torch.distributed or RcclComm)
             self.g = g = tb.generate_mesh(tb.Hexahedron, nel, left, right, perturb=0.2)
             self.dh = dh = tb.DofHandler(g)
             self.sp = sp = tb.allocate_matrix(dh)
@@ -268,7 +275,7 @@ def main():
                 self.up_idx = None if up is None else torch.from_numpy(n2d[up]).cuda()
             # the one data-path exchange: persistent send / receive buffers, pack and unpack through the C ABI (tb_gather_indexed / tb_scatter_add_indexed)
             nbrs = tb.distributed.slab_neighbours(self.lo_idx, self.up_idx, rank_, world_)
-            self.halo = tb.distributed.HaloExchange(nbrs, dist_, self.b, dev)
+            self.halo = tb.distributed.HaloExchange(nbrs, self.xdist, self.b, dev)
             self.model = model = {"pcg2019": tb.PCG2019, "tt06": tb.TT06, "fhn": tb.FHNModel, "ord": tb.ORd2011}[args.ionic]()
             self.ns = model.nstates
             self.npts = npts = dh.ndofs
@@ -336,11 +343,11 @@ def main():
             this rank's slab: interface rows of A·p packed first (tb_spmv_csr_rows), exchange posted, whole local product + pᵀA_p p behind it
             (tb_spmv_csr_dot), received partials added, all-reduce of pᵀAp, update with the two weighted sums, all-reduce, direction.  Barrier-bracketed,
             max over ranks, device scalars, no host read."""
-            npts, world_, dist_ = self.npts, self.world, self.dist
+            npts, world_, dist_, xd_ = self.npts, self.world, self.dist, self.xdist
             A = tb.heat_system_matrix(dev, self.M, self.K, 0.01)
             diag = torch.empty(npts, dtype=torch.float64, device="cuda")
             tb._lib.check(tb.lib().tb_extract_diagonal(self.K.pattern.h, A.ptr, diag.data_ptr()))
-            cg = tb.distributed.DistributedCG(None, diag, self.lo_idx, self.up_idx, self.rank, world_, dist_, device=dev, operator=(self.K.pattern, A))
+            cg = tb.distributed.DistributedCG(None, diag, self.lo_idx, self.up_idx, self.rank, world_, xd_, device=dev, operator=(self.K.pattern, A))
             xs_ = torch.zeros(npts, dtype=torch.float64, device="cuda")
             rs_ = self.b.clone() + 1.0
             ps_ = cg.dinv * rs_
@@ -348,7 +355,7 @@ def main():
             S_ = torch.zeros(6, dtype=torch.float64, device="cuda")
             tb._lib.check(tb.lib().tb_cgd_dot(dev.h, npts, cg.w.data_ptr(), rs_.data_ptr(), ps_.data_ptr(), S_[0:1].data_ptr()))
             if world_ > 1:
-                tb.distributed.all_reduce_sum(S_[0:1], dist_)
+                tb.distributed.all_reduce_sum(S_[0:1], xd_)
             for _ in range(3):
                 cg.device_step(xs_, rs_, ps_, Ap_, S_)
             self.sync()
@@ -373,7 +380,7 @@ def main():
                     "note": "one Jacobi-CG iteration on A = M - dt K under the partition (barrier-bracketed, max over ranks, host-timed over %d iterations, device "
                             "scalars, no host read): interface rows packed first, exchange overlapped with the local SpMV + p'Ap, two all-reduces" % nit}
 
-    pr = Problem(part.local_nel(), part.left, part.right, rank, world, part.interface_nodes(), gd)
+    pr = Problem(part.local_nel(), part.left, part.right, rank, world, part.interface_nodes(), gd, xd)
     g, dh, sp, npts, ns = pr.g, pr.dh, pr.sp, pr.npts, pr.ns
     elapsed = pr.time_steps(args.warmup, args.steps)
     phase = pr.phase
@@ -453,7 +460,7 @@ def main():
                                    % (n, n, nz_total, cells_total, world, part.nzl, args.strategy, "one fused pass" if fused else "two launches",
                                       " + neighbour halo sum of b" if world > 1 else "", args.ionic.upper()),
                        "cells_total": cells_total, "cells_per_gpu": g.n_cells, "dofs_per_gpu": npts, "nnz_per_gpu": sp.nnz, "ionic_model": args.ionic, "ionic_states": ns,
-                       "partition": "z-slabs", "layers_per_gpu": part.nzl, **({"backend": "gloo (shared device, test)"} if share else ({"backend": "nccl (RCCL)"} if gd is not None else {}))},
+                       "partition": "z-slabs", "layers_per_gpu": part.nzl, **({"backend": "gloo (shared device, test)"} if share else ({"backend": "nccl (RCCL)" if xd is gd else "RCCL behind the C ABI (tb_comm_*)"} if gd is not None else {}))},
             "dof_updates_per_s": ns * dofs_total * K_ / elapsed,
             "phase_ms": ({"mass+diffusion": k_ms} if fused else {"mass": phase["mass"] / K_, "diffusion": k_ms}) | {k: phase[k] / K_ for k in ("source", "halo", "reaction")},
             "phase_rates": {"matrix_integrations_per_s": 2 * g.n_cells / (mk_ms * 1e-3),

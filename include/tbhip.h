@@ -476,6 +476,26 @@ int tb_scatter_add_indexed(tb_device *dev, int64_t n, const double *d_in, const 
  * interface rows of the whole-domain product (formed by the stream kernel) by the rows it sent (formed by tb_spmv_csr_rows) before the received
  * rows are added: both sides of an interface then add the same two numbers and hold the same bits */
 int tb_scatter_indexed(tb_device *dev, int64_t n, const double *d_in, const int32_t *d_idx, double *d_vec);
+/* ---- RCCL behind the boundary (round 4; new work: the reference is shared-memory only, README.md:7) --------------------------------------------------
+ * With the pack / unpack entries above a host still needed GPU-aware message passing of its own for N > 1.  These entries put the exchange itself behind the
+ * ABI: one process per GPU, rank 0 calls tb_comm_unique_id and carries the TB_COMM_ID_BYTES bytes to the other ranks by whatever it has (a file, a socket,
+ * MPI, Distributed.jl), every rank calls tb_comm_create (ncclCommInitRank on its device), and then
+ *   tb_comm_exchange   for k < n_peers: send counts[k] doubles from d_send[k] to rank peers[k] and receive counts[k] doubles from it into d_recv[k] — ONE
+ *                      grouped call (ncclGroupStart … ncclSend / ncclRecv … ncclGroupEnd) on the device's stream; a rank may name itself as a peer
+ *   tb_comm_allreduce  in place over all ranks, TB_REDUCE_SUM or TB_REDUCE_MAX (the two scalar reductions of a CG iteration, timings)
+ * Both return when the work is enqueued on the device's stream; kernels launched behind them on that stream are ordered after it.  RCCL is opened at run
+ * time (the copy the process already holds, else librccl.so of the system; TB_RCCL_LIBRARY overrides): a single-GPU user never loads it.
+ * Sequence of a halo sum: tb_gather_indexed → tb_comm_exchange → tb_scatter_add_indexed; of the overlapped product: tb_spmv_csr_rows → tb_comm_exchange →
+ * tb_spmv_csr_dot → tb_scatter_indexed + tb_scatter_add_indexed → tb_comm_allreduce(pᵀAp). */
+typedef struct tb_comm tb_comm;
+#define TB_COMM_ID_BYTES 128
+enum { TB_REDUCE_SUM = 0, TB_REDUCE_MAX = 1 };
+int tb_comm_unique_id(void *id128);
+int tb_comm_create(tb_device *dev, const void *id128, int rank, int world_size, tb_comm **out);
+int tb_comm_destroy(tb_comm *comm);
+int tb_comm_rank_size(tb_comm *comm, int *rank, int *size);
+int tb_comm_exchange(tb_comm *comm, int n_peers, const int32_t *peers, const int64_t *counts, const double *const *d_send, double *const *d_recv);
+int tb_comm_allreduce(tb_comm *comm, double *d_buf, int64_t n, int op);
 /* Work statistics of the PATCH plan of a pattern's mesh (built on first use; no reference counterpart — the reference's strategies carry no
  * redundancy): out[0] = patches, out[1] = cell instances (a patch re-integrates the halo cells of the rows it owns: instances / cells is the
  * factor between the flops the patch kernels execute and the flops of one pass over the cells), out[2] = cells, out[3] = largest number of

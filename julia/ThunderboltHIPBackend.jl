@@ -494,6 +494,34 @@ end
 function cgd_direction!(S::HIPVector{Float64}, dinv::HIPVector{Float64}, r::HIPVector{Float64}, p::HIPVector{Float64})
     check(ccall((:tb_cgd_direction, libtbhip), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), r.dev.handle, r.n, dinv.ptr, r.ptr, p.ptr, S.ptr, S.ptr + 16))
 end
+# ---------------------------------------------------------------- RCCL behind the ABI: the exchange of the multi-GPU path without GPU-aware MPI on the Julia side.
+# Rank 0: id = comm_unique_id(); carry the 128 bytes to the other ranks (MPI.Bcast!, Distributed, a file); every rank: HIPComm(dev, id, rank, nranks).
+mutable struct HIPComm
+    handle::Ptr{Cvoid}
+    dev::MI355XDevice
+    function HIPComm(dev::MI355XDevice, id::Vector{UInt8}, rank::Integer, nranks::Integer)
+        length(id) == 128 || error("communicator id must be 128 bytes")
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:tb_comm_create, libtbhip), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint, Cint, Ref{Ptr{Cvoid}}), dev.handle, id, rank, nranks, h))
+        c = new(h[], dev)
+        finalizer(x -> ccall((:tb_comm_destroy, libtbhip), Cint, (Ptr{Cvoid},), x.handle), c)
+        return c
+    end
+end
+function comm_unique_id()
+    id = zeros(UInt8, 128)
+    check(ccall((:tb_comm_unique_id, libtbhip), Cint, (Ptr{UInt8},), id))
+    return id
+end
+# sum of interface partials: pack (halo_pack! / halo_pack_product_rows!) → this → halo_unpack_add!
+function halo_exchange!(c::HIPComm, nbs::Vector{HaloNeighbour})
+    peers = Int32[nb.peer for nb in nbs]; counts = Int64[nb.idx.n for nb in nbs]
+    send = Ptr{Float64}[nb.send.ptr for nb in nbs]; recv = Ptr{Float64}[nb.recv.ptr for nb in nbs]
+    check(ccall((:tb_comm_exchange, libtbhip), Cint, (Ptr{Cvoid}, Cint, Ptr{Int32}, Ptr{Int64}, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}}), c.handle, length(nbs), peers, counts, send, recv))
+end
+allreduce_sum!(c::HIPComm, S::HIPVector{Float64}, first::Int, n::Int) =
+    check(ccall((:tb_comm_allreduce, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Cint), c.handle, S.ptr + 8 * first, n, 0))
+
 function cgd_rotate!(S::HIPVector{Float64})
     check(ccall((:tb_cgd_rotate, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Float64}), S.dev.handle, S.ptr))
 end

@@ -41,9 +41,26 @@ def test_rccl_world_size_one_device_buffer_branches():
     assert d["cg_product_err"] < 1e-13 and d["cg_steps_finite_and_flag_clear"]
 
 
-def test_bench_under_launcher_initialises_rccl_at_world_size_one():
-    r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--n", "24", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-slab-sweep"])
+def test_rccl_behind_the_c_abi_world_size_one():
+    """tb_comm_* (RCCL opened by libtbhip itself, no torch.distributed anywhere): communicator at world size 1, the grouped send / receive of the halo
+    exchange with rank 0 as its own neighbour, sum and max all-reduces, the overlapped CG iteration — what a Julia host without GPU-aware MPI would call."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_world1_child.py"), "abi"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and lines, (r.stdout[-3000:], r.stderr[-3000:])
+    d = json.loads(lines[-1])
+    assert d["ok"] and d["backend"] == "tbhip-rccl" and d["world"] == 1, d
+    assert d["halo_device_exchange_exact"] and d["halo_second_exchange_exact"] and d["all_reduce_device"] and d["all_reduce_max"]
+    assert d["cg_product_err"] < 1e-13 and d["cg_steps_finite_and_flag_clear"]
+
+
+@pytest.mark.parametrize("exchange,backend", [("torch", "nccl (RCCL)"), ("abi", "RCCL behind the C ABI (tb_comm_*)")])
+def test_bench_under_launcher_initialises_rccl_at_world_size_one(exchange, backend):
+    """bench.py under the launcher at world size 1: process group, barrier, max-reduced timings; with --exchange abi the communicator of the C ABI is created
+    from the id that torch.distributed broadcasts, and the CG reductions / halo exchange go through tb_comm_*."""
+    r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--n", "24", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-slab-sweep", "--exchange", exchange])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-3000:], r.stderr[-3000:])
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 1 and d["config"]["backend"] == "nccl (RCCL)" and d["value"] > 0 and d["cg_iterations_per_s"] > 0
+    assert d["n_gpus"] == 1 and d["config"]["backend"] == backend and d["value"] > 0 and d["cg_iterations_per_s"] > 0

@@ -155,6 +155,12 @@ SIGNATURES = {
     "tb_cg_solve_f32": (C.c_int, [vp, vp, vp, vp, C.c_double, C.c_double, C.c_int, C.c_int, vp, vp]),
     "tb_extract_diagonal": (C.c_int, [vp, vp, vp]),
     "tb_pattern_patch_stats": (C.c_int, [vp, vp]),
+    "tb_comm_unique_id": (C.c_int, [vp]),
+    "tb_comm_create": (C.c_int, [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]),
+    "tb_comm_destroy": (C.c_int, [vp]),
+    "tb_comm_rank_size": (C.c_int, [vp, vp, vp]),
+    "tb_comm_exchange": (C.c_int, [vp, C.c_int, vp, vp, vp, vp]),
+    "tb_comm_allreduce": (C.c_int, [vp, vp, C.c_int64, C.c_int]),
     "tb_pattern_spmv_plan": (C.c_int, [vp, vp]),
     "tb_scatter_add_indexed": (C.c_int, [vp, C.c_int64, vp, vp, vp]),
     "tb_scatter_indexed": (C.c_int, [vp, C.c_int64, vp, vp, vp]),

@@ -93,10 +93,78 @@ class GeneralPartition:
         return m
 
 
+class RcclComm:
+    """RCCL communicator behind the C ABI (tb_comm_*): the exchange and the all-reduces of the multi-GPU path as the Julia host would drive them — no
+    torch.distributed on the data path.  One per process (one process per GPU).  `id128`: the 128 bytes of tb_comm_unique_id from rank 0 (None at world
+    size 1: made here); `from_torch` carries them with an existing torch.distributed group (any backend), which is then needed for nothing else.
+    Pass an instance wherever HaloExchange / DistributedCG / all_reduce_sum take `dist`."""
+
+    def __init__(self, device, rank=0, world_size=1, id128=None):
+        import ctypes as C
+        from ._lib import check, lib
+        self.dev, self.rank, self.world = device, int(rank), int(world_size)
+        if id128 is None:
+            if self.world != 1:
+                raise ValueError("RcclComm: ranks > 0 need the communicator id made by rank 0 (RcclComm.unique_id)")
+            id128 = RcclComm.unique_id()
+        self._id = bytes(id128)
+        buf = C.create_string_buffer(self._id, 128)
+        self.h = C.c_void_p()
+        check(lib().tb_comm_create(device.h, buf, self.rank, self.world, C.byref(self.h)))
+
+    @staticmethod
+    def unique_id():
+        import ctypes as C
+        from ._lib import check, lib
+        buf = C.create_string_buffer(128)
+        check(lib().tb_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def from_torch(cls, device, dist):
+        """communicator over the ranks of the default torch.distributed group: rank 0 makes the id, the group broadcasts it"""
+        rank, world = dist.get_rank(), dist.get_world_size()
+        box = [RcclComm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return cls(device, rank, world, box[0])
+
+    def exchange(self, peers, send, recv):
+        """one grouped send / receive with every listed peer (device tensors of equal length per peer), enqueued on the device's stream"""
+        import ctypes as C
+        from ._lib import check, lib
+        n = len(peers)
+        if n == 0:
+            return
+        P = (C.c_int32 * n)(*[int(p) for p in peers])
+        cnt = (C.c_int64 * n)(*[int(t.numel()) for t in send])
+        S = (C.c_void_p * n)(*[t.data_ptr() for t in send])
+        R = (C.c_void_p * n)(*[t.data_ptr() for t in recv])
+        check(lib().tb_comm_exchange(self.h, n, P, cnt, S, R))
+
+    def allreduce(self, t, op="sum"):
+        import ctypes as C
+        from ._lib import check, lib
+        assert t.is_cuda and t.is_contiguous() and t.dtype.itemsize == 8
+        check(lib().tb_comm_allreduce(self.h, C.c_void_p(t.data_ptr()), t.numel(), 0 if op == "sum" else 1))
+        return t
+
+    def close(self):
+        from ._lib import lib
+        if self.h:
+            lib().tb_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def _host_staged(vec, dist):
     """gloo moves host buffers only: device tensors are staged through the host (the CPU-backend test configuration; RCCL sends device
     buffers directly)."""
-    return vec.is_cuda and dist.get_backend() == "gloo"
+    return vec.is_cuda and not isinstance(dist, RcclComm) and dist.get_backend() == "gloo"
 
 
 def exchange_sum(vec, neighbours, dist):
@@ -140,7 +208,10 @@ class HaloExchange:
         # device tensors + an MI355XDevice: pack / unpack through libtbhip on the device's stream; device tensors without one (plain torch callers):
         # the equivalent torch calls on the same persistent buffers, like host tensors
         self.cuda = bool(like.is_cuda) and device is not None
-        self.staged = bool(like.is_cuda) and dist is not None and dist.is_initialized() and dist.get_backend() == "gloo"
+        self.abi = isinstance(dist, RcclComm)                       # exchange through tb_comm_exchange (RCCL behind the C ABI) instead of torch.distributed
+        if self.abi and not self.cuda:
+            raise ValueError("HaloExchange: an RcclComm moves device buffers of an MI355XDevice")
+        self.staged = bool(like.is_cuda) and dist is not None and not self.abi and dist.is_initialized() and dist.get_backend() == "gloo"
         self.peers, self.idx, self.idx32, self.send, self.recv, self.send_h, self.recv_h = [], [], [], [], [], [], []
         for peer, idx in neighbours:
             idx = torch.as_tensor(idx, dtype=torch.int64, device=like.device)
@@ -180,6 +251,9 @@ class HaloExchange:
 
     def start(self):
         if not self.peers:
+            return
+        if self.abi:                                                 # stream-ordered: nothing to wait for in finish()
+            self.dist.exchange(self.peers, self.send, self.recv)
             return
         dist, ops = self.dist, []
         if self.staged:
@@ -226,6 +300,8 @@ class HaloExchange:
 
 def all_reduce_sum(t, dist):
     """Sum a (small) tensor over the ranks in place; device tensors go through the host under gloo."""
+    if isinstance(dist, RcclComm):
+        return dist.allreduce(t.contiguous() if not t.is_contiguous() else t, "sum")
     if _host_staged(t, dist):
         h = t.cpu()
         dist.all_reduce(h)
