@@ -304,3 +304,30 @@ def test_pcg2019_rush_larsen_is_exact_for_gates_and_first_order(oracle):
         o.reaction_step(o.CELL_PCG2019, p, b, 1, o.LAYOUT_SOA, dt=h, want_du=False)
         errs.append(np.abs(a - b).max())
     assert errs[1] < 0.3 * errs[0]
+
+
+def test_baseline_form_of_the_per_colour_assembly_matches_the_canonical_loop(oracle):
+    """oracle.AssemblyPlan (bench.py's cpu_baseline: scatter positions looked up once, per-colour cell lists, first-touch zero fill, hexahedron instances of
+    the element routines, planned element-assembly source) against the literal sequential loop the parity tests use — same element sums, colour order
+    instead of cell order: agreement to rounding for M, K and b, with one thread and with several, and identical bits between repeated assemblies."""
+    o = oracle
+    xyz, conn = o.generate_grid_hex(7, 6, 5, (0, 0, 0), (1.0, 0.9, 1.2))
+    xyz = xyz + 0.02 * np.sin(7.0 * xyz[:, [1, 2, 0]])                       # distorted cells
+    cd, nd = o.close_dofs(o.HEX8, 1, conn, len(xyz))
+    rp, ci = o.build_pattern(cd, nd)
+    col, nc = o.color_cells(cd, nd)
+    m = o.Mesh(o.HEX8, 2, xyz, conn, cd)
+    cM = o.Coef(o.COEF_CONST_SCALAR, [1.3])
+    cK = o.Coef(o.COEF_CONST_TENSOR, np.array([[2.0, 0.3, 0.1], [0.3, 1.5, 0.2], [0.1, 0.2, 1.0]]).ravel())
+    refM, refK = o.assemble_matrix(m, 0, cM, rp, ci), o.assemble_matrix(m, 1, cK, rp, ci)
+    refb = o.assemble_source(m, o.SRC_COS_EXP, t=0.3)
+    for th in (1, 3):
+        plan = o.AssemblyPlan(m, rp, ci, col, nc, th)
+        nzM, nzK, b = plan.new_values(), plan.new_values(), np.empty(nd)
+        plan.assemble(0, cM, nzM); plan.assemble(1, cK, nzK); plan.assemble_source(o.SRC_COS_EXP, b, t=0.3)
+        assert np.abs(nzM - refM).max() < 1e-14 * np.abs(refM).max()
+        assert np.abs(nzK - refK).max() < 1e-14 * np.abs(refK).max()
+        np.testing.assert_array_equal(b, refb)                                   # element assembly sums in cell order: the same bits
+        again = plan.new_values()
+        plan.assemble(1, cK, again)
+        np.testing.assert_array_equal(again, nzK)
