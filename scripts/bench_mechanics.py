@@ -15,6 +15,7 @@ ap.add_argument("--cell-order", default="lexicographic", choices=["lexicographic
 ap.add_argument("--spmv", action="store_true", help="also time the product J·x with the assembled tangent (the block SpMV of the Krylov solvers)")
 ap.add_argument("--energy", default="ho", choices=["ho", "guccione", "humphrey", "linyin"],
                 help="passive energy: ho = Holzapfel–Ogden 2009 with hand-derived P, 𝔸 (fast path); the others run the generic instance (hyper-dual differentiation of Ψ per pair of components of F)")
+ap.add_argument("--chunks", default="", help="comma list: also time the linearisation with TB_MECH_CHUNKS set to each value (gather of chunk k beside the integration of chunk k + 1)")
 ap.add_argument("--condensed", action="store_true", help="active stress with the RDQ20-MF internal state condensed per quadrature point")
 args = ap.parse_args()
 import thunderbolt_jl_amd as tb
@@ -60,6 +61,18 @@ tl /= args.steps; tr /= args.steps
 out = {"workload": ("HO2009 + condensed RDQ20-MF active stress, " if args.condensed else "") + ("HO2009" if args.energy == "ho" else args.energy + " (generic hyper-dual instance)") + " quasi-static, Q%d displacement, %d^3 hex (%d cells, %d dofs, nnz %d), %s scatter" % (args.order, args.n, g.n_cells, dh.ndofs, sp.nnz, args.strategy),
        "linearize_ms": tl, "residual_ms": tr, "linearize_cells_per_s": g.n_cells / (tl * 1e-3), "residual_cells_per_s": g.n_cells / (tr * 1e-3),
        "host_setup_s": t_setup, "cell_order": args.cell_order}
+if args.chunks:
+    import os
+    out["linearize_ms_by_chunks"] = {}
+    for c in args.chunks.split(","):
+        os.environ["TB_MECH_CHUNKS"] = c
+        tb.update_linearization(op, du, 0.0, residual=res)
+        e[0].record()
+        for _ in range(args.steps):
+            tb.update_linearization(op, du, 0.0, residual=res)
+        e[1].record(); dev.synchronize()
+        out["linearize_ms_by_chunks"][c] = e[0].elapsed_ms(e[1]) / args.steps
+    os.environ.pop("TB_MECH_CHUNKS")
 if args.spmv:
     xs, ys = dev.to_device(np.cos(np.arange(dh.ndofs) * 1e-3)), dev.zeros(dh.ndofs)
     def prod():

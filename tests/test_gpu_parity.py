@@ -1023,6 +1023,31 @@ def test_hyperelastic_tangent_on_a_mesh_with_a_ten_cell_vertex(tb, oracle, devic
         assert rel_err(res.to_host(), rref) < 1e-11
 
 
+def test_chunked_linearization_is_bit_identical(tb, device, monkeypatch):
+    """TB_MECH_CHUNKS: the cells integrated in n launches with the gather of the rows each chunk completes on a second queue — same kernels, same cell
+    order inside every row sum, so tangent and residual equal the single-launch ones bit for bit (26³ Q2 hexahedra, 4 and 3 chunks; the switch is read
+    per call)."""
+    n = 26
+    g = tb.generate_mesh(tb.Hexahedron, (n, n, n), (0, 0, 0), (1.0, 1.0, 1.0), perturb=0.1)
+    dh = tb.DofHandler(g, tb.LagrangeCollection(2) ** 3)
+    sp = tb.allocate_matrix(dh)
+    f, s_, nn = np.array([1, 1, 0.0]) / np.sqrt(2), np.array([-1, 1, 0.0]) / np.sqrt(2), np.array([0, 0, 1.0])
+    model = tb.QuasiStaticModel("u", tb.PK1Model(tb.HolzapfelOgden2009Model(), tb.ConstantCoefficient(tb.OrthotropicMicrostructure(f, s_, nn))))
+    op = tb.setup_operator(tb.ElementAssemblyStrategy(device), model, dh, sp)
+    u = device.to_device(1e-2 * np.sin(np.pi * np.arange(dh.ndofs) / dh.ndofs))
+    res = device.zeros(dh.ndofs)
+    monkeypatch.setenv("TB_MECH_CHUNKS", "0")
+    tb.update_linearization(op, u, 0.0, residual=res)
+    J0, r0 = op.J.to_host(), res.to_host()
+    assert np.abs(J0).max() > 0
+    for chunks in ("4", "3"):
+        monkeypatch.setenv("TB_MECH_CHUNKS", chunks)
+        op.J.copy_from_host(np.full(sp.nnz, np.nan))
+        tb.update_linearization(op, u, 0.0, residual=res)
+        np.testing.assert_array_equal(op.J.to_host(), J0)
+        np.testing.assert_array_equal(res.to_host(), r0)
+
+
 def test_mechanics_properties_80_cubed(tb, oracle, device):
     """BASELINE config 4 at its own size (512 000 Q2 hexahedra, 12.5 M dofs, 2.37·10⁹ nz: the Int32 / size effects the small parity cases cannot see):
     residual and tangent of the element strategy — a sample of rows against the oracle's assembly of the cells around them, rigid translations in

@@ -97,6 +97,8 @@ int tb_device_destroy(tb_device *dev)
     if (!dev) return TB_OK;
     hipSetDevice(dev->id);
     if (dev->own_stream && dev->stream) hipStreamDestroy(dev->stream);
+    if (dev->aux_stream) hipStreamDestroy(dev->aux_stream);
+    for (hipEvent_t e : dev->aux_ev) if (e) hipEventDestroy(e);
     if (dev->d_status) hipFree(dev->d_status);
     if (dev->h_status) hipHostFree(dev->h_status);
     if (dev->d_scratch) hipFree(dev->d_scratch);

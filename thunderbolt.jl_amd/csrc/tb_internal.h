@@ -149,6 +149,8 @@ struct tb_device {
     bool defer_status = false;      // tb_device_defer_status: assembly calls return without reading the status block; tb_device_poll_status reads it
     void *d_scratch = nullptr;      // Float64 arena behind the *_f32 entry points (tb_f32.hip), grown on demand
     size_t scratch_bytes = 0;
+    hipStream_t aux_stream = nullptr; // second queue of the chunked mechanics linearisation (gather of chunk k beside the integration of chunk k + 1)
+    hipEvent_t aux_ev[2] = {nullptr, nullptr};
 };
 
 struct tb_mesh {
@@ -208,6 +210,7 @@ struct tb_pattern {
     size_t kebuf_bytes = 0;
     void *d_gnodes = nullptr;       // per field node: {first nz, row length, cell count, ≤ 8 element-matrix run offsets} of the staged gather
     int gnodes_state = 0;           // 0 not built, 1 built, −1 some node sits in more than 8 cells (direct gather is used)
+    std::vector<int32_t> h_gn_last; // running maximum of the records' last contributing cell: the record prefix completed by a chunk of cells
     int64_t max_row_len = 0;
     uint16_t *d_blockpos = nullptr; // vector fields: per cell and node pair, position of the 3×3 block inside its row
     std::unique_ptr<tb::PatchMatPlan> patch_mat;

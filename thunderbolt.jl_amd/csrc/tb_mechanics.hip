@@ -123,6 +123,7 @@ struct MechMesh {
     const double *qp_act;    // condensed internal variable: per quadrature point (a, b) — P += a ∂λ/∂F, 𝔸 += a ∂²λ/∂F² + b ∂λ/∂F ⊗ ∂λ/∂F; NULL → none
     int qp_stride;           // 2, or 5 in the rate-coupled form: (a, b, c·w) with the non-symmetric term 𝔸 += ∂λ/∂F ⊗ (c·w ⊗ f₀), w ⊗ f₀ = ∂²λ/∂F² : Ḟ
     const double *cell_xyz;  // vertex coordinates per cell (24 doubles, cell-major): the sum-factorised tangent kernel reads them with wave-uniform addresses
+    int64_t cell0;           // first cell of the launch (chunked linearisation); 0 otherwise
 #ifdef TB_ABLATION
     long long *prof;         // TB_PROF_STAMPS: 16 phase time stamps of every 256th workgroup
 #endif
@@ -175,7 +176,7 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
     // residual contracts the pulled-back stress with the reference gradients: two barriers and the 729-task gradient pass less per cell
     constexpr bool REFGRAD = (NEED_K && SF) || (!NEED_K && NEED_R && NB == 27 && NQ == 27 && T == 256); // (the residual-only kernel of the quadratic field too)
     const MechTables<FE> &tb = g_mech_tables<FE>;
-    const int64_t cell = list ? list[blockIdx.x] : blockIdx.x;
+    const int64_t cell = list ? list[blockIdx.x] : m.cell0 + blockIdx.x;
     const int tid = threadIdx.x;
 #ifdef TB_ABLATION
 #define TB_MS(k) do { if (m.prof && tid == 0 && (blockIdx.x & 255) == 7) m.prof[(blockIdx.x >> 8) * 16 + (k)] = wall_clock64(); } while (0)
@@ -1278,6 +1279,12 @@ static int ensure_gather_nodes(tb_pattern *p)
             if (g.nk >= 8) { p->gnodes_state = -1; return TB_OK; }
             g.slot[g.nk++] = (int32_t)(c * nd + 3 * a);
         }
+    // running maximum of the last contributing cell over the records (dof order): the records before the first one whose value reaches c are complete
+    // once cells [0, c) are integrated — the prefix the chunked linearisation gathers behind the integration front.  On a mesh numbered cell by cell
+    // the prefix trails the front by about one layer of cells.
+    p->h_gn_last.resize((size_t)nn);
+    int32_t run = 0;
+    for (int64_t i = 0; i < nn; ++i) { run = std::max(run, recs[i].slot[recs[i].nk - 1] / nd); p->h_gn_last[i] = run; }
     TB_HIP(hipMalloc(&p->d_gnodes, sizeof(GatherNode) * (size_t)nn));
     TB_HIP(hipMemcpy(p->d_gnodes, recs.data(), sizeof(GatherNode) * (size_t)nn, hipMemcpyHostToDevice));
     p->gnodes_state = 1;
@@ -1392,8 +1399,56 @@ static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, doubl
             kebuf = p->d_kebuf;
             if (sym) rank27 = m->d_rank27;
         }
+        // Chunked linearisation (TB_MECH_CHUNKS=n; default 8 from 32 768 cells, 0 / 1 = one launch): the cells go in n launches, and behind each the
+        // staged gather of the node rows that chunk completes runs on a second queue — the HBM-bound gather (46 GB at 80³) beside the LDS / VALU-bound
+        // integration of the next chunk.  Same kernels, same sums (a node's cells are still added in cell order): the unchunked result bit for bit.
+        // Measured at 80³ (kernel trace, profiles/r04_v2/mechanics_chunk_timeline.txt): the pairs do run side by side, but a CU that holds three
+        // integration workgroups has neither LDS (3 × 53 KB) nor registers (3 × 168) left, so every gather workgroup displaces an integration one —
+        // 2.55 ms per pair against 1.42 + 1.18 ms alone; the gain is what the pipeline ends and the dispatch gaps cost before: 21.3 → 20.7 ms.
+        const int chunks_env = [] { const char *e = getenv("TB_MECH_CHUNKS"); return e ? atoi(e) : 8; }(); // read per call: a 20 ms operation
+        bool chunked = false;
+        if (NEED_K && !sym && !MFMA && chunks_env > 1 && m->n_cells >= 4096 * (int64_t)chunks_env) {
+            if (!m->d_node_dof0) { rc = build_node_list(m); if (rc) return rc; }
+            rc = check_node_rows(p);
+            if (rc) return rc;
+            rc = ensure_gather_nodes(p);
+            if (rc) return rc;
+            chunked = p->gnodes_state > 0;
+        }
+        if (chunked) {
+            if (!dev->aux_stream) {
+                static const bool hi = [] { const char *e = getenv("TB_MECH_CHUNK_PRIO"); return e && atoi(e); }();
+                int lo_p = 0, hi_p = 0;
+                TB_HIP(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
+                TB_HIP(hipStreamCreateWithPriority(&dev->aux_stream, hipStreamNonBlocking, hi ? hi_p : lo_p));
+                for (hipEvent_t &e : dev->aux_ev) TB_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            }
+            const int nbr_pad = ((((int)p->max_row_len / 3 + 3) & ~3) + 7) & ~7;
+            const size_t glds = (size_t)4 * 4 * (3 * FE::ND * sizeof(double) + (size_t)nbr_pad);
+            int64_t n_done = 0;
+            for (int k = 0; k < chunks_env; ++k) {
+                const int64_t c0 = m->n_cells * k / chunks_env, c1 = m->n_cells * (k + 1) / chunks_env;
+                mm.cell0 = c0;
+                rc = go(nullptr, c1 - c0, 2);
+                if (rc) return rc;
+                TB_HIP(hipEventRecord(dev->aux_ev[0], dev->stream));
+                TB_HIP(hipStreamWaitEvent(dev->aux_stream, dev->aux_ev[0], 0));
+                const int64_t n1 = k + 1 == chunks_env ? m->n_nodes_field : std::upper_bound(p->h_gn_last.begin(), p->h_gn_last.end(), (int32_t)(c1 - 1)) - p->h_gn_last.begin();
+                if (n1 > n_done) {
+                    auto kg = k_gather_node_rows_lds<FE::NB, 4>;
+                    hipLaunchKernelGGL(kg, dim3((unsigned)((n1 - n_done + 3) / 4)), dim3(256), glds, dev->aux_stream, (const GatherNode *)p->d_gnodes + n_done,
+                                       n1 - n_done, kebuf, bp, d_nz, nbr_pad);
+                    TB_HIP(hipGetLastError());
+                    n_done = n1;
+                }
+            }
+            mm.cell0 = 0;
+            TB_HIP(hipEventRecord(dev->aux_ev[1], dev->aux_stream));
+            TB_HIP(hipStreamWaitEvent(dev->stream, dev->aux_ev[1], 0));
+        } else {
         rc = go(nullptr, m->n_cells, 2);
         if (rc) return rc;
+        }
 #ifdef TB_ABLATION
         if (mm.prof) { // average phase durations of the sampled workgroups (µs; wall clock 100 MHz)
             std::vector<long long> h((size_t)nmprof * 16);
@@ -1426,7 +1481,7 @@ static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, doubl
             hipLaunchKernelGGL(k, dim3((unsigned)(8 * ((ngroups + 7) / 8))), dim3(256), 4 * per_wave, dev->stream, m->d_node_dof0, m->n_nodes_field, m->ea->d_ptr,
                                m->ea->d_src, kebuf, bp, rank27, rowptr, p->d_colidx, d_nz, nbr_max, ngroups);
             TB_HIP(hipGetLastError());
-        } else if (NEED_K) {
+        } else if (NEED_K && !chunked) {
             if (!m->d_node_dof0) { rc = build_node_list(m); if (rc) return rc; }
             rc = check_node_rows(p);
             if (rc) return rc;
