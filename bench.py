@@ -64,6 +64,7 @@ def parse():
                     help="N > 1 data path: torch = torch.distributed over RCCL (batch_isend_irecv / all_reduce); abi = RCCL behind the C ABI (tb_comm_exchange / "
                          "tb_comm_allreduce, what a Julia host would call) — torch.distributed then only carries the communicator id and the timing barrier")
     ap.add_argument("--layers", type=int, default=0, help="N = 1 diagnostics: run on the n×n×LAYERS slab only (the share of one of n/LAYERS GPUs), e.g. under rocprofv3")
+    ap.add_argument("--no-spmv-mirror", action="store_true", help="CG iterations on the CSR array instead of its sliced mirror (tb_spmv_mirror)")
     ap.add_argument("--no-slab-sweep", action="store_true", help="N = 1: skip the timing of the n×n×{n/2, n/4, n/8} slabs (strong-scaling prediction)")
     ap.add_argument("--strategy", default="patch", choices=["patch", "atomic", "color"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -348,6 +349,16 @@ def main():
             diag = torch.empty(npts, dtype=torch.float64, device="cuda")
             tb._lib.check(tb.lib().tb_extract_diagonal(self.K.pattern.h, A.ptr, diag.data_ptr()))
             cg = tb.distributed.DistributedCG(None, diag, self.lo_idx, self.up_idx, self.rank, world_, xd_, device=dev, operator=(self.K.pattern, A))
+            # the solve multiplies one fixed matrix: its values are mirrored slice by slice once (tb_spmv_mirror, timed on its own) and every product of
+            # the iterations below streams the mirror; --no-spmv-mirror times the CSR kernel instead
+            e0, e1 = dev.event(), dev.event()
+            mirrored = (not args.no_spmv_mirror) and self.K.pattern.mirror(A)    # first bind of the pattern: slice table (host) + buffer
+            e0.record()
+            if mirrored:
+                self.K.pattern.mirror(A)                                         # what every later matrix of this pattern costs
+            e1.record()
+            torch.cuda.synchronize()
+            bind_ms = e0.elapsed_ms(e1) if mirrored else None
             xs_ = torch.zeros(npts, dtype=torch.float64, device="cuda")
             rs_ = self.b.clone() + 1.0
             ps_ = cg.dinv * rs_
@@ -374,8 +385,14 @@ def main():
             for _ in range(nit):
                 tb._lib.check(tb.lib().tb_spmv_csr(self.K.pattern.h, A.ptr, ps_.data_ptr(), 1.0, 0.0, Ap_.data_ptr()))   # the bare local SpMV, for reference
             ec.record()
+            self.K.pattern.mirror(None)
+            for _ in range(nit):
+                tb._lib.check(tb.lib().tb_spmv_csr(self.K.pattern.h, A.ptr, ps_.data_ptr(), 1.0, 0.0, Ap_.data_ptr()))   # … and from the CSR array
+            ed = dev.event()
+            ed.record()
             torch.cuda.synchronize()
             return {"iteration_ms": t_it * 1e3, "product_halo_dot_ms": ea.elapsed_ms(eb) / nit, "local_spmv_ms": eb.elapsed_ms(ec) / nit,
+                    "local_spmv_csr_ms": ec.elapsed_ms(ed) / nit, "spmv_mirror": bool(mirrored), "spmv_mirror_bind_ms": bind_ms,
                     "halo_bytes_per_rank": self.halo.nbytes, "rows_per_rank": npts, "nnz_per_rank": self.sp.nnz,
                     "note": "one Jacobi-CG iteration on A = M - dt K under the partition (barrier-bracketed, max over ranks, host-timed over %d iterations, device "
                             "scalars, no host read): interface rows packed first, exchange overlapped with the local SpMV + p'Ap, two all-reduces" % nit}

@@ -505,6 +505,17 @@ int tb_pattern_patch_stats(tb_pattern *pat, int64_t *out6);
  * (> 0: rows holding the same column offsets relative to their index share one table entry, the kernel reads 4 B per row instead of 4 B per
  * non-zero; −1: the pattern does not compress — table larger than nnz / 4 — and keeps the CSR kernel), out2[1] = entries of the signature table */
 int tb_pattern_spmv_plan(tb_pattern *pat, int64_t *out2);
+/* Sliced mirror of one value array for the solves that multiply a fixed matrix many times (round 4; replaces nothing in the reference, whose
+ * mul!(y, A, x) of the Krylov iteration — src/solver/time/euler.jl:94-100 through LinearSolve — reads the CSC / CSR arrays directly):
+ *   tb_spmv_mirror(pat, d_nzval)  copies the values of d_nzval into the pattern's mirror — slices of 64 consecutive rows, entry k of the 64 rows side by
+ *                                 side, zero-padded to the slice's longest row; a second copy of the values, ≈ 1 ms at 2.7·10⁸ non-zeros — and binds it:
+ *                                 from now on every product of this pattern with THIS pointer (tb_spmv_csr, tb_spmv_csr_dot, the products inside
+ *                                 tb_cg_solve and the other solvers) reads the mirror: coalesced loads, no LDS staging, the same bits as the CSR kernel.
+ *   tb_spmv_mirror(pat, NULL)     unbinds (the buffers stay for the next bind).
+ * The caller keeps the contract that a bound array is not modified: after assembling into it, or forming M − Δt·K in it again, call tb_spmv_mirror
+ * again.  Row-subset products (tb_spmv_csr_rows) and the diagonal extraction keep reading the CSR array.  TB_ERR_UNSUPPORTED for patterns without a
+ * mirror: 3×3-block rows (their own kernel), numberings whose rows share no column-offset signatures, rows longer than 255 entries. */
+int tb_spmv_mirror(tb_pattern *pat, const double *d_nzval);
 int tb_spmv_csr_rows(tb_pattern *pat, const double *d_nzval, const double *d_x, int64_t n_rows, const int32_t *d_rows, double *d_out);
 int tb_spmv_csr_dot(tb_pattern *pat, const double *d_nzval, const double *d_x, double *d_y, double *d_dot);
 /* apply_zero!(K, f, ch) on the device CSR matrix (Ferrite.apply_zero!; CSR method src/utils.jl:263-278; used by

@@ -20,6 +20,7 @@ const libtbhip = get(ENV, "TBHIP_LIBRARY", "libtbhip.so")
 
 # revision of include/tbhip.h these ccalls were written against (TB_ABI_REVISION); a library of another revision reads / writes other buffer sizes
 const TB_ABI_REVISION = 4
+const TB_ERR_UNSUPPORTED = Cint(-5) # include/tbhip.h
 function __init__()
     have = ccall((:tb_abi_revision, libtbhip), Cint, ())
     have == TB_ABI_REVISION || error("libtbhip ABI revision $have, this binding was written against $TB_ABI_REVISION")
@@ -475,6 +476,15 @@ function patch_stats(A::HIPSparseMatrixCSR)
     check(ccall((:tb_pattern_patch_stats, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Int64}), A.ddh.pattern, out))
     return out
 end
+# Sliced mirror of A's values for repeated products (a Krylov solve on a fixed matrix): mul!, mul_dot! and cg! on A then stream the mirrored copy.
+# Call again after A's values changed (update_operator!, a new M − Δt·K); unmirror! goes back to the CSR array.  false where the pattern has no mirror.
+function mirror!(A::HIPSparseMatrixCSR{Float64})
+    rc = ccall((:tb_spmv_mirror, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Float64}), A.ddh.pattern, A.nzval.ptr)
+    rc == TB_ERR_UNSUPPORTED && return false
+    check(rc)
+    return true
+end
+unmirror!(A::HIPSparseMatrixCSR{Float64}) = check(ccall((:tb_spmv_mirror, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Float64}), A.ddh.pattern, C_NULL))
 function diagonal!(d::HIPVector{Float64}, A::HIPSparseMatrixCSR{Float64})
     check(ccall((:tb_extract_diagonal, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), A.ddh.pattern, A.nzval.ptr, d.ptr))
 end

@@ -1,43 +1,60 @@
-"""CSR SpMV at n³ hexes (Q1 scalar pattern, 27 nz per interior row): time per product and algorithmic bandwidth (12 B/nnz + 16 B/row);
-TB_SPMV_LANES=16 selects the lanes-per-row kernel, unset = the stream kernel.  Also checks the product against scipy on the host."""
-import argparse
-import os
-import sys
-import time
-
+#!/usr/bin/env python3
+"""y = A·x on the 216³ heat-matrix pattern: the CSR kernel of tb_spmv_csr against the sliced mirror (tb_spmv_mirror), grid sweep of the latter.
+Prints one JSON line."""
+import argparse, json, os, sys, time
 import numpy as np
-
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=216)
-ap.add_argument("--reps", type=int, default=50)
-a = ap.parse_args()
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import thunderbolt_jl_amd as tb  # noqa: E402
+ap.add_argument("--grids", default="0,512,768,1024,1536,2048,4096,40000")
+args = ap.parse_args()
+import thunderbolt_jl_amd as tb
 dev = tb.MI355XDevice(0)
-g = tb.generate_mesh(tb.Hexahedron, (a.n,) * 3)
+g = tb.generate_mesh(tb.Hexahedron, (args.n,) * 3, perturb=0.1)
 dh = tb.DofHandler(g)
 sp = tb.allocate_matrix(dh)
-M = tb.update_operator(tb.setup_operator(tb.PatchAssemblyStrategy(dev), tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.0)), dh, sp), 0.0)
+pat = tb.DevicePattern(tb.DeviceMesh(dev, dh), sp)
 rng = np.random.default_rng(0)
-xh = rng.normal(size=dh.ndofs)
-x = dev.to_device(xh)
-y = dev.zeros(dh.ndofs)
-M.mul(y, x)
-import scipy.sparse as ssp
-ref = ssp.csr_matrix((M.A.to_host(), sp.colidx, sp.rowptr), shape=(dh.ndofs,) * 2) @ xh
-print("rel err vs scipy", np.abs(y.to_host() - ref).max() / np.abs(ref).max())
-dev.synchronize()
-t0 = time.perf_counter()
-for _ in range(a.reps):
-    M.mul(y, x)
-dev.synchronize()
-dt = (time.perf_counter() - t0) / a.reps
-print(f"n={a.n} nnz={sp.nnz} spmv {dt * 1e3:.3f} ms  {(12 * sp.nnz + 16 * dh.ndofs) / dt / 1e12:.2f} TB/s")
-b = dev.to_device(ref)
-u = dev.zeros(dh.ndofs)
-dev.synchronize()
-t0 = time.perf_counter()
-its, res = tb.cg_solve(M.pattern, M.A, b, u, rtol=1e-10, atol=0.0, maxiter=500)
-dev.synchronize()
-dt = time.perf_counter() - t0
-print(f"CG on M: {its} iterations, {dt / max(its, 1) * 1e3:.3f} ms/iteration, err {np.abs(u.to_host() - xh).max():.2e}")
+A = dev.to_device(rng.normal(size=sp.nnz))
+x, y = dev.to_device(rng.normal(size=dh.ndofs)), dev.zeros(dh.ndofs)
+L = tb.lib()
+
+def timed(reps=20):
+    for _ in range(3):
+        tb.check(L.tb_spmv_csr(pat.h, A.ptr, x.ptr, 1.0, 0.0, y.ptr))
+    e0, e1 = dev.event(), dev.event()
+    e0.record()
+    for _ in range(reps):
+        tb.check(L.tb_spmv_csr(pat.h, A.ptr, x.ptr, 1.0, 0.0, y.ptr))
+    e1.record(); dev.synchronize()
+    return e0.elapsed_ms(e1) / reps
+
+d = dev.zeros(1)
+def timed_dot(reps=20):
+    for _ in range(3):
+        tb.check(L.tb_spmv_csr_dot(pat.h, A.ptr, x.ptr, y.ptr, d.ptr))
+    e0, e1 = dev.event(), dev.event()
+    e0.record()
+    for _ in range(reps):
+        tb.check(L.tb_spmv_csr_dot(pat.h, A.ptr, x.ptr, y.ptr, d.ptr))
+    e1.record(); dev.synchronize()
+    return e0.elapsed_ms(e1) / reps
+
+out = {"rows": dh.ndofs, "nnz": sp.nnz, "csr_dot_ms": timed_dot(), "csr_ms": timed()}
+y_csr = y.to_host()
+assert pat.mirror(A)
+e0, e1 = dev.event(), dev.event()
+e0.record(); pat.mirror(A); e1.record(); dev.synchronize()
+out["mirror_bind_ms"] = e0.elapsed_ms(e1)
+out["mirror_ms_by_grid"] = {}
+for gsz in args.grids.split(","):
+    if gsz == "0":
+        os.environ.pop("TB_SPMV_MIRROR_GRID", None)
+    else:
+        os.environ["TB_SPMV_MIRROR_GRID"] = gsz
+    out.setdefault("mirror_dot_ms_by_grid", {})[gsz] = timed_dot()
+    out["mirror_ms_by_grid"][gsz] = timed()
+out["bit_identical"] = bool(np.array_equal(y.to_host(), y_csr))
+bytes_ = 8.0 * sp.nnz + 16.0 * dh.ndofs
+out["mirror_TBps"] = bytes_ / (min(out["mirror_ms_by_grid"].values()) * 1e-3) / 1e12
+print(json.dumps(out))

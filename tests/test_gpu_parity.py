@@ -2674,6 +2674,101 @@ def test_spmv_and_cg_on_ragged_superset_patterns(tb, device, long_row):
     assert its < 400 and np.abs(u.to_host() - xh).max() < 1e-8
 
 
+def test_sliced_mirror_products_equal_the_csr_products(tb, device):
+    """tb_spmv_mirror: products of a pattern with the array a sliced mirror was taken from read the mirror (64-row slices, entry-major, zero-padded) —
+    the same partial sums in the same order as the CSR kernels, so plain, (α, β) and fused xᵀAx products agree bit for bit.  Patterns: the perturbed
+    hexahedral grid with a few long rows (slices of mixed signatures, the tail loop), tetrahedra, the unstructured left-ventricle mesh, the quadratic
+    scalar field (rows of 27 … 125 entries).  Re-binding picks up changed values, unbinding returns to the CSR array, a Jacobi-CG solve takes the same
+    iterations to the same solution, and a 3 × 3-block pattern reports that it has no mirror."""
+    import scipy.sparse as ssp
+    rng = np.random.default_rng(11)
+    lib = tb.lib()
+
+    def with_long_rows(base, n):
+        P = ssp.csr_matrix((np.ones(base.nnz), base.colidx, base.rowptr), shape=(n, n))
+        extra = ssp.lil_matrix((n, n))
+        for r in rng.integers(0, n, 3):
+            extra[r, rng.choice(n, 90, replace=False)] = 1.0
+        S = (P + extra.tocsr() + extra.tocsr().T).tocsr()
+        S.sort_indices()
+        return tb.SparsityPattern(S.indptr.astype(np.int64), S.indices.astype(np.int32))
+
+    cases = []
+    g = tb.generate_mesh(tb.Hexahedron, (30, 28, 26), perturb=0.2)
+    dh = tb.DofHandler(g)
+    cases.append(("hex + long rows", dh, with_long_rows(tb.allocate_matrix(dh), dh.ndofs)))
+    g0 = tb.generate_mesh(tb.Hexahedron, (12, 11, 10), (0, 0, 0), (1, 1, 1), perturb=0.2)
+    dh = tb.DofHandler(tb.Grid(tb.Tetrahedron, g0.xyz, hex_to_tets(g0.xyz, g0.conn)))
+    cases.append(("tets", dh, tb.allocate_matrix(dh)))
+    g = tb.generate_ideal_lv_mesh_hex(24, 4, 12)
+    dh = tb.DofHandler(g)
+    cases.append(("lv", dh, tb.allocate_matrix(dh)))
+    g = tb.generate_mesh(tb.Hexahedron, (16, 15, 14), perturb=0.1)
+    dh = tb.DofHandler(g, tb.LagrangeCollection(2))
+    cases.append(("q2 scalar", dh, tb.allocate_matrix(dh)))
+    mirrored = []
+    for name, dh, sp in cases:
+        n = dh.ndofs
+        pat = tb.DevicePattern(tb.DeviceMesh(device, dh), sp)
+        vals = rng.normal(size=sp.nnz)
+        A, x = device.to_device(vals), device.to_device(rng.normal(size=n))
+        y0 = rng.normal(size=n)
+
+        def products():
+            y = device.zeros(n)
+            tb.check(lib.tb_spmv_csr(pat.h, A.ptr, x.ptr, 1.0, 0.0, y.ptr))
+            y2 = device.to_device(y0)
+            tb.check(lib.tb_spmv_csr(pat.h, A.ptr, x.ptr, -0.5, 2.0, y2.ptr))
+            y3, d = device.zeros(n), device.zeros(1)
+            tb.check(lib.tb_spmv_csr_dot(pat.h, A.ptr, x.ptr, y3.ptr, d.ptr))
+            return y.to_host(), y2.to_host(), y3.to_host(), d.to_host()[0]
+
+        ref = products()
+        if not pat.mirror(A):
+            stats = np.zeros(2, dtype=np.int64)
+            tb.check(lib.tb_pattern_spmv_plan(pat.h, stats.ctypes.data_as(tb._lib.c_i64p)))
+            assert stats[0] == -1, name                                     # only patterns that do not compress lack a mirror
+            continue
+        mirrored.append(name)
+        got = products()
+        for a, b in zip(got[:3], ref[:3]):
+            np.testing.assert_array_equal(a, b, err_msg=name)
+        assert abs(got[3] - ref[3]) <= 1e-12 * abs(ref[3]), name               # the reduction over rows is grouped differently
+        # another array with this pattern is not served from the mirror; a re-bind after a change is
+        B = device.to_device(2.0 * vals)
+        yb = device.zeros(n)
+        tb.check(lib.tb_spmv_csr(pat.h, B.ptr, x.ptr, 1.0, 0.0, yb.ptr))
+        np.testing.assert_array_equal(yb.to_host(), 2.0 * ref[0], err_msg=name)
+        A.copy_from_host(-vals)
+        assert pat.mirror(A)
+        np.testing.assert_array_equal(products()[0], -ref[0], err_msg=name)
+        pat.mirror(None)
+        A.copy_from_host(vals)
+        np.testing.assert_array_equal(products()[0], ref[0], err_msg=name)
+    assert "hex + long rows" in mirrored and "q2 scalar" in mirrored, mirrored
+    # a solve on a bound matrix: same iterations, same solution
+    g = tb.generate_mesh(tb.Hexahedron, (24, 24, 24), perturb=0.1)
+    dh = tb.DofHandler(g)
+    sp = tb.allocate_matrix(dh)
+    st = tb.PatchAssemblyStrategy(device)
+    M = tb.setup_operator(st, tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.0)), dh, sp)
+    K = tb.setup_operator(st, tb.BilinearDiffusionIntegrator(tb.ConstantCoefficient(np.eye(3))), dh, sp)
+    tb.update_operators(M, K, 0.0)
+    Aheat = tb.heat_system_matrix(device, M, K, 0.05)
+    b = device.to_device(rng.normal(size=dh.ndofs))
+    x1, x2 = device.zeros(dh.ndofs), device.zeros(dh.ndofs)
+    it1, _ = tb.cg_solve(K.pattern, Aheat, b, x1, rtol=1e-10, atol=0.0, maxiter=500)
+    assert K.pattern.mirror(Aheat)
+    it2, _ = tb.cg_solve(K.pattern, Aheat, b, x2, rtol=1e-10, atol=0.0, maxiter=500)
+    K.pattern.mirror(None)
+    assert it1 == it2 and rel_err(x2.to_host(), x1.to_host()) < 1e-12
+    # 3 × 3 block rows keep their own kernel
+    dhv = tb.DofHandler(g, tb.LagrangeCollection(1) ** 3)
+    spv = tb.allocate_matrix(dhv)
+    patv = tb.DevicePattern(tb.DeviceMesh(device, dhv), spv)
+    assert patv.mirror(device.zeros(spv.nnz)) is False
+
+
 def test_index_compressed_spmv_is_bit_identical_to_the_csr_kernel(tb, device):
     """tb_spmv_csr on a finite-element pattern takes the index-compressed kernel (rows that hold the same column offsets share one signature: 4 B per
     row instead of 4 B per non-zero).  Same lane mapping and summation order as the CSR row kernel, so the products must agree

@@ -166,6 +166,7 @@ SIGNATURES = {
     "tb_scatter_indexed": (C.c_int, [vp, C.c_int64, vp, vp, vp]),
     "tb_spmv_csr_rows": (C.c_int, [vp, vp, vp, C.c_int64, vp, vp]),
     "tb_spmv_csr_dot": (C.c_int, [vp, vp, vp, vp, vp]),
+    "tb_spmv_mirror": (C.c_int, [vp, vp]),
     "tb_apply_zero_csr": (C.c_int, [vp, vp, vp, vp, C.c_double]),
     "tb_meandiag": (C.c_int, [vp, vp, C.POINTER(C.c_double)]),
     "tb_max": (C.c_int, [vp, C.c_int64, vp, C.c_int64, C.POINTER(C.c_double)]),

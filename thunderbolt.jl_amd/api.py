@@ -423,6 +423,16 @@ class DevicePattern:
         return {"patches": int(out[0]), "instances": int(out[1]), "cells": int(out[2]), "instances_per_cell": float(out[1]) / max(int(out[2]), 1),
                 "max_instances": int(out[3]), "max_rows": int(out[4]), "lds_bytes_per_block": int(out[5])}
 
+    def mirror(self, nz):
+        """Bind a sliced mirror of the value array `nz` (tb_spmv_mirror): every product of this pattern with `nz` — tb_spmv_csr, the products of the
+        Krylov solves — then streams the mirrored copy (coalesced, no LDS staging; the same bits).  Call again after changing the matrix; `nz=None`
+        unbinds.  Returns False where the pattern has no mirror (3 × 3 block rows, numberings without shared row signatures)."""
+        rc = lib().tb_spmv_mirror(self.h, None if nz is None else nz.ptr)
+        if rc == L.TB_ERR_UNSUPPORTED:
+            return False
+        check(rc)
+        return nz is not None
+
     def __del__(self):
         try:
             if self.h:
@@ -964,8 +974,9 @@ def gmres_solve(pattern, A, b, x, rtol=1e-8, atol=1e-14, maxiter=5000, restart=5
 class BackwardEulerSolver:
     """BackwardEulerSolver(; inner_solver = KrylovJL_CG(atol, rtol)) for an AffineODEFunction (euler.jl:4-15)."""
 
-    def __init__(self, rtol=1e-5, atol=1e-6, maxiter=1000, jacobi=True):
+    def __init__(self, rtol=1e-5, atol=1e-6, maxiter=1000, jacobi=True, mirror=True):
         self.rtol, self.atol, self.maxiter, self.jacobi = rtol, atol, maxiter, jacobi
+        self.mirror = mirror   # keep a sliced mirror of the system matrix for the products of the CG (tb_spmv_mirror): a second copy of its values
 
 
 class BackwardEulerStage:
@@ -989,6 +1000,8 @@ class BackwardEulerStage:
         if rebuilt:
             heat_system_matrix(self.device, self.M, self.K, dt, self.A)         # euler.jl:104-116
             self.dt_last = dt
+            if self.solver.mirror:                                              # A stays as it is until Δt changes: its products stream the mirror
+                self.M.pattern.mirror(self.A)
         # A uₙ = b with b = M uₙ₋₁ (+ f) and the initial guess uₙ₋₁ (euler.jl:85-100): the initial residual b − A uₙ₋₁ is Δt·K·uₙ₋₁ (+ f),
         # so one product with K stands for the two with M and A
         check(lib().tb_spmv_csr(self.K.pattern.h, self.K.A.ptr, _ptr(u), float(dt), 0.0, self.b.ptr))

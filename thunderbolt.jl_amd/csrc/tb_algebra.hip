@@ -723,6 +723,7 @@ static int sig_plan(tb_pattern *p, bool forced = false)
     TB_HIP(hipMalloc((void **)&p->d_sigoff, tab.size() * sizeof(int32_t)));
     TB_HIP(hipMemcpy(p->d_sigoff, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     p->n_sig = nsig; p->sig_entries = (int64_t)tab.size();
+    p->h_rowsig = std::move(rowsig); // (the slice table of the mirror marks the slices whose rows share one signature)
     if (getenv("TB_PLAN_VERBOSE"))
         fprintf(stderr, "[tbhip] SpMV signature plan: %lld rows, %lld signatures, table %lld entries (%.4f of the column array)\n", (long long)n, (long long)nsig,
                 (long long)tab.size(), (double)tab.size() / (double)std::max<int64_t>(p->nnz, 1));
@@ -752,6 +753,189 @@ static int wave_plan(tb_pattern *p)
     return TB_OK;
 }
 
+// ---- sliced mirror (tb_spmv_mirror) ----------------------------------------------------------------------------------------------------------
+// The Krylov solves multiply one fixed matrix many times, and the CSR order is the wrong order for that on a wide machine: a lane that owns a row
+// meets its values 216 bytes apart, so every kernel above parks the run in LDS first (load → LDS → barrier → LDS → product; 0.68 ms at 216³, 3.5
+// TB/s).  The mirror stores the same values slice by slice — 64 consecutive rows, entry k of all 64 rows side by side, zero-padded to the longest
+// row of the slice — so the product is one coalesced 512-byte load per entry and wave, the x gather, and the sums: no LDS, no barrier (0.47 ms,
+// 5 TB/s; scripts/microbench/sell_spmv.hip).  Column offsets come from the row's signature as in k_spmv_sig_rows (scalar loads when the slice
+// shares one signature, which is the rule on a hexahedral mesh), and a row's partial sums are formed in that kernel's order — entries k ≡ 0, 1, 2
+// (mod 3) ascending, then s₀ + (s₁ + s₂) — so the two products agree bit for bit.  The mirror is a second copy of the values (built in ≈ 1 ms
+// at 216³) bound to the array it was taken from: the caller re-binds after changing the matrix (include/tbhip.h).
+struct MirrorSlice { int64_t base, obase; uint32_t sig, width; uint32_t pad[2]; }; // 32 bytes
+constexpr uint32_t MIRROR_MIXED = 0xFFFFFFFFu;
+constexpr int32_t MIRROR_NONE = INT32_MIN; // column offset of a padding entry
+static int mirror_plan(tb_pattern *p)
+{
+    if (p->n_slices != 0) return TB_OK;
+    int rc = spmv_plans(p);
+    if (rc) return rc;
+    if (p->b3 > 0 || p->n_sig <= 0 || p->n_rows == 0) { p->n_slices = -1; return TB_OK; }
+    const int64_t ns = (p->n_rows + 63) / 64;
+    // one record per slice: {first value, first column offset, signature shared by its 64 rows or MIXED, width}.  A slice of one signature needs no
+    // per-row metadata (offsets by scalar loads from the signature table); a mixed slice — the two ends of a grid line meet in one slice out of three at
+    // 216³ — carries its column offsets entry-major like the values (4 B per entry, padding marked), so both kinds cost two trips: record → values
+    // and offsets → x
+    std::vector<MirrorSlice> rec((size_t)ns + 1);
+    std::vector<int32_t> offs;
+    int64_t at = 0;
+    for (int64_t s = 0; s < ns; ++s) {
+        const int64_t r0 = 64 * s, r1 = std::min<int64_t>(r0 + 64, p->n_rows);
+        int64_t w = 0;
+        bool uni = r1 - r0 == 64;
+        for (int64_t r = r0; r < r1; ++r) {
+            w = std::max<int64_t>(w, p->h_rowptr[r + 1] - p->h_rowptr[r]);
+            uni = uni && p->h_rowsig[r] == p->h_rowsig[r0];
+        }
+        if (w > 255) { p->n_slices = -1; return TB_OK; }
+        rec[s] = MirrorSlice{at, uni ? -1 : (int64_t)offs.size(), uni ? p->h_rowsig[r0] : MIRROR_MIXED, (uint32_t)w, {0, 0}};
+        if (!uni) {
+            const size_t o0 = offs.size();
+            offs.resize(o0 + (size_t)(64 * w), MIRROR_NONE);
+            for (int64_t r = r0; r < r1; ++r)
+                for (int64_t k = p->h_rowptr[r]; k < p->h_rowptr[r + 1]; ++k) offs[o0 + (size_t)(64 * (k - p->h_rowptr[r]) + (r - r0))] = p->h_colidx[k] - (int32_t)r;
+        }
+        at += 64 * w;
+    }
+    rec[ns] = MirrorSlice{at, -1, MIRROR_MIXED, 0, {0, 0}};
+    MirrorSlice *db = nullptr;
+    TB_HIP(hipMalloc((void **)&db, rec.size() * sizeof(MirrorSlice)));
+    TB_HIP(hipMemcpy(db, rec.data(), rec.size() * sizeof(MirrorSlice), hipMemcpyHostToDevice));
+    if (offs.empty()) offs.push_back(0);
+    TB_HIP(hipMalloc((void **)&p->d_mir_off, offs.size() * sizeof(int32_t)));
+    TB_HIP(hipMemcpy(p->d_mir_off, offs.data(), offs.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    p->d_mir_base = db; p->mir_entries = at; p->n_slices = ns;
+    if (getenv("TB_PLAN_VERBOSE")) {
+        int64_t mixed = 0;
+        for (int64_t s = 0; s < ns; ++s) mixed += rec[s].sig == MIRROR_MIXED;
+        fprintf(stderr, "[tbhip] SpMV mirror plan: %lld slices (%lld of mixed signatures), %lld value slots for %lld non-zeros\n", (long long)ns, (long long)mixed, (long long)at,
+                (long long)p->nnz);
+    }
+    return TB_OK;
+}
+
+// values of one slice, CSR → [k][lane]: the slice's entries are one contiguous range of the value array — copied to LDS coalesced, read back
+// transposed (slices wider than the LDS block read their rows directly)
+__global__ void __launch_bounds__(256)
+k_mirror_fill(int64_t n_rows, int64_t n_slices, const MirrorSlice *__restrict__ slices, const int64_t *__restrict__ rowptr, const double *__restrict__ nz,
+              double *__restrict__ mir)
+{
+    constexpr int CAPW = 64 * 32;
+    __shared__ double s[4][CAPW];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t slice = (int64_t)blockIdx.x * 4 + wv;
+    if (slice >= n_slices) return; // waves are independent (no workgroup barrier below)
+    const int64_t r0 = slice * 64, r1 = r0 + 64 < n_rows ? r0 + 64 : n_rows;
+    const int64_t row = r0 + lane < n_rows ? r0 + lane : n_rows - 1;
+    const int64_t pa = rowptr[row], k0 = rowptr[r0];
+    const int n = r0 + lane < n_rows ? (int)(rowptr[row + 1] - pa) : 0;
+    const int total = (int)(rowptr[r1] - k0);
+    const int64_t b0 = slices[slice].base;
+    const int W = (int)slices[slice].width;
+    double *dst = mir + b0 + lane;
+    if (total <= CAPW) {
+        for (int i = lane; i < total; i += 64) s[wv][i] = nz[k0 + i];
+        __builtin_amdgcn_wave_barrier();
+        const int a = (int)(pa - k0);
+        for (int k = 0; k < W; ++k) dst[64 * k] = k < n ? s[wv][a + k] : 0.0;
+    } else {
+        for (int k = 0; k < W; ++k) dst[64 * k] = k < n ? nz[pa + k] : 0.0;
+    }
+}
+
+template <bool DOT>
+__global__ void __launch_bounds__(256)
+k_spmv_mirror(int64_t n_rows, int64_t n_slices, const MirrorSlice *__restrict__ slices, const int32_t *__restrict__ moff, const int32_t *__restrict__ sigoff,
+              const double *__restrict__ mir, const double *__restrict__ x, double alpha, double beta, double *__restrict__ y, double *__restrict__ xy)
+{
+    constexpr int NK = 27;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    double acc = 0.0;
+    for (int64_t slice = wave0; slice < n_slices; slice += nwaves) {
+        const MirrorSlice rec = slices[slice]; // wave-uniform: scalar loads
+        const int W = (int)rec.width;
+        const double *vs = mir + rec.base + lane;
+        const int64_t row = slice * 64 + lane;
+        const bool ok = row < n_rows;
+        const int64_t rc = ok ? row : n_rows - 1; // (lanes past the last row: all their entries are padding)
+        double vv[NK], xx[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) vv[k] = k < W ? __builtin_nontemporal_load(vs + 64 * k) : 0.0;
+        bool on[NK]; // entry k belongs to the lane's row (k < its length)
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+        if (rec.sig != MIRROR_MIXED) { // 64 rows of one signature: offsets by scalar loads, every row as wide as the slice
+#pragma unroll
+            for (int k = 0; k < NK; ++k) { on[k] = k < W; xx[k] = on[k] ? x[row + sigoff[rec.sig + k]] : 0.0; }
+        } else {
+            const int32_t *os = moff + rec.obase + lane;
+            int32_t oo[NK];
+#pragma unroll
+            for (int k = 0; k < NK; ++k) oo[k] = k < W ? __builtin_nontemporal_load(os + 64 * k) : MIRROR_NONE;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) { on[k] = oo[k] != MIRROR_NONE; xx[k] = on[k] ? x[rc + oo[k]] : 0.0; }
+        }
+#pragma unroll
+        for (int t_ = 0; t_ < NK / 3; ++t_) { // (the expressions of k_spmv_sig_rows: identical rounding)
+            s0 += on[3 * t_] ? vv[3 * t_] * xx[3 * t_] : 0.0;
+            s1 += on[3 * t_ + 1] ? vv[3 * t_ + 1] * xx[3 * t_ + 1] : 0.0;
+            s2 += on[3 * t_ + 2] ? vv[3 * t_ + 2] * xx[3 * t_ + 2] : 0.0;
+        }
+        for (int k = NK; k < W; k += 3) { // rows longer than 27 entries
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                if (k + j >= W) break;
+                const int32_t o = rec.sig != MIRROR_MIXED ? sigoff[rec.sig + k + j] : moff[rec.obase + 64 * (k + j) + lane];
+                if (o != MIRROR_NONE) {
+                    const double a = vs[64 * (k + j)], b = x[rc + o];
+                    if (j == 0) s0 += a * b; else if (j == 1) s1 += a * b; else s2 += a * b;
+                }
+            }
+        }
+        const double v = s0 + (s1 + s2);
+        if (ok) {
+            if constexpr (DOT) { y[row] = v; acc += x[row] * v; }
+            else y[row] = beta == 0.0 ? alpha * v : alpha * v + beta * y[row];
+        }
+    }
+    if constexpr (DOT) block_sum_to(acc, xy);
+}
+
+int launch_mirror_bind(tb_pattern *p, const double *nz)
+{
+    tb_device *dev = p->mesh->dev;
+    if (!nz) { p->mir_nz = nullptr; return TB_OK; }
+    int rc = mirror_plan(p);
+    if (rc) return rc;
+    if (p->n_slices <= 0) { set_error("tb_spmv_mirror: this pattern has no sliced mirror (3x3-block rows, a numbering without shared row signatures, or rows longer than 255 entries)"); return TB_ERR_UNSUPPORTED; }
+    if (!p->d_mir) {
+        const size_t bytes = (size_t)p->mir_entries * sizeof(double);
+        hipError_t e = hipMalloc((void **)&p->d_mir, bytes);
+        if (e != hipSuccess) { set_error("tb_spmv_mirror: value mirror (%zu B): %s", bytes, hipGetErrorString(e)); return TB_ERR_NOMEM; }
+    }
+    hipLaunchKernelGGL(k_mirror_fill, dim3((unsigned)((p->n_slices + 3) / 4)), dim3(256), 0, dev->stream, p->n_rows, p->n_slices, (const MirrorSlice *)p->d_mir_base, p->d_rowptr, nz, p->d_mir);
+    TB_HIP(hipGetLastError());
+    p->mir_nz = nz;
+    return TB_OK;
+}
+
+template <bool DOT>
+static void launch_mirror(tb_pattern *p, const double *x, double alpha, double beta, double *y, double *xy)
+{
+    static int per_cu = 0;
+    if (!per_cu) {
+        if (getenv("TB_SPMV_MIRROR_WG_PER_CU")) per_cu = atoi(getenv("TB_SPMV_MIRROR_WG_PER_CU"));
+        if (per_cu <= 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_spmv_mirror<DOT>, 256, 0) != hipSuccess || per_cu <= 0)) per_cu = 4;
+    }
+    // one slice per wave where nothing is reduced (measured at 216³: 0.52 ms against 0.57 ms with resident workgroups only); the fused xᵀAx form keeps
+    // the resident grid — its workgroups end in one atomic each
+    const int64_t grid_env = getenv("TB_SPMV_MIRROR_GRID") ? atoll(getenv("TB_SPMV_MIRROR_GRID")) : 0; // (read per launch: sweeps)
+    const int64_t cap = grid_env > 0 ? grid_env : DOT ? (int64_t)p->mesh->dev->n_cu * per_cu * 4 : (int64_t)1 << 30;
+    const unsigned grid = (unsigned)std::min<int64_t>((p->n_slices + 3) / 4, cap);
+    hipLaunchKernelGGL((k_spmv_mirror<DOT>), dim3(grid), dim3(256), 0, p->mesh->dev->stream, p->n_rows, p->n_slices, (const MirrorSlice *)p->d_mir_base, p->d_mir_off, p->d_sigoff,
+                       p->d_mir, x, alpha, beta, y, xy);
+}
+
 // TB_SPMV_KERNEL=chain: the five-trip kernel, kept as the comparison build
 static bool spmv_chain_kernel()
 {
@@ -766,6 +950,7 @@ static void launch_stream(tb_pattern *p, const double *nz, const double *x, doub
     static bool once = false;
     if (!once) { once = true; const int v = getenv("TB_SPMV_NOGATHER") ? 1 : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_spmv_nogather), &v, sizeof(int)); }
 #endif
+    if (p->mir_nz == nz && p->d_mir) { launch_mirror<DOT>(p, x, alpha, beta, y, xy); return; } // the caller bound a sliced mirror of this very array
     static const bool rows_kernel = !(getenv("TB_SPMV_KERNEL") && strcmp(getenv("TB_SPMV_KERNEL"), "rows") != 0 && strcmp(getenv("TB_SPMV_KERNEL"), "sig") != 0 &&
                                       strcmp(getenv("TB_SPMV_KERNEL"), "wave") != 0); // "rec" / "chain": entry-per-lane kernels
     const bool wave_kernel = getenv("TB_SPMV_KERNEL") && !strcmp(getenv("TB_SPMV_KERNEL"), "wave"); // read per launch: the bit-identity test switches it inside one process

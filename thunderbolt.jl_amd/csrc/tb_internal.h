@@ -199,6 +199,15 @@ struct tb_pattern {
     int32_t *d_sigoff = nullptr;    // signatures back to back: column offsets relative to the row
     int64_t n_sig = 0;              // 0 = not planned yet, −1 = the pattern does not compress (CSR kernel), > 0 = signatures in the table
     int64_t sig_entries = 0;
+    // sliced mirror of one value array (tb_spmv_mirror): per slice of 64 consecutive rows the values as [entry k][lane], zero-padded to the longest
+    // row of the slice — every value load of the product a coalesced 512-byte run, no LDS staging.  Column offsets come from the signature table.
+    double *d_mir = nullptr;        // mirrored values (Σ 64 · width doubles)
+    void *d_mir_base = nullptr;     // n_slices + 1 slice records {first value, first column offset, shared signature or none, width}
+    int32_t *d_mir_off = nullptr;   // column offsets of the slices of mixed signatures, entry-major like the values
+    std::vector<uint32_t> h_rowsig; // host copy of d_rowsig (slice table)
+    int64_t n_slices = 0;           // 0 = not planned, −1 = the pattern has no mirror (no signature plan, rows longer than 255 entries)
+    int64_t mir_entries = 0;
+    const double *mir_nz = nullptr; // the value array the mirror currently reflects (products with this pointer use it); NULL = unbound
     uint32_t *d_wrunrec = nullptr;  // wave-private SpMV (TB_SPMV_KERNEL=wave): runs of ≤ 21 rows as 16-byte records
     int64_t n_wrun = 0;
     uint16_t *d_q2pos = nullptr;    // scalar Q2 forms: position of col dof(j) in row dof(i), per cell and pair
@@ -339,6 +348,7 @@ int launch_cgd_rotate(tb_device *dev, double *d_S);
 int spmv_plans(tb_pattern *p); // builds the plans tb_spmv_csr would build on its first product
 int launch_scatter_indexed(tb_device *dev, int64_t n, const double *in, const int32_t *idx, double *vec);
 int launch_spmv_rows(tb_pattern *p, const double *nz, const double *x, int64_t n, const int32_t *rows, double *out);
+int launch_mirror_bind(tb_pattern *p, const double *nz); // tb_spmv_mirror
 int launch_extract_diagonal(tb_pattern *p, const double *nz, double *diag);
 int launch_spmv_dot(tb_pattern *pat, const double *A, const double *x, double *y, double *d_dot);
 double decode_ordered_key(unsigned long long k);
