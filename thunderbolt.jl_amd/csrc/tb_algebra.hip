@@ -922,15 +922,10 @@ int launch_mirror_bind(tb_pattern *p, const double *nz)
 template <bool DOT>
 static void launch_mirror(tb_pattern *p, const double *x, double alpha, double beta, double *y, double *xy)
 {
-    static int per_cu = 0;
-    if (!per_cu) {
-        if (getenv("TB_SPMV_MIRROR_WG_PER_CU")) per_cu = atoi(getenv("TB_SPMV_MIRROR_WG_PER_CU"));
-        if (per_cu <= 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_spmv_mirror<DOT>, 256, 0) != hipSuccess || per_cu <= 0)) per_cu = 4;
-    }
-    // one slice per wave where nothing is reduced (measured at 216³: 0.52 ms against 0.57 ms with resident workgroups only); the fused xᵀAx form keeps
-    // the resident grid — its workgroups end in one atomic each
+    // one slice per wave where nothing is reduced (measured at 216³: 0.52 ms against 0.57 ms with resident workgroups only); the fused xᵀAx form ends
+    // every workgroup in one atomic on the same scalar: 48 workgroups per CU (0.54 ms; 3 072 / 4 096 / 8 192 / 24 576 / all 40 000: 0.56 / 0.55 / 0.55 / 0.56 / 0.62)
     const int64_t grid_env = getenv("TB_SPMV_MIRROR_GRID") ? atoll(getenv("TB_SPMV_MIRROR_GRID")) : 0; // (read per launch: sweeps)
-    const int64_t cap = grid_env > 0 ? grid_env : DOT ? (int64_t)p->mesh->dev->n_cu * per_cu * 4 : (int64_t)1 << 30;
+    const int64_t cap = grid_env > 0 ? grid_env : DOT ? (int64_t)p->mesh->dev->n_cu * 48 : (int64_t)1 << 30;
     const unsigned grid = (unsigned)std::min<int64_t>((p->n_slices + 3) / 4, cap);
     hipLaunchKernelGGL((k_spmv_mirror<DOT>), dim3(grid), dim3(256), 0, p->mesh->dev->stream, p->n_rows, p->n_slices, (const MirrorSlice *)p->d_mir_base, p->d_mir_off, p->d_sigoff,
                        p->d_mir, x, alpha, beta, y, xy);
