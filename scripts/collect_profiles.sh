@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 out=gpurun_out/$tag
 mkdir -p "$out"
 # micro-benchmarks are built here (binaries are not tracked)
-for mb in mfma_f64 mfma_f64_4x4 lds_atomic wg_launch mall_reuse; do
+for mb in mfma_f64 mfma_f64_4x4 lds_atomic wg_launch mall_reuse sell_spmv; do
   [ -f scripts/microbench/$mb.hip ] && hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics scripts/microbench/$mb.hip -o scripts/microbench/$mb.bin 2>/dev/null
 done
 python3 bench.py > "$out/bench_216.json" 2> "$out/bench_216.err"
@@ -39,6 +39,13 @@ if [ "$2" != "bench-only" ]; then
   # the 27-layer slab of the strong-scaling split, kernel trace
   rocprofv3 --kernel-trace --stats -d "$out/kt27" -o kt27 -- python3 bench.py --no-cpu-baseline --layers 27 --steps 50 > /dev/null 2>&1
   python3 scripts/rocpd_summary.py "$out/kt27/kt27_results.db" --json "$out/slab27_kernel_stats.json" > "$out/slab27_kernel_stats.txt"
+  # the CG product: CSR kernel against the sliced mirror, and the synthetic all-uniform-slices bound
+  python3 scripts/bench_spmv.py > "$out/spmv_216.json" 2>/dev/null
+  [ -x scripts/microbench/sell_spmv.bin ] && ./scripts/microbench/sell_spmv.bin > "$out/sell_spmv_microbench.txt" 2>&1
+  # chunked mechanics linearisation: do integration and gather of neighbouring chunks run side by side? (kernel timeline of the last linearisations)
+  rocprofv3 --kernel-trace --output-format csv -d "$out/ktc" -- python3 scripts/bench_mechanics.py --n 80 --steps 2 --cpu-n 2 > /dev/null 2>&1
+  python3 scripts/trace_timeline.py "$out/ktc" "" 44 > "$out/mechanics_chunk_timeline.txt" 2>&1
+  rm -rf "$out/ktc"
   # scalar forms on the quadratic field
   python3 scripts/bench_q2_scalar.py --n 64 > "$out/q2_scalar_64.json" 2>/dev/null
   rocprofv3 --kernel-trace --stats -d "$out/ktq" -o ktq -- python3 scripts/bench_q2_scalar.py --n 64 --strategies element > /dev/null 2>&1
