@@ -393,10 +393,10 @@ def main():
             torch.cuda.synchronize()
             return {"iteration_ms": t_it * 1e3, "product_halo_dot_ms": ea.elapsed_ms(eb) / nit, "local_spmv_ms": eb.elapsed_ms(ec) / nit,
                     "local_spmv_csr_ms": ec.elapsed_ms(ed) / nit, "spmv_mirror": bool(mirrored), "spmv_mirror_bind_ms": bind_ms,
-                    # algorithmic bytes of one iteration: the matrix values once (8 B per non-zero) + 13 passes over vectors of the rows (product:
+                    # algorithmic bytes of one iteration: the matrix values once (8 B per non-zero) + 12–13 passes over vectors of the rows (product:
                     # p in, Ap out; update: p, Ap, x, r, D⁻¹, weights in, x, r out; direction: r, D⁻¹, p in, p out) — against the 8 TB/s of the guide
-                    "bytes_per_iteration": 8.0 * self.sp.nnz + 13 * 8.0 * npts,
-                    "hbm_frac": (8.0 * self.sp.nnz + 13 * 8.0 * npts) / (t_it * 8.0e12),
+                    "bytes_per_iteration": 8.0 * self.sp.nnz + (13 if cg.nb else 12) * 8.0 * npts,     # (no weights read without shared dofs)
+                    "hbm_frac": (8.0 * self.sp.nnz + (13 if cg.nb else 12) * 8.0 * npts) / (t_it * 8.0e12),
                     "halo_bytes_per_rank": self.halo.nbytes, "rows_per_rank": npts, "nnz_per_rank": self.sp.nnz,
                     "note": "one Jacobi-CG iteration on A = M - dt K under the partition (barrier-bracketed, max over ranks, host-timed over %d iterations, device "
                             "scalars, no host read): interface rows packed first, exchange overlapped with the local SpMV + p'Ap, two all-reduces" % nit}
