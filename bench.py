@@ -27,6 +27,7 @@ region (3·cells per step / step time, reaction included in the step time); DoF-
 per-phase rates are extra keys.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -328,6 +329,8 @@ def main():
             # the timed steps run with the status deferred (tb_device_defer_status): the mesh is fixed, so the per-call check of the warm-up steps
             # is what a time loop needs; the steps enqueue back to back and the one status read of the region sits inside it, before the clock stops
             dev.defer_status(True)
+            for k_ in self.phase:
+                self.phase[k_] = 0.0
             t0 = time.perf_counter()
             for i in range(steps):
                 self.step(warmup + i, True)
@@ -439,9 +442,16 @@ def main():
         for N in (2, 4, 8):
             L_ = n // N
             q = Problem((n, n, L_), (0.0, 0.0, 0.0), (1.0, 1.0, L_ / n), 0, 1, (None, None), None)
-            el = q.time_steps(max(2, args.warmup), max(5, args.steps))
+            # the better of two timings (this is a prediction from kernel times, not the contract's timed region: a stall of the host — the
+            # collector freeing the previous slab's multi-GB buffers, a page-in — once put 20 ms into a 0.9 ms step)
+            gc.collect(); torch.cuda.synchronize()
+            el, ph = None, None
+            for _ in range(2):
+                e_ = q.time_steps(max(2, args.warmup), max(5, args.steps))
+                if el is None or e_ < el:
+                    el, ph = e_, dict(q.phase)
             ent = {"step_ms": el / max(5, args.steps) * 1e3, "cells": q.g.n_cells, "gpus": N,
-                   "phase_ms": {k: v / max(5, args.steps) for k, v in q.phase.items() if v > 0.0}}
+                   "phase_ms": {k: v / max(5, args.steps) for k, v in ph.items() if v > 0.0}}
             ent["predicted_speedup_step"] = base["step_ms"] / ent["step_ms"]
             if dist_cg:
                 ent["cg_iteration_ms"] = q.time_cg()["iteration_ms"]
