@@ -331,10 +331,12 @@ def main():
             dev.defer_status(True)
             for k_ in self.phase:
                 self.phase[k_] = 0.0
+            gc.collect(); gc.disable()                               # no collector pause (freeing buffers of earlier set-up) between the two clock reads
             t0 = time.perf_counter()
             for i in range(steps):
                 self.step(warmup + i, True)
             torch.cuda.synchronize()
+            gc.enable()
             dev.poll_status()
             if self.dist is not None:
                 self.dist.barrier()
