@@ -513,7 +513,7 @@ int tb_pattern_spmv_plan(tb_pattern *pat, int64_t *out2);
  *                                 tb_cg_solve and the other solvers) reads the mirror: coalesced loads, no LDS staging, the same bits as the CSR kernel.
  *   tb_spmv_mirror(pat, NULL)     unbinds (the buffers stay for the next bind).
  * The caller keeps the contract that a bound array is not modified: after assembling into it, or forming M − Δt·K in it again, call tb_spmv_mirror
- * again.  Row-subset products (tb_spmv_csr_rows) and the diagonal extraction keep reading the CSR array.  TB_ERR_UNSUPPORTED for patterns without a
+ * again — and unbinds before freeing it: the binding is the address, and an allocator may hand the same address to the next matrix.  Row-subset products (tb_spmv_csr_rows) and the diagonal extraction keep reading the CSR array.  TB_ERR_UNSUPPORTED for patterns without a
  * mirror: 3×3-block rows (their own kernel), numberings whose rows share no column-offset signatures, rows longer than 255 entries. */
 int tb_spmv_mirror(tb_pattern *pat, const double *d_nzval);
 int tb_spmv_csr_rows(tb_pattern *pat, const double *d_nzval, const double *d_x, int64_t n_rows, const int32_t *d_rows, double *d_out);
