@@ -512,6 +512,8 @@ int tb_pattern_spmv_plan(tb_pattern *pat, int64_t *out2);
  *                                 from now on every product of this pattern with THIS pointer (tb_spmv_csr, tb_spmv_csr_dot, the products inside
  *                                 tb_cg_solve and the other solvers) reads the mirror: coalesced loads, no LDS staging, the same bits as the CSR kernel.
  *   tb_spmv_mirror(pat, NULL)     unbinds (the buffers stay for the next bind).
+ * A pattern holds two mirrors (the system matrix of a solve and one more — K for the right-hand side Δt·K·uₙ₋₁ of the heat step): binding an array that is
+ * already bound refreshes its mirror, a third array takes the place of the one bound longest ago.
  * The caller keeps the contract that a bound array is not modified: after assembling into it, or forming M − Δt·K in it again, call tb_spmv_mirror
  * again — and unbinds before freeing it: the binding is the address, and an allocator may hand the same address to the next matrix.  Row-subset products (tb_spmv_csr_rows) and the diagonal extraction keep reading the CSR array.  TB_ERR_UNSUPPORTED for patterns without a
  * mirror: 3×3-block rows (their own kernel), numberings whose rows share no column-offset signatures, rows longer than 255 entries. */

@@ -2742,8 +2742,18 @@ def test_sliced_mirror_products_equal_the_csr_products(tb, device):
         A.copy_from_host(-vals)
         assert pat.mirror(A)
         np.testing.assert_array_equal(products()[0], -ref[0], err_msg=name)
-        pat.mirror(None)
+        # two arrays bound at once (the system matrix and K of the heat step), a third replaces the older binding
         A.copy_from_host(vals)
+        assert pat.mirror(A) and pat.mirror(B)
+        tb.check(lib.tb_spmv_csr(pat.h, B.ptr, x.ptr, 1.0, 0.0, yb.ptr))
+        np.testing.assert_array_equal(yb.to_host(), 2.0 * ref[0], err_msg=name)
+        np.testing.assert_array_equal(products()[0], ref[0], err_msg=name)
+        Cc = device.to_device(4.0 * vals)                                           # (powers of two scale the product exactly)
+        assert pat.mirror(Cc)
+        tb.check(lib.tb_spmv_csr(pat.h, Cc.ptr, x.ptr, 1.0, 0.0, yb.ptr))
+        np.testing.assert_array_equal(yb.to_host(), 4.0 * ref[0], err_msg=name)
+        np.testing.assert_array_equal(products()[0], ref[0], err_msg=name)          # A lost its slot to Cc or kept it: the CSR array gives the same bits
+        pat.mirror(None)
         np.testing.assert_array_equal(products()[0], ref[0], err_msg=name)
     assert "hex + long rows" in mirrored and "q2 scalar" in mirrored, mirrored
     # a solve on a bound matrix: same iterations, same solution

@@ -431,6 +431,8 @@ class DevicePattern:
         if rc == L.TB_ERR_UNSUPPORTED:
             return False
         check(rc)
+        # the binding is the address: keep the bound vectors alive so that the allocator cannot hand their addresses to another matrix (two slots per pattern)
+        self._mirrored = [] if nz is None else ([v for v in getattr(self, "_mirrored", []) if v is not nz] + [nz])[-2:]
         return nz is not None
 
     def __del__(self):
@@ -991,6 +993,8 @@ class BackwardEulerStage:
         self.source = None if source is None else update_operator(setup_operator(strategy, source, dh), t0)
         self.A = DeviceVector(self.device, self.sp.nnz)
         self.b = DeviceVector(self.device, dh.ndofs)
+        if solver.mirror:                                                       # K multiplies uₙ₋₁ once per step (the right-hand side below); re-bind after update_operator(K)
+            self.K.pattern.mirror(self.K.A)
         self.dt_last = None
         self.last_iters = 0
 

@@ -904,23 +904,29 @@ k_spmv_mirror(int64_t n_rows, int64_t n_slices, const MirrorSlice *__restrict__ 
 int launch_mirror_bind(tb_pattern *p, const double *nz)
 {
     tb_device *dev = p->mesh->dev;
-    if (!nz) { p->mir_nz = nullptr; return TB_OK; }
+    if (!nz) { for (const double *&q : p->mir_nz) q = nullptr; return TB_OK; }
     int rc = mirror_plan(p);
     if (rc) return rc;
     if (p->n_slices <= 0) { set_error("tb_spmv_mirror: this pattern has no sliced mirror (3x3-block rows, a numbering without shared row signatures, or rows longer than 255 entries)"); return TB_ERR_UNSUPPORTED; }
-    if (!p->d_mir) {
+    // the slot already bound to this array (a refresh), else a free one, else the one bound longest ago
+    int slot = -1;
+    for (int i = 0; i < tb_pattern::MIRRORS; ++i) if (p->mir_nz[i] == nz) slot = i;
+    if (slot < 0) for (int i = 0; i < tb_pattern::MIRRORS; ++i) if (!p->mir_nz[i]) { slot = i; break; }
+    if (slot < 0) { slot = p->mir_next; p->mir_next = (p->mir_next + 1) % tb_pattern::MIRRORS; }
+    if (!p->d_mir[slot]) {
         const size_t bytes = (size_t)p->mir_entries * sizeof(double);
-        hipError_t e = hipMalloc((void **)&p->d_mir, bytes);
+        hipError_t e = hipMalloc((void **)&p->d_mir[slot], bytes);
         if (e != hipSuccess) { set_error("tb_spmv_mirror: value mirror (%zu B): %s", bytes, hipGetErrorString(e)); return TB_ERR_NOMEM; }
     }
-    hipLaunchKernelGGL(k_mirror_fill, dim3((unsigned)((p->n_slices + 3) / 4)), dim3(256), 0, dev->stream, p->n_rows, p->n_slices, (const MirrorSlice *)p->d_mir_base, p->d_rowptr, nz, p->d_mir);
+    hipLaunchKernelGGL(k_mirror_fill, dim3((unsigned)((p->n_slices + 3) / 4)), dim3(256), 0, dev->stream, p->n_rows, p->n_slices, (const MirrorSlice *)p->d_mir_base, p->d_rowptr, nz,
+                       p->d_mir[slot]);
     TB_HIP(hipGetLastError());
-    p->mir_nz = nz;
+    p->mir_nz[slot] = nz;
     return TB_OK;
 }
 
 template <bool DOT>
-static void launch_mirror(tb_pattern *p, const double *x, double alpha, double beta, double *y, double *xy)
+static void launch_mirror(tb_pattern *p, const double *mir, const double *x, double alpha, double beta, double *y, double *xy)
 {
     // one slice per wave where nothing is reduced (measured at 216³: 0.52 ms against 0.57 ms with resident workgroups only); the fused xᵀAx form ends
     // every workgroup in one atomic on the same scalar: 48 workgroups per CU (0.54 ms; 3 072 / 4 096 / 8 192 / 24 576 / all 40 000: 0.56 / 0.55 / 0.55 / 0.56 / 0.62)
@@ -928,7 +934,7 @@ static void launch_mirror(tb_pattern *p, const double *x, double alpha, double b
     const int64_t cap = grid_env > 0 ? grid_env : DOT ? (int64_t)p->mesh->dev->n_cu * 48 : (int64_t)1 << 30;
     const unsigned grid = (unsigned)std::min<int64_t>((p->n_slices + 3) / 4, cap);
     hipLaunchKernelGGL((k_spmv_mirror<DOT>), dim3(grid), dim3(256), 0, p->mesh->dev->stream, p->n_rows, p->n_slices, (const MirrorSlice *)p->d_mir_base, p->d_mir_off, p->d_sigoff,
-                       p->d_mir, x, alpha, beta, y, xy);
+                       mir, x, alpha, beta, y, xy);
 }
 
 // TB_SPMV_KERNEL=chain: the five-trip kernel, kept as the comparison build
@@ -945,7 +951,8 @@ static void launch_stream(tb_pattern *p, const double *nz, const double *x, doub
     static bool once = false;
     if (!once) { once = true; const int v = getenv("TB_SPMV_NOGATHER") ? 1 : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_spmv_nogather), &v, sizeof(int)); }
 #endif
-    if (p->mir_nz == nz && p->d_mir) { launch_mirror<DOT>(p, x, alpha, beta, y, xy); return; } // the caller bound a sliced mirror of this very array
+    for (int i = 0; i < tb_pattern::MIRRORS; ++i) // the caller bound a sliced mirror of this very array
+        if (p->mir_nz[i] == nz && nz) { launch_mirror<DOT>(p, p->d_mir[i], x, alpha, beta, y, xy); return; }
     static const bool rows_kernel = !(getenv("TB_SPMV_KERNEL") && strcmp(getenv("TB_SPMV_KERNEL"), "rows") != 0 && strcmp(getenv("TB_SPMV_KERNEL"), "sig") != 0 &&
                                       strcmp(getenv("TB_SPMV_KERNEL"), "wave") != 0); // "rec" / "chain": entry-per-lane kernels
     const bool wave_kernel = getenv("TB_SPMV_KERNEL") && !strcmp(getenv("TB_SPMV_KERNEL"), "wave"); // read per launch: the bit-identity test switches it inside one process

@@ -341,7 +341,7 @@ int tb_pattern_create(tb_mesh *mesh, int64_t n_rows, const int64_t *rowptr, cons
 int tb_pattern_destroy(tb_pattern *p)
 {
     if (!p) return TB_OK;
-    hipFree(p->d_rowptr); hipFree(p->d_colidx); hipFree(p->d_blkrow); hipFree(p->d_blkrec); hipFree(p->d_rowsig); hipFree(p->d_sigoff); hipFree(p->d_wrunrec); hipFree(p->d_mir); hipFree(p->d_mir_base); hipFree(p->d_mir_off); hipFree(p->d_bcol); hipFree(p->d_diagpos); hipFree(p->d_emap); hipFree(p->d_blockpos); hipFree(p->d_cg_ws); hipFree(p->d_gmres_ws); hipFree(p->d_pcg_ws); hipFree(p->d_cheb_ws); hipFree(p->d_q2pos); hipFree(p->d_kebuf); hipFree(p->d_gnodes);
+    hipFree(p->d_rowptr); hipFree(p->d_colidx); hipFree(p->d_blkrow); hipFree(p->d_blkrec); hipFree(p->d_rowsig); hipFree(p->d_sigoff); hipFree(p->d_wrunrec); for (double *q : p->d_mir) hipFree(q); hipFree(p->d_mir_base); hipFree(p->d_mir_off); hipFree(p->d_bcol); hipFree(p->d_diagpos); hipFree(p->d_emap); hipFree(p->d_blockpos); hipFree(p->d_cg_ws); hipFree(p->d_gmres_ws); hipFree(p->d_pcg_ws); hipFree(p->d_cheb_ws); hipFree(p->d_q2pos); hipFree(p->d_kebuf); hipFree(p->d_gnodes);
     free_patch_mat_plan(p);
     free_patch_fused_plan(p);
     delete p;

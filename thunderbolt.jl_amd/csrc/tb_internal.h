@@ -201,13 +201,15 @@ struct tb_pattern {
     int64_t sig_entries = 0;
     // sliced mirror of one value array (tb_spmv_mirror): per slice of 64 consecutive rows the values as [entry k][lane], zero-padded to the longest
     // row of the slice — every value load of the product a coalesced 512-byte run, no LDS staging.  Column offsets come from the signature table.
-    double *d_mir = nullptr;        // mirrored values (Σ 64 · width doubles)
+    static constexpr int MIRRORS = 2; // arrays of one pattern that can be bound at a time (the system matrix of a solve and one more: K of the heat step's right-hand side)
+    double *d_mir[MIRRORS] = {nullptr, nullptr};        // mirrored values (Σ 64 · width doubles each)
     void *d_mir_base = nullptr;     // n_slices + 1 slice records {first value, first column offset, shared signature or none, width}
     int32_t *d_mir_off = nullptr;   // column offsets of the slices of mixed signatures, entry-major like the values
     std::vector<uint32_t> h_rowsig; // host copy of d_rowsig (slice table)
     int64_t n_slices = 0;           // 0 = not planned, −1 = the pattern has no mirror (no signature plan, rows longer than 255 entries)
     int64_t mir_entries = 0;
-    const double *mir_nz = nullptr; // the value array the mirror currently reflects (products with this pointer use it); NULL = unbound
+    const double *mir_nz[MIRRORS] = {nullptr, nullptr}; // the value array each mirror currently reflects (products with this pointer use it); NULL = unbound
+    int mir_next = 0;               // slot the next new binding takes when both are in use (the one bound longest ago)
     uint32_t *d_wrunrec = nullptr;  // wave-private SpMV (TB_SPMV_KERNEL=wave): runs of ≤ 21 rows as 16-byte records
     int64_t n_wrun = 0;
     uint16_t *d_q2pos = nullptr;    // scalar Q2 forms: position of col dof(j) in row dof(i), per cell and pair
