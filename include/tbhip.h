@@ -516,7 +516,8 @@ int tb_pattern_spmv_plan(tb_pattern *pat, int64_t *out2);
  * already bound refreshes its mirror, a third array takes the place of the one bound longest ago.
  * The caller keeps the contract that a bound array is not modified: after assembling into it, or forming M − Δt·K in it again, call tb_spmv_mirror
  * again — and unbinds before freeing it: the binding is the address, and an allocator may hand the same address to the next matrix.  Row-subset products (tb_spmv_csr_rows) and the diagonal extraction keep reading the CSR array.  TB_ERR_UNSUPPORTED for patterns without a
- * mirror: 3×3-block rows (their own kernel), numberings whose rows share no column-offset signatures, rows longer than 255 entries. */
+ * mirror: 3×3-block rows (their own kernel), rows longer than 255 entries.  (Numberings whose rows share no column-offset signatures are mirrored
+ * with their offsets stored entry-major beside the values: 12 instead of 8 bytes per non-zero, still coalesced.) */
 int tb_spmv_mirror(tb_pattern *pat, const double *d_nzval);
 int tb_spmv_csr_rows(tb_pattern *pat, const double *d_nzval, const double *d_x, int64_t n_rows, const int32_t *d_rows, double *d_out);
 int tb_spmv_csr_dot(tb_pattern *pat, const double *d_nzval, const double *d_x, double *d_y, double *d_dot);

@@ -2674,7 +2674,7 @@ def test_spmv_and_cg_on_ragged_superset_patterns(tb, device, long_row):
     assert its < 400 and np.abs(u.to_host() - xh).max() < 1e-8
 
 
-def test_sliced_mirror_products_equal_the_csr_products(tb, device):
+def test_sliced_mirror_products_equal_the_csr_products(tb, device, monkeypatch):
     """tb_spmv_mirror: products of a pattern with the array a sliced mirror was taken from read the mirror (64-row slices, entry-major, zero-padded) —
     the same partial sums in the same order as the CSR kernels, so plain, (α, β) and fused xᵀAx products agree bit for bit.  Patterns: the perturbed
     hexahedral grid with a few long rows (slices of mixed signatures, the tail loop), tetrahedra, the unstructured left-ventricle mesh, the quadratic
@@ -2706,10 +2706,17 @@ def test_sliced_mirror_products_equal_the_csr_products(tb, device):
     g = tb.generate_mesh(tb.Hexahedron, (16, 15, 14), perturb=0.1)
     dh = tb.DofHandler(g, tb.LagrangeCollection(2))
     cases.append(("q2 scalar", dh, tb.allocate_matrix(dh)))
+    g = tb.generate_mesh(tb.Hexahedron, (20, 11, 9), perturb=0.2)
+    dh = tb.DofHandler(g)
+    cases.append(("hex, signature plan off", dh, tb.allocate_matrix(dh)))          # every slice carries its column offsets
     mirrored = []
     for name, dh, sp in cases:
         n = dh.ndofs
         pat = tb.DevicePattern(tb.DeviceMesh(device, dh), sp)
+        if name.endswith("plan off"):
+            monkeypatch.setenv("TB_SPMV_KERNEL", "rows")                            # read when the pattern plans its products (the first one below)
+        else:
+            monkeypatch.delenv("TB_SPMV_KERNEL", raising=False)
         vals = rng.normal(size=sp.nnz)
         A, x = device.to_device(vals), device.to_device(rng.normal(size=n))
         y0 = rng.normal(size=n)
@@ -2724,11 +2731,7 @@ def test_sliced_mirror_products_equal_the_csr_products(tb, device):
             return y.to_host(), y2.to_host(), y3.to_host(), d.to_host()[0]
 
         ref = products()
-        if not pat.mirror(A):
-            stats = np.zeros(2, dtype=np.int64)
-            tb.check(lib.tb_pattern_spmv_plan(pat.h, stats.ctypes.data_as(tb._lib.c_i64p)))
-            assert stats[0] == -1, name                                     # only patterns that do not compress lack a mirror
-            continue
+        assert pat.mirror(A), name                                          # (patterns that do not compress carry their offsets beside the values)
         mirrored.append(name)
         got = products()
         for a, b in zip(got[:3], ref[:3]):
@@ -2755,7 +2758,11 @@ def test_sliced_mirror_products_equal_the_csr_products(tb, device):
         np.testing.assert_array_equal(products()[0], ref[0], err_msg=name)          # A lost its slot to Cc or kept it: the CSR array gives the same bits
         pat.mirror(None)
         np.testing.assert_array_equal(products()[0], ref[0], err_msg=name)
-    assert "hex + long rows" in mirrored and "q2 scalar" in mirrored, mirrored
+    assert len(mirrored) == 5
+    monkeypatch.delenv("TB_SPMV_KERNEL", raising=False)
+    stats = np.zeros(2, dtype=np.int64)
+    tb.check(lib.tb_pattern_spmv_plan(pat.h, stats.ctypes.data_as(tb._lib.c_i64p)))
+    assert stats[0] == -1                                                           # the last pattern really had no signatures
     # a solve on a bound matrix: same iterations, same solution
     g = tb.generate_mesh(tb.Hexahedron, (24, 24, 24), perturb=0.1)
     dh = tb.DofHandler(g)

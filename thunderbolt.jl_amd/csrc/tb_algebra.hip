@@ -770,7 +770,8 @@ static int mirror_plan(tb_pattern *p)
     if (p->n_slices != 0) return TB_OK;
     int rc = spmv_plans(p);
     if (rc) return rc;
-    if (p->b3 > 0 || p->n_sig <= 0 || p->n_rows == 0) { p->n_slices = -1; return TB_OK; }
+    if (p->b3 > 0 || p->n_rows == 0) { p->n_slices = -1; return TB_OK; }
+    const bool have_sig = p->n_sig > 0 && (int64_t)p->h_rowsig.size() == p->n_rows; // a numbering without shared signatures: every slice carries its offsets
     const int64_t ns = (p->n_rows + 63) / 64;
     // one record per slice: {first value, first column offset, signature shared by its 64 rows or MIXED, width}.  A slice of one signature needs no
     // per-row metadata (offsets by scalar loads from the signature table); a mixed slice — the two ends of a grid line meet in one slice out of three at
@@ -782,7 +783,7 @@ static int mirror_plan(tb_pattern *p)
     for (int64_t s = 0; s < ns; ++s) {
         const int64_t r0 = 64 * s, r1 = std::min<int64_t>(r0 + 64, p->n_rows);
         int64_t w = 0;
-        bool uni = r1 - r0 == 64;
+        bool uni = have_sig && r1 - r0 == 64;
         for (int64_t r = r0; r < r1; ++r) {
             w = std::max<int64_t>(w, p->h_rowptr[r + 1] - p->h_rowptr[r]);
             uni = uni && p->h_rowsig[r] == p->h_rowsig[r0];
@@ -907,7 +908,7 @@ int launch_mirror_bind(tb_pattern *p, const double *nz)
     if (!nz) { for (const double *&q : p->mir_nz) q = nullptr; return TB_OK; }
     int rc = mirror_plan(p);
     if (rc) return rc;
-    if (p->n_slices <= 0) { set_error("tb_spmv_mirror: this pattern has no sliced mirror (3x3-block rows, a numbering without shared row signatures, or rows longer than 255 entries)"); return TB_ERR_UNSUPPORTED; }
+    if (p->n_slices <= 0) { set_error("tb_spmv_mirror: this pattern has no sliced mirror (3x3-block rows, or rows longer than 255 entries)"); return TB_ERR_UNSUPPORTED; }
     // the slot already bound to this array (a refresh), else a free one, else the one bound longest ago
     int slot = -1;
     for (int i = 0; i < tb_pattern::MIRRORS; ++i) if (p->mir_nz[i] == nz) slot = i;
