@@ -1302,7 +1302,7 @@ def test_monodomain_operator_splitting_steps(tb, oracle, device):
     np.testing.assert_allclose(one.to_host(), 1.0, rtol=1e-10)
 
 
-def test_q2_scalar_forms_properties_48_cubed(tb, oracle, device):
+def test_q2_scalar_forms_properties_48_cubed(tb, oracle, device, monkeypatch):
     """The quadratic-field matrix kernels at a size where every persistent workgroup walks > 100 cells (110 592 cells, 912 673 dofs, 5.7·10⁷ nz):
     the three strategies agree, K·1 = 0, Σ M = volume, symmetry of a sample of entries, and a sample of rows equals the oracle's sum of 27 × 27
     element matrices; heterogeneous tensor field through the same kernels."""
@@ -1325,6 +1325,16 @@ def test_q2_scalar_forms_properties_48_cubed(tb, oracle, device):
             assert np.abs(y.to_host()).max() < 1e-11 * np.abs(res[name][1]).max()          # constants are in the kernel of K
     Mh, Kh = res["element"]
     np.testing.assert_allclose(Mh.sum(), 1.0, rtol=1e-12)                                        # Σ M = volume
+    # chunked form of the element strategy (TB_Q2_CHUNKS, opt-in: gather of a chunk's rows on the second queue beside the integration of the next
+    # chunk): the same bits as one launch of each kernel
+    for ch in ("8", "3"):
+        monkeypatch.setenv("TB_Q2_CHUNKS", ch)
+        st = tb.ElementAssemblyStrategy(device)
+        M2 = tb.update_operator(tb.setup_operator(st, tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.0)), dh, sp), 0.0)
+        K2 = tb.update_operator(tb.setup_operator(st, tb.BilinearDiffusionIntegrator(tb.ConstantCoefficient(D)), dh, sp), 0.0)
+        np.testing.assert_array_equal(M2.A.to_host(), Mh)
+        np.testing.assert_array_equal(K2.A.to_host(), Kh)
+    monkeypatch.delenv("TB_Q2_CHUNKS")
     for name in ("atomic", "color"):
         assert rel_err(res[name][0], Mh) < TOL and rel_err(res[name][1], Kh) < TOL, name
     rng = np.random.default_rng(3)

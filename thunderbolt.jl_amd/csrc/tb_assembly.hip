@@ -985,7 +985,7 @@ k_matrix_q2(MeshView m, FormArgs fa, const double *__restrict__ cell_xyz, const 
 // another order (≲ 1e-15 relative); no symmetry assumed, so non-symmetric constant tensors need no variant of their own.
 template <int FORM, bool FIELD>
 __global__ void __launch_bounds__(256, 2)
-k_matrix_q2_sf(MeshView m, FormArgs fa, const double *__restrict__ cell_xyz, const int32_t *__restrict__ list, int64_t n_list, const int64_t *__restrict__ rowptr,
+k_matrix_q2_sf(MeshView m, FormArgs fa, const double *__restrict__ cell_xyz, const int32_t *__restrict__ list, int64_t cell0, int64_t n_list, const int64_t *__restrict__ rowptr,
                const uint16_t *__restrict__ pos, double *__restrict__ nz, int atomic /*0 rmw, 1 atomic, 2 store Kₑ*/, double *__restrict__ ke, Status *st)
 {
     constexpr bool DIFF = FORM == TB_FORM_DIFFUSION;
@@ -995,7 +995,7 @@ k_matrix_q2_sf(MeshView m, FormArgs fa, const double *__restrict__ cell_xyz, con
     const int tid = threadIdx.x;
     auto PH = [](int i, int q) constexpr { return i == 0 ? 0.5 * (GX * (q - 1)) * (GX * (q - 1) - 1.0) : i == 1 ? 1.0 - (GX * (q - 1)) * (GX * (q - 1)) : 0.5 * (GX * (q - 1)) * (GX * (q - 1) + 1.0); };
     auto DP = [](int i, int q) constexpr { return i == 0 ? GX * (q - 1) - 0.5 : i == 1 ? -2.0 * (GX * (q - 1)) : GX * (q - 1) + 0.5; };
-    auto cell_of = [&](int64_t k) -> int64_t { return list ? (int64_t)list[k] : k; };
+    auto cell_of = [&](int64_t k) -> int64_t { return list ? (int64_t)list[k] : cell0 + k; }; // (cell0: first cell of a chunk of the chunked element assembly)
     const int64_t ntrip = (n_list + 2) / 3;
     // task of stages 2 + 3: cell kc of the triple, (j₁, j₀, i₁, i₀) — fixed for the life of the workgroup
     const int kc = tid / 81, t81 = tid - 81 * kc;
@@ -1163,12 +1163,12 @@ k_matrix_q2_sf(MeshView m, FormArgs fa, const double *__restrict__ cell_xyz, con
 // slots come from a fixed-width table (W per row, −1 padded: one load, no pointer chase) and the index and value loads of eight cells are all in
 // flight before the first addition.
 __global__ void __launch_bounds__(256)
-k_gather_rows_q2(int64_t n_rows, const int32_t *__restrict__ ell, int W, const double *__restrict__ ke, const uint16_t *__restrict__ pos,
+k_gather_rows_q2(int64_t row0, int64_t n_rows, const int32_t *__restrict__ ell, int W, const double *__restrict__ ke, const uint16_t *__restrict__ pos,
                  const int64_t *__restrict__ rowptr, double *__restrict__ nz, int max_row)
 {
     extern __shared__ double s_rows[];
     const int hw = threadIdx.x >> 5, l = threadIdx.x & 31;
-    const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 5) + hw;
+    const int64_t r = row0 + (int64_t)blockIdx.x * (blockDim.x >> 5) + hw; // rows [row0, n_rows)
     if (r >= n_rows) return;
     double *row = s_rows + (size_t)hw * max_row;
     const int64_t g0 = rowptr[r];
@@ -1302,12 +1302,13 @@ static int run_q2(tb_form *f, tb_pattern *p, int strategy, double t, double *d_n
         }
         kebuf = p->d_kebuf;
     }
+    int64_t cell0 = 0; // first cell of the launch (chunked element assembly below)
     auto go = [&](const int32_t *list, int64_t n, int atomic) -> int {
         if (n == 0) return TB_OK;
         static const bool q2_mfma = getenv("TB_Q2_KERNEL") && !strcmp(getenv("TB_Q2_KERNEL"), "mfma"); // the matrix-core kernel (comparison)
         if (d_nz && !q2_mfma && atomic == 2) { // sum-factorised element matrices: three cells per pass, persistent (the scattering strategies keep the matrix-core kernel: it hands its entries over in entry order)
             const unsigned wg3 = (unsigned)std::min<int64_t>((n + 2) / 3, (int64_t)dev->n_cu * 6);
-#define TB_Q2S(FORM, FIELD) hipLaunchKernelGGL((k_matrix_q2_sf<FORM, FIELD>), dim3(wg3), dim3(256), 0, dev->stream, mv, fa, m->d_cell_xyz, list, n, p->d_rowptr, p->d_q2pos, d_nz, atomic, kebuf, dev->d_status)
+#define TB_Q2S(FORM, FIELD) hipLaunchKernelGGL((k_matrix_q2_sf<FORM, FIELD>), dim3(wg3), dim3(256), 0, dev->stream, mv, fa, m->d_cell_xyz, list, cell0, n, p->d_rowptr, p->d_q2pos, d_nz, atomic, kebuf, dev->d_status)
             if (f->kind == TB_FORM_MASS) { if (f->field) TB_Q2S(TB_FORM_MASS, true); else TB_Q2S(TB_FORM_MASS, false); }
             else { if (f->field) TB_Q2S(TB_FORM_DIFFUSION, true); else TB_Q2S(TB_FORM_DIFFUSION, false); }
 #undef TB_Q2S
@@ -1329,14 +1330,48 @@ static int run_q2(tb_form *f, tb_pattern *p, int strategy, double t, double *d_n
         return TB_OK;
     };
     if (ea) {
-        int rc = go(nullptr, m->n_cells, 2);
-        if (rc) return rc;
         if (!p->max_row_len) for (int64_t r = 0; r < p->n_rows; ++r) p->max_row_len = std::max<int64_t>(p->max_row_len, p->h_rowptr[r + 1] - p->h_rowptr[r]);
         const int max_row = (int)p->max_row_len;
-        rc = ensure_ea_ell(m);
+        int rc = ensure_ea_ell(m);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_gather_rows_q2, dim3((unsigned)((m->ndofs + 7) / 8)), dim3(256), sizeof(double) * 8 * (size_t)max_row, dev->stream, m->ndofs,
-                           m->ea->d_ell, m->ea->ell_w, kebuf, p->d_q2pos, p->d_rowptr, d_nz, max_row);
+        auto gather = [&](hipStream_t st, int64_t r0, int64_t r1) {
+            if (r1 > r0)
+                hipLaunchKernelGGL(k_gather_rows_q2, dim3((unsigned)((r1 - r0 + 7) / 8)), dim3(256), sizeof(double) * 8 * (size_t)max_row, st, r0, r1, m->ea->d_ell, m->ea->ell_w, kebuf,
+                                   p->d_q2pos, p->d_rowptr, d_nz, max_row);
+        };
+        // Chunked element assembly (TB_Q2_CHUNKS=n, opt-in): the cells go in n launches and the rows a chunk completes — a prefix of the dofs, by the running
+        // maximum of their last contributing cell — are gathered on the second queue beside the integration of the next chunk.  Unlike the mechanics kernels
+        // (tb_mechanics.hip) the two fit on a CU together (the integration kernel leaves 100 registers per lane and 110 KB of LDS, the gather needs 40 and 8 KB),
+        // and still it is slower: 64³ diffusion 1.31 ms in one launch of each kernel, 1.43 / 1.53 / 1.64 ms in 4 / 8 / 16 chunks — the persistent integration
+        // kernel pays its set-up and its tail once per chunk, and together the two kernels move 4.6 GB, which is 0.9 ms at the streaming rate whatever the
+        // overlap.  Same kernels, same cell order inside every row sum: the one-launch result bit for bit (tested).
+        const int chunks = [] { const char *e = getenv("TB_Q2_CHUNKS"); return e ? atoi(e) : 0; }(); // (read per call)
+        static const bool q2_mfma_ = getenv("TB_Q2_KERNEL") && !strcmp(getenv("TB_Q2_KERNEL"), "mfma");
+        if (chunks > 1 && !q2_mfma_ && m->n_cells >= 4096 * (int64_t)chunks && (int64_t)m->ea->h_done.size() == m->ndofs) {
+            rc = ensure_aux_stream(dev);
+            if (rc) return rc;
+            int64_t done = 0;
+            for (int k = 0; k < chunks; ++k) {
+                const int64_t c0 = m->n_cells * k / chunks, c1 = m->n_cells * (k + 1) / chunks;
+                cell0 = c0;
+                rc = go(nullptr, c1 - c0, 2);
+                cell0 = 0;
+                if (rc) return rc;
+                TB_HIP(hipEventRecord(dev->aux_ev[0], dev->stream));
+                TB_HIP(hipStreamWaitEvent(dev->aux_stream, dev->aux_ev[0], 0));
+                const int64_t r1 = k + 1 == chunks ? m->ndofs
+                                                   : std::upper_bound(m->ea->h_done.begin(), m->ea->h_done.end(), (int32_t)(c1 - 1)) - m->ea->h_done.begin();
+                gather(dev->aux_stream, done, r1);
+                TB_HIP(hipGetLastError());
+                done = std::max(done, r1);
+            }
+            TB_HIP(hipEventRecord(dev->aux_ev[1], dev->aux_stream));
+            TB_HIP(hipStreamWaitEvent(dev->stream, dev->aux_ev[1], 0));
+            return TB_OK;
+        }
+        rc = go(nullptr, m->n_cells, 2);
+        if (rc) return rc;
+        gather(dev->stream, 0, m->ndofs);
         TB_HIP(hipGetLastError());
         return TB_OK;
     }

@@ -56,6 +56,8 @@ struct EAPlan {                // dof → contributing (cell, local) slots, cell
     double *d_ea = nullptr;    // n_cells*ndpc element vectors
     int32_t *d_ell = nullptr;  // the same slots as a fixed-width table (ell_w per dof, −1 padded), built on first use by ensure_ea_ell
     int ell_w = 0;
+    std::vector<int32_t> h_done; // per dof (scalar fields; built with d_ell): running maximum of the last contributing cell — the dofs before the first one whose
+                                 // value reaches c are complete once cells [0, c) are integrated (chunked element assembly: gather behind the integration front)
 };
 
 // Patch plan: cells in Morton order are cut into patches; every dof (row) is owned by exactly one
@@ -351,6 +353,7 @@ int spmv_plans(tb_pattern *p); // builds the plans tb_spmv_csr would build on it
 int launch_scatter_indexed(tb_device *dev, int64_t n, const double *in, const int32_t *idx, double *vec);
 int launch_spmv_rows(tb_pattern *p, const double *nz, const double *x, int64_t n, const int32_t *rows, double *out);
 int launch_mirror_bind(tb_pattern *p, const double *nz); // tb_spmv_mirror
+int ensure_aux_stream(tb_device *dev); // second queue + two events of the chunked element assemblies (tb_mechanics.hip, scalar Q2 forms)
 int launch_extract_diagonal(tb_pattern *p, const double *nz, double *diag);
 int launch_spmv_dot(tb_pattern *pat, const double *A, const double *x, double *y, double *d_dot);
 double decode_ordered_key(unsigned long long k);

@@ -1416,13 +1416,8 @@ static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, doubl
             chunked = p->gnodes_state > 0;
         }
         if (chunked) {
-            if (!dev->aux_stream) {
-                static const bool hi = [] { const char *e = getenv("TB_MECH_CHUNK_PRIO"); return e && atoi(e); }();
-                int lo_p = 0, hi_p = 0;
-                TB_HIP(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
-                TB_HIP(hipStreamCreateWithPriority(&dev->aux_stream, hipStreamNonBlocking, hi ? hi_p : lo_p));
-                for (hipEvent_t &e : dev->aux_ev) TB_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            }
+            rc = ensure_aux_stream(dev);
+            if (rc) return rc;
             const int nbr_pad = ((((int)p->max_row_len / 3 + 3) & ~3) + 7) & ~7;
             const size_t glds = (size_t)4 * 4 * (3 * FE::ND * sizeof(double) + (size_t)nbr_pad);
             int64_t n_done = 0;

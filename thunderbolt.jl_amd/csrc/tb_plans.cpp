@@ -55,6 +55,23 @@ int ensure_ea_ell(tb_mesh *m)
     int rc = upload(m->dev, ell, &m->ea->d_ell);
     if (rc) return rc;
     m->ea->ell_w = (int)w;
+    m->ea->h_done.resize((size_t)m->ndofs);
+    int32_t run = 0;
+    for (int64_t d = 0; d < m->ndofs; ++d) { // slots of a dof are cell-ordered: the last one is its last cell
+        if (ptr[d + 1] > ptr[d]) run = std::max(run, src[ptr[d + 1] - 1] / m->ndpc);
+        m->ea->h_done[d] = run;
+    }
+    return TB_OK;
+}
+
+int ensure_aux_stream(tb_device *dev)
+{
+    if (dev->aux_stream) return TB_OK;
+    static const bool hi = [] { const char *e = getenv("TB_MECH_CHUNK_PRIO"); return e && atoi(e); }();
+    int lo_p = 0, hi_p = 0;
+    TB_HIP(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
+    TB_HIP(hipStreamCreateWithPriority(&dev->aux_stream, hipStreamNonBlocking, hi ? hi_p : lo_p));
+    for (hipEvent_t &e : dev->aux_ev) TB_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return TB_OK;
 }
 
