@@ -35,6 +35,14 @@ def role(name):
         return "reaction" if "reaction" not in out["kernels"] else None
     if "k_vector" in name or "k_source" in name:
         return "source" if "source" not in out["kernels"] else None
+    if "k_spmv_mirrorILb1E" in name:
+        return "spmv_mirror_dot"     # the product of a CG iteration (fused with pᵀAp) from the sliced mirror
+    if "k_spmv_mirrorILb0E" in name:
+        return "spmv_mirror"
+    if "k_spmv_sig_rowsILi2048ELb0E" in name:
+        return "spmv_csr"
+    if "k_mirror_fill" in name:
+        return "mirror_fill"
     return None
 
 
