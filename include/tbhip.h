@@ -508,7 +508,7 @@ int tb_pattern_spmv_plan(tb_pattern *pat, int64_t *out2);
 /* Sliced mirror of one value array for the solves that multiply a fixed matrix many times (round 4; replaces nothing in the reference, whose
  * mul!(y, A, x) of the Krylov iteration — src/solver/time/euler.jl:94-100 through LinearSolve — reads the CSC / CSR arrays directly):
  *   tb_spmv_mirror(pat, d_nzval)  copies the values of d_nzval into the pattern's mirror — slices of 64 consecutive rows, entry k of the 64 rows side by
- *                                 side, zero-padded to the slice's longest row; a second copy of the values, ≈ 1 ms at 2.7·10⁸ non-zeros — and binds it:
+ *                                 side, zero-padded to the slice's longest row; a second copy of the values, ≈ 0.8 ms at 2.7·10⁸ non-zeros — and binds it:
  *                                 from now on every product of this pattern with THIS pointer (tb_spmv_csr, tb_spmv_csr_dot, the products inside
  *                                 tb_cg_solve and the other solvers) reads the mirror: coalesced loads, no LDS staging, the same bits as the CSR kernel.
  *   tb_spmv_mirror(pat, NULL)     unbinds (the buffers stay for the next bind).

@@ -835,10 +835,17 @@ k_mirror_fill(int64_t n_rows, int64_t n_slices, const MirrorSlice *__restrict__ 
     const int W = (int)slices[slice].width;
     double *dst = mir + b0 + lane;
     if (total <= CAPW) {
-        for (int i = lane; i < total; i += 64) s[wv][i] = nz[k0 + i];
+        for (int i0 = 0; i0 < total; i0 += 64 * 8) { // eight loads in flight per lane
+            double t[8];
+#pragma unroll
+            for (int u_ = 0; u_ < 8; ++u_) { const int i = i0 + 64 * u_ + lane; t[u_] = i < total ? __builtin_nontemporal_load(nz + k0 + i) : 0.0; }
+#pragma unroll
+            for (int u_ = 0; u_ < 8; ++u_) { const int i = i0 + 64 * u_ + lane; if (i < total) s[wv][i] = t[u_]; }
+        }
         __builtin_amdgcn_wave_barrier();
         const int a = (int)(pa - k0);
-        for (int k = 0; k < W; ++k) dst[64 * k] = k < n ? s[wv][a + k] : 0.0;
+#pragma unroll 9
+        for (int k = 0; k < W; ++k) __builtin_nontemporal_store(k < n ? s[wv][a + k] : 0.0, dst + 64 * k);
     } else {
         for (int k = 0; k < W; ++k) dst[64 * k] = k < n ? nz[pa + k] : 0.0;
     }
