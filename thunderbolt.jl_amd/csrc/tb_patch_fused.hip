@@ -361,7 +361,7 @@ k_patch_hex8_staged(FormArgs faK, FormArgs faM, FusedView pv, const uint4 *__res
 // of its loads — counts word, node indices, signature ids, row descriptors, coordinates — are addressed from blockIdx alone and issued at once:
 // ONE trip to memory in front of the integration instead of header → inputs (phase stamps of the staged kernel at 216³: 3.4 of a workgroup's
 // 14.2 µs before its first barrier).  A look-ahead (one dword load per lane into the record `pf` patches ahead, so that the next workgroup's trip would end
-// in the cache hierarchy) is built in and measured slower at every distance tried (1.94 → 2.02–2.05 ms): off unless TB_PATCH_PREFETCH is set.
+// in the cache hierarchy) was built and measured slower at every distance tried (1.94 → 2.02–2.05 ms at 512 … 2 048 patches ahead); removed — its keep-alive held two registers through the integration, one of them spilled.
 // Write-out: a half-wave reads ALL its row descriptors, then ALL its accumulators, then stores (one dependent LDS round instead of five).
 // KOFF > 0: the mass block sits KOFF entries behind the stiffness block (compile-time: the second add of a pair reuses the first one's address register with
 // an immediate offset); KOFF = 0: `kcap` entries behind it (patches with more than KOFF accumulator entries)
@@ -377,6 +377,7 @@ k_patch_hex8_record(FormArgs faK, FormArgs faM, const uint8_t *__restrict__ rec,
     extern __shared__ double lds[];
     constexpr int T = 256;
     const int tid = threadIdx.x;
+    const int wave_s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #ifdef TB_ABLATION
 #define TB_ST(k) do { if (prof && tid == 0 && (blockIdx.x & 1023) == 7) prof[(blockIdx.x >> 10) * 8 + (k)] = wall_clock64(); } while (0)
 #else
@@ -394,8 +395,7 @@ k_patch_hex8_record(FormArgs faK, FormArgs faM, const uint8_t *__restrict__ rec,
     const uint8_t *r = rec + (size_t)blockIdx.x * (size_t)stride;
     const uint4 h4 = *(const uint4 *)r; // wave-uniform address: a scalar load, consumed only behind the vector loads below
     const uint32_t hw = h4.x;
-    uint32_t pfv = 0;
-    if (pf > 0 && blockIdx.x + (unsigned)pf < gridDim.x && tid * 128 < stride) pfv = *(const uint32_t *)(r + (size_t)pf * (size_t)stride + (size_t)tid * 128);
+    (void)pf; // (look-ahead touch of the record pf patches ahead: measured slower, its keep-alive cost the kernel two registers — removed)
     uint4 lnv = ((const uint4 *)(r + 16))[tid];
     const uint32_t sig = ((const uint32_t *)(r + 16 + (size_t)nem * 16))[tid];
     const uint8_t *rdp = r + 16 + (size_t)nem * 20;
@@ -472,8 +472,11 @@ k_patch_hex8_record(FormArgs faK, FormArgs faM, const uint8_t *__restrict__ rec,
     __syncthreads();
     TB_ST(4);
     if (prio) __builtin_amdgcn_s_setprio(3);
-    // write-out: one row per half-wave; all descriptors, then all accumulators, then all stores of the half-wave's rows
-    const int half = tid >> 5, hl = tid & 31;
+    // write-out: one row per half-wave; all descriptors, then all accumulators, then all stores of the half-wave's rows.  (The thread index is
+    // formed again from the lane count and the wave's number — a scalar — instead of being kept through the integration, where all 256 registers
+    // are taken: kept, it was the kernel's one spilled value.)
+    const int tidw = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) + 64 * wave_s;
+    const int half = tidw >> 5, hl = tidw & 31;
     uint4 d[RPH]; // {nz0 lo, nz0 hi, off, len}
 #pragma unroll
     for (int u = 0; u < RPH; ++u) { const int s = half + u * (T / 32); d[u] = ((const uint4 *)desc)[s < nrows ? s : 0]; if (s >= nrows) d[u].w = 0; }
@@ -507,7 +510,6 @@ k_patch_hex8_record(FormArgs faK, FormArgs faM, const uint8_t *__restrict__ rec,
             if constexpr (WM) nzM[g0] = accM[d[u].z + k];
         }
     TB_ST(5);
-    if (pfv == 0x9e3779b9u && tid == 999) st->cell = -2; // never true: keeps the look-ahead load alive without a wait before this point
 #ifdef TB_ABLATION
     if (prof) { __builtin_amdgcn_s_waitcnt(0); TB_ST(6); }
 #endif
@@ -584,7 +586,7 @@ int launch_assemble_hex8_patch(tb_form *fK, tb_form *fM, tb_pattern *p, double t
     static const bool no_record = getenv("TB_PATCH_KERNEL") && strcmp(getenv("TB_PATCH_KERNEL"), "record") != 0;
     static const int wave_prio = getenv("TB_PATCH_PRIO") ? atoi(getenv("TB_PATCH_PRIO")) : 0; // measured: no effect (1.7007 vs 1.6997 ms)
     static const int stagger = getenv("TB_PATCH_STAGGER") ? atoi(getenv("TB_PATCH_STAGGER")) : 0;
-    static const int pf_ahead = getenv("TB_PATCH_PREFETCH") ? atoi(getenv("TB_PATCH_PREFETCH")) : 0; // look-ahead distance in patches; measured at 216³: 0 → 1.94 ms, 512 → 2.03, 1024 → 2.02, 2048 → 2.05 (off by default)
+    const int pf_ahead = 0; // (look-ahead touch of later records: removed from the record kernel, see there)
     if (staged && !no_record && !fk && !fm && ensure_patch_records(p) == TB_OK) {
         PatchFusedPlan *pr = p->patch_fused.get();
         constexpr int KOFF = 4096; // fused pair: mass block at a fixed distance when it fits (150 rows of 27 entries = 4 050)
