@@ -85,7 +85,11 @@ int main(int argc, char **argv)
     double dt_last = -1.0, t = 0.0;
     int total_iters = 0;
     for (int step = 0; step < nsteps; ++step, t += dt) {
-        if (dt != dt_last) { CK(tb_heat_matrix(dev, nnz, d_M, d_K, dt, d_A)); dt_last = dt; }     /* :104-116 */
+        if (dt != dt_last) {                                                                     /* :104-116 */
+            CK(tb_heat_matrix(dev, nnz, d_M, d_K, dt, d_A)); dt_last = dt;
+            CK(tb_spmv_mirror(pat, d_A));   /* A is fixed until Δt changes: the products of the solves below stream its sliced mirror (same bits) */
+            CK(tb_spmv_mirror(pat, d_M));   /* … and so does b = M uₙ₋₁ (a pattern holds two mirrors) */
+        }
         CK(tb_spmv_csr(pat, d_M, d_u, 1.0, 0.0, d_b));                                           /* b = M uₙ₋₁, :85 */
         CK(tb_assemble_vector(fs, TB_STRATEGY_ELEMENT, t + dt, d_src));                         /* update_operator!(source, t + Δt), :88 (EA strategy, :148-153) */
         CK(tb_axpy(dev, ndofs, 1.0, d_src, d_b));                                                /* add!(b, source), :90 */
