@@ -2789,6 +2789,18 @@ def test_sliced_mirror_products_equal_the_csr_products(tb, device, monkeypatch):
     it2, _ = tb.cg_solve(K.pattern, Aheat, b, x2, rtol=1e-10, atol=0.0, maxiter=500)
     K.pattern.mirror(None)
     assert it1 == it2 and rel_err(x2.to_host(), x1.to_host()) < 1e-12
+    # assembling into a bound array drops the binding at the boundary (no stale mirror); the host mirror's update_operator binds it again
+    xr, y1, y2 = device.to_device(rng.normal(size=dh.ndofs)), device.zeros(dh.ndofs), device.zeros(dh.ndofs)
+    assert K.pattern.mirror(K.A)
+    K2 = tb.setup_operator(st, tb.BilinearDiffusionIntegrator(tb.ConstantCoefficient(2.0 * np.eye(3))), dh, sp)
+    tb.check(lib.tb_assemble_matrix(K2.form.h, K.pattern.h, st.code, 0.0, K.A.ptr))       # another form into K's array, behind the host mirror's back
+    K.mul(y1, xr)
+    tb.update_operator(K2, 0.0)
+    K2.mul(y2, xr)
+    assert rel_err(y1.to_host(), y2.to_host()) < 1e-12                                       # the product saw the new values (two PATCH assemblies agree to rounding; the stale mirror would be off by a factor 2)
+    tb.update_operator(K, 0.0)                                                               # (re-binds: K.A was bound through this host mirror)
+    assert any(v is K.A for v in K.pattern._mirrored)
+    K.pattern.mirror(None)
     # 3 × 3 block rows keep their own kernel
     dhv = tb.DofHandler(g, tb.LagrangeCollection(1) ** 3)
     spv = tb.allocate_matrix(dhv)

@@ -658,9 +658,18 @@ def setup_operator(strategy, integrator, dh, pattern=None, local_solver=None):
     return BilinearOperator(strategy, integrator, dh, pattern)
 
 
+def _rebind_mirrors(*ops):
+    """Assembling into a value array drops its sliced mirror (tb_spmv_mirror): operators whose array this host mirror had bound are bound again."""
+    for op in ops:
+        pat, A = getattr(op, "pattern", None), getattr(op, "A", None)
+        if pat is not None and A is not None and any(v is A for v in getattr(pat, "_mirrored", [])):
+            pat.mirror(A)
+
+
 def update_operator(op, t):
     """update_operator!(op, t) (src/solver/time/euler.jl:172-176)."""
     op.update(t)
+    _rebind_mirrors(op)
     return op
 
 
@@ -673,6 +682,7 @@ def update_operators(M, K, t):
     else:
         M.update(t)
         K.update(t)
+    _rebind_mirrors(M, K)
     return M, K
 
 

@@ -429,6 +429,13 @@ int tb_form_set_table(tb_form *f, const double *values, int64_t n)
 }
 
 // ------------------------------------------------------------------ assembly
+// a value array that is rewritten through the library loses its sliced mirror (tb_spmv_mirror): products fall back to the CSR array until the caller binds again
+static void mirror_drop(tb_pattern *pat, const double *d_nz)
+{
+    if (!d_nz) return;
+    for (const double *&q : pat->mir_nz) if (q == d_nz) q = nullptr;
+}
+
 int tb_assemble_matrix(tb_form *form, tb_pattern *pat, int strategy, double t, double *d_nzval)
 {
     TB_REQUIRE(form && pat && (d_nzval || pat->nnz == 0), "tb_assemble_matrix: NULL argument");
@@ -437,6 +444,7 @@ int tb_assemble_matrix(tb_form *form, tb_pattern *pat, int strategy, double t, d
     TB_REQUIRE(form->mesh->ncomp == 1, "tb_assemble_matrix: scalar fields only");
     TB_REQUIRE(strategy >= TB_STRATEGY_ATOMIC && strategy <= TB_STRATEGY_PATCH, "tb_assemble_matrix: unknown strategy %d", strategy);
     TB_HIP(hipSetDevice(form->mesh->dev->id));
+    mirror_drop(pat, d_nzval);
     if (form->mesh->n_cells == 0) { // nothing to integrate: the operator is the zero matrix (outputs are overwritten)
         if (pat->nnz) TB_HIP(hipMemsetAsync(d_nzval, 0, sizeof(double) * (size_t)pat->nnz, form->mesh->dev->stream));
         return TB_OK;
@@ -450,6 +458,7 @@ int tb_assemble_matrix_pair(tb_form *mass, tb_form *diffusion, tb_pattern *pat, 
     TB_REQUIRE(mass->kind == TB_FORM_MASS && diffusion->kind == TB_FORM_DIFFUSION, "tb_assemble_matrix_pair: expects (mass form, diffusion form)");
     TB_REQUIRE(mass->mesh == pat->mesh && diffusion->mesh == pat->mesh, "tb_assemble_matrix_pair: forms and pattern belong to different meshes");
     TB_REQUIRE(d_nzval_mass != d_nzval_diffusion || pat->nnz == 0, "tb_assemble_matrix_pair: the two outputs alias");
+    mirror_drop(pat, d_nzval_mass); mirror_drop(pat, d_nzval_diffusion);
     if (strategy == TB_STRATEGY_PATCH && mass->mesh->n_cells > 0 && hex8_patch_applicable(mass, pat) && hex8_patch_applicable(diffusion, pat)) {
         TB_HIP(hipSetDevice(mass->mesh->dev->id));
         const int rc = launch_assemble_hex8_patch(diffusion, mass, pat, t, d_nzval_diffusion, d_nzval_mass);
@@ -1182,6 +1191,7 @@ int tb_spmv_mirror(tb_pattern *pat, const double *d_nzval)
 int tb_apply_zero_csr(tb_pattern *pat, double *d_nzval, double *d_f, const uint8_t *d_prescribed, double diag)
 {
     TB_REQUIRE(pat && d_prescribed && (d_nzval || d_f), "tb_apply_zero_csr: NULL argument");
+    mirror_drop(pat, d_nzval);
     TB_HIP(hipSetDevice(pat->mesh->dev->id));
     return launch_apply_zero(pat, d_nzval, d_f, d_prescribed, diag);
 }
