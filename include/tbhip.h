@@ -514,8 +514,9 @@ int tb_pattern_spmv_plan(tb_pattern *pat, int64_t *out2);
  *   tb_spmv_mirror(pat, NULL)     unbinds (the buffers stay for the next bind).
  * A pattern holds two mirrors (the system matrix of a solve and one more — K for the right-hand side Δt·K·uₙ₋₁ of the heat step): binding an array that is
  * already bound refreshes its mirror, a third array takes the place of the one bound longest ago.
- * Assembling into a bound array through tb_assemble_matrix / tb_assemble_matrix_pair, or tb_apply_zero_csr on it, drops its binding (products fall
- * back to the CSR array).  Beyond that the caller keeps the contract that a bound array is not modified: after assembling into it, or forming M − Δt·K in it again, call tb_spmv_mirror
+ * Rewriting a bound array through the boundary — tb_assemble_matrix / tb_assemble_matrix_pair into it, tb_apply_zero_csr on it, or as the output of
+ * tb_heat_matrix / tb_axpy / tb_memcpy_h2d / tb_memset — drops its binding (products fall back to the CSR array).  What the library cannot see is the
+ * caller's own kernels: beyond the entries above the caller keeps the contract that a bound array is not modified: after assembling into it, or forming M − Δt·K in it again, call tb_spmv_mirror
  * again — and unbinds before freeing it: the binding is the address, and an allocator may hand the same address to the next matrix.  Row-subset products (tb_spmv_csr_rows) and the diagonal extraction keep reading the CSR array.  TB_ERR_UNSUPPORTED for patterns without a
  * mirror: 3×3-block rows (their own kernel), rows longer than 255 entries.  (Numberings whose rows share no column-offset signatures are mirrored
  * with their offsets stored entry-major beside the values: 12 instead of 8 bytes per non-zero, still coalesced.) */

@@ -2768,6 +2768,11 @@ def test_sliced_mirror_products_equal_the_csr_products(tb, device, monkeypatch):
         np.testing.assert_array_equal(products()[0], ref[0], err_msg=name)          # A lost its slot to Cc or kept it: the CSR array gives the same bits
         pat.mirror(None)
         np.testing.assert_array_equal(products()[0], ref[0], err_msg=name)
+        # an array rewritten through the boundary (here tb_memcpy_h2d) loses its binding: no product from a stale mirror
+        assert pat.mirror(A)
+        A.copy_from_host(2.0 * vals)
+        np.testing.assert_array_equal(products()[0], 2.0 * ref[0], err_msg=name)
+        A.copy_from_host(vals)
     assert len(mirrored) == 5
     monkeypatch.delenv("TB_SPMV_KERNEL", raising=False)
     stats = np.zeros(2, dtype=np.int64)

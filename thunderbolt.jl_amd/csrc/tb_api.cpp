@@ -1,6 +1,7 @@
 // tb_api.cpp — C-ABI entry points (include/tbhip.h): objects, memory, argument checking, error strings.
 // No arithmetic of the path lives here; kernels are in tb_assembly.hip / tb_reaction.hip / tb_algebra.hip.
 #include <algorithm>
+#include <mutex>
 #include <cmath>
 #include <cstdarg>
 #include <cstring>
@@ -183,10 +184,22 @@ int tb_free(tb_device *dev, void *d_ptr)
     return TB_OK;
 }
 
+// an array rewritten through one of the raw-array entries loses its sliced mirror.  The patterns that hold mirrors are listed process-wide (a pattern
+// leaves the list in tb_pattern_destroy without touching its mesh or device, which a host's finaliser order may already have released)
+static std::vector<tb_pattern *> &g_mirrored = *new std::vector<tb_pattern *>; // (never destroyed: a finaliser may still call tb_pattern_destroy while the process exits)
+static std::mutex &g_mirrored_mutex = *new std::mutex;
+static void mirror_drop_any(tb_device *, const void *d_dst)
+{
+    std::lock_guard<std::mutex> lock(g_mirrored_mutex);
+    for (tb_pattern *p : g_mirrored)
+        for (const double *&q : p->mir_nz) if (q && (const void *)q == d_dst) q = nullptr;
+}
+
 int tb_memcpy_h2d(tb_device *dev, void *d_dst, const void *src, size_t bytes)
 {
     TB_REQUIRE(dev && (bytes == 0 || (d_dst && src)), "tb_memcpy_h2d: NULL argument");
     if (!bytes) return TB_OK;
+    mirror_drop_any(dev, d_dst);
     TB_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, dev->stream));
     TB_HIP(hipStreamSynchronize(dev->stream));
     return TB_OK;
@@ -213,6 +226,7 @@ int tb_memset(tb_device *dev, void *d_ptr, int byte, size_t bytes)
 {
     TB_REQUIRE(dev && (bytes == 0 || d_ptr), "tb_memset: NULL argument");
     if (!bytes) return TB_OK;
+    mirror_drop_any(dev, d_ptr);
     TB_HIP(hipMemsetAsync(d_ptr, byte, bytes, dev->stream));
     return TB_OK;
 }
@@ -341,6 +355,7 @@ int tb_pattern_create(tb_mesh *mesh, int64_t n_rows, const int64_t *rowptr, cons
 int tb_pattern_destroy(tb_pattern *p)
 {
     if (!p) return TB_OK;
+    { std::lock_guard<std::mutex> lock(g_mirrored_mutex); g_mirrored.erase(std::remove(g_mirrored.begin(), g_mirrored.end(), p), g_mirrored.end()); }
     hipFree(p->d_rowptr); hipFree(p->d_colidx); hipFree(p->d_blkrow); hipFree(p->d_blkrec); hipFree(p->d_rowsig); hipFree(p->d_sigoff); hipFree(p->d_wrunrec); for (double *q : p->d_mir) hipFree(q); hipFree(p->d_mir_base); hipFree(p->d_mir_off); hipFree(p->d_bcol); hipFree(p->d_diagpos); hipFree(p->d_emap); hipFree(p->d_blockpos); hipFree(p->d_cg_ws); hipFree(p->d_gmres_ws); hipFree(p->d_pcg_ws); hipFree(p->d_cheb_ws); hipFree(p->d_q2pos); hipFree(p->d_kebuf); hipFree(p->d_gnodes);
     free_patch_mat_plan(p);
     free_patch_fused_plan(p);
@@ -999,6 +1014,7 @@ int tb_heat_matrix(tb_device *dev, int64_t nnz, const double *d_Mnz, const doubl
 {
     TB_REQUIRE(dev && d_Mnz && d_Knz && d_Anz && nnz >= 0, "tb_heat_matrix: bad argument");
     if (!nnz) return TB_OK;
+    mirror_drop_any(dev, d_Anz);
     return launch_heat_matrix(dev, nnz, d_Mnz, d_Knz, dt, d_Anz);
 }
 
@@ -1079,6 +1095,7 @@ int tb_axpy(tb_device *dev, int64_t n, double a, const double *d_x, double *d_y)
 {
     TB_REQUIRE(dev && d_x && d_y && n >= 0, "tb_axpy: bad argument");
     if (!n) return TB_OK;
+    mirror_drop_any(dev, d_y);
     return launch_axpy(dev, n, a, d_x, d_y);
 }
 
@@ -1185,6 +1202,7 @@ int tb_spmv_mirror(tb_pattern *pat, const double *d_nzval)
 {
     TB_REQUIRE(pat, "tb_spmv_mirror: pat is NULL");
     TB_HIP(hipSetDevice(pat->mesh->dev->id));
+    if (d_nzval) { std::lock_guard<std::mutex> lock(g_mirrored_mutex); if (std::find(g_mirrored.begin(), g_mirrored.end(), pat) == g_mirrored.end()) g_mirrored.push_back(pat); }
     return launch_mirror_bind(pat, d_nzval);
 }
 

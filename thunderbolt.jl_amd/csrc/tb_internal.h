@@ -139,6 +139,7 @@ struct VecPatchPlan {
 
 } // namespace tb
 
+struct tb_pattern;
 struct tb_device {
     int id = 0;
     hipStream_t stream = nullptr;
