@@ -1399,13 +1399,16 @@ static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, doubl
             kebuf = p->d_kebuf;
             if (sym) rank27 = m->d_rank27;
         }
-        // Chunked linearisation (TB_MECH_CHUNKS=n; default 8 from 32 768 cells, 0 / 1 = one launch): the cells go in n launches, and behind each the
+        // Chunked linearisation (TB_MECH_CHUNKS=n; default 8 for large Q2 meshes, see below; 0 / 1 = one launch): the cells go in n launches, and behind each the
         // staged gather of the node rows that chunk completes runs on a second queue — the HBM-bound gather (46 GB at 80³) beside the LDS / VALU-bound
         // integration of the next chunk.  Same kernels, same sums (a node's cells are still added in cell order): the unchunked result bit for bit.
         // Measured at 80³ (kernel trace, profiles/r04_v2/mechanics_chunk_timeline.txt): the pairs do run side by side, but a CU that holds three
         // integration workgroups has neither LDS (3 × 53 KB) nor registers (3 × 168) left, so every gather workgroup displaces an integration one —
         // 2.55 ms per pair against 1.42 + 1.18 ms alone; the gain is what the pipeline ends and the dispatch gaps cost before: 21.3 → 20.7 ms.
-        const int chunks_env = [] { const char *e = getenv("TB_MECH_CHUNKS"); return e ? atoi(e) : 8; }(); // read per call: a 20 ms operation
+        // default: the triquadratic field from 262 144 cells (below that, and for the first-order field, sixteen small launches cost more than the overlap returns:
+        // the 111 616-cell ventricle with a Q1 displacement took 1.26 instead of 1.11 ms)
+        const int chunks_default = FE::NB == 27 && m->n_cells >= 262144 ? 8 : 0;
+        const int chunks_env = [&] { const char *e = getenv("TB_MECH_CHUNKS"); return e ? atoi(e) : chunks_default; }(); // read per call: a 20 ms operation
         bool chunked = false;
         if (NEED_K && !sym && !MFMA && chunks_env > 1 && m->n_cells >= 4096 * (int64_t)chunks_env) {
             if (!m->d_node_dof0) { rc = build_node_list(m); if (rc) return rc; }
