@@ -483,10 +483,15 @@ int tb_scatter_indexed(tb_device *dev, int64_t n, const double *d_in, const int3
  *   tb_comm_exchange   for k < n_peers: send counts[k] doubles from d_send[k] to rank peers[k] and receive counts[k] doubles from it into d_recv[k] — ONE
  *                      grouped call (ncclGroupStart … ncclSend / ncclRecv … ncclGroupEnd) on the device's stream; a rank may name itself as a peer
  *   tb_comm_allreduce  in place over all ranks, TB_REDUCE_SUM or TB_REDUCE_MAX (the two scalar reductions of a CG iteration, timings)
- * Both return when the work is enqueued on the device's stream; kernels launched behind them on that stream are ordered after it.  RCCL is opened at run
- * time (the copy the process already holds, else librccl.so of the system; TB_RCCL_LIBRARY overrides): a single-GPU user never loads it.
- * Sequence of a halo sum: tb_gather_indexed → tb_comm_exchange → tb_scatter_add_indexed; of the overlapped product: tb_spmv_csr_rows → tb_comm_exchange →
- * tb_spmv_csr_dot → tb_scatter_indexed + tb_scatter_add_indexed → tb_comm_allreduce(pᵀAp). */
+ *   tb_comm_exchange_begin / tb_comm_exchange_end  (round 5) the same exchange on a queue of the communicator's own: begin orders it behind what the
+ *                      device's stream holds so far (the packed send buffers) and returns; kernels launched on the device's stream between begin and end run
+ *                      BESIDE the transfer; end makes the device's stream wait for it (the received values are then visible to what follows).  One
+ *                      exchange in flight per communicator (TB_ERR_BAD_ARG otherwise); end without begin is a no-op.
+ * All return when the work is enqueued; kernels launched behind tb_comm_exchange / tb_comm_allreduce / tb_comm_exchange_end on the device's stream are
+ * ordered after it.  RCCL is opened at run time (the copy the process already holds, else librccl.so of the system; TB_RCCL_LIBRARY overrides): a
+ * single-GPU user never loads it.
+ * Sequence of a halo sum: tb_gather_indexed → tb_comm_exchange → tb_scatter_add_indexed; of the overlapped product: tb_spmv_csr_rows →
+ * tb_comm_exchange_begin → tb_spmv_csr_dot → tb_comm_exchange_end → tb_scatter_indexed + tb_scatter_add_indexed → tb_comm_allreduce(pᵀAp). */
 typedef struct tb_comm tb_comm;
 #define TB_COMM_ID_BYTES 128
 enum { TB_REDUCE_SUM = 0, TB_REDUCE_MAX = 1 };
@@ -496,6 +501,8 @@ int tb_comm_destroy(tb_comm *comm);
 int tb_comm_rank_size(tb_comm *comm, int *rank, int *size);
 int tb_comm_exchange(tb_comm *comm, int n_peers, const int32_t *peers, const int64_t *counts, const double *const *d_send, double *const *d_recv);
 int tb_comm_allreduce(tb_comm *comm, double *d_buf, int64_t n, int op);
+int tb_comm_exchange_begin(tb_comm *comm, int n_peers, const int32_t *peers, const int64_t *counts, const double *const *d_send, double *const *d_recv);
+int tb_comm_exchange_end(tb_comm *comm);
 /* Work statistics of the PATCH plan of a pattern's mesh (built on first use; no reference counterpart — the reference's strategies carry no
  * redundancy): out[0] = patches, out[1] = cell instances (a patch re-integrates the halo cells of the rows it owns: instances / cells is the
  * factor between the flops the patch kernels execute and the flops of one pass over the cells), out[2] = cells, out[3] = largest number of
@@ -513,11 +520,13 @@ int tb_pattern_spmv_plan(tb_pattern *pat, int64_t *out2);
  *                                 tb_cg_solve and the other solvers) reads the mirror: coalesced loads, no LDS staging, the same bits as the CSR kernel.
  *   tb_spmv_mirror(pat, NULL)     unbinds (the buffers stay for the next bind).
  * A pattern holds two mirrors (the system matrix of a solve and one more — K for the right-hand side Δt·K·uₙ₋₁ of the heat step): binding an array that is
- * already bound refreshes its mirror, a third array takes the place of the one bound longest ago.
+ * already bound refreshes its mirror (and makes it the most recent), a third array takes the place of the one bound or refreshed longest ago.
  * Rewriting a bound array through the boundary — tb_assemble_matrix / tb_assemble_matrix_pair into it, tb_apply_zero_csr on it, or as the output of
- * tb_heat_matrix / tb_axpy / tb_memcpy_h2d / tb_memset — drops its binding (products fall back to the CSR array).  What the library cannot see is the
- * caller's own kernels: beyond the entries above the caller keeps the contract that a bound array is not modified: after assembling into it, or forming M − Δt·K in it again, call tb_spmv_mirror
- * again — and unbinds before freeing it: the binding is the address, and an allocator may hand the same address to the next matrix.  Row-subset products (tb_spmv_csr_rows) and the diagonal extraction keep reading the CSR array.  TB_ERR_UNSUPPORTED for patterns without a
+ * tb_heat_matrix / tb_axpy / tb_memcpy_h2d / tb_memcpy_d2d / tb_memset (a destination anywhere inside the array counts) — drops its binding
+ * (products fall back to the CSR array), and so does tb_free of it: the binding is the address, and an allocator may hand the same address to
+ * the next matrix.  What the library cannot see is the caller's own kernels: beyond the entries above the caller keeps the contract that a bound
+ * array is not modified; after assembling into it, or forming M − Δt·K in it again, call tb_spmv_mirror again.  Row-subset products
+ * (tb_spmv_csr_rows) and the diagonal extraction keep reading the CSR array.  TB_ERR_UNSUPPORTED for patterns without a
  * mirror: 3×3-block rows (their own kernel), rows longer than 255 entries.  (Numberings whose rows share no column-offset signatures are mirrored
  * with their offsets stored entry-major beside the values: 12 instead of 8 bytes per non-zero, still coalesced.) */
 int tb_spmv_mirror(tb_pattern *pat, const double *d_nzval);

@@ -529,6 +529,13 @@ function halo_exchange!(c::HIPComm, nbs::Vector{HaloNeighbour})
     send = Ptr{Float64}[nb.send.ptr for nb in nbs]; recv = Ptr{Float64}[nb.recv.ptr for nb in nbs]
     check(ccall((:tb_comm_exchange, libtbhip), Cint, (Ptr{Cvoid}, Cint, Ptr{Int32}, Ptr{Int64}, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}}), c.handle, length(nbs), peers, counts, send, recv))
 end
+# the same exchange on the communicator's own queue: what is launched between begin and end (the whole-domain product) runs beside the transfer
+function halo_exchange_begin!(c::HIPComm, nbs::Vector{HaloNeighbour})
+    peers = Int32[nb.peer for nb in nbs]; counts = Int64[nb.idx.n for nb in nbs]
+    send = Ptr{Float64}[nb.send.ptr for nb in nbs]; recv = Ptr{Float64}[nb.recv.ptr for nb in nbs]
+    check(ccall((:tb_comm_exchange_begin, libtbhip), Cint, (Ptr{Cvoid}, Cint, Ptr{Int32}, Ptr{Int64}, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}}), c.handle, length(nbs), peers, counts, send, recv))
+end
+halo_exchange_end!(c::HIPComm) = check(ccall((:tb_comm_exchange_end, libtbhip), Cint, (Ptr{Cvoid},), c.handle))
 allreduce_sum!(c::HIPComm, S::HIPVector{Float64}, first::Int, n::Int) =
     check(ccall((:tb_comm_allreduce, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Cint), c.handle, S.ptr + 8 * first, n, 0))
 

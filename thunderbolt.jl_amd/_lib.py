@@ -161,6 +161,8 @@ SIGNATURES = {
     "tb_comm_rank_size": (C.c_int, [vp, vp, vp]),
     "tb_comm_exchange": (C.c_int, [vp, C.c_int, vp, vp, vp, vp]),
     "tb_comm_allreduce": (C.c_int, [vp, vp, C.c_int64, C.c_int]),
+    "tb_comm_exchange_begin": (C.c_int, [vp, C.c_int, vp, vp, vp, vp]),
+    "tb_comm_exchange_end": (C.c_int, [vp]),
     "tb_pattern_spmv_plan": (C.c_int, [vp, vp]),
     "tb_scatter_add_indexed": (C.c_int, [vp, C.c_int64, vp, vp, vp]),
     "tb_scatter_indexed": (C.c_int, [vp, C.c_int64, vp, vp, vp]),

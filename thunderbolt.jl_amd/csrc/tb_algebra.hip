@@ -920,7 +920,8 @@ int launch_mirror_bind(tb_pattern *p, const double *nz)
     int slot = -1;
     for (int i = 0; i < tb_pattern::MIRRORS; ++i) if (p->mir_nz[i] == nz) slot = i;
     if (slot < 0) for (int i = 0; i < tb_pattern::MIRRORS; ++i) if (!p->mir_nz[i]) { slot = i; break; }
-    if (slot < 0) { slot = p->mir_next; p->mir_next = (p->mir_next + 1) % tb_pattern::MIRRORS; }
+    if (slot < 0) { slot = 0; for (int i = 1; i < tb_pattern::MIRRORS; ++i) if (p->mir_stamp[i] < p->mir_stamp[slot]) slot = i; } // least recently bound OR refreshed
+    p->mir_stamp[slot] = ++p->mir_clock;
     if (!p->d_mir[slot]) {
         const size_t bytes = (size_t)p->mir_entries * sizeof(double);
         hipError_t e = hipMalloc((void **)&p->d_mir[slot], bytes);

@@ -177,13 +177,6 @@ int tb_malloc(tb_device *dev, size_t bytes, void **d_ptr)
     return TB_OK;
 }
 
-int tb_free(tb_device *dev, void *d_ptr)
-{
-    TB_REQUIRE(dev, "tb_free: dev is NULL");
-    if (d_ptr) TB_HIP(hipFree(d_ptr));
-    return TB_OK;
-}
-
 // an array rewritten through one of the raw-array entries loses its sliced mirror.  The patterns that hold mirrors are listed process-wide (a pattern
 // leaves the list in tb_pattern_destroy without touching its mesh or device, which a host's finaliser order may already have released)
 static std::vector<tb_pattern *> &g_mirrored = *new std::vector<tb_pattern *>; // (never destroyed: a finaliser may still call tb_pattern_destroy while the process exits)
@@ -192,7 +185,18 @@ static void mirror_drop_any(tb_device *, const void *d_dst)
 {
     std::lock_guard<std::mutex> lock(g_mirrored_mutex);
     for (tb_pattern *p : g_mirrored)
-        for (const double *&q : p->mir_nz) if (q && (const void *)q == d_dst) q = nullptr;
+        for (const double *&q : p->mir_nz) // a write that starts anywhere inside the bound array invalidates its mirror
+            if (q && (const char *)d_dst >= (const char *)q && (const char *)d_dst < (const char *)(q + p->nnz)) q = nullptr;
+}
+
+int tb_free(tb_device *dev, void *d_ptr)
+{
+    TB_REQUIRE(dev, "tb_free: dev is NULL");
+    if (d_ptr) {
+        mirror_drop_any(dev, d_ptr); // a binding is the address: the allocator may hand it to the next matrix (host finalisers free without unmirror!)
+        TB_HIP(hipFree(d_ptr));
+    }
+    return TB_OK;
 }
 
 int tb_memcpy_h2d(tb_device *dev, void *d_dst, const void *src, size_t bytes)
@@ -218,6 +222,7 @@ int tb_memcpy_d2d(tb_device *dev, void *d_dst, const void *d_src, size_t bytes)
 {
     TB_REQUIRE(dev && (bytes == 0 || (d_dst && d_src)), "tb_memcpy_d2d: NULL argument");
     if (!bytes) return TB_OK;
+    mirror_drop_any(dev, d_dst); // copyto!(A.nzval, …) of the Julia host comes through here
     TB_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, dev->stream));
     return TB_OK;
 }
@@ -356,7 +361,7 @@ int tb_pattern_destroy(tb_pattern *p)
 {
     if (!p) return TB_OK;
     { std::lock_guard<std::mutex> lock(g_mirrored_mutex); g_mirrored.erase(std::remove(g_mirrored.begin(), g_mirrored.end(), p), g_mirrored.end()); }
-    hipFree(p->d_rowptr); hipFree(p->d_colidx); hipFree(p->d_blkrow); hipFree(p->d_blkrec); hipFree(p->d_rowsig); hipFree(p->d_sigoff); hipFree(p->d_wrunrec); for (double *q : p->d_mir) hipFree(q); hipFree(p->d_mir_base); hipFree(p->d_mir_off); hipFree(p->d_bcol); hipFree(p->d_diagpos); hipFree(p->d_emap); hipFree(p->d_blockpos); hipFree(p->d_cg_ws); hipFree(p->d_gmres_ws); hipFree(p->d_pcg_ws); hipFree(p->d_cheb_ws); hipFree(p->d_q2pos); hipFree(p->d_kebuf); hipFree(p->d_gnodes);
+    hipFree(p->d_rowptr); hipFree(p->d_colidx); hipFree(p->d_blkrow); hipFree(p->d_blkrec); hipFree(p->d_rowsig); hipFree(p->d_sigoff); hipFree(p->d_wrunrec); for (double *q : p->d_mir) hipFree(q); hipFree(p->d_mir_base); hipFree(p->d_mir_off); hipFree(p->d_bcol); hipFree(p->d_diagpos); hipFree(p->d_emap); hipFree(p->d_blockpos); hipFree(p->d_cg_ws); hipFree(p->d_gmres_ws); hipFree(p->d_pcg_ws); hipFree(p->d_cheb_ws); hipFree(p->d_q2pos); hipFree(p->d_kebuf); hipFree(p->d_qpbuf); hipFree(p->d_gnodes);
     free_patch_mat_plan(p);
     free_patch_fused_plan(p);
     delete p;

@@ -212,7 +212,7 @@ struct tb_pattern {
     int64_t n_slices = 0;           // 0 = not planned, −1 = the pattern has no mirror (no signature plan, rows longer than 255 entries)
     int64_t mir_entries = 0;
     const double *mir_nz[MIRRORS] = {nullptr, nullptr}; // the value array each mirror currently reflects (products with this pointer use it); NULL = unbound
-    int mir_next = 0;               // slot the next new binding takes when both are in use (the one bound longest ago)
+    uint64_t mir_stamp[MIRRORS] = {0, 0}, mir_clock = 0; // bind / refresh order: a new binding evicts the slot bound or refreshed longest ago (true LRU, what api.py keeps alive)
     uint32_t *d_wrunrec = nullptr;  // wave-private SpMV (TB_SPMV_KERNEL=wave): runs of ≤ 21 rows as 16-byte records
     int64_t n_wrun = 0;
     uint16_t *d_q2pos = nullptr;    // scalar Q2 forms: position of col dof(j) in row dof(i), per cell and pair
@@ -222,6 +222,8 @@ struct tb_pattern {
     int gmres_m = 0;
     double *d_kebuf = nullptr;      // element-matrix buffer of the ElementAssemblyStrategy (vector fields)
     size_t kebuf_bytes = 0;
+    double *d_qpbuf = nullptr;      // quadrature-point records of the split mechanics linearisation (k_mech_points → k_mech_contract), one launch's worth
+    size_t qpbuf_bytes = 0;
     void *d_gnodes = nullptr;       // per field node: {first nz, row length, cell count, ≤ 8 element-matrix run offsets} of the staged gather
     int gnodes_state = 0;           // 0 not built, 1 built, −1 some node sits in more than 8 cells (direct gather is used)
     std::vector<int32_t> h_gn_last; // running maximum of the records' last contributing cell: the record prefix completed by a chunk of cells

@@ -699,7 +699,7 @@ static int build_patch_fused_plan_impl(tb_pattern *p, int64_t *lds_need, int nre
 
 // One-trip records (PatchFusedPlan::d_rec): the arrays of the staged kernel copied patch by patch into fixed-stride records, read back from the device
 // copies the plan already holds (the host vectors of the builder are gone by now; this runs once per pattern).
-int ensure_patch_records(tb_pattern *p)
+static int ensure_patch_records_impl(tb_pattern *p)
 {
     PatchFusedPlan *f = p->patch_fused.get();
     const PatchPlan *pp = p->mesh->patches.get();
@@ -742,6 +742,23 @@ int ensure_patch_records(tb_pattern *p)
     if (getenv("TB_PLAN_VERBOSE"))
         fprintf(stderr, "[tbhip] one-trip patch records: %lld patches x %zu B (rows <= %d, nodes <= %d), %.2f GB\n", (long long)np, stride, rm, nm, (double)rec.size() / 1e9);
     return TB_OK;
+}
+
+// A failure on the way (the records are ≈ 1 GB at 216³: the allocation can fail) is latched — rec_stride = −1, the sticky HIP error cleared — so that the
+// following assemblies go straight to the staged kernel instead of repeating four device-to-host copies and a multi-GB host build per call.
+int ensure_patch_records(tb_pattern *p)
+{
+    const int rc = ensure_patch_records_impl(p);
+    if (rc != TB_OK && rc != TB_ERR_UNSUPPORTED) {
+        PatchFusedPlan *f = p->patch_fused.get();
+        if (f) {
+            if (f->d_rec) { (void)hipFree(f->d_rec); f->d_rec = nullptr; }
+            f->rec_stride = -1;
+        }
+        (void)hipGetLastError();
+        return TB_ERR_UNSUPPORTED;
+    }
+    return rc;
 }
 
 // The plan object is handed to the pattern on every path, so that a failed upload half way leaves nothing behind: the caller's

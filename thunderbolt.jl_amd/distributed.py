@@ -128,8 +128,9 @@ class RcclComm:
         dist.broadcast_object_list(box, src=0)
         return cls(device, rank, world, box[0])
 
-    def exchange(self, peers, send, recv):
-        """one grouped send / receive with every listed peer (device tensors of equal length per peer), enqueued on the device's stream"""
+    def exchange(self, peers, send, recv, overlapped=False):
+        """one grouped send / receive with every listed peer (device tensors of equal length per peer), enqueued on the device's stream — or, with
+        overlapped=True, on the communicator's own queue (tb_comm_exchange_begin): what the device's stream does until `exchange_end()` runs beside it"""
         import ctypes as C
         from ._lib import check, lib
         n = len(peers)
@@ -139,7 +140,11 @@ class RcclComm:
         cnt = (C.c_int64 * n)(*[int(t.numel()) for t in send])
         S = (C.c_void_p * n)(*[t.data_ptr() for t in send])
         R = (C.c_void_p * n)(*[t.data_ptr() for t in recv])
-        check(lib().tb_comm_exchange(self.h, n, P, cnt, S, R))
+        check((lib().tb_comm_exchange_begin if overlapped else lib().tb_comm_exchange)(self.h, n, P, cnt, S, R))
+
+    def exchange_end(self):
+        from ._lib import check, lib
+        check(lib().tb_comm_exchange_end(self.h))
 
     def allreduce(self, t, op="sum"):
         import ctypes as C
@@ -252,8 +257,8 @@ class HaloExchange:
     def start(self):
         if not self.peers:
             return
-        if self.abi:                                                 # stream-ordered: nothing to wait for in finish()
-            self.dist.exchange(self.peers, self.send, self.recv)
+        if self.abi:                                                 # on the communicator's queue: the kernels launched until finish() overlap it
+            self.dist.exchange(self.peers, self.send, self.recv, overlapped=True)
             return
         dist, ops = self.dist, []
         if self.staged:
@@ -272,6 +277,8 @@ class HaloExchange:
         for r in self.reqs:
             r.wait()
         self.reqs = []
+        if self.abi and self.peers:
+            self.dist.exchange_end()                                 # the device's stream waits for the transfer (no host wait)
         if self.staged:
             for r_, rh in zip(self.recv, self.recv_h):
                 r_.copy_(rh, non_blocking=True)
