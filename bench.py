@@ -46,11 +46,10 @@ FP64_VECTOR_TFLOPS = 78.6      # AMD spec sheet; FP64 MFMA runs at the same rate
 BYTES_PER_CELL_MATRIX = 272.0  # 32 B conn + 24 B coords + 27 nz × 8 B
 BYTES_PER_CELL_VECTOR = 64.0   # 32 + 24 + 8
 BYTES_PER_DOF_UPDATE = 16.0    # in place; 24 when du is materialised
-# FP64 flops of one cell instance, counted on the ISA of the shipped kernels (scripts/isa_hist.py; v_mul_f64 / v_add_f64 = 1, v_fma_f64 / v_fmac_f64 = 2)
-FLOP_PER_INSTANCE_FUSED = 430 + 354 + 2 * 465     # hex8_instance<K+M,DIAG> inside k_patch_hex8_record / k_patch_hex8_staged
-FLOP_PER_INSTANCE_K = 1400.0                      # hex8_instance<K,DIAG> (approximate: the mass part is ≈ 300 of the fused count)
-ROOFLINE_LIMITER = ("fp64 vector issue in the integration phase + latency-bound staging / write-out phases at two workgroups per CU "
-                    "(not HBM, not the LDS atomics)")
+# FP64 flops of one cell instance, counted on the ISA of the shipped kernel instances (hipcc -save-temps listing of tb_patch_fused.hip; v_mul_f64 / v_add_f64 = 1,
+# v_fma_f64 / v_fmac_f64 = 2), keyed by (matrices, tensor form) as tb_last_kernel_name() reports the instance that ran
+FLOP_PER_INSTANCE = {("K+M", "ISO"): 375 + 354 + 2 * 483, ("K+M", "DIAG"): 430 + 354 + 2 * 465, ("K+M", "GEN"): 430 + 354 + 2 * 609,
+                     ("K", "ISO"): 310 + 344 + 2 * 436, ("K", "DIAG"): 365 + 344 + 2 * 418, ("K", "GEN"): 365 + 344 + 2 * 562, ("M", "-"): 97 + 79 + 2 * 153}
 
 
 def parse():
@@ -64,11 +63,16 @@ def parse():
     ap.add_argument("--exchange", default="torch", choices=["torch", "abi"],
                     help="N > 1 data path: torch = torch.distributed over RCCL (batch_isend_irecv / all_reduce); abi = RCCL behind the C ABI (tb_comm_exchange / "
                          "tb_comm_allreduce, what a Julia host would call) — torch.distributed then only carries the communicator id and the timing barrier")
+    ap.add_argument("--mesh", default="box", choices=["box", "shuffled", "lv"],
+                    help="N = 1: box = the lexicographic n^3 box (BASELINE's configuration); shuffled = the SAME box with its cells and nodes randomly renumbered (same bytes, "
+                         "no row / scatter signatures to share: an unstructured presentation); lv = the idealised left ventricle (O-grid apex, curved thin wall) at --lv-dims")
+    ap.add_argument("--lv-dims", default="256,16,248", help="--mesh lv: circumferential, radial, longitudinal cell counts (default ~1.1 M hexahedra)")
     ap.add_argument("--layers", type=int, default=0, help="N = 1 diagnostics: run on the n×n×LAYERS slab only (the share of one of n/LAYERS GPUs), e.g. under rocprofv3")
     ap.add_argument("--no-spmv-mirror", action="store_true", help="CG iterations on the CSR array instead of its sliced mirror (tb_spmv_mirror)")
     ap.add_argument("--no-slab-sweep", action="store_true", help="N = 1: skip the timing of the n×n×{n/2, n/4, n/8} slabs (strong-scaling prediction)")
     ap.add_argument("--strategy", default="patch", choices=["patch", "atomic", "color"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="N = 1: skip the HIP-graph forms of the step and of the CG iteration (tb_graph_*)")
     ap.add_argument("--no-dist-cg", action="store_true", help="skip the (untimed-region) distributed CG iteration measurement")
     ap.add_argument("--cpu-n", type=int, default=64, help="edge of the CPU-baseline sample mesh")
     ap.add_argument("--no-cpu-big", action="store_true", help="skip the one all-cores CPU pass over the GPU run's own mesh")
@@ -113,7 +117,7 @@ def physical_cores():
 HOST_CORES = physical_cores()
 
 
-def cpu_baseline(n, kap, ionic="tt06", sizes=(64, 100), big=None):
+def cpu_baseline(n, kap, ionic="tt06", sizes=(64, 100), big=None, check=None):
     """Oracle ("port": C restatement of the reference CPU path, NOT Julia) on bounded samples of the same workload, as SURVEY §8(d) asks: 1 thread and
     all physical cores (docs/src/vroom.md:3-15: threads = physical cores, pinned — OMP_PROC_BIND / OMP_PLACES are set at the top of this file), on the
     64³ and 100³ meshes, min over repetitions after a warm-up; the 216³ mesh of the GPU run once on all cores (`big` = its host arrays).  The
@@ -129,7 +133,7 @@ def cpu_baseline(n, kap, ionic="tt06", sizes=(64, 100), big=None):
     cores, avail = HOST_CORES                                      # counted at import time: once libgomp has pinned the initial thread, its affinity mask is one core
     table = {}
 
-    def legs(tag, m, rp, ci, nd, ncells, threads_list, literal_1t):
+    def legs(tag, m, rp, ci, nd, ncells, threads_list, literal_1t, median_of=0):
         col, nc = o.color_cells(m.cell_dofs, nd)
         u = np.ascontiguousarray(np.tile(o.cell_default_state(cm, p), (nd, 1)).T).ravel().copy()
         nstates = len(u) // nd
@@ -137,8 +141,9 @@ def cpu_baseline(n, kap, ionic="tt06", sizes=(64, 100), big=None):
             plan = o.AssemblyPlan(m, rp, ci, col, nc, th)
             nzM, nzK, bvec = plan.new_values(), plan.new_values(), np.empty(nd)
             best_asm, best_rx, reps = 1e30, 1e30, 0
+            asm_t, rx_t = [], []
             t_end = time.time() + (3.0 if th == 1 else 4.0)
-            while reps < 2 or (time.time() < t_end and reps < 6):
+            while reps < 2 or len(asm_t) < median_of or (time.time() < t_end and reps < 6):
                 t0 = time.perf_counter()
                 plan.assemble(0, cM, nzM)
                 plan.assemble(1, cK, nzK)
@@ -148,8 +153,15 @@ def cpu_baseline(n, kap, ionic="tt06", sizes=(64, 100), big=None):
                 t2 = time.perf_counter()
                 if reps > 0 or th == 1:                            # the first multi-thread pass places the pages
                     best_asm, best_rx = min(best_asm, t1 - t0), min(best_rx, t2 - t1)
+                    asm_t.append(t1 - t0); rx_t.append(t2 - t1)
                 reps += 1
-            table["%s/%dt" % (tag, th)] = {"element_integrations_per_s": 3 * ncells / best_asm, "dof_updates_per_s": nstates * nd / best_rx, "reps": reps}
+            ent = {"element_integrations_per_s": 3 * ncells / best_asm, "dof_updates_per_s": nstates * nd / best_rx, "reps": reps}
+            if median_of:                                          # the stated baseline: median of the counted repetitions (the other entries keep @btime's minimum)
+                ent.update({"element_integrations_per_s_median": 3 * ncells / float(np.median(asm_t)), "dof_updates_per_s_median": nstates * nd / float(np.median(rx_t)),
+                            "counted_reps": len(asm_t)})
+            table["%s/%dt" % (tag, th)] = ent
+            if check is not None and median_of:                    # the oracle as the CHECKER of the GPU arrays (after every timed region): sampled rows of the bench's own mesh
+                table["%s/%dt" % (tag, th)]["parity"] = check(rp, ci, nzM, nzK, bvec)
             del plan, nzM, nzK, bvec
         if literal_1t:
             t0 = time.perf_counter()
@@ -166,12 +178,19 @@ def cpu_baseline(n, kap, ionic="tt06", sizes=(64, 100), big=None):
         legs("%d^3" % nn, o.Mesh(o.HEX8, 2, xyz, conn, cd), rp, ci, nd, nn ** 3, sorted({1, cores}), literal_1t=(nn == min(sizes)))
     if big is not None:
         xyz, conn, cd, nd, rp, ci, tag = big
-        legs(tag, o.Mesh(o.HEX8, 2, xyz, conn, cd), rp, ci, nd, conn.shape[0], [cores], literal_1t=False)
-    top = table["%d^3/%dt" % (n, cores)]
-    return {"value": top["element_integrations_per_s"], "unit": "element-integrations/s", "cores": cores, "kind": "port",
-            "sample": "%d^3 hex Q1 mesh (%d cells): M + K per-colour + b element-assembly, OpenMP on all %d physical cores (pinned: OMP_PROC_BIND=%s OMP_PLACES=%s), min of %d reps; "
-                      "C restatement of the reference CPU path, not Julia" % (n, n ** 3, cores, os.environ.get("OMP_PROC_BIND"), os.environ.get("OMP_PLACES"), top["reps"]),
-            "dof_updates_per_s": top["dof_updates_per_s"], "ionic_model": ionic,
+        legs(tag, o.Mesh(o.HEX8, 2, xyz, conn, cd), rp, ci, nd, conn.shape[0], [cores], literal_1t=False, median_of=3)
+        top = table["%s/%dt" % (tag, cores)]                       # the stated baseline: the mesh the GPU was timed on, all cores, median of >= 3 counted passes
+        value, rx_value = top["element_integrations_per_s_median"], top["dof_updates_per_s_median"]
+        sample = ("the bench's own %s hex Q1 mesh (%d cells): M + K per-colour + b element-assembly, OpenMP on all %d physical cores (pinned: OMP_PROC_BIND=%s OMP_PLACES=%s), "
+                  "median of %d passes after a page-placing one; C restatement of the reference CPU path, not Julia; the 64^3 / 100^3 samples and the 1-thread legs are in `table`"
+                  % (tag, conn.shape[0], cores, os.environ.get("OMP_PROC_BIND"), os.environ.get("OMP_PLACES"), top["counted_reps"]))
+    else:
+        top = table["%d^3/%dt" % (n, cores)]
+        value, rx_value = top["element_integrations_per_s"], top["dof_updates_per_s"]
+        sample = ("%d^3 hex Q1 sample mesh (%d cells; --no-cpu-big: the bench's own mesh was skipped): M + K per-colour + b element-assembly, OpenMP on all %d physical cores "
+                  "(pinned), min of %d reps; C restatement of the reference CPU path, not Julia" % (n, n ** 3, cores, top["reps"]))
+    return {"value": value, "unit": "element-integrations/s", "cores": cores, "kind": "port", "sample": sample,
+            "dof_updates_per_s": rx_value, "ionic_model": ionic, **({"parity": top["parity"]} if "parity" in top else {}),
             "table": table, "physical_cores": cores, "hardware_threads": avail, "cpu_model": cpu_model_string()}
 
 
@@ -228,9 +247,15 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
     dev = tb.MI355XDevice(device_index)
+    # torch and the library share ONE non-default stream: ordering between the two needs no events, and the stream can be captured into HIP graphs
+    # (tb_graph_*; the legacy default stream cannot)
+    torch.cuda.set_stream(torch.cuda.Stream())
     dev.set_stream(torch.cuda.current_stream().cuda_stream)
 
     n = args.n
+    if args.mesh != "box" and (world > 1 or args.layers):
+        sys.stderr.write("bench.py: --mesh %s is a one-GPU mode (z-slab partitions belong to the box)\n" % args.mesh)
+        return 2
     strong = args.scaling == "strong"
     if strong and world > n:
         sys.stderr.write("bench.py: --gpus %d exceeds the %d cell layers of the mesh\n" % (world, n))
@@ -254,7 +279,15 @@ def main():
         def __init__(self, nel, left, right, rank_, world_, lo_up, dist_, xdist_=None):
             self.world, self.rank, self.dist = world_, rank_, dist_     # dist: barrier / max over ranks of the timings (torch.distributed)
             self.xdist = xdist_ if xdist_ is not None else dist_        # xdist: halo exchange and CG reductions (torch.distributed or RcclComm)
-            self.g = g = tb.generate_mesh(tb.Hexahedron, nel, left, right, perturb=0.2)
+            self.g = g = tb.generate_mesh(tb.Hexahedron, nel if args.mesh != "lv" else (2, 2, 2), left, right, perturb=0.2)
+            if args.mesh == "shuffled":        # the same cells and nodes under random numbers: no lexicographic regularity for the plans to share (seeded)
+                rng = np.random.default_rng(2025)
+                pn, pc = rng.permutation(g.n_nodes), rng.permutation(g.n_cells)
+                inv = np.empty_like(pn); inv[pn] = np.arange(g.n_nodes)
+                self.g = g = tb.Grid(tb.Hexahedron, g.xyz[pn], inv[g.conn[pc]].astype(np.int32))
+            elif args.mesh == "lv":
+                nc_, nr_, nl_ = (int(v) for v in args.lv_dims.split(","))
+                self.g = g = tb.generate_ideal_lv_mesh_hex(nc_, nr_, nl_)
             self.dh = dh = tb.DofHandler(g)
             self.sp = sp = tb.allocate_matrix(dh)
             st = {"patch": tb.PatchAssemblyStrategy, "atomic": tb.AtomicAssemblyStrategy, "color": tb.PerColorAssemblyStrategy}[args.strategy](dev)
@@ -299,6 +332,8 @@ def main():
                 tb.update_operators(self.M, self.K, t)
             else:
                 tb.update_operator(self.K, t)
+            if i == 0:
+                self.matrix_kernel = tb.lib().tb_last_kernel_name().decode()   # the instance this call launched (the roofline's kernel)
             ev[2].record(); tb.update_operator(self.src, t)
             ev[3].record()
             if self.world > 1:
@@ -308,6 +343,34 @@ def main():
             if timed:
                 for k, name in enumerate(self.phase):
                     self.phase[name] += ev[k].elapsed_ms(ev[k + 1])
+
+        def step_plain(self, t):
+            """the calls of `step` without the phase events (what a captured step replays; one rank, no halo exchange)"""
+            if fused:
+                tb.update_operators(self.M, self.K, t)
+            else:
+                tb.update_operator(self.M, t)
+                tb.update_operator(self.K, t)
+            tb.update_operator(self.src, t)
+            tb.perform_step(self.f, self.cache, t, rdt)
+
+        def time_steps_graph(self, warmup, steps):
+            """The same step as ONE HIP-graph launch (tb_graph_*: the sequence captured once, the time of every replay set through the device's time
+            slot): W untimed launches, K timed ones, synchronize on both sides.  One rank only (the halo exchange stays outside graphs)."""
+            assert self.world == 1
+            gr = dev.capture(lambda: self.step_plain(0.0))
+            for i in range(warmup):
+                gr.launch(0.01 * i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                gr.launch(0.01 * (warmup + i))
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            dev.poll_status()
+            nodes = gr.nodes
+            gr.close()
+            return el, nodes
 
         def sync(self):
             if self.dist is not None:
@@ -383,6 +446,21 @@ def main():
             if dist_ is not None:
                 dist_.barrier()
             t_it = self.max_over_ranks((time.perf_counter() - t0) / nit)
+            graph_it = graph_nodes = graph_err = None
+            if world_ == 1 and not args.no_graph:                     # the same iteration as one HIP-graph launch (no exchange at one rank)
+                try:
+                    gr = dev.capture(lambda: cg.device_step(xs_, rs_, ps_, Ap_, S_))
+                    for _ in range(3):
+                        gr.launch(0.0)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(nit):
+                        gr.launch(0.0)
+                    torch.cuda.synchronize()
+                    graph_it, graph_nodes = (time.perf_counter() - t0) / nit, gr.nodes
+                    gr.close()
+                except Exception as ex:                               # an unsupported graph call must not cost the line
+                    graph_err = str(ex)[:200]
             ea.record()
             for _ in range(nit):
                 cg.device_iteration(ps_, Ap_, S_)                    # product + halo + pᵀAp only
@@ -396,7 +474,8 @@ def main():
             ed = dev.event()
             ed.record()
             torch.cuda.synchronize()
-            return {"iteration_ms": t_it * 1e3, "product_halo_dot_ms": ea.elapsed_ms(eb) / nit, "local_spmv_ms": eb.elapsed_ms(ec) / nit,
+            return {"iteration_ms": t_it * 1e3, "graph_iteration_ms": None if graph_it is None else graph_it * 1e3, "graph_nodes": graph_nodes, "graph_error": graph_err,
+                    "product_halo_dot_ms": ea.elapsed_ms(eb) / nit, "local_spmv_ms": eb.elapsed_ms(ec) / nit,
                     "local_spmv_csr_ms": ec.elapsed_ms(ed) / nit, "spmv_mirror": bool(mirrored), "spmv_mirror_bind_ms": bind_ms,
                     # algorithmic bytes of one iteration: the matrix values once (8 B per non-zero) + 12–13 passes over vectors of the rows (product:
                     # p in, Ap out; update: p, Ap, x, r, D⁻¹, weights in, x, r out; direction: r, D⁻¹, p in, p out) — against the 8 TB/s of the guide
@@ -410,6 +489,22 @@ def main():
     g, dh, sp, npts, ns = pr.g, pr.dh, pr.sp, pr.npts, pr.ns
     elapsed = pr.time_steps(args.warmup, args.steps)
     phase = pr.phase
+
+    def graph_step_ms(prob):
+        """(ms per step, nodes, error) of the step as one HIP-graph launch; never fatal"""
+        if world != 1 or args.no_graph:
+            return None, None, None
+        try:
+            el_, nodes_ = prob.time_steps_graph(max(2, args.warmup), max(5, args.steps))
+            return el_ / max(5, args.steps) * 1e3, nodes_, None
+        except Exception as ex:
+            try:
+                dev.defer_status(False)
+            except Exception:
+                pass
+            return None, None, str(ex)[:200]
+
+    g_ms, g_nodes, g_err = graph_step_ms(pr)
 
     # outside the timed region: the reference's own 7-state ionic model (PCG2019) on the same points, for the record
     ref_rx = None
@@ -435,11 +530,41 @@ def main():
 
     # N = 1: the slabs a strong-scaling run on N GPUs hands each rank, timed one after the other on this GPU (same kernels, same plans, no exchange)
     slab_sweep = None
-    if world == 1 and not args.no_slab_sweep and n % 8 == 0 and args.layers == 0:
+    if world == 1 and not args.no_slab_sweep and n % 8 == 0 and args.layers == 0 and args.mesh == "box":
         slab_sweep = {"layers": {}, "note": "step = M + K + b + %s reaction, cg = one Jacobi-CG iteration on A = M - dt K, each on an %dx%dxL slab of the mesh (the share of one of "
                                            "N = %d/L GPUs under --scaling strong); predicted_speedup = t(%d layers) / t(L layers): what the kernels alone allow, without the halo "
-                                           "exchange and the two all-reduces of an iteration" % (args.ionic.upper(), n, n, n, n)}
-        base = {"step_ms": elapsed / args.steps * 1e3, "cg_iteration_ms": dist_cg["iteration_ms"] if dist_cg else None}
+                                           "exchange and the two all-reduces of an iteration; *_graph: the same work as one HIP-graph launch per step / iteration (tb_graph_*); "
+                                           "*_with_exchange: best of the two forms on both sides, plus the measured world-size-1 RCCL cost of the step's halo sum / of an "
+                                           "iteration's two all-reduces (exchange_latency)" % (args.ionic.upper(), n, n, n, n)}
+        base = {"step_ms": elapsed / args.steps * 1e3, "cg_iteration_ms": dist_cg["iteration_ms"] if dist_cg else None,
+                "graph_step_ms": g_ms, "graph_cg_iteration_ms": dist_cg["graph_iteration_ms"] if dist_cg else None}
+        # what an exchange costs on this box: RCCL at world size 1 behind the C ABI, rank 0 as its own lower and upper neighbour (one interface plane each
+        # way: (n+1)² doubles) and the 8-byte all-reduce of a CG iteration — no xGMI hop in it, but the launch, the protocol and the copy kernels
+        xch = None
+        try:
+            cm = tb.distributed.RcclComm(dev, 0, 1)
+            npl = (n + 1) * (n + 1)
+            sb = [torch.zeros(npl, dtype=torch.float64, device="cuda") for _ in range(2)]
+            rb = [torch.empty(npl, dtype=torch.float64, device="cuda") for _ in range(2)]
+            sc = torch.zeros(2, dtype=torch.float64, device="cuda")
+            for _ in range(5):
+                cm.exchange([0, 0], sb, rb); cm.allreduce(sc)
+            torch.cuda.synchronize()
+            e0_, e1_, e2_ = dev.event(), dev.event(), dev.event()
+            e0_.record()
+            for _ in range(20):
+                cm.exchange([0, 0], sb, rb)
+            e1_.record()
+            for _ in range(20):
+                cm.allreduce(sc)
+            e2_.record()
+            torch.cuda.synchronize()
+            xch = {"halo_exchange_ms": e0_.elapsed_ms(e1_) / 20, "allreduce_ms": e1_.elapsed_ms(e2_) / 20, "plane_doubles": npl,
+                   "note": "RCCL behind the C ABI at world size 1 (tb_comm_exchange with rank 0 as its own two neighbours, tb_comm_allreduce of 2 doubles): stream time per call, no xGMI hop"}
+            cm.close()
+        except Exception as ex:
+            xch = {"error": str(ex)[:200]}
+        slab_sweep["exchange_latency"] = xch
         slab_sweep["layers"][str(n)] = dict(base, cells=g.n_cells)
         for N in (2, 4, 8):
             L_ = n // N
@@ -455,9 +580,30 @@ def main():
             ent = {"step_ms": el / max(5, args.steps) * 1e3, "cells": q.g.n_cells, "gpus": N,
                    "phase_ms": {k: v / max(5, args.steps) for k, v in ph.items() if v > 0.0}}
             ent["predicted_speedup_step"] = base["step_ms"] / ent["step_ms"]
+            qg_ms, _, qg_err = graph_step_ms(q)
+            ent["graph_step_ms"] = qg_ms
+            if qg_ms and base["graph_step_ms"]:
+                ent["predicted_speedup_step_graph"] = base["graph_step_ms"] / qg_ms
+            if qg_err:
+                ent["graph_error"] = qg_err
+            # with the exchange a step adds: one halo sum of b (the step's only exchange)
+            best_step = min(x_ for x_ in (ent["step_ms"], qg_ms) if x_)
+            best_base = min(x_ for x_ in (base["step_ms"], base["graph_step_ms"]) if x_)
+            if xch and "halo_exchange_ms" in xch:
+                ent["predicted_speedup_step_with_exchange"] = best_base / (best_step + xch["halo_exchange_ms"])
             if dist_cg:
-                ent["cg_iteration_ms"] = q.time_cg()["iteration_ms"]
+                qc = q.time_cg()
+                ent["cg_iteration_ms"] = qc["iteration_ms"]
                 ent["predicted_speedup_cg"] = base["cg_iteration_ms"] / ent["cg_iteration_ms"]
+                ent["graph_cg_iteration_ms"] = qc["graph_iteration_ms"]
+                if qc["graph_iteration_ms"] and base["graph_cg_iteration_ms"]:
+                    ent["predicted_speedup_cg_graph"] = base["graph_cg_iteration_ms"] / qc["graph_iteration_ms"]
+                # an iteration under a partition: the interface exchange is posted before the whole-domain product and overlaps it (not charged), the two
+                # scalar all-reduces sit on the critical path (charged)
+                if xch and "allreduce_ms" in xch:
+                    bc = min(x_ for x_ in (base["cg_iteration_ms"], base["graph_cg_iteration_ms"]) if x_)
+                    qb = min(x_ for x_ in (qc["iteration_ms"], qc["graph_iteration_ms"]) if x_)
+                    ent["predicted_speedup_cg_with_exchange"] = bc / (qb + 2 * xch["allreduce_ms"])
             slab_sweep["layers"][str(L_)] = ent
             del q
             torch.cuda.empty_cache()
@@ -466,6 +612,8 @@ def main():
         K_ = args.steps
         cells_total = n * n * nz_total
         dofs_total = (n + 1) * (n + 1) * (nz_total + 1)          # distinct dofs of the whole mesh (interface dofs, updated on both sides, counted once)
+        if args.mesh != "box":
+            cells_total, dofs_total = g.n_cells, npts
         ms = elapsed / K_ * 1e3
         k_ms = phase["diffusion"] / K_            # fused: the one M + K launch
         # algorithmic bytes of the dominant launch, each datum once: connectivity 32 B + coordinates 24 B per cell, 27 nz × 8 B per
@@ -473,25 +621,29 @@ def main():
         # element-integrations were charged its own mesh read: reported as frac_per_integration)
         bytes_per_cell = (BYTES_PER_CELL_MATRIX + 216.0) if fused else BYTES_PER_CELL_MATRIX
         achieved = bytes_per_cell * g.n_cells / (k_ms * 1e-3) / 1e9
-        if args.strategy == "patch":
-            kname = "k_patch_hex8_record<K+M,DIAG>" if fused else "k_patch_hex8_record<K,DIAG>"
-        else:
-            kname = "k_matrix_direct<Hex8<2>,DIFFUSION>"
+        kname = getattr(pr, "matrix_kernel", "") or ("k_matrix_direct<Hex8<2>,DIFFUSION>" if args.strategy != "patch" else "unknown")   # tb_last_kernel_name() after the step's matrix call
         mk_ms = k_ms + phase["mass"] / K_
         # FP64 side of the same launch (SURVEY §8d asks for both fractions).  Flops per cell instance counted on the ISA of the shipped kernel
         # (scripts/isa_hist.py on k_patch_hex8_record<K+M,DIAG>, the same element routine as the staged kernel: 430 v_mul_f64 + 354 v_add_f64 + 465 v_fma_f64 → 1 714 flop); a patch re-integrates
         # the halo cells of its rows, so the kernel executes `instances_per_cell` × that; "useful" charges every cell once.
         inst_per_cell = pr.K.pattern.patch_stats()["instances_per_cell"] if args.strategy == "patch" else 1.0
-        flop_inst = FLOP_PER_INSTANCE_FUSED if fused else FLOP_PER_INSTANCE_K
+        import re as _re
+        mk_ = _re.match(r"k_patch_hex8_\w+<([^,>]+),([^,>]+)", kname)
+        flop_key = (mk_.group(1), mk_.group(2)) if mk_ else None
+        flop_inst = FLOP_PER_INSTANCE.get(flop_key, FLOP_PER_INSTANCE[("K+M", "GEN")] if fused else FLOP_PER_INSTANCE[("K", "GEN")])
         tf_useful = flop_inst * g.n_cells / (k_ms * 1e-3) / 1e12
         out = {
             "metric": "element-integrations/sec + DoF-updates/sec, 10M-hex Q1 monodomain",
             "value": 3 * cells_total * K_ / elapsed, "unit": "element-integrations/s",
             "n_gpus": world, "steps": K_, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "monodomain hot path on the %dx%dx%d hex Q1 mesh (%d cells) in %d z-slab(s) of %d layers: assemble M + K (%s scatter, %s) + b (patch-reduced sums, 1.4 global atomics per cell)%s + %s forward-Euler reaction step"
-                                   % (n, n, nz_total, cells_total, world, part.nzl, args.strategy, "one fused pass" if fused else "two launches",
+            "config": {"workload": "monodomain hot path on %s: assemble M + K (%s scatter, %s) + b (patch-reduced sums, 1.4 global atomics per cell)%s + %s forward-Euler reaction step"
+                                   % ({"box": "the %dx%dx%d hex Q1 mesh (%d cells) in %d z-slab(s) of %d layers" % (n, n, nz_total, cells_total, world, part.nzl),
+                                       "shuffled": "the %dx%dx%d hex Q1 mesh (%d cells) with cells and nodes RANDOMLY RENUMBERED (unstructured presentation of the same mesh)" % (n, n, nz_total, cells_total),
+                                       "lv": "the idealised left-ventricle hex Q1 mesh (%s cells circumferential / radial / longitudinal + O-grid apex: %d cells, %d dofs)" % (args.lv_dims, cells_total, dofs_total)}[args.mesh],
+                                      args.strategy, "one fused pass" if fused else "two launches",
                                       " + neighbour halo sum of b" if world > 1 else "", args.ionic.upper()),
+                       "mesh": args.mesh,
                        "cells_total": cells_total, "cells_per_gpu": g.n_cells, "dofs_per_gpu": npts, "nnz_per_gpu": sp.nnz, "ionic_model": args.ionic, "ionic_states": ns,
                        "partition": "z-slabs", "layers_per_gpu": part.nzl, **({"backend": "gloo (shared device, test)"} if share else ({"backend": "nccl (RCCL)" if xd is gd else "RCCL behind the C ABI (tb_comm_*)"} if gd is not None else {}))},
             "dof_updates_per_s": ns * dofs_total * K_ / elapsed,
@@ -502,13 +654,13 @@ def main():
             # "bound" names the roofline `achieved` / `peak` are priced against (algorithmic bytes over the HBM peak, the contract's definition); the FP64
             # vector roof sits beside it in `fp64` (SURVEY §8d asks for both), `nearest_roof` says which of the two fractions is the larger, and
             # `limiter` what the counters and phase stamps say holds the kernel below both (profiles/)
-            "roofline": {"kernel": kname, "bound": "hbm", "limiter": ROOFLINE_LIMITER if fused else "see DESIGN.md §5",
+            "roofline": {"kernel": kname, "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "algorithmic_bytes_per_cell": bytes_per_cell, "launch_ms": k_ms,
                          "frac_per_integration": BYTES_PER_CELL_MATRIX * 2 * g.n_cells / (mk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "fp64": {"bound": "fp64-valu", "achieved": tf_useful, "achieved_incl_halo": tf_useful * inst_per_cell, "peak": FP64_VECTOR_TFLOPS, "unit": "TFLOP/s",
                                   "frac": tf_useful / FP64_VECTOR_TFLOPS, "frac_incl_halo": tf_useful * inst_per_cell / FP64_VECTOR_TFLOPS,
-                                  "flop_per_cell_instance": flop_inst, "instances_per_cell": inst_per_cell,
+                                  "flop_per_cell_instance": flop_inst, "flop_count_of_instance": list(flop_key) if flop_key in FLOP_PER_INSTANCE else None, "instances_per_cell": inst_per_cell,
                                   "note": "flops counted on the kernel's ISA (v_mul/v_add = 1, v_fma = 2); useful = one instance per cell, incl_halo = what the kernel executes"},
                          "reaction": {"bound": "hbm", "achieved": (BYTES_PER_DOF_UPDATE + (8 if args.keep_du else 0)) * ns * npts / (phase["reaction"] / K_ * 1e-3) / 1e9,
                                       "peak": HBM_PEAK_GBS, "unit": "GB/s"},
@@ -525,6 +677,11 @@ def main():
             out["distributed_cg"] = dist_cg
             out["cg_iterations_per_s"] = 1e3 / dist_cg["iteration_ms"]
             out["cg_dof_iterations_per_s"] = dofs_total * 1e3 / dist_cg["iteration_ms"]
+        if g_ms is not None or g_err is not None:
+            out["graph_step"] = {"ms_per_step": g_ms, "nodes": g_nodes, "error": g_err,
+                                 "value": None if g_ms is None else 3 * cells_total / (g_ms * 1e-3),
+                                 "note": "the same step replayed as ONE HIP-graph launch (tb_graph_begin / _end / _launch; time through the device's time slot), its own "
+                                         "timed loop outside the contract's region: `value` above stays the plain-launch figure whose phases the HIP events time"}
         if slab_sweep is not None:
             out["slab_sweep"] = slab_sweep
         try:  # HBM bytes per launch from this round's PMC passes (rocprofv3 cannot run inside this process): scripts/collect_profiles.sh writes the file
@@ -535,13 +692,49 @@ def main():
                     out["roofline"]["traffic"] = kk["read_bytes"] + kk["write_bytes"]
                     out["roofline"]["traffic_read"] = kk["read_bytes"]
                     out["roofline"]["traffic_write"] = kk["write_bytes"]
+                    # what holds the kernel below the HBM roof, from the numbers of this line and the counter file: wasted re-reads if traffic is well above the
+                    # algorithmic bytes, otherwise the instruction side (the FP64 fraction the kernel executes, halo included)
+                    waste = out["roofline"]["traffic"] / (bytes_per_cell * g.n_cells)
+                    out["roofline"]["limiter"] = ("traffic %.2fx the algorithmic bytes, HBM fraction %.2f, FP64 fraction incl. halo %.2f: %s" % (
+                        waste, rf["frac"], rf["fp64_frac_incl_halo"],
+                        "re-reads / metadata traffic" if waste > 1.5 else "instruction issue and latency (neither roof is near; see the SQ counters of this round's profiles/)"))
                     out["roofline"]["traffic_note"] = ("bytes per launch: reads = 32/64/128-byte TCC_EA0_RDREQ counts x their sizes (FETCH_SIZE tallies 128-B requests "
                                                        "at 64 B on gfx950), writes = WRITE_SIZE; separate rocprofv3 --pmc passes of python3 bench.py, " + tj["source"])
         except Exception:
             pass
+        # the plans this numbering got: patch statistics (halo re-integration) and whether the SpMV index compression applies
+        if args.strategy == "patch":
+            out["patch_stats"] = pr.K.pattern.patch_stats()
+        try:
+            import ctypes as _C
+            o2 = (_C.c_int64 * 2)()
+            tb._lib.check(tb.lib().tb_pattern_spmv_plan(pr.K.pattern.h, o2))
+            out["spmv_plan"] = {"row_signatures": int(o2[0]), "signature_entries": int(o2[1]), "nnz": int(sp.nnz),
+                                "form": "index-compressed (rows share column-offset signatures)" if o2[0] > 0 else "CSR fallback (the numbering shares no signatures)"}
+        except Exception as ex:
+            out["spmv_plan"] = {"error": str(ex)[:200]}
         if world == 1 and not args.no_cpu_baseline:
-            big = None if args.no_cpu_big else (g.xyz, g.conn, dh.cell_dofs, dh.ndofs, sp.rowptr, sp.colidx, "%dx%dx%d" % (n, n, nz_total))
-            out["cpu_baseline"] = cpu_baseline(args.cpu_n, kap, args.ionic, big=big)
+            tag = "%dx%dx%d" % (n, n, nz_total) if args.mesh == "box" else "%s(%d cells)" % (args.mesh, g.n_cells)
+            big = None if args.no_cpu_big else (g.xyz, g.conn, dh.cell_dofs, dh.ndofs, sp.rowptr, sp.colidx, tag)
+
+            def parity(rp_, ci_, nzM_, nzK_, b_):
+                """sampled rows of the device's M, K and b (re-assembled at t = 0) against the oracle's whole-mesh assembly of the cpu_baseline leg"""
+                tb.update_operators(pr.M, pr.K, 0.0) if fused else (tb.update_operator(pr.M, 0.0), tb.update_operator(pr.K, 0.0))
+                tb.update_operator(pr.src, 0.0)
+                torch.cuda.synchronize()
+                rows = np.unique(np.concatenate([np.random.default_rng(5).choice(dh.ndofs, 96, replace=False), [0, dh.ndofs - 1]]))
+                bh = pr.b.cpu().numpy()
+                eM = eK = 0.0
+                sM, sK = float(np.abs(nzM_).max()), float(np.abs(nzK_).max())
+                for r_ in rows:
+                    k0, k1 = int(rp_[r_]), int(rp_[r_ + 1])
+                    eM = max(eM, float(np.abs(pr.M.A.view(k0, k1 - k0).to_host() - nzM_[k0:k1]).max()) / sM)
+                    eK = max(eK, float(np.abs(pr.K.A.view(k0, k1 - k0).to_host() - nzK_[k0:k1]).max()) / sK)
+                eb = float(np.abs(bh - b_).max() / np.abs(b_).max())
+                return {"rows_sampled": int(len(rows)), "max_rel_err_M": eM, "max_rel_err_K": eK, "max_rel_err_b_all_entries": eb, "bar": 1e-10,
+                        "ok": bool(eM < 1e-10 and eK < 1e-10 and eb < 1e-10)}
+
+            out["cpu_baseline"] = cpu_baseline(args.cpu_n, kap, args.ionic, big=big, check=None if args.no_cpu_big else parity)
         print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()

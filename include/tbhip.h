@@ -144,6 +144,10 @@ enum {
 
 /* ------------------------------------------------------------------ errors */
 const char *tb_last_error_string(void);
+/* Name of the element-kernel instance the latest matrix / tangent assembly call of this thread launched, e.g. "k_patch_hex8_record<K+M,ISO,RPH20,KOFF4096>"
+ * or "k_mech_points + k_mech_contract<R> + k_gather_node_rows_lds" ("" before the first such call).  Diagnostic: lets a benchmark line name the kernel
+ * that ran (no reference counterpart). */
+const char *tb_last_kernel_name(void);
 const char *tb_version(void);
 /* Revision of this interface, bumped whenever an existing entry changes what it reads or writes through its pointers (new entries alone do not
  * bump it).  4: tb_cgd_update writes three doubles (d_out3; revisions ≤ 3 wrote two).  A host binding compares tb_abi_revision() with the
@@ -503,6 +507,23 @@ int tb_comm_exchange(tb_comm *comm, int n_peers, const int32_t *peers, const int
 int tb_comm_allreduce(tb_comm *comm, double *d_buf, int64_t n, int op);
 int tb_comm_exchange_begin(tb_comm *comm, int n_peers, const int32_t *peers, const int64_t *counts, const double *const *d_send, double *const *d_recv);
 int tb_comm_exchange_end(tb_comm *comm);
+/* ---- HIP graphs behind the boundary (round 5; no reference counterpart: the reference's time loops are host loops, src/solver/time/euler.jl:71-101) ----
+ * A time loop on a small sub-domain pays more for its launches than for its kernels (the 27-layer slab of an 8-GPU run: 0.41 ms of kernels in a
+ * 0.47 ms step, 0.095 in a 0.136 ms CG iteration).  Between tb_graph_begin and tb_graph_end every enqueue-only call on the device — assembly into
+ * fixed arrays, tb_reaction_step*, tb_spmv_csr*, tb_cgd_*, tb_heat_matrix, tb_axpy, tb_gather / tb_scatter_* — is CAPTURED instead of run;
+ * tb_graph_launch replays the whole sequence with one launch.  Rules while a capture is open: the status is deferred (tb_device_defer_status
+ * semantics; tb_device_poll_status after a launch reads what the replayed kernels raised); nothing that reads back to the host may be called
+ * (tb_memcpy_d2h, tb_dot, the solvers' convergence looks, tb_reaction_step_rtc) — tb_graph_end then fails with TB_ERR_HIP; every plan the calls
+ * need must exist already (run the sequence once, uncaptured, first).  Scalar arguments are frozen in a captured launch EXCEPT the time: forms and
+ * ionic models read it from a device slot while captured, and tb_graph_launch(graph, t) sets that slot (t and cos 2πt) ahead of the replay.
+ * TB_ERR_UNSUPPORTED: the HIP runtime lacks a graph call this needs (the caller falls back to plain calls).  tb_graph_node_count: nodes captured
+ * (kernels, memsets), for reports. */
+typedef struct tb_graph tb_graph;
+int tb_graph_begin(tb_device *dev);
+int tb_graph_end(tb_device *dev, tb_graph **out);
+int tb_graph_launch(tb_graph *graph, double t);
+int tb_graph_node_count(tb_graph *graph, int *n);
+int tb_graph_destroy(tb_graph *graph);
 /* Work statistics of the PATCH plan of a pattern's mesh (built on first use; no reference counterpart — the reference's strategies carry no
  * redundancy): out[0] = patches, out[1] = cell instances (a patch re-integrates the halo cells of the rows it owns: instances / cells is the
  * factor between the flops the patch kernels execute and the flops of one pass over the cells), out[2] = cells, out[3] = largest number of

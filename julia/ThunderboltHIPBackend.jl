@@ -39,6 +39,8 @@ mutable struct MI355XDevice{Tv, Ti} <: AbstractGPUDevice
         finalizer(d -> ccall((:tb_device_destroy, libtbhip), Cint, (Ptr{Cvoid},), d.handle), dev)
         return dev
     end
+# the kernel instance the latest assembly call launched (benchmark lines)
+last_kernel_name() = unsafe_string(ccall((:tb_last_kernel_name, libtbhip), Cstring, ()))
 end
 MI355XDevice(id = 0) = MI355XDevice{Float64, Int32}(id)
 value_type(::MI355XDevice{Tv}) where {Tv} = Tv
@@ -538,6 +540,32 @@ end
 halo_exchange_end!(c::HIPComm) = check(ccall((:tb_comm_exchange_end, libtbhip), Cint, (Ptr{Cvoid},), c.handle))
 allreduce_sum!(c::HIPComm, S::HIPVector{Float64}, first::Int, n::Int) =
     check(ccall((:tb_comm_allreduce, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Cint), c.handle, S.ptr + 8 * first, n, 0))
+
+# ---------------------------------------------------------------- HIP graphs: a fixed sequence of enqueue-only calls captured once, replayed with one launch
+# g = capture_graph(dev) do … the calls of one time step / one CG iteration … end;  launch!(g, t)
+mutable struct HIPGraph
+    handle::Ptr{Cvoid}
+    dev::MI355XDevice
+end
+function capture_graph(f::Function, dev::MI355XDevice)
+    check(ccall((:tb_graph_begin, libtbhip), Cint, (Ptr{Cvoid},), dev.handle))
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    try
+        f()
+    finally
+        rc = ccall((:tb_graph_end, libtbhip), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}), dev.handle, h)
+        check(rc)
+    end
+    g = HIPGraph(h[], dev)
+    finalizer(x -> ccall((:tb_graph_destroy, libtbhip), Cint, (Ptr{Cvoid},), x.handle), g)
+    return g
+end
+launch!(g::HIPGraph, t::Real = 0.0) = check(ccall((:tb_graph_launch, libtbhip), Cint, (Ptr{Cvoid}, Cdouble), g.handle, t))
+function node_count(g::HIPGraph)
+    n = Ref{Cint}(0)
+    check(ccall((:tb_graph_node_count, libtbhip), Cint, (Ptr{Cvoid}, Ref{Cint}), g.handle, n))
+    return Int(n[])
+end
 
 function cgd_rotate!(S::HIPVector{Float64})
     check(ccall((:tb_cgd_rotate, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Float64}), S.dev.handle, S.ptr))

@@ -53,6 +53,7 @@ TB_SARCOMERE_PELCE_SUN_LANGEVELD_1995, TB_SARCOMERE_CONSTANT_STRETCH, TB_SARCOME
 # name -> (restype, argtypes): every symbol include/tbhip.h declares
 SIGNATURES = {
     "tb_last_error_string": (C.c_char_p, []),
+    "tb_last_kernel_name": (C.c_char_p, []),
     "tb_version": (C.c_char_p, []),
     "tb_abi_revision": (C.c_int, []),
     "tb_device_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
@@ -162,6 +163,11 @@ SIGNATURES = {
     "tb_comm_exchange": (C.c_int, [vp, C.c_int, vp, vp, vp, vp]),
     "tb_comm_allreduce": (C.c_int, [vp, vp, C.c_int64, C.c_int]),
     "tb_comm_exchange_begin": (C.c_int, [vp, C.c_int, vp, vp, vp, vp]),
+    "tb_graph_begin": (C.c_int, [vp]),
+    "tb_graph_end": (C.c_int, [vp, C.POINTER(vp)]),
+    "tb_graph_launch": (C.c_int, [vp, C.c_double]),
+    "tb_graph_node_count": (C.c_int, [vp, C.POINTER(C.c_int)]),
+    "tb_graph_destroy": (C.c_int, [vp]),
     "tb_comm_exchange_end": (C.c_int, [vp]),
     "tb_pattern_spmv_plan": (C.c_int, [vp, vp]),
     "tb_scatter_add_indexed": (C.c_int, [vp, C.c_int64, vp, vp, vp]),

@@ -73,6 +73,18 @@ class MI355XDevice:
         """tb_device_poll_status: synchronise, raise the first assembly error (detJ ≤ 0, coupling missing from the pattern) since the last poll, clear."""
         check(lib().tb_device_poll_status(self.h))
 
+    def capture(self, body):
+        """HIP graph of the enqueue-only calls `body()` makes on this device (tb_graph_begin / tb_graph_end): returns a DeviceGraph whose `launch(t)` replays
+        them with one launch.  Run the sequence once uncaptured first (plans must exist); nothing inside may read back to the host."""
+        check(lib().tb_graph_begin(self.h))
+        h = C.c_void_p()
+        try:
+            body()
+        finally:
+            rc = lib().tb_graph_end(self.h, C.byref(h))
+        check(rc)
+        return DeviceGraph(self, h)
+
     def info(self):
         name = C.create_string_buffer(64)
         ncu, mem = C.c_int(), C.c_size_t()
@@ -118,6 +130,33 @@ class Event:
         try:
             if self.h:
                 lib().tb_event_destroy(self.h)
+        except Exception:
+            pass
+
+
+class DeviceGraph:
+    """a captured sequence of device work (MI355XDevice.capture); `launch(t)` sets the time slot the captured forms / ionic models read and replays it"""
+
+    def __init__(self, dev, h):
+        self.dev, self.h = dev, h
+
+    def launch(self, t=0.0):
+        check(lib().tb_graph_launch(self.h, float(t)))
+
+    @property
+    def nodes(self):
+        n = C.c_int()
+        check(lib().tb_graph_node_count(self.h, C.byref(n)))
+        return n.value
+
+    def close(self):
+        if self.h:
+            lib().tb_graph_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
         except Exception:
             pass
 

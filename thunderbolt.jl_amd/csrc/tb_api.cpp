@@ -22,6 +22,20 @@ void set_error(const char *fmt, ...)
     g_error = buf;
 }
 
+// name of the element / assembly kernel instance the latest assembly call of this thread launched (tb_last_kernel_name): what a benchmark line
+// reports as "the kernel that ran" instead of a name typed into the script
+static thread_local std::string g_last_kernel;
+void set_last_kernel(const char *fmt, ...)
+{
+    char buf[256];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_kernel = buf;
+}
+const char *last_kernel() { return g_last_kernel.c_str(); }
+
 int reset_status(tb_device *dev)
 {
     if (dev->defer_status) return TB_OK; // flags stay raised (they are only ever set) until tb_device_poll_status reads and clears them
@@ -69,6 +83,7 @@ extern "C" {
 const char *tb_last_error_string(void) { return g_error.c_str(); }
 const char *tb_version(void) { return "thunderbolt.jl_amd 0.1 (gfx950)"; }
 int tb_abi_revision(void) { return TB_ABI_REVISION; }
+const char *tb_last_kernel_name(void) { return tb::last_kernel(); }
 
 // ------------------------------------------------------------------ device
 int tb_device_create(int hip_device_id, tb_device **out)
@@ -103,6 +118,7 @@ int tb_device_destroy(tb_device *dev)
     if (dev->d_status) hipFree(dev->d_status);
     if (dev->h_status) hipHostFree(dev->h_status);
     if (dev->d_scratch) hipFree(dev->d_scratch);
+    if (dev->d_tslot) hipFree(dev->d_tslot);
     delete dev;
     return TB_OK;
 }

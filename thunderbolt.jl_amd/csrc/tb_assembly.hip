@@ -207,10 +207,10 @@ __device__ __forceinline__ double eval_source(const FormArgs &fa, const double (
 {
     switch (fa.src_kind) {
     case TB_SRC_CONST: return fa.p0;
-    case TB_SRC_NORM_PLUS_T: return sqrt(xq[0] * xq[0] + xq[1] * xq[1] + xq[2] * xq[2]) + fa.t;
+    case TB_SRC_NORM_PLUS_T: return sqrt(xq[0] * xq[0] + xq[1] * xq[1] + xq[2] * xq[2]) + (fa.tslot ? fa.tslot[0] : fa.t);
     case TB_SRC_COS_EXP: // cos(2πt)·exp(−‖x‖²) (benchmarks-cuda-linear-form.jl:15-18); ct = cos(2πt) is uniform in space: evaluated once on the host.
         // ‖x‖² is formed directly (the square of a square root differs from it by ≤ 2 ulp) and the exponential is the bounded-argument one.
-        return fa.ct * exp_b(-(xq[0] * xq[0] + xq[1] * xq[1] + xq[2] * xq[2]));
+        return (fa.tslot ? fa.tslot[1] : fa.ct) * exp_b(-(xq[0] * xq[0] + xq[1] * xq[1] + xq[2] * xq[2]));
     case TB_SRC_TABULATED: return fa.table[cell * nq + q];
     }
     return 0.0;

@@ -27,6 +27,7 @@ struct FormArgs {
     double p0;
     const double *table;
     double t, ct;
+    const double *tslot; // non-NULL while a graph capture is open: {t, cos 2πt} on the device replace the two scalars above (tb_graph.hip)
     // constant positive definite tensor D = L·Lᵀ, record kernel: coordinates are mapped by L⁻¹ at staging (row-major Linv), iso_scale = −¼·det L
     double Linv[9], iso_scale;
 #ifdef TB_ABLATION
@@ -49,6 +50,7 @@ inline FormArgs make_args(const tb_form *f, double t)
     a.table = f->d_table;
     a.t = t;
     a.ct = std::cos(2.0 * 3.141592653589793 * t);
+    a.tslot = f->mesh->dev->capturing ? f->mesh->dev->d_tslot : nullptr;
 #ifdef TB_ABLATION
     static const int dbg = getenv("TB_DEBUG_FLAGS") ? atoi(getenv("TB_DEBUG_FLAGS")) : 0;
     a.debug = dbg;

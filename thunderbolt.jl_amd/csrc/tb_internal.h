@@ -14,6 +14,8 @@
 namespace tb {
 
 void set_error(const char *fmt, ...);
+void set_last_kernel(const char *fmt, ...); // tb_last_kernel_name: the instance an assembly call launched
+const char *last_kernel();
 
 #define TB_HIP(call)                                                                          \
     do {                                                                                      \
@@ -152,6 +154,8 @@ struct tb_device {
     bool defer_status = false;      // tb_device_defer_status: assembly calls return without reading the status block; tb_device_poll_status reads it
     void *d_scratch = nullptr;      // Float64 arena behind the *_f32 entry points (tb_f32.hip), grown on demand
     size_t scratch_bytes = 0;
+    double *d_tslot = nullptr;      // {t, cos 2πt}: where time-dependent kernels read the time while a graph capture is open (tb_graph.hip)
+    bool capturing = false, defer_before_capture = false;
     hipStream_t aux_stream = nullptr; // second queue of the chunked mechanics linearisation (gather of chunk k beside the integration of chunk k + 1)
     hipEvent_t aux_ev[2] = {nullptr, nullptr};
 };

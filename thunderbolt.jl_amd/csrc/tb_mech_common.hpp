@@ -45,6 +45,30 @@ static __constant__ int g_hex27_node[27] = {make_hex27_nodes().v[0], make_hex27_
                                      make_hex27_nodes().v[15], make_hex27_nodes().v[16], make_hex27_nodes().v[17], make_hex27_nodes().v[18], make_hex27_nodes().v[19],
                                      make_hex27_nodes().v[20], make_hex27_nodes().v[21], make_hex27_nodes().v[22], make_hex27_nodes().v[23], make_hex27_nodes().v[24],
                                      make_hex27_nodes().v[25], make_hex27_nodes().v[26]};
+// Tensor-order layout of the stored element matrices of the triquadratic field (element strategy, sum-factorised kernels; round 5):
+//   Kₑ[(a,c)][(b,d)] sits at row 3·tix(a) + c, column cb(b) + 9·d with tix(a) = a₀ + 3a₁ + 9a₂ and cb(b) = 27·b₂ + 3·b₀ + b₁ (tensor indices of
+// the Ferrite nodes) — the order in which the lanes of the contraction produce their entries, so that 27 consecutive lanes store 27 consecutive
+// doubles (in Ferrite order a wave-instruction of 64 stores touched 64 different 64-byte segments, and the address path, not the arithmetic,
+// bounded the kernel).  The gather undoes it through these two 27-entry tables, packed six bits per entry into three 64-bit constants.
+constexpr uint64_t pack27(int w, bool colbase)
+{
+    uint64_t v = 0;
+    for (int i = 0; i < 10; ++i) {
+        const int a = 10 * w + i;
+        if (a < 27) {
+            const int t0 = hex27_tix(a, 0), t1 = hex27_tix(a, 1), t2 = hex27_tix(a, 2);
+            v |= (uint64_t)(colbase ? 27 * t2 + 3 * t0 + t1 : t0 + 3 * t1 + 9 * t2) << (6 * i);
+        }
+    }
+    return v;
+}
+__host__ __device__ __forceinline__ int unpack27(int a, bool colbase)
+{
+    const uint64_t w = a < 10 ? pack27(0, colbase) : a < 20 ? pack27(1, colbase) : pack27(2, colbase);
+    return (int)((w >> (6 * (a % 10))) & 63);
+}
+__host__ __device__ __forceinline__ int tix27(int a) { return unpack27(a, false); } // Ferrite node → a₀ + 3a₁ + 9a₂
+__host__ __device__ __forceinline__ int cb27(int b) { return unpack27(b, true); }   // Ferrite node → 27·b₂ + 3·b₀ + b₁
 __host__ __device__ constexpr double quad1d(int i, double x) { return i == 0 ? 0.5 * x * (x - 1.0) : i == 1 ? (1.0 - x * x) : 0.5 * x * (x + 1.0); }
 __host__ __device__ constexpr double dquad1d(int i, double x) { return i == 0 ? x - 0.5 : i == 1 ? -2.0 * x : x + 0.5; }
 

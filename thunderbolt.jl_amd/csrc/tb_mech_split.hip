@@ -26,7 +26,10 @@ using namespace tbk;
 constexpr int MP_CELLS = 9;          // cells per workgroup of k_mech_points
 __host__ __device__ constexpr int sympair(int m, int n) { return m * 9 - m * (m - 1) / 2 + (n - m); } // m ≤ n < 9 → 0..44
 
-__global__ void __launch_bounds__(256, 2)
+#ifndef TB_MECH_POINTS_WAVES
+#define TB_MECH_POINTS_WAVES 1 // one wave per SIMD, no scratch: 2.6 ms at 80³ against 3.6 ms at two waves with 74 spilled registers
+#endif
+__global__ void __launch_bounds__(256, TB_MECH_POINTS_WAVES)
 k_mech_points(MechMesh m, HOParams mat, const double *__restrict__ u, int64_t n_cells /*of this launch, from m.cell0*/, double *__restrict__ out, Status *st)
 {
     const int tid = threadIdx.x;
@@ -160,34 +163,28 @@ k_mech_contract(const double *__restrict__ qp /*records of this launch*/, int64_
     constexpr int ND = 81, NQ = 27;
     const int tid = threadIdx.x;
     const int64_t cell = cell0 + blockIdx.x;
-    __shared__ double s_A[NQ][81], s_Z1[2187], s_P[NQ][9];
-    __shared__ uint8_t s_node[32], s_tix[32];
-    if (tid < 27) { const int a = g_hex27_node[tid]; s_node[tid] = (uint8_t)a; s_tix[a] = (uint8_t)tid; }
-    {
-        const double2 *src = reinterpret_cast<const double2 *>(qp + (int64_t)blockIdx.x * QP_REC);
-        static_assert(QP_REC % 2 == 0, "records are read as 16-byte pieces");
-        double2 v[3];
+#ifndef TB_MECH_CONTRACT_PAD
+#define TB_MECH_CONTRACT_PAD 0
+#endif
+    __shared__ double s_A[NQ][81], s_Z1[2187 + TB_MECH_CONTRACT_PAD], s_P[NQ][9];
+    { // the record [entry][point] → 𝔸̂ of every point with both triangles (s_A[q][9m + n] = s_A[q][9n + m]) and P̂: a lane keeps its point, six entries each
+        const double *src = qp + (int64_t)blockIdx.x * QP_REC;
+        const int q = tid % 27, e0 = tid / 27; // e0 ≤ 9 (lanes 243..255: e0 = 9, their entries e0 + 9i ≥ 54 for i = 5 only)
+        double v[6];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) { const int k = tid + 256 * i; v[i] = k < QP_REC / 2 ? src[k] : double2{0.0, 0.0}; }
+        for (int i = 0; i < 6; ++i) { const int e = e0 + 9 * i; v[i] = e < QP_ENT ? src[e * 27 + q] : 0.0; }
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int k = tid + 256 * i;
-            if (k < QP_REC / 2) {
+        for (int i = 0; i < 6; ++i) {
+            const int e = e0 + 9 * i;
+            if (e < QP_SYM) {
+                int mrow = 0;
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int idx = 2 * k + h, e = idx / 27, q = idx - 27 * e;
-                    const double val = h ? v[i].y : v[i].x;
-                    if (e < QP_SYM) {
-                        int mrow = 0;
-#pragma unroll
-                        for (int t = 1; t < 9; ++t) mrow += e >= sympair(t, t);
-                        const int ncol = mrow + (e - sympair(mrow, mrow));
-                        s_A[q][9 * mrow + ncol] = val;
-                        s_A[q][9 * ncol + mrow] = val;
-                    } else {
-                        s_P[q][e - QP_SYM] = val;
-                    }
-                }
+                for (int t = 1; t < 9; ++t) mrow += e >= sympair(t, t);
+                const int ncol = mrow + (e - (mrow * 9 - mrow * (mrow - 1) / 2));
+                s_A[q][9 * mrow + ncol] = v[i];
+                s_A[q][9 * ncol + mrow] = v[i];
+            } else if (e < QP_ENT) {
+                s_P[q][e - QP_SYM] = v[i];
             }
         }
     }
@@ -199,7 +196,7 @@ k_mech_contract(const double *__restrict__ qp /*records of this launch*/, int64_
         if (tid < ND) {
             const int a = tid / 3, c = tid - 3 * a;
             double fa[3][3], da[3][3]; // [direction][point]
-            const int ta = s_tix[a];
+            const int ta = tix27(a);
 #pragma unroll
             for (int dir = 0; dir < 3; ++dir) {
                 const int i = dir == 0 ? ta % 3 : dir == 1 ? (ta / 3) % 3 : ta / 9;
@@ -236,9 +233,7 @@ k_mech_contract(const double *__restrict__ qp /*records of this launch*/, int64_
         const double pb = tb1 == 0 ? PH(0, q1) : tb1 == 1 ? PH(1, q1) : PH(2, q1), db = tb1 == 0 ? DP(0, q1) : tb1 == 1 ? DP(1, q1) : DP(2, q1);
         c2[0][0][q1] = pa * pb; c2[0][1][q1] = pa * db; c2[1][0][q1] = da * pb; c2[1][1][q1] = da * db;
     }
-    int rowa[3], colb[3]; // Ferrite nodes of (a₀, a₁, ·) and (b₀, b₁, ·)
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { rowa[k] = s_node[ta0 + 3 * ta1 + 9 * k]; colb[k] = s_node[tb0 + 3 * tb1 + 9 * k]; }
+    const int t27 = (tid < 243 ? tid : 0) % 27; // 9·d + 3·b₀ + b₁: the lane's column inside a b₂ block of the tensor-order row
     double *kc = ke + (int64_t)cell * (ND * ND);
     for (int c = 0; c < 3; ++c) {
         if (tid < 243) { // stage 1: task (s, d, u, q₁, q₂)
@@ -295,7 +290,7 @@ k_mech_contract(const double *__restrict__ qp /*records of this launch*/, int64_
                     double v = 0.0;
 #pragma unroll
                     for (int q2 = 0; q2 < 3; ++q2) v += PH(a2, q2) * w[0][b2][q2] + DP(a2, q2) * w[1][b2][q2];
-                    kc[(3 * rowa[a2] + c) * ND + 3 * colb[b2] + td] = v; // assemble!(assembler, dofs, Kₑ): entry ((a, c), (b, d))
+                    kc[(3 * (ta0 + 3 * ta1 + 9 * a2) + c) * ND + 27 * b2 + t27] = v; // entry ((a, c), (b, d)) in the tensor-order layout (tb_mech_common.hpp): 27 consecutive lanes, 27 consecutive doubles
                 }
         }
         lds_barrier(); // Z1 is rewritten by the next component's stage 1

@@ -658,7 +658,7 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
 #pragma unroll
                         for (int q2 = 0; q2 < 3; ++q2) v += PH(a2, q2) * w[0][b2][q2] + DP(a2, q2) * w[1][b2][q2];
                         // assemble!(assembler, dofs, Kₑ): entry ((a, c), (b, d))
-                        if (atomic == 2) ke[((int64_t)cell * ND + 3 * rowa[a2] + c) * ND + 3 * colb[b2] + td] = v;
+                        if (atomic == 2) ke[((int64_t)cell * ND + 3 * (ta0 + 3 * ta1 + 9 * a2) + c) * ND + 27 * b2 + (tid < 243 ? tid : 0) % 27] = v; // tensor-order layout (tb_mech_common.hpp)
                         else {
                             const int64_t k = rowptr[s_dof[3 * rowa[a2]] + c] + blockpos[cell * (NB * NB) + rowa[a2] * NB + colb[b2]] + td;
                             if (atomic) unsafeAtomicAdd(nz + k, v); else nz[k] += v;
@@ -772,7 +772,7 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
 // built in LDS from blockpos (27 byte stores), then every lane sums its entry over the ≤8 element matrices in cell order —
 // independent loads, all in flight together, no accumulator in LDS, each nz stored once (bit-reproducible like the
 // reference's EA strategy).  DMAJOR: row layout of the stored Kₑ is [d][b] instead of [b][d].
-template <int NB, bool DMAJOR, int NK>
+template <int NB, bool DMAJOR, int NK, bool TL = false>
 __device__ __forceinline__ void gather_rows(const double *const (&rowk)[8], const uint8_t *inv, int nbr_max, int L, int lane, double *dst0, bool first)
 {
     // the three rows of the node share the position → local-node lookup: one pass over the positions with the 3·NK loads of a position in flight
@@ -787,7 +787,7 @@ __device__ __forceinline__ void gather_rows(const double *const (&rowk)[8], cons
             const int b = inv[k * nbr_max + nbr];
             ok[k] = b != 0xFF;
             const int bb = ok[k] ? b : 0;
-            const double *src = rowk[k] + (DMAJOR ? d * NB + bb : 3 * bb + d);
+            const double *src = rowk[k] + (TL ? bb + 9 * d : DMAJOR ? d * NB + bb : 3 * bb + d); // TL: the map holds cb(b) (tensor-order columns)
 #pragma unroll
             for (int c = 0; c < 3; ++c) v[c][k] = src[c * ND];
         }
@@ -802,7 +802,7 @@ __device__ __forceinline__ void gather_rows(const double *const (&rowk)[8], cons
     }
 }
 
-template <int NB, bool DMAJOR>
+template <int NB, bool DMAJOR, bool TL = false>
 __global__ void __launch_bounds__(256)
 k_gather_node_rows(const int32_t *__restrict__ node_dof0, int64_t n_nodes, const int64_t *__restrict__ ea_ptr, const int32_t *__restrict__ ea_src,
                    const double *__restrict__ ke, const uint16_t *__restrict__ blockpos, const int64_t *__restrict__ rowptr, double *__restrict__ nz,
@@ -828,20 +828,20 @@ k_gather_node_rows(const int32_t *__restrict__ node_dof0, int64_t n_nodes, const
             const int32_t slot = ea_src[kb + k];
             const int64_t cell = slot / ND;
             const int a = (slot % ND) / 3;
-            inv[k * nbr_max + blockpos[cell * (NB * NB) + a * NB + b] / 3] = (uint8_t)b;
+            inv[k * nbr_max + blockpos[cell * (NB * NB) + a * NB + b] / 3] = (uint8_t)(TL ? cb27(b) : b);
         }
         __builtin_amdgcn_wave_barrier();
         const double *rowk[8];
 #pragma unroll
         for (int k = 0; k < KC; ++k) {
             const int32_t slot = ea_src[kb + (k < nk ? k : 0)];
-            rowk[k] = ke + ((int64_t)(slot / ND) * ND + 3 * ((slot % ND) / 3)) * ND;
+            rowk[k] = ke + ((int64_t)(slot / ND) * ND + 3 * (TL ? tix27((slot % ND) / 3) : (slot % ND) / 3)) * ND;
         }
         const bool first = kb == k0;
-        if (nkp == 1) gather_rows<NB, DMAJOR, 1>(rowk, inv, nbr_max, L, lane, nz + g0, first);
-        else if (nkp == 2) gather_rows<NB, DMAJOR, 2>(rowk, inv, nbr_max, L, lane, nz + g0, first);
-        else if (nkp == 4) gather_rows<NB, DMAJOR, 4>(rowk, inv, nbr_max, L, lane, nz + g0, first);
-        else gather_rows<NB, DMAJOR, 8>(rowk, inv, nbr_max, L, lane, nz + g0, first);
+        if (nkp == 1) gather_rows<NB, DMAJOR, 1, TL>(rowk, inv, nbr_max, L, lane, nz + g0, first);
+        else if (nkp == 2) gather_rows<NB, DMAJOR, 2, TL>(rowk, inv, nbr_max, L, lane, nz + g0, first);
+        else if (nkp == 4) gather_rows<NB, DMAJOR, 4, TL>(rowk, inv, nbr_max, L, lane, nz + g0, first);
+        else gather_rows<NB, DMAJOR, 8, TL>(rowk, inv, nbr_max, L, lane, nz + g0, first);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -858,7 +858,7 @@ struct GatherNode {
     int32_t slot[8]; // cell·ND + 3a: row offset of the node's run in the stored element matrices, cell-ordered
 };
 
-template <int NB, int KC>
+template <int NB, int KC, bool TL = false>
 __global__ void __launch_bounds__(256, KC == 4 ? 4 : 2)
 k_gather_node_rows_lds(const GatherNode *__restrict__ gn, int64_t n_nodes, const double *__restrict__ ke, const uint16_t *__restrict__ blockpos,
                        double *__restrict__ nz, int nbr_pad)
@@ -883,7 +883,9 @@ k_gather_node_rows_lds(const GatherNode *__restrict__ gn, int64_t n_nodes, const
 #pragma unroll
         for (int k = 0; k < KC; ++k)
             if (k < nk) {
-                const double *src = ke + (int64_t)rec.slot[kb + k] * ND;
+                int64_t row0 = rec.slot[kb + k]; // cell·ND + 3a
+                if constexpr (TL) { const int64_t cellk = row0 / ND; row0 = cellk * ND + 3 * tix27((int)(row0 - cellk * ND) / 3); }
+                const double *src = ke + row0 * ND;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) { const int idx = lane + 64 * j; r[k][j] = idx < RUN ? src[idx] : 0.0; }
             }
@@ -896,7 +898,7 @@ k_gather_node_rows_lds(const GatherNode *__restrict__ gn, int64_t n_nodes, const
             for (int kk = 1; kk < KC; ++kk) slot = k == kk ? rec.slot[kb + kk] : slot;
             const int64_t cell = slot / ND;
             const int a = (slot - (int32_t)cell * ND) / 3;
-            inv[k * nbr_pad + blockpos[cell * (NB * NB) + a * NB + b] / 3] = (uint8_t)b;
+            inv[k * nbr_pad + blockpos[cell * (NB * NB) + a * NB + b] / 3] = (uint8_t)(TL ? cb27(b) : b);
         }
 #pragma unroll
         for (int k = 0; k < KC; ++k)
@@ -915,7 +917,7 @@ k_gather_node_rows_lds(const GatherNode *__restrict__ gn, int64_t n_nodes, const
                     if (k < nk) {
                         const int b = inv[k * nbr_pad + nbr];
                         if (b != 0xFF) {
-                            const double *sv = buf + k * RUN + 3 * b + d;
+                            const double *sv = buf + k * RUN + (TL ? b + 9 * d : 3 * b + d);
                             acc[i][0] += sv[0];
                             acc[i][1] += sv[ND];
                             acc[i][2] += sv[2 * ND];
@@ -1370,7 +1372,7 @@ static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, doubl
                     TB_HIP(hipStreamWaitEvent(dev->aux_stream, dev->aux_ev[0], 0));
                     const int64_t n1 = k + 1 == chunks_env ? m->n_nodes_field : std::upper_bound(p->h_gn_last.begin(), p->h_gn_last.end(), (int32_t)(c1 - 1)) - p->h_gn_last.begin();
                     if (n1 > n_done) {
-                        auto kg = k_gather_node_rows_lds<FE::NB, 4>;
+                        auto kg = k_gather_node_rows_lds<FE::NB, 4, (NEED_K && CT == 2 && FE::NB == 27)>;
                         hipLaunchKernelGGL(kg, dim3((unsigned)((n1 - n_done + 3) / 4)), dim3(256), glds, dev->aux_stream, (const GatherNode *)p->d_gnodes + n_done,
                                            n1 - n_done, kebuf, bp, d_nz, nbr_pad);
                         TB_HIP(hipGetLastError());
@@ -1432,12 +1434,12 @@ static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, doubl
             if (!(MFMA && KE_DMAJOR) && !direct && p->gnodes_state > 0) {
                 const int nbr_pad = (nbr_max + 7) & ~7;
                 const size_t lds = (size_t)4 * 4 * (3 * FE::ND * sizeof(double) + (size_t)nbr_pad);
-                auto k = k_gather_node_rows_lds<FE::NB, 4>;
+                auto k = k_gather_node_rows_lds<FE::NB, 4, (NEED_K && CT == 2 && FE::NB == 27)>;
                 hipLaunchKernelGGL(k, dim3((unsigned)((m->n_nodes_field + 3) / 4)), dim3(256), lds, dev->stream, (const GatherNode *)p->d_gnodes,
                                    m->n_nodes_field, kebuf, bp, d_nz, nbr_pad);
             } else {
                 const size_t lds = (size_t)4 * 8 * nbr_max;
-                auto k = k_gather_node_rows<FE::NB, MFMA && KE_DMAJOR>;
+                auto k = k_gather_node_rows<FE::NB, MFMA && KE_DMAJOR, (NEED_K && CT == 2 && FE::NB == 27)>;
                 hipLaunchKernelGGL(k, dim3((unsigned)((m->n_nodes_field + 3) / 4)), dim3(256), lds, dev->stream, m->d_node_dof0, m->n_nodes_field,
                                    m->ea->d_ptr, m->ea->d_src, kebuf, bp, rowptr, d_nz, nbr_max);
             }

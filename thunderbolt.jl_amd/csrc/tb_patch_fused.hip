@@ -635,6 +635,7 @@ int launch_assemble_hex8_patch(tb_form *fK, tb_form *fM, tb_pattern *p, double t
 #endif
                 return TB_OK;
             };
+            set_last_kernel("k_patch_hex8_record<%s,%s,RPH%d%s>", fK && fM ? "K+M" : fK ? "K" : "M", !fK ? "-" : iso ? "ISO" : diag ? "DIAG" : "GEN", RPH, fK && fM && fixm ? ",KOFF4096" : "");
             if (fK && fM && fixm) rc = iso ? launch_rec(k_patch_hex8_record<true, true, false, true, RPH, KOFF>) : diag ? launch_rec(k_patch_hex8_record<true, true, true, false, RPH, KOFF>) : launch_rec(k_patch_hex8_record<true, true, false, false, RPH, KOFF>);
             else if (fK && fM) rc = iso ? launch_rec(k_patch_hex8_record<true, true, false, true, RPH>) : diag ? launch_rec(k_patch_hex8_record<true, true, true, false, RPH>) : launch_rec(k_patch_hex8_record<true, true, false, false, RPH>);
             else if (fK) rc = iso ? launch_rec(k_patch_hex8_record<true, false, false, true, RPH>) : diag ? launch_rec(k_patch_hex8_record<true, false, true, false, RPH>) : launch_rec(k_patch_hex8_record<true, false, false, false, RPH>);
@@ -656,6 +657,7 @@ int launch_assemble_hex8_patch(tb_form *fK, tb_form *fM, tb_pattern *p, double t
         }
         return TB_OK;
     };
+    set_last_kernel("%s<%s,%s%s%s>", staged ? "k_patch_hex8_staged" : "k_patch_hex8", fK && fM ? "K+M" : fK ? "K" : "M", !fK ? "-" : fk ? "FIELD" : diag ? "DIAG" : "GEN", fm ? ",RHO_FIELD" : "", "");
 #define TB_PL(a, b, c, d) rc = launch(k_patch_hex8_staged<a, b, c, d>, k_patch_hex8<a, b, c, d>)
 #define TB_PLD(a, b, c, d) rc = launch(k_patch_hex8_staged<a, b, c, d, true>, k_patch_hex8<a, b, c, d>)
     // constant diagonal tensors (isotropic / axis-aligned conductivities) take the variant with the cheaper A·D product

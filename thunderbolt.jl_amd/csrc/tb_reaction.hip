@@ -459,7 +459,6 @@ template <> struct CellModel<TB_CELL_ORD11> {
         emit(29, fss, 1.0 / 75.0); emit(31, fss, rcp_b(tff) * (1.0 / 2.5)); emit(32, fss, rcp_b(tfcaf) * (1.0 / 2.5));
         emit(33, xrss, rcp_b(txrf)); emit(34, xrss, rcp_b(txrs)); emit(35, xs1ss, rcp_b(txs1)); emit(36, xs1ss, txs2_r); emit(37, xk1ss, txk1_r);
     }
-    static constexpr bool SPLIT_FE = true; // forward Euler without sub-steps runs k_reaction_split: non-gate states retired before the gate pass
     __device__ __forceinline__ static bool is_gate(int k) { return (k >= 9 && k <= 29) || (k >= 31 && k <= 37); }
     __device__ __forceinline__ static void rhs_rates(const CellParams &P, const double (&u)[NS], double, double (&du)[NS], double (&rate)[NS])
     {
@@ -487,8 +486,9 @@ __device__ __forceinline__ void cell_rhs(const CellParams &P, const double (&u)[
 template <int MODEL, int LAYOUT, bool WRITE_DU, class TS = double>
 __global__ void __launch_bounds__(256)
 k_reaction(CellParams P, TS *__restrict__ u, TS *__restrict__ du_out, int64_t n, double t, double dt, int substeps,
-           double threshold, unsigned long long *__restrict__ rmax_key, const float *__restrict__ xs, int sdim)
+           double threshold, unsigned long long *__restrict__ rmax_key, const float *__restrict__ xs, int sdim, const double *__restrict__ tslot)
 {
+    if (tslot) t = tslot[0]; // replayed from a graph: the time of this launch sits on the device (tb_graph.hip)
     using M = CellModel<MODEL>;
     constexpr int NS = M::NS;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -533,59 +533,6 @@ k_reaction(CellParams P, TS *__restrict__ u, TS *__restrict__ du_out, int64_t n,
     }
 }
 
-// Forward Euler without sub-steps for the models that split their right-hand side (CellModel::SPLIT_FE: O'Hara–Rudy).  k_reaction holds the 41 states, their 41
-// rates and, until the last line of the RHS, the steady states and rate constants of all 28 gates: 408 registers, one wave per SIMD.  Here the non-gate states
-// are advanced and stored as soon as the currents are known, and the gates follow one by one — steady state, rate, new value, store — so that nothing of a gate
-// outlives its own update: two waves per SIMD.  Same expressions as the generic kernel (same parity against the oracle).  Measured SLOWER than the generic
-// kernel (1.90 against 1.71 ms at 10.2 M points: the current pass alone still spills 96 B per lane at 256 registers) — kept opt-in, see run<>().
-template <class M, class = void> struct splits_fe : std::false_type {};
-template <class M> struct splits_fe<M, std::enable_if_t<M::SPLIT_FE>> : std::true_type {};
-
-template <int MODEL, int LAYOUT, bool WRITE_DU, class TS = double>
-__global__ void __launch_bounds__(256, 2)
-k_reaction_split(CellParams P, TS *__restrict__ u, TS *__restrict__ du_out, int64_t n, double t, double dt, unsigned long long *__restrict__ rmax_key)
-{
-    using M = CellModel<MODEL>;
-    constexpr int NS = M::NS;
-    // 32-bit point index (the launcher checks n·NS < 2³¹): with the state's array as a wave-uniform base, a load or store needs one offset register
-    // instead of a 64-bit address pair per state — 41 pairs were what pushed the state-blocked layout over its register budget
-    const uint32_t stride = gridDim.x * blockDim.x, n32 = (uint32_t)n;
-    double rm = -__builtin_huge_val();
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n32; i += stride) {
-        auto at = [&](TS *base, int j) -> TS * { return LAYOUT == TB_LAYOUT_SOA ? base + (size_t)j * n + i : base + (size_t)i * NS + j; };
-        double ul[NS], dul[NS];
-#pragma unroll
-        for (int j = 0; j < NS; ++j) ul[j] = *at(u, j);
-        const double v_old = ul[M::PHI];
-        M::currents(P, ul, dul);
-        rm = fmax(rm, dul[M::PHI]);
-#pragma unroll
-        for (int j = 0; j < NS; ++j)
-            if (!M::is_gate(j)) {
-                *at(u, j) = (TS)(ul[j] + dt * dul[j]);
-                if (WRITE_DU) *at(du_out, j) = (TS)dul[j];
-            }
-        __builtin_amdgcn_sched_barrier(0); // the gate pass starts here: none of its exponentials is to be hoisted into the current pass
-        // the gate's own value is read again here (from L2 / the Infinity Cache: this point's line was fetched a few microseconds ago) instead of being held
-        // in a register through the current pass
-        M::gates(P, v_old, [&](int j, double inf, double r) {
-            TS *pj = at(u, j);
-            const double uj = (double)__builtin_nontemporal_load(pj);
-            const double d = (inf - uj) * r;
-            *pj = (TS)(uj + dt * d);
-            if (WRITE_DU) *at(du_out, j) = (TS)d;
-        });
-    }
-    if (rmax_key) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) rm = fmax(rm, __shfl_xor(rm, o, 64));
-        if ((threadIdx.x & 63) == 0) {
-            const unsigned long long b = (unsigned long long)__double_as_longlong(rm);
-            atomicMax(rmax_key, (b >> 63) ? ~b : (b | 0x8000000000000000ull));
-        }
-    }
-}
-
 // expm1 for the Rush–Larsen factor: series for small arguments (no cancellation), exp − 1 otherwise
 __device__ __forceinline__ double expm1_b(double z)
 {
@@ -608,8 +555,9 @@ __device__ __forceinline__ double expm1_b(double z)
 // in one evaluation instead of twenty forward-Euler sub-steps.
 template <int MODEL, int LAYOUT>
 __global__ void __launch_bounds__(256)
-k_reaction_rl(CellParams P, double *__restrict__ u, int64_t n, double t, double dt)
+k_reaction_rl(CellParams P, double *__restrict__ u, int64_t n, double t, double dt, const double *__restrict__ tslot)
 {
+    if (tslot) t = tslot[0];
     using M = CellModel<MODEL>;
     constexpr int NS = M::NS;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -639,8 +587,9 @@ int launch_reaction_rl(tb_device *dev, int model, const double *params, int n_pa
     const int64_t cap = (int64_t)dev->n_cu * 16;
     if (nb > cap) nb = (nb + (nb + cap - 1) / cap - 1) / ((nb + cap - 1) / cap); // balanced: every thread ⌈nb / cap⌉ points
     if (n == 0) return TB_OK;
-#define TB_RL(MODEL) do { if (layout == TB_LAYOUT_SOA) hipLaunchKernelGGL((k_reaction_rl<MODEL, TB_LAYOUT_SOA>), dim3((unsigned)nb), dim3(256), 0, dev->stream, P, d_u, n, t, dt); \
-                          else hipLaunchKernelGGL((k_reaction_rl<MODEL, TB_LAYOUT_AOS>), dim3((unsigned)nb), dim3(256), 0, dev->stream, P, d_u, n, t, dt); } while (0)
+    const double *ts = dev->capturing ? dev->d_tslot : nullptr;
+#define TB_RL(MODEL) do { if (layout == TB_LAYOUT_SOA) hipLaunchKernelGGL((k_reaction_rl<MODEL, TB_LAYOUT_SOA>), dim3((unsigned)nb), dim3(256), 0, dev->stream, P, d_u, n, t, dt, ts); \
+                          else hipLaunchKernelGGL((k_reaction_rl<MODEL, TB_LAYOUT_AOS>), dim3((unsigned)nb), dim3(256), 0, dev->stream, P, d_u, n, t, dt, ts); } while (0)
     if (model == TB_CELL_TT06) TB_RL(TB_CELL_TT06); else if (model == TB_CELL_ORD11) TB_RL(TB_CELL_ORD11); else TB_RL(TB_CELL_PCG2019);
 #undef TB_RL
     TB_HIP(hipGetLastError());
@@ -657,20 +606,7 @@ static int run(tb_device *dev, const CellParams &P, TS *u, TS *du, int64_t n, in
     const int64_t cap = per_cu > 0 ? (int64_t)dev->n_cu * per_cu : nb;
     if (nb > cap) nb = (nb + (nb + cap - 1) / cap - 1) / ((nb + cap - 1) / cap); // every thread the same number of points (⌈nb / cap⌉ each): a grid cut at `cap` left some threads 2 and most 1 at 1.3 M points
     const dim3 grid((unsigned)nb), block(bs);
-    if constexpr (splits_fe<CellModel<MODEL>>::value) {
-        // measured at 10.2 M points (O'Hara–Rudy, forward Euler): generic kernel 1.71 ms (408 registers, one wave per SIMD, no scratch), split kernel 1.90 ms (two
-        // waves per SIMD, 96 B of scratch per lane and the gates read twice) — parity-green, slower: opt-in (TB_REACTION_SPLIT=1)
-        static const bool no_split = !(getenv("TB_REACTION_SPLIT") && atoi(getenv("TB_REACTION_SPLIT")) == 1);
-        if (substeps <= 1 && !no_split && n * CellModel<MODEL>::NS < (int64_t)0x7fffffff) {
-#define TB_LAUNCH_S(L, W) hipLaunchKernelGGL((k_reaction_split<MODEL, L, W, TS>), grid, block, 0, dev->stream, P, u, du, n, t, dt, rmax_key)
-            if (layout == TB_LAYOUT_SOA) { if (du) TB_LAUNCH_S(TB_LAYOUT_SOA, true); else TB_LAUNCH_S(TB_LAYOUT_SOA, false); }
-            else { if (du) TB_LAUNCH_S(TB_LAYOUT_AOS, true); else TB_LAUNCH_S(TB_LAYOUT_AOS, false); }
-#undef TB_LAUNCH_S
-            TB_HIP(hipGetLastError());
-            return TB_OK;
-        }
-    }
-#define TB_LAUNCH(L, W) hipLaunchKernelGGL((k_reaction<MODEL, L, W, TS>), grid, block, 0, dev->stream, P, u, du, n, t, dt, substeps, thr, rmax_key, xs, sdim)
+#define TB_LAUNCH(L, W) hipLaunchKernelGGL((k_reaction<MODEL, L, W, TS>), grid, block, 0, dev->stream, P, u, du, n, t, dt, substeps, thr, rmax_key, xs, sdim, dev->capturing ? dev->d_tslot : nullptr)
     if (layout == TB_LAYOUT_SOA) { if (du) TB_LAUNCH(TB_LAYOUT_SOA, true); else TB_LAUNCH(TB_LAYOUT_SOA, false); }
     else { if (du) TB_LAUNCH(TB_LAYOUT_AOS, true); else TB_LAUNCH(TB_LAYOUT_AOS, false); }
 #undef TB_LAUNCH
