@@ -541,27 +541,11 @@ def main():
         # what an exchange costs on this box: RCCL at world size 1 behind the C ABI, rank 0 as its own lower and upper neighbour (one interface plane each
         # way: (n+1)² doubles) and the 8-byte all-reduce of a CG iteration — no xGMI hop in it, but the launch, the protocol and the copy kernels
         xch = None
-        try:
-            cm = tb.distributed.RcclComm(dev, 0, 1)
-            npl = (n + 1) * (n + 1)
-            sb = [torch.zeros(npl, dtype=torch.float64, device="cuda") for _ in range(2)]
-            rb = [torch.empty(npl, dtype=torch.float64, device="cuda") for _ in range(2)]
-            sc = torch.zeros(2, dtype=torch.float64, device="cuda")
-            for _ in range(5):
-                cm.exchange([0, 0], sb, rb); cm.allreduce(sc)
-            torch.cuda.synchronize()
-            e0_, e1_, e2_ = dev.event(), dev.event(), dev.event()
-            e0_.record()
-            for _ in range(20):
-                cm.exchange([0, 0], sb, rb)
-            e1_.record()
-            for _ in range(20):
-                cm.allreduce(sc)
-            e2_.record()
-            torch.cuda.synchronize()
-            xch = {"halo_exchange_ms": e0_.elapsed_ms(e1_) / 20, "allreduce_ms": e1_.elapsed_ms(e2_) / 20, "plane_doubles": npl,
-                   "note": "RCCL behind the C ABI at world size 1 (tb_comm_exchange with rank 0 as its own two neighbours, tb_comm_allreduce of 2 doubles): stream time per call, no xGMI hop"}
-            cm.close()
+        try:                                                         # in a child process: a crash or a hang of the communication library must not cost the line
+            import subprocess
+            r_ = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "rccl_latency.py"), str((n + 1) * (n + 1))], capture_output=True, text=True, timeout=180)
+            js_ = [l_ for l_ in r_.stdout.splitlines() if l_.startswith("{")]   # (RCCL prints its version banner behind the line at exit)
+            xch = json.loads(js_[-1]) if r_.returncode == 0 and js_ else {"error": "rc %d: %s" % (r_.returncode, r_.stderr[-300:])}
         except Exception as ex:
             xch = {"error": str(ex)[:200]}
         slab_sweep["exchange_latency"] = xch

@@ -461,6 +461,10 @@ int tb_cgd_direction(tb_device *dev, int64_t n, const double *d_dinv, const doub
 /* end of an iteration on the scalar block S = {rz, pAp, rz_new, rr, flag, rr of the last finished iteration} (SIX doubles) the three entries above
  * share: S[0] ← S[2], S[5] ← S[3], S[1] = S[2] = S[3] = 0 — one launch; the flag S[4] is left alone, the host reads (S[4], S[5]) */
 int tb_cgd_rotate(tb_device *dev, double *d_S);
+/* One whole iteration of that CG for a sub-domain without shared dofs (one rank): tb_spmv_csr_dot(pat, A, p → Ap, S[1]) → tb_cgd_update (weights = 1)
+ * → tb_cgd_direction → tb_cgd_rotate on the six-double scalar block d_S, issued from ONE call (round 5: the per-call cost of an interpreted host is a
+ * third of a thin slab's iteration).  Same kernels and results as the four calls. */
+int tb_cgd_iteration(tb_pattern *pat, const double *d_nzval, const double *d_dinv, double *d_x, double *d_r, double *d_p, double *d_Ap, double *d_S);
 /* Halo pack / unpack of the multi-GPU path — new work: the reference is shared-memory only (README.md:7); what these stand in for on one device
  * is the plain indexing of device vectors its GPU extension relies on (ext/CuThunderboltExt.jl:126-170).  Sub-domain vectors hold the dofs
  * shared with a neighbouring rank at the positions d_idx (0-based Int32, distinct within one call; both sides list the shared dofs in the same

@@ -567,6 +567,11 @@ function node_count(g::HIPGraph)
     return Int(n[])
 end
 
+# one whole iteration of the local CG (a rank without shared dofs): product + pᵀAp, update, direction, rotate in one call
+function cgd_iteration!(A::HIPSparseMatrixCSR, dinv::HIPVector{Float64}, x::HIPVector{Float64}, r::HIPVector{Float64}, p::HIPVector{Float64}, Ap::HIPVector{Float64}, S::HIPVector{Float64})
+    check(ccall((:tb_cgd_iteration, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        A.ddh.pattern, A.nzval.ptr, dinv.ptr, x.ptr, r.ptr, p.ptr, Ap.ptr, S.ptr))
+end
 function cgd_rotate!(S::HIPVector{Float64})
     check(ccall((:tb_cgd_rotate, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Float64}), S.dev.handle, S.ptr))
 end

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Round 5: graph test, unstructured-mesh plans (bisection patcher), the box bench line with slab sweep / graphs / exchange latency
+mkdir -p gpurun_out/r5
+{
+python3 -m pytest tests/test_gpu_parity.py -q -x -k "graph_replay or unstructured or config5 or patch_kernel_variants or loaded_meshes" 2>&1 | tail -6
+show() { python3 - "$1" <<'PY'
+import json,sys
+d=json.load(open(sys.argv[1]))
+print('ms/step %.3f value %.4g kernel %s frac %.3f' % (d['ms_per_step'], d['value'], d['roofline']['kernel'], d['roofline']['frac']), d['phase_ms'])
+print('graph_step', {k:v for k,v in (d.get('graph_step') or {}).items() if k!='note'})
+c=d.get('distributed_cg')
+if c: print('cg it %.4f graph %s nodes %s err %s spmv %.4f' % (c['iteration_ms'], c['graph_iteration_ms'], c['graph_nodes'], c['graph_error'], c['local_spmv_ms']))
+print('patch', d.get('patch_stats')); print('spmv_plan', d.get('spmv_plan'))
+if 'cpu_baseline' in d: print('cpu', d['cpu_baseline']['value'], d['cpu_baseline'].get('parity'))
+if 'slab_sweep' in d:
+    print('xch', d['slab_sweep'].get('exchange_latency'))
+    for k,v in d['slab_sweep']['layers'].items(): print('  ', k, {a:(round(b,4) if isinstance(b,float) else b) for a,b in v.items() if a!='phase_ms'})
+PY
+}
+TB_PLAN_VERBOSE=1 timeout 900 python3 bench.py --mesh lv --steps 20 --no-cpu-baseline 2> gpurun_out/r5/bench_lv.err | tail -1 > gpurun_out/r5/bench_lv.json; show gpurun_out/r5/bench_lv.json; grep "tbhip" gpurun_out/r5/bench_lv.err | head; tail -2 gpurun_out/r5/bench_lv.err
+timeout 900 python3 bench.py --no-cpu-baseline --steps 20 2> gpurun_out/r5/bench_graph.err | tail -1 > gpurun_out/r5/bench_graph.json; echo "rc=$?"; show gpurun_out/r5/bench_graph.json; tail -3 gpurun_out/r5/bench_graph.err
+} > gpurun_out/r5/b.log 2>&1
+tail -c 7000 gpurun_out/r5/b.log

@@ -163,6 +163,7 @@ SIGNATURES = {
     "tb_comm_exchange": (C.c_int, [vp, C.c_int, vp, vp, vp, vp]),
     "tb_comm_allreduce": (C.c_int, [vp, vp, C.c_int64, C.c_int]),
     "tb_comm_exchange_begin": (C.c_int, [vp, C.c_int, vp, vp, vp, vp]),
+    "tb_cgd_iteration": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp]),
     "tb_graph_begin": (C.c_int, [vp]),
     "tb_graph_end": (C.c_int, [vp, C.POINTER(vp)]),
     "tb_graph_launch": (C.c_int, [vp, C.c_double]),

@@ -14,6 +14,18 @@
 
 namespace tb {
 
+// TB_SPMV_KERNEL: the product library honours "rows" only — the CSR rows kernel, which is also what a pattern without shared row signatures runs (the
+// switch lets a test put it on a compressible pattern and compare bits); the older entry-per-lane kernels ("rec", "chain") and the wave-private form
+// ("wave", measured slower on thin slabs) are comparison builds: profiling library only
+static const char *spmv_kernel_env()
+{
+    const char *e = getenv("TB_SPMV_KERNEL");
+#ifndef TB_ABLATION
+    if (e && strcmp(e, "rows") != 0 && strcmp(e, "sig") != 0) return nullptr;
+#endif
+    return e;
+}
+
 static inline unsigned grid_for(tb_device *dev, int64_t n, int bs)
 {
     int64_t nb = (n + bs - 1) / bs;
@@ -596,7 +608,7 @@ k_spmv_b3(int64_t n_brows, const int64_t *__restrict__ rowptr, const int32_t *__
 static int block3_plan(tb_pattern *p)
 {
     if (p->b3 != 0) return TB_OK;
-    static const bool off = getenv("TB_SPMV_B3") && atoi(getenv("TB_SPMV_B3")) == 0;
+    static const bool off = tune_env("TB_SPMV_B3") && atoi(tune_env("TB_SPMV_B3")) == 0;
     p->b3 = -1;
     if (off || p->n_rows % 3 != 0 || p->nnz % 9 != 0 || p->nnz == 0) return TB_OK;
     std::vector<int32_t> bcol((size_t)(p->nnz / 9));
@@ -616,7 +628,7 @@ static int block3_plan(tb_pattern *p)
     TB_HIP(hipMalloc((void **)&p->d_bcol, bcol.size() * sizeof(int32_t)));
     TB_HIP(hipMemcpy(p->d_bcol, bcol.data(), bcol.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     const double avg = (double)bcol.size() / (double)nbr; // blocks per node row: 27 for Q1, 64…125 for Q2
-    static const int lanes_env = getenv("TB_SPMV_B3_LANES") ? atoi(getenv("TB_SPMV_B3_LANES")) : 0;
+    static const int lanes_env = tune_env("TB_SPMV_B3_LANES") ? atoi(tune_env("TB_SPMV_B3_LANES")) : 0;
     p->b3_lanes = lanes_env ? lanes_env : (avg > 36 ? 32 : 16); // measured: 16 ≈ 32 > 64 on Q2 (24³ contraction solve 4.7 / 4.7 / 5.2 s), 16 best on Q1
     p->b3 = 1;
     return TB_OK;
@@ -676,7 +688,7 @@ static int stream_plan(tb_pattern *p)
 static int sig_plan(tb_pattern *p, bool forced = false)
 {
     if (p->n_sig != 0) return TB_OK;
-    const bool off = !forced && getenv("TB_SPMV_KERNEL") && strcmp(getenv("TB_SPMV_KERNEL"), "sig") != 0; // "rows" / "rec" / "chain": the CSR kernels (read per pattern: A/B runs and the bit-identity test build one pattern of each kind in one process)
+    const bool off = !forced && spmv_kernel_env() && strcmp(spmv_kernel_env(), "sig") != 0; // "rows" / "rec" / "chain": the CSR kernels (read per pattern: A/B runs and the bit-identity test build one pattern of each kind in one process)
     const int64_t n = p->n_rows;
     if (off || n == 0 || p->nnz >= (int64_t)0xffffffffll) { p->n_sig = -1; return TB_OK; }
     const int64_t *rp = p->h_rowptr.data();
@@ -939,7 +951,7 @@ static void launch_mirror(tb_pattern *p, const double *mir, const double *x, dou
 {
     // one slice per wave where nothing is reduced (measured at 216³: 0.52 ms against 0.57 ms with resident workgroups only); the fused xᵀAx form ends
     // every workgroup in one atomic on the same scalar: 48 workgroups per CU (0.54 ms; 3 072 / 4 096 / 8 192 / 24 576 / all 40 000: 0.56 / 0.55 / 0.55 / 0.56 / 0.62)
-    const int64_t grid_env = getenv("TB_SPMV_MIRROR_GRID") ? atoll(getenv("TB_SPMV_MIRROR_GRID")) : 0; // (read per launch: sweeps)
+    const int64_t grid_env = tune_env("TB_SPMV_MIRROR_GRID") ? atoll(tune_env("TB_SPMV_MIRROR_GRID")) : 0; // (read per launch: sweeps)
     const int64_t cap = grid_env > 0 ? grid_env : DOT ? (int64_t)p->mesh->dev->n_cu * 48 : (int64_t)1 << 30;
     const unsigned grid = (unsigned)std::min<int64_t>((p->n_slices + 3) / 4, cap);
     hipLaunchKernelGGL((k_spmv_mirror<DOT>), dim3(grid), dim3(256), 0, p->mesh->dev->stream, p->n_rows, p->n_slices, (const MirrorSlice *)p->d_mir_base, p->d_mir_off, p->d_sigoff,
@@ -949,7 +961,7 @@ static void launch_mirror(tb_pattern *p, const double *mir, const double *x, dou
 // TB_SPMV_KERNEL=chain: the five-trip kernel, kept as the comparison build
 static bool spmv_chain_kernel()
 {
-    static const bool chain = getenv("TB_SPMV_KERNEL") && !strcmp(getenv("TB_SPMV_KERNEL"), "chain");
+    static const bool chain = spmv_kernel_env() && !strcmp(spmv_kernel_env(), "chain");
     return chain;
 }
 template <bool DOT>
@@ -962,13 +974,13 @@ static void launch_stream(tb_pattern *p, const double *nz, const double *x, doub
 #endif
     for (int i = 0; i < tb_pattern::MIRRORS; ++i) // the caller bound a sliced mirror of this very array
         if (p->mir_nz[i] == nz && nz) { launch_mirror<DOT>(p, p->d_mir[i], x, alpha, beta, y, xy); return; }
-    static const bool rows_kernel = !(getenv("TB_SPMV_KERNEL") && strcmp(getenv("TB_SPMV_KERNEL"), "rows") != 0 && strcmp(getenv("TB_SPMV_KERNEL"), "sig") != 0 &&
-                                      strcmp(getenv("TB_SPMV_KERNEL"), "wave") != 0); // "rec" / "chain": entry-per-lane kernels
-    const bool wave_kernel = getenv("TB_SPMV_KERNEL") && !strcmp(getenv("TB_SPMV_KERNEL"), "wave"); // read per launch: the bit-identity test switches it inside one process
+    static const bool rows_kernel = !(spmv_kernel_env() && strcmp(spmv_kernel_env(), "rows") != 0 && strcmp(spmv_kernel_env(), "sig") != 0 &&
+                                      strcmp(spmv_kernel_env(), "wave") != 0); // "rec" / "chain": entry-per-lane kernels
+    const bool wave_kernel = spmv_kernel_env() && !strcmp(spmv_kernel_env(), "wave"); // read per launch: the bit-identity test switches it inside one process
     if (wave_kernel && ((uintptr_t)nz & 15) == 0 && sig_plan_forced(p) == TB_OK && p->n_sig > 0 && wave_plan(p) == TB_OK && p->n_wrun > 0) {
         static int per_cu_w = 0;
         if (!per_cu_w) {
-            if (getenv("TB_SPMV_WG_PER_CU")) per_cu_w = atoi(getenv("TB_SPMV_WG_PER_CU"));
+            if (tune_env("TB_SPMV_WG_PER_CU")) per_cu_w = atoi(tune_env("TB_SPMV_WG_PER_CU"));
             if (per_cu_w <= 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_w, (const void *)k_spmv_sig_wave<DOT>, 256, 0) != hipSuccess || per_cu_w <= 0)) per_cu_w = 3;
         }
         const unsigned gmaxw = (unsigned)(p->mesh->dev->n_cu * per_cu_w);
@@ -980,7 +992,7 @@ static void launch_stream(tb_pattern *p, const double *nz, const double *x, doub
         // persistent: exactly the workgroups that are resident together (the runs are dealt round-robin, every workgroup gets the same share ± 1)
         static int per_cu = 0;
         if (!per_cu) {
-            if (getenv("TB_SPMV_WG_PER_CU")) per_cu = atoi(getenv("TB_SPMV_WG_PER_CU"));
+            if (tune_env("TB_SPMV_WG_PER_CU")) per_cu = atoi(tune_env("TB_SPMV_WG_PER_CU"));
             if (per_cu <= 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_spmv_sig_rows<SPMV_CAP, DOT>, 256, 0) != hipSuccess || per_cu <= 0)) per_cu = 3;
         }
         const unsigned gmax = (unsigned)(p->mesh->dev->n_cu * per_cu);
@@ -998,7 +1010,7 @@ static void launch_stream(tb_pattern *p, const double *nz, const double *x, doub
 
 static unsigned stream_grid(const tb_pattern *p)
 {
-    static const int64_t cap = getenv("TB_SPMV_GRID") ? atoi(getenv("TB_SPMV_GRID")) : 2048; // 256 CUs × 8 resident workgroups
+    static const int64_t cap = tune_env("TB_SPMV_GRID") ? atoi(tune_env("TB_SPMV_GRID")) : 2048; // 256 CUs × 8 resident workgroups
     return (unsigned)std::min<int64_t>(p->n_blk, cap);
 }
 
@@ -1014,7 +1026,7 @@ int spmv_plans(tb_pattern *p)
 int launch_spmv(tb_pattern *p, const double *nz, const double *x, double alpha, double beta, double *y)
 {
     tb_device *dev = p->mesh->dev;
-    static const int lanes = getenv("TB_SPMV_LANES") ? atoi(getenv("TB_SPMV_LANES")) : 0;
+    static const int lanes = tune_env("TB_SPMV_LANES") ? atoi(tune_env("TB_SPMV_LANES")) : 0;
     if (lanes == 0 && block3_plan(p) == TB_OK && p->b3 > 0) {
         launch_b3<false>(p, nz, x, alpha, beta, y, nullptr);
         TB_HIP(hipGetLastError());
@@ -1279,7 +1291,7 @@ int launch_cg(tb_pattern *pat, const double *A, const double *b, double *x, doub
     pat->last_tol = tol;
     // The host looks at (‖r‖², flag) once per `check` iterations: small systems are bound by the host round trip, not by the kernels, so they
     // run a few iterations between looks (at most check − 1 iterations past the tolerance); large ones look every iteration.
-    static const int check_env = getenv("TB_CG_CHECK_EVERY") ? atoi(getenv("TB_CG_CHECK_EVERY")) : 0;
+    static const int check_env = tune_env("TB_CG_CHECK_EVERY") ? atoi(tune_env("TB_CG_CHECK_EVERY")) : 0;
     const int check0 = check_env > 0 ? check_env : (n >= 262144 ? 1 : 4);
     int it = 0, cur = 0, last_look = 0;
     while (rnorm > tol && it < maxiter) {
@@ -1764,7 +1776,7 @@ int launch_pcg_chebyshev(tb_pattern *pat, const double *A, const double *b, doub
             lmax = std::min(gersh, 1.05 * hi);
         }
     }
-    static const double ratio_env = getenv("TB_CHEB_RATIO") ? atof(getenv("TB_CHEB_RATIO")) : 0.0;
+    static const double ratio_env = tune_env("TB_CHEB_RATIO") ? atof(tune_env("TB_CHEB_RATIO")) : 0.0;
     const int m = degree < 1 ? 1 : degree;
     const double lmin = lmax / (ratio_env > 1.0 ? ratio_env : std::max(4.0, 1.8 * m * m));
     const double theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma1 = theta / delta;
@@ -2030,7 +2042,7 @@ int launch_spmv_dot(tb_pattern *pat, const double *A, const double *x, double *y
     tb_device *dev = pat->mesh->dev;
     const int64_t n = pat->n_rows;
     if (n == 0) return TB_OK;
-    static const int lanes_env = getenv("TB_SPMV_LANES") ? atoi(getenv("TB_SPMV_LANES")) : 0;
+    static const int lanes_env = tune_env("TB_SPMV_LANES") ? atoi(tune_env("TB_SPMV_LANES")) : 0;
     if (lanes_env == 0) { int rc = block3_plan(pat); if (rc) return rc; if (pat->b3 <= 0) { rc = stream_plan(pat); if (rc) return rc; } }
     if (lanes_env == 0 && pat->b3 > 0)
         launch_b3<true>(pat, A, x, 1.0, 0.0, y, d_dot);

@@ -1155,6 +1155,22 @@ int tb_cgd_rotate(tb_device *dev, double *d_S)
     return launch_cgd_rotate(dev, d_S);
 }
 
+// One whole iteration of the device CG of a sub-domain WITHOUT shared dofs (one rank, or an isolated part): the four launches of
+// tb_spmv_csr_dot → tb_cgd_update → tb_cgd_direction → tb_cgd_rotate issued from one call.  Same kernels, same results; what it saves is the host's
+// per-call cost, which on a thin slab (0.095 ms of kernels per iteration at 216×216×27) is a third of the iteration when the host is an interpreter.
+int tb_cgd_iteration(tb_pattern *pat, const double *d_nzval, const double *d_dinv, double *d_x, double *d_r, double *d_p, double *d_Ap, double *d_S)
+{
+    TB_REQUIRE(pat && d_nzval && d_dinv && d_x && d_r && d_p && d_Ap && d_S, "tb_cgd_iteration: NULL argument");
+    tb_device *dev = pat->mesh->dev;
+    TB_HIP(hipSetDevice(dev->id));
+    const int64_t n = pat->n_rows;
+    int rc = launch_spmv_dot(pat, d_nzval, d_p, d_Ap, d_S + 1);
+    if (!rc) rc = launch_cgd_update(dev, n, nullptr, d_dinv, d_p, d_Ap, d_x, d_r, d_S, d_S + 1, d_S + 2);
+    if (!rc) rc = launch_cgd_direction(dev, n, d_dinv, d_r, d_p, d_S, d_S + 2);
+    if (!rc) rc = launch_cgd_rotate(dev, d_S);
+    return rc;
+}
+
 int tb_extract_diagonal(tb_pattern *pat, const double *d_nzval, double *d_diag)
 {
     TB_REQUIRE(pat && ((d_nzval && d_diag) || pat->n_rows == 0), "tb_extract_diagonal: NULL argument");

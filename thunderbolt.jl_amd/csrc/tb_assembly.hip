@@ -1305,7 +1305,7 @@ static int run_q2(tb_form *f, tb_pattern *p, int strategy, double t, double *d_n
     int64_t cell0 = 0; // first cell of the launch (chunked element assembly below)
     auto go = [&](const int32_t *list, int64_t n, int atomic) -> int {
         if (n == 0) return TB_OK;
-        static const bool q2_mfma = getenv("TB_Q2_KERNEL") && !strcmp(getenv("TB_Q2_KERNEL"), "mfma"); // the matrix-core kernel (comparison)
+        static const bool q2_mfma = tune_env("TB_Q2_KERNEL") && !strcmp(tune_env("TB_Q2_KERNEL"), "mfma"); // the matrix-core kernel (comparison)
         if (d_nz && !q2_mfma && atomic == 2) { // sum-factorised element matrices: three cells per pass, persistent (the scattering strategies keep the matrix-core kernel: it hands its entries over in entry order)
             const unsigned wg3 = (unsigned)std::min<int64_t>((n + 2) / 3, (int64_t)dev->n_cu * 6);
 #define TB_Q2S(FORM, FIELD) hipLaunchKernelGGL((k_matrix_q2_sf<FORM, FIELD>), dim3(wg3), dim3(256), 0, dev->stream, mv, fa, m->d_cell_xyz, list, cell0, n, p->d_rowptr, p->d_q2pos, d_nz, atomic, kebuf, dev->d_status)
@@ -1339,36 +1339,8 @@ static int run_q2(tb_form *f, tb_pattern *p, int strategy, double t, double *d_n
                 hipLaunchKernelGGL(k_gather_rows_q2, dim3((unsigned)((r1 - r0 + 7) / 8)), dim3(256), sizeof(double) * 8 * (size_t)max_row, st, r0, r1, m->ea->d_ell, m->ea->ell_w, kebuf,
                                    p->d_q2pos, p->d_rowptr, d_nz, max_row);
         };
-        // Chunked element assembly (TB_Q2_CHUNKS=n, opt-in): the cells go in n launches and the rows a chunk completes — a prefix of the dofs, by the running
-        // maximum of their last contributing cell — are gathered on the second queue beside the integration of the next chunk.  Unlike the mechanics kernels
-        // (tb_mechanics.hip) the two fit on a CU together (the integration kernel leaves 100 registers per lane and 110 KB of LDS, the gather needs 40 and 8 KB),
-        // and still it is slower: 64³ diffusion 1.31 ms in one launch of each kernel, 1.43 / 1.53 / 1.64 ms in 4 / 8 / 16 chunks — the persistent integration
-        // kernel pays its set-up and its tail once per chunk, and together the two kernels move 4.6 GB, which is 0.9 ms at the streaming rate whatever the
-        // overlap.  Same kernels, same cell order inside every row sum: the one-launch result bit for bit (tested).
-        const int chunks = [] { const char *e = getenv("TB_Q2_CHUNKS"); return e ? atoi(e) : 0; }(); // (read per call)
-        static const bool q2_mfma_ = getenv("TB_Q2_KERNEL") && !strcmp(getenv("TB_Q2_KERNEL"), "mfma");
-        if (chunks > 1 && !q2_mfma_ && m->n_cells >= 4096 * (int64_t)chunks && (int64_t)m->ea->h_done.size() == m->ndofs) {
-            rc = ensure_aux_stream(dev);
-            if (rc) return rc;
-            int64_t done = 0;
-            for (int k = 0; k < chunks; ++k) {
-                const int64_t c0 = m->n_cells * k / chunks, c1 = m->n_cells * (k + 1) / chunks;
-                cell0 = c0;
-                rc = go(nullptr, c1 - c0, 2);
-                cell0 = 0;
-                if (rc) return rc;
-                TB_HIP(hipEventRecord(dev->aux_ev[0], dev->stream));
-                TB_HIP(hipStreamWaitEvent(dev->aux_stream, dev->aux_ev[0], 0));
-                const int64_t r1 = k + 1 == chunks ? m->ndofs
-                                                   : std::upper_bound(m->ea->h_done.begin(), m->ea->h_done.end(), (int32_t)(c1 - 1)) - m->ea->h_done.begin();
-                gather(dev->aux_stream, done, r1);
-                TB_HIP(hipGetLastError());
-                done = std::max(done, r1);
-            }
-            TB_HIP(hipEventRecord(dev->aux_ev[1], dev->aux_stream));
-            TB_HIP(hipStreamWaitEvent(dev->stream, dev->aux_ev[1], 0));
-            return TB_OK;
-        }
+        // (a chunked form — gather of a chunk's rows on a second queue beside the integration of the next chunk, the scheme of the mechanics linearisation —
+        // was built, bit-identical and slower: 1.43 / 1.53 / 1.64 ms in 4 / 8 / 16 chunks against 1.31 ms at 64³; removed in round 5, docs/rounds/r04.md)
         rc = go(nullptr, m->n_cells, 2);
         if (rc) return rc;
         gather(dev->stream, 0, m->ndofs);
@@ -1617,7 +1589,7 @@ static int run_vector(tb_form *f, int strategy, double t, double *d_b)
     tb_device *dev = m->dev;
     const MeshView mv = make_view(m);
     const FormArgs fa = make_args(f, t);
-    static const bool legacy_vec = getenv("TB_VECTOR_KERNEL") && !strcmp(getenv("TB_VECTOR_KERNEL"), "legacy");
+    static const bool legacy_vec = tune_env("TB_VECTOR_KERNEL") && !strcmp(tune_env("TB_VECTOR_KERNEL"), "legacy");
     if constexpr (std::is_same<E, Hex8<2>>::value) {
         if (!legacy_vec && !f->has_cellset && (strategy == TB_STRATEGY_PATCH || strategy == TB_STRATEGY_ATOMIC)) {
             const bool halo = strategy == TB_STRATEGY_PATCH;

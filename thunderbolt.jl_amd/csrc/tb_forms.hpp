@@ -50,7 +50,11 @@ inline FormArgs make_args(const tb_form *f, double t)
     a.table = f->d_table;
     a.t = t;
     a.ct = std::cos(2.0 * 3.141592653589793 * t);
-    a.tslot = f->mesh->dev->capturing ? f->mesh->dev->d_tslot : nullptr;
+    a.tslot = nullptr;
+    if (f->mesh->dev->capturing && f->kind == TB_FORM_SOURCE) { // the one form kind whose integrand reads the time
+        a.tslot = f->mesh->dev->d_tslot;
+        f->mesh->dev->tslot_used = true;
+    }
 #ifdef TB_ABLATION
     static const int dbg = getenv("TB_DEBUG_FLAGS") ? atoi(getenv("TB_DEBUG_FLAGS")) : 0;
     a.debug = dbg;

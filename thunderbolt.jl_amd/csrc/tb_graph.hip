@@ -29,6 +29,7 @@ struct tb_graph {
     void *args[3] = {nullptr, nullptr, nullptr};
     hipKernelNodeParams kp{};
     int n_nodes = 0;
+    bool timed = false; // a captured kernel reads the time slot: the graph starts with the node that writes it
 };
 
 using namespace tb;
@@ -59,6 +60,7 @@ int tb_graph_begin(tb_device *dev)
         return TB_ERR_HIP;
     }
     dev->capturing = true;
+    dev->tslot_used = false;
     return TB_OK;
 }
 
@@ -74,6 +76,14 @@ int tb_graph_end(tb_device *dev, tb_graph **out)
     if (e != hipSuccess || !g) {
         (void)hipGetLastError();
         set_error("tb_graph_end: hipStreamEndCapture: %s (a call inside the capture synchronised, or failed)", hipGetErrorString(e));
+        // HIP 7.0 keeps refusing work on a stream whose capture was invalidated ("operation failed due to a previous error during capture"), also after
+        // hipStreamEndCapture: the library replaces a stream of its own; a stream handed in by the host (tb_device_set_stream) is the host's to replace
+        if (dev->own_stream) {
+            (void)hipStreamDestroy(dev->stream);
+            dev->stream = nullptr;
+            if (hipStreamCreateWithFlags(&dev->stream, hipStreamNonBlocking) != hipSuccess) { dev->stream = nullptr; dev->own_stream = false; }
+            (void)hipGetLastError();
+        }
         return TB_ERR_HIP;
     }
     auto gr = new tb_graph();
@@ -86,13 +96,19 @@ int tb_graph_end(tb_device *dev, tb_graph **out)
         delete gr;
         return TB_ERR_UNSUPPORTED;
     };
-    // the time node in front of every root of the captured graph
     size_t nroots = 0, nnodes = 0;
     if ((e = hipGraphGetNodes(g, nullptr, &nnodes)) != hipSuccess) return fail("hipGraphGetNodes", e);
     gr->n_nodes = (int)nnodes;
     if ((e = hipGraphGetRootNodes(g, nullptr, &nroots)) != hipSuccess) return fail("hipGraphGetRootNodes", e);
     std::vector<hipGraphNode_t> roots(nroots);
     if (nroots && (e = hipGraphGetRootNodes(g, roots.data(), &nroots)) != hipSuccess) return fail("hipGraphGetRootNodes", e);
+    // the time node in front of every root of the captured graph — only if a captured call handed the slot to a kernel (a CG iteration has no time)
+    gr->timed = dev->tslot_used;
+    if (!gr->timed) {
+        if ((e = hipGraphInstantiate(&gr->exec, g, nullptr, nullptr, 0)) != hipSuccess) return fail("hipGraphInstantiate", e);
+        *out = gr;
+        return TB_OK;
+    }
     gr->args[0] = &gr->t; gr->args[1] = &gr->ct; gr->args[2] = &gr->slot;
     gr->kp.func = (void *)k_set_time;
     gr->kp.gridDim = dim3(1); gr->kp.blockDim = dim3(1); gr->kp.sharedMemBytes = 0;
@@ -111,7 +127,7 @@ int tb_graph_launch(tb_graph *g, double t)
 {
     TB_REQUIRE(g && g->exec, "tb_graph_launch: NULL graph");
     TB_HIP(hipSetDevice(g->dev->id));
-    if (t != g->t) {
+    if (g->timed && t != g->t) {
         g->t = t; g->ct = std::cos(2.0 * 3.141592653589793 * t);
         hipError_t e = hipGraphExecKernelNodeSetParams(g->exec, g->tnode, &g->kp);
         if (e != hipSuccess) { set_error("tb_graph_launch: hipGraphExecKernelNodeSetParams: %s", hipGetErrorString(e)); (void)hipGetLastError(); return TB_ERR_UNSUPPORTED; }

@@ -5,6 +5,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <memory>
 #include <string>
 #include <vector>
@@ -14,6 +15,14 @@
 namespace tb {
 
 void set_error(const char *fmt, ...);
+// Tuning and comparison switches (launch shapes, kernels that were measured slower than the ones that ship) exist in the profiling build only
+// (`make ablation` → libtbhip_ablation.so, -DTB_ABLATION): the product library does not read them, so what they select is not product code.
+// The switches the product library does read are listed in include/tbhip.h ("Environment"), each with a test.
+#ifdef TB_ABLATION
+inline const char *tune_env(const char *name) { return getenv(name); }
+#else
+inline const char *tune_env(const char *) { return nullptr; }
+#endif
 void set_last_kernel(const char *fmt, ...); // tb_last_kernel_name: the instance an assembly call launched
 const char *last_kernel();
 
@@ -155,7 +164,7 @@ struct tb_device {
     void *d_scratch = nullptr;      // Float64 arena behind the *_f32 entry points (tb_f32.hip), grown on demand
     size_t scratch_bytes = 0;
     double *d_tslot = nullptr;      // {t, cos 2πt}: where time-dependent kernels read the time while a graph capture is open (tb_graph.hip)
-    bool capturing = false, defer_before_capture = false;
+    bool capturing = false, defer_before_capture = false, tslot_used = false; // tslot_used: a captured launch was handed the slot
     hipStream_t aux_stream = nullptr; // second queue of the chunked mechanics linearisation (gather of chunk k beside the integration of chunk k + 1)
     hipEvent_t aux_ev[2] = {nullptr, nullptr};
 };
@@ -179,6 +188,9 @@ struct tb_mesh {
     std::unique_ptr<tb::ColorPlan> colors;
     std::unique_ptr<tb::EAPlan> ea;
     std::unique_ptr<tb::PatchPlan> patches;
+    int patch_rcb = 0;            // > 0: the matrix patch plan bisects the cells into leaves of this many cells instead of tiling per-axis buckets (tb_plans.cpp)
+    bool patch_rcb_tried = false; // the bisection was compared with the tiles once
+    int patch_tile_shrink = 0;    // tile reductions the LDS-fit loop applied to the tile plan (restored when the bisection loses)
     std::unique_ptr<tb::VecPatchPlan> vpatches[2]; // [halo]
 };
 

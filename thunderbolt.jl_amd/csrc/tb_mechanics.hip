@@ -1289,7 +1289,7 @@ static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, doubl
         // gather 15.2 vs 13.3 ms (24-byte mirror pieces cost more than the halved reads save) — profiles/r03_v1/mechanics_sym_vs_full.txt
         bool sym = false;
         if (NEED_K && MFMA) {
-            const char *e = getenv("TB_MECH_KE");
+            const char *e = tune_env("TB_MECH_KE");
             if (e && !strcmp(e, "sym")) { rc = ensure_rank27(m); if (rc) return rc; sym = m->rank27_ok > 0; }
         }
         if (NEED_K) {
@@ -1317,7 +1317,7 @@ static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, doubl
         // Holzapfel–Ogden path with a symmetric tangent (the rate-coupled internal variable adds a non-symmetric term: fused kernel)
         bool split = false;
         if constexpr (NEED_K && CT == 2 && !AD && FE::NB == 27) {
-            const char *e = getenv("TB_MECH_SPLIT");
+            const char *e = tune_env("TB_MECH_SPLIT");
             split = !(e && atoi(e) == 0) && !(f->cond_model && f->d_u_prev);
         }
         auto go_ea = [&](int64_t c0, int64_t n) -> int { // cells [c0, c0 + n) → stored Kₑ / rₑ
@@ -1429,7 +1429,7 @@ static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, doubl
             const int nbr_max = (((int)p->max_row_len / 3) + 3) & ~3;
             // TB_MECH_GATHER=direct: the trip-bound kernel above, kept as the comparison build (12.8 ms against 9.1 ms at 80³; a variant staging all 8
             // cells of a vertex node at once was slower still: 66 KB of LDS per workgroup leave 8 waves per CU)
-            static const bool direct = [] { const char *e = getenv("TB_MECH_GATHER"); return e && !strcmp(e, "direct"); }();
+            static const bool direct = [] { const char *e = tune_env("TB_MECH_GATHER"); return e && !strcmp(e, "direct"); }();
             if (!(MFMA && KE_DMAJOR) && !direct) { rc = ensure_gather_nodes(p); if (rc) return rc; }
             if (!(MFMA && KE_DMAJOR) && !direct && p->gnodes_state > 0) {
                 const int nbr_pad = (nbr_max + 7) & ~7;
@@ -1594,8 +1594,8 @@ int launch_hyperelastic(tb_form *f, tb_pattern *p, int strategy, const double *d
     if (q2 && f->qorder != 3) { set_error("hyperelastic: Q2 field needs quadrature order 3"); return TB_ERR_UNSUPPORTED; }
     // Q2 tangents: sum-factorised contraction (default); TB_MECH_CONTRACT=mfma selects the matrix-core build, =vector the plain FMA sweep over
     // the points (comparison builds; TB_MECH_MFMA=0 is the older spelling of "vector")
-    const char *ce = getenv("TB_MECH_CONTRACT");
-    const bool old_vec = getenv("TB_MECH_MFMA") && atoi(getenv("TB_MECH_MFMA")) == 0;
+    const char *ce = tune_env("TB_MECH_CONTRACT");
+    const bool old_vec = tune_env("TB_MECH_MFMA") && atoi(tune_env("TB_MECH_MFMA")) == 0;
     const int ct2 = (ce && !strcmp(ce, "mfma")) ? 1 : ((ce && !strcmp(ce, "vector")) || old_vec) ? 0 : 2;
     const bool ad = !form_is_fast_path(f);
     if (f->cond_model) {

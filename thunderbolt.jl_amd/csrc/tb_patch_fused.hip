@@ -584,8 +584,8 @@ int launch_assemble_hex8_patch(tb_form *fK, tb_form *fM, tb_pattern *p, double t
     const bool diag = fK && !fk && aK.D[1] == 0.0 && aK.D[2] == 0.0 && aK.D[5] == 0.0 && aK.D[3] == 0.0 && aK.D[6] == 0.0 && aK.D[7] == 0.0;
     // one-trip record kernel: constant coefficients, patches of ≤ 256 instances (TB_PATCH_KERNEL=staged keeps the two-trip kernel for A/B runs)
     static const bool no_record = getenv("TB_PATCH_KERNEL") && strcmp(getenv("TB_PATCH_KERNEL"), "record") != 0;
-    static const int wave_prio = getenv("TB_PATCH_PRIO") ? atoi(getenv("TB_PATCH_PRIO")) : 0; // measured: no effect (1.7007 vs 1.6997 ms)
-    static const int stagger = getenv("TB_PATCH_STAGGER") ? atoi(getenv("TB_PATCH_STAGGER")) : 0;
+    static const int wave_prio = tune_env("TB_PATCH_PRIO") ? atoi(tune_env("TB_PATCH_PRIO")) : 0; // measured: no effect (1.7007 vs 1.6997 ms)
+    static const int stagger = tune_env("TB_PATCH_STAGGER") ? atoi(tune_env("TB_PATCH_STAGGER")) : 0;
     const int pf_ahead = 0; // (look-ahead touch of later records: removed from the record kernel, see there)
     if (staged && !no_record && !fk && !fm && ensure_patch_records(p) == TB_OK) {
         PatchFusedPlan *pr = p->patch_fused.get();

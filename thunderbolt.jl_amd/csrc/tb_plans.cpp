@@ -67,7 +67,7 @@ int ensure_ea_ell(tb_mesh *m)
 int ensure_aux_stream(tb_device *dev)
 {
     if (dev->aux_stream) return TB_OK;
-    static const bool hi = [] { const char *e = getenv("TB_MECH_CHUNK_PRIO"); return e && atoi(e); }();
+    static const bool hi = [] { const char *e = tune_env("TB_MECH_CHUNK_PRIO"); return e && atoi(e); }();
     int lo_p = 0, hi_p = 0;
     TB_HIP(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
     TB_HIP(hipStreamCreateWithPriority(&dev->aux_stream, hipStreamNonBlocking, hi ? hi_p : lo_p));
@@ -185,10 +185,14 @@ int build_patch_plan(tb_mesh *m, int cells_per_patch)
     // overrides; TB_PATCH_CELLS=n (or the argument) selects Morton runs of n cells instead.
     int tile[3] = {7, 7, 7};
     const bool default_tile = cells_per_patch == 0 && !getenv("TB_PATCH_TILE");
-    bool use_tiles = cells_per_patch <= 0 && !getenv("TB_PATCH_CELLS");
+    bool use_tiles = cells_per_patch <= 0 && !tune_env("TB_PATCH_CELLS");
     if (const char *e = getenv("TB_PATCH_TILE")) {
         int a, b, c;
         if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a > 0 && b > 0 && c > 0) { tile[0] = a; tile[1] = b; tile[2] = c; use_tiles = cells_per_patch <= 0; }
+    }
+    if (cells_per_patch < 0 && m->patch_rcb > 0) { // shrink request under the bisection plan: a smaller leaf
+        m->patch_rcb = std::max(16, m->patch_rcb * 7 / 8);
+        cells_per_patch = 0;
     }
     if (cells_per_patch < 0) { // shrink request from the LDS-fit retry loop: −k → k-th reduction of the tile
         for (int k = 0; k < -cells_per_patch; ++k) { int d = 0; for (int j = 1; j < 3; ++j) if (tile[j] > tile[d]) d = j; if (tile[d] > 1) --tile[d]; }
@@ -196,7 +200,7 @@ int build_patch_plan(tb_mesh *m, int cells_per_patch)
     }
     if (use_tiles) cells_per_patch = tile[0] * tile[1] * tile[2];
     else if (cells_per_patch <= 0) {
-        const char *e = getenv("TB_PATCH_CELLS");
+        const char *e = tune_env("TB_PATCH_CELLS");
         cells_per_patch = e ? atoi(e) : 256;
         if (cells_per_patch <= 0) cells_per_patch = 256;
     }
@@ -248,6 +252,36 @@ int build_patch_plan(tb_mesh *m, int cells_per_patch)
                 cells_per_patch = (int)std::min<int64_t>((int64_t)tile[0] * tile[1] * tile[2] * per_bucket, 1 << 20);
             }
         }
+        if (m->patch_rcb > 0) {
+            // Recursive coordinate bisection of the cell centroids into ⌈nc / target⌉ leaves of equal size (± 1 cell): every split cuts the current subset
+            // along the longest side of its bounding box, in proportion to the leaves either side receives.  Tiles of per-axis buckets fill a curved
+            // thin-walled mesh badly (the idealised ventricle: 132 instances per 256-lane patch, 2.28 instances per cell — half the lanes idle); leaves
+            // follow the geometry, so every patch is full.  Chosen by ensure_patch_fused when the tile plan's fill is poor (round 5).
+            const int64_t L = (nc + m->patch_rcb - 1) / m->patch_rcb;
+            std::vector<int32_t> ids(nc);
+            for (int64_t c = 0; c < nc; ++c) ids[c] = (int32_t)c;
+            struct Job { int64_t b, e, l0, nl; };
+            std::vector<Job> stack{{0, nc, 0, L}};
+            std::vector<int32_t> leaf(nc, 0);
+            while (!stack.empty()) {
+                const Job j = stack.back(); stack.pop_back();
+                if (j.nl <= 1 || j.e - j.b <= 1) { for (int64_t k = j.b; k < j.e; ++k) leaf[ids[k]] = (int32_t)j.l0; continue; }
+                double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+                for (int64_t k = j.b; k < j.e; ++k)
+                    for (int d = 0; d < 3; ++d) { const double v = cen[3 * (size_t)ids[k] + d]; mn[d] = std::min(mn[d], v); mx[d] = std::max(mx[d], v); }
+                int ax = 0;
+                for (int d = 1; d < 3; ++d) if (mx[d] - mn[d] > mx[ax] - mn[ax]) ax = d;
+                const int64_t nl_left = j.nl / 2, mid = j.b + (j.e - j.b) * nl_left / j.nl;
+                std::nth_element(ids.begin() + j.b, ids.begin() + mid, ids.begin() + j.e,
+                                 [&](int32_t a, int32_t b) { const double va = cen[3 * (size_t)a + ax], vb = cen[3 * (size_t)b + ax]; return va < vb || (va == vb && a < b); });
+                stack.push_back({mid, j.e, j.l0 + nl_left, j.nl - nl_left});
+                stack.push_back({j.b, mid, j.l0, nl_left});
+            }
+            use_tiles = true; // a leaf is a tile: a patch ends where the key changes
+            cells_per_patch = m->patch_rcb + 1;
+#pragma omp parallel for schedule(static)
+            for (int64_t c = 0; c < nc; ++c) keyed[c] = {(uint64_t)leaf[c], (int32_t)c};
+        } else {
         static const bool legacy_cut = getenv("TB_PATCH_CUT") && !strcmp(getenv("TB_PATCH_CUT"), "full"); // full tiles + sliver (rounds 1–3), for A/B runs
         auto tile_of = [&](uint32_t b, int d) -> uint64_t { return legacy_cut ? (uint64_t)(b / tile[d]) : balanced_tile(b, Rv[d], tile[d], true); };
 #pragma omp parallel for schedule(static)
@@ -259,12 +293,14 @@ int build_patch_plan(tb_mesh *m, int cells_per_patch)
                 keyed[c] = {spread21(bucket[3 * c]) | spread21(bucket[3 * c + 1]) << 1 | spread21(bucket[3 * c + 2]) << 2, (int32_t)c};
             }
         }
+        }
     }
     std::sort(keyed.begin(), keyed.end());
     // 2. patch boundaries + row ownership by first touch, in Morton order.  A patch closes after `cells_per_patch`
     //    cells or when it would own more than 9/8 of that many rows (domain-boundary patches own the extra
     //    boundary layers), which bounds the LDS accumulator block of every workgroup.
-    const int max_rows_cfg = use_tiles ? cells_per_patch + 8 : cells_per_patch + cells_per_patch / 8;
+    const int max_rows_cfg = m->patch_rcb > 0 ? m->patch_rcb + m->patch_rcb / 4 // leaves at the surface of the domain own its extra node layers
+                                              : use_tiles ? cells_per_patch + 8 : cells_per_patch + cells_per_patch / 8;
     std::vector<int32_t> owner(m->ndofs, -1);
     std::vector<int64_t> pstart(1, 0);
     {
@@ -360,7 +396,7 @@ int build_patch_plan(tb_mesh *m, int cells_per_patch)
     // 256-thread workgroups (two resident per CU at the kernels' register / LDS budget, so one patch's write-out
     // overlaps the other's arithmetic); measured best on MI355X among 64…512
     plan->threads = std::min(256, std::max(64, (plan->max_elems + 63) / 64 * 64));
-    if (const char *e = getenv("TB_PATCH_THREADS")) { const int t = atoi(e); if (t >= 64 && t <= 512 && t % 64 == 0) plan->threads = t; }
+    if (const char *e = tune_env("TB_PATCH_THREADS")) { const int t = atoi(e); if (t >= 64 && t <= 512 && t % 64 == 0) plan->threads = t; }
     plan->version = m->patches ? m->patches->version + 1 : 1;
     plan->total_elems = (int64_t)plan->h_elem_cell.size();
     plan->total_rows = (int64_t)plan->h_row_dof.size();
@@ -469,7 +505,7 @@ int ensure_patch_plans(tb_mesh *m, tb_pattern *p)
     if (!m->patches) { int rc = build_patch_plan(m, 0); if (rc) return rc; }
     if (!p) return TB_OK;
     if (p->patch_mat && p->patch_mat->version == m->patches->version) return TB_OK;
-    const bool fixed = getenv("TB_PATCH_CELLS") || getenv("TB_PATCH_TILE");
+    const bool fixed = tune_env("TB_PATCH_CELLS") || getenv("TB_PATCH_TILE");
     for (int attempt = 0; attempt < 12; ++attempt) {
         free_patch_mat_plan(p);
         int rc = build_patch_mat_plan(p);
@@ -482,6 +518,7 @@ int ensure_patch_plans(tb_mesh *m, tb_pattern *p)
         rc = build_patch_plan(m, -shrink);
         if (rc) return rc;
         m->patches->shrink = shrink;
+        if (m->patch_rcb == 0) m->patch_tile_shrink = shrink;
         m->patches->version = version + 1;
     }
     set_error("patch plan: could not fit the LDS budget");
@@ -784,12 +821,59 @@ int ensure_patch_fused(tb_mesh *m, tb_pattern *p, int nregions)
     if (p->patch_fused && p->patch_fused->version == m->patches->version && p->patch_fused->d_row_desc &&
         need(p->patch_fused.get()) <= 80 * 1024)
         return TB_OK;
-    const bool fixed = getenv("TB_PATCH_CELLS") || getenv("TB_PATCH_TILE");
+    const bool fixed = tune_env("TB_PATCH_CELLS") || getenv("TB_PATCH_TILE");
     for (int attempt = 0; attempt < 16; ++attempt) {
         free_patch_fused_plan(p);
         int64_t bytes = 0;
         int rc = build_patch_fused_plan(p, &bytes, nregions);
-        if (rc == TB_OK) return TB_OK;
+        if (rc == TB_OK) {
+            // fill of the 256-lane sweeps: tiles of per-axis buckets are full on box-like meshes (236 of 256 at 216³) and half empty on curved thin-walled
+            // ones; there the cells are bisected into equal leaves instead (build_patch_plan, patch_rcb) if that needs clearly fewer patches
+            const PatchPlan *pp = m->patches.get();
+            const double fill = (double)pp->total_elems / ((double)pp->n_patches * 256.0);
+            if (!fixed && m->patch_rcb == 0 && !m->patch_rcb_tried && fill < 0.75 && m->nverts == 8 && m->n_cells >= 4096) {
+                m->patch_rcb_tried = true;
+                const int64_t np_tiles = pp->n_patches, inst_tiles = pp->total_elems;
+                const int version = pp->version;
+                m->patch_rcb = 128; // ≈ the own cells of a full 5×5×6-node tile; shrunk by the LDS-fit loop like a tile
+                free_patch_fused_plan(p);
+                free_patch_plan(m);
+                rc = build_patch_plan(m, 0);
+                if (rc) return rc;
+                m->patches->version = version + 1;
+                int rc2 = TB_ERR_UNSUPPORTED;
+                for (int a2 = 0; a2 < 12; ++a2) {
+                    rc2 = build_patch_fused_plan(p, &bytes, nregions);
+                    bool big = rc2 == TB_ERR_UNSUPPORTED && p->patch_fused; // does not fit the LDS budget: smaller leaves
+                    if (rc2 == TB_OK && m->patches->max_elems > 320 && m->patch_rcb > 16) { big = true; rc2 = TB_ERR_UNSUPPORTED; } // a second sweep for many patches: smaller leaves too
+                    if (rc2 == TB_OK) break;
+                    free_patch_fused_plan(p);
+                    if (!big) return rc2;
+                    const int v2 = m->patches->version;
+                    free_patch_plan(m);
+                    rc = build_patch_plan(m, -1);
+                    if (rc) return rc;
+                    m->patches->version = v2 + 1;
+                }
+                const bool better = rc2 == TB_OK && m->patches->n_patches * 10 < np_tiles * 9;
+                if (getenv("TB_PLAN_VERBOSE"))
+                    fprintf(stderr, "[tbhip] patch plan: tiles %lld patches / %lld instances (fill %.2f), bisection (leaf %d) %lld patches / %lld instances -> %s\n", (long long)np_tiles,
+                            (long long)inst_tiles, fill, m->patch_rcb, rc2 == TB_OK ? (long long)m->patches->n_patches : -1LL, rc2 == TB_OK ? (long long)m->patches->total_elems : -1LL,
+                            better ? "bisection" : "tiles");
+                if (better) return TB_OK;
+                // back to the tiles
+                const int v3 = m->patches->version;
+                m->patch_rcb = 0;
+                free_patch_fused_plan(p);
+                free_patch_plan(m);
+                rc = build_patch_plan(m, m->patch_tile_shrink ? -m->patch_tile_shrink : 0);
+                if (rc) return rc;
+                m->patches->shrink = m->patch_tile_shrink;
+                m->patches->version = v3 + 1;
+                continue;
+            }
+            return TB_OK;
+        }
         const bool too_big = rc == TB_ERR_UNSUPPORTED && p->patch_fused; // the builder leaves the size-only plan behind in that case
         free_patch_fused_plan(p);
         if (!too_big) return rc;
@@ -825,7 +909,7 @@ int ensure_vec_patch_plan(tb_mesh *m, bool halo)
     if (m->vpatches[halo]) return TB_OK;
     if (m->ndpc != 8 || m->nverts != 8 || m->ncomp != 1) { set_error("vector patch plan: needs a scalar trilinear hexahedron field"); return TB_ERR_UNSUPPORTED; }
     int tile[3] = {8, 8, 8};
-    if (const char *e = getenv("TB_VPATCH_TILE")) {
+    if (const char *e = tune_env("TB_VPATCH_TILE")) {
         int a, b, c;
         if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a > 0 && b > 0 && c > 0) { tile[0] = a; tile[1] = b; tile[2] = c; }
     }

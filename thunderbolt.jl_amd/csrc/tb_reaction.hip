@@ -587,7 +587,7 @@ int launch_reaction_rl(tb_device *dev, int model, const double *params, int n_pa
     const int64_t cap = (int64_t)dev->n_cu * 16;
     if (nb > cap) nb = (nb + (nb + cap - 1) / cap - 1) / ((nb + cap - 1) / cap); // balanced: every thread ⌈nb / cap⌉ points
     if (n == 0) return TB_OK;
-    const double *ts = dev->capturing ? dev->d_tslot : nullptr;
+    const double *ts = dev->capturing ? (dev->tslot_used = true, dev->d_tslot) : nullptr;
 #define TB_RL(MODEL) do { if (layout == TB_LAYOUT_SOA) hipLaunchKernelGGL((k_reaction_rl<MODEL, TB_LAYOUT_SOA>), dim3((unsigned)nb), dim3(256), 0, dev->stream, P, d_u, n, t, dt, ts); \
                           else hipLaunchKernelGGL((k_reaction_rl<MODEL, TB_LAYOUT_AOS>), dim3((unsigned)nb), dim3(256), 0, dev->stream, P, d_u, n, t, dt, ts); } while (0)
     if (model == TB_CELL_TT06) TB_RL(TB_CELL_TT06); else if (model == TB_CELL_ORD11) TB_RL(TB_CELL_ORD11); else TB_RL(TB_CELL_PCG2019);
@@ -602,11 +602,11 @@ static int run(tb_device *dev, const CellParams &P, TS *u, TS *du, int64_t n, in
 {
     const int bs = 256;
     int64_t nb = (n + bs - 1) / bs;
-    static const int per_cu = getenv("TB_REACTION_BLOCKS_PER_CU") ? atoi(getenv("TB_REACTION_BLOCKS_PER_CU")) : 16;
+    static const int per_cu = tune_env("TB_REACTION_BLOCKS_PER_CU") ? atoi(tune_env("TB_REACTION_BLOCKS_PER_CU")) : 16;
     const int64_t cap = per_cu > 0 ? (int64_t)dev->n_cu * per_cu : nb;
     if (nb > cap) nb = (nb + (nb + cap - 1) / cap - 1) / ((nb + cap - 1) / cap); // every thread the same number of points (⌈nb / cap⌉ each): a grid cut at `cap` left some threads 2 and most 1 at 1.3 M points
     const dim3 grid((unsigned)nb), block(bs);
-#define TB_LAUNCH(L, W) hipLaunchKernelGGL((k_reaction<MODEL, L, W, TS>), grid, block, 0, dev->stream, P, u, du, n, t, dt, substeps, thr, rmax_key, xs, sdim, dev->capturing ? dev->d_tslot : nullptr)
+#define TB_LAUNCH(L, W) hipLaunchKernelGGL((k_reaction<MODEL, L, W, TS>), grid, block, 0, dev->stream, P, u, du, n, t, dt, substeps, thr, rmax_key, xs, sdim, dev->capturing ? (dev->tslot_used = true, dev->d_tslot) : nullptr)
     if (layout == TB_LAYOUT_SOA) { if (du) TB_LAUNCH(TB_LAYOUT_SOA, true); else TB_LAUNCH(TB_LAYOUT_SOA, false); }
     else { if (du) TB_LAUNCH(TB_LAYOUT_AOS, true); else TB_LAUNCH(TB_LAYOUT_AOS, false); }
 #undef TB_LAUNCH

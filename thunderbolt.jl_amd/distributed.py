@@ -214,6 +214,7 @@ class HaloExchange:
         # the equivalent torch calls on the same persistent buffers, like host tensors
         self.cuda = bool(like.is_cuda) and device is not None
         self.abi = isinstance(dist, RcclComm)                       # exchange through tb_comm_exchange (RCCL behind the C ABI) instead of torch.distributed
+        self.overlap = False                                         # ABI path: exchange on the communicator's own queue (see start())
         if self.abi and not self.cuda:
             raise ValueError("HaloExchange: an RcclComm moves device buffers of an MI355XDevice")
         self.staged = bool(like.is_cuda) and dist is not None and not self.abi and dist.is_initialized() and dist.get_backend() == "gloo"
@@ -257,8 +258,12 @@ class HaloExchange:
     def start(self):
         if not self.peers:
             return
-        if self.abi:                                                 # on the communicator's queue: the kernels launched until finish() overlap it
-            self.dist.exchange(self.peers, self.send, self.recv, overlapped=True)
+        if self.abi:
+            # stream-ordered by default.  overlap=True puts the exchange on the communicator's own queue (tb_comm_exchange_begin / _end) so that the kernels
+            # launched until finish() run beside it — measured at world size 1 (scripts/rccl_latency.py): 0.061 ms for begin + end against 0.012 ms for the
+            # in-stream exchange of one 377 KB plane each way: the two cross-queue event waits cost more than a transfer of this size takes, so the
+            # overlapped form only pays for much larger interfaces
+            self.dist.exchange(self.peers, self.send, self.recv, overlapped=self.overlap)
             return
         dist, ops = self.dist, []
         if self.staged:
@@ -277,7 +282,7 @@ class HaloExchange:
         for r in self.reqs:
             r.wait()
         self.reqs = []
-        if self.abi and self.peers:
+        if self.abi and self.peers and self.overlap:
             self.dist.exchange_end()                                 # the device's stream waits for the transfer (no host wait)
         if self.staged:
             for r_, rh in zip(self.recv, self.recv_h):
@@ -366,6 +371,7 @@ class DistributedCG:
         self.torch, self.dist = torch, dist
         self.spmv, self.rank, self.world = local_spmv, rank, world_size
         self.dev, self.look, self.operator = device, max(1, int(look)), operator
+        self.one_call = True                                          # one rank without shared dofs: a whole iteration through tb_cgd_iteration (False: the four calls)
         if device is not None and local_diag.is_cuda:
             cur = int(torch.cuda.current_stream().cuda_stream)
             if device.stream_handle != cur:
@@ -455,6 +461,10 @@ class DistributedCG:
         from ._lib import check, lib
         L, dev, n = lib(), self.dev, x.numel()
         ptr = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        if self.world == 1 and not self.nb and self.operator is not None and self.one_call:
+            pattern, nz = self.operator                              # no shared dofs: the four launches from one library call (tb_cgd_iteration)
+            check(L.tb_cgd_iteration(pattern.h, nz.ptr, ptr(self.dinv), ptr(x), ptr(r), ptr(p), ptr(Ap), ptr(S)))
+            return
         self.device_iteration(p, Ap, S)                              # S[1:4] are zero: set by the caller before the first step, by tb_cgd_rotate after every step
         w = ptr(self.w) if self.nb else None                         # no shared dofs (one rank, or an isolated part): every weight is 1, the kernel skips the read
         check(L.tb_cgd_update(dev.h, n, w, ptr(self.dinv), ptr(p), ptr(Ap), ptr(x), ptr(r), ptr(S[0:1]), ptr(S[1:2]), ptr(S[2:5])))
