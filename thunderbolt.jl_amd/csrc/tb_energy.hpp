@@ -103,7 +103,11 @@ template <class T> TB_HD T penalty_U(const EnergyParams &m, T I3)
 }
 
 // Ψ(F; f₀, s₀, n₀).  Every branch follows the expression of the reference function it cites.
-template <class T> TB_HD T energy_psi(const EnergyParams &m, const T (&F)[3][3], const double (&f0)[3], const double (&s0)[3], const double (&n0)[3])
+// Ta: the per-point active tension / calcium state (EnergyParams::Ta of a uniform state).  It travels as an argument of its own so that the parameter block
+// stays uniform over the lanes (a lane-private copy of the 330-byte block lived in scratch memory)
+// EN ≥ 0: the energy is known at compile time (the other branches vanish: the point kernel of the split linearisation is instantiated per energy — with the
+// run-time switch its loop body needs more than the 512 registers of a lone wave)
+template <class T, int EN = -1> TB_HD T energy_psi(const EnergyParams &m, const T (&F)[3][3], const double (&f0)[3], const double (&s0)[3], const double (&n0)[3], double Ta)
 {
     T C[3][3]; // C = tdot(F) = FᵀF
 #pragma unroll
@@ -124,7 +128,7 @@ template <class T> TB_HD T energy_psi(const EnergyParams &m, const T (&F)[3][3],
     };
     const double *p = m.p;
     T psi = I1 * 0.0;
-    switch (m.energy) {
+    switch (EN >= 0 ? EN : m.energy) {
     case EN_NULL: break;                                                                          // energies.jl:6-7
     case EN_BIO_NEOHOOKEAN: psi = p[0] * (I1 * inv(cbrt(I3)) - 3.0) + penalty_U(m, I3); break;    // :461-473
     case EN_TI_NEOHOOKEAN: {                                                                      // :93-128
@@ -171,7 +175,7 @@ template <class T> TB_HD T energy_psi(const EnergyParams &m, const T (&F)[3][3],
         if (hd_value(I4s) >= 1.0) { const T d = I4s - 1.0; psi = psi + (p[4] / (2.0 * p[5])) * (exp(p[5] * (d * d)) - 1.0); }
     }
     }
-    if (m.Ta != 0.0 && m.hill == HILL_NONE) psi = psi + m.Ta * sqrt(quad(f0, f0)); // active stress: ∂(Ta‖F f₀‖)/∂F (materials.jl:1200-1266, active.jl:100-113)
+    if (Ta != 0.0 && (EN >= 0 || m.hill == HILL_NONE)) psi = psi + Ta * sqrt(quad(f0, f0)); // active stress: ∂(Ta‖F f₀‖)/∂F (materials.jl:1200-1266, active.jl:100-113)
     return psi;
 }
 
@@ -186,11 +190,12 @@ TB_HD double sarcomere_lambda_a(const EnergyParams &m, double Ca)
 // Total energy of the material at F: passive part, plus — in the Hill frameworks — the active spring evaluated at Fᵉ = F·Fᵃ⁻¹.
 // All three active deformation gradients of the reference are diagonal in the (orthonormal) frame, Fᵃ = a f⊗f + b s⊗s + c n⊗n, so
 // Fᵃ⁻¹ is known in closed form and ActiveMaterialAdapter's rotated frame Fᵃf₀/‖Fᵃf₀‖ … is the frame itself (active.jl:8-21).
-template <class T> TB_HD T material_psi(const EnergyParams &m, const T (&F)[3][3], const double (&f0)[3], const double (&s0)[3], const double (&n0)[3])
+template <class T, int EN = -1> TB_HD T material_psi(const EnergyParams &m, const T (&F)[3][3], const double (&f0)[3], const double (&s0)[3], const double (&n0)[3], double Ta)
 {
-    T psi = energy_psi<T>(m, F, f0, s0, n0);
+    T psi = energy_psi<T, EN>(m, F, f0, s0, n0, Ta);
+    if constexpr (EN >= 0) return psi; // compile-time energies are instantiated for plain materials only (no Hill framework, no prestress)
     if (m.hill == HILL_NONE) return psi;
-    const double Ca = m.Ta;
+    const double Ca = Ta;
     const double la = sarcomere_lambda_a(m, Ca);
     double a = la, b = 1.0, c = 1.0;                                              // GMK: I + (λᵃ − 1) f⊗f
     if (m.adg == ADG_GMK_INCOMPRESSIBLE) { b = c = 1.0 / ::sqrt(la); }            // λᵃ f⊗f + λᵃ^{-1/2} (s⊗s + n⊗n)
@@ -219,7 +224,7 @@ template <class T> TB_HD T material_psi(const EnergyParams &m, const T (&F)[3][3
         for (int k = 0; k < 9; ++k) act.p[k] = m.ap[k];
 #pragma unroll
         for (int k = 0; k < 3; ++k) act.u[k] = m.au[k];
-        pa = energy_psi<T>(act, Fe, f0, s0, n0);
+        pa = energy_psi<T>(act, Fe, f0, s0, n0, 0.0);
     }
     return psi + (m.hill == HILL_EXTENDED ? Ca : 1.0) * pa;                        // 𝓝(state, …) = state for steady-state sarcomeres
 }
@@ -233,7 +238,7 @@ TB_HD void pair_components(int pr, int &mm, int &nn)
 }
 
 // Ψ, P_mm and 𝔸_(mm,nn) at F by one hyper-dual evaluation
-TB_HD HD energy_pair(const EnergyParams &m, const double *F9, int mm, int nn, const double (&f0)[3], const double (&s0)[3], const double (&n0)[3])
+TB_HD HD energy_pair(const EnergyParams &m, const double *F9, int mm, int nn, const double (&f0)[3], const double (&s0)[3], const double (&n0)[3], double Ta)
 {
     HD F[3][3];
 #pragma unroll
@@ -249,9 +254,33 @@ TB_HD HD energy_pair(const EnergyParams &m, const double *F9, int mm, int nn, co
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int j = 0; j < 3; ++j) Fe[i][j] = F[i][0] * m.G[j] + F[i][1] * m.G[3 + j] + F[i][2] * m.G[6 + j];
-        return material_psi<HD>(m, Fe, f0, s0, n0);
+        return material_psi<HD>(m, Fe, f0, s0, n0, Ta);
     }
-    return material_psi<HD>(m, F, f0, s0, n0);
+    return material_psi<HD>(m, F, f0, s0, n0, Ta);
+}
+
+// The same evaluation with DIRECTIONAL seeds: ε₁ along da, ε₂ along db (nine components each, row-major like F).  Ψ.a = P : da, Ψ.ab = da : 𝔸 : db.
+// With da = e_c ⊗ J⁻¹[s][·] and db = e_d ⊗ J⁻¹[u][·] (F = I + Ĥ·J⁻¹ differentiated in Ĥ) these are the pulled-back stress P̂[c][s] and tangent
+// Â[c][s][d][u] of the sum-factorised kernels, without a pull-back pass (tb_mech_split.hip).
+template <int EN = -1>
+TB_HD HD energy_pair_dir(const EnergyParams &m, const double *F9, const double (&da)[9], const double (&db)[9], const double (&f0)[3], const double (&s0)[3],
+                         const double (&n0)[3], double Ta)
+{
+    HD F[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) F[i][j] = HD{F9[3 * i + j], da[3 * i + j], db[3 * i + j], 0.0};
+    if constexpr (EN >= 0) return material_psi<HD, EN>(m, F, f0, s0, n0, Ta);
+    if (m.prestressed) {
+        HD Fe[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) Fe[i][j] = F[i][0] * m.G[j] + F[i][1] * m.G[3 + j] + F[i][2] * m.G[6 + j];
+        return material_psi<HD>(m, Fe, f0, s0, n0, Ta);
+    }
+    return material_psi<HD>(m, F, f0, s0, n0, Ta);
 }
 
 } // namespace tbk

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include "tb_internal.h"
+#include "tb_energy.hpp"
 #include "tb_material.hpp"
 #include "tb_math.hpp"
 #include "tb_mech_common.hpp"
@@ -29,8 +30,18 @@ __host__ __device__ constexpr int sympair(int m, int n) { return m * 9 - m * (m 
 #ifndef TB_MECH_POINTS_WAVES
 #define TB_MECH_POINTS_WAVES 1 // one wave per SIMD, no scratch: 2.6 ms at 80³ against 3.6 ms at two waves with 74 spilled registers
 #endif
-__global__ void __launch_bounds__(256, TB_MECH_POINTS_WAVES)
-k_mech_points(MechMesh m, HOParams mat, const double *__restrict__ u, int64_t n_cells /*of this launch, from m.cell0*/, double *__restrict__ out, Status *st)
+// AD: any energy of tb_energy.hpp by hyper-dual evaluation (the reference's Tensors.hessian route, materials.jl:1025-1040) with directional seeds in Ĥ —
+// 45 evaluations per point in a loop, each yielding one record entry directly; no LDS, the registers of a lone wave (the fused kernel's AD instances
+// spill ≈ 1 000 registers at their 168-register budget).
+#ifndef TB_MECH_AD_WAVES
+#define TB_MECH_AD_WAVES 1
+#endif
+#ifndef TB_MECH_AD_GROUPS
+#define TB_MECH_AD_GROUPS 1 // (measured: 1 → 8.2, 5 → 10.5, 9 → 13.0 ms for Guccione at 40³: every group repeats the kinematics)  // the 45 pair evaluations of a point are dealt to this many workgroups (blockIdx.y): more waves in flight for a kernel of long dependent chains
+#endif
+template <bool AD, int EN = -1>
+__global__ void __launch_bounds__(256, AD ? TB_MECH_AD_WAVES : TB_MECH_POINTS_WAVES)
+k_mech_points(MechMesh m, HOParams mat, EnergyParams en, const double *__restrict__ u, int64_t n_cells /*of this launch, from m.cell0*/, double *__restrict__ out, Status *st)
 {
     const int tid = threadIdx.x;
     const int64_t rel0 = (int64_t)blockIdx.x * MP_CELLS;
@@ -123,11 +134,44 @@ k_mech_points(MechMesh m, HOParams mat, const double *__restrict__ u, int64_t n_
 #pragma unroll
         for (int d = 0; d < 3; ++d) { mq.f[d] = f[d]; mq.s[d] = s[d]; mq.n[d] = n[d]; }
     }
-    double C[HOC_SIZE], Ff[9];
-    ho_common<false>(mq, F, C);
+    double Ff[9];
 #pragma unroll
     for (int e = 0; e < 9; ++e) Ff[e] = F[e / 3][e % 3];
     double *o = out + (rel0 + cl) * QP_REC + q;
+    if constexpr (AD) {
+        const double Ta = mq.Ta; // uniform tension × nodal activation, or the condensed (a) of this point
+        const double f0[3] = {mq.f[0], mq.f[1], mq.f[2]}, s0[3] = {mq.s[0], mq.s[1], mq.s[2]}, n0[3] = {mq.n[0], mq.n[1], mq.n[2]};
+        // condensed internal variable: + b (∂λ/∂Ĥ)_m (∂λ/∂Ĥ)_n with ∂λ/∂Ĥ[c][s] = g_c (f₀·J⁻¹[s][·]) / ‖g‖, g = F f₀
+        const double g[3] = {F[0][0] * f0[0] + F[0][1] * f0[1] + F[0][2] * f0[2], F[1][0] * f0[0] + F[1][1] * f0[1] + F[1][2] * f0[2],
+                             F[2][0] * f0[0] + F[2][1] * f0[1] + F[2][2] * f0[2]};
+        const double fj[3] = {ji[0] * f0[0] + ji[1] * f0[1] + ji[2] * f0[2], ji[3] * f0[0] + ji[4] * f0[1] + ji[5] * f0[2], ji[6] * f0[0] + ji[7] * f0[1] + ji[8] * f0[2]};
+        const double tb_over_gg = mq.Tb != 0.0 ? mq.Tb / (g[0] * g[0] + g[1] * g[1] + g[2] * g[2]) : 0.0;
+        auto sel3 = [](double a, double b, double c, int k) { return k == 0 ? a : k == 1 ? b : c; };
+        constexpr int PPG = (QP_SYM + TB_MECH_AD_GROUPS - 1) / TB_MECH_AD_GROUPS;
+        const int pr_begin = (int)blockIdx.y * PPG, pr_end = pr_begin + PPG < QP_SYM ? pr_begin + PPG : QP_SYM;
+#pragma unroll 1
+        for (int pr = pr_begin; pr < pr_end; ++pr) {
+            int mm, nn;
+            pair_components(pr, mm, nn);
+            const int c = mm / 3, s_ = mm - 3 * c, d = nn / 3, u_ = nn - 3 * d;
+            double da[9], db[9];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    da[3 * i + j] = i == c ? sel3(ji[j], ji[3 + j], ji[6 + j], s_) : 0.0;
+                    db[3 * i + j] = i == d ? sel3(ji[j], ji[3 + j], ji[6 + j], u_) : 0.0;
+                }
+            const HD r = energy_pair_dir<EN>(en, Ff, da, db, f0, s0, n0, Ta);
+            double ab = r.ab;
+            if (tb_over_gg != 0.0) ab += tb_over_gg * (sel3(g[0], g[1], g[2], c) * sel3(fj[0], fj[1], fj[2], s_)) * (sel3(g[0], g[1], g[2], d) * sel3(fj[0], fj[1], fj[2], u_));
+            o[pr * 27] = ab * dO;
+            if (mm == nn) o[(QP_SYM + mm) * 27] = r.a * dO;
+        }
+        return;
+    }
+    double C[HOC_SIZE];
+    ho_common<false>(mq, F, C);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         double row[3][9], Pc[3];
@@ -301,10 +345,28 @@ k_mech_contract(const double *__restrict__ qp /*records of this launch*/, int64_
 }
 
 
-int launch_mech_points(tb_device *dev, const MechMesh &mm, const HOParams &hp, const double *d_u, int64_t n, double *d_qp)
+int launch_mech_points(tb_device *dev, const MechMesh &mm, const HOParams &hp, const EnergyParams *ep, const double *d_u, int64_t n, double *d_qp)
 {
     if (!n) return TB_OK;
-    hipLaunchKernelGGL(k_mech_points, dim3((unsigned)((n + MP_CELLS - 1) / MP_CELLS)), dim3(256), 0, dev->stream, mm, hp, d_u, n, d_qp, dev->d_status);
+    const dim3 grid((unsigned)((n + MP_CELLS - 1) / MP_CELLS));
+    if (ep) {
+        const dim3 g2(grid.x, TB_MECH_AD_GROUPS);
+#define TB_MP(E) hipLaunchKernelGGL((k_mech_points<true, E>), g2, dim3(256), 0, dev->stream, mm, hp, *ep, d_u, n, d_qp, dev->d_status)
+        if (ep->hill != HILL_NONE || ep->prestressed) TB_MP(-1); // Hill frameworks, prestress: the run-time form
+        else switch (ep->energy) {
+            case EN_NULL: TB_MP(EN_NULL); break;
+            case EN_BIO_NEOHOOKEAN: TB_MP(EN_BIO_NEOHOOKEAN); break;
+            case EN_TI_NEOHOOKEAN: TB_MP(EN_TI_NEOHOOKEAN); break;
+            case EN_LIN_YIN_PASSIVE: TB_MP(EN_LIN_YIN_PASSIVE); break;
+            case EN_LIN_YIN_ACTIVE: TB_MP(EN_LIN_YIN_ACTIVE); break;
+            case EN_HUMPHREY_STRUMPF_YIN: TB_MP(EN_HUMPHREY_STRUMPF_YIN); break;
+            case EN_LINEAR_SPRING: TB_MP(EN_LINEAR_SPRING); break;
+            case EN_GUCCIONE_1991: TB_MP(EN_GUCCIONE_1991); break;
+            default: TB_MP(EN_HOLZAPFEL_OGDEN); break; // (with another penalty than the fast path's)
+        }
+#undef TB_MP
+    }
+    else hipLaunchKernelGGL(k_mech_points<false>, grid, dim3(256), 0, dev->stream, mm, hp, EnergyParams{}, d_u, n, d_qp, dev->d_status);
     TB_HIP(hipGetLastError());
     return TB_OK;
 }

@@ -276,11 +276,9 @@ k_hyperelastic(MechMesh m, HOParams mat, EnergyParams en, const int32_t *__restr
             const int q = t / NP, pr = t - q * NP;
             int mm = pr, nn = pr;
             if constexpr (NEED_K) pair_components(pr, mm, nn);
-            EnergyParams e = en;
             const double *o = s_C[q];
-            e.Ta = o[9];
             const double f[3] = {o[0], o[1], o[2]}, sv[3] = {o[3], o[4], o[5]}, n[3] = {o[6], o[7], o[8]};
-            const HD r = energy_pair(e, s_JI[q], mm, nn, f, sv, n);
+            const HD r = energy_pair(en, s_JI[q], mm, nn, f, sv, n, o[9]);
             const double dO = s_JI[q][9];
             if constexpr (NEED_K) {
                 double ab = r.ab;
@@ -1106,7 +1104,7 @@ int host_material_eval_form(tb_form *form, const double *F9, double *psi, double
         for (int pr = 0; pr < 45; ++pr) {
             int mm, nn;
             pair_components(pr, mm, nn);
-            const HD r = energy_pair(e, F9, mm, nn, f0, s0, n0);
+            const HD r = energy_pair(e, F9, mm, nn, f0, s0, n0, e.Ta);
             if (psi) *psi = r.v;
             if (P && mm == nn) P[mm] = r.a;
             if (A) { A[9 * mm + nn] = r.ab; A[9 * nn + mm] = r.ab; }
@@ -1316,16 +1314,16 @@ static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, doubl
         // split linearisation (round 5; comment above k_mech_points): point kernel + contraction kernel instead of the fused one.  Hand-derived
         // Holzapfel–Ogden path with a symmetric tangent (the rate-coupled internal variable adds a non-symmetric term: fused kernel)
         bool split = false;
-        if constexpr (NEED_K && CT == 2 && !AD && FE::NB == 27) {
+        if constexpr (NEED_K && CT == 2 && FE::NB == 27) {
             const char *e = tune_env("TB_MECH_SPLIT");
             split = !(e && atoi(e) == 0) && !(f->cond_model && f->d_u_prev);
         }
         auto go_ea = [&](int64_t c0, int64_t n) -> int { // cells [c0, c0 + n) → stored Kₑ / rₑ
-            if constexpr (NEED_K && CT == 2 && !AD && FE::NB == 27) {
+            if constexpr (NEED_K && CT == 2 && FE::NB == 27) {
                 if (split) {
                     if (!n) return TB_OK;
                     mm.cell0 = c0;
-                    int rcs = launch_mech_points(dev, mm, hp, d_u, n, p->d_qpbuf);
+                    int rcs = launch_mech_points(dev, mm, hp, AD ? &ep : nullptr, d_u, n, p->d_qpbuf);
                     if (!rcs) rcs = launch_mech_contract(dev, p->d_qpbuf, c0, n, kebuf, NEED_R ? rebuf : nullptr);
                     if (rcs) return rcs;
                     mm.cell0 = 0;
