@@ -1,0 +1,25 @@
+#!/bin/bash
+# Round 5, config 4: element matrices symmetric-packed by rank + pull gather — parity, A/B against the full tensor-order storage (profiling library), kernel trace
+mkdir -p gpurun_out/r5
+R=$GRAFT_REPO_ROOT
+{
+python3 -m pytest tests/test_gpu_parity.py -q -x -k "hyperelastic or chunked_linearization or condensed or nodal_fibre or mechanics_properties or config5 or other_energies or land2015 or contracting_cuboid" 2>&1 | tail -5
+run() { echo "== $*"; env "$@" timeout 600 python3 scripts/bench_mechanics.py --n 80 --steps 3 --cpu-n 2 2>&1 | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('  linearize %.2f ms residual %.2f ms' % (d['linearize_ms'], d['residual_ms']))"; }
+export TB_LIBTBHIP=$R/thunderbolt.jl_amd/libtbhip_ablation.so
+for rep in 1 2; do
+  run TB_MECH_SPLIT=0
+  run TB_MECH_KE=full
+  run TB_MECH_KE=sym2
+  run TB_MECH_KE=sym2 TB_MECH_CHUNKS=0
+  run TB_MECH_KE=sym2 TB_MECH_CHUNKS=16
+  run TB_MECH_KE=sym2 TB_MECH_CHUNKS=4
+done
+unset TB_LIBTBHIP
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/kt
+export TB_MECH_CHUNKS=0
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python3 $R/scripts/bench_mechanics.py --n 80 --steps 3 --cpu-n 2 > /tmp/kt.log 2>&1
+echo "== kernel trace, one launch per kernel (TB_MECH_CHUNKS=0), product library"
+python3 $R/scripts/rocpd_summary.py $(find /tmp/kt -name "*.db" | head -1) 2>&1 | cut -c1-200 | head -6
+} > gpurun_out/r5/f.log 2>&1
+tail -c 5000 $R/gpurun_out/r5/f.log

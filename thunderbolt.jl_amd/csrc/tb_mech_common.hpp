@@ -69,6 +69,9 @@ __host__ __device__ __forceinline__ int unpack27(int a, bool colbase)
 }
 __host__ __device__ __forceinline__ int tix27(int a) { return unpack27(a, false); } // Ferrite node → a₀ + 3a₁ + 9a₂
 __host__ __device__ __forceinline__ int cb27(int b) { return unpack27(b, true); }   // Ferrite node → 27·b₂ + 3·b₀ + b₁
+// symmetric-packed element matrix of the 27-node vector field: 378 node blocks (i ≤ j by rank) of 9 doubles
+__host__ __device__ constexpr int symblk(int i, int j) { return i * 27 - i * (i - 1) / 2 + (j - i); }
+constexpr int KE_SYM = 378 * 9;
 __host__ __device__ constexpr double quad1d(int i, double x) { return i == 0 ? 0.5 * x * (x - 1.0) : i == 1 ? (1.0 - x * x) : 0.5 * x * (x + 1.0); }
 __host__ __device__ constexpr double dquad1d(int i, double x) { return i == 0 ? x - 0.5 : i == 1 ? -2.0 * x : x + 0.5; }
 

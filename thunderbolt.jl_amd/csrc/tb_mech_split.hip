@@ -200,9 +200,11 @@ k_mech_points(MechMesh m, HOParams mat, EnergyParams en, const double *__restric
 
 // stages 1–3 of the sum-factorised contraction (comment in k_hyperelastic) from the records of k_mech_points; one cell per workgroup, Kₑ / rₑ stored
 // for the gather of the element strategy.  37 KB of LDS: four workgroups per CU where the fused kernel has three.
-template <bool NEED_R>
+// SYM: Kₑ leaves symmetric-packed by rank (block (i, j), i ≤ j, at symblk(i, j)·9 as [c][d] seen from the node of rank i; the lower blocks are not stored —
+// the gather reads them transposed): half the bytes of the 81 × 81 form, the largest stream of a linearisation.
+template <bool NEED_R, bool SYM>
 __global__ void __launch_bounds__(256, TB_MECH_CONTRACT_WAVES)
-k_mech_contract(const double *__restrict__ qp /*records of this launch*/, int64_t cell0, double *__restrict__ ke, double *__restrict__ re)
+k_mech_contract(const double *__restrict__ qp /*records of this launch*/, int64_t cell0, double *__restrict__ ke, double *__restrict__ re, const uint8_t *__restrict__ rank27)
 {
     constexpr int ND = 81, NQ = 27;
     const int tid = threadIdx.x;
@@ -278,7 +280,15 @@ k_mech_contract(const double *__restrict__ qp /*records of this launch*/, int64_
         c2[0][0][q1] = pa * pb; c2[0][1][q1] = pa * db; c2[1][0][q1] = da * pb; c2[1][1][q1] = da * db;
     }
     const int t27 = (tid < 243 ? tid : 0) % 27; // 9·d + 3·b₀ + b₁: the lane's column inside a b₂ block of the tensor-order row
-    double *kc = ke + (int64_t)cell * (ND * ND);
+    double *kc = ke + (int64_t)cell * (SYM ? KE_SYM : ND * ND);
+    int ra[3] = {0, 0, 0}, rb[3] = {0, 0, 0}; // SYM: ranks of the lane's row nodes (a₀, a₁, ·) and column nodes (b₀, b₁, ·)
+    if constexpr (SYM) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            ra[k] = rank27[cell * 32 + g_hex27_node[ta0 + 3 * ta1 + 9 * k]];
+            rb[k] = rank27[cell * 32 + g_hex27_node[tb0 + 3 * tb1 + 9 * k]];
+        }
+    }
     for (int c = 0; c < 3; ++c) {
         if (tid < 243) { // stage 1: task (s, d, u, q₁, q₂)
             int t = tid;
@@ -334,7 +344,8 @@ k_mech_contract(const double *__restrict__ qp /*records of this launch*/, int64_
                     double v = 0.0;
 #pragma unroll
                     for (int q2 = 0; q2 < 3; ++q2) v += PH(a2, q2) * w[0][b2][q2] + DP(a2, q2) * w[1][b2][q2];
-                    kc[(3 * (ta0 + 3 * ta1 + 9 * a2) + c) * ND + 27 * b2 + t27] = v; // entry ((a, c), (b, d)) in the tensor-order layout (tb_mech_common.hpp): 27 consecutive lanes, 27 consecutive doubles
+                    if constexpr (SYM) { if (ra[a2] <= rb[b2]) kc[symblk(ra[a2], rb[b2]) * 9 + 3 * c + td] = v; } // (diagonal blocks: all nine entries, from their own lanes)
+                    else kc[(3 * (ta0 + 3 * ta1 + 9 * a2) + c) * ND + 27 * b2 + t27] = v; // entry ((a, c), (b, d)) in the tensor-order layout (tb_mech_common.hpp): 27 consecutive lanes, 27 consecutive doubles
                 }
         }
         lds_barrier(); // Z1 is rewritten by the next component's stage 1
@@ -371,11 +382,16 @@ int launch_mech_points(tb_device *dev, const MechMesh &mm, const HOParams &hp, c
     return TB_OK;
 }
 
-int launch_mech_contract(tb_device *dev, const double *d_qp, int64_t cell0, int64_t n, double *d_ke, double *d_re)
+int launch_mech_contract(tb_device *dev, const double *d_qp, int64_t cell0, int64_t n, double *d_ke, double *d_re, const uint8_t *d_rank27)
 {
     if (!n) return TB_OK;
-    if (d_re) hipLaunchKernelGGL(k_mech_contract<true>, dim3((unsigned)n), dim3(256), 0, dev->stream, d_qp, cell0, d_ke, d_re);
-    else hipLaunchKernelGGL(k_mech_contract<false>, dim3((unsigned)n), dim3(256), 0, dev->stream, d_qp, cell0, d_ke, d_re);
+#define TB_MC(R, S) hipLaunchKernelGGL((k_mech_contract<R, S>), dim3((unsigned)n), dim3(256), 0, dev->stream, d_qp, cell0, d_ke, d_re, d_rank27)
+#ifdef TB_ABLATION // symmetric-packed storage: measured slower (tb_mechanics.hip), instantiated in the profiling build only
+    if (d_rank27) { if (d_re) TB_MC(true, true); else TB_MC(false, true); }
+    else
+#endif
+    { if (d_re) TB_MC(true, false); else TB_MC(false, false); }
+#undef TB_MC
     TB_HIP(hipGetLastError());
     return TB_OK;
 }

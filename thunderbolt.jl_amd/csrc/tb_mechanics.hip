@@ -28,6 +28,12 @@
 #include "tb_mech_common.hpp"
 #include "tb_mech_split.hpp"
 
+#ifdef TB_ABLATION
+#define TB_IF_ABLATION(...) __VA_ARGS__
+#else
+#define TB_IF_ABLATION(...)
+#endif
+
 namespace tb {
 using namespace tbk;
 
@@ -53,9 +59,6 @@ __global__ void k_build_blockpos(const int32_t *__restrict__ cell_dofs, int64_t 
 }
 
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
-// symmetric-packed element matrix of the 27-node vector field: 378 node blocks (i ≤ j by rank) of 9 doubles
-__host__ __device__ constexpr int symblk(int i, int j) { return i * 27 - i * (i - 1) / 2 + (j - i); }
-constexpr int KE_SYM = 378 * 9;
 #ifndef TB_KE_DMAJOR
 #define TB_KE_DMAJOR 0
 #endif
@@ -856,11 +859,17 @@ struct GatherNode {
     int32_t slot[8]; // cell·ND + 3a: row offset of the node's run in the stored element matrices, cell-ordered
 };
 
-template <int NB, int KC, bool TL = false>
+// LAYOUT of the stored element matrices: 0 rows / columns in Ferrite order, 1 tensor order (tb_mech_common.hpp), 2 symmetric-packed by rank (round 5): the
+// 378 node blocks (i ≤ j by the rank of the nodes' dofs within the cell) of 9 doubles, block (i, j) as [c][d] seen from node i — half the bytes written by
+// the contraction kernel.  A node A of rank r then finds its blocks with the nodes of higher rank in ONE contiguous run and those with the r nodes of
+// lower rank as r transposed 72-byte blocks (pulled, not mirrored: the round-3 variant WROTE the mirror pieces into other rows — partial lines — and lost);
+// either way 243 doubles per (node, cell) are staged, addressed by the neighbour's rank.
+template <int NB, int KC, int LAYOUT = 0>
 __global__ void __launch_bounds__(256, KC == 4 ? 4 : 2)
 k_gather_node_rows_lds(const GatherNode *__restrict__ gn, int64_t n_nodes, const double *__restrict__ ke, const uint16_t *__restrict__ blockpos,
-                       double *__restrict__ nz, int nbr_pad)
+                       double *__restrict__ nz, int nbr_pad, const uint8_t *__restrict__ rank27)
 {
+    constexpr bool TL = LAYOUT == 1, SYM = LAYOUT == 2;
     constexpr int ND = 3 * NB, RUN = 3 * ND, NJ = (RUN + 63) / 64, NI = 6;
     extern __shared__ double s_stage[];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -878,15 +887,32 @@ k_gather_node_rows_lds(const GatherNode *__restrict__ gn, int64_t n_nodes, const
         if (kb >= rec.nk) break;
         const int nk = rec.nk - kb < KC ? rec.nk - kb : KC;
         double r[KC][NJ];
+        int rA[KC]; // SYM: rank of this node in cell k (wave-uniform)
 #pragma unroll
-        for (int k = 0; k < KC; ++k)
+        for (int k = 0; k < KC; ++k) {
+            rA[k] = 0;
             if (k < nk) {
                 int64_t row0 = rec.slot[kb + k]; // cell·ND + 3a
+                if constexpr (SYM) {
+                    const int64_t cellk = row0 / ND;
+                    const int ra = rank27[cellk * 32 + (int)(row0 - cellk * ND) / 3];
+                    rA[k] = ra;
+                    const double *src = ke + cellk * KE_SYM;
+                    const int diag = symblk(ra, ra);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const int idx = lane + 64 * j, rb = idx / 9, e = idx - 9 * rb;
+                        const int blk = rb >= ra ? diag + (rb - ra) : symblk(rb, ra);
+                        r[k][j] = idx < RUN ? src[blk * 9 + e] : 0.0;
+                    }
+                } else {
                 if constexpr (TL) { const int64_t cellk = row0 / ND; row0 = cellk * ND + 3 * tix27((int)(row0 - cellk * ND) / 3); }
                 const double *src = ke + row0 * ND;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) { const int idx = lane + 64 * j; r[k][j] = idx < RUN ? src[idx] : 0.0; }
+                }
             }
+        }
         for (int i = lane; i < nk * nbr_pad / 4; i += 64) reinterpret_cast<uint32_t *>(inv)[i] = 0xFFFFFFFFu;
         __builtin_amdgcn_wave_barrier();
         for (int i = lane; i < nk * NB; i += 64) {
@@ -896,7 +922,7 @@ k_gather_node_rows_lds(const GatherNode *__restrict__ gn, int64_t n_nodes, const
             for (int kk = 1; kk < KC; ++kk) slot = k == kk ? rec.slot[kb + kk] : slot;
             const int64_t cell = slot / ND;
             const int a = (slot - (int32_t)cell * ND) / 3;
-            inv[k * nbr_pad + blockpos[cell * (NB * NB) + a * NB + b] / 3] = (uint8_t)(TL ? cb27(b) : b);
+            inv[k * nbr_pad + blockpos[cell * (NB * NB) + a * NB + b] / 3] = (uint8_t)(SYM ? rank27[cell * 32 + b] : TL ? cb27(b) : b);
         }
 #pragma unroll
         for (int k = 0; k < KC; ++k)
@@ -915,10 +941,19 @@ k_gather_node_rows_lds(const GatherNode *__restrict__ gn, int64_t n_nodes, const
                     if (k < nk) {
                         const int b = inv[k * nbr_pad + nbr];
                         if (b != 0xFF) {
+                            if constexpr (SYM) { // b = the neighbour's rank: block staged at b·9, as [c][d] from this node when b ≥ its rank, transposed otherwise
+                                const bool up = b >= rA[k];
+                                const double *sv = buf + k * RUN + 9 * b + (up ? d : 3 * d);
+                                const int st = up ? 3 : 1;
+                                acc[i][0] += sv[0];
+                                acc[i][1] += sv[st];
+                                acc[i][2] += sv[2 * st];
+                            } else {
                             const double *sv = buf + k * RUN + (TL ? b + 9 * d : 3 * b + d);
                             acc[i][0] += sv[0];
                             acc[i][1] += sv[ND];
                             acc[i][2] += sv[2 * ND];
+                            }
                         }
                     }
             }
@@ -1290,8 +1325,30 @@ static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, doubl
             const char *e = tune_env("TB_MECH_KE");
             if (e && !strcmp(e, "sym")) { rc = ensure_rank27(m); if (rc) return rc; sym = m->rank27_ok > 0; }
         }
+        // split linearisation (round 5; comment above k_mech_points in tb_mech_split.hip): point kernel + contraction kernel instead of the fused one —
+        // every symmetric tangent of the triquadratic field (the rate-coupled internal variable adds a non-symmetric term: fused kernel)
+        bool split = false, ke_sym2 = false;
+        if constexpr (NEED_K && CT == 2 && FE::NB == 27) {
+            const char *e = tune_env("TB_MECH_SPLIT");
+            split = !(e && atoi(e) == 0) && !(f->cond_model && f->d_u_prev);
+            // TB_MECH_KE=sym2 (profiling build only): the element matrices symmetric-packed by rank — half the bytes of the largest stream — with a staged gather
+            // that PULLS the transposed 72-byte blocks of the lower-ranked neighbours.  Parity-green and SLOWER (round 5, 80³, same box): the contraction
+            // kernel is unchanged (9.0 ms: it was never bound by its stores), the gather takes 13.1 instead of 9.4 ms — a wave-load that touches seven
+            // separate 72-byte blocks costs the address path more than the halved bytes save — linearize 23.6–24.0 against 19.6–19.9 ms.  Third negative
+            // for symmetric storage (round 3: mirror writes from the matrix-core kernel): the 81 × 81 tensor-order form stays.
+            if (split && tune_env("TB_MECH_KE") && !strcmp(tune_env("TB_MECH_KE"), "sym2")) {
+                if (!m->d_node_dof0) { rc = build_node_list(m); if (rc) return rc; }
+                rc = check_node_rows(p);
+                if (rc) return rc;
+                rc = ensure_gather_nodes(p);
+                if (rc) return rc;
+                rc = ensure_rank27(m);
+                if (rc) return rc;
+                ke_sym2 = p->gnodes_state > 0 && m->rank27_ok > 0;
+            }
+        }
         if (NEED_K) {
-            const size_t need = sizeof(double) * (size_t)m->n_cells * (sym ? (size_t)KE_SYM : (size_t)FE::ND * FE::ND);
+            const size_t need = sizeof(double) * (size_t)m->n_cells * (sym || ke_sym2 ? (size_t)KE_SYM : (size_t)FE::ND * FE::ND);
             if (p->d_kebuf && p->kebuf_bytes < need) { (void)hipFree(p->d_kebuf); p->d_kebuf = nullptr; }
             if (!p->d_kebuf) {
                 hipError_t e = hipMalloc((void **)&p->d_kebuf, need);
@@ -1311,20 +1368,13 @@ static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, doubl
         // the 111 616-cell ventricle with a Q1 displacement took 1.26 instead of 1.11 ms)
         const int chunks_default = FE::NB == 27 && m->n_cells >= 262144 ? 8 : 0;
         const int chunks_env = [&] { const char *e = getenv("TB_MECH_CHUNKS"); return e ? atoi(e) : chunks_default; }(); // read per call: a 20 ms operation
-        // split linearisation (round 5; comment above k_mech_points): point kernel + contraction kernel instead of the fused one.  Hand-derived
-        // Holzapfel–Ogden path with a symmetric tangent (the rate-coupled internal variable adds a non-symmetric term: fused kernel)
-        bool split = false;
-        if constexpr (NEED_K && CT == 2 && FE::NB == 27) {
-            const char *e = tune_env("TB_MECH_SPLIT");
-            split = !(e && atoi(e) == 0) && !(f->cond_model && f->d_u_prev);
-        }
         auto go_ea = [&](int64_t c0, int64_t n) -> int { // cells [c0, c0 + n) → stored Kₑ / rₑ
             if constexpr (NEED_K && CT == 2 && FE::NB == 27) {
                 if (split) {
                     if (!n) return TB_OK;
                     mm.cell0 = c0;
                     int rcs = launch_mech_points(dev, mm, hp, AD ? &ep : nullptr, d_u, n, p->d_qpbuf);
-                    if (!rcs) rcs = launch_mech_contract(dev, p->d_qpbuf, c0, n, kebuf, NEED_R ? rebuf : nullptr);
+                    if (!rcs) rcs = launch_mech_contract(dev, p->d_qpbuf, c0, n, kebuf, NEED_R ? rebuf : nullptr, ke_sym2 ? m->d_rank27 : nullptr);
                     if (rcs) return rcs;
                     mm.cell0 = 0;
                     return TB_OK;
@@ -1370,9 +1420,9 @@ static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, doubl
                     TB_HIP(hipStreamWaitEvent(dev->aux_stream, dev->aux_ev[0], 0));
                     const int64_t n1 = k + 1 == chunks_env ? m->n_nodes_field : std::upper_bound(p->h_gn_last.begin(), p->h_gn_last.end(), (int32_t)(c1 - 1)) - p->h_gn_last.begin();
                     if (n1 > n_done) {
-                        auto kg = k_gather_node_rows_lds<FE::NB, 4, (NEED_K && CT == 2 && FE::NB == 27)>;
-                        hipLaunchKernelGGL(kg, dim3((unsigned)((n1 - n_done + 3) / 4)), dim3(256), glds, dev->aux_stream, (const GatherNode *)p->d_gnodes + n_done,
-                                           n1 - n_done, kebuf, bp, d_nz, nbr_pad);
+                        const auto launch_g = [&](auto kg) { hipLaunchKernelGGL(kg, dim3((unsigned)((n1 - n_done + 3) / 4)), dim3(256), glds, dev->aux_stream, (const GatherNode *)p->d_gnodes + n_done,
+                                           n1 - n_done, kebuf, bp, d_nz, nbr_pad, ke_sym2 ? m->d_rank27 : nullptr); };
+                        TB_IF_ABLATION(if (ke_sym2) launch_g(k_gather_node_rows_lds<FE::NB, 4, 2>); else) launch_g(k_gather_node_rows_lds<FE::NB, 4, (NEED_K && CT == 2 && FE::NB == 27) ? 1 : 0>);
                         TB_HIP(hipGetLastError());
                         n_done = n1;
                     }
@@ -1432,9 +1482,9 @@ static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, doubl
             if (!(MFMA && KE_DMAJOR) && !direct && p->gnodes_state > 0) {
                 const int nbr_pad = (nbr_max + 7) & ~7;
                 const size_t lds = (size_t)4 * 4 * (3 * FE::ND * sizeof(double) + (size_t)nbr_pad);
-                auto k = k_gather_node_rows_lds<FE::NB, 4, (NEED_K && CT == 2 && FE::NB == 27)>;
-                hipLaunchKernelGGL(k, dim3((unsigned)((m->n_nodes_field + 3) / 4)), dim3(256), lds, dev->stream, (const GatherNode *)p->d_gnodes,
-                                   m->n_nodes_field, kebuf, bp, d_nz, nbr_pad);
+                const auto launch_g = [&](auto k) { hipLaunchKernelGGL(k, dim3((unsigned)((m->n_nodes_field + 3) / 4)), dim3(256), lds, dev->stream, (const GatherNode *)p->d_gnodes,
+                                   m->n_nodes_field, kebuf, bp, d_nz, nbr_pad, ke_sym2 ? m->d_rank27 : nullptr); };
+                TB_IF_ABLATION(if (ke_sym2) launch_g(k_gather_node_rows_lds<FE::NB, 4, 2>); else) launch_g(k_gather_node_rows_lds<FE::NB, 4, (NEED_K && CT == 2 && FE::NB == 27) ? 1 : 0>);
             } else {
                 const size_t lds = (size_t)4 * 8 * nbr_max;
                 auto k = k_gather_node_rows<FE::NB, MFMA && KE_DMAJOR, (NEED_K && CT == 2 && FE::NB == 27)>;
