@@ -19,6 +19,16 @@
  *
  * Threading: calls on one tb_device are serialised on that device's HIP stream and are synchronous
  * on return only where stated; different devices may be driven from different threads.
+ *
+ * Environment: the library reads these variables and no others (each has a test in tests/):
+ *   TB_PATCH_KERNEL = record | staged | general   patch kernel of first-order matrices (default: record where it applies; the others are what
+ *                                                 field coefficients and oversize patches run — the switch lets a test put them on any mesh)
+ *   TB_PATCH_CUT = full, TB_PATCH_TILE = "x,y,z"  tile cut / tile shape of the patch plan
+ *   TB_PATCH_ISO = 0                              constant positive definite tensors through the DIAG / general instances instead of the ISO one
+ *   TB_SPMV_KERNEL = rows                         CSR rows kernel also where the pattern compresses (what patterns without shared signatures run)
+ *   TB_MECH_CHUNKS = n                            launches of the chunked Q2 linearisation (0 / 1: one)
+ *   TB_PLAN_VERBOSE = 1                           plan statistics on stderr;   TB_RCCL_LIBRARY = path   the RCCL to open
+ * Tuning and comparison switches of earlier rounds exist in the profiling build only (make -C thunderbolt.jl_amd/csrc ablation).
  */
 #ifndef TBHIP_H
 #define TBHIP_H

@@ -46,6 +46,20 @@ if [ "$2" != "bench-only" ]; then
   rocprofv3 --kernel-trace --output-format csv -d "$out/ktc" -- python3 scripts/bench_mechanics.py --n 80 --steps 2 --cpu-n 2 > /dev/null 2>&1
   python3 scripts/trace_timeline.py "$out/ktc" "" 44 > "$out/mechanics_chunk_timeline.txt" 2>&1
   rm -rf "$out/ktc"
+  # round 5: unstructured presentations of the bench workload (random renumbering of the box; idealised ventricle), device-AD energies through the
+  # split linearisation, RCCL cost at world size 1, HBM traffic and SQ counters of the split mechanics kernels
+  python3 bench.py --mesh shuffled > "$out/bench_shuffled.json" 2> "$out/bench_shuffled.err"
+  TB_PLAN_VERBOSE=1 python3 bench.py --mesh lv > "$out/bench_lv.json" 2> "$out/bench_lv.err"
+  for en in guccione humphrey linyin ho; do python3 scripts/bench_mechanics.py --n 40 --energy $en --cpu-n 2 2>/dev/null | tail -1; done > "$out/mechanics_energies_40.json"
+  python3 scripts/rccl_latency.py 47089 2>/dev/null | grep "^{" > "$out/rccl_latency_world1.json"
+  for grp in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum" "WRITE_SIZE"; do
+    rm -rf /tmp/trm; rocprofv3 --pmc $grp -d /tmp/trm -o pmc -- python3 scripts/bench_mechanics.py --n 80 --steps 2 --cpu-n 2 > /dev/null 2>&1
+    python3 scripts/rocpd_summary.py $(find /tmp/trm -name "*.db" | head -1) 2>&1 | grep -A4 "k_mech_\|k_gather_node_rows" | cut -c1-150
+  done > "$out/mechanics_traffic_80.txt" 2>&1
+  for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS" "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"; do
+    rm -rf /tmp/trm; rocprofv3 --pmc $grp -d /tmp/trm -o pmc -- python3 scripts/bench_mechanics.py --n 40 --steps 2 --cpu-n 2 > /dev/null 2>&1
+    python3 scripts/rocpd_summary.py $(find /tmp/trm -name "*.db" | head -1) 2>&1 | grep -A9 "k_mech_\|k_gather_node_rows" | cut -c1-150
+  done > "$out/mechanics_pmc_40.txt" 2>&1
   # scalar forms on the quadratic field
   python3 scripts/bench_q2_scalar.py --n 64 > "$out/q2_scalar_64.json" 2>/dev/null
   rocprofv3 --kernel-trace --stats -d "$out/ktq" -o ktq -- python3 scripts/bench_q2_scalar.py --n 64 --strategies element > /dev/null 2>&1

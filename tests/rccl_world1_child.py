@@ -75,6 +75,17 @@ def main():
     # the plain torch-indexing statement of the same exchange on device buffers
     if abi:
         res["torch_indexing_exchange_equal"] = True               # (torch.distributed path: not part of this mode)
+        # the same exchange on the communicator's own queue (tb_comm_exchange_begin / _end, round 5): identical result, a kernel may run in between
+        halo.overlap = True
+        b3 = b.clone()
+        halo.pack(b)
+        halo.start()
+        scratch = b * 2.0                                           # something on the device's stream while the transfer is in flight
+        halo.finish(b)
+        torch.cuda.synchronize()
+        expect3 = b3.clone(); expect3[lo] += b3[lo]; expect3[up] += b3[up]
+        res["halo_overlapped_exchange_exact"] = bool(torch.equal(b, expect3)) and bool(torch.equal(scratch, b3 * 2.0))
+        halo.overlap = False
     else:
         b2 = D.exchange_sum(b1.clone(), nb, dist)
         res["torch_indexing_exchange_equal"] = bool(torch.equal(b2, expect2))
@@ -128,7 +139,7 @@ def main():
         dist.destroy_process_group()
     ok = (res["backend"] in ("nccl", "tbhip-rccl") and res["halo_device_exchange_exact"] and res["halo_second_exchange_exact"] and res["torch_indexing_exchange_equal"]
           and res["all_reduce_device"] and res["all_reduce_max"] and res["cg_product_err"] < 1e-13 and res["cg_pAp_rel_err"] < 1e-12
-          and res["cg_steps_finite_and_flag_clear"])
+          and res["cg_steps_finite_and_flag_clear"] and res.get("halo_overlapped_exchange_exact", True))
     res["ok"] = bool(ok)
     print(json.dumps(res))
     return 0 if ok else 1

@@ -3343,3 +3343,71 @@ def test_graph_replay_equals_plain_calls(tb, device):
         device.capture(lambda: src.b.to_host())
     step(cache2, 0.5)
     device.poll_status()
+
+
+def test_cgd_iteration_equals_the_four_calls(tb, device):
+    """tb_cgd_iteration (round 5: one whole local CG iteration from one call) = tb_spmv_csr_dot → tb_cgd_update → tb_cgd_direction → tb_cgd_rotate:
+    the same kernels, so the same bits, iteration after iteration."""
+    import torch
+    g = tb.generate_mesh(tb.Hexahedron, (14, 12, 10), (0, 0, 0), (1.0, 1.0, 1.0), perturb=0.2)
+    dh = tb.DofHandler(g)
+    sp = tb.allocate_matrix(dh)
+    st = tb.PatchAssemblyStrategy(device)
+    M = tb.setup_operator(st, tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.0)), dh, sp)
+    K = tb.setup_operator(st, tb.BilinearDiffusionIntegrator(tb.ConstantCoefficient(np.diag([4.5e-2, 2.0e-2, 2.0e-2]))), dh, sp)
+    tb.update_operators(M, K, 0.0)
+    A = tb.heat_system_matrix(device, M, K, 0.5)
+    torch.cuda.set_device(0)
+    device.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        diag = torch.empty(dh.ndofs, dtype=torch.float64, device="cuda")
+        tb._lib.check(tb.lib().tb_extract_diagonal(K.pattern.h, A.ptr, diag.data_ptr()))
+        out = {}
+        for one_call in (True, False):
+            cg = tb.distributed.DistributedCG(None, diag, None, None, 0, 1, None, device=device, operator=(K.pattern, A))
+            cg.one_call = one_call
+            x = torch.zeros(dh.ndofs, dtype=torch.float64, device="cuda")
+            r = torch.from_numpy(np.cos(np.arange(dh.ndofs) * 0.37) + 1.5).cuda()
+            p = cg.dinv * r
+            Ap = torch.empty_like(x)
+            S = torch.zeros(6, dtype=torch.float64, device="cuda")
+            tb._lib.check(tb.lib().tb_cgd_dot(device.h, dh.ndofs, cg.w.data_ptr(), r.data_ptr(), p.data_ptr(), S[0:1].data_ptr()))
+            for _ in range(4):
+                cg.device_step(x, r, p, Ap, S)
+            torch.cuda.synchronize()
+            out[one_call] = (x.cpu().numpy(), r.cpu().numpy(), S.cpu().numpy())
+        for a, b in zip(out[True], out[False]):
+            np.testing.assert_array_equal(a, b)
+        assert out[True][2][5] > 0 and out[True][2][4] == 0.0        # ‖r‖² parked, no breakdown flag
+    finally:
+        device.set_stream(None)
+
+
+def test_bisection_patcher_on_a_curved_thin_wall(tb, oracle, device):
+    """The tile plan of per-axis buckets fills the 256-lane sweeps of the idealised ventricle to about a half; ensure_patch_fused then bisects the cells into
+    equal leaves (round 5) if that needs clearly fewer patches.  The matrices of the new plan are the oracle's, the plan has fewer instances per patch
+    sweep wasted, and a box mesh keeps its tiles."""
+    gl = tb.generate_ideal_lv_mesh_hex(48, 6, 40)
+    dh = tb.DofHandler(gl)
+    sp = tb.allocate_matrix(dh)
+    st = tb.PatchAssemblyStrategy(device)
+    kap = np.array([[4.5e-5, 1e-5, 0], [1e-5, 2.0e-5, 0], [0, 0, 2.0e-5]])
+    M = tb.setup_operator(st, tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.3)), dh, sp)
+    K = tb.setup_operator(st, tb.BilinearDiffusionIntegrator(tb.ConstantCoefficient(kap)), dh, sp)
+    tb.update_operators(M, K, 0.0)
+    ps = K.pattern.patch_stats()
+    fill = ps["instances"] / (ps["patches"] * 256.0)
+    assert gl.n_cells >= 4096 and fill > 0.6, ps                                             # the tile plan of this mesh sits near 0.5
+    om = oracle.Mesh(oracle.HEX8, 2, gl.xyz, gl.conn, dh.cell_dofs)
+    refM = oracle.assemble_matrix(om, 0, oracle.Coef(oracle.COEF_CONST_SCALAR, [1.3]), sp.rowptr, sp.colidx)
+    refK = oracle.assemble_matrix(om, 1, oracle.Coef(oracle.COEF_CONST_TENSOR, kap.ravel()), sp.rowptr, sp.colidx)
+    assert rel_err(M.A.to_host(), refM) < TOL and rel_err(K.A.to_host(), refK) < TOL
+    assert rel_err(tb.update_operator(K, 0.0).A.to_host(), refK) < TOL                       # the one-matrix plan (refit) as well
+    gb = tb.generate_mesh(tb.Hexahedron, (20, 20, 20), (0, 0, 0), (1, 1, 1), perturb=0.2)
+    dhb = tb.DofHandler(gb)
+    spb = tb.allocate_matrix(dhb)
+    Kb = tb.setup_operator(st, tb.BilinearDiffusionIntegrator(tb.ConstantCoefficient(kap)), dhb, spb)
+    Mb = tb.setup_operator(st, tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.0)), dhb, spb)
+    tb.update_operators(Mb, Kb, 0.0)
+    psb = Kb.pattern.patch_stats()
+    assert psb["instances_per_cell"] < 1.9, psb                                               # tiles: the box's halo factor
