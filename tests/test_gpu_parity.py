@@ -3347,7 +3347,7 @@ def test_graph_replay_equals_plain_calls(tb, device):
 
 def test_cgd_iteration_equals_the_four_calls(tb, device):
     """tb_cgd_iteration (round 5: one whole local CG iteration from one call) = tb_spmv_csr_dot → tb_cgd_update → tb_cgd_direction → tb_cgd_rotate:
-    the same kernels, so the same bits, iteration after iteration."""
+    the same kernels, the same numbers (to the rounding of the atomically summed dot products), iteration after iteration."""
     import torch
     g = tb.generate_mesh(tb.Hexahedron, (14, 12, 10), (0, 0, 0), (1.0, 1.0, 1.0), perturb=0.2)
     dh = tb.DofHandler(g)
@@ -3376,8 +3376,8 @@ def test_cgd_iteration_equals_the_four_calls(tb, device):
                 cg.device_step(x, r, p, Ap, S)
             torch.cuda.synchronize()
             out[one_call] = (x.cpu().numpy(), r.cpu().numpy(), S.cpu().numpy())
-        for a, b in zip(out[True], out[False]):
-            np.testing.assert_array_equal(a, b)
+        for a, b in zip(out[True], out[False]):                        # (the dot products end in atomics whose order is free: two runs of EITHER form differ in the last bits)
+            assert rel_err(a, b) < 1e-13
         assert out[True][2][5] > 0 and out[True][2][4] == 0.0        # ‖r‖² parked, no breakdown flag
     finally:
         device.set_stream(None)
