@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 out=gpurun_out/$tag
 mkdir -p "$out"
 # micro-benchmarks are built here (binaries are not tracked)
-for mb in mfma_f64 mfma_f64_4x4 lds_atomic wg_launch mall_reuse sell_spmv; do
+for mb in mfma_f64 mfma_f64_4x4 lds_atomic wg_launch mall_reuse sell_spmv partial_rows; do
   [ -f scripts/microbench/$mb.hip ] && hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics scripts/microbench/$mb.hip -o scripts/microbench/$mb.bin 2>/dev/null
 done
 python3 bench.py > "$out/bench_216.json" 2> "$out/bench_216.err"
@@ -33,6 +33,7 @@ if [ "$2" != "bench-only" ]; then
   [ -x scripts/microbench/wg_launch.bin ] && ./scripts/microbench/wg_launch.bin > "$out/wg_launch_microbench.txt" 2>&1
   [ -x scripts/microbench/lds_atomic.bin ] && ./scripts/microbench/lds_atomic.bin > "$out/lds_atomic_microbench.txt" 2>&1
   [ -x scripts/microbench/mfma_f64_4x4.bin ] && ./scripts/microbench/mfma_f64_4x4.bin > "$out/mfma_f64_4x4_microbench.txt" 2>&1
+  [ -x scripts/microbench/partial_rows.bin ] && ./scripts/microbench/partial_rows.bin > "$out/partial_rows_microbench.txt" 2>&1
   python3 scripts/bench_tets.py --n 100 > "$out/tets_100.json" 2>/dev/null
   # coupled electromechanics on the ideal LV (config 5 as two kernel rates)
   python3 scripts/bench_electromechanics.py > "$out/electromechanics_lv.json" 2>/dev/null

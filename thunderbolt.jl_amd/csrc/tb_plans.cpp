@@ -836,6 +836,7 @@ int ensure_patch_fused(tb_mesh *m, tb_pattern *p, int nregions)
                 const int64_t np_tiles = pp->n_patches, inst_tiles = pp->total_elems;
                 const int version = pp->version;
                 m->patch_rcb = 128; // ≈ the own cells of a full 5×5×6-node tile; shrunk by the LDS-fit loop like a tile
+                const int rcb_max_inst = tune_env("TB_RCB_MAX_INST") ? atoi(tune_env("TB_RCB_MAX_INST")) : 320; // largest patch (instances) a leaf size may produce before it is shrunk
                 free_patch_fused_plan(p);
                 free_patch_plan(m);
                 rc = build_patch_plan(m, 0);
@@ -845,7 +846,7 @@ int ensure_patch_fused(tb_mesh *m, tb_pattern *p, int nregions)
                 for (int a2 = 0; a2 < 12; ++a2) {
                     rc2 = build_patch_fused_plan(p, &bytes, nregions);
                     bool big = rc2 == TB_ERR_UNSUPPORTED && p->patch_fused; // does not fit the LDS budget: smaller leaves
-                    if (rc2 == TB_OK && m->patches->max_elems > 320 && m->patch_rcb > 16) { big = true; rc2 = TB_ERR_UNSUPPORTED; } // a second sweep for many patches: smaller leaves too
+                    if (rc2 == TB_OK && m->patches->max_elems > rcb_max_inst && m->patch_rcb > 16) { big = true; rc2 = TB_ERR_UNSUPPORTED; } // a second sweep for many patches: smaller leaves too
                     if (rc2 == TB_OK) break;
                     free_patch_fused_plan(p);
                     if (!big) return rc2;
