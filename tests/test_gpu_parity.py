@@ -3403,6 +3403,9 @@ def test_bisection_patcher_on_a_curved_thin_wall(tb, oracle, device):
     refK = oracle.assemble_matrix(om, 1, oracle.Coef(oracle.COEF_CONST_TENSOR, kap.ravel()), sp.rowptr, sp.colidx)
     assert rel_err(M.A.to_host(), refM) < TOL and rel_err(K.A.to_host(), refK) < TOL
     assert rel_err(tb.update_operator(K, 0.0).A.to_host(), refK) < TOL                       # the one-matrix plan (refit) as well
+    # the vector plan bisects on its own fill (whichever plan of the mesh is built first): a linear form through leaves == the oracle's
+    b = tb.update_operator(tb.setup_operator(st, tb.LinearIntegrator(tb.AnalyticalCoefficient("cos_exp", 2.5)), dh), 0.1)
+    assert rel_err(b.b.to_host(), oracle.assemble_source(om, oracle.SRC_COS_EXP, [2.5], t=0.1)) < TOL
     gb = tb.generate_mesh(tb.Hexahedron, (20, 20, 20), (0, 0, 0), (1, 1, 1), perturb=0.2)
     dhb = tb.DofHandler(gb)
     spb = tb.allocate_matrix(dhb)

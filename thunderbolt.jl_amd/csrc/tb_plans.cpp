@@ -178,6 +178,41 @@ static inline uint64_t balanced_tile(uint32_t b, int64_t R, int tile, bool by_no
 // Patch decomposition.  Cells are ordered along a Morton curve through their centroids (works for any
 // unstructured mesh), cut into runs of `cells_per_patch`; a dof is owned by the first patch (in that
 // order) that touches it; a patch's element list = every cell touching one of its rows.
+// Recursive bisection of the cell centroids into ⌈nc / target⌉ leaves of equal size (± 1 cell).  Every split cuts the current subset across the axis
+// along which it holds the most cell LAYERS (extent ÷ mean cell extent: the halo of a patch counts cells, and anisotropic cells — the ventricle's are
+// ≈ 2 : 2 : 1 — would otherwise give leaves twice as long in cells), in proportion to the leaves either side receives.  Tiles of per-axis buckets fill a
+// curved thin-walled mesh badly (the idealised ventricle: 132 instances per 256-lane patch, 2.28 per cell); leaves follow the geometry.
+static void bisect_cells(const std::vector<double> &cen, const std::vector<double> &cext, int64_t nc, int64_t target, std::vector<int32_t> &leaf)
+{
+    const int64_t L = (nc + target - 1) / target;
+    std::vector<int32_t> ids(nc);
+    for (int64_t c = 0; c < nc; ++c) ids[c] = (int32_t)c;
+    struct Job { int64_t b, e, l0, nl; };
+    std::vector<Job> stack{{0, nc, 0, L}};
+    leaf.assign(nc, 0);
+    while (!stack.empty()) {
+        const Job j = stack.back(); stack.pop_back();
+        if (j.nl <= 1 || j.e - j.b <= 1) { for (int64_t k = j.b; k < j.e; ++k) leaf[ids[k]] = (int32_t)j.l0; continue; }
+        double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300}, es[3] = {0, 0, 0};
+        for (int64_t k = j.b; k < j.e; ++k)
+            for (int d = 0; d < 3; ++d) {
+                const double v = cen[3 * (size_t)ids[k] + d];
+                mn[d] = std::min(mn[d], v); mx[d] = std::max(mx[d], v); es[d] += cext[3 * (size_t)ids[k] + d];
+            }
+        int ax = 0;
+        double best = -1.0;
+        for (int d = 0; d < 3; ++d) {
+            const double layers = es[d] > 0.0 ? (mx[d] - mn[d]) * (double)(j.e - j.b) / es[d] : 0.0;
+            if (layers > best) { best = layers; ax = d; }
+        }
+        const int64_t nl_left = j.nl / 2, mid = j.b + (j.e - j.b) * nl_left / j.nl;
+        std::nth_element(ids.begin() + j.b, ids.begin() + mid, ids.begin() + j.e,
+                         [&](int32_t a, int32_t b) { const double va = cen[3 * (size_t)a + ax], vb = cen[3 * (size_t)b + ax]; return va < vb || (va == vb && a < b); });
+        stack.push_back({mid, j.e, j.l0 + nl_left, j.nl - nl_left});
+        stack.push_back({j.b, mid, j.l0, nl_left});
+    }
+}
+
 int build_patch_plan(tb_mesh *m, int cells_per_patch)
 {
     // Patch shape.  Default: tiles of 7×7×7 bucket cells — 343 owned rows (≈80 KB of LDS accumulators, two
@@ -213,7 +248,7 @@ int build_patch_plan(tb_mesh *m, int cells_per_patch)
     std::vector<uint32_t> bucket((size_t)nc * 3);
     int64_t Rv[3] = {1, 1, 1};
     {
-        std::vector<double> cen((size_t)nc * 3);
+        std::vector<double> cen((size_t)nc * 3), cext((size_t)nc * 3);
         double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, hsum[3] = {0, 0, 0};
 #pragma omp parallel for schedule(static) reduction(min : lo[:3]) reduction(max : hi[:3]) reduction(+ : hsum[:3])
         for (int64_t c = 0; c < nc; ++c) {
@@ -227,6 +262,7 @@ int build_patch_plan(tb_mesh *m, int cells_per_patch)
             if (nv == 8) hex_axis_extents(&m->h_xyz[0], &m->h_conn[c * 8], ext);
             for (int d = 0; d < 3; ++d) {
                 cen[3 * c + d] = sum[d] / nv;
+                cext[3 * c + d] = ext[d];
                 lo[d] = std::min(lo[d], mn[d]); hi[d] = std::max(hi[d], mx[d]); hsum[d] += ext[d];
             }
         }
@@ -252,31 +288,9 @@ int build_patch_plan(tb_mesh *m, int cells_per_patch)
                 cells_per_patch = (int)std::min<int64_t>((int64_t)tile[0] * tile[1] * tile[2] * per_bucket, 1 << 20);
             }
         }
-        if (m->patch_rcb > 0) {
-            // Recursive coordinate bisection of the cell centroids into ⌈nc / target⌉ leaves of equal size (± 1 cell): every split cuts the current subset
-            // along the longest side of its bounding box, in proportion to the leaves either side receives.  Tiles of per-axis buckets fill a curved
-            // thin-walled mesh badly (the idealised ventricle: 132 instances per 256-lane patch, 2.28 instances per cell — half the lanes idle); leaves
-            // follow the geometry, so every patch is full.  Chosen by ensure_patch_fused when the tile plan's fill is poor (round 5).
-            const int64_t L = (nc + m->patch_rcb - 1) / m->patch_rcb;
-            std::vector<int32_t> ids(nc);
-            for (int64_t c = 0; c < nc; ++c) ids[c] = (int32_t)c;
-            struct Job { int64_t b, e, l0, nl; };
-            std::vector<Job> stack{{0, nc, 0, L}};
-            std::vector<int32_t> leaf(nc, 0);
-            while (!stack.empty()) {
-                const Job j = stack.back(); stack.pop_back();
-                if (j.nl <= 1 || j.e - j.b <= 1) { for (int64_t k = j.b; k < j.e; ++k) leaf[ids[k]] = (int32_t)j.l0; continue; }
-                double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
-                for (int64_t k = j.b; k < j.e; ++k)
-                    for (int d = 0; d < 3; ++d) { const double v = cen[3 * (size_t)ids[k] + d]; mn[d] = std::min(mn[d], v); mx[d] = std::max(mx[d], v); }
-                int ax = 0;
-                for (int d = 1; d < 3; ++d) if (mx[d] - mn[d] > mx[ax] - mn[ax]) ax = d;
-                const int64_t nl_left = j.nl / 2, mid = j.b + (j.e - j.b) * nl_left / j.nl;
-                std::nth_element(ids.begin() + j.b, ids.begin() + mid, ids.begin() + j.e,
-                                 [&](int32_t a, int32_t b) { const double va = cen[3 * (size_t)a + ax], vb = cen[3 * (size_t)b + ax]; return va < vb || (va == vb && a < b); });
-                stack.push_back({mid, j.e, j.l0 + nl_left, j.nl - nl_left});
-                stack.push_back({j.b, mid, j.l0, nl_left});
-            }
+        if (m->patch_rcb > 0) { // chosen by ensure_patch_fused when the tile plan's fill is poor (round 5)
+            std::vector<int32_t> leaf;
+            bisect_cells(cen, cext, nc, m->patch_rcb, leaf);
             use_tiles = true; // a leaf is a tile: a patch ends where the key changes
             cells_per_patch = m->patch_rcb + 1;
 #pragma omp parallel for schedule(static)
@@ -836,7 +850,7 @@ int ensure_patch_fused(tb_mesh *m, tb_pattern *p, int nregions)
                 const int64_t np_tiles = pp->n_patches, inst_tiles = pp->total_elems;
                 const int version = pp->version;
                 m->patch_rcb = 128; // ≈ the own cells of a full 5×5×6-node tile; shrunk by the LDS-fit loop like a tile
-                const int rcb_max_inst = tune_env("TB_RCB_MAX_INST") ? atoi(tune_env("TB_RCB_MAX_INST")) : 320; // largest patch (instances) a leaf size may produce before it is shrunk
+                const int rcb_max_inst = tune_env("TB_RCB_MAX_INST") ? atoi(tune_env("TB_RCB_MAX_INST")) : 384; // largest patch (instances) a leaf size may produce before it is shrunk
                 free_patch_fused_plan(p);
                 free_patch_plan(m);
                 rc = build_patch_plan(m, 0);
@@ -919,7 +933,7 @@ int ensure_vec_patch_plan(tb_mesh *m, bool halo)
     std::vector<std::pair<uint64_t, int32_t>> keyed(nc);
     int64_t Rv[3] = {1, 1, 1};
     {
-        std::vector<double> cen((size_t)nc * 3);
+        std::vector<double> cen((size_t)nc * 3), cext((size_t)nc * 3);
         double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, hsum[3] = {0, 0, 0};
 #pragma omp parallel for schedule(static) reduction(min : lo[:3]) reduction(max : hi[:3]) reduction(+ : hsum[:3])
         for (int64_t c = 0; c < nc; ++c) {
@@ -933,6 +947,7 @@ int ensure_vec_patch_plan(tb_mesh *m, bool halo)
             hex_axis_extents(&m->h_xyz[0], &m->h_conn[c * 8], ext);
             for (int d = 0; d < 3; ++d) {
                 cen[3 * c + d] = sum[d] / 8;
+                cext[3 * c + d] = ext[d];
                 lo[d] = std::min(lo[d], mn[d]); hi[d] = std::max(hi[d], mx[d]); hsum[d] += ext[d];
             }
         }
@@ -953,6 +968,25 @@ int ensure_vec_patch_plan(tb_mesh *m, bool halo)
             uint64_t t3[3];
             for (int d = 0; d < 3; ++d) t3[d] = legacy_cut ? (uint64_t)(bucket[3 * c + d] / tile[d]) : balanced_tile(bucket[3 * c + d], Rv[d], tile[d], halo);
             keyed[c] = {(t3[2] << 42) | (t3[1] << 21) | t3[0], (int32_t)c};
+        }
+        // Poorly filled tiles (a curved thin wall: most tiles of the bucket grid hold a fraction of their volume, and the halo of a fragment is as large
+        // as a full tile's): equal leaves of the recursive bisection instead (bisect_cells; the matrix plan's rule, decided here on this plan's own fill
+        // so that the outcome does not depend on which plan of the mesh is built first).
+        {
+            std::vector<uint64_t> keys(nc);
+            for (int64_t c = 0; c < nc; ++c) keys[c] = keyed[c].first;
+            std::sort(keys.begin(), keys.end());
+            const int64_t ntiles = std::unique(keys.begin(), keys.end()) - keys.begin();
+            const int64_t vol = (int64_t)tile[0] * tile[1] * tile[2];
+            const double fill = ntiles > 0 ? (double)nc / ((double)ntiles * (double)vol) : 1.0;
+            const char *e = tune_env("TB_PATCH_RCB");
+            if (nc >= 4096 && fill < 0.75 && !(e && !strcmp(e, "0"))) {
+                std::vector<int32_t> leaf;
+                bisect_cells(cen, cext, nc, vol * 7 / 8, leaf);
+#pragma omp parallel for schedule(static)
+                for (int64_t c = 0; c < nc; ++c) keyed[c] = {(uint64_t)leaf[c], (int32_t)c};
+                if (getenv("TB_PLAN_VERBOSE")) fprintf(stderr, "[tbhip] vector patch plan: tile fill %.2f -> bisection, %ld leaves of <= %ld cells\n", fill, (long)((nc + vol * 7 / 8 - 1) / (vol * 7 / 8)), (long)(vol * 7 / 8));
+            }
         }
     }
     auto lex_less = [&](int32_t a, int32_t b) {
