@@ -74,6 +74,7 @@ k_spmv(int64_t nrows, const int64_t *__restrict__ rowptr, const int32_t *__restr
 }
 
 __device__ __forceinline__ void block_sum_to(double v, double *out);
+__device__ __forceinline__ void block_sum_slots(double v, double *group);
 
 // CSR "stream" SpMV: a workgroup owns a run of consecutive rows holding ≤ CAP non-zeros.  Phase 1 streams nzval / colidx of the whole run with
 // every lane busy and fully coalesced (lane i takes entry i, whatever row it belongs to), gathers x and parks the products in LDS; phase 2 sums
@@ -117,7 +118,7 @@ k_spmv_stream(int n_blk, const int32_t *__restrict__ blkrow, const int64_t *__re
         }
         __syncthreads();
     }
-    if constexpr (DOT) block_sum_to(acc, xy);
+    if constexpr (DOT) block_sum_slots(acc, xy); // xy: a slot group (block_sum_slots below)
 }
 
 #ifdef TB_ABLATION
@@ -200,7 +201,7 @@ k_spmv_stream_rec(int n_blk, const uint4 *__restrict__ blkrec, const int64_t *__
         __syncthreads();
         rec = recn;
     }
-    if constexpr (DOT) block_sum_to(acc, xy);
+    if constexpr (DOT) block_sum_slots(acc, xy); // xy: a slot group (block_sum_slots below)
 }
 
 // Row-per-lane form of the same run (default).  In the kernels above lane i takes entry i, so the 64 gathers of x in one instruction follow 2.4 rows
@@ -275,7 +276,7 @@ k_spmv_stream_rows(int n_blk, const uint4 *__restrict__ blkrec, const int64_t *_
         __syncthreads();
         rec = recn;
     }
-    if constexpr (DOT) block_sum_to(acc, xy);
+    if constexpr (DOT) block_sum_slots(acc, xy); // xy: a slot group (block_sum_slots below)
 }
 
 // Index-compressed form of the row-per-lane run (default when the pattern compresses).  On a finite-element numbering almost every row holds the same
@@ -395,7 +396,7 @@ k_spmv_sig_rows(int n_blk, const uint4 *__restrict__ blkrec, const int64_t *__re
         for (int u = 0; u < U; ++u) vj[u] = vjn[u];
         pa0 = pa0n; pe0 = pe0n; sg0 = sg0n;
     }
-    if constexpr (DOT) block_sum_to(acc, xy);
+    if constexpr (DOT) block_sum_slots(acc, xy); // xy: a slot group (block_sum_slots below)
 }
 
 // Wave-private form of k_spmv_sig_rows (TB_SPMV_KERNEL=wave; measured: 0.668 against 0.682 ms at 216³, 0.112 against 0.098 ms on the 27-layer slab — not the
@@ -505,7 +506,7 @@ k_spmv_sig_wave(int n_run, const uint4 *__restrict__ runrec, const int64_t *__re
         for (int u = 0; u < U; ++u) vj[u] = vjn[u];
         pa0 = pa0n; pe0 = pe0n; sg0 = sg0n;
     }
-    if constexpr (DOT) block_sum_to(acc, xy);
+    if constexpr (DOT) block_sum_slots(acc, xy); // xy: a slot group (block_sum_slots below)
 }
 
 __global__ void __launch_bounds__(256)
@@ -601,7 +602,7 @@ k_spmv_b3(int64_t n_brows, const int64_t *__restrict__ rowptr, const int32_t *__
             }
         }
     }
-    if constexpr (DOT) block_sum_to(acc, xy);
+    if constexpr (DOT) block_sum_slots(acc, xy); // xy: a slot group (block_sum_slots below)
 }
 
 // is the pattern a CSR of 3×3 blocks?  (checked once on the host; b3 = 1 yes / −1 no)
@@ -918,7 +919,7 @@ k_spmv_mirror(int64_t n_rows, int64_t n_slices, const MirrorSlice *__restrict__ 
             else y[row] = beta == 0.0 ? alpha * v : alpha * v + beta * y[row];
         }
     }
-    if constexpr (DOT) block_sum_to(acc, xy);
+    if constexpr (DOT) block_sum_slots(acc, xy); // xy: a slot group (block_sum_slots below)
 }
 
 int launch_mirror_bind(tb_pattern *p, const double *nz)
@@ -1151,6 +1152,57 @@ __device__ __forceinline__ void block_sum2_to(double a, double c, double *out)
     if (threadIdx.x == 64) unsafeAtomicAdd(out + 1, sm2[4] + sm2[5] + sm2[6] + sm2[7]);
 }
 
+// ---- reduction slots ----
+// A sum over the workgroups of a launch that ends in one atomic per workgroup on ONE address costs 12.2 ns per workgroup on MI355X — same-address (and
+// same-128-byte-line) atomics serialise in L2, FP64 and integer alike (scripts/microbench/tail_atomics.hip: 2 048 co-resident workgroups, two scalars of
+// one line: 51 µs; the CG update kernel on a 27-layer slab spent 23 of its 37 µs there).  The partial of workgroup b goes to slot b mod 64 of a GROUP of 64
+// slots 128 B apart instead (3 µs for the same 2 048), and whoever needs the sum adds the 64 slots: the next kernel of a fused sequence (read_slots: the
+// same xor tree in every wave, so every workgroup sees the same bits), or k_fold_slots (one wave) into a caller-owned scalar for the public one-kernel
+// entries.  Groups live in tb_device::d_slots and are zero between uses; launches of one device are stream-ordered.
+constexpr int RED_SLOTS = 64, RED_STRIDE = 16, RED_GROUP = RED_SLOTS * RED_STRIDE; // doubles
+__device__ __forceinline__ void block_sum_slots(double v, double *group)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __shared__ double sms[4];
+    if ((threadIdx.x & 63) == 0) sms[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(group + RED_STRIDE * (blockIdx.x & (RED_SLOTS - 1)), sms[0] + sms[1] + sms[2] + sms[3]);
+}
+__device__ __forceinline__ void block_sum2_slots(double a, double c, double *ga, double *gc)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
+    __shared__ double sms2[8];
+    if ((threadIdx.x & 63) == 0) { sms2[threadIdx.x >> 6] = a; sms2[4 + (threadIdx.x >> 6)] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(ga + RED_STRIDE * (blockIdx.x & (RED_SLOTS - 1)), sms2[0] + sms2[1] + sms2[2] + sms2[3]);
+    if (threadIdx.x == 64) unsafeAtomicAdd(gc + RED_STRIDE * (blockIdx.x & (RED_SLOTS - 1)), sms2[4] + sms2[5] + sms2[6] + sms2[7]);
+}
+// the sum of a group, in every lane (call with all 64 lanes of the wave active)
+__device__ __forceinline__ double read_slots(const double *group)
+{
+    double v = group[RED_STRIDE * (threadIdx.x & 63)];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// out[k] += sum of group k, the groups back to zero (k < ngroups ≤ 4; one wave per group)
+__global__ void __launch_bounds__(256) k_fold_slots(double *__restrict__ groups, double *__restrict__ out, int ngroups)
+{
+    const int k = threadIdx.x >> 6, l = threadIdx.x & 63;
+    if (k >= ngroups) return;
+    double *g = groups + (size_t)k * RED_GROUP;
+    const double v = read_slots(g);
+    g[RED_STRIDE * l] = 0.0;
+    if (l == 0) out[k] += v;
+}
+static inline double *red_group(tb_device *dev, int k) { return dev->d_slots + (size_t)k * RED_GROUP; }
+static inline void fold_slots(tb_device *dev, int first_group, double *d_out, int ngroups)
+{
+    hipLaunchKernelGGL(k_fold_slots, dim3(1), dim3(256), 0, dev->stream, red_group(dev, first_group), d_out, ngroups);
+}
+
 // r = b − Ax (Ax given), z = D⁻¹ r, p = z;  out[0] += r·z, out[1] += r·r
 __global__ void __launch_bounds__(256)
 k_cg_init(int64_t n, const double *__restrict__ b, const double *__restrict__ Ax, const double *__restrict__ dinv, double *__restrict__ r,
@@ -1223,7 +1275,7 @@ k_spmv_dot(int64_t nrows, const int64_t *__restrict__ rowptr, const int32_t *__r
         for (int o = LANES / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, LANES);
         if (sub == 0) { y[r] = v; acc += x[r] * v; }
     }
-    block_sum_to(acc, xy);
+    block_sum_slots(acc, xy); // xy: a slot group
 }
 
 __global__ void __launch_bounds__(256)
@@ -1233,9 +1285,10 @@ k_cg_update_dev(int64_t n, const double *__restrict__ rz, const double *__restri
 {
     // pᵀAp ≤ 0 with a non-zero residual: the matrix is not positive definite — remembered in a sticky flag the host reads at its next
     // convergence check; at exact convergence (r = 0 ⇒ p = 0) the step is simply empty
-    const double pap = *pAp;
-    const double alpha = pap > 0.0 ? *rz / pap : 0.0;
-    if (!(pap > 0.0) && *rz != 0.0 && blockIdx.x == 0 && threadIdx.x == 0) *flag = pap == 0.0 ? -1e-300 : pap;
+    // rz, pAp, rz_next, rr: slot groups (see "reduction slots")
+    const double pap = read_slots(pAp), rzv = read_slots(rz);
+    const double alpha = pap > 0.0 ? rzv / pap : 0.0;
+    if (!(pap > 0.0) && rzv != 0.0 && blockIdx.x == 0 && threadIdx.x == 0) *flag = pap == 0.0 ? -1e-300 : pap;
     double a = 0.0, c = 0.0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -1245,20 +1298,25 @@ k_cg_update_dev(int64_t n, const double *__restrict__ rz, const double *__restri
         a += ri * (dinv ? dinv[i] * ri : ri);
         c += ri * ri;
     }
-    block_sum_to(a, rz_next);
-    __syncthreads();
-    block_sum_to(c, rr);
+    block_sum2_slots(a, c, rz_next, rr);
 }
 
 // p = D⁻¹ r + (rz_next / rz) p; one thread retires the scalars the next iteration accumulates into
+// (rz, rz_next, retired, pAp, rr: slot groups; rr_out: the scalar the host reads — ‖r‖² of this iteration)
 __global__ void __launch_bounds__(256)
-k_cg_direction_dev(int64_t n, const double *__restrict__ rz, const double *__restrict__ rz_next, double *__restrict__ retired, double *__restrict__ pAp_rr,
-                   const double *__restrict__ r, const double *__restrict__ dinv, double *__restrict__ p)
+k_cg_direction_dev(int64_t n, const double *__restrict__ rz, const double *__restrict__ rz_next, double *__restrict__ retired, double *__restrict__ pAp,
+                   double *__restrict__ rr, double *__restrict__ rr_out, const double *__restrict__ r, const double *__restrict__ dinv, double *__restrict__ p)
 {
-    const double beta = *rz > 0.0 ? *rz_next / *rz : 0.0;
+    const double rzv = read_slots(rz), rzn = read_slots(rz_next);
+    const double beta = rzv > 0.0 ? rzn / rzv : 0.0;
+    if (blockIdx.x == 0 && threadIdx.x < 64) { // nobody else touches these three groups during this launch
+        const double v = read_slots(rr);
+        const int l = RED_STRIDE * threadIdx.x;
+        retired[l] = 0.0; pAp[l] = 0.0; rr[l] = 0.0;
+        if (threadIdx.x == 0) *rr_out = v;
+    }
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = (dinv ? dinv[i] * r[i] : r[i]) + beta * p[i];
-    if (blockIdx.x == 0 && threadIdx.x == 0) { *retired = 0.0; pAp_rr[0] = 0.0; pAp_rr[1] = 0.0; }
 }
 
 int launch_cg(tb_pattern *pat, const double *A, const double *b, double *x, double rtol, double atol, int maxiter, int jacobi, int *iters,
@@ -1285,7 +1343,11 @@ int launch_cg(tb_pattern *pat, const double *A, const double *b, double *x, doub
     double h[3];
     TB_HIP(hipMemcpyAsync(h, scal, 2 * sizeof(double), hipMemcpyDeviceToHost, dev->stream));
     TB_HIP(hipStreamSynchronize(dev->stream));
-    TB_HIP(hipMemsetAsync(scal + 1, 0, sizeof(double), dev->stream)); // slot 1 becomes the "next r·z" accumulator
+    // the loop's sums live in slot groups of the device ("reduction slots"): pᵀAp, r·z of the current / next / retired iteration (rotating), rᵀr
+    double *const g_pap = red_group(dev, 3), *const g_rr = red_group(dev, 7);
+    auto g_rz = [&](int k) { return red_group(dev, 4 + k); };
+    TB_HIP(hipMemsetAsync(g_pap, 0, 5 * RED_GROUP * sizeof(double), dev->stream));
+    TB_HIP(hipMemcpyAsync(g_rz(0), scal, sizeof(double), hipMemcpyDeviceToDevice, dev->stream)); // r·z of the start: slot 0 of the current group
     double rnorm = std::sqrt(h[1]);
     const double tol = atol + rtol * rnorm;
     pat->last_tol = tol;
@@ -1300,16 +1362,16 @@ int launch_cg(tb_pattern *pat, const double *A, const double *b, double *x, doub
         const int check = check_env > 0 ? check_env : (it >= 128 ? 8 : it >= 32 ? std::max(check0, 4) : check0);
         const int nxt = (cur + 1) % 3, ret = (cur + 2) % 3;
         if (pat->b3 > 0)
-            launch_b3<true>(pat, A, p, 1.0, 0.0, Ap, scal + 3);
+            launch_b3<true>(pat, A, p, 1.0, 0.0, Ap, g_pap);
         else if (pat->n_blk > 0)
-            launch_stream<true>(pat, A, p, 1.0, 0.0, Ap, scal + 3, stream_grid(pat));
+            launch_stream<true>(pat, A, p, 1.0, 0.0, Ap, g_pap, stream_grid(pat));
         else
-            hipLaunchKernelGGL(k_spmv_dot<LANES>, dim3(gs), dim3(256), 0, dev->stream, n, pat->d_rowptr, pat->d_colidx, A, p, Ap, scal + 3);
-        hipLaunchKernelGGL(k_cg_update_dev, dim3(g), dim3(256), 0, dev->stream, n, scal + cur, scal + 3, p, Ap, dp, x, r, scal + nxt, scal + 4, scal + 5);
+            hipLaunchKernelGGL(k_spmv_dot<LANES>, dim3(gs), dim3(256), 0, dev->stream, n, pat->d_rowptr, pat->d_colidx, A, p, Ap, g_pap);
+        hipLaunchKernelGGL(k_cg_update_dev, dim3(g), dim3(256), 0, dev->stream, n, g_rz(cur), g_pap, p, Ap, dp, x, r, g_rz(nxt), g_rr, scal + 5);
         const bool look = it + 1 - last_look >= check || it + 1 == maxiter;
         if (look) last_look = it + 1;
-        if (look) TB_HIP(hipMemcpyAsync(h, scal + 3, 3 * sizeof(double), hipMemcpyDeviceToHost, dev->stream));
-        hipLaunchKernelGGL(k_cg_direction_dev, dim3(g), dim3(256), 0, dev->stream, n, scal + cur, scal + nxt, scal + ret, scal + 3, r, dp, p);
+        hipLaunchKernelGGL(k_cg_direction_dev, dim3(g), dim3(256), 0, dev->stream, n, g_rz(cur), g_rz(nxt), g_rz(ret), g_pap, g_rr, scal + 4, r, dp, p);
+        if (look) TB_HIP(hipMemcpyAsync(h, scal + 3, 3 * sizeof(double), hipMemcpyDeviceToHost, dev->stream)); // (‖r‖² lands in scal[4] in the direction kernel)
         cur = nxt;
         ++it;
         if (!look) continue;
@@ -1900,20 +1962,23 @@ int launch_meandiag(tb_pattern *pat, const double *nz, double *result)
 
 // ---- sub-structured CG over several devices: weighted sums (a dof held by k ranks counts 1/k), every scalar in caller-owned device memory ----
 __global__ void __launch_bounds__(256)
-k_cgd_dot(int64_t n, const double *__restrict__ w, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ out)
+k_cgd_dot(int64_t n, const double *__restrict__ w, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ out /* slot group */)
 {
     double s = 0.0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) s += (w ? w[i] : 1.0) * a[i] * b[i];
-    block_sum_to(s, out);
+    block_sum_slots(s, out);
 }
 
 // α = rz / pAp (device scalars, already summed over the ranks); x += α p, r −= α Ap; out[0] += Σ w r·(D⁻¹r), out[1] += Σ w r·r
+// SL: pᵀAp is still in its slot group (the fused iteration: nothing folded it); the two sums always leave through slot groups g_rz, g_rr
+template <bool SL>
 __global__ void __launch_bounds__(256)
 k_cgd_update(int64_t n, const double *__restrict__ w, const double *__restrict__ dinv, const double *__restrict__ p, const double *__restrict__ Ap,
-             double *__restrict__ x, double *__restrict__ r, const double *__restrict__ rz, const double *__restrict__ pAp, double *__restrict__ out)
+             double *__restrict__ x, double *__restrict__ r, const double *__restrict__ rz, const double *__restrict__ pAp, double *__restrict__ out,
+             double *__restrict__ g_rz, double *__restrict__ g_rr)
 {
-    const double pap = *pAp;
+    const double pap = SL ? read_slots(pAp) : *pAp;
     const double alpha = pap > 0.0 ? *rz / pap : 0.0;
     // pᵀAp ≤ 0 while r·z ≠ 0: the operator is not positive definite (or the iteration broke down) — sticky flag in out[2], read by the host with ‖r‖²
     if (!(pap > 0.0) && *rz != 0.0 && blockIdx.x == 0 && threadIdx.x == 0) out[2] = pap == 0.0 ? -1e-300 : pap;
@@ -1927,15 +1992,17 @@ k_cgd_update(int64_t n, const double *__restrict__ w, const double *__restrict__
         a += wi * ri * (dinv ? dinv[i] * ri : ri);
         c += wi * ri * ri;
     }
-    block_sum2_to(a, c, out);
+    block_sum2_slots(a, c, g_rz, g_rr);
 }
 
 // β = rz_new / rz (device scalars); p = D⁻¹ r + β p
+template <bool SL>
 __global__ void __launch_bounds__(256)
 k_cgd_direction(int64_t n, const double *__restrict__ dinv, const double *__restrict__ r, double *__restrict__ p, const double *__restrict__ rz,
                 const double *__restrict__ rz_new)
 {
-    const double beta = *rz > 0.0 ? *rz_new / *rz : 0.0;
+    const double rzn = SL ? read_slots(rz_new) : *rz_new;
+    const double beta = *rz > 0.0 ? rzn / *rz : 0.0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = (dinv ? dinv[i] * r[i] : r[i]) + beta * p[i];
 }
@@ -1946,6 +2013,14 @@ __global__ void k_cgd_rotate(double *__restrict__ S)
 {
     if (threadIdx.x == 0) { S[0] = S[2]; S[5] = S[3]; S[1] = 0.0; S[2] = 0.0; S[3] = 0.0; }
 }
+// the same at the end of a fused iteration, whose sums are still in slot groups 0 (pᵀAp), 1 (r·z), 2 (rᵀr): r·z and ‖r‖² folded into S, the groups zeroed
+__global__ void __launch_bounds__(64) k_cgd_rotate_slots(double *__restrict__ S, double *__restrict__ groups)
+{
+    const double rz = read_slots(groups + RED_GROUP), rr = read_slots(groups + 2 * RED_GROUP);
+    const int l = RED_STRIDE * threadIdx.x;
+    groups[l] = 0.0; groups[RED_GROUP + l] = 0.0; groups[2 * RED_GROUP + l] = 0.0;
+    if (threadIdx.x == 0) { S[0] = rz; S[5] = rr; S[1] = 0.0; S[2] = 0.0; S[3] = 0.0; }
+}
 int launch_cgd_rotate(tb_device *dev, double *d_S)
 {
     hipLaunchKernelGGL(k_cgd_rotate, dim3(1), dim3(64), 0, dev->stream, d_S);
@@ -1955,21 +2030,44 @@ int launch_cgd_rotate(tb_device *dev, double *d_S)
 
 int launch_cgd_dot(tb_device *dev, int64_t n, const double *w, const double *a, const double *b, double *d_out)
 {
-    if (n > 0) hipLaunchKernelGGL(k_cgd_dot, dim3(grid_for(dev, n, 256)), dim3(256), 0, dev->stream, n, w, a, b, d_out);
+    if (n > 0) {
+        hipLaunchKernelGGL(k_cgd_dot, dim3(grid_for(dev, n, 256)), dim3(256), 0, dev->stream, n, w, a, b, red_group(dev, 0));
+        fold_slots(dev, 0, d_out, 1);
+    }
     TB_HIP(hipGetLastError());
     return TB_OK;
 }
 int launch_cgd_update(tb_device *dev, int64_t n, const double *w, const double *dinv, const double *p, const double *Ap, double *x, double *r,
                       const double *d_rz, const double *d_pAp, double *d_out3)
 {
-    // reductions end in one atomic per block and sum on ONE address: four blocks per CU (1 024 atomics) instead of eight
-    if (n > 0) hipLaunchKernelGGL(k_cgd_update, dim3(std::min<unsigned>(grid_for(dev, n, 256), (unsigned)dev->n_cu * 4)), dim3(256), 0, dev->stream, n, w, dinv, p, Ap, x, r, d_rz, d_pAp, d_out3);
+    if (n > 0) {
+        hipLaunchKernelGGL(k_cgd_update<false>, dim3(std::min<unsigned>(grid_for(dev, n, 256), (unsigned)dev->n_cu * 4)), dim3(256), 0, dev->stream, n, w, dinv, p, Ap, x, r, d_rz, d_pAp, d_out3,
+                           red_group(dev, 1), red_group(dev, 2));
+        fold_slots(dev, 1, d_out3, 2); // out3[0] += r·z, out3[1] += rᵀr
+    }
     TB_HIP(hipGetLastError());
     return TB_OK;
 }
 int launch_cgd_direction(tb_device *dev, int64_t n, const double *dinv, const double *r, double *p, const double *d_rz, const double *d_rz_new)
 {
-    if (n > 0) hipLaunchKernelGGL(k_cgd_direction, dim3(grid_for(dev, n, 256)), dim3(256), 0, dev->stream, n, dinv, r, p, d_rz, d_rz_new);
+    if (n > 0) hipLaunchKernelGGL(k_cgd_direction<false>, dim3(grid_for(dev, n, 256)), dim3(256), 0, dev->stream, n, dinv, r, p, d_rz, d_rz_new);
+    TB_HIP(hipGetLastError());
+    return TB_OK;
+}
+int launch_spmv_dot_slots(tb_pattern *pat, const double *A, const double *x, double *y, double *group);
+// One iteration of the device CG on a sub-domain without shared dofs, its three sums kept in slot groups 0–2 from kernel to kernel (no fold launches):
+// SpMV with pᵀAp → update (reads the group) → direction (reads the group) → rotate (folds r·z and ‖r‖² into S, zeroes the groups)
+int launch_cgd_iteration(tb_pattern *pat, const double *A, const double *dinv, double *x, double *r, double *p, double *Ap, double *d_S)
+{
+    tb_device *dev = pat->mesh->dev;
+    const int64_t n = pat->n_rows;
+    if (n == 0) return launch_cgd_rotate(dev, d_S);
+    int rc = launch_spmv_dot_slots(pat, A, p, Ap, red_group(dev, 0));
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_cgd_update<true>, dim3(std::min<unsigned>(grid_for(dev, n, 256), (unsigned)dev->n_cu * 4)), dim3(256), 0, dev->stream, n, (const double *)nullptr, dinv, p, Ap, x, r, d_S,
+                       red_group(dev, 0), d_S + 2, red_group(dev, 1), red_group(dev, 2));
+    hipLaunchKernelGGL(k_cgd_direction<true>, dim3(grid_for(dev, n, 256)), dim3(256), 0, dev->stream, n, dinv, r, p, d_S, red_group(dev, 1));
+    hipLaunchKernelGGL(k_cgd_rotate_slots, dim3(1), dim3(64), 0, dev->stream, d_S, red_group(dev, 0));
     TB_HIP(hipGetLastError());
     return TB_OK;
 }
@@ -2037,7 +2135,19 @@ int launch_spmv_rows(tb_pattern *p, const double *nz, const double *x, int64_t n
     return TB_OK;
 }
 // y = A x and *d_dot += xᵀ y with the kernels of the single-device CG (block / stream / lanes-per-row forms)
+int launch_spmv_dot_slots(tb_pattern *pat, const double *A, const double *x, double *y, double *d_dot);
+// y = A x and *d_dot += xᵀy: the kernels leave the sum in slot group 0, one wave folds it into the caller's scalar
 int launch_spmv_dot(tb_pattern *pat, const double *A, const double *x, double *y, double *d_dot)
+{
+    if (pat->n_rows == 0) return TB_OK;
+    tb_device *dev = pat->mesh->dev;
+    int rc = launch_spmv_dot_slots(pat, A, x, y, red_group(dev, 0));
+    if (rc) return rc;
+    fold_slots(dev, 0, d_dot, 1);
+    TB_HIP(hipGetLastError());
+    return TB_OK;
+}
+int launch_spmv_dot_slots(tb_pattern *pat, const double *A, const double *x, double *y, double *d_dot /* a slot group */)
 {
     tb_device *dev = pat->mesh->dev;
     const int64_t n = pat->n_rows;

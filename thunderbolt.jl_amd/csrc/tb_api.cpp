@@ -103,6 +103,8 @@ int tb_device_create(int hip_device_id, tb_device **out)
     dev->name = prop.gcnArchName;
     TB_HIP(hipStreamCreateWithFlags(&dev->stream, hipStreamNonBlocking));
     TB_HIP(hipMalloc((void **)&dev->d_status, sizeof(Status)));
+    TB_HIP(hipMalloc((void **)&dev->d_slots, 8 * 1024 * sizeof(double)));
+    TB_HIP(hipMemset(dev->d_slots, 0, 8 * 1024 * sizeof(double)));
     TB_HIP(hipHostMalloc((void **)&dev->h_status, sizeof(Status), hipHostMallocDefault));
     *out = dev.release();
     return TB_OK;
@@ -119,6 +121,7 @@ int tb_device_destroy(tb_device *dev)
     if (dev->h_status) hipHostFree(dev->h_status);
     if (dev->d_scratch) hipFree(dev->d_scratch);
     if (dev->d_tslot) hipFree(dev->d_tslot);
+    if (dev->d_slots) hipFree(dev->d_slots);
     delete dev;
     return TB_OK;
 }
@@ -1164,11 +1167,8 @@ int tb_cgd_iteration(tb_pattern *pat, const double *d_nzval, const double *d_din
     tb_device *dev = pat->mesh->dev;
     TB_HIP(hipSetDevice(dev->id));
     const int64_t n = pat->n_rows;
-    int rc = launch_spmv_dot(pat, d_nzval, d_p, d_Ap, d_S + 1);
-    if (!rc) rc = launch_cgd_update(dev, n, nullptr, d_dinv, d_p, d_Ap, d_x, d_r, d_S, d_S + 1, d_S + 2);
-    if (!rc) rc = launch_cgd_direction(dev, n, d_dinv, d_r, d_p, d_S, d_S + 2);
-    if (!rc) rc = launch_cgd_rotate(dev, d_S);
-    return rc;
+    (void)n;
+    return launch_cgd_iteration(pat, d_nzval, d_dinv, d_x, d_r, d_p, d_Ap, d_S);
 }
 
 int tb_extract_diagonal(tb_pattern *pat, const double *d_nzval, double *d_diag)

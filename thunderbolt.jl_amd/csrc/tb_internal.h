@@ -163,6 +163,7 @@ struct tb_device {
     bool defer_status = false;      // tb_device_defer_status: assembly calls return without reading the status block; tb_device_poll_status reads it
     void *d_scratch = nullptr;      // Float64 arena behind the *_f32 entry points (tb_f32.hip), grown on demand
     size_t scratch_bytes = 0;
+    double *d_slots = nullptr;      // reduction slots (tb_algebra.hip: block_sum_slots): RED_GROUPS groups of 64 partial sums, 128 B apart, zero between uses
     double *d_tslot = nullptr;      // {t, cos 2πt}: where time-dependent kernels read the time while a graph capture is open (tb_graph.hip)
     bool capturing = false, defer_before_capture = false, tslot_used = false; // tslot_used: a captured launch was handed the slot
     hipStream_t aux_stream = nullptr; // second queue of the chunked mechanics linearisation (gather of chunk k beside the integration of chunk k + 1)
@@ -368,6 +369,7 @@ int launch_gather_indexed(tb_device *dev, int64_t n, const double *vec, const in
 int launch_scatter_add_indexed(tb_device *dev, int64_t n, const double *in, const int32_t *idx, double *vec);
 int read_status_public(tb_device *dev); // status block → host, synchronises the stream (what check_status does when the status is not deferred)
 int launch_cgd_rotate(tb_device *dev, double *d_S);
+int launch_cgd_iteration(tb_pattern *pat, const double *A, const double *dinv, double *x, double *r, double *p, double *Ap, double *d_S);
 int spmv_plans(tb_pattern *p); // builds the plans tb_spmv_csr would build on its first product
 int launch_scatter_indexed(tb_device *dev, int64_t n, const double *in, const int32_t *idx, double *vec);
 int launch_spmv_rows(tb_pattern *p, const double *nz, const double *x, int64_t n, const int32_t *rows, double *out);
