@@ -26,6 +26,12 @@ static const char *spmv_kernel_env()
     return e;
 }
 
+// grid of a kernel of 1 024-thread workgroups that ends in a workgroup sum (block_sum_to): two per CU
+static inline unsigned grid_red(tb_device *dev, int64_t n)
+{
+    const int64_t nb = (n + 1023) / 1024, cap = (int64_t)dev->n_cu * 2;
+    return (unsigned)std::max<int64_t>(1, nb > cap ? cap : nb);
+}
 static inline unsigned grid_for(tb_device *dev, int64_t n, int bs)
 {
     int64_t nb = (n + bs - 1) / bs;
@@ -1130,14 +1136,21 @@ static int launch_extract_diag(tb_pattern *p, const double *nz, double *dinv, bo
 }
 int launch_extract_diagonal(tb_pattern *p, const double *nz, double *diag) { return launch_extract_diag(p, nz, diag, false); }
 
+// *out += the sum of v over the workgroup (4 … 16 waves).  ONE atomic per workgroup on one address: 12.2 ns each, serialised ("reduction slots" below) —
+// the kernels that end this way and run once per solver iteration are launched as 1 024-thread workgroups, two per CU (grid_red): a quarter of the
+// atomics of 256-thread workgroups at the same number of threads in flight.
 __device__ __forceinline__ void block_sum_to(double v, double *out)
 {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    __shared__ double sm[4];
+    __shared__ double sm[16];
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (threadIdx.x == 0) unsafeAtomicAdd(out, sm[0] + sm[1] + sm[2] + sm[3]);
+    if (threadIdx.x == 0) {
+        double t = sm[0] + sm[1] + sm[2] + sm[3];
+        for (int k = 4; k < (int)(blockDim.x >> 6); ++k) t += sm[k];
+        unsafeAtomicAdd(out, t);
+    }
 }
 
 // two sums of a 256-thread block with one barrier: out[0] += Σ a, out[1] += Σ c (the two atomics leave from different waves)
@@ -1221,7 +1234,7 @@ k_cg_init(int64_t n, const double *__restrict__ b, const double *__restrict__ Ax
     block_sum_to(rr, out + 1);
 }
 
-__global__ void __launch_bounds__(256) k_dot(int64_t n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ out)
+__global__ void __launch_bounds__(1024) k_dot(int64_t n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ out)
 {
     double s = 0.0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -1230,7 +1243,7 @@ __global__ void __launch_bounds__(256) k_dot(int64_t n, const double *__restrict
 }
 
 // x += α p, r −= α Ap;  out[0] += r·(D⁻¹r), out[1] += r·r
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_cg_update(int64_t n, double alpha, const double *__restrict__ p, const double *__restrict__ Ap, const double *__restrict__ dinv,
             double *__restrict__ x, double *__restrict__ r, double *__restrict__ out)
 {
@@ -1392,7 +1405,8 @@ int launch_cg(tb_pattern *pat, const double *A, const double *b, double *x, doub
 // true one), classical Gram–Schmidt with one re-orthogonalisation pass so that a whole Arnoldi step is eight launches and one
 // host read: h = Vᵀw and w −= V h are single kernels over all basis vectors.
 // ------------------------------------------------------------------------------------------------
-// out[j] += V[j]·w for j < k (blockIdx.y = j)
+// out[j · GM_HS] += V[j]·w for j < k (blockIdx.y = j)
+constexpr int GM_HS = 16; // doubles between two Arnoldi coefficients on the device
 __global__ void __launch_bounds__(256)
 k_multi_dot(int64_t n, const double *__restrict__ V, const double *__restrict__ w, double *__restrict__ out)
 {
@@ -1400,17 +1414,17 @@ k_multi_dot(int64_t n, const double *__restrict__ V, const double *__restrict__ 
     double s = 0.0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) s += v[i] * w[i];
-    block_sum_to(s, out + blockIdx.y);
+    block_sum_to(s, out + (size_t)blockIdx.y * GM_HS); // one 128-byte line per result: atomics on one line serialise ("reduction slots" below)
 }
 // w += sign · Σ_{j<k} c[j] V[j];  optionally ww += w·w of the result
-__global__ void __launch_bounds__(256)
-k_multi_axpy(int64_t n, int k, double sign, const double *__restrict__ c, const double *__restrict__ V, double *__restrict__ w, double *__restrict__ ww)
+__global__ void __launch_bounds__(1024)
+k_multi_axpy(int64_t n, int k, double sign, const double *__restrict__ c, int cstride, const double *__restrict__ V, double *__restrict__ w, double *__restrict__ ww)
 {
     double acc = 0.0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         double s = 0.0;
-        for (int j = 0; j < k; ++j) s += c[j] * V[(int64_t)j * n + i];
+        for (int j = 0; j < k; ++j) s += c[(size_t)j * cstride] * V[(int64_t)j * n + i];
         const double r = w[i] + sign * s;
         w[i] = r;
         acc += r * r;
@@ -1450,15 +1464,15 @@ int launch_gmres(tb_pattern *pat, const double *A, const double *b, double *x, d
     if (pat->gmres_m < m) {
         if (pat->d_gmres_ws) TB_HIP(hipFree(pat->d_gmres_ws));
         pat->d_gmres_ws = nullptr;
-        TB_HIP(hipMalloc((void **)&pat->d_gmres_ws, sizeof(double) * ((size_t)(m + 4) * n + 3 * (size_t)(m + 2))));
+        TB_HIP(hipMalloc((void **)&pat->d_gmres_ws, sizeof(double) * ((size_t)(m + 4) * n + (2 * GM_HS + 1) * (size_t)(m + 2))));
         pat->gmres_m = m;
     }
-    double *V = pat->d_gmres_ws, *w = V + (size_t)(m + 1) * n, *z = w + n, *dinv = z + n, *sc = dinv + n; // sc: h1[m+2] | h2[m+2] | y[m+2]
-    double *h1 = sc, *h2 = sc + (m + 2), *yd = sc + 2 * (m + 2);
+    double *V = pat->d_gmres_ws, *w = V + (size_t)(m + 1) * n, *z = w + n, *dinv = z + n, *sc = dinv + n; // sc: h1[(m+2)·GM_HS] | h2[(m+2)·GM_HS] | y[m+2]
+    double *h1 = sc, *h2 = sc + (size_t)(m + 2) * GM_HS, *yd = sc + 2 * (size_t)(m + 2) * GM_HS;
     const unsigned g = grid_for(dev, n, 256);
     if (jacobi) { const int rcd = launch_extract_diag(pat, A, dinv); if (rcd) return rcd; }
     const double *dp = jacobi ? dinv : nullptr;
-    std::vector<double> H((size_t)(m + 1) * m), cs(m), sn(m), gvec(m + 1), yh(m), hh(2 * (m + 2));
+    std::vector<double> H((size_t)(m + 1) * m), cs(m), sn(m), gvec(m + 1), yh(m), hh(2 * (size_t)(m + 2) * GM_HS);
     int it = 0;
     double rnorm = 0.0, tol = 0.0;
     bool first = true;
@@ -1483,16 +1497,18 @@ int launch_gmres(tb_pattern *pat, const double *A, const double *b, double *x, d
             hipLaunchKernelGGL(k_scale_diag, dim3(g), dim3(256), 0, dev->stream, n, 1.0, dp, V + (size_t)j * n, z);
             rc = launch_spmv(pat, A, z, 1.0, 0.0, w);
             if (rc) return rc;
-            TB_HIP(hipMemsetAsync(sc, 0, sizeof(double) * 2 * (m + 2), dev->stream));
-            hipLaunchKernelGGL(k_multi_dot, dim3(g, j + 1), dim3(256), 0, dev->stream, n, V, w, h1);
-            hipLaunchKernelGGL(k_multi_axpy, dim3(g), dim3(256), 0, dev->stream, n, j + 1, -1.0, h1, V, w, (double *)nullptr);
-            hipLaunchKernelGGL(k_multi_dot, dim3(g, j + 1), dim3(256), 0, dev->stream, n, V, w, h2);
-            hipLaunchKernelGGL(k_multi_axpy, dim3(g), dim3(256), 0, dev->stream, n, j + 1, -1.0, h2, V, w, h2 + (m + 1)); // ‖w‖² in the last slot
-            TB_HIP(hipMemcpyAsync(hh.data(), sc, sizeof(double) * 2 * (m + 2), hipMemcpyDeviceToHost, dev->stream));
+            TB_HIP(hipMemsetAsync(sc, 0, sizeof(double) * 2 * (m + 2) * GM_HS, dev->stream));
+            // every workgroup of a dot ends in one atomic on its vector's result: ≈ 8 per CU in all (j + 1 vectors share them), each result on a line of its own
+            const unsigned gd = std::max(1u, std::min(g, (unsigned)dev->n_cu * 8u / (unsigned)(j + 1)));
+            hipLaunchKernelGGL(k_multi_dot, dim3(gd, j + 1), dim3(256), 0, dev->stream, n, V, w, h1);
+            hipLaunchKernelGGL(k_multi_axpy, dim3(grid_red(dev, n)), dim3(1024), 0, dev->stream, n, j + 1, -1.0, h1, GM_HS, V, w, (double *)nullptr);
+            hipLaunchKernelGGL(k_multi_dot, dim3(gd, j + 1), dim3(256), 0, dev->stream, n, V, w, h2);
+            hipLaunchKernelGGL(k_multi_axpy, dim3(grid_red(dev, n)), dim3(1024), 0, dev->stream, n, j + 1, -1.0, h2, GM_HS, V, w, h2 + (size_t)(m + 1) * GM_HS); // ‖w‖² in the last slot
+            TB_HIP(hipMemcpyAsync(hh.data(), sc, sizeof(double) * 2 * (m + 2) * GM_HS, hipMemcpyDeviceToHost, dev->stream));
             TB_HIP(hipStreamSynchronize(dev->stream));
             double *Hj = H.data() + (size_t)j * (m + 1);
-            for (int i = 0; i <= j; ++i) Hj[i] = hh[i] + hh[(m + 2) + i];
-            const double wn = std::sqrt(hh[(m + 2) + (m + 1)]);
+            for (int i = 0; i <= j; ++i) Hj[i] = hh[(size_t)i * GM_HS] + hh[((size_t)(m + 2) + i) * GM_HS];
+            const double wn = std::sqrt(hh[((size_t)(m + 2) + (m + 1)) * GM_HS]);
             Hj[j + 1] = wn;
             if (!std::isfinite(wn)) { set_error("tb_gmres_solve: breakdown (non-finite Arnoldi vector)"); return TB_ERR_BAD_ARG; }
             for (int i = 0; i < j; ++i) { const double t = cs[i] * Hj[i] + sn[i] * Hj[i + 1]; Hj[i + 1] = -sn[i] * Hj[i] + cs[i] * Hj[i + 1]; Hj[i] = t; }
@@ -1512,7 +1528,7 @@ int launch_gmres(tb_pattern *pat, const double *A, const double *b, double *x, d
         }
         TB_HIP(hipMemcpyAsync(yd, yh.data(), sizeof(double) * j, hipMemcpyHostToDevice, dev->stream));
         TB_HIP(hipMemsetAsync(z, 0, sizeof(double) * n, dev->stream));
-        hipLaunchKernelGGL(k_multi_axpy, dim3(g), dim3(256), 0, dev->stream, n, j, 1.0, yd, V, z, (double *)nullptr);
+        hipLaunchKernelGGL(k_multi_axpy, dim3(grid_red(dev, n)), dim3(1024), 0, dev->stream, n, j, 1.0, yd, 1, V, z, (double *)nullptr);
         hipLaunchKernelGGL(k_add_diag, dim3(g), dim3(256), 0, dev->stream, n, dp, z, x);
         TB_HIP(hipStreamSynchronize(dev->stream)); // yh is reused by the next cycle
     }
@@ -1633,7 +1649,7 @@ int launch_pcg_l1gs(tb_pattern *pat, const double *A, const double *b, double *x
         rc = launch_l1gs_apply(pat, A, dtl, ps, 1, r, z);
         if (rc) return rc;
         TB_HIP(hipMemsetAsync(scal, 0, 2 * sizeof(double), dev->stream));
-        hipLaunchKernelGGL(k_dot, dim3(g), dim3(256), 0, dev->stream, n, r, z, scal);
+        hipLaunchKernelGGL(k_dot, dim3(grid_red(dev, n)), dim3(1024), 0, dev->stream, n, r, z, scal);
         TB_HIP(hipMemcpyAsync(h, scal, sizeof(double), hipMemcpyDeviceToHost, dev->stream));
         TB_HIP(hipStreamSynchronize(dev->stream));
         const double rz_new = h[0];
@@ -1643,13 +1659,13 @@ int launch_pcg_l1gs(tb_pattern *pat, const double *A, const double *b, double *x
         rc = launch_spmv(pat, A, p, 1.0, 0.0, Ap);
         if (rc) return rc;
         TB_HIP(hipMemsetAsync(scal, 0, 2 * sizeof(double), dev->stream));
-        hipLaunchKernelGGL(k_dot, dim3(g), dim3(256), 0, dev->stream, n, p, Ap, scal);
+        hipLaunchKernelGGL(k_dot, dim3(grid_red(dev, n)), dim3(1024), 0, dev->stream, n, p, Ap, scal);
         TB_HIP(hipMemcpyAsync(h, scal, sizeof(double), hipMemcpyDeviceToHost, dev->stream));
         TB_HIP(hipStreamSynchronize(dev->stream));
         if (!(h[0] > 0.0)) { set_error("tb_pcg_solve: matrix is not positive definite (pᵀAp = %g)", h[0]); return TB_ERR_BAD_ARG; }
         const double alpha = rz / h[0];
         TB_HIP(hipMemsetAsync(scal, 0, 2 * sizeof(double), dev->stream));
-        hipLaunchKernelGGL(k_cg_update, dim3(g), dim3(256), 0, dev->stream, n, alpha, p, Ap, (const double *)nullptr, x, r, scal);
+        hipLaunchKernelGGL(k_cg_update, dim3(grid_red(dev, n)), dim3(1024), 0, dev->stream, n, alpha, p, Ap, (const double *)nullptr, x, r, scal);
         TB_HIP(hipMemcpyAsync(h, scal, 2 * sizeof(double), hipMemcpyDeviceToHost, dev->stream));
         TB_HIP(hipStreamSynchronize(dev->stream));
         rnorm = std::sqrt(h[1]);
@@ -1713,7 +1729,7 @@ __global__ void __launch_bounds__(256) k_mul_to(int64_t n, const double *__restr
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = a[i] * b[i];
 }
 // w = sq∘w − β v₋₁;  out += w·v
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_lanczos_a(int64_t n, const double *__restrict__ sq, double beta, const double *__restrict__ vp, const double *__restrict__ v, double *__restrict__ w, double *__restrict__ out)
 {
     double a = 0.0;
@@ -1726,7 +1742,7 @@ k_lanczos_a(int64_t n, const double *__restrict__ sq, double beta, const double 
     block_sum_to(a, out);
 }
 // w −= α v;  out += w·w
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_lanczos_b(int64_t n, double alpha, const double *__restrict__ v, double *__restrict__ w, double *__restrict__ out)
 {
     double a = 0.0;
@@ -1752,7 +1768,7 @@ k_pcg_direction_dev(int64_t n, const double *__restrict__ rz, const double *__re
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = z[i] + beta * p[i];
 }
 // x += α p, r −= α Ap with α = rz_new / pAp from device scalars; rr += r·r; a non-positive pAp is remembered in *flag
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_pcg_update_dev(int64_t n, const double *__restrict__ rz_new, const double *__restrict__ pAp, const double *__restrict__ p, const double *__restrict__ Ap,
                  double *__restrict__ x, double *__restrict__ r, double *__restrict__ rr, double *__restrict__ flag)
 {
@@ -1793,7 +1809,7 @@ int launch_pcg_chebyshev(tb_pattern *pat, const double *A, const double *b, doub
         double *v = z, *vp = p, *t = Ap, *sq = d; // scratch: the solver's vectors are not in use yet
         hipLaunchKernelGGL(k_lanczos_init, dim3(g), dim3(256), 0, dev->stream, n, dinv, w, sq, v, vp);
         TB_HIP(hipMemsetAsync(S + 8, 0, 2 * sizeof(double), dev->stream));
-        hipLaunchKernelGGL(k_dot, dim3(g), dim3(256), 0, dev->stream, n, v, v, S + 8);
+        hipLaunchKernelGGL(k_dot, dim3(grid_red(dev, n)), dim3(1024), 0, dev->stream, n, v, v, S + 8);
         TB_HIP(hipMemcpyAsync(h, S + 8, sizeof(double), hipMemcpyDeviceToHost, dev->stream));
         TB_HIP(hipStreamSynchronize(dev->stream));
         int kdone = 0;
@@ -1805,11 +1821,11 @@ int launch_pcg_chebyshev(tb_pattern *pat, const double *A, const double *b, doub
                 rc = launch_spmv(pat, A, t, 1.0, 0.0, w);                                                    // w = A t
                 if (rc) return rc;
                 TB_HIP(hipMemsetAsync(S + 8, 0, 2 * sizeof(double), dev->stream));
-                hipLaunchKernelGGL(k_lanczos_a, dim3(g), dim3(256), 0, dev->stream, n, sq, be[k], vp, v, w, S + 8); // w = D^-½ w − β v₋₁; α = w·v
+                hipLaunchKernelGGL(k_lanczos_a, dim3(grid_red(dev, n)), dim3(1024), 0, dev->stream, n, sq, be[k], vp, v, w, S + 8); // w = D^-½ w − β v₋₁; α = w·v
                 TB_HIP(hipMemcpyAsync(h, S + 8, sizeof(double), hipMemcpyDeviceToHost, dev->stream));
                 TB_HIP(hipStreamSynchronize(dev->stream));
                 al[k] = h[0];
-                hipLaunchKernelGGL(k_lanczos_b, dim3(g), dim3(256), 0, dev->stream, n, al[k], v, w, S + 9);  // w −= α v; ‖w‖²
+                hipLaunchKernelGGL(k_lanczos_b, dim3(grid_red(dev, n)), dim3(1024), 0, dev->stream, n, al[k], v, w, S + 9);  // w −= α v; ‖w‖²
                 TB_HIP(hipMemcpyAsync(h, S + 9, sizeof(double), hipMemcpyDeviceToHost, dev->stream));
                 TB_HIP(hipStreamSynchronize(dev->stream));
                 kdone = k + 1;
@@ -1873,12 +1889,12 @@ int launch_pcg_chebyshev(tb_pattern *pat, const double *A, const double *b, doub
             // rz ← rz_new of the previous iteration; rz_new = r·z
             TB_HIP(hipMemcpyAsync(S, S + 1, sizeof(double), hipMemcpyDeviceToDevice, dev->stream));
             TB_HIP(hipMemsetAsync(S + 1, 0, 3 * sizeof(double), dev->stream));
-            hipLaunchKernelGGL(k_dot, dim3(g), dim3(256), 0, dev->stream, n, r, z, S + 1);
+            hipLaunchKernelGGL(k_dot, dim3(grid_red(dev, n)), dim3(1024), 0, dev->stream, n, r, z, S + 1);
             hipLaunchKernelGGL(k_pcg_direction_dev, dim3(g), dim3(256), 0, dev->stream, n, S, S + 1, z, p);
             rc = launch_spmv(pat, A, p, 1.0, 0.0, Ap);
             if (rc) return rc;
-            hipLaunchKernelGGL(k_dot, dim3(g), dim3(256), 0, dev->stream, n, p, Ap, S + 2);
-            hipLaunchKernelGGL(k_pcg_update_dev, dim3(g), dim3(256), 0, dev->stream, n, S + 1, S + 2, p, Ap, x, r, S + 3, S + 4);
+            hipLaunchKernelGGL(k_dot, dim3(grid_red(dev, n)), dim3(1024), 0, dev->stream, n, p, Ap, S + 2);
+            hipLaunchKernelGGL(k_pcg_update_dev, dim3(grid_red(dev, n)), dim3(1024), 0, dev->stream, n, S + 1, S + 2, p, Ap, x, r, S + 3, S + 4);
         }
         TB_HIP(hipMemcpyAsync(h, S + 3, 2 * sizeof(double), hipMemcpyDeviceToHost, dev->stream));
         TB_HIP(hipStreamSynchronize(dev->stream));
@@ -2169,7 +2185,7 @@ int launch_dot(tb_device *dev, int64_t n, const double *a, const double *b, doub
     double *scal = (double *)&dev->d_status->cell; // 8-byte scratch inside the status block
     TB_HIP(hipMemsetAsync(scal, 0, sizeof(double), dev->stream));
     if (n > 0) {
-        hipLaunchKernelGGL(k_dot, dim3(grid_for(dev, n, 256)), dim3(256), 0, dev->stream, n, a, b, scal);
+        hipLaunchKernelGGL(k_dot, dim3(grid_red(dev, n)), dim3(1024), 0, dev->stream, n, a, b, scal);
         TB_HIP(hipGetLastError());
     }
     TB_HIP(hipMemcpyAsync(result, scal, sizeof(double), hipMemcpyDeviceToHost, dev->stream));
