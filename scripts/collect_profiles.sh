@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 out=gpurun_out/$tag
 mkdir -p "$out"
 # micro-benchmarks are built here (binaries are not tracked)
-for mb in mfma_f64 mfma_f64_4x4 lds_atomic wg_launch mall_reuse sell_spmv partial_rows; do
+for mb in mfma_f64 mfma_f64_4x4 lds_atomic wg_launch mall_reuse sell_spmv partial_rows tail_atomics; do
   [ -f scripts/microbench/$mb.hip ] && hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics scripts/microbench/$mb.hip -o scripts/microbench/$mb.bin 2>/dev/null
 done
 python3 bench.py > "$out/bench_216.json" 2> "$out/bench_216.err"
@@ -34,6 +34,8 @@ if [ "$2" != "bench-only" ]; then
   [ -x scripts/microbench/lds_atomic.bin ] && ./scripts/microbench/lds_atomic.bin > "$out/lds_atomic_microbench.txt" 2>&1
   [ -x scripts/microbench/mfma_f64_4x4.bin ] && ./scripts/microbench/mfma_f64_4x4.bin > "$out/mfma_f64_4x4_microbench.txt" 2>&1
   [ -x scripts/microbench/partial_rows.bin ] && ./scripts/microbench/partial_rows.bin > "$out/partial_rows_microbench.txt" 2>&1
+  [ -x scripts/microbench/tail_atomics.bin ] && ./scripts/microbench/tail_atomics.bin > "$out/tail_atomics_microbench.txt" 2>&1
+  python3 scripts/gmres_time.py 128 > "$out/krylov_solves_128.txt" 2>/dev/null
   python3 scripts/bench_tets.py --n 100 > "$out/tets_100.json" 2>/dev/null
   # coupled electromechanics on the ideal LV (config 5 as two kernel rates)
   python3 scripts/bench_electromechanics.py > "$out/electromechanics_lv.json" 2>/dev/null
