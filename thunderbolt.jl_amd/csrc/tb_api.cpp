@@ -320,7 +320,7 @@ int tb_mesh_destroy(tb_mesh *m)
     if (!m) return TB_OK;
     hipFree(m->d_xyz); hipFree(m->d_conn); hipFree(m->d_cell_dofs); hipFree(m->d_node_dof0); hipFree(m->d_cell_xyz); hipFree(m->d_rank27);
     if (m->colors) hipFree(m->colors->d_cells);
-    if (m->ea) { hipFree(m->ea->d_ptr); hipFree(m->ea->d_src); hipFree(m->ea->d_ea); hipFree(m->ea->d_ell); }
+    if (m->ea) { hipFree(m->ea->d_ptr); hipFree(m->ea->d_src); hipFree(m->ea->d_ea); hipFree(m->ea->d_ell); hipFree(m->ea->d_ell_t); }
     free_patch_plan(m);
     free_vec_patch_plans(m);
     delete m;
@@ -380,7 +380,7 @@ int tb_pattern_destroy(tb_pattern *p)
 {
     if (!p) return TB_OK;
     { std::lock_guard<std::mutex> lock(g_mirrored_mutex); g_mirrored.erase(std::remove(g_mirrored.begin(), g_mirrored.end(), p), g_mirrored.end()); }
-    hipFree(p->d_rowptr); hipFree(p->d_colidx); hipFree(p->d_blkrow); hipFree(p->d_blkrec); hipFree(p->d_rowsig); hipFree(p->d_sigoff); hipFree(p->d_wrunrec); for (double *q : p->d_mir) hipFree(q); hipFree(p->d_mir_base); hipFree(p->d_mir_off); hipFree(p->d_bcol); hipFree(p->d_diagpos); hipFree(p->d_emap); hipFree(p->d_blockpos); hipFree(p->d_cg_ws); hipFree(p->d_gmres_ws); hipFree(p->d_pcg_ws); hipFree(p->d_cheb_ws); hipFree(p->d_q2pos); hipFree(p->d_kebuf); hipFree(p->d_qpbuf); hipFree(p->d_gnodes);
+    hipFree(p->d_rowptr); hipFree(p->d_colidx); hipFree(p->d_blkrow); hipFree(p->d_blkrec); hipFree(p->d_rowsig); hipFree(p->d_sigoff); hipFree(p->d_wrunrec); for (double *q : p->d_mir) hipFree(q); hipFree(p->d_mir_base); hipFree(p->d_mir_off); hipFree(p->d_bcol); hipFree(p->d_diagpos); hipFree(p->d_emap); hipFree(p->d_blockpos); hipFree(p->d_cg_ws); hipFree(p->d_gmres_ws); hipFree(p->d_pcg_ws); hipFree(p->d_cheb_ws); hipFree(p->d_q2pos); hipFree(p->d_q2pos_t); hipFree(p->d_kebuf); hipFree(p->d_qpbuf); hipFree(p->d_gnodes);
     free_patch_mat_plan(p);
     free_patch_fused_plan(p);
     delete p;

@@ -704,13 +704,17 @@ static int run_matrix_form(tb_form *f, tb_pattern *p, int strategy, double t, do
 // per colour.  Constant and first-order nodal coefficients (the reference's mass.jl:28-43 / diffusion.jl:28-50); sources: k_vector_q2.
 // ------------------------------------------------------------------------------------------------
 // position of column dof(j) inside row dof(i), per cell and pair (cell-major: one coalesced 729-entry read per workgroup)
+// TL: the table in the order of the stored element matrices of the element strategy (k_matrix_q2_sf: entry 27·(i₀ + 3 i₁ + 9 i₂) + 9 j₂ + 3 j₀ + j₁)
+__device__ __constant__ uint8_t g_q2_node_b[27] = {0, 8, 1, 11, 20, 9, 3, 10, 2, 16, 21, 17, 24, 26, 22, 19, 23, 18, 4, 12, 5, 15, 25, 13, 7, 14, 6}; // (= g_q2_node below)
+template <bool TL>
 __global__ void k_build_q2pos(const int32_t *__restrict__ cell_dofs, int64_t n_cells, const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
                               uint16_t *__restrict__ pos, Status *st)
 {
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= n_cells * 729) return;
     const int64_t cell = tid / 729;
-    const int i = (int)(tid % 729) / 27, j = (int)(tid % 27);
+    int i = (int)(tid % 729) / 27, j = (int)(tid % 27);
+    if (TL) { i = g_q2_node_b[i]; j = g_q2_node_b[(j / 3) % 3 + 3 * (j % 3) + 9 * (j / 9)]; }
     const int32_t *d = cell_dofs + cell * 27;
     const int32_t row = d[i], col = d[j];
     const int64_t lo0 = rowptr[row], hi0 = rowptr[row + 1];
@@ -1142,12 +1146,17 @@ k_matrix_q2_sf(MeshView m, FormArgs fa, const double *__restrict__ cell_xyz, con
                     }
             }
             const int64_t pbase = cell * 729;
+            // stored element matrices (atomic == 2) in TENSOR order: row i₀ + 3 i₁ + 9 i₂, column 9 j₂ + 3 j₀ + j₁, so that the nine lanes (j₀, j₁) of a
+            // row store nine consecutive doubles and the three stores j₂ = 0, 1, 2 complete its 216 bytes (in Ferrite's node order the 64 lanes of a
+            // store hit 64 separate 8-byte pieces of the 5.8 KB block: the mass kernel, whose arithmetic is a fifth of the diffusion kernel's, took 0.49
+            // of that one's 0.61 ms — bound by the store path); k_gather_rows_q2<true> reads the rows in this order
+            const int etl = 27 * (ti0 + 3 * ti1) + 3 * tj0 + tj1;
 #pragma unroll
             for (int i2 = 0; i2 < 3; ++i2)
 #pragma unroll
                 for (int j2 = 0; j2 < 3; ++j2) {
                     const int e = 27 * rowi[i2] + colj[j2];
-                    if (atomic == 2) ke[pbase + e] = out[i2][j2];
+                    if (atomic == 2) ke[pbase + etl + 243 * i2 + 9 * j2] = out[i2][j2];
                     else {
                         const int64_t k = rowptr[m.cell_dofs[cell * 27 + rowi[i2]]] + pos[pbase + e];
                         if (atomic) unsafeAtomicAdd(nz + k, out[i2][j2]); else nz[k] += out[i2][j2];
@@ -1162,6 +1171,10 @@ k_matrix_q2_sf(MeshView m, FormArgs fa, const double *__restrict__ cell_xyz, con
 // (27 lanes, an LDS copy of the CSR row, cells in ascending order: bit-reproducible) and stores the CSR row once.  The contributing (cell, local row)
 // slots come from a fixed-width table (W per row, −1 padded: one load, no pointer chase) and the index and value loads of eight cells are all in
 // flight before the first addition.
+// The element matrices of k_matrix_q2_sf are stored in tensor order (row i₀ + 3 i₁ + 9 i₂, column 9 j₂ + 3 j₀ + j₁); the element strategy then hands this
+// kernel the slot table and the position table in the same order (tb_mesh ea->d_ell_t, tb_pattern::d_q2pos_t), so the loads below stay one contiguous
+// run per row.  (Permuting inside this kernel instead — a row look-up between the slot load and the value load, the positions as scattered 2-byte
+// reads — was measured: 0.69 → 0.86 ms.)
 __global__ void __launch_bounds__(256)
 k_gather_rows_q2(int64_t row0, int64_t n_rows, const int32_t *__restrict__ ell, int W, const double *__restrict__ ke, const uint16_t *__restrict__ pos,
                  const int64_t *__restrict__ rowptr, double *__restrict__ nz, int max_row)
@@ -1264,7 +1277,21 @@ static int ensure_q2pos(tb_pattern *p)
     TB_HIP(hipMalloc((void **)&p->d_q2pos, sizeof(uint16_t) * n));
     int rc = reset_status(m->dev);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_build_q2pos, dim3(nblocks(n, 256)), dim3(256), 0, m->dev->stream, m->d_cell_dofs, m->n_cells, p->d_rowptr, p->d_colidx, p->d_q2pos,
+    hipLaunchKernelGGL(k_build_q2pos<false>, dim3(nblocks(n, 256)), dim3(256), 0, m->dev->stream, m->d_cell_dofs, m->n_cells, p->d_rowptr, p->d_colidx, p->d_q2pos,
+                       m->dev->d_status);
+    TB_HIP(hipGetLastError());
+    return check_status(m->dev);
+}
+// the same table in the order of the stored element matrices (element strategy)
+static int ensure_q2pos_t(tb_pattern *p)
+{
+    if (p->d_q2pos_t) return TB_OK;
+    tb_mesh *m = p->mesh;
+    const int64_t n = m->n_cells * 729;
+    TB_HIP(hipMalloc((void **)&p->d_q2pos_t, sizeof(uint16_t) * n));
+    int rc = reset_status(m->dev);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_build_q2pos<true>, dim3(nblocks(n, 256)), dim3(256), 0, m->dev->stream, m->d_cell_dofs, m->n_cells, p->d_rowptr, p->d_colidx, p->d_q2pos_t,
                        m->dev->d_status);
     TB_HIP(hipGetLastError());
     return check_status(m->dev);
@@ -1334,10 +1361,20 @@ static int run_q2(tb_form *f, tb_pattern *p, int strategy, double t, double *d_n
         const int max_row = (int)p->max_row_len;
         int rc = ensure_ea_ell(m);
         if (rc) return rc;
+        static const bool q2_mfma_g = tune_env("TB_Q2_KERNEL") && !strcmp(tune_env("TB_Q2_KERNEL"), "mfma"); // (the matrix-core kernel stores Ferrite's order)
+        const int32_t *ell = m->ea->d_ell;
+        const uint16_t *posg = p->d_q2pos;
+        if (!q2_mfma_g) {
+            rc = ensure_q2pos_t(p);
+            if (rc) return rc;
+            rc = ensure_ea_ell_q2t(m);
+            if (rc) return rc;
+            ell = m->ea->d_ell_t; posg = p->d_q2pos_t;
+        }
         auto gather = [&](hipStream_t st, int64_t r0, int64_t r1) {
             if (r1 > r0)
-                hipLaunchKernelGGL(k_gather_rows_q2, dim3((unsigned)((r1 - r0 + 7) / 8)), dim3(256), sizeof(double) * 8 * (size_t)max_row, st, r0, r1, m->ea->d_ell, m->ea->ell_w, kebuf,
-                                   p->d_q2pos, p->d_rowptr, d_nz, max_row);
+                hipLaunchKernelGGL(k_gather_rows_q2, dim3((unsigned)((r1 - r0 + 7) / 8)), dim3(256), sizeof(double) * 8 * (size_t)max_row, st, r0, r1, ell, m->ea->ell_w, kebuf,
+                                   posg, p->d_rowptr, d_nz, max_row);
         };
         // (a chunked form — gather of a chunk's rows on a second queue beside the integration of the next chunk, the scheme of the mechanics linearisation —
         // was built, bit-identical and slower: 1.43 / 1.53 / 1.64 ms in 4 / 8 / 16 chunks against 1.31 ms at 64³; removed in round 5, docs/rounds/r04.md)

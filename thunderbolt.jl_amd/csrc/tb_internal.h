@@ -66,6 +66,7 @@ struct EAPlan {                // dof → contributing (cell, local) slots, cell
     int32_t *d_src = nullptr;  // n_cells*ndpc indices into the element-vector buffer
     double *d_ea = nullptr;    // n_cells*ndpc element vectors
     int32_t *d_ell = nullptr;  // the same slots as a fixed-width table (ell_w per dof, −1 padded), built on first use by ensure_ea_ell
+    int32_t *d_ell_t = nullptr; // scalar Q2: the table with the local row of every slot replaced by its tensor index i₀ + 3 i₁ + 9 i₂ (ensure_ea_ell_q2t)
     int ell_w = 0;
     std::vector<int32_t> h_done; // per dof (scalar fields; built with d_ell): running maximum of the last contributing cell — the dofs before the first one whose
                                  // value reaches c are complete once cells [0, c) are integrated (chunked element assembly: gather behind the integration front)
@@ -233,6 +234,7 @@ struct tb_pattern {
     uint32_t *d_wrunrec = nullptr;  // wave-private SpMV (TB_SPMV_KERNEL=wave): runs of ≤ 21 rows as 16-byte records
     int64_t n_wrun = 0;
     uint16_t *d_q2pos = nullptr;    // scalar Q2 forms: position of col dof(j) in row dof(i), per cell and pair
+    uint16_t *d_q2pos_t = nullptr;  // the same in the order of the stored element matrices (element strategy: tensor order, k_matrix_q2_sf)
     double *d_pcg_ws = nullptr;     // general-preconditioner PCG workspace (r, z, p, Ap, D̃, scalars)
     double *d_cheb_ws = nullptr;    // Chebyshev-preconditioned CG workspace (r, z, p, Ap, D⁻¹, d, w, scalars)
     double *d_gmres_ws = nullptr;   // GMRES workspace: (restart+1) basis vectors + 3 vectors + scalars
@@ -301,6 +303,7 @@ int build_color_plan(tb_mesh *m);
 int build_color_plan_subset(tb_mesh *m, const std::vector<int32_t> &cells, std::unique_ptr<ColorPlan> &out);
 int build_ea_plan(tb_mesh *m);
 int ensure_ea_ell(tb_mesh *m);
+int ensure_ea_ell_q2t(tb_mesh *m);
 int build_patch_plan(tb_mesh *m, int cells_per_patch);
 int build_patch_mat_plan(tb_pattern *p);
 int ensure_patch_records(tb_pattern *p); // one-trip records of the fused plan (after ensure_patch_fused); TB_ERR_UNSUPPORTED when the patches do not fit the form

@@ -39,6 +39,22 @@ int build_ea_plan(tb_mesh *m)
     return TB_OK;
 }
 
+// scalar Q2 element strategy: the slot table for element matrices stored in tensor order (slot = cell · 27 + i₀ + 3 i₁ + 9 i₂ of the local row)
+int ensure_ea_ell_q2t(tb_mesh *m)
+{
+    int rc = ensure_ea_ell(m);
+    if (rc) return rc;
+    if (m->ea->d_ell_t) return TB_OK;
+    if (m->ndpc != 27) { set_error("tensor-order slot table: needs 27 dofs per cell"); return TB_ERR_UNSUPPORTED; }
+    static const uint8_t trow[27] = {0, 2, 8, 6, 18, 20, 26, 24, 1, 5, 7, 3, 19, 23, 25, 21, 9, 11, 17, 15, 4, 10, 14, 16, 12, 22, 13}; // Ferrite node → tensor index
+    std::vector<int32_t> ell((size_t)m->ndofs * m->ea->ell_w);
+    TB_HIP(hipMemcpy(ell.data(), m->ea->d_ell, ell.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+#pragma omp parallel for schedule(static)
+    for (int64_t k = 0; k < (int64_t)ell.size(); ++k)
+        if (ell[k] >= 0) ell[k] = ell[k] / 27 * 27 + trow[ell[k] % 27];
+    return upload(m->dev, ell, &m->ea->d_ell_t);
+}
+
 // fixed-width form of the slot lists (width = the largest number of cells at a dof, rounded up to a multiple of 8)
 int ensure_ea_ell(tb_mesh *m)
 {
