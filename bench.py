@@ -72,6 +72,8 @@ def parse():
     ap.add_argument("--no-slab-sweep", action="store_true", help="N = 1: skip the timing of the n×n×{n/2, n/4, n/8} slabs (strong-scaling prediction)")
     ap.add_argument("--strategy", default="patch", choices=["patch", "atomic", "color"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--phase-events", choices=("all", "matrix", "none"), default="all",
+                    help="HIP events recorded inside the timed steps: all six phase boundaries, only the two around the matrix pass, or none (diagnostic: what the instrumentation costs)")
     ap.add_argument("--no-graph", action="store_true", help="N = 1: skip the HIP-graph forms of the step and of the CG iteration (tb_graph_*)")
     ap.add_argument("--no-dist-cg", action="store_true", help="skip the (untimed-region) distributed CG iteration measurement")
     ap.add_argument("--cpu-n", type=int, default=64, help="edge of the CPU-baseline sample mesh")
@@ -319,30 +321,34 @@ def main():
             self.u = torch.from_numpy(np.ascontiguousarray(u0.T).ravel()).cuda()
             self.f = tb.PointwiseODEFunction(npts, model)
             self.cache = tb.setup_solver_cache(self.f, tb.ForwardEulerCellSolver(dev), u=self.u, keep_du=args.keep_du)
-            self.ev = [dev.event() for _ in range(6)]
+            self.evpool = []
             self.phase = {"mass": 0.0, "diffusion": 0.0, "source": 0.0, "halo": 0.0, "reaction": 0.0}   # fused: "diffusion" holds the M + K pass, "mass" stays 0
 
-        def step(self, i, timed):
-            t, ev = 0.01 * i, self.ev
-            ev[0].record()
+        def step(self, i, ev=None):
+            """one step; ev: six HIP events of THIS step (phase boundaries), read only after the timed region's synchronize — reading them here
+            would wait for the GPU every step, and the host's enqueue time of the next step would sit on the clock (it did through round 4:
+            the same step replayed as a graph was 4–6 % faster, most of it this wait)"""
+            t = 0.01 * i
+            allev = ev is not None and args.phase_events == "all"
+            mev = ev is not None and args.phase_events != "none"
+            if mev and (allev or not fused): ev[0].record()
             if not fused:
                 tb.update_operator(self.M, t)
-            ev[1].record()
+            if mev: ev[1].record()
             if fused:
                 tb.update_operators(self.M, self.K, t)
             else:
                 tb.update_operator(self.K, t)
             if i == 0:
                 self.matrix_kernel = tb.lib().tb_last_kernel_name().decode()   # the instance this call launched (the roofline's kernel)
-            ev[2].record(); tb.update_operator(self.src, t)
-            ev[3].record()
+            if mev: ev[2].record()
+            tb.update_operator(self.src, t)
+            if allev: ev[3].record()
             if self.world > 1:
                 self.halo.exchange_sum(self.b)
-            ev[4].record(); tb.perform_step(self.f, self.cache, t, rdt)
-            ev[5].record()
-            if timed:
-                for k, name in enumerate(self.phase):
-                    self.phase[name] += ev[k].elapsed_ms(ev[k + 1])
+            if allev: ev[4].record()
+            tb.perform_step(self.f, self.cache, t, rdt)
+            if allev: ev[5].record()
 
         def step_plain(self, t):
             """the calls of `step` without the phase events (what a captured step replays; one rank, no halo exchange)"""
@@ -387,8 +393,10 @@ def main():
         def time_steps(self, warmup, steps):
             """W untimed steps, then exactly K steps bracketed by barrier + synchronize on both sides; the MAX over ranks of the wall time"""
             for i in range(warmup):
-                self.step(i, False)                                  # status read after every assembly call: a bad mesh or pattern surfaces here
+                self.step(i)                                         # status read after every assembly call: a bad mesh or pattern surfaces here
             self.sync()
+            while len(self.evpool) < steps:                          # six events per timed step, created outside the clock
+                self.evpool.append([dev.event() for _ in range(6)])
             # the timed steps run with the status deferred (tb_device_defer_status): the mesh is fixed, so the per-call check of the warm-up steps
             # is what a time loop needs; the steps enqueue back to back and the one status read of the region sits inside it, before the clock stops
             dev.defer_status(True)
@@ -397,7 +405,7 @@ def main():
             gc.collect(); gc.disable()                               # no collector pause (freeing buffers of earlier set-up) between the two clock reads
             t0 = time.perf_counter()
             for i in range(steps):
-                self.step(warmup + i, True)
+                self.step(warmup + i, self.evpool[i])
             torch.cuda.synchronize()
             gc.enable()
             dev.poll_status()
@@ -405,6 +413,10 @@ def main():
                 self.dist.barrier()
             dt_ = self.max_over_ranks(time.perf_counter() - t0)
             dev.defer_status(False)
+            for i in range(steps):                                   # phase durations of the timed steps (the events are complete: no wait)
+                for k, name in enumerate(self.phase):
+                    recorded = args.phase_events == "all" or (args.phase_events == "matrix" and (k == 1 or (k == 0 and not fused)))
+                    self.phase[name] += self.evpool[i][k].elapsed_ms(self.evpool[i][k + 1]) if recorded else float("nan")
             return dt_
 
         def time_cg(self, nit=10):
