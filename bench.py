@@ -72,6 +72,10 @@ def parse():
     ap.add_argument("--no-slab-sweep", action="store_true", help="N = 1: skip the timing of the n×n×{n/2, n/4, n/8} slabs (strong-scaling prediction)")
     ap.add_argument("--strategy", default="patch", choices=["patch", "atomic", "color"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--preroll-ms", type=float, default=150.0,
+                    help="untimed GPU work (the loop's own steps) in front of the W warm-up steps of every timed loop, so that the clock reads steady-state "
+                         "throughput: after an idle period (plan building, a host-side pause) the GPU's power management takes ~10 steps of 3 ms to return to full "
+                         "clocks (profiles/r05_v1/clock_ramp_trace.txt: 2.33 -> 1.65 ms for the same kernel); 0 switches it off")
     ap.add_argument("--phase-events", choices=("all", "matrix", "none"), default="all",
                     help="HIP events recorded inside the timed steps: all six phase boundaries, only the two around the matrix pass, or none (diagnostic: what the instrumentation costs)")
     ap.add_argument("--no-graph", action="store_true", help="N = 1: skip the HIP-graph forms of the step and of the CG iteration (tb_graph_*)")
@@ -365,6 +369,7 @@ def main():
             slot): W untimed launches, K timed ones, synchronize on both sides.  One rank only (the halo exchange stays outside graphs)."""
             assert self.world == 1
             gr = dev.capture(lambda: self.step_plain(0.0))
+            self.preroll(lambda i: gr.launch(0.01 * i))
             for i in range(warmup):
                 gr.launch(0.01 * i)
             torch.cuda.synchronize()
@@ -383,6 +388,21 @@ def main():
                 self.dist.barrier()
             torch.cuda.synchronize()
 
+        def preroll(self, fn):
+            """args.preroll_ms of untimed launches of fn(i) back to back, so that a timed loop starts on a GPU at its steady clocks"""
+            if args.preroll_ms <= 0:
+                return
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(3):
+                fn(i)
+            torch.cuda.synchronize()
+            per = max((time.perf_counter() - t0) / 3, 1e-5)
+            n = int(min(max(args.preroll_ms * 1e-3 / per, 1), 2000))
+            for i in range(n):
+                fn(i)
+            torch.cuda.synchronize()
+
         def max_over_ranks(self, x):
             if self.dist is not None:
                 tt = torch.tensor([x], dtype=torch.float64, device=host_red)
@@ -392,17 +412,21 @@ def main():
 
         def time_steps(self, warmup, steps):
             """W untimed steps, then exactly K steps bracketed by barrier + synchronize on both sides; the MAX over ranks of the wall time"""
-            for i in range(warmup):
-                self.step(i)                                         # status read after every assembly call: a bad mesh or pattern surfaces here
-            self.sync()
             while len(self.evpool) < steps:                          # six events per timed step, created outside the clock
                 self.evpool.append([dev.event() for _ in range(6)])
+            gc.collect(); gc.disable()                               # no collector pause (freeing buffers of earlier set-up) inside the region — nor in front of it, where it would let the GPU idle
+            self.step(0)                                             # status read after every assembly call: a bad mesh or pattern surfaces here
+            dev.defer_status(True)
+            self.preroll(lambda i: self.step(i))                     # untimed: clocks (see --preroll-ms)
+            dev.defer_status(False)
+            for i in range(warmup):
+                self.step(i)                                         # the W warm-up steps, status read per call
+            self.sync()
             # the timed steps run with the status deferred (tb_device_defer_status): the mesh is fixed, so the per-call check of the warm-up steps
             # is what a time loop needs; the steps enqueue back to back and the one status read of the region sits inside it, before the clock stops
             dev.defer_status(True)
             for k_ in self.phase:
                 self.phase[k_] = 0.0
-            gc.collect(); gc.disable()                               # no collector pause (freeing buffers of earlier set-up) between the two clock reads
             t0 = time.perf_counter()
             for i in range(steps):
                 self.step(warmup + i, self.evpool[i])
@@ -447,6 +471,7 @@ def main():
             tb._lib.check(tb.lib().tb_cgd_dot(dev.h, npts, cg.w.data_ptr(), rs_.data_ptr(), ps_.data_ptr(), S_[0:1].data_ptr()))
             if world_ > 1:
                 tb.distributed.all_reduce_sum(S_[0:1], xd_)
+            self.preroll(lambda i: cg.device_step(xs_, rs_, ps_, Ap_, S_))
             for _ in range(3):
                 cg.device_step(xs_, rs_, ps_, Ap_, S_)
             self.sync()
@@ -462,6 +487,7 @@ def main():
             if world_ == 1 and not args.no_graph:                     # the same iteration as one HIP-graph launch (no exchange at one rank)
                 try:
                     gr = dev.capture(lambda: cg.device_step(xs_, rs_, ps_, Ap_, S_))
+                    self.preroll(lambda i: gr.launch(0.0))
                     for _ in range(3):
                         gr.launch(0.0)
                     torch.cuda.synchronize()
@@ -640,6 +666,7 @@ def main():
                                       args.strategy, "one fused pass" if fused else "two launches",
                                       " + neighbour halo sum of b" if world > 1 else "", args.ionic.upper()),
                        "mesh": args.mesh,
+                       "preroll_ms": args.preroll_ms,   # untimed steps in front of the W warm-up steps: the GPU's clocks (see --preroll-ms)
                        "cells_total": cells_total, "cells_per_gpu": g.n_cells, "dofs_per_gpu": npts, "nnz_per_gpu": sp.nnz, "ionic_model": args.ionic, "ionic_states": ns,
                        "partition": "z-slabs", "layers_per_gpu": part.nzl, **({"backend": "gloo (shared device, test)"} if share else ({"backend": "nccl (RCCL)" if xd is gd else "RCCL behind the C ABI (tb_comm_*)"} if gd is not None else {}))},
             "dof_updates_per_s": ns * dofs_total * K_ / elapsed,

@@ -39,3 +39,20 @@ for defer in (False, True):
     print("defer_status %s: host enqueue per step %.1f us (M+K %.1f, source %.1f, reaction %.1f; max single call %.1f), wall per step %.1f us" %
           (defer, (t1 - t0) / 20 * 1e6, r[:, 0].mean(), r[:, 1].mean(), r[:, 2].mean(), r.max(), (t2 - t0) / 20 * 1e6))
 dev.defer_status(False)
+
+# the three calls of a step touch disjoint data (matrices | b | states): one stream each, no joins — what do the queues overlap?
+streams = [torch.cuda.Stream() for _ in range(3)]
+def step3(t):
+    dev.set_stream(streams[0].cuda_stream); tb.update_operators(M, K, t)
+    dev.set_stream(streams[1].cuda_stream); tb.update_operator(src, t)
+    dev.set_stream(streams[2].cuda_stream); tb.perform_step(f, cache, t, 0.001)
+dev.defer_status(True)
+for name, fn in (("one stream", lambda t: step(t)), ("three streams", step3), ("one stream", lambda t: step(t)), ("three streams", step3)):
+    for i in range(3): fn(0.01 * i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(40): fn(0.01 * i)
+    torch.cuda.synchronize()
+    print("%-13s wall per step %.1f us" % (name, (time.perf_counter() - t0) / 40 * 1e6))
+    dev.set_stream(torch.cuda.current_stream().cuda_stream)
+dev.defer_status(False)
