@@ -23,6 +23,8 @@ for sname, st in (("atomic", tb.AtomicAssemblyStrategy(dev)), ("color", tb.PerCo
            "source": tb.setup_operator(st, tb.LinearIntegrator(tb.AnalyticalCoefficient("cos_exp")), dh)}
     for name, op in ops.items():
         tb.update_operator(op, 0.1)
+        from _preroll import preroll
+        preroll(dev, lambda: tb.update_operator(op, 0.1), 100.0)   # steady clocks
         e0, e1 = dev.event(), dev.event()
         e0.record()
         for _ in range(args.steps):
