@@ -72,6 +72,7 @@ def parse():
     ap.add_argument("--no-slab-sweep", action="store_true", help="N = 1: skip the timing of the n×n×{n/2, n/4, n/8} slabs (strong-scaling prediction)")
     ap.add_argument("--strategy", default="patch", choices=["patch", "atomic", "color"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap-exchange", action="store_true", help="N > 1: finish the halo sum of b before the reaction step starts (default: posted before, added after)")
     ap.add_argument("--preroll-ms", type=float, default=150.0,
                     help="untimed GPU work (the loop's own steps) in front of the W warm-up steps of every timed loop, so that the clock reads steady-state "
                          "throughput: after an idle period (plan building, a host-side pause) the GPU's power management takes ~10 steps of 3 ms to return to full "
@@ -348,10 +349,18 @@ def main():
             if mev: ev[2].record()
             tb.update_operator(self.src, t)
             if allev: ev[3].record()
+            # the halo sum of b and the reaction step touch disjoint data: the exchange is posted (pack + isend / irecv) in front of the reaction kernel and
+            # its partials are added behind it, so the transfer runs beside the kernel (--no-overlap-exchange: exchange, then reaction).
+            # "halo" = pack + post (+ the whole exchange without overlap); "reaction" then includes the wait and the unpack.
             if self.world > 1:
-                self.halo.exchange_sum(self.b)
+                if args.no_overlap_exchange:
+                    self.halo.exchange_sum(self.b)
+                else:
+                    self.halo.pack(self.b); self.halo.start()
             if allev: ev[4].record()
             tb.perform_step(self.f, self.cache, t, rdt)
+            if self.world > 1 and not args.no_overlap_exchange:
+                self.halo.finish(self.b)
             if allev: ev[5].record()
 
         def step_plain(self, t):
@@ -397,7 +406,7 @@ def main():
             for i in range(3):
                 fn(i)
             torch.cuda.synchronize()
-            per = max((time.perf_counter() - t0) / 3, 1e-5)
+            per = self.max_over_ranks(max((time.perf_counter() - t0) / 3, 1e-5))   # one figure for all ranks: fn may hold an exchange, every rank must launch it equally often
             n = int(min(max(args.preroll_ms * 1e-3 / per, 1), 2000))
             for i in range(n):
                 fn(i)
@@ -664,7 +673,7 @@ def main():
                                        "shuffled": "the %dx%dx%d hex Q1 mesh (%d cells) with cells and nodes RANDOMLY RENUMBERED (unstructured presentation of the same mesh)" % (n, n, nz_total, cells_total),
                                        "lv": "the idealised left-ventricle hex Q1 mesh (%s cells circumferential / radial / longitudinal + O-grid apex: %d cells, %d dofs)" % (args.lv_dims, cells_total, dofs_total)}[args.mesh],
                                       args.strategy, "one fused pass" if fused else "two launches",
-                                      " + neighbour halo sum of b" if world > 1 else "", args.ionic.upper()),
+                                      (" + neighbour halo sum of b" + ("" if args.no_overlap_exchange else " (posted before the reaction step, added behind it)")) if world > 1 else "", args.ionic.upper()),
                        "mesh": args.mesh,
                        "preroll_ms": args.preroll_ms,   # untimed steps in front of the W warm-up steps: the GPU's clocks (see --preroll-ms)
                        "cells_total": cells_total, "cells_per_gpu": g.n_cells, "dofs_per_gpu": npts, "nnz_per_gpu": sp.nnz, "ionic_model": args.ionic, "ionic_states": ns,
