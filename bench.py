@@ -377,6 +377,7 @@ def main():
             """The same step as ONE HIP-graph launch (tb_graph_*: the sequence captured once, the time of every replay set through the device's time
             slot): W untimed launches, K timed ones, synchronize on both sides.  One rank only (the halo exchange stays outside graphs)."""
             assert self.world == 1
+            gc.collect(); gc.disable()                               # (a collector pass over the set-up's arrays is a 40–80 ms pause)
             gr = dev.capture(lambda: self.step_plain(0.0))
             self.preroll(lambda i: gr.launch(0.01 * i))
             for i in range(warmup):
@@ -387,6 +388,7 @@ def main():
                 gr.launch(0.01 * (warmup + i))
             torch.cuda.synchronize()
             el = time.perf_counter() - t0
+            gc.enable()
             dev.poll_status()
             nodes = gr.nodes
             gr.close()
@@ -458,6 +460,7 @@ def main():
             (tb_spmv_csr_dot), received partials added, all-reduce of pᵀAp, update with the two weighted sums, all-reduce, direction.  Barrier-bracketed,
             max over ranks, device scalars, no host read."""
             npts, world_, dist_, xd_ = self.npts, self.world, self.dist, self.xdist
+            gc.collect(); gc.disable()                               # no collector pause inside the short timed loops below
             A = tb.heat_system_matrix(dev, self.M, self.K, 0.01)
             diag = torch.empty(npts, dtype=torch.float64, device="cuda")
             tb._lib.check(tb.lib().tb_extract_diagonal(self.K.pattern.h, A.ptr, diag.data_ptr()))
@@ -521,6 +524,7 @@ def main():
             ed = dev.event()
             ed.record()
             torch.cuda.synchronize()
+            gc.enable()
             return {"iteration_ms": t_it * 1e3, "graph_iteration_ms": None if graph_it is None else graph_it * 1e3, "graph_nodes": graph_nodes, "graph_error": graph_err,
                     "product_halo_dot_ms": ea.elapsed_ms(eb) / nit, "local_spmv_ms": eb.elapsed_ms(ec) / nit,
                     "local_spmv_csr_ms": ec.elapsed_ms(ed) / nit, "spmv_mirror": bool(mirrored), "spmv_mirror_bind_ms": bind_ms,

@@ -10,6 +10,7 @@ ap.add_argument("--n", type=int, default=100)
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--dt", type=float, default=None, help="time step (default 1.0 for FHN, 0.02 ms for TT06)")
 ap.add_argument("--ionic", default="fhn", choices=["fhn", "tt06"], help="tt06: BASELINE config 3 (ten Tusscher 2006)")
+ap.add_argument("--per-step", action="store_true", help="synchronise and print the wall time of every step (diagnostic)")
 ap.add_argument("--cell-solver", default="rl", choices=["rl", "fe"], help="TT06: Rush-Larsen (one evaluation per step) or forward Euler with 20 sub-steps")
 args = ap.parse_args()
 import thunderbolt_jl_amd as tb
@@ -44,11 +45,19 @@ cache = tb.setup_solver_cache(f, cell_solver, u=dev.to_device(np.ascontiguousarr
 ltg = tb.LieTrotterGodunov(heat, f, cache)
 ltg.step(0.0, args.dt)
 dev.synchronize()
+import gc
+gc.collect(); gc.disable()   # a collector pass over the set-up's arrays takes 40–80 ms: inside the loop it doubled the reported time per step (round 5)
 t0 = time.perf_counter()
 its = 0
+per = []
 for s in range(args.steps):
+    ts = time.perf_counter()
     assert ltg.step((s + 1) * args.dt, args.dt)
     its += heat.last_iters
+    if args.per_step:
+        dev.synchronize(); per.append((round((time.perf_counter() - ts) * 1e3, 3), heat.last_iters))
+if per:
+    print("per-step ms, iterations:", per, file=sys.stderr)
 dev.synchronize()
 el = time.perf_counter() - t0
 u = cache.un.to_host()
