@@ -4,6 +4,8 @@ import time
 
 
 def preroll(dev, fn, ms=150.0):
+    import gc
+    gc.collect(); gc.disable()   # and no collector pause (40–80 ms over a set-up's arrays) inside the loop that follows
     if ms <= 0:
         return
     dev.synchronize()
