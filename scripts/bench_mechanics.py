@@ -8,6 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=40)
 ap.add_argument("--order", type=int, default=2)
+ap.add_argument("--hill", default="", choices=["", "extended", "generalized"], help="ExtendedHillModel(HO2009, LinearSpring, GMK, PSL1995) / GeneralizedHillModel(LinYin passive + active, GMK incompressible)")
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--strategy", default="element", choices=["atomic", "color", "element"])
 ap.add_argument("--cpu-n", type=int, default=8)
@@ -38,6 +39,13 @@ sp = tb.allocate_matrix(dh)
 t_setup = time.time() - t0
 energy = {"ho": tb.HolzapfelOgden2009Model, "guccione": tb.Guccione1991PassiveModel, "humphrey": tb.HumphreyStrumpfYinModel, "linyin": tb.LinYinPassiveModel}[args.energy]()
 model = tb.QuasiStaticModel("u", tb.PK1Model(energy, tb.ConstantCoefficient(tb.OrthotropicMicrostructure([1, 0, 0], [0, 1, 0], [0, 0, 1]))))
+if args.hill:
+    ms_ = tb.ConstantCoefficient(tb.OrthotropicMicrostructure([1, 0, 0], [0, 1, 0], [0, 0, 1]))
+    sarc = tb.CaDrivenInternalSarcomereModel(tb.PelceSunLangeveld1995Model(), 0.6)
+    cm = (tb.ExtendedHillModel(tb.HolzapfelOgden2009Model(), tb.ActiveMaterialAdapter(tb.LinearSpringModel()), tb.GMKActiveDeformationGradientModel(), sarc, ms_)
+          if args.hill == "extended" else
+          tb.GeneralizedHillModel(tb.LinYinPassiveModel(), tb.ActiveMaterialAdapter(tb.LinYinActiveModel()), tb.GMKIncompressibleActiveDeformationGradientModel(), sarc, ms_))
+    model = tb.QuasiStaticModel("u", cm)
 if args.condensed:
     fsn = tb.ConstantCoefficient(tb.OrthotropicMicrostructure([1, 0, 0], [0, 1, 0], [0, 0, 1]))
     model = tb.QuasiStaticModel("u", tb.ActiveStressModel(tb.HolzapfelOgden2009Model(), tb.SimpleActiveStress(Tmax=50.0),

@@ -107,7 +107,8 @@ template <class T> TB_HD T penalty_U(const EnergyParams &m, T I3)
 // stays uniform over the lanes (a lane-private copy of the 330-byte block lived in scratch memory)
 // EN ≥ 0: the energy is known at compile time (the other branches vanish: the point kernel of the split linearisation is instantiated per energy — with the
 // run-time switch its loop body needs more than the 512 registers of a lone wave)
-template <class T, int EN = -1> TB_HD T energy_psi(const EnergyParams &m, const T (&F)[3][3], const double (&f0)[3], const double (&s0)[3], const double (&n0)[3], double Ta)
+template <class T, int EN = -1, bool HILL = false /* EN ≥ 0 inside a Hill framework: Ta carries the calcium, there is no active-stress term */>
+TB_HD T energy_psi(const EnergyParams &m, const T (&F)[3][3], const double (&f0)[3], const double (&s0)[3], const double (&n0)[3], double Ta)
 {
     T C[3][3]; // C = tdot(F) = FᵀF
 #pragma unroll
@@ -175,7 +176,7 @@ template <class T, int EN = -1> TB_HD T energy_psi(const EnergyParams &m, const 
         if (hd_value(I4s) >= 1.0) { const T d = I4s - 1.0; psi = psi + (p[4] / (2.0 * p[5])) * (exp(p[5] * (d * d)) - 1.0); }
     }
     }
-    if (Ta != 0.0 && (EN >= 0 || m.hill == HILL_NONE)) psi = psi + Ta * sqrt(quad(f0, f0)); // active stress: ∂(Ta‖F f₀‖)/∂F (materials.jl:1200-1266, active.jl:100-113)
+    if (!HILL && Ta != 0.0 && (EN >= 0 || m.hill == HILL_NONE)) psi = psi + Ta * sqrt(quad(f0, f0)); // active stress: ∂(Ta‖F f₀‖)/∂F (materials.jl:1200-1266, active.jl:100-113)
     return psi;
 }
 
@@ -190,11 +191,15 @@ TB_HD double sarcomere_lambda_a(const EnergyParams &m, double Ca)
 // Total energy of the material at F: passive part, plus — in the Hill frameworks — the active spring evaluated at Fᵉ = F·Fᵃ⁻¹.
 // All three active deformation gradients of the reference are diagonal in the (orthonormal) frame, Fᵃ = a f⊗f + b s⊗s + c n⊗n, so
 // Fᵃ⁻¹ is known in closed form and ActiveMaterialAdapter's rotated frame Fᵃf₀/‖Fᵃf₀‖ … is the frame itself (active.jl:8-21).
-template <class T, int EN = -1> TB_HD T material_psi(const EnergyParams &m, const T (&F)[3][3], const double (&f0)[3], const double (&s0)[3], const double (&n0)[3], double Ta)
+// HA ≥ 0 (with EN ≥ 0): a Hill framework whose active spring is the energy HA (an ActiveMaterialAdapter over it) or, HA = ACT_SIMPLE_ACTIVE_SPRING, the
+// SimpleActiveSpring — passive energy and active spring both fixed at compile time, so that the instance keeps its registers (the run-time form of
+// k_mech_points holds 1.3 KB in scratch).  HA = −1: no Hill framework at compile time.
+template <class T, int EN = -1, int HA = -1> TB_HD T material_psi(const EnergyParams &m, const T (&F)[3][3], const double (&f0)[3], const double (&s0)[3], const double (&n0)[3], double Ta)
 {
-    T psi = energy_psi<T, EN>(m, F, f0, s0, n0, Ta);
-    if constexpr (EN >= 0) return psi; // compile-time energies are instantiated for plain materials only (no Hill framework, no prestress)
-    if (m.hill == HILL_NONE) return psi;
+    constexpr bool HILLCT = EN >= 0 && HA >= 0;
+    T psi = energy_psi<T, EN, HILLCT>(m, F, f0, s0, n0, Ta);
+    if constexpr (EN >= 0 && !HILLCT) return psi; // compile-time energies of plain materials (no Hill framework, no prestress)
+    if (!HILLCT && m.hill == HILL_NONE) return psi;
     const double Ca = Ta;
     const double la = sarcomere_lambda_a(m, Ca);
     double a = la, b = 1.0, c = 1.0;                                              // GMK: I + (λᵃ − 1) f⊗f
@@ -211,7 +216,7 @@ template <class T, int EN = -1> TB_HD T material_psi(const EnergyParams &m, cons
 #pragma unroll
         for (int j = 0; j < 3; ++j) Fe[i][j] = F[i][0] * Ai[0][j] + F[i][1] * Ai[1][j] + F[i][2] * Ai[2][j];
     T pa;
-    if (m.act_energy == ACT_SIMPLE_ACTIVE_SPRING) { // aᶠ/2 (f₀·Cᵉ f₀ − 1)², energies.jl:334-347
+    if ((HILLCT && HA == ACT_SIMPLE_ACTIVE_SPRING) || (!HILLCT && m.act_energy == ACT_SIMPLE_ACTIVE_SPRING)) { // aᶠ/2 (f₀·Cᵉ f₀ − 1)², energies.jl:334-347
         T i4 = F[0][0] * 0.0;
 #pragma unroll
         for (int k = 0; k < 3; ++k) { const T v = Fe[k][0] * f0[0] + Fe[k][1] * f0[1] + Fe[k][2] * f0[2]; i4 = i4 + v * v; }
@@ -224,7 +229,7 @@ template <class T, int EN = -1> TB_HD T material_psi(const EnergyParams &m, cons
         for (int k = 0; k < 9; ++k) act.p[k] = m.ap[k];
 #pragma unroll
         for (int k = 0; k < 3; ++k) act.u[k] = m.au[k];
-        pa = energy_psi<T>(act, Fe, f0, s0, n0, 0.0);
+        pa = energy_psi<T, (HILLCT && HA != ACT_SIMPLE_ACTIVE_SPRING) ? HA : -1>(act, Fe, f0, s0, n0, 0.0);
     }
     return psi + (m.hill == HILL_EXTENDED ? Ca : 1.0) * pa;                        // 𝓝(state, …) = state for steady-state sarcomeres
 }
@@ -262,7 +267,7 @@ TB_HD HD energy_pair(const EnergyParams &m, const double *F9, int mm, int nn, co
 // The same evaluation with DIRECTIONAL seeds: ε₁ along da, ε₂ along db (nine components each, row-major like F).  Ψ.a = P : da, Ψ.ab = da : 𝔸 : db.
 // With da = e_c ⊗ J⁻¹[s][·] and db = e_d ⊗ J⁻¹[u][·] (F = I + Ĥ·J⁻¹ differentiated in Ĥ) these are the pulled-back stress P̂[c][s] and tangent
 // Â[c][s][d][u] of the sum-factorised kernels, without a pull-back pass (tb_mech_split.hip).
-template <int EN = -1>
+template <int EN = -1, int HA = -1>
 TB_HD HD energy_pair_dir(const EnergyParams &m, const double *F9, const double (&da)[9], const double (&db)[9], const double (&f0)[3], const double (&s0)[3],
                          const double (&n0)[3], double Ta)
 {
@@ -271,7 +276,7 @@ TB_HD HD energy_pair_dir(const EnergyParams &m, const double *F9, const double (
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) F[i][j] = HD{F9[3 * i + j], da[3 * i + j], db[3 * i + j], 0.0};
-    if constexpr (EN >= 0) return material_psi<HD, EN>(m, F, f0, s0, n0, Ta);
+    if constexpr (EN >= 0) return material_psi<HD, EN, HA>(m, F, f0, s0, n0, Ta);
     if (m.prestressed) {
         HD Fe[3][3];
 #pragma unroll

@@ -39,7 +39,7 @@ __host__ __device__ constexpr int sympair(int m, int n) { return m * 9 - m * (m 
 #ifndef TB_MECH_AD_GROUPS
 #define TB_MECH_AD_GROUPS 1 // (measured: 1 → 8.2, 5 → 10.5, 9 → 13.0 ms for Guccione at 40³: every group repeats the kinematics)  // the 45 pair evaluations of a point are dealt to this many workgroups (blockIdx.y): more waves in flight for a kernel of long dependent chains
 #endif
-template <bool AD, int EN = -1>
+template <bool AD, int EN = -1, int HA = -1>
 __global__ void __launch_bounds__(256, AD ? TB_MECH_AD_WAVES : TB_MECH_POINTS_WAVES)
 k_mech_points(MechMesh m, HOParams mat, EnergyParams en, const double *__restrict__ u, int64_t n_cells /*of this launch, from m.cell0*/, double *__restrict__ out, Status *st)
 {
@@ -162,7 +162,7 @@ k_mech_points(MechMesh m, HOParams mat, EnergyParams en, const double *__restric
                     da[3 * i + j] = i == c ? sel3(ji[j], ji[3 + j], ji[6 + j], s_) : 0.0;
                     db[3 * i + j] = i == d ? sel3(ji[j], ji[3 + j], ji[6 + j], u_) : 0.0;
                 }
-            const HD r = energy_pair_dir<EN>(en, Ff, da, db, f0, s0, n0, Ta);
+            const HD r = energy_pair_dir<EN, HA>(en, Ff, da, db, f0, s0, n0, Ta);
             double ab = r.ab;
             if (tb_over_gg != 0.0) ab += tb_over_gg * (sel3(g[0], g[1], g[2], c) * sel3(fj[0], fj[1], fj[2], s_)) * (sel3(g[0], g[1], g[2], d) * sel3(fj[0], fj[1], fj[2], u_));
             o[pr * 27] = ab * dO;
@@ -363,7 +363,14 @@ int launch_mech_points(tb_device *dev, const MechMesh &mm, const HOParams &hp, c
     if (ep) {
         const dim3 g2(grid.x, TB_MECH_AD_GROUPS);
 #define TB_MP(E) hipLaunchKernelGGL((k_mech_points<true, E>), g2, dim3(256), 0, dev->stream, mm, hp, *ep, d_u, n, d_qp, dev->d_status)
-        if (ep->hill != HILL_NONE || ep->prestressed) TB_MP(-1); // Hill frameworks, prestress: the run-time form
+#define TB_MPH(E, A) hipLaunchKernelGGL((k_mech_points<true, E, A>), g2, dim3(256), 0, dev->stream, mm, hp, *ep, d_u, n, d_qp, dev->d_status)
+        // Generalized / Extended Hill models: the (passive energy, active spring) pairings of the reference's tests and tutorials at compile time
+        const bool hill_ct = ep->hill != HILL_NONE && !ep->prestressed;
+        if (hill_ct && ep->energy == EN_HOLZAPFEL_OGDEN && ep->act_energy == EN_LINEAR_SPRING) TB_MPH(EN_HOLZAPFEL_OGDEN, EN_LINEAR_SPRING);
+        else if (hill_ct && ep->energy == EN_HOLZAPFEL_OGDEN && ep->act_energy == ACT_SIMPLE_ACTIVE_SPRING) TB_MPH(EN_HOLZAPFEL_OGDEN, ACT_SIMPLE_ACTIVE_SPRING);
+        else if (hill_ct && ep->energy == EN_LIN_YIN_PASSIVE && ep->act_energy == EN_LIN_YIN_ACTIVE) TB_MPH(EN_LIN_YIN_PASSIVE, EN_LIN_YIN_ACTIVE);
+        else if (hill_ct && ep->energy == EN_GUCCIONE_1991 && ep->act_energy == EN_LINEAR_SPRING) TB_MPH(EN_GUCCIONE_1991, EN_LINEAR_SPRING);
+        else if (ep->hill != HILL_NONE || ep->prestressed) TB_MP(-1); // other active energies, prestress: the run-time form
         else switch (ep->energy) {
             case EN_NULL: TB_MP(EN_NULL); break;
             case EN_BIO_NEOHOOKEAN: TB_MP(EN_BIO_NEOHOOKEAN); break;
@@ -376,6 +383,7 @@ int launch_mech_points(tb_device *dev, const MechMesh &mm, const HOParams &hp, c
             default: TB_MP(EN_HOLZAPFEL_OGDEN); break; // (with another penalty than the fast path's)
         }
 #undef TB_MP
+#undef TB_MPH
     }
     else hipLaunchKernelGGL(k_mech_points<false>, grid, dim3(256), 0, dev->stream, mm, hp, EnergyParams{}, d_u, n, d_qp, dev->d_status);
     TB_HIP(hipGetLastError());
