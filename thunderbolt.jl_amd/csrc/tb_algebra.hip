@@ -956,10 +956,10 @@ int launch_mirror_bind(tb_pattern *p, const double *nz)
 template <bool DOT>
 static void launch_mirror(tb_pattern *p, const double *mir, const double *x, double alpha, double beta, double *y, double *xy)
 {
-    // one slice per wave where nothing is reduced (measured at 216³: 0.52 ms against 0.57 ms with resident workgroups only); the fused xᵀAx form ends
-    // every workgroup in one atomic on the same scalar: 48 workgroups per CU (0.54 ms; 3 072 / 4 096 / 8 192 / 24 576 / all 40 000: 0.56 / 0.55 / 0.55 / 0.56 / 0.62)
+    // one slice per wave (measured at 216³: 0.52 ms against 0.57 ms with resident workgroups only).  The fused xᵀAx form was capped at 48 workgroups per CU
+    // while every workgroup ended in an atomic on ONE scalar (all 40 000: 0.62 ms); with the partials in reduction slots the cap costs 2–4 % and is gone
     const int64_t grid_env = tune_env("TB_SPMV_MIRROR_GRID") ? atoll(tune_env("TB_SPMV_MIRROR_GRID")) : 0; // (read per launch: sweeps)
-    const int64_t cap = grid_env > 0 ? grid_env : DOT ? (int64_t)p->mesh->dev->n_cu * 48 : (int64_t)1 << 30;
+    const int64_t cap = grid_env > 0 ? grid_env : (int64_t)1 << 30;
     const unsigned grid = (unsigned)std::min<int64_t>((p->n_slices + 3) / 4, cap);
     hipLaunchKernelGGL((k_spmv_mirror<DOT>), dim3(grid), dim3(256), 0, p->mesh->dev->stream, p->n_rows, p->n_slices, (const MirrorSlice *)p->d_mir_base, p->d_mir_off, p->d_sigoff,
                        mir, x, alpha, beta, y, xy);
