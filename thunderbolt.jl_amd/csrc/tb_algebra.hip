@@ -2057,7 +2057,7 @@ int launch_cgd_update(tb_device *dev, int64_t n, const double *w, const double *
                       const double *d_rz, const double *d_pAp, double *d_out3)
 {
     if (n > 0) {
-        hipLaunchKernelGGL(k_cgd_update<false>, dim3(std::min<unsigned>(grid_for(dev, n, 256), (unsigned)dev->n_cu * 4)), dim3(256), 0, dev->stream, n, w, dinv, p, Ap, x, r, d_rz, d_pAp, d_out3,
+        hipLaunchKernelGGL(k_cgd_update<false>, dim3(grid_for(dev, n, 256)), dim3(256), 0, dev->stream, n, w, dinv, p, Ap, x, r, d_rz, d_pAp, d_out3,
                            red_group(dev, 1), red_group(dev, 2));
         fold_slots(dev, 1, d_out3, 2); // out3[0] += r·z, out3[1] += rᵀr
     }
@@ -2080,7 +2080,7 @@ int launch_cgd_iteration(tb_pattern *pat, const double *A, const double *dinv, d
     if (n == 0) return launch_cgd_rotate(dev, d_S);
     int rc = launch_spmv_dot_slots(pat, A, p, Ap, red_group(dev, 0));
     if (rc) return rc;
-    hipLaunchKernelGGL(k_cgd_update<true>, dim3(std::min<unsigned>(grid_for(dev, n, 256), (unsigned)dev->n_cu * 4)), dim3(256), 0, dev->stream, n, (const double *)nullptr, dinv, p, Ap, x, r, d_S,
+    hipLaunchKernelGGL(k_cgd_update<true>, dim3(grid_for(dev, n, 256)), dim3(256), 0, dev->stream, n, (const double *)nullptr, dinv, p, Ap, x, r, d_S,
                        red_group(dev, 0), d_S + 2, red_group(dev, 1), red_group(dev, 2));
     hipLaunchKernelGGL(k_cgd_direction<true>, dim3(grid_for(dev, n, 256)), dim3(256), 0, dev->stream, n, dinv, r, p, d_S, red_group(dev, 1));
     hipLaunchKernelGGL(k_cgd_rotate_slots, dim3(1), dim3(64), 0, dev->stream, d_S, red_group(dev, 0));
