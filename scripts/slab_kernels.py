@@ -20,8 +20,8 @@ u = torch.from_numpy(np.ascontiguousarray(u0.T).ravel()).cuda()
 f = tb.PointwiseODEFunction(npts, model)
 cache = tb.setup_solver_cache(f, tb.ForwardEulerCellSolver(dev), u=u)
 e0, e1 = dev.event(), dev.event()
-def timed(fn, reps=40):
-    for _ in range(5): fn()
+def timed(fn, reps=200):
+    for _ in range(300): fn()          # (clocks: see scripts/_preroll.py)
     e0.record()
     for _ in range(reps): fn()
     e1.record(); dev.synchronize()
