@@ -3383,6 +3383,47 @@ def test_cgd_iteration_equals_the_four_calls(tb, device):
         device.set_stream(None)
 
 
+def test_sums_through_reduction_slots_accumulate_into_the_callers_scalar(tb, device):
+    """The kernels that end in a sum leave their workgroup partials in slot groups of the device (round 5: 64 slots 128 B apart instead of one address)
+    and one wave folds them into the caller's scalar.  The ABI meaning is unchanged: `*out += …` — twice the call, twice the sum — the slots are zero
+    again behind every call, the sums are the host's to 1e-13, and a solve of tb_cg_solve (whose loop keeps its sums in other groups) in between
+    disturbs nothing."""
+    import torch
+    g = tb.generate_mesh(tb.Hexahedron, (40, 30, 24), (0, 0, 0), (1.0, 1.0, 1.0), perturb=0.2)     # 30 k dofs: > 64 workgroups per launch
+    dh = tb.DofHandler(g)
+    sp = tb.allocate_matrix(dh)
+    st = tb.PatchAssemblyStrategy(device)
+    M = tb.setup_operator(st, tb.BilinearMassIntegrator(tb.ConstantCoefficient(1.0)), dh, sp)
+    K = tb.setup_operator(st, tb.BilinearDiffusionIntegrator(tb.ConstantCoefficient(np.diag([4.5e-2, 2.0e-2, 2.0e-2]))), dh, sp)
+    tb.update_operators(M, K, 0.0)
+    A = tb.heat_system_matrix(device, M, K, 0.5)
+    torch.cuda.set_device(0)
+    device.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        n = dh.ndofs
+        rng = np.random.default_rng(3)
+        a_h, b_h, w_h = rng.standard_normal(n), rng.standard_normal(n), rng.uniform(0.5, 1.0, n)
+        a, b, w = (torch.from_numpy(v).cuda() for v in (a_h, b_h, w_h))
+        S = torch.zeros(4, dtype=torch.float64, device="cuda")
+        lib, chk = tb.lib(), tb._lib.check
+        for _ in range(2):
+            chk(lib.tb_cgd_dot(device.h, n, w.data_ptr(), a.data_ptr(), b.data_ptr(), S[0:1].data_ptr()))
+        y = torch.empty(n, dtype=torch.float64, device="cuda")
+        chk(lib.tb_spmv_csr_dot(K.pattern.h, A.ptr, a.data_ptr(), y.data_ptr(), S[1:2].data_ptr()))
+        x = device.zeros(n)
+        its, res = tb.cg_solve(K.pattern, A, device.to_device(b_h), x, rtol=1e-10, atol=0.0, maxiter=200)            # other slot groups, same device
+        chk(lib.tb_spmv_csr_dot(K.pattern.h, A.ptr, a.data_ptr(), y.data_ptr(), S[1:2].data_ptr()))
+        torch.cuda.synchronize()
+        Sh = S.cpu().numpy()
+        import scipy.sparse as sps
+        Ah = sps.csr_matrix((A.to_host(), sp.colidx, sp.rowptr), shape=(n, n))
+        assert abs(Sh[0] - 2.0 * np.dot(w_h * a_h, b_h)) < 1e-13 * np.abs(w_h * a_h * b_h).sum() * 2
+        assert abs(Sh[1] - 2.0 * (a_h @ (Ah @ a_h))) < 1e-13 * (np.abs(a_h) @ (abs(Ah) @ np.abs(a_h))) * 2
+        assert rel_err(y.cpu().numpy(), Ah @ a_h) < 1e-13 and its > 0 and np.linalg.norm(Ah @ x.to_host() - b_h) <= 1e-9 * np.linalg.norm(b_h)
+    finally:
+        device.set_stream(None)
+
+
 def test_bisection_patcher_on_a_curved_thin_wall(tb, oracle, device):
     """The tile plan of per-axis buckets fills the 256-lane sweeps of the idealised ventricle to about a half; ensure_patch_fused then bisects the cells into
     equal leaves (round 5) if that needs clearly fewer patches.  The matrices of the new plan are the oracle's, the plan has fewer instances per patch
