@@ -18,7 +18,7 @@ npts = dh.ndofs
 u0 = np.tile(model.default_initial_state(), (npts, 1)); u0[:, model.phi_index] += np.linspace(0, 60, npts)
 u = torch.from_numpy(np.ascontiguousarray(u0.T).ravel()).cuda()
 f = tb.PointwiseODEFunction(npts, model)
-cache = tb.setup_solver_cache(f, tb.ForwardEulerCellSolver(dev), u=u)
+cache = tb.setup_solver_cache(f, tb.ForwardEulerCellSolver(dev), u=u, keep_du=False)
 e0, e1 = dev.event(), dev.event()
 def timed(fn, reps=200):
     for _ in range(300): fn()          # (clocks: see scripts/_preroll.py)

@@ -601,15 +601,29 @@ static int run(tb_device *dev, const CellParams &P, TS *u, TS *du, int64_t n, in
                double thr, unsigned long long *rmax_key, const float *xs, int sdim)
 {
     const int bs = 256;
-    int64_t nb = (n + bs - 1) / bs;
-    static const int per_cu = tune_env("TB_REACTION_BLOCKS_PER_CU") ? atoi(tune_env("TB_REACTION_BLOCKS_PER_CU")) : 16;
-    const int64_t cap = per_cu > 0 ? (int64_t)dev->n_cu * per_cu : nb;
-    if (nb > cap) nb = (nb + (nb + cap - 1) / cap - 1) / ((nb + cap - 1) / cap); // every thread the same number of points (⌈nb / cap⌉ each): a grid cut at `cap` left some threads 2 and most 1 at 1.3 M points
-    const dim3 grid((unsigned)nb), block(bs);
-#define TB_LAUNCH(L, W) hipLaunchKernelGGL((k_reaction<MODEL, L, W, TS>), grid, block, 0, dev->stream, P, u, du, n, t, dt, substeps, thr, rmax_key, xs, sdim, dev->capturing ? (dev->tslot_used = true, dev->d_tslot) : nullptr)
-    if (layout == TB_LAYOUT_SOA) { if (du) TB_LAUNCH(TB_LAYOUT_SOA, true); else TB_LAUNCH(TB_LAYOUT_SOA, false); }
-    else { if (du) TB_LAUNCH(TB_LAYOUT_AOS, true); else TB_LAUNCH(TB_LAYOUT_AOS, false); }
-#undef TB_LAUNCH
+    // Grid: a multiple of what is resident (`occ` workgroups per CU: 2 for the 19-state model at 243 registers, 8 for the two-state ones), every thread the
+    // same number of points.  Two generations of resident workgroups for large arrays, ONE for small ones (≤ 12 generations of single-point workgroups: the
+    // 27-layer slab of a strong-scaling run) — measured at steady clocks, TT06 (profiles/r05_v2/ab_reaction_grid.log): 216³ 0.715 ms against 0.721 at
+    // 16 workgroups per CU; 54 / 27 layers 74.2 / 69.5 ps per dof against 78.0 / 74.5.
+    auto launch = [&](auto kern) -> int {
+        static struct { const void *f; int occ; } seen[8]; // (the query is not free: once per kernel instance)
+        int occ = 0;
+        for (auto &e : seen) if (e.f == (const void *)kern) occ = e.occ;
+        if (!occ) {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, bs, 0) != hipSuccess || occ < 1) occ = 1;
+            for (auto &e : seen) if (!e.f) { e.f = (const void *)kern; e.occ = occ; break; }
+        }
+        int64_t nb = (n + bs - 1) / bs;
+        static const int per_cu_env = tune_env("TB_REACTION_BLOCKS_PER_CU") ? atoi(tune_env("TB_REACTION_BLOCKS_PER_CU")) : -1;
+        const int64_t resident = (int64_t)dev->n_cu * occ;
+        const int64_t cap = per_cu_env > 0 ? (int64_t)dev->n_cu * per_cu_env : per_cu_env == 0 ? nb : (nb <= 12 * resident ? resident : 2 * resident);
+        if (nb > cap) nb = (nb + (nb + cap - 1) / cap - 1) / ((nb + cap - 1) / cap); // every thread the same number of points (⌈nb / cap⌉ each)
+        hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(bs), 0, dev->stream, P, u, du, n, t, dt, substeps, thr, rmax_key, xs, sdim,
+                           dev->capturing ? (dev->tslot_used = true, (const double *)dev->d_tslot) : (const double *)nullptr);
+        return TB_OK;
+    };
+    if (layout == TB_LAYOUT_SOA) { if (du) launch(k_reaction<MODEL, TB_LAYOUT_SOA, true, TS>); else launch(k_reaction<MODEL, TB_LAYOUT_SOA, false, TS>); }
+    else { if (du) launch(k_reaction<MODEL, TB_LAYOUT_AOS, true, TS>); else launch(k_reaction<MODEL, TB_LAYOUT_AOS, false, TS>); }
     TB_HIP(hipGetLastError());
     return TB_OK;
 }
