@@ -20,6 +20,8 @@ for cls, dt in [(c, d) for c, d in (("PCG2019", 0.01), ("TT06", 0.001), ("ORd201
     def rl(): check(lib.tb_reaction_step_rl(dev.h, m.model_id, par, len(m.params), u.ptr, n, ns, 0, 0.0, dt))
     for name, fn in (("fe", fe), ("rl", rl)):
         fn(); fn()
+        from _preroll import preroll
+        preroll(dev, fn, 80.0)   # steady clocks
         a, b = dev.event(), dev.event()
         a.record()
         for _ in range(10):

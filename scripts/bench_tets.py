@@ -35,6 +35,8 @@ for sname in args.strategies.split(","):
         except tb.TBError as e:
             out["%s_%s" % (name, sname)] = "unsupported: %s" % str(e)[:80]
             continue
+        from _preroll import preroll
+        preroll(dev, lambda: tb.update_operator(op, 0.1), 60.0)   # steady clocks
         e0, e1 = dev.event(), dev.event()
         e0.record()
         for _ in range(args.steps):
