@@ -66,6 +66,12 @@ def parse():
     ap.add_argument("--mesh", default="box", choices=["box", "shuffled", "lv"],
                     help="N = 1: box = the lexicographic n^3 box (BASELINE's configuration); shuffled = the SAME box with its cells and nodes randomly renumbered (same bytes, "
                          "no row / scatter signatures to share: an unstructured presentation); lv = the idealised left ventricle (O-grid apex, curved thin wall) at --lv-dims")
+    ap.add_argument("--renumber", default="none", choices=["none", "dofs", "grid"],
+                    help="--mesh shuffled | lv: apply tb_host_locality_permutation first — dofs = Ferrite.renumber!(dh, dof_perm) only (cells and nodes stay as "
+                         "numbered), grid = the grid stored in the locality order as well (cells[cell_perm], nodes moved), then close!(dh)")
+    ap.add_argument("--checksums", action="store_true",
+                    help="after the timed region: two steps from the initial state, then partition-independent sums of M, K, b and the ionic states in the line "
+                         "(an N-rank run must reproduce the one-rank numbers)")
     ap.add_argument("--lv-dims", default="256,16,248", help="--mesh lv: circumferential, radial, longitudinal cell counts (default ~1.1 M hexahedra)")
     ap.add_argument("--layers", type=int, default=0, help="N = 1 diagnostics: run on the n×n×LAYERS slab only (the share of one of n/LAYERS GPUs), e.g. under rocprofv3")
     ap.add_argument("--no-spmv-mirror", action="store_true", help="CG iterations on the CSR array instead of its sliced mirror (tb_spmv_mirror)")
@@ -221,6 +227,19 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+def ferrite_pin():
+    """Whether the maintainer-side golden files of julia/make_golden.jl are present: without them Ferrite's conventions (node / cell order of generate_grid,
+    close!(dh) numbering, pattern order of src/solver/interface.jl:162-168, Gauss-point order) are SURVEY-§8(c) hypotheses, and every number says so."""
+    gd_ = os.path.join(ROOT, "tests", "golden")
+    have = sorted(f for f in (os.listdir(gd_) if os.path.isdir(gd_) else []) if f.startswith("ferrite_") and f.endswith(".json"))
+    return {"ferrite_conventions": "pinned on " + ", ".join(have) if have else "UNPINNED",
+            "note": None if have else "Ferrite conventions unpinned: whole-mesh K / M / b, dof numbering and pattern order are checked against the C oracle only "
+                                      "(tests/golden/ferrite_*.json absent; julia/make_golden.jl writes them on a machine with Julia + Ferrite)"}
+
+
+FERRITE_PIN = ferrite_pin()
+
+
 def main():
     args = parse()
     if args.gpus < 1:
@@ -260,8 +279,11 @@ def main():
     dev.set_stream(torch.cuda.current_stream().cuda_stream)
 
     n = args.n
-    if args.mesh != "box" and (world > 1 or args.layers):
-        sys.stderr.write("bench.py: --mesh %s is a one-GPU mode (z-slab partitions belong to the box)\n" % args.mesh)
+    if args.mesh != "box" and args.layers:
+        sys.stderr.write("bench.py: --layers cuts z-slabs of the box; --mesh %s is partitioned by recursive bisection (--gpus N)\n" % args.mesh)
+        return 2
+    if args.mesh != "box" and world > 1 and args.scaling == "weak":
+        sys.stderr.write("bench.py: --scaling weak replicates box slabs; --mesh %s runs strong scaling (one mesh, N parts)\n" % args.mesh)
         return 2
     strong = args.scaling == "strong"
     if strong and world > n:
@@ -280,22 +302,52 @@ def main():
         xd = tb.distributed.RcclComm.from_torch(dev, dist)
     host_red = "cpu" if share else "cuda"
 
+    # unstructured presentations: every rank builds the whole mesh (host-side generators), bisects the cell centroids into `world` parts of equal size
+    # (tb.distributed.partition_cells_rcb — the partition of SURVEY §8e for meshes that are not boxes) and keeps its own part as a local grid with
+    # the nodes it shares with every other part (GeneralPartition: both sides list them in ascending global node id, so the buffers line up)
+    full_grid, gpart = None, None
+    if args.mesh != "box":
+        if args.mesh == "lv":
+            nc_, nr_, nl_ = (int(v) for v in args.lv_dims.split(","))
+            full_grid = tb.generate_ideal_lv_mesh_hex(nc_, nr_, nl_)
+        else:                                  # the same cells and nodes under random numbers: no lexicographic regularity for the plans to share (seeded)
+            g0_ = tb.generate_mesh(tb.Hexahedron, (n, n, nz_total), (0.0, 0.0, 0.0), (1.0, 1.0, nz_total / n), perturb=0.2)
+            rng = np.random.default_rng(2025)
+            pn, pc = rng.permutation(g0_.n_nodes), rng.permutation(g0_.n_cells)
+            inv = np.empty_like(pn); inv[pn] = np.arange(g0_.n_nodes)
+            full_grid = tb.Grid(tb.Hexahedron, g0_.xyz[pn], inv[g0_.conn[pc]].astype(np.int32))
+            del g0_, pn, pc, inv
+        if world > 1:
+            cen_ = full_grid.xyz[full_grid.conn].mean(axis=1)
+            gpart = tb.distributed.GeneralPartition(full_grid.conn, tb.distributed.partition_cells_rcb(cen_, world), rank)
+            del cen_
+
     class Problem:
         """One rank's share of the workload: mesh slab, operators, source vector, halo exchange, ionic states; `step` is one pass of the hot path."""
 
         def __init__(self, nel, left, right, rank_, world_, lo_up, dist_, xdist_=None):
             self.world, self.rank, self.dist = world_, rank_, dist_     # dist: barrier / max over ranks of the timings (torch.distributed)
             self.xdist = xdist_ if xdist_ is not None else dist_        # xdist: halo exchange and CG reductions (torch.distributed or RcclComm)
-            self.g = g = tb.generate_mesh(tb.Hexahedron, nel if args.mesh != "lv" else (2, 2, 2), left, right, perturb=0.2)
-            if args.mesh == "shuffled":        # the same cells and nodes under random numbers: no lexicographic regularity for the plans to share (seeded)
-                rng = np.random.default_rng(2025)
-                pn, pc = rng.permutation(g.n_nodes), rng.permutation(g.n_cells)
-                inv = np.empty_like(pn); inv[pn] = np.arange(g.n_nodes)
-                self.g = g = tb.Grid(tb.Hexahedron, g.xyz[pn], inv[g.conn[pc]].astype(np.int32))
-            elif args.mesh == "lv":
-                nc_, nr_, nl_ = (int(v) for v in args.lv_dims.split(","))
-                self.g = g = tb.generate_ideal_lv_mesh_hex(nc_, nr_, nl_)
+            if args.mesh == "box":
+                self.g = g = tb.generate_mesh(tb.Hexahedron, nel, left, right, perturb=0.2)
+            elif gpart is not None:            # this rank's part of the bisected mesh, nodes numbered by first visit
+                self.g = g = tb.Grid(full_grid.cell_kind, full_grid.xyz[gpart.global_nodes], gpart.conn)
+            else:
+                self.g = g = full_grid
+            self.node_perm = None              # --renumber grid: new number of every node of g as it was handed in (shared-node lists follow)
+            self.renumber_s = 0.0
+            if args.renumber == "grid":
+                t0_ = time.perf_counter()
+                cp_, np_, _ = tb.locality_permutation(g)
+                self.g = g = tb.renumber_grid(g, cp_, np_)
+                self.node_perm = np_
+                self.renumber_s = time.perf_counter() - t0_
             self.dh = dh = tb.DofHandler(g)
+            if args.renumber == "dofs":
+                t0_ = time.perf_counter()
+                _, _, dp_ = tb.locality_permutation(g, dh)
+                self.dh = dh = tb.renumber_dofs(dh, dp_)
+                self.renumber_s = time.perf_counter() - t0_
             self.sp = sp = tb.allocate_matrix(dh)
             st = {"patch": tb.PatchAssemblyStrategy, "atomic": tb.AtomicAssemblyStrategy, "color": tb.PerColorAssemblyStrategy}[args.strategy](dev)
             # linear form: the atomic strategy on hexahedra is the patch-reduced kernel k_vector_hex8_patch<false> — a patch integrates its own cells only
@@ -310,20 +362,32 @@ def main():
             self.b = torch.zeros(dh.ndofs, dtype=torch.float64, device="cuda")
             self.src.b = tb.DeviceVector.wrap(dev, self.b)
             self.lo_idx = self.up_idx = None
+            nbrs = []
             if world_ > 1:
                 n2d = tb.distributed.node_to_dof(dh)
-                lo, up = lo_up
-                self.lo_idx = None if lo is None else torch.from_numpy(n2d[lo]).cuda()
-                self.up_idx = None if up is None else torch.from_numpy(n2d[up]).cuda()
+                if gpart is not None:          # general partition: one index list per neighbouring part (local nodes → dofs; peers ascending on both sides)
+                    nmap = (lambda v: v) if self.node_perm is None else (lambda v: self.node_perm[v])
+                    nbrs = [(peer, torch.from_numpy(n2d[nmap(idx)]).cuda()) for peer, idx in gpart.neighbours]
+                else:
+                    lo, up = lo_up
+                    self.lo_idx = None if lo is None else torch.from_numpy(n2d[lo]).cuda()
+                    self.up_idx = None if up is None else torch.from_numpy(n2d[up]).cuda()
+                    nbrs = tb.distributed.slab_neighbours(self.lo_idx, self.up_idx, rank_, world_)
+            self.nbrs = nbrs
             # the one data-path exchange: persistent send / receive buffers, pack and unpack through the C ABI (tb_gather_indexed / tb_scatter_add_indexed)
-            nbrs = tb.distributed.slab_neighbours(self.lo_idx, self.up_idx, rank_, world_)
             self.halo = tb.distributed.HaloExchange(nbrs, self.xdist, self.b, dev)
             self.model = model = {"pcg2019": tb.PCG2019, "tt06": tb.TT06, "fhn": tb.FHNModel, "ord": tb.ORd2011}[args.ionic]()
             self.ns = model.nstates
             self.npts = npts = dh.ndofs
             u0 = np.tile(model.default_initial_state(), (npts, 1))
-            u0[:, model.phi_index] += np.linspace(0.0, 60.0 if self.ns > 2 else 1.0, npts)
-            self.u = torch.from_numpy(np.ascontiguousarray(u0.T).ravel()).cuda()
+            if args.mesh == "box":
+                u0[:, model.phi_index] += np.linspace(0.0, 60.0 if self.ns > 2 else 1.0, npts)
+            else:                                  # a function of the dof's position: the same physical state under every numbering and every partition (--checksums)
+                xd_ = np.empty((npts, 3)); xd_[tb.distributed.node_to_dof(dh)] = g.xyz
+                self.xdof = xd_
+                u0[:, model.phi_index] += (30.0 if self.ns > 2 else 0.5) * (1.0 + np.sin(3.0 * xd_[:, 0] + 2.0 * xd_[:, 1] + xd_[:, 2]))
+            self.u0 = np.ascontiguousarray(u0.T).ravel()
+            self.u = torch.from_numpy(self.u0).cuda()
             self.f = tb.PointwiseODEFunction(npts, model)
             self.cache = tb.setup_solver_cache(self.f, tb.ForwardEulerCellSolver(dev), u=self.u, keep_du=args.keep_du)
             self.evpool = []
@@ -373,22 +437,55 @@ def main():
             tb.update_operator(self.src, t)
             tb.perform_step(self.f, self.cache, t, rdt)
 
+        def checksums(self):
+            """Partition- and numbering-independent sums of what two steps from the initial state leave behind (--checksums): every rank adds its own
+            share — shared dofs weighted 1 / multiplicity, sub-domain operators through their quadratic forms ψᵀA_pψ with ψ a function of the dof's
+            position — and the ranks' shares are all-reduced.  An N-rank run must print the numbers of the one-rank run (tests: 1e-10 relative)."""
+            npts = self.npts
+            self.u.copy_(torch.from_numpy(self.u0))
+            for i in range(2):
+                self.step(i)
+            torch.cuda.synchronize()
+            w = torch.ones(npts, dtype=torch.float64, device="cuda")
+            for _, idx in self.nbrs:
+                w[idx] += 1.0
+            w = 1.0 / w
+            xd_ = getattr(self, "xdof", None)
+            if xd_ is None:
+                xd_ = np.empty((npts, 3)); xd_[tb.distributed.node_to_dof(self.dh)] = self.g.xyz
+            psi = torch.from_numpy(np.cos(2.0 * xd_[:, 0] - xd_[:, 1]) + 0.5 * np.sin(4.0 * xd_[:, 2]) + 1.5).cuda()
+            y = torch.empty_like(psi)
+            sums = []
+            for op_ in (self.M, self.K):
+                op_.mul(tb.DeviceVector.wrap(dev, y), tb.DeviceVector.wrap(dev, psi))
+                sums.append((psi * y).sum())
+            sums += [(w * self.b * self.b).sum(), (w * self.b * psi).sum()]
+            U = self.u.view(self.ns, npts)
+            sums += [(w * U * U).sum(), (w * U[self.model.phi_index] * psi).sum()]
+            t_ = torch.stack(sums)
+            if self.world > 1:
+                tb.distributed.all_reduce_sum(t_, self.xdist)
+            names = ("psi_M_psi", "psi_K_psi", "b_b", "b_psi", "u_u", "phi_psi")
+            return {k_: float(v_) for k_, v_ in zip(names, t_.cpu().numpy())}
+
         def time_steps_graph(self, warmup, steps):
             """The same step as ONE HIP-graph launch (tb_graph_*: the sequence captured once, the time of every replay set through the device's time
             slot): W untimed launches, K timed ones, synchronize on both sides.  One rank only (the halo exchange stays outside graphs)."""
             assert self.world == 1
             gc.collect(); gc.disable()                               # (a collector pass over the set-up's arrays is a 40–80 ms pause)
-            gr = dev.capture(lambda: self.step_plain(0.0))
-            self.preroll(lambda i: gr.launch(0.01 * i))
-            for i in range(warmup):
-                gr.launch(0.01 * i)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for i in range(steps):
-                gr.launch(0.01 * (warmup + i))
-            torch.cuda.synchronize()
-            el = time.perf_counter() - t0
-            gc.enable()
+            try:                                                     # (a failed capture must not leave the collector off for the measurements behind it)
+                gr = dev.capture(lambda: self.step_plain(0.0))
+                self.preroll(lambda i: gr.launch(0.01 * i))
+                for i in range(warmup):
+                    gr.launch(0.01 * i)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(steps):
+                    gr.launch(0.01 * (warmup + i))
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t0
+            finally:
+                gc.enable()
             dev.poll_status()
             nodes = gr.nodes
             gr.close()
@@ -464,7 +561,7 @@ def main():
             A = tb.heat_system_matrix(dev, self.M, self.K, 0.01)
             diag = torch.empty(npts, dtype=torch.float64, device="cuda")
             tb._lib.check(tb.lib().tb_extract_diagonal(self.K.pattern.h, A.ptr, diag.data_ptr()))
-            cg = tb.distributed.DistributedCG(None, diag, self.lo_idx, self.up_idx, self.rank, world_, xd_, device=dev, operator=(self.K.pattern, A))
+            cg = tb.distributed.DistributedCG(None, diag, self.lo_idx, self.up_idx, self.rank, world_, xd_, neighbours=self.nbrs, device=dev, operator=(self.K.pattern, A))
             # the solve multiplies one fixed matrix: its values are mirrored slice by slice once (tb_spmv_mirror, timed on its own) and every product of
             # the iterations below streams the mirror; --no-spmv-mirror times the CSR kernel instead
             e0, e1 = dev.event(), dev.event()
@@ -536,8 +633,13 @@ def main():
                     "note": "one Jacobi-CG iteration on A = M - dt K under the partition (barrier-bracketed, max over ranks, host-timed over %d iterations, device "
                             "scalars, no host read): interface rows packed first, exchange overlapped with the local SpMV + p'Ap, two all-reduces" % nit}
 
+    t_setup0 = time.perf_counter()
     pr = Problem(part.local_nel(), part.left, part.right, rank, world, part.interface_nodes(), gd, xd)
     g, dh, sp, npts, ns = pr.g, pr.dh, pr.sp, pr.npts, pr.ns
+    t_setup1 = time.perf_counter()
+    pr.step(0)                                   # first assembly: the plans (patches, signatures, one-trip records) are built here
+    torch.cuda.synchronize()
+    t_setup2 = time.perf_counter()
     elapsed = pr.time_steps(args.warmup, args.steps)
     phase = pr.phase
 
@@ -556,6 +658,7 @@ def main():
             return None, None, str(ex)[:200]
 
     g_ms, g_nodes, g_err = graph_step_ms(pr)
+    chk = pr.checksums() if args.checksums else None
 
     # outside the timed region: the reference's own 7-state ionic model (PCG2019) on the same points, for the record
     ref_rx = None
@@ -648,7 +751,7 @@ def main():
         cells_total = n * n * nz_total
         dofs_total = (n + 1) * (n + 1) * (nz_total + 1)          # distinct dofs of the whole mesh (interface dofs, updated on both sides, counted once)
         if args.mesh != "box":
-            cells_total, dofs_total = g.n_cells, npts
+            cells_total, dofs_total = full_grid.n_cells, full_grid.n_nodes
         ms = elapsed / K_ * 1e3
         k_ms = phase["diffusion"] / K_            # fused: the one M + K launch
         # algorithmic bytes of the dominant launch, each datum once: connectivity 32 B + coordinates 24 B per cell, 27 nz × 8 B per
@@ -678,11 +781,20 @@ def main():
                                        "lv": "the idealised left-ventricle hex Q1 mesh (%s cells circumferential / radial / longitudinal + O-grid apex: %d cells, %d dofs)" % (args.lv_dims, cells_total, dofs_total)}[args.mesh],
                                       args.strategy, "one fused pass" if fused else "two launches",
                                       (" + neighbour halo sum of b" + ("" if args.no_overlap_exchange else " (posted before the reaction step, added behind it)")) if world > 1 else "", args.ionic.upper()),
-                       "mesh": args.mesh,
+                       "mesh": args.mesh, "renumber": args.renumber,
                        "preroll_ms": args.preroll_ms,   # untimed steps in front of the W warm-up steps: the GPU's clocks (see --preroll-ms)
                        "cells_total": cells_total, "cells_per_gpu": g.n_cells, "dofs_per_gpu": npts, "nnz_per_gpu": sp.nnz, "ionic_model": args.ionic, "ionic_states": ns,
-                       "partition": "z-slabs", "layers_per_gpu": part.nzl, **({"backend": "gloo (shared device, test)"} if share else ({"backend": "nccl (RCCL)" if xd is gd else "RCCL behind the C ABI (tb_comm_*)"} if gd is not None else {}))},
+                       "partition": "z-slabs" if gpart is None else "recursive coordinate bisection of the cell centroids (%d parts, this rank: %d neighbour parts, %d shared dofs)"
+                                    % (world, len(gpart.neighbours), sum(len(i_) for _, i_ in gpart.neighbours)),
+                       "layers_per_gpu": part.nzl if gpart is None else None, **({"backend": "gloo (shared device, test)"} if share else ({"backend": "nccl (RCCL)" if xd is gd else "RCCL behind the C ABI (tb_comm_*)"} if gd is not None else {}))},
             "dof_updates_per_s": ns * dofs_total * K_ / elapsed,
+            # what a host pays ONCE per mesh before the first timed step, outside `value`: host = synthetic mesh + dof table + sparsity pattern + uploads (the
+            # generators stand in for Ferrite; a Julia host passes its own arrays), first_step = the plans the first assembly builds (patch decomposition,
+            # scatter signatures, one-trip records: host code of tb_plans.cpp) + the first launches
+            "setup_s": {"total": t_setup2 - t_setup0, "host_mesh_dofs_pattern_upload": t_setup1 - t_setup0, "first_step_incl_plan_build": t_setup2 - t_setup1,
+                        "locality_renumbering": pr.renumber_s, "steps_worth": (t_setup2 - t_setup0) / (elapsed / K_)},
+            "pin": FERRITE_PIN,
+            **({"checksums": chk} if chk is not None else {}),
             "phase_ms": ({"mass+diffusion": k_ms} if fused else {"mass": phase["mass"] / K_, "diffusion": k_ms}) | {k: phase[k] / K_ for k in ("source", "halo", "reaction")},
             "phase_rates": {"matrix_integrations_per_s": 2 * g.n_cells / (mk_ms * 1e-3),
                             "source_cells_per_s": g.n_cells / (phase["source"] / K_ * 1e-3),
@@ -771,6 +883,8 @@ def main():
                         "ok": bool(eM < 1e-10 and eK < 1e-10 and eb < 1e-10)}
 
             out["cpu_baseline"] = cpu_baseline(args.cpu_n, kap, args.ionic, big=big, check=None if args.no_cpu_big else parity)
+        if FERRITE_PIN["note"]:
+            sys.stderr.write("bench.py: " + FERRITE_PIN["note"] + "\n")
         print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()

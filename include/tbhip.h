@@ -159,10 +159,13 @@ const char *tb_last_error_string(void);
  * that ran (no reference counterpart). */
 const char *tb_last_kernel_name(void);
 const char *tb_version(void);
-/* Revision of this interface, bumped whenever an existing entry changes what it reads or writes through its pointers (new entries alone do not
- * bump it).  4: tb_cgd_update writes three doubles (d_out3; revisions ≤ 3 wrote two).  A host binding compares tb_abi_revision() with the
+/* Revision of this interface, bumped whenever an existing entry changes what it reads or writes through its pointers OR entries are added (a
+ * binding written against revision n may call anything revision n declares, so a library of revision < n must be refused up front rather than at
+ * the first missing symbol).  4: tb_cgd_update writes three doubles (d_out3; revisions ≤ 3 wrote two).  5: tb_graph_*, tb_comm_exchange_begin / _end,
+ * tb_cgd_iteration, tb_last_kernel_name.  6: tb_host_locality_permutation; calls that wait for the device refuse inside an open capture
+ * (TB_ERR_BAD_ARG) instead of invalidating it.  A host binding compares tb_abi_revision() with the
  * TB_ABI_REVISION it was written against and refuses to run on a mismatch (julia/ThunderboltHIPBackend.jl does, in __init__) */
-#define TB_ABI_REVISION 4
+#define TB_ABI_REVISION 6
 int tb_abi_revision(void);
 
 /* ------------------------------------------------------------------ device (AbstractGPUDevice, src/devices.jl:3-4;
@@ -613,6 +616,18 @@ int64_t tb_host_close_dofs(int field_kind, int ncomp, int64_t n_cells, int64_t n
 /* two-pass: colidx == NULL → counts only (fills rowptr, returns nnz) */
 int64_t tb_host_build_pattern(int64_t n_cells, int ndofs_per_cell, const int32_t *cell_dofs, int64_t ndofs,
                               int64_t *rowptr, int32_t *colidx);
+
+/* Locality order for an arbitrarily numbered mesh (host-side; the numbering-insensitive cell loop of src/modeling/core/coordinate_systems.jl:145-171 has
+ * no use for one — the device plans do: shared scatter / row signatures, cache-resident SpMV gathers).  Sweep over the per-axis cell layers the patch
+ * planner cuts (exactly the (i, j, k) layers of a distorted structured grid, density-adaptive on unstructured meshes).  Outputs, each optional (NULL):
+ *   cell_perm[k]  = the cell to store k-th                     (n_cells entries)  → build the Grid with cells[cell_perm]
+ *   node_perm[v]  = new number of grid node v                  (n_nodes entries)  → nodes[invperm(node_perm)], cell node ids mapped through node_perm
+ *   dof_perm[d]   = new number of dof d                        (ndofs entries)    → Ferrite.renumber!(dh, dof_perm) before the pattern is allocated:
+ *                   first visit when the cells are traversed in cell_perm order, local dofs in cell_dofs order — what close!(dh) numbers on a grid
+ *                   stored in that order, so a lattice under any numbering receives generate_grid's own numbers back.
+ * conn / cell_dofs / the outputs are index_base-based (0 or 1); cell_dofs, ndofs_per_cell, ndofs are read only when dof_perm is asked for. */
+int tb_host_locality_permutation(int geom_kind, int64_t n_nodes, const double *xyz, int64_t n_cells, const int32_t *conn, int ndofs_per_cell,
+                                 const int32_t *cell_dofs, int64_t ndofs, int index_base, int32_t *cell_perm, int32_t *node_perm, int32_t *dof_perm);
 
 #ifdef __cplusplus
 }

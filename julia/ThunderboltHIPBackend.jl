@@ -19,7 +19,7 @@ import Thunderbolt: AbstractGPUDevice, AbstractAssemblyStrategy, AbstractSolver,
 const libtbhip = get(ENV, "TBHIP_LIBRARY", "libtbhip.so")
 
 # revision of include/tbhip.h these ccalls were written against (TB_ABI_REVISION); a library of another revision reads / writes other buffer sizes
-const TB_ABI_REVISION = 4
+const TB_ABI_REVISION = 6
 const TB_ERR_UNSUPPORTED = Cint(-5) # include/tbhip.h
 function __init__()
     have = ccall((:tb_abi_revision, libtbhip), Cint, ())
@@ -39,9 +39,9 @@ mutable struct MI355XDevice{Tv, Ti} <: AbstractGPUDevice
         finalizer(d -> ccall((:tb_device_destroy, libtbhip), Cint, (Ptr{Cvoid},), d.handle), dev)
         return dev
     end
+end
 # the kernel instance the latest assembly call launched (benchmark lines)
 last_kernel_name() = unsafe_string(ccall((:tb_last_kernel_name, libtbhip), Cstring, ()))
-end
 MI355XDevice(id = 0) = MI355XDevice{Float64, Int32}(id)
 value_type(::MI355XDevice{Tv}) where {Tv} = Tv
 index_type(::MI355XDevice{Tv, Ti}) where {Tv, Ti} = Ti
@@ -153,6 +153,25 @@ function DeviceDofHandler(dev::MI355XDevice, dh::DofHandler)
         ccall((:tb_mesh_destroy, libtbhip), Cint, (Ptr{Cvoid},), d.mesh)
     end
     return DOFHANDLERS[dh] = ddh
+end
+
+# Locality numbering for a DofHandler on an arbitrarily numbered grid (a mesh read from a file): call BEFORE the first setup_operator /
+# create_system_matrix of this DofHandler.  The reference's cell loop does not care how a mesh is numbered (src/modeling/core/coordinate_systems.jl:145-171);
+# the device plans do (shared scatter signatures, SpMV gathers that stay in the caches).  tb_host_locality_permutation sweeps the per-axis cell layers the
+# patch planner cuts and numbers the dofs by first visit in that order — what close!(dh) would number on a grid stored in that order.
+function locality_renumber!(dh::DofHandler)
+    grid = Ferrite.get_grid(dh)
+    sdim = Ferrite.getspatialdim(grid)
+    xyz = Float64[i <= sdim ? n.x[i] : 0.0 for n in grid.nodes for i in 1:3]
+    conn = Int32[v for c in grid.cells for v in c.nodes]
+    celldofs = Int32.(dh.cell_dofs)
+    kind = grid.cells[1] isa Quadrilateral ? Cint(2) : grid.cells[1] isa Hexahedron ? Cint(3) : Cint(4)
+    perm = Vector{Int32}(undef, ndofs(dh))
+    check(ccall((:tb_host_locality_permutation, libtbhip), Cint,
+        (Cint, Int64, Ptr{Float64}, Int64, Ptr{Int32}, Cint, Ptr{Int32}, Int64, Cint, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}),
+        kind, length(grid.nodes), xyz, length(grid.cells), conn, Ferrite.ndofs_per_cell(dh), celldofs, ndofs(dh), 1, C_NULL, C_NULL, perm))
+    Ferrite.renumber!(dh, Int.(perm))                    # perm[d] = new number of dof d (Ferrite's convention)
+    return dh
 end
 
 # device CSR matrix: the shared pattern + one nzval vector (rowptr / colval stay inside the library: tb_pattern_{rowptr,colidx}_device)

@@ -233,3 +233,30 @@ def test_bench_two_ranks_weak_mode_still_available():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert d["scaling"] == "weak" and d["config"]["cells_per_gpu"] == 16 ** 3 and d["config"]["cells_total"] == 2 * 16 ** 3
+
+
+def _bench_line(args, env=None, timeout=900):
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=dict(os.environ, **(env or {})), capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("mesh_args", [["--mesh", "lv", "--lv-dims", "24,4,16"], ["--mesh", "shuffled", "--n", "16"], ["--mesh", "lv", "--lv-dims", "24,4,16", "--renumber", "grid"]])
+def test_bench_unstructured_meshes_under_the_bisection_partition_match_one_rank(mesh_args):
+    """BASELINE configs[4] is an 8-GPU run on a ventricle mesh: bench.py --mesh lv (and the shuffled box) at N > 1 partitions the cells by recursive
+    coordinate bisection (tb.distributed.partition_cells_rcb / GeneralPartition: every part exchanges with every part it shares nodes with).  Two
+    ranks on cuda:0 over gloo (TB_BENCH_SHARE_DEVICE) must leave behind what one rank leaves: --checksums prints partition-independent sums of
+    M, K, b and the ionic states after two steps from the same initial state — equal to 1e-10 relative."""
+    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-graph", "--no-slab-sweep", "--checksums", "--preroll-ms", "0"] + mesh_args
+    one = _bench_line(["--gpus", "1"] + common)
+    two = _bench_line(["--gpus", "2"] + common, env={"TB_BENCH_SHARE_DEVICE": "1"})
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["config"]["backend"].startswith("gloo")
+    assert "bisection" in two["config"]["partition"] and two["config"]["cells_total"] == one["config"]["cells_total"]
+    assert two["config"]["cells_per_gpu"] * 2 in (one["config"]["cells_total"], one["config"]["cells_total"] + 1, one["config"]["cells_total"] - 1)
+    assert two["phase_ms"]["halo"] > 0.0 and two["distributed_cg"]["halo_bytes_per_rank"] > 0
+    for k, v in one["checksums"].items():
+        assert abs(two["checksums"][k] - v) <= 1e-10 * abs(v), (k, v, two["checksums"][k])

@@ -215,3 +215,42 @@ def test_bench_refuses_a_world_size_that_is_not_gpus():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64"], capture_output=True, text=True, env=env, timeout=120)
     assert r.returncode != 0 and "n_gpus" not in r.stdout           # more ranks than visible GPUs: refused before anything is launched
+
+
+@pytest.mark.parametrize("nel,order", [((6, 5, 7), 1), ((4, 3, 5), 2)])
+def test_locality_permutation_returns_a_shuffled_lattice_to_its_own_numbering(tb, nel, order):
+    """tb_host_locality_permutation on a perturbed box whose cells and nodes were renumbered at random: the cells come back in generate_grid's
+    order, the nodes in its lexicographic order, and the dofs get the numbers close!(dh) gives on the original grid (reference behaviour to match:
+    the cell loop of src/modeling/core/coordinate_systems.jl:145-171 is insensitive to numbering — the permutation only changes names)."""
+    g0 = tb.generate_mesh(tb.Hexahedron, nel, (-1, -1, -1), (1, 2, 3), perturb=0.2)
+    ip = tb.LagrangeCollection(order)
+    dh0 = tb.DofHandler(g0, ip)
+    rng = np.random.default_rng(7)
+    pn, pc = rng.permutation(g0.n_nodes), rng.permutation(g0.n_cells)
+    inv = np.empty_like(pn); inv[pn] = np.arange(g0.n_nodes)
+    gs = tb.Grid(tb.Hexahedron, g0.xyz[pn], inv[g0.conn[pc]].astype(np.int32))
+    dhs = tb.DofHandler(gs, ip)
+    cell_perm, node_perm, dof_perm = tb.locality_permutation(gs, dhs)
+    assert sorted(cell_perm) == list(range(gs.n_cells)) and sorted(node_perm) == list(range(gs.n_nodes)) and sorted(dof_perm) == list(range(dhs.ndofs))
+    gr = tb.renumber_grid(gs, cell_perm, node_perm)
+    np.testing.assert_array_equal(gr.conn, g0.conn)
+    np.testing.assert_array_equal(gr.xyz, g0.xyz)
+    # renumber!(dh, perm) on the shuffled grid, cells read in the new order = the original dof table
+    np.testing.assert_array_equal(dof_perm[dhs.cell_dofs][cell_perm], dh0.cell_dofs)
+    # … and a DofHandler closed on the renumbered grid numbers the same way (first visit)
+    np.testing.assert_array_equal(tb.DofHandler(gr, ip).cell_dofs, dh0.cell_dofs)
+
+
+def test_locality_permutation_on_tetrahedra_and_bad_arguments(tb):
+    g = tb.generate_mesh(tb.Hexahedron, (3, 3, 3), (0, 0, 0), (1, 1, 1))
+    tets = np.concatenate([g.conn[:, [0, 1, 3, 4]], g.conn[:, [1, 2, 3, 6]], g.conn[:, [1, 5, 4, 6]], g.conn[:, [3, 7, 6, 4]], g.conn[:, [1, 3, 4, 6]]]).astype(np.int32)
+    gt = tb.Grid(tb.Tetrahedron, g.xyz, tets)
+    dh = tb.DofHandler(gt)
+    cp, npm, dp = tb.locality_permutation(gt, dh)
+    assert sorted(cp) == list(range(gt.n_cells)) and sorted(npm) == list(range(gt.n_nodes)) and sorted(dp) == list(range(dh.ndofs))
+    # first visit: the first cell of the new order holds dofs 0 … 3
+    assert sorted(dp[dh.cell_dofs[cp[0]]]) == [0, 1, 2, 3]
+    L = tb._lib
+    rc = tb.lib().tb_host_locality_permutation(99, gt.n_nodes, gt.xyz.ctypes.data_as(L.c_dp), gt.n_cells, gt.conn.ctypes.data_as(L.c_i32p), 0, None, 0, 0,
+                                               cp.ctypes.data_as(L.c_i32p), None, None)
+    assert rc == L.TB_ERR_BAD_ARG and b"geom_kind" in tb.lib().tb_last_error_string()

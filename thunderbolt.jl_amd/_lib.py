@@ -184,6 +184,7 @@ SIGNATURES = {
     "tb_host_perturb_nodes": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, c_dp]),
     "tb_host_close_dofs": (C.c_int64, [C.c_int, C.c_int, C.c_int64, C.c_int64, c_i32p, c_i32p]),
     "tb_host_build_pattern": (C.c_int64, [C.c_int64, C.c_int, c_i32p, C.c_int64, c_i64p, c_i32p]),
+    "tb_host_locality_permutation": (C.c_int, [C.c_int, C.c_int64, c_dp, C.c_int64, c_i32p, C.c_int, c_i32p, C.c_int64, C.c_int, c_i32p, c_i32p, c_i32p]),
 }
 
 
@@ -205,7 +206,7 @@ def build_library(force=False):
 _lib = None
 
 
-TB_ABI_REVISION = 4   # include/tbhip.h: TB_ABI_REVISION
+TB_ABI_REVISION = 6   # include/tbhip.h: TB_ABI_REVISION
 
 
 def lib():

@@ -80,9 +80,12 @@ class MI355XDevice:
         h = C.c_void_p()
         try:
             body()
-        finally:
-            rc = lib().tb_graph_end(self.h, C.byref(h))
-        check(rc)
+        except BaseException:
+            # the capture is closed either way; a graph that did end is released (nobody will hold its handle) before the exception travels on
+            if lib().tb_graph_end(self.h, C.byref(h)) == 0 and h:
+                lib().tb_graph_destroy(h)
+            raise
+        check(lib().tb_graph_end(self.h, C.byref(h)))
         return DeviceGraph(self, h)
 
     def info(self):
@@ -396,6 +399,32 @@ class DofHandler:
 
 def ndofs(dh):
     return dh.ndofs
+
+
+def locality_permutation(grid, dh=None):
+    """tb_host_locality_permutation: (cell_perm, node_perm, dof_perm) for an arbitrarily numbered grid — cell_perm[k] = cell to store k-th,
+    node_perm[v] / dof_perm[d] = new numbers (dof_perm is None without a DofHandler).  The reference's cell loop does not care how a mesh is
+    numbered (src/modeling/core/coordinate_systems.jl:145-171); the device plans do."""
+    nc, nn = grid.n_cells, grid.n_nodes
+    cp, npm = np.empty(nc, dtype=np.int32), np.empty(nn, dtype=np.int32)
+    dp = np.empty(dh.ndofs, dtype=np.int32) if dh is not None else None
+    check(lib().tb_host_locality_permutation(grid.cell_kind, nn, grid.xyz.ctypes.data_as(L.c_dp), nc, grid.conn.ctypes.data_as(L.c_i32p),
+                                             dh.ndofs_per_cell if dh is not None else 0, dh.cell_dofs.ctypes.data_as(L.c_i32p) if dh is not None else None,
+                                             dh.ndofs if dh is not None else 0, 0, cp.ctypes.data_as(L.c_i32p), npm.ctypes.data_as(L.c_i32p),
+                                             dp.ctypes.data_as(L.c_i32p) if dp is not None else None))
+    return cp, npm, dp
+
+
+def renumber_grid(grid, cell_perm, node_perm):
+    """The same mesh stored in the locality order: cells[cell_perm], nodes moved to their new numbers (what a Julia host does before DofHandler(grid))."""
+    inv = np.empty_like(node_perm)
+    inv[node_perm] = np.arange(len(node_perm), dtype=node_perm.dtype)
+    return Grid(grid.cell_kind, grid.xyz[inv], node_perm[grid.conn[cell_perm]].astype(np.int32), dims=grid.dims)
+
+
+def renumber_dofs(dh, dof_perm):
+    """Ferrite.renumber!(dh, perm): the DofHandler with every dof d renamed dof_perm[d] (cells stay where they are)."""
+    return DofHandler(dh.grid, dh.ip, cell_dofs=dof_perm[dh.cell_dofs].astype(np.int32), ndofs=dh.ndofs)
 
 
 class SparsityPattern:

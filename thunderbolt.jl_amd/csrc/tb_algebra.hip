@@ -615,6 +615,7 @@ k_spmv_b3(int64_t n_brows, const int64_t *__restrict__ rowptr, const int32_t *__
 static int block3_plan(tb_pattern *p)
 {
     if (p->b3 != 0) return TB_OK;
+    TB_NO_CAPTURE(p->mesh->dev); // a plan is built (host work + blocking uploads) at its first use: make that use before the capture
     static const bool off = tune_env("TB_SPMV_B3") && atoi(tune_env("TB_SPMV_B3")) == 0;
     p->b3 = -1;
     if (off || p->n_rows % 3 != 0 || p->nnz % 9 != 0 || p->nnz == 0) return TB_OK;
@@ -662,6 +663,7 @@ constexpr int SPMV_CAP = TB_SPMV_CAP;
 static int stream_plan(tb_pattern *p)
 {
     if (p->n_blk != 0) return TB_OK;
+    TB_NO_CAPTURE(p->mesh->dev);
     std::vector<int32_t> cut{0};
     int64_t start = 0;
     for (int64_t r = 0; r < p->n_rows; ++r) {
@@ -695,6 +697,7 @@ static int stream_plan(tb_pattern *p)
 static int sig_plan(tb_pattern *p, bool forced = false)
 {
     if (p->n_sig != 0) return TB_OK;
+    TB_NO_CAPTURE(p->mesh->dev);
     const bool off = !forced && spmv_kernel_env() && strcmp(spmv_kernel_env(), "sig") != 0; // "rows" / "rec" / "chain": the CSR kernels (read per pattern: A/B runs and the bit-identity test build one pattern of each kind in one process)
     const int64_t n = p->n_rows;
     if (off || n == 0 || p->nnz >= (int64_t)0xffffffffll) { p->n_sig = -1; return TB_OK; }
@@ -754,6 +757,7 @@ static int sig_plan_forced(tb_pattern *p) { return sig_plan(p, true); }
 static int wave_plan(tb_pattern *p)
 {
     if (p->n_wrun != 0) return TB_OK;
+    TB_NO_CAPTURE(p->mesh->dev);
     std::vector<uint32_t> rec;
     int64_t start = 0;
     auto push = [&](int64_t r0, int64_t r1) {
@@ -787,6 +791,7 @@ constexpr int32_t MIRROR_NONE = INT32_MIN; // column offset of a padding entry
 static int mirror_plan(tb_pattern *p)
 {
     if (p->n_slices != 0) return TB_OK;
+    TB_NO_CAPTURE(p->mesh->dev);
     int rc = spmv_plans(p);
     if (rc) return rc;
     if (p->b3 > 0 || p->n_rows == 0) { p->n_slices = -1; return TB_OK; }
@@ -1059,13 +1064,14 @@ int launch_spmv(tb_pattern *p, const double *nz, const double *x, double alpha, 
 
 int launch_absmax(tb_device *dev, int64_t n, const double *x, int64_t stride, double *result)
 {
+    TB_NO_CAPTURE(dev); // the result goes to the host
     unsigned long long *d_out = (unsigned long long *)&dev->d_status->cell; // 8-byte scratch inside the status block
     TB_HIP(hipMemsetAsync(d_out, 0, sizeof(unsigned long long), dev->stream));
     hipLaunchKernelGGL(k_absmax, dim3(grid_for(dev, n, 256)), dim3(256), 0, dev->stream, n, x, stride, d_out);
     TB_HIP(hipGetLastError());
     unsigned long long bits = 0;
     TB_HIP(hipMemcpyAsync(&bits, d_out, sizeof bits, hipMemcpyDeviceToHost, dev->stream));
-    TB_HIP(hipStreamSynchronize(dev->stream));
+    TB_SYNC_STREAM(dev);
     memcpy(result, &bits, sizeof bits);
     return TB_OK;
 }
@@ -1080,6 +1086,7 @@ double decode_ordered_key(unsigned long long k)
 
 int launch_max(tb_device *dev, int64_t n, const double *x, int64_t stride, double *result)
 {
+    TB_NO_CAPTURE(dev); // the result goes to the host
     unsigned long long *d_out = (unsigned long long *)&dev->d_status->cell; // 8-byte scratch inside the status block
     TB_HIP(hipMemsetAsync(d_out, 0, sizeof(unsigned long long), dev->stream)); // key 0 < key(−∞)
     if (n > 0) {
@@ -1088,7 +1095,7 @@ int launch_max(tb_device *dev, int64_t n, const double *x, int64_t stride, doubl
     }
     unsigned long long bits = 0;
     TB_HIP(hipMemcpyAsync(&bits, d_out, sizeof bits, hipMemcpyDeviceToHost, dev->stream));
-    TB_HIP(hipStreamSynchronize(dev->stream));
+    TB_SYNC_STREAM(dev);
     *result = bits ? decode_ordered_key(bits) : -__builtin_huge_val();
     return TB_OK;
 }
@@ -1121,6 +1128,7 @@ static int launch_extract_diag(tb_pattern *p, const double *nz, double *dinv, bo
 {
     tb_device *dev = p->mesh->dev;
     if (!p->d_diagpos) {
+        TB_NO_CAPTURE(dev);
         std::vector<int64_t> pos((size_t)p->n_rows, -1);
         for (int64_t r = 0; r < p->n_rows; ++r)
             for (int64_t k = p->h_rowptr[r]; k < p->h_rowptr[r + 1]; ++k)
@@ -1336,6 +1344,7 @@ int launch_cg(tb_pattern *pat, const double *A, const double *b, double *x, doub
               double *resnorm, bool b_is_residual)
 {
     tb_device *dev = pat->mesh->dev;
+    TB_NO_CAPTURE(dev); // reads scalars back (convergence looks)
     const int64_t n = pat->n_rows;
     if (!pat->d_cg_ws) TB_HIP(hipMalloc((void **)&pat->d_cg_ws, sizeof(double) * (4 * n + 8)));
     double *r = pat->d_cg_ws, *p = r + n, *Ap = p + n, *dinv = Ap + n, *scal = dinv + n;
@@ -1355,7 +1364,7 @@ int launch_cg(tb_pattern *pat, const double *A, const double *b, double *x, doub
     hipLaunchKernelGGL(k_cg_init, dim3(g), dim3(256), 0, dev->stream, n, b, Ap, dp, r, p, scal);
     double h[3];
     TB_HIP(hipMemcpyAsync(h, scal, 2 * sizeof(double), hipMemcpyDeviceToHost, dev->stream));
-    TB_HIP(hipStreamSynchronize(dev->stream));
+    TB_SYNC_STREAM(dev);
     // the loop's sums live in slot groups of the device ("reduction slots"): pᵀAp, r·z of the current / next / retired iteration (rotating), rᵀr
     double *const g_pap = red_group(dev, 3), *const g_rr = red_group(dev, 7);
     auto g_rz = [&](int k) { return red_group(dev, 4 + k); };
@@ -1388,7 +1397,7 @@ int launch_cg(tb_pattern *pat, const double *A, const double *b, double *x, doub
         cur = nxt;
         ++it;
         if (!look) continue;
-        TB_HIP(hipStreamSynchronize(dev->stream));
+        TB_SYNC_STREAM(dev);
         if (h[2] != 0.0) { set_error("tb_cg_solve: matrix is not positive definite (pᵀAp = %g)", h[2] == -1e-300 ? 0.0 : h[2]); return TB_ERR_BAD_ARG; }
         rnorm = std::sqrt(h[1]);
     }
@@ -1459,6 +1468,7 @@ int launch_gmres(tb_pattern *pat, const double *A, const double *b, double *x, d
                  int *iters, double *resnorm)
 {
     tb_device *dev = pat->mesh->dev;
+    TB_NO_CAPTURE(dev); // reads scalars back (convergence looks)
     const int64_t n = pat->n_rows;
     const int m = restart;
     if (pat->gmres_m < m) {
@@ -1483,7 +1493,7 @@ int launch_gmres(tb_pattern *pat, const double *A, const double *b, double *x, d
         TB_HIP(hipMemsetAsync(h1, 0, sizeof(double), dev->stream));
         hipLaunchKernelGGL(k_residual, dim3(g), dim3(256), 0, dev->stream, n, b, z, w, h1);
         TB_HIP(hipMemcpyAsync(hh.data(), h1, sizeof(double), hipMemcpyDeviceToHost, dev->stream));
-        TB_HIP(hipStreamSynchronize(dev->stream));
+        TB_SYNC_STREAM(dev);
         rnorm = std::sqrt(hh[0]);
         if (first) { tol = atol + rtol * rnorm; pat->last_tol = tol; first = false; }
         if (!(rnorm > tol) || it >= maxiter) break;
@@ -1505,7 +1515,7 @@ int launch_gmres(tb_pattern *pat, const double *A, const double *b, double *x, d
             hipLaunchKernelGGL(k_multi_dot, dim3(gd, j + 1), dim3(256), 0, dev->stream, n, V, w, h2);
             hipLaunchKernelGGL(k_multi_axpy, dim3(grid_red(dev, n)), dim3(1024), 0, dev->stream, n, j + 1, -1.0, h2, GM_HS, V, w, h2 + (size_t)(m + 1) * GM_HS); // ‖w‖² in the last slot
             TB_HIP(hipMemcpyAsync(hh.data(), sc, sizeof(double) * 2 * (m + 2) * GM_HS, hipMemcpyDeviceToHost, dev->stream));
-            TB_HIP(hipStreamSynchronize(dev->stream));
+            TB_SYNC_STREAM(dev);
             double *Hj = H.data() + (size_t)j * (m + 1);
             for (int i = 0; i <= j; ++i) Hj[i] = hh[(size_t)i * GM_HS] + hh[((size_t)(m + 2) + i) * GM_HS];
             const double wn = std::sqrt(hh[((size_t)(m + 2) + (m + 1)) * GM_HS]);
@@ -1530,7 +1540,7 @@ int launch_gmres(tb_pattern *pat, const double *A, const double *b, double *x, d
         TB_HIP(hipMemsetAsync(z, 0, sizeof(double) * n, dev->stream));
         hipLaunchKernelGGL(k_multi_axpy, dim3(grid_red(dev, n)), dim3(1024), 0, dev->stream, n, j, 1.0, yd, 1, V, z, (double *)nullptr);
         hipLaunchKernelGGL(k_add_diag, dim3(g), dim3(256), 0, dev->stream, n, dp, z, x);
-        TB_HIP(hipStreamSynchronize(dev->stream)); // yh is reused by the next cycle
+        TB_SYNC_STREAM(dev); // yh is reused by the next cycle
     }
     TB_HIP(hipGetLastError());
     if (iters) *iters = it;
@@ -1627,6 +1637,7 @@ int launch_l1gs_apply(tb_pattern *pat, const double *A, const double *d_dtilde, 
 int launch_pcg_l1gs(tb_pattern *pat, const double *A, const double *b, double *x, double rtol, double atol, int maxiter, int ps, int *iters, double *resnorm)
 {
     tb_device *dev = pat->mesh->dev;
+    TB_NO_CAPTURE(dev); // reads scalars back (convergence looks)
     const int64_t n = pat->n_rows;
     if (!pat->d_pcg_ws) TB_HIP(hipMalloc((void **)&pat->d_pcg_ws, sizeof(double) * (5 * n + 8)));
     double *r = pat->d_pcg_ws, *z = r + n, *p = z + n, *Ap = p + n, *dtl = Ap + n, *scal = dtl + n;
@@ -1639,7 +1650,7 @@ int launch_pcg_l1gs(tb_pattern *pat, const double *A, const double *b, double *x
     TB_HIP(hipMemsetAsync(scal, 0, 2 * sizeof(double), dev->stream));
     hipLaunchKernelGGL(k_residual, dim3(g), dim3(256), 0, dev->stream, n, b, Ap, r, scal);
     TB_HIP(hipMemcpyAsync(h, scal, sizeof(double), hipMemcpyDeviceToHost, dev->stream));
-    TB_HIP(hipStreamSynchronize(dev->stream));
+    TB_SYNC_STREAM(dev);
     double rnorm = std::sqrt(h[0]);
     const double tol = atol + rtol * rnorm;
     pat->last_tol = tol;
@@ -1651,7 +1662,7 @@ int launch_pcg_l1gs(tb_pattern *pat, const double *A, const double *b, double *x
         TB_HIP(hipMemsetAsync(scal, 0, 2 * sizeof(double), dev->stream));
         hipLaunchKernelGGL(k_dot, dim3(grid_red(dev, n)), dim3(1024), 0, dev->stream, n, r, z, scal);
         TB_HIP(hipMemcpyAsync(h, scal, sizeof(double), hipMemcpyDeviceToHost, dev->stream));
-        TB_HIP(hipStreamSynchronize(dev->stream));
+        TB_SYNC_STREAM(dev);
         const double rz_new = h[0];
         if (it == 0) TB_HIP(hipMemcpyAsync(p, z, sizeof(double) * n, hipMemcpyDeviceToDevice, dev->stream));
         else hipLaunchKernelGGL(k_cg_direction, dim3(g), dim3(256), 0, dev->stream, n, rz_new / rz, z, (const double *)nullptr, p);
@@ -1661,13 +1672,13 @@ int launch_pcg_l1gs(tb_pattern *pat, const double *A, const double *b, double *x
         TB_HIP(hipMemsetAsync(scal, 0, 2 * sizeof(double), dev->stream));
         hipLaunchKernelGGL(k_dot, dim3(grid_red(dev, n)), dim3(1024), 0, dev->stream, n, p, Ap, scal);
         TB_HIP(hipMemcpyAsync(h, scal, sizeof(double), hipMemcpyDeviceToHost, dev->stream));
-        TB_HIP(hipStreamSynchronize(dev->stream));
+        TB_SYNC_STREAM(dev);
         if (!(h[0] > 0.0)) { set_error("tb_pcg_solve: matrix is not positive definite (pᵀAp = %g)", h[0]); return TB_ERR_BAD_ARG; }
         const double alpha = rz / h[0];
         TB_HIP(hipMemsetAsync(scal, 0, 2 * sizeof(double), dev->stream));
         hipLaunchKernelGGL(k_cg_update, dim3(grid_red(dev, n)), dim3(1024), 0, dev->stream, n, alpha, p, Ap, (const double *)nullptr, x, r, scal);
         TB_HIP(hipMemcpyAsync(h, scal, 2 * sizeof(double), hipMemcpyDeviceToHost, dev->stream));
-        TB_HIP(hipStreamSynchronize(dev->stream));
+        TB_SYNC_STREAM(dev);
         rnorm = std::sqrt(h[1]);
         ++it;
     }
@@ -1789,6 +1800,7 @@ k_pcg_update_dev(int64_t n, const double *__restrict__ rz_new, const double *__r
 int launch_pcg_chebyshev(tb_pattern *pat, const double *A, const double *b, double *x, double rtol, double atol, int maxiter, int degree, int *iters, double *resnorm)
 {
     tb_device *dev = pat->mesh->dev;
+    TB_NO_CAPTURE(dev); // reads scalars back (convergence looks)
     const int64_t n = pat->n_rows;
     if (!pat->d_cheb_ws) TB_HIP(hipMalloc((void **)&pat->d_cheb_ws, sizeof(double) * (7 * n + 16)));
     double *r = pat->d_cheb_ws, *z = r + n, *p = z + n, *Ap = p + n, *dinv = Ap + n, *d = dinv + n, *w = d + n, *S = w + n; // S: rz | rz_new | pAp | rr | flag | power sums
@@ -1811,7 +1823,7 @@ int launch_pcg_chebyshev(tb_pattern *pat, const double *A, const double *b, doub
         TB_HIP(hipMemsetAsync(S + 8, 0, 2 * sizeof(double), dev->stream));
         hipLaunchKernelGGL(k_dot, dim3(grid_red(dev, n)), dim3(1024), 0, dev->stream, n, v, v, S + 8);
         TB_HIP(hipMemcpyAsync(h, S + 8, sizeof(double), hipMemcpyDeviceToHost, dev->stream));
-        TB_HIP(hipStreamSynchronize(dev->stream));
+        TB_SYNC_STREAM(dev);
         int kdone = 0;
         if (h[0] > 0.0) {
             hipLaunchKernelGGL(k_scale_to, dim3(g), dim3(256), 0, dev->stream, n, 1.0 / std::sqrt(h[0]), v, v);
@@ -1823,11 +1835,11 @@ int launch_pcg_chebyshev(tb_pattern *pat, const double *A, const double *b, doub
                 TB_HIP(hipMemsetAsync(S + 8, 0, 2 * sizeof(double), dev->stream));
                 hipLaunchKernelGGL(k_lanczos_a, dim3(grid_red(dev, n)), dim3(1024), 0, dev->stream, n, sq, be[k], vp, v, w, S + 8); // w = D^-½ w − β v₋₁; α = w·v
                 TB_HIP(hipMemcpyAsync(h, S + 8, sizeof(double), hipMemcpyDeviceToHost, dev->stream));
-                TB_HIP(hipStreamSynchronize(dev->stream));
+                TB_SYNC_STREAM(dev);
                 al[k] = h[0];
                 hipLaunchKernelGGL(k_lanczos_b, dim3(grid_red(dev, n)), dim3(1024), 0, dev->stream, n, al[k], v, w, S + 9);  // w −= α v; ‖w‖²
                 TB_HIP(hipMemcpyAsync(h, S + 9, sizeof(double), hipMemcpyDeviceToHost, dev->stream));
-                TB_HIP(hipStreamSynchronize(dev->stream));
+                TB_SYNC_STREAM(dev);
                 kdone = k + 1;
                 be[k + 1] = std::sqrt(h[0]);
                 if (!(be[k + 1] > 1e-12 * std::fabs(al[k]))) break;                                           // invariant subspace: the Ritz values are exact
@@ -1876,7 +1888,7 @@ int launch_pcg_chebyshev(tb_pattern *pat, const double *A, const double *b, doub
     TB_HIP(hipMemsetAsync(S, 0, 8 * sizeof(double), dev->stream));
     hipLaunchKernelGGL(k_residual, dim3(g), dim3(256), 0, dev->stream, n, b, Ap, r, S + 3);
     TB_HIP(hipMemcpyAsync(h, S + 3, sizeof(double), hipMemcpyDeviceToHost, dev->stream));
-    TB_HIP(hipStreamSynchronize(dev->stream));
+    TB_SYNC_STREAM(dev);
     double rnorm = std::sqrt(h[0]);
     const double tol = atol + rtol * rnorm;
     pat->last_tol = tol;
@@ -1897,7 +1909,7 @@ int launch_pcg_chebyshev(tb_pattern *pat, const double *A, const double *b, doub
             hipLaunchKernelGGL(k_pcg_update_dev, dim3(grid_red(dev, n)), dim3(1024), 0, dev->stream, n, S + 1, S + 2, p, Ap, x, r, S + 3, S + 4);
         }
         TB_HIP(hipMemcpyAsync(h, S + 3, 2 * sizeof(double), hipMemcpyDeviceToHost, dev->stream));
-        TB_HIP(hipStreamSynchronize(dev->stream));
+        TB_SYNC_STREAM(dev);
         if (h[1] != 0.0) { set_error("tb_pcg_solve: matrix or Chebyshev preconditioner is not positive definite (pᵀAp = %g)", h[1] == -1e-300 ? 0.0 : h[1]); return TB_ERR_BAD_ARG; }
         rnorm = std::sqrt(h[0]);
     }
@@ -1960,6 +1972,7 @@ int launch_apply_zero(tb_pattern *pat, double *nz, double *f, const uint8_t *fla
 int launch_meandiag(tb_pattern *pat, const double *nz, double *result)
 {
     tb_device *dev = pat->mesh->dev;
+    TB_NO_CAPTURE(dev); // reads scalars back (convergence looks)
     const int64_t n = pat->n_rows;
     *result = 0.0;
     if (!n) return TB_OK;
@@ -1971,7 +1984,7 @@ int launch_meandiag(tb_pattern *pat, const double *nz, double *result)
     TB_HIP(hipGetLastError());
     double h = 0.0;
     TB_HIP(hipMemcpyAsync(&h, scal, sizeof h, hipMemcpyDeviceToHost, dev->stream));
-    TB_HIP(hipStreamSynchronize(dev->stream));
+    TB_SYNC_STREAM(dev);
     *result = h / (double)n;
     return TB_OK;
 }
@@ -2182,6 +2195,7 @@ int launch_spmv_dot_slots(tb_pattern *pat, const double *A, const double *x, dou
 
 int launch_dot(tb_device *dev, int64_t n, const double *a, const double *b, double *result)
 {
+    TB_NO_CAPTURE(dev); // the result goes to the host
     double *scal = (double *)&dev->d_status->cell; // 8-byte scratch inside the status block
     TB_HIP(hipMemsetAsync(scal, 0, sizeof(double), dev->stream));
     if (n > 0) {
@@ -2189,7 +2203,7 @@ int launch_dot(tb_device *dev, int64_t n, const double *a, const double *b, doub
         TB_HIP(hipGetLastError());
     }
     TB_HIP(hipMemcpyAsync(result, scal, sizeof(double), hipMemcpyDeviceToHost, dev->stream));
-    TB_HIP(hipStreamSynchronize(dev->stream));
+    TB_SYNC_STREAM(dev);
     return TB_OK;
 }
 

@@ -52,8 +52,9 @@ int check_status(tb_device *dev)
 
 static int read_status(tb_device *dev)
 {
+    TB_NO_CAPTURE(dev);
     TB_HIP(hipMemcpyAsync(dev->h_status, dev->d_status, sizeof(Status), hipMemcpyDeviceToHost, dev->stream));
-    TB_HIP(hipStreamSynchronize(dev->stream));
+    TB_SYNC_STREAM(dev);
     if (dev->h_status->neg_detj) {
         set_error("detJ <= 0 in cell %lld (0-based)", dev->h_status->cell);
         return TB_ERR_NEG_DETJ;
@@ -129,7 +130,7 @@ int tb_device_destroy(tb_device *dev)
 int tb_device_set_stream(tb_device *dev, void *hip_stream)
 {
     TB_REQUIRE(dev, "tb_device_set_stream: dev is NULL");
-    TB_HIP(hipStreamSynchronize(dev->stream));
+    TB_SYNC_STREAM(dev);
     if (dev->own_stream && dev->stream) TB_HIP(hipStreamDestroy(dev->stream));
     if (hip_stream) {
         dev->stream = (hipStream_t)hip_stream;
@@ -144,7 +145,7 @@ int tb_device_set_stream(tb_device *dev, void *hip_stream)
 int tb_device_use_null_stream(tb_device *dev)
 {
     TB_REQUIRE(dev, "tb_device_use_null_stream: dev is NULL");
-    TB_HIP(hipStreamSynchronize(dev->stream));
+    TB_SYNC_STREAM(dev);
     if (dev->own_stream && dev->stream) TB_HIP(hipStreamDestroy(dev->stream));
     dev->stream = nullptr; // the legacy default stream: ordered with every blocking stream of the process (a host framework's default stream is this one)
     dev->own_stream = false;
@@ -172,7 +173,7 @@ int tb_device_poll_status(tb_device *dev)
 int tb_device_synchronize(tb_device *dev)
 {
     TB_REQUIRE(dev, "tb_device_synchronize: dev is NULL");
-    TB_HIP(hipStreamSynchronize(dev->stream));
+    TB_SYNC_STREAM(dev);
     return TB_OK;
 }
 
@@ -200,19 +201,32 @@ int tb_malloc(tb_device *dev, size_t bytes, void **d_ptr)
 // leaves the list in tb_pattern_destroy without touching its mesh or device, which a host's finaliser order may already have released)
 static std::vector<tb_pattern *> &g_mirrored = *new std::vector<tb_pattern *>; // (never destroyed: a finaliser may still call tb_pattern_destroy while the process exits)
 static std::mutex &g_mirrored_mutex = *new std::mutex;
-static void mirror_drop_any(tb_device *, const void *d_dst)
+// bytes: extent of the write [d_dst, d_dst + bytes) — any overlap with a bound array invalidates its mirror (a memset / copy over a larger arena that
+// holds the array as a sub-range starts BEFORE it).  bytes = 0: extent unknown (tb_free of an allocation whose size the library does not track) — the
+// binding goes when the bound array starts at or behind d_dst … which for a free can only be the allocation itself or a sub-range the host carved from it;
+// sub-ranges of a freed arena whose start lies further in are the host's to unbind (tbhip.h: "an array is unbound before it is freed").
+static void mirror_drop_any(tb_device *, const void *d_dst, size_t bytes = 0)
 {
     std::lock_guard<std::mutex> lock(g_mirrored_mutex);
+    const char *w0 = (const char *)d_dst, *w1 = w0 + (bytes ? bytes : 1);
     for (tb_pattern *p : g_mirrored)
-        for (const double *&q : p->mir_nz) // a write that starts anywhere inside the bound array invalidates its mirror
-            if (q && (const char *)d_dst >= (const char *)q && (const char *)d_dst < (const char *)(q + p->nnz)) q = nullptr;
+        for (const double *&q : p->mir_nz) {
+            if (!q) continue;
+            const char *a0 = (const char *)q, *a1 = (const char *)(q + p->nnz);
+            if (w0 < a1 && w1 > a0) q = nullptr;
+        }
 }
 
 int tb_free(tb_device *dev, void *d_ptr)
 {
     TB_REQUIRE(dev, "tb_free: dev is NULL");
     if (d_ptr) {
-        mirror_drop_any(dev, d_ptr); // a binding is the address: the allocator may hand it to the next matrix (host finalisers free without unmirror!)
+        {   // every binding whose array starts inside the freed allocation goes (hipMemGetAddressRange: the allocation's own extent)
+            void *base = nullptr; size_t sz = 0;
+            if (hipMemGetAddressRange((hipDeviceptr_t *)&base, &sz, (hipDeviceptr_t)d_ptr) == hipSuccess && base == d_ptr && sz) mirror_drop_any(dev, d_ptr, sz);
+            else { (void)hipGetLastError(); mirror_drop_any(dev, d_ptr); }
+        }
+        // a binding is the address: the allocator may hand it to the next matrix (host finalisers free without unmirror!)
         TB_HIP(hipFree(d_ptr));
     }
     return TB_OK;
@@ -222,9 +236,10 @@ int tb_memcpy_h2d(tb_device *dev, void *d_dst, const void *src, size_t bytes)
 {
     TB_REQUIRE(dev && (bytes == 0 || (d_dst && src)), "tb_memcpy_h2d: NULL argument");
     if (!bytes) return TB_OK;
-    mirror_drop_any(dev, d_dst);
+    TB_NO_CAPTURE(dev); // the copy waits for the stream (src is the caller's to reuse on return)
+    mirror_drop_any(dev, d_dst, bytes);
     TB_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, dev->stream));
-    TB_HIP(hipStreamSynchronize(dev->stream));
+    TB_SYNC_STREAM(dev);
     return TB_OK;
 }
 
@@ -232,8 +247,9 @@ int tb_memcpy_d2h(tb_device *dev, void *dst, const void *d_src, size_t bytes)
 {
     TB_REQUIRE(dev && (bytes == 0 || (dst && d_src)), "tb_memcpy_d2h: NULL argument");
     if (!bytes) return TB_OK;
+    TB_NO_CAPTURE(dev);
     TB_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, dev->stream));
-    TB_HIP(hipStreamSynchronize(dev->stream));
+    TB_SYNC_STREAM(dev);
     return TB_OK;
 }
 
@@ -241,7 +257,7 @@ int tb_memcpy_d2d(tb_device *dev, void *d_dst, const void *d_src, size_t bytes)
 {
     TB_REQUIRE(dev && (bytes == 0 || (d_dst && d_src)), "tb_memcpy_d2d: NULL argument");
     if (!bytes) return TB_OK;
-    mirror_drop_any(dev, d_dst); // copyto!(A.nzval, …) of the Julia host comes through here
+    mirror_drop_any(dev, d_dst, bytes); // copyto!(A.nzval, …) of the Julia host comes through here
     TB_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, dev->stream));
     return TB_OK;
 }
@@ -250,7 +266,7 @@ int tb_memset(tb_device *dev, void *d_ptr, int byte, size_t bytes)
 {
     TB_REQUIRE(dev && (bytes == 0 || d_ptr), "tb_memset: NULL argument");
     if (!bytes) return TB_OK;
-    mirror_drop_any(dev, d_ptr);
+    mirror_drop_any(dev, d_ptr, bytes);
     TB_HIP(hipMemsetAsync(d_ptr, byte, bytes, dev->stream));
     return TB_OK;
 }
@@ -440,7 +456,7 @@ int tb_form_create(tb_mesh *mesh, int form_kind, int qorder, const tb_coef *coef
                    (long long)need_field, (long long)coef->field_len);
         TB_HIP(hipMalloc((void **)&f->d_field, sizeof(double) * need_field));
         TB_HIP(hipMemcpyAsync(f->d_field, coef->field, sizeof(double) * need_field, hipMemcpyHostToDevice, mesh->dev->stream));
-        TB_HIP(hipStreamSynchronize(mesh->dev->stream));
+        TB_SYNC_STREAM(mesh->dev);
     }
     *out = f.release();
     return TB_OK;
@@ -463,7 +479,7 @@ int tb_form_set_table(tb_form *f, const double *values, int64_t n)
     if (!f->d_table) TB_HIP(hipMalloc((void **)&f->d_table, sizeof(double) * n));
     f->table_len = n;
     TB_HIP(hipMemcpyAsync(f->d_table, values, sizeof(double) * n, hipMemcpyHostToDevice, f->mesh->dev->stream));
-    TB_HIP(hipStreamSynchronize(f->mesh->dev->stream));
+    TB_SYNC_STREAM(f->mesh->dev);
     return TB_OK;
 }
 
@@ -551,7 +567,7 @@ int tb_hyperelastic_create(tb_mesh *mesh, int qorder, const tb_material *materia
                    (long long)material->fsn_field_len);
         TB_HIP(hipMalloc((void **)&f->d_field, sizeof(double) * need));
         TB_HIP(hipMemcpyAsync(f->d_field, material->fsn_field, sizeof(double) * need, hipMemcpyHostToDevice, mesh->dev->stream));
-        TB_HIP(hipStreamSynchronize(mesh->dev->stream));
+        TB_SYNC_STREAM(mesh->dev);
     }
     *out = f.release();
     return TB_OK;
@@ -568,7 +584,7 @@ int tb_hyperelastic_set_active_tension(tb_form *form, double tension, const doub
     if (!form->d_act_field && len) TB_HIP(hipMalloc((void **)&form->d_act_field, sizeof(double) * len));
     if (len) {
         TB_HIP(hipMemcpyAsync(form->d_act_field, state_field, sizeof(double) * len, hipMemcpyHostToDevice, m->dev->stream));
-        TB_HIP(hipStreamSynchronize(m->dev->stream));
+        TB_SYNC_STREAM(m->dev);
     }
     return TB_OK;
 }
@@ -790,7 +806,7 @@ int tb_facet_form_set_field(tb_form *form, const double *field, int64_t len)
     TB_HIP(hipSetDevice(m->dev->id));
     if (!form->d_field) TB_HIP(hipMalloc((void **)&form->d_field, sizeof(double) * len));
     TB_HIP(hipMemcpyAsync(form->d_field, field, sizeof(double) * len, hipMemcpyHostToDevice, m->dev->stream));
-    TB_HIP(hipStreamSynchronize(m->dev->stream));
+    TB_SYNC_STREAM(m->dev);
     return TB_OK;
 }
 
@@ -1038,7 +1054,7 @@ int tb_heat_matrix(tb_device *dev, int64_t nnz, const double *d_Mnz, const doubl
 {
     TB_REQUIRE(dev && d_Mnz && d_Knz && d_Anz && nnz >= 0, "tb_heat_matrix: bad argument");
     if (!nnz) return TB_OK;
-    mirror_drop_any(dev, d_Anz);
+    mirror_drop_any(dev, d_Anz, (size_t)nnz * sizeof(double));
     return launch_heat_matrix(dev, nnz, d_Mnz, d_Knz, dt, d_Anz);
 }
 
@@ -1119,7 +1135,7 @@ int tb_axpy(tb_device *dev, int64_t n, double a, const double *d_x, double *d_y)
 {
     TB_REQUIRE(dev && d_x && d_y && n >= 0, "tb_axpy: bad argument");
     if (!n) return TB_OK;
-    mirror_drop_any(dev, d_y);
+    mirror_drop_any(dev, d_y, (size_t)n * sizeof(double));
     return launch_axpy(dev, n, a, d_x, d_y);
 }
 

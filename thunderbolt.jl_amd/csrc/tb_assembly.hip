@@ -675,7 +675,7 @@ static int tabulate_diffusion_field_t(tb_form *f)
         hipLaunchKernelGGL((k_tabulate_spectral<E>), dim3(nblocks(m->n_cells, 256)), dim3(256), 0, m->dev->stream, f->d_field, m->n_cells, f->coef.p[0],
                            f->coef.p[1], f->coef.p[2], sc, f->d_dtab);
     TB_HIP(hipGetLastError());
-    TB_HIP(hipStreamSynchronize(m->dev->stream));
+    TB_SYNC_STREAM(m->dev);
     (void)hipFree(f->d_field); f->d_field = nullptr;
     return TB_OK;
 }
@@ -1312,7 +1312,7 @@ static int run_q2(tb_form *f, tb_pattern *p, int strategy, double t, double *d_n
             hipLaunchKernelGGL((k_tabulate_spectral<Hex8<3>>), dim3(nblocks(m->n_cells, 256)), dim3(256), 0, dev->stream, f->d_field, m->n_cells, f->coef.p[0],
                                f->coef.p[1], f->coef.p[2], sc, f->d_dtab);
         TB_HIP(hipGetLastError());
-        TB_HIP(hipStreamSynchronize(dev->stream));
+        TB_SYNC_STREAM(dev);
         (void)hipFree(f->d_field); f->d_field = nullptr;
     }
     const MeshView mv = make_view(m);

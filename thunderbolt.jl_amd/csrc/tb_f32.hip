@@ -60,7 +60,7 @@ static int arena(tb_device *dev, size_t bytes, double **out)
 {
     TB_HIP(hipSetDevice(dev->id)); // every *_f32 entry comes through here first: the arena (and the conversion kernels behind it) belong to this device, whatever the caller's current one
     if (dev->scratch_bytes < bytes) {
-        TB_HIP(hipStreamSynchronize(dev->stream));
+        TB_SYNC_STREAM(dev);
         if (dev->d_scratch) (void)hipFree(dev->d_scratch);
         dev->d_scratch = nullptr; dev->scratch_bytes = 0;
         hipError_t e = hipMalloc((void **)&dev->d_scratch, bytes);

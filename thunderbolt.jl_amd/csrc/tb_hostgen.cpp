@@ -216,4 +216,107 @@ int64_t tb_host_build_pattern(int64_t n_cells, int ndpc, const int32_t *cell_dof
     return rowptr[ndofs];
 }
 
+/* Locality order for an arbitrarily numbered mesh (round 6).  The reference's CPU strategies are insensitive to how cells and dofs are numbered
+ * (a plain loop over the cells, src/modeling/core/coordinate_systems.jl:145-171); the device kernels are not — plans share scatter / row signatures
+ * and SpMV gathers stay inside the caches only where neighbours carry nearby numbers.  The order produced here is the sweep over the per-axis cell
+ * LAYERS the patch planner cuts (build_patch_plan: cells ranked by centroid per axis, R = extent ÷ mean cell extent equal-count buckets — exactly the
+ * (i, j, k) layers of a possibly distorted structured grid, density-adaptive elsewhere): cells lexicographic in (k, j, i) with ties broken by the
+ * centroid, nodes the same over R + 1 node layers, and dofs in the order of their first visit when the cells are traversed in the new order with the
+ * local dofs in cell_dofs order — what close!(dh) produces on a grid stored in that order, so a lattice under any numbering gets generate_grid's own. */
+int tb_host_locality_permutation(int geom_kind, int64_t n_nodes, const double *xyz, int64_t n_cells, const int32_t *conn, int ndofs_per_cell,
+                                 const int32_t *cell_dofs, int64_t ndofs, int index_base, int32_t *cell_perm, int32_t *node_perm, int32_t *dof_perm)
+{
+    TB_REQUIRE(xyz && conn && n_nodes > 0 && n_cells > 0, "tb_host_locality_permutation: bad argument");
+    TB_REQUIRE(geom_kind == TB_QUAD4 || geom_kind == TB_HEX8 || geom_kind == TB_TET4, "tb_host_locality_permutation: geom_kind must be TB_QUAD4, TB_HEX8 or TB_TET4");
+    TB_REQUIRE(index_base == 0 || index_base == 1, "tb_host_locality_permutation: index_base must be 0 or 1");
+    TB_REQUIRE(!dof_perm || (cell_dofs && ndofs_per_cell > 0 && ndofs > 0), "tb_host_locality_permutation: dof_perm needs cell_dofs, ndofs_per_cell and ndofs");
+    TB_REQUIRE(n_cells < 0x7fffffff && n_nodes < 0x7fffffff && ndofs < 0x7fffffff, "tb_host_locality_permutation: too large for Int32");
+    const int nv = geom_kind == TB_HEX8 ? 8 : 4;
+    const int64_t nc = n_cells;
+    // centroids, extents (per axis: layer spacing of a hexahedron from its face-centre differences, bounding box otherwise), domain box
+    std::vector<double> cen((size_t)nc * 3);
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, hsum[3] = {0, 0, 0};
+    static const int lo_hi[3][2][4] = {{{0, 3, 4, 7}, {1, 2, 5, 6}}, {{0, 1, 4, 5}, {3, 2, 7, 6}}, {{0, 1, 2, 3}, {4, 5, 6, 7}}};
+#pragma omp parallel for schedule(static) reduction(min : lo[:3]) reduction(max : hi[:3]) reduction(+ : hsum[:3])
+    for (int64_t c = 0; c < nc; ++c) {
+        double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300}, sum[3] = {0, 0, 0};
+        const int32_t *cn = conn + c * nv;
+        for (int a = 0; a < nv; ++a)
+            for (int d = 0; d < 3; ++d) {
+                const double v = xyz[3 * (int64_t)(cn[a] - index_base) + d];
+                sum[d] += v; mn[d] = std::min(mn[d], v); mx[d] = std::max(mx[d], v);
+            }
+        double ext[3] = {mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]};
+        if (nv == 8) {
+            ext[0] = ext[1] = ext[2] = 0.0;
+            for (int k = 0; k < 3; ++k) {
+                double e[3] = {0, 0, 0};
+                for (int a = 0; a < 4; ++a)
+                    for (int d = 0; d < 3; ++d) e[d] += 0.25 * (xyz[3 * (int64_t)(cn[lo_hi[k][1][a]] - index_base) + d] - xyz[3 * (int64_t)(cn[lo_hi[k][0][a]] - index_base) + d]);
+                for (int d = 0; d < 3; ++d) ext[d] = std::max(ext[d], std::fabs(e[d]));
+            }
+        }
+        for (int d = 0; d < 3; ++d) {
+            cen[3 * c + d] = sum[d] / nv;
+            lo[d] = std::min(lo[d], mn[d]); hi[d] = std::max(hi[d], mx[d]); hsum[d] += ext[d];
+        }
+    }
+    int64_t Rv[3];
+    for (int d = 0; d < 3; ++d) {
+        const double hmean = hsum[d] / (double)nc;
+        int64_t R = hmean > 0 ? (int64_t)std::llround((hi[d] - lo[d]) / hmean) : 1;
+        Rv[d] = std::min<int64_t>(std::max<int64_t>(R, 1), 1 << 20);
+    }
+    // layer of every item per axis: equal-count buckets of the coordinate ranks; then one sort by (layer z, layer y, layer x, x-coordinate, id)
+    auto sweep_order = [&](int64_t n, auto coord, const int64_t (&R)[3], int32_t *out) {
+        std::vector<uint32_t> layer((size_t)n * 3);
+#pragma omp parallel for schedule(static, 1) num_threads(3)
+        for (int d = 0; d < 3; ++d) {
+            std::vector<std::pair<double, int32_t>> by(n);
+            for (int64_t i = 0; i < n; ++i) by[i] = {coord(i, d), (int32_t)i};
+            std::sort(by.begin(), by.end());
+            for (int64_t r = 0; r < n; ++r) layer[3 * (size_t)by[r].second + d] = (uint32_t)((r * R[d]) / n);
+        }
+        struct Key { uint32_t k, j, i; double x; int32_t id; };
+        std::vector<Key> keys(n);
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < n; ++i) keys[i] = {layer[3 * i + 2], layer[3 * i + 1], layer[3 * i], coord(i, 0), (int32_t)i};
+        std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
+            if (a.k != b.k) return a.k < b.k;
+            if (a.j != b.j) return a.j < b.j;
+            if (a.i != b.i) return a.i < b.i;
+            if (a.x != b.x) return a.x < b.x;
+            return a.id < b.id;
+        });
+        for (int64_t i = 0; i < n; ++i) out[i] = keys[i].id;
+    };
+    std::vector<int32_t> corder((size_t)nc);
+    sweep_order(nc, [&](int64_t c, int d) { return cen[3 * c + d]; }, Rv, corder.data());
+    if (cell_perm)
+        for (int64_t k = 0; k < nc; ++k) cell_perm[k] = corder[k] + index_base;
+    if (node_perm) {
+        const int64_t Rn[3] = {Rv[0] + 1, Rv[1] + 1, geom_kind == TB_QUAD4 ? 1 : Rv[2] + 1};
+        std::vector<int32_t> norder((size_t)n_nodes);
+        sweep_order(n_nodes, [&](int64_t i, int d) { return xyz[3 * i + d]; }, Rn, norder.data());
+        for (int64_t k = 0; k < n_nodes; ++k) node_perm[norder[k]] = (int32_t)k + index_base; // node_perm[old] = new
+    }
+    if (dof_perm) {
+        std::fill(dof_perm, dof_perm + ndofs, (int32_t)-1);
+        int32_t next = 0;
+        for (int64_t k = 0; k < nc; ++k) {
+            const int32_t *cd = cell_dofs + (int64_t)corder[k] * ndofs_per_cell;
+            for (int a = 0; a < ndofs_per_cell; ++a) {
+                const int64_t d = (int64_t)cd[a] - index_base;
+                TB_REQUIRE(d >= 0 && d < ndofs, "tb_host_locality_permutation: cell_dofs entry out of range");
+                if (dof_perm[d] < 0) dof_perm[d] = next++;
+            }
+        }
+        for (int64_t d = 0; d < ndofs; ++d) { // dofs no cell touches keep their relative order behind the visited ones
+            if (dof_perm[d] < 0) dof_perm[d] = next++;
+            dof_perm[d] += index_base;
+        }
+    }
+    return TB_OK;
+}
+
 } // extern "C"

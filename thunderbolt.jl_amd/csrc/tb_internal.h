@@ -43,6 +43,23 @@ const char *last_kernel();
         }                                 \
     } while (0)
 
+// A call that waits for the device or reads back, made while a graph capture is open, would invalidate the capture — and HIP 7.0 then keeps refusing
+// work on that stream, which may be the host's own (tb_device_set_stream).  Such calls refuse BEFORE they touch the stream: the capture stays valid
+// (tb_graph_end still returns a graph of what was enqueued so far) and the stream stays usable.
+#define TB_NO_CAPTURE(dev_)                                                                                                                        \
+    do {                                                                                                                                           \
+        if ((dev_)->capturing) {                                                                                                                   \
+            tb::set_error("%s: this call waits for the device or copies to / from the host; it cannot run while a graph capture is open "         \
+                          "(tb_graph_begin ... tb_graph_end) - make it before the capture (first use of a plan) or after it", __func__);          \
+            return TB_ERR_BAD_ARG;                                                                                                                 \
+        }                                                                                                                                          \
+    } while (0)
+#define TB_SYNC_STREAM(dev_)                              \
+    do {                                                  \
+        TB_NO_CAPTURE(dev_);                              \
+        TB_HIP(hipStreamSynchronize((dev_)->stream));     \
+    } while (0)
+
 // status word written by kernels (device) and read back after each launch group
 struct Status {
     int neg_detj;        // != 0: some cell had detJ <= 0
@@ -390,9 +407,10 @@ int upload(tb_device *dev, const std::vector<T> &h, T **d)
 {
     *d = nullptr;
     if (h.empty()) return TB_OK;
+    TB_NO_CAPTURE(dev); // a blocking upload of a host vector: plan building belongs in front of a capture
     TB_HIP(hipMalloc((void **)d, h.size() * sizeof(T)));
     TB_HIP(hipMemcpyAsync(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, dev->stream));
-    TB_HIP(hipStreamSynchronize(dev->stream));
+    TB_SYNC_STREAM(dev);
     return TB_OK;
 }
 

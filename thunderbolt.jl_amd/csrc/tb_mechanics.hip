@@ -1196,6 +1196,7 @@ static int check_node_rows(tb_pattern *p)
 static int ensure_gather_nodes(tb_pattern *p)
 {
     if (p->gnodes_state) return TB_OK;
+    TB_NO_CAPTURE(p->mesh->dev);
     const tb_mesh *m = p->mesh;
     const int nb = m->nb, nd = 3 * nb;
     const int64_t nn = m->n_nodes_field;
@@ -1441,7 +1442,7 @@ static int run(tb_form *f, tb_pattern *p, int strategy, const double *d_u, doubl
 #ifdef TB_ABLATION
         if (mm.prof) { // average phase durations of the sampled workgroups (µs; wall clock 100 MHz)
             std::vector<long long> h((size_t)nmprof * 16);
-            TB_HIP(hipStreamSynchronize(dev->stream));
+            TB_SYNC_STREAM(dev);
             TB_HIP(hipMemcpy(h.data(), mm.prof, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
             double ph[14] = {0};
             int cnt = 0;

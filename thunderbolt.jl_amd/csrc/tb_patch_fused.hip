@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -387,7 +388,12 @@ k_patch_hex8_record(FormArgs faK, FormArgs faM, const uint8_t *__restrict__ rec,
     // staging and write-out are short, latency-bound instruction streams; the integration is ≈ 2 400 instructions per lane.  With two workgroups per
     // CU a wave in its staging or write-out phase shares its SIMD with a wave of the other workgroup that may be integrating: raised priority lets
     // the short phase issue its loads / stores at once instead of waiting behind the other wave's arithmetic (TB_PATCH_PRIO=0 switches it off)
-    if (prio) __builtin_amdgcn_s_setprio(3);
+    // prio ≥ 2 (profiling build): asymmetric residents — the workgroup in the CU's first LDS slot integrates at raised priority, its co-resident
+    // fills the gaps (two waves integrating at half rate each finish together and then wait together; one after the other, the second's staging /
+    // write-out hides behind the first's arithmetic)
+    bool slot0 = false;
+    if (prio >= 2) slot0 = (__builtin_amdgcn_s_getreg((31 << 11) | 6) & 0xfffu) == 0u; // HW_REG_LDS_ALLOC: base of this workgroup's LDS
+    if (prio == 1 || prio == 2) __builtin_amdgcn_s_setprio(3);
     // first generation only: the second workgroup of every CU (blocks 256…511 under round-robin dispatch) starts `stagger` × 64 cycles late, so that the
     // two residents of a CU run their integration phases in turn instead of together (uniform patches keep the offset once it is there)
     if (stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
@@ -447,7 +453,8 @@ k_patch_hex8_record(FormArgs faK, FormArgs faM, const uint8_t *__restrict__ rec,
     TB_ST(1);
     __syncthreads();
     TB_ST(2);
-    if (prio) __builtin_amdgcn_s_setprio(0);
+    if (prio == 1) __builtin_amdgcn_s_setprio(0);
+    else if (prio >= 2) { if (!slot0) __builtin_amdgcn_s_setprio(0); else if (prio == 4) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(3); }
     for (int ei = tid; ei < ne; ei += T) { // one pass for all but the domain-boundary patches (they own the extra boundary layers: up to ≈ 280 instances)
         if (ei >= T) {
             lnv = ((const uint4 *)(r + 16))[ei];
@@ -471,7 +478,7 @@ k_patch_hex8_record(FormArgs faK, FormArgs faM, const uint8_t *__restrict__ rec,
     TB_ST(3);
     __syncthreads();
     TB_ST(4);
-    if (prio) __builtin_amdgcn_s_setprio(3);
+    if (prio == 1 || prio == 2) __builtin_amdgcn_s_setprio(3);
     // write-out: one row per half-wave; all descriptors, then all accumulators, then all stores of the half-wave's rows.  (The thread index is
     // formed again from the lane count and the wave's number — a scalar — instead of being kept through the integration, where all 256 registers
     // are taken: kept, it was the kernel's one spilled value.)
@@ -513,6 +520,206 @@ k_patch_hex8_record(FormArgs faK, FormArgs faM, const uint8_t *__restrict__ rec,
 #ifdef TB_ABLATION
     if (prof) { __builtin_amdgcn_s_waitcnt(0); TB_ST(6); }
 #endif
+#undef TB_ST
+}
+
+// lane index by an instruction sequence the compiler can neither hoist out of a loop nor merge with an earlier copy: inside the persistent loop below a
+// thread index kept in a register would live through the integration, where all 256 registers are taken (it, and every address derived from it,
+// would be spilled and reloaded from scratch memory)
+__device__ __forceinline__ int lane_index_now()
+{
+    int x;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));
+    return x;
+}
+// kernel-argument bytes re-read where they are used (a scalar load from the kernarg segment through a pointer the compiler cannot see through): the
+// nine doubles of L⁻¹ are needed once per patch, at staging — as ordinary arguments they are loaded once and held in 18 SGPRs through the whole loop
+__device__ __forceinline__ const __attribute__((address_space(4))) double *kernarg_doubles_now(unsigned byte_offset)
+{
+    const __attribute__((address_space(4))) char *q = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() + byte_offset;
+    asm volatile("" : "+s"(q));
+    return (const __attribute__((address_space(4))) double *)q;
+}
+
+// Streaming form (round 6, default for constant coefficients): PERSISTENT workgroups, two per CU, each taking the patches blockIdx.x, + gridDim.x, … in
+// turn.  Why: phase stamps of the record kernel at 216³ (profiles/r06_v1/ab_stream.log) — a workgroup spends 2.0 µs staging its record, 6.4 µs integrating
+// and 2.4 µs writing its rows out; alone on its CU it integrates in 5.2 µs, and two integrating together take 7.7 µs for both, i.e. the vector pipe is
+// saturated only while BOTH residents integrate, and each resident is away from it for 4.5 of its 11 µs.  Here the staging trip of patch k + 1 is issued
+// at the start of patch k's write-out, when the integration's registers are free (loads are older than the stores behind them, and the memory counter
+// retires in order: waiting for them does not wait for the stores), lands while the rows leave, and goes to LDS behind the stores: the coordinates'
+// region is dead during a write-out and the row descriptors alternate between two buffers.  The accumulators are zeroed by the lane that reads them
+// out.  A workgroup never ends between patches, so nothing waits for its stores to drain either.  Per patch: integration → barrier → write-out +
+// staging of the next → barrier.  The write-out is straight-line code (no loop between the request of a record and its landing: the register allocator
+// splits and spills the requested values around loops, and a spilled input waits for its load at once): plans with more than 8·RPH rows or
+// 512 / 426 nodes per patch or rows longer than 32 entries keep the record kernel.
+template <bool WK, bool WM, bool DIAG, bool ISO, int RPH, int KOFF = 0>
+__global__ void __launch_bounds__(256, 2)
+k_patch_hex8_stream(FormArgs faK, FormArgs faM, const uint8_t *__restrict__ rec, int stride, int nem, int rm, int nm, int kcap, const uint8_t *__restrict__ sigtab, const int32_t *__restrict__ elem_cell, int n_patches,
+                    double *__restrict__ nzK, double *__restrict__ nzM, Status *st
+#ifdef TB_ABLATION
+                    , long long *prof
+#endif
+)
+{
+    extern __shared__ double lds[];
+    constexpr int T = 256;
+    const int wave_s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int p = blockIdx.x;
+#ifdef TB_ABLATION
+#define TB_ST(k) do { if (prof && lane_index_now() + 64 * wave_s == 0 && (p & 1023) == 7) prof[(p >> 10) * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define TB_ST(k) do { } while (0)
+#endif
+    const int kblk = KOFF > 0 ? KOFF : kcap;
+    double *accK = lds;
+    double *accM = lds + (WK && WM ? kblk : 0);
+    RowDesc *desc2 = (RowDesc *)(lds + (WK && WM ? 2 : 1) * kblk); // two descriptor buffers of rm rows
+    double *xs = (double *)(desc2 + 2 * rm);
+    constexpr int NX = ISO ? 6 : 5;
+    // inputs of a patch on their way from its record to LDS / to the integration
+    // (rd, xc are values of ONE write-out: declared per use below — as variables of the whole loop they would be merged with their stale copies where the
+    // request is conditional, stay alive through the integration and be spilled there)
+    const uint8_t *r;
+    uint4 lnv;
+    uint32_t sig, hw, e0;
+    auto request = [&](int q, int tid, uint4 &rd, double (&xc)[NX]) { // every load of patch q's record, addressed from q alone
+        r = rec + (size_t)q * (size_t)stride;
+        const uint4 h4 = *(const uint4 *)r; // wave-uniform address: a scalar load
+        hw = h4.x; e0 = h4.y;
+        lnv = ((const uint4 *)(r + 16))[tid];
+        sig = ((const uint32_t *)(r + 16 + (size_t)nem * 16))[tid];
+        const uint8_t *rdp = r + 16 + (size_t)nem * 20;
+        const double *pc = (const double *)(rdp + (size_t)rm * 16);
+        // unconditional loads at clamped indices (the record is padded to rm descriptors and nm nodes): no branch per load, nothing to merge
+        rd = ((const uint4 *)rdp)[tid < rm ? tid : rm - 1];
+        if constexpr (ISO) { // node-wise: lane t takes nodes t and t + 256 whole, so that it can map them (x′ = L⁻¹x) on their way to LDS
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int node = tid + j * T < nm ? tid + j * T : nm - 1;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) xc[3 * j + d] = pc[3 * node + d];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NX; ++j) xc[j] = pc[tid + j * T < 3 * nm ? tid + j * T : 3 * nm - 1];
+        }
+    };
+    auto land = [&](int buf, int tid, const uint4 &rd, const double (&xc)[NX]) { // … and into LDS (descriptor buffer `buf`, the coordinate block)
+        if (tid < rm) ((uint4 *)(desc2 + buf * rm))[tid] = rd;
+        if constexpr (ISO) {
+            const auto *Li = kernarg_doubles_now((unsigned)offsetof(FormArgs, Linv)); // faK is the kernel's first argument
+            auto put = [&](int node, double x0, double x1, double x2) {
+                xs[3 * node] = Li[0] * x0 + Li[1] * x1 + Li[2] * x2; xs[3 * node + 1] = Li[3] * x0 + Li[4] * x1 + Li[5] * x2; xs[3 * node + 2] = Li[6] * x0 + Li[7] * x1 + Li[8] * x2;
+            };
+#pragma unroll
+            for (int j = 0; j < 2; ++j) if (tid + j * T < nm) put(tid + j * T, xc[3 * j], xc[3 * j + 1], xc[3 * j + 2]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NX; ++j) if (tid + j * T < 3 * nm) xs[tid + j * T] = xc[j];
+        }
+    };
+    uint4 cp[4];
+    auto positions = [&]() {
+        const uint4 *cpp = (const uint4 *)(sigtab + (size_t)sig * 64); // padding lanes carry signature 0: a valid read
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cp[k] = cpp[k];
+    };
+    // first patch of this workgroup: staged as in the record kernel
+    {
+    uint4 rd0;
+    double xc0[NX];
+    request(p, lane_index_now() + 64 * wave_s, rd0, xc0);
+    {   // zero both accumulator blocks while the loads travel (later patches: zeroed by the write-out)
+        double2 *z = (double2 *)lds;
+        const int n2 = ((WK && WM ? 2 : 1) * kblk) >> 1;
+        for (int k = lane_index_now() + 64 * wave_s; k < n2; k += T) z[k] = make_double2(0.0, 0.0);
+    }
+    land(0, lane_index_now() + 64 * wave_s, rd0, xc0);
+    }
+    positions();
+    int buf = 0;
+    __syncthreads();
+    for (;;) {
+        const int nrows = (int)(hw & 0x3ff), ne = (int)(hw >> 21);
+        const RowDesc *desc = desc2 + buf * rm;
+        TB_ST(0);
+        {
+            const int tid = lane_index_now() + 64 * wave_s;
+            for (int ei = tid; ei < ne; ei += T) { // one pass for all but the patches that own extra boundary layers
+                if (ei >= T) {
+                    lnv = ((const uint4 *)(r + 16))[ei];
+                    const uint4 *cpp = (const uint4 *)(sigtab + (size_t)((const uint32_t *)(r + 16 + (size_t)nem * 16))[ei] * 64);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) cp[k] = cpp[k];
+                }
+                const uint32_t ln[8] = {lnv.x & 0xffffu, lnv.x >> 16, lnv.y & 0xffffu, lnv.y >> 16, lnv.z & 0xffffu, lnv.z >> 16, lnv.w & 0xffffu, lnv.w >> 16};
+                double x[8][3];
+#pragma unroll
+                for (int a = 0; a < 8; ++a) {
+                    const double *px = xs + 3 * ln[a];
+                    x[a][0] = px[0]; x[a][1] = px[1]; x[a][2] = px[2];
+                }
+                uint32_t ro[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ro[i] = ln[i] < (uint32_t)nrows ? desc[ln[i]].off : 0xFFFFFFFFu;
+                hex8_instance<WK, WM, false, false, DIAG, ISO>(x, [&](uint4(&c4)[4], uint32_t(&r8)[8]) { for (int k = 0; k < 4; ++k) c4[k] = cp[k]; for (int k = 0; k < 8; ++k) r8[k] = ro[k]; }, 0, faK, faM, accK, accM, st,
+                                                              elem_cell, (int64_t)e0 + ei);
+            }
+        }
+        TB_ST(1);
+        __syncthreads();
+        TB_ST(2);
+        // write-out of this patch (one row per half-wave: all descriptors, then all accumulators — zeroed behind the read —, then all stores) with the
+        // record of the next patch requested in front of it
+        const int tidw = lane_index_now() + 64 * wave_s;
+        const int pn = p + (int)gridDim.x;
+        const bool more = pn < n_patches;
+        uint4 rd;
+        double xc[NX];
+        request(more ? pn : p, tidw, rd, xc); // (unconditional: the last patch of a workgroup asks for its own record again)
+        const int half = tidw >> 5, hl = tidw & 31;
+        // two rounds of RPH / 2 rows per half-wave (all RPH at once, next to the staged inputs of the next patch, need more registers than a
+        // round holds without a spill — and a spilled input waits for its load in front of everything else)
+        constexpr int RH = RPH / 2;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint4 d[RH]; // {nz0 lo, nz0 hi, off, len}
+#pragma unroll
+            for (int u = 0; u < RH; ++u) { const int s_ = half + (h * RH + u) * (T / 32); d[u] = ((const uint4 *)desc)[s_ < nrows ? s_ : 0]; if (s_ >= nrows) d[u].w = 0; }
+            double vK[RH], vM[RH];
+#pragma unroll
+            for (int u = 0; u < RH; ++u) {
+                const uint32_t a_ = d[u].z + (hl < d[u].w ? hl : 0);
+                if constexpr (WK) vK[u] = accK[a_];
+                if constexpr (WM) vM[u] = accM[a_];
+            }
+#pragma unroll
+            for (int u = 0; u < RH; ++u)
+                if (hl < d[u].w) {
+                    if constexpr (WK) accK[d[u].z + hl] = 0.0;
+                    if constexpr (WM) accM[d[u].z + hl] = 0.0;
+                }
+            TB_ST(3);
+#pragma unroll
+            for (int u = 0; u < RH; ++u)
+                if (hl < d[u].w) {
+                    const int64_t g0 = (int64_t)(((uint64_t)d[u].y << 32) | d[u].x) + hl;
+                    if constexpr (WK) nzK[g0] = vK[u];
+                    if constexpr (WM) nzM[g0] = vM[u];
+                }
+        }
+        TB_ST(4);
+        if (!more) break;
+        buf ^= 1;
+        land(buf, tidw, rd, xc);
+        positions();
+        TB_ST(5);
+        p = pn;
+        __syncthreads();
+#ifdef TB_ABLATION
+        if (prof && lane_index_now() + 64 * wave_s == 0 && ((p - (int)gridDim.x) & 1023) == 7) prof[((p - (int)gridDim.x) >> 10) * 8 + 6] = wall_clock64();
+#endif
+    }
 #undef TB_ST
 }
 
@@ -583,7 +790,7 @@ int launch_assemble_hex8_patch(tb_form *fK, tb_form *fM, tb_pattern *p, double t
     const bool staged = pf->d_hdr && !general;
     const bool diag = fK && !fk && aK.D[1] == 0.0 && aK.D[2] == 0.0 && aK.D[5] == 0.0 && aK.D[3] == 0.0 && aK.D[6] == 0.0 && aK.D[7] == 0.0;
     // one-trip record kernel: constant coefficients, patches of ≤ 256 instances (TB_PATCH_KERNEL=staged keeps the two-trip kernel for A/B runs)
-    static const bool no_record = getenv("TB_PATCH_KERNEL") && strcmp(getenv("TB_PATCH_KERNEL"), "record") != 0;
+    static const bool no_record = getenv("TB_PATCH_KERNEL") && strcmp(getenv("TB_PATCH_KERNEL"), "record") != 0 && strcmp(getenv("TB_PATCH_KERNEL"), "stream") != 0;
     static const int wave_prio = tune_env("TB_PATCH_PRIO") ? atoi(tune_env("TB_PATCH_PRIO")) : 0; // measured: no effect (1.7007 vs 1.6997 ms)
     static const int stagger = tune_env("TB_PATCH_STAGGER") ? atoi(tune_env("TB_PATCH_STAGGER")) : 0;
     const int pf_ahead = 0; // (look-ahead touch of later records: removed from the record kernel, see there)
@@ -624,7 +831,10 @@ int launch_assemble_hex8_patch(tb_form *fK, tb_form *fM, tb_pattern *p, double t
                     iso = true;
                 }
             }
+            static const size_t lds_pad = tune_env("TB_PATCH_LDS_PAD") ? (size_t)atol(tune_env("TB_PATCH_LDS_PAD")) : 0; // profiling build: > 80 KB leaves one workgroup per CU
+            const size_t ldsr_ = ldsr;
             auto launch_rec = [&](auto k) -> int {
+                const size_t ldsr = std::max(ldsr_, lds_pad);
                 TB_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr));
 #ifdef TB_ABLATION
                 hipLaunchKernelGGL(k, dim3((unsigned)pp->n_patches), dim3(256), ldsr, dev->stream, aK, aMi, (const uint8_t *)pr->d_rec, pr->rec_stride, pr->rec_ne, pr->rec_rm, pr->rec_nm, pv.kcap,
@@ -635,6 +845,33 @@ int launch_assemble_hex8_patch(tb_form *fK, tb_form *fM, tb_pattern *p, double t
 #endif
                 return TB_OK;
             };
+            // streaming (persistent) form: the same instances behind a loop over the patches of a workgroup; needs the second descriptor buffer in LDS
+            static const char *kenv = getenv("TB_PATCH_KERNEL");
+            const size_t ldss = ldsr + (size_t)pr->rec_rm * sizeof(RowDesc);
+            if (!p->max_row_len) for (int64_t r_ = 0; r_ < p->n_rows; ++r_) p->max_row_len = std::max<int64_t>(p->max_row_len, p->h_rowptr[r_ + 1] - p->h_rowptr[r_]);
+            const bool stream = !(kenv && !strcmp(kenv, "record")) && ldss <= 80 * 1024 && (!(fK && fM) || fixm) && pp->max_rows <= 8 * RPH && p->max_row_len <= 32 &&
+                                pr->rec_nm <= (iso ? 512 : 5 * 256 / 3);
+            if (stream) {
+                const int grid = (int)std::min<int64_t>(pp->n_patches, (int64_t)2 * dev->n_cu);
+                auto launch_str = [&](auto k) -> int {
+                    TB_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldss));
+#ifdef TB_ABLATION
+                    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), ldss, dev->stream, aK, aMi, (const uint8_t *)pr->d_rec, pr->rec_stride, pr->rec_ne, pr->rec_rm, pr->rec_nm, pv.kcap,
+                                       (const uint8_t *)pf->d_sigtab, pp->d_elem_cell, (int)pp->n_patches, d_nzK, d_nzM, dev->d_status, d_prof);
+#else
+                    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), ldss, dev->stream, aK, aMi, (const uint8_t *)pr->d_rec, pr->rec_stride, pr->rec_ne, pr->rec_rm, pr->rec_nm, pv.kcap,
+                                       (const uint8_t *)pf->d_sigtab, pp->d_elem_cell, (int)pp->n_patches, d_nzK, d_nzM, dev->d_status);
+#endif
+                    return TB_OK;
+                };
+                set_last_kernel("k_patch_hex8_stream<%s,%s,RPH%d%s>", fK && fM ? "K+M" : fK ? "K" : "M", !fK ? "-" : iso ? "ISO" : diag ? "DIAG" : "GEN", RPH, fK && fM ? ",KOFF4096" : "");
+                if (fK && fM) rc = iso ? launch_str(k_patch_hex8_stream<true, true, false, true, RPH, KOFF>) : diag ? launch_str(k_patch_hex8_stream<true, true, true, false, RPH, KOFF>) : launch_str(k_patch_hex8_stream<true, true, false, false, RPH, KOFF>);
+                else if (fK) rc = iso ? launch_str(k_patch_hex8_stream<true, false, false, true, RPH>) : diag ? launch_str(k_patch_hex8_stream<true, false, true, false, RPH>) : launch_str(k_patch_hex8_stream<true, false, false, false, RPH>);
+                else rc = launch_str(k_patch_hex8_stream<false, true, false, false, RPH>);
+                if (rc) return rc;
+                TB_HIP(hipGetLastError());
+                goto done;
+            }
             set_last_kernel("k_patch_hex8_record<%s,%s,RPH%d%s>", fK && fM ? "K+M" : fK ? "K" : "M", !fK ? "-" : iso ? "ISO" : diag ? "DIAG" : "GEN", RPH, fK && fM && fixm ? ",KOFF4096" : "");
             if (fK && fM && fixm) rc = iso ? launch_rec(k_patch_hex8_record<true, true, false, true, RPH, KOFF>) : diag ? launch_rec(k_patch_hex8_record<true, true, true, false, RPH, KOFF>) : launch_rec(k_patch_hex8_record<true, true, false, false, RPH, KOFF>);
             else if (fK && fM) rc = iso ? launch_rec(k_patch_hex8_record<true, true, false, true, RPH>) : diag ? launch_rec(k_patch_hex8_record<true, true, true, false, RPH>) : launch_rec(k_patch_hex8_record<true, true, false, false, RPH>);
@@ -673,7 +910,7 @@ done:
 #ifdef TB_ABLATION
     if (d_prof && staged) { // average phase durations (µs; wall clock 100 MHz)
         std::vector<long long> h((size_t)nprof * 8);
-        TB_HIP(hipStreamSynchronize(dev->stream));
+        TB_SYNC_STREAM(dev);
         TB_HIP(hipMemcpy(h.data(), d_prof, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
         double ph[6] = {0, 0, 0, 0, 0, 0};
         int n = 0;

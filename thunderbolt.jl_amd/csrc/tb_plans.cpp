@@ -45,6 +45,7 @@ int ensure_ea_ell_q2t(tb_mesh *m)
     int rc = ensure_ea_ell(m);
     if (rc) return rc;
     if (m->ea->d_ell_t) return TB_OK;
+    TB_NO_CAPTURE(m->dev);
     if (m->ndpc != 27) { set_error("tensor-order slot table: needs 27 dofs per cell"); return TB_ERR_UNSUPPORTED; }
     static const uint8_t trow[27] = {0, 2, 8, 6, 18, 20, 26, 24, 1, 5, 7, 3, 19, 23, 25, 21, 9, 11, 17, 15, 4, 10, 14, 16, 12, 22, 13}; // Ferrite node → tensor index
     std::vector<int32_t> ell((size_t)m->ndofs * m->ea->ell_w);
@@ -772,6 +773,7 @@ static int ensure_patch_records_impl(tb_pattern *p)
     const PatchPlan *pp = p->mesh->patches.get();
     if (!f || !pp || !f->d_hdr) return TB_ERR_UNSUPPORTED;
     if (f->d_rec) return TB_OK;
+    TB_NO_CAPTURE(p->mesh->dev);
     if (f->rec_stride < 0 || pp->max_elems > 1024 || pp->max_rows > 256) { f->rec_stride = -1; return TB_ERR_UNSUPPORTED; }
     const int64_t np = pp->n_patches;
     const int rm = (pp->max_rows + 3) & ~3, nm = (f->max_nodes + 3) & ~3, nem = std::max(256, (pp->max_elems + 63) & ~63);

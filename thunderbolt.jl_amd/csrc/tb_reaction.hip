@@ -652,6 +652,7 @@ int launch_reaction(tb_device *dev, int model, const double *params, int n_param
     for (int i = 0; i < n_params && i < 48; ++i) P.p[i] = params[i];
     unsigned long long *key = nullptr;
     if (rmax) {
+        TB_NO_CAPTURE(dev); // the largest rate goes to the host
         key = (unsigned long long *)&dev->d_status->cell; // 8-byte scratch inside the status block
         TB_HIP(hipMemsetAsync(key, 0, sizeof *key, dev->stream));
     }
@@ -668,7 +669,7 @@ int launch_reaction(tb_device *dev, int model, const double *params, int n_param
     if (rc || !rmax) return rc;
     unsigned long long bits = 0;
     TB_HIP(hipMemcpyAsync(&bits, key, sizeof bits, hipMemcpyDeviceToHost, dev->stream));
-    TB_HIP(hipStreamSynchronize(dev->stream));
+    TB_SYNC_STREAM(dev);
     *rmax = bits ? decode_ordered_key(bits) : -__builtin_huge_val();
     return TB_OK;
 }

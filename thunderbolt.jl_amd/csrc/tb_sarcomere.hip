@@ -329,6 +329,7 @@ int launch_sarcomere_implicit(tb_device *dev, const double *params, double *d_Q,
                               int max_iters, double tmax, double *d_dQdl, double *d_dQdv, double *d_act, int act_stride, int32_t *d_status, int64_t *n_failed,
                               int need_sens, const int32_t *d_cells, int nq, int64_t n_cells_listed)
 {
+    if (n_failed) TB_NO_CAPTURE(dev); // the failure count goes to the host
     const SarcomereInputs in{d_stretch, d_velocity, d_calcium, stretch, velocity, calcium};
     const int64_t n_work = d_cells ? n_cells_listed * nq : n;
     if (n_work == 0) { if (n_failed) *n_failed = 0; return TB_OK; }
@@ -346,7 +347,7 @@ int launch_sarcomere_implicit(tb_device *dev, const double *params, double *d_Q,
     if (n_failed) {
         unsigned long long h = 0;
         TB_HIP(hipMemcpyAsync(&h, cnt, sizeof h, hipMemcpyDeviceToHost, dev->stream));
-        TB_HIP(hipStreamSynchronize(dev->stream));
+        TB_SYNC_STREAM(dev);
         *n_failed = (int64_t)h;
     }
     return TB_OK;
