@@ -127,7 +127,33 @@ def physical_cores():
     return (len(cores) or nthreads), nthreads
 
 
-HOST_CORES = physical_cores()
+def cgroup_cpu_quota():
+    """CPUs' worth of CPU time the container may use (cgroup v2 cpu.max / v1 cfs quota), or None without a quota.  The GPU boxes of this pool list all
+    256 hardware threads in the CPU set and cap the time at 16 CPUs: 128 pinned threads then share 16 cores' worth of time (the '7.5x from 128 cores'
+    of the round-5 line), so the baseline runs as many threads as the quota grants and `cores` states that number."""
+    try:
+        a, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if a != "max" and float(per) > 0:
+            return float(a) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and per > 0:
+            return q / per
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def usable_cores():
+    phys, hw = physical_cores()
+    q = cgroup_cpu_quota()
+    return (min(phys, max(1, int(q + 1e-9))) if q else phys), hw, phys, q
+
+
+HOST_CORES = usable_cores()
 
 
 def cpu_baseline(n, kap, ionic="tt06", sizes=(64, 100), big=None, check=None):
@@ -143,7 +169,7 @@ def cpu_baseline(n, kap, ionic="tt06", sizes=(64, 100), big=None, check=None):
     p = o.cell_default_params(cm)
     cM = o.Coef(o.COEF_CONST_SCALAR, [1.0])
     cK = o.Coef(o.COEF_CONST_TENSOR, kap.ravel(), Cm=1.0, chi=1.0, wrap=True)
-    cores, avail = HOST_CORES                                      # counted at import time: once libgomp has pinned the initial thread, its affinity mask is one core
+    cores, avail, phys_cores, quota = HOST_CORES                    # counted at import time: once libgomp has pinned the initial thread, its affinity mask is one core
     table = {}
 
     def legs(tag, m, rp, ci, nd, ncells, threads_list, literal_1t, median_of=0):
@@ -194,17 +220,23 @@ def cpu_baseline(n, kap, ionic="tt06", sizes=(64, 100), big=None, check=None):
         legs(tag, o.Mesh(o.HEX8, 2, xyz, conn, cd), rp, ci, nd, conn.shape[0], [cores], literal_1t=False, median_of=3)
         top = table["%s/%dt" % (tag, cores)]                       # the stated baseline: the mesh the GPU was timed on, all cores, median of >= 3 counted passes
         value, rx_value = top["element_integrations_per_s_median"], top["dof_updates_per_s_median"]
-        sample = ("the bench's own %s hex Q1 mesh (%d cells): M + K per-colour + b element-assembly, OpenMP on all %d physical cores (pinned: OMP_PROC_BIND=%s OMP_PLACES=%s), "
+        sample = ("the bench's own %s hex Q1 mesh (%d cells): M + K per-colour + b element-assembly, OpenMP on %d pinned cores (all the container may use; OMP_PROC_BIND=%s OMP_PLACES=%s), "
                   "median of %d passes after a page-placing one; C restatement of the reference CPU path, not Julia; the 64^3 / 100^3 samples and the 1-thread legs are in `table`"
                   % (tag, conn.shape[0], cores, os.environ.get("OMP_PROC_BIND"), os.environ.get("OMP_PLACES"), top["counted_reps"]))
     else:
         top = table["%d^3/%dt" % (n, cores)]
         value, rx_value = top["element_integrations_per_s"], top["dof_updates_per_s"]
-        sample = ("%d^3 hex Q1 sample mesh (%d cells; --no-cpu-big: the bench's own mesh was skipped): M + K per-colour + b element-assembly, OpenMP on all %d physical cores "
-                  "(pinned), min of %d reps; C restatement of the reference CPU path, not Julia" % (n, n ** 3, cores, top["reps"]))
-    return {"value": value, "unit": "element-integrations/s", "cores": cores, "kind": "port", "sample": sample,
+        sample = ("%d^3 hex Q1 sample mesh (%d cells; --no-cpu-big: the bench's own mesh was skipped): M + K per-colour + b element-assembly, OpenMP on %d pinned cores "
+                  "(all the container may use), min of %d reps; C restatement of the reference CPU path, not Julia" % (n, n ** 3, cores, top["reps"]))
+    one_t = table.get("%d^3/1t" % min(sizes), {}).get("element_integrations_per_s")
+    eff = value / (cores * one_t) if one_t else None
+    if eff is not None:                                            # the caveat travels with the number: what all cores deliver of `cores` × the one-thread rate
+        sample += ("; measured thread efficiency %.2f (all-cores rate / (%d x the 1-thread rate of the %d^3 sample)): the per-colour loop sweeps the whole value array "
+                   "once per colour and is bound by the host's memory system at this size, not by its cores" % (eff, cores, min(sizes)))
+    return {"value": value, "unit": "element-integrations/s", "cores": cores, "kind": "port", "sample": sample, "thread_efficiency": eff,
             "dof_updates_per_s": rx_value, "ionic_model": ionic, **({"parity": top["parity"]} if "parity" in top else {}),
-            "table": table, "physical_cores": cores, "hardware_threads": avail, "cpu_model": cpu_model_string()}
+            "table": table, "physical_cores": phys_cores, "cgroup_cpu_quota": quota, "hardware_threads": avail, "cpu_model": cpu_model_string(),
+            "cores_note": ("threads = min(physical cores, the container's CFS quota): the box lists %d physical cores and grants %.1f CPUs of time" % (phys_cores, quota)) if quota else None}
 
 
 def spawn_ranks(args):
@@ -365,13 +397,13 @@ def main():
             nbrs = []
             if world_ > 1:
                 n2d = tb.distributed.node_to_dof(dh)
+                nmap = (lambda v: v) if self.node_perm is None else (lambda v: self.node_perm[v])
                 if gpart is not None:          # general partition: one index list per neighbouring part (local nodes → dofs; peers ascending on both sides)
-                    nmap = (lambda v: v) if self.node_perm is None else (lambda v: self.node_perm[v])
                     nbrs = [(peer, torch.from_numpy(n2d[nmap(idx)]).cuda()) for peer, idx in gpart.neighbours]
                 else:
                     lo, up = lo_up
-                    self.lo_idx = None if lo is None else torch.from_numpy(n2d[lo]).cuda()
-                    self.up_idx = None if up is None else torch.from_numpy(n2d[up]).cuda()
+                    self.lo_idx = None if lo is None else torch.from_numpy(n2d[nmap(lo)]).cuda()
+                    self.up_idx = None if up is None else torch.from_numpy(n2d[nmap(up)]).cuda()
                     nbrs = tb.distributed.slab_neighbours(self.lo_idx, self.up_idx, rank_, world_)
             self.nbrs = nbrs
             # the one data-path exchange: persistent send / receive buffers, pack and unpack through the C ABI (tb_gather_indexed / tb_scatter_add_indexed)

@@ -746,12 +746,18 @@ struct orc_assembly_plan {
     int64_t *ea_ptr;      /* ndofs + 1 */
     int32_t *ea_src;      /* n_cells × nb slots, grouped by dof, ascending cell inside a dof */
     double *ea;           /* n_cells × nb element-vector entries */
+    /* copies of the mesh arrays whose pages were first touched by the threads that read them (round 6): the caller's arrays come from a
+     * single-threaded generator, i.e. from ONE NUMA node of a two-socket host, and every cell gathers 8 coordinate lines from them */
+    double *xyz;
+    int32_t *conn, *cell_dofs;
+    orc_mesh local;       /* the caller's mesh with the three pointers above */
 };
 
 void orc_assembly_plan_destroy(orc_assembly_plan *p)
 {
     if (!p) return;
-    free(p->color_ptr); free(p->color_cells); free(p->emap); free(p->rowptr); free(p->ea_ptr); free(p->ea_src); free(p->ea); free(p);
+    free(p->color_ptr); free(p->color_cells); free(p->emap); free(p->rowptr); free(p->ea_ptr); free(p->ea_src); free(p->ea);
+    free(p->xyz); free(p->conn); free(p->cell_dofs); free(p);
 }
 
 int orc_assembly_plan_create(const orc_mesh *m, const int64_t *rowptr, const int32_t *colidx, const int32_t *color, int ncolors, int nthreads,
@@ -801,6 +807,22 @@ int orc_assembly_plan_create(const orc_mesh *m, const int64_t *rowptr, const int
         }
     }
     if (err) { orc_assembly_plan_destroy(p); return -3; }
+    {   /* first-touch copies: cells (and the nodes, which a generated mesh numbers in the same sweep) in the static shares of the assembly loops */
+        const int ng = cv.ngeo, dim = cv.dim;
+        p->xyz = (double *)malloc(sizeof(double) * m->n_nodes * dim);
+        p->conn = (int32_t *)malloc(sizeof(int32_t) * m->n_cells * ng);
+        p->cell_dofs = (int32_t *)malloc(sizeof(int32_t) * m->n_cells * nb);
+        if (!p->xyz || !p->conn || !p->cell_dofs) { orc_assembly_plan_destroy(p); return -4; }
+#pragma omp parallel for schedule(static)
+        for (int64_t c = 0; c < m->n_cells; ++c) {
+            memcpy(p->conn + c * ng, m->conn + c * ng, sizeof(int32_t) * ng);
+            memcpy(p->cell_dofs + c * nb, m->cell_dofs + c * nb, sizeof(int32_t) * nb);
+        }
+#pragma omp parallel for schedule(static)
+        for (int64_t v = 0; v < m->n_nodes; ++v) memcpy(p->xyz + v * dim, m->xyz + v * dim, sizeof(double) * dim);
+        p->local = *m;
+        p->local.xyz = p->xyz; p->local.conn = p->conn; p->local.cell_dofs = p->cell_dofs;
+    }
     if (m->n_cells * nb < 2147483647LL) {
         p->ea_ptr = (int64_t *)calloc(ndofs + 1, sizeof(int64_t));
         p->ea_src = (int32_t *)malloc(sizeof(int32_t) * m->n_cells * nb);
@@ -827,6 +849,7 @@ int orc_assemble_source_planned(const orc_assembly_plan *p, const orc_mesh *m, i
     if (cv_setup(&cv, m->kind, m->qorder)) return -2;
     const int nb = p->nb;
     if (nb != cv.nb || p->n_cells != m->n_cells || !p->ea) return -2;
+    m = &p->local; /* the same mesh, pages placed by the threads that read them */
 #ifdef _OPENMP
     omp_set_num_threads(nthreads > 0 ? nthreads : 1);
 #endif
@@ -852,6 +875,7 @@ int orc_assemble_matrix_planned(const orc_assembly_plan *p, const orc_mesh *m, i
     if (cv_setup(&cv, m->kind, m->qorder)) return -2;
     const int nb = p->nb;
     if (nb != cv.nb || p->n_cells != m->n_cells) return -2;
+    m = &p->local; /* the same mesh, pages placed by the threads that read them */
     const int hex8 = cv.nb == 8 && cv.dim == 3 && cv.ngeo == 8 && cv.nq == 8;
 #ifdef _OPENMP
     omp_set_num_threads(nthreads > 0 ? nthreads : 1);

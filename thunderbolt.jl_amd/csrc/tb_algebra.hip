@@ -662,6 +662,7 @@ static void launch_b3(tb_pattern *p, const double *nz, const double *x, double a
 constexpr int SPMV_CAP = TB_SPMV_CAP;
 static int stream_plan(tb_pattern *p)
 {
+    PlanTimer timer("stream_plan");
     if (p->n_blk != 0) return TB_OK;
     TB_NO_CAPTURE(p->mesh->dev);
     std::vector<int32_t> cut{0};
@@ -696,6 +697,7 @@ static int stream_plan(tb_pattern *p)
 // quarter of the column array and every offset list fits the kernel (row length ≤ SPMV_CAP is checked by the stream plan); otherwise n_sig = −1.
 static int sig_plan(tb_pattern *p, bool forced = false)
 {
+    PlanTimer timer("sig_plan");
     if (p->n_sig != 0) return TB_OK;
     TB_NO_CAPTURE(p->mesh->dev);
     const bool off = !forced && spmv_kernel_env() && strcmp(spmv_kernel_env(), "sig") != 0; // "rows" / "rec" / "chain": the CSR kernels (read per pattern: A/B runs and the bit-identity test build one pattern of each kind in one process)
@@ -790,6 +792,7 @@ constexpr uint32_t MIRROR_MIXED = 0xFFFFFFFFu;
 constexpr int32_t MIRROR_NONE = INT32_MIN; // column offset of a padding entry
 static int mirror_plan(tb_pattern *p)
 {
+    PlanTimer timer("mirror_plan");
     if (p->n_slices != 0) return TB_OK;
     TB_NO_CAPTURE(p->mesh->dev);
     int rc = spmv_plans(p);

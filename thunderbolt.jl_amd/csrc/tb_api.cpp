@@ -6,6 +6,8 @@
 #include <cstdarg>
 #include <cstring>
 
+#include <omp.h>
+
 #include "tb_internal.h"
 
 namespace tb {
@@ -84,6 +86,37 @@ extern "C" {
 const char *tb_last_error_string(void) { return g_error.c_str(); }
 const char *tb_version(void) { return "thunderbolt.jl_amd 0.1 (gfx950)"; }
 int tb_abi_revision(void) { return TB_ABI_REVISION; }
+
+// Host threads for the plan builders (OpenMP loops of tb_plans.cpp / tb_hostgen.cpp).  Inside a container the CPU set usually still lists every
+// hardware thread of the machine while a CFS quota caps the CPU TIME (cgroup v2 cpu.max "quota period", v1 cpu.cfs_quota_us / cpu.cfs_period_us): 256
+// OpenMP threads under a 16-CPU quota are throttled in lock-step — the 216³ plan build measured 21 s that way.  Applied once, at the first device:
+// the default team size becomes min(what OpenMP would take, ⌈quota⌉); an explicit OMP_NUM_THREADS is left alone.
+static int cgroup_cpu_quota()
+{
+    double q = 0.0;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char a[64] = ""; double per = 0.0;
+        if (fscanf(f, "%63s %lf", a, &per) == 2 && strcmp(a, "max") != 0 && per > 0) q = atof(a) / per;
+        fclose(f);
+    } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+        double quota = -1, per = 0;
+        if (fscanf(g, "%lf", &quota) != 1) quota = -1;
+        fclose(g);
+        if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lf", &per) != 1) per = 0; fclose(h); }
+        if (quota > 0 && per > 0) q = quota / per;
+    }
+    return q > 0 ? std::max(1, (int)std::ceil(q - 1e-9)) : 0;
+}
+static void cap_host_threads_once()
+{
+    static const bool done = [] {
+        if (getenv("OMP_NUM_THREADS")) return true;
+        const int q = cgroup_cpu_quota();
+        if (q > 0 && q < omp_get_max_threads()) omp_set_num_threads(q);
+        return true;
+    }();
+    (void)done;
+}
 const char *tb_last_kernel_name(void) { return tb::last_kernel(); }
 
 // ------------------------------------------------------------------ device
@@ -95,6 +128,7 @@ int tb_device_create(int hip_device_id, tb_device **out)
     TB_HIP(hipGetDeviceCount(&n));
     TB_REQUIRE(hip_device_id >= 0 && hip_device_id < n, "tb_device_create: device %d of %d", hip_device_id, n);
     TB_HIP(hipSetDevice(hip_device_id));
+    cap_host_threads_once();
     std::unique_ptr<tb_device, int (*)(tb_device *)> dev(new tb_device, tb_device_destroy); // a failure below releases what was created so far
     dev->id = hip_device_id;
     hipDeviceProp_t prop;
@@ -106,6 +140,8 @@ int tb_device_create(int hip_device_id, tb_device **out)
     TB_HIP(hipMalloc((void **)&dev->d_status, sizeof(Status)));
     TB_HIP(hipMalloc((void **)&dev->d_slots, 8 * 1024 * sizeof(double)));
     TB_HIP(hipMemset(dev->d_slots, 0, 8 * 1024 * sizeof(double)));
+    TB_HIP(hipMalloc((void **)&dev->d_ticket, 256));
+    TB_HIP(hipMemset(dev->d_ticket, 0, 256));
     TB_HIP(hipHostMalloc((void **)&dev->h_status, sizeof(Status), hipHostMallocDefault));
     *out = dev.release();
     return TB_OK;
@@ -123,6 +159,7 @@ int tb_device_destroy(tb_device *dev)
     if (dev->d_scratch) hipFree(dev->d_scratch);
     if (dev->d_tslot) hipFree(dev->d_tslot);
     if (dev->d_slots) hipFree(dev->d_slots);
+    if (dev->d_ticket) hipFree(dev->d_ticket);
     delete dev;
     return TB_OK;
 }

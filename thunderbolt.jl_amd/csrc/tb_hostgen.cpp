@@ -222,7 +222,10 @@ int64_t tb_host_build_pattern(int64_t n_cells, int ndpc, const int32_t *cell_dof
  * LAYERS the patch planner cuts (build_patch_plan: cells ranked by centroid per axis, R = extent ÷ mean cell extent equal-count buckets — exactly the
  * (i, j, k) layers of a possibly distorted structured grid, density-adaptive elsewhere): cells lexicographic in (k, j, i) with ties broken by the
  * centroid, nodes the same over R + 1 node layers, and dofs in the order of their first visit when the cells are traversed in the new order with the
- * local dofs in cell_dofs order — what close!(dh) produces on a grid stored in that order, so a lattice under any numbering gets generate_grid's own. */
+ * local dofs in cell_dofs order — what close!(dh) produces on a grid stored in that order, so a lattice under any numbering gets generate_grid's own.
+ * (Round 6 also measured a TILE-major order — dofs numbered patch by patch, so that every patch writes one contiguous 32 KB piece of each value array
+ * instead of one piece per grid line: slower at 216³, fused M + K 1.58 → 1.67 ms and CG iteration 0.70 → 0.82 ms, profiles/r06_v1/ab_tile_order.log —
+ * and removed it.) */
 int tb_host_locality_permutation(int geom_kind, int64_t n_nodes, const double *xyz, int64_t n_cells, const int32_t *conn, int ndofs_per_cell,
                                  const int32_t *cell_dofs, int64_t ndofs, int index_base, int32_t *cell_perm, int32_t *node_perm, int32_t *dof_perm)
 {

@@ -1,6 +1,9 @@
 // tb_internal.h — private declarations shared by the host objects and the HIP kernel launchers.
 // Nothing here is part of the ABI (include/tbhip.h is).
 #pragma once
+#include <cstdio>
+#include <cstdlib>
+#include <ctime>
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -59,6 +62,31 @@ const char *last_kernel();
         TB_NO_CAPTURE(dev_);                              \
         TB_HIP(hipStreamSynchronize((dev_)->stream));     \
     } while (0)
+
+// TB_PLAN_VERBOSE=1: wall time of the host-side plan builders, stage by stage, on stderr (what `setup_s.first_step_incl_plan_build` of bench.py is made of)
+struct PlanTimer {
+    const char *name;
+    double t0;
+    bool on;
+    static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+    explicit PlanTimer(const char *n) : name(n), t0(0.0), on(getenv("TB_PLAN_VERBOSE") != nullptr) { if (on) t0 = now(); }
+    void lap(const char *what) { if (on) { const double t = now(); fprintf(stderr, "[tbhip] plan time: %-28s %-34s %8.3f s\n", name, what, t - t0); t0 = t; } }
+    ~PlanTimer() { lap("(rest)"); }
+};
+
+#ifdef __HIPCC__
+// Next ticket of a persistent kernel's patch counter, WITHOUT a wait behind the draw.  atomicAdd on an address the compiler knows to be wave-uniform is
+// rewritten into "one lane adds the wave's count, the result is broadcast": a readfirstlane of the returned value right behind the atomic, i.e. a trip
+// to L2 in front of whatever follows.  `opaque_zero` is a zero the compiler cannot prove (made by inline assembly): with it in the
+// address the atomic stays one plain returning instruction, tracked by the compiler's own wait counters like any load — the wait lands where the
+// ticket is read.  (An untracked inline-assembly atomic was tried first: the compiler's counted waits for OLDER loads then include it.)
+__device__ __forceinline__ unsigned draw_ticket_async(unsigned *ticket)
+{
+    int opaque_zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(opaque_zero));
+    return atomicAdd(ticket + opaque_zero, 1u);
+}
+#endif
 
 // status word written by kernels (device) and read back after each launch group
 struct Status {
@@ -182,6 +210,7 @@ struct tb_device {
     void *d_scratch = nullptr;      // Float64 arena behind the *_f32 entry points (tb_f32.hip), grown on demand
     size_t scratch_bytes = 0;
     double *d_slots = nullptr;      // reduction slots (tb_algebra.hip: block_sum_slots): RED_GROUPS groups of 64 partial sums, 128 B apart, zero between uses
+    unsigned *d_ticket = nullptr;   // patch tickets of the persistent patch kernels (k_patch_hex8_stream): zeroed in front of every launch
     double *d_tslot = nullptr;      // {t, cos 2πt}: where time-dependent kernels read the time while a graph capture is open (tb_graph.hip)
     bool capturing = false, defer_before_capture = false, tslot_used = false; // tslot_used: a captured launch was handed the slot
     hipStream_t aux_stream = nullptr; // second queue of the chunked mechanics linearisation (gather of chunk k beside the integration of chunk k + 1)

@@ -554,7 +554,7 @@ __device__ __forceinline__ const __attribute__((address_space(4))) double *kerna
 // 512 / 426 nodes per patch or rows longer than 32 entries keep the record kernel.
 template <bool WK, bool WM, bool DIAG, bool ISO, int RPH, int KOFF = 0>
 __global__ void __launch_bounds__(256, 2)
-k_patch_hex8_stream(FormArgs faK, FormArgs faM, const uint8_t *__restrict__ rec, int stride, int nem, int rm, int nm, int kcap, const uint8_t *__restrict__ sigtab, const int32_t *__restrict__ elem_cell, int n_patches,
+k_patch_hex8_stream(FormArgs faK, FormArgs faM, const uint8_t *__restrict__ rec, int stride, int nem, int rm, int nm, int kcap, const uint8_t *__restrict__ sigtab, const int32_t *__restrict__ elem_cell, int n_patches, unsigned *__restrict__ ticket,
                     double *__restrict__ nzK, double *__restrict__ nzM, Status *st
 #ifdef TB_ABLATION
                     , long long *prof
@@ -564,7 +564,16 @@ k_patch_hex8_stream(FormArgs faK, FormArgs faM, const uint8_t *__restrict__ rec,
     extern __shared__ double lds[];
     constexpr int T = 256;
     const int wave_s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int p = blockIdx.x;
+    // Patches are dealt by TICKET (one atomic per patch on a counter the host zeroes in front of the launch), not by blockIdx + k·gridDim: with a static deal
+    // the launch ends with its slowest workgroup — measured at 216³ (profiles/r06_v1/ab_stream.log): the sampled workgroup was through its 140 patches
+    // after 1.48 ms, the kernel took 1.85.  The ticket of the patch AFTER the next one is drawn at the start of a write-out (lane 0) and travels through an
+    // LDS word behind the second barrier, so its round trip hides behind a whole patch.
+    __shared__ unsigned tick[2];
+    if (threadIdx.x == 0) { tick[0] = atomicAdd(ticket, 1u); tick[1] = atomicAdd(ticket, 1u); }
+    __syncthreads();
+    int p = __builtin_amdgcn_readfirstlane((int)tick[0]), pn = __builtin_amdgcn_readfirstlane((int)tick[1]);
+    if (p >= n_patches) return;
+    __syncthreads(); // (tick is written again in the first write-out)
 #ifdef TB_ABLATION
 #define TB_ST(k) do { if (prof && lane_index_now() + 64 * wave_s == 0 && (p & 1023) == 7) prof[(p >> 10) * 8 + (k)] = wall_clock64(); } while (0)
 #else
@@ -580,12 +589,15 @@ k_patch_hex8_stream(FormArgs faK, FormArgs faM, const uint8_t *__restrict__ rec,
     // (rd, xc are values of ONE write-out: declared per use below — as variables of the whole loop they would be merged with their stale copies where the
     // request is conditional, stay alive through the integration and be spilled there)
     const uint8_t *r;
-    uint4 lnv;
+    uint4 lnv, hv;
     uint32_t sig, hw, e0;
     auto request = [&](int q, int tid, uint4 &rd, double (&xc)[NX]) { // every load of patch q's record, addressed from q alone
         r = rec + (size_t)q * (size_t)stride;
-        const uint4 h4 = *(const uint4 *)r; // wave-uniform address: a scalar load
-        hw = h4.x; e0 = h4.y;
+        // the header as a VECTOR load (every lane the same 16 bytes; `tid >> 31` is zero, which the compiler cannot know of an index made by inline
+        // assembly): a scalar load shares its counter with the LDS operations, whose waits are lgkmcnt(0) while one is in flight — the write-out's first
+        // LDS read would wait for this trip to memory (measured: 4.3 µs between the barrier and the stores, against 2.5 µs for the same reads in the
+        // record kernel)
+        hv = *(const uint4 *)(r + (size_t)(unsigned)(tid >> 31));
         lnv = ((const uint4 *)(r + 16))[tid];
         sig = ((const uint32_t *)(r + 16 + (size_t)nem * 16))[tid];
         const uint8_t *rdp = r + 16 + (size_t)nem * 20;
@@ -636,6 +648,7 @@ k_patch_hex8_stream(FormArgs faK, FormArgs faM, const uint8_t *__restrict__ rec,
     }
     land(0, lane_index_now() + 64 * wave_s, rd0, xc0);
     }
+    hw = __builtin_amdgcn_readfirstlane(hv.x); e0 = __builtin_amdgcn_readfirstlane(hv.y);
     positions();
     int buf = 0;
     __syncthreads();
@@ -666,58 +679,94 @@ k_patch_hex8_stream(FormArgs faK, FormArgs faM, const uint8_t *__restrict__ rec,
                                                               elem_cell, (int64_t)e0 + ei);
             }
         }
+        // every lane "reads" its positions here, the idle ones of a short patch too: on the path around the instance loop the compiler would carry the
+        // four position loads as still in flight, and its first register reuse in the write-out would wait on the memory counter — with the ticket and
+        // the next record's loads just issued behind them
+        asm volatile("" ::"v"(cp[0].x), "v"(cp[0].y), "v"(cp[0].z), "v"(cp[0].w), "v"(cp[1].x), "v"(cp[1].y), "v"(cp[1].z), "v"(cp[1].w),
+                     "v"(cp[2].x), "v"(cp[2].y), "v"(cp[2].z), "v"(cp[2].w), "v"(cp[3].x), "v"(cp[3].y), "v"(cp[3].z), "v"(cp[3].w));
         TB_ST(1);
         __syncthreads();
         TB_ST(2);
         // write-out of this patch (one row per half-wave: all descriptors, then all accumulators — zeroed behind the read —, then all stores) with the
         // record of the next patch requested in front of it
         const int tidw = lane_index_now() + 64 * wave_s;
-        const int pn = p + (int)gridDim.x;
         const bool more = pn < n_patches;
+        unsigned t_next = 0; // the patch after the next one; read behind land(), whose wait for the loads below covers it (in-order counter)
+        if (tidw == 0) t_next = draw_ticket_async(ticket);
         uint4 rd;
         double xc[NX];
         request(more ? pn : p, tidw, rd, xc); // (unconditional: the last patch of a workgroup asks for its own record again)
-        const int half = tidw >> 5, hl = tidw & 31;
-        // two rounds of RPH / 2 rows per half-wave (all RPH at once, next to the staged inputs of the next patch, need more registers than a
-        // round holds without a spill — and a spilled input waits for its load in front of everything else)
-        constexpr int RH = RPH / 2;
+        // One row per QUARTER-wave, two entries per lane (rows of ≤ 32 entries: 14 lanes carry a hexahedral mesh's 27): half the LDS reads, zero writes and
+        // global stores of the one-entry-per-lane form — the write-out shares the LDS pipe with the co-resident workgroup's integration (60 % busy there)
+        // and was bound by it (3.2 of its 4.3 µs between the barrier and the first store, profiles/r06_v1/ab_stream.log).  Two rounds of RQ / 2 rows.
+        const int quarter = tidw >> 4, e2 = (tidw & 15) << 1;
+        constexpr int RQ = RPH / 2, RH = RQ / 2; // rows per quarter-wave (16 quarter-waves × RQ = 8·RPH rows), rows per round
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             uint4 d[RH]; // {nz0 lo, nz0 hi, off, len}
 #pragma unroll
-            for (int u = 0; u < RH; ++u) { const int s_ = half + (h * RH + u) * (T / 32); d[u] = ((const uint4 *)desc)[s_ < nrows ? s_ : 0]; if (s_ >= nrows) d[u].w = 0; }
-            double vK[RH], vM[RH];
+            for (int u = 0; u < RH; ++u) { const int s_ = quarter + (h * RH + u) * (T / 16); d[u] = ((const uint4 *)desc)[s_ < nrows ? s_ : 0]; }
+            asm volatile("" ::: "memory"); // all descriptor reads in flight before the first is looked at (one LDS round trip, not RH)
+#pragma unroll
+            for (int u = 0; u < RH; ++u) if (quarter + (h * RH + u) * (T / 16) >= nrows) d[u].w = 0;
+            double vK[RH][2], vM[RH][2];
 #pragma unroll
             for (int u = 0; u < RH; ++u) {
-                const uint32_t a_ = d[u].z + (hl < d[u].w ? hl : 0);
-                if constexpr (WK) vK[u] = accK[a_];
-                if constexpr (WM) vM[u] = accM[a_];
+                const uint32_t a_ = d[u].z + ((uint32_t)e2 < d[u].w ? e2 : 0);
+                if constexpr (WK) { vK[u][0] = accK[a_]; vK[u][1] = accK[a_ + 1]; } // (the second entry of an odd row's last lane reads one slot past the row: inside the block, unused)
+                if constexpr (WM) { vM[u][0] = accM[a_]; vM[u][1] = accM[a_ + 1]; }
             }
 #pragma unroll
-            for (int u = 0; u < RH; ++u)
-                if (hl < d[u].w) {
-                    if constexpr (WK) accK[d[u].z + hl] = 0.0;
-                    if constexpr (WM) accM[d[u].z + hl] = 0.0;
+            for (int u = 0; u < RH; ++u) {
+                const uint32_t a_ = d[u].z + e2;
+                if ((uint32_t)e2 + 1 < d[u].w) {
+                    if constexpr (WK) { accK[a_] = 0.0; accK[a_ + 1] = 0.0; }
+                    if constexpr (WM) { accM[a_] = 0.0; accM[a_ + 1] = 0.0; }
+                } else if ((uint32_t)e2 < d[u].w) {
+                    if constexpr (WK) accK[a_] = 0.0;
+                    if constexpr (WM) accM[a_] = 0.0;
                 }
+            }
             TB_ST(3);
 #pragma unroll
-            for (int u = 0; u < RH; ++u)
-                if (hl < d[u].w) {
-                    const int64_t g0 = (int64_t)(((uint64_t)d[u].y << 32) | d[u].x) + hl;
-                    if constexpr (WK) nzK[g0] = vK[u];
-                    if constexpr (WM) nzM[g0] = vM[u];
+            for (int u = 0; u < RH; ++u) {
+                const int64_t g0 = (int64_t)(((uint64_t)d[u].y << 32) | d[u].x) + e2;
+#ifdef TB_PATCH_NT
+                typedef double d2_t __attribute__((ext_vector_type(2)));
+#endif
+                if ((uint32_t)e2 + 1 < d[u].w) { // 16-byte stores at 8-byte aligned addresses (global memory takes them)
+#ifdef TB_PATCH_NT
+                    if constexpr (WK) { d2_t v = {vK[u][0], vK[u][1]}; __builtin_nontemporal_store(v, (d2_t *)(nzK + g0)); }
+                    if constexpr (WM) { d2_t v = {vM[u][0], vM[u][1]}; __builtin_nontemporal_store(v, (d2_t *)(nzM + g0)); }
+#else
+                    if constexpr (WK) *(double2 *)(nzK + g0) = make_double2(vK[u][0], vK[u][1]);
+                    if constexpr (WM) *(double2 *)(nzM + g0) = make_double2(vM[u][0], vM[u][1]);
+#endif
+                } else if ((uint32_t)e2 < d[u].w) {
+#ifdef TB_PATCH_NT
+                    if constexpr (WK) __builtin_nontemporal_store(vK[u][0], nzK + g0);
+                    if constexpr (WM) __builtin_nontemporal_store(vM[u][0], nzM + g0);
+#else
+                    if constexpr (WK) nzK[g0] = vK[u][0];
+                    if constexpr (WM) nzM[g0] = vM[u][0];
+#endif
                 }
+            }
         }
         TB_ST(4);
         if (!more) break;
         buf ^= 1;
         land(buf, tidw, rd, xc);
+        // (pinned behind land()'s LDS stores: as a plain readfirstlane the scheduler lifts it into the write-out, and its wait for the header with it)
+        asm volatile("v_readfirstlane_b32 %0, %2\n\tv_readfirstlane_b32 %1, %3" : "=s"(hw), "=s"(e0) : "v"(hv.x), "v"(hv.y) : "memory");
         positions();
+        if (tidw == 0) tick[0] = t_next;
         TB_ST(5);
+        TB_ST(6);
         p = pn;
         __syncthreads();
+        pn = __builtin_amdgcn_readfirstlane((int)tick[0]); // (read by every wave before the next write-out's barrier-separated store)
 #ifdef TB_ABLATION
-        if (prof && lane_index_now() + 64 * wave_s == 0 && ((p - (int)gridDim.x) & 1023) == 7) prof[((p - (int)gridDim.x) >> 10) * 8 + 6] = wall_clock64();
 #endif
     }
 #undef TB_ST
@@ -855,12 +904,13 @@ int launch_assemble_hex8_patch(tb_form *fK, tb_form *fM, tb_pattern *p, double t
                 const int grid = (int)std::min<int64_t>(pp->n_patches, (int64_t)2 * dev->n_cu);
                 auto launch_str = [&](auto k) -> int {
                     TB_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldss));
+                    TB_HIP(hipMemsetAsync(dev->d_ticket, 0, sizeof(unsigned), dev->stream));
 #ifdef TB_ABLATION
                     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), ldss, dev->stream, aK, aMi, (const uint8_t *)pr->d_rec, pr->rec_stride, pr->rec_ne, pr->rec_rm, pr->rec_nm, pv.kcap,
-                                       (const uint8_t *)pf->d_sigtab, pp->d_elem_cell, (int)pp->n_patches, d_nzK, d_nzM, dev->d_status, d_prof);
+                                       (const uint8_t *)pf->d_sigtab, pp->d_elem_cell, (int)pp->n_patches, dev->d_ticket, d_nzK, d_nzM, dev->d_status, d_prof);
 #else
                     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), ldss, dev->stream, aK, aMi, (const uint8_t *)pr->d_rec, pr->rec_stride, pr->rec_ne, pr->rec_rm, pr->rec_nm, pv.kcap,
-                                       (const uint8_t *)pf->d_sigtab, pp->d_elem_cell, (int)pp->n_patches, d_nzK, d_nzM, dev->d_status);
+                                       (const uint8_t *)pf->d_sigtab, pp->d_elem_cell, (int)pp->n_patches, dev->d_ticket, d_nzK, d_nzM, dev->d_status);
 #endif
                     return TB_OK;
                 };

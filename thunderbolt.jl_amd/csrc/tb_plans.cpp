@@ -258,6 +258,7 @@ int build_patch_plan(tb_mesh *m, int cells_per_patch)
     }
     const int64_t nc = m->n_cells;
     const int ndpc = m->ndpc, nv = m->nverts;
+    PlanTimer timer("build_patch_plan");
     // 1. Morton order over quantile buckets.  Per axis the cells are ranked by centroid coordinate and cut into
     //    R_d equal-count buckets, R_d = extent / mean cell extent: on (mildly distorted) structured grids the
     //    buckets are exactly the cell layers (i,j,k), on unstructured meshes they adapt to the local density.
@@ -326,7 +327,9 @@ int build_patch_plan(tb_mesh *m, int cells_per_patch)
         }
         }
     }
+    timer.lap("buckets, keys");
     std::sort(keyed.begin(), keyed.end());
+    timer.lap("key sort");
     // 2. patch boundaries + row ownership by first touch, in Morton order.  A patch closes after `cells_per_patch`
     //    cells or when it would own more than 9/8 of that many rows (domain-boundary patches own the extra
     //    boundary layers), which bounds the LDS accumulator block of every workgroup.
@@ -355,6 +358,7 @@ int build_patch_plan(tb_mesh *m, int cells_per_patch)
         pstart.push_back(nc);
     }
     const int64_t np = (int64_t)pstart.size() - 1;
+    timer.lap("ownership sweep");
     // Inside a patch, cells (= threads) and hence row slots are ordered lexicographically (x fastest): lanes of a
     // wave then hit consecutive rows of the LDS accumulator block — stride-27 addresses, free of bank conflicts.
     auto lex_less = [&](int32_t a, int32_t b) {
@@ -368,10 +372,12 @@ int build_patch_plan(tb_mesh *m, int cells_per_patch)
     for (int64_t q = 0; q < np; ++q)
         std::sort(keyed.begin() + pstart[q], keyed.begin() + pstart[q + 1],
                   [&](const std::pair<uint64_t, int32_t> &a, const std::pair<uint64_t, int32_t> &b) { return lex_less(a.second, b.second); });
+    timer.lap("per-patch sorts");
     // 3. dof → cells
     std::vector<int64_t> sptr;
     std::vector<int32_t> ssrc;
     dof_slots(m, sptr, ssrc);
+    timer.lap("dof -> cells");
 
     auto plan = std::make_unique<PatchPlan>();
     plan->cells_per_patch = cells_per_patch;
@@ -424,6 +430,7 @@ int build_patch_plan(tb_mesh *m, int cells_per_patch)
         plan->max_elems = std::max<int>(plan->max_elems, (int)(elem_end - elem_begin));
         plan->max_rows = std::max<int>(plan->max_rows, (int)(row_end - row_begin));
     }
+    timer.lap("instances of every patch");
     // 256-thread workgroups (two resident per CU at the kernels' register / LDS budget, so one patch's write-out
     // overlaps the other's arithmetic); measured best on MI355X among 64…512
     plan->threads = std::min(256, std::max(64, (plan->max_elems + 63) / 64 * 64));
@@ -438,6 +445,7 @@ int build_patch_plan(tb_mesh *m, int cells_per_patch)
     if ((rc = upload(m->dev, plan->h_elem_cell, &plan->d_elem_cell))) return rc;
     if ((rc = upload(m->dev, plan->h_elem_lrow, &plan->d_elem_lrow))) return rc;
     if ((rc = upload(m->dev, plan->h_row_dof, &plan->d_row_dof))) return rc;
+    timer.lap("uploads");
     m->patches = std::move(plan);
     return TB_OK;
 }
@@ -446,6 +454,7 @@ int build_patch_plan(tb_mesh *m, int cells_per_patch)
 // position of every (i,j) coupling inside its row.
 int build_patch_mat_plan(tb_pattern *p)
 {
+    PlanTimer timer("build_patch_mat_plan");
     tb_mesh *m = p->mesh;
     const PatchPlan *pp = m->patches.get();
     const int ndpc = m->ndpc;
@@ -624,6 +633,7 @@ struct RecordTable {
 // local vertex a (Ferrite: vertex dofs in vertex order), i.e. a one-to-one node ↔ dof relation; rows of at most 255 entries.
 static int build_patch_fused_plan_impl(tb_pattern *p, int64_t *lds_need, int nregions, std::unique_ptr<PatchFusedPlan> &plan)
 {
+    PlanTimer timer("build_patch_fused_plan_impl");
     tb_mesh *m = p->mesh;
     const PatchPlan *pp = m->patches.get();
     const int ndpc = m->ndpc;
@@ -769,6 +779,7 @@ static int build_patch_fused_plan_impl(tb_pattern *p, int64_t *lds_need, int nre
 // copies the plan already holds (the host vectors of the builder are gone by now; this runs once per pattern).
 static int ensure_patch_records_impl(tb_pattern *p)
 {
+    PlanTimer timer("ensure_patch_records_impl");
     PatchFusedPlan *f = p->patch_fused.get();
     const PatchPlan *pp = p->mesh->patches.get();
     if (!f || !pp || !f->d_hdr) return TB_ERR_UNSUPPORTED;
@@ -846,7 +857,30 @@ static int build_patch_fused_plan(tb_pattern *p, int64_t *lds_need, int nregions
 // row descriptors and the node list of any patch fit 80 KiB of LDS — two workgroups per CU.
 int ensure_patch_fused(tb_mesh *m, tb_pattern *p, int nregions)
 {
-    if (!m->patches) { int rc = build_patch_plan(m, 0); if (rc) return rc; }
+    if (!m->patches) {
+        // Start from the largest tile whose full patch fits the budget by the pattern's longest row, instead of from 7×7×7 with one whole plan build per
+        // reduction (216³: six builds of 2.5 s each, 15 of the 21 s of the first assembly — TB_PLAN_VERBOSE=1 prints the stages).  The estimate is the need
+        // of a patch that owns every row of its tile; a plan that still does not fit is reduced further by the loop below, as before.
+        int k0 = 0;
+        const bool fixed0 = tune_env("TB_PATCH_CELLS") || getenv("TB_PATCH_TILE");
+        if (!fixed0 && m->patch_rcb == 0 && m->patch_tile_shrink == 0 && m->nverts == 8 && m->ndpc == 8) {
+            if (!p->max_row_len) for (int64_t r = 0; r < p->n_rows; ++r) p->max_row_len = std::max<int64_t>(p->max_row_len, p->h_rowptr[r + 1] - p->h_rowptr[r]);
+            int t[3] = {7, 7, 7};
+            auto fits = [&]() {
+                const int64_t rows = (int64_t)t[0] * t[1] * t[2], nodes = (int64_t)(t[0] + 2) * (t[1] + 2) * (t[2] + 2);
+                return (int64_t)nregions * rows * p->max_row_len * 8 + rows * 16 + nodes * 24 <= 80 * 1024;
+            };
+            while (!fits() && (t[0] > 1 || t[1] > 1 || t[2] > 1)) { // the same reduction build_patch_plan applies: the largest extent, first of equals
+                int d = 0;
+                for (int j = 1; j < 3; ++j) if (t[j] > t[d]) d = j;
+                --t[d];
+                ++k0;
+            }
+        }
+        int rc = build_patch_plan(m, k0 ? -k0 : 0);
+        if (rc) return rc;
+        if (k0) { m->patches->shrink = k0; m->patch_tile_shrink = k0; }
+    }
     auto need = [&](const PatchFusedPlan *f) {
         return (int64_t)nregions * f->max_lds_entries * 8 + (int64_t)m->patches->max_rows * 16 + (int64_t)f->max_nodes * 24;
     };
@@ -939,6 +973,7 @@ void free_vec_patch_plans(tb_mesh *m)
 // as build_patch_plan (quantile buckets per axis: exact layers on structured boxes, density-adaptive on unstructured meshes).
 int ensure_vec_patch_plan(tb_mesh *m, bool halo)
 {
+    PlanTimer timer("ensure_vec_patch_plan");
     if (m->vpatches[halo]) return TB_OK;
     if (m->ndpc != 8 || m->nverts != 8 || m->ncomp != 1) { set_error("vector patch plan: needs a scalar trilinear hexahedron field"); return TB_ERR_UNSUPPORTED; }
     int tile[3] = {8, 8, 8};
