@@ -69,6 +69,9 @@ def parse():
     ap.add_argument("--renumber", default="none", choices=["none", "dofs", "grid"],
                     help="--mesh shuffled | lv: apply tb_host_locality_permutation first — dofs = Ferrite.renumber!(dh, dof_perm) only (cells and nodes stay as "
                          "numbered), grid = the grid stored in the locality order as well (cells[cell_perm], nodes moved), then close!(dh)")
+    ap.add_argument("--trace-markers", action="store_true",
+                    help="launch a marker kernel (torch.cumsum on three integers: `scan` in its name, nothing else here launches one) right before and right after the timed "
+                         "region, outside the clock: scripts/rocpd_summary.py --between scan then averages a rocprofv3 trace over the timed launches only")
     ap.add_argument("--checksums", action="store_true",
                     help="after the timed region: two steps from the initial state, then partition-independent sums of M, K, b and the ionic states in the line "
                          "(an N-rank run must reproduce the one-rank numbers)")
@@ -561,6 +564,9 @@ def main():
             dev.defer_status(False)
             for i in range(warmup):
                 self.step(i)                                         # the W warm-up steps, status read per call
+            if args.trace_markers:
+                self.marker = torch.arange(3, device="cuda")
+                torch.cumsum(self.marker, 0)
             self.sync()
             # the timed steps run with the status deferred (tb_device_defer_status): the mesh is fixed, so the per-call check of the warm-up steps
             # is what a time loop needs; the steps enqueue back to back and the one status read of the region sits inside it, before the clock stops
@@ -576,6 +582,9 @@ def main():
             if self.dist is not None:
                 self.dist.barrier()
             dt_ = self.max_over_ranks(time.perf_counter() - t0)
+            if args.trace_markers:
+                torch.cumsum(self.marker, 0)
+                torch.cuda.synchronize()
             dev.defer_status(False)
             for i in range(steps):                                   # phase durations of the timed steps (the events are complete: no wait)
                 for k, name in enumerate(self.phase):

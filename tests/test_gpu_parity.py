@@ -612,8 +612,7 @@ def _property_checks(tb, oracle, device, n, sample=200, fused=False, kap=KAPPA_F
         kernel = tb.lib().tb_last_kernel_name().decode()
         iso_off = os.environ.get("TB_PATCH_ISO") == "0"
         want = ("DIAG" if np.count_nonzero(kap - np.diag(np.diag(kap))) == 0 else "GEN") if iso_off else "ISO"
-        # the instance this test is about did run (stream = the persistent form of the record kernel, default since round 6; TB_PATCH_KERNEL=record keeps the one-patch form)
-        assert kernel.startswith("k_patch_hex8_%s<K+M,%s" % ("record" if os.environ.get("TB_PATCH_KERNEL") == "record" else "stream", want)), kernel
+        assert kernel.startswith("k_patch_hex8_record<K+M,%s" % want), kernel    # the instance this test is about did run
     else:
         tb.update_operator(M, 0.0)
         tb.update_operator(K, 0.0)
@@ -753,10 +752,9 @@ def _patch_variant_child():
     print("PATCH_VARIANT_OK")
 
 
-@pytest.mark.parametrize("kernel,cut", [("stream", "balanced"), ("record", "balanced"), ("staged", "balanced"), ("general", "balanced"), ("record", "full"), ("stream", "full")])
+@pytest.mark.parametrize("kernel,cut", [("record", "balanced"), ("staged", "balanced"), ("general", "balanced"), ("record", "full")])
 def test_patch_kernel_variants_parity(kernel, cut):
-    """Every patch kernel that ships behind a switch — the persistent streaming kernel (default for constant coefficients since round 6), the one-trip record
-    kernel it loops (plans it does not cover, A/B runs), the two-trip staged kernel (field
+    """Every patch kernel that ships behind a switch — the one-trip record kernel (default for constant coefficients), the two-trip staged kernel (field
     coefficients, A/B runs), the unstaged general form — and both tile cuts give the oracle's matrices.  The switches are read once per process, so each
     variant runs in a child (the symmetric-accumulator variant of round 3, measured slower, is gone: DESIGN §8)."""
     import subprocess

@@ -140,8 +140,6 @@ int tb_device_create(int hip_device_id, tb_device **out)
     TB_HIP(hipMalloc((void **)&dev->d_status, sizeof(Status)));
     TB_HIP(hipMalloc((void **)&dev->d_slots, 8 * 1024 * sizeof(double)));
     TB_HIP(hipMemset(dev->d_slots, 0, 8 * 1024 * sizeof(double)));
-    TB_HIP(hipMalloc((void **)&dev->d_ticket, 256));
-    TB_HIP(hipMemset(dev->d_ticket, 0, 256));
     TB_HIP(hipHostMalloc((void **)&dev->h_status, sizeof(Status), hipHostMallocDefault));
     *out = dev.release();
     return TB_OK;
@@ -159,7 +157,6 @@ int tb_device_destroy(tb_device *dev)
     if (dev->d_scratch) hipFree(dev->d_scratch);
     if (dev->d_tslot) hipFree(dev->d_tslot);
     if (dev->d_slots) hipFree(dev->d_slots);
-    if (dev->d_ticket) hipFree(dev->d_ticket);
     delete dev;
     return TB_OK;
 }

@@ -566,122 +566,9 @@ k_vector_hex8_patch(FormArgs fa, VecPatchView pv, double *__restrict__ b, Status
     }
 }
 
-// Streaming form of the same kernel (round 6; same recipe as k_patch_hex8_stream, tb_patch_fused.hip): persistent workgroups, three per CU, patches dealt
-// by ticket.  The inputs of the next patch — two instances' node indices, 13 coordinate values and 3 dof ids per lane — are requested at the start of a
-// patch's flush, when the integration's registers are free, land behind the flush's atomics (older loads retire first: waiting for them does not wait
-// for the atomics) and go to LDS for the next integration; the node sums are zeroed by the lane that flushes them.  Covers patches of ≤ 512 instances
-// and ≤ NX·256 / 3 nodes (the 8×8×8 tiles and the bisection leaves); plans beyond that keep the one-patch kernel.
-__device__ __forceinline__ int vec_lane_index_now()
-{
-    int x;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));
-    return x;
-}
-
-template <bool HALO>
-__global__ void __launch_bounds__(256, 3)
-k_vector_hex8_stream(FormArgs fa, VecPatchView pv, int n_patches, unsigned *__restrict__ ticket, double *__restrict__ b, Status *st)
-{
-    extern __shared__ double lds[];
-    constexpr int T = 256, NI = 2, NX = 13, ND = 3;
-    const int wave_s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    __shared__ unsigned tick[2];
-    if (threadIdx.x == 0) { tick[0] = atomicAdd(ticket, 1u); tick[1] = atomicAdd(ticket, 1u); }
-    __syncthreads();
-    int p = __builtin_amdgcn_readfirstlane((int)tick[0]), pn = __builtin_amdgcn_readfirstlane((int)tick[1]);
-    if (p >= n_patches) return;
-    __syncthreads();
-    double *acc = lds;                 // one sum per patch node
-    double *xs = lds + pv.max_nodes;   // 3 per patch node
-    struct Hdr { int64_t e0, n0; int nrows, nnodes, ne; };
-    auto header = [&](int q) {
-        const uint4 h = pv.hdr[q]; // uniform address: a scalar load
-        return Hdr{(int64_t)h.x, (int64_t)h.y, (int)(h.z & 0xffff), (int)(h.z >> 16), (int)h.w};
-    };
-    auto request = [&](const Hdr &h, int tid, uint4 (&lnv)[NI], double (&xc)[NX]) { // unconditional loads at clamped indices
-#pragma unroll
-        for (int k = 0; k < NI; ++k) lnv[k] = ((const uint4 *)pv.elem_ln)[h.e0 + (tid + k * T < h.ne ? tid + k * T : h.ne - 1)];
-        const double *pc = pv.pcoord + 3 * h.n0;
-#pragma unroll
-        for (int j = 0; j < NX; ++j) xc[j] = pc[tid + j * T < 3 * h.nnodes ? tid + j * T : 3 * h.nnodes - 1];
-    };
-    // (the dof ids of a patch are fetched at the start of ITS flush, beside the next patch's inputs: carried from the staging they would live through
-    // the integration, where the 168 registers of three waves per SIMD are taken)
-    auto request_dofs = [&](const Hdr &h, int tid, int32_t (&dofs)[ND]) {
-        const int32_t *pd = pv.pdof + h.n0;
-#pragma unroll
-        for (int j = 0; j < ND; ++j) dofs[j] = pd[tid + j * T < h.nrows ? tid + j * T : h.nrows - 1];
-    };
-    auto land = [&](const Hdr &h, int tid, const double (&xc)[NX]) {
-#pragma unroll
-        for (int j = 0; j < NX; ++j) if (tid + j * T < 3 * h.nnodes) xs[tid + j * T] = xc[j];
-    };
-    Hdr hc = header(p);
-    uint4 lnv[NI];
-    {
-        double xc0[NX];
-        const int tid = vec_lane_index_now() + 64 * wave_s;
-        request(hc, tid, lnv, xc0);
-        for (int k = tid; k < pv.max_nodes; k += T) acc[k] = 0.0;
-        land(hc, tid, xc0);
-    }
-    __syncthreads();
-    for (;;) {
-        {
-            const int tid = vec_lane_index_now() + 64 * wave_s;
-#pragma unroll
-            for (int it = 0; it < NI; ++it) {
-                const int ei = tid + it * T;
-                if (ei < hc.ne) {
-                    const uint4 l4 = lnv[it];
-                    const uint32_t ln[8] = {l4.x & 0xffffu, l4.x >> 16, l4.y & 0xffffu, l4.y >> 16, l4.z & 0xffffu, l4.z >> 16, l4.w & 0xffffu, l4.w >> 16};
-                    double x[8][3];
-#pragma unroll
-                    for (int a = 0; a < 8; ++a) {
-                        const double *px = xs + 3 * ln[a];
-                        x[a][0] = px[0]; x[a][1] = px[1]; x[a][2] = px[2];
-                    }
-                    int64_t cell = 0;
-                    if (fa.src_kind == TB_SRC_TABULATED) cell = pv.elem_cell[hc.e0 + ei];
-                    double be[8];
-                    if (!hex8_sf_source(x, [&](int q, const double(&xq)[3]) { return eval_source(fa, xq, cell, q, 8); }, be)) flag_neg_detj(st, pv.elem_cell[hc.e0 + ei]);
-#pragma unroll
-                    for (int a = 0; a < 8; ++a)
-                        if (!HALO || ln[a] < (uint32_t)hc.nrows) unsafeAtomicAdd(acc + ln[a], be[a]);
-                }
-            }
-        }
-        __syncthreads();
-        const int tidw = vec_lane_index_now() + 64 * wave_s;
-        const bool more = pn < n_patches;
-        unsigned t_next = 0; // read behind land(), whose wait for the loads below covers it (in-order counter)
-        if (tidw == 0) t_next = draw_ticket_async(ticket);
-        const Hdr hn = header(more ? pn : p);
-        int32_t dofs[ND];
-        request_dofs(hc, tidw, dofs);
-        uint4 lnn[NI];
-        double xc[NX];
-        request(hn, tidw, lnn, xc);
-        // flush: every owned (HALO) / touched node once, its sum zeroed behind the read
-#pragma unroll
-        for (int j = 0; j < ND; ++j)
-            if (tidw + j * T < hc.nrows) {
-                const double v = acc[tidw + j * T];
-                acc[tidw + j * T] = 0.0;
-                if (HALO) b[dofs[j]] = v;
-                else unsafeAtomicAdd(b + dofs[j], v);
-            }
-        if (!more) break;
-        land(hn, tidw, xc);
-#pragma unroll
-        for (int k = 0; k < NI; ++k) lnv[k] = lnn[k];
-        if (tidw == 0) tick[0] = t_next;
-        hc = hn;
-        p = pn;
-        __syncthreads();
-        pn = __builtin_amdgcn_readfirstlane((int)tick[0]);
-    }
-}
+// (Round 6: a persistent, ticket-dealt streaming form of this kernel — next patch's inputs requested at the start of a patch's flush — was built and
+// measured: 0.333 against 0.334–0.339 ms at 216³, 0.077 against 0.059 ms on the 27-layer slab, where its 768 long-lived workgroups balance worse than
+// 2 460 short ones.  Removed; profiles/r06_v1/ab_stream_source_cpu16.log, ab_slab27_persistent_kernels.log.)
 
 // ------------------------------------------------------------------------------------------------
 // host launchers
@@ -1649,12 +1536,13 @@ k_patch_tet4(FormArgs faK, FormArgs faM, TetPatchView pv, const uint4 *__restric
         }
     }
     __syncthreads();
-    // write-out: one row per half-wave (rows of a tetrahedral mesh hold ≈ 15 entries), each matrix's row as one contiguous run
-    const int half = tid >> 5, hl = tid & 31;
-    for (int s = half; s < nrows; s += T / 32) {
+    // write-out: one row per QUARTER-wave (rows of a tetrahedral mesh hold ≈ 15 entries: a half-wave per row left 17 of its 32 lanes idle — round 6),
+    // each matrix's row as one contiguous run
+    const int quarter = tid >> 4, ql = tid & 15;
+    for (int s = quarter; s < nrows; s += T / 16) {
         const uint4 d = desc[s];
         const int64_t g0 = (int64_t)(((uint64_t)d.y << 32) | d.x);
-        for (uint32_t k = hl; k < d.w; k += 32) {
+        for (uint32_t k = ql; k < d.w; k += 16) {
             if constexpr (WK) nzK[g0 + k] = accK[d.z + k];
             if constexpr (WM) nzM[g0 + k] = accM[d.z + k];
         }
@@ -1753,21 +1641,6 @@ static int run_vector(tb_form *f, int strategy, double t, double *d_b)
                 const VecPatchView pv{(const uint4 *)vp->d_hdr, vp->d_elem_ln, vp->d_elem_cell, vp->d_pcoord, vp->d_pdof, vp->max_nodes};
                 const size_t lds = (size_t)vp->max_nodes * 4 * sizeof(double);
                 if (!halo) TB_HIP(hipMemsetAsync(d_b, 0, (size_t)m->ndofs * sizeof(double), dev->stream));
-                static const char *venv = getenv("TB_VECTOR_KERNEL");
-                // streaming form: patches of ≤ 512 instances whose nodes fit the 13 values per lane the request holds, rows ≤ 768
-                if (!(venv && !strcmp(venv, "patch")) && vp->max_elems <= 512 && 3 * vp->max_nodes <= 13 * 256 && vp->max_nodes <= 3 * 256) {
-                    const int grid = (int)std::min<int64_t>(vp->n_patches, (int64_t)3 * dev->n_cu);
-                    TB_HIP(hipMemsetAsync(dev->d_ticket + 16, 0, sizeof(unsigned), dev->stream)); // (a word of its own: the matrix kernel's ticket is 64 B away)
-                    if (halo) {
-                        TB_HIP(hipFuncSetAttribute((const void *)k_vector_hex8_stream<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                        hipLaunchKernelGGL(k_vector_hex8_stream<true>, dim3((unsigned)grid), dim3(256), lds, dev->stream, fa, pv, (int)vp->n_patches, dev->d_ticket + 16, d_b, dev->d_status);
-                    } else {
-                        TB_HIP(hipFuncSetAttribute((const void *)k_vector_hex8_stream<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                        hipLaunchKernelGGL(k_vector_hex8_stream<false>, dim3((unsigned)grid), dim3(256), lds, dev->stream, fa, pv, (int)vp->n_patches, dev->d_ticket + 16, d_b, dev->d_status);
-                    }
-                    TB_HIP(hipGetLastError());
-                    return TB_OK;
-                }
                 if (halo) {
                     TB_HIP(hipFuncSetAttribute((const void *)k_vector_hex8_patch<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                     hipLaunchKernelGGL(k_vector_hex8_patch<true>, dim3((unsigned)vp->n_patches), dim3(256), lds, dev->stream, fa, pv, d_b, dev->d_status);

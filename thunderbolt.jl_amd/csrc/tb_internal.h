@@ -74,19 +74,6 @@ struct PlanTimer {
     ~PlanTimer() { lap("(rest)"); }
 };
 
-#ifdef __HIPCC__
-// Next ticket of a persistent kernel's patch counter, WITHOUT a wait behind the draw.  atomicAdd on an address the compiler knows to be wave-uniform is
-// rewritten into "one lane adds the wave's count, the result is broadcast": a readfirstlane of the returned value right behind the atomic, i.e. a trip
-// to L2 in front of whatever follows.  `opaque_zero` is a zero the compiler cannot prove (made by inline assembly): with it in the
-// address the atomic stays one plain returning instruction, tracked by the compiler's own wait counters like any load — the wait lands where the
-// ticket is read.  (An untracked inline-assembly atomic was tried first: the compiler's counted waits for OLDER loads then include it.)
-__device__ __forceinline__ unsigned draw_ticket_async(unsigned *ticket)
-{
-    int opaque_zero;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(opaque_zero));
-    return atomicAdd(ticket + opaque_zero, 1u);
-}
-#endif
 
 // status word written by kernels (device) and read back after each launch group
 struct Status {
@@ -210,7 +197,6 @@ struct tb_device {
     void *d_scratch = nullptr;      // Float64 arena behind the *_f32 entry points (tb_f32.hip), grown on demand
     size_t scratch_bytes = 0;
     double *d_slots = nullptr;      // reduction slots (tb_algebra.hip: block_sum_slots): RED_GROUPS groups of 64 partial sums, 128 B apart, zero between uses
-    unsigned *d_ticket = nullptr;   // patch tickets of the persistent patch kernels (k_patch_hex8_stream): zeroed in front of every launch
     double *d_tslot = nullptr;      // {t, cos 2πt}: where time-dependent kernels read the time while a graph capture is open (tb_graph.hip)
     bool capturing = false, defer_before_capture = false, tslot_used = false; // tslot_used: a captured launch was handed the slot
     hipStream_t aux_stream = nullptr; // second queue of the chunked mechanics linearisation (gather of chunk k beside the integration of chunk k + 1)

@@ -16,7 +16,6 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
-#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -366,7 +365,7 @@ k_patch_hex8_staged(FormArgs faK, FormArgs faM, FusedView pv, const uint4 *__res
 // Write-out: a half-wave reads ALL its row descriptors, then ALL its accumulators, then stores (one dependent LDS round instead of five).
 // KOFF > 0: the mass block sits KOFF entries behind the stiffness block (compile-time: the second add of a pair reuses the first one's address register with
 // an immediate offset); KOFF = 0: `kcap` entries behind it (patches with more than KOFF accumulator entries)
-template <bool WK, bool WM, bool DIAG, bool ISO, int RPH, int KOFF = 0>
+template <bool WK, bool WM, bool DIAG, bool ISO, int RPH, int KOFF = 0, bool WQ = true>
 __global__ void __launch_bounds__(256, 2)
 k_patch_hex8_record(FormArgs faK, FormArgs faM, const uint8_t *__restrict__ rec, int stride, int nem, int rm, int nm, int kcap, const uint8_t *__restrict__ sigtab, const int32_t *__restrict__ elem_cell, int pf, int prio, int stagger,
                     double *__restrict__ nzK, double *__restrict__ nzM, Status *st
@@ -483,6 +482,55 @@ k_patch_hex8_record(FormArgs faK, FormArgs faM, const uint8_t *__restrict__ rec,
     // formed again from the lane count and the wave's number — a scalar — instead of being kept through the integration, where all 256 registers
     // are taken: kept, it was the kernel's one spilled value.)
     const int tidw = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) + 64 * wave_s;
+    if constexpr (WQ) {
+        // round 6: one row per QUARTER-wave, two entries per lane (rows of ≤ 32 entries; 14 lanes carry a hexahedral row's 27) — half the LDS reads and
+        // global stores of the one-entry-per-lane form below (kept for rows longer than 32 entries).  All descriptors, then all accumulators, then all
+        // stores, in two rounds of RPH / 4 rows per quarter-wave.
+        const int quarter = tidw >> 4, e2 = (tidw & 15) << 1;
+        constexpr int RQ = RPH / 2, RH = RQ / 2;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint4 d[RH]; // {nz0 lo, nz0 hi, off, len}
+#pragma unroll
+            for (int u = 0; u < RH; ++u) { const int s = quarter + (h * RH + u) * (T / 16); d[u] = ((const uint4 *)desc)[s < nrows ? s : 0]; }
+            asm volatile("" ::: "memory"); // all descriptor reads in flight before the first is looked at
+#pragma unroll
+            for (int u = 0; u < RH; ++u) if (quarter + (h * RH + u) * (T / 16) >= nrows) d[u].w = 0;
+            double vK[RH][2], vM[RH][2];
+#pragma unroll
+            for (int u = 0; u < RH; ++u) {
+                const uint32_t a_ = d[u].z + ((uint32_t)e2 < d[u].w ? e2 : 0);
+                if constexpr (WK) { vK[u][0] = accK[a_]; vK[u][1] = accK[a_ + 1]; } // (an odd row's last lane reads one slot past the row: inside the LDS allocation, unused)
+                if constexpr (WM) { vM[u][0] = accM[a_]; vM[u][1] = accM[a_ + 1]; }
+            }
+#pragma unroll
+            for (int u = 0; u < RH; ++u) {
+                const int64_t g0 = (int64_t)(((uint64_t)d[u].y << 32) | d[u].x) + e2;
+                if ((uint32_t)e2 + 1 < d[u].w) { // 16-byte stores at 8-byte aligned addresses (global memory takes them)
+                    if constexpr (WK) *(double2 *)(nzK + g0) = make_double2(vK[u][0], vK[u][1]);
+                    if constexpr (WM) *(double2 *)(nzM + g0) = make_double2(vM[u][0], vM[u][1]);
+                } else if ((uint32_t)e2 < d[u].w) {
+                    if constexpr (WK) nzK[g0] = vK[u][0];
+                    if constexpr (WM) nzM[g0] = vM[u][0];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < RH; ++u)
+                for (uint32_t k2 = 32 + ((uint32_t)e2 >> 1); k2 < d[u].w; k2 += 16) { // rows longer than 32 entries (nodes of an unstructured mesh with more than 8 cells)
+                    const int64_t g0 = (int64_t)(((uint64_t)d[u].y << 32) | d[u].x) + k2;
+                    if constexpr (WK) nzK[g0] = accK[d[u].z + k2];
+                    if constexpr (WM) nzM[g0] = accM[d[u].z + k2];
+                }
+        }
+        for (int s = quarter + RQ * (T / 16); s < nrows; s += T / 16) { // patches with more than 8·RPH rows
+            const uint4 dd = ((const uint4 *)desc)[s];
+            const int64_t g0 = (int64_t)(((uint64_t)dd.y << 32) | dd.x);
+            for (uint32_t k = (uint32_t)e2 >> 1; k < dd.w; k += 16) {
+                if constexpr (WK) nzK[g0 + k] = accK[dd.z + k];
+                if constexpr (WM) nzM[g0 + k] = accM[dd.z + k];
+            }
+        }
+    } else {
     const int half = tidw >> 5, hl = tidw & 31;
     uint4 d[RPH]; // {nz0 lo, nz0 hi, off, len}
 #pragma unroll
@@ -516,6 +564,7 @@ k_patch_hex8_record(FormArgs faK, FormArgs faM, const uint8_t *__restrict__ rec,
             if constexpr (WK) nzK[g0] = accK[d[u].z + k];
             if constexpr (WM) nzM[g0] = accM[d[u].z + k];
         }
+    }
     TB_ST(5);
 #ifdef TB_ABLATION
     if (prof) { __builtin_amdgcn_s_waitcnt(0); TB_ST(6); }
@@ -523,254 +572,14 @@ k_patch_hex8_record(FormArgs faK, FormArgs faM, const uint8_t *__restrict__ rec,
 #undef TB_ST
 }
 
-// lane index by an instruction sequence the compiler can neither hoist out of a loop nor merge with an earlier copy: inside the persistent loop below a
-// thread index kept in a register would live through the integration, where all 256 registers are taken (it, and every address derived from it,
-// would be spilled and reloaded from scratch memory)
-__device__ __forceinline__ int lane_index_now()
-{
-    int x;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));
-    return x;
-}
-// kernel-argument bytes re-read where they are used (a scalar load from the kernarg segment through a pointer the compiler cannot see through): the
-// nine doubles of L⁻¹ are needed once per patch, at staging — as ordinary arguments they are loaded once and held in 18 SGPRs through the whole loop
-__device__ __forceinline__ const __attribute__((address_space(4))) double *kernarg_doubles_now(unsigned byte_offset)
-{
-    const __attribute__((address_space(4))) char *q = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() + byte_offset;
-    asm volatile("" : "+s"(q));
-    return (const __attribute__((address_space(4))) double *)q;
-}
-
-// Streaming form (round 6, default for constant coefficients): PERSISTENT workgroups, two per CU, each taking the patches blockIdx.x, + gridDim.x, … in
-// turn.  Why: phase stamps of the record kernel at 216³ (profiles/r06_v1/ab_stream.log) — a workgroup spends 2.0 µs staging its record, 6.4 µs integrating
-// and 2.4 µs writing its rows out; alone on its CU it integrates in 5.2 µs, and two integrating together take 7.7 µs for both, i.e. the vector pipe is
-// saturated only while BOTH residents integrate, and each resident is away from it for 4.5 of its 11 µs.  Here the staging trip of patch k + 1 is issued
-// at the start of patch k's write-out, when the integration's registers are free (loads are older than the stores behind them, and the memory counter
-// retires in order: waiting for them does not wait for the stores), lands while the rows leave, and goes to LDS behind the stores: the coordinates'
-// region is dead during a write-out and the row descriptors alternate between two buffers.  The accumulators are zeroed by the lane that reads them
-// out.  A workgroup never ends between patches, so nothing waits for its stores to drain either.  Per patch: integration → barrier → write-out +
-// staging of the next → barrier.  The write-out is straight-line code (no loop between the request of a record and its landing: the register allocator
-// splits and spills the requested values around loops, and a spilled input waits for its load at once): plans with more than 8·RPH rows or
-// 512 / 426 nodes per patch or rows longer than 32 entries keep the record kernel.
-template <bool WK, bool WM, bool DIAG, bool ISO, int RPH, int KOFF = 0>
-__global__ void __launch_bounds__(256, 2)
-k_patch_hex8_stream(FormArgs faK, FormArgs faM, const uint8_t *__restrict__ rec, int stride, int nem, int rm, int nm, int kcap, const uint8_t *__restrict__ sigtab, const int32_t *__restrict__ elem_cell, int n_patches, unsigned *__restrict__ ticket,
-                    double *__restrict__ nzK, double *__restrict__ nzM, Status *st
-#ifdef TB_ABLATION
-                    , long long *prof
-#endif
-)
-{
-    extern __shared__ double lds[];
-    constexpr int T = 256;
-    const int wave_s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // Patches are dealt by TICKET (one atomic per patch on a counter the host zeroes in front of the launch), not by blockIdx + k·gridDim: with a static deal
-    // the launch ends with its slowest workgroup — measured at 216³ (profiles/r06_v1/ab_stream.log): the sampled workgroup was through its 140 patches
-    // after 1.48 ms, the kernel took 1.85.  The ticket of the patch AFTER the next one is drawn at the start of a write-out (lane 0) and travels through an
-    // LDS word behind the second barrier, so its round trip hides behind a whole patch.
-    __shared__ unsigned tick[2];
-    if (threadIdx.x == 0) { tick[0] = atomicAdd(ticket, 1u); tick[1] = atomicAdd(ticket, 1u); }
-    __syncthreads();
-    int p = __builtin_amdgcn_readfirstlane((int)tick[0]), pn = __builtin_amdgcn_readfirstlane((int)tick[1]);
-    if (p >= n_patches) return;
-    __syncthreads(); // (tick is written again in the first write-out)
-#ifdef TB_ABLATION
-#define TB_ST(k) do { if (prof && lane_index_now() + 64 * wave_s == 0 && (p & 1023) == 7) prof[(p >> 10) * 8 + (k)] = wall_clock64(); } while (0)
-#else
-#define TB_ST(k) do { } while (0)
-#endif
-    const int kblk = KOFF > 0 ? KOFF : kcap;
-    double *accK = lds;
-    double *accM = lds + (WK && WM ? kblk : 0);
-    RowDesc *desc2 = (RowDesc *)(lds + (WK && WM ? 2 : 1) * kblk); // two descriptor buffers of rm rows
-    double *xs = (double *)(desc2 + 2 * rm);
-    constexpr int NX = ISO ? 6 : 5;
-    // inputs of a patch on their way from its record to LDS / to the integration
-    // (rd, xc are values of ONE write-out: declared per use below — as variables of the whole loop they would be merged with their stale copies where the
-    // request is conditional, stay alive through the integration and be spilled there)
-    const uint8_t *r;
-    uint4 lnv, hv;
-    uint32_t sig, hw, e0;
-    auto request = [&](int q, int tid, uint4 &rd, double (&xc)[NX]) { // every load of patch q's record, addressed from q alone
-        r = rec + (size_t)q * (size_t)stride;
-        // the header as a VECTOR load (every lane the same 16 bytes; `tid >> 31` is zero, which the compiler cannot know of an index made by inline
-        // assembly): a scalar load shares its counter with the LDS operations, whose waits are lgkmcnt(0) while one is in flight — the write-out's first
-        // LDS read would wait for this trip to memory (measured: 4.3 µs between the barrier and the stores, against 2.5 µs for the same reads in the
-        // record kernel)
-        hv = *(const uint4 *)(r + (size_t)(unsigned)(tid >> 31));
-        lnv = ((const uint4 *)(r + 16))[tid];
-        sig = ((const uint32_t *)(r + 16 + (size_t)nem * 16))[tid];
-        const uint8_t *rdp = r + 16 + (size_t)nem * 20;
-        const double *pc = (const double *)(rdp + (size_t)rm * 16);
-        // unconditional loads at clamped indices (the record is padded to rm descriptors and nm nodes): no branch per load, nothing to merge
-        rd = ((const uint4 *)rdp)[tid < rm ? tid : rm - 1];
-        if constexpr (ISO) { // node-wise: lane t takes nodes t and t + 256 whole, so that it can map them (x′ = L⁻¹x) on their way to LDS
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int node = tid + j * T < nm ? tid + j * T : nm - 1;
-#pragma unroll
-                for (int d = 0; d < 3; ++d) xc[3 * j + d] = pc[3 * node + d];
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < NX; ++j) xc[j] = pc[tid + j * T < 3 * nm ? tid + j * T : 3 * nm - 1];
-        }
-    };
-    auto land = [&](int buf, int tid, const uint4 &rd, const double (&xc)[NX]) { // … and into LDS (descriptor buffer `buf`, the coordinate block)
-        if (tid < rm) ((uint4 *)(desc2 + buf * rm))[tid] = rd;
-        if constexpr (ISO) {
-            const auto *Li = kernarg_doubles_now((unsigned)offsetof(FormArgs, Linv)); // faK is the kernel's first argument
-            auto put = [&](int node, double x0, double x1, double x2) {
-                xs[3 * node] = Li[0] * x0 + Li[1] * x1 + Li[2] * x2; xs[3 * node + 1] = Li[3] * x0 + Li[4] * x1 + Li[5] * x2; xs[3 * node + 2] = Li[6] * x0 + Li[7] * x1 + Li[8] * x2;
-            };
-#pragma unroll
-            for (int j = 0; j < 2; ++j) if (tid + j * T < nm) put(tid + j * T, xc[3 * j], xc[3 * j + 1], xc[3 * j + 2]);
-        } else {
-#pragma unroll
-            for (int j = 0; j < NX; ++j) if (tid + j * T < 3 * nm) xs[tid + j * T] = xc[j];
-        }
-    };
-    uint4 cp[4];
-    auto positions = [&]() {
-        const uint4 *cpp = (const uint4 *)(sigtab + (size_t)sig * 64); // padding lanes carry signature 0: a valid read
-#pragma unroll
-        for (int k = 0; k < 4; ++k) cp[k] = cpp[k];
-    };
-    // first patch of this workgroup: staged as in the record kernel
-    {
-    uint4 rd0;
-    double xc0[NX];
-    request(p, lane_index_now() + 64 * wave_s, rd0, xc0);
-    {   // zero both accumulator blocks while the loads travel (later patches: zeroed by the write-out)
-        double2 *z = (double2 *)lds;
-        const int n2 = ((WK && WM ? 2 : 1) * kblk) >> 1;
-        for (int k = lane_index_now() + 64 * wave_s; k < n2; k += T) z[k] = make_double2(0.0, 0.0);
-    }
-    land(0, lane_index_now() + 64 * wave_s, rd0, xc0);
-    }
-    hw = __builtin_amdgcn_readfirstlane(hv.x); e0 = __builtin_amdgcn_readfirstlane(hv.y);
-    positions();
-    int buf = 0;
-    __syncthreads();
-    for (;;) {
-        const int nrows = (int)(hw & 0x3ff), ne = (int)(hw >> 21);
-        const RowDesc *desc = desc2 + buf * rm;
-        TB_ST(0);
-        {
-            const int tid = lane_index_now() + 64 * wave_s;
-            for (int ei = tid; ei < ne; ei += T) { // one pass for all but the patches that own extra boundary layers
-                if (ei >= T) {
-                    lnv = ((const uint4 *)(r + 16))[ei];
-                    const uint4 *cpp = (const uint4 *)(sigtab + (size_t)((const uint32_t *)(r + 16 + (size_t)nem * 16))[ei] * 64);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) cp[k] = cpp[k];
-                }
-                const uint32_t ln[8] = {lnv.x & 0xffffu, lnv.x >> 16, lnv.y & 0xffffu, lnv.y >> 16, lnv.z & 0xffffu, lnv.z >> 16, lnv.w & 0xffffu, lnv.w >> 16};
-                double x[8][3];
-#pragma unroll
-                for (int a = 0; a < 8; ++a) {
-                    const double *px = xs + 3 * ln[a];
-                    x[a][0] = px[0]; x[a][1] = px[1]; x[a][2] = px[2];
-                }
-                uint32_t ro[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) ro[i] = ln[i] < (uint32_t)nrows ? desc[ln[i]].off : 0xFFFFFFFFu;
-                hex8_instance<WK, WM, false, false, DIAG, ISO>(x, [&](uint4(&c4)[4], uint32_t(&r8)[8]) { for (int k = 0; k < 4; ++k) c4[k] = cp[k]; for (int k = 0; k < 8; ++k) r8[k] = ro[k]; }, 0, faK, faM, accK, accM, st,
-                                                              elem_cell, (int64_t)e0 + ei);
-            }
-        }
-        // every lane "reads" its positions here, the idle ones of a short patch too: on the path around the instance loop the compiler would carry the
-        // four position loads as still in flight, and its first register reuse in the write-out would wait on the memory counter — with the ticket and
-        // the next record's loads just issued behind them
-        asm volatile("" ::"v"(cp[0].x), "v"(cp[0].y), "v"(cp[0].z), "v"(cp[0].w), "v"(cp[1].x), "v"(cp[1].y), "v"(cp[1].z), "v"(cp[1].w),
-                     "v"(cp[2].x), "v"(cp[2].y), "v"(cp[2].z), "v"(cp[2].w), "v"(cp[3].x), "v"(cp[3].y), "v"(cp[3].z), "v"(cp[3].w));
-        TB_ST(1);
-        __syncthreads();
-        TB_ST(2);
-        // write-out of this patch (one row per half-wave: all descriptors, then all accumulators — zeroed behind the read —, then all stores) with the
-        // record of the next patch requested in front of it
-        const int tidw = lane_index_now() + 64 * wave_s;
-        const bool more = pn < n_patches;
-        unsigned t_next = 0; // the patch after the next one; read behind land(), whose wait for the loads below covers it (in-order counter)
-        if (tidw == 0) t_next = draw_ticket_async(ticket);
-        uint4 rd;
-        double xc[NX];
-        request(more ? pn : p, tidw, rd, xc); // (unconditional: the last patch of a workgroup asks for its own record again)
-        // One row per QUARTER-wave, two entries per lane (rows of ≤ 32 entries: 14 lanes carry a hexahedral mesh's 27): half the LDS reads, zero writes and
-        // global stores of the one-entry-per-lane form — the write-out shares the LDS pipe with the co-resident workgroup's integration (60 % busy there)
-        // and was bound by it (3.2 of its 4.3 µs between the barrier and the first store, profiles/r06_v1/ab_stream.log).  Two rounds of RQ / 2 rows.
-        const int quarter = tidw >> 4, e2 = (tidw & 15) << 1;
-        constexpr int RQ = RPH / 2, RH = RQ / 2; // rows per quarter-wave (16 quarter-waves × RQ = 8·RPH rows), rows per round
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            uint4 d[RH]; // {nz0 lo, nz0 hi, off, len}
-#pragma unroll
-            for (int u = 0; u < RH; ++u) { const int s_ = quarter + (h * RH + u) * (T / 16); d[u] = ((const uint4 *)desc)[s_ < nrows ? s_ : 0]; }
-            asm volatile("" ::: "memory"); // all descriptor reads in flight before the first is looked at (one LDS round trip, not RH)
-#pragma unroll
-            for (int u = 0; u < RH; ++u) if (quarter + (h * RH + u) * (T / 16) >= nrows) d[u].w = 0;
-            double vK[RH][2], vM[RH][2];
-#pragma unroll
-            for (int u = 0; u < RH; ++u) {
-                const uint32_t a_ = d[u].z + ((uint32_t)e2 < d[u].w ? e2 : 0);
-                if constexpr (WK) { vK[u][0] = accK[a_]; vK[u][1] = accK[a_ + 1]; } // (the second entry of an odd row's last lane reads one slot past the row: inside the block, unused)
-                if constexpr (WM) { vM[u][0] = accM[a_]; vM[u][1] = accM[a_ + 1]; }
-            }
-#pragma unroll
-            for (int u = 0; u < RH; ++u) {
-                const uint32_t a_ = d[u].z + e2;
-                if ((uint32_t)e2 + 1 < d[u].w) {
-                    if constexpr (WK) { accK[a_] = 0.0; accK[a_ + 1] = 0.0; }
-                    if constexpr (WM) { accM[a_] = 0.0; accM[a_ + 1] = 0.0; }
-                } else if ((uint32_t)e2 < d[u].w) {
-                    if constexpr (WK) accK[a_] = 0.0;
-                    if constexpr (WM) accM[a_] = 0.0;
-                }
-            }
-            TB_ST(3);
-#pragma unroll
-            for (int u = 0; u < RH; ++u) {
-                const int64_t g0 = (int64_t)(((uint64_t)d[u].y << 32) | d[u].x) + e2;
-#ifdef TB_PATCH_NT
-                typedef double d2_t __attribute__((ext_vector_type(2)));
-#endif
-                if ((uint32_t)e2 + 1 < d[u].w) { // 16-byte stores at 8-byte aligned addresses (global memory takes them)
-#ifdef TB_PATCH_NT
-                    if constexpr (WK) { d2_t v = {vK[u][0], vK[u][1]}; __builtin_nontemporal_store(v, (d2_t *)(nzK + g0)); }
-                    if constexpr (WM) { d2_t v = {vM[u][0], vM[u][1]}; __builtin_nontemporal_store(v, (d2_t *)(nzM + g0)); }
-#else
-                    if constexpr (WK) *(double2 *)(nzK + g0) = make_double2(vK[u][0], vK[u][1]);
-                    if constexpr (WM) *(double2 *)(nzM + g0) = make_double2(vM[u][0], vM[u][1]);
-#endif
-                } else if ((uint32_t)e2 < d[u].w) {
-#ifdef TB_PATCH_NT
-                    if constexpr (WK) __builtin_nontemporal_store(vK[u][0], nzK + g0);
-                    if constexpr (WM) __builtin_nontemporal_store(vM[u][0], nzM + g0);
-#else
-                    if constexpr (WK) nzK[g0] = vK[u][0];
-                    if constexpr (WM) nzM[g0] = vM[u][0];
-#endif
-                }
-            }
-        }
-        TB_ST(4);
-        if (!more) break;
-        buf ^= 1;
-        land(buf, tidw, rd, xc);
-        // (pinned behind land()'s LDS stores: as a plain readfirstlane the scheduler lifts it into the write-out, and its wait for the header with it)
-        asm volatile("v_readfirstlane_b32 %0, %2\n\tv_readfirstlane_b32 %1, %3" : "=s"(hw), "=s"(e0) : "v"(hv.x), "v"(hv.y) : "memory");
-        positions();
-        if (tidw == 0) tick[0] = t_next;
-        TB_ST(5);
-        TB_ST(6);
-        p = pn;
-        __syncthreads();
-        pn = __builtin_amdgcn_readfirstlane((int)tick[0]); // (read by every wave before the next write-out's barrier-separated store)
-#ifdef TB_ABLATION
-#endif
-    }
-#undef TB_ST
-}
+// Round 6 built a PERSISTENT form of this kernel (k_patch_hex8_stream: two workgroups per CU looping over ticket-dealt patches, the record of patch k + 1
+// requested at the start of patch k's write-out and landed in LDS behind it, accumulators zeroed by the lane that reads them out, quarter-wave
+// write-out) and removed it again: parity-green, and 2–4 % SLOWER at 216³ (1.66–1.67 against 1.60–1.62 ms on the same boxes) and 14 % slower on the
+// 27-layer slab.  Its phase stamps showed why the staging trip is not what this kernel waits for: with the trip hidden the integration phase grew from
+// 6.6 to 7.3 µs (the co-resident workgroup is then integrating more of the time) and the write-out, now always beside an integrating partner whose
+// ds_add_f64 stream keeps the LDS pipe busy, from 2.5 to 4.6 µs.  The work-skipping builds put the floor where it is: 1.22 ms with neither arithmetic
+// nor LDS adds (5.7 GB at 4.7 TB/s — the rate of a copy on this part), +0.21 ms for the arithmetic alone, +0.25 ms for the adds alone, 1.65 ms with
+// both.  Logs: profiles/r06_v1/ab_stream_*.log, ab_work_skipping_flags.log; what was kept from it is the quarter-wave write-out (WQ above).
 
 bool hex8_patch_applicable(const tb_form *f, const tb_pattern *p)
 {
@@ -839,7 +648,7 @@ int launch_assemble_hex8_patch(tb_form *fK, tb_form *fM, tb_pattern *p, double t
     const bool staged = pf->d_hdr && !general;
     const bool diag = fK && !fk && aK.D[1] == 0.0 && aK.D[2] == 0.0 && aK.D[5] == 0.0 && aK.D[3] == 0.0 && aK.D[6] == 0.0 && aK.D[7] == 0.0;
     // one-trip record kernel: constant coefficients, patches of ≤ 256 instances (TB_PATCH_KERNEL=staged keeps the two-trip kernel for A/B runs)
-    static const bool no_record = getenv("TB_PATCH_KERNEL") && strcmp(getenv("TB_PATCH_KERNEL"), "record") != 0 && strcmp(getenv("TB_PATCH_KERNEL"), "stream") != 0;
+    static const bool no_record = getenv("TB_PATCH_KERNEL") && strcmp(getenv("TB_PATCH_KERNEL"), "record") != 0;
     static const int wave_prio = tune_env("TB_PATCH_PRIO") ? atoi(tune_env("TB_PATCH_PRIO")) : 0; // measured: no effect (1.7007 vs 1.6997 ms)
     static const int stagger = tune_env("TB_PATCH_STAGGER") ? atoi(tune_env("TB_PATCH_STAGGER")) : 0;
     const int pf_ahead = 0; // (look-ahead touch of later records: removed from the record kernel, see there)
@@ -894,36 +703,10 @@ int launch_assemble_hex8_patch(tb_form *fK, tb_form *fM, tb_pattern *p, double t
 #endif
                 return TB_OK;
             };
-            // streaming (persistent) form: the same instances behind a loop over the patches of a workgroup; needs the second descriptor buffer in LDS
-            static const char *kenv = getenv("TB_PATCH_KERNEL");
-            const size_t ldss = ldsr + (size_t)pr->rec_rm * sizeof(RowDesc);
-            if (!p->max_row_len) for (int64_t r_ = 0; r_ < p->n_rows; ++r_) p->max_row_len = std::max<int64_t>(p->max_row_len, p->h_rowptr[r_ + 1] - p->h_rowptr[r_]);
-            const bool stream = !(kenv && !strcmp(kenv, "record")) && ldss <= 80 * 1024 && (!(fK && fM) || fixm) && pp->max_rows <= 8 * RPH && p->max_row_len <= 32 &&
-                                pr->rec_nm <= (iso ? 512 : 5 * 256 / 3);
-            if (stream) {
-                const int grid = (int)std::min<int64_t>(pp->n_patches, (int64_t)2 * dev->n_cu);
-                auto launch_str = [&](auto k) -> int {
-                    TB_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldss));
-                    TB_HIP(hipMemsetAsync(dev->d_ticket, 0, sizeof(unsigned), dev->stream));
-#ifdef TB_ABLATION
-                    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), ldss, dev->stream, aK, aMi, (const uint8_t *)pr->d_rec, pr->rec_stride, pr->rec_ne, pr->rec_rm, pr->rec_nm, pv.kcap,
-                                       (const uint8_t *)pf->d_sigtab, pp->d_elem_cell, (int)pp->n_patches, dev->d_ticket, d_nzK, d_nzM, dev->d_status, d_prof);
-#else
-                    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), ldss, dev->stream, aK, aMi, (const uint8_t *)pr->d_rec, pr->rec_stride, pr->rec_ne, pr->rec_rm, pr->rec_nm, pv.kcap,
-                                       (const uint8_t *)pf->d_sigtab, pp->d_elem_cell, (int)pp->n_patches, dev->d_ticket, d_nzK, d_nzM, dev->d_status);
-#endif
-                    return TB_OK;
-                };
-                set_last_kernel("k_patch_hex8_stream<%s,%s,RPH%d%s>", fK && fM ? "K+M" : fK ? "K" : "M", !fK ? "-" : iso ? "ISO" : diag ? "DIAG" : "GEN", RPH, fK && fM ? ",KOFF4096" : "");
-                if (fK && fM) rc = iso ? launch_str(k_patch_hex8_stream<true, true, false, true, RPH, KOFF>) : diag ? launch_str(k_patch_hex8_stream<true, true, true, false, RPH, KOFF>) : launch_str(k_patch_hex8_stream<true, true, false, false, RPH, KOFF>);
-                else if (fK) rc = iso ? launch_str(k_patch_hex8_stream<true, false, false, true, RPH>) : diag ? launch_str(k_patch_hex8_stream<true, false, true, false, RPH>) : launch_str(k_patch_hex8_stream<true, false, false, false, RPH>);
-                else rc = launch_str(k_patch_hex8_stream<false, true, false, false, RPH>);
-                if (rc) return rc;
-                TB_HIP(hipGetLastError());
-                goto done;
-            }
             set_last_kernel("k_patch_hex8_record<%s,%s,RPH%d%s>", fK && fM ? "K+M" : fK ? "K" : "M", !fK ? "-" : iso ? "ISO" : diag ? "DIAG" : "GEN", RPH, fK && fM && fixm ? ",KOFF4096" : "");
-            if (fK && fM && fixm) rc = iso ? launch_rec(k_patch_hex8_record<true, true, false, true, RPH, KOFF>) : diag ? launch_rec(k_patch_hex8_record<true, true, true, false, RPH, KOFF>) : launch_rec(k_patch_hex8_record<true, true, false, false, RPH, KOFF>);
+            static const bool wq_off = tune_env("TB_PATCH_WQ") && atoi(tune_env("TB_PATCH_WQ")) == 0; // profiling build: the half-wave write-out of rounds 2-5 (bench instance only)
+            if (fK && fM && fixm && iso && wq_off) rc = launch_rec(k_patch_hex8_record<true, true, false, true, RPH, KOFF, false>);
+            else if (fK && fM && fixm) rc = iso ? launch_rec(k_patch_hex8_record<true, true, false, true, RPH, KOFF>) : diag ? launch_rec(k_patch_hex8_record<true, true, true, false, RPH, KOFF>) : launch_rec(k_patch_hex8_record<true, true, false, false, RPH, KOFF>);
             else if (fK && fM) rc = iso ? launch_rec(k_patch_hex8_record<true, true, false, true, RPH>) : diag ? launch_rec(k_patch_hex8_record<true, true, true, false, RPH>) : launch_rec(k_patch_hex8_record<true, true, false, false, RPH>);
             else if (fK) rc = iso ? launch_rec(k_patch_hex8_record<true, false, false, true, RPH>) : diag ? launch_rec(k_patch_hex8_record<true, false, true, false, RPH>) : launch_rec(k_patch_hex8_record<true, false, false, false, RPH>);
             else rc = launch_rec(k_patch_hex8_record<false, true, false, false, RPH>);

@@ -779,12 +779,12 @@ static int build_patch_fused_plan_impl(tb_pattern *p, int64_t *lds_need, int nre
 // copies the plan already holds (the host vectors of the builder are gone by now; this runs once per pattern).
 static int ensure_patch_records_impl(tb_pattern *p)
 {
-    PlanTimer timer("ensure_patch_records_impl");
     PatchFusedPlan *f = p->patch_fused.get();
     const PatchPlan *pp = p->mesh->patches.get();
     if (!f || !pp || !f->d_hdr) return TB_ERR_UNSUPPORTED;
     if (f->d_rec) return TB_OK;
     TB_NO_CAPTURE(p->mesh->dev);
+    PlanTimer timer("ensure_patch_records_impl");
     if (f->rec_stride < 0 || pp->max_elems > 1024 || pp->max_rows > 256) { f->rec_stride = -1; return TB_ERR_UNSUPPORTED; }
     const int64_t np = pp->n_patches;
     const int rm = (pp->max_rows + 3) & ~3, nm = (f->max_nodes + 3) & ~3, nem = std::max(256, (pp->max_elems + 63) & ~63);
@@ -973,9 +973,9 @@ void free_vec_patch_plans(tb_mesh *m)
 // as build_patch_plan (quantile buckets per axis: exact layers on structured boxes, density-adaptive on unstructured meshes).
 int ensure_vec_patch_plan(tb_mesh *m, bool halo)
 {
-    PlanTimer timer("ensure_vec_patch_plan");
     if (m->vpatches[halo]) return TB_OK;
     if (m->ndpc != 8 || m->nverts != 8 || m->ncomp != 1) { set_error("vector patch plan: needs a scalar trilinear hexahedron field"); return TB_ERR_UNSUPPORTED; }
+    PlanTimer timer("ensure_vec_patch_plan");
     int tile[3] = {8, 8, 8};
     if (const char *e = tune_env("TB_VPATCH_TILE")) {
         int a, b, c;
