@@ -3345,6 +3345,47 @@ def test_graph_replay_equals_plain_calls(tb, device):
     device.poll_status()
 
 
+def test_synchronising_calls_inside_a_capture_refuse_without_harming_a_host_owned_stream(tb):
+    """Round 6 (advisor, medium): a call that waits for the device — tb_memcpy_d2h, tb_dot, a Krylov solve, tb_device_poll_status, the first use of a
+    plan — made while a capture is open used to invalidate the capture, and HIP then keeps refusing work on that stream; with the stream handed in by the
+    host (torch's here, tb_device_set_stream) the library cannot replace it.  Now every such call returns TB_ERR_BAD_ARG BEFORE it touches the stream:
+    the capture stays valid (what was enqueued around the refused call replays), and torch keeps working on its stream."""
+    import torch
+    from thunderbolt_jl_amd import _lib as L
+    dev = tb.MI355XDevice(0)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        dev.set_stream(stream.cuda_stream)
+        n = 4096
+        x = torch.arange(n, dtype=torch.float64, device="cuda")
+        y = torch.zeros(n, dtype=torch.float64, device="cuda")
+        xv, yv = tb.DeviceVector.wrap(dev, x), tb.DeviceVector.wrap(dev, y)
+        refused = []
+
+        def body():
+            import ctypes as C
+            L.check(tb.lib().tb_axpy(dev.h, n, 2.0, xv.ptr, yv.ptr))                      # enqueue-only: captured
+            res = C.c_double()
+            refused.append(tb.lib().tb_dot(dev.h, n, xv.ptr, yv.ptr, C.byref(res)))      # reads back: refused, nothing enqueued
+            host = np.empty(n)
+            refused.append(tb.lib().tb_memcpy_d2h(dev.h, host.ctypes.data_as(C.c_void_p), yv.ptr, n * 8))
+            refused.append(tb.lib().tb_device_poll_status(dev.h))
+            L.check(tb.lib().tb_axpy(dev.h, n, 1.0, xv.ptr, yv.ptr))                      # the capture is still open and valid
+
+        gr = dev.capture(body)
+        assert refused == [L.TB_ERR_BAD_ARG] * 3, refused
+        assert b"capture" in tb.lib().tb_last_error_string()
+        assert gr.nodes == 2
+        gr.launch(0.0)
+        gr.launch(0.0)
+        stream.synchronize()
+        np.testing.assert_array_equal(y.cpu().numpy(), 6.0 * np.arange(n))                # 2 × (2x + x)
+        z = (x * 2.0).sum().item()                                                        # torch still runs on ITS stream
+        assert z == float(n * (n - 1))
+        gr.close()
+    dev.close()
+
+
 def test_cgd_iteration_equals_the_four_calls(tb, device):
     """tb_cgd_iteration (round 5: one whole local CG iteration from one call) = tb_spmv_csr_dot → tb_cgd_update → tb_cgd_direction → tb_cgd_rotate:
     the same kernels, the same numbers (to the rounding of the atomically summed dot products), iteration after iteration."""
