@@ -260,3 +260,25 @@ def test_bench_unstructured_meshes_under_the_bisection_partition_match_one_rank(
     assert two["phase_ms"]["halo"] > 0.0 and two["distributed_cg"]["halo_bytes_per_rank"] > 0
     for k, v in one["checksums"].items():
         assert abs(two["checksums"][k] - v) <= 1e-10 * abs(v), (k, v, two["checksums"][k])
+
+
+def test_electromechanics_step_under_the_bisection_partition_matches_one_rank():
+    """BASELINE configs[4] (coupled electromechanics on the ventricle, 8 GPUs) as scripts/bench_electromechanics.py --gpus N runs it: the EP operators,
+    the ionic step, the distributed heat solve and the mechanics residual / tangent of every part, neighbour sums of the vectors.  Two ranks on one
+    device (gloo) leave the partition-independent checksums of one rank (1e-10; the heat solution itself is iterated to rtol 1e-6 and not compared)."""
+    import json
+    import subprocess
+    script = os.path.join(ROOT, "scripts", "bench_electromechanics.py")
+    common = ["--nc", "16", "--nr", "3", "--nl", "8", "--reps", "2"]
+
+    def line(extra, env=None):
+        r = subprocess.run([sys.executable, script] + common + extra, env=dict(os.environ, **(env or {})), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+    one = line(["--gpus", "1"])
+    two = line(["--gpus", "2"], env={"TB_BENCH_SHARE_DEVICE": "1"})
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["backend"].startswith("gloo") and two["shared_nodes"] > 0
+    assert two["cells_total"] == one["cells_total"] and abs(2 * two["cells_per_gpu"] - one["cells_total"]) <= 1
+    for k, v in one["checksums"].items():
+        assert abs(two["checksums"][k] - v) <= 1e-10 * max(abs(v), 1e-30), (k, v, two["checksums"][k])
