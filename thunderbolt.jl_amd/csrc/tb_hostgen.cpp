@@ -6,6 +6,7 @@
 // Algorithms are deliberately data-parallel (min-key + prefix sum, per-row merges) rather than the
 // sequential first-visit / set-insertion form of the library they mimic.
 #include <algorithm>
+#include <parallel/algorithm>
 #include <array>
 #include <cmath>
 #include <cstring>
@@ -273,18 +274,19 @@ int tb_host_locality_permutation(int geom_kind, int64_t n_nodes, const double *x
     // layer of every item per axis: equal-count buckets of the coordinate ranks; then one sort by (layer z, layer y, layer x, x-coordinate, id)
     auto sweep_order = [&](int64_t n, auto coord, const int64_t (&R)[3], int32_t *out) {
         std::vector<uint32_t> layer((size_t)n * 3);
-#pragma omp parallel for schedule(static, 1) num_threads(3)
         for (int d = 0; d < 3; ++d) {
             std::vector<std::pair<double, int32_t>> by(n);
+#pragma omp parallel for schedule(static)
             for (int64_t i = 0; i < n; ++i) by[i] = {coord(i, d), (int32_t)i};
-            std::sort(by.begin(), by.end());
+            __gnu_parallel::sort(by.begin(), by.end());
+#pragma omp parallel for schedule(static)
             for (int64_t r = 0; r < n; ++r) layer[3 * (size_t)by[r].second + d] = (uint32_t)((r * R[d]) / n);
         }
         struct Key { uint32_t k, j, i; double x; int32_t id; };
         std::vector<Key> keys(n);
 #pragma omp parallel for schedule(static)
         for (int64_t i = 0; i < n; ++i) keys[i] = {layer[3 * i + 2], layer[3 * i + 1], layer[3 * i], coord(i, 0), (int32_t)i};
-        std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
+        __gnu_parallel::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
             if (a.k != b.k) return a.k < b.k;
             if (a.j != b.j) return a.j < b.j;
             if (a.i != b.i) return a.i < b.i;

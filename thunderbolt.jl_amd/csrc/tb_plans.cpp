@@ -1,6 +1,7 @@
 // tb_plans.cpp — host-side assembly plans, built once per mesh / pattern (the analogue of
 // setup_operator, src/solver/interface.jl:17-94: colouring, element-assembly maps, patch decomposition).
 #include <algorithm>
+#include <parallel/algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -284,15 +285,16 @@ int build_patch_plan(tb_mesh *m, int cells_per_patch)
                 lo[d] = std::min(lo[d], mn[d]); hi[d] = std::max(hi[d], mx[d]); hsum[d] += ext[d];
             }
         }
-#pragma omp parallel for schedule(static, 1) num_threads(3)
-        for (int d = 0; d < 3; ++d) {
+        for (int d = 0; d < 3; ++d) { // (round 6: one axis after the other, every sort on the whole team — three one-thread sorts of 10⁷ pairs took 1.0 s)
             const double hmean = hsum[d] / (double)std::max<int64_t>(nc, 1);
             int64_t R = hmean > 0 ? (int64_t)std::llround((hi[d] - lo[d]) / hmean) : 1;
             R = std::min<int64_t>(std::max<int64_t>(R, 1), 1 << 21);
             Rv[d] = R;
             std::vector<std::pair<double, int32_t>> byc(nc);
+#pragma omp parallel for schedule(static)
             for (int64_t c = 0; c < nc; ++c) byc[c] = {cen[3 * c + d], (int32_t)c};
-            std::sort(byc.begin(), byc.end());
+            __gnu_parallel::sort(byc.begin(), byc.end());
+#pragma omp parallel for schedule(static)
             for (int64_t r = 0; r < nc; ++r) bucket[3 * (size_t)byc[r].second + d] = (uint32_t)((r * R) / nc);
         }
         // A bucket holds more than one cell where cells overlap in every coordinate — the six tetrahedra of a split hexahedron span the same box.  A
@@ -328,7 +330,7 @@ int build_patch_plan(tb_mesh *m, int cells_per_patch)
         }
     }
     timer.lap("buckets, keys");
-    std::sort(keyed.begin(), keyed.end());
+    __gnu_parallel::sort(keyed.begin(), keyed.end());
     timer.lap("key sort");
     // 2. patch boundaries + row ownership by first touch, in Morton order.  A patch closes after `cells_per_patch`
     //    cells or when it would own more than 9/8 of that many rows (domain-boundary patches own the extra
@@ -725,7 +727,7 @@ static int build_patch_fused_plan_impl(tb_pattern *p, int64_t *lds_need, int nre
     if (missing) { set_error("patch plan: a cell coupling is missing from the CSR pattern"); return TB_ERR_PATTERN; }
     std::vector<int32_t> order(nc);
     std::iota(order.begin(), order.end(), 0);
-    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+    __gnu_parallel::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
         if (hash[a] != hash[b]) return hash[a] < hash[b];
         const int r = memcmp(&sig[(size_t)a * NS], &sig[(size_t)b * NS], NS);
         return r != 0 ? r < 0 : a < b;
@@ -1004,15 +1006,16 @@ int ensure_vec_patch_plan(tb_mesh *m, bool halo)
                 lo[d] = std::min(lo[d], mn[d]); hi[d] = std::max(hi[d], mx[d]); hsum[d] += ext[d];
             }
         }
-#pragma omp parallel for schedule(static, 1) num_threads(3)
-        for (int d = 0; d < 3; ++d) {
+        for (int d = 0; d < 3; ++d) { // (round 6: one axis after the other, every sort on the whole team — three one-thread sorts of 10⁷ pairs took 1.0 s)
             const double hmean = hsum[d] / (double)std::max<int64_t>(nc, 1);
             int64_t R = hmean > 0 ? (int64_t)std::llround((hi[d] - lo[d]) / hmean) : 1;
             R = std::min<int64_t>(std::max<int64_t>(R, 1), 1 << 21);
             Rv[d] = R;
             std::vector<std::pair<double, int32_t>> byc(nc);
+#pragma omp parallel for schedule(static)
             for (int64_t c = 0; c < nc; ++c) byc[c] = {cen[3 * c + d], (int32_t)c};
-            std::sort(byc.begin(), byc.end());
+            __gnu_parallel::sort(byc.begin(), byc.end());
+#pragma omp parallel for schedule(static)
             for (int64_t r = 0; r < nc; ++r) bucket[3 * (size_t)byc[r].second + d] = (uint32_t)((r * R) / nc);
         }
         static const bool legacy_cut = getenv("TB_PATCH_CUT") && !strcmp(getenv("TB_PATCH_CUT"), "full");
@@ -1028,7 +1031,7 @@ int ensure_vec_patch_plan(tb_mesh *m, bool halo)
         {
             std::vector<uint64_t> keys(nc);
             for (int64_t c = 0; c < nc; ++c) keys[c] = keyed[c].first;
-            std::sort(keys.begin(), keys.end());
+            __gnu_parallel::sort(keys.begin(), keys.end());
             const int64_t ntiles = std::unique(keys.begin(), keys.end()) - keys.begin();
             const int64_t vol = (int64_t)tile[0] * tile[1] * tile[2];
             const double fill = ntiles > 0 ? (double)nc / ((double)ntiles * (double)vol) : 1.0;
@@ -1049,7 +1052,7 @@ int ensure_vec_patch_plan(tb_mesh *m, bool halo)
         if (A[0] != B[0]) return A[0] < B[0];
         return a < b;
     };
-    std::sort(keyed.begin(), keyed.end(), [&](const std::pair<uint64_t, int32_t> &a, const std::pair<uint64_t, int32_t> &b) {
+    __gnu_parallel::sort(keyed.begin(), keyed.end(), [&](const std::pair<uint64_t, int32_t> &a, const std::pair<uint64_t, int32_t> &b) {
         return a.first != b.first ? a.first < b.first : lex_less(a.second, b.second);
     });
     // patches: one per tile, cut further so that no patch exceeds 1000 cells (16-bit local node indices, LDS)
