@@ -198,6 +198,7 @@ int tb_device_defer_status(tb_device *dev, int on)
 int tb_device_poll_status(tb_device *dev)
 {
     TB_REQUIRE(dev, "tb_device_poll_status: NULL device");
+    TB_NO_CAPTURE(dev); // (before anything is enqueued: the status reset below would otherwise become a node of the capture)
     TB_HIP(hipSetDevice(dev->id));
     const int rc = tb::read_status_public(dev);
     TB_HIP(hipMemsetAsync(dev->d_status, 0, sizeof(Status), dev->stream));
