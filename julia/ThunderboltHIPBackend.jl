@@ -595,4 +595,159 @@ function cgd_rotate!(S::HIPVector{Float64})
     check(ccall((:tb_cgd_rotate, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Float64}), S.dev.handle, S.ptr))
 end
 
+# ---------------------------------------------------------------- round 6: the rest of the boundary the hot path's rows of SURVEY §8 use, bound the same way
+# (device queue and events; pattern accessors; Rush–Larsen and RTC reaction steps; the other Krylov entries; cell sets and accumulation of a form; facet
+# forms; sarcomere steps and the condensed-mechanics setters).  The host generators (tb_host_generate_grid_*, tb_host_close_dofs, tb_host_build_pattern,
+# tb_host_perturb_nodes) and the host-side evaluators (tb_host_material_eval*, tb_host_sarcomere_*) stay unbound: Ferrite and the reference's own Julia
+# routines are the host side of those.
+libtbhip_version() = unsafe_string(ccall((:tb_version, libtbhip), Cstring, ()))
+# the library's kernels on a queue the host framework owns (its own stream, or the legacy default stream) — ordering with the host's device work then needs no events
+set_stream!(dev::MI355XDevice, hip_stream::Ptr{Cvoid}) = check(ccall((:tb_device_set_stream, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), dev.handle, hip_stream))
+use_null_stream!(dev::MI355XDevice) = check(ccall((:tb_device_use_null_stream, libtbhip), Cint, (Ptr{Cvoid},), dev.handle))
+synchronize(dev::MI355XDevice) = check(ccall((:tb_device_synchronize, libtbhip), Cint, (Ptr{Cvoid},), dev.handle))
+function device_info(dev::MI355XDevice)
+    name = Vector{UInt8}(undef, 64); ncu = Ref{Cint}(0); mem = Ref{Csize_t}(0)
+    check(ccall((:tb_device_info, libtbhip), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Csize_t, Ref{Cint}, Ref{Csize_t}), dev.handle, name, length(name), ncu, mem))
+    return (name = unsafe_string(pointer(name)), n_cu = Int(ncu[]), hbm_bytes = Int(mem[]))
+end
+mutable struct HIPEvent
+    handle::Ptr{Cvoid}
+    function HIPEvent(dev::MI355XDevice)
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:tb_event_create, libtbhip), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}), dev.handle, h))
+        e = new(h[])
+        finalizer(x -> ccall((:tb_event_destroy, libtbhip), Cint, (Ptr{Cvoid},), x.handle), e)
+        return e
+    end
+end
+record!(dev::MI355XDevice, e::HIPEvent) = check(ccall((:tb_event_record, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), dev.handle, e.handle))
+function elapsed_ms(a::HIPEvent, b::HIPEvent)
+    ms = Ref{Cfloat}(0)
+    check(ccall((:tb_event_elapsed_ms, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Cfloat}), a.handle, b.handle, ms))
+    return Float64(ms[])
+end
+mesh_ncells(ddh::DeviceDofHandler) = Int(ccall((:tb_mesh_ncells, libtbhip), Int64, (Ptr{Cvoid},), ddh.mesh))
+mesh_ndofs(ddh::DeviceDofHandler) = Int(ccall((:tb_mesh_ndofs, libtbhip), Int64, (Ptr{Cvoid},), ddh.mesh))
+pattern_nnz(ddh::DeviceDofHandler) = Int(ccall((:tb_pattern_nnz, libtbhip), Int64, (Ptr{Cvoid},), ddh.pattern))
+rowptr_device(ddh::DeviceDofHandler) = ccall((:tb_pattern_rowptr_device, libtbhip), Ptr{Int64}, (Ptr{Cvoid},), ddh.pattern)      # 0-based, on the device
+colidx_device(ddh::DeviceDofHandler) = ccall((:tb_pattern_colidx_device, libtbhip), Ptr{Int32}, (Ptr{Cvoid},), ddh.pattern)
+function spmv_plan(A::HIPSparseMatrixCSR)   # (row signatures, signature entries): > 0 when the index-compressed product applies
+    o = zeros(Int64, 2)
+    check(ccall((:tb_pattern_spmv_plan, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Int64}), A.ddh.pattern, o))
+    return (o[1], o[2])
+end
+# cell models: states / parameters / index of the transmembrane potential, defaults (src/modeling/cells/*.jl)
+function cell_model_info(model::Integer)
+    ns = Ref{Cint}(0); np = Ref{Cint}(0); phi = Ref{Cint}(0)
+    check(ccall((:tb_cell_model_info, libtbhip), Cint, (Cint, Ref{Cint}, Ref{Cint}, Ref{Cint}), model, ns, np, phi))
+    return (Int(ns[]), Int(np[]), Int(phi[]) + 1)
+end
+function cell_model_defaults(model::Integer)
+    ns, np, _ = cell_model_info(model)
+    p = zeros(Float64, np); u0 = zeros(Float64, ns)
+    check(ccall((:tb_cell_model_defaults, libtbhip), Cint, (Cint, Ptr{Float64}, Ptr{Float64}), model, p, u0))
+    return p, u0
+end
+# Rush–Larsen step (gates exponentially, the rest forward Euler) and the reaction-tangent-controlled step (src/solver/time/rtc.jl:55-125); states SoA
+function reaction_step_rl!(u::HIPVector{Float64}, model::Integer, p::Vector{Float64}, npoints::Integer, nstates::Integer, t::Real, Δt::Real)
+    check(ccall((:tb_reaction_step_rl, libtbhip), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Cint, Ptr{Float64}, Int64, Cint, Cint, Cdouble, Cdouble),
+        u.dev.handle, model, p, length(p), u.ptr, npoints, nstates, 0, t, Δt))
+end
+function reaction_step_rtc!(u::HIPVector{Float64}, du, model::Integer, p::Vector{Float64}, npoints::Integer, nstates::Integer, t::Real, Δt::Real, substeps::Integer, threshold::Real)
+    rmax = Ref{Cdouble}(0)
+    check(ccall((:tb_reaction_step_rtc, libtbhip), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Cint, Ptr{Float64}, Ptr{Float64}, Int64, Cint, Cint, Cdouble, Cdouble, Cint, Cdouble, Ref{Cdouble}),
+        u.dev.handle, model, p, length(p), u.ptr, du === nothing ? Ptr{Float64}(C_NULL) : du.ptr, npoints, nstates, 0, t, Δt, substeps, threshold, rmax))
+    return rmax[]
+end
+# Krylov entries beside tb_cg_solve (euler.jl:94-100; newton_raphson.jl:61,215-320): CG started from a residual the caller holds, Chebyshev / ℓ₁-Gauss–Seidel
+# preconditioned CG (precond 1 / 2), restarted GMRES with a Jacobi preconditioner for the non-symmetric tangents
+function cg_from_residual!(x::HIPVector{Float64}, A::HIPSparseMatrixCSR{Float64}, r0::HIPVector{Float64}; rtol = 1e-5, atol = 1e-6, maxiter = 1000, jacobi = true)
+    it = Ref{Cint}(0); res = Ref{Cdouble}(0)
+    check(ccall((:tb_cg_solve_from_residual, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cdouble, Cdouble, Cint, Cint, Ref{Cint}, Ref{Cdouble}),
+        A.ddh.pattern, A.nzval.ptr, r0.ptr, x.ptr, rtol, atol, maxiter, jacobi ? 1 : 0, it, res))
+    return Int(it[]), res[]
+end
+function pcg!(x::HIPVector{Float64}, A::HIPSparseMatrixCSR{Float64}, b::HIPVector{Float64}; rtol = 1e-5, atol = 1e-6, maxiter = 1000, precond = 1, partsize = 64)
+    it = Ref{Cint}(0); res = Ref{Cdouble}(0)
+    check(ccall((:tb_pcg_solve, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cdouble, Cdouble, Cint, Cint, Cint, Ref{Cint}, Ref{Cdouble}),
+        A.ddh.pattern, A.nzval.ptr, b.ptr, x.ptr, rtol, atol, maxiter, precond, partsize, it, res))
+    return Int(it[]), res[]
+end
+function gmres!(x::HIPVector{Float64}, A::HIPSparseMatrixCSR{Float64}, b::HIPVector{Float64}; rtol = 1e-8, atol = 1e-10, maxiter = 1000, restart = 30, jacobi = true)
+    it = Ref{Cint}(0); res = Ref{Cdouble}(0)
+    check(ccall((:tb_gmres_solve, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cdouble, Cdouble, Cint, Cint, Cint, Ref{Cint}, Ref{Cdouble}),
+        A.ddh.pattern, A.nzval.ptr, b.ptr, x.ptr, rtol, atol, maxiter, restart, jacobi ? 1 : 0, it, res))
+    return Int(it[]), res[]
+end
+l1gs_apply!(z::HIPVector{Float64}, A::HIPSparseMatrixCSR{Float64}, r::HIPVector{Float64}; partsize = 64, sweep = 0) =
+    check(ccall((:tb_l1gs_apply, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cint, Cint, Ptr{Float64}, Ptr{Float64}), A.ddh.pattern, A.nzval.ptr, partsize, sweep, r.ptr, z.ptr))
+function absmax(v::HIPVector{Float64}; stride = 1)
+    r = Ref{Cdouble}(0)
+    check(ccall((:tb_absmax, libtbhip), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}, Int64, Ref{Cdouble}), v.dev.handle, v.n ÷ stride, v.ptr, stride, r))
+    return r[]
+end
+function meandiag(A::HIPSparseMatrixCSR{Float64})
+    r = Ref{Cdouble}(0)
+    check(ccall((:tb_meandiag, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ref{Cdouble}), A.ddh.pattern, A.nzval.ptr, r))
+    return r[]
+end
+# a form restricted to a cell set (OrderedSet of a SubDofHandler) and a form that adds to its output instead of overwriting it
+set_cellset!(form::Ptr{Cvoid}, cells::Vector{Int32}) = check(ccall((:tb_form_set_cellset, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Int32}, Int64, Cint), form, cells, length(cells), 1))
+clear_cellset!(form::Ptr{Cvoid}) = check(ccall((:tb_form_clear_cellset, libtbhip), Cint, (Ptr{Cvoid},), form))
+set_accumulate!(form::Ptr{Cvoid}, on::Bool) = check(ccall((:tb_form_set_accumulate, libtbhip), Cint, (Ptr{Cvoid}, Cint), form, on ? 1 : 0))
+# facet terms (src/modeling/solid/weak_boundary_conditions.jl): RobinBC / NormalSpringBC / BendingSpringBC / PressureFieldBC on a facet set
+function facet_form(ddh::DeviceDofHandler, bc_kind::Integer, param::Real, facets::Vector{Int32}; facet_qpoints = 0)
+    form = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:tb_facet_form_create, libtbhip), Cint, (Ptr{Cvoid}, Cint, Cdouble, Cint, Ptr{Int32}, Int64, Cint, Ref{Ptr{Cvoid}}),
+        ddh.mesh, bc_kind, param, facet_qpoints, facets, length(facets) ÷ 2, 1, form))
+    return form[]
+end
+facet_set_param!(form::Ptr{Cvoid}, param::Real) = check(ccall((:tb_facet_form_set_param, libtbhip), Cint, (Ptr{Cvoid}, Cdouble), form, param))
+facet_set_field!(form::Ptr{Cvoid}, field::Vector{Float64}) = check(ccall((:tb_facet_form_set_field, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64), form, field, length(field)))
+facet_assemble!(form::Ptr{Cvoid}, A::HIPSparseMatrixCSR{Float64}, u::HIPVector{Float64}, r::HIPVector{Float64}, t::Real) =
+    check(ccall((:tb_facet_assemble, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Cdouble, Ptr{Float64}, Ptr{Float64}), form, A.ddh.pattern, u.ptr, t, A.nzval.ptr, r.ptr))
+# sarcomere models (RDQ20-MF …): explicit and implicit pointwise steps (src/modeling/solid/materials.jl:1403-1640 condenses them per quadrature point)
+function sarcomere_model_info(model::Integer)
+    ns = Ref{Cint}(0); np = Ref{Cint}(0)
+    check(ccall((:tb_sarcomere_model_info, libtbhip), Cint, (Cint, Ref{Cint}, Ref{Cint}), model, ns, np))
+    return Int(ns[]), Int(np[])
+end
+function sarcomere_step!(Q::HIPVector{Float64}, model::Integer, p::Vector{Float64}, npoints::Integer, stretch::Real, velocity::Real, calcium::Real, t::Real, Δt::Real; substeps = 1)
+    check(ccall((:tb_sarcomere_step, libtbhip), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Float64}, Cint, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cint, Cint, Ptr{Float64}, Ptr{Float64}),
+        Q.dev.handle, model, p, length(p), Q.ptr, npoints, C_NULL, C_NULL, C_NULL, stretch, velocity, calcium, t, Δt, substeps, 0, C_NULL, C_NULL))
+end
+function sarcomere_implicit_step!(Q::HIPVector{Float64}, Qknown::HIPVector{Float64}, model::Integer, p::Vector{Float64}, npoints::Integer, stretch::Real, velocity::Real, calcium::Real, Δt::Real;
+                                  tol = 1e-10, max_iters = 20)
+    nf = Ref{Int64}(0)
+    check(ccall((:tb_sarcomere_implicit_step, libtbhip), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Float64}, Cint, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cdouble, Cdouble, Cdouble, Cdouble, Cdouble, Cint, Ptr{Float64}, Ptr{Float64},
+         Ptr{Int32}, Ref{Int64}),
+        Q.dev.handle, model, p, length(p), Q.ptr, Qknown.ptr, npoints, C_NULL, C_NULL, C_NULL, stretch, velocity, calcium, Δt, tol, max_iters, C_NULL, C_NULL, C_NULL, nf))
+    return Int(nf[])
+end
+# condensed internal variables and the other setters of a hyperelastic form (src/modeling/solid/elements.jl:411-630)
+set_active_tension!(form::Ptr{Cvoid}, tension::Real) = check(ccall((:tb_hyperelastic_set_active_tension, libtbhip), Cint, (Ptr{Cvoid}, Cdouble, Ptr{Float64}, Int64), form, tension, C_NULL, 0))
+set_prestress!(form::Ptr{Cvoid}, F0inv::Vector{Float64}) = check(ccall((:tb_hyperelastic_set_prestress, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Float64}), form, F0inv))
+set_condensation!(form::Ptr{Cvoid}, sarcomere_model::Integer, p::Vector{Float64}, tmax::Real; local_tol = 1e-10, local_max_iters = 20) =
+    check(ccall((:tb_hyperelastic_set_condensation, libtbhip), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Cint, Cdouble, Cdouble, Cint), form, sarcomere_model, p, length(p), tmax, local_tol, local_max_iters))
+function n_quadrature_points(form::Ptr{Cvoid})
+    n = Ref{Int64}(0)
+    check(ccall((:tb_hyperelastic_n_quadrature_points, libtbhip), Cint, (Ptr{Cvoid}, Ref{Int64}), form, n))
+    return Int(n[])
+end
+set_internal_state!(form::Ptr{Cvoid}, Q::HIPVector{Float64}, Qknown::HIPVector{Float64}, Δt::Real) =
+    check(ccall((:tb_hyperelastic_set_internal_state, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Cdouble), form, Q.ptr, Qknown.ptr, Δt))
+set_previous_solution!(form::Ptr{Cvoid}, uprev::HIPVector{Float64}) = check(ccall((:tb_hyperelastic_set_previous_solution, libtbhip), Cint, (Ptr{Cvoid}, Ptr{Float64}), form, uprev.ptr))
+function local_solve_report(form::Ptr{Cvoid})
+    nf = Ref{Int64}(0)
+    check(ccall((:tb_hyperelastic_local_solve_report, libtbhip), Cint, (Ptr{Cvoid}, Ref{Int64}, Ptr{Int32}, Int64), form, nf, C_NULL, 0))
+    return Int(nf[])
+end
+function comm_rank_size(c::HIPComm)
+    r = Ref{Cint}(0); n = Ref{Cint}(0)
+    check(ccall((:tb_comm_rank_size, libtbhip), Cint, (Ptr{Cvoid}, Ref{Cint}, Ref{Cint}), c.handle, r, n))
+    return Int(r[]), Int(n[])
+end
+
 end # module
