@@ -37,9 +37,16 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# the CPU baseline runs on all physical cores, pinned (docs/src/vroom.md:3-15 of the reference): libgomp reads these when it is first loaded
-os.environ.setdefault("OMP_PROC_BIND", "close")
-os.environ.setdefault("OMP_PLACES", "cores")
+# the CPU baseline runs on the cores the container may use, pinned (docs/src/vroom.md:3-15 of the reference): libgomp reads these when it is first loaded.
+# ONE-rank runs only (the baseline leg exists at N = 1 only): with the binding set, libgomp pins the INITIAL thread of every process to the first place of
+# its affinity mask — under a launcher all N ranks of a node would enqueue their kernels from the same core (round 6: found by reading, no 8-GPU box here;
+# at the 0.39 ms steps of the 27-layer slab eight ranks' launches on one core would sit on the clock).
+_OMP_PINNED_HERE = []
+if int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+    for _k, _v in (("OMP_PROC_BIND", "close"), ("OMP_PLACES", "cores")):
+        if _k not in os.environ:
+            os.environ[_k] = _v
+            _OMP_PINNED_HERE.append(_k)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 FP64_VECTOR_TFLOPS = 78.6      # AMD spec sheet; FP64 MFMA runs at the same rate on CDNA4
@@ -258,6 +265,8 @@ def spawn_ranks(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
            "--master-port", str(port), "--", os.path.abspath(__file__)] + sys.argv[1:]  # "--": the launcher's argparse must not read bench.py's options (--n is a prefix of several of its own)
     env = dict(os.environ)
+    for k in _OMP_PINNED_HERE:                 # the binding this process gave itself is not for its ranks (see the top of the file)
+        env.pop(k, None)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env)
 
