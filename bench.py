@@ -435,41 +435,70 @@ def main():
             self.f = tb.PointwiseODEFunction(npts, model)
             self.cache = tb.setup_solver_cache(self.f, tb.ForwardEulerCellSolver(dev), u=self.u, keep_du=args.keep_du)
             self.evpool = []
-            self.phase = {"mass": 0.0, "diffusion": 0.0, "source": 0.0, "halo": 0.0, "reaction": 0.0}   # fused: "diffusion" holds the M + K pass, "mass" stays 0
+            # phase → accumulated ms; the key order is the launch order of `step` (fused: "diffusion" holds the M + K pass, "mass" stays 0)
+            # TB_BENCH_SELF_EXCHANGE=first|late (one rank, a diagnostic): a real RCCL exchange in the step — rank 0 as its own two neighbours, one interface
+            # plane each way on the communicator's queue — posted where an N-rank step posts it (first) or in front of the reaction kernel (late)
+            self.selfx = None
+            sx_ = os.environ.get("TB_BENCH_SELF_EXCHANGE", "") if world_ == 1 else ""
+            if sx_:
+                npl_ = (nel[0] + 1) * (nel[1] + 1)
+                self.selfx = (tb.distributed.RcclComm(dev, 0, 1), [torch.zeros(npl_, dtype=torch.float64, device="cuda") for _ in range(2)],
+                              [torch.empty(npl_, dtype=torch.float64, device="cuda") for _ in range(2)])
+            order = ("mass", "diffusion", "source", "halo", "reaction") if world_ == 1 and sx_ != "first" else ("source", "halo", "mass", "diffusion", "reaction")
+            self.phase = {k_: 0.0 for k_ in order}
 
         def step(self, i, ev=None):
             """one step; ev: six HIP events of THIS step (phase boundaries), read only after the timed region's synchronize — reading them here
             would wait for the GPU every step, and the host's enqueue time of the next step would sit on the clock (it did through round 4:
-            the same step replayed as a graph was 4–6 % faster, most of it this wait)"""
+            the same step replayed as a graph was 4–6 % faster, most of it this wait).
+            The three forms are independent, so the order of their launches is free.  One rank: M + K, b, reaction.  N > 1: b FIRST, its interface
+            entries packed and the exchange posted, then M + K and the reaction step, then the received partials added — the transfer needs a few
+            workgroups of its own on this GPU, and beside the fused matrix pass (thousands of 11 µs workgroups) it finds them at once, where the
+            reaction kernel of a thin slab is ONE generation of resident workgroups that hold every register file until the kernel ends
+            (--no-overlap-exchange: b, exchange, M + K, reaction).  "halo" = pack + post (+ the whole exchange without overlap); "reaction" then
+            includes the wait and the unpack."""
             t = 0.01 * i
             allev = ev is not None and args.phase_events == "all"
             mev = ev is not None and args.phase_events != "none"
-            if mev and (allev or not fused): ev[0].record()
-            if not fused:
-                tb.update_operator(self.M, t)
-            if mev: ev[1].record()
-            if fused:
-                tb.update_operators(self.M, self.K, t)
-            else:
-                tb.update_operator(self.K, t)
-            if i == 0:
-                self.matrix_kernel = tb.lib().tb_last_kernel_name().decode()   # the instance this call launched (the roofline's kernel)
-            if mev: ev[2].record()
-            tb.update_operator(self.src, t)
-            if allev: ev[3].record()
-            # the halo sum of b and the reaction step touch disjoint data: the exchange is posted (pack + isend / irecv) in front of the reaction kernel and
-            # its partials are added behind it, so the transfer runs beside the kernel (--no-overlap-exchange: exchange, then reaction).
-            # "halo" = pack + post (+ the whole exchange without overlap); "reaction" then includes the wait and the unpack.
-            if self.world > 1:
-                if args.no_overlap_exchange:
-                    self.halo.exchange_sum(self.b)
+
+            def mass():
+                if not fused:
+                    tb.update_operator(self.M, t)
+
+            def matrix():
+                if fused:
+                    tb.update_operators(self.M, self.K, t)
                 else:
-                    self.halo.pack(self.b); self.halo.start()
-            if allev: ev[4].record()
-            tb.perform_step(self.f, self.cache, t, rdt)
-            if self.world > 1 and not args.no_overlap_exchange:
-                self.halo.finish(self.b)
-            if allev: ev[5].record()
+                    tb.update_operator(self.K, t)
+                if i == 0:
+                    self.matrix_kernel = tb.lib().tb_last_kernel_name().decode()   # the instance this call launched (the roofline's kernel)
+
+            def source():
+                tb.update_operator(self.src, t)
+
+            def halo():
+                if self.selfx:
+                    self.selfx[0].exchange([0, 0], self.selfx[1], self.selfx[2], overlapped=True)
+                if self.world > 1:
+                    if args.no_overlap_exchange:
+                        self.halo.exchange_sum(self.b)
+                    else:
+                        self.halo.pack(self.b); self.halo.start()
+
+            def reaction():
+                tb.perform_step(self.f, self.cache, t, rdt)
+                if self.selfx:
+                    self.selfx[0].exchange_end()
+                if self.world > 1 and not args.no_overlap_exchange:
+                    self.halo.finish(self.b)
+
+            run = {"mass": mass, "diffusion": matrix, "source": source, "halo": halo, "reaction": reaction}
+            names = list(self.phase)                                   # the order of the launches = the order of the keys (set in __init__ by the world size)
+            is_matrix = [n == "diffusion" or (n == "mass" and not fused) for n in names]
+            for k, name in enumerate(names):
+                if allev or (mev and (is_matrix[k] or (k > 0 and is_matrix[k - 1]))): ev[k].record()
+                run[name]()
+            if allev or (mev and is_matrix[-1]): ev[len(names)].record()
 
         def step_plain(self, t):
             """the calls of `step` without the phase events (what a captured step replays; one rank, no halo exchange)"""
@@ -597,7 +626,7 @@ def main():
             dev.defer_status(False)
             for i in range(steps):                                   # phase durations of the timed steps (the events are complete: no wait)
                 for k, name in enumerate(self.phase):
-                    recorded = args.phase_events == "all" or (args.phase_events == "matrix" and (k == 1 or (k == 0 and not fused)))
+                    recorded = args.phase_events == "all" or (args.phase_events == "matrix" and (name == "diffusion" or (name == "mass" and not fused)))
                     self.phase[name] += self.evpool[i][k].elapsed_ms(self.evpool[i][k + 1]) if recorded else float("nan")
             return dt_
 
