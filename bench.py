@@ -67,9 +67,12 @@ def parse():
     ap.add_argument("--n", type=int, default=216, help="cells per edge of the box (216 → 10M hexahedra)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong = the same n³ mesh cut into N z-slabs (BASELINE's configuration); weak = one n³ slab per rank")
-    ap.add_argument("--exchange", default="torch", choices=["torch", "abi"],
+    ap.add_argument("--exchange", default="auto", choices=["auto", "torch", "abi"],
                     help="N > 1 data path: torch = torch.distributed over RCCL (batch_isend_irecv / all_reduce); abi = RCCL behind the C ABI (tb_comm_exchange / "
-                         "tb_comm_allreduce, what a Julia host would call) — torch.distributed then only carries the communicator id and the timing barrier")
+                         "tb_comm_allreduce, what a Julia host would call) in the device's own queue — torch.distributed then only carries the communicator id and "
+                         "the timing barrier; auto (default) = abi where every rank can create the communicator, else torch.  Measured on one GPU with rank 0 as its own "
+                         "two neighbours (profiles/r06_v1/ab_exchange_paths_of_the_n_rank_step.log, 27 layers): a step costs +0.028 ms through the C ABI, +0.075 ms "
+                         "through torch.distributed (its fork to and join from c10d's queue)")
     ap.add_argument("--mesh", default="box", choices=["box", "shuffled", "lv"],
                     help="N = 1: box = the lexicographic n^3 box (BASELINE's configuration); shuffled = the SAME box with its cells and nodes randomly renumbered (same bytes, "
                          "no row / scatter signatures to share: an unstructured presentation); lv = the idealised left ventricle (O-grid apex, curved thin wall) at --lv-dims")
@@ -342,8 +345,26 @@ def main():
     fused = args.strategy == "patch" and not args.separate
     gd = dist if dist.is_initialized() else None
     xd = gd                                                          # what the halo exchange and the CG reductions go through
-    if gd is not None and args.exchange == "abi" and not share:
-        xd = tb.distributed.RcclComm.from_torch(dev, dist)
+    if gd is not None and args.exchange in ("auto", "abi") and not share:
+        # every rank tries, the ranks agree (min over ranks), one path for all: a rank that cannot create the communicator must not leave the others in
+        # a grouped send / receive nobody answers
+        xa_, why_ = None, ""
+        try:
+            xa_ = tb.distributed.RcclComm.from_torch(dev, dist)
+        except Exception as ex:
+            why_ = str(ex)[:300]
+        ok_ = torch.tensor([1 if xa_ is not None else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(ok_, op=dist.ReduceOp.MIN)
+        if int(ok_.item()) == 1:
+            xd = xa_
+        else:
+            if xa_ is not None:
+                xa_.close()
+            if args.exchange == "abi":
+                sys.stderr.write("bench.py: --exchange abi: the communicator of the C ABI could not be created on every rank (%s)\n" % (why_ or "another rank failed"))
+                return 2
+            if rank == 0:
+                sys.stderr.write("bench.py: --exchange auto: no communicator behind the C ABI (%s): torch.distributed carries the exchange\n" % (why_ or "another rank failed"))
     host_red = "cpu" if share else "cuda"
 
     # unstructured presentations: every rank builds the whole mesh (host-side generators), bisects the cell centroids into `world` parts of equal size
@@ -420,6 +441,25 @@ def main():
             self.nbrs = nbrs
             # the one data-path exchange: persistent send / receive buffers, pack and unpack through the C ABI (tb_gather_indexed / tb_scatter_add_indexed)
             self.halo = tb.distributed.HaloExchange(nbrs, self.xdist, self.b, dev)
+            # TB_BENCH_SELF_EXCHANGE=torch|abi|abi-overlap (one rank, a diagnostic): the N-rank step as it is — pack, exchange, unpack-add through HaloExchange, rank 0
+            # as its own lower and upper neighbour (bottom and top node plane) — over torch.distributed (RCCL at world size 1), or the C ABI's communicator
+            # in the device's queue / on its own queue.  b is summed with itself on the two planes: timings only.
+            self.selfhalo = False
+            sh_ = os.environ.get("TB_BENCH_SELF_EXCHANGE", "") if world_ == 1 and args.mesh == "box" else ""
+            if sh_ in ("torch", "abi", "abi-overlap"):
+                n2d = tb.distributed.node_to_dof(dh)
+                npl_ = (nel[0] + 1) * (nel[1] + 1)
+                planes = [torch.from_numpy(n2d[np.arange(npl_)]).cuda(), torch.from_numpy(n2d[np.arange(g.n_nodes - npl_, g.n_nodes)]).cuda()]
+                if sh_ == "torch":
+                    import torch.distributed as d1_
+                    if not d1_.is_initialized():
+                        d1_.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % (29500 + os.getpid() % 2000), rank=0, world_size=1)
+                    xd1_ = d1_
+                else:
+                    xd1_ = tb.distributed.RcclComm(dev, 0, 1)
+                self.halo = tb.distributed.HaloExchange([(0, planes[0]), (0, planes[1])], xd1_, self.b, dev)
+                self.halo.overlap = sh_ == "abi-overlap"
+                self.selfhalo = True
             self.model = model = {"pcg2019": tb.PCG2019, "tt06": tb.TT06, "fhn": tb.FHNModel, "ord": tb.ORd2011}[args.ionic]()
             self.ns = model.nstates
             self.npts = npts = dh.ndofs
@@ -440,11 +480,12 @@ def main():
             # plane each way on the communicator's queue — posted where an N-rank step posts it (first) or in front of the reaction kernel (late)
             self.selfx = None
             sx_ = os.environ.get("TB_BENCH_SELF_EXCHANGE", "") if world_ == 1 else ""
-            if sx_:
+            if sx_ in ("first", "late"):
                 npl_ = (nel[0] + 1) * (nel[1] + 1)
                 self.selfx = (tb.distributed.RcclComm(dev, 0, 1), [torch.zeros(npl_, dtype=torch.float64, device="cuda") for _ in range(2)],
                               [torch.empty(npl_, dtype=torch.float64, device="cuda") for _ in range(2)])
-            order = ("mass", "diffusion", "source", "halo", "reaction") if world_ == 1 and sx_ != "first" else ("source", "halo", "mass", "diffusion", "reaction")
+            one_rank_order = world_ == 1 and sx_ != "first" and not self.selfhalo
+            order = ("mass", "diffusion", "source", "halo", "reaction") if one_rank_order else ("source", "halo", "mass", "diffusion", "reaction")
             self.phase = {k_: 0.0 for k_ in order}
 
         def step(self, i, ev=None):
@@ -479,7 +520,7 @@ def main():
             def halo():
                 if self.selfx:
                     self.selfx[0].exchange([0, 0], self.selfx[1], self.selfx[2], overlapped=True)
-                if self.world > 1:
+                if self.world > 1 or self.selfhalo:
                     if args.no_overlap_exchange:
                         self.halo.exchange_sum(self.b)
                     else:
@@ -489,7 +530,7 @@ def main():
                 tb.perform_step(self.f, self.cache, t, rdt)
                 if self.selfx:
                     self.selfx[0].exchange_end()
-                if self.world > 1 and not args.no_overlap_exchange:
+                if (self.world > 1 or self.selfhalo) and not args.no_overlap_exchange:
                     self.halo.finish(self.b)
 
             run = {"mass": mass, "diffusion": matrix, "source": source, "halo": halo, "reaction": reaction}
@@ -614,6 +655,7 @@ def main():
             t0 = time.perf_counter()
             for i in range(steps):
                 self.step(warmup + i, self.evpool[i])
+            self.host_enqueue_ms = (time.perf_counter() - t0) / steps * 1e3    # what the host needs to enqueue a step (≥ ms_per_step: the host is the limiter)
             torch.cuda.synchronize()
             gc.enable()
             dev.poll_status()
@@ -716,6 +758,18 @@ def main():
     pr = Problem(part.local_nel(), part.left, part.right, rank, world, part.interface_nodes(), gd, xd)
     g, dh, sp, npts, ns = pr.g, pr.dh, pr.sp, pr.npts, pr.ns
     t_setup1 = time.perf_counter()
+    if world > 1:
+        # the exchange carries what it should before anything is timed through it: every rank sends rank + 1 on its shared dofs and must hold
+        # rank + 1 + Σ (peer + 1) over the parts it shares each dof with — exactly (small integers), on whichever path was chosen above
+        v_ = torch.full((npts,), float(rank + 1), dtype=torch.float64, device="cuda")
+        e_ = v_.clone()
+        for peer_, idx_ in pr.nbrs:
+            e_[idx_] += float(peer_ + 1)
+        pr.halo.exchange_sum(v_)
+        torch.cuda.synchronize()
+        if not torch.equal(v_, e_):
+            raise RuntimeError("bench.py: rank %d: the halo exchange returned wrong sums on %d of its dofs" % (rank, int((v_ != e_).sum())))
+        del v_, e_
     pr.step(0)                                   # first assembly: the plans (patches, signatures, one-trip records) are built here
     torch.cuda.synchronize()
     t_setup2 = time.perf_counter()
@@ -852,7 +906,7 @@ def main():
         out = {
             "metric": "element-integrations/sec + DoF-updates/sec, 10M-hex Q1 monodomain",
             "value": 3 * cells_total * K_ / elapsed, "unit": "element-integrations/s",
-            "n_gpus": world, "steps": K_, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "n_gpus": world, "steps": K_, "warmup": args.warmup, "ms_per_step": ms, "host_enqueue_ms_per_step": getattr(pr, "host_enqueue_ms", None), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "monodomain hot path on %s: assemble M + K (%s scatter, %s) + b (patch-reduced sums, 1.4 global atomics per cell)%s + %s forward-Euler reaction step"
                                    % ({"box": "the %dx%dx%d hex Q1 mesh (%d cells) in %d z-slab(s) of %d layers" % (n, n, nz_total, cells_total, world, part.nzl),

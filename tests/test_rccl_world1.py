@@ -55,7 +55,7 @@ def test_rccl_behind_the_c_abi_world_size_one():
     assert d["cg_product_err"] < 1e-13 and d["cg_steps_finite_and_flag_clear"]
 
 
-@pytest.mark.parametrize("exchange,backend", [("torch", "nccl (RCCL)"), ("abi", "RCCL behind the C ABI (tb_comm_*)")])
+@pytest.mark.parametrize("exchange,backend", [("torch", "nccl (RCCL)"), ("abi", "RCCL behind the C ABI (tb_comm_*)"), ("auto", "RCCL behind the C ABI (tb_comm_*)")])
 def test_bench_under_launcher_initialises_rccl_at_world_size_one(exchange, backend):
     """bench.py under the launcher at world size 1: process group, barrier, max-reduced timings; with --exchange abi the communicator of the C ABI is created
     from the id that torch.distributed broadcasts, and the CG reductions / halo exchange go through tb_comm_*."""

@@ -124,8 +124,15 @@ class RcclComm:
     def from_torch(cls, device, dist):
         """communicator over the ranks of the default torch.distributed group: rank 0 makes the id, the group broadcasts it"""
         rank, world = dist.get_rank(), dist.get_world_size()
-        box = [RcclComm.unique_id() if rank == 0 else None]
+        box = [None]
+        if rank == 0:                                                # a failure on rank 0 travels with the broadcast: every rank raises, none waits
+            try:
+                box[0] = RcclComm.unique_id()
+            except Exception as ex:
+                box[0] = "RcclComm.unique_id on rank 0: %s" % ex
         dist.broadcast_object_list(box, src=0)
+        if not isinstance(box[0], (bytes, bytearray)):
+            raise RuntimeError(str(box[0]))
         return cls(device, rank, world, box[0])
 
     def exchange(self, peers, send, recv, overlapped=False):
