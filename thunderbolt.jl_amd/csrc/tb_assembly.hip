@@ -991,6 +991,9 @@ k_matrix_q2(MeshView m, FormArgs fa, const double *__restrict__ cell_xyz, const 
 // to three waves per SIMD spilled 200 B and took 1.19 ms; a wave-per-cell form without workgroup barriers (81 tasks in two rounds of 64 lanes,
 // geometry on 27 lanes) 0.85 ms — the half-empty second rounds cost more than the barriers.  Same sums as mass.jl:28-43 / diffusion.jl:28-50 in
 // another order (≲ 1e-15 relative); no symmetry assumed, so non-symmetric constant tensors need no variant of their own.
+// (Round 6: the element matrices of a triple sent through LDS and stored as one run of 3 × 729 doubles — every wave store 512 contiguous bytes instead of
+// seven 72-byte pieces — was built and measured at 64³: mass 1.02 against 1.04 ms, diffusion 1.29 against 1.22 ms for integration + gather: the stores were
+// not what the diffusion kernel waits for, the extra barrier and 17 KB of LDS traffic per pass cost more.  Removed; profiles/r06_v1/ab_q2_element_matrices_through_lds.log.)
 template <int FORM, bool FIELD>
 __global__ void __launch_bounds__(256, 2)
 k_matrix_q2_sf(MeshView m, FormArgs fa, const double *__restrict__ cell_xyz, const int32_t *__restrict__ list, int64_t cell0, int64_t n_list, const int64_t *__restrict__ rowptr,
