@@ -350,6 +350,8 @@ def main():
         # a grouped send / receive nobody answers
         xa_, why_ = None, ""
         try:
+            if os.environ.get("TB_BENCH_NO_ABI_COMM"):               # (tests: the fall-back branch below)
+                raise RuntimeError("TB_BENCH_NO_ABI_COMM is set")
             xa_ = tb.distributed.RcclComm.from_torch(dev, dist)
         except Exception as ex:
             why_ = str(ex)[:300]

@@ -23,8 +23,8 @@ def _free_port():
     return p
 
 
-def _torchrun(script_args, timeout=900):
-    env = dict(os.environ)
+def _torchrun(script_args, timeout=900, env=None):
+    env = dict(os.environ if env is None else env)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), "--"] + script_args
@@ -64,3 +64,15 @@ def test_bench_under_launcher_initialises_rccl_at_world_size_one(exchange, backe
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-3000:], r.stderr[-3000:])
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["config"]["backend"] == backend and d["value"] > 0 and d["cg_iterations_per_s"] > 0
+
+
+def test_bench_exchange_auto_falls_back_to_torch_distributed_when_no_rank_can_create_the_communicator():
+    """--exchange auto: a rank that cannot create the C ABI's communicator votes 0, the minimum over the ranks decides, torch.distributed carries the data"""
+    env = dict(os.environ, TB_BENCH_NO_ABI_COMM="1")
+    r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--n", "24", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-slab-sweep"], env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-3000:], r.stderr[-3000:])
+    d = json.loads(lines[0])
+    assert d["config"]["backend"] == "nccl (RCCL)" and "torch.distributed carries the exchange" in r.stderr
+    r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--n", "24", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-slab-sweep", "--exchange", "abi"], env=env)
+    assert r.returncode != 0 and "could not be created on every rank" in r.stderr
