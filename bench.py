@@ -96,8 +96,11 @@ def parse():
                     help="untimed GPU work (the loop's own steps) in front of the W warm-up steps of every timed loop, so that the clock reads steady-state "
                          "throughput: after an idle period (plan building, a host-side pause) the GPU's power management takes ~10 steps of 3 ms to return to full "
                          "clocks (profiles/r05_v1/clock_ramp_trace.txt: 2.33 -> 1.65 ms for the same kernel); 0 switches it off")
-    ap.add_argument("--phase-events", choices=("all", "matrix", "none"), default="all",
-                    help="HIP events recorded inside the timed steps: all six phase boundaries, only the two around the matrix pass, or none (diagnostic: what the instrumentation costs)")
+    ap.add_argument("--phase-events", choices=("auto", "all", "matrix", "none"), default="auto",
+                    help="HIP events recorded inside the timed steps: all six phase boundaries, only the two around the matrix pass (the roofline's kernel), or none "
+                         "(diagnostic).  auto = all on one rank, matrix on N ranks, where the other phases are read from a second, instrumented pass of K steps behind "
+                         "the timed region: six event records cost a 27-layer step 12 us of its 0.38 ms (profiles/r06_v1/ab_phase_event_cost.log), nothing "
+                         "measurable of the whole box's 2.6 ms")
     ap.add_argument("--no-graph", action="store_true", help="N = 1: skip the HIP-graph forms of the step and of the CG iteration (tb_graph_*)")
     ap.add_argument("--no-dist-cg", action="store_true", help="skip the (untimed-region) distributed CG iteration measurement")
     ap.add_argument("--cpu-n", type=int, default=64, help="edge of the CPU-baseline sample mesh")
@@ -486,6 +489,7 @@ def main():
                 npl_ = (nel[0] + 1) * (nel[1] + 1)
                 self.selfx = (tb.distributed.RcclComm(dev, 0, 1), [torch.zeros(npl_, dtype=torch.float64, device="cuda") for _ in range(2)],
                               [torch.empty(npl_, dtype=torch.float64, device="cuda") for _ in range(2)])
+            self.pe_mode = args.phase_events if args.phase_events != "auto" else ("all" if world_ == 1 else "matrix")
             one_rank_order = world_ == 1 and sx_ != "first" and not self.selfhalo
             order = ("mass", "diffusion", "source", "halo", "reaction") if one_rank_order else ("source", "halo", "mass", "diffusion", "reaction")
             self.phase = {k_: 0.0 for k_ in order}
@@ -501,8 +505,8 @@ def main():
             (--no-overlap-exchange: b, exchange, M + K, reaction).  "halo" = pack + post (+ the whole exchange without overlap); "reaction" then
             includes the wait and the unpack."""
             t = 0.01 * i
-            allev = ev is not None and args.phase_events == "all"
-            mev = ev is not None and args.phase_events != "none"
+            allev = ev is not None and self.pe_mode == "all"
+            mev = ev is not None and self.pe_mode != "none"
 
             def mass():
                 if not fused:
@@ -670,9 +674,33 @@ def main():
             dev.defer_status(False)
             for i in range(steps):                                   # phase durations of the timed steps (the events are complete: no wait)
                 for k, name in enumerate(self.phase):
-                    recorded = args.phase_events == "all" or (args.phase_events == "matrix" and (name == "diffusion" or (name == "mass" and not fused)))
+                    recorded = self.pe_mode == "all" or (self.pe_mode == "matrix" and (name == "diffusion" or (name == "mass" and not fused)))
                     self.phase[name] += self.evpool[i][k].elapsed_ms(self.evpool[i][k + 1]) if recorded else float("nan")
             return dt_
+
+        def instrumented_phases(self, steps):
+            """K more steps with all six phase events, outside the timed region (every rank: a step holds an exchange): the phases the timed steps did not
+            record (--phase-events auto on N ranks).  Returns {phase: summed ms}; the matrix phase of the line stays the timed region's."""
+            keep, self.pe_mode = self.pe_mode, "all"
+            try:
+                while len(self.evpool) < steps:
+                    self.evpool.append([dev.event() for _ in range(6)])
+                dev.defer_status(True)
+                for i in range(3):
+                    self.step(i)
+                self.sync()
+                for i in range(steps):
+                    self.step(i, self.evpool[i])
+                torch.cuda.synchronize()
+                dev.defer_status(False)
+                dev.poll_status()
+                out_ = {name: 0.0 for name in self.phase}
+                for i in range(steps):
+                    for k, name in enumerate(self.phase):
+                        out_[name] += self.evpool[i][k].elapsed_ms(self.evpool[i][k + 1])
+            finally:
+                self.pe_mode = keep
+            return out_
 
         def time_cg(self, nit=10):
             """What a time step adds to the assembly under a partition — one iteration of the distributed Jacobi-CG on the heat matrix A = M − Δt·K of
@@ -777,6 +805,14 @@ def main():
     t_setup2 = time.perf_counter()
     elapsed = pr.time_steps(args.warmup, args.steps)
     phase = pr.phase
+    phase_note = None
+    if pr.pe_mode == "matrix" and args.phase_events == "auto":
+        inst_ = pr.instrumented_phases(args.steps)
+        for k_ in phase:
+            if phase[k_] != phase[k_]:                    # not recorded in the timed steps
+                phase[k_] = inst_[k_]
+        phase_note = ("the timed steps record the two events around the matrix pass only; source / halo / reaction are from a second pass of %d steps with all six "
+                      "events, behind the timed region (its matrix phase: %.4f ms)" % (args.steps, inst_["diffusion"] / args.steps))
 
     def graph_step_ms(prob):
         """(ms per step, nodes, error) of the step as one HIP-graph launch; never fatal"""
@@ -931,6 +967,7 @@ def main():
             "pin": FERRITE_PIN,
             **({"checksums": chk} if chk is not None else {}),
             "phase_ms": ({"mass+diffusion": k_ms} if fused else {"mass": phase["mass"] / K_, "diffusion": k_ms}) | {k: phase[k] / K_ for k in ("source", "halo", "reaction")},
+            **({"phase_ms_note": phase_note} if phase_note else {}),
             "phase_rates": {"matrix_integrations_per_s": 2 * g.n_cells / (mk_ms * 1e-3),
                             "source_cells_per_s": g.n_cells / (phase["source"] / K_ * 1e-3),
                             "reaction_dof_updates_per_s": ns * npts / (phase["reaction"] / K_ * 1e-3)},
