@@ -262,6 +262,20 @@ def test_bench_unstructured_meshes_under_the_bisection_partition_match_one_rank(
         assert abs(two["checksums"][k] - v) <= 1e-10 * abs(v), (k, v, two["checksums"][k])
 
 
+def test_bench_three_slabs_merged_pack_and_unpack_equal_one_call_per_neighbour():
+    """Three z-slabs of the box: the middle rank has two neighbours whose index lists (its bottom and top node plane) share no dof, so HaloExchange fills
+    both send buffers with ONE tb_gather_indexed and adds both receive buffers with ONE tb_scatter_add_indexed (slices of one allocation each).  The run
+    leaves the sums of the run that makes one call per neighbour (1e-13) (TB_HALO_SEPARATE_CALLS): the same two numbers are added on every shared dof.
+    (Not compared with one rank: every slab of the box perturbs its own interior nodes — tb_host_perturb_nodes keeps a mesh's boundary planes — so the
+    union of the slabs is a conforming mesh of the same box, not the one-rank mesh; the meshes that ARE the same under every partition are tested above.)"""
+    common = ["--gpus", "3", "--n", "24", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-graph", "--no-slab-sweep", "--no-dist-cg", "--checksums", "--preroll-ms", "0"]
+    merged = _bench_line(common, env={"TB_BENCH_SHARE_DEVICE": "1"})
+    separate = _bench_line(common, env={"TB_BENCH_SHARE_DEVICE": "1", "TB_HALO_SEPARATE_CALLS": "1"})
+    assert merged["n_gpus"] == 3 and merged["config"]["layers_per_gpu"] == 8 and merged["phase_ms"]["halo"] > 0.0
+    for k, v in separate["checksums"].items():          # (LDS and global atomics order their adds run by run: the last bits of K and b are not reproducible)
+        assert abs(merged["checksums"][k] - v) <= 1e-13 * abs(v), (k, v, merged["checksums"][k])
+
+
 def test_electromechanics_step_under_the_bisection_partition_matches_one_rank():
     """BASELINE configs[4] (coupled electromechanics on the ventricle, 8 GPUs) as scripts/bench_electromechanics.py --gpus N runs it: the EP operators,
     the ionic step, the distributed heat solve and the mechanics residual / tangent of every part, neighbour sums of the vectors.  Two ranks on one

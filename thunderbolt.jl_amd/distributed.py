@@ -236,6 +236,23 @@ class HaloExchange:
             if self.staged:
                 self.send_h.append(torch.empty(idx.numel(), dtype=like.dtype).pin_memory())
                 self.recv_h.append(torch.empty(idx.numel(), dtype=like.dtype).pin_memory())
+        # several neighbours whose index lists share no dof (the two planes of a slab): ONE gather fills every send buffer and ONE scatter-add takes every
+        # receive buffer — the buffers become slices of one allocation each.  A 47 000-entry gather is all launch: 4–6 µs of the queue per call, and a step
+        # of a thin slab is 0.4 ms (profiles/r06_v1/slab27_self_exchange_timeline_abi.txt).  Lists that share dofs (a corner of a general partition) keep
+        # one call per neighbour: tb_scatter_add_indexed wants distinct indices within a call.
+        self.cat_idx32 = None
+        import os
+        if self.cuda and len(self.peers) > 1 and not os.environ.get("TB_HALO_SEPARATE_CALLS"):     # (the switch: tests compare the two forms)
+            cat = torch.cat(self.idx)
+            if torch.unique(cat).numel() == cat.numel():
+                self.cat_idx32 = cat.to(torch.int32).contiguous()
+                self.cat_send = torch.empty(cat.numel(), dtype=like.dtype, device=like.device)
+                self.cat_recv = torch.empty(cat.numel(), dtype=like.dtype, device=like.device)
+                off = 0
+                for k, idx in enumerate(self.idx):
+                    self.send[k] = self.cat_send[off:off + idx.numel()]
+                    self.recv[k] = self.cat_recv[off:off + idx.numel()]
+                    off += idx.numel()
         self.reqs = []
 
     @property
@@ -250,6 +267,9 @@ class HaloExchange:
         """send buffers ← the partial values of the shared dofs"""
         if self.cuda:
             from ._lib import check, lib
+            if self.cat_idx32 is not None:
+                check(lib().tb_gather_indexed(self.dev.h, self.cat_idx32.numel(), self._ptr(vec), self._ptr(self.cat_idx32), self._ptr(self.cat_send)))
+                return
             for idx32, send in zip(self.idx32, self.send):
                 check(lib().tb_gather_indexed(self.dev.h, idx32.numel(), self._ptr(vec), self._ptr(idx32), self._ptr(send)))
         else:
@@ -304,6 +324,9 @@ class HaloExchange:
                     vec[idx] = send
         if self.cuda:
             from ._lib import check, lib
+            if self.cat_idx32 is not None:
+                check(lib().tb_scatter_add_indexed(self.dev.h, self.cat_idx32.numel(), self._ptr(self.cat_recv), self._ptr(self.cat_idx32), self._ptr(vec)))
+                return vec
             for idx32, recv in zip(self.idx32, self.recv):
                 check(lib().tb_scatter_add_indexed(self.dev.h, idx32.numel(), self._ptr(recv), self._ptr(idx32), self._ptr(vec)))
         else:
