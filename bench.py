@@ -398,7 +398,21 @@ def main():
         def __init__(self, nel, left, right, rank_, world_, lo_up, dist_, xdist_=None):
             self.world, self.rank, self.dist = world_, rank_, dist_     # dist: barrier / max over ranks of the timings (torch.distributed)
             self.xdist = xdist_ if xdist_ is not None else dist_        # xdist: halo exchange and CG reductions (torch.distributed or RcclComm)
-            if args.mesh == "box":
+            if args.mesh == "box" and world_ > 1:
+                # the slab of the WHOLE box's perturbed mesh: tb_host_perturb_nodes displaces the nodes of the lattice it is given and keeps that lattice's
+                # boundary planes, so a slab perturbed on its own is a conforming piece of another mesh.  The same displacement by GLOBAL layer index here:
+                # the union of the N slabs is the one-rank mesh (tests: N ranks leave the one-rank sums), interface planes included
+                self.g = g = tb.generate_mesh(tb.Hexahedron, nel, left, right, perturb=0.0)
+                px_, py_, pz_ = nel[0] + 1, nel[1] + 1, nel[2] + 1
+                X_ = g.xyz.reshape(pz_, py_, px_, 3)
+                h_ = [(X_[-1, -1, -1, d_] - X_[0, 0, 0, d_]) / nel[d_] for d_ in range(3)]
+                twopi_ = 6.283185307179586
+                s_ = (np.sin(twopi_ * (np.arange(pz_) + part.z0) / nz_total)[:, None, None] * np.sin(twopi_ * np.arange(py_) / nel[1])[None, :, None]
+                      * np.sin(twopi_ * np.arange(px_) / nel[0])[None, None, :])
+                X_[..., 0] += 0.2 * h_[0] * s_
+                X_[..., 1] -= 0.5 * 0.2 * h_[1] * s_
+                X_[..., 2] += 0.75 * 0.2 * h_[2] * s_
+            elif args.mesh == "box":
                 self.g = g = tb.generate_mesh(tb.Hexahedron, nel, left, right, perturb=0.2)
             elif gpart is not None:            # this rank's part of the bisected mesh, nodes numbered by first visit
                 self.g = g = tb.Grid(full_grid.cell_kind, full_grid.xyz[gpart.global_nodes], gpart.conn)

@@ -266,14 +266,26 @@ def test_bench_three_slabs_merged_pack_and_unpack_equal_one_call_per_neighbour()
     """Three z-slabs of the box: the middle rank has two neighbours whose index lists (its bottom and top node plane) share no dof, so HaloExchange fills
     both send buffers with ONE tb_gather_indexed and adds both receive buffers with ONE tb_scatter_add_indexed (slices of one allocation each).  The run
     leaves the sums of the run that makes one call per neighbour (1e-13) (TB_HALO_SEPARATE_CALLS): the same two numbers are added on every shared dof.
-    (Not compared with one rank: every slab of the box perturbs its own interior nodes — tb_host_perturb_nodes keeps a mesh's boundary planes — so the
-    union of the slabs is a conforming mesh of the same box, not the one-rank mesh; the meshes that ARE the same under every partition are tested above.)"""
+    (The comparison with one rank is the next test.)"""
     common = ["--gpus", "3", "--n", "24", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-graph", "--no-slab-sweep", "--no-dist-cg", "--checksums", "--preroll-ms", "0"]
     merged = _bench_line(common, env={"TB_BENCH_SHARE_DEVICE": "1"})
     separate = _bench_line(common, env={"TB_BENCH_SHARE_DEVICE": "1", "TB_HALO_SEPARATE_CALLS": "1"})
     assert merged["n_gpus"] == 3 and merged["config"]["layers_per_gpu"] == 8 and merged["phase_ms"]["halo"] > 0.0
     for k, v in separate["checksums"].items():          # (LDS and global atomics order their adds run by run: the last bits of K and b are not reproducible)
         assert abs(merged["checksums"][k] - v) <= 1e-13 * abs(v), (k, v, merged["checksums"][k])
+
+
+def test_bench_three_slabs_of_the_box_leave_the_one_rank_sums():
+    """BASELINE configs[2] at N > 1 is the SAME box in N z-slabs: every rank displaces its nodes by the whole box's perturbation (global layer index), so
+    the union of the slabs is the one-rank mesh, and the sums that do not depend on the initial state — ψᵀMψ, ψᵀKψ, Σ w b², Σ w bψ (b summed over the
+    interfaces by the step's own exchange) — equal the one-rank run's to 1e-10 (P-GPU result == 1-GPU result)."""
+    common = ["--n", "24", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-graph", "--no-slab-sweep", "--no-dist-cg", "--checksums", "--preroll-ms", "0"]
+    one = _bench_line(["--gpus", "1"] + common)
+    three = _bench_line(["--gpus", "3"] + common, env={"TB_BENCH_SHARE_DEVICE": "1"})
+    assert three["n_gpus"] == 3 and three["config"]["layers_per_gpu"] == 8 and three["phase_ms"]["halo"] > 0.0
+    for k in ("psi_M_psi", "psi_K_psi", "b_b", "b_psi"):
+        v = one["checksums"][k]
+        assert abs(three["checksums"][k] - v) <= 1e-10 * abs(v), (k, v, three["checksums"][k])
 
 
 def test_electromechanics_step_under_the_bisection_partition_matches_one_rank():
