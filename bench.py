@@ -912,8 +912,8 @@ def main():
             # with the exchange a step adds: one halo sum of b (the step's only exchange)
             best_step = min(x_ for x_ in (ent["step_ms"], qg_ms) if x_)
             best_base = min(x_ for x_ in (base["step_ms"], base["graph_step_ms"]) if x_)
-            if xch and "halo_exchange_ms" in xch:
-                ent["predicted_speedup_step_with_exchange"] = best_base / (best_step + xch["halo_exchange_ms"])
+            if xch and ("halo_sum_ms" in xch or "halo_exchange_ms" in xch):   # halo_sum_ms: gather + exchange + scatter-add, as the N-rank step runs them
+                ent["predicted_speedup_step_with_exchange"] = best_base / (best_step + xch.get("halo_sum_ms", xch.get("halo_exchange_ms")))
             if dist_cg:
                 qc = q.time_cg()
                 ent["cg_iteration_ms"] = qc["iteration_ms"]

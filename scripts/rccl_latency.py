@@ -41,9 +41,20 @@ def main():
         cm.exchange_end()
     e[3].record()
     torch.cuda.synchronize()
-    out = {"halo_exchange_ms": e[0].elapsed_ms(e[1]) / reps, "allreduce_ms": e[1].elapsed_ms(e[2]) / reps, "halo_exchange_begin_end_ms": e[2].elapsed_ms(e[3]) / reps,
+    # the whole halo sum of a step as HaloExchange runs it: one gather (both planes), the grouped send / receive in the device's queue, one scatter-add
+    vec = torch.zeros(4 * npl, dtype=torch.float64, device="cuda")
+    hx = tb.distributed.HaloExchange([(0, torch.arange(npl, device="cuda")), (0, torch.arange(3 * npl, 4 * npl, device="cuda"))], cm, vec, dev)
+    for _ in range(5):
+        hx.exchange_sum(vec)
+    e4, e5 = dev.event(), dev.event()
+    e4.record()
+    for _ in range(reps):
+        hx.exchange_sum(vec)
+    e5.record()
+    torch.cuda.synchronize()
+    out = {"halo_sum_ms": e4.elapsed_ms(e5) / reps, "halo_exchange_ms": e[0].elapsed_ms(e[1]) / reps, "allreduce_ms": e[1].elapsed_ms(e[2]) / reps, "halo_exchange_begin_end_ms": e[2].elapsed_ms(e[3]) / reps,
            "plane_doubles": npl,
-           "note": "RCCL behind the C ABI at world size 1 (tb_comm_exchange with rank 0 as its own two neighbours, tb_comm_allreduce of 2 doubles): stream time per call, no xGMI hop"}
+           "note": "RCCL behind the C ABI at world size 1 (tb_comm_exchange with rank 0 as its own two neighbours, tb_comm_allreduce of 2 doubles; halo_sum = gather + exchange + scatter-add through HaloExchange): stream time per call, no xGMI hop"}
     cm.close()
     print(json.dumps(out))
 
