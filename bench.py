@@ -965,7 +965,7 @@ def main():
                                        "shuffled": "the %dx%dx%d hex Q1 mesh (%d cells) with cells and nodes RANDOMLY RENUMBERED (unstructured presentation of the same mesh)" % (n, n, nz_total, cells_total),
                                        "lv": "the idealised left-ventricle hex Q1 mesh (%s cells circumferential / radial / longitudinal + O-grid apex: %d cells, %d dofs)" % (args.lv_dims, cells_total, dofs_total)}[args.mesh],
                                       args.strategy, "one fused pass" if fused else "two launches",
-                                      (" + neighbour halo sum of b" + ("" if args.no_overlap_exchange else " (posted before the reaction step, added behind it)")) if world > 1 else "", args.ionic.upper()),
+                                      (" + neighbour halo sum of b" + ("" if args.no_overlap_exchange else " (b is launched first and its exchange posted behind it; the received partials are added behind the reaction step)")) if world > 1 else "", args.ionic.upper()),
                        "mesh": args.mesh, "renumber": args.renumber,
                        "preroll_ms": args.preroll_ms,   # untimed steps in front of the W warm-up steps: the GPU's clocks (see --preroll-ms)
                        "cells_total": cells_total, "cells_per_gpu": g.n_cells, "dofs_per_gpu": npts, "nnz_per_gpu": sp.nnz, "ionic_model": args.ionic, "ionic_states": ns,
