@@ -874,7 +874,8 @@ def main():
                                            "N = %d/L GPUs under --scaling strong); predicted_speedup = t(%d layers) / t(L layers): what the kernels alone allow, without the halo "
                                            "exchange and the two all-reduces of an iteration; *_graph: the same work as one HIP-graph launch per step / iteration (tb_graph_*); "
                                            "*_with_exchange: best of the two forms on both sides, plus the measured world-size-1 RCCL cost of the step's halo sum / of an "
-                                           "iteration's two all-reduces (exchange_latency)" % (args.ionic.upper(), n, n, n, n)}
+                                           "iteration's two all-reduces (exchange_latency); the slabs are timed as a rank of an N-rank run times its steps (--phase-events auto: the two events "
+                                           "around the matrix pass; phase_ms from an instrumented pass behind it)" % (args.ionic.upper(), n, n, n, n)}
         base = {"step_ms": elapsed / args.steps * 1e3, "cg_iteration_ms": dist_cg["iteration_ms"] if dist_cg else None,
                 "graph_step_ms": g_ms, "graph_cg_iteration_ms": dist_cg["graph_iteration_ms"] if dist_cg else None}
         # what an exchange costs on this box: RCCL at world size 1 behind the C ABI, rank 0 as its own lower and upper neighbour (one interface plane each
@@ -895,11 +896,16 @@ def main():
             # the better of two timings (this is a prediction from kernel times, not the contract's timed region: a stall of the host — the
             # collector freeing the previous slab's multi-GB buffers, a page-in — once put 20 ms into a 0.9 ms step)
             gc.collect(); torch.cuda.synchronize()
-            el, ph = None, None
+            # timed as a rank of an N-rank run times it (--phase-events auto): the two events around the matrix pass only; the phases from an
+            # instrumented pass behind it (six event records cost a 27-layer step 12 us)
+            if args.phase_events == "auto":
+                q.pe_mode = "matrix"
+            el = None
             for _ in range(2):
                 e_ = q.time_steps(max(2, args.warmup), max(5, args.steps))
                 if el is None or e_ < el:
-                    el, ph = e_, dict(q.phase)
+                    el = e_
+            ph = q.instrumented_phases(max(5, args.steps)) if q.pe_mode == "matrix" else dict(q.phase)
             ent = {"step_ms": el / max(5, args.steps) * 1e3, "cells": q.g.n_cells, "gpus": N,
                    "phase_ms": {k: v / max(5, args.steps) for k, v in ph.items() if v > 0.0}}
             ent["predicted_speedup_step"] = base["step_ms"] / ent["step_ms"]
