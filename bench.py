@@ -484,7 +484,11 @@ def main():
             self.npts = npts = dh.ndofs
             u0 = np.tile(model.default_initial_state(), (npts, 1))
             if args.mesh == "box":
-                u0[:, model.phi_index] += np.linspace(0.0, 60.0 if self.ns > 2 else 1.0, npts)
+                # a ramp along z by the dof's POSITION (through round 5: by its index, which on a slab is another state than on the whole box): V rises from
+                # rest to rest + 60 mV over the box, the same physical state under every partition (--checksums)
+                zd_ = np.empty(npts); zd_[tb.distributed.node_to_dof(dh)] = g.xyz[:, 2]
+                zlo_, zhi_ = (0.0, nz_total / n) if world_ > 1 else (left[2], right[2])
+                u0[:, model.phi_index] += (60.0 if self.ns > 2 else 1.0) * (zd_ - zlo_) / (zhi_ - zlo_)
             else:                                  # a function of the dof's position: the same physical state under every numbering and every partition (--checksums)
                 xd_ = np.empty((npts, 3)); xd_[tb.distributed.node_to_dof(dh)] = g.xyz
                 self.xdof = xd_
