@@ -142,10 +142,10 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_ranks_hip_assembly_halo_and_cg_equal_single_rank(tb, device):
+@pytest.mark.parametrize("world", [2, 3])   # three ranks: the middle one has two neighbours — HaloExchange's merged gather / scatter-add, product rows packed into slices
+def test_ranks_hip_assembly_halo_and_cg_equal_single_rank(tb, device, world):
     import torch
     import torch.multiprocessing as mp
-    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -186,9 +186,10 @@ def test_two_ranks_hip_assembly_halo_and_cg_equal_single_rank(tb, device):
         assert extra["breakdown_reported"]
         seen[gnode] += 1
     plane = (NEL[0] + 1) * (NEL[1] + 1)
-    assert seen.min() == 1 and (seen == 2).sum() == plane
+    assert seen.min() == 1 and (seen == 2).sum() == plane * (world - 1)
     by_rank = {rank: extra for rank, _, _, _, _, _, extra in res}
-    np.testing.assert_array_equal(by_rank[0]["ap_up"], by_rank[1]["ap_lo"])       # bitwise consistent across the interface
+    for r in range(world - 1):
+        np.testing.assert_array_equal(by_rank[r]["ap_up"], by_rank[r + 1]["ap_lo"])   # bitwise consistent across every interface
 
 
 def test_bench_refuses_wrong_job_size():
