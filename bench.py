@@ -362,6 +362,8 @@ def main():
         dist.all_reduce(ok_, op=dist.ReduceOp.MIN)
         if int(ok_.item()) == 1:
             xd = xa_
+            if rank == 0 and world > 1:
+                sys.stderr.write("bench.py: halo exchange and CG reductions through the C ABI's RCCL communicator (tb_comm_*), in the device's queue\n")
         else:
             if xa_ is not None:
                 xa_.close()
