@@ -519,11 +519,12 @@ def main():
             would wait for the GPU every step, and the host's enqueue time of the next step would sit on the clock (it did through round 4:
             the same step replayed as a graph was 4–6 % faster, most of it this wait).
             The three forms are independent, so the order of their launches is free.  One rank: M + K, b, reaction.  N > 1: b FIRST, its interface
-            entries packed and the exchange posted, then M + K and the reaction step, then the received partials added — the transfer needs a few
-            workgroups of its own on this GPU, and beside the fused matrix pass (thousands of 11 µs workgroups) it finds them at once, where the
-            reaction kernel of a thin slab is ONE generation of resident workgroups that hold every register file until the kernel ends
-            (--no-overlap-exchange: b, exchange, M + K, reaction).  "halo" = pack + post (+ the whole exchange without overlap); "reaction" then
-            includes the wait and the unpack."""
+            entries packed and the exchange posted, then M + K and the reaction step, then the received partials added.  Through the C ABI (--exchange
+            auto) the grouped send / receive sits in the device's queue right behind the pack; where the exchange runs on a queue of its own
+            (torch.distributed, tb_comm_exchange_begin) its kernel needs a few workgroups of this GPU, and beside the fused matrix pass (thousands of
+            11 µs workgroups) it finds them at once, where the reaction kernel of a thin slab is ONE generation of resident workgroups that hold every
+            register file until the kernel ends (--no-overlap-exchange: b, exchange, M + K, reaction).  "halo" = pack + post (+ the whole exchange
+            when it is in the queue); "reaction" then includes the wait and the unpack."""
             t = 0.01 * i
             allev = ev is not None and self.pe_mode == "all"
             mev = ev is not None and self.pe_mode != "none"
