@@ -308,3 +308,15 @@ def test_electromechanics_step_under_the_bisection_partition_matches_one_rank():
     assert two["cells_total"] == one["cells_total"] and abs(2 * two["cells_per_gpu"] - one["cells_total"]) <= 1
     for k, v in one["checksums"].items():
         assert abs(two["checksums"][k] - v) <= 1e-10 * max(abs(v), 1e-30), (k, v, two["checksums"][k])
+
+
+@pytest.mark.parametrize("mode", ["all", "matrix", "none"])
+def test_bench_phase_event_modes_on_one_rank(mode):
+    """--phase-events: all six phase boundaries, the two around the matrix pass (what a rank of an N-rank run records in its timed steps), or none — the
+    line is printed in every mode, a phase that was not recorded is NaN, the matrix phase is there unless the mode is none."""
+    d = _bench_line(["--gpus", "1", "--n", "24", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-graph", "--no-slab-sweep", "--no-dist-cg", "--preroll-ms", "0",
+                     "--phase-events", mode])
+    ph = d["phase_ms"]
+    assert d["value"] > 0 and d["host_enqueue_ms_per_step"] > 0
+    assert (ph["mass+diffusion"] > 0) == (mode != "none")
+    assert (ph["reaction"] > 0) == (mode == "all") and (ph["source"] > 0) == (mode == "all")
