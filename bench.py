@@ -48,6 +48,20 @@ if int(os.environ.get("WORLD_SIZE", "1")) <= 1:
             os.environ[_k] = _v
             _OMP_PINNED_HERE.append(_k)
 
+# The launcher sets OMP_NUM_THREADS=1 for its ranks when the caller set nothing ("to avoid your system being overloaded"): the host-side plan builders of an
+# N-rank run then work on one thread each (two ranks of the 216³ box: 9.8 s of set-up).  A rank takes its share of the CPUs the container grants instead.
+# Nothing inside a timed region runs on host threads.
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("OMP_NUM_THREADS", "1") == "1" and "TB_BENCH_KEEP_OMP" not in os.environ:
+    def _cpus_granted():
+        try:
+            q_, p_ = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if q_ != "max":
+                return max(1, int(int(q_) / int(p_)))
+        except Exception:
+            pass
+        return os.cpu_count() or 1
+    os.environ["OMP_NUM_THREADS"] = str(max(1, min(16, _cpus_granted() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))))))
+
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 FP64_VECTOR_TFLOPS = 78.6      # AMD spec sheet; FP64 MFMA runs at the same rate on CDNA4
 BYTES_PER_CELL_MATRIX = 272.0  # 32 B conn + 24 B coords + 27 nz × 8 B
