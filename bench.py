@@ -1098,7 +1098,20 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_n, kap, args.ionic, big=big, check=None if args.no_cpu_big else parity)
         if FERRITE_PIN["note"]:
             sys.stderr.write("bench.py: " + FERRITE_PIN["note"] + "\n")
+    # The JSON line is the LAST thing on stdout.  RCCL writes a version banner through C stdio when its first communicator is created; with stdout a pipe
+    # that text sits in the C buffer until the process exits — behind the line (seen in round 6: "RCCL version : … Librccl path : …" after the JSON).  So:
+    # every rank flushes C stdio, the ranks meet, rank 0 prints, and only then are the communicators taken down.
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    if dist.is_initialized():
+        dist.barrier()
+    if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
     if dist.is_initialized():
         dist.destroy_process_group()
 

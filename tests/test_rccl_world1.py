@@ -64,6 +64,8 @@ def test_bench_under_launcher_initialises_rccl_at_world_size_one(exchange, backe
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-3000:], r.stderr[-3000:])
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["config"]["backend"] == backend and d["value"] > 0 and d["cg_iterations_per_s"] > 0
+    # the line is the LAST thing on stdout: RCCL's version banner (C stdio, buffered on a pipe until exit) is flushed in front of it
+    assert [ln for ln in r.stdout.splitlines() if ln.strip()][-1].startswith("{"), r.stdout[-1500:]
 
 
 def test_bench_exchange_auto_falls_back_to_torch_distributed_when_no_rank_can_create_the_communicator():
