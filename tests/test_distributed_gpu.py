@@ -214,6 +214,8 @@ def test_bench_two_ranks_end_to_end_on_one_device():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
+    assert "NaN" not in lines[0] and "Infinity" not in lines[0]      # strict JSON: every phase of an N-rank line is a number (--phase-events auto fills them)
+    assert [ln for ln in r.stdout.splitlines() if ln.strip()][-1] == lines[0]   # and it is the last thing on stdout
     d = json.loads(lines[0])
     # default = strong scaling: the SAME 24³ mesh in two z-slabs of 12 layers (BASELINE's 1/2/4/8-GPU configuration)
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong" and d["value"] > 0
