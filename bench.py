@@ -37,6 +37,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the pool's host driver shares device memory between processes through dmabuf only (RCCL's peer buffers); exported there already, a default here
 # the CPU baseline runs on the cores the container may use, pinned (docs/src/vroom.md:3-15 of the reference): libgomp reads these when it is first loaded.
 # ONE-rank runs only (the baseline leg exists at N = 1 only): with the binding set, libgomp pins the INITIAL thread of every process to the first place of
 # its affinity mask — under a launcher all N ranks of a node would enqueue their kernels from the same core (round 6: found by reading, no 8-GPU box here;
