@@ -1102,6 +1102,9 @@ def main():
     # The JSON line is the LAST thing on stdout.  RCCL writes a version banner through C stdio when its first communicator is created; with stdout a pipe
     # that text sits in the C buffer until the process exits — behind the line (seen in round 6: "RCCL version : … Librccl path : …" after the JSON).  So:
     # every rank flushes C stdio, the ranks meet, rank 0 prints, and only then are the communicators taken down.
+    if isinstance(xd, tb.distributed.RcclComm):          # the C ABI's communicator goes first: whatever its teardown writes is flushed with the rest
+        torch.cuda.synchronize()
+        xd.close()
     try:
         import ctypes
         ctypes.CDLL(None).fflush(None)
