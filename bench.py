@@ -363,7 +363,10 @@ def main():
     fused = args.strategy == "patch" and not args.separate
     gd = dist if dist.is_initialized() else None
     xd = gd                                                          # what the halo exchange and the CG reductions go through
-    if gd is not None and args.exchange in ("auto", "abi") and not share:
+    host_red = "cpu" if share else "cuda"
+    # (share = the one-GPU test configuration over gloo: RCCL refuses two ranks on one device, so the C ABI's communicator is tried there only when
+    # TB_RCCL_LIBRARY names another library — tests/mock_rccl, the test double that lets the multi-rank tb_comm_* path run on one GPU)
+    if gd is not None and args.exchange in ("auto", "abi") and (not share or os.environ.get("TB_RCCL_LIBRARY")):
         # every rank tries, the ranks agree (min over ranks), one path for all: a rank that cannot create the communicator must not leave the others in
         # a grouped send / receive nobody answers
         xa_, why_ = None, ""
@@ -373,7 +376,7 @@ def main():
             xa_ = tb.distributed.RcclComm.from_torch(dev, dist)
         except Exception as ex:
             why_ = str(ex)[:300]
-        ok_ = torch.tensor([1 if xa_ is not None else 0], dtype=torch.int32, device="cuda")
+        ok_ = torch.tensor([1 if xa_ is not None else 0], dtype=torch.int32, device=host_red)
         dist.all_reduce(ok_, op=dist.ReduceOp.MIN)
         if int(ok_.item()) == 1:
             xd = xa_
@@ -387,7 +390,6 @@ def main():
                 return 2
             if rank == 0:
                 sys.stderr.write("bench.py: --exchange auto: no communicator behind the C ABI (%s): torch.distributed carries the exchange\n" % (why_ or "another rank failed"))
-    host_red = "cpu" if share else "cuda"
 
     # unstructured presentations: every rank builds the whole mesh (host-side generators), bisects the cell centroids into `world` parts of equal size
     # (tb.distributed.partition_cells_rcb — the partition of SURVEY §8e for meshes that are not boxes) and keeps its own part as a local grid with
@@ -999,7 +1001,8 @@ def main():
                        "cells_total": cells_total, "cells_per_gpu": g.n_cells, "dofs_per_gpu": npts, "nnz_per_gpu": sp.nnz, "ionic_model": args.ionic, "ionic_states": ns,
                        "partition": "z-slabs" if gpart is None else "recursive coordinate bisection of the cell centroids (%d parts, this rank: %d neighbour parts, %d shared dofs)"
                                     % (world, len(gpart.neighbours), sum(len(i_) for _, i_ in gpart.neighbours)),
-                       "layers_per_gpu": part.nzl if gpart is None else None, **({"backend": "gloo (shared device, test)"} if share else ({"backend": "nccl (RCCL)" if xd is gd else "RCCL behind the C ABI (tb_comm_*)"} if gd is not None else {}))},
+                       "layers_per_gpu": part.nzl if gpart is None else None, **({"backend": "gloo (shared device, test)" if xd is gd else "the C ABI's communicator (tb_comm_*) over the library TB_RCCL_LIBRARY names (shared device, test)"} if share
+                          else ({"backend": "nccl (RCCL)" if xd is gd else "RCCL behind the C ABI (tb_comm_*)"} if gd is not None else {}))},
             "dof_updates_per_s": ns * dofs_total * K_ / elapsed,
             # what a host pays ONCE per mesh before the first timed step, outside `value`: host = synthetic mesh + dof table + sparsity pattern + uploads (the
             # generators stand in for Ferrite; a Julia host passes its own arrays), first_step = the plans the first assembly builds (patch decomposition,
