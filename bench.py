@@ -479,6 +479,8 @@ def main():
             self.nbrs = nbrs
             # the one data-path exchange: persistent send / receive buffers, pack and unpack through the C ABI (tb_gather_indexed / tb_scatter_add_indexed)
             self.halo = tb.distributed.HaloExchange(nbrs, self.xdist, self.b, dev)
+            if os.environ.get("TB_BENCH_HALO_OWN_QUEUE") and isinstance(self.xdist, tb.distributed.RcclComm):
+                self.halo.overlap = True           # (tests, comparisons) tb_comm_exchange_begin / _end: the exchange on the communicator's own queue
             # TB_BENCH_SELF_EXCHANGE=torch|abi|abi-overlap (one rank, a diagnostic): the N-rank step as it is — pack, exchange, unpack-add through HaloExchange, rank 0
             # as its own lower and upper neighbour (bottom and top node plane) — over torch.distributed (RCCL at world size 1), or the C ABI's communicator
             # in the device's queue / on its own queue.  b is summed with itself on the two planes: timings only.

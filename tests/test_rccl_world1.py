@@ -80,8 +80,8 @@ def test_bench_exchange_auto_falls_back_to_torch_distributed_when_no_rank_can_cr
     assert r.returncode != 0 and "could not be created on every rank" in r.stderr
 
 
-@pytest.mark.parametrize("mesh_args", [["--n", "24"], ["--mesh", "lv", "--lv-dims", "24,4,16"]])
-def test_three_ranks_through_the_c_abi_communicator_over_the_test_double(tmp_path, mesh_args):
+@pytest.mark.parametrize("mesh_args,own_queue", [(["--n", "24"], False), (["--mesh", "lv", "--lv-dims", "24,4,16"], False), (["--n", "24"], True)])
+def test_three_ranks_through_the_c_abi_communicator_over_the_test_double(tmp_path, mesh_args, own_queue):
     """The C ABI's multi-rank path on a one-GPU box: RCCL refuses two ranks on one device, so tests/mock_rccl (a test double for the nine entry points
     tb_comm.cpp binds: messages staged through shared memory) stands in for it — TB_RCCL_LIBRARY.  Three ranks of bench.py on cuda:0: the communicator id
     travels over torch.distributed (gloo), tb_comm_create joins three ranks, every halo sum is one tb_comm_exchange with the rank's real neighbour list (the
@@ -102,7 +102,8 @@ def test_three_ranks_through_the_c_abi_communicator_over_the_test_double(tmp_pat
         return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
 
     one = line(["--gpus", "1"], {})
-    three = line(["--gpus", "3", "--exchange", "abi"], {"TB_BENCH_SHARE_DEVICE": "1", "TB_RCCL_LIBRARY": so})
+    # own_queue: the step's exchange through tb_comm_exchange_begin / _end (the communicator's queue, joined by events) instead of the device's queue
+    three = line(["--gpus", "3", "--exchange", "abi"], dict({"TB_BENCH_SHARE_DEVICE": "1", "TB_RCCL_LIBRARY": so}, **({"TB_BENCH_HALO_OWN_QUEUE": "1"} if own_queue else {})))
     assert three["n_gpus"] == 3 and "tb_comm_*" in three["config"]["backend"] and three["phase_ms"]["halo"] > 0.0
     assert three["cg_iterations_per_s"] > 0 and three["distributed_cg"]["halo_bytes_per_rank"] > 0
     for k, v in one["checksums"].items():
